@@ -1,0 +1,282 @@
+/*
+ * hqtick.h — C ABI of the MI355X-native tako scheduling tick (libhqtick.so).
+ *
+ * This is the drop-in boundary for ONE hot path of It4innovations/hyperqueue: the server-side
+ * scheduling tick of the `tako` crate.  The reference has no FFI seam today; the seam this ABI
+ * replaces is (all paths relative to /root/reference/crates/tako/src/internal/):
+ *
+ *   run_scheduling_inner(core, comm, now)            scheduler/main.rs:50-72
+ *     = create_task_batches(core, now, None)         scheduler/batches.rs:42-181
+ *     + run_scheduling_solver(core, now, batches,..) scheduler/solver.rs:36-483
+ *     + create_task_mapping(core, solution)          scheduler/mapping.rs:23-157
+ *     + WorkerTaskMapping::send_messages order       scheduler/mapping.rs:259-292
+ *   compute_new_worker_query (stages 1-2 only)       scheduler/query.rs:12-131
+ *
+ * The Rust host (tako) keeps `Core`, `Comm` and the wire layer; it flattens `Core` into the
+ * SoA snapshot below, calls hqtick_run(), and applies the returned assignment vector exactly the way
+ * create_task_mapping()/send_messages() would (see INTEGRATION.md for the extern "C" binding).
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; all pointers are HOST pointers unless the
+ *     function name says `_device`.
+ *   - amounts are tako `ResourceAmount`: u64 fixed point, 10 000 fractions per unit,
+ *     UINT64_MAX = ResourceAmount::MAX ("unknown / unbounded")   common/resources/amount.rs:7,26-31
+ *   - task ids are packed `(job_id << 32) | job_task_id` which preserves `TaskId: Ord`  common/ids.rs:17-21
+ *   - priorities are the raw `Priority(u64)`                       common/priority.rs:43-47
+ *   - one hqtick_ctx per thread; a ctx owns its device buffers, streams and result storage;
+ *     no global state; the library never aborts the host: every failure is a negative return code.
+ */
+#ifndef HQTICK_H
+#define HQTICK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HQTICK_ABI_VERSION 1u
+
+/* ResourceAmount::MAX                                    common/resources/amount.rs:31 */
+#define HQ_AMOUNT_MAX UINT64_MAX
+/* FRACTIONS_PER_UNIT                                     common/resources/amount.rs:7 */
+#define HQ_FRACTIONS_PER_UNIT 10000u
+/* MAX_TASK_PER_WORKER                                    server/workerload.rs:12 */
+#define HQ_MAX_TASK_PER_WORKER 1024u
+/* Worker without termination_time                        server/worker.rs:320-326 */
+#define HQ_NO_TIME_LIMIT INT64_MAX
+/* PriorityCut blocker size == None                       scheduler/batches.rs:15 */
+#define HQ_BLOCKER_UNBOUNDED UINT32_MAX
+/* "no worker" in records                                 */
+#define HQ_NO_WORKER UINT32_MAX
+
+/* AllocationRequest kinds; only Amount-vs-All matters to the tick   common/resources/request.rs:14-21 */
+enum { HQ_ENTRY_AMOUNT = 0, HQ_ENTRY_ALL = 1 };
+
+/* worker_flags bits */
+enum {
+    HQ_WORKER_SN = 1u,       /* WorkerAssignment::Sn (not holding a multi-node task)  server/worker.rs:48-51 */
+    HQ_WORKER_STOPPING = 2u  /* stop_reason.is_some()                                 server/worker.rs:312-314 */
+};
+
+/* hqtick_run return codes == SchedulerResult              scheduler/main.rs:44-48 */
+enum { HQTICK_DONE = 0, HQTICK_NEED_MORE_COMPUTE = 1, HQTICK_NO_PROGRESS = 2 };
+
+/* error codes (negative) */
+enum {
+    HQTICK_E_INVALID = -1,      /* malformed snapshot (NULL pointer, unsorted ids, bad index)         */
+    HQTICK_E_NO_DEVICE = -2,    /* HIP runtime / gfx950 device / kernels not available: NO CPU fallback */
+    HQTICK_E_DEVICE = -3,       /* a HIP call failed; hqtick_last_error() has the text                */
+    HQTICK_E_CAPACITY = -4,     /* a documented capacity limit was exceeded (levels, groups, ...)     */
+    HQTICK_E_QUEUE_UNDERFLOW = -5, /* solver asked for more tasks than a queue holds: the reference
+                                      panics here (taskqueue.rs:327 unwrap)                          */
+    HQTICK_E_UNSUPPORTED = -6
+};
+
+/* assignment record kinds, in the order WorkerTaskMapping::send_messages emits them per worker
+ * (prefills first with variant None, then assigned)          scheduler/mapping.rs:268-279 */
+enum { HQ_REC_PREFILL = 0, HQ_REC_ASSIGN = 1 };
+
+/* SchedulerConfig                                           scheduler/state.rs:5-27 */
+typedef struct hqtick_config {
+    uint32_t abi_version;               /* HQTICK_ABI_VERSION */
+    uint32_t proactive_filling_reserve; /* default 16 */
+    uint32_t proactive_filling_max;     /* default 40 */
+    double mip_time_limit_s;            /* default 5.0 (60.0 under the reference's cfg(test)) */
+    int32_t device_index;               /* HIP device ordinal of this ctx */
+    uint32_t flags;                     /* reserved, 0 */
+} hqtick_config;
+
+/*
+ * Snapshot of `Core` as the tick reads it.  Caller-owned, read-only during the call.
+ *
+ * Workers (W): ALL workers of core.worker_map, sorted by ascending WorkerId.  Per-worker resource
+ * vectors are padded with zeros to R = n_resources (server/workerload.rs:25-31: missing => 0).
+ * Ready set (N): every task sitting in a TaskQueue's `queue` (not its `prefill` set), as SoA,
+ * sorted by ascending task id (the order TaskIds are minted in; hqtick_upload_ready() can sort
+ * an unsorted set on the device once, outside the tick).
+ */
+typedef struct hqtick_snapshot {
+    /* --- resources ------------------------------------------------------------------------- */
+    uint32_t n_resources; /* R = GlobalResourceMapping::n_resources()   common/resources/map.rs:76 */
+
+    /* --- workers --------------------------------------------------------------------------- */
+    uint32_t n_workers;                 /* W */
+    const uint32_t *worker_id;          /* [W] ascending                                         */
+    const uint64_t *worker_total;       /* [W*R] row-major, Worker::resources    server/worker.rs:69 */
+    const uint64_t *worker_free;        /* [W*R] SingleNodeTaskAssignment::free_resources   :44  */
+    const int64_t *worker_remaining_ns; /* [W] termination_time - now (may be negative) or HQ_NO_TIME_LIMIT */
+    const float *worker_min_utilization; /* [W] configuration.min_utilization                   */
+    const uint8_t *worker_flags;        /* [W] HQ_WORKER_* bits                                  */
+    const uint32_t *worker_group;       /* [W] dense group index in [0, n_groups)  (configuration.group) */
+    uint32_t n_groups;
+    const uint32_t *worker_map_rank;    /* [W] position of the worker in core.worker_map iteration
+                                           (hashbrown order; the Rust shim reads it off `values()`),
+                                           or NULL => emulate a map built by inserting ascending ids */
+
+    /* Worker::blocked_requests as (worker index, rq, variant) triples   server/worker.rs:70 */
+    uint32_t n_blocked;
+    const uint32_t *blocked_worker; /* index into worker arrays */
+    const uint32_t *blocked_rq;
+    const uint8_t *blocked_variant;
+
+    /* SingleNodeTaskAssignment::assigned_tasks as CSR of (rq, variant) per worker — what
+     * GapCache::get_gap subtracts (scheduler/solver.rs:296-303) and what Worker::is_free tests */
+    const uint32_t *assigned_off; /* [W+1] */
+    const uint32_t *assigned_rq;
+    const uint8_t *assigned_variant;
+
+    /* SingleNodeTaskAssignment::prefilled_tasks as CSR of rq per worker (mapping.rs:199-205) */
+    const uint32_t *prefilled_off; /* [W+1] */
+    const uint32_t *prefilled_rq;
+
+    /* --- resource requests: ResourceRqMap as CSR rq -> variants -> entries ------------------ */
+    uint32_t n_requests;              /* Q (= number of TaskQueues, taskqueue.rs:32-35)       */
+    const uint32_t *rq_variant_off;   /* [Q+1] into variant_* arrays                           */
+    const uint32_t *variant_entry_off; /* [NV+1] into entry_* arrays; entries sorted by resource id */
+    const uint32_t *variant_n_nodes;  /* [NV] 0 = single node                                  */
+    const uint64_t *variant_min_time_ns; /* [NV]                                                */
+    const uint32_t *variant_weight;   /* [NV] ResourceWeight(u32), 10 000 = 1.0                */
+    const uint32_t *entry_resource;   /* [NE] */
+    const uint8_t *entry_kind;        /* [NE] HQ_ENTRY_* */
+    const uint64_t *entry_amount;     /* [NE] (ignored for HQ_ENTRY_ALL) */
+
+    /* --- ready set SoA (TaskQueue::queue of every rq, flattened) ----------------------------- */
+    uint64_t n_ready;            /* N */
+    const uint64_t *task_id;     /* [N] ascending */
+    const uint64_t *task_priority; /* [N] */
+    const uint32_t *task_rq;     /* [N] */
+
+    /* --- TaskQueue::prefill of every rq (taskqueue.rs:118) ------------------------------------ */
+    const uint32_t *prefill_off;     /* [Q+1] */
+    const uint64_t *prefill_priority; /* [Q] valid when the rq's prefill set is non-empty        */
+    const uint64_t *prefill_task;    /* ids in the Set<TaskId>'s iteration order                  */
+    const uint32_t *prefill_worker;  /* worker INDEX holding the prefilled task                   */
+} hqtick_snapshot;
+
+/* What-if query input: fake workers appended after the real ones (scheduler/query.rs:20-56).
+ * Same layout as the worker arrays above; ids must be above every real id. */
+typedef struct hqtick_query_workers {
+    uint32_t n_workers;
+    const uint32_t *worker_id;
+    const uint64_t *worker_total; /* [n*R]; free == total for a fresh fake worker */
+    const int64_t *worker_remaining_ns;
+    const float *worker_min_utilization;
+} hqtick_query_workers;
+
+/*
+ * Result view.  All pointers are owned by the ctx and stay valid until the next call on it.
+ */
+typedef struct hqtick_result {
+    int32_t status;     /* HQTICK_DONE / NEED_MORE_COMPUTE / NO_PROGRESS */
+    uint8_t is_optimal; /* SchedulingSolution::is_optimal  scheduler/solver.rs:14-16 */
+
+    /* TaskBatch list (scheduler/batches.rs:18-27) — exposed so parity tier T1 is testable */
+    uint32_t n_batches;
+    const uint32_t *batch_rq;
+    const uint32_t *batch_size;
+    const uint32_t *batch_limit;
+    const uint8_t *batch_limit_reached;
+    const uint8_t *batch_is_blocker;
+    const uint32_t *batch_cut_off;     /* [n_batches+1] */
+    const uint32_t *cut_size;          /* [n_cuts] */
+    const uint32_t *cut_blocker_off;   /* [n_cuts+1] */
+    const uint32_t *blocker_rq;
+    const uint32_t *blocker_size;      /* HQ_BLOCKER_UNBOUNDED = None */
+
+    /* SchedulingSolution::sn_counts (solver.rs:12) flattened in the reference's iteration order:
+     * outer = sn_counts.into_iter() order, inner = counts.iter() order (mapping.rs:36,43) */
+    uint32_t n_counts;
+    const uint32_t *count_rq;
+    const uint8_t *count_variant;
+    const uint32_t *count_worker; /* worker INDEX */
+    const uint32_t *count_value;
+
+    /* WorkerTaskMapping (mapping.rs:11-21) as CSR over worker index.  Per worker the records are in
+     * the exact order send_messages() walks them: prefills, then assigned sorted by priority desc
+     * (stable).  Retracts are a separate CSR (they are sent first, as one RetractTasks message). */
+    const uint32_t *rec_off;    /* [W+1] */
+    const uint64_t *rec_task;
+    const uint8_t *rec_variant; /* 0xFF for prefills (variant None) */
+    const uint8_t *rec_kind;    /* HQ_REC_* */
+    const uint32_t *retract_off; /* [W+1] */
+    const uint64_t *retract_task;
+
+    /* scheduler_state.redirects insertions made by this tick (mapping.rs:78-100) */
+    uint32_t n_redirects;
+    const uint64_t *redirect_task;
+    const uint32_t *redirect_worker; /* worker INDEX of the new target */
+    const uint8_t *redirect_variant;
+
+    /* multi-node placements (solver.rs:442-464, mapping.rs:133-154): task + its workers, root first */
+    uint32_t n_mn;
+    const uint64_t *mn_task;
+    const uint32_t *mn_worker_off; /* [n_mn+1] */
+    const uint32_t *mn_worker;     /* worker INDEX */
+
+    /* free resources of every worker after the tick (Worker::insert_sn_task, server/worker.rs:188-196) */
+    const uint64_t *new_free; /* [W*R] */
+
+    /* timing of the last call, microseconds (host wall clock around each stage) */
+    double t_total_us, t_scan_us, t_batches_us, t_solve_us, t_mapping_us;
+} hqtick_result;
+
+/* compute_new_worker_query result: for every fake worker, 1 if it received any count
+ * (query.rs:73-95), plus the batches for inspection */
+typedef struct hqtick_query_result {
+    uint32_t n_workers;
+    const uint8_t *is_loaded; /* [n_workers] */
+    uint8_t is_optimal;
+} hqtick_query_result;
+
+typedef struct hqtick_ctx hqtick_ctx;
+
+/* Create a context bound to one HIP device.  Fails with HQTICK_E_NO_DEVICE when no gfx950
+ * device / runtime is usable — there is deliberately no CPU implementation behind this ABI. */
+int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx);
+void hqtick_destroy(hqtick_ctx *ctx);
+
+/* One scheduling tick == run_scheduling_inner().  Copies the snapshot's columns to the device,
+ * runs the tick, fills `out`.  Returns HQTICK_DONE/NEED_MORE_COMPUTE/NO_PROGRESS or a negative error. */
+int hqtick_run(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick_result *out);
+
+/* Device-resident variant: keep the ready-set columns in HBM across ticks.
+ * hqtick_upload_ready() copies (and, when `sorted`==0, sorts by task id on the device) the ready
+ * set into ctx-owned HBM buffers; hqtick_run_resident() then runs ticks against them, taking every
+ * other field (workers, requests, prefill sets) from `snapshot` and ignoring its task_* pointers. */
+int hqtick_upload_ready(hqtick_ctx *ctx, uint64_t n_ready, const uint64_t *task_id,
+                        const uint64_t *task_priority, const uint32_t *task_rq, int sorted);
+int hqtick_run_resident(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick_result *out);
+
+/* compute_new_worker_query(): batches + solver on fake workers, no mapping  scheduler/query.rs:70-71 */
+int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, const hqtick_query_workers *fake,
+                 hqtick_query_result *out);
+
+/* Text of the last error on this ctx (never NULL). */
+const char *hqtick_last_error(const hqtick_ctx *ctx);
+
+/* Library/ABI version and the gfx arch the kernels were built for ("gfx950"). */
+uint32_t hqtick_abi_version(void);
+const char *hqtick_build_arch(void);
+
+/*
+ * Measurement hooks (used by bench.py; not part of the reference surface).
+ * hqtick_kernel_stats(): HIP-event time of the ready-set streaming kernels of the last tick,
+ * measured on the ctx's own stream, and the algorithmic bytes they moved.
+ */
+typedef struct hqtick_kernel_stats {
+    double level_hist_us;   /* K1: per-(rq,priority) histogram over the ready set   */
+    double select_us;       /* K4: selection + scatter of the taken tasks            */
+    double distinct_us;     /* K0: distinct-priority discovery                       */
+    double other_us;        /* all other kernels of the tick                         */
+    double tick_gpu_us;     /* first kernel start -> last kernel end                 */
+    uint64_t algorithmic_bytes; /* N*20 + W*R*16 + Q*V*R*9 + A*13 + P*12 */
+    uint64_t n_assigned, n_prefilled;
+} hqtick_kernel_stats;
+int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HQTICK_H */

@@ -1,0 +1,269 @@
+"""TEST INFRASTRUCTURE — Python driver of the CPU oracle (oracle/hq_oracle.cpp).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+The oracle restates the reference tick in C++ and delegates the placement MILP to HiGHS, exactly as the
+reference does (crates/tako/src/internal/solver/highs.rs:65-88).  The HiGHS used here is the one bundled in
+scipy (HiGHS 1.8.0, `scipy.optimize.milp`); the reference pins `highs` 2.4.0 / `highs-sys` 1.15.0
+(Cargo.lock:1107-1122) — same solver, different release, so ties between equally good optima may differ.
+
+`canonical=True` additionally post-processes the optimum into the tie-break convention the MI355X path
+implements: among all solutions whose objective is within 1e-9 (relative) of the optimum,
+the lexicographically largest vector in column-creation order.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from hyperqueue_amd import abi  # noqa: E402  (ctypes mirror of include/hqtick.h only)
+
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+SOLVE_FN = C.CFUNCTYPE(
+    C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8),
+    C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_double,
+    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int),
+)
+
+
+class ModelView(C.Structure):
+    _fields_ = [
+        ("ncols", C.c_int), ("nrows", C.c_int),
+        ("obj", C.POINTER(C.c_double)), ("col_kind", abi.u8p), ("col_type", abi.u8p), ("col_worker", abi.u32p),
+        ("col_rq", abi.u32p), ("col_variant", abi.u8p),
+        ("row_type", abi.u8p), ("rhs", C.POINTER(C.c_double)), ("row_off", C.POINTER(C.c_int)),
+        ("row_col", C.POINTER(C.c_int)), ("row_coef", C.POINTER(C.c_double)),
+        ("x", C.POINTER(C.c_double)), ("objective", C.c_double),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the C++ restatement (g++ only; no reference sources are copied or compiled)."""
+    src = [os.path.join(_HERE, "hq_oracle.cpp"), os.path.join(_HERE, "hb_emul.h"), os.path.join(_ROOT, "include", "hqtick.h")]
+    if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src):
+        return _LIB_PATH
+    os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", _LIB_PATH, src[0]])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.oracle_create.restype = C.c_void_p
+        _lib.oracle_create.argtypes = [C.POINTER(abi.Config)]
+        _lib.oracle_destroy.argtypes = [C.c_void_p]
+        _lib.oracle_last_error.restype = C.c_char_p
+        _lib.oracle_last_error.argtypes = [C.c_void_p]
+        _lib.oracle_batches.argtypes = [C.c_void_p, C.POINTER(abi.SnapshotC), C.POINTER(abi.ResultC)]
+        _lib.oracle_tick.argtypes = [C.c_void_p, C.POINTER(abi.SnapshotC), SOLVE_FN, C.c_void_p, C.POINTER(abi.ResultC)]
+        _lib.oracle_query.argtypes = [C.c_void_p, C.POINTER(abi.SnapshotC), C.POINTER(abi.QueryWorkersC), SOLVE_FN, C.c_void_p, C.POINTER(abi.QueryResultC)]
+        _lib.oracle_last_model.argtypes = [C.c_void_p, C.POINTER(ModelView)]
+        _lib.oracle_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        _lib.oracle_prune_progressive.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, abi.u32p]
+        _lib.oracle_gap.argtypes = [C.c_void_p, C.POINTER(abi.SnapshotC), C.c_uint32, C.c_uint32, C.c_uint32, SOLVE_FN, C.c_void_p]
+        _lib.oracle_hb_order_u32.argtypes = [abi.u32p, C.c_uint32, abi.u32p]
+        _lib.oracle_hb_order_taskid.argtypes = [abi.u64p, C.c_uint32, abi.u64p]
+        _lib.oracle_hb_order_rqv.argtypes = [abi.u32p, abi.u8p, C.c_uint32, abi.u32p, abi.u8p]
+        _lib.oracle_fx_u32.restype = C.c_uint64
+        _lib.oracle_fx_u32.argtypes = [C.c_uint32]
+    return _lib
+
+
+# ------------------------------------------------------------------------------------------------------
+# HiGHS (scipy) behind the reference's LpInnerSolver contract: maximise, integer columns 0.. / 0..=1
+# ------------------------------------------------------------------------------------------------------
+def solve_milp(obj, kind, rtype, rhs, roff, rcol, rcoef, time_limit: float = 60.0, canonical: bool = False):
+    """Returns (x, objective, is_optimal) or None.  solver/highs.rs:51-88."""
+    from scipy.optimize import Bounds, LinearConstraint, milp
+    from scipy.sparse import csr_matrix
+
+    n, m = len(obj), len(rhs)
+    if n == 0:
+        return np.zeros(0), 0.0, True
+    ub = np.where(np.asarray(kind) == 1, 1.0, np.inf)
+    cons = []
+    if m:
+        A = csr_matrix((np.asarray(rcoef, float), np.asarray(rcol, np.int32), np.asarray(roff, np.int32)), shape=(m, n))
+        A.sum_duplicates()
+        lo = np.where(np.asarray(rtype) == 1, -np.inf, np.asarray(rhs, float))  # Max => (-inf, rhs]
+        hi = np.where(np.asarray(rtype) == 0, np.inf, np.asarray(rhs, float))  # Min => [rhs, inf)
+        cons.append(LinearConstraint(A, lo, hi))
+    opts = {"mip_rel_gap": 0.0, "disp": False}
+    if time_limit < 1e20:
+        opts["time_limit"] = float(time_limit)
+    c = -np.asarray(obj, float)
+    res = milp(c, constraints=cons, integrality=np.ones(n), bounds=Bounds(np.zeros(n), ub), options=opts)
+    if res.x is None:
+        return None
+    is_opt = res.status == 0
+    if res.status not in (0, 1):
+        return None
+    x = np.round(res.x)
+    z = float(np.dot(np.asarray(obj, float), x))
+    if canonical and is_opt:
+        x = _lex_max(c, cons, ub, z, x)
+        z = float(np.dot(np.asarray(obj, float), x))
+    return x, z, is_opt
+
+
+def _lex_max(c, cons, ub, z, x0):
+    """Lexicographically largest optimum: fix columns one by one at their maximum subject to obj >= z - tol."""
+    from scipy.optimize import Bounds, LinearConstraint, milp
+
+    n = len(c)
+    tol = 1e-9 * max(1.0, abs(z))
+    objrow = LinearConstraint((-c).reshape(1, n), z - tol, np.inf)
+    lo, hi = np.zeros(n), ub.copy()
+    x = x0.copy()
+    for j in range(n):
+        cj = np.zeros(n)
+        cj[j] = -1.0
+        res = milp(cj, constraints=cons + [objrow], integrality=np.ones(n), bounds=Bounds(lo, hi), options={"mip_rel_gap": 0.0, "disp": False})
+        if res.x is None or res.status != 0:
+            v = x[j]
+        else:
+            v = float(np.round(res.x[j]))
+            x = np.round(res.x)
+        lo[j] = hi[j] = v
+    return x
+
+
+class Oracle:
+    """One oracle context (== one tako `Core`'s scheduler config)."""
+
+    def __init__(self, config: Optional[abi.Config] = None, canonical: bool = False):
+        self.cfg = config or abi.make_config()
+        self.canonical = canonical
+        self._ctx = lib().oracle_create(C.byref(self.cfg))
+        self.solver_s = 0.0
+        self.last_models = []
+        self._cb = SOLVE_FN(self._solve_cb)
+
+    def __del__(self):
+        try:
+            if self._ctx:
+                lib().oracle_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def _solve_cb(self, user, ncols, obj, kind, nrows, rtype, rhs, roff, rcol, rcoef, tlimit, x_out, obj_out, is_opt):
+        t0 = time.perf_counter()
+        try:
+            o = np.ctypeslib.as_array(obj, shape=(ncols,)) if ncols else np.zeros(0)
+            k = np.ctypeslib.as_array(kind, shape=(ncols,)) if ncols else np.zeros(0, np.uint8)
+            if nrows:
+                rt = np.ctypeslib.as_array(rtype, shape=(nrows,))
+                rh = np.ctypeslib.as_array(rhs, shape=(nrows,))
+                ro = np.ctypeslib.as_array(roff, shape=(nrows + 1,))
+                nnz = int(ro[-1])
+                rc = np.ctypeslib.as_array(rcol, shape=(nnz,)) if nnz else np.zeros(0, np.int32)
+                rf = np.ctypeslib.as_array(rcoef, shape=(nnz,)) if nnz else np.zeros(0)
+            else:
+                rt, rh, ro, rc, rf = np.zeros(0, np.uint8), np.zeros(0), np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0)
+            r = solve_milp(o, k, rt, rh, ro, rc, rf, tlimit, canonical=self.canonical)
+            if r is None:
+                return 0
+            x, z, opt = r
+            for i in range(ncols):
+                x_out[i] = float(x[i])
+            obj_out[0] = z
+            is_opt[0] = 1 if opt else 0
+            return 1
+        except Exception as e:  # never let an exception cross the C boundary
+            sys.stderr.write(f"[oracle] solver callback failed: {e!r}\n")
+            return 0
+        finally:
+            self.solver_s += time.perf_counter() - t0
+
+    def error(self) -> str:
+        return lib().oracle_last_error(self._ctx).decode()
+
+    def batches(self, snap: abi.Snapshot):
+        sc, rc = snap.to_c(), abi.ResultC()
+        rcode = lib().oracle_batches(self._ctx, C.byref(sc), C.byref(rc))
+        if rcode < 0:
+            raise RuntimeError(f"oracle_batches failed: {rcode} {self.error()}")
+        return abi.parse_batches(rc)
+
+    def tick(self, snap: abi.Snapshot) -> abi.Result:
+        sc, rc = snap.to_c(), abi.ResultC()
+        rcode = lib().oracle_tick(self._ctx, C.byref(sc), self._cb, None, C.byref(rc))
+        if rcode < 0:
+            raise RuntimeError(f"oracle_tick failed: {rcode} {self.error()}")
+        return abi.parse_result(rc, len(snap.worker_id), snap.n_resources)
+
+    def query(self, snap: abi.Snapshot, fake_ids, fake_total, fake_remaining=None, fake_min_util=None):
+        sc = snap.to_c()
+        n = len(fake_ids)
+        ids = np.ascontiguousarray(fake_ids, np.uint32)
+        tot = np.ascontiguousarray(np.asarray(fake_total, np.uint64).reshape(-1))
+        rem = np.ascontiguousarray(fake_remaining if fake_remaining is not None else np.full(n, abi.HQ_NO_TIME_LIMIT), np.int64)
+        mu = np.ascontiguousarray(fake_min_util if fake_min_util is not None else np.zeros(n), np.float32)
+        q = abi.QueryWorkersC(n, ids.ctypes.data_as(abi.u32p), tot.ctypes.data_as(abi.u64p), rem.ctypes.data_as(abi.i64p), mu.ctypes.data_as(abi.f32p))
+        out = abi.QueryResultC()
+        rcode = lib().oracle_query(self._ctx, C.byref(sc), C.byref(q), self._cb, None, C.byref(out))
+        if rcode < 0:
+            raise RuntimeError(f"oracle_query failed: {rcode} {self.error()}")
+        return abi._np(out.is_loaded, n, np.uint8).astype(bool), bool(out.is_optimal)
+
+    def gap(self, snap: abi.Snapshot, high_rq: int, low_rq: int, worker_index: int) -> int:
+        sc = snap.to_c()
+        return lib().oracle_gap(self._ctx, C.byref(sc), high_rq, low_rq, worker_index, self._cb, None)
+
+    def last_model(self) -> dict:
+        v = ModelView()
+        lib().oracle_last_model(self._ctx, C.byref(v))
+        n, m = v.ncols, v.nrows
+        g = abi._np
+        roff = g(v.row_off, m + 1, np.int32) if m else np.zeros(1, np.int32)
+        nnz = int(roff[-1])
+        return dict(
+            obj=g(v.obj, n, np.float64), kind=g(v.col_kind, n, np.uint8), ctype=g(v.col_type, n, np.uint8),
+            cworker=g(v.col_worker, n, np.uint32), crq=g(v.col_rq, n, np.uint32), cvariant=g(v.col_variant, n, np.uint8),
+            rtype=g(v.row_type, m, np.uint8), rhs=g(v.rhs, m, np.float64), roff=roff,
+            rcol=g(v.row_col, nnz, np.int32), rcoef=g(v.row_coef, nnz, np.float64),
+            x=g(v.x, n, np.float64), objective=v.objective,
+        )
+
+    def stage_times_us(self) -> dict:
+        t = (C.c_double * 5)()
+        lib().oracle_stage_times(self._ctx, t)
+        return dict(load=t[0], batches=t[1], model=t[2], solve=t[3], mapping=t[4])
+
+
+def prune_progressive(n: int, prefix: int, limit: int):
+    out = np.zeros(max(n, limit), np.uint32)
+    k = lib().oracle_prune_progressive(n, prefix, limit, out.ctypes.data_as(abi.u32p))
+    return out[:k].tolist()
+
+
+def hb_order_u32(keys):
+    k = np.ascontiguousarray(keys, np.uint32)
+    out = np.zeros(len(k), np.uint32)
+    lib().oracle_hb_order_u32(k.ctypes.data_as(abi.u32p), len(k), out.ctypes.data_as(abi.u32p))
+    return out.tolist()
+
+
+def hb_order_taskid(keys):
+    k = np.ascontiguousarray(keys, np.uint64)
+    out = np.zeros(len(k), np.uint64)
+    lib().oracle_hb_order_taskid(k.ctypes.data_as(abi.u64p), len(k), out.ctypes.data_as(abi.u64p))
+    return out.tolist()

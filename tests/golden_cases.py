@@ -1,0 +1,558 @@
+"""Golden vectors: the reference's own scheduler unit tests, transcribed.
+
+Source: /root/reference/crates/tako/src/internal/tests/test_scheduler_sn.rs (cited per test as sn:<lines>),
+tests/test_scheduler_mn.rs (mn:<lines>), scheduler/batches.rs:223-250, scheduler/gap.rs:176-246.
+Every function takes a backend exposing `tick(Snapshot) -> Result`; tests/test_oracle_golden.py runs them on the
+CPU oracle (pins the oracle), tests/test_gpu_golden.py runs them through the HIP C ABI (pins the product).
+"""
+from __future__ import annotations
+
+from hyperqueue_amd import abi
+from hyperqueue_amd.core import SchedEnv, TaskBuilder as TB, WorkerBuilder as WB
+from refharness import TestCase
+
+
+def env(reserve=16, fill_max=40):
+    return SchedEnv(abi.make_config(reserve=reserve, fill_max=fill_max))
+
+
+def batches_of(rt, backend):
+    return backend.batches(rt.snapshot())
+
+
+# ---------------------------------------------------------------------------------------------- T1: batches
+def test_task_grouping_basic(backend):  # sn:14-75
+    rt = env()
+    rt.new_workers_cpus([5, 5, 5])
+    assert batches_of(rt, backend) == []
+    t1 = rt.new_task(TB().user_priority(123))
+    a = batches_of(rt, backend)
+    assert len(a) == 1 and a[0].rq == rt.task(t1).rq and a[0].cuts == [] and a[0].size == 1 and not a[0].limit_reached
+    for p in (20, 5, 123, 20):
+        rt.new_task(TB().user_priority(p))
+    a = batches_of(rt, backend)
+    assert len(a) == 1 and a[0].rq == rt.task(t1).rq and a[0].cuts == [] and a[0].size == 5 and not a[0].limit_reached
+    t6 = rt.new_task(TB().cpus(2).user_priority(123))
+    t7 = rt.new_task(TB().cpus(123).user_priority(123))
+    rt.new_task(TB().cpus(2).user_priority(123))
+    rt.new_task(TB().cpus(2).user_priority(123))
+    a = batches_of(rt, backend)
+    assert len(a) == 2
+    assert a[0].rq == rt.task(t1).rq and a[0].size == 5 and not a[0].limit_reached
+    assert a[0].cuts == [(2, [(rt.task(t6).rq, 3), (rt.task(t7).rq, None)])]
+    assert a[1].rq == rt.task(t6).rq and a[1].size == 3 and not a[1].limit_reached and a[1].cuts == []
+
+
+def test_task_grouping_blocker(backend):  # sn:78-88
+    rt = env()
+    rt.new_workers_cpus([5])
+    rt.new_task(TB().user_priority(2))
+    rt.new_task(TB().cpus(2).user_priority(1))
+    a = batches_of(rt, backend)
+    assert len(a) == 2 and a[0].is_blocker and not a[1].is_blocker
+
+
+def test_task_group_saturation(backend):  # sn:91-135
+    rt = env()
+    rt.new_workers_cpus([5, 5, 5])
+    for p in (2, 2, 4, 4, 6, 6):
+        rt.new_task(TB().cpus(4).user_priority(p))
+    a = batches_of(rt, backend)
+    assert len(a) == 1 and a[0].size == 3 and a[0].limit_reached and a[0].cuts == []
+    rt.new_task(TB().cpus(1).user_priority(5))
+    rt.new_task(TB().cpus(1).user_priority(0))
+    a = batches_of(rt, backend)
+    assert len(a) == 2
+    assert a[0].size == 3 and a[0].limit_reached and a[0].cuts == [(2, [(1, 1)])]
+    assert a[1].size == 2 and not a[1].limit_reached
+    assert a[1].cuts == [(0, [(0, 2)]), (1, [(0, None)])]
+
+
+def test_task_batching2(backend):  # sn:138-154
+    rt = env()
+    ws = rt.new_workers_cpus([3, 3, 3])
+    rt.new_task_running(TB().cpus(1), ws[0])
+    rt.new_task_running(TB().cpus(2), ws[1])
+    rt.new_task_running(TB().cpus(3), ws[2])
+    rt.new_task(TB().cpus(2))
+    rt.new_task(TB().cpus(1))
+    rt.new_task(TB().cpus(3))
+    a = batches_of(rt, backend)
+    assert len(a) == 3 and all(b.cuts == [] for b in a)
+
+
+def test_mn_task_batches1(backend):  # mn:52-70
+    rt = env()
+    rt.new_workers_cpus([5, 5, 5])
+    rt.new_task(TB().n_nodes(4))
+    assert batches_of(rt, backend) == []
+    rt.new_task(TB().n_nodes(2))
+    a = batches_of(rt, backend)
+    assert a[0].size == 1 and not a[0].limit_reached
+    rt.new_task(TB().n_nodes(2))
+    a = batches_of(rt, backend)
+    assert a[0].size == 1 and a[0].limit_reached
+
+
+def test_mn_task_batches2(backend):  # mn:73-86
+    rt = env()
+    rt.new_workers_cpus([1, 1, 1])
+    rt.new_task(TB().user_priority(0).n_nodes(3))
+    rt.new_task(TB().user_priority(5).n_nodes(2))
+    a = batches_of(rt, backend)
+    assert len(a) == 2 and a[0].size == 1 and a[1].size == 1 and len(a[0].cuts) == 1 and len(a[1].cuts) == 0
+
+
+# ---------------------------------------------------------------------------------------------- T2/T3: placement
+def test_schedule_no_priorities(backend):  # sn:157-224
+    w3, w4 = WB(3), WB(4)
+    c = TestCase(backend); c.w(w4); c.w(w3); c.check()
+    c = TestCase(backend); ts = c.c_tasks([3]); c.w(w3).expect_tasks([ts[0]]); c.check()
+    c = TestCase(backend); ts = c.c_tasks([2]); c.w(w4).expect_tasks([ts[0]]); c.w(w4); c.check()
+    c = TestCase(backend); ts = c.c_tasks([2, 2]); c.w(w4).expect_tasks(ts); c.w(w4); c.check()
+    c = TestCase(backend); ts = c.c_tasks([2, 2, 2]); c.w(w4).expect_tasks([ts[0], ts[2]]); c.w(w4).expect_tasks([ts[1]]); c.check()
+    c = TestCase(backend); ts = c.c_tasks([2, 2, 2, 2]); c.w(w4).expect_tasks([ts[0], ts[2]]); c.w(w4).expect_tasks([ts[1], ts[3]]); c.check()
+    c = TestCase(backend); ts = c.c_tasks([2, 2, 2, 2, 2]); c.w(w4).expect_tasks([ts[0], ts[2]]); c.w(w4).expect_tasks([ts[1], ts[3]]); c.check()
+    c = TestCase(backend); ts = c.c_tasks([2, 3]); c.w(w4).expect_tasks([ts[1]]); c.w(w4).expect_tasks([ts[0]]); c.check()
+    c = TestCase(backend); ts = c.c_tasks([2, 3]); c.w(w3).expect_tasks([ts[1]]); c.w(w4).expect_tasks([ts[0]]); c.check()
+    c = TestCase(backend); ts = c.c_tasks([5, 5, 1, 1, 1, 1, 1]); c.w(w4).expect_tasks([ts[2], ts[4], ts[5], ts[6]]); c.w(w4).expect_tasks([ts[3]]); c.check()
+    c = TestCase(backend); ts = c.c_tasks([3, 4, 2]); c.w(w4).expect_tasks([ts[1]]); c.w(w4).expect_tasks([ts[0]]); c.check()
+
+
+def test_schedule_priorities(backend):  # sn:227-307
+    w4, w10 = WB(4), WB(10)
+    c = TestCase(backend); ts = c.pc_tasks([(1, 2), (1, 2)]); c.w(w4).expect_tasks([ts[0], ts[1]]); c.w(w4); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(1, 2), (2, 2)]); c.w(w4).expect_tasks([ts[1], ts[0]]); c.w(w4); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(0, 4), (0, 4), (1, 2), (2, 3)]); c.w(w4).expect_tasks([ts[3]]); c.w(w4).expect_tasks([ts[2]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(0, 4), (0, 4), (1, 2), (1, 3)]); c.w(w4).expect_tasks([ts[3]]); c.w(w4).expect_tasks([ts[2]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(1, 4), (1, 4), (1, 2), (1, 3)])
+    c.w(w4).eq_class(0).expect_tasks([ts[0]]); c.w(w4).eq_class(0).expect_tasks([ts[1]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(0, 2), (4, 2), (3, 1), (2, 3)])
+    c.w(w4).eq_class(0).expect_tasks([ts[1], ts[0]]); c.w(w4).eq_class(0).expect_tasks([ts[2], ts[3]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(1, 5), (0, 4)]); c.w(w4).expect_tasks([ts[1]]); c.w(w4); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(0, 2), (4, 2), (2, 4)])
+    c.w(w4).eq_class(0).expect_tasks([ts[1], ts[0]]); c.w(w4).eq_class(0).expect_tasks([ts[2]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(9, 2), (7, 1), (6, 2)]); c.w(w4).expect_tasks(ts[:2]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(9, 2), (7, 1), (6, 2), (5, 1)]); c.w(w4).expect_tasks(ts[:2]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(9, 2), (8, 1), (7, 2), (6, 1), (5, 2), (4, 1), (3, 2), (2, 1)]); c.w(w10).expect_tasks(ts[:6]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(1, 3), (1, 3), (1, 3), (0, 1)]); c.w(w4).expect_tasks([ts[0], ts[3]]); c.check()
+
+
+def test_schedule_no_irrelevant_blocking(backend):  # sn:310-330
+    w3, w5 = WB(3), WB(5)
+    c = TestCase(backend); ts = c.pc_tasks([(10, 5), (0, 1)]); c.w(w3).expect_tasks([ts[1]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(10, 5), (9, 5), (0, 1)]); c.w(w3).expect_tasks([ts[2]]); c.w(w5).expect_tasks([ts[0]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(10, 3), (9, 2), (8, 5), (0, 1)]); c.w(w5).expect_tasks([ts[0], ts[1]]); c.w(w3).expect_tasks([ts[3]]); c.check()
+
+
+def test_schedule_some_tasks_running(backend):  # sn:333-366
+    w3 = WB(3)
+    c = TestCase(backend); c.pc_tasks([(1, 3)]); c.w(w3).running_c(1).expect_tasks([]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(1, 2)]); c.w(w3).running_c(1).expect_tasks([ts[0]]); c.check()
+    c = TestCase(backend); c.pc_tasks([(1, 3), (0, 1)]); c.w(w3).running_c(1).expect_tasks([]); c.check()
+    c = TestCase(backend); ts = c.c_tasks([2, 1, 3])
+    c.w(w3).running_c(1).expect_tasks([ts[0]]); c.w(w3).running_c(2).expect_tasks([ts[1]]); c.w(w3).running_c(2).running_c(1).expect_tasks([]); c.check()
+
+
+def test_priority_switching(backend):  # sn:369-405
+    for (w_cpus, count_a, count_b) in [(1, 2, 0), (2, 3, 1), (3, 4, 2), (4, 6, 2), (5, 7, 3), (6, 8, 4), (7, 10, 4), (8, 12, 4), (9, 12, 5), (10, 12, 5)]:
+        rt = env()
+        rt.new_named_resource("foo")
+        ta, tb = TB().cpus(1), TB().cpus(1).add_resource(1, 1)
+        w4 = WB(w_cpus).res_sum("foo", 10_000)
+        rt.new_worker(w4); rt.new_worker(w4)
+        rt.new_tasks(3, ta.user_priority(10)); rt.new_tasks(2, tb.user_priority(9)); rt.new_tasks(1, ta.user_priority(8))
+        rt.new_tasks(3, ta.user_priority(7)); rt.new_tasks(1, tb.user_priority(6)); rt.new_tasks(1, tb.user_priority(5))
+        rt.new_tasks(5, ta.user_priority(4)); rt.new_tasks(1, tb.user_priority(3))
+        rt.schedule(backend)
+        counts = rt.assigned_counts()
+        assert (counts[0], counts[1]) == (count_a, count_b), (w_cpus, counts)
+
+
+def test_schedule_gap_filling(backend):  # sn:411-449
+    w6, w12, w8 = WB(6), WB(12), WB(8)
+    c = TestCase(backend); ts = c.pc_tasks([(1, 8), (1, 8), (0, 4)]); c.w(w12).expect_tasks([ts[0], ts[2]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(1, 3), (1, 3), (1, 3), (0, 2)]); c.w(w6).expect_tasks([ts[0], ts[1]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(1, 3), (1, 3), (1, 3), (0, 1), (0, 1)]); c.w(w8).expect_tasks([ts[0], ts[1], ts[3], ts[4]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(1, 3), (1, 3), (1, 3), (2, 1), (0, 1)]); c.w(w8).expect_tasks([ts[3], ts[0], ts[1], ts[4]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(1, 3), (1, 3), (1, 3), (2, 1), (0, 1), (0, 1), (0, 1), (0, 1)])
+    c.w(w8).expect_tasks([ts[3], ts[0], ts[1], ts[4]]); c.check()
+
+
+def test_schedule_gap_filling2(backend):  # sn:462-494
+    for extra in (True, False):
+        rt = env()
+        rt.new_named_resource("foo")
+        rt.new_worker(WB(8))
+        rt.new_workers(3, WB(4).res_sum("foo", 1))
+        ta, tb, tc = TB().cpus(1), TB().cpus(3), TB().cpus(4).add_resource(1, 1)
+        rt.new_tasks(7, ta.user_priority(1)); rt.new_tasks(3, tb.user_priority(2)); rt.new_tasks(3, tc.user_priority(2))
+        if extra:
+            rt.new_tasks(2, tb.user_priority(-1)); rt.new_tasks(3, tc.user_priority(-2)); rt.new_tasks(1, ta.user_priority(-3))
+            rt.new_tasks(2, tb.user_priority(-4)); rt.new_tasks(3, tc.user_priority(-5)); rt.new_tasks(1, ta.user_priority(-6))
+        rt.schedule(backend)
+        assert rt.assigned_counts()[:3] == [2, 2, 3]
+        rt.schedule(backend)
+
+
+def test_schedule_gap_filling3(backend):  # sn:497-525
+    rt = env()
+    rt.new_named_resource("foo")
+    ws = rt.new_workers(2, WB(34))
+    ta, tb = TB().cpus(3), TB().cpus(9)
+    rt.new_tasks(5, ta.user_priority(10))
+    ts2 = rt.new_tasks(6, tb.user_priority(10))
+    ts3 = rt.new_tasks(5, ta.user_priority(9))
+    rt.schedule(backend)
+    for w in ws:
+        cpus = t3 = 0
+        for t in rt.worker_tasks(w):
+            if t in ts2:
+                cpus += 9
+            else:
+                cpus += 3
+                t3 += t in ts3
+        assert cpus == 33 and t3 <= 2
+
+
+def test_schedule_gap_filling4(backend):  # sn:528-565
+    rt = env()
+    for n in ("foo", "bar", "goo"):
+        rt.new_named_resource(n)
+    rt.new_workers(2, WB(3).res_sum("foo", 10).res_sum("goo", 10))
+    rt.new_worker(WB(3).res_sum("foo", 10).res_sum("bar", 10))
+    rt.new_tasks(5, TB().cpus(2).add_resource(3, 1).user_priority(10))
+    rt.new_tasks(2, TB().cpus(1).add_resource(1, 1).user_priority(9))
+    rt.new_tasks(10, TB().cpus(3).add_resource(1, 1).add_resource(2, 1).user_priority(8))
+    rt.schedule(backend)
+    assert rt.assigned_counts() == [2, 2, 1]
+
+
+def test_schedule_reservations(backend):  # sn:568-633
+    c = TestCase(backend); ts = c.pc_tasks([(3, 3), (2, 2)])
+    c.w(WB(3)).eq_class(0).running_c(1).expect_tasks([]); c.w(WB(3)).eq_class(0).running_c(1).expect_tasks([ts[1]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(3, 3), (2, 1), (2, 1)])
+    c.w(WB(3)).eq_class(0).running_c(1); c.w(WB(3)).eq_class(0).running_c(1).expect_tasks([ts[1], ts[2]]); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(3, 3), (2, 1), (2, 1)])
+    c.w(WB(3)).running_c(2).expect_tasks([ts[1]]); c.w(WB(3)).running_c(1); c.check()
+    c = TestCase(backend); ts = c.pc_tasks([(4, 3), (3, 3), (3, 3), (2, 1), (2, 1)])
+    c.w(WB(4)).running_c(1).expect_tasks([ts[0]]); c.w(WB(3)).running_c(2).expect_tasks([ts[3]]); c.w(WB(3)).running_c(2); c.w(WB(3)).running_c(1); c.check()
+    c = TestCase(backend); c.pc_tasks([(4, 3), (3, 3), (3, 3), (2, 1), (2, 1)])
+    c.w(WB(3)).running_c(2).expect_request(1, TB()); c.w(WB(3)).running_c(2); c.w(WB(3)).running_c(1)
+    c.w(WB(4)).expect_request(1, TB().cpus(3)).expect_request(1, TB()); c.check()
+
+
+def test_schedule_multiple_resources1(backend):  # sn:636-686
+    w4_1, w4_2 = WB(4).res_range("gpus", 1, 1), WB(4).res_range("gpus", 1, 2)
+    tb2_1, tb1_2, tb2 = TB().cpus(2).add_resource(1, 1), TB().cpus(1).add_resource(1, 2), TB().cpus(2)
+    create = lambda: TestCase(backend).resources(["gpus"])
+    c = create(); t1 = c.t(tb2_1); t2 = c.t(tb2_1); c.w(w4_2).expect_tasks([t1, t2]); c.check()
+    c = create(); t1 = c.t(tb2_1); c.t(tb2_1); c.w(w4_1).expect_tasks([t1]); c.check()
+    c = create(); t1 = c.t(tb2); c.w(w4_2).expect_tasks([t1]); c.check()
+    c = create(); t1 = c.t(tb1_2); c.w(w4_2).expect_tasks([t1]); c.check()
+    c = create(); c.t(tb1_2); c.w(w4_1).expect_tasks([]); c.check()
+    c = TestCase(backend).resources(["gpus", "foo"])
+    ta, tb, tc = TB().cpus(2).add_resource(1, 1), TB().add_resource(1, 1).add_resource(2, 2), TB().cpus(4)
+    c.t(ta); c.ts(2, tb); c.ts(2, tc); c.t(tb)
+    c.w(WB(6)).expect_request(1, tc)
+    c.w(WB(3).res_sum("gpus", 2)).expect_request(1, ta)
+    c.w(WB(5).res_sum("gpus", 20).res_sum("foo", 4)).expect_request(2, tb)
+    c.check()
+
+
+def test_schedule_multiple_resources2(backend):  # sn:689-721
+    tb2_1, tb2 = TB().cpus(2).add_resource(1, 1), TB().cpus(2)
+
+    def create():
+        c = TestCase(backend).resources(["gpus"]); c.ts(10, tb2); c.ts(10, tb2_1); return c
+
+    c = create(); c.w(WB(6)).expect_request(3, tb2); c.check()
+    c = create(); c.w(WB(6).res_sum("gpus", 10)).expect_request(3, tb2_1); c.check()
+    c = create(); c.w(WB(6).res_sum("gpus", 2)).expect_request(2, tb2_1).expect_request(1, tb2); c.check()
+    c = create(); c.w(WB(6).res_sum("gpus", 2)).expect_request(2, tb2_1).expect_request(1, tb2); c.w(WB(6)).expect_request(3, tb2); c.check()
+
+
+def test_schedule_variants1(backend):  # sn:724-755
+    tb1 = TB().cpus(2).next_variant().cpus(5)
+    c = TestCase(backend); c.ts(2, tb1); c.w(WB(11)).expect_request_v(2, tb1, 1); c.check()
+    c = TestCase(backend); c.ts(3, tb1); c.w(WB(11)).expect_request_v(2, tb1, 1); c.check()
+    c = TestCase(backend); c.ts(3, tb1); c.w(WB(14)).expect_request_v(2, tb1, 1).expect_request_v(1, tb1, 0); c.check()
+    c = TestCase(backend); c.ts(10, tb1); c.w(WB(8)).expect_request_v(4, tb1, 0); c.check()
+    c = TestCase(backend); c.ts(3, tb1); c.w(WB(8)).expect_request_v(1, tb1, 0).expect_request_v(1, tb1, 1); c.check()
+
+
+def test_schedule_variants2(backend):  # sn:758-783
+    tb1 = TB().cpus(6).next_variant().cpus(2).add_resource(1, 2)
+    create = lambda: TestCase(backend).resources(["gpus"])
+    c = create(); c.ts(10, tb1); c.w(WB(12)).expect_request_v(2, tb1, 0); c.check()
+    c = create(); c.ts(10, tb1); c.w(WB(12).res_sum("gpus", 4)).expect_request_v(1, tb1, 0).expect_request_v(2, tb1, 1); c.check()
+    c = create(); c.ts(10, tb1); c.w(WB(12).res_sum("gpus", 20)).expect_request_v(6, tb1, 1); c.check()
+
+
+def _msg_task_count(res, widx):
+    """number of tasks in the worker's ComputeTasks message (prefills + assigned)  mapping.rs:266-282."""
+    return len(res.records[widx])
+
+
+def test_no_deps_scattering_1(backend):  # sn:794-814
+    rt = env()
+    rt.new_workers_cpus([5, 5, 5])
+    rt.new_tasks(4, TB())
+    res = rt.schedule(backend)
+    assert [_msg_task_count(res, i) for i in range(3)] == [4, 0, 0]
+
+
+def test_no_deps_scattering_2(backend):  # sn:817-847
+    rt = env()
+    rt.new_workers_cpus([5, 5, 5])
+
+    def submit_and_check(expected):
+        rt.new_task()
+        rt.schedule(backend)
+        assert sorted(len(w.assigned_tasks) for w in rt.workers.values()) == expected
+
+    for i in range(1, 6):
+        submit_and_check([0, 0, i])
+    for i in range(1, 6):
+        submit_and_check([0, i, 5])
+    for i in range(1, 6):
+        submit_and_check([i, 5, 5])
+    submit_and_check([5, 5, 5])
+    submit_and_check([5, 5, 5])
+
+
+def test_no_deps_distribute(backend):  # sn:850-872
+    rt = env(reserve=10, fill_max=20)
+    rt.new_workers_cpus([10, 10, 10])
+    rt.new_tasks(150, TB())
+    res = rt.schedule(backend)
+    assert [_msg_task_count(res, i) for i in range(3)] == [30, 30, 30]
+
+
+def test_resource_time_assign(backend):  # sn:875-886
+    rt = env()
+    w1 = rt.new_worker(WB(10).time_limit_s(100))
+    rt.new_task(TB().time_request(170))
+    t2 = rt.new_task()
+    t3 = rt.new_task(TB().time_request(99))
+    rt.schedule(backend)
+    assert rt.worker_tasks(w1) == {t2, t3}
+
+
+def test_resource_time_balance1(backend):  # sn:889-904
+    rt = env()
+    w1 = rt.new_worker(WB(1).time_limit_s(50)); w2 = rt.new_worker(WB(1).time_limit_s(200)); w3 = rt.new_worker(WB(1).time_limit_s(100))
+    t1 = rt.new_task(TB().time_request(170)); t2 = rt.new_task(TB()); t3 = rt.new_task(TB().time_request(99))
+    rt.schedule(backend)
+    assert rt.worker_tasks(w1) == {t2} and rt.worker_tasks(w2) == {t1} and rt.worker_tasks(w3) == {t3}
+
+
+def _generic3(rt):
+    rt.new_generic_resource(2)
+    w1 = rt.new_worker(WB(10).res_range("Res0", 1, 10))
+    w2 = rt.new_worker(WB(10))
+    w3 = rt.new_worker(WB(10).res_range("Res0", 1, 10).res_sum("Res1", 1_000_000))
+    return w1, w2, w3
+
+
+def test_generic_resource_assign2(backend):  # sn:907-938
+    rt = env(); w1, w2, w3 = _generic3(rt)
+    ts1 = rt.new_tasks(50, TB().add_resource(1, 1))
+    rt.new_tasks(50, TB().add_resource(1, 2))
+    rt.schedule(backend)
+    assert len(rt.worker_tasks(w1)) == 10 and len(rt.worker_tasks(w2)) == 0 and len(rt.worker_tasks(w3)) == 10
+    assert all(t in ts1 for t in rt.worker_tasks(w1))
+
+
+def test_generic_resource_balance1(backend):  # sn:941-960
+    rt = env(); w1, w2, w3 = _generic3(rt)
+    rt.new_tasks(4, TB().cpus(1).add_resource(1, 5))
+    rt.schedule(backend)
+    assert [len(rt.worker_tasks(w)) for w in (w1, w2, w3)] == [2, 0, 2]
+
+
+def test_generic_resource_balance2(backend):  # sn:963-990
+    rt = env(); w1, w2, w3 = _generic3(rt)
+    rt.new_task(TB().cpus(1).add_resource(1, 5))
+    rt.new_task(TB().cpus(1).add_resource(1, 5).add_resource(2, 500_000))
+    rt.new_task(TB().cpus(1).add_resource(1, 5))
+    rt.new_task(TB().cpus(1).add_resource(1, 5).add_resource(2, 500_000))
+    rt.schedule(backend)
+    assert [len(rt.worker_tasks(w)) for w in (w1, w2, w3)] == [2, 0, 2]
+
+
+def test_generic_resource_balancing3(backend):  # sn:993-1049
+    rt = env(reserve=0, fill_max=100)
+    rt.new_generic_resource(1)
+    w1 = rt.new_worker(WB(2)); w2 = rt.new_worker(WB(2).res_range("Res0", 1, 1))
+    ts1 = rt.new_tasks(80, TB()); ts2 = rt.new_tasks(20, TB().cpus(1).add_resource(1, 1))
+    rq1, rq2 = rt.task(ts1[0]).rq, rt.task(ts2[0]).rq
+    rt.schedule(backend)
+    a = rt.worker(w1)
+    assert len(a.assigned_tasks) == 2 and all(rt.task(t).rq == rq1 for t in a.assigned_tasks)
+    assert len(a.prefilled_tasks) == 38 and all(rt.task(t).rq == rq1 for t in a.prefilled_tasks)
+    a = rt.worker(w2)
+    assert len(a.assigned_tasks) == 2 and len(a.prefilled_tasks) == 57
+    assert sum(rt.task(t).rq == rq1 for t in a.prefilled_tasks) == 38 and sum(rt.task(t).rq == rq2 for t in a.prefilled_tasks) == 19
+
+
+def test_generic_resource_variants(backend):  # sn:1052-1108
+    for (wb1, wb2, first, exp) in [
+        (WB(4), WB(4).res_range("Res0", 1, 2), 2, (2, 2)),
+        (WB(4), WB(4).res_range("Res0", 1, 2), 8, (0, 2)),
+        (WB(2), WB(5).res_range("Res0", 1, 1), 3, (0, 2)),
+    ]:
+        rt = env(); rt.new_generic_resource(1)
+        w1, w2 = rt.new_worker(wb1), rt.new_worker(wb2)
+        rt.new_tasks(4, TB().cpus(first).next_variant().cpus(1).add_resource(1, 1))
+        rt.schedule(backend)
+        assert (len(rt.worker_tasks(w1)), len(rt.worker_tasks(w2))) == exp
+
+
+def test_scheduler_two_running_three_waiting(backend):  # sn:1111-1127
+    rt = env(); rt.new_named_resource("foo")
+    w = rt.new_worker(WB(8).res_range("foo", 1, 4))
+    ts = rt.new_tasks(4, TB().cpus(1).add_resource(1, 2))
+    rt.assign_and_start_task(ts[0], w, 0); rt.assign_and_start_task(ts[1], w, 0)
+    t5 = rt.new_task(TB().cpus(2).user_priority(1))
+    rt.schedule(backend)
+    assert rt.task(t5).is_assigned() and rt.task(ts[0]).is_sn_running() and rt.task(ts[1]).is_sn_running()
+    assert rt.task(ts[2]).is_waiting() and rt.task(ts[3]).is_waiting()
+
+
+def test_many_cuts(backend):  # sn:1131-1146 (tolerance test)
+    rt = env()
+    rt.new_workers(300, WB(8))
+    ts1, ts2 = [], []
+    for i in range(3200):
+        ts1.append(rt.new_task(TB().cpus(1).user_priority(i)))
+        ts2.append(rt.new_task(TB().cpus(2).user_priority(i)))
+    rt.schedule(backend)
+    c1 = sum(rt.task(t).is_assigned() for t in ts1); c2 = sum(rt.task(t).is_assigned() for t in ts2)
+    assert abs(c1 - c2) < 10 and abs(c1 - 800) < 10 and abs(c2 - 800) < 10
+
+
+def test_prefill_basic(backend):  # sn:1169-1201
+    rt = env(reserve=4, fill_max=32)
+    ws = rt.new_workers(2, WB(8))
+    tasks = rt.new_tasks(300, TB().cpus(4))
+    rq, prio = rt.task(tasks[0]).rq, rt.task(tasks[0]).priority
+    res = rt.schedule(backend)
+    for i, w in enumerate(ws):
+        recs = res.records[i]
+        assert len(recs) == 34
+        for k, (t, v, kind) in enumerate(recs):
+            assert (v == 0xFF) == (k < 32)  # resource_rq_variant.is_none() for the 32 prefills first
+    for w in ws:
+        assert rt.prefill_count(w) == 32
+    assert rt.queue_priority_sizes(rq) == [(prio, 296)]
+
+
+def test_prefill_choose_waiting(backend):  # sn:1204-1225
+    rt = env(reserve=3, fill_max=6)
+    w1 = rt.new_worker(WB(1))
+    rt.new_tasks(15, TB())
+    rt.schedule(backend)
+    assert rt.prefill_count(w1) == 6
+    w2 = rt.new_worker(WB(1))
+    rt.schedule(backend)
+    assert rt.prefill_count(w1) == 6 and rt.prefill_count(w2) == 4
+    w3 = rt.new_worker(WB(1))
+    rt.schedule(backend)
+    assert (rt.prefill_count(w1), rt.prefill_count(w2), rt.prefill_count(w3)) == (6, 4, 0)
+
+
+def test_prefill_steal(backend):  # sn:1228-1306 (up to the retract response, which is reactor scope)
+    rt = env(reserve=3, fill_max=6)
+    w1 = rt.new_worker(WB(1))
+    tasks = rt.new_tasks(9, TB())
+    rq, prio = rt.task(tasks[0]).rq, rt.task(tasks[0]).priority
+    rt.schedule(backend)
+    assert rt.prefill_count(w1) == 5
+    w2 = rt.new_worker(WB(5))
+    assert rt.queue_priority_sizes(rq) == [(prio, 8)]
+    res = rt.schedule(backend)
+    assert len(res.retracts[0]) == 2          # RetractTasks with 2 ids to w1
+    assert len(res.records[0]) == 0
+    assert len(res.records[1]) == 3           # ComputeTasks with 3 tasks to w2
+    assert sorted(rt.redirects.values()) == [(w2, 0), (w2, 0)]
+    assert rt.prefill_count(w1) == 3 and rt.prefill_count(w2) == 0
+    assert len(rt.worker(w1).assigned_tasks) == 1 and len(rt.worker(w2).assigned_tasks) == 5
+
+
+def test_schedule_running(backend):  # sn:1309-1322
+    rt = env()
+    w = rt.new_worker(WB(14))
+    for _ in range(8):
+        rt.new_task_running(TB(), w)
+    ts = rt.new_tasks(10, TB())
+    rt.schedule(backend)
+    assert len(rt.worker(w).assigned_tasks) == 14 and sum(rt.task(t).is_assigned() for t in ts) == 6
+
+
+def test_schedule_variant_gap1(backend):  # sn:1325-1351
+    for running in (0, 1, 2):
+        rt = env(); rt.new_named_resource("gpus")
+        w = rt.new_worker(WB(14).res_sum("gpus", 4))
+        for _ in range(running):
+            rt.new_task_running(TB(), w)
+        rt.new_tasks(10, TB().user_priority(10).cpus(8).next_variant().cpus(4).add_resource(1, 2))
+        ts = rt.new_tasks(10, TB())
+        rt.schedule(backend)
+        assert sum(rt.task(t).is_assigned() for t in ts) == 2 - running
+
+
+def test_schedule_resource_weights(backend):  # sn:1354-1389
+    rt = env(); t1 = rt.new_task(TB().cpus(3)); t2 = rt.new_task(TB().cpus(2).weight(1.49)); rt.new_worker(WB(4)); rt.schedule(backend)
+    assert rt.task(t1).is_assigned() and rt.task(t2).is_waiting()
+    rt = env(); t1 = rt.new_task(TB().cpus(3).weight(1.0)); t2 = rt.new_task(TB().cpus(2).weight(1.51)); rt.new_worker(WB(4)); rt.schedule(backend)
+    assert rt.task(t1).is_waiting() and rt.task(t2).is_assigned()
+    rt = env(); ts = rt.new_tasks(5, TB().cpus(3).weight(1.1)); t1 = rt.new_task(TB().cpus_all()); rt.new_worker(WB(12)); rt.schedule(backend)
+    assert sum(rt.task(t).is_assigned() for t in ts) == 4 and rt.task(t1).is_waiting()
+    rt = env(); ts = rt.new_tasks(5, TB().cpus(3)); t1 = rt.new_task(TB().cpus_all().weight(1.1)); rt.new_worker(WB(12)); rt.schedule(backend)
+    assert sum(rt.task(t).is_assigned() for t in ts) == 0 and rt.task(t1).is_assigned()
+
+
+def test_schedule_min_utilization(backend):  # sn:1392-1466
+    def run(n, cpus, mu, running=False, weight=None, all_task=False):
+        rt = env()
+        tb = TB().cpus(3) if weight is None else TB().cpus(3).weight(weight)
+        ts = rt.new_tasks(n, tb)
+        t2 = rt.new_task(TB().cpus_all()) if all_task else None
+        w = rt.new_worker(WB(cpus).min_utilization(mu))
+        if running:
+            rt.new_task_running(TB().cpus(3), w)
+        rt.schedule(backend)
+        return sum(rt.task(t).is_assigned() for t in ts), (rt.task(t2).is_assigned() if all_task else None)
+
+    assert run(2, 9, 1.0)[0] == 0 and run(3, 9, 1.0)[0] == 3 and run(2, 9, 1.0, running=True)[0] == 2
+    assert run(2, 12, 0.5)[0] == 2 and run(2, 12, 0.51)[0] == 0 and run(3, 12, 0.51)[0] == 3
+    assert run(3, 12, 0.75)[0] == 3 and run(3, 12, 0.76)[0] == 0
+    assert run(3, 12, 1.0, weight=2.0, all_task=True) == (0, True)
+    assert run(4, 12, 1.0, weight=2.0, all_task=True) == (4, False)
+
+
+def test_schedule_bounded(backend):  # sn:1489-1513
+    rt = env(); rt.new_worker(WB(4)); t = rt.new_task(TB().cpus(999)); rt.schedule(backend)
+    assert not rt.task(t).is_assigned()
+    rt = env(); rt.new_worker(WB(4)); rt.new_tasks(2, TB().cpus(1))
+    assert backend.tick(rt.snapshot()).is_optimal
+
+
+# ---------------------------------------------------------------------------------------------- multi-node
+def test_schedule_mn_simple(backend):  # mn:89-160 (first tick + refill after finishing)
+    rt = env()
+    rt.new_workers_cpus([5, 5, 5, 5, 5])
+    t1 = rt.new_task(TB().user_priority(1).n_nodes(2)); t2 = rt.new_task(TB().user_priority(2).n_nodes(2))
+    t3 = rt.new_task(TB().user_priority(3).n_nodes(2)); t4 = rt.new_task(TB().user_priority(4).n_nodes(2))
+    rt.schedule(backend)
+    ws3, ws4 = rt.task(t3).mn_workers, rt.task(t4).mn_workers
+    assert len(ws3) == 2 and len(ws4) == 2 and not set(ws3) & set(ws4)
+    assert rt.task(t2).is_waiting() and rt.task(t1).is_waiting()
+    rt.finish_task(t3, ws3[0])
+    rt.schedule(backend)
+    ws2 = rt.task(t2).mn_workers
+    assert ws2 is not None and len(ws2) == 2 and rt.task(t1).is_waiting()
+
+
+ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]

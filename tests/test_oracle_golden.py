@@ -1,0 +1,39 @@
+"""Pins the CPU oracle against the reference's own unit-test vectors.  CPU only."""
+import pytest
+
+import golden_cases
+from hyperqueue_amd import abi
+from oracle.oracle import Oracle
+
+
+class OracleBackend:
+    """Adapter: SchedEnv carries its SchedulerConfig; the oracle ctx is created per config."""
+
+    def __init__(self):
+        self._ctx = {}
+
+    def _o(self, cfg: abi.Config) -> Oracle:
+        key = (cfg.proactive_filling_reserve, cfg.proactive_filling_max)
+        if key not in self._ctx:
+            self._ctx[key] = Oracle(cfg)
+        return self._ctx[key]
+
+    cfg = abi.make_config()
+
+    def tick(self, snap):
+        return self._o(getattr(snap, "config", None) or self.cfg).tick(snap)
+
+    def batches(self, snap):
+        return self._o(getattr(snap, "config", None) or self.cfg).batches(snap)
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return OracleBackend()
+
+
+@pytest.mark.parametrize("case", golden_cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_golden(case, backend):
+    if case.__name__ == "test_many_cuts":
+        pytest.skip("tolerance test, run in test_oracle_slow")
+    case(backend)
