@@ -1,0 +1,35 @@
+// Test hooks declared in include/hqtick_debug.h: host-side building blocks that can be unit-tested without a GPU.
+// They are NOT a CPU implementation of the tick (hqtick_run has none): only the exact MILP solver and the
+// hashbrown-order helper are reachable here.
+#include "../../include/hqtick_debug.h"
+
+#include "hb_order.h"
+#include "milp.h"
+
+extern "C" int hqtick_debug_milp_solve(int ncols, const double *obj, const uint8_t *col_kind, int nrows, const uint8_t *row_type,
+                                       const double *rhs, const int *row_off, const int *row_col, const double *row_coef,
+                                       double time_limit_s, int canonical, double *x_out, double *obj_out, int *is_optimal,
+                                       long *nodes_out) {
+    hqmilp::Model m;
+    m.obj.assign(obj, obj + ncols);
+    m.kind.assign(col_kind, col_kind + ncols);
+    m.rtype.assign(row_type, row_type + nrows);
+    m.rhs.assign(rhs, rhs + nrows);
+    m.roff.assign(row_off, row_off + nrows + 1);
+    int nnz = nrows ? row_off[nrows] : 0;
+    m.rcol.assign(row_col, row_col + nnz);
+    m.rcoef.assign(row_coef, row_coef + nnz);
+    hqmilp::Result r = hqmilp::solve(m, time_limit_s, canonical != 0);
+    if (nodes_out) *nodes_out = r.nodes;
+    if (!r.feasible) return 0;
+    for (int j = 0; j < ncols; j++) x_out[j] = r.x[j];
+    *obj_out = r.objective;
+    *is_optimal = r.optimal ? 1 : 0;
+    return 1;
+}
+
+extern "C" void hqtick_debug_map_order_u32(const uint32_t *keys, uint32_t n, uint32_t *out_pos) {
+    std::vector<uint32_t> order;
+    hqhb::insertion_order_u32(keys, n, order);
+    for (uint32_t i = 0; i < n; i++) out_pos[i] = order[i];
+}

@@ -1,0 +1,430 @@
+// Host stages: batch merge, placement model, gap cache, decode (see host_model.h).
+#include "host_model.h"
+
+#include <algorithm>
+#include <cmath>
+
+#include "hb_order.h"
+
+namespace hqhost {
+
+namespace {
+
+const double FRACTIONS = 10000.0;
+inline double units(uint64_t a) { return (double)a / FRACTIONS; }  // ResourceAmount::as_f64  amount.rs:91-93
+
+// prune_progressive  scheduler/batches.rs:183-217: keep `prefix` cuts, sample the rest quadratically
+void prune_cuts(std::vector<PriorityCut> &cuts, size_t prefix, size_t limit) {
+    size_t n = cuts.size();
+    if (n <= limit) return;
+    std::vector<size_t> pick;
+    for (size_t i = 0; i < prefix; i++) pick.push_back(i);
+    size_t slots = limit - prefix, pool = n - prefix, prev = prefix - 1;
+    for (size_t i = 0; i < slots; i++) {
+        double t = (double)i / (double)(slots - 1);
+        size_t idx = prefix + (size_t)std::round(t * t * (double)(pool - 1));
+        if (idx <= prev) idx = prev + 1;
+        pick.push_back(idx);
+        prev = idx;
+    }
+    std::vector<PriorityCut> kept;
+    kept.reserve(limit);
+    for (size_t i = 0; i < limit; i++) kept.push_back(std::move(cuts[pick[i]]));  // pick is strictly increasing: same result as the in-place swaps
+    cuts.swap(kept);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// create_task_batches  scheduler/batches.rs:42-181
+// ---------------------------------------------------------------------------------------------------------------
+std::vector<TaskBatch> create_task_batches(const Problem &pb, const std::vector<QueueLevels> &queues) {
+    std::vector<uint32_t> live;  // non-empty queues, in rq order
+    for (uint32_t q = 0; q < queues.size(); q++) if (!queues[q].levels.empty()) live.push_back(q);
+    std::vector<TaskBatch> batches(live.size());
+    if (live.empty()) return batches;
+    const WorkerSet &lim_ws = pb.custom ? *pb.custom : pb.real;
+    for (size_t b = 0; b < live.size(); b++) {
+        uint32_t rq = live[b];
+        uint32_t limit = 0;
+        if (pb.rq_multi_node(rq)) {  // :65-78
+            uint32_t frees = 0;
+            for (uint32_t w = 0; w < pb.real.n; w++) frees += pb.real.is_free(w) ? 1 : 0;
+            limit = frees / pb.variants[pb.rqs[rq].first_variant].n_nodes;
+        } else {  // :79-92
+            for (uint32_t w = 0; w < lim_ws.n; w++) {
+                if (!pb.capable_rqv(lim_ws, w, rq)) continue;
+                uint32_t runnable = 0;
+                if (lim_ws.is_sn(w)) for (uint32_t v = 0; v < pb.rqs[rq].n_variants; v++) runnable += lim_ws.tmc(w, pb.rqs[rq].first_variant + v);
+                limit += runnable > 0 ? runnable : 1;
+            }
+        }
+        batches[b].rq = rq;
+        batches[b].limit = limit;
+    }
+    // k-way merge of the queues' (priority, size) streams  :97-171
+    size_t nb = live.size();
+    std::vector<size_t> cursor(nb, 0);
+    std::vector<char> open(nb, 1);
+    auto cur_prio = [&](size_t b) { return queues[live[b]].levels[cursor[b]].first; };
+    auto absorb = [&](size_t b) {
+        TaskBatch &tb = batches[b];
+        tb.size += queues[live[b]].levels[cursor[b]].second;
+        if (tb.size > tb.limit) { tb.size = tb.limit; tb.limit_reached = true; open[b] = 0; }
+        else if (++cursor[b] >= queues[live[b]].levels.size()) open[b] = 0;
+    };
+    long last_single = -1;
+    std::vector<size_t> top;
+    for (;;) {
+        top.clear();
+        uint64_t best = 0;
+        for (size_t b = 0; b < nb; b++) {
+            if (!open[b]) continue;
+            uint64_t p = cur_prio(b);
+            if (p > best) { best = p; top.clear(); top.push_back(b); }
+            else if (p == best) top.push_back(b);
+        }
+        if (top.empty()) break;
+        if (top.size() == 1 && last_single == (long)top[0]) { absorb(top[0]); continue; }
+        for (size_t b : top) {
+            PriorityCut cut;
+            cut.size = batches[b].size;
+            for (size_t o = 0; o < nb; o++) {
+                if (o == b) continue;
+                TaskBatch &ob = batches[o];
+                if (ob.size > 0 || ob.limit_reached) {
+                    ob.is_blocker = true;
+                    cut.blockers.push_back({ob.rq, ob.limit_reached ? HQ_BLOCKER_UNBOUNDED : ob.size});
+                }
+            }
+            if (!cut.blockers.empty()) batches[b].cuts.push_back(std::move(cut));
+        }
+        for (size_t b : top) absorb(b);
+        last_single = top.size() == 1 ? (long)top[0] : -1;
+    }
+    std::vector<TaskBatch> out;
+    for (auto &tb : batches) {
+        prune_cuts(tb.cuts, 4, 32);
+        if (tb.size > 0) out.push_back(std::move(tb));
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gap  scheduler/gap.rs
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Amounts {
+    std::vector<uint64_t> a;
+    uint64_t get(uint32_t r) const { return r < a.size() ? a[r] : 0; }
+};
+
+uint32_t max_count(const Amounts &have, const VariantView &rq) {  // task_max_count_for_request  workerload.rs:121-145
+    bool any = false; uint64_t best = 0;
+    for (uint32_t e = 0; e < rq.n_entries; e++) {
+        uint64_t c = rq.kind[e] == HQ_ENTRY_ALL ? (have.get(rq.res[e]) ? 1 : 0) : std::min<uint64_t>(have.get(rq.res[e]) / rq.amount[e], HQ_MAX_TASK_PER_WORKER);
+        if (!any || c < best) best = c;
+        any = true;
+    }
+    return any ? (uint32_t)best : 0;
+}
+void take_away(Amounts &have, const VariantView &rq, uint64_t times) {  // remove / remove_multiple  workerload.rs:156-177
+    for (uint32_t e = 0; e < rq.n_entries; e++) {
+        uint32_t r = rq.res[e];
+        if (r >= have.a.size()) have.a.resize(r + 1, 0);
+        if (rq.kind[e] == HQ_ENTRY_ALL) have.a[r] = 0;
+        else { uint64_t d = rq.amount[e] * times; have.a[r] = have.a[r] > d ? have.a[r] - d : 0; }
+    }
+}
+
+struct GapCache {
+    std::map<std::pair<uint32_t, std::vector<uint64_t>>, Amounts> memo;  // (rq, WorkerResources) -> leftover   gap.rs:14-35
+    const Problem &pb;
+    explicit GapCache(const Problem &p) : pb(p) {}
+
+    // compute_gap_resources  gap.rs:95-147: per non-zero resource, how much of it the blocker's variants can use at most
+    Amounts leftover_multi_variant(uint32_t rq, const Amounts &total) {
+        const RequestView &rv = pb.rqs[rq];
+        long top = -1;
+        for (uint32_t v = 0; v < rv.n_variants; v++) { const VariantView &vv = pb.variants[rv.first_variant + v]; for (uint32_t e = 0; e < vv.n_entries; e++) top = std::max<long>(top, vv.res[e]); }
+        Amounts out;
+        if (top < 0) return out;
+        for (uint32_t r = 0; r < total.a.size(); r++) {
+            uint64_t have = total.a[r];
+            if (have == 0) continue;  // iter_pairs skips zero amounts; the result keeps one slot per visited pair
+            hqmilp::Model m;
+            for (uint32_t v = 0; v < rv.n_variants; v++) {
+                const VariantView &vv = pb.variants[rv.first_variant + v];
+                double w = 0.0;
+                for (uint32_t e = 0; e < vv.n_entries; e++) if (vv.res[e] == r) w = vv.kind[e] == HQ_ENTRY_ALL ? units(total.get(r)) : units(vv.amount[e]);
+                m.add_col(w, hqmilp::COL_NAT);
+            }
+            for (long rr = 0; rr <= top; rr++) {
+                m.begin_row(hqmilp::ROW_MAX, units(total.get((uint32_t)rr)));
+                for (uint32_t v = 0; v < rv.n_variants; v++) {
+                    const VariantView &vv = pb.variants[rv.first_variant + v];
+                    for (uint32_t e = 0; e < vv.n_entries; e++) if (vv.res[e] == (uint32_t)rr) m.term((int)v, vv.kind[e] == HQ_ENTRY_ALL ? units(total.get(r)) : units(vv.amount[e]));
+                }
+                m.end_row();
+            }
+            hqmilp::Result s = hqmilp::solve(m, 1e9, false);
+            if (!s.feasible || !s.optimal) { out.a.push_back(0); continue; }
+            uint64_t used = (uint64_t)std::ceil((float)std::round(s.objective) * 10000.0f);  // ResourceAmount::from_float(v.round() as f32)
+            out.a.push_back(have - used);
+        }
+        return out;
+    }
+
+    uint32_t gap(uint32_t high_rq, uint32_t low_rq, const Amounts &total, const std::vector<std::pair<uint32_t, uint8_t>> &assigned) {
+        if (pb.rq_multi_node(high_rq) || pb.rq_multi_node(low_rq)) return 0;
+        const RequestView &h = pb.rqs[high_rq];
+        Amounts left;
+        if (h.n_variants == 1) {
+            const VariantView &hv = pb.variants[h.first_variant];
+            for (uint32_t e = 0; e < hv.n_entries; e++) if (hv.kind[e] == HQ_ENTRY_ALL) return 0;
+            left = total;
+            take_away(left, hv, max_count(total, hv));
+        } else {
+            auto key = std::make_pair(high_rq, total.a);
+            auto it = memo.find(key);
+            if (it == memo.end()) it = memo.emplace(key, leftover_multi_variant(high_rq, total)).first;
+            left = it->second;
+        }
+        for (auto &t : assigned) if (t.first != high_rq) take_away(left, pb.variants[pb.rqs[t.first].first_variant + t.second], 1);
+        const RequestView &l = pb.rqs[low_rq];
+        uint32_t best = 0;
+        for (uint32_t v = 0; v < l.n_variants; v++) { uint32_t c = max_count(left, pb.variants[l.first_variant + v]); if (v == 0 || c < best) best = c; }
+        return best;
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// run_scheduling_solver  scheduler/solver.rs:36-483
+// ---------------------------------------------------------------------------------------------------------------
+Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &batches) {
+    Counts out;
+    if (pb.rqs.empty()) return out;  // :53-55
+    const WorkerSet &ws = pb.custom ? *pb.custom : pb.real;
+    const uint32_t R = pb.R;
+    std::vector<uint32_t> solver_workers;  // SN workers, ascending id (the worker arrays are already sorted)  :57-66
+    for (uint32_t w = 0; w < ws.n; w++) if (pb.custom || ws.is_sn(w)) solver_workers.push_back(w);
+    const size_t nw = solver_workers.size();
+    std::vector<double> pool(R, 0.0);  // resource_sums  :56,68-82
+    for (uint32_t w : solver_workers) for (uint32_t r = 0; r < R; r++) { uint64_t c = ws.free_[(size_t)w * R + r]; pool[r] += c == HQ_AMOUNT_MAX ? 1.0 : units(c); }
+
+    hqmilp::Model m;
+    std::map<std::tuple<uint32_t, uint32_t, uint8_t>, int> place;  // (worker, rq, variant) -> column   :88
+    std::map<uint32_t, std::vector<int>> count_cols;               // tasks_count_vars   :89
+    std::vector<std::vector<std::pair<int, double>>> res_terms(R);
+    std::vector<std::pair<int, double>> cpu_terms;
+    auto emit = [&](uint8_t type, double rhs, const std::vector<std::pair<int, double>> &terms) { m.begin_row(type, rhs); for (auto &t : terms) m.term(t.first, t.second); m.end_row(); };
+    auto emit_plus = [&](uint8_t type, double rhs, const std::vector<int> &cols, int extra, double coef) { m.begin_row(type, rhs); for (int c : cols) m.term(c, 1.0); m.term(extra, coef); m.end_row(); };
+    // WorkerGroup::is_capable_to_run_rq  server/workergroup.rs:35-52 (over the real worker map)
+    auto group_can_run = [&](uint32_t g, const VariantView &vv, uint32_t slot) {
+        uint32_t need = vv.multi_node() ? vv.n_nodes : 1;
+        for (uint32_t w = 0; w < pb.real.n; w++) {
+            if ((pb.real.group ? pb.real.group[w] : 0) != g) continue;
+            uint8_t f = pb.real.vf(w, slot);
+            if ((f & 4) && (vv.multi_node() || (f & 2))) { if (--need == 0) return true; }
+        }
+        return false;
+    };
+    auto group_can_run_rq = [&](uint32_t g, uint32_t rq) {
+        for (uint32_t v = 0; v < pb.rqs[rq].n_variants; v++) if (group_can_run(g, pb.variants[pb.rqs[rq].first_variant + v], pb.rqs[rq].first_variant + v)) return true;
+        return false;
+    };
+    auto is_blocked = [&](uint32_t w, uint32_t rq, uint8_t v) {
+        if (pb.custom) return false;
+        for (auto &b : ws.blocked[w]) if (b.first == rq && b.second == v) return true;
+        return false;
+    };
+
+    for (size_t wi = 0; wi < nw; wi++) {  // :95
+        uint32_t w = solver_workers[wi];
+        const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
+        cpu_terms.clear();
+        double order_factor = (double)(nw - wi);
+        for (const TaskBatch &batch : batches) {
+            const RequestView &rv = pb.rqs[batch.rq];
+            bool any_variant = false;
+            for (uint8_t v = 0; v < rv.n_variants; v++) {
+                uint32_t slot = rv.first_variant + v;
+                const VariantView &vv = pb.variants[slot];
+                uint8_t f = ws.vf(w, slot);
+                if (vv.multi_node()) {  // :101-122
+                    bool free_worker = pb.custom ? true : ws.is_free(w);
+                    if (free_worker && pb.custom) { out.error = HQTICK_E_UNSUPPORTED; out.errmsg = "multi-node batch with fake workers: the reference panics (solver.rs:104-106)"; return out; }
+                    if (free_worker && group_can_run(ws.group ? ws.group[w] : 0, vv, slot)) {
+                        double s = 0.0;  // create_mn_var  :573-597
+                        for (uint32_t r = 0; r < R; r++) if (tot[r]) s += pool[r] < 0.000001 ? 0.0 : units(tot[r]) / pool[r];
+                        int col = m.add_col(s * order_factor * ((double)vv.weight / FRACTIONS) / (double)nw, hqmilp::COL_BOOL);
+                        place[{w, batch.rq, v}] = col;
+                        for (uint32_t r = 0; r < R; r++) if (tot[r]) res_terms[r].push_back({col, units(tot[r])});
+                    }
+                } else if (!is_blocked(w, batch.rq, v) && (f & 4) && (f & 1) && (pb.custom || ws.is_sn(w))) {  // :123-126
+                    any_variant = true;
+                    double s = 0.0;  // create_sn_var  :542-571
+                    for (uint32_t e = 0; e < vv.n_entries; e++) {
+                        double g = pool[vv.res[e]];
+                        s += g < 0.000001 ? 0.0 : units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]) / g;
+                    }
+                    int col = m.add_col(s * order_factor * ((double)vv.weight / FRACTIONS) / (double)nw, hqmilp::COL_NAT);
+                    place[{w, batch.rq, v}] = col;
+                    count_cols[batch.rq].push_back(col);
+                    for (uint32_t e = 0; e < vv.n_entries; e++) {
+                        double a = units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]);
+                        res_terms[vv.res[e]].push_back({col, a});
+                        if (vv.res[e] == 0) cpu_terms.push_back({col, a});
+                    }
+                }
+            }
+            if (!any_variant && !pb.rq_multi_node(batch.rq) && batch.is_blocker && pb.capable_rqv(ws, w, batch.rq) && (pb.custom || ws.is_sn(w))) {  // :153-169
+                int col = m.add_col((double)wi / (double)(nw * 100), hqmilp::COL_BOOL);
+                count_cols[batch.rq].push_back(col);
+                for (uint32_t r = 0; r < R; r++) if (fre[r]) res_terms[r].push_back({col, units(fre[r])});
+            }
+        }
+        float mu = ws.min_util ? ws.min_util[w] : 0.0f;
+        if (mu > 0.001f && tot[0] != HQ_AMOUNT_MAX) {  // add_min_utilization  :501-540
+            double all_cpus = units(tot[0]), need = all_cpus * ((double)mu - 1.0) + units(fre[0]);
+            if (!(need < 0.0001)) {
+                int col = m.add_col(0.0, hqmilp::COL_BOOL);
+                cpu_terms.push_back({col, -need}); emit(hqmilp::ROW_MIN, 0.0, cpu_terms); cpu_terms.pop_back();
+                cpu_terms.push_back({col, -all_cpus}); emit(hqmilp::ROW_MAX, 0.0, cpu_terms); cpu_terms.pop_back();
+            }
+        }
+        for (uint32_t r = 0; r < R; r++) {  // :177-191 (an unbounded resource keeps its terms for the next worker, as in the reference)
+            if (fre[r] == HQ_AMOUNT_MAX) continue;
+            if (!res_terms[r].empty()) emit(hqmilp::ROW_MAX, units(fre[r]), res_terms[r]);
+            res_terms[r].clear();
+        }
+    }
+    // multi-node group sizes  :193-227
+    std::map<std::pair<uint32_t, uint32_t>, int> group_cols;
+    for (const TaskBatch &batch : batches) {
+        if (!pb.rq_multi_node(batch.rq)) continue;
+        double n_nodes = (double)pb.variants[pb.rqs[batch.rq].first_variant].n_nodes;
+        for (uint32_t g = 0; g < pb.n_groups; g++) {
+            std::vector<int> members;
+            for (uint32_t w = 0; w < pb.real.n; w++) {
+                if ((pb.real.group ? pb.real.group[w] : 0) != g) continue;
+                auto it = place.find({w, batch.rq, (uint8_t)0});
+                if (it != place.end()) members.push_back(it->second);
+            }
+            if (members.empty()) continue;
+            int col = m.add_col(0.0, hqmilp::COL_NAT);
+            emit_plus(hqmilp::ROW_EQ, 0.0, members, col, -n_nodes);
+            count_cols[batch.rq].push_back(col);
+            group_cols[{batch.rq, g}] = col;
+        }
+    }
+    // priority cuts  :229-430
+    std::map<std::pair<uint32_t, uint32_t>, int> short_flags;  // blocked_priority_vars
+    auto short_flag = [&](uint32_t rq, uint32_t size) -> int {  // get_bvar  :233-253
+        auto it = short_flags.find({rq, size});
+        if (it != short_flags.end()) return it->second;
+        auto cc = count_cols.find(rq);
+        if (cc == count_cols.end()) return -1;
+        int col = m.add_col(0.0, hqmilp::COL_BOOL);
+        emit_plus(hqmilp::ROW_MIN, (double)size, cc->second, col, (double)size);
+        short_flags[{rq, size}] = col;
+        return col;
+    };
+    GapCache gaps(pb);
+    for (const TaskBatch &batch : batches) {
+        auto cc = count_cols.find(batch.rq);
+        if (cc == count_cols.end()) continue;
+        const RequestView &brv = pb.rqs[batch.rq];
+        if (!batch.limit_reached) {  // :264-271
+            m.begin_row(hqmilp::ROW_MAX, (double)batch.size);
+            for (int c : cc->second) m.term(c, 1.0);
+            m.end_row();
+        }
+        double bsize = (double)batch.size;
+        std::vector<uint32_t> capped_by;  // blocked_by_unbounded
+        for (const PriorityCut &cut : batch.cuts) {
+            for (auto &bl : cut.blockers) {
+                uint32_t brq = bl.first; bool bounded = bl.second != HQ_BLOCKER_UNBOUNDED;
+                std::vector<int> no_gap;  // zero_cond
+                if (pb.rq_multi_node(batch.rq)) {
+                    for (uint32_t g = 0; g < pb.n_groups; g++) {
+                        auto it = group_cols.find({batch.rq, g});
+                        if (it != group_cols.end() && group_can_run_rq(g, brq)) no_gap.push_back(it->second);
+                    }
+                } else {
+                    for (uint32_t w : solver_workers) {
+                        if (!pb.capable_rqv(ws, w, brq)) continue;
+                        Amounts tot; tot.a.assign(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
+                        static const std::vector<std::pair<uint32_t, uint8_t>> none;
+                        uint32_t gap = gaps.gap(brq, batch.rq, tot, pb.custom ? none : ws.assigned[w]);
+                        std::vector<int> cols;
+                        for (uint8_t v = 0; v < brv.n_variants; v++) { auto it = place.find({w, batch.rq, v}); if (it != place.end()) cols.push_back(it->second); }
+                        if (gap > 0) {
+                            int fl;
+                            if (bounded && (fl = short_flag(brq, bl.second)) >= 0) emit_plus(hqmilp::ROW_MAX, (double)cut.size + bsize + (double)gap, cols, fl, bsize);
+                            else if (!bounded) { m.begin_row(hqmilp::ROW_MAX, (double)cut.size + (double)gap); for (int c : cols) m.term(c, 1.0); m.end_row(); }
+                        } else {
+                            no_gap.insert(no_gap.end(), cols.begin(), cols.end());
+                        }
+                    }
+                }
+                if (no_gap.empty()) continue;
+                int fl;
+                if (bounded && (fl = short_flag(brq, bl.second)) >= 0) emit_plus(hqmilp::ROW_MAX, bsize + (double)cut.size, no_gap, fl, bsize);
+                else if (!bounded && std::find(capped_by.begin(), capped_by.end(), brq) == capped_by.end()) {
+                    capped_by.push_back(brq);
+                    m.begin_row(hqmilp::ROW_MAX, (double)cut.size); for (int c : no_gap) m.term(c, 1.0); m.end_row();
+                }
+            }
+        }
+    }
+
+    hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true);  // :432-438
+    out.milp_nodes = sol.nodes; out.milp_cols = m.ncols(); out.milp_rows = m.nrows(); out.milp_components = sol.n_components;
+    if (!sol.feasible) return out;
+    out.is_optimal = sol.optimal;
+
+    // decode  :439-481; Map iteration orders via hb_order.h
+    std::vector<uint64_t> key_hash; std::vector<std::pair<uint32_t, uint8_t>> key_list; std::vector<std::vector<std::pair<uint32_t, uint32_t>>> key_counts;
+    std::vector<uint64_t> mn_hash; std::vector<uint32_t> mn_list; std::vector<std::vector<std::vector<uint32_t>>> mn_sets;
+    for (const TaskBatch &batch : batches) {
+        const RequestView &rv = pb.rqs[batch.rq];
+        if (pb.rq_multi_node(batch.rq)) {
+            size_t n_nodes = pb.variants[rv.first_variant].n_nodes;
+            std::vector<std::vector<uint32_t>> sets;
+            for (uint32_t w : solver_workers) {
+                auto it = place.find({w, batch.rq, (uint8_t)0});
+                if (it == place.end() || (uint32_t)std::round(sol.x[it->second]) == 0) continue;
+                if (!sets.empty() && sets.back().size() < n_nodes) sets.back().push_back(w); else sets.push_back({w});
+            }
+            if (!sets.empty()) { mn_hash.push_back(hqhb::hash_rq_variant(batch.rq, 0)); mn_list.push_back(batch.rq); mn_sets.push_back(sets); }
+        } else {
+            for (uint8_t v = 0; v < rv.n_variants; v++) {
+                std::vector<uint32_t> ids, widx, cnt;
+                for (uint32_t w : solver_workers) {
+                    auto it = place.find({w, batch.rq, v});
+                    if (it == place.end()) continue;
+                    uint32_t c = (uint32_t)std::round(sol.x[it->second]);
+                    if (c > 0) { ids.push_back(ws.id[w]); widx.push_back(w); cnt.push_back(c); }
+                }
+                if (ids.empty()) continue;
+                std::vector<uint32_t> ord;
+                hqhb::insertion_order_u32(ids.data(), (uint32_t)ids.size(), ord);
+                std::vector<std::pair<uint32_t, uint32_t>> ordered;
+                for (uint32_t k : ord) ordered.push_back({widx[k], cnt[k]});
+                key_hash.push_back(hqhb::hash_rq_variant(batch.rq, v)); key_list.push_back({batch.rq, v}); key_counts.push_back(std::move(ordered));
+            }
+        }
+    }
+    std::vector<uint32_t> ord;
+    hqhb::insertion_order(key_hash.data(), (uint32_t)key_hash.size(), ord);
+    for (uint32_t k : ord) { out.keys.push_back(key_list[k]); out.per_key.push_back(std::move(key_counts[k])); }
+    hqhb::insertion_order(mn_hash.data(), (uint32_t)mn_hash.size(), ord);
+    for (uint32_t k : ord) { out.mn_rq.push_back(mn_list[k]); out.mn_sets.push_back(std::move(mn_sets[k])); }
+    return out;
+}
+
+}  // namespace hqhost

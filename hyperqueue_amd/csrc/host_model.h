@@ -1,0 +1,108 @@
+// Host-side stages of the tick that are small and serial by nature: batch merge, MILP construction, gap cache.
+// They consume what the GPU scans produced (level histogram, per-worker capability flags) and produce the
+// per-(request, variant, worker) counts the GPU mapping stage expands.
+//
+// Reference (paths relative to /root/reference/crates/tako/src/internal/):
+//   scheduler/batches.rs:42-217   create_task_batches + prune_progressive
+//   scheduler/solver.rs:36-483    run_scheduling_solver (model + decode)
+//   scheduler/gap.rs:38-147       GapCache::get_gap / compute_gap_resources
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/hqtick.h"
+#include "milp.h"
+
+namespace hqhost {
+
+struct VariantView {
+    const uint32_t *res;   // entries, sorted by resource id
+    const uint8_t *kind;
+    const uint64_t *amount;
+    uint32_t n_entries, n_nodes, weight;
+    uint64_t min_time_ns;
+    bool multi_node() const { return n_nodes > 0; }
+};
+
+struct RequestView {
+    uint32_t first_variant, n_variants;  // global variant slots [first_variant, first_variant + n_variants)
+};
+
+// (priority, number of tasks) of one TaskQueue, highest priority first — TaskQueue::iter_priority_sizes
+struct QueueLevels {
+    std::vector<std::pair<uint64_t, uint32_t>> levels;
+};
+
+struct PriorityCut { uint32_t size; std::vector<std::pair<uint32_t, uint32_t>> blockers; };  // blocker size HQ_BLOCKER_UNBOUNDED = None
+struct TaskBatch {
+    uint32_t rq = 0, size = 0, limit = 0;
+    bool limit_reached = false, is_blocker = false;
+    std::vector<PriorityCut> cuts;
+};
+
+// Everything the host stages need to know about workers, as plain views over the snapshot + the GPU's K2 output.
+struct WorkerSet {
+    uint32_t n = 0, R = 0;
+    const uint32_t *id = nullptr;
+    const uint64_t *total = nullptr, *free_ = nullptr;  // [n*R]
+    const int64_t *remaining_ns = nullptr;
+    const float *min_util = nullptr;
+    const uint8_t *flags = nullptr;    // HQ_WORKER_*; nullptr => all SN
+    const uint32_t *group = nullptr;
+    // K2 output, indexed [w * n_variant_slots + slot]: bit0 immediate, bit1 total-capable, bit2 time ok
+    const uint8_t *vflags = nullptr;
+    const uint32_t *vtmc = nullptr;
+    uint32_t n_variant_slots = 0;
+    // sparse per-worker state
+    std::vector<std::vector<std::pair<uint32_t, uint8_t>>> blocked;   // [n]
+    std::vector<std::vector<std::pair<uint32_t, uint8_t>>> assigned;  // [n] (rq, variant) of assigned tasks
+    bool is_sn(uint32_t w) const { return flags ? (flags[w] & HQ_WORKER_SN) != 0 : true; }
+    bool stopping(uint32_t w) const { return flags ? (flags[w] & HQ_WORKER_STOPPING) != 0 : false; }
+    bool is_free(uint32_t w) const { return is_sn(w) && assigned[w].empty() && !stopping(w); }
+    uint8_t vf(uint32_t w, uint32_t slot) const { return vflags[(size_t)w * n_variant_slots + slot]; }
+    uint32_t tmc(uint32_t w, uint32_t slot) const { return vtmc[(size_t)w * n_variant_slots + slot]; }
+};
+
+struct Problem {
+    uint32_t R = 0, n_groups = 0;
+    std::vector<RequestView> rqs;
+    std::vector<VariantView> variants;  // all variant slots
+    WorkerSet real;                      // core.worker_map
+    const WorkerSet *custom = nullptr;   // what-if query: fake workers replace the worker list of the solver
+    double time_limit_s = 5.0;
+    bool rq_multi_node(uint32_t rq) const { return variants[rqs[rq].first_variant].multi_node(); }
+    // Worker::is_capable_to_run_rqv  server/worker.rs:277-296
+    bool capable_rqv(const WorkerSet &ws, uint32_t w, uint32_t rq) const {
+        for (uint32_t v = 0; v < rqs[rq].n_variants; v++) {
+            uint32_t slot = rqs[rq].first_variant + v;
+            uint8_t f = ws.vf(w, slot);
+            if ((f & 4) && (variants[slot].multi_node() || (f & 2))) return true;
+        }
+        return false;
+    }
+};
+
+std::vector<TaskBatch> create_task_batches(const Problem &pb, const std::vector<QueueLevels> &queues);
+
+struct Counts {
+    // sn_counts in the reference's iteration order: keys, and per key (worker index, count) in `counts` iteration order
+    std::vector<std::pair<uint32_t, uint8_t>> keys;
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> per_key;
+    std::vector<uint32_t> mn_rq;                               // mn_workers keys (variant 0) in iteration order
+    std::vector<std::vector<std::vector<uint32_t>>> mn_sets;   // per key: worker sets
+    bool is_optimal = true;
+    bool empty() const {
+        for (auto &k : per_key) if (!k.empty()) return false;
+        for (auto &k : mn_sets) if (!k.empty()) return false;
+        return true;
+    }
+    int error = 0; std::string errmsg;
+    long milp_nodes = 0; int milp_cols = 0, milp_rows = 0, milp_components = 0;
+};
+
+Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &batches);
+
+}  // namespace hqhost

@@ -1,0 +1,682 @@
+// libhqtick.so — the C ABI of include/hqtick.h: one scheduling tick of tako on an MI355X.
+//
+// Data flow of hqtick_run():
+//   H2D   ready-set columns (unless resident), worker/request tables
+//   GPU   K0 distinct priorities -> K0b sorted level table -> K1 (level, rq) histogram per wave slice -> K1b scan
+//         K2 per-(worker, variant) capability flags + task_max_count
+//   D2H   level table, histogram, flags                                   (small)
+//   HOST  batches (batches.rs) -> MILP (solver.rs) via the exact solver -> counts; selection plan
+//   H2D   take/base per group, round-robin tables                         (small)
+//   GPU   K4 select+scatter the taken tasks in queue order -> K5 expand to per-worker records
+//   D2H   assignment records
+// There is no CPU implementation of the scans/mapping: without a HIP device every entry point fails.
+#include "../../include/hqtick.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hb_order.h"
+#include "host_model.h"
+#include "kernels.h"
+
+namespace {
+
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) hipFree(p);
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; return false; }
+        cap = want; return true;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct hqtick_ctx {
+    hqtick_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    std::string err = "";
+    // ready set
+    DevBuf d_tid, d_tprio, d_trq; uint64_t n_ready = 0; bool resident = false;
+    // scans
+    DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist;
+    // workers / requests
+    DevBuf d_total, d_free, d_rem, d_req, d_vflags, d_vtmc;
+    // selection + mapping
+    DevBuf d_take_base, d_sel_task, d_sel_level, d_map, d_rec_task, d_rec_var, d_rec_kind;
+    // results (host)
+    std::vector<uint32_t> b_rq, b_size, b_limit, b_cut_off, c_size, c_bl_off, bl_rq, bl_size; std::vector<uint8_t> b_lr, b_blk;
+    std::vector<uint32_t> cnt_rq, cnt_worker, cnt_value; std::vector<uint8_t> cnt_variant;
+    std::vector<uint32_t> rec_off, retract_off, red_worker, mn_off, mn_worker; std::vector<uint64_t> rec_task, retract_task, red_task, mn_task, new_free;
+    std::vector<uint8_t> rec_variant, rec_kind, red_variant, q_loaded;
+    hqtick_kernel_stats stats{};
+};
+
+namespace {
+
+#define HQ_HIP(call)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return HQTICK_E_DEVICE; } \
+    } while (0)
+
+int fail(hqtick_ctx *ctx, int code, const std::string &msg) { ctx->err = msg; return code; }
+
+struct Plan {  // everything phase B hands to the GPU mapping stage
+    std::vector<uint32_t> take, base;  // [G]
+    uint32_t n_sel = 0;
+};
+
+int validate(hqtick_ctx *ctx, const hqtick_snapshot *s, bool need_tasks) {
+    if (!s) return fail(ctx, HQTICK_E_INVALID, "null snapshot");
+    if (s->n_workers && (!s->worker_id || !s->worker_total || !s->worker_free)) return fail(ctx, HQTICK_E_INVALID, "worker arrays missing");
+    for (uint32_t w = 1; w < s->n_workers; w++) if (s->worker_id[w - 1] >= s->worker_id[w]) return fail(ctx, HQTICK_E_INVALID, "worker ids not ascending");
+    if (s->n_requests && (!s->rq_variant_off || !s->variant_entry_off)) return fail(ctx, HQTICK_E_INVALID, "request arrays missing");
+    for (uint32_t q = 0; q < s->n_requests; q++) {
+        if (s->rq_variant_off[q + 1] <= s->rq_variant_off[q]) return fail(ctx, HQTICK_E_INVALID, "request without variants");
+        if (s->rq_variant_off[q + 1] - s->rq_variant_off[q] > 32) return fail(ctx, HQTICK_E_INVALID, "more than 32 variants");
+    }
+    uint32_t nv = s->n_requests ? s->rq_variant_off[s->n_requests] : 0;
+    for (uint32_t e = 0; e < (nv ? s->variant_entry_off[nv] : 0); e++) {
+        if (s->entry_resource[e] >= s->n_resources) return fail(ctx, HQTICK_E_INVALID, "entry resource id out of range");
+        if (s->entry_kind[e] == HQ_ENTRY_AMOUNT && s->entry_amount[e] == 0) return fail(ctx, HQTICK_E_INVALID, "zero amount request");
+    }
+    if (need_tasks && s->n_ready) {
+        if (!s->task_id || !s->task_priority || !s->task_rq) return fail(ctx, HQTICK_E_INVALID, "ready-set columns missing");
+        for (uint64_t i = 1; i < s->n_ready; i++) if (s->task_id[i - 1] >= s->task_id[i]) return fail(ctx, HQTICK_E_INVALID, "ready set not sorted by task id");
+    }
+    for (uint32_t k = 0; k < s->n_blocked; k++) if (s->blocked_worker[k] >= s->n_workers) return fail(ctx, HQTICK_E_INVALID, "blocked worker index");
+    return 0;
+}
+
+// Uploads the request tables into one device buffer and returns the K2 view.
+int upload_requests(hqtick_ctx *ctx, const hqtick_snapshot *s, hqk::RequestTable *rt) {
+    uint32_t nv = s->n_requests ? s->rq_variant_off[s->n_requests] : 0;
+    uint32_t ne = nv ? s->variant_entry_off[nv] : 0;
+    size_t o_off = 0, o_res = o_off + (size_t)(nv + 1) * 4, o_amt = (o_res + (size_t)ne * 4 + 7) & ~(size_t)7, o_time = o_amt + (size_t)ne * 8,
+           o_kind = o_time + (size_t)nv * 8, total = o_kind + ne + 16;
+    std::vector<unsigned char> h(total, 0);
+    if (nv) {
+        memcpy(h.data() + o_off, s->variant_entry_off, (size_t)(nv + 1) * 4);
+        memcpy(h.data() + o_res, s->entry_resource, (size_t)ne * 4);
+        memcpy(h.data() + o_amt, s->entry_amount, (size_t)ne * 8);
+        memcpy(h.data() + o_time, s->variant_min_time_ns, (size_t)nv * 8);
+        memcpy(h.data() + o_kind, s->entry_kind, ne);
+    }
+    if (!ctx->d_req.ensure(total)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc request tables");
+    HQ_HIP(hipMemcpyAsync(ctx->d_req.p, h.data(), total, hipMemcpyHostToDevice, ctx->stream));
+    HQ_HIP(hipStreamSynchronize(ctx->stream));  // h is a stack-scoped staging buffer
+    unsigned char *d = ctx->d_req.as<unsigned char>();
+    rt->variant_entry_off = (const uint32_t *)(d + o_off); rt->entry_resource = (const uint32_t *)(d + o_res);
+    rt->entry_amount = (const uint64_t *)(d + o_amt); rt->variant_min_time_ns = (const uint64_t *)(d + o_time);
+    rt->entry_kind = (const uint8_t *)(d + o_kind); rt->n_variants = nv;
+    return 0;
+}
+
+struct WorkerEval { std::vector<uint8_t> flags; std::vector<uint32_t> tmc; };
+
+// K2 on a worker set (real or fake); results copied back.
+int eval_workers(hqtick_ctx *ctx, uint32_t W, uint32_t R, const uint64_t *total, const uint64_t *free_, const int64_t *rem,
+                 const hqk::RequestTable &rt, WorkerEval *out) {
+    size_t n = (size_t)W * rt.n_variants;
+    out->flags.assign(n, 0); out->tmc.assign(n, 0);
+    if (n == 0) return 0;
+    std::vector<int64_t> rem_h(W, HQ_NO_TIME_LIMIT);
+    if (rem) memcpy(rem_h.data(), rem, (size_t)W * 8);
+    if (!ctx->d_total.ensure((size_t)W * R * 8 + 8) || !ctx->d_free.ensure((size_t)W * R * 8 + 8) || !ctx->d_rem.ensure((size_t)W * 8) ||
+        !ctx->d_vflags.ensure(n) || !ctx->d_vtmc.ensure(n * 4))
+        return fail(ctx, HQTICK_E_DEVICE, "hipMalloc worker tables");
+    if (R) {
+        HQ_HIP(hipMemcpyAsync(ctx->d_total.p, total, (size_t)W * R * 8, hipMemcpyHostToDevice, ctx->stream));
+        HQ_HIP(hipMemcpyAsync(ctx->d_free.p, free_, (size_t)W * R * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HQ_HIP(hipMemcpyAsync(ctx->d_rem.p, rem_h.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
+    hqk::worker_eval(ctx->d_total.as<uint64_t>(), ctx->d_free.as<uint64_t>(), ctx->d_rem.as<int64_t>(), W, R, rt, ctx->d_vflags.as<uint8_t>(),
+                     ctx->d_vtmc.as<uint32_t>(), ctx->stream);
+    HQ_HIP(hipGetLastError());
+    HQ_HIP(hipMemcpyAsync(out->flags.data(), ctx->d_vflags.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HQ_HIP(hipMemcpyAsync(out->tmc.data(), ctx->d_vtmc.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HQ_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+void fill_problem(hqhost::Problem &pb, const hqtick_snapshot *s, const hqtick_config &cfg, const WorkerEval &ev) {
+    pb.R = s->n_resources; pb.n_groups = s->n_groups ? s->n_groups : 1; pb.time_limit_s = cfg.mip_time_limit_s;
+    uint32_t nv = s->n_requests ? s->rq_variant_off[s->n_requests] : 0;
+    pb.rqs.resize(s->n_requests); pb.variants.resize(nv);
+    for (uint32_t q = 0; q < s->n_requests; q++) pb.rqs[q] = {s->rq_variant_off[q], s->rq_variant_off[q + 1] - s->rq_variant_off[q]};
+    for (uint32_t v = 0; v < nv; v++) {
+        uint32_t e0 = s->variant_entry_off[v];
+        pb.variants[v] = {s->entry_resource + e0, s->entry_kind + e0, s->entry_amount + e0, s->variant_entry_off[v + 1] - e0,
+                          s->variant_n_nodes ? s->variant_n_nodes[v] : 0, s->variant_weight ? s->variant_weight[v] : 10000,
+                          s->variant_min_time_ns ? s->variant_min_time_ns[v] : 0};
+    }
+    hqhost::WorkerSet &ws = pb.real;
+    ws.n = s->n_workers; ws.R = s->n_resources; ws.id = s->worker_id; ws.total = s->worker_total; ws.free_ = s->worker_free;
+    ws.remaining_ns = s->worker_remaining_ns; ws.min_util = s->worker_min_utilization; ws.flags = s->worker_flags; ws.group = s->worker_group;
+    ws.vflags = ev.flags.data(); ws.vtmc = ev.tmc.data(); ws.n_variant_slots = nv;
+    ws.blocked.assign(ws.n, {}); ws.assigned.assign(ws.n, {});
+    for (uint32_t k = 0; k < s->n_blocked; k++) ws.blocked[s->blocked_worker[k]].push_back({s->blocked_rq[k], s->blocked_variant[k]});
+    if (s->assigned_off) for (uint32_t w = 0; w < ws.n; w++) for (uint32_t k = s->assigned_off[w]; k < s->assigned_off[w + 1]; k++) ws.assigned[w].push_back({s->assigned_rq[k], s->assigned_variant[k]});
+}
+
+void export_batches(hqtick_ctx *ctx, const std::vector<hqhost::TaskBatch> &batches, hqtick_result *out) {
+    ctx->b_rq.clear(); ctx->b_size.clear(); ctx->b_limit.clear(); ctx->b_lr.clear(); ctx->b_blk.clear();
+    ctx->b_cut_off.assign(1, 0); ctx->c_size.clear(); ctx->c_bl_off.assign(1, 0); ctx->bl_rq.clear(); ctx->bl_size.clear();
+    for (auto &b : batches) {
+        ctx->b_rq.push_back(b.rq); ctx->b_size.push_back(b.size); ctx->b_limit.push_back(b.limit); ctx->b_lr.push_back(b.limit_reached); ctx->b_blk.push_back(b.is_blocker);
+        for (auto &c : b.cuts) {
+            ctx->c_size.push_back(c.size);
+            for (auto &bl : c.blockers) { ctx->bl_rq.push_back(bl.first); ctx->bl_size.push_back(bl.second); }
+            ctx->c_bl_off.push_back((uint32_t)ctx->bl_rq.size());
+        }
+        ctx->b_cut_off.push_back((uint32_t)ctx->c_size.size());
+    }
+    out->n_batches = (uint32_t)ctx->b_rq.size(); out->batch_rq = ctx->b_rq.data(); out->batch_size = ctx->b_size.data(); out->batch_limit = ctx->b_limit.data();
+    out->batch_limit_reached = ctx->b_lr.data(); out->batch_is_blocker = ctx->b_blk.data(); out->batch_cut_off = ctx->b_cut_off.data();
+    out->cut_size = ctx->c_size.data(); out->cut_blocker_off = ctx->c_bl_off.data(); out->blocker_rq = ctx->bl_rq.data(); out->blocker_size = ctx->bl_size.data();
+}
+
+struct Scan {  // result of GPU phase A
+    uint32_t L = 0, Q = 0, G = 0;
+    std::vector<uint64_t> levels;
+    std::vector<uint32_t> hist;  // [G], g = level*Q + rq
+    hqk::WaveGeom geom{};
+};
+
+// GPU phase A on the ready set currently in ctx->d_t*.
+int scan_ready(hqtick_ctx *ctx, uint32_t Q, Scan *sc) {
+    sc->Q = Q; sc->L = 0; sc->G = 0; sc->levels.clear(); sc->hist.clear();
+    uint64_t N = ctx->n_ready;
+    if (N == 0 || Q == 0) return 0;
+    if (!ctx->d_set.ensure((size_t)hqk::PRIO_SET_CAP * 8) || !ctx->d_flags.ensure(64) || !ctx->d_levels.ensure((size_t)(8192 + 2) * 8) || !ctx->d_nlevels.ensure(16))
+        return fail(ctx, HQTICK_E_DEVICE, "hipMalloc level tables");
+    HQ_HIP(hipMemsetAsync(ctx->d_set.p, 0xFF, (size_t)hqk::PRIO_SET_CAP * 8, ctx->stream));
+    HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
+    HQ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    hqk::distinct_priorities(ctx->d_tprio.as<uint64_t>(), N, ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream);
+    HQ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->stream);
+    HQ_HIP(hipGetLastError());
+    uint32_t L = 0, flags[4] = {0, 0, 0, 0};
+    HQ_HIP(hipMemcpyAsync(&L, ctx->d_nlevels.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (flags[1] || L == 0xFFFFFFFFu || L > 8192) return fail(ctx, HQTICK_E_CAPACITY, "more than 8192 distinct priority levels in the ready set");
+    if (L == 0) return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level");
+    uint64_t G64 = (uint64_t)L * Q;
+    if (G64 > hqk::MAX_GROUPS) return fail(ctx, HQTICK_E_CAPACITY, "levels x requests exceeds 16384 groups");
+    uint32_t G = (uint32_t)G64;
+    sc->L = L; sc->G = G;
+    sc->levels.resize(L);
+    HQ_HIP(hipMemcpyAsync(sc->levels.data(), ctx->d_levels.p, (size_t)L * 8, hipMemcpyDeviceToHost, ctx->stream));
+    hqk::WaveGeom &g = sc->geom;
+    g.waves_per_block = G <= hqk::MAX_GROUPS_4W ? 4 : 1;
+    uint64_t tpw = 1024;
+    while (((N + tpw - 1) / tpw) * G > (1ull << 24)) tpw *= 2;  // keep the per-slice table under 64 MiB
+    g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw);
+    if (!ctx->d_wave_tab.ensure((size_t)g.n_waves * G * 4) || !ctx->d_hist.ensure((size_t)G * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
+    HQ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
+                    ctx->d_flags.as<uint32_t>() + 2, ctx->stream);
+    HQ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g.n_waves, G, ctx->d_hist.as<uint32_t>(), ctx->stream);
+    HQ_HIP(hipGetLastError());
+    sc->hist.resize(G);
+    HQ_HIP(hipMemcpyAsync(sc->hist.data(), ctx->d_hist.p, (size_t)G * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (flags[2]) return fail(ctx, HQTICK_E_INVALID, "ready set holds a request id >= n_requests (or an unknown priority)");
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->stats.distinct_us = ms * 1000.0;
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->stats.level_hist_us = ms * 1000.0;
+    return 0;
+}
+
+// TaskQueue::iter_priority_sizes (taskqueue.rs:273-302) for every request, from the histogram and the prefill sets
+std::vector<hqhost::QueueLevels> queue_levels(const Scan &sc, const hqtick_snapshot *s) {
+    std::vector<hqhost::QueueLevels> qs(s->n_requests);
+    for (uint32_t q = 0; q < s->n_requests; q++) {
+        auto &lv = qs[q].levels;
+        for (uint32_t l = 0; l < sc.L; l++) { uint32_t c = sc.hist[(size_t)l * sc.Q + q]; if (c) lv.push_back({sc.levels[l], c}); }
+        uint32_t pfn = s->prefill_off ? s->prefill_off[q + 1] - s->prefill_off[q] : 0;
+        if (pfn) {
+            uint64_t pp = s->prefill_priority[q];
+            if (!lv.empty() && lv[0].first == pp) lv[0].second += pfn; else lv.insert(lv.begin(), {pp, pfn});
+        }
+    }
+    return qs;
+}
+
+int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool use_resident) {
+    double t0 = now_us();
+    memset(out, 0, sizeof(*out));
+    ctx->stats = hqtick_kernel_stats{};
+    int rc = validate(ctx, s, !use_resident);
+    if (rc) return rc;
+    HQ_HIP(hipSetDevice(ctx->device));
+    const uint32_t W = s->n_workers, R = s->n_resources, Q = s->n_requests;
+    if (!use_resident) {
+        uint64_t N = s->n_ready;
+        if (!ctx->d_tid.ensure(N * 8 + 8) || !ctx->d_tprio.ensure(N * 8 + 8) || !ctx->d_trq.ensure(N * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set");
+        if (N) {
+            HQ_HIP(hipMemcpyAsync(ctx->d_tid.p, s->task_id, N * 8, hipMemcpyHostToDevice, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(ctx->d_tprio.p, s->task_priority, N * 8, hipMemcpyHostToDevice, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, s->task_rq, N * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        ctx->n_ready = N; ctx->resident = false;
+    } else if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "hqtick_run_resident without hqtick_upload_ready");
+    const uint64_t N = ctx->n_ready;
+
+    // ---------------- GPU phase A ----------------
+    hqk::RequestTable rt{};
+    if ((rc = upload_requests(ctx, s, &rt))) return rc;
+    WorkerEval ev;
+    if ((rc = eval_workers(ctx, W, R, s->worker_total, s->worker_free, s->worker_remaining_ns, rt, &ev))) return rc;
+    Scan sc;
+    if ((rc = scan_ready(ctx, Q, &sc))) return rc;
+    double t1 = now_us();
+
+    // ---------------- host: batches + placement ----------------
+    hqhost::Problem pb;
+    fill_problem(pb, s, ctx->cfg, ev);
+    std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
+    std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
+    export_batches(ctx, batches, out);
+    double t2 = now_us();
+    hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
+    if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
+    double t3 = now_us();
+    out->is_optimal = cnt.is_optimal;
+    int status = HQTICK_DONE;  // scheduler/main.rs:57-68
+    if (!cnt.is_optimal) status = cnt.empty() ? HQTICK_NO_PROGRESS : HQTICK_NEED_MORE_COMPUTE;
+
+    // ---------------- host: mapping plan (create_task_mapping as index arithmetic, mapping.rs:36-157) ----------------
+    const uint32_t L = sc.L;
+    auto hist = [&](uint32_t l, uint32_t q) -> uint32_t { return sc.hist[(size_t)l * Q + q]; };
+    // per request: logical take sequence = [first level][prefilled][rest] when the prefill priority equals the top
+    // priority of the queue, else [prefilled][all levels]   (taskqueue.rs:320-355)
+    std::vector<uint32_t> q_total(Q, 0), pf_n(Q, 0), pf_start(Q, 0), seq_taken(Q, 0);
+    for (uint32_t q = 0; q < Q; q++) {
+        for (uint32_t l = 0; l < L; l++) q_total[q] += hist(l, q);
+        pf_n[q] = s->prefill_off ? s->prefill_off[q + 1] - s->prefill_off[q] : 0;
+        if (pf_n[q]) {
+            uint32_t first = L; for (uint32_t l = 0; l < L; l++) if (hist(l, q)) { first = l; break; }
+            pf_start[q] = (first < L && sc.levels[first] == s->prefill_priority[q]) ? hist(first, q) : 0;
+        }
+    }
+    const uint32_t nkeys = (uint32_t)cnt.keys.size();
+    std::vector<uint32_t> key_seg(nkeys), key_sum(nkeys);
+    ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
+    for (uint32_t k = 0; k < nkeys; k++) {
+        uint32_t q = cnt.keys[k].first, sum = 0;
+        for (auto &wc : cnt.per_key[k]) { sum += wc.second; ctx->cnt_rq.push_back(q); ctx->cnt_variant.push_back(cnt.keys[k].second); ctx->cnt_worker.push_back(wc.first); ctx->cnt_value.push_back(wc.second); }
+        key_seg[k] = seq_taken[q]; key_sum[k] = sum; seq_taken[q] += sum;
+        if (seq_taken[q] > q_total[q] + pf_n[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "solver placed more tasks than the queue holds (reference panics, taskqueue.rs:327)");
+    }
+    // multi-node placements take one task each from the head of their queue (mapping.rs:133-154)
+    std::vector<uint32_t> mn_first(cnt.mn_rq.size(), 0);
+    for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
+        uint32_t q = cnt.mn_rq[i];
+        mn_first[i] = seq_taken[q]; seq_taken[q] += (uint32_t)cnt.mn_sets[i].size();
+        if (pf_n[q]) return fail(ctx, HQTICK_E_UNSUPPORTED, "multi-node queue with a prefill set");
+        if (seq_taken[q] > q_total[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "multi-node placement exceeds its queue");
+    }
+    // sweep tables T_k(s) and per-worker key lists
+    std::vector<uint32_t> key_ord_off(nkeys + 1, 0), ord_cnt, key_t_off(nkeys + 1, 0), t_sweep;
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> wk(W);  // worker -> (key, pos)
+    std::vector<uint32_t> items(W, 0);
+    for (uint32_t k = 0; k < nkeys; k++) {
+        uint32_t maxc = 0, pos = 0;
+        for (auto &wc : cnt.per_key[k]) { ord_cnt.push_back(wc.second); maxc = std::max(maxc, wc.second); wk[wc.first].push_back({k, pos++}); items[wc.first] += wc.second; }
+        key_ord_off[k + 1] = (uint32_t)ord_cnt.size();
+        std::vector<uint32_t> ge(maxc + 2, 0);
+        for (auto &wc : cnt.per_key[k]) ge[wc.second]++;  // ge[c] = #workers with count == c
+        uint32_t more = (uint32_t)cnt.per_key[k].size(), acc = 0;
+        for (uint32_t sw = 0; sw <= maxc; sw++) { t_sweep.push_back(acc); more -= ge[sw]; acc += more; }
+        key_t_off[k + 1] = (uint32_t)t_sweep.size();
+    }
+    // worker that receives the task at index idx of key k (host mirror of the K5 arithmetic; used for prefilled tasks only)
+    auto worker_of = [&](uint32_t k, uint32_t idx) -> uint32_t {
+        const uint32_t *T = t_sweep.data() + key_t_off[k]; uint32_t ns = key_t_off[k + 1] - key_t_off[k];
+        uint32_t sw = (uint32_t)(std::upper_bound(T, T + ns, idx) - T) - 1, nth = idx - T[sw];
+        for (auto &wc : cnt.per_key[k]) if (wc.second > sw) { if (nth == 0) return wc.first; nth--; }
+        return HQ_NO_WORKER;
+    };
+    // already-prefilled tasks that this tick hands out: Prefilled{old} -> retract + redirect  (mapping.rs:81-101)
+    std::vector<std::vector<uint64_t>> retracts(W);
+    ctx->red_task.clear(); ctx->red_worker.clear(); ctx->red_variant.clear();
+    std::vector<uint32_t> pf_drained(Q, 0);
+    std::vector<std::vector<uint32_t>> pf_landed(W);  // rq of redirected tasks landing on the worker
+    std::vector<std::vector<uint32_t>> prefilled_rq(W);
+    if (s->prefilled_off) for (uint32_t w = 0; w < W; w++) prefilled_rq[w].assign(s->prefilled_rq + s->prefilled_off[w], s->prefilled_rq + s->prefilled_off[w + 1]);
+    for (uint32_t k = 0; k < nkeys; k++) {
+        uint32_t q = cnt.keys[k].first;
+        if (!pf_n[q]) continue;
+        uint32_t a = std::max(key_seg[k], pf_start[q]), b = std::min(key_seg[k] + key_sum[k], pf_start[q] + pf_n[q]);
+        for (uint32_t p = a; p < b; p++) {
+            uint32_t slot = s->prefill_off[q] + (p - pf_start[q]);
+            uint64_t task = s->prefill_task[slot]; uint32_t oldw = s->prefill_worker[slot];
+            uint32_t neww = worker_of(k, p - key_seg[k]);
+            retracts[oldw].push_back(task);
+            auto &pr = prefilled_rq[oldw]; auto it = std::find(pr.begin(), pr.end(), q); if (it != pr.end()) pr.erase(it);
+            ctx->red_task.push_back(task); ctx->red_worker.push_back(neww); ctx->red_variant.push_back(cnt.keys[k].second);
+            pf_landed[neww].push_back(q);
+            pf_drained[q]++;
+        }
+    }
+    // queue tasks taken per request (excluding the prefilled block)
+    std::vector<uint32_t> zq_taken(Q, 0);
+    for (uint32_t q = 0; q < Q; q++) zq_taken[q] = seq_taken[q] - pf_drained[q];
+    // assigned-this-tick bookkeeping per (worker, rq): records in mapping.workers[w].assigned
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> got(W);  // (rq, number of Waiting->Assigned tasks)
+    std::vector<uint32_t> n_assign(W, 0);
+    for (uint32_t k = 0; k < nkeys; k++) for (auto &wc : cnt.per_key[k]) {
+        uint32_t q = cnt.keys[k].first; bool f = false;
+        for (auto &g : got[wc.first]) if (g.first == q) { g.second += wc.second; f = true; }
+        if (!f) got[wc.first].push_back({q, wc.second});
+        n_assign[wc.first] += wc.second;
+    }
+    for (uint32_t w = 0; w < W; w++) for (uint32_t q : pf_landed[w]) { for (auto &g : got[w]) if (g.first == q) g.second--; n_assign[w]--; }
+    // workers that received a multi-node task are no longer SN (set_mn_task)
+    std::vector<char> now_mn(W, 0);
+    for (auto &sets : cnt.mn_sets) for (auto &set : sets) for (uint32_t w : set) now_mn[w] = 1;
+
+    // ---- process_proactive_filling  mapping.rs:159-234 ----
+    std::vector<uint32_t> wm_order(W);
+    if (s->worker_map_rank) { for (uint32_t w = 0; w < W; w++) wm_order[s->worker_map_rank[w]] = w; }
+    else { std::vector<uint32_t> ord; hqhb::insertion_order_u32(s->worker_id, W, ord); for (uint32_t i = 0; i < W; i++) wm_order[i] = ord[i]; }
+    std::vector<uint32_t> new_pf_total(Q, 0);
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pfl(W);  // worker -> (rq, chunk index) in queue order
+    std::vector<uint32_t> pfl_size(Q, 0);
+    {
+        // state of every queue after the takes: first level that still has tasks
+        std::vector<int> top_level(Q, -1); std::vector<uint32_t> top_left(Q, 0);
+        uint64_t global_top = 0;
+        for (uint32_t q = 0; q < Q; q++) {
+            uint32_t left = zq_taken[q];
+            for (uint32_t l = 0; l < L; l++) { uint32_t h = hist(l, q); if (h > left) { top_level[q] = (int)l; top_left[q] = h - left; break; } left -= h; }
+            if (top_level[q] >= 0) global_top = std::max(global_top, sc.levels[top_level[q]]);  // TaskQueues::top_priority  taskqueue.rs:62-68
+        }
+        for (uint32_t q = 0; q < Q; q++) {
+            if (top_level[q] < 0 || sc.levels[top_level[q]] != global_top) continue;
+            bool pf_left = pf_n[q] > pf_drained[q];
+            uint32_t tsz = (pf_left && s->prefill_priority[q] != global_top) ? 0 : top_left[q];  // top_size_no_prefill  taskqueue.rs:241-253
+            uint32_t size = tsz > ctx->cfg.proactive_filling_reserve ? tsz - ctx->cfg.proactive_filling_reserve : 0;
+            if (!size) continue;
+            std::vector<uint32_t> elig;
+            for (uint32_t w : wm_order) {
+                bool sn = (s->worker_flags ? (s->worker_flags[w] & HQ_WORKER_SN) != 0 : true) && !now_mn[w];
+                if (!sn) continue;
+                bool has = false; for (auto &g : got[w]) if (g.first == q && g.second > 0) has = true;
+                if (!has) continue;
+                if (std::find(prefilled_rq[w].begin(), prefilled_rq[w].end(), q) != prefilled_rq[w].end()) continue;
+                elig.push_back(w);
+            }
+            if (elig.empty()) continue;
+            uint32_t psz = std::min(size / (uint32_t)elig.size(), ctx->cfg.proactive_filling_max);
+            if (!psz) continue;
+            pfl_size[q] = psz;
+            for (uint32_t j = 0; j < elig.size(); j++) pfl[elig[j]].push_back({q, j});
+            new_pf_total[q] = psz * (uint32_t)elig.size();
+        }
+    }
+    // ---- selection plan per (level, rq) group ----
+    std::vector<uint32_t> rq_sel_base(Q + 1, 0);
+    for (uint32_t q = 0; q < Q; q++) rq_sel_base[q + 1] = rq_sel_base[q] + zq_taken[q] + new_pf_total[q];
+    const uint32_t n_sel = rq_sel_base[Q];
+    std::vector<uint32_t> take_base((size_t)2 * sc.G, 0);
+    for (uint32_t q = 0; q < Q; q++) {
+        uint32_t want = zq_taken[q] + new_pf_total[q], cum = 0;
+        for (uint32_t l = 0; l < L; l++) {
+            uint32_t h = hist(l, q), t = want > cum ? std::min(h, want - cum) : 0;
+            take_base[(size_t)l * Q + q] = t; take_base[(size_t)sc.G + (size_t)l * Q + q] = rq_sel_base[q] + cum;
+            cum += h;
+        }
+    }
+    // ---- K5 tables ----
+    std::vector<uint32_t> out_off(W + 1, 0), wk_off(W + 1, 0), wk_key, wk_pos, pfl_off(W + 1, 0), pfl_src, pfl_cnt;
+    uint32_t max_items = 0;
+    for (uint32_t w = 0; w < W; w++) {
+        uint32_t npf = 0;
+        std::sort(pfl[w].begin(), pfl[w].end());
+        for (auto &c : pfl[w]) { pfl_src.push_back(rq_sel_base[c.first] + zq_taken[c.first] + c.second * pfl_size[c.first]); pfl_cnt.push_back(pfl_size[c.first]); npf += pfl_size[c.first]; }
+        pfl_off[w + 1] = (uint32_t)pfl_src.size();
+        for (auto &kp : wk[w]) { wk_key.push_back(kp.first); wk_pos.push_back(kp.second); }
+        wk_off[w + 1] = (uint32_t)wk_key.size();
+        out_off[w + 1] = out_off[w] + npf + n_assign[w];
+        max_items = std::max(max_items, items[w]);
+    }
+    const uint32_t n_rec = out_off[W];
+    if ((size_t)max_items * 18 + 16 > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
+    double t4 = now_us();
+
+    // ---------------- GPU phase C ----------------
+    ctx->rec_task.assign(n_rec, 0); ctx->rec_variant.assign(n_rec, 0); ctx->rec_kind.assign(n_rec, 0);
+    std::vector<uint64_t> mn_ids;
+    if (n_sel) {
+        if (!ctx->d_take_base.ensure(take_base.size() * 4) || !ctx->d_sel_task.ensure((size_t)n_sel * 8) || !ctx->d_sel_level.ensure((size_t)n_sel * 2 + 2))
+            return fail(ctx, HQTICK_E_DEVICE, "hipMalloc selection");
+        HQ_HIP(hipMemcpyAsync(ctx->d_take_base.p, take_base.data(), take_base.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+        hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, sc.geom,
+                            ctx->d_wave_tab.as<uint32_t>(), ctx->d_take_base.as<uint32_t>(), ctx->d_take_base.as<uint32_t>() + sc.G,
+                            ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->stream);
+        HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+        HQ_HIP(hipGetLastError());
+        // pack every K5 table into one upload
+        std::vector<uint32_t> pack;
+        auto put = [&](const std::vector<uint32_t> &v) { size_t o = pack.size(); pack.insert(pack.end(), v.begin(), v.end()); if (v.empty()) pack.push_back(0); return o; };
+        std::vector<uint32_t> key_rq(nkeys), key_var_w((nkeys + 3) / 4 + 1, 0);
+        for (uint32_t k = 0; k < nkeys; k++) { key_rq[k] = cnt.keys[k].first; reinterpret_cast<uint8_t *>(key_var_w.data())[k] = cnt.keys[k].second; }
+        size_t o_rq = put(key_rq), o_var = put(key_var_w), o_seg = put(key_seg), o_ordoff = put(key_ord_off), o_ord = put(ord_cnt), o_toff = put(key_t_off),
+               o_t = put(t_sweep), o_wkoff = put(wk_off), o_wkkey = put(wk_key), o_wkpos = put(wk_pos), o_base = put(rq_sel_base), o_pfs = put(pf_start),
+               o_pfn = put(pf_n), o_pfloff = put(pfl_off), o_pflsrc = put(pfl_src), o_pflcnt = put(pfl_cnt), o_out = put(out_off);
+        if (!ctx->d_map.ensure(pack.size() * 4) || !ctx->d_rec_task.ensure((size_t)n_rec * 8 + 8) || !ctx->d_rec_var.ensure(n_rec + 8) || !ctx->d_rec_kind.ensure(n_rec + 8))
+            return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
+        HQ_HIP(hipMemcpyAsync(ctx->d_map.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        const uint32_t *d = ctx->d_map.as<uint32_t>();
+        hqk::MapKeys mk{};
+        mk.n_keys = nkeys; mk.key_rq = d + o_rq; mk.key_variant = reinterpret_cast<const uint8_t *>(d + o_var); mk.key_seg_start = d + o_seg;
+        mk.key_ord_off = d + o_ordoff; mk.ord_cnt = d + o_ord; mk.key_t_off = d + o_toff; mk.t_sweep = d + o_t; mk.wk_off = d + o_wkoff; mk.wk_key = d + o_wkkey;
+        mk.wk_pos = d + o_wkpos; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn; mk.pfl_off = d + o_pfloff; mk.pfl_src = d + o_pflsrc;
+        mk.pfl_cnt = d + o_pflcnt; mk.out_off = d + o_out;
+        HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
+        HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
+        hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->d_levels.as<uint64_t>(), max_items,
+                            ctx->d_rec_task.as<uint64_t>(), ctx->d_rec_var.as<uint8_t>(), ctx->d_rec_kind.as<uint8_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream);
+        HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+        HQ_HIP(hipGetLastError());
+        uint32_t flags[4] = {0, 0, 0, 0};
+        if (n_rec) {
+            HQ_HIP(hipMemcpyAsync(ctx->rec_task.data(), ctx->d_rec_task.p, (size_t)n_rec * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(ctx->rec_variant.data(), ctx->d_rec_var.p, n_rec, hipMemcpyDeviceToHost, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(ctx->rec_kind.data(), ctx->d_rec_kind.p, n_rec, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        // multi-node tasks: the heads of their queues
+        for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
+            size_t old = mn_ids.size(); size_t n = cnt.mn_sets[i].size();
+            mn_ids.resize(old + n);
+        }
+        {
+            size_t pos = 0;
+            for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
+                size_t n = cnt.mn_sets[i].size();
+                HQ_HIP(hipMemcpyAsync(mn_ids.data() + pos, ctx->d_sel_task.as<uint64_t>() + rq_sel_base[cnt.mn_rq[i]] + mn_first[i], n * 8, hipMemcpyDeviceToHost, ctx->stream));
+                pos += n;
+            }
+        }
+        HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (flags[0]) return fail(ctx, HQTICK_E_CAPACITY, "mapping kernel capacity exceeded");
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->stats.select_us = ms * 1000.0;
+        if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
+    }
+    // ---------------- assemble the result view ----------------
+    ctx->rec_off = out_off;
+    ctx->retract_off.assign(W + 1, 0); ctx->retract_task.clear();
+    for (uint32_t w = 0; w < W; w++) { for (uint64_t t : retracts[w]) ctx->retract_task.push_back(t); ctx->retract_off[w + 1] = (uint32_t)ctx->retract_task.size(); }
+    ctx->mn_task.clear(); ctx->mn_off.assign(1, 0); ctx->mn_worker.clear();
+    {
+        size_t pos = 0;
+        for (size_t i = 0; i < cnt.mn_rq.size(); i++) for (auto &set : cnt.mn_sets[i]) {
+            ctx->mn_task.push_back(mn_ids[pos++]);
+            for (uint32_t w : set) ctx->mn_worker.push_back(w);
+            ctx->mn_off.push_back((uint32_t)ctx->mn_worker.size());
+        }
+    }
+    // Worker::insert_sn_task for every placed task (server/worker.rs:188-196 -> workerload.rs:156-165)
+    ctx->new_free.assign(s->worker_free, s->worker_free + (size_t)W * R);
+    for (uint32_t k = 0; k < nkeys; k++) {
+        const hqhost::VariantView &vv = pb.variants[pb.rqs[cnt.keys[k].first].first_variant + cnt.keys[k].second];
+        for (auto &wc : cnt.per_key[k]) for (uint32_t e = 0; e < vv.n_entries; e++) {
+            uint64_t &f = ctx->new_free[(size_t)wc.first * R + vv.res[e]];
+            if (vv.kind[e] == HQ_ENTRY_ALL) f = 0; else { uint64_t d = vv.amount[e] * (uint64_t)wc.second; f = f > d ? f - d : 0; }
+        }
+    }
+    out->status = status;
+    out->n_counts = (uint32_t)ctx->cnt_rq.size(); out->count_rq = ctx->cnt_rq.data(); out->count_variant = ctx->cnt_variant.data();
+    out->count_worker = ctx->cnt_worker.data(); out->count_value = ctx->cnt_value.data();
+    out->rec_off = ctx->rec_off.data(); out->rec_task = ctx->rec_task.data(); out->rec_variant = ctx->rec_variant.data(); out->rec_kind = ctx->rec_kind.data();
+    out->retract_off = ctx->retract_off.data(); out->retract_task = ctx->retract_task.data();
+    out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data();
+    out->n_mn = (uint32_t)ctx->mn_task.size(); out->mn_task = ctx->mn_task.data(); out->mn_worker_off = ctx->mn_off.data(); out->mn_worker = ctx->mn_worker.data();
+    out->new_free = ctx->new_free.data();
+    double t5 = now_us();
+    out->t_total_us = t5 - t0; out->t_scan_us = t1 - t0; out->t_batches_us = t2 - t1; out->t_solve_us = t3 - t2; out->t_mapping_us = t5 - t3;
+    uint64_t n_pref = 0; for (uint32_t q = 0; q < Q; q++) n_pref += new_pf_total[q];
+    uint64_t n_asg = 0; for (uint32_t w = 0; w < W; w++) n_asg += n_assign[w];
+    uint32_t nv = Q ? s->rq_variant_off[Q] : 0;
+    ctx->stats.n_assigned = n_asg; ctx->stats.n_prefilled = n_pref;
+    ctx->stats.algorithmic_bytes = N * 20 + (uint64_t)W * R * 16 + (uint64_t)nv * R * 9 + n_asg * 13 + n_pref * 12;
+    ctx->stats.tick_gpu_us = ctx->stats.distinct_us + ctx->stats.level_hist_us + ctx->stats.select_us + ctx->stats.other_us;
+    (void)t4;
+    return status;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+uint32_t hqtick_abi_version(void) { return HQTICK_ABI_VERSION; }
+const char *hqtick_build_arch(void) { return "gfx950"; }
+
+int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
+    if (!config || !out_ctx || config->abi_version != HQTICK_ABI_VERSION) return HQTICK_E_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || config->device_index < 0 || config->device_index >= n) return HQTICK_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, config->device_index) != hipSuccess) return HQTICK_E_NO_DEVICE;
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return HQTICK_E_NO_DEVICE;  // kernels are built for gfx950 only
+    if (hipSetDevice(config->device_index) != hipSuccess) return HQTICK_E_NO_DEVICE;
+    hqtick_ctx *ctx = new hqtick_ctx();
+    ctx->cfg = *config; ctx->device = config->device_index;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
+    for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
+    *out_ctx = ctx;
+    return 0;
+}
+
+void hqtick_destroy(hqtick_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
+                      &ctx->d_total, &ctx->d_free, &ctx->d_rem, &ctx->d_req, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_take_base, &ctx->d_sel_task,
+                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec_task, &ctx->d_rec_var, &ctx->d_rec_kind};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *hqtick_last_error(const hqtick_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int hqtick_run(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick_result *out) {
+    if (!ctx || !out) return HQTICK_E_INVALID;
+    return run_tick(ctx, snapshot, out, false);
+}
+
+int hqtick_upload_ready(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority, const uint32_t *task_rq, int sorted) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (n && (!task_id || !task_priority || !task_rq)) return fail(ctx, HQTICK_E_INVALID, "null ready-set column");
+    if (!sorted) return fail(ctx, HQTICK_E_UNSUPPORTED, "device-side sort of an unsorted ready set is not implemented in this round: pass ids ascending");
+    for (uint64_t i = 1; i < n; i++) if (task_id[i - 1] >= task_id[i]) return fail(ctx, HQTICK_E_INVALID, "ready set not sorted by task id");
+    HQ_HIP(hipSetDevice(ctx->device));
+    if (!ctx->d_tid.ensure(n * 8 + 8) || !ctx->d_tprio.ensure(n * 8 + 8) || !ctx->d_trq.ensure(n * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set");
+    if (n) {
+        HQ_HIP(hipMemcpyAsync(ctx->d_tid.p, task_id, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        HQ_HIP(hipMemcpyAsync(ctx->d_tprio.p, task_priority, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, task_rq, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->n_ready = n; ctx->resident = true;
+    return 0;
+}
+
+int hqtick_run_resident(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick_result *out) {
+    if (!ctx || !out) return HQTICK_E_INVALID;
+    return run_tick(ctx, snapshot, out, true);
+}
+
+int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_workers *fake, hqtick_query_result *out) {
+    if (!ctx || !out || !fake) return HQTICK_E_INVALID;
+    int rc = validate(ctx, s, true);
+    if (rc) return rc;
+    HQ_HIP(hipSetDevice(ctx->device));
+    const uint32_t R = s->n_resources, Q = s->n_requests;
+    uint64_t N = s->n_ready;
+    if (!ctx->d_tid.ensure(N * 8 + 8) || !ctx->d_tprio.ensure(N * 8 + 8) || !ctx->d_trq.ensure(N * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set");
+    if (N) {
+        HQ_HIP(hipMemcpyAsync(ctx->d_tprio.p, s->task_priority, N * 8, hipMemcpyHostToDevice, ctx->stream));
+        HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, s->task_rq, N * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->n_ready = N; ctx->resident = false;
+    hqk::RequestTable rt{};
+    if ((rc = upload_requests(ctx, s, &rt))) return rc;
+    WorkerEval ev_real, ev_fake;
+    if ((rc = eval_workers(ctx, s->n_workers, R, s->worker_total, s->worker_free, s->worker_remaining_ns, rt, &ev_real))) return rc;
+    if ((rc = eval_workers(ctx, fake->n_workers, R, fake->worker_total, fake->worker_total, fake->worker_remaining_ns, rt, &ev_fake))) return rc;  // fresh fake workers: free == total
+    Scan sc;
+    if ((rc = scan_ready(ctx, Q, &sc))) return rc;
+    hqhost::Problem pb;
+    fill_problem(pb, s, ctx->cfg, ev_real);
+    hqhost::WorkerSet fw;
+    fw.n = fake->n_workers; fw.R = R; fw.id = fake->worker_id; fw.total = fake->worker_total; fw.free_ = fake->worker_total;
+    fw.remaining_ns = fake->worker_remaining_ns; fw.min_util = fake->worker_min_utilization; fw.flags = nullptr; fw.group = nullptr;
+    fw.vflags = ev_fake.flags.data(); fw.vtmc = ev_fake.tmc.data(); fw.n_variant_slots = rt.n_variants;
+    fw.blocked.assign(fw.n, {}); fw.assigned.assign(fw.n, {});
+    pb.custom = &fw;
+    std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
+    std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
+    hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
+    if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
+    ctx->q_loaded.assign(fake->n_workers, 0);
+    for (auto &k : cnt.per_key) for (auto &wc : k) if (wc.second > 0) ctx->q_loaded[wc.first] = 1;  // query.rs:73-81
+    out->n_workers = fake->n_workers; out->is_loaded = ctx->q_loaded.data(); out->is_optimal = cnt.is_optimal;
+    return 0;
+}
+
+int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out) {
+    if (!ctx || !out) return HQTICK_E_INVALID;
+    *out = ctx->stats;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// Exact small-MILP solver of the MI355X tick (host side of the placement stage).
+//
+// Replaces what the reference delegates to HiGHS: `LpSolver::solve_bounded` / `solve`
+// (/root/reference/crates/tako/src/internal/solver/mod.rs:200-219, solver/highs.rs:51-88): maximise c.x over
+// integer columns (`0..` nat, `0..=1` bool) subject to Min/Max/Eq rows.
+//
+// Result convention ("canonical optimum"): the model is split into the connected components of
+// its row/column incidence graph; inside every component the returned vector is the LEXICOGRAPHICALLY LARGEST
+// (column creation order) among the feasible integer vectors whose objective is within 1e-9 (relative) of the
+// component's optimum.  Where the optimum is unique (all of the reference's pinned unit tests) this is simply the
+// optimum HiGHS returns; where it is not, it makes the answer a function of the model alone.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace hqmilp {
+
+enum { COL_NAT = 0, COL_BOOL = 1 };
+enum { ROW_MIN = 0, ROW_MAX = 1, ROW_EQ = 2 };  // ConstraintType  solver/mod.rs:22-27
+
+struct Model {
+    std::vector<double> obj;
+    std::vector<uint8_t> kind;
+    std::vector<uint8_t> rtype;
+    std::vector<double> rhs;
+    std::vector<int> roff{0};
+    std::vector<int> rcol;
+    std::vector<double> rcoef;
+    int ncols() const { return (int)obj.size(); }
+    int nrows() const { return (int)rhs.size(); }
+    int add_col(double w, uint8_t k) {
+        obj.push_back(w);
+        kind.push_back(k);
+        return (int)obj.size() - 1;
+    }
+    void begin_row(uint8_t t, double b) {
+        rtype.push_back(t);
+        rhs.push_back(b);
+    }
+    void term(int c, double v) {
+        rcol.push_back(c);
+        rcoef.push_back(v);
+    }
+    void end_row() { roff.push_back((int)rcol.size()); }
+};
+
+struct Result {
+    std::vector<double> x;   // integral values
+    double objective = 0.0;  // c.x in the model's own (unscaled) coefficients
+    bool feasible = false;   // false => the reference's `None` (infeasible / unbounded)   highs.rs:82
+    bool optimal = false;    // false with feasible => time limit hit, incumbent returned   highs.rs:73-80
+    long nodes = 0, lp_iters = 0;
+    int n_components = 0;
+};
+
+// canonical=true applies the lexicographic tie-break (always on in the product; off only in solver unit tests).
+Result solve(const Model &m, double time_limit_s, bool canonical = true);
+
+}  // namespace hqmilp

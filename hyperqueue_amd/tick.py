@@ -1,0 +1,110 @@
+"""ctypes binding of libhqtick.so (include/hqtick.h).  The library is the product: there is no Python or CPU
+implementation of the tick behind this module, and loading/creating a context fails loudly when the HIP library or
+a gfx950 device is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhqtick.so")
+
+
+class HqTickError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"hqtick error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+        lib = C.CDLL(LIB_PATH)
+        P = C.POINTER
+        lib.hqtick_create.argtypes = [P(abi.Config), P(C.c_void_p)]
+        lib.hqtick_destroy.argtypes = [C.c_void_p]
+        lib.hqtick_run.argtypes = [C.c_void_p, P(abi.SnapshotC), P(abi.ResultC)]
+        lib.hqtick_upload_ready.argtypes = [C.c_void_p, C.c_uint64, abi.u64p, abi.u64p, abi.u32p, C.c_int]
+        lib.hqtick_run_resident.argtypes = [C.c_void_p, P(abi.SnapshotC), P(abi.ResultC)]
+        lib.hqtick_query.argtypes = [C.c_void_p, P(abi.SnapshotC), P(abi.QueryWorkersC), P(abi.QueryResultC)]
+        lib.hqtick_last_error.restype = C.c_char_p
+        lib.hqtick_last_error.argtypes = [C.c_void_p]
+        lib.hqtick_abi_version.restype = C.c_uint32
+        lib.hqtick_build_arch.restype = C.c_char_p
+        lib.hqtick_kernel_stats_last.argtypes = [C.c_void_p, P(abi.KernelStatsC)]
+        _LIB = lib
+    return _LIB
+
+
+class Tick:
+    """One hqtick_ctx (one HIP device, one stream).  `tick(snapshot)` == run_scheduling_inner through the C ABI."""
+
+    def __init__(self, config: Optional[abi.Config] = None):
+        self.cfg = config or abi.make_config()
+        self._lib = load()
+        ctx = C.c_void_p()
+        rc = self._lib.hqtick_create(C.byref(self.cfg), C.byref(ctx))
+        if rc != 0:
+            raise HqTickError(rc, "hqtick_create failed (no gfx950 device / HIP runtime?)")
+        self._ctx = ctx
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.hqtick_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self) -> str:
+        return self._lib.hqtick_last_error(self._ctx).decode()
+
+    def tick_raw(self, sc: abi.SnapshotC, resident: bool = False) -> abi.ResultC:
+        rc_ = abi.ResultC()
+        fn = self._lib.hqtick_run_resident if resident else self._lib.hqtick_run
+        rc = fn(self._ctx, C.byref(sc), C.byref(rc_))
+        if rc < 0:
+            raise HqTickError(rc, self._err())
+        return rc_
+
+    def tick(self, snap: abi.Snapshot, resident: bool = False) -> abi.Result:
+        sc = snap.to_c()
+        return abi.parse_result(self.tick_raw(sc, resident), len(snap.worker_id), snap.n_resources)
+
+    def batches(self, snap: abi.Snapshot):
+        return abi.parse_batches(self.tick_raw(snap.to_c()))
+
+    def upload_ready(self, task_id: np.ndarray, task_priority: np.ndarray, task_rq: np.ndarray, sorted_: bool = True):
+        a, b, c = (np.ascontiguousarray(task_id, np.uint64), np.ascontiguousarray(task_priority, np.uint64), np.ascontiguousarray(task_rq, np.uint32))
+        rc = self._lib.hqtick_upload_ready(self._ctx, len(a), a.ctypes.data_as(abi.u64p), b.ctypes.data_as(abi.u64p), c.ctypes.data_as(abi.u32p), 1 if sorted_ else 0)
+        if rc < 0:
+            raise HqTickError(rc, self._err())
+
+    def query(self, snap: abi.Snapshot, fake_ids, fake_total, fake_remaining=None, fake_min_util=None):
+        sc = snap.to_c()
+        n = len(fake_ids)
+        ids = np.ascontiguousarray(fake_ids, np.uint32)
+        tot = np.ascontiguousarray(np.asarray(fake_total, np.uint64).reshape(-1))
+        rem = np.ascontiguousarray(fake_remaining if fake_remaining is not None else np.full(n, abi.HQ_NO_TIME_LIMIT), np.int64)
+        mu = np.ascontiguousarray(fake_min_util if fake_min_util is not None else np.zeros(n), np.float32)
+        q = abi.QueryWorkersC(n, ids.ctypes.data_as(abi.u32p), tot.ctypes.data_as(abi.u64p), rem.ctypes.data_as(abi.i64p), mu.ctypes.data_as(abi.f32p))
+        out = abi.QueryResultC()
+        rc = self._lib.hqtick_query(self._ctx, C.byref(sc), C.byref(q), C.byref(out))
+        if rc < 0:
+            raise HqTickError(rc, self._err())
+        return abi._np(out.is_loaded, n, np.uint8).astype(bool), bool(out.is_optimal)
+
+    def kernel_stats(self) -> dict:
+        ks = abi.KernelStatsC()
+        self._lib.hqtick_kernel_stats_last(self._ctx, C.byref(ks))
+        return {f: getattr(ks, f) for f, _ in abi.KernelStatsC._fields_}

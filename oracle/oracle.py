@@ -89,60 +89,98 @@ def lib():
 # ------------------------------------------------------------------------------------------------------
 # HiGHS (scipy) behind the reference's LpInnerSolver contract: maximise, integer columns 0.. / 0..=1
 # ------------------------------------------------------------------------------------------------------
-def solve_milp(obj, kind, rtype, rhs, roff, rcol, rcoef, time_limit: float = 60.0, canonical: bool = False):
-    """Returns (x, objective, is_optimal) or None.  solver/highs.rs:51-88."""
+def _highs(c_max, A, lo, hi, lb, ub, time_limit=None):
+    """maximise c_max.x with HiGHS; returns (x rounded, status) or (None, status)."""
     from scipy.optimize import Bounds, LinearConstraint, milp
+
+    n = len(c_max)
+    cons = [LinearConstraint(A, lo, hi)] if A is not None and A.shape[0] else []
+    opts = {"mip_rel_gap": 0.0, "disp": False}
+    if time_limit is not None and time_limit < 1e20:
+        opts["time_limit"] = float(time_limit)
+    res = milp(-np.asarray(c_max, float), constraints=cons, integrality=np.ones(n), bounds=Bounds(lb, ub), options=opts)
+    if res.x is None or res.status not in (0, 1):
+        return None, res.status
+    return np.round(res.x), res.status
+
+
+def solve_milp(obj, kind, rtype, rhs, roff, rcol, rcoef, time_limit: float = 60.0, canonical: bool = False):
+    """Returns (x, objective, is_optimal) or None.  solver/highs.rs:51-88 (maximise; nat = 0.., bool = 0..=1)."""
     from scipy.sparse import csr_matrix
 
     n, m = len(obj), len(rhs)
+    obj = np.asarray(obj, float)
     if n == 0:
         return np.zeros(0), 0.0, True
     ub = np.where(np.asarray(kind) == 1, 1.0, np.inf)
-    cons = []
+    lb = np.zeros(n)
+    A = None
+    lo = hi = None
     if m:
         A = csr_matrix((np.asarray(rcoef, float), np.asarray(rcol, np.int32), np.asarray(roff, np.int32)), shape=(m, n))
         A.sum_duplicates()
         lo = np.where(np.asarray(rtype) == 1, -np.inf, np.asarray(rhs, float))  # Max => (-inf, rhs]
         hi = np.where(np.asarray(rtype) == 0, np.inf, np.asarray(rhs, float))  # Min => [rhs, inf)
-        cons.append(LinearConstraint(A, lo, hi))
-    opts = {"mip_rel_gap": 0.0, "disp": False}
-    if time_limit < 1e20:
-        opts["time_limit"] = float(time_limit)
-    c = -np.asarray(obj, float)
-    res = milp(c, constraints=cons, integrality=np.ones(n), bounds=Bounds(np.zeros(n), ub), options=opts)
-    if res.x is None:
+    if canonical:
+        return _solve_canonical(obj, A, lo, hi, lb, ub)
+    x, status = _highs(obj, A, lo, hi, lb, ub, time_limit)
+    if x is None:
         return None
-    is_opt = res.status == 0
-    if res.status not in (0, 1):
-        return None
-    x = np.round(res.x)
-    z = float(np.dot(np.asarray(obj, float), x))
-    if canonical and is_opt:
-        x = _lex_max(c, cons, ub, z, x)
-        z = float(np.dot(np.asarray(obj, float), x))
-    return x, z, is_opt
+    return x, float(np.dot(obj, x)), status == 0
 
 
-def _lex_max(c, cons, ub, z, x0):
-    """Lexicographically largest optimum: fix columns one by one at their maximum subject to obj >= z - tol."""
-    from scipy.optimize import Bounds, LinearConstraint, milp
+def _solve_canonical(obj, A, lo, hi, lb, ub):
+    """The tie-break convention of the MI355X path, computed with HiGHS only:
+    per connected component of the row/column graph, the lexicographically largest vector (column order) among the
+    feasible integer vectors whose objective is within 1e-9 (relative) of the component optimum."""
+    from scipy.sparse import csr_matrix, vstack
+    from scipy.sparse.csgraph import connected_components
 
-    n = len(c)
-    tol = 1e-9 * max(1.0, abs(z))
-    objrow = LinearConstraint((-c).reshape(1, n), z - tol, np.inf)
-    lo, hi = np.zeros(n), ub.copy()
-    x = x0.copy()
-    for j in range(n):
-        cj = np.zeros(n)
-        cj[j] = -1.0
-        res = milp(cj, constraints=cons + [objrow], integrality=np.ones(n), bounds=Bounds(lo, hi), options={"mip_rel_gap": 0.0, "disp": False})
-        if res.x is None or res.status != 0:
-            v = x[j]
+    n = len(obj)
+    m = A.shape[0] if A is not None else 0
+    if m:
+        pat = (A != 0).astype(np.int8)
+        ncomp, lab = connected_components((pat.T @ pat), directed=False)
+    else:
+        ncomp, lab = n, np.arange(n)
+    x = np.zeros(n)
+    for k in range(ncomp):
+        cols = np.nonzero(lab == k)[0]
+        if m:
+            rows = np.nonzero(np.asarray((pat[:, cols] != 0).sum(axis=1)).ravel() > 0)[0]
+            Ak = A[rows][:, cols]
+            lok, hik = lo[rows], hi[rows]
         else:
-            v = float(np.round(res.x[j]))
-            x = np.round(res.x)
-        lo[j] = hi[j] = v
-    return x
+            Ak, lok, hik = None, None, None
+        c = obj[cols]
+        cmax = np.abs(c).max()
+        cs = c * (1e4 / cmax) if cmax > 0 else c  # O(1e4) costs: keeps HiGHS' absolute gaps (1e-6) far below real differences
+        xk, status = _highs(cs, Ak, lok, hik, lb[cols], ub[cols])
+        if xk is None or status != 0:
+            return None
+        z = float(np.dot(cs, xk))
+        if cmax > 0:
+            cut = csr_matrix(cs.reshape(1, -1))
+            Ak2 = vstack([Ak, cut]).tocsr() if Ak is not None and Ak.shape[0] else cut
+            lo2 = np.append(lok, z - 1e-9 * abs(z)) if lok is not None else np.array([z - 1e-9 * abs(z)])
+            hi2 = np.append(hik, np.inf) if hik is not None else np.array([np.inf])
+        else:
+            Ak2, lo2, hi2 = Ak, lok, hik
+        l, u = lb[cols].copy(), ub[cols].copy()
+        for j in range(len(cols)):
+            if xk[j] >= u[j]:
+                l[j] = u[j] = xk[j]
+                continue
+            e = np.zeros(len(cols))
+            e[j] = 1.0
+            xj, status = _highs(e, Ak2, lo2, hi2, l, u)
+            if xj is None or status != 0:
+                v = xk[j]
+            else:
+                v, xk = xj[j], xj
+            l[j] = u[j] = v
+        x[cols] = xk
+    return x, float(np.dot(obj, x)), True
 
 
 class Oracle:
