@@ -24,7 +24,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-o", LIB] + srcs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-o", LIB] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -145,10 +145,9 @@ int eval_workers(hqtick_ctx *ctx, uint32_t W, uint32_t R, const uint64_t *total,
         HQ_HIP(hipMemcpyAsync(ctx->d_free.p, free_, (size_t)W * R * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     HQ_HIP(hipMemcpyAsync(ctx->d_rem.p, rem_h.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
-    hqk::worker_eval(ctx->d_total.as<uint64_t>(), ctx->d_free.as<uint64_t>(), ctx->d_rem.as<int64_t>(), W, R, rt, ctx->d_vflags.as<uint8_t>(),
-                     ctx->d_vtmc.as<uint32_t>(), ctx->stream);
-    HQ_HIP(hipGetLastError());
-    HQ_HIP(hipMemcpyAsync(out->flags.data(), ctx->d_vflags.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HQ_HIP(hqk::worker_eval(ctx->d_total.as<uint64_t>(), ctx->d_free.as<uint64_t>(), ctx->d_rem.as<int64_t>(), W, R, rt, ctx->d_vflags.as<uint8_t>(),
+                     ctx->d_vtmc.as<uint32_t>(), ctx->stream));
+        HQ_HIP(hipMemcpyAsync(out->flags.data(), ctx->d_vflags.p, n, hipMemcpyDeviceToHost, ctx->stream));
     HQ_HIP(hipMemcpyAsync(out->tmc.data(), ctx->d_vtmc.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HQ_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -203,20 +202,19 @@ int scan_ready(hqtick_ctx *ctx, uint32_t Q, Scan *sc) {
     sc->Q = Q; sc->L = 0; sc->G = 0; sc->levels.clear(); sc->hist.clear();
     uint64_t N = ctx->n_ready;
     if (N == 0 || Q == 0) return 0;
-    if (!ctx->d_set.ensure((size_t)hqk::PRIO_SET_CAP * 8) || !ctx->d_flags.ensure(64) || !ctx->d_levels.ensure((size_t)(8192 + 2) * 8) || !ctx->d_nlevels.ensure(16))
+    if (!ctx->d_set.ensure((size_t)hqk::PRIO_SET_CAP * 8) || !ctx->d_flags.ensure(64) || !ctx->d_levels.ensure((size_t)(hqk::MAX_LEVELS + 2) * 8) || !ctx->d_nlevels.ensure(16))
         return fail(ctx, HQTICK_E_DEVICE, "hipMalloc level tables");
     HQ_HIP(hipMemsetAsync(ctx->d_set.p, 0xFF, (size_t)hqk::PRIO_SET_CAP * 8, ctx->stream));
     HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
     HQ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    hqk::distinct_priorities(ctx->d_tprio.as<uint64_t>(), N, ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream);
+    HQ_HIP(hqk::distinct_priorities(ctx->d_tprio.as<uint64_t>(), N, ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream));
     HQ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-    hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->stream);
-    HQ_HIP(hipGetLastError());
-    uint32_t L = 0, flags[4] = {0, 0, 0, 0};
+    HQ_HIP(hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->stream));
+        uint32_t L = 0, flags[4] = {0, 0, 0, 0};
     HQ_HIP(hipMemcpyAsync(&L, ctx->d_nlevels.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     HQ_HIP(hipStreamSynchronize(ctx->stream));
-    if (flags[1] || L == 0xFFFFFFFFu || L > 8192) return fail(ctx, HQTICK_E_CAPACITY, "more than 8192 distinct priority levels in the ready set");
+    if (flags[1] || L == 0xFFFFFFFFu || L > hqk::MAX_LEVELS) return fail(ctx, HQTICK_E_CAPACITY, "more than 4096 distinct priority levels in the ready set");
     if (L == 0) return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level");
     uint64_t G64 = (uint64_t)L * Q;
     if (G64 > hqk::MAX_GROUPS) return fail(ctx, HQTICK_E_CAPACITY, "levels x requests exceeds 16384 groups");
@@ -231,12 +229,11 @@ int scan_ready(hqtick_ctx *ctx, uint32_t Q, Scan *sc) {
     g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw);
     if (!ctx->d_wave_tab.ensure((size_t)g.n_waves * G * 4) || !ctx->d_hist.ensure((size_t)G * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
     HQ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
-                    ctx->d_flags.as<uint32_t>() + 2, ctx->stream);
+    HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
+                    ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
     HQ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
-    hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g.n_waves, G, ctx->d_hist.as<uint32_t>(), ctx->stream);
-    HQ_HIP(hipGetLastError());
-    sc->hist.resize(G);
+    HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g.n_waves, G, ctx->d_hist.as<uint32_t>(), ctx->stream));
+        sc->hist.resize(G);
     HQ_HIP(hipMemcpyAsync(sc->hist.data(), ctx->d_hist.p, (size_t)G * 4, hipMemcpyDeviceToHost, ctx->stream));
     HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     HQ_HIP(hipStreamSynchronize(ctx->stream));
@@ -473,12 +470,11 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
             return fail(ctx, HQTICK_E_DEVICE, "hipMalloc selection");
         HQ_HIP(hipMemcpyAsync(ctx->d_take_base.p, take_base.data(), take_base.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-        hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, sc.geom,
+        HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, sc.geom,
                             ctx->d_wave_tab.as<uint32_t>(), ctx->d_take_base.as<uint32_t>(), ctx->d_take_base.as<uint32_t>() + sc.G,
-                            ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->stream);
+                            ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->stream));
         HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
-        HQ_HIP(hipGetLastError());
-        // pack every K5 table into one upload
+                // pack every K5 table into one upload
         std::vector<uint32_t> pack;
         auto put = [&](const std::vector<uint32_t> &v) { size_t o = pack.size(); pack.insert(pack.end(), v.begin(), v.end()); if (v.empty()) pack.push_back(0); return o; };
         std::vector<uint32_t> key_rq(nkeys), key_var_w((nkeys + 3) / 4 + 1, 0);
@@ -497,11 +493,10 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         mk.pfl_cnt = d + o_pflcnt; mk.out_off = d + o_out;
         HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
         HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->d_levels.as<uint64_t>(), max_items,
-                            ctx->d_rec_task.as<uint64_t>(), ctx->d_rec_var.as<uint8_t>(), ctx->d_rec_kind.as<uint8_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream);
+        HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->d_levels.as<uint64_t>(), max_items,
+                            ctx->d_rec_task.as<uint64_t>(), ctx->d_rec_var.as<uint8_t>(), ctx->d_rec_kind.as<uint8_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream));
         HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
-        HQ_HIP(hipGetLastError());
-        uint32_t flags[4] = {0, 0, 0, 0};
+                uint32_t flags[4] = {0, 0, 0, 0};
         if (n_rec) {
             HQ_HIP(hipMemcpyAsync(ctx->rec_task.data(), ctx->d_rec_task.p, (size_t)n_rec * 8, hipMemcpyDeviceToHost, ctx->stream));
             HQ_HIP(hipMemcpyAsync(ctx->rec_variant.data(), ctx->d_rec_var.p, n_rec, hipMemcpyDeviceToHost, ctx->stream));

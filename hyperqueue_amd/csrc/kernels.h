@@ -12,6 +12,7 @@ static const uint32_t PRIO_SET_CAP = 1u << 15;
 static const uint64_t PRIO_EMPTY = 0xFFFFFFFFFFFFFFFFull;  // Priority u64::MAX is representable; it is tracked by a side flag
 static const uint32_t MAX_GROUPS_4W = 2048;                // G <= this: 4 waves per block share the LDS
 static const uint32_t MAX_GROUPS = 16384;                  // hard cap on G = levels x requests
+static const uint32_t MAX_LEVELS = 4096;                   // distinct priority levels per tick (LDS sort)
 
 struct WaveGeom {
     uint32_t tasks_per_wave;  // contiguous ready-set slice a wavefront owns (multiple of 64)
@@ -21,15 +22,15 @@ struct WaveGeom {
 
 // K0: insert every task priority into the open-addressing set `set` (PRIO_SET_CAP slots, pre-filled with PRIO_EMPTY).
 // flags[0] |= 1 when some priority equals PRIO_EMPTY itself, flags[1] = 1 on overflow.
-void distinct_priorities(const uint64_t *prio, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s);
+hipError_t distinct_priorities(const uint64_t *prio, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s);
 // K0b: compact the set and sort it descending into levels[]; n_levels[0] = L.  Single workgroup.
-void sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *levels, uint32_t *n_levels, hipStream_t s);
+hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *levels, uint32_t *n_levels, hipStream_t s);
 
 // K1: per-wave-slice histogram of (level, rq) groups.  wave_cnt is [n_waves][G] (G = L*Q, g = level*Q + rq).
-void level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, uint32_t L, uint32_t Q,
+hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, uint32_t L, uint32_t Q,
                 WaveGeom geom, uint32_t *wave_cnt, uint32_t *err_flag, hipStream_t s);
 // K1b: exclusive scan of wave_cnt over the wave axis (in place -> offsets) and totals into hist[G].
-void scan_waves(uint32_t *wave_cnt, uint32_t n_waves, uint32_t G, uint32_t *hist, hipStream_t s);
+hipError_t scan_waves(uint32_t *wave_cnt, uint32_t n_waves, uint32_t G, uint32_t *hist, hipStream_t s);
 
 // K2: per (worker, variant) capability flags and task_max_count (server/workerload.rs:77-83,121-145).
 //   flags bit0: free resources cover the variant (have_immediate_resources_for_rq)
@@ -42,12 +43,12 @@ struct RequestTable {
     const uint64_t *variant_min_time_ns;
     uint32_t n_variants;
 };
-void worker_eval(const uint64_t *total, const uint64_t *free_, const int64_t *remaining_ns, uint32_t W, uint32_t R,
+hipError_t worker_eval(const uint64_t *total, const uint64_t *free_, const int64_t *remaining_ns, uint32_t W, uint32_t R,
                  RequestTable rt, uint8_t *flags, uint32_t *tmc, hipStream_t s);
 
 // K4: select the first take[g] tasks (ascending id) of every group and scatter them to sel_task/sel_level at
 // base[g] + rank.  wave_off = output of scan_waves.
-void select_scatter(const uint64_t *task_id, const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels,
+hipError_t select_scatter(const uint64_t *task_id, const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels,
                     uint32_t L, uint32_t Q, WaveGeom geom, const uint32_t *wave_off, const uint32_t *take,
                     const uint32_t *base, uint64_t *sel_task, uint16_t *sel_level, hipStream_t s);
 
@@ -77,7 +78,7 @@ struct MapKeys {
     // output placement
     const uint32_t *out_off;       // [W+1]
 };
-void expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, const uint64_t *levels,
+hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, const uint64_t *levels,
                     uint32_t max_items, uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag,
                     hipStream_t s);
 

@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) k_distinct_priorities(const uint64_t *__r
 }
 
 // ------------------------------------------------------------------------------------------------ K0b
-static const uint32_t LEVEL_CAP = 8192;  // distinct priority levels one tick can carry (64 KiB of LDS)
+static const uint32_t LEVEL_CAP = hqk::MAX_LEVELS;  // distinct priority levels one tick can carry (32 KiB of LDS)
 
 __global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict__ set, const uint32_t *__restrict__ flags,
                                                       uint64_t *__restrict__ levels, uint32_t *__restrict__ n_levels) {
@@ -326,76 +326,79 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, const uint64
 }  // namespace
 
 // ================================================================================================ host wrappers
-void distinct_priorities(const uint64_t *prio, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s) {
-    if (n == 0) return;
+hipError_t distinct_priorities(const uint64_t *prio, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s) {
+    if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 resident blocks: grid-stride the rest
     hipLaunchKernelGGL(k_distinct_priorities, dim3((unsigned)blocks), dim3(256), 0, s, prio, n, set, flags);
+    return hipGetLastError();
 }
 
-void sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *levels, uint32_t *n_levels, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_levels), hipFuncAttributeMaxDynamicSharedMemorySize, LEVEL_CAP * 8);
-        attr_set = true;
-    }
+hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *levels, uint32_t *n_levels, hipStream_t s) {
     hipLaunchKernelGGL(k_sort_levels, dim3(1), dim3(1024), LEVEL_CAP * 8, s, set, flags, levels, n_levels);
+    return hipGetLastError();
 }
 
 static uint32_t lds_levels_for(uint32_t L) { return L <= 1024 ? L : 0; }
 
 template <bool SELECT>
-static void launch_group_pass(const uint64_t *task_id, const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels,
+static hipError_t launch_group_pass(const uint64_t *task_id, const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels,
                               uint32_t L, uint32_t Q, WaveGeom geom, uint32_t *wave_tab, const uint32_t *take, const uint32_t *base,
                               uint64_t *sel_task, uint16_t *sel_level, uint32_t *err_flag, hipStream_t s) {
-    if (n == 0 || geom.n_waves == 0) return;
+    if (n == 0 || geom.n_waves == 0) return hipSuccess;
     uint32_t G = L * Q, ll = lds_levels_for(L);
+    hipError_t e;
     if (geom.waves_per_block == 4) {
         size_t lds = (size_t)ll * 8 + (size_t)4 * G * 4;
         auto kern = k_group_pass<4, SELECT>;
-        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((geom.n_waves + 3) / 4), dim3(256), lds, s, task_id, prio, rq, n, levels, L, Q,
                            geom.tasks_per_wave, geom.n_waves, ll, wave_tab, take, base, sel_task, sel_level, err_flag);
     } else {
         size_t lds = (size_t)ll * 8 + (size_t)G * 4;
         auto kern = k_group_pass<1, SELECT>;
-        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(geom.n_waves), dim3(64), lds, s, task_id, prio, rq, n, levels, L, Q, geom.tasks_per_wave,
                            geom.n_waves, ll, wave_tab, take, base, sel_task, sel_level, err_flag);
     }
+    return hipGetLastError();
 }
 
-void level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, uint32_t L, uint32_t Q, WaveGeom geom,
+hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, uint32_t L, uint32_t Q, WaveGeom geom,
                 uint32_t *wave_cnt, uint32_t *err_flag, hipStream_t s) {
-    launch_group_pass<false>(nullptr, prio, rq, n, levels, L, Q, geom, wave_cnt, nullptr, nullptr, nullptr, nullptr, err_flag, s);
+    return launch_group_pass<false>(nullptr, prio, rq, n, levels, L, Q, geom, wave_cnt, nullptr, nullptr, nullptr, nullptr, err_flag, s);
 }
 
-void scan_waves(uint32_t *wave_cnt, uint32_t n_waves, uint32_t G, uint32_t *hist, hipStream_t s) {
-    if (G == 0) return;
+hipError_t scan_waves(uint32_t *wave_cnt, uint32_t n_waves, uint32_t G, uint32_t *hist, hipStream_t s) {
+    if (G == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scan_waves, dim3(G), dim3(256), 0, s, wave_cnt, n_waves, hist);
+    return hipGetLastError();
 }
 
-void worker_eval(const uint64_t *total, const uint64_t *free_, const int64_t *remaining_ns, uint32_t W, uint32_t R, RequestTable rt,
+hipError_t worker_eval(const uint64_t *total, const uint64_t *free_, const int64_t *remaining_ns, uint32_t W, uint32_t R, RequestTable rt,
                  uint8_t *flags, uint32_t *tmc, hipStream_t s) {
     uint32_t n = W * rt.n_variants;
-    if (n == 0) return;
+    if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_worker_eval, dim3((n + 255) / 256), dim3(256), 0, s, total, free_, remaining_ns, W, R, rt, flags, tmc);
+    return hipGetLastError();
 }
 
-void select_scatter(const uint64_t *task_id, const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, uint32_t L,
+hipError_t select_scatter(const uint64_t *task_id, const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, uint32_t L,
                     uint32_t Q, WaveGeom geom, const uint32_t *wave_off, const uint32_t *take, const uint32_t *base, uint64_t *sel_task,
                     uint16_t *sel_level, hipStream_t s) {
-    launch_group_pass<true>(task_id, prio, rq, n, levels, L, Q, geom, const_cast<uint32_t *>(wave_off), take, base, sel_task, sel_level,
+    return launch_group_pass<true>(task_id, prio, rq, n, levels, L, Q, geom, const_cast<uint32_t *>(wave_off), take, base, sel_task, sel_level,
                             nullptr, s);
 }
 
-void expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, const uint64_t *levels,
+hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, const uint64_t *levels,
                     uint32_t max_items, uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, hipStream_t s) {
-    if (W == 0) return;
+    if (W == 0) return hipSuccess;
     size_t lds = (size_t)max_items * 18 + 16;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_mapping), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e;
+    if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_mapping), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, sel_task, sel_level, levels, max_items, rec_task, rec_variant,
                        rec_kind, err_flag);
+    return hipGetLastError();
 }
 
 }  // namespace hqk

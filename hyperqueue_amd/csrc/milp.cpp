@@ -12,6 +12,8 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <string>
+#include <unordered_map>
 
 namespace hqmilp {
 namespace {
@@ -198,7 +200,8 @@ struct CompSolver {
         xout = bx;
         if (timed_out) return 2;
         if (!canonical || n == 0) return 1;
-        // phase 2: lexicographically largest vector with c.x >= best - tol, by bound probing on a zero-cost tableau
+        // phase 2: among vectors with c.x >= best - tol, minimise the LAST column, then the one before it, ... (bound probing,
+        // one feasibility B&B per probe)
         double tol = 1e-9 * std::fabs(best);
         std::vector<double> A2(A), rlo2(rlo), rhi2(rhi);
         double cs = 0.0; for (int k = 0; k < n; k++) cs = std::max(cs, std::fabs(c[k]));
@@ -208,22 +211,22 @@ struct CompSolver {
         }
         int m2 = (int)rlo2.size();
         std::vector<double> flb(lb), fub(ub), cur(bx);
-        for (int j = 0; j < n; j++) {
-            double lo = cur[j], hi = fub[j];
+        for (int j = n - 1; j >= 0; j--) {  // last column first
+            double lo = flb[j], hi = cur[j];
             bool first = true;
             while (lo < hi) {
-                // first probe just above the current value: most columns fail it immediately
-                double mid = first ? lo + 1 : std::floor((lo + hi + 1) / 2);
+                // first probe just below the current value: most columns fail it immediately
+                double mid = first ? hi - 1 : std::floor((lo + hi) / 2);
                 first = false;
-                Tab t; std::vector<double> plb(flb); plb[j] = mid;
-                t.init(n, m2, A2, c, plb, fub, rlo2, rhi2);
+                Tab t; std::vector<double> pub(fub); pub[j] = mid;
+                t.init(n, m2, A2, c, flb, pub, rlo2, rhi2);
                 std::vector<double> sol;
                 bool ok = dfs_feas(t, sol);
                 lp_iters += t.iters;
                 if (timed_out) return 2;
-                if (ok) { cur = sol; lo = sol[j]; } else hi = mid - 1;
+                if (ok) { cur = sol; hi = sol[j]; } else lo = mid + 1;
             }
-            flb[j] = fub[j] = lo;
+            flb[j] = fub[j] = hi;
         }
         xout = cur;
         return 1;
@@ -291,6 +294,7 @@ Result solve(const Model &mdl, double time_limit_s, bool canonical) {
     res.n_components = (int)ccols.size();
 
     std::vector<int> local(n, -1);
+    std::unordered_map<std::string, std::pair<int, std::vector<double>>> memo;
     for (size_t ci = 0; ci < ccols.size(); ci++) {
         auto &cols = ccols[ci]; auto &rows = crows[ci];
         CompSolver cs; cs.n = (int)cols.size(); cs.m = (int)rows.size(); cs.deadline = deadline;
@@ -324,8 +328,29 @@ Result solve(const Model &mdl, double time_limit_s, bool canonical) {
             cs.rlo[r] = mdl.rtype[i] == ROW_MAX ? -INF : b;
             cs.rhi[r] = mdl.rtype[i] == ROW_MIN ? INF : b;
         }
+        // identical components (same rows, bounds and — up to 2^-40 relative — the same normalised costs) share one solve:
+        // workers with equal free/total vectors produce them by the hundred (solver.rs:95-192 builds one block per worker)
+        std::string sig;
+        bool memo_ok = (size_t)cs.m * cs.n <= 4096;
+        if (memo_ok) {
+            auto put = [&](const void *p, size_t nb) { sig.append(reinterpret_cast<const char *>(p), nb); };
+            int dims[2] = {cs.n, cs.m}; put(dims, sizeof dims);
+            put(cs.ub.data(), cs.ub.size() * 8); put(cs.A.data(), cs.A.size() * 8); put(cs.rlo.data(), cs.rlo.size() * 8); put(cs.rhi.data(), cs.rhi.size() * 8);
+            for (int k = 0; k < cs.n; k++) { long long qv = (long long)std::llround(cs.c[k] * 1099511627776.0); put(&qv, 8); }
+            auto hit = memo.find(sig);
+            if (hit != memo.end()) {
+                const std::vector<double> &xo = hit->second.second;
+                if (hit->second.first == 0) { res.feasible = false; res.optimal = false; return res; }
+                for (int k = 0; k < cs.n; k++) {
+                    if (capped[cols[k]] && xo[k] >= UB_CAP - 0.5) { res.feasible = false; res.optimal = false; return res; }
+                    res.x[cols[k]] = xo[k];
+                }
+                continue;
+            }
+        }
         std::vector<double> xo;
         int st = cs.run(canonical, xo);
+        if (memo_ok && !cs.timed_out && (st == 0 || st == 1)) memo.emplace(std::move(sig), std::make_pair(st, xo));
         res.nodes += cs.nodes; res.lp_iters += cs.lp_iters;
         if (st == 0) {
             if (cs.timed_out) { res.optimal = false; continue; }  // nothing found in time: leave zeros

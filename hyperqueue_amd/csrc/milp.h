@@ -5,10 +5,15 @@
 // integer columns (`0..` nat, `0..=1` bool) subject to Min/Max/Eq rows.
 //
 // Result convention ("canonical optimum"): the model is split into the connected components of
-// its row/column incidence graph; inside every component the returned vector is the LEXICOGRAPHICALLY LARGEST
-// (column creation order) among the feasible integer vectors whose objective is within 1e-9 (relative) of the
-// component's optimum.  Where the optimum is unique (all of the reference's pinned unit tests) this is simply the
-// optimum HiGHS returns; where it is not, it makes the answer a function of the model alone.
+// its row/column incidence graph; inside every component, among the feasible integer vectors whose objective is
+// within 1e-9 (relative) of the component's optimum, the returned one minimises the LAST column, then the one before
+// it, and so on (lexicographically smallest read from the last column backwards).  Where the optimum is unique
+// (almost all of the reference's pinned unit tests) this is simply the optimum HiGHS returns; where it is not, it
+// makes the answer a function of the model alone.  Why this order: auxiliary columns are created last
+// (scheduler/solver.rs:233-253 blocker flags), so "blocker fully placed" (flag = 0) wins ties — the one pinned test
+// with tied optima, test_schedule_gap_filling3 (tests/test_scheduler_sn.rs:497-525), is satisfied only by that choice,
+// which is also what HiGHS returns there — and among placement columns ties go to earlier batches / lower worker ids,
+// the same direction the objective's (W - idx) factor pushes.
 #pragma once
 #include <cstdint>
 #include <vector>

@@ -1,0 +1,112 @@
+"""Seeded synthetic snapshots of the shapes BASELINE.json names.  All integer; the RNG is splitmix64 so a
+C++/Rust harness can regenerate the same inputs.
+
+  c1  1 000 tasks cpus=1, 4 workers x 4 cores                       (plumbing case of benchmarks/experiment-per-task-overhead.py)
+  c2  100 000 tasks cpus=1, 256 workers x 128 cores, one priority   (uniform bin-packing)
+  c3  1 000 000 tasks over 8 request classes on {cpus, gpus/amd, mem} incl. 0.5 / 0.25 GPU fractions, 1024 workers
+      (128 c / 8 g / 512 m), one priority level, every class saturated  -> the placement model is separable per worker
+  c3p c3 with three user-priority levels (80/15/5 %): couples all workers through priority cuts (reported, not benched)
+  c4  c3 classes as 2-variant OR-lists, 4096 workers                (sharded case)
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import abi
+from .core import FR, priority_from_user, task_id
+
+MASK = (1 << 64) - 1
+
+
+def splitmix64_stream(seed: int, n: int) -> np.ndarray:
+    """n outputs of splitmix64 seeded with `seed` (vectorised: state_i = seed + (i+1)*golden)."""
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _variant(entries: List[Tuple[int, float]], weight: int = 10_000) -> dict:
+    return dict(entries=[(r, abi.HQ_ENTRY_AMOUNT, int(round(a * FR))) for r, a in entries], n_nodes=0, min_time_ns=0, weight=weight)
+
+
+# resource ids: 0 cpus, 1 gpus/amd, 2 mem
+C3_CLASSES = [
+    ([(0, 1)], 0.33),                          # 1 cpu
+    ([(0, 4)], 0.12),                          # 4 cpus
+    ([(0, 2), (1, 1)], 0.08),                  # 2 cpus + 1 gpu
+    ([(0, 1), (1, 0.5)], 0.08),                # 1 cpu + half a gpu
+    ([(0, 1), (1, 0.25)], 0.05),               # 1 cpu + quarter gpu
+    ([(0, 8), (2, 64)], 0.08),                 # 8 cpus + 64 mem
+    ([(0, 16), (1, 2), (2, 128)], 0.06),       # 16 cpus + 2 gpus + 128 mem
+    ([(0, 1), (2, 1)], 0.20),                  # 1 cpu + 1 mem
+]
+C4_ALTERNATIVES = [[(0, 2)], [(0, 16)], [(0, 8)], [(0, 4)], [(0, 2)], [(0, 32)], [(0, 64)], [(0, 2)]]
+
+
+def _uniform_workers(n: int, first_id: int, total_units: List[float]):
+    R = len(total_units)
+    total = np.tile(np.asarray([int(round(u * FR)) for u in total_units], np.uint64), (n, 1))
+    return dict(
+        n_resources=R, worker_id=np.arange(first_id, first_id + n, dtype=np.uint32), worker_total=total, worker_free=total.copy(),
+        worker_remaining_ns=np.full(n, abi.HQ_NO_TIME_LIMIT, np.int64), worker_min_utilization=np.zeros(n, np.float32),
+        worker_flags=np.full(n, abi.HQ_WORKER_SN, np.uint8), worker_group=np.zeros(n, np.uint32), n_groups=1, blocked=[],
+        assigned=[[] for _ in range(n)], prefilled=[[] for _ in range(n)],
+    )
+
+
+def _tasks(n: int, class_weights: List[float], seed: int, priorities: Optional[List[Tuple[int, float]]] = None):
+    ids = (np.uint64(1) << np.uint64(32)) | np.arange(1, n + 1, dtype=np.uint64)  # job 1, task 1..n: ascending
+    r = splitmix64_stream(seed, 2 * n)
+    u = (r[:n] >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    edges = np.cumsum(class_weights) / np.sum(class_weights)
+    rq = np.searchsorted(edges, u, side="right").clip(0, len(class_weights) - 1).astype(np.uint32)
+    if priorities:
+        u2 = (r[n:] >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+        pe = np.cumsum([p[1] for p in priorities]) / sum(p[1] for p in priorities)
+        pi = np.searchsorted(pe, u2, side="right").clip(0, len(priorities) - 1)
+        prio = np.asarray([priority_from_user(p[0]) for p in priorities], np.uint64)[pi]
+    else:
+        prio = np.full(n, priority_from_user(0), np.uint64)
+    return ids, prio, rq
+
+
+def make(name: str, seed: int = 0, n_tasks: Optional[int] = None, n_workers: Optional[int] = None) -> abi.Snapshot:
+    name = name.lower()
+    if name == "c1":
+        w = _uniform_workers(n_workers or 4, 1, [4])
+        ids, prio, rq = _tasks(n_tasks or 1_000, [1.0], seed)
+        return abi.Snapshot(requests=[[_variant([(0, 1)])]], task_id=ids, task_priority=prio, task_rq=rq, **w)
+    if name == "c2":
+        w = _uniform_workers(n_workers or 256, 1, [128])
+        ids, prio, rq = _tasks(n_tasks or 100_000, [1.0], seed)
+        return abi.Snapshot(requests=[[_variant([(0, 1)])]], task_id=ids, task_priority=prio, task_rq=rq, **w)
+    if name in ("c3", "c3p"):
+        w = _uniform_workers(n_workers or 1024, 1, [128, 8, 512])
+        pr = [(0, 0.80), (1, 0.15), (2, 0.05)] if name == "c3p" else None
+        ids, prio, rq = _tasks(n_tasks or 1_000_000, [c[1] for c in C3_CLASSES], seed, pr)
+        return abi.Snapshot(requests=[[_variant(c[0])] for c in C3_CLASSES], task_id=ids, task_priority=prio, task_rq=rq, **w)
+    if name == "c4":
+        w = _uniform_workers(n_workers or 4096, 1, [128, 8, 512])
+        ids, prio, rq = _tasks(n_tasks or 1_000_000, [c[1] for c in C3_CLASSES], seed)
+        reqs = [[_variant(c[0]), _variant(alt)] for c, alt in zip(C3_CLASSES, C4_ALTERNATIVES)]
+        return abi.Snapshot(requests=reqs, task_id=ids, task_priority=prio, task_rq=rq, **w)
+    raise ValueError(f"unknown workload {name}")
+
+
+def shard_workers(snap: abi.Snapshot, rank: int, world: int) -> abi.Snapshot:
+    """Worker shard of one rank: workers whose FxHash(worker_id) mod world == rank (north_star: hash-partitioned workers).
+    Every rank keeps the whole ready set and request table."""
+    from .hbmap import hash_u32
+
+    keep = np.asarray([hash_u32(int(w)) % world == rank for w in snap.worker_id], bool)
+    idx = np.nonzero(keep)[0]
+    return abi.Snapshot(
+        n_resources=snap.n_resources, worker_id=snap.worker_id[idx], worker_total=snap.worker_total[idx], worker_free=snap.worker_free[idx],
+        worker_remaining_ns=snap.worker_remaining_ns[idx], worker_min_utilization=snap.worker_min_utilization[idx], worker_flags=snap.worker_flags[idx],
+        worker_group=snap.worker_group[idx], n_groups=snap.n_groups, blocked=[], assigned=[snap.assigned[i] for i in idx], prefilled=[snap.prefilled[i] for i in idx],
+        requests=snap.requests, task_id=snap.task_id, task_priority=snap.task_priority, task_rq=snap.task_rq,
+    )

@@ -8,8 +8,8 @@ scipy (HiGHS 1.8.0, `scipy.optimize.milp`); the reference pins `highs` 2.4.0 / `
 (Cargo.lock:1107-1122) — same solver, different release, so ties between equally good optima may differ.
 
 `canonical=True` additionally post-processes the optimum into the tie-break convention the MI355X path
-implements: among all solutions whose objective is within 1e-9 (relative) of the optimum,
-the lexicographically largest vector in column-creation order.
+implements: per connected component of the model, among all solutions whose objective is within
+1e-9 (relative) of the component optimum, the one that minimises the last column, then the one before it, ...
 """
 from __future__ import annotations
 
@@ -131,8 +131,8 @@ def solve_milp(obj, kind, rtype, rhs, roff, rcol, rcoef, time_limit: float = 60.
 
 def _solve_canonical(obj, A, lo, hi, lb, ub):
     """The tie-break convention of the MI355X path, computed with HiGHS only:
-    per connected component of the row/column graph, the lexicographically largest vector (column order) among the
-    feasible integer vectors whose objective is within 1e-9 (relative) of the component optimum."""
+    per connected component of the row/column graph, among the feasible integer vectors whose objective is within 1e-9
+    (relative) of the component optimum, minimise the last column, then the one before it, and so on."""
     from scipy.sparse import csr_matrix, vstack
     from scipy.sparse.csgraph import connected_components
 
@@ -167,12 +167,12 @@ def _solve_canonical(obj, A, lo, hi, lb, ub):
         else:
             Ak2, lo2, hi2 = Ak, lok, hik
         l, u = lb[cols].copy(), ub[cols].copy()
-        for j in range(len(cols)):
-            if xk[j] >= u[j]:
+        for j in range(len(cols) - 1, -1, -1):  # last column first
+            if xk[j] <= l[j]:
                 l[j] = u[j] = xk[j]
                 continue
             e = np.zeros(len(cols))
-            e[j] = 1.0
+            e[j] = -1.0  # minimise x_j
             xj, status = _highs(e, Ak2, lo2, hi2, l, u)
             if xj is None or status != 0:
                 v = xk[j]

@@ -1,0 +1,190 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on the same snapshots.  Integer work: bit-exact.
+
+The oracle runs in `canonical` mode: HiGHS for every optimum, plus the documented tie-break so that
+instances with several optimal placements have one well-defined answer.
+"""
+import numpy as np
+import pytest
+
+from hyperqueue_amd import abi, workloads
+from hyperqueue_amd.core import SchedEnv, TaskBuilder as TB, WorkerBuilder as WB
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from hyperqueue_amd.tick import Tick
+
+    return Tick(abi.make_config(time_limit_s=20.0))
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle.oracle import Oracle
+
+    return Oracle(abi.make_config(time_limit_s=20.0), canonical=True)
+
+
+def assert_same(got: abi.Result, want: abi.Result):
+    assert got.status == want.status
+    assert got.batches == want.batches
+    assert got.counts == want.counts
+    assert got.records == want.records
+    assert got.retracts == want.retracts
+    assert sorted(got.redirects) == sorted(want.redirects)
+    assert got.mn == want.mn
+    assert (got.new_free == want.new_free).all()
+
+
+def random_env(seed: int) -> SchedEnv:
+    rng = np.random.default_rng(seed)
+    env = SchedEnv(abi.make_config(reserve=int(rng.integers(0, 6)), fill_max=int(rng.integers(1, 12)), time_limit_s=20.0))
+    names = ["gpus", "mem"][: int(rng.integers(0, 3))]
+    for n in names:
+        env.new_named_resource(n)
+    n_classes = int(rng.integers(1, 5))
+    builders = []
+    for _ in range(n_classes):
+        b = TB().cpus(int(rng.integers(1, 5)))
+        for ri, _n in enumerate(names):
+            if rng.random() < 0.5:
+                b = b.add_resource(ri + 1, [0.25, 0.5, 1, 2][int(rng.integers(0, 4))])
+        if rng.random() < 0.25:
+            b = b.next_variant().cpus(int(rng.integers(1, 7)))
+        builders.append(b)
+    same_prio = rng.random() < 0.5
+    for _ in range(int(rng.integers(1, 120))):
+        b = builders[int(rng.integers(0, n_classes))]
+        env.new_task(b if same_prio else b.user_priority(int(rng.integers(-2, 3))))
+    for _ in range(int(rng.integers(1, 7))):
+        wb = WB(int(rng.integers(2, 17)))
+        for n in names:
+            if rng.random() < 0.7:
+                wb = wb.res_sum(n, int(rng.integers(1, 9)))
+        env.new_worker(wb)
+    return env
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_snapshot(seed, gpu, oracle):
+    env = random_env(seed)
+    snap = env.snapshot()
+    cfg = env.config
+    from hyperqueue_amd.tick import Tick
+    from oracle.oracle import Oracle
+
+    g, o = Tick(cfg), Oracle(cfg, canonical=True)
+    assert_same(g.tick(snap), o.tick(snap))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_multi_tick(seed):
+    """schedule -> finish a few tasks -> new worker / new tasks -> schedule ...: exercises prefill sets, retracts, redirects."""
+    from hyperqueue_amd.tick import Tick
+    from oracle.oracle import Oracle
+
+    rng = np.random.default_rng(1000 + seed)
+    envs = []
+    for _ in range(2):
+        e = SchedEnv(abi.make_config(reserve=2, fill_max=5, time_limit_s=20.0))
+        envs.append(e)
+    g, o = Tick(envs[0].config), Oracle(envs[1].config, canonical=True)
+    script = []
+    n_classes = int(rng.integers(1, 3))
+    for _ in range(5):
+        script.append(("workers", [int(rng.integers(1, 7)) for _ in range(int(rng.integers(1, 3)))]))
+        script.append(("tasks", [(int(rng.integers(0, n_classes)) + 1) for _ in range(int(rng.integers(5, 40)))]))
+        script.append(("tick", None))
+        script.append(("finish", int(rng.integers(0, 4))))
+    for (op, arg) in script:
+        results = []
+        for e, be in ((envs[0], g), (envs[1], o)):
+            if op == "workers":
+                for c in arg:
+                    e.new_worker(WB(c))
+            elif op == "tasks":
+                for c in arg:
+                    e.new_task(TB().cpus(c))
+            elif op == "tick":
+                results.append(e.schedule(be))
+            elif op == "finish":
+                done = 0
+                for t in sorted(e.tasks.values(), key=lambda t: t.id):
+                    if done >= arg:
+                        break
+                    if t.state == 1:  # ASSIGNED
+                        e.finish_task(t.id, t.worker)
+                        done += 1
+        if op == "tick":
+            assert_same(results[0], results[1])
+
+
+def test_c2_exact(gpu, oracle):
+    snap = workloads.make("c2")
+    got, want = gpu.tick(snap), oracle.tick(snap)
+    assert_same(got, want)
+    # hand-derived expectation: one batch 32768/32768 limit reached, 128 per worker, 40 prefills per worker
+    assert [(b.size, b.limit, b.limit_reached) for b in got.batches] == [(32768, 32768, True)]
+    assert all(len(got.assigned(w)) == 128 and len(got.prefills(w)) == 40 for w in range(256))
+
+
+def test_c3_reduced_exact(gpu, oracle):
+    snap = workloads.make("c3", n_tasks=60_000, n_workers=48)
+    assert_same(gpu.tick(snap), oracle.tick(snap))
+
+
+def test_c4_reduced_exact(gpu, oracle):
+    snap = workloads.make("c4", n_tasks=40_000, n_workers=24)
+    assert_same(gpu.tick(snap), oracle.tick(snap))
+
+
+def test_c3_full_properties(gpu):
+    """Full BASELINE size: size-independent properties + equal MILP objective with plain HiGHS on the oracle's model."""
+    from oracle.oracle import Oracle
+
+    snap = workloads.make("c3")
+    got = gpu.tick(snap)
+    W, R = len(snap.worker_id), snap.n_resources
+    ids = snap.task_id
+    rq_of = dict(zip(ids.tolist(), snap.task_rq.tolist()))
+    seen = set()
+    used = np.zeros((W, R), np.int64)
+    per_rq = {}
+    for w in range(W):
+        for (t, v, k) in got.records[w]:
+            assert t in rq_of and t not in seen  # every record is a distinct ready task
+            seen.add(t)
+            q = rq_of[t]
+            per_rq.setdefault(q, []).append(t)
+            if k == abi.HQ_REC_ASSIGN:
+                for (r, kind, a) in snap.requests[q][v]["entries"]:
+                    used[w, r] += a
+    assert (used <= snap.worker_free.astype(np.int64)).all()  # no worker is oversubscribed
+    assert (snap.worker_free.astype(np.int64) - used == got.new_free.astype(np.int64)).all()
+    for q, ts in per_rq.items():  # take_tasks: the lowest ids of every queue (one priority level in c3), no holes
+        mine = np.sort(np.asarray(ts, np.uint64))
+        allq = ids[snap.task_rq == q]
+        assert (mine == allq[: len(mine)]).all()
+    cd = got.counts_dict()
+    for w in range(W):  # records agree with the counts
+        c = {}
+        for (t, v, k) in got.records[w]:
+            if k == abi.HQ_REC_ASSIGN:
+                c[(rq_of[t], v)] = c.get((rq_of[t], v), 0) + 1
+        assert c == {(q, v): n for (q, v, ww), n in cd.items() if ww == w}
+    # objective equality with HiGHS (tier T2): evaluate our counts in the oracle's model
+    o = Oracle(abi.make_config(time_limit_s=60.0))
+    o.tick(snap)
+    m = o.last_model()
+    x = np.zeros(len(m["obj"]))
+    for j in range(len(x)):
+        if m["ctype"][j] == 0:
+            x[j] = cd.get((int(m["crq"][j]), int(m["cvariant"][j]), int(m["cworker"][j])), 0)
+    mine_obj = float(np.dot(m["obj"], x))
+    assert abs(mine_obj - m["objective"]) <= 1e-6 * abs(m["objective"]), (mine_obj, m["objective"])
+    for i in range(len(m["rhs"])):  # and every row of the reference's model holds
+        a, b = m["roff"][i], m["roff"][i + 1]
+        act = float(np.dot(m["rcoef"][a:b], x[m["rcol"][a:b]]))
+        if m["rtype"][i] == 1:
+            assert act <= m["rhs"][i] + 1e-6

@@ -37,3 +37,25 @@ def test_golden(case, backend):
     if case.__name__ == "test_many_cuts":
         pytest.skip("tolerance test, run in test_oracle_slow")
     case(backend)
+
+
+class CanonicalOracleBackend(OracleBackend):
+    """The oracle with the MI355X path's tie-break applied: must still satisfy every reference expectation."""
+
+    def _o(self, cfg):
+        key = (cfg.proactive_filling_reserve, cfg.proactive_filling_max)
+        if key not in self._ctx:
+            self._ctx[key] = Oracle(cfg, canonical=True)
+        return self._ctx[key]
+
+
+@pytest.mark.parametrize("case", golden_cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_golden_canonical(case):
+    if case.__name__ == "test_many_cuts":
+        pytest.skip("tolerance test; canonicalisation of a 600-column model is slow")
+    case(CanonicalOracleBackend())
+
+
+@pytest.mark.slow
+def test_many_cuts_oracle():
+    golden_cases.test_many_cuts(OracleBackend())
