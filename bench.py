@@ -98,13 +98,14 @@ def main():
     for _ in range(args.warmup):
         tick.tick_raw(sc, resident=True)
     barrier()
-    lat, kstats = [], []
+    lat, kstats, stages = [], [], []
     t_begin = time.perf_counter()
     for _ in range(args.steps):
         t0 = time.perf_counter()
         res = tick.tick_raw(sc, resident=True)  # returns after the assignment vector is back in host memory
         lat.append(time.perf_counter() - t0)
         kstats.append(tick.kernel_stats())
+        stages.append((res.t_scan_us, res.t_batches_us, res.t_solve_us, res.t_mapping_us, res.t_total_us))
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t_begin
@@ -145,6 +146,7 @@ def main():
         "tick_algorithmic_bytes": int(ks["algorithmic_bytes"]),
         "tick_bytes_per_s_end_to_end_GBps": ks["algorithmic_bytes"] / float(np.median(lat)) / 1e9,
         "kernels_us": {k: round(v, 2) for k, v in k_us.items()},
+        "tick_stages_us": dict(zip(["scan_gpu_phase", "batches", "solve", "mapping_plan_gpu_d2h", "total_in_library"], [round(float(x), 1) for x in np.median(np.asarray(stages), axis=0)])),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                      "algorithmic_bytes_per_launch": k_bytes[dom], "avg_launch_us": k_us[dom], "traffic": None},
     }

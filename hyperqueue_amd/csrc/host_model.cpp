@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <string>
+#include <unordered_map>
 
 #include "hb_order.h"
 
@@ -215,6 +217,125 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     std::vector<double> pool(R, 0.0);  // resource_sums  :56,68-82
     for (uint32_t w : solver_workers) for (uint32_t r = 0; r < R; r++) { uint64_t c = ws.free_[(size_t)w * R + r]; pool[r] += c == HQ_AMOUNT_MAX ? 1.0 : units(c); }
 
+    auto is_blocked = [&](uint32_t w, uint32_t rq, uint8_t v) {
+        if (pb.custom) return false;
+        for (auto &b : ws.blocked[w]) if (b.first == rq && b.second == v) return true;
+        return false;
+    };
+
+    // ---- separable instances: no multi-node batch, no priority cut, every batch saturated -------------------------
+    // Then the model of solver.rs:95-192 has no row that spans two workers: it is one independent block per worker, and
+    // workers with the same (free, total, eligibility, min_utilization) have the same block up to the positive factor
+    // (W - idx)/W of the objective.  Solve one block per such worker class instead of building W of them.
+    bool separable = true;
+    for (const TaskBatch &b : batches) if (pb.rq_multi_node(b.rq) || !b.cuts.empty() || !b.limit_reached || b.is_blocker) separable = false;
+    if (separable && !batches.empty()) {
+        struct ColRef { uint32_t batch; uint8_t variant; };
+        std::vector<std::vector<ColRef>> class_cols;
+        std::vector<std::vector<uint32_t>> class_x;
+        std::unordered_map<std::string, uint32_t> class_of_sig;
+        std::vector<uint32_t> wclass(ws.n, 0);
+        std::string sig;
+        for (uint32_t w : solver_workers) {
+            const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
+            sig.clear();
+            sig.append(reinterpret_cast<const char *>(tot), (size_t)R * 8);
+            sig.append(reinterpret_cast<const char *>(fre), (size_t)R * 8);
+            float mu = ws.min_util ? ws.min_util[w] : 0.0f;
+            sig.append(reinterpret_cast<const char *>(&mu), 4);
+            for (const TaskBatch &batch : batches) {
+                const RequestView &rv = pb.rqs[batch.rq];
+                for (uint8_t v = 0; v < rv.n_variants; v++) {
+                    uint8_t f = ws.vf(w, rv.first_variant + v);
+                    char ok = (!is_blocked(w, batch.rq, v) && (f & 4) && (f & 1)) ? 1 : 0;
+                    sig.push_back(ok);
+                }
+            }
+            auto it = class_of_sig.find(sig);
+            if (it != class_of_sig.end()) { wclass[w] = it->second; continue; }
+            uint32_t cid = (uint32_t)class_cols.size();
+            class_of_sig.emplace(sig, cid);
+            wclass[w] = cid;
+            // the worker's block, columns and rows in the order of solver.rs:95-192
+            hqmilp::Model m;
+            std::vector<ColRef> cols;
+            std::vector<std::vector<std::pair<int, double>>> rt(R);
+            std::vector<std::pair<int, double>> cpu;
+            for (uint32_t bi = 0; bi < batches.size(); bi++) {
+                const RequestView &rv = pb.rqs[batches[bi].rq];
+                for (uint8_t v = 0; v < rv.n_variants; v++) {
+                    uint32_t slot = rv.first_variant + v;
+                    const VariantView &vv = pb.variants[slot];
+                    uint8_t f = ws.vf(w, slot);
+                    if (is_blocked(w, batches[bi].rq, v) || !(f & 4) || !(f & 1)) continue;
+                    double sc = 0.0;
+                    for (uint32_t e = 0; e < vv.n_entries; e++) {
+                        double g = pool[vv.res[e]];
+                        sc += g < 0.000001 ? 0.0 : units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]) / g;
+                    }
+                    int col = m.add_col(sc * ((double)vv.weight / FRACTIONS), hqmilp::COL_NAT);
+                    cols.push_back({bi, v});
+                    for (uint32_t e = 0; e < vv.n_entries; e++) {
+                        double a = units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]);
+                        rt[vv.res[e]].push_back({col, a});
+                        if (vv.res[e] == 0) cpu.push_back({col, a});
+                    }
+                }
+            }
+            if (mu > 0.001f && tot[0] != HQ_AMOUNT_MAX) {
+                double all_cpus = units(tot[0]), need = all_cpus * ((double)mu - 1.0) + units(fre[0]);
+                if (!(need < 0.0001)) {
+                    int col = m.add_col(0.0, hqmilp::COL_BOOL);
+                    cols.push_back({UINT32_MAX, 0});
+                    cpu.push_back({col, -need}); m.begin_row(hqmilp::ROW_MIN, 0.0); for (auto &t : cpu) m.term(t.first, t.second); m.end_row(); cpu.pop_back();
+                    cpu.push_back({col, -all_cpus}); m.begin_row(hqmilp::ROW_MAX, 0.0); for (auto &t : cpu) m.term(t.first, t.second); m.end_row(); cpu.pop_back();
+                }
+            }
+            bool unbounded_carry = false;
+            for (uint32_t r = 0; r < R; r++) {
+                if (fre[r] == HQ_AMOUNT_MAX) { if (!rt[r].empty()) unbounded_carry = true; continue; }
+                if (!rt[r].empty()) { m.begin_row(hqmilp::ROW_MAX, units(fre[r])); for (auto &t : rt[r]) m.term(t.first, t.second); m.end_row(); }
+            }
+            if (unbounded_carry) { separable = false; break; }  // MAX-amount rows leak into the next worker in the reference (solver.rs:183-185): general path
+            hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true);
+            out.milp_nodes += sol.nodes; out.milp_cols += m.ncols(); out.milp_rows += m.nrows(); out.milp_components += sol.n_components;
+            if (!sol.feasible) { out.keys.clear(); out.per_key.clear(); return out; }  // `None` => empty solution  solver.rs:433-437
+            if (!sol.optimal) out.is_optimal = false;
+            std::vector<uint32_t> xs(cols.size());
+            for (size_t c = 0; c < cols.size(); c++) xs[c] = (uint32_t)std::round(sol.x[c]);
+            class_cols.push_back(std::move(cols));
+            class_x.push_back(std::move(xs));
+        }
+        if (separable) {
+            // per class: count of every (batch, variant)
+            size_t nb = batches.size();
+            std::vector<std::vector<uint32_t>> cls_count(class_cols.size());
+            std::vector<uint32_t> voff(nb + 1, 0);
+            for (size_t b = 0; b < nb; b++) voff[b + 1] = voff[b] + pb.rqs[batches[b].rq].n_variants;
+            for (size_t c = 0; c < class_cols.size(); c++) {
+                cls_count[c].assign(voff[nb], 0);
+                for (size_t k = 0; k < class_cols[c].size(); k++) if (class_cols[c][k].batch != UINT32_MAX) cls_count[c][voff[class_cols[c][k].batch] + class_cols[c][k].variant] = class_x[c][k];
+            }
+            std::vector<uint64_t> key_hash; std::vector<std::pair<uint32_t, uint8_t>> key_list; std::vector<std::vector<std::pair<uint32_t, uint32_t>>> key_counts;
+            std::vector<uint32_t> ids, widx, cnt, ord;
+            for (size_t b = 0; b < nb; b++) {
+                for (uint8_t v = 0; v < pb.rqs[batches[b].rq].n_variants; v++) {
+                    ids.clear(); widx.clear(); cnt.clear();
+                    for (uint32_t w : solver_workers) { uint32_t c = cls_count[wclass[w]][voff[b] + v]; if (c) { ids.push_back(ws.id[w]); widx.push_back(w); cnt.push_back(c); } }
+                    if (ids.empty()) continue;
+                    hqhb::insertion_order_u32(ids.data(), (uint32_t)ids.size(), ord);
+                    std::vector<std::pair<uint32_t, uint32_t>> ordered; ordered.reserve(ord.size());
+                    for (uint32_t k : ord) ordered.push_back({widx[k], cnt[k]});
+                    key_hash.push_back(hqhb::hash_rq_variant(batches[b].rq, v)); key_list.push_back({batches[b].rq, v}); key_counts.push_back(std::move(ordered));
+                }
+            }
+            hqhb::insertion_order(key_hash.data(), (uint32_t)key_hash.size(), ord);
+            for (uint32_t k : ord) { out.keys.push_back(key_list[k]); out.per_key.push_back(std::move(key_counts[k])); }
+            return out;
+        }
+        out = Counts();  // fall through to the general path
+    }
+
     hqmilp::Model m;
     std::map<std::tuple<uint32_t, uint32_t, uint8_t>, int> place;  // (worker, rq, variant) -> column   :88
     std::map<uint32_t, std::vector<int>> count_cols;               // tasks_count_vars   :89
@@ -234,11 +355,6 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     };
     auto group_can_run_rq = [&](uint32_t g, uint32_t rq) {
         for (uint32_t v = 0; v < pb.rqs[rq].n_variants; v++) if (group_can_run(g, pb.variants[pb.rqs[rq].first_variant + v], pb.rqs[rq].first_variant + v)) return true;
-        return false;
-    };
-    auto is_blocked = [&](uint32_t w, uint32_t rq, uint8_t v) {
-        if (pb.custom) return false;
-        for (auto &b : ws.blocked[w]) if (b.first == rq && b.second == v) return true;
         return false;
     };
 

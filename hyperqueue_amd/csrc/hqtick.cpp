@@ -42,6 +42,19 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct PinBuf {  // page-locked host staging: async copies really are async and skip the runtime's bounce buffer
+    void *p = nullptr; size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) hipHostFree(p);
+        size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; return false; }
+        cap = want; return true;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 }  // namespace
 
 struct hqtick_ctx {
@@ -54,8 +67,10 @@ struct hqtick_ctx {
     DevBuf d_tid, d_tprio, d_trq; uint64_t n_ready = 0; bool resident = false;
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist;
+    bool levels_valid = false; uint32_t cached_L = 0;  // level table of the previous tick (re-validated by K1 every tick)
+    PinBuf h_up, h_a, h_plan, h_rec;
     // workers / requests
-    DevBuf d_total, d_free, d_rem, d_req, d_vflags, d_vtmc;
+    DevBuf d_up, d_vflags, d_vtmc;
     // selection + mapping
     DevBuf d_take_base, d_sel_task, d_sel_level, d_map, d_rec_task, d_rec_var, d_rec_kind;
     // results (host)
@@ -103,52 +118,49 @@ int validate(hqtick_ctx *ctx, const hqtick_snapshot *s, bool need_tasks) {
     return 0;
 }
 
-// Uploads the request tables into one device buffer and returns the K2 view.
-int upload_requests(hqtick_ctx *ctx, const hqtick_snapshot *s, hqk::RequestTable *rt) {
+struct WorkerEval { const uint8_t *flags = nullptr; const uint32_t *tmc = nullptr; std::vector<uint8_t> flags_own; std::vector<uint32_t> tmc_own; };
+
+// Packs worker tables + request tables into ONE pinned staging buffer and ONE H2D copy; returns the device views.
+struct UpView { const uint64_t *total, *free_; const int64_t *rem; hqk::RequestTable rt; };
+int upload_tables(hqtick_ctx *ctx, const hqtick_snapshot *s, uint32_t W, const uint64_t *total, const uint64_t *free_, const int64_t *rem, UpView *uv) {
+    const uint32_t R = s->n_resources;
     uint32_t nv = s->n_requests ? s->rq_variant_off[s->n_requests] : 0;
     uint32_t ne = nv ? s->variant_entry_off[nv] : 0;
-    size_t o_off = 0, o_res = o_off + (size_t)(nv + 1) * 4, o_amt = (o_res + (size_t)ne * 4 + 7) & ~(size_t)7, o_time = o_amt + (size_t)ne * 8,
-           o_kind = o_time + (size_t)nv * 8, total = o_kind + ne + 16;
-    std::vector<unsigned char> h(total, 0);
+    size_t o_tot = 0, o_free = o_tot + (size_t)W * R * 8, o_rem = o_free + (size_t)W * R * 8, o_amt = o_rem + (size_t)W * 8, o_time = o_amt + (size_t)ne * 8,
+           o_off = o_time + (size_t)nv * 8, o_res = o_off + (size_t)(nv + 1) * 4, o_kind = o_res + (size_t)ne * 4, bytes = o_kind + ne + 64;
+    if (!ctx->h_up.ensure(bytes) || !ctx->d_up.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "allocating upload staging");
+    unsigned char *h = ctx->h_up.as<unsigned char>();
+    if (W && R) { memcpy(h + o_tot, total, (size_t)W * R * 8); memcpy(h + o_free, free_, (size_t)W * R * 8); }
+    int64_t *hr = reinterpret_cast<int64_t *>(h + o_rem);
+    for (uint32_t w = 0; w < W; w++) hr[w] = rem ? rem[w] : HQ_NO_TIME_LIMIT;
     if (nv) {
-        memcpy(h.data() + o_off, s->variant_entry_off, (size_t)(nv + 1) * 4);
-        memcpy(h.data() + o_res, s->entry_resource, (size_t)ne * 4);
-        memcpy(h.data() + o_amt, s->entry_amount, (size_t)ne * 8);
-        memcpy(h.data() + o_time, s->variant_min_time_ns, (size_t)nv * 8);
-        memcpy(h.data() + o_kind, s->entry_kind, ne);
+        memcpy(h + o_amt, s->entry_amount, (size_t)ne * 8);
+        if (s->variant_min_time_ns) memcpy(h + o_time, s->variant_min_time_ns, (size_t)nv * 8); else memset(h + o_time, 0, (size_t)nv * 8);
+        memcpy(h + o_off, s->variant_entry_off, (size_t)(nv + 1) * 4);
+        memcpy(h + o_res, s->entry_resource, (size_t)ne * 4);
+        memcpy(h + o_kind, s->entry_kind, ne);
     }
-    if (!ctx->d_req.ensure(total)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc request tables");
-    HQ_HIP(hipMemcpyAsync(ctx->d_req.p, h.data(), total, hipMemcpyHostToDevice, ctx->stream));
-    HQ_HIP(hipStreamSynchronize(ctx->stream));  // h is a stack-scoped staging buffer
-    unsigned char *d = ctx->d_req.as<unsigned char>();
-    rt->variant_entry_off = (const uint32_t *)(d + o_off); rt->entry_resource = (const uint32_t *)(d + o_res);
-    rt->entry_amount = (const uint64_t *)(d + o_amt); rt->variant_min_time_ns = (const uint64_t *)(d + o_time);
-    rt->entry_kind = (const uint8_t *)(d + o_kind); rt->n_variants = nv;
+    HQ_HIP(hipMemcpyAsync(ctx->d_up.p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    unsigned char *d = ctx->d_up.as<unsigned char>();
+    uv->total = (const uint64_t *)(d + o_tot); uv->free_ = (const uint64_t *)(d + o_free); uv->rem = (const int64_t *)(d + o_rem);
+    uv->rt.entry_amount = (const uint64_t *)(d + o_amt); uv->rt.variant_min_time_ns = (const uint64_t *)(d + o_time);
+    uv->rt.variant_entry_off = (const uint32_t *)(d + o_off); uv->rt.entry_resource = (const uint32_t *)(d + o_res);
+    uv->rt.entry_kind = (const uint8_t *)(d + o_kind); uv->rt.n_variants = nv;
     return 0;
 }
 
-struct WorkerEval { std::vector<uint8_t> flags; std::vector<uint32_t> tmc; };
-
-// K2 on a worker set (real or fake); results copied back.
-int eval_workers(hqtick_ctx *ctx, uint32_t W, uint32_t R, const uint64_t *total, const uint64_t *free_, const int64_t *rem,
-                 const hqk::RequestTable &rt, WorkerEval *out) {
-    size_t n = (size_t)W * rt.n_variants;
-    out->flags.assign(n, 0); out->tmc.assign(n, 0);
+// K2 on a worker set, synchronous (used for the fake workers of hqtick_query)
+int eval_workers_sync(hqtick_ctx *ctx, const hqtick_snapshot *s, uint32_t W, const uint64_t *total, const uint64_t *free_, const int64_t *rem, WorkerEval *out) {
+    UpView uv; int rc;
+    if ((rc = upload_tables(ctx, s, W, total, free_, rem, &uv))) return rc;
+    size_t n = (size_t)W * uv.rt.n_variants;
+    out->flags_own.assign(n, 0); out->tmc_own.assign(n, 0);
+    out->flags = out->flags_own.data(); out->tmc = out->tmc_own.data();
     if (n == 0) return 0;
-    std::vector<int64_t> rem_h(W, HQ_NO_TIME_LIMIT);
-    if (rem) memcpy(rem_h.data(), rem, (size_t)W * 8);
-    if (!ctx->d_total.ensure((size_t)W * R * 8 + 8) || !ctx->d_free.ensure((size_t)W * R * 8 + 8) || !ctx->d_rem.ensure((size_t)W * 8) ||
-        !ctx->d_vflags.ensure(n) || !ctx->d_vtmc.ensure(n * 4))
-        return fail(ctx, HQTICK_E_DEVICE, "hipMalloc worker tables");
-    if (R) {
-        HQ_HIP(hipMemcpyAsync(ctx->d_total.p, total, (size_t)W * R * 8, hipMemcpyHostToDevice, ctx->stream));
-        HQ_HIP(hipMemcpyAsync(ctx->d_free.p, free_, (size_t)W * R * 8, hipMemcpyHostToDevice, ctx->stream));
-    }
-    HQ_HIP(hipMemcpyAsync(ctx->d_rem.p, rem_h.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
-    HQ_HIP(hqk::worker_eval(ctx->d_total.as<uint64_t>(), ctx->d_free.as<uint64_t>(), ctx->d_rem.as<int64_t>(), W, R, rt, ctx->d_vflags.as<uint8_t>(),
-                     ctx->d_vtmc.as<uint32_t>(), ctx->stream));
-        HQ_HIP(hipMemcpyAsync(out->flags.data(), ctx->d_vflags.p, n, hipMemcpyDeviceToHost, ctx->stream));
-    HQ_HIP(hipMemcpyAsync(out->tmc.data(), ctx->d_vtmc.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->d_vflags.ensure(n) || !ctx->d_vtmc.ensure(n * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc worker flags");
+    HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, s->n_resources, uv.rt, ctx->d_vflags.as<uint8_t>(), ctx->d_vtmc.as<uint32_t>(), ctx->stream));
+    HQ_HIP(hipMemcpyAsync(out->flags_own.data(), ctx->d_vflags.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HQ_HIP(hipMemcpyAsync(out->tmc_own.data(), ctx->d_vtmc.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HQ_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -167,7 +179,7 @@ void fill_problem(hqhost::Problem &pb, const hqtick_snapshot *s, const hqtick_co
     hqhost::WorkerSet &ws = pb.real;
     ws.n = s->n_workers; ws.R = s->n_resources; ws.id = s->worker_id; ws.total = s->worker_total; ws.free_ = s->worker_free;
     ws.remaining_ns = s->worker_remaining_ns; ws.min_util = s->worker_min_utilization; ws.flags = s->worker_flags; ws.group = s->worker_group;
-    ws.vflags = ev.flags.data(); ws.vtmc = ev.tmc.data(); ws.n_variant_slots = nv;
+    ws.vflags = ev.flags; ws.vtmc = ev.tmc; ws.n_variant_slots = nv;
     ws.blocked.assign(ws.n, {}); ws.assigned.assign(ws.n, {});
     for (uint32_t k = 0; k < s->n_blocked; k++) ws.blocked[s->blocked_worker[k]].push_back({s->blocked_rq[k], s->blocked_variant[k]});
     if (s->assigned_off) for (uint32_t w = 0; w < ws.n; w++) for (uint32_t k = s->assigned_off[w]; k < s->assigned_off[w + 1]; k++) ws.assigned[w].push_back({s->assigned_rq[k], s->assigned_variant[k]});
@@ -197,50 +209,88 @@ struct Scan {  // result of GPU phase A
     hqk::WaveGeom geom{};
 };
 
-// GPU phase A on the ready set currently in ctx->d_t*.
-int scan_ready(hqtick_ctx *ctx, uint32_t Q, Scan *sc) {
+// GPU phase A: K2 on the real workers, level table (cached across ticks, re-validated by K1), K1 + K1b on the ready set in
+// ctx->d_t*.  One stream synchronisation in the steady state.
+int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc) {
+    const uint32_t W = s->n_workers, R = s->n_resources, Q = s->n_requests;
+    const uint64_t N = ctx->n_ready;
     sc->Q = Q; sc->L = 0; sc->G = 0; sc->levels.clear(); sc->hist.clear();
-    uint64_t N = ctx->n_ready;
-    if (N == 0 || Q == 0) return 0;
-    if (!ctx->d_set.ensure((size_t)hqk::PRIO_SET_CAP * 8) || !ctx->d_flags.ensure(64) || !ctx->d_levels.ensure((size_t)(hqk::MAX_LEVELS + 2) * 8) || !ctx->d_nlevels.ensure(16))
-        return fail(ctx, HQTICK_E_DEVICE, "hipMalloc level tables");
-    HQ_HIP(hipMemsetAsync(ctx->d_set.p, 0xFF, (size_t)hqk::PRIO_SET_CAP * 8, ctx->stream));
-    HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
-    HQ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    HQ_HIP(hqk::distinct_priorities(ctx->d_tprio.as<uint64_t>(), N, ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream));
-    HQ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-    HQ_HIP(hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->stream));
-        uint32_t L = 0, flags[4] = {0, 0, 0, 0};
-    HQ_HIP(hipMemcpyAsync(&L, ctx->d_nlevels.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HQ_HIP(hipStreamSynchronize(ctx->stream));
-    if (flags[1] || L == 0xFFFFFFFFu || L > hqk::MAX_LEVELS) return fail(ctx, HQTICK_E_CAPACITY, "more than 4096 distinct priority levels in the ready set");
-    if (L == 0) return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level");
-    uint64_t G64 = (uint64_t)L * Q;
-    if (G64 > hqk::MAX_GROUPS) return fail(ctx, HQTICK_E_CAPACITY, "levels x requests exceeds 16384 groups");
-    uint32_t G = (uint32_t)G64;
-    sc->L = L; sc->G = G;
-    sc->levels.resize(L);
-    HQ_HIP(hipMemcpyAsync(sc->levels.data(), ctx->d_levels.p, (size_t)L * 8, hipMemcpyDeviceToHost, ctx->stream));
-    hqk::WaveGeom &g = sc->geom;
-    g.waves_per_block = G <= hqk::MAX_GROUPS_4W ? 4 : 1;
-    uint64_t tpw = 1024;
-    while (((N + tpw - 1) / tpw) * G > (1ull << 24)) tpw *= 2;  // keep the per-slice table under 64 MiB
-    g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw);
-    if (!ctx->d_wave_tab.ensure((size_t)g.n_waves * G * 4) || !ctx->d_hist.ensure((size_t)G * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
-    HQ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
-                    ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
-    HQ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
-    HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g.n_waves, G, ctx->d_hist.as<uint32_t>(), ctx->stream));
-        sc->hist.resize(G);
-    HQ_HIP(hipMemcpyAsync(sc->hist.data(), ctx->d_hist.p, (size_t)G * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HQ_HIP(hipStreamSynchronize(ctx->stream));
-    if (flags[2]) return fail(ctx, HQTICK_E_INVALID, "ready set holds a request id >= n_requests (or an unknown priority)");
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->stats.distinct_us = ms * 1000.0;
-    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->stats.level_hist_us = ms * 1000.0;
+    UpView uv; int rc;
+    if ((rc = upload_tables(ctx, s, W, s->worker_total, s->worker_free, s->worker_remaining_ns, &uv))) return rc;
+    const size_t nwv = (size_t)W * uv.rt.n_variants;
+    if (!ctx->d_vflags.ensure(nwv + 8) || !ctx->d_vtmc.ensure(nwv * 4 + 8) || !ctx->d_set.ensure((size_t)hqk::PRIO_SET_CAP * 8) || !ctx->d_flags.ensure(64) ||
+        !ctx->d_levels.ensure((size_t)(hqk::MAX_LEVELS + 2) * 8) || !ctx->d_nlevels.ensure(16))
+        return fail(ctx, HQTICK_E_DEVICE, "hipMalloc phase A");
+    HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, ctx->d_vflags.as<uint8_t>(), ctx->d_vtmc.as<uint32_t>(), ctx->stream));
+    const bool scan = N != 0 && Q != 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        uint32_t L = 0;
+        if (scan) {
+            if (!ctx->levels_valid) {
+                HQ_HIP(hipMemsetAsync(ctx->d_set.p, 0xFF, (size_t)hqk::PRIO_SET_CAP * 8, ctx->stream));
+                HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
+                HQ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+                HQ_HIP(hqk::distinct_priorities(ctx->d_tprio.as<uint64_t>(), N, ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream));
+                HQ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+                HQ_HIP(hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->stream));
+                uint32_t flags[4] = {0, 0, 0, 0};
+                HQ_HIP(hipMemcpyAsync(&L, ctx->d_nlevels.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+                HQ_HIP(hipStreamSynchronize(ctx->stream));
+                if (flags[1] || L == 0xFFFFFFFFu || L > hqk::MAX_LEVELS) return fail(ctx, HQTICK_E_CAPACITY, "more than 4096 distinct priority levels in the ready set");
+                if (L == 0) return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level");
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->stats.distinct_us = ms * 1000.0;
+                ctx->levels_valid = true; ctx->cached_L = L;
+            }
+            L = ctx->cached_L;
+            uint64_t G64 = (uint64_t)L * Q;
+            if (G64 > hqk::MAX_GROUPS) return fail(ctx, HQTICK_E_CAPACITY, "levels x requests exceeds 16384 groups");
+            sc->L = L; sc->G = (uint32_t)G64;
+            hqk::WaveGeom &g = sc->geom;
+            g.waves_per_block = sc->G <= hqk::MAX_GROUPS_4W ? 4 : 1;
+            uint64_t tpw = 256;
+            while (((N + tpw - 1) / tpw) * sc->G > (1ull << 24)) tpw *= 2;  // keep the per-slice table under 64 MiB
+            g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw);
+            if (!ctx->d_wave_tab.ensure((size_t)g.n_waves * sc->G * 4) || !ctx->d_hist.ensure((size_t)sc->G * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
+            HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
+            HQ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+            HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
+                                   ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
+            HQ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+            HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g.n_waves, sc->G, ctx->d_hist.as<uint32_t>(), ctx->stream));
+        }
+        // one download: [flags 16][levels L*8][hist G*4][vtmc nwv*4][vflags nwv]
+        size_t o_lv = 16, o_hist = o_lv + (size_t)sc->L * 8, o_tmc = o_hist + (size_t)sc->G * 4, o_fl = o_tmc + nwv * 4, bytes = o_fl + nwv + 16;
+        if (!ctx->h_a.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc phase A");
+        unsigned char *h = ctx->h_a.as<unsigned char>();
+        memset(h, 0, 16);
+        if (scan) {
+            HQ_HIP(hipMemcpyAsync(h, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(h + o_lv, ctx->d_levels.p, (size_t)sc->L * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(h + o_hist, ctx->d_hist.p, (size_t)sc->G * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (nwv) {
+            HQ_HIP(hipMemcpyAsync(h + o_tmc, ctx->d_vtmc.p, nwv * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(h + o_fl, ctx->d_vflags.p, nwv, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        const uint32_t *flags = reinterpret_cast<const uint32_t *>(h);
+        if (scan && (flags[2] & 2u)) return fail(ctx, HQTICK_E_INVALID, "ready set holds a request id >= n_requests");
+        if (scan && (flags[2] & 1u)) {  // a priority the cached level table does not know: rebuild the table once
+            ctx->levels_valid = false;
+            if (attempt == 0) continue;
+            return fail(ctx, HQTICK_E_DEVICE, "level table inconsistent with the ready set");
+        }
+        ev->flags = h + o_fl; ev->tmc = reinterpret_cast<const uint32_t *>(h + o_tmc);
+        if (scan) {
+            sc->levels.assign(reinterpret_cast<const uint64_t *>(h + o_lv), reinterpret_cast<const uint64_t *>(h + o_lv) + sc->L);
+            sc->hist.assign(reinterpret_cast<const uint32_t *>(h + o_hist), reinterpret_cast<const uint32_t *>(h + o_hist) + sc->G);
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->stats.level_hist_us = ms * 1000.0;
+        }
+        return 0;
+    }
     return 0;
 }
 
@@ -275,17 +325,14 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
             HQ_HIP(hipMemcpyAsync(ctx->d_tprio.p, s->task_priority, N * 8, hipMemcpyHostToDevice, ctx->stream));
             HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, s->task_rq, N * 4, hipMemcpyHostToDevice, ctx->stream));
         }
-        ctx->n_ready = N; ctx->resident = false;
+        ctx->n_ready = N; ctx->resident = false; ctx->levels_valid = false;
     } else if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "hqtick_run_resident without hqtick_upload_ready");
     const uint64_t N = ctx->n_ready;
 
     // ---------------- GPU phase A ----------------
-    hqk::RequestTable rt{};
-    if ((rc = upload_requests(ctx, s, &rt))) return rc;
     WorkerEval ev;
-    if ((rc = eval_workers(ctx, W, R, s->worker_total, s->worker_free, s->worker_remaining_ns, rt, &ev))) return rc;
     Scan sc;
-    if ((rc = scan_ready(ctx, Q, &sc))) return rc;
+    if ((rc = phase_a(ctx, s, &ev, &sc))) return rc;
     double t1 = now_us();
 
     // ---------------- host: batches + placement ----------------
@@ -337,10 +384,12 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     std::vector<uint32_t> key_ord_off(nkeys + 1, 0), ord_cnt, key_t_off(nkeys + 1, 0), t_sweep;
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> wk(W);  // worker -> (key, pos)
     std::vector<uint32_t> items(W, 0);
+    uint32_t max_count = 0;
     for (uint32_t k = 0; k < nkeys; k++) {
         uint32_t maxc = 0, pos = 0;
         for (auto &wc : cnt.per_key[k]) { ord_cnt.push_back(wc.second); maxc = std::max(maxc, wc.second); wk[wc.first].push_back({k, pos++}); items[wc.first] += wc.second; }
         key_ord_off[k + 1] = (uint32_t)ord_cnt.size();
+        max_count = std::max(max_count, maxc);
         std::vector<uint32_t> ge(maxc + 2, 0);
         for (auto &wc : cnt.per_key[k]) ge[wc.second]++;  // ge[c] = #workers with count == c
         uint32_t more = (uint32_t)cnt.per_key[k].size(), acc = 0;
@@ -459,22 +508,19 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         max_items = std::max(max_items, items[w]);
     }
     const uint32_t n_rec = out_off[W];
-    if ((size_t)max_items * 18 + 16 > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
+    if ((size_t)max_items * 18 + 16 + ((size_t)max_count + 4) * 4 > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
     double t4 = now_us();
 
     // ---------------- GPU phase C ----------------
-    ctx->rec_task.assign(n_rec, 0); ctx->rec_variant.assign(n_rec, 0); ctx->rec_kind.assign(n_rec, 0);
-    std::vector<uint64_t> mn_ids;
+    size_t n_mn_ids = 0; for (auto &sets : cnt.mn_sets) n_mn_ids += sets.size();
+    size_t o_rv = (size_t)n_rec * 8, o_rk = o_rv + n_rec, o_mn = (o_rk + n_rec + 7) & ~(size_t)7, rec_bytes = o_mn + n_mn_ids * 8 + 64;
+    if (!ctx->h_rec.ensure(rec_bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc records");
+    uint64_t *h_rec_task = ctx->h_rec.as<uint64_t>(); uint8_t *h_rec_var = ctx->h_rec.as<uint8_t>() + o_rv, *h_rec_kind = ctx->h_rec.as<uint8_t>() + o_rk;
+    uint64_t *mn_ids = reinterpret_cast<uint64_t *>(ctx->h_rec.as<uint8_t>() + o_mn);
     if (n_sel) {
-        if (!ctx->d_take_base.ensure(take_base.size() * 4) || !ctx->d_sel_task.ensure((size_t)n_sel * 8) || !ctx->d_sel_level.ensure((size_t)n_sel * 2 + 2))
+        if (!ctx->d_sel_task.ensure((size_t)n_sel * 8) || !ctx->d_sel_level.ensure((size_t)n_sel * 2 + 2))
             return fail(ctx, HQTICK_E_DEVICE, "hipMalloc selection");
-        HQ_HIP(hipMemcpyAsync(ctx->d_take_base.p, take_base.data(), take_base.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-        HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, sc.geom,
-                            ctx->d_wave_tab.as<uint32_t>(), ctx->d_take_base.as<uint32_t>(), ctx->d_take_base.as<uint32_t>() + sc.G,
-                            ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->stream));
-        HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
-                // pack every K5 table into one upload
+        // pack every K5 table into one upload
         std::vector<uint32_t> pack;
         auto put = [&](const std::vector<uint32_t> &v) { size_t o = pack.size(); pack.insert(pack.end(), v.begin(), v.end()); if (v.empty()) pack.push_back(0); return o; };
         std::vector<uint32_t> key_rq(nkeys), key_var_w((nkeys + 3) / 4 + 1, 0);
@@ -482,10 +528,17 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         size_t o_rq = put(key_rq), o_var = put(key_var_w), o_seg = put(key_seg), o_ordoff = put(key_ord_off), o_ord = put(ord_cnt), o_toff = put(key_t_off),
                o_t = put(t_sweep), o_wkoff = put(wk_off), o_wkkey = put(wk_key), o_wkpos = put(wk_pos), o_base = put(rq_sel_base), o_pfs = put(pf_start),
                o_pfn = put(pf_n), o_pfloff = put(pfl_off), o_pflsrc = put(pfl_src), o_pflcnt = put(pfl_cnt), o_out = put(out_off);
-        if (!ctx->d_map.ensure(pack.size() * 4) || !ctx->d_rec_task.ensure((size_t)n_rec * 8 + 8) || !ctx->d_rec_var.ensure(n_rec + 8) || !ctx->d_rec_kind.ensure(n_rec + 8))
+        size_t o_tb = put(take_base);
+        if (!ctx->d_map.ensure(pack.size() * 4) || !ctx->h_plan.ensure(pack.size() * 4) || !ctx->d_rec_task.ensure((size_t)n_rec * 8 + 8) || !ctx->d_rec_var.ensure(n_rec + 8) ||
+            !ctx->d_rec_kind.ensure(n_rec + 8))
             return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
-        HQ_HIP(hipMemcpyAsync(ctx->d_map.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        memcpy(ctx->h_plan.p, pack.data(), pack.size() * 4);
+        HQ_HIP(hipMemcpyAsync(ctx->d_map.p, ctx->h_plan.p, pack.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         const uint32_t *d = ctx->d_map.as<uint32_t>();
+        HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+        HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, sc.geom,
+                            ctx->d_wave_tab.as<uint32_t>(), d + o_tb, d + o_tb + sc.G, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->stream));
+        HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
         hqk::MapKeys mk{};
         mk.n_keys = nkeys; mk.key_rq = d + o_rq; mk.key_variant = reinterpret_cast<const uint8_t *>(d + o_var); mk.key_seg_start = d + o_seg;
         mk.key_ord_off = d + o_ordoff; mk.ord_cnt = d + o_ord; mk.key_t_off = d + o_toff; mk.t_sweep = d + o_t; mk.wk_off = d + o_wkoff; mk.wk_key = d + o_wkkey;
@@ -493,25 +546,21 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         mk.pfl_cnt = d + o_pflcnt; mk.out_off = d + o_out;
         HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
         HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->d_levels.as<uint64_t>(), max_items,
+        HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->d_levels.as<uint64_t>(), max_items, max_count,
                             ctx->d_rec_task.as<uint64_t>(), ctx->d_rec_var.as<uint8_t>(), ctx->d_rec_kind.as<uint8_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream));
         HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
                 uint32_t flags[4] = {0, 0, 0, 0};
         if (n_rec) {
-            HQ_HIP(hipMemcpyAsync(ctx->rec_task.data(), ctx->d_rec_task.p, (size_t)n_rec * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(ctx->rec_variant.data(), ctx->d_rec_var.p, n_rec, hipMemcpyDeviceToHost, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(ctx->rec_kind.data(), ctx->d_rec_kind.p, n_rec, hipMemcpyDeviceToHost, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(h_rec_task, ctx->d_rec_task.p, (size_t)n_rec * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(h_rec_var, ctx->d_rec_var.p, n_rec, hipMemcpyDeviceToHost, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(h_rec_kind, ctx->d_rec_kind.p, n_rec, hipMemcpyDeviceToHost, ctx->stream));
         }
         // multi-node tasks: the heads of their queues
-        for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
-            size_t old = mn_ids.size(); size_t n = cnt.mn_sets[i].size();
-            mn_ids.resize(old + n);
-        }
         {
             size_t pos = 0;
             for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
                 size_t n = cnt.mn_sets[i].size();
-                HQ_HIP(hipMemcpyAsync(mn_ids.data() + pos, ctx->d_sel_task.as<uint64_t>() + rq_sel_base[cnt.mn_rq[i]] + mn_first[i], n * 8, hipMemcpyDeviceToHost, ctx->stream));
+                HQ_HIP(hipMemcpyAsync(mn_ids + pos, ctx->d_sel_task.as<uint64_t>() + rq_sel_base[cnt.mn_rq[i]] + mn_first[i], n * 8, hipMemcpyDeviceToHost, ctx->stream));
                 pos += n;
             }
         }
@@ -547,7 +596,7 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     out->status = status;
     out->n_counts = (uint32_t)ctx->cnt_rq.size(); out->count_rq = ctx->cnt_rq.data(); out->count_variant = ctx->cnt_variant.data();
     out->count_worker = ctx->cnt_worker.data(); out->count_value = ctx->cnt_value.data();
-    out->rec_off = ctx->rec_off.data(); out->rec_task = ctx->rec_task.data(); out->rec_variant = ctx->rec_variant.data(); out->rec_kind = ctx->rec_kind.data();
+    out->rec_off = ctx->rec_off.data(); out->rec_task = h_rec_task; out->rec_variant = h_rec_var; out->rec_kind = h_rec_kind;
     out->retract_off = ctx->retract_off.data(); out->retract_task = ctx->retract_task.data();
     out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data();
     out->n_mn = (uint32_t)ctx->mn_task.size(); out->mn_task = ctx->mn_task.data(); out->mn_worker_off = ctx->mn_off.data(); out->mn_worker = ctx->mn_worker.data();
@@ -593,9 +642,10 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
-                      &ctx->d_total, &ctx->d_free, &ctx->d_rem, &ctx->d_req, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_take_base, &ctx->d_sel_task,
+                      &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_take_base, &ctx->d_sel_task,
                       &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec_task, &ctx->d_rec_var, &ctx->d_rec_kind};
     for (DevBuf *b : bufs) b->release();
+    ctx->h_up.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -621,7 +671,7 @@ int hqtick_upload_ready(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, co
         HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, task_rq, n * 4, hipMemcpyHostToDevice, ctx->stream));
         HQ_HIP(hipStreamSynchronize(ctx->stream));
     }
-    ctx->n_ready = n; ctx->resident = true;
+    ctx->n_ready = n; ctx->resident = true; ctx->levels_valid = false;
     return 0;
 }
 
@@ -643,19 +693,17 @@ int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_w
         HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, s->task_rq, N * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     ctx->n_ready = N; ctx->resident = false;
-    hqk::RequestTable rt{};
-    if ((rc = upload_requests(ctx, s, &rt))) return rc;
+    ctx->levels_valid = false;
     WorkerEval ev_real, ev_fake;
-    if ((rc = eval_workers(ctx, s->n_workers, R, s->worker_total, s->worker_free, s->worker_remaining_ns, rt, &ev_real))) return rc;
-    if ((rc = eval_workers(ctx, fake->n_workers, R, fake->worker_total, fake->worker_total, fake->worker_remaining_ns, rt, &ev_fake))) return rc;  // fresh fake workers: free == total
+    if ((rc = eval_workers_sync(ctx, s, fake->n_workers, fake->worker_total, fake->worker_total, fake->worker_remaining_ns, &ev_fake))) return rc;  // fresh fake workers: free == total
     Scan sc;
-    if ((rc = scan_ready(ctx, Q, &sc))) return rc;
+    if ((rc = phase_a(ctx, s, &ev_real, &sc))) return rc;
     hqhost::Problem pb;
     fill_problem(pb, s, ctx->cfg, ev_real);
     hqhost::WorkerSet fw;
     fw.n = fake->n_workers; fw.R = R; fw.id = fake->worker_id; fw.total = fake->worker_total; fw.free_ = fake->worker_total;
     fw.remaining_ns = fake->worker_remaining_ns; fw.min_util = fake->worker_min_utilization; fw.flags = nullptr; fw.group = nullptr;
-    fw.vflags = ev_fake.flags.data(); fw.vtmc = ev_fake.tmc.data(); fw.n_variant_slots = rt.n_variants;
+    fw.vflags = ev_fake.flags; fw.vtmc = ev_fake.tmc; fw.n_variant_slots = Q ? s->rq_variant_off[Q] : 0;
     fw.blocked.assign(fw.n, {}); fw.assigned.assign(fw.n, {});
     pb.custom = &fw;
     std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);

@@ -79,7 +79,7 @@ struct MapKeys {
     const uint32_t *out_off;       // [W+1]
 };
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, const uint64_t *levels,
-                    uint32_t max_items, uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag,
+                    uint32_t max_items, uint32_t max_count, uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag,
                     hipStream_t s);
 
 }  // namespace hqk

@@ -46,41 +46,49 @@ __device__ __forceinline__ uint32_t level_of(const uint64_t *lv, uint32_t L, uin
 // ------------------------------------------------------------------------------------------------ K0
 __global__ void __launch_bounds__(256) k_distinct_priorities(const uint64_t *__restrict__ prio, uint64_t n,
                                                              uint64_t *__restrict__ set, uint32_t *__restrict__ flags) {
-    __shared__ uint64_t cache[256];  // block-local "already published" filter
+    __shared__ unsigned long long cache[256];  // block-local claim table: one wave per block publishes a given value
     for (int i = threadIdx.x; i < 256; i += blockDim.x) cache[i] = PRIO_EMPTY;
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t rounds = (n + stride - 1) / stride;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint64_t r = 0; r < rounds; r++, i += stride) {
-        bool active = i < n;
-        uint64_t p = active ? prio[i] : 0;
-        if (active && p == PRIO_EMPTY) { atomicOr(&flags[0], 1u); active = false; }
-        if (active && cache[mix64(p) & 255u] == p) active = false;
-        // one lane per distinct value of the wave publishes it
-        uint64_t todo = __ballot(active);
-        while (todo) {
-            int first = __ffsll((long long)todo) - 1;
-            uint64_t lead = __shfl(p, first, 64);
-            bool same = active && p == lead;
-            if ((int)lane_id() == first) {
-                uint64_t h = mix64(lead);
-                uint32_t slot = (uint32_t)h & (PRIO_SET_CAP - 1);
-                bool done = false;
-                for (uint32_t probe = 0; probe < PRIO_SET_CAP; probe++) {
-                    uint64_t cur = set[slot];
-                    if (cur == lead) { done = true; break; }
-                    if (cur == PRIO_EMPTY) {
-                        uint64_t old = atomicCAS((unsigned long long *)&set[slot], (unsigned long long)PRIO_EMPTY, (unsigned long long)lead);
-                        if (old == PRIO_EMPTY || old == lead) { done = true; break; }
+    const uint64_t rounds = (n + 4 * stride - 1) / (4 * stride);
+    uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t r = 0; r < rounds; r++, i0 += 4 * stride) {
+        uint64_t pv[4];
+        bool av[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { uint64_t i = i0 + u * stride; av[u] = i < n; pv[u] = av[u] ? prio[i] : 0; }  // 4 independent loads in flight
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            bool active = av[u];
+            uint64_t p = pv[u];
+            if (active && p == PRIO_EMPTY) { atomicOr(&flags[0], 1u); active = false; }
+            if (active && cache[mix64(p) & 255u] == p) active = false;
+            uint64_t todo = __ballot(active);
+            while (todo) {  // one lane per distinct value of the wave
+                int first = __ffsll((long long)todo) - 1;
+                uint64_t lead = __shfl((unsigned long long)p, first, 64);
+                bool same = active && p == lead;
+                if ((int)lane_id() == first) {
+                    uint64_t h = mix64(lead);
+                    unsigned long long claimed = atomicCAS(&cache[h & 255u], (unsigned long long)PRIO_EMPTY, (unsigned long long)lead);
+                    if (claimed != lead) {  // first wave of this block to see the value (or a cache collision): publish globally
+                        uint32_t slot = (uint32_t)h & (PRIO_SET_CAP - 1);
+                        bool done = false;
+                        for (uint32_t probe = 0; probe < PRIO_SET_CAP; probe++) {
+                            uint64_t cur = set[slot];
+                            if (cur == lead) { done = true; break; }
+                            if (cur == PRIO_EMPTY) {
+                                uint64_t old = atomicCAS((unsigned long long *)&set[slot], (unsigned long long)PRIO_EMPTY, (unsigned long long)lead);
+                                if (old == PRIO_EMPTY || old == lead) { done = true; break; }
+                            }
+                            slot = (slot + 1) & (PRIO_SET_CAP - 1);
+                        }
+                        if (!done) atomicExch(&flags[1], 1u);
                     }
-                    slot = (slot + 1) & (PRIO_SET_CAP - 1);
                 }
-                if (!done) atomicExch(&flags[1], 1u);
-                cache[h & 255u] = lead;
+                todo &= ~__ballot(same);
+                active = active && !same;
             }
-            todo &= ~__ballot(same);
-            active = active && !same;
         }
     }
 }
@@ -162,7 +170,8 @@ __global__ void __launch_bounds__(WPB * 64) k_group_pass(const uint64_t *__restr
         uint32_t g = 0;
         if (active) {
             uint32_t lv = level_of(lvp, L, p);
-            if (lv >= L || lvp[lv] != p || q >= Q) { if (!SELECT) atomicExch(err_flag, 1u); active = false; }
+            if (lv >= L || lvp[lv] != p) { if (!SELECT) atomicOr(err_flag, 1u); active = false; }        // priority missing from the level table
+            else if (q >= Q) { if (!SELECT) atomicOr(err_flag, 2u); active = false; }                   // request id out of range
             else g = lv * Q + q;
         }
         uint64_t peers = match_any(g, nbits, active);
@@ -244,14 +253,13 @@ __global__ void __launch_bounds__(256) k_worker_eval(const uint64_t *__restrict_
 // ------------------------------------------------------------------------------------------------ K5
 __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, const uint64_t *__restrict__ sel_task,
                                                         const uint16_t *__restrict__ sel_level, const uint64_t *__restrict__ levels,
-                                                        uint32_t max_items, uint64_t *__restrict__ rec_task,
+                                                        uint32_t max_items, uint32_t max_count, uint64_t *__restrict__ rec_task,
                                                         uint8_t *__restrict__ rec_variant, uint8_t *__restrict__ rec_kind,
                                                         uint32_t *__restrict__ err_flag) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *e_task = reinterpret_cast<uint64_t *>(smem);
     uint64_t *e_prio = e_task + max_items;
     uint16_t *e_meta = reinterpret_cast<uint16_t *>(e_prio + max_items);  // variant | valid << 8
-    __shared__ uint32_t s_pref[65];  // element prefix of up to 64 keys at a time
     const uint32_t w = blockIdx.x;
     const uint32_t k0 = mk.wk_off[w], k1 = mk.wk_off[w + 1];
     const uint32_t out0 = mk.out_off[w];
@@ -267,43 +275,38 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, const uint64
         npf += cnt;
     }
     // gather the tasks of every (request, variant) key this worker takes part in, in key order then sweep order
+    uint32_t *h_cnt = reinterpret_cast<uint32_t *>(e_meta + max_items + (max_items & 1));  // [max_count + 2] histogram of the counts ahead of us
     uint32_t n = 0;
-    for (uint32_t kb = k0; kb < k1; kb += 64) {
-        uint32_t nk = k1 - kb < 64 ? k1 - kb : 64;
-        if (threadIdx.x == 0) {
-            uint32_t acc = n;
-            for (uint32_t j = 0; j < nk; j++) {
-                s_pref[j] = acc;
-                uint32_t key = mk.wk_key[kb + j];
-                acc += mk.ord_cnt[mk.key_ord_off[key] + mk.wk_pos[kb + j]];
-            }
-            s_pref[nk] = acc;
-        }
+    for (uint32_t kk = k0; kk < k1; kk++) {
+        const uint32_t key = mk.wk_key[kk], pos = mk.wk_pos[kk];
+        const uint32_t *cnts = mk.ord_cnt + mk.key_ord_off[key];
+        const uint32_t c = cnts[pos];
+        const uint32_t maxc = mk.key_t_off[key + 1] - mk.key_t_off[key] - 1;  // T has maxc + 1 entries
+        if (n + c > max_items || maxc > max_count) { if (threadIdx.x == 0) atomicExch(err_flag, 2u); return; }
+        for (uint32_t t = threadIdx.x; t <= maxc + 1; t += blockDim.x) h_cnt[t] = 0;
         __syncthreads();
-        uint32_t n_end = s_pref[nk];
-        if (n_end > max_items) { if (threadIdx.x == 0) atomicExch(err_flag, 2u); return; }
-        for (uint32_t e = n + threadIdx.x; e < n_end; e += blockDim.x) {
-            uint32_t j = 0;
-            while (s_pref[j + 1] <= e) j++;
-            uint32_t key = mk.wk_key[kb + j], pos = mk.wk_pos[kb + j], s = e - s_pref[j];
-            const uint32_t *cnts = mk.ord_cnt + mk.key_ord_off[key];
-            uint32_t rank = 0;  // workers before this one in the Map's iteration order that still hold a count in sweep s
-            for (uint32_t jj = 0; jj < pos; jj++) rank += cnts[jj] > s ? 1u : 0u;
+        for (uint32_t jj = threadIdx.x; jj < pos; jj += blockDim.x) atomicAdd(&h_cnt[cnts[jj]], 1u);  // workers ahead of us in the Map's iteration order
+        __syncthreads();
+        const uint32_t q = mk.key_rq[key];
+        const uint32_t pfs = mk.rq_pf_start[q], pfn = mk.rq_pf_n[q], seg = mk.key_seg_start[key], sbase = mk.rq_sel_base[q];
+        const uint8_t variant = mk.key_variant[key];
+        for (uint32_t s = threadIdx.x; s < c; s += blockDim.x) {
+            uint32_t rank = 0;  // workers before this one that still hold a count in sweep s: counts > s
+            for (uint32_t cc = s + 1; cc <= maxc; cc++) rank += h_cnt[cc];
             uint32_t k = mk.t_sweep[mk.key_t_off[key] + s] + rank;  // index of the task inside the key's take_tasks() vector
-            uint32_t p = mk.key_seg_start[key] + k;                  // position in the queue's logical sequence
-            uint32_t q = mk.key_rq[key];
-            uint32_t pfs = mk.rq_pf_start[q], pfn = mk.rq_pf_n[q];
+            uint32_t p = seg + k;                                    // position in the queue's logical sequence
+            uint32_t e = n + s;
             if (p >= pfs && p < pfs + pfn) {                         // an already-prefilled task: retract/redirect is host work
                 e_meta[e] = 0; e_task[e] = 0; e_prio[e] = 0;
             } else {
-                uint32_t src = mk.rq_sel_base[q] + (p >= pfs + pfn ? p - pfn : p);
+                uint32_t src = sbase + (p >= pfs + pfn ? p - pfn : p);
                 e_task[e] = sel_task[src];
                 e_prio[e] = levels[sel_level[src]];
-                e_meta[e] = (uint16_t)(mk.key_variant[key] | 0x100u);
+                e_meta[e] = (uint16_t)(variant | 0x100u);
             }
         }
         __syncthreads();
-        n = n_end;
+        n += c;
     }
     // stable sort by priority descending (mapping.rs:128-131) by rank counting
     for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
@@ -328,8 +331,8 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, const uint64
 // ================================================================================================ host wrappers
 hipError_t distinct_priorities(const uint64_t *prio, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    uint64_t blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 resident blocks: grid-stride the rest
+    uint64_t blocks = (n + 1023) / 1024;
+    if (blocks > 512) blocks = 512;  // two blocks per CU: every block publishes each distinct value once, so fewer blocks = fewer same-address atomics
     hipLaunchKernelGGL(k_distinct_priorities, dim3((unsigned)blocks), dim3(256), 0, s, prio, n, set, flags);
     return hipGetLastError();
 }
@@ -391,12 +394,12 @@ hipError_t select_scatter(const uint64_t *task_id, const uint64_t *prio, const u
 }
 
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, const uint64_t *levels,
-                    uint32_t max_items, uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, hipStream_t s) {
+                    uint32_t max_items, uint32_t max_count, uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, hipStream_t s) {
     if (W == 0) return hipSuccess;
-    size_t lds = (size_t)max_items * 18 + 16;
+    size_t lds = (size_t)max_items * 18 + 16 + ((size_t)max_count + 4) * 4;
     hipError_t e;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_mapping), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, sel_task, sel_level, levels, max_items, rec_task, rec_variant,
+    hipLaunchKernelGGL(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, sel_task, sel_level, levels, max_items, max_count, rec_task, rec_variant,
                        rec_kind, err_flag);
     return hipGetLastError();
 }
