@@ -1,0 +1,71 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol include/hqtick.h declares, its struct
+layouts match the ctypes mirror, and it fails loudly (no CPU fallback) when asked to run without a gfx950 device."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from hyperqueue_amd import abi, tick
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(header: str):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hqtick_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.mark.parametrize("header", ["hqtick.h", "hqtick_debug.h"])
+def test_every_declared_symbol_is_exported(header):
+    lib = tick.load()
+    names = _declared_functions(header)
+    assert len(names) >= 2
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/{header} but not exported by libhqtick.so"
+
+
+def test_versions():
+    lib = tick.load()
+    assert lib.hqtick_abi_version() == abi.HQTICK_ABI_VERSION
+    assert lib.hqtick_build_arch() == b"gfx950"
+
+
+def test_struct_layouts_match_header():
+    """Compile a tiny C program against include/hqtick.h printing sizeof/offsetof; compare with the ctypes mirror."""
+    pairs = {
+        "hqtick_config": abi.Config, "hqtick_snapshot": abi.SnapshotC, "hqtick_query_workers": abi.QueryWorkersC,
+        "hqtick_result": abi.ResultC, "hqtick_query_result": abi.QueryResultC, "hqtick_kernel_stats": abi.KernelStatsC,
+    }
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "hqtick.h"', "int main(void){"]
+    for cname, cls in pairs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines.append("return 0;}")
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "l.c"), os.path.join(d, "l")
+        open(src, "w").write("\n".join(lines))
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, src])
+        out = subprocess.check_output([exe]).decode().split("\n")
+    got = dict(l.split() for l in out if l)
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got[f"{cname}.{f}"]) == getattr(cls, f).offset, f"{cname}.{f}"
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the no-device path cannot be observed")
+    with pytest.raises(tick.HqTickError) as e:
+        tick.Tick(abi.make_config())
+    assert e.value.code == abi.HQTICK_E_NO_DEVICE
+    lib = tick.load()
+    assert lib.hqtick_create(None, None) == abi.HQTICK_E_INVALID
+    assert lib.hqtick_run(None, None, None) == abi.HQTICK_E_INVALID

@@ -1,0 +1,87 @@
+"""Host-side building blocks of libhqtick.so that do not need a GPU: the exact MILP solver (vs HiGHS through the
+oracle's solver entry) and the hashbrown iteration-order helper (vs the oracle's independent emulation)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hyperqueue_amd import abi, tick
+from oracle import oracle as orc
+
+
+def product_milp(obj, kind, rtype, rhs, roff, rcol, rcoef, canonical=True, time_limit=30.0):
+    lib = tick.load()
+    n, m = len(obj), len(rhs)
+    obj = np.ascontiguousarray(obj, np.float64); kind = np.ascontiguousarray(kind, np.uint8)
+    rtype = np.ascontiguousarray(rtype, np.uint8); rhs = np.ascontiguousarray(rhs, np.float64)
+    roff = np.ascontiguousarray(roff, np.int32); rcol = np.ascontiguousarray(rcol, np.int32); rcoef = np.ascontiguousarray(rcoef, np.float64)
+    x = np.zeros(max(n, 1)); z = C.c_double(); opt = C.c_int(); nodes = C.c_long()
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    ok = lib.hqtick_debug_milp_solve(
+        C.c_int(n), obj.ctypes.data_as(dp), kind.ctypes.data_as(abi.u8p), C.c_int(m), rtype.ctypes.data_as(abi.u8p), rhs.ctypes.data_as(dp),
+        roff.ctypes.data_as(ip), rcol.ctypes.data_as(ip), rcoef.ctypes.data_as(dp), C.c_double(time_limit), C.c_int(1 if canonical else 0),
+        x.ctypes.data_as(dp), C.byref(z), C.byref(opt), C.byref(nodes))
+    return (x[:n].copy(), z.value, bool(opt.value)) if ok else None
+
+
+def random_model(rng):
+    """Shaped like the tick's model: non-negative objective, packing rows, a few big-M rows with bool columns."""
+    n = int(rng.integers(2, 10)); m = int(rng.integers(1, 6))
+    obj = rng.integers(0, 6, n) / 4.0
+    kind = (rng.random(n) < 0.25).astype(np.uint8)
+    rtype, rhs, roff, rcol, rcoef = [], [], [0], [], []
+    for i in range(m):
+        cols = np.nonzero(rng.random(n) < 0.6)[0]
+        if len(cols) == 0:
+            cols = np.array([int(rng.integers(0, n))])
+        rtype.append(1); rhs.append(float(rng.integers(1, 12)))
+        rcol += cols.tolist(); rcoef += (rng.integers(1, 5, len(cols)) * 0.5).tolist(); roff.append(len(rcol))
+    # every nat column bounded by a row
+    rtype.append(1); rhs.append(float(rng.integers(3, 20))); rcol += list(range(n)); rcoef += [1.0] * n; roff.append(len(rcol))
+    if rng.random() < 0.5 and kind.any():  # a Min row through a bool ("blocker short" flag shape, solver.rs:243-250)
+        b = int(np.nonzero(kind)[0][0]); s = float(rng.integers(1, 4))
+        cols = [j for j in range(n) if j != b and not kind[j]][:3]
+        if cols:
+            rtype.append(0); rhs.append(s); rcol += cols + [b]; rcoef += [1.0] * len(cols) + [s]; roff.append(len(rcol))
+    return obj, kind, np.array(rtype, np.uint8), np.array(rhs), np.array(roff, np.int32), np.array(rcol, np.int32), np.array(rcoef)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_milp_matches_highs(seed):
+    rng = np.random.default_rng(seed)
+    mdl = random_model(rng)
+    want = orc.solve_milp(*mdl, time_limit=30.0, canonical=False)
+    got = product_milp(*mdl, canonical=False)
+    assert (want is None) == (got is None)
+    if want is None:
+        return
+    assert got[2] and want[2]
+    assert abs(got[1] - want[1]) <= 1e-7 * max(1.0, abs(want[1]))  # same optimum value
+    # and the canonical optimum is exactly the oracle's canonicalised HiGHS optimum
+    wantc = orc.solve_milp(*mdl, time_limit=30.0, canonical=True)
+    gotc = product_milp(*mdl, canonical=True)
+    assert np.array_equal(np.round(gotc[0]), np.round(wantc[0])), (gotc[0], wantc[0])
+    assert abs(gotc[1] - want[1]) <= 1e-7 * max(1.0, abs(want[1]))
+
+
+def test_milp_infeasible_is_none():
+    # x0 >= 3 and x0 <= 1
+    r = product_milp([1.0], [0], [0, 1], [3.0, 1.0], [0, 1, 2], [0, 0], [1.0, 1.0])
+    assert r is None
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 8, 15, 28, 29, 57, 200, 1024, 4096])
+def test_map_order_matches_oracle_emulation(n):
+    lib = tick.load()
+    rng = np.random.default_rng(n)
+    for keys in (np.arange(50, 50 + n, dtype=np.uint32), np.sort(rng.choice(1 << 20, n, replace=False)).astype(np.uint32)):
+        out = np.zeros(n, np.uint32)
+        lib.hqtick_debug_map_order_u32(keys.ctypes.data_as(abi.u32p), C.c_uint32(n), out.ctypes.data_as(abi.u32p))
+        assert sorted(out.tolist()) == list(range(n))
+        assert keys[out].tolist() == orc.hb_order_u32(keys)
+
+
+def test_map_order_reference_pins():
+    """workers {50, 51} iterate (50, 51) — pinned by test_schedule_no_priorities (test_scheduler_sn.rs:183-187)."""
+    assert orc.hb_order_u32([50, 51]) == [50, 51]
+    assert orc.hb_order_u32([50, 51, 52]) == [52, 50, 51]
