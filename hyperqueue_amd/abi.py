@@ -150,6 +150,7 @@ class KernelStatsC(C.Structure):
         ("select_us", C.c_double),
         ("distinct_us", C.c_double),
         ("other_us", C.c_double),
+        ("scan_us", C.c_double),
         ("tick_gpu_us", C.c_double),
         ("algorithmic_bytes", C.c_uint64),
         ("n_assigned", C.c_uint64),

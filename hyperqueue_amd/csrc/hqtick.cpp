@@ -11,6 +11,7 @@
 //   D2H   assignment records
 // There is no CPU implementation of the scans/mapping: without a HIP device every entry point fails.
 #include "../../include/hqtick.h"
+#include "../../include/hqtick_debug.h"
 
 #include <hip/hip_runtime.h>
 
@@ -57,28 +58,45 @@ struct PinBuf {  // page-locked host staging: async copies really are async and 
 
 }  // namespace
 
+namespace {
+// Reusable host scratch of the mapping plan (no per-tick allocation in the steady state).
+struct PlanScratch {
+    std::vector<uint32_t> q_total, pf_n, pf_start, seq_taken, pf_drained, zq_taken, new_pf_total, pfl_size, rq_sel_base;
+    std::vector<uint32_t> key_seg, key_sum, key_rq, key_var_w, key_ord_off, ord_cnt, key_t_off, key_bits_off, wpos;
+    std::vector<uint32_t> items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, pfl_j, out_off, take_base, mn_first, pack;
+    std::vector<uint8_t> now_mn;
+    std::vector<std::pair<uint32_t, uint64_t>> retract_pairs;  // (old worker, task)
+    // cached worker_map iteration order (emulated) for the last worker-id set
+    std::vector<uint32_t> cached_ids, cached_order;
+};
+
+}  // namespace
+
 struct hqtick_ctx {
     hqtick_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[12] = {};
     std::string err = "";
     // ready set
     DevBuf d_tid, d_tprio, d_trq; uint64_t n_ready = 0; bool resident = false;
     // scans
-    DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist;
+    DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0;  // level table of the previous tick (re-validated by K1 every tick)
     PinBuf h_up, h_a, h_plan, h_rec;
     // workers / requests
     DevBuf d_up, d_vflags, d_vtmc;
     // selection + mapping
-    DevBuf d_take_base, d_sel_task, d_sel_level, d_map, d_rec_task, d_rec_var, d_rec_kind;
+    DevBuf d_sel_task, d_sel_level, d_map, d_rec, d_tsweep, d_bits, d_pre;
+    hqhost::Problem pb;
+    PlanScratch plan;
     // results (host)
     std::vector<uint32_t> b_rq, b_size, b_limit, b_cut_off, c_size, c_bl_off, bl_rq, bl_size; std::vector<uint8_t> b_lr, b_blk;
     std::vector<uint32_t> cnt_rq, cnt_worker, cnt_value; std::vector<uint8_t> cnt_variant;
     std::vector<uint32_t> rec_off, retract_off, red_worker, mn_off, mn_worker; std::vector<uint64_t> rec_task, retract_task, red_task, mn_task, new_free;
     std::vector<uint8_t> rec_variant, rec_kind, red_variant, q_loaded;
     hqtick_kernel_stats stats{};
+    double tl[32] = {}; int ntl = 0;  // debug timeline (us since tick start), hqtick_debug_timeline()
 };
 
 namespace {
@@ -251,14 +269,16 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc)
             g.waves_per_block = sc->G <= hqk::MAX_GROUPS_4W ? 4 : 1;
             uint64_t tpw = 256;
             while (((N + tpw - 1) / tpw) * sc->G > (1ull << 24)) tpw *= 2;  // keep the per-slice table under 64 MiB
-            g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw);
-            if (!ctx->d_wave_tab.ensure((size_t)g.n_waves * sc->G * 4) || !ctx->d_hist.ensure((size_t)sc->G * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
+            g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw); g.tab_stride = (g.n_waves + 15u) & ~15u;
+            if (!ctx->d_wave_tab.ensure((size_t)g.tab_stride * sc->G * 4) || !ctx->d_hist.ensure((size_t)sc->G * 4) || !ctx->d_gkey.ensure(N * 2 + 16))
+                return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
             HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
             HQ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
             HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
-                                   ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
+                                   ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
             HQ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
-            HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g.n_waves, sc->G, ctx->d_hist.as<uint32_t>(), ctx->stream));
+            HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, ctx->d_hist.as<uint32_t>(), ctx->stream));
+            HQ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
         }
         // one download: [flags 16][levels L*8][hist G*4][vtmc nwv*4][vflags nwv]
         size_t o_lv = 16, o_hist = o_lv + (size_t)sc->L * 8, o_tmc = o_hist + (size_t)sc->G * 4, o_fl = o_tmc + nwv * 4, bytes = o_fl + nwv + 16;
@@ -288,6 +308,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc)
             sc->hist.assign(reinterpret_cast<const uint32_t *>(h + o_hist), reinterpret_cast<const uint32_t *>(h + o_hist) + sc->G);
             float ms = 0;
             if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->stats.level_hist_us = ms * 1000.0;
+            if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[8]) == hipSuccess) ctx->stats.scan_us = ms * 1000.0;
         }
         return 0;
     }
@@ -311,6 +332,8 @@ std::vector<hqhost::QueueLevels> queue_levels(const Scan &sc, const hqtick_snaps
 
 int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool use_resident) {
     double t0 = now_us();
+    ctx->ntl = 0;
+    auto mark = [&]() { if (ctx->ntl < 32) ctx->tl[ctx->ntl++] = now_us() - t0; };
     memset(out, 0, sizeof(*out));
     ctx->stats = hqtick_kernel_stats{};
     int rc = validate(ctx, s, !use_resident);
@@ -333,237 +356,244 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     WorkerEval ev;
     Scan sc;
     if ((rc = phase_a(ctx, s, &ev, &sc))) return rc;
+    mark();  // 0: phase A done
     double t1 = now_us();
 
     // ---------------- host: batches + placement ----------------
-    hqhost::Problem pb;
+    hqhost::Problem &pb = ctx->pb;
     fill_problem(pb, s, ctx->cfg, ev);
     std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
     std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
     export_batches(ctx, batches, out);
+    mark();  // 1: batches
     double t2 = now_us();
     hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
+    mark();  // 2: solve
     double t3 = now_us();
     out->is_optimal = cnt.is_optimal;
     int status = HQTICK_DONE;  // scheduler/main.rs:57-68
     if (!cnt.is_optimal) status = cnt.empty() ? HQTICK_NO_PROGRESS : HQTICK_NEED_MORE_COMPUTE;
 
     // ---------------- host: mapping plan (create_task_mapping as index arithmetic, mapping.rs:36-157) ----------------
+    PlanScratch &ps = ctx->plan;
     const uint32_t L = sc.L;
+    const uint32_t NONE = 0xFFFFFFFFu;
     auto hist = [&](uint32_t l, uint32_t q) -> uint32_t { return sc.hist[(size_t)l * Q + q]; };
     // per request: logical take sequence = [first level][prefilled][rest] when the prefill priority equals the top
     // priority of the queue, else [prefilled][all levels]   (taskqueue.rs:320-355)
-    std::vector<uint32_t> q_total(Q, 0), pf_n(Q, 0), pf_start(Q, 0), seq_taken(Q, 0);
+    ps.q_total.assign(Q, 0); ps.pf_n.assign(Q, 0); ps.pf_start.assign(Q, 0); ps.seq_taken.assign(Q, 0);
     for (uint32_t q = 0; q < Q; q++) {
-        for (uint32_t l = 0; l < L; l++) q_total[q] += hist(l, q);
-        pf_n[q] = s->prefill_off ? s->prefill_off[q + 1] - s->prefill_off[q] : 0;
-        if (pf_n[q]) {
+        for (uint32_t l = 0; l < L; l++) ps.q_total[q] += hist(l, q);
+        ps.pf_n[q] = s->prefill_off ? s->prefill_off[q + 1] - s->prefill_off[q] : 0;
+        if (ps.pf_n[q]) {
             uint32_t first = L; for (uint32_t l = 0; l < L; l++) if (hist(l, q)) { first = l; break; }
-            pf_start[q] = (first < L && sc.levels[first] == s->prefill_priority[q]) ? hist(first, q) : 0;
+            ps.pf_start[q] = (first < L && sc.levels[first] == s->prefill_priority[q]) ? hist(first, q) : 0;
         }
     }
     const uint32_t nkeys = (uint32_t)cnt.keys.size();
-    std::vector<uint32_t> key_seg(nkeys), key_sum(nkeys);
+    ps.key_seg.assign(nkeys, 0); ps.key_sum.assign(nkeys, 0); ps.key_rq.assign(nkeys, 0); ps.key_var_w.assign((nkeys + 3) / 4 + 1, 0);
+    ps.key_ord_off.assign(nkeys + 1, 0); ps.ord_cnt.clear(); ps.key_t_off.assign(nkeys + 1, 0); ps.key_bits_off.assign(nkeys + 1, 0);
+    ps.wpos.assign((size_t)nkeys * W, NONE);
+    ps.items.assign(W, 0); ps.n_assign.assign(W, 0); ps.asg_qw.assign((size_t)Q * W, 0);
     ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
-    for (uint32_t k = 0; k < nkeys; k++) {
-        uint32_t q = cnt.keys[k].first, sum = 0;
-        for (auto &wc : cnt.per_key[k]) { sum += wc.second; ctx->cnt_rq.push_back(q); ctx->cnt_variant.push_back(cnt.keys[k].second); ctx->cnt_worker.push_back(wc.first); ctx->cnt_value.push_back(wc.second); }
-        key_seg[k] = seq_taken[q]; key_sum[k] = sum; seq_taken[q] += sum;
-        if (seq_taken[q] > q_total[q] + pf_n[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "solver placed more tasks than the queue holds (reference panics, taskqueue.rs:327)");
-    }
-    // multi-node placements take one task each from the head of their queue (mapping.rs:133-154)
-    std::vector<uint32_t> mn_first(cnt.mn_rq.size(), 0);
-    for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
-        uint32_t q = cnt.mn_rq[i];
-        mn_first[i] = seq_taken[q]; seq_taken[q] += (uint32_t)cnt.mn_sets[i].size();
-        if (pf_n[q]) return fail(ctx, HQTICK_E_UNSUPPORTED, "multi-node queue with a prefill set");
-        if (seq_taken[q] > q_total[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "multi-node placement exceeds its queue");
-    }
-    // sweep tables T_k(s) and per-worker key lists
-    std::vector<uint32_t> key_ord_off(nkeys + 1, 0), ord_cnt, key_t_off(nkeys + 1, 0), t_sweep;
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> wk(W);  // worker -> (key, pos)
-    std::vector<uint32_t> items(W, 0);
     uint32_t max_count = 0;
     for (uint32_t k = 0; k < nkeys; k++) {
-        uint32_t maxc = 0, pos = 0;
-        for (auto &wc : cnt.per_key[k]) { ord_cnt.push_back(wc.second); maxc = std::max(maxc, wc.second); wk[wc.first].push_back({k, pos++}); items[wc.first] += wc.second; }
-        key_ord_off[k + 1] = (uint32_t)ord_cnt.size();
+        const uint32_t q = cnt.keys[k].first; const uint8_t v = cnt.keys[k].second;
+        ps.key_rq[k] = q; reinterpret_cast<uint8_t *>(ps.key_var_w.data())[k] = v;
+        uint32_t sum = 0, maxc = 0, pos = 0;
+        uint32_t *wp = ps.wpos.data() + (size_t)k * W, *aq = ps.asg_qw.data() + (size_t)q * W;
+        for (auto &wc : cnt.per_key[k]) {
+            sum += wc.second; maxc = std::max(maxc, wc.second);
+            ctx->cnt_rq.push_back(q); ctx->cnt_variant.push_back(v); ctx->cnt_worker.push_back(wc.first); ctx->cnt_value.push_back(wc.second);
+            ps.ord_cnt.push_back(wc.second);
+            wp[wc.first] = pos++; ps.items[wc.first] += wc.second; ps.n_assign[wc.first] += wc.second; aq[wc.first] += wc.second;
+        }
+        ps.key_ord_off[k + 1] = (uint32_t)ps.ord_cnt.size();
+        ps.key_t_off[k + 1] = ps.key_t_off[k] + maxc + 1;  // sweeps 0..maxc
+        ps.key_bits_off[k + 1] = ps.key_bits_off[k] + (maxc + 1) * ((pos + 63) / 64);
         max_count = std::max(max_count, maxc);
-        std::vector<uint32_t> ge(maxc + 2, 0);
-        for (auto &wc : cnt.per_key[k]) ge[wc.second]++;  // ge[c] = #workers with count == c
-        uint32_t more = (uint32_t)cnt.per_key[k].size(), acc = 0;
-        for (uint32_t sw = 0; sw <= maxc; sw++) { t_sweep.push_back(acc); more -= ge[sw]; acc += more; }
-        key_t_off[k + 1] = (uint32_t)t_sweep.size();
+        ps.key_seg[k] = ps.seq_taken[q]; ps.key_sum[k] = sum; ps.seq_taken[q] += sum;
+        if (ps.seq_taken[q] > ps.q_total[q] + ps.pf_n[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "solver placed more tasks than the queue holds (reference panics, taskqueue.rs:327)");
     }
-    // worker that receives the task at index idx of key k (host mirror of the K5 arithmetic; used for prefilled tasks only)
-    auto worker_of = [&](uint32_t k, uint32_t idx) -> uint32_t {
-        const uint32_t *T = t_sweep.data() + key_t_off[k]; uint32_t ns = key_t_off[k + 1] - key_t_off[k];
-        uint32_t sw = (uint32_t)(std::upper_bound(T, T + ns, idx) - T) - 1, nth = idx - T[sw];
-        for (auto &wc : cnt.per_key[k]) if (wc.second > sw) { if (nth == 0) return wc.first; nth--; }
-        return HQ_NO_WORKER;
-    };
+    const uint32_t n_units = ps.key_t_off[nkeys], n_bit_words = ps.key_bits_off[nkeys];
+    // multi-node placements take one task each from the head of their queue (mapping.rs:133-154)
+    ps.mn_first.assign(cnt.mn_rq.size(), 0);
+    for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
+        uint32_t q = cnt.mn_rq[i];
+        ps.mn_first[i] = ps.seq_taken[q]; ps.seq_taken[q] += (uint32_t)cnt.mn_sets[i].size();
+        if (ps.pf_n[q]) return fail(ctx, HQTICK_E_UNSUPPORTED, "multi-node queue with a prefill set");
+        if (ps.seq_taken[q] > ps.q_total[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "multi-node placement exceeds its queue");
+    }
     // already-prefilled tasks that this tick hands out: Prefilled{old} -> retract + redirect  (mapping.rs:81-101)
-    std::vector<std::vector<uint64_t>> retracts(W);
+    ps.retract_pairs.clear();
     ctx->red_task.clear(); ctx->red_worker.clear(); ctx->red_variant.clear();
-    std::vector<uint32_t> pf_drained(Q, 0);
-    std::vector<std::vector<uint32_t>> pf_landed(W);  // rq of redirected tasks landing on the worker
-    std::vector<std::vector<uint32_t>> prefilled_rq(W);
-    if (s->prefilled_off) for (uint32_t w = 0; w < W; w++) prefilled_rq[w].assign(s->prefilled_rq + s->prefilled_off[w], s->prefilled_rq + s->prefilled_off[w + 1]);
+    ps.pf_drained.assign(Q, 0);
+    ps.has_pf.assign((size_t)Q * W, 0);  // SingleNodeTaskAssignment::prefilled_tasks as per-(rq, worker) counts
+    if (s->prefilled_off) for (uint32_t w = 0; w < W; w++) for (uint32_t i = s->prefilled_off[w]; i < s->prefilled_off[w + 1]; i++) if (s->prefilled_rq[i] < Q) ps.has_pf[(size_t)s->prefilled_rq[i] * W + w]++;
     for (uint32_t k = 0; k < nkeys; k++) {
-        uint32_t q = cnt.keys[k].first;
-        if (!pf_n[q]) continue;
-        uint32_t a = std::max(key_seg[k], pf_start[q]), b = std::min(key_seg[k] + key_sum[k], pf_start[q] + pf_n[q]);
+        const uint32_t q = cnt.keys[k].first;
+        if (!ps.pf_n[q]) continue;
+        uint32_t a = std::max(ps.key_seg[k], ps.pf_start[q]), b = std::min(ps.key_seg[k] + ps.key_sum[k], ps.pf_start[q] + ps.pf_n[q]);
+        if (a >= b) continue;
+        // host mirror of the K5 arithmetic for this key (prefilled tasks only): T(s) and the worker of index idx
+        const auto &pk = cnt.per_key[k];
+        uint32_t maxc = 0; for (auto &wc : pk) maxc = std::max(maxc, wc.second);
+        std::vector<uint32_t> ge(maxc + 2, 0), T; T.reserve(maxc + 1);
+        for (auto &wc : pk) ge[wc.second]++;
+        uint32_t more = (uint32_t)pk.size(), acc = 0;
+        for (uint32_t sw = 0; sw <= maxc; sw++) { T.push_back(acc); more -= ge[sw]; acc += more; }
+        auto worker_of = [&](uint32_t idx) -> uint32_t {
+            uint32_t sw = (uint32_t)(std::upper_bound(T.begin(), T.end(), idx) - T.begin()) - 1, nth = idx - T[sw];
+            for (auto &wc : pk) if (wc.second > sw) { if (nth == 0) return wc.first; nth--; }
+            return HQ_NO_WORKER;
+        };
         for (uint32_t p = a; p < b; p++) {
-            uint32_t slot = s->prefill_off[q] + (p - pf_start[q]);
+            uint32_t slot = s->prefill_off[q] + (p - ps.pf_start[q]);
             uint64_t task = s->prefill_task[slot]; uint32_t oldw = s->prefill_worker[slot];
-            uint32_t neww = worker_of(k, p - key_seg[k]);
-            retracts[oldw].push_back(task);
-            auto &pr = prefilled_rq[oldw]; auto it = std::find(pr.begin(), pr.end(), q); if (it != pr.end()) pr.erase(it);
+            uint32_t neww = worker_of(p - ps.key_seg[k]);
+            ps.retract_pairs.push_back({oldw, task});
+            if (oldw < W && ps.has_pf[(size_t)q * W + oldw]) ps.has_pf[(size_t)q * W + oldw]--;
             ctx->red_task.push_back(task); ctx->red_worker.push_back(neww); ctx->red_variant.push_back(cnt.keys[k].second);
-            pf_landed[neww].push_back(q);
-            pf_drained[q]++;
+            if (neww < W) { ps.asg_qw[(size_t)q * W + neww]--; ps.n_assign[neww]--; }  // a redirect is not a new `assigned` record
+            ps.pf_drained[q]++;
         }
     }
     // queue tasks taken per request (excluding the prefilled block)
-    std::vector<uint32_t> zq_taken(Q, 0);
-    for (uint32_t q = 0; q < Q; q++) zq_taken[q] = seq_taken[q] - pf_drained[q];
-    // assigned-this-tick bookkeeping per (worker, rq): records in mapping.workers[w].assigned
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> got(W);  // (rq, number of Waiting->Assigned tasks)
-    std::vector<uint32_t> n_assign(W, 0);
-    for (uint32_t k = 0; k < nkeys; k++) for (auto &wc : cnt.per_key[k]) {
-        uint32_t q = cnt.keys[k].first; bool f = false;
-        for (auto &g : got[wc.first]) if (g.first == q) { g.second += wc.second; f = true; }
-        if (!f) got[wc.first].push_back({q, wc.second});
-        n_assign[wc.first] += wc.second;
-    }
-    for (uint32_t w = 0; w < W; w++) for (uint32_t q : pf_landed[w]) { for (auto &g : got[w]) if (g.first == q) g.second--; n_assign[w]--; }
+    ps.zq_taken.assign(Q, 0);
+    for (uint32_t q = 0; q < Q; q++) ps.zq_taken[q] = ps.seq_taken[q] - ps.pf_drained[q];
     // workers that received a multi-node task are no longer SN (set_mn_task)
-    std::vector<char> now_mn(W, 0);
-    for (auto &sets : cnt.mn_sets) for (auto &set : sets) for (uint32_t w : set) now_mn[w] = 1;
+    ps.now_mn.assign(W, 0);
+    for (auto &sets : cnt.mn_sets) for (auto &set : sets) for (uint32_t w : set) ps.now_mn[w] = 1;
+    mark();  // 3: key tables + retracts
 
     // ---- process_proactive_filling  mapping.rs:159-234 ----
-    std::vector<uint32_t> wm_order(W);
-    if (s->worker_map_rank) { for (uint32_t w = 0; w < W; w++) wm_order[s->worker_map_rank[w]] = w; }
-    else { std::vector<uint32_t> ord; hqhb::insertion_order_u32(s->worker_id, W, ord); for (uint32_t i = 0; i < W; i++) wm_order[i] = ord[i]; }
-    std::vector<uint32_t> new_pf_total(Q, 0);
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pfl(W);  // worker -> (rq, chunk index) in queue order
-    std::vector<uint32_t> pfl_size(Q, 0);
+    if (s->worker_map_rank) { ps.wm_order.assign(W, 0); for (uint32_t w = 0; w < W; w++) ps.wm_order[s->worker_map_rank[w]] = w; }
+    else {
+        if (ps.cached_ids.size() != W || (W && memcmp(ps.cached_ids.data(), s->worker_id, (size_t)W * 4) != 0)) {
+            ps.cached_ids.assign(s->worker_id, s->worker_id + W);
+            hqhb::insertion_order_u32(s->worker_id, W, ps.cached_order);
+        }
+        ps.wm_order = ps.cached_order;
+    }
+    ps.new_pf_total.assign(Q, 0); ps.pfl_size.assign(Q, 0);
+    ps.pfq_src.clear(); ps.pfq_size.clear(); ps.pfl_j.clear();
+    std::vector<uint32_t> pfq_rq;
     {
         // state of every queue after the takes: first level that still has tasks
         std::vector<int> top_level(Q, -1); std::vector<uint32_t> top_left(Q, 0);
         uint64_t global_top = 0;
         for (uint32_t q = 0; q < Q; q++) {
-            uint32_t left = zq_taken[q];
+            uint32_t left = ps.zq_taken[q];
             for (uint32_t l = 0; l < L; l++) { uint32_t h = hist(l, q); if (h > left) { top_level[q] = (int)l; top_left[q] = h - left; break; } left -= h; }
             if (top_level[q] >= 0) global_top = std::max(global_top, sc.levels[top_level[q]]);  // TaskQueues::top_priority  taskqueue.rs:62-68
         }
         for (uint32_t q = 0; q < Q; q++) {
             if (top_level[q] < 0 || sc.levels[top_level[q]] != global_top) continue;
-            bool pf_left = pf_n[q] > pf_drained[q];
+            bool pf_left = ps.pf_n[q] > ps.pf_drained[q];
             uint32_t tsz = (pf_left && s->prefill_priority[q] != global_top) ? 0 : top_left[q];  // top_size_no_prefill  taskqueue.rs:241-253
             uint32_t size = tsz > ctx->cfg.proactive_filling_reserve ? tsz - ctx->cfg.proactive_filling_reserve : 0;
             if (!size) continue;
-            std::vector<uint32_t> elig;
-            for (uint32_t w : wm_order) {
-                bool sn = (s->worker_flags ? (s->worker_flags[w] & HQ_WORKER_SN) != 0 : true) && !now_mn[w];
-                if (!sn) continue;
-                bool has = false; for (auto &g : got[w]) if (g.first == q && g.second > 0) has = true;
-                if (!has) continue;
-                if (std::find(prefilled_rq[w].begin(), prefilled_rq[w].end(), q) != prefilled_rq[w].end()) continue;
-                elig.push_back(w);
+            ps.elig.clear();
+            const uint32_t *aq = ps.asg_qw.data() + (size_t)q * W, *hp = ps.has_pf.data() + (size_t)q * W;
+            for (uint32_t w : ps.wm_order) {
+                bool sn = (s->worker_flags ? (s->worker_flags[w] & HQ_WORKER_SN) != 0 : true) && !ps.now_mn[w];
+                if (sn && aq[w] > 0 && hp[w] == 0) ps.elig.push_back(w);
             }
-            if (elig.empty()) continue;
-            uint32_t psz = std::min(size / (uint32_t)elig.size(), ctx->cfg.proactive_filling_max);
+            if (ps.elig.empty()) continue;
+            uint32_t psz = std::min(size / (uint32_t)ps.elig.size(), ctx->cfg.proactive_filling_max);
             if (!psz) continue;
-            pfl_size[q] = psz;
-            for (uint32_t j = 0; j < elig.size(); j++) pfl[elig[j]].push_back({q, j});
-            new_pf_total[q] = psz * (uint32_t)elig.size();
+            ps.pfl_size[q] = psz;
+            pfq_rq.push_back(q);
+            size_t o = ps.pfl_j.size(); ps.pfl_j.resize(o + W, NONE);
+            for (uint32_t j = 0; j < ps.elig.size(); j++) ps.pfl_j[o + ps.elig[j]] = j;
+            ps.new_pf_total[q] = psz * (uint32_t)ps.elig.size();
         }
     }
+    mark();  // 4: prefill plan
     // ---- selection plan per (level, rq) group ----
-    std::vector<uint32_t> rq_sel_base(Q + 1, 0);
-    for (uint32_t q = 0; q < Q; q++) rq_sel_base[q + 1] = rq_sel_base[q] + zq_taken[q] + new_pf_total[q];
-    const uint32_t n_sel = rq_sel_base[Q];
-    std::vector<uint32_t> take_base((size_t)2 * sc.G, 0);
+    ps.rq_sel_base.assign(Q + 1, 0);
+    for (uint32_t q = 0; q < Q; q++) ps.rq_sel_base[q + 1] = ps.rq_sel_base[q] + ps.zq_taken[q] + ps.new_pf_total[q];
+    const uint32_t n_sel = ps.rq_sel_base[Q];
+    ps.take_base.assign((size_t)2 * sc.G, 0);
     for (uint32_t q = 0; q < Q; q++) {
-        uint32_t want = zq_taken[q] + new_pf_total[q], cum = 0;
+        uint32_t want = ps.zq_taken[q] + ps.new_pf_total[q], cum = 0;
         for (uint32_t l = 0; l < L; l++) {
             uint32_t h = hist(l, q), t = want > cum ? std::min(h, want - cum) : 0;
-            take_base[(size_t)l * Q + q] = t; take_base[(size_t)sc.G + (size_t)l * Q + q] = rq_sel_base[q] + cum;
+            ps.take_base[(size_t)l * Q + q] = t; ps.take_base[(size_t)sc.G + (size_t)l * Q + q] = ps.rq_sel_base[q] + cum;
             cum += h;
         }
     }
-    // ---- K5 tables ----
-    std::vector<uint32_t> out_off(W + 1, 0), wk_off(W + 1, 0), wk_key, wk_pos, pfl_off(W + 1, 0), pfl_src, pfl_cnt;
+    for (uint32_t q : pfq_rq) { ps.pfq_src.push_back(ps.rq_sel_base[q] + ps.zq_taken[q]); ps.pfq_size.push_back(ps.pfl_size[q]); }
+    const uint32_t n_pfq = (uint32_t)pfq_rq.size();
+    // ---- output offsets ----
+    ps.out_off.assign(W + 1, 0);
     uint32_t max_items = 0;
     for (uint32_t w = 0; w < W; w++) {
         uint32_t npf = 0;
-        std::sort(pfl[w].begin(), pfl[w].end());
-        for (auto &c : pfl[w]) { pfl_src.push_back(rq_sel_base[c.first] + zq_taken[c.first] + c.second * pfl_size[c.first]); pfl_cnt.push_back(pfl_size[c.first]); npf += pfl_size[c.first]; }
-        pfl_off[w + 1] = (uint32_t)pfl_src.size();
-        for (auto &kp : wk[w]) { wk_key.push_back(kp.first); wk_pos.push_back(kp.second); }
-        wk_off[w + 1] = (uint32_t)wk_key.size();
-        out_off[w + 1] = out_off[w] + npf + n_assign[w];
-        max_items = std::max(max_items, items[w]);
+        for (uint32_t pi = 0; pi < n_pfq; pi++) if (ps.pfl_j[(size_t)pi * W + w] != NONE) npf += ps.pfq_size[pi];
+        ps.out_off[w + 1] = ps.out_off[w] + npf + ps.n_assign[w];
+        max_items = std::max(max_items, ps.items[w]);
     }
-    const uint32_t n_rec = out_off[W];
-    if ((size_t)max_items * 18 + 16 + ((size_t)max_count + 4) * 4 > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
+    const uint32_t n_rec = ps.out_off[W];
+    if (hqk::expand_mapping_lds(max_items, nkeys) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
+    mark();  // 5: K5 tables
     double t4 = now_us();
 
     // ---------------- GPU phase C ----------------
     size_t n_mn_ids = 0; for (auto &sets : cnt.mn_sets) n_mn_ids += sets.size();
-    size_t o_rv = (size_t)n_rec * 8, o_rk = o_rv + n_rec, o_mn = (o_rk + n_rec + 7) & ~(size_t)7, rec_bytes = o_mn + n_mn_ids * 8 + 64;
+    size_t o_rv = (size_t)n_rec * 8, o_rk = o_rv + n_rec, o_mn = (o_rk + n_rec + 7) & ~(size_t)7, o_fl = o_mn + n_mn_ids * 8, rec_bytes = o_fl + 64;
     if (!ctx->h_rec.ensure(rec_bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc records");
     uint64_t *h_rec_task = ctx->h_rec.as<uint64_t>(); uint8_t *h_rec_var = ctx->h_rec.as<uint8_t>() + o_rv, *h_rec_kind = ctx->h_rec.as<uint8_t>() + o_rk;
     uint64_t *mn_ids = reinterpret_cast<uint64_t *>(ctx->h_rec.as<uint8_t>() + o_mn);
     if (n_sel) {
         if (!ctx->d_sel_task.ensure((size_t)n_sel * 8) || !ctx->d_sel_level.ensure((size_t)n_sel * 2 + 2))
             return fail(ctx, HQTICK_E_DEVICE, "hipMalloc selection");
-        // pack every K5 table into one upload
-        std::vector<uint32_t> pack;
+        // pack every plan table into one upload
+        std::vector<uint32_t> &pack = ps.pack; pack.clear();
         auto put = [&](const std::vector<uint32_t> &v) { size_t o = pack.size(); pack.insert(pack.end(), v.begin(), v.end()); if (v.empty()) pack.push_back(0); return o; };
-        std::vector<uint32_t> key_rq(nkeys), key_var_w((nkeys + 3) / 4 + 1, 0);
-        for (uint32_t k = 0; k < nkeys; k++) { key_rq[k] = cnt.keys[k].first; reinterpret_cast<uint8_t *>(key_var_w.data())[k] = cnt.keys[k].second; }
-        size_t o_rq = put(key_rq), o_var = put(key_var_w), o_seg = put(key_seg), o_ordoff = put(key_ord_off), o_ord = put(ord_cnt), o_toff = put(key_t_off),
-               o_t = put(t_sweep), o_wkoff = put(wk_off), o_wkkey = put(wk_key), o_wkpos = put(wk_pos), o_base = put(rq_sel_base), o_pfs = put(pf_start),
-               o_pfn = put(pf_n), o_pfloff = put(pfl_off), o_pflsrc = put(pfl_src), o_pflcnt = put(pfl_cnt), o_out = put(out_off);
-        size_t o_tb = put(take_base);
-        if (!ctx->d_map.ensure(pack.size() * 4) || !ctx->h_plan.ensure(pack.size() * 4) || !ctx->d_rec_task.ensure((size_t)n_rec * 8 + 8) || !ctx->d_rec_var.ensure(n_rec + 8) ||
-            !ctx->d_rec_kind.ensure(n_rec + 8))
+        size_t o_rq = put(ps.key_rq), o_var = put(ps.key_var_w), o_seg = put(ps.key_seg), o_ordoff = put(ps.key_ord_off), o_ord = put(ps.ord_cnt), o_toff = put(ps.key_t_off),
+               o_boff = put(ps.key_bits_off), o_wpos = put(ps.wpos), o_base = put(ps.rq_sel_base), o_pfs = put(ps.pf_start), o_pfn = put(ps.pf_n),
+               o_pqs = put(ps.pfq_src), o_pqz = put(ps.pfq_size), o_pflj = put(ps.pfl_j), o_out = put(ps.out_off);
+        size_t o_tb = put(ps.take_base);
+        // device record buffer: [task u64 x n_rec][variant u8 x n_rec][kind u8 x n_rec] -> one D2H copy
+        if (!ctx->d_map.ensure(pack.size() * 4) || !ctx->h_plan.ensure(pack.size() * 4) || !ctx->d_rec.ensure(o_mn + 64) ||
+            !ctx->d_tsweep.ensure((size_t)n_units * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) || !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
             return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
+        mark();  // 6: pack
         memcpy(ctx->h_plan.p, pack.data(), pack.size() * 4);
         HQ_HIP(hipMemcpyAsync(ctx->d_map.p, ctx->h_plan.p, pack.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         const uint32_t *d = ctx->d_map.as<uint32_t>();
-        HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-        HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, sc.geom,
-                            ctx->d_wave_tab.as<uint32_t>(), d + o_tb, d + o_tb + sc.G, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->stream));
-        HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
         hqk::MapKeys mk{};
         mk.n_keys = nkeys; mk.key_rq = d + o_rq; mk.key_variant = reinterpret_cast<const uint8_t *>(d + o_var); mk.key_seg_start = d + o_seg;
-        mk.key_ord_off = d + o_ordoff; mk.ord_cnt = d + o_ord; mk.key_t_off = d + o_toff; mk.t_sweep = d + o_t; mk.wk_off = d + o_wkoff; mk.wk_key = d + o_wkkey;
-        mk.wk_pos = d + o_wkpos; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn; mk.pfl_off = d + o_pfloff; mk.pfl_src = d + o_pflsrc;
-        mk.pfl_cnt = d + o_pflcnt; mk.out_off = d + o_out;
+        mk.key_ord_off = d + o_ordoff; mk.ord_cnt = d + o_ord; mk.key_t_off = d + o_toff; mk.key_bits_off = d + o_boff;
+        mk.t_sweep = ctx->d_tsweep.as<uint32_t>(); mk.bits = ctx->d_bits.as<uint64_t>(); mk.pre = ctx->d_pre.as<uint32_t>();
+        mk.wpos = d + o_wpos; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn;
+        mk.n_pfq = n_pfq; mk.pfq_src = d + o_pqs; mk.pfq_size = d + o_pqz; mk.pfl_j = d + o_pflj; mk.out_off = d + o_out;
+        HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+        HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), d + o_tb, d + o_tb + sc.G,
+                            ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->stream));
+        HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
         HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
         HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->d_levels.as<uint64_t>(), max_items, max_count,
-                            ctx->d_rec_task.as<uint64_t>(), ctx->d_rec_var.as<uint8_t>(), ctx->d_rec_kind.as<uint8_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream));
+        HQ_HIP(hqk::sweep_bits(mk, n_units, ctx->stream));
+        uint8_t *drec = ctx->d_rec.as<uint8_t>();
+        HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), max_items, reinterpret_cast<uint64_t *>(drec),
+                            drec + o_rv, drec + o_rk, ctx->d_flags.as<uint32_t>(), ctx->stream));
         HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
-                uint32_t flags[4] = {0, 0, 0, 0};
-        if (n_rec) {
-            HQ_HIP(hipMemcpyAsync(h_rec_task, ctx->d_rec_task.p, (size_t)n_rec * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(h_rec_var, ctx->d_rec_var.p, n_rec, hipMemcpyDeviceToHost, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(h_rec_kind, ctx->d_rec_kind.p, n_rec, hipMemcpyDeviceToHost, ctx->stream));
-        }
+        if (n_rec) HQ_HIP(hipMemcpyAsync(h_rec_task, drec, o_rk + n_rec, hipMemcpyDeviceToHost, ctx->stream));
         // multi-node tasks: the heads of their queues
         {
             size_t pos = 0;
             for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
                 size_t n = cnt.mn_sets[i].size();
-                HQ_HIP(hipMemcpyAsync(mn_ids + pos, ctx->d_sel_task.as<uint64_t>() + rq_sel_base[cnt.mn_rq[i]] + mn_first[i], n * 8, hipMemcpyDeviceToHost, ctx->stream));
+                HQ_HIP(hipMemcpyAsync(mn_ids + pos, ctx->d_sel_task.as<uint64_t>() + ps.rq_sel_base[cnt.mn_rq[i]] + ps.mn_first[i], n * 8, hipMemcpyDeviceToHost, ctx->stream));
                 pos += n;
             }
         }
+        uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
+        flags[0] = 0;
+        mark();  // 7: phase C enqueued
         HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         HQ_HIP(hipStreamSynchronize(ctx->stream));
         if (flags[0]) return fail(ctx, HQTICK_E_CAPACITY, "mapping kernel capacity exceeded");
@@ -571,10 +601,16 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->stats.select_us = ms * 1000.0;
         if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
     }
+    mark();  // 8: phase C synced
     // ---------------- assemble the result view ----------------
-    ctx->rec_off = out_off;
-    ctx->retract_off.assign(W + 1, 0); ctx->retract_task.clear();
-    for (uint32_t w = 0; w < W; w++) { for (uint64_t t : retracts[w]) ctx->retract_task.push_back(t); ctx->retract_off[w + 1] = (uint32_t)ctx->retract_task.size(); }
+    ctx->rec_off = ps.out_off;
+    ctx->retract_off.assign(W + 1, 0); ctx->retract_task.assign(ps.retract_pairs.size(), 0);
+    {
+        for (auto &rp : ps.retract_pairs) if (rp.first < W) ctx->retract_off[rp.first + 1]++;
+        for (uint32_t w = 0; w < W; w++) ctx->retract_off[w + 1] += ctx->retract_off[w];
+        std::vector<uint32_t> cur(ctx->retract_off.begin(), ctx->retract_off.end() - 1);
+        for (auto &rp : ps.retract_pairs) if (rp.first < W) ctx->retract_task[cur[rp.first]++] = rp.second;  // stable: per worker in emission order
+    }
     ctx->mn_task.clear(); ctx->mn_off.assign(1, 0); ctx->mn_worker.clear();
     {
         size_t pos = 0;
@@ -601,15 +637,16 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data();
     out->n_mn = (uint32_t)ctx->mn_task.size(); out->mn_task = ctx->mn_task.data(); out->mn_worker_off = ctx->mn_off.data(); out->mn_worker = ctx->mn_worker.data();
     out->new_free = ctx->new_free.data();
+    mark();  // 9: result assembled
     double t5 = now_us();
     out->t_total_us = t5 - t0; out->t_scan_us = t1 - t0; out->t_batches_us = t2 - t1; out->t_solve_us = t3 - t2; out->t_mapping_us = t5 - t3;
-    uint64_t n_pref = 0; for (uint32_t q = 0; q < Q; q++) n_pref += new_pf_total[q];
-    uint64_t n_asg = 0; for (uint32_t w = 0; w < W; w++) n_asg += n_assign[w];
+    uint64_t n_pref = 0; for (uint32_t q = 0; q < Q; q++) n_pref += ps.new_pf_total[q];
+    uint64_t n_asg = 0; for (uint32_t w = 0; w < W; w++) n_asg += ps.n_assign[w];
     uint32_t nv = Q ? s->rq_variant_off[Q] : 0;
     ctx->stats.n_assigned = n_asg; ctx->stats.n_prefilled = n_pref;
     ctx->stats.algorithmic_bytes = N * 20 + (uint64_t)W * R * 16 + (uint64_t)nv * R * 9 + n_asg * 13 + n_pref * 12;
-    ctx->stats.tick_gpu_us = ctx->stats.distinct_us + ctx->stats.level_hist_us + ctx->stats.select_us + ctx->stats.other_us;
-    (void)t4;
+    ctx->stats.tick_gpu_us = ctx->stats.distinct_us + ctx->stats.level_hist_us + ctx->stats.scan_us + ctx->stats.select_us + ctx->stats.other_us;
+    (void)t4; (void)max_count;
     return status;
 }
 
@@ -642,8 +679,8 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
-                      &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_take_base, &ctx->d_sel_task,
-                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec_task, &ctx->d_rec_var, &ctx->d_rec_kind};
+                      &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
+                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre};
     for (DevBuf *b : bufs) b->release();
     ctx->h_up.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
@@ -714,6 +751,13 @@ int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_w
     for (auto &k : cnt.per_key) for (auto &wc : k) if (wc.second > 0) ctx->q_loaded[wc.first] = 1;  // query.rs:73-81
     out->n_workers = fake->n_workers; out->is_loaded = ctx->q_loaded.data(); out->is_optimal = cnt.is_optimal;
     return 0;
+}
+
+int hqtick_debug_timeline(const hqtick_ctx *ctx, double *out, int cap) {
+    if (!ctx || !out) return 0;
+    int n = ctx->ntl < cap ? ctx->ntl : cap;
+    for (int i = 0; i < n; i++) out[i] = ctx->tl[i];
+    return n;
 }
 
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out) {

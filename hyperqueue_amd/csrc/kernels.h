@@ -15,10 +15,12 @@ static const uint32_t MAX_GROUPS = 16384;                  // hard cap on G = le
 static const uint32_t MAX_LEVELS = 4096;                   // distinct priority levels per tick (LDS sort)
 
 struct WaveGeom {
-    uint32_t tasks_per_wave;  // contiguous ready-set slice a wavefront owns (multiple of 64)
+    uint32_t tasks_per_wave;  // contiguous ready-set slice a wavefront owns (multiple of 256)
     uint32_t n_waves;         // number of slices
     uint32_t waves_per_block; // 4 or 1
+    uint32_t tab_stride;      // row stride of wave_tab (n_waves rounded up to 16 entries)
 };
+static const uint16_t GKEY_INVALID = 0xFFFFu;
 
 // K0: insert every task priority into the open-addressing set `set` (PRIO_SET_CAP slots, pre-filled with PRIO_EMPTY).
 // flags[0] |= 1 when some priority equals PRIO_EMPTY itself, flags[1] = 1 on overflow.
@@ -26,11 +28,13 @@ hipError_t distinct_priorities(const uint64_t *prio, uint64_t n, uint64_t *set, 
 // K0b: compact the set and sort it descending into levels[]; n_levels[0] = L.  Single workgroup.
 hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *levels, uint32_t *n_levels, hipStream_t s);
 
-// K1: per-wave-slice histogram of (level, rq) groups.  wave_cnt is [n_waves][G] (G = L*Q, g = level*Q + rq).
+// K1: per-slice histogram of (level, rq) groups.  wave_tab is [G][tab_stride] (G = L*Q, g = level*Q + rq); also writes
+// the per-task group key gkey[i] = g (GKEY_INVALID for a task whose priority / rq is not in the tables) that K4 re-reads
+// instead of the 12 B/task priority + rq columns.
 hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, uint32_t L, uint32_t Q,
-                WaveGeom geom, uint32_t *wave_cnt, uint32_t *err_flag, hipStream_t s);
-// K1b: exclusive scan of wave_cnt over the wave axis (in place -> offsets) and totals into hist[G].
-hipError_t scan_waves(uint32_t *wave_cnt, uint32_t n_waves, uint32_t G, uint32_t *hist, hipStream_t s);
+                WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, hipStream_t s);
+// K1b: exclusive scan of every wave_tab row (in place -> offsets) and the row totals into hist[G].
+hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, hipStream_t s);
 
 // K2: per (worker, variant) capability flags and task_max_count (server/workerload.rs:77-83,121-145).
 //   flags bit0: free resources cover the variant (have_immediate_resources_for_rq)
@@ -47,13 +51,16 @@ hipError_t worker_eval(const uint64_t *total, const uint64_t *free_, const int64
                  RequestTable rt, uint8_t *flags, uint32_t *tmc, hipStream_t s);
 
 // K4: select the first take[g] tasks (ascending id) of every group and scatter them to sel_task/sel_level at
-// base[g] + rank.  wave_off = output of scan_waves.
-hipError_t select_scatter(const uint64_t *task_id, const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels,
-                    uint32_t L, uint32_t Q, WaveGeom geom, const uint32_t *wave_off, const uint32_t *take,
-                    const uint32_t *base, uint64_t *sel_task, uint16_t *sel_level, hipStream_t s);
+// base[g] + rank.  wave_off = output of scan_waves; slices whose groups are all exhausted exit without reading.
+hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_t n, uint32_t Q, uint32_t G, WaveGeom geom,
+                    const uint32_t *wave_off, const uint32_t *take, const uint32_t *base, uint64_t *sel_task, uint16_t *sel_level,
+                    hipStream_t s);
 
 // K5: expand per-(request,variant,worker) counts into the per-worker assignment records, in the order
 // WorkerTaskMapping::send_messages emits them (scheduler/mapping.rs:36-131,259-282).
+// The round-robin of mapping.rs:42-124 hands the task at index  T_k(s) + #{j < p : c_j > s}  of key k's take_tasks()
+// vector to the worker at position p (Map iteration order) in sweep s, with T_k(s) = sum_j min(c_j, s).  K5a builds, per
+// (key, sweep), the bit row [c_j > s] with per-word prefix popcounts and T_k(s); K5b gathers per worker.
 struct MapKeys {
     uint32_t n_keys;
     const uint32_t *key_rq;        // [n_keys]
@@ -61,25 +68,27 @@ struct MapKeys {
     const uint32_t *key_seg_start; // [n_keys] position of the key's first task in its queue's logical sequence
     const uint32_t *key_ord_off;   // [n_keys+1] into ord_cnt (workers with a count, in Map iteration order)
     const uint32_t *ord_cnt;       // counts in iteration order
-    const uint32_t *key_t_off;     // [n_keys+1] into t_sweep
-    const uint32_t *t_sweep;       // T_i(s) = sum_j min(c_j, s), s = 0..maxc_i
-    // per worker CSR of the keys it takes part in
-    const uint32_t *wk_off;        // [W+1]
-    const uint32_t *wk_key;        // key index
-    const uint32_t *wk_pos;        // position of the worker in that key's iteration order
+    const uint32_t *key_t_off;     // [n_keys+1] sweep units: key k owns units [key_t_off[k], key_t_off[k+1]) = sweeps 0..maxc_k
+    const uint32_t *key_bits_off;  // [n_keys] first word of key k's bit rows (row s at + s * words_k, words_k = ceil(n_k / 64))
+    uint32_t *t_sweep;             // [n_units]  T_k(s)                     (written by K5a)
+    uint64_t *bits;                // bit rows                               (written by K5a)
+    uint32_t *pre;                 // per-word exclusive prefix popcounts    (written by K5a)
+    const uint32_t *wpos;          // [n_keys * W] position of worker w in key k's iteration order, 0xFFFFFFFF = none
     // per request: where the selected queue tasks of rq start in sel_*, and the prefilled block of its logical sequence
     const uint32_t *rq_sel_base;   // [Q]
     const uint32_t *rq_pf_start;   // [Q]
     const uint32_t *rq_pf_n;       // [Q]
-    // new prefills (process_proactive_filling): per worker CSR of (absolute sel index, count)
-    const uint32_t *pfl_off;       // [W+1]
-    const uint32_t *pfl_src;
-    const uint32_t *pfl_cnt;
+    // new prefills (process_proactive_filling): per prefilling request pi, worker w takes chunk pfl_j[pi*W+w] (or none)
+    uint32_t n_pfq;
+    const uint32_t *pfq_src;       // [n_pfq] absolute sel index of chunk 0
+    const uint32_t *pfq_size;      // [n_pfq] chunk length
+    const uint32_t *pfl_j;         // [n_pfq * W]
     // output placement
     const uint32_t *out_off;       // [W+1]
 };
-hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, const uint64_t *levels,
-                    uint32_t max_items, uint32_t max_count, uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag,
-                    hipStream_t s);
+hipError_t sweep_bits(MapKeys mk, uint32_t n_units, hipStream_t s);
+hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, uint32_t max_items,
+                    uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, hipStream_t s);
+size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys);
 
 }  // namespace hqk

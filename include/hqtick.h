@@ -269,7 +269,8 @@ typedef struct hqtick_kernel_stats {
     double level_hist_us;   /* K1: per-(rq,priority) histogram over the ready set   */
     double select_us;       /* K4: selection + scatter of the taken tasks            */
     double distinct_us;     /* K0: distinct-priority discovery                       */
-    double other_us;        /* all other kernels of the tick                         */
+    double other_us;        /* K5a + K5b: round-robin bit rows + per-worker expansion */
+    double scan_us;         /* K1b: scan of the per-slice counts                     */
     double tick_gpu_us;     /* first kernel start -> last kernel end                 */
     uint64_t algorithmic_bytes; /* N*20 + W*R*16 + Q*V*R*9 + A*13 + P*12 */
     uint64_t n_assigned, n_prefilled;

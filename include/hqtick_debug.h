@@ -24,6 +24,11 @@ int hqtick_debug_milp_solve(int ncols, const double *obj, const uint8_t *col_kin
  * out_pos[i] = index into `keys` of the i-th element visited (scheduler/mapping.rs:43). */
 void hqtick_debug_map_order_u32(const uint32_t *keys, uint32_t n, uint32_t *out_pos);
 
+/* Host wall-clock marks (microseconds since the start of the last tick) at the internal stage boundaries of
+ * hqtick_run(); bench tooling only.  Returns the number of marks written. */
+struct hqtick_ctx;
+int hqtick_debug_timeline(const struct hqtick_ctx *ctx, double *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif
