@@ -151,6 +151,7 @@ class KernelStatsC(C.Structure):
         ("distinct_us", C.c_double),
         ("other_us", C.c_double),
         ("scan_us", C.c_double),
+        ("sweep_us", C.c_double),
         ("tick_gpu_us", C.c_double),
         ("algorithmic_bytes", C.c_uint64),
         ("n_assigned", C.c_uint64),

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <string>
 #include <unordered_map>
 
@@ -11,6 +12,19 @@
 namespace hqhost {
 
 namespace {
+
+// Iteration order of a Map<WorkerId,_> built from `ids` (hb_order.h), memoised on the id list: every (request, variant) key
+// of one tick — and usually consecutive ticks — inserts the same workers.
+const std::vector<uint32_t> &cached_worker_order(const std::vector<uint32_t> &ids) {
+    struct Entry { std::vector<uint32_t> ids, order; };
+    static thread_local Entry cache[4];
+    static thread_local unsigned next = 0;
+    for (Entry &e : cache) if (e.ids.size() == ids.size() && (ids.empty() || memcmp(e.ids.data(), ids.data(), ids.size() * 4) == 0)) return e.order;
+    Entry &e = cache[next++ & 3];
+    e.ids = ids;
+    hqhb::insertion_order_u32(ids.data(), (uint32_t)ids.size(), e.order);
+    return e.order;
+}
 
 const double FRACTIONS = 10000.0;
 inline double units(uint64_t a) { return (double)a / FRACTIONS; }  // ResourceAmount::as_f64  amount.rs:91-93
@@ -236,20 +250,31 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         std::unordered_map<std::string, uint32_t> class_of_sig;
         std::vector<uint32_t> wclass(ws.n, 0);
         std::string sig;
+        // slots of every (batch, variant) column, so the eligibility bits of a worker are one pass over its K2 flag row
+        std::vector<uint32_t> col_slot; std::vector<uint32_t> col_rq; std::vector<uint8_t> col_v;
+        for (const TaskBatch &batch : batches) {
+            const RequestView &rv = pb.rqs[batch.rq];
+            for (uint8_t v = 0; v < rv.n_variants; v++) { col_slot.push_back(rv.first_variant + v); col_rq.push_back(batch.rq); col_v.push_back(v); }
+        }
+        const uint32_t nvs = ws.n_variant_slots;
+        long prev = -1;  // previous solver worker: neighbours usually share a class, which three short memcmps establish
         for (uint32_t w : solver_workers) {
             const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
+            float mu = ws.min_util ? ws.min_util[w] : 0.0f;
+            if (prev >= 0 && (pb.custom || (ws.blocked[w].empty() && ws.blocked[prev].empty())) && mu == (ws.min_util ? ws.min_util[prev] : 0.0f) &&
+                memcmp(tot, ws.total + (size_t)prev * R, (size_t)R * 8) == 0 && memcmp(fre, ws.free_ + (size_t)prev * R, (size_t)R * 8) == 0 &&
+                memcmp(ws.vflags + (size_t)w * nvs, ws.vflags + (size_t)prev * nvs, nvs) == 0) {
+                wclass[w] = wclass[prev]; prev = w;
+                continue;
+            }
+            prev = w;
             sig.clear();
             sig.append(reinterpret_cast<const char *>(tot), (size_t)R * 8);
             sig.append(reinterpret_cast<const char *>(fre), (size_t)R * 8);
-            float mu = ws.min_util ? ws.min_util[w] : 0.0f;
             sig.append(reinterpret_cast<const char *>(&mu), 4);
-            for (const TaskBatch &batch : batches) {
-                const RequestView &rv = pb.rqs[batch.rq];
-                for (uint8_t v = 0; v < rv.n_variants; v++) {
-                    uint8_t f = ws.vf(w, rv.first_variant + v);
-                    char ok = (!is_blocked(w, batch.rq, v) && (f & 4) && (f & 1)) ? 1 : 0;
-                    sig.push_back(ok);
-                }
+            for (size_t c = 0; c < col_slot.size(); c++) {
+                uint8_t f = ws.vf(w, col_slot[c]);
+                sig.push_back((!is_blocked(w, col_rq[c], col_v[c]) && (f & 4) && (f & 1)) ? 1 : 0);
             }
             auto it = class_of_sig.find(sig);
             if (it != class_of_sig.end()) { wclass[w] = it->second; continue; }
@@ -323,9 +348,9 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     ids.clear(); widx.clear(); cnt.clear();
                     for (uint32_t w : solver_workers) { uint32_t c = cls_count[wclass[w]][voff[b] + v]; if (c) { ids.push_back(ws.id[w]); widx.push_back(w); cnt.push_back(c); } }
                     if (ids.empty()) continue;
-                    hqhb::insertion_order_u32(ids.data(), (uint32_t)ids.size(), ord);
-                    std::vector<std::pair<uint32_t, uint32_t>> ordered; ordered.reserve(ord.size());
-                    for (uint32_t k : ord) ordered.push_back({widx[k], cnt[k]});
+                    const std::vector<uint32_t> &word = cached_worker_order(ids);
+                    std::vector<std::pair<uint32_t, uint32_t>> ordered; ordered.reserve(word.size());
+                    for (uint32_t k : word) ordered.push_back({widx[k], cnt[k]});
                     key_hash.push_back(hqhb::hash_rq_variant(batches[b].rq, v)); key_list.push_back({batches[b].rq, v}); key_counts.push_back(std::move(ordered));
                 }
             }
@@ -527,10 +552,9 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     if (c > 0) { ids.push_back(ws.id[w]); widx.push_back(w); cnt.push_back(c); }
                 }
                 if (ids.empty()) continue;
-                std::vector<uint32_t> ord;
-                hqhb::insertion_order_u32(ids.data(), (uint32_t)ids.size(), ord);
-                std::vector<std::pair<uint32_t, uint32_t>> ordered;
-                for (uint32_t k : ord) ordered.push_back({widx[k], cnt[k]});
+                const std::vector<uint32_t> &word = cached_worker_order(ids);
+                std::vector<std::pair<uint32_t, uint32_t>> ordered; ordered.reserve(word.size());
+                for (uint32_t k : word) ordered.push_back({widx[k], cnt[k]});
                 key_hash.push_back(hqhb::hash_rq_variant(batch.rq, v)); key_list.push_back({batch.rq, v}); key_counts.push_back(std::move(ordered));
             }
         }

@@ -43,17 +43,19 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct PinBuf {  // page-locked host staging: async copies really are async and skip the runtime's bounce buffer
-    void *p = nullptr; size_t cap = 0;
+struct PinBuf {  // page-locked, device-mapped host memory: kernels read small inputs from it and write small outputs into it
+    void *p = nullptr; void *dp = nullptr; size_t cap = 0;  // dp = the same memory as the device sees it
     bool ensure(size_t bytes) {
         if (bytes <= cap) return true;
         if (p) hipHostFree(p);
         size_t want = bytes + bytes / 4 + 4096;
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; return false; }
+        if (hipHostMalloc(&p, want, hipHostMallocMapped) != hipSuccess) { p = nullptr; dp = nullptr; cap = 0; return false; }
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) { hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; return false; }
         cap = want; return true;
     }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
-    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *dev() const { return reinterpret_cast<T *>(dp); }
+    void release() { if (p) hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }
 };
 
 }  // namespace
@@ -62,7 +64,7 @@ namespace {
 // Reusable host scratch of the mapping plan (no per-tick allocation in the steady state).
 struct PlanScratch {
     std::vector<uint32_t> q_total, pf_n, pf_start, seq_taken, pf_drained, zq_taken, new_pf_total, pfl_size, rq_sel_base;
-    std::vector<uint32_t> key_seg, key_sum, key_rq, key_var_w, key_ord_off, ord_cnt, key_t_off, key_bits_off, wpos;
+    std::vector<uint32_t> key_seg, key_sum, key_rq, key_var_w, key_ord_off, ord_cnt, key_t_off, key_bits_off, wpos, wcnt;
     std::vector<uint32_t> items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, pfl_j, out_off, take_base, mn_first, pack;
     std::vector<uint8_t> now_mn;
     std::vector<std::pair<uint32_t, uint64_t>> retract_pairs;  // (old worker, task)
@@ -82,8 +84,8 @@ struct hqtick_ctx {
     DevBuf d_tid, d_tprio, d_trq; uint64_t n_ready = 0; bool resident = false;
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
-    bool levels_valid = false; uint32_t cached_L = 0;  // level table of the previous tick (re-validated by K1 every tick)
-    PinBuf h_up, h_a, h_plan, h_rec;
+    bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
+    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec;
     // workers / requests
     DevBuf d_up, d_vflags, d_vtmc;
     // selection + mapping
@@ -136,21 +138,23 @@ int validate(hqtick_ctx *ctx, const hqtick_snapshot *s, bool need_tasks) {
     return 0;
 }
 
-struct WorkerEval { const uint8_t *flags = nullptr; const uint32_t *tmc = nullptr; std::vector<uint8_t> flags_own; std::vector<uint32_t> tmc_own; };
+struct WorkerEval { const uint8_t *flags = nullptr; const uint32_t *tmc = nullptr; };
 
-// Packs worker tables + request tables into ONE pinned staging buffer and ONE H2D copy; returns the device views.
-struct UpView { const uint64_t *total, *free_; const int64_t *rem; hqk::RequestTable rt; };
-int upload_tables(hqtick_ctx *ctx, const hqtick_snapshot *s, uint32_t W, const uint64_t *total, const uint64_t *free_, const int64_t *rem, UpView *uv) {
+// Packs worker tables + request tables into ONE pinned, device-mapped staging buffer that K2 reads in place (every byte
+// crosses PCIe once per workgroup; no H2D copy command).
+struct UpView { const uint64_t *total, *free_; const int64_t *rem; hqk::RequestTable rt; uint32_t n_entries; };
+int upload_tables(hqtick_ctx *ctx, const hqtick_snapshot *s, uint32_t W, const uint64_t *total, const uint64_t *free_, const int64_t *rem, PinBuf &buf, UpView *uv) {
     const uint32_t R = s->n_resources;
     uint32_t nv = s->n_requests ? s->rq_variant_off[s->n_requests] : 0;
     uint32_t ne = nv ? s->variant_entry_off[nv] : 0;
     size_t o_tot = 0, o_free = o_tot + (size_t)W * R * 8, o_rem = o_free + (size_t)W * R * 8, o_amt = o_rem + (size_t)W * 8, o_time = o_amt + (size_t)ne * 8,
            o_off = o_time + (size_t)nv * 8, o_res = o_off + (size_t)(nv + 1) * 4, o_kind = o_res + (size_t)ne * 4, bytes = o_kind + ne + 64;
-    if (!ctx->h_up.ensure(bytes) || !ctx->d_up.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "allocating upload staging");
-    unsigned char *h = ctx->h_up.as<unsigned char>();
+    if (hqk::worker_eval_lds(R, nv, ne) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "request table + 32 worker rows exceed the 150 KiB the worker-evaluation kernel stages in LDS");
+    if (!buf.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "allocating upload staging");
+    unsigned char *h = buf.as<unsigned char>();
     if (W && R) { memcpy(h + o_tot, total, (size_t)W * R * 8); memcpy(h + o_free, free_, (size_t)W * R * 8); }
     int64_t *hr = reinterpret_cast<int64_t *>(h + o_rem);
-    for (uint32_t w = 0; w < W; w++) hr[w] = rem ? rem[w] : HQ_NO_TIME_LIMIT;
+    if (rem) memcpy(hr, rem, (size_t)W * 8); else for (uint32_t w = 0; w < W; w++) hr[w] = HQ_NO_TIME_LIMIT;
     if (nv) {
         memcpy(h + o_amt, s->entry_amount, (size_t)ne * 8);
         if (s->variant_min_time_ns) memcpy(h + o_time, s->variant_min_time_ns, (size_t)nv * 8); else memset(h + o_time, 0, (size_t)nv * 8);
@@ -158,27 +162,23 @@ int upload_tables(hqtick_ctx *ctx, const hqtick_snapshot *s, uint32_t W, const u
         memcpy(h + o_res, s->entry_resource, (size_t)ne * 4);
         memcpy(h + o_kind, s->entry_kind, ne);
     }
-    HQ_HIP(hipMemcpyAsync(ctx->d_up.p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-    unsigned char *d = ctx->d_up.as<unsigned char>();
+    unsigned char *d = buf.dev<unsigned char>();
     uv->total = (const uint64_t *)(d + o_tot); uv->free_ = (const uint64_t *)(d + o_free); uv->rem = (const int64_t *)(d + o_rem);
     uv->rt.entry_amount = (const uint64_t *)(d + o_amt); uv->rt.variant_min_time_ns = (const uint64_t *)(d + o_time);
     uv->rt.variant_entry_off = (const uint32_t *)(d + o_off); uv->rt.entry_resource = (const uint32_t *)(d + o_res);
-    uv->rt.entry_kind = (const uint8_t *)(d + o_kind); uv->rt.n_variants = nv;
+    uv->rt.entry_kind = (const uint8_t *)(d + o_kind); uv->rt.n_variants = nv; uv->n_entries = ne;
     return 0;
 }
 
-// K2 on a worker set, synchronous (used for the fake workers of hqtick_query)
+// K2 on a worker set, synchronous (used for the fake workers of hqtick_query); results land in pinned memory
 int eval_workers_sync(hqtick_ctx *ctx, const hqtick_snapshot *s, uint32_t W, const uint64_t *total, const uint64_t *free_, const int64_t *rem, WorkerEval *out) {
     UpView uv; int rc;
-    if ((rc = upload_tables(ctx, s, W, total, free_, rem, &uv))) return rc;
+    if ((rc = upload_tables(ctx, s, W, total, free_, rem, ctx->h_up2, &uv))) return rc;
     size_t n = (size_t)W * uv.rt.n_variants;
-    out->flags_own.assign(n, 0); out->tmc_own.assign(n, 0);
-    out->flags = out->flags_own.data(); out->tmc = out->tmc_own.data();
+    if (!ctx->h_q.ensure(n * 5 + 64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc query eval");
+    out->tmc = ctx->h_q.as<uint32_t>(); out->flags = ctx->h_q.as<uint8_t>() + n * 4;
     if (n == 0) return 0;
-    if (!ctx->d_vflags.ensure(n) || !ctx->d_vtmc.ensure(n * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc worker flags");
-    HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, s->n_resources, uv.rt, ctx->d_vflags.as<uint8_t>(), ctx->d_vtmc.as<uint32_t>(), ctx->stream));
-    HQ_HIP(hipMemcpyAsync(out->flags_own.data(), ctx->d_vflags.p, n, hipMemcpyDeviceToHost, ctx->stream));
-    HQ_HIP(hipMemcpyAsync(out->tmc_own.data(), ctx->d_vtmc.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, s->n_resources, uv.rt, uv.n_entries, ctx->h_q.dev<uint8_t>() + n * 4, ctx->h_q.dev<uint32_t>(), ctx->stream));
     HQ_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -233,14 +233,11 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc)
     const uint32_t W = s->n_workers, R = s->n_resources, Q = s->n_requests;
     const uint64_t N = ctx->n_ready;
     sc->Q = Q; sc->L = 0; sc->G = 0; sc->levels.clear(); sc->hist.clear();
-    UpView uv; int rc;
-    if ((rc = upload_tables(ctx, s, W, s->worker_total, s->worker_free, s->worker_remaining_ns, &uv))) return rc;
-    const size_t nwv = (size_t)W * uv.rt.n_variants;
-    if (!ctx->d_vflags.ensure(nwv + 8) || !ctx->d_vtmc.ensure(nwv * 4 + 8) || !ctx->d_set.ensure((size_t)hqk::PRIO_SET_CAP * 8) || !ctx->d_flags.ensure(64) ||
-        !ctx->d_levels.ensure((size_t)(hqk::MAX_LEVELS + 2) * 8) || !ctx->d_nlevels.ensure(16))
+    if (!ctx->d_set.ensure((size_t)hqk::PRIO_SET_CAP * 8) || !ctx->d_flags.ensure(64) || !ctx->d_levels.ensure((size_t)(hqk::MAX_LEVELS + 2) * 8) || !ctx->d_nlevels.ensure(16))
         return fail(ctx, HQTICK_E_DEVICE, "hipMalloc phase A");
-    HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, ctx->d_vflags.as<uint8_t>(), ctx->d_vtmc.as<uint32_t>(), ctx->stream));
     const bool scan = N != 0 && Q != 0;
+    const uint32_t nvs = Q ? s->rq_variant_off[Q] : 0;
+    const size_t nwv = (size_t)W * nvs;
     for (int attempt = 0; attempt < 2; attempt++) {
         uint32_t L = 0;
         if (scan) {
@@ -257,6 +254,10 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc)
                 HQ_HIP(hipStreamSynchronize(ctx->stream));
                 if (flags[1] || L == 0xFFFFFFFFu || L > hqk::MAX_LEVELS) return fail(ctx, HQTICK_E_CAPACITY, "more than 4096 distinct priority levels in the ready set");
                 if (L == 0) return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level");
+                ctx->h_levels.resize(L);
+                HQ_HIP(hipMemcpyAsync(ctx->h_levels.data(), ctx->d_levels.p, (size_t)L * 8, hipMemcpyDeviceToHost, ctx->stream));
+                HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
+                HQ_HIP(hipStreamSynchronize(ctx->stream));
                 float ms = 0;
                 if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->stats.distinct_us = ms * 1000.0;
                 ctx->levels_valid = true; ctx->cached_L = L;
@@ -265,35 +266,31 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc)
             uint64_t G64 = (uint64_t)L * Q;
             if (G64 > hqk::MAX_GROUPS) return fail(ctx, HQTICK_E_CAPACITY, "levels x requests exceeds 16384 groups");
             sc->L = L; sc->G = (uint32_t)G64;
+        }
+        // host-visible outputs of phase A, written in place by the kernels: [flags 16][hist G*4][vtmc nwv*4][vflags nwv]
+        size_t o_hist = 16, o_tmc = o_hist + (size_t)sc->G * 4, o_fl = o_tmc + nwv * 4, bytes = o_fl + nwv + 16;
+        if (!ctx->h_a.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc phase A");
+        unsigned char *h = ctx->h_a.as<unsigned char>(), *hd = ctx->h_a.dev<unsigned char>();
+        memset(h, 0, 16);
+        if (scan) {
             hqk::WaveGeom &g = sc->geom;
             g.waves_per_block = sc->G <= hqk::MAX_GROUPS_4W ? 4 : 1;
             uint64_t tpw = 256;
             while (((N + tpw - 1) / tpw) * sc->G > (1ull << 24)) tpw *= 2;  // keep the per-slice table under 64 MiB
             g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw); g.tab_stride = (g.n_waves + 15u) & ~15u;
-            if (!ctx->d_wave_tab.ensure((size_t)g.tab_stride * sc->G * 4) || !ctx->d_hist.ensure((size_t)sc->G * 4) || !ctx->d_gkey.ensure(N * 2 + 16))
-                return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
-            HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
-            HQ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+            if (!ctx->d_wave_tab.ensure((size_t)g.tab_stride * sc->G * 4) || !ctx->d_gkey.ensure(N * 2 + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
+            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
             HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
                                    ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
-            HQ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
-            HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, ctx->d_hist.as<uint32_t>(), ctx->stream));
-            HQ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
+            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+            HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
+                                   reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream));
+            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
         }
-        // one download: [flags 16][levels L*8][hist G*4][vtmc nwv*4][vflags nwv]
-        size_t o_lv = 16, o_hist = o_lv + (size_t)sc->L * 8, o_tmc = o_hist + (size_t)sc->G * 4, o_fl = o_tmc + nwv * 4, bytes = o_fl + nwv + 16;
-        if (!ctx->h_a.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc phase A");
-        unsigned char *h = ctx->h_a.as<unsigned char>();
-        memset(h, 0, 16);
-        if (scan) {
-            HQ_HIP(hipMemcpyAsync(h, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(h + o_lv, ctx->d_levels.p, (size_t)sc->L * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(h + o_hist, ctx->d_hist.p, (size_t)sc->G * 4, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        if (nwv) {
-            HQ_HIP(hipMemcpyAsync(h + o_tmc, ctx->d_vtmc.p, nwv * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(h + o_fl, ctx->d_vflags.p, nwv, hipMemcpyDeviceToHost, ctx->stream));
-        }
+        // K2 reads the packed tables from pinned memory while the scans run
+        UpView uv; int rc;
+        if ((rc = upload_tables(ctx, s, W, s->worker_total, s->worker_free, s->worker_remaining_ns, ctx->h_up, &uv))) return rc;
+        HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc), ctx->stream));
         HQ_HIP(hipStreamSynchronize(ctx->stream));
         const uint32_t *flags = reinterpret_cast<const uint32_t *>(h);
         if (scan && (flags[2] & 2u)) return fail(ctx, HQTICK_E_INVALID, "ready set holds a request id >= n_requests");
@@ -304,11 +301,11 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc)
         }
         ev->flags = h + o_fl; ev->tmc = reinterpret_cast<const uint32_t *>(h + o_tmc);
         if (scan) {
-            sc->levels.assign(reinterpret_cast<const uint64_t *>(h + o_lv), reinterpret_cast<const uint64_t *>(h + o_lv) + sc->L);
+            sc->levels = ctx->h_levels;
             sc->hist.assign(reinterpret_cast<const uint32_t *>(h + o_hist), reinterpret_cast<const uint32_t *>(h + o_hist) + sc->G);
             float ms = 0;
-            if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->stats.level_hist_us = ms * 1000.0;
-            if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[8]) == hipSuccess) ctx->stats.scan_us = ms * 1000.0;
+            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->stats.level_hist_us = ms * 1000.0;
+            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[8]) == hipSuccess) ctx->stats.scan_us = ms * 1000.0;
         }
         return 0;
     }
@@ -394,25 +391,25 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     const uint32_t nkeys = (uint32_t)cnt.keys.size();
     ps.key_seg.assign(nkeys, 0); ps.key_sum.assign(nkeys, 0); ps.key_rq.assign(nkeys, 0); ps.key_var_w.assign((nkeys + 3) / 4 + 1, 0);
     ps.key_ord_off.assign(nkeys + 1, 0); ps.ord_cnt.clear(); ps.key_t_off.assign(nkeys + 1, 0); ps.key_bits_off.assign(nkeys + 1, 0);
-    ps.wpos.assign((size_t)nkeys * W, NONE);
+    ps.wpos.assign((size_t)nkeys * W, NONE); ps.wcnt.assign((size_t)nkeys * W, 0);
     ps.items.assign(W, 0); ps.n_assign.assign(W, 0); ps.asg_qw.assign((size_t)Q * W, 0);
     ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
-    uint32_t max_count = 0;
+    uint32_t max_count = 0, max_nk = 0;
     for (uint32_t k = 0; k < nkeys; k++) {
         const uint32_t q = cnt.keys[k].first; const uint8_t v = cnt.keys[k].second;
         ps.key_rq[k] = q; reinterpret_cast<uint8_t *>(ps.key_var_w.data())[k] = v;
         uint32_t sum = 0, maxc = 0, pos = 0;
-        uint32_t *wp = ps.wpos.data() + (size_t)k * W, *aq = ps.asg_qw.data() + (size_t)q * W;
+        uint32_t *wp = ps.wpos.data() + (size_t)k * W, *wcn = ps.wcnt.data() + (size_t)k * W, *aq = ps.asg_qw.data() + (size_t)q * W;
         for (auto &wc : cnt.per_key[k]) {
             sum += wc.second; maxc = std::max(maxc, wc.second);
             ctx->cnt_rq.push_back(q); ctx->cnt_variant.push_back(v); ctx->cnt_worker.push_back(wc.first); ctx->cnt_value.push_back(wc.second);
             ps.ord_cnt.push_back(wc.second);
-            wp[wc.first] = pos++; ps.items[wc.first] += wc.second; ps.n_assign[wc.first] += wc.second; aq[wc.first] += wc.second;
+            wp[wc.first] = pos++; wcn[wc.first] = wc.second; ps.items[wc.first] += wc.second; ps.n_assign[wc.first] += wc.second; aq[wc.first] += wc.second;
         }
         ps.key_ord_off[k + 1] = (uint32_t)ps.ord_cnt.size();
         ps.key_t_off[k + 1] = ps.key_t_off[k] + maxc + 1;  // sweeps 0..maxc
         ps.key_bits_off[k + 1] = ps.key_bits_off[k] + (maxc + 1) * ((pos + 63) / 64);
-        max_count = std::max(max_count, maxc);
+        max_count = std::max(max_count, maxc); max_nk = std::max(max_nk, pos);
         ps.key_seg[k] = ps.seq_taken[q]; ps.key_sum[k] = sum; ps.seq_taken[q] += sum;
         if (ps.seq_taken[q] > ps.q_total[q] + ps.pf_n[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "solver placed more tasks than the queue holds (reference panics, taskqueue.rs:327)");
     }
@@ -537,6 +534,7 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     }
     const uint32_t n_rec = ps.out_off[W];
     if (hqk::expand_mapping_lds(max_items, nkeys) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
+    if (max_nk > hqk::SWEEP_MAX_WORKERS) return fail(ctx, HQTICK_E_CAPACITY, "more than 24576 workers share one (request, variant) placement: beyond the round-robin kernel's LDS staging");
     mark();  // 5: K5 tables
     double t4 = now_us();
 
@@ -553,35 +551,34 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         std::vector<uint32_t> &pack = ps.pack; pack.clear();
         auto put = [&](const std::vector<uint32_t> &v) { size_t o = pack.size(); pack.insert(pack.end(), v.begin(), v.end()); if (v.empty()) pack.push_back(0); return o; };
         size_t o_rq = put(ps.key_rq), o_var = put(ps.key_var_w), o_seg = put(ps.key_seg), o_ordoff = put(ps.key_ord_off), o_ord = put(ps.ord_cnt), o_toff = put(ps.key_t_off),
-               o_boff = put(ps.key_bits_off), o_wpos = put(ps.wpos), o_base = put(ps.rq_sel_base), o_pfs = put(ps.pf_start), o_pfn = put(ps.pf_n),
+               o_boff = put(ps.key_bits_off), o_wpos = put(ps.wpos), o_wcnt = put(ps.wcnt), o_base = put(ps.rq_sel_base), o_pfs = put(ps.pf_start), o_pfn = put(ps.pf_n),
                o_pqs = put(ps.pfq_src), o_pqz = put(ps.pfq_size), o_pflj = put(ps.pfl_j), o_out = put(ps.out_off);
         size_t o_tb = put(ps.take_base);
         // device record buffer: [task u64 x n_rec][variant u8 x n_rec][kind u8 x n_rec] -> one D2H copy
-        if (!ctx->d_map.ensure(pack.size() * 4) || !ctx->h_plan.ensure(pack.size() * 4) || !ctx->d_rec.ensure(o_mn + 64) ||
+        if (!ctx->d_map.ensure(pack.size() * 4 + 16) || !ctx->h_plan.ensure(pack.size() * 4 + 16) ||
             !ctx->d_tsweep.ensure((size_t)n_units * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) || !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
             return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
         mark();  // 6: pack
         memcpy(ctx->h_plan.p, pack.data(), pack.size() * 4);
-        HQ_HIP(hipMemcpyAsync(ctx->d_map.p, ctx->h_plan.p, pack.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         const uint32_t *d = ctx->d_map.as<uint32_t>();
         hqk::MapKeys mk{};
         mk.n_keys = nkeys; mk.key_rq = d + o_rq; mk.key_variant = reinterpret_cast<const uint8_t *>(d + o_var); mk.key_seg_start = d + o_seg;
         mk.key_ord_off = d + o_ordoff; mk.ord_cnt = d + o_ord; mk.key_t_off = d + o_toff; mk.key_bits_off = d + o_boff;
         mk.t_sweep = ctx->d_tsweep.as<uint32_t>(); mk.bits = ctx->d_bits.as<uint64_t>(); mk.pre = ctx->d_pre.as<uint32_t>();
-        mk.wpos = d + o_wpos; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn;
+        mk.wpos = d + o_wpos; mk.wcnt = d + o_wcnt; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn;
         mk.n_pfq = n_pfq; mk.pfq_src = d + o_pqs; mk.pfq_size = d + o_pqz; mk.pfl_j = d + o_pflj; mk.out_off = d + o_out;
-        HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-        HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), d + o_tb, d + o_tb + sc.G,
-                            ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->stream));
-        HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
-        HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
-        HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        HQ_HIP(hqk::sweep_bits(mk, n_units, ctx->stream));
-        uint8_t *drec = ctx->d_rec.as<uint8_t>();
+        uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
+        flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
+        if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+        HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.dev<uint32_t>() + o_tb,
+                            d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, pack.size() * 4, ctx->stream));
+        if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+        HQ_HIP(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
+        if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
+        uint8_t *drec = ctx->h_rec.dev<uint8_t>();  // K5b writes the records straight into the caller-visible pinned buffer (PCIe-bound, no copy command)
         HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), max_items, reinterpret_cast<uint64_t *>(drec),
-                            drec + o_rv, drec + o_rk, ctx->d_flags.as<uint32_t>(), ctx->stream));
-        HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
-        if (n_rec) HQ_HIP(hipMemcpyAsync(h_rec_task, drec, o_rk + n_rec, hipMemcpyDeviceToHost, ctx->stream));
+                            drec + o_rv, drec + o_rk, reinterpret_cast<uint32_t *>(drec + o_fl), ctx->stream));
+        if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         // multi-node tasks: the heads of their queues
         {
             size_t pos = 0;
@@ -591,15 +588,13 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
                 pos += n;
             }
         }
-        uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
-        flags[0] = 0;
         mark();  // 7: phase C enqueued
-        HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         HQ_HIP(hipStreamSynchronize(ctx->stream));
         if (flags[0]) return fail(ctx, HQTICK_E_CAPACITY, "mapping kernel capacity exceeded");
         float ms = 0;
-        if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->stats.select_us = ms * 1000.0;
-        if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
+        if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->stats.select_us = ms * 1000.0;
+        if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->stats.sweep_us = ms * 1000.0;
+        if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
     }
     mark();  // 8: phase C synced
     // ---------------- assemble the result view ----------------
@@ -645,7 +640,7 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     uint32_t nv = Q ? s->rq_variant_off[Q] : 0;
     ctx->stats.n_assigned = n_asg; ctx->stats.n_prefilled = n_pref;
     ctx->stats.algorithmic_bytes = N * 20 + (uint64_t)W * R * 16 + (uint64_t)nv * R * 9 + n_asg * 13 + n_pref * 12;
-    ctx->stats.tick_gpu_us = ctx->stats.distinct_us + ctx->stats.level_hist_us + ctx->stats.scan_us + ctx->stats.select_us + ctx->stats.other_us;
+    ctx->stats.tick_gpu_us = ctx->stats.distinct_us + ctx->stats.level_hist_us + ctx->stats.scan_us + ctx->stats.select_us + ctx->stats.sweep_us + ctx->stats.other_us;
     (void)t4; (void)max_count;
     return status;
 }
@@ -668,8 +663,10 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     if (hipSetDevice(config->device_index) != hipSuccess) return HQTICK_E_NO_DEVICE;
     hqtick_ctx *ctx = new hqtick_ctx();
     ctx->cfg = *config; ctx->device = config->device_index;
+    ctx->timing = (config->flags & HQTICK_FLAG_NO_KERNEL_TIMING) == 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
+    if (!ctx->d_flags.ensure(64) || hipMemset(ctx->d_flags.p, 0, 64) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     *out_ctx = ctx;
     return 0;
 }
@@ -682,7 +679,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
                       &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre};
     for (DevBuf *b : bufs) b->release();
-    ctx->h_up.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release();
+    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -34,7 +34,8 @@ hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *lev
 hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, uint32_t L, uint32_t Q,
                 WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, hipStream_t s);
 // K1b: exclusive scan of every wave_tab row (in place -> offsets) and the row totals into hist[G].
-hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, hipStream_t s);
+// err_in (device) is forwarded to err_out (may be pinned host memory) by the same launch.
+hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, uint32_t *err_in, uint32_t *err_out, hipStream_t s);
 
 // K2: per (worker, variant) capability flags and task_max_count (server/workerload.rs:77-83,121-145).
 //   flags bit0: free resources cover the variant (have_immediate_resources_for_rq)
@@ -48,13 +49,17 @@ struct RequestTable {
     uint32_t n_variants;
 };
 hipError_t worker_eval(const uint64_t *total, const uint64_t *free_, const int64_t *remaining_ns, uint32_t W, uint32_t R,
-                 RequestTable rt, uint8_t *flags, uint32_t *tmc, hipStream_t s);
+                 RequestTable rt, uint32_t n_entries, uint8_t *flags, uint32_t *tmc, hipStream_t s);
+size_t worker_eval_lds(uint32_t R, uint32_t n_variants, uint32_t n_entries);  // LDS the launch needs (request table + 32 worker rows)
 
 // K4: select the first take[g] tasks (ascending id) of every group and scatter them to sel_task/sel_level at
 // base[g] + rank.  wave_off = output of scan_waves; slices whose groups are all exhausted exit without reading.
+// The selection plan is `take[G] | base[G]`: take_pinned points at it inside the pinned plan buffer (read once per workgroup
+// into LDS), take_dev at its copy in HBM (used by the large-G variant).  The same launch copies the whole plan
+// (plan_bytes from plan_src, pinned, to plan_dst, HBM) with ride-along workgroups so that no copy-engine command is needed.
 hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_t n, uint32_t Q, uint32_t G, WaveGeom geom,
-                    const uint32_t *wave_off, const uint32_t *take, const uint32_t *base, uint64_t *sel_task, uint16_t *sel_level,
-                    hipStream_t s);
+                    const uint32_t *wave_off, const uint32_t *take_pinned, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_level,
+                    const void *plan_src, void *plan_dst, size_t plan_bytes, hipStream_t s);
 
 // K5: expand per-(request,variant,worker) counts into the per-worker assignment records, in the order
 // WorkerTaskMapping::send_messages emits them (scheduler/mapping.rs:36-131,259-282).
@@ -74,6 +79,7 @@ struct MapKeys {
     uint64_t *bits;                // bit rows                               (written by K5a)
     uint32_t *pre;                 // per-word exclusive prefix popcounts    (written by K5a)
     const uint32_t *wpos;          // [n_keys * W] position of worker w in key k's iteration order, 0xFFFFFFFF = none
+    const uint32_t *wcnt;          // [n_keys * W] count of worker w in key k (0 = none)
     // per request: where the selected queue tasks of rq start in sel_*, and the prefilled block of its logical sequence
     const uint32_t *rq_sel_base;   // [Q]
     const uint32_t *rq_pf_start;   // [Q]
@@ -86,7 +92,8 @@ struct MapKeys {
     // output placement
     const uint32_t *out_off;       // [W+1]
 };
-hipError_t sweep_bits(MapKeys mk, uint32_t n_units, hipStream_t s);
+hipError_t sweep_bits(MapKeys mk, uint32_t max_count, uint32_t max_workers_per_key, hipStream_t s);
+static const uint32_t SWEEP_MAX_WORKERS = 24576;  // workers per key the round-robin kernel stages in LDS
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, uint32_t max_items,
                     uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, hipStream_t s);
 size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys);

@@ -188,37 +188,41 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------ K1b
-// One wavefront per group row: 16 consecutive entries per lane (4 x dwordx4), local prefix + one wave scan per 1024 entries.
+// One wavefront per group row: 64 consecutive entries per lane (16 x dwordx4 in flight), local prefix + one wave scan per
+// 4096 entries.  The row total goes to hist[] — which may live in pinned host memory (written once per row).
 __global__ void __launch_bounds__(256) k_scan_rows(uint32_t *__restrict__ wave_tab, uint32_t n_waves, uint32_t stride, uint32_t G,
-                                                   uint32_t *__restrict__ hist) {
+                                                   uint32_t *__restrict__ hist, uint32_t *__restrict__ err_in,
+                                                   uint32_t *__restrict__ err_out) {
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row == 0 && threadIdx.x == 0 && err_out) { err_out[0] = err_in[0]; err_in[0] = 0; }  // K1's validation flags: forwarded to the host-visible word, device word re-armed
     if (row >= G) return;
     const uint32_t lane = lane_id();
     uint32_t *r = wave_tab + (size_t)row * stride;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_waves; base += 1024) {
-        const uint32_t i0 = base + lane * 16;
-        uint32_t v[16];
-        if (i0 < stride) {  // stride is a multiple of 16: the whole 16-entry run is inside the row
-            const uint4 *src = reinterpret_cast<const uint4 *>(r + i0);
+    for (uint32_t base = 0; base < n_waves; base += 4096) {
+        const uint32_t i0 = base + lane * 64;
+        uint4 v[16];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { uint4 t = src[k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = 0;
+        for (int k = 0; k < 16; k++) {  // stride is a multiple of 16 entries: every 4-entry group is inside the row or fully outside
+            const uint32_t i = i0 + 4 * k;
+            v[k] = i < stride ? *reinterpret_cast<const uint4 *>(r + i) : make_uint4(0, 0, 0, 0);
         }
         uint32_t run = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) { uint32_t t = (i0 + k < n_waves) ? v[k] : 0u; v[k] = run; run += t; }  // padding entries count as 0
+        for (int k = 0; k < 16; k++) {  // padding entries (index >= n_waves) count as 0
+            const uint32_t i = i0 + 4 * k;
+            uint32_t t0 = i < n_waves ? v[k].x : 0u, t1 = i + 1 < n_waves ? v[k].y : 0u, t2 = i + 2 < n_waves ? v[k].z : 0u, t3 = i + 3 < n_waves ? v[k].w : 0u;
+            v[k].x = run; run += t0; v[k].y = run; run += t1; v[k].z = run; run += t2; v[k].w = run; run += t3;
+        }
         uint32_t incl = run;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += t; }
         const uint32_t excl = carry + incl - run;
         const uint32_t total = __shfl(incl, 63, 64);
-        if (i0 < stride) {
-            uint4 *dst = reinterpret_cast<uint4 *>(r + i0);
 #pragma unroll
-            for (int k = 0; k < 4; k++) dst[k] = make_uint4(v[4 * k] + excl, v[4 * k + 1] + excl, v[4 * k + 2] + excl, v[4 * k + 3] + excl);
+        for (int k = 0; k < 16; k++) {
+            const uint32_t i = i0 + 4 * k;
+            if (i < stride) *reinterpret_cast<uint4 *>(r + i) = make_uint4(v[k].x + excl, v[k].y + excl, v[k].z + excl, v[k].w + excl);
         }
         carry += total;
     }
@@ -232,8 +236,14 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
                                                      uint32_t Q, uint32_t G, uint32_t tasks_per_wave, uint32_t n_waves, uint32_t stride,
                                                      const uint32_t *__restrict__ wave_off, const uint32_t *__restrict__ take,
                                                      const uint32_t *__restrict__ base, uint64_t *__restrict__ sel_task,
-                                                     uint16_t *__restrict__ sel_level) {
+                                                     uint16_t *__restrict__ sel_level, uint32_t n_select_blocks,
+                                                     const uint4 *__restrict__ copy_src, uint4 *__restrict__ copy_dst, uint32_t copy_n16) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x >= n_select_blocks) {  // ride-along workgroups: bring the mapping plan from pinned host memory into HBM for K5a/K5b
+        const uint32_t nb = gridDim.x - n_select_blocks;
+        for (uint32_t i = (blockIdx.x - n_select_blocks) * blockDim.x + threadIdx.x; i < copy_n16; i += nb * blockDim.x) copy_dst[i] = copy_src[i];
+        return;
+    }
     uint32_t *s_all = reinterpret_cast<uint32_t *>(smem);
     uint32_t *s_cnt = s_all + (threadIdx.x >> 6) * G;
     const uint32_t *tk = take, *bs = base;
@@ -244,24 +254,27 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
     }
     const uint32_t lane = lane_id();
     const uint32_t wave = blockIdx.x * WPB + (threadIdx.x >> 6);
-    bool need = false;
-    if (wave < n_waves) {
-        for (uint32_t g = lane; g < G; g += 64) { uint32_t o = wave_off[(size_t)g * stride + wave]; s_cnt[g] = o; need = need || o < take[g]; }
-    }
-    __syncthreads();
-    if (wave >= n_waves || !__ballot(need)) return;  // every group this slice could feed is already exhausted by earlier slices
+    if (LDS_PLAN) __syncthreads();
+    if (wave >= n_waves) return;
+    bool need = false;  // counters are wave-private: no workgroup barrier from here on
+    for (uint32_t g = lane; g < G; g += 64) { uint32_t o = wave_off[(size_t)g * stride + wave]; s_cnt[g] = o; need = need || o < tk[g]; }
+    if (!__ballot(need)) return;  // every group this slice could feed is already exhausted by earlier slices
     int nbits = 0; while ((1u << nbits) < G) nbits++;
     const uint64_t begin = (uint64_t)wave * tasks_per_wave;
     const uint64_t end = begin + tasks_per_wave < n ? begin + tasks_per_wave : n;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     for (uint64_t b = begin; b < end; b += 256) {
         uint16_t kv[4];
+        uint64_t idv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { uint64_t i = b + (uint64_t)u * 64 + lane; kv[u] = i < end ? gkey[i] : GKEY_INVALID; }
+        for (int u = 0; u < 4; u++) {  // keys and ids of the whole 256-task tile in flight before the first use
+            uint64_t i = b + (uint64_t)u * 64 + lane;
+            kv[u] = i < end ? gkey[i] : GKEY_INVALID;
+            idv[u] = i < end ? task_id[i] : 0;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (b + (uint64_t)u * 64 >= end) break;  // wave-uniform
-            const uint64_t i = b + (uint64_t)u * 64 + lane;
             const uint32_t g = kv[u];
             const bool active = g != GKEY_INVALID;
             const uint64_t peers = match_any(g, nbits, active);
@@ -271,7 +284,7 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
                 const uint32_t rank = cur + before;
                 if (rank < tk[g]) {
                     const uint32_t dst = bs[g] + rank;
-                    sel_task[dst] = task_id[i];
+                    sel_task[dst] = idv[u];
                     sel_level[dst] = (uint16_t)(g / Q);
                 }
                 if (before == 0) s_cnt[g] = cur + (uint32_t)__popcll(peers);
@@ -281,85 +294,123 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ K2
+// One workgroup per 32 workers.  Worker rows and the whole request table are staged in LDS with coalesced loads (the inputs
+// may sit in pinned host memory: every byte crosses PCIe once per workgroup), then one thread per (worker, variant).
+// LDS: [total 32*R u64][free 32*R u64][rem 32 i64][entry_amount NE u64][variant_min_time NV u64][variant_entry_off NV+1 u32]
+//      [entry_resource NE u32][entry_kind NE u8]
 __global__ void __launch_bounds__(256) k_worker_eval(const uint64_t *__restrict__ total, const uint64_t *__restrict__ free_,
                                                      const int64_t *__restrict__ remaining_ns, uint32_t W, uint32_t R, RequestTable rt,
-                                                     uint8_t *__restrict__ flags, uint32_t *__restrict__ tmc) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= W * rt.n_variants) return;
-    uint32_t w = t / rt.n_variants, v = t % rt.n_variants;
-    bool imm = true, cap = true;
-    uint64_t best = 0xFFFFFFFFFFFFFFFFull;
-    bool any = false;
-    for (uint32_t e = rt.variant_entry_off[v]; e < rt.variant_entry_off[v + 1]; e++) {
-        uint32_t r = rt.entry_resource[e];
-        uint64_t f = r < R ? free_[(size_t)w * R + r] : 0, tt = r < R ? total[(size_t)w * R + r] : 0;
-        uint64_t c;
-        if (rt.entry_kind[e] == 0) {  // amount
-            uint64_t a = rt.entry_amount[e];
-            imm = imm && a <= f; cap = cap && a <= tt;
-            c = f / a; if (c > 1024) c = 1024;            // MAX_TASK_PER_WORKER  workerload.rs:12,131
-        } else {                                           // All: min_amount = 1 fraction  request.rs:34-36
-            imm = imm && f >= 1; cap = cap && tt >= 1;
-            c = f == 0 ? 0 : 1;                            // workerload.rs:133-141
+                                                     uint32_t n_entries, uint8_t *__restrict__ flags, uint32_t *__restrict__ tmc) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t NV = rt.n_variants, NE = n_entries;
+    uint64_t *s_tot = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *s_free = s_tot + 32 * R;
+    int64_t *s_rem = reinterpret_cast<int64_t *>(s_free + 32 * R);
+    uint64_t *s_amt = reinterpret_cast<uint64_t *>(s_rem + 32);
+    uint64_t *s_time = s_amt + NE;
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(s_time + NV);
+    uint32_t *s_res = s_off + NV + 1;
+    uint8_t *s_kind = reinterpret_cast<uint8_t *>(s_res + NE);
+    const uint32_t w0 = blockIdx.x * 32, nw = W - w0 < 32 ? W - w0 : 32;
+    for (uint32_t i = threadIdx.x; i < nw * R; i += blockDim.x) { s_tot[i] = total[(size_t)w0 * R + i]; s_free[i] = free_[(size_t)w0 * R + i]; }
+    for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) s_rem[i] = remaining_ns[w0 + i];
+    for (uint32_t i = threadIdx.x; i < NE; i += blockDim.x) { s_amt[i] = rt.entry_amount[i]; s_res[i] = rt.entry_resource[i]; s_kind[i] = rt.entry_kind[i]; }
+    for (uint32_t i = threadIdx.x; i < NV; i += blockDim.x) s_time[i] = rt.variant_min_time_ns[i];
+    for (uint32_t i = threadIdx.x; i <= NV; i += blockDim.x) s_off[i] = rt.variant_entry_off[i];
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < nw * NV; idx += blockDim.x) {
+        const uint32_t wl = idx / NV, v = idx % NV;
+        bool imm = true, cap = true, any = false;
+        uint64_t best = 0xFFFFFFFFFFFFFFFFull;
+        for (uint32_t e = s_off[v]; e < s_off[v + 1]; e++) {
+            const uint32_t r = s_res[e];
+            const uint64_t f = r < R ? s_free[wl * R + r] : 0, tt = r < R ? s_tot[wl * R + r] : 0;
+            uint64_t c;
+            if (s_kind[e] == 0) {  // amount
+                const uint64_t a = s_amt[e];
+                imm = imm && a <= f; cap = cap && a <= tt;
+                c = f / a; if (c > 1024) c = 1024;            // MAX_TASK_PER_WORKER  workerload.rs:12,131
+            } else {                                           // All: min_amount = 1 fraction  request.rs:34-36
+                imm = imm && f >= 1; cap = cap && tt >= 1;
+                c = f == 0 ? 0 : 1;                            // workerload.rs:133-141
+            }
+            if (!any || c < best) best = c;
+            any = true;
         }
-        if (!any || c < best) best = c;
-        any = true;
+        const int64_t rem = s_rem[wl];
+        const bool time_ok = rem == INT64_MAX || (rem >= 0 && (uint64_t)rem >= s_time[v]);  // worker.rs:320-326
+        const size_t t = (size_t)(w0 + wl) * NV + v;
+        flags[t] = (imm ? 1 : 0) | (cap ? 2 : 0) | (time_ok ? 4 : 0);
+        tmc[t] = any ? (uint32_t)best : 0;
     }
-    int64_t rem = remaining_ns[w];
-    bool time_ok = rem == INT64_MAX || (rem >= 0 && (uint64_t)rem >= rt.variant_min_time_ns[v]);  // worker.rs:320-326
-    flags[t] = (imm ? 1 : 0) | (cap ? 2 : 0) | (time_ok ? 4 : 0);
-    tmc[t] = any ? (uint32_t)best : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ K5a
-// One wavefront per (key, sweep) unit: bit row [c_j > s] over the key's workers in Map iteration order (one __ballot per 64
-// workers), exclusive prefix popcount per word, and T_k(s) = sum_j min(c_j, s).
-__global__ void __launch_bounds__(256) k_sweep_bits(MapKeys mk, uint32_t n_units) {
-    const uint32_t unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (unit >= n_units) return;
-    const uint32_t lane = lane_id();
-    uint32_t lo = 0, hi = mk.n_keys;  // last key with key_t_off[k] <= unit
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (mk.key_t_off[mid] <= unit) lo = mid; else hi = mid; }
-    const uint32_t k = lo, s = unit - mk.key_t_off[k];
+// Grid (sweep quad, key): a workgroup stages its key's counts (Map iteration order) in LDS, then each of its 4 wavefronts
+// builds the bit row of ONE sweep s: lane l assembles word l = [c_j > s] for j in [64 l, 64 l + 64) from LDS (row-padded,
+// conflict-free), a wave scan of the popcounts gives the per-word exclusive prefix, and T_k(s) = sum_j min(c_j, s).
+static const uint32_t SWEEP_LDS_COUNTS = 24576;  // workers per key whose counts fit the LDS staging (96 KiB + padding)
+
+__global__ void __launch_bounds__(256) k_sweep_bits(MapKeys mk) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *s_c = reinterpret_cast<uint32_t *>(smem);  // count of position j at s_c[j + (j >> 6)]
+    const uint32_t k = blockIdx.y, lane = lane_id();
+    const uint32_t t0 = mk.key_t_off[k], n_sweeps = mk.key_t_off[k + 1] - t0;  // sweeps 0..maxc
+    if (blockIdx.x * 4 >= n_sweeps) return;
     const uint32_t nk = mk.key_ord_off[k + 1] - mk.key_ord_off[k];
     const uint32_t *cnts = mk.ord_cnt + mk.key_ord_off[k];
     const uint32_t words = (nk + 63) >> 6;
+    for (uint32_t j = threadIdx.x; j < words * 64; j += blockDim.x) s_c[j + (j >> 6)] = j < nk ? cnts[j] : 0u;
+    __syncthreads();
+    const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_sweeps) return;
     const size_t row = (size_t)mk.key_bits_off[k] + (size_t)s * words;
-    uint32_t running = 0, summin = 0;
-    for (uint32_t wd = 0; wd < words; wd++) {
-        const uint32_t j = wd * 64 + lane;
-        const uint32_t c = j < nk ? cnts[j] : 0u;
-        const uint64_t m = __ballot(c > s);
-        summin += c < s ? c : s;
-        if (lane == 0) { mk.bits[row + wd] = m; mk.pre[row + wd] = running; }
-        running += (uint32_t)__popcll(m);
+    uint32_t carry = 0, summin = 0;
+    for (uint32_t w0 = 0; w0 < words; w0 += 64) {
+        const uint32_t wd = w0 + lane;
+        uint64_t m = 0;
+        if (wd < words) {
+            const uint32_t *c = s_c + (size_t)wd * 65;
+#pragma unroll 8
+            for (uint32_t i = 0; i < 64; i++) { const uint32_t cv = c[i]; m |= (uint64_t)(cv > s) << i; summin += cv < s ? cv : s; }
+        }
+        const uint32_t pc = (uint32_t)__popcll(m);
+        uint32_t incl = pc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += t; }
+        if (wd < words) { mk.bits[row + wd] = m; mk.pre[row + wd] = carry + incl - pc; }
+        carry += __shfl(incl, 63, 64);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) summin += __shfl_xor(summin, off, 64);
-    if (lane == 0) mk.t_sweep[unit] = summin;
+    if (lane == 0) mk.t_sweep[t0 + s] = summin;
 }
 
 // ------------------------------------------------------------------------------------------------ K5b
 // One workgroup per worker.  LDS: e_task u64[max_items] | e_lvl u16[max_items] | e_meta u16[max_items] | k_start u32[n_keys+1]
-// | k_pos u32[n_keys] | k_cnt u32[n_keys] | misc u32[4]
+// | k_pos | k_cnt | k_rq | k_seg | k_toff | k_boff | k_words  (u32[n_keys] each) | k_var u8[n_keys] (padded) | misc u32[4]
 __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, const uint64_t *__restrict__ sel_task,
                                                         const uint16_t *__restrict__ sel_level, uint32_t max_items,
                                                         uint64_t *__restrict__ rec_task, uint8_t *__restrict__ rec_variant,
                                                         uint8_t *__restrict__ rec_kind, uint32_t *__restrict__ err_flag) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t nkeys = mk.n_keys;
     uint64_t *e_task = reinterpret_cast<uint64_t *>(smem);
     uint16_t *e_lvl = reinterpret_cast<uint16_t *>(e_task + max_items);
     uint16_t *e_meta = e_lvl + max_items;  // variant | valid << 8
     uint32_t *k_start = reinterpret_cast<uint32_t *>(e_meta + max_items);  // 12 B per item: stays 4-byte aligned
-    uint32_t *k_pos = k_start + mk.n_keys + 1;
-    uint32_t *k_cnt = k_pos + mk.n_keys;
-    uint32_t *misc = k_cnt + mk.n_keys;  // [0] min level, [1] max level, [2] holes
-    const uint32_t w = blockIdx.x, nkeys = mk.n_keys, lane = lane_id();
+    uint32_t *k_pos = k_start + nkeys + 1;
+    uint32_t *k_cnt = k_pos + nkeys, *k_rq = k_cnt + nkeys, *k_seg = k_rq + nkeys, *k_toff = k_seg + nkeys, *k_boff = k_toff + nkeys, *k_words = k_boff + nkeys;
+    uint32_t *misc = k_words + nkeys;  // [0] min level, [1] max level, [2] holes
+    uint8_t *k_var = reinterpret_cast<uint8_t *>(misc + 4);
+    const uint32_t w = blockIdx.x, lane = lane_id();
     const uint32_t out0 = mk.out_off[w];
-    for (uint32_t k = threadIdx.x; k < nkeys; k += blockDim.x) {
-        const uint32_t pos = mk.wpos[(size_t)k * W + w];
-        k_pos[k] = pos;
-        k_cnt[k] = pos == 0xFFFFFFFFu ? 0u : mk.ord_cnt[mk.key_ord_off[k] + pos];
+    for (uint32_t k = threadIdx.x; k < nkeys; k += blockDim.x) {  // every per-key table in one round of independent loads
+        k_pos[k] = mk.wpos[(size_t)k * W + w];
+        k_cnt[k] = mk.wcnt[(size_t)k * W + w];
+        k_rq[k] = mk.key_rq[k]; k_seg[k] = mk.key_seg_start[k]; k_toff[k] = mk.key_t_off[k]; k_boff[k] = mk.key_bits_off[k];
+        k_words[k] = (mk.key_ord_off[k + 1] - mk.key_ord_off[k] + 63) >> 6;
+        k_var[k] = mk.key_variant[k];
     }
     if (threadIdx.x == 0) { misc[0] = 0xFFFFu; misc[1] = 0; misc[2] = 0; }
     __syncthreads();
@@ -378,7 +429,7 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
     }
     __syncthreads();
     const uint32_t n = k_start[nkeys];
-    if (n > max_items) { if (threadIdx.x == 0) atomicExch(err_flag, 2u); return; }
+    if (n > max_items) { if (threadIdx.x == 0) err_flag[0] = 2u; return; }
     // new prefills first, in queue (request id) order (mapping.rs:266-272)
     uint32_t npf = 0;
     for (uint32_t pi = 0; pi < mk.n_pfq; pi++) {
@@ -397,23 +448,22 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
         uint32_t lo = 0, hi = nkeys;  // last key with k_start[k] <= e (it is the non-empty one)
         while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (k_start[mid] <= e) lo = mid; else hi = mid; }
         const uint32_t k = lo, s = e - k_start[k], pos = k_pos[k];
-        const uint32_t nk = mk.key_ord_off[k + 1] - mk.key_ord_off[k];
-        const uint32_t words = (nk + 63) >> 6;
-        const size_t cell = (size_t)mk.key_bits_off[k] + (size_t)s * words + (pos >> 6);
-        const uint32_t rank = mk.pre[cell] + (uint32_t)__popcll(mk.bits[cell] & ((1ull << (pos & 63)) - 1ull));
-        const uint32_t idx = mk.t_sweep[mk.key_t_off[k] + s] + rank;  // index inside the key's take_tasks() vector
-        const uint32_t q = mk.key_rq[k];
-        const uint32_t pfs = mk.rq_pf_start[q], pfn = mk.rq_pf_n[q];
-        const uint32_t p = mk.key_seg_start[k] + idx;                 // position in the queue's logical sequence
+        const size_t cell = (size_t)k_boff[k] + (size_t)s * k_words[k] + (pos >> 6);
+        const uint32_t q = k_rq[k];
+        const uint32_t pre = mk.pre[cell], tsw = mk.t_sweep[k_toff[k] + s];
+        const uint64_t bw = mk.bits[cell];
+        const uint32_t pfs = mk.rq_pf_start[q], pfn = mk.rq_pf_n[q], sbase = mk.rq_sel_base[q];
+        const uint32_t idx = tsw + pre + (uint32_t)__popcll(bw & ((1ull << (pos & 63)) - 1ull));  // index inside the key's take_tasks() vector
+        const uint32_t p = k_seg[k] + idx;                              // position in the queue's logical sequence
         if (p >= pfs && p < pfs + pfn) {                               // an already-prefilled task: retract/redirect is host work
             e_meta[e] = 0; e_task[e] = 0; e_lvl[e] = 0;
             misc[2] = 1;
         } else {
-            const uint32_t src = mk.rq_sel_base[q] + (p >= pfs + pfn ? p - pfn : p);
+            const uint32_t src = sbase + (p >= pfs + pfn ? p - pfn : p);
             const uint16_t lv = sel_level[src];
             e_task[e] = sel_task[src];
             e_lvl[e] = lv;
-            e_meta[e] = (uint16_t)(mk.key_variant[k] | 0x100u);
+            e_meta[e] = (uint16_t)(k_var[k] | 0x100u);
             atomicMin(&misc[0], (uint32_t)lv);
             atomicMax(&misc[1], (uint32_t)lv);
         }
@@ -480,49 +530,74 @@ hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, cons
     return hipGetLastError();
 }
 
-hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, hipStream_t s) {
+hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, uint32_t *err_in, uint32_t *err_out, hipStream_t s) {
     if (G == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scan_rows, dim3((G + 3) / 4), dim3(256), 0, s, wave_tab, geom.n_waves, geom.tab_stride, G, hist);
+    hipLaunchKernelGGL(k_scan_rows, dim3((G + 3) / 4), dim3(256), 0, s, wave_tab, geom.n_waves, geom.tab_stride, G, hist, err_in, err_out);
     return hipGetLastError();
+}
+
+static __global__ void __launch_bounds__(256) k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_t n, uint32_t Q, uint32_t G, WaveGeom geom,
-                    const uint32_t *wave_off, const uint32_t *take, const uint32_t *base, uint64_t *sel_task, uint16_t *sel_level,
-                    hipStream_t s) {
-    if (n == 0 || geom.n_waves == 0 || G == 0) return hipSuccess;
+                    const uint32_t *wave_off, const uint32_t *take_pinned, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_level,
+                    const void *plan_src, void *plan_dst, size_t plan_bytes, hipStream_t s) {
+    const uint32_t n16 = (uint32_t)((plan_bytes + 15) / 16);
+    const bool sel = n != 0 && geom.n_waves != 0 && G != 0;
     hipError_t e;
-    if (geom.waves_per_block == 4) {
+    if (sel && geom.waves_per_block == 4) {
+        // take/base are staged in LDS once per workgroup: read them from the pinned plan, and let ride-along workgroups
+        // copy the whole plan into HBM for the kernels that follow
         size_t lds = (size_t)6 * G * 4;
         auto kern = k_select<4, true>;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((geom.n_waves + 3) / 4), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves,
-                           geom.tab_stride, wave_off, take, base, sel_task, sel_level);
-    } else {
-        size_t lds = (size_t)G * 4;
-        auto kern = k_select<1, false>;
-        if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(geom.n_waves), dim3(64), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves,
-                           geom.tab_stride, wave_off, take, base, sel_task, sel_level);
+        const uint32_t nsb = (geom.n_waves + 3) / 4, ncb = n16 ? (n16 + 1023) / 1024 : 0;
+        hipLaunchKernelGGL(kern, dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
+                           take_pinned, take_pinned + G, sel_task, sel_level, nsb, reinterpret_cast<const uint4 *>(plan_src), reinterpret_cast<uint4 *>(plan_dst), n16);
+        return hipGetLastError();
     }
+    if (n16) {
+        hipLaunchKernelGGL(k_copy16, dim3((n16 + 1023) / 1024), dim3(256), 0, s, reinterpret_cast<const uint4 *>(plan_src), reinterpret_cast<uint4 *>(plan_dst), n16);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (!sel) return hipSuccess;
+    size_t lds = (size_t)G * 4;
+    auto kern = k_select<1, false>;
+    if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(geom.n_waves), dim3(64), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
+                       take_dev, take_dev + G, sel_task, sel_level, geom.n_waves, (const uint4 *)nullptr, (uint4 *)nullptr, 0u);
     return hipGetLastError();
+}
+
+size_t worker_eval_lds(uint32_t R, uint32_t n_variants, uint32_t n_entries) {
+    return (size_t)32 * R * 16 + 32 * 8 + (size_t)n_entries * 13 + (size_t)n_variants * 12 + 4 + 16;
 }
 
 hipError_t worker_eval(const uint64_t *total, const uint64_t *free_, const int64_t *remaining_ns, uint32_t W, uint32_t R, RequestTable rt,
-                 uint8_t *flags, uint32_t *tmc, hipStream_t s) {
-    uint32_t n = W * rt.n_variants;
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_worker_eval, dim3((n + 255) / 256), dim3(256), 0, s, total, free_, remaining_ns, W, R, rt, flags, tmc);
+                 uint32_t n_entries, uint8_t *flags, uint32_t *tmc, hipStream_t s) {
+    if (W == 0 || rt.n_variants == 0) return hipSuccess;
+    size_t lds = worker_eval_lds(R, rt.n_variants, n_entries);
+    hipError_t e;
+    if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_worker_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_worker_eval, dim3((W + 31) / 32), dim3(256), lds, s, total, free_, remaining_ns, W, R, rt, n_entries, flags, tmc);
     return hipGetLastError();
 }
 
-hipError_t sweep_bits(MapKeys mk, uint32_t n_units, hipStream_t s) {
-    if (n_units == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sweep_bits, dim3((n_units + 3) / 4), dim3(256), 0, s, mk, n_units);
+size_t sweep_bits_lds(uint32_t max_workers_per_key) { return ((size_t)((max_workers_per_key + 63) / 64) * 65 + 1) * 4; }
+
+hipError_t sweep_bits(MapKeys mk, uint32_t max_count, uint32_t max_workers_per_key, hipStream_t s) {
+    if (mk.n_keys == 0) return hipSuccess;
+    if (max_workers_per_key > SWEEP_LDS_COUNTS) return hipErrorInvalidValue;
+    size_t lds = sweep_bits_lds(max_workers_per_key);
+    hipError_t e;
+    if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_bits), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sweep_bits, dim3((max_count + 1 + 3) / 4, mk.n_keys), dim3(256), lds, s, mk);
     return hipGetLastError();
 }
 
 size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys) {
-    return (size_t)max_items * 12 + 4 + ((size_t)3 * n_keys + 1 + 4) * 4;
+    return (size_t)max_items * 12 + ((size_t)8 * n_keys + 1 + 4) * 4 + n_keys + 16;
 }
 
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, uint32_t max_items,

@@ -210,23 +210,33 @@ struct CompSolver {
             rlo2.push_back((best - tol) / cs); rhi2.push_back(INF);
         }
         int m2 = (int)rlo2.size();
-        std::vector<double> flb(lb), fub(ub), cur(bx);
+        std::vector<double> cur(bx);
+        // One tableau carries the columns fixed so far; every probe is a copy of it with one tightened bound, re-optimised by
+        // the dual simplex from the parent basis (a handful of pivots) instead of a cold start.
+        Tab warm; warm.init(n, m2, A2, c, lb, ub, rlo2, rhi2);
+        if (warm.solve(200000) != LP_OPT) { xout = cur; return 1; }  // cannot happen: `cur` is feasible for it
         for (int j = n - 1; j >= 0; j--) {  // last column first
-            double lo = flb[j], hi = cur[j];
+            double lo = lb[j], hi = cur[j];
             bool first = true;
             while (lo < hi) {
                 // first probe just below the current value: most columns fail it immediately
                 double mid = first ? hi - 1 : std::floor((lo + hi) / 2);
                 first = false;
-                Tab t; std::vector<double> pub(fub); pub[j] = mid;
-                t.init(n, m2, A2, c, flb, pub, rlo2, rhi2);
+                Tab t = warm;
+                t.set_ub(j, mid);
                 std::vector<double> sol;
                 bool ok = dfs_feas(t, sol);
-                lp_iters += t.iters;
+                lp_iters += t.iters - warm.iters;
                 if (timed_out) return 2;
                 if (ok) { cur = sol; hi = sol[j]; } else lo = mid + 1;
             }
-            flb[j] = fub[j] = hi;
+            warm.set_lb(j, hi); warm.set_ub(j, hi);
+            if (warm.solve(200000) != LP_OPT) {  // numerically lost the basis: rebuild it with the bounds fixed so far
+                std::vector<double> flb(lb), fub(ub);
+                for (int k = n - 1; k >= j; k--) flb[k] = fub[k] = cur[k];
+                warm = Tab(); warm.init(n, m2, A2, c, flb, fub, rlo2, rhi2);
+                if (warm.solve(200000) != LP_OPT) { xout = cur; return 1; }
+            }
         }
         xout = cur;
         return 1;

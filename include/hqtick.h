@@ -78,6 +78,9 @@ enum {
  * (prefills first with variant None, then assigned)          scheduler/mapping.rs:268-279 */
 enum { HQ_REC_PREFILL = 0, HQ_REC_ASSIGN = 1 };
 
+/* hqtick_config.flags: skip the HIP events that feed hqtick_kernel_stats_last() (saves ~6 API calls per tick) */
+#define HQTICK_FLAG_NO_KERNEL_TIMING 1u
+
 /* SchedulerConfig                                           scheduler/state.rs:5-27 */
 typedef struct hqtick_config {
     uint32_t abi_version;               /* HQTICK_ABI_VERSION */
@@ -85,7 +88,7 @@ typedef struct hqtick_config {
     uint32_t proactive_filling_max;     /* default 40 */
     double mip_time_limit_s;            /* default 5.0 (60.0 under the reference's cfg(test)) */
     int32_t device_index;               /* HIP device ordinal of this ctx */
-    uint32_t flags;                     /* reserved, 0 */
+    uint32_t flags;                     /* HQTICK_FLAG_* */
 } hqtick_config;
 
 /*
@@ -269,8 +272,9 @@ typedef struct hqtick_kernel_stats {
     double level_hist_us;   /* K1: per-(rq,priority) histogram over the ready set   */
     double select_us;       /* K4: selection + scatter of the taken tasks            */
     double distinct_us;     /* K0: distinct-priority discovery                       */
-    double other_us;        /* K5a + K5b: round-robin bit rows + per-worker expansion */
+    double other_us;        /* K5b: per-worker expansion into records               */
     double scan_us;         /* K1b: scan of the per-slice counts                     */
+    double sweep_us;        /* K5a: round-robin bit rows                             */
     double tick_gpu_us;     /* first kernel start -> last kernel end                 */
     uint64_t algorithmic_bytes; /* N*20 + W*R*16 + Q*V*R*9 + A*13 + P*12 */
     uint64_t n_assigned, n_prefilled;
