@@ -52,6 +52,10 @@ def cpu_baseline(snap, ticks: int):
     }
 
 
+# HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md §HBM); None = not collected
+TRAFFIC = {"level_hist": None, "select_scatter": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +64,7 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,7 +91,10 @@ def main():
     from hyperqueue_amd.tick import Tick
 
     snap = workloads.make(args.workload, seed=args.seed + rank)  # replicas: every rank schedules its own (differently seeded) ready set
-    tick = Tick(abi.make_config(time_limit_s=5.0, device_index=local_rank))
+    cfg = abi.make_config(time_limit_s=5.0, device_index=local_rank)
+    if args.no_kernel_timing:
+        cfg.flags |= 1
+    tick = Tick(cfg)
     tick.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
     sc = snap.to_c()
 
@@ -127,13 +135,22 @@ def main():
 
     n_ready, W, R = len(snap.task_id), len(snap.worker_id), snap.n_resources
     mean = lambda k: float(np.mean([s[k] for s in kstats]))
-    k_us = {"distinct_priorities": mean("distinct_us"), "level_hist": mean("level_hist_us"), "select_scatter": mean("select_us"), "expand_mapping": mean("other_us")}
-    # algorithmic bytes each streaming kernel has to move per launch
     sel = assigned + prefilled
-    k_bytes = {"distinct_priorities": n_ready * 8, "level_hist": n_ready * 12, "select_scatter": n_ready * 12 + sel * (8 + 8 + 2), "expand_mapping": sel * (8 + 2 + 8 + 2)}
-    dom = max(k_us, key=lambda k: k_us[k])
-    achieved = k_bytes[dom] / (k_us[dom] * 1e-6) / 1e9 if k_us[dom] > 0 else 0.0
-    peak = 8000.0
+    G = max(1, len(snap.requests) * len(np.unique(snap.task_priority)))  # groups = requests x distinct priority levels
+    # per kernel: HIP-event duration inside the timed ticks (us), algorithmic bytes per launch, what bounds it
+    kernels = {
+        "level_hist": dict(us=mean("level_hist_us"), bytes=n_ready * 12, bound="hbm", what="K1: priority u64 + rq u32 of every ready task"),
+        "scan_waves": dict(us=mean("scan_us"), bytes=G * ((n_ready + 255) // 256) * 8, bound="latency", what="K1b: per-slice counts -> offsets"),
+        "select_scatter": dict(us=mean("select_us"), bytes=n_ready * 8 + sel * 10, bound="hbm", what="K4: id u64 of every ready task + (id, level) of the taken ones"),
+        "sweep_bits": dict(us=mean("sweep_us"), bytes=0, bound="latency", what="K5a: round-robin bit rows"),
+        "expand_mapping": dict(us=mean("other_us"), bytes=sel * 10 + sel * 10, bound="pcie", what="K5b: gathers (id, level) and writes the records straight into pinned host memory"),
+    }
+    for k in kernels.values():
+        k["GBps"] = k["bytes"] / (k["us"] * 1e-6) / 1e9 if k["us"] > 0 else 0.0
+        k["us"] = round(k["us"], 2)
+    hbm = {k: v for k, v in kernels.items() if v["bound"] == "hbm"}
+    dom = max(hbm, key=lambda k: hbm[k]["us"])
+    achieved, peak = kernels[dom]["GBps"], 8000.0
     value = total_assigned * args.steps / elapsed
     out = {
         "metric": "tasks_assigned_per_sec", "value": value, "unit": "tasks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -145,10 +162,14 @@ def main():
         "assigned_per_tick": assigned, "prefilled_per_tick": prefilled,
         "tick_algorithmic_bytes": int(ks["algorithmic_bytes"]),
         "tick_bytes_per_s_end_to_end_GBps": ks["algorithmic_bytes"] / float(np.median(lat)) / 1e9,
-        "kernels_us": {k: round(v, 2) for k, v in k_us.items()},
-        "tick_stages_us": dict(zip(["scan_gpu_phase", "batches", "solve", "mapping_plan_gpu_d2h", "total_in_library"], [round(float(x), 1) for x in np.median(np.asarray(stages), axis=0)])),
+        "tick_bytes_per_s_gpu_kernels_GBps": ks["algorithmic_bytes"] / (sum(v["us"] for v in kernels.values()) * 1e-6) / 1e9,
+        "kernels": kernels,
+        "tick_stages_us": dict(zip(["gpu_phase_a_scans", "batches", "solve", "mapping_plan_gpu_phase_c", "total_in_library"], [round(float(x), 1) for x in np.median(np.asarray(stages), axis=0)])),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                     "algorithmic_bytes_per_launch": k_bytes[dom], "avg_launch_us": k_us[dom], "traffic": None},
+                     "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": kernels[dom]["us"], "traffic": TRAFFIC.get(dom),
+                     "timing": "HIP events on the library's stream, recorded around every launch inside the timed ticks (includes ~2 us of event/dispatch latency per launch; "
+                               "rocprofv3 kernel durations are in profiles/)",
+                     "note": "longest HBM-resident kernel; expand_mapping is longer but PCIe-bound by design (it emits the result into host memory: see kernels.expand_mapping, PCIe Gen5 x16 peak 63 GB/s)"},
     }
     if world == 1 and args.cpu_ticks > 0:
         try:

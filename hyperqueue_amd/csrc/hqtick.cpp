@@ -67,6 +67,7 @@ struct PlanScratch {
     std::vector<uint32_t> key_seg, key_sum, key_rq, key_var_w, key_ord_off, ord_cnt, key_t_off, key_bits_off, wpos, wcnt;
     std::vector<uint32_t> items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, pfl_j, out_off, take_base, mn_first, pack;
     std::vector<uint8_t> now_mn;
+    std::vector<uint32_t> sink_hdr;
     std::vector<std::pair<uint32_t, uint64_t>> retract_pairs;  // (old worker, task)
     // cached worker_map iteration order (emulated) for the last worker-id set
     std::vector<uint32_t> cached_ids, cached_order;
@@ -85,7 +86,7 @@ struct hqtick_ctx {
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
-    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec;
+    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr;
     // workers / requests
     DevBuf d_up, d_vflags, d_vtmc;
     // selection + mapping
@@ -98,6 +99,8 @@ struct hqtick_ctx {
     std::vector<uint32_t> rec_off, retract_off, red_worker, mn_off, mn_worker; std::vector<uint64_t> rec_task, retract_task, red_task, mn_task, new_free;
     std::vector<uint8_t> rec_variant, rec_kind, red_variant, q_loaded;
     hqtick_kernel_stats stats{};
+    uint32_t shard_index = 0, shard_count = 1;       // hqtick_set_shard
+    void *sink = nullptr; size_t sink_bytes = 0;      // hqtick_set_record_sink (device memory)
     double tl[32] = {}; int ntl = 0;  // debug timeline (us since tick start), hqtick_debug_timeline()
 };
 
@@ -527,6 +530,7 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     ps.out_off.assign(W + 1, 0);
     uint32_t max_items = 0;
     for (uint32_t w = 0; w < W; w++) {
+        if (ctx->shard_count > 1 && hqhb::hash_worker_id(s->worker_id[w]) % ctx->shard_count != ctx->shard_index) { ps.out_off[w + 1] = ps.out_off[w]; continue; }  // another rank's worker
         uint32_t npf = 0;
         for (uint32_t pi = 0; pi < n_pfq; pi++) if (ps.pfl_j[(size_t)pi * W + w] != NONE) npf += ps.pfq_size[pi];
         ps.out_off[w + 1] = ps.out_off[w] + npf + ps.n_assign[w];
@@ -576,8 +580,23 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         HQ_HIP(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
         if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
         uint8_t *drec = ctx->h_rec.dev<uint8_t>();  // K5b writes the records straight into the caller-visible pinned buffer (PCIe-bound, no copy command)
-        HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), max_items, reinterpret_cast<uint64_t *>(drec),
-                            drec + o_rv, drec + o_rk, reinterpret_cast<uint32_t *>(drec + o_fl), ctx->stream));
+        uint64_t *k_task = reinterpret_cast<uint64_t *>(drec); uint8_t *k_var = drec + o_rv, *k_kind = drec + o_rk;
+        if (ctx->sink) {  // multi-GPU: records stay in HBM, laid out for the all-gather (include/hqtick.h)
+            const uint32_t cap = hqtick_sink_capacity_records(W, ctx->sink_bytes);
+            if (n_rec > cap || hqtick_sink_bytes(W, cap) > ctx->sink_bytes) return fail(ctx, HQTICK_E_CAPACITY, "record sink too small for this tick");
+            uint8_t *sk = reinterpret_cast<uint8_t *>(ctx->sink);
+            const size_t so_off = 16, so_task = (so_off + (size_t)(W + 1) * 4 + 7) & ~(size_t)7, so_var = so_task + (size_t)cap * 8, so_kind = so_var + cap;
+            // header + rec_off ride in the plan buffer's tail: stage them in pinned memory and copy with the stream
+            std::vector<uint32_t> &hdr = ps.sink_hdr; hdr.assign(4 + W + 1, 0);
+            hdr[0] = n_rec; hdr[1] = W; hdr[2] = HQTICK_SINK_MAGIC; hdr[3] = cap;
+            memcpy(hdr.data() + 4, ps.out_off.data(), (size_t)(W + 1) * 4);
+            if (!ctx->h_sinkhdr.ensure(hdr.size() * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc sink header");
+            memcpy(ctx->h_sinkhdr.p, hdr.data(), hdr.size() * 4);
+            HQ_HIP(hipMemcpyAsync(sk, ctx->h_sinkhdr.p, hdr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            k_task = reinterpret_cast<uint64_t *>(sk + so_task); k_var = sk + so_var; k_kind = sk + so_kind;
+        }
+        HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), max_items, k_task, k_var, k_kind,
+                            reinterpret_cast<uint32_t *>(drec + o_fl), ctx->stream));
         if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         // multi-node tasks: the heads of their queues
         {
@@ -595,6 +614,12 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->stats.select_us = ms * 1000.0;
         if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->stats.sweep_us = ms * 1000.0;
         if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
+    }
+    if (!n_sel && ctx->sink) {  // nothing placed: still publish an empty, well-formed sink
+        if (hqtick_sink_bytes(W, 0) > ctx->sink_bytes) return fail(ctx, HQTICK_E_CAPACITY, "record sink too small for this tick");
+        std::vector<uint32_t> &hdr = ps.sink_hdr; hdr.assign(4 + W + 1, 0);
+        hdr[1] = W; hdr[2] = HQTICK_SINK_MAGIC; hdr[3] = hqtick_sink_capacity_records(W, ctx->sink_bytes);
+        HQ_HIP(hipMemcpy(ctx->sink, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
     }
     mark();  // 8: phase C synced
     // ---------------- assemble the result view ----------------
@@ -627,7 +652,8 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     out->status = status;
     out->n_counts = (uint32_t)ctx->cnt_rq.size(); out->count_rq = ctx->cnt_rq.data(); out->count_variant = ctx->cnt_variant.data();
     out->count_worker = ctx->cnt_worker.data(); out->count_value = ctx->cnt_value.data();
-    out->rec_off = ctx->rec_off.data(); out->rec_task = h_rec_task; out->rec_variant = h_rec_var; out->rec_kind = h_rec_kind;
+    out->rec_off = ctx->rec_off.data();
+    if (!ctx->sink) { out->rec_task = h_rec_task; out->rec_variant = h_rec_var; out->rec_kind = h_rec_kind; }
     out->retract_off = ctx->retract_off.data(); out->retract_task = ctx->retract_task.data();
     out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data();
     out->n_mn = (uint32_t)ctx->mn_task.size(); out->mn_task = ctx->mn_task.data(); out->mn_worker_off = ctx->mn_off.data(); out->mn_worker = ctx->mn_worker.data();
@@ -679,7 +705,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
                       &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre};
     for (DevBuf *b : bufs) b->release();
-    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release();
+    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -747,6 +773,33 @@ int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_w
     ctx->q_loaded.assign(fake->n_workers, 0);
     for (auto &k : cnt.per_key) for (auto &wc : k) if (wc.second > 0) ctx->q_loaded[wc.first] = 1;  // query.rs:73-81
     out->n_workers = fake->n_workers; out->is_loaded = ctx->q_loaded.data(); out->is_optimal = cnt.is_optimal;
+    return 0;
+}
+
+int hqtick_set_shard(hqtick_ctx *ctx, uint32_t shard_index, uint32_t shard_count) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (shard_count > 1 && shard_index >= shard_count) return fail(ctx, HQTICK_E_INVALID, "shard_index >= shard_count");
+    ctx->shard_index = shard_count > 1 ? shard_index : 0; ctx->shard_count = shard_count > 1 ? shard_count : 1;
+    return 0;
+}
+
+size_t hqtick_sink_bytes(uint32_t n_workers, uint32_t capacity_records) {
+    size_t o_task = (16 + (size_t)(n_workers + 1) * 4 + 7) & ~(size_t)7;
+    return (o_task + (size_t)capacity_records * 10 + 15) & ~(size_t)15;
+}
+
+uint32_t hqtick_sink_capacity_records(uint32_t n_workers, size_t capacity_bytes) {
+    size_t fixed = hqtick_sink_bytes(n_workers, 0);
+    if (capacity_bytes < fixed) return 0;
+    size_t cap = (capacity_bytes - fixed) / 10;
+    while (cap && hqtick_sink_bytes(n_workers, (uint32_t)cap) > capacity_bytes) cap--;
+    return cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+}
+
+int hqtick_set_record_sink(hqtick_ctx *ctx, void *device_ptr, size_t capacity_bytes) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & 15)) return fail(ctx, HQTICK_E_INVALID, "record sink must be 16-byte aligned");
+    ctx->sink = device_ptr; ctx->sink_bytes = device_ptr ? capacity_bytes : 0;
     return 0;
 }
 

@@ -405,6 +405,7 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
     uint8_t *k_var = reinterpret_cast<uint8_t *>(misc + 4);
     const uint32_t w = blockIdx.x, lane = lane_id();
     const uint32_t out0 = mk.out_off[w];
+    if (mk.out_off[w + 1] == out0) return;  // no record for this worker (or the worker belongs to another rank's shard)
     for (uint32_t k = threadIdx.x; k < nkeys; k += blockDim.x) {  // every per-key table in one round of independent loads
         k_pos[k] = mk.wpos[(size_t)k * W + w];
         k_cnt[k] = mk.wcnt[(size_t)k * W + w];

@@ -1,0 +1,167 @@
+"""Worker-sharded tick across the GPUs of one node (BASELINE.json north_star).
+
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI).  Every rank runs the tick on the SAME
+snapshot: the ready-set scans, the batches and the placement are replicated and deterministic, so no data has to be
+exchanged before the mapping stage.  Each rank expands and emits the records of the workers it owns,
+
+    owner(worker) = FxHash(worker_id) % world_size                      (hbmap.hash_u32, the hash tako's Map uses)
+
+into a fixed-capacity device buffer (the "record sink", include/hqtick.h), and ONE all-gather of those buffers merges the
+shards' assignment vectors on every rank.  `ShardedTick.tick()` returns the merged result in the same `abi.Result` shape as
+the single-GPU path.
+
+The collective plumbing is backend-agnostic so that it can be tested on CPU (gloo, world_size 2) with a stand-in tick:
+`tick_fn(snapshot) -> abi.Result` produces the FULL result, of which this rank packs only its own shard.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+from . import abi
+from .hbmap import hash_u32
+
+SINK_MAGIC = 0x48515354
+
+
+def owner_of(worker_id: int, world: int) -> int:
+    return hash_u32(int(worker_id)) % world if world > 1 else 0
+
+
+def sink_layout(n_workers: int, cap: int) -> Tuple[int, int, int, int, int]:
+    """(off_off, off_task, off_variant, off_kind, total bytes) — must match hqtick_sink_bytes() in csrc/hqtick.cpp."""
+    o_off = 16
+    o_task = (o_off + (n_workers + 1) * 4 + 7) & ~7
+    o_var = o_task + cap * 8
+    o_kind = o_var + cap
+    total = (o_task + cap * 10 + 15) & ~15
+    return o_off, o_task, o_var, o_kind, total
+
+
+def pack_shard(res: abi.Result, worker_ids, rank: int, world: int, cap: int) -> np.ndarray:
+    """CPU stand-in for what K5b + the sink header copy produce on the GPU: this rank's records in sink layout."""
+    W = len(worker_ids)
+    o_off, o_task, o_var, o_kind, total = sink_layout(W, cap)
+    buf = np.zeros(total, np.uint8)
+    off = np.zeros(W + 1, np.uint32)
+    tasks, variants, kinds = [], [], []
+    for w in range(W):
+        if owner_of(worker_ids[w], world) == rank:
+            for (t, v, k) in res.records[w]:
+                tasks.append(t); variants.append(v); kinds.append(k)
+        off[w + 1] = len(tasks)
+    n = len(tasks)
+    if n > cap:
+        raise ValueError(f"record sink too small: {n} records, capacity {cap}")
+    buf[0:16].view(np.uint32)[:] = [n, W, SINK_MAGIC, cap]
+    buf[o_off:o_off + (W + 1) * 4].view(np.uint32)[:] = off
+    buf[o_task:o_task + n * 8].view(np.uint64)[:] = np.asarray(tasks, np.uint64)
+    buf[o_var:o_var + n] = np.asarray(variants, np.uint8)
+    buf[o_kind:o_kind + n] = np.asarray(kinds, np.uint8)
+    return buf
+
+
+def merge_shards(merged: np.ndarray, world: int, n_workers: int, cap: int) -> List[List[Tuple[int, int, int]]]:
+    """Per-worker record lists from the all-gathered sinks (rank-major)."""
+    o_off, o_task, o_var, o_kind, total = sink_layout(n_workers, cap)
+    assert merged.size == world * total, (merged.size, world, total)
+    records: List[List[Tuple[int, int, int]]] = [[] for _ in range(n_workers)]
+    for r in range(world):
+        b = merged[r * total:(r + 1) * total]
+        n, W, magic, c = b[0:16].view(np.uint32).tolist()
+        if magic != SINK_MAGIC or W != n_workers or c != cap:
+            raise ValueError(f"shard {r}: bad sink header {(n, W, hex(magic), c)}")
+        off = b[o_off:o_off + (W + 1) * 4].view(np.uint32)
+        t = b[o_task:o_task + n * 8].view(np.uint64).tolist()
+        v = b[o_var:o_var + n].tolist()
+        k = b[o_kind:o_kind + n].tolist()
+        for w in range(W):
+            a, e = int(off[w]), int(off[w + 1])
+            if e > a:
+                assert not records[w], f"worker {w} has records in two shards"
+                records[w] = list(zip(t[a:e], v[a:e], k[a:e]))
+    return records
+
+
+class ShardedTick:
+    """`tick(snapshot)` on every rank -> merged `abi.Result` on every rank.
+
+    backend "hip": libhqtick.so with hqtick_set_shard + a device record sink, merged by one RCCL all-gather.
+    backend callable: CPU stand-in (tests): `tick_fn(snapshot) -> abi.Result` (full result), merged by one gloo all-gather.
+    """
+
+    def __init__(self, config: Optional[abi.Config] = None, rank: int = 0, world: int = 1, records_per_shard: int = 1 << 18,
+                 backend="hip", group=None):
+        import torch
+
+        self.torch = torch
+        self.rank, self.world, self.cap, self.group = rank, world, int(records_per_shard), group
+        self.cfg = config or abi.make_config()
+        self.backend = backend
+        self._sink = self._merged = None
+        self._sink_workers = -1
+        if backend == "hip":
+            from .tick import Tick
+
+            self.t = Tick(self.cfg)
+            lib = self.t._lib
+            lib.hqtick_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+            lib.hqtick_set_record_sink.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+            lib.hqtick_sink_bytes.restype = C.c_size_t
+            lib.hqtick_sink_bytes.argtypes = [C.c_uint32, C.c_uint32]
+            rc = lib.hqtick_set_shard(self.t._ctx, rank, world)
+            if rc:
+                raise RuntimeError(f"hqtick_set_shard failed: {rc}")
+
+    def _buffers(self, n_workers: int):
+        if self._sink_workers != n_workers:
+            total = sink_layout(n_workers, self.cap)[4]
+            dev = f"cuda:{self.cfg.device_index}" if self.backend == "hip" else "cpu"
+            self._sink = self.torch.zeros(total, dtype=self.torch.uint8, device=dev)
+            self._merged = self.torch.zeros(total * self.world, dtype=self.torch.uint8, device=dev)
+            self._sink_workers = n_workers
+            if self.backend == "hip":
+                assert self.t._lib.hqtick_sink_bytes(n_workers, self.cap) == total
+                rc = self.t._lib.hqtick_set_record_sink(self.t._ctx, C.c_void_p(self._sink.data_ptr()), C.c_size_t(total))
+                if rc:
+                    raise RuntimeError(f"hqtick_set_record_sink failed: {rc}")
+        return self._sink, self._merged
+
+    def upload_ready(self, task_id, task_priority, task_rq):
+        self.t.upload_ready(task_id, task_priority, task_rq)
+
+    def tick_local(self, sc: abi.SnapshotC, n_workers: int, resident: bool = False):
+        """This rank's shard only, no collective: (local ResultC, this rank's sink as a device tensor)."""
+        sink, _ = self._buffers(n_workers)
+        return self.t.tick_raw(sc, resident=resident), sink
+
+    def tick_device(self, sc: abi.SnapshotC, n_workers: int, resident: bool = False):
+        """The timed part on the GPU: sharded tick + the one all-gather.  Returns (local ResultC, merged device tensor)."""
+        sink, merged = self._buffers(n_workers)
+        res = self.t.tick_raw(sc, resident=resident)  # returns after this shard's kernels have finished (stream-synchronised)
+        if self.world > 1:
+            self.torch.distributed.all_gather_into_tensor(merged, sink, group=self.group)
+        else:
+            merged.copy_(sink)
+        return res, merged
+
+    def tick(self, snap: abi.Snapshot, resident: bool = False) -> abi.Result:
+        W = len(snap.worker_id)
+        if self.backend == "hip":
+            res_c, merged = self.tick_device(snap.to_c(), W, resident)
+            out = abi.parse_result(res_c, W, snap.n_resources)  # records empty here: they live in the sink
+            host = merged.cpu().numpy()
+        else:
+            full = self.backend(snap)
+            sink, merged = self._buffers(W)
+            sink.copy_(self.torch.from_numpy(pack_shard(full, snap.worker_id, self.rank, self.world, self.cap)))
+            if self.world > 1:
+                self.torch.distributed.all_gather_into_tensor(merged, sink, group=self.group)
+            else:
+                merged.copy_(sink)
+            out = full
+            host = merged.numpy()
+        out.records = merge_shards(host, self.world, W, self.cap)
+        return out

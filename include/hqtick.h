@@ -252,6 +252,28 @@ int hqtick_upload_ready(hqtick_ctx *ctx, uint64_t n_ready, const uint64_t *task_
                         const uint64_t *task_priority, const uint32_t *task_rq, int sorted);
 int hqtick_run_resident(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick_result *out);
 
+/*
+ * Multi-GPU: worker sharding.  Every rank (one ctx per GPU) runs the tick on the SAME snapshot — scans, batches and the
+ * placement are replicated and deterministic — but expands and emits records only for the workers it owns:
+ *     FxHash(worker_id) % shard_count == shard_index       (FxHash = fxhash 0.2.1 of the u32 id, as tako's Map uses)
+ * rec_off[] of the result then holds zero-length ranges for the other workers.  shard_count <= 1 switches sharding off.
+ */
+int hqtick_set_shard(hqtick_ctx *ctx, uint32_t shard_index, uint32_t shard_count);
+
+/*
+ * Record sink in DEVICE memory (for the RCCL all-gather that merges the shards' assignment vectors).  While a sink is set,
+ * the records of a tick are written into it instead of host memory (result.rec_task/rec_variant/rec_kind are NULL;
+ * result.rec_off stays valid).  Layout, all little-endian, with cap = hqtick_sink_capacity_records(W, capacity_bytes):
+ *     u32 header[4] = { n_records, W, HQTICK_SINK_MAGIC, cap }
+ *     u32 rec_off[W + 1]        (+ 4 bytes of padding when W is even, so that the next array is 8-byte aligned)
+ *     u64 task[cap]   u8 variant[cap]   u8 kind[cap]
+ * A tick whose records do not fit returns HQTICK_E_CAPACITY.  device_ptr == NULL removes the sink.
+ */
+#define HQTICK_SINK_MAGIC 0x48515354u
+int hqtick_set_record_sink(hqtick_ctx *ctx, void *device_ptr, size_t capacity_bytes);
+size_t hqtick_sink_bytes(uint32_t n_workers, uint32_t capacity_records);
+uint32_t hqtick_sink_capacity_records(uint32_t n_workers, size_t capacity_bytes);
+
 /* compute_new_worker_query(): batches + solver on fake workers, no mapping  scheduler/query.rs:70-71 */
 int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, const hqtick_query_workers *fake,
                  hqtick_query_result *out);

@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime: import it BEFORE libhqtick.so pulls in /opt/rocm's, so the process ends up with one runtime
+# (the sharded path hands torch tensors to the library; bench.py imports torch first for the same reason).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -189,3 +189,62 @@ def test_c3_full_properties(gpu):
         act = float(np.dot(m["rcoef"][a:b], x[m["rcol"][a:b]]))
         if m["rtype"][i] == 1:
             assert act <= m["rhs"][i] + 1e-6
+
+
+# ------------------------------------------------------------------------------------------------------ worker shards
+def _merged_from_sequential_shards(snap, cfg, world, cap):
+    """Runs the `world` shards one after the other on this GPU (no collective) and merges their device sinks."""
+    from hyperqueue_amd import sharded
+
+    W = len(snap.worker_id)
+    sinks, last = [], None
+    for r in range(world):
+        st = sharded.ShardedTick(cfg, rank=r, world=world, records_per_shard=cap)
+        res_c, sink = st.tick_local(snap.to_c(), W)
+        sinks.append(sink.cpu().numpy().copy())
+        last = abi.parse_result(res_c, W, snap.n_resources)
+        owned = [len(x) for x in last.records]
+        assert sum(owned) == 0  # records live in the sink, not in host memory
+        st.t.close()
+    return last, sharded.merge_shards(np.concatenate(sinks), world, W, cap)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_random_snapshots(world, oracle):
+    from oracle.oracle import Oracle
+
+    for seed in (3, 11, 17, 29):
+        env = random_env(seed)
+        snap = env.snapshot()
+        want = Oracle(env.config, canonical=True).tick(snap)
+        last, records = _merged_from_sequential_shards(snap, env.config, world, 512)
+        assert records == want.records
+        assert last.counts == want.counts and last.batches == want.batches and (last.new_free == want.new_free).all()
+
+
+def test_sharded_c3_reduced(gpu, oracle):
+    from hyperqueue_amd import sharded
+
+    snap = workloads.make("c3", n_tasks=60_000, n_workers=48)
+    want = oracle.tick(snap)
+    cfg = abi.make_config(time_limit_s=20.0)
+    last, records = _merged_from_sequential_shards(snap, cfg, 4, 8192)
+    assert records == want.records
+    # every shard emitted only its own workers
+    st = sharded.ShardedTick(cfg, rank=1, world=4, records_per_shard=8192)
+    res_c, sink = st.tick_local(snap.to_c(), len(snap.worker_id))
+    off = np.ctypeslib.as_array(res_c.rec_off, shape=(len(snap.worker_id) + 1,))
+    for w in range(len(snap.worker_id)):
+        mine = sharded.owner_of(int(snap.worker_id[w]), 4) == 1
+        assert (off[w + 1] - off[w] == len(want.records[w])) if mine else (off[w + 1] == off[w])
+
+
+def test_sharded_sink_too_small():
+    from hyperqueue_amd import sharded
+    from hyperqueue_amd.tick import HqTickError
+
+    snap = workloads.make("c2", n_tasks=5_000, n_workers=16)
+    st = sharded.ShardedTick(abi.make_config(), rank=0, world=2, records_per_shard=8)
+    with pytest.raises(HqTickError) as e:
+        st.tick_local(snap.to_c(), len(snap.worker_id))
+    assert e.value.code == abi.HQTICK_E_CAPACITY
