@@ -7,9 +7,9 @@ fractional GPUs, 1024 workers), cold: every worker empty, every task ready.  The
 the timed region starts (hqtick_upload_ready); worker/request tables (50 KB) are part of the snapshot handed over each tick.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3]
-  N > 1: launched by torch.distributed.run, one rank per GPU.  The tick of ONE server does not shard without an exchange
-  step that this round does not implement, so ranks run independent scheduler replicas
-  ("replicas only"): value = N x per-replica rate, scaling "weak", no data-path collective.
+  N > 1: launched by torch.distributed.run, one rank per GPU: ONE scheduler whose workers are hash-sharded over the ranks
+  (hyperqueue_amd/sharded.py); weak scaling — 1024 workers and 1 M ready tasks per GPU; one RCCL all-gather merges
+  the shards' assignment vectors; value = tasks assigned by the whole job per second.
 
 Prints ONE JSON line on rank 0.
 """
@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
+    ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
     ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
     args = ap.parse_args()
 
@@ -90,13 +91,38 @@ def main():
     from hyperqueue_amd import abi, workloads
     from hyperqueue_amd.tick import Tick
 
-    snap = workloads.make(args.workload, seed=args.seed + rank)  # replicas: every rank schedules its own (differently seeded) ready set
+    # N = 1: the plain tick.  N > 1: ONE scheduler whose workers are hash-sharded over the ranks (hyperqueue_amd/sharded.py): every rank
+    # holds the same snapshot (ready set replicated in its HBM), expands the records of its own workers, and one RCCL all-gather merges
+    # the shards' assignment vectors; rank 0 then pulls the merged vector to the host.  Weak scaling: 1024 workers and 1 M ready tasks
+    # per GPU, so every request class stays saturated and each rank emits the same number of records as the N = 1 run.
+    n_workers_per_gpu, n_tasks_per_gpu = {"c2": (256, 100_000), "c3": (1024, 1_000_000), "c4": (4096, 1_000_000)}.get(args.workload, (1024, 1_000_000))
+    snap = workloads.make(args.workload, seed=args.seed, n_tasks=n_tasks_per_gpu * world, n_workers=n_workers_per_gpu * world)
     cfg = abi.make_config(time_limit_s=5.0, device_index=local_rank)
     if args.no_kernel_timing:
         cfg.flags |= 1
-    tick = Tick(cfg)
-    tick.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
     sc = snap.to_c()
+    W_all = len(snap.worker_id)
+    if world == 1 and not args.force_sharded:
+        tick = Tick(cfg)
+        tick.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
+        step = lambda: tick.tick_raw(sc, resident=True)  # returns after the assignment vector is in host memory
+    else:
+        from hyperqueue_amd.sharded import ShardedTick
+
+        st = ShardedTick(cfg, rank=rank, world=world, records_per_shard=int(1.5 * 200 * n_workers_per_gpu))
+        st.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+        tick = st.t
+        host_merged = None
+
+        def step():
+            nonlocal host_merged
+            res, merged = st.tick_device(sc, W_all, resident=True)  # sharded tick + the one all-gather (RCCL)
+            if rank == 0:  # the scheduler process pulls the merged assignment vector to the host
+                if host_merged is None:
+                    host_merged = torch.empty(merged.shape, dtype=merged.dtype, pin_memory=True)
+                host_merged.copy_(merged, non_blocking=True)
+            torch.cuda.synchronize()
+            return res
 
     def barrier():
         if dist is not None:
@@ -104,13 +130,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        tick.tick_raw(sc, resident=True)
+        step()
     barrier()
     lat, kstats, stages = [], [], []
     t_begin = time.perf_counter()
     for _ in range(args.steps):
         t0 = time.perf_counter()
-        res = tick.tick_raw(sc, resident=True)  # returns after the assignment vector is back in host memory
+        res = step()
         lat.append(time.perf_counter() - t0)
         kstats.append(tick.kernel_stats())
         stages.append((res.t_scan_us, res.t_batches_us, res.t_solve_us, res.t_mapping_us, res.t_total_us))
@@ -122,12 +148,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ks = kstats[-1]
-    assigned, prefilled = int(ks["n_assigned"]), int(ks["n_prefilled"])
+    assigned, prefilled = int(ks["n_assigned"]), int(ks["n_prefilled"])  # whole-job counts: the placement is replicated on every rank
     total_assigned = assigned
-    if dist is not None:
-        t = torch.tensor([assigned], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_assigned = int(t.item())
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -143,7 +165,8 @@ def main():
         "scan_waves": dict(us=mean("scan_us"), bytes=G * ((n_ready + 255) // 256) * 8, bound="latency", what="K1b: per-slice counts -> offsets"),
         "select_scatter": dict(us=mean("select_us"), bytes=n_ready * 8 + sel * 10, bound="hbm", what="K4: id u64 of every ready task + (id, level) of the taken ones"),
         "sweep_bits": dict(us=mean("sweep_us"), bytes=0, bound="latency", what="K5a: round-robin bit rows"),
-        "expand_mapping": dict(us=mean("other_us"), bytes=sel * 10 + sel * 10, bound="pcie", what="K5b: gathers (id, level) and writes the records straight into pinned host memory"),
+        "expand_mapping": dict(us=mean("other_us"), bytes=(sel * 10 + sel * 10) // world, bound="pcie" if world == 1 else "hbm-latency",
+                               what="K5b: gathers (id, level) and writes this rank's records " + ("straight into pinned host memory" if world == 1 else "into the HBM record sink")),
     }
     for k in kernels.values():
         k["GBps"] = k["bytes"] / (k["us"] * 1e-6) / 1e9 if k["us"] > 0 else 0.0
@@ -157,7 +180,8 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {n_ready} ready tasks x {W} workers x {R} resource kinds, {len(snap.requests)} request classes, cold tick",
-                   "parallelism": "single" if world == 1 else f"replicas{world}", "ready_set": "resident in HBM", "seed": args.seed},
+                   "parallelism": "single" if world == 1 else f"worker-shards x{world}: FxHash(worker_id) % {world}, ready set replicated, one RCCL all-gather of the record sinks, merged vector D2H on rank 0",
+                   "ready_set": "resident in HBM", "seed": args.seed},
         "p50_tick_ms": 1e3 * float(np.median(lat)), "p95_tick_ms": 1e3 * float(np.percentile(lat, 95)),
         "assigned_per_tick": assigned, "prefilled_per_tick": prefilled,
         "tick_algorithmic_bytes": int(ks["algorithmic_bytes"]),

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -99,8 +100,11 @@ struct hqtick_ctx {
     std::vector<uint32_t> rec_off, retract_off, red_worker, mn_off, mn_worker; std::vector<uint64_t> rec_task, retract_task, red_task, mn_task, new_free;
     std::vector<uint8_t> rec_variant, rec_kind, red_variant, q_loaded;
     hqtick_kernel_stats stats{};
+    uint32_t tpw_hint = 0;                            // HQTICK_TPW (tuning knob): tasks per wavefront slice
     uint32_t shard_index = 0, shard_count = 1;       // hqtick_set_shard
     void *sink = nullptr; size_t sink_bytes = 0;      // hqtick_set_record_sink (device memory)
+    // launch state of the last tick (hqtick_debug_time_kernel re-launches K1 / K4 on it)
+    hqk::WaveGeom last_geom{}; uint32_t last_L = 0, last_Q = 0, last_G = 0; size_t last_tb = 0, last_plan_bytes = 0, last_hist_off = 0; bool last_valid = false;
     double tl[32] = {}; int ntl = 0;  // debug timeline (us since tick start), hqtick_debug_timeline()
 };
 
@@ -278,12 +282,12 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc)
         if (scan) {
             hqk::WaveGeom &g = sc->geom;
             g.waves_per_block = sc->G <= hqk::MAX_GROUPS_4W ? 4 : 1;
-            uint64_t tpw = 256;
+            uint64_t tpw = ctx->tpw_hint ? ctx->tpw_hint : 256;
             while (((N + tpw - 1) / tpw) * sc->G > (1ull << 24)) tpw *= 2;  // keep the per-slice table under 64 MiB
             g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw); g.tab_stride = (g.n_waves + 15u) & ~15u;
             if (!ctx->d_wave_tab.ensure((size_t)g.tab_stride * sc->G * 4) || !ctx->d_gkey.ensure(N * 2 + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
             if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-            HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
+            HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
                                    ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
             if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
             HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
@@ -573,8 +577,9 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         mk.n_pfq = n_pfq; mk.pfq_src = d + o_pqs; mk.pfq_size = d + o_pqz; mk.pfl_j = d + o_pflj; mk.out_off = d + o_out;
         uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
         flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
+        ctx->last_geom = sc.geom; ctx->last_L = L; ctx->last_Q = Q; ctx->last_G = sc.G; ctx->last_tb = o_tb; ctx->last_plan_bytes = pack.size() * 4; ctx->last_valid = true;
         if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-        HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.dev<uint32_t>() + o_tb,
+        HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
                             d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, pack.size() * 4, ctx->stream));
         if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
         HQ_HIP(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
@@ -595,7 +600,7 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
             HQ_HIP(hipMemcpyAsync(sk, ctx->h_sinkhdr.p, hdr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             k_task = reinterpret_cast<uint64_t *>(sk + so_task); k_var = sk + so_var; k_kind = sk + so_kind;
         }
-        HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), max_items, k_task, k_var, k_kind,
+        HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
                             reinterpret_cast<uint32_t *>(drec + o_fl), ctx->stream));
         if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         // multi-node tasks: the heads of their queues
@@ -690,6 +695,7 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     hqtick_ctx *ctx = new hqtick_ctx();
     ctx->cfg = *config; ctx->device = config->device_index;
     ctx->timing = (config->flags & HQTICK_FLAG_NO_KERNEL_TIMING) == 0;
+    if (const char *e = getenv("HQTICK_TPW")) { long v = atol(e); if (v >= 64 && v <= (1 << 20) && v % 64 == 0) ctx->tpw_hint = (uint32_t)v; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     if (!ctx->d_flags.ensure(64) || hipMemset(ctx->d_flags.p, 0, 64) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
@@ -800,6 +806,31 @@ int hqtick_set_record_sink(hqtick_ctx *ctx, void *device_ptr, size_t capacity_by
     if (!ctx) return HQTICK_E_INVALID;
     if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & 15)) return fail(ctx, HQTICK_E_INVALID, "record sink must be 16-byte aligned");
     ctx->sink = device_ptr; ctx->sink_bytes = device_ptr ? capacity_bytes : 0;
+    return 0;
+}
+
+int hqtick_debug_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us) {
+    if (!ctx || !avg_us || iters <= 0) return HQTICK_E_INVALID;
+    if (!ctx->last_valid || !ctx->resident) return fail(ctx, HQTICK_E_INVALID, "hqtick_debug_time_kernel needs a preceding hqtick_run_resident tick that placed tasks");
+    HQ_HIP(hipSetDevice(ctx->device));
+    const uint64_t N = ctx->n_ready; const hqk::WaveGeom g = ctx->last_geom;
+    const uint32_t *d = ctx->d_map.as<uint32_t>();
+    uint32_t *hist_dev = reinterpret_cast<uint32_t *>(ctx->h_a.dev<unsigned char>() + 16);
+    HQ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
+    for (int i = 0; i < iters; i++) {
+        if (which == 0) HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), ctx->last_L, ctx->last_Q, g, ctx->d_wave_tab.as<uint32_t>(),
+                                              ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
+        else if (which == 1) HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, ctx->last_Q, ctx->last_G, g, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + ctx->last_tb,
+                                                        d + ctx->last_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, ctx->last_plan_bytes, ctx->stream));
+        else return fail(ctx, HQTICK_E_INVALID, "which: 0 = level_hist, 1 = select_scatter");
+    }
+    HQ_HIP(hipEventRecord(ctx->ev[11], ctx->stream));
+    if (which == 0)  // K1 left raw counts in the slice table: turn them back into offsets
+        HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, ctx->last_G, hist_dev, ctx->d_flags.as<uint32_t>() + 2, reinterpret_cast<uint32_t *>(ctx->h_a.dev<unsigned char>()) + 2, ctx->stream));
+    HQ_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    HQ_HIP(hipEventElapsedTime(&ms, ctx->ev[10], ctx->ev[11]));
+    *avg_us = (double)ms * 1000.0 / iters;
     return 0;
 }
 

@@ -30,9 +30,10 @@ hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *lev
 
 // K1: per-slice histogram of (level, rq) groups.  wave_tab is [G][tab_stride] (G = L*Q, g = level*Q + rq); also writes
 // the per-task group key gkey[i] = g (GKEY_INVALID for a task whose priority / rq is not in the tables) that K4 re-reads
-// instead of the 12 B/task priority + rq columns.
-hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, uint32_t L, uint32_t Q,
-                WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, hipStream_t s);
+// instead of the 12 B/task priority + rq columns.  levels = descending table in HBM, levels_host = the same on the host (passed in
+// the kernel arguments when L <= 4, so the common case needs neither a staging load nor a barrier).
+hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, const uint64_t *levels_host, uint32_t L,
+                uint32_t Q, WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, hipStream_t s);
 // K1b: exclusive scan of every wave_tab row (in place -> offsets) and the row totals into hist[G].
 // err_in (device) is forwarded to err_out (may be pinned host memory) by the same launch.
 hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, uint32_t *err_in, uint32_t *err_out, hipStream_t s);
@@ -52,13 +53,13 @@ hipError_t worker_eval(const uint64_t *total, const uint64_t *free_, const int64
                  RequestTable rt, uint32_t n_entries, uint8_t *flags, uint32_t *tmc, hipStream_t s);
 size_t worker_eval_lds(uint32_t R, uint32_t n_variants, uint32_t n_entries);  // LDS the launch needs (request table + 32 worker rows)
 
-// K4: select the first take[g] tasks (ascending id) of every group and scatter them to sel_task/sel_level at
-// base[g] + rank.  wave_off = output of scan_waves; slices whose groups are all exhausted exit without reading.
-// The selection plan is `take[G] | base[G]`: take_pinned points at it inside the pinned plan buffer (read once per workgroup
-// into LDS), take_dev at its copy in HBM (used by the large-G variant).  The same launch copies the whole plan
-// (plan_bytes from plan_src, pinned, to plan_dst, HBM) with ride-along workgroups so that no copy-engine command is needed.
+// K4: select the first take[g] tasks (ascending id) of every group and scatter them to sel_task/sel_key at base[g] + rank
+// (sel_key = the task's group key; its priority level is key / Q).  wave_off = output of scan_waves; slices whose groups are
+// all exhausted exit early.  The selection plan is `take[G] | base[G]`: take_host points at it in host memory (passed in the
+// kernel arguments when G <= 64), take_dev at its place inside the HBM copy of the plan.  The same launch copies the whole
+// plan (plan_bytes from plan_src, pinned, to plan_dst, HBM) with ride-along workgroups when G <= 64, else with its own launch.
 hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_t n, uint32_t Q, uint32_t G, WaveGeom geom,
-                    const uint32_t *wave_off, const uint32_t *take_pinned, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_level,
+                    const uint32_t *wave_off, const uint32_t *take_host, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_key,
                     const void *plan_src, void *plan_dst, size_t plan_bytes, hipStream_t s);
 
 // K5: expand per-(request,variant,worker) counts into the per-worker assignment records, in the order
@@ -94,7 +95,7 @@ struct MapKeys {
 };
 hipError_t sweep_bits(MapKeys mk, uint32_t max_count, uint32_t max_workers_per_key, hipStream_t s);
 static const uint32_t SWEEP_MAX_WORKERS = 24576;  // workers per key the round-robin kernel stages in LDS
-hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, uint32_t max_items,
+hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_key, uint32_t Q, uint32_t max_items,
                     uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, hipStream_t s);
 size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys);
 

@@ -136,50 +136,61 @@ __global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------ K1
-// LDS layout: [levels: lds_levels u64][counters: WPB*G u32].  Every wavefront owns a contiguous slice of the ready set and a
-// private counter row, so no block-level synchronisation is needed after the level table is staged.
-template <int WPB>
+// Every wavefront owns a contiguous slice of the ready set and a private LDS counter row.  A lane handles two consecutive
+// tasks per 128-task tile (one dwordx4 of priorities, one dwordx2 of request ids, one dword of group keys), two tiles in
+// flight.  With at most 4 priority levels the level table travels in the kernel arguments: no staging load, no barrier.
+// LDS layout: [levels: lds_levels u64][counters: WPB*G u32].
+struct Levels4 { uint64_t v[4]; };
+
+template <int WPB, bool SMALL_L>
 __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restrict__ prio, const uint32_t *__restrict__ rq, uint64_t n,
-                                                         const uint64_t *__restrict__ levels, uint32_t L, uint32_t Q,
+                                                         const uint64_t *__restrict__ levels, Levels4 l4, uint32_t L, uint32_t Q,
                                                          uint32_t tasks_per_wave, uint32_t n_waves, uint32_t stride, uint32_t lds_levels,
                                                          uint32_t *__restrict__ wave_tab, uint16_t *__restrict__ gkey,
                                                          uint32_t *__restrict__ err_flag) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t G = L * Q;
     uint64_t *s_levels = reinterpret_cast<uint64_t *>(smem);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)lds_levels * 8) + (threadIdx.x >> 6) * G;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)(SMALL_L ? 0 : lds_levels) * 8) + (threadIdx.x >> 6) * G;
     const uint32_t lane = lane_id();
     const uint32_t wave = blockIdx.x * WPB + (threadIdx.x >> 6);
-    for (uint32_t i = threadIdx.x; i < lds_levels; i += blockDim.x) s_levels[i] = levels[i];
+    if (!SMALL_L) for (uint32_t i = threadIdx.x; i < lds_levels; i += blockDim.x) s_levels[i] = levels[i];
     for (uint32_t g = lane; g < G; g += 64) s_cnt[g] = 0;
-    __syncthreads();
+    if (!SMALL_L) __syncthreads();
     if (wave >= n_waves) return;
     const uint64_t *lvp = lds_levels ? s_levels : levels;
-    const uint64_t lv0 = lvp[0];
     const uint64_t begin = (uint64_t)wave * tasks_per_wave;
     const uint64_t end = begin + tasks_per_wave < n ? begin + tasks_per_wave : n;
     uint32_t err = 0;
+    // (priority, rq) -> group key, counting it; GKEY_INVALID for a task the tables do not cover
+    auto classify = [&](uint64_t p, uint32_t q) -> uint16_t {
+        uint32_t lv;
+        if (SMALL_L) lv = p == l4.v[0] ? 0u : (L > 1 && p == l4.v[1]) ? 1u : (L > 2 && p == l4.v[2]) ? 2u : (L > 3 && p == l4.v[3]) ? 3u : L;
+        else { lv = level_of(lvp, L, p); if (lv < L && lvp[lv] != p) lv = L; }
+        if (lv >= L) { err |= 1u; return GKEY_INVALID; }       // priority missing from the level table
+        if (q >= Q) { err |= 2u; return GKEY_INVALID; }        // request id out of range
+        const uint32_t g = lv * Q + q;
+        atomicAdd(&s_cnt[g], 1u);
+        return (uint16_t)g;
+    };
     for (uint64_t b = begin; b < end; b += 256) {
-        uint64_t pv[4];
-        uint32_t qv[4];
-        bool av[4];
+        ulonglong2 pv[2];
+        uint2 qv[2];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {  // 8 independent loads in flight per lane before the first use
-            uint64_t i = b + (uint64_t)u * 64 + lane;
-            av[u] = i < end;
-            pv[u] = av[u] ? prio[i] : 0;
-            qv[u] = av[u] ? rq[i] : 0;
+        for (int u = 0; u < 2; u++) {  // both tiles' loads in flight before the first use
+            const uint64_t i = b + (uint64_t)u * 128 + 2 * lane;
+            if (i + 1 < end) { pv[u] = *reinterpret_cast<const ulonglong2 *>(prio + i); qv[u] = *reinterpret_cast<const uint2 *>(rq + i); }
+            else if (i < end) { pv[u] = make_ulonglong2(prio[i], 0); qv[u] = make_uint2(rq[i], 0); }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (!av[u]) continue;
-            uint64_t i = b + (uint64_t)u * 64 + lane;
-            uint32_t lv = L == 1 ? (pv[u] == lv0 ? 0u : 1u) : level_of(lvp, L, pv[u]);
-            uint16_t key = GKEY_INVALID;
-            if (lv >= L || lvp[lv] != pv[u]) err |= 1u;       // priority missing from the level table
-            else if (qv[u] >= Q) err |= 2u;                   // request id out of range
-            else { uint32_t g = lv * Q + qv[u]; key = (uint16_t)g; atomicAdd(&s_cnt[g], 1u); }
-            gkey[i] = key;
+        for (int u = 0; u < 2; u++) {
+            const uint64_t i = b + (uint64_t)u * 128 + 2 * lane;
+            if (i + 1 < end) {
+                const uint32_t k0 = classify(pv[u].x, qv[u].x), k1 = classify(pv[u].y, qv[u].y);
+                *reinterpret_cast<uint32_t *>(gkey + i) = k0 | (k1 << 16);
+            } else if (i < end) {
+                gkey[i] = classify(pv[u].x, qv[u].x);
+            }
         }
     }
     if (err) atomicOr(err_flag, err);
@@ -230,47 +241,61 @@ __global__ void __launch_bounds__(256) k_scan_rows(uint32_t *__restrict__ wave_t
 }
 
 // ------------------------------------------------------------------------------------------------ K4
-// LDS layout: [counters: WPB*G u32]([take G][base G] when LDS_PLAN).
-template <int WPB, bool LDS_PLAN>
+// LDS layout: [counters: WPB*G u32]([take G][base G] when the plan is staged).
+// PLAN: 0 = take/base arrive in the kernel arguments (G <= 64: no load from pinned or global memory on the critical path),
+//       1 = staged into LDS from `take`/`base`,  2 = read in place (large G, one wavefront per workgroup).
+struct SelPlan64 { uint32_t take[64], base[64]; };
+
+template <int WPB, int PLAN>
 __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict__ task_id, const uint16_t *__restrict__ gkey, uint64_t n,
                                                      uint32_t Q, uint32_t G, uint32_t tasks_per_wave, uint32_t n_waves, uint32_t stride,
                                                      const uint32_t *__restrict__ wave_off, const uint32_t *__restrict__ take,
-                                                     const uint32_t *__restrict__ base, uint64_t *__restrict__ sel_task,
-                                                     uint16_t *__restrict__ sel_level, uint32_t n_select_blocks,
+                                                     const uint32_t *__restrict__ base, SelPlan64 pa, uint64_t *__restrict__ sel_task,
+                                                     uint16_t *__restrict__ sel_key, uint32_t n_select_blocks,
                                                      const uint4 *__restrict__ copy_src, uint4 *__restrict__ copy_dst, uint32_t copy_n16) {
     extern __shared__ __align__(16) unsigned char smem[];
-    if (blockIdx.x >= n_select_blocks) {  // ride-along workgroups: bring the mapping plan from pinned host memory into HBM for K5a/K5b
-        const uint32_t nb = gridDim.x - n_select_blocks;
-        for (uint32_t i = (blockIdx.x - n_select_blocks) * blockDim.x + threadIdx.x; i < copy_n16; i += nb * blockDim.x) copy_dst[i] = copy_src[i];
+    const uint32_t n_copy_blocks = gridDim.x - n_select_blocks;
+    if (blockIdx.x < n_copy_blocks) {  // ride-along workgroups, dispatched FIRST so their PCIe round trip hides under the selection:
+        // bring the mapping plan from pinned host memory into HBM for K5a/K5b
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < copy_n16; i += n_copy_blocks * blockDim.x) copy_dst[i] = copy_src[i];
         return;
     }
+    const uint32_t sel_block = blockIdx.x - n_copy_blocks;
     uint32_t *s_all = reinterpret_cast<uint32_t *>(smem);
     uint32_t *s_cnt = s_all + (threadIdx.x >> 6) * G;
     const uint32_t *tk = take, *bs = base;
-    if (LDS_PLAN) {
+    if (PLAN != 2) {
         uint32_t *s_take = s_all + WPB * G, *s_base = s_take + G;
-        for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) { s_take[g] = take[g]; s_base[g] = base[g]; }
+        for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) { s_take[g] = PLAN == 0 ? pa.take[g] : take[g]; s_base[g] = PLAN == 0 ? pa.base[g] : base[g]; }
         tk = s_take; bs = s_base;
     }
     const uint32_t lane = lane_id();
-    const uint32_t wave = blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (LDS_PLAN) __syncthreads();
+    const uint32_t wave = sel_block * WPB + (threadIdx.x >> 6);
+    if (PLAN != 2) __syncthreads();
     if (wave >= n_waves) return;
+    const uint64_t begin = (uint64_t)wave * tasks_per_wave;
+    const uint64_t end = begin + tasks_per_wave < n ? begin + tasks_per_wave : n;
+    uint16_t kv[4];
+    uint64_t idv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {  // first tile's keys and ids in flight while the slice offsets arrive (wasted only on exhausted slices)
+        uint64_t i = begin + (uint64_t)u * 64 + lane;
+        kv[u] = i < end ? gkey[i] : GKEY_INVALID;
+        idv[u] = i < end ? task_id[i] : 0;
+    }
     bool need = false;  // counters are wave-private: no workgroup barrier from here on
     for (uint32_t g = lane; g < G; g += 64) { uint32_t o = wave_off[(size_t)g * stride + wave]; s_cnt[g] = o; need = need || o < tk[g]; }
     if (!__ballot(need)) return;  // every group this slice could feed is already exhausted by earlier slices
     int nbits = 0; while ((1u << nbits) < G) nbits++;
-    const uint64_t begin = (uint64_t)wave * tasks_per_wave;
-    const uint64_t end = begin + tasks_per_wave < n ? begin + tasks_per_wave : n;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     for (uint64_t b = begin; b < end; b += 256) {
-        uint16_t kv[4];
-        uint64_t idv[4];
+        if (b != begin) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {  // keys and ids of the whole 256-task tile in flight before the first use
-            uint64_t i = b + (uint64_t)u * 64 + lane;
-            kv[u] = i < end ? gkey[i] : GKEY_INVALID;
-            idv[u] = i < end ? task_id[i] : 0;
+            for (int u = 0; u < 4; u++) {
+                uint64_t i = b + (uint64_t)u * 64 + lane;
+                kv[u] = i < end ? gkey[i] : GKEY_INVALID;
+                idv[u] = i < end ? task_id[i] : 0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -285,7 +310,7 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
                 if (rank < tk[g]) {
                     const uint32_t dst = bs[g] + rank;
                     sel_task[dst] = idv[u];
-                    sel_level[dst] = (uint16_t)(g / Q);
+                    sel_key[dst] = (uint16_t)g;  // group key; its level is g / Q (K5b)
                 }
                 if (before == 0) s_cnt[g] = cur + (uint32_t)__popcll(peers);
             }
@@ -390,7 +415,7 @@ __global__ void __launch_bounds__(256) k_sweep_bits(MapKeys mk) {
 // One workgroup per worker.  LDS: e_task u64[max_items] | e_lvl u16[max_items] | e_meta u16[max_items] | k_start u32[n_keys+1]
 // | k_pos | k_cnt | k_rq | k_seg | k_toff | k_boff | k_words  (u32[n_keys] each) | k_var u8[n_keys] (padded) | misc u32[4]
 __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, const uint64_t *__restrict__ sel_task,
-                                                        const uint16_t *__restrict__ sel_level, uint32_t max_items,
+                                                        const uint16_t *__restrict__ sel_key, uint32_t Q, uint32_t max_items,
                                                         uint64_t *__restrict__ rec_task, uint8_t *__restrict__ rec_variant,
                                                         uint8_t *__restrict__ rec_kind, uint32_t *__restrict__ err_flag) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -461,7 +486,7 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
             misc[2] = 1;
         } else {
             const uint32_t src = sbase + (p >= pfs + pfn ? p - pfn : p);
-            const uint16_t lv = sel_level[src];
+            const uint16_t lv = (uint16_t)(sel_key[src] / Q);  // priority level of the task's group
             e_task[e] = sel_task[src];
             e_lvl[e] = lv;
             e_meta[e] = (uint16_t)(k_var[k] | 0x100u);
@@ -510,24 +535,25 @@ hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *lev
 
 static uint32_t lds_levels_for(uint32_t L) { return L <= 1024 ? L : 0; }
 
-hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, uint32_t L, uint32_t Q, WaveGeom geom,
-                uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, hipStream_t s) {
+hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, const uint64_t *levels_host, uint32_t L, uint32_t Q,
+                WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, hipStream_t s) {
     if (n == 0 || geom.n_waves == 0) return hipSuccess;
-    const uint32_t G = L * Q, ll = lds_levels_for(L);
+    const uint32_t G = L * Q;
+    const bool small = L <= 4 && levels_host != nullptr;
+    const uint32_t ll = small ? 0 : lds_levels_for(L);
+    Levels4 l4{};
+    if (small) for (uint32_t i = 0; i < L; i++) l4.v[i] = levels_host[i];
     hipError_t e;
-    if (geom.waves_per_block == 4) {
-        size_t lds = (size_t)ll * 8 + (size_t)4 * G * 4;
-        auto kern = k_level_hist<4>;
-        if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((geom.n_waves + 3) / 4), dim3(256), lds, s, prio, rq, n, levels, L, Q, geom.tasks_per_wave, geom.n_waves,
-                           geom.tab_stride, ll, wave_tab, gkey, err_flag);
-    } else {
-        size_t lds = (size_t)ll * 8 + (size_t)G * 4;
-        auto kern = k_level_hist<1>;
-        if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(geom.n_waves), dim3(64), lds, s, prio, rq, n, levels, L, Q, geom.tasks_per_wave, geom.n_waves,
-                           geom.tab_stride, ll, wave_tab, gkey, err_flag);
-    }
+#define HQK_LAUNCH_HIST(WPB, SMALL, GRID, BLOCK)                                                                                                     \
+    do {                                                                                                                                             \
+        size_t lds = (size_t)ll * 8 + (size_t)(WPB) * G * 4;                                                                                          \
+        auto kern = k_level_hist<WPB, SMALL>;                                                                                                        \
+        if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e; \
+        hipLaunchKernelGGL(kern, dim3(GRID), dim3(BLOCK), lds, s, prio, rq, n, levels, l4, L, Q, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, ll, wave_tab, gkey, err_flag); \
+    } while (0)
+    if (geom.waves_per_block == 4) { if (small) HQK_LAUNCH_HIST(4, true, (geom.n_waves + 3) / 4, 256); else HQK_LAUNCH_HIST(4, false, (geom.n_waves + 3) / 4, 256); }
+    else { if (small) HQK_LAUNCH_HIST(1, true, geom.n_waves, 64); else HQK_LAUNCH_HIST(1, false, geom.n_waves, 64); }
+#undef HQK_LAUNCH_HIST
     return hipGetLastError();
 }
 
@@ -542,32 +568,42 @@ static __global__ void __launch_bounds__(256) k_copy16(const uint4 *__restrict__
 }
 
 hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_t n, uint32_t Q, uint32_t G, WaveGeom geom,
-                    const uint32_t *wave_off, const uint32_t *take_pinned, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_level,
+                    const uint32_t *wave_off, const uint32_t *take_host, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_key,
                     const void *plan_src, void *plan_dst, size_t plan_bytes, hipStream_t s) {
     const uint32_t n16 = (uint32_t)((plan_bytes + 15) / 16);
     const bool sel = n != 0 && geom.n_waves != 0 && G != 0;
     hipError_t e;
-    if (sel && geom.waves_per_block == 4) {
-        // take/base are staged in LDS once per workgroup: read them from the pinned plan, and let ride-along workgroups
-        // copy the whole plan into HBM for the kernels that follow
+    if (sel && geom.waves_per_block == 4 && G <= 64) {
+        // small plan: take/base travel in the kernel arguments; ride-along workgroups copy the whole plan into HBM for K5a/K5b
+        SelPlan64 pa{};
+        for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; }
         size_t lds = (size_t)6 * G * 4;
-        auto kern = k_select<4, true>;
-        if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         const uint32_t nsb = (geom.n_waves + 3) / 4, ncb = n16 ? (n16 + 1023) / 1024 : 0;
-        hipLaunchKernelGGL(kern, dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
-                           take_pinned, take_pinned + G, sel_task, sel_level, nsb, reinterpret_cast<const uint4 *>(plan_src), reinterpret_cast<uint4 *>(plan_dst), n16);
+        hipLaunchKernelGGL((k_select<4, 0>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
+                           reinterpret_cast<uint4 *>(plan_dst), n16);
         return hipGetLastError();
     }
-    if (n16) {
+    if (n16) {  // larger plans: copy first (own launch), then select from the HBM copy
         hipLaunchKernelGGL(k_copy16, dim3((n16 + 1023) / 1024), dim3(256), 0, s, reinterpret_cast<const uint4 *>(plan_src), reinterpret_cast<uint4 *>(plan_dst), n16);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (!sel) return hipSuccess;
+    SelPlan64 none{};
+    if (geom.waves_per_block == 4) {
+        size_t lds = (size_t)6 * G * 4;
+        auto kern = k_select<4, 1>;
+        if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        const uint32_t nsb = (geom.n_waves + 3) / 4;
+        hipLaunchKernelGGL(kern, dim3(nsb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
+                           sel_task, sel_key, nsb, (const uint4 *)nullptr, (uint4 *)nullptr, 0u);
+        return hipGetLastError();
+    }
     size_t lds = (size_t)G * 4;
-    auto kern = k_select<1, false>;
+    auto kern = k_select<1, 2>;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(geom.n_waves), dim3(64), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
-                       take_dev, take_dev + G, sel_task, sel_level, geom.n_waves, (const uint4 *)nullptr, (uint4 *)nullptr, 0u);
+    hipLaunchKernelGGL(kern, dim3(geom.n_waves), dim3(64), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
+                       sel_task, sel_key, geom.n_waves, (const uint4 *)nullptr, (uint4 *)nullptr, 0u);
     return hipGetLastError();
 }
 
@@ -601,13 +637,13 @@ size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys) {
     return (size_t)max_items * 12 + ((size_t)8 * n_keys + 1 + 4) * 4 + n_keys + 16;
 }
 
-hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_level, uint32_t max_items,
+hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_key, uint32_t Q, uint32_t max_items,
                     uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, hipStream_t s) {
     if (W == 0) return hipSuccess;
     size_t lds = expand_mapping_lds(max_items, mk.n_keys);
     hipError_t e;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_mapping), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, W, sel_task, sel_level, max_items, rec_task, rec_variant, rec_kind, err_flag);
+    hipLaunchKernelGGL(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, W, sel_task, sel_key, Q, max_items, rec_task, rec_variant, rec_kind, err_flag);
     return hipGetLastError();
 }
 

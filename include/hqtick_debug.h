@@ -27,6 +27,10 @@ void hqtick_debug_map_order_u32(const uint32_t *keys, uint32_t n, uint32_t *out_
 /* Host wall-clock marks (microseconds since the start of the last tick) at the internal stage boundaries of
  * hqtick_run(); bench tooling only.  Returns the number of marks written. */
 struct hqtick_ctx;
+/* Re-launches one streaming kernel of the last resident tick `iters` times back to back between two HIP events on the ctx's
+ * stream and returns the average launch duration (which: 0 = K1 level_hist, 1 = K4 select_scatter).  Amortises the ~2 us of
+ * event/dispatch latency that a single bracketed launch inside a tick carries. */
+int hqtick_debug_time_kernel(struct hqtick_ctx *ctx, int which, int iters, double *avg_us);
 int hqtick_debug_timeline(const struct hqtick_ctx *ctx, double *out, int cap);
 
 #ifdef __cplusplus
