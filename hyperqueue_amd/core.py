@@ -158,6 +158,23 @@ WAITING, ASSIGNED, RUNNING, PREFILLED, RETRACTING, RUNNING_MN, FINISHED = range(
 
 
 @dataclass
+@dataclass
+class WorkerTypeQuery:
+    """control.rs `WorkerTypeQuery` (crates/tako/src/control.rs:98-123) with the descriptor reduced to (name, units) sums."""
+
+    resources: List[Tuple[str, float]] = field(default_factory=list)
+    partial: bool = False
+    time_limit_s: Optional[float] = None
+    max_sn_workers: int = 1
+    max_workers_per_allocation: int = 1
+    min_utilization: float = 0.0
+
+    @staticmethod
+    def cpus(n, **kw) -> "WorkerTypeQuery":
+        return WorkerTypeQuery(resources=[("cpus", n)], **kw)
+
+
+@dataclass
 class Task:
     id: int
     rq: int
@@ -174,6 +191,7 @@ class Task:
     def is_sn_running(self): return self.state == RUNNING
     def is_prefilled(self): return self.state == PREFILLED
     def is_retracting(self): return self.state == RETRACTING
+    def is_mn_running(self): return self.state == RUNNING_MN
 
 
 @dataclass
@@ -235,7 +253,10 @@ class SchedEnv:
 
     @property
     def n_resources(self) -> int:
-        return len(self.resource_names)
+        # GlobalResourceMapping::n_resources() counts NAMED resources (map.rs:76); a request may still carry an id nobody named
+        # (tests/test_query.rs:735-755) — workers simply hold 0 of it.  The ABI wants every entry id < R, so R covers both.
+        used = max([e[0] + 1 for vs in self.requests for v in vs for e in v["entries"]], default=0)
+        return max(len(self.resource_names), used)
 
     # -- tasks -----------------------------------------------------------------------------------------
     def new_task(self, builder: Optional[TaskBuilder] = None) -> int:
@@ -499,6 +520,57 @@ class SchedEnv:
         res = backend.tick(self.snapshot())
         self.apply(res)
         return res
+
+    def new_worker_query(self, backend, queries: List[WorkerTypeQuery]):
+        """compute_new_worker_query  scheduler/query.rs:12-131: fake workers per query (ids above every real id, `MAX` amounts
+        for the resources a partial query does not name), batches + solver through `backend.query`, then the counts per query
+        and the multi-node allocations (pure queue bookkeeping, query.rs:97-124).
+        Returns (single_node_workers_per_query, [(worker_type, worker_per_allocation, max_allocations)])."""
+        for q in queries:  # query.rs:22-26: every named resource gets an id
+            for name, _ in q.resources:
+                self.new_named_resource(name)
+        R = self.n_resources
+        names = sorted(self.resource_names, key=lambda n: self.resource_names[n])
+        ids, totals, rem, mu = [], [], [], []
+        next_id = max([self.worker_id_counter] + list(self.workers)) + 1
+        for q in queries:
+            for _ in range(q.max_sn_workers):
+                named = set(self.resource_names.values())
+                row = [abi.HQ_AMOUNT_MAX if (q.partial and r in named) else 0 for r in range(R)]  # query.rs:33-47: only NAMED resources
+                for name, units in q.resources:
+                    row[self.resource_names[name]] = amount(units)
+                ids.append(next_id); next_id += 1
+                totals.append(row)
+                rem.append(abi.HQ_NO_TIME_LIMIT if q.time_limit_s is None else int(round(q.time_limit_s * 1e9)))
+                mu.append(q.min_utilization)
+        snap = self.snapshot()
+        if ids:
+            loaded, _opt = backend.query(snap, np.asarray(ids, np.uint32), np.asarray(totals, np.uint64).reshape(len(ids), R), np.asarray(rem, np.int64), np.asarray(mu, np.float32))
+        else:
+            loaded = np.zeros(0, bool)
+        counts, k = [], 0
+        for q in queries:
+            counts.append(int(np.sum(loaded[k:k + q.max_sn_workers]))); k += q.max_sn_workers
+        allocs = []
+        for rq, variants in enumerate(self.requests):  # task_queues.iter(): one queue per request id
+            v0 = variants[0]
+            if v0["n_nodes"] == 0:
+                continue
+            for i, q in enumerate(queries):
+                if q.time_limit_s is not None and v0["min_time_ns"] > int(round(q.time_limit_s * 1e9)):
+                    continue
+                if q.max_workers_per_allocation >= v0["n_nodes"]:
+                    allocs.append((i, v0["n_nodes"], len(self.ready[rq])))
+                    break
+        allocs.sort(key=lambda a: (a[0], a[1]))
+        return counts, allocs
+
+    def cancel_task(self, tid: int):
+        """on_cancel_tasks restricted to what the tick observes (server/reactor.rs:706-790): a waiting task leaves its queue."""
+        t = self.tasks[tid]
+        assert t.state == WAITING
+        self.ready[t.rq].discard(tid)
+        t.state = FINISHED
 
     # -- bookkeeping used by tests ----------------------------------------------------------------------
     def assigned_counts(self) -> List[int]:

@@ -8,7 +8,7 @@ CPU oracle (pins the oracle), tests/test_gpu_golden.py runs them through the HIP
 from __future__ import annotations
 
 from hyperqueue_amd import abi
-from hyperqueue_amd.core import SchedEnv, TaskBuilder as TB, WorkerBuilder as WB
+from hyperqueue_amd.core import SchedEnv, TaskBuilder as TB, WorkerBuilder as WB, WorkerTypeQuery as WQ
 from refharness import TestCase
 
 
@@ -553,6 +553,321 @@ def test_schedule_mn_simple(backend):  # mn:89-160 (first tick + refill after fi
     rt.schedule(backend)
     ws2 = rt.task(t2).mn_workers
     assert ws2 is not None and len(ws2) == 2 and rt.task(t1).is_waiting()
+
+
+def _mn_status(ws, w):
+    return "root" if ws and ws[0] == w else ("nonroot" if ws and w in ws else "none")
+
+
+def test_schedule_mn_reserve(backend):  # mn:138-196: a finished MN task frees its workers for the next one, one tick each
+    rt = env()
+    ws = rt.new_workers_cpus([1, 1, 1])
+    t1 = rt.new_task(TB().user_priority(10).n_nodes(3)); t2 = rt.new_task(TB().user_priority(5).n_nodes(2)); t3 = rt.new_task(TB().user_priority(0).n_nodes(3))
+    rt.schedule(backend)
+    ws1 = rt.task(t1).mn_workers
+    assert ws1 is not None and sorted(ws1) == sorted(ws) and rt.task(t2).is_waiting() and rt.task(t3).is_waiting()
+    rt.finish_task(t1, ws1[0])
+    rt.schedule(backend)
+    ws2 = rt.task(t2).mn_workers
+    assert ws2 is not None and len(ws2) == 2 and set(ws2) <= set(ws) and rt.task(t3).is_waiting()
+    rt.finish_task(t2, ws2[0])
+    rt.schedule(backend)
+    ws3 = rt.task(t3).mn_workers
+    assert ws3 is not None and sorted(ws3) == sorted(ws)
+    rt.finish_task(t3, ws3[0])
+    r = rt.schedule(backend)
+    assert r.mn == [] and all(not recs for recs in r.records)
+
+
+def test_schedule_mn_fill(backend):  # mn:199-214: 3 + 5 + 1 + 2 nodes fill all 11 workers
+    rt = env()
+    rt.new_workers_cpus([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+    ts = [rt.new_task(TB().n_nodes(n)) for n in (3, 5, 1, 2)]
+    rt.schedule(backend)
+    assert all(w.mn_task is not None for w in rt.workers.values())
+    assert all(rt.task(t).is_mn_running() for t in ts)
+
+
+def test_mn_not_enough(backend):  # mn:217-237
+    rt = env()
+    rt.new_workers_cpus([4])
+    ts = [rt.new_task(TB().n_nodes(n)) for n in (3, 5, 11, 2)]
+    rt.schedule(backend)
+    assert all(w.mn_task is None for w in rt.workers.values())
+    assert all(rt.task(t).is_waiting() for t in ts)
+
+
+def test_mn_sleep_wakeup_one_by_one(backend):  # mn:240-263
+    rt = env()
+    t1 = rt.new_task(TB().n_nodes(4).user_priority(10))
+    rt.new_workers_cpus([4, 1])
+    rt.schedule(backend)
+    assert rt.task(t1).is_waiting()
+    t2 = rt.new_task(TB().n_nodes(2).user_priority(1))
+    rt.schedule(backend)
+    assert rt.task(t1).is_waiting() and rt.task(t2).is_mn_running()
+    rt.finish_task(t2, rt.task(t2).mn_workers[0])
+    rt.new_worker(WB(1)); rt.new_worker(WB(1))
+    rt.schedule(backend)
+    assert rt.task(t1).is_mn_running()
+
+
+def test_mn_sleep_wakeup_at_once(backend):  # mn:266-275
+    rt = env()
+    rt.new_workers_cpus([4, 1])
+    t1 = rt.new_task(TB().n_nodes(4).user_priority(10)); t2 = rt.new_task(TB().n_nodes(2).user_priority(1))
+    rt.schedule(backend)
+    assert rt.task(t1).is_waiting() and rt.task(t2).is_mn_running()
+
+
+def test_mn_schedule_on_groups(backend):  # mn:278-288: two workers in different groups cannot host a 2-node task
+    rt = env()
+    rt.new_worker(WB(1).group("group1")); rt.new_worker(WB(1).group("group2"))
+    t1 = rt.new_task(TB().n_nodes(2))
+    rt.schedule(backend)
+    assert rt.task(t1).is_waiting()
+
+
+def test_schedule_mn_time_request1(backend):  # mn:291-306
+    rt = env()
+    rt.new_worker(WB(1)); rt.new_worker(WB(1).time_limit_s(29_999)); rt.new_worker(WB(1).time_limit_s(30_001))
+    t1 = rt.new_task(TB().n_nodes(3).time_request(30_000))
+    rt.schedule(backend)
+    assert rt.task(t1).is_waiting()
+    t2 = rt.new_task(TB().n_nodes(2).time_request(30_000))
+    rt.schedule(backend)
+    assert rt.task(t1).is_waiting() and rt.task(t2).is_mn_running()
+
+
+def test_schedule_mn_time_request2(backend):  # mn:309-317
+    rt = env()
+    rt.new_worker(WB(1).time_limit_s(59_999)); rt.new_worker(WB(1).time_limit_s(29_999)); rt.new_worker(WB(1).time_limit_s(30_001))
+    t1 = rt.new_task(TB().n_nodes(3).time_request(23_998))
+    rt.schedule(backend)
+    assert rt.task(t1).is_mn_running()
+
+
+def test_schedule_mn_and_sn1(backend):  # mn:320-328
+    rt = env()
+    rt.new_workers_cpus([4, 4])
+    t1 = rt.new_task(TB().n_nodes(2).user_priority(2)); t2 = rt.new_task(TB().cpus(4).user_priority(1))
+    rt.schedule(backend)
+    assert rt.task(t1).is_mn_running() and rt.task(t2).is_waiting()
+
+
+def test_schedule_mn_and_sn2(backend):  # mn:331-339
+    rt = env()
+    rt.new_workers_cpus([4, 4])
+    t1 = rt.new_task(TB().n_nodes(2).user_priority(1)); t2 = rt.new_task(TB().cpus(4).user_priority(2))
+    rt.schedule(backend)
+    assert rt.task(t1).is_waiting() and rt.task(t2).is_assigned()
+
+
+def test_schedule_mn_and_sn3(backend):  # mn:342-350
+    rt = env()
+    rt.new_workers_cpus([4, 4])
+    t1 = rt.new_task(TB().n_nodes(2).user_priority(1)); t2 = rt.new_task(TB().cpus(4).user_priority(1))
+    rt.schedule(backend)
+    assert rt.task(t1).is_mn_running() and rt.task(t2).is_waiting()
+
+
+def test_schedule_mn_and_sn4(backend):  # mn:353-361
+    rt = env()
+    rt.new_workers_cpus([4, 3, 4])
+    t1 = rt.new_task(TB().n_nodes(2).user_priority(1)); t2 = rt.new_task(TB().cpus(4).user_priority(1))
+    rt.schedule(backend)
+    assert rt.task(t1).is_mn_running() and rt.task(t2).is_assigned()
+
+
+# ---------------------------------------------------------------------------------------------- autoalloc what-if query
+# tests/test_query.rs (q:<lines>): compute_new_worker_query on fake workers; multi_node_allocations = (type, nodes, max)
+def test_query_no_tasks(backend):  # q:12-28
+    rt = env()
+    assert rt.new_worker_query(backend, [WQ.cpus(4, max_sn_workers=2)]) == ([0], [])
+
+
+def test_query_enough_workers(backend):  # q:31-52
+    rt = env()
+    rt.new_workers_cpus([2, 3]); rt.new_tasks_cpus([3, 1, 1])
+    rt.schedule(backend)
+    assert rt.new_worker_query(backend, [WQ.cpus(4, max_sn_workers=2)]) == ([0], [])
+
+
+def test_query_no_enough_workers1(backend):  # q:55-85
+    rt = env()
+    rt.new_workers_cpus([2, 3]); rt.new_tasks_cpus([3, 3, 1])
+    rt.schedule(backend)
+    assert rt.new_worker_query(backend, [WQ.cpus(2, max_sn_workers=2), WQ.cpus(3, max_sn_workers=2)]) == ([0, 1], [])
+
+
+def test_query_enough_workers2(backend):  # q:88-121
+    rt = env()
+    w1 = rt.new_worker_cpus(2)
+    rt.new_task_running(TB(), w1); rt.new_task_assigned(TB(), w1)
+    rt.schedule(backend)
+    assert rt.new_worker_query(backend, [WQ.cpus(2, max_sn_workers=2), WQ.cpus(3, max_sn_workers=2)]) == ([0, 0], [])
+
+
+def test_query_not_enough_workers3(backend):  # q:124-159
+    rt = env()
+    w1 = rt.new_worker_cpus(2)
+    rt.new_task_running(TB(), w1); rt.new_task_assigned(TB(), w1); rt.new_task(TB())
+    rt.schedule(backend)
+    assert rt.new_worker_query(backend, [WQ.cpus(2, max_sn_workers=2), WQ.cpus(3, max_sn_workers=2)]) == ([1, 0], [])
+
+
+def test_query_many_workers_needed(backend):  # q:162-197
+    rt = env()
+    rt.new_workers_cpus([4, 4, 4]); rt.new_tasks(100, TB())
+    rt.schedule(backend)
+    r = rt.new_worker_query(backend, [WQ.cpus(2, max_sn_workers=5), WQ.cpus(1, max_sn_workers=1), WQ.cpus(3, max_sn_workers=200)])
+    assert r == ([5, 1, 26], [])
+
+
+def test_query_multi_node_tasks(backend):  # q:200-246
+    rt = env()
+    rt.new_workers_cpus([4, 4, 4])
+    rt.new_tasks(5, TB().n_nodes(3)); rt.new_tasks(10, TB().n_nodes(6)); rt.new_tasks(5, TB().n_nodes(12))
+    rt.new_tasks(20, TB().n_nodes(3).user_priority(10)); rt.new_task(TB().n_nodes(1))
+    rt.schedule(backend)
+    counts, allocs = rt.new_worker_query(backend, [WQ.cpus(1, max_sn_workers=1, max_workers_per_allocation=3), WQ.cpus(1, max_sn_workers=1, max_workers_per_allocation=11)])
+    assert counts == [0, 0]
+    assert allocs == [(0, 1, 1), (0, 3, 24), (1, 6, 10)]  # 25 three-node tasks, one is running
+
+
+def test_query_multi_node_time_limit(backend):  # q:249-269
+    rt = env()
+    rt.new_task(TB().n_nodes(4).time_request(750))
+    rt.schedule(backend)
+    for secs, allocs in ((740, 0), (760, 1)):
+        _, a = rt.new_worker_query(backend, [WQ.cpus(1, time_limit_s=secs, max_sn_workers=4, max_workers_per_allocation=4)])
+        assert len(a) == allocs
+
+
+def test_query_min_utilization1(backend):  # q:272-302
+    rt = env()
+    rt.new_tasks_cpus([3, 1, 1])
+    rt.schedule(backend)
+    for mu, alloc, cpus in ((0.5, 0, 12), (0.3, 1, 12), (0.8, 0, 12), (1.0, 1, 5), (0.5, 2, 3), (0.7, 1, 3)):
+        assert rt.new_worker_query(backend, [WQ.cpus(cpus, max_sn_workers=2, min_utilization=mu)]) == ([alloc], []), (mu, alloc, cpus)
+
+
+def test_query_min_utilization2(backend):  # q:305-345
+    rt = env()
+    rt.new_named_resource("gpus")
+    rt.new_tasks(2, TB().cpus(10).add_resource(1, 20))
+    rt.schedule(backend)
+    for mu, alloc, cpus, gpus in ((0.49, 1, 29, 40), (0.49, 0, 29, 30), (0.67, 0, 41, 30), (0.50, 0, 41, 200), (0.45, 1, 39, 200)):
+        q = WQ(resources=[("cpus", cpus), ("gpus", gpus)], max_sn_workers=2, min_utilization=mu)
+        assert rt.new_worker_query(backend, [q]) == ([alloc], []), (mu, alloc, cpus, gpus)
+
+
+def test_query_min_utilization3(backend):  # q:348-372
+    rt = env()
+    rt.new_tasks(2, TB().cpus(2))
+    assert rt.new_worker_query(backend, [WQ.cpus(4, max_sn_workers=2, min_utilization=1.0)]) == ([1], [])
+
+
+def test_query_min_utilization_vs_partial(backend):  # q:375-418
+    for cpu_tasks, gpu_tasks, alloc in ((1, 0, 0), (2, 0, 1), (3, 0, 1), (4, 1, 2), (1, 1, 1), (2, 1, 1), (3, 1, 2), (4, 1, 2), (0, 1, 0), (0, 2, 1), (0, 3, 1), (0, 4, 2), (0, 0, 0)):
+        rt = env()
+        rt.new_named_resource("gpus")
+        rt.new_tasks(cpu_tasks, TB().cpus(2)); rt.new_tasks(gpu_tasks, TB().cpus(2).add_resource(1, 1))
+        r = rt.new_worker_query(backend, [WQ.cpus(4, partial=True, max_sn_workers=2, min_utilization=1.0)])
+        assert r == ([alloc], []), (cpu_tasks, gpu_tasks, alloc, r)
+
+
+def test_query_min_utilization_vs_partial2(backend):  # q:421-442
+    for cpu_tasks, alloc in ((1, 1), (2, 1), (3, 1), (4, 1), (0, 0)):
+        rt = env()
+        rt.new_tasks(cpu_tasks, TB().cpus(2))
+        r = rt.new_worker_query(backend, [WQ(resources=[], partial=True, max_sn_workers=2, min_utilization=1.0)])
+        assert r == ([alloc], []), (cpu_tasks, alloc, r)
+
+
+def test_query_min_time2(backend):  # q:445-478
+    rt = env()
+    rt.new_task(TB().cpus(1).time_request(100).next_variant().cpus(4).time_request(50))
+    rt.schedule(backend)
+    for cpus, secs, alloc in ((2, 75, 0), (1, 101, 1), (4, 50, 1)):
+        assert rt.new_worker_query(backend, [WQ.cpus(cpus, time_limit_s=secs, max_sn_workers=2)]) == ([alloc], []), (cpus, secs)
+
+
+def test_query_min_time1(backend):  # q:481-540
+    rt = env()
+    rt.new_task(TB().cpus(1).time_request(100)); rt.new_task(TB().cpus(10).time_request(100))
+    rt.schedule(backend)
+    assert rt.new_worker_query(backend, [WQ.cpus(10, time_limit_s=99, max_sn_workers=2)]) == ([0], [])
+    assert rt.new_worker_query(backend, [WQ.cpus(10, time_limit_s=101, max_sn_workers=2)]) == ([2], [])
+    assert rt.new_worker_query(backend, [WQ.cpus(1, time_limit_s=101, max_sn_workers=2)]) == ([1], [])
+
+
+def test_query_sn_leftovers1(backend):  # q:543-575
+    for n, m in ((1, 0), (4, 0), (8, 0), (9, 1), (12, 1)):
+        rt = env()
+        rt.new_workers_cpus([4]); rt.new_tasks(n, TB().cpus(1).time_request(5_000))
+        rt.schedule(backend)
+        counts, _ = rt.new_worker_query(backend, [WQ.cpus(2, max_sn_workers=2), WQ(resources=[], partial=True, max_sn_workers=2)])
+        assert counts[1] == m, (n, m, counts)
+
+
+def test_query_sn_leftovers2(backend):  # q:578-598
+    for cpus, out in ((1, 0), (2, 3)):
+        rt = env()
+        rt.new_tasks(100, TB().cpus(2))
+        rt.schedule(backend)
+        counts, _ = rt.new_worker_query(backend, [WQ.cpus(cpus, partial=True, max_sn_workers=3)])
+        assert counts == [out]
+
+
+def test_query_sn_leftovers(backend):  # q:601-640
+    rt = env()
+    rt.new_task(TB().cpus(4).time_request(750)); rt.new_task(TB().cpus(8).time_request(1750))
+    rt.schedule(backend)
+    qs = [WQ(resources=[], partial=True, time_limit_s=t, max_sn_workers=3, max_workers_per_allocation=3) for t in (1000, 50, None)]
+    counts, _ = rt.new_worker_query(backend, qs)
+    assert counts == [1, 0, 1]
+
+
+def test_query_partial_query_cpus(backend):  # q:643-682
+    rt = env()
+    rt.new_task_cpus(4); rt.new_tasks(4, TB().cpus(8))
+    rt.schedule(backend)
+    qs = [WQ.cpus(4, partial=True, max_sn_workers=2, max_workers_per_allocation=3), WQ.cpus(16, partial=True, time_limit_s=50, max_sn_workers=5, max_workers_per_allocation=3),
+          WQ(resources=[], partial=True, max_sn_workers=3, max_workers_per_allocation=3)]
+    counts, _ = rt.new_worker_query(backend, qs)
+    assert counts == [1, 2, 0]
+
+
+def test_query_partial_query_gpus1(backend):  # q:685-732
+    for gpus, has_extra, out in ((4, False, 3), (4, True, 3), (None, False, 2), (None, True, 2), (0, False, 0), (0, True, 0), (100, False, 2), (100, True, 2)):
+        rt = env()
+        rt.new_named_resource("gpus"); rt.new_named_resource("foo")
+        b = TB().cpus(1).add_resource(1, 2)
+        if has_extra:
+            b = b.add_resource(2, 1)
+        rt.new_tasks(10, b)
+        rt.schedule(backend)
+        res = [("cpus", 8)] + ([("gpus", gpus)] if gpus is not None else [])
+        counts, _ = rt.new_worker_query(backend, [WQ(resources=res, partial=True, max_sn_workers=3, max_workers_per_allocation=3)])
+        assert counts == [out], (gpus, has_extra, out, counts)
+
+
+def test_query_unknown_do_not_add_extra(backend):  # q:735-755: resource id 1 has no name, so a partial fake worker holds none of it
+    rt = env()
+    rt.new_task(TB()); rt.new_task(TB().cpus(1).add_resource(1, 1)); rt.new_task(TB()); rt.new_task(TB().cpus(1).add_resource(1, 1))
+    counts, _ = rt.new_worker_query(backend, [WQ.cpus(1, partial=True, max_sn_workers=5, max_workers_per_allocation=3)])
+    assert counts == [2]
+
+
+def test_query_after_task_cancel(backend):  # q:758-771
+    rt = env()
+    t1 = rt.new_task_cpus(10)
+    rt.new_worker(WB(1))
+    rt.schedule(backend)
+    rt.cancel_task(t1)
+    counts, _ = rt.new_worker_query(backend, [WQ(resources=[], partial=True, max_sn_workers=5, max_workers_per_allocation=3)])
+    assert counts == [0]
 
 
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]

@@ -27,6 +27,9 @@ class GpuBackend:
     def batches(self, snap):
         return self._t(getattr(snap, "config", None) or abi.make_config()).batches(snap)
 
+    def query(self, snap, *a):
+        return self._t(getattr(snap, "config", None) or abi.make_config()).query(snap, *a)
+
 
 @pytest.fixture(scope="module")
 def backend():

@@ -26,6 +26,9 @@ class OracleBackend:
     def batches(self, snap):
         return self._o(getattr(snap, "config", None) or self.cfg).batches(snap)
 
+    def query(self, snap, *a):
+        return self._o(getattr(snap, "config", None) or self.cfg).query(snap, *a)
+
 
 @pytest.fixture(scope="module")
 def backend():
