@@ -135,8 +135,44 @@ struct CompSolver {
     long nodes = 0, lp_iters = 0;
     // incumbent
     bool have = false; double best = -INF; std::vector<double> bx;
+    bool canonical_done = true;
 
-    bool time_up() { if (timed_out) return true; if ((nodes & 31) == 0 && wall() > deadline) timed_out = true; return timed_out; }
+    long pivots = 0, pivot_limit = -1;  // deterministic work budget of the tie-break phase (wall clock stays the backstop)
+    bool time_up() { if (timed_out) return true; if ((pivot_limit >= 0 && pivots > pivot_limit) || ((nodes & 31) == 0 && wall() > deadline)) timed_out = true; return timed_out; }
+    int solve_counted(Tab &t) { long before = t.iters; int r = t.solve(200000); pivots += t.iters - before; return r; }
+
+    // Primal heuristic: from an integer point inside the bounds (e.g. the floor of an LP solution), keep it only if every row holds,
+    // then raise columns greedily — most valuable first — as far as the rows allow.  The placement models are packing
+    // problems whose LP bound is usually attained, so a maximal point found here often closes the search at the root.
+    std::vector<int> by_cost;
+    void greedy_from(std::vector<double> x) {
+        std::vector<double> act(m, 0.0);
+        for (int i = 0; i < m; i++) { double a = 0.0; const double *row = &A[(size_t)i * n]; for (int j = 0; j < n; j++) a += row[j] * x[j]; act[i] = a; }
+        for (int i = 0; i < m; i++) if (act[i] < rlo[i] - FEAS_TOL || act[i] > rhi[i] + FEAS_TOL) return;
+        if (by_cost.empty()) {
+            by_cost.resize(n); std::iota(by_cost.begin(), by_cost.end(), 0);
+            std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return c[a] > c[b]; });
+        }
+        for (int j : by_cost) {
+            if (c[j] <= 0.0) break;
+            double step = ub[j] - x[j];
+            for (int i = 0; i < m && step >= 1.0; i++) {
+                double a = A[(size_t)i * n + j];
+                if (a > 0.0 && rhi[i] < INF) step = std::min(step, std::floor((rhi[i] - act[i]) / a + 1e-9));
+                else if (a < 0.0 && rlo[i] > -INF) step = std::min(step, std::floor((act[i] - rlo[i]) / -a + 1e-9));
+            }
+            if (step < 1.0) continue;
+            x[j] += step;
+            for (int i = 0; i < m; i++) { double a = A[(size_t)i * n + j]; if (a != 0.0) act[i] += a * step; }
+        }
+        double z = 0.0; for (int j = 0; j < n; j++) z += c[j] * x[j];
+        if (!have || z > best + 1e-12 * std::fabs(best)) { have = true; best = z; bx = x; }
+    }
+    void round_and_repair(const Tab &t) {
+        std::vector<double> x(n);
+        for (int j = 0; j < n; j++) x[j] = std::min(ub[j], std::max(lb[j], std::floor(t.x[j] + INT_TOL)));
+        greedy_from(std::move(x));
+    }
 
     static int pick_fractional(const Tab &t) {
         int j = -1; double bd = INT_TOL;
@@ -151,11 +187,15 @@ struct CompSolver {
     void dfs_opt(Tab &t) {
         nodes++;
         if (time_up()) return;
-        int s = t.solve(200000);
+        int s = solve_counted(t);
         if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return; }
         double z = t.objective();
         if (have && z <= best + 1e-12 * std::fabs(best)) return;
         int j = pick_fractional(t);
+        if (j >= 0 && (nodes == 1 || (nodes & 63) == 0)) {  // root and every 64th node: try to close the gap from this LP point
+            round_and_repair(t);
+            if (have && z <= best + 1e-12 * std::fabs(best)) return;
+        }
         if (j < 0) {
             have = true; best = z; bx.assign(t.x.begin(), t.x.begin() + n);
             for (auto &v : bx) v = std::round(v);
@@ -177,7 +217,7 @@ struct CompSolver {
     bool dfs_feas(Tab &t, std::vector<double> &out) {
         nodes++;
         if (time_up()) return false;
-        int s = t.solve(200000);
+        int s = solve_counted(t);
         if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return false; }
         int j = pick_fractional(t);
         if (j < 0) { out.assign(t.x.begin(), t.x.begin() + n); for (auto &v : out) v = std::round(v); return true; }
@@ -194,6 +234,7 @@ struct CompSolver {
     // returns: 0 infeasible, 1 optimal, 2 incumbent only (time limit)
     int run(bool canonical, std::vector<double> &xout) {
         Tab root; root.init(n, m, A, c, lb, ub, rlo, rhi);
+        greedy_from(lb);
         dfs_opt(root);
         lp_iters += root.iters;
         if (!have) return 0;
@@ -213,6 +254,8 @@ struct CompSolver {
         std::vector<double> cur(bx);
         // One tableau carries the columns fixed so far; every probe is a copy of it with one tightened bound, re-optimised by
         // the dual simplex from the parent basis (a handful of pivots) instead of a cold start.
+        // Budget in simplex pivots, not seconds: every replica of a sharded scheduler must take the same decision here.
+        pivot_limit = pivots + std::max<long>(3000, 4 * pivots);
         Tab warm; warm.init(n, m2, A2, c, lb, ub, rlo2, rhi2);
         if (warm.solve(200000) != LP_OPT) { xout = cur; return 1; }  // cannot happen: `cur` is feasible for it
         for (int j = n - 1; j >= 0; j--) {  // last column first
@@ -227,7 +270,7 @@ struct CompSolver {
                 std::vector<double> sol;
                 bool ok = dfs_feas(t, sol);
                 lp_iters += t.iters - warm.iters;
-                if (timed_out) return 2;
+                if (timed_out) { xout = cur; canonical_done = false; return 1; }  // optimal (phase 1 proved it) but the tie-break ran out of time
                 if (ok) { cur = sol; hi = sol[j]; } else lo = mid + 1;
             }
             warm.set_lb(j, hi); warm.set_ub(j, hi);

@@ -38,6 +38,4 @@ def backend():
 
 @pytest.mark.parametrize("case", golden_cases.ALL_CASES, ids=lambda f: f.__name__)
 def test_golden_gpu(case, backend):
-    if case.__name__ == "test_many_cuts":
-        pytest.skip("tolerance test with a 600-column coupled MILP: exercised by the oracle only in this round")
     case(backend)

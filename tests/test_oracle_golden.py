@@ -55,7 +55,9 @@ class CanonicalOracleBackend(OracleBackend):
 @pytest.mark.parametrize("case", golden_cases.ALL_CASES, ids=lambda f: f.__name__)
 def test_golden_canonical(case):
     if case.__name__ == "test_many_cuts":
-        pytest.skip("tolerance test; canonicalisation of a 600-column model is slow")
+        pytest.skip("tolerance test; canonicalising a 600-column model with one HiGHS call per column is slow")
+    if case.__name__ == "test_schedule_many_distinct_shapes_stays_bounded":
+        pytest.skip("time-bound test; 1200 HiGHS calls to canonicalise would break the bound by construction")
     case(CanonicalOracleBackend())
 
 
