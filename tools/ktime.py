@@ -8,7 +8,8 @@ from hyperqueue_amd.tick import Tick
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-snap = workloads.make(name)
+n_tasks = int(sys.argv[3]) if len(sys.argv) > 3 else None
+snap = workloads.make(name, n_tasks=n_tasks)
 t = Tick(abi.make_config(time_limit_s=5.0))
 t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
 sc = snap.to_c()
@@ -20,6 +21,6 @@ for which, nm, nbytes in ((0, "level_hist", len(snap.task_id) * 12), (1, "select
     for rep in range(3):
         rc = t._lib.hqtick_debug_time_kernel(t._ctx, which, iters, C.byref(us))
         assert rc == 0, t._err()
-    print(f"TPW={os.environ.get('HQTICK_TPW', '256')} {nm}: {us.value:.2f} us/launch back-to-back  -> {nbytes / us.value / 1e3:.0f} GB/s on {nbytes / 1e6:.1f} MB")
+    print(f"N={len(snap.task_id)} TPW={os.environ.get('HQTICK_TPW', '256')} {nm}: {us.value:.2f} us/launch back-to-back  -> {nbytes / us.value / 1e3:.0f} GB/s on {nbytes / 1e6:.1f} MB")
 r = t.tick_raw(sc, resident=True)
 print("tick still consistent:", r.status, t.kernel_stats()["n_assigned"])
