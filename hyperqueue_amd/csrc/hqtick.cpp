@@ -83,7 +83,9 @@ struct hqtick_ctx {
     hipEvent_t ev[12] = {};
     std::string err = "";
     // ready set
-    DevBuf d_tid, d_tprio, d_trq; uint64_t n_ready = 0; bool resident = false;
+    DevBuf d_tid, d_tprio, d_trq; uint64_t n_ready = 0; bool resident = false;  // n_ready = physical length (tombstones included)
+    DevBuf d_tid2, d_tprio2, d_trq2, d_slice, d_add;   // alternate columns + scratch of the resident deltas (hqtick_ready_*)
+    uint64_t n_live = 0; uint32_t last_n_sel = 0; bool last_consumed = true;
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
@@ -577,10 +579,11 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         mk.n_pfq = n_pfq; mk.pfq_src = d + o_pqs; mk.pfq_size = d + o_pqz; mk.pfl_j = d + o_pflj; mk.out_off = d + o_out;
         uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
         flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
+        ctx->last_n_sel = n_sel; ctx->last_consumed = false;
         ctx->last_geom = sc.geom; ctx->last_L = L; ctx->last_Q = Q; ctx->last_G = sc.G; ctx->last_tb = o_tb; ctx->last_plan_bytes = pack.size() * 4; ctx->last_valid = true;
         if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
         HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
-                            d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, pack.size() * 4, ctx->stream));
+                            d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, pack.size() * 4, nullptr, ctx->stream));
         if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
         HQ_HIP(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
         if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
@@ -620,6 +623,7 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->stats.sweep_us = ms * 1000.0;
         if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
     }
+    if (!n_sel) { ctx->last_n_sel = 0; ctx->last_consumed = true; }
     if (!n_sel && ctx->sink) {  // nothing placed: still publish an empty, well-formed sink
         if (hqtick_sink_bytes(W, 0) > ctx->sink_bytes) return fail(ctx, HQTICK_E_CAPACITY, "record sink too small for this tick");
         std::vector<uint32_t> &hdr = ps.sink_hdr; hdr.assign(4 + W + 1, 0);
@@ -709,7 +713,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
-                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre};
+                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add};
     for (DevBuf *b : bufs) b->release();
     ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
@@ -737,7 +741,7 @@ int hqtick_upload_ready(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, co
         HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, task_rq, n * 4, hipMemcpyHostToDevice, ctx->stream));
         HQ_HIP(hipStreamSynchronize(ctx->stream));
     }
-    ctx->n_ready = n; ctx->resident = true; ctx->levels_valid = false;
+    ctx->n_ready = n; ctx->n_live = n; ctx->resident = true; ctx->levels_valid = false; ctx->last_valid = false; ctx->last_consumed = true;
     return 0;
 }
 
@@ -745,6 +749,103 @@ int hqtick_run_resident(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick
     if (!ctx || !out) return HQTICK_E_INVALID;
     return run_tick(ctx, snapshot, out, true);
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- resident ready-set deltas (f1)
+namespace {
+// Drops tombstones and merges `n_add` new tasks (device arrays, ids ascending) into fresh columns; swaps them in.
+int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, const uint32_t *arq, uint32_t n_add) {
+    const uint64_t N = ctx->n_ready, new_n = ctx->n_live + n_add;
+    if (!ctx->d_tid2.ensure(new_n * 8 + 8) || !ctx->d_tprio2.ensure(new_n * 8 + 8) || !ctx->d_trq2.ensure(new_n * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set (rebuild)");
+    if (N == 0) {  // nothing resident: the batch becomes the ready set
+        if (n_add) {
+            HQ_HIP(hipMemcpyAsync(ctx->d_tid2.p, aid, (size_t)n_add * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(ctx->d_tprio2.p, aprio, (size_t)n_add * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            HQ_HIP(hipMemcpyAsync(ctx->d_trq2.p, arq, (size_t)n_add * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    } else {
+        const uint32_t n_slices = (uint32_t)((N + 255) / 256), stride = (n_slices + 15u) & ~15u;
+        if (!ctx->d_slice.ensure((size_t)stride * 4 + 64) || !ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc slice table");
+        uint32_t *flag = ctx->h_q.as<uint32_t>(); flag[0] = 0; flag[1] = 0;
+        hqk::WaveGeom g{256, n_slices, 4, stride};
+        HQ_HIP(hqk::ready_live_count(ctx->d_trq.as<uint32_t>(), N, ctx->d_slice.as<uint32_t>(), ctx->stream));
+        HQ_HIP(hqk::scan_waves(ctx->d_slice.as<uint32_t>(), g, 1, ctx->h_q.dev<uint32_t>() + 1, nullptr, nullptr, ctx->stream));
+        HQ_HIP(hqk::ready_rebuild(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_slice.as<uint32_t>(), aid, aprio, arq, n_add,
+                                  ctx->d_tid2.as<uint64_t>(), ctx->d_tprio2.as<uint64_t>(), ctx->d_trq2.as<uint32_t>(), ctx->h_q.dev<uint32_t>(), ctx->stream));
+        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (flag[1] != ctx->n_live) return fail(ctx, HQTICK_E_DEVICE, "resident ready set: live-task count out of sync");
+        if (flag[0] & 4u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: a task id is already in the ready set");
+    }
+    std::swap(ctx->d_tid, ctx->d_tid2); std::swap(ctx->d_tprio, ctx->d_tprio2); std::swap(ctx->d_trq, ctx->d_trq2);
+    ctx->n_ready = new_n; ctx->n_live = new_n; ctx->last_valid = false; ctx->last_consumed = true;
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+uint64_t hqtick_ready_count(const hqtick_ctx *ctx) { return ctx && ctx->resident ? ctx->n_live : 0; }
+
+int hqtick_ready_consume_last(hqtick_ctx *ctx) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set");
+    if (ctx->last_consumed) return 0;  // nothing handed out since the last consume
+    if (!ctx->last_valid) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_consume_last needs a preceding hqtick_run_resident");
+    HQ_HIP(hipSetDevice(ctx->device));
+    const uint32_t *d = ctx->d_map.as<uint32_t>();
+    // the selection of the last tick once more, writing tombstones instead of the selected ids (same offsets table, same plan)
+    HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), ctx->n_ready, ctx->last_Q, ctx->last_G, ctx->last_geom, ctx->d_wave_tab.as<uint32_t>(),
+                               ctx->h_plan.as<uint32_t>() + ctx->last_tb, d + ctx->last_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), nullptr, nullptr, 0,
+                               ctx->d_trq.as<uint32_t>(), ctx->stream));
+    ctx->n_live -= ctx->last_n_sel; ctx->last_consumed = true; ctx->last_valid = false;
+    if (ctx->n_ready > 4096 && ctx->n_live * 2 < ctx->n_ready) return rebuild_ready(ctx, nullptr, nullptr, nullptr, 0);  // more tombstones than tasks: compact
+    return 0;
+}
+
+int hqtick_ready_remove(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id) {
+    if (!ctx || (n && !task_id)) return HQTICK_E_INVALID;
+    if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set");
+    if (n == 0 || ctx->n_ready == 0) return 0;
+    if (n > 0xFFFFFFFFull) return fail(ctx, HQTICK_E_CAPACITY, "more than 2^32 ids in one delta");
+    HQ_HIP(hipSetDevice(ctx->device));
+    if (!ctx->d_add.ensure(n * 8 + 8) || !ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
+    uint32_t *cnt = ctx->h_q.as<uint32_t>(); cnt[0] = 0;
+    HQ_HIP(hipMemcpyAsync(ctx->d_add.p, task_id, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HQ_HIP(hqk::ready_mark_removed(ctx->d_tid.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), ctx->n_ready, ctx->d_add.as<uint64_t>(), (uint32_t)n, ctx->h_q.dev<uint32_t>(), ctx->stream));
+    HQ_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_live -= cnt[0]; ctx->last_valid = false; ctx->last_consumed = true;
+    return (int)cnt[0];  // number of tasks that were in the set
+}
+
+int hqtick_ready_add(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority, const uint32_t *task_rq) {
+    if (!ctx || (n && (!task_id || !task_priority || !task_rq))) return HQTICK_E_INVALID;
+    if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set (hqtick_upload_ready with n = 0 creates an empty one)");
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFFFull) return fail(ctx, HQTICK_E_CAPACITY, "more than 2^32 ids in one delta");
+    for (uint64_t i = 1; i < n; i++) if (task_id[i - 1] >= task_id[i]) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
+    for (uint64_t i = 0; i < n; i++) if (task_rq[i] == 0xFFFFFFFFu) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
+    HQ_HIP(hipSetDevice(ctx->device));
+    size_t o_p = (n * 8 + 15) & ~(size_t)15, o_q = o_p * 2;
+    if (!ctx->d_add.ensure(o_q + n * 4 + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
+    unsigned char *d = ctx->d_add.as<unsigned char>();
+    HQ_HIP(hipMemcpyAsync(d, task_id, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HQ_HIP(hipMemcpyAsync(d + o_p, task_priority, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HQ_HIP(hipMemcpyAsync(d + o_q, task_rq, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + o_p), reinterpret_cast<const uint32_t *>(d + o_q), (uint32_t)n);
+}
+
+int hqtick_ready_compact(hqtick_ctx *ctx) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set");
+    if (ctx->n_live == ctx->n_ready) return 0;
+    HQ_HIP(hipSetDevice(ctx->device));
+    return rebuild_ready(ctx, nullptr, nullptr, nullptr, 0);
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_workers *fake, hqtick_query_result *out) {
     if (!ctx || !out || !fake) return HQTICK_E_INVALID;
@@ -821,7 +922,7 @@ int hqtick_debug_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_
         if (which == 0) HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), ctx->last_L, ctx->last_Q, g, ctx->d_wave_tab.as<uint32_t>(),
                                               ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
         else if (which == 1) HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, ctx->last_Q, ctx->last_G, g, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + ctx->last_tb,
-                                                        d + ctx->last_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, ctx->last_plan_bytes, ctx->stream));
+                                                        d + ctx->last_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, ctx->last_plan_bytes, nullptr, ctx->stream));
         else return fail(ctx, HQTICK_E_INVALID, "which: 0 = level_hist, 1 = select_scatter");
     }
     HQ_HIP(hipEventRecord(ctx->ev[11], ctx->stream));

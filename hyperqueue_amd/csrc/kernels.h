@@ -21,6 +21,7 @@ struct WaveGeom {
     uint32_t tab_stride;      // row stride of wave_tab (n_waves rounded up to 16 entries)
 };
 static const uint16_t GKEY_INVALID = 0xFFFFu;
+static const uint32_t RQ_TOMBSTONE = 0xFFFFFFFFu;  // rq column value of a task that left the resident ready set
 
 // K0: insert every task priority into the open-addressing set `set` (PRIO_SET_CAP slots, pre-filled with PRIO_EMPTY).
 // flags[0] |= 1 when some priority equals PRIO_EMPTY itself, flags[1] = 1 on overflow.
@@ -60,7 +61,8 @@ size_t worker_eval_lds(uint32_t R, uint32_t n_variants, uint32_t n_entries);  //
 // plan (plan_bytes from plan_src, pinned, to plan_dst, HBM) with ride-along workgroups when G <= 64, else with its own launch.
 hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_t n, uint32_t Q, uint32_t G, WaveGeom geom,
                     const uint32_t *wave_off, const uint32_t *take_host, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_key,
-                    const void *plan_src, void *plan_dst, size_t plan_bytes, hipStream_t s);
+                    const void *plan_src, void *plan_dst, size_t plan_bytes, uint32_t *mark_rq, hipStream_t s);
+// mark_rq != NULL: consume mode — instead of scattering, every selected task gets rq = RQ_TOMBSTONE in that column.
 
 // K5: expand per-(request,variant,worker) counts into the per-worker assignment records, in the order
 // WorkerTaskMapping::send_messages emits them (scheduler/mapping.rs:36-131,259-282).
@@ -98,5 +100,12 @@ static const uint32_t SWEEP_MAX_WORKERS = 24576;  // workers per key the round-r
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_key, uint32_t Q, uint32_t max_items,
                     uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, hipStream_t s);
 size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys);
+
+// Resident ready-set deltas: tombstone the given ids (sorted id column, binary search), count live tasks per
+// 256-task slice, and rebuild the columns dropping tombstones while merging a sorted batch of new tasks.
+hipError_t ready_mark_removed(const uint64_t *ids, uint32_t *rq, uint64_t n, const uint64_t *rm, uint32_t n_rm, uint32_t *n_done, hipStream_t s);
+hipError_t ready_live_count(const uint32_t *rq, uint64_t n, uint32_t *slice_cnt, hipStream_t s);
+hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint32_t *orq, uint64_t n, const uint32_t *slice_off, const uint64_t *aid,
+                   const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t *nid, uint64_t *nprio, uint32_t *nrq, uint32_t *err_flag, hipStream_t s);
 
 }  // namespace hqk

@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
         uint32_t lv;
         if (SMALL_L) lv = p == l4.v[0] ? 0u : (L > 1 && p == l4.v[1]) ? 1u : (L > 2 && p == l4.v[2]) ? 2u : (L > 3 && p == l4.v[3]) ? 3u : L;
         else { lv = level_of(lvp, L, p); if (lv < L && lvp[lv] != p) lv = L; }
+        if (q == RQ_TOMBSTONE) return GKEY_INVALID;            // task already handed out / removed (hqtick_ready_*): not an error
         if (lv >= L) { err |= 1u; return GKEY_INVALID; }       // priority missing from the level table
         if (q >= Q) { err |= 2u; return GKEY_INVALID; }        // request id out of range
         const uint32_t g = lv * Q + q;
@@ -252,7 +253,8 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
                                                      const uint32_t *__restrict__ wave_off, const uint32_t *__restrict__ take,
                                                      const uint32_t *__restrict__ base, SelPlan64 pa, uint64_t *__restrict__ sel_task,
                                                      uint16_t *__restrict__ sel_key, uint32_t n_select_blocks,
-                                                     const uint4 *__restrict__ copy_src, uint4 *__restrict__ copy_dst, uint32_t copy_n16) {
+                                                     const uint4 *__restrict__ copy_src, uint4 *__restrict__ copy_dst, uint32_t copy_n16,
+                                                     uint32_t *__restrict__ mark_rq) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t n_copy_blocks = gridDim.x - n_select_blocks;
     if (blockIdx.x < n_copy_blocks) {  // ride-along workgroups, dispatched FIRST so their PCIe round trip hides under the selection:
@@ -308,9 +310,13 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
                 const uint32_t cur = s_cnt[g];  // wave-private counter: leaders of distinct groups write distinct words
                 const uint32_t rank = cur + before;
                 if (rank < tk[g]) {
-                    const uint32_t dst = bs[g] + rank;
-                    sel_task[dst] = idv[u];
-                    sel_key[dst] = (uint16_t)g;  // group key; its level is g / Q (K5b)
+                    if (mark_rq) {  // consume mode (hqtick_ready_consume_last): the task leaves the ready set
+                        mark_rq[b + (uint64_t)u * 64 + lane] = RQ_TOMBSTONE;
+                    } else {
+                        const uint32_t dst = bs[g] + rank;
+                        sel_task[dst] = idv[u];
+                        sel_key[dst] = (uint16_t)g;  // group key; its level is g / Q (K5b)
+                    }
                 }
                 if (before == 0) s_cnt[g] = cur + (uint32_t)__popcll(peers);
             }
@@ -517,6 +523,97 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ resident ready-set deltas (f1)
+// TaskQueues::add_ready_task / take_tasks / remove on the HBM-resident columns (scheduler/taskqueue.rs:37-43,146-217,304-355).
+// Removal is a tombstone in the rq column (RQ_TOMBSTONE); k_rebuild drops tombstones and merges a sorted batch of new tasks.
+
+// one thread per id to remove: binary search in the sorted id column
+__global__ void __launch_bounds__(256) k_mark_removed(const uint64_t *__restrict__ ids, uint32_t *__restrict__ rq, uint64_t n,
+                                                      const uint64_t *__restrict__ rm, uint32_t n_rm, uint32_t *__restrict__ n_done) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rm) return;
+    const uint64_t want = rm[t];
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ids[mid] < want) lo = mid + 1; else hi = mid; }
+    // a removed-and-re-added id can sit next to its own tombstone: take the live one
+    while (lo < n && ids[lo] == want && rq[lo] == RQ_TOMBSTONE) lo++;
+    if (lo < n && ids[lo] == want) { rq[lo] = RQ_TOMBSTONE; atomicAdd(n_done, 1u); }
+}
+
+// live tasks per 256-task slice
+__global__ void __launch_bounds__(256) k_live_count(const uint32_t *__restrict__ rq, uint64_t n, uint32_t n_slices, uint32_t *__restrict__ slice_cnt) {
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    if (wave >= n_slices) return;
+    const uint64_t begin = (uint64_t)wave * 256;
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const uint64_t i = begin + (uint64_t)u * 64 + lane; c += (uint32_t)__popcll(__ballot(i < n && rq[i] != RQ_TOMBSTONE)); }
+    if (lane == 0) slice_cnt[wave] = c;
+}
+
+// One wavefront per 256-task slice of the old columns: drops tombstones and merges the slice's share of the (sorted) batch of
+// new tasks — those whose id falls between the slice's first id and the next slice's first id — into the new columns.
+// LDS per wavefront: ids u64[256] | live prefix u32[257].
+__global__ void __launch_bounds__(256) k_rebuild(const uint64_t *__restrict__ oid, const uint64_t *__restrict__ oprio, const uint32_t *__restrict__ orq,
+                                                 uint64_t n, uint32_t n_slices, const uint32_t *__restrict__ slice_off,
+                                                 const uint64_t *__restrict__ aid, const uint64_t *__restrict__ aprio, const uint32_t *__restrict__ arq,
+                                                 uint32_t n_add, uint64_t *__restrict__ nid, uint64_t *__restrict__ nprio, uint32_t *__restrict__ nrq,
+                                                 uint32_t *__restrict__ err_flag) {
+    __shared__ uint64_t s_id_all[4][256];
+    __shared__ uint32_t s_pre_all[4][257];
+    const uint32_t wv = threadIdx.x >> 6, wave = blockIdx.x * 4 + wv, lane = lane_id();
+    if (wave >= n_slices) return;
+    uint64_t *s_id = s_id_all[wv];
+    uint32_t *s_pre = s_pre_all[wv];
+    const uint64_t begin = (uint64_t)wave * 256;
+    const uint32_t len = (uint32_t)(n - begin < 256 ? n - begin : 256);
+    uint64_t idv[4], pv[4];
+    uint32_t qv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t e = (uint32_t)u * 64 + lane;
+        const bool ok = e < len;
+        idv[u] = ok ? oid[begin + e] : 0; pv[u] = ok ? oprio[begin + e] : 0; qv[u] = ok ? orq[begin + e] : RQ_TOMBSTONE;
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t run = 0, pre[4];
+    bool live[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        live[u] = qv[u] != RQ_TOMBSTONE;
+        const uint64_t b = __ballot(live[u]);
+        pre[u] = run + (uint32_t)__popcll(b & lt);
+        run += (uint32_t)__popcll(b);
+        const uint32_t e = (uint32_t)u * 64 + lane;
+        s_id[e] = idv[u];
+        s_pre[e] = pre[u];
+    }
+    if (lane == 0) s_pre[len] = run;  // live tasks of the whole slice (entries beyond len are not live)
+    // this slice's share of the new tasks: [lb0, lb1) of the sorted batch
+    auto lower_bound_add = [&](uint64_t key) -> uint32_t { uint32_t lo = 0, hi = n_add; while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (aid[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
+    const uint32_t lb0 = wave == 0 ? 0u : lower_bound_add(oid[begin]);
+    const uint32_t lb1 = wave + 1 >= n_slices ? n_add : lower_bound_add(oid[begin + 256]);
+    const uint32_t base = slice_off[wave];
+    // surviving old tasks
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (!live[u]) continue;
+        uint32_t lo = lb0, hi = lb1;  // new tasks of this slice with a smaller id
+        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (aid[mid] < idv[u]) lo = mid + 1; else hi = mid; }
+        if (lo < lb1 && aid[lo] == idv[u]) atomicOr(err_flag, 4u);  // the id is already in the ready set
+        const uint64_t dst = (uint64_t)base + pre[u] + lo;
+        nid[dst] = idv[u]; nprio[dst] = pv[u]; nrq[dst] = qv[u];
+    }
+    // new tasks of this slice (LDS reads below see this wavefront's own writes: DS operations of one wave execute in order)
+    for (uint32_t j = lb0 + lane; j < lb1; j += 64) {
+        const uint64_t key = aid[j];
+        uint32_t lo = 0, hi = len;  // old tasks of the slice with a smaller id
+        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_id[mid] < key) lo = mid + 1; else hi = mid; }
+        const uint64_t dst = (uint64_t)base + s_pre[lo] + j;
+        nid[dst] = key; nprio[dst] = aprio[j]; nrq[dst] = arq[j];
+    }
+}
+
 }  // namespace
 
 // ================================================================================================ host wrappers
@@ -569,7 +666,7 @@ static __global__ void __launch_bounds__(256) k_copy16(const uint4 *__restrict__
 
 hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_t n, uint32_t Q, uint32_t G, WaveGeom geom,
                     const uint32_t *wave_off, const uint32_t *take_host, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_key,
-                    const void *plan_src, void *plan_dst, size_t plan_bytes, hipStream_t s) {
+                    const void *plan_src, void *plan_dst, size_t plan_bytes, uint32_t *mark_rq, hipStream_t s) {
     const uint32_t n16 = (uint32_t)((plan_bytes + 15) / 16);
     const bool sel = n != 0 && geom.n_waves != 0 && G != 0;
     hipError_t e;
@@ -581,7 +678,7 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
         const uint32_t nsb = (geom.n_waves + 3) / 4, ncb = n16 ? (n16 + 1023) / 1024 : 0;
         hipLaunchKernelGGL((k_select<4, 0>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
-                           reinterpret_cast<uint4 *>(plan_dst), n16);
+                           reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq);
         return hipGetLastError();
     }
     if (n16) {  // larger plans: copy first (own launch), then select from the HBM copy
@@ -596,14 +693,14 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         const uint32_t nsb = (geom.n_waves + 3) / 4;
         hipLaunchKernelGGL(kern, dim3(nsb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
-                           sel_task, sel_key, nsb, (const uint4 *)nullptr, (uint4 *)nullptr, 0u);
+                           sel_task, sel_key, nsb, (const uint4 *)nullptr, (uint4 *)nullptr, 0u, mark_rq);
         return hipGetLastError();
     }
     size_t lds = (size_t)G * 4;
     auto kern = k_select<1, 2>;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(geom.n_waves), dim3(64), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
-                       sel_task, sel_key, geom.n_waves, (const uint4 *)nullptr, (uint4 *)nullptr, 0u);
+                       sel_task, sel_key, geom.n_waves, (const uint4 *)nullptr, (uint4 *)nullptr, 0u, mark_rq);
     return hipGetLastError();
 }
 
@@ -644,6 +741,27 @@ hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, cons
     hipError_t e;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_mapping), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, W, sel_task, sel_key, Q, max_items, rec_task, rec_variant, rec_kind, err_flag);
+    return hipGetLastError();
+}
+
+hipError_t ready_mark_removed(const uint64_t *ids, uint32_t *rq, uint64_t n, const uint64_t *rm, uint32_t n_rm, uint32_t *n_done, hipStream_t s) {
+    if (n == 0 || n_rm == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mark_removed, dim3((n_rm + 255) / 256), dim3(256), 0, s, ids, rq, n, rm, n_rm, n_done);
+    return hipGetLastError();
+}
+
+hipError_t ready_live_count(const uint32_t *rq, uint64_t n, uint32_t *slice_cnt, hipStream_t s) {
+    const uint32_t n_slices = (uint32_t)((n + 255) / 256);
+    if (n_slices == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_live_count, dim3((n_slices + 3) / 4), dim3(256), 0, s, rq, n, n_slices, slice_cnt);
+    return hipGetLastError();
+}
+
+hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint32_t *orq, uint64_t n, const uint32_t *slice_off, const uint64_t *aid,
+                   const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t *nid, uint64_t *nprio, uint32_t *nrq, uint32_t *err_flag, hipStream_t s) {
+    const uint32_t n_slices = (uint32_t)((n + 255) / 256);
+    if (n_slices == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rebuild, dim3((n_slices + 3) / 4), dim3(256), 0, s, oid, oprio, orq, n, n_slices, slice_off, aid, aprio, arq, n_add, nid, nprio, nrq, err_flag);
     return hipGetLastError();
 }
 

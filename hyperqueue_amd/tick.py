@@ -90,6 +90,35 @@ class Tick:
         if rc < 0:
             raise HqTickError(rc, self._err())
 
+    # -- resident ready-set deltas (include/hqtick.h) -------------------------------------------------------
+    def _chk(self, rc: int) -> int:
+        if rc < 0:
+            raise HqTickError(rc, self._err())
+        return rc
+
+    def ready_consume_last(self):
+        self._lib.hqtick_ready_consume_last.argtypes = [C.c_void_p]
+        self._chk(self._lib.hqtick_ready_consume_last(self._ctx))
+
+    def ready_remove(self, task_id) -> int:
+        a = np.ascontiguousarray(task_id, np.uint64)
+        self._lib.hqtick_ready_remove.argtypes = [C.c_void_p, C.c_uint64, abi.u64p]
+        return self._chk(self._lib.hqtick_ready_remove(self._ctx, len(a), a.ctypes.data_as(abi.u64p)))
+
+    def ready_add(self, task_id, task_priority, task_rq):
+        a, b, c = (np.ascontiguousarray(task_id, np.uint64), np.ascontiguousarray(task_priority, np.uint64), np.ascontiguousarray(task_rq, np.uint32))
+        self._lib.hqtick_ready_add.argtypes = [C.c_void_p, C.c_uint64, abi.u64p, abi.u64p, abi.u32p]
+        self._chk(self._lib.hqtick_ready_add(self._ctx, len(a), a.ctypes.data_as(abi.u64p), b.ctypes.data_as(abi.u64p), c.ctypes.data_as(abi.u32p)))
+
+    def ready_compact(self):
+        self._lib.hqtick_ready_compact.argtypes = [C.c_void_p]
+        self._chk(self._lib.hqtick_ready_compact(self._ctx))
+
+    def ready_count(self) -> int:
+        self._lib.hqtick_ready_count.restype = C.c_uint64
+        self._lib.hqtick_ready_count.argtypes = [C.c_void_p]
+        return int(self._lib.hqtick_ready_count(self._ctx))
+
     def query(self, snap: abi.Snapshot, fake_ids, fake_total, fake_remaining=None, fake_min_util=None):
         sc = snap.to_c()
         n = len(fake_ids)

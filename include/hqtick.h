@@ -253,6 +253,25 @@ int hqtick_upload_ready(hqtick_ctx *ctx, uint64_t n_ready, const uint64_t *task_
 int hqtick_run_resident(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick_result *out);
 
 /*
+ * Resident ready-set deltas: what the reactor's event handlers do to TaskQueues between two ticks, applied to
+ * the HBM-resident columns instead of re-uploading them.
+ *   hqtick_ready_consume_last  every task the last hqtick_run_resident handed out (assigned, newly prefilled, multi-node)
+ *                              leaves the set — take_tasks / take_tasks_for_prefill / take_one   scheduler/taskqueue.rs:304-373
+ *   hqtick_ready_remove        ids (any order) leave the set — TaskQueue::remove on cancel        scheduler/taskqueue.rs:146-217
+ *                              returns how many of them were present
+ *   hqtick_ready_add           new ready tasks, ids strictly ascending — TaskQueues::add_ready_task scheduler/taskqueue.rs:37-43
+ *   hqtick_ready_compact       drop the tombstones now (done automatically when they outnumber the live tasks, and by every add)
+ *   hqtick_ready_count         live tasks in the set
+ * Removal writes a tombstone into the rq column (4 B per task); add / compact stream the columns once (20 B read + 20 B written per
+ * live task) through a merge kernel.  Request id 0xFFFFFFFF is reserved for the tombstone.
+ */
+int hqtick_ready_consume_last(hqtick_ctx *ctx);
+int hqtick_ready_remove(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id);
+int hqtick_ready_add(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority, const uint32_t *task_rq);
+int hqtick_ready_compact(hqtick_ctx *ctx);
+uint64_t hqtick_ready_count(const hqtick_ctx *ctx);
+
+/*
  * Multi-GPU: worker sharding.  Every rank (one ctx per GPU) runs the tick on the SAME snapshot — scans, batches and the
  * placement are replicated and deterministic — but expands and emits records only for the workers it owns:
  *     FxHash(worker_id) % shard_count == shard_index       (FxHash = fxhash 0.2.1 of the u32 id, as tako's Map uses)
