@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
+    ap.add_argument("--steady-steps", type=int, default=20, help="steps of the steady-state (delta-updated resident set) measurement, 0 = skip")
     ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
     ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
@@ -222,6 +223,45 @@ def main():
                 sweep.append({"kernel": nm, "n_ready": n_big, "avg_launch_us": round(us, 2), "GBps": n_big * bpt / (us * 1e-6) / 1e9, "frac": n_big * bpt / (us * 1e-6) / 1e9 / peak})
             t2.close()
         out["roofline_vs_n"] = sweep
+    if world == 1 and not args.force_sharded and args.steady_steps > 0:
+        # Steady state of the reference's own throughput benchmark shape (benchmarks/experiment-per-task-overhead.py: zero-worker, `sleep 0`):
+        # everything a tick hands out has finished before the next one, and as many new tasks have become ready.  The ready set stays in HBM
+        # and is updated by deltas (hqtick_ready_consume_last / hqtick_ready_add) — nothing is re-uploaded but the new tasks.
+        ts = Tick(cfg)
+        ts.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
+        def handed_out(res):  # ids of the records of a tick (assigned + prefilled)
+            n_rec = int(np.ctypeslib.as_array(res.rec_off, shape=(W + 1,))[W])
+            return np.ctypeslib.as_array(res.rec_task, shape=(n_rec,)).copy()
+
+        rq_of = snap.task_rq.copy()  # rq by (job_task_id - 1): every id here is job 1, task 1..n
+        res = ts.tick_raw(sc, resident=True)
+        gone = handed_out(res)
+        ts.ready_consume_last()
+        next_id = int(snap.task_id[-1]) + 1
+        t_add, t_tick, t_cons, per_step = [], [], [], []
+        for _ in range(args.steady_steps + 2):
+            k = len(gone)
+            new_rq = rq_of[(gone & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1]  # arrivals replace exactly what left, class by class
+            rq_of = np.concatenate([rq_of, new_rq])
+            new_ids = np.arange(next_id, next_id + k, dtype=np.uint64); next_id += k
+            new_prio = np.full(k, snap.task_priority[0], np.uint64)
+            a = time.perf_counter(); ts.ready_add(new_ids, new_prio, new_rq)
+            b = time.perf_counter(); res = ts.tick_raw(sc, resident=True)
+            c = time.perf_counter(); ts.ready_consume_last(); torch.cuda.synchronize()
+            d = time.perf_counter()
+            gone = handed_out(res)
+            t_add.append(b - a); t_tick.append(c - b); t_cons.append(d - c); per_step.append(len(gone))
+        per_step = int(np.median(per_step[2:]))
+        t_add, t_tick, t_cons = (np.asarray(x[2:]) for x in (t_add, t_tick, t_cons))
+        step = t_add + t_tick + t_cons
+        out["steady_state"] = {
+            "what": "per step: hqtick_ready_add(new tasks) + hqtick_run_resident + hqtick_ready_consume_last; workers empty again before every tick (sleep-0 tasks)",
+            "steps": args.steady_steps, "ready_set_before_each_tick": int(ts.ready_count()) + per_step, "tasks_handed_out_per_step": per_step,
+            "p50_step_ms": 1e3 * float(np.median(step)), "tasks_per_s": per_step / float(np.median(step)),
+            "p50_add_us": 1e6 * float(np.median(t_add)), "p50_tick_us": 1e6 * float(np.median(t_tick)), "p50_consume_us": 1e6 * float(np.median(t_cons)),
+            "delta_bytes_host_to_device_per_step": per_step * 20,
+        }
+        ts.close()
     if world == 1 and args.cpu_ticks > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(snap, args.cpu_ticks)

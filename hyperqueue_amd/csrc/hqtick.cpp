@@ -84,12 +84,12 @@ struct hqtick_ctx {
     std::string err = "";
     // ready set
     DevBuf d_tid, d_tprio, d_trq; uint64_t n_ready = 0; bool resident = false;  // n_ready = physical length (tombstones included)
-    DevBuf d_tid2, d_tprio2, d_trq2, d_slice, d_add;   // alternate columns + scratch of the resident deltas (hqtick_ready_*)
+    DevBuf d_tid2, d_tprio2, d_trq2, d_slice, d_add, d_pre8;   // alternate columns + scratch of the resident deltas (hqtick_ready_*)
     uint64_t n_live = 0; uint32_t last_n_sel = 0; bool last_consumed = true;
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
-    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr;
+    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add;
     // workers / requests
     DevBuf d_up, d_vflags, d_vtmc;
     // selection + mapping
@@ -713,9 +713,9 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
-                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add};
+                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8};
     for (DevBuf *b : bufs) b->release();
-    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release();
+    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -766,13 +766,13 @@ int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, c
         }
     } else {
         const uint32_t n_slices = (uint32_t)((N + 255) / 256), stride = (n_slices + 15u) & ~15u;
-        if (!ctx->d_slice.ensure((size_t)stride * 4 + 64) || !ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc slice table");
+        if (!ctx->d_slice.ensure((size_t)stride * 4 + 64) || !ctx->h_q.ensure(64) || !ctx->d_pre8.ensure(N + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc slice table");
         uint32_t *flag = ctx->h_q.as<uint32_t>(); flag[0] = 0; flag[1] = 0;
         hqk::WaveGeom g{256, n_slices, 4, stride};
         HQ_HIP(hqk::ready_live_count(ctx->d_trq.as<uint32_t>(), N, ctx->d_slice.as<uint32_t>(), ctx->stream));
         HQ_HIP(hqk::scan_waves(ctx->d_slice.as<uint32_t>(), g, 1, ctx->h_q.dev<uint32_t>() + 1, nullptr, nullptr, ctx->stream));
-        HQ_HIP(hqk::ready_rebuild(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_slice.as<uint32_t>(), aid, aprio, arq, n_add,
-                                  ctx->d_tid2.as<uint64_t>(), ctx->d_tprio2.as<uint64_t>(), ctx->d_trq2.as<uint32_t>(), ctx->h_q.dev<uint32_t>(), ctx->stream));
+        HQ_HIP(hqk::ready_rebuild(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, (uint32_t)ctx->n_live, ctx->d_slice.as<uint32_t>(), aid, aprio, arq, n_add,
+                                  ctx->d_tid2.as<uint64_t>(), ctx->d_tprio2.as<uint64_t>(), ctx->d_trq2.as<uint32_t>(), ctx->d_pre8.as<uint8_t>(), ctx->h_q.dev<uint32_t>(), ctx->stream));
         HQ_HIP(hipStreamSynchronize(ctx->stream));
         if (flag[1] != ctx->n_live) return fail(ctx, HQTICK_E_DEVICE, "resident ready set: live-task count out of sync");
         if (flag[0] & 4u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: a task id is already in the ready set");
@@ -811,7 +811,9 @@ int hqtick_ready_remove(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id) {
     HQ_HIP(hipSetDevice(ctx->device));
     if (!ctx->d_add.ensure(n * 8 + 8) || !ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
     uint32_t *cnt = ctx->h_q.as<uint32_t>(); cnt[0] = 0;
-    HQ_HIP(hipMemcpyAsync(ctx->d_add.p, task_id, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->h_add.ensure(n * 8 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc delta staging");
+    memcpy(ctx->h_add.p, task_id, n * 8);
+    HQ_HIP(hipMemcpyAsync(ctx->d_add.p, ctx->h_add.p, n * 8, hipMemcpyHostToDevice, ctx->stream));
     HQ_HIP(hqk::ready_mark_removed(ctx->d_tid.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), ctx->n_ready, ctx->d_add.as<uint64_t>(), (uint32_t)n, ctx->h_q.dev<uint32_t>(), ctx->stream));
     HQ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_live -= cnt[0]; ctx->last_valid = false; ctx->last_consumed = true;
@@ -826,12 +828,12 @@ int hqtick_ready_add(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const
     for (uint64_t i = 1; i < n; i++) if (task_id[i - 1] >= task_id[i]) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
     for (uint64_t i = 0; i < n; i++) if (task_rq[i] == 0xFFFFFFFFu) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
     HQ_HIP(hipSetDevice(ctx->device));
-    size_t o_p = (n * 8 + 15) & ~(size_t)15, o_q = o_p * 2;
-    if (!ctx->d_add.ensure(o_q + n * 4 + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
-    unsigned char *d = ctx->d_add.as<unsigned char>();
-    HQ_HIP(hipMemcpyAsync(d, task_id, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HQ_HIP(hipMemcpyAsync(d + o_p, task_priority, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HQ_HIP(hipMemcpyAsync(d + o_q, task_rq, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    // stage through pinned memory: a pageable hipMemcpy of a few MB costs ~1 ms each in page pinning
+    size_t o_p = (n * 8 + 15) & ~(size_t)15, o_q = o_p * 2, bytes = o_q + n * 4 + 16;
+    if (!ctx->d_add.ensure(bytes) || !ctx->h_add.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
+    unsigned char *h = ctx->h_add.as<unsigned char>(), *d = ctx->d_add.as<unsigned char>();
+    memcpy(h, task_id, n * 8); memcpy(h + o_p, task_priority, n * 8); memcpy(h + o_q, task_rq, n * 4);
+    HQ_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
     return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + o_p), reinterpret_cast<const uint32_t *>(d + o_q), (uint32_t)n);
 }
 

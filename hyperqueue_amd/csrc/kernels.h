@@ -105,7 +105,7 @@ size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys);
 // 256-task slice, and rebuild the columns dropping tombstones while merging a sorted batch of new tasks.
 hipError_t ready_mark_removed(const uint64_t *ids, uint32_t *rq, uint64_t n, const uint64_t *rm, uint32_t n_rm, uint32_t *n_done, hipStream_t s);
 hipError_t ready_live_count(const uint32_t *rq, uint64_t n, uint32_t *slice_cnt, hipStream_t s);
-hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint32_t *orq, uint64_t n, const uint32_t *slice_off, const uint64_t *aid,
-                   const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t *nid, uint64_t *nprio, uint32_t *nrq, uint32_t *err_flag, hipStream_t s);
+hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint32_t *orq, uint64_t n, uint32_t n_live, const uint32_t *slice_off, const uint64_t *aid,
+                   const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t *nid, uint64_t *nprio, uint32_t *nrq, uint8_t *pre8, uint32_t *err_flag, hipStream_t s);
 
 }  // namespace hqk

@@ -551,20 +551,16 @@ __global__ void __launch_bounds__(256) k_live_count(const uint32_t *__restrict__
     if (lane == 0) slice_cnt[wave] = c;
 }
 
-// One wavefront per 256-task slice of the old columns: drops tombstones and merges the slice's share of the (sorted) batch of
-// new tasks — those whose id falls between the slice's first id and the next slice's first id — into the new columns.
-// LDS per wavefront: ids u64[256] | live prefix u32[257].
+// Rebuild, pass 1 — one wavefront per 256-task slice of the old columns: every surviving task moves to
+//     slice_off[slice] + (live tasks before it in the slice) + (new tasks with a smaller id),
+// the last term found by a binary search inside the slice's share [lb0, lb1) of the sorted batch (two searches per slice).
+// Also records, per old position, the live count before it inside its slice (u8) for pass 2.
 __global__ void __launch_bounds__(256) k_rebuild(const uint64_t *__restrict__ oid, const uint64_t *__restrict__ oprio, const uint32_t *__restrict__ orq,
                                                  uint64_t n, uint32_t n_slices, const uint32_t *__restrict__ slice_off,
-                                                 const uint64_t *__restrict__ aid, const uint64_t *__restrict__ aprio, const uint32_t *__restrict__ arq,
-                                                 uint32_t n_add, uint64_t *__restrict__ nid, uint64_t *__restrict__ nprio, uint32_t *__restrict__ nrq,
-                                                 uint32_t *__restrict__ err_flag) {
-    __shared__ uint64_t s_id_all[4][256];
-    __shared__ uint32_t s_pre_all[4][257];
-    const uint32_t wv = threadIdx.x >> 6, wave = blockIdx.x * 4 + wv, lane = lane_id();
+                                                 const uint64_t *__restrict__ aid, uint32_t n_add, uint64_t *__restrict__ nid, uint64_t *__restrict__ nprio,
+                                                 uint32_t *__restrict__ nrq, uint8_t *__restrict__ pre8, uint32_t *__restrict__ err_flag) {
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
     if (wave >= n_slices) return;
-    uint64_t *s_id = s_id_all[wv];
-    uint32_t *s_pre = s_pre_all[wv];
     const uint64_t begin = (uint64_t)wave * 256;
     const uint32_t len = (uint32_t)(n - begin < 256 ? n - begin : 256);
     uint64_t idv[4], pv[4];
@@ -575,43 +571,43 @@ __global__ void __launch_bounds__(256) k_rebuild(const uint64_t *__restrict__ oi
         const bool ok = e < len;
         idv[u] = ok ? oid[begin + e] : 0; pv[u] = ok ? oprio[begin + e] : 0; qv[u] = ok ? orq[begin + e] : RQ_TOMBSTONE;
     }
-    const uint64_t lt = (1ull << lane) - 1ull;
-    uint32_t run = 0, pre[4];
-    bool live[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        live[u] = qv[u] != RQ_TOMBSTONE;
-        const uint64_t b = __ballot(live[u]);
-        pre[u] = run + (uint32_t)__popcll(b & lt);
-        run += (uint32_t)__popcll(b);
-        const uint32_t e = (uint32_t)u * 64 + lane;
-        s_id[e] = idv[u];
-        s_pre[e] = pre[u];
-    }
-    if (lane == 0) s_pre[len] = run;  // live tasks of the whole slice (entries beyond len are not live)
-    // this slice's share of the new tasks: [lb0, lb1) of the sorted batch
     auto lower_bound_add = [&](uint64_t key) -> uint32_t { uint32_t lo = 0, hi = n_add; while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (aid[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
-    const uint32_t lb0 = wave == 0 ? 0u : lower_bound_add(oid[begin]);
-    const uint32_t lb1 = wave + 1 >= n_slices ? n_add : lower_bound_add(oid[begin + 256]);
+    const uint32_t lb0 = (wave == 0 || n_add == 0) ? 0u : lower_bound_add(oid[begin]);
+    const uint32_t lb1 = (wave + 1 >= n_slices || n_add == 0) ? n_add : lower_bound_add(oid[begin + 256]);
     const uint32_t base = slice_off[wave];
-    // surviving old tasks
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t run = 0;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        if (!live[u]) continue;
+        const uint32_t e = (uint32_t)u * 64 + lane;
+        const bool live = qv[u] != RQ_TOMBSTONE;
+        const uint64_t b = __ballot(live);
+        const uint32_t pre = run + (uint32_t)__popcll(b & lt);
+        run += (uint32_t)__popcll(b);
+        if (e < len) pre8[begin + e] = (uint8_t)pre;  // <= 255: at most e live tasks precede position e
+        if (!live) continue;
         uint32_t lo = lb0, hi = lb1;  // new tasks of this slice with a smaller id
         while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (aid[mid] < idv[u]) lo = mid + 1; else hi = mid; }
         if (lo < lb1 && aid[lo] == idv[u]) atomicOr(err_flag, 4u);  // the id is already in the ready set
-        const uint64_t dst = (uint64_t)base + pre[u] + lo;
+        const uint64_t dst = (uint64_t)base + pre + lo;
         nid[dst] = idv[u]; nprio[dst] = pv[u]; nrq[dst] = qv[u];
     }
-    // new tasks of this slice (LDS reads below see this wavefront's own writes: DS operations of one wave execute in order)
-    for (uint32_t j = lb0 + lane; j < lb1; j += 64) {
-        const uint64_t key = aid[j];
-        uint32_t lo = 0, hi = len;  // old tasks of the slice with a smaller id
-        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_id[mid] < key) lo = mid + 1; else hi = mid; }
-        const uint64_t dst = (uint64_t)base + s_pre[lo] + j;
-        nid[dst] = key; nprio[dst] = aprio[j]; nrq[dst] = arq[j];
-    }
+}
+
+// Rebuild, pass 2 — one thread per new task: it lands behind the live old tasks with a smaller id and the new tasks before it.
+__global__ void __launch_bounds__(256) k_merge_adds(const uint64_t *__restrict__ oid, uint64_t n, const uint32_t *__restrict__ slice_off,
+                                                    const uint8_t *__restrict__ pre8, uint32_t n_live, const uint64_t *__restrict__ aid,
+                                                    const uint64_t *__restrict__ aprio, const uint32_t *__restrict__ arq, uint32_t n_add,
+                                                    uint64_t *__restrict__ nid, uint64_t *__restrict__ nprio, uint32_t *__restrict__ nrq) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_add) return;
+    const uint64_t key = aid[j];
+    uint64_t lo = 0, hi = n;  // first old position with id >= key
+    if (n && oid[n - 1] < key) lo = n;  // the usual case: fresh ids sort behind everything resident
+    else while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (oid[mid] < key) lo = mid + 1; else hi = mid; }
+    const uint32_t live_before = lo >= n ? n_live : slice_off[lo >> 8] + pre8[lo];
+    const uint64_t dst = (uint64_t)live_before + j;
+    nid[dst] = key; nprio[dst] = aprio[j]; nrq[dst] = arq[j];
 }
 
 }  // namespace
@@ -757,11 +753,14 @@ hipError_t ready_live_count(const uint32_t *rq, uint64_t n, uint32_t *slice_cnt,
     return hipGetLastError();
 }
 
-hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint32_t *orq, uint64_t n, const uint32_t *slice_off, const uint64_t *aid,
-                   const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t *nid, uint64_t *nprio, uint32_t *nrq, uint32_t *err_flag, hipStream_t s) {
+hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint32_t *orq, uint64_t n, uint32_t n_live, const uint32_t *slice_off, const uint64_t *aid,
+                   const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t *nid, uint64_t *nprio, uint32_t *nrq, uint8_t *pre8, uint32_t *err_flag, hipStream_t s) {
     const uint32_t n_slices = (uint32_t)((n + 255) / 256);
     if (n_slices == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rebuild, dim3((n_slices + 3) / 4), dim3(256), 0, s, oid, oprio, orq, n, n_slices, slice_off, aid, aprio, arq, n_add, nid, nprio, nrq, err_flag);
+    hipLaunchKernelGGL(k_rebuild, dim3((n_slices + 3) / 4), dim3(256), 0, s, oid, oprio, orq, n, n_slices, slice_off, aid, n_add, nid, nprio, nrq, pre8, err_flag);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || n_add == 0) return e;
+    hipLaunchKernelGGL(k_merge_adds, dim3((n_add + 255) / 256), dim3(256), 0, s, oid, n, slice_off, pre8, n_live, aid, aprio, arq, n_add, nid, nprio, nrq);
     return hipGetLastError();
 }
 
