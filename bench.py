@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
+    ap.add_argument("--priority-ticks", type=int, default=3, help="ticks of the three-priority-level variant c3p (0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=20, help="steps of the steady-state (delta-updated resident set) measurement, 0 = skip")
     ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
@@ -262,6 +263,22 @@ def main():
             "delta_bytes_host_to_device_per_step": per_step * 20,
         }
         ts.close()
+    if world == 1 and not args.force_sharded and args.workload == "c3" and args.priority_ticks > 0:
+        # the same size with three user-priority levels (SURVEY §8d's C3 mix, 80/15/5 %): priority cuts couple every worker, the model is one
+        # 8 k-column x 22 k-row component and the tick is dominated by the host-side exact solve (reported, not the headline: BASELINE.json's
+        # config names no priorities)
+        sp = workloads.make("c3p", seed=args.seed)
+        tp = Tick(cfg)
+        tp.upload_ready(sp.task_id, sp.task_priority, sp.task_rq, sorted_=True)
+        scp = sp.to_c()
+        tl, info = [], None
+        for _ in range(args.priority_ticks):
+            t0 = time.perf_counter(); rp = tp.tick_raw(scp, resident=True); tl.append(time.perf_counter() - t0)
+            info = (rp.status, int(rp.is_optimal), tp.kernel_stats(), rp.t_solve_us)
+        out["multi_priority"] = {"workload": "c3p: c3 with user priorities {0, 1, 2} at 80/15/5 %", "ticks": args.priority_ticks, "p50_tick_ms": 1e3 * float(np.median(tl)),
+                                 "status": info[0], "is_optimal": bool(info[1]), "assigned_per_tick": int(info[2]["n_assigned"]), "prefilled_per_tick": int(info[2]["n_prefilled"]),
+                                 "solve_ms": info[3] / 1e3, "tasks_assigned_per_sec": int(info[2]["n_assigned"]) / float(np.median(tl))}
+        tp.close()
     if world == 1 and args.cpu_ticks > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(snap, args.cpu_ticks)

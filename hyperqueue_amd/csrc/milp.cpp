@@ -1,10 +1,12 @@
-// Exact small-MILP solver (see milp.h).  Branch-and-bound over a dense bounded-variable DUAL simplex that is
-// warm-started from the parent node, followed by a lexicographic canonicalisation pass.
+// Exact small-MILP solver (see milp.h).  Branch-and-bound over a bounded-variable DUAL simplex on a dense tableau that holds only
+// the ACTIVE rows: constraints enter the tableau when the current LP point violates them (the placement model carries one cut row per
+// worker, blocker and cut — scheduler/solver.rs:274-429 — almost all of them slack at the optimum), children are warm-started from the
+// parent's tableau, and a lexicographic canonicalisation pass follows.
 //
-// Why dual simplex: every objective coefficient of the tick's model is >= 0 (scheduler/solver.rs:542-597) and every
-// placement column has a finite upper bound implied by its worker's resource rows, so "all logicals basic, costly
-// columns at their upper bound" is dual feasible from the start, and a B&B child differs from its parent by one
-// bound — exactly the case the dual method re-optimises in a handful of pivots.
+// Why dual simplex: every objective coefficient of the tick's model is >= 0 (scheduler/solver.rs:542-597) and every placement column
+// has a finite upper bound implied by its worker's resource rows, so "costly columns at their upper bound, no row active" is dual
+// feasible from the start; a violated row that enters, or a B&B child that differs from its parent by one bound, is exactly the case the
+// dual method re-optimises in a handful of pivots.
 #include "milp.h"
 
 #include <algorithm>
@@ -23,61 +25,115 @@ const double FEAS_TOL = 1e-9;   // primal bound violation (rows are scaled to ma
 const double PIV_TOL = 1e-9;
 const double INT_TOL = 1e-7;
 const double UB_CAP = 1048576.0;  // columns with no derivable bound (unbounded models => `None`, highs.rs:82)
+const double TAB_LIMIT = 6.0e7;   // doubles in one tableau (480 MB): beyond it the LP gives up (reported like a time limit)
 
 double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 enum { BASIC = 0, AT_LO = 1, AT_UP = 2 };
 enum { LP_OPT = 0, LP_INFEAS = 1, LP_LIMIT = 2 };
 
-// A component's LP in "rows are logical variables" form:  A x - s = 0,  lo <= s <= hi,  lb <= x <= ub.
+// Sparse rows of one component (local column ids), scaled to max |coef| = 1:  lo <= a.x <= hi
+struct Rows {
+    int n = 0, m = 0;
+    std::vector<int> off{0}, col;
+    std::vector<double> coef, lo, hi;
+    void add(const std::vector<std::pair<int, double>> &terms, double lo_, double hi_) {
+        for (auto &t : terms) { col.push_back(t.first); coef.push_back(t.second); }
+        off.push_back((int)col.size()); lo.push_back(lo_); hi.push_back(hi_); m++;
+    }
+    double activity(int i, const double *x) const { double a = 0.0; for (int k = off[i]; k < off[i + 1]; k++) a += coef[k] * x[col[k]]; return a; }
+};
+
+// LP  max c.x,  lb <= x <= ub,  rows of R — as a tableau over the rows activated so far.  Columns: [0, n) structural,
+// [n, n + ma) the slacks s_a = a_row.x of the active rows.  Every tableau row r reads  x_B[r] + sum_{j nonbasic} T[r][j] x_j = 0.
 struct Tab {
-    int n = 0, m = 0, N = 0;
+    const Rows *R = nullptr;
+    int n = 0, ma = 0, cap = 0, stride = 0;
     std::vector<double> T, d, x, lb, ub, cost;
-    std::vector<int> B;
+    std::vector<int> B, arow, where;
     std::vector<uint8_t> st;
     long iters = 0;
+    double ops = 0.0;         // tableau elements touched so far (pivots, row activations, separation scans): the deterministic work measure
+    double deadline = 1e300;  // wall-clock backstop inside long re-optimisations
 
-    void init(int n_, int m_, const std::vector<double> &A, const std::vector<double> &c, const std::vector<double> &clb,
-              const std::vector<double> &cub, const std::vector<double> &rlo, const std::vector<double> &rhi) {
-        n = n_; m = m_; N = n + m;
-        T.assign((size_t)m * N, 0.0);
-        for (int i = 0; i < m; i++) {
-            for (int j = 0; j < n; j++) T[(size_t)i * N + j] = -A[(size_t)i * n + j];
-            T[(size_t)i * N + n + i] = 1.0;
-        }
-        cost.assign(N, 0.0);
-        for (int j = 0; j < n; j++) cost[j] = c[j];
-        d = cost;
-        lb.assign(N, 0.0); ub.assign(N, 0.0);
-        for (int j = 0; j < n; j++) { lb[j] = clb[j]; ub[j] = cub[j]; }
-        for (int i = 0; i < m; i++) { lb[n + i] = rlo[i]; ub[n + i] = rhi[i]; }
-        st.assign(N, AT_LO); x.assign(N, 0.0); B.resize(m);
+    Tab() = default;
+    Tab(Tab &&) = default;
+    Tab &operator=(Tab &&) = default;
+    // B&B children and tie-break probes copy their parent: copy the active rows only, into a tableau with a little headroom
+    Tab(const Tab &o) : R(o.R), n(o.n), ma(o.ma), cap(o.ma + 16), stride(o.n + o.ma + 16), B(o.B), arow(o.arow), where(o.where), iters(o.iters), ops(o.ops + (double)(o.ma + 1) * (double)(o.n + o.ma)), deadline(o.deadline) {
+        T.assign((size_t)cap * stride, 0.0);
+        const int N = o.width();
+        for (int r = 0; r < ma; r++) memcpy(&T[(size_t)r * stride], &o.T[(size_t)r * o.stride], sizeof(double) * N);
+        auto cp = [&](std::vector<double> &dst, const std::vector<double> &src) { dst.assign(stride, 0.0); memcpy(dst.data(), src.data(), sizeof(double) * N); };
+        cp(d, o.d); cp(x, o.x); cp(lb, o.lb); cp(ub, o.ub); cp(cost, o.cost);
+        st.assign(stride, AT_LO); memcpy(st.data(), o.st.data(), N);
+    }
+    Tab &operator=(const Tab &o) { if (this != &o) { Tab t(o); *this = std::move(t); } return *this; }
+
+    void init(const Rows *rows, const std::vector<double> &c, const std::vector<double> &clb, const std::vector<double> &cub) {
+        R = rows; n = rows->n; ma = 0; cap = 32; stride = n + cap;
+        T.assign((size_t)cap * stride, 0.0);
+        cost.assign(stride, 0.0); d.assign(stride, 0.0); x.assign(stride, 0.0); lb.assign(stride, 0.0); ub.assign(stride, 0.0); st.assign(stride, AT_LO);
+        B.clear(); arow.clear(); where.assign(rows->m, -1);
         for (int j = 0; j < n; j++) {
-            if (cost[j] > 0.0) { st[j] = AT_UP; x[j] = ub[j]; } else { st[j] = AT_LO; x[j] = lb[j]; }
-        }
-        for (int i = 0; i < m; i++) {
-            B[i] = n + i; st[n + i] = BASIC;
-            double s = 0.0;
-            for (int j = 0; j < n; j++) s += A[(size_t)i * n + j] * x[j];
-            x[n + i] = s;
+            cost[j] = d[j] = c[j]; lb[j] = clb[j]; ub[j] = cub[j];
+            if (c[j] > 0.0) { st[j] = AT_UP; x[j] = cub[j]; } else { st[j] = AT_LO; x[j] = clb[j]; }
         }
     }
     double objective() const { double z = 0.0; for (int j = 0; j < n; j++) z += cost[j] * x[j]; return z; }
+    int width() const { return n + ma; }
+
+    void grow() {
+        int ncap = cap * 2, nstride = n + ncap;
+        std::vector<double> nT((size_t)ncap * nstride, 0.0);
+        for (int r = 0; r < ma; r++) memcpy(&nT[(size_t)r * nstride], &T[(size_t)r * stride], sizeof(double) * width());
+        T.swap(nT);
+        for (auto *v : {&d, &x, &lb, &ub, &cost}) v->resize(nstride, 0.0);
+        st.resize(nstride, AT_LO);
+        cap = ncap; stride = nstride;
+    }
+
+    // constraint i of R enters the tableau with its slack basic
+    bool activate(int i) {
+        if (ma == cap) { if ((double)cap * 2.0 * (double)(n + cap * 2) > TAB_LIMIT) return false; grow(); }
+        const int a = ma, k = n + a, N = width();
+        double *v = &T[(size_t)a * stride];
+        std::fill(v, v + N + 1, 0.0);
+        double act = 0.0;
+        for (int t = R->off[i]; t < R->off[i + 1]; t++) { v[R->col[t]] -= R->coef[t]; act += R->coef[t] * x[R->col[t]]; }
+        for (int r = 0; r < a; r++) {  // express the row in the current nonbasic columns
+            const int kb = B[r];
+            if (kb >= n) continue;
+            const double f = v[kb];
+            if (f == 0.0) continue;
+            const double *row = &T[(size_t)r * stride];
+            for (int j = 0; j < N; j++) v[j] -= f * row[j];
+            v[kb] = 0.0;
+            ops += N;
+        }
+        v[k] = 1.0;
+        B.push_back(k); arow.push_back(i); where[i] = a;
+        st[k] = BASIC; lb[k] = R->lo[i]; ub[k] = R->hi[i]; cost[k] = 0.0; d[k] = 0.0; x[k] = act;
+        ma++;
+        return true;
+    }
 
     // move a nonbasic variable to a new value, updating the basic ones
     void shift_nonbasic(int j, double nv) {
         double dl = nv - x[j];
         if (dl == 0.0) return;
-        for (int i = 0; i < m; i++) { double t = T[(size_t)i * N + j]; if (t != 0.0) x[B[i]] -= t * dl; }
+        for (int r = 0; r < ma; r++) { double t = T[(size_t)r * stride + j]; if (t != 0.0) x[B[r]] -= t * dl; }
         x[j] = nv;
     }
     void set_lb(int j, double v) { lb[j] = v; if (st[j] == AT_LO) shift_nonbasic(j, v); else if (st[j] == AT_UP && ub[j] < v) shift_nonbasic(j, v); }
     void set_ub(int j, double v) { ub[j] = v; if (st[j] == AT_UP) shift_nonbasic(j, v); else if (st[j] == AT_LO && lb[j] > v) shift_nonbasic(j, v); }
 
-    int solve(long max_iters) {
+    // dual simplex over the active rows
+    int reoptimise(long max_iters) {
+        const int N = width();
         for (long it = 0; it < max_iters; it++) {
             int r = -1; double best = FEAS_TOL; bool below = false;
-            for (int i = 0; i < m; i++) {
+            for (int i = 0; i < ma; i++) {
                 int k = B[i]; double v = x[k];
                 if (v < lb[k] - FEAS_TOL) { double inf = lb[k] - v; if (inf > best) { best = inf; r = i; below = true; } }
                 else if (v > ub[k] + FEAS_TOL) { double inf = v - ub[k]; if (inf > best) { best = inf; r = i; below = false; } }
@@ -85,12 +141,12 @@ struct Tab {
             if (r < 0) return LP_OPT;
             int k = B[r];
             if (lb[k] > ub[k] + FEAS_TOL) return LP_INFEAS;
-            const double *row = &T[(size_t)r * N];
+            double *prow = &T[(size_t)r * stride];
             int q = -1; double bratio = INF, babs = 0.0;
             for (int j = 0; j < N; j++) {
                 if (st[j] == BASIC) continue;
                 if (lb[j] == ub[j]) continue;  // fixed: cannot move
-                double a = row[j];
+                double a = prow[j];
                 bool elig;
                 if (below) elig = (st[j] == AT_LO && a < -PIV_TOL) || (st[j] == AT_UP && a > PIV_TOL);
                 else elig = (st[j] == AT_LO && a > PIV_TOL) || (st[j] == AT_UP && a < -PIV_TOL);
@@ -100,24 +156,25 @@ struct Tab {
             }
             if (q < 0) return LP_INFEAS;
             iters++;
+            if ((iters & 63) == 0 && wall() > deadline) return LP_LIMIT;
             double target = below ? lb[k] : ub[k];
-            double piv = row[q];
+            double piv = prow[q];
             double dq = (x[k] - target) / piv;
-            for (int i = 0; i < m; i++) { double t = T[(size_t)i * N + q]; if (t != 0.0) x[B[i]] -= t * dq; }
+            for (int i = 0; i < ma; i++) { double t = T[(size_t)i * stride + q]; if (t != 0.0) x[B[i]] -= t * dq; }
             x[q] += dq;
             x[k] = target;
-            // pivot
-            double *prow = &T[(size_t)r * N];
             double inv = 1.0 / piv;
             for (int j = 0; j < N; j++) prow[j] *= inv;
             prow[q] = 1.0;
-            for (int i = 0; i < m; i++) {
+            ops += 3.0 * N + ma;
+            for (int i = 0; i < ma; i++) {
                 if (i == r) continue;
-                double f = T[(size_t)i * N + q];
+                double *ri = &T[(size_t)i * stride];
+                double f = ri[q];
                 if (f == 0.0) continue;
-                double *ri = &T[(size_t)i * N];
                 for (int j = 0; j < N; j++) ri[j] -= f * prow[j];
                 ri[q] = 0.0;
+                ops += N;
             }
             double f = d[q];
             if (f != 0.0) { for (int j = 0; j < N; j++) d[j] -= f * prow[j]; d[q] = 0.0; }
@@ -126,44 +183,75 @@ struct Tab {
         }
         return LP_LIMIT;
     }
+
+    // LP optimum over ALL rows of R: re-optimise, bring in the rows the point violates, repeat
+    int solve(long max_iters) {
+        std::vector<std::pair<double, int>> bad;
+        for (;;) {
+            int s = reoptimise(max_iters);
+            if (s != LP_OPT) return s;
+            bad.clear();
+            ops += (double)R->col.size();
+            for (int i = 0; i < R->m; i++) {
+                if (where[i] >= 0) continue;
+                double a = R->activity(i, x.data());
+                double v = std::max(R->lo[i] - a, a - R->hi[i]);
+                if (v > FEAS_TOL) bad.push_back({-v, i});
+            }
+            if (bad.empty()) return LP_OPT;
+            std::sort(bad.begin(), bad.end());  // most violated first; ties by row index: deterministic
+            size_t take = std::min<size_t>(bad.size(), std::max<size_t>(32, bad.size() / 4));
+            for (size_t t = 0; t < take; t++) if (!activate(bad[t].second)) return LP_LIMIT;
+        }
+    }
 };
 
 struct CompSolver {
-    int n = 0, m = 0;
-    std::vector<double> A, c, lb, ub, rlo, rhi;
+    int n = 0;
+    Rows R;
+    std::vector<double> c, lb, ub;
     double deadline = 0; bool timed_out = false;
     long nodes = 0, lp_iters = 0;
     // incumbent
     bool have = false; double best = -INF; std::vector<double> bx;
     bool canonical_done = true;
 
-    long pivots = 0, pivot_limit = -1;  // deterministic work budget of the tie-break phase (wall clock stays the backstop)
-    bool time_up() { if (timed_out) return true; if ((pivot_limit >= 0 && pivots > pivot_limit) || ((nodes & 31) == 0 && wall() > deadline)) timed_out = true; return timed_out; }
-    int solve_counted(Tab &t) { long before = t.iters; int r = t.solve(200000); pivots += t.iters - before; return r; }
+    // Deterministic work budget of the tie-break phase, in tableau element updates (a pivot or a tableau copy touches ma x width of them);
+    // the wall clock stays the backstop.  Work, not seconds: every replica of a sharded scheduler must take the same decision here.
+    double work = 0.0, work_limit = -1.0;
+    bool time_up() { if (timed_out) return true; if ((work_limit >= 0 && work > work_limit) || ((nodes & 31) == 0 && wall() > deadline)) timed_out = true; return timed_out; }
+    int solve_counted(Tab &t) { double before = t.ops; int r = t.solve(200000); work += t.ops - before; return r; }
 
+    // column-wise view of R for the primal heuristic
+    std::vector<int> coff, crow; std::vector<double> ccoef; std::vector<int> by_cost;
+    void build_columns() {
+        coff.assign(n + 1, 0);
+        for (int k = 0; k < (int)R.col.size(); k++) coff[R.col[k] + 1]++;
+        for (int j = 0; j < n; j++) coff[j + 1] += coff[j];
+        crow.resize(R.col.size()); ccoef.resize(R.col.size());
+        std::vector<int> cur(coff.begin(), coff.end() - 1);
+        for (int i = 0; i < R.m; i++) for (int k = R.off[i]; k < R.off[i + 1]; k++) { int j = R.col[k]; crow[cur[j]] = i; ccoef[cur[j]++] = R.coef[k]; }
+        by_cost.resize(n); std::iota(by_cost.begin(), by_cost.end(), 0);
+        std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return c[a] > c[b]; });
+    }
     // Primal heuristic: from an integer point inside the bounds (e.g. the floor of an LP solution), keep it only if every row holds,
     // then raise columns greedily — most valuable first — as far as the rows allow.  The placement models are packing
     // problems whose LP bound is usually attained, so a maximal point found here often closes the search at the root.
-    std::vector<int> by_cost;
     void greedy_from(std::vector<double> x) {
-        std::vector<double> act(m, 0.0);
-        for (int i = 0; i < m; i++) { double a = 0.0; const double *row = &A[(size_t)i * n]; for (int j = 0; j < n; j++) a += row[j] * x[j]; act[i] = a; }
-        for (int i = 0; i < m; i++) if (act[i] < rlo[i] - FEAS_TOL || act[i] > rhi[i] + FEAS_TOL) return;
-        if (by_cost.empty()) {
-            by_cost.resize(n); std::iota(by_cost.begin(), by_cost.end(), 0);
-            std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return c[a] > c[b]; });
-        }
+        if (coff.empty()) build_columns();
+        std::vector<double> act(R.m);
+        for (int i = 0; i < R.m; i++) { act[i] = R.activity(i, x.data()); if (act[i] < R.lo[i] - FEAS_TOL || act[i] > R.hi[i] + FEAS_TOL) return; }
         for (int j : by_cost) {
             if (c[j] <= 0.0) break;
             double step = ub[j] - x[j];
-            for (int i = 0; i < m && step >= 1.0; i++) {
-                double a = A[(size_t)i * n + j];
-                if (a > 0.0 && rhi[i] < INF) step = std::min(step, std::floor((rhi[i] - act[i]) / a + 1e-9));
-                else if (a < 0.0 && rlo[i] > -INF) step = std::min(step, std::floor((act[i] - rlo[i]) / -a + 1e-9));
+            for (int k = coff[j]; k < coff[j + 1] && step >= 1.0; k++) {
+                const int i = crow[k]; const double a = ccoef[k];
+                if (a > 0.0 && R.hi[i] < INF) step = std::min(step, std::floor((R.hi[i] - act[i]) / a + 1e-9));
+                else if (a < 0.0 && R.lo[i] > -INF) step = std::min(step, std::floor((act[i] - R.lo[i]) / -a + 1e-9));
             }
             if (step < 1.0) continue;
             x[j] += step;
-            for (int i = 0; i < m; i++) { double a = A[(size_t)i * n + j]; if (a != 0.0) act[i] += a * step; }
+            for (int k = coff[j]; k < coff[j + 1]; k++) act[crow[k]] += ccoef[k] * step;
         }
         double z = 0.0; for (int j = 0; j < n; j++) z += c[j] * x[j];
         if (!have || z > best + 1e-12 * std::fabs(best)) { have = true; best = z; bx = x; }
@@ -197,7 +285,7 @@ struct CompSolver {
             if (have && z <= best + 1e-12 * std::fabs(best)) return;
         }
         if (j < 0) {
-            have = true; best = z; bx.assign(t.x.begin(), t.x.begin() + n);
+            have = true; bx.assign(t.x.begin(), t.x.begin() + n);
             for (auto &v : bx) v = std::round(v);
             double zz = 0.0; for (int k = 0; k < n; k++) zz += c[k] * bx[k];
             best = zz;
@@ -233,7 +321,7 @@ struct CompSolver {
 
     // returns: 0 infeasible, 1 optimal, 2 incumbent only (time limit)
     int run(bool canonical, std::vector<double> &xout) {
-        Tab root; root.init(n, m, A, c, lb, ub, rlo, rhi);
+        Tab root; root.init(&R, c, lb, ub); root.deadline = deadline;
         greedy_from(lb);
         dfs_opt(root);
         lp_iters += root.iters;
@@ -244,20 +332,24 @@ struct CompSolver {
         // phase 2: among vectors with c.x >= best - tol, minimise the LAST column, then the one before it, ... (bound probing,
         // one feasibility B&B per probe)
         double tol = 1e-9 * std::fabs(best);
-        std::vector<double> A2(A), rlo2(rlo), rhi2(rhi);
+        Rows R2 = R;
         double cs = 0.0; for (int k = 0; k < n; k++) cs = std::max(cs, std::fabs(c[k]));
         if (cs > 0.0) {
-            for (int k = 0; k < n; k++) A2.push_back(c[k] / cs);
-            rlo2.push_back((best - tol) / cs); rhi2.push_back(INF);
+            std::vector<std::pair<int, double>> terms;
+            for (int k = 0; k < n; k++) if (c[k] != 0.0) terms.push_back({k, c[k] / cs});
+            R2.add(terms, (best - tol) / cs, INF);
         }
-        int m2 = (int)rlo2.size();
         std::vector<double> cur(bx);
         // One tableau carries the columns fixed so far; every probe is a copy of it with one tightened bound, re-optimised by
         // the dual simplex from the parent basis (a handful of pivots) instead of a cold start.
-        // Budget in simplex pivots, not seconds: every replica of a sharded scheduler must take the same decision here.
-        pivot_limit = pivots + std::max<long>(3000, 4 * pivots);
-        Tab warm; warm.init(n, m2, A2, c, lb, ub, rlo2, rhi2);
-        if (warm.solve(200000) != LP_OPT) { xout = cur; return 1; }  // cannot happen: `cur` is feasible for it
+        work_limit = work + std::max(2.0e8, work);
+        Tab warm; warm.init(&R2, c, lb, ub); warm.deadline = deadline;
+        if (solve_counted(warm) != LP_OPT) { xout = cur; return 1; }  // cannot happen: `cur` is feasible for it
+        {   // every column above its lower bound costs at least one probe = one tableau copy: skip the whole phase when that alone
+            // exceeds the budget (large models keep the optimum they found — decided by size, identically on every replica)
+            double probes = 0.0; for (int j = 0; j < n; j++) if (cur[j] > lb[j]) probes += 1.0;
+            if (work + probes * (double)(warm.ma + 1) * (double)warm.width() > work_limit) { canonical_done = false; xout = cur; return 1; }
+        }
         for (int j = n - 1; j >= 0; j--) {  // last column first
             double lo = lb[j], hi = cur[j];
             bool first = true;
@@ -266,19 +358,22 @@ struct CompSolver {
                 double mid = first ? hi - 1 : std::floor((lo + hi) / 2);
                 first = false;
                 Tab t = warm;
+                work += (double)(warm.ma + 1) * (double)warm.width();
                 t.set_ub(j, mid);
                 std::vector<double> sol;
                 bool ok = dfs_feas(t, sol);
                 lp_iters += t.iters - warm.iters;
-                if (timed_out) { xout = cur; canonical_done = false; return 1; }  // optimal (phase 1 proved it) but the tie-break ran out of time
+                if (timed_out) { xout = cur; canonical_done = false; return 1; }  // optimal (phase 1 proved it) but the tie-break ran out of budget
                 if (ok) { cur = sol; hi = sol[j]; } else lo = mid + 1;
             }
+            const bool unmoved = std::fabs(warm.x[j] - hi) <= FEAS_TOL;  // already sitting there: fixing it changes neither the point nor its optimality
             warm.set_lb(j, hi); warm.set_ub(j, hi);
-            if (warm.solve(200000) != LP_OPT) {  // numerically lost the basis: rebuild it with the bounds fixed so far
+            if (unmoved) continue;
+            if (solve_counted(warm) != LP_OPT) {  // numerically lost the basis: rebuild it with the bounds fixed so far
                 std::vector<double> flb(lb), fub(ub);
                 for (int k = n - 1; k >= j; k--) flb[k] = fub[k] = cur[k];
-                warm = Tab(); warm.init(n, m2, A2, c, flb, fub, rlo2, rhi2);
-                if (warm.solve(200000) != LP_OPT) { xout = cur; return 1; }
+                warm = Tab(); warm.init(&R2, c, flb, fub); warm.deadline = deadline;
+                if (solve_counted(warm) != LP_OPT) { xout = cur; return 1; }
             }
         }
         xout = cur;
@@ -292,6 +387,66 @@ struct DSU {
     int find(int a) { while (p[a] != a) { p[a] = p[p[a]]; a = p[a]; } return a; }
     void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[std::max(a, b)] = std::min(a, b); }
 };
+
+// Sparse primal heuristic on the whole model (any size; O(passes x nnz)).  Start: every count column 0, every zero-cost bool that a
+// `>=` row needs at x = 0 (the "blocker short" flags, scheduler/solver.rs:233-253) at 1 — i.e. every lower-priority batch capped at
+// its cut — then raise columns greedily, most valuable first, as far as the rows allow; drop the flags whose `>=` row meanwhile
+// holds without them (that lifts the caps they imposed) and raise again.  The result is a priority-respecting maximal packing.
+// Returns false when the start point is not feasible (then there is simply no incumbent from here).
+bool sparse_greedy(const Model &mdl, const std::vector<double> &ub, std::vector<double> &x) {
+    const int n = mdl.ncols(), m = mdl.nrows();
+    std::vector<int> coff(n + 1, 0), crow; std::vector<double> ccoef;
+    for (int k = 0; k < (int)mdl.rcol.size(); k++) coff[mdl.rcol[k] + 1]++;
+    for (int j = 0; j < n; j++) coff[j + 1] += coff[j];
+    crow.resize(mdl.rcol.size()); ccoef.resize(mdl.rcol.size());
+    { std::vector<int> cur(coff.begin(), coff.end() - 1);
+      for (int i = 0; i < m; i++) for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) { int j = mdl.rcol[k]; crow[cur[j]] = i; ccoef[cur[j]++] = mdl.rcoef[k]; } }
+    x.assign(n, 0.0);
+    for (int i = 0; i < m; i++) {
+        if (mdl.rtype[i] == ROW_MAX || mdl.rhs[i] <= 1e-9) continue;  // a `>=`/`==` row violated at 0: switch on a zero-cost bool with a large enough coefficient
+        for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) {
+            int j = mdl.rcol[k];
+            if (mdl.kind[j] == COL_BOOL && mdl.obj[j] == 0.0 && mdl.rcoef[k] >= mdl.rhs[i] - 1e-9) { x[j] = 1.0; break; }
+        }
+    }
+    std::vector<double> act(m, 0.0);
+    for (int i = 0; i < m; i++) { double a = 0.0; for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) a += mdl.rcoef[k] * x[mdl.rcol[k]]; act[i] = a; }
+    auto row_ok = [&](int i, double a) {
+        const double tol = 1e-7 * (1.0 + std::fabs(mdl.rhs[i]));
+        return mdl.rtype[i] == ROW_MAX ? a <= mdl.rhs[i] + tol : (mdl.rtype[i] == ROW_MIN ? a >= mdl.rhs[i] - tol : std::fabs(a - mdl.rhs[i]) <= tol);
+    };
+    for (int i = 0; i < m; i++) if (!row_ok(i, act[i])) return false;
+    std::vector<int> order(n); std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return mdl.obj[a] > mdl.obj[b]; });
+    for (int pass = 0; pass < 64; pass++) {
+        bool changed = false;
+        for (int j : order) {
+            if (mdl.obj[j] <= 0.0) break;
+            double step = ub[j] - x[j];
+            for (int k = coff[j]; k < coff[j + 1] && step >= 1.0; k++) {
+                const int i = crow[k]; const double a = ccoef[k];
+                if (mdl.rtype[i] == ROW_EQ) { step = 0.0; break; }
+                if (a > 0.0 && mdl.rtype[i] == ROW_MAX) step = std::min(step, std::floor((mdl.rhs[i] - act[i]) / a + 1e-9));
+                else if (a < 0.0 && mdl.rtype[i] == ROW_MIN) step = std::min(step, std::floor((act[i] - mdl.rhs[i]) / -a + 1e-9));
+            }
+            if (step < 1.0) continue;
+            x[j] += step; changed = true;
+            for (int k = coff[j]; k < coff[j + 1]; k++) act[crow[k]] += ccoef[k] * step;
+        }
+        bool dropped = false;
+        for (int j = 0; j < n; j++) {  // flags that are no longer needed
+            if (mdl.kind[j] != COL_BOOL || mdl.obj[j] != 0.0 || x[j] != 1.0) continue;
+            bool ok = true;
+            for (int k = coff[j]; k < coff[j + 1] && ok; k++) ok = row_ok(crow[k], act[crow[k]] - ccoef[k]);
+            if (!ok) continue;
+            x[j] = 0.0; dropped = true;
+            for (int k = coff[j]; k < coff[j + 1]; k++) act[crow[k]] -= ccoef[k];
+        }
+        if (!changed && !dropped) break;
+        if (!dropped) break;  // nothing was unlocked: another raise pass cannot move anything
+    }
+    return true;
+}
 
 }  // namespace
 
@@ -326,6 +481,11 @@ Result solve(const Model &mdl, double time_limit_s, bool canonical) {
     std::vector<char> capped(n, 0);
     for (int j = 0; j < n; j++) if (ub[j] >= INF) { ub[j] = UB_CAP; capped[j] = 1; }
 
+    // ---- a feasible point for the whole model, before any LP: seeds every component's search and is the answer for components the
+    // dense method cannot take ----
+    std::vector<double> hx;
+    const bool have_hx = sparse_greedy(mdl, ub, hx);
+
     // ---- connected components ----
     DSU dsu(n);
     for (int i = 0; i < m; i++) for (int k = mdl.roff[i] + 1; k < mdl.roff[i + 1]; k++) dsu.unite(mdl.rcol[mdl.roff[i]], mdl.rcol[k]);
@@ -350,45 +510,46 @@ Result solve(const Model &mdl, double time_limit_s, bool canonical) {
     std::unordered_map<std::string, std::pair<int, std::vector<double>>> memo;
     for (size_t ci = 0; ci < ccols.size(); ci++) {
         auto &cols = ccols[ci]; auto &rows = crows[ci];
-        CompSolver cs; cs.n = (int)cols.size(); cs.m = (int)rows.size(); cs.deadline = deadline;
+        CompSolver cs; cs.n = (int)cols.size(); cs.deadline = deadline;
+        const int cm = (int)rows.size();
         for (int k = 0; k < cs.n; k++) local[cols[k]] = k;
         cs.c.resize(cs.n); cs.lb.assign(cs.n, 0.0); cs.ub.resize(cs.n);
         double cmax = 0.0;
         for (int k = 0; k < cs.n; k++) cmax = std::max(cmax, std::fabs(mdl.obj[cols[k]]));
         if (cmax == 0.0) cmax = 1.0;
         for (int k = 0; k < cs.n; k++) { cs.c[k] = mdl.obj[cols[k]] / cmax; cs.ub[k] = ub[cols[k]]; }  // costs O(1): scale-free pivoting
-        if (cs.m == 0) {  // free columns: at their upper bound if it pays (or for the lexicographic rule)
+        if (cm == 0) {  // free columns: at their upper bound if it pays (or for the lexicographic rule)
             for (int k = 0; k < cs.n; k++) {
                 if (capped[cols[k]]) { res.feasible = false; res.optimal = false; return res; }
                 res.x[cols[k]] = cs.ub[k];
             }
             continue;
         }
-        if ((double)cs.m * (double)(cs.n + cs.m) > 4.0e7) {  // too large for the dense exact method in this round
-            res.optimal = false;  // all-zero placement (every blocker flag = 1) is feasible: keep x = 0, beta = 1
-            for (int k = 0; k < cs.n; k++) res.x[cols[k]] = 0.0;
-            // satisfy Min rows of the form sum + s*beta >= s
-            for (int i : rows) if (mdl.rtype[i] == ROW_MIN && mdl.rhs[i] > 0) { int last = mdl.rcol[mdl.roff[i + 1] - 1]; res.x[last] = 1.0; }
-            continue;
-        }
-        cs.A.assign((size_t)cs.m * cs.n, 0.0); cs.rlo.resize(cs.m); cs.rhi.resize(cs.m);
-        for (int r = 0; r < cs.m; r++) {
+        cs.R.n = cs.n;
+        std::vector<std::pair<int, double>> terms;
+        for (int r = 0; r < cm; r++) {
             int i = rows[r]; double sc = 0.0;
-            for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) sc = std::max(sc, std::fabs(mdl.rcoef[k]));
+            terms.clear();
+            for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) {  // duplicate columns of one row are summed
+                int lc = local[mdl.rcol[k]]; bool dup = false;
+                for (auto &t : terms) if (t.first == lc) { t.second += mdl.rcoef[k]; dup = true; break; }
+                if (!dup) terms.push_back({lc, mdl.rcoef[k]});
+            }
+            for (auto &t : terms) sc = std::max(sc, std::fabs(t.second));
             if (sc == 0.0) sc = 1.0;
-            for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) cs.A[(size_t)r * cs.n + local[mdl.rcol[k]]] += mdl.rcoef[k] / sc;
+            for (auto &t : terms) t.second /= sc;
             double b = mdl.rhs[i] / sc;
-            cs.rlo[r] = mdl.rtype[i] == ROW_MAX ? -INF : b;
-            cs.rhi[r] = mdl.rtype[i] == ROW_MIN ? INF : b;
+            cs.R.add(terms, mdl.rtype[i] == ROW_MAX ? -INF : b, mdl.rtype[i] == ROW_MIN ? INF : b);
         }
         // identical components (same rows, bounds and — up to 2^-40 relative — the same normalised costs) share one solve:
         // workers with equal free/total vectors produce them by the hundred (solver.rs:95-192 builds one block per worker)
         std::string sig;
-        bool memo_ok = (size_t)cs.m * cs.n <= 4096;
+        bool memo_ok = cs.R.col.size() + (size_t)cs.n + (size_t)cm <= 8192;
         if (memo_ok) {
             auto put = [&](const void *p, size_t nb) { sig.append(reinterpret_cast<const char *>(p), nb); };
-            int dims[2] = {cs.n, cs.m}; put(dims, sizeof dims);
-            put(cs.ub.data(), cs.ub.size() * 8); put(cs.A.data(), cs.A.size() * 8); put(cs.rlo.data(), cs.rlo.size() * 8); put(cs.rhi.data(), cs.rhi.size() * 8);
+            int dims[2] = {cs.n, cm}; put(dims, sizeof dims);
+            put(cs.ub.data(), cs.ub.size() * 8); put(cs.R.off.data(), cs.R.off.size() * 4); put(cs.R.col.data(), cs.R.col.size() * 4);
+            put(cs.R.coef.data(), cs.R.coef.size() * 8); put(cs.R.lo.data(), cs.R.lo.size() * 8); put(cs.R.hi.data(), cs.R.hi.size() * 8);
             for (int k = 0; k < cs.n; k++) { long long qv = (long long)std::llround(cs.c[k] * 1099511627776.0); put(&qv, 8); }
             auto hit = memo.find(sig);
             if (hit != memo.end()) {
@@ -401,12 +562,21 @@ Result solve(const Model &mdl, double time_limit_s, bool canonical) {
                 continue;
             }
         }
+        if (have_hx) {  // incumbent from the sparse heuristic (restricted to this component it is feasible for the component)
+            cs.bx.resize(cs.n); double z = 0.0;
+            for (int k = 0; k < cs.n; k++) { cs.bx[k] = hx[cols[k]]; z += cs.c[k] * cs.bx[k]; }
+            cs.have = true; cs.best = z;
+        }
         std::vector<double> xo;
         int st = cs.run(canonical, xo);
         if (memo_ok && !cs.timed_out && (st == 0 || st == 1)) memo.emplace(std::move(sig), std::make_pair(st, xo));
         res.nodes += cs.nodes; res.lp_iters += cs.lp_iters;
         if (st == 0) {
-            if (cs.timed_out) { res.optimal = false; continue; }  // nothing found in time: leave zeros
+            if (cs.timed_out) {  // nothing found in time: all-zero placement with every blocker flag on (feasible for the tick's models)
+                res.optimal = false;
+                for (int i : rows) if (mdl.rtype[i] == ROW_MIN && mdl.rhs[i] > 0) { int last = mdl.rcol[mdl.roff[i + 1] - 1]; if (mdl.kind[last] == COL_BOOL) res.x[last] = 1.0; }
+                continue;
+            }
             res.feasible = false; res.optimal = false; return res;
         }
         if (st == 2) res.optimal = false;
