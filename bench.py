@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
-    ap.add_argument("--priority-ticks", type=int, default=3, help="ticks of the three-priority-level variant c3p (0 = skip)")
+    ap.add_argument("--priority-ticks", type=int, default=1, help="ticks of the three-priority-level variant c3p (0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=20, help="steps of the steady-state (delta-updated resident set) measurement, 0 = skip")
     ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")

@@ -281,6 +281,10 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc)
         if (!ctx->h_a.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc phase A");
         unsigned char *h = ctx->h_a.as<unsigned char>(), *hd = ctx->h_a.dev<unsigned char>();
         memset(h, 0, 16);
+        // K2 reads the packed tables from pinned memory; with a ready set to scan it rides along the K1 launch
+        UpView uv; int rc;
+        if ((rc = upload_tables(ctx, s, W, s->worker_total, s->worker_free, s->worker_remaining_ns, ctx->h_up, &uv))) return rc;
+        hqk::WorkerEvalArgs wea{uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc)};
         if (scan) {
             hqk::WaveGeom &g = sc->geom;
             g.waves_per_block = sc->G <= hqk::MAX_GROUPS_4W ? 4 : 1;
@@ -290,16 +294,14 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc)
             if (!ctx->d_wave_tab.ensure((size_t)g.tab_stride * sc->G * 4) || !ctx->d_gkey.ensure(N * 2 + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
             if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
             HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
-                                   ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
+                                   ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, &wea, ctx->stream));
             if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
             HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
                                    reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream));
             if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
+        } else {
+            HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc), ctx->stream));
         }
-        // K2 reads the packed tables from pinned memory while the scans run
-        UpView uv; int rc;
-        if ((rc = upload_tables(ctx, s, W, s->worker_total, s->worker_free, s->worker_remaining_ns, ctx->h_up, &uv))) return rc;
-        HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc), ctx->stream));
         HQ_HIP(hipStreamSynchronize(ctx->stream));
         const uint32_t *flags = reinterpret_cast<const uint32_t *>(h);
         if (scan && (flags[2] & 2u)) return fail(ctx, HQTICK_E_INVALID, "ready set holds a request id >= n_requests");
@@ -922,7 +924,7 @@ int hqtick_debug_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_
     HQ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
     for (int i = 0; i < iters; i++) {
         if (which == 0) HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), ctx->last_L, ctx->last_Q, g, ctx->d_wave_tab.as<uint32_t>(),
-                                              ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->stream));
+                                              ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, nullptr, ctx->stream));
         else if (which == 1) HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, ctx->last_Q, ctx->last_G, g, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + ctx->last_tb,
                                                         d + ctx->last_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, ctx->last_plan_bytes, nullptr, ctx->stream));
         else return fail(ctx, HQTICK_E_INVALID, "which: 0 = level_hist, 1 = select_scatter");

@@ -33,8 +33,9 @@ hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *lev
 // the per-task group key gkey[i] = g (GKEY_INVALID for a task whose priority / rq is not in the tables) that K4 re-reads
 // instead of the 12 B/task priority + rq columns.  levels = descending table in HBM, levels_host = the same on the host (passed in
 // the kernel arguments when L <= 4, so the common case needs neither a staging load nor a barrier).
+struct WorkerEvalArgs;  // K2 riding along (below)
 hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, const uint64_t *levels_host, uint32_t L,
-                uint32_t Q, WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, hipStream_t s);
+                uint32_t Q, WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, const WorkerEvalArgs *ride_along, hipStream_t s);
 // K1b: exclusive scan of every wave_tab row (in place -> offsets) and the row totals into hist[G].
 // err_in (device) is forwarded to err_out (may be pinned host memory) by the same launch.
 hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, uint32_t *err_in, uint32_t *err_out, hipStream_t s);
@@ -53,6 +54,10 @@ struct RequestTable {
 hipError_t worker_eval(const uint64_t *total, const uint64_t *free_, const int64_t *remaining_ns, uint32_t W, uint32_t R,
                  RequestTable rt, uint32_t n_entries, uint8_t *flags, uint32_t *tmc, hipStream_t s);
 size_t worker_eval_lds(uint32_t R, uint32_t n_variants, uint32_t n_entries);  // LDS the launch needs (request table + 32 worker rows)
+// The same evaluation as extra workgroups of the K1 launch (level_hist's `ride_along`): one launch and one kernel boundary less per tick.
+struct WorkerEvalArgs {
+    const uint64_t *total, *free_; const int64_t *remaining_ns; uint32_t W, R; RequestTable rt; uint32_t n_entries; uint8_t *flags; uint32_t *tmc;
+};
 
 // K4: select the first take[g] tasks (ascending id) of every group and scatter them to sel_task/sel_key at base[g] + rank
 // (sel_key = the task's group key; its priority level is key / Q).  wave_off = output of scan_waves; slices whose groups are

@@ -135,6 +135,68 @@ __global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) levels[i + shift] = lv[i];
 }
 
+// ------------------------------------------------------------------------------------------------ K2
+// One workgroup per 32 workers.  Worker rows and the whole request table are staged in LDS with coalesced loads (the inputs
+// may sit in pinned host memory: every byte crosses PCIe once per workgroup), then one thread per (worker, variant).
+// LDS: [total 32*R u64][free 32*R u64][rem 32 i64][entry_amount NE u64][variant_min_time NV u64][variant_entry_off NV+1 u32]
+//      [entry_resource NE u32][entry_kind NE u8]
+struct EvalArgs {
+    const uint64_t *total, *free_; const int64_t *remaining_ns; uint32_t W, R; RequestTable rt; uint32_t n_entries; uint8_t *flags; uint32_t *tmc;
+};
+
+__device__ __forceinline__ void worker_eval_block(unsigned char *smem, uint32_t block, const EvalArgs &ea) {
+    const uint64_t *__restrict__ total = ea.total, *__restrict__ free_ = ea.free_;
+    const int64_t *__restrict__ remaining_ns = ea.remaining_ns;
+    const RequestTable &rt = ea.rt;
+    uint8_t *__restrict__ flags = ea.flags; uint32_t *__restrict__ tmc = ea.tmc;
+    const uint32_t W = ea.W, R = ea.R, NV = rt.n_variants, NE = ea.n_entries;
+    uint64_t *s_tot = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *s_free = s_tot + 32 * R;
+    int64_t *s_rem = reinterpret_cast<int64_t *>(s_free + 32 * R);
+    uint64_t *s_amt = reinterpret_cast<uint64_t *>(s_rem + 32);
+    uint64_t *s_time = s_amt + NE;
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(s_time + NV);
+    uint32_t *s_res = s_off + NV + 1;
+    uint8_t *s_kind = reinterpret_cast<uint8_t *>(s_res + NE);
+    const uint32_t w0 = block * 32, nw = W - w0 < 32 ? W - w0 : 32;
+    for (uint32_t i = threadIdx.x; i < nw * R; i += blockDim.x) { s_tot[i] = total[(size_t)w0 * R + i]; s_free[i] = free_[(size_t)w0 * R + i]; }
+    for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) s_rem[i] = remaining_ns[w0 + i];
+    for (uint32_t i = threadIdx.x; i < NE; i += blockDim.x) { s_amt[i] = rt.entry_amount[i]; s_res[i] = rt.entry_resource[i]; s_kind[i] = rt.entry_kind[i]; }
+    for (uint32_t i = threadIdx.x; i < NV; i += blockDim.x) s_time[i] = rt.variant_min_time_ns[i];
+    for (uint32_t i = threadIdx.x; i <= NV; i += blockDim.x) s_off[i] = rt.variant_entry_off[i];
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < nw * NV; idx += blockDim.x) {
+        const uint32_t wl = idx / NV, v = idx % NV;
+        bool imm = true, cap = true, any = false;
+        uint64_t best = 0xFFFFFFFFFFFFFFFFull;
+        for (uint32_t e = s_off[v]; e < s_off[v + 1]; e++) {
+            const uint32_t r = s_res[e];
+            const uint64_t f = r < R ? s_free[wl * R + r] : 0, tt = r < R ? s_tot[wl * R + r] : 0;
+            uint64_t c;
+            if (s_kind[e] == 0) {  // amount
+                const uint64_t a = s_amt[e];
+                imm = imm && a <= f; cap = cap && a <= tt;
+                c = f / a; if (c > 1024) c = 1024;            // MAX_TASK_PER_WORKER  workerload.rs:12,131
+            } else {                                           // All: min_amount = 1 fraction  request.rs:34-36
+                imm = imm && f >= 1; cap = cap && tt >= 1;
+                c = f == 0 ? 0 : 1;                            // workerload.rs:133-141
+            }
+            if (!any || c < best) best = c;
+            any = true;
+        }
+        const int64_t rem = s_rem[wl];
+        const bool time_ok = rem == INT64_MAX || (rem >= 0 && (uint64_t)rem >= s_time[v]);  // worker.rs:320-326
+        const size_t t = (size_t)(w0 + wl) * NV + v;
+        flags[t] = (imm ? 1 : 0) | (cap ? 2 : 0) | (time_ok ? 4 : 0);
+        tmc[t] = any ? (uint32_t)best : 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_worker_eval(EvalArgs ea) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    worker_eval_block(smem, blockIdx.x, ea);
+}
+
 // ------------------------------------------------------------------------------------------------ K1
 // Every wavefront owns a contiguous slice of the ready set and a private LDS counter row.  A lane handles two consecutive
 // tasks per 128-task tile (one dwordx4 of priorities, one dwordx2 of request ids, one dword of group keys), two tiles in
@@ -147,13 +209,18 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
                                                          const uint64_t *__restrict__ levels, Levels4 l4, uint32_t L, uint32_t Q,
                                                          uint32_t tasks_per_wave, uint32_t n_waves, uint32_t stride, uint32_t lds_levels,
                                                          uint32_t *__restrict__ wave_tab, uint16_t *__restrict__ gkey,
-                                                         uint32_t *__restrict__ err_flag) {
+                                                         uint32_t *__restrict__ err_flag, uint32_t n_eval_blocks, EvalArgs ea) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x < n_eval_blocks) {  // ride-along workgroups (dispatched first): K2, whose PCIe round trips hide under the scan
+        worker_eval_block(smem, blockIdx.x, ea);
+        return;
+    }
+    const uint32_t hist_block = blockIdx.x - n_eval_blocks;
     const uint32_t G = L * Q;
     uint64_t *s_levels = reinterpret_cast<uint64_t *>(smem);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)(SMALL_L ? 0 : lds_levels) * 8) + (threadIdx.x >> 6) * G;
     const uint32_t lane = lane_id();
-    const uint32_t wave = blockIdx.x * WPB + (threadIdx.x >> 6);
+    const uint32_t wave = hist_block * WPB + (threadIdx.x >> 6);
     if (!SMALL_L) for (uint32_t i = threadIdx.x; i < lds_levels; i += blockDim.x) s_levels[i] = levels[i];
     for (uint32_t g = lane; g < G; g += 64) s_cnt[g] = 0;
     if (!SMALL_L) __syncthreads();
@@ -321,58 +388,6 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
                 if (before == 0) s_cnt[g] = cur + (uint32_t)__popcll(peers);
             }
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ K2
-// One workgroup per 32 workers.  Worker rows and the whole request table are staged in LDS with coalesced loads (the inputs
-// may sit in pinned host memory: every byte crosses PCIe once per workgroup), then one thread per (worker, variant).
-// LDS: [total 32*R u64][free 32*R u64][rem 32 i64][entry_amount NE u64][variant_min_time NV u64][variant_entry_off NV+1 u32]
-//      [entry_resource NE u32][entry_kind NE u8]
-__global__ void __launch_bounds__(256) k_worker_eval(const uint64_t *__restrict__ total, const uint64_t *__restrict__ free_,
-                                                     const int64_t *__restrict__ remaining_ns, uint32_t W, uint32_t R, RequestTable rt,
-                                                     uint32_t n_entries, uint8_t *__restrict__ flags, uint32_t *__restrict__ tmc) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t NV = rt.n_variants, NE = n_entries;
-    uint64_t *s_tot = reinterpret_cast<uint64_t *>(smem);
-    uint64_t *s_free = s_tot + 32 * R;
-    int64_t *s_rem = reinterpret_cast<int64_t *>(s_free + 32 * R);
-    uint64_t *s_amt = reinterpret_cast<uint64_t *>(s_rem + 32);
-    uint64_t *s_time = s_amt + NE;
-    uint32_t *s_off = reinterpret_cast<uint32_t *>(s_time + NV);
-    uint32_t *s_res = s_off + NV + 1;
-    uint8_t *s_kind = reinterpret_cast<uint8_t *>(s_res + NE);
-    const uint32_t w0 = blockIdx.x * 32, nw = W - w0 < 32 ? W - w0 : 32;
-    for (uint32_t i = threadIdx.x; i < nw * R; i += blockDim.x) { s_tot[i] = total[(size_t)w0 * R + i]; s_free[i] = free_[(size_t)w0 * R + i]; }
-    for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) s_rem[i] = remaining_ns[w0 + i];
-    for (uint32_t i = threadIdx.x; i < NE; i += blockDim.x) { s_amt[i] = rt.entry_amount[i]; s_res[i] = rt.entry_resource[i]; s_kind[i] = rt.entry_kind[i]; }
-    for (uint32_t i = threadIdx.x; i < NV; i += blockDim.x) s_time[i] = rt.variant_min_time_ns[i];
-    for (uint32_t i = threadIdx.x; i <= NV; i += blockDim.x) s_off[i] = rt.variant_entry_off[i];
-    __syncthreads();
-    for (uint32_t idx = threadIdx.x; idx < nw * NV; idx += blockDim.x) {
-        const uint32_t wl = idx / NV, v = idx % NV;
-        bool imm = true, cap = true, any = false;
-        uint64_t best = 0xFFFFFFFFFFFFFFFFull;
-        for (uint32_t e = s_off[v]; e < s_off[v + 1]; e++) {
-            const uint32_t r = s_res[e];
-            const uint64_t f = r < R ? s_free[wl * R + r] : 0, tt = r < R ? s_tot[wl * R + r] : 0;
-            uint64_t c;
-            if (s_kind[e] == 0) {  // amount
-                const uint64_t a = s_amt[e];
-                imm = imm && a <= f; cap = cap && a <= tt;
-                c = f / a; if (c > 1024) c = 1024;            // MAX_TASK_PER_WORKER  workerload.rs:12,131
-            } else {                                           // All: min_amount = 1 fraction  request.rs:34-36
-                imm = imm && f >= 1; cap = cap && tt >= 1;
-                c = f == 0 ? 0 : 1;                            // workerload.rs:133-141
-            }
-            if (!any || c < best) best = c;
-            any = true;
-        }
-        const int64_t rem = s_rem[wl];
-        const bool time_ok = rem == INT64_MAX || (rem >= 0 && (uint64_t)rem >= s_time[v]);  // worker.rs:320-326
-        const size_t t = (size_t)(w0 + wl) * NV + v;
-        flags[t] = (imm ? 1 : 0) | (cap ? 2 : 0) | (time_ok ? 4 : 0);
-        tmc[t] = any ? (uint32_t)best : 0;
     }
 }
 
@@ -629,20 +644,28 @@ hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *lev
 static uint32_t lds_levels_for(uint32_t L) { return L <= 1024 ? L : 0; }
 
 hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, const uint64_t *levels_host, uint32_t L, uint32_t Q,
-                WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, hipStream_t s) {
+                WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, const WorkerEvalArgs *ride_along, hipStream_t s) {
     if (n == 0 || geom.n_waves == 0) return hipSuccess;
     const uint32_t G = L * Q;
     const bool small = L <= 4 && levels_host != nullptr;
     const uint32_t ll = small ? 0 : lds_levels_for(L);
     Levels4 l4{};
     if (small) for (uint32_t i = 0; i < L; i++) l4.v[i] = levels_host[i];
+    EvalArgs ea{};
+    uint32_t neb = 0; size_t eval_lds = 0;
+    if (ride_along && ride_along->W && ride_along->rt.n_variants) {
+        ea = EvalArgs{ride_along->total, ride_along->free_, ride_along->remaining_ns, ride_along->W, ride_along->R, ride_along->rt, ride_along->n_entries, ride_along->flags, ride_along->tmc};
+        neb = (ride_along->W + 31) / 32; eval_lds = worker_eval_lds(ride_along->R, ride_along->rt.n_variants, ride_along->n_entries);
+    }
     hipError_t e;
 #define HQK_LAUNCH_HIST(WPB, SMALL, GRID, BLOCK)                                                                                                     \
     do {                                                                                                                                             \
         size_t lds = (size_t)ll * 8 + (size_t)(WPB) * G * 4;                                                                                          \
+        if (eval_lds > lds) lds = eval_lds;                                                                                                          \
         auto kern = k_level_hist<WPB, SMALL>;                                                                                                        \
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e; \
-        hipLaunchKernelGGL(kern, dim3(GRID), dim3(BLOCK), lds, s, prio, rq, n, levels, l4, L, Q, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, ll, wave_tab, gkey, err_flag); \
+        hipLaunchKernelGGL(kern, dim3((GRID) + neb), dim3(BLOCK), lds, s, prio, rq, n, levels, l4, L, Q, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, ll, wave_tab, gkey, \
+                           err_flag, neb, ea);                                                                                                       \
     } while (0)
     if (geom.waves_per_block == 4) { if (small) HQK_LAUNCH_HIST(4, true, (geom.n_waves + 3) / 4, 256); else HQK_LAUNCH_HIST(4, false, (geom.n_waves + 3) / 4, 256); }
     else { if (small) HQK_LAUNCH_HIST(1, true, geom.n_waves, 64); else HQK_LAUNCH_HIST(1, false, geom.n_waves, 64); }
@@ -710,7 +733,7 @@ hipError_t worker_eval(const uint64_t *total, const uint64_t *free_, const int64
     size_t lds = worker_eval_lds(R, rt.n_variants, n_entries);
     hipError_t e;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_worker_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_worker_eval, dim3((W + 31) / 32), dim3(256), lds, s, total, free_, remaining_ns, W, R, rt, n_entries, flags, tmc);
+    hipLaunchKernelGGL(k_worker_eval, dim3((W + 31) / 32), dim3(256), lds, s, EvalArgs{total, free_, remaining_ns, W, R, rt, n_entries, flags, tmc});
     return hipGetLastError();
 }
 
