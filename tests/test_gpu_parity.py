@@ -248,3 +248,61 @@ def test_sharded_sink_too_small():
     with pytest.raises(HqTickError) as e:
         st.tick_local(snap.to_c(), len(snap.worker_id))
     assert e.value.code == abi.HQTICK_E_CAPACITY
+
+
+# ------------------------------------------------------------------------------------------------------ BASELINE sizes
+def test_c4_full_sharded_properties():
+    """BASELINE configs[3]: 1 M tasks with 2-variant OR-lists, 4096 workers, 8 worker shards.  The oracle needs minutes at this size,
+    so: every shard through the HIP library, merged, checked for the size-independent properties + agreement of the replicated parts."""
+    from hyperqueue_amd import sharded
+
+    snap = workloads.make("c4")
+    cfg = abi.make_config(time_limit_s=20.0)
+    W, R, world, cap = len(snap.worker_id), snap.n_resources, 8, 1 << 18
+    sinks, results = [], []
+    for r in range(world):
+        st = sharded.ShardedTick(cfg, rank=r, world=world, records_per_shard=cap)
+        res_c, sink = st.tick_local(snap.to_c(), W)
+        sinks.append(sink.cpu().numpy().copy())
+        results.append(abi.parse_result(res_c, W, R))
+        st.t.close()
+    records = sharded.merge_shards(np.concatenate(sinks), world, W, cap)
+    for r in results[1:]:  # replicated stages agree on every rank
+        assert r.counts == results[0].counts and r.batches == results[0].batches and (r.new_free == results[0].new_free).all()
+    got = results[0]
+    ids = snap.task_id
+    rq_of = snap.task_rq
+    idx_of = lambda t: int(t & 0xFFFFFFFF) - 1  # job 1, task 1..n
+    seen = np.zeros(len(ids), bool)
+    used = np.zeros((W, R), np.int64)
+    cd = got.counts_dict()
+    per_rq_max = {}
+    for w in range(W):
+        c = {}
+        for (t, v, k) in records[w]:
+            i = idx_of(t)
+            assert ids[i] == t and not seen[i]
+            seen[i] = True
+            q = int(rq_of[i])
+            per_rq_max[q] = max(per_rq_max.get(q, -1), i)
+            if k == abi.HQ_REC_ASSIGN:
+                c[(q, v)] = c.get((q, v), 0) + 1
+                for (res, kind, a) in snap.requests[q][v]["entries"]:
+                    used[w, res] += a
+        assert c == {(q, v): n for (q, v, ww), n in cd.items() if ww == w}  # records agree with the counts
+    assert (used <= snap.worker_free.astype(np.int64)).all()
+    assert (snap.worker_free.astype(np.int64) - used == got.new_free.astype(np.int64)).all()
+    for q, last in per_rq_max.items():  # take_tasks: a prefix of every queue, no holes (one priority level)
+        mine = seen[: last + 1][rq_of[: last + 1] == q]
+        assert mine.all()
+    assert seen.sum() == sum(len(r) for r in records) > 0
+
+
+def test_c3_full_equals_oracle_cold_tick(gpu):
+    """BASELINE configs[2] at full size against the canonical oracle: 1 M tasks x 1024 workers (the oracle needs ~2 s here)."""
+    from oracle.oracle import Oracle
+
+    snap = workloads.make("c3")
+    got = gpu.tick(snap)
+    want = Oracle(abi.make_config(time_limit_s=60.0), canonical=True).tick(snap)
+    assert_same(got, want)

@@ -162,3 +162,38 @@ def test_resident_add_rejects_duplicates_and_unsorted():
     assert t.ready_count() == 1_990
     t.ready_compact()
     assert t.ready_count() == 1_990
+
+
+def test_resident_steady_state_full_c3():
+    """BASELINE size (1 M tasks x 1024 workers): cold tick, then two steady-state steps (everything handed out has finished, as many
+    tasks of the same classes arrive) with the ready set updated on the device only — every tick bit-exact with the oracle on the
+    equivalent full snapshot."""
+    from hyperqueue_amd.tick import Tick
+    from oracle.oracle import Oracle
+
+    cfg = abi.make_config(time_limit_s=60.0)
+    snap = workloads.make("c3")
+    t = Tick(cfg)
+    o = Oracle(cfg, canonical=True)
+    t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+    ids, prio, rq = snap.task_id.copy(), snap.task_priority.copy(), snap.task_rq.copy()
+    empty = abi.Snapshot(**{f: getattr(snap, f) for f in (
+        "n_resources", "worker_id", "worker_total", "worker_free", "worker_remaining_ns", "worker_min_utilization", "worker_flags", "worker_group",
+        "n_groups", "blocked", "assigned", "prefilled", "requests")}, task_id=np.zeros(0, np.uint64), task_priority=np.zeros(0, np.uint64), task_rq=np.zeros(0, np.uint32))
+    next_id = int(ids[-1]) + 1
+    for step in range(3):
+        got = t.tick(empty, resident=True)
+        full = abi.Snapshot(**{f: getattr(snap, f) for f in (
+            "n_resources", "worker_id", "worker_total", "worker_free", "worker_remaining_ns", "worker_min_utilization", "worker_flags", "worker_group",
+            "n_groups", "blocked", "assigned", "prefilled", "requests")}, task_id=ids, task_priority=prio, task_rq=rq)
+        assert_same(got, o.tick(full))
+        t.ready_consume_last()
+        gone = np.asarray(sorted(tt for recs in got.records for (tt, _, _) in recs), np.uint64)
+        keep = ~np.isin(ids, gone)
+        gone_rq = rq[~keep]
+        ids, prio, rq = ids[keep], prio[keep], rq[keep]
+        assert t.ready_count() == len(ids)
+        new_ids = np.arange(next_id, next_id + len(gone), dtype=np.uint64); next_id += len(gone)
+        t.ready_add(new_ids, np.full(len(gone), prio[0], np.uint64), gone_rq)
+        ids, prio, rq = np.concatenate([ids, new_ids]), np.concatenate([prio, np.full(len(gone), prio[0], np.uint64)]), np.concatenate([rq, gone_rq])
+        assert t.ready_count() == len(ids) == 1_000_000
