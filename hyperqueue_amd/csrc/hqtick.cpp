@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -238,7 +239,8 @@ struct Scan {  // result of GPU phase A
 
 // GPU phase A: K2 on the real workers, level table (cached across ticks, re-validated by K1), K1 + K1b on the ready set in
 // ctx->d_t*.  One stream synchronisation in the steady state.
-int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc) {
+// `while_gpu_runs` (may be null) is host work that needs only the ADDRESSES of K2's output, run between the launches and the sync.
+int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc, const std::function<void()> *while_gpu_runs = nullptr) {
     const uint32_t W = s->n_workers, R = s->n_resources, Q = s->n_requests;
     const uint64_t N = ctx->n_ready;
     sc->Q = Q; sc->L = 0; sc->G = 0; sc->levels.clear(); sc->hist.clear();
@@ -302,6 +304,8 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc)
         } else {
             HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc), ctx->stream));
         }
+        ev->flags = h + o_fl; ev->tmc = reinterpret_cast<const uint32_t *>(h + o_tmc);
+        if (while_gpu_runs) (*while_gpu_runs)();
         HQ_HIP(hipStreamSynchronize(ctx->stream));
         const uint32_t *flags = reinterpret_cast<const uint32_t *>(h);
         if (scan && (flags[2] & 2u)) return fail(ctx, HQTICK_E_INVALID, "ready set holds a request id >= n_requests");
@@ -363,13 +367,13 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     // ---------------- GPU phase A ----------------
     WorkerEval ev;
     Scan sc;
-    if ((rc = phase_a(ctx, s, &ev, &sc))) return rc;
+    hqhost::Problem &pb = ctx->pb;
+    const std::function<void()> prep = [&]() { fill_problem(pb, s, ctx->cfg, ev); };  // request/worker views: no GPU output needed yet
+    if ((rc = phase_a(ctx, s, &ev, &sc, &prep))) return rc;
     mark();  // 0: phase A done
     double t1 = now_us();
 
     // ---------------- host: batches + placement ----------------
-    hqhost::Problem &pb = ctx->pb;
-    fill_problem(pb, s, ctx->cfg, ev);
     std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
     std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
     export_batches(ctx, batches, out);
@@ -551,6 +555,27 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     double t4 = now_us();
 
     // ---------------- GPU phase C ----------------
+    bool assembled = false;
+    auto assemble_host_part = [&]() {  // everything of the result that needs no GPU output: overlapped with phase C
+        assembled = true;
+        ctx->rec_off = ps.out_off;
+        ctx->retract_off.assign(W + 1, 0); ctx->retract_task.assign(ps.retract_pairs.size(), 0);
+        {
+            for (auto &rp : ps.retract_pairs) if (rp.first < W) ctx->retract_off[rp.first + 1]++;
+            for (uint32_t w = 0; w < W; w++) ctx->retract_off[w + 1] += ctx->retract_off[w];
+            std::vector<uint32_t> cur(ctx->retract_off.begin(), ctx->retract_off.end() - 1);
+            for (auto &rp : ps.retract_pairs) if (rp.first < W) ctx->retract_task[cur[rp.first]++] = rp.second;  // stable: per worker in emission order
+        }
+        // Worker::insert_sn_task for every placed task (server/worker.rs:188-196 -> workerload.rs:156-165)
+        ctx->new_free.assign(s->worker_free, s->worker_free + (size_t)W * R);
+        for (uint32_t k = 0; k < nkeys; k++) {
+            const hqhost::VariantView &vv = pb.variants[pb.rqs[cnt.keys[k].first].first_variant + cnt.keys[k].second];
+            for (auto &wc : cnt.per_key[k]) for (uint32_t e = 0; e < vv.n_entries; e++) {
+                uint64_t &f = ctx->new_free[(size_t)wc.first * R + vv.res[e]];
+                if (vv.kind[e] == HQ_ENTRY_ALL) f = 0; else { uint64_t d = vv.amount[e] * (uint64_t)wc.second; f = f > d ? f - d : 0; }
+            }
+        }
+    };
     size_t n_mn_ids = 0; for (auto &sets : cnt.mn_sets) n_mn_ids += sets.size();
     size_t o_rv = (size_t)n_rec * 8, o_rk = o_rv + n_rec, o_mn = (o_rk + n_rec + 7) & ~(size_t)7, o_fl = o_mn + n_mn_ids * 8, rec_bytes = o_fl + 64;
     if (!ctx->h_rec.ensure(rec_bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc records");
@@ -618,6 +643,7 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
             }
         }
         mark();  // 7: phase C enqueued
+        assemble_host_part();
         HQ_HIP(hipStreamSynchronize(ctx->stream));
         if (flags[0]) return fail(ctx, HQTICK_E_CAPACITY, "mapping kernel capacity exceeded");
         float ms = 0;
@@ -633,15 +659,8 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         HQ_HIP(hipMemcpy(ctx->sink, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
     }
     mark();  // 8: phase C synced
-    // ---------------- assemble the result view ----------------
-    ctx->rec_off = ps.out_off;
-    ctx->retract_off.assign(W + 1, 0); ctx->retract_task.assign(ps.retract_pairs.size(), 0);
-    {
-        for (auto &rp : ps.retract_pairs) if (rp.first < W) ctx->retract_off[rp.first + 1]++;
-        for (uint32_t w = 0; w < W; w++) ctx->retract_off[w + 1] += ctx->retract_off[w];
-        std::vector<uint32_t> cur(ctx->retract_off.begin(), ctx->retract_off.end() - 1);
-        for (auto &rp : ps.retract_pairs) if (rp.first < W) ctx->retract_task[cur[rp.first]++] = rp.second;  // stable: per worker in emission order
-    }
+    // ---------------- assemble the result view (the GPU-dependent part; the rest ran while the GPU worked) ----------------
+    if (!assembled) assemble_host_part();
     ctx->mn_task.clear(); ctx->mn_off.assign(1, 0); ctx->mn_worker.clear();
     {
         size_t pos = 0;
@@ -649,15 +668,6 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
             ctx->mn_task.push_back(mn_ids[pos++]);
             for (uint32_t w : set) ctx->mn_worker.push_back(w);
             ctx->mn_off.push_back((uint32_t)ctx->mn_worker.size());
-        }
-    }
-    // Worker::insert_sn_task for every placed task (server/worker.rs:188-196 -> workerload.rs:156-165)
-    ctx->new_free.assign(s->worker_free, s->worker_free + (size_t)W * R);
-    for (uint32_t k = 0; k < nkeys; k++) {
-        const hqhost::VariantView &vv = pb.variants[pb.rqs[cnt.keys[k].first].first_variant + cnt.keys[k].second];
-        for (auto &wc : cnt.per_key[k]) for (uint32_t e = 0; e < vv.n_entries; e++) {
-            uint64_t &f = ctx->new_free[(size_t)wc.first * R + vv.res[e]];
-            if (vv.kind[e] == HQ_ENTRY_ALL) f = 0; else { uint64_t d = vv.amount[e] * (uint64_t)wc.second; f = f > d ? f - d : 0; }
         }
     }
     out->status = status;
