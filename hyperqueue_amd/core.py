@@ -465,6 +465,8 @@ class SchedEnv:
         wids = sorted(self.workers)
         if res.status < 0:
             raise RuntimeError(f"tick failed: {res.status}")
+        # create_task_mapping drains the prefill sets (take_tasks) for every worker before process_proactive_filling refills any
+        # (mapping.rs:36-157 then :159-234): all retracts first, then the records
         for i, wid in enumerate(wids):
             w = self.workers[wid]
             for tid in res.retracts[i]:  # Prefilled{old} -> Retracting{old}  mapping.rs:81-101
@@ -474,6 +476,8 @@ class SchedEnv:
                 t.state = RETRACTING
                 p, s = self.prefill[t.rq]
                 s.remove(tid)
+        for i, wid in enumerate(wids):
+            w = self.workers[wid]
             for (tid, v, kind) in res.records[i]:
                 t = self.tasks[tid]
                 if kind == abi.HQ_REC_ASSIGN:  # Waiting -> Assigned  mapping.rs:53-65

@@ -96,7 +96,7 @@ def test_resident_multi_tick_equals_full_snapshots(seed):
                 elif op == "open_gate":
                     gt = e.tasks[e._gate]
                     e.ready[gt.rq].discard(e._gate)
-                    gt.state = 5  # FINISHED
+                    gt.state = 6  # FINISHED
                     for c in gt.consumers:
                         ct = e.tasks[c]
                         ct.unfinished_deps -= 1
