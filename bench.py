@@ -33,7 +33,7 @@ def cpu_baseline(snap, ticks: int):
     from hyperqueue_amd import abi
     from oracle.oracle import Oracle
 
-    o = Oracle(abi.make_config(time_limit_s=5.0))
+    o = Oracle(abi.make_config(time_limit_s=5.0), reference_solver_options=True)  # HiGHS with its default options, as the reference runs it
     lat, assigned = [], 0
     for _ in range(ticks):
         t0 = time.perf_counter()

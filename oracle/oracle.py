@@ -89,6 +89,9 @@ def lib():
 # ------------------------------------------------------------------------------------------------------
 # HiGHS (scipy) behind the reference's LpInnerSolver contract: maximise, integer columns 0.. / 0..=1
 # ------------------------------------------------------------------------------------------------------
+_PRESOLVE_ON = False  # set by Oracle(reference_solver_options=True): HiGHS exactly as the reference configures it (cpu_baseline timing)
+
+
 def _highs(c_max, A, lo, hi, lb, ub, time_limit=None):
     """maximise c_max.x with HiGHS; returns (x rounded, status) or (None, status)."""
     from scipy.optimize import Bounds, LinearConstraint, milp
@@ -104,7 +107,7 @@ def _highs(c_max, A, lo, hi, lb, ub, time_limit=None):
     # retry without it whenever a large model comes back infeasible.  (bench.py's cpu_baseline times the large models as the reference
     # would run them, presolve on.)
     nnz = int(A.nnz) if A is not None else 0
-    if nnz <= 200_000:
+    if nnz <= 200_000 and not _PRESOLVE_ON:
         opts["presolve"] = False
     res = milp(-np.asarray(c_max, float), constraints=cons, integrality=np.ones(n), bounds=Bounds(lb, ub), options=opts)
     if res.status == 2 and "presolve" not in opts:
@@ -196,9 +199,10 @@ def _solve_canonical(obj, A, lo, hi, lb, ub):
 class Oracle:
     """One oracle context (== one tako `Core`'s scheduler config)."""
 
-    def __init__(self, config: Optional[abi.Config] = None, canonical: bool = False):
+    def __init__(self, config: Optional[abi.Config] = None, canonical: bool = False, reference_solver_options: bool = False):
         self.cfg = config or abi.make_config()
         self.canonical = canonical
+        self.reference_solver_options = reference_solver_options
         self._ctx = lib().oracle_create(C.byref(self.cfg))
         self.solver_s = 0.0
         self.last_models = []
@@ -226,7 +230,12 @@ class Oracle:
                 rf = np.ctypeslib.as_array(rcoef, shape=(nnz,)) if nnz else np.zeros(0)
             else:
                 rt, rh, ro, rc, rf = np.zeros(0, np.uint8), np.zeros(0), np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0)
-            r = solve_milp(o, k, rt, rh, ro, rc, rf, tlimit, canonical=self.canonical)
+            global _PRESOLVE_ON
+            _PRESOLVE_ON = self.reference_solver_options
+            try:
+                r = solve_milp(o, k, rt, rh, ro, rc, rf, tlimit, canonical=self.canonical)
+            finally:
+                _PRESOLVE_ON = False
             if r is None:
                 return 0
             x, z, opt = r
