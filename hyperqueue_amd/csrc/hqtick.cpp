@@ -743,15 +743,26 @@ int hqtick_run(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick_result *
 int hqtick_upload_ready(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority, const uint32_t *task_rq, int sorted) {
     if (!ctx) return HQTICK_E_INVALID;
     if (n && (!task_id || !task_priority || !task_rq)) return fail(ctx, HQTICK_E_INVALID, "null ready-set column");
-    if (!sorted) return fail(ctx, HQTICK_E_UNSUPPORTED, "device-side sort of an unsorted ready set is not implemented in this round: pass ids ascending");
-    for (uint64_t i = 1; i < n; i++) if (task_id[i - 1] >= task_id[i]) return fail(ctx, HQTICK_E_INVALID, "ready set not sorted by task id");
+    if (sorted) for (uint64_t i = 1; i < n; i++) if (task_id[i - 1] >= task_id[i]) return fail(ctx, HQTICK_E_INVALID, "ready set not sorted by task id");
+    for (uint64_t i = 0; i < n; i++) if (task_rq[i] == 0xFFFFFFFFu) return fail(ctx, HQTICK_E_INVALID, "request id 0xFFFFFFFF is reserved");
     HQ_HIP(hipSetDevice(ctx->device));
-    if (!ctx->d_tid.ensure(n * 8 + 8) || !ctx->d_tprio.ensure(n * 8 + 8) || !ctx->d_trq.ensure(n * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set");
+    ctx->resident = false;  // whatever was resident is being overwritten: only a complete upload makes the set usable again
+    uint64_t n_pow2 = 1; while (n_pow2 < n) n_pow2 <<= 1;
+    const uint64_t cap = sorted ? n : n_pow2;
+    if (!ctx->d_tid.ensure(cap * 8 + 8) || !ctx->d_tprio.ensure(cap * 8 + 8) || !ctx->d_trq.ensure(cap * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set");
     if (n) {
         HQ_HIP(hipMemcpyAsync(ctx->d_tid.p, task_id, n * 8, hipMemcpyHostToDevice, ctx->stream));
         HQ_HIP(hipMemcpyAsync(ctx->d_tprio.p, task_priority, n * 8, hipMemcpyHostToDevice, ctx->stream));
         HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, task_rq, n * 4, hipMemcpyHostToDevice, ctx->stream));
-        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (!sorted) {  // the host handed over its queues in whatever order it walked them: sort by id on the device, once
+            if (!ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc");
+            uint32_t *flag = ctx->h_q.as<uint32_t>(); flag[0] = 0;
+            HQ_HIP(hqk::sort_ready(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), n, n_pow2, ctx->h_q.dev<uint32_t>(), ctx->stream));
+            HQ_HIP(hipStreamSynchronize(ctx->stream));
+            if (flag[0]) return fail(ctx, HQTICK_E_INVALID, "ready set holds a task id twice (or the id 2^64 - 1)");
+        } else {
+            HQ_HIP(hipStreamSynchronize(ctx->stream));
+        }
     }
     ctx->n_ready = n; ctx->n_live = n; ctx->resident = true; ctx->levels_valid = false; ctx->last_valid = false; ctx->last_consumed = true;
     return 0;

@@ -113,4 +113,8 @@ hipError_t ready_live_count(const uint32_t *rq, uint64_t n, uint32_t *slice_cnt,
 hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint32_t *orq, uint64_t n, uint32_t n_live, const uint32_t *slice_off, const uint64_t *aid,
                    const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t *nid, uint64_t *nprio, uint32_t *nrq, uint8_t *pre8, uint32_t *err_flag, hipStream_t s);
 
+// hqtick_upload_ready(sorted = 0): in-place bitonic sort of the three columns by id (buffers sized for n_pow2 elements, the next
+// power of two >= n; the padding is filled with sentinels here).  dup_flag |= 1 when two ids are equal.
+hipError_t sort_ready(uint64_t *id, uint64_t *prio, uint32_t *rq, uint64_t n, uint64_t n_pow2, uint32_t *dup_flag, hipStream_t s);
+
 }  // namespace hqk

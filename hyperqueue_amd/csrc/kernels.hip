@@ -625,6 +625,35 @@ __global__ void __launch_bounds__(256) k_merge_adds(const uint64_t *__restrict__
     nid[dst] = key; nprio[dst] = aprio[j]; nrq[dst] = arq[j];
 }
 
+// ------------------------------------------------------------------------------------------------ upload of an unsorted ready set
+// Bitonic sort of (id, priority, rq) triples by id in global memory — one launch per (k, j) stage.  Used once per
+// hqtick_upload_ready(sorted = 0); n is padded to a power of two with id = 2^64 - 1 sentinels that sort to the end.
+__global__ void __launch_bounds__(256) k_bitonic_step(uint64_t *__restrict__ id, uint64_t *__restrict__ prio, uint32_t *__restrict__ rq,
+                                                      uint64_t n_pow2, uint64_t j, uint64_t k) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pow2) return;
+    const uint64_t l = i ^ j;
+    if (l <= i) return;
+    const uint64_t a = id[i], b = id[l];
+    const bool up = (i & k) == 0;
+    if (up ? a > b : a < b) {
+        id[i] = b; id[l] = a;
+        const uint64_t pa = prio[i]; prio[i] = prio[l]; prio[l] = pa;
+        const uint32_t qa = rq[i]; rq[i] = rq[l]; rq[l] = qa;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fill_sentinel(uint64_t *__restrict__ id, uint64_t from, uint64_t to) {
+    const uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < to) id[i] = 0xFFFFFFFFFFFFFFFFull;
+}
+
+// first adjacent pair that is not strictly ascending (duplicates / sentinel collisions) -> flag
+__global__ void __launch_bounds__(256) k_check_sorted(const uint64_t *__restrict__ id, uint64_t n, uint32_t *__restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 < n && id[i] >= id[i + 1]) atomicOr(flag, 1u);
+}
+
 }  // namespace
 
 // ================================================================================================ host wrappers
@@ -784,6 +813,16 @@ hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint3
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || n_add == 0) return e;
     hipLaunchKernelGGL(k_merge_adds, dim3((n_add + 255) / 256), dim3(256), 0, s, oid, n, slice_off, pre8, n_live, aid, aprio, arq, n_add, nid, nprio, nrq);
+    return hipGetLastError();
+}
+
+hipError_t sort_ready(uint64_t *id, uint64_t *prio, uint32_t *rq, uint64_t n, uint64_t n_pow2, uint32_t *dup_flag, hipStream_t s) {
+    if (n <= 1) return hipSuccess;
+    if (n_pow2 > n) hipLaunchKernelGGL(k_fill_sentinel, dim3((unsigned)((n_pow2 - n + 255) / 256)), dim3(256), 0, s, id, n, n_pow2);
+    const unsigned blocks = (unsigned)((n_pow2 + 255) / 256);
+    for (uint64_t k = 2; k <= n_pow2; k <<= 1)
+        for (uint64_t j = k >> 1; j > 0; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3(blocks), dim3(256), 0, s, id, prio, rq, n_pow2, j, k);
+    hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, id, n, dup_flag);
     return hipGetLastError();
 }
 

@@ -245,7 +245,7 @@ void hqtick_destroy(hqtick_ctx *ctx);
 int hqtick_run(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick_result *out);
 
 /* Device-resident variant: keep the ready-set columns in HBM across ticks.
- * hqtick_upload_ready() copies (and, when `sorted`==0, sorts by task id on the device) the ready
+ * hqtick_upload_ready() copies (and, when `sorted`==0, sorts by task id on the device: bitonic, once per upload) the ready
  * set into ctx-owned HBM buffers; hqtick_run_resident() then runs ticks against them, taking every
  * other field (workers, requests, prefill sets) from `snapshot` and ignoring its task_* pointers. */
 int hqtick_upload_ready(hqtick_ctx *ctx, uint64_t n_ready, const uint64_t *task_id,

@@ -43,7 +43,6 @@ def test_resident_misuse(good):
     expect(abi.HQTICK_E_INVALID, lambda: t.tick(good, resident=True))  # no hqtick_upload_ready yet
     expect(abi.HQTICK_E_INVALID, lambda: t.ready_add(good.task_id[:3], good.task_priority[:3], good.task_rq[:3]))
     expect(abi.HQTICK_E_INVALID, lambda: t.ready_consume_last())
-    expect(abi.HQTICK_E_UNSUPPORTED, lambda: t.upload_ready(good.task_id[::-1].copy(), good.task_priority, good.task_rq, sorted_=False))
     expect(abi.HQTICK_E_INVALID, lambda: t.upload_ready(good.task_id[::-1].copy(), good.task_priority, good.task_rq, sorted_=True))
     t.upload_ready(good.task_id, good.task_priority, good.task_rq)
     t.ready_consume_last()  # nothing handed out yet: a no-op
@@ -71,3 +70,23 @@ def test_empty_inputs():
     assert t.ready_count() == 0
     t.ready_add(np.asarray([7, 9], np.uint64), np.full(2, 1 << 63, np.uint64), np.zeros(2, np.uint32))  # first tasks of an empty resident set
     assert t.ready_count() == 2
+
+
+def test_unsorted_upload_is_sorted_on_the_device(good):
+    """hqtick_upload_ready(sorted = 0): any order in, same ticks out; duplicates are rejected."""
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(good.task_id))
+    a, b = Tick(abi.make_config()), Tick(abi.make_config())
+    a.upload_ready(good.task_id, good.task_priority, good.task_rq, sorted_=True)
+    b.upload_ready(good.task_id[perm], good.task_priority[perm], good.task_rq[perm], sorted_=False)
+    ra, rb = a.tick(good, resident=True), b.tick(good, resident=True)
+    assert ra.records == rb.records and ra.counts == rb.counts and sum(len(x) for x in ra.records) > 0
+    ids = good.task_id[perm].copy(); ids[7] = ids[1234]
+    expect(abi.HQTICK_E_INVALID, lambda: b.upload_ready(ids, good.task_priority[perm], good.task_rq[perm], sorted_=False))
+    expect(abi.HQTICK_E_INVALID, lambda: b.tick(good, resident=True))  # a failed upload leaves no resident set behind
+    for n in (1, 2, 3, 255, 257, 4097):  # sizes around the power-of-two padding
+        s = workloads.make("c3", n_tasks=n, n_workers=2)
+        p = rng.permutation(n)
+        b.upload_ready(s.task_id[p], s.task_priority[p], s.task_rq[p], sorted_=False)
+        a.upload_ready(s.task_id, s.task_priority, s.task_rq, sorted_=True)
+        assert a.tick(s, resident=True).records == b.tick(s, resident=True).records
