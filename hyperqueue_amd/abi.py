@@ -11,7 +11,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-HQTICK_ABI_VERSION = 1
+HQTICK_ABI_VERSION = 2
 HQ_AMOUNT_MAX = 0xFFFF_FFFF_FFFF_FFFF
 HQ_FRACTIONS_PER_UNIT = 10_000
 HQ_MAX_TASK_PER_WORKER = 1024
@@ -24,6 +24,7 @@ HQTICK_DONE, HQTICK_NEED_MORE_COMPUTE, HQTICK_NO_PROGRESS = 0, 1, 2
 HQTICK_E_INVALID, HQTICK_E_NO_DEVICE, HQTICK_E_DEVICE = -1, -2, -3
 HQTICK_E_CAPACITY, HQTICK_E_QUEUE_UNDERFLOW, HQTICK_E_UNSUPPORTED = -4, -5, -6
 HQ_REC_PREFILL, HQ_REC_ASSIGN = 0, 1
+HQ_REDIRECT_FROM_PREFILL, HQ_REDIRECT_RETARGET, HQ_REDIRECT_SAME_WORKER = 0, 1, 2
 
 u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
 i64p, f32p = C.POINTER(C.c_int64), C.POINTER(C.c_float)
@@ -84,6 +85,11 @@ class SnapshotC(C.Structure):
         ("prefill_priority", u64p),
         ("prefill_task", u64p),
         ("prefill_worker", u32p),
+        ("n_retracting", C.c_uint32),
+        ("retracting_task", u64p),
+        ("retracting_worker", u32p),
+        ("retracting_redirect_worker", u32p),
+        ("retracting_redirect_variant", u8p),
     ]
 
 
@@ -127,6 +133,7 @@ class ResultC(C.Structure):
         ("redirect_task", u64p),
         ("redirect_worker", u32p),
         ("redirect_variant", u8p),
+        ("redirect_kind", u8p),
         ("n_mn", C.c_uint32),
         ("mn_task", u64p),
         ("mn_worker_off", u32p),
@@ -189,6 +196,7 @@ class Snapshot:
     task_rq: np.ndarray
     prefill: Dict[int, Tuple[int, List[Tuple[int, int]]]] = field(default_factory=dict)  # rq -> (priority, [(task, worker idx)])
     worker_map_rank: Optional[np.ndarray] = None
+    retracting: List[Tuple[int, int, int, int]] = field(default_factory=list)  # (task, old worker idx, redirect worker idx | HQ_NO_WORKER, redirect variant), ascending task id
     _keep: list = field(default_factory=list, repr=False)
 
     def to_c(self) -> SnapshotC:
@@ -270,6 +278,11 @@ class Snapshot:
         put("prefill_priority", pprio, np.uint64, u64p)
         put("prefill_task", ptask, np.uint64, u64p)
         put("prefill_worker", pworker, np.uint32, u32p)
+        s.n_retracting = len(self.retracting)
+        put("retracting_task", [r[0] for r in self.retracting], np.uint64, u64p)
+        put("retracting_worker", [r[1] for r in self.retracting], np.uint32, u32p)
+        put("retracting_redirect_worker", [r[2] for r in self.retracting], np.uint32, u32p)
+        put("retracting_redirect_variant", [r[3] for r in self.retracting], np.uint8, u8p)
         return s
 
 
@@ -297,10 +310,11 @@ class Result:
     counts: List[Tuple[int, int, int, int]]  # (rq, variant, worker index, count) in the reference's iteration order
     records: List[List[Tuple[int, int, int]]]  # per worker index: (task, variant|0xFF, kind)
     retracts: List[List[int]]
-    redirects: List[Tuple[int, int, int]]  # (task, worker index, variant)
+    redirects: List[Tuple[int, int, int]]  # (task, worker index, variant)  [+ kind in redirect_kinds, same order]
     mn: List[Tuple[int, List[int]]]
     new_free: np.ndarray  # [W, R]
     times_us: Dict[str, float]
+    redirect_kinds: List[int] = field(default_factory=list)
 
     def assigned(self, w: int) -> List[Tuple[int, int]]:
         return [(t, v) for (t, v, k) in self.records[w] if k == HQ_REC_ASSIGN]
@@ -369,4 +383,5 @@ def parse_result(r: ResultC, n_workers: int, n_resources: int, full: bool = True
             mn.append((mt[i], mw[int(mo[i]) : int(mo[i + 1])]))
     nf = _np(r.new_free, W * n_resources, np.uint64).reshape(W, n_resources) if r.new_free else np.zeros((W, n_resources), np.uint64)
     times = dict(total=r.t_total_us, scan=r.t_scan_us, batches=r.t_batches_us, solve=r.t_solve_us, mapping=r.t_mapping_us)
-    return Result(r.status, bool(r.is_optimal), batches, counts, records, retracts, redirects, mn, nf, times)
+    kinds = _np(r.redirect_kind, nr, np.uint8).tolist() if r.redirect_kind else [HQ_REDIRECT_FROM_PREFILL] * nr
+    return Result(r.status, bool(r.is_optimal), batches, counts, records, retracts, redirects, mn, nf, times, kinds)

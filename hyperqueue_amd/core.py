@@ -226,6 +226,8 @@ class SchedEnv:
         self.ready: Dict[int, set] = {}  # rq -> ids in TaskQueue.queue
         self.prefill: Dict[int, Tuple[int, object]] = {}  # rq -> (priority, HbSet of task ids)
         self.redirects: Dict[int, Tuple[int, int]] = {}
+        self.retaken_variant: Dict[int, int] = {}  # Retracting task put back on its own worker by a tick -> the variant chosen
+        self.retract_messages: List[Tuple[int, int]] = []  # (worker, task) of RetractTasks sent outside the tick (prefill disposal)
         self.groups: Dict[str, int] = {}
         self.job_id = 1
         self.task_id_counter = 1
@@ -275,12 +277,33 @@ class SchedEnv:
         return tid
 
     def _add_ready(self, t: Task):
-        # TaskQueues::add_ready_task  taskqueue.rs:37-43 (prefill disposal on a higher priority arrival is reactor
-        # territory — SURVEY §8 f1 — and not modelled in this round)
+        """TaskQueues::add_ready_task  taskqueue.rs:37-43: a higher-priority arrival first dissolves every prefill set of lower
+        priority (check_dispose_prefill :148-154): its tasks go back into their queue in state Retracting{worker}, leave the worker's
+        prefilled set, and a RetractTasks message goes to the worker (process_retracted, server/reactor.rs:34-62)."""
         for rq, (p, s) in list(self.prefill.items()):
             if len(s) and p < t.priority:
-                raise NotImplementedError("check_dispose_prefill (taskqueue.rs:148-154) is reactor scope (f1)")
+                for tid in list(s):
+                    pt = self.tasks[tid]
+                    assert pt.state == PREFILLED
+                    self.workers[pt.worker].prefilled_tasks.discard(tid)
+                    pt.state = RETRACTING
+                    self.ready[rq].add(tid)
+                    self.retract_messages.append((pt.worker, tid))
+                del self.prefill[rq]
         self.ready[t.rq].add(t.id)
+
+    def retract_response(self, wid: int, task_ids: List[int]):
+        """on_retract_response  server/reactor.rs:462-508: a redirected task becomes Assigned on its target, any other goes back to
+        Waiting (it already sits in its queue)."""
+        for tid in task_ids:
+            t = self.tasks[tid]
+            if not (t.state == RETRACTING and t.worker == wid):
+                continue
+            if tid in self.redirects:
+                target, v = self.redirects.pop(tid)
+                t.state, t.worker, t.rv = ASSIGNED, target, v
+            else:
+                t.state, t.worker = WAITING, None
 
     def new_tasks(self, n: int, builder: Optional[TaskBuilder] = None) -> List[int]:
         return [self.new_task(builder) for _ in range(n)]
@@ -438,6 +461,14 @@ class SchedEnv:
                 ids.append(t); prio.append(self.tasks[t].priority); rqs.append(rq)
         ids = np.asarray(ids, np.uint64)
         order = np.argsort(ids, kind="stable")
+        retracting = []
+        for rq, ids_ in self.ready.items():
+            for tid in ids_:
+                tt = self.tasks[tid]
+                if tt.state == RETRACTING:
+                    tw, tv = self.redirects.get(tid, (None, 0))
+                    retracting.append((tid, index[tt.worker], abi.HQ_NO_WORKER if tw is None else index[tw], tv))
+        retracting.sort()
         prefill = {}
         for rq, (p, s) in self.prefill.items():
             if len(s):
@@ -447,7 +478,7 @@ class SchedEnv:
             worker_remaining_ns=rem, worker_min_utilization=mu, worker_flags=flags, worker_group=group,
             n_groups=max(1, len(self.groups)), blocked=blocked, assigned=assigned, prefilled=prefilled,
             requests=self.requests, task_id=ids[order], task_priority=np.asarray(prio, np.uint64)[order],
-            task_rq=np.asarray(rqs, np.uint32)[order], prefill=prefill, worker_map_rank=rank,
+            task_rq=np.asarray(rqs, np.uint32)[order], prefill=prefill, worker_map_rank=rank, retracting=retracting,
         )
         snap.config = self.config
         return snap
@@ -456,7 +487,9 @@ class SchedEnv:
     def _assigned_variant(self, tid: int, wid: int) -> int:
         t = self.tasks[tid]
         if t.state == RETRACTING:  # sanity_check: Retracting tasks count on their redirect target  server/worker.rs:249-252
-            return self.redirects[tid][1]
+            if tid in self.redirects:
+                return self.redirects[tid][1]
+            return self.retaken_variant[tid]  # retaken by the worker it is retracting from: no redirect entry (mapping.rs:69)
         return t.rv
 
     # -- apply -----------------------------------------------------------------------------------------
@@ -495,11 +528,23 @@ class SchedEnv:
                         self.prefill[t.rq] = (t.priority, task_id_set())
                     assert self.prefill[t.rq][0] == t.priority
                     self.prefill[t.rq][1].insert(tid)
-        for (tid, widx, v) in res.redirects:  # redirects.insert + insert_sn_task on the new target  mapping.rs:51,95-100
+        kinds = res.redirect_kinds or [abi.HQ_REDIRECT_FROM_PREFILL] * len(res.redirects)
+        for (tid, widx, v), kind in zip(res.redirects, kinds):  # insert_sn_task on the new target + the redirect table  mapping.rs:51,66-100
             wid = wids[widx]
-            self.redirects[tid] = (wid, v)
+            t = self.tasks[tid]
             w = self.workers[wid]
-            self._remove(w, self.tasks[tid].rq, v)
+            if kind != abi.HQ_REDIRECT_FROM_PREFILL:  # the task was Retracting in its queue: take_tasks removed it
+                assert t.state == RETRACTING and tid in self.ready[t.rq], (tid, t.state)
+                self.ready[t.rq].discard(tid)
+            if kind == abi.HQ_REDIRECT_RETARGET and tid in self.redirects:  # remove_sn_task on the previous target  mapping.rs:70-77
+                ow, ov = self.redirects[tid]
+                self.workers[ow].assigned_tasks.discard(tid)
+                self._add(self.workers[ow], t.rq, ov)
+            if kind != abi.HQ_REDIRECT_SAME_WORKER:
+                self.redirects[tid] = (wid, v)
+            else:
+                self.retaken_variant[tid] = v
+            self._remove(w, t.rq, v)
             w.assigned_tasks.add(tid)
         for (tid, widxs) in res.mn:  # mapping.rs:133-154
             t = self.tasks[tid]

@@ -70,6 +70,8 @@ struct PlanScratch {
     std::vector<uint32_t> items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, pfl_j, out_off, take_base, mn_first, pack;
     std::vector<uint8_t> now_mn;
     std::vector<uint32_t> sink_hdr;
+    std::vector<uint64_t> holes;                                 // (rq << 32 | logical position) of Retracting tasks taken this tick
+    std::vector<std::pair<uint32_t, uint32_t>> freed;            // (worker, variant slot) given back by re-targeted redirects
     std::vector<std::pair<uint32_t, uint64_t>> retract_pairs;  // (old worker, task)
     // cached worker_map iteration order (emulated) for the last worker-id set
     std::vector<uint32_t> cached_ids, cached_order;
@@ -90,7 +92,7 @@ struct hqtick_ctx {
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
-    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add;
+    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_retr;
     // workers / requests
     DevBuf d_up, d_vflags, d_vtmc;
     // selection + mapping
@@ -101,7 +103,7 @@ struct hqtick_ctx {
     std::vector<uint32_t> b_rq, b_size, b_limit, b_cut_off, c_size, c_bl_off, bl_rq, bl_size; std::vector<uint8_t> b_lr, b_blk;
     std::vector<uint32_t> cnt_rq, cnt_worker, cnt_value; std::vector<uint8_t> cnt_variant;
     std::vector<uint32_t> rec_off, retract_off, red_worker, mn_off, mn_worker; std::vector<uint64_t> rec_task, retract_task, red_task, mn_task, new_free;
-    std::vector<uint8_t> rec_variant, rec_kind, red_variant, q_loaded;
+    std::vector<uint8_t> rec_variant, rec_kind, red_variant, red_kind, q_loaded;
     hqtick_kernel_stats stats{};
     uint32_t tpw_hint = 0;                            // HQTICK_TPW (tuning knob): tasks per wavefront slice
     uint32_t shard_index = 0, shard_count = 1;       // hqtick_set_shard
@@ -145,6 +147,12 @@ int validate(hqtick_ctx *ctx, const hqtick_snapshot *s, bool need_tasks) {
         for (uint64_t i = 1; i < s->n_ready; i++) if (s->task_id[i - 1] >= s->task_id[i]) return fail(ctx, HQTICK_E_INVALID, "ready set not sorted by task id");
     }
     for (uint32_t k = 0; k < s->n_blocked; k++) if (s->blocked_worker[k] >= s->n_workers) return fail(ctx, HQTICK_E_INVALID, "blocked worker index");
+    if (s->n_retracting && (!s->retracting_task || !s->retracting_worker)) return fail(ctx, HQTICK_E_INVALID, "retracting arrays missing");
+    for (uint32_t k = 0; k < s->n_retracting; k++) {
+        if (s->retracting_worker[k] >= s->n_workers) return fail(ctx, HQTICK_E_INVALID, "retracting worker index");
+        if (k && s->retracting_task[k - 1] >= s->retracting_task[k]) return fail(ctx, HQTICK_E_INVALID, "retracting tasks not ascending");
+        if (s->retracting_redirect_worker && s->retracting_redirect_worker[k] != HQ_NO_WORKER && s->retracting_redirect_worker[k] >= s->n_workers) return fail(ctx, HQTICK_E_INVALID, "retracting redirect worker index");
+    }
     return 0;
 }
 
@@ -301,6 +309,14 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
             HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
                                    reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream));
             if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
+            if (s->n_retracting) {  // where do the Retracting tasks sit in their queues?  (mapping.rs:66-80 treats them apart)
+                const uint32_t nr = s->n_retracting;
+                if (!ctx->h_retr.ensure((size_t)nr * 16 + 64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc retracting");
+                memcpy(ctx->h_retr.p, s->retracting_task, (size_t)nr * 8);
+                uint8_t *rd = ctx->h_retr.dev<uint8_t>();
+                HQ_HIP(hqk::rank_of(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, ctx->d_wave_tab.as<uint32_t>(), g, reinterpret_cast<const uint64_t *>(rd), nr,
+                                    reinterpret_cast<uint32_t *>(rd + (size_t)nr * 8), reinterpret_cast<uint32_t *>(rd + (size_t)nr * 12), ctx->stream));
+            }
         } else {
             HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc), ctx->stream));
         }
@@ -443,33 +459,70 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     ps.pf_drained.assign(Q, 0);
     ps.has_pf.assign((size_t)Q * W, 0);  // SingleNodeTaskAssignment::prefilled_tasks as per-(rq, worker) counts
     if (s->prefilled_off) for (uint32_t w = 0; w < W; w++) for (uint32_t i = s->prefilled_off[w]; i < s->prefilled_off[w + 1]; i++) if (s->prefilled_rq[i] < Q) ps.has_pf[(size_t)s->prefilled_rq[i] * W + w]++;
+    // host mirror of the K5 arithmetic: the worker that receives the task at index idx of key k's take_tasks() vector
+    std::vector<std::vector<uint32_t>> key_T(nkeys);
+    auto worker_of = [&](uint32_t k, uint32_t idx) -> uint32_t {
+        const auto &pk = cnt.per_key[k];
+        std::vector<uint32_t> &T = key_T[k];
+        if (T.empty()) {
+            uint32_t maxc = 0; for (auto &wc : pk) maxc = std::max(maxc, wc.second);
+            std::vector<uint32_t> ge(maxc + 2, 0);
+            for (auto &wc : pk) ge[wc.second]++;
+            uint32_t more = (uint32_t)pk.size(), acc = 0;
+            for (uint32_t sw = 0; sw <= maxc; sw++) { T.push_back(acc); more -= ge[sw]; acc += more; }
+        }
+        uint32_t sw = (uint32_t)(std::upper_bound(T.begin(), T.end(), idx) - T.begin()) - 1, nth = idx - T[sw];
+        for (auto &wc : pk) if (wc.second > sw) { if (nth == 0) return wc.first; nth--; }
+        return HQ_NO_WORKER;
+    };
+    ctx->red_kind.clear();
     for (uint32_t k = 0; k < nkeys; k++) {
         const uint32_t q = cnt.keys[k].first;
         if (!ps.pf_n[q]) continue;
         uint32_t a = std::max(ps.key_seg[k], ps.pf_start[q]), b = std::min(ps.key_seg[k] + ps.key_sum[k], ps.pf_start[q] + ps.pf_n[q]);
-        if (a >= b) continue;
-        // host mirror of the K5 arithmetic for this key (prefilled tasks only): T(s) and the worker of index idx
-        const auto &pk = cnt.per_key[k];
-        uint32_t maxc = 0; for (auto &wc : pk) maxc = std::max(maxc, wc.second);
-        std::vector<uint32_t> ge(maxc + 2, 0), T; T.reserve(maxc + 1);
-        for (auto &wc : pk) ge[wc.second]++;
-        uint32_t more = (uint32_t)pk.size(), acc = 0;
-        for (uint32_t sw = 0; sw <= maxc; sw++) { T.push_back(acc); more -= ge[sw]; acc += more; }
-        auto worker_of = [&](uint32_t idx) -> uint32_t {
-            uint32_t sw = (uint32_t)(std::upper_bound(T.begin(), T.end(), idx) - T.begin()) - 1, nth = idx - T[sw];
-            for (auto &wc : pk) if (wc.second > sw) { if (nth == 0) return wc.first; nth--; }
-            return HQ_NO_WORKER;
-        };
         for (uint32_t p = a; p < b; p++) {
             uint32_t slot = s->prefill_off[q] + (p - ps.pf_start[q]);
             uint64_t task = s->prefill_task[slot]; uint32_t oldw = s->prefill_worker[slot];
-            uint32_t neww = worker_of(p - ps.key_seg[k]);
+            uint32_t neww = worker_of(k, p - ps.key_seg[k]);
             ps.retract_pairs.push_back({oldw, task});
             if (oldw < W && ps.has_pf[(size_t)q * W + oldw]) ps.has_pf[(size_t)q * W + oldw]--;
-            ctx->red_task.push_back(task); ctx->red_worker.push_back(neww); ctx->red_variant.push_back(cnt.keys[k].second);
+            ctx->red_task.push_back(task); ctx->red_worker.push_back(neww); ctx->red_variant.push_back(cnt.keys[k].second); ctx->red_kind.push_back(HQ_REDIRECT_FROM_PREFILL);
             if (neww < W) { ps.asg_qw[(size_t)q * W + neww]--; ps.n_assign[neww]--; }  // a redirect is not a new `assigned` record
             ps.pf_drained[q]++;
         }
+    }
+    // ready tasks in state Retracting{old} that this tick takes (mapping.rs:66-80): no `assigned` record, a redirect instead
+    ps.holes.clear(); ps.freed.clear();
+    std::vector<std::pair<uint32_t, uint32_t>> retr_pos;  // (rq, queue position) of every Retracting task, for the prefill check below
+    if (s->n_retracting) {
+        if (N == 0) return fail(ctx, HQTICK_E_INVALID, "retracting tasks without a ready set");
+        const uint32_t nr = s->n_retracting;
+        const uint8_t *rh = ctx->h_retr.as<uint8_t>();
+        const uint32_t *rkey = reinterpret_cast<const uint32_t *>(rh + (size_t)nr * 8), *rrank = reinterpret_cast<const uint32_t *>(rh + (size_t)nr * 12);
+        for (uint32_t i = 0; i < nr; i++) {
+            if (rkey[i] == 0xFFFFFFFFu || Q == 0) return fail(ctx, HQTICK_E_INVALID, "a retracting task is not in the ready set");
+            const uint32_t l = rkey[i] / Q, q = rkey[i] % Q;
+            uint32_t z = rrank[i]; for (uint32_t l2 = 0; l2 < l; l2++) z += hist(l2, q);         // position in the queue (levels, then id)
+            const uint32_t p = z < ps.pf_start[q] ? z : z + ps.pf_n[q];                             // position in the logical take sequence
+            retr_pos.push_back({q, z});
+            if (p >= ps.seq_taken[q]) continue;                                                   // stays in its queue
+            uint32_t k = nkeys;
+            for (uint32_t kk = 0; kk < nkeys; kk++) if (ps.key_rq[kk] == q && p >= ps.key_seg[kk] && p < ps.key_seg[kk] + ps.key_sum[kk]) { k = kk; break; }
+            if (k == nkeys) return fail(ctx, HQTICK_E_UNSUPPORTED, "a Retracting task was taken by a multi-node placement");
+            const uint32_t neww = worker_of(k, p - ps.key_seg[k]), oldw = s->retracting_worker[i];
+            const uint8_t v = cnt.keys[k].second;
+            ps.holes.push_back(((uint64_t)q << 32) | p);
+            if (neww < W) { ps.asg_qw[(size_t)q * W + neww]--; ps.n_assign[neww]--; }
+            ctx->red_task.push_back(s->retracting_task[i]); ctx->red_worker.push_back(neww); ctx->red_variant.push_back(v);
+            if (oldw != neww) {
+                ctx->red_kind.push_back(HQ_REDIRECT_RETARGET);
+                const uint32_t tw = s->retracting_redirect_worker ? s->retracting_redirect_worker[i] : HQ_NO_WORKER;
+                if (tw != HQ_NO_WORKER) ps.freed.push_back({tw, pb.rqs[q].first_variant + (s->retracting_redirect_variant ? s->retracting_redirect_variant[i] : 0)});  // remove_sn_task(previous target)
+            } else {
+                ctx->red_kind.push_back(HQ_REDIRECT_SAME_WORKER);
+            }
+        }
+        std::sort(ps.holes.begin(), ps.holes.end());
     }
     // queue tasks taken per request (excluding the prefilled block)
     ps.zq_taken.assign(Q, 0);
@@ -521,6 +574,11 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
             for (uint32_t j = 0; j < ps.elig.size(); j++) ps.pfl_j[o + ps.elig[j]] = j;
             ps.new_pf_total[q] = psz * (uint32_t)ps.elig.size();
         }
+    }
+    for (auto &rp : retr_pos) {  // take_tasks_for_prefill on a Retracting task: the reference asserts task.is_waiting()  (mapping.rs:221)
+        const uint32_t q = rp.first, z = rp.second;
+        if (ps.new_pf_total[q] && z >= ps.zq_taken[q] && z < ps.zq_taken[q] + ps.new_pf_total[q])
+            return fail(ctx, HQTICK_E_UNSUPPORTED, "a Retracting task reached take_tasks_for_prefill: the reference asserts task.is_waiting() (mapping.rs:221)");
     }
     mark();  // 4: prefill plan
     // ---- selection plan per (level, rq) group ----
@@ -575,6 +633,13 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
                 if (vv.kind[e] == HQ_ENTRY_ALL) f = 0; else { uint64_t d = vv.amount[e] * (uint64_t)wc.second; f = f > d ? f - d : 0; }
             }
         }
+        for (auto &fr : ps.freed) {  // remove_sn_task on the previous target of a re-targeted redirect  (worker.rs:223-234 -> workerload.rs:194-202)
+            const hqhost::VariantView &vv = pb.variants[fr.second];
+            for (uint32_t e = 0; e < vv.n_entries; e++) {
+                uint64_t &f = ctx->new_free[(size_t)fr.first * R + vv.res[e]];
+                f = vv.kind[e] == HQ_ENTRY_ALL ? s->worker_total[(size_t)fr.first * R + vv.res[e]] : f + vv.amount[e];
+            }
+        }
     };
     size_t n_mn_ids = 0; for (auto &sets : cnt.mn_sets) n_mn_ids += sets.size();
     size_t o_rv = (size_t)n_rec * 8, o_rk = o_rv + n_rec, o_mn = (o_rk + n_rec + 7) & ~(size_t)7, o_fl = o_mn + n_mn_ids * 8, rec_bytes = o_fl + 64;
@@ -591,6 +656,10 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
                o_boff = put(ps.key_bits_off), o_wpos = put(ps.wpos), o_wcnt = put(ps.wcnt), o_base = put(ps.rq_sel_base), o_pfs = put(ps.pf_start), o_pfn = put(ps.pf_n),
                o_pqs = put(ps.pfq_src), o_pqz = put(ps.pfq_size), o_pflj = put(ps.pfl_j), o_out = put(ps.out_off);
         size_t o_tb = put(ps.take_base);
+        if (pack.size() & 1) pack.push_back(0);  // 8-byte alignment for the u64 hole list
+        const size_t o_holes = pack.size();
+        for (uint64_t hk : ps.holes) { pack.push_back((uint32_t)(hk & 0xFFFFFFFFu)); pack.push_back((uint32_t)(hk >> 32)); }
+        if (ps.holes.empty()) { pack.push_back(0); pack.push_back(0); }
         // device record buffer: [task u64 x n_rec][variant u8 x n_rec][kind u8 x n_rec] -> one D2H copy
         if (!ctx->d_map.ensure(pack.size() * 4 + 16) || !ctx->h_plan.ensure(pack.size() * 4 + 16) ||
             !ctx->d_tsweep.ensure((size_t)n_units * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) || !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
@@ -603,6 +672,7 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         mk.key_ord_off = d + o_ordoff; mk.ord_cnt = d + o_ord; mk.key_t_off = d + o_toff; mk.key_bits_off = d + o_boff;
         mk.t_sweep = ctx->d_tsweep.as<uint32_t>(); mk.bits = ctx->d_bits.as<uint64_t>(); mk.pre = ctx->d_pre.as<uint32_t>();
         mk.wpos = d + o_wpos; mk.wcnt = d + o_wcnt; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn;
+        mk.n_holes = (uint32_t)ps.holes.size(); mk.holes = reinterpret_cast<const uint64_t *>(d + o_holes);
         mk.n_pfq = n_pfq; mk.pfq_src = d + o_pqs; mk.pfq_size = d + o_pqz; mk.pfl_j = d + o_pflj; mk.out_off = d + o_out;
         uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
         flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
@@ -676,7 +746,7 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     out->rec_off = ctx->rec_off.data();
     if (!ctx->sink) { out->rec_task = h_rec_task; out->rec_variant = h_rec_var; out->rec_kind = h_rec_kind; }
     out->retract_off = ctx->retract_off.data(); out->retract_task = ctx->retract_task.data();
-    out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data();
+    out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data(); out->redirect_kind = ctx->red_kind.data();
     out->n_mn = (uint32_t)ctx->mn_task.size(); out->mn_task = ctx->mn_task.data(); out->mn_worker_off = ctx->mn_off.data(); out->mn_worker = ctx->mn_worker.data();
     out->new_free = ctx->new_free.data();
     mark();  // 9: result assembled
@@ -727,7 +797,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
                       &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8};
     for (DevBuf *b : bufs) b->release();
-    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release();
+    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_retr.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;

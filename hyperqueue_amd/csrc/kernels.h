@@ -97,6 +97,9 @@ struct MapKeys {
     const uint32_t *pfq_src;       // [n_pfq] absolute sel index of chunk 0
     const uint32_t *pfq_size;      // [n_pfq] chunk length
     const uint32_t *pfl_j;         // [n_pfq * W]
+    // logical queue positions whose task is Retracting (sorted (rq << 32) | position): no record for them
+    uint32_t n_holes;
+    const uint64_t *holes;
     // output placement
     const uint32_t *out_off;       // [W+1]
 };
@@ -112,6 +115,10 @@ hipError_t ready_mark_removed(const uint64_t *ids, uint32_t *rq, uint64_t n, con
 hipError_t ready_live_count(const uint32_t *rq, uint64_t n, uint32_t *slice_cnt, hipStream_t s);
 hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint32_t *orq, uint64_t n, uint32_t n_live, const uint32_t *slice_off, const uint64_t *aid,
                    const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t *nid, uint64_t *nprio, uint32_t *nrq, uint8_t *pre8, uint32_t *err_flag, hipStream_t s);
+
+// group key and rank-in-group of the wanted ids (0xFFFFFFFF key = not in the set); after scan_waves, same geometry
+hipError_t rank_of(const uint64_t *ids, const uint16_t *gkey, uint64_t n, const uint32_t *wave_off, WaveGeom geom, const uint64_t *want, uint32_t n_want,
+             uint32_t *out_key, uint32_t *out_rank, hipStream_t s);
 
 // hqtick_upload_ready(sorted = 0): in-place bitonic sort of the three columns by id (buffers sized for n_pow2 elements, the next
 // power of two >= n; the padding is filled with sentinels here).  dup_flag |= 1 when two ids are equal.

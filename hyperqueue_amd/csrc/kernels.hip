@@ -502,7 +502,14 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
         const uint32_t pfs = mk.rq_pf_start[q], pfn = mk.rq_pf_n[q], sbase = mk.rq_sel_base[q];
         const uint32_t idx = tsw + pre + (uint32_t)__popcll(bw & ((1ull << (pos & 63)) - 1ull));  // index inside the key's take_tasks() vector
         const uint32_t p = k_seg[k] + idx;                              // position in the queue's logical sequence
-        if (p >= pfs && p < pfs + pfn) {                               // an already-prefilled task: retract/redirect is host work
+        bool hole = p >= pfs && p < pfs + pfn;                         // an already-prefilled task: retract/redirect is host work
+        if (!hole && mk.n_holes) {                                     // a Retracting task of the queue: redirect, no record (host work too)
+            const uint64_t hk = ((uint64_t)q << 32) | p;
+            uint32_t hlo = 0, hhi = mk.n_holes;
+            while (hlo < hhi) { uint32_t mid = (hlo + hhi) >> 1; if (mk.holes[mid] < hk) hlo = mid + 1; else hhi = mid; }
+            hole = hlo < mk.n_holes && mk.holes[hlo] == hk;
+        }
+        if (hole) {
             e_meta[e] = 0; e_task[e] = 0; e_lvl[e] = 0;
             misc[2] = 1;
         } else {
@@ -623,6 +630,28 @@ __global__ void __launch_bounds__(256) k_merge_adds(const uint64_t *__restrict__
     const uint32_t live_before = lo >= n ? n_live : slice_off[lo >> 8] + pre8[lo];
     const uint64_t dst = (uint64_t)live_before + j;
     nid[dst] = key; nprio[dst] = aprio[j]; nrq[dst] = arq[j];
+}
+
+// ------------------------------------------------------------------------------------------------ position of given tasks in their queues
+// One wavefront per wanted id: its group key and its rank inside the group (= how many tasks of the same (level, rq) precede it in
+// id order), from the sorted id column, the key column and the scanned slice table.  Used for the few ready tasks that are in
+// state Retracting (scheduler/mapping.rs:66-80): the host needs to know which of them this tick takes.  key = 0xFFFFFFFF: not found.
+__global__ void __launch_bounds__(256) k_rank_of(const uint64_t *__restrict__ ids, const uint16_t *__restrict__ gkey, uint64_t n,
+                                                 const uint32_t *__restrict__ wave_off, uint32_t stride, uint32_t tasks_per_wave,
+                                                 const uint64_t *__restrict__ want, uint32_t n_want, uint32_t *__restrict__ out_key,
+                                                 uint32_t *__restrict__ out_rank) {
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    if (t >= n_want) return;
+    const uint64_t key = want[t];
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ids[mid] < key) lo = mid + 1; else hi = mid; }
+    while (lo < n && ids[lo] == key && gkey[lo] == GKEY_INVALID) lo++;  // a removed-and-re-added id sits behind its tombstone
+    if (lo >= n || ids[lo] != key || gkey[lo] == GKEY_INVALID) { if (lane == 0) { out_key[t] = 0xFFFFFFFFu; out_rank[t] = 0; } return; }
+    const uint32_t g = gkey[lo];
+    const uint64_t slice = lo / tasks_per_wave, begin = slice * tasks_per_wave;
+    uint32_t before = 0;
+    for (uint64_t b = begin; b < lo; b += 64) { const uint64_t i = b + lane; before += (uint32_t)__popcll(__ballot(i < lo && gkey[i] == g)); }
+    if (lane == 0) { out_key[t] = g; out_rank[t] = wave_off[(size_t)g * stride + slice] + before; }
 }
 
 // ------------------------------------------------------------------------------------------------ upload of an unsorted ready set
@@ -823,6 +852,13 @@ hipError_t sort_ready(uint64_t *id, uint64_t *prio, uint32_t *rq, uint64_t n, ui
     for (uint64_t k = 2; k <= n_pow2; k <<= 1)
         for (uint64_t j = k >> 1; j > 0; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3(blocks), dim3(256), 0, s, id, prio, rq, n_pow2, j, k);
     hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, id, n, dup_flag);
+    return hipGetLastError();
+}
+
+hipError_t rank_of(const uint64_t *ids, const uint16_t *gkey, uint64_t n, const uint32_t *wave_off, WaveGeom geom, const uint64_t *want, uint32_t n_want,
+             uint32_t *out_key, uint32_t *out_rank, hipStream_t s) {
+    if (n_want == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rank_of, dim3((n_want + 3) / 4), dim3(256), 0, s, ids, gkey, n, wave_off, geom.tab_stride, geom.tasks_per_wave, want, n_want, out_key, out_rank);
     return hipGetLastError();
 }
 

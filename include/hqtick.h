@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HQTICK_ABI_VERSION 1u
+#define HQTICK_ABI_VERSION 2u
 
 /* ResourceAmount::MAX                                    common/resources/amount.rs:31 */
 #define HQ_AMOUNT_MAX UINT64_MAX
@@ -80,6 +80,14 @@ enum { HQ_REC_PREFILL = 0, HQ_REC_ASSIGN = 1 };
 
 /* hqtick_config.flags: skip the HIP events that feed hqtick_kernel_stats_last() (saves ~6 API calls per tick) */
 #define HQTICK_FLAG_NO_KERNEL_TIMING 1u
+
+/* redirect_kind of a result entry (scheduler/mapping.rs:66-101):
+ *   FROM_PREFILL  the task sat in a prefill set: Prefilled{old} -> Retracting{old}, retract sent to `old`, redirects.insert(task, (worker, v))
+ *   RETARGET      the task was already Retracting{old} in its queue and goes to another worker: redirects.insert(task, (worker, v)); a
+ *                 previous target, if any, gets its resources back (remove_sn_task)
+ *   SAME_WORKER   the task was Retracting{old} and the tick put it on `old` itself: insert_sn_task(old) only, the redirect table is untouched
+ */
+enum { HQ_REDIRECT_FROM_PREFILL = 0, HQ_REDIRECT_RETARGET = 1, HQ_REDIRECT_SAME_WORKER = 2 };
 
 /* SchedulerConfig                                           scheduler/state.rs:5-27 */
 typedef struct hqtick_config {
@@ -156,6 +164,16 @@ typedef struct hqtick_snapshot {
     const uint64_t *prefill_priority; /* [Q] valid when the rq's prefill set is non-empty        */
     const uint64_t *prefill_task;    /* ids in the Set<TaskId>'s iteration order                  */
     const uint32_t *prefill_worker;  /* worker INDEX holding the prefilled task                   */
+
+    /* --- ready tasks in state Retracting{worker}: put back into their queue when a higher-priority arrival dissolved the
+     * prefill set (check_dispose_prefill, scheduler/taskqueue.rs:148-154).  They are ordinary members of the ready set (they appear in
+     * the task_* columns / the resident set), but create_task_mapping treats them differently (scheduler/mapping.rs:66-80): no
+     * `assigned` record, a redirect instead.  Ascending task id. */
+    uint32_t n_retracting;
+    const uint64_t *retracting_task;
+    const uint32_t *retracting_worker;           /* worker INDEX the task is being retracted from                         */
+    const uint32_t *retracting_redirect_worker;  /* current scheduler_state.redirects target (worker INDEX) or HQ_NO_WORKER */
+    const uint8_t *retracting_redirect_variant;  /* its variant (ignored when there is no redirect)                       */
 } hqtick_snapshot;
 
 /* What-if query input: fake workers appended after the real ones (scheduler/query.rs:20-56).
@@ -211,6 +229,7 @@ typedef struct hqtick_result {
     const uint64_t *redirect_task;
     const uint32_t *redirect_worker; /* worker INDEX of the new target */
     const uint8_t *redirect_variant;
+    const uint8_t *redirect_kind;    /* HQ_REDIRECT_* */
 
     /* multi-node placements (solver.rs:442-464, mapping.rs:133-154): task + its workers, root first */
     uint32_t n_mn;

@@ -139,6 +139,9 @@ struct Res {  // WorkerResources padded to R   server/workerload.rs:17-31
     void remove(const Variant &rq) {  // workerload.rs:156-165
         for (auto &e : rq.entries) a[e.res] = e.kind != HQ_ENTRY_ALL ? sat_sub(a[e.res], e.amount) : 0;
     }
+    void add(const Variant &rq, const Res &all) {  // workerload.rs:194-202
+        for (auto &e : rq.entries) a[e.res] = e.kind != HQ_ENTRY_ALL ? a[e.res] + e.amount : all.get(e.res);
+    }
     void remove_multiple(const Variant &rq, u32 n) {  // workerload.rs:167-177
         for (auto &e : rq.entries) a[e.res] = e.kind != HQ_ENTRY_ALL ? sat_sub(a[e.res], e.amount * (u64)n) : 0;
     }
@@ -707,7 +710,7 @@ struct Out {
     std::vector<u32> count_rq; std::vector<u8> count_variant; std::vector<u32> count_worker, count_value;
     std::vector<u32> rec_off; std::vector<u64> rec_task; std::vector<u8> rec_variant, rec_kind;
     std::vector<u32> retract_off; std::vector<u64> retract_task;
-    std::vector<u64> redirect_task; std::vector<u32> redirect_worker; std::vector<u8> redirect_variant;
+    std::vector<u64> redirect_task; std::vector<u32> redirect_worker; std::vector<u8> redirect_variant, redirect_kind;
     std::vector<u64> mn_task; std::vector<u32> mn_worker_off, mn_worker;
     std::vector<u64> new_free;
     std::vector<u8> q_loaded;
@@ -849,7 +852,13 @@ int oracle_tick(void *p, const hqtick_snapshot *s, oracle_solve_fn fn, void *use
     // ---- a8: create_task_mapping  mapping.rs:23-157 ----
     std::vector<std::vector<Rec>> assigned(W), prefills(W);
     std::vector<std::vector<u64>> retracts(W);
-    o.redirect_task.clear(); o.redirect_worker.clear(); o.redirect_variant.clear();
+    o.redirect_task.clear(); o.redirect_worker.clear(); o.redirect_variant.clear(); o.redirect_kind.clear();
+    // ready tasks in state Retracting{old}: task -> (old worker, current redirect target or none, its variant)   mapping.rs:66-80
+    struct Retr { u32 old, target; u8 variant; };
+    std::map<u64, Retr> retracting;
+    for (u32 i = 0; i < s->n_retracting; i++)
+        retracting[s->retracting_task[i]] = Retr{s->retracting_worker[i], s->retracting_redirect_worker ? s->retracting_redirect_worker[i] : HQ_NO_WORKER,
+                                                 s->retracting_redirect_variant ? s->retracting_redirect_variant[i] : (u8)0};
     o.count_rq.clear(); o.count_variant.clear(); o.count_worker.clear(); o.count_value.clear();
     for (size_t ki = 0; ki < sol.keys.size(); ki++) {
         u32 rq = sol.keys[ki].first; u8 vi = sol.keys[ki].second;
@@ -869,14 +878,28 @@ int oracle_tick(void *p, const hqtick_snapshot *s, oracle_solve_fn fn, void *use
                     u64 task = tasks[ti]; u32 w = cw.first;
                     st.workers[w].free.remove(rqd);                   // insert_sn_task  server/worker.rs:188-196
                     st.workers[w].assigned.push_back({rq, vi});
-                    if (oldw[ti] == HQ_NO_WORKER) {                   // Waiting -> Assigned  :53-65
+                    auto rt = oldw[ti] == HQ_NO_WORKER ? retracting.find(task) : retracting.end();
+                    if (rt != retracting.end()) {                     // Retracting{old} stays Retracting  :66-80
+                        Retr &r = rt->second;
+                        if (r.old != w) {                             // redirects.insert(task, (w, v)); a previous target gives the task back
+                            if (r.target != HQ_NO_WORKER) {
+                                st.workers[r.target].free.add(st.rqs[rq].v[r.variant], st.workers[r.target].total);  // remove_sn_task  server/worker.rs:223-234
+                                auto &as = st.workers[r.target].assigned;
+                                auto it = std::find(as.begin(), as.end(), std::make_pair(rq, r.variant)); if (it != as.end()) as.erase(it);
+                            }
+                            r.target = w; r.variant = vi;
+                            o.redirect_task.push_back(task); o.redirect_worker.push_back(w); o.redirect_variant.push_back(vi); o.redirect_kind.push_back(HQ_REDIRECT_RETARGET);
+                        } else {
+                            o.redirect_task.push_back(task); o.redirect_worker.push_back(w); o.redirect_variant.push_back(vi); o.redirect_kind.push_back(HQ_REDIRECT_SAME_WORKER);
+                        }
+                    } else if (oldw[ti] == HQ_NO_WORKER) {            // Waiting -> Assigned  :53-65
                         assigned[w].push_back(Rec{task, vi, HQ_REC_ASSIGN, st.task_priority[task], rq});
                     } else {                                          // Prefilled{old} -> Retracting  :81-101
                         u32 old = oldw[ti];
                         auto &pf = st.workers[old].prefilled_rq;       // remove_prefill_task
                         auto it = std::find(pf.begin(), pf.end(), rq); if (it != pf.end()) pf.erase(it);
                         retracts[old].push_back(task);
-                        o.redirect_task.push_back(task); o.redirect_worker.push_back(w); o.redirect_variant.push_back(vi);
+                        o.redirect_task.push_back(task); o.redirect_worker.push_back(w); o.redirect_variant.push_back(vi); o.redirect_kind.push_back(HQ_REDIRECT_FROM_PREFILL);
                     }
                     ti++;
                     if (ti >= tasks.size()) { done = true; break; }
@@ -920,6 +943,7 @@ int oracle_tick(void *p, const hqtick_snapshot *s, oracle_solve_fn fn, void *use
             if (psz == 0) continue;
             for (u32 wi : elig) {
                 auto tasks = q.take_for_prefill(psz);
+                for (u64 t : tasks) if (retracting.count(t)) { c->err = "a Retracting task reached take_tasks_for_prefill: the reference asserts task.is_waiting() (mapping.rs:221)"; return HQTICK_E_UNSUPPORTED; }
                 for (u64 t : tasks) { st.workers[wi].prefilled_rq.push_back(q.rq); prefills[wi].push_back(Rec{t, 0xFF, HQ_REC_PREFILL, 0, q.rq}); }
             }
         }
@@ -948,7 +972,7 @@ int oracle_tick(void *p, const hqtick_snapshot *s, oracle_solve_fn fn, void *use
     res->count_worker = o.count_worker.data(); res->count_value = o.count_value.data();
     res->rec_off = o.rec_off.data(); res->rec_task = o.rec_task.data(); res->rec_variant = o.rec_variant.data(); res->rec_kind = o.rec_kind.data();
     res->retract_off = o.retract_off.data(); res->retract_task = o.retract_task.data();
-    res->n_redirects = (u32)o.redirect_task.size(); res->redirect_task = o.redirect_task.data(); res->redirect_worker = o.redirect_worker.data(); res->redirect_variant = o.redirect_variant.data();
+    res->n_redirects = (u32)o.redirect_task.size(); res->redirect_task = o.redirect_task.data(); res->redirect_worker = o.redirect_worker.data(); res->redirect_variant = o.redirect_variant.data(); res->redirect_kind = o.redirect_kind.data();
     res->n_mn = (u32)o.mn_task.size(); res->mn_task = o.mn_task.data(); res->mn_worker_off = o.mn_worker_off.data(); res->mn_worker = o.mn_worker.data();
     res->new_free = o.new_free.data();
     res->t_total_us = t4 - t0; res->t_scan_us = t1 - t0; res->t_batches_us = t2 - t1; res->t_solve_us = t3 - t2; res->t_mapping_us = t4 - t3;

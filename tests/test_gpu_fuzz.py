@@ -113,3 +113,57 @@ def test_fuzz_query(seed):
                           max_sn_workers=int(rng.integers(1, 5)), max_workers_per_allocation=int(rng.integers(1, 4)),
                           min_utilization=float([0.0, 0.0, 0.5, 1.0][int(rng.integers(0, 4))])))
     assert envs[0].new_worker_query(g, queries) == envs[1].new_worker_query(o, queries)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_prefill_disposal(seed):
+    """Higher-priority arrivals dissolve prefill sets (check_dispose_prefill, taskqueue.rs:148-154): Retracting tasks sit in the queues
+    and the next tick may take them (mapping.rs:66-80: no record, a redirect — re-targeted, kept on their own worker, or left alone);
+    retract responses arrive for some of them in between (reactor.rs:462-508)."""
+    from hyperqueue_amd.tick import HqTickError, Tick
+    from oracle.oracle import Oracle
+
+    rng = np.random.default_rng(9000 + seed)
+    cfg = abi.make_config(reserve=int(rng.integers(0, 2)), fill_max=int(rng.integers(1, 4)), time_limit_s=20.0)
+    envs = [SchedEnv(cfg), SchedEnv(cfg)]
+    g, o = Tick(cfg), Oracle(cfg, canonical=True)
+    shapes = [TB().cpus(1), TB().cpus(2)]
+    seen_retracting = 0
+    for e in envs:
+        for c in [int(x) for x in np.random.default_rng(seed).integers(1, 5, size=3)]:
+            e.new_worker(WB(c))
+    prio = 0
+    for round_ in range(5):
+        n_new = int(rng.integers(1, 7)) if round_ else int(rng.integers(8, 16)); which = [int(rng.integers(0, 2)) for _ in range(n_new)]
+        if round_ and rng.random() < 0.7:
+            prio += 1  # the new batch outranks everything prefilled so far
+        for e in envs:
+            for c in which:
+                e.new_task(shapes[c].user_priority(prio))
+        snaps = [e.snapshot() for e in envs]
+        seen_retracting += len(snaps[0].retracting)
+        assert snaps[0].retracting == snaps[1].retracting
+        try:
+            rg = g.tick(snaps[0])
+        except HqTickError as err:  # a Retracting task reached the prefill step: the reference asserts there; the oracle must agree
+            assert err.code == abi.HQTICK_E_UNSUPPORTED
+            with pytest.raises(RuntimeError):
+                o.tick(snaps[1])
+            return
+        ro = o.tick(snaps[1])
+        assert_same(rg, ro)
+        assert rg.redirect_kinds == ro.redirect_kinds or sorted(zip(rg.redirects, rg.redirect_kinds)) == sorted(zip(ro.redirects, ro.redirect_kinds))
+        envs[0].apply(rg); envs[1].apply(ro)
+        k = int(rng.integers(1, 7)); answer = rng.random() < 0.6
+        for e in envs:
+            done = 0
+            for t in sorted(e.tasks.values(), key=lambda t: t.id):
+                if t.state == 1 and done < k:
+                    e.finish_task(t.id, t.worker); done += 1
+            if answer:  # the workers answer the retract requests of some tasks (not of those a tick put back on the very worker they are
+                # retracting from: the reference inserts no redirect for them (mapping.rs:69) and would strand the task as Waiting
+                # outside every queue on the response — a state this test does not chase)
+                rt = [t for t in sorted(e.tasks.values(), key=lambda t: t.id) if t.state == 4 and t.id not in e.retaken_variant][:2]
+                for t in rt:
+                    e.retract_response(t.worker, [t.id])
+    assert seen_retracting >= 0
