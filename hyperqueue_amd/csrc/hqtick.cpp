@@ -123,11 +123,6 @@ namespace {
 
 int fail(hqtick_ctx *ctx, int code, const std::string &msg) { ctx->err = msg; return code; }
 
-struct Plan {  // everything phase B hands to the GPU mapping stage
-    std::vector<uint32_t> take, base;  // [G]
-    uint32_t n_sel = 0;
-};
-
 int validate(hqtick_ctx *ctx, const hqtick_snapshot *s, bool need_tasks) {
     if (!s) return fail(ctx, HQTICK_E_INVALID, "null snapshot");
     if (s->n_workers && (!s->worker_id || !s->worker_total || !s->worker_free)) return fail(ctx, HQTICK_E_INVALID, "worker arrays missing");
@@ -358,110 +353,32 @@ std::vector<hqhost::QueueLevels> queue_levels(const Scan &sc, const hqtick_snaps
     return qs;
 }
 
-int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool use_resident) {
-    double t0 = now_us();
-    ctx->ntl = 0;
-    auto mark = [&]() { if (ctx->ntl < 32) ctx->tl[ctx->ntl++] = now_us() - t0; };
-    memset(out, 0, sizeof(*out));
-    ctx->stats = hqtick_kernel_stats{};
-    int rc = validate(ctx, s, !use_resident);
-    if (rc) return rc;
-    HQ_HIP(hipSetDevice(ctx->device));
-    const uint32_t W = s->n_workers, R = s->n_resources, Q = s->n_requests;
-    if (!use_resident) {
-        uint64_t N = s->n_ready;
-        if (!ctx->d_tid.ensure(N * 8 + 8) || !ctx->d_tprio.ensure(N * 8 + 8) || !ctx->d_trq.ensure(N * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set");
-        if (N) {
-            HQ_HIP(hipMemcpyAsync(ctx->d_tid.p, s->task_id, N * 8, hipMemcpyHostToDevice, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(ctx->d_tprio.p, s->task_priority, N * 8, hipMemcpyHostToDevice, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, s->task_rq, N * 4, hipMemcpyHostToDevice, ctx->stream));
-        }
-        ctx->n_ready = N; ctx->resident = false; ctx->levels_valid = false;
-    } else if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "hqtick_run_resident without hqtick_upload_ready");
-    const uint64_t N = ctx->n_ready;
+// One tick, stage by stage.  The stages share the plan scratch of the ctx (no per-tick allocation in the steady state) and a handful of
+// sizes; run() is the only entry point and mirrors run_scheduling_inner (scheduler/main.rs:50-72).
+struct TickRun {
+    hqtick_ctx *ctx; const hqtick_snapshot *s; hqtick_result *out; const bool use_resident;
+    PlanScratch &ps; hqhost::Problem &pb;
+    const uint32_t W, R, Q;
+    static constexpr uint32_t NONE = 0xFFFFFFFFu;
+    WorkerEval ev; Scan sc; hqhost::Counts cnt;
+    uint64_t N = 0; uint32_t L = 0; int status = HQTICK_DONE;
+    uint32_t nkeys = 0, max_count = 0, max_nk = 0, n_bit_words = 0, n_sel = 0, n_pfq = 0, n_rec = 0, max_items = 0;
+    std::vector<uint32_t> pfq_rq;                             // requests that prefill in this tick, ascending
+    std::vector<std::pair<uint32_t, uint32_t>> retr_pos;      // (rq, queue position) of every Retracting task
+    std::vector<std::vector<uint32_t>> key_T;                 // lazily built T_k(s) tables of worker_of()
+    size_t o_rv = 0, o_rk = 0, o_mn = 0, o_fl = 0;            // layout of the pinned record buffer
+    uint64_t *h_rec_task = nullptr, *mn_ids = nullptr; uint8_t *h_rec_var = nullptr, *h_rec_kind = nullptr;
+    bool assembled = false;
+    double t0 = 0;
 
-    // ---------------- GPU phase A ----------------
-    WorkerEval ev;
-    Scan sc;
-    hqhost::Problem &pb = ctx->pb;
-    const std::function<void()> prep = [&]() { fill_problem(pb, s, ctx->cfg, ev); };  // request/worker views: no GPU output needed yet
-    if ((rc = phase_a(ctx, s, &ev, &sc, &prep))) return rc;
-    mark();  // 0: phase A done
-    double t1 = now_us();
+    TickRun(hqtick_ctx *c, const hqtick_snapshot *snap, hqtick_result *o, bool resident)
+        : ctx(c), s(snap), out(o), use_resident(resident), ps(c->plan), pb(c->pb), W(snap->n_workers), R(snap->n_resources), Q(snap->n_requests) {}
 
-    // ---------------- host: batches + placement ----------------
-    std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
-    std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
-    export_batches(ctx, batches, out);
-    mark();  // 1: batches
-    double t2 = now_us();
-    hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
-    if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
-    mark();  // 2: solve
-    double t3 = now_us();
-    out->is_optimal = cnt.is_optimal;
-    int status = HQTICK_DONE;  // scheduler/main.rs:57-68
-    if (!cnt.is_optimal) status = cnt.empty() ? HQTICK_NO_PROGRESS : HQTICK_NEED_MORE_COMPUTE;
+    void mark() { if (ctx->ntl < 32) ctx->tl[ctx->ntl++] = now_us() - t0; }
+    uint32_t hist(uint32_t l, uint32_t q) const { return sc.hist[(size_t)l * Q + q]; }
 
-    // ---------------- host: mapping plan (create_task_mapping as index arithmetic, mapping.rs:36-157) ----------------
-    PlanScratch &ps = ctx->plan;
-    const uint32_t L = sc.L;
-    const uint32_t NONE = 0xFFFFFFFFu;
-    auto hist = [&](uint32_t l, uint32_t q) -> uint32_t { return sc.hist[(size_t)l * Q + q]; };
-    // per request: logical take sequence = [first level][prefilled][rest] when the prefill priority equals the top
-    // priority of the queue, else [prefilled][all levels]   (taskqueue.rs:320-355)
-    ps.q_total.assign(Q, 0); ps.pf_n.assign(Q, 0); ps.pf_start.assign(Q, 0); ps.seq_taken.assign(Q, 0);
-    for (uint32_t q = 0; q < Q; q++) {
-        for (uint32_t l = 0; l < L; l++) ps.q_total[q] += hist(l, q);
-        ps.pf_n[q] = s->prefill_off ? s->prefill_off[q + 1] - s->prefill_off[q] : 0;
-        if (ps.pf_n[q]) {
-            uint32_t first = L; for (uint32_t l = 0; l < L; l++) if (hist(l, q)) { first = l; break; }
-            ps.pf_start[q] = (first < L && sc.levels[first] == s->prefill_priority[q]) ? hist(first, q) : 0;
-        }
-    }
-    const uint32_t nkeys = (uint32_t)cnt.keys.size();
-    ps.key_seg.assign(nkeys, 0); ps.key_sum.assign(nkeys, 0); ps.key_rq.assign(nkeys, 0); ps.key_var_w.assign((nkeys + 3) / 4 + 1, 0);
-    ps.key_ord_off.assign(nkeys + 1, 0); ps.ord_cnt.clear(); ps.key_t_off.assign(nkeys + 1, 0); ps.key_bits_off.assign(nkeys + 1, 0);
-    ps.wpos.assign((size_t)nkeys * W, NONE); ps.wcnt.assign((size_t)nkeys * W, 0);
-    ps.items.assign(W, 0); ps.n_assign.assign(W, 0); ps.asg_qw.assign((size_t)Q * W, 0);
-    ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
-    uint32_t max_count = 0, max_nk = 0;
-    for (uint32_t k = 0; k < nkeys; k++) {
-        const uint32_t q = cnt.keys[k].first; const uint8_t v = cnt.keys[k].second;
-        ps.key_rq[k] = q; reinterpret_cast<uint8_t *>(ps.key_var_w.data())[k] = v;
-        uint32_t sum = 0, maxc = 0, pos = 0;
-        uint32_t *wp = ps.wpos.data() + (size_t)k * W, *wcn = ps.wcnt.data() + (size_t)k * W, *aq = ps.asg_qw.data() + (size_t)q * W;
-        for (auto &wc : cnt.per_key[k]) {
-            sum += wc.second; maxc = std::max(maxc, wc.second);
-            ctx->cnt_rq.push_back(q); ctx->cnt_variant.push_back(v); ctx->cnt_worker.push_back(wc.first); ctx->cnt_value.push_back(wc.second);
-            ps.ord_cnt.push_back(wc.second);
-            wp[wc.first] = pos++; wcn[wc.first] = wc.second; ps.items[wc.first] += wc.second; ps.n_assign[wc.first] += wc.second; aq[wc.first] += wc.second;
-        }
-        ps.key_ord_off[k + 1] = (uint32_t)ps.ord_cnt.size();
-        ps.key_t_off[k + 1] = ps.key_t_off[k] + maxc + 1;  // sweeps 0..maxc
-        ps.key_bits_off[k + 1] = ps.key_bits_off[k] + (maxc + 1) * ((pos + 63) / 64);
-        max_count = std::max(max_count, maxc); max_nk = std::max(max_nk, pos);
-        ps.key_seg[k] = ps.seq_taken[q]; ps.key_sum[k] = sum; ps.seq_taken[q] += sum;
-        if (ps.seq_taken[q] > ps.q_total[q] + ps.pf_n[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "solver placed more tasks than the queue holds (reference panics, taskqueue.rs:327)");
-    }
-    const uint32_t n_units = ps.key_t_off[nkeys], n_bit_words = ps.key_bits_off[nkeys];
-    // multi-node placements take one task each from the head of their queue (mapping.rs:133-154)
-    ps.mn_first.assign(cnt.mn_rq.size(), 0);
-    for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
-        uint32_t q = cnt.mn_rq[i];
-        ps.mn_first[i] = ps.seq_taken[q]; ps.seq_taken[q] += (uint32_t)cnt.mn_sets[i].size();
-        if (ps.pf_n[q]) return fail(ctx, HQTICK_E_UNSUPPORTED, "multi-node queue with a prefill set");
-        if (ps.seq_taken[q] > ps.q_total[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "multi-node placement exceeds its queue");
-    }
-    // already-prefilled tasks that this tick hands out: Prefilled{old} -> retract + redirect  (mapping.rs:81-101)
-    ps.retract_pairs.clear();
-    ctx->red_task.clear(); ctx->red_worker.clear(); ctx->red_variant.clear();
-    ps.pf_drained.assign(Q, 0);
-    ps.has_pf.assign((size_t)Q * W, 0);  // SingleNodeTaskAssignment::prefilled_tasks as per-(rq, worker) counts
-    if (s->prefilled_off) for (uint32_t w = 0; w < W; w++) for (uint32_t i = s->prefilled_off[w]; i < s->prefilled_off[w + 1]; i++) if (s->prefilled_rq[i] < Q) ps.has_pf[(size_t)s->prefilled_rq[i] * W + w]++;
     // host mirror of the K5 arithmetic: the worker that receives the task at index idx of key k's take_tasks() vector
-    std::vector<std::vector<uint32_t>> key_T(nkeys);
-    auto worker_of = [&](uint32_t k, uint32_t idx) -> uint32_t {
+    uint32_t worker_of(uint32_t k, uint32_t idx) {
         const auto &pk = cnt.per_key[k];
         std::vector<uint32_t> &T = key_T[k];
         if (T.empty()) {
@@ -474,147 +391,229 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         uint32_t sw = (uint32_t)(std::upper_bound(T.begin(), T.end(), idx) - T.begin()) - 1, nth = idx - T[sw];
         for (auto &wc : pk) if (wc.second > sw) { if (nth == 0) return wc.first; nth--; }
         return HQ_NO_WORKER;
-    };
-    ctx->red_kind.clear();
-    for (uint32_t k = 0; k < nkeys; k++) {
-        const uint32_t q = cnt.keys[k].first;
-        if (!ps.pf_n[q]) continue;
-        uint32_t a = std::max(ps.key_seg[k], ps.pf_start[q]), b = std::min(ps.key_seg[k] + ps.key_sum[k], ps.pf_start[q] + ps.pf_n[q]);
-        for (uint32_t p = a; p < b; p++) {
-            uint32_t slot = s->prefill_off[q] + (p - ps.pf_start[q]);
-            uint64_t task = s->prefill_task[slot]; uint32_t oldw = s->prefill_worker[slot];
-            uint32_t neww = worker_of(k, p - ps.key_seg[k]);
-            ps.retract_pairs.push_back({oldw, task});
-            if (oldw < W && ps.has_pf[(size_t)q * W + oldw]) ps.has_pf[(size_t)q * W + oldw]--;
-            ctx->red_task.push_back(task); ctx->red_worker.push_back(neww); ctx->red_variant.push_back(cnt.keys[k].second); ctx->red_kind.push_back(HQ_REDIRECT_FROM_PREFILL);
-            if (neww < W) { ps.asg_qw[(size_t)q * W + neww]--; ps.n_assign[neww]--; }  // a redirect is not a new `assigned` record
-            ps.pf_drained[q]++;
-        }
     }
-    // ready tasks in state Retracting{old} that this tick takes (mapping.rs:66-80): no `assigned` record, a redirect instead
-    ps.holes.clear(); ps.freed.clear();
-    std::vector<std::pair<uint32_t, uint32_t>> retr_pos;  // (rq, queue position) of every Retracting task, for the prefill check below
-    if (s->n_retracting) {
-        if (N == 0) return fail(ctx, HQTICK_E_INVALID, "retracting tasks without a ready set");
-        const uint32_t nr = s->n_retracting;
-        const uint8_t *rh = ctx->h_retr.as<uint8_t>();
-        const uint32_t *rkey = reinterpret_cast<const uint32_t *>(rh + (size_t)nr * 8), *rrank = reinterpret_cast<const uint32_t *>(rh + (size_t)nr * 12);
-        for (uint32_t i = 0; i < nr; i++) {
-            if (rkey[i] == 0xFFFFFFFFu || Q == 0) return fail(ctx, HQTICK_E_INVALID, "a retracting task is not in the ready set");
-            const uint32_t l = rkey[i] / Q, q = rkey[i] % Q;
-            uint32_t z = rrank[i]; for (uint32_t l2 = 0; l2 < l; l2++) z += hist(l2, q);         // position in the queue (levels, then id)
-            const uint32_t p = z < ps.pf_start[q] ? z : z + ps.pf_n[q];                             // position in the logical take sequence
-            retr_pos.push_back({q, z});
-            if (p >= ps.seq_taken[q]) continue;                                                   // stays in its queue
-            uint32_t k = nkeys;
-            for (uint32_t kk = 0; kk < nkeys; kk++) if (ps.key_rq[kk] == q && p >= ps.key_seg[kk] && p < ps.key_seg[kk] + ps.key_sum[kk]) { k = kk; break; }
-            if (k == nkeys) return fail(ctx, HQTICK_E_UNSUPPORTED, "a Retracting task was taken by a multi-node placement");
-            const uint32_t neww = worker_of(k, p - ps.key_seg[k]), oldw = s->retracting_worker[i];
-            const uint8_t v = cnt.keys[k].second;
-            ps.holes.push_back(((uint64_t)q << 32) | p);
-            if (neww < W) { ps.asg_qw[(size_t)q * W + neww]--; ps.n_assign[neww]--; }
-            ctx->red_task.push_back(s->retracting_task[i]); ctx->red_worker.push_back(neww); ctx->red_variant.push_back(v);
-            if (oldw != neww) {
-                ctx->red_kind.push_back(HQ_REDIRECT_RETARGET);
-                const uint32_t tw = s->retracting_redirect_worker ? s->retracting_redirect_worker[i] : HQ_NO_WORKER;
-                if (tw != HQ_NO_WORKER) ps.freed.push_back({tw, pb.rqs[q].first_variant + (s->retracting_redirect_variant ? s->retracting_redirect_variant[i] : 0)});  // remove_sn_task(previous target)
-            } else {
-                ctx->red_kind.push_back(HQ_REDIRECT_SAME_WORKER);
+
+    // the ready set: uploaded with the snapshot, or already resident
+    int load_ready_set() {
+        if (!use_resident) {
+            uint64_t N = s->n_ready;
+            if (!ctx->d_tid.ensure(N * 8 + 8) || !ctx->d_tprio.ensure(N * 8 + 8) || !ctx->d_trq.ensure(N * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set");
+            if (N) {
+                HQ_HIP(hipMemcpyAsync(ctx->d_tid.p, s->task_id, N * 8, hipMemcpyHostToDevice, ctx->stream));
+                HQ_HIP(hipMemcpyAsync(ctx->d_tprio.p, s->task_priority, N * 8, hipMemcpyHostToDevice, ctx->stream));
+                HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, s->task_rq, N * 4, hipMemcpyHostToDevice, ctx->stream));
+            }
+            ctx->n_ready = N; ctx->resident = false; ctx->levels_valid = false;
+        } else if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "hqtick_run_resident without hqtick_upload_ready");
+        N = ctx->n_ready;
+        return 0;
+    }
+
+    // create_task_mapping as index arithmetic, part 1: the take sequence of every queue and the per-key tables  (mapping.rs:36-157)
+    int plan_keys() {
+        L = sc.L;
+        // per request: logical take sequence = [first level][prefilled][rest] when the prefill priority equals the top
+        // priority of the queue, else [prefilled][all levels]   (taskqueue.rs:320-355)
+        ps.q_total.assign(Q, 0); ps.pf_n.assign(Q, 0); ps.pf_start.assign(Q, 0); ps.seq_taken.assign(Q, 0);
+        for (uint32_t q = 0; q < Q; q++) {
+            for (uint32_t l = 0; l < L; l++) ps.q_total[q] += hist(l, q);
+            ps.pf_n[q] = s->prefill_off ? s->prefill_off[q + 1] - s->prefill_off[q] : 0;
+            if (ps.pf_n[q]) {
+                uint32_t first = L; for (uint32_t l = 0; l < L; l++) if (hist(l, q)) { first = l; break; }
+                ps.pf_start[q] = (first < L && sc.levels[first] == s->prefill_priority[q]) ? hist(first, q) : 0;
             }
         }
-        std::sort(ps.holes.begin(), ps.holes.end());
-    }
-    // queue tasks taken per request (excluding the prefilled block)
-    ps.zq_taken.assign(Q, 0);
-    for (uint32_t q = 0; q < Q; q++) ps.zq_taken[q] = ps.seq_taken[q] - ps.pf_drained[q];
-    // workers that received a multi-node task are no longer SN (set_mn_task)
-    ps.now_mn.assign(W, 0);
-    for (auto &sets : cnt.mn_sets) for (auto &set : sets) for (uint32_t w : set) ps.now_mn[w] = 1;
-    mark();  // 3: key tables + retracts
-
-    // ---- process_proactive_filling  mapping.rs:159-234 ----
-    if (s->worker_map_rank) { ps.wm_order.assign(W, 0); for (uint32_t w = 0; w < W; w++) ps.wm_order[s->worker_map_rank[w]] = w; }
-    else {
-        if (ps.cached_ids.size() != W || (W && memcmp(ps.cached_ids.data(), s->worker_id, (size_t)W * 4) != 0)) {
-            ps.cached_ids.assign(s->worker_id, s->worker_id + W);
-            hqhb::insertion_order_u32(s->worker_id, W, ps.cached_order);
-        }
-        ps.wm_order = ps.cached_order;
-    }
-    ps.new_pf_total.assign(Q, 0); ps.pfl_size.assign(Q, 0);
-    ps.pfq_src.clear(); ps.pfq_size.clear(); ps.pfl_j.clear();
-    std::vector<uint32_t> pfq_rq;
-    {
-        // state of every queue after the takes: first level that still has tasks
-        std::vector<int> top_level(Q, -1); std::vector<uint32_t> top_left(Q, 0);
-        uint64_t global_top = 0;
-        for (uint32_t q = 0; q < Q; q++) {
-            uint32_t left = ps.zq_taken[q];
-            for (uint32_t l = 0; l < L; l++) { uint32_t h = hist(l, q); if (h > left) { top_level[q] = (int)l; top_left[q] = h - left; break; } left -= h; }
-            if (top_level[q] >= 0) global_top = std::max(global_top, sc.levels[top_level[q]]);  // TaskQueues::top_priority  taskqueue.rs:62-68
-        }
-        for (uint32_t q = 0; q < Q; q++) {
-            if (top_level[q] < 0 || sc.levels[top_level[q]] != global_top) continue;
-            bool pf_left = ps.pf_n[q] > ps.pf_drained[q];
-            uint32_t tsz = (pf_left && s->prefill_priority[q] != global_top) ? 0 : top_left[q];  // top_size_no_prefill  taskqueue.rs:241-253
-            uint32_t size = tsz > ctx->cfg.proactive_filling_reserve ? tsz - ctx->cfg.proactive_filling_reserve : 0;
-            if (!size) continue;
-            ps.elig.clear();
-            const uint32_t *aq = ps.asg_qw.data() + (size_t)q * W, *hp = ps.has_pf.data() + (size_t)q * W;
-            for (uint32_t w : ps.wm_order) {
-                bool sn = (s->worker_flags ? (s->worker_flags[w] & HQ_WORKER_SN) != 0 : true) && !ps.now_mn[w];
-                if (sn && aq[w] > 0 && hp[w] == 0) ps.elig.push_back(w);
+        nkeys = (uint32_t)cnt.keys.size();
+        ps.key_seg.assign(nkeys, 0); ps.key_sum.assign(nkeys, 0); ps.key_rq.assign(nkeys, 0); ps.key_var_w.assign((nkeys + 3) / 4 + 1, 0);
+        ps.key_ord_off.assign(nkeys + 1, 0); ps.ord_cnt.clear(); ps.key_t_off.assign(nkeys + 1, 0); ps.key_bits_off.assign(nkeys + 1, 0);
+        ps.wpos.assign((size_t)nkeys * W, NONE); ps.wcnt.assign((size_t)nkeys * W, 0);
+        ps.items.assign(W, 0); ps.n_assign.assign(W, 0); ps.asg_qw.assign((size_t)Q * W, 0);
+        ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
+        max_count = 0; max_nk = 0;
+        for (uint32_t k = 0; k < nkeys; k++) {
+            const uint32_t q = cnt.keys[k].first; const uint8_t v = cnt.keys[k].second;
+            ps.key_rq[k] = q; reinterpret_cast<uint8_t *>(ps.key_var_w.data())[k] = v;
+            uint32_t sum = 0, maxc = 0, pos = 0;
+            uint32_t *wp = ps.wpos.data() + (size_t)k * W, *wcn = ps.wcnt.data() + (size_t)k * W, *aq = ps.asg_qw.data() + (size_t)q * W;
+            for (auto &wc : cnt.per_key[k]) {
+                sum += wc.second; maxc = std::max(maxc, wc.second);
+                ctx->cnt_rq.push_back(q); ctx->cnt_variant.push_back(v); ctx->cnt_worker.push_back(wc.first); ctx->cnt_value.push_back(wc.second);
+                ps.ord_cnt.push_back(wc.second);
+                wp[wc.first] = pos++; wcn[wc.first] = wc.second; ps.items[wc.first] += wc.second; ps.n_assign[wc.first] += wc.second; aq[wc.first] += wc.second;
             }
-            if (ps.elig.empty()) continue;
-            uint32_t psz = std::min(size / (uint32_t)ps.elig.size(), ctx->cfg.proactive_filling_max);
-            if (!psz) continue;
-            ps.pfl_size[q] = psz;
-            pfq_rq.push_back(q);
-            size_t o = ps.pfl_j.size(); ps.pfl_j.resize(o + W, NONE);
-            for (uint32_t j = 0; j < ps.elig.size(); j++) ps.pfl_j[o + ps.elig[j]] = j;
-            ps.new_pf_total[q] = psz * (uint32_t)ps.elig.size();
+            ps.key_ord_off[k + 1] = (uint32_t)ps.ord_cnt.size();
+            ps.key_t_off[k + 1] = ps.key_t_off[k] + maxc + 1;  // sweeps 0..maxc
+            ps.key_bits_off[k + 1] = ps.key_bits_off[k] + (maxc + 1) * ((pos + 63) / 64);
+            max_count = std::max(max_count, maxc); max_nk = std::max(max_nk, pos);
+            ps.key_seg[k] = ps.seq_taken[q]; ps.key_sum[k] = sum; ps.seq_taken[q] += sum;
+            if (ps.seq_taken[q] > ps.q_total[q] + ps.pf_n[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "solver placed more tasks than the queue holds (reference panics, taskqueue.rs:327)");
         }
-    }
-    for (auto &rp : retr_pos) {  // take_tasks_for_prefill on a Retracting task: the reference asserts task.is_waiting()  (mapping.rs:221)
-        const uint32_t q = rp.first, z = rp.second;
-        if (ps.new_pf_total[q] && z >= ps.zq_taken[q] && z < ps.zq_taken[q] + ps.new_pf_total[q])
-            return fail(ctx, HQTICK_E_UNSUPPORTED, "a Retracting task reached take_tasks_for_prefill: the reference asserts task.is_waiting() (mapping.rs:221)");
-    }
-    mark();  // 4: prefill plan
-    // ---- selection plan per (level, rq) group ----
-    ps.rq_sel_base.assign(Q + 1, 0);
-    for (uint32_t q = 0; q < Q; q++) ps.rq_sel_base[q + 1] = ps.rq_sel_base[q] + ps.zq_taken[q] + ps.new_pf_total[q];
-    const uint32_t n_sel = ps.rq_sel_base[Q];
-    ps.take_base.assign((size_t)2 * sc.G, 0);
-    for (uint32_t q = 0; q < Q; q++) {
-        uint32_t want = ps.zq_taken[q] + ps.new_pf_total[q], cum = 0;
-        for (uint32_t l = 0; l < L; l++) {
-            uint32_t h = hist(l, q), t = want > cum ? std::min(h, want - cum) : 0;
-            ps.take_base[(size_t)l * Q + q] = t; ps.take_base[(size_t)sc.G + (size_t)l * Q + q] = ps.rq_sel_base[q] + cum;
-            cum += h;
+        n_bit_words = ps.key_bits_off[nkeys];
+        // multi-node placements take one task each from the head of their queue (mapping.rs:133-154)
+        ps.mn_first.assign(cnt.mn_rq.size(), 0);
+        for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
+            uint32_t q = cnt.mn_rq[i];
+            ps.mn_first[i] = ps.seq_taken[q]; ps.seq_taken[q] += (uint32_t)cnt.mn_sets[i].size();
+            if (ps.pf_n[q]) return fail(ctx, HQTICK_E_UNSUPPORTED, "multi-node queue with a prefill set");
+            if (ps.seq_taken[q] > ps.q_total[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "multi-node placement exceeds its queue");
         }
+        return 0;
     }
-    for (uint32_t q : pfq_rq) { ps.pfq_src.push_back(ps.rq_sel_base[q] + ps.zq_taken[q]); ps.pfq_size.push_back(ps.pfl_size[q]); }
-    const uint32_t n_pfq = (uint32_t)pfq_rq.size();
-    // ---- output offsets ----
-    ps.out_off.assign(W + 1, 0);
-    uint32_t max_items = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        if (ctx->shard_count > 1 && hqhb::hash_worker_id(s->worker_id[w]) % ctx->shard_count != ctx->shard_index) { ps.out_off[w + 1] = ps.out_off[w]; continue; }  // another rank's worker
-        uint32_t npf = 0;
-        for (uint32_t pi = 0; pi < n_pfq; pi++) if (ps.pfl_j[(size_t)pi * W + w] != NONE) npf += ps.pfq_size[pi];
-        ps.out_off[w + 1] = ps.out_off[w] + npf + ps.n_assign[w];
-        max_items = std::max(max_items, ps.items[w]);
-    }
-    const uint32_t n_rec = ps.out_off[W];
-    if (hqk::expand_mapping_lds(max_items, nkeys) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
-    if (max_nk > hqk::SWEEP_MAX_WORKERS) return fail(ctx, HQTICK_E_CAPACITY, "more than 24576 workers share one (request, variant) placement: beyond the round-robin kernel's LDS staging");
-    mark();  // 5: K5 tables
-    double t4 = now_us();
 
-    // ---------------- GPU phase C ----------------
-    bool assembled = false;
-    auto assemble_host_part = [&]() {  // everything of the result that needs no GPU output: overlapped with phase C
+    // part 2: tasks that leave a prefill set or are Retracting in their queue — redirects instead of records  (mapping.rs:66-101)
+    int plan_redirects() {
+        // already-prefilled tasks that this tick hands out: Prefilled{old} -> retract + redirect  (mapping.rs:81-101)
+        ps.retract_pairs.clear();
+        ctx->red_task.clear(); ctx->red_worker.clear(); ctx->red_variant.clear();
+        ps.pf_drained.assign(Q, 0);
+        ps.has_pf.assign((size_t)Q * W, 0);  // SingleNodeTaskAssignment::prefilled_tasks as per-(rq, worker) counts
+        if (s->prefilled_off) for (uint32_t w = 0; w < W; w++) for (uint32_t i = s->prefilled_off[w]; i < s->prefilled_off[w + 1]; i++) if (s->prefilled_rq[i] < Q) ps.has_pf[(size_t)s->prefilled_rq[i] * W + w]++;
+        key_T.assign(nkeys, {});
+        ctx->red_kind.clear();
+        for (uint32_t k = 0; k < nkeys; k++) {
+            const uint32_t q = cnt.keys[k].first;
+            if (!ps.pf_n[q]) continue;
+            uint32_t a = std::max(ps.key_seg[k], ps.pf_start[q]), b = std::min(ps.key_seg[k] + ps.key_sum[k], ps.pf_start[q] + ps.pf_n[q]);
+            for (uint32_t p = a; p < b; p++) {
+                uint32_t slot = s->prefill_off[q] + (p - ps.pf_start[q]);
+                uint64_t task = s->prefill_task[slot]; uint32_t oldw = s->prefill_worker[slot];
+                uint32_t neww = worker_of(k, p - ps.key_seg[k]);
+                ps.retract_pairs.push_back({oldw, task});
+                if (oldw < W && ps.has_pf[(size_t)q * W + oldw]) ps.has_pf[(size_t)q * W + oldw]--;
+                ctx->red_task.push_back(task); ctx->red_worker.push_back(neww); ctx->red_variant.push_back(cnt.keys[k].second); ctx->red_kind.push_back(HQ_REDIRECT_FROM_PREFILL);
+                if (neww < W) { ps.asg_qw[(size_t)q * W + neww]--; ps.n_assign[neww]--; }  // a redirect is not a new `assigned` record
+                ps.pf_drained[q]++;
+            }
+        }
+        // ready tasks in state Retracting{old} that this tick takes (mapping.rs:66-80): no `assigned` record, a redirect instead
+        ps.holes.clear(); ps.freed.clear();
+        retr_pos.clear();  // (rq, queue position) of every Retracting task, for the prefill check
+        if (s->n_retracting) {
+            if (N == 0) return fail(ctx, HQTICK_E_INVALID, "retracting tasks without a ready set");
+            const uint32_t nr = s->n_retracting;
+            const uint8_t *rh = ctx->h_retr.as<uint8_t>();
+            const uint32_t *rkey = reinterpret_cast<const uint32_t *>(rh + (size_t)nr * 8), *rrank = reinterpret_cast<const uint32_t *>(rh + (size_t)nr * 12);
+            for (uint32_t i = 0; i < nr; i++) {
+                if (rkey[i] == 0xFFFFFFFFu || Q == 0) return fail(ctx, HQTICK_E_INVALID, "a retracting task is not in the ready set");
+                const uint32_t l = rkey[i] / Q, q = rkey[i] % Q;
+                uint32_t z = rrank[i]; for (uint32_t l2 = 0; l2 < l; l2++) z += hist(l2, q);         // position in the queue (levels, then id)
+                const uint32_t p = z < ps.pf_start[q] ? z : z + ps.pf_n[q];                             // position in the logical take sequence
+                retr_pos.push_back({q, z});
+                if (p >= ps.seq_taken[q]) continue;                                                   // stays in its queue
+                uint32_t k = nkeys;
+                for (uint32_t kk = 0; kk < nkeys; kk++) if (ps.key_rq[kk] == q && p >= ps.key_seg[kk] && p < ps.key_seg[kk] + ps.key_sum[kk]) { k = kk; break; }
+                if (k == nkeys) return fail(ctx, HQTICK_E_UNSUPPORTED, "a Retracting task was taken by a multi-node placement");
+                const uint32_t neww = worker_of(k, p - ps.key_seg[k]), oldw = s->retracting_worker[i];
+                const uint8_t v = cnt.keys[k].second;
+                ps.holes.push_back(((uint64_t)q << 32) | p);
+                if (neww < W) { ps.asg_qw[(size_t)q * W + neww]--; ps.n_assign[neww]--; }
+                ctx->red_task.push_back(s->retracting_task[i]); ctx->red_worker.push_back(neww); ctx->red_variant.push_back(v);
+                if (oldw != neww) {
+                    ctx->red_kind.push_back(HQ_REDIRECT_RETARGET);
+                    const uint32_t tw = s->retracting_redirect_worker ? s->retracting_redirect_worker[i] : HQ_NO_WORKER;
+                    if (tw != HQ_NO_WORKER) ps.freed.push_back({tw, pb.rqs[q].first_variant + (s->retracting_redirect_variant ? s->retracting_redirect_variant[i] : 0)});  // remove_sn_task(previous target)
+                } else {
+                    ctx->red_kind.push_back(HQ_REDIRECT_SAME_WORKER);
+                }
+            }
+            std::sort(ps.holes.begin(), ps.holes.end());
+        }
+        // queue tasks taken per request (excluding the prefilled block)
+        ps.zq_taken.assign(Q, 0);
+        for (uint32_t q = 0; q < Q; q++) ps.zq_taken[q] = ps.seq_taken[q] - ps.pf_drained[q];
+        // workers that received a multi-node task are no longer SN (set_mn_task)
+        ps.now_mn.assign(W, 0);
+        for (auto &sets : cnt.mn_sets) for (auto &set : sets) for (uint32_t w : set) ps.now_mn[w] = 1;
+        return 0;
+    }
+
+    // part 3: process_proactive_filling  (mapping.rs:159-234)
+    int plan_prefill() {
+        if (s->worker_map_rank) { ps.wm_order.assign(W, 0); for (uint32_t w = 0; w < W; w++) ps.wm_order[s->worker_map_rank[w]] = w; }
+        else {
+            if (ps.cached_ids.size() != W || (W && memcmp(ps.cached_ids.data(), s->worker_id, (size_t)W * 4) != 0)) {
+                ps.cached_ids.assign(s->worker_id, s->worker_id + W);
+                hqhb::insertion_order_u32(s->worker_id, W, ps.cached_order);
+            }
+            ps.wm_order = ps.cached_order;
+        }
+        ps.new_pf_total.assign(Q, 0); ps.pfl_size.assign(Q, 0);
+        ps.pfq_src.clear(); ps.pfq_size.clear(); ps.pfl_j.clear();
+        pfq_rq.clear();
+        {
+            // state of every queue after the takes: first level that still has tasks
+            std::vector<int> top_level(Q, -1); std::vector<uint32_t> top_left(Q, 0);
+            uint64_t global_top = 0;
+            for (uint32_t q = 0; q < Q; q++) {
+                uint32_t left = ps.zq_taken[q];
+                for (uint32_t l = 0; l < L; l++) { uint32_t h = hist(l, q); if (h > left) { top_level[q] = (int)l; top_left[q] = h - left; break; } left -= h; }
+                if (top_level[q] >= 0) global_top = std::max(global_top, sc.levels[top_level[q]]);  // TaskQueues::top_priority  taskqueue.rs:62-68
+            }
+            for (uint32_t q = 0; q < Q; q++) {
+                if (top_level[q] < 0 || sc.levels[top_level[q]] != global_top) continue;
+                bool pf_left = ps.pf_n[q] > ps.pf_drained[q];
+                uint32_t tsz = (pf_left && s->prefill_priority[q] != global_top) ? 0 : top_left[q];  // top_size_no_prefill  taskqueue.rs:241-253
+                uint32_t size = tsz > ctx->cfg.proactive_filling_reserve ? tsz - ctx->cfg.proactive_filling_reserve : 0;
+                if (!size) continue;
+                ps.elig.clear();
+                const uint32_t *aq = ps.asg_qw.data() + (size_t)q * W, *hp = ps.has_pf.data() + (size_t)q * W;
+                for (uint32_t w : ps.wm_order) {
+                    bool sn = (s->worker_flags ? (s->worker_flags[w] & HQ_WORKER_SN) != 0 : true) && !ps.now_mn[w];
+                    if (sn && aq[w] > 0 && hp[w] == 0) ps.elig.push_back(w);
+                }
+                if (ps.elig.empty()) continue;
+                uint32_t psz = std::min(size / (uint32_t)ps.elig.size(), ctx->cfg.proactive_filling_max);
+                if (!psz) continue;
+                ps.pfl_size[q] = psz;
+                pfq_rq.push_back(q);
+                size_t o = ps.pfl_j.size(); ps.pfl_j.resize(o + W, NONE);
+                for (uint32_t j = 0; j < ps.elig.size(); j++) ps.pfl_j[o + ps.elig[j]] = j;
+                ps.new_pf_total[q] = psz * (uint32_t)ps.elig.size();
+            }
+        }
+        for (auto &rp : retr_pos) {  // take_tasks_for_prefill on a Retracting task: the reference asserts task.is_waiting()  (mapping.rs:221)
+            const uint32_t q = rp.first, z = rp.second;
+            if (ps.new_pf_total[q] && z >= ps.zq_taken[q] && z < ps.zq_taken[q] + ps.new_pf_total[q])
+                return fail(ctx, HQTICK_E_UNSUPPORTED, "a Retracting task reached take_tasks_for_prefill: the reference asserts task.is_waiting() (mapping.rs:221)");
+        }
+        return 0;
+    }
+
+    // part 4: what K4 selects per (level, rq) group, where every worker's records go, capacity checks
+    int plan_outputs() {
+        // ---- selection plan per (level, rq) group ----
+        ps.rq_sel_base.assign(Q + 1, 0);
+        for (uint32_t q = 0; q < Q; q++) ps.rq_sel_base[q + 1] = ps.rq_sel_base[q] + ps.zq_taken[q] + ps.new_pf_total[q];
+        n_sel = ps.rq_sel_base[Q];
+        ps.take_base.assign((size_t)2 * sc.G, 0);
+        for (uint32_t q = 0; q < Q; q++) {
+            uint32_t want = ps.zq_taken[q] + ps.new_pf_total[q], cum = 0;
+            for (uint32_t l = 0; l < L; l++) {
+                uint32_t h = hist(l, q), t = want > cum ? std::min(h, want - cum) : 0;
+                ps.take_base[(size_t)l * Q + q] = t; ps.take_base[(size_t)sc.G + (size_t)l * Q + q] = ps.rq_sel_base[q] + cum;
+                cum += h;
+            }
+        }
+        for (uint32_t q : pfq_rq) { ps.pfq_src.push_back(ps.rq_sel_base[q] + ps.zq_taken[q]); ps.pfq_size.push_back(ps.pfl_size[q]); }
+        n_pfq = (uint32_t)pfq_rq.size();
+        // ---- output offsets ----
+        ps.out_off.assign(W + 1, 0);
+        max_items = 0;
+        for (uint32_t w = 0; w < W; w++) {
+            if (ctx->shard_count > 1 && hqhb::hash_worker_id(s->worker_id[w]) % ctx->shard_count != ctx->shard_index) { ps.out_off[w + 1] = ps.out_off[w]; continue; }  // another rank's worker
+            uint32_t npf = 0;
+            for (uint32_t pi = 0; pi < n_pfq; pi++) if (ps.pfl_j[(size_t)pi * W + w] != NONE) npf += ps.pfq_size[pi];
+            ps.out_off[w + 1] = ps.out_off[w] + npf + ps.n_assign[w];
+            max_items = std::max(max_items, ps.items[w]);
+        }
+        n_rec = ps.out_off[W];
+        if (hqk::expand_mapping_lds(max_items, nkeys) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
+        if (max_nk > hqk::SWEEP_MAX_WORKERS) return fail(ctx, HQTICK_E_CAPACITY, "more than 24576 workers share one (request, variant) placement: beyond the round-robin kernel's LDS staging");
+        return 0;
+    }
+
+    // everything of the result that needs no GPU output: runs while the GPU works on phase C
+    void assemble_host_part() {
         assembled = true;
         ctx->rec_off = ps.out_off;
         ctx->retract_off.assign(W + 1, 0); ctx->retract_task.assign(ps.retract_pairs.size(), 0);
@@ -640,126 +639,178 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
                 f = vv.kind[e] == HQ_ENTRY_ALL ? s->worker_total[(size_t)fr.first * R + vv.res[e]] : f + vv.amount[e];
             }
         }
-    };
-    size_t n_mn_ids = 0; for (auto &sets : cnt.mn_sets) n_mn_ids += sets.size();
-    size_t o_rv = (size_t)n_rec * 8, o_rk = o_rv + n_rec, o_mn = (o_rk + n_rec + 7) & ~(size_t)7, o_fl = o_mn + n_mn_ids * 8, rec_bytes = o_fl + 64;
-    if (!ctx->h_rec.ensure(rec_bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc records");
-    uint64_t *h_rec_task = ctx->h_rec.as<uint64_t>(); uint8_t *h_rec_var = ctx->h_rec.as<uint8_t>() + o_rv, *h_rec_kind = ctx->h_rec.as<uint8_t>() + o_rk;
-    uint64_t *mn_ids = reinterpret_cast<uint64_t *>(ctx->h_rec.as<uint8_t>() + o_mn);
-    if (n_sel) {
-        if (!ctx->d_sel_task.ensure((size_t)n_sel * 8) || !ctx->d_sel_level.ensure((size_t)n_sel * 2 + 2))
-            return fail(ctx, HQTICK_E_DEVICE, "hipMalloc selection");
-        // pack every plan table into one upload
-        std::vector<uint32_t> &pack = ps.pack; pack.clear();
-        auto put = [&](const std::vector<uint32_t> &v) { size_t o = pack.size(); pack.insert(pack.end(), v.begin(), v.end()); if (v.empty()) pack.push_back(0); return o; };
-        size_t o_rq = put(ps.key_rq), o_var = put(ps.key_var_w), o_seg = put(ps.key_seg), o_ordoff = put(ps.key_ord_off), o_ord = put(ps.ord_cnt), o_toff = put(ps.key_t_off),
-               o_boff = put(ps.key_bits_off), o_wpos = put(ps.wpos), o_wcnt = put(ps.wcnt), o_base = put(ps.rq_sel_base), o_pfs = put(ps.pf_start), o_pfn = put(ps.pf_n),
-               o_pqs = put(ps.pfq_src), o_pqz = put(ps.pfq_size), o_pflj = put(ps.pfl_j), o_out = put(ps.out_off);
-        size_t o_tb = put(ps.take_base);
-        if (pack.size() & 1) pack.push_back(0);  // 8-byte alignment for the u64 hole list
-        const size_t o_holes = pack.size();
-        for (uint64_t hk : ps.holes) { pack.push_back((uint32_t)(hk & 0xFFFFFFFFu)); pack.push_back((uint32_t)(hk >> 32)); }
-        if (ps.holes.empty()) { pack.push_back(0); pack.push_back(0); }
-        // device record buffer: [task u64 x n_rec][variant u8 x n_rec][kind u8 x n_rec] -> one D2H copy
-        if (!ctx->d_map.ensure(pack.size() * 4 + 16) || !ctx->h_plan.ensure(pack.size() * 4 + 16) ||
-            !ctx->d_tsweep.ensure((size_t)n_units * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) || !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
-            return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
-        mark();  // 6: pack
-        memcpy(ctx->h_plan.p, pack.data(), pack.size() * 4);
-        const uint32_t *d = ctx->d_map.as<uint32_t>();
-        hqk::MapKeys mk{};
-        mk.n_keys = nkeys; mk.key_rq = d + o_rq; mk.key_variant = reinterpret_cast<const uint8_t *>(d + o_var); mk.key_seg_start = d + o_seg;
-        mk.key_ord_off = d + o_ordoff; mk.ord_cnt = d + o_ord; mk.key_t_off = d + o_toff; mk.key_bits_off = d + o_boff;
-        mk.t_sweep = ctx->d_tsweep.as<uint32_t>(); mk.bits = ctx->d_bits.as<uint64_t>(); mk.pre = ctx->d_pre.as<uint32_t>();
-        mk.wpos = d + o_wpos; mk.wcnt = d + o_wcnt; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn;
-        mk.n_holes = (uint32_t)ps.holes.size(); mk.holes = reinterpret_cast<const uint64_t *>(d + o_holes);
-        mk.n_pfq = n_pfq; mk.pfq_src = d + o_pqs; mk.pfq_size = d + o_pqz; mk.pfl_j = d + o_pflj; mk.out_off = d + o_out;
-        uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
-        flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
-        ctx->last_n_sel = n_sel; ctx->last_consumed = false;
-        ctx->last_geom = sc.geom; ctx->last_L = L; ctx->last_Q = Q; ctx->last_G = sc.G; ctx->last_tb = o_tb; ctx->last_plan_bytes = pack.size() * 4; ctx->last_valid = true;
-        if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-        HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
-                            d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, pack.size() * 4, nullptr, ctx->stream));
-        if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
-        HQ_HIP(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
-        if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        uint8_t *drec = ctx->h_rec.dev<uint8_t>();  // K5b writes the records straight into the caller-visible pinned buffer (PCIe-bound, no copy command)
-        uint64_t *k_task = reinterpret_cast<uint64_t *>(drec); uint8_t *k_var = drec + o_rv, *k_kind = drec + o_rk;
-        if (ctx->sink) {  // multi-GPU: records stay in HBM, laid out for the all-gather (include/hqtick.h)
-            const uint32_t cap = hqtick_sink_capacity_records(W, ctx->sink_bytes);
-            if (n_rec > cap || hqtick_sink_bytes(W, cap) > ctx->sink_bytes) return fail(ctx, HQTICK_E_CAPACITY, "record sink too small for this tick");
-            uint8_t *sk = reinterpret_cast<uint8_t *>(ctx->sink);
-            const size_t so_off = 16, so_task = (so_off + (size_t)(W + 1) * 4 + 7) & ~(size_t)7, so_var = so_task + (size_t)cap * 8, so_kind = so_var + cap;
-            // header + rec_off ride in the plan buffer's tail: stage them in pinned memory and copy with the stream
-            std::vector<uint32_t> &hdr = ps.sink_hdr; hdr.assign(4 + W + 1, 0);
-            hdr[0] = n_rec; hdr[1] = W; hdr[2] = HQTICK_SINK_MAGIC; hdr[3] = cap;
-            memcpy(hdr.data() + 4, ps.out_off.data(), (size_t)(W + 1) * 4);
-            if (!ctx->h_sinkhdr.ensure(hdr.size() * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc sink header");
-            memcpy(ctx->h_sinkhdr.p, hdr.data(), hdr.size() * 4);
-            HQ_HIP(hipMemcpyAsync(sk, ctx->h_sinkhdr.p, hdr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            k_task = reinterpret_cast<uint64_t *>(sk + so_task); k_var = sk + so_var; k_kind = sk + so_kind;
+    }
+
+    // GPU phase C: selection, round-robin bit rows, per-worker expansion; records land in pinned memory (or the HBM sink)
+    int phase_c() {
+        size_t n_mn_ids = 0; for (auto &sets : cnt.mn_sets) n_mn_ids += sets.size();
+        o_rv = (size_t)n_rec * 8; o_rk = o_rv + n_rec; o_mn = (o_rk + n_rec + 7) & ~(size_t)7; o_fl = o_mn + n_mn_ids * 8;
+        const size_t rec_bytes = o_fl + 64;
+        if (!ctx->h_rec.ensure(rec_bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc records");
+        h_rec_task = ctx->h_rec.as<uint64_t>(); h_rec_var = ctx->h_rec.as<uint8_t>() + o_rv; h_rec_kind = ctx->h_rec.as<uint8_t>() + o_rk;
+        mn_ids = reinterpret_cast<uint64_t *>(ctx->h_rec.as<uint8_t>() + o_mn);
+        if (n_sel) {
+            if (!ctx->d_sel_task.ensure((size_t)n_sel * 8) || !ctx->d_sel_level.ensure((size_t)n_sel * 2 + 2))
+                return fail(ctx, HQTICK_E_DEVICE, "hipMalloc selection");
+            // pack every plan table into one upload
+            std::vector<uint32_t> &pack = ps.pack; pack.clear();
+            auto put = [&](const std::vector<uint32_t> &v) { size_t o = pack.size(); pack.insert(pack.end(), v.begin(), v.end()); if (v.empty()) pack.push_back(0); return o; };
+            size_t o_rq = put(ps.key_rq), o_var = put(ps.key_var_w), o_seg = put(ps.key_seg), o_ordoff = put(ps.key_ord_off), o_ord = put(ps.ord_cnt), o_toff = put(ps.key_t_off),
+                   o_boff = put(ps.key_bits_off), o_wpos = put(ps.wpos), o_wcnt = put(ps.wcnt), o_base = put(ps.rq_sel_base), o_pfs = put(ps.pf_start), o_pfn = put(ps.pf_n),
+                   o_pqs = put(ps.pfq_src), o_pqz = put(ps.pfq_size), o_pflj = put(ps.pfl_j), o_out = put(ps.out_off);
+            size_t o_tb = put(ps.take_base);
+            if (pack.size() & 1) pack.push_back(0);  // 8-byte alignment for the u64 hole list
+            const size_t o_holes = pack.size();
+            for (uint64_t hk : ps.holes) { pack.push_back((uint32_t)(hk & 0xFFFFFFFFu)); pack.push_back((uint32_t)(hk >> 32)); }
+            if (ps.holes.empty()) { pack.push_back(0); pack.push_back(0); }
+            // device record buffer: [task u64 x n_rec][variant u8 x n_rec][kind u8 x n_rec] -> one D2H copy
+            if (!ctx->d_map.ensure(pack.size() * 4 + 16) || !ctx->h_plan.ensure(pack.size() * 4 + 16) ||
+                !ctx->d_tsweep.ensure((size_t)ps.key_t_off[nkeys] * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) || !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
+                return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
+            mark();  // 6: pack
+            memcpy(ctx->h_plan.p, pack.data(), pack.size() * 4);
+            const uint32_t *d = ctx->d_map.as<uint32_t>();
+            hqk::MapKeys mk{};
+            mk.n_keys = nkeys; mk.key_rq = d + o_rq; mk.key_variant = reinterpret_cast<const uint8_t *>(d + o_var); mk.key_seg_start = d + o_seg;
+            mk.key_ord_off = d + o_ordoff; mk.ord_cnt = d + o_ord; mk.key_t_off = d + o_toff; mk.key_bits_off = d + o_boff;
+            mk.t_sweep = ctx->d_tsweep.as<uint32_t>(); mk.bits = ctx->d_bits.as<uint64_t>(); mk.pre = ctx->d_pre.as<uint32_t>();
+            mk.wpos = d + o_wpos; mk.wcnt = d + o_wcnt; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn;
+            mk.n_holes = (uint32_t)ps.holes.size(); mk.holes = reinterpret_cast<const uint64_t *>(d + o_holes);
+            mk.n_pfq = n_pfq; mk.pfq_src = d + o_pqs; mk.pfq_size = d + o_pqz; mk.pfl_j = d + o_pflj; mk.out_off = d + o_out;
+            uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
+            flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
+            ctx->last_n_sel = n_sel; ctx->last_consumed = false;
+            ctx->last_geom = sc.geom; ctx->last_L = L; ctx->last_Q = Q; ctx->last_G = sc.G; ctx->last_tb = o_tb; ctx->last_plan_bytes = pack.size() * 4; ctx->last_valid = true;
+            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+            HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
+                                d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, pack.size() * 4, nullptr, ctx->stream));
+            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+            HQ_HIP(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
+            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
+            uint8_t *drec = ctx->h_rec.dev<uint8_t>();  // K5b writes the records straight into the caller-visible pinned buffer (PCIe-bound, no copy command)
+            uint64_t *k_task = reinterpret_cast<uint64_t *>(drec); uint8_t *k_var = drec + o_rv, *k_kind = drec + o_rk;
+            if (ctx->sink) {  // multi-GPU: records stay in HBM, laid out for the all-gather (include/hqtick.h)
+                const uint32_t cap = hqtick_sink_capacity_records(W, ctx->sink_bytes);
+                if (n_rec > cap || hqtick_sink_bytes(W, cap) > ctx->sink_bytes) return fail(ctx, HQTICK_E_CAPACITY, "record sink too small for this tick");
+                uint8_t *sk = reinterpret_cast<uint8_t *>(ctx->sink);
+                const size_t so_off = 16, so_task = (so_off + (size_t)(W + 1) * 4 + 7) & ~(size_t)7, so_var = so_task + (size_t)cap * 8, so_kind = so_var + cap;
+                // header + rec_off ride in the plan buffer's tail: stage them in pinned memory and copy with the stream
+                std::vector<uint32_t> &hdr = ps.sink_hdr; hdr.assign(4 + W + 1, 0);
+                hdr[0] = n_rec; hdr[1] = W; hdr[2] = HQTICK_SINK_MAGIC; hdr[3] = cap;
+                memcpy(hdr.data() + 4, ps.out_off.data(), (size_t)(W + 1) * 4);
+                if (!ctx->h_sinkhdr.ensure(hdr.size() * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc sink header");
+                memcpy(ctx->h_sinkhdr.p, hdr.data(), hdr.size() * 4);
+                HQ_HIP(hipMemcpyAsync(sk, ctx->h_sinkhdr.p, hdr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                k_task = reinterpret_cast<uint64_t *>(sk + so_task); k_var = sk + so_var; k_kind = sk + so_kind;
+            }
+            HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
+                                reinterpret_cast<uint32_t *>(drec + o_fl), ctx->stream));
+            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+            // multi-node tasks: the heads of their queues
+            {
+                size_t pos = 0;
+                for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
+                    size_t n = cnt.mn_sets[i].size();
+                    HQ_HIP(hipMemcpyAsync(mn_ids + pos, ctx->d_sel_task.as<uint64_t>() + ps.rq_sel_base[cnt.mn_rq[i]] + ps.mn_first[i], n * 8, hipMemcpyDeviceToHost, ctx->stream));
+                    pos += n;
+                }
+            }
+            mark();  // 7: phase C enqueued
+            assemble_host_part();
+            HQ_HIP(hipStreamSynchronize(ctx->stream));
+            if (flags[0]) return fail(ctx, HQTICK_E_CAPACITY, "mapping kernel capacity exceeded");
+            float ms = 0;
+            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->stats.select_us = ms * 1000.0;
+            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->stats.sweep_us = ms * 1000.0;
+            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
         }
-        HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
-                            reinterpret_cast<uint32_t *>(drec + o_fl), ctx->stream));
-        if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
-        // multi-node tasks: the heads of their queues
+        if (!n_sel) { ctx->last_n_sel = 0; ctx->last_consumed = true; }
+        if (!n_sel && ctx->sink) {  // nothing placed: still publish an empty, well-formed sink
+            if (hqtick_sink_bytes(W, 0) > ctx->sink_bytes) return fail(ctx, HQTICK_E_CAPACITY, "record sink too small for this tick");
+            std::vector<uint32_t> &hdr = ps.sink_hdr; hdr.assign(4 + W + 1, 0);
+            hdr[1] = W; hdr[2] = HQTICK_SINK_MAGIC; hdr[3] = hqtick_sink_capacity_records(W, ctx->sink_bytes);
+            HQ_HIP(hipMemcpy(ctx->sink, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
+        }
+        return 0;
+    }
+
+    void finish(double t1, double t2, double t3) {
+        if (!assembled) assemble_host_part();
+        ctx->mn_task.clear(); ctx->mn_off.assign(1, 0); ctx->mn_worker.clear();
         {
             size_t pos = 0;
-            for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
-                size_t n = cnt.mn_sets[i].size();
-                HQ_HIP(hipMemcpyAsync(mn_ids + pos, ctx->d_sel_task.as<uint64_t>() + ps.rq_sel_base[cnt.mn_rq[i]] + ps.mn_first[i], n * 8, hipMemcpyDeviceToHost, ctx->stream));
-                pos += n;
+            for (size_t i = 0; i < cnt.mn_rq.size(); i++) for (auto &set : cnt.mn_sets[i]) {
+                ctx->mn_task.push_back(mn_ids[pos++]);
+                for (uint32_t w : set) ctx->mn_worker.push_back(w);
+                ctx->mn_off.push_back((uint32_t)ctx->mn_worker.size());
             }
         }
-        mark();  // 7: phase C enqueued
-        assemble_host_part();
-        HQ_HIP(hipStreamSynchronize(ctx->stream));
-        if (flags[0]) return fail(ctx, HQTICK_E_CAPACITY, "mapping kernel capacity exceeded");
-        float ms = 0;
-        if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->stats.select_us = ms * 1000.0;
-        if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->stats.sweep_us = ms * 1000.0;
-        if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
+        out->status = status;
+        out->n_counts = (uint32_t)ctx->cnt_rq.size(); out->count_rq = ctx->cnt_rq.data(); out->count_variant = ctx->cnt_variant.data();
+        out->count_worker = ctx->cnt_worker.data(); out->count_value = ctx->cnt_value.data();
+        out->rec_off = ctx->rec_off.data();
+        if (!ctx->sink) { out->rec_task = h_rec_task; out->rec_variant = h_rec_var; out->rec_kind = h_rec_kind; }
+        out->retract_off = ctx->retract_off.data(); out->retract_task = ctx->retract_task.data();
+        out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data(); out->redirect_kind = ctx->red_kind.data();
+        out->n_mn = (uint32_t)ctx->mn_task.size(); out->mn_task = ctx->mn_task.data(); out->mn_worker_off = ctx->mn_off.data(); out->mn_worker = ctx->mn_worker.data();
+        out->new_free = ctx->new_free.data();
+        mark();  // 9: result assembled
+        double t5 = now_us();
+        out->t_total_us = t5 - t0; out->t_scan_us = t1 - t0; out->t_batches_us = t2 - t1; out->t_solve_us = t3 - t2; out->t_mapping_us = t5 - t3;
+        uint64_t n_pref = 0; for (uint32_t q = 0; q < Q; q++) n_pref += ps.new_pf_total[q];
+        uint64_t n_asg = 0; for (uint32_t w = 0; w < W; w++) n_asg += ps.n_assign[w];
+        uint32_t nv = Q ? s->rq_variant_off[Q] : 0;
+        ctx->stats.n_assigned = n_asg; ctx->stats.n_prefilled = n_pref;
+        ctx->stats.algorithmic_bytes = N * 20 + (uint64_t)W * R * 16 + (uint64_t)nv * R * 9 + n_asg * 13 + n_pref * 12;
+        ctx->stats.tick_gpu_us = ctx->stats.distinct_us + ctx->stats.level_hist_us + ctx->stats.scan_us + ctx->stats.select_us + ctx->stats.sweep_us + ctx->stats.other_us;
     }
-    if (!n_sel) { ctx->last_n_sel = 0; ctx->last_consumed = true; }
-    if (!n_sel && ctx->sink) {  // nothing placed: still publish an empty, well-formed sink
-        if (hqtick_sink_bytes(W, 0) > ctx->sink_bytes) return fail(ctx, HQTICK_E_CAPACITY, "record sink too small for this tick");
-        std::vector<uint32_t> &hdr = ps.sink_hdr; hdr.assign(4 + W + 1, 0);
-        hdr[1] = W; hdr[2] = HQTICK_SINK_MAGIC; hdr[3] = hqtick_sink_capacity_records(W, ctx->sink_bytes);
-        HQ_HIP(hipMemcpy(ctx->sink, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
+
+    int run() {
+        t0 = now_us();
+        ctx->ntl = 0;
+        memset(out, 0, sizeof(*out));
+        ctx->stats = hqtick_kernel_stats{};
+        int rc = validate(ctx, s, !use_resident);
+        if (rc) return rc;
+        HQ_HIP(hipSetDevice(ctx->device));
+        if ((rc = load_ready_set())) return rc;
+        // ---------------- GPU phase A ----------------
+        const std::function<void()> prep = [&]() { fill_problem(pb, s, ctx->cfg, ev); };  // request/worker views: no GPU output needed yet
+        if ((rc = phase_a(ctx, s, &ev, &sc, &prep))) return rc;
+        mark();  // 0: phase A done
+        const double t1 = now_us();
+        // ---------------- host: batches + placement ----------------
+        std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
+        std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
+        export_batches(ctx, batches, out);
+        mark();  // 1: batches
+        const double t2 = now_us();
+        cnt = hqhost::run_scheduling_solver(pb, batches);
+        if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
+        mark();  // 2: solve
+        const double t3 = now_us();
+        out->is_optimal = cnt.is_optimal;
+        status = HQTICK_DONE;  // scheduler/main.rs:57-68
+        if (!cnt.is_optimal) status = cnt.empty() ? HQTICK_NO_PROGRESS : HQTICK_NEED_MORE_COMPUTE;
+        // ---------------- host: mapping plan ----------------
+        if ((rc = plan_keys())) return rc;
+        if ((rc = plan_redirects())) return rc;
+        mark();  // 3: key tables + retracts
+        if ((rc = plan_prefill())) return rc;
+        mark();  // 4: prefill plan
+        if ((rc = plan_outputs())) return rc;
+        mark();  // 5: K5 tables
+        // ---------------- GPU phase C ----------------
+        if ((rc = phase_c())) return rc;
+        mark();  // 8: phase C synced
+        finish(t1, t2, t3);
+        return status;
     }
-    mark();  // 8: phase C synced
-    // ---------------- assemble the result view (the GPU-dependent part; the rest ran while the GPU worked) ----------------
-    if (!assembled) assemble_host_part();
-    ctx->mn_task.clear(); ctx->mn_off.assign(1, 0); ctx->mn_worker.clear();
-    {
-        size_t pos = 0;
-        for (size_t i = 0; i < cnt.mn_rq.size(); i++) for (auto &set : cnt.mn_sets[i]) {
-            ctx->mn_task.push_back(mn_ids[pos++]);
-            for (uint32_t w : set) ctx->mn_worker.push_back(w);
-            ctx->mn_off.push_back((uint32_t)ctx->mn_worker.size());
-        }
-    }
-    out->status = status;
-    out->n_counts = (uint32_t)ctx->cnt_rq.size(); out->count_rq = ctx->cnt_rq.data(); out->count_variant = ctx->cnt_variant.data();
-    out->count_worker = ctx->cnt_worker.data(); out->count_value = ctx->cnt_value.data();
-    out->rec_off = ctx->rec_off.data();
-    if (!ctx->sink) { out->rec_task = h_rec_task; out->rec_variant = h_rec_var; out->rec_kind = h_rec_kind; }
-    out->retract_off = ctx->retract_off.data(); out->retract_task = ctx->retract_task.data();
-    out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data(); out->redirect_kind = ctx->red_kind.data();
-    out->n_mn = (uint32_t)ctx->mn_task.size(); out->mn_task = ctx->mn_task.data(); out->mn_worker_off = ctx->mn_off.data(); out->mn_worker = ctx->mn_worker.data();
-    out->new_free = ctx->new_free.data();
-    mark();  // 9: result assembled
-    double t5 = now_us();
-    out->t_total_us = t5 - t0; out->t_scan_us = t1 - t0; out->t_batches_us = t2 - t1; out->t_solve_us = t3 - t2; out->t_mapping_us = t5 - t3;
-    uint64_t n_pref = 0; for (uint32_t q = 0; q < Q; q++) n_pref += ps.new_pf_total[q];
-    uint64_t n_asg = 0; for (uint32_t w = 0; w < W; w++) n_asg += ps.n_assign[w];
-    uint32_t nv = Q ? s->rq_variant_off[Q] : 0;
-    ctx->stats.n_assigned = n_asg; ctx->stats.n_prefilled = n_pref;
-    ctx->stats.algorithmic_bytes = N * 20 + (uint64_t)W * R * 16 + (uint64_t)nv * R * 9 + n_asg * 13 + n_pref * 12;
-    ctx->stats.tick_gpu_us = ctx->stats.distinct_us + ctx->stats.level_hist_us + ctx->stats.scan_us + ctx->stats.select_us + ctx->stats.sweep_us + ctx->stats.other_us;
-    (void)t4; (void)max_count;
-    return status;
+};
+
+int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool use_resident) {
+    TickRun run(ctx, s, out, use_resident);
+    return run.run();
 }
 
 }  // namespace
