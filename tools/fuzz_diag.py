@@ -1,5 +1,10 @@
+#!/usr/bin/env python
+"""Diagnose fuzz seeds (needs a GPU): python tools/fuzz_diag.py <seed>...  — prints which result fields differ between the HIP path and the
+canonical oracle, the snapshot, both count lists and the oracle's model size."""
 import sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import torch, numpy as np
 import test_gpu_fuzz as f
 from hyperqueue_amd.tick import Tick

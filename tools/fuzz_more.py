@@ -1,5 +1,9 @@
+#!/usr/bin/env python
+"""Extended randomised parity campaign (needs a GPU): runs tests/test_gpu_fuzz.py::test_fuzz_scenario for seeds 120..2599 and lists the failing ones."""
 import sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import torch
 import test_gpu_fuzz as f
 bad=[]

@@ -1,5 +1,10 @@
+#!/usr/bin/env python
+"""Coverage of the prefill-disposal fuzz (needs a GPU): how often Retracting tasks were re-targeted / kept on their worker / hit the reference's
+prefill assert over 600 scenarios, and whether the HIP path and the oracle ever disagreed."""
 import sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import torch, numpy as np
 from hyperqueue_amd import abi
 from hyperqueue_amd.core import SchedEnv, TaskBuilder as TB, WorkerBuilder as WB
