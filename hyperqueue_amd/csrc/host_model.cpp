@@ -237,12 +237,17 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         return false;
     };
 
-    // ---- separable instances: no multi-node batch, no priority cut, every batch saturated -------------------------
-    // Then the model of solver.rs:95-192 has no row that spans two workers: it is one independent block per worker, and
-    // workers with the same (free, total, eligibility, min_utilization) have the same block up to the positive factor
-    // (W - idx)/W of the objective.  Solve one block per such worker class instead of building W of them.
+    // ---- separable instances: no multi-node batch, no priority cut ------------------------------------------------
+    // Then the only rows of solver.rs:95-271 that span two workers are the batch-size rows `sum_w x <= size_b` of the batches that are
+    // not saturated.  Without them the model is one independent block per worker, and workers with the same (free, total,
+    // eligibility, min_utilization) have the same block up to the positive factor (W - idx)/W of the objective: solve one block per
+    // such worker class instead of building W of them.  The size rows are treated as lazy constraints: if the block optima respect
+    // them, that point is optimal for the full model too (it is optimal for a relaxation and feasible) and it is the canonical one
+    // (the optimal set of the full model is the product of the block-optimal sets cut by the size rows; the per-block lexicographic
+    // minima form the lexicographic minimum of the product, hence of any subset that contains it).  If a size row is violated the
+    // general path below takes over.
     bool separable = true;
-    for (const TaskBatch &b : batches) if (pb.rq_multi_node(b.rq) || !b.cuts.empty() || !b.limit_reached || b.is_blocker) separable = false;
+    for (const TaskBatch &b : batches) if (pb.rq_multi_node(b.rq) || !b.cuts.empty() || b.is_blocker) separable = false;
     if (separable && !batches.empty()) {
         struct ColRef { uint32_t batch; uint8_t variant; };
         std::vector<std::vector<ColRef>> class_cols;
@@ -331,16 +336,26 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             class_cols.push_back(std::move(cols));
             class_x.push_back(std::move(xs));
         }
+        // per class: count of every (batch, variant)
+        const size_t nb = batches.size();
+        std::vector<std::vector<uint32_t>> cls_count(class_cols.size());
+        std::vector<uint32_t> voff(nb + 1, 0);
+        for (size_t b = 0; b < nb; b++) voff[b + 1] = voff[b] + pb.rqs[batches[b].rq].n_variants;
         if (separable) {
-            // per class: count of every (batch, variant)
-            size_t nb = batches.size();
-            std::vector<std::vector<uint32_t>> cls_count(class_cols.size());
-            std::vector<uint32_t> voff(nb + 1, 0);
-            for (size_t b = 0; b < nb; b++) voff[b + 1] = voff[b] + pb.rqs[batches[b].rq].n_variants;
             for (size_t c = 0; c < class_cols.size(); c++) {
                 cls_count[c].assign(voff[nb], 0);
                 for (size_t k = 0; k < class_cols[c].size(); k++) if (class_cols[c][k].batch != UINT32_MAX) cls_count[c][voff[class_cols[c][k].batch] + class_cols[c][k].variant] = class_x[c][k];
             }
+            bool sizes_hold = true;  // the lazy batch-size rows  solver.rs:264-271
+            for (size_t b = 0; b < nb && sizes_hold; b++) {
+                if (batches[b].limit_reached) continue;
+                uint64_t placed = 0;
+                for (uint32_t w : solver_workers) for (uint32_t v = voff[b]; v < voff[b + 1]; v++) placed += cls_count[wclass[w]][v];
+                if (placed > batches[b].size) sizes_hold = false;
+            }
+            if (!sizes_hold) separable = false;
+        }
+        if (separable) {
             std::vector<uint64_t> key_hash; std::vector<std::pair<uint32_t, uint8_t>> key_list; std::vector<std::vector<std::pair<uint32_t, uint32_t>>> key_counts;
             std::vector<uint32_t> ids, widx, cnt, ord;
             for (size_t b = 0; b < nb; b++) {

@@ -29,3 +29,4 @@ for l, v in zip(labels, m):
     print(f"{l:12s} at {v:8.1f} us  (+{v - prev:7.1f})")
     prev = v
 print({k: round(float(np.median([s[k] for s in ks])), 2) for k in ks[0]})
+print("status", int(r.status), "is_optimal", int(r.is_optimal), "assigned+prefilled records", int(r.n_records) if hasattr(r, "n_records") else "?")
