@@ -93,6 +93,11 @@ class SnapshotC(C.Structure):
     ]
 
 
+class GraphStatsC(C.Structure):
+    _fields_ = [("n_tasks", C.c_uint64), ("n_slots", C.c_uint64), ("n_edges_live", C.c_uint64), ("n_edges_pool", C.c_uint64), ("n_runs", C.c_uint64),
+                ("hash_capacity", C.c_uint64), ("hash_tombstones", C.c_uint64), ("bytes_hbm", C.c_uint64), ("last_kernel_us", C.c_double)]
+
+
 class QueryWorkersC(C.Structure):
     _fields_ = [
         ("n_workers", C.c_uint32),

@@ -24,41 +24,18 @@
 #include <string>
 #include <vector>
 
+#include "devbuf.h"
+#include "graph.h"
 #include "hb_order.h"
 #include "host_model.h"
 #include "kernels.h"
 
+using hqbuf::DevBuf;
+using hqbuf::PinBuf;
+
 namespace {
 
 double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-struct DevBuf {
-    void *p = nullptr; size_t cap = 0;
-    bool ensure(size_t bytes) {
-        if (bytes <= cap) return true;
-        if (p) hipFree(p);
-        size_t want = bytes + bytes / 4 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; return false; }
-        cap = want; return true;
-    }
-    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
-    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
-};
-
-struct PinBuf {  // page-locked, device-mapped host memory: kernels read small inputs from it and write small outputs into it
-    void *p = nullptr; void *dp = nullptr; size_t cap = 0;  // dp = the same memory as the device sees it
-    bool ensure(size_t bytes) {
-        if (bytes <= cap) return true;
-        if (p) hipHostFree(p);
-        size_t want = bytes + bytes / 4 + 4096;
-        if (hipHostMalloc(&p, want, hipHostMallocMapped) != hipSuccess) { p = nullptr; dp = nullptr; cap = 0; return false; }
-        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) { hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; return false; }
-        cap = want; return true;
-    }
-    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
-    template <typename T> T *dev() const { return reinterpret_cast<T *>(dp); }
-    void release() { if (p) hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }
-};
 
 }  // namespace
 
@@ -110,6 +87,7 @@ struct hqtick_ctx {
     void *sink = nullptr; size_t sink_bytes = 0;      // hqtick_set_record_sink (device memory)
     // launch state of the last tick (hqtick_debug_time_kernel re-launches K1 / K4 on it)
     hqk::WaveGeom last_geom{}; uint32_t last_L = 0, last_Q = 0, last_G = 0; size_t last_tb = 0, last_plan_bytes = 0, last_hist_off = 0; bool last_valid = false;
+    hqgraph::Graph graph;  // hqtick_graph_*: dependency counters + consumer lists in HBM
     double tl[32] = {}; int ntl = 0;  // debug timeline (us since tick start), hqtick_debug_timeline()
 };
 
@@ -848,6 +826,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
                       &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8};
     for (DevBuf *b : bufs) b->release();
+    ctx->graph.release();
     ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_retr.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -979,6 +958,76 @@ int hqtick_ready_add(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const
     memcpy(h, task_id, n * 8); memcpy(h + o_p, task_priority, n * 8); memcpy(h + o_q, task_rq, n * 4);
     HQ_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
     return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + o_p), reinterpret_cast<const uint32_t *>(d + o_q), (uint32_t)n);
+}
+
+// ---------------------------------------------------------------------------------------------- dependency graph (f1)
+namespace {
+int graph_fail(hqtick_ctx *ctx, int rc) { ctx->err = ctx->graph.err; return rc; }
+int graph_pre(hqtick_ctx *ctx) {
+    if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set (hqtick_upload_ready with n = 0 creates an empty one)");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, HQTICK_E_DEVICE, "hipSetDevice");
+    return 0;
+}
+}  // namespace
+
+int hqtick_graph_add_tasks(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority, const uint32_t *task_rq, const uint32_t *dep_off,
+                           const uint64_t *dep_task_id) {
+    if (!ctx || (n && (!task_id || !task_priority || !task_rq))) return HQTICK_E_INVALID;
+    if (n && dep_off && dep_off[n] && !dep_task_id) return HQTICK_E_INVALID;
+    if (int rc = graph_pre(ctx)) return rc;
+    int r = ctx->graph.add(n, task_id, task_priority, task_rq, dep_off, dep_task_id, ctx->stream);
+    if (r < 0) return graph_fail(ctx, r);
+    if (r > 0) { if (int rc = rebuild_ready(ctx, ctx->graph.out_id(), ctx->graph.out_prio(), ctx->graph.out_rq(), (uint32_t)r)) return rc; }
+    return r;
+}
+
+int hqtick_graph_finish(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id) {
+    if (!ctx || (n && !task_id)) return HQTICK_E_INVALID;
+    if (int rc = graph_pre(ctx)) return rc;
+    int r = ctx->graph.finish(n, task_id, ctx->stream);
+    // released consumers join the ready set even when the call reports ERR_NOT_READY: the graph itself is consistent
+    const uint32_t rel = ctx->graph.n_out();
+    if (rel) { if (int rc = rebuild_ready(ctx, ctx->graph.out_id(), ctx->graph.out_prio(), ctx->graph.out_rq(), rel)) return rc; }
+    if (r < 0) return graph_fail(ctx, r);
+    return r;
+}
+
+int hqtick_graph_remove(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, int recursive) {
+    if (!ctx || (n && !task_id)) return HQTICK_E_INVALID;
+    if (int rc = graph_pre(ctx)) return rc;
+    int r = ctx->graph.remove(n, task_id, recursive != 0, ctx->stream);
+    if (r < 0) return graph_fail(ctx, r);
+    if (r > 0 && ctx->n_ready) {  // TaskQueue::remove for the ones that were ready  core.rs:227-231
+        if (!ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc");
+        uint32_t *cnt = ctx->h_q.as<uint32_t>(); cnt[0] = 0;
+        HQ_HIP(hqk::ready_mark_removed(ctx->d_tid.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), ctx->n_ready, ctx->graph.out_id(), (uint32_t)r, ctx->h_q.dev<uint32_t>(), ctx->stream));
+        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->n_live -= cnt[0]; ctx->last_valid = false; ctx->last_consumed = true;
+    }
+    return r;
+}
+
+const uint64_t *hqtick_graph_last_ids(const hqtick_ctx *ctx, uint64_t *n) {
+    if (!ctx) { if (n) *n = 0; return nullptr; }
+    if (n) *n = ctx->graph.n_out();
+    return ctx->graph.n_out() ? ctx->graph.out_id_host() : nullptr;
+}
+
+uint64_t hqtick_graph_last_unknown(const hqtick_ctx *ctx) { return ctx ? ctx->graph.n_unknown() : 0; }
+
+int hqtick_graph_unfinished(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, uint32_t *out) {
+    if (!ctx || (n && (!task_id || !out))) return HQTICK_E_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, HQTICK_E_DEVICE, "hipSetDevice");
+    int r = ctx->graph.unfinished(n, task_id, out, ctx->stream);
+    return r < 0 ? graph_fail(ctx, r) : 0;
+}
+
+int hqtick_graph_get_stats(const hqtick_ctx *ctx, hqtick_graph_stats *out) {
+    if (!ctx || !out) return HQTICK_E_INVALID;
+    hqgraph::Stats st = ctx->graph.stats();
+    out->n_tasks = st.n_tasks; out->n_slots = st.n_slots; out->n_edges_live = st.n_edges_live; out->n_edges_pool = st.n_edges_pool; out->n_runs = st.n_runs;
+    out->hash_capacity = st.hash_capacity; out->hash_tombstones = st.hash_tombstones; out->bytes_hbm = st.bytes_hbm; out->last_kernel_us = ctx->graph.last_kernel_us();
+    return 0;
 }
 
 int hqtick_ready_compact(hqtick_ctx *ctx) {

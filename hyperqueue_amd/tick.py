@@ -119,6 +119,58 @@ class Tick:
         self._lib.hqtick_ready_count.argtypes = [C.c_void_p]
         return int(self._lib.hqtick_ready_count(self._ctx))
 
+    # -- device-resident dependency graph (include/hqtick.h) --------------------------------------------------
+    def _graph_last_ids(self) -> np.ndarray:
+        n = C.c_uint64()
+        self._lib.hqtick_graph_last_ids.restype = abi.u64p
+        self._lib.hqtick_graph_last_ids.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        p = self._lib.hqtick_graph_last_ids(self._ctx, C.byref(n))
+        return abi._np(p, n.value, np.uint64).copy() if n.value else np.zeros(0, np.uint64)
+
+    def graph_add_tasks(self, task_id, task_priority, task_rq, deps) -> np.ndarray:
+        """on_new_tasks (reactor.rs:188-220).  `deps` = one list of task ids per task, or a (dep_off, dep_task_id) CSR pair.
+        Returns the ids that are ready now (ascending); they are already merged into the resident ready set."""
+        a, b, c = (np.ascontiguousarray(task_id, np.uint64), np.ascontiguousarray(task_priority, np.uint64), np.ascontiguousarray(task_rq, np.uint32))
+        if isinstance(deps, tuple):
+            off, dep = np.ascontiguousarray(deps[0], np.uint32), np.ascontiguousarray(deps[1], np.uint64)
+        else:
+            off = np.zeros(len(a) + 1, np.uint32)
+            off[1:] = np.cumsum([len(d) for d in deps])
+            dep = np.ascontiguousarray([x for d in deps for x in d], np.uint64)
+        self._lib.hqtick_graph_add_tasks.argtypes = [C.c_void_p, C.c_uint64, abi.u64p, abi.u64p, abi.u32p, abi.u32p, abi.u64p]
+        self._chk(self._lib.hqtick_graph_add_tasks(self._ctx, len(a), a.ctypes.data_as(abi.u64p), b.ctypes.data_as(abi.u64p), c.ctypes.data_as(abi.u32p),
+                                                   off.ctypes.data_as(abi.u32p), dep.ctypes.data_as(abi.u64p)))
+        return self._graph_last_ids()
+
+    def graph_finish(self, task_id) -> tuple[np.ndarray, int]:
+        """task_finished (reactor.rs:510-590) for a batch.  Returns (released ids ascending, number of unknown ids)."""
+        a = np.ascontiguousarray(task_id, np.uint64)
+        self._lib.hqtick_graph_finish.argtypes = [C.c_void_p, C.c_uint64, abi.u64p]
+        self._chk(self._lib.hqtick_graph_finish(self._ctx, len(a), a.ctypes.data_as(abi.u64p)))
+        self._lib.hqtick_graph_last_unknown.restype = C.c_uint64
+        self._lib.hqtick_graph_last_unknown.argtypes = [C.c_void_p]
+        return self._graph_last_ids(), int(self._lib.hqtick_graph_last_unknown(self._ctx))
+
+    def graph_remove(self, task_id, recursive: bool = False) -> np.ndarray:
+        """Core::remove_task (core.rs:222-240), with the transitive consumers if `recursive` (task.rs:235-250).  Returns the removed ids."""
+        a = np.ascontiguousarray(task_id, np.uint64)
+        self._lib.hqtick_graph_remove.argtypes = [C.c_void_p, C.c_uint64, abi.u64p, C.c_int]
+        self._chk(self._lib.hqtick_graph_remove(self._ctx, len(a), a.ctypes.data_as(abi.u64p), 1 if recursive else 0))
+        return self._graph_last_ids()
+
+    def graph_unfinished(self, task_id) -> np.ndarray:
+        a = np.ascontiguousarray(task_id, np.uint64)
+        out = np.zeros(len(a), np.uint32)
+        self._lib.hqtick_graph_unfinished.argtypes = [C.c_void_p, C.c_uint64, abi.u64p, abi.u32p]
+        self._chk(self._lib.hqtick_graph_unfinished(self._ctx, len(a), a.ctypes.data_as(abi.u64p), out.ctypes.data_as(abi.u32p)))
+        return out
+
+    def graph_stats(self) -> dict:
+        st = abi.GraphStatsC()
+        self._lib.hqtick_graph_get_stats.argtypes = [C.c_void_p, C.POINTER(abi.GraphStatsC)]
+        self._chk(self._lib.hqtick_graph_get_stats(self._ctx, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in abi.GraphStatsC._fields_}
+
     def query(self, snap: abi.Snapshot, fake_ids, fake_total, fake_remaining=None, fake_min_util=None):
         sc = snap.to_c()
         n = len(fake_ids)

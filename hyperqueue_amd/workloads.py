@@ -7,6 +7,7 @@ C++/Rust harness can regenerate the same inputs.
       (128 c / 8 g / 512 m), one priority level, every class saturated  -> the placement model is separable per worker
   c3p c3 with three user-priority levels (80/15/5 %): couples all workers through priority cuts (reported, not benched)
   c4  c3 classes as 2-variant OR-lists, 4096 workers                (sharded case)
+  c5  make_dag(): 1 000 000-node random DAG over the c3 classes, fan-in ~ Poisson(3) from lower ids (dependency-graph case)
 """
 from __future__ import annotations
 
@@ -95,6 +96,27 @@ def make(name: str, seed: int = 0, n_tasks: Optional[int] = None, n_workers: Opt
         reqs = [[_variant(c[0]), _variant(alt)] for c, alt in zip(C3_CLASSES, C4_ALTERNATIVES)]
         return abi.Snapshot(requests=reqs, task_id=ids, task_priority=prio, task_rq=rq, **w)
     raise ValueError(f"unknown workload {name}")
+
+
+def make_dag(n: int = 1_000_000, seed: int = 0, mean_fan_in: float = 3.0):
+    """BASELINE config 5: `n` tasks of the c3 classes in submission order; task i depends on ~Poisson(mean_fan_in)
+    distinct tasks drawn uniformly from the ones before it.  Returns (task_id, priority, rq, dep_off u32[n + 1], dep_task_id u64[E])."""
+    ids, prio, rq = _tasks(n, [c[1] for c in C3_CLASSES], seed)
+    r = splitmix64_stream(seed ^ 0x5EED, n)
+    u = (r >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    kmax = 24
+    pmf = np.exp(-mean_fan_in) * np.cumprod(np.concatenate([[1.0], mean_fan_in / np.arange(1, kmax)]))
+    k = np.searchsorted(np.cumsum(pmf), u, side="right").clip(0, kmax - 1)
+    k = np.minimum(k, np.arange(n))  # task i has only i predecessors
+    cons = np.repeat(np.arange(n, dtype=np.int64), k)
+    r2 = splitmix64_stream(seed ^ 0xDA6, len(cons))
+    u2 = (r2 >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    dep = np.minimum((u2 * cons).astype(np.int64), cons - 1)
+    pair = np.unique(cons * n + dep)  # distinct (consumer, dependency) pairs, sorted by consumer then dependency
+    cons, dep = pair // n, pair % n
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum(np.bincount(cons, minlength=n))
+    return ids, prio, rq, off, ids[dep]
 
 
 def shard_workers(snap: abi.Snapshot, rank: int, world: int) -> abi.Snapshot:

@@ -291,6 +291,52 @@ int hqtick_ready_compact(hqtick_ctx *ctx);
 uint64_t hqtick_ready_count(const hqtick_ctx *ctx);
 
 /*
+ * Device-resident dependency graph (BASELINE config 5): the `Waiting{unfinished_deps}` counters and the consumer
+ * sets of tako's task map live in HBM next to the ready set, so a batch of `Finished` updates releases its consumers into the
+ * resident ready set on the device.  A resident ready set must exist (hqtick_upload_ready with n = 0 creates an empty one).
+ *   hqtick_graph_add_tasks   on_new_tasks  server/reactor.rs:188-220.  Tasks in submission order; dep_off[n + 1] / dep_task_id is
+ *                            the CSR of Task::task_deps (each list free of duplicates, as hyperqueue's submit guarantees,
+ *                            crates/hyperqueue/src/server/client/submit.rs:446).  A dependency is kept only if the task map holds
+ *                            it when the consumer is processed: ids that are not in the graph (finished tasks), the task itself and
+ *                            tasks LATER in the same batch are dropped, exactly as `find_task_mut` misses them.  Tasks with no kept
+ *                            dependency are merged into the ready set (Core::add_task, server/core.rs:213-218).
+ *                            Returns how many tasks of the batch are ready now.  HQTICK_E_INVALID (graph unchanged) if an id is
+ *                            already in the graph or listed twice (the reference asserts, core.rs:217).
+ *   hqtick_graph_finish      task_finished  server/reactor.rs:510-590: every consumer's counter is decremented
+ *                            (Task::decrease_unfinished_deps, server/task.rs:207-216); consumers reaching 0 are merged into the ready
+ *                            set (add_ready_task); the finished tasks leave the graph (Core::remove_task).  Ids that are not in the
+ *                            graph are counted (hqtick_graph_last_unknown; "Unknown task finished", reactor.rs:565-567).  The tasks
+ *                            must not be in the ready set any more (they were handed out by a tick).  Returns the number of
+ *                            released tasks.
+ *   hqtick_graph_remove      Core::remove_task  server/core.rs:222-240 for cancel (on_cancel_tasks, reactor.rs:706-780) and failed
+ *                            dependencies (task_failed, reactor.rs:606-704): the tasks leave the graph and, if they are there, the
+ *                            ready set.  recursive != 0 also removes their transitive consumers
+ *                            (Task::collect_recursive_consumers, server/task.rs:235-250).  Returns the number of removed tasks.
+ *   hqtick_graph_last_ids    ids the last graph call produced (ready-now / released / removed tasks), ASCENDING, in pinned host
+ *                            memory owned by the ctx; valid until the next graph call.  The host shim uses them to keep its Task
+ *                            objects in step (state Waiting{0}, client notifications).
+ *   hqtick_graph_unfinished  Task::get_unfinished_deps for each id; 0xFFFFFFFF for ids that are not in the graph (test accessor).
+ * Task ids >= 0xFFFFFFFFFFFFFFFE are reserved.  Memory: 52 B per task slot + 24 B per hash bucket (2-4 buckets per task) + 20 B per
+ * dependency edge; pools grow on demand and are compacted when the dead edges of finished producers fill them.
+ */
+typedef struct hqtick_graph_stats {
+    uint64_t n_tasks;          /* tasks in the graph (waiting, ready, assigned, running)   */
+    uint64_t n_slots;          /* task slots ever used (high-water mark)                    */
+    uint64_t n_edges_live, n_edges_pool, n_runs;
+    uint64_t hash_capacity, hash_tombstones;
+    uint64_t bytes_hbm;
+    double last_kernel_us;     /* HIP-event time of the dominant kernel(s) of the last graph call */
+} hqtick_graph_stats;
+int hqtick_graph_add_tasks(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority,
+                           const uint32_t *task_rq, const uint32_t *dep_off, const uint64_t *dep_task_id);
+int hqtick_graph_finish(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id);
+int hqtick_graph_remove(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, int recursive);
+const uint64_t *hqtick_graph_last_ids(const hqtick_ctx *ctx, uint64_t *n);
+uint64_t hqtick_graph_last_unknown(const hqtick_ctx *ctx);
+int hqtick_graph_unfinished(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, uint32_t *out);
+int hqtick_graph_get_stats(const hqtick_ctx *ctx, hqtick_graph_stats *out);
+
+/*
  * Multi-GPU: worker sharding.  Every rank (one ctx per GPU) runs the tick on the SAME snapshot — scans, batches and the
  * placement are replicated and deterministic — but expands and emits records only for the workers it owns:
  *     FxHash(worker_id) % shard_count == shard_index       (FxHash = fxhash 0.2.1 of the u32 id, as tako's Map uses)

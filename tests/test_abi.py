@@ -38,7 +38,7 @@ def test_struct_layouts_match_header():
     """Compile a tiny C program against include/hqtick.h printing sizeof/offsetof; compare with the ctypes mirror."""
     pairs = {
         "hqtick_config": abi.Config, "hqtick_snapshot": abi.SnapshotC, "hqtick_query_workers": abi.QueryWorkersC,
-        "hqtick_result": abi.ResultC, "hqtick_query_result": abi.QueryResultC, "hqtick_kernel_stats": abi.KernelStatsC,
+        "hqtick_result": abi.ResultC, "hqtick_query_result": abi.QueryResultC, "hqtick_kernel_stats": abi.KernelStatsC, "hqtick_graph_stats": abi.GraphStatsC,
     }
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "hqtick.h"', "int main(void){"]
     for cname, cls in pairs.items():

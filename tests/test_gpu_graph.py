@@ -1,0 +1,212 @@
+"""Device-resident dependency graph (hqtick_graph_*) against oracle/graph_oracle.py: the reference's own
+dependency tests, randomised DAG churn, hub / chain shapes, error behaviour, and the interplay with the resident ready set."""
+import numpy as np
+import pytest
+
+from graph_cases import CASES
+from hyperqueue_amd import abi, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def T():
+    from hyperqueue_amd.tick import Tick
+
+    t = Tick(abi.make_config(time_limit_s=20.0))
+    t.upload_ready(np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    return t
+
+
+def _add(t, tasks):
+    return t.graph_add_tasks([i for i, *_ in tasks], [p for _, p, _, _ in tasks], [q for _, _, q, _ in tasks], [list(d) for *_, d in tasks]).tolist()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_case(T, name):
+    n_ready = 0
+    for st in CASES[name]():
+        op = st[0]
+        if op == "add":
+            ready = _add(T, [(i, 0, 0, deps) for i, deps in st[1]])
+            n_ready += len(ready)
+            if "ready" in st[2]:
+                assert ready == sorted(st[2]["ready"])
+            for i, n in st[2].get("unfinished", {}).items():
+                assert T.graph_unfinished([i])[0] == n
+        elif op == "take":
+            assert T.ready_remove(np.asarray(st[1], np.uint64)) == len(st[1])  # stands for the tick handing them out
+            n_ready -= len(st[1])
+        elif op == "finish":
+            rel, unknown = T.graph_finish(st[1])
+            assert unknown == 0 and rel.tolist() == sorted(st[2]["released"])
+            n_ready += len(rel)
+            for i, n in st[2].get("unfinished", {}).items():
+                assert T.graph_unfinished([i])[0] == n
+        elif op == "fail":
+            removed = T.graph_remove([st[1]], recursive=True).tolist()
+            assert removed == sorted(st[2]["removed"])
+        elif op == "collect":
+            removed = T.graph_remove([st[1]], recursive=True).tolist()
+            assert removed == sorted([st[1]] + st[2]["consumers"])
+            n_ready -= 1
+        elif op == "exists":
+            for i, e in st[1].items():
+                assert (T.graph_unfinished([i])[0] != 0xFFFFFFFF) == e
+        if op not in ("fail",):
+            assert T.ready_count() == n_ready
+
+
+def test_dep_later_in_batch_is_dropped(T):
+    assert _add(T, [(1, 0, 0, [2]), (2, 0, 0, [1]), (3, 0, 0, [3])]) == [1, 3]
+    assert T.graph_unfinished([1, 2, 3, 4]).tolist() == [0, 1, 0, 0xFFFFFFFF]
+
+
+def test_errors_leave_the_graph_unchanged(T):
+    from hyperqueue_amd.tick import HqTickError
+
+    assert _add(T, [(5, 1, 0, []), (6, 1, 0, [5])]) == [5]
+    with pytest.raises(HqTickError) as e:
+        _add(T, [(9, 1, 0, []), (6, 1, 0, [])])  # 6 exists: core.rs:217
+    assert e.value.code == abi.HQTICK_E_INVALID
+    with pytest.raises(HqTickError) as e:
+        _add(T, [(10, 1, 0, []), (11, 1, 0, []), (10, 1, 0, [])])
+    assert e.value.code == abi.HQTICK_E_INVALID
+    assert T.graph_unfinished([5, 6, 9, 10, 11]).tolist() == [0, 1, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF]
+    assert T.graph_stats()["n_tasks"] == 2 and T.ready_count() == 1
+    assert _add(T, [(9, 1, 0, [6]), (10, 1, 0, [])]) == [10]
+    T.ready_remove([5])
+    rel, unknown = T.graph_finish([5, 77, 5])
+    assert rel.tolist() == [6] and unknown == 2
+    with pytest.raises(HqTickError):  # 9 still waits for 6: reactor.rs:551-555 unreachable!()
+        T.graph_finish([9])
+
+
+def _random_dag_run(T, seed, n_rounds, batch, p_unknown=0.05):
+    from oracle.graph_oracle import GraphOracle
+
+    rng = np.random.default_rng(seed)
+    g = GraphOracle()
+    next_id, running = 1, []
+    for rnd in range(n_rounds):
+        # --- submit a batch: deps on live tasks (any state), on finished ones, on later ones of the same batch
+        n = int(rng.integers(1, batch))
+        ids = [(int(rng.integers(1, 4)) << 32) | (next_id + k) for k in range(n)]
+        next_id += n
+        if rng.random() < 0.5:
+            rng.shuffle(ids)
+        live = list(g.tasks)
+        tasks = []
+        for k, i in enumerate(ids):
+            pool = live + ids  # earlier AND later ids of the batch
+            nd = int(min(len(pool), rng.poisson(2.0)))
+            deps = set(int(x) for x in rng.choice(pool, nd, replace=False)) if nd else set()
+            if rng.random() < p_unknown:
+                deps.add(int(rng.integers(1 << 40, 1 << 41)))
+            tasks.append((i, int(rng.integers(0, 5)) << 32, int(rng.integers(0, 3)), sorted(deps)))
+        want = g.on_new_tasks(tasks)
+        assert _add(T, tasks) == want
+        # --- the scheduler hands out some ready tasks
+        rd = sorted(g.ready)
+        take = [i for i in rd if rng.random() < 0.6]
+        if take:
+            g.take_from_ready(take)
+            assert T.ready_remove(np.asarray(take, np.uint64)) == len(take)
+            running += take
+        # --- some running tasks finish (plus unknown ids and a duplicate)
+        rng.shuffle(running)
+        k = int(rng.integers(0, len(running) + 1))
+        fin, running = running[:k], running[k:]
+        extra = [int(rng.integers(1 << 42, 1 << 43))] if rng.random() < 0.3 else []
+        if fin and rng.random() < 0.3:
+            extra.append(fin[0])
+        rel_w, unk_w = g.task_finished(fin + extra)
+        rel, unk = T.graph_finish(fin + extra) if fin + extra else (np.zeros(0, np.uint64), 0)
+        assert rel.tolist() == rel_w and unk == unk_w
+        # --- sometimes a task fails / is cancelled: it and its transitive consumers leave
+        if rng.random() < 0.35 and g.tasks:
+            victims = [int(x) for x in rng.choice(list(g.tasks), int(min(len(g.tasks), rng.integers(1, 4))), replace=False)]
+            rec = bool(rng.random() < 0.8)
+            if not rec:  # the reference only removes a lone task when nothing depends on it
+                victims = [v for v in victims if not g.tasks[v].consumers]
+            if victims:
+                rm_w, _ = g.remove(victims, rec)
+                assert T.graph_remove(victims, recursive=rec).tolist() == rm_w
+                running = [r for r in running if r in g.tasks]
+        assert T.ready_count() == len(g.ready)
+        assert T.graph_stats()["n_tasks"] == len(g.tasks)
+        probe = list(g.tasks)[:200] + [next_id + 10_000]
+        assert T.graph_unfinished(probe).tolist() == [g.unfinished(i) for i in probe]
+    return g
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_dag_churn(T, seed):
+    _random_dag_run(T, 9000 + seed, n_rounds=40, batch=60)
+
+
+def test_random_dag_churn_long_with_pool_growth(T):
+    g = _random_dag_run(T, 4242, n_rounds=120, batch=400)
+    st = T.graph_stats()
+    assert st["n_slots"] < 120 * 400  # slots were recycled
+    assert st["n_edges_live"] <= st["n_edges_pool"]
+
+
+def test_ready_set_after_graph_ops_ticks_like_the_oracle(T):
+    """the tasks the graph released are really in the resident ready set: a resident tick equals the oracle's tick on the oracle's ready set"""
+    from oracle.oracle import Oracle
+
+    g = _random_dag_run(T, 77, n_rounds=30, batch=80)
+    base = workloads.make("c1")
+    ids = np.asarray(sorted(g.ready), np.uint64)
+    assert len(ids) > 0
+    snap_kw = {f: getattr(base, f) for f in ("n_resources", "worker_id", "worker_total", "worker_free", "worker_remaining_ns", "worker_min_utilization", "worker_flags",
+                                             "worker_group", "n_groups", "blocked", "assigned", "prefilled", "prefill", "worker_map_rank")}
+    reqs = [base.requests[0]] * 3  # rq 0..2 all `cpus = 1`
+    full = abi.Snapshot(**snap_kw, requests=reqs, task_id=ids, task_priority=np.asarray([g.ready[int(i)][0] for i in ids], np.uint64),
+                        task_rq=np.asarray([g.ready[int(i)][1] for i in ids], np.uint32))
+    stripped = abi.Snapshot(**snap_kw, requests=reqs, task_id=np.zeros(0, np.uint64), task_priority=np.zeros(0, np.uint64), task_rq=np.zeros(0, np.uint32))
+    got = T.tick(stripped, resident=True)
+    want = Oracle(abi.make_config(time_limit_s=20.0), canonical=True).tick(full)
+    assert got.batches == want.batches and got.counts == want.counts and got.records == want.records
+
+
+def test_hub_and_chain(T):
+    """one producer with 100 000 consumers (the wide-run kernel) and a 300-deep chain (level-synchronous recursive removal)"""
+    hub = 1
+    cons = list(range(2, 100_002))
+    assert _add(T, [(hub, 0, 0, [])] + [(c, 0, 0, [hub]) for c in cons]) == [hub]
+    chain = list(range(200_000, 200_300))
+    assert _add(T, [(chain[0], 0, 1, [hub])] + [(chain[k], 0, 1, [chain[k - 1]]) for k in range(1, 300)]) == []
+    assert T.graph_unfinished([cons[0], cons[-1], chain[0], chain[5]]).tolist() == [1, 1, 1, 1]
+    removed = T.graph_remove([chain[0]], recursive=True).tolist()
+    assert removed == chain
+    T.ready_remove([hub])
+    rel, unk = T.graph_finish([hub])
+    assert unk == 0 and rel.tolist() == cons
+    assert T.ready_count() == len(cons) and T.graph_stats()["n_tasks"] == len(cons)
+
+
+def test_c5_shape_drains_level_by_level(T):
+    """BASELINE config 5 shape, reduced: random DAG with Poisson(3) fan-in from lower ids; finishing everything that is ready, wave after
+    wave, releases every task exactly once and in the same waves as the oracle"""
+    from oracle.graph_oracle import GraphOracle
+
+    n = 60_000
+    ids, prio, rq, off, dep = workloads.make_dag(n, seed=5)
+    g = GraphOracle()
+    want = g.on_new_tasks([(int(ids[i]), int(prio[i]), int(rq[i]), [int(x) for x in dep[off[i]:off[i + 1]]]) for i in range(n)])
+    ready = T.graph_add_tasks(ids, prio, rq, (off, dep)).tolist()
+    assert ready == want
+    unf = T.graph_unfinished(ids)
+    assert unf.tolist() == [g.unfinished(int(i)) for i in ids]
+    done, waves = 0, 0
+    while ready:
+        assert T.ready_remove(np.asarray(ready, np.uint64)) == len(ready)
+        g.take_from_ready(ready)
+        rel_w, _ = g.task_finished(ready)
+        rel, unk = T.graph_finish(ready)
+        assert unk == 0 and rel.tolist() == rel_w
+        done += len(ready); waves += 1
+        ready = rel.tolist()
+    assert done == n and waves > 3 and T.graph_stats()["n_tasks"] == 0
