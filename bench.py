@@ -56,6 +56,74 @@ def cpu_baseline(snap, ticks: int):
 TRAFFIC = {"level_hist": 12_077_923 + 2_250_112, "select_scatter": 11_124_532 + 2_017_088}  # profiles/r01/final/summary.csv (c3, N = 1 M)
 
 
+def dag_churn(cfg, steps: int, seed: int, n_classes: int):
+    """BASELINE config 5 on one GPU: the 1 M-node DAG lives in the device dependency graph (hqtick_graph_*); per tick the tasks handed out by
+    the previous tick finish (their consumers are released into the resident ready set on the device), 10 % of the workers are lost (their
+    tasks return to the ready set) and replaced, then hqtick_run_resident + hqtick_ready_consume_last."""
+    from hyperqueue_amd import workloads
+    from hyperqueue_amd.tick import Tick
+
+    n = 1_000_000
+    ids, prio, rq, off, dep = workloads.make_dag(n, seed=seed)
+    rq = (rq % np.uint32(n_classes)).astype(np.uint32)
+    t = Tick(cfg)
+    t.upload_ready(np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    a = time.perf_counter(); ready0 = t.graph_add_tasks(ids, prio, rq, (off, dep)); t_add = time.perf_counter() - a
+    add_kernel_us = t.graph_stats()["last_kernel_us"]
+    drv = workloads.DagChurn(n_workers=1024, churn=0.10, seed=seed)
+    W = 1024
+    rows = []
+    for step in range(steps + 2):
+        snap_now = drv.snapshot()  # keeps the arrays `sc` points into alive
+        sc = snap_now.to_c()
+        a = time.perf_counter(); res = t.tick_raw(sc, resident=True)
+        b = time.perf_counter(); t.ready_consume_last()
+        c = time.perf_counter()
+        rec_off = np.ctypeslib.as_array(res.rec_off, shape=(W + 1,)).astype(np.int64)
+        rec_task = np.ctypeslib.as_array(res.rec_task, shape=(int(rec_off[W]),)).copy()
+        finished, returned = drv.after_tick(rec_off, rec_task)
+        idx = (returned & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1
+        d = time.perf_counter()
+        if len(returned):
+            t.ready_add(returned, prio[idx], rq[idx])
+        e = time.perf_counter()
+        rel, unk = t.graph_finish(finished) if len(finished) else (np.zeros(0, np.uint64), 0)
+        f = time.perf_counter()
+        st = t.graph_stats()
+        rows.append(dict(tick=b - a, consume=c - b, readd=e - d, finish=f - e, n_out=len(rec_task), n_fin=len(finished), n_ret=len(returned), n_rel=len(rel),
+                         finish_kernel_us=st["last_kernel_us"], ready=int(t.ready_count()), status=int(res.status), optimal=int(res.is_optimal)))
+        if len(rec_task) == 0:
+            break
+    st = t.graph_stats()
+    t.close()
+    use = rows[2:] if len(rows) > 4 else rows
+    med = lambda k: float(np.median([r[k] for r in use]))
+    step_s = np.asarray([r["tick"] + r["consume"] + r["readd"] + r["finish"] for r in use])
+    handed = np.asarray([r["n_out"] for r in use])
+    # algorithmic bytes of the release kernel per step (DESIGN.md §8b): per finished task id 8 + hash bucket 12 + state 4 + gen 4 + head 4 + run record 12,
+    # per consumer edge 8 + gen 4 + counter 4, per released task id 8 + output pair 12
+    fin, rel = med("n_fin"), med("n_rel")
+    edges = 3.0 * fin  # mean fan-out = mean fan-in
+    fin_bytes = fin * 44 + edges * 16 + rel * 20
+    ku = med("finish_kernel_us")
+    return {
+        "workload": f"c5: {n}-node random DAG (fan-in ~ Poisson(3) from lower ids, {len(dep)} edges) over the first {n_classes} c3 classes, 1024 workers, 10 % of the workers lost "
+                    "and replaced per tick",
+        "note": "the frontier of this DAG (~50 k ready tasks) is below the cluster's capacity, so no batch is saturated and the placement model couples all workers through the "
+                "batch-size rows (host MILP; DESIGN.md §8b).  With all 8 c3 classes that model (8192 x 3080) runs into the 5 s time limit in HiGHS and in this solver alike, which is "
+                "why the default loop uses fewer classes: it measures the graph + tick pipeline, not the time limit",
+        "graph_add_ms": 1e3 * t_add, "graph_add_link_kernels_us": add_kernel_us, "initially_ready": int(len(ready0)),
+        "graph_bytes_hbm": int(st["bytes_hbm"]),
+        "steps": len(use), "p50_step_ms": 1e3 * float(np.median(step_s)), "tasks_handed_out_per_step": int(np.median(handed)),
+        "tasks_per_s": float(handed.sum() / step_s.sum()),
+        "p50_tick_us": 1e6 * med("tick"), "p50_consume_us": 1e6 * med("consume"), "p50_return_lost_workers_tasks_us": 1e6 * med("readd"),
+        "p50_graph_finish_us": 1e6 * med("finish"), "p50_finished_per_step": int(fin), "p50_released_per_step": int(rel), "p50_returned_per_step": int(med("n_ret")),
+        "finish_kernel": {"avg_us": ku, "algorithmic_bytes": int(fin_bytes), "GBps": fin_bytes / (ku * 1e-6) / 1e9 if ku > 0 else None,
+                          "note": "dependent random 4-16 B accesses (hash probe -> slot -> run -> edge -> counter RMW): latency-bound, not a streaming kernel"},
+        "ready_set_p50": int(med("ready")), "all_ticks_optimal": bool(all(r["optimal"] for r in use)),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +134,8 @@ def main():
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
     ap.add_argument("--priority-ticks", type=int, default=1, help="ticks of the three-priority-level variant c3p (0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=20, help="steps of the steady-state (delta-updated resident set) measurement, 0 = skip")
+    ap.add_argument("--dag-steps", type=int, default=12, help="ticks of the config-5 loop (1 M-node DAG in the device graph + 10 %% worker churn per tick), 0 = skip")
+    ap.add_argument("--dag-classes", type=int, default=2, help="request classes of the config-5 DAG (first N of the c3 classes; 8 = all, every tick then runs into the MILP time limit)")
     ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
     ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
@@ -263,6 +333,8 @@ def main():
             "delta_bytes_host_to_device_per_step": per_step * 20,
         }
         ts.close()
+    if world == 1 and not args.force_sharded and args.workload == "c3" and args.dag_steps > 0:
+        out["dag_churn"] = dag_churn(cfg, args.dag_steps, args.seed, args.dag_classes)
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.priority_ticks > 0:
         # the same size with three user-priority levels (SURVEY §8d's C3 mix, 80/15/5 %): priority cuts couple every worker, the model is one
         # 8 k-column x 22 k-row component and the tick is dominated by the host-side exact solve (reported, not the headline: BASELINE.json's

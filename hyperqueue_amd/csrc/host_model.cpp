@@ -246,10 +246,14 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     // (the optimal set of the full model is the product of the block-optimal sets cut by the size rows; the per-block lexicographic
     // minima form the lexicographic minimum of the product, hence of any subset that contains it).  If a size row is violated the
     // general path below takes over.
+    struct SeqStart { uint32_t w, batch; uint8_t variant; uint32_t count; };
+    std::vector<SeqStart> seq_start;  // starting point handed to the coupled solve when the lazy size rows fail
     bool separable = true;
     for (const TaskBatch &b : batches) if (pb.rq_multi_node(b.rq) || !b.cuts.empty() || b.is_blocker) separable = false;
     if (separable && !batches.empty()) {
         struct ColRef { uint32_t batch; uint8_t variant; };
+        std::vector<hqmilp::Model> class_model;
+        std::vector<uint8_t> class_has_flag;
         std::vector<std::vector<ColRef>> class_cols;
         std::vector<std::vector<uint32_t>> class_x;
         std::unordered_map<std::string, uint32_t> class_of_sig;
@@ -333,8 +337,10 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             if (!sol.optimal) out.is_optimal = false;
             std::vector<uint32_t> xs(cols.size());
             for (size_t c = 0; c < cols.size(); c++) xs[c] = (uint32_t)std::round(sol.x[c]);
+            { uint8_t fl = 0; for (auto &cr : cols) if (cr.batch == UINT32_MAX) fl = 1; class_has_flag.push_back(fl); }
             class_cols.push_back(std::move(cols));
             class_x.push_back(std::move(xs));
+            class_model.push_back(std::move(m));
         }
         // per class: count of every (batch, variant)
         const size_t nb = batches.size();
@@ -353,7 +359,51 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 for (uint32_t w : solver_workers) for (uint32_t v = voff[b]; v < voff[b + 1]; v++) placed += cls_count[wclass[w]][v];
                 if (placed > batches[b].size) sizes_hold = false;
             }
-            if (!sizes_hold) separable = false;
+            if (!sizes_hold) {
+                separable = false;
+                // Starting point for the coupled model below: workers in objective order (the (W - idx)/W factor prefers the low indices), each one
+                // takes the optimum of ITS block given what the earlier ones left of every unsaturated batch.  Not optimal in general, but it fills
+                // the early workers exactly — the part the LP-rounding heuristics of the solver are weakest at.
+                bool usable = true;
+                for (uint8_t fl : class_has_flag) if (fl) usable = false;  // min_utilization flags are not part of the hint
+                if (usable) {
+                    std::vector<double> rem(nb);
+                    for (size_t b = 0; b < nb; b++) rem[b] = batches[b].limit_reached ? 1e18 : (double)batches[b].size;
+                    std::vector<std::vector<uint32_t>> last_x(class_cols.size());  // last solution per class: still optimal while it fits into `rem`
+                    for (uint32_t w : solver_workers) {
+                        const uint32_t c = wclass[w];
+                        const auto &cols = class_cols[c];
+                        bool reuse = !last_x[c].empty();
+                        if (reuse) {
+                            std::vector<double> need(nb, 0.0);
+                            for (size_t k = 0; k < cols.size(); k++) need[cols[k].batch] += last_x[c][k];
+                            for (size_t b = 0; b < nb; b++) if (need[b] > rem[b]) reuse = false;
+                        }
+                        if (!reuse) {
+                            hqmilp::Model bm = class_model[c];
+                            for (size_t b = 0; b < nb; b++) {
+                                if (rem[b] >= 1e17) continue;
+                                bool any = false;
+                                for (size_t k = 0; k < cols.size(); k++) if (cols[k].batch == b) any = true;
+                                if (!any) continue;
+                                bm.begin_row(hqmilp::ROW_MAX, rem[b]);
+                                for (size_t k = 0; k < cols.size(); k++) if (cols[k].batch == b) bm.term((int)k, 1.0);
+                                bm.end_row();
+                            }
+                            hqmilp::Result bs = hqmilp::solve(bm, std::min(0.05, pb.time_limit_s), false);
+                            if (!bs.feasible) { seq_start.clear(); usable = false; break; }
+                            last_x[c].assign(cols.size(), 0);
+                            for (size_t k = 0; k < cols.size(); k++) last_x[c][k] = (uint32_t)std::round(bs.x[k]);
+                        }
+                        for (size_t k = 0; k < cols.size(); k++) {
+                            const uint32_t cnt = last_x[c][k];
+                            if (!cnt) continue;
+                            seq_start.push_back({w, cols[k].batch, cols[k].variant, cnt});
+                            if (rem[cols[k].batch] < 1e17) rem[cols[k].batch] -= cnt;
+                        }
+                    }
+                }
+            }
         }
         if (separable) {
             std::vector<uint64_t> key_hash; std::vector<std::pair<uint32_t, uint8_t>> key_list; std::vector<std::vector<std::pair<uint32_t, uint32_t>>> key_counts;
@@ -538,6 +588,14 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         }
     }
 
+    if (!seq_start.empty()) {
+        m.start.assign(m.ncols(), 0.0);
+        for (const SeqStart &ss : seq_start) {
+            auto it = place.find({ss.w, batches[ss.batch].rq, ss.variant});
+            if (it == place.end()) { m.start.clear(); break; }
+            m.start[it->second] = ss.count;
+        }
+    }
     hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true);  // :432-438
     out.milp_nodes = sol.nodes; out.milp_cols = m.ncols(); out.milp_rows = m.nrows(); out.milp_components = sol.n_components;
     if (!sol.feasible) return out;

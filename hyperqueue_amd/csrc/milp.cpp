@@ -262,6 +262,34 @@ struct CompSolver {
         greedy_from(std::move(x));
     }
 
+    // Objective lattice: if every cost is an integer multiple of q (the tick's costs are amount/pool x weight x (W - idx)/W, rationals with a
+    // common denominator), an integral point better than the incumbent is better by at least q: nodes whose LP bound is below best + q hold none.
+    double quantum = 0.0;
+    void find_quantum() {
+        double cmaxv = 0.0; for (int j = 0; j < n; j++) cmaxv = std::max(cmaxv, std::fabs(c[j]));
+        if (cmaxv == 0.0) return;
+        const double tol = 1e-10 * cmaxv;
+        double g = 0.0;
+        for (int j = 0; j < n; j++) {
+            double a = std::fabs(c[j]), b = g;
+            if (a < tol) continue;
+            if (b == 0.0) { g = a; continue; }
+            if (a < b) std::swap(a, b);
+            for (int it = 0; it < 200 && b > tol; it++) { double r = std::fmod(a, b); if (b - r < tol) r = 0.0; a = b; b = r; }
+            g = a;
+            if (g < 1e-6 * cmaxv) return;  // no useful lattice
+        }
+        if (g <= 0.0) return;
+        for (int j = 0; j < n; j++) { double k = c[j] / g; if (std::fabs(k - std::round(k)) > 1e-7) return; }
+        quantum = g;
+    }
+    // a node with LP bound z can be dropped when no integral point in it beats the incumbent
+    bool cannot_improve(double z) const {
+        if (!have) return false;
+        if (z <= best + 1e-12 * std::fabs(best)) return true;
+        return quantum > 0.0 && z < best + quantum * (1.0 - 1e-6);
+    }
+
     static int pick_fractional(const Tab &t) {
         int j = -1; double bd = INT_TOL;
         for (int k = 0; k < t.n; k++) {
@@ -278,11 +306,11 @@ struct CompSolver {
         int s = solve_counted(t);
         if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return; }
         double z = t.objective();
-        if (have && z <= best + 1e-12 * std::fabs(best)) return;
+        if (cannot_improve(z)) return;
         int j = pick_fractional(t);
         if (j >= 0 && (nodes == 1 || (nodes & 63) == 0)) {  // root and every 64th node: try to close the gap from this LP point
             round_and_repair(t);
-            if (have && z <= best + 1e-12 * std::fabs(best)) return;
+            if (cannot_improve(z)) return;
         }
         if (j < 0) {
             have = true; bx.assign(t.x.begin(), t.x.begin() + n);
@@ -323,6 +351,7 @@ struct CompSolver {
     int run(bool canonical, std::vector<double> &xout) {
         Tab root; root.init(&R, c, lb, ub); root.deadline = deadline;
         greedy_from(lb);
+        find_quantum();
         dfs_opt(root);
         lp_iters += root.iters;
         if (!have) return 0;
@@ -484,7 +513,22 @@ Result solve(const Model &mdl, double time_limit_s, bool canonical) {
     // ---- a feasible point for the whole model, before any LP: seeds every component's search and is the answer for components the
     // dense method cannot take ----
     std::vector<double> hx;
-    const bool have_hx = sparse_greedy(mdl, ub, hx);
+    bool have_hx = sparse_greedy(mdl, ub, hx);
+    if ((int)mdl.start.size() == n) {  // caller's starting point: taken if feasible and better
+        bool ok = true; double zs = 0.0, zh = 0.0;
+        for (int j = 0; j < n && ok; j++) { double v = mdl.start[j]; if (v < -1e-9 || v > ub[j] + 1e-9 || std::fabs(v - std::round(v)) > 1e-9) ok = false; zs += mdl.obj[j] * v; }
+        for (int i = 0; i < m && ok; i++) {
+            double a = 0.0, sc = 0.0;
+            for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) { a += mdl.rcoef[k] * mdl.start[mdl.rcol[k]]; sc = std::max(sc, std::fabs(mdl.rcoef[k])); }
+            const double tol = 1e-9 * std::max(1.0, sc);
+            if (mdl.rtype[i] != ROW_MIN && a > mdl.rhs[i] + tol) ok = false;
+            if (mdl.rtype[i] != ROW_MAX && a < mdl.rhs[i] - tol) ok = false;
+        }
+        if (ok) {
+            if (have_hx) for (int j = 0; j < n; j++) zh += mdl.obj[j] * hx[j];
+            if (!have_hx || zs > zh) { hx = mdl.start; have_hx = true; }
+        }
+    }
 
     // ---- connected components ----
     DSU dsu(n);

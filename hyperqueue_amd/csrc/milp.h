@@ -31,6 +31,7 @@ struct Model {
     std::vector<int> roff{0};
     std::vector<int> rcol;
     std::vector<double> rcoef;
+    std::vector<double> start;  // optional integral starting point (ncols values); used as incumbent if it satisfies every row
     int ncols() const { return (int)obj.size(); }
     int nrows() const { return (int)rhs.size(); }
     int add_col(double w, uint8_t k) {

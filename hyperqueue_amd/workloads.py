@@ -119,6 +119,49 @@ def make_dag(n: int = 1_000_000, seed: int = 0, mean_fan_in: float = 3.0):
     return ids, prio, rq, off, ids[dep]
 
 
+class DagChurn:
+    """Driver of BASELINE config 5 (DAG + 10 % worker churn per tick), independent of the backend that ticks.
+
+    Between two ticks every task the last tick handed out (assigned or prefilled) finishes — the `sleep 0` model of
+    benchmarks/experiment-per-task-overhead.py — except the tasks on the workers that are lost in between: those go back to the ready
+    queues (on_remove_worker, reactor.rs:64-186) and the lost workers are replaced by fresh ones (new, larger ids, same resources).
+    """
+
+    def __init__(self, n_workers: int = 1024, churn: float = 0.10, seed: int = 0):
+        w = _uniform_workers(n_workers, 1, [128, 8, 512])
+        self.kw = dict(w)
+        self.requests = [[_variant(c[0])] for c in C3_CLASSES]
+        self.worker_id = np.asarray(w["worker_id"], np.uint32).copy()
+        self.next_worker = int(self.worker_id.max()) + 1
+        self.n_lost = int(round(churn * n_workers))
+        self.seed, self.step = seed, 0
+
+    def snapshot(self, task_id=None, task_priority=None, task_rq=None) -> abi.Snapshot:
+        """the current workers; without task columns the ready set is the resident one"""
+        kw = dict(self.kw); kw["worker_id"] = self.worker_id.copy()
+        z = np.zeros(0, np.uint64)
+        return abi.Snapshot(requests=self.requests, task_id=z if task_id is None else np.asarray(task_id, np.uint64),
+                            task_priority=z if task_priority is None else np.asarray(task_priority, np.uint64),
+                            task_rq=np.zeros(0, np.uint32) if task_rq is None else np.asarray(task_rq, np.uint32), **kw)
+
+    def after_tick(self, rec_off: np.ndarray, rec_task: np.ndarray):
+        """-> (finished ids, ids returned to the ready queues ascending); replaces the lost workers"""
+        W = len(self.worker_id)
+        self.step += 1
+        r = splitmix64_stream(self.seed * 1_000_003 + self.step, W)
+        lost = np.sort(np.argsort(r, kind="stable")[: self.n_lost])
+        on_lost = np.zeros(len(rec_task), bool)
+        for w in lost:
+            on_lost[int(rec_off[w]) : int(rec_off[w + 1])] = True
+        returned = np.sort(rec_task[on_lost])
+        finished = rec_task[~on_lost]
+        keep = np.ones(W, bool); keep[lost] = False
+        fresh = np.arange(self.next_worker, self.next_worker + len(lost), dtype=np.uint32)
+        self.next_worker += len(lost)
+        self.worker_id = np.concatenate([self.worker_id[keep], fresh])
+        return finished, returned
+
+
 def shard_workers(snap: abi.Snapshot, rank: int, world: int) -> abi.Snapshot:
     """Worker shard of one rank: workers whose FxHash(worker_id) mod world == rank (north_star: hash-partitioned workers).
     Every rank keeps the whole ready set and request table."""
