@@ -248,6 +248,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     // general path below takes over.
     struct SeqStart { uint32_t w, batch; uint8_t variant; uint32_t count; };
     std::vector<SeqStart> seq_start;  // starting point handed to the coupled solve when the lazy size rows fail
+    std::vector<uint8_t> worker_off;  // workers that are empty in EVERY optimum of the coupled model (see below): their columns are not created
     bool separable = true;
     for (const TaskBatch &b : batches) if (pb.rq_multi_node(b.rq) || !b.cuts.empty() || b.is_blocker) separable = false;
     if (separable && !batches.empty()) {
@@ -361,6 +362,57 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             }
             if (!sizes_hold) {
                 separable = false;
+                // Workers that no optimum uses.  Without cuts, blockers and multi-node batches two workers of one class (same free, total, eligibility, no
+                // min_utilization) can exchange their whole contents, and a single task can move to any worker that has room for it; both moves keep every
+                // row satisfied and, as the objective factor (W - idx)/W falls strictly with the index while every cost is positive, moving towards the
+                // lower index strictly improves.  So in EVERY optimal solution (a) the non-empty workers of a class are its first k ones, (b) no task of the
+                // k-th one fits into the room left on an earlier one: each earlier worker uses more than free_e - dmax_e of some resource e (dmax_e = the
+                // largest single request), and at most (D_e - 1) / (free_e - dmax_e) workers can do that with a total demand of D_e.  Hence
+                //     k <= min(#tasks, 1 + sum_e (D_e - 1) / (free_e - dmax_e)),
+                // and dropping the class's later workers removes no optimal solution: the canonical optimum is unchanged.  This is what keeps "a few ready
+                // tasks, a thousand idle workers" — the everyday case between bursts — a small model.
+                worker_off.assign(ws.n, 0);
+                {
+                    std::vector<uint32_t> n_in_class(class_cols.size(), 0), seen(class_cols.size(), 0), keep(class_cols.size(), UINT32_MAX);
+                    for (uint32_t w : solver_workers) n_in_class[wclass[w]]++;
+                    std::vector<uint32_t> rep(class_cols.size(), UINT32_MAX);
+                    for (uint32_t w : solver_workers) if (rep[wclass[w]] == UINT32_MAX) rep[wclass[w]] = w;
+                    for (size_t c = 0; c < class_cols.size(); c++) {
+                        if (class_has_flag[c] || rep[c] == UINT32_MAX) continue;
+                        const uint64_t *fre = ws.free_ + (size_t)rep[c] * R, *tot = ws.total + (size_t)rep[c] * R;
+                        bool ok = true;
+                        uint64_t n_tasks = 0;
+                        std::vector<uint64_t> dmax(R, 0);
+                        std::vector<long double> D(R, 0.0L);
+                        std::vector<uint8_t> batch_seen(nb, 0);
+                        std::vector<std::vector<uint64_t>> bmax(nb, std::vector<uint64_t>(R, 0));  // per batch: largest amount over its eligible variants
+                        for (const ColRef &cr : class_cols[c]) {
+                            if (cr.batch == UINT32_MAX) { ok = false; break; }
+                            const uint32_t slot = pb.rqs[batches[cr.batch].rq].first_variant + cr.variant;
+                            const VariantView &vv = pb.variants[slot];
+                            if (class_model[c].obj.empty()) { ok = false; break; }
+                            if (!batch_seen[cr.batch]) { batch_seen[cr.batch] = 1; n_tasks += batches[cr.batch].size; }
+                            for (uint32_t e = 0; e < vv.n_entries; e++) {
+                                const uint64_t a = vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e];
+                                bmax[cr.batch][vv.res[e]] = std::max(bmax[cr.batch][vv.res[e]], a);
+                                dmax[vv.res[e]] = std::max(dmax[vv.res[e]], a);
+                            }
+                        }
+                        for (double cj : class_model[c].obj) if (!(cj > 0.0)) ok = false;  // the exchange argument needs strictly positive costs
+                        if (!ok) continue;
+                        for (size_t b = 0; b < nb; b++) if (batch_seen[b]) for (uint32_t r = 0; r < R; r++) D[r] += (long double)bmax[b][r] * (long double)batches[b].size;
+                        long double k = 1.0L; bool bounded = true;
+                        for (uint32_t r = 0; r < R && bounded; r++) {
+                            if (dmax[r] == 0 || D[r] <= 0.0L) continue;
+                            if (fre[r] == HQ_AMOUNT_MAX || fre[r] <= dmax[r]) { bounded = false; break; }
+                            k += std::floor((D[r] - 1.0L) / (long double)(fre[r] - dmax[r]));
+                        }
+                        uint64_t kk = n_tasks;
+                        if (bounded && k < (long double)kk) kk = (uint64_t)k;
+                        if (kk < n_in_class[c]) keep[c] = (uint32_t)kk;
+                    }
+                    for (uint32_t w : solver_workers) { const uint32_t c = wclass[w]; if (seen[c]++ >= keep[c]) worker_off[w] = 1; }
+                }
                 // Starting point for the coupled model below: workers in objective order (the (W - idx)/W factor prefers the low indices), each one
                 // takes the optimum of ITS block given what the earlier ones left of every unsaturated batch.  Not optimal in general, but it fills
                 // the early workers exactly — the part the LP-rounding heuristics of the solver are weakest at.
@@ -450,6 +502,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
 
     for (size_t wi = 0; wi < nw; wi++) {  // :95
         uint32_t w = solver_workers[wi];
+        if (!worker_off.empty() && worker_off[w]) continue;  // empty in every optimum (see the separable section): no columns, no rows
         const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
         cpu_terms.clear();
         double order_factor = (double)(nw - wi);
