@@ -290,11 +290,17 @@ struct CompSolver {
         return quantum > 0.0 && z < best + quantum * (1.0 - 1e-6);
     }
 
+    // Branching column: among the fractional ones the most valuable (largest cost), ties by fractionality.  The tick's objective is
+    // (W - idx)/W x (normalised resources of the request): deciding the expensive placements first — big requests on the low-index workers —
+    // fixes the part of the packing everything else has to fit around, and the up-branch-first dive lands on good incumbents early.  Against
+    // "most fractional" this turns unsaturated multi-class models from time-outs into millisecond proofs at <= 8 workers.
     static int pick_fractional(const Tab &t) {
-        int j = -1; double bd = INT_TOL;
+        int j = -1; double bc = -1.0, bf = 0.0;
         for (int k = 0; k < t.n; k++) {
-            double v = t.x[k], fr = std::fabs(v - std::round(v));
-            if (fr > bd) { bd = fr; j = k; }
+            const double v = t.x[k], fr = std::fabs(v - std::round(v));
+            if (fr <= INT_TOL) continue;
+            const double c = t.cost[k];
+            if (c > bc + 1e-12 || (c > bc - 1e-12 && fr > bf)) { bc = c; bf = fr; j = k; }
         }
         return j;
     }
