@@ -38,9 +38,9 @@ enum ErrBits : uint32_t {
 };
 
 struct Ctl {  // device-resident counters; published to pinned host memory at the end of every operation
+    uint32_t run_top;     // run records in use            } one 8-byte word: k_g_link_alloc bumps both with a single 64-bit atomic
+    uint32_t edge_top;    // edge pool entries in use      }   (live + dead)
     uint32_t free_top;    // entries on the free-slot stack
-    uint32_t run_top;     // run records in use
-    uint32_t edge_top;    // edge pool entries in use (live + dead)
     uint32_t edges_dead;  // edges of producers that have left the graph
     uint32_t n_out;       // entries of the operation's output list (released / removed / ready-now tasks)
     uint32_t n_unknown;   // ids of the operation that are not in the graph

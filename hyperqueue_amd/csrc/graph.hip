@@ -10,7 +10,6 @@ namespace hqgraph {
 
 namespace {
 
-constexpr uint32_t BIG_RUN = 8192;     // runs longer than this are released by the whole grid (hub tasks)
 constexpr uint32_t BIG_GRID = 1024;
 constexpr uint32_t SORT_CH = 4096;     // elements per workgroup in the LDS stages of the sort: 256 threads x 16, 48 KB
 constexpr uint32_t BFS_LEVELS_PER_SYNC = 8;
@@ -57,6 +56,11 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want) {
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// sum over the wavefront (every lane must call)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 __device__ __forceinline__ uint32_t new_slot(const View &v, uint32_t i, uint32_t free_top0, uint32_t n_slots0) {
     return i < free_top0 ? v.free_slot[free_top0 - 1u - i] : n_slots0 + (i - free_top0);
 }
@@ -116,12 +120,28 @@ __global__ void __launch_bounds__(256) k_g_link_count(View v, const uint32_t *__
 }
 
 __global__ void __launch_bounds__(256) k_g_link_alloc(View v, uint32_t E, const uint32_t *__restrict__ edge_ds, const uint32_t *__restrict__ edge_rank, uint32_t cap_edges) {
-    uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= E || v.ctl->err) return;
-    const uint32_t ds = edge_ds[e];
-    if (ds == NONE || edge_rank[e] != 0) return;
-    const uint32_t len = v.tmp_cnt[ds];
-    const uint32_t r = atomicAdd(&v.ctl->run_top, 1u), base = atomicAdd(&v.ctl->edge_top, len);
+    __shared__ uint32_t w_runs[4], w_len[4], b_run[4], b_edge[4];
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t ds = NONE, len = 0;
+    if (e < E && !v.ctl->err) { ds = edge_ds[e]; if (ds != NONE && edge_rank[e] == 0) len = v.tmp_cnt[ds]; else ds = NONE; }
+    // one run record and `len` edge slots per producer of the batch.  Both pool counters sit in one 8-byte word and are bumped by ONE 64-bit
+    // atomic per workgroup: same-address atomics serialise at ~10 ns each, one per wavefront and counter was 1 ms at 3 M edges
+    const uint64_t m = __ballot(ds != NONE);
+    const uint32_t my_run = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    uint32_t incl = len;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
+    if (lane == 63) { w_runs[wid] = (uint32_t)__popcll(m); w_len[wid] = incl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tr = w_runs[0] + w_runs[1] + w_runs[2] + w_runs[3], tl = w_len[0] + w_len[1] + w_len[2] + w_len[3];
+        unsigned long long old = 0;
+        if (tr) old = atomicAdd(reinterpret_cast<unsigned long long *>(&v.ctl->run_top), ((unsigned long long)tl << 32) | tr);
+        uint32_t br = (uint32_t)old, be = (uint32_t)(old >> 32);
+        for (int w = 0; w < 4; w++) { b_run[w] = br; b_edge[w] = be; br += w_runs[w]; be += w_len[w]; }
+    }
+    __syncthreads();
+    if (ds == NONE) return;
+    const uint32_t r = b_run[wid] + my_run, base = b_edge[wid] + incl - len;
     if (base + len > cap_edges || r >= cap_edges) { atomicOr(&v.ctl->err, (uint32_t)ERR_CAPACITY); v.tmp_base[ds] = NONE; return; }
     v.run_off[r] = base; v.run_len[r] = len; v.run_next[r] = v.head[ds]; v.head[ds] = r;
     v.tmp_base[ds] = base;
@@ -144,11 +164,20 @@ __global__ void __launch_bounds__(256) k_g_link_fill(View v, const uint32_t *__r
 }
 
 __global__ void __launch_bounds__(256) k_g_collect_ready(View v, uint32_t n, uint32_t free_top0, uint32_t n_slots0, uint64_t *__restrict__ okey, uint32_t *__restrict__ oval) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint32_t wcnt[4], wbase[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     bool want = false; uint32_t sl = 0;
     if (i < n && !v.ctl->err) { sl = new_slot(v, i, free_top0, n_slots0); want = v.unfinished[sl] == 0; }
-    uint32_t pos = wave_append(&v.ctl->n_out, want);
-    if (want) { okey[pos] = v.id[sl]; oval[pos] = sl; }
+    const uint64_t m = __ballot(want);
+    if (lane == 0) wcnt[wid] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic per workgroup
+        const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        uint32_t b = tot ? atomicAdd(&v.ctl->n_out, tot) : 0;
+        for (int w = 0; w < 4; w++) { wbase[w] = b; b += wcnt[w]; }
+    }
+    __syncthreads();
+    if (want) { const uint32_t pos = wbase[wid] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); okey[pos] = v.id[sl]; oval[pos] = sl; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- finish
@@ -167,15 +196,13 @@ __device__ __forceinline__ void release_range(const View &v, uint32_t off, uint3
     }
 }
 
-// one wavefront per finished task  (task_finished, reactor.rs:510-590)
-__global__ void __launch_bounds__(256) k_g_finish(View v, const uint64_t *__restrict__ ids, uint32_t n, uint64_t *__restrict__ okey, uint32_t *__restrict__ oval,
-                                                  uint2 *__restrict__ big, uint32_t big_cap) {
-    const uint32_t w = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (w >= n) return;
-    uint32_t slot = NONE;
-    if (lane == 0) {
-        const uint64_t id = ids[w];
-        uint32_t pos = ht_find_pos(v, id);
+// task_finished, reactor.rs:510-590, in three steps.
+// (1) one thread per finished id: find it, claim it (exactly once even if listed twice), drop it from the table, recycle its slot
+__global__ void __launch_bounds__(256) k_g_finish_claim(View v, const uint64_t *__restrict__ ids, uint32_t n, uint32_t *__restrict__ slot_of) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t slot = NONE; bool unknown = false;
+    if (i < n) {
+        uint32_t pos = ht_find_pos(v, ids[i]);
         if (pos != NONE) {
             const uint32_t sl = v.ht_val[pos];
             const uint32_t old = atomicExch(&v.unfinished[sl], ST_FREE);
@@ -183,30 +210,55 @@ __global__ void __launch_bounds__(256) k_g_finish(View v, const uint64_t *__rest
             else {
                 if (old != 0) atomicOr(&v.ctl->err, (uint32_t)ERR_NOT_READY);
                 v.ht_key[pos] = HT_TOMB; v.gen[sl] += 1;
-                v.free_slot[atomicAdd(&v.ctl->free_top, 1u)] = sl;
                 slot = sl;
             }
         }
-        if (pos == NONE) atomicAdd(&v.ctl->n_unknown, 1u);
+        unknown = pos == NONE;
     }
-    slot = __shfl(slot, 0);
-    if (slot == NONE) return;
-    uint32_t r = v.head[slot], dead = 0;
-    while (r != NONE) {
-        const uint32_t off = v.run_off[r], len = v.run_len[r];
-        dead += len;
-        if (len > BIG_RUN) {
-            if (lane == 0) { uint32_t b = atomicAdd(&v.ctl->n_big, 1u); if (b < big_cap) big[b] = make_uint2(off, len); else atomicOr(&v.ctl->err, (uint32_t)ERR_CAPACITY); }
-        } else release_range(v, off, len, lane, 64, okey, oval);
-        r = v.run_next[r];
-    }
-    if (lane == 0) { v.head[slot] = NONE; atomicAdd(&v.ctl->edges_dead, dead); }
+    const uint32_t fp = wave_append(&v.ctl->free_top, slot != NONE);
+    if (slot != NONE) v.free_slot[fp] = slot;
+    const uint64_t um = __ballot(unknown);
+    if (um && __lane_id() == (uint32_t)__ffsll((long long)um) - 1u) atomicAdd(&v.ctl->n_unknown, (uint32_t)__popcll(um));
+    if (i < n) slot_of[i] = slot;
 }
 
-// hub tasks: each long run is released by the whole grid
+constexpr uint32_t SHORT_RUN = 4;      // runs up to this length are released by the thread that owns the finished task
+constexpr uint32_t RUN_CHUNK = 4096;   // longer runs are cut into chunks of this many edges, one wavefront each
+
+// (2) one thread per finished task: decrement the consumers of its short runs, defer the long ones
+__global__ void __launch_bounds__(256) k_g_finish_release(View v, const uint32_t *__restrict__ slot_of, uint32_t n, uint64_t *__restrict__ okey, uint32_t *__restrict__ oval,
+                                                          uint2 *__restrict__ big, uint32_t big_cap) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t dead = 0;
+    const uint32_t slot = i < n ? slot_of[i] : NONE;
+    if (slot != NONE) {
+        for (uint32_t r = v.head[slot]; r != NONE; r = v.run_next[r]) {
+            const uint32_t off = v.run_off[r], len = v.run_len[r];
+            dead += len;
+            if (len > SHORT_RUN) {
+                const uint32_t nch = (len + RUN_CHUNK - 1) / RUN_CHUNK, b = atomicAdd(&v.ctl->n_big, nch);
+                if (b + nch <= big_cap) for (uint32_t c = 0; c < nch; c++) big[b + c] = make_uint2(off + c * RUN_CHUNK, min(RUN_CHUNK, len - c * RUN_CHUNK));
+                else atomicOr(&v.ctl->err, (uint32_t)ERR_CAPACITY);
+                continue;
+            }
+            for (uint32_t e = 0; e < len; e++) {  // divergent trip counts: the ballot inside wave_append covers the lanes that are here
+                const uint2 ed = v.edge[off + e];
+                bool rel = false;
+                if (v.gen[ed.x] == ed.y) rel = atomicSub(&v.unfinished[ed.x], 1u) == 1u;   // Task::decrease_unfinished_deps  task.rs:207-216
+                const uint32_t pos = wave_append(&v.ctl->n_out, rel);
+                if (rel) { okey[pos] = v.id[ed.x]; oval[pos] = ed.x; }
+            }
+        }
+        v.head[slot] = NONE;
+    }
+    dead = wave_sum(dead);
+    if (dead && __lane_id() == 0) atomicAdd(&v.ctl->edges_dead, dead);
+}
+
+// (3) hub tasks: one wavefront per chunk of a long run
 __global__ void __launch_bounds__(256) k_g_big_runs(View v, const uint2 *__restrict__ big, uint64_t *__restrict__ okey, uint32_t *__restrict__ oval) {
-    const uint32_t nb = v.ctl->n_big;
-    for (uint32_t b = 0; b < nb; b++) release_range(v, big[b].x, big[b].y, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, okey, oval);
+    const uint32_t nb = v.ctl->n_big, lane = threadIdx.x & 63, n_waves = gridDim.x * 4;
+    for (uint32_t b = (blockIdx.x * 256 + threadIdx.x) >> 6; b < nb; b += n_waves) release_range(v, big[b].x, big[b].y, lane, 64, okey, oval);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- remove
@@ -593,16 +645,20 @@ int Graph::finish(uint64_t n, const uint64_t *id, hipStream_t s) {
     View v = view();
     Ctl *c = d_ctl.as<Ctl>();
     G_HIP(hipMemsetAsync(&c->n_out, 0, 16, s));  // n_out, n_unknown, err, n_big
+    // deferred-run list: one entry per started RUN_CHUNK of a run longer than SHORT_RUN
+    const uint64_t big_cap = (uint64_t)edge_top / RUN_CHUNK + (uint64_t)edge_top / SHORT_RUN + 64;
+    if (!d_big.ensure(big_cap * sizeof(uint2)) || !d_erk.ensure(n * 4 + 64)) return fail(HQTICK_E_DEVICE, "hipMalloc graph staging");
     G_HIP(hipEventRecord(ev0, s));
-    hipLaunchKernelGGL(k_g_finish, dim3(nblk(n * 64)), dim3(256), 0, s, v, d_stage.as<uint64_t>(), (uint32_t)n, d_okey.as<uint64_t>(), d_oval.as<uint32_t>(), d_big.as<uint2>(), 65536u);
-    G_HIP(hipEventRecord(ev1, s));
+    hipLaunchKernelGGL(k_g_finish_claim, dim3(nblk(n)), dim3(256), 0, s, v, d_stage.as<uint64_t>(), (uint32_t)n, d_erk.as<uint32_t>());
+    hipLaunchKernelGGL(k_g_finish_release, dim3(nblk(n)), dim3(256), 0, s, v, d_erk.as<uint32_t>(), (uint32_t)n, d_okey.as<uint64_t>(), d_oval.as<uint32_t>(), d_big.as<uint2>(), (uint32_t)big_cap);
     hipLaunchKernelGGL(k_g_big_runs, dim3(BIG_GRID), dim3(256), 0, s, v, d_big.as<uint2>(), d_okey.as<uint64_t>(), d_oval.as<uint32_t>());
+    G_HIP(hipEventRecord(ev1, s));
     G_HIP(hipGetLastError());
     if (int rc = finish_output(s, true)) return rc;
     const uint32_t e = h_ctl.as<Ctl>()->err;
     const uint64_t gone = n - n_unknown_;
     n_live_ -= gone;
-    if (e & ERR_CAPACITY) return fail(HQTICK_E_CAPACITY, "dependency graph: more than 65536 hub runs in one batch");
+    if (e & ERR_CAPACITY) return fail(HQTICK_E_CAPACITY, "dependency graph: deferred-run list overflow");
     if (e & ERR_NOT_READY) return fail(HQTICK_E_INVALID, "hqtick_graph_finish: a finished task still had unfinished dependencies");
     return (int)n_out_;
 }
