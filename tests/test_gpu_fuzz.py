@@ -167,3 +167,62 @@ def test_fuzz_prefill_disposal(seed):
                 for t in rt:
                     e.retract_response(t.worker, [t.id])
     assert seen_retracting >= 0
+
+
+def build_idle_cluster(seed: int):
+    """Few ready tasks, many identical idle workers, one priority: the unsaturated coupled model with provably empty workers dropped
+    (host_model.cpp, "Workers that no optimum uses") — the oracle solves the FULL model, so a wrong exchange argument shows here."""
+    rng = np.random.default_rng(seed)
+    cfg = abi.make_config(reserve=int(rng.integers(0, 3)), fill_max=int(rng.integers(1, 4)), time_limit_s=30.0)
+    envs = [SchedEnv(cfg), SchedEnv(cfg)]
+    names = ["gpus", "mem"][: int(rng.integers(0, 3))]
+    shapes = []
+    for _ in range(int(rng.integers(1, 4))):
+        b = TB().cpus(int(rng.integers(1, 6)))
+        for ri in range(len(names)):
+            if rng.random() < 0.5:
+                b = b.add_resource(ri + 1, [0.5, 1, 2][int(rng.integers(0, 3))])
+        if rng.random() < 0.2:
+            b = b.weight([0.5, 2.0][int(rng.integers(0, 2))])
+        if rng.random() < 0.2:
+            b = b.next_variant().cpus(int(rng.integers(1, 7)))
+        shapes.append(b)
+    groups = []  # (count, builder): one or two worker classes, interleaved ids
+    for _ in range(int(rng.integers(1, 3))):
+        wb = WB(int(rng.integers(4, 17)))
+        for n in names:
+            if rng.random() < 0.7:
+                wb = wb.res_sum(n, int(rng.integers(1, 5)))
+        groups.append((int(rng.integers(8, 25)), wb))
+    order = [gi for gi, (cnt, _) in enumerate(groups) for _ in range(cnt)]
+    rng.shuffle(order)
+    tasks = [int(rng.integers(0, len(shapes))) for _ in range(int(rng.integers(1, 25)))]
+    for e in envs:
+        for n in names:
+            e.new_named_resource(n)
+        for gi in order:
+            e.new_worker(groups[gi][1])
+        for s in tasks:
+            e.new_task(shapes[s])
+    return cfg, envs
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_idle_cluster(seed):
+    from hyperqueue_amd.tick import Tick
+    from oracle.oracle import Oracle
+
+    cfg, envs = build_idle_cluster(7000 + seed)
+    backends = [Tick(cfg), Oracle(cfg, canonical=True)]
+    for tick_no in range(2):
+        res = [e.schedule(b) for e, b in zip(envs, backends)]
+        if not (res[0].is_optimal and res[1].is_optimal):
+            pytest.skip("a solver hit its limit: nothing to compare")
+        assert_same(res[0], res[1])
+        for e in envs:  # a few tasks finish, the rest keep their workers busy
+            done = 0
+            for t in sorted(e.tasks.values(), key=lambda t: t.id):
+                if t.state == 1 and done < 3:
+                    e.finish_task(t.id, t.worker); done += 1
+            for s in range(3):
+                e.new_task(TB().cpus(1 + (tick_no + s) % 3))
