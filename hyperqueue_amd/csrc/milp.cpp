@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <climits>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -131,12 +132,18 @@ struct Tab {
     // dual simplex over the active rows
     int reoptimise(long max_iters) {
         const int N = width();
+        const long bland_after = 400 + 8L * (ma + 8);  // a re-optimisation normally takes a handful of pivots; far beyond that it is stalling on
+                                                        // degenerate ties: switch to smallest-index choices (Bland), which cannot cycle
         for (long it = 0; it < max_iters; it++) {
-            int r = -1; double best = FEAS_TOL; bool below = false;
+            const bool bland = it > bland_after;
+            int r = -1; double best = FEAS_TOL; bool below = false; int rk = INT32_MAX;
             for (int i = 0; i < ma; i++) {
                 int k = B[i]; double v = x[k];
-                if (v < lb[k] - FEAS_TOL) { double inf = lb[k] - v; if (inf > best) { best = inf; r = i; below = true; } }
-                else if (v > ub[k] + FEAS_TOL) { double inf = v - ub[k]; if (inf > best) { best = inf; r = i; below = false; } }
+                double inf = 0.0; bool bl = false;
+                if (v < lb[k] - FEAS_TOL) { inf = lb[k] - v; bl = true; }
+                else if (v > ub[k] + FEAS_TOL) inf = v - ub[k];
+                else continue;
+                if (bland ? k < rk : inf > best) { best = inf; r = i; below = bl; rk = k; }
             }
             if (r < 0) return LP_OPT;
             int k = B[r];
@@ -152,7 +159,7 @@ struct Tab {
                 else elig = (st[j] == AT_LO && a > PIV_TOL) || (st[j] == AT_UP && a < -PIV_TOL);
                 if (!elig) continue;
                 double ratio = std::fabs(d[j]) / std::fabs(a);
-                if (ratio < bratio - 1e-13 || (ratio <= bratio + 1e-13 && std::fabs(a) > babs)) { bratio = ratio; babs = std::fabs(a); q = j; }
+                if (ratio < bratio - 1e-13 || (!bland && ratio <= bratio + 1e-13 && std::fabs(a) > babs)) { bratio = ratio; babs = std::fabs(a); q = j; }
             }
             if (q < 0) return LP_INFEAS;
             iters++;
@@ -215,6 +222,9 @@ struct CompSolver {
     // incumbent
     bool have = false; double best = -INF; std::vector<double> bx;
     bool canonical_done = true;
+    // search control of phase 1: a plain dive first (good incumbents fast), then — if that does not finish within its node budget — a restart
+    // from the root with strong branching, which proves what the dive found with far fewer nodes
+    bool strong = false, aborted = false; long node_budget = -1;
 
     // Deterministic work budget of the tie-break phase, in tableau element updates (a pivot or a tableau copy touches ma x width of them);
     // the wall clock stays the backstop.  Work, not seconds: every replica of a sharded scheduler must take the same decision here.
@@ -308,7 +318,8 @@ struct CompSolver {
     // phase 1: maximise
     void dfs_opt(Tab &t) {
         nodes++;
-        if (time_up()) return;
+        if (aborted || time_up()) return;
+        if (node_budget >= 0 && nodes > node_budget) { aborted = true; return; }
         int s = solve_counted(t);
         if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return; }
         double z = t.objective();
@@ -324,6 +335,50 @@ struct CompSolver {
             double zz = 0.0; for (int k = 0; k < n; k++) zz += c[k] * bx[k];
             best = zz;
             return;
+        }
+        const int SB = 32;
+        if (strong && have) {
+            // strong branching over the SB most valuable fractional columns: both children are solved, the column whose children lose the most
+            // bound is branched on, and a child that cannot hold anything better fixes the column the other way at once
+            std::vector<std::pair<double, int>> cand;
+            for (int k = 0; k < n; k++) { double fr = std::fabs(t.x[k] - std::round(t.x[k])); if (fr > INT_TOL) cand.push_back({-t.cost[k], k}); }
+            std::sort(cand.begin(), cand.end());
+            if ((int)cand.size() > SB) cand.resize(SB);
+            double best_score = -1.0; int best_k = -1;
+            for (auto &cd : cand) {
+                const int k = cd.second; const double vk = t.x[k];
+                if (std::fabs(vk - std::round(vk)) <= INT_TOL) continue;  // became integral through an earlier fixing
+                double dz[2]; bool dead[2];
+                for (int side = 0; side < 2; side++) {
+                    Tab c = t;
+                    if (side == 0) c.set_lb(k, std::ceil(vk - INT_TOL)); else c.set_ub(k, std::floor(vk + INT_TOL));
+                    int cs = solve_counted(c);
+                    nodes++;
+                    if (cs == LP_LIMIT) { timed_out = true; return; }
+                    dead[side] = cs != LP_OPT || cannot_improve(c.objective());
+                    dz[side] = cs == LP_OPT ? std::max(0.0, z - c.objective()) : 1e9;
+                    if (!dead[side] && pick_fractional(c) < 0) {  // the child's LP optimum is integral: a better incumbent, and this child is finished
+                        bx.assign(c.x.begin(), c.x.begin() + n);
+                        for (auto &v : bx) v = std::round(v);
+                        double zz = 0.0; for (int q = 0; q < n; q++) zz += this->c[q] * bx[q];
+                        best = zz; have = true; dead[side] = true;
+                    }
+                }
+                if (dead[0] && dead[1]) return;  // neither child can improve: the node is done
+                if (dead[0] || dead[1]) {        // one child is empty: tighten the column here and re-solve the node
+                    if (dead[0]) t.set_ub(k, std::floor(vk + INT_TOL)); else t.set_lb(k, std::ceil(vk - INT_TOL));
+                    int cs = solve_counted(t);
+                    if (cs != LP_OPT) { if (cs == LP_LIMIT) timed_out = true; return; }
+                    z = t.objective();
+                    if (cannot_improve(z)) return;
+                    continue;
+                }
+                const double score = std::max(dz[0], 1e-9) * std::max(dz[1], 1e-9);
+                if (score > best_score) { best_score = score; best_k = k; }
+            }
+            const int jj = pick_fractional(t);
+            if (jj < 0) { dfs_opt(t); return; }  // integral after the fixings: let the node handler record it (cheap re-solve)
+            if (best_k >= 0 && best_score > 1e-15 && std::fabs(t.x[best_k] - std::round(t.x[best_k])) > INT_TOL) j = best_k; else j = jj;  // degenerate scores: the static rule
         }
         double v = t.x[j];
         {
@@ -358,7 +413,18 @@ struct CompSolver {
         Tab root; root.init(&R, c, lb, ub); root.deadline = deadline;
         greedy_from(lb);
         find_quantum();
-        dfs_opt(root);
+        // Portfolio over restarts from the root (the incumbent carries over): a plain dive, then strong branching, each with a node budget that
+        // quadruples per pair.  The dive finds incumbents and closes easy trees; strong branching proves plateaus the dive would need millions of
+        // nodes for; neither dominates, and a problem that needs N nodes of its better strategy is done after < 3 N.
+        long budget = std::min<long>(20000, std::max<long>(2000, 1300000 / std::max(1, n)));
+        for (int phase = 0;; phase++) {
+            aborted = false; strong = (phase & 1) != 0; node_budget = nodes + budget;
+            if (phase > 0) { lp_iters += root.iters; root = Tab(); root.init(&R, c, lb, ub); root.deadline = deadline; }
+            dfs_opt(root);
+            if (!aborted || timed_out) break;
+            if (phase & 1) budget *= 4;
+        }
+        aborted = false; strong = false; node_budget = -1;
         lp_iters += root.iters;
         if (!have) return 0;
         xout = bx;
