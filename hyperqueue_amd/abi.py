@@ -11,7 +11,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-HQTICK_ABI_VERSION = 2
+HQTICK_ABI_VERSION = 3
 HQ_AMOUNT_MAX = 0xFFFF_FFFF_FFFF_FFFF
 HQ_FRACTIONS_PER_UNIT = 10_000
 HQ_MAX_TASK_PER_WORKER = 1024
@@ -112,6 +112,7 @@ class ResultC(C.Structure):
     _fields_ = [
         ("status", C.c_int32),
         ("is_optimal", C.c_uint8),
+        ("is_canonical", C.c_uint8),
         ("n_batches", C.c_uint32),
         ("batch_rq", u32p),
         ("batch_size", u32p),
@@ -320,6 +321,7 @@ class Result:
     new_free: np.ndarray  # [W, R]
     times_us: Dict[str, float]
     redirect_kinds: List[int] = field(default_factory=list)
+    is_canonical: bool = True  # hqtick_result.is_canonical: the tie-break phase completed
 
     def assigned(self, w: int) -> List[Tuple[int, int]]:
         return [(t, v) for (t, v, k) in self.records[w] if k == HQ_REC_ASSIGN]
@@ -389,4 +391,4 @@ def parse_result(r: ResultC, n_workers: int, n_resources: int, full: bool = True
     nf = _np(r.new_free, W * n_resources, np.uint64).reshape(W, n_resources) if r.new_free else np.zeros((W, n_resources), np.uint64)
     times = dict(total=r.t_total_us, scan=r.t_scan_us, batches=r.t_batches_us, solve=r.t_solve_us, mapping=r.t_mapping_us)
     kinds = _np(r.redirect_kind, nr, np.uint8).tolist() if r.redirect_kind else [HQ_REDIRECT_FROM_PREFILL] * nr
-    return Result(r.status, bool(r.is_optimal), batches, counts, records, retracts, redirects, mn, nf, times, kinds)
+    return Result(r.status, bool(r.is_optimal), batches, counts, records, retracts, redirects, mn, nf, times, kinds, bool(r.is_canonical))

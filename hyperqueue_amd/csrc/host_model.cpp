@@ -336,6 +336,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             out.milp_nodes += sol.nodes; out.milp_cols += m.ncols(); out.milp_rows += m.nrows(); out.milp_components += sol.n_components;
             if (!sol.feasible) { out.keys.clear(); out.per_key.clear(); return out; }  // `None` => empty solution  solver.rs:433-437
             if (!sol.optimal) out.is_optimal = false;
+            if (!sol.canonical) out.is_canonical = false;
             std::vector<uint32_t> xs(cols.size());
             for (size_t c = 0; c < cols.size(); c++) xs[c] = (uint32_t)std::round(sol.x[c]);
             { uint8_t fl = 0; for (auto &cr : cols) if (cr.batch == UINT32_MAX) fl = 1; class_has_flag.push_back(fl); }
@@ -653,6 +654,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     out.milp_nodes = sol.nodes; out.milp_cols = m.ncols(); out.milp_rows = m.nrows(); out.milp_components = sol.n_components;
     if (!sol.feasible) return out;
     out.is_optimal = sol.optimal;
+    out.is_canonical = sol.canonical && sol.optimal;
 
     // decode  :439-481; Map iteration orders via hb_order.h
     std::vector<uint64_t> key_hash; std::vector<std::pair<uint32_t, uint8_t>> key_list; std::vector<std::vector<std::pair<uint32_t, uint32_t>>> key_counts;

@@ -94,6 +94,7 @@ struct Counts {
     std::vector<uint32_t> mn_rq;                               // mn_workers keys (variant 0) in iteration order
     std::vector<std::vector<std::vector<uint32_t>>> mn_sets;   // per key: worker sets
     bool is_optimal = true;
+    bool is_canonical = true;  // every solve completed its tie-break phase
     bool empty() const {
         for (auto &k : per_key) if (!k.empty()) return false;
         for (auto &k : mn_sets) if (!k.empty()) return false;

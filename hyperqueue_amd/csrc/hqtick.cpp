@@ -768,6 +768,7 @@ struct TickRun {
         mark();  // 2: solve
         const double t3 = now_us();
         out->is_optimal = cnt.is_optimal;
+        out->is_canonical = cnt.is_canonical && cnt.is_optimal;
         status = HQTICK_DONE;  // scheduler/main.rs:57-68
         if (!cnt.is_optimal) status = cnt.empty() ? HQTICK_NO_PROGRESS : HQTICK_NEED_MORE_COMPUTE;
         // ---------------- host: mapping plan ----------------

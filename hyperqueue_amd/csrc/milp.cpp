@@ -555,7 +555,7 @@ Result solve(const Model &mdl, double time_limit_s, bool canonical) {
     Result res;
     int n = mdl.ncols(), m = mdl.nrows();
     res.x.assign(n, 0.0);
-    res.feasible = true; res.optimal = true;
+    res.feasible = true; res.optimal = true; res.canonical = canonical;
     if (n == 0) return res;
     double deadline = wall() + (time_limit_s > 0 ? time_limit_s : 1e18);
 
@@ -685,7 +685,8 @@ Result solve(const Model &mdl, double time_limit_s, bool canonical) {
         }
         std::vector<double> xo;
         int st = cs.run(canonical, xo);
-        if (memo_ok && !cs.timed_out && (st == 0 || st == 1)) memo.emplace(std::move(sig), std::make_pair(st, xo));
+        if (memo_ok && !cs.timed_out && cs.canonical_done && (st == 0 || st == 1)) memo.emplace(std::move(sig), std::make_pair(st, xo));
+        if (!cs.canonical_done || st == 2) res.canonical = false;
         res.nodes += cs.nodes; res.lp_iters += cs.lp_iters;
         if (st == 0) {
             if (cs.timed_out) {  // nothing found in time: all-zero placement with every blocker flag on (feasible for the tick's models)

@@ -55,6 +55,7 @@ struct Result {
     double objective = 0.0;  // c.x in the model's own (unscaled) coefficients
     bool feasible = false;   // false => the reference's `None` (infeasible / unbounded)   highs.rs:82
     bool optimal = false;    // false with feasible => time limit hit, incumbent returned   highs.rs:73-80
+    bool canonical = true;   // false: some component's tie-break phase was skipped / cut short (or not requested): x is an optimum, not THE canonical one
     long nodes = 0, lp_iters = 0;
     int n_components = 0;
 };

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HQTICK_ABI_VERSION 2u
+#define HQTICK_ABI_VERSION 3u
 
 /* ResourceAmount::MAX                                    common/resources/amount.rs:31 */
 #define HQ_AMOUNT_MAX UINT64_MAX
@@ -192,6 +192,9 @@ typedef struct hqtick_query_workers {
 typedef struct hqtick_result {
     int32_t status;     /* HQTICK_DONE / NEED_MORE_COMPUTE / NO_PROGRESS */
     uint8_t is_optimal; /* SchedulingSolution::is_optimal  scheduler/solver.rs:14-16 */
+    uint8_t is_canonical; /* 1: among the optimal placements this is the canonical one — the answer is a function of the
+                             snapshot alone.  0: optimal (or an incumbent) but the tie-break phase was skipped or ran out of its work budget:
+                             only the objective value can be compared with another solver's answer.  (ABI 3; uses former padding.) */
 
     /* TaskBatch list (scheduler/batches.rs:18-27) — exposed so parity tier T1 is testable */
     uint32_t n_batches;

@@ -963,7 +963,7 @@ int oracle_tick(void *p, const hqtick_snapshot *s, oracle_solve_fn fn, void *use
     double t4 = now_us();
 
     memset(res, 0, sizeof(*res));
-    res->status = status; res->is_optimal = sol.is_optimal;
+    res->status = status; res->is_optimal = sol.is_optimal; res->is_canonical = sol.is_optimal;  // the Python driver applies the tie-break (oracle.py)
     res->n_batches = (u32)o.batch_rq.size(); res->batch_rq = o.batch_rq.data(); res->batch_size = o.batch_size.data();
     res->batch_limit = o.batch_limit.data(); res->batch_limit_reached = o.batch_lr.data(); res->batch_is_blocker = o.batch_blk.data();
     res->batch_cut_off = o.batch_cut_off.data(); res->cut_size = o.cut_size.data(); res->cut_blocker_off = o.cut_blocker_off.data();
