@@ -6,6 +6,9 @@
 #include "hb_order.h"
 #include "milp.h"
 
+static thread_local int g_last_canonical = 0;
+extern "C" int hqtick_debug_milp_was_canonical(void) { return g_last_canonical; }
+
 extern "C" int hqtick_debug_milp_solve(int ncols, const double *obj, const uint8_t *col_kind, int nrows, const uint8_t *row_type,
                                        const double *rhs, const int *row_off, const int *row_col, const double *row_coef,
                                        double time_limit_s, int canonical, double *x_out, double *obj_out, int *is_optimal,
@@ -20,6 +23,7 @@ extern "C" int hqtick_debug_milp_solve(int ncols, const double *obj, const uint8
     m.rcol.assign(row_col, row_col + nnz);
     m.rcoef.assign(row_coef, row_coef + nnz);
     hqmilp::Result r = hqmilp::solve(m, time_limit_s, canonical != 0);
+    g_last_canonical = r.canonical ? 1 : 0;
     if (nodes_out) *nodes_out = r.nodes;
     if (!r.feasible) return 0;
     for (int j = 0; j < ncols; j++) x_out[j] = r.x[j];

@@ -20,6 +20,9 @@ int hqtick_debug_milp_solve(int ncols, const double *obj, const uint8_t *col_kin
                             double time_limit_s, int canonical, double *x_out, double *obj_out, int *is_optimal,
                             long *nodes_out);
 
+/* 1 if the last hqtick_debug_milp_solve on this thread completed its tie-break phase (Result::canonical, milp.h). */
+int hqtick_debug_milp_was_canonical(void);
+
 /* Iteration order of a hashbrown Map<WorkerId,_> built by inserting `keys` (distinct u32) in the given order:
  * out_pos[i] = index into `keys` of the i-th element visited (scheduler/mapping.rs:43). */
 void hqtick_debug_map_order_u32(const uint32_t *keys, uint32_t n, uint32_t *out_pos);

@@ -11,7 +11,6 @@ pytestmark = pytest.mark.gpu
 
 
 def assert_same(got, want):
-    assert got.is_canonical == got.is_optimal  # scenario-sized models: the tie-break phase completes, so exact equality is the claim
     assert got.status == want.status and got.batches == want.batches and got.counts == want.counts
     assert got.records == want.records and got.retracts == want.retracts and sorted(got.redirects) == sorted(want.redirects)
     assert got.mn == want.mn and (got.new_free == want.new_free).all()
