@@ -163,7 +163,7 @@ struct Tab {
             }
             if (q < 0) return LP_INFEAS;
             iters++;
-            if ((iters & 63) == 0 && wall() > deadline) return LP_LIMIT;
+            if (((iters & 63) == 0 || (double)ma * (double)N > 2.0e5) && wall() > deadline) return LP_LIMIT;  // a pivot of a large tableau costs milliseconds
             double target = below ? lb[k] : ub[k];
             double piv = prow[q];
             double dq = (x[k] - target) / piv;
@@ -208,7 +208,10 @@ struct Tab {
             if (bad.empty()) return LP_OPT;
             std::sort(bad.begin(), bad.end());  // most violated first; ties by row index: deterministic
             size_t take = std::min<size_t>(bad.size(), std::max<size_t>(32, bad.size() / 4));
-            for (size_t t = 0; t < take; t++) if (!activate(bad[t].second)) return LP_LIMIT;
+            for (size_t t = 0; t < take; t++) {
+                if (!activate(bad[t].second)) return LP_LIMIT;
+                if ((t & 15) == 15 && wall() > deadline) return LP_LIMIT;
+            }
         }
     }
 };
@@ -349,6 +352,7 @@ struct CompSolver {
                 const int k = cd.second; const double vk = t.x[k];
                 if (std::fabs(vk - std::round(vk)) <= INT_TOL) continue;  // became integral through an earlier fixing
                 double dz[2]; bool dead[2];
+                if (wall() > deadline) { timed_out = true; return; }  // a child LP of a large model takes milliseconds: check the clock per candidate
                 for (int side = 0; side < 2; side++) {
                     Tab c = t;
                     if (side == 0) c.set_lb(k, std::ceil(vk - INT_TOL)); else c.set_ub(k, std::floor(vk + INT_TOL));
