@@ -900,6 +900,8 @@ int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, c
         HQ_HIP(hipStreamSynchronize(ctx->stream));
         if (flag[1] != ctx->n_live) return fail(ctx, HQTICK_E_DEVICE, "resident ready set: live-task count out of sync");
         if (flag[0] & 4u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: a task id is already in the ready set");
+        if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
+        if (flag[0] & 16u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
     }
     std::swap(ctx->d_tid, ctx->d_tid2); std::swap(ctx->d_tprio, ctx->d_tprio2); std::swap(ctx->d_trq, ctx->d_trq2);
     ctx->n_ready = new_n; ctx->n_live = new_n; ctx->last_valid = false; ctx->last_consumed = true;
@@ -949,8 +951,10 @@ int hqtick_ready_add(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const
     if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set (hqtick_upload_ready with n = 0 creates an empty one)");
     if (n == 0) return 0;
     if (n > 0xFFFFFFFFull) return fail(ctx, HQTICK_E_CAPACITY, "more than 2^32 ids in one delta");
-    for (uint64_t i = 1; i < n; i++) if (task_id[i - 1] >= task_id[i]) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
-    for (uint64_t i = 0; i < n; i++) if (task_rq[i] == 0xFFFFFFFFu) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
+    if (ctx->n_ready == 0) {  // nothing resident: the batch is copied as it is, so it is checked here; otherwise the merge kernel validates it
+        for (uint64_t i = 1; i < n; i++) if (task_id[i - 1] >= task_id[i]) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
+        for (uint64_t i = 0; i < n; i++) if (task_rq[i] == 0xFFFFFFFFu) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
+    }
     HQ_HIP(hipSetDevice(ctx->device));
     // stage through pinned memory: a pageable hipMemcpy of a few MB costs ~1 ms each in page pinning
     size_t o_p = (n * 8 + 15) & ~(size_t)15, o_q = o_p * 2, bytes = o_q + n * 4 + 16;

@@ -620,10 +620,13 @@ __global__ void __launch_bounds__(256) k_rebuild(const uint64_t *__restrict__ oi
 __global__ void __launch_bounds__(256) k_merge_adds(const uint64_t *__restrict__ oid, uint64_t n, const uint32_t *__restrict__ slice_off,
                                                     const uint8_t *__restrict__ pre8, uint32_t n_live, const uint64_t *__restrict__ aid,
                                                     const uint64_t *__restrict__ aprio, const uint32_t *__restrict__ arq, uint32_t n_add,
-                                                    uint64_t *__restrict__ nid, uint64_t *__restrict__ nprio, uint32_t *__restrict__ nrq) {
+                                                    uint64_t *__restrict__ nid, uint64_t *__restrict__ nprio, uint32_t *__restrict__ nrq, uint32_t *__restrict__ err_flag) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_add) return;
     const uint64_t key = aid[j];
+    // the batch is validated here, not in a host loop over it: ids strictly ascending (8), request id 0xFFFFFFFF reserved for the tombstone (16)
+    if (j > 0 && aid[j - 1] >= key) atomicOr(err_flag, 8u);
+    if (arq[j] == RQ_TOMBSTONE) atomicOr(err_flag, 16u);
     uint64_t lo = 0, hi = n;  // first old position with id >= key
     if (n && oid[n - 1] < key) lo = n;  // the usual case: fresh ids sort behind everything resident
     else while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (oid[mid] < key) lo = mid + 1; else hi = mid; }
@@ -841,7 +844,7 @@ hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint3
     hipLaunchKernelGGL(k_rebuild, dim3((n_slices + 3) / 4), dim3(256), 0, s, oid, oprio, orq, n, n_slices, slice_off, aid, n_add, nid, nprio, nrq, pre8, err_flag);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || n_add == 0) return e;
-    hipLaunchKernelGGL(k_merge_adds, dim3((n_add + 255) / 256), dim3(256), 0, s, oid, n, slice_off, pre8, n_live, aid, aprio, arq, n_add, nid, nprio, nrq);
+    hipLaunchKernelGGL(k_merge_adds, dim3((n_add + 255) / 256), dim3(256), 0, s, oid, n, slice_off, pre8, n_live, aid, aprio, arq, n_add, nid, nprio, nrq, err_flag);
     return hipGetLastError();
 }
 
