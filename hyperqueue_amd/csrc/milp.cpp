@@ -323,6 +323,11 @@ struct CompSolver {
         nodes++;
         if (aborted || time_up()) return;
         if (node_budget >= 0 && nodes > node_budget) { aborted = true; return; }
+        {   // a node of a large tableau costs a copy of it (~20 ns per element with the page faults): check the clock every time, and do not start
+            // a copy that cannot finish in the time that is left
+            const double elems = (double)t.ma * (double)t.width();
+            if (elems > 1.0e6 && deadline - wall() < 2.0e-8 * elems) { timed_out = true; return; }
+        }
         int s = solve_counted(t);
         if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return; }
         double z = t.objective();
@@ -340,7 +345,7 @@ struct CompSolver {
             return;
         }
         const int SB = 32;
-        if (strong && have) {
+        if (strong && have && (double)t.ma * (double)t.width() <= 4.0e6) {  // two tableau copies per candidate: not for the large models
             // strong branching over the SB most valuable fractional columns: both children are solved, the column whose children lose the most
             // bound is branched on, and a child that cannot hold anything better fixes the column the other way at once
             std::vector<std::pair<double, int>> cand;
