@@ -85,3 +85,24 @@ def test_map_order_reference_pins():
     """workers {50, 51} iterate (50, 51) — pinned by test_schedule_no_priorities (test_scheduler_sn.rs:183-187)."""
     assert orc.hb_order_u32([50, 51]) == [50, 51]
     assert orc.hb_order_u32([50, 51, 52]) == [52, 50, 51]
+
+
+@pytest.mark.parametrize("n_workers,n_ready", [(4, 86), (4, 193), (8, 172), (16, 344)])
+def test_unsaturated_multi_class_models_are_proven(n_workers, n_ready):
+    """Fewer ready tasks than the cluster holds, all eight c3 classes: no batch is saturated and the batch-size rows couple every worker
+    ("Unsaturated ticks").  Most-fractional branching timed out on every one of these; the value-ordered branching + restart
+    portfolio must prove them, with HiGHS's objective."""
+    from hyperqueue_amd import workloads
+
+    ids, prio, rq, off, dep = workloads.make_dag(100_000, seed=0)
+    src = np.nonzero((off[1:] - off[:-1]) == 0)[0][:n_ready]
+    assert len(src) == n_ready
+    drv = workloads.DagChurn(n_workers=n_workers, churn=0.1, seed=0)
+    snap = drv.snapshot(ids[src], prio[src], rq[src])
+    o = orc.Oracle(abi.make_config(time_limit_s=60.0))
+    w = o.tick(snap)
+    m = o.last_model()
+    assert w.is_optimal and len(m["obj"]) == 8 * n_workers
+    got = product_milp(m["obj"], m["kind"], m["rtype"], m["rhs"], m["roff"], m["rcol"], m["rcoef"], canonical=False, time_limit=60.0)
+    assert got is not None and got[2], "not proven optimal"
+    assert abs(got[1] - m["objective"]) <= 1e-9 * abs(m["objective"])
