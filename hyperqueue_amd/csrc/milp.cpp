@@ -57,14 +57,37 @@ struct Tab {
     double ops = 0.0;         // tableau elements touched so far (pivots, row activations, separation scans): the deterministic work measure
     double deadline = 1e300;  // wall-clock backstop inside long re-optimisations
 
+    // Tableau storage is recycled through a small per-thread pool: a B&B node copies its parent's tableau, and a fresh std::vector of a megabyte
+    // is an mmap + page faults + munmap per node — more than the copy itself.
+    static std::vector<std::vector<double>> &pool() { static thread_local std::vector<std::vector<double>> p; return p; }
+    static std::vector<double> take_buffer(size_t elems) {
+        auto &p = pool();
+        for (size_t i = p.size(); i-- > 0;) if (p[i].size() >= elems) { std::vector<double> b = std::move(p[i]); p.erase(p.begin() + (long)i); return b; }
+        return std::vector<double>(elems);
+    }
+    static bool poolable(const std::vector<double> &b) { return b.size() >= 4096 && b.size() <= (1u << 20) && pool().size() < 64; }  // <= 8 MB each, <= 64 of them
+    ~Tab() { if (poolable(T)) pool().push_back(std::move(T)); }
     Tab() = default;
     Tab(Tab &&) = default;
-    Tab &operator=(Tab &&) = default;
+    Tab &operator=(Tab &&o) {
+        if (this != &o) {
+            if (poolable(T)) pool().push_back(std::move(T));
+            R = o.R; n = o.n; ma = o.ma; cap = o.cap; stride = o.stride;
+            T = std::move(o.T); d = std::move(o.d); x = std::move(o.x); lb = std::move(o.lb); ub = std::move(o.ub); cost = std::move(o.cost);
+            B = std::move(o.B); arow = std::move(o.arow); where = std::move(o.where); st = std::move(o.st);
+            iters = o.iters; ops = o.ops; deadline = o.deadline;
+        }
+        return *this;
+    }
     // B&B children and tie-break probes copy their parent: copy the active rows only, into a tableau with a little headroom
     Tab(const Tab &o) : R(o.R), n(o.n), ma(o.ma), cap(o.ma + 16), stride(o.n + o.ma + 16), B(o.B), arow(o.arow), where(o.where), iters(o.iters), ops(o.ops + (double)(o.ma + 1) * (double)(o.n + o.ma)), deadline(o.deadline) {
-        T.assign((size_t)cap * stride, 0.0);
+        T = take_buffer((size_t)cap * stride);  // contents unspecified: rows < ma are written below, rows >= ma by activate() before any use
         const int N = o.width();
-        for (int r = 0; r < ma; r++) memcpy(&T[(size_t)r * stride], &o.T[(size_t)r * o.stride], sizeof(double) * N);
+        for (int r = 0; r < ma; r++) {
+            double *dst = &T[(size_t)r * stride];
+            memcpy(dst, &o.T[(size_t)r * o.stride], sizeof(double) * N);
+            std::fill(dst + N, dst + stride, 0.0);  // the columns later slacks will take
+        }
         auto cp = [&](std::vector<double> &dst, const std::vector<double> &src) { dst.assign(stride, 0.0); memcpy(dst.data(), src.data(), sizeof(double) * N); };
         cp(d, o.d); cp(x, o.x); cp(lb, o.lb); cp(ub, o.ub); cp(cost, o.cost);
         st.assign(stride, AT_LO); memcpy(st.data(), o.st.data(), N);
@@ -99,7 +122,7 @@ struct Tab {
         if (ma == cap) { if ((double)cap * 2.0 * (double)(n + cap * 2) > TAB_LIMIT) return false; grow(); }
         const int a = ma, k = n + a, N = width();
         double *v = &T[(size_t)a * stride];
-        std::fill(v, v + N + 1, 0.0);
+        std::fill(v, v + stride, 0.0);  // the whole row: recycled storage is not zero beyond what the copy constructor wrote
         double act = 0.0;
         for (int t = R->off[i]; t < R->off[i + 1]; t++) { v[R->col[t]] -= R->coef[t]; act += R->coef[t] * x[R->col[t]]; }
         for (int r = 0; r < a; r++) {  // express the row in the current nonbasic columns
