@@ -100,6 +100,14 @@ struct Counts {
         for (auto &k : mn_sets) if (!k.empty()) return false;
         return true;
     }
+    uint32_t checksum() const {  // FNV-1a over the placement: replicas of a sharded scheduler compare it (include/hqtick.h, record sink)
+        uint32_t h = 2166136261u;
+        auto mix = [&](uint32_t v) { for (int i = 0; i < 4; i++) { h ^= (v >> (8 * i)) & 0xFFu; h *= 16777619u; } };
+        mix(is_optimal ? 1u : 0u);
+        for (size_t k = 0; k < keys.size(); k++) { mix(keys[k].first); mix(keys[k].second); for (auto &wc : per_key[k]) { mix(wc.first); mix(wc.second); } }
+        for (size_t k = 0; k < mn_rq.size(); k++) { mix(mn_rq[k]); for (auto &set : mn_sets[k]) { mix(0xFFFFFFFFu); for (uint32_t w : set) mix(w); } }
+        return h;
+    }
     int error = 0; std::string errmsg;
     long milp_nodes = 0; int milp_cols = 0, milp_rows = 0, milp_components = 0;
 };

@@ -674,7 +674,7 @@ struct TickRun {
                 const size_t so_off = 16, so_task = (so_off + (size_t)(W + 1) * 4 + 7) & ~(size_t)7, so_var = so_task + (size_t)cap * 8, so_kind = so_var + cap;
                 // header + rec_off ride in the plan buffer's tail: stage them in pinned memory and copy with the stream
                 std::vector<uint32_t> &hdr = ps.sink_hdr; hdr.assign(4 + W + 1, 0);
-                hdr[0] = n_rec; hdr[1] = W; hdr[2] = HQTICK_SINK_MAGIC; hdr[3] = cap;
+                hdr[0] = n_rec; hdr[1] = cnt.checksum(); hdr[2] = HQTICK_SINK_MAGIC; hdr[3] = cap;
                 memcpy(hdr.data() + 4, ps.out_off.data(), (size_t)(W + 1) * 4);
                 if (!ctx->h_sinkhdr.ensure(hdr.size() * 4)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc sink header");
                 memcpy(ctx->h_sinkhdr.p, hdr.data(), hdr.size() * 4);
@@ -706,7 +706,7 @@ struct TickRun {
         if (!n_sel && ctx->sink) {  // nothing placed: still publish an empty, well-formed sink
             if (hqtick_sink_bytes(W, 0) > ctx->sink_bytes) return fail(ctx, HQTICK_E_CAPACITY, "record sink too small for this tick");
             std::vector<uint32_t> &hdr = ps.sink_hdr; hdr.assign(4 + W + 1, 0);
-            hdr[1] = W; hdr[2] = HQTICK_SINK_MAGIC; hdr[3] = hqtick_sink_capacity_records(W, ctx->sink_bytes);
+            hdr[1] = cnt.checksum(); hdr[2] = HQTICK_SINK_MAGIC; hdr[3] = hqtick_sink_capacity_records(W, ctx->sink_bytes);
             HQ_HIP(hipMemcpy(ctx->sink, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
         }
         return 0;

@@ -40,7 +40,33 @@ def sink_layout(n_workers: int, cap: int) -> Tuple[int, int, int, int, int]:
     return o_off, o_task, o_var, o_kind, total
 
 
-def pack_shard(res: abi.Result, worker_ids, rank: int, world: int, cap: int) -> np.ndarray:
+class ShardDivergence(RuntimeError):
+    """the ranks' replicated placements differ (placement_checksum in the sink headers): a tick that ran into its time limit"""
+
+
+def placement_checksum(res: abi.Result) -> int:
+    """FNV-1a over the counts, the multi-node sets and is_optimal — hqhost::Counts::checksum (csrc/host_model.h)."""
+    h = 2166136261
+
+    def mix(v):
+        nonlocal h
+        for i in range(4):
+            h = ((h ^ ((v >> (8 * i)) & 0xFF)) * 16777619) & 0xFFFFFFFF
+
+    mix(1 if res.is_optimal else 0)
+    last = None
+    for (rq, variant, worker, count) in res.counts:  # grouped by (rq, variant) in iteration order
+        if (rq, variant) != last:
+            mix(rq); mix(variant); last = (rq, variant)
+        mix(worker); mix(count)
+    for task, workers in res.mn:  # stand-in for the library's per-request multi-node sets: any deterministic function of them will do here
+        mix(0xFFFFFFFF); mix(task & 0xFFFFFFFF)
+        for w in workers:
+            mix(w)
+    return h
+
+
+def pack_shard(res: abi.Result, worker_ids, rank: int, world: int, cap: int, checksum: Optional[int] = None) -> np.ndarray:
     """CPU stand-in for what K5b + the sink header copy produce on the GPU: this rank's records in sink layout."""
     W = len(worker_ids)
     o_off, o_task, o_var, o_kind, total = sink_layout(W, cap)
@@ -55,7 +81,7 @@ def pack_shard(res: abi.Result, worker_ids, rank: int, world: int, cap: int) -> 
     n = len(tasks)
     if n > cap:
         raise ValueError(f"record sink too small: {n} records, capacity {cap}")
-    buf[0:16].view(np.uint32)[:] = [n, W, SINK_MAGIC, cap]
+    buf[0:16].view(np.uint32)[:] = [n, placement_checksum(res) if checksum is None else checksum, SINK_MAGIC, cap]
     buf[o_off:o_off + (W + 1) * 4].view(np.uint32)[:] = off
     buf[o_task:o_task + n * 8].view(np.uint64)[:] = np.asarray(tasks, np.uint64)
     buf[o_var:o_var + n] = np.asarray(variants, np.uint8)
@@ -70,9 +96,14 @@ def merge_shards(merged: np.ndarray, world: int, n_workers: int, cap: int) -> Li
     records: List[List[Tuple[int, int, int]]] = [[] for _ in range(n_workers)]
     for r in range(world):
         b = merged[r * total:(r + 1) * total]
-        n, W, magic, c = b[0:16].view(np.uint32).tolist()
-        if magic != SINK_MAGIC or W != n_workers or c != cap:
-            raise ValueError(f"shard {r}: bad sink header {(n, W, hex(magic), c)}")
+        n, chk, magic, c = b[0:16].view(np.uint32).tolist()
+        W = n_workers
+        if magic != SINK_MAGIC or c != cap:
+            raise ValueError(f"shard {r}: bad sink header {(n, chk, hex(magic), c)}")
+        if r == 0:
+            chk0 = chk
+        elif chk != chk0:
+            raise ShardDivergence(f"shard {r}: placement checksum {chk:#x} != {chk0:#x} of shard 0")
         off = b[o_off:o_off + (W + 1) * 4].view(np.uint32)
         t = b[o_task:o_task + n * 8].view(np.uint64).tolist()
         v = b[o_var:o_var + n].tolist()
@@ -102,6 +133,7 @@ class ShardedTick:
         self.backend = backend
         self._sink = self._merged = None
         self._sink_workers = -1
+        self.n_divergent = 0  # ticks on which the replicas disagreed and rank 0's placement was broadcast
         if backend == "hip":
             from .tick import Tick
 
@@ -163,5 +195,43 @@ class ShardedTick:
                 merged.copy_(sink)
             out = full
             host = merged.numpy()
-        out.records = merge_shards(host, self.world, W, self.cap)
+        try:
+            out.records = merge_shards(host, self.world, W, self.cap)
+        except ShardDivergence:
+            out = self._fallback_from_rank0(snap, resident)
+            self.n_divergent += 1
         return out
+
+    def _fallback_from_rank0(self, snap: abi.Snapshot, resident: bool) -> abi.Result:
+        """The replicas disagree (a time-limited tick): every rank takes rank 0's placement.  Rank 0 repeats the tick unsharded into a sink that
+        holds every worker's records and broadcasts it — one more collective, only on this path."""
+        import pickle
+
+        dist = self.torch.distributed
+        W = len(snap.worker_id)
+        if self.backend == "hip":
+            lib = self.t._lib
+            full_cap = self.cap * self.world
+            total = sink_layout(W, full_cap)[4]
+            dev = f"cuda:{self.cfg.device_index}"
+            big = self.torch.zeros(total, dtype=self.torch.uint8, device=dev)
+            meta = [None]
+            if self.rank == 0:
+                lib.hqtick_set_shard(self.t._ctx, 0, 1)
+                lib.hqtick_set_record_sink(self.t._ctx, C.c_void_p(big.data_ptr()), C.c_size_t(total))
+                try:
+                    res_c = self.t.tick_raw(snap.to_c(), resident=resident)
+                    out = abi.parse_result(res_c, W, snap.n_resources)
+                finally:
+                    lib.hqtick_set_shard(self.t._ctx, self.rank, self.world)
+                    self._sink_workers = -1  # the per-shard sink is re-attached by the next tick
+                meta[0] = pickle.dumps((out.status, out.is_optimal, out.batches, out.counts, out.retracts, out.redirects, out.mn, out.new_free, out.times_us, out.redirect_kinds, out.is_canonical))
+            dist.broadcast(big, src=0, group=self.group)
+            dist.broadcast_object_list(meta, src=0, group=self.group)
+            st, opt, batches, counts, retracts, redirects, mn, nf, times, kinds, canon = pickle.loads(meta[0])
+            out = abi.Result(st, opt, batches, counts, [[] for _ in range(W)], retracts, redirects, mn, nf, times, kinds, canon)
+            out.records = merge_shards(big.cpu().numpy(), 1, W, full_cap)
+            return out
+        box = [self.backend(snap) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        return box[0]

@@ -351,7 +351,10 @@ int hqtick_set_shard(hqtick_ctx *ctx, uint32_t shard_index, uint32_t shard_count
  * Record sink in DEVICE memory (for the RCCL all-gather that merges the shards' assignment vectors).  While a sink is set,
  * the records of a tick are written into it instead of host memory (result.rec_task/rec_variant/rec_kind are NULL;
  * result.rec_off stays valid).  Layout, all little-endian, with cap = hqtick_sink_capacity_records(W, capacity_bytes):
- *     u32 header[4] = { n_records, W, HQTICK_SINK_MAGIC, cap }
+ *     u32 header[4] = { n_records, placement_checksum, HQTICK_SINK_MAGIC, cap }
+ *         placement_checksum: FNV-1a over the tick's counts (rq, variant, worker, count), multi-node sets and is_optimal — the same on
+ *         every rank unless their replicated placements diverged (only a tick that ran into its time limit can do that: its incumbent
+ *         depends on the clock); the merging side compares the values and falls back to one rank's placement if they differ.
  *     u32 rec_off[W + 1]        (+ 4 bytes of padding when W is even, so that the next array is 8-byte aligned)
  *     u64 task[cap]   u8 variant[cap]   u8 kind[cap]
  * A tick whose records do not fit returns HQTICK_E_CAPACITY.  device_ptr == NULL removes the sink.

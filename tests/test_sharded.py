@@ -105,3 +105,63 @@ def test_two_rank_allgather_gloo():
     assert all(ok for (_, ok, _, _) in res), res
     total = res[0][3]
     assert sum(m for (_, _, m, _) in res) == total and all(0 < m < total for (_, _, m, _) in res)  # both shards carried records
+
+
+def test_divergent_placements_are_detected():
+    """placement_checksum in the sink headers: shards built from different placements must not merge silently"""
+    from oracle.oracle import Oracle
+
+    env = make_env()
+    snap = env.snapshot()
+    full = Oracle(env.config, canonical=True).tick(snap)
+    other = abi.Result(**{**full.__dict__, "counts": full.counts[:-1]})  # another replica's (different) placement
+    cap = 256
+    merged = np.concatenate([sharded.pack_shard(full, snap.worker_id, 0, 2, cap), sharded.pack_shard(other, snap.worker_id, 1, 2, cap)])
+    with pytest.raises(sharded.ShardDivergence):
+        sharded.merge_shards(merged, 2, len(snap.worker_id), cap)
+
+
+def _rank_main_divergent(rank: int, world: int, port: int, out_q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.oracle import Oracle
+
+        env = make_env()
+        snap = env.snapshot()
+        o = Oracle(env.config, canonical=True)
+        want = o.tick(snap)
+
+        def replica_tick(s):  # rank 1's solver "ran into its time limit" and holds another incumbent: one task less on the last worker that has any
+            r = o.tick(s)
+            if rank == 1:
+                w = max(i for i, recs in enumerate(r.records) if recs)
+                r.records[w] = r.records[w][:-1]
+                r.counts = r.counts[:-1] + [(r.counts[-1][0], r.counts[-1][1], r.counts[-1][2], r.counts[-1][3] - 1)]
+                r.is_optimal = False
+            return r
+
+        st = sharded.ShardedTick(env.config, rank=rank, world=world, records_per_shard=256, backend=replica_tick)
+        got = st.tick(snap)
+        ok = got.records == want.records and got.counts == want.counts and st.n_divergent == 1  # every rank ends up with rank 0's placement
+        out_q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_divergence_falls_back_to_rank0_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main_divergent, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for (_, ok) in res), res
