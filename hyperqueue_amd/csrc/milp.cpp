@@ -550,6 +550,7 @@ struct CompSolver {
                 return 2;
             }
         }
+        const double t_search = wall();
         for (int phase = 0;; phase++) {
             aborted = false; strong = (phase & 1) != 0; node_budget = nodes + budget;
             if (phase > 0) { lp_iters += root.iters; root = Tab(); root.init(&R, c, lb, ub); root.deadline = deadline; }
@@ -557,8 +558,10 @@ struct CompSolver {
             if (!aborted || timed_out) break;
             if (node_cap >= 0 && nodes >= node_cap) { timed_out = true; break; }
             if (phase == 0 && !in_lns) {  // the dive did not finish: improve its incumbent before the expensive phases
-                const double left = deadline - wall();
-                lns_schedule(wall() + 0.3 * left);
+                // at most 30 % of what is left, and not more than three times what the dive itself took: a model that strong branching proves
+                // in a second must not spend six in here first
+                const double now = wall(), left = deadline - now, dive = now - t_search;
+                lns_schedule(now + std::min(0.3 * left, std::max(0.05, 3.0 * dive)));
             }
             if (phase & 1) budget *= 4;
         }
