@@ -376,6 +376,23 @@ struct CompSolver {
             best = zz;
             return;
         }
+        if (have) {
+            // Reduced-cost bound tightening: moving a nonbasic column k by delta away from its bound costs at least |d_k| delta of the LP bound z (the
+            // duals of the active rows bound the whole model), and only points worth `need` or more are of interest below this node.  With the
+            // near-optimal incumbents of the window search the room z - need is a few objective quanta, which pins most columns.
+            const double need = quantum > 0.0 ? best + quantum * (1.0 - 1e-6) : best + 1e-12 * std::fabs(best);
+            const double room = z - need;
+            if (room >= 0.0) {
+                for (int k = 0; k < n; k++) {
+                    if (t.st[k] == BASIC || t.lb[k] == t.ub[k]) continue;
+                    const double dk = std::fabs(t.d[k]);
+                    if (dk < 1e-9) continue;
+                    const double steps = std::floor(room / dk + 1e-9);
+                    if (steps >= t.ub[k] - t.lb[k]) continue;
+                    if (t.st[k] == AT_UP) t.lb[k] = t.ub[k] - steps; else t.ub[k] = t.lb[k] + steps;
+                }
+            }
+        }
         const int SB = 32;
         if (strong && have && (double)t.ma * (double)t.width() <= 4.0e6) {  // two tableau copies per candidate: not for the large models
             // strong branching over the SB most valuable fractional columns: both children are solved, the column whose children lose the most
