@@ -887,4 +887,68 @@ def test_schedule_many_distinct_shapes_stays_bounded(backend):  # sn:1469-1486: 
     assert r.is_optimal and used == 20 * 64, (r.is_optimal, used)
 
 
+# ---- end-to-end pins of the reference's Python suite (tests/test_resources.py): a job is RUNNING there iff the first tick after the
+# submission assigned it (the worker starts every assigned task at once), WAITING iff it did not
+
+
+def _assigned(rt, ids):
+    from hyperqueue_amd.core import ASSIGNED
+
+    return [rt.tasks[t].state == ASSIGNED for t in ids]
+
+
+def test_e2e_resources_and_many_priorities(backend):  # tests/test_resources.py:548-561
+    rt = env()
+    rt.new_named_resource("foo")
+    foo = [rt.new_task(TB().cpus(1).add_resource(1, 2).user_priority(i * 10)) for i in range(1, 10)]
+    one = [rt.new_task(TB().cpus(1).user_priority(i // 3 - 5)) for i in range(12)]
+    rt.new_worker(WB(12).res_sum("foo", 6))
+    rt.schedule(backend)
+    assert _assigned(rt, foo + one) == 6 * [False] + 3 * [True] + 3 * [False] + 9 * [True]
+
+
+def test_e2e_resources_and_priorities_submit_before_worker(backend):  # tests/test_resources.py:533-545
+    rt = env()
+    rt.new_named_resource("foo")
+    foo = [rt.new_task(TB().cpus(1).add_resource(1, 2)) for _ in range(4)]
+    low = rt.new_task(TB().cpus(2).user_priority(-1))
+    rt.new_worker(WB(8).res_sum("foo", 4))
+    rt.schedule(backend)
+    a = _assigned(rt, foo)
+    assert _assigned(rt, [low]) == [True] and a.count(True) == 2 and a.count(False) == 2
+
+
+def test_e2e_resources_and_priorities_one_by_one_submit(backend):  # tests/test_resources.py:513-530
+    rt = env()
+    rt.new_named_resource("foo")
+    rt.new_worker(WB(8).res_sum("foo", 4))
+    foo = []
+    for _ in range(4):
+        foo.append(rt.new_task(TB().cpus(1).add_resource(1, 2)))
+        rt.schedule(backend)
+        for t in foo:
+            if _assigned(rt, [t]) == [True]:
+                rt.start_task(t)
+    low = rt.new_task(TB().cpus(2).user_priority(-1))
+    rt.schedule(backend)
+    from hyperqueue_amd.core import RUNNING, ASSIGNED
+
+    states = [rt.tasks[t].state in (RUNNING, ASSIGNED) for t in foo + [low]]
+    assert states == [True, True, False, False, True]
+
+
+def test_e2e_scheduler_unschedulable_sn_blocker(backend):  # tests/test_resources.py:620-640 (reproducer for #1121: get_bvar -> None, solver.rs:237)
+    rt = env()
+    rt.new_worker(WB(4))
+    first = rt.new_task(TB().cpus(1).user_priority(1000))
+    rt.schedule(backend)
+    assert _assigned(rt, [first]) == [True]
+    rt.start_task(first)
+    big = rt.new_task(TB().cpus(4).user_priority(100))
+    mid = rt.new_tasks(5, TB().cpus(2).user_priority(50))
+    rt.new_tasks(5, TB().cpus(4).user_priority(1))
+    rt.schedule(backend)  # must not fail; the 2-cpu tasks stay behind the 4-cpu blocker: "WAITING (5)"
+    assert _assigned(rt, [big] + mid) == 6 * [False]
+
+
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]
