@@ -1083,6 +1083,36 @@ int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_w
     return 0;
 }
 
+// Test hook (include/hqtick_debug.h): the host stages on caller-supplied scan outputs.  No device is touched.
+int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot *s, const uint8_t *vflags, const uint32_t *vtmc, uint32_t n_levels,
+                             const uint64_t *levels, const uint32_t *hist, hqtick_result *out) {
+    if (!config || !s || !out) return HQTICK_E_INVALID;
+    static thread_local hqtick_ctx *holder = nullptr;  // owns the result arrays; never creates a stream or a buffer
+    if (!holder) holder = new hqtick_ctx();
+    hqtick_ctx *ctx = holder;
+    ctx->cfg = *config;
+    if (int rc = validate(ctx, s, false)) return rc;
+    WorkerEval ev; ev.flags = vflags; ev.tmc = vtmc;
+    hqhost::Problem pb;
+    fill_problem(pb, s, ctx->cfg, ev);
+    Scan sc; sc.Q = s->n_requests; sc.L = n_levels; sc.G = n_levels * s->n_requests;
+    sc.levels.assign(levels, levels + n_levels); sc.hist.assign(hist, hist + (size_t)n_levels * s->n_requests);
+    std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
+    std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
+    memset(out, 0, sizeof(*out));
+    export_batches(ctx, batches, out);
+    hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
+    if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
+    ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
+    for (size_t k = 0; k < cnt.keys.size(); k++)
+        for (auto &wc : cnt.per_key[k]) { ctx->cnt_rq.push_back(cnt.keys[k].first); ctx->cnt_variant.push_back(cnt.keys[k].second); ctx->cnt_worker.push_back(wc.first); ctx->cnt_value.push_back(wc.second); }
+    out->n_counts = (uint32_t)ctx->cnt_rq.size(); out->count_rq = ctx->cnt_rq.data(); out->count_variant = ctx->cnt_variant.data();
+    out->count_worker = ctx->cnt_worker.data(); out->count_value = ctx->cnt_value.data();
+    out->is_optimal = cnt.is_optimal; out->is_canonical = cnt.is_canonical && cnt.is_optimal;
+    out->status = cnt.is_optimal ? HQTICK_DONE : (cnt.empty() ? HQTICK_NO_PROGRESS : HQTICK_NEED_MORE_COMPUTE);
+    return out->status;
+}
+
 int hqtick_set_shard(hqtick_ctx *ctx, uint32_t shard_index, uint32_t shard_count) {
     if (!ctx) return HQTICK_E_INVALID;
     if (shard_count > 1 && shard_index >= shard_count) return fail(ctx, HQTICK_E_INVALID, "shard_index >= shard_count");

@@ -1,13 +1,14 @@
 /*
  * hqtick_debug.h — test hooks exported by libhqtick.so next to the product ABI (include/hqtick.h).
  *
- * These expose two HOST-side building blocks of the tick so they can be unit-tested on a machine without a GPU.
+ * These expose HOST-side building blocks of the tick so they can be unit-tested on a machine without a GPU.
  * They are not part of the reference's surface and are not a CPU path of the tick: hqtick_run() has no CPU
  * implementation and fails with HQTICK_E_NO_DEVICE when no gfx950 device is present.
  */
 #ifndef HQTICK_DEBUG_H
 #define HQTICK_DEBUG_H
 #include <stdint.h>
+#include "hqtick.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -19,6 +20,16 @@ int hqtick_debug_milp_solve(int ncols, const double *obj, const uint8_t *col_kin
                             const double *rhs, const int *row_off, const int *row_col, const double *row_coef,
                             double time_limit_s, int canonical, double *x_out, double *obj_out, int *is_optimal,
                             long *nodes_out);
+
+/* The HOST stages of a tick — create_task_batches + run_scheduling_solver (scheduler/batches.rs:42-181, scheduler/solver.rs:36-483) — on
+ * caller-supplied outputs of the GPU scans, so that this logic can be unit-tested on a machine without a GPU.  This is not a tick: the scans
+ * (K0/K1/K2), the selection and the mapping have no CPU implementation, and nothing in the product calls this.
+ *   vflags[W * NV], vtmc[W * NV]   what K2 (k_worker_eval) writes per (worker, variant slot): bit 0 fits the free resources now, bit 1 fits the
+ *                                  total resources, bit 2 the worker's remaining time covers min_time; task_max_count_for_request
+ *   levels[L] (descending), hist[L * Q]   what K0/K1/K1b produce: the distinct priorities of the ready set and the task count per (level, rq)
+ * Fills status, is_optimal, is_canonical, the batch arrays and the count arrays of `out` (valid until the next call on this thread). */
+int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot *snapshot, const uint8_t *vflags, const uint32_t *vtmc,
+                             uint32_t n_levels, const uint64_t *levels, const uint32_t *hist, hqtick_result *out);
 
 /* 1 if the last hqtick_debug_milp_solve on this thread completed its tie-break phase (Result::canonical, milp.h). */
 int hqtick_debug_milp_was_canonical(void);

@@ -1,0 +1,62 @@
+"""The tick's HOST stages (batches + placement: separable path, lazy size rows, empty-worker elimination, exact solver) on a machine
+without a GPU, through hqtick_debug_host_stages: same batches and same counts as the canonical oracle on the randomised scenario
+families of the GPU fuzz suite.  (The scan kernels, the selection and the mapping run only on the GPU: tests/test_gpu_*.py.)"""
+import numpy as np
+import pytest
+
+from host_stages import HostStages
+from hyperqueue_amd import abi
+from hyperqueue_amd.core import TaskBuilder as TB
+
+
+def _same_host_part(got, want):
+    assert got.status == want.status and got.is_optimal == want.is_optimal
+    assert got.batches == want.batches
+    if got.is_canonical or not got.is_optimal:
+        assert got.counts == want.counts
+    else:  # optimal but the tie-break phase was cut short: same number of tasks per (rq, variant) at least — the objective-level claim
+        agg = lambda r: sorted((q, v, sum(c for (q2, v2, _, c) in r.counts if (q2, v2) == (q, v))) for (q, v) in {(q, v) for (q, v, _, _) in r.counts})
+        assert sum(c for *_, c in got.counts) == sum(c for *_, c in want.counts), (agg(got), agg(want))
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_host_stages_fuzz_scenarios(seed):
+    import test_gpu_fuzz as f
+    from oracle.oracle import Oracle
+
+    cfg, envs, _rng = f.build(seed)
+    o = Oracle(cfg, canonical=True)
+    hs = HostStages(cfg)
+    e = envs[1]
+    for _ in range(2):
+        snap = e.snapshot()
+        got = hs.stages(snap)
+        want = e.schedule(o)
+        if not want.is_optimal:
+            pytest.skip("oracle hit its limit")
+        _same_host_part(got, want)
+        done = 0
+        for t in sorted(e.tasks.values(), key=lambda t: t.id):
+            if t.state == 1 and done < 2:
+                e.finish_task(t.id, t.worker); done += 1
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_host_stages_idle_cluster(seed):
+    """few ready tasks on many identical idle workers: the reduced coupled model (empty workers eliminated) against the oracle's full model"""
+    import test_gpu_fuzz as f
+    from oracle.oracle import Oracle
+
+    cfg, envs = f.build_idle_cluster(20_000 + seed)
+    o = Oracle(cfg, canonical=True)
+    hs = HostStages(cfg)
+    e = envs[1]
+    for tick_no in range(2):
+        snap = e.snapshot()
+        got = hs.stages(snap)
+        want = e.schedule(o)
+        if not (want.is_optimal and got.is_optimal):
+            pytest.skip("a solver hit its limit")
+        _same_host_part(got, want)
+        for s in range(3):
+            e.new_task(TB().cpus(1 + (tick_no + s) % 3))
