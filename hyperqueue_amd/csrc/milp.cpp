@@ -716,7 +716,23 @@ bool sparse_greedy(const Model &mdl, const std::vector<double> &ub, std::vector<
 
 }  // namespace
 
-Result solve(const Model &mdl, double time_limit_s, bool canonical) {
+// Row feasibility follows the solver the reference uses: HiGHS accepts a MIP solution whose rows are violated by at most
+// mip_feasibility_tolerance = 1e-6 (absolute, original units).  That matters for one kind of row: the min_utilization pair of
+// scheduler/solver.rs:501-540 multiplies its on/off flag by a value derived from an f32 (0.3 -> 0.30000001192...), e.g.
+// "cpus >= 3.00000012 * flag", where every other term lives on the 1/10000 grid of ResourceAmount.  HiGHS takes 3 cpus as enough; a strict
+// solver would demand 4 (found by the CPU campaign of tools/host_fuzz.py, 1 scenario in 6000).  Relaxing the row bounds by the tolerance is not
+// an option for an LP-based search (every vertex then sits 1e-6 off the integers); instead the coefficient of a BOOL column is snapped to that
+// grid when it is within the tolerance of it — for a 0/1 column this changes the row activity by at most the tolerance, i.e. it accepts
+// exactly what HiGHS accepts there.
+const double ROW_TOL = 1e-6;
+
+Result solve(const Model &mdl_in, double time_limit_s, bool canonical) {
+    Model mdl = mdl_in;
+    for (size_t k = 0; k < mdl.rcoef.size(); k++) {
+        if (mdl.kind[mdl.rcol[k]] != COL_BOOL) continue;
+        const double c = mdl.rcoef[k], g = std::round(c * 10000.0) / 10000.0;
+        if (g != c && std::fabs(g - c) <= ROW_TOL) mdl.rcoef[k] = g;
+    }
     Result res;
     int n = mdl.ncols(), m = mdl.nrows();
     res.x.assign(n, 0.0);
