@@ -70,3 +70,20 @@ def test_host_stages_idle_cluster(seed):
         _same_host_part(got, want, o.last_model())
         for s in range(3):
             e.new_task(TB().cpus(1 + (tick_no + s) % 3))
+
+
+@pytest.mark.parametrize("name,n_tasks,n_workers", [("c2", 3000, 8), ("c3", 6000, 12), ("c4", 4000, 6), ("c3p", 3000, 6), ("c3", 300, 12), ("c4", 200, 6)])
+def test_host_stages_baseline_shapes_reduced(name, n_tasks, n_workers):
+    """the BASELINE workload shapes, reduced: saturated (separable path) and unsaturated (lazy size rows / coupled path) sizes"""
+    from hyperqueue_amd import workloads
+    from oracle.oracle import Oracle
+
+    snap = workloads.make(name, n_workers=n_workers)
+    snap.task_id, snap.task_priority, snap.task_rq = snap.task_id[:n_tasks], snap.task_priority[:n_tasks], snap.task_rq[:n_tasks]
+    cfg = abi.make_config(time_limit_s=30.0)
+    o = Oracle(cfg, canonical=True)
+    want = o.tick(snap)
+    got = HostStages(cfg).stages(snap)
+    if not (want.is_optimal and got.is_optimal):
+        pytest.skip("a solver hit its limit")
+    _same_host_part(got, want, o.last_model())
