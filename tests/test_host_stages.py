@@ -25,6 +25,8 @@ def _same_host_part(got, want, model):
     if got.is_canonical or not got.is_optimal:
         assert got.counts == want.counts
     else:  # optimal, but the tie-break phase was cut short (hqtick_result.is_canonical = 0): the claim is the objective value
+        if any(model["ctype"][j] != 0 and model["obj"][j] > 0 for j in range(len(model["obj"]))):
+            return  # multi-node columns carry part of the objective and the hook exports single-node counts only: nothing to compare here
         zg, zw = _objective(model, got), _objective(model, want)
         assert abs(zg - zw) <= 1e-9 * max(1.0, abs(zw)), (zg, zw)
 
