@@ -89,3 +89,48 @@ def test_host_stages_baseline_shapes_reduced(name, n_tasks, n_workers):
     if not (want.is_optimal and got.is_optimal):
         pytest.skip("a solver hit its limit")
     _same_host_part(got, want, o.last_model())
+
+
+def build_unsaturated(seed: int):
+    """a handful of workers of one or two kinds, several request shapes over up to three resources, fewer tasks than the cluster holds:
+    the coupled model with the batch-size rows binding ("Unsaturated ticks"), at sizes the canonical oracle still solves"""
+    from hyperqueue_amd.core import SchedEnv, WorkerBuilder as WB
+
+    rng = np.random.default_rng(seed)
+    cfg = abi.make_config(reserve=int(rng.integers(0, 3)), fill_max=int(rng.integers(1, 4)), time_limit_s=30.0)
+    e = SchedEnv(cfg)
+    names = ["gpus", "mem"][: int(rng.integers(0, 3))]
+    for n in names:
+        e.new_named_resource(n)
+    kinds = []
+    for _ in range(int(rng.integers(1, 3))):
+        wb = WB(int(rng.integers(8, 33)))
+        for n in names:
+            wb = wb.res_sum(n, int(rng.integers(2, 9)))
+        kinds.append(wb)
+    for _ in range(int(rng.integers(3, 9))):
+        e.new_worker(kinds[int(rng.integers(0, len(kinds)))])
+    shapes = []
+    for _ in range(int(rng.integers(2, 6))):
+        b = TB().cpus([1, 1, 2, 4, 8][int(rng.integers(0, 5))])
+        for ri in range(len(names)):
+            if rng.random() < 0.5:
+                b = b.add_resource(ri + 1, [0.25, 0.5, 1, 2][int(rng.integers(0, 4))])
+        shapes.append(b)
+    for _ in range(int(rng.integers(10, 120))):
+        e.new_task(shapes[int(rng.integers(0, len(shapes)))])
+    return cfg, e
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_host_stages_unsaturated(seed):
+    from oracle.oracle import Oracle
+
+    cfg, e = build_unsaturated(50_000 + seed)
+    o = Oracle(cfg, canonical=True)
+    snap = e.snapshot()
+    got = HostStages(cfg).stages(snap)
+    want = o.tick(snap)
+    if not (want.is_optimal and got.is_optimal):
+        pytest.skip("a solver hit its limit")
+    _same_host_part(got, want, o.last_model())

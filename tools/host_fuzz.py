@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Large CPU campaign of tests/test_host_stages.py: host stages (batches + placement) vs the canonical oracle on many more seeds, in parallel.
-  python tools/host_fuzz.py <family: fuzz|idle> <first seed> <n seeds> [processes]"""
+  python tools/host_fuzz.py <family: fuzz|idle|unsat> <first seed> <n seeds> [processes]"""
 import multiprocessing as mp
 import os
 import sys
@@ -14,7 +14,7 @@ def run(args):
     import test_host_stages as t
 
     try:
-        (t.test_host_stages_fuzz_scenarios if family == "fuzz" else t.test_host_stages_idle_cluster)(seed)
+        {"fuzz": t.test_host_stages_fuzz_scenarios, "idle": t.test_host_stages_idle_cluster, "unsat": t.test_host_stages_unsaturated}[family](seed)
         return (seed, "ok", "")
     except BaseException as e:  # pytest.skip raises a BaseException subclass
         kind = "skip" if type(e).__name__ == "Skipped" else "FAIL"
