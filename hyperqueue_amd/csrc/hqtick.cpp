@@ -1113,6 +1113,37 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
     return out->status;
 }
 
+int hqtick_debug_host_query(const hqtick_config *config, const hqtick_snapshot *s, const hqtick_query_workers *fake, const uint8_t *vflags, const uint32_t *vtmc,
+                            const uint8_t *fake_vflags, const uint32_t *fake_vtmc, uint32_t n_levels, const uint64_t *levels, const uint32_t *hist,
+                            hqtick_query_result *out) {
+    if (!config || !s || !fake || !out) return HQTICK_E_INVALID;
+    static thread_local hqtick_ctx *holder = nullptr;
+    if (!holder) holder = new hqtick_ctx();
+    hqtick_ctx *ctx = holder;
+    ctx->cfg = *config;
+    if (int rc = validate(ctx, s, false)) return rc;
+    const uint32_t R = s->n_resources, Q = s->n_requests;
+    WorkerEval ev; ev.flags = vflags; ev.tmc = vtmc;
+    hqhost::Problem pb;
+    fill_problem(pb, s, ctx->cfg, ev);
+    hqhost::WorkerSet fw;  // as in hqtick_query
+    fw.n = fake->n_workers; fw.R = R; fw.id = fake->worker_id; fw.total = fake->worker_total; fw.free_ = fake->worker_total;
+    fw.remaining_ns = fake->worker_remaining_ns; fw.min_util = fake->worker_min_utilization; fw.flags = nullptr; fw.group = nullptr;
+    fw.vflags = fake_vflags; fw.vtmc = fake_vtmc; fw.n_variant_slots = Q ? s->rq_variant_off[Q] : 0;
+    fw.blocked.assign(fw.n, {}); fw.assigned.assign(fw.n, {});
+    pb.custom = &fw;
+    Scan sc; sc.Q = Q; sc.L = n_levels; sc.G = n_levels * Q;
+    sc.levels.assign(levels, levels + n_levels); sc.hist.assign(hist, hist + (size_t)n_levels * Q);
+    std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
+    std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
+    hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
+    if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
+    ctx->q_loaded.assign(fake->n_workers, 0);
+    for (auto &k : cnt.per_key) for (auto &wc : k) if (wc.second > 0) ctx->q_loaded[wc.first] = 1;  // query.rs:73-81
+    out->n_workers = fake->n_workers; out->is_loaded = ctx->q_loaded.data(); out->is_optimal = cnt.is_optimal;
+    return 0;
+}
+
 int hqtick_set_shard(hqtick_ctx *ctx, uint32_t shard_index, uint32_t shard_count) {
     if (!ctx) return HQTICK_E_INVALID;
     if (shard_count > 1 && shard_index >= shard_count) return fail(ctx, HQTICK_E_INVALID, "shard_index >= shard_count");

@@ -31,6 +31,13 @@ int hqtick_debug_milp_solve(int ncols, const double *obj, const uint8_t *col_kin
 int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot *snapshot, const uint8_t *vflags, const uint32_t *vtmc,
                              uint32_t n_levels, const uint64_t *levels, const uint32_t *hist, hqtick_result *out);
 
+/* The host stages of hqtick_query (compute_new_worker_query, scheduler/query.rs:12-131) on caller-supplied scan outputs: as above, plus
+ * fake_vflags / fake_vtmc [fake->n_workers * NV] = what K2 writes for the fake workers (free == total).  Fills `out` (valid until the next call
+ * on this thread). */
+int hqtick_debug_host_query(const hqtick_config *config, const hqtick_snapshot *snapshot, const hqtick_query_workers *fake,
+                            const uint8_t *vflags, const uint32_t *vtmc, const uint8_t *fake_vflags, const uint32_t *fake_vtmc,
+                            uint32_t n_levels, const uint64_t *levels, const uint32_t *hist, hqtick_query_result *out);
+
 /* 1 if the last hqtick_debug_milp_solve on this thread completed its tie-break phase (Result::canonical, milp.h). */
 int hqtick_debug_milp_was_canonical(void);
 

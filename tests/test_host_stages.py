@@ -134,3 +134,34 @@ def test_host_stages_unsaturated(seed):
     if not (want.is_optimal and got.is_optimal):
         pytest.skip("a solver hit its limit")
     _same_host_part(got, want, o.last_model())
+
+
+class _QueryOnlyBackend:
+    """the reference's query tests call only `query`; anything else here would mean a test that needs the GPU stages"""
+
+    def __init__(self):
+        self._hs = {}
+
+    def query(self, snap, *a):
+        cfg = getattr(snap, "config", None) or abi.make_config()
+        key = (cfg.proactive_filling_reserve, cfg.proactive_filling_max)
+        if key not in self._hs:
+            self._hs[key] = HostStages(cfg)
+        return self._hs[key].query(snap, *a)
+
+    def tick(self, snap):  # a few query tests schedule first: the oracle stands in for the full tick, the query itself goes through the hook
+        from oracle.oracle import Oracle
+
+        return Oracle(getattr(snap, "config", None) or abi.make_config(), canonical=True).tick(snap)
+
+
+def _query_cases():
+    import golden_cases
+
+    return [c for c in golden_cases.ALL_CASES if c.__name__.startswith("test_query")]
+
+
+@pytest.mark.parametrize("case", _query_cases(), ids=lambda f: f.__name__)
+def test_reference_query_cases_through_host_hook(case):
+    """compute_new_worker_query (tests/test_query.rs, 22 cases) with the host stages of hqtick_query running on this machine"""
+    case(_QueryOnlyBackend())
