@@ -456,6 +456,46 @@ struct CompSolver {
         if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return false; }
         int j = pick_fractional(t);
         if (j < 0) { out.assign(t.x.begin(), t.x.begin() + n); for (auto &v : out) v = std::round(v); return true; }
+        if ((double)t.ma * (double)t.width() <= 4.0e6) {
+            // strong branching for the feasibility search: a probe of the tie-break phase is mostly a PROOF that nothing fits (the objective row pins
+            // the point to the optimal face); solving both children of the most valuable fractional columns finds the column whose children die
+            // soonest, and a column with one dead child is fixed on the spot
+            std::vector<std::pair<double, int>> cand;
+            for (int k = 0; k < n; k++) { double fr = std::fabs(t.x[k] - std::round(t.x[k])); if (fr > INT_TOL) cand.push_back({-t.cost[k], k}); }
+            std::sort(cand.begin(), cand.end());
+            if ((int)cand.size() > 16) cand.resize(16);
+            const double z = t.objective();
+            double best_score = -1.0; int best_k = -1;
+            for (auto &cd : cand) {
+                const int k = cd.second; const double vk = t.x[k];
+                if (std::fabs(vk - std::round(vk)) <= INT_TOL) continue;
+                if (time_up()) return false;
+                double dz[2]; bool dead[2];
+                for (int side = 0; side < 2; side++) {
+                    Tab c = t;
+                    work += (double)(t.ma + 1) * (double)t.width();
+                    if (side == 0) c.set_lb(k, std::ceil(vk - INT_TOL)); else c.set_ub(k, std::floor(vk + INT_TOL));
+                    const int cs = solve_counted(c);
+                    nodes++;
+                    if (cs == LP_LIMIT) { timed_out = true; return false; }
+                    dead[side] = cs != LP_OPT;
+                    dz[side] = dead[side] ? 1e9 : std::max(0.0, z - c.objective());
+                    if (!dead[side] && pick_fractional(c) < 0) { out.assign(c.x.begin(), c.x.begin() + n); for (auto &v : out) v = std::round(v); return true; }
+                }
+                if (dead[0] && dead[1]) return false;
+                if (dead[0] || dead[1]) {
+                    if (dead[0]) t.set_ub(k, std::floor(vk + INT_TOL)); else t.set_lb(k, std::ceil(vk - INT_TOL));
+                    const int cs = solve_counted(t);
+                    if (cs != LP_OPT) { if (cs == LP_LIMIT) timed_out = true; return false; }
+                    continue;
+                }
+                const double score = std::max(dz[0], 1e-9) * std::max(dz[1], 1e-9);
+                if (score > best_score) { best_score = score; best_k = k; }
+            }
+            j = pick_fractional(t);
+            if (j < 0) { out.assign(t.x.begin(), t.x.begin() + n); for (auto &v : out) v = std::round(v); return true; }
+            if (best_k >= 0 && best_score > 1e-15 && std::fabs(t.x[best_k] - std::round(t.x[best_k])) > INT_TOL) j = best_k;
+        }
         double v = t.x[j];
         {
             Tab up = t;
