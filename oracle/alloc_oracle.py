@@ -1,0 +1,835 @@
+"""CPU oracle of the worker-side `ResourceAllocator` -- TEST INFRASTRUCTURE ONLY.
+
+Only `tests/` may import this file; the product (`hyperqueue_amd/csrc/allocator.cpp` behind `include/hqalloc.h`)
+never does.  A plain-Python restatement of the reference, function by function (paths relative to
+/root/reference/crates/tako/src/internal/):
+
+    worker/resources/allocator.rs:32-227   ResourceAllocator::{new, try_allocate, release_allocation, is_enabled}
+    worker/resources/pool.rs:60-505        ResourcePool::{new, concise_state, claim_*, release_allocation}
+    worker/resources/concise.rs:26-203     ConciseResourceState / ConciseFreeResources
+    worker/resources/groups.rs:61-155      group_solver (the NUMA / coupling MILP)
+    common/resources/allocation.rs         Allocation / ResourceAllocation / AllocationIndex
+
+Third-party behaviour that is observable here and not under /root/reference:
+  * the iteration order of `Map<ResourceIndex, ResourceFractions>` (hashbrown 0.17.1 + fxhash 0.2.1, Cargo.lock) decides
+    which partially used index `best_fraction_match` (pool.rs:372-380) returns when several hold the same remainder;
+    `HbMap` below restates the published SwissTable algorithm (insertions, removals with tombstones, growth, in-place
+    rehash) -- the same spec as SURVEY.md App. C;
+  * `group_solver` hands a 0/1 model to HiGHS; where its optimum is not unique the group set HiGHS returns is an
+    artefact of that build.  The oracle enumerates the 0/1 vectors (<= 3 resources x <= 8 groups in practice) and
+    returns the canonical optimum of csrc/milp.h (ties: minimise the last column first), and `highs_objective`
+    re-solves the same model with scipy's HiGHS as a second opinion on the objective value.
+
+Pinned by the reference's 30 allocator tests, transcribed in tests/alloc_cases.py.
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+FRACTIONS_PER_UNIT = 10_000  # common/resources/amount.rs:7
+FAST_MAX_GROUPS = 8          # pool.rs:57
+MASK64 = (1 << 64) - 1
+
+# AllocationRequest kinds (common/resources/request.rs:14-21); numbering = include/hqtick.h entry kinds
+COMPACT, TIGHT, SCATTER, FORCE_COMPACT, FORCE_TIGHT, ALL = 0, 1, 2, 3, 4, 5
+
+
+def amount(units: int, fractions: int = 0) -> int:
+    """ResourceAmount::new (amount.rs:33-36)."""
+    assert 0 <= fractions < FRACTIONS_PER_UNIT
+    return units * FRACTIONS_PER_UNIT + fractions
+
+
+def split(a: int) -> Tuple[int, int]:
+    """ResourceAmount::split (amount.rs:79-81)."""
+    return a // FRACTIONS_PER_UNIT, a % FRACTIONS_PER_UNIT
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# hashbrown::HashMap<u32, u32, FxBuildHasher>: only what the pools use (insert of a new key, get_mut, remove, iter, clone)
+# ------------------------------------------------------------------------------------------------------------------
+class HbMap:
+    WIDTH = 16
+    EMPTY, DELETED = 0xFF, 0x80
+
+    def __init__(self):
+        self.nb = 0
+        self.items = 0
+        self.growth_left = 0
+        self.ctrl: List[int] = []
+        self.keys: List[int] = []
+        self.vals: List[int] = []
+
+    @staticmethod
+    def hash(key: int) -> int:
+        return ((key & 0xFFFFFFFF) * 0x517CC1B727220A95) & MASK64  # FxHasher::write_u32 from state 0
+
+    @staticmethod
+    def _capacity(nb: int) -> int:
+        return nb - 1 if nb <= 8 else nb // 8 * 7
+
+    @staticmethod
+    def _buckets_for(cap: int) -> int:
+        if cap < 4:
+            return 4
+        if cap < 8:
+            return 8
+        if cap < 15:
+            return 16
+        want, p = cap * 8 // 7, 1
+        while p < want:
+            p <<= 1
+        return p
+
+    def _alloc(self, nb: int):
+        self.nb = nb
+        self.ctrl = [self.EMPTY] * (nb + self.WIDTH)
+        self.keys = [0] * nb
+        self.vals = [0] * nb
+        self.growth_left = self._capacity(nb)
+        self.items = 0
+
+    def _set_ctrl(self, i: int, c: int):
+        self.ctrl[i] = c
+        self.ctrl[((i - self.WIDTH) & (self.nb - 1)) + self.WIDTH] = c
+
+    def _special_in_group(self, pos: int) -> int:
+        for b in range(self.WIDTH):
+            if self.ctrl[pos + b] & 0x80:
+                return b
+        return -1
+
+    def _insert_slot(self, h: int) -> int:
+        mask = self.nb - 1
+        pos, stride = h & mask, 0
+        while True:
+            b = self._special_in_group(pos)
+            if b >= 0:
+                idx = (pos + b) & mask
+                if not self.ctrl[idx] & 0x80:  # trailing mirror bytes of a table smaller than a group
+                    idx = self._special_in_group(0)
+                return idx
+            stride += self.WIDTH
+            pos = (pos + stride) & mask
+
+    def _find(self, key: int) -> int:
+        if self.nb == 0:
+            return -1
+        h = self.hash(key)
+        tag, mask = h >> 57, self.nb - 1
+        pos, stride = h & mask, 0
+        while True:
+            saw_empty = False
+            for b in range(self.WIDTH):
+                c = self.ctrl[pos + b]
+                if c == tag:
+                    idx = (pos + b) & mask
+                    if not self.ctrl[idx] & 0x80 and self.keys[idx] == key:
+                        return idx
+                elif c == self.EMPTY:
+                    saw_empty = True
+            if saw_empty:
+                return -1
+            stride += self.WIDTH
+            pos = (pos + stride) & mask
+
+    def _put(self, key: int, val: int):
+        h = self.hash(key)
+        idx = self._insert_slot(h)
+        if self.ctrl[idx] == self.EMPTY:
+            self.growth_left -= 1
+        self._set_ctrl(idx, h >> 57)
+        self.keys[idx], self.vals[idx] = key, val
+        self.items += 1
+
+    def _resize(self, cap: int):
+        live = [(self.keys[i], self.vals[i]) for i in range(self.nb) if not self.ctrl[i] & 0x80]
+        self._alloc(self._buckets_for(cap))
+        for k, v in live:
+            self._put(k, v)
+
+    def _rehash_in_place(self):
+        nb, mask, W = self.nb, self.nb - 1, self.WIDTH
+        for i in range(nb):
+            self.ctrl[i] = self.EMPTY if self.ctrl[i] & 0x80 else self.DELETED
+        if nb < W:
+            for i in range(nb, W):
+                self.ctrl[i] = self.EMPTY
+            for i in range(nb):
+                self.ctrl[W + i] = self.ctrl[i]
+        else:
+            for i in range(W):
+                self.ctrl[nb + i] = self.ctrl[i]
+        for i in range(nb):
+            if self.ctrl[i] != self.DELETED:
+                continue
+            while True:
+                h = self.hash(self.keys[i])
+                ni, home = self._insert_slot(h), h & mask
+                if ((i - home) & mask) // W == ((ni - home) & mask) // W:
+                    self._set_ctrl(i, h >> 57)
+                    break
+                prev = self.ctrl[ni]
+                self._set_ctrl(ni, h >> 57)
+                if prev == self.EMPTY:
+                    self._set_ctrl(i, self.EMPTY)
+                    self.keys[ni], self.vals[ni] = self.keys[i], self.vals[i]
+                    break
+                self.keys[i], self.keys[ni] = self.keys[ni], self.keys[i]
+                self.vals[i], self.vals[ni] = self.vals[ni], self.vals[i]
+        self.growth_left = self._capacity(nb) - self.items
+
+    def _reserve_one(self):
+        if self.growth_left >= 1:
+            return
+        if self.nb == 0:
+            self._alloc(self._buckets_for(1))
+            return
+        full = self._capacity(self.nb)
+        if self.items + 1 <= full // 2:
+            self._rehash_in_place()
+        else:
+            self._resize(max(self.items + 1, full + 1))
+
+    def insert(self, key: int, val: int):
+        """HashMap::insert: reserve(1) happens before the key is looked up."""
+        self._reserve_one()
+        i = self._find(key)
+        if i >= 0:
+            self.vals[i] = val
+        else:
+            self._put(key, val)
+
+    def get(self, key: int) -> Optional[int]:
+        i = self._find(key)
+        return None if i < 0 else self.vals[i]
+
+    def set(self, key: int, val: int):
+        i = self._find(key)
+        assert i >= 0
+        self.vals[i] = val
+
+    def remove(self, key: int):
+        i = self._find(key)
+        assert i >= 0
+        W, mask = self.WIDTH, self.nb - 1
+        before = (i - W) & mask
+        lead = 0
+        for b in range(W - 1, -1, -1):
+            if self.ctrl[before + b] == self.EMPTY:
+                break
+            lead += 1
+        trail = 0
+        for b in range(W):
+            if self.ctrl[i + b] == self.EMPTY:
+                break
+            trail += 1
+        if lead + trail >= W:
+            self._set_ctrl(i, self.DELETED)
+        else:
+            self._set_ctrl(i, self.EMPTY)
+            self.growth_left += 1
+        self.items -= 1
+
+    def items_in_order(self) -> List[Tuple[int, int]]:
+        return [(self.keys[i], self.vals[i]) for i in range(self.nb) if not self.ctrl[i] & 0x80]
+
+    def values(self) -> List[int]:
+        return [v for _, v in self.items_in_order()]
+
+    def __contains__(self, key: int) -> bool:
+        return self._find(key) >= 0
+
+    def __len__(self) -> int:
+        return self.items
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Descriptor / request / allocation records
+# ------------------------------------------------------------------------------------------------------------------
+EMPTY_POOL, INDICES_POOL, GROUPS_POOL, SUM_POOL = 0, 1, 2, 3
+
+
+@dataclass
+class PoolDesc:
+    """One `ResourceDescriptorItem` after label resolution (pool.rs:61-117): List -> positions 0..n-1, Range -> start..=end,
+    Groups -> positions of the flattened groups (worker/resources/map.rs:20-38), Sum -> size."""
+    kind: int = EMPTY_POOL
+    groups: List[List[int]] = field(default_factory=list)  # INDICES: one group
+    size: int = 0                                          # SUM: fixed-point size
+
+
+def range_pool(start: int, end: int) -> PoolDesc:
+    return PoolDesc(INDICES_POOL, [list(range(start, end + 1))])
+
+
+def simple_indices(size: int) -> PoolDesc:
+    """ResourceDescriptorKind::simple_indices (descriptor.rs:113-124)."""
+    return PoolDesc(SUM_POOL, size=0) if size == 0 else range_pool(0, size - 1)
+
+
+def regular_sockets(n_sockets: int, socket_size: int) -> PoolDesc:
+    """ResourceDescriptorKind::regular_sockets (descriptor.rs:40-58)."""
+    if n_sockets == 1:
+        return simple_indices(socket_size)
+    return PoolDesc(GROUPS_POOL, [list(range(s * socket_size, (s + 1) * socket_size)) for s in range(n_sockets)])
+
+
+def sum_pool(size: int) -> PoolDesc:
+    return PoolDesc(SUM_POOL, size=size)
+
+
+@dataclass
+class Descriptor:
+    pools: List[PoolDesc]                                   # indexed by ResourceId
+    coupling: List[Tuple[int, int, int, int, int]] = field(default_factory=list)  # (resource1, group1, resource2, group2, weight)
+
+
+@dataclass
+class Entry:
+    resource_id: int
+    kind: int
+    amount: int = 0
+
+
+def request(entries: Sequence[Entry]) -> List[Entry]:
+    """ResBuilder::finish (tests/utils/resources.rs:104-121): one cpu is added when resource 0 is missing; entries sorted by id."""
+    es = list(entries)
+    if not any(e.resource_id == 0 for e in es):
+        es.insert(0, Entry(0, COMPACT, amount(1)))
+    return sorted(es, key=lambda e: e.resource_id)
+
+
+@dataclass
+class AllocationIndex:
+    index: int
+    group_idx: int
+    fractions: int
+
+
+@dataclass
+class ResourceAllocation:
+    resource_id: int
+    amount: int
+    indices: List[AllocationIndex]
+
+
+@dataclass
+class Allocation:
+    resources: List[ResourceAllocation] = field(default_factory=list)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Pools (pool.rs)
+# ------------------------------------------------------------------------------------------------------------------
+class Pool:
+    def __init__(self, desc: PoolDesc):
+        self.kind = desc.kind
+        if desc.kind == INDICES_POOL:
+            self.indices = [list(desc.groups[0])]
+            self.fractions = [HbMap()]
+            self.full_size = amount(len(desc.groups[0]))
+        elif desc.kind == GROUPS_POOL:
+            self.indices = [list(g) for g in desc.groups]
+            self.fractions = [HbMap() for _ in desc.groups]
+            self.full_size = amount(sum(len(g) for g in desc.groups))
+        elif desc.kind == SUM_POOL:
+            self.full_size = desc.size
+            self.free = desc.size
+        else:
+            self.full_size = 0
+
+    def group_amounts(self) -> List[int]:
+        """pool.rs:27-37."""
+        return [amount(len(i), max(f.values(), default=0)) for i, f in zip(self.indices, self.fractions)]
+
+    def concise_state(self) -> List[List]:
+        """pool.rs:135-162; a concise group is [units, {index: fractions}] (order of that map is never observed)."""
+        if self.kind == EMPTY_POOL:
+            return []
+        if self.kind == SUM_POOL:
+            units, frac = split(self.free)
+            return [[units, {0: frac} if frac > 0 else {}]]
+        return [[len(i), dict(f.items_in_order())] for i, f in zip(self.indices, self.fractions)]
+
+    def current_free(self) -> int:
+        """pool.rs:555-566 (test helper)."""
+        if self.kind == EMPTY_POOL:
+            return 0
+        if self.kind == SUM_POOL:
+            return self.free
+        return amount(sum(len(g) for g in self.indices))
+
+    # -- helpers ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def best_fraction_match(fmap: HbMap, fractions: int) -> Optional[int]:
+        """pool.rs:372-380: first minimum, in the map's iteration order, among the entries with enough left."""
+        best = None
+        for k, f in fmap.items_in_order():
+            if f >= fractions and (best is None or f < best[1]):
+                best = (k, f)
+        return None if best is None else best[0]
+
+    @staticmethod
+    def take_indices(pool_indices: List[int], group: int, units: int, out: List[AllocationIndex]):
+        """pool.rs:305-318."""
+        for _ in range(units):
+            out.append(AllocationIndex(pool_indices.pop(), group, 0))
+
+    def take_fraction_index_or_split(self, g: int, fractions: int, out: List[AllocationIndex]):
+        """pool.rs:320-347."""
+        if fractions == 0:
+            return
+        fmap = self.fractions[g]
+        k = self.best_fraction_match(fmap, fractions)
+        if k is not None:
+            fmap.set(k, fmap.get(k) - fractions)
+            out.append(AllocationIndex(k, g, fractions))
+        else:
+            index = self.indices[g].pop()
+            fmap.insert(index, FRACTIONS_PER_UNIT - fractions)
+            out.append(AllocationIndex(index, g, fractions))
+
+    def try_take_fraction(self, g: int, fractions: int, out: List[AllocationIndex]) -> bool:
+        """pool.rs:349-370."""
+        if fractions == 0:
+            return False
+        fmap = self.fractions[g]
+        k = self.best_fraction_match(fmap, fractions)
+        if k is None:
+            return False
+        fmap.set(k, fmap.get(k) - fractions)
+        out.append(AllocationIndex(k, g, fractions))
+        return True
+
+    # -- claims -------------------------------------------------------------------------------------------------
+    def claim_all_from_groups(self) -> List[AllocationIndex]:
+        """pool.rs:164-178."""
+        out = []
+        for g, group in enumerate(self.indices):
+            out.extend(AllocationIndex(i, g, 0) for i in group)
+            self.indices[g] = []
+        return out
+
+    def claim_scatter_from_groups(self, amt: int, group_set: Optional[Sequence[int]]) -> List[AllocationIndex]:
+        """pool.rs:180-232."""
+        out: List[AllocationIndex] = []
+        units, fractions = split(amt)
+        index = 0
+        while units > 0 or fractions > 0:
+            g = group_set[index] if group_set is not None else index
+            if units > 0:
+                if self.indices[g]:
+                    units -= 1
+                    out.append(AllocationIndex(self.indices[g].pop(), g, 0))
+            else:
+                k = self.best_fraction_match(self.fractions[g], fractions)
+                if k is not None:
+                    self.fractions[g].set(k, self.fractions[g].get(k) - fractions)
+                    out.append(AllocationIndex(k, g, fractions))
+                    fractions = 0
+                elif self.indices[g]:
+                    i = self.indices[g].pop()
+                    self.fractions[g].insert(i, FRACTIONS_PER_UNIT - fractions)
+                    out.append(AllocationIndex(i, g, fractions))
+                    fractions = 0
+            index = (index + 1) % (len(group_set) if group_set is not None else len(self.indices))
+        out.sort(key=lambda i: (i.fractions, i.group_idx, i.index))
+        return out
+
+    def claim_compact_from_groups(self, amt: int, group_set: Optional[Sequence[int]]) -> List[AllocationIndex]:
+        """pool.rs:234-303."""
+        out: List[AllocationIndex] = []
+        remaining = amt
+        fraction_idx = None
+        amounts = self.group_amounts()
+        allowed = lambda i: group_set is None or i in group_set
+        while True:
+            fit = [(a, i) for i, a in enumerate(amounts) if a >= remaining and allowed(i)]
+            if fit:
+                g = min(fit, key=lambda t: t[0])[1]  # min_by_key: first minimum
+                units, fractions = split(remaining)
+                self.take_indices(self.indices[g], g, units, out)
+                self.take_fraction_index_or_split(g, fractions, out)
+                break
+            g, best = None, None
+            for i, a in enumerate(amounts):  # max_by_key: last maximum
+                if allowed(i) and (best is None or a >= best):
+                    g, best = i, a
+            amounts[g] = 0
+            units, fractions = split(remaining)
+            size = len(self.indices[g])
+            units -= size
+            assert units >= 0
+            self.take_indices(self.indices[g], g, size, out)
+            if self.try_take_fraction(g, fractions, out):
+                fraction_idx = len(out) - 1
+                fractions = 0
+            remaining = amount(units, fractions)
+        if fraction_idx is not None:
+            out[fraction_idx], out[-1] = out[-1], out[fraction_idx]
+        return out
+
+    def claim_resources_with_group_mask(self, resource_id: int, kind: int, amt: int, group_set: Sequence[int]) -> ResourceAllocation:
+        """pool.rs:382-405 -- note the naming: Compact/ForceCompact walk the groups round-robin, Tight/ForceTight fill them."""
+        assert self.kind == GROUPS_POOL
+        if kind in (COMPACT, FORCE_COMPACT):
+            idx = self.claim_scatter_from_groups(amt, group_set)
+        elif kind in (TIGHT, FORCE_TIGHT):
+            idx = self.claim_compact_from_groups(amt, group_set)
+        else:
+            raise AssertionError("unreachable")
+        return ResourceAllocation(resource_id, amt, idx)
+
+    def claim_resources(self, resource_id: int, kind: int, amt: int) -> ResourceAllocation:
+        """pool.rs:407-455."""
+        if self.kind == INDICES_POOL:
+            a = self.full_size if kind == ALL else amt
+            units, fractions = split(a)
+            out: List[AllocationIndex] = []
+            self.take_indices(self.indices[0], 0, units, out)
+            self.take_fraction_index_or_split(0, fractions, out)
+            return ResourceAllocation(resource_id, a, out)
+        if self.kind == GROUPS_POOL:
+            if kind == SCATTER:
+                return ResourceAllocation(resource_id, amt, self.claim_scatter_from_groups(amt, None))
+            if kind == ALL:
+                return ResourceAllocation(resource_id, self.full_size, self.claim_all_from_groups())
+            raise AssertionError("unreachable: claimed through the coupled solver")
+        if self.kind == SUM_POOL:
+            a = self.full_size if kind == ALL else amt
+            self.free -= a
+            return ResourceAllocation(resource_id, a, [])
+        raise AssertionError("unreachable")
+
+    def release_allocation(self, al: ResourceAllocation):
+        """pool.rs:457-501."""
+        if self.kind == SUM_POOL:
+            self.free += al.amount
+            assert self.free <= self.full_size and not al.indices
+            return
+        assert self.kind in (INDICES_POOL, GROUPS_POOL)
+        for ai in reversed(al.indices):
+            g = ai.group_idx
+            if self.kind == INDICES_POOL:
+                assert g == 0
+            if ai.fractions == 0:
+                self.indices[g].append(ai.index)
+            else:
+                f = self.fractions[g].get(ai.index) + ai.fractions
+                if f == FRACTIONS_PER_UNIT:
+                    self.fractions[g].remove(ai.index)
+                    self.indices[g].append(ai.index)
+                else:
+                    self.fractions[g].set(ai.index, f)
+
+    def validate(self):
+        """pool.rs:507-545."""
+        if self.kind in (INDICES_POOL, GROUPS_POOL):
+            flat = [i for g in self.indices for i in g]
+            assert len(set(flat)) == len(flat)
+            assert len(flat) <= self.full_size // FRACTIONS_PER_UNIT
+            for i in flat:
+                assert all(i not in f for f in self.fractions)
+            for f in self.fractions:
+                assert all(v < FRACTIONS_PER_UNIT for v in f.values())
+        elif self.kind == SUM_POOL:
+            assert self.free <= self.full_size
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Concise free resources (concise.rs)
+# ------------------------------------------------------------------------------------------------------------------
+class Concise:
+    def __init__(self, states: List[List[List]]):
+        self.states = states  # per resource: list of [units, {index: fractions}]
+
+    def clone(self) -> "Concise":
+        return Concise([[[u, dict(f)] for u, f in st] for st in self.states])
+
+    def _remove_fractions(self, r: int, g: int, index: int, fractions: int):
+        """concise.rs:31-46."""
+        grp = self.states[r][g]
+        old = grp[1].setdefault(index, 0)
+        if old < fractions:
+            grp[1][index] = FRACTIONS_PER_UNIT + old - fractions
+            assert grp[0] > 0
+            grp[0] -= 1
+        else:
+            grp[1][index] = old - fractions
+
+    def _add_fractions(self, r: int, g: int, index: int, fractions: int):
+        """concise.rs:78-92."""
+        grp = self.states[r][g]
+        v = grp[1].setdefault(index, 0) + fractions
+        if v >= FRACTIONS_PER_UNIT:
+            v -= FRACTIONS_PER_UNIT
+            grp[0] += 1
+        grp[1][index] = v
+
+    def _apply(self, ra: ResourceAllocation, sign: int):
+        """concise.rs:48-76 (remove) and :94-119 (add)."""
+        r = ra.resource_id
+        st = self.states[r]
+        frac_op = self._remove_fractions if sign < 0 else self._add_fractions
+        if len(st) == 1:
+            units, fractions = split(ra.amount)
+            if sign < 0:
+                assert st[0][0] >= units
+            st[0][0] += sign * units
+            if fractions > 0:
+                if not ra.indices:
+                    frac_op(r, 0, 0, fractions)
+                else:
+                    for ai in reversed(ra.indices):
+                        if ai.fractions == 0:
+                            break
+                        frac_op(r, 0, ai.index, ai.fractions)
+        else:
+            for ai in ra.indices:
+                if ai.fractions == 0:
+                    if sign < 0:
+                        assert st[ai.group_idx][0] > 0
+                    st[ai.group_idx][0] += sign
+                else:
+                    frac_op(r, ai.group_idx, ai.index, ai.fractions)
+
+    def remove(self, al: Allocation):
+        for ra in al.resources:
+            self._apply(ra, -1)
+
+    def add(self, al: Allocation):
+        for ra in al.resources:
+            self._apply(ra, +1)
+
+    def amount_max_alloc(self, r: int) -> int:
+        """concise.rs:130-134."""
+        st = self.states[r]
+        return amount(sum(g[0] for g in st), max((v for g in st for v in g[1].values()), default=0))
+
+    def amount_max_per_group(self, r: int) -> List[Tuple[int, int]]:
+        """concise.rs:136-141."""
+        return [(g[0], max(g[1].values(), default=0)) for g in self.states[r]]
+
+    def units_per_group(self, r: int) -> List[int]:
+        return [g[0] for g in self.states[r]]
+
+    def amount_sum(self, r: int) -> int:
+        """concise.rs:148-152 (test helper)."""
+        return sum(g[0] * FRACTIONS_PER_UNIT + sum(g[1].values()) for g in self.states[r])
+
+    def stripped(self, r: int) -> List[Tuple[int, Dict[int, int]]]:
+        """concise.rs:155-169."""
+        return [(g[0], {k: v for k, v in g[1].items() if v > 0}) for g in self.states[r]]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# group_solver (groups.rs:61-155)
+# ------------------------------------------------------------------------------------------------------------------
+@dataclass
+class GroupModel:
+    """The 0/1 model of groups.rs: bool columns per (coupled entry, group), Min rows, and per coupling weight a [0,1] column
+    u with u <= v1, u <= v2 (weights are u16 >= 0, so u = min(v1, v2) at every optimum)."""
+    obj: List[float]
+    var_of: List[List[int]]                       # per coupled entry: column of every group
+    rows: List[Tuple[float, List[Tuple[int, float]]]]  # (rhs, [(col, coef)]) all of type Min
+    links: List[Tuple[int, int, float]]           # (col v1, col v2, weight)
+
+
+def build_group_model(free: Concise, entries: Sequence[Entry], weights: Sequence[Tuple[int, int, int, int, float]]) -> GroupModel:
+    obj: List[float] = []
+    var_of: List[List[int]] = []
+    rows = []
+    for e in entries:
+        units, fractions = split(e.amount)
+        upg = free.units_per_group(e.resource_id)
+        if fractions == 0:  # groups.rs:72-84
+            vs = []
+            for u in upg:
+                vs.append(len(obj))
+                obj.append(-1024.0 - float(u) / 32.0)
+            rows.append((float(units), [(v, float(u)) for v, u in zip(vs, upg)]))
+        else:  # groups.rs:85-118
+            amounts = free.amount_max_per_group(e.resource_id)
+            second = False
+            vs = []
+            for (_, f) in amounts:
+                vs.append(len(obj))
+                if f >= fractions:
+                    second = True
+                    obj.append(-1024.0 + (float(f) / (float(FRACTIONS_PER_UNIT) / 16.0)))
+                else:
+                    obj.append(-1024.0)
+            rows.append((float(units + 1), [(v, float(u + 1 if f >= fractions else u)) for v, (u, f) in zip(vs, amounts)]))
+            if units > 0 and second:
+                rows.append((float(units), [(v, float(u)) for v, u in zip(vs, upg)]))
+        var_of.append(vs)
+    links = []
+    for (r1, g1, r2, g2, w) in weights:  # groups.rs:121-141
+        p1 = next((i for i, e in enumerate(entries) if e.resource_id == r1), None)
+        if p1 is None:
+            continue
+        p2 = next((i for i, e in enumerate(entries) if e.resource_id == r2), None)
+        if p2 is None:
+            continue
+        links.append((var_of[p1][g1], var_of[p2][g2], float(w)))
+    return GroupModel(obj, var_of, rows, links)
+
+
+def solve_group_model(m: GroupModel) -> Optional[Tuple[List[int], float]]:
+    """Exhaustive 0/1 search; canonical optimum of csrc/milp.h (the u columns come last and carry weight >= 0, so after them
+    the tie-break reads the v columns from the last one backwards)."""
+    n = len(m.obj)
+    assert n <= 22, "oracle enumerates; keep coupled requests small"
+    feasible = []
+    for bits in itertools.product((0, 1), repeat=n):
+        if any(sum(c * bits[v] for v, c in terms) < rhs - 1e-9 for rhs, terms in m.rows):
+            continue
+        val = sum(o * b for o, b in zip(m.obj, bits)) + sum(w for a, b, w in m.links if bits[a] and bits[b])
+        feasible.append((val, bits))
+    if not feasible:
+        return None
+    top = max(v for v, _ in feasible)
+    tol = 1e-9 * max(1.0, abs(top))
+    val, bits = min((fb for fb in feasible if fb[0] >= top - tol), key=lambda fb: tuple(reversed(fb[1])))
+    return list(bits), val
+
+
+def highs_objective(m: GroupModel) -> Optional[float]:
+    """Second opinion: the same model through scipy's HiGHS (the reference's solver family), objective value only."""
+    import numpy as np
+    from scipy.optimize import Bounds, LinearConstraint, milp
+
+    n, k = len(m.obj), len(m.links)
+    c = np.array(m.obj + [w for _, _, w in m.links])
+    A, lo = [], []
+    for rhs, terms in m.rows:
+        row = np.zeros(n + k)
+        for v, coef in terms:
+            row[v] += coef
+        A.append(row)
+        lo.append(rhs)
+    for j, (a, b, _) in enumerate(m.links):
+        for v in (a, b):
+            row = np.zeros(n + k)
+            row[v], row[n + j] = 1.0, -1.0
+            A.append(row)
+            lo.append(0.0)
+    integrality = np.array([1] * n + [0] * k)
+    res = milp(-c, constraints=LinearConstraint(np.array(A), np.array(lo), np.inf), integrality=integrality, bounds=Bounds(0, 1))
+    if res.status != 0:
+        return None
+    return float(-res.fun)
+
+
+def group_solver(free: Concise, entries: Sequence[Entry], weights) -> Optional[Tuple[List[List[int]], float]]:
+    m = build_group_model(free, entries, weights)
+    sol = solve_group_model(m)
+    if sol is None:
+        return None
+    bits, val = sol
+    return [[g for g, v in enumerate(vs) if bits[v] > 0.5] for vs in m.var_of], val
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ResourceAllocator (allocator.rs)
+# ------------------------------------------------------------------------------------------------------------------
+class ResourceAllocator:
+    def __init__(self, desc: Descriptor):
+        """allocator.rs:33-98 (resource names and labels are resolved by the caller: pools are indexed by ResourceId)."""
+        self.pools = [Pool(p) for p in desc.pools]
+        self.free_resources = Concise([p.concise_state() for p in self.pools])
+        self.coupling_weights = [(r1, g1, r2, g2, float(w)) for (r1, g1, r2, g2, w) in desc.coupling]
+        self.optional_objectives: Dict[Tuple, float] = {}
+        self.all_resources = self.free_resources.clone()
+
+    def _coupled(self, rq: Sequence[Entry]) -> List[Entry]:
+        return [e for e in rq if e.resource_id < len(self.pools) and self.pools[e.resource_id].kind == GROUPS_POOL and e.kind in (COMPACT, TIGHT, FORCE_COMPACT, FORCE_TIGHT)]
+
+    def has_resources_for_request(self, rq: Sequence[Entry]) -> bool:
+        """allocator.rs:115-167."""
+        for e in rq:
+            if e.resource_id >= len(self.pools):
+                return False
+            max_alloc = self.free_resources.amount_max_alloc(e.resource_id)
+            if e.kind == ALL:
+                if max_alloc != self.pools[e.resource_id].full_size:
+                    return False
+            elif e.amount > max_alloc:
+                return False
+        coupling = self._coupled(rq)
+        if all(e.kind not in (FORCE_COMPACT, FORCE_TIGHT) for e in coupling):
+            return True
+        sol = group_solver(self.free_resources, coupling, self.coupling_weights)
+        if sol is None:
+            return False
+        key = tuple((e.resource_id, e.kind, e.amount) for e in rq)
+        if key not in self.optional_objectives:
+            _, cost = group_solver(self.all_resources, coupling, self.coupling_weights)
+            self.optional_objectives[key] = cost - 0.1
+        return sol[1] >= self.optional_objectives[key]
+
+    is_enabled = has_resources_for_request  # allocator.rs:206-213
+
+    def claim_resources(self, rq: Sequence[Entry]) -> Allocation:
+        """allocator.rs:169-204."""
+        al = Allocation()
+        coupling = []
+        for e in rq:
+            pool = self.pools[e.resource_id]
+            if pool.kind == GROUPS_POOL and e.kind in (COMPACT, TIGHT, FORCE_COMPACT, FORCE_TIGHT):
+                coupling.append(e)
+                continue
+            al.resources.append(pool.claim_resources(e.resource_id, e.kind, e.amount))
+        if not coupling:
+            return al
+        groups, _ = group_solver(self.free_resources, coupling, self.coupling_weights)
+        for e, gs in zip(coupling, groups):
+            al.resources.append(self.pools[e.resource_id].claim_resources_with_group_mask(e.resource_id, e.kind, e.amount, gs))
+        al.resources.sort(key=lambda r: r.resource_id)
+        return al
+
+    def try_allocate(self, rq: Sequence[Entry]) -> Optional[Allocation]:
+        """allocator.rs:215-227."""
+        if not self.has_resources_for_request(rq):
+            return None
+        al = self.claim_resources(rq)
+        self.free_resources.remove(al)
+        return al
+
+    def release_allocation(self, al: Allocation):
+        """allocator.rs:104-113."""
+        self.free_resources.add(al)
+        for ra in al.resources:
+            self.pools[ra.resource_id].release_allocation(ra)
+
+    def force_claim_from_groups(self, resource: int, groups: Sequence[int], amt: int) -> Allocation:
+        """test_allocator.rs:24-39."""
+        al = Allocation([self.pools[resource].claim_resources_with_group_mask(resource, COMPACT, amt, list(groups))])
+        self.free_resources.remove(al)
+        return al
+
+    def validate(self):
+        """allocator.rs:229-235."""
+        for r, pool in enumerate(self.pools):
+            pool.validate()
+            got = [(u, {k: v for k, v in f.items() if v > 0}) for u, f in pool.concise_state()]
+            assert got == self.free_resources.stripped(r), (r, got, self.free_resources.stripped(r))
+
+    # -- helpers of the reference's tests -----------------------------------------------------------------------
+    def get_current_free(self, r: int) -> int:
+        return self.pools[r].current_free()
+
+    def concise_amount_sum(self, r: int) -> int:
+        """`allocator.pools[r].concise_state().amount_sum()`."""
+        return Concise([self.pools[r].concise_state()]).amount_sum(0)
+
+    def free_amount_sum(self, r: int) -> int:
+        """`allocator.free_resources.get(r).amount_sum()`."""
+        return self.free_resources.amount_sum(r)
+
+    def free_groups(self, r: int) -> List[Tuple[int, Dict[int, int]]]:
+        """`allocator.free_resources.get(r)` as [(units, {index: fractions})]."""
+        return [(g[0], dict(g[1])) for g in self.free_resources.states[r]]
