@@ -19,7 +19,27 @@ def hipcc() -> str:
     return "hipcc"
 
 
+ALLOC_LIB = os.path.join(HERE, "libhqalloc.so")
+ALLOC_SOURCES = ["allocator.cpp", "milp.cpp"]
+ALLOC_HEADERS = ["hb_table.h", "milp.h", os.path.join("..", "..", "include", "hqalloc.h")]
+
+
+def build_alloc(force: bool = False, verbose: bool = False) -> str:
+    """libhqalloc.so: the worker-side allocator (include/hqalloc.h).  Host-only on purpose -- worker nodes have no MI355X -- so
+    it is compiled with g++ and has no HIP dependency."""
+    srcs = [os.path.join(CSRC, s) for s in ALLOC_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in ALLOC_HEADERS]
+    if not force and os.path.exists(ALLOC_LIB) and all(os.path.getmtime(ALLOC_LIB) >= os.path.getmtime(d) for d in deps):
+        return ALLOC_LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", ALLOC_LIB] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return ALLOC_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    build_alloc(force, verbose)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):

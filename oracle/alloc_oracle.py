@@ -20,7 +20,7 @@ Third-party behaviour that is observable here and not under /root/reference:
     returns the canonical optimum of csrc/milp.h (ties: minimise the last column first), and `highs_objective`
     re-solves the same model with scipy's HiGHS as a second opinion on the objective value.
 
-Pinned by the reference's 30 allocator tests, transcribed in tests/alloc_cases.py.
+Pinned by the 26 tests of the reference's worker/resources/test_allocator.rs, transcribed in tests/alloc_cases.py.
 """
 from __future__ import annotations
 
@@ -417,9 +417,11 @@ class Pool:
         """pool.rs:180-232."""
         out: List[AllocationIndex] = []
         units, fractions = split(amt)
-        index = 0
+        index, idle = 0, 0
+        n_walk = len(group_set) if group_set is not None else len(self.indices)
         while units > 0 or fractions > 0:
             g = group_set[index] if group_set is not None else index
+            before = (units, fractions)
             if units > 0:
                 if self.indices[g]:
                     units -= 1
@@ -435,7 +437,9 @@ class Pool:
                     self.fractions[g].insert(i, FRACTIONS_PER_UNIT - fractions)
                     out.append(AllocationIndex(i, g, fractions))
                     fractions = 0
-            index = (index + 1) % (len(group_set) if group_set is not None else len(self.indices))
+            idle = 0 if (units, fractions) != before else idle + 1
+            assert idle <= n_walk, "a full walk over the groups served nothing (the reference would spin)"
+            index = (index + 1) % n_walk
         out.sort(key=lambda i: (i.fractions, i.group_idx, i.index))
         return out
 
@@ -458,6 +462,7 @@ class Pool:
             for i, a in enumerate(amounts):  # max_by_key: last maximum
                 if allowed(i) and (best is None or a >= best):
                     g, best = i, a
+            assert g is not None and amounts[g] > 0, "nothing left in the allowed groups (the reference would spin)"
             amounts[g] = 0
             units, fractions = split(remaining)
             size = len(self.indices[g])
