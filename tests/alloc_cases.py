@@ -486,4 +486,107 @@ def test_tight_scattering(api):
     assert r1[0].group_idx != r1[4].group_idx
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# End-to-end pins of the reference's pytest suite (paths relative to /root/reference/tests/): a worker with the given
+# `--cpus` / `--resource` / `--coupling`, one task at a time on an idle worker, the indices the task saw in
+# HQ_RESOURCE_VALUES_* grouped as the test groups them.  Labels there are strings; the allocator works on positions of the
+# flattened groups (worker/resources/map.rs:28-37), so a label's group is its position's group.
+def label_groups(api, groups):
+    """`[[1, 2, 3, 4], [11, ...]]` -> pool over positions + position -> label."""
+    flat = [x for g in groups for x in g]
+    pos, out = 0, []
+    for g in groups:
+        out.append(list(range(pos, pos + len(g))))
+        pos += len(g)
+    return api.PoolDesc(api.GROUPS_POOL, out, 0), flat
+
+
+def sizes_by_decade(al, r, labels):
+    """`groups()` of test_resources.py:565-569 / test_coupling.py:160-168: Counter(label // 10) values, sorted."""
+    c = {}
+    for i in get_indices(al, r):
+        c[labels[i] // 10] = c.get(labels[i] // 10, 0) + 1
+    return sorted(c.values())
+
+
+def test_e2e_tight_vs_compact_policy(api):
+    """test_resources.py:572-596"""
+    pool, labels = label_groups(api, [[1, 2, 3, 4], [11, 12, 13, 14], [21, 22, 23, 24]])
+    for kind, expect in ((api.TIGHT, [2, 4]), (api.FORCE_TIGHT, [2, 4]), (api.COMPACT, [3, 3]), (api.FORCE_COMPACT, [3, 3])):
+        ac = api.ResourceAllocator(api.Descriptor([pool]))
+        al = ac.try_allocate(rq(api, (0, kind, units(api, 6))))
+        assert sizes_by_decade(al, 0, labels) == expect
+        ac.release_allocation(al)
+        ac.validate()
+
+
+def test_e2e_fractional_force_compact(api):
+    """test_resources.py:599-606: a hundred 0.3 compact! tasks come and go, then 2.5 compact! takes groups of 1 and 2."""
+    pool, labels = label_groups(api, [[1, 2], [11, 12], [21, 22]])
+    ac = api.ResourceAllocator(api.Descriptor([pool]))
+    small = rq(api, (0, api.FORCE_COMPACT, api.amount(0, 3000)))
+    running = []
+    for _ in range(100):
+        al = ac.try_allocate(small)
+        if al is None:  # worker full: the oldest task ends
+            ac.release_allocation(running.pop(0))
+            al = ac.try_allocate(small)
+        assert al is not None
+        running.append(al)
+    for al in running:
+        ac.release_allocation(al)
+    ac.validate()
+    al = ac.try_allocate(rq(api, (0, api.FORCE_COMPACT, api.amount(2, 5000))))
+    assert sizes_by_decade(al, 0, labels) == [1, 2]
+
+
+def test_e2e_job_num_of_cpus(api):
+    """test_cpus.py:19-72 (worker `--cpus 3x4`)"""
+    ac = api.ResourceAllocator(api.Descriptor([api.regular_sockets(3, 4)]))
+    for kind, n, sockets in ((api.COMPACT, 1, 1), (api.SCATTER, 2, 2), (api.FORCE_COMPACT, 4, 1), (api.FORCE_COMPACT, 5, 2)):
+        al = ac.try_allocate(rq(api, (0, kind, units(api, n))))
+        idx = get_indices(al, 0)
+        assert len(idx) == n and len(set(x // 4 for x in idx)) == sockets
+        ac.release_allocation(al)
+    al = ac.try_allocate(rq(api, (0, api.ALL, 0)))
+    assert sorted(get_indices(al, 0)) == list(range(12))
+
+
+def test_e2e_coupling_alloc1(api):
+    """test_coupling.py:54-110: cpus [[1,2,3],[4,5,6]] coupled group-wise with foo [[10,20,30,40],[50,60,70,80]];
+    `cpus=1` + `foo=3 compact!` (then `foo=1 compact!`) always lands in one NUMA group."""
+    cpus, cl = label_groups(api, [[1, 2, 3], [4, 5, 6]])
+    foo, fl = label_groups(api, [[10, 20, 30, 40], [50, 60, 70, 80]])
+    ac = api.ResourceAllocator(api.Descriptor([cpus, api.sum_pool(units(api, 123)), foo], [(0, 0, 2, 0, 256), (0, 1, 2, 1, 256)]))
+    for n_foo in (3, 1):
+        running = []
+        for _ in range(50):
+            r = rq(api, (0, api.COMPACT, units(api, 1)), (2, api.FORCE_COMPACT, units(api, n_foo)))
+            al = ac.try_allocate(r)
+            while al is None:
+                ac.release_allocation(running.pop(0))
+                al = ac.try_allocate(r)
+            g = set(cl[i] // 4 for i in get_indices(al, 0)) | set(fl[i] // 50 for i in get_indices(al, 2))
+            assert len(g) == 1
+            running.append(al)
+        for al in running:
+            ac.release_allocation(al)
+        ac.validate()
+
+
+def test_e2e_coupling_combined(api):
+    """test_coupling.py:154-199: the seven (cpus policy, foo policy) rows on an idle worker."""
+    cpus, cl = label_groups(api, [[1, 2, 3, 4], [11, 12, 13, 14], [21, 22, 23, 24]])
+    foo, fl = label_groups(api, [[1, 2], [10, 11], [22, 21]])
+    coupling = [(0, g, 1, g, 256) for g in range(3)]
+    T, S, Cp = api.TIGHT, api.SCATTER, api.COMPACT
+    for kc, kf, expect in ((T, T, ([2, 4], [2])), (S, S, ([2, 2, 2], [1, 1])), (Cp, Cp, ([3, 3], [2])), (T, Cp, ([2, 4], [2])),
+                           (Cp, T, ([3, 3], [2])), (S, T, ([2, 2, 2], [2])), (S, Cp, ([2, 2, 2], [2]))):
+        ac = api.ResourceAllocator(api.Descriptor([cpus, foo], coupling))
+        al = ac.try_allocate(rq(api, (0, kc, units(api, 6)), (1, kf, units(api, 2))))
+        assert (sizes_by_decade(al, 0, cl), sizes_by_decade(al, 1, fl)) == expect, (kc, kf)
+        ac.release_allocation(al)
+        ac.validate()
+
+
 CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]
