@@ -165,3 +165,54 @@ def _query_cases():
 def test_reference_query_cases_through_host_hook(case):
     """compute_new_worker_query (tests/test_query.rs, 22 cases) with the host stages of hqtick_query running on this machine"""
     case(_QueryOnlyBackend())
+
+
+class _ShadowBackend:
+    """Every tick of a reference case: the canonical oracle produces the full result the case asserts on; the product's host stages
+    (batches + placement through hqtick_debug_host_stages) run on the same snapshot and must give the same batches and counts."""
+
+    def __init__(self):
+        self._o, self._hs, self.flags, self.ticks = {}, {}, [], 0
+
+    def _pair(self, snap):
+        from oracle.oracle import Oracle
+
+        cfg = getattr(snap, "config", None) or abi.make_config()
+        key = (cfg.proactive_filling_reserve, cfg.proactive_filling_max)
+        if key not in self._o:
+            self._o[key], self._hs[key] = Oracle(cfg, canonical=True), HostStages(cfg)
+        return self._o[key], self._hs[key]
+
+    def tick(self, snap):
+        o, hs = self._pair(snap)
+        want = o.tick(snap)
+        got = hs.stages(snap)
+        _same_host_part(got, want, o.last_model())
+        self.flags.append(got.is_canonical == got.is_optimal)
+        self.ticks += 1
+        return want
+
+    def batches(self, snap):
+        o, hs = self._pair(snap)
+        want = o.batches(snap)
+        assert hs.stages(snap).batches == want
+        return want
+
+    def query(self, snap, *a):
+        return self._pair(snap)[1].query(snap, *a)
+
+
+def _tick_cases():
+    import golden_cases
+
+    slow = ("test_many_cuts", "test_schedule_many_distinct_shapes_stays_bounded")  # canonicalising 600 / 1200 columns with one HiGHS call each
+    return [c for c in golden_cases.ALL_CASES if not c.__name__.startswith("test_query") and c.__name__ not in slow]
+
+
+@pytest.mark.parametrize("case", _tick_cases(), ids=lambda f: f.__name__)
+def test_reference_cases_host_stages_shadow(case):
+    """the reference's scheduler tests (sn, mn, batches, end-to-end) on CPU: the product's batches + placement equal the canonical oracle's on
+    every tick, and the tie-break phase completes (the assertion tests/test_gpu_golden.py makes on the GPU)"""
+    b = _ShadowBackend()
+    case(b)
+    assert all(b.flags), "tie-break phase cut short on a reference-sized model"
