@@ -8,8 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhqtick.so")
-SOURCES = ["hqtick.cpp", "host_model.cpp", "milp.cpp", "debug_capi.cpp", "kernels.hip", "graph.hip"]
-HEADERS = ["kernels.h", "graph.h", "devbuf.h", "host_model.h", "milp.h", "hb_order.h", os.path.join("..", "..", "include", "hqtick.h"), os.path.join("..", "..", "include", "hqtick_debug.h")]
+SOURCES = ["hqtick.cpp", "host_model.cpp", "milp.cpp", "debug_capi.cpp", "kernels.hip", "graph.hip", "wire.hip"]
+HEADERS = ["kernels.h", "graph.h", "devbuf.h", "host_model.h", "milp.h", "hb_order.h", "wire_core.h", os.path.join("..", "..", "include", "hqwire.h"), os.path.join("..", "..", "include", "hqtick.h"), os.path.join("..", "..", "include", "hqtick_debug.h")]
 
 
 def hipcc() -> str:

@@ -1,0 +1,430 @@
+// Wire encoding of the tick's worker messages (include/hqwire.h): the phases of the three kernels.
+//
+// Each kernel is a fixed sequence of PHASES separated by workgroup barriers; inside a phase a thread depends on no other thread of the
+// same phase (LDS atomics apart).  The phases are plain functions of (arguments, LDS block, slot, tid), compiled for the device (kernels in
+// wire.hip) and for the host, where the debug hook of include/hqtick_debug.h runs them for tid = 0..255 in turn -- so the CPU test suite
+// executes the very same code the GPU does, minus the hardware.  Byte layout: bincode 1.3.3 fixint, little endian
+// (/root/reference/crates/tako/src/internal/transfer/auth.rs:253-263); struct field order: messages/worker.rs:27-57.
+#pragma once
+#include <cstdint>
+
+#include "../../include/hqwire.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HQW_HD __host__ __device__ inline
+#else
+#define HQW_HD inline
+#endif
+
+namespace hqwire {
+
+constexpr int BLOCK = 256;
+constexpr uint32_t HT = 4096, NONE = 0xFFFFFFFFu, MAXREC = HQWIRE_MAX_RECORDS;
+static_assert(HT >= 2 * MAXREC, "dedup table load factor <= 0.5");
+
+struct Args {
+    hqwire_tables t;
+    hqwire_records r;
+    hqwire_output o;
+    uint32_t n_slots;
+    // views into o.scratch
+    uint64_t *slot_len;    // [2 * n_slots] bytes of the RetractTasks / ComputeTasks message of every slot
+    uint32_t *slot_ncfg;   // [n_slots]     distinct configurations of the slot's ComputeTasks message
+    uint32_t *rec_row;     // [n_rec]       row of the record's task in the attribute table
+    uint32_t *rec_shared;  // [n_rec]       shared_index of the record
+    uint32_t *cfg_list;    // [n_rec]       slot's configurations in first-occurrence order, at [slot's first record + k]
+};
+
+HQW_HD uint64_t scratch_bytes(uint64_t n_rec, uint64_t n_slots) { return 16 * n_slots + 4 * ((n_slots + 1) & ~1ull) + 12 * n_rec + 16; }
+
+HQW_HD void bind_scratch(Args &a) {
+    uint8_t *p = (uint8_t *)a.o.scratch;
+    const uint64_t n_rec = (uint64_t)a.r.n_records + a.r.n_mn;
+    a.slot_len = (uint64_t *)p;
+    p += 16 * (uint64_t)a.n_slots;
+    a.slot_ncfg = (uint32_t *)p;
+    p += 4 * (((uint64_t)a.n_slots + 1) & ~1ull);
+    a.rec_row = (uint32_t *)p;
+    a.rec_shared = a.rec_row + n_rec;
+    a.cfg_list = a.rec_shared + n_rec;
+}
+
+// ---- what one message slot covers -------------------------------------------------------------------------------------------------------
+struct Slot {
+    uint32_t rec0, n;   // records [rec0, rec0 + n) in the scratch numbering (multi-node tasks follow the workers' records)
+    uint32_t n_retract, retract0;
+    bool mn;
+    uint32_t mn_k;
+};
+HQW_HD Slot slot_of(const Args &a, uint32_t s) {
+    Slot v{};
+    if (s < a.r.n_workers) {
+        v.rec0 = a.r.rec_off[s];
+        v.n = a.r.rec_off[s + 1] - v.rec0;
+        if (a.r.retract_off) {
+            v.retract0 = a.r.retract_off[s];
+            v.n_retract = a.r.retract_off[s + 1] - v.retract0;
+        }
+    } else {
+        v.mn = true;
+        v.mn_k = s - a.r.n_workers;
+        v.rec0 = a.r.n_records + v.mn_k;
+        v.n = 1;
+    }
+    return v;
+}
+struct Rec {
+    uint64_t task;
+    bool variant_some;
+    uint8_t variant;
+    uint32_t n_nodes, node0;
+};
+HQW_HD Rec rec_of(const Args &a, const Slot &s, uint32_t i) {  // i: index inside the slot
+    Rec r{};
+    if (s.mn) {  // ComputeTasksBuilder::single_task(task, 0.into(), worker_ids)   mapping.rs:284-291
+        r.task = a.r.mn_task[s.mn_k];
+        r.variant_some = true;
+        r.variant = 0;
+        r.node0 = a.r.mn_worker_off[s.mn_k];
+        r.n_nodes = a.r.mn_worker_off[s.mn_k + 1] - r.node0;
+    } else {
+        r.task = a.r.rec_task[s.rec0 + i];
+        r.variant_some = a.r.rec_kind[s.rec0 + i] != 0;  // prefills travel with variant None   mapping.rs:267-272
+        r.variant = a.r.rec_variant[s.rec0 + i];
+    }
+    return r;
+}
+HQW_HD void run_of(uint32_t n, int tid, uint32_t &lo, uint32_t &hi) {  // contiguous share of thread tid
+    const uint32_t per = (n + BLOCK - 1) / BLOCK;
+    lo = (uint32_t)tid * per < n ? (uint32_t)tid * per : n;
+    hi = lo + per < n ? lo + per : n;
+}
+
+// ---- sizes (messages/worker.rs:27-45; estimates: server/task.rs:405-433) -------------------------------------------------------------------
+HQW_HD uint64_t entry_len(const Args &a, uint32_t row) { return a.t.entry_some[row] ? a.t.entry_off[row + 1] - a.t.entry_off[row] : 0; }
+HQW_HD uint64_t rec_bytes(const Args &a, const Rec &r, uint32_t row) {
+    return 42 + (r.variant_some ? 1 : 0) + 4ull * r.n_nodes + (a.t.entry_some[row] ? 8 + entry_len(a, row) : 0);
+}
+HQW_HD uint64_t rec_estimate(const Args &a, const Rec &r, uint32_t row) { return 34 + 4ull * r.n_nodes + entry_len(a, row); }
+HQW_HD uint64_t body_len(const Args &a, uint32_t cfg) { return a.t.body_off[cfg + 1] - a.t.body_off[cfg]; }
+HQW_HD uint64_t shared_bytes(const Args &a, uint32_t cfg) { return 1 + (a.t.config_time_some[cfg] ? 12 : 0) + 8 + body_len(a, cfg); }
+HQW_HD uint64_t shared_estimate(const Args &a, uint32_t cfg) { return 16 + body_len(a, cfg); }
+
+// ---- little-endian stores at any alignment -------------------------------------------------------------------------------------------------
+HQW_HD uint8_t *put8(uint8_t *p, uint8_t v) {
+    *p = v;
+    return p + 1;
+}
+HQW_HD uint8_t *put32(uint8_t *p, uint32_t v) {
+    for (int b = 0; b < 4; b++) p[b] = (uint8_t)(v >> (8 * b));
+    return p + 4;
+}
+HQW_HD uint8_t *put64(uint8_t *p, uint64_t v) {
+    for (int b = 0; b < 8; b++) p[b] = (uint8_t)(v >> (8 * b));
+    return p + 8;
+}
+
+// ---- LDS atomics (plain on the host, where the phases run one thread at a time) ------------------------------------------------------------
+HQW_HD uint32_t lds_cas(uint32_t *p, uint32_t expect, uint32_t val) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicCAS(p, expect, val);
+#else
+    const uint32_t old = *p;
+    if (old == expect) *p = val;
+    return old;
+#endif
+}
+HQW_HD void lds_min(uint32_t *p, uint32_t val) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, val);
+#else
+    if (val < *p) *p = val;
+#endif
+}
+
+HQW_HD uint32_t find_row(const Args &a, uint64_t task) {  // lower bound in the ascending id column
+    uint64_t lo = 0, hi = a.t.n_tasks;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a.t.task_id[mid] < task) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < a.t.n_tasks && a.t.task_id[lo] == task ? (uint32_t)lo : NONE;
+}
+HQW_HD uint32_t hash_cfg(uint32_t cfg) { return (cfg * 2654435761u) >> 20; }  // 12 bits = HT
+
+// =========================================================================================================================================
+// Kernel 1 "plan": one workgroup per slot.  Row lookup, per-message configuration dedup (ComputeTasksBuilder::configuration_index,
+// task.rs:327,346-359: shared_index = rank of the configuration's first occurrence in the message), byte lengths.
+// =========================================================================================================================================
+struct PlanLds {
+    uint32_t key[HT], val[HT];  // configuration -> index (inside the slot) of its first record; later -> its rank
+    uint32_t cfg_list[MAXREC];
+    uint8_t first[MAXREC];
+    uint64_t part_bytes[BLOCK], part_est[BLOCK];
+    uint32_t part_cnt[BLOCK], base_cnt[BLOCK];
+    uint64_t rec_total, est_total;
+    uint32_t n_cfg, bad;
+};
+
+HQW_HD uint32_t ht_find(const PlanLds &l, uint32_t cfg) {
+    uint32_t h = hash_cfg(cfg);
+    while (l.key[h] != cfg) h = (h + 1) & (HT - 1);
+    return h;
+}
+
+HQW_HD void plan_p0(const Args &, PlanLds &l, uint32_t, int tid) {
+    for (uint32_t j = (uint32_t)tid; j < HT; j += BLOCK) l.key[j] = l.val[j] = NONE;
+    if (tid == 0) {
+        l.bad = HQWIRE_SLOT_OK;
+        l.n_cfg = 0;
+        l.rec_total = l.est_total = 0;
+    }
+}
+HQW_HD void plan_p1(const Args &a, PlanLds &l, uint32_t s, int tid) {
+    const Slot sv = slot_of(a, s);
+    l.part_bytes[tid] = l.part_est[tid] = 0;
+    if (sv.n > MAXREC) {
+        if (tid == 0) l.bad = HQWIRE_SLOT_TOO_MANY;
+        return;
+    }
+    uint32_t lo, hi;
+    run_of(sv.n, tid, lo, hi);
+    uint64_t bytes = 0, est = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        const Rec r = rec_of(a, sv, i);
+        uint32_t row = find_row(a, r.task);
+        if (row != NONE && a.t.task_config[row] >= a.t.n_configs) row = NONE;
+        a.rec_row[sv.rec0 + i] = row;
+        if (row == NONE) {
+            l.bad = HQWIRE_SLOT_UNKNOWN;  // same value from every thread that stores it
+            continue;
+        }
+        bytes += rec_bytes(a, r, row);
+        est += rec_estimate(a, r, row);
+        const uint32_t cfg = a.t.task_config[row];
+        for (uint32_t h = hash_cfg(cfg);; h = (h + 1) & (HT - 1)) {
+            const uint32_t prev = lds_cas(&l.key[h], NONE, cfg);
+            if (prev == NONE || prev == cfg) {
+                lds_min(&l.val[h], i);
+                break;
+            }
+        }
+    }
+    l.part_bytes[tid] = bytes;
+    l.part_est[tid] = est;
+}
+HQW_HD void plan_p2(const Args &a, PlanLds &l, uint32_t s, int tid) {
+    const Slot sv = slot_of(a, s);
+    l.part_cnt[tid] = 0;
+    if (sv.n > MAXREC) return;
+    uint32_t lo, hi, cnt = 0;
+    run_of(sv.n, tid, lo, hi);
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t row = a.rec_row[sv.rec0 + i];  // written by this thread in p1
+        const bool f = row != NONE && l.val[ht_find(l, a.t.task_config[row])] == i;
+        l.first[i] = f ? 1 : 0;
+        cnt += f ? 1 : 0;
+    }
+    l.part_cnt[tid] = cnt;
+}
+HQW_HD void plan_p3(const Args &, PlanLds &l, uint32_t, int tid) {
+    if (tid != 0) return;
+    uint32_t c = 0;
+    uint64_t b = 0, e = 0;
+    for (int t = 0; t < BLOCK; t++) {
+        l.base_cnt[t] = c;
+        c += l.part_cnt[t];
+        b += l.part_bytes[t];
+        e += l.part_est[t];
+    }
+    l.n_cfg = c;
+    l.rec_total = b;
+    l.est_total = e;
+}
+HQW_HD void plan_p4(const Args &a, PlanLds &l, uint32_t s, int tid) {
+    const Slot sv = slot_of(a, s);
+    if (sv.n > MAXREC) return;
+    uint32_t lo, hi, k = l.base_cnt[tid];
+    run_of(sv.n, tid, lo, hi);
+    for (uint32_t i = lo; i < hi; i++) {
+        if (!l.first[i]) continue;
+        const uint32_t cfg = a.t.task_config[a.rec_row[sv.rec0 + i]];
+        l.val[ht_find(l, cfg)] = k;  // from here on the table maps configuration -> shared_index (nobody reads first-indices any more)
+        l.cfg_list[k] = cfg;
+        a.cfg_list[sv.rec0 + k] = cfg;
+        k++;
+    }
+}
+HQW_HD void plan_p5(const Args &a, PlanLds &l, uint32_t s, int tid) {
+    const Slot sv = slot_of(a, s);
+    l.part_bytes[tid] = l.part_est[tid] = 0;
+    if (sv.n > MAXREC) return;
+    uint32_t lo, hi;
+    run_of(sv.n, tid, lo, hi);
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t row = a.rec_row[sv.rec0 + i];
+        a.rec_shared[sv.rec0 + i] = row == NONE ? NONE : l.val[ht_find(l, a.t.task_config[row])];
+    }
+    uint64_t bytes = 0, est = 0;
+    for (uint32_t k = (uint32_t)tid; k < l.n_cfg; k += BLOCK) {
+        bytes += shared_bytes(a, l.cfg_list[k]);
+        est += shared_estimate(a, l.cfg_list[k]);
+    }
+    l.part_bytes[tid] = bytes;
+    l.part_est[tid] = est;
+}
+HQW_HD void plan_p6(const Args &a, PlanLds &l, uint32_t s, int tid) {
+    if (tid != 0) return;
+    const Slot sv = slot_of(a, s);
+    uint64_t sh = 0, est = l.est_total;
+    for (int t = 0; t < BLOCK; t++) {
+        sh += l.part_bytes[t];
+        est += l.part_est[t];
+    }
+    uint32_t status = l.bad;
+    if (status == HQWIRE_SLOT_OK && est > HQWIRE_MAX_TASK_MSG_SIZE) status = HQWIRE_SLOT_OVERSIZE;  // create_message_on_overflow  task.rs:388-400
+    a.o.slot_status[s] = (uint8_t)status;
+    a.slot_ncfg[s] = l.n_cfg;
+    a.slot_len[2 * s] = sv.n_retract ? 12 + 8ull * sv.n_retract : 0;                                  // tag + len + ids
+    a.slot_len[2 * s + 1] = (status == HQWIRE_SLOT_OK && sv.n) ? 4 + 8 + l.rec_total + 8 + sh : 0;    // tag + len + tasks + len + shared
+}
+
+// =========================================================================================================================================
+// Kernel 2 "scan": one workgroup.  Exclusive scan of the 2 * n_slots message lengths -> slot_off, header.
+// =========================================================================================================================================
+struct ScanLds {
+    uint64_t part[BLOCK], base[BLOCK];
+};
+HQW_HD void scan_p1(const Args &a, ScanLds &l, int tid) {
+    uint32_t lo, hi;
+    run_of(2 * a.n_slots, tid, lo, hi);
+    uint64_t sum = 0;
+    for (uint32_t j = lo; j < hi; j++) sum += a.slot_len[j];
+    l.part[tid] = sum;
+}
+HQW_HD void scan_p2(const Args &a, ScanLds &l, int tid) {
+    if (tid != 0) return;
+    uint64_t run = 0;
+    for (int t = 0; t < BLOCK; t++) {
+        l.base[t] = run;
+        run += l.part[t];
+    }
+    a.o.slot_off[2 * (uint64_t)a.n_slots] = run;
+    a.o.header[0] = run > a.o.capacity ? HQWIRE_CAPACITY : HQWIRE_OK;
+    a.o.header[1] = a.n_slots;
+    a.o.header[2] = (uint32_t)run;
+    a.o.header[3] = (uint32_t)(run >> 32);
+}
+HQW_HD void scan_p3(const Args &a, ScanLds &l, int tid) {
+    uint32_t lo, hi;
+    run_of(2 * a.n_slots, tid, lo, hi);
+    uint64_t run = l.base[tid];
+    for (uint32_t j = lo; j < hi; j++) {
+        a.o.slot_off[j] = run;
+        run += a.slot_len[j];
+    }
+}
+
+// =========================================================================================================================================
+// Kernel 3 "emit": one workgroup per slot writes its messages.
+// =========================================================================================================================================
+struct EmitLds {
+    uint64_t part_rec[BLOCK], part_sh[BLOCK], base_rec[BLOCK], base_sh[BLOCK];
+    uint32_t body_rel[MAXREC];  // offset of shared entry k's body inside the ComputeTasks message
+    uint64_t rec_total;
+};
+HQW_HD bool emit_active(const Args &a, uint32_t s) { return a.o.header[0] == HQWIRE_OK && a.slot_len[2 * s + 1] != 0; }
+
+HQW_HD void emit_p1(const Args &a, EmitLds &l, uint32_t s, int tid) {
+    const Slot sv = slot_of(a, s);
+    l.part_rec[tid] = l.part_sh[tid] = 0;
+    if (a.o.header[0] != HQWIRE_OK) return;
+    if (a.slot_len[2 * s]) {  // ToWorkerMessage::RetractTasks(TaskIdsMsg { ids })   mapping.rs:261-266
+        uint8_t *m = a.o.bytes + a.o.slot_off[2 * s];
+        if (tid == 0) put64(put32(m, 1), sv.n_retract);
+        for (uint32_t j = (uint32_t)tid; j < sv.n_retract; j += BLOCK) {
+            const uint64_t id = a.r.retract_task[sv.retract0 + j];
+            put32(put32(m + 12 + 8ull * j, (uint32_t)(id >> 32)), (uint32_t)id);
+        }
+    }
+    if (!emit_active(a, s)) return;
+    uint32_t lo, hi;
+    run_of(sv.n, tid, lo, hi);
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += rec_bytes(a, rec_of(a, sv, i), a.rec_row[sv.rec0 + i]);
+    l.part_rec[tid] = sum;
+    run_of(a.slot_ncfg[s], tid, lo, hi);
+    sum = 0;
+    for (uint32_t k = lo; k < hi; k++) sum += shared_bytes(a, a.cfg_list[sv.rec0 + k]);
+    l.part_sh[tid] = sum;
+}
+HQW_HD void emit_p2(const Args &a, EmitLds &l, uint32_t s, int tid) {
+    if (tid != 0 || !emit_active(a, s)) return;
+    uint64_t r = 0, h = 0;
+    for (int t = 0; t < BLOCK; t++) {
+        l.base_rec[t] = r;
+        r += l.part_rec[t];
+        l.base_sh[t] = h;
+        h += l.part_sh[t];
+    }
+    l.rec_total = r;
+    const Slot sv = slot_of(a, s);
+    uint8_t *m = a.o.bytes + a.o.slot_off[2 * s + 1];
+    put64(put32(m, 0), sv.n);                      // ToWorkerMessage::ComputeTasks, tasks.len()
+    put64(m + 12 + r, a.slot_ncfg[s]);             // shared_data.len()
+}
+HQW_HD void emit_p3(const Args &a, EmitLds &l, uint32_t s, int tid) {
+    if (!emit_active(a, s)) return;
+    const Slot sv = slot_of(a, s);
+    uint8_t *m = a.o.bytes + a.o.slot_off[2 * s + 1];
+    uint32_t lo, hi;
+    run_of(sv.n, tid, lo, hi);
+    uint8_t *p = m + 12 + l.base_rec[tid];
+    for (uint32_t i = lo; i < hi; i++) {  // ComputeTaskSeparateData   messages/worker.rs:27-39
+        const Rec r = rec_of(a, sv, i);
+        const uint32_t row = a.rec_row[sv.rec0 + i];
+        p = put64(p, a.rec_shared[sv.rec0 + i]);                                    // shared_index: usize
+        p = put32(put32(p, (uint32_t)(r.task >> 32)), (uint32_t)r.task);             // id: TaskId { job_id, job_task_id }
+        p = put32(p, a.t.task_rq[row]);                                             // resource_rq_id
+        p = put8(p, r.variant_some ? 1 : 0);                                        // resource_rq_variant: Option<u8>
+        if (r.variant_some) p = put8(p, r.variant);
+        p = put32(p, a.t.task_instance[row]);                                       // instance_id
+        p = put64(p, a.t.task_priority[row]);                                       // priority
+        p = put64(p, r.n_nodes);                                                    // node_list: Vec<WorkerId>
+        for (uint32_t j = 0; j < r.n_nodes; j++) p = put32(p, a.r.worker_id[a.r.mn_worker[r.node0 + j]]);
+        p = put8(p, a.t.entry_some[row] ? 1 : 0);                                   // entry: Option<ThinVec<u8>>
+        if (a.t.entry_some[row]) {
+            const uint64_t n = entry_len(a, row), e0 = a.t.entry_off[row];
+            p = put64(p, n);
+            for (uint64_t b = 0; b < n; b++) p[b] = a.t.entry_blob[e0 + b];
+            p += n;
+        }
+    }
+    run_of(a.slot_ncfg[s], tid, lo, hi);
+    const uint64_t shared0 = 12 + l.rec_total + 8;
+    p = m + shared0 + l.base_sh[tid];
+    for (uint32_t k = lo; k < hi; k++) {  // ComputeTaskSharedData   messages/worker.rs:41-45 (the body itself: phase 4)
+        const uint32_t cfg = a.cfg_list[sv.rec0 + k];
+        p = put8(p, a.t.config_time_some[cfg] ? 1 : 0);
+        if (a.t.config_time_some[cfg]) p = put32(put64(p, a.t.config_time_secs[cfg]), a.t.config_time_nanos[cfg]);
+        p = put64(p, body_len(a, cfg));
+        l.body_rel[k] = (uint32_t)(p - m);
+        p += body_len(a, cfg);
+    }
+}
+HQW_HD void emit_p4(const Args &a, EmitLds &l, uint32_t s, int tid) {
+    if (!emit_active(a, s)) return;
+    const Slot sv = slot_of(a, s);
+    uint8_t *m = a.o.bytes + a.o.slot_off[2 * s + 1];
+    const uint32_t n_cfg = a.slot_ncfg[s];
+    for (uint32_t k = 0; k < n_cfg; k++) {  // bodies: the whole workgroup copies each one, byte-coalesced
+        const uint32_t cfg = a.cfg_list[sv.rec0 + k];
+        const uint64_t n = body_len(a, cfg), b0 = a.t.body_off[cfg];
+        uint8_t *dst = m + l.body_rel[k];
+        for (uint64_t b = (uint64_t)tid; b < n; b += BLOCK) dst[b] = a.t.body_blob[b0 + b];
+    }
+}
+
+}  // namespace hqwire

@@ -1,0 +1,226 @@
+"""ctypes binding of include/hqwire.h: the worker-message wire encoding of a tick.
+
+`WireTables` / `WireRecords` flatten the host's view -- task attributes, interned `TaskConfiguration`s, the tick's mapping -- into the SoA
+arrays of the ABI.  `encode_device` places them in HBM (torch tensors, plumbing only) and runs the three kernels of
+`hqwire_encode_device`; `encode_host_debug` hands host arrays to `hqwire_debug_encode_host`, which executes the same phase functions on
+the CPU (tests only).  There is no Python encoder here: the oracle lives in `oracle/wire_oracle.py` and is imported by tests only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import tick
+
+HQWIRE_ABI_VERSION = 1
+HQWIRE_MAX_RECORDS = 2048
+SLOT_OK, SLOT_OVERSIZE, SLOT_UNKNOWN, SLOT_TOO_MANY = 0, 1, 2, 3
+HQWIRE_OK, HQWIRE_CAPACITY = 0, 1
+
+_vp = C.c_void_p
+
+
+class TablesC(C.Structure):
+    _fields_ = [("n_tasks", C.c_uint64), ("task_id", _vp), ("task_rq", _vp), ("task_instance", _vp), ("task_priority", _vp), ("task_config", _vp),
+                ("entry_some", _vp), ("entry_off", _vp), ("entry_blob", _vp), ("n_configs", C.c_uint32), ("config_time_some", _vp),
+                ("config_time_secs", _vp), ("config_time_nanos", _vp), ("body_off", _vp), ("body_blob", _vp)]
+
+
+class RecordsC(C.Structure):
+    _fields_ = [("n_workers", C.c_uint32), ("n_records", C.c_uint32), ("worker_id", _vp), ("rec_off", _vp), ("rec_task", _vp), ("rec_variant", _vp),
+                ("rec_kind", _vp), ("retract_off", _vp), ("retract_task", _vp), ("n_mn", C.c_uint32), ("mn_task", _vp), ("mn_worker_off", _vp),
+                ("mn_worker", _vp)]
+
+
+class OutputC(C.Structure):
+    _fields_ = [("bytes", _vp), ("capacity", C.c_uint64), ("slot_off", _vp), ("slot_status", _vp), ("header", _vp), ("scratch", _vp),
+                ("scratch_bytes", C.c_uint64)]
+
+
+SYMBOLS = ["hqwire_scratch_bytes", "hqwire_encode_device", "hqwire_abi_version"]
+
+
+def load() -> C.CDLL:
+    lib = tick.load()
+    lib.hqwire_scratch_bytes.argtypes = [C.c_uint64, C.c_uint64]
+    lib.hqwire_scratch_bytes.restype = C.c_uint64
+    lib.hqwire_encode_device.argtypes = [C.POINTER(TablesC), C.POINTER(RecordsC), C.POINTER(OutputC), _vp]
+    lib.hqwire_debug_encode_host.argtypes = [C.POINTER(TablesC), C.POINTER(RecordsC), C.POINTER(OutputC)]
+    lib.hqwire_abi_version.restype = C.c_uint32
+    return lib
+
+
+@dataclass
+class WireTables:
+    """Arrays of `hqwire_tables` (numpy, host)."""
+    task_id: np.ndarray
+    task_rq: np.ndarray
+    task_instance: np.ndarray
+    task_priority: np.ndarray
+    task_config: np.ndarray
+    entry_some: np.ndarray
+    entry_off: np.ndarray
+    entry_blob: np.ndarray
+    config_time_some: np.ndarray
+    config_time_secs: np.ndarray
+    config_time_nanos: np.ndarray
+    body_off: np.ndarray
+    body_blob: np.ndarray
+
+    @staticmethod
+    def build(attrs: Dict[int, Tuple[int, int, int, int, Optional[bytes]]], configs: Sequence[Tuple[Optional[Tuple[int, int]], bytes]]) -> "WireTables":
+        """attrs: task id -> (rq, instance_id, priority, config index, entry or None); configs: [(time_limit (secs, nanos) or None, body)]."""
+        ids = sorted(attrs)
+        entry_off, blob = [0], bytearray()
+        for t in ids:
+            e = attrs[t][4]
+            if e is not None:
+                blob += e
+            entry_off.append(len(blob))
+        body_off, bodies = [0], bytearray()
+        for (_, body) in configs:
+            bodies += body
+            body_off.append(len(bodies))
+        u8 = lambda b: np.frombuffer(bytes(b) or b"\0", np.uint8).copy()
+        return WireTables(
+            np.array(ids, np.uint64), np.array([attrs[t][0] for t in ids], np.uint32), np.array([attrs[t][1] for t in ids], np.uint32),
+            np.array([attrs[t][2] for t in ids], np.uint64), np.array([attrs[t][3] for t in ids], np.uint32),
+            np.array([attrs[t][4] is not None for t in ids], np.uint8), np.array(entry_off, np.uint64), u8(blob),
+            np.array([c[0] is not None for c in configs], np.uint8), np.array([c[0][0] if c[0] else 0 for c in configs], np.uint64),
+            np.array([c[0][1] if c[0] else 0 for c in configs], np.uint32), np.array(body_off, np.uint64), u8(bodies))
+
+    @property
+    def n_tasks(self) -> int:
+        return len(self.task_id)
+
+    @property
+    def n_configs(self) -> int:
+        return len(self.config_time_some)
+
+    def arrays(self) -> List[np.ndarray]:
+        return [self.task_id, self.task_rq, self.task_instance, self.task_priority, self.task_config, self.entry_some, self.entry_off, self.entry_blob,
+                self.config_time_some, self.config_time_secs, self.config_time_nanos, self.body_off, self.body_blob]
+
+
+@dataclass
+class WireRecords:
+    """Arrays of `hqwire_records` (numpy, host) -- the layout of `hqtick_result` / the record sink."""
+    worker_id: np.ndarray
+    rec_off: np.ndarray
+    rec_task: np.ndarray
+    rec_variant: np.ndarray
+    rec_kind: np.ndarray
+    retract_off: np.ndarray
+    retract_task: np.ndarray
+    mn_task: np.ndarray
+    mn_worker_off: np.ndarray
+    mn_worker: np.ndarray
+
+    @staticmethod
+    def build(worker_ids: Sequence[int], records: Sequence[Sequence[Tuple[int, int, int]]], retracts: Sequence[Sequence[int]],
+              mn: Sequence[Tuple[int, Sequence[int]]] = ()) -> "WireRecords":
+        rec_off, ret_off, mn_off = [0], [0], [0]
+        for r in records:
+            rec_off.append(rec_off[-1] + len(r))
+        for r in retracts:
+            ret_off.append(ret_off[-1] + len(r))
+        for (_, ws) in mn:
+            mn_off.append(mn_off[-1] + len(ws))
+        flat = [x for r in records for x in r]
+        return WireRecords(
+            np.array(worker_ids, np.uint32), np.array(rec_off, np.uint32), np.array([x[0] for x in flat], np.uint64),
+            np.array([x[1] & 0xFF for x in flat], np.uint8), np.array([x[2] for x in flat], np.uint8), np.array(ret_off, np.uint32),
+            np.array([t for r in retracts for t in r], np.uint64), np.array([t for (t, _) in mn], np.uint64), np.array(mn_off, np.uint32),
+            np.array([w for (_, ws) in mn for w in ws], np.uint32))
+
+    @property
+    def n_workers(self) -> int:
+        return len(self.worker_id)
+
+    @property
+    def n_records(self) -> int:
+        return int(self.rec_off[-1])
+
+    @property
+    def n_mn(self) -> int:
+        return len(self.mn_task)
+
+    def arrays(self) -> List[np.ndarray]:
+        return [self.worker_id, self.rec_off, self.rec_task, self.rec_variant, self.rec_kind, self.retract_off, self.retract_task, self.mn_task,
+                self.mn_worker_off, self.mn_worker]
+
+
+@dataclass
+class WireResult:
+    status: int                    # HQWIRE_OK / HQWIRE_CAPACITY
+    total_bytes: int
+    slot_status: np.ndarray        # [n_slots]
+    slot_off: np.ndarray           # [2 * n_slots + 1]
+    data: bytes
+
+    def messages(self, records: WireRecords) -> List[Tuple[int, bytes]]:
+        """[(worker id, message bytes)] in the order `send_messages` emits them (mapping.rs:259-292); slots the device did not build
+        (slot_status != 0) contribute their RetractTasks message only."""
+        out = []
+        W = records.n_workers
+        for s in range(len(self.slot_status)):
+            wid = int(records.worker_id[s]) if s < W else int(records.worker_id[records.mn_worker[records.mn_worker_off[s - W]]])
+            for j in (2 * s, 2 * s + 1):
+                lo, hi = int(self.slot_off[j]), int(self.slot_off[j + 1])
+                if hi > lo:
+                    out.append((wid, self.data[lo:hi]))
+        return out
+
+
+def _padded(a: np.ndarray) -> np.ndarray:
+    return a if a.size else np.zeros(1, a.dtype)  # never hand a NULL pointer for an empty array
+
+
+def _structs(t: WireTables, r: WireRecords, ptrs_t: List[int], ptrs_r: List[int]):
+    tc = TablesC(t.n_tasks, *ptrs_t[:8], t.n_configs, *ptrs_t[8:])
+    rc = RecordsC(r.n_workers, r.n_records, *ptrs_r[:7], r.n_mn, *ptrs_r[7:])
+    return tc, rc
+
+
+def encode_host_debug(t: WireTables, r: WireRecords, capacity: int) -> WireResult:
+    """`hqwire_debug_encode_host`: the kernels' phase functions on the CPU (tests only)."""
+    lib = load()
+    ta, ra = [_padded(np.ascontiguousarray(a)) for a in t.arrays()], [_padded(np.ascontiguousarray(a)) for a in r.arrays()]
+    tc, rc = _structs(t, r, [a.ctypes.data for a in ta], [a.ctypes.data for a in ra])
+    S = r.n_workers + r.n_mn
+    data, slot_off, status, header = np.zeros(max(1, capacity), np.uint8), np.zeros(2 * S + 1, np.uint64), np.zeros(max(1, S), np.uint8), np.zeros(4, np.uint32)
+    scratch = np.zeros(int(lib.hqwire_scratch_bytes(r.n_records + r.n_mn, S)) // 8 + 1, np.uint64)
+    oc = OutputC(data.ctypes.data, capacity, slot_off.ctypes.data, status.ctypes.data, header.ctypes.data, scratch.ctypes.data, scratch.nbytes)
+    rc_ = lib.hqwire_debug_encode_host(C.byref(tc), C.byref(rc), C.byref(oc))
+    if rc_ != 0:
+        raise tick.HqTickError(rc_, "hqwire_debug_encode_host")
+    total = int(header[2]) | int(header[3]) << 32
+    return WireResult(int(header[0]), total, status[:S].copy(), slot_off, data[:total].tobytes() if header[0] == HQWIRE_OK else b"")
+
+
+def encode_device(t: WireTables, r: WireRecords, capacity: int, device: str = "cuda:0") -> WireResult:
+    """`hqwire_encode_device`: tables and records in HBM, three kernels on torch's current stream, result copied back for inspection."""
+    import torch
+
+    lib = load()
+    dev = torch.device(device)
+    put = lambda a: torch.from_numpy(_padded(np.ascontiguousarray(a)).view(np.uint8).copy()).to(dev)
+    tt, rt = [put(a) for a in t.arrays()], [put(a) for a in r.arrays()]
+    tc, rc = _structs(t, r, [x.data_ptr() for x in tt], [x.data_ptr() for x in rt])
+    S = r.n_workers + r.n_mn
+    zeros = lambda n: torch.zeros(max(8, int(n)), dtype=torch.uint8, device=dev)
+    data, slot_off, status, header = zeros(capacity), zeros(8 * (2 * S + 1)), zeros(S), zeros(16)
+    scratch = zeros(int(lib.hqwire_scratch_bytes(r.n_records + r.n_mn, S)) + 8)
+    oc = OutputC(data.data_ptr(), capacity, slot_off.data_ptr(), status.data_ptr(), header.data_ptr(), scratch.data_ptr(), scratch.numel())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc_ = lib.hqwire_encode_device(C.byref(tc), C.byref(rc), C.byref(oc), _vp(stream))
+    if rc_ != 0:
+        raise tick.HqTickError(rc_, "hqwire_encode_device")
+    torch.cuda.synchronize(dev)
+    h = header.cpu().numpy().view(np.uint32)
+    total = int(h[2]) | int(h[3]) << 32
+    return WireResult(int(h[0]), total, status.cpu().numpy()[:S].copy(), slot_off.cpu().numpy().view(np.uint64)[: 2 * S + 1].copy(),
+                      data[:total].cpu().numpy().tobytes() if h[0] == HQWIRE_OK else b"")

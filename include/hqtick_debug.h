@@ -54,6 +54,14 @@ struct hqtick_ctx;
 int hqtick_debug_time_kernel(struct hqtick_ctx *ctx, int which, int iters, double *avg_us);
 int hqtick_debug_timeline(const struct hqtick_ctx *ctx, double *out, int cap);
 
+/* The wire encoding of include/hqwire.h on HOST memory: the same phase functions the three kernels run (csrc/wire_core.h), executed for
+ * thread 0..255 in turn with a loop end standing in for each workgroup barrier.  Same arguments as hqwire_encode_device, all pointers host
+ * pointers.  Lets the CPU test suite execute the encoder's logic; it is not a product path (hqwire_encode_device has no CPU fallback). */
+struct hqwire_tables;
+struct hqwire_records;
+struct hqwire_output;
+int hqwire_debug_encode_host(const struct hqwire_tables *tables, const struct hqwire_records *records, const struct hqwire_output *out);
+
 #ifdef __cplusplus
 }
 #endif

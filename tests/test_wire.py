@@ -1,0 +1,112 @@
+"""Wire encoding of the tick's worker messages (include/hqwire.h) on a machine without a GPU: the phase functions the three kernels run
+(csrc/wire_core.h), executed through hqwire_debug_encode_host, against the bincode oracle -- byte for byte, message order included."""
+import re
+import os
+
+import numpy as np
+import pytest
+
+import wire_cases as wc
+from hyperqueue_amd import wire
+from oracle import wire_oracle as wo
+
+
+def test_oracle_known_bytes():
+    """bincode fixint by hand for one two-task message (spec in oracle/wire_oracle.py's header)."""
+    a = {(1 << 32) | 7: wo.TaskAttr(2, 5, 0x8000000000000000, 0, None), (1 << 32) | 9: wo.TaskAttr(3, 6, 0x8000000100000000, 0, b"ab")}
+    msgs = wo.send_messages(a, [wo.Config((2, 3), b"xyz")], [50], [[((1 << 32) | 7, 0xFF, 0), ((1 << 32) | 9, 1, 1)]], [[(2 << 32) | 1]])
+    assert msgs[0] == (50, bytes.fromhex("01000000" "0100000000000000" "02000000" "01000000"))
+    want = (
+        "00000000" "0200000000000000"
+        # task 1@7: shared 0, id, rq 2, variant None, instance 5, priority, no nodes, no entry
+        "0000000000000000" "01000000" "07000000" "02000000" "00" "05000000" "0000000000000080" "0000000000000000" "00"
+        # task 1@9: shared 0, id, rq 3, Some(1), instance 6, priority, no nodes, Some(b"ab")
+        "0000000000000000" "01000000" "09000000" "03000000" "0101" "06000000" "0000000001000080" "0000000000000000" "01" "0200000000000000" "6162"
+        # shared data: one entry, Some(Duration{2 s, 3 ns}), body "xyz"
+        "0100000000000000" "01" "0200000000000000" "03000000" "0300000000000000" "78797a")
+    assert msgs[1] == (50, bytes.fromhex(want))
+
+
+def test_oracle_fragmentation():
+    """create_message_on_overflow (server/task.rs:388-400): the message is cut right after the task that pushes the estimate over the limit,
+    and the configuration index starts again."""
+    a = {i: wo.TaskAttr(0, 0, 0, 0, None) for i in range(1, 7)}
+    c = [wo.Config(None, b"x" * 100)]
+    msgs = wo.send_messages(a, c, [1], [[(i, 0, 1) for i in range(1, 7)]], [[]], limit=116 + 34 + 34)
+    # estimates: shared 116, each task 34 -> after task 3 the estimate (218) exceeds 184: cut; the next message starts with the body again
+    assert [m[1][4:12] for m in msgs] == [(3).to_bytes(8, "little"), (3).to_bytes(8, "little")]
+    assert all(m[1].count(b"x" * 100) == 1 for m in msgs)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_debug_hook_matches_oracle(seed):
+    wc.check_scenario(wire.encode_host_debug, wc.random_scenario(seed))
+
+
+def test_wide_message_dedup():
+    """one worker with 2000 records over 12 configurations: every thread owns a run of records; shared_index = rank of first occurrence"""
+    sc = wc.random_scenario(99, n_workers=1, max_rec=2000)
+    attrs, configs, worker_ids, records, retracts, mn = sc
+    ids = sorted(attrs)
+    import random
+    rnd = random.Random(3)
+    more = {((5 << 32) | i): (1, i, 7, rnd.randrange(len(configs)), None) for i in range(1, 2001)}
+    attrs.update(more)
+    records[0] = [(t, 0, 1) for t in more][:2000]
+    wc.check_scenario(wire.encode_host_debug, (attrs, configs, worker_ids, records, retracts, []), capacity=1 << 24)
+
+
+def test_tick_mapping():
+    wc.check_scenario(wire.encode_host_debug, wc.tick_scenario())
+
+
+def test_slot_conditions():
+    attrs = {1: (0, 0, 0, 0, None), 2: (0, 0, 0, 1, None), 3: (0, 0, 0, 0, None)}
+    configs = [(None, b"small"), (None, bytes(33 << 20))]  # the second body alone exceeds MAX_TASK_MSG_SIZE
+    worker_ids = [10, 11, 12, 13]
+    records = [[(1, 0, 1)], [(2, 0, 1)], [(99, 0, 1)], [(3, 0, 1)] * (wire.HQWIRE_MAX_RECORDS + 1)]
+    retracts = [[], [5], [], []]
+    t, r = wc.tables_and_records(attrs, configs, worker_ids, records, retracts, [])
+    res = wire.encode_host_debug(t, r, 1 << 20)
+    assert res.status == wire.HQWIRE_OK
+    assert res.slot_status.tolist() == [wire.SLOT_OK, wire.SLOT_OVERSIZE, wire.SLOT_UNKNOWN, wire.SLOT_TOO_MANY]
+    msgs = res.messages(r)
+    want = wc.oracle_messages({k: v for k, v in attrs.items()}, configs, worker_ids[:1], records[:1], retracts[:1], [])
+    assert msgs[0] == want[0]
+    assert msgs[1] == (11, wo.retract_message([5])) and len(msgs) == 2  # the host builds the ComputeTasks messages of slots 1-3 itself
+
+
+def test_capacity_reported():
+    sc = wc.random_scenario(7)
+    t, r = wc.tables_and_records(*sc)
+    full = wire.encode_host_debug(t, r, 1 << 22)
+    small = wire.encode_host_debug(t, r, max(0, full.total_bytes - 1))
+    assert full.total_bytes > 0 and small.status == wire.HQWIRE_CAPACITY and small.total_bytes == full.total_bytes and small.data == b""
+
+
+def test_empty_tick():
+    t, r = wc.tables_and_records({1: (0, 0, 0, 0, None)}, [(None, b"")], [4, 5], [[], []], [[], []], [])
+    res = wire.encode_host_debug(t, r, 64)
+    assert res.status == wire.HQWIRE_OK and res.total_bytes == 0 and res.messages(r) == []
+
+
+def test_exports_and_no_cpu_fallback():
+    lib = wire.load()
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "hqwire.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(hqwire_[a-z_]+)\s*\(", header))
+    assert declared == set(wire.SYMBOLS)
+    for n in declared:
+        assert hasattr(lib, n)
+    assert lib.hqwire_abi_version() == wire.HQWIRE_ABI_VERSION
+    import torch
+
+    if not torch.cuda.is_available():  # the product entry point refuses to run without a device
+        import ctypes as C
+
+        t, r = wc.tables_and_records({1: (0, 0, 0, 0, None)}, [(None, b"")], [4], [[(1, 0, 1)]], [[]], [])
+        ta, ra = [wire._padded(a) for a in t.arrays()], [wire._padded(a) for a in r.arrays()]
+        tc, rc = wire._structs(t, r, [a.ctypes.data for a in ta], [a.ctypes.data for a in ra])
+        bufs = [np.zeros(64, np.uint64) for _ in range(5)]
+        oc = wire.OutputC(bufs[0].ctypes.data, 64, bufs[1].ctypes.data, bufs[2].ctypes.data, bufs[3].ctypes.data, bufs[4].ctypes.data, bufs[4].nbytes)
+        assert lib.hqwire_encode_device(C.byref(tc), C.byref(rc), C.byref(oc), None) == -2  # HQTICK_E_NO_DEVICE

@@ -1,0 +1,59 @@
+"""hqwire_encode_device on a real MI355X: tables and records in HBM, three kernels, the bytes compared with the bincode oracle.
+(File name sorts last on purpose: this kernel family was written at the end of round 1, after the round's GPU budget was spent; its phase
+functions are covered on the CPU by tests/test_wire.py, the launches themselves are first exercised here.)"""
+import random
+
+import pytest
+
+import wire_cases as wc
+from hyperqueue_amd import wire
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_device_matches_oracle(seed):
+    wc.check_scenario(wire.encode_device, wc.random_scenario(seed))
+
+
+def test_device_tick_mapping():
+    wc.check_scenario(wire.encode_device, wc.tick_scenario())
+
+
+def test_device_wide_message():
+    rnd = random.Random(3)
+    configs = [(None if i % 2 else (60 * i, 0), bytes([i]) * (50 * i)) for i in range(12)]
+    attrs = {((5 << 32) | i): (1, i, 7, rnd.randrange(12), None if i % 3 else b"e%d" % i) for i in range(1, 2001)}
+    wc.check_scenario(wire.encode_device, (attrs, configs, [77], [[(t, 0, 1) for t in attrs]], [[]], []), capacity=1 << 24)
+
+
+def test_device_c3_shape():
+    """BASELINE C3's cold tick shape: 1024 workers x (120 prefills + 64 assigned) records, 8 request classes = 8 configurations"""
+    rnd = random.Random(11)
+    configs = [((3600, 0), b"body-of-class-%d" % i * 8) for i in range(8)]
+    W, per = 1024, 184
+    attrs, records = {}, []
+    tid = 1
+    for w in range(W):
+        recs = []
+        for j in range(per):
+            t = (1 << 32) | tid
+            tid += 1
+            attrs[t] = (rnd.randrange(8), 0, 0x8000000000000000, rnd.randrange(8), None)
+            recs.append((t, 0xFF, 0) if j < 120 else (t, 0, 1))
+        records.append(recs)
+    res = wc.check_scenario(wire.encode_device, (attrs, configs, list(range(1, W + 1)), records, [[] for _ in range(W)], []), capacity=1 << 25)
+    assert res.total_bytes > W * per * 42
+
+
+def test_device_slot_conditions_and_capacity():
+    attrs = {1: (0, 0, 0, 0, None), 3: (0, 0, 0, 0, None)}
+    configs = [(None, b"small")]
+    records = [[(1, 0, 1)], [(99, 0, 1)], [(3, 0, 1)] * (wire.HQWIRE_MAX_RECORDS + 1)]
+    t, r = wc.tables_and_records(attrs, configs, [10, 11, 12], records, [[], [5], []], [])
+    res = wire.encode_device(t, r, 1 << 16)
+    assert res.status == wire.HQWIRE_OK
+    assert res.slot_status.tolist() == [wire.SLOT_OK, wire.SLOT_UNKNOWN, wire.SLOT_TOO_MANY]
+    assert len(res.messages(r)) == 2
+    small = wire.encode_device(t, r, res.total_bytes - 1)
+    assert small.status == wire.HQWIRE_CAPACITY and small.total_bytes == res.total_bytes
