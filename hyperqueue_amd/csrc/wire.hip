@@ -99,8 +99,12 @@ int hqwire_encode_device(const hqwire_tables *tables, const hqwire_records *reco
 
 // CPU debug hook: the same phases on HOST memory, one emulated thread after the other (a barrier = the end of a loop over tid).
 // Test infrastructure for machines without a GPU; the product entry point is hqwire_encode_device.
-int hqwire_debug_encode_host(const hqwire_tables *tables, const hqwire_records *records, const hqwire_output *out) {
+// `order` picks the sequence in which the 256 emulated threads of a phase run (0 ascending, 1 descending, 2 a fixed permutation): a phase
+// whose result depended on that sequence would be a race on the GPU.
+int hqwire_debug_encode_host_order(const hqwire_tables *tables, const hqwire_records *records, const hqwire_output *out, int order) {
     Args a;
+    int seq[BLOCK];
+    for (int i = 0; i < BLOCK; i++) seq[i] = order == 1 ? BLOCK - 1 - i : order == 2 ? (i * 77 + 13) % BLOCK : i;  // 77 is coprime to 256
     if (!make_args(tables, records, out, a)) return HQTICK_E_INVALID;
     PlanLds *pl = new (std::nothrow) PlanLds;
     ScanLds *sl = new (std::nothrow) ScanLds;
@@ -112,7 +116,7 @@ int hqwire_debug_encode_host(const hqwire_tables *tables, const hqwire_records *
         return HQTICK_E_DEVICE;
     }
 #define HQW_PHASE(fn, lds, s) \
-    for (int tid = 0; tid < BLOCK; tid++) fn(a, lds, s, tid)
+    for (int q = 0; q < BLOCK; q++) fn(a, lds, s, seq[q])
     for (uint32_t s = 0; s < a.n_slots; s++) {
         HQW_PHASE(plan_p0, *pl, s);
         HQW_PHASE(plan_p1, *pl, s);
@@ -122,9 +126,9 @@ int hqwire_debug_encode_host(const hqwire_tables *tables, const hqwire_records *
         HQW_PHASE(plan_p5, *pl, s);
         HQW_PHASE(plan_p6, *pl, s);
     }
-    for (int tid = 0; tid < BLOCK; tid++) scan_p1(a, *sl, tid);
-    for (int tid = 0; tid < BLOCK; tid++) scan_p2(a, *sl, tid);
-    for (int tid = 0; tid < BLOCK; tid++) scan_p3(a, *sl, tid);
+    for (int q = 0; q < BLOCK; q++) scan_p1(a, *sl, seq[q]);
+    for (int q = 0; q < BLOCK; q++) scan_p2(a, *sl, seq[q]);
+    for (int q = 0; q < BLOCK; q++) scan_p3(a, *sl, seq[q]);
     for (uint32_t s = 0; s < a.n_slots; s++) {
         HQW_PHASE(emit_p1, *el, s);
         HQW_PHASE(emit_p2, *el, s);
@@ -136,6 +140,10 @@ int hqwire_debug_encode_host(const hqwire_tables *tables, const hqwire_records *
     delete sl;
     delete el;
     return 0;
+}
+
+int hqwire_debug_encode_host(const hqwire_tables *tables, const hqwire_records *records, const hqwire_output *out) {
+    return hqwire_debug_encode_host_order(tables, records, out, 0);
 }
 
 }  // extern "C"

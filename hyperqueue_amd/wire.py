@@ -49,6 +49,7 @@ def load() -> C.CDLL:
     lib.hqwire_scratch_bytes.restype = C.c_uint64
     lib.hqwire_encode_device.argtypes = [C.POINTER(TablesC), C.POINTER(RecordsC), C.POINTER(OutputC), _vp]
     lib.hqwire_debug_encode_host.argtypes = [C.POINTER(TablesC), C.POINTER(RecordsC), C.POINTER(OutputC)]
+    lib.hqwire_debug_encode_host_order.argtypes = [C.POINTER(TablesC), C.POINTER(RecordsC), C.POINTER(OutputC), C.c_int]
     lib.hqwire_abi_version.restype = C.c_uint32
     return lib
 
@@ -185,8 +186,8 @@ def _structs(t: WireTables, r: WireRecords, ptrs_t: List[int], ptrs_r: List[int]
     return tc, rc
 
 
-def encode_host_debug(t: WireTables, r: WireRecords, capacity: int) -> WireResult:
-    """`hqwire_debug_encode_host`: the kernels' phase functions on the CPU (tests only)."""
+def encode_host_debug(t: WireTables, r: WireRecords, capacity: int, order: int = 0) -> WireResult:
+    """`hqwire_debug_encode_host_order`: the kernels' phase functions on the CPU (tests only); `order` = sequence of the emulated threads."""
     lib = load()
     ta, ra = [_padded(np.ascontiguousarray(a)) for a in t.arrays()], [_padded(np.ascontiguousarray(a)) for a in r.arrays()]
     tc, rc = _structs(t, r, [a.ctypes.data for a in ta], [a.ctypes.data for a in ra])
@@ -194,9 +195,9 @@ def encode_host_debug(t: WireTables, r: WireRecords, capacity: int) -> WireResul
     data, slot_off, status, header = np.zeros(max(1, capacity), np.uint8), np.zeros(2 * S + 1, np.uint64), np.zeros(max(1, S), np.uint8), np.zeros(4, np.uint32)
     scratch = np.zeros(int(lib.hqwire_scratch_bytes(r.n_records + r.n_mn, S)) // 8 + 1, np.uint64)
     oc = OutputC(data.ctypes.data, capacity, slot_off.ctypes.data, status.ctypes.data, header.ctypes.data, scratch.ctypes.data, scratch.nbytes)
-    rc_ = lib.hqwire_debug_encode_host(C.byref(tc), C.byref(rc), C.byref(oc))
+    rc_ = lib.hqwire_debug_encode_host_order(C.byref(tc), C.byref(rc), C.byref(oc), order)
     if rc_ != 0:
-        raise tick.HqTickError(rc_, "hqwire_debug_encode_host")
+        raise tick.HqTickError(rc_, "hqwire_debug_encode_host_order")
     total = int(header[2]) | int(header[3]) << 32
     return WireResult(int(header[0]), total, status[:S].copy(), slot_off, data[:total].tobytes() if header[0] == HQWIRE_OK else b"")
 

@@ -61,6 +61,9 @@ struct hqwire_tables;
 struct hqwire_records;
 struct hqwire_output;
 int hqwire_debug_encode_host(const struct hqwire_tables *tables, const struct hqwire_records *records, const struct hqwire_output *out);
+/* As above with the emulated threads of every phase run in another sequence (0 ascending, 1 descending, 2 a fixed permutation): the bytes
+ * must not depend on it -- a phase that did would be a data race on the GPU. */
+int hqwire_debug_encode_host_order(const struct hqwire_tables *tables, const struct hqwire_records *records, const struct hqwire_output *out, int order);
 
 #ifdef __cplusplus
 }

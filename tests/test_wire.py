@@ -43,6 +43,22 @@ def test_debug_hook_matches_oracle(seed):
     wc.check_scenario(wire.encode_host_debug, wc.random_scenario(seed))
 
 
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 99])
+def test_thread_order_does_not_matter(seed, order):
+    """the emulated threads of every phase in descending / permuted sequence: a phase depending on it would be a race on the GPU"""
+    enc = lambda t, r, cap: wire.encode_host_debug(t, r, cap, order)
+    if seed == 99:  # 2000 records in one message: every thread owns a run, the dedup table is busy
+        import random
+
+        rnd = random.Random(3)
+        configs = [(None, bytes([i]) * (10 * i)) for i in range(12)]
+        attrs = {((5 << 32) | i): (1, i, 7, rnd.randrange(12), None) for i in range(1, 2001)}
+        wc.check_scenario(enc, (attrs, configs, [77], [[(t, 0, 1) for t in attrs]], [[]], []), capacity=1 << 24)
+    else:
+        wc.check_scenario(enc, wc.random_scenario(seed))
+
+
 def test_wide_message_dedup():
     """one worker with 2000 records over 12 configurations: every thread owns a run of records; shared_index = rank of first occurrence"""
     sc = wc.random_scenario(99, n_workers=1, max_rec=2000)
