@@ -130,6 +130,22 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int):
     }
 
 
+def wire_block(iters: int):
+    """Row f3: the wire encoding of a C3-shaped mapping, measured in a SUBPROCESS (tools/wire_bench.py) -- these kernels
+    had not run on hardware when round 1 ended, and whatever happens there must not cost the headline line."""
+    import subprocess
+
+    try:
+        p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "wire_bench.py"), "--iters", str(iters)],
+                           capture_output=True, text=True, timeout=180)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"exit {p.returncode}", "stderr_tail": p.stderr[-400:]}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +158,7 @@ def main():
     ap.add_argument("--steady-steps", type=int, default=20, help="steps of the steady-state (delta-updated resident set) measurement, 0 = skip")
     ap.add_argument("--dag-steps", type=int, default=12, help="ticks of the config-5 loop (1 M-node DAG in the device graph + 10 %% worker churn per tick), 0 = skip")
     ap.add_argument("--dag-classes", type=int, default=2, help="request classes of the config-5 DAG (first N of the c3 classes; 8 = all, every tick then runs into the MILP time limit)")
+    ap.add_argument("--wire-iters", type=int, default=50, help="launch triples of the wire-encoding measurement (row f3, in a subprocess), 0 = skip")
     ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
     ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
@@ -364,6 +381,8 @@ def main():
             out["tick_latency_ratio_vs_cpu"] = out["cpu_baseline"]["tick_s"] / float(np.median(lat))
         except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
             out["cpu_baseline"] = {"error": repr(e)}
+    if world == 1 and not args.force_sharded and args.workload == "c3" and args.wire_iters > 0:
+        out["wire"] = wire_block(args.wire_iters)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,86 @@
+"""First hardware measurement of the wire encoding (include/hqwire.h) on BASELINE C3's cold-tick shape:
+1024 workers x (120 prefills + 64 assigned) records, 8 configurations.  Checks the device bytes against the oracle once, then times
+`hqwire_encode_device` (three kernels) with events on the stream the kernels run on.  Prints ONE JSON line.
+
+    python tools/wire_bench.py [--iters 50]
+
+bench.py runs this in a subprocess (the kernels had not run on hardware when round 1 ended; a fault here must not take the headline
+measurement with it).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+
+    import wire_cases as wc
+    from hyperqueue_amd import wire
+
+    rnd = random.Random(11)
+    W, per, n_cfg = 1024, 184, 8
+    configs = [((3600, 0), b"body-of-class-%d" % i * 64) for i in range(n_cfg)]  # ~1 KB program bodies
+    attrs, records, tid = {}, [], 1
+    for w in range(W):
+        recs = []
+        for j in range(per):
+            t = (1 << 32) | tid
+            tid += 1
+            attrs[t] = (rnd.randrange(8), 0, 0x8000000000000000, rnd.randrange(n_cfg), None)
+            recs.append((t, 0xFF, 0) if j < 120 else (t, 0, 1))
+        records.append(recs)
+    sc = (attrs, configs, list(range(1, W + 1)), records, [[] for _ in range(W)], [])
+    t0 = time.perf_counter()
+    want = wc.oracle_messages(*sc)
+    oracle_s = time.perf_counter() - t0
+    t, r = wc.tables_and_records(*sc)
+    cap = 1 << 25
+    res = wire.encode_device(t, r, cap)
+    got = res.messages(r)
+    parity = res.status == 0 and bool((res.slot_status == 0).all()) and got == want
+
+    # timed region: everything resident, same launches, events on torch's current stream (the stream handed to the library)
+    lib = wire.load()
+    dev = torch.device("cuda:0")
+    put = lambda a: torch.from_numpy(wire._padded(np.ascontiguousarray(a)).view(np.uint8).copy()).to(dev)
+    tt, rt = [put(a) for a in t.arrays()], [put(a) for a in r.arrays()]
+    tc, rc = wire._structs(t, r, [x.data_ptr() for x in tt], [x.data_ptr() for x in rt])
+    S = r.n_workers + r.n_mn
+    z = lambda n: torch.zeros(max(8, int(n)), dtype=torch.uint8, device=dev)
+    data, slot_off, status, header = z(cap), z(8 * (2 * S + 1)), z(S), z(16)
+    scratch = z(int(lib.hqwire_scratch_bytes(r.n_records + r.n_mn, S)) + 8)
+    oc = wire.OutputC(data.data_ptr(), cap, slot_off.data_ptr(), status.data_ptr(), header.data_ptr(), scratch.data_ptr(), scratch.numel())
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for _ in range(5):
+        lib.hqwire_encode_device(C.byref(tc), C.byref(rc), C.byref(oc), stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        lib.hqwire_encode_device(C.byref(tc), C.byref(rc), C.byref(oc), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / args.iters
+    n_rec = r.n_records
+    body_bytes = sum(len(b) for _, b in configs)
+    algo = n_rec * (10 + 29) + res.total_bytes + W * body_bytes  # records + attributes read, message bytes written, bodies read once per message
+    print(json.dumps({"workload": "c3 cold-tick mapping: 1024 workers x 184 records, 8 configurations of ~1 KB", "records": n_rec, "message_bytes": res.total_bytes,
+                      "parity_with_oracle": parity, "us_per_encode": us, "records_per_sec": n_rec / (us * 1e-6), "algorithmic_bytes": algo,
+                      "achieved_GBps": algo / (us * 1e-6) / 1e9, "oracle_python_s": oracle_s, "iters": args.iters}))
+
+
+if __name__ == "__main__":
+    main()
