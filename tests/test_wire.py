@@ -126,3 +126,35 @@ def test_exports_and_no_cpu_fallback():
         bufs = [np.zeros(64, np.uint64) for _ in range(5)]
         oc = wire.OutputC(bufs[0].ctypes.data, 64, bufs[1].ctypes.data, bufs[2].ctypes.data, bufs[3].ctypes.data, bufs[4].ctypes.data, bufs[4].nbytes)
         assert lib.hqwire_encode_device(C.byref(tc), C.byref(rc), C.byref(oc), None) == -2  # HQTICK_E_NO_DEVICE
+
+
+@pytest.mark.parametrize("seed", range(40, 60))
+def test_roundtrip_through_independent_decoder(seed):
+    """encode (kernel phases via the debug hook) -> decode with a decoder that shares nothing with the encoder oracle -> the tick's mapping"""
+    sc = wc.random_scenario(seed)
+    t, r = wc.tables_and_records(*sc)
+    res = wire.encode_host_debug(t, r, 1 << 22)
+    wc.check_roundtrip(sc, res.messages(r))
+    wc.check_roundtrip(sc, wc.oracle_messages(*sc))  # and the oracle's own bytes
+
+
+def test_roundtrip_c3_shape():
+    """the full C3 cold-tick shape (1024 workers x 184 records): size-independent property instead of a byte comparison"""
+    import random
+
+    rnd = random.Random(11)
+    configs = [((3600, 0), b"body-of-class-%d" % i * 8) for i in range(8)]
+    attrs, records, tid = {}, [], 1
+    for w in range(1024):
+        recs = []
+        for j in range(184):
+            t = (1 << 32) | tid
+            tid += 1
+            attrs[t] = (rnd.randrange(8), w, 0x8000000000000000 + j, rnd.randrange(8), None if j % 5 else b"x" * (j % 7))
+            recs.append((t, 0xFF, 0) if j < 120 else (t, j % 3, 1))
+        records.append(recs)
+    sc = (attrs, configs, list(range(1, 1025)), records, [[] for _ in range(1024)], [])
+    t, r = wc.tables_and_records(*sc)
+    res = wire.encode_host_debug(t, r, 1 << 25)
+    assert res.status == 0 and (res.slot_status == 0).all()
+    wc.check_roundtrip(sc, res.messages(r))

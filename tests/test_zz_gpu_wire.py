@@ -20,6 +20,13 @@ def test_device_tick_mapping():
     wc.check_scenario(wire.encode_device, wc.tick_scenario())
 
 
+@pytest.mark.parametrize("seed", range(40, 46))
+def test_device_roundtrip_through_independent_decoder(seed):
+    sc = wc.random_scenario(seed)
+    t, r = wc.tables_and_records(*sc)
+    wc.check_roundtrip(sc, wire.encode_device(t, r, 1 << 22).messages(r))
+
+
 def test_device_wide_message():
     rnd = random.Random(3)
     configs = [(None if i % 2 else (60 * i, 0), bytes([i]) * (50 * i)) for i in range(12)]

@@ -88,3 +88,88 @@ def tick_scenario():
     worker_ids = [int(w) for w in snap.worker_id]
     assert sum(len(r) for r in res.records) > 40
     return attrs, configs, worker_ids, res.records, res.retracts, []
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Independent DECODER (what the worker's `deserialize::<ToWorkerMessage>` does, transfer/auth.rs:265-275 + messages/worker.rs:27-88):
+# round-trip properties that do not depend on the encoder oracle.
+class _Reader:
+    def __init__(self, b):
+        self.b, self.p = b, 0
+
+    def take(self, n):
+        assert self.p + n <= len(self.b), "truncated message"
+        out = self.b[self.p:self.p + n]
+        self.p += n
+        return out
+
+    def u8(self):
+        return self.take(1)[0]
+
+    def u32(self):
+        return int.from_bytes(self.take(4), "little")
+
+    def u64(self):
+        return int.from_bytes(self.take(8), "little")
+
+    def option(self, f):
+        tag = self.u8()
+        assert tag in (0, 1), "bad Option tag"
+        return f() if tag else None
+
+
+def decode_message(b):
+    """-> ("retract", [task ids]) or ("compute", [task dict], [(time_limit, body)]); asserts the message is consumed exactly."""
+    r = _Reader(b)
+    tag = r.u32()
+    if tag == 1:
+        ids = [(r.u32() << 32) | r.u32() for _ in range(r.u64())]
+        assert r.p == len(b)
+        return "retract", ids
+    assert tag == 0
+    tasks = []
+    for _ in range(r.u64()):
+        d = {"shared_index": r.u64(), "id": (r.u32() << 32) | r.u32(), "rq": r.u32(), "variant": r.option(r.u8), "instance_id": r.u32(), "priority": r.u64()}
+        d["node_list"] = [r.u32() for _ in range(r.u64())]
+        d["entry"] = r.option(lambda: r.take(r.u64()))
+        tasks.append(d)
+    shared = []
+    for _ in range(r.u64()):
+        tl = r.option(lambda: (r.u64(), r.u32()))
+        shared.append((tl, r.take(r.u64())))
+    assert r.p == len(b), "trailing bytes"
+    return "compute", tasks, shared
+
+
+def check_roundtrip(sc, messages):
+    """Every task of the mapping arrives exactly once, in send order, with its own attributes and -- through shared_index -- its own
+    configuration; shared data holds each configuration of a message once, in first-use order."""
+    attrs, configs, worker_ids, records, retracts, mn = sc
+    per_worker = {}
+    for wid, b in messages:
+        per_worker.setdefault(wid, []).append(decode_message(b))
+    mn_by_root = {}
+    for (task, ws) in mn:
+        mn_by_root.setdefault(worker_ids[ws[0]], []).append((task, [worker_ids[i] for i in ws]))
+    for w, wid in enumerate(worker_ids):
+        msgs = per_worker.get(wid, [])
+        want_retract = [("retract", list(retracts[w]))] if retracts[w] else []
+        assert [m for m in msgs if m[0] == "retract"] == want_retract
+        if want_retract:
+            assert msgs[0][0] == "retract"  # retracts go first (mapping.rs:261-266)
+        computes = [m for m in msgs if m[0] == "compute"]
+        sn = [m for m in computes if all(not t["node_list"] for t in m[1])]
+        flat = [(t, m[2]) for m in sn for t in m[1]]
+        assert len(flat) == len(records[w])
+        for (t, shared), (task, variant, kind) in zip(flat, records[w]):
+            rq, inst, prio, cfg, entry = attrs[task]
+            assert (t["id"], t["rq"], t["instance_id"], t["priority"], t["entry"]) == (task, rq, inst, prio, entry)
+            assert t["variant"] == (None if kind == 0 else variant)
+            assert shared[t["shared_index"]] == configs[cfg]
+        for m in sn:
+            used = [t["shared_index"] for t in m[1]]
+            first_use = list(dict.fromkeys(used))
+            assert first_use == list(range(len(m[2]))), "shared data not in first-use order / unused entries"
+            assert len(set((tl, body, ) for tl, body in m[2])) >= 1
+        got_mn = [(m[1][0]["id"], m[1][0]["node_list"]) for m in computes if any(t["node_list"] for t in m[1])]
+        assert got_mn == mn_by_root.get(wid, [])
