@@ -17,7 +17,7 @@ Third-party behaviour that is observable here and not under /root/reference:
     rehash) -- the same spec as SURVEY.md App. C;
   * `group_solver` hands a 0/1 model to HiGHS; where its optimum is not unique the group set HiGHS returns is an
     artefact of that build.  The oracle enumerates the 0/1 vectors (<= 3 resources x <= 8 groups in practice) and
-    returns the canonical optimum of csrc/milp.h (ties: minimise the last column first), and `highs_objective`
+    returns the canonical optimum of csrc/milp.h (ties: minimise the last column first -- link columns, then later groups), and `highs_objective`
     re-solves the same model with scipy's HiGHS as a second opinion on the objective value.
 
 Pinned by the 26 tests of the reference's worker/resources/test_allocator.rs, transcribed in tests/alloc_cases.py.
@@ -684,21 +684,24 @@ def build_group_model(free: Concise, entries: Sequence[Entry], weights: Sequence
 
 
 def solve_group_model(m: GroupModel) -> Optional[Tuple[List[int], float]]:
-    """Exhaustive 0/1 search; canonical optimum of csrc/milp.h (the u columns come last and carry weight >= 0, so after them
-    the tie-break reads the v columns from the last one backwards)."""
+    """Exhaustive 0/1 search; canonical optimum of csrc/milp.h over the model's FULL column vector: the v columns in creation order, then one
+    link column per coupling weight (u = min(v1, v2) where the weight is positive, 0 where it is zero -- both follow from "maximise, then
+    minimise the last column first").  Among the optimal vectors the one that is smallest read from the last column backwards wins, so ties
+    between equally good group sets are broken by the LINK columns first (created last), then by the later groups."""
     n = len(m.obj)
     assert n <= 22, "oracle enumerates; keep coupled requests small"
     feasible = []
     for bits in itertools.product((0, 1), repeat=n):
         if any(sum(c * bits[v] for v, c in terms) < rhs - 1e-9 for rhs, terms in m.rows):
             continue
-        val = sum(o * b for o, b in zip(m.obj, bits)) + sum(w for a, b, w in m.links if bits[a] and bits[b])
-        feasible.append((val, bits))
+        links = tuple(1 if (w > 0 and bits[a] and bits[b]) else 0 for a, b, w in m.links)
+        val = sum(o * b for o, b in zip(m.obj, bits)) + sum(w * u for (_, _, w), u in zip(m.links, links))
+        feasible.append((val, bits, links))
     if not feasible:
         return None
-    top = max(v for v, _ in feasible)
+    top = max(f[0] for f in feasible)
     tol = 1e-9 * max(1.0, abs(top))
-    val, bits = min((fb for fb in feasible if fb[0] >= top - tol), key=lambda fb: tuple(reversed(fb[1])))
+    val, bits, _ = min((f for f in feasible if f[0] >= top - tol), key=lambda f: tuple(reversed(f[1] + f[2])))
     return list(bits), val
 
 
