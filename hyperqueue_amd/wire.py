@@ -202,19 +202,10 @@ def encode_host_debug(t: WireTables, r: WireRecords, capacity: int, order: int =
     return WireResult(int(header[0]), total, status[:S].copy(), slot_off, data[:total].tobytes() if header[0] == HQWIRE_OK else b"")
 
 
-def encode_device(t: WireTables, r: WireRecords, capacity: int, device: str = "cuda:0") -> WireResult:
-    """`hqwire_encode_device`: tables and records in HBM, three kernels on torch's current stream, result copied back for inspection."""
-    import torch
-
-    lib = load()
-    dev = torch.device(device)
-    put = lambda a: torch.from_numpy(_padded(np.ascontiguousarray(a)).view(np.uint8).copy()).to(dev)
-    tt, rt = [put(a) for a in t.arrays()], [put(a) for a in r.arrays()]
-    tc, rc = _structs(t, r, [x.data_ptr() for x in tt], [x.data_ptr() for x in rt])
-    S = r.n_workers + r.n_mn
+def _run_device(lib, torch, dev, tc: TablesC, rc: RecordsC, n_slots: int, n_rec_incl_mn: int, capacity: int) -> WireResult:
     zeros = lambda n: torch.zeros(max(8, int(n)), dtype=torch.uint8, device=dev)
-    data, slot_off, status, header = zeros(capacity), zeros(8 * (2 * S + 1)), zeros(S), zeros(16)
-    scratch = zeros(int(lib.hqwire_scratch_bytes(r.n_records + r.n_mn, S)) + 8)
+    data, slot_off, status, header = zeros(capacity), zeros(8 * (2 * n_slots + 1)), zeros(n_slots), zeros(16)
+    scratch = zeros(int(lib.hqwire_scratch_bytes(n_rec_incl_mn, n_slots)) + 8)
     oc = OutputC(data.data_ptr(), capacity, slot_off.data_ptr(), status.data_ptr(), header.data_ptr(), scratch.data_ptr(), scratch.numel())
     stream = torch.cuda.current_stream(dev).cuda_stream
     rc_ = lib.hqwire_encode_device(C.byref(tc), C.byref(rc), C.byref(oc), _vp(stream))
@@ -223,5 +214,38 @@ def encode_device(t: WireTables, r: WireRecords, capacity: int, device: str = "c
     torch.cuda.synchronize(dev)
     h = header.cpu().numpy().view(np.uint32)
     total = int(h[2]) | int(h[3]) << 32
-    return WireResult(int(h[0]), total, status.cpu().numpy()[:S].copy(), slot_off.cpu().numpy().view(np.uint64)[: 2 * S + 1].copy(),
+    return WireResult(int(h[0]), total, status.cpu().numpy()[:n_slots].copy(), slot_off.cpu().numpy().view(np.uint64)[: 2 * n_slots + 1].copy(),
                       data[:total].cpu().numpy().tobytes() if h[0] == HQWIRE_OK else b"")
+
+
+def _upload(torch, dev, arrays: List[np.ndarray]):
+    return [torch.from_numpy(_padded(np.ascontiguousarray(a)).view(np.uint8).copy()).to(dev) for a in arrays]
+
+
+def encode_device(t: WireTables, r: WireRecords, capacity: int, device: str = "cuda:0") -> WireResult:
+    """`hqwire_encode_device`: tables and records in HBM, three kernels on torch's current stream, result copied back for inspection."""
+    import torch
+
+    lib, dev = load(), torch.device(device)
+    tt, rt = _upload(torch, dev, t.arrays()), _upload(torch, dev, r.arrays())
+    tc, rc = _structs(t, r, [x.data_ptr() for x in tt], [x.data_ptr() for x in rt])
+    return _run_device(lib, torch, dev, tc, rc, r.n_workers + r.n_mn, r.n_records + r.n_mn, capacity)
+
+
+def encode_from_sink(t: WireTables, sink, n_workers: int, sink_cap_records: int, n_records: int, side: WireRecords, capacity: int) -> WireResult:
+    """The chained path of DESIGN.md 8d: the tick left its records in a device record sink (`hqtick_set_record_sink`; `sink` = that torch
+    tensor), the encoder reads `rec_off / task / variant / kind` right there.  `side` carries what the sink does not hold -- worker ids,
+    retract and multi-node CSRs of the tick's result (a few entries, uploaded here); its own rec_* arrays are ignored."""
+    import torch
+
+    from .sharded import sink_layout
+
+    lib, dev = load(), sink.device
+    o_off, o_task, o_var, o_kind, _total = sink_layout(n_workers, sink_cap_records)
+    tt, st = _upload(torch, dev, t.arrays()), _upload(torch, dev, side.arrays())
+    base = sink.data_ptr()
+    ptrs_r = [st[0].data_ptr(), base + o_off, base + o_task, base + o_var, base + o_kind, st[5].data_ptr(), st[6].data_ptr(), st[7].data_ptr(),
+              st[8].data_ptr(), st[9].data_ptr()]
+    tc = TablesC(t.n_tasks, *[x.data_ptr() for x in tt[:8]], t.n_configs, *[x.data_ptr() for x in tt[8:]])
+    rc = RecordsC(n_workers, n_records, *ptrs_r[:7], side.n_mn, *ptrs_r[7:])
+    return _run_device(lib, torch, dev, tc, rc, n_workers + side.n_mn, n_records + side.n_mn, capacity)

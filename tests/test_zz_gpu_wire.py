@@ -64,3 +64,39 @@ def test_device_slot_conditions_and_capacity():
     assert len(res.messages(r)) == 2
     small = wire.encode_device(t, r, res.total_bytes - 1)
     assert small.status == wire.HQWIRE_CAPACITY and small.total_bytes == res.total_bytes
+
+
+def test_tick_to_bytes_through_the_record_sink():
+    """DESIGN.md 8d end to end: a real tick (HIP library) leaves its records in a device record sink, hqwire_encode_device reads them there, and
+    the bytes equal what the oracle's tick + the bincode oracle produce for the same snapshot."""
+    import numpy as np
+
+    from hyperqueue_amd import sharded
+    from hyperqueue_amd.core import SchedEnv, TaskBuilder as TB, WorkerBuilder as WB
+    from oracle.oracle import Oracle
+
+    env = SchedEnv()
+    env.new_named_resource("gpus/amd")
+    env.new_workers(6, WB(16).res_sum("gpus/amd", 2))
+    env.new_tasks(200, TB().cpus(1))
+    env.new_tasks(40, TB().cpus(4).user_priority(1))
+    env.new_tasks(30, TB().cpus(2).add_resource(1, 0.5))
+    snap = env.snapshot()
+    want = Oracle(env.config, canonical=True).tick(snap)
+    W, cap = len(snap.worker_id), 4096
+    st = sharded.ShardedTick(env.config, rank=0, world=1, records_per_shard=cap)
+    res_c, sink = st.tick_local(snap.to_c(), W)
+    n_records = int(np.ctypeslib.as_array(res_c.rec_off, shape=(W + 1,))[W])
+    assert n_records == sum(len(r) for r in want.records) > 0
+    rnd = random.Random(9)
+    configs = [(None, b"prog-a" * 30), ((600, 0), b"prog-b" * 70), ((5, 250), b"")]
+    attrs = {t: (rnd.randrange(4), rnd.randrange(50), (0x80000000 + rnd.randrange(3)) << 32, rnd.randrange(3), None if rnd.random() < 0.6 else b"e-%d" % (t & 0xFFFF))
+             for recs in want.records for (t, v, k) in recs}
+    worker_ids = [int(w) for w in snap.worker_id]
+    sc = (attrs, configs, worker_ids, want.records, want.retracts, [])
+    tables, side = wc.tables_and_records(*sc)
+    got = wire.encode_from_sink(tables, sink, W, cap, n_records, side, 1 << 22)
+    assert got.status == wire.HQWIRE_OK and (got.slot_status == 0).all()
+    assert got.messages(side) == wc.oracle_messages(*sc)
+    wc.check_roundtrip(sc, got.messages(side))
+    st.t.close()
