@@ -574,6 +574,23 @@ def test_e2e_coupling_alloc1(api):
         ac.validate()
 
 
+def test_e2e_coupling_alloc2(api):
+    """test_coupling.py:106-159: `cpus=4, foo=2` then `cpus=2, foo=4` on cpus [[1,2,3],[10,11,12],[21,22,23]] coupled group-wise with
+    foo [[1,2,3],[10,11,12],[20,21,23]]; each task's cpus and foos together touch exactly two NUMA groups (label // 10).  Both jobs are
+    submitted before the worker connects, so they are started back to back; the property must hold for either start order."""
+    cpus, cl = label_groups(api, [[1, 2, 3], [10, 11, 12], [21, 22, 23]])
+    foo, fl = label_groups(api, [[1, 2, 3], [10, 11, 12], [20, 21, 23]])
+    coupling = [(0, g, 2, g, 256) for g in range(3)]
+    jobs = [((0, api.COMPACT, units(api, 4)), (2, api.COMPACT, units(api, 2))), ((0, api.COMPACT, units(api, 2)), (2, api.COMPACT, units(api, 4)))]
+    for order in (jobs, jobs[::-1]):
+        ac = api.ResourceAllocator(api.Descriptor([cpus, api.sum_pool(units(api, 123)), foo], coupling))
+        for entries in order:
+            al = ac.try_allocate(rq(api, *entries))
+            g = set(cl[i] // 10 for i in get_indices(al, 0)) | set(fl[i] // 10 for i in get_indices(al, 2))
+            assert len(g) == 2, (entries, g)
+        ac.validate()
+
+
 def test_e2e_coupling_combined(api):
     """test_coupling.py:154-199: the seven (cpus policy, foo policy) rows on an idle worker."""
     cpus, cl = label_groups(api, [[1, 2, 3, 4], [11, 12, 13, 14], [21, 22, 23, 24]])
