@@ -951,4 +951,71 @@ def test_e2e_scheduler_unschedulable_sn_blocker(backend):  # tests/test_resource
     assert _assigned(rt, [big] + mid) == 6 * [False]
 
 
+# ---- more end-to-end pins of the reference's Python suite (added late in round 1: they run against the oracle, through the CPU shadow of the
+# product's host stages, and on the GPU from tests/test_zz_gpu_wire.py only -- E2E_EXTRA_CASES, not ALL_CASES)
+
+
+def e2e_job_priority(backend):  # tests/test_job.py:653-711: one 1-cpu worker, jobs with priorities 1, 3, 3, 0 -> started in the order 2, 3, 1, 4
+    rt = env()
+    jobs = [rt.new_task(TB().cpus(1).user_priority(p)) for p in (1, 3, 3, 0)]
+    w = rt.new_worker(WB(1))
+    order = []
+    for _ in range(4):
+        rt.schedule(backend)
+        now = [t for t in jobs if _assigned(rt, [t]) == [True]]
+        assert len(now) == 1
+        order.append(jobs.index(now[0]) + 1)
+        rt.start_task(now[0])
+        rt.finish_task(now[0], w)
+    assert order == [2, 3, 1, 4]
+
+
+def e2e_submit_mn(backend):  # tests/test_job_mn.py:10-34: `--nodes=3` waits on two workers, runs on three of four
+    rt = env()
+    rt.new_worker(WB(1)); rt.new_worker(WB(1))
+    t = rt.new_task(TB().n_nodes(3))
+    rt.schedule(backend)
+    assert rt.task(t).is_waiting()
+    rt.new_worker(WB(1)); rt.new_worker(WB(1))
+    rt.schedule(backend)
+    assert rt.task(t).is_mn_running() and len(set(rt.task(t).mn_workers)) == 3 and set(rt.task(t).mn_workers) <= set(rt.workers)
+
+
+def e2e_submit_mn_different_groups(backend):  # tests/test_job_mn.py:97-107: 2 + 2 workers in two groups cannot host 3 nodes; a third g2 worker can
+    rt = env()
+    rt.new_worker(WB(1).group("g1")); rt.new_worker(WB(1).group("g1"))
+    g2 = [rt.new_worker(WB(1).group("g2")), rt.new_worker(WB(1).group("g2"))]
+    t = rt.new_task(TB().n_nodes(3))
+    rt.schedule(backend)
+    assert rt.task(t).is_waiting()
+    g2.append(rt.new_worker(WB(1).group("g2")))
+    rt.schedule(backend)
+    assert rt.task(t).is_mn_running() and sorted(rt.task(t).mn_workers) == sorted(g2)
+
+
+def e2e_scheduler_unschedulable_mn_blocker(backend):  # tests/test_job_mn.py:110-120 (reproducer for #1121): the array must not wait for the 2-node job
+    rt = env()
+    rt.new_worker(WB(1).group("groupA")); rt.new_worker(WB(1).group("groupB"))
+    mn = rt.new_task(TB().n_nodes(2).user_priority(10).time_request(3600))
+    arr = rt.new_tasks(5, TB().cpus(1).user_priority(0))
+    rt.schedule(backend)
+    assert rt.task(mn).is_waiting() and _assigned(rt, arr).count(True) == 2
+
+
+def e2e_submit_mn_time_request(backend):  # tests/test_job_mn.py:123-132: two workers + one with 1 s left cannot host a 2 s three-node task (only two
+    # capable workers in the group); with a fourth worker that has 3 s left the group is capable and the task starts.  (Which three of the four
+    # get it is not asserted there: the model creates a column for every FREE worker of a capable group, solver.rs:101-108 -- no per-worker time check.)
+    rt = env()
+    rt.new_worker(WB(1)); rt.new_worker(WB(1))
+    rt.new_worker(WB(1).time_limit_s(1))
+    t = rt.new_task(TB().n_nodes(3).time_request(2))
+    rt.schedule(backend)
+    assert rt.task(t).is_waiting()
+    rt.new_worker(WB(1).time_limit_s(3))
+    rt.schedule(backend)
+    assert rt.task(t).is_mn_running() and len(set(rt.task(t).mn_workers)) == 3
+
+
+E2E_EXTRA_CASES = [e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
+
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]

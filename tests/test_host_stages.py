@@ -216,3 +216,16 @@ def test_reference_cases_host_stages_shadow(case):
     b = _ShadowBackend()
     case(b)
     assert all(b.flags), "tie-break phase cut short on a reference-sized model"
+
+
+def _extra_cases():
+    import golden_cases
+
+    return golden_cases.E2E_EXTRA_CASES
+
+
+@pytest.mark.parametrize("case", _extra_cases(), ids=lambda f: f.__name__)
+def test_e2e_extra_host_stages_shadow(case):
+    b = _ShadowBackend()
+    case(b)
+    assert all(b.flags) and b.ticks >= 1

@@ -64,3 +64,10 @@ def test_golden_canonical(case):
 @pytest.mark.slow
 def test_many_cuts_oracle():
     golden_cases.test_many_cuts(OracleBackend())
+
+
+@pytest.mark.parametrize("case", golden_cases.E2E_EXTRA_CASES, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("canonical", [False, True])
+def test_e2e_extra(case, canonical):
+    """five more scheduling outcomes of the reference's pytest suite (tests/test_job.py, tests/test_job_mn.py)"""
+    case(CanonicalOracleBackend() if canonical else OracleBackend())

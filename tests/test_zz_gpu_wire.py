@@ -100,3 +100,20 @@ def test_tick_to_bytes_through_the_record_sink():
     assert got.messages(side) == wc.oracle_messages(*sc)
     wc.check_roundtrip(sc, got.messages(side))
     st.t.close()
+
+
+# ---- the five late end-to-end pins of tests/golden_cases.py::E2E_EXTRA_CASES through the HIP C ABI (kept out of test_gpu_golden.py so that
+# a surprise here cannot stop the GPU suite early)
+def _extra():
+    import golden_cases
+
+    return golden_cases.E2E_EXTRA_CASES
+
+
+@pytest.mark.parametrize("case", _extra(), ids=lambda f: f.__name__)
+def test_e2e_extra_gpu(case):
+    from test_gpu_golden import GpuBackend
+
+    b = GpuBackend()
+    case(b)
+    assert all(b.flags)
