@@ -1016,6 +1016,30 @@ def e2e_submit_mn_time_request(backend):  # tests/test_job_mn.py:123-132: two wo
     assert rt.task(t).is_mn_running() and len(set(rt.task(t).mn_workers)) == 3
 
 
-E2E_EXTRA_CASES = [e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
+def extra_schedule_apply_mapping(backend):  # tests/test_scheduler_mapping.rs:6-14: one task -> exactly one message, to w1
+    rt = env()
+    w1 = rt.new_worker(WB(5))
+    t = rt.new_task(TB().cpus(5))
+    res = rt.schedule(backend)
+    assert [len(r) for r in res.records] == [1] and res.records[0][0][0] == t and res.retracts == [[]] and res.mn == [] and sorted(rt.workers) == [w1]
+
+
+def extra_schedule_mapping_do_not_change(backend):  # tests/test_scheduler_mapping.rs:16-45
+    rt = env()
+    rt.new_named_resource("gpus")
+    w1 = rt.new_worker(WB(6).res_sum("gpus", 2))
+    rt.new_worker(WB(3))
+    t1 = rt.new_task(TB().cpus(5))
+    rt.schedule(backend)
+    assert rt.task(t1).is_assigned() and rt.task(t1).worker == w1
+    res = rt.schedule(backend)
+    assert all(not r for r in res.records) and all(not r for r in res.retracts) and not res.mn
+    rt.new_worker(WB(6))
+    rt.new_task(TB().cpus(4).add_resource(1, 2))
+    res = rt.schedule(backend)
+    assert all(not r for r in res.records) and all(not r for r in res.retracts) and not res.mn
+
+
+E2E_EXTRA_CASES = [extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
 
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]
