@@ -103,43 +103,8 @@ int hqwire_encode_device(const hqwire_tables *tables, const hqwire_records *reco
 // whose result depended on that sequence would be a race on the GPU.
 int hqwire_debug_encode_host_order(const hqwire_tables *tables, const hqwire_records *records, const hqwire_output *out, int order) {
     Args a;
-    int seq[BLOCK];
-    for (int i = 0; i < BLOCK; i++) seq[i] = order == 1 ? BLOCK - 1 - i : order == 2 ? (i * 77 + 13) % BLOCK : i;  // 77 is coprime to 256
     if (!make_args(tables, records, out, a)) return HQTICK_E_INVALID;
-    PlanLds *pl = new (std::nothrow) PlanLds;
-    ScanLds *sl = new (std::nothrow) ScanLds;
-    EmitLds *el = new (std::nothrow) EmitLds;
-    if (!pl || !sl || !el) {
-        delete pl;
-        delete sl;
-        delete el;
-        return HQTICK_E_DEVICE;
-    }
-#define HQW_PHASE(fn, lds, s) \
-    for (int q = 0; q < BLOCK; q++) fn(a, lds, s, seq[q])
-    for (uint32_t s = 0; s < a.n_slots; s++) {
-        HQW_PHASE(plan_p0, *pl, s);
-        HQW_PHASE(plan_p1, *pl, s);
-        HQW_PHASE(plan_p2, *pl, s);
-        HQW_PHASE(plan_p3, *pl, s);
-        HQW_PHASE(plan_p4, *pl, s);
-        HQW_PHASE(plan_p5, *pl, s);
-        HQW_PHASE(plan_p6, *pl, s);
-    }
-    for (int q = 0; q < BLOCK; q++) scan_p1(a, *sl, seq[q]);
-    for (int q = 0; q < BLOCK; q++) scan_p2(a, *sl, seq[q]);
-    for (int q = 0; q < BLOCK; q++) scan_p3(a, *sl, seq[q]);
-    for (uint32_t s = 0; s < a.n_slots; s++) {
-        HQW_PHASE(emit_p1, *el, s);
-        HQW_PHASE(emit_p2, *el, s);
-        HQW_PHASE(emit_p3, *el, s);
-        HQW_PHASE(emit_p4, *el, s);
-    }
-#undef HQW_PHASE
-    delete pl;
-    delete sl;
-    delete el;
-    return 0;
+    return run_on_host(a, order) ? 0 : HQTICK_E_DEVICE;
 }
 
 int hqwire_debug_encode_host(const hqwire_tables *tables, const hqwire_records *records, const hqwire_output *out) {

@@ -7,6 +7,7 @@
 // (/root/reference/crates/tako/src/internal/transfer/auth.rs:253-263); struct field order: messages/worker.rs:27-57.
 #pragma once
 #include <cstdint>
+#include <new>
 
 #include "../../include/hqwire.h"
 
@@ -425,6 +426,45 @@ HQW_HD void emit_p4(const Args &a, EmitLds &l, uint32_t s, int tid) {
         uint8_t *dst = m + l.body_rel[k];
         for (uint64_t b = (uint64_t)tid; b < n; b += BLOCK) dst[b] = a.t.body_blob[b0 + b];
     }
+}
+
+// ---- host execution of the phases (debug hook, sanitizer harness): one emulated thread after the other, a loop end = a workgroup barrier --------
+// `order`: sequence of the 256 emulated threads inside every phase (0 ascending, 1 descending, 2 a fixed permutation) -- the result must not
+// depend on it.  Returns false when the LDS stand-ins cannot be allocated.
+inline bool run_on_host(const Args &a, int order) {
+    int seq[BLOCK];
+    for (int i = 0; i < BLOCK; i++) seq[i] = order == 1 ? BLOCK - 1 - i : order == 2 ? (i * 77 + 13) % BLOCK : i;  // 77 is coprime to 256
+    PlanLds *pl = new (std::nothrow) PlanLds;
+    ScanLds *sl = new (std::nothrow) ScanLds;
+    EmitLds *el = new (std::nothrow) EmitLds;
+    const bool ok = pl && sl && el;
+    if (ok) {
+#define HQW_PHASE(fn, lds, s) \
+    for (int q = 0; q < BLOCK; q++) fn(a, lds, s, seq[q])
+        for (uint32_t s = 0; s < a.n_slots; s++) {
+            HQW_PHASE(plan_p0, *pl, s);
+            HQW_PHASE(plan_p1, *pl, s);
+            HQW_PHASE(plan_p2, *pl, s);
+            HQW_PHASE(plan_p3, *pl, s);
+            HQW_PHASE(plan_p4, *pl, s);
+            HQW_PHASE(plan_p5, *pl, s);
+            HQW_PHASE(plan_p6, *pl, s);
+        }
+        for (int q = 0; q < BLOCK; q++) scan_p1(a, *sl, seq[q]);
+        for (int q = 0; q < BLOCK; q++) scan_p2(a, *sl, seq[q]);
+        for (int q = 0; q < BLOCK; q++) scan_p3(a, *sl, seq[q]);
+        for (uint32_t s = 0; s < a.n_slots; s++) {
+            HQW_PHASE(emit_p1, *el, s);
+            HQW_PHASE(emit_p2, *el, s);
+            HQW_PHASE(emit_p3, *el, s);
+            HQW_PHASE(emit_p4, *el, s);
+        }
+#undef HQW_PHASE
+    }
+    delete pl;
+    delete sl;
+    delete el;
+    return ok;
 }
 
 }  // namespace hqwire

@@ -158,3 +158,14 @@ def test_roundtrip_c3_shape():
     res = wire.encode_host_debug(t, r, 1 << 25)
     assert res.status == 0 and (res.slot_status == 0).all()
     wc.check_roundtrip(sc, res.messages(r))
+
+
+def test_phases_under_sanitizers():
+    """tools/wire_asan.py: the phase functions under AddressSanitizer + UBSan with every array in an exact-size heap block (an out-of-bounds
+    access would be a memory fault on the GPU)"""
+    import subprocess
+    import sys
+
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "..", "tools", "wire_asan.py"), "--seeds", "8"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "0 problems" in p.stdout
