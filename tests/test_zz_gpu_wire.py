@@ -11,30 +11,65 @@ from hyperqueue_amd import wire
 pytestmark = pytest.mark.gpu
 
 
+# ---- the five late end-to-end pins of tests/golden_cases.py::E2E_EXTRA_CASES through the HIP C ABI (kept out of test_gpu_golden.py so that
+# a surprise here cannot stop the GPU suite early)
+def _extra():
+    import golden_cases
+
+    return golden_cases.E2E_EXTRA_CASES
+
+
+@pytest.mark.parametrize("case", _extra(), ids=lambda f: f.__name__)
+def test_e2e_extra_gpu(case):
+    from test_gpu_golden import GpuBackend
+
+    b = GpuBackend()
+    case(b)
+    assert all(b.flags)
+
+
+@pytest.fixture(scope="module")
+def wire_canary():
+    """First contact of the wire kernels with hardware happens in a SUBPROCESS: a device fault there kills that process, not the GPU suite.
+    The in-process tests below run only if the canary came back clean."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import wire_cases as wc\nfrom hyperqueue_amd import wire\n"
+            "for seed in (0, 1, 2):\n    wc.check_scenario(wire.encode_device, wc.random_scenario(seed))\nprint('canary ok')\n") % (
+        os.path.join(os.path.dirname(__file__), ".."), os.path.dirname(__file__))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    if p.returncode != 0 or "canary ok" not in p.stdout:
+        pytest.fail("wire kernels failed their first hardware run (subprocess): exit %s\n%s" % (p.returncode, (p.stdout + p.stderr)[-1500:]))
+    return True
+
+
 @pytest.mark.parametrize("seed", range(12))
-def test_device_matches_oracle(seed):
+def test_device_matches_oracle(seed, wire_canary):
     wc.check_scenario(wire.encode_device, wc.random_scenario(seed))
 
 
-def test_device_tick_mapping():
+def test_device_tick_mapping(wire_canary):
     wc.check_scenario(wire.encode_device, wc.tick_scenario())
 
 
 @pytest.mark.parametrize("seed", range(40, 46))
-def test_device_roundtrip_through_independent_decoder(seed):
+def test_device_roundtrip_through_independent_decoder(seed, wire_canary):
     sc = wc.random_scenario(seed)
     t, r = wc.tables_and_records(*sc)
     wc.check_roundtrip(sc, wire.encode_device(t, r, 1 << 22).messages(r))
 
 
-def test_device_wide_message():
+def test_device_wide_message(wire_canary):
     rnd = random.Random(3)
     configs = [(None if i % 2 else (60 * i, 0), bytes([i]) * (50 * i)) for i in range(12)]
     attrs = {((5 << 32) | i): (1, i, 7, rnd.randrange(12), None if i % 3 else b"e%d" % i) for i in range(1, 2001)}
     wc.check_scenario(wire.encode_device, (attrs, configs, [77], [[(t, 0, 1) for t in attrs]], [[]], []), capacity=1 << 24)
 
 
-def test_device_c3_shape():
+def test_device_c3_shape(wire_canary):
     """BASELINE C3's cold tick shape: 1024 workers x (120 prefills + 64 assigned) records, 8 request classes = 8 configurations"""
     rnd = random.Random(11)
     configs = [((3600, 0), b"body-of-class-%d" % i * 8) for i in range(8)]
@@ -53,7 +88,7 @@ def test_device_c3_shape():
     assert res.total_bytes > W * per * 42
 
 
-def test_device_slot_conditions_and_capacity():
+def test_device_slot_conditions_and_capacity(wire_canary):
     attrs = {1: (0, 0, 0, 0, None), 3: (0, 0, 0, 0, None)}
     configs = [(None, b"small")]
     records = [[(1, 0, 1)], [(99, 0, 1)], [(3, 0, 1)] * (wire.HQWIRE_MAX_RECORDS + 1)]
@@ -66,7 +101,7 @@ def test_device_slot_conditions_and_capacity():
     assert small.status == wire.HQWIRE_CAPACITY and small.total_bytes == res.total_bytes
 
 
-def test_tick_to_bytes_through_the_record_sink():
+def test_tick_to_bytes_through_the_record_sink(wire_canary):
     """DESIGN.md 8d end to end: a real tick (HIP library) leaves its records in a device record sink, hqwire_encode_device reads them there, and
     the bytes equal what the oracle's tick + the bincode oracle produce for the same snapshot."""
     import numpy as np
@@ -100,20 +135,3 @@ def test_tick_to_bytes_through_the_record_sink():
     assert got.messages(side) == wc.oracle_messages(*sc)
     wc.check_roundtrip(sc, got.messages(side))
     st.t.close()
-
-
-# ---- the five late end-to-end pins of tests/golden_cases.py::E2E_EXTRA_CASES through the HIP C ABI (kept out of test_gpu_golden.py so that
-# a surprise here cannot stop the GPU suite early)
-def _extra():
-    import golden_cases
-
-    return golden_cases.E2E_EXTRA_CASES
-
-
-@pytest.mark.parametrize("case", _extra(), ids=lambda f: f.__name__)
-def test_e2e_extra_gpu(case):
-    from test_gpu_golden import GpuBackend
-
-    b = GpuBackend()
-    case(b)
-    assert all(b.flags)
