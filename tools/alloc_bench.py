@@ -41,7 +41,23 @@ def run(mod, desc, rq, fill, seconds):
     return (time.perf_counter() - t0) / max(1, n) * 1e6
 
 
+def native():
+    """tools/alloc_bench.cpp: the same mixes from C, without ctypes between the timer and the library."""
+    import subprocess
+    import tempfile
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    lib = os.path.abspath(os.path.join(root, "hyperqueue_amd"))
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "alloc_bench")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tools", "alloc_bench.cpp"), "-L" + lib, "-lhqalloc", "-Wl,-rpath," + lib])
+        print(subprocess.run([exe], capture_output=True, text=True, check=True).stdout, end="")
+
+
 if __name__ == "__main__":
+    if "--native" in sys.argv:
+        native()
+        sys.exit(0)
     for (name, d1, r1, fill), (_, d2, r2, _) in zip(mixes(api), mixes(ora)):
         a = run(api, d1, r1, fill, 1.0)
         o = run(ora, d2, r2, fill, 1.0)
