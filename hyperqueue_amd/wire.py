@@ -249,3 +249,80 @@ def encode_from_sink(t: WireTables, sink, n_workers: int, sink_cap_records: int,
     tc = TablesC(t.n_tasks, *[x.data_ptr() for x in tt[:8]], t.n_configs, *[x.data_ptr() for x in tt[8:]])
     rc = RecordsC(n_workers, n_records, *ptrs_r[:7], side.n_mn, *ptrs_r[7:])
     return _run_device(lib, torch, dev, tc, rc, n_workers + side.n_mn, n_records + side.n_mn, capacity)
+
+
+# ---- worker-sharded ticks: every rank encodes the messages of ITS workers, one all-gather merges the byte buffers -----------------
+def shard_records(r: WireRecords, rank: int, world: int) -> WireRecords:
+    """The mapping as rank `rank` of a worker-sharded tick holds it: records and retracts of its own workers only
+    (owner = FxHash(worker_id) % world, hqtick_set_shard); multi-node messages are rank 0's."""
+    from .sharded import owner_of
+
+    mine = [owner_of(int(w), world) == rank for w in r.worker_id]
+    recs = [[(int(r.rec_task[i]), int(r.rec_variant[i]), int(r.rec_kind[i])) for i in range(int(r.rec_off[w]), int(r.rec_off[w + 1]))] if mine[w] else []
+            for w in range(r.n_workers)]
+    rets = [[int(t) for t in r.retract_task[int(r.retract_off[w]):int(r.retract_off[w + 1])]] if mine[w] else [] for w in range(r.n_workers)]
+    mn = [(int(r.mn_task[k]), [int(x) for x in r.mn_worker[int(r.mn_worker_off[k]):int(r.mn_worker_off[k + 1])]]) for k in range(r.n_mn)] if rank == 0 else []
+    out = WireRecords.build([int(w) for w in r.worker_id], recs, rets, mn)
+    return out
+
+
+def pack_wire_shard(res: WireResult, n_slots: int, capacity: int) -> np.ndarray:
+    """Fixed-size shard buffer for the all-gather: u64 total | u64 slot_off[2 * n_slots + 1] | bytes[capacity]."""
+    if res.status != HQWIRE_OK or res.total_bytes > capacity:
+        raise ValueError(f"wire shard does not fit: {res.total_bytes} bytes, capacity {capacity}")
+    head = np.full(2 * n_slots + 2, res.total_bytes, np.uint64)  # slots this rank does not have (padding up to the widest rank) stay empty ranges
+    head[0] = res.total_bytes
+    head[1:1 + len(res.slot_off)] = res.slot_off
+    body = np.zeros(capacity, np.uint8)
+    body[: res.total_bytes] = np.frombuffer(res.data, np.uint8)
+    return np.concatenate([head.view(np.uint8), body])
+
+
+def merge_wire_shards(merged: np.ndarray, world: int, n_slots_per_rank: Sequence[int], capacity: int, worker_id_of_slot) -> List[Tuple[int, bytes]]:
+    """[(worker id, message bytes)] from the all-gathered shard buffers, slot by slot (worker-index order, multi-node slots last; of every
+    slot only its owner holds bytes).  `worker_id_of_slot(rank, slot)` names the receiver."""
+    out: List[Tuple[int, bytes]] = []
+    views, pos = [], 0
+    for rnk in range(world):
+        S = n_slots_per_rank[rnk]
+        size = 8 * (2 * S + 2) + capacity
+        buf = merged[pos:pos + size]
+        pos += size
+        head = buf[: 8 * (2 * S + 2)].view(np.uint64)
+        views.append((S, head[1:], buf[8 * (2 * S + 2):]))
+    for s in range(max(n_slots_per_rank)):
+        for rnk in range(world):
+            S, off, body = views[rnk]
+            if s >= S:
+                continue
+            for j in (2 * s, 2 * s + 1):
+                lo, hi = int(off[j]), int(off[j + 1])
+                if hi > lo:
+                    out.append((worker_id_of_slot(rnk, s), body[lo:hi].tobytes()))
+    return out
+
+
+def all_gather_messages(res: WireResult, records: WireRecords, world: int, capacity: int, group=None) -> List[Tuple[int, bytes]]:
+    """One `all_gather` of the ranks' shard buffers (RCCL on the GPUs; gloo in the CPU tests), then the merge: every rank ends up with the
+    tick's full message list.  Ranks agree on n_workers; rank 0 may carry extra multi-node slots."""
+    import torch
+    import torch.distributed as dist
+
+    W = records.n_workers
+    n_slots = len(res.slot_status)
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([n_slots], dtype=torch.int64), group=group)
+    slots = [max(int(c.item()) for c in counts)] * world  # equal-sized buffers: pad to the widest rank (rank 0 carries the multi-node slots)
+    mine = torch.from_numpy(pack_wire_shard(res, slots[0], capacity))
+    bufs = [torch.zeros(8 * (2 * S + 2) + capacity, dtype=torch.uint8) for S in slots]
+    dist.all_gather(bufs, mine, group=group)
+    merged = np.concatenate([b.numpy() for b in bufs])
+    mn_root = {}  # multi-node slots exist on rank 0 only; every rank learns their receivers from rank 0's records
+    obj = [[int(records.worker_id[records.mn_worker[records.mn_worker_off[k]]]) for k in range(records.n_mn)] if dist.get_rank(group) == 0 else None]
+    dist.broadcast_object_list(obj, src=0, group=group)
+    roots = obj[0]
+
+    def receiver(rnk, s):
+        return int(records.worker_id[s]) if s < W else roots[s - W]
+
+    return merge_wire_shards(merged, world, slots, capacity, receiver)

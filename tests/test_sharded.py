@@ -165,3 +165,44 @@ def test_two_rank_divergence_falls_back_to_rank0_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for (_, ok) in res), res
+
+
+# ---- row f3 sharded: every rank encodes the messages of its own workers (here: the kernels' phase functions through the CPU debug hook), one
+# all-gather of the byte buffers, every rank holds the tick's full message list
+def _wire_rank_main(rank: int, world: int, port: int, out_q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import wire_cases as wc
+        from hyperqueue_amd import wire
+
+        sc = wc.random_scenario(12, n_workers=9)  # 59 records, 18 retracts, one multi-node task
+        tables, full = wc.tables_and_records(*sc)
+        mine = wire.shard_records(full, rank, world)
+        res = wire.encode_host_debug(tables, mine, 1 << 20)
+        got = wire.all_gather_messages(res, mine, world, 1 << 20)
+        want = wc.oracle_messages(*sc)
+        own_bytes = res.total_bytes
+        out_q.put((rank, got == want, own_bytes, sum(len(b) for _, b in want)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_wire_allgather_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wire_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for (_, ok, _, _) in res), res
+    total = res[0][3]
+    assert sum(b for (_, _, b, _) in res) == total and all(0 < b < total for (_, _, b, _) in res)  # both shards carried message bytes
