@@ -1040,6 +1040,56 @@ def extra_schedule_mapping_do_not_change(backend):  # tests/test_scheduler_mappi
     assert all(not r for r in res.records) and all(not r for r in res.retracts) and not res.mn
 
 
-E2E_EXTRA_CASES = [extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
+def _setup_prefill(backend):  # tests/test_reactor.rs:775-795
+    rt = env(reserve=1, fill_max=1)
+    tasks = rt.new_tasks(3, TB())
+    w1 = rt.new_worker(WB(1))
+    rt.schedule(backend)
+    return rt, w1, tasks
+
+
+def extra_reactor_setup_prefill(backend):  # tests/test_reactor.rs:775-795 + what test_prefill_* assert about the state it leaves (:797-991)
+    rt, w1, tasks = _setup_prefill(backend)
+    states = [(rt.task(t).is_assigned(), rt.task(t).is_prefilled(), rt.task(t).is_waiting()) for t in tasks]
+    assert sorted(states) == sorted([(True, False, False), (False, True, False), (False, False, True)])
+    assert rt.prefill_count(w1) == 1 and len(rt.worker(w1).assigned_tasks) == 1
+    # test_prefill_submit_same_priority (:828-848): an arrival of the same priority leaves the prefill alone ...
+    prefilled = next(t for t in tasks if rt.task(t).is_prefilled())
+    rt.new_task(TB().cpus(2))
+    assert rt.task(prefilled).is_prefilled() and rt.retract_messages == []
+    # ... test_prefill_submit_high_priority (:797-826): a higher one dissolves it: RetractTasks([t2]) to w1, t2 Retracting{w1}
+    rt.new_task(TB().cpus(1).user_priority(10))
+    assert rt.task(prefilled).is_retracting() and rt.task(prefilled).worker == w1 and rt.retract_messages == [(w1, prefilled)]
+
+
+def extra_reactor_setup_retracting(backend):  # tests/test_reactor.rs:993-1007 + test_steal_rejected / _source_worker_lost (:1109-1137): the redirect target
+    rt, w1, tasks = _setup_prefill(backend)
+    w2 = rt.new_worker(WB(2))
+    res = rt.schedule(backend)
+    retracting = [t for t in tasks if rt.task(t).is_retracting()]
+    assert len(retracting) == 1 and rt.task(retracting[0]).worker == w1
+    assert res.retracts[0] == retracting                      # RetractTasks to w1
+    assert rt.redirects == {retracting[0]: (w2, 0)}           # on retract response / reject / loss of w1 the task is Assigned on w2
+    rt.retract_response(w1, retracting)
+    assert rt.task(retracting[0]).is_assigned() and rt.task(retracting[0]).worker == w2 and rt.redirects == {}
+
+
+def extra_reactor_prefill_started_on_same_worker(backend):  # tests/test_reactor.rs:865-903
+    rt = env(reserve=0, fill_max=3)
+    t1 = rt.new_task(TB())
+    w1 = rt.new_worker(WB(2))
+    rt.schedule(backend)
+    assert rt.task(t1).is_assigned()
+    tasks = rt.new_tasks(2, TB())
+    rt.schedule(backend)
+    prefilled = [t for t in tasks if rt.task(t).is_prefilled()]
+    assigned = [t for t in tasks if rt.task(t).is_assigned()]
+    assert len(prefilled) == 1 and len(assigned) == 1
+    rt.finish_task(t1, w1)
+    rt.schedule(backend)
+    assert rt.task(prefilled[0]).is_retracting()  # taken by the very worker that holds it as a prefill: retract + redirect to itself
+
+
+E2E_EXTRA_CASES = [extra_reactor_setup_prefill, extra_reactor_setup_retracting, extra_reactor_prefill_started_on_same_worker, extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
 
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]
