@@ -426,6 +426,31 @@ class SchedEnv:
     def block_request(self, wid: int, rq: int, variant: int):
         self.workers[wid].blocked_requests.add((rq, variant))
 
+    def reject_task(self, tid: int, wid: int, variant: Optional[int] = 0):
+        """on_task_update(RejectRequest) = task_reject  server/reactor.rs:365-442, the Assigned and Prefilled arms: the worker blocks the
+        (request, variant), gives the task's resources back, and the task returns to its queue as Waiting (the Retracting arm with a redirect
+        is `retract_response`'s twin and is not needed by the scheduler tests)."""
+        t = self.tasks[tid]
+        w = self.workers[wid]
+        if variant is not None:
+            w.blocked_requests.add((t.rq, variant))
+        if t.state == ASSIGNED:
+            if t.worker == wid and variant == t.rv:
+                w.assigned_tasks.discard(tid)
+                self._add(w, t.rq, t.rv)  # remove_sn_task  server/worker.rs:223-234
+        elif t.state == PREFILLED:
+            w.prefilled_tasks.discard(tid)
+            p, sset = self.prefill[t.rq]
+            sset.remove(tid)
+        else:
+            raise AssertionError("unreachable in the reference (reactor.rs:434-439)")
+        t.state, t.worker = WAITING, None
+        self._add_ready(t)
+
+    def enable_request(self, wid: int, rq: int, variant: int):
+        """on_task_update(EnableRequest) = request_enabled  server/reactor.rs:444-458."""
+        self.workers[wid].blocked_requests.discard((rq, variant))
+
     # -- flatten ---------------------------------------------------------------------------------------
     def snapshot(self) -> abi.Snapshot:
         R = self.n_resources

@@ -1090,6 +1090,48 @@ def extra_reactor_prefill_started_on_same_worker(backend):  # tests/test_reactor
     assert rt.task(prefilled[0]).is_retracting()  # taken by the very worker that holds it as a prefill: retract + redirect to itself
 
 
-E2E_EXTRA_CASES = [extra_reactor_setup_prefill, extra_reactor_setup_retracting, extra_reactor_prefill_started_on_same_worker, extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
+def extra_reactor_task_reject1(backend):  # tests/test_reactor.rs:664-705: a rejected request stays blocked on that worker until EnableRequest
+    rt = env()
+    w = rt.new_worker(WB(4))
+    t = rt.new_task(TB())
+    rt.schedule(backend)
+    assert rt.task(t).is_assigned()
+    rt.reject_task(t, w, 0)
+    assert rt.task(t).is_waiting() and rt.worker(w).free == rt.worker(w).total
+    rt.schedule(backend)
+    assert rt.task(t).is_waiting() and rt.worker(w).free == rt.worker(w).total
+    rt.enable_request(w, rt.task(t).rq, 0)
+    rt.schedule(backend)
+    assert rt.task(t).is_assigned()
+
+
+def extra_reactor_task_reject2(backend):  # tests/test_reactor.rs:707-734: with variant 0 blocked the task is placed with variant 1
+    rt = env()
+    w = rt.new_worker(WB(4))
+    t = rt.new_task(TB().cpus(4).next_variant().cpus(2))
+    rt.schedule(backend)
+    assert rt.task(t).is_assigned() and (rt.task(t).worker, rt.task(t).rv) == (w, 0)
+    rt.reject_task(t, w, 0)
+    assert rt.task(t).is_waiting()
+    rt.schedule(backend)
+    assert rt.task(t).is_assigned() and (rt.task(t).worker, rt.task(t).rv) == (w, 1)
+    assert rt.worker(w).free != rt.worker(w).total
+
+
+def extra_reactor_task_reject3(backend):  # tests/test_reactor.rs:736-773
+    rt = env()
+    w = rt.new_worker(WB(4))
+    t1, t2 = rt.new_task(TB()), rt.new_task(TB())
+    rt.schedule(backend)
+    assert rt.task(t1).is_assigned() and rt.task(t2).is_assigned()
+    rt.reject_task(t1, w, 0)
+    assert rt.task(t1).is_waiting() and rt.task(t2).is_assigned()
+    rt.reject_task(t2, w, 0)
+    assert rt.task(t1).is_waiting() and rt.task(t2).is_waiting()
+    rt.schedule(backend)  # both stay: the only worker has the request blocked
+    assert rt.task(t1).is_waiting() and rt.task(t2).is_waiting()
+
+
+E2E_EXTRA_CASES = [extra_reactor_task_reject1, extra_reactor_task_reject2, extra_reactor_task_reject3, extra_reactor_setup_prefill, extra_reactor_setup_retracting, extra_reactor_prefill_started_on_same_worker, extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
 
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]
