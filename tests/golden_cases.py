@@ -1062,6 +1062,15 @@ def extra_reactor_setup_prefill(backend):  # tests/test_reactor.rs:775-795 + wha
     assert rt.task(prefilled).is_retracting() and rt.task(prefilled).worker == w1 and rt.retract_messages == [(w1, prefilled)]
 
 
+def extra_reactor_prefill_rejected(backend):  # tests/test_reactor.rs:932-947 (+ a tick afterwards: the worker has the request blocked, nothing moves)
+    rt, w1, tasks = _setup_prefill(backend)
+    prefilled = next(t for t in tasks if rt.task(t).is_prefilled())
+    rt.reject_task(prefilled, w1, 0)
+    assert rt.task(prefilled).is_waiting() and rt.worker(w1).blocked_requests and rt.prefill_count(w1) == 0
+    res = rt.schedule(backend)
+    assert all(not r for r in res.records) and rt.task(prefilled).is_waiting()
+
+
 def extra_reactor_setup_retracting(backend):  # tests/test_reactor.rs:993-1007 + test_steal_rejected / _source_worker_lost (:1109-1137): the redirect target
     rt, w1, tasks = _setup_prefill(backend)
     w2 = rt.new_worker(WB(2))
@@ -1132,6 +1141,6 @@ def extra_reactor_task_reject3(backend):  # tests/test_reactor.rs:736-773
     assert rt.task(t1).is_waiting() and rt.task(t2).is_waiting()
 
 
-E2E_EXTRA_CASES = [extra_reactor_task_reject1, extra_reactor_task_reject2, extra_reactor_task_reject3, extra_reactor_setup_prefill, extra_reactor_setup_retracting, extra_reactor_prefill_started_on_same_worker, extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
+E2E_EXTRA_CASES = [extra_reactor_prefill_rejected, extra_reactor_task_reject1, extra_reactor_task_reject2, extra_reactor_task_reject3, extra_reactor_setup_prefill, extra_reactor_setup_retracting, extra_reactor_prefill_started_on_same_worker, extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
 
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]
