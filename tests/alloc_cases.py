@@ -591,6 +591,13 @@ def test_e2e_coupling_alloc2(api):
         ac.validate()
 
 
+def test_e2e_integration_force_compact(api):
+    """crates/tako/src/internal/tests/integration/test_resources.rs:251-276: `cpus = 4 compact!` runs on a 2 x 2 socket worker (both groups)"""
+    ac = api.ResourceAllocator(api.Descriptor([api.regular_sockets(2, 2)]))
+    al = ac.try_allocate(rq(api, (0, api.FORCE_COMPACT, units(api, 4))))
+    assert al is not None and sorted(get_indices(al, 0)) == [0, 1, 2, 3] and get_sockets(al, 0) == [0, 1]
+
+
 def test_e2e_coupling_combined(api):
     """test_coupling.py:154-199: the seven (cpus policy, foo policy) rows on an idle worker."""
     cpus, cl = label_groups(api, [[1, 2, 3, 4], [11, 12, 13, 14], [21, 22, 23, 24]])

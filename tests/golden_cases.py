@@ -1141,6 +1141,65 @@ def extra_reactor_task_reject3(backend):  # tests/test_reactor.rs:736-773
     assert rt.task(t1).is_waiting() and rt.task(t2).is_waiting()
 
 
-E2E_EXTRA_CASES = [extra_reactor_prefill_rejected, extra_reactor_task_reject1, extra_reactor_task_reject2, extra_reactor_task_reject3, extra_reactor_setup_prefill, extra_reactor_setup_retracting, extra_reactor_prefill_started_on_same_worker, extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
+# ---- the reference's in-process integration tests (crates/tako/src/internal/tests/integration/test_resources.rs): real workers run `sleep 1`
+# tasks; what they observe (running tasks per worker, total duration) is decided by the first tick after everything is connected
+def _running_per_worker(rt):
+    return sorted(len(rt.worker(w).assigned_tasks) for w in rt.workers)
+
+
+def integ_submit_2_sleeps_on_1(backend):  # integration/test_resources.rs:17-49: one 1-cpu worker runs task 1, then task 2
+    rt = env()
+    t1, t2 = rt.new_task(TB()), rt.new_task(TB())
+    w = rt.new_worker(WB(1))
+    rt.schedule(backend)
+    assert rt.task(t1).is_assigned() and not rt.task(t2).is_assigned()
+    rt.start_task(t1); rt.finish_task(t1, w)
+    rt.schedule(backend)
+    assert rt.task(t2).is_assigned()
+
+
+def integ_submit_2_sleeps_on_2(backend):  # :52-83: a 2-cpu worker runs both at once
+    rt = env()
+    ts = rt.new_tasks(2, TB())
+    rt.new_worker(WB(2))
+    rt.schedule(backend)
+    assert all(rt.task(t).is_assigned() for t in ts)
+
+
+def integ_submit_2_sleeps_on_separated_2(backend):  # :85-121: three 1-cpu workers, two tasks: one each, one worker stays empty
+    rt = env()
+    rt.new_tasks(2, TB())
+    rt.new_workers(3, WB(1))
+    rt.schedule(backend)
+    assert _running_per_worker(rt) == [0, 1, 1]
+
+
+def integ_submit_sleeps_more_cpus1(backend):  # :123-172: tasks of 3, 2, 2 cpus on two 4-cpu workers run at once, one worker with 1 task, one with 2
+    rt = env()
+    for c in (3, 2, 2):
+        rt.new_task(TB().cpus(c))
+    rt.new_workers(2, WB(4))
+    rt.schedule(backend)
+    assert _running_per_worker(rt) == [1, 2]
+
+
+def integ_submit_sleeps_more_cpus2(backend):  # :174-210: 3, 2, 2, 3 cpus on two 4-cpu workers need two rounds (>= 2 s of 1 s sleeps)
+    rt = env()
+    ts = [rt.new_task(TB().cpus(c)) for c in (3, 2, 2, 3)]
+    rt.new_workers(2, WB(4))
+    rt.schedule(backend)
+    assert sum(rt.task(t).is_assigned() for t in ts) < 4
+
+
+def integ_submit_sleeps_more_cpus3(backend):  # :212-249: the same tasks on two 5-cpu workers all run in the first round (<= 2.3 s)
+    rt = env()
+    ts = [rt.new_task(TB().cpus(c)) for c in (3, 2, 2, 3)]
+    rt.new_workers(2, WB(5))
+    rt.schedule(backend)
+    assert all(rt.task(t).is_assigned() for t in ts) and _running_per_worker(rt) == [2, 2]
+
+
+E2E_EXTRA_CASES = [integ_submit_2_sleeps_on_1, integ_submit_2_sleeps_on_2, integ_submit_2_sleeps_on_separated_2, integ_submit_sleeps_more_cpus1,
+                   integ_submit_sleeps_more_cpus2, integ_submit_sleeps_more_cpus3, extra_reactor_prefill_rejected, extra_reactor_task_reject1, extra_reactor_task_reject2, extra_reactor_task_reject3, extra_reactor_setup_prefill, extra_reactor_setup_retracting, extra_reactor_prefill_started_on_same_worker, extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
 
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]
