@@ -1199,7 +1199,29 @@ def integ_submit_sleeps_more_cpus3(backend):  # :212-249: the same tasks on two 
     assert all(rt.task(t).is_assigned() for t in ts) and _running_per_worker(rt) == [2, 2]
 
 
-E2E_EXTRA_CASES = [integ_submit_2_sleeps_on_1, integ_submit_2_sleeps_on_2, integ_submit_2_sleeps_on_separated_2, integ_submit_sleeps_more_cpus1,
+def integ_query_no_output(backend):  # integration/test_basic.rs:128-180: a 1-cpu task with a 1-cpu worker around asks for no new worker -- before the
+    # right after the submit ("immediate call": ServerRef::new_worker_query first finishes the pending scheduling, crates/tako/src/control.rs:134-154,
+    # so the task is already placed when the query model is built) and once it runs ("delayed call")
+    q = [WQ.cpus(12, max_sn_workers=2, max_workers_per_allocation=2)]
+    rt = env()
+    rt.new_worker(WB(1))
+    t = rt.new_task(TB())
+    rt.schedule(backend)
+    assert rt.task(t).is_assigned() and rt.new_worker_query(backend, q) == ([0], [])
+    rt.start_task(t)
+    assert rt.new_worker_query(backend, q) == ([0], [])
+
+
+def integ_query_new_workers(backend):  # integration/test_basic.rs:182-232: a 5-cpu task that the 1-cpu worker cannot run asks for one 12-cpu worker
+    q = [WQ.cpus(12, max_sn_workers=2, max_workers_per_allocation=2)]
+    rt = env()
+    rt.new_worker(WB(1))
+    rt.new_task(TB().cpus(5))
+    rt.schedule(backend)  # control.rs:134-154; nothing can be placed
+    assert rt.new_worker_query(backend, q) == ([1], [])
+
+
+E2E_EXTRA_CASES = [integ_query_no_output, integ_query_new_workers, integ_submit_2_sleeps_on_1, integ_submit_2_sleeps_on_2, integ_submit_2_sleeps_on_separated_2, integ_submit_sleeps_more_cpus1,
                    integ_submit_sleeps_more_cpus2, integ_submit_sleeps_more_cpus3, extra_reactor_prefill_rejected, extra_reactor_task_reject1, extra_reactor_task_reject2, extra_reactor_task_reject3, extra_reactor_setup_prefill, extra_reactor_setup_retracting, extra_reactor_prefill_started_on_same_worker, extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
 
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]
