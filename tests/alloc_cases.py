@@ -591,6 +591,82 @@ def test_e2e_coupling_alloc2(api):
         ac.validate()
 
 
+def test_e2e_fractions_sharing_small(api):
+    """test_resources.py:210-237: worker `foo=[a,b]`, four tasks of foo=0.4 run at once; every index is shared by exactly two of them"""
+    ac = api.ResourceAllocator(api.Descriptor([api.simple_indices(4), api.simple_indices(2)]))
+    seen = {}
+    for _ in range(4):
+        al = ac.try_allocate(rq(api, (1, api.COMPACT, api.amount(0, 4000))))
+        (i,) = get_indices(al, 1)
+        seen[i] = seen.get(i, 0) + 1
+    assert seen == {0: 2, 1: 2}
+    ac.validate()
+
+
+def test_e2e_fractions_sharing_larger(api):
+    """test_resources.py:240-270: ten indices, four tasks of foo=2.5 at once: eight whole indices used once each, two indices shared by two halves"""
+    ac = api.ResourceAllocator(api.Descriptor([api.simple_indices(4), api.simple_indices(10)]))
+    whole, frac = {}, {}
+    for _ in range(4):
+        al = ac.try_allocate(rq(api, (1, api.COMPACT, api.amount(2, 5000))))
+        idx = get_indices(al, 1)
+        for i in idx[:-1]:
+            whole[i] = whole.get(i, 0) + 1
+        frac[idx[-1]] = frac.get(idx[-1], 0) + 1
+    assert tuple(frac.values()) == (2, 2) and tuple(whole.values()) == (1,) * 8
+    ac.validate()
+
+
+def test_e2e_fractions_scatter(api):
+    """test_resources.py:163-182: foo=[[a,b,c],[i,j,k],[x,y],[v,w]], one task of foo=3.5 gets four different indices"""
+    foo, _ = label_groups(api, [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]])
+    ac = api.ResourceAllocator(api.Descriptor([api.simple_indices(4), foo]))
+    al = ac.try_allocate(rq(api, (1, api.COMPACT, api.amount(3, 5000))))
+    idx = get_indices(al, 1)
+    assert len(idx) == 4 and len(set(idx)) == 4
+
+
+def test_e2e_range_multiple_allocated_values(api):
+    """test_resources.py:107-135 / :68-104 / :273-295: `fairy=range(31-36)`, three tasks of fairy=2 hold six different values of the range; a sum
+    resource next to it yields no indices; `foo=[a,b,c]` with foo=2 yields two different labels"""
+    ac = api.ResourceAllocator(api.Descriptor([api.simple_indices(4), api.range_pool(31, 36), api.sum_pool(units(api, 2_000_000))]))
+    vals = []
+    for _ in range(3):
+        al = ac.try_allocate(rq(api, (1, api.COMPACT, units(api, 2)), (2, api.COMPACT, units(api, 1000))))
+        assert len(get_indices(al, 1)) == 2 and get_indices(al, 2) == []
+        vals += get_indices(al, 1)
+    assert all(31 <= v <= 36 for v in vals) and len(set(vals)) == 6
+    ac = api.ResourceAllocator(api.Descriptor([api.simple_indices(1), api.simple_indices(3)]))
+    al = ac.try_allocate(rq(api, (1, api.COMPACT, units(api, 2))))
+    assert len(set(get_indices(al, 1))) == 2 and set(get_indices(al, 1)) <= {0, 1, 2}
+
+
+def test_e2e_fractions_blocked(api):
+    """test_resources.py:606-610: `cpus=2`, three tasks of 0.6 cpus: the amounts add up to 1.8 <= 2, but a third 0.6 fits on no single cpu -- the
+    worker rejects it (the server then blocks the request, test_reactor.rs:664-705) until one of the first two has finished"""
+    ac = api.ResourceAllocator(api.Descriptor([api.simple_indices(2)]))
+    r = rq(api, (0, api.COMPACT, api.amount(0, 6000)))
+    a1, a2 = ac.try_allocate(r), ac.try_allocate(r)
+    assert a1 is not None and a2 is not None and get_indices(a1, 0) != get_indices(a2, 0)
+    assert ac.try_allocate(r) is None and not ac.is_enabled(r)
+    ac.release_allocation(a1)
+    assert ac.is_enabled(r) and ac.try_allocate(r) is not None
+
+
+def test_e2e_strict_compact_blocked(api):
+    """test_resources.py:613-617: cpus [[1,2,3],[11,12,13]], three tasks of `2 compact!`: two run (one per socket), the third would need both
+    sockets and is rejected until a socket is whole again"""
+    cpus, _ = label_groups(api, [[1, 2, 3], [11, 12, 13]])
+    ac = api.ResourceAllocator(api.Descriptor([cpus]))
+    r = rq(api, (0, api.FORCE_COMPACT, units(api, 2)))
+    a1, a2 = ac.try_allocate(r), ac.try_allocate(r)
+    assert len(get_sockets(a1, 0)) == 1 and len(get_sockets(a2, 0)) == 1 and get_sockets(a1, 0) != get_sockets(a2, 0)
+    assert ac.try_allocate(r) is None
+    ac.release_allocation(a2)
+    a3 = ac.try_allocate(r)
+    assert a3 is not None and len(get_sockets(a3, 0)) == 1
+
+
 def test_e2e_integration_force_compact(api):
     """crates/tako/src/internal/tests/integration/test_resources.rs:251-276: `cpus = 4 compact!` runs on a 2 x 2 socket worker (both groups)"""
     ac = api.ResourceAllocator(api.Descriptor([api.regular_sockets(2, 2)]))

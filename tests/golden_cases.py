@@ -1221,7 +1221,32 @@ def integ_query_new_workers(backend):  # integration/test_basic.rs:182-232: a 5-
     assert rt.new_worker_query(backend, q) == ([1], [])
 
 
-E2E_EXTRA_CASES = [integ_query_no_output, integ_query_new_workers, integ_submit_2_sleeps_on_1, integ_submit_2_sleeps_on_2, integ_submit_2_sleeps_on_separated_2, integ_submit_sleeps_more_cpus1,
+def e2e_resource_fractions_sum(backend):  # tests/test_resources.py:138-160, :185-207
+    rt = env()
+    rt.new_named_resource("foo")
+    rt.new_worker(WB(4).res_sum("foo", 2))
+    ts = rt.new_tasks(4, TB().cpus(1).add_resource(1, 0.5))
+    rt.schedule(backend)
+    assert all(rt.task(t).is_assigned() for t in ts)          # four halves of foo=sum(2) start together
+    rt = env()
+    rt.new_named_resource("foo")
+    rt.new_worker(WB(4).res_sum("foo", 2.2))
+    ts = rt.new_tasks(4, TB().cpus(1).add_resource(1, 0.6))
+    rt.schedule(backend)
+    assert sum(rt.task(t).is_assigned() for t in ts) == 3     # 4 x 0.6 > 2.2: the fourth starts a second later
+
+
+def e2e_ignore_worker_without_resource(backend):  # tests/test_resources.py:39-65: fairy=1 + potato=1 000 000 fits none of the three workers
+    rt = env()
+    rt.new_named_resource("fairy"); rt.new_named_resource("potato")
+    t = rt.new_task(TB().cpus(1).add_resource(1, 1).add_resource(2, 1_000_000))
+    for wb in (WB(4), WB(4).res_sum("fairy", 1000), WB(4).res_sum("fairy", 2).res_sum("potato", 500)):
+        rt.new_worker(wb)
+        rt.schedule(backend)
+        assert rt.task(t).is_waiting()
+
+
+E2E_EXTRA_CASES = [e2e_resource_fractions_sum, e2e_ignore_worker_without_resource, integ_query_no_output, integ_query_new_workers, integ_submit_2_sleeps_on_1, integ_submit_2_sleeps_on_2, integ_submit_2_sleeps_on_separated_2, integ_submit_sleeps_more_cpus1,
                    integ_submit_sleeps_more_cpus2, integ_submit_sleeps_more_cpus3, extra_reactor_prefill_rejected, extra_reactor_task_reject1, extra_reactor_task_reject2, extra_reactor_task_reject3, extra_reactor_setup_prefill, extra_reactor_setup_retracting, extra_reactor_prefill_started_on_same_worker, extra_schedule_apply_mapping, extra_schedule_mapping_do_not_change, e2e_job_priority, e2e_submit_mn, e2e_submit_mn_different_groups, e2e_scheduler_unschedulable_mn_blocker, e2e_submit_mn_time_request]
 
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("test_") and callable(v)]
