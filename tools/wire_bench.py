@@ -48,6 +48,9 @@ def main():
     oracle_s = time.perf_counter() - t0
     t, r = wc.tables_and_records(*sc)
     cap = 1 << 25
+    t0 = time.perf_counter()
+    wire.encode_host_debug(t, r, cap)  # the same phase functions on ONE host core (debug hook): a CPU figure next to the GPU one, not a product path
+    cpu_phases_s = time.perf_counter() - t0
     res = wire.encode_device(t, r, cap)
     got = res.messages(r)
     parity = res.status == 0 and bool((res.slot_status == 0).all()) and got == want
@@ -79,7 +82,7 @@ def main():
     algo = n_rec * (10 + 29) + res.total_bytes + W * body_bytes  # records + attributes read, message bytes written, bodies read once per message
     print(json.dumps({"workload": "c3 cold-tick mapping: 1024 workers x 184 records, 8 configurations of ~1 KB", "records": n_rec, "message_bytes": res.total_bytes,
                       "parity_with_oracle": parity, "us_per_encode": us, "records_per_sec": n_rec / (us * 1e-6), "algorithmic_bytes": algo,
-                      "achieved_GBps": algo / (us * 1e-6) / 1e9, "oracle_python_s": oracle_s, "iters": args.iters}))
+                      "achieved_GBps": algo / (us * 1e-6) / 1e9, "oracle_python_s": oracle_s, "cpu_one_core_same_phases_s": cpu_phases_s, "iters": args.iters}))
 
 
 if __name__ == "__main__":
