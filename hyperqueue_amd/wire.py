@@ -241,7 +241,13 @@ def encode_from_sink(t: WireTables, sink, n_workers: int, sink_cap_records: int,
     from .sharded import sink_layout
 
     lib, dev = load(), sink.device
-    o_off, o_task, o_var, o_kind, _total = sink_layout(n_workers, sink_cap_records)
+    # the library derives the record capacity from the sink's byte size (hqtick.cpp: hqtick_sink_capacity_records); the array offsets follow from it
+    lib.hqtick_sink_capacity_records.restype = C.c_uint32
+    lib.hqtick_sink_capacity_records.argtypes = [C.c_uint32, C.c_size_t]
+    cap = int(lib.hqtick_sink_capacity_records(n_workers, sink.numel()))
+    if sink_cap_records and cap != sink_cap_records:
+        raise ValueError(f"sink of {sink.numel()} bytes holds {cap} records, caller assumed {sink_cap_records}")
+    o_off, o_task, o_var, o_kind, _total = sink_layout(n_workers, cap)
     tt, st = _upload(torch, dev, t.arrays()), _upload(torch, dev, side.arrays())
     base = sink.data_ptr()
     ptrs_r = [st[0].data_ptr(), base + o_off, base + o_task, base + o_var, base + o_kind, st[5].data_ptr(), st[6].data_ptr(), st[7].data_ptr(),
