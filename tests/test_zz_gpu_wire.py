@@ -19,13 +19,18 @@ def _extra():
     return golden_cases.E2E_EXTRA_CASES
 
 
-@pytest.mark.parametrize("case", _extra(), ids=lambda f: f.__name__)
-def test_e2e_extra_gpu(case):
+@pytest.fixture(scope="module")
+def gpu_backend():
     from test_gpu_golden import GpuBackend
 
-    b = GpuBackend()
-    case(b)
-    assert all(b.flags)
+    return GpuBackend()  # one set of contexts for all cases, as in test_gpu_golden.py
+
+
+@pytest.mark.parametrize("case", _extra(), ids=lambda f: f.__name__)
+def test_e2e_extra_gpu(case, gpu_backend):
+    gpu_backend.flags.clear()
+    case(gpu_backend)
+    assert all(gpu_backend.flags)
 
 
 @pytest.fixture(scope="module")
