@@ -169,6 +169,11 @@ class KernelStatsC(C.Structure):
         ("algorithmic_bytes", C.c_uint64),
         ("n_assigned", C.c_uint64),
         ("n_prefilled", C.c_uint64),
+        ("block_solve_us", C.c_double),
+        ("n_classes_device", C.c_uint32),
+        ("n_classes_host", C.c_uint32),
+        ("block_steps_max", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
 

@@ -1,15 +1,28 @@
-"""Builds libhqtick.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.  No JIT cache: the .so travels with the repo snapshot."""
+"""Builds the native pieces in-tree for gfx950 with hipcc.  No JIT cache: the .so files travel with the repo snapshot.
+
+  libhqtick.so       the product: include/hqtick.h + include/hqwire.h, nothing else (HIP kernels + C ABI + host stages)
+  libhqtick_test.so  the same objects plus the CPU test hooks of include/hqtick_debug.h (-DHQTICK_TEST_HOOKS): what the `-m "not gpu"`
+                     tests load to exercise host logic and the kernels' phase functions without a GPU.  Nothing in the product loads it.
+  libhqalloc.so      worker-side allocator (include/hqalloc.h), host-only g++
+"""
 from __future__ import annotations
 
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libhqtick.so")
-SOURCES = ["hqtick.cpp", "host_model.cpp", "milp.cpp", "debug_capi.cpp", "kernels.hip", "graph.hip", "wire.hip"]
-HEADERS = ["kernels.h", "graph.h", "devbuf.h", "host_model.h", "milp.h", "hb_order.h", "wire_core.h", os.path.join("..", "..", "include", "hqwire.h"), os.path.join("..", "..", "include", "hqtick.h"), os.path.join("..", "..", "include", "hqtick_debug.h")]
+TEST_LIB = os.path.join(HERE, "libhqtick_test.so")
+SOURCES = ["hqtick.cpp", "host_model.cpp", "milp.cpp", "kernels.hip", "graph.hip", "wire.hip", "block_solve.hip"]
+HOOKED = ["hqtick.cpp", "wire.hip"]          # sources that carry #ifdef HQTICK_TEST_HOOKS sections
+TEST_ONLY = ["debug_capi.cpp"]               # sources of the test library only
+HEADERS = ["kernels.h", "block_core.h", "block_solve.h", "graph.h", "devbuf.h", "host_model.h", "milp.h", "hb_order.h", "wire_core.h",
+           os.path.join("..", "..", "include", "hqwire.h"), os.path.join("..", "..", "include", "hqtick.h"), os.path.join("..", "..", "include", "hqtick_debug.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def hipcc() -> str:
@@ -38,16 +51,38 @@ def build_alloc(force: bool = False, verbose: bool = False) -> str:
     return ALLOC_LIB
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    build_alloc(force, verbose)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
-        return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-o", LIB] + srcs
+def _compile(src: str, hooks: bool, force: bool, verbose: bool) -> str:
+    """one source -> one object under _obj/ (rebuilt when the source or any header is newer)"""
+    os.makedirs(OBJ, exist_ok=True)
+    obj = os.path.join(OBJ, src.replace(".", "_") + ("_hooks" if hooks else "") + ".o")
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS if os.path.exists(os.path.join(CSRC, h))]
+    if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
+        return obj
+    cmd = [hipcc()] + FLAGS + (["-DHQTICK_TEST_HOOKS=1"] if hooks else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    return obj
+
+
+def _link(lib: str, objs, verbose: bool) -> str:
+    if os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(o) for o in objs):
+        return lib
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + list(objs) + ["-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return lib
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """everything: libhqalloc.so, libhqtick.so (product), libhqtick_test.so (product objects + CPU test hooks)"""
+    build_alloc(force, verbose)
+    jobs = [(s, False) for s in SOURCES] + [(s, True) for s in HOOKED + TEST_ONLY]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        objs = dict(zip(jobs, ex.map(lambda j: _compile(j[0], j[1], force, verbose), jobs)))
+    _link(LIB, [objs[(s, False)] for s in SOURCES], verbose)
+    _link(TEST_LIB, [objs[(s, s in HOOKED)] for s in SOURCES] + [objs[(s, True)] for s in TEST_ONLY], verbose)
     return LIB
 
 

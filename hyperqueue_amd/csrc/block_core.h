@@ -1,0 +1,576 @@
+// Exact solver of ONE worker-class block of the separable placement model, one wavefront per block.
+//
+// Where it sits: run_scheduling_solver (/root/reference/crates/tako/src/internal/scheduler/solver.rs:95-192) creates, per worker, one `nat`
+// column per (batch, variant) the worker can run now and one row per resource: sum_j a[r][j] x_j <= free[r].  On a tick without priority
+// cuts, blockers and multi-node batches these per-worker blocks are the whole model (host_model.cpp, "separable instances"), workers with
+// the same (free, total, eligibility) share one block, and a steady-state cluster has about as many such classes as workers.  Each block is a
+// bounded integer knapsack with <= 4 resource rows and <= 32 columns; the blocks are independent -- the W-way data parallelism of the tick.
+//
+// Result convention = csrc/milp.h's canonical optimum: among the integer points within 1e-9 (relative) of the optimum the one that
+// minimises the LAST column, then the one before it, ...  Feasibility is decided in exact u64 `ResourceAmount` arithmetic (the host solver
+// works in f64 units with a 1e-9 tolerance; on the 1/10000 grid the two agree).
+//
+// Algorithm (all of a wavefront's 64 lanes work on the same block):
+//   build     columns / rows from the class descriptor, rows divided by their gcd, costs in the reference's operation order (solver.rs:550-568)
+//   duals     every basis of the dual polyhedron {y >= 0, A^T y >= c} is tried (lane-strided over the C(n + m, m) choices of m tight
+//             constraints; 4 x 4 elimination in registers).  A basic point y that covers a column set C (a_j . y >= c_j for j in C) bounds every
+//             sub-problem over columns F within C:  LP_F(rem) <= y . rem.  The pool keeps (y, cover mask, tight-column mask).
+//   greedy    64 column orders, one per lane, each raised to its maximum: the best one is the first incumbent
+//   walk      depth-first over the columns of a WORK PROBLEM in its search order — large requests are decided first, the two smallest are left
+//             for the leaves (that order cuts the trees ~10x against the model's own column order).  The 64 lanes evaluate 64 values of the
+//             current column at once (child bound = fixed part + min over the level's duals of y . rem), __ballot gives the survivors;
+//             with two columns left the lanes enumerate one and the other follows exactly -> 64 complete solutions per step.
+//   phase 1   walk over all columns, maximising.
+//   phase 2   for j = n-1 .. 0: the smallest value of column j for which the columns before it can still reach optimum - 1e-9, by probes
+//             "any point with x_j <= mid?" (a walk that stops at the first leaf; the cap enters the bound as a Lagrangian penalty), first just
+//             below the current value, then bisecting.  The result is the lexicographic minimum read from the last column = the canonical optimum.
+// Everything lane-varying is a function of (lane) handed to the Wave policy (ballot / arg-max / each); the uniform control flow is shared by
+// the device kernel (block_solve.hip, Wave = one wavefront) and the host emulation the CPU tests run (lanes in a loop).
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HQB_HD __host__ __device__ inline
+#define HQB_UNROLL _Pragma("unroll")
+#else
+#define HQB_HD inline
+#define HQB_UNROLL
+#endif
+
+namespace hqblock {
+
+constexpr int NMAX = 32;     // columns of one block
+constexpr int MMAX = 4;      // resource rows of one block
+constexpr int WAVE = 64;
+constexpr int PCAP = 448;    // dual points kept per block (a C3-shaped block has ~65; what does not fit is dropped: weaker bounds, same answer)
+constexpr int DPRE = 48;     // dual points a level of the walk looks at (C3-shaped: <= 43)
+constexpr int GCOLS = 64;    // (batch, variant) columns of a tick the eligibility mask can address
+constexpr int64_t UB_LIMIT = 65535;  // a column that could be taken more often than this goes to the host solver
+
+enum { ST_OK = 0, ST_BUDGET = 1, ST_UNSUPPORTED = 2 };
+
+// The tick's (batch, variant) columns, shared by every class: request entries, weight, resource pool sums (solver.rs:68-82).
+struct ColTable {
+    uint32_t n_cols, R;
+    const uint32_t *ent_off;     // [n_cols + 1]
+    const uint32_t *ent_res;     // resource id
+    const uint8_t *ent_kind;     // HQ_ENTRY_AMOUNT = 0 / HQ_ENTRY_ALL = 1
+    const uint64_t *ent_amount;
+    const uint32_t *weight;      // [n_cols] ResourceWeight, 10 000 = 1.0
+    const double *pool;          // [R] resource_sums
+};
+// One worker class: what the block depends on.
+struct ClassTable {
+    uint32_t n_classes;
+    const uint64_t *free_;   // [n_classes * R]   never HQ_AMOUNT_MAX on a resource an eligible column uses (the host keeps those classes)
+    const uint64_t *total;   // [n_classes * R]
+    const uint64_t *elig;    // [n_classes]       bit g: column g exists on this class's workers (solver.rs:123-126)
+};
+struct Output {
+    uint32_t *x;        // [n_classes * n_cols] count per column (0 where not eligible)
+    uint32_t *status;   // [n_classes] ST_*
+    uint32_t *steps;    // [n_classes] search steps of both phases (statistics)
+};
+
+struct Shared {  // one block's working set: LDS on the device
+    int n, m, status;
+    uint32_t steps, steps_p1;
+    int gcol[NMAX];                 // block column -> tick column
+    double c[NMAX];
+    int64_t a[MMAX][NMAX];
+    int64_t cap[MMAX];
+    uint8_t pi[NMAX];               // block columns by ascending size (the search decides the large ones first)
+    // dual pool
+    uint32_t npool;
+    double py[PCAP][MMAX];
+    uint32_t pcover[PCAP], ptight[PCAP];
+    // work problem: columns in search order (position wn - 1 is decided first)
+    int wn;
+    uint8_t wcol[NMAX];
+    double wc[NMAX];
+    int64_t wa[MMAX][NMAX];
+    uint32_t wmask[NMAX + 1];       // block columns at positions < k
+    uint16_t dl[NMAX + 1][DPRE];    // per level: pool entries that are vertices of that level's dual polyhedron
+    float dpen[NMAX + 1][DPRE];     // ... and the penalty of a capped column (phase 2), rounded up
+    int64_t wcap[NMAX];             // upper cap of a position (INT64_MAX = none)
+    uint32_t dcnt[NMAX + 1];
+    // level stack of the walk (level k = number of positions still free)
+    int64_t rem[NMAX + 1][MMAX];
+    double zfix[NMAX + 1];
+    int64_t ptr[NMAX + 1], ub[NMAX + 1];
+    uint32_t xsel[NMAX];            // by position
+    // incumbent / completion, by block column
+    uint32_t xbest[NMAX];
+    double best;
+    // greedy
+    uint8_t perm[WAVE][NMAX];
+    uint16_t gx[WAVE][NMAX];
+    double lane_val[WAVE];
+    uint32_t binom[NMAX + MMAX + 1][MMAX + 1];
+};
+
+HQB_HD int64_t gcd64(int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; }
+
+// min over the level's dual points of y . rem: an upper bound of the LP over the positions [0, k), hence of its integer optimum
+HQB_HD double lp_bound(const Shared &S, int k, const int64_t *rem) {
+    const int cnt = (int)(S.dcnt[k] < (uint32_t)DPRE ? S.dcnt[k] : (uint32_t)DPRE);
+    if (cnt == 0) return 1e300;
+    const double r0 = (double)rem[0], r1 = (double)rem[1], r2 = (double)rem[2], r3 = (double)rem[3];
+    double best = 1e300;
+    for (int i = 0; i < cnt; i++) {
+        const double *d = S.py[S.dl[k][i]];
+        const double v = d[0] * r0 + d[1] * r1 + d[2] * r2 + d[3] * r3 + (double)S.dpen[k][i];
+        best = v < best ? v : best;
+    }
+    return best;
+}
+
+// ---- step 1: the block of one class -----------------------------------------------------------------------------------------------------------
+HQB_HD void build_block(Shared &S, const ColTable &ct, const ClassTable &cl, uint32_t cls) {
+    S.status = ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = 0; S.npool = 0;
+    const uint32_t R = ct.R;
+    const uint64_t *fre = cl.free_ + (size_t)cls * R, *tot = cl.total + (size_t)cls * R;
+    const uint64_t elig = cl.elig[cls];
+    int row_of[64];
+    for (int r = 0; r < 64; r++) row_of[r] = -1;
+    for (int r = 0; r < MMAX; r++) { S.cap[r] = 0; for (int j = 0; j < NMAX; j++) S.a[r][j] = 0; }
+    if (ct.n_cols > (uint32_t)GCOLS || R > 64) { S.status = ST_UNSUPPORTED; return; }
+    int n = 0, m = 0;
+    for (uint32_t g = 0; g < ct.n_cols; g++) {
+        if (!((elig >> g) & 1)) continue;
+        if (n >= NMAX) { S.status = ST_UNSUPPORTED; return; }
+        double sc = 0.0;  // create_sn_var  solver.rs:550-568, same operation order as host_model.cpp
+        for (uint32_t e = ct.ent_off[g]; e < ct.ent_off[g + 1]; e++) {
+            const uint32_t r = ct.ent_res[e];
+            const uint64_t amt = ct.ent_kind[e] ? tot[r] : ct.ent_amount[e];
+            const double pool = ct.pool[r];
+            sc += pool < 0.000001 ? 0.0 : ((double)amt / 10000.0) / pool;
+            if (fre[r] == UINT64_MAX) { S.status = ST_UNSUPPORTED; return; }  // unbounded row: the reference's carry-over (solver.rs:183-185) is a host matter
+            if (amt == 0) continue;
+            if (row_of[r] < 0) { if (m >= MMAX) { S.status = ST_UNSUPPORTED; return; } row_of[r] = m; S.cap[m] = (int64_t)fre[r]; m++; }
+            if (amt > (uint64_t)INT64_MAX || fre[r] > (uint64_t)INT64_MAX) { S.status = ST_UNSUPPORTED; return; }
+            S.a[row_of[r]][n] += (int64_t)amt;
+        }
+        S.c[n] = sc * ((double)ct.weight[g] / 10000.0);
+        S.gcol[n] = (int)g;
+        bool any = false;
+        for (int r = 0; r < m; r++) if (S.a[r][n] > 0) any = true;
+        if (!any) { S.status = ST_UNSUPPORTED; return; }  // a column no row bounds
+        n++;
+    }
+    // rows on their own grid: amounts and capacity divided by the row's gcd (the capacity rounds down: what is cut off no column can use)
+    for (int r = 0; r < m; r++) {
+        int64_t g = 0;
+        for (int j = 0; j < n; j++) g = gcd64(g, S.a[r][j]);
+        if (g > 1) { for (int j = 0; j < n; j++) S.a[r][j] /= g; S.cap[r] /= g; }
+    }
+    double size[NMAX];
+    for (int j = 0; j < n; j++) {
+        int64_t ub = INT64_MAX;
+        double sz = 0.0;
+        for (int r = 0; r < m; r++) if (S.a[r][j] > 0) { int64_t q = S.cap[r] / S.a[r][j]; ub = q < ub ? q : ub; sz += (double)S.a[r][j] / (double)(S.cap[r] + 1); }
+        if (ub > UB_LIMIT) { S.status = ST_UNSUPPORTED; return; }
+        size[j] = sz;
+        S.pi[j] = (uint8_t)j;
+    }
+    for (int i = 1; i < n; i++) { uint8_t p = S.pi[i]; int q = i - 1; while (q >= 0 && size[S.pi[q]] > size[p]) { S.pi[q + 1] = S.pi[q]; q--; } S.pi[q + 1] = p; }  // stable
+    S.n = n; S.m = m;
+    for (int i = 0; i <= NMAX + MMAX; i++)
+        for (int p = 0; p <= MMAX; p++) S.binom[i][p] = p == 0 ? 1u : (i == 0 ? 0u : S.binom[i - 1][p - 1] + S.binom[i - 1][p]);
+}
+
+// ---- step 2: dual points ------------------------------------------------------------------------------------------------------------------------
+// Basis number t of the C(n + m, m) choices of m tight constraints among {column j: a_j . y = c_j} and {row r: y_r = 0}.
+template <class W>
+HQB_HD void dual_candidate(W &wv, Shared &S, uint32_t t) {
+    const int n = S.n, m = S.m;
+    double M[MMAX][MMAX + 1];
+    HQB_UNROLL
+    for (int i = 0; i < MMAX; i++) {
+        HQB_UNROLL
+        for (int q = 0; q <= MMAX; q++) M[i][q] = (i >= m && q == i) ? 1.0 : 0.0;  // padding rows: y_r = 0
+    }
+    uint32_t tight = 0;
+    int maxcol = -1;
+    {   // unrank: items come out in descending order
+        uint32_t rest = t;
+        int hi = n + m;
+        HQB_UNROLL
+        for (int eq = 0; eq < MMAX; eq++) {
+            if (eq < m) {
+                const int p = m - eq;
+                int i = hi - 1;
+                while (S.binom[i][p] > rest) i--;
+                rest -= S.binom[i][p];
+                hi = i;
+                if (i < n) {
+                    HQB_UNROLL
+                    for (int r = 0; r < MMAX; r++) M[eq][r] = (double)S.a[r][i];
+                    M[eq][MMAX] = S.c[i];
+                    tight |= 1u << i;
+                    if (i > maxcol) maxcol = i;
+                } else {
+                    HQB_UNROLL
+                    for (int r = 0; r < MMAX; r++) M[eq][r] = (r == i - n) ? 1.0 : 0.0;
+                }
+            }
+        }
+    }
+    // Gauss-Jordan with partial pivoting, fixed 4 x 4 so that everything stays in registers
+    HQB_UNROLL
+    for (int col = 0; col < MMAX; col++) {
+        int piv = col; double pv = M[col][col] < 0 ? -M[col][col] : M[col][col];
+        HQB_UNROLL
+        for (int i = col + 1; i < MMAX; i++) { double v = M[i][col] < 0 ? -M[i][col] : M[i][col]; if (v > pv) { pv = v; piv = i; } }
+        if (!(pv > 1e-300)) return;  // singular
+        HQB_UNROLL
+        for (int i = col + 1; i < MMAX; i++) if (i == piv) {
+            HQB_UNROLL
+            for (int q = 0; q <= MMAX; q++) { double tmp = M[col][q]; M[col][q] = M[i][q]; M[i][q] = tmp; }
+        }
+        const double inv = 1.0 / M[col][col];
+        HQB_UNROLL
+        for (int q = 0; q <= MMAX; q++) M[col][q] *= inv;
+        HQB_UNROLL
+        for (int i = 0; i < MMAX; i++) if (i != col) {
+            const double f = M[i][col];
+            HQB_UNROLL
+            for (int q = 0; q <= MMAX; q++) M[i][q] -= f * M[col][q];
+        }
+    }
+    double y[MMAX], ymax = 0.0;
+    HQB_UNROLL
+    for (int r = 0; r < MMAX; r++) { y[r] = M[r][MMAX]; if (!(y[r] == y[r]) || y[r] > 1e280 || y[r] < -1e280) return; double v = y[r] < 0 ? -y[r] : y[r]; ymax = v > ymax ? v : ymax; }
+    HQB_UNROLL
+    for (int r = 0; r < MMAX; r++) { if (y[r] < -1e-9 * ymax) return; if (y[r] < 0.0) y[r] = 0.0; }
+    // the columns the point covers, and the factor that makes the cover exact in floating point (tight columns come out equal up to rounding)
+    uint32_t cover = 0; double f = 1.0;
+    for (int j = 0; j < n; j++) {
+        double s = 0.0;
+        HQB_UNROLL
+        for (int r = 0; r < MMAX; r++) s += (double)S.a[r][j] * y[r];
+        if (s < S.c[j] * (1.0 - 1e-11)) continue;
+        cover |= 1u << j;
+        if (s < S.c[j]) { const double q = S.c[j] / s; f = q > f ? q : f; }
+    }
+    if ((tight & ~cover) != 0) return;
+    // Useful for some walk?  The walks visit the column sets {first k columns of pi that are < j} (j = n: phase 1).  The point is a vertex for such a
+    // set F iff tight within F within cover; the most permissive j is maxcol + 1, the smallest k the one that reaches the last tight column of pi.
+    {
+        const uint32_t low = maxcol + 1 >= 32 ? 0xFFFFFFFFu : ((1u << (maxcol + 1)) - 1u);
+        uint32_t pref = 0, left = tight;
+        for (int i = 0; i < n && left; i++) { const uint32_t b = 1u << S.pi[i]; pref |= b; left &= ~b; }
+        if (maxcol < 0) pref = 0;
+        if ((pref & low & ~cover) != 0) return;
+    }
+    f *= 1.0 + 1e-15;
+    const uint32_t slot = wv.atomic_inc(&S.npool);
+    if (slot < (uint32_t)PCAP) {
+        HQB_UNROLL
+        for (int r = 0; r < MMAX; r++) S.py[slot][r] = y[r] * f;
+        S.pcover[slot] = cover; S.ptight[slot] = tight;
+    }
+}
+
+// ---- step 3: greedy incumbents -----------------------------------------------------------------------------------------------------------------
+HQB_HD uint32_t xorshift32(uint32_t &s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+
+HQB_HD void greedy_lane(Shared &S, int lane) {
+    const int n = S.n, m = S.m;
+    uint8_t *pm = S.perm[lane];
+    for (int j = 0; j < n; j++) pm[j] = (uint8_t)j;
+    if (lane == 3) { for (int j = 0; j < n; j++) pm[j] = (uint8_t)(n - 1 - j); }
+    else if (lane != 2) {
+        // lanes 0 / 1: by value density / by cost, descending (insertion sort); other lanes: that order shuffled
+        double key[NMAX];
+        for (int j = 0; j < n; j++) {
+            double w = 0.0;
+            for (int r = 0; r < m; r++) if (S.a[r][j] > 0) w += S.cap[r] > 0 ? (double)S.a[r][j] / (double)S.cap[r] : 1e30;
+            key[j] = lane == 1 ? S.c[j] : (w > 0.0 ? S.c[j] / w : 0.0);
+        }
+        for (int i = 1; i < n; i++) { uint8_t p = pm[i]; int q = i - 1; while (q >= 0 && key[pm[q]] < key[p]) { pm[q + 1] = pm[q]; q--; } pm[q + 1] = p; }
+        if (lane >= 4) { uint32_t s = 0x9E3779B9u * (uint32_t)(lane + 1); for (int i = n - 1; i > 0; i--) { int q = (int)(xorshift32(s) % (uint32_t)(i + 1)); uint8_t tmp = pm[i]; pm[i] = pm[q]; pm[q] = tmp; } }
+    }
+    int64_t rem[MMAX];
+    for (int r = 0; r < MMAX; r++) rem[r] = S.cap[r];
+    uint16_t *x = S.gx[lane];
+    for (int j = 0; j < n; j++) x[j] = 0;
+    for (int i = 0; i < n; i++) {
+        const int j = pm[i];
+        if (!(S.c[j] > 0.0)) continue;
+        int64_t ub = INT64_MAX;
+        for (int r = 0; r < m; r++) if (S.a[r][j] > 0) { int64_t q = rem[r] / S.a[r][j]; ub = q < ub ? q : ub; }
+        if (ub <= 0) continue;
+        x[j] = (uint16_t)ub;
+        for (int r = 0; r < m; r++) rem[r] -= ub * S.a[r][j];
+    }
+    double z = 0.0;
+    for (int j = n - 1; j >= 0; j--) z = z + S.c[j] * (double)x[j];
+    S.lane_val[lane] = z;
+}
+
+// ---- the work problem of one walk ---------------------------------------------------------------------------------------------------------------
+// Columns: the ones of `cols` (mask of block columns) in the order of pi.  `capcol` (or -1) is a column whose value is capped at `capval`
+// (phase 2's probes).  Level lists: a pool point bounds the level with free set F when it is a vertex of F's dual polyhedron (tight within F
+// within cover).  With a capped column j in F the LP has one more dual variable, the multiplier of x_j <= L; its vertices are the ones above
+// plus (y, mu = c_j - a_j . y > 0) with y a vertex for F \ {j}: those enter with the penalty L * mu   (bound = y . rem + penalty).
+template <class W>
+HQB_HD void setup_work(W &wv, Shared &S, uint32_t cols, int capcol, int64_t capval) {
+    if (wv.first()) {
+        int wn = 0;
+        S.wmask[0] = 0;
+        for (int i = 0; i < S.n; i++) { const int j = S.pi[i]; if ((cols >> j) & 1) { S.wcol[wn] = (uint8_t)j; wn++; } }
+        for (int p = 0; p < wn; p++) {
+            const int j = S.wcol[p];
+            S.wc[p] = S.c[j];
+            S.wcap[p] = j == capcol ? capval : INT64_MAX;
+            for (int r = 0; r < MMAX; r++) S.wa[r][p] = S.a[r][j];
+            S.wmask[p + 1] = S.wmask[p] | (1u << j);
+        }
+        S.wn = wn;
+        for (int k = 0; k <= NMAX; k++) S.dcnt[k] = 0;
+    }
+    wv.sync();
+    const int wn = S.wn;
+    const uint32_t np = S.npool < (uint32_t)PCAP ? S.npool : (uint32_t)PCAP;
+    const uint32_t capbit = capcol >= 0 ? 1u << capcol : 0u;
+    wv.each([&](int lane) {
+        for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) {
+            const uint32_t cover = S.pcover[i], tight = S.ptight[i];
+            double mu = 0.0;
+            if (capbit && !(cover & capbit)) {
+                double s = 0.0;
+                for (int r = 0; r < MMAX; r++) s += (double)S.a[r][capcol] * S.py[i][r];
+                mu = (S.c[capcol] - s) * (1.0 + 1e-12);
+                if (mu < 0.0) mu = 0.0;
+            }
+            for (int k = 1; k <= wn; k++) {
+                const uint32_t F = S.wmask[k];
+                double pen = 0.0;
+                bool use = (tight & ~F) == 0 && (F & ~cover) == 0;
+                if (!use && (F & capbit)) { const uint32_t G = F & ~capbit; if ((tight & ~G) == 0 && (G & ~cover) == 0) { use = true; pen = (double)capval * mu; } }
+                if (use) { const uint32_t slot = wv.atomic_inc(&S.dcnt[k]); if (slot < (uint32_t)DPRE) { S.dl[k][slot] = (uint16_t)i; S.dpen[k][slot] = pen > 0.0 ? (float)(pen * (1.0 + 2e-7)) : 0.0f; } }
+            }
+        }
+    });
+    wv.sync();
+}
+
+HQB_HD int64_t level_ub(const Shared &S, int k) {  // how often the column at position k - 1 fits into rem[k]
+    const int p = k - 1;
+    int64_t ub = S.wcap[p];
+    for (int r = 0; r < S.m; r++) if (S.wa[r][p] > 0) { int64_t q = S.rem[k][r] / S.wa[r][p]; ub = q < ub ? q : ub; }
+    return ub;
+}
+
+// Two positions left (1 and 0): position 1 takes v1, position 0 follows exactly with its maximum.
+HQB_HD bool terminal_lane(const Shared &S, int64_t v1, int64_t *x0_out, double *val_out) {
+    if (v1 < 0 || v1 > S.ub[2]) return false;
+    int64_t x0max = S.wcap[0];
+    for (int r = 0; r < S.m; r++) {
+        const int64_t left = S.rem[2][r] - v1 * S.wa[r][1];
+        if (S.wa[r][0] > 0) { int64_t q = left / S.wa[r][0]; x0max = q < x0max ? q : x0max; }
+    }
+    *x0_out = x0max;
+    *val_out = (S.zfix[2] + S.wc[1] * (double)v1) + S.wc[0] * (double)x0max;
+    return true;
+}
+
+enum { MODE_MAX = 0, MODE_FIND = 1 };
+#ifdef HQB_TRACE
+static uint32_t g_trace_maxlist = 0, g_trace_maxpool = 0; static unsigned long g_trace_probes = 0;
+#endif
+
+// One walk over the work problem from the state the caller put into rem[wn] / zfix[wn]; every level takes its largest values first.
+//   MODE_MAX   maximise into S.best / S.xbest.
+//   MODE_FIND  stop at the first complete point whose objective is >= thr and write it into S.xbest (work columns only); *found_out tells
+//              whether there was one.
+// Returns false when the step budget ran out.
+template <class W>
+HQB_HD bool walk(W &wv, Shared &S, int mode, double thr, uint32_t *budget, bool *found_out) {
+    const int wn = S.wn, m = S.m;
+    bool found = false;
+    if (wn == 1) {  // a single position: no search
+        if (wv.first()) {
+            int64_t ub = S.wcap[0];
+            for (int r = 0; r < m; r++) if (S.wa[r][0] > 0) { int64_t q = S.rem[1][r] / S.wa[r][0]; ub = q < ub ? q : ub; }
+            const double val = S.zfix[1] + S.wc[0] * (double)ub;
+            if (mode == MODE_MAX) { if (val > S.best) { S.best = val; S.xbest[S.wcol[0]] = (uint32_t)ub; } }
+            else { S.ptr[1] = val >= thr ? 1 : 0; if (val >= thr) S.xbest[S.wcol[0]] = (uint32_t)ub; }
+        }
+        wv.sync();
+        if (mode == MODE_FIND) found = S.ptr[1] != 0;
+        if (found_out) *found_out = found;
+        return true;
+    }
+    if (wv.first()) { S.ub[wn] = level_ub(S, wn); S.ptr[wn] = S.ub[wn]; }
+    wv.sync();
+    int k = wn;
+    uint32_t steps = 0;
+    bool in_budget = true;
+    while (k <= wn) {
+        if (steps >= *budget) { in_budget = false; break; }
+        steps++;
+        const int64_t p = S.ptr[k], ubk = S.ub[k];
+        if (p < 0) { k++; continue; }  // level exhausted
+        const int pos = k - 1;
+        if (k == 2) {  // leaves: every lane a complete point
+            auto eval = [&](int lane, int64_t *x0, double *val) { return terminal_lane(S, p - lane, x0, val); };
+            if (mode == MODE_FIND) {
+                const uint64_t mask = wv.ballot([&](int lane) { int64_t x0; double val; return eval(lane, &x0, &val) && val >= thr; });
+                if (mask) {
+                    const int l = wv.ctz(mask);
+                    if (wv.first()) {
+                        int64_t x0 = 0; double val = 0; eval(l, &x0, &val);
+                        S.xsel[1] = (uint32_t)(p - l); S.xsel[0] = (uint32_t)x0;
+                        for (int q = 0; q < wn; q++) S.xbest[S.wcol[q]] = S.xsel[q];
+                    }
+                    wv.sync();
+                    found = true;
+                    break;
+                }
+            } else {
+                int l = -1;
+                const double top = wv.argmax([&](int lane) { int64_t x0; double val; return eval(lane, &x0, &val) ? val : -1.0; }, &l);
+                if (l >= 0 && top > S.best) {
+                    wv.sync();  // every lane has read S.best
+                    if (wv.first()) {
+                        int64_t x0 = 0; double val = 0; eval(l, &x0, &val);
+                        S.xsel[1] = (uint32_t)(p - l); S.xsel[0] = (uint32_t)x0;
+                        for (int q = 0; q < wn; q++) S.xbest[S.wcol[q]] = S.xsel[q];
+                        S.best = val;
+                    }
+                }
+            }
+            if (wv.first()) S.ptr[2] = p - WAVE;
+            wv.sync();
+            continue;
+        }
+        // inner level: 64 values of the column at `pos` at once
+        const double cut = mode == MODE_FIND ? thr : S.best + 1e-12 * (S.best < 0 ? -S.best : S.best);
+        const double zk = S.zfix[k], cj = S.wc[pos];
+        const uint64_t mask = wv.ballot([&](int lane) {
+            const int64_t v = p - lane;
+            if (v < 0 || v > ubk) return false;
+            int64_t rem[MMAX];
+            for (int r = 0; r < MMAX; r++) rem[r] = S.rem[k][r] - v * S.wa[r][pos];
+            const double bound = (zk + cj * (double)v) + lp_bound(S, k - 1, rem);
+            return mode == MODE_FIND ? bound >= cut : bound > cut;
+        });
+        if (!mask) { if (wv.first()) S.ptr[k] = p - WAVE; wv.sync(); continue; }
+        const int l = wv.ctz(mask);
+        const int64_t v = p - l;
+        if (wv.first()) {
+            S.xsel[pos] = (uint32_t)v;
+            S.ptr[k] = v - 1;
+            for (int r = 0; r < MMAX; r++) S.rem[k - 1][r] = S.rem[k][r] - v * S.wa[r][pos];
+            S.zfix[k - 1] = zk + cj * (double)v;
+            S.ub[k - 1] = level_ub(S, k - 1);
+            S.ptr[k - 1] = S.ub[k - 1];
+        }
+        wv.sync();
+        k--;
+    }
+    *budget -= steps < *budget ? steps : *budget;
+    if (wv.first()) S.steps += steps;
+    wv.sync();
+    if (found_out) *found_out = found;
+    return in_budget;
+}
+
+// ---- the whole block ----------------------------------------------------------------------------------------------------------------------------
+template <class W>
+HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &cl, uint32_t cls, const Output &out, uint32_t budget) {
+    if (wv.first()) build_block(S, ct, cl, cls);
+    wv.sync();
+    uint32_t *x = out.x + (size_t)cls * ct.n_cols;
+    wv.each([&](int lane) { for (uint32_t g = lane; g < ct.n_cols; g += WAVE) x[g] = 0; });
+    if (S.status != ST_OK || S.n == 0) {
+        if (wv.first()) { out.status[cls] = (uint32_t)S.status; out.steps[cls] = 0; }
+        return;
+    }
+    const int n = S.n, m = S.m;
+    const uint32_t total = S.binom[n + m][m];
+    wv.each([&](int lane) { for (uint32_t t = (uint32_t)lane; t < total; t += WAVE) dual_candidate(wv, S, t); });
+    wv.sync();
+    wv.each([&](int lane) { greedy_lane(S, lane); });
+    wv.sync();
+    {
+        int l = 0;
+        const double top = wv.argmax([&](int lane) { return S.lane_val[lane]; }, &l);
+        if (wv.first()) { S.best = top; for (int j = 0; j < n; j++) S.xbest[j] = S.gx[l][j]; }
+        wv.sync();
+    }
+    const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    uint32_t left = budget;
+    bool ok = true;
+    // phase 1 unless the incumbent already meets the root bound
+    setup_work(wv, S, all, -1, 0);
+    {
+        int64_t cap[MMAX];
+        for (int r = 0; r < MMAX; r++) cap[r] = S.cap[r];
+        const double root = lp_bound(S, n, cap);
+        if (!(root <= S.best + 1e-12 * S.best)) {
+            if (wv.first()) { for (int r = 0; r < MMAX; r++) S.rem[n][r] = S.cap[r]; S.zfix[n] = 0.0; }
+            wv.sync();
+            ok = walk(wv, S, MODE_MAX, 0.0, &left, nullptr);
+        }
+        if (wv.first()) S.steps_p1 = S.steps;
+        wv.sync();
+    }
+    // phase 2: S.xbest is a point with objective >= thr throughout; column by column from the last one its value is pushed down by probes
+    // "is there a point with x_j <= mid (the later columns fixed) that still reaches thr" — first just below the current value (most columns
+    // fail that at once), then by bisection, as csrc/milp.cpp does
+    if (ok) {
+        const double thr = S.best - 1e-9 * (S.best < 0 ? -S.best : S.best);
+        int64_t capf[MMAX];
+        for (int r = 0; r < MMAX; r++) capf[r] = S.cap[r];
+        double zf = 0.0;
+        for (int j = n - 1; j >= 0 && ok; j--) {
+            int64_t lo = 0, hi = (int64_t)S.xbest[j];
+            bool first = true;
+            while (lo < hi && ok) {
+                const int64_t mid = first ? hi - 1 : (lo + hi) / 2;
+                first = false;
+                setup_work(wv, S, j >= 31 ? all : (all & ((2u << j) - 1u)), j, mid);
+                if (wv.first()) { for (int r = 0; r < MMAX; r++) S.rem[S.wn][r] = capf[r]; S.zfix[S.wn] = zf; }
+                wv.sync();
+                bool found = false;
+                ok = walk(wv, S, MODE_FIND, thr, &left, &found);
+                wv.sync();
+#ifdef HQB_TRACE
+                { uint32_t mx = 0; for (int k = 1; k <= S.wn; k++) mx = S.dcnt[k] > mx ? S.dcnt[k] : mx; if (mx > g_trace_maxlist) g_trace_maxlist = mx; if (S.npool > g_trace_maxpool) g_trace_maxpool = S.npool; g_trace_probes++; }
+#endif
+                if (found) hi = (int64_t)S.xbest[j]; else lo = mid + 1;
+            }
+            const uint32_t xj = S.xbest[j];
+            for (int r = 0; r < MMAX; r++) capf[r] -= (int64_t)xj * S.a[r][j];
+            zf = zf + S.c[j] * (double)xj;
+        }
+    }
+    wv.sync();
+    if (wv.first()) {
+        out.status[cls] = ok ? (uint32_t)ST_OK : (uint32_t)ST_BUDGET;
+        out.steps[cls] = S.steps;
+        if (ok) for (int j = 0; j < n; j++) x[S.gcol[j]] = S.xbest[j];
+    }
+}
+
+// ---- host emulation of a wavefront (CPU tests; also what documents the contract of the Wave policy) ---------------------------------------------
+struct HostWave {
+    bool first() const { return true; }
+    void sync() {}
+    uint32_t atomic_inc(uint32_t *p) { return (*p)++; }
+    static int ctz(uint64_t m) { int i = 0; while (!((m >> i) & 1)) i++; return i; }
+    template <class F> void each(F f) { for (int l = 0; l < WAVE; l++) f(l); }
+    template <class F> uint64_t ballot(F f) { uint64_t m = 0; for (int l = 0; l < WAVE; l++) if (f(l)) m |= 1ull << l; return m; }
+    template <class F> double argmax(F f, int *lane) {  // largest value, lowest lane among equals; *lane = -1 when every value is negative
+        double best = -1.0; int bl = -1;
+        for (int l = 0; l < WAVE; l++) { double v = f(l); if (v > best) { best = v; bl = l; } }
+        *lane = bl;
+        return best;
+    }
+};
+
+}  // namespace hqblock

@@ -253,116 +253,193 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     for (const TaskBatch &b : batches) if (pb.rq_multi_node(b.rq) || !b.cuts.empty() || b.is_blocker) separable = false;
     if (separable && !batches.empty()) {
         struct ColRef { uint32_t batch; uint8_t variant; };
-        std::vector<hqmilp::Model> class_model;
-        std::vector<uint8_t> class_has_flag;
-        std::vector<std::vector<ColRef>> class_cols;
-        std::vector<std::vector<uint32_t>> class_x;
-        std::unordered_map<std::string, uint32_t> class_of_sig;
-        std::vector<uint32_t> wclass(ws.n, 0);
-        std::string sig;
-        // slots of every (batch, variant) column, so the eligibility bits of a worker are one pass over its K2 flag row
-        std::vector<uint32_t> col_slot; std::vector<uint32_t> col_rq; std::vector<uint8_t> col_v;
-        for (const TaskBatch &batch : batches) {
-            const RequestView &rv = pb.rqs[batch.rq];
-            for (uint8_t v = 0; v < rv.n_variants; v++) { col_slot.push_back(rv.first_variant + v); col_rq.push_back(batch.rq); col_v.push_back(v); }
-        }
-        const uint32_t nvs = ws.n_variant_slots;
-        long prev = -1;  // previous solver worker: neighbours usually share a class, which three short memcmps establish
-        for (uint32_t w : solver_workers) {
-            const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
-            float mu = ws.min_util ? ws.min_util[w] : 0.0f;
-            if (prev >= 0 && (pb.custom || (ws.blocked[w].empty() && ws.blocked[prev].empty())) && mu == (ws.min_util ? ws.min_util[prev] : 0.0f) &&
-                memcmp(tot, ws.total + (size_t)prev * R, (size_t)R * 8) == 0 && memcmp(fre, ws.free_ + (size_t)prev * R, (size_t)R * 8) == 0 &&
-                memcmp(ws.vflags + (size_t)w * nvs, ws.vflags + (size_t)prev * nvs, nvs) == 0) {
-                wclass[w] = wclass[prev]; prev = w;
-                continue;
-            }
-            prev = w;
-            sig.clear();
-            sig.append(reinterpret_cast<const char *>(tot), (size_t)R * 8);
-            sig.append(reinterpret_cast<const char *>(fre), (size_t)R * 8);
-            sig.append(reinterpret_cast<const char *>(&mu), 4);
-            for (size_t c = 0; c < col_slot.size(); c++) {
-                uint8_t f = ws.vf(w, col_slot[c]);
-                sig.push_back((!is_blocked(w, col_rq[c], col_v[c]) && (f & 4) && (f & 1)) ? 1 : 0);
-            }
-            auto it = class_of_sig.find(sig);
-            if (it != class_of_sig.end()) { wclass[w] = it->second; continue; }
-            uint32_t cid = (uint32_t)class_cols.size();
-            class_of_sig.emplace(sig, cid);
-            wclass[w] = cid;
-            // the worker's block, columns and rows in the order of solver.rs:95-192
-            hqmilp::Model m;
-            std::vector<ColRef> cols;
-            std::vector<std::vector<std::pair<int, double>>> rt(R);
-            std::vector<std::pair<int, double>> cpu;
-            for (uint32_t bi = 0; bi < batches.size(); bi++) {
-                const RequestView &rv = pb.rqs[batches[bi].rq];
-                for (uint8_t v = 0; v < rv.n_variants; v++) {
-                    uint32_t slot = rv.first_variant + v;
-                    const VariantView &vv = pb.variants[slot];
-                    uint8_t f = ws.vf(w, slot);
-                    if (is_blocked(w, batches[bi].rq, v) || !(f & 4) || !(f & 1)) continue;
-                    double sc = 0.0;
-                    for (uint32_t e = 0; e < vv.n_entries; e++) {
-                        double g = pool[vv.res[e]];
-                        sc += g < 0.000001 ? 0.0 : units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]) / g;
-                    }
-                    int col = m.add_col(sc * ((double)vv.weight / FRACTIONS), hqmilp::COL_NAT);
-                    cols.push_back({bi, v});
-                    for (uint32_t e = 0; e < vv.n_entries; e++) {
-                        double a = units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]);
-                        rt[vv.res[e]].push_back({col, a});
-                        if (vv.res[e] == 0) cpu.push_back({col, a});
-                    }
-                }
-            }
-            if (mu > 0.001f && tot[0] != HQ_AMOUNT_MAX) {
-                double all_cpus = units(tot[0]), need = all_cpus * ((double)mu - 1.0) + units(fre[0]);
-                if (!(need < 0.0001)) {
-                    int col = m.add_col(0.0, hqmilp::COL_BOOL);
-                    cols.push_back({UINT32_MAX, 0});
-                    cpu.push_back({col, -need}); m.begin_row(hqmilp::ROW_MIN, 0.0); for (auto &t : cpu) m.term(t.first, t.second); m.end_row(); cpu.pop_back();
-                    cpu.push_back({col, -all_cpus}); m.begin_row(hqmilp::ROW_MAX, 0.0); for (auto &t : cpu) m.term(t.first, t.second); m.end_row(); cpu.pop_back();
-                }
-            }
-            bool unbounded_carry = false;
-            for (uint32_t r = 0; r < R; r++) {
-                if (fre[r] == HQ_AMOUNT_MAX) { if (!rt[r].empty()) unbounded_carry = true; continue; }
-                if (!rt[r].empty()) { m.begin_row(hqmilp::ROW_MAX, units(fre[r])); for (auto &t : rt[r]) m.term(t.first, t.second); m.end_row(); }
-            }
-            if (unbounded_carry) { separable = false; break; }  // MAX-amount rows leak into the next worker in the reference (solver.rs:183-185): general path
-            hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true);
-            out.milp_nodes += sol.nodes; out.milp_cols += m.ncols(); out.milp_rows += m.nrows(); out.milp_components += sol.n_components;
-            if (!sol.feasible) { out.keys.clear(); out.per_key.clear(); return out; }  // `None` => empty solution  solver.rs:433-437
-            if (!sol.optimal) out.is_optimal = false;
-            if (!sol.canonical) out.is_canonical = false;
-            std::vector<uint32_t> xs(cols.size());
-            for (size_t c = 0; c < cols.size(); c++) xs[c] = (uint32_t)std::round(sol.x[c]);
-            { uint8_t fl = 0; for (auto &cr : cols) if (cr.batch == UINT32_MAX) fl = 1; class_has_flag.push_back(fl); }
-            class_cols.push_back(std::move(cols));
-            class_x.push_back(std::move(xs));
-            class_model.push_back(std::move(m));
-        }
-        // per class: count of every (batch, variant)
         const size_t nb = batches.size();
-        std::vector<std::vector<uint32_t>> cls_count(class_cols.size());
+        // the tick's (batch, variant) columns, in the order of solver.rs:95-192: column g of batch b, variant v is voff[b] + v
         std::vector<uint32_t> voff(nb + 1, 0);
         for (size_t b = 0; b < nb; b++) voff[b + 1] = voff[b] + pb.rqs[batches[b].rq].n_variants;
-        if (separable) {
-            for (size_t c = 0; c < class_cols.size(); c++) {
-                cls_count[c].assign(voff[nb], 0);
-                for (size_t k = 0; k < class_cols[c].size(); k++) if (class_cols[c][k].batch != UINT32_MAX) cls_count[c][voff[class_cols[c][k].batch] + class_cols[c][k].variant] = class_x[c][k];
+        const uint32_t NC = voff[nb];
+        std::vector<uint32_t> col_slot(NC), col_rq(NC), col_batch(NC); std::vector<uint8_t> col_v(NC);
+        for (size_t b = 0; b < nb; b++) {
+            const RequestView &rv = pb.rqs[batches[b].rq];
+            for (uint8_t v = 0; v < rv.n_variants; v++) { const uint32_t g = voff[b] + v; col_slot[g] = rv.first_variant + v; col_rq[g] = batches[b].rq; col_batch[g] = (uint32_t)b; col_v[g] = v; }
+        }
+        // ---- worker classes: same (total, free, min_utilization, eligibility bits) => same block ----
+        const uint32_t EW = (NC + 63) / 64, SW = 2 * R + 1 + EW;  // signature words
+        std::vector<uint64_t> sigs; std::vector<uint32_t> rep;     // per class: signature, first worker
+        std::vector<uint32_t> wclass(ws.n, 0);
+        {
+            size_t cap = 64; while (cap < 2 * nw + 2) cap <<= 1;
+            std::vector<uint32_t> table(cap, UINT32_MAX);
+            std::vector<uint64_t> tmp(SW);
+            const uint32_t nvs = ws.n_variant_slots;
+            long prev = -1;  // previous solver worker: neighbours usually share a class, which three short memcmps establish
+            for (uint32_t w : solver_workers) {
+                const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
+                const float mu = ws.min_util ? ws.min_util[w] : 0.0f;
+                if (prev >= 0 && (pb.custom || (ws.blocked[w].empty() && ws.blocked[prev].empty())) && mu == (ws.min_util ? ws.min_util[prev] : 0.0f) &&
+                    memcmp(tot, ws.total + (size_t)prev * R, (size_t)R * 8) == 0 && memcmp(fre, ws.free_ + (size_t)prev * R, (size_t)R * 8) == 0 &&
+                    memcmp(ws.vflags + (size_t)w * nvs, ws.vflags + (size_t)prev * nvs, nvs) == 0) {
+                    wclass[w] = wclass[prev]; prev = w;
+                    continue;
+                }
+                prev = w;
+                memcpy(tmp.data(), tot, (size_t)R * 8); memcpy(tmp.data() + R, fre, (size_t)R * 8);
+                uint32_t mubits; memcpy(&mubits, &mu, 4); tmp[2 * R] = mubits;
+                for (uint32_t e = 0; e < EW; e++) tmp[2 * R + 1 + e] = 0;
+                const bool any_blocked = !pb.custom && !ws.blocked[w].empty();
+                for (uint32_t g = 0; g < NC; g++) {
+                    const uint8_t f = ws.vf(w, col_slot[g]);
+                    if ((f & 4) && (f & 1) && !(any_blocked && is_blocked(w, col_rq[g], col_v[g]))) tmp[2 * R + 1 + g / 64] |= 1ull << (g % 64);
+                }
+                uint64_t h = 0x9E3779B97F4A7C15ull;
+                for (uint32_t i = 0; i < SW; i++) { h ^= tmp[i]; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+                size_t slot = (size_t)h & (cap - 1);
+                uint32_t cid = UINT32_MAX;
+                while (table[slot] != UINT32_MAX) {
+                    if (memcmp(sigs.data() + (size_t)table[slot] * SW, tmp.data(), (size_t)SW * 8) == 0) { cid = table[slot]; break; }
+                    slot = (slot + 1) & (cap - 1);
+                }
+                if (cid == UINT32_MAX) { cid = (uint32_t)rep.size(); table[slot] = cid; rep.push_back(w); sigs.insert(sigs.end(), tmp.begin(), tmp.end()); }
+                wclass[w] = cid;
             }
+        }
+        const uint32_t ncls = (uint32_t)rep.size();
+        auto elig = [&](uint32_t c, uint32_t g) { return (sigs[(size_t)c * SW + 2 * R + 1 + g / 64] >> (g % 64)) & 1; };
+        auto class_mu_flag = [&](uint32_t c) {  // does add_min_utilization create its on/off column?  solver.rs:501-521
+            const uint32_t w = rep[c];
+            const float mu = ws.min_util ? ws.min_util[w] : 0.0f;
+            const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
+            if (!(mu > 0.001f && tot[0] != HQ_AMOUNT_MAX)) return false;
+            const double need = units(tot[0]) * ((double)mu - 1.0) + units(fre[0]);
+            return !(need < 0.0001);
+        };
+        // the block of one class as a model for the exact host solver: columns and rows in the order of solver.rs:95-192
+        auto build_class_model = [&](uint32_t c, hqmilp::Model &m, std::vector<ColRef> &cols) {
+            const uint32_t w = rep[c];
+            const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
+            const float mu = ws.min_util ? ws.min_util[w] : 0.0f;
+            std::vector<std::vector<std::pair<int, double>>> rt(R);
+            std::vector<std::pair<int, double>> cpu;
+            for (uint32_t g = 0; g < NC; g++) {
+                if (!elig(c, g)) continue;
+                const VariantView &vv = pb.variants[col_slot[g]];
+                double sc = 0.0;
+                for (uint32_t e = 0; e < vv.n_entries; e++) {
+                    double gp = pool[vv.res[e]];
+                    sc += gp < 0.000001 ? 0.0 : units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]) / gp;
+                }
+                int col = m.add_col(sc * ((double)vv.weight / FRACTIONS), hqmilp::COL_NAT);
+                cols.push_back({col_batch[g], col_v[g]});
+                for (uint32_t e = 0; e < vv.n_entries; e++) {
+                    double a = units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]);
+                    rt[vv.res[e]].push_back({col, a});
+                    if (vv.res[e] == 0) cpu.push_back({col, a});
+                }
+            }
+            if (class_mu_flag(c)) {
+                const double all_cpus = units(tot[0]), need = all_cpus * ((double)mu - 1.0) + units(fre[0]);
+                int col = m.add_col(0.0, hqmilp::COL_BOOL);
+                cols.push_back({UINT32_MAX, 0});
+                cpu.push_back({col, -need}); m.begin_row(hqmilp::ROW_MIN, 0.0); for (auto &t : cpu) m.term(t.first, t.second); m.end_row(); cpu.pop_back();
+                cpu.push_back({col, -all_cpus}); m.begin_row(hqmilp::ROW_MAX, 0.0); for (auto &t : cpu) m.term(t.first, t.second); m.end_row(); cpu.pop_back();
+            }
+            for (uint32_t r = 0; r < R; r++) {
+                if (fre[r] == HQ_AMOUNT_MAX) continue;
+                if (!rt[r].empty()) { m.begin_row(hqmilp::ROW_MAX, units(fre[r])); for (auto &t : rt[r]) m.term(t.first, t.second); m.end_row(); }
+            }
+        };
+        // MAX-amount rows leak into the next worker in the reference (solver.rs:183-185): such a tick takes the general path
+        for (uint32_t c = 0; c < ncls && separable; c++) {
+            const uint64_t *fre = ws.free_ + (size_t)rep[c] * R;
+            bool any_max = false;
+            for (uint32_t r = 0; r < R; r++) if (fre[r] == HQ_AMOUNT_MAX) any_max = true;
+            if (!any_max) continue;
+            for (uint32_t g = 0; g < NC && separable; g++) {
+                if (!elig(c, g)) continue;
+                const VariantView &vv = pb.variants[col_slot[g]];
+                for (uint32_t e = 0; e < vv.n_entries; e++) if (fre[vv.res[e]] == HQ_AMOUNT_MAX) separable = false;
+            }
+        }
+        // ---- solve one block per class: on the device (one wavefront per class, csrc/block_core.h) where the block qualifies, else here ----
+        std::vector<uint32_t> X((size_t)ncls * NC, 0);  // canonical optimum of every class, by tick column
+        std::vector<uint8_t> solved(ncls, 0), class_has_flag(ncls, 0);
+        if (separable) {
+            for (uint32_t c = 0; c < ncls; c++) class_has_flag[c] = class_mu_flag(c) ? 1 : 0;
+            std::vector<uint32_t> dev_cls;
+            if (pb.blocks && NC <= (uint32_t)hqblock::GCOLS) for (uint32_t c = 0; c < ncls; c++) if (!class_has_flag[c]) dev_cls.push_back(c);
+            if (pb.blocks && dev_cls.size() >= pb.block_min_classes) {
+                std::vector<uint32_t> ent_off(NC + 1, 0), ent_res, weight(NC); std::vector<uint8_t> ent_kind; std::vector<uint64_t> ent_amount;
+                for (uint32_t g = 0; g < NC; g++) {
+                    const VariantView &vv = pb.variants[col_slot[g]];
+                    for (uint32_t e = 0; e < vv.n_entries; e++) { ent_res.push_back(vv.res[e]); ent_kind.push_back(vv.kind[e]); ent_amount.push_back(vv.amount[e]); }
+                    ent_off[g + 1] = (uint32_t)ent_res.size(); weight[g] = vv.weight;
+                }
+                const uint32_t nd = (uint32_t)dev_cls.size();
+                std::vector<uint64_t> cfree((size_t)nd * R), ctot((size_t)nd * R), celig(nd);
+                for (uint32_t i = 0; i < nd; i++) {
+                    const uint32_t c = dev_cls[i];
+                    memcpy(ctot.data() + (size_t)i * R, sigs.data() + (size_t)c * SW, (size_t)R * 8);
+                    memcpy(cfree.data() + (size_t)i * R, sigs.data() + (size_t)c * SW + R, (size_t)R * 8);
+                    celig[i] = sigs[(size_t)c * SW + 2 * R + 1];
+                }
+                std::vector<uint32_t> dx((size_t)nd * NC, 0), dstatus(nd, hqblock::ST_UNSUPPORTED), dsteps(nd, 0);
+                hqblock::ColTable ct{NC, R, ent_off.data(), ent_res.data(), ent_kind.data(), ent_amount.data(), weight.data(), pool.data()};
+                hqblock::ClassTable cl{nd, cfree.data(), ctot.data(), celig.data()};
+                hqblock::Output bo{dx.data(), dstatus.data(), dsteps.data()};
+                if (pb.blocks->solve(ct, cl, bo)) {
+                    for (uint32_t i = 0; i < nd; i++) {
+                        if (dstatus[i] != hqblock::ST_OK) continue;
+                        const uint32_t c = dev_cls[i];
+                        // the answer must fit the worker's rows (exact integer check; anything else is solved again here)
+                        bool fits = true;
+                        for (uint32_t r = 0; r < R && fits; r++) {
+                            unsigned __int128 used = 0;
+                            for (uint32_t g = 0; g < NC; g++) {
+                                const uint32_t xv = dx[(size_t)i * NC + g];
+                                if (!xv) continue;
+                                if (!elig(c, g)) { fits = false; break; }
+                                const VariantView &vv = pb.variants[col_slot[g]];
+                                for (uint32_t e = 0; e < vv.n_entries; e++) if (vv.res[e] == r) used += (unsigned __int128)(vv.kind[e] == HQ_ENTRY_ALL ? ctot[(size_t)i * R + r] : vv.amount[e]) * xv;
+                            }
+                            if (used > cfree[(size_t)i * R + r]) fits = false;
+                        }
+                        if (!fits) continue;
+                        memcpy(X.data() + (size_t)c * NC, dx.data() + (size_t)i * NC, (size_t)NC * 4);
+                        solved[c] = 1; out.blocks_device++;
+                        out.block_steps_max = std::max(out.block_steps_max, dsteps[i]);
+                    }
+                }
+            }
+            for (uint32_t c = 0; c < ncls; c++) {
+                if (solved[c]) continue;
+                hqmilp::Model m; std::vector<ColRef> cols;
+                build_class_model(c, m, cols);
+                hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true);
+                out.milp_nodes += sol.nodes; out.milp_cols += m.ncols(); out.milp_rows += m.nrows(); out.milp_components += sol.n_components;
+                out.blocks_host++;
+                if (!sol.feasible) { out.keys.clear(); out.per_key.clear(); return out; }  // `None` => empty solution  solver.rs:433-437
+                if (!sol.optimal) out.is_optimal = false;
+                if (!sol.canonical) out.is_canonical = false;
+                for (size_t k = 0; k < cols.size(); k++) if (cols[k].batch != UINT32_MAX) X[(size_t)c * NC + voff[cols[k].batch] + cols[k].variant] = (uint32_t)std::round(sol.x[k]);
+            }
+        }
+        if (separable) {
             bool sizes_hold = true;  // the lazy batch-size rows  solver.rs:264-271
-            for (size_t b = 0; b < nb && sizes_hold; b++) {
-                if (batches[b].limit_reached) continue;
-                uint64_t placed = 0;
-                for (uint32_t w : solver_workers) for (uint32_t v = voff[b]; v < voff[b + 1]; v++) placed += cls_count[wclass[w]][v];
-                if (placed > batches[b].size) sizes_hold = false;
+            {
+                std::vector<uint64_t> n_in_class(ncls, 0);
+                for (uint32_t w : solver_workers) n_in_class[wclass[w]]++;
+                for (size_t b = 0; b < nb && sizes_hold; b++) {
+                    if (batches[b].limit_reached) continue;
+                    uint64_t placed = 0;
+                    for (uint32_t c = 0; c < ncls; c++) for (uint32_t v = voff[b]; v < voff[b + 1]; v++) placed += n_in_class[c] * X[(size_t)c * NC + v];
+                    if (placed > batches[b].size) sizes_hold = false;
+                }
             }
             if (!sizes_hold) {
                 separable = false;
+                std::vector<hqmilp::Model> class_model(ncls);
+                std::vector<std::vector<ColRef>> class_cols(ncls);
+                for (uint32_t c = 0; c < ncls; c++) build_class_model(c, class_model[c], class_cols[c]);
                 // Workers that no optimum uses.  Without cuts, blockers and multi-node batches two workers of one class (same free, total, eligibility, no
                 // min_utilization) can exchange their whole contents, and a single task can move to any worker that has room for it; both moves keep every
                 // row satisfied and, as the objective factor (W - idx)/W falls strictly with the index while every cost is positive, moving towards the
@@ -376,10 +453,8 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 {
                     std::vector<uint32_t> n_in_class(class_cols.size(), 0), seen(class_cols.size(), 0), keep(class_cols.size(), UINT32_MAX);
                     for (uint32_t w : solver_workers) n_in_class[wclass[w]]++;
-                    std::vector<uint32_t> rep(class_cols.size(), UINT32_MAX);
-                    for (uint32_t w : solver_workers) if (rep[wclass[w]] == UINT32_MAX) rep[wclass[w]] = w;
                     for (size_t c = 0; c < class_cols.size(); c++) {
-                        if (class_has_flag[c] || rep[c] == UINT32_MAX) continue;
+                        if (class_has_flag[c]) continue;
                         const uint64_t *fre = ws.free_ + (size_t)rep[c] * R, *tot = ws.total + (size_t)rep[c] * R;
                         bool ok = true;
                         uint64_t n_tasks = 0;
@@ -464,7 +539,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             for (size_t b = 0; b < nb; b++) {
                 for (uint8_t v = 0; v < pb.rqs[batches[b].rq].n_variants; v++) {
                     ids.clear(); widx.clear(); cnt.clear();
-                    for (uint32_t w : solver_workers) { uint32_t c = cls_count[wclass[w]][voff[b] + v]; if (c) { ids.push_back(ws.id[w]); widx.push_back(w); cnt.push_back(c); } }
+                    for (uint32_t w : solver_workers) { uint32_t c = X[(size_t)wclass[w] * NC + voff[b] + v]; if (c) { ids.push_back(ws.id[w]); widx.push_back(w); cnt.push_back(c); } }
                     if (ids.empty()) continue;
                     const std::vector<uint32_t> &word = cached_worker_order(ids);
                     std::vector<std::pair<uint32_t, uint32_t>> ordered; ordered.reserve(word.size());

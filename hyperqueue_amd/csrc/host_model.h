@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/hqtick.h"
+#include "block_core.h"
 #include "milp.h"
 
 namespace hqhost {
@@ -66,7 +67,16 @@ struct WorkerSet {
     uint32_t tmc(uint32_t w, uint32_t slot) const { return vtmc[(size_t)w * n_variant_slots + slot]; }
 };
 
+// Batch solver of the per-class blocks of the separable path (run_scheduling_solver below): the tick hands in the launcher of
+// k_block_solve (csrc/block_solve.hip).  All pointers of the tables are host memory; false = not solved (the host solver takes over).
+struct BlockSolver {
+    virtual ~BlockSolver() {}
+    virtual bool solve(const hqblock::ColTable &cols, const hqblock::ClassTable &classes, const hqblock::Output &out) = 0;
+};
+
 struct Problem {
+    BlockSolver *blocks = nullptr;       // nullptr: every block on the host
+    uint32_t block_min_classes = 1;      // fewer device-eligible classes than this: not worth a launch
     uint32_t R = 0, n_groups = 0;
     std::vector<RequestView> rqs;
     std::vector<VariantView> variants;  // all variant slots
@@ -110,6 +120,7 @@ struct Counts {
     }
     int error = 0; std::string errmsg;
     long milp_nodes = 0; int milp_cols = 0, milp_rows = 0, milp_components = 0;
+    uint32_t blocks_device = 0, blocks_host = 0, block_steps_max = 0;  // separable path: classes solved by k_block_solve / by the host solver
 };
 
 Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &batches);

@@ -11,9 +11,13 @@
 //   D2H   assignment records
 // There is no CPU implementation of the scans/mapping: without a HIP device every entry point fails.
 #include "../../include/hqtick.h"
+#ifdef HQTICK_TEST_HOOKS
 #include "../../include/hqtick_debug.h"
+#endif
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -24,6 +28,7 @@
 #include <string>
 #include <vector>
 
+#include "block_solve.h"
 #include "devbuf.h"
 #include "graph.h"
 #include "hb_order.h"
@@ -69,7 +74,8 @@ struct hqtick_ctx {
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
-    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_retr;
+    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_retr, h_blk;
+    uint32_t block_budget = 4096, block_min_classes = 1;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
     // workers / requests
     DevBuf d_up, d_vflags, d_vtmc;
     // selection + mapping
@@ -85,10 +91,11 @@ struct hqtick_ctx {
     uint32_t tpw_hint = 0;                            // HQTICK_TPW (tuning knob): tasks per wavefront slice
     uint32_t shard_index = 0, shard_count = 1;       // hqtick_set_shard
     void *sink = nullptr; size_t sink_bytes = 0;      // hqtick_set_record_sink (device memory)
-    // launch state of the last tick (hqtick_debug_time_kernel re-launches K1 / K4 on it)
+    // launch state of the last tick (hqtick_time_kernel re-launches K1 / K4 on it)
     hqk::WaveGeom last_geom{}; uint32_t last_L = 0, last_Q = 0, last_G = 0; size_t last_tb = 0, last_plan_bytes = 0, last_hist_off = 0; bool last_valid = false;
     hqgraph::Graph graph;  // hqtick_graph_*: dependency counters + consumer lists in HBM
-    double tl[32] = {}; int ntl = 0;  // debug timeline (us since tick start), hqtick_debug_timeline()
+    ncclComm_t comm = nullptr; uint32_t comm_rank = 0, comm_world = 0;  // hqtick_comm_init (RCCL, loaded on first use)
+    double tl[32] = {}; int ntl = 0;  // debug timeline (us since tick start), hqtick_timeline()
 };
 
 namespace {
@@ -330,6 +337,37 @@ std::vector<hqhost::QueueLevels> queue_levels(const Scan &sc, const hqtick_snaps
     }
     return qs;
 }
+
+// The per-class blocks of the separable placement on the device (csrc/block_solve.hip): tables staged in ONE pinned, device-mapped buffer
+// that the kernel reads in place (a few dozen bytes per class) and writes its answers into; one launch, one synchronisation.
+struct DeviceBlocks : hqhost::BlockSolver {
+    hqtick_ctx *ctx;
+    explicit DeviceBlocks(hqtick_ctx *c) : ctx(c) {}
+    bool solve(const hqblock::ColTable &ct, const hqblock::ClassTable &cl, const hqblock::Output &out) override {
+        const uint32_t NC = ct.n_cols, R = ct.R, nd = cl.n_classes, ne = ct.ent_off[NC];
+        auto al8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+        const size_t o_off = 0, o_res = al8(o_off + (size_t)(NC + 1) * 4), o_w = al8(o_res + (size_t)ne * 4), o_kind = al8(o_w + (size_t)NC * 4), o_amt = al8(o_kind + ne),
+                     o_pool = o_amt + (size_t)ne * 8, o_free = o_pool + (size_t)R * 8, o_tot = o_free + (size_t)nd * R * 8, o_elig = o_tot + (size_t)nd * R * 8,
+                     o_x = o_elig + (size_t)nd * 8, o_st = o_x + al8((size_t)nd * NC * 4), o_steps = o_st + al8((size_t)nd * 4), bytes = o_steps + al8((size_t)nd * 4) + 64;
+        if (!ctx->h_blk.ensure(bytes)) return false;
+        unsigned char *h = ctx->h_blk.as<unsigned char>(), *d = ctx->h_blk.dev<unsigned char>();
+        memcpy(h + o_off, ct.ent_off, (size_t)(NC + 1) * 4); memcpy(h + o_res, ct.ent_res, (size_t)ne * 4); memcpy(h + o_w, ct.weight, (size_t)NC * 4);
+        memcpy(h + o_kind, ct.ent_kind, ne); memcpy(h + o_amt, ct.ent_amount, (size_t)ne * 8); memcpy(h + o_pool, ct.pool, (size_t)R * 8);
+        memcpy(h + o_free, cl.free_, (size_t)nd * R * 8); memcpy(h + o_tot, cl.total, (size_t)nd * R * 8); memcpy(h + o_elig, cl.elig, (size_t)nd * 8);
+        hqblock::ColTable dct{NC, R, (const uint32_t *)(d + o_off), (const uint32_t *)(d + o_res), (const uint8_t *)(d + o_kind), (const uint64_t *)(d + o_amt), (const uint32_t *)(d + o_w), (const double *)(d + o_pool)};
+        hqblock::ClassTable dcl{nd, (const uint64_t *)(d + o_free), (const uint64_t *)(d + o_tot), (const uint64_t *)(d + o_elig)};
+        hqblock::Output dout{(uint32_t *)(d + o_x), (uint32_t *)(d + o_st), (uint32_t *)(d + o_steps)};
+        if (ctx->timing && hipEventRecord(ctx->ev[9], ctx->stream) != hipSuccess) return false;
+        if (hqblock::block_solve(dct, dcl, dout, ctx->block_budget, ctx->stream) != hipSuccess) return false;
+        if (ctx->timing && hipEventRecord(ctx->ev[10], ctx->stream) != hipSuccess) return false;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+        memcpy(out.x, h + o_x, (size_t)nd * NC * 4); memcpy(out.status, h + o_st, (size_t)nd * 4); memcpy(out.steps, h + o_steps, (size_t)nd * 4);
+        float ms = 0;
+        if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]) == hipSuccess) ctx->stats.block_solve_us = ms * 1000.0;
+        ctx->stats.n_classes_device = nd;
+        return true;
+    }
+};
 
 // One tick, stage by stage.  The stages share the plan scratch of the ctx (no per-tick allocation in the steady state) and a handful of
 // sizes; run() is the only entry point and mirrors run_scheduling_inner (scheduler/main.rs:50-72).
@@ -740,7 +778,7 @@ struct TickRun {
         uint32_t nv = Q ? s->rq_variant_off[Q] : 0;
         ctx->stats.n_assigned = n_asg; ctx->stats.n_prefilled = n_pref;
         ctx->stats.algorithmic_bytes = N * 20 + (uint64_t)W * R * 16 + (uint64_t)nv * R * 9 + n_asg * 13 + n_pref * 12;
-        ctx->stats.tick_gpu_us = ctx->stats.distinct_us + ctx->stats.level_hist_us + ctx->stats.scan_us + ctx->stats.select_us + ctx->stats.sweep_us + ctx->stats.other_us;
+        ctx->stats.tick_gpu_us = ctx->stats.distinct_us + ctx->stats.level_hist_us + ctx->stats.scan_us + ctx->stats.block_solve_us + ctx->stats.select_us + ctx->stats.sweep_us + ctx->stats.other_us;
     }
 
     int run() {
@@ -763,8 +801,12 @@ struct TickRun {
         export_batches(ctx, batches, out);
         mark();  // 1: batches
         const double t2 = now_us();
+        DeviceBlocks dev_blocks(ctx);
+        pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes;
         cnt = hqhost::run_scheduling_solver(pb, batches);
+        pb.blocks = nullptr;
         if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
+        ctx->stats.n_classes_device = cnt.blocks_device; ctx->stats.n_classes_host = cnt.blocks_host; ctx->stats.block_steps_max = cnt.block_steps_max;
         mark();  // 2: solve
         const double t3 = now_us();
         out->is_optimal = cnt.is_optimal;
@@ -812,6 +854,8 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     ctx->cfg = *config; ctx->device = config->device_index;
     ctx->timing = (config->flags & HQTICK_FLAG_NO_KERNEL_TIMING) == 0;
     if (const char *e = getenv("HQTICK_TPW")) { long v = atol(e); if (v >= 64 && v <= (1 << 20) && v % 64 == 0) ctx->tpw_hint = (uint32_t)v; }
+    if (const char *e = getenv("HQTICK_BLOCK_BUDGET")) { long v = atol(e); if (v >= 1 && v <= (1 << 24)) ctx->block_budget = (uint32_t)v; }
+    if (const char *e = getenv("HQTICK_BLOCK_MIN_CLASSES")) { long v = atol(e); if (v >= 0) ctx->block_min_classes = (uint32_t)v; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     if (!ctx->d_flags.ensure(64) || hipMemset(ctx->d_flags.p, 0, 64) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
@@ -819,6 +863,7 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     return 0;
 }
 
+static void rccl_destroy_comm(hqtick_ctx *ctx);
 void hqtick_destroy(hqtick_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
@@ -827,8 +872,9 @@ void hqtick_destroy(hqtick_ctx *ctx) {
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
                       &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8};
     for (DevBuf *b : bufs) b->release();
+    if (ctx->comm) { rccl_destroy_comm(ctx); }
     ctx->graph.release();
-    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_retr.release();
+    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_retr.release(); ctx->h_blk.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1075,12 +1121,45 @@ int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_w
     pb.custom = &fw;
     std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
     std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
+    DeviceBlocks dev_blocks(ctx);
+    pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes;
     hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
     ctx->q_loaded.assign(fake->n_workers, 0);
     for (auto &k : cnt.per_key) for (auto &wc : k) if (wc.second > 0) ctx->q_loaded[wc.first] = 1;  // query.rs:73-81
     out->n_workers = fake->n_workers; out->is_loaded = ctx->q_loaded.data(); out->is_optimal = cnt.is_optimal;
     return 0;
+}
+
+#ifdef HQTICK_TEST_HOOKS
+// ---- libhqtick_test.so only (include/hqtick_debug.h): CPU hooks for the test suite.  Not compiled into libhqtick.so. ----
+namespace {
+// k_block_solve's algorithm (csrc/block_core.h) with the wavefront emulated by a loop over its 64 lanes
+struct EmulatedBlocks : hqhost::BlockSolver {
+    uint32_t budget;
+    explicit EmulatedBlocks(uint32_t b) : budget(b) {}
+    bool solve(const hqblock::ColTable &ct, const hqblock::ClassTable &cl, const hqblock::Output &out) override {
+        static thread_local hqblock::Shared *S = new hqblock::Shared();
+        hqblock::HostWave wv;
+        for (uint32_t c = 0; c < cl.n_classes; c++) hqblock::solve_block(wv, *S, ct, cl, c, out, budget);
+        return true;
+    }
+};
+thread_local int g_block_emulation = 0;
+thread_local uint32_t g_block_budget = 4096, g_last_blocks_device = 0, g_last_blocks_host = 0;
+}  // namespace
+
+void hqtick_debug_set_block_emulation(int on, uint32_t budget) { g_block_emulation = on; if (budget) g_block_budget = budget; }
+void hqtick_debug_last_blocks(uint32_t *n_emulated, uint32_t *n_host) { if (n_emulated) *n_emulated = g_last_blocks_device; if (n_host) *n_host = g_last_blocks_host; }
+
+int hqtick_debug_block_solve_host(uint32_t n_cols, uint32_t n_resources, const uint32_t *ent_off, const uint32_t *ent_res, const uint8_t *ent_kind, const uint64_t *ent_amount,
+                                  const uint32_t *weight, const double *pool, uint32_t n_classes, const uint64_t *free_, const uint64_t *total, const uint64_t *elig,
+                                  uint32_t budget, uint32_t *x, uint32_t *status, uint32_t *steps) {
+    hqblock::ColTable ct{n_cols, n_resources, ent_off, ent_res, ent_kind, ent_amount, weight, pool};
+    hqblock::ClassTable cl{n_classes, free_, total, elig};
+    hqblock::Output out{x, status, steps};
+    EmulatedBlocks emu(budget ? budget : 4096);
+    return emu.solve(ct, cl, out) ? 0 : HQTICK_E_DEVICE;
 }
 
 // Test hook (include/hqtick_debug.h): the host stages on caller-supplied scan outputs.  No device is touched.
@@ -1101,8 +1180,11 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
     std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
     memset(out, 0, sizeof(*out));
     export_batches(ctx, batches, out);
+    EmulatedBlocks emu(g_block_budget);
+    if (g_block_emulation) { pb.blocks = &emu; pb.block_min_classes = 1; }
     hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
+    g_last_blocks_device = cnt.blocks_device; g_last_blocks_host = cnt.blocks_host;
     ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
     for (size_t k = 0; k < cnt.keys.size(); k++)
         for (auto &wc : cnt.per_key[k]) { ctx->cnt_rq.push_back(cnt.keys[k].first); ctx->cnt_variant.push_back(cnt.keys[k].second); ctx->cnt_worker.push_back(wc.first); ctx->cnt_value.push_back(wc.second); }
@@ -1136,6 +1218,8 @@ int hqtick_debug_host_query(const hqtick_config *config, const hqtick_snapshot *
     sc.levels.assign(levels, levels + n_levels); sc.hist.assign(hist, hist + (size_t)n_levels * Q);
     std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
     std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
+    EmulatedBlocks emu(g_block_budget);
+    if (g_block_emulation) { pb.blocks = &emu; pb.block_min_classes = 1; }
     hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
     ctx->q_loaded.assign(fake->n_workers, 0);
@@ -1143,6 +1227,8 @@ int hqtick_debug_host_query(const hqtick_config *config, const hqtick_snapshot *
     out->n_workers = fake->n_workers; out->is_loaded = ctx->q_loaded.data(); out->is_optimal = cnt.is_optimal;
     return 0;
 }
+
+#endif  // HQTICK_TEST_HOOKS
 
 int hqtick_set_shard(hqtick_ctx *ctx, uint32_t shard_index, uint32_t shard_count) {
     if (!ctx) return HQTICK_E_INVALID;
@@ -1171,9 +1257,9 @@ int hqtick_set_record_sink(hqtick_ctx *ctx, void *device_ptr, size_t capacity_by
     return 0;
 }
 
-int hqtick_debug_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us) {
+int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us) {
     if (!ctx || !avg_us || iters <= 0) return HQTICK_E_INVALID;
-    if (!ctx->last_valid || !ctx->resident) return fail(ctx, HQTICK_E_INVALID, "hqtick_debug_time_kernel needs a preceding hqtick_run_resident tick that placed tasks");
+    if (!ctx->last_valid || !ctx->resident) return fail(ctx, HQTICK_E_INVALID, "hqtick_time_kernel needs a preceding hqtick_run_resident tick that placed tasks");
     HQ_HIP(hipSetDevice(ctx->device));
     const uint64_t N = ctx->n_ready; const hqk::WaveGeom g = ctx->last_geom;
     const uint32_t *d = ctx->d_map.as<uint32_t>();
@@ -1196,7 +1282,7 @@ int hqtick_debug_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_
     return 0;
 }
 
-int hqtick_debug_timeline(const hqtick_ctx *ctx, double *out, int cap) {
+int hqtick_timeline(const hqtick_ctx *ctx, double *out, int cap) {
     if (!ctx || !out) return 0;
     int n = ctx->ntl < cap ? ctx->ntl : cap;
     for (int i = 0; i < n; i++) out[i] = ctx->tl[i];
@@ -1210,3 +1296,80 @@ int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- RCCL all-gather of the shards' record sinks
+// north_star: "workers hash-partitioned across the GPUs of one node with a single RCCL allgather over xGMI to merge the assignment vector".
+// librccl is loaded on first use (dlopen), so that a single-GPU host needs no RCCL at all and a process that already carries one (e.g.
+// PyTorch's) shares it.
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) get_id = nullptr;
+    decltype(&ncclCommInitRank) init_rank = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclCommDestroy) destroy = nullptr;
+    decltype(&ncclGetErrorString) err = nullptr;
+    bool ok() const { return h && get_id && init_rank && all_gather && destroy && err; }
+};
+Rccl &rccl() {
+    static Rccl r;
+    if (!r.h) {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+        if (r.h) {
+            r.get_id = (decltype(r.get_id))dlsym(r.h, "ncclGetUniqueId"); r.init_rank = (decltype(r.init_rank))dlsym(r.h, "ncclCommInitRank");
+            r.all_gather = (decltype(r.all_gather))dlsym(r.h, "ncclAllGather"); r.destroy = (decltype(r.destroy))dlsym(r.h, "ncclCommDestroy");
+            r.err = (decltype(r.err))dlsym(r.h, "ncclGetErrorString");
+        }
+    }
+    return r;
+}
+}  // namespace
+
+extern "C" {
+
+int hqtick_comm_unique_id(void *id_out) {
+    if (!id_out) return HQTICK_E_INVALID;
+    Rccl &r = rccl();
+    if (!r.ok()) return HQTICK_E_NO_DEVICE;
+    ncclUniqueId id;
+    if (r.get_id(&id) != ncclSuccess) return HQTICK_E_DEVICE;
+    static_assert(sizeof(id) == HQTICK_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int hqtick_comm_init(hqtick_ctx *ctx, const void *id, uint32_t rank, uint32_t world) {
+    if (!ctx || !id || world == 0 || rank >= world) return HQTICK_E_INVALID;
+    Rccl &r = rccl();
+    if (!r.ok()) return fail(ctx, HQTICK_E_NO_DEVICE, "librccl.so could not be loaded");
+    HQ_HIP(hipSetDevice(ctx->device));
+    if (ctx->comm) { r.destroy(ctx->comm); ctx->comm = nullptr; }
+    ncclUniqueId uid; memcpy(&uid, id, sizeof(uid));
+    ncclResult_t rc = r.init_rank(&ctx->comm, (int)world, uid, (int)rank);
+    if (rc != ncclSuccess) { ctx->comm = nullptr; return fail(ctx, HQTICK_E_DEVICE, std::string("ncclCommInitRank: ") + r.err(rc)); }
+    ctx->comm_rank = rank; ctx->comm_world = world;
+    return hqtick_set_shard(ctx, rank, world);
+}
+
+int hqtick_shard_allgather(hqtick_ctx *ctx, void *recv_device, size_t recv_bytes) {
+    if (!ctx || !recv_device) return HQTICK_E_INVALID;
+    if (!ctx->comm) return fail(ctx, HQTICK_E_INVALID, "hqtick_shard_allgather without hqtick_comm_init");
+    if (!ctx->sink || !ctx->sink_bytes) return fail(ctx, HQTICK_E_INVALID, "hqtick_shard_allgather without a record sink (hqtick_set_record_sink)");
+    if (recv_bytes < (size_t)ctx->comm_world * ctx->sink_bytes) return fail(ctx, HQTICK_E_CAPACITY, "receive buffer smaller than world x sink bytes");
+    HQ_HIP(hipSetDevice(ctx->device));
+    ncclResult_t rc = rccl().all_gather(ctx->sink, recv_device, ctx->sink_bytes, ncclUint8, ctx->comm, ctx->stream);
+    if (rc != ncclSuccess) return fail(ctx, HQTICK_E_DEVICE, std::string("ncclAllGather: ") + rccl().err(rc));
+    HQ_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int hqtick_comm_destroy(hqtick_ctx *ctx) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (ctx->comm) { hipSetDevice(ctx->device); rccl().destroy(ctx->comm); ctx->comm = nullptr; }
+    ctx->comm_world = 0; ctx->comm_rank = 0;
+    return 0;
+}
+
+}  // extern "C"
+
+static void rccl_destroy_comm(hqtick_ctx *ctx) { hqtick_comm_destroy(ctx); }

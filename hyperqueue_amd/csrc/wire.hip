@@ -11,7 +11,9 @@
 #include <new>
 
 #include "../../include/hqtick.h"
+#ifdef HQTICK_TEST_HOOKS
 #include "../../include/hqtick_debug.h"
+#endif
 #include "wire_core.h"
 
 using namespace hqwire;
@@ -97,6 +99,7 @@ int hqwire_encode_device(const hqwire_tables *tables, const hqwire_records *reco
     return hipGetLastError() == hipSuccess ? 0 : HQTICK_E_DEVICE;
 }
 
+#ifdef HQTICK_TEST_HOOKS  // libhqtick_test.so only
 // CPU debug hook: the same phases on HOST memory, one emulated thread after the other (a barrier = the end of a loop over tid).
 // Test infrastructure for machines without a GPU; the product entry point is hqwire_encode_device.
 // `order` picks the sequence in which the 256 emulated threads of a phase run (0 ascending, 1 descending, 2 a fixed permutation): a phase
@@ -110,5 +113,6 @@ int hqwire_debug_encode_host_order(const hqwire_tables *tables, const hqwire_rec
 int hqwire_debug_encode_host(const hqwire_tables *tables, const hqwire_records *records, const hqwire_output *out) {
     return hqwire_debug_encode_host_order(tables, records, out, 0);
 }
+#endif  // HQTICK_TEST_HOOKS
 
 }  // extern "C"

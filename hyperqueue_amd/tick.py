@@ -186,10 +186,10 @@ class Tick:
         return abi._np(out.is_loaded, n, np.uint8).astype(bool), bool(out.is_optimal)
 
     def time_kernel(self, which: int, iters: int = 100) -> float:
-        """hqtick_debug_time_kernel: average duration (us) of `iters` back-to-back launches of K1 (0) / K4 (1) on the last resident tick."""
+        """hqtick_time_kernel: average duration (us) of `iters` back-to-back launches of K1 (0) / K4 (1) on the last resident tick."""
         us = C.c_double()
-        self._lib.hqtick_debug_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
-        rc = self._lib.hqtick_debug_time_kernel(self._ctx, which, iters, C.byref(us))
+        self._lib.hqtick_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        rc = self._lib.hqtick_time_kernel(self._ctx, which, iters, C.byref(us))
         if rc < 0:
             raise HqTickError(rc, self._err())
         return us.value

@@ -48,8 +48,6 @@ def load() -> C.CDLL:
     lib.hqwire_scratch_bytes.argtypes = [C.c_uint64, C.c_uint64]
     lib.hqwire_scratch_bytes.restype = C.c_uint64
     lib.hqwire_encode_device.argtypes = [C.POINTER(TablesC), C.POINTER(RecordsC), C.POINTER(OutputC), _vp]
-    lib.hqwire_debug_encode_host.argtypes = [C.POINTER(TablesC), C.POINTER(RecordsC), C.POINTER(OutputC)]
-    lib.hqwire_debug_encode_host_order.argtypes = [C.POINTER(TablesC), C.POINTER(RecordsC), C.POINTER(OutputC), C.c_int]
     lib.hqwire_abi_version.restype = C.c_uint32
     return lib
 
@@ -187,8 +185,14 @@ def _structs(t: WireTables, r: WireRecords, ptrs_t: List[int], ptrs_r: List[int]
 
 
 def encode_host_debug(t: WireTables, r: WireRecords, capacity: int, order: int = 0) -> WireResult:
-    """`hqwire_debug_encode_host_order`: the kernels' phase functions on the CPU (tests only); `order` = sequence of the emulated threads."""
-    lib = load()
+    """`hqwire_debug_encode_host_order` of libhqtick_test.so: the kernels' phase functions on the CPU (tests only; the product library has no such
+    entry point); `order` = sequence of the emulated threads."""
+    from . import _testhooks
+
+    lib = _testhooks.load()
+    lib.hqwire_scratch_bytes.argtypes = [C.c_uint64, C.c_uint64]
+    lib.hqwire_scratch_bytes.restype = C.c_uint64
+    lib.hqwire_debug_encode_host_order.argtypes = [C.POINTER(TablesC), C.POINTER(RecordsC), C.POINTER(OutputC), C.c_int]
     ta, ra = [_padded(np.ascontiguousarray(a)) for a in t.arrays()], [_padded(np.ascontiguousarray(a)) for a in r.arrays()]
     tc, rc = _structs(t, r, [a.ctypes.data for a in ta], [a.ctypes.data for a in ra])
     S = r.n_workers + r.n_mn

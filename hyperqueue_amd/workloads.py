@@ -8,6 +8,9 @@ C++/Rust harness can regenerate the same inputs.
   c3p c3 with three user-priority levels (80/15/5 %): couples all workers through priority cuts (reported, not benched)
   c4  c3 classes as 2-variant OR-lists, 4096 workers                (sharded case)
   c5  make_dag(): 1 000 000-node random DAG over the c3 classes, fan-in ~ Poisson(3) from lower ids (dependency-graph case)
+  c3s / c4s  make_steady(): c3 / c4 in the STEADY STATE of SURVEY.md §8(d) — every worker is running a packed mix of tasks of which a random
+      10 % have just finished, so the free vectors differ from worker to worker (about one worker class per worker) while the ready set is
+      still large enough to saturate every request class
 """
 from __future__ import annotations
 
@@ -96,6 +99,42 @@ def make(name: str, seed: int = 0, n_tasks: Optional[int] = None, n_workers: Opt
         reqs = [[_variant(c[0]), _variant(alt)] for c, alt in zip(C3_CLASSES, C4_ALTERNATIVES)]
         return abi.Snapshot(requests=reqs, task_id=ids, task_priority=prio, task_rq=rq, **w)
     raise ValueError(f"unknown workload {name}")
+
+
+def make_steady(name: str = "c3", seed: int = 0, n_tasks: Optional[int] = None, n_workers: Optional[int] = None, release: float = 0.10) -> abi.Snapshot:
+    """SURVEY.md §8(d) "steady-state variant": the cluster of `name` (c3 / c4) mid-run.  Every worker is first filled with a random mix of
+    tasks drawn by the class weights until five draws in a row no longer fit, then each running task finishes with probability `release`;
+    `worker_free` = total - what still runs, `assigned` = the running (rq, variant 0) list.  The ready set is the one of `name`."""
+    snap = make(name, seed=seed, n_tasks=n_tasks, n_workers=n_workers)
+    W, R = len(snap.worker_id), snap.n_resources
+    need = np.zeros((len(C3_CLASSES), R), np.int64)
+    for q, (entries, _) in enumerate(C3_CLASSES):
+        for r, a in entries:
+            need[q, r] = int(round(a * FR))
+    edges = np.cumsum([c[1] for c in C3_CLASSES]) / np.sum([c[1] for c in C3_CLASSES])
+    free = np.asarray(snap.worker_total, np.int64).copy()
+    assigned = []
+    draws = splitmix64_stream(seed ^ 0x57EAD, W * 512).reshape(W, 512)
+    for w in range(W):
+        running, misses, i = [], 0, 0
+        while misses < 5 and i < 384:
+            u = float(draws[w, i] >> np.uint64(11)) / float(1 << 53); i += 1
+            q = int(np.searchsorted(edges, u, side="right").clip(0, len(C3_CLASSES) - 1))
+            if (free[w] >= need[q]).all():
+                free[w] -= need[q]; running.append(q); misses = 0
+            else:
+                misses += 1
+        keep = []
+        for k, q in enumerate(running):
+            u = float(draws[w, 384 + (k % 128)] >> np.uint64(11)) / float(1 << 53)
+            if u < release:
+                free[w] += need[q]
+            else:
+                keep.append((q, 0))
+        assigned.append(keep)
+    snap.worker_free = free.astype(np.uint64)
+    snap.assigned = assigned
+    return snap
 
 
 def make_dag(n: int = 1_000_000, seed: int = 0, mean_fan_in: float = 3.0):

@@ -364,6 +364,22 @@ int hqtick_set_record_sink(hqtick_ctx *ctx, void *device_ptr, size_t capacity_by
 size_t hqtick_sink_bytes(uint32_t n_workers, uint32_t capacity_records);
 uint32_t hqtick_sink_capacity_records(uint32_t n_workers, size_t capacity_bytes);
 
+/*
+ * The merge of the shards inside the boundary: one RCCL all-gather (over xGMI on one node) of every rank's record sink, so that a host
+ * that loads this library needs nothing else for the multi-GPU path.  librccl is loaded on first use (dlopen).
+ *   hqtick_comm_unique_id   rank 0 creates the 128-byte communicator id; the host carries it to the other ranks by its own means
+ *   hqtick_comm_init        every rank, collectively: ncclCommInitRank on the ctx's device; also hqtick_set_shard(rank, world)
+ *   hqtick_shard_allgather  after a tick with a record sink set: recv_device (device memory, >= world x sink capacity_bytes) receives the
+ *                           sinks of ranks 0..world-1 back to back, each in the layout documented above; returns when the data is there
+ *                           (ncclAllGather on the ctx's stream + one synchronisation).  Every rank must use the same capacity_bytes.
+ *   hqtick_comm_destroy     ncclCommDestroy (also done by hqtick_destroy)
+ */
+#define HQTICK_COMM_ID_BYTES 128
+int hqtick_comm_unique_id(void *id_out);
+int hqtick_comm_init(hqtick_ctx *ctx, const void *id, uint32_t rank, uint32_t world);
+int hqtick_shard_allgather(hqtick_ctx *ctx, void *recv_device, size_t recv_bytes);
+int hqtick_comm_destroy(hqtick_ctx *ctx);
+
 /* compute_new_worker_query(): batches + solver on fake workers, no mapping  scheduler/query.rs:70-71 */
 int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, const hqtick_query_workers *fake,
                  hqtick_query_result *out);
@@ -390,8 +406,17 @@ typedef struct hqtick_kernel_stats {
     double tick_gpu_us;     /* first kernel start -> last kernel end                 */
     uint64_t algorithmic_bytes; /* N*20 + W*R*16 + Q*V*R*9 + A*13 + P*12 */
     uint64_t n_assigned, n_prefilled;
+    double block_solve_us;  /* k_block_solve: the per-worker-class blocks of the separable placement (one wavefront per class) */
+    uint32_t n_classes_device, n_classes_host; /* worker classes solved by k_block_solve / by the host solver in the last tick */
+    uint32_t block_steps_max, reserved0;       /* most search steps any class took                                             */
 } hqtick_kernel_stats;
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
+/* Re-launches one streaming kernel of the last resident tick `iters` times back to back between two HIP events on the ctx's
+ * stream and returns the average launch duration (which: 0 = K1 level_hist, 1 = K4 select_scatter).  GPU only. */
+int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us);
+/* Host wall-clock marks (microseconds since the start of the last tick) at the internal stage boundaries of the last tick;
+ * returns the number of marks written (bench tooling). */
+int hqtick_timeline(const hqtick_ctx *ctx, double *out, int cap);
 
 #ifdef __cplusplus
 }

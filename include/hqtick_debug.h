@@ -1,9 +1,10 @@
 /*
- * hqtick_debug.h — test hooks exported by libhqtick.so next to the product ABI (include/hqtick.h).
+ * hqtick_debug.h — test hooks exported by libhqtick_test.so ONLY (the product library libhqtick.so exports include/hqtick.h and
+ * include/hqwire.h and nothing else; the hooks below are compiled under -DHQTICK_TEST_HOOKS, hyperqueue_amd/build.py::build_test).
  *
  * These expose HOST-side building blocks of the tick so they can be unit-tested on a machine without a GPU.
  * They are not part of the reference's surface and are not a CPU path of the tick: hqtick_run() has no CPU
- * implementation and fails with HQTICK_E_NO_DEVICE when no gfx950 device is present.
+ * implementation and fails with HQTICK_E_NO_DEVICE when no gfx950 device is present — in either library.
  */
 #ifndef HQTICK_DEBUG_H
 #define HQTICK_DEBUG_H
@@ -45,14 +46,19 @@ int hqtick_debug_milp_was_canonical(void);
  * out_pos[i] = index into `keys` of the i-th element visited (scheduler/mapping.rs:43). */
 void hqtick_debug_map_order_u32(const uint32_t *keys, uint32_t n, uint32_t *out_pos);
 
-/* Host wall-clock marks (microseconds since the start of the last tick) at the internal stage boundaries of
- * hqtick_run(); bench tooling only.  Returns the number of marks written. */
-struct hqtick_ctx;
-/* Re-launches one streaming kernel of the last resident tick `iters` times back to back between two HIP events on the ctx's
- * stream and returns the average launch duration (which: 0 = K1 level_hist, 1 = K4 select_scatter).  Amortises the ~2 us of
- * event/dispatch latency that a single bracketed launch inside a tick carries. */
-int hqtick_debug_time_kernel(struct hqtick_ctx *ctx, int which, int iters, double *avg_us);
-int hqtick_debug_timeline(const struct hqtick_ctx *ctx, double *out, int cap);
+/* The per-worker-class block solver of the separable placement (csrc/block_core.h = the algorithm of k_block_solve) with the wavefront
+ * emulated on the CPU: the 64 lanes of every lane-parallel step run in a loop.  Arguments = the kernel's tables (hqblock::ColTable /
+ * ClassTable / Output) as host arrays: the tick's (batch, variant) columns as a CSR of request entries + weight + resource pool sums, per class
+ * free[R] / total[R] / eligibility mask; out: x[n_classes * n_cols], status[n_classes] (0 ok, 1 step budget exhausted, 2 block shape not
+ * supported), steps[n_classes]. */
+int hqtick_debug_block_solve_host(uint32_t n_cols, uint32_t n_resources, const uint32_t *ent_off, const uint32_t *ent_res, const uint8_t *ent_kind,
+                                  const uint64_t *ent_amount, const uint32_t *weight, const double *pool, uint32_t n_classes, const uint64_t *free_,
+                                  const uint64_t *total, const uint64_t *elig, uint32_t budget, uint32_t *x, uint32_t *status, uint32_t *steps);
+/* on != 0: hqtick_debug_host_stages / _host_query (this thread) solve the class blocks of the separable path with that emulation instead
+ * of the host MILP solver — the code path of a GPU tick, minus the hardware.  budget = search steps per class (0 keeps the current one). */
+void hqtick_debug_set_block_emulation(int on, uint32_t budget);
+/* classes the last hqtick_debug_host_stages call solved through the emulation / with the host solver */
+void hqtick_debug_last_blocks(uint32_t *n_emulated, uint32_t *n_host);
 
 /* The wire encoding of include/hqwire.h on HOST memory: the same phase functions the three kernels run (csrc/wire_core.h), executed for
  * thread 0..255 in turn with a loop end standing in for each workgroup barrier.  Same arguments as hqwire_encode_device, all pointers host

@@ -70,7 +70,9 @@ class HostStages:
 
     def __init__(self, config=None):
         self.cfg = config or abi.make_config()
-        self.lib = tick.load()
+        from hyperqueue_amd import _testhooks
+
+        self.lib = _testhooks.load()  # libhqtick_test.so: the product library exports no CPU hook
         self.lib.hqtick_debug_host_stages.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.SnapshotC), abi.u8p, abi.u32p, C.c_uint32, abi.u64p, abi.u32p, C.POINTER(abi.ResultC)]
 
     def stages(self, snap: abi.Snapshot) -> abi.Result:

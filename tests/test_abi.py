@@ -13,19 +13,33 @@ from hyperqueue_amd import abi, tick
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions(header: str):
+def _declared(header: str, prefix: str):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(hqtick_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"_[a-z0-9_]+)\s*\(", src)))
 
 
-@pytest.mark.parametrize("header", ["hqtick.h", "hqtick_debug.h"])
-def test_every_declared_symbol_is_exported(header):
+@pytest.mark.parametrize("header,prefix", [("hqtick.h", "hqtick"), ("hqwire.h", "hqwire")])
+def test_every_declared_symbol_is_exported(header, prefix):
     lib = tick.load()
-    names = _declared_functions(header)
+    names = _declared(header, prefix)
     assert len(names) >= 2
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/{header} but not exported by libhqtick.so"
+
+
+def test_test_hooks_live_in_the_test_library_only():
+    """include/hqtick_debug.h is exported by libhqtick_test.so and by nothing else: the product library has no CPU entry point."""
+    from hyperqueue_amd import _testhooks
+
+    names = _declared("hqtick_debug.h", "hqtick") + _declared("hqtick_debug.h", "hqwire")
+    assert len(names) >= 8
+    test_lib, product = _testhooks.load(), tick.load()
+    for n in names:
+        assert hasattr(test_lib, n), f"{n} declared in include/hqtick_debug.h but not exported by libhqtick_test.so"
+        assert not hasattr(product, n), f"libhqtick.so exports the test hook {n}"
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", tick.LIB_PATH]).decode()
+    assert "debug" not in exported, [l for l in exported.splitlines() if "debug" in l]
 
 
 def test_versions():

@@ -1,0 +1,188 @@
+"""The per-worker-class block solver of the separable placement (csrc/block_core.h = the algorithm of k_block_solve) on a machine without a GPU:
+the wavefront is emulated by a loop over its 64 lanes (libhqtick_test.so, hqtick_debug_block_solve_host / hqtick_debug_set_block_emulation), so
+the CPU suite executes the code the GPU runs.  Checked against the exact host solver (csrc/milp.cpp, canonical optimum) block by block, and
+against the canonical oracle (HiGHS) on whole ticks of the steady-state shapes.  The GPU tests of the kernel itself: tests/test_gpu_blocks.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from host_stages import HostStages
+from hyperqueue_amd import _testhooks, abi, workloads
+
+C3 = [[(0, 1)], [(0, 4)], [(0, 2), (1, 1)], [(0, 1), (1, 0.5)], [(0, 1), (1, 0.25)], [(0, 8), (2, 64)], [(0, 16), (1, 2), (2, 128)], [(0, 1), (2, 1)]]
+
+
+def block_solve_host(cols, weight, pool, free, total, elig, budget=20000):
+    """cols: per column a list of (resource, kind, amount); free/total [n_classes, R]; elig [n_classes] masks -> (x, status, steps)"""
+    lib = _testhooks.load()
+    off = np.zeros(len(cols) + 1, np.uint32); off[1:] = np.cumsum([len(c) for c in cols])
+    res = np.ascontiguousarray([e[0] for c in cols for e in c], np.uint32); kind = np.ascontiguousarray([e[1] for c in cols for e in c], np.uint8)
+    amt = np.ascontiguousarray([e[2] for c in cols for e in c], np.uint64)
+    weight = np.ascontiguousarray(weight, np.uint32); pool = np.ascontiguousarray(pool, np.float64)
+    free = np.ascontiguousarray(free, np.uint64); total = np.ascontiguousarray(total, np.uint64); elig = np.ascontiguousarray(elig, np.uint64)
+    n_cls, R = free.shape
+    x = np.zeros((n_cls, len(cols)), np.uint32); status = np.zeros(n_cls, np.uint32); steps = np.zeros(n_cls, np.uint32)
+    dp = C.POINTER(C.c_double)
+    lib.hqtick_debug_block_solve_host.argtypes = [C.c_uint32, C.c_uint32, abi.u32p, abi.u32p, abi.u8p, abi.u64p, abi.u32p, dp, C.c_uint32, abi.u64p, abi.u64p, abi.u64p,
+                                                  C.c_uint32, abi.u32p, abi.u32p, abi.u32p]
+    rc = lib.hqtick_debug_block_solve_host(len(cols), R, off.ctypes.data_as(abi.u32p), res.ctypes.data_as(abi.u32p), kind.ctypes.data_as(abi.u8p), amt.ctypes.data_as(abi.u64p),
+                                           weight.ctypes.data_as(abi.u32p), pool.ctypes.data_as(dp), n_cls, free.ctypes.data_as(abi.u64p), total.ctypes.data_as(abi.u64p),
+                                           elig.ctypes.data_as(abi.u64p), budget, x.ctypes.data_as(abi.u32p), status.ctypes.data_as(abi.u32p), steps.ctypes.data_as(abi.u32p))
+    assert rc == 0
+    return x, status, steps
+
+
+def milp_block(cols, weight, pool, free, total, elig):
+    """the same block through the exact host solver (hqtick_debug_milp_solve, canonical), built as host_model.cpp builds it"""
+    from test_host_logic import product_milp
+
+    R = len(free)
+    obj, rows, colmap = [], [[] for _ in range(R)], {}
+    for g, c in enumerate(cols):
+        if not (int(elig) >> g) & 1:
+            continue
+        sc = 0.0
+        for (r, k, a) in c:
+            amt = int(total[r]) if k else int(a)
+            sc += 0.0 if pool[r] < 0.000001 else (amt / 10000.0) / pool[r]
+        j = len(obj); colmap[g] = j
+        obj.append(sc * (weight[g] / 10000.0))
+        for (r, k, a) in c:
+            rows[r].append((j, (int(total[r]) if k else int(a)) / 10000.0))
+    if not obj:
+        return np.zeros(len(cols), np.uint32)
+    rtype, rhs, roff, rcol, rcoef = [], [], [0], [], []
+    for r in range(R):
+        if rows[r]:
+            rtype.append(1); rhs.append(int(free[r]) / 10000.0)
+            for (j, a) in rows[r]:
+                rcol.append(j); rcoef.append(a)
+            roff.append(len(rcol))
+    got = product_milp(obj, [0] * len(obj), rtype, rhs, roff, rcol, rcoef, canonical=True)
+    assert got is not None and got[2]
+    x = np.zeros(len(cols), np.uint32)
+    for g, j in colmap.items():
+        x[g] = int(round(got[0][j]))
+    return x
+
+
+def c3_block_case(rng):
+    cols = [[(r, 0, int(round(a * 10000))) for r, a in c] for c in C3]
+    weight = [10000 if rng.integers(4) else int(rng.integers(5000, 25000)) for _ in cols]
+    total = np.asarray([1280000, 80000, 5120000], np.uint64)
+    free = np.asarray([int(rng.integers(0, 129)) * 10000, int(rng.integers(0, 33)) * 2500, int(rng.integers(0, 513)) * 10000], np.uint64)
+    pool = np.asarray([1024 * 128.0, 1024 * 8.0, 1024 * 512.0]) * rng.uniform(0.05, 0.95, 3)
+    elig = 0xFF if rng.integers(8) else int(rng.integers(1, 256))
+    return cols, weight, pool, free, total, elig
+
+
+def random_block_case(rng):
+    R = int(rng.integers(1, 5)); n = int(rng.integers(1, 11))
+    total = (rng.integers(1, 65, R) * 10000).astype(np.uint64)
+    free = np.asarray([t if rng.integers(5) == 0 else int(rng.integers(0, t // 100 + 1)) * 100 for t in total], np.uint64)
+    pool = rng.integers(1, 50000, R) / 7.0
+    grid = [10000, 20000, 40000, 5000, 2500, 80000, 30000, 15000, 70000]
+    cols = []
+    for _ in range(n):
+        ent = [(r, 1 if rng.integers(16) == 0 else 0, grid[int(rng.integers(len(grid)))]) for r in range(R) if rng.integers(2)]
+        if not ent:
+            ent = [(int(rng.integers(R)), 0, grid[int(rng.integers(len(grid)))])]
+        cols.append(ent)
+    weight = [10000 if rng.integers(3) else int(rng.integers(1000, 31000)) for _ in cols]
+    elig = (1 << n) - 1
+    if rng.integers(4) == 0:
+        elig &= int(rng.integers(0, 1 << n))
+    return cols, weight, pool, free, total, elig
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_emulated_block_equals_exact_solver(seed):
+    """single blocks: the emulated wavefront returns the canonical optimum of csrc/milp.cpp, column for column"""
+    rng = np.random.default_rng(seed)
+    for k in range(6):
+        cols, weight, pool, free, total, elig = (c3_block_case if k % 2 == 0 else random_block_case)(rng)
+        x, status, steps = block_solve_host(cols, weight, pool, free[None, :], total[None, :], [elig])
+        assert status[0] in (0, 1)
+        if status[0] == 1:
+            continue  # step budget exhausted: the tick hands such a class to the host solver (covered by test_budget_exhaustion_falls_back)
+        want = milp_block(cols, weight, pool, free, total, elig)
+        assert x[0].tolist() == want.tolist(), (seed, k, steps[0])
+        # exact feasibility in ResourceAmount arithmetic
+        used = np.zeros(len(free), object)
+        for g, c in enumerate(cols):
+            for (r, kd, a) in c:
+                used[r] += (int(total[r]) if kd else int(a)) * int(x[0][g])
+        assert all(int(used[r]) <= int(free[r]) for r in range(len(free)))
+
+
+def test_block_shapes_outside_the_kernel_are_refused():
+    cols = [[(0, 0, 10000)]] * 40  # 40 eligible columns > 32 per block
+    x, status, _ = block_solve_host(cols, [10000] * 40, [100.0], np.asarray([[1280000]], np.uint64), np.asarray([[1280000]], np.uint64), [(1 << 40) - 1])
+    assert status[0] == 2 and not x.any()
+    cols = [[(r, 0, 10000)] for r in range(5)]  # five resource rows > 4
+    x, status, _ = block_solve_host(cols, [10000] * 5, [100.0] * 5, np.full((1, 5), 50000, np.uint64), np.full((1, 5), 50000, np.uint64), [31])
+    assert status[0] == 2
+    x, status, _ = block_solve_host([[(0, 0, 1)]], [10000], [100.0], np.asarray([[10 ** 9]], np.uint64), np.asarray([[10 ** 9]], np.uint64), [1])
+    assert status[0] == 2  # a column that fits 10^9 times: beyond the kernel's value range
+    x, status, _ = block_solve_host([[(0, 0, 10000)]], [10000], [100.0], np.asarray([[2 ** 64 - 1]], np.uint64), np.asarray([[50000]], np.uint64), [1])
+    assert status[0] == 2  # HQ_AMOUNT_MAX free: the reference's carry-over row, a host matter
+    x, status, _ = block_solve_host([[(0, 0, 10000)]], [10000], [100.0], np.asarray([[50000]], np.uint64), np.asarray([[50000]], np.uint64), [0])
+    assert status[0] == 0 and not x.any()  # nothing eligible
+
+
+def _emulated(cfg, snap, budget=4096):
+    lib = _testhooks.load()
+    lib.hqtick_debug_set_block_emulation.argtypes = [C.c_int, C.c_uint32]
+    lib.hqtick_debug_set_block_emulation(1, budget)
+    try:
+        res = HostStages(cfg).stages(snap)
+        a, b = C.c_uint32(), C.c_uint32()
+        lib.hqtick_debug_last_blocks(C.byref(a), C.byref(b))
+        return res, a.value, b.value
+    finally:
+        lib.hqtick_debug_set_block_emulation(0, 0)
+
+
+@pytest.mark.parametrize("name,n_workers,seed", [("c3", 48, 0), ("c3", 64, 1), ("c4", 40, 2), ("c3", 96, 3)])
+def test_steady_state_tick_emulated_blocks_vs_oracle(name, n_workers, seed):
+    """SURVEY §8(d) steady state, reduced: heterogeneous free vectors (one class per worker), every class saturated -> the separable path with one
+    block per worker; blocks through the emulated kernel == blocks through the host solver == the canonical oracle"""
+    from oracle.oracle import Oracle
+
+    snap = workloads.make_steady(name, seed=seed, n_tasks=60_000, n_workers=n_workers)
+    cfg = abi.make_config(time_limit_s=30.0)
+    got, n_emu, n_host = _emulated(cfg, snap)
+    plain = HostStages(cfg).stages(snap)
+    assert n_emu >= n_workers // 2 and n_host == 0, (n_emu, n_host)
+    assert got.is_optimal and got.is_canonical and plain.is_optimal
+    assert got.batches == plain.batches and got.counts == plain.counts
+    want = Oracle(cfg, canonical=True).tick(snap)
+    if want.is_optimal:
+        assert got.batches == want.batches
+        assert got.counts == want.counts
+
+
+def test_budget_exhaustion_falls_back_to_host_solver():
+    """with a step budget of 1 every searched class is handed back (status 1) and the host solver gives the same counts"""
+    snap = workloads.make_steady("c3", seed=5, n_tasks=40_000, n_workers=24)
+    cfg = abi.make_config(time_limit_s=30.0)
+    got, n_emu, n_host = _emulated(cfg, snap, budget=1)
+    plain = HostStages(cfg).stages(snap)
+    assert n_host > 0
+    assert got.counts == plain.counts and got.batches == plain.batches
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_scenarios_emulated_blocks_equal_host_blocks(seed):
+    """the randomised scenario family of the GPU fuzz suite (blocked requests, min_utilization, time limits, `All` entries, weights, MAX amounts):
+    wherever the tick is separable, emulated blocks and host blocks give the same counts; elsewhere the switch changes nothing"""
+    import test_gpu_fuzz as f
+
+    cfg, envs, _rng = f.build(seed)
+    snap = envs[1].snapshot()
+    got, _, _ = _emulated(cfg, snap)
+    plain = HostStages(cfg).stages(snap)
+    assert got.status == plain.status and got.batches == plain.batches
+    if plain.is_canonical and got.is_canonical:
+        assert got.counts == plain.counts

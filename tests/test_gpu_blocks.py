@@ -1,0 +1,100 @@
+"""k_block_solve on the MI355X (through the C ABI): the per-worker-class blocks of the separable placement, one wavefront per class.
+Steady-state snapshots (heterogeneous free vectors, about one class per worker) — bit-exact against the canonical oracle at
+reduced size, against the host-solver path of the same library at full size, plus the stats that show the kernel did the work."""
+import os
+
+import numpy as np
+import pytest
+
+from hyperqueue_amd import abi, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def _tick(cfg=None, **env):
+    from hyperqueue_amd.tick import Tick
+
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return Tick(cfg or abi.make_config(time_limit_s=20.0))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return _tick()
+
+
+@pytest.fixture(scope="module")
+def host_blocks():
+    return _tick(HQTICK_BLOCK_MIN_CLASSES=1 << 30)  # never enough classes for a launch: every block through csrc/milp.cpp
+
+
+@pytest.mark.parametrize("name,n_workers,seed", [("c3", 48, 0), ("c3", 128, 1), ("c4", 64, 2)])
+def test_steady_state_reduced_vs_oracle(dev, name, n_workers, seed):
+    from oracle.oracle import Oracle
+
+    snap = workloads.make_steady(name, seed=seed, n_tasks=80_000, n_workers=n_workers)
+    got = dev.tick(snap)
+    ks = dev.kernel_stats()
+    assert ks["n_classes_device"] >= n_workers // 2 and ks["n_classes_host"] == 0, ks
+    want = Oracle(abi.make_config(time_limit_s=20.0), canonical=True).tick(snap)
+    assert got.is_optimal and got.is_canonical
+    assert got.batches == want.batches
+    assert got.counts == want.counts
+    assert got.records == want.records
+    assert (got.new_free == want.new_free).all()
+
+
+@pytest.mark.parametrize("name,seed", [("c3", 0), ("c3", 7), ("c4", 3)])
+def test_steady_state_full_size_device_blocks_equal_host_blocks(dev, host_blocks, name, seed):
+    """BASELINE size (1 M ready tasks, 1024 / 4096 workers), steady state: ~1000 / ~4000 distinct classes"""
+    snap = workloads.make_steady(name, seed=seed)
+    a = dev.tick(snap)
+    ks = dev.kernel_stats()
+    b = host_blocks.tick(snap)
+    kh = host_blocks.kernel_stats()
+    assert ks["n_classes_device"] > 500 and ks["n_classes_host"] == 0 and kh["n_classes_device"] == 0 and kh["n_classes_host"] > 500, (ks, kh)
+    assert a.is_optimal and a.is_canonical and b.is_optimal and b.is_canonical
+    assert a.batches == b.batches
+    assert a.counts == b.counts
+    assert a.records == b.records
+    assert (a.new_free == b.new_free).all()
+    # size-independent properties: nothing over-committed, every placed task was ready, no task twice
+    free = np.asarray(snap.worker_free, np.int64)
+    assert (np.asarray(a.new_free, np.int64) >= 0).all() and (np.asarray(a.new_free, np.int64) <= free.reshape(a.new_free.shape)).all()
+    ids = np.asarray([t for recs in a.records for (t, _, _) in recs], np.uint64)
+    assert len(np.unique(ids)) == len(ids) and np.isin(ids, snap.task_id).all()
+
+
+def test_tiny_step_budget_hands_classes_to_the_host(dev):
+    snap = workloads.make_steady("c3", seed=11, n_tasks=50_000, n_workers=64)
+    want = dev.tick(snap)
+    t = _tick(HQTICK_BLOCK_BUDGET=1)
+    got = t.tick(snap)
+    ks = t.kernel_stats()
+    t.close()
+    assert ks["n_classes_host"] > 0
+    assert got.counts == want.counts and got.records == want.records
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_family_device_blocks_equal_host_blocks(dev, host_blocks, seed):
+    import test_gpu_fuzz as f
+
+    cfg, envs, _rng = f.build(seed)
+    snap = envs[1].snapshot()
+    a, b = _tick(cfg), _tick(cfg, HQTICK_BLOCK_MIN_CLASSES=1 << 30)
+    try:
+        ra, rb = a.tick(snap), b.tick(snap)
+    finally:
+        a.close(); b.close()
+    assert ra.status == rb.status and ra.batches == rb.batches
+    if ra.is_canonical and rb.is_canonical:
+        assert ra.counts == rb.counts and ra.records == rb.records

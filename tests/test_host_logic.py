@@ -5,12 +5,12 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from hyperqueue_amd import abi, tick
+from hyperqueue_amd import _testhooks, abi
 from oracle import oracle as orc
 
 
 def product_milp(obj, kind, rtype, rhs, roff, rcol, rcoef, canonical=True, time_limit=30.0):
-    lib = tick.load()
+    lib = _testhooks.load()
     n, m = len(obj), len(rhs)
     obj = np.ascontiguousarray(obj, np.float64); kind = np.ascontiguousarray(kind, np.uint8)
     rtype = np.ascontiguousarray(rtype, np.uint8); rhs = np.ascontiguousarray(rhs, np.float64)
@@ -72,7 +72,7 @@ def test_milp_infeasible_is_none():
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 8, 15, 28, 29, 57, 200, 1024, 4096])
 def test_map_order_matches_oracle_emulation(n):
-    lib = tick.load()
+    lib = _testhooks.load()
     rng = np.random.default_rng(n)
     for keys in (np.arange(50, 50 + n, dtype=np.uint32), np.sort(rng.choice(1 << 20, n, replace=False)).astype(np.uint32)):
         out = np.zeros(n, np.uint32)

@@ -15,11 +15,11 @@ t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
 sc = snap.to_c()
 for _ in range(3):
     t.tick_raw(sc, resident=True)
-t._lib.hqtick_debug_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+t._lib.hqtick_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
 for which, nm, nbytes in ((0, "level_hist", len(snap.task_id) * 12), (1, "select_scatter", len(snap.task_id) * 8)):
     us = C.c_double()
     for rep in range(3):
-        rc = t._lib.hqtick_debug_time_kernel(t._ctx, which, iters, C.byref(us))
+        rc = t._lib.hqtick_time_kernel(t._ctx, which, iters, C.byref(us))
         assert rc == 0, t._err()
     print(f"N={len(snap.task_id)} TPW={os.environ.get('HQTICK_TPW', '256')} {nm}: {us.value:.2f} us/launch back-to-back  -> {nbytes / us.value / 1e3:.0f} GB/s on {nbytes / 1e6:.1f} MB")
 r = t.tick_raw(sc, resident=True)

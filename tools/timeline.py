@@ -13,12 +13,12 @@ snap = workloads.make(name)
 t = Tick(abi.make_config(time_limit_s=5.0))
 t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
 sc = snap.to_c()
-t._lib.hqtick_debug_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+t._lib.hqtick_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
 rows, ks = [], []
 for i in range(n + 5):
     r = t.tick_raw(sc, resident=True)
     buf = (C.c_double * 32)()
-    k = t._lib.hqtick_debug_timeline(t._ctx, buf, 32)
+    k = t._lib.hqtick_timeline(t._ctx, buf, 32)
     if i >= 5:
         rows.append([buf[j] for j in range(k)] + [r.t_total_us])
         ks.append(t.kernel_stats())
