@@ -173,7 +173,10 @@ class KernelStatsC(C.Structure):
         ("n_classes_device", C.c_uint32),
         ("n_classes_host", C.c_uint32),
         ("block_steps_max", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("n_classes", C.c_uint32),
+        ("solve_classify_us", C.c_double),
+        ("solve_blocks_us", C.c_double),
+        ("solve_decode_us", C.c_double),
     ]
 
 

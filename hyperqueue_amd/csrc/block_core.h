@@ -71,16 +71,19 @@ struct Output {
     uint32_t *x;        // [n_classes * n_cols] count per column (0 where not eligible)
     uint32_t *status;   // [n_classes] ST_*
     uint32_t *steps;    // [n_classes] search steps of both phases (statistics)
+    uint64_t *prof;     // optional [n_classes * 8] timestamps (wavefront clock) at the stage boundaries of solve_block; nullptr = off
 };
 
 struct Shared {  // one block's working set: LDS on the device
     int n, m, status;
     uint32_t steps, steps_p1;
+    uint64_t usedres;               // resources some eligible column touches
     int gcol[NMAX];                 // block column -> tick column
     double c[NMAX];
     int64_t a[MMAX][NMAX];
     int64_t cap[MMAX];
     uint8_t pi[NMAX];               // block columns by ascending size (the search decides the large ones first)
+    uint8_t pd[NMAX];               // block columns by descending value density (first greedy order)
     // dual pool
     uint32_t npool;
     double py[PCAP][MMAX];
@@ -110,7 +113,29 @@ struct Shared {  // one block's working set: LDS on the device
     uint32_t binom[NMAX + MMAX + 1][MMAX + 1];
 };
 
-HQB_HD int64_t gcd64(int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; }
+constexpr int EMAX = 256;                   // request entries of all columns together (staged in LDS)
+constexpr int64_t VAL_LIMIT = 1ll << 52;    // amounts and capacities stay exact in f64 (div_floor below)
+
+// floor(a / b) for 0 <= a, 0 < b, both below 2^52: the f64 quotient is off by at most one, which two multiplications repair.  (64-bit integer
+// division is a ~200-instruction software routine on the GPU; this is the walk's innermost operation.)
+HQB_HD int64_t div_floor(int64_t a, int64_t b) {
+    int64_t q = (int64_t)((double)a / (double)b);
+    if (q * b > a) q--;
+    else if ((q + 1) * b <= a) q++;
+    return q;
+}
+HQB_HD int64_t gcd64(int64_t a, int64_t b) {  // binary gcd: shifts and subtractions only
+    if (a == 0) return b;
+    if (b == 0) return a;
+    const int sh = __builtin_ctzll((unsigned long long)(a | b));
+    a >>= __builtin_ctzll((unsigned long long)a);
+    while (b) {
+        b >>= __builtin_ctzll((unsigned long long)b);
+        if (a > b) { const int64_t t = a; a = b; b = t; }
+        b -= a;
+    }
+    return a << sh;
+}
 
 // min over the level's dual points of y . rem: an upper bound of the LP over the positions [0, k), hence of its integer optimum
 HQB_HD double lp_bound(const Shared &S, int k, const int64_t *rem) {
@@ -127,57 +152,125 @@ HQB_HD double lp_bound(const Shared &S, int k, const int64_t *rem) {
 }
 
 // ---- step 1: the block of one class -----------------------------------------------------------------------------------------------------------
-HQB_HD void build_block(Shared &S, const ColTable &ct, const ClassTable &cl, uint32_t cls) {
-    S.status = ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = 0; S.npool = 0;
-    const uint32_t R = ct.R;
-    const uint64_t *fre = cl.free_ + (size_t)cls * R, *tot = cl.total + (size_t)cls * R;
-    const uint64_t elig = cl.elig[cls];
-    int row_of[64];
-    for (int r = 0; r < 64; r++) row_of[r] = -1;
-    for (int r = 0; r < MMAX; r++) { S.cap[r] = 0; for (int j = 0; j < NMAX; j++) S.a[r][j] = 0; }
-    if (ct.n_cols > (uint32_t)GCOLS || R > 64) { S.status = ST_UNSUPPORTED; return; }
-    int n = 0, m = 0;
-    for (uint32_t g = 0; g < ct.n_cols; g++) {
-        if (!((elig >> g) & 1)) continue;
-        if (n >= NMAX) { S.status = ST_UNSUPPORTED; return; }
-        double sc = 0.0;  // create_sn_var  solver.rs:550-568, same operation order as host_model.cpp
-        for (uint32_t e = ct.ent_off[g]; e < ct.ent_off[g + 1]; e++) {
-            const uint32_t r = ct.ent_res[e];
-            const uint64_t amt = ct.ent_kind[e] ? tot[r] : ct.ent_amount[e];
-            const double pool = ct.pool[r];
-            sc += pool < 0.000001 ? 0.0 : ((double)amt / 10000.0) / pool;
-            if (fre[r] == UINT64_MAX) { S.status = ST_UNSUPPORTED; return; }  // unbounded row: the reference's carry-over (solver.rs:183-185) is a host matter
-            if (amt == 0) continue;
-            if (row_of[r] < 0) { if (m >= MMAX) { S.status = ST_UNSUPPORTED; return; } row_of[r] = m; S.cap[m] = (int64_t)fre[r]; m++; }
-            if (amt > (uint64_t)INT64_MAX || fre[r] > (uint64_t)INT64_MAX) { S.status = ST_UNSUPPORTED; return; }
-            S.a[row_of[r]][n] += (int64_t)amt;
+// The tables arrive in device-visible HOST memory (pinned): a dependent chain of loads from there costs a PCIe round trip each, so the wavefront
+// first copies what it needs into LDS with one wide load per lane (the staging area overlays the dual pool, which is empty at this point), then
+// lane g builds column g.
+struct Stage {
+    uint32_t ent_off[GCOLS + 1];
+    uint32_t ent_res[EMAX];
+    uint64_t ent_amount[EMAX];
+    uint32_t weight[GCOLS];
+    double pool[64];
+    uint64_t free_[64], total[64];
+    uint8_t ent_kind[EMAX];
+};
+static_assert(sizeof(Stage) <= sizeof(double) * PCAP * MMAX, "the staging area overlays the dual pool");
+
+template <class W>
+HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &cl, uint32_t cls) {
+    const uint32_t R = ct.R, NC = ct.n_cols;
+    Stage &st = *reinterpret_cast<Stage *>(&S.py[0][0]);
+    if (wv.first()) { S.status = ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = 0; S.npool = 0; S.usedres = 0; }
+    if (NC > (uint32_t)GCOLS || R > 64 || NC == 0) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
+    const uint32_t ne = ct.ent_off[NC];  // one uniform load
+    if (ne > (uint32_t)EMAX) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
+    const uint64_t elig = cl.elig[cls] & (NC >= 64 ? ~0ull : ((1ull << NC) - 1ull));
+    wv.each([&](int lane) {
+        for (uint32_t i = (uint32_t)lane; i <= NC; i += WAVE) st.ent_off[i] = ct.ent_off[i];
+        for (uint32_t i = (uint32_t)lane; i < NC; i += WAVE) st.weight[i] = ct.weight[i];
+        for (uint32_t i = (uint32_t)lane; i < ne; i += WAVE) { st.ent_res[i] = ct.ent_res[i]; st.ent_amount[i] = ct.ent_amount[i]; st.ent_kind[i] = ct.ent_kind[i]; }
+        for (uint32_t i = (uint32_t)lane; i < R; i += WAVE) { st.pool[i] = ct.pool[i]; st.free_[i] = cl.free_[(size_t)cls * R + i]; st.total[i] = cl.total[(size_t)cls * R + i]; }
+        for (int i = lane; i < MMAX * NMAX; i += WAVE) S.a[i / NMAX][i % NMAX] = 0;
+        if (lane < MMAX) S.cap[lane] = 0;
+        for (int i = lane; i < (NMAX + MMAX + 1) * (MMAX + 1); i += WAVE) {  // binomial table C(i, p), p <= 4
+            const uint32_t n_ = (uint32_t)(i / (MMAX + 1)), p = (uint32_t)(i % (MMAX + 1));
+            uint32_t v = 1;
+            if (p > n_) v = 0; else for (uint32_t q = 0; q < p; q++) v = v * (n_ - q) / (q + 1);
+            S.binom[n_][p] = v;
         }
-        S.c[n] = sc * ((double)ct.weight[g] / 10000.0);
-        S.gcol[n] = (int)g;
-        bool any = false;
-        for (int r = 0; r < m; r++) if (S.a[r][n] > 0) any = true;
-        if (!any) { S.status = ST_UNSUPPORTED; return; }  // a column no row bounds
-        n++;
-    }
+    });
+    wv.sync();
+    const int n = __builtin_popcountll(elig);
+    if (n > NMAX) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
+    // column g by lane g: cost in the reference's operation order (create_sn_var, solver.rs:550-568), the resources it touches
+    wv.each([&](int lane) {
+        const uint32_t g = (uint32_t)lane;
+        if (g >= NC || !((elig >> g) & 1)) return;
+        double sc = 0.0; bool any = false, bad = false;
+        for (uint32_t e = st.ent_off[g]; e < st.ent_off[g + 1]; e++) {
+            const uint32_t r = st.ent_res[e];
+            const uint64_t amt = st.ent_kind[e] ? st.total[r] : st.ent_amount[e];
+            const double pool = st.pool[r];
+            sc += pool < 0.000001 ? 0.0 : ((double)amt / 10000.0) / pool;
+            if (st.free_[r] == UINT64_MAX) bad = true;  // unbounded row: the reference's carry-over (solver.rs:183-185) is a host matter
+            if (amt == 0) continue;
+            if (amt >= (uint64_t)VAL_LIMIT || (st.free_[r] >= (uint64_t)VAL_LIMIT)) bad = true;
+            any = true;
+            wv.atomic_or64(&S.usedres, 1ull << r);
+        }
+        if (!any) bad = true;  // a column no row bounds
+        const int j = __builtin_popcountll(elig & ((1ull << g) - 1ull));
+        S.c[j] = sc * ((double)st.weight[g] / 10000.0);
+        S.gcol[j] = (int)g;
+        if (bad) S.status = ST_UNSUPPORTED;
+    });
+    wv.sync();
+    const uint64_t used = S.usedres;
+    const int m = __builtin_popcountll(used);
+    if (S.status != ST_OK || m > MMAX) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
+    wv.each([&](int lane) {
+        const uint32_t g = (uint32_t)lane;
+        if (g < R && ((used >> g) & 1)) S.cap[__builtin_popcountll(used & ((1ull << g) - 1ull))] = (int64_t)st.free_[g];
+        if (g >= NC || !((elig >> g) & 1)) return;
+        const int j = __builtin_popcountll(elig & ((1ull << g) - 1ull));
+        for (uint32_t e = st.ent_off[g]; e < st.ent_off[g + 1]; e++) {
+            const uint32_t r = st.ent_res[e];
+            const uint64_t amt = st.ent_kind[e] ? st.total[r] : st.ent_amount[e];
+            if (amt) S.a[__builtin_popcountll(used & ((1ull << r) - 1ull))][j] += (int64_t)amt;
+        }
+    });
+    wv.sync();
     // rows on their own grid: amounts and capacity divided by the row's gcd (the capacity rounds down: what is cut off no column can use)
-    for (int r = 0; r < m; r++) {
+    wv.each([&](int lane) {
+        if (lane >= m) return;
         int64_t g = 0;
-        for (int j = 0; j < n; j++) g = gcd64(g, S.a[r][j]);
-        if (g > 1) { for (int j = 0; j < n; j++) S.a[r][j] /= g; S.cap[r] /= g; }
-    }
-    double size[NMAX];
-    for (int j = 0; j < n; j++) {
-        int64_t ub = INT64_MAX;
-        double sz = 0.0;
-        for (int r = 0; r < m; r++) if (S.a[r][j] > 0) { int64_t q = S.cap[r] / S.a[r][j]; ub = q < ub ? q : ub; sz += (double)S.a[r][j] / (double)(S.cap[r] + 1); }
-        if (ub > UB_LIMIT) { S.status = ST_UNSUPPORTED; return; }
-        size[j] = sz;
-        S.pi[j] = (uint8_t)j;
-    }
-    for (int i = 1; i < n; i++) { uint8_t p = S.pi[i]; int q = i - 1; while (q >= 0 && size[S.pi[q]] > size[p]) { S.pi[q + 1] = S.pi[q]; q--; } S.pi[q + 1] = p; }  // stable
-    S.n = n; S.m = m;
-    for (int i = 0; i <= NMAX + MMAX; i++)
-        for (int p = 0; p <= MMAX; p++) S.binom[i][p] = p == 0 ? 1u : (i == 0 ? 0u : S.binom[i - 1][p - 1] + S.binom[i - 1][p]);
+        for (int j = 0; j < n; j++) g = gcd64(g, S.a[lane][j]);
+        if (g > 1) { for (int j = 0; j < n; j++) if (S.a[lane][j]) S.a[lane][j] = div_floor(S.a[lane][j], g); S.cap[lane] = div_floor(S.cap[lane], g); }
+    });
+    wv.sync();
+    // search order: columns by ascending size (stable), by rank counting; a column that fits too often goes to the host
+    wv.each([&](int lane) {
+        if (lane >= n) return;
+        int64_t ub = INT64_MAX; double sz = 0.0;
+        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0) { int64_t q = div_floor(S.cap[r], S.a[r][lane]); ub = q < ub ? q : ub; sz += (double)S.a[r][lane] / (double)(S.cap[r] + 1); }
+        if (ub > UB_LIMIT) S.status = ST_UNSUPPORTED;
+        S.lane_val[lane] = sz;
+    });
+    wv.sync();
+    wv.each([&](int lane) {
+        if (lane >= n) return;
+        const double mine = S.lane_val[lane];
+        int rank = 0;
+        for (int i = 0; i < n; i++) { const double o = S.lane_val[i]; if (o < mine || (o == mine && i < lane)) rank++; }
+        S.pi[rank] = (uint8_t)lane;
+    });
+    wv.sync();
+    wv.each([&](int lane) {  // value density c_j / sum_r a_rj / cap_r
+        if (lane >= n) return;
+        double w = 0.0;
+        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0) w += S.cap[r] > 0 ? (double)S.a[r][lane] / (double)S.cap[r] : 1e30;
+        S.lane_val[lane] = w > 0.0 ? S.c[lane] / w : 0.0;
+    });
+    wv.sync();
+    wv.each([&](int lane) {
+        if (lane >= n) return;
+        const double mine = S.lane_val[lane];
+        int rank = 0;
+        for (int i = 0; i < n; i++) { const double o = S.lane_val[i]; if (o > mine || (o == mine && i < lane)) rank++; }
+        S.pd[rank] = (uint8_t)lane;
+    });
+    if (wv.first()) { S.n = n; S.m = m; }
+    wv.sync();
 }
 
 // ---- step 2: dual points ------------------------------------------------------------------------------------------------------------------------
@@ -279,19 +372,9 @@ HQB_HD uint32_t xorshift32(uint32_t &s) { s ^= s << 13; s ^= s >> 17; s ^= s << 
 HQB_HD void greedy_lane(Shared &S, int lane) {
     const int n = S.n, m = S.m;
     uint8_t *pm = S.perm[lane];
-    for (int j = 0; j < n; j++) pm[j] = (uint8_t)j;
-    if (lane == 3) { for (int j = 0; j < n; j++) pm[j] = (uint8_t)(n - 1 - j); }
-    else if (lane != 2) {
-        // lanes 0 / 1: by value density / by cost, descending (insertion sort); other lanes: that order shuffled
-        double key[NMAX];
-        for (int j = 0; j < n; j++) {
-            double w = 0.0;
-            for (int r = 0; r < m; r++) if (S.a[r][j] > 0) w += S.cap[r] > 0 ? (double)S.a[r][j] / (double)S.cap[r] : 1e30;
-            key[j] = lane == 1 ? S.c[j] : (w > 0.0 ? S.c[j] / w : 0.0);
-        }
-        for (int i = 1; i < n; i++) { uint8_t p = pm[i]; int q = i - 1; while (q >= 0 && key[pm[q]] < key[p]) { pm[q + 1] = pm[q]; q--; } pm[q + 1] = p; }
-        if (lane >= 4) { uint32_t s = 0x9E3779B9u * (uint32_t)(lane + 1); for (int i = n - 1; i > 0; i--) { int q = (int)(xorshift32(s) % (uint32_t)(i + 1)); uint8_t tmp = pm[i]; pm[i] = pm[q]; pm[q] = tmp; } }
-    }
+    // lane 0: by value density (descending); 1: large requests first; 2: small first; 3 / 4: the model's order and its reverse; others: shuffles
+    for (int j = 0; j < n; j++) pm[j] = lane == 0 ? S.pd[j] : lane == 1 ? S.pi[n - 1 - j] : lane == 2 ? S.pi[j] : lane == 4 ? (uint8_t)(n - 1 - j) : (uint8_t)j;
+    if (lane >= 5) { uint32_t s = 0x9E3779B9u * (uint32_t)(lane + 1); for (int i = n - 1; i > 0; i--) { int q = (int)(xorshift32(s) % (uint32_t)(i + 1)); uint8_t tmp = pm[i]; pm[i] = pm[q]; pm[q] = tmp; } }
     int64_t rem[MMAX];
     for (int r = 0; r < MMAX; r++) rem[r] = S.cap[r];
     uint16_t *x = S.gx[lane];
@@ -300,7 +383,7 @@ HQB_HD void greedy_lane(Shared &S, int lane) {
         const int j = pm[i];
         if (!(S.c[j] > 0.0)) continue;
         int64_t ub = INT64_MAX;
-        for (int r = 0; r < m; r++) if (S.a[r][j] > 0) { int64_t q = rem[r] / S.a[r][j]; ub = q < ub ? q : ub; }
+        for (int r = 0; r < m; r++) if (S.a[r][j] > 0) { int64_t q = div_floor(rem[r], S.a[r][j]); ub = q < ub ? q : ub; }
         if (ub <= 0) continue;
         x[j] = (uint16_t)ub;
         for (int r = 0; r < m; r++) rem[r] -= ub * S.a[r][j];
@@ -317,20 +400,24 @@ HQB_HD void greedy_lane(Shared &S, int lane) {
 // plus (y, mu = c_j - a_j . y > 0) with y a vertex for F \ {j}: those enter with the penalty L * mu   (bound = y . rem + penalty).
 template <class W>
 HQB_HD void setup_work(W &wv, Shared &S, uint32_t cols, int capcol, int64_t capval) {
-    if (wv.first()) {
-        int wn = 0;
-        S.wmask[0] = 0;
-        for (int i = 0; i < S.n; i++) { const int j = S.pi[i]; if ((cols >> j) & 1) { S.wcol[wn] = (uint8_t)j; wn++; } }
-        for (int p = 0; p < wn; p++) {
-            const int j = S.wcol[p];
-            S.wc[p] = S.c[j];
-            S.wcap[p] = j == capcol ? capval : INT64_MAX;
-            for (int r = 0; r < MMAX; r++) S.wa[r][p] = S.a[r][j];
-            S.wmask[p + 1] = S.wmask[p] | (1u << j);
-        }
-        S.wn = wn;
-        for (int k = 0; k <= NMAX; k++) S.dcnt[k] = 0;
-    }
+    const uint64_t selmask = wv.ballot([&](int lane) { return lane < S.n && ((cols >> S.pi[lane]) & 1); });
+    wv.each([&](int lane) {
+        if (lane <= NMAX) S.dcnt[lane] = 0;
+        if (lane >= S.n || !((selmask >> lane) & 1)) return;
+        const int p = __builtin_popcountll(selmask & ((1ull << lane) - 1ull)), j = S.pi[lane];
+        S.wcol[p] = (uint8_t)j;
+        S.wc[p] = S.c[j];
+        S.wcap[p] = j == capcol ? capval : INT64_MAX;
+        for (int r = 0; r < MMAX; r++) S.wa[r][p] = S.a[r][j];
+    });
+    if (wv.first()) S.wn = __builtin_popcountll(selmask);
+    wv.sync();
+    wv.each([&](int lane) {
+        if (lane > S.wn) return;
+        uint32_t mask = 0;
+        for (int q = 0; q < lane; q++) mask |= 1u << S.wcol[q];
+        S.wmask[lane] = mask;
+    });
     wv.sync();
     const int wn = S.wn;
     const uint32_t np = S.npool < (uint32_t)PCAP ? S.npool : (uint32_t)PCAP;
@@ -360,7 +447,7 @@ HQB_HD void setup_work(W &wv, Shared &S, uint32_t cols, int capcol, int64_t capv
 HQB_HD int64_t level_ub(const Shared &S, int k) {  // how often the column at position k - 1 fits into rem[k]
     const int p = k - 1;
     int64_t ub = S.wcap[p];
-    for (int r = 0; r < S.m; r++) if (S.wa[r][p] > 0) { int64_t q = S.rem[k][r] / S.wa[r][p]; ub = q < ub ? q : ub; }
+    for (int r = 0; r < S.m; r++) if (S.wa[r][p] > 0) { int64_t q = div_floor(S.rem[k][r], S.wa[r][p]); ub = q < ub ? q : ub; }
     return ub;
 }
 
@@ -370,7 +457,7 @@ HQB_HD bool terminal_lane(const Shared &S, int64_t v1, int64_t *x0_out, double *
     int64_t x0max = S.wcap[0];
     for (int r = 0; r < S.m; r++) {
         const int64_t left = S.rem[2][r] - v1 * S.wa[r][1];
-        if (S.wa[r][0] > 0) { int64_t q = left / S.wa[r][0]; x0max = q < x0max ? q : x0max; }
+        if (S.wa[r][0] > 0) { int64_t q = left < 0 ? -1 : div_floor(left, S.wa[r][0]); x0max = q < x0max ? q : x0max; }
     }
     *x0_out = x0max;
     *val_out = (S.zfix[2] + S.wc[1] * (double)v1) + S.wc[0] * (double)x0max;
@@ -394,7 +481,7 @@ HQB_HD bool walk(W &wv, Shared &S, int mode, double thr, uint32_t *budget, bool 
     if (wn == 1) {  // a single position: no search
         if (wv.first()) {
             int64_t ub = S.wcap[0];
-            for (int r = 0; r < m; r++) if (S.wa[r][0] > 0) { int64_t q = S.rem[1][r] / S.wa[r][0]; ub = q < ub ? q : ub; }
+            for (int r = 0; r < m; r++) if (S.wa[r][0] > 0) { int64_t q = div_floor(S.rem[1][r], S.wa[r][0]); ub = q < ub ? q : ub; }
             const double val = S.zfix[1] + S.wc[0] * (double)ub;
             if (mode == MODE_MAX) { if (val > S.best) { S.best = val; S.xbest[S.wcol[0]] = (uint32_t)ub; } }
             else { S.ptr[1] = val >= thr ? 1 : 0; if (val >= thr) S.xbest[S.wcol[0]] = (uint32_t)ub; }
@@ -482,8 +569,10 @@ HQB_HD bool walk(W &wv, Shared &S, int mode, double thr, uint32_t *budget, bool 
 // ---- the whole block ----------------------------------------------------------------------------------------------------------------------------
 template <class W>
 HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &cl, uint32_t cls, const Output &out, uint32_t budget) {
-    if (wv.first()) build_block(S, ct, cl, cls);
-    wv.sync();
+    uint64_t *prof = out.prof ? out.prof + (size_t)cls * 8 : nullptr;
+    if (prof && wv.first()) prof[0] = wv.now();
+    build_block(wv, S, ct, cl, cls);
+    if (prof && wv.first()) prof[1] = wv.now();
     uint32_t *x = out.x + (size_t)cls * ct.n_cols;
     wv.each([&](int lane) { for (uint32_t g = lane; g < ct.n_cols; g += WAVE) x[g] = 0; });
     if (S.status != ST_OK || S.n == 0) {
@@ -494,8 +583,10 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
     const uint32_t total = S.binom[n + m][m];
     wv.each([&](int lane) { for (uint32_t t = (uint32_t)lane; t < total; t += WAVE) dual_candidate(wv, S, t); });
     wv.sync();
+    if (prof && wv.first()) prof[2] = wv.now();
     wv.each([&](int lane) { greedy_lane(S, lane); });
     wv.sync();
+    if (prof && wv.first()) prof[3] = wv.now();
     {
         int l = 0;
         const double top = wv.argmax([&](int lane) { return S.lane_val[lane]; }, &l);
@@ -518,6 +609,7 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
         }
         if (wv.first()) S.steps_p1 = S.steps;
         wv.sync();
+        if (prof && wv.first()) prof[4] = wv.now();
     }
     // phase 2: S.xbest is a point with objective >= thr throughout; column by column from the last one its value is pushed down by probes
     // "is there a point with x_j <= mid (the later columns fixed) that still reaches thr" — first just below the current value (most columns
@@ -550,6 +642,7 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
         }
     }
     wv.sync();
+    if (prof && wv.first()) { prof[5] = wv.now(); prof[6] = S.steps_p1; prof[7] = S.npool; }
     if (wv.first()) {
         out.status[cls] = ok ? (uint32_t)ST_OK : (uint32_t)ST_BUDGET;
         out.steps[cls] = S.steps;
@@ -559,9 +652,11 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
 
 // ---- host emulation of a wavefront (CPU tests; also what documents the contract of the Wave policy) ---------------------------------------------
 struct HostWave {
+    uint64_t now() const { return 0; }
     bool first() const { return true; }
     void sync() {}
     uint32_t atomic_inc(uint32_t *p) { return (*p)++; }
+    void atomic_or64(uint64_t *p, uint64_t v) { *p |= v; }
     static int ctz(uint64_t m) { int i = 0; while (!((m >> i) & 1)) i++; return i; }
     template <class F> void each(F f) { for (int l = 0; l < WAVE; l++) f(l); }
     template <class F> uint64_t ballot(F f) { uint64_t m = 0; for (int l = 0; l < WAVE; l++) if (f(l)) m |= 1ull << l; return m; }

@@ -16,9 +16,11 @@ namespace hqblock {
 namespace {
 
 struct DevWave {
+    __device__ uint64_t now() const { return wall_clock64(); }  // 100 MHz
     __device__ bool first() const { return threadIdx.x == 0; }
     __device__ void sync() { __syncthreads(); }
     __device__ uint32_t atomic_inc(uint32_t *p) { return atomicAdd(p, 1u); }
+    __device__ void atomic_or64(uint64_t *p, uint64_t v) { atomicOr((unsigned long long *)p, (unsigned long long)v); }
     __device__ static int ctz(uint64_t m) { return __ffsll((long long)m) - 1; }
     template <class F> __device__ void each(F f) { f((int)threadIdx.x); }
     template <class F> __device__ uint64_t ballot(F f) { return __ballot(f((int)threadIdx.x) ? 1 : 0); }

@@ -2,6 +2,7 @@
 #include "host_model.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -26,6 +27,7 @@ const std::vector<uint32_t> &cached_worker_order(const std::vector<uint32_t> &id
     return e.order;
 }
 
+double clock_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 const double FRACTIONS = 10000.0;
 inline double units(uint64_t a) { return (double)a / FRACTIONS; }  // ResourceAmount::as_f64  amount.rs:91-93
 
@@ -192,7 +194,7 @@ struct GapCache {
         return out;
     }
 
-    uint32_t gap(uint32_t high_rq, uint32_t low_rq, const Amounts &total, const std::vector<std::pair<uint32_t, uint8_t>> &assigned) {
+    uint32_t gap(uint32_t high_rq, uint32_t low_rq, const Amounts &total, const uint32_t *asg_rq, const uint8_t *asg_variant, uint32_t n_asg) {
         if (pb.rq_multi_node(high_rq) || pb.rq_multi_node(low_rq)) return 0;
         const RequestView &h = pb.rqs[high_rq];
         Amounts left;
@@ -207,7 +209,7 @@ struct GapCache {
             if (it == memo.end()) it = memo.emplace(key, leftover_multi_variant(high_rq, total)).first;
             left = it->second;
         }
-        for (auto &t : assigned) if (t.first != high_rq) take_away(left, pb.variants[pb.rqs[t.first].first_variant + t.second], 1);
+        for (uint32_t i = 0; i < n_asg; i++) if (asg_rq[i] != high_rq) take_away(left, pb.variants[pb.rqs[asg_rq[i]].first_variant + asg_variant[i]], 1);
         const RequestView &l = pb.rqs[low_rq];
         uint32_t best = 0;
         for (uint32_t v = 0; v < l.n_variants; v++) { uint32_t c = max_count(left, pb.variants[l.first_variant + v]); if (v == 0 || c < best) best = c; }
@@ -253,6 +255,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     for (const TaskBatch &b : batches) if (pb.rq_multi_node(b.rq) || !b.cuts.empty() || b.is_blocker) separable = false;
     if (separable && !batches.empty()) {
         struct ColRef { uint32_t batch; uint8_t variant; };
+        const double t_sep0 = clock_us();
         const size_t nb = batches.size();
         // the tick's (batch, variant) columns, in the order of solver.rs:95-192: column g of batch b, variant v is voff[b] + v
         std::vector<uint32_t> voff(nb + 1, 0);
@@ -304,6 +307,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             }
         }
         const uint32_t ncls = (uint32_t)rep.size();
+        const double t_sep1 = clock_us();
         auto elig = [&](uint32_t c, uint32_t g) { return (sigs[(size_t)c * SW + 2 * R + 1 + g / 64] >> (g % 64)) & 1; };
         auto class_mu_flag = [&](uint32_t c) {  // does add_min_utilization create its on/off column?  solver.rs:501-521
             const uint32_t w = rep[c];
@@ -385,7 +389,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 std::vector<uint32_t> dx((size_t)nd * NC, 0), dstatus(nd, hqblock::ST_UNSUPPORTED), dsteps(nd, 0);
                 hqblock::ColTable ct{NC, R, ent_off.data(), ent_res.data(), ent_kind.data(), ent_amount.data(), weight.data(), pool.data()};
                 hqblock::ClassTable cl{nd, cfree.data(), ctot.data(), celig.data()};
-                hqblock::Output bo{dx.data(), dstatus.data(), dsteps.data()};
+                hqblock::Output bo{dx.data(), dstatus.data(), dsteps.data(), nullptr};
                 if (pb.blocks->solve(ct, cl, bo)) {
                     for (uint32_t i = 0; i < nd; i++) {
                         if (dstatus[i] != hqblock::ST_OK) continue;
@@ -423,6 +427,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 for (size_t k = 0; k < cols.size(); k++) if (cols[k].batch != UINT32_MAX) X[(size_t)c * NC + voff[cols[k].batch] + cols[k].variant] = (uint32_t)std::round(sol.x[k]);
             }
         }
+        const double t_sep2 = clock_us();
         if (separable) {
             bool sizes_hold = true;  // the lazy batch-size rows  solver.rs:264-271
             {
@@ -549,11 +554,19 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             }
             hqhb::insertion_order(key_hash.data(), (uint32_t)key_hash.size(), ord);
             for (uint32_t k : ord) { out.keys.push_back(key_list[k]); out.per_key.push_back(std::move(key_counts[k])); }
+            out.n_classes = ncls; out.t_classify_us = t_sep1 - t_sep0; out.t_blocks_us = t_sep2 - t_sep1; out.t_decode_us = clock_us() - t_sep2;
             return out;
         }
         out = Counts();  // fall through to the general path
     }
 
+    // the gap rows below dereference the snapshot's assigned (rq, variant) lists: a bad index is the caller's error, not a crash
+    if (!pb.custom && ws.assigned_off) {
+        bool any_cut = false;
+        for (const TaskBatch &b : batches) if (!b.cuts.empty()) any_cut = true;
+        if (any_cut) for (uint32_t i = 0, e = ws.n ? ws.assigned_off[ws.n] : 0; i < e; i++)
+            if (ws.assigned_rq[i] >= pb.rqs.size() || ws.assigned_variant[i] >= pb.rqs[ws.assigned_rq[i]].n_variants) { out.error = HQTICK_E_INVALID; out.errmsg = "assigned (rq, variant) out of range"; return out; }
+    }
     hqmilp::Model m;
     std::map<std::tuple<uint32_t, uint32_t, uint8_t>, int> place;  // (worker, rq, variant) -> column   :88
     std::map<uint32_t, std::vector<int>> count_cols;               // tasks_count_vars   :89
@@ -693,8 +706,8 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     for (uint32_t w : solver_workers) {
                         if (!pb.capable_rqv(ws, w, brq)) continue;
                         Amounts tot; tot.a.assign(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
-                        static const std::vector<std::pair<uint32_t, uint8_t>> none;
-                        uint32_t gap = gaps.gap(brq, batch.rq, tot, pb.custom ? none : ws.assigned[w]);
+                        const uint32_t a0 = (pb.custom || !ws.assigned_off) ? 0 : ws.assigned_off[w], na = pb.custom ? 0 : ws.n_assigned(w);
+                        uint32_t gap = gaps.gap(brq, batch.rq, tot, na ? ws.assigned_rq + a0 : nullptr, na ? ws.assigned_variant + a0 : nullptr, na);
                         std::vector<int> cols;
                         for (uint8_t v = 0; v < brv.n_variants; v++) { auto it = place.find({w, batch.rq, v}); if (it != place.end()) cols.push_back(it->second); }
                         if (gap > 0) {

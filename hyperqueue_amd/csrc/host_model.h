@@ -59,10 +59,12 @@ struct WorkerSet {
     uint32_t n_variant_slots = 0;
     // sparse per-worker state
     std::vector<std::vector<std::pair<uint32_t, uint8_t>>> blocked;   // [n]
-    std::vector<std::vector<std::pair<uint32_t, uint8_t>>> assigned;  // [n] (rq, variant) of assigned tasks
+    // SingleNodeTaskAssignment::assigned_tasks as the snapshot's CSR (views, not copies; nullptr = nothing assigned)
+    const uint32_t *assigned_off = nullptr, *assigned_rq = nullptr; const uint8_t *assigned_variant = nullptr;
+    uint32_t n_assigned(uint32_t w) const { return assigned_off ? assigned_off[w + 1] - assigned_off[w] : 0; }
     bool is_sn(uint32_t w) const { return flags ? (flags[w] & HQ_WORKER_SN) != 0 : true; }
     bool stopping(uint32_t w) const { return flags ? (flags[w] & HQ_WORKER_STOPPING) != 0 : false; }
-    bool is_free(uint32_t w) const { return is_sn(w) && assigned[w].empty() && !stopping(w); }
+    bool is_free(uint32_t w) const { return is_sn(w) && n_assigned(w) == 0 && !stopping(w); }
     uint8_t vf(uint32_t w, uint32_t slot) const { return vflags[(size_t)w * n_variant_slots + slot]; }
     uint32_t tmc(uint32_t w, uint32_t slot) const { return vtmc[(size_t)w * n_variant_slots + slot]; }
 };
@@ -120,7 +122,8 @@ struct Counts {
     }
     int error = 0; std::string errmsg;
     long milp_nodes = 0; int milp_cols = 0, milp_rows = 0, milp_components = 0;
-    uint32_t blocks_device = 0, blocks_host = 0, block_steps_max = 0;  // separable path: classes solved by k_block_solve / by the host solver
+    uint32_t blocks_device = 0, blocks_host = 0, block_steps_max = 0, n_classes = 0;
+    double t_classify_us = 0, t_blocks_us = 0, t_decode_us = 0;  // separable path: worker classes / block solves (device wait included) / counts in Map order  // separable path: classes solved by k_block_solve / by the host solver
 };
 
 Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &batches);

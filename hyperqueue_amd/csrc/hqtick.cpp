@@ -75,6 +75,7 @@ struct hqtick_ctx {
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
     PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_retr, h_blk;
+    PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
     uint32_t block_budget = 4096, block_min_classes = 1;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
     // workers / requests
     DevBuf d_up, d_vflags, d_vtmc;
@@ -94,6 +95,7 @@ struct hqtick_ctx {
     // launch state of the last tick (hqtick_time_kernel re-launches K1 / K4 on it)
     hqk::WaveGeom last_geom{}; uint32_t last_L = 0, last_Q = 0, last_G = 0; size_t last_tb = 0, last_plan_bytes = 0, last_hist_off = 0; bool last_valid = false;
     hqgraph::Graph graph;  // hqtick_graph_*: dependency counters + consumer lists in HBM
+    hqtick_ctx *qctx = nullptr;  // hqtick_query's private sub-context
     ncclComm_t comm = nullptr; uint32_t comm_rank = 0, comm_world = 0;  // hqtick_comm_init (RCCL, loaded on first use)
     double tl[32] = {}; int ntl = 0;  // debug timeline (us since tick start), hqtick_timeline()
 };
@@ -126,7 +128,29 @@ int validate(hqtick_ctx *ctx, const hqtick_snapshot *s, bool need_tasks) {
         if (!s->task_id || !s->task_priority || !s->task_rq) return fail(ctx, HQTICK_E_INVALID, "ready-set columns missing");
         for (uint64_t i = 1; i < s->n_ready; i++) if (s->task_id[i - 1] >= s->task_id[i]) return fail(ctx, HQTICK_E_INVALID, "ready set not sorted by task id");
     }
-    for (uint32_t k = 0; k < s->n_blocked; k++) if (s->blocked_worker[k] >= s->n_workers) return fail(ctx, HQTICK_E_INVALID, "blocked worker index");
+    if (s->n_blocked && (!s->blocked_worker || !s->blocked_rq || !s->blocked_variant)) return fail(ctx, HQTICK_E_INVALID, "blocked arrays missing");
+    for (uint32_t k = 0; k < s->n_blocked; k++) {
+        if (s->blocked_worker[k] >= s->n_workers) return fail(ctx, HQTICK_E_INVALID, "blocked worker index");
+        if (s->blocked_rq[k] >= s->n_requests) return fail(ctx, HQTICK_E_INVALID, "blocked request id out of range");
+        if (s->blocked_variant[k] >= s->rq_variant_off[s->blocked_rq[k] + 1] - s->rq_variant_off[s->blocked_rq[k]]) return fail(ctx, HQTICK_E_INVALID, "blocked variant out of range");
+    }
+    if (s->worker_group) for (uint32_t w = 0; w < s->n_workers; w++) if (s->worker_group[w] >= (s->n_groups ? s->n_groups : 1)) return fail(ctx, HQTICK_E_INVALID, "worker_group >= n_groups");
+    // CSR offsets: monotone, and their arrays present.  (The ENTRIES of assigned_* are checked where they are dereferenced — the gap rows of a
+    // tick with priority cuts, host_model.cpp — so that the common tick does not pay a pass over every running task.)
+    if (s->assigned_off) {
+        for (uint32_t w = 0; w < s->n_workers; w++) if (s->assigned_off[w] > s->assigned_off[w + 1]) return fail(ctx, HQTICK_E_INVALID, "assigned_off not monotone");
+        if (s->n_workers && s->assigned_off[s->n_workers] && (!s->assigned_rq || !s->assigned_variant)) return fail(ctx, HQTICK_E_INVALID, "assigned arrays missing");
+    }
+    if (s->prefilled_off) {
+        for (uint32_t w = 0; w < s->n_workers; w++) if (s->prefilled_off[w] > s->prefilled_off[w + 1]) return fail(ctx, HQTICK_E_INVALID, "prefilled_off not monotone");
+        if (s->n_workers && s->prefilled_off[s->n_workers] && !s->prefilled_rq) return fail(ctx, HQTICK_E_INVALID, "prefilled_rq missing");
+    }
+    if (s->prefill_off) {
+        for (uint32_t q = 0; q < s->n_requests; q++) if (s->prefill_off[q] > s->prefill_off[q + 1]) return fail(ctx, HQTICK_E_INVALID, "prefill_off not monotone");
+        const uint32_t np = s->n_requests ? s->prefill_off[s->n_requests] : 0;
+        if (np && (!s->prefill_priority || !s->prefill_task || !s->prefill_worker)) return fail(ctx, HQTICK_E_INVALID, "prefill arrays missing");
+        for (uint32_t i = 0; i < np; i++) if (s->prefill_worker[i] >= s->n_workers) return fail(ctx, HQTICK_E_INVALID, "prefill worker index");
+    }
     if (s->n_retracting && (!s->retracting_task || !s->retracting_worker)) return fail(ctx, HQTICK_E_INVALID, "retracting arrays missing");
     for (uint32_t k = 0; k < s->n_retracting; k++) {
         if (s->retracting_worker[k] >= s->n_workers) return fail(ctx, HQTICK_E_INVALID, "retracting worker index");
@@ -196,9 +220,9 @@ void fill_problem(hqhost::Problem &pb, const hqtick_snapshot *s, const hqtick_co
     ws.n = s->n_workers; ws.R = s->n_resources; ws.id = s->worker_id; ws.total = s->worker_total; ws.free_ = s->worker_free;
     ws.remaining_ns = s->worker_remaining_ns; ws.min_util = s->worker_min_utilization; ws.flags = s->worker_flags; ws.group = s->worker_group;
     ws.vflags = ev.flags; ws.vtmc = ev.tmc; ws.n_variant_slots = nv;
-    ws.blocked.assign(ws.n, {}); ws.assigned.assign(ws.n, {});
+    ws.blocked.assign(ws.n, {});
+    ws.assigned_off = s->assigned_off; ws.assigned_rq = s->assigned_rq; ws.assigned_variant = s->assigned_variant;
     for (uint32_t k = 0; k < s->n_blocked; k++) ws.blocked[s->blocked_worker[k]].push_back({s->blocked_rq[k], s->blocked_variant[k]});
-    if (s->assigned_off) for (uint32_t w = 0; w < ws.n; w++) for (uint32_t k = s->assigned_off[w]; k < s->assigned_off[w + 1]; k++) ws.assigned[w].push_back({s->assigned_rq[k], s->assigned_variant[k]});
 }
 
 void export_batches(hqtick_ctx *ctx, const std::vector<hqhost::TaskBatch> &batches, hqtick_result *out) {
@@ -356,7 +380,13 @@ struct DeviceBlocks : hqhost::BlockSolver {
         memcpy(h + o_free, cl.free_, (size_t)nd * R * 8); memcpy(h + o_tot, cl.total, (size_t)nd * R * 8); memcpy(h + o_elig, cl.elig, (size_t)nd * 8);
         hqblock::ColTable dct{NC, R, (const uint32_t *)(d + o_off), (const uint32_t *)(d + o_res), (const uint8_t *)(d + o_kind), (const uint64_t *)(d + o_amt), (const uint32_t *)(d + o_w), (const double *)(d + o_pool)};
         hqblock::ClassTable dcl{nd, (const uint64_t *)(d + o_free), (const uint64_t *)(d + o_tot), (const uint64_t *)(d + o_elig)};
-        hqblock::Output dout{(uint32_t *)(d + o_x), (uint32_t *)(d + o_st), (uint32_t *)(d + o_steps)};
+        uint64_t *dprof = nullptr;
+        if (ctx->block_profile) {  // HQTICK_BLOCK_PROFILE=1: per-class stage timestamps (tools/block_profile.py)
+            if (!ctx->h_blkprof.ensure((size_t)nd * 64 + 64)) return false;
+            memset(ctx->h_blkprof.p, 0, (size_t)nd * 64);
+            dprof = ctx->h_blkprof.dev<uint64_t>(); ctx->n_blkprof = nd;
+        }
+        hqblock::Output dout{(uint32_t *)(d + o_x), (uint32_t *)(d + o_st), (uint32_t *)(d + o_steps), dprof};
         if (ctx->timing && hipEventRecord(ctx->ev[9], ctx->stream) != hipSuccess) return false;
         if (hqblock::block_solve(dct, dcl, dout, ctx->block_budget, ctx->stream) != hipSuccess) return false;
         if (ctx->timing && hipEventRecord(ctx->ev[10], ctx->stream) != hipSuccess) return false;
@@ -806,7 +836,8 @@ struct TickRun {
         cnt = hqhost::run_scheduling_solver(pb, batches);
         pb.blocks = nullptr;
         if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
-        ctx->stats.n_classes_device = cnt.blocks_device; ctx->stats.n_classes_host = cnt.blocks_host; ctx->stats.block_steps_max = cnt.block_steps_max;
+        ctx->stats.n_classes_device = cnt.blocks_device; ctx->stats.n_classes_host = cnt.blocks_host; ctx->stats.block_steps_max = cnt.block_steps_max; ctx->stats.n_classes = cnt.n_classes;
+        ctx->stats.solve_classify_us = cnt.t_classify_us; ctx->stats.solve_blocks_us = cnt.t_blocks_us; ctx->stats.solve_decode_us = cnt.t_decode_us;
         mark();  // 2: solve
         const double t3 = now_us();
         out->is_optimal = cnt.is_optimal;
@@ -854,6 +885,7 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     ctx->cfg = *config; ctx->device = config->device_index;
     ctx->timing = (config->flags & HQTICK_FLAG_NO_KERNEL_TIMING) == 0;
     if (const char *e = getenv("HQTICK_TPW")) { long v = atol(e); if (v >= 64 && v <= (1 << 20) && v % 64 == 0) ctx->tpw_hint = (uint32_t)v; }
+    if (const char *e = getenv("HQTICK_BLOCK_PROFILE")) ctx->block_profile = atoi(e) != 0;
     if (const char *e = getenv("HQTICK_BLOCK_BUDGET")) { long v = atol(e); if (v >= 1 && v <= (1 << 24)) ctx->block_budget = (uint32_t)v; }
     if (const char *e = getenv("HQTICK_BLOCK_MIN_CLASSES")) { long v = atol(e); if (v >= 0) ctx->block_min_classes = (uint32_t)v; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
@@ -872,9 +904,11 @@ void hqtick_destroy(hqtick_ctx *ctx) {
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
                       &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8};
     for (DevBuf *b : bufs) b->release();
+    if (ctx->qctx) { hqtick_destroy(ctx->qctx); ctx->qctx = nullptr; }
+    hipSetDevice(ctx->device);
     if (ctx->comm) { rccl_destroy_comm(ctx); }
     ctx->graph.release();
-    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_retr.release(); ctx->h_blk.release();
+    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_retr.release(); ctx->h_blk.release(); ctx->h_blkprof.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -979,7 +1013,7 @@ int hqtick_ready_remove(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id) {
     if (!ctx || (n && !task_id)) return HQTICK_E_INVALID;
     if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set");
     if (n == 0 || ctx->n_ready == 0) return 0;
-    if (n > 0xFFFFFFFFull) return fail(ctx, HQTICK_E_CAPACITY, "more than 2^32 ids in one delta");
+    if (n > 0x7FFFFFFFull) return fail(ctx, HQTICK_E_CAPACITY, "more than 2^31 - 1 ids in one delta (the count of removed tasks is the int return value)");
     HQ_HIP(hipSetDevice(ctx->device));
     if (!ctx->d_add.ensure(n * 8 + 8) || !ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
     uint32_t *cnt = ctx->h_q.as<uint32_t>(); cnt[0] = 0;
@@ -1093,8 +1127,22 @@ int hqtick_ready_compact(hqtick_ctx *ctx) {
 
 extern "C" {
 
+// The what-if query runs on the live Core between two ticks (crates/tako/src/control.rs:125-155): it must not disturb what the ctx keeps
+// resident (ready-set columns, level table, the last tick's selection that hqtick_ready_consume_last replays, the dependency graph).  It
+// therefore runs on a private sub-context — same device, own stream and buffers — created on first use.
+static int query_on(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_workers *fake, hqtick_query_result *out);
 int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_workers *fake, hqtick_query_result *out) {
     if (!ctx || !out || !fake) return HQTICK_E_INVALID;
+    if (!ctx->qctx) {
+        hqtick_config cfg = ctx->cfg; cfg.flags |= HQTICK_FLAG_NO_KERNEL_TIMING;
+        int rc = hqtick_create(&cfg, &ctx->qctx);
+        if (rc) { ctx->qctx = nullptr; return fail(ctx, rc, "creating the query sub-context failed"); }
+    }
+    int rc = query_on(ctx->qctx, s, fake, out);
+    if (rc < 0) ctx->err = ctx->qctx->err;
+    return rc;
+}
+static int query_on(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_workers *fake, hqtick_query_result *out) {
     int rc = validate(ctx, s, true);
     if (rc) return rc;
     HQ_HIP(hipSetDevice(ctx->device));
@@ -1117,7 +1165,7 @@ int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_query_w
     fw.n = fake->n_workers; fw.R = R; fw.id = fake->worker_id; fw.total = fake->worker_total; fw.free_ = fake->worker_total;
     fw.remaining_ns = fake->worker_remaining_ns; fw.min_util = fake->worker_min_utilization; fw.flags = nullptr; fw.group = nullptr;
     fw.vflags = ev_fake.flags; fw.vtmc = ev_fake.tmc; fw.n_variant_slots = Q ? s->rq_variant_off[Q] : 0;
-    fw.blocked.assign(fw.n, {}); fw.assigned.assign(fw.n, {});
+    fw.blocked.assign(fw.n, {});
     pb.custom = &fw;
     std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
     std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
@@ -1157,7 +1205,7 @@ int hqtick_debug_block_solve_host(uint32_t n_cols, uint32_t n_resources, const u
                                   uint32_t budget, uint32_t *x, uint32_t *status, uint32_t *steps) {
     hqblock::ColTable ct{n_cols, n_resources, ent_off, ent_res, ent_kind, ent_amount, weight, pool};
     hqblock::ClassTable cl{n_classes, free_, total, elig};
-    hqblock::Output out{x, status, steps};
+    hqblock::Output out{x, status, steps, nullptr};
     EmulatedBlocks emu(budget ? budget : 4096);
     return emu.solve(ct, cl, out) ? 0 : HQTICK_E_DEVICE;
 }
@@ -1212,7 +1260,7 @@ int hqtick_debug_host_query(const hqtick_config *config, const hqtick_snapshot *
     fw.n = fake->n_workers; fw.R = R; fw.id = fake->worker_id; fw.total = fake->worker_total; fw.free_ = fake->worker_total;
     fw.remaining_ns = fake->worker_remaining_ns; fw.min_util = fake->worker_min_utilization; fw.flags = nullptr; fw.group = nullptr;
     fw.vflags = fake_vflags; fw.vtmc = fake_vtmc; fw.n_variant_slots = Q ? s->rq_variant_off[Q] : 0;
-    fw.blocked.assign(fw.n, {}); fw.assigned.assign(fw.n, {});
+    fw.blocked.assign(fw.n, {});
     pb.custom = &fw;
     Scan sc; sc.Q = Q; sc.L = n_levels; sc.G = n_levels * Q;
     sc.levels.assign(levels, levels + n_levels); sc.hist.assign(hist, hist + (size_t)n_levels * Q);
@@ -1287,6 +1335,12 @@ int hqtick_timeline(const hqtick_ctx *ctx, double *out, int cap) {
     int n = ctx->ntl < cap ? ctx->ntl : cap;
     for (int i = 0; i < n; i++) out[i] = ctx->tl[i];
     return n;
+}
+
+const uint64_t *hqtick_block_profile_last(const hqtick_ctx *ctx, uint32_t *n_classes) {
+    if (!ctx || !ctx->block_profile || !ctx->n_blkprof) { if (n_classes) *n_classes = 0; return nullptr; }
+    if (n_classes) *n_classes = ctx->n_blkprof;
+    return ctx->h_blkprof.as<uint64_t>();
 }
 
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out) {

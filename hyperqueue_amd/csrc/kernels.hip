@@ -557,9 +557,12 @@ __global__ void __launch_bounds__(256) k_mark_removed(const uint64_t *__restrict
     const uint64_t want = rm[t];
     uint64_t lo = 0, hi = n;
     while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ids[mid] < want) lo = mid + 1; else hi = mid; }
-    // a removed-and-re-added id can sit next to its own tombstone: take the live one
-    while (lo < n && ids[lo] == want && rq[lo] == RQ_TOMBSTONE) lo++;
-    if (lo < n && ids[lo] == want) { rq[lo] = RQ_TOMBSTONE; atomicAdd(n_done, 1u); }
+    // a removed-and-re-added id can sit next to its own tombstone: take the live one.  The claim is an atomic exchange, so an id listed twice
+    // in one call (or removed concurrently) is counted once — TaskQueue::remove is idempotent (scheduler/taskqueue.rs:196-217).
+    for (; lo < n && ids[lo] == want; lo++) {
+        if (rq[lo] == RQ_TOMBSTONE) continue;
+        if (atomicExch(&rq[lo], RQ_TOMBSTONE) != RQ_TOMBSTONE) { atomicAdd(n_done, 1u); break; }
+    }
 }
 
 // live tasks per 256-task slice

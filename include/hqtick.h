@@ -380,7 +380,9 @@ int hqtick_comm_init(hqtick_ctx *ctx, const void *id, uint32_t rank, uint32_t wo
 int hqtick_shard_allgather(hqtick_ctx *ctx, void *recv_device, size_t recv_bytes);
 int hqtick_comm_destroy(hqtick_ctx *ctx);
 
-/* compute_new_worker_query(): batches + solver on fake workers, no mapping  scheduler/query.rs:70-71 */
+/* compute_new_worker_query(): batches + solver on fake workers, no mapping  scheduler/query.rs:70-71.  Takes its ready set from the
+ * snapshot's task_* columns and runs on a private sub-context: a resident ready set, the last tick's selection (hqtick_ready_consume_last)
+ * and the dependency graph of `ctx` are left untouched, so a query may be issued between any two resident ticks. */
 int hqtick_query(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, const hqtick_query_workers *fake,
                  hqtick_query_result *out);
 
@@ -408,7 +410,9 @@ typedef struct hqtick_kernel_stats {
     uint64_t n_assigned, n_prefilled;
     double block_solve_us;  /* k_block_solve: the per-worker-class blocks of the separable placement (one wavefront per class) */
     uint32_t n_classes_device, n_classes_host; /* worker classes solved by k_block_solve / by the host solver in the last tick */
-    uint32_t block_steps_max, reserved0;       /* most search steps any class took                                             */
+    uint32_t block_steps_max, n_classes;       /* most search steps any class took; worker classes of the separable placement  */
+    double solve_classify_us, solve_blocks_us, solve_decode_us; /* host wall clock inside the placement stage: worker classes, block solves
+                                                  (launch + wait included), counts into the reference's Map iteration order */
 } hqtick_kernel_stats;
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
 /* Re-launches one streaming kernel of the last resident tick `iters` times back to back between two HIP events on the ctx's
@@ -417,6 +421,9 @@ int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us);
 /* Host wall-clock marks (microseconds since the start of the last tick) at the internal stage boundaries of the last tick;
  * returns the number of marks written (bench tooling). */
 int hqtick_timeline(const hqtick_ctx *ctx, double *out, int cap);
+/* With HQTICK_BLOCK_PROFILE=1 in the environment at hqtick_create: 8 u64 per class of the last k_block_solve launch — 100 MHz timestamps
+ * at start / block built / duals / greedy / phase 1 / phase 2 done, then phase-1 steps and dual-pool size.  NULL when off. */
+const uint64_t *hqtick_block_profile_last(const hqtick_ctx *ctx, uint32_t *n_classes);
 
 #ifdef __cplusplus
 }

@@ -121,7 +121,7 @@ int main(int argc, char **argv) {
         hqblock::ColTable ct{c.n_cols, c.R, c.ent_off.data(), c.ent_res.data(), c.ent_kind.data(), c.ent_amount.data(), c.weight.data(), c.pool.data()};
         hqblock::ClassTable cl{1, c.free_.data(), c.total.data(), &c.elig};
         std::vector<uint32_t> x(c.n_cols, 7); uint32_t status = 9, steps = 0;
-        hqblock::Output out{x.data(), &status, &steps};
+        hqblock::Output out{x.data(), &status, &steps, nullptr};
         hqblock::HostWave wv;
         auto t0 = std::chrono::steady_clock::now();
         hqblock::solve_block(wv, S, ct, cl, 0, out, budget);
