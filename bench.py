@@ -130,6 +130,113 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int):
     }
 
 
+def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: float = 0.10):
+    """SURVEY.md §8(d) steady state on one GPU: after the cold tick, every running task finishes with probability `release` before the next tick
+    ("free a random 10 % of assigned tasks per tick and re-run"), so the workers' free vectors all differ (about one worker class per worker) and
+    the placement is ~1000 different bounded knapsacks per tick — solved by k_block_solve, one wavefront per class.  The ready set stays
+    resident and saturated (arrivals replace what was handed out, class by class).  Prefilled tasks leave the queue but are not tracked as
+    running (the sleep-0 model of benchmarks/experiment-per-task-overhead.py: they are done before the next tick)."""
+    import dataclasses
+
+    from hyperqueue_amd import abi
+    from hyperqueue_amd.tick import Tick
+
+    W, R, Q = len(snap.worker_id), snap.n_resources, len(snap.requests)
+    need = np.zeros((Q, R), np.int64)
+    for q, variants in enumerate(snap.requests):
+        for (r, _k, a) in variants[0]["entries"]:
+            need[q, r] = int(a)
+    total = np.asarray(snap.worker_total, np.int64).reshape(W, R)
+    running = np.zeros((W, Q), np.int64)
+    rng = np.random.default_rng(seed)
+    ts = Tick(cfg)
+    ts.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
+    rq_of = snap.task_rq.copy()
+    alive = np.ones(len(rq_of), bool)
+    next_id = int(snap.task_id[-1]) + 1
+    new_ids = np.zeros(0, np.uint64); new_prio = np.zeros(0, np.uint64); new_rq = np.zeros(0, np.uint32)
+    rows, last_snap = [], None
+    for step in range(steps + 3):
+        free = total - running @ need
+        assert (free >= 0).all()
+        assigned = [[(int(q), 0) for q in np.repeat(np.arange(Q), running[w])] for w in range(W)]
+        cur = dataclasses.replace(snap, _keep=[], worker_free=free.astype(np.uint64), assigned=assigned, task_id=np.zeros(0, np.uint64), task_priority=np.zeros(0, np.uint64), task_rq=np.zeros(0, np.uint32))
+        sc = cur.to_c()
+        a = time.perf_counter()
+        if len(new_ids):
+            ts.ready_add(new_ids, new_prio, new_rq)
+        b = time.perf_counter()
+        res = ts.tick_raw(sc, resident=True)
+        c = time.perf_counter()
+        ts.ready_consume_last()
+        d = time.perf_counter()
+        ks = ts.kernel_stats()
+        n_cnt = int(res.n_counts)
+        cw = np.ctypeslib.as_array(res.count_worker, shape=(n_cnt,)).astype(np.int64) if n_cnt else np.zeros(0, np.int64)
+        cq = np.ctypeslib.as_array(res.count_rq, shape=(n_cnt,)).astype(np.int64) if n_cnt else np.zeros(0, np.int64)
+        cv = np.ctypeslib.as_array(res.count_value, shape=(n_cnt,)).astype(np.int64) if n_cnt else np.zeros(0, np.int64)
+        last_snap = (free.copy(), [list(x) for x in assigned], alive.copy(), rq_of.copy(), (cw.copy(), cq.copy(), cv.copy()))
+        np.add.at(running, (cw, cq), cv)
+        n_rec = int(np.ctypeslib.as_array(res.rec_off, shape=(W + 1,))[W])
+        gone = np.ctypeslib.as_array(res.rec_task, shape=(n_rec,)).copy() if n_rec else np.zeros(0, np.uint64)
+        idx = (gone & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1
+        alive[idx] = False
+        new_rq = rq_of[idx]
+        rq_of = np.concatenate([rq_of, new_rq]); alive = np.concatenate([alive, np.ones(len(idx), bool)])
+        new_ids = np.arange(next_id, next_id + len(idx), dtype=np.uint64); next_id += len(idx)
+        new_prio = np.full(len(idx), snap.task_priority[0], np.uint64)
+        rows.append(dict(add=b - a, tick=c - b, consume=d - c, assigned=int(cv.sum()), handed=n_rec, status=int(res.status), optimal=int(res.is_optimal), canonical=int(res.is_canonical),
+                         t_scan=res.t_scan_us, t_batches=res.t_batches_us, t_solve=res.t_solve_us, t_map=res.t_mapping_us, **{k: ks[k] for k in
+                         ("n_classes", "n_classes_device", "n_classes_host", "block_solve_us", "block_steps_max", "solve_classify_us", "solve_blocks_us", "solve_decode_us", "level_hist_us", "select_us", "other_us")}))
+        running -= rng.binomial(running, release)
+    ts.close()
+    use = rows[3:]
+    med = lambda k: float(np.median([r[k] for r in use]))
+    step_s = np.asarray([r["add"] + r["tick"] + r["consume"] for r in use])
+    out = {
+        "workload": f"c3 steady state: {len(snap.task_id)} ready tasks (resident, refilled), {W} workers each running a packed mix of which a random {int(release * 100)} % finishes per tick",
+        "steps": len(use), "p50_step_ms": 1e3 * float(np.median(step_s)), "p50_tick_ms": 1e3 * med("tick"), "p95_tick_ms": 1e3 * float(np.percentile([r["tick"] for r in use], 95)),
+        "p50_add_us": 1e6 * med("add"), "p50_consume_us": 1e6 * med("consume"),
+        "assigned_per_tick": int(med("assigned")), "handed_out_per_tick": int(med("handed")), "tasks_assigned_per_sec": med("assigned") / float(np.median(step_s)),
+        "worker_classes_per_tick": int(med("n_classes")), "classes_solved_on_device": int(med("n_classes_device")), "classes_solved_on_host": int(med("n_classes_host")),
+        "all_ticks_optimal_and_canonical": bool(all(r["optimal"] and r["canonical"] for r in use)),
+        "block_solve_kernel": {"avg_us": med("block_solve_us"), "classes_per_launch": int(med("n_classes_device")), "classes_per_s": med("n_classes_device") / (med("block_solve_us") * 1e-6) if med("block_solve_us") > 0 else None,
+                               "max_search_steps": int(max(r["block_steps_max"] for r in use)),
+                               "bound": "latency / integer-f64 ALU in LDS: one wavefront per class, 40 KB of LDS per block (4 blocks per CU); not an HBM-bound kernel (a class reads ~60 B)"},
+        "tick_stages_us": {"gpu_phase_a_scans": med("t_scan"), "batches": med("t_batches"), "placement": med("t_solve"), "placement_worker_classes": med("solve_classify_us"),
+                           "placement_block_solves_incl_launch_and_wait": med("solve_blocks_us"), "placement_counts_in_map_order": med("solve_decode_us"), "mapping_plan_gpu_phase_c": med("t_map")},
+    }
+    if cpu_ticks > 0 and last_snap is not None:
+        try:
+            from oracle.oracle import Oracle
+
+            free, assigned, alive_m, rq_all, gpu_counts = last_snap
+            ids_all = (np.uint64(1) << np.uint64(32)) | np.arange(1, len(rq_all) + 1, dtype=np.uint64)
+            keep = np.nonzero(alive_m)[0]
+            full = dataclasses.replace(snap, _keep=[], worker_free=free.astype(np.uint64), assigned=assigned, task_id=ids_all[keep], task_priority=np.full(len(keep), snap.task_priority[0], np.uint64), task_rq=rq_all[keep])
+            o = Oracle(abi.make_config(time_limit_s=5.0), reference_solver_options=True)
+            lat, n_asg, opt = [], 0, True
+            for _ in range(cpu_ticks):
+                t0 = time.perf_counter(); r = o.tick(full); lat.append(time.perf_counter() - t0)
+                n_asg = sum(1 for recs in r.records for (_, _, k) in recs if k == abi.HQ_REC_ASSIGN); opt = bool(r.is_optimal)
+            tick_s = float(np.median(lat))
+            # both sides maximise the same objective (scheduler/solver.rs:542-571): c.x of the GPU tick's counts in the oracle's own model of the snapshot
+            mdl = o.last_model()
+            gd = {(int(q), int(w)): int(v) for w, q, v in zip(*gpu_counts)}
+            xg = np.asarray([gd.get((int(mdl["crq"][j]), int(mdl["cworker"][j])), 0) if mdl["ctype"][j] == 0 else 0 for j in range(len(mdl["obj"]))], np.float64)
+            out["objective"] = {"gpu_tick": float(np.dot(mdl["obj"], xg)), "cpu_baseline": float(mdl["objective"]),
+                                "note": "same snapshot; equal objective = both optimal (the reference's answer is HiGHS's optimum; where optima tie, which one it returns is an artefact of HiGHS — DESIGN.md §4)"}
+            out["cpu_baseline"] = {"value": n_asg / tick_s, "unit": "tasks/s", "cores": 1, "kind": "port", "tick_s": tick_s, "assigned_per_tick": n_asg, "is_optimal": opt,
+                                   "sample": f"{cpu_ticks} tick(s) of the snapshot the last timed GPU tick saw ({len(keep)} ready tasks x {W} heterogeneous workers)",
+                                   "stages_us": {k: round(v, 1) for k, v in o.stage_times_us().items()},
+                                   "note": "restatement of the reference (C++ -O2) + HiGHS 1.8.0 with default options on the un-reduced model (8 k columns); both sides optimal, tied optima may differ"}
+            out["speedup_vs_cpu_baseline"] = out["tasks_assigned_per_sec"] / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] > 0 else None
+            out["tick_latency_ratio_vs_cpu"] = tick_s / float(np.median([r["tick"] for r in use]))
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
 def wire_block(iters: int):
     """Row f3: the wire encoding of a C3-shaped mapping, measured in a SUBPROCESS (tools/wire_bench.py) -- these kernels
     had not run on hardware when round 1 ended, and whatever happens there must not cost the headline line."""
@@ -156,6 +263,7 @@ def main():
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
     ap.add_argument("--priority-ticks", type=int, default=1, help="ticks of the three-priority-level variant c3p (0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=20, help="steps of the steady-state (delta-updated resident set) measurement, 0 = skip")
+    ap.add_argument("--hetero-steps", type=int, default=25, help="ticks of the heterogeneous-worker steady state (SURVEY 8d: 10 %% of the running tasks finish per tick), 0 = skip")
     ap.add_argument("--dag-steps", type=int, default=12, help="ticks of the config-5 loop (1 M-node DAG in the device graph + 10 %% worker churn per tick), 0 = skip")
     ap.add_argument("--dag-classes", type=int, default=2, help="request classes of the config-5 DAG (first N of the c3 classes; 8 = all, every tick then runs into the MILP time limit)")
     ap.add_argument("--wire-iters", type=int, default=50, help="launch triples of the wire-encoding measurement (row f3, in a subprocess), 0 = skip")
@@ -356,6 +464,8 @@ def main():
             "delta_bytes_host_to_device_per_step": per_step * 20,
         }
         ts.close()
+    if world == 1 and not args.force_sharded and args.workload == "c3" and args.hetero_steps > 0:
+        out["steady_hetero"] = steady_hetero(cfg, snap, args.hetero_steps, args.seed, min(args.cpu_ticks, 1))
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.dag_steps > 0:
         out["dag_churn"] = dag_churn(cfg, args.dag_steps, args.seed, args.dag_classes)
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.priority_ticks > 0:

@@ -59,6 +59,10 @@ struct ColTable {
     const uint64_t *ent_amount;
     const uint32_t *weight;      // [n_cols] ResourceWeight, 10 000 = 1.0
     const double *pool;          // [R] resource_sums
+    // When the arrays above lie in ONE allocation [blob, blob + blob_bytes) (16-byte aligned, blob_bytes a multiple of 16, <= BLOB_MAX) the kernel
+    // stages it into LDS with one 16-byte load per lane and reads the tables from there; nullptr: the arrays are read where they are.
+    const void *blob;
+    uint32_t blob_bytes;
 };
 // One worker class: what the block depends on.
 struct ClassTable {
@@ -86,7 +90,7 @@ struct Shared {  // one block's working set: LDS on the device
     uint8_t pd[NMAX];               // block columns by descending value density (first greedy order)
     // dual pool
     uint32_t npool;
-    double py[PCAP][MMAX];
+    alignas(16) double py[PCAP][MMAX];  // (16-byte aligned: the staging area of build_block overlays it)
     uint32_t pcover[PCAP], ptight[PCAP];
     // work problem: columns in search order (position wn - 1 is decided first)
     int wn;
@@ -113,7 +117,8 @@ struct Shared {  // one block's working set: LDS on the device
     uint32_t binom[NMAX + MMAX + 1][MMAX + 1];
 };
 
-constexpr int EMAX = 256;                   // request entries of all columns together (staged in LDS)
+constexpr int BLOB_MAX = 8192;               // largest column table the kernel stages in LDS
+struct alignas(16) V16 { uint64_t lo, hi; };
 constexpr int64_t VAL_LIMIT = 1ll << 52;    // amounts and capacities stay exact in f64 (div_floor below)
 
 // floor(a / b) for 0 <= a, 0 < b, both below 2^52: the f64 quotient is off by at most one, which two multiplications repair.  (64-bit integer
@@ -155,31 +160,27 @@ HQB_HD double lp_bound(const Shared &S, int k, const int64_t *rem) {
 // The tables arrive in device-visible HOST memory (pinned): a dependent chain of loads from there costs a PCIe round trip each, so the wavefront
 // first copies what it needs into LDS with one wide load per lane (the staging area overlays the dual pool, which is empty at this point), then
 // lane g builds column g.
-struct Stage {
-    uint32_t ent_off[GCOLS + 1];
-    uint32_t ent_res[EMAX];
-    uint64_t ent_amount[EMAX];
-    uint32_t weight[GCOLS];
-    double pool[64];
-    uint64_t free_[64], total[64];
-    uint8_t ent_kind[EMAX];
-};
-static_assert(sizeof(Stage) <= sizeof(double) * PCAP * MMAX, "the staging area overlays the dual pool");
-
+// The tables arrive in device-visible HOST memory (pinned): every dependent load from there is a PCIe round trip (~2 us), so the wavefront
+// first copies the column table (one allocation, a few hundred bytes) and its class's free / total rows into LDS with one wide load per lane —
+// the staging area overlays the dual pool, which is empty at this point — and lane g then builds column g from LDS.
 template <class W>
-HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &cl, uint32_t cls) {
-    const uint32_t R = ct.R, NC = ct.n_cols;
-    Stage &st = *reinterpret_cast<Stage *>(&S.py[0][0]);
+HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTable &cl, uint32_t cls) {
+    const uint32_t R = ct_in.R, NC = ct_in.n_cols;
+    uint8_t *area = reinterpret_cast<uint8_t *>(&S.py[0][0]);
+    static_assert(sizeof(double) * PCAP * MMAX >= BLOB_MAX + 64 * 8 * 2, "the staging area overlays the dual pool");
+    uint64_t *sfree = reinterpret_cast<uint64_t *>(area + BLOB_MAX), *stotal = sfree + 64;
+    ColTable ct = ct_in;
     if (wv.first()) { S.status = ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = 0; S.npool = 0; S.usedres = 0; }
     if (NC > (uint32_t)GCOLS || R > 64 || NC == 0) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
-    const uint32_t ne = ct.ent_off[NC];  // one uniform load
-    if (ne > (uint32_t)EMAX) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
     const uint64_t elig = cl.elig[cls] & (NC >= 64 ? ~0ull : ((1ull << NC) - 1ull));
+    const bool staged = ct_in.blob != nullptr && ct_in.blob_bytes <= (uint32_t)BLOB_MAX && (ct_in.blob_bytes & 15u) == 0;
     wv.each([&](int lane) {
-        for (uint32_t i = (uint32_t)lane; i <= NC; i += WAVE) st.ent_off[i] = ct.ent_off[i];
-        for (uint32_t i = (uint32_t)lane; i < NC; i += WAVE) st.weight[i] = ct.weight[i];
-        for (uint32_t i = (uint32_t)lane; i < ne; i += WAVE) { st.ent_res[i] = ct.ent_res[i]; st.ent_amount[i] = ct.ent_amount[i]; st.ent_kind[i] = ct.ent_kind[i]; }
-        for (uint32_t i = (uint32_t)lane; i < R; i += WAVE) { st.pool[i] = ct.pool[i]; st.free_[i] = cl.free_[(size_t)cls * R + i]; st.total[i] = cl.total[(size_t)cls * R + i]; }
+        if (staged) {
+            const V16 *src = reinterpret_cast<const V16 *>(ct_in.blob);
+            V16 *dst = reinterpret_cast<V16 *>(area);
+            for (uint32_t i = (uint32_t)lane; i < ct_in.blob_bytes / 16; i += WAVE) dst[i] = src[i];
+        }
+        for (uint32_t i = (uint32_t)lane; i < R; i += WAVE) { sfree[i] = cl.free_[(size_t)cls * R + i]; stotal[i] = cl.total[(size_t)cls * R + i]; }
         for (int i = lane; i < MMAX * NMAX; i += WAVE) S.a[i / NMAX][i % NMAX] = 0;
         if (lane < MMAX) S.cap[lane] = 0;
         for (int i = lane; i < (NMAX + MMAX + 1) * (MMAX + 1); i += WAVE) {  // binomial table C(i, p), p <= 4
@@ -190,6 +191,13 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
         }
     });
     wv.sync();
+    if (staged) {  // the table pointers now point into LDS
+        const uint8_t *base = reinterpret_cast<const uint8_t *>(ct_in.blob);
+        auto re = [&](const void *p) { return area + (reinterpret_cast<const uint8_t *>(p) - base); };
+        ct.ent_off = reinterpret_cast<const uint32_t *>(re(ct_in.ent_off)); ct.ent_res = reinterpret_cast<const uint32_t *>(re(ct_in.ent_res));
+        ct.ent_kind = re(ct_in.ent_kind); ct.ent_amount = reinterpret_cast<const uint64_t *>(re(ct_in.ent_amount));
+        ct.weight = reinterpret_cast<const uint32_t *>(re(ct_in.weight)); ct.pool = reinterpret_cast<const double *>(re(ct_in.pool));
+    }
     const int n = __builtin_popcountll(elig);
     if (n > NMAX) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
     // column g by lane g: cost in the reference's operation order (create_sn_var, solver.rs:550-568), the resources it touches
@@ -197,20 +205,20 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
         const uint32_t g = (uint32_t)lane;
         if (g >= NC || !((elig >> g) & 1)) return;
         double sc = 0.0; bool any = false, bad = false;
-        for (uint32_t e = st.ent_off[g]; e < st.ent_off[g + 1]; e++) {
-            const uint32_t r = st.ent_res[e];
-            const uint64_t amt = st.ent_kind[e] ? st.total[r] : st.ent_amount[e];
-            const double pool = st.pool[r];
+        for (uint32_t e = ct.ent_off[g]; e < ct.ent_off[g + 1]; e++) {
+            const uint32_t r = ct.ent_res[e];
+            const uint64_t amt = ct.ent_kind[e] ? stotal[r] : ct.ent_amount[e];
+            const double pool = ct.pool[r];
             sc += pool < 0.000001 ? 0.0 : ((double)amt / 10000.0) / pool;
-            if (st.free_[r] == UINT64_MAX) bad = true;  // unbounded row: the reference's carry-over (solver.rs:183-185) is a host matter
+            if (sfree[r] == UINT64_MAX) bad = true;  // unbounded row: the reference's carry-over (solver.rs:183-185) is a host matter
             if (amt == 0) continue;
-            if (amt >= (uint64_t)VAL_LIMIT || (st.free_[r] >= (uint64_t)VAL_LIMIT)) bad = true;
+            if (amt >= (uint64_t)VAL_LIMIT || (sfree[r] >= (uint64_t)VAL_LIMIT)) bad = true;
             any = true;
             wv.atomic_or64(&S.usedres, 1ull << r);
         }
         if (!any) bad = true;  // a column no row bounds
         const int j = __builtin_popcountll(elig & ((1ull << g) - 1ull));
-        S.c[j] = sc * ((double)st.weight[g] / 10000.0);
+        S.c[j] = sc * ((double)ct.weight[g] / 10000.0);
         S.gcol[j] = (int)g;
         if (bad) S.status = ST_UNSUPPORTED;
     });
@@ -220,12 +228,12 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
     if (S.status != ST_OK || m > MMAX) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
     wv.each([&](int lane) {
         const uint32_t g = (uint32_t)lane;
-        if (g < R && ((used >> g) & 1)) S.cap[__builtin_popcountll(used & ((1ull << g) - 1ull))] = (int64_t)st.free_[g];
+        if (g < R && ((used >> g) & 1)) S.cap[__builtin_popcountll(used & ((1ull << g) - 1ull))] = (int64_t)sfree[g];
         if (g >= NC || !((elig >> g) & 1)) return;
         const int j = __builtin_popcountll(elig & ((1ull << g) - 1ull));
-        for (uint32_t e = st.ent_off[g]; e < st.ent_off[g + 1]; e++) {
-            const uint32_t r = st.ent_res[e];
-            const uint64_t amt = st.ent_kind[e] ? st.total[r] : st.ent_amount[e];
+        for (uint32_t e = ct.ent_off[g]; e < ct.ent_off[g + 1]; e++) {
+            const uint32_t r = ct.ent_res[e];
+            const uint64_t amt = ct.ent_kind[e] ? stotal[r] : ct.ent_amount[e];
             if (amt) S.a[__builtin_popcountll(used & ((1ull << r) - 1ull))][j] += (int64_t)amt;
         }
     });

@@ -387,7 +387,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     celig[i] = sigs[(size_t)c * SW + 2 * R + 1];
                 }
                 std::vector<uint32_t> dx((size_t)nd * NC, 0), dstatus(nd, hqblock::ST_UNSUPPORTED), dsteps(nd, 0);
-                hqblock::ColTable ct{NC, R, ent_off.data(), ent_res.data(), ent_kind.data(), ent_amount.data(), weight.data(), pool.data()};
+                hqblock::ColTable ct{NC, R, ent_off.data(), ent_res.data(), ent_kind.data(), ent_amount.data(), weight.data(), pool.data(), nullptr, 0};
                 hqblock::ClassTable cl{nd, cfree.data(), ctot.data(), celig.data()};
                 hqblock::Output bo{dx.data(), dstatus.data(), dsteps.data(), nullptr};
                 if (pb.blocks->solve(ct, cl, bo)) {

@@ -371,14 +371,14 @@ struct DeviceBlocks : hqhost::BlockSolver {
         const uint32_t NC = ct.n_cols, R = ct.R, nd = cl.n_classes, ne = ct.ent_off[NC];
         auto al8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
         const size_t o_off = 0, o_res = al8(o_off + (size_t)(NC + 1) * 4), o_w = al8(o_res + (size_t)ne * 4), o_kind = al8(o_w + (size_t)NC * 4), o_amt = al8(o_kind + ne),
-                     o_pool = o_amt + (size_t)ne * 8, o_free = o_pool + (size_t)R * 8, o_tot = o_free + (size_t)nd * R * 8, o_elig = o_tot + (size_t)nd * R * 8,
+                     o_pool = o_amt + (size_t)ne * 8, o_free = (o_pool + (size_t)R * 8 + 15) & ~(size_t)15, o_tot = o_free + (size_t)nd * R * 8, o_elig = o_tot + (size_t)nd * R * 8,
                      o_x = o_elig + (size_t)nd * 8, o_st = o_x + al8((size_t)nd * NC * 4), o_steps = o_st + al8((size_t)nd * 4), bytes = o_steps + al8((size_t)nd * 4) + 64;
         if (!ctx->h_blk.ensure(bytes)) return false;
         unsigned char *h = ctx->h_blk.as<unsigned char>(), *d = ctx->h_blk.dev<unsigned char>();
         memcpy(h + o_off, ct.ent_off, (size_t)(NC + 1) * 4); memcpy(h + o_res, ct.ent_res, (size_t)ne * 4); memcpy(h + o_w, ct.weight, (size_t)NC * 4);
         memcpy(h + o_kind, ct.ent_kind, ne); memcpy(h + o_amt, ct.ent_amount, (size_t)ne * 8); memcpy(h + o_pool, ct.pool, (size_t)R * 8);
         memcpy(h + o_free, cl.free_, (size_t)nd * R * 8); memcpy(h + o_tot, cl.total, (size_t)nd * R * 8); memcpy(h + o_elig, cl.elig, (size_t)nd * 8);
-        hqblock::ColTable dct{NC, R, (const uint32_t *)(d + o_off), (const uint32_t *)(d + o_res), (const uint8_t *)(d + o_kind), (const uint64_t *)(d + o_amt), (const uint32_t *)(d + o_w), (const double *)(d + o_pool)};
+        hqblock::ColTable dct{NC, R, (const uint32_t *)(d + o_off), (const uint32_t *)(d + o_res), (const uint8_t *)(d + o_kind), (const uint64_t *)(d + o_amt), (const uint32_t *)(d + o_w), (const double *)(d + o_pool), d, (uint32_t)o_free};  // [0, o_free) = the column table: staged into LDS by the kernel
         hqblock::ClassTable dcl{nd, (const uint64_t *)(d + o_free), (const uint64_t *)(d + o_tot), (const uint64_t *)(d + o_elig)};
         uint64_t *dprof = nullptr;
         if (ctx->block_profile) {  // HQTICK_BLOCK_PROFILE=1: per-class stage timestamps (tools/block_profile.py)
@@ -1189,7 +1189,17 @@ struct EmulatedBlocks : hqhost::BlockSolver {
     bool solve(const hqblock::ColTable &ct, const hqblock::ClassTable &cl, const hqblock::Output &out) override {
         static thread_local hqblock::Shared *S = new hqblock::Shared();
         hqblock::HostWave wv;
-        for (uint32_t c = 0; c < cl.n_classes; c++) hqblock::solve_block(wv, *S, ct, cl, c, out, budget);
+        // the column table as ONE 16-byte-aligned allocation, as the tick stages it for the kernel: the emulation then takes the LDS-staging path too
+        const uint32_t NC = ct.n_cols, R = ct.R, ne = ct.ent_off[NC];
+        auto al8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+        const size_t o_res = al8((size_t)(NC + 1) * 4), o_w = al8(o_res + (size_t)ne * 4), o_kind = al8(o_w + (size_t)NC * 4), o_amt = al8(o_kind + ne), o_pool = o_amt + (size_t)ne * 8,
+                     bytes = (o_pool + (size_t)R * 8 + 15) & ~(size_t)15;
+        std::vector<hqblock::V16> store(bytes / 16 + 1);
+        unsigned char *b = reinterpret_cast<unsigned char *>(store.data());
+        memcpy(b, ct.ent_off, (size_t)(NC + 1) * 4); memcpy(b + o_res, ct.ent_res, (size_t)ne * 4); memcpy(b + o_w, ct.weight, (size_t)NC * 4);
+        memcpy(b + o_kind, ct.ent_kind, ne); memcpy(b + o_amt, ct.ent_amount, (size_t)ne * 8); memcpy(b + o_pool, ct.pool, (size_t)R * 8);
+        hqblock::ColTable bt{NC, R, (const uint32_t *)b, (const uint32_t *)(b + o_res), b + o_kind, (const uint64_t *)(b + o_amt), (const uint32_t *)(b + o_w), (const double *)(b + o_pool), b, (uint32_t)bytes};
+        for (uint32_t c = 0; c < cl.n_classes; c++) hqblock::solve_block(wv, *S, (c & 1) ? ct : bt, cl, c, out, budget);  // odd classes: tables read in place
         return true;
     }
 };
@@ -1203,7 +1213,7 @@ void hqtick_debug_last_blocks(uint32_t *n_emulated, uint32_t *n_host) { if (n_em
 int hqtick_debug_block_solve_host(uint32_t n_cols, uint32_t n_resources, const uint32_t *ent_off, const uint32_t *ent_res, const uint8_t *ent_kind, const uint64_t *ent_amount,
                                   const uint32_t *weight, const double *pool, uint32_t n_classes, const uint64_t *free_, const uint64_t *total, const uint64_t *elig,
                                   uint32_t budget, uint32_t *x, uint32_t *status, uint32_t *steps) {
-    hqblock::ColTable ct{n_cols, n_resources, ent_off, ent_res, ent_kind, ent_amount, weight, pool};
+    hqblock::ColTable ct{n_cols, n_resources, ent_off, ent_res, ent_kind, ent_amount, weight, pool, nullptr, 0};
     hqblock::ClassTable cl{n_classes, free_, total, elig};
     hqblock::Output out{x, status, steps, nullptr};
     EmulatedBlocks emu(budget ? budget : 4096);

@@ -118,7 +118,7 @@ int main(int argc, char **argv) {
             for (uint32_t q = 0; q < c.n_cols; q++) { uint32_t g = idx[q]; for (uint32_t e = c.ent_off[g]; e < c.ent_off[g + 1]; e++) { d.ent_res.push_back(c.ent_res[e]); d.ent_kind.push_back(c.ent_kind[e]); d.ent_amount.push_back(c.ent_amount[e]); } d.ent_off.push_back((uint32_t)d.ent_res.size()); d.weight.push_back(c.weight[g]); if ((c.elig >> g) & 1) d.elig |= 1ull << q; }
             c = d;
         }
-        hqblock::ColTable ct{c.n_cols, c.R, c.ent_off.data(), c.ent_res.data(), c.ent_kind.data(), c.ent_amount.data(), c.weight.data(), c.pool.data()};
+        hqblock::ColTable ct{c.n_cols, c.R, c.ent_off.data(), c.ent_res.data(), c.ent_kind.data(), c.ent_amount.data(), c.weight.data(), c.pool.data(), nullptr, 0};
         hqblock::ClassTable cl{1, c.free_.data(), c.total.data(), &c.elig};
         std::vector<uint32_t> x(c.n_cols, 7); uint32_t status = 9, steps = 0;
         hqblock::Output out{x.data(), &status, &steps, nullptr};
