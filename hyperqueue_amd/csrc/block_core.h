@@ -7,8 +7,10 @@
 // bounded integer knapsack with <= 4 resource rows and <= 32 columns; the blocks are independent -- the W-way data parallelism of the tick.
 //
 // Result convention = csrc/milp.h's canonical optimum: among the integer points within 1e-9 (relative) of the optimum the one that
-// minimises the LAST column, then the one before it, ...  Feasibility is decided in exact u64 `ResourceAmount` arithmetic (the host solver
-// works in f64 units with a 1e-9 tolerance; on the 1/10000 grid the two agree).
+// minimises the LAST column, then the one before it, ...  Feasibility is decided in exact integer `ResourceAmount` arithmetic (the host solver
+// works in f64 units with a 1e-9 tolerance; on the 1/10000 grid the two agree).  The integers are CARRIED in f64: every amount, capacity and
+// product stays below 2^52, where f64 add / mul / fma are exact — the MI355X runs f64 at full rate while 64-bit integer multiply and divide
+// are multi-instruction sequences, and a single wavefront per block exposes every instruction's latency.
 //
 // Algorithm (all of a wavefront's 64 lanes work on the same block):
 //   build     columns / rows from the class descriptor, rows divided by their gcd, costs in the reference's operation order (solver.rs:550-568)
@@ -27,6 +29,7 @@
 // Everything lane-varying is a function of (lane) handed to the Wave policy (ballot / arg-max / each); the uniform control flow is shared by
 // the device kernel (block_solve.hip, Wave = one wavefront) and the host emulation the CPU tests run (lanes in a loop).
 #pragma once
+#include <cmath>
 #include <cstdint>
 
 #if defined(__HIPCC__)
@@ -43,10 +46,10 @@ namespace hqblock {
 constexpr int NMAX = 32;     // columns of one block
 constexpr int MMAX = 4;      // resource rows of one block
 constexpr int WAVE = 64;
-constexpr int PCAP = 448;    // dual points kept per block (a C3-shaped block has ~65; what does not fit is dropped: weaker bounds, same answer)
+constexpr int PCAP = 400;    // dual points kept per block (a C3-shaped block has ~65; what does not fit is dropped: weaker bounds, same answer)
 constexpr int DPRE = 48;     // dual points a level of the walk looks at (C3-shaped: <= 43)
 constexpr int GCOLS = 64;    // (batch, variant) columns of a tick the eligibility mask can address
-constexpr int64_t UB_LIMIT = 65535;  // a column that could be taken more often than this goes to the host solver
+constexpr int32_t UB_LIMIT = 65535;  // a column that could be taken more often than this goes to the host solver
 
 enum { ST_OK = 0, ST_BUDGET = 1, ST_UNSUPPORTED = 2 };
 
@@ -84,50 +87,63 @@ struct Shared {  // one block's working set: LDS on the device
     uint64_t usedres;               // resources some eligible column touches
     int gcol[NMAX];                 // block column -> tick column
     double c[NMAX];
-    int64_t a[MMAX][NMAX];
-    int64_t cap[MMAX];
+    double a[MMAX][NMAX], ainv[MMAX][NMAX];  // amounts on the row's own grid (integers carried in f64) and their reciprocals (0 where the column does not use the row)
+    double cap[MMAX];
     uint8_t pi[NMAX];               // block columns by ascending size (the search decides the large ones first)
     uint8_t pd[NMAX];               // block columns by descending value density (first greedy order)
     // dual pool
     uint32_t npool;
     alignas(16) double py[PCAP][MMAX];  // (16-byte aligned: the staging area of build_block overlays it)
     uint32_t pcover[PCAP], ptight[PCAP];
+    uint16_t porder[PCAP];          // pool entries by ascending y . cap: the tightest bounds at the root come first in every level's list
     // work problem: columns in search order (position wn - 1 is decided first)
     int wn;
     uint8_t wcol[NMAX];
     double wc[NMAX];
-    int64_t wa[MMAX][NMAX];
+    double wa[MMAX][NMAX], winv[MMAX][NMAX];
     uint32_t wmask[NMAX + 1];       // block columns at positions < k
     uint16_t dl[NMAX + 1][DPRE];    // per level: pool entries that are vertices of that level's dual polyhedron
     float dpen[NMAX + 1][DPRE];     // ... and the penalty of a capped column (phase 2), rounded up
-    int64_t wcap[NMAX];             // upper cap of a position (INT64_MAX = none)
+    int32_t wcap[NMAX];             // upper cap of a position (INT32_MAX = none)
     uint32_t dcnt[NMAX + 1];
     // level stack of the walk (level k = number of positions still free)
-    int64_t rem[NMAX + 1][MMAX];
+    double rem[NMAX + 1][MMAX];
     double zfix[NMAX + 1];
-    int64_t ptr[NMAX + 1], ub[NMAX + 1];
+    int32_t ptr[NMAX + 1], ub[NMAX + 1];
     uint32_t xsel[NMAX];            // by position
     // incumbent / completion, by block column
     uint32_t xbest[NMAX];
     double best;
     // greedy
-    uint8_t perm[WAVE][NMAX];
-    uint16_t gx[WAVE][NMAX];
+    uint8_t perm[NMAX][WAVE];       // [column slot][lane]: lanes side by side, so that a wavefront's accesses spread over the LDS banks
+    uint16_t gx[NMAX][WAVE];
     double lane_val[WAVE];
-    uint32_t binom[NMAX + MMAX + 1][MMAX + 1];
+    uint32_t lane_rng[WAVE];        // setup_work: level ranges of the pool entry a lane is looking at
+    uint64_t lmask[NMAX + 1];       // setup_work: per level, which of the 64 entries of the current pass enter its list
 };
 
 constexpr int BLOB_MAX = 8192;               // largest column table the kernel stages in LDS
 struct alignas(16) V16 { uint64_t lo, hi; };
-constexpr int64_t VAL_LIMIT = 1ll << 52;    // amounts and capacities stay exact in f64 (div_floor below)
+constexpr int64_t VAL_LIMIT = 1ll << 52;    // amounts and capacities stay exact in f64
 
-// floor(a / b) for 0 <= a, 0 < b, both below 2^52: the f64 quotient is off by at most one, which two multiplications repair.  (64-bit integer
-// division is a ~200-instruction software routine on the GPU; this is the walk's innermost operation.)
-HQB_HD int64_t div_floor(int64_t a, int64_t b) {
-    int64_t q = (int64_t)((double)a / (double)b);
-    if (q * b > a) q--;
-    else if ((q + 1) * b <= a) q++;
-    return q;
+// How often an amount `a` (> 0, reciprocal `inv`) fits into `rem` (>= 0): floor(rem / a) without a division.  rem * inv is within 2^-51 relative
+// of the quotient, so its floor is off by at most one; the remainder fma(-q, a, rem) is exact (integers below 2^53) and repairs it.
+HQB_HD int32_t fits(double rem, double a, double inv) {
+    double q = floor(rem * inv);
+    const double r = fma(-q, a, rem);
+    if (r < 0.0) q -= 1.0;
+    else if (r >= a) q += 1.0;
+    return q > 2147483647.0 ? 2147483647 : (int32_t)q;
+}
+// C(i, p) for p <= 4, i <= NMAX + MMAX: closed form (the divisions are by constants)
+HQB_HD uint32_t binom(uint32_t i, int p) {
+    switch (p) {
+        case 0: return 1u;
+        case 1: return i;
+        case 2: return i < 2 ? 0u : i * (i - 1) / 2;
+        case 3: return i < 3 ? 0u : i * (i - 1) * (i - 2) / 6;
+        default: return i < 4 ? 0u : i * (i - 1) * (i - 2) * (i - 3) / 24;
+    }
 }
 HQB_HD int64_t gcd64(int64_t a, int64_t b) {  // binary gcd: shifts and subtractions only
     if (a == 0) return b;
@@ -143,10 +159,10 @@ HQB_HD int64_t gcd64(int64_t a, int64_t b) {  // binary gcd: shifts and subtract
 }
 
 // min over the level's dual points of y . rem: an upper bound of the LP over the positions [0, k), hence of its integer optimum
-HQB_HD double lp_bound(const Shared &S, int k, const int64_t *rem) {
+HQB_HD double lp_bound(const Shared &S, int k, const double *rem) {
     const int cnt = (int)(S.dcnt[k] < (uint32_t)DPRE ? S.dcnt[k] : (uint32_t)DPRE);
     if (cnt == 0) return 1e300;
-    const double r0 = (double)rem[0], r1 = (double)rem[1], r2 = (double)rem[2], r3 = (double)rem[3];
+    const double r0 = rem[0], r1 = rem[1], r2 = rem[2], r3 = rem[3];
     double best = 1e300;
     for (int i = 0; i < cnt; i++) {
         const double *d = S.py[S.dl[k][i]];
@@ -169,6 +185,10 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTabl
     uint8_t *area = reinterpret_cast<uint8_t *>(&S.py[0][0]);
     static_assert(sizeof(double) * PCAP * MMAX >= BLOB_MAX + 64 * 8 * 2, "the staging area overlays the dual pool");
     uint64_t *sfree = reinterpret_cast<uint64_t *>(area + BLOB_MAX), *stotal = sfree + 64;
+    // integer amounts while the rows are brought onto their own grid (gcd); overlays the greedy vectors, which are not in use yet
+    static_assert(sizeof(uint16_t) * NMAX * WAVE >= sizeof(int64_t) * (MMAX * NMAX + MMAX), "a64 overlays gx");
+    int64_t (*a64)[NMAX] = reinterpret_cast<int64_t (*)[NMAX]>(&S.gx[0][0]);
+    int64_t *cap64 = &a64[MMAX - 1][NMAX - 1] + 1;
     ColTable ct = ct_in;
     if (wv.first()) { S.status = ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = 0; S.npool = 0; S.usedres = 0; }
     if (NC > (uint32_t)GCOLS || R > 64 || NC == 0) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
@@ -181,14 +201,8 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTabl
             for (uint32_t i = (uint32_t)lane; i < ct_in.blob_bytes / 16; i += WAVE) dst[i] = src[i];
         }
         for (uint32_t i = (uint32_t)lane; i < R; i += WAVE) { sfree[i] = cl.free_[(size_t)cls * R + i]; stotal[i] = cl.total[(size_t)cls * R + i]; }
-        for (int i = lane; i < MMAX * NMAX; i += WAVE) S.a[i / NMAX][i % NMAX] = 0;
-        if (lane < MMAX) S.cap[lane] = 0;
-        for (int i = lane; i < (NMAX + MMAX + 1) * (MMAX + 1); i += WAVE) {  // binomial table C(i, p), p <= 4
-            const uint32_t n_ = (uint32_t)(i / (MMAX + 1)), p = (uint32_t)(i % (MMAX + 1));
-            uint32_t v = 1;
-            if (p > n_) v = 0; else for (uint32_t q = 0; q < p; q++) v = v * (n_ - q) / (q + 1);
-            S.binom[n_][p] = v;
-        }
+        for (int i = lane; i < MMAX * NMAX; i += WAVE) a64[i / NMAX][i % NMAX] = 0;
+        if (lane < MMAX) cap64[lane] = 0;
     });
     wv.sync();
     if (staged) {  // the table pointers now point into LDS
@@ -228,29 +242,35 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTabl
     if (S.status != ST_OK || m > MMAX) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
     wv.each([&](int lane) {
         const uint32_t g = (uint32_t)lane;
-        if (g < R && ((used >> g) & 1)) S.cap[__builtin_popcountll(used & ((1ull << g) - 1ull))] = (int64_t)sfree[g];
+        if (g < R && ((used >> g) & 1)) cap64[__builtin_popcountll(used & ((1ull << g) - 1ull))] = (int64_t)sfree[g];
         if (g >= NC || !((elig >> g) & 1)) return;
         const int j = __builtin_popcountll(elig & ((1ull << g) - 1ull));
         for (uint32_t e = ct.ent_off[g]; e < ct.ent_off[g + 1]; e++) {
             const uint32_t r = ct.ent_res[e];
             const uint64_t amt = ct.ent_kind[e] ? stotal[r] : ct.ent_amount[e];
-            if (amt) S.a[__builtin_popcountll(used & ((1ull << r) - 1ull))][j] += (int64_t)amt;
+            if (amt) a64[__builtin_popcountll(used & ((1ull << r) - 1ull))][j] += (int64_t)amt;
         }
     });
     wv.sync();
-    // rows on their own grid: amounts and capacity divided by the row's gcd (the capacity rounds down: what is cut off no column can use)
+    // rows on their own grid: amounts and capacity divided by the row's gcd (the capacity rounds down: what is cut off no column can use); from
+    // here on the integers live in f64
     wv.each([&](int lane) {
-        if (lane >= m) return;
+        if (lane >= MMAX) return;
         int64_t g = 0;
-        for (int j = 0; j < n; j++) g = gcd64(g, S.a[lane][j]);
-        if (g > 1) { for (int j = 0; j < n; j++) if (S.a[lane][j]) S.a[lane][j] = div_floor(S.a[lane][j], g); S.cap[lane] = div_floor(S.cap[lane], g); }
+        if (lane < m) for (int j = 0; j < n; j++) g = gcd64(g, a64[lane][j]);
+        if (g < 1) g = 1;
+        for (int j = 0; j < NMAX; j++) {
+            const double v = (lane < m && j < n) ? (double)a64[lane][j] / (double)g : 0.0;  // exact: g divides the amount, both below 2^52
+            S.a[lane][j] = v; S.ainv[lane][j] = v > 0.0 ? 1.0 / v : 0.0;
+        }
+        S.cap[lane] = lane < m ? (double)(cap64[lane] / g) : 0.0;
     });
     wv.sync();
     // search order: columns by ascending size (stable), by rank counting; a column that fits too often goes to the host
     wv.each([&](int lane) {
         if (lane >= n) return;
-        int64_t ub = INT64_MAX; double sz = 0.0;
-        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0) { int64_t q = div_floor(S.cap[r], S.a[r][lane]); ub = q < ub ? q : ub; sz += (double)S.a[r][lane] / (double)(S.cap[r] + 1); }
+        int32_t ub = 2147483647; double sz = 0.0;
+        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0.0) { const int32_t q = fits(S.cap[r], S.a[r][lane], S.ainv[r][lane]); ub = q < ub ? q : ub; sz += S.a[r][lane] / (S.cap[r] + 1.0); }
         if (ub > UB_LIMIT) S.status = ST_UNSUPPORTED;
         S.lane_val[lane] = sz;
     });
@@ -266,7 +286,7 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTabl
     wv.each([&](int lane) {  // value density c_j / sum_r a_rj / cap_r
         if (lane >= n) return;
         double w = 0.0;
-        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0) w += S.cap[r] > 0 ? (double)S.a[r][lane] / (double)S.cap[r] : 1e30;
+        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0.0) w += S.cap[r] > 0.0 ? S.a[r][lane] / S.cap[r] : 1e30;
         S.lane_val[lane] = w > 0.0 ? S.c[lane] / w : 0.0;
     });
     wv.sync();
@@ -302,12 +322,12 @@ HQB_HD void dual_candidate(W &wv, Shared &S, uint32_t t) {
             if (eq < m) {
                 const int p = m - eq;
                 int i = hi - 1;
-                while (S.binom[i][p] > rest) i--;
-                rest -= S.binom[i][p];
+                while (binom((uint32_t)i, p) > rest) i--;
+                rest -= binom((uint32_t)i, p);
                 hi = i;
                 if (i < n) {
                     HQB_UNROLL
-                    for (int r = 0; r < MMAX; r++) M[eq][r] = (double)S.a[r][i];
+                    for (int r = 0; r < MMAX; r++) M[eq][r] = S.a[r][i];
                     M[eq][MMAX] = S.c[i];
                     tight |= 1u << i;
                     if (i > maxcol) maxcol = i;
@@ -350,7 +370,7 @@ HQB_HD void dual_candidate(W &wv, Shared &S, uint32_t t) {
     for (int j = 0; j < n; j++) {
         double s = 0.0;
         HQB_UNROLL
-        for (int r = 0; r < MMAX; r++) s += (double)S.a[r][j] * y[r];
+        for (int r = 0; r < MMAX; r++) s += S.a[r][j] * y[r];
         if (s < S.c[j] * (1.0 - 1e-11)) continue;
         cover |= 1u << j;
         if (s < S.c[j]) { const double q = S.c[j] / s; f = q > f ? q : f; }
@@ -379,25 +399,23 @@ HQB_HD uint32_t xorshift32(uint32_t &s) { s ^= s << 13; s ^= s >> 17; s ^= s << 
 
 HQB_HD void greedy_lane(Shared &S, int lane) {
     const int n = S.n, m = S.m;
-    uint8_t *pm = S.perm[lane];
     // lane 0: by value density (descending); 1: large requests first; 2: small first; 3 / 4: the model's order and its reverse; others: shuffles
-    for (int j = 0; j < n; j++) pm[j] = lane == 0 ? S.pd[j] : lane == 1 ? S.pi[n - 1 - j] : lane == 2 ? S.pi[j] : lane == 4 ? (uint8_t)(n - 1 - j) : (uint8_t)j;
-    if (lane >= 5) { uint32_t s = 0x9E3779B9u * (uint32_t)(lane + 1); for (int i = n - 1; i > 0; i--) { int q = (int)(xorshift32(s) % (uint32_t)(i + 1)); uint8_t tmp = pm[i]; pm[i] = pm[q]; pm[q] = tmp; } }
-    int64_t rem[MMAX];
+    for (int j = 0; j < n; j++) S.perm[j][lane] = lane == 0 ? S.pd[j] : lane == 1 ? S.pi[n - 1 - j] : lane == 2 ? S.pi[j] : lane == 4 ? (uint8_t)(n - 1 - j) : (uint8_t)j;
+    if (lane >= 5) { uint32_t s = 0x9E3779B9u * (uint32_t)(lane + 1); for (int i = n - 1; i > 0; i--) { int q = (int)(xorshift32(s) % (uint32_t)(i + 1)); uint8_t tmp = S.perm[i][lane]; S.perm[i][lane] = S.perm[q][lane]; S.perm[q][lane] = tmp; } }
+    double rem[MMAX];
     for (int r = 0; r < MMAX; r++) rem[r] = S.cap[r];
-    uint16_t *x = S.gx[lane];
-    for (int j = 0; j < n; j++) x[j] = 0;
+    for (int j = 0; j < n; j++) S.gx[j][lane] = 0;
     for (int i = 0; i < n; i++) {
-        const int j = pm[i];
+        const int j = S.perm[i][lane];
         if (!(S.c[j] > 0.0)) continue;
-        int64_t ub = INT64_MAX;
-        for (int r = 0; r < m; r++) if (S.a[r][j] > 0) { int64_t q = div_floor(rem[r], S.a[r][j]); ub = q < ub ? q : ub; }
+        int32_t ub = 2147483647;
+        for (int r = 0; r < m; r++) if (S.a[r][j] > 0.0) { const int32_t q = fits(rem[r], S.a[r][j], S.ainv[r][j]); ub = q < ub ? q : ub; }
         if (ub <= 0) continue;
-        x[j] = (uint16_t)ub;
-        for (int r = 0; r < m; r++) rem[r] -= ub * S.a[r][j];
+        S.gx[j][lane] = (uint16_t)ub;
+        for (int r = 0; r < m; r++) rem[r] -= (double)ub * S.a[r][j];
     }
     double z = 0.0;
-    for (int j = n - 1; j >= 0; j--) z = z + S.c[j] * (double)x[j];
+    for (int j = n - 1; j >= 0; j--) z = z + S.c[j] * (double)S.gx[j][lane];
     S.lane_val[lane] = z;
 }
 
@@ -407,16 +425,15 @@ HQB_HD void greedy_lane(Shared &S, int lane) {
 // within cover).  With a capped column j in F the LP has one more dual variable, the multiplier of x_j <= L; its vertices are the ones above
 // plus (y, mu = c_j - a_j . y > 0) with y a vertex for F \ {j}: those enter with the penalty L * mu   (bound = y . rem + penalty).
 template <class W>
-HQB_HD void setup_work(W &wv, Shared &S, uint32_t cols, int capcol, int64_t capval) {
+HQB_HD void setup_work(W &wv, Shared &S, uint32_t cols, int capcol, int32_t capval) {
     const uint64_t selmask = wv.ballot([&](int lane) { return lane < S.n && ((cols >> S.pi[lane]) & 1); });
     wv.each([&](int lane) {
-        if (lane <= NMAX) S.dcnt[lane] = 0;
         if (lane >= S.n || !((selmask >> lane) & 1)) return;
         const int p = __builtin_popcountll(selmask & ((1ull << lane) - 1ull)), j = S.pi[lane];
         S.wcol[p] = (uint8_t)j;
         S.wc[p] = S.c[j];
-        S.wcap[p] = j == capcol ? capval : INT64_MAX;
-        for (int r = 0; r < MMAX; r++) S.wa[r][p] = S.a[r][j];
+        S.wcap[p] = j == capcol ? capval : 2147483647;
+        for (int r = 0; r < MMAX; r++) { S.wa[r][p] = S.a[r][j]; S.winv[r][p] = S.ainv[r][j]; }
     });
     if (wv.first()) S.wn = __builtin_popcountll(selmask);
     wv.sync();
@@ -430,42 +447,80 @@ HQB_HD void setup_work(W &wv, Shared &S, uint32_t cols, int capcol, int64_t capv
     const int wn = S.wn;
     const uint32_t np = S.npool < (uint32_t)PCAP ? S.npool : (uint32_t)PCAP;
     const uint32_t capbit = capcol >= 0 ? 1u << capcol : 0u;
-    wv.each([&](int lane) {
-        for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) {
-            const uint32_t cover = S.pcover[i], tight = S.ptight[i];
-            double mu = 0.0;
-            if (capbit && !(cover & capbit)) {
-                double s = 0.0;
-                for (int r = 0; r < MMAX; r++) s += (double)S.a[r][capcol] * S.py[i][r];
-                mu = (S.c[capcol] - s) * (1.0 + 1e-12);
-                if (mu < 0.0) mu = 0.0;
-            }
-            for (int k = 1; k <= wn; k++) {
-                const uint32_t F = S.wmask[k];
-                double pen = 0.0;
-                bool use = (tight & ~F) == 0 && (F & ~cover) == 0;
-                if (!use && (F & capbit)) { const uint32_t G = F & ~capbit; if ((tight & ~G) == 0 && (G & ~cover) == 0) { use = true; pen = (double)capval * mu; } }
-                if (use) { const uint32_t slot = wv.atomic_inc(&S.dcnt[k]); if (slot < (uint32_t)DPRE) { S.dl[k][slot] = (uint16_t)i; S.dpen[k][slot] = pen > 0.0 ? (float)(pen * (1.0 + 2e-7)) : 0.0f; } }
-            }
-        }
-    });
+    // Level lists in pool order (porder: tightest at the root first).  The level sets are nested (F_1 < F_2 < ... ), so an entry is a vertex for
+    // a contiguous range of levels — [lo, hi] as it is, [lo2, hi2] through the capped column's multiplier — which its lane works out once; one
+    // ballot per level then gives every entry its slot (prefix popcount), with nothing but registers between the ballots.
+    if (wv.first()) for (int k = 0; k <= NMAX; k++) S.dcnt[k] = 0;
     wv.sync();
+    for (uint32_t base = 0; base < np; base += WAVE) {
+        wv.each([&](int lane) {
+            const uint32_t rk = base + (uint32_t)lane;
+            uint32_t rng = 0x00FF00FFu;  // lo = 255 > hi = 0: empty ranges
+            double mu = 0.0;
+            if (rk < np) {
+                const uint32_t i = S.porder[rk], cover = S.pcover[i], tight = S.ptight[i];
+                int lo = 255, hi = 0, lo2 = 255, hi2 = 0;
+                for (int k = 1; k <= wn; k++) {
+                    const uint32_t F = S.wmask[k];
+                    if ((tight & ~F) == 0 && (F & ~cover) == 0) { if (k < lo) lo = k; hi = k; }
+                    else if (F & capbit) { const uint32_t G = F & ~capbit; if ((tight & ~G) == 0 && (G & ~cover) == 0) { if (k < lo2) lo2 = k; hi2 = k; } }
+                }
+                if (hi2) {
+                    double sdot = 0.0;
+                    for (int r = 0; r < MMAX; r++) sdot += S.a[r][capcol] * S.py[i][r];
+                    mu = (S.c[capcol] - sdot) * (1.0 + 1e-12);
+                    if (mu < 0.0) mu = 0.0;
+                }
+                rng = (uint32_t)lo | ((uint32_t)hi << 8) | ((uint32_t)lo2 << 16) | ((uint32_t)hi2 << 24);
+            }
+            S.lane_rng[lane] = rng; S.lane_val[lane] = mu;
+        });
+        wv.sync();
+        for (int k = 1; k <= wn; k++) {
+            const uint64_t mask = wv.ballot([&](int lane) {
+                const uint32_t rng = S.lane_rng[lane];
+                const uint32_t kk = (uint32_t)k;
+                return ((rng & 0xFFu) <= kk && kk <= ((rng >> 8) & 0xFFu)) || (((rng >> 16) & 0xFFu) <= kk && kk <= (rng >> 24));
+            });
+            if (wv.first()) S.lmask[k] = mask;
+        }
+        wv.sync();
+        wv.each([&](int lane) {
+            const uint32_t rng = S.lane_rng[lane];
+            if (rng == 0x00FF00FFu) return;
+            const uint16_t i = S.porder[base + (uint32_t)lane];
+            const uint32_t lo = rng & 0xFFu, hi = (rng >> 8) & 0xFFu, lo2 = (rng >> 16) & 0xFFu, hi2 = rng >> 24;
+            const double pen = (double)capval * S.lane_val[lane];
+            const float penf = pen > 0.0 ? (float)(pen * (1.0 + 2e-7)) : 0.0f;
+            for (uint32_t k = 1; k <= (uint32_t)wn; k++) {
+                const bool plain = lo <= k && k <= hi, capped = lo2 <= k && k <= hi2;
+                if (!plain && !capped) continue;
+                const uint32_t slot = S.dcnt[k] + (uint32_t)__builtin_popcountll(S.lmask[k] & ((1ull << lane) - 1ull));
+                if (slot >= (uint32_t)DPRE) continue;
+                S.dl[k][slot] = i;
+                S.dpen[k][slot] = plain ? 0.0f : penf;
+            }
+        });
+        wv.sync();
+        if (wv.first()) for (int k = 1; k <= wn; k++) S.dcnt[k] += (uint32_t)__builtin_popcountll(S.lmask[k]);
+        wv.sync();
+    }
 }
 
-HQB_HD int64_t level_ub(const Shared &S, int k) {  // how often the column at position k - 1 fits into rem[k]
+HQB_HD int32_t level_ub(const Shared &S, int k) {  // how often the column at position k - 1 fits into rem[k]
     const int p = k - 1;
-    int64_t ub = S.wcap[p];
-    for (int r = 0; r < S.m; r++) if (S.wa[r][p] > 0) { int64_t q = div_floor(S.rem[k][r], S.wa[r][p]); ub = q < ub ? q : ub; }
+    int32_t ub = S.wcap[p];
+    for (int r = 0; r < S.m; r++) if (S.wa[r][p] > 0.0) { const int32_t q = fits(S.rem[k][r], S.wa[r][p], S.winv[r][p]); ub = q < ub ? q : ub; }
     return ub;
 }
 
 // Two positions left (1 and 0): position 1 takes v1, position 0 follows exactly with its maximum.
-HQB_HD bool terminal_lane(const Shared &S, int64_t v1, int64_t *x0_out, double *val_out) {
+HQB_HD bool terminal_lane(const Shared &S, int32_t v1, int32_t *x0_out, double *val_out) {
     if (v1 < 0 || v1 > S.ub[2]) return false;
-    int64_t x0max = S.wcap[0];
+    int32_t x0max = S.wcap[0];
     for (int r = 0; r < S.m; r++) {
-        const int64_t left = S.rem[2][r] - v1 * S.wa[r][1];
-        if (S.wa[r][0] > 0) { int64_t q = left < 0 ? -1 : div_floor(left, S.wa[r][0]); x0max = q < x0max ? q : x0max; }
+        const double left = fma(-(double)v1, S.wa[r][1], S.rem[2][r]);
+        if (S.wa[r][0] > 0.0) { const int32_t q = left < 0.0 ? -1 : fits(left, S.wa[r][0], S.winv[r][0]); x0max = q < x0max ? q : x0max; }
     }
     *x0_out = x0max;
     *val_out = (S.zfix[2] + S.wc[1] * (double)v1) + S.wc[0] * (double)x0max;
@@ -473,6 +528,7 @@ HQB_HD bool terminal_lane(const Shared &S, int64_t v1, int64_t *x0_out, double *
 }
 
 enum { MODE_MAX = 0, MODE_FIND = 1 };
+struct Probe { double rem[MMAX]; double base, b; };  // one child of a level while its bound is being evaluated
 #ifdef HQB_TRACE
 static uint32_t g_trace_maxlist = 0, g_trace_maxpool = 0; static unsigned long g_trace_probes = 0;
 #endif
@@ -488,8 +544,8 @@ HQB_HD bool walk(W &wv, Shared &S, int mode, double thr, uint32_t *budget, bool 
     bool found = false;
     if (wn == 1) {  // a single position: no search
         if (wv.first()) {
-            int64_t ub = S.wcap[0];
-            for (int r = 0; r < m; r++) if (S.wa[r][0] > 0) { int64_t q = div_floor(S.rem[1][r], S.wa[r][0]); ub = q < ub ? q : ub; }
+            int32_t ub = S.wcap[0];
+            for (int r = 0; r < m; r++) if (S.wa[r][0] > 0.0) { const int32_t q = fits(S.rem[1][r], S.wa[r][0], S.winv[r][0]); ub = q < ub ? q : ub; }
             const double val = S.zfix[1] + S.wc[0] * (double)ub;
             if (mode == MODE_MAX) { if (val > S.best) { S.best = val; S.xbest[S.wcol[0]] = (uint32_t)ub; } }
             else { S.ptr[1] = val >= thr ? 1 : 0; if (val >= thr) S.xbest[S.wcol[0]] = (uint32_t)ub; }
@@ -507,17 +563,17 @@ HQB_HD bool walk(W &wv, Shared &S, int mode, double thr, uint32_t *budget, bool 
     while (k <= wn) {
         if (steps >= *budget) { in_budget = false; break; }
         steps++;
-        const int64_t p = S.ptr[k], ubk = S.ub[k];
+        const int32_t p = S.ptr[k], ubk = S.ub[k];
         if (p < 0) { k++; continue; }  // level exhausted
         const int pos = k - 1;
         if (k == 2) {  // leaves: every lane a complete point
-            auto eval = [&](int lane, int64_t *x0, double *val) { return terminal_lane(S, p - lane, x0, val); };
+            auto eval = [&](int lane, int32_t *x0, double *val) { return terminal_lane(S, p - lane, x0, val); };
             if (mode == MODE_FIND) {
-                const uint64_t mask = wv.ballot([&](int lane) { int64_t x0; double val; return eval(lane, &x0, &val) && val >= thr; });
+                const uint64_t mask = wv.ballot([&](int lane) { int32_t x0; double val; return eval(lane, &x0, &val) && val >= thr; });
                 if (mask) {
                     const int l = wv.ctz(mask);
                     if (wv.first()) {
-                        int64_t x0 = 0; double val = 0; eval(l, &x0, &val);
+                        int32_t x0 = 0; double val = 0; eval(l, &x0, &val);
                         S.xsel[1] = (uint32_t)(p - l); S.xsel[0] = (uint32_t)x0;
                         for (int q = 0; q < wn; q++) S.xbest[S.wcol[q]] = S.xsel[q];
                     }
@@ -527,11 +583,11 @@ HQB_HD bool walk(W &wv, Shared &S, int mode, double thr, uint32_t *budget, bool 
                 }
             } else {
                 int l = -1;
-                const double top = wv.argmax([&](int lane) { int64_t x0; double val; return eval(lane, &x0, &val) ? val : -1.0; }, &l);
+                const double top = wv.argmax([&](int lane) { int32_t x0; double val; return eval(lane, &x0, &val) ? val : -1.0; }, &l);
                 if (l >= 0 && top > S.best) {
                     wv.sync();  // every lane has read S.best
                     if (wv.first()) {
-                        int64_t x0 = 0; double val = 0; eval(l, &x0, &val);
+                        int32_t x0 = 0; double val = 0; eval(l, &x0, &val);
                         S.xsel[1] = (uint32_t)(p - l); S.xsel[0] = (uint32_t)x0;
                         for (int q = 0; q < wn; q++) S.xbest[S.wcol[q]] = S.xsel[q];
                         S.best = val;
@@ -545,21 +601,35 @@ HQB_HD bool walk(W &wv, Shared &S, int mode, double thr, uint32_t *budget, bool 
         // inner level: 64 values of the column at `pos` at once
         const double cut = mode == MODE_FIND ? thr : S.best + 1e-12 * (S.best < 0 ? -S.best : S.best);
         const double zk = S.zfix[k], cj = S.wc[pos];
-        const uint64_t mask = wv.ballot([&](int lane) {
-            const int64_t v = p - lane;
-            if (v < 0 || v > ubk) return false;
-            int64_t rem[MMAX];
-            for (int r = 0; r < MMAX; r++) rem[r] = S.rem[k][r] - v * S.wa[r][pos];
-            const double bound = (zk + cj * (double)v) + lp_bound(S, k - 1, rem);
-            return mode == MODE_FIND ? bound >= cut : bound > cut;
-        });
+        // child bounds, the level's duals in chunks of 8 (tightest first): once a chunk has pruned every child the rest is not evaluated
+        const int cnt = (int)(S.dcnt[k - 1] < (uint32_t)DPRE ? S.dcnt[k - 1] : (uint32_t)DPRE);
+        const uint64_t mask = wv.ballot_chunked((cnt + 7) / 8,
+            [&](int lane, Probe &st) {
+                const int32_t v = p - lane;
+                if (v < 0 || v > ubk) return false;
+                for (int r = 0; r < MMAX; r++) st.rem[r] = fma(-(double)v, S.wa[r][pos], S.rem[k][r]);
+                st.base = zk + cj * (double)v; st.b = 1e300;
+                return true;
+            },
+            [&](int lane, Probe &st, int c) {
+                const int hi = (c + 1) * 8 < cnt ? (c + 1) * 8 : cnt;
+                double b = st.b;
+                for (int i = c * 8; i < hi; i++) {
+                    const double *d = S.py[S.dl[k - 1][i]];
+                    const double val = d[0] * st.rem[0] + d[1] * st.rem[1] + d[2] * st.rem[2] + d[3] * st.rem[3] + (double)S.dpen[k - 1][i];
+                    b = val < b ? val : b;
+                }
+                st.b = b;
+                const double bound = st.base + b;
+                return mode == MODE_FIND ? bound >= cut : bound > cut;
+            });
         if (!mask) { if (wv.first()) S.ptr[k] = p - WAVE; wv.sync(); continue; }
         const int l = wv.ctz(mask);
-        const int64_t v = p - l;
+        const int32_t v = p - l;
         if (wv.first()) {
             S.xsel[pos] = (uint32_t)v;
             S.ptr[k] = v - 1;
-            for (int r = 0; r < MMAX; r++) S.rem[k - 1][r] = S.rem[k][r] - v * S.wa[r][pos];
+            for (int r = 0; r < MMAX; r++) S.rem[k - 1][r] = fma(-(double)v, S.wa[r][pos], S.rem[k][r]);
             S.zfix[k - 1] = zk + cj * (double)v;
             S.ub[k - 1] = level_ub(S, k - 1);
             S.ptr[k - 1] = S.ub[k - 1];
@@ -588,9 +658,25 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
         return;
     }
     const int n = S.n, m = S.m;
-    const uint32_t total = S.binom[n + m][m];
+    const uint32_t total = binom((uint32_t)(n + m), m);
     wv.each([&](int lane) { for (uint32_t t = (uint32_t)lane; t < total; t += WAVE) dual_candidate(wv, S, t); });
     wv.sync();
+    {   // pool order: ascending y . cap (rank counting; the keys sit in the not-yet-used penalty array)
+        const uint32_t np = S.npool < (uint32_t)PCAP ? S.npool : (uint32_t)PCAP;
+        float *pkey = &S.dpen[0][0];
+        static_assert((NMAX + 1) * DPRE >= PCAP, "pool keys overlay dpen");
+        wv.each([&](int lane) { for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) pkey[i] = (float)(S.py[i][0] * S.cap[0] + S.py[i][1] * S.cap[1] + S.py[i][2] * S.cap[2] + S.py[i][3] * S.cap[3]); });
+        wv.sync();
+        wv.each([&](int lane) {
+            for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) {
+                const float mine = pkey[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < np; j++) { const float o = pkey[j]; rank += (o < mine || (o == mine && j < i)) ? 1u : 0u; }
+                S.porder[rank] = (uint16_t)i;
+            }
+        });
+        wv.sync();
+    }
     if (prof && wv.first()) prof[2] = wv.now();
     wv.each([&](int lane) { greedy_lane(S, lane); });
     wv.sync();
@@ -598,7 +684,7 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
     {
         int l = 0;
         const double top = wv.argmax([&](int lane) { return S.lane_val[lane]; }, &l);
-        if (wv.first()) { S.best = top; for (int j = 0; j < n; j++) S.xbest[j] = S.gx[l][j]; }
+        if (wv.first()) { S.best = top; for (int j = 0; j < n; j++) S.xbest[j] = S.gx[j][l]; }
         wv.sync();
     }
     const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
@@ -607,7 +693,7 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
     // phase 1 unless the incumbent already meets the root bound
     setup_work(wv, S, all, -1, 0);
     {
-        int64_t cap[MMAX];
+        double cap[MMAX];
         for (int r = 0; r < MMAX; r++) cap[r] = S.cap[r];
         const double root = lp_bound(S, n, cap);
         if (!(root <= S.best + 1e-12 * S.best)) {
@@ -624,14 +710,14 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
     // fail that at once), then by bisection, as csrc/milp.cpp does
     if (ok) {
         const double thr = S.best - 1e-9 * (S.best < 0 ? -S.best : S.best);
-        int64_t capf[MMAX];
+        double capf[MMAX];
         for (int r = 0; r < MMAX; r++) capf[r] = S.cap[r];
         double zf = 0.0;
         for (int j = n - 1; j >= 0 && ok; j--) {
-            int64_t lo = 0, hi = (int64_t)S.xbest[j];
+            int32_t lo = 0, hi = (int32_t)S.xbest[j];
             bool first = true;
             while (lo < hi && ok) {
-                const int64_t mid = first ? hi - 1 : (lo + hi) / 2;
+                const int32_t mid = first ? hi - 1 : (lo + hi) / 2;
                 first = false;
                 setup_work(wv, S, j >= 31 ? all : (all & ((2u << j) - 1u)), j, mid);
                 if (wv.first()) { for (int r = 0; r < MMAX; r++) S.rem[S.wn][r] = capf[r]; S.zfix[S.wn] = zf; }
@@ -642,10 +728,10 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
 #ifdef HQB_TRACE
                 { uint32_t mx = 0; for (int k = 1; k <= S.wn; k++) mx = S.dcnt[k] > mx ? S.dcnt[k] : mx; if (mx > g_trace_maxlist) g_trace_maxlist = mx; if (S.npool > g_trace_maxpool) g_trace_maxpool = S.npool; g_trace_probes++; }
 #endif
-                if (found) hi = (int64_t)S.xbest[j]; else lo = mid + 1;
+                if (found) hi = (int32_t)S.xbest[j]; else lo = mid + 1;
             }
             const uint32_t xj = S.xbest[j];
-            for (int r = 0; r < MMAX; r++) capf[r] -= (int64_t)xj * S.a[r][j];
+            for (int r = 0; r < MMAX; r++) capf[r] -= (double)xj * S.a[r][j];
             zf = zf + S.c[j] * (double)xj;
         }
     }
@@ -668,6 +754,17 @@ struct HostWave {
     static int ctz(uint64_t m) { int i = 0; while (!((m >> i) & 1)) i++; return i; }
     template <class F> void each(F f) { for (int l = 0; l < WAVE; l++) f(l); }
     template <class F> uint64_t ballot(F f) { uint64_t m = 0; for (int l = 0; l < WAVE; l++) if (f(l)) m |= 1ull << l; return m; }
+    // lanes whose init() holds and whose chunk(c) holds for every c < nchunks.  The device stops as soon as no lane is left (block_solve.hip).
+    template <class I, class Ch> uint64_t ballot_chunked(int nchunks, I init, Ch chunk) {
+        uint64_t m = 0;
+        for (int l = 0; l < WAVE; l++) {
+            Probe st;
+            bool alive = init(l, st);
+            for (int c = 0; c < nchunks && alive; c++) alive = chunk(l, st, c);
+            if (alive) m |= 1ull << l;
+        }
+        return m;
+    }
     template <class F> double argmax(F f, int *lane) {  // largest value, lowest lane among equals; *lane = -1 when every value is negative
         double best = -1.0; int bl = -1;
         for (int l = 0; l < WAVE; l++) { double v = f(l); if (v > best) { best = v; bl = l; } }

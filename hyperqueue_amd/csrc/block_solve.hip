@@ -24,6 +24,15 @@ struct DevWave {
     __device__ static int ctz(uint64_t m) { return __ffsll((long long)m) - 1; }
     template <class F> __device__ void each(F f) { f((int)threadIdx.x); }
     template <class F> __device__ uint64_t ballot(F f) { return __ballot(f((int)threadIdx.x) ? 1 : 0); }
+    template <class I, class Ch> __device__ uint64_t ballot_chunked(int nchunks, I init, Ch chunk) {
+        Probe st;
+        bool alive = init((int)threadIdx.x, st);
+        for (int c = 0; c < nchunks; c++) {
+            if (!__ballot(alive ? 1 : 0)) break;  // every child is pruned: the remaining duals cannot bring one back
+            if (alive) alive = chunk((int)threadIdx.x, st, c);
+        }
+        return __ballot(alive ? 1 : 0);
+    }
     template <class F> __device__ double argmax(F f, int *lane) {
         // butterfly over the wavefront: every lane ends with (largest value, lowest lane holding it)
         double v = f((int)threadIdx.x);

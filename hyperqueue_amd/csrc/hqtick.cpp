@@ -76,9 +76,9 @@ struct hqtick_ctx {
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
     PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_retr, h_blk;
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
-    uint32_t block_budget = 4096, block_min_classes = 1;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
+    uint32_t block_budget = 4096, block_min_classes = 12;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
     // workers / requests
-    DevBuf d_up, d_vflags, d_vtmc;
+    DevBuf d_up, d_vflags, d_vtmc, d_blk;
     // selection + mapping
     DevBuf d_sel_task, d_sel_level, d_map, d_rec, d_tsweep, d_bits, d_pre;
     hqhost::Problem pb;
@@ -374,10 +374,14 @@ struct DeviceBlocks : hqhost::BlockSolver {
                      o_pool = o_amt + (size_t)ne * 8, o_free = (o_pool + (size_t)R * 8 + 15) & ~(size_t)15, o_tot = o_free + (size_t)nd * R * 8, o_elig = o_tot + (size_t)nd * R * 8,
                      o_x = o_elig + (size_t)nd * 8, o_st = o_x + al8((size_t)nd * NC * 4), o_steps = o_st + al8((size_t)nd * 4), bytes = o_steps + al8((size_t)nd * 4) + 64;
         if (!ctx->h_blk.ensure(bytes)) return false;
-        unsigned char *h = ctx->h_blk.as<unsigned char>(), *d = ctx->h_blk.dev<unsigned char>();
+        if (!ctx->d_blk.ensure(o_x + 64)) return false;
+        unsigned char *h = ctx->h_blk.as<unsigned char>(), *d = ctx->d_blk.as<unsigned char>(), *dpin = ctx->h_blk.dev<unsigned char>();
         memcpy(h + o_off, ct.ent_off, (size_t)(NC + 1) * 4); memcpy(h + o_res, ct.ent_res, (size_t)ne * 4); memcpy(h + o_w, ct.weight, (size_t)NC * 4);
         memcpy(h + o_kind, ct.ent_kind, ne); memcpy(h + o_amt, ct.ent_amount, (size_t)ne * 8); memcpy(h + o_pool, ct.pool, (size_t)R * 8);
         memcpy(h + o_free, cl.free_, (size_t)nd * R * 8); memcpy(h + o_tot, cl.total, (size_t)nd * R * 8); memcpy(h + o_elig, cl.elig, (size_t)nd * 8);
+        // inputs: one copy into HBM (929 wavefronts reading the same table through PCIe reads would queue behind each other); outputs: written by the
+        // kernel straight into pinned memory
+        if (hipMemcpyAsync(d, h, o_x, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
         hqblock::ColTable dct{NC, R, (const uint32_t *)(d + o_off), (const uint32_t *)(d + o_res), (const uint8_t *)(d + o_kind), (const uint64_t *)(d + o_amt), (const uint32_t *)(d + o_w), (const double *)(d + o_pool), d, (uint32_t)o_free};  // [0, o_free) = the column table: staged into LDS by the kernel
         hqblock::ClassTable dcl{nd, (const uint64_t *)(d + o_free), (const uint64_t *)(d + o_tot), (const uint64_t *)(d + o_elig)};
         uint64_t *dprof = nullptr;
@@ -386,7 +390,7 @@ struct DeviceBlocks : hqhost::BlockSolver {
             memset(ctx->h_blkprof.p, 0, (size_t)nd * 64);
             dprof = ctx->h_blkprof.dev<uint64_t>(); ctx->n_blkprof = nd;
         }
-        hqblock::Output dout{(uint32_t *)(d + o_x), (uint32_t *)(d + o_st), (uint32_t *)(d + o_steps), dprof};
+        hqblock::Output dout{(uint32_t *)(dpin + o_x), (uint32_t *)(dpin + o_st), (uint32_t *)(dpin + o_steps), dprof};
         if (ctx->timing && hipEventRecord(ctx->ev[9], ctx->stream) != hipSuccess) return false;
         if (hqblock::block_solve(dct, dcl, dout, ctx->block_budget, ctx->stream) != hipSuccess) return false;
         if (ctx->timing && hipEventRecord(ctx->ev[10], ctx->stream) != hipSuccess) return false;
@@ -902,7 +906,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
-                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8};
+                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8, &ctx->d_blk};
     for (DevBuf *b : bufs) b->release();
     if (ctx->qctx) { hqtick_destroy(ctx->qctx); ctx->qctx = nullptr; }
     hipSetDevice(ctx->device);

@@ -28,7 +28,7 @@ def _tick(cfg=None, **env):
 
 @pytest.fixture(scope="module")
 def dev():
-    return _tick()
+    return _tick(HQTICK_BLOCK_MIN_CLASSES=1)  # default: 12 classes before the launch pays off (tools/block_threshold.py)
 
 
 @pytest.fixture(scope="module")
@@ -90,7 +90,7 @@ def test_fuzz_family_device_blocks_equal_host_blocks(dev, host_blocks, seed):
 
     cfg, envs, _rng = f.build(seed)
     snap = envs[1].snapshot()
-    a, b = _tick(cfg), _tick(cfg, HQTICK_BLOCK_MIN_CLASSES=1 << 30)
+    a, b = _tick(cfg, HQTICK_BLOCK_MIN_CLASSES=1), _tick(cfg, HQTICK_BLOCK_MIN_CLASSES=1 << 30)  # even a single class goes through the kernel
     try:
         ra, rb = a.tick(snap), b.tick(snap)
     finally:
