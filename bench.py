@@ -260,6 +260,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="N > 1: weak = the workload grows with N (default for c2 / c3), strong = the configuration as written (default for c4 = BASELINE configs[3])")
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
     ap.add_argument("--priority-ticks", type=int, default=1, help="ticks of the three-priority-level variant c3p (0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=20, help="steps of the steady-state (delta-updated resident set) measurement, 0 = skip")
@@ -267,6 +268,7 @@ def main():
     ap.add_argument("--dag-steps", type=int, default=12, help="ticks of the config-5 loop (1 M-node DAG in the device graph + 10 %% worker churn per tick), 0 = skip")
     ap.add_argument("--dag-classes", type=int, default=2, help="request classes of the config-5 DAG (first N of the c3 classes; 8 = all, every tick then runs into the MILP time limit)")
     ap.add_argument("--wire-iters", type=int, default=50, help="launch triples of the wire-encoding measurement (row f3, in a subprocess), 0 = skip")
+    ap.add_argument("--no-b2b", dest="b2b", action="store_false", help="skip the 100 back-to-back launches of K1 / K4 (so that a rocprofv3 summary of this run averages the in-tick launches only)")
     ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
     ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
@@ -300,7 +302,10 @@ def main():
     # the shards' assignment vectors; rank 0 then pulls the merged vector to the host.  Weak scaling: 1024 workers and 1 M ready tasks
     # per GPU, so every request class stays saturated and each rank emits the same number of records as the N = 1 run.
     n_workers_per_gpu, n_tasks_per_gpu = {"c2": (256, 100_000), "c3": (1024, 1_000_000), "c4": (4096, 1_000_000)}.get(args.workload, (1024, 1_000_000))
-    snap = workloads.make(args.workload, seed=args.seed, n_tasks=n_tasks_per_gpu * world, n_workers=n_workers_per_gpu * world)
+    # --scaling strong: the configuration as BASELINE.json writes it, whatever N is (configs[3]: c4 = 4096 workers, 1 M tasks, hash-sharded over the GPUs)
+    scaling = args.scaling or ("strong" if args.workload == "c4" else "weak")
+    mult = world if scaling == "weak" else 1
+    snap = workloads.make(args.workload, seed=args.seed, n_tasks=n_tasks_per_gpu * mult, n_workers=n_workers_per_gpu * mult)
     cfg = abi.make_config(time_limit_s=5.0, device_index=local_rank)
     if args.no_kernel_timing:
         cfg.flags |= 1
@@ -313,7 +318,7 @@ def main():
     else:
         from hyperqueue_amd.sharded import ShardedTick
 
-        st = ShardedTick(cfg, rank=rank, world=world, records_per_shard=int(1.5 * 200 * n_workers_per_gpu))
+        st = ShardedTick(cfg, rank=rank, world=world, records_per_shard=int(1.5 * 200 * n_workers_per_gpu * mult / world) + 4096)
         st.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
         tick = st.t
         host_merged = None
@@ -333,6 +338,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    tick.set_kernel_timing(False)  # the timed region carries no timing events at all
     for _ in range(args.warmup):
         step()
     barrier()
@@ -342,11 +348,18 @@ def main():
         t0 = time.perf_counter()
         res = step()
         lat.append(time.perf_counter() - t0)
-        kstats.append(tick.kernel_stats())
         stages.append((res.t_scan_us, res.t_batches_us, res.t_solve_us, res.t_mapping_us, res.t_total_us))
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t_begin
+    # per-kernel durations: a second pass over the same ticks with every measured kernel bracketed by start / stop events at its dispatch
+    # (hipExtLaunchKernel — the kernel's own duration, as rocprofv3's kernel trace reports it)
+    if not args.no_kernel_timing:
+        tick.set_kernel_timing(True)
+    for _ in range(max(10, min(args.steps, 50))):
+        step()
+        kstats.append(tick.kernel_stats())
+    torch.cuda.synchronize()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -381,20 +394,22 @@ def main():
     # kernel trace agrees with, profiles/r01/final/).  `achieved` uses the back-to-back figure; the in-tick one is reported next to it.
     dom = "level_hist"
     b2b = {}
-    if world == 1 and not args.force_sharded and not args.no_kernel_timing:
+    if world == 1 and not args.force_sharded and not args.no_kernel_timing and args.b2b:
         for which, nm in ((0, "level_hist"), (1, "select_scatter")):
             b2b[nm] = round(tick.time_kernel(which, 100), 2)
             kernels[nm]["us_back_to_back"] = b2b[nm]
             kernels[nm]["GBps_back_to_back"] = kernels[nm]["bytes"] / (b2b[nm] * 1e-6) / 1e9
-    dom_us = b2b.get(dom, kernels[dom]["us"])
+    dom_us = kernels[dom]["us"]  # the launch inside the tick (K1 + the K2 ride-along workgroups), dispatch-level events
     achieved, peak = (kernels[dom]["bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0), 8000.0
+    pcie_peak = 63.0  # GB/s, PCIe Gen5 x16 one direction (what K5b's stores into pinned host memory cross)
+    em = kernels["expand_mapping"]
     value = total_assigned * args.steps / elapsed
     out = {
         "metric": "tasks_assigned_per_sec", "value": value, "unit": "tasks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {n_ready} ready tasks x {W} workers x {R} resource kinds, {len(snap.requests)} request classes, cold tick",
-                   "parallelism": "single" if world == 1 else f"worker-shards x{world}: FxHash(worker_id) % {world}, ready set replicated, one RCCL all-gather of the record sinks, merged vector D2H on rank 0",
+                   "parallelism": "single" if world == 1 else f"worker-shards x{world}: FxHash(worker_id) % {world}, ready set replicated, one RCCL all-gather of the record sinks inside libhqtick.so (hqtick_shard_allgather), merged vector D2H on rank 0",
                    "ready_set": "resident in HBM", "seed": args.seed},
         "p50_tick_ms": 1e3 * float(np.median(lat)), "p95_tick_ms": 1e3 * float(np.percentile(lat, 95)),
         "assigned_per_tick": assigned, "prefilled_per_tick": prefilled,
@@ -404,12 +419,17 @@ def main():
         "kernels": kernels,
         "tick_stages_us": dict(zip(["gpu_phase_a_scans", "batches", "solve", "mapping_plan_gpu_phase_c", "total_in_library"], [round(float(x), 1) for x in np.median(np.asarray(stages), axis=0)])),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                     "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": dom_us, "avg_launch_us_in_tick_events": kernels[dom]["us"],
+                     "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": dom_us, "avg_launch_us_back_to_back": b2b.get(dom),
                      "traffic": TRAFFIC.get(dom) if args.workload == "c3" else None,
-                     "timing": "HIP events on the library's stream: avg_launch_us = 100 back-to-back launches after the timed region; avg_launch_us_in_tick_events = one bracketed "
-                               "launch inside every timed tick (adds event/dispatch latency of an idle stream); rocprofv3 kernel trace in profiles/r01/final/",
-                     "note": "K1 streams the whole ready set (12 B/task); at 1 M tasks a launch is latency-bound (12 MB = 1.9 us at 6.3 TB/s achievable) — see roofline_vs_n for the "
-                             "same kernel on larger ready sets.  expand_mapping takes longer but is PCIe-bound by design: it writes the result into host memory (kernels.expand_mapping)"},
+                     "timing": "start / stop events at the dispatch of the launch INSIDE the tick (hipExtLaunchKernel), averaged over the stats pass after the timed region; "
+                               "the rocprofv3 kernel trace of this command (profiles/r02/) lists the same launches",
+                     "note": "K1 streams the whole ready set (12 B/task).  At 1 M tasks the set (20 MB) lives in the 256 MiB Infinity Cache across ticks and a launch is latency-bound "
+                             "(12 MB = 1.9 us at 6.3 TB/s achievable): see roofline_vs_n / profiles/r02 for the same kernel beyond the cache.  The K2 ride-along workgroups of the same "
+                             "launch read the worker tables from pinned host memory (PCIe round trips), which is what stretches the in-tick launch over the stand-alone one"},
+        "roofline_time_dominant_kernel": {"kernel": "expand_mapping", "bound": "pcie", "achieved": em["GBps"] / 2.0, "peak": pcie_peak, "unit": "GB/s",
+                                          "frac": em["GBps"] / 2.0 / pcie_peak, "bytes_over_pcie_per_launch": em["bytes"] // 2, "avg_launch_us": em["us"],
+                                          "note": "K5b writes the records (10 B each) straight into the caller's pinned host buffer: the launch lasts as long as the PCIe writes do; "
+                                                  "its HBM side (the same 10 B per record gathered from the selection) is negligible"},
     }
     if world == 1 and not args.force_sharded and not args.no_kernel_timing and args.roofline_sweep:
         sweep = []

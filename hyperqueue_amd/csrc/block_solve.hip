@@ -7,8 +7,10 @@
 // XCD-aware mapping is needed.  Integer / f64 scalar work on data that lives in LDS: not an HBM-bound kernel, not MFMA work either — its
 // figure of merit is classes solved per second.  The algorithm is in block_core.h (shared with the CPU emulation the tests run).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "block_core.h"
+#include "kernels.h"
 #include "block_solve.h"
 
 namespace hqblock {
@@ -58,7 +60,8 @@ __global__ __launch_bounds__(WAVE) void k_block_solve(ColTable ct, ClassTable cl
 
 hipError_t block_solve(const ColTable &ct, const ClassTable &cl, const Output &out, uint32_t budget, hipStream_t s) {
     if (cl.n_classes == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_block_solve, dim3(cl.n_classes), dim3(WAVE), 0, s, ct, cl, out, budget);
+    hqk::LaunchTimer t = hqk::take_launch_timer();
+    hipExtLaunchKernelGGL(k_block_solve, dim3(cl.n_classes), dim3(WAVE), 0, s, t.start, t.stop, 0, ct, cl, out, budget);
     return hipGetLastError();
 }
 

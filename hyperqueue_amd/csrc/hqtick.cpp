@@ -306,13 +306,12 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
             while (((N + tpw - 1) / tpw) * sc->G > (1ull << 24)) tpw *= 2;  // keep the per-slice table under 64 MiB
             g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw); g.tab_stride = (g.n_waves + 15u) & ~15u;
             if (!ctx->d_wave_tab.ensure((size_t)g.tab_stride * sc->G * 4) || !ctx->d_gkey.ensure(N * 2 + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
-            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+            if (ctx->timing) hqk::time_next_launch(ctx->ev[2], ctx->ev[3]);
             HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
                                    ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, &wea, ctx->stream));
-            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+            if (ctx->timing) hqk::time_next_launch(ctx->ev[0], ctx->ev[8]);
             HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
                                    reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream));
-            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[8], ctx->stream));
             if (s->n_retracting) {  // where do the Retracting tasks sit in their queues?  (mapping.rs:66-80 treats them apart)
                 const uint32_t nr = s->n_retracting;
                 if (!ctx->h_retr.ensure((size_t)nr * 16 + 64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc retracting");
@@ -340,7 +339,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
             sc->hist.assign(reinterpret_cast<const uint32_t *>(h + o_hist), reinterpret_cast<const uint32_t *>(h + o_hist) + sc->G);
             float ms = 0;
             if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->stats.level_hist_us = ms * 1000.0;
-            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[8]) == hipSuccess) ctx->stats.scan_us = ms * 1000.0;
+            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[8]) == hipSuccess) ctx->stats.scan_us = ms * 1000.0;
         }
         return 0;
     }
@@ -391,9 +390,8 @@ struct DeviceBlocks : hqhost::BlockSolver {
             dprof = ctx->h_blkprof.dev<uint64_t>(); ctx->n_blkprof = nd;
         }
         hqblock::Output dout{(uint32_t *)(dpin + o_x), (uint32_t *)(dpin + o_st), (uint32_t *)(dpin + o_steps), dprof};
-        if (ctx->timing && hipEventRecord(ctx->ev[9], ctx->stream) != hipSuccess) return false;
+        if (ctx->timing) hqk::time_next_launch(ctx->ev[9], ctx->ev[10]);
         if (hqblock::block_solve(dct, dcl, dout, ctx->block_budget, ctx->stream) != hipSuccess) return false;
-        if (ctx->timing && hipEventRecord(ctx->ev[10], ctx->stream) != hipSuccess) return false;
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
         memcpy(out.x, h + o_x, (size_t)nd * NC * 4); memcpy(out.status, h + o_st, (size_t)nd * 4); memcpy(out.steps, h + o_steps, (size_t)nd * 4);
         float ms = 0;
@@ -731,12 +729,11 @@ struct TickRun {
             flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
             ctx->last_n_sel = n_sel; ctx->last_consumed = false;
             ctx->last_geom = sc.geom; ctx->last_L = L; ctx->last_Q = Q; ctx->last_G = sc.G; ctx->last_tb = o_tb; ctx->last_plan_bytes = pack.size() * 4; ctx->last_valid = true;
-            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+            if (ctx->timing) hqk::time_next_launch(ctx->ev[4], ctx->ev[5]);
             HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
                                 d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, pack.size() * 4, nullptr, ctx->stream));
-            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+            if (ctx->timing) hqk::time_next_launch(ctx->ev[1], ctx->ev[6]);
             HQ_HIP(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
-            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
             uint8_t *drec = ctx->h_rec.dev<uint8_t>();  // K5b writes the records straight into the caller-visible pinned buffer (PCIe-bound, no copy command)
             uint64_t *k_task = reinterpret_cast<uint64_t *>(drec); uint8_t *k_var = drec + o_rv, *k_kind = drec + o_rk;
             if (ctx->sink) {  // multi-GPU: records stay in HBM, laid out for the all-gather (include/hqtick.h)
@@ -753,9 +750,9 @@ struct TickRun {
                 HQ_HIP(hipMemcpyAsync(sk, ctx->h_sinkhdr.p, hdr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
                 k_task = reinterpret_cast<uint64_t *>(sk + so_task); k_var = sk + so_var; k_kind = sk + so_kind;
             }
+            if (ctx->timing) hqk::time_next_launch(ctx->ev[7], ctx->ev[11]);
             HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
                                 reinterpret_cast<uint32_t *>(drec + o_fl), ctx->stream));
-            if (ctx->timing) HQ_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
             // multi-node tasks: the heads of their queues
             {
                 size_t pos = 0;
@@ -771,8 +768,8 @@ struct TickRun {
             if (flags[0]) return fail(ctx, HQTICK_E_CAPACITY, "mapping kernel capacity exceeded");
             float ms = 0;
             if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->stats.select_us = ms * 1000.0;
-            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->stats.sweep_us = ms * 1000.0;
-            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
+            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[6]) == hipSuccess) ctx->stats.sweep_us = ms * 1000.0;
+            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[11]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
         }
         if (!n_sel) { ctx->last_n_sel = 0; ctx->last_consumed = true; }
         if (!n_sel && ctx->sink) {  // nothing placed: still publish an empty, well-formed sink
@@ -1355,6 +1352,12 @@ const uint64_t *hqtick_block_profile_last(const hqtick_ctx *ctx, uint32_t *n_cla
     if (!ctx || !ctx->block_profile || !ctx->n_blkprof) { if (n_classes) *n_classes = 0; return nullptr; }
     if (n_classes) *n_classes = ctx->n_blkprof;
     return ctx->h_blkprof.as<uint64_t>();
+}
+
+int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on) {
+    if (!ctx) return HQTICK_E_INVALID;
+    ctx->timing = on != 0;
+    return 0;
 }
 
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out) {

@@ -6,6 +6,13 @@
 
 namespace hqk {
 
+// Kernel timing: the NEXT launch of one of the measured kernels (K1, K1b, K4, K5a, K5b, k_block_solve) on this thread is bracketed by these two
+// events at the dispatch itself (hipExtLaunchKernelGGL: the events take their timestamps from the kernel's own start / completion signal — the
+// source rocprofv3's kernel trace reads — not from markers queued around it, which add the event's own dispatch latency).
+void time_next_launch(hipEvent_t start, hipEvent_t stop);
+struct LaunchTimer { hipEvent_t start = nullptr, stop = nullptr; };
+LaunchTimer take_launch_timer();
+
 // Capacity of the distinct-priority hash set (power of two).  More distinct priority levels than
 // HQK_PRIO_SET_CAP/2 in one ready set is reported as HQTICK_E_CAPACITY.
 static const uint32_t PRIO_SET_CAP = 1u << 15;

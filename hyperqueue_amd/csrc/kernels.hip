@@ -12,6 +12,19 @@
 // K5a/K5b expand per-(request, variant, worker) counts into per-worker records (mapping.rs:36-131): K5a one wavefront per
 // (key, sweep) builds ballot bit rows of the round-robin, K5b one workgroup per worker gathers its records.
 #include "kernels.h"
+#include <hip/hip_ext.h>
+
+namespace hqk {
+namespace { thread_local LaunchTimer g_timer; }
+void time_next_launch(hipEvent_t start, hipEvent_t stop) { g_timer.start = start; g_timer.stop = stop; }
+LaunchTimer take_launch_timer() { LaunchTimer t = g_timer; g_timer = LaunchTimer{}; return t; }
+}  // namespace hqk
+// a measured launch: bracketed by the pending timer's events (if any) at the dispatch
+#define HQK_TIMED_LAUNCH(kern, grid, block, lds, s, ...)                                                  \
+    do {                                                                                                  \
+        hqk::LaunchTimer t_ = hqk::take_launch_timer();                                                   \
+        hipExtLaunchKernelGGL(kern, grid, block, lds, s, t_.start, t_.stop, 0, __VA_ARGS__);              \
+    } while (0)
 
 namespace hqk {
 
@@ -728,7 +741,7 @@ hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, cons
         if (eval_lds > lds) lds = eval_lds;                                                                                                          \
         auto kern = k_level_hist<WPB, SMALL>;                                                                                                        \
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e; \
-        hipLaunchKernelGGL(kern, dim3((GRID) + neb), dim3(BLOCK), lds, s, prio, rq, n, levels, l4, L, Q, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, ll, wave_tab, gkey, \
+        HQK_TIMED_LAUNCH(kern, dim3((GRID) + neb), dim3(BLOCK), lds, s, prio, rq, n, levels, l4, L, Q, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, ll, wave_tab, gkey, \
                            err_flag, neb, ea);                                                                                                       \
     } while (0)
     if (geom.waves_per_block == 4) { if (small) HQK_LAUNCH_HIST(4, true, (geom.n_waves + 3) / 4, 256); else HQK_LAUNCH_HIST(4, false, (geom.n_waves + 3) / 4, 256); }
@@ -739,7 +752,7 @@ hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, cons
 
 hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, uint32_t *err_in, uint32_t *err_out, hipStream_t s) {
     if (G == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scan_rows, dim3((G + 3) / 4), dim3(256), 0, s, wave_tab, geom.n_waves, geom.tab_stride, G, hist, err_in, err_out);
+    HQK_TIMED_LAUNCH(k_scan_rows, dim3((G + 3) / 4), dim3(256), 0, s, wave_tab, geom.n_waves, geom.tab_stride, G, hist, err_in, err_out);
     return hipGetLastError();
 }
 
@@ -759,7 +772,7 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
         for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; }
         size_t lds = (size_t)6 * G * 4;
         const uint32_t nsb = (geom.n_waves + 3) / 4, ncb = n16 ? (n16 + 1023) / 1024 : 0;
-        hipLaunchKernelGGL((k_select<4, 0>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
+        HQK_TIMED_LAUNCH((k_select<4, 0>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
                            reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq);
         return hipGetLastError();
@@ -775,14 +788,14 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
         auto kern = k_select<4, 1>;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         const uint32_t nsb = (geom.n_waves + 3) / 4;
-        hipLaunchKernelGGL(kern, dim3(nsb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
+        HQK_TIMED_LAUNCH(kern, dim3(nsb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
                            sel_task, sel_key, nsb, (const uint4 *)nullptr, (uint4 *)nullptr, 0u, mark_rq);
         return hipGetLastError();
     }
     size_t lds = (size_t)G * 4;
     auto kern = k_select<1, 2>;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(geom.n_waves), dim3(64), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
+    HQK_TIMED_LAUNCH(kern, dim3(geom.n_waves), dim3(64), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
                        sel_task, sel_key, geom.n_waves, (const uint4 *)nullptr, (uint4 *)nullptr, 0u, mark_rq);
     return hipGetLastError();
 }
@@ -809,7 +822,7 @@ hipError_t sweep_bits(MapKeys mk, uint32_t max_count, uint32_t max_workers_per_k
     size_t lds = sweep_bits_lds(max_workers_per_key);
     hipError_t e;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_bits), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sweep_bits, dim3((max_count + 1 + 3) / 4, mk.n_keys), dim3(256), lds, s, mk);
+    HQK_TIMED_LAUNCH(k_sweep_bits, dim3((max_count + 1 + 3) / 4, mk.n_keys), dim3(256), lds, s, mk);
     return hipGetLastError();
 }
 
@@ -823,7 +836,7 @@ hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, cons
     size_t lds = expand_mapping_lds(max_items, mk.n_keys);
     hipError_t e;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_mapping), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, W, sel_task, sel_key, Q, max_items, rec_task, rec_variant, rec_kind, err_flag);
+    HQK_TIMED_LAUNCH(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, W, sel_task, sel_key, Q, max_items, rec_task, rec_variant, rec_kind, err_flag);
     return hipGetLastError();
 }
 

@@ -124,7 +124,7 @@ class ShardedTick:
     """
 
     def __init__(self, config: Optional[abi.Config] = None, rank: int = 0, world: int = 1, records_per_shard: int = 1 << 18,
-                 backend="hip", group=None):
+                 backend="hip", group=None, collective: str = "auto"):
         import torch
 
         self.torch = torch
@@ -134,6 +134,8 @@ class ShardedTick:
         self._sink = self._merged = None
         self._sink_workers = -1
         self.n_divergent = 0  # ticks on which the replicas disagreed and rank 0's placement was broadcast
+        self.collective = "torch"
+        self._fallback_ids = None
         if backend == "hip":
             from .tick import Tick
 
@@ -146,6 +148,29 @@ class ShardedTick:
             rc = lib.hqtick_set_shard(self.t._ctx, rank, world)
             if rc:
                 raise RuntimeError(f"hqtick_set_shard failed: {rc}")
+            # The merge collective lives INSIDE the C ABI (hqtick_comm_init / hqtick_shard_allgather: librccl, loaded by the library): a Rust host
+            # needs nothing else.  torch.distributed only carries the 128-byte communicator id from rank 0 to the other ranks here — the job any
+            # out-of-band channel of the host (its own TCP connections) would do.  collective="torch" keeps the all_gather_into_tensor path.
+            if collective == "auto":  # the library's collective whenever this process really is one rank of `world` (else: shards simulated in one process)
+                d = torch.distributed
+                collective = "library" if (world > 1 and d.is_available() and d.is_initialized() and d.get_world_size(group) == world) else "torch"
+            self.collective = collective
+            if collective == "library":
+                lib.hqtick_comm_unique_id.argtypes = [C.c_void_p]
+                lib.hqtick_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+                lib.hqtick_shard_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+                uid = (C.c_ubyte * 128)()
+                if rank == 0:
+                    rc = lib.hqtick_comm_unique_id(uid)
+                    if rc:
+                        raise RuntimeError(f"hqtick_comm_unique_id failed: {rc}")
+                if world > 1:
+                    box = [bytes(uid)]
+                    torch.distributed.broadcast_object_list(box, src=0, group=group)
+                    uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+                rc = lib.hqtick_comm_init(self.t._ctx, uid, rank, world)
+                if rc:
+                    raise RuntimeError(f"hqtick_comm_init failed: {rc}: {self.t._err()}")
 
     def _buffers(self, n_workers: int):
         if self._sink_workers != n_workers:
@@ -173,7 +198,11 @@ class ShardedTick:
         """The timed part on the GPU: sharded tick + the one all-gather.  Returns (local ResultC, merged device tensor)."""
         sink, merged = self._buffers(n_workers)
         res = self.t.tick_raw(sc, resident=resident)  # returns after this shard's kernels have finished (stream-synchronised)
-        if self.world > 1:
+        if self.collective == "library":  # ncclAllGather on the ctx's stream, inside libhqtick.so; returns when the merged vector is there
+            rc = self.t._lib.hqtick_shard_allgather(self.t._ctx, C.c_void_p(merged.data_ptr()), C.c_size_t(merged.numel()))
+            if rc:
+                raise RuntimeError(f"hqtick_shard_allgather failed: {rc}: {self.t._err()}")
+        elif self.world > 1:
             self.torch.distributed.all_gather_into_tensor(merged, sink, group=self.group)
         else:
             merged.copy_(sink)
@@ -195,12 +224,24 @@ class ShardedTick:
                 merged.copy_(sink)
             out = full
             host = merged.numpy()
+        self._fallback_ids = None
         try:
             out.records = merge_shards(host, self.world, W, self.cap)
         except ShardDivergence:
             out = self._fallback_from_rank0(snap, resident)
             self.n_divergent += 1
+            # what the applied placement handed out: the ranks other than 0 still hold their own (divergent) selection as "last tick"
+            self._fallback_ids = np.asarray(sorted([t for recs in out.records for (t, _v, _k) in recs] + [t for (t, _ws) in out.mn]), np.uint64)
         return out
+
+    def consume_last(self):
+        """hqtick_ready_consume_last for the sharded scheduler: every replica's resident ready set loses what the APPLIED placement handed out.
+        After a divergence that is rank 0's placement, which the other ranks remove by id (their own last selection is not what was applied)."""
+        if getattr(self, "_fallback_ids", None) is not None and self.rank != 0:
+            self.t.ready_remove(self._fallback_ids)
+        else:
+            self.t.ready_consume_last()
+        self._fallback_ids = None
 
     def _fallback_from_rank0(self, snap: abi.Snapshot, resident: bool) -> abi.Result:
         """The replicas disagree (a time-limited tick): every rank takes rank 0's placement.  Rank 0 repeats the tick unsharded into a sink that

@@ -194,6 +194,10 @@ class Tick:
             raise HqTickError(rc, self._err())
         return us.value
 
+    def set_kernel_timing(self, on: bool):
+        self._lib.hqtick_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self._lib.hqtick_set_kernel_timing(self._ctx, 1 if on else 0))
+
     def kernel_stats(self) -> dict:
         ks = abi.KernelStatsC()
         self._lib.hqtick_kernel_stats_last(self._ctx, C.byref(ks))

@@ -415,6 +415,10 @@ typedef struct hqtick_kernel_stats {
                                                   (launch + wait included), counts into the reference's Map iteration order */
 } hqtick_kernel_stats;
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
+/* Switch the per-kernel timing on / off at run time (HQTICK_FLAG_NO_KERNEL_TIMING sets the initial state).  When on, the measured kernels are
+ * bracketed by start / stop events AT THE DISPATCH (hipExtLaunchKernel): the duration is the kernel's own, the figure rocprofv3's kernel trace
+ * reports, without the latency of markers queued around it. */
+int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on);
 /* Re-launches one streaming kernel of the last resident tick `iters` times back to back between two HIP events on the ctx's
  * stream and returns the average launch duration (which: 0 = K1 level_hist, 1 = K4 select_scatter).  GPU only. */
 int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us);

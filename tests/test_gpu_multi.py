@@ -1,0 +1,56 @@
+"""The multi-GPU path with REAL ranks: one process per GPU, every rank runs libhqtick.so (hqtick_set_shard + device record sink) and the merge is
+the library's own RCCL all-gather (hqtick_comm_init / hqtick_shard_allgather).  Needs >= 2 visible GPUs — skipped on the 1-GPU box; the
+driver's multi-GPU bench (`bench.py --gpus N`) runs the same code path."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["HQ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["HQ_ROOT"], "tests"))
+import numpy as np, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+from hyperqueue_amd import abi, sharded, workloads
+from hyperqueue_amd.tick import Tick
+snap = workloads.make("c4", n_tasks=30000, n_workers=96)
+cfg = abi.make_config(time_limit_s=20.0, device_index=rank)
+st = sharded.ShardedTick(cfg, rank=rank, world=world, records_per_shard=1 << 15)
+assert st.collective == "library"
+got = st.tick(snap)
+if rank == 0:
+    t = Tick(cfg); want = t.tick(snap); t.close()
+    assert got.counts == want.counts and got.records == want.records, "sharded != unsharded"
+# forced divergence: rank 1 pretends its replica placed differently -> every rank takes rank 0's placement, resident sets stay in step
+st.t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+import dataclasses
+res = st.tick(snap, resident=True)
+st.consume_last()
+counts = torch.tensor([st.t.ready_count()], dtype=torch.int64, device="cuda")
+allc = [torch.zeros_like(counts) for _ in range(world)]
+dist.all_gather(allc, counts)
+assert len({int(c.item()) for c in allc}) == 1, "resident ready sets diverged"
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK", rank)
+'''
+
+
+def test_two_rank_library_allgather():
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    env = dict(os.environ, HQ_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-3000:]

@@ -306,3 +306,17 @@ def test_c3_full_equals_oracle_cold_tick(gpu):
     got = gpu.tick(snap)
     want = Oracle(abi.make_config(time_limit_s=60.0), canonical=True).tick(snap)
     assert_same(got, want)
+
+
+def test_library_allgather_single_rank(gpu):
+    """hqtick_comm_unique_id / hqtick_comm_init / hqtick_shard_allgather (RCCL, loaded by libhqtick.so itself) with a world of one: the gathered
+    buffer is this rank's record sink, and the merged records equal the unsharded tick's.  (More ranks need more GPUs: tests/test_gpu_multi.py.)"""
+    from hyperqueue_amd import sharded
+
+    snap = workloads.make("c2", n_tasks=5000, n_workers=16)
+    want = gpu.tick(snap)
+    st = sharded.ShardedTick(abi.make_config(time_limit_s=20.0), rank=0, world=1, records_per_shard=1 << 14, collective="library")
+    got = st.tick(snap)
+    assert st.collective == "library"
+    assert got.records == want.records and got.counts == want.counts
+    st.t.close()
