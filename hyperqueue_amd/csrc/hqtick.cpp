@@ -108,7 +108,24 @@ namespace {
         if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return HQTICK_E_DEVICE; } \
     } while (0)
 
+// a launch wrapper that was handed a timer (hqk::time_next_launch) but returned without launching must not leave it to the next launch
+#define HQ_HIP_TIMED(call)                                                                                    \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        hqk::take_launch_timer();                                                                             \
+        if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return HQTICK_E_DEVICE; } \
+    } while (0)
+
 int fail(hqtick_ctx *ctx, int code, const std::string &msg) { ctx->err = msg; return code; }
+
+// duration between two dispatch events in us, or -1 when the pair was not recorded by a launch of this tick (the runtime's error state is
+// cleared: an unrecorded event must not surface as the "last error" of the next launch)
+double elapsed_us(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a, b) == hipSuccess) return (double)ms * 1000.0;
+    (void)hipGetLastError();
+    return -1.0;
+}
 
 int validate(hqtick_ctx *ctx, const hqtick_snapshot *s, bool need_tasks) {
     if (!s) return fail(ctx, HQTICK_E_INVALID, "null snapshot");
@@ -307,10 +324,10 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
             g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw); g.tab_stride = (g.n_waves + 15u) & ~15u;
             if (!ctx->d_wave_tab.ensure((size_t)g.tab_stride * sc->G * 4) || !ctx->d_gkey.ensure(N * 2 + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
             if (ctx->timing) hqk::time_next_launch(ctx->ev[2], ctx->ev[3]);
-            HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
+            HQ_HIP_TIMED(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
                                    ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, &wea, ctx->stream));
             if (ctx->timing) hqk::time_next_launch(ctx->ev[0], ctx->ev[8]);
-            HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
+            HQ_HIP_TIMED(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
                                    reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream));
             if (s->n_retracting) {  // where do the Retracting tasks sit in their queues?  (mapping.rs:66-80 treats them apart)
                 const uint32_t nr = s->n_retracting;
@@ -337,9 +354,8 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
         if (scan) {
             sc->levels = ctx->h_levels;
             sc->hist.assign(reinterpret_cast<const uint32_t *>(h + o_hist), reinterpret_cast<const uint32_t *>(h + o_hist) + sc->G);
-            float ms = 0;
-            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->stats.level_hist_us = ms * 1000.0;
-            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[8]) == hipSuccess) ctx->stats.scan_us = ms * 1000.0;
+            if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[2], ctx->ev[3]); if (us_ >= 0) ctx->stats.level_hist_us = us_; }
+            if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[0], ctx->ev[8]); if (us_ >= 0) ctx->stats.scan_us = us_; }
         }
         return 0;
     }
@@ -391,11 +407,12 @@ struct DeviceBlocks : hqhost::BlockSolver {
         }
         hqblock::Output dout{(uint32_t *)(dpin + o_x), (uint32_t *)(dpin + o_st), (uint32_t *)(dpin + o_steps), dprof};
         if (ctx->timing) hqk::time_next_launch(ctx->ev[9], ctx->ev[10]);
-        if (hqblock::block_solve(dct, dcl, dout, ctx->block_budget, ctx->stream) != hipSuccess) return false;
+        const hipError_t be = hqblock::block_solve(dct, dcl, dout, ctx->block_budget, ctx->stream);
+        hqk::take_launch_timer();
+        if (be != hipSuccess) return false;
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
         memcpy(out.x, h + o_x, (size_t)nd * NC * 4); memcpy(out.status, h + o_st, (size_t)nd * 4); memcpy(out.steps, h + o_steps, (size_t)nd * 4);
-        float ms = 0;
-        if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]) == hipSuccess) ctx->stats.block_solve_us = ms * 1000.0;
+        if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[9], ctx->ev[10]); if (us_ >= 0) ctx->stats.block_solve_us = us_; }
         ctx->stats.n_classes_device = nd;
         return true;
     }
@@ -730,10 +747,10 @@ struct TickRun {
             ctx->last_n_sel = n_sel; ctx->last_consumed = false;
             ctx->last_geom = sc.geom; ctx->last_L = L; ctx->last_Q = Q; ctx->last_G = sc.G; ctx->last_tb = o_tb; ctx->last_plan_bytes = pack.size() * 4; ctx->last_valid = true;
             if (ctx->timing) hqk::time_next_launch(ctx->ev[4], ctx->ev[5]);
-            HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
+            HQ_HIP_TIMED(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
                                 d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, pack.size() * 4, nullptr, ctx->stream));
             if (ctx->timing) hqk::time_next_launch(ctx->ev[1], ctx->ev[6]);
-            HQ_HIP(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
+            HQ_HIP_TIMED(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
             uint8_t *drec = ctx->h_rec.dev<uint8_t>();  // K5b writes the records straight into the caller-visible pinned buffer (PCIe-bound, no copy command)
             uint64_t *k_task = reinterpret_cast<uint64_t *>(drec); uint8_t *k_var = drec + o_rv, *k_kind = drec + o_rk;
             if (ctx->sink) {  // multi-GPU: records stay in HBM, laid out for the all-gather (include/hqtick.h)
@@ -751,7 +768,7 @@ struct TickRun {
                 k_task = reinterpret_cast<uint64_t *>(sk + so_task); k_var = sk + so_var; k_kind = sk + so_kind;
             }
             if (ctx->timing) hqk::time_next_launch(ctx->ev[7], ctx->ev[11]);
-            HQ_HIP(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
+            HQ_HIP_TIMED(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
                                 reinterpret_cast<uint32_t *>(drec + o_fl), ctx->stream));
             // multi-node tasks: the heads of their queues
             {
@@ -766,10 +783,9 @@ struct TickRun {
             assemble_host_part();
             HQ_HIP(hipStreamSynchronize(ctx->stream));
             if (flags[0]) return fail(ctx, HQTICK_E_CAPACITY, "mapping kernel capacity exceeded");
-            float ms = 0;
-            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->stats.select_us = ms * 1000.0;
-            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[6]) == hipSuccess) ctx->stats.sweep_us = ms * 1000.0;
-            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[11]) == hipSuccess) ctx->stats.other_us = ms * 1000.0;
+            if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[4], ctx->ev[5]); if (us_ >= 0) ctx->stats.select_us = us_; }
+            if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[1], ctx->ev[6]); if (us_ >= 0) ctx->stats.sweep_us = us_; }
+            if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[7], ctx->ev[11]); if (us_ >= 0) ctx->stats.other_us = us_; }
         }
         if (!n_sel) { ctx->last_n_sel = 0; ctx->last_consumed = true; }
         if (!n_sel && ctx->sink) {  // nothing placed: still publish an empty, well-formed sink

@@ -41,6 +41,16 @@ def main(dirs):
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 ctr[short(r["Kernel_Name"]) + f" grid={grid_of(r)}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if not dur:  # a counter-only pass (--pmc without a trace domain): launches and durations from the counter rows themselves
+            seen = set()
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    key = (f, r.get("Dispatch_Id"))
+                    if key in seen:
+                        continue
+                    seen.add(key)
+                    t = int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) if r.get("End_Timestamp") and r.get("Start_Timestamp") else 0
+                    dur[short(r["Kernel_Name"]) + f" grid={grid_of(r)}"].append(t)
         names = sorted(dur, key=lambda k: -sum(dur[k]))
         cols = sorted({c for k in ctr for c in ctr[k]})
         hdr = ["kernel", "launches", "avg_ns", "min_ns", "max_ns"] + [f"{c}_avg" for c in cols] + (["FETCH_SIZE_x2_bytes"] if "FETCH_SIZE" in cols else []) + (["WRITE_SIZE_bytes"] if "WRITE_SIZE" in cols else [])

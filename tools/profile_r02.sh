@@ -11,12 +11,12 @@ mkdir -p "$OUT"
 BENCH="python $ROOT/bench.py --steps 50 --warmup 5 --no-b2b --no-roofline-sweep --steady-steps 0 --hetero-steps 0 --dag-steps 0 --priority-ticks 0 --wire-iters 0 --cpu-ticks 0"
 run_trace() {  # name, command...
   local name=$1; shift
-  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/$name" -- "$@" > "$OUT/$name.log" 2>&1 )
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- "$@" > "$OUT/$name.log" 2>&1 )
   python profiles/summarize.py "$OUT/$name" > "$OUT/$name.summary.csv" 2>> "$OUT/$name.log"
 }
 run_pmc() {  # name, counter, command...
   local name=$1 c=$2; shift 2
-  ( cd /tmp && timeout 400 rocprofv3 --pmc "$c" -d "$OUT/${name}_$c" -- "$@" > "$OUT/${name}_$c.log" 2>&1 )
+  ( cd /tmp && timeout 400 rocprofv3 --pmc "$c" --output-format csv -d "$OUT/${name}_$c" -- "$@" > "$OUT/${name}_$c.log" 2>&1 )
   python profiles/summarize.py "$OUT/${name}_$c" > "$OUT/${name}_$c.summary.csv" 2>> "$OUT/${name}_$c.log"
 }
 # 1. the bench command: kernel trace, then HBM traffic counters
