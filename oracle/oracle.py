@@ -175,6 +175,24 @@ def solve_milp(obj, kind, rtype, rhs, roff, rcol, rcoef, time_limit: float = 60.
     return x, float(np.dot(obj, x)), status == 0
 
 
+_IN_LAZY = [False]
+
+
+def _column_components(A, n):
+    """connected components of the columns of A (two columns are connected when a row holds both), through the bipartite row/column graph:
+    nnz(A) edges instead of the column-by-column product, which a single row with thousands of entries blows up quadratically"""
+    from scipy.sparse import bmat, csr_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    m = A.shape[0]
+    pat = csr_matrix((np.ones(A.nnz, np.int8), A.indices, A.indptr), shape=A.shape) if hasattr(A, "indptr") else (A != 0).astype(np.int8)
+    g = bmat([[None, pat.T], [pat, None]], format="csr")  # nodes: n columns, then m rows
+    _, lab_all = connected_components(g, directed=False)
+    lab = lab_all[:n]
+    uniq, lab = np.unique(lab, return_inverse=True)
+    return len(uniq), lab
+
+
 def _solve_canonical(obj, A, lo, hi, lb, ub):
     """The tie-break convention of the MI355X path, computed with HiGHS only:
     per connected component of the row/column graph, among the feasible integer vectors whose objective is within 1e-9
@@ -184,23 +202,57 @@ def _solve_canonical(obj, A, lo, hi, lb, ub):
 
     n = len(obj)
     m = A.shape[0] if A is not None else 0
+    # Lazy counting rows.  The batch-size rows `sum x <= size` (scheduler/solver.rs:264-271: all-ones, no lower bound) are the only rows that tie the
+    # workers of a cut-free tick together; at BASELINE config 4 (4096 workers, no batch saturated) they make the model ONE component of 65 536
+    # columns on which HiGHS holds an unproven incumbent after minutes.  A relaxation argument that needs no insight into the product: drop those
+    # rows, solve what falls apart component by component, and check the dropped rows on the result — if they hold, the point is optimal for the
+    # full model (optimal for a relaxation, feasible) and, every component carrying its own lexicographic minimum, it is the canonical one.
+    # If one is violated the full model is solved as before.
+    if m and not _IN_LAZY[0]:
+        Acsr = A.tocsr()
+        nnz_row = np.diff(Acsr.indptr)
+        not_one = np.add.reduceat((Acsr.data != 1.0).astype(np.int64), np.minimum(Acsr.indptr[:-1], max(Acsr.nnz - 1, 0))) if Acsr.nnz else np.zeros(m, np.int64)
+        ones = (nnz_row > 1) & (np.where(nnz_row > 0, not_one, 1) == 0)
+        lazy = np.nonzero(ones & np.isneginf(lo) & np.isfinite(hi))[0]
+        if len(lazy):
+            keep = np.setdiff1d(np.arange(m), lazy)
+            nc_k = _column_components(Acsr[keep], n)[0] if len(keep) else n
+            if nc_k > 1:
+                _IN_LAZY[0] = True
+                try:
+                    got = _solve_canonical(obj, Acsr[keep] if len(keep) else None, lo[keep], hi[keep], lb, ub)
+                finally:
+                    _IN_LAZY[0] = False
+                if got is not None and np.all(Acsr[lazy] @ got[0] <= hi[lazy] + 1e-6):
+                    return got
     if m:
-        pat = (A != 0).astype(np.int8)
-        ncomp, lab = connected_components((pat.T @ pat), directed=False)
+        ncomp, lab = _column_components(A, n)
     else:
         ncomp, lab = n, np.arange(n)
     x = np.zeros(n)
+    memo = {}  # identical components (same rows, bounds and — to 12 digits — normalised costs) are solved once
+    order = np.argsort(lab, kind="stable")
+    starts = np.searchsorted(lab[order], np.arange(ncomp + 1))
+    Acsc = A.tocsc() if m else None
     for k in range(ncomp):
-        cols = np.nonzero(lab == k)[0]
+        cols = order[starts[k]:starts[k + 1]]
         if m:
-            rows = np.nonzero(np.asarray((pat[:, cols] != 0).sum(axis=1)).ravel() > 0)[0]
-            Ak = A[rows][:, cols]
+            sub = Acsc[:, cols]
+            rows = np.unique(sub.indices)
+            Ak = sub.tocsr()[rows]
             lok, hik = lo[rows], hi[rows]
         else:
             Ak, lok, hik = None, None, None
         c = obj[cols]
         cmax = np.abs(c).max()
         cs = c * (1e4 / cmax) if cmax > 0 else c  # O(1e4) costs: keeps HiGHS' absolute gaps (1e-6) far below real differences
+        key = None
+        if Ak is not None:
+            Ak.sort_indices()
+            key = (np.round(cs, 8).tobytes(), Ak.indptr.tobytes(), Ak.indices.tobytes(), Ak.data.tobytes(), lok.tobytes(), hik.tobytes(), lb[cols].tobytes(), ub[cols].tobytes())
+            if key in memo:
+                x[cols] = memo[key]
+                continue
         xk, status = _highs(cs, Ak, lok, hik, lb[cols], ub[cols])
         if xk is None or status != 0:
             return None
@@ -226,6 +278,8 @@ def _solve_canonical(obj, A, lo, hi, lb, ub):
                 v, xk = xj[j], xj
             l[j] = u[j] = v
         x[cols] = xk
+        if key is not None:
+            memo[key] = xk
     return x, float(np.dot(obj, x)), True
 
 

@@ -46,7 +46,7 @@ def snapshot_from_json(d: dict):
     cfg = abi.make_config(reserve=d["config"]["reserve"], fill_max=d["config"]["fill_max"], time_limit_s=60.0)
     if "ready_set_generator" in d:
         g = d["ready_set_generator"]
-        base = workloads.make(g["workload"], seed=g["seed"], n_tasks=g["n_tasks"], n_workers=g["n_workers"])
+        base = workloads.make(g["workload"], seed=g["seed"], n_tasks=g["n_tasks"], n_workers=g["n_workers"])  # (c3s / c4s: only the ready set is taken from here)
         ids, prio, rq = base.task_id, base.task_priority, base.task_rq
     else:
         ids, prio, rq = np.asarray(d["task_id"], np.uint64), np.asarray(d["task_priority"], np.uint64), np.asarray(d["task_rq"], np.uint32)
@@ -86,6 +86,59 @@ def result_digest(r: abi.Result) -> dict:
     d["records"] = None
     d["records_digest"] = recs
     return d
+
+
+def big_digest(r: abi.Result) -> dict:
+    """BASELINE-size results: SHA-256 of the count list, of every record in emission order and of the free vectors, plus the small parts in full"""
+    import hashlib
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+    counts = np.asarray(r.counts, np.uint32).reshape(-1, 4)
+    recs = np.asarray([(t, v, k, w) for w, lst in enumerate(r.records) for (t, v, k) in lst], np.uint64).reshape(-1, 4)
+    per_key = {}
+    for (q, v, w, c) in r.counts:
+        a = per_key.setdefault(f"{q}/{v}", [0, 0]); a[0] += c; a[1] += 1
+    return dict(status=r.status, is_optimal=r.is_optimal,
+                batches=[dict(rq=b.rq, size=b.size, limit=b.limit, limit_reached=b.limit_reached, is_blocker=b.is_blocker, n_cuts=len(b.cuts)) for b in r.batches],
+                n_counts=len(counts), counts_sha256=sha(counts), tasks_and_workers_per_key=per_key, n_records=len(recs), records_sha256=sha(recs),
+                n_assigned=int((recs[:, 2] == abi.HQ_REC_ASSIGN).sum()) if len(recs) else 0, new_free_sha256=sha(np.asarray(r.new_free, np.uint64)),
+                n_retracts=sum(len(x) for x in r.retracts), n_redirects=len(r.redirects), n_mn=len(r.mn))
+
+
+def big_snapshot(gen: dict):
+    """BASELINE-size snapshots are stored by their generator call only"""
+    if gen.get("steady"):
+        snap = workloads.make_steady(gen["workload"], seed=gen["seed"], n_tasks=gen.get("n_tasks"), n_workers=gen.get("n_workers"))
+    else:
+        snap = workloads.make(gen["workload"], seed=gen["seed"], n_tasks=gen.get("n_tasks"), n_workers=gen.get("n_workers"))
+    return snap, abi.make_config(time_limit_s=60.0)
+
+
+BIG = {  # name -> generator call; the oracle needs seconds (c4: one distinct worker class) to minutes (steady state: ~1000 distinct classes, HiGHS each)
+    "c4_full": dict(workload="c4", seed=0),
+    "c2_full": dict(workload="c2", seed=0),
+    "c3_full": dict(workload="c3", seed=0),
+    "c3_steady_256": dict(workload="c3", seed=4, steady=True, n_tasks=300_000, n_workers=256),
+    "c3_steady_full": dict(workload="c3", seed=0, steady=True),   # 1 M ready tasks, 1024 workers, 929 distinct worker classes
+    "c4_steady_512": dict(workload="c4", seed=2, steady=True, n_tasks=500_000, n_workers=512),
+}
+
+
+def make_big(names=None):
+    from oracle.oracle import Oracle
+
+    os.makedirs(os.path.join(HERE, "big"), exist_ok=True)
+    for name, gen in BIG.items():
+        if names and name not in names:
+            continue
+        snap, cfg = big_snapshot(gen)
+        r = Oracle(cfg, canonical=True).tick(snap)
+        assert r.is_optimal, name
+        with open(os.path.join(HERE, "big", name + ".json"), "w") as f:
+            json.dump(dict(generator=gen, expect=big_digest(r)), f, indent=1)
+        print(name, "written")
 
 
 def multi_tick_env(seed: int) -> SchedEnv:
@@ -136,4 +189,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        make_big(sys.argv[2:])
+    else:
+        main()

@@ -163,6 +163,24 @@ def test_steady_state_tick_emulated_blocks_vs_oracle(name, n_workers, seed):
         assert got.counts == want.counts
 
 
+@pytest.mark.parametrize("name", ["c4", "c3s"])
+def test_full_size_host_stages_vs_oracle(name):
+    """BASELINE SIZE on the CPU: config 4 cold (4096 workers x 2-variant OR-lists, 1 M tasks: the lazy size rows make it one 16-column block) and
+    config 3 in the steady state (1024 workers, 929 distinct classes) — the product's placement (host blocks and the emulated kernel) against the
+    canonical oracle (HiGHS per independent component, counting rows checked afterwards: oracle.py::_solve_canonical)"""
+    from oracle.oracle import Oracle
+
+    snap = workloads.make("c4") if name == "c4" else workloads.make_steady("c3", seed=0)
+    cfg = abi.make_config(time_limit_s=60.0)
+    plain = HostStages(cfg).stages(snap)
+    emu, n_emu, n_host = _emulated(cfg, snap)
+    want = Oracle(cfg, canonical=True).tick(snap)
+    assert want.is_optimal and plain.is_optimal and plain.is_canonical and emu.is_canonical
+    assert n_emu >= (1 if name == "c4" else 900) and n_host == 0
+    assert plain.batches == want.batches and plain.counts == want.counts
+    assert emu.counts == want.counts
+
+
 def test_budget_exhaustion_falls_back_to_host_solver():
     """with a step budget of 1 every searched class is handed back (status 1) and the host solver gives the same counts"""
     snap = workloads.make_steady("c3", seed=5, n_tasks=40_000, n_workers=24)

@@ -296,6 +296,30 @@ def test_c4_full_sharded_properties():
         mine = seen[: last + 1][rq_of[: last + 1] == q]
         assert mine.all()
     assert seen.sum() == sum(len(r) for r in records) > 0
+    # ... and the COUNTS, record for record: the merged shards against the committed full-size fixture (the canonical oracle's answer:
+    # HiGHS on the one distinct 16-column worker block, the batch-size rows verified afterwards — tests/golden/make_fixtures.py big)
+    import json, os, sys
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, golden)
+    from make_fixtures import big_digest
+
+    got.records = records
+    exp = json.load(open(os.path.join(golden, "big", "c4_full.json")))["expect"]
+    g = json.loads(json.dumps(big_digest(got)))
+    for key in exp:
+        assert g[key] == exp[key], key
+
+
+def test_c4_full_equals_oracle_cold_tick(gpu):
+    """BASELINE configs[3] at full size against the canonical oracle run here (a few seconds: one distinct worker class)."""
+    from oracle.oracle import Oracle
+
+    snap = workloads.make("c4")
+    got = gpu.tick(snap)
+    want = Oracle(abi.make_config(time_limit_s=60.0), canonical=True).tick(snap)
+    assert want.is_optimal
+    assert_same(got, want)
 
 
 def test_c3_full_equals_oracle_cold_tick(gpu):
