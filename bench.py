@@ -60,7 +60,7 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int):
     """BASELINE config 5 on one GPU: the 1 M-node DAG lives in the device dependency graph (hqtick_graph_*); per tick the tasks handed out by
     the previous tick finish (their consumers are released into the resident ready set on the device), 10 % of the workers are lost (their
     tasks return to the ready set) and replaced, then hqtick_run_resident + hqtick_ready_consume_last."""
-    from hyperqueue_amd import workloads
+    from hyperqueue_amd import abi, workloads
     from hyperqueue_amd.tick import Tick
 
     n = 1_000_000
@@ -80,7 +80,7 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int):
         b = time.perf_counter(); t.ready_consume_last()
         c = time.perf_counter()
         rec_off = np.ctypeslib.as_array(res.rec_off, shape=(W + 1,)).astype(np.int64)
-        rec_task = np.ctypeslib.as_array(res.rec_task, shape=(int(rec_off[W]),)).copy()
+        rec_task = abi.record_task_ids(res, W)
         finished, returned = drv.after_tick(rec_off, rec_task)
         idx = (returned & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1
         d = time.perf_counter()
@@ -178,7 +178,7 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
         last_snap = (free.copy(), [list(x) for x in assigned], alive.copy(), rq_of.copy(), (cw.copy(), cq.copy(), cv.copy()))
         np.add.at(running, (cw, cq), cv)
         n_rec = int(np.ctypeslib.as_array(res.rec_off, shape=(W + 1,))[W])
-        gone = np.ctypeslib.as_array(res.rec_task, shape=(n_rec,)).copy() if n_rec else np.zeros(0, np.uint64)
+        gone = abi.record_task_ids(res, W)
         idx = (gone & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1
         alive[idx] = False
         new_rq = rq_of[idx]
@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--dag-steps", type=int, default=12, help="ticks of the config-5 loop (1 M-node DAG in the device graph + 10 %% worker churn per tick), 0 = skip")
     ap.add_argument("--dag-classes", type=int, default=2, help="request classes of the config-5 DAG (first N of the c3 classes; 8 = all, every tick then runs into the MILP time limit)")
     ap.add_argument("--wire-iters", type=int, default=50, help="launch triples of the wire-encoding measurement (row f3, in a subprocess), 0 = skip")
+    ap.add_argument("--full-records", action="store_true", help="10-byte records (u64 id, variant, kind) instead of the compact emission (HQTICK_FLAG_COMPACT_RECORDS)")
     ap.add_argument("--no-b2b", dest="b2b", action="store_false", help="skip the 100 back-to-back launches of K1 / K4 (so that a rocprofv3 summary of this run averages the in-tick launches only)")
     ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
@@ -308,7 +309,9 @@ def main():
     snap = workloads.make(args.workload, seed=args.seed, n_tasks=n_tasks_per_gpu * mult, n_workers=n_workers_per_gpu * mult)
     cfg = abi.make_config(time_limit_s=5.0, device_index=local_rank)
     if args.no_kernel_timing:
-        cfg.flags |= 1
+        cfg.flags |= abi.HQTICK_FLAG_NO_KERNEL_TIMING
+    if not args.full_records:
+        cfg.flags |= abi.HQTICK_FLAG_COMPACT_RECORDS  # records cross PCIe as u32 low halves + runs of (job, variant, kind): include/hqtick.h
     sc = snap.to_c()
     W_all = len(snap.worker_id)
     if world == 1 and not args.force_sharded:
@@ -382,7 +385,7 @@ def main():
         "scan_waves": dict(us=mean("scan_us"), bytes=G * ((n_ready + 255) // 256) * 8, bound="latency", what="K1b: per-slice counts -> offsets"),
         "select_scatter": dict(us=mean("select_us"), bytes=n_ready * 8 + sel * 10, bound="hbm", what="K4: id u64 of every ready task + (id, level) of the taken ones"),
         "sweep_bits": dict(us=mean("sweep_us"), bytes=0, bound="latency", what="K5a: round-robin bit rows"),
-        "expand_mapping": dict(us=mean("other_us"), bytes=(sel * 10 + sel * 10) // world, bound="pcie" if world == 1 else "hbm-latency",
+        "expand_mapping": dict(us=mean("other_us"), bytes=(sel * 10 + sel * (10 if args.full_records or world > 1 else 4)) // world, bound="pcie" if world == 1 else "hbm-latency",
                                what="K5b: gathers (id, level) and writes this rank's records " + ("straight into pinned host memory" if world == 1 else "into the HBM record sink")),
     }
     for k in kernels.values():
@@ -403,6 +406,7 @@ def main():
     achieved, peak = (kernels[dom]["bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0), 8000.0
     pcie_peak = 63.0  # GB/s, PCIe Gen5 x16 one direction (what K5b's stores into pinned host memory cross)
     em = kernels["expand_mapping"]
+    pcie_bytes = sel * (10 if args.full_records else 4) // world
     value = total_assigned * args.steps / elapsed
     out = {
         "metric": "tasks_assigned_per_sec", "value": value, "unit": "tasks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -426,10 +430,10 @@ def main():
                      "note": "K1 streams the whole ready set (12 B/task).  At 1 M tasks the set (20 MB) lives in the 256 MiB Infinity Cache across ticks and a launch is latency-bound "
                              "(12 MB = 1.9 us at 6.3 TB/s achievable): see roofline_vs_n / profiles/r02 for the same kernel beyond the cache.  The K2 ride-along workgroups of the same "
                              "launch read the worker tables from pinned host memory (PCIe round trips), which is what stretches the in-tick launch over the stand-alone one"},
-        "roofline_time_dominant_kernel": {"kernel": "expand_mapping", "bound": "pcie", "achieved": em["GBps"] / 2.0, "peak": pcie_peak, "unit": "GB/s",
-                                          "frac": em["GBps"] / 2.0 / pcie_peak, "bytes_over_pcie_per_launch": em["bytes"] // 2, "avg_launch_us": em["us"],
-                                          "note": "K5b writes the records (10 B each) straight into the caller's pinned host buffer: the launch lasts as long as the PCIe writes do; "
-                                                  "its HBM side (the same 10 B per record gathered from the selection) is negligible"},
+        "roofline_time_dominant_kernel": {"kernel": "expand_mapping", "bound": "pcie", "achieved": pcie_bytes / (em["us"] * 1e-6) / 1e9 if em["us"] > 0 else 0.0, "peak": pcie_peak, "unit": "GB/s",
+                                          "frac": (pcie_bytes / (em["us"] * 1e-6) / 1e9 / pcie_peak) if em["us"] > 0 else 0.0, "bytes_over_pcie_per_launch": pcie_bytes, "avg_launch_us": em["us"],
+                                          "note": "K5b writes the records straight into the caller's pinned host buffer (compact emission: 4 B per record + 10 B per run of equal "
+                                                  "(job, variant, kind); --full-records: 10 B per record): the launch lasts as long as the PCIe writes do"},
     }
     if world == 1 and not args.force_sharded and not args.no_kernel_timing and args.roofline_sweep:
         sweep = []
@@ -452,8 +456,7 @@ def main():
         ts = Tick(cfg)
         ts.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
         def handed_out(res):  # ids of the records of a tick (assigned + prefilled)
-            n_rec = int(np.ctypeslib.as_array(res.rec_off, shape=(W + 1,))[W])
-            return np.ctypeslib.as_array(res.rec_task, shape=(n_rec,)).copy()
+            return abi.record_task_ids(res, W)
 
         rq_of = snap.task_rq.copy()  # rq by (job_task_id - 1): every id here is job 1, task 1..n
         res = ts.tick_raw(sc, resident=True)

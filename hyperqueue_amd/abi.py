@@ -11,7 +11,8 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-HQTICK_ABI_VERSION = 3
+HQTICK_ABI_VERSION = 4
+HQTICK_FLAG_NO_KERNEL_TIMING, HQTICK_FLAG_COMPACT_RECORDS = 1, 2
 HQ_AMOUNT_MAX = 0xFFFF_FFFF_FFFF_FFFF
 HQ_FRACTIONS_PER_UNIT = 10_000
 HQ_MAX_TASK_PER_WORKER = 1024
@@ -41,9 +42,9 @@ class Config(C.Structure):
     ]
 
 
-def make_config(reserve: int = 16, fill_max: int = 40, time_limit_s: float = 60.0, device_index: int = 0) -> Config:
+def make_config(reserve: int = 16, fill_max: int = 40, time_limit_s: float = 60.0, device_index: int = 0, flags: int = 0) -> Config:
     """SchedulerConfig defaults (scheduler/state.rs:19-27); 60 s is the reference's cfg(test) limit."""
-    return Config(HQTICK_ABI_VERSION, reserve, fill_max, time_limit_s, device_index, 0)
+    return Config(HQTICK_ABI_VERSION, reserve, fill_max, time_limit_s, device_index, flags)
 
 
 class SnapshotC(C.Structure):
@@ -135,6 +136,12 @@ class ResultC(C.Structure):
         ("rec_kind", u8p),
         ("retract_off", u32p),
         ("retract_task", u64p),
+        ("rec_task_lo", u32p),
+        ("run_start", u32p),
+        ("run_cnt", u32p),
+        ("run_first", u32p),
+        ("run_job", u32p),
+        ("run_meta", C.POINTER(C.c_uint16)),
         ("n_redirects", C.c_uint32),
         ("redirect_task", u64p),
         ("redirect_worker", u32p),
@@ -361,6 +368,39 @@ def parse_batches(r: ResultC) -> List[Batch]:
     return out
 
 
+def expand_compact(r: ResultC, W: int, off: np.ndarray):
+    """(task ids, variants, kinds) of every record from the compact emission — what the host shim does while it applies the records"""
+    n = int(off[-1])
+    lo = _np(r.rec_task_lo, n, np.uint32).astype(np.uint64)
+    rs, rc = _np(r.run_start, W, np.uint32), _np(r.run_cnt, W, np.uint32)
+    task = np.zeros(n, np.uint64); var = np.zeros(n, np.uint8); kind = np.zeros(n, np.uint8)
+    have = np.nonzero(off[1:] > off[:-1])[0]
+    if len(have):
+        hi_run = int(max(int(rs[w]) + int(rc[w]) for w in have))
+        first, job, meta = _np(r.run_first, hi_run, np.uint32), _np(r.run_job, hi_run, np.uint32), _np(r.run_meta, hi_run, np.uint16)
+        for w in have:
+            a, b, s0, c = int(off[w]), int(off[w + 1]), int(rs[w]), int(rc[w])
+            assert c >= 1 and first[s0] == 0, (w, c)
+            starts = first[s0:s0 + c].astype(np.int64)
+            assert (np.diff(starts) > 0).all() and starts[-1] < b - a
+            lens = np.diff(np.append(starts, b - a))
+            task[a:b] = (np.repeat(job[s0:s0 + c].astype(np.uint64), lens) << np.uint64(32)) | lo[a:b]
+            var[a:b] = np.repeat((meta[s0:s0 + c] & 0xFF).astype(np.uint8), lens)
+            kind[a:b] = np.repeat((meta[s0:s0 + c] >> 8).astype(np.uint8), lens)
+    return task.tolist(), var.tolist(), kind.tolist()
+
+
+def record_task_ids(r: ResultC, W: int) -> np.ndarray:
+    """task ids of every record of a tick in CSR order (rec_off), from either emission format"""
+    off = _np(r.rec_off, W + 1, np.uint32)
+    n = int(off[-1])
+    if n == 0:
+        return np.zeros(0, np.uint64)
+    if r.rec_task_lo:
+        return np.asarray(expand_compact(r, W, off)[0], np.uint64)
+    return _np(r.rec_task, n, np.uint64).copy()
+
+
 def parse_result(r: ResultC, n_workers: int, n_resources: int, full: bool = True) -> Result:
     batches = parse_batches(r)
     nc = r.n_counts
@@ -378,7 +418,10 @@ def parse_result(r: ResultC, n_workers: int, n_resources: int, full: bool = True
     if r.rec_off and W:
         off = _np(r.rec_off, W + 1, np.uint32)
         n = int(off[-1])
-        t, v, k = _np(r.rec_task, n, np.uint64).tolist(), _np(r.rec_variant, n, np.uint8).tolist(), _np(r.rec_kind, n, np.uint8).tolist()
+        if n and r.rec_task_lo:  # compact emission (HQTICK_FLAG_COMPACT_RECORDS): u32 low halves + runs of (job, variant, kind)
+            t, v, k = expand_compact(r, W, off)
+        else:
+            t, v, k = _np(r.rec_task, n, np.uint64).tolist(), _np(r.rec_variant, n, np.uint8).tolist(), _np(r.rec_kind, n, np.uint8).tolist()
         for w in range(W):
             a, b = int(off[w]), int(off[w + 1])
             records[w] = list(zip(t[a:b], v[a:b], k[a:b]))

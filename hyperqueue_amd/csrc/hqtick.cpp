@@ -78,7 +78,7 @@ struct hqtick_ctx {
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
     uint32_t block_budget = 4096, block_min_classes = 12;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
     // workers / requests
-    DevBuf d_up, d_vflags, d_vtmc, d_blk;
+    DevBuf d_up, d_vflags, d_vtmc, d_blk, d_runctr;
     // selection + mapping
     DevBuf d_sel_task, d_sel_level, d_map, d_rec, d_tsweep, d_bits, d_pre;
     hqhost::Problem pb;
@@ -432,6 +432,7 @@ struct TickRun {
     std::vector<std::pair<uint32_t, uint32_t>> retr_pos;      // (rq, queue position) of every Retracting task
     std::vector<std::vector<uint32_t>> key_T;                 // lazily built T_k(s) tables of worker_of()
     size_t o_rv = 0, o_rk = 0, o_mn = 0, o_fl = 0;            // layout of the pinned record buffer
+    bool compact = false; size_t o_rs = 0, o_rc = 0, o_rf = 0, o_rj = 0, o_rm = 0; uint32_t max_out = 0;  // compact emission (HQTICK_FLAG_COMPACT_RECORDS)
     uint64_t *h_rec_task = nullptr, *mn_ids = nullptr; uint8_t *h_rec_var = nullptr, *h_rec_kind = nullptr;
     bool assembled = false;
     double t0 = 0;
@@ -663,16 +664,18 @@ struct TickRun {
         n_pfq = (uint32_t)pfq_rq.size();
         // ---- output offsets ----
         ps.out_off.assign(W + 1, 0);
-        max_items = 0;
+        max_items = 0; max_out = 0;
+        compact = (ctx->cfg.flags & HQTICK_FLAG_COMPACT_RECORDS) != 0 && !ctx->sink;
         for (uint32_t w = 0; w < W; w++) {
             if (ctx->shard_count > 1 && hqhb::hash_worker_id(s->worker_id[w]) % ctx->shard_count != ctx->shard_index) { ps.out_off[w + 1] = ps.out_off[w]; continue; }  // another rank's worker
             uint32_t npf = 0;
             for (uint32_t pi = 0; pi < n_pfq; pi++) if (ps.pfl_j[(size_t)pi * W + w] != NONE) npf += ps.pfq_size[pi];
             ps.out_off[w + 1] = ps.out_off[w] + npf + ps.n_assign[w];
             max_items = std::max(max_items, ps.items[w]);
+            max_out = std::max(max_out, npf + ps.n_assign[w]);
         }
         n_rec = ps.out_off[W];
-        if (hqk::expand_mapping_lds(max_items, nkeys) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
+        if (hqk::expand_mapping_lds(max_items, nkeys, compact ? max_out : 0) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
         if (max_nk > hqk::SWEEP_MAX_WORKERS) return fail(ctx, HQTICK_E_CAPACITY, "more than 24576 workers share one (request, variant) placement: beyond the round-robin kernel's LDS staging");
         return 0;
     }
@@ -709,7 +712,11 @@ struct TickRun {
     // GPU phase C: selection, round-robin bit rows, per-worker expansion; records land in pinned memory (or the HBM sink)
     int phase_c() {
         size_t n_mn_ids = 0; for (auto &sets : cnt.mn_sets) n_mn_ids += sets.size();
-        o_rv = (size_t)n_rec * 8; o_rk = o_rv + n_rec; o_mn = (o_rk + n_rec + 7) & ~(size_t)7; o_fl = o_mn + n_mn_ids * 8;
+        if (compact) {  // [rec_lo u32 x n_rec][run_start u32 x W][run_cnt u32 x W][run_first u32 x n_rec][run_job u32 x n_rec][run_meta u16 x n_rec] (at most one run per record)
+            o_rs = (size_t)n_rec * 4; o_rc = o_rs + (size_t)W * 4; o_rf = o_rc + (size_t)W * 4; o_rj = o_rf + (size_t)n_rec * 4; o_rm = o_rj + (size_t)n_rec * 4;
+            o_rv = o_rk = 0; o_mn = (o_rm + (size_t)n_rec * 2 + 7) & ~(size_t)7;
+        } else { o_rv = (size_t)n_rec * 8; o_rk = o_rv + n_rec; o_mn = (o_rk + n_rec + 7) & ~(size_t)7; }
+        o_fl = o_mn + n_mn_ids * 8;
         const size_t rec_bytes = o_fl + 64;
         if (!ctx->h_rec.ensure(rec_bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc records");
         h_rec_task = ctx->h_rec.as<uint64_t>(); h_rec_var = ctx->h_rec.as<uint8_t>() + o_rv; h_rec_kind = ctx->h_rec.as<uint8_t>() + o_rk;
@@ -730,7 +737,7 @@ struct TickRun {
             if (ps.holes.empty()) { pack.push_back(0); pack.push_back(0); }
             // device record buffer: [task u64 x n_rec][variant u8 x n_rec][kind u8 x n_rec] -> one D2H copy
             if (!ctx->d_map.ensure(pack.size() * 4 + 16) || !ctx->h_plan.ensure(pack.size() * 4 + 16) ||
-                !ctx->d_tsweep.ensure((size_t)ps.key_t_off[nkeys] * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) || !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
+                !ctx->d_runctr.ensure(64) || !ctx->d_tsweep.ensure((size_t)ps.key_t_off[nkeys] * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) || !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
                 return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
             mark();  // 6: pack
             memcpy(ctx->h_plan.p, pack.data(), pack.size() * 4);
@@ -741,6 +748,7 @@ struct TickRun {
             mk.t_sweep = ctx->d_tsweep.as<uint32_t>(); mk.bits = ctx->d_bits.as<uint64_t>(); mk.pre = ctx->d_pre.as<uint32_t>();
             mk.wpos = d + o_wpos; mk.wcnt = d + o_wcnt; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn;
             mk.n_holes = (uint32_t)ps.holes.size(); mk.holes = reinterpret_cast<const uint64_t *>(d + o_holes);
+            mk.run_counter = compact ? ctx->d_runctr.as<uint32_t>() : nullptr;
             mk.n_pfq = n_pfq; mk.pfq_src = d + o_pqs; mk.pfq_size = d + o_pqz; mk.pfl_j = d + o_pflj; mk.out_off = d + o_out;
             uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
             flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
@@ -768,8 +776,11 @@ struct TickRun {
                 k_task = reinterpret_cast<uint64_t *>(sk + so_task); k_var = sk + so_var; k_kind = sk + so_kind;
             }
             if (ctx->timing) hqk::time_next_launch(ctx->ev[7], ctx->ev[11]);
+            hqk::CompactOut co{};
+            if (compact) co = hqk::CompactOut{reinterpret_cast<uint32_t *>(drec), reinterpret_cast<uint32_t *>(drec + o_rs), reinterpret_cast<uint32_t *>(drec + o_rc), reinterpret_cast<uint32_t *>(drec + o_rf),
+                                              reinterpret_cast<uint32_t *>(drec + o_rj), reinterpret_cast<uint16_t *>(drec + o_rm), ctx->d_runctr.as<uint32_t>(), n_rec};
             HQ_HIP_TIMED(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
-                                reinterpret_cast<uint32_t *>(drec + o_fl), ctx->stream));
+                                reinterpret_cast<uint32_t *>(drec + o_fl), co, max_out, ctx->stream));
             // multi-node tasks: the heads of their queues
             {
                 size_t pos = 0;
@@ -812,7 +823,11 @@ struct TickRun {
         out->n_counts = (uint32_t)ctx->cnt_rq.size(); out->count_rq = ctx->cnt_rq.data(); out->count_variant = ctx->cnt_variant.data();
         out->count_worker = ctx->cnt_worker.data(); out->count_value = ctx->cnt_value.data();
         out->rec_off = ctx->rec_off.data();
-        if (!ctx->sink) { out->rec_task = h_rec_task; out->rec_variant = h_rec_var; out->rec_kind = h_rec_kind; }
+        if (compact && n_sel) {
+            const uint8_t *hb = ctx->h_rec.as<uint8_t>();
+            out->rec_task_lo = reinterpret_cast<const uint32_t *>(hb); out->run_start = reinterpret_cast<const uint32_t *>(hb + o_rs); out->run_cnt = reinterpret_cast<const uint32_t *>(hb + o_rc);
+            out->run_first = reinterpret_cast<const uint32_t *>(hb + o_rf); out->run_job = reinterpret_cast<const uint32_t *>(hb + o_rj); out->run_meta = reinterpret_cast<const uint16_t *>(hb + o_rm);
+        } else if (!ctx->sink) { out->rec_task = h_rec_task; out->rec_variant = h_rec_var; out->rec_kind = h_rec_kind; }
         out->retract_off = ctx->retract_off.data(); out->retract_task = ctx->retract_task.data();
         out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data(); out->redirect_kind = ctx->red_kind.data();
         out->n_mn = (uint32_t)ctx->mn_task.size(); out->mn_task = ctx->mn_task.data(); out->mn_worker_off = ctx->mn_off.data(); out->mn_worker = ctx->mn_worker.data();
@@ -919,7 +934,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
-                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8, &ctx->d_blk};
+                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8, &ctx->d_blk, &ctx->d_runctr};
     for (DevBuf *b : bufs) b->release();
     if (ctx->qctx) { hqtick_destroy(ctx->qctx); ctx->qctx = nullptr; }
     hipSetDevice(ctx->device);

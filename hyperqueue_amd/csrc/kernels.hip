@@ -414,6 +414,7 @@ __global__ void __launch_bounds__(256) k_sweep_bits(MapKeys mk) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *s_c = reinterpret_cast<uint32_t *>(smem);  // count of position j at s_c[j + (j >> 6)]
     const uint32_t k = blockIdx.y, lane = lane_id();
+    if (mk.run_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *mk.run_counter = 0;  // K5b's run allocator (same stream: ordered before it)
     const uint32_t t0 = mk.key_t_off[k], n_sweeps = mk.key_t_off[k + 1] - t0;  // sweeps 0..maxc
     if (blockIdx.x * 4 >= n_sweeps) return;
     const uint32_t nk = mk.key_ord_off[k + 1] - mk.key_ord_off[k];
@@ -448,16 +449,22 @@ __global__ void __launch_bounds__(256) k_sweep_bits(MapKeys mk) {
 // ------------------------------------------------------------------------------------------------ K5b
 // One workgroup per worker.  LDS: e_task u64[max_items] | e_lvl u16[max_items] | e_meta u16[max_items] | k_start u32[n_keys+1]
 // | k_pos | k_cnt | k_rq | k_seg | k_toff | k_boff | k_words  (u32[n_keys] each) | k_var u8[n_keys] (padded) | misc u32[4]
+// Compact emission (HQTICK_FLAG_COMPACT_RECORDS): the records cross PCIe as 4 bytes each — the low half of the task id — plus one 10-byte RUN per
+// maximal stretch of a worker's records that share (job id, variant, kind).  LDS then also holds the worker's final sequence:
+// f_task u64[max_out] | f_meta u16[max_out] (variant | kind << 8) behind the tables above.
 __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, const uint64_t *__restrict__ sel_task,
                                                         const uint16_t *__restrict__ sel_key, uint32_t Q, uint32_t max_items,
                                                         uint64_t *__restrict__ rec_task, uint8_t *__restrict__ rec_variant,
-                                                        uint8_t *__restrict__ rec_kind, uint32_t *__restrict__ err_flag) {
+                                                        uint8_t *__restrict__ rec_kind, uint32_t *__restrict__ err_flag, CompactOut co, uint32_t max_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t nkeys = mk.n_keys;
     uint64_t *e_task = reinterpret_cast<uint64_t *>(smem);
-    uint16_t *e_lvl = reinterpret_cast<uint16_t *>(e_task + max_items);
+    uint64_t *f_task = e_task + max_items;  // compact mode only (max_out == 0 otherwise)
+    uint16_t *e_lvl = reinterpret_cast<uint16_t *>(f_task + max_out);
     uint16_t *e_meta = e_lvl + max_items;  // variant | valid << 8
-    uint32_t *k_start = reinterpret_cast<uint32_t *>(e_meta + max_items);  // 12 B per item: stays 4-byte aligned
+    uint16_t *f_meta = e_meta + max_items;
+    uint32_t *k_start = reinterpret_cast<uint32_t *>(f_meta + max_out + ((max_items * 2 + max_out) & 1u));  // keeps 4-byte alignment
+    const bool compact = co.rec_lo != nullptr;
     uint32_t *k_pos = k_start + nkeys + 1;
     uint32_t *k_cnt = k_pos + nkeys, *k_rq = k_cnt + nkeys, *k_seg = k_rq + nkeys, *k_toff = k_seg + nkeys, *k_boff = k_toff + nkeys, *k_words = k_boff + nkeys;
     uint32_t *misc = k_words + nkeys;  // [0] min level, [1] max level, [2] holes
@@ -497,6 +504,7 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
         if (j == 0xFFFFFFFFu) continue;
         const uint32_t cnt = mk.pfq_size[pi], src = mk.pfq_src[pi] + j * cnt;
         for (uint32_t t = threadIdx.x; t < cnt; t += blockDim.x) {
+            if (compact) { if (npf + t < max_out) { f_task[npf + t] = sel_task[src + t]; f_meta[npf + t] = 0x00FFu; } continue; }
             rec_task[out0 + npf + t] = sel_task[src + t];
             rec_variant[out0 + npf + t] = 0xFF;
             rec_kind[out0 + npf + t] = 0;  // HQ_REC_PREFILL
@@ -551,11 +559,41 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
                 pos += (lo_ < lv || (lo_ == lv && o < e)) ? 1u : 0u;
             }
         }
+        if (compact) { if (npf + pos < max_out) { f_task[npf + pos] = e_task[e]; f_meta[npf + pos] = (uint16_t)((meta & 0xFFu) | 0x100u); } continue; }
         const uint32_t dst = out0 + npf + pos;
         rec_task[dst] = e_task[e];
         rec_variant[dst] = (uint8_t)(meta & 0xFFu);
         rec_kind[dst] = 1;  // HQ_REC_ASSIGN
     }
+    if (!compact) return;
+    // ---- compact emission: runs of equal (job, variant, kind) over the worker's final sequence ----
+    __syncthreads();
+    const uint32_t tot = mk.out_off[w + 1] - out0;
+    if (tot > max_out) { if (threadIdx.x == 0) err_flag[0] = 2u; return; }
+    __shared__ uint32_t s_wave[4], s_base;
+    const uint32_t chunk = (tot + blockDim.x - 1) / blockDim.x, lo = threadIdx.x * chunk, hi = lo + chunk < tot ? lo + chunk : tot;
+    auto boundary = [&](uint32_t i) { return i == 0 || (uint32_t)(f_task[i] >> 32) != (uint32_t)(f_task[i - 1] >> 32) || f_meta[i] != f_meta[i - 1]; };
+    uint32_t mine = 0;
+    for (uint32_t i = lo; i < hi; i++) mine += boundary(i) ? 1u : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += t; }
+    if (lane == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) before += s_wave[wv];
+    if (threadIdx.x == 0) {
+        const uint32_t n_runs = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        const uint32_t base = atomicAdd(co.run_counter, n_runs);
+        if (base + n_runs > co.run_cap) { err_flag[0] = 2u; s_base = 0xFFFFFFFFu; }
+        else { s_base = base; co.run_start[w] = base; co.run_cnt[w] = n_runs; }
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    if (base == 0xFFFFFFFFu) return;
+    uint32_t r = base + before;
+    for (uint32_t i = lo; i < hi; i++) if (boundary(i)) { co.run_first[r] = i; co.run_job[r] = (uint32_t)(f_task[i] >> 32); co.run_meta[r] = f_meta[i]; r++; }
+    for (uint32_t i = threadIdx.x; i < tot; i += blockDim.x) co.rec_lo[out0 + i] = (uint32_t)f_task[i];
 }
 
 // ------------------------------------------------------------------------------------------------ resident ready-set deltas (f1)
@@ -826,17 +864,18 @@ hipError_t sweep_bits(MapKeys mk, uint32_t max_count, uint32_t max_workers_per_k
     return hipGetLastError();
 }
 
-size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys) {
-    return (size_t)max_items * 12 + ((size_t)8 * n_keys + 1 + 4) * 4 + n_keys + 16;
+size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys, uint32_t max_out) {
+    return (size_t)max_items * 12 + (size_t)max_out * 10 + 2 + ((size_t)8 * n_keys + 1 + 4) * 4 + n_keys + 16;
 }
 
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_key, uint32_t Q, uint32_t max_items,
-                    uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, hipStream_t s) {
+                    uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, CompactOut co, uint32_t max_out, hipStream_t s) {
     if (W == 0) return hipSuccess;
-    size_t lds = expand_mapping_lds(max_items, mk.n_keys);
+    if (!co.rec_lo) max_out = 0;
+    size_t lds = expand_mapping_lds(max_items, mk.n_keys, max_out);
     hipError_t e;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_mapping), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    HQK_TIMED_LAUNCH(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, W, sel_task, sel_key, Q, max_items, rec_task, rec_variant, rec_kind, err_flag);
+    HQK_TIMED_LAUNCH(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, W, sel_task, sel_key, Q, max_items, rec_task, rec_variant, rec_kind, err_flag, co, max_out);
     return hipGetLastError();
 }
 

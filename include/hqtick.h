@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HQTICK_ABI_VERSION 3u
+#define HQTICK_ABI_VERSION 4u
 
 /* ResourceAmount::MAX                                    common/resources/amount.rs:31 */
 #define HQ_AMOUNT_MAX UINT64_MAX
@@ -80,6 +80,11 @@ enum { HQ_REC_PREFILL = 0, HQ_REC_ASSIGN = 1 };
 
 /* hqtick_config.flags: skip the HIP events that feed hqtick_kernel_stats_last() (saves ~6 API calls per tick) */
 #define HQTICK_FLAG_NO_KERNEL_TIMING 1u
+/* hqtick_config.flags: compact record emission.  The records of a tick cross PCIe as 4 bytes each (rec_task_lo = job_task_id, the low half of the
+ * packed task id) plus one 10-byte RUN per maximal stretch of a worker's records that share (job_id, variant, kind) — instead of 10 bytes per
+ * record.  result.rec_task / rec_variant / rec_kind are NULL then; see the run_* fields of hqtick_result.  (Ignored while a device record sink is
+ * set: the sink keeps its own layout.) */
+#define HQTICK_FLAG_COMPACT_RECORDS 2u
 
 /* redirect_kind of a result entry (scheduler/mapping.rs:66-101):
  *   FROM_PREFILL  the task sat in a prefill set: Prefilled{old} -> Retracting{old}, retract sent to `old`, redirects.insert(task, (worker, v))
@@ -226,6 +231,16 @@ typedef struct hqtick_result {
     const uint8_t *rec_kind;    /* HQ_REC_* */
     const uint32_t *retract_off; /* [W+1] */
     const uint64_t *retract_task;
+    /* Compact emission (HQTICK_FLAG_COMPACT_RECORDS; NULL otherwise).  Worker w's records are rec_off[w] .. rec_off[w + 1] as before; record i of
+     * that range has task id (run_job << 32) | rec_task_lo[rec_off[w] + i], variant run_meta & 0xFF (0xFF = None: a prefill) and kind run_meta >> 8,
+     * where the run is the one of run_start[w] .. run_start[w] + run_cnt[w] with the largest run_first <= i (runs ascend by run_first; the first
+     * one starts at 0).  run_start / run_cnt are defined only for workers with records. */
+    const uint32_t *rec_task_lo; /* [n_records] */
+    const uint32_t *run_start;   /* [W] */
+    const uint32_t *run_cnt;     /* [W] */
+    const uint32_t *run_first;
+    const uint32_t *run_job;
+    const uint16_t *run_meta;
 
     /* scheduler_state.redirects insertions made by this tick (mapping.rs:78-100) */
     uint32_t n_redirects;

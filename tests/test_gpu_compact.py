@@ -1,0 +1,99 @@
+"""Compact record emission (HQTICK_FLAG_COMPACT_RECORDS, include/hqtick.h): the records cross PCIe as the u32 low halves of the task ids plus
+one run per stretch of equal (job, variant, kind).  Expanded again (abi.expand_compact = what the host shim does), they must be the very
+records of the default emission: checked on the committed fixtures (small and BASELINE size), on scenarios with several jobs per worker, prefill
+sets and priority levels, and on the randomised family."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from hyperqueue_amd import abi, workloads
+from hyperqueue_amd.core import SchedEnv, TaskBuilder as TB, WorkerBuilder as WB
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _pair(cfg):
+    from hyperqueue_amd.tick import Tick
+
+    c2 = abi.make_config(reserve=cfg.proactive_filling_reserve, fill_max=cfg.proactive_filling_max, time_limit_s=cfg.mip_time_limit_s, flags=abi.HQTICK_FLAG_COMPACT_RECORDS)
+    return Tick(cfg), Tick(c2)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.json"))), ids=lambda p: os.path.basename(p)[:-5])
+def test_compact_reproduces_fixture(path):
+    from test_fixtures import _check, _load
+
+    snap, cfg, exp = _load(path)
+    plain, comp = _pair(cfg)
+    try:
+        rc = comp.tick_raw(snap.to_c())
+        assert (rc.rec_task_lo and not rc.rec_task) or int(np.ctypeslib.as_array(rc.rec_off, shape=(len(snap.worker_id) + 1,))[-1]) == 0
+        _check(comp.tick(snap), exp)
+    finally:
+        plain.close(); comp.close()
+
+
+@pytest.mark.parametrize("name", ["c4_full", "c3_steady_full", "c2_full"])
+def test_compact_reproduces_big_fixture(name):
+    from test_fixtures import _check_big, _load_big
+
+    snap, cfg, exp = _load_big(os.path.join(GOLDEN, "big", name + ".json"))
+    plain, comp = _pair(cfg)
+    try:
+        _check_big(comp.tick(snap), exp)
+    finally:
+        plain.close(); comp.close()
+
+
+def test_compact_runs_split_on_job_variant_and_kind():
+    """several jobs interleaved in one queue, two variants, prefills and two priority levels on the same workers"""
+    env = SchedEnv(abi.make_config(reserve=2, fill_max=6, time_limit_s=20.0))
+    env.new_named_resource("gpus/amd")
+    env.new_workers(5, WB(12).res_sum("gpus/amd", 2))
+    for job in (3, 1, 7):
+        env.job_id = job if hasattr(env, "job_id") else None
+        env.new_tasks(40, TB().cpus(1))
+    env.new_tasks(25, TB().cpus(2).user_priority(2))
+    env.new_tasks(10, TB().cpus(1).add_resource(1, 1).next_variant().cpus(3))
+    snap = env.snapshot()
+    # spread the tasks over several jobs: rewrite the ids' high halves, keeping the column sorted
+    ids = snap.task_id.copy()
+    lo = ids & np.uint64(0xFFFFFFFF)
+    job = (np.arange(len(ids)) // 17 + 1).astype(np.uint64)
+    snap.task_id = (job << np.uint64(32)) | lo
+    assert (np.diff(snap.task_id.astype(np.int64)) > 0).all()
+    plain, comp = _pair(env.config)
+    try:
+        a, b = plain.tick(snap), comp.tick(snap)
+        assert a.records == b.records and a.counts == b.counts and a.retracts == b.retracts
+        rc = comp.tick_raw(snap.to_c())
+        W = len(snap.worker_id)
+        cnt = np.ctypeslib.as_array(rc.run_cnt, shape=(W,))
+        off = np.ctypeslib.as_array(rc.rec_off, shape=(W + 1,))
+        assert max(int(cnt[w]) for w in range(W) if off[w + 1] > off[w]) >= 3  # jobs / kinds really split the runs
+    finally:
+        plain.close(); comp.close()
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_compact_equals_default_on_fuzz_family(seed):
+    import test_gpu_fuzz as f
+
+    cfg, envs, _rng = f.build(seed)
+    snap = envs[1].snapshot()
+    plain, comp = _pair(cfg)
+    try:
+        try:
+            a = plain.tick(snap)
+        except Exception as e:  # scenarios the library refuses (E_UNSUPPORTED): refused in both modes
+            with pytest.raises(type(e)):
+                comp.tick(snap)
+            return
+        b = comp.tick(snap)
+        assert a.status == b.status and a.records == b.records and a.retracts == b.retracts and sorted(a.redirects) == sorted(b.redirects) and a.mn == b.mn
+    finally:
+        plain.close(); comp.close()
