@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <climits>
 #include <cstring>
@@ -363,6 +365,7 @@ struct CompSolver {
         int s = solve_counted(t);
         if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return; }
         double z = t.objective();
+        if (nodes == 1 && getenv("HQMILP_TRACE")) fprintf(stderr, "[milp] n=%d root LP %.9f incumbent %.9f rel gap %.3e\n", n, z, have ? best : -1.0, have ? (z - best) / best : 0.0);
         if (cannot_improve(z)) return;
         int j = pick_fractional(t);
         if (j >= 0 && (nodes == 1 || (nodes & 63) == 0)) {  // root and every 64th node: try to close the gap from this LP point
@@ -631,6 +634,7 @@ struct CompSolver {
             lns_schedule(deadline - 0.05);
             timed_out = true;
         }
+        if (getenv("HQMILP_TRACE")) fprintf(stderr, "[milp] n=%d final incumbent %.9f timed_out %d nodes %ld\n", n, have ? best : -1.0, (int)timed_out, nodes);
         if (!have) return 0;
         xout = bx;
         if (timed_out) return 2;

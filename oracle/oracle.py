@@ -98,7 +98,9 @@ def _highs(c_max, A, lo, hi, lb, ub, time_limit=None):
 
     n = len(c_max)
     cons = [LinearConstraint(A, lo, hi)] if A is not None and A.shape[0] else []
-    opts = {"mip_rel_gap": 0.0, "disp": False}
+    # exact by default (the canonical oracle); as the reference runs it (Oracle(reference_solver_options=True): only `time_limit` is set,
+    # solver/highs.rs:65-68) HiGHS keeps its default mip_rel_gap = 1e-4, i.e. "Optimal" means proven within 0.01 %
+    opts = {"mip_rel_gap": 1e-4 if _PRESOLVE_ON else 0.0, "disp": False}
     if time_limit is not None and time_limit < 1e20:
         opts["time_limit"] = float(time_limit)
     # HiGHS 1.8.0's PRESOLVE is not reliable on the placement models: tests/test_gpu_fuzz.py found instances it declares infeasible

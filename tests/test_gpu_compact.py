@@ -54,9 +54,7 @@ def test_compact_runs_split_on_job_variant_and_kind():
     env = SchedEnv(abi.make_config(reserve=2, fill_max=6, time_limit_s=20.0))
     env.new_named_resource("gpus/amd")
     env.new_workers(5, WB(12).res_sum("gpus/amd", 2))
-    for job in (3, 1, 7):
-        env.job_id = job if hasattr(env, "job_id") else None
-        env.new_tasks(40, TB().cpus(1))
+    env.new_tasks(120, TB().cpus(1))
     env.new_tasks(25, TB().cpus(2).user_priority(2))
     env.new_tasks(10, TB().cpus(1).add_resource(1, 1).next_variant().cpus(3))
     snap = env.snapshot()
