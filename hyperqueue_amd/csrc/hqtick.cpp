@@ -65,6 +65,8 @@ struct hqtick_ctx {
     hqtick_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // K2 (worker evaluation: PCIe-latency-bound reads of the worker tables) runs here, next to K1 + K1b on `stream`
+    bool k2_own_stream = true;     // HQTICK_K2_RIDE_ALONG=1 puts it back into K1's launch (round 1's layout)
     hipEvent_t ev[12] = {};
     std::string err = "";
     // ready set
@@ -324,8 +326,9 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
             g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw); g.tab_stride = (g.n_waves + 15u) & ~15u;
             if (!ctx->d_wave_tab.ensure((size_t)g.tab_stride * sc->G * 4) || !ctx->d_gkey.ensure(N * 2 + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
             if (ctx->timing) hqk::time_next_launch(ctx->ev[2], ctx->ev[3]);
+            if (ctx->k2_own_stream) HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc), ctx->stream2));
             HQ_HIP_TIMED(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
-                                   ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, &wea, ctx->stream));
+                                   ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->k2_own_stream ? nullptr : &wea, ctx->stream));
             if (ctx->timing) hqk::time_next_launch(ctx->ev[0], ctx->ev[8]);
             HQ_HIP_TIMED(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
                                    reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream));
@@ -343,6 +346,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
         ev->flags = h + o_fl; ev->tmc = reinterpret_cast<const uint32_t *>(h + o_tmc);
         if (while_gpu_runs) (*while_gpu_runs)();
         HQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (scan && ctx->k2_own_stream) HQ_HIP(hipStreamSynchronize(ctx->stream2));
         const uint32_t *flags = reinterpret_cast<const uint32_t *>(h);
         if (scan && (flags[2] & 2u)) return fail(ctx, HQTICK_E_INVALID, "ready set holds a request id >= n_requests");
         if (scan && (flags[2] & 1u)) {  // a priority the cached level table does not know: rebuild the table once
@@ -921,6 +925,8 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     if (const char *e = getenv("HQTICK_BLOCK_BUDGET")) { long v = atol(e); if (v >= 1 && v <= (1 << 24)) ctx->block_budget = (uint32_t)v; }
     if (const char *e = getenv("HQTICK_BLOCK_MIN_CLASSES")) { long v = atol(e); if (v >= 0) ctx->block_min_classes = (uint32_t)v; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return HQTICK_E_DEVICE; }
+    if (const char *e = getenv("HQTICK_K2_RIDE_ALONG")) ctx->k2_own_stream = atoi(e) == 0;
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     if (!ctx->d_flags.ensure(64) || hipMemset(ctx->d_flags.p, 0, 64) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     *out_ctx = ctx;
@@ -932,6 +938,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
     DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
                       &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8, &ctx->d_blk, &ctx->d_runctr};
@@ -943,6 +950,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_retr.release(); ctx->h_blk.release(); ctx->h_blkprof.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 

@@ -37,11 +37,13 @@ class ResidentBackend:
         assert self.t.ready_count() == len(want)
         stripped = abi.Snapshot(**{f: getattr(snap, f) for f in (
             "n_resources", "worker_id", "worker_total", "worker_free", "worker_remaining_ns", "worker_min_utilization", "worker_flags", "worker_group",
-            "n_groups", "blocked", "assigned", "prefilled", "requests", "prefill", "worker_map_rank")},
+            "n_groups", "blocked", "assigned", "prefilled", "requests", "prefill", "worker_map_rank", "retracting")},
             task_id=np.zeros(0, np.uint64), task_priority=np.zeros(0, np.uint64), task_rq=np.zeros(0, np.uint32))
         res = self.t.tick(stripped, resident=True)
         self.t.ready_consume_last()
         gone = [t for recs in res.records for (t, _, _) in recs] + [t for (t, _) in res.mn]
+        # Retracting tasks the tick took out of their queue leave no record, only a redirect (mapping.rs:66-80)
+        gone += [t for (t, _w, _v), k in zip(res.redirects, res.redirect_kinds) if k != abi.HQ_REDIRECT_FROM_PREFILL]
         for t in gone:
             del self.mirror[t]
         self.stats["consumed"] += len(gone)
@@ -119,6 +121,56 @@ def test_resident_multi_tick_equals_full_snapshots(seed):
                 assert_same(results[0], results[1])
     st = backends[0].stats
     assert st["consumed"] > 0 and st["adds"] > 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_resident_rising_priorities_dissolve_prefill_sets(seed):
+    """Priorities RISE from round to round: a higher-priority arrival dissolves the prefill sets (check_dispose_prefill, scheduler/taskqueue.rs:148-154),
+    their tasks return to the queues in state Retracting — to the resident set as ordinary `hqtick_ready_add` deltas, listed in the snapshot's
+    retracting_* arrays — and the next tick may take them (redirect, no record).  Every tick of the delta-updated resident set must equal the oracle's
+    tick on the full snapshot; retract responses arrive for some tasks in between (reactor.rs:462-508)."""
+    from hyperqueue_amd.tick import HqTickError
+    from oracle.oracle import Oracle
+
+    rng = np.random.default_rng(7000 + seed)
+    cfg = abi.make_config(reserve=int(rng.integers(0, 2)), fill_max=int(rng.integers(1, 4)), time_limit_s=20.0)
+    envs = [SchedEnv(cfg), SchedEnv(cfg)]
+    be, o = ResidentBackend(cfg), Oracle(cfg, canonical=True)
+    shapes = [TB().cpus(1), TB().cpus(2)]
+    for e in envs:
+        for c in [int(x) for x in np.random.default_rng(seed).integers(1, 5, size=3)]:
+            e.new_worker(WB(c))
+    prio, seen_retracting = 0, 0
+    for round_ in range(6):
+        n_new = int(rng.integers(1, 7)) if round_ else int(rng.integers(8, 16)); which = [int(rng.integers(0, 2)) for _ in range(n_new)]
+        if round_ and rng.random() < 0.7:
+            prio += 1  # the new batch outranks everything prefilled so far
+        for e in envs:
+            for c in which:
+                e.new_task(shapes[c].user_priority(prio))
+        snaps = [e.snapshot() for e in envs]
+        seen_retracting += len(snaps[0].retracting)
+        try:
+            rg = be.tick(snaps[0])
+        except HqTickError as err:  # a Retracting task reached the prefill step: the reference asserts there; the oracle must agree
+            assert err.code == abi.HQTICK_E_UNSUPPORTED
+            with pytest.raises(RuntimeError):
+                o.tick(snaps[1])
+            return
+        ro = o.tick(snaps[1])
+        assert_same(rg, ro)
+        envs[0].apply(rg); envs[1].apply(ro)
+        k = int(rng.integers(1, 7)); answer = rng.random() < 0.6
+        for e in envs:
+            done = 0
+            for t in sorted(e.tasks.values(), key=lambda t: t.id):
+                if t.state == 1 and done < k:
+                    e.finish_task(t.id, t.worker); done += 1
+            if answer:
+                rt = [t for t in sorted(e.tasks.values(), key=lambda t: t.id) if t.state == 4 and t.id not in e.retaken_variant][:2]
+                for t in rt:
+                    e.retract_response(t.worker, [t.id])
+    assert be.stats["consumed"] > 0
 
 
 def test_resident_deltas_on_c3_reduced():
