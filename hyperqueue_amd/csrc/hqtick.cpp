@@ -66,7 +66,9 @@ struct hqtick_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // K2 (worker evaluation: PCIe-latency-bound reads of the worker tables) runs here, next to K1 + K1b on `stream`
-    bool k2_own_stream = true;     // HQTICK_K2_RIDE_ALONG=1 puts it back into K1's launch (round 1's layout)
+    bool k2_own_stream = false;    // HQTICK_K2_RIDE_ALONG=0: K2 as its own launch on stream2.  Measured (profiles/r02/README.md): K1 alone then takes 4.8 us instead of
+                                   // 8.2 us (0.31 vs 0.18 of the HBM roofline), but the second stream's launch + synchronisation make phase A 36 us instead of 28 us:
+                                   // the ride-along layout stays the default because the TICK is what counts
     hipEvent_t ev[12] = {};
     std::string err = "";
     // ready set
