@@ -37,6 +37,8 @@ __global__ __launch_bounds__(BLOCK) void k_wire_plan(Args a) {
     plan_p5(a, lds, s, tid);
     __syncthreads();
     plan_p6(a, lds, s, tid);
+    __syncthreads();
+    plan_p7(a, lds, s, tid);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_wire_scan(Args a) {
@@ -53,13 +55,17 @@ __global__ __launch_bounds__(BLOCK) void k_wire_emit(Args a) {
     __shared__ EmitLds lds;
     const uint32_t s = blockIdx.x;
     const int tid = (int)threadIdx.x;
-    emit_p1(a, lds, s, tid);
-    __syncthreads();
-    emit_p2(a, lds, s, tid);
-    __syncthreads();
-    emit_p3(a, lds, s, tid);
-    __syncthreads();
-    emit_p4(a, lds, s, tid);
+    const uint32_t nf = nfrag_of(a, s) ? nfrag_of(a, s) : 1;  // uniform per workgroup; fragment 0 also carries the slot's RetractTasks message
+    for (uint32_t f = 0; f < nf; f++) {
+        emit_p1(a, lds, s, f, tid);
+        __syncthreads();
+        emit_p2(a, lds, s, f, tid);
+        __syncthreads();
+        emit_p3(a, lds, s, f, tid);
+        __syncthreads();
+        emit_p4(a, lds, s, f, tid);
+        __syncthreads();
+    }
 }
 
 bool make_args(const hqwire_tables *t, const hqwire_records *r, const hqwire_output *o, Args &a) {
@@ -75,6 +81,9 @@ bool make_args(const hqwire_tables *t, const hqwire_records *r, const hqwire_out
     a.o = *o;
     a.n_slots = r->n_workers + r->n_mn;
     if (o->scratch_bytes < scratch_bytes((uint64_t)r->n_records + r->n_mn, a.n_slots)) return false;
+    if ((reinterpret_cast<uintptr_t>(o->scratch) & 7) || (reinterpret_cast<uintptr_t>(o->slot_off) & 7)) return false;  // u64 stores in bind_scratch / scan_p3
+    if ((o->slot_nfrag == nullptr) != (o->frag_end == nullptr)) return false;
+    if (o->frag_end && (reinterpret_cast<uintptr_t>(o->frag_end) & 7)) return false;
     bind_scratch(a);
     return true;
 }

@@ -21,7 +21,7 @@
 namespace hqwire {
 
 constexpr int BLOCK = 256;
-constexpr uint32_t HT = 4096, NONE = 0xFFFFFFFFu, MAXREC = HQWIRE_MAX_RECORDS;
+constexpr uint32_t HT = 4096, NONE = 0xFFFFFFFFu, MAXREC = HQWIRE_MAX_RECORDS, FMAX = HQWIRE_MAX_FRAGMENTS;
 static_assert(HT >= 2 * MAXREC, "dedup table load factor <= 0.5");
 
 struct Args {
@@ -35,9 +35,13 @@ struct Args {
     uint32_t *rec_row;     // [n_rec]       row of the record's task in the attribute table
     uint32_t *rec_shared;  // [n_rec]       shared_index of the record
     uint32_t *cfg_list;    // [n_rec]       slot's configurations in first-occurrence order, at [slot's first record + k]
+                           //               (a fragmented slot: every fragment's list at [slot's first record + fragment's first record + k])
+    uint32_t *frag_rec;    // [n_slots * FMAX] record index (inside the slot) at which fragment f ends
+    uint32_t *frag_ncfg;   // [n_slots * FMAX] distinct configurations of fragment f
+    uint64_t limit;        // the builder's estimate limit
 };
 
-HQW_HD uint64_t scratch_bytes(uint64_t n_rec, uint64_t n_slots) { return 16 * n_slots + 4 * ((n_slots + 1) & ~1ull) + 12 * n_rec + 16; }
+HQW_HD uint64_t scratch_bytes(uint64_t n_rec, uint64_t n_slots) { return 16 * n_slots + 4 * ((n_slots + 1) & ~1ull) + 12 * n_rec + 8ull * FMAX * n_slots + 16; }
 
 HQW_HD void bind_scratch(Args &a) {
     uint8_t *p = (uint8_t *)a.o.scratch;
@@ -49,6 +53,9 @@ HQW_HD void bind_scratch(Args &a) {
     a.rec_row = (uint32_t *)p;
     a.rec_shared = a.rec_row + n_rec;
     a.cfg_list = a.rec_shared + n_rec;
+    a.frag_rec = a.cfg_list + n_rec;
+    a.frag_ncfg = a.frag_rec + (uint64_t)FMAX * a.n_slots;
+    a.limit = a.o.msg_size_limit ? a.o.msg_size_limit : HQWIRE_MAX_TASK_MSG_SIZE;
 }
 
 // ---- what one message slot covers -------------------------------------------------------------------------------------------------------
@@ -166,7 +173,7 @@ struct PlanLds {
     uint64_t part_bytes[BLOCK], part_est[BLOCK];
     uint32_t part_cnt[BLOCK], base_cnt[BLOCK];
     uint64_t rec_total, est_total;
-    uint32_t n_cfg, bad;
+    uint32_t n_cfg, bad, n_frag;
 };
 
 HQW_HD uint32_t ht_find(const PlanLds &l, uint32_t cfg) {
@@ -285,11 +292,59 @@ HQW_HD void plan_p6(const Args &a, PlanLds &l, uint32_t s, int tid) {
         est += l.part_est[t];
     }
     uint32_t status = l.bad;
-    if (status == HQWIRE_SLOT_OK && est > HQWIRE_MAX_TASK_MSG_SIZE) status = HQWIRE_SLOT_OVERSIZE;  // create_message_on_overflow  task.rs:388-400
-    a.o.slot_status[s] = (uint8_t)status;
+    l.n_frag = (status == HQWIRE_SLOT_OK && sv.n) ? 1 : 0;
+    if (status == HQWIRE_SLOT_OK && est > a.limit) {  // create_message_on_overflow  task.rs:388-400
+        if (a.o.slot_nfrag && a.o.frag_end) l.n_frag = FMAX + 1;  // "cut it": phase 7 finds the cuts
+        else status = HQWIRE_SLOT_OVERSIZE;
+    }
+    l.bad = status;
     a.slot_ncfg[s] = l.n_cfg;
     a.slot_len[2 * s] = sv.n_retract ? 12 + 8ull * sv.n_retract : 0;                                  // tag + len + ids
     a.slot_len[2 * s + 1] = (status == HQWIRE_SLOT_OK && sv.n) ? 4 + 8 + l.rec_total + 8 + sh : 0;    // tag + len + tasks + len + shared
+    if (l.n_frag == 1) { a.frag_rec[(uint64_t)s * FMAX] = sv.n; a.frag_ncfg[(uint64_t)s * FMAX] = l.n_cfg; }
+}
+// Fragmentation of an over-limit slot, exactly as the builder does it (task.rs:346-400): records in send order; a configuration's shared
+// estimate counts at its first use INSIDE the current message, then the record's own estimate; the message is cut after the record that
+// takes the estimate past the limit, and the configuration index starts afresh.  One thread: the cut positions are a sequential
+// function of the running estimate (rare path: a worker receiving more than 32 MiB of task data in one tick).
+HQW_HD void plan_p7(const Args &a, PlanLds &l, uint32_t s, int tid) {
+    if (tid != 0) return;
+    const Slot sv = slot_of(a, s);
+    if (l.n_frag == FMAX + 1) {
+        uint32_t nf = 0, r0 = 0, ncfg = 0;
+        uint64_t est = 0, bytes = 0, total = 0;
+        for (uint32_t j = 0; j < HT; j++) l.key[j] = l.val[j] = NONE;
+        bool too_many = false;
+        for (uint32_t i = 0; i < sv.n; i++) {
+            const uint32_t row = a.rec_row[sv.rec0 + i], cfg = a.t.task_config[row];
+            uint32_t h = hash_cfg(cfg);
+            while (l.key[h] != NONE && l.key[h] != cfg) h = (h + 1) & (HT - 1);
+            if (l.key[h] == NONE) {
+                l.key[h] = cfg; l.val[h] = ncfg;
+                a.cfg_list[sv.rec0 + r0 + ncfg] = cfg;
+                ncfg++;
+                est += shared_estimate(a, cfg); bytes += shared_bytes(a, cfg);
+            }
+            a.rec_shared[sv.rec0 + i] = l.val[h];
+            const Rec r = rec_of(a, sv, i);
+            est += rec_estimate(a, r, row); bytes += rec_bytes(a, r, row);
+            const bool last = i + 1 == sv.n;
+            if (est > a.limit || last) {
+                if (nf == FMAX) { too_many = true; break; }
+                a.frag_rec[(uint64_t)s * FMAX + nf] = i + 1; a.frag_ncfg[(uint64_t)s * FMAX + nf] = ncfg;
+                total += 4 + 8 + 8 + bytes;
+                nf++;
+                r0 = i + 1; ncfg = 0; est = 0; bytes = 0;
+                if (!last) for (uint32_t j = 0; j < HT; j++) l.key[j] = l.val[j] = NONE;
+            }
+        }
+        if (too_many) { l.bad = HQWIRE_SLOT_OVERSIZE; l.n_frag = 0; a.slot_len[2 * s + 1] = 0; }
+        else { l.n_frag = nf; a.slot_len[2 * s + 1] = total; }
+    }
+    a.o.slot_status[s] = (uint8_t)l.bad;
+    if (a.o.slot_nfrag) a.o.slot_nfrag[s] = l.bad == HQWIRE_SLOT_OK ? l.n_frag : 0;
+    if (!a.o.slot_nfrag) { /* fragment tables live in the scratch only */ }
+    a.slot_ncfg[s] = (a.slot_ncfg[s] & 0x00FFFFFFu) | ((l.bad == HQWIRE_SLOT_OK ? l.n_frag : 0) << 24);  // emit reads the fragment count from here (nfrag_of)
 }
 
 // =========================================================================================================================================
@@ -334,15 +389,26 @@ HQW_HD void scan_p3(const Args &a, ScanLds &l, int tid) {
 struct EmitLds {
     uint64_t part_rec[BLOCK], part_sh[BLOCK], base_rec[BLOCK], base_sh[BLOCK];
     uint32_t body_rel[MAXREC];  // offset of shared entry k's body inside the ComputeTasks message
-    uint64_t rec_total;
+    uint64_t rec_total, msg_base;
 };
+HQW_HD uint32_t nfrag_of(const Args &a, uint32_t s) { return a.slot_ncfg[s] >> 24; }
 HQW_HD bool emit_active(const Args &a, uint32_t s) { return a.o.header[0] == HQWIRE_OK && a.slot_len[2 * s + 1] != 0; }
+// fragment f of slot s: its records [r0, r1) (indices inside the slot), its configuration list and count
+struct Frag { uint32_t r0, r1, ncfg, cfg0; };
+HQW_HD Frag frag_of(const Args &a, const Slot &sv, uint32_t s, uint32_t f) {
+    Frag g{};
+    g.r0 = f ? a.frag_rec[(uint64_t)s * FMAX + f - 1] : 0;
+    g.r1 = a.frag_rec[(uint64_t)s * FMAX + f];
+    g.ncfg = a.frag_ncfg[(uint64_t)s * FMAX + f];
+    g.cfg0 = sv.rec0 + g.r0;
+    return g;
+}
 
-HQW_HD void emit_p1(const Args &a, EmitLds &l, uint32_t s, int tid) {
+HQW_HD void emit_p1(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) {
     const Slot sv = slot_of(a, s);
     l.part_rec[tid] = l.part_sh[tid] = 0;
     if (a.o.header[0] != HQWIRE_OK) return;
-    if (a.slot_len[2 * s]) {  // ToWorkerMessage::RetractTasks(TaskIdsMsg { ids })   mapping.rs:261-266
+    if (f == 0 && a.slot_len[2 * s]) {  // ToWorkerMessage::RetractTasks(TaskIdsMsg { ids })   mapping.rs:261-266
         uint8_t *m = a.o.bytes + a.o.slot_off[2 * s];
         if (tid == 0) put64(put32(m, 1), sv.n_retract);
         for (uint32_t j = (uint32_t)tid; j < sv.n_retract; j += BLOCK) {
@@ -351,17 +417,18 @@ HQW_HD void emit_p1(const Args &a, EmitLds &l, uint32_t s, int tid) {
         }
     }
     if (!emit_active(a, s)) return;
+    const Frag g = frag_of(a, sv, s, f);
     uint32_t lo, hi;
-    run_of(sv.n, tid, lo, hi);
+    run_of(g.r1 - g.r0, tid, lo, hi);
     uint64_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += rec_bytes(a, rec_of(a, sv, i), a.rec_row[sv.rec0 + i]);
+    for (uint32_t i = g.r0 + lo; i < g.r0 + hi; i++) sum += rec_bytes(a, rec_of(a, sv, i), a.rec_row[sv.rec0 + i]);
     l.part_rec[tid] = sum;
-    run_of(a.slot_ncfg[s], tid, lo, hi);
+    run_of(g.ncfg, tid, lo, hi);
     sum = 0;
-    for (uint32_t k = lo; k < hi; k++) sum += shared_bytes(a, a.cfg_list[sv.rec0 + k]);
+    for (uint32_t k = lo; k < hi; k++) sum += shared_bytes(a, a.cfg_list[g.cfg0 + k]);
     l.part_sh[tid] = sum;
 }
-HQW_HD void emit_p2(const Args &a, EmitLds &l, uint32_t s, int tid) {
+HQW_HD void emit_p2(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) {
     if (tid != 0 || !emit_active(a, s)) return;
     uint64_t r = 0, h = 0;
     for (int t = 0; t < BLOCK; t++) {
@@ -372,18 +439,22 @@ HQW_HD void emit_p2(const Args &a, EmitLds &l, uint32_t s, int tid) {
     }
     l.rec_total = r;
     const Slot sv = slot_of(a, s);
-    uint8_t *m = a.o.bytes + a.o.slot_off[2 * s + 1];
-    put64(put32(m, 0), sv.n);                      // ToWorkerMessage::ComputeTasks, tasks.len()
-    put64(m + 12 + r, a.slot_ncfg[s]);             // shared_data.len()
+    const Frag g = frag_of(a, sv, s, f);
+    l.msg_base = f ? a.o.frag_end[(uint64_t)s * FMAX + f - 1] : a.o.slot_off[2 * s + 1];
+    uint8_t *m = a.o.bytes + l.msg_base;
+    put64(put32(m, 0), g.r1 - g.r0);               // ToWorkerMessage::ComputeTasks, tasks.len()
+    put64(m + 12 + r, g.ncfg);                     // shared_data.len()
+    if (a.o.frag_end) a.o.frag_end[(uint64_t)s * FMAX + f] = l.msg_base + 12 + r + 8 + h;
 }
-HQW_HD void emit_p3(const Args &a, EmitLds &l, uint32_t s, int tid) {
+HQW_HD void emit_p3(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) {
     if (!emit_active(a, s)) return;
     const Slot sv = slot_of(a, s);
-    uint8_t *m = a.o.bytes + a.o.slot_off[2 * s + 1];
+    const Frag g = frag_of(a, sv, s, f);
+    uint8_t *m = a.o.bytes + l.msg_base;
     uint32_t lo, hi;
-    run_of(sv.n, tid, lo, hi);
+    run_of(g.r1 - g.r0, tid, lo, hi);
     uint8_t *p = m + 12 + l.base_rec[tid];
-    for (uint32_t i = lo; i < hi; i++) {  // ComputeTaskSeparateData   messages/worker.rs:27-39
+    for (uint32_t i = g.r0 + lo; i < g.r0 + hi; i++) {  // ComputeTaskSeparateData   messages/worker.rs:27-39
         const Rec r = rec_of(a, sv, i);
         const uint32_t row = a.rec_row[sv.rec0 + i];
         p = put64(p, a.rec_shared[sv.rec0 + i]);                                    // shared_index: usize
@@ -403,11 +474,11 @@ HQW_HD void emit_p3(const Args &a, EmitLds &l, uint32_t s, int tid) {
             p += n;
         }
     }
-    run_of(a.slot_ncfg[s], tid, lo, hi);
+    run_of(g.ncfg, tid, lo, hi);
     const uint64_t shared0 = 12 + l.rec_total + 8;
     p = m + shared0 + l.base_sh[tid];
     for (uint32_t k = lo; k < hi; k++) {  // ComputeTaskSharedData   messages/worker.rs:41-45 (the body itself: phase 4)
-        const uint32_t cfg = a.cfg_list[sv.rec0 + k];
+        const uint32_t cfg = a.cfg_list[g.cfg0 + k];
         p = put8(p, a.t.config_time_some[cfg] ? 1 : 0);
         if (a.t.config_time_some[cfg]) p = put32(put64(p, a.t.config_time_secs[cfg]), a.t.config_time_nanos[cfg]);
         p = put64(p, body_len(a, cfg));
@@ -415,13 +486,13 @@ HQW_HD void emit_p3(const Args &a, EmitLds &l, uint32_t s, int tid) {
         p += body_len(a, cfg);
     }
 }
-HQW_HD void emit_p4(const Args &a, EmitLds &l, uint32_t s, int tid) {
+HQW_HD void emit_p4(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) {
     if (!emit_active(a, s)) return;
     const Slot sv = slot_of(a, s);
-    uint8_t *m = a.o.bytes + a.o.slot_off[2 * s + 1];
-    const uint32_t n_cfg = a.slot_ncfg[s];
-    for (uint32_t k = 0; k < n_cfg; k++) {  // bodies: the whole workgroup copies each one, byte-coalesced
-        const uint32_t cfg = a.cfg_list[sv.rec0 + k];
+    const Frag g = frag_of(a, sv, s, f);
+    uint8_t *m = a.o.bytes + l.msg_base;
+    for (uint32_t k = 0; k < g.ncfg; k++) {  // bodies: the whole workgroup copies each one, byte-coalesced
+        const uint32_t cfg = a.cfg_list[g.cfg0 + k];
         const uint64_t n = body_len(a, cfg), b0 = a.t.body_off[cfg];
         uint8_t *dst = m + l.body_rel[k];
         for (uint64_t b = (uint64_t)tid; b < n; b += BLOCK) dst[b] = a.t.body_blob[b0 + b];
@@ -449,15 +520,19 @@ inline bool run_on_host(const Args &a, int order) {
             HQW_PHASE(plan_p4, *pl, s);
             HQW_PHASE(plan_p5, *pl, s);
             HQW_PHASE(plan_p6, *pl, s);
+            HQW_PHASE(plan_p7, *pl, s);
         }
         for (int q = 0; q < BLOCK; q++) scan_p1(a, *sl, seq[q]);
         for (int q = 0; q < BLOCK; q++) scan_p2(a, *sl, seq[q]);
         for (int q = 0; q < BLOCK; q++) scan_p3(a, *sl, seq[q]);
         for (uint32_t s = 0; s < a.n_slots; s++) {
-            HQW_PHASE(emit_p1, *el, s);
-            HQW_PHASE(emit_p2, *el, s);
-            HQW_PHASE(emit_p3, *el, s);
-            HQW_PHASE(emit_p4, *el, s);
+            const uint32_t nf = nfrag_of(a, s) ? nfrag_of(a, s) : 1;  // a slot without a ComputeTasks part still runs fragment 0: its RetractTasks message
+            for (uint32_t f = 0; f < nf; f++) {
+                for (int q = 0; q < BLOCK; q++) emit_p1(a, *el, s, f, seq[q]);
+                for (int q = 0; q < BLOCK; q++) emit_p2(a, *el, s, f, seq[q]);
+                for (int q = 0; q < BLOCK; q++) emit_p3(a, *el, s, f, seq[q]);
+                for (int q = 0; q < BLOCK; q++) emit_p4(a, *el, s, f, seq[q]);
+            }
         }
 #undef HQW_PHASE
     }

@@ -15,7 +15,8 @@ import numpy as np
 
 from . import tick
 
-HQWIRE_ABI_VERSION = 1
+HQWIRE_ABI_VERSION = 2
+HQWIRE_MAX_FRAGMENTS = 16
 HQWIRE_MAX_RECORDS = 2048
 SLOT_OK, SLOT_OVERSIZE, SLOT_UNKNOWN, SLOT_TOO_MANY = 0, 1, 2, 3
 HQWIRE_OK, HQWIRE_CAPACITY = 0, 1
@@ -37,7 +38,7 @@ class RecordsC(C.Structure):
 
 class OutputC(C.Structure):
     _fields_ = [("bytes", _vp), ("capacity", C.c_uint64), ("slot_off", _vp), ("slot_status", _vp), ("header", _vp), ("scratch", _vp),
-                ("scratch_bytes", C.c_uint64)]
+                ("scratch_bytes", C.c_uint64), ("slot_nfrag", _vp), ("frag_end", _vp), ("msg_size_limit", C.c_uint64)]
 
 
 SYMBOLS = ["hqwire_scratch_bytes", "hqwire_encode_device", "hqwire_abi_version"]
@@ -159,6 +160,8 @@ class WireResult:
     slot_status: np.ndarray        # [n_slots]
     slot_off: np.ndarray           # [2 * n_slots + 1]
     data: bytes
+    slot_nfrag: Optional[np.ndarray] = None  # [n_slots] ComputeTasks messages per slot (fragmentation, hqwire ABI 2)
+    frag_end: Optional[np.ndarray] = None    # [n_slots * HQWIRE_MAX_FRAGMENTS]
 
     def messages(self, records: WireRecords) -> List[Tuple[int, bytes]]:
         """[(worker id, message bytes)] in the order `send_messages` emits them (mapping.rs:259-292); slots the device did not build
@@ -167,10 +170,17 @@ class WireResult:
         W = records.n_workers
         for s in range(len(self.slot_status)):
             wid = int(records.worker_id[s]) if s < W else int(records.worker_id[records.mn_worker[records.mn_worker_off[s - W]]])
-            for j in (2 * s, 2 * s + 1):
-                lo, hi = int(self.slot_off[j]), int(self.slot_off[j + 1])
-                if hi > lo:
-                    out.append((wid, self.data[lo:hi]))
+            lo, hi = int(self.slot_off[2 * s]), int(self.slot_off[2 * s + 1])
+            if hi > lo:
+                out.append((wid, self.data[lo:hi]))  # RetractTasks
+            lo, hi = int(self.slot_off[2 * s + 1]), int(self.slot_off[2 * s + 2])
+            if hi > lo:
+                nf = int(self.slot_nfrag[s]) if self.slot_nfrag is not None else 1
+                for f in range(max(nf, 1)):  # a worker's ComputeTasks part: one message, or the fragments the builder's size limit cuts it into
+                    end = int(self.frag_end[s * HQWIRE_MAX_FRAGMENTS + f]) if (self.frag_end is not None and nf >= 1) else hi
+                    out.append((wid, self.data[lo:end]))
+                    lo = end
+                assert lo == hi, (s, lo, hi)
         return out
 
 
@@ -184,7 +194,7 @@ def _structs(t: WireTables, r: WireRecords, ptrs_t: List[int], ptrs_r: List[int]
     return tc, rc
 
 
-def encode_host_debug(t: WireTables, r: WireRecords, capacity: int, order: int = 0) -> WireResult:
+def encode_host_debug(t: WireTables, r: WireRecords, capacity: int, order: int = 0, limit: int = 0, fragments: bool = True) -> WireResult:
     """`hqwire_debug_encode_host_order` of libhqtick_test.so: the kernels' phase functions on the CPU (tests only; the product library has no such
     entry point); `order` = sequence of the emulated threads."""
     from . import _testhooks
@@ -198,19 +208,24 @@ def encode_host_debug(t: WireTables, r: WireRecords, capacity: int, order: int =
     S = r.n_workers + r.n_mn
     data, slot_off, status, header = np.zeros(max(1, capacity), np.uint8), np.zeros(2 * S + 1, np.uint64), np.zeros(max(1, S), np.uint8), np.zeros(4, np.uint32)
     scratch = np.zeros(int(lib.hqwire_scratch_bytes(r.n_records + r.n_mn, S)) // 8 + 1, np.uint64)
-    oc = OutputC(data.ctypes.data, capacity, slot_off.ctypes.data, status.ctypes.data, header.ctypes.data, scratch.ctypes.data, scratch.nbytes)
+    nfrag, frag_end = np.zeros(max(1, S), np.uint32), np.zeros(max(1, S) * HQWIRE_MAX_FRAGMENTS, np.uint64)
+    oc = OutputC(data.ctypes.data, capacity, slot_off.ctypes.data, status.ctypes.data, header.ctypes.data, scratch.ctypes.data, scratch.nbytes,
+                 nfrag.ctypes.data if fragments else None, frag_end.ctypes.data if fragments else None, limit)
     rc_ = lib.hqwire_debug_encode_host_order(C.byref(tc), C.byref(rc), C.byref(oc), order)
     if rc_ != 0:
         raise tick.HqTickError(rc_, "hqwire_debug_encode_host_order")
     total = int(header[2]) | int(header[3]) << 32
-    return WireResult(int(header[0]), total, status[:S].copy(), slot_off, data[:total].tobytes() if header[0] == HQWIRE_OK else b"")
+    return WireResult(int(header[0]), total, status[:S].copy(), slot_off, data[:total].tobytes() if header[0] == HQWIRE_OK else b"",
+                      nfrag[:S].copy() if fragments else None, frag_end if fragments else None)
 
 
-def _run_device(lib, torch, dev, tc: TablesC, rc: RecordsC, n_slots: int, n_rec_incl_mn: int, capacity: int) -> WireResult:
+def _run_device(lib, torch, dev, tc: TablesC, rc: RecordsC, n_slots: int, n_rec_incl_mn: int, capacity: int, limit: int = 0) -> WireResult:
     zeros = lambda n: torch.zeros(max(8, int(n)), dtype=torch.uint8, device=dev)
     data, slot_off, status, header = zeros(capacity), zeros(8 * (2 * n_slots + 1)), zeros(n_slots), zeros(16)
     scratch = zeros(int(lib.hqwire_scratch_bytes(n_rec_incl_mn, n_slots)) + 8)
-    oc = OutputC(data.data_ptr(), capacity, slot_off.data_ptr(), status.data_ptr(), header.data_ptr(), scratch.data_ptr(), scratch.numel())
+    nfrag, frag_end = zeros(4 * max(1, n_slots)), zeros(8 * max(1, n_slots) * HQWIRE_MAX_FRAGMENTS)
+    oc = OutputC(data.data_ptr(), capacity, slot_off.data_ptr(), status.data_ptr(), header.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                 nfrag.data_ptr(), frag_end.data_ptr(), limit)
     stream = torch.cuda.current_stream(dev).cuda_stream
     rc_ = lib.hqwire_encode_device(C.byref(tc), C.byref(rc), C.byref(oc), _vp(stream))
     if rc_ != 0:
@@ -219,21 +234,22 @@ def _run_device(lib, torch, dev, tc: TablesC, rc: RecordsC, n_slots: int, n_rec_
     h = header.cpu().numpy().view(np.uint32)
     total = int(h[2]) | int(h[3]) << 32
     return WireResult(int(h[0]), total, status.cpu().numpy()[:n_slots].copy(), slot_off.cpu().numpy().view(np.uint64)[: 2 * n_slots + 1].copy(),
-                      data[:total].cpu().numpy().tobytes() if h[0] == HQWIRE_OK else b"")
+                      data[:total].cpu().numpy().tobytes() if h[0] == HQWIRE_OK else b"",
+                      nfrag.cpu().numpy().view(np.uint32)[:n_slots].copy(), frag_end.cpu().numpy().view(np.uint64).copy())
 
 
 def _upload(torch, dev, arrays: List[np.ndarray]):
     return [torch.from_numpy(_padded(np.ascontiguousarray(a)).view(np.uint8).copy()).to(dev) for a in arrays]
 
 
-def encode_device(t: WireTables, r: WireRecords, capacity: int, device: str = "cuda:0") -> WireResult:
+def encode_device(t: WireTables, r: WireRecords, capacity: int, device: str = "cuda:0", limit: int = 0) -> WireResult:
     """`hqwire_encode_device`: tables and records in HBM, three kernels on torch's current stream, result copied back for inspection."""
     import torch
 
     lib, dev = load(), torch.device(device)
     tt, rt = _upload(torch, dev, t.arrays()), _upload(torch, dev, r.arrays())
     tc, rc = _structs(t, r, [x.data_ptr() for x in tt], [x.data_ptr() for x in rt])
-    return _run_device(lib, torch, dev, tc, rc, r.n_workers + r.n_mn, r.n_records + r.n_mn, capacity)
+    return _run_device(lib, torch, dev, tc, rc, r.n_workers + r.n_mn, r.n_records + r.n_mn, capacity, limit)
 
 
 def encode_from_sink(t: WireTables, sink, n_workers: int, sink_cap_records: int, n_records: int, side: WireRecords, capacity: int) -> WireResult:
@@ -280,6 +296,8 @@ def pack_wire_shard(res: WireResult, n_slots: int, capacity: int) -> np.ndarray:
     """Fixed-size shard buffer for the all-gather: u64 total | u64 slot_off[2 * n_slots + 1] | bytes[capacity]."""
     if res.status != HQWIRE_OK or res.total_bytes > capacity:
         raise ValueError(f"wire shard does not fit: {res.total_bytes} bytes, capacity {capacity}")
+    if res.slot_nfrag is not None and (res.slot_nfrag > 1).any():
+        raise ValueError("a fragmented slot (> 32 MiB for one worker): this exchange format carries one ComputeTasks message per slot")
     head = np.full(2 * n_slots + 2, res.total_bytes, np.uint64)  # slots this rank does not have (padding up to the widest rank) stay empty ranges
     head[0] = res.total_bytes
     head[1:1 + len(res.slot_off)] = res.slot_off

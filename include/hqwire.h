@@ -15,9 +15,16 @@
  * Message slots: slot w < n_workers = worker index w (its RetractTasks message, then its ComputeTasks message);
  * slot n_workers + k = multi-node task k (one ComputeTasks message for worker_id[mn_worker[mn_worker_off[k]]], the root).
  *
- * Not covered on the device, reported per slot so the host builds those messages itself (they are rare):
- *   HQWIRE_SLOT_OVERSIZE  the builder's size estimate exceeds MAX_TASK_MSG_SIZE = 32 MiB (task.rs:315,388-400): the reference would
- *                         fragment the message there
+ * Fragmentation (ABI 2).  ComputeTasksBuilder cuts a worker's message whenever its size estimate passes MAX_TASK_MSG_SIZE = 32 MiB
+ * (create_message_on_overflow, task.rs:388-400): the message so far is sent, the configuration index starts afresh.  With
+ * hqwire_output.slot_nfrag / frag_end set the device does the same: the ComputeTasks range of a slot then holds slot_nfrag[s] messages back to
+ * back, message f ending at frag_end[s * HQWIRE_MAX_FRAGMENTS + f] (absolute offset; message 0 starts at slot_off[2s + 1]), each with its own
+ * shared-data list and shared_index numbering.
+ *
+ * Not covered on the device, reported per slot so the host builds the slot's ComputeTasks messages itself (they are rare).  The slot's
+ * RetractTasks message IS emitted in every case — only the ComputeTasks part falls back:
+ *   HQWIRE_SLOT_OVERSIZE  more than HQWIRE_MAX_FRAGMENTS messages for one slot (> 512 MiB for one worker in one tick), or an estimate above the
+ *                         limit while the caller passed no fragment arrays
  *   HQWIRE_SLOT_TOO_MANY  more than HQWIRE_MAX_RECORDS records for one worker in one tick (device-side dedup table)
  *   HQWIRE_SLOT_UNKNOWN   a record names a task id that is not in the attribute table
  * No CPU implementation behind this entry point: without a gfx950 device it returns HQTICK_E_NO_DEVICE.
@@ -31,9 +38,10 @@
 extern "C" {
 #endif
 
-#define HQWIRE_ABI_VERSION 1u
+#define HQWIRE_ABI_VERSION 2u
 #define HQWIRE_MAX_RECORDS 2048u                 /* records per worker message handled on the device */
 #define HQWIRE_MAX_TASK_MSG_SIZE (32u << 20)     /* MAX_FRAME_SIZE / 4 (crates/tako/src/lib.rs:31, server/task.rs:315) */
+#define HQWIRE_MAX_FRAGMENTS 16u                 /* ComputeTasks messages one slot may be cut into on the device */
 
 enum { HQWIRE_SLOT_OK = 0, HQWIRE_SLOT_OVERSIZE = 1, HQWIRE_SLOT_UNKNOWN = 2, HQWIRE_SLOT_TOO_MANY = 3 };
 enum { HQWIRE_OK = 0, HQWIRE_CAPACITY = 1 };     /* header[0] */
@@ -81,8 +89,12 @@ typedef struct hqwire_output {
     uint64_t *slot_off;    /* [2 * n_slots + 1]: RetractTasks of slot s = [off[2s], off[2s+1]), ComputeTasks = [off[2s+1], off[2s+2]) */
     uint8_t *slot_status;  /* [n_slots] HQWIRE_SLOT_*                                                               */
     uint32_t *header;      /* [4] = { HQWIRE_OK / HQWIRE_CAPACITY, n_slots, total bytes low, total bytes high }     */
-    void *scratch;         /* hqwire_scratch_bytes(n_records + n_mn, n_slots)                                       */
+    void *scratch;         /* hqwire_scratch_bytes(n_records + n_mn, n_slots); 8-byte aligned                       */
     uint64_t scratch_bytes;
+    /* ABI 2: fragmentation.  Both NULL = off (an estimate above the limit then marks the slot HQWIRE_SLOT_OVERSIZE). */
+    uint32_t *slot_nfrag;  /* [n_slots] ComputeTasks messages of the slot (0 = none)                                */
+    uint64_t *frag_end;    /* [n_slots * HQWIRE_MAX_FRAGMENTS] absolute end offset of message f of slot s           */
+    uint64_t msg_size_limit; /* 0 = HQWIRE_MAX_TASK_MSG_SIZE; the builder's estimate limit (tests use small values)  */
 } hqwire_output;
 
 uint64_t hqwire_scratch_bytes(uint64_t n_records_incl_mn, uint64_t n_slots);

@@ -83,13 +83,52 @@ def test_slot_conditions():
     records = [[(1, 0, 1)], [(2, 0, 1)], [(99, 0, 1)], [(3, 0, 1)] * (wire.HQWIRE_MAX_RECORDS + 1)]
     retracts = [[], [5], [], []]
     t, r = wc.tables_and_records(attrs, configs, worker_ids, records, retracts, [])
-    res = wire.encode_host_debug(t, r, 1 << 20)
+    res = wire.encode_host_debug(t, r, 1 << 20, fragments=False)  # without fragment arrays an over-limit slot is the host's (hqwire ABI 1 behaviour)
     assert res.status == wire.HQWIRE_OK
     assert res.slot_status.tolist() == [wire.SLOT_OK, wire.SLOT_OVERSIZE, wire.SLOT_UNKNOWN, wire.SLOT_TOO_MANY]
     msgs = res.messages(r)
     want = wc.oracle_messages({k: v for k, v in attrs.items()}, configs, worker_ids[:1], records[:1], retracts[:1], [])
     assert msgs[0] == want[0]
     assert msgs[1] == (11, wo.retract_message([5])) and len(msgs) == 2  # the host builds the ComputeTasks messages of slots 1-3 itself
+
+
+@pytest.mark.parametrize("seed,limit", [(s, l) for s in range(100, 112) for l in (700, 1500, 4000)])
+def test_fragmentation_matches_the_builder(seed, limit):
+    """ComputeTasksBuilder cuts a worker's message whenever its size estimate passes the limit and starts the configuration index afresh
+    (create_message_on_overflow, server/task.rs:388-400): with a small limit on both sides the device phases must produce the same messages
+    as the oracle's builder — same cuts, same shared-data lists, same shared_index numbering — in every emulated thread order."""
+    sc = wc.random_scenario(seed, max_rec=60)
+    for order in (0, 1, 2):
+        res = wc.check_scenario(lambda t, r, cap: wire.encode_host_debug(t, r, cap, order, limit=limit), sc, limit=limit)
+    assert res.slot_nfrag is not None
+    wc.check_roundtrip(sc, res.messages(wc.tables_and_records(*sc)[1]))
+
+
+def test_fragmentation_really_cuts():
+    """one worker, 100 records over 5 configurations, limit 600: nine messages, each with its own shared-data list"""
+    rnd = __import__("random").Random(3)
+    configs = [(None if k % 2 else (k, 7), bytes([65 + k]) * (10 + 13 * k)) for k in range(5)]
+    attrs = {(1 << 32) | i: (i % 3, i, (0x80000000 + i % 2) << 32, rnd.randrange(5), None if i % 4 else b"e" * (i % 9)) for i in range(1, 101)}
+    recs = [((1 << 32) | i, i % 2, 1 if i % 5 else 0) for i in range(1, 101)]
+    recs = [(t, 0xFF if k == 0 else v, k) for (t, v, k) in recs]
+    sc = (attrs, configs, [42], [recs], [[(1 << 32) | 500]], [])
+    res = wc.check_scenario(lambda t, r, cap: wire.encode_host_debug(t, r, cap, limit=600), sc, limit=600)
+    assert 5 <= int(res.slot_nfrag[0]) <= wire.HQWIRE_MAX_FRAGMENTS
+    msgs = res.messages(wc.tables_and_records(*sc)[1])
+    assert len(msgs) == 1 + int(res.slot_nfrag[0]) and msgs[0][1][:4] == (1).to_bytes(4, "little")  # RetractTasks first
+    wc.check_roundtrip(sc, msgs)
+
+
+def test_fragment_count_limit_and_single_oversize_task():
+    attrs = {i: (0, 0, 0, 0, bytes(50)) for i in range(1, 41)}
+    configs = [(None, b"x" * 10)]
+    t, r = wc.tables_and_records(attrs, configs, [7, 8], [[(i, 0, 1) for i in range(1, 41)], [(1, 0, 1)]], [[9], []], [])
+    res = wire.encode_host_debug(t, r, 1 << 20, limit=60)  # every task passes the limit on its own: 40 messages > HQWIRE_MAX_FRAGMENTS
+    assert res.slot_status.tolist() == [wire.SLOT_OVERSIZE, wire.SLOT_OK] and res.slot_nfrag.tolist() == [0, 1]
+    msgs = res.messages(r)
+    assert msgs[0] == (7, wo.retract_message([9]))  # the RetractTasks message of a refused slot is still there
+    want = wc.oracle_messages(attrs, configs, [8], [[(1, 0, 1)]], [[]], [], limit=60)
+    assert msgs[1:] == want  # a single task above the limit is one message (the builder cuts AFTER adding it)
 
 
 def test_capacity_reported():

@@ -140,3 +140,23 @@ def test_tick_to_bytes_through_the_record_sink(wire_canary):
     assert got.messages(side) == wc.oracle_messages(*sc)
     wc.check_roundtrip(sc, got.messages(side))
     st.t.close()
+
+
+@pytest.mark.parametrize("seed,limit", [(s, l) for s in range(100, 106) for l in (700, 4000)])
+def test_device_fragmentation_matches_the_builder(seed, limit, wire_canary):
+    """create_message_on_overflow (server/task.rs:388-400) on the device: with the builder's limit lowered on both sides, the kernels cut every
+    worker's ComputeTasks message where the oracle's builder cuts it, each fragment with its own shared-data list and shared_index numbering"""
+    sc = wc.random_scenario(seed, max_rec=60)
+    res = wc.check_scenario(lambda t, r, cap: wire.encode_device(t, r, cap, limit=limit), sc, limit=limit)
+    wc.check_roundtrip(sc, res.messages(wc.tables_and_records(*sc)[1]))
+
+
+def test_device_fragmentation_really_cuts(wire_canary):
+    rnd = random.Random(3)
+    configs = [(None if k % 2 else (k, 7), bytes([65 + k]) * (10 + 13 * k)) for k in range(5)]
+    attrs = {(1 << 32) | i: (i % 3, i, (0x80000000 + i % 2) << 32, rnd.randrange(5), None if i % 4 else b"e" * (i % 9)) for i in range(1, 101)}
+    recs = [((1 << 32) | i, 0xFF if i % 5 == 0 else i % 2, 0 if i % 5 == 0 else 1) for i in range(1, 101)]
+    sc = (attrs, configs, [42, 43], [recs, recs[:3]], [[(1 << 32) | 500], []], [])
+    res = wc.check_scenario(lambda t, r, cap: wire.encode_device(t, r, cap, limit=600), sc, limit=600)
+    assert 5 <= int(res.slot_nfrag[0]) <= wire.HQWIRE_MAX_FRAGMENTS and int(res.slot_nfrag[1]) == 1
+    wc.check_roundtrip(sc, res.messages(wc.tables_and_records(*sc)[1]))

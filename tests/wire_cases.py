@@ -43,23 +43,24 @@ def random_scenario(seed, n_workers=None, max_rec=30):
     return attrs, configs, worker_ids, records, retracts, mn
 
 
-def oracle_messages(attrs, configs, worker_ids, records, retracts, mn):
+def oracle_messages(attrs, configs, worker_ids, records, retracts, mn, limit=None):
     a = {t: wo.TaskAttr(*v) for t, v in attrs.items()}
     c = [wo.Config(tl, body) for (tl, body) in configs]
-    return wo.send_messages(a, c, worker_ids, records, retracts, mn)
+    return wo.send_messages(a, c, worker_ids, records, retracts, mn, **({} if limit is None else {"limit": limit}))
 
 
 def tables_and_records(attrs, configs, worker_ids, records, retracts, mn):
     return wire.WireTables.build(attrs, configs), wire.WireRecords.build(worker_ids, records, retracts, mn)
 
 
-def check_scenario(encode, sc, capacity=1 << 22):
-    """`encode(tables, records, capacity) -> WireResult` against the oracle: same messages, byte for byte, in send order."""
+def check_scenario(encode, sc, capacity=1 << 22, limit=None):
+    """`encode(tables, records, capacity) -> WireResult` against the oracle: same messages, byte for byte, in send order.  `limit`: the builder's
+    size-estimate limit on both sides (default: the reference's 32 MiB) — small values exercise the fragmentation (task.rs:388-400)."""
     t, r = tables_and_records(*sc)
     res = encode(t, r, capacity)
     assert res.status == wire.HQWIRE_OK
     assert (res.slot_status == 0).all()
-    got, want = res.messages(r), oracle_messages(*sc)
+    got, want = res.messages(r), oracle_messages(*sc, limit=limit)
     assert len(got) == len(want)
     for (gw, gb), (ww, wb) in zip(got, want):
         assert gw == ww

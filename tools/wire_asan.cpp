@@ -1,7 +1,8 @@
 // Sanitizer harness for the wire-encoding phases (csrc/wire_core.h): every input / output / scratch array in its own heap block of EXACTLY the
 // size the ABI promises, the phases run under AddressSanitizer + UBSan -- an out-of-bounds access that the ctypes tests would survive
 // silently (and that would be a memory fault on the GPU) aborts here.  Built and driven by tools/wire_asan.py; CPU only, test tooling.
-//   wire_asan <scenario.bin> <capacity> <order>  ->  writes <scenario.bin>.out = header[4] u32 | slot_status | slot_off | bytes
+//   wire_asan <scenario.bin> <capacity> <order> [limit]  ->  writes <scenario.bin>.out = header[4] u32 | slot_status | slot_off |
+//   (limit given: slot_nfrag u32[S] | frag_end u64[S * HQWIRE_MAX_FRAGMENTS] |) bytes.  A limit turns the fragmentation on (hqwire ABI 2).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +37,7 @@ int main(int argc, char **argv) {
     cur = buf.data();
     const uint64_t capacity = strtoull(argv[2], nullptr, 10);
     const int order = atoi(argv[3]);
+    const uint64_t limit = argc > 4 ? strtoull(argv[4], nullptr, 10) : 0;
 
     hqwire::Args a{};
     a.t.n_tasks = take_u64();
@@ -76,6 +78,11 @@ int main(int argc, char **argv) {
     a.o.header = (uint32_t *)malloc(16);
     a.o.scratch = malloc(sb);
     a.o.scratch_bytes = sb;
+    if (limit) {
+        a.o.slot_nfrag = (uint32_t *)malloc(S ? 4 * S : 1);
+        a.o.frag_end = (uint64_t *)malloc(S ? 8 * S * HQWIRE_MAX_FRAGMENTS : 1);
+        a.o.msg_size_limit = limit;
+    }
     hqwire::bind_scratch(a);
     if (!hqwire::run_on_host(a, order)) return 3;
 
@@ -84,10 +91,15 @@ int main(int argc, char **argv) {
     fwrite(a.o.header, 4, 4, o);
     fwrite(a.o.slot_status, 1, S, o);
     fwrite(a.o.slot_off, 8, 2 * S + 1, o);
+    if (limit) {
+        fwrite(a.o.slot_nfrag, 4, S, o);
+        fwrite(a.o.frag_end, 8, S * HQWIRE_MAX_FRAGMENTS, o);
+    }
     const uint64_t total = (uint64_t)a.o.header[2] | (uint64_t)a.o.header[3] << 32;
     if (a.o.header[0] == HQWIRE_OK) fwrite(a.o.bytes, 1, total, o);
     fclose(o);
     free(a.o.bytes); free(a.o.slot_off); free(a.o.slot_status); free(a.o.header); free(a.o.scratch);
+    free(a.o.slot_nfrag); free(a.o.frag_end);
     for (void *p : blocks) free(p);
     return 0;
 }
