@@ -27,6 +27,8 @@ const double INF = 1e300;
 const double FEAS_TOL = 1e-9;   // primal bound violation (rows are scaled to max |coef| = 1)
 const double PIV_TOL = 1e-9;
 const double INT_TOL = 1e-7;
+const int LNS_FIRST_COLS = 128;          // models from this size on improve the greedy incumbent by window search before any tree search
+const double EXACT_PASS_WORK = 5.0e7;    // floor of the exact pass's budget after a gap certificate, in tableau element updates (~50 ms)
 const double UB_CAP = 1048576.0;  // columns with no derivable bound (unbounded models => `None`, highs.rs:82)
 const double TAB_LIMIT = 6.0e7;   // doubles in one tableau (480 MB): beyond it the LP gives up (reported like a time limit)
 
@@ -250,6 +252,13 @@ struct Tab {
     }
 };
 
+struct DSUlite {
+    std::vector<int> p;
+    explicit DSUlite(int n) : p(n) { std::iota(p.begin(), p.end(), 0); }
+    int find(int a) { while (p[a] != a) { p[a] = p[p[a]]; a = p[a]; } return a; }
+    void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[std::max(a, b)] = std::min(a, b); }
+};
+
 struct CompSolver {
     int n = 0;
     Rows R;
@@ -311,8 +320,9 @@ struct CompSolver {
 
     // Objective lattice: if every cost is an integer multiple of q (the tick's costs are amount/pool x weight x (W - idx)/W, rationals with a
     // common denominator), an integral point better than the incumbent is better by at least q: nodes whose LP bound is below best + q hold none.
-    double quantum = 0.0;
+    double quantum = 0.0, lattice = -1.0;  // lattice >= 0: handed down by the parent model (window sub-problems), no search
     void find_quantum() {
+        if (lattice >= 0.0) { quantum = lattice; return; }
         double cmaxv = 0.0; for (int j = 0; j < n; j++) cmaxv = std::max(cmaxv, std::fabs(c[j]));
         if (cmaxv == 0.0) return;
         const double tol = 1e-10 * cmaxv;
@@ -331,10 +341,21 @@ struct CompSolver {
         quantum = g;
     }
     // a node with LP bound z can be dropped when no integral point in it beats the incumbent
-    bool cannot_improve(double z) const {
+    // What "optimal" means (milp.h): the reference's HiGHS stops at mip_rel_gap = 1e-4, so a node whose LP bound is within rel_gap of the incumbent
+    // is closed.  `gap_pruned` records that this rule (and not the exact one) closed a node: the incumbent is then certified, not proven exact.
+    double rel_gap = 0.0;
+    bool gap_pruned = false;
+    double root_bound = INF;  // LP bound of the whole component, once the root LP is solved
+    bool certified() const { return have && rel_gap > 0.0 && root_bound <= best + rel_gap * std::fabs(best); }
+    double t_begin = wall();
+    bool tracing = getenv("HQMILP_TRACE") != nullptr;
+    void trace(const char *what) { if (tracing && !in_lns) fprintf(stderr, "[milp] n=%d t=%.3fs %s: incumbent %.9f nodes %ld\n", n, wall() - t_begin, what, have ? best : -1.0, nodes); }
+    bool cannot_improve(double z) {
         if (!have) return false;
         if (z <= best + 1e-12 * std::fabs(best)) return true;
-        return quantum > 0.0 && z < best + quantum * (1.0 - 1e-6);
+        if (quantum > 0.0 && z < best + quantum * (1.0 - 1e-6)) return true;
+        if (rel_gap > 0.0 && z <= best + rel_gap * std::fabs(best)) { gap_pruned = true; return true; }
+        return false;
     }
 
     // Branching column: among the fractional ones the most valuable (largest cost), ties by fractionality.  The tick's objective is
@@ -365,7 +386,7 @@ struct CompSolver {
         int s = solve_counted(t);
         if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return; }
         double z = t.objective();
-        if (nodes == 1 && getenv("HQMILP_TRACE")) fprintf(stderr, "[milp] n=%d root LP %.9f incumbent %.9f rel gap %.3e\n", n, z, have ? best : -1.0, have ? (z - best) / best : 0.0);
+        if (nodes == 1 && tracing && !in_lns) fprintf(stderr, "[milp] n=%d root LP %.9f incumbent %.9f rel gap %.3e\n", n, z, have ? best : -1.0, have ? (z - best) / best : 0.0);
         if (cannot_improve(z)) return;
         int j = pick_fractional(t);
         if (j >= 0 && (nodes == 1 || (nodes & 63) == 0)) {  // root and every 64th node: try to close the gap from this LP point
@@ -517,56 +538,118 @@ struct CompSolver {
     bool in_lns = false;
     // window = columns [start, start + win) and, with stride > 0, also [start + stride, start + stride + win): neighbouring workers, or two groups
     // of workers far apart (tasks move between the early, well-paid workers and the late ones)
+    std::vector<int> lns_local; std::vector<char> lns_row_mark; double lns_stat[5] = {0, 0, 0, 0, 0};
+    // one neighbourhood: the columns `wcols` are free, every other column keeps its incumbent value; true when the incumbent improved
+    bool lns_solve(const std::vector<int> &wcols, double until, long cap, const std::vector<double> *base = nullptr) {
+        const std::vector<double> &fx = base ? *base : bx;  // values of the columns outside the neighbourhood
+        const int wn = (int)wcols.size();
+        if (coff.empty()) build_columns();
+        if (lns_local.empty()) { lns_local.assign(n, -1); lns_row_mark.assign(R.m, 0); }
+        std::vector<int> &local = lns_local; std::vector<char> &row_mark = lns_row_mark;
+        bool any_room = false;
+        for (int j : wcols) if (ub[j] > lb[j]) any_room = true;
+        if (!any_room) return false;
+        std::vector<int> rows_used; std::vector<std::pair<int, double>> terms;
+        CompSolver sub; sub.n = wn; sub.in_lns = true; sub.deadline = until;  // per-window limit = the node cap below, not a clock: same answer on every replica
+        sub.c.resize(wn); sub.lb.resize(wn); sub.ub.resize(wn);
+        for (int q = 0; q < wn; q++) { sub.c[q] = c[wcols[q]]; sub.lb[q] = lb[wcols[q]]; sub.ub[q] = ub[wcols[q]]; }
+        sub.R.n = wn;
+        for (int q = 0; q < wn; q++) { const int j = wcols[q]; local[j] = q; for (int k = coff[j]; k < coff[j + 1]; k++) if (!row_mark[crow[k]]) { row_mark[crow[k]] = 1; rows_used.push_back(crow[k]); } }
+        std::sort(rows_used.begin(), rows_used.end());
+        for (int i : rows_used) {
+            row_mark[i] = 0;
+            terms.clear(); double fixed = 0.0;
+            for (int k = R.off[i]; k < R.off[i + 1]; k++) { const int j = R.col[k]; if (local[j] >= 0) terms.push_back({local[j], R.coef[k]}); else fixed += R.coef[k] * fx[j]; }
+            sub.R.add(terms, R.lo[i] <= -INF ? -INF : R.lo[i] - fixed, R.hi[i] >= INF ? INF : R.hi[i] - fixed);
+        }
+        for (int j : wcols) local[j] = -1;
+        double z0 = 0.0;
+        if (!base) {
+            sub.bx.resize(wn); for (int q = 0; q < wn; q++) sub.bx[q] = bx[wcols[q]];
+            for (int j = 0; j < wn; j++) z0 += sub.c[j] * sub.bx[j];
+            sub.have = true; sub.best = z0;
+        } else {  // RENS: the neighbourhood of the LP point — its columns between floor and ceiling, no incumbent of its own; worth it only above the incumbent
+            double zfix = 0.0; for (int j = 0; j < n; j++) zfix += c[j] * fx[j];
+            for (int q = 0; q < wn; q++) { const int j = wcols[q]; zfix -= c[j] * fx[j]; sub.lb[q] = std::max(lb[j], std::floor(fx[j] + INT_TOL)); sub.ub[q] = std::min(ub[j], sub.lb[q] + 1.0); }
+            z0 = best - zfix;  // what the neighbourhood has to beat
+            sub.have = true; sub.best = z0; sub.bx.assign(wn, 0.0);  // a cutoff, not a point: adopted below only if beaten
+        } sub.lattice = quantum;  // the window's costs are a subset of this model's: an improvement is at least one quantum
+        sub.node_cap = cap;
+        std::vector<double> xw;
+        const int st = sub.run(false, xw);
+        nodes += sub.nodes; lp_iters += sub.lp_iters;
+        if (base && tracing) fprintf(stderr, "[milp] rens sub: st %d best %.9f cutoff %.9f nodes %ld\n", st, sub.best, z0, sub.nodes);
+        if ((st == 1 || st == 2) && sub.best > z0 + 1e-12 * std::fabs(best)) {
+            if (base) bx = fx;
+            for (int q = 0; q < wn; q++) bx[wcols[q]] = xw[q];
+            double zz = 0.0; for (int j = 0; j < n; j++) zz += c[j] * bx[j];
+            best = zz;
+            return true;
+        }
+        return false;
+    }
     bool lns_windows(double until, int win, int stride = 0, int groups = 2) {
         if (!have || in_lns || n <= win) return false;
         bool improved = false;
-        if (coff.empty()) build_columns();
-        std::vector<int> local(n, -1), rows_used; std::vector<char> row_mark(R.m, 0);
-        std::vector<std::pair<int, double>> terms;
         std::vector<int> wcols;
-        for (int start = 0; start < n && wall() < until && !timed_out; start += (stride > 0 ? win : win / 2)) {
+        for (int start = 0; start < n && wall() < until && !timed_out && !certified(); start += (stride > 0 ? win : win / 2)) {
             wcols.clear();
             for (int j = start; j < std::min(n, start + win); j++) wcols.push_back(j);
             if (stride > 0) {
                 if (start + stride >= n) break;
                 for (int g = 1; g < groups; g++) for (int j = start + g * stride; j < std::min(n, start + g * stride + win); j++) wcols.push_back(j);
             }
-            const int wn = (int)wcols.size();
-            bool any_room = false;
-            for (int j : wcols) if (ub[j] > lb[j]) any_room = true;
-            if (!any_room) continue;
-            CompSolver sub; sub.n = wn; sub.in_lns = true; sub.deadline = until;  // per-window limit = the node cap below, not a clock: same answer on every replica
-            sub.c.resize(wn); sub.lb.resize(wn); sub.ub.resize(wn);
-            for (int q = 0; q < wn; q++) { sub.c[q] = c[wcols[q]]; sub.lb[q] = lb[wcols[q]]; sub.ub[q] = ub[wcols[q]]; }
-            sub.R.n = wn;
-            rows_used.clear();
-            for (int q = 0; q < wn; q++) { const int j = wcols[q]; local[j] = q; for (int k = coff[j]; k < coff[j + 1]; k++) if (!row_mark[crow[k]]) { row_mark[crow[k]] = 1; rows_used.push_back(crow[k]); } }
-            std::sort(rows_used.begin(), rows_used.end());
-            for (int i : rows_used) {
-                row_mark[i] = 0;
-                terms.clear(); double fixed = 0.0;
-                for (int k = R.off[i]; k < R.off[i + 1]; k++) { const int j = R.col[k]; if (local[j] >= 0) terms.push_back({local[j], R.coef[k]}); else fixed += R.coef[k] * bx[j]; }
-                sub.R.add(terms, R.lo[i] <= -INF ? -INF : R.lo[i] - fixed, R.hi[i] >= INF ? INF : R.hi[i] - fixed);
-            }
-            for (int j : wcols) local[j] = -1;
-            sub.bx.resize(wn); for (int q = 0; q < wn; q++) sub.bx[q] = bx[wcols[q]];
-            double z0 = 0.0; for (int j = 0; j < wn; j++) z0 += sub.c[j] * sub.bx[j];
-            sub.have = true; sub.best = z0; sub.quantum = 0.0;
-            sub.node_cap = 1000;
-            std::vector<double> xw;
-            const int st = sub.run(false, xw);
-            nodes += sub.nodes; lp_iters += sub.lp_iters;
-            if ((st == 1 || st == 2) && sub.best > z0 + 1e-12 * std::fabs(best)) {
-                for (int q = 0; q < wn; q++) bx[wcols[q]] = xw[q];
-                double zz = 0.0; for (int j = 0; j < n; j++) zz += c[j] * bx[j];
-                best = zz; improved = true;
-            }
+            const long n0 = nodes; const double t0 = wall();
+            const bool imp = lns_solve(wcols, until, lns_cap);
+            improved |= imp;
+            if (tracing) { lns_stat[0] += 1; lns_stat[1] += imp; lns_stat[2] += (double)(nodes - n0); lns_stat[3] += wall() - t0; if (nodes - n0 >= lns_cap) lns_stat[4] += 1; }
         }
+        if (tracing) { fprintf(stderr, "[milp]   windows win=%d stride=%d: %g solved, %g improved, %g nodes, %.3fs, %g capped; quantum %g incumbent %.9f\n", win, stride, lns_stat[0], lns_stat[1], lns_stat[2], lns_stat[3], lns_stat[4], quantum, best); for (auto &v : lns_stat) v = 0; }
         return improved;
     }
     // the whole schedule: neighbours (32, 64 columns), then pairs of 32-column groups at halving distances; repeated while something improves
-    void lns_schedule(double until) {
-        for (int round = 0; round < 8 && wall() < until && !timed_out; round++) {
+    // LP-guided windows.  Blocks = the connected components of the model without its wide rows (a worker's columns; the batch-size rows are what
+    // is left out).  Where the root LP pays a block more than the incumbent does there is something to gain, where it pays less there is something to
+    // give: windows pair the blocks with the largest deficit with those of the largest surplus, which the index-based windows only meet by chance.
+    std::vector<int> block_of; int n_blocks = 0;
+    void find_blocks() {
+        DSUlite d(n);
+        const int wide = std::max(12, n / 32);
+        for (int i = 0; i < R.m; i++) { if (R.off[i + 1] - R.off[i] > wide) continue; for (int k = R.off[i] + 1; k < R.off[i + 1]; k++) d.unite(R.col[R.off[i]], R.col[k]); }
+        block_of.assign(n, -1); n_blocks = 0;
+        std::vector<int> id(n, -1);
+        for (int j = 0; j < n; j++) { const int r = d.find(j); if (id[r] < 0) id[r] = n_blocks++; block_of[j] = id[r]; }
+    }
+    bool lns_guided(double until) {
+        if (lp_x.empty() || in_lns || !have) return false;
+        if (block_of.empty()) find_blocks();
+        if (n_blocks < 4 || n_blocks > n / 2) return false;
+        bool improved = false;
+        for (int pass = 0; pass < 6 && wall() < until && !timed_out && !certified(); pass++) {
+            std::vector<double> gain(n_blocks, 0.0);
+            for (int j = 0; j < n; j++) gain[block_of[j]] += c[j] * (lp_x[j] - bx[j]);
+            std::vector<int> order(n_blocks); std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gain[a] > gain[b]; });
+            const int half = 4, shift = pass * 2;
+            if (2 * (half + shift) > n_blocks) break;
+            std::vector<char> take(n_blocks, 0);
+            for (int k = 0; k < half; k++) { take[order[shift + k]] = 1; take[order[n_blocks - 1 - shift - k]] = 1; }
+            std::vector<int> wcols;
+            for (int j = 0; j < n; j++) if (take[block_of[j]]) wcols.push_back(j);
+            if (wcols.size() > 160) continue;
+            const double before = best;
+            if (lns_solve(wcols, until, std::max<long>(lns_cap, 8000))) { improved = true; pass = -1; }  // the ranking has changed: start over
+            if (tracing) fprintf(stderr, "[milp]   guided window (%d columns, shift %d): %.9f -> %.9f\n", (int)wcols.size(), shift, before, best);
+        }
+        return improved;
+    }
+    // Cheap windows first (1000 nodes each: most windows close far below that), and only when a whole round finds nothing the cap goes up 8x —
+    // the few windows that hold the last improvements are plateaus of their own.
+    long lns_cap = 1000;
+    std::vector<double> lp_x;  // root LP optimum
+    void lns_schedule(double until, bool escalate = true) {
+        lns_cap = 1000;
+        for (int round = 0; round < 16 && wall() < until && !timed_out && !certified(); round++) {
             bool any = false;
             any |= lns_windows(until, 32);
             any |= lns_windows(until, 64);
@@ -574,7 +657,8 @@ struct CompSolver {
             if (!any && n > 1024) any |= lns_windows(until, 128);  // nothing left for the small windows: 16 workers at a time
             if (!any && n > 1024) any |= lns_windows(until, 8, n / 8, 8);   // eight small groups spread over the whole index range
             if (!any && n > 1024) any |= lns_windows(until, 16, n / 4, 4);
-            if (!any) break;
+            if (!any) any |= lns_guided(until);
+            if (!any) { if (!escalate || lns_cap >= 64000) break; lns_cap *= 8; }
         }
     }
     long node_cap = -1;  // hard cap on the nodes of this solver (window sub-problems)
@@ -610,22 +694,65 @@ struct CompSolver {
                 return 2;
             }
         }
-        const double t_search = wall();
-        for (int phase = 0;; phase++) {
-            aborted = false; strong = (phase & 1) != 0; node_budget = nodes + budget;
-            if (phase > 0) { lp_iters += root.iters; root = Tab(); root.init(&R, c, lb, ub); root.deadline = deadline; }
-            dfs_opt(root);
-            if (!aborted || timed_out) break;
-            if (node_cap >= 0 && nodes >= node_cap) { timed_out = true; break; }
-            if (phase == 0 && !in_lns) {  // the dive did not finish: improve its incumbent before the expensive phases
-                // at most 30 % of what is left, and not more than three times what the dive itself took: a model that strong branching proves
-                // in a second must not spend six in here first
-                const double now = wall(), left = deadline - now, dive = now - t_search;
-                lns_schedule(now + std::min(0.3 * left, std::max(0.05, 3.0 * dive)));
-            }
-            if (phase & 1) budget *= 4;
+        // Larger models: the window search BEFORE the tree.  A node of a 1000-column tableau costs a millisecond (a dive of 2000 nodes: seconds), the
+        // windows take the greedy incumbent to within 1e-4 of the root LP bound in a fraction of that — and then the root closes the search.
+        bool lns_done = false;
+        if (!in_lns && have && n >= LNS_FIRST_COLS) {
+            if (solve_counted(root) == LP_OPT) { root_bound = root.objective(); lp_x.assign(root.x.begin(), root.x.begin() + n); }  // the bound the windows work towards (dfs_opt finds the tableau solved)
+            const double now = wall();
+            trace("window search first");
+            lns_schedule(now + 0.3 * (deadline - now), false);  // cheap windows only: what they leave open the tree below usually closes faster than bigger windows would
+            lns_done = true;
         }
-        aborted = false; strong = false; node_budget = -1;
+        const int first_strong = lns_done ? 1 : 0;  // with the windows' incumbent in hand the proof comes first, the dive (an incumbent finder) second
+        auto search = [&]() {
+            const double t_search = wall();
+            long bud = budget;
+            for (int phase = 0;; phase++) {
+                strong = ((phase + first_strong) & 1) != 0;
+                trace(strong ? "strong-branching phase" : "dive phase");
+                aborted = false; node_budget = nodes + bud;
+                if (node_cap >= 0) node_budget = std::min(node_budget, node_cap);
+                if (phase > 0) { lp_iters += root.iters; root = Tab(); root.init(&R, c, lb, ub); root.deadline = deadline; }
+                if (root_bound == INF && solve_counted(root) == LP_OPT) root_bound = root.objective();  // dfs_opt finds the tableau solved
+                dfs_opt(root);
+                if (!aborted || timed_out) break;
+                if (node_cap >= 0 && nodes >= node_cap) { timed_out = true; break; }
+                if (phase == 0 && !in_lns && !lns_done) {  // the dive did not finish: improve its incumbent before the expensive phases
+                    // at most 30 % of what is left, and not more than three times what the dive itself took: a model that strong branching proves
+                    // in a second must not spend six in here first
+                    const double now = wall(), left = deadline - now, dive = now - t_search;
+                    trace("window search");
+                    lns_schedule(now + std::min(0.3 * left, std::max(0.05, 3.0 * dive)));
+                    lns_done = true;
+                }
+                if (phase & 1) bud *= 4;
+            }
+            aborted = false; strong = false; node_budget = -1;
+        };
+        const double work0 = work;
+        search();
+        const double work_search = work - work0;  // the tree search alone: the windows before it are not a measure of how hard the proof is
+        if (!timed_out && gap_pruned && have && !in_lns) {
+            // Certified within rel_gap, which is all the reference asks of its solver.  The canonical answer needs the EXACT optimum: one more search
+            // from the root with the exact pruning rule only, on a deterministic work budget (element updates, not seconds: every replica of a
+            // sharded scheduler takes the same decision) — small coupled ticks finish it in milliseconds, the plateaus do not and keep the certificate.
+            trace("certified; exact pass");
+            const double keep_gap = rel_gap; rel_gap = 0.0;
+            work_limit = work + std::max(EXACT_PASS_WORK, work_search);
+            lp_iters += root.iters; root = Tab(); root.init(&R, c, lb, ub); root.deadline = deadline;
+            lns_done = true;
+            search();
+            work_limit = -1.0; rel_gap = keep_gap;
+            if (timed_out) {  // budget (or clock) ran out: the certificate stands, the answer is not canonical
+                timed_out = false; canonical_done = false;
+                    lp_iters += root.iters;
+                deadline = hard_deadline;
+                trace("exact pass gave up");
+                xout = bx;
+                return 1;
+            }
+        }
         lp_iters += root.iters;
         deadline = hard_deadline;
         if (timed_out && have && !in_lns && deadline - wall() > 0.2) {
@@ -770,7 +897,7 @@ bool sparse_greedy(const Model &mdl, const std::vector<double> &ub, std::vector<
 // exactly what HiGHS accepts there.
 const double ROW_TOL = 1e-6;
 
-Result solve(const Model &mdl_in, double time_limit_s, bool canonical) {
+Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double rel_gap) {
     Model mdl = mdl_in;
     for (size_t k = 0; k < mdl.rcoef.size(); k++) {
         if (mdl.kind[mdl.rcol[k]] != COL_BOOL) continue;
@@ -852,6 +979,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical) {
     for (size_t ci = 0; ci < ccols.size(); ci++) {
         auto &cols = ccols[ci]; auto &rows = crows[ci];
         CompSolver cs; cs.n = (int)cols.size(); cs.deadline = deadline;
+        cs.rel_gap = rel_gap;
         const int cm = (int)rows.size();
         for (int k = 0; k < cs.n; k++) local[cols[k]] = k;
         cs.c.resize(cs.n); cs.lb.assign(cs.n, 0.0); cs.ub.resize(cs.n);

@@ -54,13 +54,19 @@ struct Result {
     std::vector<double> x;   // integral values
     double objective = 0.0;  // c.x in the model's own (unscaled) coefficients
     bool feasible = false;   // false => the reference's `None` (infeasible / unbounded)   highs.rs:82
-    bool optimal = false;    // false with feasible => time limit hit, incumbent returned   highs.rs:73-80
+    bool optimal = false;    // false with feasible => time limit hit, incumbent returned   highs.rs:73-80; true = certified within rel_gap (below)
     bool canonical = true;   // false: some component's tie-break phase was skipped / cut short (or not requested): x is an optimum, not THE canonical one
     long nodes = 0, lp_iters = 0;
     int n_components = 0;
 };
 
+// What the reference calls optimal: solve_bounded sets `time_limit` and nothing else (solver/highs.rs:65-68), so HiGHS runs with its default
+// mip_rel_gap = 1e-4 and reports HighsModelStatus::Optimal as soon as (dual bound - incumbent) <= 1e-4 |incumbent|.
+const double REFERENCE_MIP_REL_GAP = 1e-4;
+
 // canonical=true applies the lexicographic tie-break (always on in the product; off only in solver unit tests).
-Result solve(const Model &m, double time_limit_s, bool canonical = true);
+// rel_gap: `optimal` = every component's incumbent is certified within rel_gap of its bound (0: proven exact only).  A certified component gets one
+// more, work-budgeted search with the exact rule; only where that finishes does the tie-break run, otherwise `canonical` comes back false.
+Result solve(const Model &m, double time_limit_s, bool canonical = true, double rel_gap = REFERENCE_MIP_REL_GAP);
 
 }  // namespace hqmilp

@@ -30,7 +30,7 @@ for W in [int(a) for a in args] or [4, 8, 16, 32]:
         t0 = time.time(); g = hs.stages(snap); tg = time.time() - t0
         line = f"W={W:5d} fill={fill:.2f} ready={k:6d} | product {tg:6.2f}s opt={int(g.is_optimal)} canonical={int(g.is_canonical)} assigned={sum(c for *_, c in g.counts)}"
         if with_oracle:
-            o = Oracle(abi.make_config(time_limit_s=limit))
+            o = Oracle(abi.make_config(time_limit_s=limit), reference_solver_options="--exact-oracle" not in sys.argv)  # HiGHS as the reference configures it (mip_rel_gap 1e-4)
             t0 = time.time(); w = o.tick(snap); to = time.time() - t0
             m = o.last_model()
             cd = g.counts_dict()
