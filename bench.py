@@ -503,9 +503,26 @@ def main():
         for _ in range(args.priority_ticks):
             t0 = time.perf_counter(); rp = tp.tick_raw(scp, resident=True); tl.append(time.perf_counter() - t0)
             info = (rp.status, int(rp.is_optimal), tp.kernel_stats(), rp.t_solve_us)
+            ncp = rp.n_counts  # (rq, variant, worker index) -> count of the last tick, for the objective comparison below
+            gdp = dict(zip(zip(abi._np(rp.count_rq, ncp, np.uint32).tolist(), abi._np(rp.count_variant, ncp, np.uint8).tolist(), abi._np(rp.count_worker, ncp, np.uint32).tolist()),
+                           abi._np(rp.count_value, ncp, np.uint32).tolist())) if ncp else {}
         out["multi_priority"] = {"workload": "c3p: c3 with user priorities {0, 1, 2} at 80/15/5 %", "ticks": args.priority_ticks, "p50_tick_ms": 1e3 * float(np.median(tl)),
                                  "status": info[0], "is_optimal": bool(info[1]), "assigned_per_tick": int(info[2]["n_assigned"]), "prefilled_per_tick": int(info[2]["n_prefilled"]),
-                                 "solve_ms": info[3] / 1e3, "tasks_assigned_per_sec": int(info[2]["n_assigned"]) / float(np.median(tl))}
+                                 "solve_ms": info[3] / 1e3, "tasks_assigned_per_sec": int(info[2]["n_assigned"]) / float(np.median(tl)),
+                                 "is_optimal_means": "certified within HiGHS's default mip_rel_gap = 1e-4, which is all the reference's solve_bounded asks for (solver/highs.rs:65-68)"}
+        if args.cpu_ticks > 0:
+            try:  # the same snapshot through the reference-configured HiGHS (one tick, 5 s limit as in the reference): what the drop-in replaces on this workload
+                from oracle.oracle import Oracle
+                op = Oracle(abi.make_config(time_limit_s=5.0), reference_solver_options=True)
+                t0 = time.perf_counter(); wp = op.tick(sp); tcp = time.perf_counter() - t0
+                mp = op.last_model()
+                xg = np.asarray([gdp.get((int(mp["crq"][j]), int(mp["cvariant"][j]), int(mp["cworker"][j])), 0) if mp["ctype"][j] == 0 else 0 for j in range(len(mp["obj"]))], np.float64)
+                out["multi_priority"]["objective"] = {"gpu_tick": float(np.dot(mp["obj"], xg)), "cpu_baseline": float(mp["objective"])}
+                out["multi_priority"]["cpu_baseline"] = {"tick_s": tcp, "is_optimal": bool(wp.is_optimal), "kind": "port", "cores": 1,
+                                                         "assigned_per_tick": sum(1 for recs in wp.records for (_, _, k) in recs if k == abi.HQ_REC_ASSIGN),
+                                                         "sample": "1 tick of the full c3p workload, HiGHS 1.8.0 with the reference's options (time_limit = 5 s only)"}
+            except Exception as e:
+                out["multi_priority"]["cpu_baseline"] = {"error": repr(e)}
         tp.close()
     if world == 1 and args.cpu_ticks > 0:
         try:

@@ -683,6 +683,7 @@ struct CompSolver {
             root.deadline = t0 + 0.5 * (hard_deadline - t0);
             const int s0 = solve_counted(root);
             root.deadline = deadline;
+            if (tracing) fprintf(stderr, "[milp] n=%d m=%d large-model root LP: status %d after %.3fs, %ld iterations, %d active rows, value %.6f incumbent %.6f\n", n, R.m, s0, wall() - t0, (long)root.iters, root.ma, s0 == LP_OPT ? root.objective() : -1.0, best);
             if (s0 == LP_LIMIT && hard_deadline - wall() > 0.2) {
                 nodes++;
                 deadline = hard_deadline;
@@ -730,38 +731,49 @@ struct CompSolver {
             }
             aborted = false; strong = false; node_budget = -1;
         };
+        // A node of the tree costs a copy of the tableau: above ~8 M elements (10 ms) the windows are the better use of the time that is left,
+        // and their incumbent is checked against the root bound like any other.
+        const bool tree_affordable = in_lns || (double)std::max(root.ma, 1) * (double)root.width() <= 8.0e6;
         const double work0 = work;
-        search();
+        bool by_root_bound = false;  // certified by the root LP bound alone (no tree, or before it)
+        if (certified()) by_root_bound = true;
+        else if (tree_affordable) search();
+        else timed_out = true;  // straight to the window search below
         const double work_search = work - work0;  // the tree search alone: the windows before it are not a measure of how hard the proof is
-        if (!timed_out && gap_pruned && have && !in_lns) {
+        lp_iters += root.iters;
+        deadline = hard_deadline;
+        if (timed_out && have && !in_lns && deadline - wall() > 0.2) {
+            // out of its share of the time (large model), too large for a tree, or the LP gave up on size (tableau budget): what is left goes to the
+            // window improvement — which stops as soon as the incumbent is within rel_gap of the root bound
+            timed_out = false;
+            trace("window search for the rest of the time");
+            lns_schedule(deadline - 0.05);
+            if (certified()) by_root_bound = true; else timed_out = true;
+        }
+        if (!timed_out && (gap_pruned || by_root_bound) && have && !in_lns) {
             // Certified within rel_gap, which is all the reference asks of its solver.  The canonical answer needs the EXACT optimum: one more search
             // from the root with the exact pruning rule only, on a deterministic work budget (element updates, not seconds: every replica of a
             // sharded scheduler takes the same decision) — small coupled ticks finish it in milliseconds, the plateaus do not and keep the certificate.
             trace("certified; exact pass");
-            const double keep_gap = rel_gap; rel_gap = 0.0;
-            work_limit = work + std::max(EXACT_PASS_WORK, work_search);
-            lp_iters += root.iters; root = Tab(); root.init(&R, c, lb, ub); root.deadline = deadline;
-            lns_done = true;
-            search();
-            work_limit = -1.0; rel_gap = keep_gap;
-            if (timed_out) {  // budget (or clock) ran out: the certificate stands, the answer is not canonical
+            bool exact = false;
+            if (tree_affordable) {
+                const double keep_gap = rel_gap; rel_gap = 0.0;
+                work_limit = work + std::max(EXACT_PASS_WORK, work_search);
+                root = Tab(); root.init(&R, c, lb, ub); root.deadline = deadline;
+                lns_done = true;
+                search();
+                lp_iters += root.iters;
+                work_limit = -1.0; rel_gap = keep_gap;
+                exact = !timed_out;
+            }
+            if (!exact) {  // budget (or clock) ran out: the certificate stands, the answer is not canonical
                 timed_out = false; canonical_done = false;
-                    lp_iters += root.iters;
-                deadline = hard_deadline;
-                trace("exact pass gave up");
+                trace("certificate only");
                 xout = bx;
                 return 1;
             }
         }
-        lp_iters += root.iters;
-        deadline = hard_deadline;
-        if (timed_out && have && !in_lns && deadline - wall() > 0.2) {
-            // out of its share of the time (large model), or the LP gave up on size (tableau budget): what is left goes to the window improvement
-            timed_out = false;
-            lns_schedule(deadline - 0.05);
-            timed_out = true;
-        }
-        if (getenv("HQMILP_TRACE")) fprintf(stderr, "[milp] n=%d final incumbent %.9f timed_out %d nodes %ld\n", n, have ? best : -1.0, (int)timed_out, nodes);
+        if (tracing && !in_lns) fprintf(stderr, "[milp] n=%d final incumbent %.9f timed_out %d nodes %ld\n", n, have ? best : -1.0, (int)timed_out, nodes);
         if (!have) return 0;
         xout = bx;
         if (timed_out) return 2;

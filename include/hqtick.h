@@ -196,10 +196,13 @@ typedef struct hqtick_query_workers {
  */
 typedef struct hqtick_result {
     int32_t status;     /* HQTICK_DONE / NEED_MORE_COMPUTE / NO_PROGRESS */
-    uint8_t is_optimal; /* SchedulingSolution::is_optimal  scheduler/solver.rs:14-16 */
-    uint8_t is_canonical; /* 1: among the optimal placements this is the canonical one — the answer is a function of the
-                             snapshot alone.  0: optimal (or an incumbent) but the tie-break phase was skipped or ran out of its work budget:
-                             only the objective value can be compared with another solver's answer.  (ABI 3; uses former padding.) */
+    uint8_t is_optimal; /* SchedulingSolution::is_optimal  scheduler/solver.rs:14-16 — with the reference's meaning: solve_bounded sets only
+                           `time_limit` (solver/highs.rs:65-68), so HiGHS reports Optimal once the incumbent is within its default
+                           mip_rel_gap = 1e-4 of the dual bound.  1 here = certified within that same 1e-4 (or proven exact). */
+    uint8_t is_canonical; /* 1: the placement is the EXACT optimum and, among the optimal placements, the canonical one — the answer
+                             is a function of the snapshot alone.  0: certified-optimal (or an incumbent) but the exact pass / the tie-break phase
+                             was skipped or ran out of its work budget: only the objective value can be compared with another solver's answer.
+                             (ABI 3; uses former padding.) */
 
     /* TaskBatch list (scheduler/batches.rs:18-27) — exposed so parity tier T1 is testable */
     uint32_t n_batches;

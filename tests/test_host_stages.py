@@ -24,11 +24,12 @@ def _same_host_part(got, want, model):
     assert got.batches == want.batches
     if got.is_canonical or not got.is_optimal:
         assert got.counts == want.counts
-    else:  # optimal, but the tie-break phase was cut short (hqtick_result.is_canonical = 0): the claim is the objective value
+    else:  # optimal in the reference's sense (certified within HiGHS's default mip_rel_gap = 1e-4) but not canonical (hqtick_result.is_canonical = 0:
+        # the exact pass or the tie-break phase ran out of its budget): the claim is the objective value, within that gap of the exact oracle's
         if any(model["ctype"][j] != 0 and model["obj"][j] > 0 for j in range(len(model["obj"]))):
             return  # multi-node columns carry part of the objective and the hook exports single-node counts only: nothing to compare here
         zg, zw = _objective(model, got), _objective(model, want)
-        assert abs(zg - zw) <= 1e-9 * max(1.0, abs(zw)), (zg, zw)
+        assert zw * (1.0 - 1e-4) - 1e-12 <= zg <= zw + 1e-9 * max(1.0, abs(zw)), (zg, zw)
 
 
 @pytest.mark.parametrize("seed", range(150))
