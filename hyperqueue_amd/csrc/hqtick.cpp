@@ -438,6 +438,7 @@ struct TickRun {
     std::vector<std::pair<uint32_t, uint32_t>> retr_pos;      // (rq, queue position) of every Retracting task
     std::vector<std::vector<uint32_t>> key_T;                 // lazily built T_k(s) tables of worker_of()
     size_t o_rv = 0, o_rk = 0, o_mn = 0, o_fl = 0;            // layout of the pinned record buffer
+    bool may_reorder = false;  // the mapping kernel needs its stable sort: several priority levels, Retracting holes or prefilled tasks inside the queues
     bool compact = false; size_t o_rs = 0, o_rc = 0, o_rf = 0, o_rj = 0, o_rm = 0; uint32_t max_out = 0;  // compact emission (HQTICK_FLAG_COMPACT_RECORDS)
     uint64_t *h_rec_task = nullptr, *mn_ids = nullptr; uint8_t *h_rec_var = nullptr, *h_rec_kind = nullptr;
     bool assembled = false;
@@ -681,7 +682,8 @@ struct TickRun {
             max_out = std::max(max_out, npf + ps.n_assign[w]);
         }
         n_rec = ps.out_off[W];
-        if (hqk::expand_mapping_lds(max_items, nkeys, compact ? max_out : 0) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
+        may_reorder = sc.L > 1 || !ps.holes.empty() || (s->prefill_off && s->prefill_off[Q] > 0);
+        if (hqk::expand_mapping_lds(max_items, nkeys, compact ? max_out : 0, may_reorder) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "a worker receives more tasks in one tick than the mapping kernel stages in LDS");
         if (max_nk > hqk::SWEEP_MAX_WORKERS) return fail(ctx, HQTICK_E_CAPACITY, "more than 24576 workers share one (request, variant) placement: beyond the round-robin kernel's LDS staging");
         return 0;
     }
@@ -786,7 +788,7 @@ struct TickRun {
             if (compact) co = hqk::CompactOut{reinterpret_cast<uint32_t *>(drec), reinterpret_cast<uint32_t *>(drec + o_rs), reinterpret_cast<uint32_t *>(drec + o_rc), reinterpret_cast<uint32_t *>(drec + o_rf),
                                               reinterpret_cast<uint32_t *>(drec + o_rj), reinterpret_cast<uint16_t *>(drec + o_rm), ctx->d_runctr.as<uint32_t>(), n_rec};
             HQ_HIP_TIMED(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
-                                reinterpret_cast<uint32_t *>(drec + o_fl), co, max_out, ctx->stream));
+                                reinterpret_cast<uint32_t *>(drec + o_fl), co, max_out, may_reorder, ctx->stream));
             // multi-node tasks: the heads of their queues
             {
                 size_t pos = 0;

@@ -125,8 +125,10 @@ struct CompactOut {
     uint32_t run_cap;
 };
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_key, uint32_t Q, uint32_t max_items,
-                    uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, CompactOut co, uint32_t max_out, hipStream_t s);
-size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys, uint32_t max_out = 0);
+                    uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, CompactOut co, uint32_t max_out, bool may_reorder, hipStream_t s);
+// may_reorder: the tick has more than one priority level, Retracting holes or prefilled tasks in the queues — a worker's records then need the stable
+// sort of mapping.rs:128-131 (an LDS key array of the next power of two above max_items); without it the items are emitted in gather order
+size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys, uint32_t max_out, bool may_reorder);
 
 // Resident ready-set deltas: tombstone the given ids (sorted id column, binary search), count live tasks per
 // 256-task slice, and rebuild the columns dropping tombstones while merging a sorted batch of new tasks.

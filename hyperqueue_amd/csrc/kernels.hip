@@ -455,7 +455,8 @@ __global__ void __launch_bounds__(256) k_sweep_bits(MapKeys mk) {
 __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, const uint64_t *__restrict__ sel_task,
                                                         const uint16_t *__restrict__ sel_key, uint32_t Q, uint32_t max_items,
                                                         uint64_t *__restrict__ rec_task, uint8_t *__restrict__ rec_variant,
-                                                        uint8_t *__restrict__ rec_kind, uint32_t *__restrict__ err_flag, CompactOut co, uint32_t max_out) {
+                                                        uint8_t *__restrict__ rec_kind, uint32_t *__restrict__ err_flag, CompactOut co, uint32_t max_out,
+                                                        uint32_t sort_cap) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t nkeys = mk.n_keys;
     uint64_t *e_task = reinterpret_cast<uint64_t *>(smem);
@@ -468,7 +469,8 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
     uint32_t *k_pos = k_start + nkeys + 1;
     uint32_t *k_cnt = k_pos + nkeys, *k_rq = k_cnt + nkeys, *k_seg = k_rq + nkeys, *k_toff = k_seg + nkeys, *k_boff = k_toff + nkeys, *k_words = k_boff + nkeys;
     uint32_t *misc = k_words + nkeys;  // [0] min level, [1] max level, [2] holes
-    uint8_t *k_var = reinterpret_cast<uint8_t *>(misc + 4);
+    uint32_t *s_key = misc + 4;        // [sort_cap] (level << 16 | item) keys of the stable sort; sort_cap = 0 on ticks that cannot reorder
+    uint8_t *k_var = reinterpret_cast<uint8_t *>(s_key + sort_cap);
     const uint32_t w = blockIdx.x, lane = lane_id();
     const uint32_t out0 = mk.out_off[w];
     if (mk.out_off[w + 1] == out0) return;  // no record for this worker (or the worker belongs to another rank's shard)
@@ -545,12 +547,40 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
     }
     __syncthreads();
     const bool trivial = misc[2] == 0 && misc[0] >= misc[1];  // one priority level, no holes: already in final order
-    // stable sort by priority descending == level ascending (mapping.rs:128-131) by rank counting
-    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+    // stable sort by priority descending == level ascending (mapping.rs:128-131).  Sorting (level << 16 | item) is a stable sort by level; a bitonic
+    // network over the next power of two in LDS: O(n log^2 n / 256) per thread (n = 1024 records, 3 levels: 55 steps of 4 compare-exchanges, where
+    // counting ranks costs 4096 LDS reads per record).  Holes (no record) sort to the end.
+    uint32_t P = 0;
+    if (!trivial && sort_cap) {
+        P = 1; while (P < n) P <<= 1;
+        if (P > sort_cap || P > 65536u) P = 0;  // cannot happen (the host sizes sort_cap from max_items); rank counting below stays correct
+    }
+    if (P) {
+        for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) s_key[i] = (i < n && (e_meta[i] & 0x100u)) ? ((uint32_t)e_lvl[i] << 16 | i) : 0xFFFFFFFFu;
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
+                    const uint32_t o = i ^ j;
+                    if (o > i) {
+                        const uint32_t a = s_key[i], b = s_key[o];
+                        if ((a > b) == ((i & k) == 0)) { s_key[i] = b; s_key[o] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+        uint32_t e = t, pos = t;  // trivial: already in final order
+        if (P) {                  // position t takes the item the network put there
+            const uint32_t key = s_key[t];
+            if (key == 0xFFFFFFFFu) continue;
+            e = key & 0xFFFFu;
+        }
         const uint16_t meta = e_meta[e];
         if (!(meta & 0x100u)) continue;
-        uint32_t pos = e;
-        if (!trivial) {
+        if (!trivial && !P) {     // fallback: rank counting
             const uint16_t lv = e_lvl[e];
             pos = 0;
             for (uint32_t o = 0; o < n; o++) {
@@ -864,18 +894,21 @@ hipError_t sweep_bits(MapKeys mk, uint32_t max_count, uint32_t max_workers_per_k
     return hipGetLastError();
 }
 
-size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys, uint32_t max_out) {
-    return (size_t)max_items * 12 + (size_t)max_out * 10 + 2 + ((size_t)8 * n_keys + 1 + 4) * 4 + n_keys + 16;
+uint32_t expand_mapping_sort_cap(uint32_t max_items) { uint32_t p = 1; while (p < max_items) p <<= 1; return p; }
+
+size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys, uint32_t max_out, bool may_reorder) {
+    return (size_t)max_items * 12 + (size_t)max_out * 10 + 2 + ((size_t)8 * n_keys + 1 + 4) * 4 + n_keys + 16 + (may_reorder ? (size_t)expand_mapping_sort_cap(max_items) * 4 : 0);
 }
 
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_key, uint32_t Q, uint32_t max_items,
-                    uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, CompactOut co, uint32_t max_out, hipStream_t s) {
+                    uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, CompactOut co, uint32_t max_out, bool may_reorder, hipStream_t s) {
     if (W == 0) return hipSuccess;
     if (!co.rec_lo) max_out = 0;
-    size_t lds = expand_mapping_lds(max_items, mk.n_keys, max_out);
+    size_t lds = expand_mapping_lds(max_items, mk.n_keys, max_out, may_reorder);
+    const uint32_t sort_cap = may_reorder ? expand_mapping_sort_cap(max_items) : 0;
     hipError_t e;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_mapping), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    HQK_TIMED_LAUNCH(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, W, sel_task, sel_key, Q, max_items, rec_task, rec_variant, rec_kind, err_flag, co, max_out);
+    HQK_TIMED_LAUNCH(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, W, sel_task, sel_key, Q, max_items, rec_task, rec_variant, rec_kind, err_flag, co, max_out, sort_cap);
     return hipGetLastError();
 }
 
