@@ -155,7 +155,7 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
     alive = np.ones(len(rq_of), bool)
     next_id = int(snap.task_id[-1]) + 1
     new_ids = np.zeros(0, np.uint64); new_prio = np.zeros(0, np.uint64); new_rq = np.zeros(0, np.uint32)
-    rows, last_snap = [], None
+    rows, last_snap, prev_free, n_changed = [], None, None, []
     for step in range(steps + 3):
         free = total - running @ need
         assert (free >= 0).all()
@@ -165,6 +165,13 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
         a = time.perf_counter()
         if len(new_ids):
             ts.ready_add(new_ids, new_prio, new_rq)
+        if prev_free is None:
+            ts.cluster_upload(sc)
+        else:  # the rows the reactor's handlers touched since the last tick (tasks started by it, tasks finished since): deltas into the HBM tables
+            changed = np.nonzero((free != prev_free).any(axis=1))[0].astype(np.uint32)
+            ts.cluster_update_workers(changed, free[changed].astype(np.uint64))
+            n_changed.append(len(changed))
+        prev_free = free.copy()
         b = time.perf_counter()
         res = ts.tick_raw(sc, resident=True)
         c = time.perf_counter()
@@ -196,7 +203,7 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
     out = {
         "workload": f"c3 steady state: {len(snap.task_id)} ready tasks (resident, refilled), {W} workers each running a packed mix of which a random {int(release * 100)} % finishes per tick",
         "steps": len(use), "p50_step_ms": 1e3 * float(np.median(step_s)), "p50_tick_ms": 1e3 * med("tick"), "p95_tick_ms": 1e3 * float(np.percentile([r["tick"] for r in use], 95)),
-        "p50_add_us": 1e6 * med("add"), "p50_consume_us": 1e6 * med("consume"),
+        "p50_add_us": 1e6 * med("add"), "p50_consume_us": 1e6 * med("consume"), "worker_rows_sent_per_tick": int(np.median(n_changed)) if n_changed else 0,
         "assigned_per_tick": int(med("assigned")), "handed_out_per_tick": int(med("handed")), "tasks_assigned_per_sec": med("assigned") / float(np.median(step_s)),
         "worker_classes_per_tick": int(med("n_classes")), "classes_solved_on_device": int(med("n_classes_device")), "classes_solved_on_host": int(med("n_classes_host")),
         "all_ticks_optimal_and_canonical": bool(all(r["optimal"] and r["canonical"] for r in use)),
@@ -262,6 +269,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="N > 1: weak = the workload grows with N (default for c2 / c3), strong = the configuration as written (default for c4 = BASELINE configs[3])")
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
+    ap.add_argument("--no-resident-cluster", action="store_true", help="pack the worker tables per tick instead of keeping them in HBM (hqtick_cluster_*)")
     ap.add_argument("--priority-ticks", type=int, default=1, help="ticks of the three-priority-level variant c3p (0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=20, help="steps of the steady-state (delta-updated resident set) measurement, 0 = skip")
     ap.add_argument("--hetero-steps", type=int, default=25, help="ticks of the heterogeneous-worker steady state (SURVEY 8d: 10 %% of the running tasks finish per tick), 0 = skip")
@@ -317,6 +325,8 @@ def main():
     if world == 1 and not args.force_sharded:
         tick = Tick(cfg)
         tick.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
+        if not args.no_resident_cluster:
+            tick.cluster_upload(sc)  # worker rows + request tables resident in HBM (ABI 5); between the cold ticks of this loop no worker row changes: no delta to send
         step = lambda: tick.tick_raw(sc, resident=True)  # returns after the assignment vector is in host memory
     else:
         from hyperqueue_amd.sharded import ShardedTick
@@ -324,6 +334,8 @@ def main():
         st = ShardedTick(cfg, rank=rank, world=world, records_per_shard=int(1.5 * 200 * n_workers_per_gpu * mult / world) + 4096)
         st.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
         tick = st.t
+        if not args.no_resident_cluster:
+            tick.cluster_upload(sc)
         host_merged = None
 
         def step():

@@ -11,7 +11,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-HQTICK_ABI_VERSION = 4
+HQTICK_ABI_VERSION = 5
 HQTICK_FLAG_NO_KERNEL_TIMING, HQTICK_FLAG_COMPACT_RECORDS = 1, 2
 HQ_AMOUNT_MAX = 0xFFFF_FFFF_FFFF_FFFF
 HQ_FRACTIONS_PER_UNIT = 10_000

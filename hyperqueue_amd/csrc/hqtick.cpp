@@ -83,6 +83,10 @@ struct hqtick_ctx {
     uint32_t block_budget = 4096, block_min_classes = 12;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
     // workers / requests
     DevBuf d_up, d_vflags, d_vtmc, d_blk, d_runctr;
+    // cluster tables resident in HBM (hqtick_cluster_*): worker rows + request tables in the layout of upload_tables; the host sends rows that changed
+    DevBuf d_cluster; PinBuf h_cl, h_cld; bool cluster_valid = false, cluster_check = false, cl_pending = false; uint32_t cl_W = 0, cl_R = 0;
+    std::vector<unsigned char> cl_rt;  // host copy of the request-table part as uploaded (compared per tick: a few hundred bytes)
+    hipEvent_t cl_ev = nullptr;
     // selection + mapping
     DevBuf d_sel_task, d_sel_level, d_map, d_rec, d_tsweep, d_bits, d_pre;
     hqhost::Problem pb;
@@ -186,30 +190,81 @@ struct WorkerEval { const uint8_t *flags = nullptr; const uint32_t *tmc = nullpt
 // Packs worker tables + request tables into ONE pinned, device-mapped staging buffer that K2 reads in place (every byte
 // crosses PCIe once per workgroup; no H2D copy command).
 struct UpView { const uint64_t *total, *free_; const int64_t *rem; hqk::RequestTable rt; uint32_t n_entries; };
+struct TabLayout { size_t o_tot, o_free, o_rem, o_amt, o_time, o_off, o_res, o_kind, bytes; uint32_t nv, ne; };
+TabLayout table_layout(const hqtick_snapshot *s, uint32_t W) {
+    TabLayout L{};
+    const uint32_t R = s->n_resources;
+    L.nv = s->n_requests ? s->rq_variant_off[s->n_requests] : 0;
+    L.ne = L.nv ? s->variant_entry_off[L.nv] : 0;
+    L.o_tot = 0; L.o_free = L.o_tot + (size_t)W * R * 8; L.o_rem = L.o_free + (size_t)W * R * 8; L.o_amt = L.o_rem + (size_t)W * 8; L.o_time = L.o_amt + (size_t)L.ne * 8;
+    L.o_off = L.o_time + (size_t)L.nv * 8; L.o_res = L.o_off + (size_t)(L.nv + 1) * 4; L.o_kind = L.o_res + (size_t)L.ne * 4; L.bytes = L.o_kind + L.ne + 64;
+    return L;
+}
+void pack_worker_rows(unsigned char *h, const TabLayout &L, uint32_t W, uint32_t R, const uint64_t *total, const uint64_t *free_, const int64_t *rem) {
+    if (W && R) { memcpy(h + L.o_tot, total, (size_t)W * R * 8); memcpy(h + L.o_free, free_, (size_t)W * R * 8); }
+    int64_t *hr = reinterpret_cast<int64_t *>(h + L.o_rem);
+    if (rem) memcpy(hr, rem, (size_t)W * 8); else for (uint32_t w = 0; w < W; w++) hr[w] = HQ_NO_TIME_LIMIT;
+}
+void pack_request_tables(unsigned char *h, const TabLayout &L, const hqtick_snapshot *s) {
+    if (!L.nv) return;
+    memcpy(h + L.o_amt, s->entry_amount, (size_t)L.ne * 8);
+    if (s->variant_min_time_ns) memcpy(h + L.o_time, s->variant_min_time_ns, (size_t)L.nv * 8); else memset(h + L.o_time, 0, (size_t)L.nv * 8);
+    memcpy(h + L.o_off, s->variant_entry_off, (size_t)(L.nv + 1) * 4);
+    memcpy(h + L.o_res, s->entry_resource, (size_t)L.ne * 4);
+    memcpy(h + L.o_kind, s->entry_kind, L.ne);
+}
+void view_tables(unsigned char *d, const TabLayout &L, UpView *uv) {
+    uv->total = (const uint64_t *)(d + L.o_tot); uv->free_ = (const uint64_t *)(d + L.o_free); uv->rem = (const int64_t *)(d + L.o_rem);
+    uv->rt.entry_amount = (const uint64_t *)(d + L.o_amt); uv->rt.variant_min_time_ns = (const uint64_t *)(d + L.o_time);
+    uv->rt.variant_entry_off = (const uint32_t *)(d + L.o_off); uv->rt.entry_resource = (const uint32_t *)(d + L.o_res);
+    uv->rt.entry_kind = (const uint8_t *)(d + L.o_kind); uv->rt.n_variants = L.nv; uv->n_entries = L.ne;
+}
 int upload_tables(hqtick_ctx *ctx, const hqtick_snapshot *s, uint32_t W, const uint64_t *total, const uint64_t *free_, const int64_t *rem, PinBuf &buf, UpView *uv) {
     const uint32_t R = s->n_resources;
-    uint32_t nv = s->n_requests ? s->rq_variant_off[s->n_requests] : 0;
-    uint32_t ne = nv ? s->variant_entry_off[nv] : 0;
-    size_t o_tot = 0, o_free = o_tot + (size_t)W * R * 8, o_rem = o_free + (size_t)W * R * 8, o_amt = o_rem + (size_t)W * 8, o_time = o_amt + (size_t)ne * 8,
-           o_off = o_time + (size_t)nv * 8, o_res = o_off + (size_t)(nv + 1) * 4, o_kind = o_res + (size_t)ne * 4, bytes = o_kind + ne + 64;
-    if (hqk::worker_eval_lds(R, nv, ne) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "request table + 32 worker rows exceed the 150 KiB the worker-evaluation kernel stages in LDS");
-    if (!buf.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "allocating upload staging");
+    const TabLayout L = table_layout(s, W);
+    if (hqk::worker_eval_lds(R, L.nv, L.ne) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "request table + 32 worker rows exceed the 150 KiB the worker-evaluation kernel stages in LDS");
+    if (!buf.ensure(L.bytes)) return fail(ctx, HQTICK_E_DEVICE, "allocating upload staging");
     unsigned char *h = buf.as<unsigned char>();
-    if (W && R) { memcpy(h + o_tot, total, (size_t)W * R * 8); memcpy(h + o_free, free_, (size_t)W * R * 8); }
-    int64_t *hr = reinterpret_cast<int64_t *>(h + o_rem);
-    if (rem) memcpy(hr, rem, (size_t)W * 8); else for (uint32_t w = 0; w < W; w++) hr[w] = HQ_NO_TIME_LIMIT;
-    if (nv) {
-        memcpy(h + o_amt, s->entry_amount, (size_t)ne * 8);
-        if (s->variant_min_time_ns) memcpy(h + o_time, s->variant_min_time_ns, (size_t)nv * 8); else memset(h + o_time, 0, (size_t)nv * 8);
-        memcpy(h + o_off, s->variant_entry_off, (size_t)(nv + 1) * 4);
-        memcpy(h + o_res, s->entry_resource, (size_t)ne * 4);
-        memcpy(h + o_kind, s->entry_kind, ne);
+    pack_worker_rows(h, L, W, R, total, free_, rem);
+    pack_request_tables(h, L, s);
+    view_tables(buf.dev<unsigned char>(), L, uv);
+    return 0;
+}
+
+// The same tables from HBM (hqtick_cluster_upload): worker rows are the caller's responsibility (hqtick_cluster_update_workers), the request tables are
+// compared with what was uploaded and re-sent when the snapshot brings new request classes.
+int resident_tables(hqtick_ctx *ctx, const hqtick_snapshot *s, uint32_t W, UpView *uv) {
+    const uint32_t R = s->n_resources;
+    if (W != ctx->cl_W || R != ctx->cl_R) return fail(ctx, HQTICK_E_INVALID, "cluster tables in HBM were uploaded for another worker set (hqtick_cluster_upload after workers join or leave)");
+    const TabLayout L = table_layout(s, W);
+    if (hqk::worker_eval_lds(R, L.nv, L.ne) > 150 * 1024) return fail(ctx, HQTICK_E_CAPACITY, "request table + 32 worker rows exceed the 150 KiB the worker-evaluation kernel stages in LDS");
+    const size_t rt_bytes = L.bytes - L.o_amt;
+    if (ctx->cl_pending) { HQ_HIP(hipEventSynchronize(ctx->cl_ev)); ctx->cl_pending = false; }  // h_cl is the staging of the previous request-table upload
+    if (L.bytes > ctx->d_cluster.cap) {  // the request tables outgrew the allocation: move the worker rows over
+        DevBuf nb;
+        if (!nb.ensure(L.bytes * 2)) return fail(ctx, HQTICK_E_DEVICE, "allocating cluster tables");
+        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        HQ_HIP(hipMemcpy(nb.p, ctx->d_cluster.p, L.o_amt, hipMemcpyDeviceToDevice));
+        ctx->d_cluster.release(); ctx->d_cluster = nb;
     }
-    unsigned char *d = buf.dev<unsigned char>();
-    uv->total = (const uint64_t *)(d + o_tot); uv->free_ = (const uint64_t *)(d + o_free); uv->rem = (const int64_t *)(d + o_rem);
-    uv->rt.entry_amount = (const uint64_t *)(d + o_amt); uv->rt.variant_min_time_ns = (const uint64_t *)(d + o_time);
-    uv->rt.variant_entry_off = (const uint32_t *)(d + o_off); uv->rt.entry_resource = (const uint32_t *)(d + o_res);
-    uv->rt.entry_kind = (const uint8_t *)(d + o_kind); uv->rt.n_variants = nv; uv->n_entries = ne;
+    if (!ctx->h_cl.ensure(L.bytes)) return fail(ctx, HQTICK_E_DEVICE, "allocating cluster tables");
+    unsigned char *h = ctx->h_cl.as<unsigned char>();
+    memset(h + L.o_amt, 0, rt_bytes);
+    pack_request_tables(h, L, s);
+    if (ctx->cl_rt.size() != rt_bytes || memcmp(ctx->cl_rt.data(), h + L.o_amt, rt_bytes) != 0) {  // new request classes: a few hundred bytes, stream-ordered before K2
+        HQ_HIP(hipMemcpyAsync(ctx->d_cluster.as<unsigned char>() + L.o_amt, h + L.o_amt, rt_bytes, hipMemcpyHostToDevice, ctx->stream));
+        HQ_HIP(hipEventRecord(ctx->cl_ev, ctx->stream)); ctx->cl_pending = true;
+        ctx->cl_rt.assign(h + L.o_amt, h + L.o_amt + rt_bytes);
+    }
+    if (ctx->cluster_check) {  // HQTICK_CHECK_CLUSTER=1 (tests): the rows in HBM must be the rows of the snapshot
+        std::vector<unsigned char> dev(L.o_amt);
+        HQ_HIP(hipMemcpyAsync(dev.data(), ctx->d_cluster.p, L.o_amt, hipMemcpyDeviceToHost, ctx->stream));
+        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<unsigned char> want(L.o_amt);
+        pack_worker_rows(want.data(), L, W, R, s->worker_total, s->worker_free, s->worker_remaining_ns);
+        if (memcmp(dev.data(), want.data(), L.o_amt) != 0) return fail(ctx, HQTICK_E_INVALID, "cluster tables in HBM differ from the snapshot's worker rows (a missed hqtick_cluster_update_workers)");
+    }
+    view_tables(ctx->d_cluster.as<unsigned char>(), L, uv);
     return 0;
 }
 
@@ -318,7 +373,8 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
         memset(h, 0, 16);
         // K2 reads the packed tables from pinned memory; with a ready set to scan it rides along the K1 launch
         UpView uv; int rc;
-        if ((rc = upload_tables(ctx, s, W, s->worker_total, s->worker_free, s->worker_remaining_ns, ctx->h_up, &uv))) return rc;
+        if (ctx->cluster_valid) { if ((rc = resident_tables(ctx, s, W, &uv))) return rc; }
+        else if ((rc = upload_tables(ctx, s, W, s->worker_total, s->worker_free, s->worker_remaining_ns, ctx->h_up, &uv))) return rc;
         hqk::WorkerEvalArgs wea{uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc)};
         if (scan) {
             hqk::WaveGeom &g = sc->geom;
@@ -931,6 +987,8 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return HQTICK_E_DEVICE; }
     if (const char *e = getenv("HQTICK_K2_RIDE_ALONG")) ctx->k2_own_stream = atoi(e) == 0;
+    if (const char *e = getenv("HQTICK_CHECK_CLUSTER")) ctx->cluster_check = atoi(e) != 0;
+    if (hipEventCreate(&ctx->cl_ev) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     if (!ctx->d_flags.ensure(64) || hipMemset(ctx->d_flags.p, 0, 64) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     *out_ctx = ctx;
@@ -945,8 +1003,10 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
     DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
-                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8, &ctx->d_blk, &ctx->d_runctr};
+                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8, &ctx->d_blk, &ctx->d_runctr, &ctx->d_cluster};
     for (DevBuf *b : bufs) b->release();
+    ctx->h_cl.release(); ctx->h_cld.release();
+    if (ctx->cl_ev) hipEventDestroy(ctx->cl_ev);
     if (ctx->qctx) { hqtick_destroy(ctx->qctx); ctx->qctx = nullptr; }
     hipSetDevice(ctx->device);
     if (ctx->comm) { rccl_destroy_comm(ctx); }
@@ -1156,6 +1216,58 @@ int hqtick_graph_get_stats(const hqtick_ctx *ctx, hqtick_graph_stats *out) {
     hqgraph::Stats st = ctx->graph.stats();
     out->n_tasks = st.n_tasks; out->n_slots = st.n_slots; out->n_edges_live = st.n_edges_live; out->n_edges_pool = st.n_edges_pool; out->n_runs = st.n_runs;
     out->hash_capacity = st.hash_capacity; out->hash_tombstones = st.hash_tombstones; out->bytes_hbm = st.bytes_hbm; out->last_kernel_us = ctx->graph.last_kernel_us();
+    return 0;
+}
+
+// ---- cluster tables resident in HBM (row f1: the reactor's worker bookkeeping as deltas) ----
+int hqtick_cluster_upload(hqtick_ctx *ctx, const hqtick_snapshot *s) {
+    if (!ctx || !s) return HQTICK_E_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, HQTICK_E_NO_DEVICE, "hipSetDevice failed");
+    int rc = validate(ctx, s, false);
+    if (rc) return rc;
+    const uint32_t W = s->n_workers, R = s->n_resources;
+    const TabLayout L = table_layout(s, W);
+    if (ctx->cl_pending) { HQ_HIP(hipEventSynchronize(ctx->cl_ev)); ctx->cl_pending = false; }
+    HQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (!ctx->h_cl.ensure(L.bytes) || !ctx->d_cluster.ensure(L.bytes + 65536)) return fail(ctx, HQTICK_E_DEVICE, "allocating cluster tables");
+    unsigned char *h = ctx->h_cl.as<unsigned char>();
+    memset(h, 0, L.bytes);
+    pack_worker_rows(h, L, W, R, s->worker_total, s->worker_free, s->worker_remaining_ns);
+    pack_request_tables(h, L, s);
+    HQ_HIP(hipMemcpyAsync(ctx->d_cluster.p, h, L.bytes, hipMemcpyHostToDevice, ctx->stream));
+    HQ_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->cl_rt.assign(h + L.o_amt, h + L.bytes);
+    ctx->cl_W = W; ctx->cl_R = R; ctx->cluster_valid = true;
+    return 0;
+}
+
+int hqtick_cluster_update_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *worker_index, const uint64_t *free_rows, const int64_t *remaining_ns) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (!ctx->cluster_valid) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_update_workers without hqtick_cluster_upload");
+    if (n == 0) return 0;
+    if (!worker_index || !free_rows) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_update_workers: null array");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, HQTICK_E_NO_DEVICE, "hipSetDevice failed");
+    const uint32_t W = ctx->cl_W, R = ctx->cl_R;
+    for (uint32_t i = 0; i < n; i++) if (worker_index[i] >= W) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_update_workers: worker index out of range");
+    // staging: [free n*R u64][rem n i64][index n u32]; the scatter kernel reads it in place (pinned, device-mapped) — wait for the previous one first
+    if (ctx->cl_pending) { HQ_HIP(hipEventSynchronize(ctx->cl_ev)); ctx->cl_pending = false; }
+    const size_t o_rem = (size_t)n * R * 8, o_idx = o_rem + (size_t)n * 8, bytes = o_idx + (size_t)n * 4 + 16;
+    if (!ctx->h_cld.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "allocating delta staging");
+    unsigned char *h = ctx->h_cld.as<unsigned char>(), *d = ctx->h_cld.dev<unsigned char>();
+    memcpy(h, free_rows, o_rem);
+    if (remaining_ns) memcpy(h + o_rem, remaining_ns, (size_t)n * 8);
+    memcpy(h + o_idx, worker_index, (size_t)n * 4);
+    unsigned char *base = ctx->d_cluster.as<unsigned char>();
+    const size_t WR8 = (size_t)W * R * 8;
+    HQ_HIP(hqk::scatter_worker_rows(reinterpret_cast<uint64_t *>(base + WR8), reinterpret_cast<int64_t *>(base + 2 * WR8), R, n, reinterpret_cast<const uint32_t *>(d + o_idx),
+                                    reinterpret_cast<const uint64_t *>(d), remaining_ns ? reinterpret_cast<const int64_t *>(d + o_rem) : nullptr, ctx->stream));
+    HQ_HIP(hipEventRecord(ctx->cl_ev, ctx->stream)); ctx->cl_pending = true;
+    return 0;
+}
+
+int hqtick_cluster_drop(hqtick_ctx *ctx) {
+    if (!ctx) return HQTICK_E_INVALID;
+    ctx->cluster_valid = false;
     return 0;
 }
 

@@ -130,6 +130,9 @@ hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, cons
 // sort of mapping.rs:128-131 (an LDS key array of the next power of two above max_items); without it the items are emitted in gather order
 size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys, uint32_t max_out, bool may_reorder);
 
+// Resident cluster tables (f1): rows of the worker table that changed, scattered into the HBM copy (inputs may sit in pinned host memory)
+hipError_t scatter_worker_rows(uint64_t *free_, int64_t *rem, uint32_t R, uint32_t n, const uint32_t *idx, const uint64_t *rows, const int64_t *new_rem, hipStream_t s);
+
 // Resident ready-set deltas: tombstone the given ids (sorted id column, binary search), count live tasks per
 // 256-task slice, and rebuild the columns dropping tombstones while merging a sorted batch of new tasks.
 hipError_t ready_mark_removed(const uint64_t *ids, uint32_t *rq, uint64_t n, const uint64_t *rm, uint32_t n_rm, uint32_t *n_done, hipStream_t s);

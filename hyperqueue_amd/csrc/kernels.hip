@@ -626,6 +626,17 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
     for (uint32_t i = threadIdx.x; i < tot; i += blockDim.x) co.rec_lo[out0 + i] = (uint32_t)f_task[i];
 }
 
+// ------------------------------------------------------------------------------------------------ resident cluster tables (f1)
+// Rows of the worker table that changed since the last tick (tasks finished or started, time limits running down): one thread per (row, resource).
+__global__ void __launch_bounds__(256) k_scatter_worker_rows(uint64_t *__restrict__ free_, int64_t *__restrict__ rem, uint32_t R, uint32_t n,
+                                                             const uint32_t *__restrict__ idx, const uint64_t *__restrict__ rows, const int64_t *__restrict__ new_rem) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * R) return;
+    const uint32_t i = t / R, r = t % R, w = idx[i];
+    free_[(size_t)w * R + r] = rows[t];
+    if (r == 0 && new_rem) rem[w] = new_rem[i];
+}
+
 // ------------------------------------------------------------------------------------------------ resident ready-set deltas (f1)
 // TaskQueues::add_ready_task / take_tasks / remove on the HBM-resident columns (scheduler/taskqueue.rs:37-43,146-217,304-355).
 // Removal is a tombstone in the rq column (RQ_TOMBSTONE); k_rebuild drops tombstones and merges a sorted batch of new tasks.
@@ -909,6 +920,12 @@ hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, cons
     hipError_t e;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_expand_mapping), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     HQK_TIMED_LAUNCH(k_expand_mapping, dim3(W), dim3(256), lds, s, mk, W, sel_task, sel_key, Q, max_items, rec_task, rec_variant, rec_kind, err_flag, co, max_out, sort_cap);
+    return hipGetLastError();
+}
+
+hipError_t scatter_worker_rows(uint64_t *free_, int64_t *rem, uint32_t R, uint32_t n, const uint32_t *idx, const uint64_t *rows, const int64_t *new_rem, hipStream_t s) {
+    if (n == 0 || R == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_worker_rows, dim3((n * R + 255) / 256), dim3(256), 0, s, free_, rem, R, n, idx, rows, new_rem);
     return hipGetLastError();
 }
 

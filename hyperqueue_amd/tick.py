@@ -119,6 +119,26 @@ class Tick:
         self._lib.hqtick_ready_count.argtypes = [C.c_void_p]
         return int(self._lib.hqtick_ready_count(self._ctx))
 
+    # -- cluster tables resident in HBM (include/hqtick.h, ABI 5) ------------------------------------------------------------
+    def cluster_upload(self, snap):
+        """worker rows + request tables of `snap` (abi.Snapshot or SnapshotC) -> HBM; later ticks read them there"""
+        sc = snap.to_c() if hasattr(snap, "to_c") else snap
+        self._lib.hqtick_cluster_upload.argtypes = [C.c_void_p, C.POINTER(abi.SnapshotC)]
+        self._chk(self._lib.hqtick_cluster_upload(self._ctx, C.byref(sc)))
+
+    def cluster_update_workers(self, worker_index, free_rows, remaining_ns=None):
+        """rows whose free resources (and optionally remaining lifetime) changed since the last call"""
+        idx = np.ascontiguousarray(worker_index, np.uint32)
+        rows = np.ascontiguousarray(free_rows, np.uint64).reshape(-1)
+        rem = None if remaining_ns is None else np.ascontiguousarray(remaining_ns, np.int64)
+        self._lib.hqtick_cluster_update_workers.argtypes = [C.c_void_p, C.c_uint32, abi.u32p, abi.u64p, C.POINTER(C.c_int64)]
+        self._chk(self._lib.hqtick_cluster_update_workers(self._ctx, len(idx), idx.ctypes.data_as(abi.u32p), rows.ctypes.data_as(abi.u64p),
+                                                          None if rem is None else rem.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def cluster_drop(self):
+        self._lib.hqtick_cluster_drop.argtypes = [C.c_void_p]
+        self._chk(self._lib.hqtick_cluster_drop(self._ctx))
+
     # -- device-resident dependency graph (include/hqtick.h, SURVEY §8 f1) --------------------------------------------------
     def _graph_last_ids(self) -> np.ndarray:
         n = C.c_uint64()

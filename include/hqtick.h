@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HQTICK_ABI_VERSION 4u
+#define HQTICK_ABI_VERSION 5u
 
 /* ResourceAmount::MAX                                    common/resources/amount.rs:31 */
 #define HQ_AMOUNT_MAX UINT64_MAX
@@ -310,6 +310,25 @@ int hqtick_ready_remove(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id);
 int hqtick_ready_add(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority, const uint32_t *task_rq);
 int hqtick_ready_compact(hqtick_ctx *ctx);
 uint64_t hqtick_ready_count(const hqtick_ctx *ctx);
+
+/*
+ * Cluster tables resident in HBM (ABI 5): the worker rows (total, free, remaining lifetime) and the request tables K2 reads every
+ * tick stay on the device, and the reactor sends what its event handlers change instead of the library re-packing W rows per tick:
+ *   hqtick_cluster_upload          the snapshot's worker_total / worker_free / worker_remaining_ns and request tables -> HBM.  Again whenever
+ *                                  workers join or leave (on_new_worker / on_remove_worker, server/reactor.rs:20-186: the row count changes).
+ *   hqtick_cluster_update_workers  n rows whose free resources (and, with remaining_ns != NULL, remaining lifetime) changed since the last call —
+ *                                  tasks started (the previous tick's assignments, Worker::insert_sn_task) or finished (on_task_finished),
+ *                                  time limits running down.  worker_index[n] are row numbers of the uploaded set, free_rows[n * n_resources].
+ *                                  Applied in stream order before the next tick; returns without synchronising.
+ *   hqtick_cluster_drop            back to per-tick packing.
+ * While the tables are resident, hqtick_run / hqtick_run_resident read the worker rows from HBM (the snapshot's worker arrays still feed the host-side
+ * model build and MUST hold the same values: the caller owns that invariant; HQTICK_CHECK_CLUSTER=1 in the environment makes every tick verify it and
+ * fail with HQTICK_E_INVALID).  New request classes in a snapshot are detected and re-sent by the tick itself (a few hundred bytes).  A snapshot with
+ * another n_workers / n_resources than the uploaded set is refused (HQTICK_E_INVALID).
+ */
+int hqtick_cluster_upload(hqtick_ctx *ctx, const hqtick_snapshot *snapshot);
+int hqtick_cluster_update_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *worker_index, const uint64_t *free_rows, const int64_t *remaining_ns);
+int hqtick_cluster_drop(hqtick_ctx *ctx);
 
 /*
  * Device-resident dependency graph (BASELINE config 5): the `Waiting{unfinished_deps}` counters and the consumer
