@@ -612,6 +612,7 @@ struct CompSolver {
     // is left out).  Where the root LP pays a block more than the incumbent does there is something to gain, where it pays less there is something to
     // give: windows pair the blocks with the largest deficit with those of the largest surplus, which the index-based windows only meet by chance.
     std::vector<int> block_of; int n_blocks = 0;
+    std::vector<double> lag_value, lag_rcost;  // after lagrangian_bound(): V_b(pi*) per block and the reduced costs c - pi* A per column
     void find_blocks() {
         DSUlite d(n);
         const int wide = std::max(12, n / 32);
@@ -627,6 +628,10 @@ struct CompSolver {
         bool improved = false;
         for (int pass = 0; pass < 6 && wall() < until && !timed_out && !certified(); pass++) {
             std::vector<double> gain(n_blocks, 0.0);
+            if (!lag_value.empty()) {  // regret at the Lagrangian's prices: V_b(pi*) - (c - pi* A).x_b >= 0; the regrets and the priced slack of the wide rows add up to the whole gap
+                for (int b = 0; b < n_blocks; b++) gain[b] = lag_value[b];
+                for (int j = 0; j < n; j++) gain[block_of[j]] -= lag_rcost[j] * bx[j];
+            } else
             for (int j = 0; j < n; j++) gain[block_of[j]] += c[j] * (lp_x[j] - bx[j]);
             std::vector<int> order(n_blocks); std::iota(order.begin(), order.end(), 0);
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gain[a] > gain[b]; });
@@ -642,6 +647,121 @@ struct CompSolver {
             if (tracing) fprintf(stderr, "[milp]   guided window (%d columns, shift %d): %.9f -> %.9f\n", (int)wcols.size(), shift, before, best);
         }
         return improved;
+    }
+    // Lagrangian bound over the wide rows.  The model without its wide rows (batch sizes; a handful) is one small LP per block (a worker: 8 columns x
+    // 3 rows), and for ANY multipliers pi >= 0 on the wide rows   pi.h + sum_blocks max { (c - pi A).x : x in block }   bounds the model from above —
+    // at the best pi it IS the LP bound.  That makes the bound of an 8 192 x 3 080 model a matter of 9-variable cutting-plane LPs (Kelley) and a few
+    // hundred sweeps over 1 024 tiny block LPs, where the dense tableau of the whole model does not finish in seconds.  Any iterate gives a valid
+    // bound; the loop stops when the master's lower estimate is within 1e-5 of the best bound seen.
+    bool lagrangian_bound(double until, double *bound_out) {
+        if (block_of.empty()) find_blocks();
+        if (n_blocks < 8) return false;
+        for (int j = 0; j < n; j++) if (lb[j] != 0.0) return false;
+        // rows: inside one block, or wide
+        std::vector<int> wide; std::vector<int> row_block(R.m, -1);
+        for (int i = 0; i < R.m; i++) {
+            int b = -1; bool multi = false;
+            for (int k = R.off[i]; k < R.off[i + 1]; k++) { const int bb = block_of[R.col[k]]; if (b < 0) b = bb; else if (bb != b) { multi = true; break; } }
+            if (multi) { if (R.lo[i] > -INF || R.hi[i] >= INF) return false; wide.push_back(i); }
+            else { if (R.lo[i] > FEAS_TOL || R.hi[i] < -FEAS_TOL) return false; row_block[i] = b; }
+        }
+        const int nw = (int)wide.size();
+        if (nw == 0 || nw > 64) return false;
+        struct Block { std::vector<int> cols; Rows rows; std::vector<double> lb, ub, cost; Tab tab; };
+        std::vector<Block> blocks(n_blocks);
+        std::vector<int> local(n, -1);
+        for (int j = 0; j < n; j++) { Block &B = blocks[block_of[j]]; local[j] = (int)B.cols.size(); B.cols.push_back(j); B.lb.push_back(0.0); B.ub.push_back(ub[j]); }
+        for (auto &B : blocks) { B.rows.n = (int)B.cols.size(); B.cost.resize(B.cols.size()); }
+        std::vector<std::pair<int, double>> terms;
+        for (int i = 0; i < R.m; i++) {
+            if (row_block[i] < 0) continue;
+            terms.clear();
+            for (int k = R.off[i]; k < R.off[i + 1]; k++) terms.push_back({local[R.col[k]], R.coef[k]});
+            if (!terms.empty()) blocks[row_block[i]].rows.add(terms, R.lo[i], R.hi[i]);
+        }
+        // wide rows column-wise: for column j the (wide row, coefficient) pairs
+        std::vector<int> woff(n + 1, 0), wrow; std::vector<double> wcoef;
+        for (int q = 0; q < nw; q++) for (int k = R.off[wide[q]]; k < R.off[wide[q] + 1]; k++) woff[R.col[k] + 1]++;
+        for (int j = 0; j < n; j++) woff[j + 1] += woff[j];
+        wrow.resize(woff[n]); wcoef.resize(woff[n]);
+        { std::vector<int> cur(woff.begin(), woff.end() - 1);
+          for (int q = 0; q < nw; q++) for (int k = R.off[wide[q]]; k < R.off[wide[q] + 1]; k++) { const int j = R.col[k]; wrow[cur[j]] = q; wcoef[cur[j]++] = R.coef[k]; } }
+        std::vector<double> h(nw), pmax(nw, 0.0);
+        for (int q = 0; q < nw; q++) h[q] = R.hi[wide[q]];
+        for (int j = 0; j < n; j++) for (int k = woff[j]; k < woff[j + 1]; k++) if (wcoef[k] > 1e-12 && c[j] > 0.0) pmax[wrow[k]] = std::max(pmax[wrow[k]], c[j] / wcoef[k]);
+        // one evaluation: value of the Lagrangian at pi, the activity of the wide rows and c.x at its maximiser
+        std::vector<double> act(nw), xcur(n, 0.0);
+        auto eval = [&](const std::vector<double> &pi, double *cx) -> double {
+            std::fill(act.begin(), act.end(), 0.0);
+            double total = 0.0, cxs = 0.0;
+            for (int q = 0; q < nw; q++) total += pi[q] * h[q];
+            for (auto &B : blocks) {
+                const int nb = (int)B.cols.size();
+                for (int l = 0; l < nb; l++) { const int j = B.cols[l]; double cj = c[j]; for (int k = woff[j]; k < woff[j + 1]; k++) cj -= pi[wrow[k]] * wcoef[k]; B.cost[l] = cj; }
+                B.tab.init(&B.rows, B.cost, B.lb, B.ub);
+                const double ops0 = B.tab.ops;
+                if (B.tab.solve(100000) != LP_OPT) return INF;
+                work += B.tab.ops - ops0;
+                total += B.tab.objective();
+                for (int l = 0; l < nb; l++) { const double xv = B.tab.x[l]; const int j = B.cols[l]; xcur[j] = xv; if (xv == 0.0) continue; cxs += c[j] * xv; for (int k = woff[j]; k < woff[j + 1]; k++) act[wrow[k]] += wcoef[k] * xv; }
+            }
+            *cx = cxs;
+            return total;
+        };
+        std::vector<double> pi(nw, 0.0), pi_best(nw, 0.0);
+        double cx = 0.0;
+        double ub_best = eval(pi, &cx);
+        if (ub_best >= INF) return false;
+        const double theta_scale = std::max(ub_best, 1e-9);
+        // master:  max  -pi.h - theta   s.t.  theta + pi.act_k >= cx_k  for every evaluated point k;   variables [pi (nw) | theta / theta_scale]
+        Rows M; M.n = nw + 1;
+        std::vector<double> mc(nw + 1), mlb(nw + 1, 0.0), mub(nw + 1);
+        for (int q = 0; q < nw; q++) { mc[q] = -h[q] / theta_scale; mub[q] = pmax[q] > 0.0 ? pmax[q] : 0.0; }
+        mc[nw] = -1.0; mub[nw] = 2.0;
+        std::vector<std::vector<float>> cut_x; std::vector<double> cut_scale;  // the maximisers behind the cuts: their convex combination by the master's
+                                                                                 // duals is (nearly) an optimal point of the LP relaxation — what the LP-guided windows compare with
+        auto add_cut = [&]() {
+            cut_x.emplace_back(xcur.begin(), xcur.end());
+            terms.clear(); double sc = 1.0;
+            for (int q = 0; q < nw; q++) if (act[q] != 0.0) { terms.push_back({q, act[q] / theta_scale}); sc = std::max(sc, std::fabs(act[q] / theta_scale)); }
+            terms.push_back({nw, 1.0});
+            for (auto &t : terms) t.second /= sc;
+            M.add(terms, cx / theta_scale / sc, INF);
+            cut_scale.push_back(sc);
+        };
+        add_cut();
+        int it = 0;
+        std::vector<double> lambda;
+        for (; it < 600 && wall() < until; it++) {
+            Tab mt; mt.init(&M, mc, mlb, mub);
+            if (mt.solve(100000) != LP_OPT) break;
+            const double lb_master = -mt.objective() * theta_scale;  // no pi does better than this
+            lambda.assign(M.m, 0.0);
+            for (int k = 0; k < M.m; k++) { const int a = mt.where[k]; if (a >= 0 && mt.st[M.n + a] != BASIC) lambda[k] = std::fabs(mt.d[M.n + a]) / cut_scale[k]; }
+            if (ub_best - lb_master <= 1e-5 * std::fabs(ub_best)) break;
+            for (int q = 0; q < nw; q++) pi[q] = mt.x[q];
+            const double v = eval(pi, &cx);
+            if (v >= INF) break;
+            if (v < ub_best) { ub_best = v; pi_best = pi; }
+            add_cut();
+        }
+        if (tracing) fprintf(stderr, "[milp] n=%d lagrangian bound over %d wide rows, %d blocks: %.9f after %d evaluations, t=%.3fs\n", n, nw, n_blocks, ub_best, it + 1, wall() - t_begin);
+        double lsum = 0.0; for (double l : lambda) lsum += l;
+        if (lsum > 0.0 && lambda.size() <= cut_x.size()) {
+            lp_x.assign(n, 0.0);
+            for (size_t k = 0; k < lambda.size(); k++) { if (lambda[k] == 0.0) continue; const double wgt = lambda[k] / lsum; const std::vector<float> &xk = cut_x[k]; for (int j = 0; j < n; j++) lp_x[j] += wgt * xk[j]; }
+        }
+        // what the guided windows rank blocks by: the block's Lagrangian value at the best multipliers, and the reduced costs c - pi A
+        {
+            double cx2 = 0.0;
+            eval(pi_best, &cx2);
+            lag_value.assign(n_blocks, 0.0);
+            for (int b = 0; b < n_blocks; b++) lag_value[b] = blocks[b].tab.objective();
+            lag_rcost.assign(n, 0.0);
+            for (int j = 0; j < n; j++) { double cj = c[j]; for (int k = woff[j]; k < woff[j + 1]; k++) cj -= pi_best[wrow[k]] * wcoef[k]; lag_rcost[j] = cj; }
+        }
+        *bound_out = ub_best * (1.0 + 1e-9) + 1e-12;
+        return true;
     }
     // Cheap windows first (1000 nodes each: most windows close far below that), and only when a whole round finds nothing the cap goes up 8x —
     // the few windows that hold the last improvements are plateaus of their own.
@@ -675,6 +795,24 @@ struct CompSolver {
         const double hard_deadline = deadline;
         const bool reserve_tail = n > 2000 && !in_lns;  // large model: the search below gets 70 % of the time, the window improvement the rest
         if (reserve_tail) { const double t0 = wall(); deadline = t0 + 0.7 * (hard_deadline - t0); root.deadline = deadline; }
+        if (n > 2000 && have && !in_lns) {
+            // Large model with block structure (an unsaturated tick of the whole cluster: one block per worker, the batch-size rows across): its LP bound
+            // comes from the Lagrangian over the wide rows in a fraction of a second, and the rest of the time belongs to the window search, which stops
+            // as soon as the incumbent is within rel_gap of that bound.
+            const double tl0 = wall();
+            double lag = INF;
+            if (rel_gap > 0.0 && lagrangian_bound(tl0 + 0.3 * (hard_deadline - tl0), &lag)) {
+                root_bound = lag;
+                nodes++;
+                deadline = hard_deadline;
+                trace("window search against the Lagrangian bound");
+                lns_schedule(deadline - 0.05);
+                xout = bx;
+                if (certified()) { canonical_done = false; trace("certificate only"); return 1; }
+                timed_out = true;
+                return 2;
+            }
+        }
         if (n > 2000 && have && !in_lns) {
             // Large model: the root LP gets half of the time.  From an all-at-upper start the dual simplex needs about one pivot per column, and when
             // most rows are violated there (unsaturated ticks: every resource row) each pivot touches the whole tableau — minutes at 8 k columns.  If

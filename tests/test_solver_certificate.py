@@ -30,6 +30,24 @@ def _unsaturated(dag_sources, W, fill, ncls=8):
 
 # (workers, fill, seconds the reference-configured HiGHS 1.8 needs on the build container): every one of these was `is_optimal = 0` after 5 s in round 1
 CASES = [(5, 0.45, 0.06), (32, 0.20, 1.2), (32, 0.45, 0.10), (64, 0.20, 2.1), (128, 0.20, 0.63), (128, 0.45, 0.39)]
+# the whole BASELINE cluster, unsaturated: an 8 192 x 3 080 model on which HiGHS and the round-1 solver both hit the 5 s limit.  The bound comes from the
+# Lagrangian over the batch-size rows (milp.cpp::lagrangian_bound), the incumbent from the window search: certified in a fraction of a second
+LARGE = [(256, 0.20), (512, 0.20), (1024, 0.20), (256, 0.45)]
+
+
+@pytest.mark.parametrize("W,fill", LARGE)
+def test_unsaturated_tick_of_a_large_cluster_is_certified(dag_sources, W, fill):
+    snap = _unsaturated(dag_sources, W, fill)
+    hs = HostStages(abi.make_config(time_limit_s=5.0))
+    t0 = time.perf_counter()
+    got = hs.stages(snap)
+    took = time.perf_counter() - t0
+    assert got.status == abi.HQTICK_DONE and got.is_optimal, (W, fill, took)
+    assert took < 2.5, took
+    n_ready = len(snap.task_id)
+    if fill <= 0.2:  # everything fits: every ready task is placed
+        assert sum(c for *_, c in got.counts) == n_ready
+
 
 
 @pytest.mark.parametrize("W,fill,highs_s", CASES)
