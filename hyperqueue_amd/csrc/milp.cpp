@@ -746,6 +746,41 @@ struct CompSolver {
             add_cut();
         }
         if (tracing) fprintf(stderr, "[milp] n=%d lagrangian bound over %d wide rows, %d blocks: %.9f after %d evaluations, t=%.3fs\n", n, nw, n_blocks, ub_best, it + 1, wall() - t_begin);
+        // Price-directed construction: block after block (the model's column order: worker index), each takes the integer optimum of its own block at the
+        // Lagrangian's prices — slightly discounted, so that a block which is indifferent about a scarce column takes it — within what the wide rows
+        // still have left.  The prices keep the early, well-paid blocks from hogging what later ones need, which is where the plain greedy start loses.
+        if (have && wall() < until) {
+            std::vector<double> xi(n, 0.0), left(h);
+            bool ok = true;
+            for (auto &B : blocks) {
+                const int nb = (int)B.cols.size();
+                CompSolver sub; sub.n = nb; sub.in_lns = true; sub.deadline = until; sub.node_cap = 2000;
+                sub.c.resize(nb); sub.lb.assign(nb, 0.0); sub.ub = B.ub; sub.R = B.rows;
+                for (int l = 0; l < nb; l++) {
+                    const int j = B.cols[l]; double cj = c[j];
+                    for (int k = woff[j]; k < woff[j + 1]; k++) {
+                        cj -= 0.999 * pi_best[wrow[k]] * wcoef[k];
+                        if (wcoef[k] > 1e-12) sub.ub[l] = std::min(sub.ub[l], std::floor(std::max(0.0, left[wrow[k]]) / wcoef[k] + 1e-9));
+                    }
+                    sub.c[l] = cj;
+                }
+                std::vector<double> xb;
+                const int st = sub.run(false, xb);
+                nodes += sub.nodes;
+                if (st == 0 || (int)xb.size() != nb) { ok = false; break; }
+                for (int l = 0; l < nb; l++) {
+                    const int j = B.cols[l]; if (xb[l] <= 0.0 || sub.c[l] <= 0.0) continue;  // columns the prices make worthless stay out
+                    xi[j] = xb[l];
+                    for (int k = woff[j]; k < woff[j + 1]; k++) left[wrow[k]] -= wcoef[k] * xb[l];
+                }
+            }
+            for (int q = 0; q < nw; q++) if (left[q] < -FEAS_TOL) ok = false;  // several wide rows on one column could overshoot: then the point is simply not used
+            if (ok) {
+                const double before = best;
+                greedy_from(xi);
+                if (tracing) fprintf(stderr, "[milp] n=%d price-directed construction: incumbent %.9f -> %.9f, t=%.3fs\n", n, before, best, wall() - t_begin);
+            }
+        }
         double lsum = 0.0; for (double l : lambda) lsum += l;
         if (lsum > 0.0 && lambda.size() <= cut_x.size()) {
             lp_x.assign(n, 0.0);
