@@ -444,8 +444,10 @@ def main():
                              "launch read the worker tables from pinned host memory (PCIe round trips), which is what stretches the in-tick launch over the stand-alone one"},
         "roofline_time_dominant_kernel": {"kernel": "expand_mapping", "bound": "pcie", "achieved": pcie_bytes / (em["us"] * 1e-6) / 1e9 if em["us"] > 0 else 0.0, "peak": pcie_peak, "unit": "GB/s",
                                           "frac": (pcie_bytes / (em["us"] * 1e-6) / 1e9 / pcie_peak) if em["us"] > 0 else 0.0, "bytes_over_pcie_per_launch": pcie_bytes, "avg_launch_us": em["us"],
-                                          "note": "K5b writes the records straight into the caller's pinned host buffer (compact emission: 4 B per record + 10 B per run of equal "
-                                                  "(job, variant, kind); --full-records: 10 B per record): the launch lasts as long as the PCIe writes do"},
+                                          "note": "K5b writes the records straight into the caller's pinned host buffer (compact emission: 4 B per record, counted here, + 12 B per run of equal "
+                                                  "(job, variant, kind) + 8 B per worker; --full-records: 10 B per record).  Ablation on the MI355X (profiles/r02/README.md): 11.9 us of the launch is the "
+                                                  "kernel itself (gather from HBM, LDS sort), 12.6 us the record bytes crossing PCIe (60 GB/s), 1.4 us runs + spans; a shared run counter (one "
+                                                  "atomicAdd per workgroup on one address) had cost another 8.5 us until the runs moved into the slots of their own records"},
     }
     if world == 1 and not args.force_sharded and not args.no_kernel_timing and args.roofline_sweep:
         sweep = []

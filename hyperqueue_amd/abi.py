@@ -137,11 +137,8 @@ class ResultC(C.Structure):
         ("retract_off", u32p),
         ("retract_task", u64p),
         ("rec_task_lo", u32p),
-        ("run_start", u32p),
-        ("run_cnt", u32p),
-        ("run_first", u32p),
-        ("run_job", u32p),
-        ("run_meta", C.POINTER(C.c_uint16)),
+        ("run_span", u32p),  # hqtick_run_span[W]: (start, count) pairs
+        ("runs", u32p),      # hqtick_rec_run[]: (first, job, meta) triples
         ("n_redirects", C.c_uint32),
         ("redirect_task", u64p),
         ("redirect_worker", u32p),
@@ -372,12 +369,14 @@ def expand_compact(r: ResultC, W: int, off: np.ndarray):
     """(task ids, variants, kinds) of every record from the compact emission — what the host shim does while it applies the records"""
     n = int(off[-1])
     lo = _np(r.rec_task_lo, n, np.uint32).astype(np.uint64)
-    rs, rc = _np(r.run_start, W, np.uint32), _np(r.run_cnt, W, np.uint32)
+    span = _np(r.run_span, 2 * W, np.uint32).reshape(W, 2)
+    rs, rc = span[:, 0], span[:, 1]
     task = np.zeros(n, np.uint64); var = np.zeros(n, np.uint8); kind = np.zeros(n, np.uint8)
     have = np.nonzero(off[1:] > off[:-1])[0]
     if len(have):
         hi_run = int(max(int(rs[w]) + int(rc[w]) for w in have))
-        first, job, meta = _np(r.run_first, hi_run, np.uint32), _np(r.run_job, hi_run, np.uint32), _np(r.run_meta, hi_run, np.uint16)
+        runs = _np(r.runs, 3 * hi_run, np.uint32).reshape(hi_run, 3)
+        first, job, meta = runs[:, 0], runs[:, 1], runs[:, 2].astype(np.uint16)
         for w in have:
             a, b, s0, c = int(off[w]), int(off[w + 1]), int(rs[w]), int(rc[w])
             assert c >= 1 and first[s0] == 0, (w, c)

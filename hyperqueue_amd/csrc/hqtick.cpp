@@ -82,7 +82,7 @@ struct hqtick_ctx {
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
     uint32_t block_budget = 4096, block_min_classes = 12;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
     // workers / requests
-    DevBuf d_up, d_vflags, d_vtmc, d_blk, d_runctr;
+    DevBuf d_up, d_vflags, d_vtmc, d_blk;
     // cluster tables resident in HBM (hqtick_cluster_*): worker rows + request tables in the layout of upload_tables; the host sends rows that changed
     DevBuf d_cluster; PinBuf h_cl, h_cld; bool cluster_valid = false, cluster_check = false, cl_pending = false; uint32_t cl_W = 0, cl_R = 0;
     std::vector<unsigned char> cl_rt;  // host copy of the request-table part as uploaded (compared per tick: a few hundred bytes)
@@ -495,7 +495,7 @@ struct TickRun {
     std::vector<std::vector<uint32_t>> key_T;                 // lazily built T_k(s) tables of worker_of()
     size_t o_rv = 0, o_rk = 0, o_mn = 0, o_fl = 0;            // layout of the pinned record buffer
     bool may_reorder = false;  // the mapping kernel needs its stable sort: several priority levels, Retracting holes or prefilled tasks inside the queues
-    bool compact = false; size_t o_rs = 0, o_rc = 0, o_rf = 0, o_rj = 0, o_rm = 0; uint32_t max_out = 0;  // compact emission (HQTICK_FLAG_COMPACT_RECORDS)
+    bool compact = false; size_t o_rs = 0, o_rf = 0; uint32_t max_out = 0;  // compact emission (HQTICK_FLAG_COMPACT_RECORDS)
     uint64_t *h_rec_task = nullptr, *mn_ids = nullptr; uint8_t *h_rec_var = nullptr, *h_rec_kind = nullptr;
     bool assembled = false;
     double t0 = 0;
@@ -776,9 +776,9 @@ struct TickRun {
     // GPU phase C: selection, round-robin bit rows, per-worker expansion; records land in pinned memory (or the HBM sink)
     int phase_c() {
         size_t n_mn_ids = 0; for (auto &sets : cnt.mn_sets) n_mn_ids += sets.size();
-        if (compact) {  // [rec_lo u32 x n_rec][run_start u32 x W][run_cnt u32 x W][run_first u32 x n_rec][run_job u32 x n_rec][run_meta u16 x n_rec] (at most one run per record)
-            o_rs = (size_t)n_rec * 4; o_rc = o_rs + (size_t)W * 4; o_rf = o_rc + (size_t)W * 4; o_rj = o_rf + (size_t)n_rec * 4; o_rm = o_rj + (size_t)n_rec * 4;
-            o_rv = o_rk = 0; o_mn = (o_rm + (size_t)n_rec * 2 + 7) & ~(size_t)7;
+        if (compact) {  // [rec_lo u32 x n_rec][run_span (start, count) x W][runs 12 B x n_rec] (at most one run per record)
+            o_rs = ((size_t)n_rec * 4 + 7) & ~(size_t)7; o_rf = o_rs + (size_t)W * 8;
+            o_rv = o_rk = 0; o_mn = (o_rf + (size_t)n_rec * 12 + 7) & ~(size_t)7;
         } else { o_rv = (size_t)n_rec * 8; o_rk = o_rv + n_rec; o_mn = (o_rk + n_rec + 7) & ~(size_t)7; }
         o_fl = o_mn + n_mn_ids * 8;
         const size_t rec_bytes = o_fl + 64;
@@ -801,7 +801,7 @@ struct TickRun {
             if (ps.holes.empty()) { pack.push_back(0); pack.push_back(0); }
             // device record buffer: [task u64 x n_rec][variant u8 x n_rec][kind u8 x n_rec] -> one D2H copy
             if (!ctx->d_map.ensure(pack.size() * 4 + 16) || !ctx->h_plan.ensure(pack.size() * 4 + 16) ||
-                !ctx->d_runctr.ensure(64) || !ctx->d_tsweep.ensure((size_t)ps.key_t_off[nkeys] * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) || !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
+                !ctx->d_tsweep.ensure((size_t)ps.key_t_off[nkeys] * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) || !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
                 return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
             mark();  // 6: pack
             memcpy(ctx->h_plan.p, pack.data(), pack.size() * 4);
@@ -812,7 +812,6 @@ struct TickRun {
             mk.t_sweep = ctx->d_tsweep.as<uint32_t>(); mk.bits = ctx->d_bits.as<uint64_t>(); mk.pre = ctx->d_pre.as<uint32_t>();
             mk.wpos = d + o_wpos; mk.wcnt = d + o_wcnt; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn;
             mk.n_holes = (uint32_t)ps.holes.size(); mk.holes = reinterpret_cast<const uint64_t *>(d + o_holes);
-            mk.run_counter = compact ? ctx->d_runctr.as<uint32_t>() : nullptr;
             mk.n_pfq = n_pfq; mk.pfq_src = d + o_pqs; mk.pfq_size = d + o_pqz; mk.pfl_j = d + o_pflj; mk.out_off = d + o_out;
             uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
             flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
@@ -841,8 +840,7 @@ struct TickRun {
             }
             if (ctx->timing) hqk::time_next_launch(ctx->ev[7], ctx->ev[11]);
             hqk::CompactOut co{};
-            if (compact) co = hqk::CompactOut{reinterpret_cast<uint32_t *>(drec), reinterpret_cast<uint32_t *>(drec + o_rs), reinterpret_cast<uint32_t *>(drec + o_rc), reinterpret_cast<uint32_t *>(drec + o_rf),
-                                              reinterpret_cast<uint32_t *>(drec + o_rj), reinterpret_cast<uint16_t *>(drec + o_rm), ctx->d_runctr.as<uint32_t>(), n_rec};
+            if (compact) co = hqk::CompactOut{reinterpret_cast<uint32_t *>(drec), reinterpret_cast<uint2 *>(drec + o_rs), reinterpret_cast<uint32_t *>(drec + o_rf)};
             HQ_HIP_TIMED(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
                                 reinterpret_cast<uint32_t *>(drec + o_fl), co, max_out, may_reorder, ctx->stream));
             // multi-node tasks: the heads of their queues
@@ -889,8 +887,7 @@ struct TickRun {
         out->rec_off = ctx->rec_off.data();
         if (compact && n_sel) {
             const uint8_t *hb = ctx->h_rec.as<uint8_t>();
-            out->rec_task_lo = reinterpret_cast<const uint32_t *>(hb); out->run_start = reinterpret_cast<const uint32_t *>(hb + o_rs); out->run_cnt = reinterpret_cast<const uint32_t *>(hb + o_rc);
-            out->run_first = reinterpret_cast<const uint32_t *>(hb + o_rf); out->run_job = reinterpret_cast<const uint32_t *>(hb + o_rj); out->run_meta = reinterpret_cast<const uint16_t *>(hb + o_rm);
+            out->rec_task_lo = reinterpret_cast<const uint32_t *>(hb); out->run_span = reinterpret_cast<const hqtick_run_span *>(hb + o_rs); out->runs = reinterpret_cast<const hqtick_rec_run *>(hb + o_rf);
         } else if (!ctx->sink) { out->rec_task = h_rec_task; out->rec_variant = h_rec_var; out->rec_kind = h_rec_kind; }
         out->retract_off = ctx->retract_off.data(); out->retract_task = ctx->retract_task.data();
         out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data(); out->redirect_kind = ctx->red_kind.data();
@@ -1003,7 +1000,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
     DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
-                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8, &ctx->d_blk, &ctx->d_runctr, &ctx->d_cluster};
+                      &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8, &ctx->d_blk, &ctx->d_cluster};
     for (DevBuf *b : bufs) b->release();
     ctx->h_cl.release(); ctx->h_cld.release();
     if (ctx->cl_ev) hipEventDestroy(ctx->cl_ev);

@@ -109,20 +109,14 @@ struct MapKeys {
     const uint64_t *holes;
     // output placement
     const uint32_t *out_off;       // [W+1]
-    uint32_t *run_counter;         // compact emission: K5a zeroes it for K5b (nullptr = not in use)
 };
 hipError_t sweep_bits(MapKeys mk, uint32_t max_count, uint32_t max_workers_per_key, hipStream_t s);
 static const uint32_t SWEEP_MAX_WORKERS = 24576;  // workers per key the round-robin kernel stages in LDS
 // Compact emission (hqtick.h, HQTICK_FLAG_COMPACT_RECORDS): rec_lo == nullptr switches it off.
 struct CompactOut {
     uint32_t *rec_lo;       // [n_rec] low 32 bits of every record's task id, per-worker CSR order (rec_off)
-    uint32_t *run_start;    // [W] first run of the worker in the run arrays
-    uint32_t *run_cnt;      // [W]
-    uint32_t *run_first;    // [run_cap] index of the run's first record inside its worker's range
-    uint32_t *run_job;      // [run_cap] high 32 bits of the task ids of the run
-    uint16_t *run_meta;     // [run_cap] variant | kind << 8
-    uint32_t *run_counter;  // device memory, zero before the launch
-    uint32_t run_cap;
+    uint2 *run_span;        // [W] (first run of the worker = its first record's offset, number of runs)    = hqtick_run_span
+    uint32_t *runs;         // [n_rec * 3] per run: index of its first record inside the worker's range, high 32 bits of its task ids, variant | kind << 8   = hqtick_rec_run
 };
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_key, uint32_t Q, uint32_t max_items,
                     uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, CompactOut co, uint32_t max_out, bool may_reorder, hipStream_t s);

@@ -191,6 +191,14 @@ typedef struct hqtick_query_workers {
     const float *worker_min_utilization;
 } hqtick_query_workers;
 
+/* Compact emission (HQTICK_FLAG_COMPACT_RECORDS): one run = a maximal stretch of a worker's records that share (job id, variant, kind) */
+typedef struct hqtick_rec_run {
+    uint32_t first; /* index of the run's first record inside its worker's range */
+    uint32_t job;   /* high 32 bits of the task ids of the run (the job id of HyperQueue's TaskId packing) */
+    uint32_t meta;  /* variant | kind << 8 (low 16 bits; the rest is zero) */
+} hqtick_rec_run;
+typedef struct hqtick_run_span { uint32_t start, count; } hqtick_run_span;
+
 /*
  * Result view.  All pointers are owned by the ctx and stay valid until the next call on it.
  */
@@ -235,15 +243,14 @@ typedef struct hqtick_result {
     const uint32_t *retract_off; /* [W+1] */
     const uint64_t *retract_task;
     /* Compact emission (HQTICK_FLAG_COMPACT_RECORDS; NULL otherwise).  Worker w's records are rec_off[w] .. rec_off[w + 1] as before; record i of
-     * that range has task id (run_job << 32) | rec_task_lo[rec_off[w] + i], variant run_meta & 0xFF (0xFF = None: a prefill) and kind run_meta >> 8,
-     * where the run is the one of run_start[w] .. run_start[w] + run_cnt[w] with the largest run_first <= i (runs ascend by run_first; the first
-     * one starts at 0).  run_start / run_cnt are defined only for workers with records. */
-    const uint32_t *rec_task_lo; /* [n_records] */
-    const uint32_t *run_start;   /* [W] */
-    const uint32_t *run_cnt;     /* [W] */
-    const uint32_t *run_first;
-    const uint32_t *run_job;
-    const uint16_t *run_meta;
+     * that range has task id (run.job << 32) | rec_task_lo[rec_off[w] + i], variant run.meta & 0xFF (0xFF = None: a prefill) and kind run.meta >> 8,
+     * where `run` is the one of runs[run_span[w].start .. + run_span[w].count) with the largest run.first <= i (runs ascend by `first`; the first one
+     * starts at 0).  run_span is defined only for workers with records; a worker's runs sit in the run slots of its own records (run_span[w].start ==
+     * rec_off[w]: at most one run per record, so no allocation is needed on the device).  (ABI 5: the runs are 12-byte records and the span one 8-byte pair — every
+     * store of the mapping kernel crosses PCIe as a write of its own, and three arrays of 4 + 4 + 2 bytes per run cost a third of the launch.) */
+    const uint32_t *rec_task_lo;        /* [n_records] */
+    const struct hqtick_run_span *run_span; /* [W] */
+    const struct hqtick_rec_run *runs;
 
     /* scheduler_state.redirects insertions made by this tick (mapping.rs:78-100) */
     uint32_t n_redirects;

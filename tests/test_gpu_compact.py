@@ -70,7 +70,7 @@ def test_compact_runs_split_on_job_variant_and_kind():
         assert a.records == b.records and a.counts == b.counts and a.retracts == b.retracts
         rc = comp.tick_raw(snap.to_c())
         W = len(snap.worker_id)
-        cnt = np.ctypeslib.as_array(rc.run_cnt, shape=(W,))
+        cnt = np.ctypeslib.as_array(rc.run_span, shape=(2 * W,)).reshape(W, 2)[:, 1]
         off = np.ctypeslib.as_array(rc.rec_off, shape=(W + 1,))
         assert max(int(cnt[w]) for w in range(W) if off[w + 1] > off[w]) >= 3  # jobs / kinds really split the runs
     finally:
