@@ -78,7 +78,7 @@ struct hqtick_ctx {
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
-    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_retr, h_blk;
+    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_retr, h_blk, h_k5a;
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
     uint32_t block_budget = 4096, block_min_classes = 12;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
     // workers / requests
@@ -87,6 +87,7 @@ struct hqtick_ctx {
     DevBuf d_cluster; PinBuf h_cl, h_cld; bool cluster_valid = false, cluster_check = false, cl_pending = false; uint32_t cl_W = 0, cl_R = 0;
     std::vector<unsigned char> cl_rt;  // host copy of the request-table part as uploaded (compared per tick: a few hundred bytes)
     hipEvent_t cl_ev = nullptr;
+    bool sweep_inflight = false;  // an early K5a launch not yet covered by a stream synchronisation
     // selection + mapping
     DevBuf d_sel_task, d_sel_level, d_map, d_rec, d_tsweep, d_bits, d_pre;
     hqhost::Problem pb;
@@ -494,6 +495,7 @@ struct TickRun {
     std::vector<std::pair<uint32_t, uint32_t>> retr_pos;      // (rq, queue position) of every Retracting task
     std::vector<std::vector<uint32_t>> key_T;                 // lazily built T_k(s) tables of worker_of()
     size_t o_rv = 0, o_rk = 0, o_mn = 0, o_fl = 0;            // layout of the pinned record buffer
+    bool sweep_launched = false;  // K5a went out right after the key tables (launch_sweep_early)
     bool may_reorder = false;  // the mapping kernel needs its stable sort: several priority levels, Retracting holes or prefilled tasks inside the queues
     bool compact = false; size_t o_rs = 0, o_rf = 0; uint32_t max_out = 0;  // compact emission (HQTICK_FLAG_COMPACT_RECORDS)
     uint64_t *h_rec_task = nullptr, *mn_ids = nullptr; uint8_t *h_rec_var = nullptr, *h_rec_kind = nullptr;
@@ -773,6 +775,30 @@ struct TickRun {
         }
     }
 
+    // K5a needs the key tables only (counts in Map order per key): it goes out as soon as plan_keys() has them, reading its four small tables in place
+    // from pinned memory, and runs while the host plans redirects, prefills and outputs — 5.4 us and a launch boundary off the critical path.
+    int launch_sweep_early() {
+        sweep_launched = false;
+        if (nkeys == 0 || n_bit_words == 0 || max_nk > hqk::SWEEP_MAX_WORKERS) return 0;  // (the capacity error is reported by plan_outputs)
+        if (ctx->sweep_inflight) { HQ_HIP(hipStreamSynchronize(ctx->stream)); ctx->sweep_inflight = false; }  // a tick that failed after its early launch: its kernel still reads h_k5a
+        const size_t n_ord = ps.ord_cnt.size(), words = 3 * (size_t)(nkeys + 1) + n_ord;
+        if (!ctx->h_k5a.ensure(words * 4 + 64) || !ctx->d_tsweep.ensure((size_t)ps.key_t_off[nkeys] * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) ||
+            !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
+            return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
+        uint32_t *h = ctx->h_k5a.as<uint32_t>();
+        const uint32_t *d = ctx->h_k5a.dev<uint32_t>();
+        const size_t o_toff = 0, o_ordoff = nkeys + 1, o_boff = 2 * (size_t)(nkeys + 1), o_ord = 3 * (size_t)(nkeys + 1);
+        memcpy(h + o_toff, ps.key_t_off.data(), (size_t)(nkeys + 1) * 4); memcpy(h + o_ordoff, ps.key_ord_off.data(), (size_t)(nkeys + 1) * 4);
+        memcpy(h + o_boff, ps.key_bits_off.data(), (size_t)(nkeys + 1) * 4); if (n_ord) memcpy(h + o_ord, ps.ord_cnt.data(), n_ord * 4);
+        hqk::MapKeys mk{};
+        mk.n_keys = nkeys; mk.key_t_off = d + o_toff; mk.key_ord_off = d + o_ordoff; mk.key_bits_off = d + o_boff; mk.ord_cnt = d + o_ord;
+        mk.t_sweep = ctx->d_tsweep.as<uint32_t>(); mk.bits = ctx->d_bits.as<uint64_t>(); mk.pre = ctx->d_pre.as<uint32_t>();
+        if (ctx->timing) hqk::time_next_launch(ctx->ev[1], ctx->ev[6]);
+        HQ_HIP_TIMED(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
+        sweep_launched = true; ctx->sweep_inflight = true;
+        return 0;
+    }
+
     // GPU phase C: selection, round-robin bit rows, per-worker expansion; records land in pinned memory (or the HBM sink)
     int phase_c() {
         size_t n_mn_ids = 0; for (auto &sets : cnt.mn_sets) n_mn_ids += sets.size();
@@ -820,8 +846,10 @@ struct TickRun {
             if (ctx->timing) hqk::time_next_launch(ctx->ev[4], ctx->ev[5]);
             HQ_HIP_TIMED(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
                                 d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, pack.size() * 4, nullptr, ctx->stream));
-            if (ctx->timing) hqk::time_next_launch(ctx->ev[1], ctx->ev[6]);
-            HQ_HIP_TIMED(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
+            if (!sweep_launched) {
+                if (ctx->timing) hqk::time_next_launch(ctx->ev[1], ctx->ev[6]);
+                HQ_HIP_TIMED(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
+            }
             uint8_t *drec = ctx->h_rec.dev<uint8_t>();  // K5b writes the records straight into the caller-visible pinned buffer (PCIe-bound, no copy command)
             uint64_t *k_task = reinterpret_cast<uint64_t *>(drec); uint8_t *k_var = drec + o_rv, *k_kind = drec + o_rk;
             if (ctx->sink) {  // multi-GPU: records stay in HBM, laid out for the all-gather (include/hqtick.h)
@@ -855,6 +883,7 @@ struct TickRun {
             mark();  // 7: phase C enqueued
             assemble_host_part();
             HQ_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->sweep_inflight = false;
             if (flags[0]) return fail(ctx, HQTICK_E_CAPACITY, "mapping kernel capacity exceeded");
             if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[4], ctx->ev[5]); if (us_ >= 0) ctx->stats.select_us = us_; }
             if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[1], ctx->ev[6]); if (us_ >= 0) ctx->stats.sweep_us = us_; }
@@ -939,6 +968,7 @@ struct TickRun {
         if (!cnt.is_optimal) status = cnt.empty() ? HQTICK_NO_PROGRESS : HQTICK_NEED_MORE_COMPUTE;
         // ---------------- host: mapping plan ----------------
         if ((rc = plan_keys())) return rc;
+        if ((rc = launch_sweep_early())) return rc;
         if ((rc = plan_redirects())) return rc;
         mark();  // 3: key tables + retracts
         if ((rc = plan_prefill())) return rc;
@@ -1008,7 +1038,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->comm) { rccl_destroy_comm(ctx); }
     ctx->graph.release();
-    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_retr.release(); ctx->h_blk.release(); ctx->h_blkprof.release();
+    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_retr.release(); ctx->h_blk.release(); ctx->h_blkprof.release(); ctx->h_k5a.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
