@@ -7,12 +7,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hyperqueue_amd import abi, workloads
 from hyperqueue_amd.tick import Tick
 
-name = sys.argv[1] if len(sys.argv) > 1 else "c3"
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+name = args[0] if args else "c3"
+n = int(args[1]) if len(args) > 1 else 30
 snap = workloads.make(name)
-t = Tick(abi.make_config(time_limit_s=5.0))
+t = Tick(abi.make_config(time_limit_s=5.0, flags=abi.HQTICK_FLAG_COMPACT_RECORDS))  # as bench.py runs it
 t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
 sc = snap.to_c()
+t.cluster_upload(sc)
+if "--timed" not in sys.argv:
+    t.set_kernel_timing(False)
 t._lib.hqtick_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
 rows, ks = [], []
 for i in range(n + 5):
