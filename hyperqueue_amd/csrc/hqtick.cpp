@@ -382,6 +382,9 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
             g.waves_per_block = sc->G <= hqk::MAX_GROUPS_4W ? 4 : 1;
             uint64_t tpw = ctx->tpw_hint ? ctx->tpw_hint : 256;
             while (((N + tpw - 1) / tpw) * sc->G > (1ull << 24)) tpw *= 2;  // keep the per-slice table under 64 MiB
+            if (!ctx->tpw_hint) while ((N + tpw - 1) / tpw > 32768) tpw *= 2;  // and the rows K1b scans short: one wavefront scans a row of n_waves entries, 4096 per
+                                                                                 // step (64 M tasks at 256 per slice: 250 k entries = 400 us for K1b against 160 us for K1;
+                                                                                 // 32 k slices of 2048 tasks keep K1 / K4 at 8 k workgroups and K1b at 8 steps)
             g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw); g.tab_stride = (g.n_waves + 15u) & ~15u;
             if (!ctx->d_wave_tab.ensure((size_t)g.tab_stride * sc->G * 4) || !ctx->d_gkey.ensure(N * 2 + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
             if (ctx->timing) hqk::time_next_launch(ctx->ev[2], ctx->ev[3]);
