@@ -53,7 +53,7 @@ def cpu_baseline(snap, ticks: int):
 
 
 # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md §HBM); None = not collected
-TRAFFIC = {"level_hist": 12_187_513 + 2_293_120, "select_scatter": 11_127_379 + 2_017_088, "expand_mapping": 7_069_904 + 1_933_414}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
+TRAFFIC = {"level_hist": 12_149_827 + 2_293_120, "select_scatter": 11_107_891 + 2_017_088, "expand_mapping": 7_092_732 + 819_200}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
 
 
 def dag_churn(cfg, steps: int, seed: int, n_classes: int):
