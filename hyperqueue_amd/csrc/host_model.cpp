@@ -62,20 +62,30 @@ std::vector<TaskBatch> create_task_batches(const Problem &pb, const std::vector<
     std::vector<TaskBatch> batches(live.size());
     if (live.empty()) return batches;
     const WorkerSet &lim_ws = pb.custom ? *pb.custom : pb.real;
+    // limits  :65-92.  Single-node requests: one pass over the workers (K2's per-(worker, variant) rows are worker-major: the rq-major loop of the
+    // reference walks them with a stride of one row per step), accumulating every live request's limit at once.
+    std::vector<uint32_t> sn_limit(live.size(), 0);
+    {
+        std::vector<uint32_t> sn_b;  // live single-node requests
+        for (size_t b = 0; b < live.size(); b++) if (!pb.rq_multi_node(live[b])) sn_b.push_back((uint32_t)b);
+        for (uint32_t w = 0; w < lim_ws.n && !sn_b.empty(); w++) {
+            const bool sn = lim_ws.is_sn(w);
+            for (uint32_t b : sn_b) {
+                const uint32_t rq = live[b];
+                if (!pb.capable_rqv(lim_ws, w, rq)) continue;
+                uint32_t runnable = 0;
+                if (sn) for (uint32_t v = 0; v < pb.rqs[rq].n_variants; v++) runnable += lim_ws.tmc(w, pb.rqs[rq].first_variant + v);
+                sn_limit[b] += runnable > 0 ? runnable : 1;
+            }
+        }
+    }
     for (size_t b = 0; b < live.size(); b++) {
         uint32_t rq = live[b];
-        uint32_t limit = 0;
+        uint32_t limit = sn_limit[b];
         if (pb.rq_multi_node(rq)) {  // :65-78
             uint32_t frees = 0;
             for (uint32_t w = 0; w < pb.real.n; w++) frees += pb.real.is_free(w) ? 1 : 0;
             limit = frees / pb.variants[pb.rqs[rq].first_variant].n_nodes;
-        } else {  // :79-92
-            for (uint32_t w = 0; w < lim_ws.n; w++) {
-                if (!pb.capable_rqv(lim_ws, w, rq)) continue;
-                uint32_t runnable = 0;
-                if (lim_ws.is_sn(w)) for (uint32_t v = 0; v < pb.rqs[rq].n_variants; v++) runnable += lim_ws.tmc(w, pb.rqs[rq].first_variant + v);
-                limit += runnable > 0 ? runnable : 1;
-            }
         }
         batches[b].rq = rq;
         batches[b].limit = limit;
