@@ -550,11 +550,13 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         }
         if (separable) {
             std::vector<uint64_t> key_hash; std::vector<std::pair<uint32_t, uint8_t>> key_list; std::vector<std::vector<std::pair<uint32_t, uint32_t>>> key_counts;
-            std::vector<uint32_t> ids, widx, cnt, ord;
+            std::vector<uint32_t> ids(solver_workers.size()), widx(solver_workers.size()), cnt(solver_workers.size()), ord;
             for (size_t b = 0; b < nb; b++) {
                 for (uint8_t v = 0; v < pb.rqs[batches[b].rq].n_variants; v++) {
-                    ids.clear(); widx.clear(); cnt.clear();
-                    for (uint32_t w : solver_workers) { uint32_t c = X[(size_t)wclass[w] * NC + voff[b] + v]; if (c) { ids.push_back(ws.id[w]); widx.push_back(w); cnt.push_back(c); } }
+                    size_t nz = 0;
+                    ids.resize(solver_workers.size()); widx.resize(solver_workers.size()); cnt.resize(solver_workers.size());
+                    for (uint32_t w : solver_workers) { const uint32_t c = X[(size_t)wclass[w] * NC + voff[b] + v]; if (c) { ids[nz] = ws.id[w]; widx[nz] = w; cnt[nz] = c; nz++; } }
+                    ids.resize(nz); widx.resize(nz); cnt.resize(nz);
                     if (ids.empty()) continue;
                     const std::vector<uint32_t> &word = cached_worker_order(ids);
                     std::vector<std::pair<uint32_t, uint32_t>> ordered; ordered.reserve(word.size());

@@ -559,23 +559,26 @@ struct TickRun {
         }
         nkeys = (uint32_t)cnt.keys.size();
         ps.key_seg.assign(nkeys, 0); ps.key_sum.assign(nkeys, 0); ps.key_rq.assign(nkeys, 0); ps.key_var_w.assign((nkeys + 3) / 4 + 1, 0);
-        ps.key_ord_off.assign(nkeys + 1, 0); ps.ord_cnt.clear(); ps.key_t_off.assign(nkeys + 1, 0); ps.key_bits_off.assign(nkeys + 1, 0);
+        ps.key_ord_off.assign(nkeys + 1, 0); ps.key_t_off.assign(nkeys + 1, 0); ps.key_bits_off.assign(nkeys + 1, 0);
         ps.wpos.assign((size_t)nkeys * W, NONE); ps.wcnt.assign((size_t)nkeys * W, 0);
         ps.items.assign(W, 0); ps.n_assign.assign(W, 0); ps.asg_qw.assign((size_t)Q * W, 0);
-        ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
+        size_t n_cnt = 0; for (uint32_t k = 0; k < nkeys; k++) n_cnt += cnt.per_key[k].size();
+        ctx->cnt_rq.resize(n_cnt); ctx->cnt_variant.resize(n_cnt); ctx->cnt_worker.resize(n_cnt); ctx->cnt_value.resize(n_cnt); ps.ord_cnt.resize(n_cnt);
+        uint32_t *c_rq = ctx->cnt_rq.data(), *c_w = ctx->cnt_worker.data(), *c_v = ctx->cnt_value.data(), *c_ord = ps.ord_cnt.data(); uint8_t *c_var = ctx->cnt_variant.data();
+        size_t ci = 0;
         max_count = 0; max_nk = 0;
         for (uint32_t k = 0; k < nkeys; k++) {
             const uint32_t q = cnt.keys[k].first; const uint8_t v = cnt.keys[k].second;
             ps.key_rq[k] = q; reinterpret_cast<uint8_t *>(ps.key_var_w.data())[k] = v;
             uint32_t sum = 0, maxc = 0, pos = 0;
-            uint32_t *wp = ps.wpos.data() + (size_t)k * W, *wcn = ps.wcnt.data() + (size_t)k * W, *aq = ps.asg_qw.data() + (size_t)q * W;
-            for (auto &wc : cnt.per_key[k]) {
-                sum += wc.second; maxc = std::max(maxc, wc.second);
-                ctx->cnt_rq.push_back(q); ctx->cnt_variant.push_back(v); ctx->cnt_worker.push_back(wc.first); ctx->cnt_value.push_back(wc.second);
-                ps.ord_cnt.push_back(wc.second);
-                wp[wc.first] = pos++; wcn[wc.first] = wc.second; ps.items[wc.first] += wc.second; ps.n_assign[wc.first] += wc.second; aq[wc.first] += wc.second;
+            uint32_t *wp = ps.wpos.data() + (size_t)k * W, *wcn = ps.wcnt.data() + (size_t)k * W, *aq = ps.asg_qw.data() + (size_t)q * W, *items = ps.items.data(), *nas = ps.n_assign.data();
+            for (auto &wc : cnt.per_key[k]) {  // (worker, count) in the Map's iteration order
+                const uint32_t w = wc.first, c = wc.second;
+                sum += c; maxc = std::max(maxc, c);
+                c_rq[ci] = q; c_var[ci] = v; c_w[ci] = w; c_v[ci] = c; c_ord[ci] = c; ci++;
+                wp[w] = pos++; wcn[w] = c; items[w] += c; nas[w] += c; aq[w] += c;
             }
-            ps.key_ord_off[k + 1] = (uint32_t)ps.ord_cnt.size();
+            ps.key_ord_off[k + 1] = (uint32_t)ci;
             ps.key_t_off[k + 1] = ps.key_t_off[k] + maxc + 1;  // sweeps 0..maxc
             ps.key_bits_off[k + 1] = ps.key_bits_off[k] + (maxc + 1) * ((pos + 63) / 64);
             max_count = std::max(max_count, maxc); max_nk = std::max(max_nk, pos);
