@@ -875,7 +875,9 @@ struct CompSolver {
             if (solve_counted(root) == LP_OPT) { root_bound = root.objective(); lp_x.assign(root.x.begin(), root.x.begin() + n); }  // the bound the windows work towards (dfs_opt finds the tableau solved)
             const double now = wall();
             trace("window search first");
-            lns_schedule(now + 0.3 * (deadline - now), false);  // cheap windows only: what they leave open the tree below usually closes faster than bigger windows would
+            (void)now;
+            lns_schedule(deadline, false);  // cheap windows only (what they leave open the tree below usually closes faster than bigger windows would), until they
+                                            // stall or the incumbent is certified — not until a clock says so: replicas of a sharded scheduler walk the same sequence
             lns_done = true;
         }
         const int first_strong = lns_done ? 1 : 0;  // with the windows' incumbent in hand the proof comes first, the dive (an incumbent finder) second
