@@ -151,6 +151,8 @@ class ShardedTick:
             # The merge collective lives INSIDE the C ABI (hqtick_comm_init / hqtick_shard_allgather: librccl, loaded by the library): a Rust host
             # needs nothing else.  torch.distributed only carries the 128-byte communicator id from rank 0 to the other ranks here — the job any
             # out-of-band channel of the host (its own TCP connections) would do.  collective="torch" keeps the all_gather_into_tensor path.
+            # collective="host": the shards are staged through host memory and merged by whatever backend the process group has (gloo) — no RCCL; this is
+            # what lets two real ranks share ONE GPU in tests/test_gpu_multi.py (RCCL refuses two ranks on one device).
             if collective == "auto":  # the library's collective whenever this process really is one rank of `world` (else: shards simulated in one process)
                 d = torch.distributed
                 collective = "library" if (world > 1 and d.is_available() and d.is_initialized() and d.get_world_size(group) == world) else "torch"
@@ -198,10 +200,18 @@ class ShardedTick:
         """The timed part on the GPU: sharded tick + the one all-gather.  Returns (local ResultC, merged device tensor)."""
         sink, merged = self._buffers(n_workers)
         res = self.t.tick_raw(sc, resident=resident)  # returns after this shard's kernels have finished (stream-synchronised)
+        if getattr(self, "_corrupt_next_checksum", False):  # test hook (tests/test_gpu_multi.py): this replica pretends it placed differently
+            sink[4:8] = sink[4:8] ^ 0xFF
+            self._corrupt_next_checksum = False
         if self.collective == "library":  # ncclAllGather on the ctx's stream, inside libhqtick.so; returns when the merged vector is there
             rc = self.t._lib.hqtick_shard_allgather(self.t._ctx, C.c_void_p(merged.data_ptr()), C.c_size_t(merged.numel()))
             if rc:
                 raise RuntimeError(f"hqtick_shard_allgather failed: {rc}: {self.t._err()}")
+        elif self.collective == "host" and self.world > 1:
+            mine = sink.cpu()
+            parts = [self.torch.empty_like(mine) for _ in range(self.world)]
+            self.torch.distributed.all_gather(parts, mine, group=self.group)
+            merged = self.torch.cat(parts)
         elif self.world > 1:
             self.torch.distributed.all_gather_into_tensor(merged, sink, group=self.group)
         else:
@@ -267,7 +277,12 @@ class ShardedTick:
                     lib.hqtick_set_shard(self.t._ctx, self.rank, self.world)
                     self._sink_workers = -1  # the per-shard sink is re-attached by the next tick
                 meta[0] = pickle.dumps((out.status, out.is_optimal, out.batches, out.counts, out.retracts, out.redirects, out.mn, out.new_free, out.times_us, out.redirect_kinds, out.is_canonical))
-            dist.broadcast(big, src=0, group=self.group)
+            if self.collective == "host":
+                big_h = big.cpu()
+                dist.broadcast(big_h, src=0, group=self.group)
+                big = big_h
+            else:
+                dist.broadcast(big, src=0, group=self.group)
             dist.broadcast_object_list(meta, src=0, group=self.group)
             st, opt, batches, counts, retracts, redirects, mn, nf, times, kinds, canon = pickle.loads(meta[0])
             out = abi.Result(st, opt, batches, counts, [[] for _ in range(W)], retracts, redirects, mn, nf, times, kinds, canon)

@@ -41,6 +41,56 @@ print("RANK_OK", rank)
 '''
 
 
+WORKER_ONE_GPU = r'''
+import os, sys
+sys.path.insert(0, os.environ["HQ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["HQ_ROOT"], "tests"))
+import numpy as np, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+from hyperqueue_amd import abi, sharded, workloads
+from hyperqueue_amd.tick import Tick
+cfg = abi.make_config(time_limit_s=20.0, device_index=0)
+st = sharded.ShardedTick(cfg, rank=rank, world=world, records_per_shard=1 << 15, collective="host")
+for name, kw in (("c4", dict(n_tasks=30000, n_workers=96)), ("c3p", dict(n_tasks=4000, n_workers=10))):
+    snap = workloads.make(name, **kw)
+    got = st.tick(snap)
+    if rank == 0:
+        t = Tick(cfg); want = t.tick(snap); t.close()
+        assert got.counts == want.counts and got.records == want.records and got.retracts == want.retracts, "sharded != unsharded: " + name
+# resident ready set + consume on every replica, then a forced divergence (rank 1 corrupts its checksum word): every rank takes rank 0's placement
+snap = workloads.make("c3", n_tasks=20000, n_workers=32)
+st.t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+res = st.tick(snap, resident=True)
+st.consume_last()
+if rank == 1:
+    st._corrupt_next_checksum = True
+n0 = st.n_divergent
+out = st.tick(snap, resident=True)
+assert st.n_divergent == n0 + 1, "the forced divergence was not detected"
+st.consume_last()
+counts = torch.tensor([st.t.ready_count()], dtype=torch.int64)
+allc = [torch.zeros_like(counts) for _ in range(world)]
+dist.all_gather(allc, counts)
+assert len({int(c.item()) for c in allc}) == 1, "resident ready sets diverged"
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK", rank)
+'''
+
+
+def test_two_ranks_on_one_gpu_run_the_library_shards():
+    """Two processes, each one rank of a 2-way sharded scheduler running libhqtick.so (hqtick_set_shard + device record sink) on the SAME MI355X;
+    the shards are merged across the processes through gloo (host-staged) because RCCL refuses two ranks on one device.  Everything of the
+    multi-process path except the RCCL call itself — which test_gpu_parity.py::test_library_allgather_single_rank and the two-GPU test below cover."""
+    env = dict(os.environ, HQ_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_ONE_GPU], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-3000:]
+
+
 def test_two_rank_library_allgather():
     import torch
 
