@@ -66,6 +66,7 @@ struct hqtick_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // K2 (worker evaluation: PCIe-latency-bound reads of the worker tables) runs here, next to K1 + K1b on `stream`
+    bool k2_on_hist = false;       // HQTICK_K2_RIDE_ALONG=1: K2 rides along K1's launch (round 1 / first half of round 2); default: along K1b's
     bool k2_own_stream = false;    // HQTICK_K2_RIDE_ALONG=0: K2 as its own launch on stream2.  Measured (profiles/r02/README.md): K1 alone then takes 4.8 us instead of
                                    // 8.2 us (0.31 vs 0.18 of the HBM roofline), but the second stream's launch + synchronisation make phase A 36 us instead of 28 us:
                                    // the ride-along layout stays the default because the TICK is what counts
@@ -390,10 +391,10 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
             if (ctx->timing) hqk::time_next_launch(ctx->ev[2], ctx->ev[3]);
             if (ctx->k2_own_stream) HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc), ctx->stream2));
             HQ_HIP_TIMED(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
-                                   ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->k2_own_stream ? nullptr : &wea, ctx->stream));
+                                   ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->k2_on_hist ? &wea : nullptr, ctx->stream));
             if (ctx->timing) hqk::time_next_launch(ctx->ev[0], ctx->ev[8]);
             HQ_HIP_TIMED(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
-                                   reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream));
+                                   reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream, (ctx->k2_own_stream || ctx->k2_on_hist) ? nullptr : &wea));
             if (s->n_retracting) {  // where do the Retracting tasks sit in their queues?  (mapping.rs:66-80 treats them apart)
                 const uint32_t nr = s->n_retracting;
                 if (!ctx->h_retr.ensure((size_t)nr * 16 + 64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc retracting");
@@ -1019,7 +1020,7 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     if (const char *e = getenv("HQTICK_BLOCK_MIN_CLASSES")) { long v = atol(e); if (v >= 0) ctx->block_min_classes = (uint32_t)v; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return HQTICK_E_DEVICE; }
-    if (const char *e = getenv("HQTICK_K2_RIDE_ALONG")) ctx->k2_own_stream = atoi(e) == 0;
+    if (const char *e = getenv("HQTICK_K2_RIDE_ALONG")) { ctx->k2_own_stream = atoi(e) == 0; ctx->k2_on_hist = atoi(e) == 1; }
     if (const char *e = getenv("HQTICK_CHECK_CLUSTER")) ctx->cluster_check = atoi(e) != 0;
     if (hipEventCreate(&ctx->cl_ev) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }

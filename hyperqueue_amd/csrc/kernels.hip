@@ -284,8 +284,13 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
 // 4096 entries.  The row total goes to hist[] — which may live in pinned host memory (written once per row).
 __global__ void __launch_bounds__(256) k_scan_rows(uint32_t *__restrict__ wave_tab, uint32_t n_waves, uint32_t stride, uint32_t G,
                                                    uint32_t *__restrict__ hist, uint32_t *__restrict__ err_in,
-                                                   uint32_t *__restrict__ err_out) {
-    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                   uint32_t *__restrict__ err_out, uint32_t n_eval_blocks, EvalArgs ea) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x < n_eval_blocks) {  // ride-along workgroups (dispatched first): K2.  This launch is a latency chain of 6 us on two workgroups; K2's 32
+        worker_eval_block(smem, blockIdx.x, ea);  // workgroups run beside it for free, and K1's launch — the one the roofline is priced on — is K1 alone
+        return;
+    }
+    const uint32_t row = (blockIdx.x - n_eval_blocks) * 4 + (threadIdx.x >> 6);
     if (row == 0 && threadIdx.x == 0 && err_out) { err_out[0] = err_in[0]; err_in[0] = 0; }  // K1's validation flags: forwarded to the host-visible word, device word re-armed
     if (row >= G) return;
     const uint32_t lane = lane_id();
@@ -833,9 +838,17 @@ hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, cons
     return hipGetLastError();
 }
 
-hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, uint32_t *err_in, uint32_t *err_out, hipStream_t s) {
+hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, uint32_t *err_in, uint32_t *err_out, hipStream_t s, const WorkerEvalArgs *ride_along) {
     if (G == 0) return hipSuccess;
-    HQK_TIMED_LAUNCH(k_scan_rows, dim3((G + 3) / 4), dim3(256), 0, s, wave_tab, geom.n_waves, geom.tab_stride, G, hist, err_in, err_out);
+    EvalArgs ea{};
+    uint32_t neb = 0; size_t lds = 0;
+    if (ride_along && ride_along->W && ride_along->rt.n_variants) {
+        ea = EvalArgs{ride_along->total, ride_along->free_, ride_along->remaining_ns, ride_along->W, ride_along->R, ride_along->rt, ride_along->n_entries, ride_along->flags, ride_along->tmc};
+        neb = (ride_along->W + 31) / 32; lds = worker_eval_lds(ride_along->R, ride_along->rt.n_variants, ride_along->n_entries);
+        hipError_t e;
+        if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    }
+    HQK_TIMED_LAUNCH(k_scan_rows, dim3((G + 3) / 4 + neb), dim3(256), lds, s, wave_tab, geom.n_waves, geom.tab_stride, G, hist, err_in, err_out, neb, ea);
     return hipGetLastError();
 }
 

@@ -873,9 +873,7 @@ struct CompSolver {
         bool lns_done = false;
         if (!in_lns && have && n >= LNS_FIRST_COLS) {
             if (solve_counted(root) == LP_OPT) { root_bound = root.objective(); lp_x.assign(root.x.begin(), root.x.begin() + n); }  // the bound the windows work towards (dfs_opt finds the tableau solved)
-            const double now = wall();
             trace("window search first");
-            (void)now;
             lns_schedule(deadline, false);  // cheap windows only (what they leave open the tree below usually closes faster than bigger windows would), until they
                                             // stall or the incumbent is certified — not until a clock says so: replicas of a sharded scheduler walk the same sequence
             lns_done = true;
