@@ -414,7 +414,7 @@ def main():
             b2b[nm] = round(tick.time_kernel(which, 100), 2)
             kernels[nm]["us_back_to_back"] = b2b[nm]
             kernels[nm]["GBps_back_to_back"] = kernels[nm]["bytes"] / (b2b[nm] * 1e-6) / 1e9
-    dom_us = kernels[dom]["us"]  # the launch inside the tick (K1 + the K2 ride-along workgroups), dispatch-level events
+    dom_us = kernels[dom]["us"]  # the launch inside the tick, dispatch-level events
     achieved, peak = (kernels[dom]["bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0), 8000.0
     pcie_peak = 63.0  # GB/s, PCIe Gen5 x16 one direction (what K5b's stores into pinned host memory cross)
     em = kernels["expand_mapping"]
@@ -440,8 +440,8 @@ def main():
                      "timing": "start / stop events at the dispatch of the launch INSIDE the tick (hipExtLaunchKernel), averaged over the stats pass after the timed region; "
                                "the rocprofv3 kernel trace of this command (profiles/r02/) lists the same launches",
                      "note": "K1 streams the whole ready set (12 B/task).  At 1 M tasks the set (20 MB) lives in the 256 MiB Infinity Cache across ticks and a launch is latency-bound "
-                             "(12 MB = 1.9 us at 6.3 TB/s achievable): see roofline_vs_n / profiles/r02 for the same kernel beyond the cache.  The K2 ride-along workgroups of the same "
-                             "launch read the worker tables from pinned host memory (PCIe round trips), which is what stretches the in-tick launch over the stand-alone one"},
+                             "(12 MB = 1.9 us at 6.3 TB/s achievable): see roofline_vs_n / profiles/r02 for the same kernel beyond the cache.  K2 (worker evaluation) rides along K1b's "
+                             "launch, not this one (HQTICK_K2_RIDE_ALONG=1 puts it back: 5.8 us instead of 4.7)"},
         "roofline_time_dominant_kernel": {"kernel": "expand_mapping", "bound": "pcie", "achieved": pcie_bytes / (em["us"] * 1e-6) / 1e9 if em["us"] > 0 else 0.0, "peak": pcie_peak, "unit": "GB/s",
                                           "frac": (pcie_bytes / (em["us"] * 1e-6) / 1e9 / pcie_peak) if em["us"] > 0 else 0.0, "bytes_over_pcie_per_launch": pcie_bytes, "avg_launch_us": em["us"],
                                           "note": "K5b writes the records straight into the caller's pinned host buffer (compact emission: 4 B per record, counted here, + 12 B per run of equal "
