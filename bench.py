@@ -53,7 +53,7 @@ def cpu_baseline(snap, ticks: int):
 
 
 # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md §HBM); None = not collected
-TRAFFIC = {"level_hist": 12_149_827 + 2_293_120, "select_scatter": 11_107_891 + 2_017_088, "expand_mapping": 7_092_732 + 819_200}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
+TRAFFIC = {"level_hist": 12_084_109 + 2_250_112, "select_scatter": 11_107_891 + 2_017_088, "expand_mapping": 7_092_732 + 819_200}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
 
 
 def dag_churn(cfg, steps: int, seed: int, n_classes: int):
@@ -460,7 +460,12 @@ def main():
                 t2.tick_raw(sc2, resident=True)
             for which, nm, bpt in ((0, "level_hist", 12), (1, "select_scatter", 8)):
                 us = t2.time_kernel(which, 50)
-                sweep.append({"kernel": nm, "n_ready": n_big, "avg_launch_us": round(us, 2), "GBps": n_big * bpt / (us * 1e-6) / 1e9, "frac": n_big * bpt / (us * 1e-6) / 1e9 / peak})
+                row = {"kernel": nm, "n_ready": n_big, "avg_launch_us": round(us, 2)}
+                if which == 0:  # K1 reads every task: N x 12 B is what crosses HBM (profiles/r02: FETCH_SIZE x2 = 12 B x N)
+                    row.update({"GBps": n_big * bpt / (us * 1e-6) / 1e9, "frac": n_big * bpt / (us * 1e-6) / 1e9 / peak})
+                else:  # K4's slices stop as soon as the groups they could feed are exhausted (65 536 + 122 880 tasks are taken out of N)
+                    row["note"] = "slices behind the last taken task of their groups exit after their first 256-task tile: the bytes read depend on the slice size, no bandwidth figure"
+                sweep.append(row)
             t2.close()
         out["roofline_vs_n"] = sweep
     if world == 1 and not args.force_sharded and args.steady_steps > 0:
