@@ -21,8 +21,10 @@ inline uint64_t hash_rq_variant(uint32_t rq, uint8_t v) { return fx_step(fx_step
 inline void insertion_order(const uint64_t *hashes, uint32_t n, std::vector<uint32_t> &order) {
     const int GROUP = 16;                 // SSE2 group width on x86-64
     const uint32_t VACANT = 0xFFFFFFFFu;
-    std::vector<uint32_t> owner;          // bucket -> insertion index (VACANT = empty control byte)
     using std::size_t;
+    // two bucket arrays (bucket -> insertion index, VACANT = empty control byte) that swap roles at every growth: no allocation per growth step
+    static thread_local std::vector<uint32_t> buf_a, buf_b;
+    std::vector<uint32_t> *owner = &buf_a, *spare = &buf_b;
     size_t nbuckets = 0, used = 0, room = 0;
     auto capacity_of = [](size_t nb) { return nb <= 8 ? nb - 1 : nb / 8 * 7; };
     auto buckets_for = [](size_t cap) -> size_t {
@@ -35,14 +37,19 @@ inline void insertion_order(const uint64_t *hashes, uint32_t n, std::vector<uint
     };
     // first vacant bucket along the triangular probe sequence; groups are GROUP consecutive control bytes starting
     // at an arbitrary position, and tables smaller than a group see vacant padding before their mirrored bytes.
-    auto place = [&](std::vector<uint32_t> &tab, size_t nb, uint64_t h) -> size_t {
+    auto place = [&](uint32_t *tab, size_t nb, uint64_t h) -> size_t {
         size_t mask = nb - 1, pos = (size_t)h & mask, stride = 0;
+        if (nb >= (size_t)GROUP) {  // the common case: a group is 16 consecutive buckets (wrapping)
+            for (;;) {
+                for (int b = 0; b < GROUP; b++) { const size_t idx = (pos + b) & mask; if (tab[idx] == VACANT) return idx; }
+                stride += GROUP;
+                pos = (pos + stride) & mask;
+            }
+        }
         for (;;) {
             for (int b = 0; b < GROUP; b++) {
                 size_t lane = pos + b;
-                bool vacant;
-                if (nb < (size_t)GROUP) vacant = lane < nb ? tab[lane] == VACANT : (lane < (size_t)GROUP ? true : tab[lane - GROUP] == VACANT);
-                else vacant = tab[lane & mask] == VACANT;
+                const bool vacant = lane < nb ? tab[lane] == VACANT : (lane < (size_t)GROUP ? true : tab[lane - GROUP] == VACANT);
                 if (vacant) {
                     size_t idx = lane & mask;
                     if (tab[idx] != VACANT) {  // landed on padding of a tiny table: rescan from bucket 0
@@ -59,19 +66,22 @@ inline void insertion_order(const uint64_t *hashes, uint32_t n, std::vector<uint
         if (room == 0) {  // reserve(1): grow to hold max(items + 1, full_capacity + 1) and re-insert in iteration order
             size_t want = nbuckets == 0 ? 1 : (used + 1 > capacity_of(nbuckets) + 1 ? used + 1 : capacity_of(nbuckets) + 1);
             size_t nb = buckets_for(want);
-            std::vector<uint32_t> bigger(nb, VACANT);
-            for (size_t b = 0; b < nbuckets; b++) if (owner[b] != VACANT) bigger[place(bigger, nb, hashes[owner[b]])] = owner[b];
-            owner.swap(bigger);
+            spare->assign(nb, VACANT);
+            uint32_t *big = spare->data(); const uint32_t *old = owner->data();
+            for (size_t b = 0; b < nbuckets; b++) if (old[b] != VACANT) big[place(big, nb, hashes[old[b]])] = old[b];
+            std::swap(owner, spare);
             nbuckets = nb;
             room = capacity_of(nb) - used;
         }
-        owner[place(owner, nbuckets, hashes[i])] = i;
+        uint32_t *tab = owner->data();
+        tab[place(tab, nbuckets, hashes[i])] = i;
         used++;
         room--;
     }
     order.clear();
     order.reserve(n);
-    for (size_t b = 0; b < nbuckets; b++) if (owner[b] != VACANT) order.push_back(owner[b]);
+    const uint32_t *tab = owner->data();
+    for (size_t b = 0; b < nbuckets; b++) if (tab[b] != VACANT) order.push_back(tab[b]);
 }
 
 inline void insertion_order_u32(const uint32_t *keys, uint32_t n, std::vector<uint32_t> &order) {
