@@ -607,7 +607,8 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
     const uint32_t tot = mk.out_off[w + 1] - out0;
     if (tot > max_out) { if (threadIdx.x == 0) err_flag[0] = 2u; return; }
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_run[RUN_STAGE * 3];  // the worker's runs as they go out: 12-byte records, written to the host by whole wavefronts
+    uint32_t *s_run = reinterpret_cast<uint32_t *>(smem + ((reinterpret_cast<uintptr_t>(k_var + nkeys) - reinterpret_cast<uintptr_t>(smem) + 3) & ~(uintptr_t)3));  // [RUN_STAGE * 3], compact
+                                                                                           // launches only: the worker's runs as they go out, 12-byte records
     const uint32_t chunk = (tot + blockDim.x - 1) / blockDim.x, lo = threadIdx.x * chunk, hi = lo + chunk < tot ? lo + chunk : tot;
     auto boundary = [&](uint32_t i) { return i == 0 || (uint32_t)(f_task[i] >> 32) != (uint32_t)(f_task[i - 1] >> 32) || f_meta[i] != f_meta[i - 1]; };
     uint32_t mine = 0;
@@ -925,7 +926,8 @@ hipError_t sweep_bits(MapKeys mk, uint32_t max_count, uint32_t max_workers_per_k
 uint32_t expand_mapping_sort_cap(uint32_t max_items) { uint32_t p = 1; while (p < max_items) p <<= 1; return p; }
 
 size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys, uint32_t max_out, bool may_reorder) {
-    return (size_t)max_items * 12 + (size_t)max_out * 10 + 2 + ((size_t)8 * n_keys + 1 + 4) * 4 + n_keys + 16 + (may_reorder ? (size_t)expand_mapping_sort_cap(max_items) * 4 : 0);
+    return (size_t)max_items * 12 + (size_t)max_out * 10 + 2 + ((size_t)8 * n_keys + 1 + 4) * 4 + n_keys + 16 + (may_reorder ? (size_t)expand_mapping_sort_cap(max_items) * 4 : 0) +
+           (max_out ? (size_t)RUN_STAGE * 12 + 4 : 0);  // max_out != 0 = compact emission: the run stage
 }
 
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_key, uint32_t Q, uint32_t max_items,
