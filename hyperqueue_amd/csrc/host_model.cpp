@@ -54,6 +54,62 @@ void prune_cuts(std::vector<PriorityCut> &cuts, size_t prefix, size_t limit) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
+// workers with identical rows (host_model.h, WorkerGroups)
+// ---------------------------------------------------------------------------------------------------------------
+void group_equal_rows(WorkerSet &ws, bool all_solver) {
+    WorkerGroups &g = ws.rows;
+    const uint32_t n = ws.n, R = ws.R;
+    g.of.resize(n); g.rep.clear(); g.count.clear();
+    static thread_local std::vector<uint32_t> table;
+    size_t cap = 64; while (cap < 2 * (size_t)n + 2) cap <<= 1;
+    bool table_ready = false;  // the open-addressing table is only needed once two neighbours differ
+    auto same = [&](uint32_t a, uint32_t b) {
+        if (ws.remaining_ns && ws.remaining_ns[a] != ws.remaining_ns[b]) return false;
+        if (ws.flags && ws.flags[a] != ws.flags[b]) return false;
+        if (ws.min_util && memcmp(ws.min_util + a, ws.min_util + b, 4) != 0) return false;
+        const uint64_t *fa = ws.free_ + (size_t)a * R, *fb = ws.free_ + (size_t)b * R, *ta = ws.total + (size_t)a * R, *tb = ws.total + (size_t)b * R;
+        uint64_t diff = 0;
+        for (uint32_t r = 0; r < R; r++) diff |= (fa[r] ^ fb[r]) | (ta[r] ^ tb[r]);  // a handful of words: no call, no branch
+        return diff == 0;
+    };
+    auto hash_row = [&](uint32_t w) {
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        auto mix = [&](uint64_t v) { h ^= v; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; };
+        for (uint32_t r = 0; r < R; r++) { mix(ws.total[(size_t)w * R + r]); mix(ws.free_[(size_t)w * R + r]); }
+        if (ws.remaining_ns) mix((uint64_t)ws.remaining_ns[w]);
+        if (ws.min_util) { uint32_t b; memcpy(&b, ws.min_util + w, 4); mix(b); }
+        if (ws.flags) mix(ws.flags[w]);
+        return h;
+    };
+    long prev = -1;  // previous worker without a blocked request: neighbours usually agree
+    for (uint32_t w = 0; w < n; w++) {
+        if (!ws.blocked.empty() && !ws.blocked[w].empty()) {  // a blocked (request, variant) changes the worker's eligibility: a group of its own
+            g.of[w] = (uint32_t)g.rep.size(); g.rep.push_back(w); g.count.push_back(1);
+            continue;
+        }
+        if (prev >= 0 && same(w, (uint32_t)prev)) { const uint32_t id = g.of[prev]; g.of[w] = id; g.count[id]++; prev = w; continue; }
+        if (!table_ready) {
+            table.assign(cap, UINT32_MAX); table_ready = true;
+            if (prev >= 0) table[(size_t)hash_row((uint32_t)prev) & (cap - 1)] = g.of[prev];  // everything so far is one group (or blocked singletons)
+        }
+        prev = w;
+        size_t slot = (size_t)hash_row(w) & (cap - 1);
+        uint32_t id = UINT32_MAX;
+        while (table[slot] != UINT32_MAX) {
+            if (same(w, g.rep[table[slot]])) { id = table[slot]; break; }
+            slot = (slot + 1) & (cap - 1);
+        }
+        if (id == UINT32_MAX) { id = (uint32_t)g.rep.size(); table[slot] = id; g.rep.push_back(w); g.count.push_back(0); }
+        g.of[w] = id; g.count[id]++;
+    }
+    g.solver_workers.clear(); g.solver_workers.reserve(n);
+    for (uint32_t w = 0; w < n; w++) if (all_solver || ws.is_sn(w)) g.solver_workers.push_back(w);
+    g.pool.assign(R, 0.0);
+    for (uint32_t w : g.solver_workers) for (uint32_t r = 0; r < R; r++) { const uint64_t c = ws.free_[(size_t)w * R + r]; g.pool[r] += c == HQ_AMOUNT_MAX ? 1.0 : units(c); }
+    g.valid = true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // create_task_batches  scheduler/batches.rs:42-181
 // ---------------------------------------------------------------------------------------------------------------
 std::vector<TaskBatch> create_task_batches(const Problem &pb, const std::vector<QueueLevels> &queues) {
@@ -68,16 +124,19 @@ std::vector<TaskBatch> create_task_batches(const Problem &pb, const std::vector<
     {
         std::vector<uint32_t> sn_b;  // live single-node requests
         for (size_t b = 0; b < live.size(); b++) if (!pb.rq_multi_node(live[b])) sn_b.push_back((uint32_t)b);
-        for (uint32_t w = 0; w < lim_ws.n && !sn_b.empty(); w++) {
+        auto add_worker = [&](uint32_t w, uint32_t times) {  // `times` workers with the rows of w
             const bool sn = lim_ws.is_sn(w);
             for (uint32_t b : sn_b) {
                 const uint32_t rq = live[b];
                 if (!pb.capable_rqv(lim_ws, w, rq)) continue;
                 uint32_t runnable = 0;
                 if (sn) for (uint32_t v = 0; v < pb.rqs[rq].n_variants; v++) runnable += lim_ws.tmc(w, pb.rqs[rq].first_variant + v);
-                sn_limit[b] += runnable > 0 ? runnable : 1;
+                sn_limit[b] += (runnable > 0 ? runnable : 1) * times;  // u32 arithmetic wraps like the repeated addition would
             }
-        }
+        };
+        if (sn_b.empty()) {}
+        else if (lim_ws.rows.valid) for (size_t g = 0; g < lim_ws.rows.rep.size(); g++) add_worker(lim_ws.rows.rep[g], lim_ws.rows.count[g]);
+        else for (uint32_t w = 0; w < lim_ws.n; w++) add_worker(w, 1);
     }
     for (size_t b = 0; b < live.size(); b++) {
         uint32_t rq = live[b];
@@ -237,11 +296,15 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     if (pb.rqs.empty()) return out;  // :53-55
     const WorkerSet &ws = pb.custom ? *pb.custom : pb.real;
     const uint32_t R = pb.R;
-    std::vector<uint32_t> solver_workers;  // SN workers, ascending id (the worker arrays are already sorted)  :57-66
-    for (uint32_t w = 0; w < ws.n; w++) if (pb.custom || ws.is_sn(w)) solver_workers.push_back(w);
+    std::vector<uint32_t> own_workers; std::vector<double> own_pool;
+    if (!ws.rows.valid) {  // (the tick forms these while the GPU runs phase A: group_equal_rows)
+        for (uint32_t w = 0; w < ws.n; w++) if (pb.custom || ws.is_sn(w)) own_workers.push_back(w);
+        own_pool.assign(R, 0.0);
+        for (uint32_t w : own_workers) for (uint32_t r = 0; r < R; r++) { uint64_t c = ws.free_[(size_t)w * R + r]; own_pool[r] += c == HQ_AMOUNT_MAX ? 1.0 : units(c); }
+    }
+    const std::vector<uint32_t> &solver_workers = ws.rows.valid ? ws.rows.solver_workers : own_workers;  // SN workers, ascending id (the worker arrays are already sorted)  :57-66
     const size_t nw = solver_workers.size();
-    std::vector<double> pool(R, 0.0);  // resource_sums  :56,68-82
-    for (uint32_t w : solver_workers) for (uint32_t r = 0; r < R; r++) { uint64_t c = ws.free_[(size_t)w * R + r]; pool[r] += c == HQ_AMOUNT_MAX ? 1.0 : units(c); }
+    const std::vector<double> &pool = ws.rows.valid ? ws.rows.pool : own_pool;  // resource_sums  :56,68-82
 
     auto is_blocked = [&](uint32_t w, uint32_t rq, uint8_t v) {
         if (pb.custom) return false;
@@ -280,22 +343,15 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         const uint32_t EW = (NC + 63) / 64, SW = 2 * R + 1 + EW;  // signature words
         std::vector<uint64_t> sigs; std::vector<uint32_t> rep;     // per class: signature, first worker
         std::vector<uint32_t> wclass(ws.n, 0);
+        std::vector<uint64_t> n_in_class;                          // solver workers per class
         {
             size_t cap = 64; while (cap < 2 * nw + 2) cap <<= 1;
             std::vector<uint32_t> table(cap, UINT32_MAX);
             std::vector<uint64_t> tmp(SW);
-            const uint32_t nvs = ws.n_variant_slots;
-            long prev = -1;  // previous solver worker: neighbours usually share a class, which three short memcmps establish
-            for (uint32_t w : solver_workers) {
+            // class of the workers whose rows equal those of w: signature from w's rows and K2's answer for w
+            auto class_of = [&](uint32_t w) {
                 const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
                 const float mu = ws.min_util ? ws.min_util[w] : 0.0f;
-                if (prev >= 0 && (pb.custom || (ws.blocked[w].empty() && ws.blocked[prev].empty())) && mu == (ws.min_util ? ws.min_util[prev] : 0.0f) &&
-                    memcmp(tot, ws.total + (size_t)prev * R, (size_t)R * 8) == 0 && memcmp(fre, ws.free_ + (size_t)prev * R, (size_t)R * 8) == 0 &&
-                    memcmp(ws.vflags + (size_t)w * nvs, ws.vflags + (size_t)prev * nvs, nvs) == 0) {
-                    wclass[w] = wclass[prev]; prev = w;
-                    continue;
-                }
-                prev = w;
                 memcpy(tmp.data(), tot, (size_t)R * 8); memcpy(tmp.data() + R, fre, (size_t)R * 8);
                 uint32_t mubits; memcpy(&mubits, &mu, 4); tmp[2 * R] = mubits;
                 for (uint32_t e = 0; e < EW; e++) tmp[2 * R + 1 + e] = 0;
@@ -312,8 +368,20 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     if (memcmp(sigs.data() + (size_t)table[slot] * SW, tmp.data(), (size_t)SW * 8) == 0) { cid = table[slot]; break; }
                     slot = (slot + 1) & (cap - 1);
                 }
-                if (cid == UINT32_MAX) { cid = (uint32_t)rep.size(); table[slot] = cid; rep.push_back(w); sigs.insert(sigs.end(), tmp.begin(), tmp.end()); }
-                wclass[w] = cid;
+                if (cid == UINT32_MAX) { cid = (uint32_t)rep.size(); table[slot] = cid; rep.push_back(w); n_in_class.push_back(0); sigs.insert(sigs.end(), tmp.begin(), tmp.end()); }
+                return cid;
+            };
+            if (ws.rows.valid) {  // one signature per group of workers with equal rows (formed while the GPU ran phase A); groups come in the order of their first worker,
+                                  // so the classes are numbered as a pass over the workers would number them
+                const WorkerGroups &gr = ws.rows;
+                std::vector<uint32_t> gclass(gr.rep.size(), UINT32_MAX);
+                for (size_t g = 0; g < gr.rep.size(); g++) {
+                    if (!(pb.custom || ws.is_sn(gr.rep[g]))) continue;  // the flags byte is part of the group key: all of the group or none
+                    gclass[g] = class_of(gr.rep[g]); n_in_class[gclass[g]] += gr.count[g];
+                }
+                for (uint32_t w : solver_workers) wclass[w] = gclass[gr.of[w]];
+            } else {
+                for (uint32_t w : solver_workers) { wclass[w] = class_of(w); n_in_class[wclass[w]]++; }
             }
         }
         const uint32_t ncls = (uint32_t)rep.size();
@@ -441,8 +509,6 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         if (separable) {
             bool sizes_hold = true;  // the lazy batch-size rows  solver.rs:264-271
             {
-                std::vector<uint64_t> n_in_class(ncls, 0);
-                for (uint32_t w : solver_workers) n_in_class[wclass[w]]++;
                 for (size_t b = 0; b < nb && sizes_hold; b++) {
                     if (batches[b].limit_reached) continue;
                     uint64_t placed = 0;
@@ -466,8 +532,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 // tasks, a thousand idle workers" — the everyday case between bursts — a small model.
                 worker_off.assign(ws.n, 0);
                 {
-                    std::vector<uint32_t> n_in_class(class_cols.size(), 0), seen(class_cols.size(), 0), keep(class_cols.size(), UINT32_MAX);
-                    for (uint32_t w : solver_workers) n_in_class[wclass[w]]++;
+                    std::vector<uint32_t> seen(class_cols.size(), 0), keep(class_cols.size(), UINT32_MAX);
                     for (size_t c = 0; c < class_cols.size(); c++) {
                         if (class_has_flag[c]) continue;
                         const uint64_t *fre = ws.free_ + (size_t)rep[c] * R, *tot = ws.total + (size_t)rep[c] * R;
@@ -550,17 +615,34 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         }
         if (separable) {
             std::vector<uint64_t> key_hash; std::vector<std::pair<uint32_t, uint8_t>> key_list; std::vector<std::vector<std::pair<uint32_t, uint32_t>>> key_counts;
-            std::vector<uint32_t> ids(solver_workers.size()), widx(solver_workers.size()), cnt(solver_workers.size()), ord;
+            // The workers of a key are those whose class places something in its column: keys with the same set of classes share the id list and its Map
+            // order (a cold tick has one class: one list for all keys).
+            struct WorkerList { std::vector<uint8_t> mask; std::vector<uint32_t> widx, order; };  // order: a copy — the memo behind cached_worker_order recycles its entries
+            std::vector<WorkerList> lists;
+            std::vector<uint8_t> mask(ncls);
+            std::vector<uint32_t> ids, ord;
             for (size_t b = 0; b < nb; b++) {
                 for (uint8_t v = 0; v < pb.rqs[batches[b].rq].n_variants; v++) {
-                    size_t nz = 0;
-                    ids.resize(solver_workers.size()); widx.resize(solver_workers.size()); cnt.resize(solver_workers.size());
-                    for (uint32_t w : solver_workers) { const uint32_t c = X[(size_t)wclass[w] * NC + voff[b] + v]; if (c) { ids[nz] = ws.id[w]; widx[nz] = w; cnt[nz] = c; nz++; } }
-                    ids.resize(nz); widx.resize(nz); cnt.resize(nz);
-                    if (ids.empty()) continue;
-                    const std::vector<uint32_t> &word = cached_worker_order(ids);
-                    std::vector<std::pair<uint32_t, uint32_t>> ordered; ordered.reserve(word.size());
-                    for (uint32_t k : word) ordered.push_back({widx[k], cnt[k]});
+                    const uint32_t g = voff[b] + v;
+                    bool any = false;
+                    for (uint32_t c = 0; c < ncls; c++) { mask[c] = X[(size_t)c * NC + g] != 0; any = any || mask[c]; }
+                    if (!any) continue;
+                    const WorkerList *wl = nullptr;
+                    for (const WorkerList &l : lists) if (memcmp(l.mask.data(), mask.data(), ncls) == 0) { wl = &l; break; }
+                    if (!wl) {
+                        lists.emplace_back();
+                        WorkerList &l = lists.back();
+                        l.mask = mask; l.widx.reserve(solver_workers.size()); ids.clear(); ids.reserve(solver_workers.size());
+                        for (uint32_t w : solver_workers) if (mask[wclass[w]]) { ids.push_back(ws.id[w]); l.widx.push_back(w); }
+                        l.order = cached_worker_order(ids);
+                        wl = &l;
+                    }
+                    std::vector<std::pair<uint32_t, uint32_t>> ordered(wl->order.size());
+                    {
+                        const uint32_t *word = wl->order.data(), *widx = wl->widx.data(), *xg = X.data() + g;
+                        std::pair<uint32_t, uint32_t> *o = ordered.data();
+                        for (size_t k = 0, e = ordered.size(); k < e; k++) { const uint32_t w = widx[word[k]]; o[k] = {w, xg[(size_t)wclass[w] * NC]}; }
+                    }
                     key_hash.push_back(hqhb::hash_rq_variant(batches[b].rq, v)); key_list.push_back({batches[b].rq, v}); key_counts.push_back(std::move(ordered));
                 }
             }

@@ -44,8 +44,20 @@ struct TaskBatch {
     std::vector<PriorityCut> cuts;
 };
 
+// Workers whose snapshot rows are identical: same total / free / remaining time / min_utilization / flags and no blocked request.  K2's row of a
+// worker (capability bits, task_max_count) is a function of exactly these columns and the request tables, so the groups can be formed from the
+// snapshot alone — while the GPU still runs phase A — and the per-worker loops of create_task_batches (limits) and of the separable placement
+// (worker classes) run once per group.  Groups are numbered in the order of their first worker.
+struct WorkerGroups {
+    std::vector<uint32_t> of, rep, count;  // [n] group of worker w; [n_groups] first worker / number of workers
+    std::vector<uint32_t> solver_workers;  // the workers run_scheduling_solver models (solver.rs:57-66), ascending
+    std::vector<double> pool;              // resource_sums over them (solver.rs:56,68-82), summed in worker order like the reference
+    bool valid = false;
+};
+
 // Everything the host stages need to know about workers, as plain views over the snapshot + the GPU's K2 output.
 struct WorkerSet {
+    WorkerGroups rows;
     uint32_t n = 0, R = 0;
     const uint32_t *id = nullptr;
     const uint64_t *total = nullptr, *free_ = nullptr;  // [n*R]
@@ -59,6 +71,7 @@ struct WorkerSet {
     uint32_t n_variant_slots = 0;
     // sparse per-worker state
     std::vector<std::vector<std::pair<uint32_t, uint8_t>>> blocked;   // [n]
+    uint32_t n_blocked_lists = 0;   // entries in `blocked` (0: every list is empty and the vector can be reused as it is)
     // SingleNodeTaskAssignment::assigned_tasks as the snapshot's CSR (views, not copies; nullptr = nothing assigned)
     const uint32_t *assigned_off = nullptr, *assigned_rq = nullptr; const uint8_t *assigned_variant = nullptr;
     uint32_t n_assigned(uint32_t w) const { return assigned_off ? assigned_off[w + 1] - assigned_off[w] : 0; }
@@ -96,6 +109,9 @@ struct Problem {
         return false;
     }
 };
+
+void group_equal_rows(WorkerSet &ws, bool all_solver);  // fills ws.rows (needs id / total / free_ / remaining_ns / min_util / flags / blocked; not K2's output);
+                                                       // all_solver: every worker is a solver worker (the fake workers of a what-if query), else the SN ones
 
 std::vector<TaskBatch> create_task_batches(const Problem &pb, const std::vector<QueueLevels> &queues);
 

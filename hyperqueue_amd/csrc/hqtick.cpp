@@ -298,9 +298,11 @@ void fill_problem(hqhost::Problem &pb, const hqtick_snapshot *s, const hqtick_co
     ws.n = s->n_workers; ws.R = s->n_resources; ws.id = s->worker_id; ws.total = s->worker_total; ws.free_ = s->worker_free;
     ws.remaining_ns = s->worker_remaining_ns; ws.min_util = s->worker_min_utilization; ws.flags = s->worker_flags; ws.group = s->worker_group;
     ws.vflags = ev.flags; ws.vtmc = ev.tmc; ws.n_variant_slots = nv;
-    ws.blocked.assign(ws.n, {});
+    if (ws.blocked.size() != ws.n || ws.n_blocked_lists) { ws.blocked.assign(ws.n, {}); ws.n_blocked_lists = 0; }  // (4096 empty lists re-made per tick cost more than the batches stage)
     ws.assigned_off = s->assigned_off; ws.assigned_rq = s->assigned_rq; ws.assigned_variant = s->assigned_variant;
     for (uint32_t k = 0; k < s->n_blocked; k++) ws.blocked[s->blocked_worker[k]].push_back({s->blocked_rq[k], s->blocked_variant[k]});
+    ws.n_blocked_lists = s->n_blocked;
+    hqhost::group_equal_rows(ws, false);  // needs nothing of K2's output: in a tick this runs while the GPU works on phase A
 }
 
 void export_batches(hqtick_ctx *ctx, const std::vector<hqhost::TaskBatch> &batches, hqtick_result *out) {
@@ -1356,6 +1358,7 @@ static int query_on(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_quer
     fw.remaining_ns = fake->worker_remaining_ns; fw.min_util = fake->worker_min_utilization; fw.flags = nullptr; fw.group = nullptr;
     fw.vflags = ev_fake.flags; fw.vtmc = ev_fake.tmc; fw.n_variant_slots = Q ? s->rq_variant_off[Q] : 0;
     fw.blocked.assign(fw.n, {});
+    hqhost::group_equal_rows(fw, true);
     pb.custom = &fw;
     std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
     std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
@@ -1461,6 +1464,7 @@ int hqtick_debug_host_query(const hqtick_config *config, const hqtick_snapshot *
     fw.remaining_ns = fake->worker_remaining_ns; fw.min_util = fake->worker_min_utilization; fw.flags = nullptr; fw.group = nullptr;
     fw.vflags = fake_vflags; fw.vtmc = fake_vtmc; fw.n_variant_slots = Q ? s->rq_variant_off[Q] : 0;
     fw.blocked.assign(fw.n, {});
+    hqhost::group_equal_rows(fw, true);
     pb.custom = &fw;
     Scan sc; sc.Q = Q; sc.L = n_levels; sc.G = n_levels * Q;
     sc.levels.assign(levels, levels + n_levels); sc.hist.assign(hist, hist + (size_t)n_levels * Q);
