@@ -618,7 +618,8 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             // The workers of a key are those whose class places something in its column: keys with the same set of classes share the id list and its Map
             // order (a cold tick has one class: one list for all keys).
             struct WorkerList { std::vector<uint8_t> mask; std::vector<uint32_t> widx, order; };  // order: a copy — the memo behind cached_worker_order recycles its entries
-            std::vector<WorkerList> lists;
+            std::vector<WorkerList> lists; lists.reserve((size_t)NC + 1);  // (pointers into it are kept below)
+            std::vector<uint32_t> key_g, key_l;
             std::vector<uint8_t> mask(ncls);
             std::vector<uint32_t> ids, ord;
             for (size_t b = 0; b < nb; b++) {
@@ -644,10 +645,23 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                         for (size_t k = 0, e = ordered.size(); k < e; k++) { const uint32_t w = widx[word[k]]; o[k] = {w, xg[(size_t)wclass[w] * NC]}; }
                     }
                     key_hash.push_back(hqhb::hash_rq_variant(batches[b].rq, v)); key_list.push_back({batches[b].rq, v}); key_counts.push_back(std::move(ordered));
+                    key_g.push_back(g); key_l.push_back((uint32_t)(wl - lists.data()));
                 }
             }
             hqhb::insertion_order(key_hash.data(), (uint32_t)key_hash.size(), ord);
-            for (uint32_t k : ord) { out.keys.push_back(key_list[k]); out.per_key.push_back(std::move(key_counts[k])); }
+            for (uint32_t k : ord) { out.keys.push_back(key_list[k]); out.per_key.push_back(std::move(key_counts[k])); out.key_col.push_back(key_g[k]); out.key_list.push_back(key_l[k]); }
+            if (!pb.custom) {  // the per-class form of the same counts, for the mapping plan (host_model.h)
+                out.by_class = true; out.n_cols = NC;
+                out.class_x = X; out.class_x.resize((size_t)(ncls + 1) * NC, 0);
+                out.wclass.assign(ws.n, ncls);
+                for (uint32_t w : solver_workers) out.wclass[w] = wclass[w];
+                out.lists.resize(lists.size());
+                for (size_t i = 0; i < lists.size(); i++) {
+                    const WorkerList &l = lists[i];
+                    std::vector<uint32_t> &dst = out.lists[i].widx; dst.resize(l.order.size());
+                    for (size_t k = 0; k < l.order.size(); k++) dst[k] = l.widx[l.order[k]];
+                }
+            }
             out.n_classes = ncls; out.t_classify_us = t_sep1 - t_sep0; out.t_blocks_us = t_sep2 - t_sep1; out.t_decode_us = clock_us() - t_sep2;
             return out;
         }

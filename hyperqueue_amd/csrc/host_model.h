@@ -121,6 +121,14 @@ struct Counts {
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> per_key;
     std::vector<uint32_t> mn_rq;                               // mn_workers keys (variant 0) in iteration order
     std::vector<std::vector<std::vector<uint32_t>>> mn_sets;   // per key: worker sets
+    // Separable ticks also say how the counts came about — per worker class — so that the mapping plan can fill its per-(key, worker) tables with
+    // sequential passes over the workers instead of scattering the pairs above: count of key k on worker w = class_x[wclass[w] * n_cols + key_col[k]]
+    // (workers outside the solver carry the all-zero class n_classes), and keys whose worker lists are equal share one list (workers in Map order).
+    struct WorkerList { std::vector<uint32_t> widx; };
+    bool by_class = false;
+    uint32_t n_cols = 0;
+    std::vector<uint32_t> wclass, class_x, key_col, key_list;
+    std::vector<WorkerList> lists;
     bool is_optimal = true;
     bool is_canonical = true;  // every solve completed its tie-break phase
     bool empty() const {

@@ -49,7 +49,7 @@ namespace {
 struct PlanScratch {
     std::vector<uint32_t> q_total, pf_n, pf_start, seq_taken, pf_drained, zq_taken, new_pf_total, pfl_size, rq_sel_base;
     std::vector<uint32_t> key_seg, key_sum, key_rq, key_var_w, key_ord_off, ord_cnt, key_t_off, key_bits_off, wpos, wcnt;
-    std::vector<uint32_t> items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, pfl_j, out_off, take_base, mn_first, pack;
+    std::vector<uint32_t> list_pos, pf_flag, pf_flag_prev, items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, pfl_j, out_off, take_base, mn_first, pack;
     std::vector<uint8_t> now_mn;
     std::vector<uint32_t> sink_hdr;
     std::vector<uint64_t> holes;                                 // (rq << 32 | logical position) of Retracting tasks taken this tick
@@ -89,6 +89,7 @@ struct hqtick_ctx {
     std::vector<unsigned char> cl_rt;  // host copy of the request-table part as uploaded (compared per tick: a few hundred bytes)
     hipEvent_t cl_ev = nullptr;
     bool sweep_inflight = false;  // an early K5a launch not yet covered by a stream synchronisation
+    bool wait_on_kernel = true;   // HQ_HIP_LAST; HQTICK_WAIT_ON_KERNEL=0: hipStreamSynchronize at every wait (A/B)
     // selection + mapping
     DevBuf d_sel_task, d_sel_level, d_map, d_rec, d_tsweep, d_bits, d_pre;
     hqhost::Problem pb;
@@ -123,6 +124,17 @@ namespace {
     do {                                                                                                      \
         hipError_t e_ = (call);                                                                               \
         hqk::take_launch_timer();                                                                             \
+        if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return HQTICK_E_DEVICE; } \
+    } while (0)
+
+// The last launch of a phase carries a stop event (hipExtLaunchKernel: the dispatch's own completion signal), and the host waits on THAT instead of
+// hipStreamSynchronize, which submits a marker packet of its own and returns 5.6 us after the kernel is done where the kernel's signal is seen after 2.8 us
+// (tools/exp/launch_latency.hip, MI355X / ROCm 7.2).  `launched` = the wrapper really launched (it consumed the pending timer); otherwise the
+// caller falls back to the stream.
+#define HQ_HIP_LAST(call, launched)                                                                           \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        (launched) = hqk::take_launch_timer().stop == nullptr && ctx->wait_on_kernel;                        \
         if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return HQTICK_E_DEVICE; } \
     } while (0)
 
@@ -376,6 +388,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
         unsigned char *h = ctx->h_a.as<unsigned char>(), *hd = ctx->h_a.dev<unsigned char>();
         memset(h, 0, 16);
         // K2 reads the packed tables from pinned memory; with a ready set to scan it rides along the K1 launch
+        bool scan_is_last = false;  // K1b was launched and nothing follows it on the stream
         UpView uv; int rc;
         if (ctx->cluster_valid) { if ((rc = resident_tables(ctx, s, W, &uv))) return rc; }
         else if ((rc = upload_tables(ctx, s, W, s->worker_total, s->worker_free, s->worker_remaining_ns, ctx->h_up, &uv))) return rc;
@@ -394,9 +407,10 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
             if (ctx->k2_own_stream) HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc), ctx->stream2));
             HQ_HIP_TIMED(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
                                    ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->k2_on_hist ? &wea : nullptr, ctx->stream));
-            if (ctx->timing) hqk::time_next_launch(ctx->ev[0], ctx->ev[8]);
-            HQ_HIP_TIMED(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
-                                   reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream, (ctx->k2_own_stream || ctx->k2_on_hist) ? nullptr : &wea));
+            hqk::time_next_launch(ctx->timing ? ctx->ev[0] : nullptr, ctx->ev[8]);  // ev[8]: K1b's completion — what the host waits on below
+            HQ_HIP_LAST(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
+                                   reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream, (ctx->k2_own_stream || ctx->k2_on_hist) ? nullptr : &wea), scan_is_last);
+            if (s->n_retracting) scan_is_last = false;  // k_rank_of follows
             if (s->n_retracting) {  // where do the Retracting tasks sit in their queues?  (mapping.rs:66-80 treats them apart)
                 const uint32_t nr = s->n_retracting;
                 if (!ctx->h_retr.ensure((size_t)nr * 16 + 64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc retracting");
@@ -410,7 +424,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
         }
         ev->flags = h + o_fl; ev->tmc = reinterpret_cast<const uint32_t *>(h + o_tmc);
         if (while_gpu_runs) (*while_gpu_runs)();
-        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (scan && scan_is_last) HQ_HIP(hipEventSynchronize(ctx->ev[8])); else HQ_HIP(hipStreamSynchronize(ctx->stream));
         if (scan && ctx->k2_own_stream) HQ_HIP(hipStreamSynchronize(ctx->stream2));
         const uint32_t *flags = reinterpret_cast<const uint32_t *>(h);
         if (scan && (flags[2] & 2u)) return fail(ctx, HQTICK_E_INVALID, "ready set holds a request id >= n_requests");
@@ -475,11 +489,11 @@ struct DeviceBlocks : hqhost::BlockSolver {
             dprof = ctx->h_blkprof.dev<uint64_t>(); ctx->n_blkprof = nd;
         }
         hqblock::Output dout{(uint32_t *)(dpin + o_x), (uint32_t *)(dpin + o_st), (uint32_t *)(dpin + o_steps), dprof};
-        if (ctx->timing) hqk::time_next_launch(ctx->ev[9], ctx->ev[10]);
+        hqk::time_next_launch(ctx->timing ? ctx->ev[9] : nullptr, ctx->ev[10]);
         const hipError_t be = hqblock::block_solve(dct, dcl, dout, ctx->block_budget, ctx->stream);
-        hqk::take_launch_timer();
+        const bool launched = hqk::take_launch_timer().stop == nullptr && ctx->wait_on_kernel;
         if (be != hipSuccess) return false;
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+        if ((launched ? hipEventSynchronize(ctx->ev[10]) : hipStreamSynchronize(ctx->stream)) != hipSuccess) return false;  // the kernel's own completion signal (HQ_HIP_LAST)
         memcpy(out.x, h + o_x, (size_t)nd * NC * 4); memcpy(out.status, h + o_st, (size_t)nd * 4); memcpy(out.steps, h + o_steps, (size_t)nd * 4);
         if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[9], ctx->ev[10]); if (us_ >= 0) ctx->stats.block_solve_us = us_; }
         ctx->stats.n_classes_device = nd;
@@ -563,19 +577,37 @@ struct TickRun {
         nkeys = (uint32_t)cnt.keys.size();
         ps.key_seg.assign(nkeys, 0); ps.key_sum.assign(nkeys, 0); ps.key_rq.assign(nkeys, 0); ps.key_var_w.assign((nkeys + 3) / 4 + 1, 0);
         ps.key_ord_off.assign(nkeys + 1, 0); ps.key_t_off.assign(nkeys + 1, 0); ps.key_bits_off.assign(nkeys + 1, 0);
-        ps.wpos.assign((size_t)nkeys * W, NONE); ps.wcnt.assign((size_t)nkeys * W, 0);
+        const bool by_class = cnt.by_class && cnt.wclass.size() == W && cnt.key_col.size() == nkeys;
+        if (by_class) { ps.wpos.resize((size_t)nkeys * W); ps.wcnt.resize((size_t)nkeys * W); }  // every row is written in full below
+        else { ps.wpos.assign((size_t)nkeys * W, NONE); ps.wcnt.assign((size_t)nkeys * W, 0); }
         ps.items.assign(W, 0); ps.n_assign.assign(W, 0); ps.asg_qw.assign((size_t)Q * W, 0);
         size_t n_cnt = 0; for (uint32_t k = 0; k < nkeys; k++) n_cnt += cnt.per_key[k].size();
         ctx->cnt_rq.resize(n_cnt); ctx->cnt_variant.resize(n_cnt); ctx->cnt_worker.resize(n_cnt); ctx->cnt_value.resize(n_cnt); ps.ord_cnt.resize(n_cnt);
         uint32_t *c_rq = ctx->cnt_rq.data(), *c_w = ctx->cnt_worker.data(), *c_v = ctx->cnt_value.data(), *c_ord = ps.ord_cnt.data(); uint8_t *c_var = ctx->cnt_variant.data();
         size_t ci = 0;
         max_count = 0; max_nk = 0;
+        if (by_class) {  // position of every worker in each distinct worker list (Map order), built once per list
+            ps.list_pos.assign(cnt.lists.size() * (size_t)W, NONE);
+            for (size_t l = 0; l < cnt.lists.size(); l++) {
+                uint32_t *lp = ps.list_pos.data() + l * W; const std::vector<uint32_t> &wi = cnt.lists[l].widx;
+                for (uint32_t i = 0; i < wi.size(); i++) lp[wi[i]] = i;
+            }
+        }
         for (uint32_t k = 0; k < nkeys; k++) {
             const uint32_t q = cnt.keys[k].first; const uint8_t v = cnt.keys[k].second;
             ps.key_rq[k] = q; reinterpret_cast<uint8_t *>(ps.key_var_w.data())[k] = v;
             uint32_t sum = 0, maxc = 0, pos = 0;
             uint32_t *wp = ps.wpos.data() + (size_t)k * W, *wcn = ps.wcnt.data() + (size_t)k * W, *aq = ps.asg_qw.data() + (size_t)q * W, *items = ps.items.data(), *nas = ps.n_assign.data();
-            for (auto &wc : cnt.per_key[k]) {  // (worker, count) in the Map's iteration order
+            if (by_class) {  // separable tick: the count of a worker is its class's; sequential passes instead of scattering (worker, count) pairs
+                const uint32_t *xg = cnt.class_x.data() + cnt.key_col[k], *wcl = cnt.wclass.data(); const uint32_t NCc = cnt.n_cols;
+                const std::vector<uint32_t> &wi = cnt.lists[cnt.key_list[k]].widx;
+                for (uint32_t w = 0; w < W; w++) { const uint32_t c = xg[(size_t)wcl[w] * NCc]; wcn[w] = c; items[w] += c; aq[w] += c; }
+                memcpy(wp, ps.list_pos.data() + (size_t)cnt.key_list[k] * W, (size_t)W * 4);
+                pos = (uint32_t)wi.size();
+                std::fill(c_rq + ci, c_rq + ci + pos, q); memset(c_var + ci, v, pos); memcpy(c_w + ci, wi.data(), (size_t)pos * 4);
+                for (uint32_t i = 0; i < pos; i++) { const uint32_t c = wcn[wi[i]]; c_v[ci + i] = c; c_ord[ci + i] = c; sum += c; maxc = std::max(maxc, c); }
+                ci += pos;
+            } else for (auto &wc : cnt.per_key[k]) {  // (worker, count) in the Map's iteration order
                 const uint32_t w = wc.first, c = wc.second;
                 sum += c; maxc = std::max(maxc, c);
                 c_rq[ci] = q; c_var[ci] = v; c_w[ci] = w; c_v[ci] = c; c_ord[ci] = c; ci++;
@@ -588,6 +620,7 @@ struct TickRun {
             ps.key_seg[k] = ps.seq_taken[q]; ps.key_sum[k] = sum; ps.seq_taken[q] += sum;
             if (ps.seq_taken[q] > ps.q_total[q] + ps.pf_n[q]) return fail(ctx, HQTICK_E_QUEUE_UNDERFLOW, "solver placed more tasks than the queue holds (reference panics, taskqueue.rs:327)");
         }
+        if (by_class) memcpy(ps.n_assign.data(), ps.items.data(), (size_t)W * 4);  // equal until the redirects are taken off
         n_bit_words = ps.key_bits_off[nkeys];
         // multi-node placements take one task each from the head of their queue (mapping.rs:133-154)
         ps.mn_first.assign(cnt.mn_rq.size(), 0);
@@ -689,26 +722,38 @@ struct TickRun {
                 for (uint32_t l = 0; l < L; l++) { uint32_t h = hist(l, q); if (h > left) { top_level[q] = (int)l; top_left[q] = h - left; break; } left -= h; }
                 if (top_level[q] >= 0) global_top = std::max(global_top, sc.levels[top_level[q]]);  // TaskQueues::top_priority  taskqueue.rs:62-68
             }
+            size_t prev_row = SIZE_MAX;  // the pfl_j row that belongs to pf_flag_prev
             for (uint32_t q = 0; q < Q; q++) {
                 if (top_level[q] < 0 || sc.levels[top_level[q]] != global_top) continue;
                 bool pf_left = ps.pf_n[q] > ps.pf_drained[q];
                 uint32_t tsz = (pf_left && s->prefill_priority[q] != global_top) ? 0 : top_left[q];  // top_size_no_prefill  taskqueue.rs:241-253
                 uint32_t size = tsz > ctx->cfg.proactive_filling_reserve ? tsz - ctx->cfg.proactive_filling_reserve : 0;
                 if (!size) continue;
-                ps.elig.clear();
+                // eligible workers: flags in index order (a branch-free pass), their ranks in worker_map order only when the set differs from the
+                // previous request's (on a saturated tick every worker serves every class: one walk of the order for all requests)
                 const uint32_t *aq = ps.asg_qw.data() + (size_t)q * W, *hp = ps.has_pf.data() + (size_t)q * W;
-                for (uint32_t w : ps.wm_order) {
-                    bool sn = (s->worker_flags ? (s->worker_flags[w] & HQ_WORKER_SN) != 0 : true) && !ps.now_mn[w];
-                    if (sn && aq[w] > 0 && hp[w] == 0) ps.elig.push_back(w);
+                ps.pf_flag.resize(W);
+                uint32_t n_elig = 0;
+                for (uint32_t w = 0; w < W; w++) {
+                    const uint32_t sn = ((s->worker_flags ? (s->worker_flags[w] & HQ_WORKER_SN) != 0 : true) && !ps.now_mn[w]) ? 1u : 0u;
+                    const uint32_t f = sn & (aq[w] > 0 ? 1u : 0u) & (hp[w] == 0 ? 1u : 0u);
+                    ps.pf_flag[w] = f; n_elig += f;
                 }
-                if (ps.elig.empty()) continue;
-                uint32_t psz = std::min(size / (uint32_t)ps.elig.size(), ctx->cfg.proactive_filling_max);
+                if (!n_elig) continue;
+                uint32_t psz = std::min(size / n_elig, ctx->cfg.proactive_filling_max);
                 if (!psz) continue;
                 ps.pfl_size[q] = psz;
                 pfq_rq.push_back(q);
-                size_t o = ps.pfl_j.size(); ps.pfl_j.resize(o + W, NONE);
-                for (uint32_t j = 0; j < ps.elig.size(); j++) ps.pfl_j[o + ps.elig[j]] = j;
-                ps.new_pf_total[q] = psz * (uint32_t)ps.elig.size();
+                size_t o = ps.pfl_j.size(); ps.pfl_j.resize(o + W);
+                if (prev_row != SIZE_MAX && memcmp(ps.pf_flag.data(), ps.pf_flag_prev.data(), (size_t)W * 4) == 0) memcpy(ps.pfl_j.data() + o, ps.pfl_j.data() + prev_row, (size_t)W * 4);
+                else {
+                    uint32_t *row = ps.pfl_j.data() + o; const uint32_t *fl = ps.pf_flag.data();
+                    uint32_t j = 0;
+                    for (uint32_t w : ps.wm_order) { const uint32_t f = fl[w]; row[w] = f ? j : NONE; j += f; }
+                    ps.pf_flag_prev.swap(ps.pf_flag);
+                }
+                prev_row = o;
+                ps.new_pf_total[q] = psz * n_elig;
             }
         }
         for (auto &rp : retr_pos) {  // take_tasks_for_prefill on a Retracting task: the reference asserts task.is_waiting()  (mapping.rs:221)
@@ -875,11 +920,13 @@ struct TickRun {
                 HQ_HIP(hipMemcpyAsync(sk, ctx->h_sinkhdr.p, hdr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
                 k_task = reinterpret_cast<uint64_t *>(sk + so_task); k_var = sk + so_var; k_kind = sk + so_kind;
             }
-            if (ctx->timing) hqk::time_next_launch(ctx->ev[7], ctx->ev[11]);
+            hqk::time_next_launch(ctx->timing ? ctx->ev[7] : nullptr, ctx->ev[11]);  // ev[11]: K5b's completion — what the host waits on below
             hqk::CompactOut co{};
             if (compact) co = hqk::CompactOut{reinterpret_cast<uint32_t *>(drec), reinterpret_cast<uint2 *>(drec + o_rs), reinterpret_cast<uint32_t *>(drec + o_rf)};
-            HQ_HIP_TIMED(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
-                                reinterpret_cast<uint32_t *>(drec + o_fl), co, max_out, may_reorder, ctx->stream));
+            bool expand_is_last = false;
+            HQ_HIP_LAST(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
+                                reinterpret_cast<uint32_t *>(drec + o_fl), co, max_out, may_reorder, ctx->stream), expand_is_last);
+            if (!cnt.mn_rq.empty()) expand_is_last = false;  // copies of the multi-node task ids follow
             // multi-node tasks: the heads of their queues
             {
                 size_t pos = 0;
@@ -891,7 +938,7 @@ struct TickRun {
             }
             mark();  // 7: phase C enqueued
             assemble_host_part();
-            HQ_HIP(hipStreamSynchronize(ctx->stream));
+            if (expand_is_last) HQ_HIP(hipEventSynchronize(ctx->ev[11])); else HQ_HIP(hipStreamSynchronize(ctx->stream));
             ctx->sweep_inflight = false;
             if (flags[0]) return fail(ctx, HQTICK_E_CAPACITY, "mapping kernel capacity exceeded");
             if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[4], ctx->ev[5]); if (us_ >= 0) ctx->stats.select_us = us_; }
@@ -1024,6 +1071,7 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return HQTICK_E_DEVICE; }
     if (const char *e = getenv("HQTICK_K2_RIDE_ALONG")) { ctx->k2_own_stream = atoi(e) == 0; ctx->k2_on_hist = atoi(e) == 1; }
     if (const char *e = getenv("HQTICK_CHECK_CLUSTER")) ctx->cluster_check = atoi(e) != 0;
+    if (const char *e = getenv("HQTICK_WAIT_ON_KERNEL")) ctx->wait_on_kernel = atoi(e) != 0;
     if (hipEventCreate(&ctx->cl_ev) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     if (!ctx->d_flags.ensure(64) || hipMemset(ctx->d_flags.p, 0, 64) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
