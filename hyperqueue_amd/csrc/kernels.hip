@@ -450,6 +450,7 @@ __global__ void __launch_bounds__(256) k_sweep_bits(MapKeys mk) {
     if (lane == 0) mk.t_sweep[t0 + s] = summin;
 }
 
+static const uint32_t PF_STAGE = 64;    // prefilling requests whose chunk descriptors K5b stages in LDS (one wavefront scans them)
 static const uint32_t RUN_STAGE = 512;  // runs of one worker staged in LDS before they are written (6 KB)
 
 // ------------------------------------------------------------------------------------------------ K5b
@@ -478,8 +479,12 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
     uint32_t *s_key = misc + 4;        // [sort_cap] (level << 16 | item) keys of the stable sort; sort_cap = 0 on ticks that cannot reorder
     uint8_t *k_var = reinterpret_cast<uint8_t *>(s_key + sort_cap);
     const uint32_t w = blockIdx.x, lane = lane_id();
-    const uint32_t out0 = mk.out_off[w];
-    if (mk.out_off[w + 1] == out0) return;  // no record for this worker (or the worker belongs to another rank's shard)
+    // Three rounds of global loads, each issued as one batch: (1) the worker's output range, its row of every per-key table and its prefill chunks;
+    // (2) the round-robin cells of its items + the ids of its prefill records; (3) the ids and group keys of its items.  (Five dependent rounds —
+    // range, tables, chunk index, chunk ids, cells, ids — cost the launch ~4 us more.)
+    __shared__ uint32_t p_j[PF_STAGE], p_cnt[PF_STAGE], p_src[PF_STAGE], p_start[PF_STAGE + 1];  // the worker's chunk of every prefilling request
+    const bool pf_staged = mk.n_pfq <= PF_STAGE;
+    const uint32_t out0 = mk.out_off[w], out1 = mk.out_off[w + 1];
     for (uint32_t k = threadIdx.x; k < nkeys; k += blockDim.x) {  // every per-key table in one round of independent loads
         k_pos[k] = mk.wpos[(size_t)k * W + w];
         k_cnt[k] = mk.wcnt[(size_t)k * W + w];
@@ -487,6 +492,11 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
         k_words[k] = (mk.key_ord_off[k + 1] - mk.key_ord_off[k] + 63) >> 6;
         k_var[k] = mk.key_variant[k];
     }
+    if (pf_staged && threadIdx.x < mk.n_pfq) {
+        const uint32_t pi = threadIdx.x, j = mk.pfl_j[(size_t)pi * W + w], c = mk.pfq_size[pi];
+        p_j[pi] = j; p_cnt[pi] = j == 0xFFFFFFFFu ? 0u : c; p_src[pi] = mk.pfq_src[pi] + (j == 0xFFFFFFFFu ? 0u : j * c);
+    }
+    if (out1 == out0) return;  // no record for this worker (or the worker belongs to another rank's shard)
     if (threadIdx.x == 0) { misc[0] = 0xFFFFu; misc[1] = 0; misc[2] = 0; }
     __syncthreads();
     if (threadIdx.x < 64) {  // exclusive scan of the per-key counts
@@ -501,13 +511,21 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
             carry += __shfl(incl, 63, 64);
         }
         if (lane == 0) k_start[nkeys] = carry;
+    } else if (threadIdx.x < 128 && pf_staged) {  // second wavefront: exclusive scan of the prefill chunk lengths (PF_STAGE == 64: one step)
+        const uint32_t c = lane < mk.n_pfq ? p_cnt[lane] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += t; }
+        if (lane < mk.n_pfq) p_start[lane] = incl - c;
+        if (lane == 63) p_start[mk.n_pfq] = incl;
     }
     __syncthreads();
     const uint32_t n = k_start[nkeys];
     if (n > max_items) { if (threadIdx.x == 0) err_flag[0] = 2u; return; }
     // new prefills first, in queue (request id) order (mapping.rs:266-272)
     uint32_t npf = 0;
-    for (uint32_t pi = 0; pi < mk.n_pfq; pi++) {
+    if (pf_staged) npf = mk.n_pfq ? p_start[mk.n_pfq] : 0u;
+    else for (uint32_t pi = 0; pi < mk.n_pfq; pi++) {  // more prefilling requests than the stage holds: chunk by chunk
         const uint32_t j = mk.pfl_j[(size_t)pi * W + w];
         if (j == 0xFFFFFFFFu) continue;
         const uint32_t cnt = mk.pfq_size[pi], src = mk.pfq_src[pi] + j * cnt;
@@ -519,36 +537,52 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
         }
         npf += cnt;
     }
-    // gather: item e = (key k, sweep s) in key order then sweep order
-    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-        uint32_t lo = 0, hi = nkeys;  // last key with k_start[k] <= e (it is the non-empty one)
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (k_start[mid] <= e) lo = mid; else hi = mid; }
-        const uint32_t k = lo, s = e - k_start[k], pos = k_pos[k];
-        const size_t cell = (size_t)k_boff[k] + (size_t)s * k_words[k] + (pos >> 6);
-        const uint32_t q = k_rq[k];
-        const uint32_t pre = mk.pre[cell], tsw = mk.t_sweep[k_toff[k] + s];
-        const uint64_t bw = mk.bits[cell];
-        const uint32_t pfs = mk.rq_pf_start[q], pfn = mk.rq_pf_n[q], sbase = mk.rq_sel_base[q];
-        const uint32_t idx = tsw + pre + (uint32_t)__popcll(bw & ((1ull << (pos & 63)) - 1ull));  // index inside the key's take_tasks() vector
-        const uint32_t p = k_seg[k] + idx;                              // position in the queue's logical sequence
-        bool hole = p >= pfs && p < pfs + pfn;                         // an already-prefilled task: retract/redirect is host work
-        if (!hole && mk.n_holes) {                                     // a Retracting task of the queue: redirect, no record (host work too)
-            const uint64_t hk = ((uint64_t)q << 32) | p;
-            uint32_t hlo = 0, hhi = mk.n_holes;
-            while (hlo < hhi) { uint32_t mid = (hlo + hhi) >> 1; if (mk.holes[mid] < hk) hlo = mid + 1; else hhi = mid; }
-            hole = hlo < mk.n_holes && mk.holes[hlo] == hk;
+    // prefill records and gathered items side by side: thread t handles prefill record u = base + t and item e = base + t of every 256-wide step, so that
+    // the loads of both are in flight together.  Item e = (key k, sweep s) in key order then sweep order.
+    const uint32_t n_pf_staged = pf_staged ? npf : 0u;
+    for (uint32_t base = 0; base < (n > n_pf_staged ? n : n_pf_staged); base += blockDim.x) {
+        const uint32_t u = base + threadIdx.x, e = u;
+        const bool do_pf = u < n_pf_staged, do_item = e < n;
+        uint64_t pf_id = 0;
+        if (do_pf) {
+            uint32_t lo = 0, hi = mk.n_pfq;  // last chunk with p_start[pi] <= u (empty chunks have equal starts: the last one is the non-empty one)
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (p_start[mid] <= u) lo = mid; else hi = mid; }
+            pf_id = sel_task[p_src[lo] + (u - p_start[lo])];
         }
-        if (hole) {
-            e_meta[e] = 0; e_task[e] = 0; e_lvl[e] = 0;
-            misc[2] = 1;
-        } else {
-            const uint32_t src = sbase + (p >= pfs + pfn ? p - pfn : p);
-            const uint16_t lv = (uint16_t)(sel_key[src] / Q);  // priority level of the task's group
-            e_task[e] = sel_task[src];
-            e_lvl[e] = lv;
-            e_meta[e] = (uint16_t)(k_var[k] | 0x100u);
-            atomicMin(&misc[0], (uint32_t)lv);
-            atomicMax(&misc[1], (uint32_t)lv);
+        if (do_item) {
+            uint32_t lo = 0, hi = nkeys;  // last key with k_start[k] <= e (it is the non-empty one)
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (k_start[mid] <= e) lo = mid; else hi = mid; }
+            const uint32_t k = lo, s = e - k_start[k], pos = k_pos[k];
+            const size_t cell = (size_t)k_boff[k] + (size_t)s * k_words[k] + (pos >> 6);
+            const uint32_t q = k_rq[k];
+            const uint32_t pre = mk.pre[cell], tsw = mk.t_sweep[k_toff[k] + s];
+            const uint64_t bw = mk.bits[cell];
+            const uint32_t pfs = mk.rq_pf_start[q], pfn = mk.rq_pf_n[q], sbase = mk.rq_sel_base[q];
+            const uint32_t idx = tsw + pre + (uint32_t)__popcll(bw & ((1ull << (pos & 63)) - 1ull));  // index inside the key's take_tasks() vector
+            const uint32_t p = k_seg[k] + idx;                              // position in the queue's logical sequence
+            bool hole = p >= pfs && p < pfs + pfn;                         // an already-prefilled task: retract/redirect is host work
+            if (!hole && mk.n_holes) {                                     // a Retracting task of the queue: redirect, no record (host work too)
+                const uint64_t hk = ((uint64_t)q << 32) | p;
+                uint32_t hlo = 0, hhi = mk.n_holes;
+                while (hlo < hhi) { uint32_t mid = (hlo + hhi) >> 1; if (mk.holes[mid] < hk) hlo = mid + 1; else hhi = mid; }
+                hole = hlo < mk.n_holes && mk.holes[hlo] == hk;
+            }
+            if (hole) {
+                e_meta[e] = 0; e_task[e] = 0; e_lvl[e] = 0;
+                misc[2] = 1;
+            } else {
+                const uint32_t src = sbase + (p >= pfs + pfn ? p - pfn : p);
+                const uint16_t lv = (uint16_t)(sel_key[src] / Q);  // priority level of the task's group
+                e_task[e] = sel_task[src];
+                e_lvl[e] = lv;
+                e_meta[e] = (uint16_t)(k_var[k] | 0x100u);
+                atomicMin(&misc[0], (uint32_t)lv);
+                atomicMax(&misc[1], (uint32_t)lv);
+            }
+        }
+        if (do_pf) {
+            if (compact) { if (u < max_out) { f_task[u] = pf_id; f_meta[u] = 0x00FFu; } }
+            else { rec_task[out0 + u] = pf_id; rec_variant[out0 + u] = 0xFF; rec_kind[out0 + u] = 0; }  // HQ_REC_PREFILL
         }
     }
     __syncthreads();
