@@ -277,6 +277,7 @@ def main():
     ap.add_argument("--dag-classes", type=int, default=8, help="request classes of the config-5 DAG (first N of the c3 classes; 8 = all, as BASELINE config 5 names them)")
     ap.add_argument("--wire-iters", type=int, default=50, help="launch triples of the wire-encoding measurement (row f3, in a subprocess), 0 = skip")
     ap.add_argument("--full-records", action="store_true", help="10-byte records (u64 id, variant, kind) instead of the compact emission (HQTICK_FLAG_COMPACT_RECORDS)")
+    ap.add_argument("--u32-records", action="store_true", help="compact emission with 4-byte low halves (ABI 4/5) instead of the 16-bit differences of ABI 6 (HQTICK_FLAG_COMPACT_DELTA16)")
     ap.add_argument("--no-b2b", dest="b2b", action="store_false", help="skip the 100 back-to-back launches of K1 / K4 (so that a rocprofv3 summary of this run averages the in-tick launches only)")
     ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
@@ -320,6 +321,9 @@ def main():
         cfg.flags |= abi.HQTICK_FLAG_NO_KERNEL_TIMING
     if not args.full_records:
         cfg.flags |= abi.HQTICK_FLAG_COMPACT_RECORDS  # records cross PCIe as u32 low halves + runs of (job, variant, kind): include/hqtick.h
+        if not args.u32_records:
+            cfg.flags |= abi.HQTICK_FLAG_COMPACT_DELTA16  # ... as 16-bit differences of the low halves (ABI 6): 2 bytes per record
+    rec_bytes = 10 if args.full_records else (4 if args.u32_records else 2)  # what one record costs on PCIe (runs and spans on top in the compact forms)
     sc = snap.to_c()
     W_all = len(snap.worker_id)
     if world == 1 and not args.force_sharded:
@@ -397,7 +401,7 @@ def main():
         "scan_waves": dict(us=mean("scan_us"), bytes=G * ((n_ready + 255) // 256) * 8, bound="latency", what="K1b: per-slice counts -> offsets"),
         "select_scatter": dict(us=mean("select_us"), bytes=n_ready * 8 + sel * 10, bound="hbm", what="K4: id u64 of every ready task + (id, level) of the taken ones"),
         "sweep_bits": dict(us=mean("sweep_us"), bytes=0, bound="latency", what="K5a: round-robin bit rows"),
-        "expand_mapping": dict(us=mean("other_us"), bytes=(sel * 10 + sel * (10 if args.full_records or world > 1 else 4)) // world, bound="pcie" if world == 1 else "hbm-latency",
+        "expand_mapping": dict(us=mean("other_us"), bytes=(sel * 10 + sel * (10 if world > 1 else rec_bytes)) // world, bound="pcie" if world == 1 else "hbm-latency",
                                what="K5b: gathers (id, level) and writes this rank's records " + ("straight into pinned host memory" if world == 1 else "into the HBM record sink")),
     }
     for k in kernels.values():
@@ -418,7 +422,7 @@ def main():
     achieved, peak = (kernels[dom]["bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0), 8000.0
     pcie_peak = 63.0  # GB/s, PCIe Gen5 x16 one direction (what K5b's stores into pinned host memory cross)
     em = kernels["expand_mapping"]
-    pcie_bytes = sel * (10 if args.full_records else 4) // world
+    pcie_bytes = sel * rec_bytes // world
     value = total_assigned * args.steps / elapsed
     out = {
         "metric": "tasks_assigned_per_sec", "value": value, "unit": "tasks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -444,10 +448,12 @@ def main():
                              "launch, not this one (HQTICK_K2_RIDE_ALONG=1 puts it back: 5.8 us instead of 4.7)"},
         "roofline_time_dominant_kernel": {"kernel": "expand_mapping", "bound": "pcie", "achieved": pcie_bytes / (em["us"] * 1e-6) / 1e9 if em["us"] > 0 else 0.0, "peak": pcie_peak, "unit": "GB/s",
                                           "frac": (pcie_bytes / (em["us"] * 1e-6) / 1e9 / pcie_peak) if em["us"] > 0 else 0.0, "bytes_over_pcie_per_launch": pcie_bytes, "avg_launch_us": em["us"],
-                                          "note": "K5b writes the records straight into the caller's pinned host buffer (compact emission: 4 B per record, counted here, + 12 B per run of equal "
-                                                  "(job, variant, kind) + 8 B per worker; --full-records: 10 B per record).  Ablation on the MI355X (profiles/r02/README.md): 11.9 us of the launch is the "
-                                                  "kernel itself (gather from HBM, LDS sort), 12.6 us the record bytes crossing PCIe (60 GB/s), 1.4 us runs + spans; a shared run counter (one "
-                                                  "atomicAdd per workgroup on one address) had cost another 8.5 us until the runs moved into the slots of their own records"},
+                                          "bytes_per_record": rec_bytes,
+                                          "note": "K5b writes the records straight into the caller's pinned host buffer.  Emission forms (include/hqtick.h): 10 B per record (--full-records), "
+                                                  "4 B low halves + 12 B per run of equal (job, variant, kind) + 8 B per worker (--u32-records, ABI 4/5), or — the default since ABI 6 — 16-bit "
+                                                  "differences of the low halves (2 B per record, 6 B where a difference does not fit) + 16 B per run.  On the MI355X (DESIGN.md 3c): ~12 us of the "
+                                                  "launch is the kernel itself (gathers from HBM, LDS placement, run scan), the rest the bytes crossing PCIe at the link's rate (~60 GB/s): "
+                                                  "25.5 us with 4 B per record, 20.0 us with 2 B"},
     }
     if world == 1 and not args.force_sharded and not args.no_kernel_timing and args.roofline_sweep:
         sweep = []

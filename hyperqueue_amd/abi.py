@@ -11,8 +11,8 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-HQTICK_ABI_VERSION = 5
-HQTICK_FLAG_NO_KERNEL_TIMING, HQTICK_FLAG_COMPACT_RECORDS = 1, 2
+HQTICK_ABI_VERSION = 6
+HQTICK_FLAG_NO_KERNEL_TIMING, HQTICK_FLAG_COMPACT_RECORDS, HQTICK_FLAG_COMPACT_DELTA16 = 1, 2, 4
 HQ_AMOUNT_MAX = 0xFFFF_FFFF_FFFF_FFFF
 HQ_FRACTIONS_PER_UNIT = 10_000
 HQ_MAX_TASK_PER_WORKER = 1024
@@ -139,6 +139,8 @@ class ResultC(C.Structure):
         ("rec_task_lo", u32p),
         ("run_span", u32p),  # hqtick_run_span[W]: (start, count) pairs
         ("runs", u32p),      # hqtick_rec_run[]: (first, job, meta) triples
+        ("rec_delta16", C.POINTER(C.c_uint16)),  # HQTICK_FLAG_COMPACT_DELTA16: unit streams, worker w's at unit 4 * rec_off[w]
+        ("runs16", u32p),    # hqtick_rec_run16[]: (first, job, meta, first_lo)
         ("n_redirects", C.c_uint32),
         ("redirect_task", u64p),
         ("redirect_worker", u32p),
@@ -389,12 +391,60 @@ def expand_compact(r: ResultC, W: int, off: np.ndarray):
     return task.tolist(), var.tolist(), kind.tolist()
 
 
+def expand_delta16(r: ResultC, W: int, off: np.ndarray):
+    """(task ids, variants, kinds) of every record from the 16-bit-difference emission (HQTICK_FLAG_COMPACT_DELTA16) — the decoder of include/hqtick.h"""
+    n = int(off[-1])
+    span = _np(r.run_span, 2 * W, np.uint32).reshape(W, 2)
+    task = np.zeros(n, np.uint64); var = np.zeros(n, np.uint8); kind = np.zeros(n, np.uint8)
+    have = np.nonzero(off[1:] > off[:-1])[0]
+    if not len(have):
+        return [], [], []
+    hi_run = int(max(int(span[w, 0]) + int(span[w, 1]) for w in have))
+    runs = _np(r.runs16, 4 * hi_run, np.uint32).reshape(hi_run, 4)
+    units_all = _np(r.rec_delta16, 4 * n, np.uint16)
+    for w in have:
+        a, b, s0, c = int(off[w]), int(off[w + 1]), int(span[w, 0]), int(span[w, 1])
+        assert c >= 1 and runs[s0, 0] == 0 and s0 == a, (w, c)
+        tot = b - a
+        starts = runs[s0:s0 + c, 0].astype(np.int64)
+        assert (np.diff(starts) > 0).all() and starts[-1] < tot
+        lens = np.diff(np.append(starts, tot))
+        units = units_all[4 * a:4 * a + 3 * tot].astype(np.int64)
+        opens = np.zeros(tot, bool); opens[starts] = True
+        lo = np.zeros(tot, np.int64)
+        lo[starts] = runs[s0:s0 + c, 3].astype(np.int64)
+        n_plain = tot - c  # records that read units
+        if n_plain and not (units[:n_plain] == 0xFFFF).any():  # no escape: one unit per record, running sums inside every run
+            d = np.zeros(tot, np.int64); d[~opens] = units[:n_plain]
+            seg = np.repeat(np.arange(c), lens)
+            cs = np.cumsum(d); base = cs[starts]  # cs at a run's first record (its own d is 0)
+            lo = (lo[starts][seg] + cs - base[seg]) & 0xFFFFFFFF
+        elif n_plain:
+            up = 0; prev = 0
+            for i in range(tot):
+                if opens[i]:
+                    prev = int(lo[i]); continue
+                u = int(units[up])
+                if u != 0xFFFF:
+                    prev = (prev + u) & 0xFFFFFFFF; up += 1
+                else:
+                    prev = int(units[up + 1]) | (int(units[up + 2]) << 16); up += 3
+                lo[i] = prev
+        task[a:b] = (np.repeat(runs[s0:s0 + c, 1].astype(np.uint64), lens) << np.uint64(32)) | lo.astype(np.uint64)
+        meta = runs[s0:s0 + c, 2].astype(np.uint16)
+        var[a:b] = np.repeat((meta & 0xFF).astype(np.uint8), lens)
+        kind[a:b] = np.repeat((meta >> 8).astype(np.uint8), lens)
+    return task.tolist(), var.tolist(), kind.tolist()
+
+
 def record_task_ids(r: ResultC, W: int) -> np.ndarray:
     """task ids of every record of a tick in CSR order (rec_off), from either emission format"""
     off = _np(r.rec_off, W + 1, np.uint32)
     n = int(off[-1])
     if n == 0:
         return np.zeros(0, np.uint64)
+    if r.rec_delta16:
+        return np.asarray(expand_delta16(r, W, off)[0], np.uint64)
     if r.rec_task_lo:
         return np.asarray(expand_compact(r, W, off)[0], np.uint64)
     return _np(r.rec_task, n, np.uint64).copy()
@@ -417,7 +467,9 @@ def parse_result(r: ResultC, n_workers: int, n_resources: int, full: bool = True
     if r.rec_off and W:
         off = _np(r.rec_off, W + 1, np.uint32)
         n = int(off[-1])
-        if n and r.rec_task_lo:  # compact emission (HQTICK_FLAG_COMPACT_RECORDS): u32 low halves + runs of (job, variant, kind)
+        if n and r.rec_delta16:  # HQTICK_FLAG_COMPACT_DELTA16: 16-bit differences + runs that carry their first low id
+            t, v, k = expand_delta16(r, W, off)
+        elif n and r.rec_task_lo:  # compact emission (HQTICK_FLAG_COMPACT_RECORDS): u32 low halves + runs of (job, variant, kind)
             t, v, k = expand_compact(r, W, off)
         else:
             t, v, k = _np(r.rec_task, n, np.uint64).tolist(), _np(r.rec_variant, n, np.uint8).tolist(), _np(r.rec_kind, n, np.uint8).tolist()

@@ -517,7 +517,7 @@ struct TickRun {
     size_t o_rv = 0, o_rk = 0, o_mn = 0, o_fl = 0;            // layout of the pinned record buffer
     bool sweep_launched = false;  // K5a went out right after the key tables (launch_sweep_early)
     bool may_reorder = false;  // the mapping kernel needs its stable sort: several priority levels, Retracting holes or prefilled tasks inside the queues
-    bool compact = false; size_t o_rs = 0, o_rf = 0; uint32_t max_out = 0;  // compact emission (HQTICK_FLAG_COMPACT_RECORDS)
+    bool compact = false, delta16 = false; size_t o_rs = 0, o_rf = 0; uint32_t max_out = 0;  // compact emission (HQTICK_FLAG_COMPACT_RECORDS / _DELTA16)
     uint64_t *h_rec_task = nullptr, *mn_ids = nullptr; uint8_t *h_rec_var = nullptr, *h_rec_kind = nullptr;
     bool assembled = false;
     double t0 = 0;
@@ -784,7 +784,7 @@ struct TickRun {
         // ---- output offsets ----
         ps.out_off.assign(W + 1, 0);
         max_items = 0; max_out = 0;
-        compact = (ctx->cfg.flags & HQTICK_FLAG_COMPACT_RECORDS) != 0 && !ctx->sink;
+        compact = (ctx->cfg.flags & (HQTICK_FLAG_COMPACT_RECORDS | HQTICK_FLAG_COMPACT_DELTA16)) != 0 && !ctx->sink;
         for (uint32_t w = 0; w < W; w++) {
             if (ctx->shard_count > 1 && hqhb::hash_worker_id(s->worker_id[w]) % ctx->shard_count != ctx->shard_index) { ps.out_off[w + 1] = ps.out_off[w]; continue; }  // another rank's worker
             uint32_t npf = 0;
@@ -856,9 +856,10 @@ struct TickRun {
     // GPU phase C: selection, round-robin bit rows, per-worker expansion; records land in pinned memory (or the HBM sink)
     int phase_c() {
         size_t n_mn_ids = 0; for (auto &sets : cnt.mn_sets) n_mn_ids += sets.size();
-        if (compact) {  // [rec_lo u32 x n_rec][run_span (start, count) x W][runs 12 B x n_rec] (at most one run per record)
-            o_rs = ((size_t)n_rec * 4 + 7) & ~(size_t)7; o_rf = o_rs + (size_t)W * 8;
-            o_rv = o_rk = 0; o_mn = (o_rf + (size_t)n_rec * 12 + 7) & ~(size_t)7;
+        delta16 = compact && (ctx->cfg.flags & HQTICK_FLAG_COMPACT_DELTA16) != 0;
+        if (compact) {  // [rec_lo u32 x n_rec | units u16 x 4 n_rec][run_span (start, count) x W][runs 12 | 16 B x n_rec] (at most one run per record)
+            o_rs = delta16 ? (size_t)n_rec * 8 : (((size_t)n_rec * 4 + 7) & ~(size_t)7); o_rf = o_rs + (size_t)W * 8;
+            o_rv = o_rk = 0; o_mn = (o_rf + (size_t)n_rec * (delta16 ? 16 : 12) + 7) & ~(size_t)7;
         } else { o_rv = (size_t)n_rec * 8; o_rk = o_rv + n_rec; o_mn = (o_rk + n_rec + 7) & ~(size_t)7; }
         o_fl = o_mn + n_mn_ids * 8;
         const size_t rec_bytes = o_fl + 64;
@@ -922,7 +923,8 @@ struct TickRun {
             }
             hqk::time_next_launch(ctx->timing ? ctx->ev[7] : nullptr, ctx->ev[11]);  // ev[11]: K5b's completion — what the host waits on below
             hqk::CompactOut co{};
-            if (compact) co = hqk::CompactOut{reinterpret_cast<uint32_t *>(drec), reinterpret_cast<uint2 *>(drec + o_rs), reinterpret_cast<uint32_t *>(drec + o_rf)};
+            if (compact) co = hqk::CompactOut{reinterpret_cast<uint32_t *>(drec), reinterpret_cast<uint2 *>(drec + o_rs), reinterpret_cast<uint32_t *>(drec + o_rf),
+                                              delta16 ? reinterpret_cast<uint16_t *>(drec) : nullptr};
             bool expand_is_last = false;
             HQ_HIP_LAST(hqk::expand_mapping(mk, W, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), Q, max_items, k_task, k_var, k_kind,
                                 reinterpret_cast<uint32_t *>(drec + o_fl), co, max_out, may_reorder, ctx->stream), expand_is_last);
@@ -972,7 +974,9 @@ struct TickRun {
         out->rec_off = ctx->rec_off.data();
         if (compact && n_sel) {
             const uint8_t *hb = ctx->h_rec.as<uint8_t>();
-            out->rec_task_lo = reinterpret_cast<const uint32_t *>(hb); out->run_span = reinterpret_cast<const hqtick_run_span *>(hb + o_rs); out->runs = reinterpret_cast<const hqtick_rec_run *>(hb + o_rf);
+            out->run_span = reinterpret_cast<const hqtick_run_span *>(hb + o_rs);
+            if (delta16) { out->rec_delta16 = reinterpret_cast<const uint16_t *>(hb); out->runs16 = reinterpret_cast<const hqtick_rec_run16 *>(hb + o_rf); }
+            else { out->rec_task_lo = reinterpret_cast<const uint32_t *>(hb); out->runs = reinterpret_cast<const hqtick_rec_run *>(hb + o_rf); }
         } else if (!ctx->sink) { out->rec_task = h_rec_task; out->rec_variant = h_rec_var; out->rec_kind = h_rec_kind; }
         out->retract_off = ctx->retract_off.data(); out->retract_task = ctx->retract_task.data();
         out->n_redirects = (uint32_t)ctx->red_task.size(); out->redirect_task = ctx->red_task.data(); out->redirect_worker = ctx->red_worker.data(); out->redirect_variant = ctx->red_variant.data(); out->redirect_kind = ctx->red_kind.data();

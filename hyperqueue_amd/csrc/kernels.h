@@ -118,6 +118,8 @@ struct CompactOut {
     uint32_t *rec_lo;       // [n_rec] low 32 bits of every record's task id, per-worker CSR order (rec_off)
     uint2 *run_span;        // [W] (first run of the worker = its first record's offset, number of runs)    = hqtick_run_span
     uint32_t *runs;         // [n_rec * 3] per run: index of its first record inside the worker's range, high 32 bits of its task ids, variant | kind << 8   = hqtick_rec_run
+    uint16_t *units;        // HQTICK_FLAG_COMPACT_DELTA16 (else nullptr): [n_rec * 4] 16-bit unit streams, worker w's at unit 4 * rec_off[w]; rec_lo is unused and
+                            // the runs are 4 words (+ the low id of the run's first record) = hqtick_rec_run16
 };
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_key, uint32_t Q, uint32_t max_items,
                     uint64_t *rec_task, uint8_t *rec_variant, uint8_t *rec_kind, uint32_t *err_flag, CompactOut co, uint32_t max_out, bool may_reorder, hipStream_t s);

@@ -640,34 +640,67 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
     __syncthreads();
     const uint32_t tot = mk.out_off[w + 1] - out0;
     if (tot > max_out) { if (threadIdx.x == 0) err_flag[0] = 2u; return; }
-    __shared__ uint32_t s_wave[4];
-    uint32_t *s_run = reinterpret_cast<uint32_t *>(smem + ((reinterpret_cast<uintptr_t>(k_var + nkeys) - reinterpret_cast<uintptr_t>(smem) + 3) & ~(uintptr_t)3));  // [RUN_STAGE * 3], compact
-                                                                                           // launches only: the worker's runs as they go out, 12-byte records
+    __shared__ uint32_t s_wave[4], s_wave_u[4];
+    const bool d16 = co.units != nullptr;  // HQTICK_FLAG_COMPACT_DELTA16: 16-bit differences instead of 32-bit low halves
+    const uint32_t RW = d16 ? 4u : 3u;     // words per run record
+    uint32_t *s_run = reinterpret_cast<uint32_t *>(smem + ((reinterpret_cast<uintptr_t>(k_var + nkeys) - reinterpret_cast<uintptr_t>(smem) + 3) & ~(uintptr_t)3));  // [RUN_STAGE * RW], compact
+                                                                                           // launches only: the worker's runs as they go out
+    uint16_t *s_units = reinterpret_cast<uint16_t *>(s_run + RUN_STAGE * 4);                // [3 * max_out + 1] delta mode: the worker's unit stream
     const uint32_t chunk = (tot + blockDim.x - 1) / blockDim.x, lo = threadIdx.x * chunk, hi = lo + chunk < tot ? lo + chunk : tot;
     auto boundary = [&](uint32_t i) { return i == 0 || (uint32_t)(f_task[i] >> 32) != (uint32_t)(f_task[i - 1] >> 32) || f_meta[i] != f_meta[i - 1]; };
-    uint32_t mine = 0;
-    for (uint32_t i = lo; i < hi; i++) mine += boundary(i) ? 1u : 0u;
-    uint32_t incl = mine;
+    // delta mode: a record that does not open a run travels as ONE 16-bit unit = its low id minus its predecessor's (records of one (worker, key) come in
+    // ascending id order, a few thousand ids apart), or as THREE units (0xFFFF, low 16 bits, high 16 bits) when the difference does not fit; the record
+    // that opens a run has its low id in the run record
+    auto usize = [&](uint32_t i) { return boundary(i) ? 0u : (((uint32_t)f_task[i] - (uint32_t)f_task[i - 1]) < 0xFFFFu ? 1u : 3u); };
+    uint32_t mine = 0, mine_u = 0;
+    for (uint32_t i = lo; i < hi; i++) { mine += boundary(i) ? 1u : 0u; if (d16) mine_u += usize(i); }
+    uint32_t incl = mine, incl_u = mine_u;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += t; }
-    if (lane == 63) s_wave[threadIdx.x >> 6] = incl;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, 64), tu = __shfl_up(incl_u, off, 64);
+        if ((int)lane >= off) { incl += t; incl_u += tu; }
+    }
+    if (lane == 63) { s_wave[threadIdx.x >> 6] = incl; s_wave_u[threadIdx.x >> 6] = incl_u; }
     __syncthreads();
-    uint32_t before = incl - mine;
-    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) before += s_wave[wv];
-    const uint32_t n_runs = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    uint32_t before = incl - mine, before_u = incl_u - mine_u;
+    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) { before += s_wave[wv]; before_u += s_wave_u[wv]; }
+    const uint32_t n_runs = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3], n_units = s_wave_u[0] + s_wave_u[1] + s_wave_u[2] + s_wave_u[3];
     // The worker's runs go to the run slots out0 .. out0 + n_runs (a worker has at most one run per record, so the record offsets double as run
     // offsets): no allocation.  A shared counter here — one atomicAdd per workgroup on one address — serialised the 1024 workgroups of the launch
     // for 8.5 us of its 35 (measured by replacing it with a constant).
     if (threadIdx.x == 0) co.run_span[w] = make_uint2(out0, n_runs);  // one 8-byte store
-    // Every store below crosses PCIe as a write of its own: the runs are 12-byte records staged in LDS and written by consecutive lanes.
+    // Every store below crosses PCIe as a write of its own: the runs are 12- / 16-byte records staged in LDS and written by consecutive lanes.
     const bool staged = n_runs <= RUN_STAGE;
     uint32_t r = before;
-    if (staged) for (uint32_t i = lo; i < hi; i++) if (boundary(i)) { s_run[3 * r] = i; s_run[3 * r + 1] = (uint32_t)(f_task[i] >> 32); s_run[3 * r + 2] = f_meta[i]; r++; }
+    if (staged) for (uint32_t i = lo; i < hi; i++) if (boundary(i)) {
+        s_run[RW * r] = i; s_run[RW * r + 1] = (uint32_t)(f_task[i] >> 32); s_run[RW * r + 2] = f_meta[i];
+        if (d16) s_run[RW * r + 3] = (uint32_t)f_task[i];
+        r++;
+    }
+    if (d16) {
+        uint32_t up = before_u;
+        for (uint32_t i = lo; i < hi; i++) {
+            if (boundary(i)) continue;
+            const uint32_t cur = (uint32_t)f_task[i], d = cur - (uint32_t)f_task[i - 1];
+            if (d < 0xFFFFu) s_units[up++] = (uint16_t)d;
+            else { s_units[up] = 0xFFFFu; s_units[up + 1] = (uint16_t)cur; s_units[up + 2] = (uint16_t)(cur >> 16); up += 3; }
+        }
+    }
     __syncthreads();
-    uint32_t *runs = co.runs + (size_t)out0 * 3;
-    if (staged) { for (uint32_t i = threadIdx.x; i < n_runs * 3; i += blockDim.x) runs[i] = s_run[i]; }
-    else for (uint32_t i = lo; i < hi; i++) if (boundary(i)) { runs[3 * r] = i; runs[3 * r + 1] = (uint32_t)(f_task[i] >> 32); runs[3 * r + 2] = f_meta[i]; r++; }  // more runs than the stage holds: each thread writes its own
-    for (uint32_t i = threadIdx.x; i < tot; i += blockDim.x) co.rec_lo[out0 + i] = (uint32_t)f_task[i];
+    uint32_t *runs = co.runs + (size_t)out0 * RW;
+    if (staged) { for (uint32_t i = threadIdx.x; i < n_runs * RW; i += blockDim.x) runs[i] = s_run[i]; }
+    else for (uint32_t i = lo; i < hi; i++) if (boundary(i)) {  // more runs than the stage holds: each thread writes its own
+        runs[RW * r] = i; runs[RW * r + 1] = (uint32_t)(f_task[i] >> 32); runs[RW * r + 2] = f_meta[i];
+        if (d16) runs[RW * r + 3] = (uint32_t)f_task[i];
+        r++;
+    }
+    if (d16) {  // the unit stream of worker w starts at unit 4 * out0 (8-byte aligned; at most 3 units per record): pairs of units leave as 4-byte stores
+        if (threadIdx.x == 0 && (n_units & 1u)) s_units[n_units] = 0;
+        __syncthreads();
+        uint32_t *dst = reinterpret_cast<uint32_t *>(co.units + (size_t)out0 * 4);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(s_units);
+        for (uint32_t i = threadIdx.x; i < (n_units + 1) / 2; i += blockDim.x) dst[i] = src[i];
+    } else for (uint32_t i = threadIdx.x; i < tot; i += blockDim.x) co.rec_lo[out0 + i] = (uint32_t)f_task[i];
 }
 
 // ------------------------------------------------------------------------------------------------ resident cluster tables (f1)
@@ -961,7 +994,7 @@ uint32_t expand_mapping_sort_cap(uint32_t max_items) { uint32_t p = 1; while (p 
 
 size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys, uint32_t max_out, bool may_reorder) {
     return (size_t)max_items * 12 + (size_t)max_out * 10 + 2 + ((size_t)8 * n_keys + 1 + 4) * 4 + n_keys + 16 + (may_reorder ? (size_t)expand_mapping_sort_cap(max_items) * 4 : 0) +
-           (max_out ? (size_t)RUN_STAGE * 12 + 4 : 0);  // max_out != 0 = compact emission: the run stage
+           (max_out ? (size_t)RUN_STAGE * 16 + 4 + (size_t)max_out * 6 + 8 : 0);  // max_out != 0 = compact emission: the run stage + the 16-bit unit stream (delta mode)
 }
 
 hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, const uint16_t *sel_key, uint32_t Q, uint32_t max_items,

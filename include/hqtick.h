@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HQTICK_ABI_VERSION 5u
+#define HQTICK_ABI_VERSION 6u
 
 /* ResourceAmount::MAX                                    common/resources/amount.rs:31 */
 #define HQ_AMOUNT_MAX UINT64_MAX
@@ -85,6 +85,12 @@ enum { HQ_REC_PREFILL = 0, HQ_REC_ASSIGN = 1 };
  * record.  result.rec_task / rec_variant / rec_kind are NULL then; see the run_* fields of hqtick_result.  (Ignored while a device record sink is
  * set: the sink keeps its own layout.) */
 #define HQTICK_FLAG_COMPACT_RECORDS 2u
+/* hqtick_config.flags, on top of COMPACT_RECORDS (ABI 6): the low halves travel as 16-bit DIFFERENCES.  The records of one (worker, request) come in
+ * ascending id order, a few thousand ids apart on a large cluster, so a record that does not open a run is one 16-bit unit — its job_task_id minus its
+ * predecessor's — or three units (0xFFFF, low 16 bits, high 16 bits of its job_task_id) when that difference is negative or above 0xFFFE; the record
+ * that opens a run has its job_task_id in the run record (hqtick_rec_run16.first_lo).  2 bytes per record instead of 4: the mapping kernel's launch is
+ * bound by these bytes crossing PCIe (C3: 25.6 -> ~20 us).  result.rec_task_lo / runs are NULL then; see rec_delta16 / runs16. */
+#define HQTICK_FLAG_COMPACT_DELTA16 4u
 
 /* redirect_kind of a result entry (scheduler/mapping.rs:66-101):
  *   FROM_PREFILL  the task sat in a prefill set: Prefilled{old} -> Retracting{old}, retract sent to `old`, redirects.insert(task, (worker, v))
@@ -198,6 +204,8 @@ typedef struct hqtick_rec_run {
     uint32_t meta;  /* variant | kind << 8 (low 16 bits; the rest is zero) */
 } hqtick_rec_run;
 typedef struct hqtick_run_span { uint32_t start, count; } hqtick_run_span;
+/* HQTICK_FLAG_COMPACT_DELTA16: the run record also carries the low half of its first record's task id */
+typedef struct hqtick_rec_run16 { uint32_t first, job, meta, first_lo; } hqtick_rec_run16;
 
 /*
  * Result view.  All pointers are owned by the ctx and stay valid until the next call on it.
@@ -251,6 +259,12 @@ typedef struct hqtick_result {
     const uint32_t *rec_task_lo;        /* [n_records] */
     const struct hqtick_run_span *run_span; /* [W] */
     const struct hqtick_rec_run *runs;
+    /* HQTICK_FLAG_COMPACT_DELTA16 (ABI 6; NULL otherwise, and rec_task_lo / runs are NULL then).  run_span as above, indexing runs16.  Worker w's unit
+     * stream starts at rec_delta16[4 * rec_off[w]] (at most 3 units per record; the slack keeps every stream 8-byte aligned).  Decoding the records of w
+     * in order: a record that opens a run (i == run.first) has job_task_id = run.first_lo and consumes no unit; any other record reads one unit u:
+     * u != 0xFFFF -> job_task_id = previous job_task_id + u;  u == 0xFFFF -> job_task_id = next unit | next-but-one unit << 16 (three units consumed). */
+    const uint16_t *rec_delta16;
+    const struct hqtick_rec_run16 *runs16;
 
     /* scheduler_state.redirects insertions made by this tick (mapping.rs:78-100) */
     uint32_t n_redirects;
