@@ -106,3 +106,56 @@ def test_unsaturated_multi_class_models_are_proven(n_workers, n_ready):
     got = product_milp(m["obj"], m["kind"], m["rtype"], m["rhs"], m["roff"], m["rcol"], m["rcoef"], canonical=False, time_limit=60.0)
     assert got is not None and got[2], "not proven optimal"
     assert abs(got[1] - m["objective"]) <= 1e-9 * abs(m["objective"])
+
+
+def _encode_delta16(records_per_worker):
+    """The emission format of HQTICK_FLAG_COMPACT_DELTA16 as include/hqtick.h states it, written here from the specification (NOT the kernel):
+    per worker runs of equal (job, variant, kind) carrying their first low id, every other record one 16-bit difference or the three-unit form."""
+    W = len(records_per_worker)
+    off = np.zeros(W + 1, np.uint32)
+    for w, recs in enumerate(records_per_worker):
+        off[w + 1] = off[w] + len(recs)
+    n = int(off[-1])
+    units = np.zeros(4 * max(n, 1), np.uint16); runs = np.zeros((max(n, 1), 4), np.uint32); span = np.zeros((W, 2), np.uint32)
+    for w, recs in enumerate(records_per_worker):
+        a = int(off[w]); u = 4 * a; nr = 0
+        for i, (task, var, kind) in enumerate(recs):
+            job, lo = task >> 32, task & 0xFFFFFFFF
+            meta = var | (kind << 8)
+            if i == 0 or (recs[i - 1][0] >> 32) != job or (recs[i - 1][1] | (recs[i - 1][2] << 8)) != meta:
+                runs[a + nr] = (i, job, meta, lo); nr += 1
+                continue
+            d = (lo - (recs[i - 1][0] & 0xFFFFFFFF)) & 0xFFFFFFFF
+            if d < 0xFFFF:
+                units[u] = d; u += 1
+            else:
+                units[u:u + 3] = (0xFFFF, lo & 0xFFFF, lo >> 16); u += 3
+        span[w] = (a, nr)
+    return off, units, runs, span
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_delta16_decoder_round_trip(seed):
+    """abi.expand_delta16 (the host shim's decoder, which the GPU tests rely on) against an encoder written from the header's text: jobs, variants and
+    kinds that split runs, differences at the limits of the one-unit form, negative differences, low halves up to 2^32 - 1, workers without records"""
+    rng = np.random.default_rng(seed)
+    recs = []
+    for w in range(9):
+        if w % 4 == 3:
+            recs.append([]); continue
+        out = []
+        lo = int(rng.integers(1, 1000))
+        for i in range(int(rng.integers(1, 80))):
+            step = int(rng.choice([1, 7, 8191, 65534, 65535, 65536, 70000, -5, -100000])) if seed else int(rng.integers(1, 60000))  # seed 0: no escape (the vectorised path)
+            lo = (lo + step) % (1 << 32)
+            if rng.random() < 0.05 and seed:
+                lo = 0xFFFFFFFF
+            out.append(((int(rng.integers(1, 3)) << 32) | lo, int(rng.choice([0, 1, 0xFF])), int(rng.integers(0, 2))))
+        recs.append(out)
+    off, units, runs, span = _encode_delta16(recs)
+    r = abi.ResultC()
+    r.rec_off = off.ctypes.data_as(abi.u32p); r.run_span = span.ctypes.data_as(abi.u32p); r.runs16 = runs.ctypes.data_as(abi.u32p)
+    r.rec_delta16 = units.ctypes.data_as(C.POINTER(C.c_uint16))
+    t, v, k = abi.expand_delta16(r, len(recs), off)
+    flat = [x for rr in recs for x in rr]
+    assert t == [x[0] for x in flat] and v == [x[1] for x in flat] and k == [x[2] for x in flat]
