@@ -151,13 +151,25 @@ HQW_HD void lds_min(uint32_t *p, uint32_t val) {
 #endif
 }
 
-HQW_HD uint32_t find_row(const Args &a, uint64_t task) {  // lower bound in the ascending id column
-    uint64_t lo = 0, hi = a.t.n_tasks;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (a.t.task_id[mid] < task) lo = mid + 1;
-        else hi = mid;
+// Lower bound in the ascending id column.  A binary search over a million rows is a chain of 20 dependent global loads (~14 us of k_wire_plan's 41):
+// here every step loads 15 pivots at once and keeps one sixteenth of the range, 5 rounds instead of 20.
+HQW_HD uint32_t find_row(const Args &a, uint64_t task) {
+    uint64_t lo = 0, hi = a.t.n_tasks;  // answer in [lo, hi]: rows below lo are < task, rows from hi on are >= task
+    while (hi - lo > 16) {
+        const uint64_t step = (hi - lo + 15) / 16;
+        uint64_t piv[15];
+        for (int j = 0; j < 15; j++) { const uint64_t i = lo + (uint64_t)(j + 1) * step; piv[j] = i < hi ? a.t.task_id[i] : ~0ull; }  // independent loads: one round trip
+        int below = 0;  // pivots < task (they ascend; positions past hi count as +inf)
+        for (int j = 0; j < 15; j++) below += (lo + (uint64_t)(j + 1) * step < hi && piv[j] < task) ? 1 : 0;
+        const uint64_t nlo = below ? lo + (uint64_t)below * step + 1 : lo;  // the last pivot below the task is itself excluded
+        const uint64_t nhi = below < 15 && lo + (uint64_t)(below + 1) * step < hi ? lo + (uint64_t)(below + 1) * step : hi;
+        lo = nlo; hi = nhi;
     }
+    uint64_t v[16];
+    for (int j = 0; j < 16; j++) v[j] = lo + j < hi ? a.t.task_id[lo + j] : ~0ull;
+    uint32_t c = 0;
+    for (int j = 0; j < 16; j++) c += (lo + j < hi && v[j] < task) ? 1u : 0u;
+    lo += c;
     return lo < a.t.n_tasks && a.t.task_id[lo] == task ? (uint32_t)lo : NONE;
 }
 HQW_HD uint32_t hash_cfg(uint32_t cfg) { return (cfg * 2654435761u) >> 20; }  // 12 bits = HT
@@ -167,11 +179,12 @@ HQW_HD uint32_t hash_cfg(uint32_t cfg) { return (cfg * 2654435761u) >> 20; }  //
 // task.rs:327,346-359: shared_index = rank of the configuration's first occurrence in the message), byte lengths.
 // =========================================================================================================================================
 struct PlanLds {
+    // 39.9 KB: four workgroups per CU (160 KB), i.e. the 1024 slots of a BASELINE tick are resident at once (at 49 KB — with an LDS copy of the slot's
+    // configuration list and 32-bit counters — three fitted, and the launch took two rounds)
     uint32_t key[HT], val[HT];  // configuration -> index (inside the slot) of its first record; later -> its rank
-    uint32_t cfg_list[MAXREC];
     uint8_t first[MAXREC];
     uint64_t part_bytes[BLOCK], part_est[BLOCK];
-    uint32_t part_cnt[BLOCK], base_cnt[BLOCK];
+    uint16_t part_cnt[BLOCK], base_cnt[BLOCK];  // <= MAXREC
     uint64_t rec_total, est_total;
     uint32_t n_cfg, bad, n_frag;
 };
@@ -235,14 +248,14 @@ HQW_HD void plan_p2(const Args &a, PlanLds &l, uint32_t s, int tid) {
         l.first[i] = f ? 1 : 0;
         cnt += f ? 1 : 0;
     }
-    l.part_cnt[tid] = cnt;
+    l.part_cnt[tid] = (uint16_t)cnt;
 }
 HQW_HD void plan_p3(const Args &, PlanLds &l, uint32_t, int tid) {
     if (tid != 0) return;
     uint32_t c = 0;
     uint64_t b = 0, e = 0;
     for (int t = 0; t < BLOCK; t++) {
-        l.base_cnt[t] = c;
+        l.base_cnt[t] = (uint16_t)c;
         c += l.part_cnt[t];
         b += l.part_bytes[t];
         e += l.part_est[t];
@@ -260,8 +273,7 @@ HQW_HD void plan_p4(const Args &a, PlanLds &l, uint32_t s, int tid) {
         if (!l.first[i]) continue;
         const uint32_t cfg = a.t.task_config[a.rec_row[sv.rec0 + i]];
         l.val[ht_find(l, cfg)] = k;  // from here on the table maps configuration -> shared_index (nobody reads first-indices any more)
-        l.cfg_list[k] = cfg;
-        a.cfg_list[sv.rec0 + k] = cfg;
+        a.cfg_list[sv.rec0 + k] = cfg;  // (read back in phase 5 by other threads of this workgroup: behind the barrier)
         k++;
     }
 }
@@ -277,8 +289,9 @@ HQW_HD void plan_p5(const Args &a, PlanLds &l, uint32_t s, int tid) {
     }
     uint64_t bytes = 0, est = 0;
     for (uint32_t k = (uint32_t)tid; k < l.n_cfg; k += BLOCK) {
-        bytes += shared_bytes(a, l.cfg_list[k]);
-        est += shared_estimate(a, l.cfg_list[k]);
+        const uint32_t cfg = a.cfg_list[sv.rec0 + k];
+        bytes += shared_bytes(a, cfg);
+        est += shared_estimate(a, cfg);
     }
     l.part_bytes[tid] = bytes;
     l.part_est[tid] = est;
