@@ -30,11 +30,17 @@ __global__ __launch_bounds__(BLOCK) void k_wire_plan(Args a) {
     __syncthreads();
     plan_p2(a, lds, s, tid);
     __syncthreads();
-    plan_p3(a, lds, s, tid);
+    plan_p3a(a, lds, s, tid);
+    __syncthreads();
+    plan_p3b(a, lds, s, tid);
+    __syncthreads();
+    plan_p3c(a, lds, s, tid);
     __syncthreads();
     plan_p4(a, lds, s, tid);
     __syncthreads();
     plan_p5(a, lds, s, tid);
+    __syncthreads();
+    plan_p6a(a, lds, s, tid);
     __syncthreads();
     plan_p6(a, lds, s, tid);
     __syncthreads();
@@ -46,7 +52,11 @@ __global__ __launch_bounds__(BLOCK) void k_wire_scan(Args a) {
     const int tid = (int)threadIdx.x;
     scan_p1(a, lds, tid);
     __syncthreads();
+    scan_p2a(a, lds, tid);
+    __syncthreads();
     scan_p2(a, lds, tid);
+    __syncthreads();
+    scan_p2c(a, lds, tid);
     __syncthreads();
     scan_p3(a, lds, tid);
 }
@@ -59,7 +69,11 @@ __global__ __launch_bounds__(BLOCK) void k_wire_emit(Args a) {
     for (uint32_t f = 0; f < nf; f++) {
         emit_p1(a, lds, s, f, tid);
         __syncthreads();
+        emit_p2a(a, lds, s, f, tid);
+        __syncthreads();
         emit_p2(a, lds, s, f, tid);
+        __syncthreads();
+        emit_p2c(a, lds, s, f, tid);
         __syncthreads();
         emit_p3(a, lds, s, f, tid);
         __syncthreads();

@@ -20,7 +20,7 @@
 
 namespace hqwire {
 
-constexpr int BLOCK = 256;
+constexpr int BLOCK = 256, GROUPS = 16, GSIZE = BLOCK / GROUPS;
 constexpr uint32_t HT = 4096, NONE = 0xFFFFFFFFu, MAXREC = HQWIRE_MAX_RECORDS, FMAX = HQWIRE_MAX_FRAGMENTS;
 static_assert(HT >= 2 * MAXREC, "dedup table load factor <= 0.5");
 
@@ -120,17 +120,43 @@ HQW_HD uint64_t shared_bytes(const Args &a, uint32_t cfg) { return 1 + (a.t.conf
 HQW_HD uint64_t shared_estimate(const Args &a, uint32_t cfg) { return 16 + body_len(a, cfg); }
 
 // ---- little-endian stores at any alignment -------------------------------------------------------------------------------------------------
+// On the device a 4- or 8-byte value leaves as ONE store instruction whatever its alignment (gfx950 global memory takes unaligned dword / qword
+// accesses): a 43-byte record is 9 store instructions instead of 43 single bytes.  On the host (debug hook) memcpy says the same thing.
 HQW_HD uint8_t *put8(uint8_t *p, uint8_t v) {
     *p = v;
     return p + 1;
 }
 HQW_HD uint8_t *put32(uint8_t *p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<uint32_t __attribute__((aligned(1))) *>(p) = v;
+#else
     for (int b = 0; b < 4; b++) p[b] = (uint8_t)(v >> (8 * b));
+#endif
     return p + 4;
 }
 HQW_HD uint8_t *put64(uint8_t *p, uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<uint64_t __attribute__((aligned(1))) *>(p) = v;
+#else
     for (int b = 0; b < 8; b++) p[b] = (uint8_t)(v >> (8 * b));
+#endif
     return p + 8;
+}
+// n bytes from src to dst, both at any alignment, by the threads tid, tid + stride, ...: single bytes up to the first 16-byte boundary of dst, 16-byte
+// stores (unaligned 16-byte loads) through the middle, single bytes at the end
+HQW_HD void copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n, int tid, int stride) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t head = n < 16 ? n : ((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15);
+    for (uint64_t b = (uint64_t)tid; b < head; b += stride) dst[b] = src[b];
+    const uint64_t n16 = (n - head) / 16;
+    typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u4_unaligned;
+    typedef uint32_t __attribute__((ext_vector_type(4))) u4;
+    for (uint64_t q = (uint64_t)tid; q < n16; q += stride)
+        *reinterpret_cast<u4 *>(dst + head + 16 * q) = *reinterpret_cast<const u4_unaligned *>(src + head + 16 * q);
+    for (uint64_t b = head + 16 * n16 + (uint64_t)tid; b < n; b += stride) dst[b] = src[b];
+#else
+    for (uint64_t b = (uint64_t)tid; b < n; b += stride) dst[b] = src[b];
+#endif
 }
 
 // ---- LDS atomics (plain on the host, where the phases run one thread at a time) ------------------------------------------------------------
@@ -185,6 +211,8 @@ struct PlanLds {
     uint8_t first[MAXREC];
     uint64_t part_bytes[BLOCK], part_est[BLOCK];
     uint16_t part_cnt[BLOCK], base_cnt[BLOCK];  // <= MAXREC
+    uint64_t grp_bytes[GROUPS], grp_est[GROUPS];  // sums over 16 consecutive threads' parts (two-level sums: a single thread walking 256 LDS entries
+    uint32_t grp_cnt[GROUPS], grp_base[GROUPS];   // costs ~10 us of dependent LDS latency per walk; 16 + 16 + 15 steps cost 2)
     uint64_t rec_total, est_total;
     uint32_t n_cfg, bad, n_frag;
 };
@@ -250,19 +278,26 @@ HQW_HD void plan_p2(const Args &a, PlanLds &l, uint32_t s, int tid) {
     }
     l.part_cnt[tid] = (uint16_t)cnt;
 }
-HQW_HD void plan_p3(const Args &, PlanLds &l, uint32_t, int tid) {
+HQW_HD void plan_p3a(const Args &, PlanLds &l, uint32_t, int tid) {  // group sums of the per-thread record counts / bytes / estimates
+    if (tid >= GROUPS) return;
+    uint32_t c = 0;
+    uint64_t b = 0, e = 0;
+    for (int t = tid * GSIZE; t < (tid + 1) * GSIZE; t++) { c += l.part_cnt[t]; b += l.part_bytes[t]; e += l.part_est[t]; }
+    l.grp_cnt[tid] = c; l.grp_bytes[tid] = b; l.grp_est[tid] = e;
+}
+HQW_HD void plan_p3b(const Args &, PlanLds &l, uint32_t, int tid) {
     if (tid != 0) return;
     uint32_t c = 0;
     uint64_t b = 0, e = 0;
-    for (int t = 0; t < BLOCK; t++) {
-        l.base_cnt[t] = (uint16_t)c;
-        c += l.part_cnt[t];
-        b += l.part_bytes[t];
-        e += l.part_est[t];
-    }
+    for (int g = 0; g < GROUPS; g++) { l.grp_base[g] = c; c += l.grp_cnt[g]; b += l.grp_bytes[g]; e += l.grp_est[g]; }
     l.n_cfg = c;
     l.rec_total = b;
     l.est_total = e;
+}
+HQW_HD void plan_p3c(const Args &, PlanLds &l, uint32_t, int tid) {  // every thread: distinct configurations first seen by the threads before it
+    uint32_t c = l.grp_base[tid / GSIZE];
+    for (int t = (tid / GSIZE) * GSIZE; t < tid; t++) c += l.part_cnt[t];
+    l.base_cnt[tid] = (uint16_t)c;
 }
 HQW_HD void plan_p4(const Args &a, PlanLds &l, uint32_t s, int tid) {
     const Slot sv = slot_of(a, s);
@@ -296,13 +331,19 @@ HQW_HD void plan_p5(const Args &a, PlanLds &l, uint32_t s, int tid) {
     l.part_bytes[tid] = bytes;
     l.part_est[tid] = est;
 }
+HQW_HD void plan_p6a(const Args &, PlanLds &l, uint32_t, int tid) {  // group sums of the shared-data bytes / estimates
+    if (tid >= GROUPS) return;
+    uint64_t b = 0, e = 0;
+    for (int t = tid * GSIZE; t < (tid + 1) * GSIZE; t++) { b += l.part_bytes[t]; e += l.part_est[t]; }
+    l.grp_bytes[tid] = b; l.grp_est[tid] = e;
+}
 HQW_HD void plan_p6(const Args &a, PlanLds &l, uint32_t s, int tid) {
     if (tid != 0) return;
     const Slot sv = slot_of(a, s);
     uint64_t sh = 0, est = l.est_total;
-    for (int t = 0; t < BLOCK; t++) {
-        sh += l.part_bytes[t];
-        est += l.part_est[t];
+    for (int g = 0; g < GROUPS; g++) {
+        sh += l.grp_bytes[g];
+        est += l.grp_est[g];
     }
     uint32_t status = l.bad;
     l.n_frag = (status == HQWIRE_SLOT_OK && sv.n) ? 1 : 0;
@@ -364,7 +405,7 @@ HQW_HD void plan_p7(const Args &a, PlanLds &l, uint32_t s, int tid) {
 // Kernel 2 "scan": one workgroup.  Exclusive scan of the 2 * n_slots message lengths -> slot_off, header.
 // =========================================================================================================================================
 struct ScanLds {
-    uint64_t part[BLOCK], base[BLOCK];
+    uint64_t part[BLOCK], base[BLOCK], grp[GROUPS], grp_base[GROUPS];
 };
 HQW_HD void scan_p1(const Args &a, ScanLds &l, int tid) {
     uint32_t lo, hi;
@@ -373,18 +414,29 @@ HQW_HD void scan_p1(const Args &a, ScanLds &l, int tid) {
     for (uint32_t j = lo; j < hi; j++) sum += a.slot_len[j];
     l.part[tid] = sum;
 }
+HQW_HD void scan_p2a(const Args &, ScanLds &l, int tid) {
+    if (tid >= GROUPS) return;
+    uint64_t sum = 0;
+    for (int t = tid * GSIZE; t < (tid + 1) * GSIZE; t++) sum += l.part[t];
+    l.grp[tid] = sum;
+}
 HQW_HD void scan_p2(const Args &a, ScanLds &l, int tid) {
     if (tid != 0) return;
     uint64_t run = 0;
-    for (int t = 0; t < BLOCK; t++) {
-        l.base[t] = run;
-        run += l.part[t];
+    for (int g = 0; g < GROUPS; g++) {
+        l.grp_base[g] = run;
+        run += l.grp[g];
     }
     a.o.slot_off[2 * (uint64_t)a.n_slots] = run;
     a.o.header[0] = run > a.o.capacity ? HQWIRE_CAPACITY : HQWIRE_OK;
     a.o.header[1] = a.n_slots;
     a.o.header[2] = (uint32_t)run;
     a.o.header[3] = (uint32_t)(run >> 32);
+}
+HQW_HD void scan_p2c(const Args &, ScanLds &l, int tid) {
+    uint64_t run = l.grp_base[tid / GSIZE];
+    for (int t = (tid / GSIZE) * GSIZE; t < tid; t++) run += l.part[t];
+    l.base[tid] = run;
 }
 HQW_HD void scan_p3(const Args &a, ScanLds &l, int tid) {
     uint32_t lo, hi;
@@ -401,6 +453,7 @@ HQW_HD void scan_p3(const Args &a, ScanLds &l, int tid) {
 // =========================================================================================================================================
 struct EmitLds {
     uint64_t part_rec[BLOCK], part_sh[BLOCK], base_rec[BLOCK], base_sh[BLOCK];
+    uint64_t grp_rec[GROUPS], grp_sh[GROUPS], gbase_rec[GROUPS], gbase_sh[GROUPS];
     uint32_t body_rel[MAXREC];  // offset of shared entry k's body inside the ComputeTasks message
     uint64_t rec_total, msg_base;
 };
@@ -441,14 +494,20 @@ HQW_HD void emit_p1(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) 
     for (uint32_t k = lo; k < hi; k++) sum += shared_bytes(a, a.cfg_list[g.cfg0 + k]);
     l.part_sh[tid] = sum;
 }
+HQW_HD void emit_p2a(const Args &a, EmitLds &l, uint32_t s, uint32_t, int tid) {
+    if (tid >= GROUPS || !emit_active(a, s)) return;
+    uint64_t r = 0, h = 0;
+    for (int t = tid * GSIZE; t < (tid + 1) * GSIZE; t++) { r += l.part_rec[t]; h += l.part_sh[t]; }
+    l.grp_rec[tid] = r; l.grp_sh[tid] = h;
+}
 HQW_HD void emit_p2(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) {
     if (tid != 0 || !emit_active(a, s)) return;
     uint64_t r = 0, h = 0;
-    for (int t = 0; t < BLOCK; t++) {
-        l.base_rec[t] = r;
-        r += l.part_rec[t];
-        l.base_sh[t] = h;
-        h += l.part_sh[t];
+    for (int g = 0; g < GROUPS; g++) {
+        l.gbase_rec[g] = r;
+        r += l.grp_rec[g];
+        l.gbase_sh[g] = h;
+        h += l.grp_sh[g];
     }
     l.rec_total = r;
     const Slot sv = slot_of(a, s);
@@ -458,6 +517,12 @@ HQW_HD void emit_p2(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) 
     put64(put32(m, 0), g.r1 - g.r0);               // ToWorkerMessage::ComputeTasks, tasks.len()
     put64(m + 12 + r, g.ncfg);                     // shared_data.len()
     if (a.o.frag_end) a.o.frag_end[(uint64_t)s * FMAX + f] = l.msg_base + 12 + r + 8 + h;
+}
+HQW_HD void emit_p2c(const Args &a, EmitLds &l, uint32_t s, uint32_t, int tid) {
+    if (!emit_active(a, s)) return;
+    uint64_t r = l.gbase_rec[tid / GSIZE], h = l.gbase_sh[tid / GSIZE];
+    for (int t = (tid / GSIZE) * GSIZE; t < tid; t++) { r += l.part_rec[t]; h += l.part_sh[t]; }
+    l.base_rec[tid] = r; l.base_sh[tid] = h;
 }
 HQW_HD void emit_p3(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) {
     if (!emit_active(a, s)) return;
@@ -483,7 +548,7 @@ HQW_HD void emit_p3(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) 
         if (a.t.entry_some[row]) {
             const uint64_t n = entry_len(a, row), e0 = a.t.entry_off[row];
             p = put64(p, n);
-            for (uint64_t b = 0; b < n; b++) p[b] = a.t.entry_blob[e0 + b];
+            copy_bytes(p, a.t.entry_blob + e0, n, 0, 1);
             p += n;
         }
     }
@@ -508,7 +573,7 @@ HQW_HD void emit_p4(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) 
         const uint32_t cfg = a.cfg_list[g.cfg0 + k];
         const uint64_t n = body_len(a, cfg), b0 = a.t.body_off[cfg];
         uint8_t *dst = m + l.body_rel[k];
-        for (uint64_t b = (uint64_t)tid; b < n; b += BLOCK) dst[b] = a.t.body_blob[b0 + b];
+        copy_bytes(dst, a.t.body_blob + b0, n, tid, BLOCK);
     }
 }
 
@@ -529,20 +594,27 @@ inline bool run_on_host(const Args &a, int order) {
             HQW_PHASE(plan_p0, *pl, s);
             HQW_PHASE(plan_p1, *pl, s);
             HQW_PHASE(plan_p2, *pl, s);
-            HQW_PHASE(plan_p3, *pl, s);
+            HQW_PHASE(plan_p3a, *pl, s);
+            HQW_PHASE(plan_p3b, *pl, s);
+            HQW_PHASE(plan_p3c, *pl, s);
             HQW_PHASE(plan_p4, *pl, s);
             HQW_PHASE(plan_p5, *pl, s);
+            HQW_PHASE(plan_p6a, *pl, s);
             HQW_PHASE(plan_p6, *pl, s);
             HQW_PHASE(plan_p7, *pl, s);
         }
         for (int q = 0; q < BLOCK; q++) scan_p1(a, *sl, seq[q]);
+        for (int q = 0; q < BLOCK; q++) scan_p2a(a, *sl, seq[q]);
         for (int q = 0; q < BLOCK; q++) scan_p2(a, *sl, seq[q]);
+        for (int q = 0; q < BLOCK; q++) scan_p2c(a, *sl, seq[q]);
         for (int q = 0; q < BLOCK; q++) scan_p3(a, *sl, seq[q]);
         for (uint32_t s = 0; s < a.n_slots; s++) {
             const uint32_t nf = nfrag_of(a, s) ? nfrag_of(a, s) : 1;  // a slot without a ComputeTasks part still runs fragment 0: its RetractTasks message
             for (uint32_t f = 0; f < nf; f++) {
                 for (int q = 0; q < BLOCK; q++) emit_p1(a, *el, s, f, seq[q]);
+                for (int q = 0; q < BLOCK; q++) emit_p2a(a, *el, s, f, seq[q]);
                 for (int q = 0; q < BLOCK; q++) emit_p2(a, *el, s, f, seq[q]);
+                for (int q = 0; q < BLOCK; q++) emit_p2c(a, *el, s, f, seq[q]);
                 for (int q = 0; q < BLOCK; q++) emit_p3(a, *el, s, f, seq[q]);
                 for (int q = 0; q < BLOCK; q++) emit_p4(a, *el, s, f, seq[q]);
             }
