@@ -469,22 +469,21 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 hqblock::ClassTable cl{nd, cfree.data(), ctot.data(), celig.data()};
                 hqblock::Output bo{dx.data(), dstatus.data(), dsteps.data(), nullptr};
                 if (pb.blocks->solve(ct, cl, bo)) {
+                    std::vector<unsigned __int128> used;
                     for (uint32_t i = 0; i < nd; i++) {
                         if (dstatus[i] != hqblock::ST_OK) continue;
                         const uint32_t c = dev_cls[i];
                         // the answer must fit the worker's rows (exact integer check; anything else is solved again here)
                         bool fits = true;
-                        for (uint32_t r = 0; r < R && fits; r++) {
-                            unsigned __int128 used = 0;
-                            for (uint32_t g = 0; g < NC; g++) {
-                                const uint32_t xv = dx[(size_t)i * NC + g];
-                                if (!xv) continue;
-                                if (!elig(c, g)) { fits = false; break; }
-                                const VariantView &vv = pb.variants[col_slot[g]];
-                                for (uint32_t e = 0; e < vv.n_entries; e++) if (vv.res[e] == r) used += (unsigned __int128)(vv.kind[e] == HQ_ENTRY_ALL ? ctot[(size_t)i * R + r] : vv.amount[e]) * xv;
-                            }
-                            if (used > cfree[(size_t)i * R + r]) fits = false;
+                        used.assign(R, 0);
+                        for (uint32_t g = 0; g < NC && fits; g++) {
+                            const uint32_t xv = dx[(size_t)i * NC + g];
+                            if (!xv) continue;
+                            if (!elig(c, g)) { fits = false; break; }
+                            const VariantView &vv = pb.variants[col_slot[g]];
+                            for (uint32_t e = 0; e < vv.n_entries; e++) used[vv.res[e]] += (unsigned __int128)(vv.kind[e] == HQ_ENTRY_ALL ? ctot[(size_t)i * R + vv.res[e]] : vv.amount[e]) * xv;
                         }
+                        for (uint32_t r = 0; r < R && fits; r++) if (used[r] > cfree[(size_t)i * R + r]) fits = false;
                         if (!fits) continue;
                         memcpy(X.data() + (size_t)c * NC, dx.data() + (size_t)i * NC, (size_t)NC * 4);
                         solved[c] = 1; out.blocks_device++;

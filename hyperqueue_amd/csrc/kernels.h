@@ -76,6 +76,9 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
                     const uint32_t *wave_off, const uint32_t *take_host, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_key,
                     const void *plan_src, void *plan_dst, size_t plan_bytes, uint32_t *mark_rq, hipStream_t s);
 // mark_rq != NULL: consume mode — instead of scattering, every selected task gets rq = RQ_TOMBSTONE in that column.
+// A small table from pinned (device-mapped) host memory into HBM by a kernel of the stream (16-byte loads across PCIe): a few microseconds where the copy
+// engine's hipMemcpyAsync costs 10-15 on its own.  bytes is rounded up to 16: both buffers must have that slack.
+hipError_t copy_pinned_to_hbm(const void *src_device_ptr, void *dst, size_t bytes, hipStream_t s);
 
 // K5: expand per-(request,variant,worker) counts into the per-worker assignment records, in the order
 // WorkerTaskMapping::send_messages emits them (scheduler/mapping.rs:36-131,259-282).

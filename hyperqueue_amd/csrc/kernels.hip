@@ -924,6 +924,13 @@ static __global__ void __launch_bounds__(256) k_copy16(const uint4 *__restrict__
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+hipError_t copy_pinned_to_hbm(const void *src, void *dst, size_t bytes, hipStream_t s) {
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    if (!n16) return hipSuccess;
+    hipLaunchKernelGGL(k_copy16, dim3((n16 + 1023) / 1024), dim3(256), 0, s, reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(dst), n16);
+    return hipGetLastError();
+}
+
 hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_t n, uint32_t Q, uint32_t G, WaveGeom geom,
                     const uint32_t *wave_off, const uint32_t *take_host, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_key,
                     const void *plan_src, void *plan_dst, size_t plan_bytes, uint32_t *mark_rq, hipStream_t s) {
