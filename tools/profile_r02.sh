@@ -23,6 +23,11 @@ run_pmc() {  # name, counter, command...
 run_trace bench_c3 $BENCH
 grep '^{' "$OUT/bench_c3.log" | tail -1 > "$OUT/bench_c3_under_rocprof.json"
 for c in FETCH_SIZE WRITE_SIZE; do run_pmc bench_c3 $c $BENCH; done
+# 1b. 200 cold ticks that ALL carry the dispatch events (what bench.py's stats pass does), and 200 that carry none (what its timed region does): the bench
+# command above mixes 55 ticks without events and 50 with them, and a K1 launched without a start event is the first packet the GPU sees after the host's
+# writes — its recorded duration then includes the acquire at the head of the queue (7.5 us against 4.6 us)
+run_trace ticks_with_events python $ROOT/tools/timeline.py c3 200 --timed
+run_trace ticks_without_events python $ROOT/tools/timeline.py c3 200
 # 2. the streaming kernels beyond the Infinity Cache: 16 M and 64 M ready tasks (tools/ktime.py: 3 ticks + back-to-back launches of K1 / K4)
 for n in 16000000 64000000; do
   run_trace ktime_$n python $ROOT/tools/ktime.py c3 20 $n
