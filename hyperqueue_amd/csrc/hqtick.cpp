@@ -48,9 +48,12 @@ namespace {
 // Reusable host scratch of the mapping plan (no per-tick allocation in the steady state).
 struct PlanScratch {
     std::vector<uint32_t> q_total, pf_n, pf_start, seq_taken, pf_drained, zq_taken, new_pf_total, pfl_size, rq_sel_base;
-    std::vector<uint32_t> key_seg, key_sum, key_rq, key_var_w, key_ord_off, ord_cnt, key_t_off, key_bits_off, wpos, wcnt;
-    std::vector<uint32_t> list_pos, pf_flag, pf_flag_prev, items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, pfl_j, out_off, take_base, mn_first, pack;
+    std::vector<uint32_t> key_seg, key_sum, key_rq, key_var_w, key_ord_off, ord_cnt, key_t_off, key_bits_off;
+    std::vector<uint32_t> list_pos, pf_flag, pf_flag_prev, items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, out_off, take_base, mn_first, pack;
     std::vector<uint8_t> now_mn;
+    // the three per-(key | request, worker) tables of the plan are built IN the pinned buffer K4's ride-along workgroups copy from (a memcpy of ~100 KB per
+    // tick otherwise): [wpos nkeys * W][wcnt nkeys * W][pfl_j Q * W] at its head, the small tables behind them (phase_c)
+    uint32_t *wpos = nullptr, *wcnt = nullptr, *pfl_j = nullptr; size_t pfl_rows = 0, plan_head_words = 0;
     std::vector<uint32_t> sink_hdr;
     std::vector<uint64_t> holes;                                 // (rq << 32 | logical position) of Retracting tasks taken this tick
     std::vector<std::pair<uint32_t, uint32_t>> freed;            // (worker, variant slot) given back by re-targeted redirects
@@ -578,8 +581,14 @@ struct TickRun {
         ps.key_seg.assign(nkeys, 0); ps.key_sum.assign(nkeys, 0); ps.key_rq.assign(nkeys, 0); ps.key_var_w.assign((nkeys + 3) / 4 + 1, 0);
         ps.key_ord_off.assign(nkeys + 1, 0); ps.key_t_off.assign(nkeys + 1, 0); ps.key_bits_off.assign(nkeys + 1, 0);
         const bool by_class = cnt.by_class && cnt.wclass.size() == W && cnt.key_col.size() == nkeys;
-        if (by_class) { ps.wpos.resize((size_t)nkeys * W); ps.wcnt.resize((size_t)nkeys * W); }  // every row is written in full below
-        else { ps.wpos.assign((size_t)nkeys * W, NONE); ps.wcnt.assign((size_t)nkeys * W, 0); }
+        {   // the big tables live at the head of the pinned plan buffer; everything else of the plan (phase_c) is a few KB behind them
+            ps.plan_head_words = (size_t)nkeys * W * 2 + (size_t)Q * W;
+            size_t n_cnt0 = 0; for (uint32_t k = 0; k < nkeys; k++) n_cnt0 += cnt.per_key[k].size();
+            const size_t small = (size_t)8 * (nkeys + 4) + n_cnt0 + (size_t)6 * (Q + 2) + (W + 2) + (size_t)2 * sc.G + (size_t)2 * s->n_retracting + 64;
+            if (!ctx->h_plan.ensure((ps.plan_head_words + small) * 4 + 64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc plan");
+            ps.wpos = ctx->h_plan.as<uint32_t>(); ps.wcnt = ps.wpos + (size_t)nkeys * W; ps.pfl_j = ps.wcnt + (size_t)nkeys * W; ps.pfl_rows = 0;
+        }
+        if (!by_class) { std::fill(ps.wpos, ps.wpos + (size_t)nkeys * W, NONE); std::fill(ps.wcnt, ps.wcnt + (size_t)nkeys * W, 0u); }  // (by class: every row is written in full below)
         ps.items.assign(W, 0); ps.n_assign.assign(W, 0); ps.asg_qw.assign((size_t)Q * W, 0);
         size_t n_cnt = 0; for (uint32_t k = 0; k < nkeys; k++) n_cnt += cnt.per_key[k].size();
         ctx->cnt_rq.resize(n_cnt); ctx->cnt_variant.resize(n_cnt); ctx->cnt_worker.resize(n_cnt); ctx->cnt_value.resize(n_cnt); ps.ord_cnt.resize(n_cnt);
@@ -597,7 +606,7 @@ struct TickRun {
             const uint32_t q = cnt.keys[k].first; const uint8_t v = cnt.keys[k].second;
             ps.key_rq[k] = q; reinterpret_cast<uint8_t *>(ps.key_var_w.data())[k] = v;
             uint32_t sum = 0, maxc = 0, pos = 0;
-            uint32_t *wp = ps.wpos.data() + (size_t)k * W, *wcn = ps.wcnt.data() + (size_t)k * W, *aq = ps.asg_qw.data() + (size_t)q * W, *items = ps.items.data(), *nas = ps.n_assign.data();
+            uint32_t *wp = ps.wpos + (size_t)k * W, *wcn = ps.wcnt + (size_t)k * W, *aq = ps.asg_qw.data() + (size_t)q * W, *items = ps.items.data(), *nas = ps.n_assign.data();
             if (by_class) {  // separable tick: the count of a worker is its class's; sequential passes instead of scattering (worker, count) pairs
                 const uint32_t *xg = cnt.class_x.data() + cnt.key_col[k], *wcl = cnt.wclass.data(); const uint32_t NCc = cnt.n_cols;
                 const std::vector<uint32_t> &wi = cnt.lists[cnt.key_list[k]].widx;
@@ -711,7 +720,7 @@ struct TickRun {
             ps.wm_order = ps.cached_order;
         }
         ps.new_pf_total.assign(Q, 0); ps.pfl_size.assign(Q, 0);
-        ps.pfq_src.clear(); ps.pfq_size.clear(); ps.pfl_j.clear();
+        ps.pfq_src.clear(); ps.pfq_size.clear(); ps.pfl_rows = 0;
         pfq_rq.clear();
         {
             // state of every queue after the takes: first level that still has tasks
@@ -744,10 +753,10 @@ struct TickRun {
                 if (!psz) continue;
                 ps.pfl_size[q] = psz;
                 pfq_rq.push_back(q);
-                size_t o = ps.pfl_j.size(); ps.pfl_j.resize(o + W);
-                if (prev_row != SIZE_MAX && memcmp(ps.pf_flag.data(), ps.pf_flag_prev.data(), (size_t)W * 4) == 0) memcpy(ps.pfl_j.data() + o, ps.pfl_j.data() + prev_row, (size_t)W * 4);
+                const size_t o = ps.pfl_rows++ * W;  // (at most Q rows: one per request)
+                if (prev_row != SIZE_MAX && memcmp(ps.pf_flag.data(), ps.pf_flag_prev.data(), (size_t)W * 4) == 0) memcpy(ps.pfl_j + o, ps.pfl_j + prev_row, (size_t)W * 4);
                 else {
-                    uint32_t *row = ps.pfl_j.data() + o; const uint32_t *fl = ps.pf_flag.data();
+                    uint32_t *row = ps.pfl_j + o; const uint32_t *fl = ps.pf_flag.data();
                     uint32_t j = 0;
                     for (uint32_t w : ps.wm_order) { const uint32_t f = fl[w]; row[w] = f ? j : NONE; j += f; }
                     ps.pf_flag_prev.swap(ps.pf_flag);
@@ -869,23 +878,25 @@ struct TickRun {
         if (n_sel) {
             if (!ctx->d_sel_task.ensure((size_t)n_sel * 8) || !ctx->d_sel_level.ensure((size_t)n_sel * 2 + 2))
                 return fail(ctx, HQTICK_E_DEVICE, "hipMalloc selection");
-            // pack every plan table into one upload
-            std::vector<uint32_t> &pack = ps.pack; pack.clear();
-            auto put = [&](const std::vector<uint32_t> &v) { size_t o = pack.size(); pack.insert(pack.end(), v.begin(), v.end()); if (v.empty()) pack.push_back(0); return o; };
+            // the plan in one upload: the big tables are already at the head of the pinned buffer (plan_keys / plan_prefill), the small ones go behind them
+            uint32_t *hp = ctx->h_plan.as<uint32_t>();
+            size_t cur = ps.plan_head_words;
+            auto put = [&](const std::vector<uint32_t> &v) { const size_t o = cur; if (!v.empty()) memcpy(hp + cur, v.data(), v.size() * 4); cur += v.size(); if (v.empty()) hp[cur++] = 0; return o; };
+            const size_t o_wpos = 0, o_wcnt = (size_t)nkeys * W, o_pflj = (size_t)2 * nkeys * W;
             size_t o_rq = put(ps.key_rq), o_var = put(ps.key_var_w), o_seg = put(ps.key_seg), o_ordoff = put(ps.key_ord_off), o_ord = put(ps.ord_cnt), o_toff = put(ps.key_t_off),
-                   o_boff = put(ps.key_bits_off), o_wpos = put(ps.wpos), o_wcnt = put(ps.wcnt), o_base = put(ps.rq_sel_base), o_pfs = put(ps.pf_start), o_pfn = put(ps.pf_n),
-                   o_pqs = put(ps.pfq_src), o_pqz = put(ps.pfq_size), o_pflj = put(ps.pfl_j), o_out = put(ps.out_off);
+                   o_boff = put(ps.key_bits_off), o_base = put(ps.rq_sel_base), o_pfs = put(ps.pf_start), o_pfn = put(ps.pf_n),
+                   o_pqs = put(ps.pfq_src), o_pqz = put(ps.pfq_size), o_out = put(ps.out_off);
             size_t o_tb = put(ps.take_base);
-            if (pack.size() & 1) pack.push_back(0);  // 8-byte alignment for the u64 hole list
-            const size_t o_holes = pack.size();
-            for (uint64_t hk : ps.holes) { pack.push_back((uint32_t)(hk & 0xFFFFFFFFu)); pack.push_back((uint32_t)(hk >> 32)); }
-            if (ps.holes.empty()) { pack.push_back(0); pack.push_back(0); }
-            // device record buffer: [task u64 x n_rec][variant u8 x n_rec][kind u8 x n_rec] -> one D2H copy
-            if (!ctx->d_map.ensure(pack.size() * 4 + 16) || !ctx->h_plan.ensure(pack.size() * 4 + 16) ||
+            if (cur & 1) hp[cur++] = 0;  // 8-byte alignment for the u64 hole list
+            const size_t o_holes = cur;
+            for (uint64_t hk : ps.holes) { hp[cur++] = (uint32_t)(hk & 0xFFFFFFFFu); hp[cur++] = (uint32_t)(hk >> 32); }
+            if (ps.holes.empty()) { hp[cur++] = 0; hp[cur++] = 0; }
+            const size_t plan_words = cur;
+            if (plan_words * 4 + 16 > ctx->h_plan.cap) return fail(ctx, HQTICK_E_DEVICE, "mapping plan larger than its buffer");  // (sized in plan_keys)
+            if (!ctx->d_map.ensure(plan_words * 4 + 16) ||
                 !ctx->d_tsweep.ensure((size_t)ps.key_t_off[nkeys] * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) || !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
                 return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
             mark();  // 6: pack
-            memcpy(ctx->h_plan.p, pack.data(), pack.size() * 4);
             const uint32_t *d = ctx->d_map.as<uint32_t>();
             hqk::MapKeys mk{};
             mk.n_keys = nkeys; mk.key_rq = d + o_rq; mk.key_variant = reinterpret_cast<const uint8_t *>(d + o_var); mk.key_seg_start = d + o_seg;
@@ -897,10 +908,10 @@ struct TickRun {
             uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
             flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
             ctx->last_n_sel = n_sel; ctx->last_consumed = false;
-            ctx->last_geom = sc.geom; ctx->last_L = L; ctx->last_Q = Q; ctx->last_G = sc.G; ctx->last_tb = o_tb; ctx->last_plan_bytes = pack.size() * 4; ctx->last_valid = true;
+            ctx->last_geom = sc.geom; ctx->last_L = L; ctx->last_Q = Q; ctx->last_G = sc.G; ctx->last_tb = o_tb; ctx->last_plan_bytes = plan_words * 4; ctx->last_valid = true;
             if (ctx->timing) hqk::time_next_launch(ctx->ev[4], ctx->ev[5]);
             HQ_HIP_TIMED(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
-                                d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, pack.size() * 4, nullptr, ctx->stream));
+                                d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, plan_words * 4, nullptr, ctx->stream));
             if (!sweep_launched) {
                 if (ctx->timing) hqk::time_next_launch(ctx->ev[1], ctx->ev[6]);
                 HQ_HIP_TIMED(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));

@@ -424,7 +424,15 @@ __global__ void __launch_bounds__(256) k_sweep_bits(MapKeys mk) {
     const uint32_t nk = mk.key_ord_off[k + 1] - mk.key_ord_off[k];
     const uint32_t *cnts = mk.ord_cnt + mk.key_ord_off[k];
     const uint32_t words = (nk + 63) >> 6;
-    for (uint32_t j = threadIdx.x; j < words * 64; j += blockDim.x) s_c[j + (j >> 6)] = j < nk ? cnts[j] : 0u;
+    // the counts may sit in pinned host memory (the early launch reads its tables in place): eight loads in flight per thread and round trip — one
+    // load per trip cost the launch four PCIe latencies at 1024 workers per key
+    for (uint32_t j0 = threadIdx.x; j0 < words * 64; j0 += 8 * blockDim.x) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t j = j0 + u * blockDim.x; v[u] = j < nk ? cnts[j] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t j = j0 + u * blockDim.x; if (j < words * 64) s_c[j + (j >> 6)] = v[u]; }
+    }
     __syncthreads();
     const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= n_sweeps) return;
@@ -921,13 +929,13 @@ hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *h
 }
 
 static __global__ void __launch_bounds__(256) k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];  // (launched with one element per thread)
 }
 
 hipError_t copy_pinned_to_hbm(const void *src, void *dst, size_t bytes, hipStream_t s) {
     const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
     if (!n16) return hipSuccess;
-    hipLaunchKernelGGL(k_copy16, dim3((n16 + 1023) / 1024), dim3(256), 0, s, reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(dst), n16);
+    hipLaunchKernelGGL(k_copy16, dim3((n16 + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(dst), n16);  // one PCIe round trip
     return hipGetLastError();
 }
 
@@ -942,14 +950,14 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
         SelPlan64 pa{};
         for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; }
         size_t lds = (size_t)6 * G * 4;
-        const uint32_t nsb = (geom.n_waves + 3) / 4, ncb = n16 ? (n16 + 1023) / 1024 : 0;
+        const uint32_t nsb = (geom.n_waves + 3) / 4, ncb = n16 ? (n16 + 255) / 256 : 0;  // one 16-byte PCIe read per thread: a single round trip (four per thread cost the launch 2.7 us)
         HQK_TIMED_LAUNCH((k_select<4, 0>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
                            reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq);
         return hipGetLastError();
     }
     if (n16) {  // larger plans: copy first (own launch), then select from the HBM copy
-        hipLaunchKernelGGL(k_copy16, dim3((n16 + 1023) / 1024), dim3(256), 0, s, reinterpret_cast<const uint4 *>(plan_src), reinterpret_cast<uint4 *>(plan_dst), n16);
+        hipLaunchKernelGGL(k_copy16, dim3((n16 + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint4 *>(plan_src), reinterpret_cast<uint4 *>(plan_dst), n16);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (!sel) return hipSuccess;

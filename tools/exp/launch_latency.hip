@@ -112,6 +112,28 @@ int main(int argc, char **argv) {
         }
         printf("5 us kernel launched with a stop event (hipExtLaunchKernelGGL): hipEventSynchronize(stop) %.1f | hipEventQuery(stop) spin %.1f | same, event without timing %.1f us\n", med(a), med(b), med(c));
     }
+    {   // host cost of the launch call itself, by flavour (the stream is drained between the calls)
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        std::vector<double> a, b, c, d;
+        for (int it = 0; it < 400; it++) {
+            double t0 = now_us(); hipLaunchKernelGGL(k_empty, dim3(1024), dim3(256), 0, s); double t1 = now_us(); hipStreamSynchronize(s);
+            if (it >= 100) a.push_back(t1 - t0);
+            t0 = now_us(); hipExtLaunchKernelGGL(k_empty, dim3(1024), dim3(256), 0, s, nullptr, nullptr, 0); t1 = now_us(); hipStreamSynchronize(s);
+            if (it >= 100) b.push_back(t1 - t0);
+            t0 = now_us(); hipExtLaunchKernelGGL(k_empty, dim3(1024), dim3(256), 0, s, nullptr, e1, 0); t1 = now_us(); hipStreamSynchronize(s);
+            if (it >= 100) c.push_back(t1 - t0);
+            t0 = now_us(); hipExtLaunchKernelGGL(k_empty, dim3(1024), dim3(256), 0, s, e0, e1, 0); t1 = now_us(); hipStreamSynchronize(s);
+            if (it >= 100) d.push_back(t1 - t0);
+        }
+        printf("launch CALL on the host: hipLaunchKernelGGL %.2f | hipExtLaunchKernelGGL without events %.2f | with a stop event %.2f | with start + stop %.2f us\n", med(a), med(b), med(c), med(d));
+        // two launches back to back, the second with a stop event (what phase C does)
+        std::vector<double> e;
+        for (int it = 0; it < 400; it++) {
+            double t0 = now_us(); hipLaunchKernelGGL(k_empty, dim3(1024), dim3(256), 0, s); hipExtLaunchKernelGGL(k_empty, dim3(1024), dim3(256), 0, s, nullptr, e1, 0); double t1 = now_us(); hipStreamSynchronize(s);
+            if (it >= 100) e.push_back(t1 - t0);
+        }
+        printf("two launch calls back to back (plain, then with a stop event): %.2f us\n", med(e));
+    }
     // a graph of one kernel
     hipGraph_t g; hipGraphExec_t ge;
     hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
