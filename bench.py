@@ -53,7 +53,7 @@ def cpu_baseline(snap, ticks: int):
 
 
 # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md §HBM); None = not collected
-TRAFFIC = {"level_hist": 12_083_990 + 2_250_112, "select_scatter": 11_127_340 + 2_017_088, "expand_mapping": 7_080_119 + 458_752}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
+TRAFFIC = {"level_hist": 12_084_109 + 2_250_112, "select_scatter": 11_147_865 + 2_037_568, "expand_mapping": 7_086_235 + 458_752}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
 
 
 def dag_churn(cfg, steps: int, seed: int, n_classes: int):
