@@ -48,6 +48,11 @@ class Tick:
 
     def __init__(self, config: Optional[abi.Config] = None):
         self.cfg = config or abi.make_config()
+        extra = int(os.environ.get("HQTICK_TEST_FLAGS", "0") or 0)  # campaigns (tools/fuzz_more.py): the same scenarios through another emission form
+        if extra:
+            c = abi.Config.from_buffer_copy(self.cfg)
+            c.flags |= extra
+            self.cfg = c
         self._lib = load()
         ctx = C.c_void_p()
         rc = self._lib.hqtick_create(C.byref(self.cfg), C.byref(ctx))

@@ -13,6 +13,8 @@
 
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 __global__ void k_empty() {}
+struct Big { uint64_t v[96]; };   // 768 bytes of kernel arguments (K4: a 512-byte plan + 20 scalars; K5b: a 27-field table struct)
+__global__ void k_bigargs(Big b, uint32_t *out) { if (out && threadIdx.x == 9999) out[0] = (uint32_t)b.v[3]; }
 // one workgroup: tells the host it has STARTED (flag0), burns `spin` x 10 ns, tells the host it is done (flag1)
 __global__ void k_marks(volatile uint32_t *flag, uint32_t seq, uint32_t spin) {
     if (threadIdx.x == 0) flag[0] = seq;
@@ -126,6 +128,16 @@ int main(int argc, char **argv) {
             if (it >= 100) d.push_back(t1 - t0);
         }
         printf("launch CALL on the host: hipLaunchKernelGGL %.2f | hipExtLaunchKernelGGL without events %.2f | with a stop event %.2f | with start + stop %.2f us\n", med(a), med(b), med(c), med(d));
+        {
+            Big big{}; std::vector<double> f, g2;
+            for (int it = 0; it < 400; it++) {
+                double t0 = now_us(); hipLaunchKernelGGL(k_bigargs, dim3(1024), dim3(256), 0, s, big, (uint32_t *)nullptr); double t1 = now_us(); hipStreamSynchronize(s);
+                if (it >= 100) f.push_back(t1 - t0);
+                t0 = now_us(); hipExtLaunchKernelGGL(k_bigargs, dim3(1024), dim3(256), 12000, s, nullptr, e1, 0, big, (uint32_t *)nullptr); t1 = now_us(); hipStreamSynchronize(s);
+                if (it >= 100) g2.push_back(t1 - t0);
+            }
+            printf("launch CALL with 776 bytes of kernel arguments: plain %.2f | with a stop event and 12 KB of dynamic LDS %.2f us\n", med(f), med(g2));
+        }
         // two launches back to back, the second with a stop event (what phase C does)
         std::vector<double> e;
         for (int it = 0; it < 400; it++) {
