@@ -154,7 +154,7 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
     rq_of = snap.task_rq.copy()
     alive = np.ones(len(rq_of), bool)
     next_id = int(snap.task_id[-1]) + 1
-    new_ids = np.zeros(0, np.uint64); new_prio = np.zeros(0, np.uint64); new_rq = np.zeros(0, np.uint32)
+    n_staged = 0
     rows, last_snap, prev_free, n_changed = [], None, None, []
     for step in range(steps + 3):
         free = total - running @ need
@@ -163,8 +163,8 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
         cur = dataclasses.replace(snap, _keep=[], worker_free=free.astype(np.uint64), assigned=assigned, task_id=np.zeros(0, np.uint64), task_priority=np.zeros(0, np.uint64), task_rq=np.zeros(0, np.uint32))
         sc = cur.to_c()
         a = time.perf_counter()
-        if len(new_ids):
-            ts.ready_add(new_ids, new_prio, new_rq)
+        if n_staged:
+            ts.ready_add_staged(n_staged)  # the arrivals were written straight into the library's pinned staging buffer (hqtick_ready_add_stage): no copy on the host
         if prev_free is None:
             ts.cluster_upload(sc)
         else:  # the rows the reactor's handlers touched since the last tick (tasks started by it, tasks finished since): deltas into the HBM tables
@@ -188,10 +188,13 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
         gone = abi.record_task_ids(res, W)
         idx = (gone & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1
         alive[idx] = False
+        n_staged = len(idx)
+        v_id, v_prio, v_rq = ts.ready_add_stage(n_staged)  # the reactor writes the new ready tasks where the merge kernel's upload starts from
         new_rq = rq_of[idx]
+        v_rq[:] = new_rq
         rq_of = np.concatenate([rq_of, new_rq]); alive = np.concatenate([alive, np.ones(len(idx), bool)])
-        new_ids = np.arange(next_id, next_id + len(idx), dtype=np.uint64); next_id += len(idx)
-        new_prio = np.full(len(idx), snap.task_priority[0], np.uint64)
+        v_id[:] = np.arange(next_id, next_id + len(idx), dtype=np.uint64); next_id += len(idx)
+        v_prio[:] = snap.task_priority[0]
         rows.append(dict(add=b - a, tick=c - b, consume=d - c, assigned=int(cv.sum()), handed=n_rec, status=int(res.status), optimal=int(res.is_optimal), canonical=int(res.is_canonical),
                          t_scan=res.t_scan_us, t_batches=res.t_batches_us, t_solve=res.t_solve_us, t_map=res.t_mapping_us, **{k: ks[k] for k in
                          ("n_classes", "n_classes_device", "n_classes_host", "block_solve_us", "block_steps_max", "solve_classify_us", "solve_blocks_us", "solve_decode_us", "level_hist_us", "select_us", "other_us")}))
@@ -480,6 +483,8 @@ def main():
         # and is updated by deltas (hqtick_ready_consume_last / hqtick_ready_add) — nothing is re-uploaded but the new tasks.
         ts = Tick(cfg)
         ts.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
+        if not args.no_resident_cluster:
+            ts.cluster_upload(sc)  # as in the headline loop: the workers are empty again before every tick, no row changes
         def handed_out(res):  # ids of the records of a tick (assigned + prefilled)
             return abi.record_task_ids(res, W)
 
@@ -493,9 +498,11 @@ def main():
             k = len(gone)
             new_rq = rq_of[(gone & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1]  # arrivals replace exactly what left, class by class
             rq_of = np.concatenate([rq_of, new_rq])
-            new_ids = np.arange(next_id, next_id + k, dtype=np.uint64); next_id += k
-            new_prio = np.full(k, snap.task_priority[0], np.uint64)
-            a = time.perf_counter(); ts.ready_add(new_ids, new_prio, new_rq)
+            v_id, v_prio, v_rq = ts.ready_add_stage(k)  # the arrivals are written straight into the library's pinned staging buffer
+            v_id[:] = np.arange(next_id, next_id + k, dtype=np.uint64); next_id += k
+            v_prio[:] = snap.task_priority[0]
+            v_rq[:] = new_rq
+            a = time.perf_counter(); ts.ready_add_staged(k)
             b = time.perf_counter(); res = ts.tick_raw(sc, resident=True)
             c = time.perf_counter(); ts.ready_consume_last(); torch.cuda.synchronize()
             d = time.perf_counter()
@@ -505,7 +512,7 @@ def main():
         t_add, t_tick, t_cons = (np.asarray(x[2:]) for x in (t_add, t_tick, t_cons))
         step = t_add + t_tick + t_cons
         out["steady_state"] = {
-            "what": "per step: hqtick_ready_add(new tasks) + hqtick_run_resident + hqtick_ready_consume_last; workers empty again before every tick (sleep-0 tasks)",
+            "what": "per step: hqtick_ready_add_staged(new tasks, written in place into the pinned staging buffer) + hqtick_run_resident + hqtick_ready_consume_last; workers empty again before every tick (sleep-0 tasks)",
             "steps": args.steady_steps, "ready_set_before_each_tick": int(ts.ready_count()) + per_step, "tasks_handed_out_per_step": per_step,
             "p50_step_ms": 1e3 * float(np.median(step)), "tasks_per_s": per_step / float(np.median(step)),
             "p50_add_us": 1e6 * float(np.median(t_add)), "p50_tick_us": 1e6 * float(np.median(t_tick)), "p50_consume_us": 1e6 * float(np.median(t_cons)),

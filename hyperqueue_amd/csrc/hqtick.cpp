@@ -79,6 +79,7 @@ struct hqtick_ctx {
     DevBuf d_tid, d_tprio, d_trq; uint64_t n_ready = 0; bool resident = false;  // n_ready = physical length (tombstones included)
     DevBuf d_tid2, d_tprio2, d_trq2, d_slice, d_add, d_pre8;   // alternate columns + scratch of the resident deltas (hqtick_ready_*)
     uint64_t n_live = 0; uint32_t last_n_sel = 0; bool last_consumed = true;
+    uint64_t add_staged_n = 0;  // tasks hqtick_ready_add_stage made room for (0: nothing staged)
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
@@ -1229,23 +1230,55 @@ int hqtick_ready_remove(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id) {
     return (int)cnt[0];  // number of tasks that were in the set
 }
 
-int hqtick_ready_add(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority, const uint32_t *task_rq) {
-    if (!ctx || (n && (!task_id || !task_priority || !task_rq))) return HQTICK_E_INVALID;
+// The batch of new ready tasks is staged in pinned memory (a pageable hipMemcpy of a few MB costs ~1 ms in page pinning).  The caller can write it there
+// directly: hqtick_ready_add_stage hands out the three column pointers for n tasks, hqtick_ready_add_staged merges what was written (no copy on the host);
+// hqtick_ready_add = stage + memcpy + merge for callers that have the columns elsewhere.
+namespace {
+struct AddLayout { size_t o_p, o_q, bytes; };
+AddLayout add_layout(uint64_t n) { AddLayout L; L.o_p = (n * 8 + 15) & ~(size_t)15; L.o_q = L.o_p * 2; L.bytes = L.o_q + n * 4 + 16; return L; }
+}  // namespace
+
+int hqtick_ready_add_stage(hqtick_ctx *ctx, uint64_t n, uint64_t **task_id, uint64_t **task_priority, uint32_t **task_rq) {
+    if (!ctx || !task_id || !task_priority || !task_rq) return HQTICK_E_INVALID;
     if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set (hqtick_upload_ready with n = 0 creates an empty one)");
-    if (n == 0) return 0;
     if (n > 0xFFFFFFFFull) return fail(ctx, HQTICK_E_CAPACITY, "more than 2^32 ids in one delta");
+    HQ_HIP(hipSetDevice(ctx->device));
+    const AddLayout L = add_layout(n);
+    if (!ctx->h_add.ensure(L.bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc delta staging");
+    unsigned char *h = ctx->h_add.as<unsigned char>();
+    *task_id = reinterpret_cast<uint64_t *>(h); *task_priority = reinterpret_cast<uint64_t *>(h + L.o_p); *task_rq = reinterpret_cast<uint32_t *>(h + L.o_q);
+    ctx->add_staged_n = n;
+    return 0;
+}
+
+int hqtick_ready_add_staged(hqtick_ctx *ctx, uint64_t n) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set (hqtick_upload_ready with n = 0 creates an empty one)");
+    if (n > ctx->add_staged_n) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add_staged: more tasks than hqtick_ready_add_stage made room for");
+    const AddLayout L = add_layout(ctx->add_staged_n);  // the layout the pointers were handed out for
+    ctx->add_staged_n = 0;
+    if (n == 0) return 0;
+    const unsigned char *h = ctx->h_add.as<unsigned char>();
+    const uint64_t *task_id = reinterpret_cast<const uint64_t *>(h); const uint32_t *task_rq = reinterpret_cast<const uint32_t *>(h + L.o_q);
     if (ctx->n_ready == 0) {  // nothing resident: the batch is copied as it is, so it is checked here; otherwise the merge kernel validates it
         for (uint64_t i = 1; i < n; i++) if (task_id[i - 1] >= task_id[i]) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
         for (uint64_t i = 0; i < n; i++) if (task_rq[i] == 0xFFFFFFFFu) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
     }
     HQ_HIP(hipSetDevice(ctx->device));
-    // stage through pinned memory: a pageable hipMemcpy of a few MB costs ~1 ms each in page pinning
-    size_t o_p = (n * 8 + 15) & ~(size_t)15, o_q = o_p * 2, bytes = o_q + n * 4 + 16;
-    if (!ctx->d_add.ensure(bytes) || !ctx->h_add.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
-    unsigned char *h = ctx->h_add.as<unsigned char>(), *d = ctx->d_add.as<unsigned char>();
-    memcpy(h, task_id, n * 8); memcpy(h + o_p, task_priority, n * 8); memcpy(h + o_q, task_rq, n * 4);
-    HQ_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + o_p), reinterpret_cast<const uint32_t *>(d + o_q), (uint32_t)n);
+    if (!ctx->d_add.ensure(L.bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
+    unsigned char *d = ctx->d_add.as<unsigned char>();
+    HQ_HIP(hipMemcpyAsync(d, h, L.o_q + n * 4, hipMemcpyHostToDevice, ctx->stream));
+    return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + L.o_p), reinterpret_cast<const uint32_t *>(d + L.o_q), (uint32_t)n);
+}
+
+int hqtick_ready_add(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority, const uint32_t *task_rq) {
+    if (!ctx || (n && (!task_id || !task_priority || !task_rq))) return HQTICK_E_INVALID;
+    if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set (hqtick_upload_ready with n = 0 creates an empty one)");
+    if (n == 0) return 0;
+    uint64_t *hi = nullptr, *hp = nullptr; uint32_t *hq = nullptr;
+    if (int rc = hqtick_ready_add_stage(ctx, n, &hi, &hp, &hq)) return rc;
+    memcpy(hi, task_id, n * 8); memcpy(hp, task_priority, n * 8); memcpy(hq, task_rq, n * 4);
+    return hqtick_ready_add_staged(ctx, n);
 }
 
 // ---------------------------------------------------------------------------------------------- dependency graph (f1)

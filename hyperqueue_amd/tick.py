@@ -115,6 +115,19 @@ class Tick:
         self._lib.hqtick_ready_add.argtypes = [C.c_void_p, C.c_uint64, abi.u64p, abi.u64p, abi.u32p]
         self._chk(self._lib.hqtick_ready_add(self._ctx, len(a), a.ctypes.data_as(abi.u64p), b.ctypes.data_as(abi.u64p), c.ctypes.data_as(abi.u32p)))
 
+    def ready_add_stage(self, n: int):
+        """(ids u64[n], priorities u64[n], rqs u32[n]) as numpy views of the library's pinned staging buffer: fill them, then ready_add_staged(n)"""
+        pi, pp, pq = abi.u64p(), abi.u64p(), abi.u32p()
+        self._lib.hqtick_ready_add_stage.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(abi.u64p), C.POINTER(abi.u64p), C.POINTER(abi.u32p)]
+        self._chk(self._lib.hqtick_ready_add_stage(self._ctx, n, C.byref(pi), C.byref(pp), C.byref(pq)))
+        if n == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32)
+        return (np.ctypeslib.as_array(pi, shape=(n,)), np.ctypeslib.as_array(pp, shape=(n,)), np.ctypeslib.as_array(pq, shape=(n,)))
+
+    def ready_add_staged(self, n: int):
+        self._lib.hqtick_ready_add_staged.argtypes = [C.c_void_p, C.c_uint64]
+        self._chk(self._lib.hqtick_ready_add_staged(self._ctx, n))
+
     def ready_compact(self):
         self._lib.hqtick_ready_compact.argtypes = [C.c_void_p]
         self._chk(self._lib.hqtick_ready_compact(self._ctx))

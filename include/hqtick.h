@@ -321,6 +321,8 @@ int hqtick_run_resident(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick
  *   hqtick_ready_remove        ids (any order) leave the set — TaskQueue::remove on cancel        scheduler/taskqueue.rs:146-217
  *                              returns how many of them were present
  *   hqtick_ready_add           new ready tasks, ids strictly ascending — TaskQueues::add_ready_task scheduler/taskqueue.rs:37-43
+ *   hqtick_ready_add_stage /   the same without a copy on the host (ABI 6): _stage hands out the three columns of the library's pinned staging buffer for
+ *   hqtick_ready_add_staged    n tasks (valid until the next ready_add* call), the reactor writes the new tasks there, _staged(n' <= n) merges the first n'
  *   hqtick_ready_compact       drop the tombstones now (done automatically when they outnumber the live tasks, and by every add)
  *   hqtick_ready_count         live tasks in the set
  * Removal writes a tombstone into the rq column (4 B per task); add / compact stream the columns once (20 B read + 20 B written per
@@ -329,6 +331,8 @@ int hqtick_run_resident(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick
 int hqtick_ready_consume_last(hqtick_ctx *ctx);
 int hqtick_ready_remove(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id);
 int hqtick_ready_add(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority, const uint32_t *task_rq);
+int hqtick_ready_add_stage(hqtick_ctx *ctx, uint64_t n, uint64_t **task_id, uint64_t **task_priority, uint32_t **task_rq);
+int hqtick_ready_add_staged(hqtick_ctx *ctx, uint64_t n);
 int hqtick_ready_compact(hqtick_ctx *ctx);
 uint64_t hqtick_ready_count(const hqtick_ctx *ctx);
 

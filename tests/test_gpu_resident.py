@@ -31,7 +31,13 @@ class ResidentBackend:
                 assert self.t.ready_remove(np.asarray(rm[::-1], np.uint64)) == len(rm)  # any order
                 self.stats["removes"] += len(rm)
             if add:
-                self.t.ready_add(np.asarray(add, np.uint64), np.asarray([want[i][0] for i in add], np.uint64), np.asarray([want[i][1] for i in add], np.uint32))
+                a_id, a_prio, a_rq = np.asarray(add, np.uint64), np.asarray([want[i][0] for i in add], np.uint64), np.asarray([want[i][1] for i in add], np.uint32)
+                if self.stats["adds"] % 2:  # every other delta through the zero-copy form: written in place into the pinned staging buffer (with room to spare)
+                    v_id, v_prio, v_rq = self.t.ready_add_stage(len(add) + 3)
+                    v_id[:len(add)] = a_id; v_prio[:len(add)] = a_prio; v_rq[:len(add)] = a_rq
+                    self.t.ready_add_staged(len(add))
+                else:
+                    self.t.ready_add(a_id, a_prio, a_rq)
                 self.stats["adds"] += len(add)
         self.mirror = dict(want)
         assert self.t.ready_count() == len(want)
@@ -214,6 +220,20 @@ def test_resident_add_rejects_duplicates_and_unsorted():
     assert t.ready_count() == 1_990
     t.ready_compact()
     assert t.ready_count() == 1_990
+    # the zero-copy form: more tasks committed than staged for is refused, a commit without a stage too; a shorter commit takes the first n'
+    with pytest.raises(HqTickError):
+        t.ready_add_staged(1)
+    v_id, v_prio, v_rq = t.ready_add_stage(4)
+    with pytest.raises(HqTickError):
+        t.ready_add_staged(5)
+    v_id, v_prio, v_rq = t.ready_add_stage(4)
+    v_id[:] = snap.task_id[-1] + np.arange(1, 5, dtype=np.uint64); v_prio[:] = snap.task_priority[0]; v_rq[:] = 0
+    t.ready_add_staged(3)
+    assert t.ready_count() == 1_993
+    v_id, v_prio, v_rq = t.ready_add_stage(1)  # a duplicate through the staged form is caught by the merge kernel like any other
+    v_id[:] = snap.task_id[-1] + np.uint64(2); v_prio[:] = snap.task_priority[0]; v_rq[:] = 0
+    with pytest.raises(HqTickError):
+        t.ready_add_staged(1)
 
 
 def test_resident_steady_state_full_c3():
