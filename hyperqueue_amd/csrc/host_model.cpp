@@ -650,7 +650,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             hqhb::insertion_order(key_hash.data(), (uint32_t)key_hash.size(), ord);
             for (uint32_t k : ord) { out.keys.push_back(key_list[k]); out.per_key.push_back(std::move(key_counts[k])); out.key_col.push_back(key_g[k]); out.key_list.push_back(key_l[k]); }
             if (!pb.custom) {  // the per-class form of the same counts, for the mapping plan (host_model.h)
-                out.by_class = true; out.n_cols = NC;
+                out.by_class = true; out.n_cols = NC; out.one_class = ncls == 1 && solver_workers.size() == ws.n;
                 out.class_x = X; out.class_x.resize((size_t)(ncls + 1) * NC, 0);
                 out.wclass.assign(ws.n, ncls);
                 for (uint32_t w : solver_workers) out.wclass[w] = wclass[w];

@@ -126,6 +126,7 @@ struct Counts {
     // (workers outside the solver carry the all-zero class n_classes), and keys whose worker lists are equal share one list (workers in Map order).
     struct WorkerList { std::vector<uint32_t> widx; };
     bool by_class = false;
+    bool one_class = false;  // by_class with a single class that holds every worker: the count of a key is one number
     uint32_t n_cols = 0;
     std::vector<uint32_t> wclass, class_x, key_col, key_list;
     std::vector<WorkerList> lists;

@@ -49,7 +49,7 @@ namespace {
 struct PlanScratch {
     std::vector<uint32_t> q_total, pf_n, pf_start, seq_taken, pf_drained, zq_taken, new_pf_total, pfl_size, rq_sel_base;
     std::vector<uint32_t> key_seg, key_sum, key_rq, key_var_w, key_ord_off, ord_cnt, key_t_off, key_bits_off;
-    std::vector<uint32_t> list_pos, pf_flag, pf_flag_prev, items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, out_off, take_base, mn_first, pack;
+    std::vector<uint32_t> list_pos, pf_flag, pf_flag_prev, sn_ok, items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, out_off, take_base, mn_first, pack;
     std::vector<uint8_t> now_mn;
     // the three per-(key | request, worker) tables of the plan are built IN the pinned buffer K4's ride-along workgroups copy from (a memcpy of ~100 KB per
     // tick otherwise): [wpos nkeys * W][wcnt nkeys * W][pfl_j Q * W] at its head, the small tables behind them (phase_c)
@@ -582,6 +582,7 @@ struct TickRun {
         ps.key_seg.assign(nkeys, 0); ps.key_sum.assign(nkeys, 0); ps.key_rq.assign(nkeys, 0); ps.key_var_w.assign((nkeys + 3) / 4 + 1, 0);
         ps.key_ord_off.assign(nkeys + 1, 0); ps.key_t_off.assign(nkeys + 1, 0); ps.key_bits_off.assign(nkeys + 1, 0);
         const bool by_class = cnt.by_class && cnt.wclass.size() == W && cnt.key_col.size() == nkeys;
+        ctx->last_valid = false;  // the previous tick's plan is overwritten from here on: hqtick_ready_consume_last refers to THIS tick or to none (if it fails)
         {   // the big tables live at the head of the pinned plan buffer; everything else of the plan (phase_c) is a few KB behind them
             ps.plan_head_words = (size_t)nkeys * W * 2 + (size_t)Q * W;
             size_t n_cnt0 = 0; for (uint32_t k = 0; k < nkeys; k++) n_cnt0 += cnt.per_key[k].size();
@@ -611,11 +612,13 @@ struct TickRun {
             if (by_class) {  // separable tick: the count of a worker is its class's; sequential passes instead of scattering (worker, count) pairs
                 const uint32_t *xg = cnt.class_x.data() + cnt.key_col[k], *wcl = cnt.wclass.data(); const uint32_t NCc = cnt.n_cols;
                 const std::vector<uint32_t> &wi = cnt.lists[cnt.key_list[k]].widx;
-                for (uint32_t w = 0; w < W; w++) { const uint32_t c = xg[(size_t)wcl[w] * NCc]; wcn[w] = c; items[w] += c; aq[w] += c; }
+                if (cnt.one_class) { const uint32_t c = xg[0]; for (uint32_t w = 0; w < W; w++) { wcn[w] = c; items[w] += c; aq[w] += c; } }  // a cold tick on identical workers (vectorises)
+                else for (uint32_t w = 0; w < W; w++) { const uint32_t c = xg[(size_t)wcl[w] * NCc]; wcn[w] = c; items[w] += c; aq[w] += c; }
                 memcpy(wp, ps.list_pos.data() + (size_t)cnt.key_list[k] * W, (size_t)W * 4);
                 pos = (uint32_t)wi.size();
                 std::fill(c_rq + ci, c_rq + ci + pos, q); memset(c_var + ci, v, pos); memcpy(c_w + ci, wi.data(), (size_t)pos * 4);
-                for (uint32_t i = 0; i < pos; i++) { const uint32_t c = wcn[wi[i]]; c_v[ci + i] = c; c_ord[ci + i] = c; sum += c; maxc = std::max(maxc, c); }
+                if (cnt.one_class) { const uint32_t c = xg[0]; std::fill(c_v + ci, c_v + ci + pos, c); std::fill(c_ord + ci, c_ord + ci + pos, c); sum = c * pos; maxc = c; }
+                else for (uint32_t i = 0; i < pos; i++) { const uint32_t c = wcn[wi[i]]; c_v[ci + i] = c; c_ord[ci + i] = c; sum += c; maxc = std::max(maxc, c); }
                 ci += pos;
             } else for (auto &wc : cnt.per_key[k]) {  // (worker, count) in the Map's iteration order
                 const uint32_t w = wc.first, c = wc.second;
@@ -718,8 +721,10 @@ struct TickRun {
                 ps.cached_ids.assign(s->worker_id, s->worker_id + W);
                 hqhb::insertion_order_u32(s->worker_id, W, ps.cached_order);
             }
-            ps.wm_order = ps.cached_order;
         }
+        const std::vector<uint32_t> &wm_order = s->worker_map_rank ? ps.wm_order : ps.cached_order;  // (no copy of the cached order)
+        ps.sn_ok.resize(W);  // per worker: still a single-node worker after this tick's multi-node placements
+        for (uint32_t w = 0; w < W; w++) ps.sn_ok[w] = ((s->worker_flags ? (s->worker_flags[w] & HQ_WORKER_SN) != 0 : true) && !ps.now_mn[w]) ? 1u : 0u;
         ps.new_pf_total.assign(Q, 0); ps.pfl_size.assign(Q, 0);
         ps.pfq_src.clear(); ps.pfq_size.clear(); ps.pfl_rows = 0;
         pfq_rq.clear();
@@ -744,10 +749,9 @@ struct TickRun {
                 const uint32_t *aq = ps.asg_qw.data() + (size_t)q * W, *hp = ps.has_pf.data() + (size_t)q * W;
                 ps.pf_flag.resize(W);
                 uint32_t n_elig = 0;
-                for (uint32_t w = 0; w < W; w++) {
-                    const uint32_t sn = ((s->worker_flags ? (s->worker_flags[w] & HQ_WORKER_SN) != 0 : true) && !ps.now_mn[w]) ? 1u : 0u;
-                    const uint32_t f = sn & (aq[w] > 0 ? 1u : 0u) & (hp[w] == 0 ? 1u : 0u);
-                    ps.pf_flag[w] = f; n_elig += f;
+                {
+                    uint32_t *fl = ps.pf_flag.data(); const uint32_t *sn = ps.sn_ok.data();
+                    for (uint32_t w = 0; w < W; w++) { const uint32_t f = sn[w] & (aq[w] != 0 ? 1u : 0u) & (hp[w] == 0 ? 1u : 0u); fl[w] = f; n_elig += f; }  // (vectorises)
                 }
                 if (!n_elig) continue;
                 uint32_t psz = std::min(size / n_elig, ctx->cfg.proactive_filling_max);
@@ -759,7 +763,7 @@ struct TickRun {
                 else {
                     uint32_t *row = ps.pfl_j + o; const uint32_t *fl = ps.pf_flag.data();
                     uint32_t j = 0;
-                    for (uint32_t w : ps.wm_order) { const uint32_t f = fl[w]; row[w] = f ? j : NONE; j += f; }
+                    for (uint32_t w : wm_order) { const uint32_t f = fl[w]; row[w] = f ? j : NONE; j += f; }
                     ps.pf_flag_prev.swap(ps.pf_flag);
                 }
                 prev_row = o;
