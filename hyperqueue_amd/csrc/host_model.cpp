@@ -637,8 +637,9 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                         l.order = cached_worker_order(ids);
                         wl = &l;
                     }
-                    std::vector<std::pair<uint32_t, uint32_t>> ordered(wl->order.size());
-                    {
+                    std::vector<std::pair<uint32_t, uint32_t>> ordered;
+                    if (pb.custom) {  // (the tick's own results carry the per-class form instead and build pairs on demand: Counts::pairs)
+                        ordered.resize(wl->order.size());
                         const uint32_t *word = wl->order.data(), *widx = wl->widx.data(), *xg = X.data() + g;
                         std::pair<uint32_t, uint32_t> *o = ordered.data();
                         for (size_t k = 0, e = ordered.size(); k < e; k++) { const uint32_t w = widx[word[k]]; o[k] = {w, xg[(size_t)wclass[w] * NC]}; }
@@ -650,7 +651,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             hqhb::insertion_order(key_hash.data(), (uint32_t)key_hash.size(), ord);
             for (uint32_t k : ord) { out.keys.push_back(key_list[k]); out.per_key.push_back(std::move(key_counts[k])); out.key_col.push_back(key_g[k]); out.key_list.push_back(key_l[k]); }
             if (!pb.custom) {  // the per-class form of the same counts, for the mapping plan (host_model.h)
-                out.by_class = true; out.n_cols = NC; out.one_class = ncls == 1 && solver_workers.size() == ws.n;
+                out.by_class = true; out.pairs_built = false; out.n_cols = NC; out.one_class = ncls == 1 && solver_workers.size() == ws.n;
                 out.class_x = X; out.class_x.resize((size_t)(ncls + 1) * NC, 0);
                 out.wclass.assign(ws.n, ncls);
                 for (uint32_t w : solver_workers) out.wclass[w] = wclass[w];

@@ -130,9 +130,23 @@ struct Counts {
     uint32_t n_cols = 0;
     std::vector<uint32_t> wclass, class_x, key_col, key_list;
     std::vector<WorkerList> lists;
+    // by_class results leave per_key EMPTY (building 8 x 1024 pairs costs the cold tick 3 us nobody needs): pairs() builds them on demand
+    bool pairs_built = true;
+    void pairs() {
+        if (pairs_built) return;
+        per_key.assign(keys.size(), {});
+        for (size_t k = 0; k < keys.size(); k++) {
+            const std::vector<uint32_t> &wi = lists[key_list[k]].widx;
+            auto &out = per_key[k]; out.resize(wi.size());
+            for (size_t i = 0; i < wi.size(); i++) out[i] = {wi[i], class_x[(size_t)wclass[wi[i]] * n_cols + key_col[k]]};
+        }
+        pairs_built = true;
+    }
+    size_t key_size(size_t k) const { return pairs_built ? per_key[k].size() : lists[key_list[k]].widx.size(); }  // workers of key k
     bool is_optimal = true;
     bool is_canonical = true;  // every solve completed its tie-break phase
     bool empty() const {
+        if (!pairs_built) { for (size_t k = 0; k < keys.size(); k++) if (key_size(k)) return false; }
         for (auto &k : per_key) if (!k.empty()) return false;
         for (auto &k : mn_sets) if (!k.empty()) return false;
         return true;
@@ -141,7 +155,11 @@ struct Counts {
         uint32_t h = 2166136261u;
         auto mix = [&](uint32_t v) { for (int i = 0; i < 4; i++) { h ^= (v >> (8 * i)) & 0xFFu; h *= 16777619u; } };
         mix(is_optimal ? 1u : 0u);
-        for (size_t k = 0; k < keys.size(); k++) { mix(keys[k].first); mix(keys[k].second); for (auto &wc : per_key[k]) { mix(wc.first); mix(wc.second); } }
+        for (size_t k = 0; k < keys.size(); k++) {
+            mix(keys[k].first); mix(keys[k].second);
+            if (pairs_built) for (auto &wc : per_key[k]) { mix(wc.first); mix(wc.second); }
+            else for (uint32_t w : lists[key_list[k]].widx) { mix(w); mix(class_x[(size_t)wclass[w] * n_cols + key_col[k]]); }  // the same (worker, count) sequence
+        }
         for (size_t k = 0; k < mn_rq.size(); k++) { mix(mn_rq[k]); for (auto &set : mn_sets[k]) { mix(0xFFFFFFFFu); for (uint32_t w : set) mix(w); } }
         return h;
     }

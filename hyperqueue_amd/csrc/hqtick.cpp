@@ -534,6 +534,7 @@ struct TickRun {
 
     // host mirror of the K5 arithmetic: the worker that receives the task at index idx of key k's take_tasks() vector
     uint32_t worker_of(uint32_t k, uint32_t idx) {
+        cnt.pairs();  // (rare path: redirects)
         const auto &pk = cnt.per_key[k];
         std::vector<uint32_t> &T = key_T[k];
         if (T.empty()) {
@@ -585,14 +586,14 @@ struct TickRun {
         ctx->last_valid = false;  // the previous tick's plan is overwritten from here on: hqtick_ready_consume_last refers to THIS tick or to none (if it fails)
         {   // the big tables live at the head of the pinned plan buffer; everything else of the plan (phase_c) is a few KB behind them
             ps.plan_head_words = (size_t)nkeys * W * 2 + (size_t)Q * W;
-            size_t n_cnt0 = 0; for (uint32_t k = 0; k < nkeys; k++) n_cnt0 += cnt.per_key[k].size();
+            size_t n_cnt0 = 0; for (uint32_t k = 0; k < nkeys; k++) n_cnt0 += cnt.key_size(k);
             const size_t small = (size_t)8 * (nkeys + 4) + n_cnt0 + (size_t)6 * (Q + 2) + (W + 2) + (size_t)2 * sc.G + (size_t)2 * s->n_retracting + 64;
             if (!ctx->h_plan.ensure((ps.plan_head_words + small) * 4 + 64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc plan");
             ps.wpos = ctx->h_plan.as<uint32_t>(); ps.wcnt = ps.wpos + (size_t)nkeys * W; ps.pfl_j = ps.wcnt + (size_t)nkeys * W; ps.pfl_rows = 0;
         }
         if (!by_class) { std::fill(ps.wpos, ps.wpos + (size_t)nkeys * W, NONE); std::fill(ps.wcnt, ps.wcnt + (size_t)nkeys * W, 0u); }  // (by class: every row is written in full below)
         ps.items.assign(W, 0); ps.n_assign.assign(W, 0); ps.asg_qw.assign((size_t)Q * W, 0);
-        size_t n_cnt = 0; for (uint32_t k = 0; k < nkeys; k++) n_cnt += cnt.per_key[k].size();
+        size_t n_cnt = 0; for (uint32_t k = 0; k < nkeys; k++) n_cnt += cnt.key_size(k);
         ctx->cnt_rq.resize(n_cnt); ctx->cnt_variant.resize(n_cnt); ctx->cnt_worker.resize(n_cnt); ctx->cnt_value.resize(n_cnt); ps.ord_cnt.resize(n_cnt);
         uint32_t *c_rq = ctx->cnt_rq.data(), *c_w = ctx->cnt_worker.data(), *c_v = ctx->cnt_value.data(), *c_ord = ps.ord_cnt.data(); uint8_t *c_var = ctx->cnt_variant.data();
         size_t ci = 0;
@@ -620,7 +621,7 @@ struct TickRun {
                 if (cnt.one_class) { const uint32_t c = xg[0]; std::fill(c_v + ci, c_v + ci + pos, c); std::fill(c_ord + ci, c_ord + ci + pos, c); sum = c * pos; maxc = c; }
                 else for (uint32_t i = 0; i < pos; i++) { const uint32_t c = wcn[wi[i]]; c_v[ci + i] = c; c_ord[ci + i] = c; sum += c; maxc = std::max(maxc, c); }
                 ci += pos;
-            } else for (auto &wc : cnt.per_key[k]) {  // (worker, count) in the Map's iteration order
+            } else for (auto &wc : (cnt.pairs(), cnt.per_key[k])) {  // (worker, count) in the Map's iteration order
                 const uint32_t w = wc.first, c = wc.second;
                 sum += c; maxc = std::max(maxc, c);
                 c_rq[ci] = q; c_var[ci] = v; c_w[ci] = w; c_v[ci] = c; c_ord[ci] = c; ci++;
@@ -829,9 +830,14 @@ struct TickRun {
         ctx->new_free.assign(s->worker_free, s->worker_free + (size_t)W * R);
         for (uint32_t k = 0; k < nkeys; k++) {
             const hqhost::VariantView &vv = pb.variants[pb.rqs[cnt.keys[k].first].first_variant + cnt.keys[k].second];
-            for (auto &wc : cnt.per_key[k]) for (uint32_t e = 0; e < vv.n_entries; e++) {
-                uint64_t &f = ctx->new_free[(size_t)wc.first * R + vv.res[e]];
-                if (vv.kind[e] == HQ_ENTRY_ALL) f = 0; else { uint64_t d = vv.amount[e] * (uint64_t)wc.second; f = f > d ? f - d : 0; }
+            const uint32_t *wcn = ps.wcnt + (size_t)k * W;  // this key's count per worker (0 = none): the plan's own row
+            for (uint32_t w = 0; w < W; w++) {
+                const uint32_t c = wcn[w];
+                if (!c) continue;
+                for (uint32_t e = 0; e < vv.n_entries; e++) {
+                    uint64_t &f = ctx->new_free[(size_t)w * R + vv.res[e]];
+                    if (vv.kind[e] == HQ_ENTRY_ALL) f = 0; else { uint64_t d = vv.amount[e] * (uint64_t)c; f = f > d ? f - d : 0; }
+                }
             }
         }
         for (auto &fr : ps.freed) {  // remove_sn_task on the previous target of a re-targeted redirect  (worker.rs:223-234 -> workerload.rs:194-202)
@@ -1537,6 +1543,7 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
     g_last_blocks_device = cnt.blocks_device; g_last_blocks_host = cnt.blocks_host;
     ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
+    cnt.pairs();
     for (size_t k = 0; k < cnt.keys.size(); k++)
         for (auto &wc : cnt.per_key[k]) { ctx->cnt_rq.push_back(cnt.keys[k].first); ctx->cnt_variant.push_back(cnt.keys[k].second); ctx->cnt_worker.push_back(wc.first); ctx->cnt_value.push_back(wc.second); }
     out->n_counts = (uint32_t)ctx->cnt_rq.size(); out->count_rq = ctx->cnt_rq.data(); out->count_variant = ctx->cnt_variant.data();
