@@ -188,6 +188,11 @@ class ShardedTick:
                     raise RuntimeError(f"hqtick_set_record_sink failed: {rc}")
         return self._sink, self._merged
 
+    def set_capacity(self, records_per_shard: int):
+        """another sink capacity (every rank must choose the same: the all-gather moves fixed-size blocks); the buffers are re-made on the next tick"""
+        self.cap = int(records_per_shard)
+        self._sink_workers = -1
+
     def upload_ready(self, task_id, task_priority, task_rq):
         self.t.upload_ready(task_id, task_priority, task_rq)
 
