@@ -53,6 +53,12 @@ def cpu_baseline(snap, ticks: int):
 
 
 # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md §HBM); None = not collected
+# rocprofv3 --kernel-trace durations of K1's in-tick launch (profiles/r02/README.md): ticks whose launches carry dispatch events (what this file's stats pass
+# does and `avg_launch_us` reports), ticks without any (the timed region: K1 is then the first packet behind the host's writes and its recorded duration
+# includes the queue's system-scope acquire), and the driver-style bench command, which mixes 55 of the latter with 50 of the former
+ROCPROF_K1 = {"avg_launch_us_ticks_with_events": 5.46, "avg_launch_us_ticks_without_events": 7.41, "avg_launch_us_bench_command_mixture": 6.81,
+              "frac_with_events": 12.0 / 5.46 / 8.0, "frac_without_events": 12.0 / 7.41 / 8.0, "frac_mixture": 12.0 / 6.81 / 8.0,
+              "files": "profiles/r02/ticks_with_events.summary.csv, ticks_without_events.summary.csv, bench_c3.summary.csv"}
 TRAFFIC = {"level_hist": 12_084_109 + 2_250_112, "select_scatter": 11_147_865 + 2_037_568, "expand_mapping": 7_086_235 + 458_752}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
 
 
@@ -457,6 +463,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                      "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": dom_us, "avg_launch_us_back_to_back": b2b.get(dom),
                      "traffic": TRAFFIC.get(dom) if args.workload == "c3" else None,
+                     "rocprofv3": ROCPROF_K1 if args.workload == "c3" else None,
                      "timing": "start / stop events at the dispatch of the launch INSIDE the tick (hipExtLaunchKernel), averaged over the stats pass after the timed region; "
                                "the rocprofv3 kernel trace of this command (profiles/r02/) lists the same launches",
                      "note": "K1 streams the whole ready set (12 B/task).  At 1 M tasks the set (20 MB) lives in the 256 MiB Infinity Cache across ticks and a launch is latency-bound "
