@@ -330,13 +330,14 @@ __global__ void __launch_bounds__(256) k_scan_rows(uint32_t *__restrict__ wave_t
 // LDS layout: [counters: WPB*G u32]([take G][base G] when the plan is staged).
 // PLAN: 0 = take/base arrive in the kernel arguments (G <= 64: no load from pinned or global memory on the critical path),
 //       1 = staged into LDS from `take`/`base`,  2 = read in place (large G, one wavefront per workgroup).
-struct SelPlan64 { uint32_t take[64], base[64]; };
+template <int N> struct SelPlanN { uint32_t take[N], base[N]; };  // the plan in the kernel arguments: 8 bytes per group of the launch call's argument block
+                                                                  // (a launch call costs ~1.7 ns per argument byte on the host: 16 groups = 128 B, 64 = 512 B)
 
-template <int WPB, int PLAN>
+template <int WPB, int PLAN, int PN>
 __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict__ task_id, const uint16_t *__restrict__ gkey, uint64_t n,
                                                      uint32_t Q, uint32_t G, uint32_t tasks_per_wave, uint32_t n_waves, uint32_t stride,
                                                      const uint32_t *__restrict__ wave_off, const uint32_t *__restrict__ take,
-                                                     const uint32_t *__restrict__ base, SelPlan64 pa, uint64_t *__restrict__ sel_task,
+                                                     const uint32_t *__restrict__ base, SelPlanN<PN> pa, uint64_t *__restrict__ sel_task,
                                                      uint16_t *__restrict__ sel_key, uint32_t n_select_blocks,
                                                      const uint4 *__restrict__ copy_src, uint4 *__restrict__ copy_dst, uint32_t copy_n16,
                                                      uint32_t *__restrict__ mark_rq) {
@@ -947,13 +948,21 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
     hipError_t e;
     if (sel && geom.waves_per_block == 4 && G <= 64) {
         // small plan: take/base travel in the kernel arguments; ride-along workgroups copy the whole plan into HBM for K5a/K5b
-        SelPlan64 pa{};
-        for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; }
         size_t lds = (size_t)6 * G * 4;
         const uint32_t nsb = (geom.n_waves + 3) / 4, ncb = n16 ? (n16 + 255) / 256 : 0;  // one 16-byte PCIe read per thread: a single round trip (four per thread cost the launch 2.7 us)
-        HQK_TIMED_LAUNCH((k_select<4, 0>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
-                           reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq);
+        if (G <= 16) {
+            SelPlanN<16> pa{};
+            for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; }
+            HQK_TIMED_LAUNCH((k_select<4, 0, 16>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
+                               reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq);
+        } else {
+            SelPlanN<64> pa{};
+            for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; }
+            HQK_TIMED_LAUNCH((k_select<4, 0, 64>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
+                               reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq);
+        }
         return hipGetLastError();
     }
     if (n16) {  // larger plans: copy first (own launch), then select from the HBM copy
@@ -961,10 +970,10 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (!sel) return hipSuccess;
-    SelPlan64 none{};
+    SelPlanN<1> none{};
     if (geom.waves_per_block == 4) {
         size_t lds = (size_t)6 * G * 4;
-        auto kern = k_select<4, 1>;
+        auto kern = k_select<4, 1, 1>;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         const uint32_t nsb = (geom.n_waves + 3) / 4;
         HQK_TIMED_LAUNCH(kern, dim3(nsb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
@@ -972,7 +981,7 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
         return hipGetLastError();
     }
     size_t lds = (size_t)G * 4;
-    auto kern = k_select<1, 2>;
+    auto kern = k_select<1, 2, 1>;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     HQK_TIMED_LAUNCH(kern, dim3(geom.n_waves), dim3(64), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
                        sel_task, sel_key, geom.n_waves, (const uint4 *)nullptr, (uint4 *)nullptr, 0u, mark_rq);
