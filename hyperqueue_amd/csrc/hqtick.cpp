@@ -359,12 +359,14 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
     const size_t nwv = (size_t)W * nvs;
     for (int attempt = 0; attempt < 2; attempt++) {
         uint32_t L = 0;
+        bool levels_fresh = false;  // the level table was (re)built by this attempt
         if (scan) {
             if (!ctx->levels_valid) {
                 HQ_HIP(hipMemsetAsync(ctx->d_set.p, 0xFF, (size_t)hqk::PRIO_SET_CAP * 8, ctx->stream));
                 HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
                 HQ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-                HQ_HIP(hqk::distinct_priorities(ctx->d_tprio.as<uint64_t>(), N, ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream));
+                HQ_HIP(hqk::distinct_priorities(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream));
+                levels_fresh = true;
                 HQ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
                 HQ_HIP(hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->stream));
                 uint32_t flags[4] = {0, 0, 0, 0};
@@ -441,6 +443,14 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
         if (scan) {
             sc->levels = ctx->h_levels;
             sc->hist.assign(reinterpret_cast<const uint32_t *>(h + o_hist), reinterpret_cast<const uint32_t *>(h + o_hist) + sc->G);
+            // A level without a single task (its tasks were handed out or cancelled since the table was built — or the table was built from a column that
+            // was still being written) only costs: more groups, and beyond 4 levels / 2048 groups the slower kernel variants.  This tick is right either
+            // way (empty levels take part in nothing); the next one rediscovers the levels.
+            for (uint32_t l = 0; l < sc->L && ctx->levels_valid && !levels_fresh; l++) {  // (a table built in this very tick is not questioned: no rediscovery loop)
+                uint64_t tot = 0;
+                for (uint32_t q = 0; q < Q; q++) tot += sc->hist[(size_t)l * Q + q];
+                if (tot == 0) ctx->levels_valid = false;
+            }
             if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[2], ctx->ev[3]); if (us_ >= 0) ctx->stats.level_hist_us = us_; }
             if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[0], ctx->ev[8]); if (us_ >= 0) ctx->stats.scan_us = us_; }
         }
@@ -1146,9 +1156,11 @@ int hqtick_upload_ready(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, co
     const uint64_t cap = sorted ? n : n_pow2;
     if (!ctx->d_tid.ensure(cap * 8 + 8) || !ctx->d_tprio.ensure(cap * 8 + 8) || !ctx->d_trq.ensure(cap * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set");
     if (n) {
-        HQ_HIP(hipMemcpyAsync(ctx->d_tid.p, task_id, n * 8, hipMemcpyHostToDevice, ctx->stream));
-        HQ_HIP(hipMemcpyAsync(ctx->d_tprio.p, task_priority, n * 8, hipMemcpyHostToDevice, ctx->stream));
-        HQ_HIP(hipMemcpyAsync(ctx->d_trq.p, task_rq, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        // blocking copies: the caller's columns are pageable memory, and this is the one call whose result every later tick trusts (a level table built from
+        // a column that was still arriving would list whatever the buffer held before; seen once under rocprofv3 with the asynchronous form)
+        HQ_HIP(hipMemcpy(ctx->d_tid.p, task_id, n * 8, hipMemcpyHostToDevice));
+        HQ_HIP(hipMemcpy(ctx->d_tprio.p, task_priority, n * 8, hipMemcpyHostToDevice));
+        HQ_HIP(hipMemcpy(ctx->d_trq.p, task_rq, n * 4, hipMemcpyHostToDevice));
         if (!sorted) {  // the host handed over its queues in whatever order it walked them: sort by id on the device, once
             if (!ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc");
             uint32_t *flag = ctx->h_q.as<uint32_t>(); flag[0] = 0;

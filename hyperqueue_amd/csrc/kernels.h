@@ -32,7 +32,7 @@ static const uint32_t RQ_TOMBSTONE = 0xFFFFFFFFu;  // rq column value of a task 
 
 // K0: insert every task priority into the open-addressing set `set` (PRIO_SET_CAP slots, pre-filled with PRIO_EMPTY).
 // flags[0] |= 1 when some priority equals PRIO_EMPTY itself, flags[1] = 1 on overflow.
-hipError_t distinct_priorities(const uint64_t *prio, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s);
+hipError_t distinct_priorities(const uint64_t *prio, const uint32_t *rq, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s);  // rq (may be NULL): tasks with rq == RQ_TOMBSTONE do not count
 // K0b: compact the set and sort it descending into levels[]; n_levels[0] = L.  Single workgroup.
 hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *levels, uint32_t *n_levels, hipStream_t s);
 

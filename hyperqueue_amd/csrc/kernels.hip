@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t level_of(const uint64_t *lv, uint32_t L, uin
 }
 
 // ------------------------------------------------------------------------------------------------ K0
-__global__ void __launch_bounds__(256) k_distinct_priorities(const uint64_t *__restrict__ prio, uint64_t n,
+__global__ void __launch_bounds__(256) k_distinct_priorities(const uint64_t *__restrict__ prio, const uint32_t *__restrict__ rq, uint64_t n,
                                                              uint64_t *__restrict__ set, uint32_t *__restrict__ flags) {
     __shared__ unsigned long long cache[256];  // block-local claim table: one wave per block publishes a given value
     for (int i = threadIdx.x; i < 256; i += blockDim.x) cache[i] = PRIO_EMPTY;
@@ -71,7 +71,10 @@ __global__ void __launch_bounds__(256) k_distinct_priorities(const uint64_t *__r
         uint64_t pv[4];
         bool av[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { uint64_t i = i0 + u * stride; av[u] = i < n; pv[u] = av[u] ? prio[i] : 0; }  // 4 independent loads in flight
+        for (int u = 0; u < 4; u++) {  // 4 independent loads in flight; a tombstone (task handed out / removed since the last compaction) has no level any more
+            uint64_t i = i0 + u * stride; av[u] = i < n; pv[u] = av[u] ? prio[i] : 0;
+            if (rq && av[u] && rq[i] == RQ_TOMBSTONE) av[u] = false;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             bool active = av[u];
@@ -870,11 +873,11 @@ __global__ void __launch_bounds__(256) k_check_sorted(const uint64_t *__restrict
 }  // namespace
 
 // ================================================================================================ host wrappers
-hipError_t distinct_priorities(const uint64_t *prio, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s) {
+hipError_t distinct_priorities(const uint64_t *prio, const uint32_t *rq, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 1023) / 1024;
     if (blocks > 512) blocks = 512;  // two blocks per CU: every block publishes each distinct value once, so fewer blocks = fewer same-address atomics
-    hipLaunchKernelGGL(k_distinct_priorities, dim3((unsigned)blocks), dim3(256), 0, s, prio, n, set, flags);
+    hipLaunchKernelGGL(k_distinct_priorities, dim3((unsigned)blocks), dim3(256), 0, s, prio, rq, n, set, flags);
     return hipGetLastError();
 }
 

@@ -1,5 +1,7 @@
 """Resident ready set kept in HBM across ticks and updated by deltas (hqtick_ready_*): every tick of a scripted
 multi-tick scenario must equal the oracle's tick on the full snapshot of the same moment."""
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -269,3 +271,37 @@ def test_resident_steady_state_full_c3():
         t.ready_add(new_ids, np.full(len(gone), prio[0], np.uint64), gone_rq)
         ids, prio, rq = np.concatenate([ids, new_ids]), np.concatenate([prio, np.full(len(gone), prio[0], np.uint64)]), np.concatenate([rq, gone_rq])
         assert t.ready_count() == len(ids) == 1_000_000
+
+
+def test_level_table_drops_levels_without_live_tasks():
+    """The level table is cached across ticks (K1 re-validates it).  Once every task of a level has been handed out the level only costs — more groups,
+    slower kernel variants — so the tick that sees it empty asks the next one to rediscover the levels; tombstones do not count as members of a level
+    (otherwise the rediscovery would find the level again, tick after tick, until the next compaction).  Placement must be unaffected throughout."""
+    from hyperqueue_amd.tick import Tick
+    from oracle.oracle import Oracle
+
+    env = SchedEnv(abi.make_config(reserve=0, fill_max=1, time_limit_s=20.0))
+    env.new_workers(3, WB(4))
+    env.new_tasks(6, TB().cpus(1).user_priority(5))   # the whole top level fits into the first tick
+    env.new_tasks(400, TB().cpus(1))
+    snap = env.snapshot()
+    t = Tick(env.config)
+    t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+    stripped = dataclasses.replace(snap, _keep=[], task_id=np.zeros(0, np.uint64), task_priority=np.zeros(0, np.uint64), task_rq=np.zeros(0, np.uint32))
+    sc = stripped.to_c()
+    want = Oracle(env.config, canonical=True).tick(snap)
+    got = abi.parse_result(t.tick_raw(sc, resident=True), len(snap.worker_id), snap.n_resources)
+    assert got.records == want.records
+    assert t.kernel_stats()["distinct_us"] > 0            # tick 1 builds the table: two levels
+    top = {int(i) for i, p in zip(snap.task_id, snap.task_priority) if p == snap.task_priority.max()}
+    assert top <= {tid for recs in got.records for (tid, _v, _k) in recs}
+    t.ready_consume_last()                                   # the top level is all tombstones now
+    n_live = t.ready_count()
+    r2 = abi.parse_result(t.tick_raw(sc, resident=True), len(snap.worker_id), snap.n_resources)   # sees the empty level; still the cached table
+    assert t.kernel_stats()["distinct_us"] == 0
+    r3 = abi.parse_result(t.tick_raw(sc, resident=True), len(snap.worker_id), snap.n_resources)   # rediscovers: one level
+    assert t.kernel_stats()["distinct_us"] > 0
+    r4 = abi.parse_result(t.tick_raw(sc, resident=True), len(snap.worker_id), snap.n_resources)   # and keeps that table
+    assert t.kernel_stats()["distinct_us"] == 0
+    assert r2.records == r3.records == r4.records and t.ready_count() == n_live
+    t.close()
