@@ -49,7 +49,7 @@ namespace {
 struct PlanScratch {
     std::vector<uint32_t> q_total, pf_n, pf_start, seq_taken, pf_drained, zq_taken, new_pf_total, pfl_size, rq_sel_base;
     std::vector<uint32_t> key_seg, key_sum, key_rq, key_var_w, key_ord_off, ord_cnt, key_t_off, key_bits_off;
-    std::vector<uint32_t> list_pos, pf_flag, pf_flag_prev, sn_ok, items, n_assign, asg_qw, has_pf, wm_order, elig, pfq_src, pfq_size, out_off, take_base, mn_first, pack;
+    std::vector<uint32_t> list_pos, pf_flag, pf_flag_prev, sn_ok, items, n_assign, asg_qw, has_pf, wm_order, pfq_src, pfq_size, out_off, take_base, mn_first;
     std::vector<uint8_t> now_mn;
     // the three per-(key | request, worker) tables of the plan are built IN the pinned buffer K4's ride-along workgroups copy from (a memcpy of ~100 KB per
     // tick otherwise): [wpos nkeys * W][wcnt nkeys * W][pfl_j Q * W] at its head, the small tables behind them (phase_c)
