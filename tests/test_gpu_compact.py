@@ -78,6 +78,13 @@ def test_compact_runs_split_on_job_variant_and_kind(mode):
         assert a.records == b.records and a.counts == b.counts and a.retracts == b.retracts
         rc = comp.tick_raw(snap.to_c())
         W = len(snap.worker_id)
+        import records_c  # the header-only C walker of include/hqtick_records.h on the library's own output, in this emission form and in the full one
+
+        flat = [(t, v, k) for recs in a.records for (t, v, k) in recs]
+        n, ct, cv, ck, cw = records_c.walk(rc, W)
+        assert n == len(flat) and list(zip(ct, cv, ck)) == flat and cw == [w for w, recs in enumerate(a.records) for _ in recs]
+        n, ct, cv, ck, cw = records_c.walk(plain.tick_raw(snap.to_c()), W)
+        assert n == len(flat) and list(zip(ct, cv, ck)) == flat
         cnt = np.ctypeslib.as_array(rc.run_span, shape=(2 * W,)).reshape(W, 2)[:, 1]
         off = np.ctypeslib.as_array(rc.rec_off, shape=(W + 1,))
         assert max(int(cnt[w]) for w in range(W) if off[w + 1] > off[w]) >= 3  # jobs / kinds really split the runs
@@ -128,5 +135,9 @@ def test_delta16_escapes_and_limits(spacing):
         a, b = plain.tick(snap), comp.tick(snap)
         assert sum(len(r) for r in a.records) > 300
         assert a.records == b.records and a.counts == b.counts and a.retracts == b.retracts
+        import records_c
+
+        n, ct, cv, ck, _cw = records_c.walk(comp.tick_raw(snap.to_c()), len(snap.worker_id))
+        assert list(zip(ct, cv, ck)) == [(t, v, k) for recs in a.records for (t, v, k) in recs]
     finally:
         plain.close(); comp.close()

@@ -159,3 +159,31 @@ def test_delta16_decoder_round_trip(seed):
     t, v, k = abi.expand_delta16(r, len(recs), off)
     flat = [x for rr in recs for x in rr]
     assert t == [x[0] for x in flat] and v == [x[1] for x in flat] and k == [x[2] for x in flat]
+    # the header-only C walker of include/hqtick_records.h (what a host shim would use) visits the same records, worker by worker
+    import records_c
+
+    n, ct, cv, ck, cw = records_c.walk(r, len(recs))
+    assert n == len(flat) and ct == t and cv == v and ck == k and cw == [w for w, rr in enumerate(recs) for _ in rr]
+
+
+def test_record_walker_full_and_u32_forms():
+    """include/hqtick_records.h on the other two emission forms (built here from the header's text) and on a result without host records"""
+    import records_c
+
+    recs = [[((3 << 32) | 10, 0xFF, 0), ((3 << 32) | 99, 0xFF, 0), ((3 << 32) | 7, 1, 1), ((4 << 32) | 8, 1, 1)], [], [((9 << 32) | 0xFFFFFFFF, 0, 1)]]
+    flat = [x for rr in recs for x in rr]
+    off = np.asarray([0, 4, 4, 5], np.uint32)
+    task = np.asarray([x[0] for x in flat], np.uint64); var = np.asarray([x[1] for x in flat], np.uint8); kind = np.asarray([x[2] for x in flat], np.uint8)
+    r = abi.ResultC()
+    r.rec_off = off.ctypes.data_as(abi.u32p); r.rec_task = task.ctypes.data_as(abi.u64p); r.rec_variant = var.ctypes.data_as(abi.u8p); r.rec_kind = kind.ctypes.data_as(abi.u8p)
+    n, ct, cv, ck, cw = records_c.walk(r, 3)
+    assert (n, ct, cv, ck, cw) == (5, task.tolist(), var.tolist(), kind.tolist(), [0, 0, 0, 0, 2])
+    lo = (task & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    runs = np.asarray([[0, 3, 0xFF | (0 << 8)], [2, 3, 1 | (1 << 8)], [3, 4, 1 | (1 << 8)], [0, 0, 0], [0, 9, 0 | (1 << 8)]], np.uint32)  # a worker's runs sit in the slots of its own records
+    span = np.asarray([[0, 3], [0, 0], [4, 1]], np.uint32)
+    r2 = abi.ResultC()
+    r2.rec_off = off.ctypes.data_as(abi.u32p); r2.rec_task_lo = lo.ctypes.data_as(abi.u32p); r2.run_span = span.ctypes.data_as(abi.u32p); r2.runs = runs.ctypes.data_as(abi.u32p)
+    assert records_c.walk(r2, 3) == (5, task.tolist(), var.tolist(), kind.tolist(), [0, 0, 0, 0, 2])
+    assert abi.expand_compact(r2, 3, off) == (task.tolist(), var.tolist(), kind.tolist())
+    r3 = abi.ResultC(); r3.rec_off = off.ctypes.data_as(abi.u32p)   # records left in a device sink: nothing to walk
+    assert records_c.walk(r3, 3)[0] == -1
