@@ -711,8 +711,10 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
         __syncthreads();
         uint32_t *dst = reinterpret_cast<uint32_t *>(co.units + (size_t)out0 * 4);
         const uint32_t *src = reinterpret_cast<const uint32_t *>(s_units);
-        for (uint32_t i = threadIdx.x; i < (n_units + 1) / 2; i += blockDim.x) dst[i] = src[i];
-    } else for (uint32_t i = threadIdx.x; i < tot; i += blockDim.x) co.rec_lo[out0 + i] = (uint32_t)f_task[i];
+        // system-scope (write-through) stores: the units start crossing PCIe as they are issued instead of when the launch's final release writes the L2 back
+        // (19.4 instead of 20.0 us)
+        for (uint32_t i = threadIdx.x; i < (n_units + 1) / 2; i += blockDim.x) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else for (uint32_t i = threadIdx.x; i < tot; i += blockDim.x) __hip_atomic_store(co.rec_lo + out0 + i, (uint32_t)f_task[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------------ resident cluster tables (f1)
