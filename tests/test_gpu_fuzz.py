@@ -218,6 +218,16 @@ def test_fuzz_idle_cluster(seed):
         res = [e.schedule(b) for e, b in zip(envs, backends)]
         if not (res[0].is_optimal and res[1].is_optimal):
             pytest.skip("a solver hit its limit: nothing to compare")
+        if not res[0].is_canonical:
+            # optimal in the reference's sense (certified within HiGHS's default mip_rel_gap) but the tie-break phase of the coupled model ran out of its budget
+            # (hqtick_result.is_canonical = 0): the claim is the objective value, and the two placements may differ from here on
+            from test_host_stages import _objective
+
+            model = backends[1].last_model()
+            assert res[0].status == res[1].status and res[0].batches == res[1].batches
+            zg, zw = _objective(model, res[0]), _objective(model, res[1])
+            assert zw * (1.0 - 1e-4) - 1e-12 <= zg <= zw + 1e-9 * max(1.0, abs(zw)), (zg, zw)
+            return
         assert_same(res[0], res[1])
         for e in envs:  # a few tasks finish, the rest keep their workers busy
             done = 0
