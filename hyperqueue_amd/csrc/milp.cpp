@@ -1118,6 +1118,50 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             if (g != c && std::fabs(g - c) <= ROW_TOL) snapped.rcoef[k] = g;
         }
     }
+    // ---- capacities on the integer hull of their row: a `<=` row whose coefficients are positive multiples of the ResourceAmount grid (1/10000) can only be
+    // filled to a sum of its amounts.  5 cpus with requests of 2 and 4 cpus hold 4, never 5 — the LP thinks 5, and on a cluster of such workers its bound sits
+    // 13 % above the integer optimum (20 workers, 19 tasks: 19 M branch-and-bound nodes, 19 s, against milliseconds with the row cut down to 4; HiGHS gets there
+    // with its own coefficient tightening).  The new right-hand side is the largest reachable sum not above the old one: gcd first, then — while the row is
+    // short in units — an unbounded-knapsack reachability pass.  No integer point is lost, so optimum and canonical optimum are unchanged.
+    {
+        const Model &src = need_snap ? snapped : mdl_in;
+        const double GRID = 10000.0;
+        std::vector<long long> ci;
+        std::vector<uint8_t> reach;
+        std::vector<long long> last_ci; double last_rhs = 0.0, last_new = 0.0; bool have_last = false;  // the rows of identical workers are identical: one pass for all of them
+        for (int i = 0; i < src.nrows(); i++) {
+            if (src.rtype[i] != ROW_MAX) continue;
+            const int a = src.roff[i], b = src.roff[i + 1];
+            if (b - a < 1 || !(src.rhs[i] > 0.0) || src.rhs[i] > 1e11) continue;
+            ci.clear();
+            bool ok = true;
+            for (int k = a; k < b && ok; k++) {
+                const double c = src.rcoef[k] * GRID, r = std::round(c);
+                if (!(src.rcoef[k] > 0.0) || r < 1.0 || std::fabs(c - r) > 1e-6 * std::max(1.0, r) || r > 9e15) ok = false; else ci.push_back((long long)r);
+            }
+            if (!ok) continue;
+            double new_rhs;
+            if (have_last && ci == last_ci && src.rhs[i] == last_rhs) new_rhs = last_new;
+            else {
+                long long g = 0;
+                for (long long c : ci) { long long x = c, y = g; while (y) { const long long t = x % y; x = y; y = t; } g = x; }
+                const long long cap = (long long)std::floor(src.rhs[i] * GRID + 1e-6);
+                long long units = cap / g;  // the capacity in units of the gcd
+                long long cmin = ci[0]; for (long long c : ci) cmin = std::min(cmin, c);
+                if (cmin != g && units <= 65536) {  // (a request of one gcd unit reaches every multiple: nothing to search)
+                    reach.assign((size_t)units + 1, 0); reach[0] = 1;
+                    for (long long sidx = 1; sidx <= units; sidx++) for (long long c : ci) { const long long st = c / g; if (st <= sidx && reach[(size_t)(sidx - st)]) { reach[(size_t)sidx] = 1; break; } }
+                    while (units > 0 && !reach[(size_t)units]) units--;
+                }
+                new_rhs = (double)(units * g) / GRID;
+                last_ci = ci; last_rhs = src.rhs[i]; last_new = new_rhs; have_last = true;
+            }
+            if (new_rhs < src.rhs[i] - 1e-9) {
+                if (!need_snap) { snapped = mdl_in; need_snap = true; }
+                snapped.rhs[i] = new_rhs;
+            }
+        }
+    }
     const Model &mdl = need_snap ? snapped : mdl_in;
     Result res;
     int n = mdl.ncols(), m = mdl.nrows();
