@@ -323,6 +323,10 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     // general path below takes over.
     struct SeqStart { uint32_t w, batch; uint8_t variant; uint32_t count; };
     std::vector<SeqStart> seq_start;  // starting point handed to the coupled solve when the lazy size rows fail
+    // Per worker: the integer optimum of its OWN block (its resource rows alone) in base costs, known when the tick went through the separable section first.
+    // The coupled model gets one row per worker from it, "this worker's part of the objective cannot exceed what the worker can hold": the LP of a bin-packing-like
+    // tick (a 7-cpu worker, requests of 2 / 3 / 5 cpus that also compete for 2 gpus) fills every worker fractionally to 100 % and sits 20 % above the optimum.
+    std::vector<double> block_z;
     std::vector<uint8_t> worker_off;  // workers that are empty in EVERY optimum of the coupled model (see below): their columns are not created
     bool separable = true;
     for (const TaskBatch &b : batches) if (pb.rq_multi_node(b.rq) || !b.cuts.empty() || b.is_blocker) separable = false;
@@ -520,6 +524,17 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 std::vector<hqmilp::Model> class_model(ncls);
                 std::vector<std::vector<ColRef>> class_cols(ncls);
                 for (uint32_t c = 0; c < ncls; c++) build_class_model(c, class_model[c], class_cols[c]);
+                if (out.is_optimal) {  // (every class block was solved to its exact optimum above)
+                    std::vector<double> zc(ncls, -1.0);
+                    for (uint32_t c = 0; c < ncls; c++) {
+                        if (class_has_flag[c]) continue;
+                        double z = 0.0;
+                        for (size_t k = 0; k < class_cols[c].size(); k++) if (class_cols[c][k].batch != UINT32_MAX) z += class_model[c].obj[k] * (double)X[(size_t)c * NC + voff[class_cols[c][k].batch] + class_cols[c][k].variant];
+                        zc[c] = z;
+                    }
+                    block_z.assign(ws.n, -1.0);
+                    for (uint32_t w : solver_workers) block_z[w] = zc[wclass[w]];
+                }
                 // Workers that no optimum uses.  Without cuts, blockers and multi-node batches two workers of one class (same free, total, eligibility, no
                 // min_utilization) can exchange their whole contents, and a single task can move to any worker that has room for it; both moves keep every
                 // row satisfied and, as the objective factor (W - idx)/W falls strictly with the index while every cost is positive, moving towards the
@@ -679,7 +694,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     std::map<std::tuple<uint32_t, uint32_t, uint8_t>, int> place;  // (worker, rq, variant) -> column   :88
     std::map<uint32_t, std::vector<int>> count_cols;               // tasks_count_vars   :89
     std::vector<std::vector<std::pair<int, double>>> res_terms(R);
-    std::vector<std::pair<int, double>> cpu_terms;
+    std::vector<std::pair<int, double>> cpu_terms, block_terms;
     auto emit = [&](uint8_t type, double rhs, const std::vector<std::pair<int, double>> &terms) { m.begin_row(type, rhs); for (auto &t : terms) m.term(t.first, t.second); m.end_row(); };
     auto emit_plus = [&](uint8_t type, double rhs, const std::vector<int> &cols, int extra, double coef) { m.begin_row(type, rhs); for (int c : cols) m.term(c, 1.0); m.term(extra, coef); m.end_row(); };
     // WorkerGroup::is_capable_to_run_rq  server/workergroup.rs:35-52 (over the real worker map)
@@ -702,6 +717,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         if (!worker_off.empty() && worker_off[w]) continue;  // empty in every optimum (see the separable section): no columns, no rows
         const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
         cpu_terms.clear();
+        block_terms.clear();
         double order_factor = (double)(nw - wi);
         for (const TaskBatch &batch : batches) {
             const RequestView &rv = pb.rqs[batch.rq];
@@ -730,6 +746,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     int col = m.add_col(s * order_factor * ((double)vv.weight / FRACTIONS) / (double)nw, hqmilp::COL_NAT);
                     place[{w, batch.rq, v}] = col;
                     count_cols[batch.rq].push_back(col);
+                    block_terms.push_back({col, s * ((double)vv.weight / FRACTIONS)});
                     for (uint32_t e = 0; e < vv.n_entries; e++) {
                         double a = units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]);
                         res_terms[vv.res[e]].push_back({col, a});
@@ -752,6 +769,8 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 cpu_terms.push_back({col, -all_cpus}); emit(hqmilp::ROW_MAX, 0.0, cpu_terms); cpu_terms.pop_back();
             }
         }
+        if (!block_z.empty() && block_z[w] >= 0.0 && block_terms.size() >= 2)  // the worker's block optimum caps its share of the objective (see block_z)
+            emit(hqmilp::ROW_MAX, block_z[w] * (1.0 + 1e-9) + 1e-12, block_terms);
         for (uint32_t r = 0; r < R; r++) {  // :177-191 (an unbounded resource keeps its terms for the next worker, as in the reference)
             if (fre[r] == HQ_AMOUNT_MAX) continue;
             if (!res_terms[r].empty()) emit(hqmilp::ROW_MAX, units(fre[r]), res_terms[r]);
