@@ -1171,8 +1171,8 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             {
                 const long long cap_new = (long long)std::llround(new_rhs * GRID);
                 long long cmin = ci[0]; for (long long c : ci) cmin = std::min(cmin, c);
-                const int CUT_ITEMS = 8;
-                if (cap_new / cmin <= CUT_ITEMS && b - a >= 2) {
+                const int CUT_ITEMS = 32;
+                if (cap_new / cmin <= CUT_ITEMS && b - a >= 2 && src.ncols() <= 512) {
                     cut_d.assign(ci.begin(), ci.end());
                     std::sort(cut_d.begin(), cut_d.end()); cut_d.erase(std::unique(cut_d.begin(), cut_d.end()), cut_d.end());
                     for (long long d : cut_d) {
