@@ -1099,7 +1099,7 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     hqtick_ctx *ctx = new hqtick_ctx();
     ctx->cfg = *config; ctx->device = config->device_index;
     ctx->timing = (config->flags & HQTICK_FLAG_NO_KERNEL_TIMING) == 0;
-    if (const char *e = getenv("HQTICK_TPW")) { long v = atol(e); if (v >= 64 && v <= (1 << 20) && v % 64 == 0) ctx->tpw_hint = (uint32_t)v; }
+    if (const char *e = getenv("HQTICK_TPW")) { long v = atol(e); if (v >= 256 && v <= (1 << 20) && v % 256 == 0) ctx->tpw_hint = (uint32_t)v; }
     if (const char *e = getenv("HQTICK_BLOCK_PROFILE")) ctx->block_profile = atoi(e) != 0;
     if (const char *e = getenv("HQTICK_BLOCK_BUDGET")) { long v = atol(e); if (v >= 1 && v <= (1 << 24)) ctx->block_budget = (uint32_t)v; }
     if (const char *e = getenv("HQTICK_BLOCK_MIN_CLASSES")) { long v = atol(e); if (v >= 0) ctx->block_min_classes = (uint32_t)v; }

@@ -888,6 +888,66 @@ hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *lev
     return hipGetLastError();
 }
 
+// K1b for long rows (more than 1024 slices: the BASELINE sizes): one WORKGROUP per group row.  A thread takes 16 entries of a 4096-entry step as four
+// coalesced dwordx4 (consecutive lanes, consecutive 16 bytes: 8 cache lines per load instruction where the one-wavefront-per-row kernel above touches
+// 64), the four 1024-entry quarters are scanned side by side (wave scan + 16 wave totals through LDS, one barrier per step).  3 907 entries per row at
+// C3: 4.2 us against 6.3.
+__global__ void __launch_bounds__(256) k_scan_rows_wg(uint32_t *__restrict__ wave_tab, uint32_t n_waves, uint32_t stride, uint32_t G,
+                                                      uint32_t *__restrict__ hist, uint32_t *__restrict__ err_in,
+                                                      uint32_t *__restrict__ err_out, uint32_t n_eval_blocks, EvalArgs ea) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t s_wt[2][4][4];  // [step parity][quarter][wavefront]: inclusive totals
+    if (blockIdx.x < n_eval_blocks) {   // ride-along workgroups (dispatched first): K2, as in k_scan_rows
+        worker_eval_block(smem, blockIdx.x, ea);
+        return;
+    }
+    const uint32_t row = blockIdx.x - n_eval_blocks;
+    if (row == 0 && threadIdx.x == 0 && err_out) { err_out[0] = err_in[0]; err_in[0] = 0; }
+    if (row >= G) return;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    uint32_t *r = wave_tab + (size_t)row * stride;
+    uint32_t carry = 0;
+    for (uint32_t base = 0, par = 0; base < n_waves; base += 4096, par ^= 1) {
+        uint4 v[4];
+        uint32_t sum[4], incl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // stride is a multiple of 16 entries: every 4-entry group is inside the row or fully outside
+            const uint32_t i = base + k * 1024 + threadIdx.x * 4;
+            v[k] = i < stride ? *reinterpret_cast<const uint4 *>(r + i) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // padding entries (index >= n_waves) count as 0
+            const uint32_t i = base + k * 1024 + threadIdx.x * 4;
+            const uint32_t t0 = i < n_waves ? v[k].x : 0u, t1 = i + 1 < n_waves ? v[k].y : 0u, t2 = i + 2 < n_waves ? v[k].z : 0u, t3 = i + 3 < n_waves ? v[k].w : 0u;
+            v[k].x = 0; v[k].y = t0; v[k].z = t0 + t1; v[k].w = t0 + t1 + t2;
+            sum[k] = t0 + t1 + t2 + t3; incl[k] = sum[k];
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t t = __shfl_up(incl[k], off, 64); if ((int)lane >= off) incl[k] += t; }
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) s_wt[par][k][wv] = incl[k];
+        }
+        __syncthreads();  // (the other parity's totals are rewritten only after every thread has passed the NEXT barrier: no second one needed)
+        uint32_t off = carry;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) { const uint32_t t = s_wt[par][k][w]; all += t; if (w < wv) before += t; }
+            const uint32_t excl = off + before + incl[k] - sum[k];
+            const uint32_t i = base + k * 1024 + threadIdx.x * 4;
+            if (i < stride) *reinterpret_cast<uint4 *>(r + i) = make_uint4(v[k].x + excl, v[k].y + excl, v[k].z + excl, v[k].w + excl);
+            off += all;
+        }
+        carry = off;
+    }
+    if (threadIdx.x == 0) hist[row] = carry;
+}
+
 static uint32_t lds_levels_for(uint32_t L) { return L <= 1024 ? L : 0; }
 
 hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, const uint64_t *levels_host, uint32_t L, uint32_t Q,
@@ -929,6 +989,12 @@ hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *h
         neb = (ride_along->W + 31) / 32; lds = worker_eval_lds(ride_along->R, ride_along->rt.n_variants, ride_along->n_entries);
         hipError_t e;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    }
+    if (geom.n_waves > 1024) {  // long rows: a workgroup each
+        hipError_t e;
+        if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_rows_wg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        HQK_TIMED_LAUNCH(k_scan_rows_wg, dim3(G + neb), dim3(256), lds, s, wave_tab, geom.n_waves, geom.tab_stride, G, hist, err_in, err_out, neb, ea);
+        return hipGetLastError();
     }
     HQK_TIMED_LAUNCH(k_scan_rows, dim3((G + 3) / 4 + neb), dim3(256), lds, s, wave_tab, geom.n_waves, geom.tab_stride, G, hist, err_in, err_out, neb, ea);
     return hipGetLastError();

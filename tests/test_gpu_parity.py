@@ -344,3 +344,36 @@ def test_library_allgather_single_rank(gpu):
     assert st.collective == "library"
     assert got.records == want.records and got.counts == want.counts
     st.t.close()
+
+
+@pytest.mark.parametrize("tpw", [512, 1024, 2048])
+def test_slice_size_is_not_observable(tpw, oracle, monkeypatch):
+    """The ready set is scanned in per-wavefront slices (256 tasks; larger ones from 8 M tasks on, `HQTICK_TPW` as the tuning knob): every
+    output must be the same whatever the slice size — selection order (`pop_first`, taskqueue.rs:273-302) included."""
+    from hyperqueue_amd.tick import Tick
+    from oracle.oracle import Oracle
+
+    monkeypatch.setenv("HQTICK_TPW", str(tpw))
+    snap = workloads.make("c3", n_tasks=60_000, n_workers=64)
+    assert_same(Tick(abi.make_config(time_limit_s=20.0)).tick(snap), oracle.tick(snap))
+    for seed in (3, 11, 27, 33):
+        env = random_env(seed)
+        s = env.snapshot()
+        assert_same(Tick(env.config).tick(s), Oracle(env.config, canonical=True).tick(s))
+
+
+def test_long_rows_scan_kernel_equals_short_rows_kernel(monkeypatch):
+    """K1b has two forms (kernels.hip): a wavefront per group row for rows of up to 1024 slices, a workgroup per row above.  2.5 M ready tasks in
+    slices of 256 are rows of 9 766 slices — three 4096-entry steps of the workgroup form — and rows of 611 with slices of 4096: same tick, same bytes."""
+    from hyperqueue_amd.tick import Tick
+
+    snap = workloads.make("c3", n_tasks=2_500_000, n_workers=512)
+    results = []
+    for tpw in (256, 4096):
+        monkeypatch.setenv("HQTICK_TPW", str(tpw))
+        results.append(Tick(abi.make_config(time_limit_s=20.0)).tick(snap))
+    a, b = results
+    assert a.status == b.status == 0 and a.is_optimal and b.is_optimal
+    assert a.batches == b.batches and a.counts == b.counts
+    assert a.records == b.records and sum(len(r) for r in a.records) > 50_000
+    assert (a.new_free == b.new_free).all()

@@ -28,6 +28,8 @@ for c in FETCH_SIZE WRITE_SIZE; do run_pmc bench_c3 $c $BENCH; done
 # writes — its recorded duration then includes the acquire at the head of the queue (7.5 us against 4.6 us)
 run_trace ticks_with_events python $ROOT/tools/timeline.py c3 200 --timed
 run_trace ticks_without_events python $ROOT/tools/timeline.py c3 200
+# (PROFILE_PARTS=tick: only the tick's own traces above — enough after a change to one of the tick's kernels)
+if [ "${PROFILE_PARTS:-all}" = "tick" ]; then find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +; ls -la "$OUT"; exit 0; fi
 # 2. the streaming kernels beyond the Infinity Cache: 16 M and 64 M ready tasks (tools/ktime.py: 3 ticks + back-to-back launches of K1 / K4)
 for n in 16000000 64000000; do
   run_trace ktime_$n python $ROOT/tools/ktime.py c3 20 $n
