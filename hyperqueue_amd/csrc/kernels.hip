@@ -369,14 +369,18 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
     uint16_t kv[4];
     uint64_t idv[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {  // first tile's keys and ids in flight while the slice offsets arrive (wasted only on exhausted slices)
+    for (int u = 0; u < 4; u++) {  // first tile's keys (2 B per task) in flight while the slice offsets arrive (wasted only on exhausted slices)
         uint64_t i = begin + (uint64_t)u * 64 + lane;
         kv[u] = i < end ? gkey[i] : GKEY_INVALID;
-        idv[u] = i < end ? task_id[i] : 0;
     }
     bool need = false;  // counters are wave-private: no workgroup barrier from here on
     for (uint32_t g = lane; g < G; g += 64) { uint32_t o = wave_off[(size_t)g * stride + wave]; s_cnt[g] = o; need = need || o < tk[g]; }
     if (!__ballot(need)) return;  // every group this slice could feed is already exhausted by earlier slices
+#pragma unroll
+    for (int u = 0; u < 4; u++) {  // the ids (8 B per task) only for slices that still feed a group: a tick that takes 19 % of the ready set reads 2 MB of ids, not 8
+        uint64_t i = begin + (uint64_t)u * 64 + lane;
+        idv[u] = i < end ? task_id[i] : 0;
+    }
     int nbits = 0; while ((1u << nbits) < G) nbits++;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     for (uint64_t b = begin; b < end; b += 256) {
