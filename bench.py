@@ -56,11 +56,11 @@ def cpu_baseline(snap, ticks: int):
 # rocprofv3 --kernel-trace durations of K1's in-tick launch (profiles/r02/README.md): ticks whose launches carry dispatch events (what this file's stats pass
 # does and `avg_launch_us` reports), ticks without any (the timed region: K1 is then the first packet behind the host's writes and its recorded duration
 # includes the queue's system-scope acquire), and the driver-style bench command, which mixes 55 of the latter with 50 of the former
-ROCPROF_K1 = {"avg_launch_us_ticks_with_events": 4.53, "avg_launch_us_ticks_without_events": 7.05, "avg_launch_us_bench_command_mixture": 5.46,
-              "frac_with_events": 12.0 / 4.53 / 8.0, "frac_without_events": 12.0 / 7.05 / 8.0, "frac_mixture": 12.0 / 5.46 / 8.0,
-              "earlier_runs_of_the_round": "with events 4.73-5.46, without 5.96-7.41, mixture 5.06-6.81 us",
+ROCPROF_K1 = {"avg_launch_us_ticks_with_events": 4.86, "avg_launch_us_ticks_without_events": 7.76, "avg_launch_us_bench_command_mixture": 6.25,
+              "frac_with_events": 12.0 / 4.86 / 8.0, "frac_without_events": 12.0 / 7.76 / 8.0, "frac_mixture": 12.0 / 6.25 / 8.0,
+              "earlier_runs_of_the_round": "with events 4.53-5.46, without 5.96-7.41, mixture 5.06-6.81 us",
               "files": "profiles/r02/ticks_with_events.summary.csv, ticks_without_events.summary.csv, bench_c3.summary.csv"}
-TRAFFIC = {"level_hist": 12_086_027 + 2_250_112, "select_scatter": 11_147_870 + 2_037_568, "expand_mapping": 7_060_604 + 458_752}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
+TRAFFIC = {"level_hist": 12_046_346 + 2_250_112, "select_scatter": 8_061_011 + 2_037_568, "expand_mapping": 7_023_645 + 458_752}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
 
 
 def dag_churn(cfg, steps: int, seed: int, n_classes: int):
