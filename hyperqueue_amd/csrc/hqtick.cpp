@@ -1635,7 +1635,11 @@ int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us) {
     const uint64_t N = ctx->n_ready; const hqk::WaveGeom g = ctx->last_geom;
     const uint32_t *d = ctx->d_map.as<uint32_t>();
     uint32_t *hist_dev = reinterpret_cast<uint32_t *>(ctx->h_a.dev<unsigned char>() + 16);
-    HQ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
+    // HQTICK_KTIME_GRAPH: the launches captured into one graph and replayed — no host launch cost between them (a launch call with K1's argument block takes
+    // longer than the kernel runs at 1 M tasks), so (graph duration) / iters is what the GPU spends per launch, kernel boundary included
+    const bool as_graph = getenv("HQTICK_KTIME_GRAPH") != nullptr;
+    if (as_graph) HQ_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    else HQ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
     for (int i = 0; i < iters; i++) {
         if (which == 0) HQ_HIP(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), ctx->last_L, ctx->last_Q, g, ctx->d_wave_tab.as<uint32_t>(),
                                               ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, nullptr, ctx->stream));
@@ -1643,7 +1647,17 @@ int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us) {
                                                         d + ctx->last_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, ctx->last_plan_bytes, nullptr, ctx->stream));
         else return fail(ctx, HQTICK_E_INVALID, "which: 0 = level_hist, 1 = select_scatter");
     }
-    HQ_HIP(hipEventRecord(ctx->ev[11], ctx->stream));
+    if (as_graph) {
+        hipGraph_t gr = nullptr; hipGraphExec_t ge = nullptr;
+        HQ_HIP(hipStreamEndCapture(ctx->stream, &gr));
+        HQ_HIP(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        HQ_HIP(hipGraphLaunch(ge, ctx->stream));  // once untimed
+        HQ_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
+        HQ_HIP(hipGraphLaunch(ge, ctx->stream));
+        HQ_HIP(hipEventRecord(ctx->ev[11], ctx->stream));
+        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        hipGraphExecDestroy(ge); hipGraphDestroy(gr);
+    } else HQ_HIP(hipEventRecord(ctx->ev[11], ctx->stream));
     if (which == 0)  // K1 left raw counts in the slice table: turn them back into offsets
         HQ_HIP(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, ctx->last_G, hist_dev, ctx->d_flags.as<uint32_t>() + 2, reinterpret_cast<uint32_t *>(ctx->h_a.dev<unsigned char>()) + 2, ctx->stream));
     HQ_HIP(hipStreamSynchronize(ctx->stream));

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Back-to-back kernel timing sweep (bench tooling; needs a GPU): python tools/ktime.py [workload] [iters]"""
+"""Back-to-back kernel timing sweep (bench tooling; needs a GPU): python tools/ktime.py [workload] [iters] [n_tasks]
+HQTICK_KTIME_GRAPH=1: the launches replayed from one captured graph (no host launch cost between them)."""
 import ctypes as C, os, sys
 import torch  # noqa: F401  (one HIP runtime in the process)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +22,6 @@ for which, nm, nbytes in ((0, "level_hist", len(snap.task_id) * 12), (1, "select
     for rep in range(3):
         rc = t._lib.hqtick_time_kernel(t._ctx, which, iters, C.byref(us))
         assert rc == 0, t._err()
-    print(f"N={len(snap.task_id)} TPW={os.environ.get('HQTICK_TPW', '256')} {nm}: {us.value:.2f} us/launch back-to-back  -> {nbytes / us.value / 1e3:.0f} GB/s on {nbytes / 1e6:.1f} MB")
+    print(f"N={len(snap.task_id)} TPW={os.environ.get('HQTICK_TPW', '256')} {nm}: {us.value:.2f} us/launch {'in a graph' if os.environ.get('HQTICK_KTIME_GRAPH') else 'back-to-back'}  -> {nbytes / us.value / 1e3:.0f} GB/s on {nbytes / 1e6:.1f} MB")
 r = t.tick_raw(sc, resident=True)
 print("tick still consistent:", r.status, t.kernel_stats()["n_assigned"])
