@@ -441,6 +441,12 @@ def main():
             b2b[nm] = round(tick.time_kernel(which, 100), 2)
             kernels[nm]["us_back_to_back"] = b2b[nm]
             kernels[nm]["GBps_back_to_back"] = kernels[nm]["bytes"] / (b2b[nm] * 1e-6) / 1e9
+    empty_us = None
+    if world == 1 and not args.force_sharded and not args.no_kernel_timing:
+        try:
+            empty_us = round(tick.time_kernel(2, 100), 2)  # an empty kernel of K1's grid under the same per-dispatch events: the floor of the measure
+        except Exception:
+            empty_us = None
     dom_us = kernels[dom]["us"]  # the launch inside the tick, dispatch-level events
     achieved, peak = (kernels[dom]["bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0), 8000.0
     pcie_peak = 63.0  # GB/s, PCIe Gen5 x16 one direction (what K5b's stores into pinned host memory cross)
@@ -463,6 +469,10 @@ def main():
         "tick_stages_us": dict(zip(["gpu_phase_a_scans", "batches", "solve", "mapping_plan_gpu_phase_c", "total_in_library"], [round(float(x), 1) for x in np.median(np.asarray(stages), axis=0)])),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                      "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": dom_us, "avg_launch_us_back_to_back": b2b.get(dom),
+                     "empty_launch_us": empty_us,
+                     "empty_launch_note": "an EMPTY kernel of K1's grid, measured like avg_launch_us (own start / stop events at the dispatch): the floor of that measure — the bytes of a "
+                                          "1 M-task launch cannot be priced above algorithmic_bytes / empty_launch_us; from one graph replayed without events K1 takes 3.85 us per launch, "
+                                          "its loads + store alone 2.2 us (tools/exp/stream_floor.hip, DESIGN.md 3)",
                      "traffic": TRAFFIC.get(dom) if args.workload == "c3" else None,
                      "rocprofv3": ROCPROF_K1 if args.workload == "c3" else None,
                      "timing": "start / stop events at the dispatch of the launch INSIDE the tick (hipExtLaunchKernel), averaged over the stats pass after the timed region; "

@@ -1635,6 +1635,18 @@ int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us) {
     const uint64_t N = ctx->n_ready; const hqk::WaveGeom g = ctx->last_geom;
     const uint32_t *d = ctx->d_map.as<uint32_t>();
     uint32_t *hist_dev = reinterpret_cast<uint32_t *>(ctx->h_a.dev<unsigned char>() + 16);
+    if (which == 2) {  // calibration: an EMPTY kernel of K1's grid, each launch bracketed by its own start / stop events like the stats pass of a tick
+        double sum = 0.0; int cnt = 0;
+        for (int i = 0; i < iters; i++) {
+            hqk::time_next_launch(ctx->ev[2], ctx->ev[3]);
+            HQ_HIP(hqk::empty_like_level_hist(g, ctx->stream));
+            HQ_HIP(hipStreamSynchronize(ctx->stream));
+            const double us_ = elapsed_us(ctx->ev[2], ctx->ev[3]);
+            if (us_ >= 0) { sum += us_; cnt++; }
+        }
+        *avg_us = cnt ? sum / cnt : 0.0;
+        return 0;
+    }
     // HQTICK_KTIME_GRAPH: the launches captured into one graph and replayed — no host launch cost between them (a launch call with K1's argument block takes
     // longer than the kernel runs at 1 M tasks), so (graph duration) / iters is what the GPU spends per launch, kernel boundary included
     const bool as_graph = getenv("HQTICK_KTIME_GRAPH") != nullptr;
@@ -1645,7 +1657,7 @@ int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us) {
                                               ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, nullptr, ctx->stream));
         else if (which == 1) HQ_HIP(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, ctx->last_Q, ctx->last_G, g, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + ctx->last_tb,
                                                         d + ctx->last_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, ctx->last_plan_bytes, nullptr, ctx->stream));
-        else return fail(ctx, HQTICK_E_INVALID, "which: 0 = level_hist, 1 = select_scatter");
+        else return fail(ctx, HQTICK_E_INVALID, "which: 0 = level_hist, 1 = select_scatter, 2 = empty kernel of level_hist's grid");
     }
     if (as_graph) {
         hipGraph_t gr = nullptr; hipGraphExec_t ge = nullptr;

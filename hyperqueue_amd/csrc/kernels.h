@@ -45,6 +45,7 @@ hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, cons
                 uint32_t Q, WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, const WorkerEvalArgs *ride_along, hipStream_t s);
 // K1b: exclusive scan of every wave_tab row (in place -> offsets) and the row totals into hist[G].
 // err_in (device) is forwarded to err_out (may be pinned host memory) by the same launch.
+hipError_t empty_like_level_hist(WaveGeom geom, hipStream_t s);  // an empty kernel of K1's grid (calibration of the per-dispatch timing)
 hipError_t scan_waves(uint32_t *wave_tab, WaveGeom geom, uint32_t G, uint32_t *hist, uint32_t *err_in, uint32_t *err_out, hipStream_t s,
                       const WorkerEvalArgs *ride_along = nullptr);  // ride_along: K2 as extra workgroups of this launch
 

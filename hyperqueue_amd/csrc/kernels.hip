@@ -954,6 +954,16 @@ __global__ void __launch_bounds__(256) k_scan_rows_wg(uint32_t *__restrict__ wav
 
 static uint32_t lds_levels_for(uint32_t L) { return L <= 1024 ? L : 0; }
 
+// An empty kernel of K1's grid, launched the way the measured kernels are: what a dispatch bracketed by its own start / stop events records when the kernel does
+// nothing (bench.py: `roofline.empty_launch_us` — the floor of the duration `roofline.frac` is priced on).
+static __global__ void __launch_bounds__(256) k_empty_grid(uint32_t) {}
+hipError_t empty_like_level_hist(WaveGeom geom, hipStream_t s) {
+    if (geom.n_waves == 0) return hipSuccess;
+    if (geom.waves_per_block == 4) HQK_TIMED_LAUNCH(k_empty_grid, dim3((geom.n_waves + 3) / 4), dim3(256), 0, s, geom.n_waves);
+    else HQK_TIMED_LAUNCH(k_empty_grid, dim3(geom.n_waves), dim3(64), 0, s, geom.n_waves);
+    return hipGetLastError();
+}
+
 hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, const uint64_t *levels_host, uint32_t L, uint32_t Q,
                 WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, const WorkerEvalArgs *ride_along, hipStream_t s) {
     if (n == 0 || geom.n_waves == 0) return hipSuccess;

@@ -482,7 +482,8 @@ int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
  * reports, without the latency of markers queued around it. */
 int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on);
 /* Re-launches one streaming kernel of the last resident tick `iters` times back to back between two HIP events on the ctx's
- * stream and returns the average launch duration (which: 0 = K1 level_hist, 1 = K4 select_scatter).  GPU only. */
+ * stream and returns the average launch duration (which: 0 = K1 level_hist, 1 = K4 select_scatter).  which = 2: an EMPTY kernel of K1's grid, every launch
+ * bracketed by its own dispatch events as in hqtick_set_kernel_timing — what that measure records for a kernel that does nothing.  GPU only. */
 int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us);
 /* Host wall-clock marks (microseconds since the start of the last tick) at the internal stage boundaries of the last tick;
  * returns the number of marks written (bench tooling). */
