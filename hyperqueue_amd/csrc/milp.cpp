@@ -437,6 +437,32 @@ struct CompSolver {
                 }
             }
         }
+        {   // Branch on a ROW first where one offers itself: an active row whose coefficients are all equal (a batch-size row: how many tasks of the batch are
+            // placed in total) has an integral activity at every integer point, and its slack is a column of the tableau like any other.  With identical
+            // workers the LP optimum keeps such a total fractional while it shuffles single (worker, class) columns around: branching on the columns
+            // enumerates the symmetric packings one by one (8 workers x 5 classes, 86 of 88 tasks fit: 2.4 M nodes without proof in 10 s), branching on
+            // the total decides what the symmetric packings have in common.
+            int ba = -1; double bfr = 1e-6;
+            for (int a = 0; a < t.ma && strong; a++) {
+                const double u = row_unit[(size_t)t.arow[a]];
+                if (u <= 0.0) continue;
+                const double act = t.x[t.n + a] / u, fr = std::fabs(act - std::round(act));
+                if (fr > bfr) { bfr = fr; ba = a; }
+            }
+            if (ba >= 0) {
+                const int k = t.n + ba;
+                const double u = row_unit[(size_t)t.arow[ba]], act = t.x[k] / u;
+                {
+                    Tab up = t;
+                    up.set_lb(k, std::ceil(act - INT_TOL) * u);
+                    dfs_opt(up);
+                    lp_iters += up.iters - t.iters;
+                }
+                t.set_ub(k, std::floor(act + INT_TOL) * u);
+                dfs_opt(t);
+                return;
+            }
+        }
         const int SB = 32;
         if (strong && have && (double)t.ma * (double)t.width() <= 4.0e6) {  // two tableau copies per candidate: not for the large models
             // strong branching over the SB most valuable fractional columns: both children are solved, the column whose children lose the most
@@ -632,6 +658,7 @@ struct CompSolver {
     // is left out).  Where the root LP pays a block more than the incumbent does there is something to gain, where it pays less there is something to
     // give: windows pair the blocks with the largest deficit with those of the largest surplus, which the index-based windows only meet by chance.
     std::vector<int> block_of; int n_blocks = 0;
+    std::vector<double> row_unit;  // per row: u > 0 when every coefficient of the row equals u (three terms or more) — its activity / u is an integer at every integer point
     std::vector<double> lag_value, lag_rcost;  // after lagrangian_bound(): V_b(pi*) per block and the reduced costs c - pi* A per column
     void find_blocks() {
         DSUlite d(n);
@@ -840,6 +867,14 @@ struct CompSolver {
 
     // returns: 0 infeasible, 1 optimal, 2 incumbent only (time limit)
     int run(bool canonical, std::vector<double> &xout) {
+        row_unit.assign((size_t)R.m, 0.0);
+        for (int i = 0; i < R.m && !in_lns && n <= 2000; i++) {  // (not inside the windows of the large-model search: their sub-models are tuned as they are)
+            const int a = R.off[i], b = R.off[i + 1];
+            if (b - a < 3 || !(R.coef[a] > 0.0) || R.lo[i] > -INF || !(R.hi[i] < INF)) continue;  // `<=` rows only (the tick's batch-size and resource rows)
+            bool same = true;
+            for (int k = a + 1; k < b && same; k++) same = R.coef[k] == R.coef[a];
+            if (same) row_unit[i] = R.coef[a];
+        }
         Tab root; root.init(&R, c, lb, ub); root.deadline = deadline;
         greedy_from(lb);
         find_quantum();
