@@ -105,6 +105,7 @@ struct Shared {  // one block's working set: LDS on the device
     uint16_t dl[NMAX + 1][DPRE];    // per level: pool entries that are vertices of that level's dual polyhedron
     float dpen[NMAX + 1][DPRE];     // ... and the penalty of a capped column (phase 2), rounded up
     int32_t wcap[NMAX];             // upper cap of a position (INT32_MAX = none)
+    int32_t colcap[NMAX];           // upper cap of a block column (INT32_MAX = none): the priced blocks of the coupled solve (price_core.h) carry their model bounds here
     uint32_t dcnt[NMAX + 1];
     // level stack of the walk (level k = number of positions still free)
     double rem[NMAX + 1][MMAX];
@@ -191,6 +192,7 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTabl
     int64_t *cap64 = &a64[MMAX - 1][NMAX - 1] + 1;
     ColTable ct = ct_in;
     if (wv.first()) { S.status = ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = 0; S.npool = 0; S.usedres = 0; }
+    wv.each([&](int lane) { if (lane < NMAX) S.colcap[lane] = 2147483647; });
     if (NC > (uint32_t)GCOLS || R > 64 || NC == 0) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
     const uint64_t elig = cl.elig[cls] & (NC >= 64 ? ~0ull : ((1ull << NC) - 1ull));
     const bool staged = ct_in.blob != nullptr && ct_in.blob_bytes <= (uint32_t)BLOB_MAX && (ct_in.blob_bytes & 15u) == 0;
@@ -408,7 +410,7 @@ HQB_HD void greedy_lane(Shared &S, int lane) {
     for (int i = 0; i < n; i++) {
         const int j = S.perm[i][lane];
         if (!(S.c[j] > 0.0)) continue;
-        int32_t ub = 2147483647;
+        int32_t ub = S.colcap[j];
         for (int r = 0; r < m; r++) if (S.a[r][j] > 0.0) { const int32_t q = fits(rem[r], S.a[r][j], S.ainv[r][j]); ub = q < ub ? q : ub; }
         if (ub <= 0) continue;
         S.gx[j][lane] = (uint16_t)ub;
@@ -432,7 +434,7 @@ HQB_HD void setup_work(W &wv, Shared &S, uint32_t cols, int capcol, int32_t capv
         const int p = __builtin_popcountll(selmask & ((1ull << lane) - 1ull)), j = S.pi[lane];
         S.wcol[p] = (uint8_t)j;
         S.wc[p] = S.c[j];
-        S.wcap[p] = j == capcol ? capval : 2147483647;
+        S.wcap[p] = (j == capcol && capval < S.colcap[j]) ? capval : S.colcap[j];
         for (int r = 0; r < MMAX; r++) { S.wa[r][p] = S.a[r][j]; S.winv[r][p] = S.ainv[r][j]; }
     });
     if (wv.first()) S.wn = __builtin_popcountll(selmask);
@@ -751,6 +753,7 @@ struct HostWave {
     void sync() {}
     uint32_t atomic_inc(uint32_t *p) { return (*p)++; }
     void atomic_or64(uint64_t *p, uint64_t v) { *p |= v; }
+    void atomic_add_i64(long long *p, long long v) { *p += v; }
     static int ctz(uint64_t m) { int i = 0; while (!((m >> i) & 1)) i++; return i; }
     template <class F> void each(F f) { for (int l = 0; l < WAVE; l++) f(l); }
     template <class F> uint64_t ballot(F f) { uint64_t m = 0; for (int l = 0; l < WAVE; l++) if (f(l)) m |= 1ull << l; return m; }

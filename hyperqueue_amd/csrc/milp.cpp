@@ -8,6 +8,8 @@
 // feasible from the start; a violated row that enters, or a B&B child that differs from its parent by one bound, is exactly the case the
 // dual method re-optimises in a handful of pivots.
 #include "milp.h"
+#include "lp_tab.h"
+#include "price.h"
 
 #include <algorithm>
 #include <chrono>
@@ -23,254 +25,7 @@
 namespace hqmilp {
 namespace {
 
-const double INF = 1e300;
-const double FEAS_TOL = 1e-9;   // primal bound violation (rows are scaled to max |coef| = 1)
-const double PIV_TOL = 1e-9;
-const double INT_TOL = 1e-7;
-const int LNS_FIRST_COLS = 128;          // models from this size on improve the greedy incumbent by window search before any tree search
-const double EXACT_PASS_WORK = 5.0e7;    // floor of the exact pass's budget after a gap certificate, in tableau element updates (~50 ms)
-const double UB_CAP = 1048576.0;  // columns with no derivable bound (unbounded models => `None`, highs.rs:82)
-const double TAB_LIMIT = 6.0e7;   // doubles in one tableau (480 MB): beyond it the LP gives up (reported like a time limit)
-
-// y[0..n) -= f * x[0..n): the row update of a pivot, where the solver spends its time.  Compiled for AVX2 on the host pass (every x86-64 server
-// CPU of the last decade has it); no FMA contraction, so the arithmetic is the same mul + sub as the plain loop.
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
-__attribute__((target("avx2")))
-#endif
-inline void axpy_neg(double *__restrict__ y, const double *__restrict__ x, double f, int n) {
-    for (int j = 0; j < n; j++) y[j] -= f * x[j];
-}
-
-double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-enum { BASIC = 0, AT_LO = 1, AT_UP = 2 };
-enum { LP_OPT = 0, LP_INFEAS = 1, LP_LIMIT = 2 };
-
-// Sparse rows of one component (local column ids), scaled to max |coef| = 1:  lo <= a.x <= hi
-struct Rows {
-    int n = 0, m = 0;
-    std::vector<int> off{0}, col;
-    std::vector<double> coef, lo, hi;
-    void add(const std::vector<std::pair<int, double>> &terms, double lo_, double hi_) {
-        for (auto &t : terms) { col.push_back(t.first); coef.push_back(t.second); }
-        off.push_back((int)col.size()); lo.push_back(lo_); hi.push_back(hi_); m++;
-    }
-    double activity(int i, const double *x) const { double a = 0.0; for (int k = off[i]; k < off[i + 1]; k++) a += coef[k] * x[col[k]]; return a; }
-};
-
-// LP  max c.x,  lb <= x <= ub,  rows of R — as a tableau over the rows activated so far.  Columns: [0, n) structural,
-// [n, n + ma) the slacks s_a = a_row.x of the active rows.  Every tableau row r reads  x_B[r] + sum_{j nonbasic} T[r][j] x_j = 0.
-struct Tab {
-    const Rows *R = nullptr;
-    int n = 0, ma = 0, cap = 0, stride = 0;
-    std::vector<double> T, d, x, lb, ub, cost;
-    std::vector<int> B, arow, where;
-    std::vector<uint8_t> st;
-    long iters = 0;
-    double ops = 0.0;         // tableau elements touched so far (pivots, row activations, separation scans): the deterministic work measure
-    double deadline = 1e300;  // wall-clock backstop inside long re-optimisations
-
-    // Tableau storage is recycled through a small per-thread pool: a B&B node copies its parent's tableau, and a fresh std::vector of a megabyte
-    // is an mmap + page faults + munmap per node — more than the copy itself.
-    static std::vector<std::vector<double>> &pool() { static thread_local std::vector<std::vector<double>> p; return p; }
-    static std::vector<double> take_buffer(size_t elems) {
-        auto &p = pool();
-        for (size_t i = p.size(); i-- > 0;) if (p[i].size() >= elems) { std::vector<double> b = std::move(p[i]); p.erase(p.begin() + (long)i); return b; }
-        return std::vector<double>(elems);
-    }
-    static bool poolable(const std::vector<double> &b) { return b.size() >= 4096 && b.size() <= (1u << 20) && pool().size() < 64; }  // <= 8 MB each, <= 64 of them
-    // Small tableaus (the 8-column block of a worker class: ~40 copies per solve, ten vectors each) recycle ALL their vectors: a retired Tab leaves them in a
-    // per-thread list of shells and the next copy / init adopts one, so that its assign()s find the capacity in place.  (Of the 337 heap allocations of a
-    // C3-block solve 200 were these; the solve is 18 us on the build container, 10 us on the MI355X box's host.)
-    struct Shell { std::vector<double> T, d, x, lb, ub, cost; std::vector<int> B, arow, where; std::vector<uint8_t> st; };
-    static std::vector<Shell> &shells() { static thread_local std::vector<Shell> s; return s; }
-    void swap_with(Shell &b) { T.swap(b.T); d.swap(b.d); x.swap(b.x); lb.swap(b.lb); ub.swap(b.ub); cost.swap(b.cost); B.swap(b.B); arow.swap(b.arow); where.swap(b.where); st.swap(b.st); }
-    void adopt_shell() { auto &s = shells(); if (s.empty()) return; swap_with(s.back()); s.pop_back(); }
-    void retire() {  // give the storage away (the object is about to be destroyed or overwritten)
-        if (poolable(T)) { pool().push_back(std::move(T)); T = std::vector<double>(); }
-        if (d.capacity() == 0 || T.capacity() > 4096) return;
-        auto &s = shells();
-        if (s.size() >= 64) return;
-        s.emplace_back();
-        swap_with(s.back());
-    }
-    ~Tab() { retire(); }
-    Tab() = default;
-    Tab(Tab &&) = default;
-    Tab &operator=(Tab &&o) {
-        if (this != &o) {
-            retire();
-            R = o.R; n = o.n; ma = o.ma; cap = o.cap; stride = o.stride;
-            T = std::move(o.T); d = std::move(o.d); x = std::move(o.x); lb = std::move(o.lb); ub = std::move(o.ub); cost = std::move(o.cost);
-            B = std::move(o.B); arow = std::move(o.arow); where = std::move(o.where); st = std::move(o.st);
-            iters = o.iters; ops = o.ops; deadline = o.deadline;
-        }
-        return *this;
-    }
-    // B&B children and tie-break probes copy their parent: copy the active rows only, into a tableau with a little headroom
-    Tab(const Tab &o) : R(o.R), n(o.n), ma(o.ma), cap(o.ma + 16), stride(o.n + o.ma + 16), iters(o.iters), ops(o.ops + (double)(o.ma + 1) * (double)(o.n + o.ma)), deadline(o.deadline) {
-        adopt_shell();
-        B = o.B; arow = o.arow; where = o.where;
-        const size_t need = (size_t)cap * stride;
-        if (need >= 4096) { T = take_buffer(need); }  // contents unspecified: rows < ma are written below, rows >= ma by activate() before any use
-        else if (T.size() < need) T.resize(need);
-        const int N = o.width();
-        for (int r = 0; r < ma; r++) {
-            double *dst = &T[(size_t)r * stride];
-            memcpy(dst, &o.T[(size_t)r * o.stride], sizeof(double) * N);
-            std::fill(dst + N, dst + stride, 0.0);  // the columns later slacks will take
-        }
-        auto cp = [&](std::vector<double> &dst, const std::vector<double> &src) { dst.assign(stride, 0.0); memcpy(dst.data(), src.data(), sizeof(double) * N); };
-        cp(d, o.d); cp(x, o.x); cp(lb, o.lb); cp(ub, o.ub); cp(cost, o.cost);
-        st.assign(stride, AT_LO); memcpy(st.data(), o.st.data(), N);
-    }
-    Tab &operator=(const Tab &o) { if (this != &o) { Tab t(o); *this = std::move(t); } return *this; }
-
-    void init(const Rows *rows, const std::vector<double> &c, const std::vector<double> &clb, const std::vector<double> &cub) {
-        R = rows; n = rows->n; ma = 0; cap = 32; stride = n + cap;
-        if (d.capacity() == 0) adopt_shell();
-        T.assign((size_t)cap * stride, 0.0);
-        cost.assign(stride, 0.0); d.assign(stride, 0.0); x.assign(stride, 0.0); lb.assign(stride, 0.0); ub.assign(stride, 0.0); st.assign(stride, AT_LO);
-        B.clear(); arow.clear(); where.assign(rows->m, -1);
-        for (int j = 0; j < n; j++) {
-            cost[j] = d[j] = c[j]; lb[j] = clb[j]; ub[j] = cub[j];
-            if (c[j] > 0.0) { st[j] = AT_UP; x[j] = cub[j]; } else { st[j] = AT_LO; x[j] = clb[j]; }
-        }
-    }
-    double objective() const { double z = 0.0; for (int j = 0; j < n; j++) z += cost[j] * x[j]; return z; }
-    int width() const { return n + ma; }
-
-    void grow() {
-        int ncap = cap * 2, nstride = n + ncap;
-        std::vector<double> nT((size_t)ncap * nstride, 0.0);
-        for (int r = 0; r < ma; r++) memcpy(&nT[(size_t)r * nstride], &T[(size_t)r * stride], sizeof(double) * width());
-        T.swap(nT);
-        for (auto *v : {&d, &x, &lb, &ub, &cost}) v->resize(nstride, 0.0);
-        st.resize(nstride, AT_LO);
-        cap = ncap; stride = nstride;
-    }
-
-    // constraint i of R enters the tableau with its slack basic
-    bool activate(int i) {
-        if (ma == cap) { if ((double)cap * 2.0 * (double)(n + cap * 2) > TAB_LIMIT) return false; grow(); }
-        const int a = ma, k = n + a, N = width();
-        double *v = &T[(size_t)a * stride];
-        std::fill(v, v + stride, 0.0);  // the whole row: recycled storage is not zero beyond what the copy constructor wrote
-        double act = 0.0;
-        for (int t = R->off[i]; t < R->off[i + 1]; t++) { v[R->col[t]] -= R->coef[t]; act += R->coef[t] * x[R->col[t]]; }
-        for (int r = 0; r < a; r++) {  // express the row in the current nonbasic columns
-            const int kb = B[r];
-            if (kb >= n) continue;
-            const double f = v[kb];
-            if (f == 0.0) continue;
-            const double *row = &T[(size_t)r * stride];
-            axpy_neg(v, row, f, N);
-            v[kb] = 0.0;
-            ops += N;
-        }
-        v[k] = 1.0;
-        B.push_back(k); arow.push_back(i); where[i] = a;
-        st[k] = BASIC; lb[k] = R->lo[i]; ub[k] = R->hi[i]; cost[k] = 0.0; d[k] = 0.0; x[k] = act;
-        ma++;
-        return true;
-    }
-
-    // move a nonbasic variable to a new value, updating the basic ones
-    void shift_nonbasic(int j, double nv) {
-        double dl = nv - x[j];
-        if (dl == 0.0) return;
-        for (int r = 0; r < ma; r++) { double t = T[(size_t)r * stride + j]; if (t != 0.0) x[B[r]] -= t * dl; }
-        x[j] = nv;
-    }
-    void set_lb(int j, double v) { lb[j] = v; if (st[j] == AT_LO) shift_nonbasic(j, v); else if (st[j] == AT_UP && ub[j] < v) shift_nonbasic(j, v); }
-    void set_ub(int j, double v) { ub[j] = v; if (st[j] == AT_UP) shift_nonbasic(j, v); else if (st[j] == AT_LO && lb[j] > v) shift_nonbasic(j, v); }
-
-    // dual simplex over the active rows
-    int reoptimise(long max_iters) {
-        const int N = width();
-        const long bland_after = 400 + 8L * (ma + 8);  // a re-optimisation normally takes a handful of pivots; far beyond that it is stalling on
-                                                        // degenerate ties: switch to smallest-index choices (Bland), which cannot cycle
-        for (long it = 0; it < max_iters; it++) {
-            const bool bland = it > bland_after;
-            int r = -1; double best = FEAS_TOL; bool below = false; int rk = INT32_MAX;
-            for (int i = 0; i < ma; i++) {
-                int k = B[i]; double v = x[k];
-                double inf = 0.0; bool bl = false;
-                if (v < lb[k] - FEAS_TOL) { inf = lb[k] - v; bl = true; }
-                else if (v > ub[k] + FEAS_TOL) inf = v - ub[k];
-                else continue;
-                if (bland ? k < rk : inf > best) { best = inf; r = i; below = bl; rk = k; }
-            }
-            if (r < 0) return LP_OPT;
-            int k = B[r];
-            if (lb[k] > ub[k] + FEAS_TOL) return LP_INFEAS;
-            double *prow = &T[(size_t)r * stride];
-            int q = -1; double bratio = INF, babs = 0.0;
-            for (int j = 0; j < N; j++) {
-                if (st[j] == BASIC) continue;
-                if (lb[j] == ub[j]) continue;  // fixed: cannot move
-                double a = prow[j];
-                bool elig;
-                if (below) elig = (st[j] == AT_LO && a < -PIV_TOL) || (st[j] == AT_UP && a > PIV_TOL);
-                else elig = (st[j] == AT_LO && a > PIV_TOL) || (st[j] == AT_UP && a < -PIV_TOL);
-                if (!elig) continue;
-                double ratio = std::fabs(d[j]) / std::fabs(a);
-                if (ratio < bratio - 1e-13 || (!bland && ratio <= bratio + 1e-13 && std::fabs(a) > babs)) { bratio = ratio; babs = std::fabs(a); q = j; }
-            }
-            if (q < 0) return LP_INFEAS;
-            iters++;
-            if (((iters & 63) == 0 || (double)ma * (double)N > 2.0e5) && wall() > deadline) return LP_LIMIT;  // a pivot of a large tableau costs milliseconds
-            double target = below ? lb[k] : ub[k];
-            double piv = prow[q];
-            double dq = (x[k] - target) / piv;
-            for (int i = 0; i < ma; i++) { double t = T[(size_t)i * stride + q]; if (t != 0.0) x[B[i]] -= t * dq; }
-            x[q] += dq;
-            x[k] = target;
-            double inv = 1.0 / piv;
-            for (int j = 0; j < N; j++) prow[j] *= inv;
-            prow[q] = 1.0;
-            ops += 3.0 * N + ma;
-            for (int i = 0; i < ma; i++) {
-                if (i == r) continue;
-                double *ri = &T[(size_t)i * stride];
-                double f = ri[q];
-                if (f == 0.0) continue;
-                axpy_neg(ri, prow, f, N);
-                ri[q] = 0.0;
-                ops += N;
-            }
-            double f = d[q];
-            if (f != 0.0) { axpy_neg(d.data(), prow, f, N); d[q] = 0.0; }
-            st[k] = below ? AT_LO : AT_UP;
-            st[q] = BASIC; B[r] = q;
-        }
-        return LP_LIMIT;
-    }
-
-    // LP optimum over ALL rows of R: re-optimise, bring in the rows the point violates, repeat
-    int solve(long max_iters) {
-        std::vector<std::pair<double, int>> bad;
-        for (;;) {
-            int s = reoptimise(max_iters);
-            if (s != LP_OPT) return s;
-            bad.clear();
-            ops += (double)R->col.size();
-            for (int i = 0; i < R->m; i++) {
-                if (where[i] >= 0) continue;
-                double a = R->activity(i, x.data());
-                double v = std::max(R->lo[i] - a, a - R->hi[i]);
-                if (v > FEAS_TOL) bad.push_back({-v, i});
-            }
-            if (bad.empty()) return LP_OPT;
-            std::sort(bad.begin(), bad.end());  // most violated first; ties by row index: deterministic
-            size_t take = std::min<size_t>(bad.size(), std::max<size_t>(32, bad.size() / 4));
-            for (size_t t = 0; t < take; t++) {
-                if (!activate(bad[t].second)) return LP_LIMIT;
-                if ((t & 15) == 15 && wall() > deadline) return LP_LIMIT;
-            }
-        }
-    }
-};
+using namespace lp;
 
 struct DSUlite {
     std::vector<int> p;
@@ -283,6 +38,12 @@ struct CompSolver {
     int n = 0;
     Rows R;
     std::vector<double> c, lb, ub;
+    // the coupled solve by price sweeps (csrc/price.h): where the sweeps run, and what the model's builder said about its structure
+    hqprice::Sweeper *sweeper = nullptr;
+    std::vector<double> row_scale;       // R's row i times row_scale[i] = the model's row
+    std::vector<uint8_t> row_implied;
+    std::vector<int32_t> col_group;
+    int price_sweeps = 0, price_rounds = 0; double price_us = 0.0;
     double deadline = 0; bool timed_out = false;
     long nodes = 0, lp_iters = 0;
     // incumbent
@@ -331,6 +92,29 @@ struct CompSolver {
         }
         double z = 0.0; for (int j = 0; j < n; j++) z += c[j] * x[j];
         if (!have || z > best + 1e-12 * std::fabs(best)) { have = true; best = z; bx = x; }
+    }
+    // A point from outside (the price sweeps): false when it violates a row or a bound; else raised greedily like greedy_from, returned in place
+    bool polish_point(std::vector<double> &x, double &value) {
+        if (coff.empty()) build_columns();
+        if ((int)x.size() != n) return false;
+        for (int j = 0; j < n; j++) if (x[j] < lb[j] - FEAS_TOL || x[j] > ub[j] + FEAS_TOL) return false;
+        std::vector<double> act(R.m);
+        for (int i = 0; i < R.m; i++) { act[i] = R.activity(i, x.data()); if (act[i] < R.lo[i] - FEAS_TOL || act[i] > R.hi[i] + FEAS_TOL) return false; }
+        for (int j : by_cost) {
+            if (c[j] <= 0.0) break;
+            double step = ub[j] - x[j];
+            for (int k = coff[j]; k < coff[j + 1] && step >= 1.0; k++) {
+                const int i = crow[k]; const double a = ccoef[k];
+                if (a > 0.0 && R.hi[i] < INF) step = std::min(step, std::floor((R.hi[i] - act[i]) / a + 1e-9));
+                else if (a < 0.0 && R.lo[i] > -INF) step = std::min(step, std::floor((act[i] - R.lo[i]) / -a + 1e-9));
+            }
+            if (step < 1.0) continue;
+            x[j] += step;
+            for (int k = coff[j]; k < coff[j + 1]; k++) act[crow[k]] += ccoef[k] * step;
+        }
+        double z = 0.0; for (int j = 0; j < n; j++) z += c[j] * x[j];
+        value = z;
+        return true;
     }
     void round_and_repair(const Tab &t) {
         std::vector<double> x(n);
@@ -885,6 +669,37 @@ struct CompSolver {
         const double hard_deadline = deadline;
         const bool reserve_tail = n > 2000 && !in_lns;  // large model: the search below gets 70 % of the time, the window improvement the rest
         if (reserve_tail) { const double t0 = wall(); deadline = t0 + 0.7 * (hard_deadline - t0); root.deadline = deadline; }
+        if (sweeper && !in_lns && rel_gap > 0.0 && n >= (int)sweeper->min_cols && (int)col_group.size() == n) {
+            // The coupled model by price sweeps (csrc/price.h): the wide rows priced out, every worker's block solved exactly per set of prices on the
+            // MI355X, the incumbent rounded from the sweeps' own integer patterns.  Deterministic (no clock inside): replicas decide alike.
+            const double tp0 = wall();
+            hqprice::Request rq;
+            rq.n = n; rq.m = R.m; rq.roff = R.off.data(); rq.rcol = R.col.data(); rq.rcoef = R.coef.data(); rq.rlo = R.lo.data(); rq.rhi = R.hi.data();
+            rq.row_scale = row_scale.data(); rq.row_implied = (int)row_implied.size() == R.m ? row_implied.data() : nullptr; rq.col_group = col_group.data();
+            rq.c = c.data(); rq.ub = ub.data(); rq.incumbent = have ? bx.data() : nullptr; rq.incumbent_value = best; rq.rel_gap = rel_gap; rq.trace = tracing;
+            rq.polish = [this](std::vector<double> &x, double &value) { return polish_point(x, value); };
+            bool lbzero = true; for (int j = 0; j < n && lbzero; j++) lbzero = lb[j] == 0.0;
+            hqprice::Answer pa;
+            if (lbzero) pa = hqprice::solve(rq, *sweeper);
+            price_us = (wall() - tp0) * 1e6;
+            if (tracing) fprintf(stderr, "[milp] n=%d price sweeps: ran %d (%s) sweeps %u rounds %u bound %.9f point %.9f incumbent %.9f, %.3f ms of which %.3f ms inside the sweeps\n", n, (int)pa.ran, pa.why, pa.sweeps, pa.rounds, pa.ran ? pa.bound : -1.0, pa.x.empty() ? -1.0 : pa.x_value, have ? best : -1.0, price_us / 1e3, sweeper->stat_sweep_us / 1e3);
+            if (pa.ran) {
+                price_sweeps = (int)pa.sweeps; price_rounds = (int)pa.rounds;
+                nodes += pa.sweeps;
+                if (!pa.x.empty() && (!have || pa.x_value > best)) { bx = pa.x; best = pa.x_value; have = true; }
+                root_bound = std::min(root_bound, pa.bound * (1.0 + 1e-9) + 1e-12);
+                deadline = hard_deadline;
+                if (certified()) { canonical_done = false; xout = bx; trace("certified by the price sweeps"); return 1; }
+                if (have) {  // what the sweeps leave open goes to the host's window search, against their bound
+                    trace("window search against the price bound");
+                    lns_schedule(deadline - 0.05);
+                    xout = bx;
+                    if (certified()) { canonical_done = false; trace("certificate only"); return 1; }
+                    timed_out = true;
+                    return 2;
+                }
+            }
+        }
         if (n > 2000 && have && !in_lns) {
             // Large model with block structure (an unsaturated tick of the whole cluster: one block per worker, the batch-size rows across): its LP bound
             // comes from the Lagrangian over the wide rows in a fraction of a second, and the rest of the time belongs to the window search, which stops
@@ -1137,7 +952,7 @@ bool sparse_greedy(const Model &mdl, const std::vector<double> &ub, std::vector<
 // exactly what HiGHS accepts there.
 const double ROW_TOL = 1e-6;
 
-Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double rel_gap) {
+Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double rel_gap, hqprice::Sweeper *sweeper) {
     Model snapped;  // a copy of the model only when a coefficient really has to be snapped (a block of a worker class has no BOOL column at all)
     bool need_snap = false;
     for (size_t k = 0; k < mdl_in.rcoef.size() && !need_snap; k++) {
@@ -1341,7 +1156,9 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             for (auto &t : terms) t.second /= sc;
             double b = mdl.rhs[i] / sc;
             cs.R.add(terms, mdl.rtype[i] == ROW_MAX ? -INF : b, mdl.rtype[i] == ROW_MIN ? INF : b);
+            if (sweeper) { cs.row_scale.push_back(sc); cs.row_implied.push_back((size_t)i < mdl.row_implied.size() ? mdl.row_implied[(size_t)i] : 0); }
         }
+        if (sweeper && (int)mdl.col_group.size() == n) { cs.sweeper = sweeper; cs.col_group.resize(cs.n); for (int k = 0; k < cs.n; k++) cs.col_group[k] = mdl.col_group[cols[k]]; }
         // identical components (same rows, bounds and — up to 2^-40 relative — the same normalised costs) share one solve:
         // workers with equal free/total vectors produce them by the hundred (solver.rs:95-192 builds one block per worker)
         std::string sig;
@@ -1373,6 +1190,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
         if (memo_ok && !cs.timed_out && cs.canonical_done && (st == 0 || st == 1)) memo.emplace(std::move(sig), std::make_pair(st, xo));
         if (!cs.canonical_done || st == 2) res.canonical = false;
         res.nodes += cs.nodes; res.lp_iters += cs.lp_iters;
+        res.price_sweeps += cs.price_sweeps; res.price_rounds += cs.price_rounds; res.price_total_us += cs.price_us;
         if (st == 0) {
             if (cs.timed_out) {  // nothing found in time: all-zero placement with every blocker flag on (feasible for the tick's models)
                 res.optimal = false;

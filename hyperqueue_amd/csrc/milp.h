@@ -18,6 +18,8 @@
 #include <cstdint>
 #include <vector>
 
+namespace hqprice { struct Sweeper; }
+
 namespace hqmilp {
 
 enum { COL_NAT = 0, COL_BOOL = 1 };
@@ -32,6 +34,12 @@ struct Model {
     std::vector<int> rcol;
     std::vector<double> rcoef;
     std::vector<double> start;  // optional integral starting point (ncols values); used as incumbent if it satisfies every row
+    // Optional structure hints of the model's builder (both empty = none; the solver's answer never depends on them, only how fast it gets there):
+    //   col_group[j] >= 0: column j belongs to that block (the tick: a worker's placement columns, solver.rs:95-192); -1: a column of the whole model
+    //                      (the "blocker short" flags, solver.rs:233-253).  What the price sweeps of csrc/price.cpp decompose along.
+    //   row_implied[i] != 0: row i is implied, for INTEGER points, by the other rows of its block (a cut from the block's own integer optimum)
+    std::vector<int32_t> col_group;
+    std::vector<uint8_t> row_implied;
     int ncols() const { return (int)obj.size(); }
     int nrows() const { return (int)rhs.size(); }
     int add_col(double w, uint8_t k) {
@@ -58,6 +66,8 @@ struct Result {
     bool canonical = true;   // false: some component's tie-break phase was skipped / cut short (or not requested): x is an optimum, not THE canonical one
     long nodes = 0, lp_iters = 0;
     int n_components = 0;
+    int price_sweeps = 0, price_rounds = 0;      // block sweeps of the coupled solve / flag configurations tried (0: the host-only search ran)
+    double price_bound_us = 0, price_total_us = 0;
 };
 
 // What the reference calls optimal: solve_bounded sets `time_limit` and nothing else (solver/highs.rs:65-68), so HiGHS runs with its default
@@ -67,6 +77,8 @@ const double REFERENCE_MIP_REL_GAP = 1e-4;
 // canonical=true applies the lexicographic tie-break (always on in the product; off only in solver unit tests).
 // rel_gap: `optimal` = every component's incumbent is certified within rel_gap of its bound (0: proven exact only).  A certified component gets one
 // more, work-budgeted search with the exact rule; only where that finishes does the tie-break run, otherwise `canonical` comes back false.
-Result solve(const Model &m, double time_limit_s, bool canonical = true, double rel_gap = REFERENCE_MIP_REL_GAP);
+// sweeper (optional): the block sweeps of the coupled solve (csrc/price.h) — on the MI355X in the tick (k_price_sweep), the emulated wavefront in the CPU
+// tests; nullptr: the host-only search.  Used for large components whose columns carry `col_group`.
+Result solve(const Model &m, double time_limit_s, bool canonical = true, double rel_gap = REFERENCE_MIP_REL_GAP, hqprice::Sweeper *sweeper = nullptr);
 
 }  // namespace hqmilp

@@ -1,0 +1,544 @@
+// The coupled placement solve by price sweeps: host side (see price.h for the method, price_core.h for what one sweep does per block).
+#include "price.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "lp_tab.h"
+
+namespace hqprice {
+namespace {
+
+using hqmilp::lp::BASIC;
+using hqmilp::lp::INF;
+using hqmilp::lp::LP_OPT;
+using hqmilp::lp::Rows;
+using hqmilp::lp::Tab;
+
+constexpr int KMAX_HOST = 128;   // == price_core.h's KMAX (not included here: this file is host-only and also part of libhqalloc.so)
+constexpr int NMAX_BLOCK = 32, MMAX_BLOCK = 4;
+constexpr double GRID = 10000.0;  // ResourceAmount fractions per unit  common/resources/amount.rs:7
+constexpr int MAX_ROUNDS = 6, MAX_SWEEPS = 256;
+
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct CapRow { int flat; double rhs; std::vector<std::pair<int, double>> g; };  // x_flat + sum_g coef B_g <= rhs (the column's own coefficient divided out)
+
+struct Prob {
+    HostTables T;
+    std::vector<int> flat_of, model_of;       // model column <-> flat column (-1: global)
+    std::vector<int> gmodel;                   // global columns (model index)
+    std::vector<double> gcost;
+    int K = 0, G = 0;
+    std::vector<double> h;                     // wide rows in <= form
+    std::vector<uint8_t> ge;                   // the row was a `>=` row (entered negated)
+    std::vector<std::vector<std::pair<int, double>>> g_rows;   // per global column: (wide row, coefficient in <= form)
+    std::vector<int> r_off, r_col; std::vector<int32_t> r_coef;  // wide rows row-wise over the flat columns
+    std::vector<CapRow> caps;
+    std::vector<int32_t> base_cap;
+    std::vector<int> block_of_flat;
+};
+
+long long gcd_ll(long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a < 0 ? -a : a; }
+
+// The component -> blocks + wide rows.  Returns nullptr on success, else what kept the model on the host.
+const char *build(const Request &rq, Prob &P) {
+    const int n = rq.n;
+    if (!rq.col_group) return "no block hints";
+    // blocks in order of their first column (the tick: worker order)
+    std::vector<int> gid; gid.reserve(n);
+    int max_group = -1;
+    for (int j = 0; j < n; j++) max_group = std::max(max_group, rq.col_group[j]);
+    std::vector<int> block_of_group((size_t)max_group + 1, -1);
+    std::vector<int> bsize;
+    std::vector<int> blk(n, -1);
+    for (int j = 0; j < n; j++) {
+        const int g = rq.col_group[j];
+        if (g < 0) { P.gmodel.push_back(j); continue; }
+        if (block_of_group[g] < 0) { block_of_group[g] = (int)bsize.size(); bsize.push_back(0); }
+        blk[j] = block_of_group[g];
+        if (++bsize[blk[j]] > NMAX_BLOCK) return "block with more than 32 columns";
+    }
+    const int nb = (int)bsize.size();
+    if (nb < 8) return "fewer than 8 blocks";
+    P.G = (int)P.gmodel.size();
+    for (int j : P.gmodel) {
+        if (rq.ub[j] != 1.0) return "global column that is not 0/1";
+        if (rq.c[j] < 0.0) return "global column with negative cost";
+        P.gcost.push_back(rq.c[j]);
+    }
+    std::vector<int> gidx(n, -1);
+    for (int g = 0; g < P.G; g++) gidx[P.gmodel[g]] = g;
+    HostTables &T = P.T;
+    T.n_blocks = (uint32_t)nb;
+    T.blk_off.assign((size_t)nb + 1, 0);
+    for (int b = 0; b < nb; b++) T.blk_off[b + 1] = T.blk_off[b] + (uint32_t)bsize[b];
+    T.n_cols = T.blk_off[nb];
+    P.flat_of.assign(n, -1); P.model_of.assign(T.n_cols, -1); P.block_of_flat.assign(T.n_cols, -1);
+    {
+        std::vector<uint32_t> cur(T.blk_off.begin(), T.blk_off.end() - 1);
+        for (int j = 0; j < n; j++) if (blk[j] >= 0) { const int f = (int)cur[blk[j]]++; P.flat_of[j] = f; P.model_of[f] = j; P.block_of_flat[f] = blk[j]; }
+    }
+    T.col_cost.assign(T.n_cols, 0.0); T.col_a.assign((size_t)T.n_cols * MMAX_BLOCK, 0.0); T.col_cap.assign(T.n_cols, 0);
+    T.blk_m.assign(nb, 0); T.blk_cap.assign((size_t)nb * MMAX_BLOCK, 0.0);
+    for (uint32_t f = 0; f < T.n_cols; f++) {
+        const int j = P.model_of[f];
+        if (rq.c[j] < 0.0) return "negative cost";
+        if (!(rq.ub[j] <= 65535.0)) return "column bound above 65535";
+        T.col_cost[f] = rq.c[j];
+        T.col_cap[f] = (int32_t)std::floor(rq.ub[j] + 1e-9);
+    }
+    struct WideTmp { double h; uint8_t ge; std::vector<std::pair<int, int32_t>> cols; std::vector<std::pair<int, double>> g; };
+    std::vector<WideTmp> wide;
+    for (int i = 0; i < rq.m; i++) {
+        const int a = rq.roff[i], e = rq.roff[i + 1];
+        if (a == e) continue;
+        const double sc = rq.row_scale[i];
+        int b0 = -2; bool multi = false, has_g = false, nonneg = true;
+        int n_bcols = 0;
+        for (int k = a; k < e; k++) {
+            const int j = rq.rcol[k];
+            if (rq.rcoef[k] < 0.0) nonneg = false;
+            if (blk[j] < 0) { has_g = true; continue; }
+            n_bcols++;
+            if (b0 == -2) b0 = blk[j]; else if (blk[j] != b0) multi = true;
+        }
+        const bool is_le = rq.rlo[i] <= -INF, is_ge = rq.rhi[i] >= INF;
+        if (is_le && is_ge) continue;  // no constraint at all
+        if (!multi && !has_g && b0 >= 0) {  // a row of one block
+            if (rq.row_implied && rq.row_implied[i]) continue;  // implied for integer points by the block's other rows: the sweeps solve the blocks in integers
+            if (is_le && nonneg) {  // no point within the column bounds (which the block carries as caps) can violate it: e.g. the per-worker cut rows of a large cut
+                double amax = 0.0;
+                for (int k = a; k < e; k++) amax += rq.rcoef[k] * rq.ub[rq.rcol[k]];
+                if (amax <= rq.rhi[i] * (1.0 + 1e-12) + 1e-9) continue;
+            }
+            if (!is_le || !nonneg || rq.rhi[i] < 0.0) return "block row that is not a packing row";
+            const int r = T.blk_m[b0];
+            if (r >= MMAX_BLOCK) return "block with more than 4 rows";
+            long long g = 0; bool ok = true;
+            std::vector<std::pair<int, long long>> ai;
+            for (int k = a; k < e && ok; k++) {
+                const double v = rq.rcoef[k] * sc * GRID, rv = std::round(v);
+                if (rv < 1.0 || std::fabs(v - rv) > 1e-6 * std::max(1.0, rv) || rv >= 4.0e15) ok = false;
+                else { ai.push_back({P.flat_of[rq.rcol[k]], (long long)rv}); g = gcd_ll(g, (long long)rv); }
+            }
+            if (!ok) return "block row off the ResourceAmount grid";
+            const double capv = rq.rhi[i] * sc * GRID;
+            if (capv >= 4.0e15) return "block row capacity too large";
+            const long long capi = (long long)std::floor(capv + 1e-6);
+            if (g < 1) g = 1;
+            for (auto &t : ai) T.col_a[(size_t)t.first * MMAX_BLOCK + r] += (double)(t.second / g);  // (duplicate terms of one row are summed)
+            T.blk_cap[(size_t)b0 * MMAX_BLOCK + r] = (double)(capi / g);
+            T.blk_m[b0] = (uint8_t)(r + 1);
+            continue;
+        }
+        if (!is_le && !is_ge) return "equality or range row across blocks";
+        // vacuous rows: a `<=` row no point within the column bounds can violate, a `>=` row that holds at zero
+        if (is_le && nonneg) {
+            double amax = 0.0;
+            for (int k = a; k < e; k++) amax += rq.rcoef[k] * rq.ub[rq.rcol[k]];
+            if (amax <= rq.rhi[i] * (1.0 + 1e-12) + 1e-9) continue;
+        }
+        if (is_ge && nonneg && rq.rlo[i] <= 1e-12) continue;
+        if (!multi && has_g && n_bcols >= 1 && is_le && nonneg) {  // one block + flags: a conditional bound of the block's column(s)
+            if (n_bcols != 1) return "conditional bound over several columns of a block";
+            CapRow cr; cr.flat = -1; cr.rhs = 0.0;
+            double cx = 0.0;
+            for (int k = a; k < e; k++) if (blk[rq.rcol[k]] >= 0) { cr.flat = P.flat_of[rq.rcol[k]]; cx = rq.rcoef[k]; }
+            if (!(cx > 0.0)) return "conditional bound with a zero coefficient";
+            cr.rhs = rq.rhi[i] / cx;
+            for (int k = a; k < e; k++) if (blk[rq.rcol[k]] < 0) cr.g.push_back({gidx[rq.rcol[k]], rq.rcoef[k] / cx});
+            P.caps.push_back(std::move(cr));
+            continue;
+        }
+        if (n_bcols == 0) return "row over global columns only";
+        WideTmp w; w.ge = is_ge ? 1 : 0;
+        const double sign = is_le ? 1.0 : -1.0;
+        w.h = sign * (is_le ? rq.rhi[i] : rq.rlo[i]) * sc;
+        for (int k = a; k < e; k++) {
+            const int j = rq.rcol[k];
+            const double v = sign * rq.rcoef[k] * sc;
+            if (blk[j] < 0) { w.g.push_back({gidx[j], v}); continue; }
+            const double rv = std::round(v);
+            if (std::fabs(v - rv) > 1e-7 * std::max(1.0, std::fabs(rv)) || std::fabs(rv) > 1.0e9) return "wide row with a non-integer coefficient";
+            if (rv != 0.0) w.cols.push_back({P.flat_of[j], (int32_t)rv});
+        }
+        wide.push_back(std::move(w));
+        if ((int)wide.size() > KMAX_HOST) return "more than 128 wide rows";
+    }
+    for (int b = 0; b < nb; b++) if (T.blk_m[b] == 0) return "block without a resource row";
+    // every column of a block must be bounded by its block: a cap below 65536 is there (checked above); amounts that do not fit even once leave ub 0
+    P.K = (int)wide.size(); T.K = (uint32_t)P.K;
+    if (P.K == 0) return "no wide row";
+    P.h.resize(P.K); P.ge.resize(P.K); P.g_rows.assign(P.G, {});
+    std::vector<uint32_t> cnt(T.n_cols + 1, 0);
+    P.r_off.assign(1, 0);
+    for (int k = 0; k < P.K; k++) {
+        P.h[k] = wide[k].h; P.ge[k] = wide[k].ge;
+        for (auto &t : wide[k].cols) { cnt[t.first + 1]++; P.r_col.push_back(t.first); P.r_coef.push_back(t.second); }
+        P.r_off.push_back((int)P.r_col.size());
+        for (auto &t : wide[k].g) P.g_rows[t.first].push_back({k, t.second});
+    }
+    T.col_woff.assign(T.n_cols + 1, 0);
+    for (uint32_t f = 0; f < T.n_cols; f++) T.col_woff[f + 1] = T.col_woff[f] + cnt[f + 1];
+    T.w_row.resize(T.col_woff[T.n_cols]); T.w_coef.resize(T.col_woff[T.n_cols]);
+    {
+        std::vector<uint32_t> cur(T.col_woff.begin(), T.col_woff.end() - 1);
+        for (int k = 0; k < P.K; k++) for (auto &t : wide[k].cols) { const uint32_t p = cur[t.first]++; T.w_row[p] = (uint16_t)k; T.w_coef[p] = t.second; }
+    }
+    P.base_cap = T.col_cap;
+    return nullptr;
+}
+
+struct Cut { double cx = 0, bnd = 0; std::vector<long long> act; std::vector<double> pi; };
+
+struct Solver {
+    const Request &rq; Sweeper &sw; Prob P;
+    std::vector<Cut> cuts;
+    double relaxed_bound = INF;   // min over every evaluated pi of the Lagrangian with the flags relaxed to [0, 1]
+    std::vector<double> relaxed_pi;
+    double theta_scale = 1.0;
+    std::vector<double> pmax;
+    bool failed = false;
+    size_t cut_lo = 0;            // the master works on cuts[cut_lo ..): points evaluated under the column bounds now in force
+    bool base_caps = true;        // the sweeps run under the model's own column bounds (only those bound the relaxed model)
+    Solver(const Request &r, Sweeper &s) : rq(r), sw(s) {}
+
+    // one sweep at pi; returns the cut's index or -1
+    int evaluate(const std::vector<double> &pi) {
+        if ((int)cuts.size() >= MAX_SWEEPS) return -1;
+        SweepTotals tot;
+        const double t0 = now_us();
+        if (!sw.sweep(pi.data(), tot)) { failed = true; return -1; }
+        sw.stat_sweep_us += now_us() - t0; sw.stat_sweeps++;
+        Cut c; c.cx = tot.cx; c.bnd = tot.bnd; c.act = tot.act; c.pi = pi;
+        cuts.push_back(std::move(c));
+        // the model's bound at these prices, flags relaxed: pi.h + sum_w V_w(pi) + sum_g max(0, c_g - pi.A_g)
+        double L = cuts.back().bnd;
+        for (int k = 0; k < P.K; k++) L += pi[k] * P.h[k];
+        for (int g = 0; g < P.G; g++) { double r = P.gcost[g]; for (auto &t : P.g_rows[g]) r -= pi[t.first] * t.second; if (r > 0.0) L += r; }
+        if (base_caps && L < relaxed_bound) { relaxed_bound = L; relaxed_pi = pi; }
+        return (int)cuts.size() - 1;
+    }
+    double fixed_value(const Cut &c, const std::vector<double> &hB, double cB) const {
+        double L = c.bnd + cB;
+        for (int k = 0; k < P.K; k++) L += c.pi[k] * hB[k];
+        return L;
+    }
+
+    // Cutting-plane master (Kelley) for the model with its flags fixed: minimise pi.hB + theta over theta + pi.act_k >= cx_k.  Returns false when the
+    // configuration cannot beat `cutoff` (or is infeasible); on success `lambda` holds the master's multipliers of the cuts (summing to 1) and pi_out
+    // the final prices.
+    bool kelley(const std::vector<double> &hB, double cB, double cutoff, double tol, std::vector<double> &lambda, std::vector<double> &pi_out, double *bound_out) {
+        const int K = P.K;
+        Rows M; M.n = K + 1;
+        std::vector<double> mc(K + 1), mlb(K + 1, 0.0), mub(K + 1);
+        for (int k = 0; k < K; k++) { mc[k] = -hB[k] / theta_scale; mub[k] = pmax[k]; }
+        mc[K] = -1.0; mub[K] = 4.0;
+        std::vector<double> cut_scale;
+        std::vector<std::pair<int, double>> terms;
+        size_t in_master = cut_lo;
+        auto push_cuts = [&](Tab *mt) {
+            for (; in_master < cuts.size(); in_master++) {
+                const Cut &c = cuts[in_master];
+                terms.clear(); double sc = 1.0;
+                for (int k = 0; k < K; k++) if (c.act[k] != 0) { const double v = (double)c.act[k] / theta_scale; terms.push_back({k, v}); sc = std::max(sc, std::fabs(v)); }
+                terms.push_back({K, 1.0});
+                for (auto &t : terms) t.second /= sc;
+                M.add(terms, c.cx / theta_scale / sc, INF);
+                cut_scale.push_back(sc);
+                if (mt) mt->where.push_back(-1);
+            }
+        };
+        push_cuts(nullptr);
+        Tab mt; mt.init(&M, mc, mlb, mub);
+        double ub_best = INF; std::vector<double> pi_best(K, 0.0);
+        for (size_t k = cut_lo; k < cuts.size(); k++) { const double L = fixed_value(cuts[k], hB, cB); if (L < ub_best) { ub_best = L; pi_best = cuts[k].pi; } }
+        std::vector<double> pi(K), pi_prev_master;
+        double lb_master = -INF;
+        bool converged = false;
+        for (int it = 0; it < 200; it++) {
+            if (mt.solve(200000) != LP_OPT) return false;
+            lb_master = -mt.objective() * theta_scale + cB;
+            if (ub_best < cutoff) return false;                         // even the relaxation of this configuration is below the incumbent
+            if (ub_best - lb_master <= tol * std::fabs(ub_best)) { converged = true; break; }
+            bool same = !pi_prev_master.empty();
+            for (int k = 0; k < K && same; k++) same = std::fabs(mt.x[k] - pi_prev_master[k]) <= 1e-15 + 1e-12 * std::fabs(mt.x[k]);
+            pi_prev_master.assign(mt.x.begin(), mt.x.begin() + K);
+            const double alpha = (it < 3 || same) ? 0.0 : 0.3;       // in-out: between the best point so far and the master's proposal
+            for (int k = 0; k < K; k++) pi[k] = alpha * pi_best[k] + (1.0 - alpha) * mt.x[k];
+            const int ci = evaluate(pi);
+            if (ci < 0) break;
+            const double L = fixed_value(cuts[ci], hB, cB);
+            if (L < ub_best) { ub_best = L; pi_best = pi; }
+            push_cuts(&mt);
+        }
+        if (!converged) {
+            if (mt.solve(200000) != LP_OPT) return false;
+            lb_master = -mt.objective() * theta_scale + cB;
+            if (ub_best - lb_master > 1e-3 * std::fabs(ub_best)) return false;  // nowhere near: no usable multipliers
+        }
+        lambda.assign(cuts.size(), 0.0);
+        double lsum = 0.0;
+        for (size_t k = 0; k + cut_lo < cuts.size() && k < (size_t)M.m; k++) { const int a = mt.where[k]; if (a >= 0 && mt.st[M.n + a] != BASIC) { lambda[k + cut_lo] = std::fabs(mt.d[M.n + a]) / cut_scale[k]; lsum += lambda[k + cut_lo]; } }
+        if (!(lsum > 0.0)) return false;
+        for (double &l : lambda) l /= lsum;
+        pi_out.assign(mt.x.begin(), mt.x.begin() + K);
+        *bound_out = ub_best;
+        return true;
+    }
+
+    // One integer pattern per block out of the active cuts' maximisers, by error diffusion over the wide rows' running totals; then the repair.
+    // `hB`: right-hand sides with the flags fixed.  Returns the point over the flat columns (empty: no usable point).
+    std::vector<uint16_t> round_patterns(const std::vector<double> &lambda, const std::vector<double> &pi, const std::vector<double> &hB) {
+        const int K = P.K; const HostTables &T = P.T;
+        const uint32_t S = (uint32_t)cuts.size();
+        const uint16_t *pat = sw.patterns(S);
+        if (!pat) { failed = true; return {}; }
+        std::vector<int> active;
+        for (uint32_t k = 0; k < S; k++) if (lambda[k] > 1e-9) active.push_back((int)k);
+        if (active.empty()) return {};
+        double lsum = 0.0; for (int k : active) lsum += lambda[k];
+        const int Q = (int)active.size();
+        // row weights: relative deviation; rows the LP leaves slack count little
+        std::vector<double> lpact(K, 0.0), wgt(K);
+        for (int k : active) for (int r = 0; r < K; r++) lpact[r] += lambda[k] / lsum * (double)cuts[k].act[r];
+        for (int r = 0; r < K; r++) {
+            const bool tight = pi[r] > 1e-12 || hB[r] - lpact[r] <= 1e-6 * std::max(1.0, std::fabs(hB[r]));
+            wgt[r] = (tight ? 1.0 : 0.02) / std::max(1.0, std::fabs(hB[r]));
+        }
+        auto block_act = [&](uint32_t b, const uint16_t *x, std::vector<double> &out) {  // A_w x of block b for the pattern row x (flat layout)
+            std::fill(out.begin(), out.end(), 0.0);
+            for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { const uint16_t xv = x[f]; if (!xv) continue; for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) out[T.w_row[e]] += (double)T.w_coef[e] * (double)xv; }
+        };
+        std::vector<uint16_t> x(T.n_cols, 0);
+        std::vector<double> cum(K, 0.0), tgt(K, 0.0);
+        std::vector<std::vector<double>> cand(Q, std::vector<double>(K));
+        std::vector<int> chosen(T.n_blocks, 0);
+        for (uint32_t b = 0; b < T.n_blocks; b++) {
+            for (int q = 0; q < Q; q++) { block_act(b, pat + (size_t)active[q] * T.n_cols, cand[q]); const double l = lambda[active[q]] / lsum; for (int r = 0; r < K; r++) tgt[r] += l * cand[q][r]; }
+            int bq = 0; double be = INF;
+            for (int q = 0; q < Q; q++) {
+                double e = 0.0;
+                for (int r = 0; r < K; r++) e += std::fabs(cum[r] + cand[q][r] - tgt[r]) * wgt[r];
+                if (e < be - 1e-15) { be = e; bq = q; }
+            }
+            for (int r = 0; r < K; r++) cum[r] += cand[bq][r];
+            chosen[b] = active[bq];
+            memcpy(&x[T.blk_off[b]], pat + (size_t)active[bq] * T.n_cols + T.blk_off[b], (size_t)(T.blk_off[b + 1] - T.blk_off[b]) * 2);
+        }
+        // `>=` rows that came out short: single-block pattern switches (any sweep's pattern of that block) that close the shortfall at the least loss
+        auto ge_short = [&](const std::vector<double> &c) { double s = 0.0; for (int r = 0; r < K; r++) if (P.ge[r] && c[r] > hB[r] + 1e-9) s += c[r] - hB[r]; return s; };
+        if (ge_short(cum) > 0.0) {
+            std::vector<int> pool = active;
+            for (int k = (int)S - 1; k >= 0 && (int)pool.size() < Q + 12; k--) if (std::find(pool.begin(), pool.end(), k) == pool.end()) pool.push_back(k);
+            std::vector<double> a0(K), a1(K), c2(K);
+            double cmax = 0.0; for (double c : T.col_cost) cmax = std::max(cmax, c);
+            for (int moves = 0; moves < 256 && ge_short(cum) > 0.0; moves++) {
+                const double base = ge_short(cum);
+                double best_score = -INF; int bb = -1, bk = -1;
+                for (uint32_t b = 0; b < T.n_blocks; b++) {
+                    block_act(b, pat + (size_t)chosen[b] * T.n_cols, a0);
+                    double v0 = 0.0; for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) v0 += T.col_cost[f] * (double)x[f];
+                    for (int k : pool) {
+                        if (k == chosen[b]) continue;
+                        const uint16_t *px = pat + (size_t)k * T.n_cols;
+                        block_act(b, px, a1);
+                        double gain = 0.0, newviol = 0.0;
+                        for (int r = 0; r < K; r++) {
+                            const double c = cum[r] - a0[r] + a1[r];
+                            if (P.ge[r]) { gain += std::max(0.0, cum[r] - hB[r]) - std::max(0.0, c - hB[r]); }
+                            else newviol += std::max(0.0, c - hB[r]) - std::max(0.0, cum[r] - hB[r]);
+                        }
+                        if (!(gain > 1e-9)) continue;
+                        double v1 = 0.0; for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) v1 += T.col_cost[f] * (double)px[f];
+                        const double score = gain * 10.0 * cmax - (v0 - v1) - std::max(0.0, newviol) * cmax;
+                        if (score > best_score) { best_score = score; bb = (int)b; bk = k; }
+                    }
+                }
+                if (bb < 0) break;
+                block_act((uint32_t)bb, pat + (size_t)chosen[bb] * T.n_cols, a0);
+                block_act((uint32_t)bb, pat + (size_t)bk * T.n_cols, a1);
+                for (int r = 0; r < K; r++) cum[r] += a1[r] - a0[r];
+                chosen[bb] = bk;
+                memcpy(&x[T.blk_off[bb]], pat + (size_t)bk * T.n_cols + T.blk_off[bb], (size_t)(T.blk_off[bb + 1] - T.blk_off[bb]) * 2);
+                if (ge_short(cum) >= base - 1e-9) break;
+            }
+            if (ge_short(cum) > 0.0) return {};
+        }
+        // `<=` rows that came out over: take single tasks away, the cheapest first, never pushing a `>=` row short
+        for (int r = 0; r < K; r++) {
+            if (cum[r] <= hB[r] + 1e-9) continue;
+            std::vector<int> cols;
+            for (int k = P.r_off[r]; k < P.r_off[r + 1]; k++) if (P.r_coef[k] > 0 && x[P.r_col[k]] > 0) cols.push_back(k);
+            std::sort(cols.begin(), cols.end(), [&](int a, int b) { const double ca = T.col_cost[P.r_col[a]] / P.r_coef[a], cb = T.col_cost[P.r_col[b]] / P.r_coef[b]; return ca < cb || (ca == cb && a > b); });
+            for (int k : cols) {
+                const int f = P.r_col[k];
+                while (x[f] > 0 && cum[r] > hB[r] + 1e-9) {
+                    bool ok = true;
+                    for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1] && ok; e++) if (T.w_coef[e] < 0 && cum[T.w_row[e]] - (double)T.w_coef[e] > hB[T.w_row[e]] + 1e-9) ok = false;
+                    if (!ok) break;
+                    x[f]--;
+                    for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) cum[T.w_row[e]] -= (double)T.w_coef[e];
+                }
+                if (cum[r] <= hB[r] + 1e-9) break;
+            }
+            if (cum[r] > hB[r] + 1e-9) return {};
+        }
+        return x;
+    }
+};
+
+}  // namespace
+
+Answer solve(const Request &rq, Sweeper &sw) {
+    Answer ans;
+    Solver S(rq, sw);
+    if (const char *why = build(rq, S.P)) { ans.why = why; return ans; }
+    Prob &P = S.P;
+    const int K = P.K, G = P.G;
+    sw.stat_sweeps = 0; sw.stat_sweep_us = 0;
+    if (!sw.begin(P.T, MAX_SWEEPS)) { ans.why = "sweeper refused the model"; return ans; }
+    struct Ender { Sweeper &s; ~Ender() { s.end(); } } ender{sw};
+    // price caps: beyond pmax every column of the row has a negative reduced cost (`<=` rows); for `>=` rows a multiple of the largest cost per unit
+    S.pmax.assign(K, 0.0);
+    {
+        double cmax = 0.0; for (double c : P.T.col_cost) cmax = std::max(cmax, c);
+        for (int k = 0; k < K; k++) {
+            double p = 0.0; bool neg = false; int32_t amin = INT32_MAX;
+            for (int t = P.r_off[k]; t < P.r_off[k + 1]; t++) {
+                const int32_t a = P.r_coef[t];
+                if (a > 0) p = std::max(p, P.T.col_cost[P.r_col[t]] / (double)a); else { neg = true; amin = std::min(amin, -a); }
+            }
+            if (neg) p = std::max(p, 64.0 * cmax / (double)std::max<int32_t>(1, amin));
+            S.pmax[k] = p;
+        }
+    }
+    std::vector<double> pi0(K, 0.0);
+    if (S.evaluate(pi0) < 0) { ans.why = "sweep failed"; return ans; }
+    S.theta_scale = std::max(S.cuts[0].bnd, 1e-9);
+    ans.ran = true;
+    double best_value = rq.incumbent ? rq.incumbent_value : -INF;
+    std::vector<double> B(G, 1.0);
+    std::vector<double> hB(K);
+    std::vector<int32_t> caps(P.base_cap);
+    std::vector<double> final_pi;
+    for (int round = 0; round < MAX_ROUNDS && !S.failed; round++) {
+        ans.rounds++;
+        double cB = 0.0;
+        for (int k = 0; k < K; k++) hB[k] = P.h[k];
+        for (int g = 0; g < G; g++) { cB += P.gcost[g] * B[g]; for (auto &t : P.g_rows[g]) hB[t.first] -= t.second * B[g]; }
+        if (!P.caps.empty()) {  // conditional bounds with the flags fixed
+            caps = P.base_cap;
+            for (const CapRow &cr : P.caps) { double r = cr.rhs; for (auto &t : cr.g) r -= t.second * B[t.first]; const double c = std::floor(r + 1e-9); if (c < (double)caps[cr.flat]) caps[cr.flat] = c < 0.0 ? 0 : (int32_t)c; }
+            if (!sw.set_caps(caps.data())) { S.failed = true; break; }
+            // (the cuts of earlier rounds are points of THEIR bounds: a round with other bounds starts a new master)
+            S.base_caps = false; S.cut_lo = S.cuts.size();
+            if (S.evaluate(pi0) < 0) break;
+        }
+        std::vector<double> lambda, pi;
+        double bound_B = INF;
+        const double cutoff = best_value > -INF ? best_value * (1.0 - 1e-12) : -INF;
+        if (!S.kelley(hB, cB, cutoff, std::max(1e-6, rq.rel_gap / 50.0), lambda, pi, &bound_B)) break;
+        final_pi = pi;
+        std::vector<uint16_t> xf = S.round_patterns(lambda, pi, hB);
+        if (xf.empty()) break;
+        std::vector<double> x(rq.n, 0.0);
+        for (uint32_t f = 0; f < P.T.n_cols; f++) x[P.model_of[f]] = (double)xf[f];
+        for (int g = 0; g < G; g++) x[P.gmodel[g]] = B[g];
+        double value = 0.0;
+        if (!rq.polish || !rq.polish(x, value)) break;  // the caller's rows say no: nothing to build on
+        if (rq.trace) fprintf(stderr, "[price] round %d: %zu sweeps so far, bound with these flags %.9f, point %.9f, model bound %.9f\n", round, S.cuts.size(), bound_B, value, S.relaxed_bound);
+        if (value > best_value) { best_value = value; ans.x = x; ans.x_value = value; }
+        if (S.relaxed_bound <= best_value + rq.rel_gap * std::fabs(best_value)) break;  // certified
+        // flags whose rows hold without them are dropped (they only ever restrict)
+        bool dropped = false;
+        std::vector<double> act(K, 0.0);
+        for (int k = 0; k < K; k++) for (int t = P.r_off[k]; t < P.r_off[k + 1]; t++) act[k] += (double)P.r_coef[t] * x[P.model_of[P.r_col[t]]];
+        for (int g = 0; g < G; g++) for (auto &t : P.g_rows[g]) act[t.first] += t.second * x[P.gmodel[g]];
+        for (int g = 0; g < G; g++) {
+            if (B[g] != 1.0 || P.gcost[g] != 0.0 || x[P.gmodel[g]] != 1.0) continue;
+            bool ok = true;
+            for (auto &t : P.g_rows[g]) if (act[t.first] - t.second > P.h[t.first] + 1e-7 * (1.0 + std::fabs(P.h[t.first]))) ok = false;
+            if (!ok) continue;
+            B[g] = 0.0; dropped = true;
+            for (auto &t : P.g_rows[g]) act[t.first] -= t.second;
+        }
+        if (!dropped) break;
+    }
+    if (S.failed) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
+    // Not certified against the bound seen so far and the model has flags: the master of the RELAXED model (flags in [0, 1]) may still bring the bound
+    // down — its cuts are the points already evaluated, the flags enter through one extra variable each (mu_g >= c_g - pi.A_g, mu_g >= 0).
+    if (G > 0 && best_value > -INF && S.relaxed_bound > best_value + rq.rel_gap * std::fabs(best_value)) {
+        if (!S.base_caps) {  // back to the model's own column bounds: only sweeps under those bound the relaxed model
+            if (!sw.set_caps(P.base_cap.data())) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
+            S.base_caps = true; S.cut_lo = S.cuts.size();
+            if (S.evaluate(pi0) < 0) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
+        }
+        Rows M; M.n = K + 1 + G;
+        std::vector<double> mc(M.n), mlb(M.n, 0.0), mub(M.n);
+        for (int k = 0; k < K; k++) { mc[k] = -P.h[k] / S.theta_scale; mub[k] = S.pmax[k]; }
+        mc[K] = -1.0; mub[K] = 4.0;
+        for (int g = 0; g < G; g++) { mc[K + 1 + g] = -1.0; mub[K + 1 + g] = 4.0; }
+        std::vector<std::pair<int, double>> terms;
+        for (int g = 0; g < G; g++) {  // mu_g + pi.A_g >= c_g
+            terms.clear(); double sc = 1.0;
+            for (auto &t : P.g_rows[g]) { const double v = t.second / S.theta_scale; terms.push_back({t.first, v}); sc = std::max(sc, std::fabs(v)); }
+            terms.push_back({K + 1 + g, 1.0});
+            for (auto &t : terms) t.second /= sc;
+            M.add(terms, P.gcost[g] / S.theta_scale / sc, INF);
+        }
+        size_t in_master = S.cut_lo;
+        Tab mt;
+        auto push_cuts = [&](bool live) {
+            for (; in_master < S.cuts.size(); in_master++) {
+                const Cut &c = S.cuts[in_master];
+                terms.clear(); double sc = 1.0;
+                for (int k = 0; k < K; k++) if (c.act[k] != 0) { const double v = (double)c.act[k] / S.theta_scale; terms.push_back({k, v}); sc = std::max(sc, std::fabs(v)); }
+                terms.push_back({K, 1.0});
+                for (auto &t : terms) t.second /= sc;
+                M.add(terms, c.cx / S.theta_scale / sc, INF);
+                if (live) mt.where.push_back(-1);
+            }
+        };
+        push_cuts(false);
+        mt.init(&M, mc, mlb, mub);
+        std::vector<double> pi(K), pi_best = S.relaxed_pi.empty() ? std::vector<double>(K, 0.0) : S.relaxed_pi, prev;
+        for (int it = 0; it < 120; it++) {
+            if (mt.solve(200000) != LP_OPT) break;
+            const double lb_master = -mt.objective() * S.theta_scale;
+            if (S.relaxed_bound <= best_value + rq.rel_gap * std::fabs(best_value)) break;   // certified
+            if (S.relaxed_bound - lb_master <= 1e-6 * std::fabs(S.relaxed_bound)) break;      // the bound is what it is
+            bool same = !prev.empty();
+            for (int k = 0; k < K && same; k++) same = std::fabs(mt.x[k] - prev[k]) <= 1e-15 + 1e-12 * std::fabs(mt.x[k]);
+            prev.assign(mt.x.begin(), mt.x.begin() + K);
+            const double alpha = (it < 2 || same) ? 0.0 : 0.3;
+            for (int k = 0; k < K; k++) pi[k] = alpha * pi_best[k] + (1.0 - alpha) * mt.x[k];
+            const double before = S.relaxed_bound;
+            if (S.evaluate(pi) < 0) break;
+            if (S.relaxed_bound < before) pi_best = pi;
+            push_cuts(true);
+        }
+        if (S.failed) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
+    }
+    ans.bound = S.relaxed_bound;
+    ans.sweeps = (uint32_t)sw.stat_sweeps;
+    // for the host's guided windows: blocks, their values and the reduced costs at the last prices
+    if (!final_pi.empty()) {
+        ans.block_of.assign(rq.n, -1); ans.rcost.assign(rq.n, 0.0);
+        for (uint32_t f = 0; f < P.T.n_cols; f++) {
+            const int j = P.model_of[f];
+            ans.block_of[j] = P.block_of_flat[f];
+            double r = P.T.col_cost[f];
+            for (uint32_t e = P.T.col_woff[f]; e < P.T.col_woff[f + 1]; e++) r -= final_pi[P.T.w_row[e]] * (double)P.T.w_coef[e];
+            ans.rcost[j] = r;
+        }
+    }
+    return ans;
+}
+
+}  // namespace hqprice

@@ -1,0 +1,207 @@
+// One PRICE SWEEP of the coupled placement model: every worker's block solved exactly under the current prices of the model's wide rows.
+//
+// Where it sits.  run_scheduling_solver (/root/reference/crates/tako/src/internal/scheduler/solver.rs:95-192) creates one block of `nat` columns
+// per worker — one column per (batch, variant) the worker can run, one row per resource — and couples the blocks through a handful of WIDE rows:
+// the batch-size rows of unsaturated batches (:264-271), the "blocker short" rows (:233-253) and the priority-cut rows over the workers where a
+// blocker leaves no gap (:395-429).  The reference hands the whole thing to HiGHS (solver/highs.rs:65-88).  Here the wide rows are priced out
+// (csrc/price.cpp: Dantzig-Wolfe / Lagrangian over the wide rows, a cutting-plane master of K + 1 variables on the host), and what is left per set
+// of prices pi is W independent bounded integer knapsacks
+//        V_w(pi) = max { (c_w - pi A_w) . x :  R_w x <= free_w,  0 <= x <= cap,  x integer }        (<= 32 columns, <= 4 rows)
+// — the W-way data parallelism of the coupled tick, one wavefront per worker, solved EXACTLY (integer blocks, not their LP relaxation: the bound
+// pi . h + sum_w V_w(pi) is then at least as tight as the LP bound HiGHS starts from, and every sweep's maximisers are integer patterns the primal
+// side can use as they are).  The block solver is block_core.h's: dual-vertex pool, 64 greedy fills, depth-first walk with 64 children per step.
+//
+// Everything lane-varying goes through the Wave policy, so the CPU tests execute the same code with the wavefront emulated (hqblock::HostWave).
+#pragma once
+#include "block_core.h"
+
+namespace hqprice {
+
+using hqblock::MMAX;
+using hqblock::NMAX;
+using hqblock::Shared;
+using hqblock::WAVE;
+
+constexpr int KMAX = 128;  // wide rows of one model (prices staged in LDS)
+
+// The model's blocks, flattened (device-visible memory).  Column q of block b is entry blk_off[b] + q of the col_* arrays.
+struct Tables {
+    uint32_t n_blocks, n_cols, K;
+    const uint32_t *blk_off;   // [n_blocks + 1]
+    const uint8_t *blk_m;      // [n_blocks] resource rows of the block (<= MMAX)
+    const double *blk_cap;     // [n_blocks * MMAX] capacities on the row's own grid (integers carried in f64)
+    const double *col_cost;    // [n_cols] objective coefficient (the component's scaled costs, >= 0)
+    const double *col_a;       // [n_cols * MMAX] amounts on the row's grid (integers carried in f64; 0 = the column does not use the row)
+    const int32_t *col_cap;    // [n_cols] upper bound of the column
+    const uint32_t *col_woff;  // [n_cols + 1] the column's entries in the wide rows
+    const uint16_t *w_row;     // wide row index (< K)
+    const int32_t *w_coef;     // integer coefficient (in the row's <= form: a `>=` row enters negated)
+};
+
+// What one sweep leaves behind.
+struct SweepOut {
+    uint16_t *x;          // [n_cols] the maximisers: one integer pattern per block
+    double *blk_cx;       // [n_blocks] c . x of the block's pattern (original costs)
+    double *blk_rc;       // [n_blocks] (c - pi A) . x
+    double *blk_bnd;      // [n_blocks] >= V_w(pi): equal to blk_rc (plus rounding slack) unless the block's search ran out of budget, then its LP bound
+    long long *act;       // [K] sum over blocks of A_w x — integer coefficients, so the atomic sums are exact and order-free
+    uint32_t *blk_steps;  // [n_blocks] search steps (0 = closed at the root); bit 31: budget exhausted
+};
+
+// columns of a priced block whose reduced cost is at most this fraction of the block's largest original cost stay at zero (their possible
+// contribution is added to the block's bound)
+constexpr double RC_DROP = 1e-12;
+
+template <class W>
+HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *pi, uint32_t b, const SweepOut &out, uint32_t budget) {
+    const uint32_t c0 = t.blk_off[b], nb = t.blk_off[b + 1] - c0;
+    const int m = (int)t.blk_m[b];
+    // stage the prices: the dual pool is empty at this point, its storage is the staging area
+    double *spi = &S.py[0][0];
+    static_assert(hqblock::PCAP * MMAX >= KMAX, "the prices are staged in the dual pool's storage");
+    wv.each([&](int lane) {
+        for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) spi[k] = pi[k];
+        if (lane < NMAX) S.colcap[lane] = 2147483647;
+        if (lane < MMAX) S.cap[lane] = lane < m ? t.blk_cap[(size_t)b * MMAX + lane] : 0.0;
+    });
+    if (wv.first()) { S.status = hqblock::ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = m; S.npool = 0; S.usedres = 0; }
+    wv.sync();
+    // lane q: reduced cost of column q
+    wv.each([&](int lane) {
+        double rc = -1.0, cost = 0.0;
+        if ((uint32_t)lane < nb) {
+            const uint32_t j = c0 + (uint32_t)lane;
+            cost = t.col_cost[j];
+            rc = cost;
+            for (uint32_t e = t.col_woff[j]; e < t.col_woff[j + 1]; e++) rc -= spi[t.w_row[e]] * (double)t.w_coef[e];
+        }
+        S.lane_val[lane] = rc;
+        S.gx[0][lane] = 0;  // (reused below as the eligibility flags' scratch: cleared)
+    });
+    wv.sync();
+    int lmax = -1;
+    const double cmax = wv.argmax([&](int lane) { return (uint32_t)lane < nb ? t.col_cost[c0 + (uint32_t)lane] : -1.0; }, &lmax);
+    const double thr = (cmax > 0.0 ? cmax : 1.0) * RC_DROP;
+    const uint64_t elig = wv.ballot([&](int lane) { return (uint32_t)lane < nb && S.lane_val[lane] > thr && t.col_cap[c0 + (uint32_t)lane] >= 1; });
+    const int n = __builtin_popcountll(elig);
+    wv.sync();  // every lane has read the prices: the pool's storage may be written again
+    // the columns that stay: compacted, reduced cost as the block's cost
+    wv.each([&](int lane) {
+        if (!((elig >> lane) & 1)) return;
+        const int q = __builtin_popcountll(elig & ((1ull << lane) - 1ull));
+        const uint32_t j = c0 + (uint32_t)lane;
+        S.c[q] = S.lane_val[lane];
+        S.gcol[q] = lane;
+        S.colcap[q] = t.col_cap[j];
+        for (int r = 0; r < MMAX; r++) { const double v = r < m ? t.col_a[(size_t)j * MMAX + r] : 0.0; S.a[r][q] = v; S.ainv[r][q] = v > 0.0 ? 1.0 / v : 0.0; }
+    });
+    // what the dropped columns could add at most (0 < rc <= thr): part of the block's bound
+    double dropped = 0.0;
+    for (uint32_t q = 0; q < nb; q++) {
+        const double rc = S.lane_val[q];
+        if (((elig >> q) & 1) || !(rc > 0.0)) continue;
+        dropped += rc * (double)(t.col_cap[c0 + q] < 65536 ? t.col_cap[c0 + q] : 65536);
+    }
+    wv.sync();
+    for (int q = n; q < NMAX; q++) if (wv.first()) { S.c[q] = 0.0; for (int r = 0; r < MMAX; r++) { S.a[r][q] = 0.0; S.ainv[r][q] = 0.0; } }
+    if (wv.first()) S.n = n;
+    wv.sync();
+    uint16_t *x = out.x + c0;
+    if (n == 0) {
+        wv.each([&](int lane) { if ((uint32_t)lane < nb) x[lane] = 0; });
+        if (wv.first()) { out.blk_cx[b] = 0.0; out.blk_rc[b] = 0.0; out.blk_bnd[b] = dropped; out.blk_steps[b] = 0; }
+        return;
+    }
+    // search order (ascending size) and greedy order (descending value density), by rank counting — as build_block does for a class block
+    wv.each([&](int lane) {
+        if (lane >= n) return;
+        double sz = 0.0;
+        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0.0) sz += S.a[r][lane] / (S.cap[r] + 1.0);
+        S.lane_val[lane] = sz;
+    });
+    wv.sync();
+    wv.each([&](int lane) {
+        if (lane >= n) return;
+        const double mine = S.lane_val[lane];
+        int rank = 0;
+        for (int i = 0; i < n; i++) { const double o = S.lane_val[i]; if (o < mine || (o == mine && i < lane)) rank++; }
+        S.pi[rank] = (uint8_t)lane;
+    });
+    wv.sync();
+    wv.each([&](int lane) {
+        if (lane >= n) return;
+        double w = 0.0;
+        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0.0) w += S.cap[r] > 0.0 ? S.a[r][lane] / S.cap[r] : 1e30;
+        S.lane_val[lane] = w > 0.0 ? S.c[lane] / w : 0.0;
+    });
+    wv.sync();
+    wv.each([&](int lane) {
+        if (lane >= n) return;
+        const double mine = S.lane_val[lane];
+        int rank = 0;
+        for (int i = 0; i < n; i++) { const double o = S.lane_val[i]; if (o > mine || (o == mine && i < lane)) rank++; }
+        S.pd[rank] = (uint8_t)lane;
+    });
+    wv.sync();
+    // dual pool
+    const uint32_t total = hqblock::binom((uint32_t)(n + m), m);
+    wv.each([&](int lane) { for (uint32_t tt = (uint32_t)lane; tt < total; tt += WAVE) hqblock::dual_candidate(wv, S, tt); });
+    wv.sync();
+    {
+        const uint32_t np = S.npool < (uint32_t)hqblock::PCAP ? S.npool : (uint32_t)hqblock::PCAP;
+        float *pkey = &S.dpen[0][0];
+        wv.each([&](int lane) { for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) pkey[i] = (float)(S.py[i][0] * S.cap[0] + S.py[i][1] * S.cap[1] + S.py[i][2] * S.cap[2] + S.py[i][3] * S.cap[3]); });
+        wv.sync();
+        wv.each([&](int lane) {
+            for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) {
+                const float mine = pkey[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < np; j++) { const float o = pkey[j]; rank += (o < mine || (o == mine && j < i)) ? 1u : 0u; }
+                S.porder[rank] = (uint16_t)i;
+            }
+        });
+        wv.sync();
+    }
+    wv.each([&](int lane) { hqblock::greedy_lane(S, lane); });
+    wv.sync();
+    {
+        int l = 0;
+        const double top = wv.argmax([&](int lane) { return S.lane_val[lane]; }, &l);
+        if (wv.first()) { S.best = top; for (int j = 0; j < n; j++) S.xbest[j] = S.gx[j][l]; }
+        wv.sync();
+    }
+    const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    hqblock::setup_work(wv, S, all, -1, 0);
+    double capv[MMAX];
+    for (int r = 0; r < MMAX; r++) capv[r] = S.cap[r];
+    const double root = hqblock::lp_bound(S, n, capv);
+    bool ok = true;
+    uint32_t left = budget;
+    if (!(root <= S.best + 1e-12 * S.best)) {
+        if (wv.first()) { for (int r = 0; r < MMAX; r++) S.rem[n][r] = S.cap[r]; S.zfix[n] = 0.0; }
+        wv.sync();
+        ok = hqblock::walk(wv, S, hqblock::MODE_MAX, 0.0, &left, nullptr);
+    }
+    wv.sync();
+    // results: the pattern, its value at the original and at the reduced costs, the block's contribution to the wide rows
+    wv.each([&](int lane) {
+        if ((uint32_t)lane >= nb) return;
+        uint32_t xv = 0;
+        if ((elig >> lane) & 1) xv = S.xbest[__builtin_popcountll(elig & ((1ull << lane) - 1ull))];
+        x[lane] = (uint16_t)xv;
+        if (!xv) return;
+        const uint32_t j = c0 + (uint32_t)lane;
+        for (uint32_t e = t.col_woff[j]; e < t.col_woff[j + 1]; e++) wv.atomic_add_i64(&out.act[t.w_row[e]], (long long)t.w_coef[e] * (long long)xv);
+    });
+    if (wv.first()) {
+        double cx = 0.0, rc = 0.0;  // fixed order: the same sums on every replica
+        for (int q = 0; q < n; q++) { const double xv = (double)S.xbest[q]; cx += t.col_cost[c0 + (uint32_t)S.gcol[q]] * xv; rc += S.c[q] * xv; }
+        out.blk_cx[b] = cx;
+        out.blk_rc[b] = rc;
+        // the walk closes a node whose bound is within 1e-12 (relative) of the incumbent: the optimum is not above best * (1 + 1e-12)
+        out.blk_bnd[b] = (ok ? rc * (1.0 + 2e-12) : (root > rc ? root : rc)) + dropped;
+        out.blk_steps[b] = S.steps | (ok ? 0u : 0x80000000u);
+    }
+}
+
+}  // namespace hqprice

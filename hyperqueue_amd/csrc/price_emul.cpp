@@ -1,0 +1,41 @@
+// libhqtick_test.so only: the price sweeps of the coupled solve (csrc/price_core.h = the algorithm of k_price_sweep) with the wavefront emulated on
+// the CPU — the 64 lanes of every lane-parallel step run in a loop — so that the CPU test suite executes the kernel's logic and the host side of
+// csrc/price.cpp without a GPU.  Not a product path: libhqtick.so has no CPU sweeper, its coupled solve needs the MI355X (csrc/price.hip).
+#include "price_emul.h"
+
+#include <cstring>
+
+#include "price_core.h"
+
+namespace hqprice {
+
+bool EmulatedSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
+    T = &t; caps = t.col_cap; n_sweeps = 0; cap_sweeps = max_sweeps;
+    pats.clear();
+    blk_cx.assign(t.n_blocks, 0.0); blk_rc.assign(t.n_blocks, 0.0); blk_bnd.assign(t.n_blocks, 0.0); blk_steps.assign(t.n_blocks, 0);
+    return t.K <= (uint32_t)KMAX;
+}
+bool EmulatedSweeper::set_caps(const int32_t *c) { caps.assign(c, c + T->n_cols); return true; }
+bool EmulatedSweeper::sweep(const double *pi, SweepTotals &out) {
+    if (n_sweeps >= cap_sweeps) return false;
+    static thread_local hqblock::Shared *S = new hqblock::Shared();
+    hqblock::HostWave wv;
+    const HostTables &t = *T;
+    Tables tv{t.n_blocks, t.n_cols, t.K, t.blk_off.data(), t.blk_m.data(), t.blk_cap.data(), t.col_cost.data(), t.col_a.data(), caps.data(), t.col_woff.data(), t.w_row.data(), t.w_coef.data()};
+    pats.resize((size_t)(n_sweeps + 1) * t.n_cols);
+    out.act.assign(t.K, 0);
+    SweepOut so{pats.data() + (size_t)n_sweeps * t.n_cols, blk_cx.data(), blk_rc.data(), blk_bnd.data(), out.act.data(), blk_steps.data()};
+    for (uint32_t b = 0; b < t.n_blocks; b++) solve_priced_block(wv, *S, tv, pi, b, so, budget);
+    out.cx = out.rc = out.bnd = 0.0; out.n_budget = 0; out.max_steps = 0;
+    for (uint32_t b = 0; b < t.n_blocks; b++) {  // block order: what the device's last workgroup does too
+        out.cx += blk_cx[b]; out.rc += blk_rc[b]; out.bnd += blk_bnd[b];
+        if (blk_steps[b] & 0x80000000u) out.n_budget++;
+        out.max_steps = std::max(out.max_steps, blk_steps[b] & 0x7FFFFFFFu);
+    }
+    n_sweeps++;
+    return true;
+}
+const uint16_t *EmulatedSweeper::patterns(uint32_t n) { return n <= n_sweeps ? pats.data() : nullptr; }
+void EmulatedSweeper::end() {}
+
+}  // namespace hqprice

@@ -1,0 +1,24 @@
+// libhqtick_test.so only (see price_emul.cpp).
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "price.h"
+
+namespace hqprice {
+
+struct EmulatedSweeper : Sweeper {
+    const HostTables *T = nullptr;
+    std::vector<int32_t> caps;
+    std::vector<uint16_t> pats;
+    std::vector<double> blk_cx, blk_rc, blk_bnd;
+    std::vector<uint32_t> blk_steps;
+    uint32_t n_sweeps = 0, cap_sweeps = 0;
+    bool begin(const HostTables &t, uint32_t max_sweeps) override;
+    bool set_caps(const int32_t *col_cap) override;
+    bool sweep(const double *pi, SweepTotals &out) override;
+    const uint16_t *patterns(uint32_t n_sweeps) override;
+    void end() override;
+};
+
+}  // namespace hqprice
