@@ -11,7 +11,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-HQTICK_ABI_VERSION = 6
+HQTICK_ABI_VERSION = 7
 HQTICK_FLAG_NO_KERNEL_TIMING, HQTICK_FLAG_COMPACT_RECORDS, HQTICK_FLAG_COMPACT_DELTA16 = 1, 2, 4
 HQ_AMOUNT_MAX = 0xFFFF_FFFF_FFFF_FFFF
 HQ_FRACTIONS_PER_UNIT = 10_000
@@ -183,6 +183,8 @@ class KernelStatsC(C.Structure):
         ("solve_classify_us", C.c_double),
         ("solve_blocks_us", C.c_double),
         ("solve_decode_us", C.c_double),
+        ("price_sweeps", C.c_uint32), ("price_rounds", C.c_uint32), ("milp_cols", C.c_uint32), ("milp_rows", C.c_uint32),
+        ("price_us", C.c_double), ("price_sweep_us", C.c_double), ("milp_us", C.c_double), ("model_us", C.c_double),
     ]
 
 

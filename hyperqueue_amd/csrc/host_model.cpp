@@ -449,6 +449,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         // ---- solve one block per class: on the device (one wavefront per class, csrc/block_core.h) where the block qualifies, else here ----
         std::vector<uint32_t> X((size_t)ncls * NC, 0);  // canonical optimum of every class, by tick column
         std::vector<uint8_t> solved(ncls, 0), class_has_flag(ncls, 0);
+        bool blocks_exact = true;  // every class block solved to its EXACT optimum (device blocks are; a host block that came back with a gap certificate only is not)
         if (separable) {
             for (uint32_t c = 0; c < ncls; c++) class_has_flag[c] = class_mu_flag(c) ? 1 : 0;
             std::vector<uint32_t> dev_cls;
@@ -504,7 +505,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 out.blocks_host++;
                 if (!sol.feasible) { out.keys.clear(); out.per_key.clear(); return out; }  // `None` => empty solution  solver.rs:433-437
                 if (!sol.optimal) out.is_optimal = false;
-                if (!sol.canonical) out.is_canonical = false;
+                if (!sol.canonical) { out.is_canonical = false; blocks_exact = false; }  // certificate only: the incumbent may sit up to rel_gap below the block's optimum
                 for (size_t k = 0; k < cols.size(); k++) if (cols[k].batch != UINT32_MAX) X[(size_t)c * NC + voff[cols[k].batch] + cols[k].variant] = (uint32_t)std::round(sol.x[k]);
             }
         }
@@ -524,7 +525,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 std::vector<hqmilp::Model> class_model(ncls);
                 std::vector<std::vector<ColRef>> class_cols(ncls);
                 for (uint32_t c = 0; c < ncls; c++) build_class_model(c, class_model[c], class_cols[c]);
-                if (out.is_optimal) {  // (every class block was solved to its exact optimum above)
+                if (out.is_optimal && blocks_exact) {  // every class block was solved to its EXACT optimum above: only then is "share <= block optimum" valid for every integer point
                     std::vector<double> zc(ncls, -1.0);
                     for (uint32_t c = 0; c < ncls; c++) {
                         if (class_has_flag[c]) continue;
@@ -691,6 +692,9 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             if (ws.assigned_rq[i] >= pb.rqs.size() || ws.assigned_variant[i] >= pb.rqs[ws.assigned_rq[i]].n_variants) { out.error = HQTICK_E_INVALID; out.errmsg = "assigned (rq, variant) out of range"; return out; }
     }
     hqmilp::Model m;
+    const double t_model0 = clock_us();
+    // structure hints for the coupled solve (csrc/price.h): a worker's columns form a block, the flags and group sizes belong to the whole model
+    auto addc = [&](double w, uint8_t kind, int32_t group) { m.col_group.push_back(group); return m.add_col(w, kind); };
     std::map<std::tuple<uint32_t, uint32_t, uint8_t>, int> place;  // (worker, rq, variant) -> column   :88
     std::map<uint32_t, std::vector<int>> count_cols;               // tasks_count_vars   :89
     std::vector<std::vector<std::pair<int, double>>> res_terms(R);
@@ -732,7 +736,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     if (free_worker && group_can_run(ws.group ? ws.group[w] : 0, vv, slot)) {
                         double s = 0.0;  // create_mn_var  :573-597
                         for (uint32_t r = 0; r < R; r++) if (tot[r]) s += pool[r] < 0.000001 ? 0.0 : units(tot[r]) / pool[r];
-                        int col = m.add_col(s * order_factor * ((double)vv.weight / FRACTIONS) / (double)nw, hqmilp::COL_BOOL);
+                        int col = addc(s * order_factor * ((double)vv.weight / FRACTIONS) / (double)nw, hqmilp::COL_BOOL, (int32_t)wi);
                         place[{w, batch.rq, v}] = col;
                         for (uint32_t r = 0; r < R; r++) if (tot[r]) res_terms[r].push_back({col, units(tot[r])});
                     }
@@ -743,7 +747,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                         double g = pool[vv.res[e]];
                         s += g < 0.000001 ? 0.0 : units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]) / g;
                     }
-                    int col = m.add_col(s * order_factor * ((double)vv.weight / FRACTIONS) / (double)nw, hqmilp::COL_NAT);
+                    int col = addc(s * order_factor * ((double)vv.weight / FRACTIONS) / (double)nw, hqmilp::COL_NAT, (int32_t)wi);
                     place[{w, batch.rq, v}] = col;
                     count_cols[batch.rq].push_back(col);
                     block_terms.push_back({col, s * ((double)vv.weight / FRACTIONS)});
@@ -755,7 +759,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 }
             }
             if (!any_variant && !pb.rq_multi_node(batch.rq) && batch.is_blocker && pb.capable_rqv(ws, w, batch.rq) && (pb.custom || ws.is_sn(w))) {  // :153-169
-                int col = m.add_col((double)wi / (double)(nw * 100), hqmilp::COL_BOOL);
+                int col = addc((double)wi / (double)(nw * 100), hqmilp::COL_BOOL, (int32_t)wi);
                 count_cols[batch.rq].push_back(col);
                 for (uint32_t r = 0; r < R; r++) if (fre[r]) res_terms[r].push_back({col, units(fre[r])});
             }
@@ -764,13 +768,13 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         if (mu > 0.001f && tot[0] != HQ_AMOUNT_MAX) {  // add_min_utilization  :501-540
             double all_cpus = units(tot[0]), need = all_cpus * ((double)mu - 1.0) + units(fre[0]);
             if (!(need < 0.0001)) {
-                int col = m.add_col(0.0, hqmilp::COL_BOOL);
+                int col = addc(0.0, hqmilp::COL_BOOL, (int32_t)wi);
                 cpu_terms.push_back({col, -need}); emit(hqmilp::ROW_MIN, 0.0, cpu_terms); cpu_terms.pop_back();
                 cpu_terms.push_back({col, -all_cpus}); emit(hqmilp::ROW_MAX, 0.0, cpu_terms); cpu_terms.pop_back();
             }
         }
         if (!block_z.empty() && block_z[w] >= 0.0 && block_terms.size() >= 2)  // the worker's block optimum caps its share of the objective (see block_z)
-            emit(hqmilp::ROW_MAX, block_z[w] * (1.0 + 1e-9) + 1e-12, block_terms);
+            { emit(hqmilp::ROW_MAX, block_z[w] * (1.0 + 1e-9) + 1e-12, block_terms); m.row_implied.resize(m.nrows(), 0); m.row_implied.back() = 1; }  // (implied, for integer points, by the worker's resource rows)
         for (uint32_t r = 0; r < R; r++) {  // :177-191 (an unbounded resource keeps its terms for the next worker, as in the reference)
             if (fre[r] == HQ_AMOUNT_MAX) continue;
             if (!res_terms[r].empty()) emit(hqmilp::ROW_MAX, units(fre[r]), res_terms[r]);
@@ -790,7 +794,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 if (it != place.end()) members.push_back(it->second);
             }
             if (members.empty()) continue;
-            int col = m.add_col(0.0, hqmilp::COL_NAT);
+            int col = addc(0.0, hqmilp::COL_NAT, -1);
             emit_plus(hqmilp::ROW_EQ, 0.0, members, col, -n_nodes);
             count_cols[batch.rq].push_back(col);
             group_cols[{batch.rq, g}] = col;
@@ -803,7 +807,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         if (it != short_flags.end()) return it->second;
         auto cc = count_cols.find(rq);
         if (cc == count_cols.end()) return -1;
-        int col = m.add_col(0.0, hqmilp::COL_BOOL);
+        int col = addc(0.0, hqmilp::COL_BOOL, -1);
         emit_plus(hqmilp::ROW_MIN, (double)size, cc->second, col, (double)size);
         short_flags[{rq, size}] = col;
         return col;
@@ -865,7 +869,10 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             m.start[it->second] = ss.count;
         }
     }
-    hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true);  // :432-438
+    m.row_implied.resize(m.nrows(), 0);
+    const double t_model1 = clock_us();
+    hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438
+    out.model_us = t_model1 - t_model0; out.milp_us = clock_us() - t_model1; out.price_sweeps = sol.price_sweeps; out.price_rounds = sol.price_rounds; out.price_us = sol.price_total_us;
     out.milp_nodes = sol.nodes; out.milp_cols = m.ncols(); out.milp_rows = m.nrows(); out.milp_components = sol.n_components;
     if (!sol.feasible) return out;
     out.is_optimal = sol.optimal;

@@ -29,6 +29,10 @@
 #include <vector>
 
 #include "block_solve.h"
+#include "price_dev.h"
+#ifdef HQTICK_TEST_HOOKS
+#include "price_emul.h"
+#endif
 #include "devbuf.h"
 #include "graph.h"
 #include "hb_order.h"
@@ -85,6 +89,7 @@ struct hqtick_ctx {
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
     PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_retr, h_blk, h_k5a;
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
+    hqprice::DeviceSweeper *pricer = nullptr;  // k_price_sweep: the block sweeps of the coupled placement (csrc/price.hip); HQTICK_PRICE=0 keeps coupled ticks on the host search
     uint32_t block_budget = 4096, block_min_classes = 12;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
     // workers / requests
     DevBuf d_up, d_vflags, d_vtmc, d_blk;
@@ -1046,9 +1051,11 @@ struct TickRun {
         mark();  // 1: batches
         const double t2 = now_us();
         DeviceBlocks dev_blocks(ctx);
-        pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes;
+        pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes; pb.pricer = ctx->pricer;
         cnt = hqhost::run_scheduling_solver(pb, batches);
-        pb.blocks = nullptr;
+        pb.blocks = nullptr; pb.pricer = nullptr;
+        ctx->stats.price_sweeps = (uint32_t)cnt.price_sweeps; ctx->stats.price_rounds = (uint32_t)cnt.price_rounds; ctx->stats.price_us = cnt.price_us; ctx->stats.milp_us = cnt.milp_us; ctx->stats.model_us = cnt.model_us;
+        ctx->stats.price_sweep_us = ctx->pricer ? ctx->pricer->stat_sweep_us : 0.0; ctx->stats.milp_cols = (uint32_t)cnt.milp_cols; ctx->stats.milp_rows = (uint32_t)cnt.milp_rows;
         if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
         ctx->stats.n_classes_device = cnt.blocks_device; ctx->stats.n_classes_host = cnt.blocks_host; ctx->stats.block_steps_max = cnt.block_steps_max; ctx->stats.n_classes = cnt.n_classes;
         ctx->stats.solve_classify_us = cnt.t_classify_us; ctx->stats.solve_blocks_us = cnt.t_blocks_us; ctx->stats.solve_decode_us = cnt.t_decode_us;
@@ -1108,6 +1115,12 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
     if (const char *e = getenv("HQTICK_K2_RIDE_ALONG")) { ctx->k2_own_stream = atoi(e) == 0; ctx->k2_on_hist = atoi(e) == 1; }
     if (const char *e = getenv("HQTICK_CHECK_CLUSTER")) ctx->cluster_check = atoi(e) != 0;
     if (const char *e = getenv("HQTICK_WAIT_ON_KERNEL")) ctx->wait_on_kernel = atoi(e) != 0;
+    {
+        bool price = true; uint32_t min_cols = 0;
+        if (const char *e = getenv("HQTICK_PRICE")) price = atoi(e) != 0;
+        if (const char *e = getenv("HQTICK_PRICE_MIN_COLS")) { long v = atol(e); if (v > 0) min_cols = (uint32_t)v; }
+        if (price) { ctx->pricer = new hqprice::DeviceSweeper(ctx->stream); ctx->pricer->budget = ctx->block_budget; if (min_cols) ctx->pricer->min_cols = min_cols; }
+    }
     if (hipEventCreate(&ctx->cl_ev) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     if (!ctx->d_flags.ensure(64) || hipMemset(ctx->d_flags.p, 0, 64) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
@@ -1121,6 +1134,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
+    delete ctx->pricer; ctx->pricer = nullptr;
     DevBuf *bufs[] = {&ctx->d_tid, &ctx->d_tprio, &ctx->d_trq, &ctx->d_set, &ctx->d_flags, &ctx->d_levels, &ctx->d_nlevels, &ctx->d_wave_tab, &ctx->d_hist,
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
                       &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8, &ctx->d_blk, &ctx->d_cluster};
@@ -1481,7 +1495,7 @@ static int query_on(hqtick_ctx *ctx, const hqtick_snapshot *s, const hqtick_quer
     std::vector<hqhost::QueueLevels> qlv = queue_levels(sc, s);
     std::vector<hqhost::TaskBatch> batches = hqhost::create_task_batches(pb, qlv);
     DeviceBlocks dev_blocks(ctx);
-    pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes;
+    pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes; pb.pricer = ctx->pricer;
     hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
     ctx->q_loaded.assign(fake->n_workers, 0);
@@ -1514,10 +1528,12 @@ struct EmulatedBlocks : hqhost::BlockSolver {
         return true;
     }
 };
-thread_local int g_block_emulation = 0;
+thread_local int g_block_emulation = 0, g_price_emulation = 0; thread_local uint32_t g_price_min_cols = 0, g_last_price_sweeps = 0, g_last_price_rounds = 0;
 thread_local uint32_t g_block_budget = 4096, g_last_blocks_device = 0, g_last_blocks_host = 0;
 }  // namespace
 
+void hqtick_debug_set_price_emulation(int on, uint32_t min_cols) { g_price_emulation = on; g_price_min_cols = min_cols; }
+void hqtick_debug_last_price(uint32_t *sweeps, uint32_t *rounds) { if (sweeps) *sweeps = g_last_price_sweeps; if (rounds) *rounds = g_last_price_rounds; }
 void hqtick_debug_set_block_emulation(int on, uint32_t budget) { g_block_emulation = on; if (budget) g_block_budget = budget; }
 void hqtick_debug_last_blocks(uint32_t *n_emulated, uint32_t *n_host) { if (n_emulated) *n_emulated = g_last_blocks_device; if (n_host) *n_host = g_last_blocks_host; }
 
@@ -1551,9 +1567,11 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
     export_batches(ctx, batches, out);
     EmulatedBlocks emu(g_block_budget);
     if (g_block_emulation) { pb.blocks = &emu; pb.block_min_classes = 1; }
+    hqprice::EmulatedSweeper pemu;
+    if (g_price_emulation) { pemu.budget = g_block_budget; if (g_price_min_cols) pemu.min_cols = g_price_min_cols; pb.pricer = &pemu; }
     hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
-    g_last_blocks_device = cnt.blocks_device; g_last_blocks_host = cnt.blocks_host;
+    g_last_blocks_device = cnt.blocks_device; g_last_blocks_host = cnt.blocks_host; g_last_price_sweeps = (uint32_t)cnt.price_sweeps; g_last_price_rounds = (uint32_t)cnt.price_rounds;
     ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
     cnt.pairs();
     for (size_t k = 0; k < cnt.keys.size(); k++)

@@ -690,7 +690,7 @@ struct CompSolver {
                 root_bound = std::min(root_bound, pa.bound * (1.0 + 1e-9) + 1e-12);
                 deadline = hard_deadline;
                 if (certified()) { canonical_done = false; xout = bx; trace("certified by the price sweeps"); return 1; }
-                if (have) {  // what the sweeps leave open goes to the host's window search, against their bound
+                if (have && n > 2000) {  // what the sweeps leave open goes to the host's window search, against their bound (smaller models: the tree below)
                     trace("window search against the price bound");
                     lns_schedule(deadline - 0.05);
                     xout = bx;
@@ -742,7 +742,7 @@ struct CompSolver {
         // windows take the greedy incumbent to within 1e-4 of the root LP bound in a fraction of that — and then the root closes the search.
         bool lns_done = false;
         if (!in_lns && have && n >= LNS_FIRST_COLS) {
-            if (solve_counted(root) == LP_OPT) { root_bound = root.objective(); lp_x.assign(root.x.begin(), root.x.begin() + n); }  // the bound the windows work towards (dfs_opt finds the tableau solved)
+            if (solve_counted(root) == LP_OPT) { root_bound = std::min(root_bound, root.objective()); lp_x.assign(root.x.begin(), root.x.begin() + n); }  // the bound the windows work towards (dfs_opt finds the tableau solved)
             trace("window search first");
             lns_schedule(deadline, false);  // cheap windows only (what they leave open the tree below usually closes faster than bigger windows would), until they
                                             // stall or the incumbent is certified — not until a clock says so: replicas of a sharded scheduler walk the same sequence
@@ -1038,8 +1038,10 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
         }
         if (!cuts.empty()) {
             if (!need_snap) { snapped = mdl_in; need_snap = true; }
+            snapped.row_implied.resize((size_t)snapped.nrows(), 0);
             for (const auto &cu : cuts) {
                 const int a = mdl_in.roff[cu.row], b = mdl_in.roff[cu.row + 1];
+                snapped.row_implied.push_back(1);  // holds at every integer point of the row it was rounded from
                 snapped.begin_row(ROW_MAX, (double)cu.rhs);
                 for (int k = a; k < b; k++) { const long long c = (long long)std::llround(mdl_in.rcoef[k] * GRID) / cu.d; if (c) snapped.term(mdl_in.rcol[k], (double)c); }
                 snapped.end_row();

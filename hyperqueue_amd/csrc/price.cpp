@@ -118,7 +118,10 @@ const char *build(const Request &rq, Prob &P) {
             }
             if (!is_le || !nonneg || rq.rhi[i] < 0.0) return "block row that is not a packing row";
             const int r = T.blk_m[b0];
-            if (r >= MMAX_BLOCK) return "block with more than 4 rows";
+            if (r >= MMAX_BLOCK) {
+                if (rq.trace) { fprintf(stderr, "[price] 5th row of block %d: hi %.6f scale %.6f:", b0, rq.rhi[i], sc); for (int k = a; k < e; k++) fprintf(stderr, " %.6f*x%d(ub %.0f)", rq.rcoef[k] * sc, rq.rcol[k], rq.ub[rq.rcol[k]]); fprintf(stderr, "\n"); }
+                return "block with more than 4 rows";
+            }
             long long g = 0; bool ok = true;
             std::vector<std::pair<int, long long>> ai;
             for (int k = a; k < e && ok; k++) {
@@ -423,11 +426,15 @@ Answer solve(const Request &rq, Sweeper &sw) {
     S.theta_scale = std::max(S.cuts[0].bnd, 1e-9);
     ans.ran = true;
     double best_value = rq.incumbent ? rq.incumbent_value : -INF;
-    std::vector<double> B(G, 1.0);
     std::vector<double> hB(K);
     std::vector<int32_t> caps(P.base_cap);
     std::vector<double> final_pi;
-    for (int round = 0; round < MAX_ROUNDS && !S.failed; round++) {
+    std::vector<std::vector<double>> tried;   // flag configurations already solved
+    auto certified = [&]() { return best_value > -INF && S.relaxed_bound <= best_value + rq.rel_gap * std::fabs(best_value); };
+    // One flag configuration: master to convergence, one pattern per block, repair, the caller's polish.  Returns the point's value (-INF: nothing
+    // usable came out) and leaves the point in x.
+    auto try_config = [&](const std::vector<double> &B, std::vector<double> &x) -> double {
+        tried.push_back(B);
         ans.rounds++;
         double cB = 0.0;
         for (int k = 0; k < K; k++) hB[k] = P.h[k];
@@ -435,27 +442,29 @@ Answer solve(const Request &rq, Sweeper &sw) {
         if (!P.caps.empty()) {  // conditional bounds with the flags fixed
             caps = P.base_cap;
             for (const CapRow &cr : P.caps) { double r = cr.rhs; for (auto &t : cr.g) r -= t.second * B[t.first]; const double c = std::floor(r + 1e-9); if (c < (double)caps[cr.flat]) caps[cr.flat] = c < 0.0 ? 0 : (int32_t)c; }
-            if (!sw.set_caps(caps.data())) { S.failed = true; break; }
+            if (!sw.set_caps(caps.data())) { S.failed = true; return -INF; }
             // (the cuts of earlier rounds are points of THEIR bounds: a round with other bounds starts a new master)
             S.base_caps = false; S.cut_lo = S.cuts.size();
-            if (S.evaluate(pi0) < 0) break;
+            if (S.evaluate(pi0) < 0) return -INF;
         }
         std::vector<double> lambda, pi;
         double bound_B = INF;
         const double cutoff = best_value > -INF ? best_value * (1.0 - 1e-12) : -INF;
-        if (!S.kelley(hB, cB, cutoff, std::max(1e-6, rq.rel_gap / 50.0), lambda, pi, &bound_B)) break;
+        if (!S.kelley(hB, cB, cutoff, std::max(1e-6, rq.rel_gap / 50.0), lambda, pi, &bound_B)) return -INF;
         final_pi = pi;
         std::vector<uint16_t> xf = S.round_patterns(lambda, pi, hB);
-        if (xf.empty()) break;
-        std::vector<double> x(rq.n, 0.0);
+        if (xf.empty()) return -INF;
+        x.assign(rq.n, 0.0);
         for (uint32_t f = 0; f < P.T.n_cols; f++) x[P.model_of[f]] = (double)xf[f];
         for (int g = 0; g < G; g++) x[P.gmodel[g]] = B[g];
         double value = 0.0;
-        if (!rq.polish || !rq.polish(x, value)) break;  // the caller's rows say no: nothing to build on
-        if (rq.trace) fprintf(stderr, "[price] round %d: %zu sweeps so far, bound with these flags %.9f, point %.9f, model bound %.9f\n", round, S.cuts.size(), bound_B, value, S.relaxed_bound);
+        if (!rq.polish || !rq.polish(x, value)) return -INF;  // the caller's rows say no
+        if (rq.trace) fprintf(stderr, "[price] configuration %u: %zu sweeps so far, bound with these flags %.9f, point %.9f, model bound %.9f\n", ans.rounds, S.cuts.size(), bound_B, value, S.relaxed_bound);
         if (value > best_value) { best_value = value; ans.x = x; ans.x_value = value; }
-        if (S.relaxed_bound <= best_value + rq.rel_gap * std::fabs(best_value)) break;  // certified
-        // flags whose rows hold without them are dropped (they only ever restrict)
+        return value;
+    };
+    // flags of x whose rows hold without them are dropped (they only ever restrict): the rule of milp.cpp's sparse_greedy.  True if B changed.
+    auto drop_flags = [&](std::vector<double> &B, const std::vector<double> &x) {
         bool dropped = false;
         std::vector<double> act(K, 0.0);
         for (int k = 0; k < K; k++) for (int t = P.r_off[k]; t < P.r_off[k + 1]; t++) act[k] += (double)P.r_coef[t] * x[P.model_of[P.r_col[t]]];
@@ -468,12 +477,26 @@ Answer solve(const Request &rq, Sweeper &sw) {
             B[g] = 0.0; dropped = true;
             for (auto &t : P.g_rows[g]) act[t.first] -= t.second;
         }
-        if (!dropped) break;
-    }
+        return dropped;
+    };
+    auto was_tried = [&](const std::vector<double> &B) { for (auto &t : tried) if (t == B) return true; return false; };
+    // a configuration and what dropping leads to from there
+    auto descend = [&](std::vector<double> B) {
+        for (int round = 0; round < MAX_ROUNDS && !S.failed && !was_tried(B); round++) {
+            std::vector<double> x;
+            if (try_config(B, x) == -INF) break;
+            if (certified()) break;
+            if (!drop_flags(B, x)) break;
+        }
+    };
+    descend(std::vector<double>(G, 1.0));   // every flag on: always feasible for the tick's models (every lower-priority batch capped at its cut)
     if (S.failed) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
     // Not certified against the bound seen so far and the model has flags: the master of the RELAXED model (flags in [0, 1]) may still bring the bound
-    // down — its cuts are the points already evaluated, the flags enter through one extra variable each (mu_g >= c_g - pi.A_g, mu_g >= 0).
-    if (G > 0 && best_value > -INF && S.relaxed_bound > best_value + rq.rel_gap * std::fabs(best_value)) {
+    // down — its cuts are the points already evaluated, the flags enter through one extra variable each (mu_g >= c_g - pi.A_g, mu_g >= 0).  Its
+    // multipliers of the flag rows are the flags' LP values: the configuration they round to, and single flags forced off in the order of those
+    // values, are tried next ("place every higher-priority task of that class": often worth a little utilisation for what it unlocks).
+    std::vector<double> Blp;
+    if (G > 0 && best_value > -INF && !certified()) {
         if (!S.base_caps) {  // back to the model's own column bounds: only sweeps under those bound the relaxed model
             if (!sw.set_caps(P.base_cap.data())) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
             S.base_caps = true; S.cut_lo = S.cuts.size();
@@ -508,8 +531,11 @@ Answer solve(const Request &rq, Sweeper &sw) {
         push_cuts(false);
         mt.init(&M, mc, mlb, mub);
         std::vector<double> pi(K), pi_best = S.relaxed_pi.empty() ? std::vector<double>(K, 0.0) : S.relaxed_pi, prev;
+        bool master_ok = false;
         for (int it = 0; it < 120; it++) {
+            master_ok = false;
             if (mt.solve(200000) != LP_OPT) break;
+            master_ok = true;
             const double lb_master = -mt.objective() * S.theta_scale;
             if (S.relaxed_bound <= best_value + rq.rel_gap * std::fabs(best_value)) break;   // certified
             if (S.relaxed_bound - lb_master <= 1e-6 * std::fabs(S.relaxed_bound)) break;      // the bound is what it is
@@ -522,6 +548,31 @@ Answer solve(const Request &rq, Sweeper &sw) {
             if (S.evaluate(pi) < 0) break;
             if (S.relaxed_bound < before) pi_best = pi;
             push_cuts(true);
+        }
+        if (S.failed) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
+        if (master_ok || mt.solve(200000) == LP_OPT) {
+            Blp.assign(G, 0.0);
+            for (int g = 0; g < G; g++) { const int ar = mt.where[g]; if (ar >= 0 && mt.st[M.n + ar] != BASIC) { double sc = 1.0; for (auto &t : P.g_rows[g]) sc = std::max(sc, std::fabs(t.second / S.theta_scale)); Blp[g] = std::min(1.0, std::fabs(mt.d[M.n + ar]) / sc); } }
+        }
+    }
+    if (!Blp.empty() && !certified() && P.caps.empty()) {
+        std::vector<double> B(G);
+        for (int g = 0; g < G; g++) B[g] = (Blp[g] > 0.5 || P.gcost[g] > 0.0) ? 1.0 : 0.0;
+        descend(B);
+        // single flags of the best configuration forced off, least LP value first
+        for (int trial = 0; trial < 12 && !certified() && !S.failed && !ans.x.empty(); trial++) {
+            std::vector<double> cur(G);
+            for (int g = 0; g < G; g++) cur[g] = ans.x[P.gmodel[g]];
+            int pick = -1; double pv = INF;
+            for (int g = 0; g < G; g++) {
+                if (cur[g] != 1.0 || P.gcost[g] != 0.0) continue;
+                std::vector<double> t = cur; t[g] = 0.0;
+                if (was_tried(t)) continue;
+                if (Blp[g] < pv) { pv = Blp[g]; pick = g; }
+            }
+            if (pick < 0) break;
+            cur[pick] = 0.0;
+            descend(cur);
         }
         if (S.failed) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
     }

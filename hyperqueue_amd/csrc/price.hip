@@ -1,0 +1,160 @@
+// k_price_sweep: one PRICE SWEEP of the coupled placement model on the MI355X — every worker's block solved exactly under the current prices of the
+// model's wide rows (run_scheduling_solver's model, /root/reference/crates/tako/src/internal/scheduler/solver.rs:95-430, which the reference hands to
+// HiGHS, solver/highs.rs:65-88; the method is in price.h, the per-block algorithm in price_core.h / block_core.h).
+//
+// Launch shape: grid = number of blocks (one per worker: 1024-4096), block = 64 threads = ONE wave64, ~41 KB of LDS per block (dual vertices, level
+// stack, the 64 greedy vectors) -> 4 blocks per CU, 1024 resident on the 256 CUs, dealt round-robin over the 8 XCDs by the dispatcher; the blocks
+// share nothing but the prices (<= 1 KB, in the kernel arguments) — no XCD-aware mapping is needed.  Integer / f64 scalar work on LDS-resident data:
+// not an HBM kernel (a block reads ~0.5-2 KB of tables) and not MFMA work; its figure of merit is block solves per second.
+//
+// A sweep is one link of a serial chain (master LP on the host -> prices -> sweep -> cut -> master ...), so its LATENCY is what counts:
+//   * prices travel in the kernel arguments: no copy, no PCIe read by 1024 wavefronts;
+//   * the wide rows' activities are integer, accumulated with 64-bit atomics in HBM: exact, order-free, the same on every replica;
+//   * the last workgroup to finish (a ticket in HBM) adds up the per-block values in a fixed order and writes the sweep's totals + a sequence
+//     number straight into pinned host memory; the host waits on that word instead of a stream synchronisation (the marker packet behind
+//     hipStreamSynchronize costs ~6 us per call);
+//   * the patterns stay in HBM (a ring of sweeps) and cross PCIe once, when the master has converged and the primal side needs them.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+
+#include "dev_wave.h"
+#include "price_core.h"
+#include "price_dev.h"
+
+namespace hqprice {
+
+namespace {
+
+struct SweepResult {   // pinned host memory, written by the last workgroup of a sweep
+    double cx, rc, bnd;
+    uint32_t n_budget, max_steps;
+    long long act[KMAX];
+    uint32_t seq;      // written last (release, system scope)
+};
+
+struct SweepArgs {
+    Tables t;
+    SweepOut out;
+    uint32_t budget, seq;
+    uint32_t *ticket;
+    SweepResult *res;
+    double pi[KMAX];
+};
+
+__global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
+    __shared__ Shared S;
+    __shared__ uint32_t s_last;
+    hqblock::DevWave wv;
+    solve_priced_block(wv, S, a.t, a.pi, blockIdx.x, a.out, a.budget);
+    __threadfence();  // the block's results before its ticket
+    if (threadIdx.x == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // the last workgroup: totals in a fixed order (lane l takes blocks l, l + 64, ...; lane 0 adds the 64 partial sums in lane order)
+    const uint32_t nb = a.t.n_blocks;
+    double cx = 0.0, rc = 0.0, bnd = 0.0; uint32_t nbud = 0, mx = 0;
+    for (uint32_t b = threadIdx.x; b < nb; b += WAVE) {
+        cx += a.out.blk_cx[b]; rc += a.out.blk_rc[b]; bnd += a.out.blk_bnd[b];
+        const uint32_t st = a.out.blk_steps[b];
+        nbud += st >> 31; const uint32_t s = st & 0x7FFFFFFFu; mx = s > mx ? s : mx;
+    }
+    double *red = &S.py[0][0];  // the pool's storage again: 3 x 64 doubles + 2 x 64 words
+    uint32_t *redu = reinterpret_cast<uint32_t *>(red + 3 * WAVE);
+    red[threadIdx.x] = cx; red[WAVE + threadIdx.x] = rc; red[2 * WAVE + threadIdx.x] = bnd; redu[threadIdx.x] = nbud; redu[WAVE + threadIdx.x] = mx;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < a.t.K; k += WAVE) { a.res->act[k] = a.out.act[k]; a.out.act[k] = 0; }  // (and ready for the next sweep)
+    if (threadIdx.x == 0) {
+        double tcx = 0.0, trc = 0.0, tb = 0.0; uint32_t tn = 0, tm = 0;
+        for (int l = 0; l < WAVE; l++) { tcx += red[l]; trc += red[WAVE + l]; tb += red[2 * WAVE + l]; tn += redu[l]; tm = redu[WAVE + l] > tm ? redu[WAVE + l] : tm; }
+        a.res->cx = tcx; a.res->rc = trc; a.res->bnd = tb; a.res->n_budget = tn; a.res->max_steps = tm;
+        *a.ticket = 0;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&a.res->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+size_t al16(size_t v) { return (v + 15) & ~(size_t)15; }
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+DeviceSweeper::~DeviceSweeper() { h_stage.release(); h_res.release(); h_pats.release(); d_tab.release(); d_pats.release(); d_blk.release(); d_sync.release(); }
+
+bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
+    if (t.K > (uint32_t)KMAX || t.n_blocks == 0) return false;
+    T = &t; n_sweeps = 0; cap_sweeps = max_sweeps;
+    const size_t nw = t.w_row.size();
+    o_off = 0; o_m = al16(o_off + (size_t)(t.n_blocks + 1) * 4); o_cap = al16(o_m + t.n_blocks); o_cost = al16(o_cap + (size_t)t.n_blocks * MMAX * 8);
+    o_a = al16(o_cost + (size_t)t.n_cols * 8); o_ccap = al16(o_a + (size_t)t.n_cols * MMAX * 8); o_woff = al16(o_ccap + (size_t)t.n_cols * 4);
+    o_wrow = al16(o_woff + (size_t)(t.n_cols + 1) * 4); o_wcoef = al16(o_wrow + nw * 2); tab_bytes = al16(o_wcoef + nw * 4);
+    if (!h_stage.ensure(tab_bytes) || !d_tab.ensure(tab_bytes) || !h_res.ensure(sizeof(SweepResult) + 64)) return false;
+    if (!d_pats.ensure((size_t)max_sweeps * t.n_cols * 2) || !d_blk.ensure((size_t)t.n_blocks * 28 + 64) || !d_sync.ensure(64 + (size_t)KMAX * 8)) return false;
+    unsigned char *h = h_stage.as<unsigned char>();
+    memcpy(h + o_off, t.blk_off.data(), (size_t)(t.n_blocks + 1) * 4); memcpy(h + o_m, t.blk_m.data(), t.n_blocks); memcpy(h + o_cap, t.blk_cap.data(), (size_t)t.n_blocks * MMAX * 8);
+    memcpy(h + o_cost, t.col_cost.data(), (size_t)t.n_cols * 8); memcpy(h + o_a, t.col_a.data(), (size_t)t.n_cols * MMAX * 8); memcpy(h + o_ccap, t.col_cap.data(), (size_t)t.n_cols * 4);
+    memcpy(h + o_woff, t.col_woff.data(), (size_t)(t.n_cols + 1) * 4);
+    if (nw) { memcpy(h + o_wrow, t.w_row.data(), nw * 2); memcpy(h + o_wcoef, t.w_coef.data(), nw * 4); }
+    if (hipMemcpyAsync(d_tab.p, h, tab_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return false;
+    if (hipMemsetAsync(d_sync.p, 0, 64 + (size_t)KMAX * 8, stream) != hipSuccess) return false;  // ticket + the wide rows' accumulators
+    SweepResult *r = h_res.as<SweepResult>();
+    seq = r->seq;  // (whatever the last solve left: the next sweep writes seq + 1)
+    return true;
+}
+
+bool DeviceSweeper::set_caps(const int32_t *col_cap) {
+    if (!T) return false;
+    memcpy(h_stage.as<unsigned char>() + o_ccap, col_cap, (size_t)T->n_cols * 4);
+    return hipMemcpyAsync(d_tab.as<unsigned char>() + o_ccap, h_stage.as<unsigned char>() + o_ccap, (size_t)T->n_cols * 4, hipMemcpyHostToDevice, stream) == hipSuccess;
+}
+
+bool DeviceSweeper::sweep(const double *pi, SweepTotals &out) {
+    if (!T || n_sweeps >= cap_sweeps) return false;
+    const HostTables &t = *T;
+    unsigned char *d = d_tab.as<unsigned char>();
+    SweepArgs a;
+    a.t = Tables{t.n_blocks, t.n_cols, t.K, (const uint32_t *)(d + o_off), (const uint8_t *)(d + o_m), (const double *)(d + o_cap), (const double *)(d + o_cost), (const double *)(d + o_a),
+                 (const int32_t *)(d + o_ccap), (const uint32_t *)(d + o_woff), (const uint16_t *)(d + o_wrow), (const int32_t *)(d + o_wcoef)};
+    unsigned char *blk = d_blk.as<unsigned char>();
+    a.out = SweepOut{d_pats.as<uint16_t>() + (size_t)n_sweeps * t.n_cols, (double *)blk, (double *)(blk + (size_t)t.n_blocks * 8), (double *)(blk + (size_t)t.n_blocks * 16),
+                     (long long *)(d_sync.as<unsigned char>() + 64), (uint32_t *)(blk + (size_t)t.n_blocks * 24)};
+    a.budget = budget; a.seq = ++seq; a.ticket = d_sync.as<uint32_t>(); a.res = h_res.dev<SweepResult>();
+    memset(a.pi, 0, sizeof(a.pi));
+    memcpy(a.pi, pi, (size_t)t.K * 8);
+    const double t0 = now_us();
+    hipLaunchKernelGGL(k_price_sweep, dim3(t.n_blocks), dim3(WAVE), 0, stream, a);
+    if (hipGetLastError() != hipSuccess) return false;
+    // wait for the sweep's own completion word (pinned memory); the stream synchronisation is the fallback after 2 s
+    volatile SweepResult *r = h_res.as<SweepResult>();
+    for (uint64_t spins = 0;; spins++) {
+        if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) == a.seq) break;
+        if ((spins & 0xFFFF) == 0xFFFF && now_us() - t0 > 2.0e6) {
+            if (hipStreamSynchronize(stream) != hipSuccess) return false;
+            if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) != a.seq) return false;
+            break;
+        }
+    }
+    last_kernel_us = now_us() - t0;
+    total_sweeps++; total_block_solves += t.n_blocks; total_us += last_kernel_us;
+    out.cx = r->cx; out.rc = r->rc; out.bnd = r->bnd; out.n_budget = r->n_budget; out.max_steps = r->max_steps;
+    out.act.resize(t.K);
+    for (uint32_t k = 0; k < t.K; k++) out.act[k] = r->act[k];
+    n_sweeps++;
+    return true;
+}
+
+const uint16_t *DeviceSweeper::patterns(uint32_t n) {
+    if (!T || n > n_sweeps) return nullptr;
+    const size_t bytes = (size_t)n * T->n_cols * 2;
+    if (!h_pats.ensure(bytes + 64)) return nullptr;
+    if (hipMemcpyAsync(h_pats.p, d_pats.p, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
+    return h_pats.as<uint16_t>();
+}
+
+void DeviceSweeper::end() { T = nullptr; }
+
+}  // namespace hqprice

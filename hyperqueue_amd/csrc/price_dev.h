@@ -1,0 +1,29 @@
+// The price sweeps of the coupled solve on the MI355X (csrc/price.hip): k_price_sweep, one wavefront per worker block.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "devbuf.h"
+#include "price.h"
+
+namespace hqprice {
+
+struct DeviceSweeper : Sweeper {
+    hipStream_t stream = nullptr;
+    hqbuf::PinBuf h_stage, h_res, h_pats;
+    hqbuf::DevBuf d_tab, d_pats, d_blk, d_sync;
+    const HostTables *T = nullptr;
+    size_t o_off = 0, o_m = 0, o_cap = 0, o_cost = 0, o_a = 0, o_ccap = 0, o_woff = 0, o_wrow = 0, o_wcoef = 0, tab_bytes = 0;
+    uint32_t n_sweeps = 0, cap_sweeps = 0, seq = 0;
+    double last_kernel_us = 0;   // duration of the last sweep as the host saw it (launch -> result visible)
+    // statistics for the bench line
+    uint64_t total_sweeps = 0, total_block_solves = 0; double total_us = 0;
+    explicit DeviceSweeper(hipStream_t s) : stream(s) {}
+    ~DeviceSweeper() override;
+    bool begin(const HostTables &t, uint32_t max_sweeps) override;
+    bool set_caps(const int32_t *col_cap) override;
+    bool sweep(const double *pi, SweepTotals &out) override;
+    const uint16_t *patterns(uint32_t n_sweeps) override;
+    void end() override;
+};
+
+}  // namespace hqprice

@@ -26,12 +26,17 @@ bool EmulatedSweeper::sweep(const double *pi, SweepTotals &out) {
     out.act.assign(t.K, 0);
     SweepOut so{pats.data() + (size_t)n_sweeps * t.n_cols, blk_cx.data(), blk_rc.data(), blk_bnd.data(), out.act.data(), blk_steps.data()};
     for (uint32_t b = 0; b < t.n_blocks; b++) solve_priced_block(wv, *S, tv, pi, b, so, budget);
-    out.cx = out.rc = out.bnd = 0.0; out.n_budget = 0; out.max_steps = 0;
-    for (uint32_t b = 0; b < t.n_blocks; b++) {  // block order: what the device's last workgroup does too
-        out.cx += blk_cx[b]; out.rc += blk_rc[b]; out.bnd += blk_bnd[b];
+    // the device's order: lane l of the last workgroup adds blocks l, l + 64, ...; lane 0 then adds the 64 partial sums in lane order — the same
+    // floating-point sums here, so that a GPU tick and the emulation walk the same sequence of prices
+    double pcx[WAVE] = {0}, prc[WAVE] = {0}, pb[WAVE] = {0};
+    out.n_budget = 0; out.max_steps = 0;
+    for (uint32_t b = 0; b < t.n_blocks; b++) {
+        pcx[b % WAVE] += blk_cx[b]; prc[b % WAVE] += blk_rc[b]; pb[b % WAVE] += blk_bnd[b];
         if (blk_steps[b] & 0x80000000u) out.n_budget++;
         out.max_steps = std::max(out.max_steps, blk_steps[b] & 0x7FFFFFFFu);
     }
+    out.cx = out.rc = out.bnd = 0.0;
+    for (int l = 0; l < WAVE; l++) { out.cx += pcx[l]; out.rc += prc[l]; out.bnd += pb[l]; }
     n_sweeps++;
     return true;
 }

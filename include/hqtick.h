@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HQTICK_ABI_VERSION 6u
+#define HQTICK_ABI_VERSION 7u  /* 7: hqtick_kernel_stats carries the price-sweep figures of coupled ticks; cluster membership deltas */
 
 /* ResourceAmount::MAX                                    common/resources/amount.rs:31 */
 #define HQ_AMOUNT_MAX UINT64_MAX
@@ -475,6 +475,11 @@ typedef struct hqtick_kernel_stats {
     uint32_t block_steps_max, n_classes;       /* most search steps any class took; worker classes of the separable placement  */
     double solve_classify_us, solve_blocks_us, solve_decode_us; /* host wall clock inside the placement stage: worker classes, block solves
                                                   (launch + wait included), counts into the reference's Map iteration order */
+    /* coupled ticks (priority cuts, unsaturated batches): the placement by price sweeps (k_price_sweep, csrc/price.hip) */
+    uint32_t price_sweeps, price_rounds;   /* sweeps over all worker blocks / flag configurations of the last tick (0: the host search ran alone)   */
+    uint32_t milp_cols, milp_rows;         /* size of the coupled model                                                                              */
+    double price_us, price_sweep_us;       /* host wall clock inside the price solve / inside the sweeps (launch -> totals visible in pinned memory) */
+    double milp_us, model_us;              /* host wall clock of the whole solve of the coupled model / of building it (solver.rs:95-430)            */
 } hqtick_kernel_stats;
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
 /* Switch the per-kernel timing on / off at run time (HQTICK_FLAG_NO_KERNEL_TIMING sets the initial state).  When on, the measured kernels are

@@ -60,6 +60,19 @@ void hqtick_debug_set_block_emulation(int on, uint32_t budget);
 /* classes the last hqtick_debug_host_stages call solved through the emulation / with the host solver */
 void hqtick_debug_last_blocks(uint32_t *n_emulated, uint32_t *n_host);
 
+/* The coupled placement by price sweeps (csrc/price.cpp; k_price_sweep's algorithm in csrc/price_core.h) with the wavefront emulated on the CPU.
+ * on != 0: hqtick_debug_host_stages (this thread) hands coupled models of at least min_cols columns (0: the default) to the sweeps — the code path
+ * of a GPU tick, minus the hardware. */
+void hqtick_debug_set_price_emulation(int on, uint32_t min_cols);
+/* sweeps over all blocks / flag configurations of the last hqtick_debug_host_stages call (0: the host search ran alone) */
+void hqtick_debug_last_price(uint32_t *sweeps, uint32_t *rounds);
+/* hqtick_debug_milp_solve on a model that carries the builder's structure hints (col_group: block of every column, -1 = a column of the whole model;
+ * row_implied: rows implied for integer points by their block's other rows; both may be NULL), with the price sweeps run through the emulated
+ * wavefront when use_sweeps != 0.  stats_out (optional, 4 doubles): sweeps, rounds, microseconds inside the price solve, canonical flag. */
+int hqtick_debug_milp_solve_priced(int ncols, const double *obj, const uint8_t *col_kind, const int32_t *col_group, int nrows, const uint8_t *row_type,
+                                   const uint8_t *row_implied, const double *rhs, const int *row_off, const int *row_col, const double *row_coef,
+                                   double time_limit_s, int use_sweeps, uint32_t min_cols, double *x_out, double *obj_out, int *is_optimal, double *stats_out);
+
 /* The wire encoding of include/hqwire.h on HOST memory: the same phase functions the three kernels run (csrc/wire_core.h), executed for
  * thread 0..255 in turn with a loop end standing in for each workgroup barrier.  Same arguments as hqwire_encode_device, all pointers host
  * pointers.  Lets the CPU test suite execute the encoder's logic; it is not a product path (hqwire_encode_device has no CPU fallback). */

@@ -796,7 +796,11 @@ bool load_state(State &st, const hqtick_snapshot *s, const hqtick_config *cfg) {
     return true;
 }
 
-struct Ctx { hqtick_config cfg; Out out; std::string err; double t_load = 0, t_batches = 0, t_model = 0, t_solve = 0, t_mapping = 0; };
+struct Ctx {
+    hqtick_config cfg; Out out; std::string err; double t_load = 0, t_batches = 0, t_model = 0, t_solve = 0, t_mapping = 0;
+    // one-shot: the next oracle_tick takes its placement from here instead of the solver (parity tier T3: mapping given counts, scheduler/mapping.rs:23-234)
+    bool given = false, g_optimal = true; std::vector<u32> g_rq, g_worker, g_value; std::vector<u8> g_variant;
+};
 
 }  // namespace
 
@@ -807,6 +811,15 @@ void oracle_destroy(void *p) { delete (Ctx *)p; }
 const char *oracle_last_error(void *p) { return ((Ctx *)p)->err.c_str(); }
 
 // create_task_batches only (tier T1)
+// The next oracle_tick on this ctx skips the MILP: its solution is the given single-node counts (worker = index into the snapshot's worker arrays).
+// Batches, model (for the column mapping), decode into the reference's Map orders, create_task_mapping, proactive filling and the record order are
+// computed as always — what remains is exactly "the reference's mapping stage given these counts" (tier T3).
+void oracle_set_given_counts(void *p, uint32_t n, const uint32_t *rq, const uint8_t *variant, const uint32_t *worker, const uint32_t *value, int is_optimal) {
+    Ctx *c = (Ctx *)p;
+    c->g_rq.assign(rq, rq + n); c->g_variant.assign(variant, variant + n); c->g_worker.assign(worker, worker + n); c->g_value.assign(value, value + n);
+    c->g_optimal = is_optimal != 0; c->given = true;
+}
+
 int oracle_batches(void *p, const hqtick_snapshot *s, hqtick_result *res) {
     Ctx *c = (Ctx *)p; State st;
     if (!load_state(st, s, &c->cfg)) { c->err = "invalid snapshot"; return HQTICK_E_INVALID; }
@@ -839,7 +852,20 @@ int oracle_tick(void *p, const hqtick_snapshot *s, oracle_solve_fn fn, void *use
         if (g_error) { c->err = g_errmsg; return g_error; }
         double gap_solve = solver.solve_us;
         std::vector<double> x; double objv = 0; int is_opt = 1;
-        bool ok = run_solver(solver, bm.m, st.cfg.mip_time_limit_s, x, &objv, &is_opt);  // :433-437
+        bool ok;
+        if (c->given) {  // T3 "given counts" (oracle_set_given_counts): the placement comes from the caller, everything after it is the reference's
+            x.assign((size_t)bm.m.ncols(), 0.0);
+            ok = true;
+            for (size_t i = 0; i < c->g_rq.size(); i++) {
+                auto it = bm.placements.find({c->g_worker[i], c->g_rq[i], c->g_variant[i]});
+                if (it == bm.placements.end()) { c->err = "given count for a (worker, rq, variant) without a placement column"; c->given = false; return HQTICK_E_INVALID; }
+                x[(size_t)it->second] = (double)c->g_value[i];
+            }
+            for (int j = 0; j < bm.m.ncols(); j++) objv += bm.m.obj[(size_t)j] * x[(size_t)j];
+            is_opt = c->g_optimal ? 1 : 0;
+            c->given = false;
+        } else
+        ok = run_solver(solver, bm.m, st.cfg.mip_time_limit_s, x, &objv, &is_opt);  // :433-437
         (void)gap_solve;
         if (ok) sol = decode(st, batches, bm, workers, nullptr, x, is_opt != 0);
         o.last_x = x; o.last_obj = objv; o.last_model = std::move(bm);

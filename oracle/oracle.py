@@ -75,6 +75,7 @@ def lib():
         _lib.oracle_tick.argtypes = [C.c_void_p, C.POINTER(abi.SnapshotC), SOLVE_FN, C.c_void_p, C.POINTER(abi.ResultC)]
         _lib.oracle_query.argtypes = [C.c_void_p, C.POINTER(abi.SnapshotC), C.POINTER(abi.QueryWorkersC), SOLVE_FN, C.c_void_p, C.POINTER(abi.QueryResultC)]
         _lib.oracle_last_model.argtypes = [C.c_void_p, C.POINTER(ModelView)]
+        _lib.oracle_set_given_counts.argtypes = [C.c_void_p, C.c_uint32, abi.u32p, abi.u8p, abi.u32p, abi.u32p, C.c_int]
         _lib.oracle_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         _lib.oracle_prune_progressive.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, abi.u32p]
         _lib.oracle_gap.argtypes = [C.c_void_p, C.POINTER(abi.SnapshotC), C.c_uint32, C.c_uint32, C.c_uint32, SOLVE_FN, C.c_void_p]
@@ -355,6 +356,19 @@ class Oracle:
         if rcode < 0:
             raise RuntimeError(f"oracle_tick failed: {rcode} {self.error()}")
         return abi.parse_result(rc, len(snap.worker_id), snap.n_resources)
+
+    def tick_given(self, snap: abi.Snapshot, counts, is_optimal: bool = True) -> abi.Result:
+        """Parity tier T3: the reference's tick with the MILP's answer GIVEN — `counts` = (rq, variant, worker index, count) tuples, e.g. the
+        product's — so that decode, create_task_mapping (scheduler/mapping.rs:23-234), proactive filling and the record order are the reference's on
+        exactly the product's placement.  The model is still built (column mapping; `last_model()["x"]` holds the given point)."""
+        cs = [(int(a), int(b), int(c), int(d)) for a, b, c, d in counts if d]
+        rq = np.ascontiguousarray([c[0] for c in cs], np.uint32); v = np.ascontiguousarray([c[1] for c in cs], np.uint8)
+        w = np.ascontiguousarray([c[2] for c in cs], np.uint32); val = np.ascontiguousarray([c[3] for c in cs], np.uint32)
+        z32, z8 = np.zeros(1, np.uint32), np.zeros(1, np.uint8)
+        pick = lambda a, z: a if len(a) else z
+        lib().oracle_set_given_counts(self._ctx, len(cs), pick(rq, z32).ctypes.data_as(abi.u32p), pick(v, z8).ctypes.data_as(abi.u8p), pick(w, z32).ctypes.data_as(abi.u32p),
+                                      pick(val, z32).ctypes.data_as(abi.u32p), 1 if is_optimal else 0)
+        return self.tick(snap)
 
     def query(self, snap: abi.Snapshot, fake_ids, fake_total, fake_remaining=None, fake_min_util=None):
         sc = snap.to_c()

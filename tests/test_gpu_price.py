@@ -1,0 +1,168 @@
+"""Coupled ticks through the C ABI with the placement solved by k_price_sweep (csrc/price.hip) — GPU only.
+
+1. The kernel against its CPU emulation: the same tick through the HIP library and through the host stages with the emulated wavefront
+   (tests/test_price.py) must walk the same sweeps to the same counts (the sums of a sweep are integer or fixed-order, so the two are bit-equal).
+2. VERDICT r02 item 1: the BASELINE-size coupled ticks — c3p (1 M tasks x 1024 workers, three priority levels) and the first wave of config 5
+   (every source of the 1 M-node DAG on the idle cluster) — as WHOLE ticks through the C ABI: status DONE / is_optimal; objective within 1e-4 of a
+   bound that needs no solver; every row of the oracle's (= the reference's) model satisfied by the counts; and parity tier T3 "given counts": the
+   oracle's decode + create_task_mapping + proactive filling on the product's counts (Oracle.tick_given, scheduler/mapping.rs:23-234) must give the
+   product's records, retracts, redirects and free vectors exactly.  What stays unpinned is which of the (tied, or 1e-4-close) optima was chosen.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from hyperqueue_amd import abi, workloads
+from hyperqueue_amd.tick import Tick
+
+pytestmark = pytest.mark.gpu
+
+
+def _tick(snap, tl=5.0, min_cols=None, monkeypatch=None):
+    if min_cols is not None:
+        monkeypatch.setenv("HQTICK_PRICE_MIN_COLS", str(min_cols))
+    t = Tick(abi.make_config(time_limit_s=tl))
+    try:
+        res = t.tick(snap)
+        return res, t.kernel_stats()
+    finally:
+        t.close()
+
+
+def _dag_sources():
+    ids, prio, rq, off, dep = workloads.make_dag(1_000_000, seed=0)
+    return ids, prio, rq, np.nonzero((off[1:] - off[:-1]) == 0)[0]
+
+
+def _unsaturated(W, fill):
+    ids, prio, rq, src = _dag_sources()
+    sel = src[: min(len(src), int(len(src) * W / 1024 * fill / 0.45))]
+    drv = workloads.DagChurn(n_workers=W, churn=0.1, seed=0)
+    return drv.snapshot(ids[sel], prio[sel], (rq[sel] % 8).astype(np.uint32))
+
+
+CASES = {
+    "c3p-64": lambda: workloads.make("c3p", n_tasks=160_000, n_workers=64),
+    "c3p-256": lambda: workloads.make("c3p", n_tasks=400_000, n_workers=256),
+    "unsat-256-45": lambda: _unsaturated(256, 0.45),
+    "unsat-512-20": lambda: _unsaturated(512, 0.20),
+    "steady-c3p-128": lambda: workloads.make_steady("c3p", seed=3, n_workers=128, n_tasks=200_000),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_sweeps_walk_the_emulations_path(name, monkeypatch):
+    from test_price import stages
+
+    snap = CASES[name]()
+    got, ks = _tick(snap, min_cols=64, monkeypatch=monkeypatch)
+    want, sweeps, rounds = stages(snap, True, min_cols=64)
+    assert ks["price_sweeps"] > 0
+    assert (ks["price_sweeps"], ks["price_rounds"]) == (sweeps, rounds)
+    assert got.status == want.status and got.is_optimal == want.is_optimal
+    assert got.batches == want.batches and got.counts == want.counts
+
+
+def _model_point(model, counts):
+    """the counts as a point of the oracle's model; flag columns (zero-cost 0/1) switched on where their `>=` row needs them (they are existential)"""
+    cd = {(q, v, w): c for (q, v, w, c) in counts}
+    n = len(model["obj"])
+    x = np.zeros(n)
+    for j in range(n):
+        if model["ctype"][j] == 0:
+            x[j] = cd.get((int(model["crq"][j]), int(model["cvariant"][j]), int(model["cworker"][j])), 0)
+    roff, rcol, rcoef = model["roff"], model["rcol"], model["rcoef"]
+    for i in range(len(model["rhs"])):
+        if model["rtype"][i] != 0:
+            continue
+        a, b = roff[i], roff[i + 1]
+        act = float(np.dot(rcoef[a:b], x[rcol[a:b]]))
+        if act < model["rhs"][i] - 1e-6:
+            for k in range(a, b):
+                j = rcol[k]
+                if model["kind"][j] == 1 and model["obj"][j] == 0.0 and rcoef[k] >= model["rhs"][i] - 1e-9:
+                    x[j] = 1.0
+                    break
+    return x
+
+
+def _rows_hold(model, x):
+    from scipy.sparse import csr_matrix
+
+    A = csr_matrix((model["rcoef"], model["rcol"], model["roff"]), shape=(len(model["rhs"]), len(x)))
+    act = A @ x
+    rt, rhs = model["rtype"], model["rhs"]
+    return bool(np.all(act[rt == 1] <= rhs[rt == 1] + 1e-6) and np.all(act[rt == 0] >= rhs[rt == 0] - 1e-6) and np.all(np.abs(act[rt == 2] - rhs[rt == 2]) <= 1e-6))
+
+
+def _full_tick_checks(snap, bound_fn):
+    from oracle.oracle import Oracle
+
+    got, ks = _tick(snap)
+    assert got.status == abi.HQTICK_DONE and got.is_optimal
+    assert ks["price_sweeps"] > 0  # the coupled model went through k_price_sweep
+    o = Oracle(abi.make_config(time_limit_s=5.0))
+    want = o.tick_given(snap, got.counts, is_optimal=True)
+    model = o.last_model()
+    x = _model_point(model, got.counts)
+    assert _rows_hold(model, x)  # every row of the reference's model
+    z = float(np.dot(model["obj"], x))
+    bound = bound_fn(model)
+    assert bound * (1.0 - 1e-4) <= z <= bound * (1.0 + 1e-9), (z, bound)
+    # T3 given counts: everything downstream of the MILP, record for record
+    assert got.batches == want.batches
+    assert got.counts == want.counts  # (the Map iteration orders of the decode)
+    assert got.records == want.records
+    assert got.retracts == want.retracts and got.redirects == want.redirects
+    assert (got.new_free == want.new_free).all()
+    return got, ks, z, bound
+
+
+def test_c3p_full_tick_on_the_gpu():
+    """BASELINE.md C3 with three priority levels, full size.  Bound without a solver: every worker packed completely."""
+    snap = workloads.make("c3p", n_tasks=1_000_000, n_workers=1024)
+    W = 1024
+    _full_tick_checks(snap, lambda m: sum(3.0 * (W - w) / W / W for w in range(W)))
+
+
+def _lp_bound(model):
+    """LP relaxation of the oracle's model (HiGHS simplex: seconds at 8 192 columns) — an upper bound of the MILP optimum"""
+    from scipy.optimize import linprog
+    from scipy.sparse import csr_matrix
+
+    n, m = len(model["obj"]), len(model["rhs"])
+    A = csr_matrix((model["rcoef"], model["rcol"], model["roff"]), shape=(m, n))
+    sign = np.where(model["rtype"] == 0, -1.0, 1.0)
+    assert not (model["rtype"] == 2).any()
+    ub = np.where(model["kind"] == 1, 1.0, np.inf)
+    res = linprog(-model["obj"], A_ub=A.multiply(sign[:, None]).tocsr(), b_ub=model["rhs"] * sign, bounds=list(zip(np.zeros(n), ub)), method="highs")
+    assert res.status == 0
+    return -res.fun
+
+
+def test_config5_first_wave_full_tick_on_the_gpu():
+    """BASELINE config 5, first tick: the 49 642 sources of the 1 M-node DAG, all eight classes, on the idle 1024-worker cluster
+    (an 8 192-column coupled model: no batch is saturated).  Bound: the LP relaxation of the reference's model."""
+    ids, prio, rq, src = _dag_sources()
+    drv = workloads.DagChurn(n_workers=1024, churn=0.1, seed=0)
+    snap = drv.snapshot(ids[src], prio[src], (rq[src] % 8).astype(np.uint32))
+    _full_tick_checks(snap, _lp_bound)
+
+
+def test_host_search_and_price_sweeps_agree(monkeypatch):
+    """HQTICK_PRICE=0 keeps the coupled tick on the host's search (round 2's path): both certify within 1e-4, so the objectives agree to that"""
+    snap = _unsaturated(256, 0.45)
+    got, ks = _tick(snap)
+    assert ks["price_sweeps"] > 0 and got.is_optimal
+    monkeypatch.setenv("HQTICK_PRICE", "0")
+    host, ks0 = _tick(snap)
+    assert ks0["price_sweeps"] == 0 and host.is_optimal
+    from oracle.oracle import Oracle
+
+    o = Oracle(abi.make_config(time_limit_s=0.2), reference_solver_options=True)
+    o.tick(snap)
+    m = o.last_model()
+    zg = float(np.dot(m["obj"], _model_point(m, got.counts))); zh = float(np.dot(m["obj"], _model_point(m, host.counts)))
+    assert abs(zg - zh) <= 1e-4 * max(zg, zh)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Coupled ticks through the C ABI with the price sweeps (k_price_sweep) on and off: c3p at BASELINE size, the config-5 first wave and the
+unsaturated 1024-worker probes of DESIGN.md §4.  Prints status, objective-free figures (assigned tasks), the solve's stage times and sweeps.
+  python tools/price_probe.py [c3p 0.2 0.45 wave ...] [--repeat N] [--no-host]"""
+import os, sys, time, json
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime per process, as in bench.py)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hyperqueue_amd import abi, workloads
+from hyperqueue_amd.tick import Tick
+
+_dag = None
+
+
+def snapshot(which):
+    global _dag
+    if which == "c3p":
+        return workloads.make("c3p", n_tasks=1_000_000, n_workers=1024)
+    if which.startswith("c3p:"):
+        w = int(which.split(":")[1])
+        return workloads.make("c3p", n_tasks=1000 * w, n_workers=w)
+    if _dag is None:
+        ids, prio, rq, off, dep = workloads.make_dag(1_000_000, seed=0)
+        _dag = (ids, prio, rq, np.nonzero((off[1:] - off[:-1]) == 0)[0])
+    ids, prio, rq, src = _dag
+    if which == "wave":  # config 5's first wave: every source of the DAG on the idle cluster
+        sel = src
+    else:
+        fill = float(which)
+        sel = src[: min(len(src), int(len(src) * fill / 0.45))]
+    drv = workloads.DagChurn(n_workers=1024, churn=0.1, seed=0)
+    return drv.snapshot(ids[sel], prio[sel], (rq[sel] % 8).astype(np.uint32))
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    repeat = int(sys.argv[sys.argv.index("--repeat") + 1]) if "--repeat" in sys.argv else 3
+    cases = args or ["c3p", "wave", "0.2", "0.45"]
+    out = {}
+    for which in cases:
+        snap = snapshot(which)
+        for mode in (["price"] if "--no-host" in sys.argv else ["price", "host"]):
+            os.environ["HQTICK_PRICE"] = "1" if mode == "price" else "0"
+            t = Tick(abi.make_config(time_limit_s=5.0))
+            best = None
+            for r in range(repeat if mode == "price" else 1):
+                t0 = time.perf_counter()
+                res = t.tick(snap)
+                dt = time.perf_counter() - t0
+                ks = t.kernel_stats()
+                rec = dict(ms=round(dt * 1e3, 3), status=res.status, is_optimal=bool(res.is_optimal), assigned=int(sum(len(x) for x in res.records)),
+                           sweeps=ks["price_sweeps"], rounds=ks["price_rounds"], price_ms=round(ks["price_us"] / 1e3, 3), sweep_ms=round(ks["price_sweep_us"] / 1e3, 3),
+                           milp_ms=round(ks["milp_us"] / 1e3, 3), model_ms=round(ks["model_us"] / 1e3, 3), cols=ks["milp_cols"], rows=ks["milp_rows"])
+                if best is None or rec["ms"] < best["ms"]:
+                    best = rec
+            counts = {(a, b, c): d for a, b, c, d in res.counts}
+            best["n_counts"] = len(counts)
+            out[f"{which}/{mode}"] = best
+            print(which, mode, json.dumps(best), flush=True)
+            t.close()
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open("gpurun_out/price_probe.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
