@@ -293,6 +293,7 @@ struct GapCache {
 // ---------------------------------------------------------------------------------------------------------------
 Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &batches) {
     Counts out;
+    const double t_enter = clock_us();
     if (pb.rqs.empty()) return out;  // :53-55
     const WorkerSet &ws = pb.custom ? *pb.custom : pb.real;
     const uint32_t R = pb.R;
@@ -589,6 +590,10 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 // the early workers exactly — the part the LP-rounding heuristics of the solver are weakest at.
                 bool usable = true;
                 for (uint8_t fl : class_has_flag) if (fl) usable = false;  // min_utilization flags are not part of the hint
+                if (usable && pb.pricer) {
+                    size_t kept = 0; for (uint32_t w : solver_workers) if (!worker_off[w]) kept++;
+                    if (kept * NC >= 2 * (size_t)pb.pricer->min_cols) usable = false;
+                }  // the price sweeps build their own incumbent: the W sequential block solves would cost more than they do
                 if (usable) {
                     std::vector<double> rem(nb);
                     for (size_t b = 0; b < nb; b++) rem[b] = batches[b].limit_reached ? 1e18 : (double)batches[b].size;
@@ -695,7 +700,11 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     const double t_model0 = clock_us();
     // structure hints for the coupled solve (csrc/price.h): a worker's columns form a block, the flags and group sizes belong to the whole model
     auto addc = [&](double w, uint8_t kind, int32_t group) { m.col_group.push_back(group); return m.add_col(w, kind); };
-    std::map<std::tuple<uint32_t, uint32_t, uint8_t>, int> place;  // (worker, rq, variant) -> column   :88
+    // (worker, rq, variant) -> column   :88   — a flat table over (worker, variant slot), -1 = no column
+    const uint32_t NVS = ws.n_variant_slots;
+    std::vector<int> place_col((size_t)ws.n * NVS, -1);
+    std::vector<uint32_t> col_ub;  // per column: how often the request fits into the worker's free resources (what its resource rows allow at most)
+    auto place_get = [&](uint32_t w, uint32_t rq, uint8_t v) -> int { return place_col[(size_t)w * NVS + pb.rqs[rq].first_variant + v]; };
     std::map<uint32_t, std::vector<int>> count_cols;               // tasks_count_vars   :89
     std::vector<std::vector<std::pair<int, double>>> res_terms(R);
     std::vector<std::pair<int, double>> cpu_terms, block_terms;
@@ -737,7 +746,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                         double s = 0.0;  // create_mn_var  :573-597
                         for (uint32_t r = 0; r < R; r++) if (tot[r]) s += pool[r] < 0.000001 ? 0.0 : units(tot[r]) / pool[r];
                         int col = addc(s * order_factor * ((double)vv.weight / FRACTIONS) / (double)nw, hqmilp::COL_BOOL, (int32_t)wi);
-                        place[{w, batch.rq, v}] = col;
+                        place_col[(size_t)w * NVS + slot] = col; col_ub.resize((size_t)col + 1, 1); col_ub[col] = 1;
                         for (uint32_t r = 0; r < R; r++) if (tot[r]) res_terms[r].push_back({col, units(tot[r])});
                     }
                 } else if (!is_blocked(w, batch.rq, v) && (f & 4) && (f & 1) && (pb.custom || ws.is_sn(w))) {  // :123-126
@@ -748,7 +757,16 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                         s += g < 0.000001 ? 0.0 : units(vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e]) / g;
                     }
                     int col = addc(s * order_factor * ((double)vv.weight / FRACTIONS) / (double)nw, hqmilp::COL_NAT, (int32_t)wi);
-                    place[{w, batch.rq, v}] = col;
+                    place_col[(size_t)w * NVS + slot] = col;
+                    {   // the column's own bound: min over its entries of floor(free / amount)
+                        uint64_t ubc = UINT32_MAX;
+                        for (uint32_t e = 0; e < vv.n_entries; e++) {
+                            const uint64_t f = fre[vv.res[e]], am = vv.kind[e] == HQ_ENTRY_ALL ? tot[vv.res[e]] : vv.amount[e];
+                            if (f == HQ_AMOUNT_MAX || am == 0) continue;
+                            ubc = std::min<uint64_t>(ubc, f / am);
+                        }
+                        col_ub.resize((size_t)col + 1, UINT32_MAX); col_ub[col] = (uint32_t)ubc;
+                    }
                     count_cols[batch.rq].push_back(col);
                     block_terms.push_back({col, s * ((double)vv.weight / FRACTIONS)});
                     for (uint32_t e = 0; e < vv.n_entries; e++) {
@@ -790,8 +808,8 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             std::vector<int> members;
             for (uint32_t w = 0; w < pb.real.n; w++) {
                 if ((pb.real.group ? pb.real.group[w] : 0) != g) continue;
-                auto it = place.find({w, batch.rq, (uint8_t)0});
-                if (it != place.end()) members.push_back(it->second);
+                const int pc = place_get(w, batch.rq, 0);
+                if (pc >= 0) members.push_back(pc);
             }
             if (members.empty()) continue;
             int col = addc(0.0, hqmilp::COL_NAT, -1);
@@ -813,6 +831,21 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         return col;
     };
     GapCache gaps(pb);
+    // the gap depends on the worker's total resources and on what runs there: workers with the same signature share one computation per (blocker, batch)
+    std::vector<uint32_t> gap_sig; std::map<std::vector<uint64_t>, uint32_t> sig_ids; std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> gap_memo;
+    auto sig_of = [&](uint32_t w) -> uint32_t {
+        if (gap_sig.empty()) gap_sig.assign(ws.n, UINT32_MAX);
+        if (gap_sig[w] != UINT32_MAX) return gap_sig[w];
+        std::vector<uint64_t> key(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
+        if (!pb.custom && ws.assigned_off) {
+            const size_t k0 = key.size();
+            for (uint32_t i = ws.assigned_off[w]; i < ws.assigned_off[w + 1]; i++) key.push_back(((uint64_t)ws.assigned_rq[i] << 8) | ws.assigned_variant[i]);
+            std::sort(key.begin() + (long)k0, key.end());  // (saturating subtractions commute: the multiset of running tasks decides)
+        }
+        auto it = sig_ids.find(key);
+        if (it == sig_ids.end()) it = sig_ids.emplace(std::move(key), (uint32_t)sig_ids.size()).first;
+        return gap_sig[w] = it->second;
+    };
     for (const TaskBatch &batch : batches) {
         auto cc = count_cols.find(batch.rq);
         if (cc == count_cols.end()) continue;
@@ -828,6 +861,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             for (auto &bl : cut.blockers) {
                 uint32_t brq = bl.first; bool bounded = bl.second != HQ_BLOCKER_UNBOUNDED;
                 std::vector<int> no_gap;  // zero_cond
+                std::vector<int> cols;
                 if (pb.rq_multi_node(batch.rq)) {
                     for (uint32_t g = 0; g < pb.n_groups; g++) {
                         auto it = group_cols.find({batch.rq, g});
@@ -836,12 +870,24 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 } else {
                     for (uint32_t w : solver_workers) {
                         if (!pb.capable_rqv(ws, w, brq)) continue;
-                        Amounts tot; tot.a.assign(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
-                        const uint32_t a0 = (pb.custom || !ws.assigned_off) ? 0 : ws.assigned_off[w], na = pb.custom ? 0 : ws.n_assigned(w);
-                        uint32_t gap = gaps.gap(brq, batch.rq, tot, na ? ws.assigned_rq + a0 : nullptr, na ? ws.assigned_variant + a0 : nullptr, na);
-                        std::vector<int> cols;
-                        for (uint8_t v = 0; v < brv.n_variants; v++) { auto it = place.find({w, batch.rq, v}); if (it != place.end()) cols.push_back(it->second); }
+                        uint32_t gap;
+                        {
+                            const auto gkey = std::make_tuple(brq, batch.rq, sig_of(w));
+                            auto git = gap_memo.find(gkey);
+                            if (git == gap_memo.end()) {
+                                Amounts tot; tot.a.assign(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
+                                const uint32_t a0 = (pb.custom || !ws.assigned_off) ? 0 : ws.assigned_off[w], na = pb.custom ? 0 : ws.n_assigned(w);
+                                git = gap_memo.emplace(gkey, gaps.gap(brq, batch.rq, tot, na ? ws.assigned_rq + a0 : nullptr, na ? ws.assigned_variant + a0 : nullptr, na)).first;
+                            }
+                            gap = git->second;
+                        }
+                        cols.clear();
+                        uint64_t cols_ub = 0;
+                        for (uint8_t v = 0; v < brv.n_variants; v++) { const int pc = place_get(w, batch.rq, v); if (pc >= 0) { cols.push_back(pc); cols_ub += col_ub[(size_t)pc]; } }
                         if (gap > 0) {
+                            // (a row no point within the columns' own bounds can violate is not emitted: with cuts in the thousands and workers that hold
+                            // a hundred tasks that is every one of the W x cuts x blockers rows of a large tick — the model's points are the same)
+                            if (cols.empty() || cols_ub <= (uint64_t)cut.size + gap) continue;
                             int fl;
                             if (bounded && (fl = short_flag(brq, bl.second)) >= 0) emit_plus(hqmilp::ROW_MAX, (double)cut.size + bsize + (double)gap, cols, fl, bsize);
                             else if (!bounded) { m.begin_row(hqmilp::ROW_MAX, (double)cut.size + (double)gap); for (int c : cols) m.term(c, 1.0); m.end_row(); }
@@ -864,15 +910,15 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     if (!seq_start.empty()) {
         m.start.assign(m.ncols(), 0.0);
         for (const SeqStart &ss : seq_start) {
-            auto it = place.find({ss.w, batches[ss.batch].rq, ss.variant});
-            if (it == place.end()) { m.start.clear(); break; }
-            m.start[it->second] = ss.count;
+            const int pc = place_get(ss.w, batches[ss.batch].rq, ss.variant);
+            if (pc < 0) { m.start.clear(); break; }
+            m.start[pc] = ss.count;
         }
     }
     m.row_implied.resize(m.nrows(), 0);
     const double t_model1 = clock_us();
     hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438
-    out.model_us = t_model1 - t_model0; out.milp_us = clock_us() - t_model1; out.price_sweeps = sol.price_sweeps; out.price_rounds = sol.price_rounds; out.price_us = sol.price_total_us;
+    out.pre_us = t_model0 - t_enter; out.model_us = t_model1 - t_model0; out.milp_us = clock_us() - t_model1; out.price_sweeps = sol.price_sweeps; out.price_rounds = sol.price_rounds; out.price_us = sol.price_total_us;
     out.milp_nodes = sol.nodes; out.milp_cols = m.ncols(); out.milp_rows = m.nrows(); out.milp_components = sol.n_components;
     if (!sol.feasible) return out;
     out.is_optimal = sol.optimal;
@@ -887,8 +933,8 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             size_t n_nodes = pb.variants[rv.first_variant].n_nodes;
             std::vector<std::vector<uint32_t>> sets;
             for (uint32_t w : solver_workers) {
-                auto it = place.find({w, batch.rq, (uint8_t)0});
-                if (it == place.end() || (uint32_t)std::round(sol.x[it->second]) == 0) continue;
+                const int pc = place_get(w, batch.rq, 0);
+                if (pc < 0 || (uint32_t)std::round(sol.x[pc]) == 0) continue;
                 if (!sets.empty() && sets.back().size() < n_nodes) sets.back().push_back(w); else sets.push_back({w});
             }
             if (!sets.empty()) { mn_hash.push_back(hqhb::hash_rq_variant(batch.rq, 0)); mn_list.push_back(batch.rq); mn_sets.push_back(sets); }
@@ -896,9 +942,9 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             for (uint8_t v = 0; v < rv.n_variants; v++) {
                 std::vector<uint32_t> ids, widx, cnt;
                 for (uint32_t w : solver_workers) {
-                    auto it = place.find({w, batch.rq, v});
-                    if (it == place.end()) continue;
-                    uint32_t c = (uint32_t)std::round(sol.x[it->second]);
+                    const int pc = place_get(w, batch.rq, v);
+                    if (pc < 0) continue;
+                    uint32_t c = (uint32_t)std::round(sol.x[pc]);
                     if (c > 0) { ids.push_back(ws.id[w]); widx.push_back(w); cnt.push_back(c); }
                 }
                 if (ids.empty()) continue;

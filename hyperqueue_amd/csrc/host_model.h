@@ -167,7 +167,7 @@ struct Counts {
     }
     int error = 0; std::string errmsg;
     long milp_nodes = 0; int milp_cols = 0, milp_rows = 0, milp_components = 0;
-    int price_sweeps = 0, price_rounds = 0; double price_us = 0, milp_us = 0, model_us = 0;  // coupled path: block sweeps / flag rounds of csrc/price.cpp, time inside them, inside hqmilp::solve, building the model
+    int price_sweeps = 0, price_rounds = 0; double price_us = 0, milp_us = 0, model_us = 0, pre_us = 0;  // coupled path: block sweeps / flag rounds of csrc/price.cpp, time inside them, inside hqmilp::solve, building the model
     uint32_t blocks_device = 0, blocks_host = 0, block_steps_max = 0, n_classes = 0;
     double t_classify_us = 0, t_blocks_us = 0, t_decode_us = 0;  // separable path: worker classes / block solves (device wait included) / counts in Map order  // separable path: classes solved by k_block_solve / by the host solver
 };

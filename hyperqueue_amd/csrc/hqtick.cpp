@@ -1054,7 +1054,7 @@ struct TickRun {
         pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes; pb.pricer = ctx->pricer;
         cnt = hqhost::run_scheduling_solver(pb, batches);
         pb.blocks = nullptr; pb.pricer = nullptr;
-        ctx->stats.price_sweeps = (uint32_t)cnt.price_sweeps; ctx->stats.price_rounds = (uint32_t)cnt.price_rounds; ctx->stats.price_us = cnt.price_us; ctx->stats.milp_us = cnt.milp_us; ctx->stats.model_us = cnt.model_us;
+        ctx->stats.price_sweeps = (uint32_t)cnt.price_sweeps; ctx->stats.price_rounds = (uint32_t)cnt.price_rounds; ctx->stats.price_us = cnt.price_us; ctx->stats.milp_us = cnt.milp_us; ctx->stats.model_us = cnt.model_us; ctx->stats.solve_pre_us = cnt.pre_us;
         ctx->stats.price_sweep_us = ctx->pricer ? ctx->pricer->stat_sweep_us : 0.0; ctx->stats.milp_cols = (uint32_t)cnt.milp_cols; ctx->stats.milp_rows = (uint32_t)cnt.milp_rows;
         if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
         ctx->stats.n_classes_device = cnt.blocks_device; ctx->stats.n_classes_host = cnt.blocks_host; ctx->stats.block_steps_max = cnt.block_steps_max; ctx->stats.n_classes = cnt.n_classes;

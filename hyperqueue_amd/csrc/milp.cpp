@@ -953,6 +953,9 @@ bool sparse_greedy(const Model &mdl, const std::vector<double> &ub, std::vector<
 const double ROW_TOL = 1e-6;
 
 Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double rel_gap, hqprice::Sweeper *sweeper) {
+    static const bool tracing_solve = getenv("HQMILP_TRACE") != nullptr;
+    const double ts0 = wall();
+    auto tmark = [&](const char *what) { if (tracing_solve && mdl_in.ncols() > 1000) fprintf(stderr, "[milp] solve(): %s at %.3f ms\n", what, (wall() - ts0) * 1e3); };
     Model snapped;  // a copy of the model only when a coefficient really has to be snapped (a block of a worker class has no BOOL column at all)
     bool need_snap = false;
     for (size_t k = 0; k < mdl_in.rcoef.size() && !need_snap; k++) {
@@ -1048,6 +1051,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             }
         }
     }
+    tmark("presolve done");
     const Model &mdl = need_snap ? snapped : mdl_in;
     Result res;
     int n = mdl.ncols(), m = mdl.nrows();
@@ -1081,8 +1085,10 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
 
     // ---- a feasible point for the whole model, before any LP: seeds every component's search and is the answer for components the
     // dense method cannot take ----
+    tmark("bounds done");
     std::vector<double> hx;
     bool have_hx = sparse_greedy(mdl, ub, hx);
+    tmark("sparse greedy done");
     if ((int)mdl.start.size() == n) {  // caller's starting point: taken if feasible and better
         bool ok = true; double zs = 0.0, zh = 0.0;
         for (int j = 0; j < n && ok; j++) { double v = mdl.start[j]; if (v < -1e-9 || v > ub[j] + 1e-9 || std::fabs(v - std::round(v)) > 1e-9) ok = false; zs += mdl.obj[j] * v; }
@@ -1118,6 +1124,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
         crows[comp_of[mdl.rcol[mdl.roff[i]]]].push_back(i);
     }
     res.n_components = (int)ccols.size();
+    tmark("components done");
 
     std::vector<int> local(n, -1);
     std::unordered_map<std::string, std::pair<int, std::vector<double>>> memo;
@@ -1145,13 +1152,14 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             cs.R.col.reserve(nnz); cs.R.coef.reserve(nnz); cs.R.off.reserve((size_t)cm + 2); cs.R.lo.reserve((size_t)cm + 1); cs.R.hi.reserve((size_t)cm + 1);  // (+1: the tie-break's objective row)
         }
         std::vector<std::pair<int, double>> terms;
+        std::vector<int> term_row((size_t)cs.n, -1), term_pos((size_t)cs.n, 0);
         for (int r = 0; r < cm; r++) {
             int i = rows[r]; double sc = 0.0;
             terms.clear();
-            for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) {  // duplicate columns of one row are summed
-                int lc = local[mdl.rcol[k]]; bool dup = false;
-                for (auto &t : terms) if (t.first == lc) { t.second += mdl.rcoef[k]; dup = true; break; }
-                if (!dup) terms.push_back({lc, mdl.rcoef[k]});
+            for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) {  // duplicate columns of one row are summed (stamp per column: a wide row has a thousand terms)
+                const int lc = local[mdl.rcol[k]];
+                if (term_row[(size_t)lc] == r) terms[(size_t)term_pos[(size_t)lc]].second += mdl.rcoef[k];
+                else { term_row[(size_t)lc] = r; term_pos[(size_t)lc] = (int)terms.size(); terms.push_back({lc, mdl.rcoef[k]}); }
             }
             for (auto &t : terms) sc = std::max(sc, std::fabs(t.second));
             if (sc == 0.0) sc = 1.0;
@@ -1187,8 +1195,10 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             for (int k = 0; k < cs.n; k++) { cs.bx[k] = hx[cols[k]]; z += cs.c[k] * cs.bx[k]; }
             cs.have = true; cs.best = z;
         }
+        tmark("component rows built");
         std::vector<double> xo;
         int st = cs.run(canonical, xo);
+        tmark("component solved");
         if (memo_ok && !cs.timed_out && cs.canonical_done && (st == 0 || st == 1)) memo.emplace(std::move(sig), std::make_pair(st, xo));
         if (!cs.canonical_done || st == 2) res.canonical = false;
         res.nodes += cs.nodes; res.lp_iters += cs.lp_iters;

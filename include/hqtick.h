@@ -480,6 +480,7 @@ typedef struct hqtick_kernel_stats {
     uint32_t milp_cols, milp_rows;         /* size of the coupled model                                                                              */
     double price_us, price_sweep_us;       /* host wall clock inside the price solve / inside the sweeps (launch -> totals visible in pinned memory) */
     double milp_us, model_us;              /* host wall clock of the whole solve of the coupled model / of building it (solver.rs:95-430)            */
+    double solve_pre_us;                   /* ... and of what the placement stage did before it (worker classes, the separable attempt)               */
 } hqtick_kernel_stats;
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
 /* Switch the per-kernel timing on / off at run time (HQTICK_FLAG_NO_KERNEL_TIMING sets the initial state).  When on, the measured kernels are

@@ -32,6 +32,31 @@ def snapshot(which):
     return drv.snapshot(ids[sel], prio[sel], (rq[sel] % 8).astype(np.uint32))
 
 
+def timeline(t, snap, which, n=12):
+    """median stage marks of the resident tick (ready set + cluster tables in HBM, as the bench's loop)"""
+    import ctypes as C
+    t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+    sc = snap.to_c()
+    t.cluster_upload(sc)
+    t.set_kernel_timing(False)
+    t._lib.hqtick_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+    rows, ks = [], []
+    for i in range(n + 3):
+        r = t.tick_raw(sc, resident=True)
+        buf = (C.c_double * 32)()
+        k = t._lib.hqtick_timeline(t._ctx, buf, 32)
+        if i >= 3:
+            rows.append([buf[j] for j in range(k)] + [r.t_total_us]); ks.append(t.kernel_stats())
+    m = np.median(np.asarray(rows), axis=0)
+    labels = ["phaseA", "batches", "solve", "keytables", "prefillplan", "k5tables", "pack", "C_enqueued", "C_synced", "assembled", "total"]
+    prev, parts = 0.0, []
+    for l, v in zip(labels, m):
+        parts.append(f"{l} +{v - prev:.0f}"); prev = v
+    med = {k: round(float(np.median([s[k] for s in ks])), 1) for k in ("solve_pre_us", "model_us", "milp_us", "price_us", "price_sweep_us", "price_sweeps", "price_rounds")}
+    print(which, "resident timeline (us):", " | ".join(parts), "| total", round(float(m[-1]), 1), med, flush=True)
+    t.cluster_drop()
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     repeat = int(sys.argv[sys.argv.index("--repeat") + 1]) if "--repeat" in sys.argv else 3
@@ -41,7 +66,9 @@ def main():
         snap = snapshot(which)
         for mode in (["price"] if "--no-host" in sys.argv else ["price", "host"]):
             os.environ["HQTICK_PRICE"] = "1" if mode == "price" else "0"
-            t = Tick(abi.make_config(time_limit_s=5.0))
+            t = Tick(abi.make_config(time_limit_s=5.0, flags=abi.HQTICK_FLAG_COMPACT_RECORDS | abi.HQTICK_FLAG_COMPACT_DELTA16))  # as bench.py runs it
+            if "--timeline" in sys.argv and mode == "price":
+                timeline(t, snap, which)
             best = None
             for r in range(repeat if mode == "price" else 1):
                 t0 = time.perf_counter()
