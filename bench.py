@@ -28,6 +28,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def cpu_model() -> str:
+    """the host CPU as /proc/cpuinfo names it (state the CPU model and '1 core' next to every CPU baseline)"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(snap, ticks: int):
     """The CPU oracle (restatement of the reference tick + HiGHS 1.8.0 for the MILP) on this host, 1 core, same snapshot."""
     from hyperqueue_amd import abi
@@ -43,7 +54,7 @@ def cpu_baseline(snap, ticks: int):
     st = o.stage_times_us()
     med = float(np.median(lat))
     return {
-        "value": assigned / med, "unit": "tasks/s", "cores": 1, "kind": "port",
+        "value": assigned / med, "unit": "tasks/s", "cores": 1, "cpu": cpu_model(), "kind": "port",
         "sample": f"{ticks} cold tick(s) of the full workload ({len(snap.task_id)} tasks x {len(snap.worker_id)} workers), "
                   f"median {med:.2f} s/tick, {assigned} tasks assigned/tick",
         "tick_s": med, "assigned_per_tick": assigned,
@@ -63,7 +74,7 @@ ROCPROF_K1 = {"avg_launch_us_ticks_with_events": 4.86, "avg_launch_us_ticks_with
 TRAFFIC = {"level_hist": 12_046_346 + 2_250_112, "select_scatter": 8_061_011 + 2_037_568, "expand_mapping": 7_023_645 + 458_752}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
 
 
-def dag_churn(cfg, steps: int, seed: int, n_classes: int):
+def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random", cpu_ticks: int = 1):
     """BASELINE config 5 on one GPU: the 1 M-node DAG lives in the device dependency graph (hqtick_graph_*); per tick the tasks handed out by
     the previous tick finish (their consumers are released into the resident ready set on the device), 10 % of the workers are lost (their
     tasks return to the ready set) and replaced, then hqtick_run_resident + hqtick_ready_consume_last."""
@@ -71,25 +82,33 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int):
     from hyperqueue_amd.tick import Tick
 
     n = 1_000_000
-    ids, prio, rq, off, dep = workloads.make_dag(n, seed=seed)
+    ids, prio, rq, off, dep = workloads.make_dag(n, seed=seed) if shape == "random" else workloads.make_dag_layered(n, width=20_000, seed=seed)
     rq = (rq % np.uint32(n_classes)).astype(np.uint32)
+    in_ready = np.zeros(n, bool)  # host mirror of the resident ready set's membership (for the CPU baseline's snapshots only; ids are job 1, task 1..n)
+    ix = lambda a: (np.asarray(a, np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1
     t = Tick(cfg)
     t.upload_ready(np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
     a = time.perf_counter(); ready0 = t.graph_add_tasks(ids, prio, rq, (off, dep)); t_add = time.perf_counter() - a
     add_kernel_us = t.graph_stats()["last_kernel_us"]
+    in_ready[ix(ready0)] = True
     drv = workloads.DagChurn(n_workers=1024, churn=0.10, seed=seed)
     W = 1024
-    rows = []
+    rows, base_snaps = [], {}
     for step in range(steps + 2):
         snap_now = drv.snapshot()  # keeps the arrays `sc` points into alive
         sc = snap_now.to_c()
+        if cpu_ticks > 0 and step in (0, steps + 1):  # what the CPU baseline is timed on: the first wave, and the loop's last tick
+            sel = np.nonzero(in_ready)[0]
+            base_snaps[step] = drv.snapshot(ids[sel], prio[sel], rq[sel])
         a = time.perf_counter(); res = t.tick_raw(sc, resident=True)
         b = time.perf_counter(); t.ready_consume_last()
         c = time.perf_counter()
+        ks_now = t.kernel_stats()
         rec_off = np.ctypeslib.as_array(res.rec_off, shape=(W + 1,)).astype(np.int64)
         rec_task = abi.record_task_ids(res, W)
         finished, returned = drv.after_tick(rec_off, rec_task)
         idx = (returned & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1
+        in_ready[ix(rec_task)] = False; in_ready[idx] = True
         d = time.perf_counter()
         if len(returned):
             t.ready_add(returned, prio[idx], rq[idx])
@@ -97,8 +116,10 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int):
         rel, unk = t.graph_finish(finished) if len(finished) else (np.zeros(0, np.uint64), 0)
         f = time.perf_counter()
         st = t.graph_stats()
+        in_ready[ix(rel)] = True
         rows.append(dict(tick=b - a, consume=c - b, readd=e - d, finish=f - e, n_out=len(rec_task), n_fin=len(finished), n_ret=len(returned), n_rel=len(rel),
-                         finish_kernel_us=st["last_kernel_us"], ready=int(t.ready_count()), status=int(res.status), optimal=int(res.is_optimal)))
+                         finish_kernel_us=st["last_kernel_us"], ready=int(t.ready_count()), status=int(res.status), optimal=int(res.is_optimal),
+                         sweeps=ks_now["price_sweeps"], sweep_us=ks_now["price_sweep_us"], milp_us=ks_now["milp_us"], cols=ks_now["milp_cols"]))
         if len(rec_task) == 0:
             break
     st = t.graph_stats()
@@ -116,12 +137,26 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int):
     edges = 3.0 * fin  # mean fan-out = mean fan-in
     fin_bytes = fin * 44 + edges * 16 + rel * 20
     ku = med("finish_kernel_us")
+    base = {}
+    for step_no, bs in base_snaps.items():  # the reference-configured oracle (HiGHS, 5 s limit as in the reference) on the snapshots the GPU ticked
+        try:
+            from oracle.oracle import Oracle
+
+            o = Oracle(abi.make_config(time_limit_s=5.0), reference_solver_options=True)
+            t0 = time.perf_counter(); r = o.tick(bs); dt = time.perf_counter() - t0
+            n_asg = sum(1 for recs in r.records for (_, _, k) in recs if k == abi.HQ_REC_ASSIGN)
+            base["first_wave" if step_no == 0 else "last_tick"] = {"value": n_asg / dt, "unit": "tasks/s", "cores": 1, "cpu": cpu_model(), "kind": "port", "tick_s": dt, "is_optimal": bool(r.is_optimal),
+                                                                   "assigned_per_tick": n_asg, "sample": f"1 tick of the snapshot the GPU ticked ({len(bs.task_id)} ready tasks x 1024 workers)",
+                                                                   "gpu_tick_s": rows[step_no]["tick"] if step_no < len(rows) else None}
+        except Exception as e:
+            base["first_wave" if step_no == 0 else "last_tick"] = {"error": repr(e)}
+    shape_txt = "random DAG (fan-in ~ Poisson(3) from lower ids" if shape == "random" else "layered DAG (layers of 20 000 tasks, fan-in 3 from the previous layer"
     return {
-        "workload": f"c5: {n}-node random DAG (fan-in ~ Poisson(3) from lower ids, {len(dep)} edges) over the first {n_classes} c3 classes, 1024 workers, 10 % of the workers lost "
-                    "and replaced per tick",
-        "note": "the frontier of this DAG (~50 k ready tasks) is below the cluster's capacity, so no batch is saturated and the placement model couples all workers through the "
-                "batch-size rows (host MILP; DESIGN.md §8b).  With all 8 c3 classes the first wave is an 8192 x 3080 model on which HiGHS runs into the reference's 5 s limit; "
-                "round 2 certifies it through the Lagrangian bound over the batch-size rows (DESIGN.md §4), so the loop runs with the full class mix",
+        "workload": f"c5: {n}-node {shape_txt}, {len(dep)} edges) over the first {n_classes} c3 classes, 1024 workers, 10 % of the workers lost and replaced per tick",
+        "note": "the frontier stays below the cluster's capacity, so no batch is saturated and the placement model couples all workers through the batch-size rows: every tick with "
+                "at least ~1000 model columns goes through k_price_sweep (DESIGN.md §4b); smaller ones (a few dozen ready tasks) stay with the host search",
+        "cpu_baseline": base,
+        "p50_price_sweeps_per_tick": int(med("sweeps")), "p50_model_columns": int(med("cols")), "p50_coupled_solve_us": med("milp_us"), "p50_sweeps_us": med("sweep_us"),
         "graph_add_ms": 1e3 * t_add, "graph_add_link_kernels_us": add_kernel_us, "initially_ready": int(len(ready0)),
         "graph_bytes_hbm": int(st["bytes_hbm"]),
         "steps": len(use), "p50_step_ms": 1e3 * float(np.median(step_s)), "tasks_handed_out_per_step": int(np.median(handed)),
@@ -132,7 +167,7 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int):
                           "note": "dependent random 4-16 B accesses (hash probe -> slot -> run -> edge -> counter RMW): latency-bound, not a streaming kernel"},
         "first_wave": {"finished": first["n_fin"], "released": first["n_rel"], "graph_finish_call_us": 1e6 * first["finish"], "finish_kernel_us": first["finish_kernel_us"],
                        "algorithmic_bytes": int(first_bytes), "GBps": first_bytes / (first["finish_kernel_us"] * 1e-6) / 1e9 if first["finish_kernel_us"] > 0 else None,
-                       "tick_us": 1e6 * first["tick"], "handed_out": first["n_out"]},
+                       "tick_us": 1e6 * first["tick"], "handed_out": first["n_out"], "price_sweeps": int(first["sweeps"]), "model_columns": int(first["cols"]), "is_optimal": bool(first["optimal"])},
         "ready_set_p50": int(med("ready")), "all_ticks_optimal": bool(all(r["optimal"] for r in use)),
     }
 
@@ -243,7 +278,7 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
             xg = np.asarray([gd.get((int(mdl["crq"][j]), int(mdl["cworker"][j])), 0) if mdl["ctype"][j] == 0 else 0 for j in range(len(mdl["obj"]))], np.float64)
             out["objective"] = {"gpu_tick": float(np.dot(mdl["obj"], xg)), "cpu_baseline": float(mdl["objective"]),
                                 "note": "same snapshot; equal objective = both optimal (the reference's answer is HiGHS's optimum; where optima tie, which one it returns is an artefact of HiGHS — DESIGN.md §4)"}
-            out["cpu_baseline"] = {"value": n_asg / tick_s, "unit": "tasks/s", "cores": 1, "kind": "port", "tick_s": tick_s, "assigned_per_tick": n_asg, "is_optimal": opt,
+            out["cpu_baseline"] = {"value": n_asg / tick_s, "unit": "tasks/s", "cores": 1, "cpu": cpu_model(), "kind": "port", "tick_s": tick_s, "assigned_per_tick": n_asg, "is_optimal": opt,
                                    "sample": f"{cpu_ticks} tick(s) of the snapshot the last timed GPU tick saw ({len(keep)} ready tasks x {W} heterogeneous workers)",
                                    "stages_us": {k: round(v, 1) for k, v in o.stage_times_us().items()},
                                    "note": "restatement of the reference (C++ -O2) + HiGHS 1.8.0 with default options on the un-reduced model (8 k columns); both sides optimal, tied optima may differ"}
@@ -275,12 +310,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--workload", default=None, help="c2 / c3 / c4; default: c3 on one GPU (BASELINE configs[2], the headline), c4 = BASELINE configs[3] as written (4096 workers, 1 M tasks, "
+                                                   "hash-sharded over the GPUs + one RCCL all-gather, strong scaling) when launched on N > 1 GPUs; `--workload c3 --scaling weak` is the weak-scaling mode")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="N > 1: weak = the workload grows with N (default for c2 / c3), strong = the configuration as written (default for c4 = BASELINE configs[3])")
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
     ap.add_argument("--no-resident-cluster", action="store_true", help="pack the worker tables per tick instead of keeping them in HBM (hqtick_cluster_*)")
-    ap.add_argument("--priority-ticks", type=int, default=1, help="ticks of the three-priority-level variant c3p (0 = skip)")
+    ap.add_argument("--priority-ticks", type=int, default=5, help="ticks of the three-priority-level variant c3p (0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=20, help="steps of the steady-state (delta-updated resident set) measurement, 0 = skip")
     ap.add_argument("--hetero-steps", type=int, default=25, help="ticks of the heterogeneous-worker steady state (SURVEY 8d: 10 %% of the running tasks finish per tick), 0 = skip")
     ap.add_argument("--dag-steps", type=int, default=12, help="ticks of the config-5 loop (1 M-node DAG in the device graph + 10 %% worker churn per tick), 0 = skip")
@@ -297,6 +333,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.workload is None:
+        args.workload = "c4" if world > 1 else "c3"
     import torch
 
     if not torch.cuda.is_available():
@@ -457,8 +495,11 @@ def main():
         "metric": "tasks_assigned_per_sec", "value": value, "unit": "tasks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {n_ready} ready tasks x {W} workers x {R} resource kinds, {len(snap.requests)} request classes, cold tick",
-                   "parallelism": "single" if world == 1 else f"worker-shards x{world}: FxHash(worker_id) % {world}, ready set replicated, one RCCL all-gather of the record sinks inside libhqtick.so (hqtick_shard_allgather), merged vector D2H on rank 0",
+        "config": {"workload": f"{args.workload}: {n_ready} ready tasks x {W} workers x {R} resource kinds, {len(snap.requests)} request classes, "
+                               f"{len(np.unique(snap.task_priority))} priority level(s), cold tick (every class saturated: the placement separates per worker; "
+                               "the same size with three priority levels is `multi_priority` below)",
+                   "parallelism": "single" if world == 1 else f"worker-shards x{world}: FxHash(worker_id) % {world}, ready set replicated, one RCCL all-gather of the record sinks inside libhqtick.so (hqtick_shard_allgather; "
+                                   f"communicator of {getattr(st, 'comm_world', world)} ranks), merged vector D2H on rank 0",
                    "ready_set": "resident in HBM", "seed": args.seed},
         "p50_tick_ms": 1e3 * float(np.median(lat)), "p95_tick_ms": 1e3 * float(np.percentile(lat, 95)),
         "assigned_per_tick": assigned, "prefilled_per_tick": prefilled,
@@ -553,7 +594,8 @@ def main():
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.hetero_steps > 0:
         out["steady_hetero"] = steady_hetero(cfg, snap, args.hetero_steps, args.seed, min(args.cpu_ticks, 1))
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.dag_steps > 0:
-        out["dag_churn"] = dag_churn(cfg, args.dag_steps, args.seed, args.dag_classes)
+        out["dag_churn"] = dag_churn(cfg, args.dag_steps, args.seed, args.dag_classes, "random", min(args.cpu_ticks, 1))
+        out["dag_churn_layered"] = dag_churn(cfg, args.dag_steps, args.seed, args.dag_classes, "layered", min(args.cpu_ticks, 1))
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.priority_ticks > 0:
         # the same size with three user-priority levels (SURVEY §8d's C3 mix, 80/15/5 %): priority cuts couple every worker, the model is one
         # 8 k-column x 22 k-row component and the tick is dominated by the host-side exact solve (reported, not the headline: BASELINE.json's
@@ -572,6 +614,13 @@ def main():
         out["multi_priority"] = {"workload": "c3p: c3 with user priorities {0, 1, 2} at 80/15/5 %", "ticks": args.priority_ticks, "p50_tick_ms": 1e3 * float(np.median(tl)),
                                  "status": info[0], "is_optimal": bool(info[1]), "assigned_per_tick": int(info[2]["n_assigned"]), "prefilled_per_tick": int(info[2]["n_prefilled"]),
                                  "solve_ms": info[3] / 1e3, "tasks_assigned_per_sec": int(info[2]["n_assigned"]) / float(np.median(tl)),
+                                 "model": {"columns": int(info[2]["milp_cols"]), "rows": int(info[2]["milp_rows"]), "note": "rows no point within the column bounds can violate are not emitted (DESIGN.md §4b)"},
+                                 "coupled_solve": {"build_model_ms": info[2]["model_us"] / 1e3, "solve_ms": info[2]["milp_us"] / 1e3, "price_solve_ms": info[2]["price_us"] / 1e3,
+                                                   "sweeps_ms": info[2]["price_sweep_us"] / 1e3, "sweeps": int(info[2]["price_sweeps"]), "flag_configurations": int(info[2]["price_rounds"])},
+                                 "price_sweep_kernel": {"kernel": "k_price_sweep", "blocks_per_sweep": 1024, "avg_sweep_us": (info[2]["price_sweep_us"] / info[2]["price_sweeps"]) if info[2]["price_sweeps"] else None,
+                                                        "block_solves_per_s": (1024 * info[2]["price_sweeps"] / (info[2]["price_sweep_us"] * 1e-6)) if info[2]["price_sweep_us"] > 0 else None,
+                                                        "bound": "latency / integer-f64 ALU in LDS: one wavefront per worker block (exact bounded knapsack under the current prices), ~41 KB of LDS; "
+                                                                 "not an HBM kernel (a block reads 0.5-2 KB), not MFMA work; figure of merit: exact block solves per second (launch -> totals in pinned memory)"},
                                  "is_optimal_means": "certified within HiGHS's default mip_rel_gap = 1e-4, which is all the reference's solve_bounded asks for (solver/highs.rs:65-68)"}
         if args.cpu_ticks > 0:
             try:  # the same snapshot through the reference-configured HiGHS (one tick, 5 s limit as in the reference): what the drop-in replaces on this workload
@@ -581,7 +630,7 @@ def main():
                 mp = op.last_model()
                 xg = np.asarray([gdp.get((int(mp["crq"][j]), int(mp["cvariant"][j]), int(mp["cworker"][j])), 0) if mp["ctype"][j] == 0 else 0 for j in range(len(mp["obj"]))], np.float64)
                 out["multi_priority"]["objective"] = {"gpu_tick": float(np.dot(mp["obj"], xg)), "cpu_baseline": float(mp["objective"])}
-                out["multi_priority"]["cpu_baseline"] = {"tick_s": tcp, "is_optimal": bool(wp.is_optimal), "kind": "port", "cores": 1,
+                out["multi_priority"]["cpu_baseline"] = {"tick_s": tcp, "is_optimal": bool(wp.is_optimal), "kind": "port", "cores": 1, "cpu": cpu_model(),
                                                          "assigned_per_tick": sum(1 for recs in wp.records for (_, _, k) in recs if k == abi.HQ_REC_ASSIGN),
                                                          "sample": "1 tick of the full c3p workload, HiGHS 1.8.0 with the reference's options (time_limit = 5 s only)"}
             except Exception as e:

@@ -23,6 +23,10 @@ TEST_ONLY = ["debug_capi.cpp", "price_emul.cpp"]               # sources of the 
 HEADERS = ["kernels.h", "block_core.h", "price_core.h", "price.h", "price_emul.h", "price_dev.h", "lp_tab.h", "dev_wave.h", "block_solve.h", "graph.h", "devbuf.h", "host_model.h", "milp.h", "hb_order.h", "wire_core.h",
            os.path.join("..", "..", "include", "hqwire.h"), os.path.join("..", "..", "include", "hqtick.h"), os.path.join("..", "..", "include", "hqtick_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
+# The price sweeps choose among tied block optima by floating-point comparisons: no fused multiply-add contraction in the two places that run that
+# arithmetic (the kernel and its CPU emulation), so that a GPU tick and the emulated tick of the CPU suite walk the same sequence of prices.
+# (block_core.h's explicit fma() calls are the same operation on both sides.)
+EXTRA_FLAGS = {"price.hip": ["-ffp-contract=off"], "price_emul.cpp": ["-ffp-contract=off"]}
 
 
 def hipcc() -> str:
@@ -58,7 +62,7 @@ def _compile(src: str, hooks: bool, force: bool, verbose: bool) -> str:
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS if os.path.exists(os.path.join(CSRC, h))]
     if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
         return obj
-    cmd = [hipcc()] + FLAGS + (["-DHQTICK_TEST_HOOKS=1"] if hooks else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-DHQTICK_TEST_HOOKS=1"] if hooks else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -401,7 +401,10 @@ struct Solver {
 Answer solve(const Request &rq, Sweeper &sw) {
     Answer ans;
     Solver S(rq, sw);
+    const double tp0 = now_us();
+    auto tmark = [&](const char *what) { if (rq.trace) fprintf(stderr, "[price] %s at %.3f ms (sweeps so far %.3f ms)\n", what, (now_us() - tp0) / 1e3, sw.stat_sweep_us / 1e3); };
     if (const char *why = build(rq, S.P)) { ans.why = why; return ans; }
+    tmark("model flattened");
     Prob &P = S.P;
     const int K = P.K, G = P.G;
     sw.stat_sweeps = 0; sw.stat_sweep_us = 0;
@@ -451,14 +454,17 @@ Answer solve(const Request &rq, Sweeper &sw) {
         double bound_B = INF;
         const double cutoff = best_value > -INF ? best_value * (1.0 - 1e-12) : -INF;
         if (!S.kelley(hB, cB, cutoff, std::max(1e-6, rq.rel_gap / 50.0), lambda, pi, &bound_B)) return -INF;
+        tmark("master converged");
         final_pi = pi;
         std::vector<uint16_t> xf = S.round_patterns(lambda, pi, hB);
+        tmark("patterns rounded");
         if (xf.empty()) return -INF;
         x.assign(rq.n, 0.0);
         for (uint32_t f = 0; f < P.T.n_cols; f++) x[P.model_of[f]] = (double)xf[f];
         for (int g = 0; g < G; g++) x[P.gmodel[g]] = B[g];
         double value = 0.0;
         if (!rq.polish || !rq.polish(x, value)) return -INF;  // the caller's rows say no
+        tmark("polished");
         if (rq.trace) fprintf(stderr, "[price] configuration %u: %zu sweeps so far, bound with these flags %.9f, point %.9f, model bound %.9f\n", ans.rounds, S.cuts.size(), bound_B, value, S.relaxed_bound);
         if (value > best_value) { best_value = value; ans.x = x; ans.x_value = value; }
         return value;

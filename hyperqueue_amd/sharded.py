@@ -157,6 +157,7 @@ class ShardedTick:
                 d = torch.distributed
                 collective = "library" if (world > 1 and d.is_available() and d.is_initialized() and d.get_world_size(group) == world) else "torch"
             self.collective = collective
+            self.comm_world = world if collective == "library" else 0  # ranks of the library's RCCL communicator (0: the collective is not the library's)
             if collective == "library":
                 lib.hqtick_comm_unique_id.argtypes = [C.c_void_p]
                 lib.hqtick_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]

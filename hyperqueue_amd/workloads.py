@@ -158,6 +158,26 @@ def make_dag(n: int = 1_000_000, seed: int = 0, mean_fan_in: float = 3.0):
     return ids, prio, rq, off, ids[dep]
 
 
+def make_dag_layered(n: int = 1_000_000, width: int = 20_000, seed: int = 0, fan_in: int = 3):
+    """A second DAG shape next to SURVEY.md's: layers of `width` tasks in submission order, every task of layer L depends on
+    `fan_in` distinct tasks drawn uniformly from layer L - 1.  Its frontier is a whole layer (>= 10^4 ready tasks per tick) where make_dag's narrows to
+    ~100 after the sources.  Returns the same tuple as make_dag."""
+    ids, prio, rq = _tasks(n, [c[1] for c in C3_CLASSES], seed)
+    idx = np.arange(n, dtype=np.int64)
+    layer = idx // width
+    has = layer > 0
+    cons = np.repeat(idx[has], fan_in)
+    r = splitmix64_stream(seed ^ 0x1A7E6, len(cons))
+    u = (r >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    lo = (np.repeat(layer[has], fan_in) - 1) * width
+    dep = lo + np.minimum((u * width).astype(np.int64), width - 1)
+    pair = np.unique(cons * n + dep)
+    cons, dep = pair // n, pair % n
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum(np.bincount(cons, minlength=n))
+    return ids, prio, rq, off, ids[dep]
+
+
 class DagChurn:
     """Driver of BASELINE config 5 (DAG + 10 % worker churn per tick), independent of the backend that ticks.
 
