@@ -94,9 +94,12 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random",
     drv = workloads.DagChurn(n_workers=1024, churn=0.10, seed=seed)
     W = 1024
     rows, base_snaps = [], {}
+    t.cluster_upload(drv.snapshot().to_c())  # ONCE: afterwards the worker set changes through membership deltas only (ABI 7) and the snapshots carry no worker arrays
+    total_row = np.asarray(drv.kw["worker_total"], np.uint64).reshape(W, -1)[0]
+    t_delta = []
     for step in range(steps + 2):
         snap_now = drv.snapshot()  # keeps the arrays `sc` points into alive
-        sc = snap_now.to_c()
+        sc = snap_now.to_c(resident_workers=True)
         if cpu_ticks > 0 and step in (0, steps + 1):  # what the CPU baseline is timed on: the first wave, and the loop's last tick
             sel = np.nonzero(in_ready)[0]
             base_snaps[step] = drv.snapshot(ids[sel], prio[sel], rq[sel])
@@ -109,6 +112,10 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random",
         finished, returned = drv.after_tick(rec_off, rec_task)
         idx = (returned & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1
         in_ready[ix(rec_task)] = False; in_ready[idx] = True
+        d0 = time.perf_counter()
+        t.cluster_remove_workers(drv.last_lost_ids)  # on_remove_worker / on_new_worker as deltas: one re-pack kernel each, no re-upload
+        t.cluster_add_workers(drv.last_fresh_ids, np.tile(total_row, (len(drv.last_fresh_ids), 1)))
+        t_delta.append(time.perf_counter() - d0)
         d = time.perf_counter()
         if len(returned):
             t.ready_add(returned, prio[idx], rq[idx])
@@ -156,6 +163,9 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random",
         "note": "the frontier stays below the cluster's capacity, so no batch is saturated and the placement model couples all workers through the batch-size rows: every tick with "
                 "at least ~1000 model columns goes through k_price_sweep (DESIGN.md §4b); smaller ones (a few dozen ready tasks) stay with the host search",
         "cpu_baseline": base,
+        "worker_churn": {"how": "hqtick_cluster_remove_workers + hqtick_cluster_add_workers per tick (ABI 7): the lost rows leave and the fresh ones join the HBM-resident tables through one re-pack "
+                                "kernel each; the snapshots of the loop carry no worker arrays (worker_id == NULL)", "workers_replaced_per_tick": int(drv.n_lost),
+                         "p50_membership_deltas_us": 1e6 * float(np.median(t_delta)) if t_delta else None},
         "p50_price_sweeps_per_tick": int(med("sweeps")), "p50_model_columns": int(med("cols")), "p50_coupled_solve_us": med("milp_us"), "p50_sweeps_us": med("sweep_us"),
         "graph_add_ms": 1e3 * t_add, "graph_add_link_kernels_us": add_kernel_us, "initially_ready": int(len(ready0)),
         "graph_bytes_hbm": int(st["bytes_hbm"]),

@@ -221,7 +221,10 @@ class Snapshot:
     retracting: List[Tuple[int, int, int, int]] = field(default_factory=list)  # (task, old worker idx, redirect worker idx | HQ_NO_WORKER, redirect variant), ascending task id
     _keep: list = field(default_factory=list, repr=False)
 
-    def to_c(self) -> SnapshotC:
+    def to_c(self, resident_workers: bool = False) -> SnapshotC:
+        """resident_workers: leave the worker side out (worker_id == NULL, n_workers = 0, no blocked triples) — the library completes it from the
+        worker set it keeps itself (hqtick_cluster_upload / _add_workers / _remove_workers / _set_blocked / _update_workers, ABI 7); the per-worker
+        CSRs of running and prefilled tasks still travel (they belong to the task side of the reactor's state)."""
         keep = self._keep
         keep.clear()
         W = len(self.worker_id)
@@ -235,21 +238,25 @@ class Snapshot:
             return a
 
         s.n_resources = R
-        s.n_workers = W
-        put("worker_id", self.worker_id, np.uint32, u32p)
-        put("worker_total", np.asarray(self.worker_total, dtype=np.uint64).reshape(W * R), np.uint64, u64p)
-        put("worker_free", np.asarray(self.worker_free, dtype=np.uint64).reshape(W * R), np.uint64, u64p)
-        put("worker_remaining_ns", self.worker_remaining_ns, np.int64, i64p)
-        put("worker_min_utilization", self.worker_min_utilization, np.float32, f32p)
-        put("worker_flags", self.worker_flags, np.uint8, u8p)
-        put("worker_group", self.worker_group, np.uint32, u32p)
-        s.n_groups = self.n_groups
-        if self.worker_map_rank is not None:
-            put("worker_map_rank", self.worker_map_rank, np.uint32, u32p)
-        s.n_blocked = len(self.blocked)
-        put("blocked_worker", [b[0] for b in self.blocked], np.uint32, u32p)
-        put("blocked_rq", [b[1] for b in self.blocked], np.uint32, u32p)
-        put("blocked_variant", [b[2] for b in self.blocked], np.uint8, u8p)
+        if resident_workers:
+            s.n_workers = 0
+            s.n_groups = self.n_groups
+        else:
+            s.n_workers = W
+            put("worker_id", self.worker_id, np.uint32, u32p)
+            put("worker_total", np.asarray(self.worker_total, dtype=np.uint64).reshape(W * R), np.uint64, u64p)
+            put("worker_free", np.asarray(self.worker_free, dtype=np.uint64).reshape(W * R), np.uint64, u64p)
+            put("worker_remaining_ns", self.worker_remaining_ns, np.int64, i64p)
+            put("worker_min_utilization", self.worker_min_utilization, np.float32, f32p)
+            put("worker_flags", self.worker_flags, np.uint8, u8p)
+            put("worker_group", self.worker_group, np.uint32, u32p)
+            s.n_groups = self.n_groups
+            if self.worker_map_rank is not None:
+                put("worker_map_rank", self.worker_map_rank, np.uint32, u32p)
+            s.n_blocked = len(self.blocked)
+            put("blocked_worker", [b[0] for b in self.blocked], np.uint32, u32p)
+            put("blocked_rq", [b[1] for b in self.blocked], np.uint32, u32p)
+            put("blocked_variant", [b[2] for b in self.blocked], np.uint8, u8p)
         off = np.zeros(W + 1, dtype=np.uint32)
         off[1:] = np.cumsum([len(a) for a in self.assigned]) if W else []
         put("assigned_off", off, np.uint32, u32p)

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -97,6 +98,14 @@ struct hqtick_ctx {
     DevBuf d_cluster; PinBuf h_cl, h_cld; bool cluster_valid = false, cluster_check = false, cl_pending = false; uint32_t cl_W = 0, cl_R = 0;
     std::vector<unsigned char> cl_rt;  // host copy of the request-table part as uploaded (compared per tick: a few hundred bytes)
     hipEvent_t cl_ev = nullptr;
+    // host mirror of the resident worker set (ABI 7): what a snapshot with worker_id == NULL is completed from, kept current by the hqtick_cluster_* deltas
+    struct ClusterMirror {
+        bool valid = false; uint32_t n_groups = 1;
+        std::vector<uint32_t> id, group; std::vector<uint64_t> total, free_; std::vector<int64_t> rem; std::vector<float> min_util; std::vector<uint8_t> flags;
+        std::map<uint32_t, std::vector<std::pair<uint32_t, uint8_t>>> blocked;   // worker id -> (rq, variant)
+        std::vector<uint32_t> blk_worker, blk_rq; std::vector<uint8_t> blk_variant; bool blk_dirty = true;  // the same as (worker index, rq, variant) triples
+    } mirror;
+    DevBuf d_cluster2;  // the re-packed tables of a membership change (swapped with d_cluster)
     bool sweep_inflight = false;  // an early K5a launch not yet covered by a stream synchronisation
     bool wait_on_kernel = true;   // HQ_HIP_LAST; HQTICK_WAIT_ON_KERNEL=0: hipStreamSynchronize at every wait (A/B)
     // selection + mapping
@@ -1083,6 +1092,23 @@ struct TickRun {
 };
 
 int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool use_resident) {
+    hqtick_snapshot full;
+    if (s && s->worker_id == nullptr && ctx->cluster_valid && ctx->mirror.valid) {  // the worker side lives in the library (hqtick_cluster_*, ABI 7)
+        hqtick_ctx::ClusterMirror &m = ctx->mirror;
+        const uint32_t W = (uint32_t)m.id.size();
+        if (s->n_workers != 0 && s->n_workers != W) return fail(ctx, HQTICK_E_INVALID, "snapshot without worker arrays: n_workers must be 0 or the resident worker count");
+        if (s->n_resources != ctx->cl_R) return fail(ctx, HQTICK_E_INVALID, "snapshot without worker arrays: n_resources differs from the resident tables");
+        if (m.blk_dirty) {
+            m.blk_worker.clear(); m.blk_rq.clear(); m.blk_variant.clear();
+            for (uint32_t w = 0; w < W; w++) { auto it = m.blocked.find(m.id[w]); if (it == m.blocked.end()) continue; for (auto &p : it->second) { m.blk_worker.push_back(w); m.blk_rq.push_back(p.first); m.blk_variant.push_back(p.second); } }
+            m.blk_dirty = false;
+        }
+        full = *s;
+        full.n_workers = W; full.worker_id = m.id.data(); full.worker_total = m.total.data(); full.worker_free = m.free_.data(); full.worker_remaining_ns = m.rem.data();
+        full.worker_min_utilization = m.min_util.data(); full.worker_flags = m.flags.data(); full.worker_group = m.group.data(); full.n_groups = m.n_groups; full.worker_map_rank = nullptr;
+        full.n_blocked = (uint32_t)m.blk_worker.size(); full.blocked_worker = m.blk_worker.data(); full.blocked_rq = m.blk_rq.data(); full.blocked_variant = m.blk_variant.data();
+        s = &full;
+    }
     TickRun run(ctx, s, out, use_resident);
     return run.run();
 }
@@ -1139,7 +1165,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
                       &ctx->d_up, &ctx->d_vflags, &ctx->d_vtmc, &ctx->d_sel_task, &ctx->d_gkey,
                       &ctx->d_sel_level, &ctx->d_map, &ctx->d_rec, &ctx->d_tsweep, &ctx->d_bits, &ctx->d_pre, &ctx->d_tid2, &ctx->d_tprio2, &ctx->d_trq2, &ctx->d_slice, &ctx->d_add, &ctx->d_pre8, &ctx->d_blk, &ctx->d_cluster};
     for (DevBuf *b : bufs) b->release();
-    ctx->h_cl.release(); ctx->h_cld.release();
+    ctx->h_cl.release(); ctx->h_cld.release(); ctx->d_cluster2.release();
     if (ctx->cl_ev) hipEventDestroy(ctx->cl_ev);
     if (ctx->qctx) { hqtick_destroy(ctx->qctx); ctx->qctx = nullptr; }
     hipSetDevice(ctx->device);
@@ -1406,6 +1432,19 @@ int hqtick_cluster_upload(hqtick_ctx *ctx, const hqtick_snapshot *s) {
     HQ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->cl_rt.assign(h + L.o_amt, h + L.bytes);
     ctx->cl_W = W; ctx->cl_R = R; ctx->cluster_valid = true;
+    {   // the host mirror (ABI 7)
+        hqtick_ctx::ClusterMirror &m = ctx->mirror;
+        m.id.assign(s->worker_id, s->worker_id + W);
+        m.total.assign(s->worker_total, s->worker_total + (size_t)W * R); m.free_.assign(s->worker_free, s->worker_free + (size_t)W * R);
+        m.rem.assign(W, HQ_NO_TIME_LIMIT); if (s->worker_remaining_ns) m.rem.assign(s->worker_remaining_ns, s->worker_remaining_ns + W);
+        m.min_util.assign(W, 0.0f); if (s->worker_min_utilization) m.min_util.assign(s->worker_min_utilization, s->worker_min_utilization + W);
+        m.flags.assign(W, HQ_WORKER_SN); if (s->worker_flags) m.flags.assign(s->worker_flags, s->worker_flags + W);
+        m.group.assign(W, 0); if (s->worker_group) m.group.assign(s->worker_group, s->worker_group + W);
+        m.n_groups = s->n_groups ? s->n_groups : 1;
+        m.blocked.clear();
+        for (uint32_t i = 0; i < s->n_blocked; i++) m.blocked[s->worker_id[s->blocked_worker[i]]].push_back({s->blocked_rq[i], s->blocked_variant[i]});
+        m.blk_dirty = true; m.valid = true;
+    }
     return 0;
 }
 
@@ -1425,6 +1464,10 @@ int hqtick_cluster_update_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *w
     memcpy(h, free_rows, o_rem);
     if (remaining_ns) memcpy(h + o_rem, remaining_ns, (size_t)n * 8);
     memcpy(h + o_idx, worker_index, (size_t)n * 4);
+    if (ctx->mirror.valid) for (uint32_t i = 0; i < n; i++) {  // the host mirror follows
+        memcpy(ctx->mirror.free_.data() + (size_t)worker_index[i] * R, free_rows + (size_t)i * R, (size_t)R * 8);
+        if (remaining_ns) ctx->mirror.rem[worker_index[i]] = remaining_ns[i];
+    }
     unsigned char *base = ctx->d_cluster.as<unsigned char>();
     const size_t WR8 = (size_t)W * R * 8;
     HQ_HIP(hqk::scatter_worker_rows(reinterpret_cast<uint64_t *>(base + WR8), reinterpret_cast<int64_t *>(base + 2 * WR8), R, n, reinterpret_cast<const uint32_t *>(d + o_idx),
@@ -1435,7 +1478,111 @@ int hqtick_cluster_update_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *w
 
 int hqtick_cluster_drop(hqtick_ctx *ctx) {
     if (!ctx) return HQTICK_E_INVALID;
-    ctx->cluster_valid = false;
+    ctx->cluster_valid = false; ctx->mirror.valid = false;
+    return 0;
+}
+
+// Membership change: the rows `src` (old row index, or W_old + k for the k-th staged new worker) become the new table; one re-pack kernel, request tables copied
+// device to device.  The staging of `add_*` rows sits behind the index list in the pinned delta buffer.
+static int cluster_repack(hqtick_ctx *ctx, const std::vector<uint32_t> &src, uint32_t n_add, const uint64_t *add_total, const uint64_t *add_free, const int64_t *add_rem) {
+    const uint32_t W_old = ctx->cl_W, R = ctx->cl_R, W_new = (uint32_t)src.size();
+    HQ_HIP(hipSetDevice(ctx->device));
+    if (ctx->cl_pending) { HQ_HIP(hipEventSynchronize(ctx->cl_ev)); ctx->cl_pending = false; }
+    const size_t rt_bytes = ctx->cl_rt.size();
+    const size_t o_amt_old = ((size_t)2 * W_old * R + W_old) * 8, o_amt_new = ((size_t)2 * W_new * R + W_new) * 8;
+    if (!ctx->d_cluster2.ensure(o_amt_new + rt_bytes + 65536)) return fail(ctx, HQTICK_E_DEVICE, "allocating cluster tables");
+    const size_t o_tot = ((size_t)W_new * 4 + 15) & ~(size_t)15, o_fr = o_tot + (size_t)n_add * R * 8, o_rem = o_fr + (size_t)n_add * R * 8, bytes = o_rem + (size_t)n_add * 8 + 64;
+    if (!ctx->h_cld.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "allocating delta staging");
+    unsigned char *h = ctx->h_cld.as<unsigned char>(), *d = ctx->h_cld.dev<unsigned char>();
+    memcpy(h, src.data(), (size_t)W_new * 4);
+    if (n_add) { memcpy(h + o_tot, add_total, (size_t)n_add * R * 8); memcpy(h + o_fr, add_free, (size_t)n_add * R * 8); memcpy(h + o_rem, add_rem, (size_t)n_add * 8); }
+    unsigned char *ob = ctx->d_cluster.as<unsigned char>(), *nb = ctx->d_cluster2.as<unsigned char>();
+    const size_t WR8o = (size_t)W_old * R * 8, WR8n = (size_t)W_new * R * 8;
+    HQ_HIP(hqk::repack_worker_rows(reinterpret_cast<const uint64_t *>(ob), reinterpret_cast<const uint64_t *>(ob + WR8o), reinterpret_cast<const int64_t *>(ob + 2 * WR8o), W_old, R, W_new,
+                                   reinterpret_cast<const uint32_t *>(d), reinterpret_cast<const uint64_t *>(d + o_tot), reinterpret_cast<const uint64_t *>(d + o_fr), reinterpret_cast<const int64_t *>(d + o_rem),
+                                   reinterpret_cast<uint64_t *>(nb), reinterpret_cast<uint64_t *>(nb + WR8n), reinterpret_cast<int64_t *>(nb + 2 * WR8n), ctx->stream));
+    if (rt_bytes) HQ_HIP(hipMemcpyAsync(nb + o_amt_new, ob + o_amt_old, rt_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HQ_HIP(hipEventRecord(ctx->cl_ev, ctx->stream)); ctx->cl_pending = true;
+    std::swap(ctx->d_cluster, ctx->d_cluster2);
+    ctx->cl_W = W_new;
+    return 0;
+}
+
+int hqtick_cluster_add_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *worker_id, const uint64_t *total_rows, const uint64_t *free_rows, const int64_t *remaining_ns,
+                               const float *min_utilization, const uint8_t *flags, const uint32_t *group) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (!ctx->cluster_valid || !ctx->mirror.valid) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_add_workers without hqtick_cluster_upload");
+    if (n == 0) return 0;
+    if (!worker_id || !total_rows || !free_rows) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_add_workers: null array");
+    hqtick_ctx::ClusterMirror &m = ctx->mirror;
+    const uint32_t W = ctx->cl_W, R = ctx->cl_R;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t prev = i ? worker_id[i - 1] : (W ? m.id[W - 1] : 0u);
+        if ((i || W) && worker_id[i] <= prev) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_add_workers: ids must ascend above every id present");
+        if (group && group[i] >= 65536) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_add_workers: group index");
+    }
+    std::vector<uint32_t> src(W + n);
+    for (uint32_t i = 0; i < W + n; i++) src[i] = i;
+    std::vector<int64_t> rem(n, HQ_NO_TIME_LIMIT);
+    if (remaining_ns) rem.assign(remaining_ns, remaining_ns + n);
+    if (int rc = cluster_repack(ctx, src, n, total_rows, free_rows, rem.data())) return rc;
+    m.id.insert(m.id.end(), worker_id, worker_id + n);
+    m.total.insert(m.total.end(), total_rows, total_rows + (size_t)n * R); m.free_.insert(m.free_.end(), free_rows, free_rows + (size_t)n * R);
+    m.rem.insert(m.rem.end(), rem.begin(), rem.end());
+    for (uint32_t i = 0; i < n; i++) {
+        m.min_util.push_back(min_utilization ? min_utilization[i] : 0.0f); m.flags.push_back(flags ? flags[i] : (uint8_t)HQ_WORKER_SN);
+        m.group.push_back(group ? group[i] : 0u); if (group && group[i] + 1 > m.n_groups) m.n_groups = group[i] + 1;
+    }
+    m.blk_dirty = true;
+    return 0;
+}
+
+int hqtick_cluster_remove_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *worker_id) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (!ctx->cluster_valid || !ctx->mirror.valid) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_remove_workers without hqtick_cluster_upload");
+    if (n == 0) return 0;
+    if (!worker_id) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_remove_workers: null array");
+    hqtick_ctx::ClusterMirror &m = ctx->mirror;
+    const uint32_t W = ctx->cl_W, R = ctx->cl_R;
+    std::vector<uint8_t> gone(W, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        auto it = std::lower_bound(m.id.begin(), m.id.end(), worker_id[i]);
+        if (it == m.id.end() || *it != worker_id[i] || gone[it - m.id.begin()]) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_remove_workers: unknown (or repeated) worker id");
+        gone[it - m.id.begin()] = 1;
+    }
+    std::vector<uint32_t> src; src.reserve(W - n);
+    for (uint32_t w = 0; w < W; w++) if (!gone[w]) src.push_back(w);
+    if (int rc = cluster_repack(ctx, src, 0, nullptr, nullptr, nullptr)) return rc;
+    uint32_t k = 0;
+    for (uint32_t w = 0; w < W; w++) {
+        if (gone[w]) { m.blocked.erase(m.id[w]); continue; }
+        if (k != w) {
+            m.id[k] = m.id[w]; m.rem[k] = m.rem[w]; m.min_util[k] = m.min_util[w]; m.flags[k] = m.flags[w]; m.group[k] = m.group[w];
+            memmove(m.total.data() + (size_t)k * R, m.total.data() + (size_t)w * R, (size_t)R * 8); memmove(m.free_.data() + (size_t)k * R, m.free_.data() + (size_t)w * R, (size_t)R * 8);
+        }
+        k++;
+    }
+    m.id.resize(k); m.rem.resize(k); m.min_util.resize(k); m.flags.resize(k); m.group.resize(k); m.total.resize((size_t)k * R); m.free_.resize((size_t)k * R);
+    m.blk_dirty = true;
+    return 0;
+}
+
+int hqtick_cluster_set_blocked(hqtick_ctx *ctx, uint32_t worker_id, uint32_t n, const uint32_t *rq, const uint8_t *variant) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (!ctx->cluster_valid || !ctx->mirror.valid) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_set_blocked without hqtick_cluster_upload");
+    hqtick_ctx::ClusterMirror &m = ctx->mirror;
+    if (!std::binary_search(m.id.begin(), m.id.end(), worker_id)) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_set_blocked: unknown worker id");
+    if (n && (!rq || !variant)) return fail(ctx, HQTICK_E_INVALID, "hqtick_cluster_set_blocked: null array");
+    if (n == 0) m.blocked.erase(worker_id);
+    else { auto &v = m.blocked[worker_id]; v.clear(); for (uint32_t i = 0; i < n; i++) v.push_back({rq[i], variant[i]}); }
+    m.blk_dirty = true;
+    return 0;
+}
+
+int hqtick_cluster_workers(const hqtick_ctx *ctx, uint32_t *n_workers, const uint32_t **worker_id) {
+    if (!ctx || !ctx->mirror.valid) return HQTICK_E_INVALID;
+    if (n_workers) *n_workers = (uint32_t)ctx->mirror.id.size();
+    if (worker_id) *worker_id = ctx->mirror.id.data();
     return 0;
 }
 

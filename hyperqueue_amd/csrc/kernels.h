@@ -134,6 +134,10 @@ size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys, uint32_t max_out,
 // Resident cluster tables (f1): rows of the worker table that changed, scattered into the HBM copy (inputs may sit in pinned host memory)
 hipError_t scatter_worker_rows(uint64_t *free_, int64_t *rem, uint32_t R, uint32_t n, const uint32_t *idx, const uint64_t *rows, const int64_t *new_rem, hipStream_t s);
 
+// ... and the whole table re-packed when workers join or leave: new row i = old row src[i], or staged new worker src[i] - W_old
+hipError_t repack_worker_rows(const uint64_t *old_total, const uint64_t *old_free, const int64_t *old_rem, uint32_t W_old, uint32_t R, uint32_t W_new, const uint32_t *src,
+                              const uint64_t *add_total, const uint64_t *add_free, const int64_t *add_rem, uint64_t *new_total, uint64_t *new_free, int64_t *new_rem, hipStream_t s);
+
 // Resident ready-set deltas: tombstone the given ids (sorted id column, binary search), count live tasks per
 // 256-task slice, and rebuild the columns dropping tombstones while merging a sorted batch of new tasks.
 hipError_t ready_mark_removed(const uint64_t *ids, uint32_t *rq, uint64_t n, const uint64_t *rm, uint32_t n_rm, uint32_t *n_done, hipStream_t s);

@@ -732,6 +732,25 @@ __global__ void __launch_bounds__(256) k_scatter_worker_rows(uint64_t *__restric
     if (r == 0 && new_rem) rem[w] = new_rem[i];
 }
 
+// Workers joined or left (on_new_worker / on_remove_worker, server/reactor.rs:20-186): the three row blocks are re-packed into a fresh table.
+// Row i of the new table comes from old row src[i] (src[i] < W_old) or from row src[i] - W_old of the staged new workers (pinned memory).
+__global__ void __launch_bounds__(256) k_repack_worker_rows(const uint64_t *__restrict__ old_total, const uint64_t *__restrict__ old_free, const int64_t *__restrict__ old_rem,
+                                                            uint32_t W_old, uint32_t R, uint32_t W_new, const uint32_t *__restrict__ src,
+                                                            const uint64_t *__restrict__ add_total, const uint64_t *__restrict__ add_free, const int64_t *__restrict__ add_rem,
+                                                            uint64_t *__restrict__ new_total, uint64_t *__restrict__ new_free, int64_t *__restrict__ new_rem) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W_new * R) return;
+    const uint32_t i = t / R, r = t % R, sidx = src[i];
+    if (sidx < W_old) {
+        new_total[t] = old_total[(size_t)sidx * R + r]; new_free[t] = old_free[(size_t)sidx * R + r];
+        if (r == 0) new_rem[i] = old_rem[sidx];
+    } else {
+        const uint32_t a = sidx - W_old;
+        new_total[t] = add_total[(size_t)a * R + r]; new_free[t] = add_free[(size_t)a * R + r];
+        if (r == 0) new_rem[i] = add_rem[a];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ resident ready-set deltas (f1)
 // TaskQueues::add_ready_task / take_tasks / remove on the HBM-resident columns (scheduler/taskqueue.rs:37-43,146-217,304-355).
 // Removal is a tombstone in the rq column (RQ_TOMBSTONE); k_rebuild drops tombstones and merges a sorted batch of new tasks.
@@ -1121,6 +1140,13 @@ hipError_t expand_mapping(MapKeys mk, uint32_t W, const uint64_t *sel_task, cons
 hipError_t scatter_worker_rows(uint64_t *free_, int64_t *rem, uint32_t R, uint32_t n, const uint32_t *idx, const uint64_t *rows, const int64_t *new_rem, hipStream_t s) {
     if (n == 0 || R == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scatter_worker_rows, dim3((n * R + 255) / 256), dim3(256), 0, s, free_, rem, R, n, idx, rows, new_rem);
+    return hipGetLastError();
+}
+
+hipError_t repack_worker_rows(const uint64_t *old_total, const uint64_t *old_free, const int64_t *old_rem, uint32_t W_old, uint32_t R, uint32_t W_new, const uint32_t *src,
+                              const uint64_t *add_total, const uint64_t *add_free, const int64_t *add_rem, uint64_t *new_total, uint64_t *new_free, int64_t *new_rem, hipStream_t s) {
+    if (W_new == 0 || R == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_repack_worker_rows, dim3((W_new * R + 255) / 256), dim3(256), 0, s, old_total, old_free, old_rem, W_old, R, W_new, src, add_total, add_free, add_rem, new_total, new_free, new_rem);
     return hipGetLastError();
 }
 

@@ -82,8 +82,9 @@ class Tick:
             raise HqTickError(rc, self._err())
         return rc_
 
-    def tick(self, snap: abi.Snapshot, resident: bool = False) -> abi.Result:
-        sc = snap.to_c()
+    def tick(self, snap: abi.Snapshot, resident: bool = False, resident_workers: bool = False) -> abi.Result:
+        """resident_workers: the snapshot travels without its worker side; the library completes it from its own worker set (hqtick_cluster_*, ABI 7)"""
+        sc = snap.to_c(resident_workers=resident_workers)
         return abi.parse_result(self.tick_raw(sc, resident), len(snap.worker_id), snap.n_resources)
 
     def batches(self, snap: abi.Snapshot):
@@ -152,6 +153,34 @@ class Tick:
         self._lib.hqtick_cluster_update_workers.argtypes = [C.c_void_p, C.c_uint32, abi.u32p, abi.u64p, C.POINTER(C.c_int64)]
         self._chk(self._lib.hqtick_cluster_update_workers(self._ctx, len(idx), idx.ctypes.data_as(abi.u32p), rows.ctypes.data_as(abi.u64p),
                                                           None if rem is None else rem.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def cluster_add_workers(self, worker_id, total_rows, free_rows=None, remaining_ns=None, min_utilization=None, flags=None, group=None):
+        """on_new_worker (ABI 7): ids ascending above every id present; they take the row indices W .. W + n - 1"""
+        ids = np.ascontiguousarray(worker_id, np.uint32)
+        tot = np.ascontiguousarray(total_rows, np.uint64).reshape(-1)
+        fre = tot if free_rows is None else np.ascontiguousarray(free_rows, np.uint64).reshape(-1)
+        opt = lambda a, dt, ct: (None, None) if a is None else (lambda v: (v, v.ctypes.data_as(C.POINTER(ct))))(np.ascontiguousarray(a, dt))
+        rem, prem = opt(remaining_ns, np.int64, C.c_int64); mu, pmu = opt(min_utilization, np.float32, C.c_float); fl, pfl = opt(flags, np.uint8, C.c_uint8); gr, pgr = opt(group, np.uint32, C.c_uint32)
+        self._lib.hqtick_cluster_add_workers.argtypes = [C.c_void_p, C.c_uint32, abi.u32p, abi.u64p, abi.u64p, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)]
+        self._chk(self._lib.hqtick_cluster_add_workers(self._ctx, len(ids), ids.ctypes.data_as(abi.u32p), tot.ctypes.data_as(abi.u64p), fre.ctypes.data_as(abi.u64p), prem, pmu, pfl, pgr))
+
+    def cluster_remove_workers(self, worker_id):
+        """on_remove_worker (ABI 7): by id; later rows move up"""
+        ids = np.ascontiguousarray(worker_id, np.uint32)
+        self._lib.hqtick_cluster_remove_workers.argtypes = [C.c_void_p, C.c_uint32, abi.u32p]
+        self._chk(self._lib.hqtick_cluster_remove_workers(self._ctx, len(ids), ids.ctypes.data_as(abi.u32p)))
+
+    def cluster_set_blocked(self, worker_id: int, pairs):
+        """Worker::blocked_requests of one worker := pairs of (rq, variant) (ABI 7)"""
+        rq = np.ascontiguousarray([p[0] for p in pairs], np.uint32); v = np.ascontiguousarray([p[1] for p in pairs], np.uint8)
+        self._lib.hqtick_cluster_set_blocked.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, abi.u32p, abi.u8p]
+        self._chk(self._lib.hqtick_cluster_set_blocked(self._ctx, int(worker_id), len(pairs), rq.ctypes.data_as(abi.u32p) if len(pairs) else None, v.ctypes.data_as(abi.u8p) if len(pairs) else None))
+
+    def cluster_workers(self) -> np.ndarray:
+        n = C.c_uint32(); p = abi.u32p()
+        self._lib.hqtick_cluster_workers.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(abi.u32p)]
+        self._chk(self._lib.hqtick_cluster_workers(self._ctx, C.byref(n), C.byref(p)))
+        return abi._np(p, n.value, np.uint32).copy() if n.value else np.zeros(0, np.uint32)
 
     def cluster_drop(self):
         self._lib.hqtick_cluster_drop.argtypes = [C.c_void_p]

@@ -217,6 +217,7 @@ class DagChurn:
         keep = np.ones(W, bool); keep[lost] = False
         fresh = np.arange(self.next_worker, self.next_worker + len(lost), dtype=np.uint32)
         self.next_worker += len(lost)
+        self.last_lost_ids, self.last_fresh_ids = self.worker_id[lost].copy(), fresh  # what a delta-driven host forwards (hqtick_cluster_remove_workers / _add_workers)
         self.worker_id = np.concatenate([self.worker_id[keep], fresh])
         return finished, returned
 

@@ -354,6 +354,29 @@ uint64_t hqtick_ready_count(const hqtick_ctx *ctx);
 int hqtick_cluster_upload(hqtick_ctx *ctx, const hqtick_snapshot *snapshot);
 int hqtick_cluster_update_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *worker_index, const uint64_t *free_rows, const int64_t *remaining_ns);
 int hqtick_cluster_drop(hqtick_ctx *ctx);
+/*
+ * Cluster MEMBERSHIP and blocked requests as deltas (ABI 7): the worker set itself lives in the library between ticks — rows in HBM for the scans, a
+ * mirror in host memory for the host stages — and the reactor forwards what its handlers do:
+ *   hqtick_cluster_add_workers     on_new_worker  server/reactor.rs:20-32 (Core::new_worker): n workers with ids ascending and above every id present
+ *                                  (WorkerIds are minted ascending), their total / free rows [n * R], and (NULL = the defaults of a fresh single-node
+ *                                  worker) remaining lifetime, min_utilization, HQ_WORKER_* flags, group.  They take the row indices W .. W + n - 1.
+ *   hqtick_cluster_remove_workers  on_remove_worker  server/reactor.rs:64-186: the rows of these ids leave; later rows move up (the row index of a
+ *                                  worker is its position in ascending id order, as in a snapshot).  Unknown ids are an error (HQTICK_E_INVALID).
+ *   hqtick_cluster_set_blocked     Worker::blocked_requests  server/worker.rs:70 of ONE worker, replaced by the n given (rq, variant) pairs:
+ *                                  task_reject adds a pair (reactor.rs:365-445), EnableRequest removes it (request_enabled, reactor.rs:447-460),
+ *                                  n = 0 clears.
+ *   hqtick_cluster_workers         the current ids in row order (valid until the next membership call).
+ * One re-pack kernel per membership call (rows read from HBM, new rows from pinned staging); nothing is re-uploaded.
+ * A tick whose snapshot has worker_id == NULL takes the WHOLE worker side from the library: ids, total / free rows (as kept current by
+ * hqtick_cluster_update_workers), remaining lifetime, min_utilization, flags, groups and the blocked pairs; n_workers must be 0 or the current count,
+ * worker_map_rank is emulated, and the per-worker CSRs assigned_off / prefilled_off (if given) must have current-count + 1 entries.  The reactor then
+ * no longer flattens W x R worker arrays per tick.
+ */
+int hqtick_cluster_add_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *worker_id, const uint64_t *total_rows, const uint64_t *free_rows,
+                               const int64_t *remaining_ns, const float *min_utilization, const uint8_t *flags, const uint32_t *group);
+int hqtick_cluster_remove_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *worker_id);
+int hqtick_cluster_set_blocked(hqtick_ctx *ctx, uint32_t worker_id, uint32_t n, const uint32_t *rq, const uint8_t *variant);
+int hqtick_cluster_workers(const hqtick_ctx *ctx, uint32_t *n_workers, const uint32_t **worker_id);
 
 /*
  * Device-resident dependency graph (BASELINE config 5): the `Waiting{unfinished_deps}` counters and the consumer

@@ -101,3 +101,84 @@ def test_new_request_classes_reach_the_resident_tables():
     _same(res.tick(two), plain.tick(two))
     _same(res.tick(small), plain.tick(small))  # and back
     plain.close(); res.close()
+
+
+def _subset(snap, keep_idx, extra=None):
+    """the snapshot with only the workers `keep_idx` (row indices), optionally followed by new workers extra = (ids, total rows, free rows)"""
+    W, R = len(snap.worker_id), snap.n_resources
+    tot = np.array(snap.worker_total, np.uint64).reshape(W, R); fre = np.array(snap.worker_free, np.uint64).reshape(W, R)
+    k = np.asarray(keep_idx, np.int64)
+    remap = {int(w): i for i, w in enumerate(k)}
+    ids, t, f = snap.worker_id[k], tot[k], fre[k]
+    rem, mu, fl, gr = snap.worker_remaining_ns[k], snap.worker_min_utilization[k], snap.worker_flags[k], snap.worker_group[k]
+    asg, pre = [snap.assigned[i] for i in k], [snap.prefilled[i] for i in k]
+    if extra is not None:
+        eids, et, ef = extra
+        n = len(eids)
+        ids = np.concatenate([ids, np.asarray(eids, np.uint32)]); t = np.concatenate([t, et]); f = np.concatenate([f, ef])
+        rem = np.concatenate([rem, np.full(n, abi.HQ_NO_TIME_LIMIT, np.int64)]); mu = np.concatenate([mu, np.zeros(n, np.float32)])
+        fl = np.concatenate([fl, np.full(n, abi.HQ_WORKER_SN, np.uint8)]); gr = np.concatenate([gr, np.zeros(n, np.uint32)])
+        asg = asg + [[] for _ in range(n)]; pre = pre + [[] for _ in range(n)]
+    blocked = [(remap[b[0]], b[1], b[2]) for b in snap.blocked if b[0] in remap]
+    return dataclasses.replace(snap, _keep=[], worker_id=ids, worker_total=t.reshape(-1), worker_free=f.reshape(-1), worker_remaining_ns=rem, worker_min_utilization=mu,
+                               worker_flags=fl, worker_group=gr, assigned=asg, prefilled=pre, blocked=blocked)
+
+
+def test_workers_join_leave_and_reject_without_a_re_upload(oracle_free=None):
+    """ABI 7 (row f1: on_new_worker / on_remove_worker / task_reject as deltas): after ONE hqtick_cluster_upload the worker set changes only through
+    hqtick_cluster_remove_workers / _add_workers / _set_blocked / _update_workers, and the ticks' snapshots carry no worker arrays at all — every
+    tick equals the plain tick (and the oracle) on the full snapshot of the same state."""
+    from oracle.oracle import Oracle
+
+    plain, res = _tick(), _tick(HQTICK_CHECK_CLUSTER=1)
+    o = Oracle(abi.make_config(time_limit_s=20.0), canonical=True)
+    snap = workloads.make_steady("c3", seed=5, n_tasks=40_000, n_workers=32)
+    W, R = len(snap.worker_id), snap.n_resources
+    res.cluster_upload(snap)
+    _same(res.tick(snap, resident_workers=True), plain.tick(snap))
+    # three workers are lost (on_remove_worker): rows leave, later rows move up
+    lost = [3, 10, 31]
+    keep = [w for w in range(W) if w not in lost]
+    res.cluster_remove_workers(snap.worker_id[lost])
+    s1 = _subset(snap, keep)
+    assert res.cluster_workers().tolist() == s1.worker_id.tolist()
+    got = res.tick(s1, resident_workers=True)
+    _same(got, plain.tick(s1))
+    want = o.tick(s1)
+    assert got.counts == want.counts and got.records == want.records
+    # two fresh workers join (on_new_worker): larger ids, idle
+    top = int(snap.worker_id.max())
+    tot_row = np.array(snap.worker_total, np.uint64).reshape(W, R)[0]
+    extra = ([top + 1, top + 5], np.stack([tot_row, tot_row]), np.stack([tot_row, tot_row // np.uint64(2)]))
+    res.cluster_add_workers(extra[0], extra[1], extra[2])
+    s2 = _subset(snap, keep, extra)
+    _same(res.tick(s2, resident_workers=True), plain.tick(s2))
+    # a worker rejects (rq 0, variant 0) and (rq 3, variant 0) (task_reject -> blocked_requests); another one rejected and was re-enabled
+    wid = int(s2.worker_id[4])
+    res.cluster_set_blocked(wid, [(0, 0), (3, 0)])
+    res.cluster_set_blocked(int(s2.worker_id[7]), [(1, 0)])
+    res.cluster_set_blocked(int(s2.worker_id[7]), [])
+    s3 = dataclasses.replace(s2, _keep=[], blocked=[(4, 0, 0), (4, 3, 0)])
+    got = res.tick(s3, resident_workers=True)
+    _same(got, plain.tick(s3))
+    want = o.tick(s3)
+    assert got.counts == want.counts and got.records == want.records
+    # rows change (tasks start / finish) by index of the CURRENT set, then the blocked worker leaves: its pairs go with it
+    W3 = len(s3.worker_id)
+    free = np.array(s3.worker_free, np.uint64).reshape(W3, R).copy()
+    free[[1, 4, W3 - 1]] = np.array(s3.worker_total, np.uint64).reshape(W3, R)[[1, 4, W3 - 1]]
+    res.cluster_update_workers([1, 4, W3 - 1], free[[1, 4, W3 - 1]])
+    s4 = _with_free(s3, free.reshape(-1))
+    _same(res.tick(s4, resident_workers=True), plain.tick(s4))
+    res.cluster_remove_workers([wid])
+    s5 = _subset(s4, [w for w in range(W3) if w != 4])
+    assert s5.blocked == []
+    _same(res.tick(s5, resident_workers=True), plain.tick(s5))
+    # errors: unknown id, ids that do not ascend above the set
+    from hyperqueue_amd.tick import HqTickError
+
+    with pytest.raises(HqTickError):
+        res.cluster_remove_workers([wid])
+    with pytest.raises(HqTickError):
+        res.cluster_add_workers([1], tot_row.reshape(1, -1))
+    plain.close(); res.close()
