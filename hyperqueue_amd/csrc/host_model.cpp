@@ -887,9 +887,11 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                         if (gap > 0) {
                             // (a row no point within the columns' own bounds can violate is not emitted: with cuts in the thousands and workers that hold
                             // a hundred tasks that is every one of the W x cuts x blockers rows of a large tick — the model's points are the same)
-                            if (cols.empty() || cols_ub <= (uint64_t)cut.size + gap) continue;
-                            int fl;
-                            if (bounded && (fl = short_flag(brq, bl.second)) >= 0) emit_plus(hqmilp::ROW_MAX, (double)cut.size + bsize + (double)gap, cols, fl, bsize);
+                            // The flag column itself is created as the reference creates it (get_bvar, :233-253: even for a worker without a placement
+                            // column) — the model's COLUMNS, and with them the canonical tie-break, stay exactly the reference's.
+                            int fl = bounded ? short_flag(brq, bl.second) : -1;
+                            if (cols_ub <= (uint64_t)cut.size + gap) continue;
+                            if (bounded && fl >= 0) emit_plus(hqmilp::ROW_MAX, (double)cut.size + bsize + (double)gap, cols, fl, bsize);
                             else if (!bounded) { m.begin_row(hqmilp::ROW_MAX, (double)cut.size + (double)gap); for (int c : cols) m.term(c, 1.0); m.end_row(); }
                         } else {
                             no_gap.insert(no_gap.end(), cols.begin(), cols.end());

@@ -1793,6 +1793,7 @@ int hqtick_set_record_sink(hqtick_ctx *ctx, void *device_ptr, size_t capacity_by
     return 0;
 }
 
+#ifdef HQTICK_TEST_HOOKS  // measurement hooks of the tools (include/hqtick_debug.h): libhqtick_test.so only
 int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us) {
     if (!ctx || !avg_us || iters <= 0) return HQTICK_E_INVALID;
     if (!ctx->last_valid || !ctx->resident) return fail(ctx, HQTICK_E_INVALID, "hqtick_time_kernel needs a preceding hqtick_run_resident tick that placed tasks");
@@ -1856,6 +1857,7 @@ const uint64_t *hqtick_block_profile_last(const hqtick_ctx *ctx, uint32_t *n_cla
     if (n_classes) *n_classes = ctx->n_blkprof;
     return ctx->h_blkprof.as<uint64_t>();
 }
+#endif
 
 int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on) {
     if (!ctx) return HQTICK_E_INVALID;

@@ -12,7 +12,9 @@ import numpy as np
 from . import abi
 
 _LIB = None
+_MLIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhqtick.so")
+MEASURE_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhqtick_test.so")
 
 
 class HqTickError(RuntimeError):
@@ -21,39 +23,48 @@ class HqTickError(RuntimeError):
         self.code = code
 
 
-def load():
-    global _LIB
+def load(measure: bool = False):
+    """the product library; measure=True: libhqtick_test.so — the same objects plus the measurement hooks of include/hqtick_debug.h (hqtick_time_kernel,
+    hqtick_timeline, hqtick_block_profile_last) that the tools under tools/ use.  bench.py, the tests and smoke() run the product library."""
+    global _LIB, _MLIB
+    if measure:
+        if _MLIB is None:
+            _MLIB = _bind(C.CDLL(MEASURE_LIB_PATH))
+        return _MLIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
-        lib = C.CDLL(LIB_PATH)
-        P = C.POINTER
-        lib.hqtick_create.argtypes = [P(abi.Config), P(C.c_void_p)]
-        lib.hqtick_destroy.argtypes = [C.c_void_p]
-        lib.hqtick_run.argtypes = [C.c_void_p, P(abi.SnapshotC), P(abi.ResultC)]
-        lib.hqtick_upload_ready.argtypes = [C.c_void_p, C.c_uint64, abi.u64p, abi.u64p, abi.u32p, C.c_int]
-        lib.hqtick_run_resident.argtypes = [C.c_void_p, P(abi.SnapshotC), P(abi.ResultC)]
-        lib.hqtick_query.argtypes = [C.c_void_p, P(abi.SnapshotC), P(abi.QueryWorkersC), P(abi.QueryResultC)]
-        lib.hqtick_last_error.restype = C.c_char_p
-        lib.hqtick_last_error.argtypes = [C.c_void_p]
-        lib.hqtick_abi_version.restype = C.c_uint32
-        lib.hqtick_build_arch.restype = C.c_char_p
-        lib.hqtick_kernel_stats_last.argtypes = [C.c_void_p, P(abi.KernelStatsC)]
-        _LIB = lib
+        _LIB = _bind(C.CDLL(LIB_PATH))
     return _LIB
+
+
+def _bind(lib):
+    P = C.POINTER
+    lib.hqtick_create.argtypes = [P(abi.Config), P(C.c_void_p)]
+    lib.hqtick_destroy.argtypes = [C.c_void_p]
+    lib.hqtick_run.argtypes = [C.c_void_p, P(abi.SnapshotC), P(abi.ResultC)]
+    lib.hqtick_upload_ready.argtypes = [C.c_void_p, C.c_uint64, abi.u64p, abi.u64p, abi.u32p, C.c_int]
+    lib.hqtick_run_resident.argtypes = [C.c_void_p, P(abi.SnapshotC), P(abi.ResultC)]
+    lib.hqtick_query.argtypes = [C.c_void_p, P(abi.SnapshotC), P(abi.QueryWorkersC), P(abi.QueryResultC)]
+    lib.hqtick_last_error.restype = C.c_char_p
+    lib.hqtick_last_error.argtypes = [C.c_void_p]
+    lib.hqtick_abi_version.restype = C.c_uint32
+    lib.hqtick_build_arch.restype = C.c_char_p
+    lib.hqtick_kernel_stats_last.argtypes = [C.c_void_p, P(abi.KernelStatsC)]
+    return lib
 
 
 class Tick:
     """One hqtick_ctx (one HIP device, one stream).  `tick(snapshot)` == run_scheduling_inner through the C ABI."""
 
-    def __init__(self, config: Optional[abi.Config] = None):
+    def __init__(self, config: Optional[abi.Config] = None, measure: bool = False):
         self.cfg = config or abi.make_config()
         extra = int(os.environ.get("HQTICK_TEST_FLAGS", "0") or 0)  # campaigns (tools/fuzz_more.py): the same scenarios through another emission form
         if extra:
             c = abi.Config.from_buffer_copy(self.cfg)
             c.flags |= extra
             self.cfg = c
-        self._lib = load()
+        self._lib = load(measure)
         ctx = C.c_void_p()
         rc = self._lib.hqtick_create(C.byref(self.cfg), C.byref(ctx))
         if rc != 0:
@@ -253,7 +264,7 @@ class Tick:
         return abi._np(out.is_loaded, n, np.uint8).astype(bool), bool(out.is_optimal)
 
     def time_kernel(self, which: int, iters: int = 100) -> float:
-        """hqtick_time_kernel: average duration (us) of `iters` back-to-back launches of K1 (0) / K4 (1) on the last resident tick."""
+        """hqtick_time_kernel (measurement library only: Tick(..., measure=True)): average duration (us) of `iters` back-to-back launches of K1 (0) / K4 (1)."""
         us = C.c_double()
         self._lib.hqtick_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         rc = self._lib.hqtick_time_kernel(self._ctx, which, iters, C.byref(us))

@@ -510,17 +510,6 @@ int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
  * bracketed by start / stop events AT THE DISPATCH (hipExtLaunchKernel): the duration is the kernel's own, the figure rocprofv3's kernel trace
  * reports, without the latency of markers queued around it. */
 int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on);
-/* Re-launches one streaming kernel of the last resident tick `iters` times back to back between two HIP events on the ctx's
- * stream and returns the average launch duration (which: 0 = K1 level_hist, 1 = K4 select_scatter).  which = 2: an EMPTY kernel of K1's grid, every launch
- * bracketed by its own dispatch events as in hqtick_set_kernel_timing — what that measure records for a kernel that does nothing.  GPU only. */
-int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us);
-/* Host wall-clock marks (microseconds since the start of the last tick) at the internal stage boundaries of the last tick;
- * returns the number of marks written (bench tooling). */
-int hqtick_timeline(const hqtick_ctx *ctx, double *out, int cap);
-/* With HQTICK_BLOCK_PROFILE=1 in the environment at hqtick_create: 8 u64 per class of the last k_block_solve launch — 100 MHz timestamps
- * at start / block built / duals / greedy / phase 1 / phase 2 done, then phase-1 steps and dual-pool size.  NULL when off. */
-const uint64_t *hqtick_block_profile_last(const hqtick_ctx *ctx, uint32_t *n_classes);
-
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,19 @@ void hqtick_debug_set_block_emulation(int on, uint32_t budget);
 /* classes the last hqtick_debug_host_stages call solved through the emulation / with the host solver */
 void hqtick_debug_last_blocks(uint32_t *n_emulated, uint32_t *n_host);
 
+/* Measurement hooks of the tools under tools/ (round 3: moved here from the product's header; libhqtick_test.so is the same objects + these).  GPU only. */
+/* Re-launches one streaming kernel of the last resident tick `iters` times back to back between two HIP events on the ctx's
+ * stream and returns the average launch duration (which: 0 = K1 level_hist, 1 = K4 select_scatter).  which = 2: an EMPTY kernel of K1's grid, every launch
+ * bracketed by its own dispatch events as in hqtick_set_kernel_timing — what that measure records for a kernel that does nothing.  GPU only. */
+int hqtick_time_kernel(hqtick_ctx *ctx, int which, int iters, double *avg_us);
+/* Host wall-clock marks (microseconds since the start of the last tick) at the internal stage boundaries of the last tick;
+ * returns the number of marks written (bench tooling). */
+int hqtick_timeline(const hqtick_ctx *ctx, double *out, int cap);
+/* With HQTICK_BLOCK_PROFILE=1 in the environment at hqtick_create: 8 u64 per class of the last k_block_solve launch — 100 MHz timestamps
+ * at start / block built / duals / greedy / phase 1 / phase 2 done, then phase-1 steps and dual-pool size.  NULL when off. */
+const uint64_t *hqtick_block_profile_last(const hqtick_ctx *ctx, uint32_t *n_classes);
+
+
 /* The coupled placement by price sweeps (csrc/price.cpp; k_price_sweep's algorithm in csrc/price_core.h) with the wavefront emulated on the CPU.
  * on != 0: hqtick_debug_host_stages (this thread) hands coupled models of at least min_cols columns (0: the default) to the sweeps — the code path
  * of a GPU tick, minus the hardware. */

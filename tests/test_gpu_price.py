@@ -59,7 +59,8 @@ def test_device_sweeps_walk_the_emulations_path(name, monkeypatch):
     snap = CASES[name]()
     got, ks = _tick(snap, min_cols=64, monkeypatch=monkeypatch)
     want, sweeps, rounds = stages(snap, True, min_cols=64)
-    assert ks["price_sweeps"] > 0
+    if not name.startswith("steady"):  # (a saturated cluster mid-run can be certified by its first sweep — or separate per worker and never reach the sweeps)
+        assert ks["price_sweeps"] > 0
     assert (ks["price_sweeps"], ks["price_rounds"]) == (sweeps, rounds)
     assert got.status == want.status and got.is_optimal == want.is_optimal
     assert got.batches == want.batches and got.counts == want.counts

@@ -230,3 +230,45 @@ def test_e2e_extra_host_stages_shadow(case):
     b = _ShadowBackend()
     case(b)
     assert all(b.flags) and b.ticks >= 1
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_host_stages_prefill_disposal_family(seed):
+    """the scenario family of tests/test_gpu_fuzz.py::test_fuzz_prefill_disposal (priority arrivals dissolving prefill sets, Retracting tasks in the
+    queues, retract responses) through the host stages: the coupled models of these ticks have tied optima, so the counts pin the model's COLUMNS
+    (the flags the reference creates even for workers without a placement column, solver.rs:233-253) — a round-3 regression the GPU run caught"""
+    from hyperqueue_amd.core import SchedEnv, WorkerBuilder as WB
+    from oracle.oracle import Oracle
+
+    rng = np.random.default_rng(9000 + seed)
+    cfg = abi.make_config(reserve=int(rng.integers(0, 2)), fill_max=int(rng.integers(1, 4)), time_limit_s=20.0)
+    e = SchedEnv(cfg)
+    o, hs = Oracle(cfg, canonical=True), HostStages(cfg)
+    shapes = [TB().cpus(1), TB().cpus(2)]
+    for c in [int(x) for x in np.random.default_rng(seed).integers(1, 5, size=3)]:
+        e.new_worker(WB(c))
+    prio = 0
+    for round_ in range(5):
+        n_new = int(rng.integers(1, 7)) if round_ else int(rng.integers(8, 16)); which = [int(rng.integers(0, 2)) for _ in range(n_new)]
+        if round_ and rng.random() < 0.7:
+            prio += 1
+        for c in which:
+            e.new_task(shapes[c].user_priority(prio))
+        snap = e.snapshot()
+        try:
+            want = o.tick(snap)
+        except RuntimeError:  # a Retracting task reached the prefill step: the reference asserts there
+            return
+        got = hs.stages(snap)
+        if not (want.is_optimal and got.is_optimal):
+            pytest.skip("a solver hit its limit")
+        _same_host_part(got, want, o.last_model())
+        e.apply(want)
+        k = int(rng.integers(1, 7)); answer = rng.random() < 0.6
+        done = 0
+        for t in sorted(e.tasks.values(), key=lambda t: t.id):
+            if t.state == 1 and done < k:
+                e.finish_task(t.id, t.worker); done += 1
+        if answer:
+            for t in [t for t in sorted(e.tasks.values(), key=lambda t: t.id) if t.state == 4 and t.id not in e.retaken_variant][:2]:
+                e.retract_response(t.worker, [t.id])

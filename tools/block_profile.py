@@ -9,7 +9,7 @@ from hyperqueue_amd import abi, workloads
 from hyperqueue_amd.tick import Tick
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 snap = workloads.make_steady(name, seed=0)
-t = Tick(abi.make_config(time_limit_s=5.0))
+t = Tick(abi.make_config(time_limit_s=5.0), measure=True)
 t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
 sc = snap.to_c()
 for _ in range(3):

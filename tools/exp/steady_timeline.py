@@ -4,7 +4,7 @@ sys.path.insert(0, os.getcwd())
 from hyperqueue_amd import abi, workloads
 from hyperqueue_amd.tick import Tick
 snap = workloads.make("c3"); sc = snap.to_c(); W = len(snap.worker_id)
-t = Tick(abi.make_config(time_limit_s=5.0, flags=6))
+t = Tick(abi.make_config(time_limit_s=5.0, flags=6), measure=True)
 t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq); t.cluster_upload(sc); t.set_kernel_timing(False)
 t._lib.hqtick_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
 rq_of = snap.task_rq.copy(); res = t.tick_raw(sc, resident=True); gone = abi.record_task_ids(res, W); t.ready_consume_last()

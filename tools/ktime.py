@@ -11,7 +11,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 n_tasks = int(sys.argv[3]) if len(sys.argv) > 3 else None
 snap = workloads.make(name, n_tasks=n_tasks)
-t = Tick(abi.make_config(time_limit_s=5.0))
+t = Tick(abi.make_config(time_limit_s=5.0), measure=True)
 t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
 sc = snap.to_c()
 for _ in range(3):

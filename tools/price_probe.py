@@ -66,7 +66,7 @@ def main():
         snap = snapshot(which)
         for mode in (["price"] if "--no-host" in sys.argv else ["price", "host"]):
             os.environ["HQTICK_PRICE"] = "1" if mode == "price" else "0"
-            t = Tick(abi.make_config(time_limit_s=5.0, flags=abi.HQTICK_FLAG_COMPACT_RECORDS | abi.HQTICK_FLAG_COMPACT_DELTA16))  # as bench.py runs it
+            t = Tick(abi.make_config(time_limit_s=5.0, flags=abi.HQTICK_FLAG_COMPACT_RECORDS | abi.HQTICK_FLAG_COMPACT_DELTA16), measure=True)  # as bench.py runs it
             if "--timeline" in sys.argv and mode == "price":
                 timeline(t, snap, which)
             best = None

@@ -21,7 +21,7 @@ print("distinct free vectors:", len(np.unique(np.asarray(snap.worker_free), axis
 for label, env in (("device blocks", {}), ("host blocks", {"HQTICK_BLOCK_MIN_CLASSES": str(1 << 30)})):
     os.environ.pop("HQTICK_BLOCK_MIN_CLASSES", None)
     os.environ.update(env)
-    t = Tick(abi.make_config(time_limit_s=5.0))
+    t = Tick(abi.make_config(time_limit_s=5.0), measure=True)
     t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
     t._lib.hqtick_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     rows, ks = [], []
