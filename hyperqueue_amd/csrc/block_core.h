@@ -754,6 +754,7 @@ struct HostWave {
     uint32_t atomic_inc(uint32_t *p) { return (*p)++; }
     void atomic_or64(uint64_t *p, uint64_t v) { *p |= v; }
     void atomic_add_i64(long long *p, long long v) { *p += v; }
+    void lds_add_i64(long long *p, long long v) { *p += v; }
     static int ctz(uint64_t m) { int i = 0; while (!((m >> i) & 1)) i++; return i; }
     template <class F> void each(F f) { for (int l = 0; l < WAVE; l++) f(l); }
     template <class F> uint64_t ballot(F f) { uint64_t m = 0; for (int l = 0; l < WAVE; l++) if (f(l)) m |= 1ull << l; return m; }

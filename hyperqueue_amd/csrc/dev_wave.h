@@ -14,6 +14,7 @@ struct DevWave {
     __device__ uint32_t atomic_inc(uint32_t *p) { return atomicAdd(p, 1u); }
     __device__ void atomic_or64(uint64_t *p, uint64_t v) { atomicOr((unsigned long long *)p, (unsigned long long)v); }
     __device__ void atomic_add_i64(long long *p, long long v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }  // two's complement: the sum of signed terms
+    __device__ void lds_add_i64(long long *p, long long v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }  // (an LDS address: ds_add_u64)
     __device__ static int ctz(uint64_t m) { return __ffsll((long long)m) - 1; }
     template <class F> __device__ void each(F f) { f((int)threadIdx.x); }
     template <class F> __device__ uint64_t ballot(F f) { return __ballot(f((int)threadIdx.x) ? 1 : 0); }

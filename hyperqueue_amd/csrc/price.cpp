@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <numeric>
 
 #include "lp_tab.h"
@@ -38,6 +39,11 @@ struct Prob {
     std::vector<uint8_t> ge;                   // the row was a `>=` row (entered negated)
     std::vector<std::vector<std::pair<int, double>>> g_rows;   // per global column: (wide row, coefficient in <= form)
     std::vector<int> r_off, r_col; std::vector<int32_t> r_coef;  // wide rows row-wise over the flat columns
+    std::vector<uint32_t> c_off; std::vector<uint16_t> c_row; std::vector<int32_t> c_coef;  // ... and column-wise (host side: rounding and repair work per ROW)
+    // Wide rows with the same left-hand side over the block columns (the cut rows of one batch against its several blockers differ in their flag only) share
+    // ONE activity: the device prices and accumulates per GROUP (T.K groups, price of a group = sum of its rows' prices), the host expands to rows.
+    std::vector<int> grp_of;   // [K] row -> group
+    int KG = 0;
     std::vector<CapRow> caps;
     std::vector<int32_t> base_cap;
     std::vector<int> block_of_flat;
@@ -171,11 +177,11 @@ const char *build(const Request &rq, Prob &P) {
             if (rv != 0.0) w.cols.push_back({P.flat_of[j], (int32_t)rv});
         }
         wide.push_back(std::move(w));
-        if ((int)wide.size() > KMAX_HOST) return "more than 128 wide rows";
+        if ((int)wide.size() > 1024) return "more than 1024 wide rows";
     }
     for (int b = 0; b < nb; b++) if (T.blk_m[b] == 0) return "block without a resource row";
     // every column of a block must be bounded by its block: a cap below 65536 is there (checked above); amounts that do not fit even once leave ub 0
-    P.K = (int)wide.size(); T.K = (uint32_t)P.K;
+    P.K = (int)wide.size();
     if (P.K == 0) return "no wide row";
     P.h.resize(P.K); P.ge.resize(P.K); P.g_rows.assign(P.G, {});
     std::vector<uint32_t> cnt(T.n_cols + 1, 0);
@@ -186,12 +192,33 @@ const char *build(const Request &rq, Prob &P) {
         P.r_off.push_back((int)P.r_col.size());
         for (auto &t : wide[k].g) P.g_rows[t.first].push_back({k, t.second});
     }
-    T.col_woff.assign(T.n_cols + 1, 0);
-    for (uint32_t f = 0; f < T.n_cols; f++) T.col_woff[f + 1] = T.col_woff[f] + cnt[f + 1];
-    T.w_row.resize(T.col_woff[T.n_cols]); T.w_coef.resize(T.col_woff[T.n_cols]);
+    // row-level column CSR (host)
+    P.c_off.assign(T.n_cols + 1, 0);
+    for (uint32_t f = 0; f < T.n_cols; f++) P.c_off[f + 1] = P.c_off[f] + cnt[f + 1];
+    P.c_row.resize(P.c_off[T.n_cols]); P.c_coef.resize(P.c_off[T.n_cols]);
     {
+        std::vector<uint32_t> cur(P.c_off.begin(), P.c_off.end() - 1);
+        for (int k = 0; k < P.K; k++) for (auto &t : wide[k].cols) { const uint32_t p = cur[t.first]++; P.c_row[p] = (uint16_t)k; P.c_coef[p] = t.second; }
+    }
+    // groups of rows with identical left-hand sides, and the device's column CSR over groups
+    P.grp_of.assign(P.K, -1);
+    {
+        std::map<std::vector<std::pair<int, int32_t>>, int> seen;
+        std::vector<int> rep;
+        for (int k = 0; k < P.K; k++) {
+            auto it = seen.find(wide[k].cols);
+            if (it == seen.end()) { it = seen.emplace(wide[k].cols, (int)rep.size()).first; rep.push_back(k); }
+            P.grp_of[k] = it->second;
+        }
+        P.KG = (int)rep.size(); T.K = (uint32_t)P.KG;
+        if (P.KG > KMAX_HOST) return "more than 128 distinct wide left-hand sides";
+        std::vector<uint32_t> gcnt(T.n_cols + 1, 0);
+        for (int g = 0; g < P.KG; g++) for (auto &t : wide[rep[g]].cols) gcnt[t.first + 1]++;
+        T.col_woff.assign(T.n_cols + 1, 0);
+        for (uint32_t f = 0; f < T.n_cols; f++) T.col_woff[f + 1] = T.col_woff[f] + gcnt[f + 1];
+        T.w_row.resize(T.col_woff[T.n_cols]); T.w_coef.resize(T.col_woff[T.n_cols]);
         std::vector<uint32_t> cur(T.col_woff.begin(), T.col_woff.end() - 1);
-        for (int k = 0; k < P.K; k++) for (auto &t : wide[k].cols) { const uint32_t p = cur[t.first]++; T.w_row[p] = (uint16_t)k; T.w_coef[p] = t.second; }
+        for (int g = 0; g < P.KG; g++) for (auto &t : wide[rep[g]].cols) { const uint32_t p = cur[t.first]++; T.w_row[p] = (uint16_t)g; T.w_coef[p] = t.second; }
     }
     P.base_cap = T.col_cap;
     return nullptr;
@@ -215,10 +242,14 @@ struct Solver {
     int evaluate(const std::vector<double> &pi) {
         if ((int)cuts.size() >= MAX_SWEEPS) return -1;
         SweepTotals tot;
+        std::vector<double> pig(P.KG, 0.0);
+        for (int k = 0; k < P.K; k++) pig[P.grp_of[k]] += pi[k];
         const double t0 = now_us();
-        if (!sw.sweep(pi.data(), tot)) { failed = true; return -1; }
+        if (!sw.sweep(pig.data(), tot)) { failed = true; return -1; }
         sw.stat_sweep_us += now_us() - t0; sw.stat_sweeps++;
-        Cut c; c.cx = tot.cx; c.bnd = tot.bnd; c.act = tot.act; c.pi = pi;
+        Cut c; c.cx = tot.cx; c.bnd = tot.bnd; c.pi = pi;
+        c.act.resize(P.K);
+        for (int k = 0; k < P.K; k++) c.act[k] = tot.act[P.grp_of[k]];
         cuts.push_back(std::move(c));
         // the model's bound at these prices, flags relaxed: pi.h + sum_w V_w(pi) + sum_g max(0, c_g - pi.A_g)
         double L = cuts.back().bnd;
@@ -316,7 +347,7 @@ struct Solver {
         }
         auto block_act = [&](uint32_t b, const uint16_t *x, std::vector<double> &out) {  // A_w x of block b for the pattern row x (flat layout)
             std::fill(out.begin(), out.end(), 0.0);
-            for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { const uint16_t xv = x[f]; if (!xv) continue; for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) out[T.w_row[e]] += (double)T.w_coef[e] * (double)xv; }
+            for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { const uint16_t xv = x[f]; if (!xv) continue; for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) out[P.c_row[e]] += (double)P.c_coef[e] * (double)xv; }
         };
         std::vector<uint16_t> x(T.n_cols, 0);
         std::vector<double> cum(K, 0.0), tgt(K, 0.0);
@@ -383,10 +414,10 @@ struct Solver {
                 const int f = P.r_col[k];
                 while (x[f] > 0 && cum[r] > hB[r] + 1e-9) {
                     bool ok = true;
-                    for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1] && ok; e++) if (T.w_coef[e] < 0 && cum[T.w_row[e]] - (double)T.w_coef[e] > hB[T.w_row[e]] + 1e-9) ok = false;
+                    for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1] && ok; e++) if (P.c_coef[e] < 0 && cum[P.c_row[e]] - (double)P.c_coef[e] > hB[P.c_row[e]] + 1e-9) ok = false;
                     if (!ok) break;
                     x[f]--;
-                    for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) cum[T.w_row[e]] -= (double)T.w_coef[e];
+                    for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) cum[P.c_row[e]] -= (double)P.c_coef[e];
                 }
                 if (cum[r] <= hB[r] + 1e-9) break;
             }
@@ -591,7 +622,7 @@ Answer solve(const Request &rq, Sweeper &sw) {
             const int j = P.model_of[f];
             ans.block_of[j] = P.block_of_flat[f];
             double r = P.T.col_cost[f];
-            for (uint32_t e = P.T.col_woff[f]; e < P.T.col_woff[f + 1]; e++) r -= final_pi[P.T.w_row[e]] * (double)P.T.w_coef[e];
+            for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) r -= final_pi[P.c_row[e]] * (double)P.c_coef[e];
             ans.rcost[j] = r;
         }
     }

@@ -16,8 +16,12 @@
 //   * the patterns stay in HBM (a ring of sweeps) and cross PCIe once, when the master has converged and the primal side needs them.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "dev_wave.h"
 #include "price_core.h"
@@ -65,7 +69,11 @@ __global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
     uint32_t *redu = reinterpret_cast<uint32_t *>(red + 3 * WAVE);
     red[threadIdx.x] = cx; red[WAVE + threadIdx.x] = rc; red[2 * WAVE + threadIdx.x] = bnd; redu[threadIdx.x] = nbud; redu[WAVE + threadIdx.x] = mx;
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < a.t.K; k += WAVE) { a.res->act[k] = a.out.act[k]; a.out.act[k] = 0; }  // (and ready for the next sweep)
+    for (uint32_t k = threadIdx.x; k < a.t.K; k += WAVE) {  // the ASLOTS partial vectors -> the sweep's activities (and the slots ready for the next sweep)
+        long long sum = 0;
+        for (int sl = 0; sl < ASLOTS; sl++) { sum += a.out.act[(size_t)sl * a.t.K + k]; a.out.act[(size_t)sl * a.t.K + k] = 0; }
+        a.res->act[k] = sum;
+    }
     if (threadIdx.x == 0) {
         double tcx = 0.0, trc = 0.0, tb = 0.0; uint32_t tn = 0, tm = 0;
         for (int l = 0; l < WAVE; l++) { tcx += red[l]; trc += red[WAVE + l]; tb += red[2 * WAVE + l]; tn += redu[l]; tm = redu[WAVE + l] > tm ? redu[WAVE + l] : tm; }
@@ -86,20 +94,21 @@ DeviceSweeper::~DeviceSweeper() { h_stage.release(); h_res.release(); h_pats.rel
 
 bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     if (t.K > (uint32_t)KMAX || t.n_blocks == 0) return false;
+    if (profile && !h_prof.ensure((size_t)t.n_blocks * 64 + 64)) return false;
     T = &t; n_sweeps = 0; cap_sweeps = max_sweeps;
     const size_t nw = t.w_row.size();
     o_off = 0; o_m = al16(o_off + (size_t)(t.n_blocks + 1) * 4); o_cap = al16(o_m + t.n_blocks); o_cost = al16(o_cap + (size_t)t.n_blocks * MMAX * 8);
     o_a = al16(o_cost + (size_t)t.n_cols * 8); o_ccap = al16(o_a + (size_t)t.n_cols * MMAX * 8); o_woff = al16(o_ccap + (size_t)t.n_cols * 4);
     o_wrow = al16(o_woff + (size_t)(t.n_cols + 1) * 4); o_wcoef = al16(o_wrow + nw * 2); tab_bytes = al16(o_wcoef + nw * 4);
     if (!h_stage.ensure(tab_bytes) || !d_tab.ensure(tab_bytes) || !h_res.ensure(sizeof(SweepResult) + 64)) return false;
-    if (!d_pats.ensure((size_t)max_sweeps * t.n_cols * 2) || !d_blk.ensure((size_t)t.n_blocks * 28 + 64) || !d_sync.ensure(64 + (size_t)KMAX * 8)) return false;
+    if (!d_pats.ensure((size_t)max_sweeps * t.n_cols * 2) || !d_blk.ensure((size_t)t.n_blocks * 28 + 64) || !d_sync.ensure(64 + (size_t)ASLOTS * KMAX * 8)) return false;
     unsigned char *h = h_stage.as<unsigned char>();
     memcpy(h + o_off, t.blk_off.data(), (size_t)(t.n_blocks + 1) * 4); memcpy(h + o_m, t.blk_m.data(), t.n_blocks); memcpy(h + o_cap, t.blk_cap.data(), (size_t)t.n_blocks * MMAX * 8);
     memcpy(h + o_cost, t.col_cost.data(), (size_t)t.n_cols * 8); memcpy(h + o_a, t.col_a.data(), (size_t)t.n_cols * MMAX * 8); memcpy(h + o_ccap, t.col_cap.data(), (size_t)t.n_cols * 4);
     memcpy(h + o_woff, t.col_woff.data(), (size_t)(t.n_cols + 1) * 4);
     if (nw) { memcpy(h + o_wrow, t.w_row.data(), nw * 2); memcpy(h + o_wcoef, t.w_coef.data(), nw * 4); }
     if (hipMemcpyAsync(d_tab.p, h, tab_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return false;
-    if (hipMemsetAsync(d_sync.p, 0, 64 + (size_t)KMAX * 8, stream) != hipSuccess) return false;  // ticket + the wide rows' accumulators
+    if (hipMemsetAsync(d_sync.p, 0, 64 + (size_t)ASLOTS * KMAX * 8, stream) != hipSuccess) return false;  // ticket + the wide rows' accumulators
     SweepResult *r = h_res.as<SweepResult>();
     seq = r->seq;  // (whatever the last solve left: the next sweep writes seq + 1)
     return true;
@@ -120,7 +129,7 @@ bool DeviceSweeper::sweep(const double *pi, SweepTotals &out) {
                  (const int32_t *)(d + o_ccap), (const uint32_t *)(d + o_woff), (const uint16_t *)(d + o_wrow), (const int32_t *)(d + o_wcoef)};
     unsigned char *blk = d_blk.as<unsigned char>();
     a.out = SweepOut{d_pats.as<uint16_t>() + (size_t)n_sweeps * t.n_cols, (double *)blk, (double *)(blk + (size_t)t.n_blocks * 8), (double *)(blk + (size_t)t.n_blocks * 16),
-                     (long long *)(d_sync.as<unsigned char>() + 64), (uint32_t *)(blk + (size_t)t.n_blocks * 24)};
+                     (long long *)(d_sync.as<unsigned char>() + 64), (uint32_t *)(blk + (size_t)t.n_blocks * 24), profile ? h_prof.dev<uint64_t>() : nullptr};
     a.budget = budget; a.seq = ++seq; a.ticket = d_sync.as<uint32_t>(); a.res = h_res.dev<SweepResult>();
     memset(a.pi, 0, sizeof(a.pi));
     memcpy(a.pi, pi, (size_t)t.K * 8);
@@ -138,6 +147,12 @@ bool DeviceSweeper::sweep(const double *pi, SweepTotals &out) {
         }
     }
     last_kernel_us = now_us() - t0;
+    if (profile) {  // HQTICK_PRICE_PROFILE=1: per-stage medians over the blocks of this sweep (100 MHz wavefront clock), accumulated for end()
+        const uint64_t *pr = h_prof.as<uint64_t>();
+        for (int st = 0; st < 6; st++) { std::vector<double> v; v.reserve(t.n_blocks); for (uint32_t b = 0; b < t.n_blocks; b++) if (pr[(size_t)b * 8 + st + 1] >= pr[(size_t)b * 8 + st] && pr[(size_t)b * 8 + st + 1]) v.push_back((double)(pr[(size_t)b * 8 + st + 1] - pr[(size_t)b * 8 + st]) / 100.0); if (v.empty()) continue; std::sort(v.begin(), v.end()); prof_med[st] += v[v.size() / 2]; prof_max[st] += v.back(); }
+        double smax = 0; for (uint32_t b = 0; b < t.n_blocks; b++) smax = std::max(smax, (double)pr[(size_t)b * 8 + 7]);
+        prof_steps += smax; prof_n++;
+    }
     total_sweeps++; total_block_solves += t.n_blocks; total_us += last_kernel_us;
     out.cx = r->cx; out.rc = r->rc; out.bnd = r->bnd; out.n_budget = r->n_budget; out.max_steps = r->max_steps;
     out.act.resize(t.K);
@@ -155,6 +170,15 @@ const uint16_t *DeviceSweeper::patterns(uint32_t n) {
     return h_pats.as<uint16_t>();
 }
 
-void DeviceSweeper::end() { T = nullptr; }
+void DeviceSweeper::end() {
+    if (profile && prof_n) {
+        static const char *names[6] = {"reduced costs + compaction", "dual pool + order", "greedy fills", "level lists + root bound", "walk", "results + activities"};
+        fprintf(stderr, "[price profile] %d sweeps, per block and sweep (us; median over blocks / slowest block, averaged over the sweeps):", prof_n);
+        for (int st = 0; st < 6; st++) fprintf(stderr, "  %s %.1f / %.1f;", names[st], prof_med[st] / prof_n, prof_max[st] / prof_n);
+        fprintf(stderr, "  most search steps of a block %.0f; sweep as the host saw it %.1f us\n", prof_steps / prof_n, total_us / (double)std::max<uint64_t>(1, total_sweeps));
+        for (int st = 0; st < 6; st++) prof_med[st] = prof_max[st] = 0; prof_steps = 0; prof_n = 0;
+    }
+    T = nullptr;
+}
 
 }  // namespace hqprice

@@ -22,7 +22,8 @@ using hqblock::NMAX;
 using hqblock::Shared;
 using hqblock::WAVE;
 
-constexpr int KMAX = 128;  // wide rows of one model (prices staged in LDS)
+constexpr int KMAX = 128;  // distinct wide left-hand sides of one model (prices staged in LDS)
+constexpr int ASLOTS = 16; // the wide rows' activities are accumulated in ASLOTS partial vectors (block b adds into slot b % ASLOTS): 1024 blocks on one address serialise in L2
 
 // The model's blocks, flattened (device-visible memory).  Column q of block b is entry blk_off[b] + q of the col_* arrays.
 struct Tables {
@@ -44,8 +45,9 @@ struct SweepOut {
     double *blk_cx;       // [n_blocks] c . x of the block's pattern (original costs)
     double *blk_rc;       // [n_blocks] (c - pi A) . x
     double *blk_bnd;      // [n_blocks] >= V_w(pi): equal to blk_rc (plus rounding slack) unless the block's search ran out of budget, then its LP bound
-    long long *act;       // [K] sum over blocks of A_w x — integer coefficients, so the atomic sums are exact and order-free
+    long long *act;       // [ASLOTS * K] partial sums over blocks of A_w x — integer coefficients, so the atomic sums are exact and order-free
     uint32_t *blk_steps;  // [n_blocks] search steps (0 = closed at the root); bit 31: budget exhausted
+    uint64_t *prof;       // optional [n_blocks * 8]: wavefront clock at the stage boundaries (tools/price_probe.py --profile); nullptr = off
 };
 
 // columns of a priced block whose reduced cost is at most this fraction of the block's largest original cost stay at zero (their possible
@@ -56,6 +58,8 @@ template <class W>
 HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *pi, uint32_t b, const SweepOut &out, uint32_t budget) {
     const uint32_t c0 = t.blk_off[b], nb = t.blk_off[b + 1] - c0;
     const int m = (int)t.blk_m[b];
+    uint64_t *prof = out.prof ? out.prof + (size_t)b * 8 : nullptr;
+    if (prof && wv.first()) { prof[0] = wv.now(); for (int i = 1; i < 8; i++) prof[i] = 0; }
     // stage the prices: the dual pool is empty at this point, its storage is the staging area
     double *spi = &S.py[0][0];
     static_assert(hqblock::PCAP * MMAX >= KMAX, "the prices are staged in the dual pool's storage");
@@ -76,7 +80,6 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
             for (uint32_t e = t.col_woff[j]; e < t.col_woff[j + 1]; e++) rc -= spi[t.w_row[e]] * (double)t.w_coef[e];
         }
         S.lane_val[lane] = rc;
-        S.gx[0][lane] = 0;  // (reused below as the eligibility flags' scratch: cleared)
     });
     wv.sync();
     int lmax = -1;
@@ -112,6 +115,7 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
         if (wv.first()) { out.blk_cx[b] = 0.0; out.blk_rc[b] = 0.0; out.blk_bnd[b] = dropped; out.blk_steps[b] = 0; }
         return;
     }
+    if (prof && wv.first()) prof[1] = wv.now();  // reduced costs, columns compacted
     // search order (ascending size) and greedy order (descending value density), by rank counting — as build_block does for a class block
     wv.each([&](int lane) {
         if (lane >= n) return;
@@ -162,8 +166,10 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
         });
         wv.sync();
     }
+    if (prof && wv.first()) prof[2] = wv.now();  // dual pool built and ordered
     wv.each([&](int lane) { hqblock::greedy_lane(S, lane); });
     wv.sync();
+    if (prof && wv.first()) prof[3] = wv.now();  // greedy fills
     {
         int l = 0;
         const double top = wv.argmax([&](int lane) { return S.lane_val[lane]; }, &l);
@@ -175,6 +181,7 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
     double capv[MMAX];
     for (int r = 0; r < MMAX; r++) capv[r] = S.cap[r];
     const double root = hqblock::lp_bound(S, n, capv);
+    if (prof && wv.first()) prof[4] = wv.now();  // level lists, root bound
     bool ok = true;
     uint32_t left = budget;
     if (!(root <= S.best + 1e-12 * S.best)) {
@@ -183,7 +190,13 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
         ok = hqblock::walk(wv, S, hqblock::MODE_MAX, 0.0, &left, nullptr);
     }
     wv.sync();
-    // results: the pattern, its value at the original and at the reduced costs, the block's contribution to the wide rows
+    if (prof && wv.first()) prof[5] = wv.now();  // walk
+    // results: the pattern, its value at the original and at the reduced costs, the block's contribution to the wide rows — summed per block in LDS first
+    // (the level stack's storage: the walk is over), then ONE global atomic per row the block touches
+    long long *lact = reinterpret_cast<long long *>(&S.rem[0][0]);
+    static_assert(sizeof(S.rem) >= sizeof(long long) * KMAX, "the block's activities are summed in the level stack's storage");
+    wv.each([&](int lane) { for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) lact[k] = 0; });
+    wv.sync();
     wv.each([&](int lane) {
         if ((uint32_t)lane >= nb) return;
         uint32_t xv = 0;
@@ -191,7 +204,12 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
         x[lane] = (uint16_t)xv;
         if (!xv) return;
         const uint32_t j = c0 + (uint32_t)lane;
-        for (uint32_t e = t.col_woff[j]; e < t.col_woff[j + 1]; e++) wv.atomic_add_i64(&out.act[t.w_row[e]], (long long)t.w_coef[e] * (long long)xv);
+        for (uint32_t e = t.col_woff[j]; e < t.col_woff[j + 1]; e++) wv.lds_add_i64(&lact[t.w_row[e]], (long long)t.w_coef[e] * (long long)xv);
+    });
+    wv.sync();
+    wv.each([&](int lane) {
+        long long *slot = out.act + (size_t)(b % (uint32_t)ASLOTS) * t.K;
+        for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) if (lact[k] != 0) wv.atomic_add_i64(&slot[k], lact[k]);
     });
     if (wv.first()) {
         double cx = 0.0, rc = 0.0;  // fixed order: the same sums on every replica
@@ -201,6 +219,7 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
         // the walk closes a node whose bound is within 1e-12 (relative) of the incumbent: the optimum is not above best * (1 + 1e-12)
         out.blk_bnd[b] = (ok ? rc * (1.0 + 2e-12) : (root > rc ? root : rc)) + dropped;
         out.blk_steps[b] = S.steps | (ok ? 0u : 0x80000000u);
+        if (prof) { prof[6] = wv.now(); prof[7] = S.steps; }
     }
 }
 

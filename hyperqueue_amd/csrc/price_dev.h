@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "devbuf.h"
 #include "price.h"
 
@@ -9,7 +11,8 @@ namespace hqprice {
 
 struct DeviceSweeper : Sweeper {
     hipStream_t stream = nullptr;
-    hqbuf::PinBuf h_stage, h_res, h_pats;
+    hqbuf::PinBuf h_stage, h_res, h_pats, h_prof;
+    bool profile = getenv("HQTICK_PRICE_PROFILE") != nullptr; double prof_med[6] = {0}, prof_max[6] = {0}, prof_steps = 0; int prof_n = 0;
     hqbuf::DevBuf d_tab, d_pats, d_blk, d_sync;
     const HostTables *T = nullptr;
     size_t o_off = 0, o_m = 0, o_cap = 0, o_cost = 0, o_a = 0, o_ccap = 0, o_woff = 0, o_wrow = 0, o_wcoef = 0, tab_bytes = 0;

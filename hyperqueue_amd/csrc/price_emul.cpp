@@ -23,9 +23,11 @@ bool EmulatedSweeper::sweep(const double *pi, SweepTotals &out) {
     const HostTables &t = *T;
     Tables tv{t.n_blocks, t.n_cols, t.K, t.blk_off.data(), t.blk_m.data(), t.blk_cap.data(), t.col_cost.data(), t.col_a.data(), caps.data(), t.col_woff.data(), t.w_row.data(), t.w_coef.data()};
     pats.resize((size_t)(n_sweeps + 1) * t.n_cols);
-    out.act.assign(t.K, 0);
-    SweepOut so{pats.data() + (size_t)n_sweeps * t.n_cols, blk_cx.data(), blk_rc.data(), blk_bnd.data(), out.act.data(), blk_steps.data()};
+    std::vector<long long> slots((size_t)ASLOTS * t.K, 0);
+    SweepOut so{pats.data() + (size_t)n_sweeps * t.n_cols, blk_cx.data(), blk_rc.data(), blk_bnd.data(), slots.data(), blk_steps.data(), nullptr};
     for (uint32_t b = 0; b < t.n_blocks; b++) solve_priced_block(wv, *S, tv, pi, b, so, budget);
+    out.act.assign(t.K, 0);
+    for (int sl = 0; sl < ASLOTS; sl++) for (uint32_t k = 0; k < t.K; k++) out.act[k] += slots[(size_t)sl * t.K + k];
     // the device's order: lane l of the last workgroup adds blocks l, l + 64, ...; lane 0 then adds the 64 partial sums in lane order — the same
     // floating-point sums here, so that a GPU tick and the emulation walk the same sequence of prices
     double pcx[WAVE] = {0}, prc[WAVE] = {0}, pb[WAVE] = {0};
