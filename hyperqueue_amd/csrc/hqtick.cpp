@@ -106,6 +106,10 @@ struct hqtick_ctx {
         std::vector<uint32_t> blk_worker, blk_rq; std::vector<uint8_t> blk_variant; bool blk_dirty = true;  // the same as (worker index, rq, variant) triples
     } mirror;
     DevBuf d_cluster2;  // the re-packed tables of a membership change (swapped with d_cluster)
+    // resident table of Retracting tasks (ABI 7): task -> (worker id it is retracting from, still in its queue?, redirect target id / variant)
+    struct RetrEntry { uint32_t old_id; bool in_queue; bool has_redirect; uint32_t target_id; uint8_t variant; };
+    std::map<uint64_t, RetrEntry> retr;
+    std::vector<uint64_t> retr_task, resp_task; std::vector<uint32_t> retr_worker, retr_red_worker, resp_worker; std::vector<uint8_t> retr_red_variant, resp_variant;
     bool sweep_inflight = false;  // an early K5a launch not yet covered by a stream synchronisation
     bool wait_on_kernel = true;   // HQ_HIP_LAST; HQTICK_WAIT_ON_KERNEL=0: hipStreamSynchronize at every wait (A/B)
     // selection + mapping
@@ -1093,6 +1097,7 @@ struct TickRun {
 
 int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool use_resident) {
     hqtick_snapshot full;
+    bool copied = false;
     if (s && s->worker_id == nullptr && ctx->cluster_valid && ctx->mirror.valid) {  // the worker side lives in the library (hqtick_cluster_*, ABI 7)
         hqtick_ctx::ClusterMirror &m = ctx->mirror;
         const uint32_t W = (uint32_t)m.id.size();
@@ -1103,14 +1108,50 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
             for (uint32_t w = 0; w < W; w++) { auto it = m.blocked.find(m.id[w]); if (it == m.blocked.end()) continue; for (auto &p : it->second) { m.blk_worker.push_back(w); m.blk_rq.push_back(p.first); m.blk_variant.push_back(p.second); } }
             m.blk_dirty = false;
         }
-        full = *s;
+        full = *s; copied = true;
         full.n_workers = W; full.worker_id = m.id.data(); full.worker_total = m.total.data(); full.worker_free = m.free_.data(); full.worker_remaining_ns = m.rem.data();
         full.worker_min_utilization = m.min_util.data(); full.worker_flags = m.flags.data(); full.worker_group = m.group.data(); full.n_groups = m.n_groups; full.worker_map_rank = nullptr;
         full.n_blocked = (uint32_t)m.blk_worker.size(); full.blocked_worker = m.blk_worker.data(); full.blocked_rq = m.blk_rq.data(); full.blocked_variant = m.blk_variant.data();
         s = &full;
     }
-    TickRun run(ctx, s, out, use_resident);
-    return run.run();
+    const bool retr_resident = s && s->n_retracting == HQ_RETRACTING_RESIDENT;
+    if (retr_resident) {  // the Retracting tasks of the queues come from the library's table (hqtick_retracting_*, ABI 7)
+        if (!s->worker_id) return fail(ctx, HQTICK_E_INVALID, "resident retracting table without worker ids (hqtick_cluster_upload, or worker arrays in the snapshot)");
+        const uint32_t W = s->n_workers;
+        auto index_of = [&](uint32_t id) -> uint32_t { const uint32_t *b = s->worker_id, *e = b + W, *it = std::lower_bound(b, e, id); return (it != e && *it == id) ? (uint32_t)(it - b) : HQ_NO_WORKER; };
+        ctx->retr_task.clear(); ctx->retr_worker.clear(); ctx->retr_red_worker.clear(); ctx->retr_red_variant.clear();
+        for (auto &kv : ctx->retr) {  // (std::map: ascending task id, as the snapshot wants it)
+            if (!kv.second.in_queue) continue;
+            const uint32_t oi = index_of(kv.second.old_id);
+            if (oi == HQ_NO_WORKER) return fail(ctx, HQTICK_E_INVALID, "a Retracting task's worker is not in the worker set");
+            ctx->retr_task.push_back(kv.first); ctx->retr_worker.push_back(oi);
+            ctx->retr_red_worker.push_back(kv.second.has_redirect ? index_of(kv.second.target_id) : HQ_NO_WORKER); ctx->retr_red_variant.push_back(kv.second.variant);
+        }
+        if (!copied) { full = *s; copied = true; s = &full; }
+        full.n_retracting = (uint32_t)ctx->retr_task.size();
+        full.retracting_task = ctx->retr_task.data(); full.retracting_worker = ctx->retr_worker.data();
+        full.retracting_redirect_worker = ctx->retr_red_worker.data(); full.retracting_redirect_variant = ctx->retr_red_variant.data();
+    }
+    int rc;
+    {
+        TickRun run(ctx, s, out, use_resident);
+        rc = run.run();
+    }
+    if (rc >= 0 && retr_resident) {  // what create_task_mapping did to task states and redirects (mapping.rs:66-101), applied to the table
+        const uint32_t W = s->n_workers;
+        for (uint32_t w = 0; w < W && w + 1 < ctx->retract_off.size(); w++)   // Prefilled{old} -> Retracting{old}: out of a prefill set, not in a queue
+            for (uint32_t i = ctx->retract_off[w]; i < ctx->retract_off[w + 1]; i++) ctx->retr[ctx->retract_task[i]] = hqtick_ctx::RetrEntry{s->worker_id[w], false, false, 0, 0};
+        for (size_t i = 0; i < ctx->red_task.size(); i++) {
+            auto it = ctx->retr.find(ctx->red_task[i]);
+            if (it == ctx->retr.end()) continue;
+            hqtick_ctx::RetrEntry &e = it->second;
+            const uint8_t kind = i < ctx->red_kind.size() ? ctx->red_kind[i] : (uint8_t)HQ_REDIRECT_FROM_PREFILL;
+            e.in_queue = false;  // take_tasks removed it from its queue (or it came out of a prefill set)
+            if (kind == HQ_REDIRECT_SAME_WORKER) { e.has_redirect = false; continue; }  // back on the worker it is retracting from: no redirect entry (mapping.rs:69)
+            if (ctx->red_worker[i] < W) { e.has_redirect = true; e.target_id = s->worker_id[ctx->red_worker[i]]; e.variant = ctx->red_variant[i]; }
+        }
+    }
+    return rc;
 }
 
 }  // namespace
@@ -1562,6 +1603,8 @@ int hqtick_cluster_remove_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *w
         }
         k++;
     }
+    for (uint32_t i = 0; i < n; i++)  // Retracting tasks of a lost worker leave the table; a lost redirect target only clears the redirect
+        for (auto it = ctx->retr.begin(); it != ctx->retr.end();) { if (it->second.old_id == worker_id[i]) it = ctx->retr.erase(it); else { if (it->second.has_redirect && it->second.target_id == worker_id[i]) it->second.has_redirect = false; ++it; } }
     m.id.resize(k); m.rem.resize(k); m.min_util.resize(k); m.flags.resize(k); m.group.resize(k); m.total.resize((size_t)k * R); m.free_.resize((size_t)k * R);
     m.blk_dirty = true;
     return 0;
@@ -1585,6 +1628,34 @@ int hqtick_cluster_workers(const hqtick_ctx *ctx, uint32_t *n_workers, const uin
     if (worker_id) *worker_id = ctx->mirror.id.data();
     return 0;
 }
+
+int hqtick_retracting_add(hqtick_ctx *ctx, uint32_t n, const uint64_t *task_id, const uint32_t *worker_id) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (n && (!task_id || !worker_id)) return fail(ctx, HQTICK_E_INVALID, "hqtick_retracting_add: null array");
+    for (uint32_t i = 0; i < n; i++) ctx->retr[task_id[i]] = hqtick_ctx::RetrEntry{worker_id[i], true, false, 0, 0};
+    return 0;
+}
+
+int hqtick_retract_response(hqtick_ctx *ctx, uint32_t worker_id, uint32_t n, const uint64_t *task_id, uint32_t *n_assigned, const uint64_t **assigned_task,
+                            const uint32_t **assigned_worker_id, const uint8_t **assigned_variant) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (n && !task_id) return fail(ctx, HQTICK_E_INVALID, "hqtick_retract_response: null array");
+    ctx->resp_task.clear(); ctx->resp_worker.clear(); ctx->resp_variant.clear();
+    int left = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        auto it = ctx->retr.find(task_id[i]);
+        if (it == ctx->retr.end() || it->second.old_id != worker_id) continue;  // "retracted task is in invalid state"  reactor.rs:476-481
+        if (it->second.has_redirect) { ctx->resp_task.push_back(task_id[i]); ctx->resp_worker.push_back(it->second.target_id); ctx->resp_variant.push_back(it->second.variant); }
+        ctx->retr.erase(it); left++;
+    }
+    if (n_assigned) *n_assigned = (uint32_t)ctx->resp_task.size();
+    if (assigned_task) *assigned_task = ctx->resp_task.data();
+    if (assigned_worker_id) *assigned_worker_id = ctx->resp_worker.data();
+    if (assigned_variant) *assigned_variant = ctx->resp_variant.data();
+    return left;
+}
+
+uint32_t hqtick_retracting_count(const hqtick_ctx *ctx) { return ctx ? (uint32_t)ctx->retr.size() : 0u; }
 
 int hqtick_ready_compact(hqtick_ctx *ctx) {
     if (!ctx) return HQTICK_E_INVALID;

@@ -93,9 +93,12 @@ class Tick:
             raise HqTickError(rc, self._err())
         return rc_
 
-    def tick(self, snap: abi.Snapshot, resident: bool = False, resident_workers: bool = False) -> abi.Result:
-        """resident_workers: the snapshot travels without its worker side; the library completes it from its own worker set (hqtick_cluster_*, ABI 7)"""
+    def tick(self, snap: abi.Snapshot, resident: bool = False, resident_workers: bool = False, resident_retracting: bool = False) -> abi.Result:
+        """resident_workers: the snapshot travels without its worker side; the library completes it from its own worker set (hqtick_cluster_*, ABI 7).
+        resident_retracting: the Retracting tasks of the queues come from the library's own table (hqtick_retracting_*, ABI 7)"""
         sc = snap.to_c(resident_workers=resident_workers)
+        if resident_retracting:
+            sc.n_retracting = 0xFFFFFFFF; sc.retracting_task = None; sc.retracting_worker = None; sc.retracting_redirect_worker = None; sc.retracting_redirect_variant = None
         return abi.parse_result(self.tick_raw(sc, resident), len(snap.worker_id), snap.n_resources)
 
     def batches(self, snap: abi.Snapshot):
@@ -192,6 +195,26 @@ class Tick:
         self._lib.hqtick_cluster_workers.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(abi.u32p)]
         self._chk(self._lib.hqtick_cluster_workers(self._ctx, C.byref(n), C.byref(p)))
         return abi._np(p, n.value, np.uint32).copy() if n.value else np.zeros(0, np.uint32)
+
+    def retracting_add(self, task_id, worker_id):
+        """process_retracted outside a tick (ABI 7): tasks back in their queue as Retracting{worker id}"""
+        t = np.ascontiguousarray(task_id, np.uint64); w = np.ascontiguousarray(worker_id, np.uint32)
+        self._lib.hqtick_retracting_add.argtypes = [C.c_void_p, C.c_uint32, abi.u64p, abi.u32p]
+        self._chk(self._lib.hqtick_retracting_add(self._ctx, len(t), t.ctypes.data_as(abi.u64p), w.ctypes.data_as(abi.u32p)))
+
+    def retract_response(self, worker_id: int, task_id):
+        """on_retract_response (ABI 7) -> [(task, target worker id, variant)] of the tasks that are now Assigned to their redirect target"""
+        t = np.ascontiguousarray(task_id, np.uint64)
+        n = C.c_uint32(); pt, pw, pv = abi.u64p(), abi.u32p(), abi.u8p()
+        self._lib.hqtick_retract_response.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, abi.u64p, C.POINTER(C.c_uint32), C.POINTER(abi.u64p), C.POINTER(abi.u32p), C.POINTER(abi.u8p)]
+        self._chk(self._lib.hqtick_retract_response(self._ctx, int(worker_id), len(t), t.ctypes.data_as(abi.u64p), C.byref(n), C.byref(pt), C.byref(pw), C.byref(pv)))
+        k = n.value
+        return list(zip(abi._np(pt, k, np.uint64).tolist(), abi._np(pw, k, np.uint32).tolist(), abi._np(pv, k, np.uint8).tolist())) if k else []
+
+    def retracting_count(self) -> int:
+        self._lib.hqtick_retracting_count.restype = C.c_uint32
+        self._lib.hqtick_retracting_count.argtypes = [C.c_void_p]
+        return int(self._lib.hqtick_retracting_count(self._ctx))
 
     def cluster_drop(self):
         self._lib.hqtick_cluster_drop.argtypes = [C.c_void_p]

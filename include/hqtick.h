@@ -377,6 +377,28 @@ int hqtick_cluster_add_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *work
 int hqtick_cluster_remove_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *worker_id);
 int hqtick_cluster_set_blocked(hqtick_ctx *ctx, uint32_t worker_id, uint32_t n, const uint32_t *rq, const uint8_t *variant);
 int hqtick_cluster_workers(const hqtick_ctx *ctx, uint32_t *n_workers, const uint32_t **worker_id);
+/*
+ * Retracting tasks as deltas (ABI 7; on_retract_response, process_retracted — server/reactor.rs:34-62,462-508).  The table of tasks in state
+ * Retracting{worker} — with their scheduler_state.redirects entry — can live in the library instead of travelling in every snapshot:
+ *   hqtick_retracting_add      process_retracted outside a tick: a higher-priority arrival dissolved a prefill set (check_dispose_prefill,
+ *                              scheduler/taskqueue.rs:148-154) and these tasks went back into their queue as Retracting{worker}.  worker = worker id.
+ *   (the tick itself)          a tick run with snapshot->n_retracting == HQ_RETRACTING_RESIDENT takes the in-queue entries of the table as its
+ *                              retracting_* arrays (worker ids -> row indices of the resident worker set: needs hqtick_cluster_upload) and, when it
+ *                              succeeds, applies to the table what create_task_mapping does to task states and redirects (scheduler/mapping.rs:66-101):
+ *                              a prefilled task it hands to another worker enters as Retracting{old} with a redirect, a Retracting task it takes gets its
+ *                              redirect (re)targeted, or none when it lands on the worker it is retracting from.
+ *   hqtick_retract_response    on_retract_response for one worker: every listed task that is Retracting{that worker} leaves the table — with a redirect
+ *                              it is now Assigned to the target (reported in the three output arrays, valid until the next call: the host sends the
+ *                              ComputeTasks message), without one it is an ordinary Waiting task of its queue again.  Other ids are ignored, as in the
+ *                              reference ("retracted task in invalid state").  Returns the number of tasks that left the table.
+ *   hqtick_retracting_count    entries in the table.
+ * Entries whose old worker is removed (hqtick_cluster_remove_workers) leave the table; a removed redirect TARGET only clears the redirect.
+ */
+#define HQ_RETRACTING_RESIDENT 0xFFFFFFFFu
+int hqtick_retracting_add(hqtick_ctx *ctx, uint32_t n, const uint64_t *task_id, const uint32_t *worker_id);
+int hqtick_retract_response(hqtick_ctx *ctx, uint32_t worker_id, uint32_t n, const uint64_t *task_id, uint32_t *n_assigned, const uint64_t **assigned_task,
+                            const uint32_t **assigned_worker_id, const uint8_t **assigned_variant);
+uint32_t hqtick_retracting_count(const hqtick_ctx *ctx);
 
 /*
  * Device-resident dependency graph (BASELINE config 5): the `Waiting{unfinished_deps}` counters and the consumer

@@ -182,3 +182,59 @@ def test_workers_join_leave_and_reject_without_a_re_upload(oracle_free=None):
     with pytest.raises(HqTickError):
         res.cluster_add_workers([1], tot_row.reshape(1, -1))
     plain.close(); res.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_retracting_table_resident_in_the_library(seed):
+    """ABI 7 (row f1: process_retracted / on_retract_response as deltas, server/reactor.rs:34-62,462-508): the Retracting tasks and their redirects live
+    in the library — hqtick_retracting_add when a higher-priority arrival dissolves a prefill set, the ticks' own effects on task states and redirects
+    (mapping.rs:66-101) applied by the library itself, hqtick_retract_response when a worker answers — and every tick run with
+    n_retracting = HQ_RETRACTING_RESIDENT equals the tick on the snapshot that carries the retracting arrays (the scenario family of
+    tests/test_gpu_fuzz.py::test_fuzz_prefill_disposal)."""
+    from hyperqueue_amd.core import SchedEnv, TaskBuilder as TB, WorkerBuilder as WB
+    from hyperqueue_amd.tick import HqTickError, Tick
+
+    rng = np.random.default_rng(9000 + seed)
+    cfg = abi.make_config(reserve=int(rng.integers(0, 2)), fill_max=int(rng.integers(1, 4)), time_limit_s=20.0)
+    e = SchedEnv(cfg)
+    g, r = Tick(cfg), Tick(cfg)
+    shapes = [TB().cpus(1), TB().cpus(2)]
+    for c in [int(x) for x in np.random.default_rng(seed).integers(1, 5, size=3)]:
+        e.new_worker(WB(c))
+    prio, seen, n_msgs = 0, 0, 0
+    for round_ in range(5):
+        n_new = int(rng.integers(1, 7)) if round_ else int(rng.integers(8, 16)); which = [int(rng.integers(0, 2)) for _ in range(n_new)]
+        if round_ and rng.random() < 0.7:
+            prio += 1
+        for c in which:
+            e.new_task(shapes[c].user_priority(prio))
+        new_msgs = e.retract_messages[n_msgs:]; n_msgs = len(e.retract_messages)  # prefill sets dissolved by these arrivals: (worker id, task)
+        if new_msgs:
+            r.retracting_add([t for (_, t) in new_msgs], [w for (w, _) in new_msgs])
+        snap = e.snapshot()
+        seen += len(snap.retracting)
+        try:
+            want = g.tick(snap)
+        except HqTickError as err:  # a Retracting task reached the prefill step: the reference asserts there
+            assert err.code == abi.HQTICK_E_UNSUPPORTED
+            with pytest.raises(HqTickError):
+                r.tick(snap, resident_retracting=True)
+            break
+        got = r.tick(snap, resident_retracting=True)
+        _same(got, want)
+        assert got.redirects == want.redirects and got.redirect_kinds == want.redirect_kinds
+        e.apply(want)
+        k = int(rng.integers(1, 7)); answer = rng.random() < 0.6
+        done = 0
+        for t in sorted(e.tasks.values(), key=lambda t: t.id):
+            if t.state == 1 and done < k:
+                e.finish_task(t.id, t.worker); done += 1
+        if answer:
+            for t in [t for t in sorted(e.tasks.values(), key=lambda t: t.id) if t.state == 4 and t.id not in e.retaken_variant][:2]:
+                expect = [(t.id,) + tuple(e.redirects[t.id])] if t.id in e.redirects else []
+                wid = t.worker
+                e.retract_response(wid, [t.id])
+                assert r.retract_response(wid, [t.id]) == expect
+        # the table holds exactly the tasks the mirror of the reactor has in state Retracting (those a tick put back on their own worker included)
+        assert r.retracting_count() == sum(1 for t in e.tasks.values() if t.state == 4)
+    g.close(); r.close()
