@@ -40,7 +40,7 @@ struct Sweeper {
     virtual bool sweep(const double *pi, SweepTotals &out) = 0;             // sweep number = count of sweeps since begin()
     virtual const uint16_t *patterns(uint32_t n_sweeps) = 0;                // host pointer to the patterns of sweeps [0, n_sweeps): [n_sweeps][n_cols]
     virtual void end() = 0;
-    uint32_t min_cols = 1024;   // components below this many columns stay with the host search
+    uint32_t min_cols = 256;    // components below this many columns stay with the host search (a sweep is ~80 us whatever the block count: below ~250 columns the host tree is usually done first)
     uint32_t budget = 4096;     // search steps per block and sweep
     // statistics of the last solve
     uint32_t stat_sweeps = 0;

@@ -66,6 +66,28 @@ def test_device_sweeps_walk_the_emulations_path(name, monkeypatch):
     assert got.batches == want.batches and got.counts == want.counts
 
 
+@pytest.mark.parametrize("seed", range(2000, 2024))
+def test_device_sweeps_equal_emulation_on_random_clusters(seed, monkeypatch):
+    """tools/price_fuzz.py's family (clusters mid-run: every worker its own block; 1-3 priority levels; 12-192 workers), the sweeps forced on from 16
+    columns: k_price_sweep and its emulation solve thousands of different priced blocks here, and any difference in one pattern would send the master
+    down another path — sweeps, configurations, status and counts must all be equal"""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from price_fuzz import scenario
+    from test_price import stages
+
+    snap = scenario(seed)[0]
+    got, ks = _tick(snap, min_cols=16, monkeypatch=monkeypatch)
+    want, sweeps, rounds = stages(snap, True, min_cols=16)
+    assert (ks["price_sweeps"], ks["price_rounds"]) == (sweeps, rounds)
+    assert got.status == want.status and got.is_optimal == want.is_optimal and got.batches == want.batches
+    if sweeps and want.is_optimal and not want.is_canonical:  # (a tick the host tree finished exactly is compared too: same incumbent in, same search)
+        assert got.counts == want.counts
+    elif want.is_optimal:
+        assert got.counts == want.counts
+
+
 def _model_point(model, counts):
     """the counts as a point of the oracle's model; flag columns (zero-cost 0/1) switched on where their `>=` row needs them (they are existential)"""
     cd = {(q, v, w): c for (q, v, w, c) in counts}
