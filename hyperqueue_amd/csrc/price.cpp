@@ -296,9 +296,9 @@ struct Solver {
         double lb_master = -INF;
         bool converged = false;
         for (int it = 0; it < 200; it++) {
-            if (mt.solve(200000) != LP_OPT) return false;
+            { const int st = mt.solve(200000); if (st != LP_OPT) { if (rq.trace) fprintf(stderr, "[price] master LP status %d at iteration %d (%d cuts)\n", st, it, M.m); return false; } }
             lb_master = -mt.objective() * theta_scale + cB;
-            if (ub_best < cutoff) return false;                         // even the relaxation of this configuration is below the incumbent
+            if (ub_best < cutoff) { if (rq.trace) fprintf(stderr, "[price] configuration bounded by %.9f, below the incumbent %.9f\n", ub_best, cutoff); return false; }  // even the relaxation of this configuration is below the incumbent
             if (ub_best - lb_master <= tol * std::fabs(ub_best)) { converged = true; break; }
             bool same = !pi_prev_master.empty();
             for (int k = 0; k < K && same; k++) same = std::fabs(mt.x[k] - pi_prev_master[k]) <= 1e-15 + 1e-12 * std::fabs(mt.x[k]);
@@ -314,7 +314,7 @@ struct Solver {
         if (!converged) {
             if (mt.solve(200000) != LP_OPT) return false;
             lb_master = -mt.objective() * theta_scale + cB;
-            if (ub_best - lb_master > 1e-3 * std::fabs(ub_best)) return false;  // nowhere near: no usable multipliers
+            if (ub_best - lb_master > 1e-3 * std::fabs(ub_best)) { if (rq.trace) fprintf(stderr, "[price] master not converged: %.9f vs %.9f\n", ub_best, lb_master); return false; }  // nowhere near: no usable multipliers
         }
         lambda.assign(cuts.size(), 0.0);
         double lsum = 0.0;
@@ -526,7 +526,12 @@ Answer solve(const Request &rq, Sweeper &sw) {
             if (!drop_flags(B, x)) break;
         }
     };
-    descend(std::vector<double>(G, 1.0));   // every flag on: always feasible for the tick's models (every lower-priority batch capped at its cut)
+    if (rq.incumbent && G > 0) {  // the caller's incumbent (milp.cpp's sparse_greedy: flags on, raise, drop the flags no longer needed, raise again) names a configuration
+        std::vector<double> B(G);
+        for (int g = 0; g < G; g++) B[g] = rq.incumbent[P.gmodel[g]] > 0.5 ? 1.0 : 0.0;
+        descend(B);
+    }
+    if (ans.x.empty() && !S.failed) descend(std::vector<double>(G, 1.0));   // every flag on: always feasible for the tick's models (every lower-priority batch capped at its cut)
     if (S.failed) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
     // Not certified against the bound seen so far and the model has flags: the master of the RELAXED model (flags in [0, 1]) may still bring the bound
     // down — its cuts are the points already evaluated, the flags enter through one extra variable each (mu_g >= c_g - pi.A_g, mu_g >= 0).  Its

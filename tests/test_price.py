@@ -124,3 +124,24 @@ def test_heterogeneous_coupled_ticks_by_price_sweeps(W, seed, n_ready, levels):
     if got.is_optimal and want.is_optimal:  # (placement columns only on both sides: the flag columns of blocked workers carry a sliver of the objective)
         zw = _objective(model, want)
         assert zg >= zw * (1.0 - 1e-4) - 1e-12, (zg, zw, sweeps)
+
+
+@pytest.mark.parametrize("variant", ["unsaturated", "priorities"])
+def test_c4_shaped_coupled_ticks_by_price_sweeps(variant):
+    """BASELINE configs[3]'s shape (every class a 2-variant OR-list: 16 columns per worker block), reduced to 512 workers.  Unsaturated: the one-component
+    model HiGHS cannot close at full size; with priorities: flags + cut rows on top — the flag configuration comes from the solver's own
+    greedy incumbent."""
+    from oracle.oracle import Oracle
+
+    snap = workloads.make("c4", n_tasks=20_000 if variant == "unsaturated" else 150_000, n_workers=512)
+    if variant == "priorities":
+        rng = np.random.default_rng(1)
+        snap.task_priority = np.asarray([priority_from_user(int(p)) for p in rng.choice([0, 1, 2], len(snap.task_id), p=[0.8, 0.15, 0.05])], np.uint64)
+    got, sweeps, rounds = stages(snap, True, tl=10.0)
+    assert sweeps > 0 and got.status == abi.HQTICK_DONE and got.is_optimal
+    host, _, _ = stages(snap, False, tl=5.0)
+    o = Oracle(abi.make_config(time_limit_s=0.2), reference_solver_options=True)
+    o.tick(snap)
+    model = o.last_model()
+    zg, zh = _objective(model, got), _objective(model, host)
+    assert zg >= zh * (1.0 - 1e-4), (zg, zh)
