@@ -644,6 +644,33 @@ def main():
             except Exception as e:
                 out["multi_priority"]["cpu_baseline"] = {"error": repr(e)}
         tp.close()
+        # ... and the same three priority levels on a BUSY cluster (workloads.make_steady: every worker runs a packed mix of which 10 % just finished, ~930 distinct free
+        # vectors): the everyday production tick — priorities AND heterogeneous workers.  The cuts make it one coupled model of all 1024 workers.
+        try:
+            ss = workloads.make_steady("c3p", seed=args.seed)
+            tq = Tick(cfg)
+            tq.upload_ready(ss.task_id, ss.task_priority, ss.task_rq, sorted_=True)
+            scq = ss.to_c()
+            tl2, inf2 = [], None
+            for _ in range(args.priority_ticks + 1):
+                t0 = time.perf_counter(); rq_ = tq.tick_raw(scq, resident=True); tl2.append(time.perf_counter() - t0)
+                inf2 = (int(rq_.status), int(rq_.is_optimal), tq.kernel_stats())
+            tq.close()
+            out["multi_priority_busy_cluster"] = {"workload": "c3p on a cluster mid-run (workloads.make_steady('c3p')): 1 M ready tasks at three priority levels, 1024 workers with ~930 distinct free vectors",
+                                                  "p50_tick_ms": 1e3 * float(np.median(tl2[1:])), "status": inf2[0], "is_optimal": bool(inf2[1]), "assigned_per_tick": int(inf2[2]["n_assigned"]),
+                                                  "prefilled_per_tick": int(inf2[2]["n_prefilled"]), "model_columns": int(inf2[2]["milp_cols"]), "model_rows": int(inf2[2]["milp_rows"]),
+                                                  "price_sweeps": int(inf2[2]["price_sweeps"]), "coupled_solve_ms": inf2[2]["milp_us"] / 1e3, "build_model_ms": inf2[2]["model_us"] / 1e3,
+                                                  "note": "round 2's host search ran into its limit on this tick (status NEED_MORE_COMPUTE after seconds); the first price sweep's own patterns are feasible "
+                                                          "for the wide rows here, so one sweep certifies it"}
+            if args.cpu_ticks > 0:
+                from oracle.oracle import Oracle
+                oq = Oracle(abi.make_config(time_limit_s=5.0), reference_solver_options=True)
+                t0 = time.perf_counter(); wq = oq.tick(ss); tcq = time.perf_counter() - t0
+                out["multi_priority_busy_cluster"]["cpu_baseline"] = {"tick_s": tcq, "is_optimal": bool(wq.is_optimal), "kind": "port", "cores": 1, "cpu": cpu_model(),
+                                                                        "assigned_per_tick": sum(1 for recs in wq.records for (_, _, k) in recs if k == abi.HQ_REC_ASSIGN),
+                                                                        "sample": "1 tick of the same snapshot, HiGHS 1.8.0 with the reference's options (time_limit = 5 s only)"}
+        except Exception as e:
+            out["multi_priority_busy_cluster"] = {"error": repr(e)}
     if world == 1 and args.cpu_ticks > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(snap, args.cpu_ticks)

@@ -16,6 +16,8 @@ def snapshot(which):
     global _dag
     if which == "c3p":
         return workloads.make("c3p", n_tasks=1_000_000, n_workers=1024)
+    if which == "c3ps":  # a busy cluster (every worker its own free vector) + three priority levels + 1 M ready tasks: the everyday production tick
+        return workloads.make_steady("c3p", seed=0)
     if which.startswith("c3p:"):
         w = int(which.split(":")[1])
         return workloads.make("c3p", n_tasks=1000 * w, n_workers=w)
