@@ -721,6 +721,36 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
             while (lo < hi && ok) {
                 const int32_t mid = first ? hi - 1 : (lo + hi) / 2;
                 first = false;
+                {   // Root bound of the probe before its level lists are built (setup_work is ~5 us of a ~7 us probe, and most probes fail): a pool point that
+                    // is a dual vertex for the columns 0..j — as it is, or through the multiplier mu = c_j - a_j . y of the cap x_j <= mid — bounds the probe's
+                    // LP by y . cap + mu * mid.  If even the best of them stays below the threshold no point with x_j <= mid reaches it.
+                    const uint32_t F = j >= 31 ? all : (all & ((2u << j) - 1u)), jb = 1u << j, G = F & ~jb;
+                    const uint32_t np = S.npool < (uint32_t)PCAP ? S.npool : (uint32_t)PCAP;
+                    int lbest = -1;
+                    wv.sync();
+                    wv.argmax([&](int lane) {
+                        double best = 1e300;
+                        for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) {
+                            const uint32_t cover = S.pcover[i], tight = S.ptight[i];
+                            double pen;
+                            if ((tight & ~F) == 0 && (F & ~cover) == 0) pen = 0.0;
+                            else if ((tight & ~G) == 0 && (G & ~cover) == 0) {
+                                double sdot = 0.0;
+                                for (int r = 0; r < MMAX; r++) sdot += S.a[r][j] * S.py[i][r];
+                                const double mu = (S.c[j] - sdot) * (1.0 + 1e-12);
+                                pen = mu > 0.0 ? mu * (double)mid * (1.0 + 2e-7) : 0.0;
+                            } else continue;
+                            const double v = S.py[i][0] * capf[0] + S.py[i][1] * capf[1] + S.py[i][2] * capf[2] + S.py[i][3] * capf[3] + pen;
+                            best = v < best ? v : best;
+                        }
+                        S.lane_val[lane] = best;
+                        return best < 1e299 ? 1.0 / (1.0 + (best > 0.0 ? best : 0.0)) : -1.0;  // (decreasing in the bound: the arg-max is the lane with the smallest one; -1: no point applies)
+                    }, &lbest);
+                    wv.sync();
+                    const bool fails = lbest >= 0 && zf + S.lane_val[lbest] < thr;
+                    wv.sync();
+                    if (fails) { lo = mid + 1; continue; }
+                }
                 setup_work(wv, S, j >= 31 ? all : (all & ((2u << j) - 1u)), j, mid);
                 if (wv.first()) { for (int r = 0; r < MMAX; r++) S.rem[S.wn][r] = capf[r]; S.zfix[S.wn] = zf; }
                 wv.sync();
