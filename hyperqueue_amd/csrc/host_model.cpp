@@ -263,13 +263,15 @@ struct GapCache {
         return out;
     }
 
-    uint32_t gap(uint32_t high_rq, uint32_t low_rq, const Amounts &total, const uint32_t *asg_rq, const uint8_t *asg_variant, uint32_t n_asg) {
-        if (pb.rq_multi_node(high_rq) || pb.rq_multi_node(low_rq)) return 0;
+    // What the blocker leaves of a worker (gap.rs:44-84): the worker's total minus as many blocker tasks as fit, minus what runs there (other requests only).
+    // asg_cnt (optional): the running tasks given as DISTINCT (rq, variant) pairs with their multiplicities — saturating subtractions commute, so
+    // taking a pair away `count` times at once is the same as the reference's one-by-one loop (gap.rs:79-84).  false: the gap is 0 whatever the batch.
+    bool leftover(uint32_t high_rq, const Amounts &total, const uint32_t *asg_rq, const uint8_t *asg_variant, uint32_t n_asg, const uint32_t *asg_cnt, Amounts &left) {
+        if (pb.rq_multi_node(high_rq)) return false;
         const RequestView &h = pb.rqs[high_rq];
-        Amounts left;
         if (h.n_variants == 1) {
             const VariantView &hv = pb.variants[h.first_variant];
-            for (uint32_t e = 0; e < hv.n_entries; e++) if (hv.kind[e] == HQ_ENTRY_ALL) return 0;
+            for (uint32_t e = 0; e < hv.n_entries; e++) if (hv.kind[e] == HQ_ENTRY_ALL) return false;
             left = total;
             take_away(left, hv, max_count(total, hv));
         } else {
@@ -278,11 +280,22 @@ struct GapCache {
             if (it == memo.end()) it = memo.emplace(key, leftover_multi_variant(high_rq, total)).first;
             left = it->second;
         }
-        for (uint32_t i = 0; i < n_asg; i++) if (asg_rq[i] != high_rq) take_away(left, pb.variants[pb.rqs[asg_rq[i]].first_variant + asg_variant[i]], 1);
+        for (uint32_t i = 0; i < n_asg; i++) if (asg_rq[i] != high_rq) take_away(left, pb.variants[pb.rqs[asg_rq[i]].first_variant + asg_variant[i]], asg_cnt ? asg_cnt[i] : 1);
+        return true;
+    }
+    // how many tasks of the batch fit into what is left (gap.rs:86-92)
+    uint32_t fit(uint32_t low_rq, const Amounts &left) {
+        if (pb.rq_multi_node(low_rq)) return 0;
         const RequestView &l = pb.rqs[low_rq];
         uint32_t best = 0;
         for (uint32_t v = 0; v < l.n_variants; v++) { uint32_t c = max_count(left, pb.variants[l.first_variant + v]); if (v == 0 || c < best) best = c; }
         return best;
+    }
+    uint32_t gap(uint32_t high_rq, uint32_t low_rq, const Amounts &total, const uint32_t *asg_rq, const uint8_t *asg_variant, uint32_t n_asg, const uint32_t *asg_cnt = nullptr) {
+        if (pb.rq_multi_node(high_rq) || pb.rq_multi_node(low_rq)) return 0;
+        Amounts left;
+        if (!leftover(high_rq, total, asg_rq, asg_variant, n_asg, asg_cnt, left)) return 0;
+        return fit(low_rq, left);
     }
 };
 
@@ -830,18 +843,33 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         short_flags[{rq, size}] = col;
         return col;
     };
+    static const bool trace_model = getenv("HQMILP_TRACE") != nullptr;
+    if (trace_model) fprintf(stderr, "[model] worker blocks built at %.3f ms\n", (clock_us() - t_model0) / 1e3);
     GapCache gaps(pb);
     // the gap depends on the worker's total resources and on what runs there: workers with the same signature share one computation per (blocker, batch)
-    std::vector<uint32_t> gap_sig; std::map<std::vector<uint64_t>, uint32_t> sig_ids; std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> gap_memo;
+    std::vector<uint32_t> gap_sig; std::map<std::vector<uint64_t>, uint32_t> sig_ids;
+    const size_t n_sig_cap = (size_t)ws.n + 1;  // signatures are numbered below the worker count
+    std::vector<uint8_t> left_state; std::vector<Amounts> left_of;  // per (blocker rq, signature): 0 not computed, 1 leftover in left_of, 2 gap is 0 by rule
+    // a worker's running tasks as distinct (rq, variant) pairs with counts (a busy worker runs ~100 tasks of ~8 kinds: the gap of every (blocker, batch) pair walks this list)
+    std::vector<uint32_t> agg_off, agg_rq, agg_cnt; std::vector<uint8_t> agg_variant;
+    auto build_agg = [&]() {
+        agg_off.assign((size_t)ws.n + 1, 0);
+        if (pb.custom || !ws.assigned_off) return;
+        std::vector<uint32_t> keys;
+        for (uint32_t w = 0; w < ws.n; w++) {
+            keys.clear();
+            for (uint32_t i = ws.assigned_off[w]; i < ws.assigned_off[w + 1]; i++) keys.push_back((ws.assigned_rq[i] << 8) | ws.assigned_variant[i]);
+            std::sort(keys.begin(), keys.end());
+            for (size_t i = 0; i < keys.size();) { size_t j = i; while (j < keys.size() && keys[j] == keys[i]) j++; agg_rq.push_back(keys[i] >> 8); agg_variant.push_back((uint8_t)(keys[i] & 0xFFu)); agg_cnt.push_back((uint32_t)(j - i)); i = j; }
+            agg_off[w + 1] = (uint32_t)agg_rq.size();
+        }
+    };
     auto sig_of = [&](uint32_t w) -> uint32_t {
         if (gap_sig.empty()) gap_sig.assign(ws.n, UINT32_MAX);
         if (gap_sig[w] != UINT32_MAX) return gap_sig[w];
         std::vector<uint64_t> key(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
-        if (!pb.custom && ws.assigned_off) {
-            const size_t k0 = key.size();
-            for (uint32_t i = ws.assigned_off[w]; i < ws.assigned_off[w + 1]; i++) key.push_back(((uint64_t)ws.assigned_rq[i] << 8) | ws.assigned_variant[i]);
-            std::sort(key.begin() + (long)k0, key.end());  // (saturating subtractions commute: the multiset of running tasks decides)
-        }
+        if (agg_off.empty()) build_agg();
+        for (uint32_t i = agg_off[w]; i < agg_off[w + 1]; i++) key.push_back(((uint64_t)agg_cnt[i] << 32) | ((uint64_t)agg_rq[i] << 8) | agg_variant[i]);  // (sorted by (rq, variant): the multiset of running tasks decides — saturating subtractions commute)
         auto it = sig_ids.find(key);
         if (it == sig_ids.end()) it = sig_ids.emplace(std::move(key), (uint32_t)sig_ids.size()).first;
         return gap_sig[w] = it->second;
@@ -862,6 +890,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 uint32_t brq = bl.first; bool bounded = bl.second != HQ_BLOCKER_UNBOUNDED;
                 std::vector<int> no_gap;  // zero_cond
                 std::vector<int> cols;
+                int fl_cached = -2;
                 if (pb.rq_multi_node(batch.rq)) {
                     for (uint32_t g = 0; g < pb.n_groups; g++) {
                         auto it = group_cols.find({batch.rq, g});
@@ -871,15 +900,17 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     for (uint32_t w : solver_workers) {
                         if (!pb.capable_rqv(ws, w, brq)) continue;
                         uint32_t gap;
-                        {
-                            const auto gkey = std::make_tuple(brq, batch.rq, sig_of(w));
-                            auto git = gap_memo.find(gkey);
-                            if (git == gap_memo.end()) {
+                        {   // what the blocker leaves of this worker: once per (blocker, worker signature), then one fit per batch
+                            const uint32_t sg = sig_of(w);
+                            const size_t li = (size_t)brq * n_sig_cap + sg;
+                            if (li >= left_state.size()) { left_state.resize(((size_t)pb.rqs.size()) * n_sig_cap, 0); left_of.resize(left_state.size()); }
+                            if (left_state[li] == 0) {
                                 Amounts tot; tot.a.assign(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
-                                const uint32_t a0 = (pb.custom || !ws.assigned_off) ? 0 : ws.assigned_off[w], na = pb.custom ? 0 : ws.n_assigned(w);
-                                git = gap_memo.emplace(gkey, gaps.gap(brq, batch.rq, tot, na ? ws.assigned_rq + a0 : nullptr, na ? ws.assigned_variant + a0 : nullptr, na)).first;
+                                if (agg_off.empty()) build_agg();
+                                const uint32_t a0 = agg_off[w], na = agg_off[w + 1] - a0;
+                                left_state[li] = gaps.leftover(brq, tot, na ? agg_rq.data() + a0 : nullptr, na ? agg_variant.data() + a0 : nullptr, na, na ? agg_cnt.data() + a0 : nullptr, left_of[li]) ? 1 : 2;
                             }
-                            gap = git->second;
+                            gap = left_state[li] == 1 ? gaps.fit(batch.rq, left_of[li]) : 0;
                         }
                         cols.clear();
                         uint64_t cols_ub = 0;
@@ -889,7 +920,8 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                             // a hundred tasks that is every one of the W x cuts x blockers rows of a large tick — the model's points are the same)
                             // The flag column itself is created as the reference creates it (get_bvar, :233-253: even for a worker without a placement
                             // column) — the model's COLUMNS, and with them the canonical tie-break, stay exactly the reference's.
-                            int fl = bounded ? short_flag(brq, bl.second) : -1;
+                            if (bounded && fl_cached == -2) fl_cached = short_flag(brq, bl.second);  // (created at its first use, as get_bvar does; the same flag for every worker of this pair)
+                            const int fl = bounded ? fl_cached : -1;
                             if (cols_ub <= (uint64_t)cut.size + gap) continue;
                             if (bounded && fl >= 0) emit_plus(hqmilp::ROW_MAX, (double)cut.size + bsize + (double)gap, cols, fl, bsize);
                             else if (!bounded) { m.begin_row(hqmilp::ROW_MAX, (double)cut.size + (double)gap); for (int c : cols) m.term(c, 1.0); m.end_row(); }
@@ -919,6 +951,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     }
     m.row_implied.resize(m.nrows(), 0);
     const double t_model1 = clock_us();
+    if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu worker signatures\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), sig_ids.size());
     hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438
     out.pre_us = t_model0 - t_enter; out.model_us = t_model1 - t_model0; out.milp_us = clock_us() - t_model1; out.price_sweeps = sol.price_sweeps; out.price_rounds = sol.price_rounds; out.price_us = sol.price_total_us;
     out.milp_nodes = sol.nodes; out.milp_cols = m.ncols(); out.milp_rows = m.nrows(); out.milp_components = sol.n_components;
