@@ -1274,6 +1274,10 @@ int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, c
             HQ_HIP(hipMemcpyAsync(ctx->d_tid2.p, aid, (size_t)n_add * 8, hipMemcpyDeviceToDevice, ctx->stream));
             HQ_HIP(hipMemcpyAsync(ctx->d_tprio2.p, aprio, (size_t)n_add * 8, hipMemcpyDeviceToDevice, ctx->stream));
             HQ_HIP(hipMemcpyAsync(ctx->d_trq2.p, arq, (size_t)n_add * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            // The batch came through the pinned staging buffer (hqtick_ready_add_staged's host-to-device copy is queued ahead of these): the caller may
+            // stage the NEXT batch into the same buffer as soon as this call returns, so the copies must be over by then (the merge path
+            // below synchronises for its validation flags anyway).
+            HQ_HIP(hipStreamSynchronize(ctx->stream));
         }
     } else {
         const uint32_t n_slices = (uint32_t)((N + 255) / 256), stride = (n_slices + 15u) & ~15u;

@@ -305,3 +305,31 @@ def test_level_table_drops_levels_without_live_tasks():
     assert t.kernel_stats()["distinct_us"] == 0
     assert r2.records == r3.records == r4.records and t.ready_count() == n_live
     t.close()
+
+
+def test_staging_twice_onto_an_empty_resident_set():
+    """hqtick_ready_add_stage hands out pointers into ONE pinned buffer; with nothing resident the batch is only copied (no merge kernel, no
+    validation wait) — the call must not return while the copy still reads the buffer, or the next staged batch overwrites the first one in flight"""
+    from hyperqueue_amd.tick import Tick
+
+    snap = workloads.make("c3", n_tasks=400_000, n_workers=64)
+    t = Tick(abi.make_config(time_limit_s=20.0))
+    half = len(snap.task_id) // 2
+    for rep in range(3):
+        t.upload_ready(np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32))  # an empty resident set
+        a, b, c = t.ready_add_stage(half)
+        a[:] = snap.task_id[:half]; b[:] = snap.task_priority[:half]; c[:] = snap.task_rq[:half]
+        t.ready_add_staged(half)  # nothing resident: the batch becomes the set
+        a, b, c = t.ready_add_stage(len(snap.task_id) - half)  # the same buffer again, immediately
+        a[:] = snap.task_id[half:]; b[:] = snap.task_priority[half:]; c[:] = snap.task_rq[half:]
+        t.ready_add_staged(len(snap.task_id) - half)
+        assert t.ready_count() == len(snap.task_id)
+        got = t.tick(dataclasses_replace_ready(snap), resident=True)
+        want = Tick(abi.make_config(time_limit_s=20.0)).tick(snap)
+        assert got.counts == want.counts and got.records == want.records
+
+
+def dataclasses_replace_ready(snap):
+    import dataclasses
+
+    return dataclasses.replace(snap, _keep=[], task_id=np.zeros(0, np.uint64), task_priority=np.zeros(0, np.uint64), task_rq=np.zeros(0, np.uint32))
