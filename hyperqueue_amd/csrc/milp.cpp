@@ -151,8 +151,10 @@ struct CompSolver {
     bool gap_pruned = false;
     double root_bound = INF;  // LP bound of the whole component, once the root LP is solved
     bool certified() const { return have && rel_gap > 0.0 && root_bound <= best + rel_gap * std::fabs(best); }
-    double t_begin = wall();
-    bool tracing = getenv("HQMILP_TRACE") != nullptr;
+    // (read once per process: a CompSolver is constructed per window of the window search and per class block — thousands per tick)
+    static bool trace_enabled() { static const bool on = getenv("HQMILP_TRACE") != nullptr; return on; }
+    bool tracing = trace_enabled();
+    double t_begin = tracing ? wall() : 0.0;
     void trace(const char *what) { if (tracing && !in_lns) fprintf(stderr, "[milp] n=%d t=%.3fs %s: incumbent %.9f nodes %ld\n", n, wall() - t_begin, what, have ? best : -1.0, nodes); }
     bool cannot_improve(double z) {
         if (!have) return false;
