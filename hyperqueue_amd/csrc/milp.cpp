@@ -52,6 +52,7 @@ struct CompSolver {
     // search control of phase 1: a plain dive first (good incumbents fast), then — if that does not finish within its node budget — a restart
     // from the root with strong branching, which proves what the dive found with far fewer nodes
     bool strong = false, aborted = false; long node_budget = -1;
+    bool cert_stop = false;  // the incumbent came within rel_gap of the component's bound (root LP, or the tighter bound of the price sweeps) while the tree was running: stop it
 
     // Deterministic work budget of the tie-break phase, in tableau element updates (a pivot or a tableau copy touches ma x width of them);
     // the wall clock stays the backstop.  Work, not seconds: every replica of a sharded scheduler must take the same decision here.
@@ -183,6 +184,7 @@ struct CompSolver {
     void dfs_opt(Tab &t) {
         nodes++;
         if (aborted || time_up()) return;
+        if (cert_stop || (rel_gap > 0.0 && !in_lns && work_limit < 0 && certified())) { cert_stop = true; aborted = true; return; }
         if (node_budget >= 0 && nodes > node_budget) { aborted = true; return; }
         {   // a node of a large tableau costs a copy of it (~20 ns per element with the page faults): check the clock every time, and do not start
             // a copy that cannot finish in the time that is left
@@ -762,6 +764,7 @@ struct CompSolver {
                 if (phase > 0) { lp_iters += root.iters; root = Tab(); root.init(&R, c, lb, ub); root.deadline = deadline; }
                 if (root_bound == INF && solve_counted(root) == LP_OPT) root_bound = root.objective();  // dfs_opt finds the tableau solved
                 dfs_opt(root);
+                if (cert_stop) break;
                 if (!aborted || timed_out) break;
                 if (node_cap >= 0 && nodes >= node_cap) { timed_out = true; break; }
                 if (phase == 0 && !in_lns && !lns_done) {  // the dive did not finish: improve its incumbent before the expensive phases
@@ -771,6 +774,7 @@ struct CompSolver {
                     trace("window search");
                     lns_schedule(now + std::min(0.3 * left, std::max(0.05, 3.0 * dive)));
                     lns_done = true;
+                    if (rel_gap > 0.0 && work_limit < 0 && certified()) { cert_stop = true; break; }
                 }
                 if (phase & 1) bud *= 4;
             }
@@ -782,7 +786,7 @@ struct CompSolver {
         const double work0 = work;
         bool by_root_bound = false;  // certified by the root LP bound alone (no tree, or before it)
         if (certified()) by_root_bound = true;
-        else if (tree_affordable) search();
+        else if (tree_affordable) { search(); if (cert_stop) { by_root_bound = true; cert_stop = false; } }
         else timed_out = true;  // straight to the window search below
         const double work_search = work - work0;  // the tree search alone: the windows before it are not a measure of how hard the proof is
         lp_iters += root.iters;

@@ -23,7 +23,8 @@ using hqmilp::lp::Tab;
 constexpr int KMAX_HOST = 128;   // == price_core.h's KMAX (not included here: this file is host-only and also part of libhqalloc.so)
 constexpr int NMAX_BLOCK = 32, MMAX_BLOCK = 4;
 constexpr double GRID = 10000.0;  // ResourceAmount fractions per unit  common/resources/amount.rs:7
-constexpr int MAX_ROUNDS = 6, MAX_SWEEPS = 256;
+constexpr int MAX_ROUNDS = 6;
+constexpr int BP_MAX_NODES = 600;   // nodes of the branch-and-price phase (a deterministic count, like every limit in here)
 
 double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -224,7 +225,14 @@ const char *build(const Request &rq, Prob &P) {
     return nullptr;
 }
 
-struct Cut { double cx = 0, bnd = 0; std::vector<long long> act; std::vector<double> pi; };
+struct Cut {
+    double cx = 0, bnd = 0; std::vector<long long> act; std::vector<double> pi;
+    // the maximisers, one integer pattern per block, in the model's own variables: fetched from the device on demand (the sweep solved in variables shifted by `lo`)
+    std::vector<uint16_t> x; bool fetched = false; std::vector<std::pair<uint32_t, int32_t>> lo;
+};
+
+// a node of the branch-and-price phase: flags fixed or free, bounds on single block columns
+struct BPNode { std::vector<int8_t> flag; std::vector<std::pair<uint32_t, int32_t>> lo, hi; double bound = INF; int depth = 0; };
 
 struct Solver {
     const Request &rq; Sweeper &sw; Prob P;
@@ -235,12 +243,15 @@ struct Solver {
     std::vector<double> pmax;
     bool failed = false;
     size_t cut_lo = 0;            // the master works on cuts[cut_lo ..): points evaluated under the column bounds now in force
+    int max_sweeps = 256;
+    // branch-and-price: the node whose bounds the device tables carry right now (empty lo list = the model's own bounds), and what its lower bounds add per sweep
+    std::vector<std::pair<uint32_t, int32_t>> node_lo, node_caps; double node_cl = 0.0; std::vector<double> node_Al; bool at_root = true;
     bool base_caps = true;        // the sweeps run under the model's own column bounds (only those bound the relaxed model)
     Solver(const Request &r, Sweeper &s) : rq(r), sw(s) {}
 
     // one sweep at pi; returns the cut's index or -1
     int evaluate(const std::vector<double> &pi) {
-        if ((int)cuts.size() >= MAX_SWEEPS) return -1;
+        if ((int)cuts.size() >= max_sweeps) return -1;
         SweepTotals tot;
         std::vector<double> pig(P.KG, 0.0);
         for (int k = 0; k < P.K; k++) pig[P.grp_of[k]] += pi[k];
@@ -250,12 +261,16 @@ struct Solver {
         Cut c; c.cx = tot.cx; c.bnd = tot.bnd; c.pi = pi;
         c.act.resize(P.K);
         for (int k = 0; k < P.K; k++) c.act[k] = tot.act[P.grp_of[k]];
+        if (!node_lo.empty()) {  // the sweep ran in variables shifted by the node's lower bounds: back to the model's own (c.l, A.l and the bound's (c - pi A).l)
+            c.lo = node_lo; c.cx += node_cl; c.bnd += node_cl;
+            for (int k = 0; k < P.K; k++) { c.act[k] += (long long)std::llround(node_Al[k]); c.bnd -= pi[k] * node_Al[k]; }
+        }
         cuts.push_back(std::move(c));
         // the model's bound at these prices, flags relaxed: pi.h + sum_w V_w(pi) + sum_g max(0, c_g - pi.A_g)
         double L = cuts.back().bnd;
         for (int k = 0; k < P.K; k++) L += pi[k] * P.h[k];
         for (int g = 0; g < P.G; g++) { double r = P.gcost[g]; for (auto &t : P.g_rows[g]) r -= pi[t.first] * t.second; if (r > 0.0) L += r; }
-        if (base_caps && L < relaxed_bound) { relaxed_bound = L; relaxed_pi = pi; }
+        if (base_caps && at_root && L < relaxed_bound) { relaxed_bound = L; relaxed_pi = pi; }
         return (int)cuts.size() - 1;
     }
     double fixed_value(const Cut &c, const std::vector<double> &hB, double cB) const {
@@ -326,15 +341,37 @@ struct Solver {
         return true;
     }
 
+    // the patterns of the cuts that have none yet, from the device's ring (one copy for the lot)
+    bool fetch_patterns() {
+        size_t first = cuts.size();
+        for (size_t k = 0; k < cuts.size(); k++) if (!cuts[k].fetched) { first = k; break; }
+        if (first == cuts.size()) return true;
+        const uint32_t count = (uint32_t)(cuts.size() - first);
+        const uint16_t *pat = sw.patterns((uint32_t)first, count);
+        if (!pat) { failed = true; return false; }
+        const uint32_t nc = P.T.n_cols;
+        for (uint32_t i = 0; i < count; i++) {
+            Cut &c = cuts[first + i];
+            if (c.fetched) continue;
+            c.x.assign(pat + (size_t)i * nc, pat + (size_t)(i + 1) * nc);
+            for (auto &l : c.lo) c.x[l.first] = (uint16_t)(c.x[l.first] + l.second);
+            c.fetched = true;
+        }
+        return true;
+    }
+
     // One integer pattern per block out of the active cuts' maximisers, by error diffusion over the wide rows' running totals; then the repair.
     // `hB`: right-hand sides with the flags fixed.  Returns the point over the flat columns (empty: no usable point).
-    std::vector<uint16_t> round_patterns(const std::vector<double> &lambda, const std::vector<double> &pi, const std::vector<double> &hB) {
+    // `usable` (optional): cuts whose patterns may be used at all (branch-and-price: those that respect the node's bounds); `lo_of` (optional): lower
+    // bounds of single columns the repair must not go below.
+    std::vector<uint16_t> round_patterns(const std::vector<double> &lambda, const std::vector<double> &pi, const std::vector<double> &hB,
+                                         const std::vector<char> *usable = nullptr, const std::vector<int32_t> *lo_of = nullptr) {
         const int K = P.K; const HostTables &T = P.T;
         const uint32_t S = (uint32_t)cuts.size();
-        const uint16_t *pat = sw.patterns(S);
-        if (!pat) { failed = true; return {}; }
+        if (!fetch_patterns()) return {};
+        auto pat_of = [&](int k) { return cuts[(size_t)k].x.data(); };
         std::vector<int> active;
-        for (uint32_t k = 0; k < S; k++) if (lambda[k] > 1e-9) active.push_back((int)k);
+        for (uint32_t k = 0; k < S; k++) if (lambda[k] > 1e-9 && (!usable || (*usable)[k])) active.push_back((int)k);
         if (active.empty()) return {};
         double lsum = 0.0; for (int k : active) lsum += lambda[k];
         const int Q = (int)active.size();
@@ -354,7 +391,7 @@ struct Solver {
         std::vector<std::vector<double>> cand(Q, std::vector<double>(K));
         std::vector<int> chosen(T.n_blocks, 0);
         for (uint32_t b = 0; b < T.n_blocks; b++) {
-            for (int q = 0; q < Q; q++) { block_act(b, pat + (size_t)active[q] * T.n_cols, cand[q]); const double l = lambda[active[q]] / lsum; for (int r = 0; r < K; r++) tgt[r] += l * cand[q][r]; }
+            for (int q = 0; q < Q; q++) { block_act(b, pat_of(active[q]), cand[q]); const double l = lambda[active[q]] / lsum; for (int r = 0; r < K; r++) tgt[r] += l * cand[q][r]; }
             int bq = 0; double be = INF;
             for (int q = 0; q < Q; q++) {
                 double e = 0.0;
@@ -363,24 +400,24 @@ struct Solver {
             }
             for (int r = 0; r < K; r++) cum[r] += cand[bq][r];
             chosen[b] = active[bq];
-            memcpy(&x[T.blk_off[b]], pat + (size_t)active[bq] * T.n_cols + T.blk_off[b], (size_t)(T.blk_off[b + 1] - T.blk_off[b]) * 2);
+            memcpy(&x[T.blk_off[b]], pat_of(active[bq]) + T.blk_off[b], (size_t)(T.blk_off[b + 1] - T.blk_off[b]) * 2);
         }
         // `>=` rows that came out short: single-block pattern switches (any sweep's pattern of that block) that close the shortfall at the least loss
         auto ge_short = [&](const std::vector<double> &c) { double s = 0.0; for (int r = 0; r < K; r++) if (P.ge[r] && c[r] > hB[r] + 1e-9) s += c[r] - hB[r]; return s; };
         if (ge_short(cum) > 0.0) {
             std::vector<int> pool = active;
-            for (int k = (int)S - 1; k >= 0 && (int)pool.size() < Q + 12; k--) if (std::find(pool.begin(), pool.end(), k) == pool.end()) pool.push_back(k);
+            for (int k = (int)S - 1; k >= 0 && (int)pool.size() < Q + 12; k--) if ((!usable || (*usable)[k]) && std::find(pool.begin(), pool.end(), k) == pool.end()) pool.push_back(k);
             std::vector<double> a0(K), a1(K), c2(K);
             double cmax = 0.0; for (double c : T.col_cost) cmax = std::max(cmax, c);
             for (int moves = 0; moves < 256 && ge_short(cum) > 0.0; moves++) {
                 const double base = ge_short(cum);
                 double best_score = -INF; int bb = -1, bk = -1;
                 for (uint32_t b = 0; b < T.n_blocks; b++) {
-                    block_act(b, pat + (size_t)chosen[b] * T.n_cols, a0);
+                    block_act(b, pat_of(chosen[b]), a0);
                     double v0 = 0.0; for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) v0 += T.col_cost[f] * (double)x[f];
                     for (int k : pool) {
                         if (k == chosen[b]) continue;
-                        const uint16_t *px = pat + (size_t)k * T.n_cols;
+                        const uint16_t *px = pat_of(k);
                         block_act(b, px, a1);
                         double gain = 0.0, newviol = 0.0;
                         for (int r = 0; r < K; r++) {
@@ -395,11 +432,11 @@ struct Solver {
                     }
                 }
                 if (bb < 0) break;
-                block_act((uint32_t)bb, pat + (size_t)chosen[bb] * T.n_cols, a0);
-                block_act((uint32_t)bb, pat + (size_t)bk * T.n_cols, a1);
+                block_act((uint32_t)bb, pat_of(chosen[bb]), a0);
+                block_act((uint32_t)bb, pat_of(bk), a1);
                 for (int r = 0; r < K; r++) cum[r] += a1[r] - a0[r];
                 chosen[bb] = bk;
-                memcpy(&x[T.blk_off[bb]], pat + (size_t)bk * T.n_cols + T.blk_off[bb], (size_t)(T.blk_off[bb + 1] - T.blk_off[bb]) * 2);
+                memcpy(&x[T.blk_off[bb]], pat_of(bk) + T.blk_off[bb], (size_t)(T.blk_off[bb + 1] - T.blk_off[bb]) * 2);
                 if (ge_short(cum) >= base - 1e-9) break;
             }
             if (ge_short(cum) > 0.0) return {};
@@ -412,7 +449,7 @@ struct Solver {
             std::sort(cols.begin(), cols.end(), [&](int a, int b) { const double ca = T.col_cost[P.r_col[a]] / P.r_coef[a], cb = T.col_cost[P.r_col[b]] / P.r_coef[b]; return ca < cb || (ca == cb && a > b); });
             for (int k : cols) {
                 const int f = P.r_col[k];
-                while (x[f] > 0 && cum[r] > hB[r] + 1e-9) {
+                while (x[f] > (lo_of ? (uint16_t)(*lo_of)[f] : 0) && cum[r] > hB[r] + 1e-9) {
                     bool ok = true;
                     for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1] && ok; e++) if (P.c_coef[e] < 0 && cum[P.c_row[e]] - (double)P.c_coef[e] > hB[P.c_row[e]] + 1e-9) ok = false;
                     if (!ok) break;
@@ -424,6 +461,135 @@ struct Solver {
             if (cum[r] > hB[r] + 1e-9) return {};
         }
         return x;
+    }
+
+    // ------------------------------------------------------------------------------------------------ branch and price
+    // What the root leaves open is the integrality of the FLAGS and of the few blocks the wide rows force to mix patterns.  Nodes fix flags (first) or
+    // bound one block column (x <= floor / x >= ceil of its value in the node's LP point); a node's bound is the same Lagrangian, its sweeps run with the
+    // column caps hi - lo and the block capacities minus what the lower bounds use, in variables shifted by lo; cuts of other nodes are reused wherever
+    // their patterns respect the node's bounds.  Depth first, the child nearer to the LP point first; a node is closed when its bound is within rel_gap
+    // of the incumbent.  All limits are counts (nodes, sweeps): replicas decide alike.
+    struct NodeLP { double bound = INF; bool pruned = false; std::vector<double> lambda, pi, bfrac; };
+
+    bool apply_node(const BPNode &nd, std::vector<int32_t> &lo_arr, std::vector<int32_t> &hi_arr) {
+        const HostTables &T = P.T;
+        lo_arr.assign(T.n_cols, 0); hi_arr = P.base_cap;
+        for (auto &l : nd.lo) lo_arr[l.first] = std::max(lo_arr[l.first], l.second);
+        for (auto &h : nd.hi) hi_arr[h.first] = std::min(hi_arr[h.first], h.second);
+        node_caps.clear();
+        for (const CapRow &cr : P.caps) {  // a conditional bound applies once every flag of its row is fixed (before that the node is relaxed by leaving it out)
+            double r = cr.rhs; bool all_fixed = true;
+            for (auto &t : cr.g) { if (nd.flag[t.first] < 0) { all_fixed = false; break; } r -= t.second * (double)nd.flag[t.first]; }
+            if (!all_fixed) continue;
+            const double c = std::floor(r + 1e-9);
+            const int32_t cap = c < 0.0 ? 0 : (c > 65535.0 ? 65535 : (int32_t)c);
+            if (cap < hi_arr[cr.flat]) { hi_arr[cr.flat] = cap; node_caps.push_back({(uint32_t)cr.flat, cap}); }
+        }
+        std::vector<int32_t> caps(T.n_cols); std::vector<double> bcap(T.blk_cap);
+        node_lo.clear(); node_cl = 0.0; node_Al.assign(P.K, 0.0);
+        for (uint32_t f = 0; f < T.n_cols; f++) {
+            if (hi_arr[f] < lo_arr[f]) return false;
+            caps[f] = hi_arr[f] - lo_arr[f];
+            const int32_t l = lo_arr[f];
+            if (l <= 0) continue;
+            node_lo.push_back({f, l}); node_cl += T.col_cost[f] * (double)l;
+            for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) node_Al[P.c_row[e]] += (double)P.c_coef[e] * (double)l;
+            const int b = P.block_of_flat[f];
+            for (int r = 0; r < MMAX_BLOCK; r++) bcap[(size_t)b * MMAX_BLOCK + r] -= T.col_a[(size_t)f * MMAX_BLOCK + r] * (double)l;
+        }
+        for (double v : bcap) if (v < 0.0) return false;  // the lower bounds alone overfill a worker
+        if (!sw.set_caps(caps.data()) || !sw.set_block_caps(bcap.data())) { failed = true; return false; }
+        at_root = nd.lo.empty() && nd.hi.empty() && node_caps.empty();
+        return true;
+    }
+
+    void node_master(const BPNode &nd, double cutoff, double tol, NodeLP &out, std::vector<char> &usable) {
+        const int K = P.K, G = P.G;
+        out = NodeLP(); out.bound = nd.bound;
+        if (!fetch_patterns()) return;
+        usable.assign(cuts.size(), 1);
+        for (size_t k = 0; k < cuts.size(); k++) {
+            const std::vector<uint16_t> &x = cuts[k].x;
+            for (auto &l : nd.lo) if ((int32_t)x[l.first] < l.second) { usable[k] = 0; break; }
+            if (usable[k]) for (auto &h : nd.hi) if ((int32_t)x[h.first] > h.second) { usable[k] = 0; break; }
+            if (usable[k]) for (auto &h : node_caps) if ((int32_t)x[h.first] > h.second) { usable[k] = 0; break; }
+        }
+        std::vector<double> hN(P.h); double cN = 0.0;
+        std::vector<int> freeg;
+        for (int g = 0; g < G; g++) {
+            if (nd.flag[g] < 0) { freeg.push_back(g); continue; }
+            cN += P.gcost[g] * (double)nd.flag[g];
+            for (auto &t : P.g_rows[g]) hN[t.first] -= t.second * (double)nd.flag[g];
+        }
+        const int F = (int)freeg.size();
+        Rows M; M.n = K + 1 + F;
+        std::vector<double> mc(M.n), mlb(M.n, 0.0), mub(M.n);
+        for (int k = 0; k < K; k++) { mc[k] = -hN[k] / theta_scale; mub[k] = pmax[k]; }
+        mc[K] = -1.0; mub[K] = 4.0;
+        for (int i = 0; i < F; i++) { mc[K + 1 + i] = -1.0; mub[K + 1 + i] = 4.0; }
+        std::vector<std::pair<int, double>> terms;
+        std::vector<double> row_scale; std::vector<int> row_cut;
+        for (int i = 0; i < F; i++) {  // mu_g + pi.A_g >= c_g
+            const int g = freeg[i];
+            terms.clear(); double sc = 1.0;
+            for (auto &t : P.g_rows[g]) { const double v = t.second / theta_scale; terms.push_back({t.first, v}); sc = std::max(sc, std::fabs(v)); }
+            terms.push_back({K + 1 + i, 1.0});
+            for (auto &t : terms) t.second /= sc;
+            M.add(terms, P.gcost[g] / theta_scale / sc, INF);
+            row_scale.push_back(sc); row_cut.push_back(-1);
+        }
+        Tab mt;
+        auto add_cut = [&](size_t k, bool live) {
+            const Cut &c = cuts[k];
+            terms.clear(); double sc = 1.0;
+            for (int r = 0; r < K; r++) if (c.act[r] != 0) { const double v = (double)c.act[r] / theta_scale; terms.push_back({r, v}); sc = std::max(sc, std::fabs(v)); }
+            terms.push_back({K, 1.0});
+            for (auto &t : terms) t.second /= sc;
+            M.add(terms, c.cx / theta_scale / sc, INF);
+            row_scale.push_back(sc); row_cut.push_back((int)k);
+            if (live) mt.where.push_back(-1);
+        };
+        for (size_t k = 0; k < cuts.size(); k++) if (usable[k]) add_cut(k, false);
+        mt.init(&M, mc, mlb, mub);
+        auto node_value = [&](const Cut &c) {  // the node's Lagrangian at the cut's prices
+            double L = c.bnd + cN;
+            for (int k = 0; k < K; k++) L += c.pi[k] * hN[k];
+            for (int g : freeg) { double r = P.gcost[g]; for (auto &t : P.g_rows[g]) r -= c.pi[t.first] * t.second; if (r > 0.0) L += r; }
+            return L;
+        };
+        std::vector<double> pi(K), pi_best, prev;
+        bool ok = false;
+        for (int it = 0; it < 80; it++) {
+            ok = false;
+            if (mt.solve(200000) != LP_OPT) break;
+            ok = true;
+            const double lbm = -mt.objective() * theta_scale + cN;
+            if (out.bound <= cutoff) { out.pruned = true; break; }
+            if (out.bound - lbm <= tol * std::fabs(out.bound)) break;
+            bool same = !prev.empty();
+            for (int k = 0; k < K && same; k++) same = std::fabs(mt.x[k] - prev[k]) <= 1e-15 + 1e-12 * std::fabs(mt.x[k]);
+            prev.assign(mt.x.begin(), mt.x.begin() + K);
+            const double alpha = (it < 2 || same || pi_best.empty()) ? 0.0 : 0.3;
+            for (int k = 0; k < K; k++) pi[k] = (alpha > 0.0 ? alpha * pi_best[k] : 0.0) + (1.0 - alpha) * mt.x[k];
+            const int ci = evaluate(pi);
+            if (ci < 0) { ok = false; break; }
+            usable.push_back(1);
+            const double L = node_value(cuts[ci]);
+            if (L < out.bound) { out.bound = L; pi_best = pi; }
+            add_cut((size_t)ci, true);
+        }
+        if (!ok || out.pruned) return;
+        out.lambda.assign(cuts.size(), 0.0); out.bfrac.assign(G, 0.0);
+        double lsum = 0.0;
+        for (int r = 0; r < M.m; r++) {
+            const int a = mt.where[r];
+            if (a < 0 || mt.st[M.n + a] == BASIC) continue;
+            const double v = std::fabs(mt.d[M.n + a]) / row_scale[r];
+            if (row_cut[r] >= 0) { out.lambda[row_cut[r]] = v; lsum += v; } else out.bfrac[freeg[r]] = std::min(1.0, v);
+        }
+        for (int g = 0; g < G; g++) if (nd.flag[g] >= 0) out.bfrac[g] = (double)nd.flag[g];
+        if (lsum > 0.0) for (double &l : out.lambda) l /= lsum; else out.lambda.clear();
+        out.pi.assign(mt.x.begin(), mt.x.begin() + K);
     }
 };
 
@@ -439,7 +605,8 @@ Answer solve(const Request &rq, Sweeper &sw) {
     Prob &P = S.P;
     const int K = P.K, G = P.G;
     sw.stat_sweeps = 0; sw.stat_sweep_us = 0;
-    if (!sw.begin(P.T, MAX_SWEEPS)) { ans.why = "sweeper refused the model"; return ans; }
+    S.max_sweeps = (int)std::min<size_t>(4096, std::max<size_t>(256, ((size_t)64 << 20) / ((size_t)P.T.n_cols * 2 + 1)));  // the device keeps every sweep's patterns: at most 64 MB of them
+    if (!sw.begin(P.T, (uint32_t)S.max_sweeps)) { ans.why = "sweeper refused the model"; return ans; }
     struct Ender { Sweeper &s; ~Ender() { s.end(); } } ender{sw};
     // price caps: beyond pmax every column of the row has a negative reduced cost (`<=` rows); for `>=` rows a multiple of the largest cost per unit
     S.pmax.assign(K, 0.0);
@@ -618,7 +785,70 @@ Answer solve(const Request &rq, Sweeper &sw) {
         }
         if (S.failed) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
     }
-    ans.bound = S.relaxed_bound;
+    // ---- branch and price: what the configurations above leave open, on models small enough for a few hundred more sweeps to be cheap ----
+    double bp_bound = INF;
+    if (best_value > -INF && !certified() && !S.failed && P.T.n_cols <= 16384) {
+        S.base_caps = true;  // every node sets its own column bounds from here on
+        int col_nodes = 0;  // branching on single columns moves the bound of these models very little (a mixing worker passes its role to the next one): a short leash
+        auto closes = [&](double bound) { return bound <= best_value + rq.rel_gap * std::fabs(best_value); };
+        std::vector<BPNode> stack;
+        { BPNode root; root.flag.assign(G, -1); root.bound = S.relaxed_bound; stack.push_back(std::move(root)); }
+        double closed_max = -INF;  // the largest bound among the closed nodes: with the open ones it bounds the model
+        int nodes = 0;
+        std::vector<int32_t> lo_arr, hi_arr; std::vector<char> usable;
+        while (!stack.empty() && nodes < BP_MAX_NODES && (int)S.cuts.size() + 8 < S.max_sweeps && !S.failed) {
+            BPNode nd = std::move(stack.back()); stack.pop_back();
+            if (closes(nd.bound)) { closed_max = std::max(closed_max, nd.bound); continue; }
+            nodes++;
+            if (!S.apply_node(nd, lo_arr, hi_arr)) { if (S.failed) break; continue; }  // empty node
+            Solver::NodeLP lp;
+            S.node_master(nd, best_value, std::max(2e-6, rq.rel_gap / 20.0), lp, usable);
+            if (S.failed) break;
+            if (lp.pruned || closes(lp.bound)) { closed_max = std::max(closed_max, std::min(lp.bound, nd.bound)); continue; }
+            if (lp.lambda.empty()) { stack.push_back(std::move(nd)); break; }  // no usable multipliers (master trouble): leave the node open
+            nd.bound = std::min(nd.bound, lp.bound);
+            // flags first: the free flag whose LP value is least decided
+            int bg = -1; double bd = 1e-6;
+            for (int g = 0; g < G; g++) if (nd.flag[g] < 0) { const double d = std::min(lp.bfrac[g], 1.0 - lp.bfrac[g]); if (d > bd) { bd = d; bg = g; } }
+            if (bg < 0) {  // every flag is 0 or 1 in the LP point: the node's patterns make a point
+                std::vector<double> Bn(G), hBn(P.h);
+                for (int g = 0; g < G; g++) { Bn[g] = lp.bfrac[g] > 0.5 ? 1.0 : 0.0; for (auto &t : P.g_rows[g]) hBn[t.first] -= t.second * Bn[g]; }
+                std::vector<uint16_t> xf = S.round_patterns(lp.lambda, lp.pi, hBn, &usable, &lo_arr);
+                if (!xf.empty()) {
+                    std::vector<double> x(rq.n, 0.0);
+                    for (uint32_t f = 0; f < P.T.n_cols; f++) x[P.model_of[f]] = (double)xf[f];
+                    for (int g = 0; g < G; g++) x[P.gmodel[g]] = Bn[g];
+                    double value = 0.0;
+                    if (rq.polish && rq.polish(x, value) && value > best_value) { best_value = value; ans.x = x; ans.x_value = value; }
+                }
+                if (closes(nd.bound)) { closed_max = std::max(closed_max, nd.bound); continue; }
+            }
+            BPNode a = nd, b = nd; a.depth = b.depth = nd.depth + 1;
+            if (bg >= 0) {
+                const int8_t first = lp.bfrac[bg] > 0.5 ? 1 : 0;
+                a.flag[bg] = first; b.flag[bg] = (int8_t)(1 - first);
+            } else {  // the block column whose LP value is furthest from an integer (cost-weighted)
+                if (++col_nodes > 48) { stack.push_back(std::move(nd)); break; }
+                int bf = -1; double bs = 1e-7, bv = 0.0;
+                std::vector<double> xl(P.T.n_cols, 0.0);
+                for (size_t k = 0; k < S.cuts.size(); k++) { const double l = k < lp.lambda.size() ? lp.lambda[k] : 0.0; if (l <= 0.0 || !usable[k]) continue; const uint16_t *px = S.cuts[k].x.data(); for (uint32_t f = 0; f < P.T.n_cols; f++) xl[f] += l * (double)px[f]; }
+                for (uint32_t f = 0; f < P.T.n_cols; f++) { const double fr = xl[f] - std::floor(xl[f]); const double sc = std::min(fr, 1.0 - fr) * (P.T.col_cost[f] + 1e-9); if (std::min(fr, 1.0 - fr) > 1e-6 && sc > bs) { bs = sc; bf = (int)f; bv = xl[f]; } }
+                if (bf < 0) { closed_max = std::max(closed_max, nd.bound); continue; }  // an integral LP point that still did not close: nothing to branch on (its value IS the bound)
+                const int32_t fl = (int32_t)std::floor(bv);
+                BPNode dn = nd, up = nd; dn.depth = up.depth = nd.depth + 1;
+                dn.hi.push_back({(uint32_t)bf, fl}); up.lo.push_back({(uint32_t)bf, fl + 1});
+                if (bv - fl < 0.5) { a = std::move(dn); b = std::move(up); } else { a = std::move(up); b = std::move(dn); }
+            }
+            stack.push_back(std::move(b)); stack.push_back(std::move(a));  // (a = the child nearer to the LP point: popped first)
+        }
+        bp_bound = closed_max;
+        for (const BPNode &nd : stack) bp_bound = std::max(bp_bound, nd.bound);
+        if (rq.trace) fprintf(stderr, "[price] branch and price: %d nodes, %zu left open, %zu sweeps in all, bound %.9f, incumbent %.9f\n", nodes, stack.size(), S.cuts.size(), bp_bound, best_value);
+        // back to the model's own bounds (a later caller of this sweeper starts from begin() anyway)
+        S.node_lo.clear(); S.at_root = true;
+        if (S.failed) { ans.ran = false; ans.why = "sweep failed"; ans.x.clear(); return ans; }
+    }
+    ans.bound = std::min(S.relaxed_bound, bp_bound > -INF ? bp_bound : INF);
     ans.sweeps = (uint32_t)sw.stat_sweeps;
     // for the host's guided windows: blocks, their values and the reduced costs at the last prices
     if (!final_pi.empty()) {

@@ -37,8 +37,9 @@ struct Sweeper {
     virtual ~Sweeper() {}
     virtual bool begin(const HostTables &t, uint32_t max_sweeps) = 0;       // false: cannot run this model (the host search takes over)
     virtual bool set_caps(const int32_t *col_cap) = 0;                      // new column bounds for the following sweeps
+    virtual bool set_block_caps(const double *blk_cap) = 0;                 // new row capacities [n_blocks * 4] (a branch that fixes part of a block's content)
     virtual bool sweep(const double *pi, SweepTotals &out) = 0;             // sweep number = count of sweeps since begin()
-    virtual const uint16_t *patterns(uint32_t n_sweeps) = 0;                // host pointer to the patterns of sweeps [0, n_sweeps): [n_sweeps][n_cols]
+    virtual const uint16_t *patterns(uint32_t first, uint32_t count) = 0;   // host pointer to the patterns of sweeps [first, first + count): [count][n_cols]
     virtual void end() = 0;
     uint32_t min_cols = 256;    // components below this many columns stay with the host search (a sweep is ~80 us whatever the block count: below ~250 columns the host tree is usually done first)
     uint32_t budget = 4096;     // search steps per block and sweep

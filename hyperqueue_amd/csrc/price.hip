@@ -120,6 +120,13 @@ bool DeviceSweeper::set_caps(const int32_t *col_cap) {
     return hipMemcpyAsync(d_tab.as<unsigned char>() + o_ccap, h_stage.as<unsigned char>() + o_ccap, (size_t)T->n_cols * 4, hipMemcpyHostToDevice, stream) == hipSuccess;
 }
 
+bool DeviceSweeper::set_block_caps(const double *blk_cap) {
+    if (!T) return false;
+    const size_t bytes = (size_t)T->n_blocks * MMAX * 8;
+    memcpy(h_stage.as<unsigned char>() + o_cap, blk_cap, bytes);
+    return hipMemcpyAsync(d_tab.as<unsigned char>() + o_cap, h_stage.as<unsigned char>() + o_cap, bytes, hipMemcpyHostToDevice, stream) == hipSuccess;
+}
+
 bool DeviceSweeper::sweep(const double *pi, SweepTotals &out) {
     if (!T || n_sweeps >= cap_sweeps) return false;
     const HostTables &t = *T;
@@ -161,11 +168,12 @@ bool DeviceSweeper::sweep(const double *pi, SweepTotals &out) {
     return true;
 }
 
-const uint16_t *DeviceSweeper::patterns(uint32_t n) {
-    if (!T || n > n_sweeps) return nullptr;
-    const size_t bytes = (size_t)n * T->n_cols * 2;
+const uint16_t *DeviceSweeper::patterns(uint32_t first, uint32_t count) {
+    if (!T || first + count > n_sweeps) return nullptr;
+    const size_t bytes = (size_t)count * T->n_cols * 2;
     if (!h_pats.ensure(bytes + 64)) return nullptr;
-    if (hipMemcpyAsync(h_pats.p, d_pats.p, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return nullptr;
+    if (count == 0) return h_pats.as<uint16_t>();
+    if (hipMemcpyAsync(h_pats.p, d_pats.as<uint16_t>() + (size_t)first * T->n_cols, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return nullptr;
     if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
     return h_pats.as<uint16_t>();
 }

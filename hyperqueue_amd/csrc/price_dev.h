@@ -24,8 +24,9 @@ struct DeviceSweeper : Sweeper {
     ~DeviceSweeper() override;
     bool begin(const HostTables &t, uint32_t max_sweeps) override;
     bool set_caps(const int32_t *col_cap) override;
+    bool set_block_caps(const double *blk_cap) override;
     bool sweep(const double *pi, SweepTotals &out) override;
-    const uint16_t *patterns(uint32_t n_sweeps) override;
+    const uint16_t *patterns(uint32_t first, uint32_t count) override;
     void end() override;
 };
 

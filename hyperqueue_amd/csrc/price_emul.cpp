@@ -10,18 +10,19 @@
 namespace hqprice {
 
 bool EmulatedSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
-    T = &t; caps = t.col_cap; n_sweeps = 0; cap_sweeps = max_sweeps;
+    T = &t; caps = t.col_cap; bcaps = t.blk_cap; n_sweeps = 0; cap_sweeps = max_sweeps;
     pats.clear();
     blk_cx.assign(t.n_blocks, 0.0); blk_rc.assign(t.n_blocks, 0.0); blk_bnd.assign(t.n_blocks, 0.0); blk_steps.assign(t.n_blocks, 0);
     return t.K <= (uint32_t)KMAX;
 }
 bool EmulatedSweeper::set_caps(const int32_t *c) { caps.assign(c, c + T->n_cols); return true; }
+bool EmulatedSweeper::set_block_caps(const double *c) { bcaps.assign(c, c + (size_t)T->n_blocks * MMAX); return true; }
 bool EmulatedSweeper::sweep(const double *pi, SweepTotals &out) {
     if (n_sweeps >= cap_sweeps) return false;
     static thread_local hqblock::Shared *S = new hqblock::Shared();
     hqblock::HostWave wv;
     const HostTables &t = *T;
-    Tables tv{t.n_blocks, t.n_cols, t.K, t.blk_off.data(), t.blk_m.data(), t.blk_cap.data(), t.col_cost.data(), t.col_a.data(), caps.data(), t.col_woff.data(), t.w_row.data(), t.w_coef.data()};
+    Tables tv{t.n_blocks, t.n_cols, t.K, t.blk_off.data(), t.blk_m.data(), bcaps.data(), t.col_cost.data(), t.col_a.data(), caps.data(), t.col_woff.data(), t.w_row.data(), t.w_coef.data()};
     pats.resize((size_t)(n_sweeps + 1) * t.n_cols);
     std::vector<long long> slots((size_t)ASLOTS * t.K, 0);
     SweepOut so{pats.data() + (size_t)n_sweeps * t.n_cols, blk_cx.data(), blk_rc.data(), blk_bnd.data(), slots.data(), blk_steps.data(), nullptr};
@@ -42,7 +43,7 @@ bool EmulatedSweeper::sweep(const double *pi, SweepTotals &out) {
     n_sweeps++;
     return true;
 }
-const uint16_t *EmulatedSweeper::patterns(uint32_t n) { return n <= n_sweeps ? pats.data() : nullptr; }
+const uint16_t *EmulatedSweeper::patterns(uint32_t first, uint32_t count) { return first + count <= n_sweeps ? pats.data() + (size_t)first * T->n_cols : nullptr; }
 void EmulatedSweeper::end() {}
 
 }  // namespace hqprice

@@ -10,14 +10,16 @@ namespace hqprice {
 struct EmulatedSweeper : Sweeper {
     const HostTables *T = nullptr;
     std::vector<int32_t> caps;
+    std::vector<double> bcaps;
     std::vector<uint16_t> pats;
     std::vector<double> blk_cx, blk_rc, blk_bnd;
     std::vector<uint32_t> blk_steps;
     uint32_t n_sweeps = 0, cap_sweeps = 0;
     bool begin(const HostTables &t, uint32_t max_sweeps) override;
     bool set_caps(const int32_t *col_cap) override;
+    bool set_block_caps(const double *blk_cap) override;
     bool sweep(const double *pi, SweepTotals &out) override;
-    const uint16_t *patterns(uint32_t n_sweeps) override;
+    const uint16_t *patterns(uint32_t first, uint32_t count) override;
     void end() override;
 };
 

@@ -19,6 +19,25 @@ def _objective(model, res):
     return float(np.dot(model["obj"], x))
 
 
+def _completed_objective(model, res):
+    """c.x of a result's counts completed with the best values of the model's other columns (flag columns of blocked workers carry part of the objective,
+    and the hook exports placement counts only): the placement columns fixed, HiGHS picks the rest"""
+    from oracle.oracle import solve_milp
+
+    cd = {(q, v, w): c for (q, v, w, c) in res.counts}
+    n = len(model["obj"])
+    roff, rcol, rcoef = list(model["roff"]), list(model["rcol"]), list(model["rcoef"])
+    rtype, rhs = list(model["rtype"]), list(model["rhs"])
+    for j in range(n):
+        if model["ctype"][j] == 0:
+            v = cd.get((int(model["crq"][j]), int(model["cvariant"][j]), int(model["cworker"][j])), 0)
+            for t in (0, 1):  # x_j >= v and x_j <= v
+                rcol.append(j), rcoef.append(1.0), roff.append(len(rcol)), rtype.append(t), rhs.append(float(v))
+    out = solve_milp(model["obj"], model["kind"], np.asarray(rtype, np.uint8), np.asarray(rhs, float), np.asarray(roff), np.asarray(rcol), np.asarray(rcoef, float), time_limit=60.0)
+    assert out is not None, "the placement counts admit no completion: infeasible point"
+    return out[1]
+
+
 def _same_host_part(got, want, model):
     assert got.status == want.status and got.is_optimal == want.is_optimal
     assert got.batches == want.batches

@@ -11,7 +11,7 @@ import pytest
 from host_stages import HostStages
 from hyperqueue_amd import abi, workloads
 from hyperqueue_amd.core import priority_from_user
-from test_host_stages import _objective
+from test_host_stages import _completed_objective, _objective
 
 
 def stages(snap, emulate: bool, min_cols: int = 0, tl: float = 5.0):
@@ -121,9 +121,9 @@ def test_heterogeneous_coupled_ticks_by_price_sweeps(W, seed, n_ready, levels):
     zg, zh = _objective(model, got), _objective(model, host)
     if got.is_optimal and host.is_optimal:
         assert abs(zg - zh) <= 1e-4 * max(zg, zh) + 1e-12, (zg, zh, sweeps)
-    if got.is_optimal and want.is_optimal:  # (placement columns only on both sides: the flag columns of blocked workers carry a sliver of the objective)
-        zw = _objective(model, want)
-        assert zg >= zw * (1.0 - 1e-4) - 1e-12, (zg, zw, sweeps)
+    if got.is_optimal and want.is_optimal:  # the whole objective on both sides: the flag columns of blocked workers carry part of it
+        zg_all, zw_all = _completed_objective(model, got), float(model["objective"])
+        assert zg_all >= zw_all * (1.0 - 1e-4) - 1e-12, (zg_all, zw_all, sweeps)
 
 
 @pytest.mark.parametrize("variant", ["unsaturated", "priorities"])

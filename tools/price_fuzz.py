@@ -36,15 +36,18 @@ def one(seed):
     snap, W, levels, steady, n_ready = scenario(seed)
     t0 = time.time(); got, sweeps, rounds = stages(snap, True, min_cols=16, tl=5.0); tg = time.time() - t0
     t0 = time.time(); host, _, _ = stages(snap, False, tl=5.0); th = time.time() - t0
-    o = Oracle(abi.make_config(time_limit_s=0.05), reference_solver_options=True)
+    with_highs = os.environ.get("PRICE_FUZZ_HIGHS") == "1"  # also time the reference-configured HiGHS (5 s limit) on the same snapshot
+    o = Oracle(abi.make_config(time_limit_s=5.0 if with_highs else 0.05), reference_solver_options=True)
+    t0 = time.time(); opt_ref = None
     try:
-        o.tick(snap)
+        opt_ref = bool(o.tick(snap).is_optimal)
     except Exception:
         pass
+    tr = time.time() - t0
     m = o.last_model()
     zg, zh = _objective(m, got), _objective(m, host)
     bad = got.is_optimal and host.is_optimal and abs(zg - zh) > 1e-4 * max(zg, zh) + 1e-12
-    return dict(seed=seed, W=W, levels=levels, steady=steady, n=n_ready, sweeps=sweeps, rounds=rounds, opt_g=bool(got.is_optimal), opt_h=bool(host.is_optimal), zg=zg, zh=zh, tg=tg, th=th, bad=bool(bad))
+    return dict(seed=seed, W=W, levels=levels, steady=steady, n=n_ready, sweeps=sweeps, rounds=rounds, opt_g=bool(got.is_optimal), opt_h=bool(host.is_optimal), zg=zg, zh=zh, tg=tg, th=th, bad=bool(bad), opt_ref=opt_ref if with_highs else None, tr=tr, zr=float(m["objective"]) if with_highs else None, cols=len(m["obj"]))
 
 
 def main():
@@ -60,6 +63,10 @@ def main():
     ran = [r for r in rows if r["sweeps"] > 0]
     print(f"{len(rows)} scenarios, sweeps ran on {len(ran)}, certified with sweeps {sum(r['opt_g'] for r in ran)}, host-only certified {sum(r['opt_h'] for r in rows)}, "
           f"sweeps better by >1e-4: {sum(1 for r in rows if r['zg'] > r['zh'] * (1 + 1e-4))}, host better by >1e-4: {sum(1 for r in rows if r['zh'] > r['zg'] * (1 + 1e-4))}, disagreements among certified: {len(bad)}")
+    if rows and rows[0]["opt_ref"] is not None:
+        print(f"reference-configured HiGHS (5 s): certified {sum(1 for r in rows if r['opt_ref'])}; certified by HiGHS but not by the sweeps path: "
+              f"{[ (r['seed'], r['W'], r['levels'], r['cols'], round(r['tr'], 2)) for r in rows if r['opt_ref'] and not r['opt_g']]}; by the sweeps path but not HiGHS: {sum(1 for r in rows if r['opt_g'] and not r['opt_ref'])}; "
+              f"HiGHS time {sum(r['tr'] for r in rows):.1f} s")
     print(f"time: sweeps path {sum(r['tg'] for r in rows):.1f} s, host path {sum(r['th'] for r in rows):.1f} s")
 
 
