@@ -229,6 +229,8 @@ struct Cut {
     double cx = 0, bnd = 0; std::vector<long long> act; std::vector<double> pi;
     // the maximisers, one integer pattern per block, in the model's own variables: fetched from the device on demand (the sweep solved in variables shifted by `lo`)
     std::vector<uint16_t> x; bool fetched = false; std::vector<std::pair<uint32_t, int32_t>> lo;
+    // the same per part of the model (PARTS contiguous ranges of blocks): the root master keeps one value function per part
+    std::vector<double> pcx; std::vector<long long> pact;  // [PARTS], [PARTS * K]
 };
 
 // a node of the branch-and-price phase: flags fixed or free, bounds on single block columns
@@ -261,6 +263,10 @@ struct Solver {
         Cut c; c.cx = tot.cx; c.bnd = tot.bnd; c.pi = pi;
         c.act.resize(P.K);
         for (int k = 0; k < P.K; k++) c.act[k] = tot.act[P.grp_of[k]];
+        if (node_lo.empty() && tot.part_cx.size() == (size_t)PARTS && tot.part_act.size() == (size_t)PARTS * P.KG) {
+            c.pcx = tot.part_cx; c.pact.resize((size_t)PARTS * P.K);
+            for (int p = 0; p < PARTS; p++) for (int k = 0; k < P.K; k++) c.pact[(size_t)p * P.K + k] = tot.part_act[(size_t)p * P.KG + P.grp_of[k]];
+        }
         if (!node_lo.empty()) {  // the sweep ran in variables shifted by the node's lower bounds: back to the model's own (c.l, A.l and the bound's (c - pi A).l)
             c.lo = node_lo; c.cx += node_cl; c.bnd += node_cl;
             for (int k = 0; k < P.K; k++) { c.act[k] += (long long)std::llround(node_Al[k]); c.bnd -= pi[k] * node_Al[k]; }
@@ -282,27 +288,37 @@ struct Solver {
     // Cutting-plane master (Kelley) for the model with its flags fixed: minimise pi.hB + theta over theta + pi.act_k >= cx_k.  Returns false when the
     // configuration cannot beat `cutoff` (or is infeasible); on success `lambda` holds the master's multipliers of the cuts (summing to 1) and pi_out
     // the final prices.
+    //
+    // The master is DISAGGREGATED over the model's parts: sum_w V_w(pi) is a sum over PARTS contiguous ranges of workers, every sweep returns each part's
+    // own c.x and activities, and the master keeps one theta per part — its model of the dual function is the sum of PARTS piecewise-linear models
+    // instead of one, which takes a third of the sweeps to the same accuracy (the first wave of the layered config-5 DAG: 61 -> 19-22).  The workers
+    // are in objective order (factor (W - idx) / W, solver.rs:542-571), so contiguous ranges are the parts that differ most from one another.
     bool kelley(const std::vector<double> &hB, double cB, double cutoff, double tol, std::vector<double> &lambda, std::vector<double> &pi_out, double *bound_out) {
         const int K = P.K;
-        Rows M; M.n = K + 1;
-        std::vector<double> mc(K + 1), mlb(K + 1, 0.0), mub(K + 1);
+        const uint32_t per = (P.T.n_blocks + PARTS - 1) / PARTS;
+        const int NP = (int)((P.T.n_blocks + per - 1) / per);  // parts that hold blocks
+        Rows M; M.n = K + NP;
+        std::vector<double> mc(K + NP), mlb(K + NP, 0.0), mub(K + NP);
         for (int k = 0; k < K; k++) { mc[k] = -hB[k] / theta_scale; mub[k] = pmax[k]; }
-        mc[K] = -1.0; mub[K] = 4.0;
+        for (int p = 0; p < NP; p++) { mc[K + p] = -1.0; mub[K + p] = 4.0; }
         std::vector<double> cut_scale;
         std::vector<std::pair<int, double>> terms;
         size_t in_master = cut_lo;
         auto push_cuts = [&](Tab *mt) {
             for (; in_master < cuts.size(); in_master++) {
                 const Cut &c = cuts[in_master];
-                terms.clear(); double sc = 1.0;
-                for (int k = 0; k < K; k++) if (c.act[k] != 0) { const double v = (double)c.act[k] / theta_scale; terms.push_back({k, v}); sc = std::max(sc, std::fabs(v)); }
-                terms.push_back({K, 1.0});
-                for (auto &t : terms) t.second /= sc;
-                M.add(terms, c.cx / theta_scale / sc, INF);
-                cut_scale.push_back(sc);
-                if (mt) mt->where.push_back(-1);
+                for (int p = 0; p < NP; p++) {
+                    terms.clear(); double sc = 1.0;
+                    for (int k = 0; k < K; k++) { const long long a = c.pact[(size_t)p * K + k]; if (a != 0) { const double v = (double)a / theta_scale; terms.push_back({k, v}); sc = std::max(sc, std::fabs(v)); } }
+                    terms.push_back({K + p, 1.0});
+                    for (auto &t : terms) t.second /= sc;
+                    M.add(terms, c.pcx[p] / theta_scale / sc, INF);
+                    cut_scale.push_back(sc);
+                    if (mt) mt->where.push_back(-1);
+                }
             }
         };
+        for (size_t k = cut_lo; k < cuts.size(); k++) if (cuts[k].pcx.empty()) { if (rq.trace) fprintf(stderr, "[price] master: cut %zu without part sums\n", k); return false; }  // (a sweeper without part sums: cannot happen with the two in this tree)
         push_cuts(nullptr);
         Tab mt; mt.init(&M, mc, mlb, mub);
         double ub_best = INF; std::vector<double> pi_best(K, 0.0);
@@ -331,11 +347,28 @@ struct Solver {
             lb_master = -mt.objective() * theta_scale + cB;
             if (ub_best - lb_master > 1e-3 * std::fabs(ub_best)) { if (rq.trace) fprintf(stderr, "[price] master not converged: %.9f vs %.9f\n", ub_best, lb_master); return false; }  // nowhere near: no usable multipliers
         }
-        lambda.assign(cuts.size(), 0.0);
-        double lsum = 0.0;
-        for (size_t k = 0; k + cut_lo < cuts.size() && k < (size_t)M.m; k++) { const int a = mt.where[k]; if (a >= 0 && mt.st[M.n + a] != BASIC) { lambda[k + cut_lo] = std::fabs(mt.d[M.n + a]) / cut_scale[k]; lsum += lambda[k + cut_lo]; } }
-        if (!(lsum > 0.0)) return false;
-        for (double &l : lambda) l /= lsum;
+        // multipliers per (cut, part): every part's sum to 1
+        lambda.assign(cuts.size() * PARTS, 0.0);
+        std::vector<double> lsum(NP, 0.0);
+        for (size_t r = 0; r / NP + cut_lo < cuts.size() && r < (size_t)M.m; r++) {
+            const int a = mt.where[r];
+            if (a < 0 || mt.st[M.n + a] == BASIC) continue;
+            const size_t k = r / NP + cut_lo; const int p = (int)(r % NP);
+            const double v = std::fabs(mt.d[M.n + a]) / cut_scale[r];
+            lambda[k * PARTS + p] = v; lsum[p] += v;
+        }
+        for (int p = 0; p < NP; p++) if (!(lsum[p] > 0.0)) {
+            // no cut of the part binds: its theta sits on its bound 0 — at the final prices the part's workers take nothing (or nothing worth anything).
+            // Its point is the pattern of the cut that is worth most at those prices.
+            size_t bk = cut_lo; double bv = -INF;
+            for (size_t k = cut_lo; k < cuts.size(); k++) {
+                double v = cuts[k].pcx[p];
+                for (int r = 0; r < K; r++) v -= mt.x[r] * (double)cuts[k].pact[(size_t)p * K + r];
+                if (v > bv) { bv = v; bk = k; }
+            }
+            lambda[bk * PARTS + p] = 1.0; lsum[p] = 1.0;
+        }
+        for (size_t k = cut_lo; k < cuts.size(); k++) for (int p = 0; p < NP; p++) lambda[k * PARTS + p] /= lsum[p];
         pi_out.assign(mt.x.begin(), mt.x.begin() + K);
         *bound_out = ub_best;
         return true;
@@ -370,14 +403,24 @@ struct Solver {
         const uint32_t S = (uint32_t)cuts.size();
         if (!fetch_patterns()) return {};
         auto pat_of = [&](int k) { return cuts[(size_t)k].x.data(); };
+        // lambda: [cut * PARTS + part], every part's multipliers summing to 1 (a caller with one multiplier per cut repeats it for every part)
+        const uint32_t per = (T.n_blocks + PARTS - 1) / PARTS;
+        auto lam = [&](int k, uint32_t p) { return lambda[(size_t)k * PARTS + p]; };
         std::vector<int> active;
-        for (uint32_t k = 0; k < S; k++) if (lambda[k] > 1e-9 && (!usable || (*usable)[k])) active.push_back((int)k);
+        for (uint32_t k = 0; k < S; k++) {
+            if (usable && !(*usable)[k]) continue;
+            bool any = false; for (uint32_t p = 0; p < (uint32_t)PARTS && !any; p++) any = lam((int)k, p) > 1e-9;
+            if (any) active.push_back((int)k);
+        }
         if (active.empty()) return {};
-        double lsum = 0.0; for (int k : active) lsum += lambda[k];
         const int Q = (int)active.size();
         // row weights: relative deviation; rows the LP leaves slack count little
         std::vector<double> lpact(K, 0.0), wgt(K);
-        for (int k : active) for (int r = 0; r < K; r++) lpact[r] += lambda[k] / lsum * (double)cuts[k].act[r];
+        for (int k : active) {
+            const Cut &c = cuts[k];
+            if (c.pact.empty()) { for (int r = 0; r < K; r++) lpact[r] += lam(k, 0) * (double)c.act[r]; continue; }
+            for (uint32_t p = 0; p < (uint32_t)PARTS; p++) { const double l = lam(k, p); if (l > 0.0) for (int r = 0; r < K; r++) lpact[r] += l * (double)c.pact[(size_t)p * P.K + r]; }
+        }
         for (int r = 0; r < K; r++) {
             const bool tight = pi[r] > 1e-12 || hB[r] - lpact[r] <= 1e-6 * std::max(1.0, std::fabs(hB[r]));
             wgt[r] = (tight ? 1.0 : 0.02) / std::max(1.0, std::fabs(hB[r]));
@@ -391,13 +434,16 @@ struct Solver {
         std::vector<std::vector<double>> cand(Q, std::vector<double>(K));
         std::vector<int> chosen(T.n_blocks, 0);
         for (uint32_t b = 0; b < T.n_blocks; b++) {
-            for (int q = 0; q < Q; q++) { block_act(b, pat_of(active[q]), cand[q]); const double l = lambda[active[q]] / lsum; for (int r = 0; r < K; r++) tgt[r] += l * cand[q][r]; }
-            int bq = 0; double be = INF;
+            const uint32_t part = b / per;
+            for (int q = 0; q < Q; q++) { const double l = lam(active[q], part); if (!(l > 1e-9)) continue; block_act(b, pat_of(active[q]), cand[q]); for (int r = 0; r < K; r++) tgt[r] += l * cand[q][r]; }
+            int bq = -1; double be = INF;
             for (int q = 0; q < Q; q++) {
+                if (!(lam(active[q], part) > 1e-9)) continue;  // (only the cuts the part's LP point is made of: their patterns are optimal at the final prices)
                 double e = 0.0;
                 for (int r = 0; r < K; r++) e += std::fabs(cum[r] + cand[q][r] - tgt[r]) * wgt[r];
                 if (e < be - 1e-15) { be = e; bq = q; }
             }
+            if (bq < 0) return {};
             for (int r = 0; r < K; r++) cum[r] += cand[bq][r];
             chosen[b] = active[bq];
             memcpy(&x[T.blk_off[b]], pat_of(active[bq]) + T.blk_off[b], (size_t)(T.blk_off[b + 1] - T.blk_off[b]) * 2);
@@ -813,7 +859,9 @@ Answer solve(const Request &rq, Sweeper &sw) {
             if (bg < 0) {  // every flag is 0 or 1 in the LP point: the node's patterns make a point
                 std::vector<double> Bn(G), hBn(P.h);
                 for (int g = 0; g < G; g++) { Bn[g] = lp.bfrac[g] > 0.5 ? 1.0 : 0.0; for (auto &t : P.g_rows[g]) hBn[t.first] -= t.second * Bn[g]; }
-                std::vector<uint16_t> xf = S.round_patterns(lp.lambda, lp.pi, hBn, &usable, &lo_arr);
+                std::vector<double> lam_parts(lp.lambda.size() * PARTS);
+                for (size_t k = 0; k < lp.lambda.size(); k++) for (int p = 0; p < PARTS; p++) lam_parts[k * PARTS + p] = lp.lambda[k];
+                std::vector<uint16_t> xf = S.round_patterns(lam_parts, lp.pi, hBn, &usable, &lo_arr);
                 if (!xf.empty()) {
                     std::vector<double> x(rq.n, 0.0);
                     for (uint32_t f = 0; f < P.T.n_cols; f++) x[P.model_of[f]] = (double)xf[f];

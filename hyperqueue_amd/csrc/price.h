@@ -30,7 +30,11 @@ struct SweepTotals {
     double cx = 0, rc = 0, bnd = 0;     // sums over the blocks, in block order
     uint32_t n_budget = 0, max_steps = 0;
     std::vector<long long> act;         // [K]
+    // the same per PART of the model (PARTS contiguous ranges of blocks, price_core.h's ASLOTS): the master models every part's value function on its own
+    std::vector<double> part_cx;        // [PARTS]
+    std::vector<long long> part_act;    // [PARTS * K]
 };
+constexpr int PARTS = 16;
 
 // Where the sweeps run: the MI355X (csrc/price.hip) in the tick, the emulated wavefront (libhqtick_test.so) in the CPU tests.
 struct Sweeper {

@@ -29,12 +29,16 @@
 
 namespace hqprice {
 
+static_assert(PARTS == ASLOTS, "the master's parts are the kernel's activity slots");
+
 namespace {
 
 struct SweepResult {   // pinned host memory, written by the last workgroup of a sweep
     double cx, rc, bnd;
     uint32_t n_budget, max_steps;
     long long act[KMAX];
+    double part_cx[ASLOTS];
+    long long part_act[ASLOTS * KMAX];   // [part * K + k]: only the first ASLOTS * K entries are written
     uint32_t seq;      // written last (release, system scope)
 };
 
@@ -67,11 +71,21 @@ __global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
     }
     double *red = &S.py[0][0];  // the pool's storage again: 3 x 64 doubles + 2 x 64 words
     uint32_t *redu = reinterpret_cast<uint32_t *>(red + 3 * WAVE);
+    {   // c.x per part, in a fixed order: four lanes per part take every fourth block of its range, the first of them adds the four partial sums
+        const uint32_t per = part_size(nb), g = threadIdx.x >> 2, p = threadIdx.x & 3u;
+        const uint32_t b0 = g * per, b1 = b0 + per < nb ? b0 + per : nb;
+        double s = 0.0;
+        for (uint32_t b = b0 + p; b < b1; b += 4) s += a.out.blk_cx[b];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (p == 0) a.res->part_cx[g] = ((red[threadIdx.x] + red[threadIdx.x + 1]) + red[threadIdx.x + 2]) + red[threadIdx.x + 3];
+        __syncthreads();
+    }
     red[threadIdx.x] = cx; red[WAVE + threadIdx.x] = rc; red[2 * WAVE + threadIdx.x] = bnd; redu[threadIdx.x] = nbud; redu[WAVE + threadIdx.x] = mx;
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < a.t.K; k += WAVE) {  // the ASLOTS partial vectors -> the sweep's activities (and the slots ready for the next sweep)
         long long sum = 0;
-        for (int sl = 0; sl < ASLOTS; sl++) { sum += a.out.act[(size_t)sl * a.t.K + k]; a.out.act[(size_t)sl * a.t.K + k] = 0; }
+        for (int sl = 0; sl < ASLOTS; sl++) { const long long v = a.out.act[(size_t)sl * a.t.K + k]; sum += v; a.res->part_act[(size_t)sl * a.t.K + k] = v; a.out.act[(size_t)sl * a.t.K + k] = 0; }
         a.res->act[k] = sum;
     }
     if (threadIdx.x == 0) {
@@ -164,6 +178,9 @@ bool DeviceSweeper::sweep(const double *pi, SweepTotals &out) {
     out.cx = r->cx; out.rc = r->rc; out.bnd = r->bnd; out.n_budget = r->n_budget; out.max_steps = r->max_steps;
     out.act.resize(t.K);
     for (uint32_t k = 0; k < t.K; k++) out.act[k] = r->act[k];
+    out.part_cx.assign(r->part_cx, r->part_cx + ASLOTS);
+    out.part_act.resize((size_t)ASLOTS * t.K);
+    for (size_t i = 0; i < (size_t)ASLOTS * t.K; i++) out.part_act[i] = r->part_act[i];
     n_sweeps++;
     return true;
 }

@@ -23,7 +23,9 @@ using hqblock::Shared;
 using hqblock::WAVE;
 
 constexpr int KMAX = 128;  // distinct wide left-hand sides of one model (prices staged in LDS)
-constexpr int ASLOTS = 16; // the wide rows' activities are accumulated in ASLOTS partial vectors (block b adds into slot b % ASLOTS): 1024 blocks on one address serialise in L2
+constexpr int ASLOTS = 16; // the wide rows' activities are accumulated in ASLOTS partial vectors, one per PART of the model = contiguous range of blocks (block b adds into
+                           // slot b / ceil(n_blocks / ASLOTS)): 1024 blocks on one address serialise in L2 — and the master takes the parts' cuts one by one (price.h)
+HQB_HD uint32_t part_size(uint32_t n_blocks) { return (n_blocks + (uint32_t)ASLOTS - 1) / (uint32_t)ASLOTS; }
 
 // The model's blocks, flattened (device-visible memory).  Column q of block b is entry blk_off[b] + q of the col_* arrays.
 struct Tables {
@@ -208,7 +210,7 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
     });
     wv.sync();
     wv.each([&](int lane) {
-        long long *slot = out.act + (size_t)(b % (uint32_t)ASLOTS) * t.K;
+        long long *slot = out.act + (size_t)(b / part_size(t.n_blocks)) * t.K;
         for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) if (lact[k] != 0) wv.atomic_add_i64(&slot[k], lact[k]);
     });
     if (wv.first()) {

@@ -9,6 +9,8 @@
 
 namespace hqprice {
 
+static_assert(PARTS == ASLOTS, "the master's parts are the kernel's activity slots");
+
 bool EmulatedSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     T = &t; caps = t.col_cap; bcaps = t.blk_cap; n_sweeps = 0; cap_sweeps = max_sweeps;
     pats.clear();
@@ -29,6 +31,17 @@ bool EmulatedSweeper::sweep(const double *pi, SweepTotals &out) {
     for (uint32_t b = 0; b < t.n_blocks; b++) solve_priced_block(wv, *S, tv, pi, b, so, budget);
     out.act.assign(t.K, 0);
     for (int sl = 0; sl < ASLOTS; sl++) for (uint32_t k = 0; k < t.K; k++) out.act[k] += slots[(size_t)sl * t.K + k];
+    out.part_act = slots;
+    out.part_cx.assign(ASLOTS, 0.0);
+    {   // the device's order again: four lanes per part, every fourth block each, then the four partial sums
+        const uint32_t per = part_size(t.n_blocks);
+        for (uint32_t g = 0; g < (uint32_t)ASLOTS; g++) {
+            const uint32_t b0 = g * per, b1 = std::min(t.n_blocks, b0 + per);
+            double s4[4] = {0, 0, 0, 0};
+            for (uint32_t p = 0; p < 4; p++) for (uint32_t b = b0 + p; b < b1; b += 4) s4[p] += blk_cx[b];
+            out.part_cx[g] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
+        }
+    }
     // the device's order: lane l of the last workgroup adds blocks l, l + 64, ...; lane 0 then adds the 64 partial sums in lane order — the same
     // floating-point sums here, so that a GPU tick and the emulation walk the same sequence of prices
     double pcx[WAVE] = {0}, prc[WAVE] = {0}, pb[WAVE] = {0};
