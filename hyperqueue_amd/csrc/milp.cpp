@@ -156,7 +156,7 @@ struct CompSolver {
     static bool trace_enabled() { static const bool on = getenv("HQMILP_TRACE") != nullptr; return on; }
     bool tracing = trace_enabled();
     double t_begin = tracing ? wall() : 0.0;
-    void trace(const char *what) { if (tracing && !in_lns) fprintf(stderr, "[milp] n=%d t=%.3fs %s: incumbent %.9f nodes %ld\n", n, wall() - t_begin, what, have ? best : -1.0, nodes); }
+    void trace(const char *what) { if (tracing && !in_lns) fprintf(stderr, "[milp] n=%d t=%.6fs %s: incumbent %.9f nodes %ld\n", n, wall() - t_begin, what, have ? best : -1.0, nodes); }
     bool cannot_improve(double z) {
         if (!have) return false;
         if (z <= best + 1e-12 * std::fabs(best)) return true;
@@ -655,24 +655,7 @@ struct CompSolver {
 
     // returns: 0 infeasible, 1 optimal, 2 incumbent only (time limit)
     int run(bool canonical, std::vector<double> &xout) {
-        row_unit.assign((size_t)R.m, 0.0);
-        for (int i = 0; i < R.m && !in_lns && n <= 2000; i++) {  // (not inside the windows of the large-model search: their sub-models are tuned as they are)
-            const int a = R.off[i], b = R.off[i + 1];
-            if (b - a < 3 || !(R.coef[a] > 0.0) || R.lo[i] > -INF || !(R.hi[i] < INF)) continue;  // `<=` rows only (the tick's batch-size and resource rows)
-            bool same = true;
-            for (int k = a + 1; k < b && same; k++) same = R.coef[k] == R.coef[a];
-            if (same) row_unit[i] = R.coef[a];
-        }
-        Tab root; root.init(&R, c, lb, ub); root.deadline = deadline;
-        greedy_from(lb);
-        find_quantum();
-        // Portfolio over restarts from the root (the incumbent carries over): a plain dive, then strong branching, each with a node budget that
-        // quadruples per pair.  The dive finds incumbents and closes easy trees; strong branching proves plateaus the dive would need millions of
-        // nodes for; neither dominates, and a problem that needs N nodes of its better strategy is done after < 3 N.
-        long budget = std::min<long>(20000, std::max<long>(2000, 1300000 / std::max(1, n)));
-        const double hard_deadline = deadline;
-        const bool reserve_tail = n > 2000 && !in_lns;  // large model: the search below gets 70 % of the time, the window improvement the rest
-        if (reserve_tail) { const double t0 = wall(); deadline = t0 + 0.7 * (hard_deadline - t0); root.deadline = deadline; }
+        // (first: a model the sweeps certify needs neither the root tableau nor the greedy pass from zero below — 1.6 ms of a 3 ms tick at 8 k columns)
         if (sweeper && !in_lns && rel_gap > 0.0 && n >= (int)sweeper->min_cols && (int)col_group.size() == n) {
             // The coupled model by price sweeps (csrc/price.h): the wide rows priced out, every worker's block solved exactly per set of prices on the
             // MI355X, the incumbent rounded from the sweeps' own integer patterns.  Deterministic (no clock inside): replicas decide alike.
@@ -692,7 +675,6 @@ struct CompSolver {
                 nodes += pa.sweeps;
                 if (!pa.x.empty() && (!have || pa.x_value > best)) { bx = pa.x; best = pa.x_value; have = true; }
                 root_bound = std::min(root_bound, pa.bound * (1.0 + 1e-9) + 1e-12);
-                deadline = hard_deadline;
                 if (certified()) { canonical_done = false; xout = bx; trace("certified by the price sweeps"); return 1; }
                 if (have && n > 2000) {  // what the sweeps leave open goes to the host's window search, against their bound (smaller models: the tree below)
                     trace("window search against the price bound");
@@ -704,6 +686,24 @@ struct CompSolver {
                 }
             }
         }
+        row_unit.assign((size_t)R.m, 0.0);
+        for (int i = 0; i < R.m && !in_lns && n <= 2000; i++) {  // (not inside the windows of the large-model search: their sub-models are tuned as they are)
+            const int a = R.off[i], b = R.off[i + 1];
+            if (b - a < 3 || !(R.coef[a] > 0.0) || R.lo[i] > -INF || !(R.hi[i] < INF)) continue;  // `<=` rows only (the tick's batch-size and resource rows)
+            bool same = true;
+            for (int k = a + 1; k < b && same; k++) same = R.coef[k] == R.coef[a];
+            if (same) row_unit[i] = R.coef[a];
+        }
+        Tab root; root.init(&R, c, lb, ub); root.deadline = deadline;
+        greedy_from(lb);
+        find_quantum();
+        // Portfolio over restarts from the root (the incumbent carries over): a plain dive, then strong branching, each with a node budget that
+        // quadruples per pair.  The dive finds incumbents and closes easy trees; strong branching proves plateaus the dive would need millions of
+        // nodes for; neither dominates, and a problem that needs N nodes of its better strategy is done after < 3 N.
+        long budget = std::min<long>(20000, std::max<long>(2000, 1300000 / std::max(1, n)));
+        const double hard_deadline = deadline;
+        const bool reserve_tail = n > 2000 && !in_lns;  // large model: the search below gets 70 % of the time, the window improvement the rest
+        if (reserve_tail) { const double t0 = wall(); deadline = t0 + 0.7 * (hard_deadline - t0); root.deadline = deadline; }
         if (n > 2000 && have && !in_lns) {
             // Large model with block structure (an unsaturated tick of the whole cluster: one block per worker, the batch-size rows across): its LP bound
             // comes from the Lagrangian over the wide rows in a fraction of a second, and the rest of the time belongs to the window search, which stops

@@ -204,12 +204,14 @@ const char *build(const Request &rq, Prob &P) {
     // groups of rows with identical left-hand sides, and the device's column CSR over groups
     P.grp_of.assign(P.K, -1);
     {
-        std::map<std::vector<std::pair<int, int32_t>>, int> seen;
         std::vector<int> rep;
+        std::vector<uint64_t> sig(P.K);   // (a hash of the left-hand side first: the rows are a thousand terms long, an ordered map of them compares them term by term)
+        for (int k = 0; k < P.K; k++) { uint64_t h = 1469598103934665603ull; for (auto &t : wide[k].cols) { h = (h ^ (uint64_t)(uint32_t)t.first) * 1099511628211ull; h = (h ^ (uint64_t)(uint32_t)t.second) * 1099511628211ull; } sig[k] = h; }
         for (int k = 0; k < P.K; k++) {
-            auto it = seen.find(wide[k].cols);
-            if (it == seen.end()) { it = seen.emplace(wide[k].cols, (int)rep.size()).first; rep.push_back(k); }
-            P.grp_of[k] = it->second;
+            int g = -1;
+            for (size_t i = 0; i < rep.size() && g < 0; i++) if (sig[rep[i]] == sig[k] && wide[rep[i]].cols == wide[k].cols) g = (int)i;
+            if (g < 0) { g = (int)rep.size(); rep.push_back(k); }
+            P.grp_of[k] = g;
         }
         P.KG = (int)rep.size(); T.K = (uint32_t)P.KG;
         if (P.KG > KMAX_HOST) return "more than 128 distinct wide left-hand sides";
@@ -401,6 +403,7 @@ struct Solver {
                                          const std::vector<char> *usable = nullptr, const std::vector<int32_t> *lo_of = nullptr) {
         const int K = P.K; const HostTables &T = P.T;
         const uint32_t S = (uint32_t)cuts.size();
+        const double t_r0 = now_us();
         if (!fetch_patterns()) return {};
         auto pat_of = [&](int k) { return cuts[(size_t)k].x.data(); };
         // lambda: [cut * PARTS + part], every part's multipliers summing to 1 (a caller with one multiplier per cut repeats it for every part)
@@ -448,6 +451,7 @@ struct Solver {
             chosen[b] = active[bq];
             memcpy(&x[T.blk_off[b]], pat_of(active[bq]) + T.blk_off[b], (size_t)(T.blk_off[b + 1] - T.blk_off[b]) * 2);
         }
+        if (rq.trace) fprintf(stderr, "[price]   rounding: diffusion done at %.3f us, %d active cuts\n", now_us() - t_r0, Q);
         // `>=` rows that came out short: single-block pattern switches (any sweep's pattern of that block) that close the shortfall at the least loss
         auto ge_short = [&](const std::vector<double> &c) { double s = 0.0; for (int r = 0; r < K; r++) if (P.ge[r] && c[r] > hB[r] + 1e-9) s += c[r] - hB[r]; return s; };
         if (ge_short(cum) > 0.0) {
@@ -455,38 +459,78 @@ struct Solver {
             for (int k = (int)S - 1; k >= 0 && (int)pool.size() < Q + 12; k--) if ((!usable || (*usable)[k]) && std::find(pool.begin(), pool.end(), k) == pool.end()) pool.push_back(k);
             std::vector<double> a0(K), a1(K), c2(K);
             double cmax = 0.0; for (double c : T.col_cost) cmax = std::max(cmax, c);
-            for (int moves = 0; moves < 256 && ge_short(cum) > 0.0; moves++) {
+            // Passes: every switch that would help under the current totals is scored once, the list is walked best first and a switch applied if it still
+            // helps under the totals as they are by then (one block once per pass) — a pass costs what ONE move of a best-move-at-a-time loop costs.
+            struct Cand { double score; uint32_t b; int k; };
+            std::vector<Cand> cl;
+            auto evaluate_switch = [&](uint32_t b, int k, double v0, double &score) {  // a0 = the block's current activities
+                const uint16_t *px = pat_of(k);
+                block_act(b, px, a1);
+                double gain = 0.0, newviol = 0.0;
+                for (int r = 0; r < K; r++) {
+                    if (a0[r] == a1[r]) continue;
+                    const double c = cum[r] - a0[r] + a1[r];
+                    if (P.ge[r]) gain += std::max(0.0, cum[r] - hB[r]) - std::max(0.0, c - hB[r]);
+                    else newviol += std::max(0.0, c - hB[r]) - std::max(0.0, cum[r] - hB[r]);
+                }
+                if (!(gain > 1e-9)) return false;
+                double v1 = 0.0; for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) v1 += T.col_cost[f] * (double)px[f];
+                score = gain * 10.0 * cmax - (v0 - v1) - std::max(0.0, newviol) * cmax;
+                return true;
+            };
+            auto value_of = [&](uint32_t b) { double v = 0.0; for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) v += T.col_cost[f] * (double)x[f]; return v; };
+            for (int pass = 0; pass < 64 && ge_short(cum) > 0.0; pass++) {
                 const double base = ge_short(cum);
-                double best_score = -INF; int bb = -1, bk = -1;
+                cl.clear();
+                std::vector<char> is_short(K, 0);
+                for (int r = 0; r < K; r++) is_short[r] = P.ge[r] && cum[r] > hB[r] + 1e-9;
                 for (uint32_t b = 0; b < T.n_blocks; b++) {
-                    block_act(b, pat_of(chosen[b]), a0);
-                    double v0 = 0.0; for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) v0 += T.col_cost[f] * (double)x[f];
                     for (int k : pool) {
                         if (k == chosen[b]) continue;
                         const uint16_t *px = pat_of(k);
-                        block_act(b, px, a1);
-                        double gain = 0.0, newviol = 0.0;
-                        for (int r = 0; r < K; r++) {
-                            const double c = cum[r] - a0[r] + a1[r];
-                            if (P.ge[r]) { gain += std::max(0.0, cum[r] - hB[r]) - std::max(0.0, c - hB[r]); }
-                            else newviol += std::max(0.0, c - hB[r]) - std::max(0.0, cum[r] - hB[r]);
+                        // a cheap score first — what the switch takes off the short rows (its columns' entries in those rows only) against the value it gives
+                        // up; the full look (every row, new violations) happens when the switch is about to be applied
+                        double gain = 0.0, dv = 0.0; bool differs = false;
+                        for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) {
+                            const int d = (int)px[f] - (int)x[f];
+                            if (!d) continue;
+                            differs = true; dv += T.col_cost[f] * (double)d;
+                            for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) if (is_short[P.c_row[e]]) gain -= (double)P.c_coef[e] * (double)d;
                         }
-                        if (!(gain > 1e-9)) continue;
-                        double v1 = 0.0; for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) v1 += T.col_cost[f] * (double)px[f];
-                        const double score = gain * 10.0 * cmax - (v0 - v1) - std::max(0.0, newviol) * cmax;
-                        if (score > best_score) { best_score = score; bb = (int)b; bk = k; }
+                        if (!differs || !(gain > 1e-9)) continue;
+                        cl.push_back({std::min(gain, base) * 10.0 * cmax + dv, b, k});
                     }
                 }
-                if (bb < 0) break;
-                block_act((uint32_t)bb, pat_of(chosen[bb]), a0);
-                block_act((uint32_t)bb, pat_of(bk), a1);
-                for (int r = 0; r < K; r++) cum[r] += a1[r] - a0[r];
-                chosen[bb] = bk;
-                memcpy(&x[T.blk_off[bb]], pat_of(bk) + T.blk_off[bb], (size_t)(T.blk_off[bb + 1] - T.blk_off[bb]) * 2);
+                if (rq.trace) fprintf(stderr, "[price]     pass %d: short by %.1f, %zu candidate switches, at %.3f us\n", pass, base, cl.size(), now_us() - t_r0);
+                if (cl.empty()) break;
+                // (the best few hundred are all a pass ever applies: the rest wait for the next pass, which scores them against the totals as they are then)
+                const size_t top = std::min<size_t>(cl.size(), 512);
+                std::partial_sort(cl.begin(), cl.begin() + (long)top, cl.end(), [](const Cand &p, const Cand &q) { return p.score > q.score || (p.score == q.score && (p.b < q.b || (p.b == q.b && p.k < q.k))); });
+                cl.resize(top);
+                std::vector<char> moved(T.n_blocks, 0);
+                for (const Cand &cd : cl) {
+                    if (!(ge_short(cum) > 0.0)) break;
+                    if (moved[cd.b]) continue;
+                    {   // still worth the full look?  (the rows it was scored on may have been closed by the switches before it)
+                        const uint16_t *px = pat_of(cd.k); double gain = 0.0;
+                        for (uint32_t f = T.blk_off[cd.b]; f < T.blk_off[cd.b + 1]; f++) {
+                            const int d = (int)px[f] - (int)x[f];
+                            if (d) for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) { const int r = P.c_row[e]; if (P.ge[r] && cum[r] > hB[r] + 1e-9) gain -= (double)P.c_coef[e] * (double)d; }
+                        }
+                        if (!(gain > 1e-9)) continue;
+                    }
+                    block_act(cd.b, pat_of(chosen[cd.b]), a0);
+                    double score;
+                    if (!evaluate_switch(cd.b, cd.k, value_of(cd.b), score)) continue;  // (a1 = the new pattern's activities)
+                    for (int r = 0; r < K; r++) cum[r] += a1[r] - a0[r];
+                    chosen[cd.b] = cd.k; moved[cd.b] = 1;
+                    memcpy(&x[T.blk_off[cd.b]], pat_of(cd.k) + T.blk_off[cd.b], (size_t)(T.blk_off[cd.b + 1] - T.blk_off[cd.b]) * 2);
+                }
                 if (ge_short(cum) >= base - 1e-9) break;
             }
             if (ge_short(cum) > 0.0) return {};
         }
+        if (rq.trace) fprintf(stderr, "[price]   rounding: >= repair done at %.3f us\n", now_us() - t_r0);
         // `<=` rows that came out over: take single tasks away, the cheapest first, never pushing a `>=` row short
         for (int r = 0; r < K; r++) {
             if (cum[r] <= hB[r] + 1e-9) continue;
