@@ -189,3 +189,35 @@ def test_host_search_and_price_sweeps_agree(monkeypatch):
     m = o.last_model()
     zg = float(np.dot(m["obj"], _model_point(m, got.counts))); zh = float(np.dot(m["obj"], _model_point(m, host.counts)))
     assert abs(zg - zh) <= 1e-4 * max(zg, zh)
+
+
+def test_layered_dag_loop_full_ticks_on_the_gpu():
+    """BASELINE config 5 as a loop (the second DAG shape of bench.py: layers of 20 000 tasks): five consecutive ticks, each a coupled model of the whole
+    cluster, each checked like the first wave — certificate against the LP bound, every row of the reference's model, T3 given counts.  Between the
+    ticks the handed-out tasks finish, the tasks on the 10 % of workers that are lost return to the ready set, fresh workers (new ids: other Map
+    iteration orders) replace them and the next layer joins (its dependencies are the finished layer: workloads.make_dag_layered)."""
+    ids, prio, rq, off, dep = workloads.make_dag_layered(200_000, width=20_000, seed=1)
+    rq = (rq % np.uint32(8)).astype(np.uint32)
+    drv = workloads.DagChurn(n_workers=1024, churn=0.10, seed=1)
+    ready = np.nonzero((off[1:] - off[:-1]) == 0)[0]
+    nxt = 20_000  # first task index of the next layer
+    sweeps = []
+    for step in range(5):
+        snap = drv.snapshot(ids[ready], prio[ready], rq[ready])
+        got, ks, z, bound = _full_tick_checks(snap, _lp_bound)
+        sweeps.append(ks["price_sweeps"])
+        W = len(snap.worker_id)
+        rec_off = np.zeros(W + 1, np.int64)
+        rec_task = []
+        for w in range(W):  # (records are per worker index: every handed-out task, assigned or prefilled)
+            rec_task.extend(int(t) for (t, v, k) in got.records[w])
+            rec_off[w + 1] = len(rec_task)
+        rec_task = np.asarray(rec_task, np.uint64)
+        finished, returned = drv.after_tick(rec_off, rec_task)
+        handed = set(int(t) for t in rec_task)
+        back = set(int(t) for t in returned)
+        keep = [i for i in ready if int(ids[i]) not in handed or int(ids[i]) in back]
+        new_layer = list(range(nxt, min(nxt + 20_000, len(ids))))
+        nxt += 20_000
+        ready = np.asarray(sorted(set(keep) | set(new_layer)), np.int64)
+    assert all(s > 0 for s in sweeps)
