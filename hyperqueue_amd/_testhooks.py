@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhqtick_test.so")
+# HQTICK_TEST_LIB: another build of the same library (tools/host_asan.sh: the AddressSanitizer / UBSan build)
+LIB_PATH = os.environ.get("HQTICK_TEST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhqtick_test.so")
 
 
 def load() -> C.CDLL:

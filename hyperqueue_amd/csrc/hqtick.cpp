@@ -1607,8 +1607,12 @@ int hqtick_cluster_remove_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *w
         }
         k++;
     }
-    for (uint32_t i = 0; i < n; i++)  // Retracting tasks of a lost worker leave the table; a lost redirect target only clears the redirect
-        for (auto it = ctx->retr.begin(); it != ctx->retr.end();) { if (it->second.old_id == worker_id[i]) it = ctx->retr.erase(it); else { if (it->second.has_redirect && it->second.target_id == worker_id[i]) it->second.has_redirect = false; ++it; } }
+    if (!ctx->retr.empty()) {  // Retracting tasks of a lost worker leave the table; a lost redirect target only clears the redirect (one pass over the table, whatever n is)
+        std::vector<uint32_t> lost(worker_id, worker_id + n);
+        std::sort(lost.begin(), lost.end());
+        auto is_lost = [&](uint32_t id) { return std::binary_search(lost.begin(), lost.end(), id); };
+        for (auto it = ctx->retr.begin(); it != ctx->retr.end();) { if (is_lost(it->second.old_id)) it = ctx->retr.erase(it); else { if (it->second.has_redirect && is_lost(it->second.target_id)) it->second.has_redirect = false; ++it; } }
+    }
     m.id.resize(k); m.rem.resize(k); m.min_util.resize(k); m.flags.resize(k); m.group.resize(k); m.total.resize((size_t)k * R); m.free_.resize((size_t)k * R);
     m.blk_dirty = true;
     return 0;
