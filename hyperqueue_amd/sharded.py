@@ -172,8 +172,16 @@ class ShardedTick:
                     torch.distributed.broadcast_object_list(box, src=0, group=group)
                     uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
                 rc = lib.hqtick_comm_init(self.t._ctx, uid, rank, world)
-                if rc:
-                    raise RuntimeError(f"hqtick_comm_init failed: {rc}: {self.t._err()}")
+                ok = torch.tensor([0 if rc else 1], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu")
+                if world > 1:  # every rank takes the same path: if the library's communicator did not come up SOMEWHERE, all of them merge through torch.distributed
+                    torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=group)
+                if int(ok.item()) == 0:
+                    if world == 1:
+                        raise RuntimeError(f"hqtick_comm_init failed: {rc}: {self.t._err()}")
+                    import warnings
+
+                    warnings.warn(f"hqtick_comm_init failed on some rank (here: {rc}): the shards are merged by torch.distributed.all_gather_into_tensor instead of the library's RCCL call")
+                    self.collective = "torch"; self.comm_world = 0
 
     def _buffers(self, n_workers: int):
         if self._sink_workers != n_workers:
