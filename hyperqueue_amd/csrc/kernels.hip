@@ -588,12 +588,13 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
                 misc[2] = 1;
             } else {
                 const uint32_t src = sbase + (p >= pfs + pfn ? p - pfn : p);
-                const uint16_t lv = (uint16_t)(sel_key[src] / Q);  // priority level of the task's group
+                // priority level of the task's group — only a tick that can reorder needs it (sort_cap != 0: several levels, holes or prefilled tasks): the cold
+                // tick skips one strided 2-byte gather per record (a 64-byte line each)
+                const uint16_t lv = sort_cap ? (uint16_t)(sel_key[src] / Q) : (uint16_t)0;
                 e_task[e] = sel_task[src];
                 e_lvl[e] = lv;
                 e_meta[e] = (uint16_t)(k_var[k] | 0x100u);
-                atomicMin(&misc[0], (uint32_t)lv);
-                atomicMax(&misc[1], (uint32_t)lv);
+                if (sort_cap) { atomicMin(&misc[0], (uint32_t)lv); atomicMax(&misc[1], (uint32_t)lv); }
             }
         }
         if (do_pf) {
