@@ -11,7 +11,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 name = args[0] if args else "c3"
 n = int(args[1]) if len(args) > 1 else 30
 snap = workloads.make(name)
-t = Tick(abi.make_config(time_limit_s=5.0, flags=abi.HQTICK_FLAG_COMPACT_RECORDS | (0 if "--u32" in sys.argv else abi.HQTICK_FLAG_COMPACT_DELTA16)))  # as bench.py runs it
+t = Tick(abi.make_config(time_limit_s=5.0, flags=abi.HQTICK_FLAG_COMPACT_RECORDS | (0 if "--u32" in sys.argv else abi.HQTICK_FLAG_COMPACT_DELTA16)), measure=True)  # as bench.py runs it (measure: hqtick_timeline lives in the test library)
 t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
 sc = snap.to_c()
 t.cluster_upload(sc)
