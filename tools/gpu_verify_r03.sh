@@ -2,7 +2,7 @@
 # round-3 verification call: whole GPU suite, the price probe, the default bench
 set -u
 export TMPDIR=/tmp
-OUT=gpurun_out/r03f
+OUT=gpurun_out/r03_verify
 mkdir -p "$OUT"
 timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; echo "pytest exit $?" >> "$OUT/pytest_gpu.log"
 timeout 600 python tools/price_probe.py c3p wave 0.2 0.45 --no-host --timeline > "$OUT/price_probe.log" 2>&1
