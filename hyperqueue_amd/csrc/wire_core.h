@@ -590,11 +590,14 @@ HQW_HD void emit_p4(const Args &a, EmitLds &l, uint32_t s, uint32_t f, int tid) 
     const Slot sv = slot_of(a, s);
     const Frag g = frag_of(a, sv, s, f);
     uint8_t *m = a.o.bytes + l.msg_base;
-    for (uint32_t k = 0; k < g.ncfg; k++) {  // bodies: the whole workgroup copies each one, byte-coalesced
+    // bodies: one wavefront per body, the four wavefronts of the workgroup on four bodies at a time (byte-coalesced 16-byte stores).  The whole workgroup on
+    // one body after the other was eight load -> store round trips in a row for a typical message (8 configurations of ~1 KB: a body is 64 stores of 16 bytes, a
+    // quarter of the workgroup); this is two.
+    for (uint32_t k = (uint32_t)tid / 64; k < g.ncfg; k += BLOCK / 64) {
         const uint32_t cfg = a.cfg_list[g.cfg0 + k];
         const uint64_t n = body_len(a, cfg), b0 = a.t.body_off[cfg];
         uint8_t *dst = m + l.body_rel[k];
-        copy_bytes(dst, a.t.body_blob + b0, n, tid, BLOCK);
+        copy_bytes(dst, a.t.body_blob + b0, n, tid % 64, 64);
     }
 }
 
