@@ -267,6 +267,9 @@ HQW_HD void plan_p1(const Args &a, PlanLds &l, uint32_t s, int tid) {
         uint32_t row = find_row(a, r.task);
         if (row != NONE && a.t.task_config[row] >= a.t.n_configs) row = NONE;
         a.rec_row[sv.rec0 + i] = row;
+        // (rec_shared holds the record's configuration until phase 5 turns it into the shared index: phases 2, 4 and 5 read it back with one coalesced load
+        // instead of the chain rec_row -> task_config, two dependent gathers each)
+        a.rec_shared[sv.rec0 + i] = row == NONE ? NONE : a.t.task_config[row];
         if (row == NONE) {
             l.bad = HQWIRE_SLOT_UNKNOWN;  // same value from every thread that stores it
             continue;
@@ -292,8 +295,8 @@ HQW_HD void plan_p2(const Args &a, PlanLds &l, uint32_t s, int tid) {
     uint32_t lo, hi, cnt = 0;
     run_of(sv.n, tid, lo, hi);
     for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t row = a.rec_row[sv.rec0 + i];  // written by this thread in p1
-        const bool f = row != NONE && l.val[ht_find(l, a.t.task_config[row])] == i;
+        const uint32_t cfg = a.rec_shared[sv.rec0 + i];  // written by this thread in p1
+        const bool f = cfg != NONE && l.val[ht_find(l, cfg)] == i;
         l.first[i] = f ? 1 : 0;
         cnt += f ? 1 : 0;
     }
@@ -327,7 +330,7 @@ HQW_HD void plan_p4(const Args &a, PlanLds &l, uint32_t s, int tid) {
     run_of(sv.n, tid, lo, hi);
     for (uint32_t i = lo; i < hi; i++) {
         if (!l.first[i]) continue;
-        const uint32_t cfg = a.t.task_config[a.rec_row[sv.rec0 + i]];
+        const uint32_t cfg = a.rec_shared[sv.rec0 + i];
         l.val[ht_find(l, cfg)] = k;  // from here on the table maps configuration -> shared_index (nobody reads first-indices any more)
         a.cfg_list[sv.rec0 + k] = cfg;  // (read back in phase 5 by other threads of this workgroup: behind the barrier)
         k++;
@@ -340,8 +343,8 @@ HQW_HD void plan_p5(const Args &a, PlanLds &l, uint32_t s, int tid) {
     uint32_t lo, hi;
     run_of(sv.n, tid, lo, hi);
     for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t row = a.rec_row[sv.rec0 + i];
-        a.rec_shared[sv.rec0 + i] = row == NONE ? NONE : l.val[ht_find(l, a.t.task_config[row])];
+        const uint32_t cfg = a.rec_shared[sv.rec0 + i];  // (this thread's own record: phases 1, 2, 4 and 5 walk the same runs)
+        a.rec_shared[sv.rec0 + i] = cfg == NONE ? NONE : l.val[ht_find(l, cfg)];
     }
     uint64_t bytes = 0, est = 0;
     for (uint32_t k = (uint32_t)tid; k < l.n_cfg; k += BLOCK) {
