@@ -205,6 +205,7 @@ def test_phases_under_sanitizers():
     import subprocess
     import sys
 
-    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "..", "tools", "wire_asan.py"), "--seeds", "8"], capture_output=True, text=True, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS", "HQTICK_TEST_LIB")}  # (the harness brings its own sanitizer runtime: not the one tools/host_asan.sh preloads)
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "..", "tools", "wire_asan.py"), "--seeds", "8"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "0 problems" in p.stdout
