@@ -25,6 +25,9 @@ constexpr int NMAX_BLOCK = 32, MMAX_BLOCK = 4;
 constexpr double GRID = 10000.0;  // ResourceAmount fractions per unit  common/resources/amount.rs:7
 constexpr int MAX_ROUNDS = 6;
 constexpr int BP_MAX_NODES = 600;   // nodes of the branch-and-price phase (a deterministic count, like every limit in here)
+constexpr double BP_MAX_STEPS = 1.5e6;  // ... and search steps of the slowest blocks summed over the sweeps (~1 us each: see Solver::sweep_steps)
+constexpr double BP_MAX_WORK = 1.5e9; // ... and tableau elements its masters may touch (lp_tab.h's `ops`: ~1e9 per second): with thousands of cuts in the master a node
+                                      // costs milliseconds, and a 10 k-column model spent 8 s here against a 5 s time limit before this cap (deterministic like the counts)
 
 double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -247,6 +250,12 @@ struct Solver {
     std::vector<double> pmax;
     bool failed = false;
     size_t cut_lo = 0;            // the master works on cuts[cut_lo ..): points evaluated under the column bounds now in force
+    double work = 0.0;            // tableau elements touched by the masters so far (Tab::ops)
+    // What the sweeps themselves cost, in the kernel's own unit: a sweep lasts as long as its slowest block, ~1 us per search step on top of ~60 us.  Blocks that
+    // run out of their step budget return an LP bound instead of their optimum: the total stays a valid bound, but the master's cuts (patterns) and its evaluations
+    // (bounds) no longer describe the same function and the cutting-plane loop stops converging — a model whose blocks do that sweep after sweep (16-column blocks of a
+    // busy C4 cluster) is not one for this path.
+    double sweep_steps = 0.0; int budget_sweeps = 0;
     int max_sweeps = 256;
     // branch-and-price: the node whose bounds the device tables carry right now (empty lo list = the model's own bounds), and what its lower bounds add per sweep
     std::vector<std::pair<uint32_t, int32_t>> node_lo, node_caps; double node_cl = 0.0; std::vector<double> node_Al; bool at_root = true;
@@ -262,6 +271,8 @@ struct Solver {
         const double t0 = now_us();
         if (!sw.sweep(pig.data(), tot)) { failed = true; return -1; }
         sw.stat_sweep_us += now_us() - t0; sw.stat_sweeps++;
+        sweep_steps += 64.0 + (double)tot.max_steps;
+        if (tot.n_budget > std::max<uint32_t>(4, P.T.n_blocks / 64)) budget_sweeps++;
         Cut c; c.cx = tot.cx; c.bnd = tot.bnd; c.pi = pi;
         c.act.resize(P.K);
         for (int k = 0; k < P.K; k++) c.act[k] = tot.act[P.grp_of[k]];
@@ -340,6 +351,7 @@ struct Solver {
             for (int k = 0; k < K; k++) pi[k] = alpha * pi_best[k] + (1.0 - alpha) * mt.x[k];
             const int ci = evaluate(pi);
             if (ci < 0) break;
+            if (budget_sweeps >= 8) { if (rq.trace) fprintf(stderr, "[price] blocks keep running out of their search budget (%d sweeps): not a model for the sweeps\n", budget_sweeps); return false; }
             const double L = fixed_value(cuts[ci], hB, cB);
             if (L < ub_best) { ub_best = L; pi_best = pi; }
             push_cuts(&mt);
@@ -671,6 +683,7 @@ struct Solver {
             if (L < out.bound) { out.bound = L; pi_best = pi; }
             add_cut((size_t)ci, true);
         }
+        work += mt.ops;
         if (!ok || out.pruned) return;
         out.lambda.assign(cuts.size(), 0.0); out.bfrac.assign(G, 0.0);
         double lsum = 0.0;
@@ -896,7 +909,7 @@ Answer solve(const Request &rq, Sweeper &sw) {
     }
     // ---- branch and price: what the configurations above leave open, on models small enough for a few hundred more sweeps to be cheap ----
     double bp_bound = INF;
-    if (best_value > -INF && !certified() && !S.failed && P.T.n_cols <= 16384) {
+    if (best_value > -INF && !certified() && !S.failed && P.T.n_cols <= 16384 && S.budget_sweeps < 8) {
         S.base_caps = true;  // every node sets its own column bounds from here on
         int col_nodes = 0;  // branching on single columns moves the bound of these models very little (a mixing worker passes its role to the next one): a short leash
         auto closes = [&](double bound) { return bound <= best_value + rq.rel_gap * std::fabs(best_value); };
@@ -905,7 +918,7 @@ Answer solve(const Request &rq, Sweeper &sw) {
         double closed_max = -INF;  // the largest bound among the closed nodes: with the open ones it bounds the model
         int nodes = 0;
         std::vector<int32_t> lo_arr, hi_arr; std::vector<char> usable;
-        while (!stack.empty() && nodes < BP_MAX_NODES && (int)S.cuts.size() + 8 < S.max_sweeps && !S.failed) {
+        while (!stack.empty() && nodes < BP_MAX_NODES && (int)S.cuts.size() + 8 < S.max_sweeps && S.work < BP_MAX_WORK && S.sweep_steps < BP_MAX_STEPS && !S.failed) {
             BPNode nd = std::move(stack.back()); stack.pop_back();
             if (closes(nd.bound)) { closed_max = std::max(closed_max, nd.bound); continue; }
             nodes++;
