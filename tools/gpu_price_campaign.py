@@ -2,7 +2,7 @@
 """One-off GPU campaign of the coupled path at cluster scale (needs a GPU): random clusters of 256-1024 workers mid-run, 1-3 priority levels, ready sets that do not
 saturate — each through the HIP tick and through the emulated sweeps of the CPU hooks (the same path bit for bit: sweeps, configurations, status, counts), and each
 certified tick through the oracle's mapping on the product's counts (T3 given counts: records, retracts, redirects, free vectors).
-    python tools/gpu_price_campaign.py [first_seed] [count]"""
+    python tools/gpu_price_campaign.py [first_seed] [count] [--big]        (--big: clusters of 2048 / 4096 workers, up to the 65 536 columns of BASELINE configs[3])"""
 import os
 import sys
 import time
@@ -20,9 +20,12 @@ from oracle.oracle import Oracle
 from test_price import stages
 
 
+BIG = "--big" in sys.argv
+
+
 def scenario(seed):
     rng = np.random.default_rng(seed)
-    W = int(rng.choice([256, 384, 512, 768, 1024]))
+    W = int(rng.choice([2048, 4096] if BIG else [256, 384, 512, 768, 1024]))
     levels = int(rng.integers(1, 4))
     steady = rng.random() < 0.6
     n_ready = int(rng.integers(W * 4, W * 60))
@@ -36,8 +39,9 @@ def scenario(seed):
 
 
 def main():
-    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    first = int(args[0]) if len(args) > 0 else 0
+    count = int(args[1]) if len(args) > 1 else 40
     bad = 0; certified = 0; swept = 0; t_gpu = []
     for seed in range(first, first + count):
         snap, info = scenario(seed)
