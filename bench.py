@@ -671,6 +671,27 @@ def main():
                                                                         "sample": "1 tick of the same snapshot, HiGHS 1.8.0 with the reference's options (time_limit = 5 s only)"}
         except Exception as e:
             out["multi_priority_busy_cluster"] = {"error": repr(e)}
+        # ... and BASELINE configs[3]'s cluster (4096 workers, every class a 2-variant OR-list) with a ready set that does NOT saturate it: one coupled model of 65 536
+        # columns through the batch-size rows — the model HiGHS holds an unproven incumbent on after minutes (no CPU baseline here for that reason)
+        try:
+            s4 = workloads.make("c4", seed=8, n_workers=4096, n_tasks=56_761)
+            t4 = Tick(cfg)
+            t4.upload_ready(s4.task_id, s4.task_priority, s4.task_rq, sorted_=True)
+            sc4 = s4.to_c()
+            tl4, inf4 = [], None
+            for _ in range(max(3, args.priority_ticks // 2) + 1):
+                t0 = time.perf_counter(); r4 = t4.tick_raw(sc4, resident=True); tl4.append(time.perf_counter() - t0)
+                inf4 = (int(r4.status), int(r4.is_optimal), t4.kernel_stats())
+            t4.close()
+            out["config4_unsaturated"] = {"workload": "c4's cluster (4096 workers x 2-variant requests) with 56 761 ready tasks: no batch saturated, one coupled model of all workers",
+                                          "p50_tick_ms": 1e3 * float(np.median(tl4[1:])), "status": inf4[0], "is_optimal": bool(inf4[1]), "assigned_per_tick": int(inf4[2]["n_assigned"]),
+                                          "model_columns": int(inf4[2]["milp_cols"]), "model_rows": int(inf4[2]["milp_rows"]), "price_sweeps": int(inf4[2]["price_sweeps"]),
+                                          "sweeps_ms": inf4[2]["price_sweep_us"] / 1e3, "avg_sweep_us": (inf4[2]["price_sweep_us"] / inf4[2]["price_sweeps"]) if inf4[2]["price_sweeps"] else None,
+                                          "coupled_solve_ms": inf4[2]["milp_us"] / 1e3, "build_model_ms": inf4[2]["model_us"] / 1e3,
+                                          "tasks_assigned_per_sec": int(inf4[2]["n_assigned"]) / float(np.median(tl4[1:])),
+                                          "note": "4096 blocks of 16 columns per sweep: four rounds of resident workgroups on the 256 CUs; parity: tests/test_gpu_price.py::test_config4_unsaturated_full_tick_on_the_gpu"}
+        except Exception as e:
+            out["config4_unsaturated"] = {"error": repr(e)}
     if world == 1 and args.cpu_ticks > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(snap, args.cpu_ticks)
