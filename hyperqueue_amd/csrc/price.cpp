@@ -183,7 +183,14 @@ const char *build(const Request &rq, Prob &P) {
         wide.push_back(std::move(w));
         if ((int)wide.size() > 1024) return "more than 1024 wide rows";
     }
-    for (int b = 0; b < nb; b++) if (T.blk_m[b] == 0) return "block without a resource row";
+    for (int b = 0; b < nb; b++) if (T.blk_m[b] == 0) {
+        // every resource row of this worker is slack at its column bounds (a nearly idle worker and a short ready set: the caps bind, not the resources).  The kernel
+        // wants a row: the sum of the block's columns against the sum of their caps — never binding either.
+        double total = 0.0;
+        for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { T.col_a[(size_t)f * MMAX_BLOCK] = 1.0; total += (double)T.col_cap[f]; }
+        T.blk_cap[(size_t)b * MMAX_BLOCK] = total;
+        T.blk_m[b] = 1;
+    }
     // every column of a block must be bounded by its block: a cap below 65536 is there (checked above); amounts that do not fit even once leave ub 0
     P.K = (int)wide.size();
     if (P.K == 0) return "no wide row";
@@ -909,7 +916,7 @@ Answer solve(const Request &rq, Sweeper &sw) {
     }
     // ---- branch and price: what the configurations above leave open, on models small enough for a few hundred more sweeps to be cheap ----
     double bp_bound = INF;
-    if (best_value > -INF && !certified() && !S.failed && P.T.n_cols <= 16384 && S.budget_sweeps < 8) {
+    if (best_value > -INF && !certified() && !S.failed && P.T.n_cols <= 131072 && S.budget_sweeps < 8) {
         S.base_caps = true;  // every node sets its own column bounds from here on
         int col_nodes = 0;  // branching on single columns moves the bound of these models very little (a mixing worker passes its role to the next one): a short leash
         auto closes = [&](double bound) { return bound <= best_value + rq.rel_gap * std::fabs(best_value); };
