@@ -45,6 +45,7 @@ struct CompSolver {
     std::vector<int32_t> col_group;
     int price_sweeps = 0, price_rounds = 0; double price_us = 0.0;
     double deadline = 0; bool timed_out = false;
+    double time_limit_s = 5.0;  // the configured limit itself (not what is left of it): what count-based budgets are scaled by, so that replicas scale them alike
     long nodes = 0, lp_iters = 0;
     // incumbent
     bool have = false; double best = -INF; std::vector<double> bx;
@@ -663,7 +664,7 @@ struct CompSolver {
             hqprice::Request rq;
             rq.n = n; rq.m = R.m; rq.roff = R.off.data(); rq.rcol = R.col.data(); rq.rcoef = R.coef.data(); rq.rlo = R.lo.data(); rq.rhi = R.hi.data();
             rq.row_scale = row_scale.data(); rq.row_implied = (int)row_implied.size() == R.m ? row_implied.data() : nullptr; rq.col_group = col_group.data();
-            rq.c = c.data(); rq.ub = ub.data(); rq.incumbent = have ? bx.data() : nullptr; rq.incumbent_value = best; rq.rel_gap = rel_gap; rq.trace = tracing;
+            rq.c = c.data(); rq.ub = ub.data(); rq.incumbent = have ? bx.data() : nullptr; rq.incumbent_value = best; rq.rel_gap = rel_gap; rq.trace = tracing; rq.time_limit_s = time_limit_s; rq.deadline_s = deadline;
             rq.polish = [this](std::vector<double> &x, double &value) { return polish_point(x, value); };
             bool lbzero = true; for (int j = 0; j < n && lbzero; j++) lbzero = lb[j] == 0.0;
             hqprice::Answer pa;
@@ -1136,7 +1137,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
     std::unordered_map<std::string, std::pair<int, std::vector<double>>> memo;
     for (size_t ci = 0; ci < ccols.size(); ci++) {
         auto &cols = ccols[ci]; auto &rows = crows[ci];
-        CompSolver cs; cs.n = (int)cols.size(); cs.deadline = deadline;
+        CompSolver cs; cs.n = (int)cols.size(); cs.deadline = deadline; cs.time_limit_s = time_limit_s;
         cs.rel_gap = rel_gap;
         const int cm = (int)rows.size();
         for (int k = 0; k < cs.n; k++) local[cols[k]] = k;

@@ -25,8 +25,9 @@ constexpr int NMAX_BLOCK = 32, MMAX_BLOCK = 4;
 constexpr double GRID = 10000.0;  // ResourceAmount fractions per unit  common/resources/amount.rs:7
 constexpr int MAX_ROUNDS = 6;
 constexpr int BP_MAX_NODES = 600;   // nodes of the branch-and-price phase (a deterministic count, like every limit in here)
-constexpr double BP_MAX_STEPS = 1.5e6;  // ... and search steps of the slowest blocks summed over the sweeps (~1 us each: see Solver::sweep_steps)
-constexpr double BP_MAX_WORK = 1.5e9; // ... and tableau elements its masters may touch (lp_tab.h's `ops`: ~1e9 per second): with thousands of cuts in the master a node
+// (per second of the caller's configured time limit: generous — what keeps the phase inside the limit is its wall-clock guard at 70 % of it)
+constexpr double BP_MAX_STEPS = 3.0e6;   // ... and search steps of the slowest blocks summed over the sweeps (0.3-1 us each: see Solver::sweep_steps)
+constexpr double BP_MAX_WORK = 1.0e9; // ... and tableau elements its masters may touch (lp_tab.h's `ops`: ~1e9 per second): with thousands of cuts in the master a node
                                       // costs milliseconds, and a 10 k-column model spent 8 s here against a 5 s time limit before this cap (deterministic like the counts)
 
 double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -358,6 +359,7 @@ struct Solver {
             for (int k = 0; k < K; k++) pi[k] = alpha * pi_best[k] + (1.0 - alpha) * mt.x[k];
             const int ci = evaluate(pi);
             if (ci < 0) break;
+            if (now_us() * 1e-6 > rq.deadline_s - 0.3 * rq.time_limit_s) { if (rq.trace) fprintf(stderr, "[price] 70 %% of the time limit gone inside the master loop\n"); return false; }
             if (budget_sweeps >= 8) { if (rq.trace) fprintf(stderr, "[price] blocks keep running out of their search budget (%d sweeps): not a model for the sweeps\n", budget_sweeps); return false; }
             const double L = fixed_value(cuts[ci], hB, cB);
             if (L < ub_best) { ub_best = L; pi_best = pi; }
@@ -749,6 +751,7 @@ Answer solve(const Request &rq, Sweeper &sw) {
     // usable came out) and leaves the point in x.
     auto try_config = [&](const std::vector<double> &B, std::vector<double> &x) -> double {
         tried.push_back(B);
+        if (now_us() * 1e-6 > rq.deadline_s - 0.3 * rq.time_limit_s) return -INF;  // (the one clock of this path: see Request::deadline_s)
         ans.rounds++;
         double cB = 0.0;
         for (int k = 0; k < K; k++) hB[k] = P.h[k];
@@ -925,7 +928,8 @@ Answer solve(const Request &rq, Sweeper &sw) {
         double closed_max = -INF;  // the largest bound among the closed nodes: with the open ones it bounds the model
         int nodes = 0;
         std::vector<int32_t> lo_arr, hi_arr; std::vector<char> usable;
-        while (!stack.empty() && nodes < BP_MAX_NODES && (int)S.cuts.size() + 8 < S.max_sweeps && S.work < BP_MAX_WORK && S.sweep_steps < BP_MAX_STEPS && !S.failed) {
+        while (!stack.empty() && nodes < BP_MAX_NODES && (int)S.cuts.size() + 8 < S.max_sweeps && S.work < BP_MAX_WORK * rq.time_limit_s && S.sweep_steps < BP_MAX_STEPS * rq.time_limit_s &&
+               now_us() * 1e-6 < rq.deadline_s - 0.3 * rq.time_limit_s && !S.failed) {
             BPNode nd = std::move(stack.back()); stack.pop_back();
             if (closes(nd.bound)) { closed_max = std::max(closed_max, nd.bound); continue; }
             nodes++;

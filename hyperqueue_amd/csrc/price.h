@@ -61,6 +61,9 @@ struct Request {
     const double *c = nullptr, *ub = nullptr;
     const double *incumbent = nullptr; double incumbent_value = 0.0;  // nullptr: none
     double rel_gap = 1e-4;
+    double time_limit_s = 5.0;  // the caller's CONFIGURED time limit: the deterministic work caps of the branch-and-price phase scale with it
+    double deadline_s = 1e300;  // ... and the wall-clock point (steady clock, seconds) at which that limit runs out: the one clock in this path — branch-and-price stops at
+                                // 70 % of the limit whatever its counts say (like the host search it hands over to, a tick that gets there may differ between replicas)
     // checks a point against ALL rows of the component, raises what can still be raised, returns the value; false: the point violates a row
     std::function<bool(std::vector<double> &x, double &value)> polish;
     bool trace = false;

@@ -79,9 +79,13 @@ def test_device_sweeps_equal_emulation_on_random_clusters(seed, monkeypatch):
 
     snap = scenario(seed)[0]
     got, ks = _tick(snap, min_cols=16, monkeypatch=monkeypatch)
-    want, sweeps, rounds = stages(snap, True, min_cols=16)
+    want, sweeps, rounds = stages(snap, True, min_cols=16, tl=60.0)  # (emulated sweeps are ~100x slower: the time the GPU's 5 s are worth)
+    assert got.batches == want.batches
+    if not (got.is_optimal and want.is_optimal):  # a tick cut by its time limit is cut by the clock: nothing to compare sweep by sweep
+        assert not got.is_optimal or want.is_optimal  # (what the GPU certifies in 5 s the emulation certifies in 60)
+        return
     assert (ks["price_sweeps"], ks["price_rounds"]) == (sweeps, rounds)
-    assert got.status == want.status and got.is_optimal == want.is_optimal and got.batches == want.batches
+    assert got.status == want.status
     if sweeps and want.is_optimal and not want.is_canonical:  # (a tick the host tree finished exactly is compared too: same incumbent in, same search)
         assert got.counts == want.counts
     elif want.is_optimal:

@@ -51,11 +51,12 @@ def main():
             ks = t.kernel_stats()
         finally:
             t.close()
-        want, sweeps, rounds = stages(snap, True)
+        want, sweeps, rounds = stages(snap, True, tl=60.0)  # (the emulated sweeps are ~100x slower than the kernel's: give them the time to reach what the GPU reaches in its 5 s)
         line = dict(seed=seed, **info, sweeps=int(ks["price_sweeps"]), rounds=int(ks["price_rounds"]), optimal=bool(got.is_optimal), tick_ms=round(dt * 1e3, 2), cols=int(ks["milp_cols"]))
         problems = []
-        if (int(ks["price_sweeps"]), int(ks["price_rounds"])) != (sweeps, rounds): problems.append(f"sweeps {ks['price_sweeps']}/{ks['price_rounds']} vs emulation {sweeps}/{rounds}")
-        if got.status != want.status or got.is_optimal != want.is_optimal or got.batches != want.batches: problems.append("status / batches differ from the emulation")
+        # (a tick that runs into its time limit is cut by the clock — on the emulation, which is 100x slower per sweep, much earlier: only certified ticks are compared sweep by sweep)
+        if got.is_optimal and want.is_optimal and (int(ks["price_sweeps"]), int(ks["price_rounds"])) != (sweeps, rounds): problems.append(f"sweeps {ks['price_sweeps']}/{ks['price_rounds']} vs emulation {sweeps}/{rounds}")
+        if got.batches != want.batches or (got.is_optimal and want.is_optimal and got.status != want.status): problems.append("status / batches differ from the emulation")
         if want.is_optimal and got.is_optimal and got.counts != want.counts: problems.append("counts differ from the emulation")
         if got.is_optimal:
             certified += 1
