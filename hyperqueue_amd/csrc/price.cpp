@@ -27,7 +27,7 @@ constexpr int MAX_ROUNDS = 6;
 constexpr int BP_MAX_NODES = 600;   // nodes of the branch-and-price phase (a deterministic count, like every limit in here)
 // (per second of the caller's configured time limit: generous — what keeps the phase inside the limit is its wall-clock guard at 70 % of it)
 constexpr double BP_MAX_STEPS = 3.0e6;   // ... and search steps of the slowest blocks summed over the sweeps (0.3-1 us each: see Solver::sweep_steps)
-constexpr double BP_MAX_WORK = 1.0e9; // ... and tableau elements its masters may touch (lp_tab.h's `ops`: ~1e9 per second): with thousands of cuts in the master a node
+constexpr double BP_MAX_WORK = 3.0e9; // ... and tableau elements its masters may touch (lp_tab.h's `ops`: ~1e9 per second): with thousands of cuts in the master a node
                                       // costs milliseconds, and a 10 k-column model spent 8 s here against a 5 s time limit before this cap (deterministic like the counts)
 
 double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
