@@ -238,3 +238,49 @@ def test_retracting_table_resident_in_the_library(seed):
         # the table holds exactly the tasks the mirror of the reactor has in state Retracting (those a tick put back on their own worker included)
         assert r.retracting_count() == sum(1 for t in e.tasks.values() if t.state == 4)
     g.close(); r.close()
+
+
+def test_membership_deltas_at_cluster_scale_on_coupled_ticks():
+    """The same deltas at BASELINE scale, on ticks the price sweeps solve: 1024 workers mid-run, three priority levels (every tick one coupled model of the whole
+    cluster), 100 workers lost and 100 fresh ones joining per step, rejects, row changes — the resident tick (no worker arrays in the snapshot) equals the plain tick
+    on the full snapshot of the same state at every step, and the last state's mapping equals the oracle's on the same counts (T3)."""
+    from oracle.oracle import Oracle
+
+    plain, res = _tick(), _tick(HQTICK_CHECK_CLUSTER=1)
+    snap = workloads.make_steady("c3p", seed=11, n_tasks=300_000, n_workers=1024)
+    R = snap.n_resources
+    res.cluster_upload(snap)
+    a, b = res.tick(snap, resident_workers=True), plain.tick(snap)
+    _same(a, b)
+    assert res.kernel_stats()["price_sweeps"] > 0 and a.is_optimal
+    rng = np.random.default_rng(11)
+    cur = snap
+    for step in range(3):
+        W = len(cur.worker_id)
+        lost = np.sort(rng.choice(W, 100, replace=False))
+        keep = [w for w in range(W) if w not in set(lost.tolist())]
+        res.cluster_remove_workers(cur.worker_id[lost])
+        top = int(cur.worker_id.max())
+        tot_row = np.array(cur.worker_total, np.uint64).reshape(W, R)[0]
+        ids = [top + 1 + i for i in range(100)]
+        extra = (ids, np.stack([tot_row] * 100), np.stack([tot_row] * 100))
+        res.cluster_add_workers(extra[0], extra[1], extra[2])
+        cur = _subset(cur, keep, extra)
+        # a few rejects and row changes on the new set
+        wb = int(rng.integers(0, len(cur.worker_id)))
+        res.cluster_set_blocked(int(cur.worker_id[wb]), [(0, 0), (5, 0)])
+        cur = dataclasses.replace(cur, _keep=[], blocked=[bl for bl in cur.blocked if bl[0] != wb] + [(wb, 0, 0), (wb, 5, 0)])
+        Wn = len(cur.worker_id)
+        rows = np.sort(rng.choice(Wn, 40, replace=False))
+        free = np.array(cur.worker_free, np.uint64).reshape(Wn, R).copy()
+        free[rows] = np.array(cur.worker_total, np.uint64).reshape(Wn, R)[rows]
+        res.cluster_update_workers(rows.tolist(), free[rows])
+        cur = _with_free(cur, free.reshape(-1))
+        assert res.cluster_workers().tolist() == cur.worker_id.tolist()
+        a, b = res.tick(cur, resident_workers=True), plain.tick(cur)
+        _same(a, b)
+        assert a.is_optimal
+    o = Oracle(abi.make_config(time_limit_s=5.0))
+    want = o.tick_given(cur, a.counts, is_optimal=True)
+    assert a.counts == want.counts and a.records == want.records and a.retracts == want.retracts and (a.new_free == want.new_free).all()
+    plain.close(); res.close()
