@@ -236,3 +236,57 @@ def test_config4_unsaturated_full_tick_on_the_gpu():
     snap = workloads.make("c4", seed=8, n_workers=4096, n_tasks=56_761)
     got, ks, z, _ = _full_tick_checks(snap, None)
     assert ks["milp_cols"] == 65536
+
+
+def test_config5_loop_through_the_resident_state_on_the_gpu():
+    """BASELINE config 5 as bench.py runs it — the DAG in the device dependency graph (hqtick_graph_*), the ready set and the cluster tables resident, workers leaving
+    and joining through the membership deltas, snapshots without task columns or worker arrays — with every tick checked: certified, and the mapping equal to the
+    oracle's on the product's counts (T3) for the FULL snapshot of the same state, rebuilt on the host from the mirrors a reactor would hold."""
+    from oracle.oracle import Oracle
+
+    n = 150_000
+    ids, prio, rq, off, dep = workloads.make_dag_layered(n, width=20_000, seed=3)
+    rq = (rq % np.uint32(8)).astype(np.uint32)
+    in_ready = np.zeros(n, bool)
+    ix = lambda a: (np.asarray(a, np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1
+    t = Tick(abi.make_config(time_limit_s=5.0))
+    try:
+        t.upload_ready(np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+        ready0 = t.graph_add_tasks(ids, prio, rq, (off, dep))
+        in_ready[ix(ready0)] = True
+        drv = workloads.DagChurn(n_workers=1024, churn=0.10, seed=3)
+        W = 1024
+        t.cluster_upload(drv.snapshot())
+        total_row = np.asarray(drv.kw["worker_total"], np.uint64).reshape(W, -1)[0]
+        swept = 0
+        for step in range(5):
+            sel = np.nonzero(in_ready)[0]
+            full = drv.snapshot(ids[sel], prio[sel], rq[sel])  # the same state as a full snapshot (what the oracle gets)
+            got = t.tick(drv.snapshot(), resident=True, resident_workers=True)
+            ks = t.kernel_stats()
+            swept += int(ks["price_sweeps"] > 0)
+            assert got.status == abi.HQTICK_DONE and got.is_optimal, (step, got.status)
+            o = Oracle(abi.make_config(time_limit_s=5.0))
+            want = o.tick_given(full, got.counts, is_optimal=True)
+            assert got.batches == want.batches and got.counts == want.counts, step
+            assert got.records == want.records and got.retracts == want.retracts and got.redirects == want.redirects, step
+            assert (got.new_free == want.new_free).all()
+            t.ready_consume_last()
+            rec_off = np.zeros(W + 1, np.int64); rec_task = []
+            for w in range(W):
+                rec_task.extend(int(x) for (x, v, k) in got.records[w]); rec_off[w + 1] = len(rec_task)
+            rec_task = np.asarray(rec_task, np.uint64)
+            if len(rec_task) == 0:
+                break
+            finished, returned = drv.after_tick(rec_off, rec_task)
+            idx = ix(returned)
+            in_ready[ix(rec_task)] = False; in_ready[idx] = True
+            t.cluster_remove_workers(drv.last_lost_ids)
+            t.cluster_add_workers(drv.last_fresh_ids, np.tile(total_row, (len(drv.last_fresh_ids), 1)))
+            if len(returned):
+                t.ready_add(returned, prio[idx], rq[idx])
+            rel, unk = t.graph_finish(finished) if len(finished) else (np.zeros(0, np.uint64), 0)
+            in_ready[ix(rel)] = True
+        assert swept >= 3  # the loop's ticks are coupled models of the whole cluster: k_price_sweep solved them
+    finally:
+        t.close()
