@@ -377,3 +377,33 @@ def test_long_rows_scan_kernel_equals_short_rows_kernel(monkeypatch):
     assert a.batches == b.batches and a.counts == b.counts
     assert a.records == b.records and sum(len(r) for r in a.records) > 50_000
     assert (a.new_free == b.new_free).all()
+
+
+def test_c3p_full_sharded_replicas_agree():
+    """BASELINE C3 with three priority levels (one coupled model of 8 205 columns, solved by the price sweeps) as FOUR worker shards: every rank solves the same
+    model on its own context — the replicated stages must agree bit for bit (counts, batches, free vectors: the price path has no clock on a tick that certifies), and
+    the merged shard records must be the plain tick's records."""
+    from hyperqueue_amd import sharded
+
+    snap = workloads.make("c3p")
+    cfg = abi.make_config(time_limit_s=20.0)
+    W, R, world, cap = len(snap.worker_id), snap.n_resources, 4, 1 << 17
+    sinks, results = [], []
+    for r in range(world):
+        st = sharded.ShardedTick(cfg, rank=r, world=world, records_per_shard=cap)
+        res_c, sink = st.tick_local(snap.to_c(), W)
+        sinks.append(sink.cpu().numpy().copy())
+        results.append(abi.parse_result(res_c, W, R))
+        assert st.t.kernel_stats()["price_sweeps"] > 0
+        st.t.close()
+    records = sharded.merge_shards(np.concatenate(sinks), world, W, cap)
+    for r in results[1:]:
+        assert r.is_optimal and r.counts == results[0].counts and r.batches == results[0].batches and (r.new_free == results[0].new_free).all()
+    from hyperqueue_amd.tick import Tick
+
+    t = Tick(cfg)
+    try:
+        plain = t.tick(snap)
+    finally:
+        t.close()
+    assert plain.counts == results[0].counts and records == plain.records and (plain.new_free == results[0].new_free).all()
