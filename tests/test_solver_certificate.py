@@ -89,8 +89,8 @@ def test_c3p_reduced_is_certified():
 def test_c3p_at_baseline_size_is_certified():
     """BASELINE.md's C3 with three priority levels at full size (1024 workers, 1 M tasks; 8 205 columns x 37 958 rows): HiGHS holds 1.367 after 5 s and
     1.5014 after 60 s without a proof; the product certifies its incumbent against the root LP bound — in 1.6 s on the MI355X box's host and 3.5 s on an
-    idle build container, i.e. inside the reference's 5 s limit.  The test gives it 15 s so that a loaded CI machine (this suite runs 8
+    idle build container, i.e. inside the reference's 5 s limit.  The test gives it 45 s so that a loaded CI machine (this suite runs 8
     tests at a time) cannot turn a timing figure into a failure: what is asserted is the certificate."""
     snap = workloads.make("c3p", n_tasks=1_000_000, n_workers=1024)
-    got = HostStages(abi.make_config(time_limit_s=15.0)).stages(snap)
+    got = HostStages(abi.make_config(time_limit_s=45.0)).stages(snap)
     assert got.status == abi.HQTICK_DONE and got.is_optimal
