@@ -466,6 +466,20 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         bool blocks_exact = true;  // every class block solved to its EXACT optimum (device blocks are; a host block that came back with a gap certificate only is not)
         if (separable) {
             for (uint32_t c = 0; c < ncls; c++) class_has_flag[c] = class_mu_flag(c) ? 1 : 0;
+            // one class block through the host's exact solver; -1: infeasible (the reference's `None`)
+            auto solve_class_on_host = [&](uint32_t c) -> int {
+                hqmilp::Model m; std::vector<ColRef> cols;
+                build_class_model(c, m, cols);
+                hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true);
+                out.milp_nodes += sol.nodes; out.milp_cols += m.ncols(); out.milp_rows += m.nrows(); out.milp_components += sol.n_components;
+                out.blocks_host++;
+                if (!sol.feasible) return -1;
+                if (!sol.optimal) out.is_optimal = false;
+                if (!sol.canonical) { out.is_canonical = false; blocks_exact = false; }  // certificate only: the incumbent may sit up to rel_gap below the block's optimum
+                for (size_t k = 0; k < cols.size(); k++) if (cols[k].batch != UINT32_MAX) X[(size_t)c * NC + voff[cols[k].batch] + cols[k].variant] = (uint32_t)std::round(sol.x[k]);
+                solved[c] = 1;
+                return 0;
+            };
             std::vector<uint32_t> dev_cls;
             if (pb.blocks && NC <= (uint32_t)hqblock::GCOLS) for (uint32_t c = 0; c < ncls; c++) if (!class_has_flag[c]) dev_cls.push_back(c);
             if (pb.blocks && dev_cls.size() >= pb.block_min_classes) {
@@ -475,11 +489,14 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     for (uint32_t e = 0; e < vv.n_entries; e++) { ent_res.push_back(vv.res[e]); ent_kind.push_back(vv.kind[e]); ent_amount.push_back(vv.amount[e]); }
                     ent_off[g + 1] = (uint32_t)ent_res.size(); weight[g] = vv.weight;
                 }
-                const uint32_t nd = (uint32_t)dev_cls.size();
+                uint32_t nd = (uint32_t)dev_cls.size();
+                std::vector<uint32_t> held;  // classes the host solves itself while the kernel runs (below)
                 if (nd > 1024) {
-                    // More classes than the 1024 blocks the chip holds at once (a busy C4 cluster: ~3000): the launch's span is its start spread plus its slowest block, and
-                    // the slow blocks are the classes with the most room (the more fits, the deeper the search).  Longest first: classes by descending free share of
+                    // The launch's span is its start spread (more classes than the 1024 blocks the chip holds at once: a busy C4 cluster has ~3000) plus its slowest block,
+                    // and the slow blocks are the classes with the most room (the more fits, the deeper the search).  Longest first: classes by descending free share of
                     // resource 0, a 256-bucket counting sort (stable: equal shares keep their order) — k_block_solve 824 -> 620 us on the 3050-class C4 steady state.
+                    // And the very hardest ones are not launched at all: the host solves them with its own solver WHILE the kernel runs — a wavefront takes 400-600 us
+                    // for what the host does in tens (tools/block_profile.py: the 16 slowest classes of that launch are its first 16 in this order).
                     static const bool ordered = !(getenv("HQTICK_BLOCK_ORDER") && atoi(getenv("HQTICK_BLOCK_ORDER")) == 0);
                     if (ordered) {
                         std::vector<uint32_t> cnt(257, 0), sorted_cls(nd); std::vector<uint8_t> bk(nd);
@@ -492,6 +509,10 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                         for (int b = 0; b < 256; b++) cnt[b + 1] += cnt[b];
                         for (uint32_t i = 0; i < nd; i++) sorted_cls[cnt[bk[i]]++] = dev_cls[i];
                         dev_cls.swap(sorted_cls);
+                        static const int hold = getenv("HQTICK_BLOCK_HOLD") ? atoi(getenv("HQTICK_BLOCK_HOLD")) : 24;  // (3050-class C4 steady state: 0 -> 619 us kernel / 1.53 ms tick, 16 -> 491 / 1.42, 32 -> 467 / 1.40;
+                                                                                                                      // on a 929-class c3 launch, all resident, the order predicts nothing and holding back costs 20 us)
+                        const uint32_t k = pb.blocks->overlaps() ? std::min<uint32_t>((uint32_t)std::max(0, hold), nd / 64) : 0;
+                        if (k) { held.assign(dev_cls.begin(), dev_cls.begin() + k); dev_cls.erase(dev_cls.begin(), dev_cls.begin() + k); nd -= k; }
                     }
                 }
                 std::vector<uint64_t> cfree((size_t)nd * R), ctot((size_t)nd * R), celig(nd);
@@ -505,7 +526,13 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 hqblock::ColTable ct{NC, R, ent_off.data(), ent_res.data(), ent_kind.data(), ent_amount.data(), weight.data(), pool.data(), nullptr, 0};
                 hqblock::ClassTable cl{nd, cfree.data(), ctot.data(), celig.data()};
                 hqblock::Output bo{dx.data(), dstatus.data(), dsteps.data(), nullptr};
-                if (pb.blocks->solve(ct, cl, bo)) {
+                bool dev_ok = pb.blocks->begin(ct, cl, bo);
+                for (uint32_t c : held) {  // (the kernel is running)
+                    const int hr = solve_class_on_host(c);
+                    if (hr < 0) { if (dev_ok) pb.blocks->finish(); out.keys.clear(); out.per_key.clear(); return out; }
+                }
+                dev_ok = dev_ok && pb.blocks->finish();
+                if (dev_ok) {
                     std::vector<unsigned __int128> used;
                     for (uint32_t i = 0; i < nd; i++) {
                         if (dstatus[i] != hqblock::ST_OK) continue;
@@ -530,15 +557,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             }
             for (uint32_t c = 0; c < ncls; c++) {
                 if (solved[c]) continue;
-                hqmilp::Model m; std::vector<ColRef> cols;
-                build_class_model(c, m, cols);
-                hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true);
-                out.milp_nodes += sol.nodes; out.milp_cols += m.ncols(); out.milp_rows += m.nrows(); out.milp_components += sol.n_components;
-                out.blocks_host++;
-                if (!sol.feasible) { out.keys.clear(); out.per_key.clear(); return out; }  // `None` => empty solution  solver.rs:433-437
-                if (!sol.optimal) out.is_optimal = false;
-                if (!sol.canonical) { out.is_canonical = false; blocks_exact = false; }  // certificate only: the incumbent may sit up to rel_gap below the block's optimum
-                for (size_t k = 0; k < cols.size(); k++) if (cols[k].batch != UINT32_MAX) X[(size_t)c * NC + voff[cols[k].batch] + cols[k].variant] = (uint32_t)std::round(sol.x[k]);
+                if (solve_class_on_host(c) < 0) { out.keys.clear(); out.per_key.clear(); return out; }  // `None` => empty solution  solver.rs:433-437
             }
         }
         const double t_sep2 = clock_us();

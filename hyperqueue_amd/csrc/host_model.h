@@ -88,6 +88,12 @@ struct WorkerSet {
 struct BlockSolver {
     virtual ~BlockSolver() {}
     virtual bool solve(const hqblock::ColTable &cols, const hqblock::ClassTable &classes, const hqblock::Output &out) = 0;
+    // The same in two halves, so that the host can work while the kernel runs (it solves the classes it held back: the hardest ones, which would otherwise be the
+    // launch's span).  begin() returns once the launch is enqueued, finish() when the answers are in `out`.  Default: everything in begin().
+    virtual bool begin(const hqblock::ColTable &cols, const hqblock::ClassTable &classes, const hqblock::Output &out) { begun_ok = solve(cols, classes, out); return begun_ok; }
+    virtual bool finish() { return begun_ok; }
+    virtual bool overlaps() const { return false; }  // begin() really returns before the answers are there
+    bool begun_ok = false;
 };
 
 struct Problem {

@@ -497,7 +497,12 @@ std::vector<hqhost::QueueLevels> queue_levels(const Scan &sc, const hqtick_snaps
 struct DeviceBlocks : hqhost::BlockSolver {
     hqtick_ctx *ctx;
     explicit DeviceBlocks(hqtick_ctx *c) : ctx(c) {}
-    bool solve(const hqblock::ColTable &ct, const hqblock::ClassTable &cl, const hqblock::Output &out) override {
+    bool solve(const hqblock::ColTable &ct, const hqblock::ClassTable &cl, const hqblock::Output &out) override { return begin(ct, cl, out) && finish(); }
+    bool overlaps() const override { return true; }
+    // state between begin() and finish()
+    hqblock::Output p_out{}; size_t p_ox = 0, p_ost = 0, p_osteps = 0; uint32_t p_nd = 0, p_nc = 0; bool p_launched = false, p_pending = false;
+    bool begin(const hqblock::ColTable &ct, const hqblock::ClassTable &cl, const hqblock::Output &out) override {
+        p_pending = false;
         const uint32_t NC = ct.n_cols, R = ct.R, nd = cl.n_classes, ne = ct.ent_off[NC];
         auto al8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
         const size_t o_off = 0, o_res = al8(o_off + (size_t)(NC + 1) * 4), o_w = al8(o_res + (size_t)ne * 4), o_kind = al8(o_w + (size_t)NC * 4), o_amt = al8(o_kind + ne),
@@ -525,10 +530,17 @@ struct DeviceBlocks : hqhost::BlockSolver {
         const hipError_t be = hqblock::block_solve(dct, dcl, dout, ctx->block_budget, ctx->stream);
         const bool launched = hqk::take_launch_timer().stop == nullptr && ctx->wait_on_kernel;
         if (be != hipSuccess) return false;
-        if ((launched ? hipEventSynchronize(ctx->ev[10]) : hipStreamSynchronize(ctx->stream)) != hipSuccess) return false;  // the kernel's own completion signal (HQ_HIP_LAST)
-        memcpy(out.x, h + o_x, (size_t)nd * NC * 4); memcpy(out.status, h + o_st, (size_t)nd * 4); memcpy(out.steps, h + o_steps, (size_t)nd * 4);
+        p_out = out; p_ox = o_x; p_ost = o_st; p_osteps = o_steps; p_nd = nd; p_nc = NC; p_launched = launched; p_pending = true;
+        return true;
+    }
+    bool finish() override {
+        if (!p_pending) return false;
+        p_pending = false;
+        if ((p_launched ? hipEventSynchronize(ctx->ev[10]) : hipStreamSynchronize(ctx->stream)) != hipSuccess) return false;  // the kernel's own completion signal (HQ_HIP_LAST)
+        const unsigned char *h = ctx->h_blk.as<unsigned char>();
+        memcpy(p_out.x, h + p_ox, (size_t)p_nd * p_nc * 4); memcpy(p_out.status, h + p_ost, (size_t)p_nd * 4); memcpy(p_out.steps, h + p_osteps, (size_t)p_nd * 4);
         if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[9], ctx->ev[10]); if (us_ >= 0) ctx->stats.block_solve_us = us_; }
-        ctx->stats.n_classes_device = nd;
+        ctx->stats.n_classes_device = p_nd;
         return true;
     }
 };

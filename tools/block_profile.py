@@ -29,3 +29,6 @@ for i, nm in enumerate(names):
 tot = ts[:, 5] - ts[:, 0]
 print(f"per class total median {np.median(tot):.2f} p99 {np.percentile(tot, 99):.2f} max {tot.max():.2f}; phase-1 steps max {a[:, 6].max()}, pool max {a[:, 7].max()}")
 print(t.kernel_stats())
+order = np.argsort(-tot)
+print("launch positions of the 20 slowest classes (0 = launched first):", order[:20].tolist())
+print("their times us:", [round(float(tot[i]), 1) for i in order[:20]])
