@@ -79,11 +79,11 @@ def test_device_sweeps_equal_emulation_on_random_clusters(seed, monkeypatch):
 
     snap = scenario(seed)[0]
     got, ks = _tick(snap, min_cols=16, monkeypatch=monkeypatch)
+    if not got.is_optimal:  # a tick cut by its time limit is cut by the clock: nothing to compare sweep by sweep (and the emulation would run into ITS limit for a minute)
+        pytest.skip("not certified within the time limit on the GPU: a clock-cut tick has no path to compare")
     want, sweeps, rounds = stages(snap, True, min_cols=16, tl=60.0)  # (emulated sweeps are ~100x slower: the time the GPU's 5 s are worth)
     assert got.batches == want.batches
-    if not (got.is_optimal and want.is_optimal):  # a tick cut by its time limit is cut by the clock: nothing to compare sweep by sweep
-        assert not got.is_optimal or want.is_optimal  # (what the GPU certifies in 5 s the emulation certifies in 60)
-        return
+    assert want.is_optimal  # what the GPU certifies in 5 s the emulation certifies in 60
     assert (ks["price_sweeps"], ks["price_rounds"]) == (sweeps, rounds)
     assert got.status == want.status
     if sweeps and want.is_optimal and not want.is_canonical:  # (a tick the host tree finished exactly is compared too: same incumbent in, same search)
