@@ -1768,9 +1768,11 @@ struct EmulatedBlocks : hqhost::BlockSolver {
 };
 thread_local int g_block_emulation = 0, g_price_emulation = 0; thread_local uint32_t g_price_min_cols = 0, g_last_price_sweeps = 0, g_last_price_rounds = 0;
 thread_local uint32_t g_block_budget = 4096, g_last_blocks_device = 0, g_last_blocks_host = 0;
+thread_local double g_last_stage_us[3] = {0, 0, 0};
 }  // namespace
 
 void hqtick_debug_set_price_emulation(int on, uint32_t min_cols) { g_price_emulation = on; g_price_min_cols = min_cols; }
+void hqtick_debug_last_stage_us(double *out3) { if (out3) for (int i = 0; i < 3; i++) out3[i] = g_last_stage_us[i]; }
 void hqtick_debug_last_price(uint32_t *sweeps, uint32_t *rounds) { if (sweeps) *sweeps = g_last_price_sweeps; if (rounds) *rounds = g_last_price_rounds; }
 void hqtick_debug_set_block_emulation(int on, uint32_t budget) { g_block_emulation = on; if (budget) g_block_budget = budget; }
 void hqtick_debug_last_blocks(uint32_t *n_emulated, uint32_t *n_host) { if (n_emulated) *n_emulated = g_last_blocks_device; if (n_host) *n_host = g_last_blocks_host; }
@@ -1810,6 +1812,7 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
     hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
     g_last_blocks_device = cnt.blocks_device; g_last_blocks_host = cnt.blocks_host; g_last_price_sweeps = (uint32_t)cnt.price_sweeps; g_last_price_rounds = (uint32_t)cnt.price_rounds;
+    g_last_stage_us[0] = cnt.t_classify_us; g_last_stage_us[1] = cnt.t_blocks_us; g_last_stage_us[2] = cnt.t_decode_us;
     ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
     cnt.pairs();
     for (size_t k = 0; k < cnt.keys.size(); k++)

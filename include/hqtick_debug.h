@@ -57,6 +57,8 @@ int hqtick_debug_block_solve_host(uint32_t n_cols, uint32_t n_resources, const u
 /* on != 0: hqtick_debug_host_stages / _host_query (this thread) solve the class blocks of the separable path with that emulation instead
  * of the host MILP solver — the code path of a GPU tick, minus the hardware.  budget = search steps per class (0 keeps the current one). */
 void hqtick_debug_set_block_emulation(int on, uint32_t budget);
+/* host wall clock of the separable placement's stages in the last hqtick_debug_host_stages call: worker classes, block solves, counts into Map order (us) */
+void hqtick_debug_last_stage_us(double *out3);
 /* classes the last hqtick_debug_host_stages call solved through the emulation / with the host solver */
 void hqtick_debug_last_blocks(uint32_t *n_emulated, uint32_t *n_host);
 
