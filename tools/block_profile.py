@@ -32,3 +32,24 @@ print(t.kernel_stats())
 order = np.argsort(-tot)
 print("launch positions of the 20 slowest classes (0 = launched first):", order[:20].tolist())
 print("their times us:", [round(float(tot[i]), 1) for i in order[:20]])
+if n.value <= 1024:  # launch order = class order = order of first appearance of the free vector among the workers
+    free = np.asarray(snap.worker_free, np.uint64).reshape(len(snap.worker_id), -1)
+    seen, cls_free = {}, []
+    for row in free:
+        k = tuple(int(x) for x in row)
+        if k not in seen:
+            seen[k] = len(cls_free); cls_free.append(k)
+    if len(cls_free) == n.value:
+        cf = np.asarray(cls_free, np.float64) / 10000.0
+        print("free (cpu, gpu, mem) of the 12 slowest:", [tuple(round(float(v), 2) for v in cf[i]) for i in order[:12]])
+        print("free of 8 typical (median time):", [tuple(round(float(v), 2) for v in cf[i]) for i in order[len(order) // 2: len(order) // 2 + 8]])
+        for r in range(cf.shape[1]):
+            print(f"corr(time, free[{r}]) = {np.corrcoef(tot, cf[:, r])[0, 1]:.3f}")
+        steps = a[:, 6].astype(np.float64)
+        print("corr(time, phase-1 steps) =", round(float(np.corrcoef(tot, steps)[0, 1]), 3))
+        tot_row = np.asarray(snap.worker_total, np.float64).reshape(len(snap.worker_id), -1)[0] / 10000.0
+        share = cf / tot_row
+        for name_, key in (("min share", share.min(axis=1)), ("product of shares", share.prod(axis=1)), ("cpu share", share[:, 0]), ("sum of shares", share.sum(axis=1))):
+            rank = np.argsort(-key, kind="stable")
+            pos = {int(c): i for i, c in enumerate(rank)}
+            print(f"predictor {name_}: ranks of the 20 slowest:", sorted(pos[int(i)] for i in order[:20]), " corr", round(float(np.corrcoef(tot, key)[0, 1]), 3))
