@@ -316,6 +316,28 @@ def wire_block(iters: int):
         return {"error": repr(e)}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run, N ranks on this node, rendezvous on 127.0.0.1 (a free port)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -341,9 +363,15 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: launch the N ranks ourselves (one process per GPU, the same command line the driver uses) and hand their
+        # line through.  With WORLD_SIZE in the environment this process IS one of the ranks (torch.distributed.run started it).
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running (and reporting n_gpus =) {world} rank(s)", file=sys.stderr)
     if args.workload is None:
         args.workload = "c4" if world > 1 else "c3"
     import torch

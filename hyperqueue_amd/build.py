@@ -22,7 +22,7 @@ HOOKED = ["hqtick.cpp", "wire.hip"]          # sources that carry #ifdef HQTICK_
 TEST_ONLY = ["debug_capi.cpp", "price_emul.cpp"]               # sources of the test library only
 HEADERS = ["kernels.h", "block_core.h", "price_core.h", "price.h", "price_emul.h", "price_dev.h", "lp_tab.h", "dev_wave.h", "block_solve.h", "graph.h", "devbuf.h", "host_model.h", "milp.h", "hb_order.h", "wire_core.h",
            os.path.join("..", "..", "include", "hqwire.h"), os.path.join("..", "..", "include", "hqtick.h"), os.path.join("..", "..", "include", "hqtick_debug.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
 # The price sweeps choose among tied block optima by floating-point comparisons: no fused multiply-add contraction in the two places that run that
 # arithmetic (the kernel and its CPU emulation), so that a GPU tick and the emulated tick of the CPU suite walk the same sequence of prices.
 # (block_core.h's explicit fma() calls are the same operation on both sides.)
@@ -37,6 +37,7 @@ def hipcc() -> str:
 
 
 ALLOC_LIB = os.path.join(HERE, "libhqalloc.so")
+EXPORTS = os.path.join(CSRC, "exports.map")  # linker version script: only hqtick_* / hqwire_* / hqalloc_* leave the libraries (libstdc++'s instantiations carry default visibility of their own)
 ALLOC_SOURCES = ["allocator.cpp", "milp.cpp", "price.cpp"]
 ALLOC_HEADERS = ["hb_table.h", "milp.h", "lp_tab.h", "price.h", os.path.join("..", "..", "include", "hqalloc.h")]
 
@@ -45,10 +46,10 @@ def build_alloc(force: bool = False, verbose: bool = False) -> str:
     """libhqalloc.so: the worker-side allocator (include/hqalloc.h).  Host-only on purpose -- worker nodes have no MI355X -- so
     it is compiled with g++ and has no HIP dependency."""
     srcs = [os.path.join(CSRC, s) for s in ALLOC_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ALLOC_HEADERS]
+    deps = srcs + [os.path.join(CSRC, h) for h in ALLOC_HEADERS] + [EXPORTS]
     if not force and os.path.exists(ALLOC_LIB) and all(os.path.getmtime(ALLOC_LIB) >= os.path.getmtime(d) for d in deps):
         return ALLOC_LIB
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", ALLOC_LIB] + srcs
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-shared", "-Wall", "-Wl,--version-script=" + EXPORTS, "-o", ALLOC_LIB] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -70,9 +71,9 @@ def _compile(src: str, hooks: bool, force: bool, verbose: bool) -> str:
 
 
 def _link(lib: str, objs, verbose: bool) -> str:
-    if os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(o) for o in objs):
+    if os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(o) for o in list(objs) + [EXPORTS]):
         return lib
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + list(objs) + ["-ldl"]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORTS, "-o", lib] + list(objs) + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

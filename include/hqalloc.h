@@ -26,6 +26,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: what this header declares is its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define HQALLOC_ABI_VERSION 1u
 #define HQALLOC_FRACTIONS_PER_UNIT 10000u
@@ -128,6 +132,9 @@ int hqalloc_force_claim_from_groups(hqalloc_ctx *ctx, uint32_t resource, uint32_
 const char *hqalloc_last_error(const hqalloc_ctx *ctx);
 uint32_t hqalloc_abi_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

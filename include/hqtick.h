@@ -35,6 +35,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: what this header declares is its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define HQTICK_ABI_VERSION 7u  /* 7: hqtick_kernel_stats carries the price-sweep figures of coupled ticks; cluster membership deltas */
 
@@ -532,6 +536,9 @@ int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
  * bracketed by start / stop events AT THE DISPATCH (hipExtLaunchKernel): the duration is the kernel's own, the figure rocprofv3's kernel trace
  * reports, without the latency of markers queued around it. */
 int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on);
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: what this header declares is its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* The exact MILP solver standing where the reference calls HiGHS (solver/highs.rs:51-88).  Maximise obj.x,
  * col_kind 0 = nat (0..), 1 = bool (0..=1); row_type 0 = Min (>=), 1 = Max (<=), 2 = Eq.  Returns 1 when a solution
@@ -99,6 +103,9 @@ int hqwire_debug_encode_host(const struct hqwire_tables *tables, const struct hq
  * must not depend on it -- a phase that did would be a data race on the GPU. */
 int hqwire_debug_encode_host_order(const struct hqwire_tables *tables, const struct hqwire_records *records, const struct hqwire_output *out, int order);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

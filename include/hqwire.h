@@ -37,6 +37,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: what this header declares is its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define HQWIRE_ABI_VERSION 2u
 #define HQWIRE_MAX_RECORDS 2048u                 /* records per worker message handled on the device */
@@ -107,6 +111,9 @@ int hqwire_encode_device(const hqwire_tables *tables, const hqwire_records *reco
 
 uint32_t hqwire_abi_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

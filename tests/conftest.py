@@ -38,3 +38,13 @@ def oracle_backend():
             return self._cache[key]
 
     return _Backend()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """which side ran into a solver limit, and how often (tests/limits.py): printed, so that such ticks are counted instead of vanishing as skips"""
+    try:
+        from limits import SIDES
+    except Exception:
+        return
+    if any(SIDES.values()):
+        terminalreporter.write_line(f"solver limits hit in this session: product only {SIDES['product']}, canonical oracle only {SIDES['oracle']}, both {SIDES['both']}")

@@ -66,6 +66,15 @@ def test_device_sweeps_walk_the_emulations_path(name, monkeypatch):
     assert got.batches == want.batches and got.counts == want.counts
 
 
+# Seeds of the family below that the product may leave uncertified within 5 s although plain HiGHS certifies them (the primal side of small
+# hard models).  Explicit and counted: the list may shrink, test_the_allow_list_is_short keeps it from growing.
+UNCERTIFIED_ALLOWED = frozenset()
+
+
+def test_the_allow_list_is_short():
+    assert len(UNCERTIFIED_ALLOWED) <= 2
+
+
 @pytest.mark.parametrize("seed", range(2000, 2024))
 def test_device_sweeps_equal_emulation_on_random_clusters(seed, monkeypatch):
     """tools/price_fuzz.py's family (clusters mid-run: every worker its own block; 1-3 priority levels; 12-192 workers), the sweeps forced on from 16
@@ -79,49 +88,23 @@ def test_device_sweeps_equal_emulation_on_random_clusters(seed, monkeypatch):
 
     snap = scenario(seed)[0]
     got, ks = _tick(snap, min_cols=16, monkeypatch=monkeypatch)
-    if not got.is_optimal:  # a tick cut by its time limit is cut by the clock: nothing to compare sweep by sweep (and the emulation would run into ITS limit for a minute)
-        pytest.skip("not certified within the time limit on the GPU: a clock-cut tick has no path to compare")
+    if not got.is_optimal:
+        # A tick cut by its time limit is cut by the clock: there is no path to compare sweep by sweep (and the emulation would run into ITS limit for a minute).
+        # It is not skipped: its answer must be a feasible point of the reference's model with the oracle's mapping on it (T3), and a tick that plain HiGHS
+        # certifies under the same limit fails the test unless its seed is on the counted allow-list.
+        from limits import uncertified
+
+        uncertified(snap, got, seed, UNCERTIFIED_ALLOWED, 5.0, "price_fuzz")
+        return
     want, sweeps, rounds = stages(snap, True, min_cols=16, tl=60.0)  # (emulated sweeps are ~100x slower: the time the GPU's 5 s are worth)
     assert got.batches == want.batches
     assert want.is_optimal  # what the GPU certifies in 5 s the emulation certifies in 60
     assert (ks["price_sweeps"], ks["price_rounds"]) == (sweeps, rounds)
     assert got.status == want.status
-    if sweeps and want.is_optimal and not want.is_canonical:  # (a tick the host tree finished exactly is compared too: same incumbent in, same search)
-        assert got.counts == want.counts
-    elif want.is_optimal:
-        assert got.counts == want.counts
+    assert got.counts == want.counts  # (a tick the host tree finished exactly is compared too: same incumbent in, same search)
 
 
-def _model_point(model, counts):
-    """the counts as a point of the oracle's model; flag columns (zero-cost 0/1) switched on where their `>=` row needs them (they are existential)"""
-    cd = {(q, v, w): c for (q, v, w, c) in counts}
-    n = len(model["obj"])
-    x = np.zeros(n)
-    for j in range(n):
-        if model["ctype"][j] == 0:
-            x[j] = cd.get((int(model["crq"][j]), int(model["cvariant"][j]), int(model["cworker"][j])), 0)
-    roff, rcol, rcoef = model["roff"], model["rcol"], model["rcoef"]
-    for i in range(len(model["rhs"])):
-        if model["rtype"][i] != 0:
-            continue
-        a, b = roff[i], roff[i + 1]
-        act = float(np.dot(rcoef[a:b], x[rcol[a:b]]))
-        if act < model["rhs"][i] - 1e-6:
-            for k in range(a, b):
-                j = rcol[k]
-                if model["kind"][j] == 1 and model["obj"][j] == 0.0 and rcoef[k] >= model["rhs"][i] - 1e-9:
-                    x[j] = 1.0
-                    break
-    return x
-
-
-def _rows_hold(model, x):
-    from scipy.sparse import csr_matrix
-
-    A = csr_matrix((model["rcoef"], model["rcol"], model["roff"]), shape=(len(model["rhs"]), len(x)))
-    act = A @ x
-    rt, rhs = model["rtype"], model["rhs"]
-    return bool(np.all(act[rt == 1] <= rhs[rt == 1] + 1e-6) and np.all(act[rt == 0] >= rhs[rt == 0] - 1e-6) and np.all(np.abs(act[rt == 2] - rhs[rt == 2]) <= 1e-6))
+from limits import model_point as _model_point, rows_hold as _rows_hold  # noqa: E402
 
 
 def _full_tick_checks(snap, bound_fn):
