@@ -154,7 +154,7 @@ def multi_tick_env(seed: int) -> SchedEnv:
     return env
 
 
-def main():
+def main(only=None):
     from oracle.oracle import Oracle
     from test_gpu_parity import random_env
 
@@ -182,6 +182,13 @@ def main():
         r = Oracle(cfg, canonical=True).tick(snap)
         out[f"{name}_{kw['n_tasks']}x{kw['n_workers']}"] = dict(
             snapshot=snapshot_to_json(snap, cfg, gen=dict(workload=name, seed=0, **kw)), expect=result_digest(r))
+    # BASELINE configs[0] at full size: 1 000 single-core tasks on 4 workers x 4 cores (benchmarks/experiment-per-task-overhead.py:33-55) — small enough to be
+    # stored with its columns and every record
+    cfg = abi.make_config(time_limit_s=60.0)
+    snap = workloads.make("c1", seed=0)
+    out["c1_1000x4"] = dict(snapshot=snapshot_to_json(snap, cfg), expect=result_to_json(Oracle(cfg, canonical=True).tick(snap)))
+    if only:
+        out = {k: v for k, v in out.items() if k in only}
     for k, v in out.items():
         with open(os.path.join(HERE, k + ".json"), "w") as f:
             json.dump(v, f, separators=(",", ":"))
@@ -192,4 +199,4 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "big":
         make_big(sys.argv[2:])
     else:
-        main()
+        main(sys.argv[1:])  # names given: only those files are rewritten

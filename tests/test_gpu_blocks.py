@@ -119,3 +119,48 @@ def test_steady_state_c3_full_size_objective_equals_plain_highs(dev, seed):
     assert _rows_hold(m, x)
     z = float(np.dot(m["obj"], x))
     assert z >= m["objective"] * (1.0 - 1e-9) - 1e-12 and abs(z - m["objective"]) <= 1e-4 * abs(m["objective"]), (z, m["objective"])
+
+
+def test_steady_state_c4_512_objective_equals_plain_highs(dev):
+    """the same for the C4 shape (2-variant OR-lists): tests/golden/big/c4_steady_512.json's snapshot — 512 busy workers, 5.4 k columns after elimination — against
+    PLAIN HiGHS on the reference's model: equal objective (tier T2), every row satisfied by the product's counts."""
+    from limits import model_point, rows_hold
+    from oracle.oracle import Oracle
+
+    snap = workloads.make_steady("c4", seed=2, n_tasks=500_000, n_workers=512)
+    got = dev.tick(snap)
+    assert got.is_optimal
+    o = Oracle(abi.make_config(time_limit_s=60.0))
+    want = o.tick(snap)
+    assert want.is_optimal
+    m = o.last_model()
+    x = model_point(m, got.counts)
+    assert rows_hold(m, x)
+    z = float(np.dot(m["obj"], x))
+    assert z >= m["objective"] * (1.0 - 1e-9) - 1e-12 and abs(z - m["objective"]) <= 1e-4 * abs(m["objective"]), (z, m["objective"])
+
+
+def test_c4_full_objective_within_the_gap_of_the_lp_bound(dev):
+    """BASELINE configs[3] at full size.  Plain HiGHS holds an unproven incumbent on this 65 536-column model after minutes, so the T2 check is made against a
+    bound that needs no MILP solver: the LP relaxation of the reference's model (HiGHS simplex, ~2 s).  The product's counts satisfy every row of that model
+    and their objective is within the reference's mip_rel_gap = 1e-4 of the bound — i.e. HiGHS itself would accept this point as optimal (solver/highs.rs:65-68)."""
+    from limits import model_point, rows_hold
+    from oracle.oracle import Oracle
+    from scipy.optimize import linprog
+    from scipy.sparse import csr_matrix
+
+    snap = workloads.make("c4")
+    got = dev.tick(snap)
+    assert got.is_optimal
+    o = Oracle(abi.make_config(time_limit_s=0.5))  # only the model is wanted: the solve is cut short
+    o.tick(snap)
+    m = o.last_model()
+    x = model_point(m, got.counts)
+    assert rows_hold(m, x)
+    rt = m["rtype"]
+    assert (rt == 1).all()  # a saturated tick: resource rows only (<=)
+    A = csr_matrix((m["rcoef"], m["rcol"], m["roff"]), shape=(len(m["rhs"]), len(m["obj"])))
+    lp = linprog(-np.asarray(m["obj"]), A_ub=A, b_ub=np.asarray(m["rhs"]), bounds=(0, None), method="highs")
+    assert lp.status == 0
+    bound, z = -lp.fun, float(np.dot(m["obj"], x))
+    assert z <= bound * (1.0 + 1e-9) and z >= bound * (1.0 - 1e-4), (z, bound)

@@ -129,6 +129,46 @@ def test_c2_exact(gpu, oracle):
     assert all(len(got.assigned(w)) == 128 and len(got.prefills(w)) == 40 for w in range(256))
 
 
+def test_c1_exact_and_drained_like_the_benchmark(gpu, oracle):
+    """BASELINE configs[0] at full size (benchmarks/experiment-per-task-overhead.py:33-55: 1 000 single-core `sleep 0` tasks, 4 workers x 4 cores): the first
+    tick against the oracle and the committed fixture's shape, then the benchmark's own loop — everything a tick hands out finishes before the next tick —
+    until the queue is empty, HIP and oracle side by side, every tick record for record."""
+    snap = workloads.make("c1")
+    got, want = gpu.tick(snap), oracle.tick(snap)
+    assert_same(got, want)
+    assert [(b.size, b.limit, b.limit_reached) for b in got.batches] == [(16, 16, True)]          # 4 workers x 4 cores of 1-cpu tasks
+    assert all(len(got.assigned(w)) == 4 and len(got.prefills(w)) == 40 for w in range(4))      # + proactive filling: max 40 per worker
+    cfg = abi.make_config(time_limit_s=60.0)
+    envs = [SchedEnv(cfg), SchedEnv(cfg)]
+    for e in envs:
+        e.new_workers(4, WB(4))
+        e.new_tasks(1000, TB().cpus(1))
+    from hyperqueue_amd.tick import Tick
+    from oracle.oracle import Oracle
+
+    backends = [Tick(cfg), Oracle(cfg, canonical=True)]
+    handed, ticks = 0, 0
+    while any(t.state == 0 for t in envs[0].tasks.values()) and ticks < 400:
+        rs = [e.schedule(b) for e, b in zip(envs, backends)]
+        assert_same(rs[0], rs[1])
+        handed += sum(1 for recs in rs[0].records for (_, _, k) in recs if k == abi.HQ_REC_ASSIGN)
+        for e in envs:
+            # the workers answer the tick's retracts (a task the tick took out of a prefill set is Retracting{old} until `old` lets it go: reactor.rs:462-508) ...
+            by_worker = {}
+            for t in e.tasks.values():
+                if t.state == 4:
+                    by_worker.setdefault(t.worker, []).append(t.id)
+            for wid, tids in sorted(by_worker.items()):
+                e.retract_response(wid, sorted(tids))
+            # ... and `sleep 0`: every assigned task has finished before the next tick
+            for t in sorted(e.tasks.values(), key=lambda t: t.id):
+                if t.state == 1:
+                    e.finish_task(t.id, t.worker)
+        ticks += 1
+    assert not any(t.state == 0 for t in envs[0].tasks.values()) and handed >= 1000 - 4 * 40
+    backends[0].close()
+
+
 def test_c3_reduced_exact(gpu, oracle):
     snap = workloads.make("c3", n_tasks=60_000, n_workers=48)
     assert_same(gpu.tick(snap), oracle.tick(snap))
