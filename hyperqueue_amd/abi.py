@@ -11,7 +11,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-HQTICK_ABI_VERSION = 7
+HQTICK_ABI_VERSION = 8
 HQTICK_FLAG_NO_KERNEL_TIMING, HQTICK_FLAG_COMPACT_RECORDS, HQTICK_FLAG_COMPACT_DELTA16 = 1, 2, 4
 HQ_AMOUNT_MAX = 0xFFFF_FFFF_FFFF_FFFF
 HQ_FRACTIONS_PER_UNIT = 10_000
@@ -19,6 +19,7 @@ HQ_MAX_TASK_PER_WORKER = 1024
 HQ_NO_TIME_LIMIT = 0x7FFF_FFFF_FFFF_FFFF
 HQ_BLOCKER_UNBOUNDED = 0xFFFF_FFFF
 HQ_NO_WORKER = 0xFFFF_FFFF
+HQ_RETRACTING_RESIDENT = HQ_WORKERS_RESIDENT = 0xFFFF_FFFF  # sentinels of n_retracting / n_workers: that side of the snapshot lives in the library
 HQ_ENTRY_AMOUNT, HQ_ENTRY_ALL = 0, 1
 HQ_WORKER_SN, HQ_WORKER_STOPPING = 1, 2
 HQTICK_DONE, HQTICK_NEED_MORE_COMPUTE, HQTICK_NO_PROGRESS = 0, 1, 2
@@ -239,7 +240,7 @@ class Snapshot:
 
         s.n_resources = R
         if resident_workers:
-            s.n_workers = 0
+            s.n_workers = HQ_WORKERS_RESIDENT  # fails loudly if the library holds no worker set (0 would run as a tick of zero workers)
             s.n_groups = self.n_groups
         else:
             s.n_workers = W

@@ -337,6 +337,53 @@ class SchedEnv:
     def new_workers(self, n: int, builder: WorkerBuilder) -> List[int]:
         return [self.new_worker(builder) for _ in range(n)]
 
+    def remove_worker(self, wid: int) -> List[Tuple[int, int, int]]:
+        """on_remove_worker  server/reactor.rs:64-147, what the scheduler state sees of it.  The lost worker's assigned / running tasks go back to their queues
+        as Waiting (add_ready_task: may dissolve lower-priority prefill sets); a task that is Retracting{old} and was REDIRECTED to the lost worker loses the
+        redirect and goes back into its queue, still Retracting{old} (:89-94); its prefilled tasks move from the prefill set into the queue (:97-104).  Then every
+        task Retracting{lost worker}: with a redirect it becomes Assigned{target} and the target gets its ComputeTasks message, without one it is Waiting
+        (:124-145).  Returns those messages as (task, target worker id, variant)."""
+        w = self.workers.pop(wid)
+        self.worker_map.remove(wid)
+        if w.sn():
+            for tid in sorted(w.assigned_tasks):
+                t = self.tasks[tid]
+                if t.state == RETRACTING:
+                    assert self.redirects.pop(tid, None) is not None
+                else:
+                    assert t.state in (ASSIGNED, RUNNING) and t.worker == wid
+                    t.state, t.worker, t.rv = WAITING, None, None
+                self._add_ready(t)
+            for tid in sorted(w.prefilled_tasks):
+                t = self.tasks[tid]
+                assert t.state == PREFILLED and t.worker == wid
+                t.state, t.worker = WAITING, None
+                self.prefill[t.rq][1].remove(tid)  # move_prefilled_task_to_ready  taskqueue.rs:263-271: plain add(), no prefill disposal
+                self.ready[t.rq].add(tid)
+        else:
+            tid, _is_root = w.mn_task
+            t = self.tasks[tid]
+            assert t.state == RUNNING_MN
+            if t.mn_workers[0] == wid:  # root: the task returns to its queue, the other nodes are free again
+                for other in t.mn_workers[1:]:
+                    if other in self.workers:
+                        self.workers[other].mn_task = None
+                t.state, t.mn_workers = WAITING, None
+                self._add_ready(t)
+            else:
+                t.mn_workers = [x for x in t.mn_workers if x != wid]
+        sent = []
+        for t in sorted(self.tasks.values(), key=lambda t: t.id):
+            if t.state == RETRACTING and t.worker == wid:
+                if t.id in self.redirects:
+                    target, v = self.redirects.pop(t.id)
+                    t.state, t.worker, t.rv = ASSIGNED, target, v
+                    sent.append((t.id, target, v))
+                else:
+                    t.state, t.worker = WAITING, None
+                self.retaken_variant.pop(t.id, None)
+        return sent
+
     def new_worker_cpus(self, cpus: int) -> int:
         return self.new_worker(WorkerBuilder(cpus))
 

@@ -1110,10 +1110,13 @@ struct TickRun {
 int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool use_resident) {
     hqtick_snapshot full;
     bool copied = false;
+    if (s && s->n_workers == HQ_WORKERS_RESIDENT && !(s->worker_id == nullptr && ctx->cluster_valid && ctx->mirror.valid))
+        return fail(ctx, HQTICK_E_INVALID, s->worker_id ? "n_workers == HQ_WORKERS_RESIDENT with worker arrays in the snapshot"
+                                                         : "n_workers == HQ_WORKERS_RESIDENT without a resident worker set (hqtick_cluster_upload; dropped by hqtick_cluster_drop)");
     if (s && s->worker_id == nullptr && ctx->cluster_valid && ctx->mirror.valid) {  // the worker side lives in the library (hqtick_cluster_*, ABI 7)
         hqtick_ctx::ClusterMirror &m = ctx->mirror;
         const uint32_t W = (uint32_t)m.id.size();
-        if (s->n_workers != 0 && s->n_workers != W) return fail(ctx, HQTICK_E_INVALID, "snapshot without worker arrays: n_workers must be 0 or the resident worker count");
+        if (s->n_workers != 0 && s->n_workers != HQ_WORKERS_RESIDENT && s->n_workers != W) return fail(ctx, HQTICK_E_INVALID, "snapshot without worker arrays: n_workers must be HQ_WORKERS_RESIDENT, 0 or the resident worker count");
         if (s->n_resources != ctx->cl_R) return fail(ctx, HQTICK_E_INVALID, "snapshot without worker arrays: n_resources differs from the resident tables");
         if (m.blk_dirty) {
             m.blk_worker.clear(); m.blk_rq.clear(); m.blk_variant.clear();
@@ -1159,7 +1162,7 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
             hqtick_ctx::RetrEntry &e = it->second;
             const uint8_t kind = i < ctx->red_kind.size() ? ctx->red_kind[i] : (uint8_t)HQ_REDIRECT_FROM_PREFILL;
             e.in_queue = false;  // take_tasks removed it from its queue (or it came out of a prefill set)
-            if (kind == HQ_REDIRECT_SAME_WORKER) { e.has_redirect = false; continue; }  // back on the worker it is retracting from: no redirect entry (mapping.rs:69)
+            if (kind == HQ_REDIRECT_SAME_WORKER) continue;  // back on the worker it is retracting from: insert_sn_task(old) only, the redirect table is untouched (mapping.rs:66-80)
             if (ctx->red_worker[i] < W) { e.has_redirect = true; e.target_id = s->worker_id[ctx->red_worker[i]]; e.variant = ctx->red_variant[i]; }
         }
     }
@@ -1619,14 +1622,37 @@ int hqtick_cluster_remove_workers(hqtick_ctx *ctx, uint32_t n, const uint32_t *w
         }
         k++;
     }
-    if (!ctx->retr.empty()) {  // Retracting tasks of a lost worker leave the table; a lost redirect target only clears the redirect (one pass over the table, whatever n is)
+    ctx->resp_task.clear(); ctx->resp_worker.clear(); ctx->resp_variant.clear();
+    if (!ctx->retr.empty()) {  // on_remove_worker's two passes over the Retracting tasks (server/reactor.rs:86-147), one pass over the table whatever n is
         std::vector<uint32_t> lost(worker_id, worker_id + n);
         std::sort(lost.begin(), lost.end());
         auto is_lost = [&](uint32_t id) { return std::binary_search(lost.begin(), lost.end(), id); };
-        for (auto it = ctx->retr.begin(); it != ctx->retr.end();) { if (is_lost(it->second.old_id)) it = ctx->retr.erase(it); else { if (it->second.has_redirect && is_lost(it->second.target_id)) it->second.has_redirect = false; ++it; } }
+        for (auto it = ctx->retr.begin(); it != ctx->retr.end();) {
+            hqtick_ctx::RetrEntry &e = it->second;
+            if (is_lost(e.old_id)) {
+                // the worker it was retracting from is gone: with a redirect (to a worker that stays) the task is Assigned{target} now and the host sends its
+                // ComputeTasks message (reactor.rs:131-141) — reported through hqtick_cluster_last_reassigned; without one it is a Waiting task of its queue
+                if (e.has_redirect && !is_lost(e.target_id)) { ctx->resp_task.push_back(it->first); ctx->resp_worker.push_back(e.target_id); ctx->resp_variant.push_back(e.variant); }
+                it = ctx->retr.erase(it);
+                continue;
+            }
+            // the redirect TARGET is gone: the redirect is dropped and the task goes back into its queue, still Retracting{old} (reactor.rs:89-94: redirects.remove +
+            // add_ready_task) — the host re-adds it to the resident ready set with the other tasks of the lost worker; the next tick sees it as Retracting again
+            if (e.has_redirect && is_lost(e.target_id)) { e.has_redirect = false; e.in_queue = true; }
+            ++it;
+        }
     }
     m.id.resize(k); m.rem.resize(k); m.min_util.resize(k); m.flags.resize(k); m.group.resize(k); m.total.resize((size_t)k * R); m.free_.resize((size_t)k * R);
     m.blk_dirty = true;
+    return 0;
+}
+
+int hqtick_cluster_last_reassigned(const hqtick_ctx *ctx, uint32_t *n, const uint64_t **task_id, const uint32_t **worker_id, const uint8_t **variant) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (n) *n = (uint32_t)ctx->resp_task.size();
+    if (task_id) *task_id = ctx->resp_task.data();
+    if (worker_id) *worker_id = ctx->resp_worker.data();
+    if (variant) *variant = ctx->resp_variant.data();
     return 0;
 }
 

@@ -98,7 +98,7 @@ class Tick:
         resident_retracting: the Retracting tasks of the queues come from the library's own table (hqtick_retracting_*, ABI 7)"""
         sc = snap.to_c(resident_workers=resident_workers)
         if resident_retracting:
-            sc.n_retracting = 0xFFFFFFFF; sc.retracting_task = None; sc.retracting_worker = None; sc.retracting_redirect_worker = None; sc.retracting_redirect_variant = None
+            sc.n_retracting = abi.HQ_RETRACTING_RESIDENT; sc.retracting_task = None; sc.retracting_worker = None; sc.retracting_redirect_worker = None; sc.retracting_redirect_variant = None
         return abi.parse_result(self.tick_raw(sc, resident), len(snap.worker_id), snap.n_resources)
 
     def batches(self, snap: abi.Snapshot):
@@ -179,10 +179,16 @@ class Tick:
         self._chk(self._lib.hqtick_cluster_add_workers(self._ctx, len(ids), ids.ctypes.data_as(abi.u32p), tot.ctypes.data_as(abi.u64p), fre.ctypes.data_as(abi.u64p), prem, pmu, pfl, pgr))
 
     def cluster_remove_workers(self, worker_id):
-        """on_remove_worker (ABI 7): by id; later rows move up"""
+        """on_remove_worker (ABI 7): by id; later rows move up.  Returns [(task, target worker id, variant)]: Retracting tasks of the removed workers that carried a
+        redirect and are Assigned to its target from now on — the host sends their ComputeTasks messages (ABI 8, hqtick_cluster_last_reassigned)"""
         ids = np.ascontiguousarray(worker_id, np.uint32)
         self._lib.hqtick_cluster_remove_workers.argtypes = [C.c_void_p, C.c_uint32, abi.u32p]
         self._chk(self._lib.hqtick_cluster_remove_workers(self._ctx, len(ids), ids.ctypes.data_as(abi.u32p)))
+        n = C.c_uint32(); pt, pw, pv = abi.u64p(), abi.u32p(), abi.u8p()
+        self._lib.hqtick_cluster_last_reassigned.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(abi.u64p), C.POINTER(abi.u32p), C.POINTER(abi.u8p)]
+        self._chk(self._lib.hqtick_cluster_last_reassigned(self._ctx, C.byref(n), C.byref(pt), C.byref(pw), C.byref(pv)))
+        k = n.value
+        return list(zip(abi._np(pt, k, np.uint64).tolist(), abi._np(pw, k, np.uint32).tolist(), abi._np(pv, k, np.uint8).tolist())) if k else []
 
     def cluster_set_blocked(self, worker_id: int, pairs):
         """Worker::blocked_requests of one worker := pairs of (rq, variant) (ABI 7)"""

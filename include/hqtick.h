@@ -40,7 +40,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define HQTICK_ABI_VERSION 7u  /* 7: hqtick_kernel_stats carries the price-sweep figures of coupled ticks; cluster membership deltas */
+#define HQTICK_ABI_VERSION 8u  /* 8: HQ_WORKERS_RESIDENT, hqtick_cluster_last_reassigned; 7: hqtick_kernel_stats carries the price-sweep figures of coupled ticks; cluster membership deltas */
 
 /* ResourceAmount::MAX                                    common/resources/amount.rs:31 */
 #define HQ_AMOUNT_MAX UINT64_MAX
@@ -372,7 +372,9 @@ int hqtick_cluster_drop(hqtick_ctx *ctx);
  *   hqtick_cluster_workers         the current ids in row order (valid until the next membership call).
  * One re-pack kernel per membership call (rows read from HBM, new rows from pinned staging); nothing is re-uploaded.
  * A tick whose snapshot has worker_id == NULL takes the WHOLE worker side from the library: ids, total / free rows (as kept current by
- * hqtick_cluster_update_workers), remaining lifetime, min_utilization, flags, groups and the blocked pairs; n_workers must be 0 or the current count,
+ * hqtick_cluster_update_workers), remaining lifetime, min_utilization, flags, groups and the blocked pairs.  Say so with n_workers = HQ_WORKERS_RESIDENT: such a
+ * tick FAILS (HQTICK_E_INVALID) when the library holds no worker set (never uploaded, or hqtick_cluster_drop) instead of running as a legitimate tick of
+ * zero workers, which is what n_workers = 0 with NULL arrays means without a resident set (with one, 0 and the current count are accepted as before).
  * worker_map_rank is emulated, and the per-worker CSRs assigned_off / prefilled_off (if given) must have current-count + 1 entries.  The reactor then
  * no longer flattens W x R worker arrays per tick.
  */
@@ -396,13 +398,20 @@ int hqtick_cluster_workers(const hqtick_ctx *ctx, uint32_t *n_workers, const uin
  *                              ComputeTasks message), without one it is an ordinary Waiting task of its queue again.  Other ids are ignored, as in the
  *                              reference ("retracted task in invalid state").  Returns the number of tasks that left the table.
  *   hqtick_retracting_count    entries in the table.
- * Entries whose old worker is removed (hqtick_cluster_remove_workers) leave the table; a removed redirect TARGET only clears the redirect.
+ * hqtick_cluster_remove_workers applies on_remove_worker (server/reactor.rs:86-147) to the table: an entry whose OLD worker is removed leaves it — with a
+ * redirect to a worker that stays the task is Assigned{target} from now on and the host owes the target its ComputeTasks message: those (task, target id,
+ * variant) triples are read with hqtick_cluster_last_reassigned (valid until the next hqtick_cluster_remove_workers / hqtick_retract_response call); without
+ * one it is an ordinary Waiting task of its queue.  An entry whose redirect TARGET is removed loses the redirect and is in its queue again, still
+ * Retracting{old} (redirects.remove + add_ready_task): the host re-adds the task to the resident ready set (hqtick_ready_add) with the lost worker's other tasks.
  */
 #define HQ_RETRACTING_RESIDENT 0xFFFFFFFFu
+/* hqtick_snapshot.n_workers of a tick whose worker side is the library's resident worker set (worker_id == NULL) */
+#define HQ_WORKERS_RESIDENT 0xFFFFFFFFu
 int hqtick_retracting_add(hqtick_ctx *ctx, uint32_t n, const uint64_t *task_id, const uint32_t *worker_id);
 int hqtick_retract_response(hqtick_ctx *ctx, uint32_t worker_id, uint32_t n, const uint64_t *task_id, uint32_t *n_assigned, const uint64_t **assigned_task,
                             const uint32_t **assigned_worker_id, const uint8_t **assigned_variant);
 uint32_t hqtick_retracting_count(const hqtick_ctx *ctx);
+int hqtick_cluster_last_reassigned(const hqtick_ctx *ctx, uint32_t *n, const uint64_t **task_id, const uint32_t **worker_id, const uint8_t **variant);
 
 /*
  * Device-resident dependency graph (BASELINE config 5): the `Waiting{unfinished_deps}` counters and the consumer

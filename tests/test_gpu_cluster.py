@@ -240,6 +240,93 @@ def test_retracting_table_resident_in_the_library(seed):
     g.close(); r.close()
 
 
+@pytest.mark.parametrize("seed", range(30))
+def test_worker_removal_with_the_resident_retracting_table(seed):
+    """hqtick_cluster_remove_workers against on_remove_worker (server/reactor.rs:86-147) on the resident Retracting table.  The scenario family of
+    the test above, with the worker set resident too; once redirected Retracting tasks exist a worker is lost — the one such a task is retracting FROM (the task
+    becomes Assigned{target}: the library must report it, hqtick_cluster_last_reassigned, exactly as SchedEnv.remove_worker sends the ComputeTasks message) or the
+    redirect's TARGET (the task loses the redirect and sits in its queue again, still Retracting{old}: the next resident tick must see it as such).  Every tick
+    on the resident state equals the plain tick on the mirror's full snapshot."""
+    from hyperqueue_amd.core import SchedEnv, TaskBuilder as TB, WorkerBuilder as WB
+    from hyperqueue_amd.tick import HqTickError, Tick
+
+    rng = np.random.default_rng(12_000 + seed)
+    cfg = abi.make_config(reserve=int(rng.integers(0, 2)), fill_max=int(rng.integers(1, 4)), time_limit_s=20.0)
+    e = SchedEnv(cfg)
+    g, r = Tick(cfg), Tick(cfg)
+    shapes = [TB().cpus(1), TB().cpus(2)]
+    for c in [int(x) for x in np.random.default_rng(seed).integers(1, 5, size=4)]:
+        e.new_worker(WB(c))
+    prio, n_msgs, removed, uploaded = 0, 0, 0, False
+
+    def sync_rows(snap):  # the reactor's row deltas: every row, each tick (the table is a handful of workers)
+        W = len(snap.worker_id)
+        r.cluster_update_workers(list(range(W)), np.asarray(snap.worker_free, np.uint64).reshape(W, snap.n_resources))
+
+    for round_ in range(7):
+        n_new = int(rng.integers(1, 7)) if round_ else int(rng.integers(8, 16))
+        if round_ and rng.random() < 0.7:
+            prio += 1
+        for _ in range(n_new):
+            e.new_task(shapes[int(rng.integers(0, 2))].user_priority(prio))
+        new_msgs = e.retract_messages[n_msgs:]; n_msgs = len(e.retract_messages)
+        if new_msgs:
+            r.retracting_add([t for (_, t) in new_msgs], [w for (w, _) in new_msgs])
+        snap = e.snapshot()
+        if not uploaded:
+            r.cluster_upload(snap); uploaded = True
+        else:
+            sync_rows(snap)
+        try:
+            want = g.tick(snap)
+        except HqTickError as err:
+            assert err.code == abi.HQTICK_E_UNSUPPORTED
+            break
+        got = r.tick(snap, resident_workers=True, resident_retracting=True)
+        _same(got, want)
+        assert got.redirects == want.redirects and got.redirect_kinds == want.redirect_kinds
+        e.apply(want)
+        done = 0
+        for t in sorted(e.tasks.values(), key=lambda t: t.id):
+            if t.state == 1 and done < int(rng.integers(1, 5)):
+                e.finish_task(t.id, t.worker); done += 1
+        # lose a worker that matters to a redirected Retracting task, if there is one (never the last two workers)
+        red = [(t.id, t.worker, e.redirects[t.id][0]) for t in sorted(e.tasks.values(), key=lambda t: t.id) if t.state == 4 and t.id in e.redirects]
+        if red and len(e.workers) > 2 and removed < 2:
+            tid, old, target = red[int(rng.integers(0, len(red)))]
+            wid = old if rng.random() < 0.5 else target
+            if any(e.tasks[x].state == 4 and x not in e.redirects for x in e.workers[wid].assigned_tasks):
+                continue  # a Retracting task retaken by its own worker sits there: the reference's assert fires in on_remove_worker (reactor.rs:90) — not a scenario
+            sent = e.remove_worker(wid)
+            assert r.cluster_remove_workers([wid]) == sent
+            removed += 1
+            new_msgs = e.retract_messages[n_msgs:]; n_msgs = len(e.retract_messages)  # add_ready_task of the returned tasks may have dissolved prefill sets
+            if new_msgs:
+                r.retracting_add([t for (_, t) in new_msgs], [w for (w, _) in new_msgs])
+            assert r.cluster_workers().tolist() == sorted(e.workers)
+        assert r.retracting_count() == sum(1 for t in e.tasks.values() if t.state == 4)
+    g.close(); r.close()
+
+
+def test_resident_workers_without_a_worker_set_fail_loudly():
+    """n_workers = HQ_WORKERS_RESIDENT with nothing resident (never uploaded / dropped) is HQTICK_E_INVALID, not a legitimate tick of zero workers"""
+    from hyperqueue_amd.tick import HqTickError
+
+    t = _tick()
+    snap = workloads.make_steady("c3", seed=3, n_tasks=5_000, n_workers=8)
+    with pytest.raises(HqTickError) as err:
+        t.tick(snap, resident_workers=True)
+    assert err.value.code == abi.HQTICK_E_INVALID
+    t.cluster_upload(snap)
+    a = t.tick(snap, resident_workers=True)
+    assert sum(len(x) for x in a.records) > 0
+    t.cluster_drop()
+    with pytest.raises(HqTickError) as err:
+        t.tick(snap, resident_workers=True)
+    assert err.value.code == abi.HQTICK_E_INVALID and "HQ_WORKERS_RESIDENT" in str(err.value)
+    t.close()
+
+
 def test_membership_deltas_at_cluster_scale_on_coupled_ticks():
     """The same deltas at BASELINE scale, on ticks the price sweeps solve: 1024 workers mid-run, three priority levels (every tick one coupled model of the whole
     cluster), 100 workers lost and 100 fresh ones joining per step, rejects, row changes — the resident tick (no worker arrays in the snapshot) equals the plain tick
