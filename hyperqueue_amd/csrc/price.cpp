@@ -279,6 +279,7 @@ struct Solver {
         const double t0 = now_us();
         if (!sw.sweep(pig.data(), tot)) { failed = true; return -1; }
         sw.stat_sweep_us += now_us() - t0; sw.stat_sweeps++;
+        if (!sw.merges_clock() && now_us() * 1e-6 > sw.guard_s) sw.time_up = true;  // (a sharded sweeper has merged the ranks' readings inside sweep(): a local reading here could split the replicas)
         sweep_steps += 64.0 + (double)tot.max_steps;
         if (tot.n_budget > std::max<uint32_t>(4, P.T.n_blocks / 64)) budget_sweeps++;
         Cut c; c.cx = tot.cx; c.bnd = tot.bnd; c.pi = pi;
@@ -359,7 +360,7 @@ struct Solver {
             for (int k = 0; k < K; k++) pi[k] = alpha * pi_best[k] + (1.0 - alpha) * mt.x[k];
             const int ci = evaluate(pi);
             if (ci < 0) break;
-            if (now_us() * 1e-6 > rq.deadline_s - 0.3 * rq.time_limit_s) { if (rq.trace) fprintf(stderr, "[price] 70 %% of the time limit gone inside the master loop\n"); return false; }
+            if (sw.time_up) { if (rq.trace) fprintf(stderr, "[price] 70 %% of the time limit gone inside the master loop\n"); return false; }
             if (budget_sweeps >= 8) { if (rq.trace) fprintf(stderr, "[price] blocks keep running out of their search budget (%d sweeps): not a model for the sweeps\n", budget_sweeps); return false; }
             const double L = fixed_value(cuts[ci], hB, cB);
             if (L < ub_best) { ub_best = L; pi_best = pi; }
@@ -720,6 +721,7 @@ Answer solve(const Request &rq, Sweeper &sw) {
     Prob &P = S.P;
     const int K = P.K, G = P.G;
     sw.stat_sweeps = 0; sw.stat_sweep_us = 0;
+    sw.guard_s = rq.deadline_s - 0.3 * rq.time_limit_s; sw.time_up = false;  // (first read at the first sweep)
     S.max_sweeps = (int)std::min<size_t>(4096, std::max<size_t>(256, ((size_t)64 << 20) / ((size_t)P.T.n_cols * 2 + 1)));  // the device keeps every sweep's patterns: at most 64 MB of them
     if (!sw.begin(P.T, (uint32_t)S.max_sweeps)) { ans.why = "sweeper refused the model"; return ans; }
     struct Ender { Sweeper &s; ~Ender() { s.end(); } } ender{sw};
@@ -751,7 +753,7 @@ Answer solve(const Request &rq, Sweeper &sw) {
     // usable came out) and leaves the point in x.
     auto try_config = [&](const std::vector<double> &B, std::vector<double> &x) -> double {
         tried.push_back(B);
-        if (now_us() * 1e-6 > rq.deadline_s - 0.3 * rq.time_limit_s) return -INF;  // (the one clock of this path: see Request::deadline_s)
+        if (sw.time_up) return -INF;  // (the one clock of this path, read at the sweeps: see Request::deadline_s, Sweeper::time_up)
         ans.rounds++;
         double cB = 0.0;
         for (int k = 0; k < K; k++) hB[k] = P.h[k];
@@ -929,7 +931,7 @@ Answer solve(const Request &rq, Sweeper &sw) {
         int nodes = 0;
         std::vector<int32_t> lo_arr, hi_arr; std::vector<char> usable;
         while (!stack.empty() && nodes < BP_MAX_NODES && (int)S.cuts.size() + 8 < S.max_sweeps && S.work < BP_MAX_WORK * rq.time_limit_s && S.sweep_steps < BP_MAX_STEPS * rq.time_limit_s &&
-               now_us() * 1e-6 < rq.deadline_s - 0.3 * rq.time_limit_s && !S.failed) {
+               !sw.time_up && !S.failed) {
             BPNode nd = std::move(stack.back()); stack.pop_back();
             if (closes(nd.bound)) { closed_max = std::max(closed_max, nd.bound); continue; }
             nodes++;

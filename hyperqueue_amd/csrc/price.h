@@ -36,6 +36,15 @@ struct SweepTotals {
 };
 constexpr int PARTS = 16;
 
+// What a sweep over a RANGE of blocks leaves (worker-range shards): arrays indexed by ABSOLUTE block number, valid inside the range; the partial
+// activity vectors of all PARTS (those outside the range zero).  Host memory, valid until the next call.
+struct RangeValues { const double *cx = nullptr, *rc = nullptr, *bnd = nullptr; const uint32_t *steps = nullptr; const long long *part_act = nullptr; };
+
+// The sweep's totals from the per-block values, in the ORDER THE KERNEL's last workgroup adds them (csrc/price.hip): lane l takes blocks l, l + 64, ..., lane 0
+// then adds the 64 partial sums in lane order; c.x per part by four lanes, every fourth block each.  One definition for the emulation, for the shards' merge
+// and (restated in device code) the kernel: a sharded tick, a plain tick and the emulated tick walk the same sequence of prices.
+void totals_from_blocks(uint32_t n_blocks, uint32_t K, const double *cx, const double *rc, const double *bnd, const uint32_t *steps, const long long *part_act, SweepTotals &out);
+
 // Where the sweeps run: the MI355X (csrc/price.hip) in the tick, the emulated wavefront (libhqtick_test.so) in the CPU tests.
 struct Sweeper {
     virtual ~Sweeper() {}
@@ -45,6 +54,13 @@ struct Sweeper {
     virtual bool sweep(const double *pi, SweepTotals &out) = 0;             // sweep number = count of sweeps since begin()
     virtual const uint16_t *patterns(uint32_t first, uint32_t count) = 0;   // host pointer to the patterns of sweeps [first, first + count): [count][n_cols]
     virtual void end() = 0;
+    // one sweep over the blocks [b0, b1) only — this rank's worker range of a sharded scheduler; the patterns of the other blocks' columns are left untouched
+    virtual bool sweep_range(const double *pi, uint32_t b0, uint32_t b1, RangeValues &out) { (void)pi; (void)b0; (void)b1; (void)out; return false; }
+    // The one clock of the price path (Request::deadline_s) is read HERE, at a sweep, and nowhere else: `time_up` turns true (and stays) once a sweep ends past the
+    // guard.  A sharded sweeper ORs the ranks' readings inside the sweep's exchange, so that every replica leaves the sweeps at the same sweep.
+    double guard_s = 1e300;     // steady-clock second at which the sweeps stop being worth starting (set by solve())
+    bool time_up = false;
+    virtual bool merges_clock() const { return false; }   // true: sweep() itself sets time_up (from every rank's reading)
     uint32_t min_cols = 256;    // components below this many columns stay with the host search (a sweep is ~80 us whatever the block count: below ~250 columns the host tree is usually done first)
     uint32_t budget = 4096;     // search steps per block and sweep
     // statistics of the last solve
@@ -81,5 +97,37 @@ struct Answer {
 };
 
 Answer solve(const Request &rq, Sweeper &sw);
+
+// All-gather of small host buffers between the ranks of a sharded scheduler: librccl inside the library (hqtick_comm_init) or a callback of the host
+// (hqtick_set_exchange) — csrc/hqtick.cpp.  Every rank contributes `bytes` (the same everywhere); recv gets world x bytes, rank-major.
+struct Exchange {
+    uint32_t rank = 0, world = 1;
+    virtual ~Exchange() {}
+    virtual bool allgather(const void *send, void *recv, size_t bytes) = 0;
+    uint64_t n_calls = 0, n_bytes = 0; double us = 0;   // statistics
+};
+
+// A sweeper that runs only THIS rank's blocks — the contiguous range made of its share of the master's 16 PARTS (worker ranges) — and completes every sweep with
+// one small all-gather: per block (c.x, reduced value, bound, steps), per part the activity vector, and the rank's reading of the clock (the blocks
+// are independent per worker; what couples them is the master, which stays replicated).  The totals are then added up in the kernel's order from the complete
+// per-block arrays, so every rank — and the unsharded tick — sees bit-identical cuts.  Patterns cross once, when the master asks for them.
+struct ShardedSweeper : Sweeper {
+    Sweeper &inner; Exchange &ex;
+    const HostTables *T = nullptr;
+    std::vector<uint32_t> rank_b0, rank_b1, rank_p0, rank_p1;   // blocks / parts of every rank
+    uint32_t max_blocks = 0, max_parts = 0, max_cols = 0;
+    std::vector<unsigned char> send, recv;
+    std::vector<double> cx, rc, bnd; std::vector<uint32_t> steps; std::vector<long long> part_act;
+    std::vector<uint16_t> pats;
+    uint32_t n_sweeps = 0;
+    ShardedSweeper(Sweeper &in, Exchange &e) : inner(in), ex(e) { min_cols = in.min_cols; budget = in.budget; }
+    bool begin(const HostTables &t, uint32_t max_sweeps) override;
+    bool set_caps(const int32_t *col_cap) override { return inner.set_caps(col_cap); }
+    bool set_block_caps(const double *blk_cap) override { return inner.set_block_caps(blk_cap); }
+    bool sweep(const double *pi, SweepTotals &out) override;
+    const uint16_t *patterns(uint32_t first, uint32_t count) override;
+    void end() override { inner.end(); T = nullptr; }
+    bool merges_clock() const override { return true; }
+};
 
 }  // namespace hqprice

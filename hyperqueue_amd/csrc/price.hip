@@ -48,6 +48,10 @@ struct SweepArgs {
     uint32_t budget, seq;
     uint32_t *ticket;
     SweepResult *res;
+    // worker-range shards (price.h: ShardedSweeper): the grid covers the blocks [first, first + gridDim.x) only, and instead of the sweep's totals the last
+    // workgroup leaves the range's per-block values in pinned memory (lv_*: arrays indexed by absolute block) — the totals are added up after the ranks' all-gather
+    uint32_t first, local;
+    double *lv_cx, *lv_rc, *lv_bnd; uint32_t *lv_steps;
     double pi[KMAX];
 };
 
@@ -55,12 +59,21 @@ __global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
     __shared__ Shared S;
     __shared__ uint32_t s_last;
     hqblock::DevWave wv;
-    solve_priced_block(wv, S, a.t, a.pi, blockIdx.x, a.out, a.budget);
+    solve_priced_block(wv, S, a.t, a.pi, a.first + blockIdx.x, a.out, a.budget);
     __threadfence();  // the block's results before its ticket
     if (threadIdx.x == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
     __threadfence();
+    if (a.local) {  // this rank's share of a sharded sweep: per-block values and the partial activity vectors as they are, no totals
+        for (uint32_t b = a.first + threadIdx.x; b < a.first + gridDim.x; b += WAVE) { a.lv_cx[b] = a.out.blk_cx[b]; a.lv_rc[b] = a.out.blk_rc[b]; a.lv_bnd[b] = a.out.blk_bnd[b]; a.lv_steps[b] = a.out.blk_steps[b]; }
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ASLOTS * a.t.K; i += WAVE) { a.res->part_act[i] = a.out.act[i]; a.out.act[i] = 0; }
+        if (threadIdx.x == 0) *a.ticket = 0;
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&a.res->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     // the last workgroup: totals in a fixed order (lane l takes blocks l, l + 64, ...; lane 0 adds the 64 partial sums in lane order)
     const uint32_t nb = a.t.n_blocks;
     double cx = 0.0, rc = 0.0, bnd = 0.0; uint32_t nbud = 0, mx = 0;
@@ -104,7 +117,7 @@ double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::
 
 }  // namespace
 
-DeviceSweeper::~DeviceSweeper() { h_stage.release(); h_res.release(); h_pats.release(); d_tab.release(); d_pats.release(); d_blk.release(); d_sync.release(); }
+DeviceSweeper::~DeviceSweeper() { h_stage.release(); h_res.release(); h_pats.release(); h_blkv.release(); d_tab.release(); d_pats.release(); d_blk.release(); d_sync.release(); }
 
 bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     if (t.K > (uint32_t)KMAX || t.n_blocks == 0) return false;
@@ -141,8 +154,26 @@ bool DeviceSweeper::set_block_caps(const double *blk_cap) {
     return hipMemcpyAsync(d_tab.as<unsigned char>() + o_cap, h_stage.as<unsigned char>() + o_cap, bytes, hipMemcpyHostToDevice, stream) == hipSuccess;
 }
 
-bool DeviceSweeper::sweep(const double *pi, SweepTotals &out) {
-    if (!T || n_sweeps >= cap_sweeps) return false;
+bool DeviceSweeper::sweep(const double *pi, SweepTotals &out) { return launch(pi, 0, T ? T->n_blocks : 0, false, &out); }
+
+bool DeviceSweeper::sweep_range(const double *pi, uint32_t b0, uint32_t b1, RangeValues &rv) {
+    if (!T || b1 > T->n_blocks || b0 > b1) return false;
+    const uint32_t nb = T->n_blocks;
+    if (!h_blkv.ensure((size_t)nb * 28 + 64)) return false;
+    if (b1 > b0) { if (!launch(pi, b0, b1, true, nullptr)) return false; }
+    else {  // a rank without blocks (more ranks than parts): nothing to launch, the sweep still counts (the ring of patterns stays aligned across the ranks)
+        if (n_sweeps >= cap_sweeps) return false;
+        SweepResult *r = h_res.as<SweepResult>();
+        memset(r->part_act, 0, sizeof(r->part_act));
+        n_sweeps++;
+    }
+    unsigned char *h = h_blkv.as<unsigned char>();
+    rv = RangeValues{(const double *)h, (const double *)(h + (size_t)nb * 8), (const double *)(h + (size_t)nb * 16), (const uint32_t *)(h + (size_t)nb * 24), h_res.as<SweepResult>()->part_act};
+    return true;
+}
+
+bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool local, SweepTotals *outp) {
+    if (!T || n_sweeps >= cap_sweeps || b1 <= b0) return false;
     const HostTables &t = *T;
     unsigned char *d = d_tab.as<unsigned char>();
     SweepArgs a;
@@ -152,10 +183,13 @@ bool DeviceSweeper::sweep(const double *pi, SweepTotals &out) {
     a.out = SweepOut{d_pats.as<uint16_t>() + (size_t)n_sweeps * t.n_cols, (double *)blk, (double *)(blk + (size_t)t.n_blocks * 8), (double *)(blk + (size_t)t.n_blocks * 16),
                      (long long *)(d_sync.as<unsigned char>() + 64), (uint32_t *)(blk + (size_t)t.n_blocks * 24), profile ? h_prof.dev<uint64_t>() : nullptr};
     a.budget = budget; a.seq = ++seq; a.ticket = d_sync.as<uint32_t>(); a.res = h_res.dev<SweepResult>();
+    a.first = b0; a.local = local ? 1u : 0u;
+    if (local) { unsigned char *lv = h_blkv.dev<unsigned char>(); a.lv_cx = (double *)lv; a.lv_rc = (double *)(lv + (size_t)t.n_blocks * 8); a.lv_bnd = (double *)(lv + (size_t)t.n_blocks * 16); a.lv_steps = (uint32_t *)(lv + (size_t)t.n_blocks * 24); }
+    else { a.lv_cx = a.lv_rc = a.lv_bnd = nullptr; a.lv_steps = nullptr; }
     memset(a.pi, 0, sizeof(a.pi));
     memcpy(a.pi, pi, (size_t)t.K * 8);
     const double t0 = now_us();
-    hipLaunchKernelGGL(k_price_sweep, dim3(t.n_blocks), dim3(WAVE), 0, stream, a);
+    hipLaunchKernelGGL(k_price_sweep, dim3(b1 - b0), dim3(WAVE), 0, stream, a);
     if (hipGetLastError() != hipSuccess) return false;
     // wait for the sweep's own completion word (pinned memory); the stream synchronisation is the fallback after 2 s
     volatile SweepResult *r = h_res.as<SweepResult>();
@@ -174,14 +208,16 @@ bool DeviceSweeper::sweep(const double *pi, SweepTotals &out) {
         double smax = 0; for (uint32_t b = 0; b < t.n_blocks; b++) smax = std::max(smax, (double)pr[(size_t)b * 8 + 7]);
         prof_steps += smax; prof_n++;
     }
-    total_sweeps++; total_block_solves += t.n_blocks; total_us += last_kernel_us;
+    total_sweeps++; total_block_solves += b1 - b0; total_us += last_kernel_us;
+    n_sweeps++;
+    if (!outp) return true;
+    SweepTotals &out = *outp;
     out.cx = r->cx; out.rc = r->rc; out.bnd = r->bnd; out.n_budget = r->n_budget; out.max_steps = r->max_steps;
     out.act.resize(t.K);
     for (uint32_t k = 0; k < t.K; k++) out.act[k] = r->act[k];
     out.part_cx.assign(r->part_cx, r->part_cx + ASLOTS);
     out.part_act.resize((size_t)ASLOTS * t.K);
     for (size_t i = 0; i < (size_t)ASLOTS * t.K; i++) out.part_act[i] = r->part_act[i];
-    n_sweeps++;
     return true;
 }
 

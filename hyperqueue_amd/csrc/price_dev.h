@@ -11,7 +11,7 @@ namespace hqprice {
 
 struct DeviceSweeper : Sweeper {
     hipStream_t stream = nullptr;
-    hqbuf::PinBuf h_stage, h_res, h_pats, h_prof;
+    hqbuf::PinBuf h_stage, h_res, h_pats, h_prof, h_blkv;
     bool profile = getenv("HQTICK_PRICE_PROFILE") != nullptr; double prof_med[6] = {0}, prof_max[6] = {0}, prof_steps = 0; int prof_n = 0;
     hqbuf::DevBuf d_tab, d_pats, d_blk, d_sync;
     const HostTables *T = nullptr;
@@ -26,6 +26,8 @@ struct DeviceSweeper : Sweeper {
     bool set_caps(const int32_t *col_cap) override;
     bool set_block_caps(const double *blk_cap) override;
     bool sweep(const double *pi, SweepTotals &out) override;
+    bool sweep_range(const double *pi, uint32_t b0, uint32_t b1, RangeValues &out) override;   // this rank's blocks of a sharded sweep (price.h: ShardedSweeper)
+    bool launch(const double *pi, uint32_t b0, uint32_t b1, bool local, SweepTotals *out);
     const uint16_t *patterns(uint32_t first, uint32_t count) override;
     void end() override;
 };

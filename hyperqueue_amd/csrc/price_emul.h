@@ -14,11 +14,13 @@ struct EmulatedSweeper : Sweeper {
     std::vector<uint16_t> pats;
     std::vector<double> blk_cx, blk_rc, blk_bnd;
     std::vector<uint32_t> blk_steps;
+    std::vector<long long> slots;
     uint32_t n_sweeps = 0, cap_sweeps = 0;
     bool begin(const HostTables &t, uint32_t max_sweeps) override;
     bool set_caps(const int32_t *col_cap) override;
     bool set_block_caps(const double *blk_cap) override;
     bool sweep(const double *pi, SweepTotals &out) override;
+    bool sweep_range(const double *pi, uint32_t b0, uint32_t b1, RangeValues &out) override;
     const uint16_t *patterns(uint32_t first, uint32_t count) override;
     void end() override;
 };
