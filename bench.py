@@ -316,6 +316,91 @@ def wire_block(iters: int):
         return {"error": repr(e)}
 
 
+def multi_rank_extras(cfg, rank: int, world: int, local_rank: int, ticks: int = 5):
+    """N > 1 only, EVERY rank calls it (collectives inside): what the ranks add beyond the expansion of the records.
+      config4_unsaturated  BASELINE configs[3]'s cluster (4096 workers x 2-variant requests) with a ready set that saturates nothing: ONE coupled model of 65 536 columns, 4096
+                           worker blocks per price sweep = four rounds of resident workgroups on one MI355X.  Sharded solve (include/hqtick.h, hqtick_set_exchange / the
+                           library's RCCL communicator): every rank sweeps its 4096 / N blocks, one small all-gather per sweep — against the same tick with the solve replicated
+                           on every rank (HQTICK_SHARD_SOLVE=0).  Equal counts on both (checked here through the placement checksum of the sink headers).
+      config4_strong       configs[3] as written: c4, 1 M ready tasks x 4096 workers hash-sharded over the ranks (strong scaling; the placement is one class block)."""
+    import torch
+
+    from hyperqueue_amd import abi, workloads
+    from hyperqueue_amd.sharded import ShardedTick
+
+    out = {}
+
+    def run(snap, shard_solve: bool, n_ticks: int):
+        old = os.environ.get("HQTICK_SHARD_SOLVE")
+        os.environ["HQTICK_SHARD_SOLVE"] = "1" if shard_solve else "0"  # (read once, in hqtick_create)
+        try:
+            st = ShardedTick(cfg, rank=rank, world=world, records_per_shard=int(1.2 * 300 * len(snap.worker_id) / world) + 8192)
+        finally:
+            if old is None:
+                os.environ.pop("HQTICK_SHARD_SOLVE", None)
+            else:
+                os.environ["HQTICK_SHARD_SOLVE"] = old
+        st.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+        sc = snap.to_c()
+        st.t.cluster_upload(sc)
+        lat, ks, chk = [], None, None
+        for _ in range(n_ticks + 1):
+            torch.distributed.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res, merged = st.tick_device(sc, len(snap.worker_id), resident=True)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+            ks = st.t.kernel_stats()
+            chk = (int(res.status), int(res.is_optimal), int(merged[4:8].cpu().numpy().view(np.uint32)[0]))  # the placement checksum of this rank's sink header
+        t = torch.tensor([float(np.median(lat[1:]))], dtype=torch.float64, device=f"cuda:{local_rank}")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        st.t.close()
+        return float(t.item()), ks, chk, st.collective
+
+    try:
+        s4 = workloads.make("c4", seed=8, n_workers=4096, n_tasks=56_761)
+        a_s, a_ks, a_chk, coll = run(s4, True, ticks)
+        b_s, b_ks, b_chk, _ = run(s4, False, max(2, ticks // 2))
+        out["config4_unsaturated"] = {
+            "workload": "c4's cluster (4096 workers x 2-variant requests) with 56 761 ready tasks: one coupled model of all workers", "merge_collective": coll,
+            "sharded_solve": {"p50_tick_ms": 1e3 * a_s, "status": a_chk[0], "is_optimal": bool(a_chk[1]), "price_sweeps": int(a_ks["price_sweeps"]), "blocks_per_sweep_and_rank": 4096 // world,
+                              "avg_sweep_us_incl_exchange": (a_ks["price_sweep_us"] / a_ks["price_sweeps"]) if a_ks["price_sweeps"] else None,
+                              "exchange_calls": int(a_ks["exchange_calls"]), "exchange_us_per_call": (a_ks["exchange_us"] / a_ks["exchange_calls"]) if a_ks["exchange_calls"] else None,
+                              "exchange_bytes_per_call": (a_ks["exchange_bytes"] / a_ks["exchange_calls"]) if a_ks["exchange_calls"] else None, "coupled_solve_ms": a_ks["milp_us"] / 1e3},
+            "replicated_solve": {"p50_tick_ms": 1e3 * b_s, "status": b_chk[0], "is_optimal": bool(b_chk[1]), "price_sweeps": int(b_ks["price_sweeps"]),
+                                 "avg_sweep_us": (b_ks["price_sweep_us"] / b_ks["price_sweeps"]) if b_ks["price_sweeps"] else None, "coupled_solve_ms": b_ks["milp_us"] / 1e3},
+            "same_placement": bool(a_chk == b_chk),
+        }
+    except Exception as e:  # noqa: BLE001
+        out["config4_unsaturated"] = {"error": repr(e)}
+    try:
+        sf = workloads.make("c4", seed=0)
+        c_s, c_ks, c_chk, coll = run(sf, True, ticks)
+        out["config4_strong"] = {"workload": "c4: 1 M ready tasks x 4096 workers (BASELINE configs[3] as written), hash-sharded over the ranks", "scaling": "strong", "merge_collective": coll,
+                                 "p50_tick_ms": 1e3 * c_s, "assigned_per_tick": int(c_ks["n_assigned"]), "tasks_assigned_per_sec": int(c_ks["n_assigned"]) / c_s if c_s > 0 else None,
+                                 "note": "timed: sharded tick + the all-gather of the record sinks (no D2H of the merged vector in this block)"}
+    except Exception as e:  # noqa: BLE001
+        out["config4_strong"] = {"error": repr(e)}
+    return out
+
+
+def watchdog(seconds: float, last_words):
+    """a timer that ends the process if what follows does not come back: the extras of a multi-rank run must never cost the line of the timed region"""
+    import threading
+
+    def fire():
+        try:
+            last_words()
+        finally:
+            sys.stdout.flush()
+            os._exit(0)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run, N ranks on this node, rendezvous on 127.0.0.1 (a free port)."""
     import socket
@@ -343,8 +428,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=None, help="c2 / c3 / c4; default: c3 on one GPU (BASELINE configs[2], the headline), c4 = BASELINE configs[3] as written (4096 workers, 1 M tasks, "
-                                                   "hash-sharded over the GPUs + one RCCL all-gather, strong scaling) when launched on N > 1 GPUs; `--workload c3 --scaling weak` is the weak-scaling mode")
+    ap.add_argument("--workload", default=None, help="c2 / c3 / c4; default c3 (BASELINE configs[2], the headline) — on N > 1 GPUs per rank (weak scaling: 1024 workers and 1 M ready tasks per GPU, "
+                                                   "hash-sharded + one RCCL all-gather); c4 = BASELINE configs[3] as written (4096 workers, 1 M tasks, strong scaling)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="N > 1: weak = the workload grows with N (default for c2 / c3), strong = the configuration as written (default for c4 = BASELINE configs[3])")
     ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
@@ -359,6 +444,8 @@ def main():
     ap.add_argument("--u32-records", action="store_true", help="compact emission with 4-byte low halves (ABI 4/5) instead of the 16-bit differences of ABI 6 (HQTICK_FLAG_COMPACT_DELTA16)")
     ap.add_argument("--no-b2b", dest="b2b", action="store_false", help="skip the 100 back-to-back launches of K1 / K4 (so that a rocprofv3 summary of this run averages the in-tick launches only)")
     ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
+    ap.add_argument("--no-multi-extras", dest="multi_extras", action="store_false", help="N > 1: skip the blocks after the timed region (configs[3]'s coupled tick with the solve split over the ranks vs replicated; c4 strong scaling)")
+    ap.add_argument("--extras-timeout", type=float, default=240.0, help="N > 1: seconds the extra blocks may take before the line is printed without them")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
     ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
     args = ap.parse_args()
@@ -373,7 +460,9 @@ def main():
     if rank == 0 and world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running (and reporting n_gpus =) {world} rank(s)", file=sys.stderr)
     if args.workload is None:
-        args.workload = "c4" if world > 1 else "c3"
+        # one curve for N = 1, 2, 4, 8: the headline workload (BASELINE configs[2]) per GPU — weak scaling, 1024 workers and 1 M ready tasks per rank.  configs[3] as
+        # written (c4: 4096 workers hash-sharded over the ranks, strong scaling) is `--workload c4`, and rides along in the N > 1 line as `config4_strong`.
+        args.workload = "c3"
     import torch
 
     if not torch.cuda.is_available():
@@ -447,7 +536,25 @@ def main():
     if not (world == 1 and not args.force_sharded):
         # The sinks are fixed-capacity blocks (one all-gather, one D2H of the merged vector): size them to what the workload really emits — the largest shard
         # of a first tick plus 10 % — instead of the a-priori bound above, which is 1.6x the C3 tick's records and would travel over xGMI and PCIe every tick.
-        r0 = step()
+        # The first multi-rank tick also proves the merge path: if the library's RCCL communicator fails its first all-gather on ANY rank, every rank falls back
+        # to torch.distributed's collective for the rest of the run (and the line says which one carried the timed ticks).
+        first_err = None
+        try:
+            r0 = step()
+        except Exception as e:  # noqa: BLE001
+            first_err, r0 = repr(e), None
+        if dist is not None:
+            t_ok = torch.tensor([0 if first_err else 1], dtype=torch.int32, device=f"cuda:{local_rank}")
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            if int(t_ok.item()) == 0:
+                if st.collective != "library":
+                    raise SystemExit(f"bench.py: the first sharded tick failed: {first_err}")
+                print(f"bench.py rank {rank}: the library's RCCL all-gather failed on some rank ({first_err}); merging through torch.distributed instead", file=sys.stderr)
+                st.collective, st.comm_world = "torch", 0
+                st._install_exchange()
+                r0 = step()
+        elif first_err:
+            raise SystemExit(f"bench.py: the first sharded tick failed: {first_err}")
         n_mine = int(np.ctypeslib.as_array(r0.rec_off, shape=(W_all + 1,))[W_all])
         n_max = n_mine
         if dist is not None:
@@ -488,6 +595,9 @@ def main():
     total_assigned = assigned
     if rank != 0:
         if dist is not None:
+            if args.multi_extras:
+                watchdog(args.extras_timeout, lambda: None)
+                multi_rank_extras(cfg, rank, world, local_rank)
             dist.destroy_process_group()
         return
 
@@ -530,8 +640,10 @@ def main():
         "config": {"workload": f"{args.workload}: {n_ready} ready tasks x {W} workers x {R} resource kinds, {len(snap.requests)} request classes, "
                                f"{len(np.unique(snap.task_priority))} priority level(s), cold tick (every class saturated: the placement separates per worker; "
                                "the same size with three priority levels is `multi_priority` below)",
-                   "parallelism": "single" if world == 1 else f"worker-shards x{world}: FxHash(worker_id) % {world}, ready set replicated, one RCCL all-gather of the record sinks inside libhqtick.so (hqtick_shard_allgather; "
-                                   f"communicator of {getattr(st, 'comm_world', world)} ranks), merged vector D2H on rank 0",
+                   "parallelism": "single" if world == 1 else f"worker-shards x{world}: FxHash(worker_id) % {world}, ready set replicated, one RCCL all-gather of the record sinks "
+                                   + (f"inside libhqtick.so (hqtick_shard_allgather; communicator of {getattr(st, 'comm_world', world)} ranks)" if getattr(st, "collective", "") == "library"
+                                      else f"through torch.distributed ({getattr(st, 'collective', '?')})") + ", merged vector D2H on rank 0",
+                   "ranks": world, "ranks_in_the_library_communicator": int(getattr(st, "comm_world", 0)) if world > 1 or args.force_sharded else 0,
                    "ready_set": "resident in HBM", "seed": args.seed},
         "p50_tick_ms": 1e3 * float(np.median(lat)), "p95_tick_ms": 1e3 * float(np.percentile(lat, 95)),
         "assigned_per_tick": assigned, "prefilled_per_tick": prefilled,
@@ -729,7 +841,13 @@ def main():
             out["cpu_baseline"] = {"error": repr(e)}
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.wire_iters > 0:
         out["wire"] = wire_block(args.wire_iters)
+    if dist is not None and args.multi_extras:
+        # after everything the line is quoted on: if a rank gets lost in there, the watchdog prints the line as it stands and ends the process
+        wd = watchdog(args.extras_timeout, lambda: print(json.dumps(dict(out, multi_rank={"error": f"did not come back within {args.extras_timeout:.0f} s"}))))
+        out["multi_rank"] = multi_rank_extras(cfg, rank, world, local_rank)
+        wd.cancel()
     print(json.dumps(out))
+    sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

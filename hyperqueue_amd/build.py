@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libhqtick.so")
 TEST_LIB = os.path.join(HERE, "libhqtick_test.so")
-SOURCES = ["hqtick.cpp", "host_model.cpp", "milp.cpp", "price.cpp", "kernels.hip", "graph.hip", "wire.hip", "block_solve.hip", "price.hip"]
+SOURCES = ["hqtick.cpp", "host_model.cpp", "milp.cpp", "price.cpp", "price_shard.cpp", "kernels.hip", "graph.hip", "wire.hip", "block_solve.hip", "price.hip"]
 HOOKED = ["hqtick.cpp", "wire.hip"]          # sources that carry #ifdef HQTICK_TEST_HOOKS sections
 TEST_ONLY = ["debug_capi.cpp", "price_emul.cpp"]               # sources of the test library only
 HEADERS = ["kernels.h", "block_core.h", "price_core.h", "price.h", "price_emul.h", "price_dev.h", "lp_tab.h", "dev_wave.h", "block_solve.h", "graph.h", "devbuf.h", "host_model.h", "milp.h", "hb_order.h", "wire_core.h",

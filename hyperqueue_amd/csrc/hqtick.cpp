@@ -130,6 +130,12 @@ struct hqtick_ctx {
     hqgraph::Graph graph;  // hqtick_graph_*: dependency counters + consumer lists in HBM
     hqtick_ctx *qctx = nullptr;  // hqtick_query's private sub-context
     ncclComm_t comm = nullptr; uint32_t comm_rank = 0, comm_world = 0;  // hqtick_comm_init (RCCL, loaded on first use)
+    // sharded placement solve: the ranks split the coupled solve's price sweeps and the separable solve's class blocks, one small all-gather of host
+    // buffers per sweep / per launch — through the host's callback (hqtick_set_exchange) or the library's own RCCL communicator
+    hqtick_exchange_fn xfn = nullptr; void *xuser = nullptr;
+    DevBuf d_xsend, d_xrecv; PinBuf h_xsend, h_xrecv;
+    uint32_t shard_min_blocks = 1025, shard_min_classes = 1025; bool shard_solve = true;
+    uint64_t x_calls = 0, x_bytes = 0; double x_us = 0;
     double tl[32] = {}; int ntl = 0;  // debug timeline (us since tick start), hqtick_timeline()
 };
 
@@ -541,6 +547,68 @@ struct DeviceBlocks : hqhost::BlockSolver {
         memcpy(p_out.x, h + p_ox, (size_t)p_nd * p_nc * 4); memcpy(p_out.status, h + p_ost, (size_t)p_nd * 4); memcpy(p_out.steps, h + p_osteps, (size_t)p_nd * 4);
         if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[9], ctx->ev[10]); if (us_ >= 0) ctx->stats.block_solve_us = us_; }
         ctx->stats.n_classes_device = p_nd;
+        return true;
+    }
+};
+
+// The ranks' exchange of small host buffers (csrc/price.h: Exchange): the host's callback if one is set, else the library's RCCL communicator.
+bool rccl_allgather_host(hqtick_ctx *ctx, const void *send, void *recv, size_t bytes);  // (bottom of this file, next to the other RCCL calls)
+struct CtxExchange : hqprice::Exchange {
+    hqtick_ctx *ctx;
+    explicit CtxExchange(hqtick_ctx *c) : ctx(c) { rank = c->shard_index; world = c->shard_count; }
+    static bool available(const hqtick_ctx *c) { return c->shard_solve && c->shard_count > 1 && (c->xfn || (c->comm && c->comm_world == c->shard_count)); }
+    bool allgather(const void *send, void *recv, size_t bytes) override {
+        if (ctx->xfn) return ctx->xfn(ctx->xuser, send, recv, bytes) == 0;
+        return rccl_allgather_host(ctx, send, recv, bytes);
+    }
+    ~CtxExchange() override { ctx->x_calls += n_calls; ctx->x_bytes += n_bytes; ctx->x_us += us; }
+};
+
+// The class blocks of a separable tick over the ranks: class i of the launch goes to rank i % world (the launch is ordered longest first: a strided deal spreads the
+// hard classes), every rank runs its share through the inner solver, ONE all-gather of (x, status, steps) completes the answer on every rank.  A rank whose inner
+// solver fails reports its classes as unsolved — every rank then sends the same classes to its host solver, and the replicas stay in step.
+struct ShardedBlocks : hqhost::BlockSolver {
+    hqhost::BlockSolver &inner; hqprice::Exchange &ex; uint32_t min_classes;
+    hqblock::Output p_out{}; uint32_t p_nd = 0, p_nc = 0, p_nm = 0; bool p_pass = false, p_inner_ok = false, p_pending = false;
+    std::vector<uint64_t> cfree, ctot, celig; std::vector<uint32_t> dx, dst, dsteps; std::vector<unsigned char> send, recv;
+    ShardedBlocks(hqhost::BlockSolver &in, hqprice::Exchange &e, uint32_t mc) : inner(in), ex(e), min_classes(mc) {}
+    bool overlaps() const override { return inner.overlaps(); }
+    bool solve(const hqblock::ColTable &ct, const hqblock::ClassTable &cl, const hqblock::Output &out) override { return begin(ct, cl, out) && finish(); }
+    bool begin(const hqblock::ColTable &ct, const hqblock::ClassTable &cl, const hqblock::Output &out) override {
+        p_pass = ex.world <= 1 || cl.n_classes < min_classes;
+        if (p_pass) return inner.begin(ct, cl, out);
+        const uint32_t nd = cl.n_classes, R = ct.R, NC = ct.n_cols, W = ex.world, me = ex.rank;
+        const uint32_t nm = nd > me ? (nd - me + W - 1) / W : 0;
+        cfree.resize((size_t)nm * R); ctot.resize((size_t)nm * R); celig.resize(nm);
+        for (uint32_t j = 0; j < nm; j++) {
+            const size_t i = (size_t)me + (size_t)j * W;
+            memcpy(cfree.data() + (size_t)j * R, cl.free_ + i * R, (size_t)R * 8); memcpy(ctot.data() + (size_t)j * R, cl.total + i * R, (size_t)R * 8); celig[j] = cl.elig[i];
+        }
+        dx.assign((size_t)nm * NC, 0); dst.assign(nm, hqblock::ST_UNSUPPORTED); dsteps.assign(nm, 0);
+        p_out = out; p_nd = nd; p_nc = NC; p_nm = nm; p_pending = true;
+        p_inner_ok = nm == 0 || inner.begin(ct, hqblock::ClassTable{nm, cfree.data(), ctot.data(), celig.data()}, hqblock::Output{dx.data(), dst.data(), dsteps.data(), nullptr});
+        return true;  // (whatever the inner solver said: this rank still owes the others its part of the exchange)
+    }
+    bool finish() override {
+        if (p_pass) return inner.finish();
+        if (!p_pending) return false;
+        p_pending = false;
+        if (p_nm && !(p_inner_ok && inner.finish())) { std::fill(dst.begin(), dst.end(), (uint32_t)hqblock::ST_UNSUPPORTED); std::fill(dx.begin(), dx.end(), 0u); }
+        const uint32_t W = ex.world, NC = p_nc, mx = (p_nd + W - 1) / W;
+        const size_t o_st = (size_t)mx * NC * 4, o_steps = o_st + (size_t)mx * 4, bytes = (o_steps + (size_t)mx * 4 + 7) & ~(size_t)7;
+        send.assign(bytes, 0); recv.resize(bytes * W);
+        if (p_nm) { memcpy(send.data(), dx.data(), (size_t)p_nm * NC * 4); memcpy(send.data() + o_st, dst.data(), (size_t)p_nm * 4); memcpy(send.data() + o_steps, dsteps.data(), (size_t)p_nm * 4); }
+        const double t0 = now_us();
+        if (!ex.allgather(send.data(), recv.data(), bytes)) return false;
+        ex.us += now_us() - t0; ex.n_calls++; ex.n_bytes += bytes * W;
+        for (uint32_t r = 0; r < W; r++) {
+            const unsigned char *b = recv.data() + (size_t)r * bytes;
+            const uint32_t nr = p_nd > r ? (p_nd - r + W - 1) / W : 0;
+            for (uint32_t j = 0; j < nr; j++) {
+                const size_t i = (size_t)r + (size_t)j * W;
+                memcpy(p_out.x + i * NC, b + (size_t)j * NC * 4, (size_t)NC * 4); memcpy(p_out.status + i, b + o_st + (size_t)j * 4, 4); memcpy(p_out.steps + i, b + o_steps + (size_t)j * 4, 4);
+            }
+        }
         return true;
     }
 };
@@ -1077,10 +1145,23 @@ struct TickRun {
         const double t2 = now_us();
         DeviceBlocks dev_blocks(ctx);
         pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes; pb.pricer = ctx->pricer;
-        cnt = hqhost::run_scheduling_solver(pb, batches);
+        double shard_sweep_us = -1.0;
+        ctx->x_calls = 0; ctx->x_bytes = 0; ctx->x_us = 0;
+        if (CtxExchange::available(ctx)) {  // the ranks of a sharded scheduler split the sweeps and the class blocks (no-ops below their thresholds)
+            CtxExchange xch(ctx);
+            ShardedBlocks sh_blocks(dev_blocks, xch, ctx->shard_min_classes);
+            pb.blocks = &sh_blocks;
+            if (ctx->pricer) {
+                hqprice::ShardedSweeper sh_sweeps(*ctx->pricer, xch, ctx->shard_min_blocks);
+                pb.pricer = &sh_sweeps;
+                cnt = hqhost::run_scheduling_solver(pb, batches);
+                shard_sweep_us = sh_sweeps.stat_sweep_us;
+            } else cnt = hqhost::run_scheduling_solver(pb, batches);
+        } else cnt = hqhost::run_scheduling_solver(pb, batches);
         pb.blocks = nullptr; pb.pricer = nullptr;
         ctx->stats.price_sweeps = (uint32_t)cnt.price_sweeps; ctx->stats.price_rounds = (uint32_t)cnt.price_rounds; ctx->stats.price_us = cnt.price_us; ctx->stats.milp_us = cnt.milp_us; ctx->stats.model_us = cnt.model_us; ctx->stats.solve_pre_us = cnt.pre_us;
-        ctx->stats.price_sweep_us = ctx->pricer ? ctx->pricer->stat_sweep_us : 0.0; ctx->stats.milp_cols = (uint32_t)cnt.milp_cols; ctx->stats.milp_rows = (uint32_t)cnt.milp_rows;
+        ctx->stats.price_sweep_us = shard_sweep_us >= 0.0 ? shard_sweep_us : (ctx->pricer ? ctx->pricer->stat_sweep_us : 0.0); ctx->stats.milp_cols = (uint32_t)cnt.milp_cols; ctx->stats.milp_rows = (uint32_t)cnt.milp_rows;
+        ctx->stats.exchange_calls = (uint32_t)ctx->x_calls; ctx->stats.exchange_bytes = ctx->x_bytes; ctx->stats.exchange_us = ctx->x_us;
         if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
         ctx->stats.n_classes_device = cnt.blocks_device; ctx->stats.n_classes_host = cnt.blocks_host; ctx->stats.block_steps_max = cnt.block_steps_max; ctx->stats.n_classes = cnt.n_classes;
         ctx->stats.solve_classify_us = cnt.t_classify_us; ctx->stats.solve_blocks_us = cnt.t_blocks_us; ctx->stats.solve_decode_us = cnt.t_decode_us;
@@ -1203,6 +1284,9 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
         if (const char *e = getenv("HQTICK_PRICE_MIN_COLS")) { long v = atol(e); if (v > 0) min_cols = (uint32_t)v; }
         if (price) { ctx->pricer = new hqprice::DeviceSweeper(ctx->stream); ctx->pricer->budget = ctx->block_budget; if (min_cols) ctx->pricer->min_cols = min_cols; }
     }
+    if (const char *e = getenv("HQTICK_SHARD_SOLVE")) ctx->shard_solve = atoi(e) != 0;
+    if (const char *e = getenv("HQTICK_SHARD_MIN_BLOCKS")) { long v = atol(e); if (v >= 0) ctx->shard_min_blocks = (uint32_t)v; }
+    if (const char *e = getenv("HQTICK_SHARD_MIN_CLASSES")) { long v = atol(e); if (v >= 0) ctx->shard_min_classes = (uint32_t)v; }
     if (hipEventCreate(&ctx->cl_ev) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
     if (!ctx->d_flags.ensure(64) || hipMemset(ctx->d_flags.p, 0, 64) != hipSuccess) { delete ctx; return HQTICK_E_DEVICE; }
@@ -1798,6 +1882,12 @@ thread_local double g_last_stage_us[3] = {0, 0, 0};
 }  // namespace
 
 void hqtick_debug_set_price_emulation(int on, uint32_t min_cols) { g_price_emulation = on; g_price_min_cols = min_cols; }
+// the host stages as ONE RANK of a sharded scheduler: emulated sweeps / class blocks over this rank's share, completed through `fn` (tests/test_sharded.py: gloo)
+thread_local hqtick_exchange_fn g_xfn = nullptr; thread_local void *g_xuser = nullptr; thread_local uint32_t g_xrank = 0, g_xworld = 1, g_xmin_blocks = 1, g_xmin_classes = 1, g_xcalls = 0;
+void hqtick_debug_set_exchange(hqtick_exchange_fn fn, void *user, uint32_t rank, uint32_t world, uint32_t min_blocks, uint32_t min_classes) {
+    g_xfn = fn; g_xuser = user; g_xrank = rank; g_xworld = world ? world : 1; g_xmin_blocks = min_blocks; g_xmin_classes = min_classes;
+}
+uint32_t hqtick_debug_last_exchange_calls(void) { return g_xcalls; }
 void hqtick_debug_last_stage_us(double *out3) { if (out3) for (int i = 0; i < 3; i++) out3[i] = g_last_stage_us[i]; }
 void hqtick_debug_last_price(uint32_t *sweeps, uint32_t *rounds) { if (sweeps) *sweeps = g_last_price_sweeps; if (rounds) *rounds = g_last_price_rounds; }
 void hqtick_debug_set_block_emulation(int on, uint32_t budget) { g_block_emulation = on; if (budget) g_block_budget = budget; }
@@ -1835,7 +1925,17 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
     if (g_block_emulation) { pb.blocks = &emu; pb.block_min_classes = 1; }
     hqprice::EmulatedSweeper pemu;
     if (g_price_emulation) { pemu.budget = g_block_budget; if (g_price_min_cols) pemu.min_cols = g_price_min_cols; pb.pricer = &pemu; }
-    hqhost::Counts cnt = hqhost::run_scheduling_solver(pb, batches);
+    hqhost::Counts cnt;
+    if (g_xfn && g_xworld > 1) {  // this call is one rank of a sharded scheduler
+        struct FnExchange : hqprice::Exchange { bool allgather(const void *snd, void *rcv, size_t bytes) override { return g_xfn(g_xuser, snd, rcv, bytes) == 0; } } xch;
+        xch.rank = g_xrank; xch.world = g_xworld;
+        ShardedBlocks sh_blocks(emu, xch, g_xmin_classes);
+        hqprice::ShardedSweeper sh_sweeps(pemu, xch, g_xmin_blocks);
+        if (pb.blocks) pb.blocks = &sh_blocks;
+        if (pb.pricer) pb.pricer = &sh_sweeps;
+        cnt = hqhost::run_scheduling_solver(pb, batches);
+        g_xcalls = (uint32_t)xch.n_calls;
+    } else cnt = hqhost::run_scheduling_solver(pb, batches);
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
     g_last_blocks_device = cnt.blocks_device; g_last_blocks_host = cnt.blocks_host; g_last_price_sweeps = (uint32_t)cnt.price_sweeps; g_last_price_rounds = (uint32_t)cnt.price_rounds;
     g_last_stage_us[0] = cnt.t_classify_us; g_last_stage_us[1] = cnt.t_blocks_us; g_last_stage_us[2] = cnt.t_decode_us;
@@ -1890,6 +1990,12 @@ int hqtick_set_shard(hqtick_ctx *ctx, uint32_t shard_index, uint32_t shard_count
     if (!ctx) return HQTICK_E_INVALID;
     if (shard_count > 1 && shard_index >= shard_count) return fail(ctx, HQTICK_E_INVALID, "shard_index >= shard_count");
     ctx->shard_index = shard_count > 1 ? shard_index : 0; ctx->shard_count = shard_count > 1 ? shard_count : 1;
+    return 0;
+}
+
+int hqtick_set_exchange(hqtick_ctx *ctx, hqtick_exchange_fn fn, void *user) {
+    if (!ctx) return HQTICK_E_INVALID;
+    ctx->xfn = fn; ctx->xuser = fn ? user : nullptr;
     return 0;
 }
 
@@ -2058,6 +2164,37 @@ int hqtick_shard_allgather(hqtick_ctx *ctx, void *recv_device, size_t recv_bytes
     HQ_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+
+}  // extern "C"
+
+namespace {
+// all-gather of a small HOST buffer through the RCCL communicator: staged through HBM (ncclAllGather wants device memory on both sides)
+bool rccl_allgather_host(hqtick_ctx *ctx, const void *send, void *recv, size_t bytes) {
+    if (!ctx->comm || bytes == 0) return false;
+    const size_t total = bytes * ctx->comm_world;
+    if (!ctx->h_xsend.ensure(bytes) || !ctx->h_xrecv.ensure(total) || !ctx->d_xsend.ensure(bytes) || !ctx->d_xrecv.ensure(total)) return false;
+    if (hipSetDevice(ctx->device) != hipSuccess) return false;
+    memcpy(ctx->h_xsend.p, send, bytes);
+    if (hipMemcpyAsync(ctx->d_xsend.p, ctx->h_xsend.p, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
+    if (rccl().all_gather(ctx->d_xsend.p, ctx->d_xrecv.p, bytes, ncclUint8, ctx->comm, ctx->stream) != ncclSuccess) return false;
+    if (hipMemcpyAsync(ctx->h_xrecv.p, ctx->d_xrecv.p, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+    memcpy(recv, ctx->h_xrecv.p, total);
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+#ifdef HQTICK_TEST_HOOKS
+// libhqtick_test.so: one all-gather of a host buffer through the library's RCCL communicator, as the sharded solve issues it per sweep — for the single-rank
+// round trip of the GPU suite (recv == send) and for timing the exchange's fixed cost (H2D + ncclAllGather + D2H + one stream synchronisation)
+int hqtick_debug_exchange(hqtick_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank) {
+    if (!ctx || !send || !recv) return HQTICK_E_INVALID;
+    if (!ctx->comm) return fail(ctx, HQTICK_E_INVALID, "hqtick_debug_exchange without hqtick_comm_init");
+    return rccl_allgather_host(ctx, send, recv, bytes_per_rank) ? 0 : fail(ctx, HQTICK_E_DEVICE, "the RCCL exchange failed");
+}
+#endif
 
 int hqtick_comm_destroy(hqtick_ctx *ctx) {
     if (!ctx) return HQTICK_E_INVALID;

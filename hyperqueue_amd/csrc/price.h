@@ -120,14 +120,16 @@ struct ShardedSweeper : Sweeper {
     std::vector<double> cx, rc, bnd; std::vector<uint32_t> steps; std::vector<long long> part_act;
     std::vector<uint16_t> pats;
     uint32_t n_sweeps = 0;
-    ShardedSweeper(Sweeper &in, Exchange &e) : inner(in), ex(e) { min_cols = in.min_cols; budget = in.budget; }
+    uint32_t min_blocks = 1025;   // models with fewer blocks are swept whole by every rank (one round of resident workgroups: a sweep costs ~70 us whatever its block count up to 1024)
+    bool pass = false;            // ... decided in begin(), the same on every rank
+    ShardedSweeper(Sweeper &in, Exchange &e, uint32_t min_blocks_) : inner(in), ex(e), min_blocks(min_blocks_) { min_cols = in.min_cols; budget = in.budget; }
     bool begin(const HostTables &t, uint32_t max_sweeps) override;
     bool set_caps(const int32_t *col_cap) override { return inner.set_caps(col_cap); }
     bool set_block_caps(const double *blk_cap) override { return inner.set_block_caps(blk_cap); }
     bool sweep(const double *pi, SweepTotals &out) override;
     const uint16_t *patterns(uint32_t first, uint32_t count) override;
     void end() override { inner.end(); T = nullptr; }
-    bool merges_clock() const override { return true; }
+    bool merges_clock() const override { return !pass; }
 };
 
 }  // namespace hqprice

@@ -44,6 +44,8 @@ bool ShardedSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     inner.budget = budget;
     if (!inner.begin(t, max_sweeps)) return false;
     T = &t; n_sweeps = 0;
+    pass = ex.world <= 1 || t.n_blocks < min_blocks;
+    if (pass) return true;
     const uint32_t W = ex.world, nb = t.n_blocks, per = part_size(nb);
     rank_b0.assign(W, 0); rank_b1.assign(W, 0); rank_p0.assign(W, 0); rank_p1.assign(W, 0);
     max_blocks = max_parts = max_cols = 0;
@@ -61,6 +63,7 @@ bool ShardedSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
 // blob of one rank and sweep: [u64 clock flag][cx mb][rc mb][bnd mb] doubles, [part_act mp * K] i64, [steps mb] u32
 bool ShardedSweeper::sweep(const double *pi, SweepTotals &out) {
     if (!T) return false;
+    if (pass) { n_sweeps++; return inner.sweep(pi, out); }
     const HostTables &t = *T;
     const uint32_t me = ex.rank, W = ex.world, mb = max_blocks, mp = max_parts, K = t.K;
     RangeValues rv;
@@ -95,6 +98,7 @@ bool ShardedSweeper::sweep(const double *pi, SweepTotals &out) {
 // the patterns of sweeps [first, first + count): every rank holds its own columns of each; one all-gather of [count][max_cols] u16 per rank completes them
 const uint16_t *ShardedSweeper::patterns(uint32_t first, uint32_t count) {
     if (!T || first + count > n_sweeps) return nullptr;
+    if (pass) return inner.patterns(first, count);
     const HostTables &t = *T;
     const uint32_t me = ex.rank, W = ex.world, mc = max_cols, nc = t.n_cols;
     pats.assign((size_t)count * nc + 1, 0);

@@ -183,6 +183,27 @@ class ShardedTick:
                     warnings.warn(f"hqtick_comm_init failed on some rank (here: {rc}): the shards are merged by torch.distributed.all_gather_into_tensor instead of the library's RCCL call")
                     self.collective = "torch"; self.comm_world = 0
 
+            if world > 1 and self.collective in ("host", "torch") and torch.distributed.is_available() and torch.distributed.is_initialized():
+                self._install_exchange()  # the placement solve is split over the ranks too (include/hqtick.h: hqtick_set_exchange); "library": the RCCL communicator does it
+
+    def _install_exchange(self):
+        """the ranks' exchange of small host buffers inside the tick, through the process group this ShardedTick merges with (gloo: CPU tensors; nccl: staged through
+        the device) — what a Rust host would do over its own channel"""
+        torch, world, group = self.torch, self.world, self.group
+        dev = None if self.collective == "host" else torch.device("cuda", self.cfg.device_index)
+
+        def exchange(send, recv, n):
+            mine = torch.frombuffer((C.c_ubyte * n).from_address(send), dtype=torch.uint8).clone()
+            if dev is not None:
+                mine = mine.to(dev)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(parts, mine, group=group)
+            whole = torch.cat(parts).cpu().contiguous().numpy()
+            C.memmove(recv, whole.ctypes.data, n * world)
+            return 0
+
+        self.t.set_exchange(exchange)
+
     def _buffers(self, n_workers: int):
         if self._sink_workers != n_workers:
             total = sink_layout(n_workers, self.cap)[4]

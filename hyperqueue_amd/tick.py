@@ -178,6 +178,14 @@ class Tick:
         self._lib.hqtick_cluster_add_workers.argtypes = [C.c_void_p, C.c_uint32, abi.u32p, abi.u64p, abi.u64p, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)]
         self._chk(self._lib.hqtick_cluster_add_workers(self._ctx, len(ids), ids.ctypes.data_as(abi.u32p), tot.ctypes.data_as(abi.u64p), fre.ctypes.data_as(abi.u64p), prem, pmu, pfl, pgr))
 
+    def set_exchange(self, fn):
+        """hqtick_set_exchange (ABI 8): fn(send_ptr, recv_ptr, bytes_per_rank) -> 0, an all-gather of host memory between the ranks of a sharded scheduler (the
+        placement's price sweeps and class blocks are then split over the ranks); None removes it"""
+        XFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+        self._lib.hqtick_set_exchange.argtypes = [C.c_void_p, XFN, C.c_void_p]
+        self._xfn = XFN((lambda _u, s, r, n: fn(s, r, n))) if fn is not None else XFN(0)  # kept alive with the Tick
+        self._chk(self._lib.hqtick_set_exchange(self._ctx, self._xfn, None))
+
     def cluster_remove_workers(self, worker_id):
         """on_remove_worker (ABI 7): by id; later rows move up.  Returns [(task, target worker id, variant)]: Retracting tasks of the removed workers that carried a
         redirect and are Assigned to its target from now on — the host sends their ComputeTasks messages (ABI 8, hqtick_cluster_last_reassigned)"""

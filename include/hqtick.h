@@ -495,6 +495,23 @@ uint32_t hqtick_sink_capacity_records(uint32_t n_workers, size_t capacity_bytes)
  *   hqtick_comm_destroy     ncclCommDestroy (also done by hqtick_destroy)
  */
 #define HQTICK_COMM_ID_BYTES 128
+/*
+ * The placement itself over the ranks (ABI 8; SURVEY.md §8e: the per-worker blocks are independent, what couples them stays replicated).  With
+ * shard_count > 1 and an exchange — the library's RCCL communicator (hqtick_comm_init with world == shard_count) or a callback of the host — every rank
+ *   * runs only ITS worker range of a coupled tick's price sweeps (k_price_sweep over its share of the master's 16 worker ranges) and completes each sweep
+ *     with one small all-gather: per block (c.x, reduced value, bound, steps), per range the wide rows' activities, and the rank's reading of the clock, so
+ *     that every replica sees bit-identical cuts and leaves the sweeps at the same sweep; the patterns cross once, when the master asks for them;
+ *   * solves only every shard_count-th class block of a separable tick (k_block_solve) and completes the launch with one all-gather of the answers.
+ * Results are the unsharded tick's, bit for bit (tests/test_sharded.py, tests/test_gpu_multi.py).  Models under HQTICK_SHARD_MIN_BLOCKS blocks / launches
+ * under HQTICK_SHARD_MIN_CLASSES classes (default 1025 both: what one MI355X holds resident at once) are solved whole by every rank, without an exchange;
+ * HQTICK_SHARD_SOLVE=0 switches the split off.  EVERY rank must run the same ticks: a rank that stops calling leaves the others in the collective.
+ *   hqtick_exchange_fn    all-gather of host memory: this rank contributes bytes_per_rank bytes at `send`; on return `recv` holds shard_count x bytes_per_rank
+ *                         bytes, rank-major.  0 = ok.  Called from inside hqtick_run* on the calling thread, a few KB per call.
+ *   hqtick_set_exchange   install (fn != NULL) or remove the callback; it takes precedence over the RCCL communicator.  rank / world are those of
+ *                         hqtick_set_shard.
+ */
+typedef int (*hqtick_exchange_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+int hqtick_set_exchange(hqtick_ctx *ctx, hqtick_exchange_fn fn, void *user);
 int hqtick_comm_unique_id(void *id_out);
 int hqtick_comm_init(hqtick_ctx *ctx, const void *id, uint32_t rank, uint32_t world);
 int hqtick_shard_allgather(hqtick_ctx *ctx, void *recv_device, size_t recv_bytes);
@@ -539,6 +556,10 @@ typedef struct hqtick_kernel_stats {
     double price_us, price_sweep_us;       /* host wall clock inside the price solve / inside the sweeps (launch -> totals visible in pinned memory) */
     double milp_us, model_us;              /* host wall clock of the whole solve of the coupled model / of building it (solver.rs:95-430)            */
     double solve_pre_us;                   /* ... and of what the placement stage did before it (worker classes, the separable attempt)               */
+    /* sharded placement solve (hqtick_set_exchange / hqtick_comm_init): the ranks' exchanges inside the last tick */
+    uint32_t exchange_calls, exchange_pad; /* all-gathers of host buffers (one per sharded sweep, one per pattern fetch, one per class-block launch)          */
+    uint64_t exchange_bytes;               /* bytes received by this rank in them                                                                              */
+    double exchange_us;                    /* host wall clock inside them                                                                                      */
 } hqtick_kernel_stats;
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
 /* Switch the per-kernel timing on / off at run time (HQTICK_FLAG_NO_KERNEL_TIMING sets the initial state).  When on, the measured kernels are

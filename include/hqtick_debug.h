@@ -103,6 +103,12 @@ int hqwire_debug_encode_host(const struct hqwire_tables *tables, const struct hq
  * must not depend on it -- a phase that did would be a data race on the GPU. */
 int hqwire_debug_encode_host_order(const struct hqwire_tables *tables, const struct hqwire_records *records, const struct hqwire_output *out, int order);
 
+/* hqtick_debug_host_stages as ONE RANK of a sharded scheduler (include/hqtick.h: hqtick_set_exchange): the emulated sweeps / class blocks run over this rank's
+ * share and are completed through `fn`; min_blocks / min_classes = the thresholds below which every rank solves the whole model.  fn = NULL: off. */
+void hqtick_debug_set_exchange(hqtick_exchange_fn fn, void *user, uint32_t rank, uint32_t world, uint32_t min_blocks, uint32_t min_classes);
+uint32_t hqtick_debug_last_exchange_calls(void);
+/* one exchange of the sharded solve through the library's RCCL communicator (hqtick_comm_init): recv gets world x bytes_per_rank bytes */
+int hqtick_debug_exchange(hqtick_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank);
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

@@ -80,6 +80,11 @@ def parse(header_src: str, structs, consts):
                 n = item
             out_enums.append((n, nxt))
             nxt += 1
+    for m in re.finditer(r"typedef\s+([\w \t\*]+?)\(\s*\*\s*(\w+)\s*\)\s*\(([^;]*?)\)\s*;", src, flags=re.S):  # function-pointer types (callbacks)
+        ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        params = [split_decl(a)[:2] for a in args.split(",")] if args and args != "void" else []
+        structs.add(name)
+        out_structs.append((name, ("fnptr", ret, params)))
     for m in re.finditer(r"typedef\s+struct\s+(\w+)\s+(\w+)\s*;", src):  # opaque handles
         structs.add(m.group(2))
         out_structs.append((m.group(2), None))
@@ -144,6 +149,13 @@ def generate() -> str:
             lines.append(f"pub const {n}: i32 = {v};")
         lines.append("")
         for name, fields in st:
+            if isinstance(fields, tuple) and fields[0] == "fnptr":
+                _, ret, params = fields
+                ps = ", ".join(f"{n}: {rust_type(t, structs)}" for t, n in params)
+                rr = "" if ret == "void" else f" -> {rust_type(ret, structs)}"
+                lines.append(f"pub type {camel(name)} = Option<unsafe extern \"C\" fn({ps}){rr}>;  // {name}: NULL = none")
+                lines.append("")
+                continue
             if fields is None:
                 lines.append(f"#[repr(C)] pub struct {camel(name)} {{ _opaque: [u8; 0] }}  // {name}: opaque handle")
                 lines.append("")
