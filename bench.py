@@ -63,15 +63,38 @@ def cpu_baseline(snap, ticks: int):
     }
 
 
-# HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md §HBM); None = not collected
-# rocprofv3 --kernel-trace durations of K1's in-tick launch (profiles/r02/README.md): ticks whose launches carry dispatch events (what this file's stats pass
-# does and `avg_launch_us` reports), ticks without any (the timed region: K1 is then the first packet behind the host's writes and its recorded duration
-# includes the queue's system-scope acquire), and the driver-style bench command, which mixes 55 of the latter with 50 of the former
-ROCPROF_K1 = {"avg_launch_us_ticks_with_events": 4.86, "avg_launch_us_ticks_without_events": 7.76, "avg_launch_us_bench_command_mixture": 6.25,
-              "frac_with_events": 12.0 / 4.86 / 8.0, "frac_without_events": 12.0 / 7.76 / 8.0, "frac_mixture": 12.0 / 6.25 / 8.0,
-              "earlier_runs_of_the_round": "with events 4.53-5.46, without 5.96-7.41, mixture 5.06-6.81 us",
-              "files": "profiles/r02/ticks_with_events.summary.csv, ticks_without_events.summary.csv, bench_c3.summary.csv"}
-TRAFFIC = {"level_hist": 12_046_346 + 2_250_112, "select_scatter": 8_061_011 + 2_037_568, "expand_mapping": 7_023_645 + 458_752}  # profiles/r02/bench_c3_{FETCH,WRITE}_SIZE.summary.csv (c3, N = 1 M)
+def committed_profile(kernel_substr: str):
+    """HBM bytes per launch and kernel-trace durations of one kernel, READ at run time from the newest committed rocprofv3 summaries of the bench command
+    (profiles/rNN/bench_c3*.summary.csv, written by profiles/summarize.py; FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md §HBM, each counter in its own --pmc pass).
+    A PMC pass cannot run inside this process (one profiler session per run), so the line quotes the committed passes — and says which files.  None: no such files."""
+    import glob
+
+    root = os.path.join(ROOT, "profiles")
+    for d in sorted(glob.glob(os.path.join(root, "r[0-9][0-9]")), reverse=True):
+        files = {k: os.path.join(d, f"bench_c3{suf}.summary.csv") for k, suf in (("trace", ""), ("fetch", "_FETCH_SIZE"), ("write", "_WRITE_SIZE"))}
+        if not all(os.path.exists(f) for f in files.values()):
+            continue
+
+        def row(path):  # (kernel names carry commas — `k_level_hist<4, true>` — and are not quoted: the numeric columns are split off from the right)
+            lines = [l.rstrip("\n") for l in open(path) if not l.startswith("==")]
+            hdr = lines[0].split(",")
+            for l in lines[1:]:
+                parts = l.rsplit(",", len(hdr) - 1)
+                if len(parts) == len(hdr) and kernel_substr in parts[0]:
+                    return dict(zip(hdr, parts))
+            return None
+
+        tr, fe, wr = row(files["trace"]), row(files["fetch"]), row(files["write"])
+        if not (tr and fe and wr):
+            continue
+        fetch, write = int(float(fe["FETCH_SIZE_x2_bytes"])), int(float(wr["WRITE_SIZE_bytes"]))
+        return {"traffic_bytes_per_launch": fetch + write, "fetch_x2_bytes": fetch, "write_bytes": write,
+                "kernel_trace": {"launches": int(tr["launches"]), "avg_ns": float(tr["avg_ns"]), "min_ns": float(tr["min_ns"]), "max_ns": float(tr["max_ns"])},
+                "files": [os.path.relpath(f, ROOT) for f in files.values()],
+                "note": "per launch, from the committed rocprofv3 passes of `bench.py --steps 50 --warmup 5` (headline loop only); kernel-trace average over the event-less launches of the "
+                        "timed region (K1 as the first packet behind the host's writes: its recorded span includes the queue's system-scope acquire) and the event-carrying "
+                        "launches of the stats pass — profiles/r04/k1_per_launch.txt lists them one by one"}
+    return None
 
 
 def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random", cpu_ticks: int = 1):
@@ -623,6 +646,7 @@ def main():
     # kernel trace agrees with, profiles/r01/final/).  `achieved` uses the back-to-back figure; the in-tick one is reported next to it.
     dom = "level_hist"
     b2b = {}
+    prof_k1 = committed_profile("k_level_hist")
     # What an event-bracketed launch costs at least, whatever it does: tools/exp/dispatch_floor.hip on this hardware (profiles/r03/dispatch_floor.txt) — an EMPTY
     # kernel records 3.9 us for every grid from 64 x 1024 to 1024 x 256 threads, K1's work as a persistent grid of any shape 4.1-4.3 us.  (Round 2 measured the
     # same floor through hqtick_time_kernel, which has moved to the measurement library libhqtick_test.so with the other tool hooks.)
@@ -659,8 +683,8 @@ def main():
                                           "events for EVERY grid shape tried (64 x 1024 ... 1024 x 256 threads), and K1's work as a persistent grid of any of those shapes 4.1-4.3 us: at 1 M tasks the "
                                           "launch sits on a fixed per-dispatch floor, not on its workgroup count — 12 MB cannot be priced above 12 MB / 3.9 us = 0.38 of 8 TB/s by this measure, "
                                           "whatever the kernel does (VERDICT r02 item 3 asked for a persistent grid or a micro-benchmark proving the floor: this is the latter)",
-                     "traffic": TRAFFIC.get(dom) if args.workload == "c3" else None,
-                     "rocprofv3": ROCPROF_K1 if args.workload == "c3" else None,
+                     "traffic": (prof_k1 or {}).get("traffic_bytes_per_launch") if args.workload == "c3" else None,
+                     "rocprofv3": prof_k1 if args.workload == "c3" else None,
                      "timing": "start / stop events at the dispatch of the launch INSIDE the tick (hipExtLaunchKernel), averaged over the stats pass after the timed region; "
                                "the rocprofv3 kernel trace of this command (profiles/r02/) lists the same launches",
                      "note": "K1 streams the whole ready set (12 B/task).  At 1 M tasks the set (20 MB) lives in the 256 MiB Infinity Cache across ticks and a launch is latency-bound "
@@ -841,6 +865,18 @@ def main():
             out["cpu_baseline"] = {"error": repr(e)}
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.wire_iters > 0:
         out["wire"] = wire_block(args.wire_iters)
+    # The headline is the best case twice over (one priority level: the placement separates into one 8-column block; the same tick repeated on a resident set, nothing
+    # consumed).  Its two honest neighbours ride right behind `value`: the same workload inside add -> tick -> consume, and SURVEY §8d's C3 as written, with three
+    # priority levels (one coupled model of all workers).  Details of both further down the line (`steady_state`, `multi_priority`).
+    nb = {}
+    ss, mp_ = out.get("steady_state"), out.get("multi_priority")
+    if isinstance(ss, dict) and "tasks_per_s" in ss:
+        nb["steady_state_add_tick_consume"] = {"tasks_handed_out_per_sec": ss["tasks_per_s"], "p50_step_ms": ss["p50_step_ms"], "p50_tick_us_inside_the_loop": ss["p50_tick_us"]}
+    if isinstance(mp_, dict) and "tasks_assigned_per_sec" in mp_:
+        nb["c3_with_three_priority_levels"] = {"tasks_assigned_per_sec": mp_["tasks_assigned_per_sec"], "p50_tick_ms": mp_["p50_tick_ms"], "is_optimal": mp_["is_optimal"]}
+    head = ("metric", "value", "unit")
+    out = {**{k: out[k] for k in head}, "value_is": "cold c3 tick, one priority level, repeated on the resident ready set (best case); see `neighbours`", "neighbours": nb,
+           **{k: v for k, v in out.items() if k not in head}}
     if dist is not None and args.multi_extras:
         # after everything the line is quoted on: if a rank gets lost in there, the watchdog prints the line as it stands and ends the process
         wd = watchdog(args.extras_timeout, lambda: print(json.dumps(dict(out, multi_rank={"error": f"did not come back within {args.extras_timeout:.0f} s"}))))
