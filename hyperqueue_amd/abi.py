@@ -186,6 +186,7 @@ class KernelStatsC(C.Structure):
         ("solve_decode_us", C.c_double),
         ("price_sweeps", C.c_uint32), ("price_rounds", C.c_uint32), ("milp_cols", C.c_uint32), ("milp_rows", C.c_uint32),
         ("price_us", C.c_double), ("price_sweep_us", C.c_double), ("milp_us", C.c_double), ("model_us", C.c_double), ("solve_pre_us", C.c_double),
+        ("n_classes_verified", C.c_uint32), ("n_classes_mismatch", C.c_uint32), ("n_classes_rejected", C.c_uint32), ("guard_pad", C.c_uint32),
         ("exchange_calls", C.c_uint32), ("exchange_pad", C.c_uint32), ("exchange_bytes", C.c_uint64), ("exchange_us", C.c_double),
     ]
 

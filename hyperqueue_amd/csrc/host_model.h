@@ -100,6 +100,8 @@ struct Problem {
     BlockSolver *blocks = nullptr;       // nullptr: every block on the host
     hqprice::Sweeper *pricer = nullptr;  // the block sweeps of the coupled solve (csrc/price.h): k_price_sweep in the tick; nullptr: host-only search
     uint32_t block_min_classes = 1;      // fewer device-eligible classes than this: not worth a launch
+    uint32_t block_verify = 2;           // classes of every device launch the host solves itself while the kernel runs, to compare (0: none, UINT32_MAX: all)
+    uint32_t tick_seq = 0;               // moves the sample window from tick to tick (the ctx's tick counter: the same on every replica)
     uint32_t R = 0, n_groups = 0;
     std::vector<RequestView> rqs;
     std::vector<VariantView> variants;  // all variant slots
@@ -175,6 +177,7 @@ struct Counts {
     long milp_nodes = 0; int milp_cols = 0, milp_rows = 0, milp_components = 0;
     int price_sweeps = 0, price_rounds = 0; double price_us = 0, milp_us = 0, model_us = 0, pre_us = 0;  // coupled path: block sweeps / flag rounds of csrc/price.cpp, time inside them, inside hqmilp::solve, building the model
     uint32_t blocks_device = 0, blocks_host = 0, block_steps_max = 0, n_classes = 0;
+    uint32_t blocks_verified = 0, blocks_mismatch = 0, blocks_rejected = 0;  // device block answers re-solved by the host while the kernel ran / of those: different / answers the O(columns) checks threw out
     double t_classify_us = 0, t_blocks_us = 0, t_decode_us = 0;  // separable path: worker classes / block solves (device wait included) / counts in Map order  // separable path: classes solved by k_block_solve / by the host solver
 };
 

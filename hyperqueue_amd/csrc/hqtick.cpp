@@ -135,6 +135,7 @@ struct hqtick_ctx {
     hqtick_exchange_fn xfn = nullptr; void *xuser = nullptr;
     DevBuf d_xsend, d_xrecv; PinBuf h_xsend, h_xrecv;
     uint32_t shard_min_blocks = 1025, shard_min_classes = 1025; bool shard_solve = true;
+    uint32_t block_verify = 2, tick_seq = 0;  // HQTICK_BLOCK_VERIFY: classes of a k_block_solve launch the host re-solves while the kernel runs (host_model.h: Problem::block_verify)
     uint64_t x_calls = 0, x_bytes = 0; double x_us = 0;
     double tl[32] = {}; int ntl = 0;  // debug timeline (us since tick start), hqtick_timeline()
 };
@@ -1145,6 +1146,7 @@ struct TickRun {
         const double t2 = now_us();
         DeviceBlocks dev_blocks(ctx);
         pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes; pb.pricer = ctx->pricer;
+        pb.block_verify = ctx->block_verify; pb.tick_seq = ctx->tick_seq++;
         double shard_sweep_us = -1.0;
         ctx->x_calls = 0; ctx->x_bytes = 0; ctx->x_us = 0;
         if (CtxExchange::available(ctx)) {  // the ranks of a sharded scheduler split the sweeps and the class blocks (no-ops below their thresholds)
@@ -1161,6 +1163,7 @@ struct TickRun {
         pb.blocks = nullptr; pb.pricer = nullptr;
         ctx->stats.price_sweeps = (uint32_t)cnt.price_sweeps; ctx->stats.price_rounds = (uint32_t)cnt.price_rounds; ctx->stats.price_us = cnt.price_us; ctx->stats.milp_us = cnt.milp_us; ctx->stats.model_us = cnt.model_us; ctx->stats.solve_pre_us = cnt.pre_us;
         ctx->stats.price_sweep_us = shard_sweep_us >= 0.0 ? shard_sweep_us : (ctx->pricer ? ctx->pricer->stat_sweep_us : 0.0); ctx->stats.milp_cols = (uint32_t)cnt.milp_cols; ctx->stats.milp_rows = (uint32_t)cnt.milp_rows;
+        ctx->stats.n_classes_verified = cnt.blocks_verified; ctx->stats.n_classes_mismatch = cnt.blocks_mismatch; ctx->stats.n_classes_rejected = cnt.blocks_rejected;
         ctx->stats.exchange_calls = (uint32_t)ctx->x_calls; ctx->stats.exchange_bytes = ctx->x_bytes; ctx->stats.exchange_us = ctx->x_us;
         if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
         ctx->stats.n_classes_device = cnt.blocks_device; ctx->stats.n_classes_host = cnt.blocks_host; ctx->stats.block_steps_max = cnt.block_steps_max; ctx->stats.n_classes = cnt.n_classes;
@@ -1284,6 +1287,7 @@ int hqtick_create(const hqtick_config *config, hqtick_ctx **out_ctx) {
         if (const char *e = getenv("HQTICK_PRICE_MIN_COLS")) { long v = atol(e); if (v > 0) min_cols = (uint32_t)v; }
         if (price) { ctx->pricer = new hqprice::DeviceSweeper(ctx->stream); ctx->pricer->budget = ctx->block_budget; if (min_cols) ctx->pricer->min_cols = min_cols; }
     }
+    if (const char *e = getenv("HQTICK_BLOCK_VERIFY")) ctx->block_verify = strcmp(e, "all") == 0 ? 0xFFFFFFFFu : (uint32_t)std::max(0L, atol(e));
     if (const char *e = getenv("HQTICK_SHARD_SOLVE")) ctx->shard_solve = atoi(e) != 0;
     if (const char *e = getenv("HQTICK_SHARD_MIN_BLOCKS")) { long v = atol(e); if (v >= 0) ctx->shard_min_blocks = (uint32_t)v; }
     if (const char *e = getenv("HQTICK_SHARD_MIN_CLASSES")) { long v = atol(e); if (v >= 0) ctx->shard_min_classes = (uint32_t)v; }
@@ -1873,14 +1877,31 @@ struct EmulatedBlocks : hqhost::BlockSolver {
         memcpy(b + o_kind, ct.ent_kind, ne); memcpy(b + o_amt, ct.ent_amount, (size_t)ne * 8); memcpy(b + o_pool, ct.pool, (size_t)R * 8);
         hqblock::ColTable bt{NC, R, (const uint32_t *)b, (const uint32_t *)(b + o_res), b + o_kind, (const uint64_t *)(b + o_amt), (const uint32_t *)(b + o_w), (const double *)(b + o_pool), b, (uint32_t)bytes};
         for (uint32_t c = 0; c < cl.n_classes; c++) hqblock::solve_block(wv, *S, (c & 1) ? ct : bt, cl, c, out, budget);  // odd classes: tables read in place
+        if (corrupt_mode && corrupt_class < cl.n_classes && out.status[corrupt_class] == hqblock::ST_OK) {  // fault injection (tests/test_block_solve.py): what a wrong kernel would hand back
+            uint32_t *x = out.x + (size_t)corrupt_class * NC;
+            if (corrupt_mode == 1) { for (uint32_t g = 0; g < NC; g++) if (x[g]) { x[g]--; break; } }               // one task short: feasible, not maximal
+            else if (corrupt_mode == 2) { for (uint32_t g = NC; g-- > 0;) if (x[g]) { x[g] += 1000; break; } }       // does not fit the rows
+            else if (corrupt_mode == 3) {                                                                             // everything on ONE column: corrupt_fill = column << 16 | count
+                const uint32_t col = corrupt_fill >> 16, n = corrupt_fill & 0xFFFFu;
+                if (col < NC) { for (uint32_t g = 0; g < NC; g++) x[g] = 0; x[col] = n; }
+            }
+        }
         return true;
     }
+    int corrupt_mode = 0; uint32_t corrupt_class = 0, corrupt_fill = 0;
 };
 thread_local int g_block_emulation = 0, g_price_emulation = 0; thread_local uint32_t g_price_min_cols = 0, g_last_price_sweeps = 0, g_last_price_rounds = 0;
 thread_local uint32_t g_block_budget = 4096, g_last_blocks_device = 0, g_last_blocks_host = 0;
+thread_local uint32_t g_block_verify = 2, g_tick_seq = 0, g_last_guard[3] = {0, 0, 0}; thread_local int g_corrupt_mode = 0; thread_local uint32_t g_corrupt_class = 0, g_corrupt_fill = 0;
 thread_local double g_last_stage_us[3] = {0, 0, 0};
 }  // namespace
 
+void hqtick_debug_set_block_guard(uint32_t verify, uint32_t tick_seq, int corrupt_mode, uint32_t corrupt_class, uint32_t corrupt_fill) {
+    g_block_verify = verify; g_tick_seq = tick_seq; g_corrupt_mode = corrupt_mode; g_corrupt_class = corrupt_class; g_corrupt_fill = corrupt_fill;
+}
+void hqtick_debug_last_block_guard(uint32_t *verified, uint32_t *mismatch, uint32_t *rejected) {
+    if (verified) *verified = g_last_guard[0]; if (mismatch) *mismatch = g_last_guard[1]; if (rejected) *rejected = g_last_guard[2];
+}
 void hqtick_debug_set_price_emulation(int on, uint32_t min_cols) { g_price_emulation = on; g_price_min_cols = min_cols; }
 // the host stages as ONE RANK of a sharded scheduler: emulated sweeps / class blocks over this rank's share, completed through `fn` (tests/test_sharded.py: gloo)
 thread_local hqtick_exchange_fn g_xfn = nullptr; thread_local void *g_xuser = nullptr; thread_local uint32_t g_xrank = 0, g_xworld = 1, g_xmin_blocks = 1, g_xmin_classes = 1, g_xcalls = 0;
@@ -1922,7 +1943,9 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
     memset(out, 0, sizeof(*out));
     export_batches(ctx, batches, out);
     EmulatedBlocks emu(g_block_budget);
+    emu.corrupt_mode = g_corrupt_mode; emu.corrupt_class = g_corrupt_class; emu.corrupt_fill = g_corrupt_fill;
     if (g_block_emulation) { pb.blocks = &emu; pb.block_min_classes = 1; }
+    pb.block_verify = g_block_verify; pb.tick_seq = g_tick_seq;
     hqprice::EmulatedSweeper pemu;
     if (g_price_emulation) { pemu.budget = g_block_budget; if (g_price_min_cols) pemu.min_cols = g_price_min_cols; pb.pricer = &pemu; }
     hqhost::Counts cnt;
@@ -1937,6 +1960,7 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
         g_xcalls = (uint32_t)xch.n_calls;
     } else cnt = hqhost::run_scheduling_solver(pb, batches);
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
+    g_last_guard[0] = cnt.blocks_verified; g_last_guard[1] = cnt.blocks_mismatch; g_last_guard[2] = cnt.blocks_rejected;
     g_last_blocks_device = cnt.blocks_device; g_last_blocks_host = cnt.blocks_host; g_last_price_sweeps = (uint32_t)cnt.price_sweeps; g_last_price_rounds = (uint32_t)cnt.price_rounds;
     g_last_stage_us[0] = cnt.t_classify_us; g_last_stage_us[1] = cnt.t_blocks_us; g_last_stage_us[2] = cnt.t_decode_us;
     ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();

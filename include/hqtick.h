@@ -556,6 +556,10 @@ typedef struct hqtick_kernel_stats {
     double price_us, price_sweep_us;       /* host wall clock inside the price solve / inside the sweeps (launch -> totals visible in pinned memory) */
     double milp_us, model_us;              /* host wall clock of the whole solve of the coupled model / of building it (solver.rs:95-430)            */
     double solve_pre_us;                   /* ... and of what the placement stage did before it (worker classes, the separable attempt)               */
+    /* the guard on k_block_solve's answers: classes of the launch the host solved itself while the kernel ran (HQTICK_BLOCK_VERIFY, default 2 per launch, a window that
+     * moves with the tick count) / of those: answers that differed (any: the whole launch is re-solved on the host) / answers thrown out by the per-class checks
+     * (fits the rows, no room left for another task) and re-solved on the host */
+    uint32_t n_classes_verified, n_classes_mismatch, n_classes_rejected, guard_pad;
     /* sharded placement solve (hqtick_set_exchange / hqtick_comm_init): the ranks' exchanges inside the last tick */
     uint32_t exchange_calls, exchange_pad; /* all-gathers of host buffers (one per sharded sweep, one per pattern fetch, one per class-block launch)          */
     uint64_t exchange_bytes;               /* bytes received by this rank in them                                                                              */

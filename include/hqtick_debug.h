@@ -103,6 +103,12 @@ int hqwire_debug_encode_host(const struct hqwire_tables *tables, const struct hq
  * must not depend on it -- a phase that did would be a data race on the GPU. */
 int hqwire_debug_encode_host_order(const struct hqwire_tables *tables, const struct hqwire_records *records, const struct hqwire_output *out, int order);
 
+/* The guard on the class blocks' answers (csrc/host_model.cpp; hqtick_kernel_stats.n_classes_verified / _mismatch / _rejected) under fault injection: `verify` classes
+ * of the launch are re-solved by the host (window starting at tick_seq * verify; UINT32_MAX = all), and the emulated blocks corrupt the answer of launch position
+ * corrupt_class: mode 1 = one task short (feasible, not maximal), 2 = does not fit the rows, 3 = everything on ONE column, corrupt_fill = column << 16 | count (a count that
+ * exactly fills a row every column needs is feasible and maximal, yet not the optimum), 0 = off. */
+void hqtick_debug_set_block_guard(uint32_t verify, uint32_t tick_seq, int corrupt_mode, uint32_t corrupt_class, uint32_t corrupt_fill);
+void hqtick_debug_last_block_guard(uint32_t *verified, uint32_t *mismatch, uint32_t *rejected);
 /* hqtick_debug_host_stages as ONE RANK of a sharded scheduler (include/hqtick.h: hqtick_set_exchange): the emulated sweeps / class blocks run over this rank's
  * share and are completed through `fn`; min_blocks / min_classes = the thresholds below which every rank solves the whole model.  fn = NULL: off. */
 void hqtick_debug_set_exchange(hqtick_exchange_fn fn, void *user, uint32_t rank, uint32_t world, uint32_t min_blocks, uint32_t min_classes);

@@ -204,3 +204,61 @@ def test_fuzz_scenarios_emulated_blocks_equal_host_blocks(seed):
     assert got.status == plain.status and got.batches == plain.batches
     if plain.is_canonical and got.is_canonical:
         assert got.counts == plain.counts
+
+
+# ------------------------------------------------------------------------------------------------ the guard on the device's answers
+def _guarded(cfg, snap, verify, tick_seq=0, mode=0, cls=0, fill=0):
+    """host stages with the emulated blocks under fault injection -> (result, classes taken from the device, solved by the host, (verified, mismatch, rejected))"""
+    lib = _testhooks.load()
+    lib.hqtick_debug_set_block_guard.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32]
+    lib.hqtick_debug_last_block_guard.argtypes = [C.POINTER(C.c_uint32)] * 3
+    lib.hqtick_debug_set_block_guard(verify, tick_seq, mode, cls, fill)
+    try:
+        res, n_emu, n_host = _emulated(cfg, snap)
+    finally:
+        lib.hqtick_debug_set_block_guard(2, 0, 0, 0, 0)
+    v, m, r = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    lib.hqtick_debug_last_block_guard(C.byref(v), C.byref(m), C.byref(r))
+    return res, n_emu, n_host, (v.value, m.value, r.value)
+
+
+def test_device_block_answers_are_not_taken_on_trust():
+    """VERDICT r03 next 3 / ADVICE r02 #5: a k_block_solve answer used to be accepted once it FITS the rows.  Now every answer must also be MAXIMAL (all costs are
+    positive: room for one more task = not an optimum), and a sample of the launch is re-solved by the host's exact solver while the kernel runs and compared column
+    by column — one difference and the whole launch is re-solved on the host.  Faults are injected behind the emulated wavefront (what a wrong kernel would hand
+    back); the tick's counts must come out as if nothing had happened, and the guard's counters must say who caught what."""
+    snap = workloads.make_steady("c3", seed=1, n_tasks=60_000, n_workers=64)
+    cfg = abi.make_config(time_limit_s=30.0)
+    clean, n_emu, n_host, (ver, mis, rej) = _guarded(cfg, snap, verify=2)
+    assert clean.is_optimal and clean.is_canonical and n_host == 0 and (ver, mis, rej) == (2, 0, 0) and n_emu >= 32
+    n_cls = n_emu
+    # 1. one task short on one class: feasible, so the old check let it through; not maximal -> thrown out, that class re-solved by the host
+    for cls in (0, 5, n_cls - 1):
+        got, n_emu, n_host, (ver, mis, rej) = _guarded(cfg, snap, verify=0, mode=1, cls=cls)
+        assert (mis, rej) == (0, 1) and n_host == 1 and n_emu == n_cls - 1
+        assert got.counts == clean.counts and got.is_canonical
+    # 2. an answer that does not fit the rows: as before
+    got, n_emu, n_host, (ver, mis, rej) = _guarded(cfg, snap, verify=0, mode=2, cls=3)
+    assert rej == 1 and n_host == 1 and got.counts == clean.counts
+    # 3. feasible AND maximal but not optimal — everything on one column, exactly filling a row: no O(columns) check can see it.  The sample does, when its
+    #    window covers the class: the window moves with the tick counter, so over n_cls / verify ticks every class of a steady cluster is looked at once.
+    #    (fill: how often the class's first used column fits — found by running the fault with verify = all and growing counts until the reject check lets it pass)
+    caught_at = None
+    for fill in range(1, 129):  # column 0 = the 1-cpu request: as many of them as the class has free cpus leave no room for anything (every c3 request needs a cpu)
+        got, n_emu, n_host, (ver, mis, rej) = _guarded(cfg, snap, verify=0, mode=3, cls=7, fill=(0 << 16) | fill)
+        if rej == 0:  # this count fills the cpu row exactly: the per-class checks accept it ...
+            assert got.counts != clean.counts  # ... and WITHOUT the sample the wrong answer is placed
+            caught_at = (0 << 16) | fill
+            break
+    assert caught_at is not None
+    seen = []
+    for tick_seq in range((n_cls + 1) // 2):
+        got, n_emu, n_host, (ver, mis, rej) = _guarded(cfg, snap, verify=2, tick_seq=tick_seq, mode=3, cls=7, fill=caught_at)
+        seen.append(mis)
+        if mis:
+            assert n_emu == 0 and got.counts == clean.counts and got.is_canonical  # the launch was distrusted as a whole and re-solved
+        else:
+            assert got.counts != clean.counts
+    assert sum(seen) == 1  # exactly the tick whose window held class 7
+    got, n_emu, n_host, (ver, mis, rej) = _guarded(cfg, snap, verify=0xFFFFFFFF, mode=3, cls=7, fill=caught_at)
+    assert mis == 1 and got.counts == clean.counts
