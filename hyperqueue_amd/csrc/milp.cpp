@@ -36,6 +36,8 @@ struct DSUlite {
 
 void order_by_cost_desc(const double *c, int n, std::vector<int> &out);
 
+const bool cuts_on = !(getenv("HQMILP_CUTS") && atoi(getenv("HQMILP_CUTS")) == 0);
+
 struct CompSolver {
     int n = 0;
     Rows R;
@@ -121,6 +123,161 @@ struct CompSolver {
         value = z;
         return true;
     }
+    // ---- Gomory mixed-integer cuts at the root ------------------------------------------------------------------------------------------------------------------
+    // The tick's coupled models are pure integer programs whose LP bound sits percent above the optimum (every worker a knapsack with fractional requests, the
+    // batch-size rows across them) and whose Lagrangian / Dantzig-Wolfe bound still sits 2e-4..6e-4 above it on small clusters mid-run — twice the reference's
+    // mip_rel_gap, with thousands of near-tied block patterns below it that no branching on single columns separates (tools/price_fuzz.py: the ticks HiGHS
+    // certifies and round 3 did not).  HiGHS closes exactly those at its ROOT: a few rounds of cuts take the LP bound down to the optimum itself.  The same here:
+    // every basic integer column with a fractional LP value gives one GMI cut from its tableau row (the tableau is dense and explicit, lp_tab.h) —
+    //     x_k + sum_j abar_j t_j = beta,  t_j >= 0 the nonbasic columns' distances from their bounds  =>  sum_j gamma_j t_j >= 1,
+    //     gamma_j = f_j / f_0 or (1 - f_j) / (1 - f_0) for an integer t_j (structural columns; slacks of rows whose coefficients share a unit), abar_j / f_0 or
+    //     -abar_j / (1 - f_0) for a continuous one —
+    // written back over the structural columns and appended to R like any other row (the LP activates it when violated; the tree's nodes inherit it).  Guarded the
+    // usual way: fractionality of the source row in [0.02, 0.98], bounded dynamism, a small rhs relaxation, and a cut the incumbent violates is thrown away.
+    std::vector<double> slack_unit;   // per row of R: its activity is an integer multiple of this (0: unknown / continuous)
+    int cuts_added = 0;
+    void find_slack_units() {
+        slack_unit.assign((size_t)R.m, 0.0);
+        for (int i = 0; i < R.m; i++) {
+            const int a = R.off[i], b = R.off[i + 1];
+            if (b <= a) continue;
+            // coefficients are the model's (multiples of 1e-4) divided by row_scale: on the grid 1e-4 / scale
+            const double sc = (size_t)i < row_scale.size() ? row_scale[(size_t)i] : 1.0;
+            long long g = 0; bool ok = true;
+            for (int k = a; k < b && ok; k++) {
+                const double v = R.coef[k] * sc * 10000.0; const double rv = std::round(v);
+                if (std::fabs(v - rv) > 1e-6 * std::max(1.0, std::fabs(v)) || std::fabs(rv) > 1e15) { ok = false; break; }
+                long long x = (long long)std::fabs(rv), y = g; while (y) { const long long tt = x % y; x = y; y = tt; } g = x;
+            }
+            if (!ok || g <= 0) continue;
+            const double unit = (double)g / (sc * 10000.0);
+            // the bounds the slack is measured from must lie on the same grid (presolve snaps the right-hand sides of `<=` rows to reachable values)
+            auto on_grid = [&](double v) { if (!(std::fabs(v) < INF)) return true; const double q = v / unit; return std::fabs(q - std::round(q)) <= 1e-7 * std::max(1.0, std::fabs(q)); };
+            if (on_grid(R.lo[i]) && on_grid(R.hi[i])) slack_unit[(size_t)i] = unit;
+        }
+    }
+    int gmi_round(Tab &t, Rows &RC, int max_cuts) {
+        const int N = t.width();
+        struct Cut { std::vector<std::pair<int, double>> terms; double rhs, eff; };
+        std::vector<Cut> found;
+        std::vector<double> alpha(n);
+        for (int r = 0; r < t.ma; r++) {
+            const int k = t.B[r];
+            if (k >= n) continue;
+            const double beta = t.x[k], f0 = beta - std::floor(beta);
+            if (f0 < 0.02 || f0 > 0.98) continue;
+            const double *row = &t.T[(size_t)r * t.stride];
+            std::fill(alpha.begin(), alpha.end(), 0.0);
+            double rho = 1.0; bool bad = false;
+            for (int j = 0; j < N && !bad; j++) {
+                if (t.st[j] == BASIC || row[j] == 0.0) continue;
+                if (t.lb[j] == t.ub[j]) continue;  // fixed: t_j = 0 always
+                const bool up = t.st[j] == AT_UP;
+                const double abar = up ? -row[j] : row[j];
+                double gamma, unit = 1.0; bool integer_t = j < n;
+                if (j >= n) { const double u = slack_unit[(size_t)t.arow[j - n]]; if (u > 0.0) { integer_t = true; unit = u; } }
+                if (integer_t) {
+                    const double au = abar * unit; double fj = au - std::floor(au);
+                    if (fj < 1e-9 || fj > 1.0 - 1e-9) fj = 0.0;
+                    gamma = (fj <= f0 ? fj / f0 : (1.0 - fj) / (1.0 - f0)) / unit;
+                } else gamma = abar >= 0.0 ? abar / f0 : -abar / (1.0 - f0);
+                if (gamma == 0.0) continue;
+                if (!(gamma < 1e9)) { bad = true; break; }
+                // gamma * t_j with t_j = x_j - lb_j (at lower) or ub_j - x_j (at upper); a slack x_j is its row's activity
+                const double bound = up ? t.ub[j] : t.lb[j];
+                if (!(std::fabs(bound) < 1e15)) { bad = true; break; }
+                const double sgn = up ? -1.0 : 1.0;
+                rho += sgn * gamma * bound;
+                if (j < n) alpha[j] += sgn * gamma;
+                else { const int i = t.arow[j - n]; for (int q = RC.off[i]; q < RC.off[i + 1]; q++) alpha[RC.col[q]] += sgn * gamma * RC.coef[q]; }
+            }
+            if (bad) continue;
+            // sum alpha_i x_i >= rho.  Tiny coefficients are dropped against the column's bound (a relaxation), then the dynamism is checked
+            double amax = 0.0; for (int i = 0; i < n; i++) amax = std::max(amax, std::fabs(alpha[i]));
+            if (!(amax > 1e-12)) continue;
+            Cut cut; double amin = INF, lhs = 0.0, norm = 0.0;
+            for (int i = 0; i < n; i++) {
+                const double a = alpha[i];
+                if (a == 0.0) continue;
+                if (std::fabs(a) < 1e-7 * amax) { const double w = a > 0.0 ? ub[i] : lb[i]; if (!(std::fabs(w) < 1e9)) { bad = true; break; } rho -= a * w; continue; }
+                cut.terms.push_back({i, a}); amin = std::min(amin, std::fabs(a)); lhs += a * t.x[i]; norm += a * a;
+            }
+            if (bad || cut.terms.empty() || amax / amin > 1e6) continue;
+            rho -= 1e-9 * (std::fabs(rho) + amax);  // numerical safety: the cut is relaxed a hair
+            const double viol = rho - lhs;
+            if (viol <= 1e-6 * amax) continue;
+            if (have) {  // never cut the incumbent off
+                double li = 0.0; for (auto &tm : cut.terms) li += tm.second * bx[tm.first];
+                if (li < rho - 1e-9 * (std::fabs(rho) + amax)) continue;
+            }
+            for (auto &tm : cut.terms) tm.second /= amax;
+            cut.rhs = rho / amax; cut.eff = viol / std::sqrt(norm);
+            found.push_back(std::move(cut));
+        }
+        std::sort(found.begin(), found.end(), [](const Cut &a, const Cut &b) { return a.eff > b.eff; });
+        int added = 0;
+        for (auto &cu : found) {
+            if (added >= max_cuts) break;
+            if (cu.eff < 1e-5) break;
+            RC.add(cu.terms, cu.rhs, INF);
+            slack_unit.push_back(0.0);
+            t.where.push_back(-1);
+            added++;
+        }
+        cuts_added += added;
+        return added;
+    }
+    // Dual feasibility of a solved tableau (max problem: a nonbasic column at its lower bound must not gain, one at its upper bound must not lose): what makes its
+    // objective a BOUND.  The dense tableau is never refactored, and cuts bring coefficient ranges of 1e6 into it: a warm re-solve can come back "optimal" from a
+    // basis whose reduced costs have drifted (tools/price_fuzz.py seed 29: 142.262 where a cold solve of the same rows gives 142.399) — such a value bounds nothing.
+    static bool dual_feasible(const Tab &t, double tol) {
+        const int N = t.width();
+        for (int j = 0; j < N; j++) {
+            if (t.st[j] == BASIC || t.lb[j] == t.ub[j]) continue;
+            if (t.st[j] == AT_LO ? t.d[j] > tol : t.d[j] < -tol) return false;
+        }
+        return true;
+    }
+    // Rounds of cuts on a COPY of the rows, for the bound only: the tree below keeps working on the model's own rows (its canonical answers must not depend on the
+    // numerics of cut rows).  A round's value counts when its tableau is dual feasible; the final value is taken from a COLD solve over the final rows, the larger of
+    // the two when they differ.
+    void root_cuts(const Tab &root0) {
+        if (in_lns || n > 600 || rel_gap <= 0.0) return;  // (the models the sweeps never see, 256 columns and below by default, and a little beyond; an LP of 1000+ columns is too slow to re-solve 40 times)
+        const double work_cap = work + 3.0e8 * std::max(0.2, time_limit_s / 5.0);  // a deterministic budget (tableau element updates: ~0.3 s of a 5 s limit), like every other one in here
+        Rows RC = R;
+        find_slack_units();
+        Tab root = root0; root.R = &RC;
+        double prev = root.objective(), accepted = prev;
+        int stall = 0;
+        for (int round = 0; round < 40 && !time_up() && work < work_cap; round++) {
+            if (have && accepted <= best + rel_gap * std::fabs(best)) break;
+            const int added = gmi_round(root, RC, 40 + n / 8);
+            if (!added) break;
+            bool ok = solve_counted(root) == LP_OPT && dual_feasible(root, 1e-7);
+            if (!ok) {  // once more from a cold start over the same rows
+                root = Tab(); root.init(&RC, c, lb, ub); root.deadline = deadline;
+                ok = solve_counted(root) == LP_OPT && dual_feasible(root, 1e-7);
+                if (!ok) break;
+            }
+            const double z = root.objective();
+            if (tracing) fprintf(stderr, "[milp] n=%d cut round %d: %d cuts, LP bound %.9f -> %.9f (%d rows active of %d)\n", n, round, added, prev, z, root.ma, RC.m);
+            if (z > accepted * (1.0 + 1e-9) + 1e-12) break;  // a bound cannot rise when rows are added: the arithmetic has gone wrong, keep what was accepted
+            accepted = z;
+            if (prev - z < 1e-7 * std::fabs(prev)) { if (++stall >= 3) break; } else stall = 0;
+            prev = z;
+            if (RC.m > 40 * n + 4000) break;
+        }
+        if (RC.m > R.m && accepted < root0.objective()) {  // the certificate's bound: confirmed by a cold solve of the final rows
+            Tab cold; cold.init(&RC, c, lb, ub); cold.deadline = deadline;
+            if (solve_counted(cold) == LP_OPT && dual_feasible(cold, 1e-7)) {
+                const double zc = cold.objective();
+                if (tracing) fprintf(stderr, "[milp] n=%d cuts: %d rows added, bound %.9f (cold solve of the final rows: %.9f)\n", n, RC.m - R.m, accepted, zc);
+                root_bound = std::min(root_bound, std::max(accepted, zc) * (1.0 + 1e-9) + 1e-12);
+            }
+        }
+        cuts_added = RC.m - R.m;
+    }
+
     void round_and_repair(const Tab &t) {
         std::vector<double> x(n);
         for (int j = 0; j < n; j++) x[j] = std::min(ub[j], std::max(lb[j], std::floor(t.x[j] + INT_TOL)));
@@ -750,7 +907,10 @@ struct CompSolver {
         // windows take the greedy incumbent to within 1e-4 of the root LP bound in a fraction of that — and then the root closes the search.
         bool lns_done = false;
         if (!in_lns && have && n >= LNS_FIRST_COLS) {
-            if (solve_counted(root) == LP_OPT) { root_bound = std::min(root_bound, root.objective()); lp_x.assign(root.x.begin(), root.x.begin() + n); }  // the bound the windows work towards (dfs_opt finds the tableau solved)
+            if (solve_counted(root) == LP_OPT) {
+                root_bound = std::min(root_bound, root.objective()); lp_x.assign(root.x.begin(), root.x.begin() + n);  // the bound the windows work towards (dfs_opt finds the tableau solved)
+                if (cuts_on && !certified()) { root_cuts(root); trace("root cuts done"); }
+            }
             trace("window search first");
             lns_schedule(deadline, false);  // cheap windows only (what they leave open the tree below usually closes faster than bigger windows would), until they
                                             // stall or the incumbent is certified — not until a clock says so: replicas of a sharded scheduler walk the same sequence
