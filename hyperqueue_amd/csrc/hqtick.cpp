@@ -54,6 +54,7 @@ namespace {
 struct PlanScratch {
     std::vector<uint32_t> q_total, pf_n, pf_start, seq_taken, pf_drained, zq_taken, new_pf_total, pfl_size, rq_sel_base;
     std::vector<uint32_t> key_seg, key_sum, key_rq, key_var_w, key_ord_off, ord_cnt, key_t_off, key_bits_off;
+    std::vector<uint32_t> key_tr;   // per key: c > 0 = stored worker-major by K4 (kernels.h: MapKeys::key_tr)
     std::vector<uint32_t> list_pos, pf_flag, pf_flag_prev, sn_ok, items, n_assign, asg_qw, has_pf, wm_order, pfq_src, pfq_size, out_off, take_base, mn_first;
     std::vector<uint8_t> now_mn;
     // the three per-(key | request, worker) tables of the plan are built IN the pinned buffer K4's ride-along workgroups copy from (a memcpy of ~100 KB per
@@ -629,6 +630,8 @@ struct TickRun {
     std::vector<std::vector<uint32_t>> key_T;                 // lazily built T_k(s) tables of worker_of()
     size_t o_rv = 0, o_rk = 0, o_mn = 0, o_fl = 0;            // layout of the pinned record buffer
     bool sweep_launched = false;  // K5a went out right after the key tables (launch_sweep_early)
+    uint32_t n_tr = 0;            // keys K4 stores worker-major (PlanScratch::key_tr)
+    const bool transpose_on = !(getenv("HQTICK_TRANSPOSE") && atoi(getenv("HQTICK_TRANSPOSE")) == 0);
     bool may_reorder = false;  // the mapping kernel needs its stable sort: several priority levels, Retracting holes or prefilled tasks inside the queues
     bool compact = false, delta16 = false; size_t o_rs = 0, o_rf = 0; uint32_t max_out = 0;  // compact emission (HQTICK_FLAG_COMPACT_RECORDS / _DELTA16)
     uint64_t *h_rec_task = nullptr, *mn_ids = nullptr; uint8_t *h_rec_var = nullptr, *h_rec_kind = nullptr;
@@ -696,7 +699,7 @@ struct TickRun {
         {   // the big tables live at the head of the pinned plan buffer; everything else of the plan (phase_c) is a few KB behind them
             ps.plan_head_words = (size_t)nkeys * W * 2 + (size_t)Q * W;
             size_t n_cnt0 = 0; for (uint32_t k = 0; k < nkeys; k++) n_cnt0 += cnt.key_size(k);
-            const size_t small = (size_t)8 * (nkeys + 4) + n_cnt0 + (size_t)6 * (Q + 2) + (W + 2) + (size_t)2 * sc.G + (size_t)2 * s->n_retracting + 64;
+            const size_t small = (size_t)9 * (nkeys + 4) + n_cnt0 + (size_t)6 * (Q + 2) + (W + 2) + (size_t)4 * sc.G + (size_t)2 * s->n_retracting + 64;
             if (!ctx->h_plan.ensure((ps.plan_head_words + small) * 4 + 64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc plan");
             ps.wpos = ctx->h_plan.as<uint32_t>(); ps.wcnt = ps.wpos + (size_t)nkeys * W; ps.pfl_j = ps.wcnt + (size_t)nkeys * W; ps.pfl_rows = 0;
         }
@@ -745,6 +748,21 @@ struct TickRun {
         }
         if (by_class) memcpy(ps.n_assign.data(), ps.items.data(), (size_t)W * 4);  // equal until the redirects are taken off
         n_bit_words = ps.key_bits_off[nkeys];
+        // Worker-major selection (kernels.hip: SelPlanN): a request served by ONE key that starts at the head of its queue and gives every one of its workers the same
+        // count — the cold tick on identical workers, and every saturated class of a homogeneous cluster — is written by K4 so that each worker's ids are contiguous.
+        // Only plain queues: no prefill set in front of the request, no Retracting task anywhere in this tick (holes are positions of the queue order).
+        ps.key_tr.assign(nkeys, 0);
+        n_tr = 0;
+        if (transpose_on && s->n_retracting == 0) {
+            std::vector<uint32_t> &nk = ps.pf_drained;  // (scratch: keys per request; plan_redirects re-assigns it)
+            nk.assign(Q, 0);
+            for (uint32_t k = 0; k < nkeys; k++) nk[ps.key_rq[k]]++;
+            for (uint32_t k = 0; k < nkeys; k++) {
+                const uint32_t q = ps.key_rq[k], n = ps.key_ord_off[k + 1] - ps.key_ord_off[k], c = ps.key_t_off[k + 1] - ps.key_t_off[k] - 1;
+                if (nk[q] != 1 || ps.key_seg[k] != 0 || ps.pf_n[q] != 0 || n == 0 || c == 0 || c > 0xFFFFu || n > 0xFFFFu || (uint64_t)n * c != ps.key_sum[k]) continue;
+                ps.key_tr[k] = c; n_tr++;
+            }
+        }
         // multi-node placements take one task each from the head of their queue (mapping.rs:133-154)
         ps.mn_first.assign(cnt.mn_rq.size(), 0);
         for (size_t i = 0; i < cnt.mn_rq.size(); i++) {
@@ -894,13 +912,21 @@ struct TickRun {
         ps.rq_sel_base.assign(Q + 1, 0);
         for (uint32_t q = 0; q < Q; q++) ps.rq_sel_base[q + 1] = ps.rq_sel_base[q] + ps.zq_taken[q] + ps.new_pf_total[q];
         n_sel = ps.rq_sel_base[Q];
-        ps.take_base.assign((size_t)2 * sc.G, 0);
+        ps.take_base.assign((size_t)4 * sc.G, 0);  // [take][base][tnc][tsb] per (level, rq) group (kernels.hip: SelPlanN)
         for (uint32_t q = 0; q < Q; q++) {
             uint32_t want = ps.zq_taken[q] + ps.new_pf_total[q], cum = 0;
             for (uint32_t l = 0; l < L; l++) {
                 uint32_t h = hist(l, q), t = want > cum ? std::min(h, want - cum) : 0;
                 ps.take_base[(size_t)l * Q + q] = t; ps.take_base[(size_t)sc.G + (size_t)l * Q + q] = ps.rq_sel_base[q] + cum;
                 cum += h;
+            }
+        }
+        if (n_tr) {
+            if (!ps.holes.empty()) return fail(ctx, HQTICK_E_UNSUPPORTED, "internal: worker-major selection on a tick with holes");  // (cannot happen: no Retracting task, no hole)
+            for (uint32_t k = 0; k < nkeys; k++) {
+                if (!ps.key_tr[k]) continue;
+                const uint32_t q = ps.key_rq[k], n = ps.key_ord_off[k + 1] - ps.key_ord_off[k];
+                for (uint32_t l = 0; l < L; l++) { ps.take_base[(size_t)2 * sc.G + (size_t)l * Q + q] = (n << 16) | ps.key_tr[k]; ps.take_base[(size_t)3 * sc.G + (size_t)l * Q + q] = ps.rq_sel_base[q]; }
             }
         }
         for (uint32_t q : pfq_rq) { ps.pfq_src.push_back(ps.rq_sel_base[q] + ps.zq_taken[q]); ps.pfq_size.push_back(ps.pfl_size[q]); }
@@ -963,18 +989,19 @@ struct TickRun {
     int launch_sweep_early() {
         sweep_launched = false;
         if (nkeys == 0 || n_bit_words == 0 || max_nk > hqk::SWEEP_MAX_WORKERS) return 0;  // (the capacity error is reported by plan_outputs)
+        if (n_tr == nkeys) { sweep_launched = true; return 0; }  // every key is stored worker-major: no bit row is ever read — no launch at all
         if (ctx->sweep_inflight) { HQ_HIP(hipStreamSynchronize(ctx->stream)); ctx->sweep_inflight = false; }  // a tick that failed after its early launch: its kernel still reads h_k5a
-        const size_t n_ord = ps.ord_cnt.size(), words = 3 * (size_t)(nkeys + 1) + n_ord;
+        const size_t n_ord = ps.ord_cnt.size(), words = 4 * (size_t)(nkeys + 1) + n_ord;
         if (!ctx->h_k5a.ensure(words * 4 + 64) || !ctx->d_tsweep.ensure((size_t)ps.key_t_off[nkeys] * 4 + 16) || !ctx->d_bits.ensure((size_t)n_bit_words * 8 + 16) ||
             !ctx->d_pre.ensure((size_t)n_bit_words * 4 + 16))
             return fail(ctx, HQTICK_E_DEVICE, "hipMalloc mapping");
         uint32_t *h = ctx->h_k5a.as<uint32_t>();
         const uint32_t *d = ctx->h_k5a.dev<uint32_t>();
-        const size_t o_toff = 0, o_ordoff = nkeys + 1, o_boff = 2 * (size_t)(nkeys + 1), o_ord = 3 * (size_t)(nkeys + 1);
+        const size_t o_toff = 0, o_ordoff = nkeys + 1, o_boff = 2 * (size_t)(nkeys + 1), o_tr = 3 * (size_t)(nkeys + 1), o_ord = 4 * (size_t)(nkeys + 1);
         memcpy(h + o_toff, ps.key_t_off.data(), (size_t)(nkeys + 1) * 4); memcpy(h + o_ordoff, ps.key_ord_off.data(), (size_t)(nkeys + 1) * 4);
-        memcpy(h + o_boff, ps.key_bits_off.data(), (size_t)(nkeys + 1) * 4); if (n_ord) memcpy(h + o_ord, ps.ord_cnt.data(), n_ord * 4);
+        memcpy(h + o_boff, ps.key_bits_off.data(), (size_t)(nkeys + 1) * 4); memcpy(h + o_tr, ps.key_tr.data(), (size_t)nkeys * 4); if (n_ord) memcpy(h + o_ord, ps.ord_cnt.data(), n_ord * 4);
         hqk::MapKeys mk{};
-        mk.n_keys = nkeys; mk.key_t_off = d + o_toff; mk.key_ord_off = d + o_ordoff; mk.key_bits_off = d + o_boff; mk.ord_cnt = d + o_ord;
+        mk.n_keys = nkeys; mk.key_t_off = d + o_toff; mk.key_ord_off = d + o_ordoff; mk.key_bits_off = d + o_boff; mk.ord_cnt = d + o_ord; mk.key_tr = d + o_tr;
         mk.t_sweep = ctx->d_tsweep.as<uint32_t>(); mk.bits = ctx->d_bits.as<uint64_t>(); mk.pre = ctx->d_pre.as<uint32_t>();
         if (ctx->timing) hqk::time_next_launch(ctx->ev[1], ctx->ev[6]);
         HQ_HIP_TIMED(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
@@ -1004,7 +1031,7 @@ struct TickRun {
             auto put = [&](const std::vector<uint32_t> &v) { const size_t o = cur; if (!v.empty()) memcpy(hp + cur, v.data(), v.size() * 4); cur += v.size(); if (v.empty()) hp[cur++] = 0; return o; };
             const size_t o_wpos = 0, o_wcnt = (size_t)nkeys * W, o_pflj = (size_t)2 * nkeys * W;
             size_t o_rq = put(ps.key_rq), o_var = put(ps.key_var_w), o_seg = put(ps.key_seg), o_ordoff = put(ps.key_ord_off), o_ord = put(ps.ord_cnt), o_toff = put(ps.key_t_off),
-                   o_boff = put(ps.key_bits_off), o_base = put(ps.rq_sel_base), o_pfs = put(ps.pf_start), o_pfn = put(ps.pf_n),
+                   o_boff = put(ps.key_bits_off), o_tr = put(ps.key_tr), o_base = put(ps.rq_sel_base), o_pfs = put(ps.pf_start), o_pfn = put(ps.pf_n),
                    o_pqs = put(ps.pfq_src), o_pqz = put(ps.pfq_size), o_out = put(ps.out_off);
             size_t o_tb = put(ps.take_base);
             if (cur & 1) hp[cur++] = 0;  // 8-byte alignment for the u64 hole list
@@ -1020,7 +1047,7 @@ struct TickRun {
             const uint32_t *d = ctx->d_map.as<uint32_t>();
             hqk::MapKeys mk{};
             mk.n_keys = nkeys; mk.key_rq = d + o_rq; mk.key_variant = reinterpret_cast<const uint8_t *>(d + o_var); mk.key_seg_start = d + o_seg;
-            mk.key_ord_off = d + o_ordoff; mk.ord_cnt = d + o_ord; mk.key_t_off = d + o_toff; mk.key_bits_off = d + o_boff;
+            mk.key_ord_off = d + o_ordoff; mk.ord_cnt = d + o_ord; mk.key_t_off = d + o_toff; mk.key_bits_off = d + o_boff; mk.key_tr = d + o_tr;
             mk.t_sweep = ctx->d_tsweep.as<uint32_t>(); mk.bits = ctx->d_bits.as<uint64_t>(); mk.pre = ctx->d_pre.as<uint32_t>();
             mk.wpos = d + o_wpos; mk.wcnt = d + o_wcnt; mk.rq_sel_base = d + o_base; mk.rq_pf_start = d + o_pfs; mk.rq_pf_n = d + o_pfn;
             mk.n_holes = (uint32_t)ps.holes.size(); mk.holes = reinterpret_cast<const uint64_t *>(d + o_holes);
@@ -1032,7 +1059,7 @@ struct TickRun {
             if (ctx->timing) hqk::time_next_launch(ctx->ev[4], ctx->ev[5]);
             HQ_HIP_TIMED(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
                                 d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, plan_words * 4, nullptr, ctx->stream));
-            if (!sweep_launched) {
+            if (!sweep_launched && n_tr < nkeys) {
                 if (ctx->timing) hqk::time_next_launch(ctx->ev[1], ctx->ev[6]);
                 HQ_HIP_TIMED(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
             }

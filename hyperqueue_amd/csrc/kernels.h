@@ -95,6 +95,8 @@ struct MapKeys {
     const uint32_t *ord_cnt;       // counts in iteration order
     const uint32_t *key_t_off;     // [n_keys+1] sweep units: key k owns units [key_t_off[k], key_t_off[k+1]) = sweeps 0..maxc_k
     const uint32_t *key_bits_off;  // [n_keys] first word of key k's bit rows (row s at + s * words_k, words_k = ceil(n_k / 64))
+    const uint32_t *key_tr;        // [n_keys] c > 0: every worker of the key takes exactly c tasks and K4 stored the key's tasks WORKER-MAJOR (the task of the worker at
+                                   // position j and sweep s at rq_sel_base + j * c + s): K5b reads its c ids contiguously and needs no round-robin cell; 0: queue order
     uint32_t *t_sweep;             // [n_units]  T_k(s)                     (written by K5a)
     uint64_t *bits;                // bit rows                               (written by K5a)
     uint32_t *pre;                 // per-word exclusive prefix popcounts    (written by K5a)

@@ -333,7 +333,11 @@ __global__ void __launch_bounds__(256) k_scan_rows(uint32_t *__restrict__ wave_t
 // LDS layout: [counters: WPB*G u32]([take G][base G] when the plan is staged).
 // PLAN: 0 = take/base arrive in the kernel arguments (G <= 64: no load from pinned or global memory on the critical path),
 //       1 = staged into LDS from `take`/`base`,  2 = read in place (large G, one wavefront per workgroup).
-template <int N> struct SelPlanN { uint32_t take[N], base[N]; };  // the plan in the kernel arguments: 8 bytes per group of the launch call's argument block
+// tnc / tsb: the TRANSPOSED scatter of a group (K5b's gather).  A request whose single placement key gives every one of its n workers the same count c
+// is taken round-robin: the task at position p of the queue goes to the worker at list position p % n as its (p / n)-th task — worker w's tasks sit n * 8 bytes apart in
+// queue order, and K5b's gather touched one 64-byte line per record (6.0 MB fetched for 2.3 MB of algorithmic bytes).  With tnc[g] = n << 16 | c (0: off) and
+// tsb[g] = the request's base in sel_* (so that p = base[g] - tsb[g] + rank), K4 writes the task to tsb + (p % n) * c + p / n instead: each worker's ids contiguous.
+template <int N> struct SelPlanN { uint32_t take[N], base[N], tnc[N], tsb[N]; };  // the plan in the kernel arguments: 8 bytes per group of the launch call's argument block
                                                                   // (a launch call costs ~1.7 ns per argument byte on the host: 16 groups = 128 B, 64 = 512 B)
 
 template <int WPB, int PLAN, int PN>
@@ -354,11 +358,15 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
     const uint32_t sel_block = blockIdx.x - n_copy_blocks;
     uint32_t *s_all = reinterpret_cast<uint32_t *>(smem);
     uint32_t *s_cnt = s_all + (threadIdx.x >> 6) * G;
-    const uint32_t *tk = take, *bs = base;
+    const uint32_t *tk = take, *bs = base, *tnc = base + G, *tsb = base + 2 * G;  // the plan in memory: [take G][base G][tnc G][tsb G]
     if (PLAN != 2) {
         uint32_t *s_take = s_all + WPB * G, *s_base = s_take + G;
-        for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) { s_take[g] = PLAN == 0 ? pa.take[g] : take[g]; s_base[g] = PLAN == 0 ? pa.base[g] : base[g]; }
-        tk = s_take; bs = s_base;
+        uint32_t *s_tnc = s_base + G, *s_tsb = s_tnc + G;
+        for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) {
+            s_take[g] = PLAN == 0 ? pa.take[g] : take[g]; s_base[g] = PLAN == 0 ? pa.base[g] : base[g];
+            s_tnc[g] = PLAN == 0 ? pa.tnc[g] : base[G + g]; s_tsb[g] = PLAN == 0 ? pa.tsb[g] : base[2 * G + g];
+        }
+        tk = s_take; bs = s_base; tnc = s_tnc; tsb = s_tsb;
     }
     const uint32_t lane = lane_id();
     const uint32_t wave = sel_block * WPB + (threadIdx.x >> 6);
@@ -406,7 +414,12 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
                     if (mark_rq) {  // consume mode (hqtick_ready_consume_last): the task leaves the ready set
                         mark_rq[b + (uint64_t)u * 64 + lane] = RQ_TOMBSTONE;
                     } else {
-                        const uint32_t dst = bs[g] + rank;
+                        uint32_t dst = bs[g] + rank;
+                        const uint32_t nc = tnc[g];
+                        if (nc) {  // worker-major: position p of the request's queue -> (worker p % n, its task p / n)
+                            const uint32_t sb = tsb[g], p = dst - sb, nw = nc >> 16, c = nc & 0xFFFFu;
+                            if (p < nw * c) { const uint32_t sw = p / nw; dst = sb + (p - sw * nw) * c + sw; }
+                        }
                         sel_task[dst] = idv[u];
                         sel_key[dst] = (uint16_t)g;  // group key; its level is g / Q (K5b)
                     }
@@ -427,6 +440,7 @@ __global__ void __launch_bounds__(256) k_sweep_bits(MapKeys mk) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *s_c = reinterpret_cast<uint32_t *>(smem);  // count of position j at s_c[j + (j >> 6)]
     const uint32_t k = blockIdx.y, lane = lane_id();
+    if (mk.key_tr[k]) return;  // a key stored worker-major by K4 (every worker the same count): nobody reads its bit rows
     const uint32_t t0 = mk.key_t_off[k], n_sweeps = mk.key_t_off[k + 1] - t0;  // sweeps 0..maxc
     if (blockIdx.x * 4 >= n_sweeps) return;
     const uint32_t nk = mk.key_ord_off[k + 1] - mk.key_ord_off[k];
@@ -491,7 +505,8 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
     const bool compact = co.rec_lo != nullptr;
     uint32_t *k_pos = k_start + nkeys + 1;
     uint32_t *k_cnt = k_pos + nkeys, *k_rq = k_cnt + nkeys, *k_seg = k_rq + nkeys, *k_toff = k_seg + nkeys, *k_boff = k_toff + nkeys, *k_words = k_boff + nkeys;
-    uint32_t *misc = k_words + nkeys;  // [0] min level, [1] max level, [2] holes
+    uint32_t *k_trc = k_words + nkeys;
+    uint32_t *misc = k_trc + nkeys;  // [0] min level, [1] max level, [2] holes
     uint32_t *s_key = misc + 4;        // [sort_cap] (level << 16 | item) keys of the stable sort; sort_cap = 0 on ticks that cannot reorder
     uint8_t *k_var = reinterpret_cast<uint8_t *>(s_key + sort_cap);
     const uint32_t w = blockIdx.x, lane = lane_id();
@@ -506,6 +521,7 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
         k_cnt[k] = mk.wcnt[(size_t)k * W + w];
         k_rq[k] = mk.key_rq[k]; k_seg[k] = mk.key_seg_start[k]; k_toff[k] = mk.key_t_off[k]; k_boff[k] = mk.key_bits_off[k];
         k_words[k] = (mk.key_ord_off[k + 1] - mk.key_ord_off[k] + 63) >> 6;
+        k_trc[k] = mk.key_tr[k];
         k_var[k] = mk.key_variant[k];
     }
     if (pf_staged && threadIdx.x < mk.n_pfq) {
@@ -569,6 +585,19 @@ __global__ void __launch_bounds__(256) k_expand_mapping(MapKeys mk, uint32_t W, 
             uint32_t lo = 0, hi = nkeys;  // last key with k_start[k] <= e (it is the non-empty one)
             while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (k_start[mid] <= e) lo = mid; else hi = mid; }
             const uint32_t k = lo, s = e - k_start[k], pos = k_pos[k];
+            if (k_trc[k]) {  // worker-major key: this worker's tasks are the k_trc[k] ids from its own offset on (no cell, no hole: the host transposes only plain queues)
+                const uint32_t src = mk.rq_sel_base[k_rq[k]] + pos * k_trc[k] + s;
+                const uint16_t lv = sort_cap ? (uint16_t)(sel_key[src] / Q) : (uint16_t)0;
+                e_task[e] = sel_task[src];
+                e_lvl[e] = lv;
+                e_meta[e] = (uint16_t)(k_var[k] | 0x100u);
+                if (sort_cap) { atomicMin(&misc[0], (uint32_t)lv); atomicMax(&misc[1], (uint32_t)lv); }
+                if (do_pf) {
+                    if (compact) { if (u < max_out) { f_task[u] = pf_id; f_meta[u] = 0x00FFu; } }
+                    else { rec_task[out0 + u] = pf_id; rec_variant[out0 + u] = 0xFF; rec_kind[out0 + u] = 0; }
+                }
+                continue;
+            }
             const size_t cell = (size_t)k_boff[k] + (size_t)s * k_words[k] + (pos >> 6);
             const uint32_t q = k_rq[k];
             const uint32_t pre = mk.pre[cell], tsw = mk.t_sweep[k_toff[k] + s];
@@ -1053,17 +1082,17 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
     hipError_t e;
     if (sel && geom.waves_per_block == 4 && G <= 64) {
         // small plan: take/base travel in the kernel arguments; ride-along workgroups copy the whole plan into HBM for K5a/K5b
-        size_t lds = (size_t)6 * G * 4;
+        size_t lds = (size_t)8 * G * 4;
         const uint32_t nsb = (geom.n_waves + 3) / 4, ncb = n16 ? (n16 + 255) / 256 : 0;  // one 16-byte PCIe read per thread: a single round trip (four per thread cost the launch 2.7 us)
         if (G <= 16) {
             SelPlanN<16> pa{};
-            for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; }
+            for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; pa.tnc[g] = take_host[2 * G + g]; pa.tsb[g] = take_host[3 * G + g]; }
             HQK_TIMED_LAUNCH((k_select<4, 0, 16>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
                                (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
                                reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq);
         } else {
             SelPlanN<64> pa{};
-            for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; }
+            for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; pa.tnc[g] = take_host[2 * G + g]; pa.tsb[g] = take_host[3 * G + g]; }
             HQK_TIMED_LAUNCH((k_select<4, 0, 64>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
                                (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
                                reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq);
@@ -1077,7 +1106,7 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
     if (!sel) return hipSuccess;
     SelPlanN<1> none{};
     if (geom.waves_per_block == 4) {
-        size_t lds = (size_t)6 * G * 4;
+        size_t lds = (size_t)8 * G * 4;
         auto kern = k_select<4, 1, 1>;
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         const uint32_t nsb = (geom.n_waves + 3) / 4;
@@ -1122,7 +1151,7 @@ hipError_t sweep_bits(MapKeys mk, uint32_t max_count, uint32_t max_workers_per_k
 uint32_t expand_mapping_sort_cap(uint32_t max_items) { uint32_t p = 1; while (p < max_items) p <<= 1; return p; }
 
 size_t expand_mapping_lds(uint32_t max_items, uint32_t n_keys, uint32_t max_out, bool may_reorder) {
-    return (size_t)max_items * 12 + (size_t)max_out * 10 + 2 + ((size_t)8 * n_keys + 1 + 4) * 4 + n_keys + 16 + (may_reorder ? (size_t)expand_mapping_sort_cap(max_items) * 4 : 0) +
+    return (size_t)max_items * 12 + (size_t)max_out * 10 + 2 + ((size_t)9 * n_keys + 1 + 4) * 4 + n_keys + 16 + (may_reorder ? (size_t)expand_mapping_sort_cap(max_items) * 4 : 0) +
            (max_out ? (size_t)RUN_STAGE * 16 + 4 + (size_t)max_out * 6 + 8 : 0);  // max_out != 0 = compact emission: the run stage + the 16-bit unit stream (delta mode)
 }
 
