@@ -469,6 +469,7 @@ def main():
     ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
     ap.add_argument("--no-multi-extras", dest="multi_extras", action="store_false", help="N > 1: skip the blocks after the timed region (configs[3]'s coupled tick with the solve split over the ranks vs replicated; c4 strong scaling)")
     ap.add_argument("--extras-timeout", type=float, default=240.0, help="N > 1: seconds the extra blocks may take before the line is printed without them")
+    ap.add_argument("--plain-adds", action="store_true", help="steady-state loop: new tasks as three full columns (hqtick_ready_add_staged, 20 B per task) instead of the packed form")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
     ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
     args = ap.parse_args()
@@ -742,11 +743,20 @@ def main():
             k = len(gone)
             new_rq = rq_of[(gone & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1]  # arrivals replace exactly what left, class by class
             rq_of = np.concatenate([rq_of, new_rq])
-            v_id, v_prio, v_rq = ts.ready_add_stage(k)  # the arrivals are written straight into the library's pinned staging buffer
-            v_id[:] = np.arange(next_id, next_id + k, dtype=np.uint64); next_id += k
-            v_prio[:] = snap.task_priority[0]
-            v_rq[:] = new_rq
-            a = time.perf_counter(); ts.ready_add_staged(k)
+            # the arrivals in the PACKED form (hqtick_ready_add_packed, ABI 8): freshly minted ids are one consecutive run, one priority, u16 request ids — 2 bytes per
+            # task over PCIe instead of 20 (--plain-adds: the three full columns through the pinned staging buffer, as up to round 3)
+            rq16 = new_rq.astype(np.uint16)
+            if args.plain_adds:
+                v_id, v_prio, v_rq = ts.ready_add_stage(k)
+                v_id[:] = np.arange(next_id, next_id + k, dtype=np.uint64)
+                v_prio[:] = snap.task_priority[0]
+                v_rq[:] = new_rq
+            a = time.perf_counter()
+            if args.plain_adds:
+                ts.ready_add_staged(k)
+            else:
+                ts.ready_add_packed([(next_id, k)], [(int(snap.task_priority[0]), k)], rq16)
+            next_id += k
             b = time.perf_counter(); res = ts.tick_raw(sc, resident=True)
             c = time.perf_counter(); ts.ready_consume_last(); torch.cuda.synchronize()
             d = time.perf_counter()
@@ -756,11 +766,11 @@ def main():
         t_add, t_tick, t_cons = (np.asarray(x[2:]) for x in (t_add, t_tick, t_cons))
         step = t_add + t_tick + t_cons
         out["steady_state"] = {
-            "what": "per step: hqtick_ready_add_staged(new tasks, written in place into the pinned staging buffer) + hqtick_run_resident + hqtick_ready_consume_last; workers empty again before every tick (sleep-0 tasks)",
+            "what": "per step: hqtick_ready_add_packed / _staged (the new tasks) + hqtick_run_resident + hqtick_ready_consume_last; workers empty again before every tick (sleep-0 tasks)",
             "steps": args.steady_steps, "ready_set_before_each_tick": int(ts.ready_count()) + per_step, "tasks_handed_out_per_step": per_step,
             "p50_step_ms": 1e3 * float(np.median(step)), "tasks_per_s": per_step / float(np.median(step)),
             "p50_add_us": 1e6 * float(np.median(t_add)), "p50_tick_us": 1e6 * float(np.median(t_tick)), "p50_consume_us": 1e6 * float(np.median(t_cons)),
-            "delta_bytes_host_to_device_per_step": per_step * 20,
+            "delta_bytes_host_to_device_per_step": per_step * (20 if args.plain_adds else 2), "adds": "plain columns (20 B per task)" if args.plain_adds else "packed (hqtick_ready_add_packed: 2 B per task)",
         }
         ts.close()
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.hetero_steps > 0:

@@ -89,7 +89,7 @@ struct hqtick_ctx {
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
-    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_retr, h_blk, h_k5a;
+    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_addp, h_retr, h_blk, h_k5a;
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
     hqprice::DeviceSweeper *pricer = nullptr;  // k_price_sweep: the block sweeps of the coupled placement (csrc/price.hip); HQTICK_PRICE=0 keeps coupled ticks on the host search
     uint32_t block_budget = 4096, block_min_classes = 12;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
@@ -1342,7 +1342,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->comm) { rccl_destroy_comm(ctx); }
     ctx->graph.release();
-    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_retr.release(); ctx->h_blk.release(); ctx->h_blkprof.release(); ctx->h_k5a.release();
+    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_addp.release(); ctx->h_retr.release(); ctx->h_blk.release(); ctx->h_blkprof.release(); ctx->h_k5a.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
@@ -1505,6 +1505,40 @@ int hqtick_ready_add_staged(hqtick_ctx *ctx, uint64_t n) {
     if (!ctx->d_add.ensure(L.bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
     unsigned char *d = ctx->d_add.as<unsigned char>();
     HQ_HIP(hipMemcpyAsync(d, h, L.o_q + n * 4, hipMemcpyHostToDevice, ctx->stream));
+    return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + L.o_p), reinterpret_cast<const uint32_t *>(d + L.o_q), (uint32_t)n);
+}
+
+int hqtick_ready_add_packed(hqtick_ctx *ctx, uint64_t n, uint32_t n_id_runs, const uint64_t *id_run_start, const uint32_t *id_run_len, const uint32_t *id_off,
+                            uint32_t n_prio_runs, const uint64_t *prio_run_value, const uint32_t *prio_run_len, const uint16_t *task_rq) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set (hqtick_upload_ready with n = 0 creates an empty one)");
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFFFull) return fail(ctx, HQTICK_E_CAPACITY, "more than 2^32 ids in one delta");
+    if (!n_id_runs || !n_prio_runs || !id_run_start || !id_run_len || !prio_run_value || !prio_run_len || !task_rq) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add_packed: null array");
+    // the small run tables are checked here (a handful of entries); ids ascending across the whole batch, duplicates against the resident set and the reserved
+    // request id are checked by the merge kernel, as for hqtick_ready_add
+    uint64_t tot = 0; for (uint32_t r = 0; r < n_id_runs; r++) { if (!id_run_len[r]) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add_packed: empty id run"); tot += id_run_len[r]; }
+    if (tot != n) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add_packed: the id runs do not add up to n");
+    tot = 0; for (uint32_t r = 0; r < n_prio_runs; r++) { if (!prio_run_len[r]) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add_packed: empty priority run"); tot += prio_run_len[r]; }
+    if (tot != n) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add_packed: the priority runs do not add up to n");
+    HQ_HIP(hipSetDevice(ctx->device));
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_is = 0, o_if = al(o_is + (size_t)n_id_runs * 8), o_pv = al(o_if + (size_t)(n_id_runs + 1) * 4), o_pf = al(o_pv + (size_t)n_prio_runs * 8), o_off = al(o_pf + (size_t)(n_prio_runs + 1) * 4),
+                 o_rq = al(o_off + (id_off ? (size_t)n * 4 : 0)), bytes = al(o_rq + (size_t)n * 2);
+    if (!ctx->h_addp.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc packed delta staging");
+    const AddLayout L = add_layout(n);
+    if (!ctx->d_add.ensure(L.bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
+    unsigned char *h = ctx->h_addp.as<unsigned char>(), *hd = ctx->h_addp.dev<unsigned char>(), *d = ctx->d_add.as<unsigned char>();
+    memcpy(h + o_is, id_run_start, (size_t)n_id_runs * 8); memcpy(h + o_pv, prio_run_value, (size_t)n_prio_runs * 8);
+    uint32_t *idf = reinterpret_cast<uint32_t *>(h + o_if), *pf = reinterpret_cast<uint32_t *>(h + o_pf);
+    idf[0] = 0; for (uint32_t r = 0; r < n_id_runs; r++) idf[r + 1] = idf[r] + id_run_len[r];
+    pf[0] = 0; for (uint32_t r = 0; r < n_prio_runs; r++) pf[r + 1] = pf[r] + prio_run_len[r];
+    if (id_off) memcpy(h + o_off, id_off, (size_t)n * 4);
+    memcpy(h + o_rq, task_rq, (size_t)n * 2);
+    // the expansion kernel reads the packed batch in place (pinned, device-mapped): what crosses PCIe is the packed form
+    HQ_HIP(hqk::ready_unpack_adds((uint32_t)n, n_id_runs, reinterpret_cast<const uint64_t *>(hd + o_is), reinterpret_cast<const uint32_t *>(hd + o_if), id_off ? reinterpret_cast<const uint32_t *>(hd + o_off) : nullptr,
+                                  n_prio_runs, reinterpret_cast<const uint64_t *>(hd + o_pv), reinterpret_cast<const uint32_t *>(hd + o_pf), reinterpret_cast<const uint16_t *>(hd + o_rq),
+                                  reinterpret_cast<uint64_t *>(d), reinterpret_cast<uint64_t *>(d + L.o_p), reinterpret_cast<uint32_t *>(d + L.o_q), ctx->stream));
     return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + L.o_p), reinterpret_cast<const uint32_t *>(d + L.o_q), (uint32_t)n);
 }
 

@@ -874,6 +874,30 @@ __global__ void __launch_bounds__(256) k_merge_adds(const uint64_t *__restrict__
     nid[dst] = key; nprio[dst] = aprio[j]; nrq[dst] = arq[j];
 }
 
+// A PACKED batch of new ready tasks (hqtick_ready_add_packed) expanded into the three columns the merge works on: what crossed PCIe is 2-6 bytes per task — the
+// tasks a submit or a finished wave makes ready have ids in a few consecutive runs, one priority per run, and a request id that fits 16 bits — instead of 20.
+// One thread per task: its id run and its priority run by binary search over the runs' first positions (a handful of entries, read from pinned memory in place).
+struct PackedAdds {
+    uint32_t n, n_id_runs, n_prio_runs;
+    const uint64_t *id_start; const uint32_t *id_first;      // [n_id_runs] first id / first position of the run;  id_first[n_id_runs] = n
+    const uint32_t *id_off;                                   // [n] offset from the run's first id, or nullptr: position inside the run (consecutive ids)
+    const uint64_t *prio_value; const uint32_t *prio_first;   // [n_prio_runs], prio_first[n_prio_runs] = n
+    const uint16_t *rq;                                       // [n]
+};
+__global__ void __launch_bounds__(256) k_unpack_adds(PackedAdds pa, uint64_t *__restrict__ aid, uint64_t *__restrict__ aprio, uint32_t *__restrict__ arq) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= pa.n) return;
+    uint32_t lo = 0, hi = pa.n_id_runs;  // last run with id_first <= j
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pa.id_first[mid] <= j) lo = mid; else hi = mid; }
+    const uint32_t off = pa.id_off ? pa.id_off[j] : j - pa.id_first[lo];
+    aid[j] = pa.id_start[lo] + off;
+    uint32_t plo = 0, phi = pa.n_prio_runs;
+    while (phi - plo > 1) { const uint32_t mid = (plo + phi) >> 1; if (pa.prio_first[mid] <= j) plo = mid; else phi = mid; }
+    aprio[j] = pa.prio_value[plo];
+    const uint32_t q = pa.rq[j];
+    arq[j] = q == 0xFFFFu ? RQ_TOMBSTONE : q;  // (0xFFFF is not a request id of the packed form: it trips the merge's reserved-id check)
+}
+
 // ------------------------------------------------------------------------------------------------ position of given tasks in their queues
 // One wavefront per wanted id: its group key and its rank inside the group (= how many tasks of the same (level, rq) precede it in
 // id order), from the sorted id column, the key column and the scanned slice table.  Used for the few ready tasks that are in
@@ -1201,6 +1225,14 @@ hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint3
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || n_add == 0) return e;
     hipLaunchKernelGGL(k_merge_adds, dim3((n_add + 255) / 256), dim3(256), 0, s, oid, n, slice_off, pre8, n_live, aid, aprio, arq, n_add, nid, nprio, nrq, err_flag);
+    return hipGetLastError();
+}
+
+hipError_t ready_unpack_adds(uint32_t n, uint32_t n_id_runs, const uint64_t *id_start, const uint32_t *id_first, const uint32_t *id_off, uint32_t n_prio_runs, const uint64_t *prio_value,
+                             const uint32_t *prio_first, const uint16_t *rq, uint64_t *aid, uint64_t *aprio, uint32_t *arq, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    PackedAdds pa{n, n_id_runs, n_prio_runs, id_start, id_first, id_off, prio_value, prio_first, rq};
+    hipLaunchKernelGGL(k_unpack_adds, dim3((n + 255) / 256), dim3(256), 0, s, pa, aid, aprio, arq);
     return hipGetLastError();
 }
 

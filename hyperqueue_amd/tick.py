@@ -186,6 +186,19 @@ class Tick:
         self._xfn = XFN((lambda _u, s, r, n: fn(s, r, n))) if fn is not None else XFN(0)  # kept alive with the Tick
         self._chk(self._lib.hqtick_set_exchange(self._ctx, self._xfn, None))
 
+    def ready_add_packed(self, id_runs, prio_runs, task_rq, id_off=None):
+        """hqtick_ready_add_packed (ABI 8): id_runs = [(first id, length)], prio_runs = [(priority, length)], task_rq u16 per task, id_off = None (consecutive ids inside a
+        run) or u32 offsets from the run's first id — 2-6 bytes per task over PCIe instead of hqtick_ready_add's 20"""
+        rq = np.ascontiguousarray(task_rq, np.uint16)
+        n = len(rq)
+        ist = np.ascontiguousarray([r[0] for r in id_runs], np.uint64); iln = np.ascontiguousarray([r[1] for r in id_runs], np.uint32)
+        pv = np.ascontiguousarray([r[0] for r in prio_runs], np.uint64); pln = np.ascontiguousarray([r[1] for r in prio_runs], np.uint32)
+        off = None if id_off is None else np.ascontiguousarray(id_off, np.uint32)
+        u16p = C.POINTER(C.c_uint16)
+        self._lib.hqtick_ready_add_packed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, abi.u64p, abi.u32p, abi.u32p, C.c_uint32, abi.u64p, abi.u32p, u16p]
+        self._chk(self._lib.hqtick_ready_add_packed(self._ctx, n, len(ist), ist.ctypes.data_as(abi.u64p), iln.ctypes.data_as(abi.u32p), off.ctypes.data_as(abi.u32p) if off is not None else None,
+                                                   len(pv), pv.ctypes.data_as(abi.u64p), pln.ctypes.data_as(abi.u32p), rq.ctypes.data_as(u16p)))
+
     def cluster_remove_workers(self, worker_id):
         """on_remove_worker (ABI 7): by id; later rows move up.  Returns [(task, target worker id, variant)]: Retracting tasks of the removed workers that carried a
         redirect and are Assigned to its target from now on — the host sends their ComputeTasks messages (ABI 8, hqtick_cluster_last_reassigned)"""

@@ -333,3 +333,63 @@ def dataclasses_replace_ready(snap):
     import dataclasses
 
     return dataclasses.replace(snap, _keep=[], task_id=np.zeros(0, np.uint64), task_priority=np.zeros(0, np.uint64), task_rq=np.zeros(0, np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_packed_adds_equal_plain_adds(seed):
+    """hqtick_ready_add_packed (ABI 8): the batch as runs of ids + runs of priorities + u16 request ids, expanded on the device — the resident set it leaves is the one
+    hqtick_ready_add leaves for the same tasks (checked through the ticks that follow: same records from both contexts, and against the oracle on the full snapshot)."""
+    from hyperqueue_amd.tick import HqTickError, Tick
+    from oracle.oracle import Oracle
+
+    rng = np.random.default_rng(700 + seed)
+    cfg = abi.make_config(time_limit_s=20.0)
+    snap = workloads.make("c3", n_tasks=20_000, n_workers=24, seed=seed)
+    a, b = Tick(cfg), Tick(cfg)
+    for t in (a, b):
+        t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+    ids, prio, rq = snap.task_id.copy(), snap.task_priority.copy(), snap.task_rq.copy()
+    empty = abi.Snapshot(**{f: getattr(snap, f) for f in (
+        "n_resources", "worker_id", "worker_total", "worker_free", "worker_remaining_ns", "worker_min_utilization", "worker_flags", "worker_group",
+        "n_groups", "blocked", "assigned", "prefilled", "requests")}, task_id=np.zeros(0, np.uint64), task_priority=np.zeros(0, np.uint64), task_rq=np.zeros(0, np.uint32))
+    p0, p1 = int(snap.task_priority[0]), int(snap.task_priority[0]) + (1 << 32)
+    for step in range(3):
+        # a batch of 1-4 id runs: below every resident id (job 0), between jobs, above; consecutive ids (id_off = None) on even seeds, gaps inside the runs on odd ones
+        n_runs = int(rng.integers(1, 5))
+        runs, offs, all_ids = [], [], []
+        for r in range(n_runs):
+            job = [0, 2, 3, 4][r] + 10 * step
+            ln = int(rng.integers(1, 4000))
+            start = (job << 32) | int(rng.integers(1, 1000))
+            off = np.arange(ln, dtype=np.uint32) if seed % 2 == 0 else np.cumsum(rng.integers(1, 5, ln)).astype(np.uint32)
+            runs.append((start, ln)); offs.append(off); all_ids.append(np.uint64(start) + off.astype(np.uint64))
+        new_ids = np.concatenate(all_ids); n = len(new_ids)
+        assert (np.diff(new_ids.astype(np.int64)) > 0).all()
+        cut = int(rng.integers(0, n + 1))
+        prio_runs = [(p0, cut), (p1, n - cut)] if 0 < cut < n else [(p0, n)]
+        new_prio = np.concatenate([np.full(l, v, np.uint64) for v, l in prio_runs])
+        new_rq = rng.integers(0, 8, n).astype(np.uint32)
+        a.ready_add(new_ids, new_prio, new_rq)
+        b.ready_add_packed(runs, prio_runs, new_rq.astype(np.uint16), None if seed % 2 == 0 else np.concatenate(offs))
+        ids, prio, rq = np.concatenate([ids, new_ids]), np.concatenate([prio, new_prio]), np.concatenate([rq, new_rq])
+        order = np.argsort(ids, kind="stable"); ids, prio, rq = ids[order], prio[order], rq[order]
+        assert a.ready_count() == b.ready_count() == len(ids)
+        ra, rb = a.tick(empty, resident=True), b.tick(empty, resident=True)
+        assert_same(rb, ra)
+        full = abi.Snapshot(**{f: getattr(snap, f) for f in (
+            "n_resources", "worker_id", "worker_total", "worker_free", "worker_remaining_ns", "worker_min_utilization", "worker_flags", "worker_group",
+            "n_groups", "blocked", "assigned", "prefilled", "requests")}, task_id=ids, task_priority=prio, task_rq=rq)
+        assert_same(rb, Oracle(cfg, canonical=True).tick(full))
+        for t in (a, b):
+            t.ready_consume_last()
+        gone = np.asarray(sorted(tt for recs in ra.records for (tt, _, _) in recs), np.uint64)
+        keep = ~np.isin(ids, gone)
+        ids, prio, rq = ids[keep], prio[keep], rq[keep]
+    # errors are the plain form's: a duplicate id, runs that do not add up, an unsorted batch
+    with pytest.raises(HqTickError):
+        b.ready_add_packed([(int(ids[5]), 1)], [(p0, 1)], np.zeros(1, np.uint16))
+    with pytest.raises(HqTickError):
+        b.ready_add_packed([(1 << 50, 3)], [(p0, 2)], np.zeros(3, np.uint16))
+    with pytest.raises(HqTickError):
+        b.ready_add_packed([((1 << 50) + 10, 2), (1 << 50, 2)], [(p0, 4)], np.zeros(4, np.uint16))
+    a.close(); b.close()
