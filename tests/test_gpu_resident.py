@@ -352,7 +352,7 @@ def test_packed_adds_equal_plain_adds(seed):
     empty = abi.Snapshot(**{f: getattr(snap, f) for f in (
         "n_resources", "worker_id", "worker_total", "worker_free", "worker_remaining_ns", "worker_min_utilization", "worker_flags", "worker_group",
         "n_groups", "blocked", "assigned", "prefilled", "requests")}, task_id=np.zeros(0, np.uint64), task_priority=np.zeros(0, np.uint64), task_rq=np.zeros(0, np.uint32))
-    p0, p1 = int(snap.task_priority[0]), int(snap.task_priority[0]) + (1 << 32)
+    p0 = int(snap.task_priority[0]); p1 = p0  # (two runs of the same value: a second priority LEVEL would make every tick a coupled model of all workers — seconds each)
     for step in range(3):
         # a batch of 1-4 id runs: below every resident id (job 0), between jobs, above; consecutive ids (id_off = None) on even seeds, gaps inside the runs on odd ones
         n_runs = int(rng.integers(1, 5))
