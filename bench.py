@@ -523,6 +523,11 @@ def main():
         cfg.flags |= abi.HQTICK_FLAG_COMPACT_RECORDS  # records cross PCIe as u32 low halves + runs of (job, variant, kind): include/hqtick.h
         if not args.u32_records:
             cfg.flags |= abi.HQTICK_FLAG_COMPACT_DELTA16  # ... as 16-bit differences of the low halves (ABI 6): 2 bytes per record
+    # The product keeps the answers of its last host-solved class blocks (hqtick.h: HQTICK_FLAG_NO_BLOCK_MEMO).  The headline repeats ONE tick: with the table on, its block
+    # solve would be a lookup — so the headline context switches it off (nothing cached inside the timed region); the loops below, whose ticks see a changing ready set,
+    # run the product's default and say how often the table answered.
+    loop_cfg = type(cfg).from_buffer_copy(cfg)
+    cfg.flags |= abi.HQTICK_FLAG_NO_BLOCK_MEMO
     rec_bytes = 10 if args.full_records else (4 if args.u32_records else 2)  # what one record costs on PCIe (runs and spans on top in the compact forms)
     sc = snap.to_c()
     W_all = len(snap.worker_id)
@@ -726,7 +731,7 @@ def main():
         # Steady state of the reference's own throughput benchmark shape (benchmarks/experiment-per-task-overhead.py: zero-worker, `sleep 0`):
         # everything a tick hands out has finished before the next one, and as many new tasks have become ready.  The ready set stays in HBM
         # and is updated by deltas (hqtick_ready_consume_last / hqtick_ready_add) — nothing is re-uploaded but the new tasks.
-        ts = Tick(cfg)
+        ts = Tick(loop_cfg)
         ts.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
         if not args.no_resident_cluster:
             ts.cluster_upload(sc)  # as in the headline loop: the workers are empty again before every tick, no row changes
@@ -738,7 +743,7 @@ def main():
         gone = handed_out(res)
         ts.ready_consume_last()
         next_id = int(snap.task_id[-1]) + 1
-        t_add, t_tick, t_cons, per_step = [], [], [], []
+        t_add, t_tick, t_cons, per_step, memo_hits = [], [], [], [], 0
         for _ in range(args.steady_steps + 2):
             k = len(gone)
             new_rq = rq_of[(gone & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1]  # arrivals replace exactly what left, class by class
@@ -761,6 +766,7 @@ def main():
             c = time.perf_counter(); ts.ready_consume_last(); torch.cuda.synchronize()
             d = time.perf_counter()
             gone = handed_out(res)
+            memo_hits += int(ts.kernel_stats()["n_classes_memo"])
             t_add.append(b - a); t_tick.append(c - b); t_cons.append(d - c); per_step.append(len(gone))
         per_step = int(np.median(per_step[2:]))
         t_add, t_tick, t_cons = (np.asarray(x[2:]) for x in (t_add, t_tick, t_cons))
@@ -770,14 +776,16 @@ def main():
             "steps": args.steady_steps, "ready_set_before_each_tick": int(ts.ready_count()) + per_step, "tasks_handed_out_per_step": per_step,
             "p50_step_ms": 1e3 * float(np.median(step)), "tasks_per_s": per_step / float(np.median(step)),
             "p50_add_us": 1e6 * float(np.median(t_add)), "p50_tick_us": 1e6 * float(np.median(t_tick)), "p50_consume_us": 1e6 * float(np.median(t_cons)),
+            "add_batches_appended_behind_the_resident_columns": int(ts.kernel_stats()["ready_appends"]), "of_add_batches": args.steady_steps + 2,
+            "host_class_blocks_answered_from_the_contexts_table": memo_hits,
             "delta_bytes_host_to_device_per_step": per_step * (20 if args.plain_adds else 2), "adds": "plain columns (20 B per task)" if args.plain_adds else "packed (hqtick_ready_add_packed: 2 B per task)",
         }
         ts.close()
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.hetero_steps > 0:
-        out["steady_hetero"] = steady_hetero(cfg, snap, args.hetero_steps, args.seed, min(args.cpu_ticks, 1))
+        out["steady_hetero"] = steady_hetero(loop_cfg, snap, args.hetero_steps, args.seed, min(args.cpu_ticks, 1))
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.dag_steps > 0:
-        out["dag_churn"] = dag_churn(cfg, args.dag_steps, args.seed, args.dag_classes, "random", min(args.cpu_ticks, 1))
-        out["dag_churn_layered"] = dag_churn(cfg, args.dag_steps, args.seed, args.dag_classes, "layered", min(args.cpu_ticks, 1))
+        out["dag_churn"] = dag_churn(loop_cfg, args.dag_steps, args.seed, args.dag_classes, "random", min(args.cpu_ticks, 1))
+        out["dag_churn_layered"] = dag_churn(loop_cfg, args.dag_steps, args.seed, args.dag_classes, "layered", min(args.cpu_ticks, 1))
     if world == 1 and not args.force_sharded and args.workload == "c3" and args.priority_ticks > 0:
         # the same size with three user-priority levels (SURVEY §8d's C3 mix, 80/15/5 %): priority cuts couple every worker, the model is one
         # 8 k-column x 22 k-row component and the tick is dominated by the host-side exact solve (reported, not the headline: BASELINE.json's

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 HQTICK_ABI_VERSION = 8
-HQTICK_FLAG_NO_KERNEL_TIMING, HQTICK_FLAG_COMPACT_RECORDS, HQTICK_FLAG_COMPACT_DELTA16 = 1, 2, 4
+HQTICK_FLAG_NO_KERNEL_TIMING, HQTICK_FLAG_COMPACT_RECORDS, HQTICK_FLAG_COMPACT_DELTA16, HQTICK_FLAG_NO_BLOCK_MEMO = 1, 2, 4, 8
 HQ_AMOUNT_MAX = 0xFFFF_FFFF_FFFF_FFFF
 HQ_FRACTIONS_PER_UNIT = 10_000
 HQ_MAX_TASK_PER_WORKER = 1024
@@ -186,8 +186,8 @@ class KernelStatsC(C.Structure):
         ("solve_decode_us", C.c_double),
         ("price_sweeps", C.c_uint32), ("price_rounds", C.c_uint32), ("milp_cols", C.c_uint32), ("milp_rows", C.c_uint32),
         ("price_us", C.c_double), ("price_sweep_us", C.c_double), ("milp_us", C.c_double), ("model_us", C.c_double), ("solve_pre_us", C.c_double),
-        ("n_classes_verified", C.c_uint32), ("n_classes_mismatch", C.c_uint32), ("n_classes_rejected", C.c_uint32), ("guard_pad", C.c_uint32),
-        ("exchange_calls", C.c_uint32), ("exchange_pad", C.c_uint32), ("exchange_bytes", C.c_uint64), ("exchange_us", C.c_double),
+        ("n_classes_verified", C.c_uint32), ("n_classes_mismatch", C.c_uint32), ("n_classes_rejected", C.c_uint32), ("n_classes_memo", C.c_uint32),
+        ("exchange_calls", C.c_uint32), ("ready_appends", C.c_uint32), ("exchange_bytes", C.c_uint64), ("exchange_us", C.c_double),
     ]
 
 

@@ -116,6 +116,26 @@ void group_equal_rows(WorkerSet &ws, bool all_solver) {
 // ---------------------------------------------------------------------------------------------------------------
 // create_task_batches  scheduler/batches.rs:42-181
 // ---------------------------------------------------------------------------------------------------------------
+const BlockMemo::Entry *BlockMemo::find(const hqmilp::Model &m) {
+    auto &k = scratch; k.clear();
+    auto put_bytes = [&](const void *p, size_t n) { const unsigned char *b = static_cast<const unsigned char *>(p); k.insert(k.end(), b, b + n); };
+    auto put_vec = [&](const auto &v) { const uint64_t n = v.size(); put_bytes(&n, 8); if (n) put_bytes(v.data(), n * sizeof(v[0])); };
+    put_vec(m.obj); put_vec(m.kind); put_vec(m.rtype); put_vec(m.rhs); put_vec(m.roff); put_vec(m.rcol); put_vec(m.rcoef); put_vec(m.start); put_vec(m.col_group); put_vec(m.row_implied);
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    size_t i = 0;
+    for (; i + 8 <= k.size(); i += 8) { uint64_t w; memcpy(&w, k.data() + i, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+    for (; i < k.size(); i++) { h = (h ^ k[i]) * 0x100000001B3ull; }
+    scratch_hash = h;
+    for (const Entry &e : entries) if (e.hash == h && e.key.size() == k.size() && memcmp(e.key.data(), k.data(), k.size()) == 0) return &e;
+    return nullptr;
+}
+
+void BlockMemo::put(const hqmilp::Result &r) {
+    if (entries.size() < CAP) entries.emplace_back();
+    Entry &e = entries[entries.size() < CAP ? entries.size() - 1 : (next++ % CAP)];
+    e.hash = scratch_hash; e.key = scratch; e.x = r.x; e.nodes = r.nodes; e.n_components = r.n_components;
+}
+
 std::vector<TaskBatch> create_task_batches(const Problem &pb, const std::vector<QueueLevels> &queues) {
     std::vector<uint32_t> live;  // non-empty queues, in rq order
     for (uint32_t q = 0; q < queues.size(); q++) if (!queues[q].levels.empty()) live.push_back(q);
@@ -475,9 +495,16 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             auto solve_class_on_host = [&](uint32_t c) -> int {
                 hqmilp::Model m; std::vector<ColRef> cols;
                 build_class_model(c, m, cols);
+                out.blocks_host++; out.milp_cols += m.ncols(); out.milp_rows += m.nrows();
+                if (const BlockMemo::Entry *hit = pb.memo ? pb.memo->find(m) : nullptr) {  // this very block, solved to its canonical optimum by an earlier tick
+                    out.blocks_memo++; out.milp_nodes += hit->nodes; out.milp_components += hit->n_components;
+                    for (size_t k = 0; k < cols.size(); k++) if (cols[k].batch != UINT32_MAX) X[(size_t)c * NC + voff[cols[k].batch] + cols[k].variant] = (uint32_t)std::round(hit->x[k]);
+                    solved[c] = 1;
+                    return 0;
+                }
                 hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true);
-                out.milp_nodes += sol.nodes; out.milp_cols += m.ncols(); out.milp_rows += m.nrows(); out.milp_components += sol.n_components;
-                out.blocks_host++;
+                out.milp_nodes += sol.nodes; out.milp_components += sol.n_components;
+                if (pb.memo && sol.feasible && sol.optimal && sol.canonical) pb.memo->put(sol);
                 if (!sol.feasible) return -1;
                 if (!sol.optimal) out.is_optimal = false;
                 if (!sol.canonical) { out.is_canonical = false; blocks_exact = false; }  // certificate only: the incumbent may sit up to rel_gap below the block's optimum

@@ -96,7 +96,21 @@ struct BlockSolver {
     bool begun_ok = false;
 };
 
+// The last class blocks the host solver answered with a certified canonical optimum, keyed by the block's whole model: an identical block of a later tick is
+// answered from here (hqtick.h: HQTICK_FLAG_NO_BLOCK_MEMO).  Small on purpose — a steady cluster has a handful of host-solved classes; the device solves the many.
+struct BlockMemo {
+    struct Entry { uint64_t hash = 0; std::vector<unsigned char> key; std::vector<double> x; long nodes = 0; int n_components = 0; };
+    static constexpr size_t CAP = 64;
+    std::vector<Entry> entries;
+    size_t next = 0;
+    std::vector<unsigned char> scratch;  // the key of the model being looked up (kept between find and put)
+    uint64_t scratch_hash = 0;
+    const Entry *find(const hqmilp::Model &m);
+    void put(const hqmilp::Result &r);    // under the key of the last find()
+};
+
 struct Problem {
+    BlockMemo *memo = nullptr;           // nullptr: every host block is solved
     BlockSolver *blocks = nullptr;       // nullptr: every block on the host
     hqprice::Sweeper *pricer = nullptr;  // the block sweeps of the coupled solve (csrc/price.h): k_price_sweep in the tick; nullptr: host-only search
     uint32_t block_min_classes = 1;      // fewer device-eligible classes than this: not worth a launch
@@ -178,6 +192,7 @@ struct Counts {
     int price_sweeps = 0, price_rounds = 0; double price_us = 0, milp_us = 0, model_us = 0, pre_us = 0;  // coupled path: block sweeps / flag rounds of csrc/price.cpp, time inside them, inside hqmilp::solve, building the model
     uint32_t blocks_device = 0, blocks_host = 0, block_steps_max = 0, n_classes = 0;
     uint32_t blocks_verified = 0, blocks_mismatch = 0, blocks_rejected = 0;  // device block answers re-solved by the host while the kernel ran / of those: different / answers the O(columns) checks threw out
+    uint32_t blocks_memo = 0;  // host blocks answered from Problem::memo
     double t_classify_us = 0, t_blocks_us = 0, t_decode_us = 0;  // separable path: worker classes / block solves (device wait included) / counts in Map order  // separable path: classes solved by k_block_solve / by the host solver
 };
 

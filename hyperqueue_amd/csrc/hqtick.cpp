@@ -85,6 +85,9 @@ struct hqtick_ctx {
     DevBuf d_tid, d_tprio, d_trq; uint64_t n_ready = 0; bool resident = false;  // n_ready = physical length (tombstones included)
     DevBuf d_tid2, d_tprio2, d_trq2, d_slice, d_add, d_pre8;   // alternate columns + scratch of the resident deltas (hqtick_ready_*)
     uint64_t n_live = 0; uint32_t last_n_sel = 0; bool last_consumed = true;
+    uint64_t max_id = 0; bool max_id_valid = false;  // an upper bound of every resident id (the last one after an upload / a rebuild): a batch that starts above it is appended
+    uint32_t n_appends = 0;
+    hqhost::BlockMemo block_memo;  // host class blocks of earlier ticks (host_model.h)
     uint64_t add_staged_n = 0;  // tasks hqtick_ready_add_stage made room for (0: nothing staged)
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
@@ -1174,6 +1177,7 @@ struct TickRun {
         DeviceBlocks dev_blocks(ctx);
         pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes; pb.pricer = ctx->pricer;
         pb.block_verify = ctx->block_verify; pb.tick_seq = ctx->tick_seq++;
+        pb.memo = (ctx->cfg.flags & HQTICK_FLAG_NO_BLOCK_MEMO) ? nullptr : &ctx->block_memo;
         double shard_sweep_us = -1.0;
         ctx->x_calls = 0; ctx->x_bytes = 0; ctx->x_us = 0;
         if (CtxExchange::available(ctx)) {  // the ranks of a sharded scheduler split the sweeps and the class blocks (no-ops below their thresholds)
@@ -1190,7 +1194,7 @@ struct TickRun {
         pb.blocks = nullptr; pb.pricer = nullptr;
         ctx->stats.price_sweeps = (uint32_t)cnt.price_sweeps; ctx->stats.price_rounds = (uint32_t)cnt.price_rounds; ctx->stats.price_us = cnt.price_us; ctx->stats.milp_us = cnt.milp_us; ctx->stats.model_us = cnt.model_us; ctx->stats.solve_pre_us = cnt.pre_us;
         ctx->stats.price_sweep_us = shard_sweep_us >= 0.0 ? shard_sweep_us : (ctx->pricer ? ctx->pricer->stat_sweep_us : 0.0); ctx->stats.milp_cols = (uint32_t)cnt.milp_cols; ctx->stats.milp_rows = (uint32_t)cnt.milp_rows;
-        ctx->stats.n_classes_verified = cnt.blocks_verified; ctx->stats.n_classes_mismatch = cnt.blocks_mismatch; ctx->stats.n_classes_rejected = cnt.blocks_rejected;
+        ctx->stats.n_classes_verified = cnt.blocks_verified; ctx->stats.n_classes_mismatch = cnt.blocks_mismatch; ctx->stats.n_classes_rejected = cnt.blocks_rejected; ctx->stats.n_classes_memo = cnt.blocks_memo;
         ctx->stats.exchange_calls = (uint32_t)ctx->x_calls; ctx->stats.exchange_bytes = ctx->x_bytes; ctx->stats.exchange_us = ctx->x_us;
         if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
         ctx->stats.n_classes_device = cnt.blocks_device; ctx->stats.n_classes_host = cnt.blocks_host; ctx->stats.block_steps_max = cnt.block_steps_max; ctx->stats.n_classes = cnt.n_classes;
@@ -1383,6 +1387,8 @@ int hqtick_upload_ready(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, co
         }
     }
     ctx->n_ready = n; ctx->n_live = n; ctx->resident = true; ctx->levels_valid = false; ctx->last_valid = false; ctx->last_consumed = true;
+    ctx->max_id = 0; ctx->max_id_valid = true;
+    if (sorted) { if (n) ctx->max_id = task_id[n - 1]; } else for (uint64_t i = 0; i < n; i++) ctx->max_id = std::max(ctx->max_id, task_id[i]);
     return 0;
 }
 
@@ -1396,9 +1402,27 @@ int hqtick_run_resident(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick
 // ---------------------------------------------------------------------------------------------- resident ready-set deltas (f1)
 namespace {
 // Drops tombstones and merges `n_add` new tasks (device arrays, ids ascending) into fresh columns; swaps them in.
-int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, const uint32_t *arq, uint32_t n_add) {
+bool append_enabled() { static const bool on = !(getenv("HQTICK_APPEND") && atoi(getenv("HQTICK_APPEND")) == 0); return on; }
+// `first_id` / `last_id`: the batch's smallest and largest id when the caller knows them on the host (0 / 0: it does not — the device graph's releases).
+int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t first_id = 0, uint64_t last_id = 0) {
     const uint64_t N = ctx->n_ready, new_n = ctx->n_live + n_add;
-    if (!ctx->d_tid2.ensure(new_n * 8 + 8) || !ctx->d_tprio2.ensure(new_n * 8 + 8) || !ctx->d_trq2.ensure(new_n * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set (rebuild)");
+    if (append_enabled() && N > 0 && n_add > 0 && last_id >= first_id && first_id > 0 && ctx->max_id_valid && first_id > ctx->max_id &&
+        ctx->d_tid.cap >= (N + n_add) * 8 + 8 && ctx->d_tprio.cap >= (N + n_add) * 8 + 8 && ctx->d_trq.cap >= (N + n_add) * 4 + 8) {
+        // Fresh ids behind everything resident, and room at the tail: ONE kernel instead of four (the columns are not re-written; what the ticks consumed stays as
+        // tombstones until hqtick_ready_consume_last / _compact find more tombstones than tasks).  The steady loop's add: 136 -> ~50 us.
+        if (!ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc");
+        uint32_t *flag = ctx->h_q.as<uint32_t>(); flag[0] = 0;
+        HQ_HIP(hqk::ready_append(aid, aprio, arq, n_add, ctx->max_id, ctx->d_tid.as<uint64_t>() + N, ctx->d_tprio.as<uint64_t>() + N, ctx->d_trq.as<uint32_t>() + N, ctx->h_q.dev<uint32_t>(), ctx->stream));
+        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (flag[0] & 4u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: a task id is already in the ready set");
+        if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
+        if (flag[0] & 16u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
+        ctx->n_ready = N + n_add; ctx->n_live += n_add; ctx->last_valid = false; ctx->last_consumed = true; ctx->max_id = last_id; ctx->n_appends++;
+        return 0;
+    }
+    // (a rebuild leaves room behind the columns: the next fresh batches are appended)
+    const uint64_t room = new_n + std::max<uint64_t>(new_n, 4096);
+    if (!ctx->d_tid2.ensure(room * 8 + 8) || !ctx->d_tprio2.ensure(room * 8 + 8) || !ctx->d_trq2.ensure(room * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set (rebuild)");
     if (N == 0) {  // nothing resident: the batch becomes the ready set
         if (n_add) {
             HQ_HIP(hipMemcpyAsync(ctx->d_tid2.p, aid, (size_t)n_add * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1418,7 +1442,10 @@ int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, c
         HQ_HIP(hqk::scan_waves(ctx->d_slice.as<uint32_t>(), g, 1, ctx->h_q.dev<uint32_t>() + 1, nullptr, nullptr, ctx->stream));
         HQ_HIP(hqk::ready_rebuild(ctx->d_tid.as<uint64_t>(), ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, (uint32_t)ctx->n_live, ctx->d_slice.as<uint32_t>(), aid, aprio, arq, n_add,
                                   ctx->d_tid2.as<uint64_t>(), ctx->d_tprio2.as<uint64_t>(), ctx->d_trq2.as<uint32_t>(), ctx->d_pre8.as<uint8_t>(), ctx->h_q.dev<uint32_t>(), ctx->stream));
+        uint64_t *last_back = reinterpret_cast<uint64_t *>(ctx->h_q.as<unsigned char>() + 16);  // the new last id comes back with the flags: the bound appends are decided by
+        if (new_n) HQ_HIP(hipMemcpyAsync(last_back, ctx->d_tid2.as<uint64_t>() + (new_n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
         HQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (new_n) { ctx->max_id = *last_back; ctx->max_id_valid = true; first_id = last_id = 0; }
         if (flag[1] != ctx->n_live) return fail(ctx, HQTICK_E_DEVICE, "resident ready set: live-task count out of sync");
         if (flag[0] & 4u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: a task id is already in the ready set");
         if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
@@ -1426,6 +1453,9 @@ int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, c
     }
     std::swap(ctx->d_tid, ctx->d_tid2); std::swap(ctx->d_tprio, ctx->d_tprio2); std::swap(ctx->d_trq, ctx->d_trq2);
     ctx->n_ready = new_n; ctx->n_live = new_n; ctx->last_valid = false; ctx->last_consumed = true;
+    if (N == 0 && n_add) {  // (the empty set took the batch as it is: its last id is the bound when the caller named it)
+        if (last_id >= first_id && first_id > 0) { ctx->max_id = last_id; ctx->max_id_valid = true; } else ctx->max_id_valid = false;
+    }
     return 0;
 }
 }  // namespace
@@ -1505,7 +1535,7 @@ int hqtick_ready_add_staged(hqtick_ctx *ctx, uint64_t n) {
     if (!ctx->d_add.ensure(L.bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
     unsigned char *d = ctx->d_add.as<unsigned char>();
     HQ_HIP(hipMemcpyAsync(d, h, L.o_q + n * 4, hipMemcpyHostToDevice, ctx->stream));
-    return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + L.o_p), reinterpret_cast<const uint32_t *>(d + L.o_q), (uint32_t)n);
+    return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + L.o_p), reinterpret_cast<const uint32_t *>(d + L.o_q), (uint32_t)n, task_id[0], task_id[n - 1]);
 }
 
 int hqtick_ready_add_packed(hqtick_ctx *ctx, uint64_t n, uint32_t n_id_runs, const uint64_t *id_run_start, const uint32_t *id_run_len, const uint32_t *id_off,
@@ -1535,11 +1565,30 @@ int hqtick_ready_add_packed(hqtick_ctx *ctx, uint64_t n, uint32_t n_id_runs, con
     pf[0] = 0; for (uint32_t r = 0; r < n_prio_runs; r++) pf[r + 1] = pf[r] + prio_run_len[r];
     if (id_off) memcpy(h + o_off, id_off, (size_t)n * 4);
     memcpy(h + o_rq, task_rq, (size_t)n * 2);
+    // the batch's id range, from the run tables: what decides between appending and merging
+    const uint64_t first_id = id_run_start[0] + (id_off ? id_off[0] : 0u);
+    const uint64_t last_id = id_run_start[n_id_runs - 1] + (id_off ? id_off[n - 1] : id_run_len[n_id_runs - 1] - 1u);
+    const uint64_t N = ctx->n_ready;
+    if (append_enabled() && N > 0 && ctx->max_id_valid && first_id > ctx->max_id && last_id >= first_id &&
+        ctx->d_tid.cap >= (N + n) * 8 + 8 && ctx->d_tprio.cap >= (N + n) * 8 + 8 && ctx->d_trq.cap >= (N + n) * 4 + 8) {
+        // fresh ids, room at the tail: the expansion kernel writes the batch where it belongs and validates it — the whole add is this one launch
+        if (!ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc");
+        uint32_t *flag = ctx->h_q.as<uint32_t>(); flag[0] = 0;
+        HQ_HIP(hqk::ready_unpack_adds((uint32_t)n, n_id_runs, reinterpret_cast<const uint64_t *>(hd + o_is), reinterpret_cast<const uint32_t *>(hd + o_if), id_off ? reinterpret_cast<const uint32_t *>(hd + o_off) : nullptr,
+                                      n_prio_runs, reinterpret_cast<const uint64_t *>(hd + o_pv), reinterpret_cast<const uint32_t *>(hd + o_pf), reinterpret_cast<const uint16_t *>(hd + o_rq),
+                                      ctx->d_tid.as<uint64_t>() + N, ctx->d_tprio.as<uint64_t>() + N, ctx->d_trq.as<uint32_t>() + N, ctx->max_id, ctx->h_q.dev<uint32_t>(), ctx->stream));
+        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (flag[0] & 4u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: a task id is already in the ready set");
+        if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
+        if (flag[0] & 16u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
+        ctx->n_ready = N + n; ctx->n_live += n; ctx->last_valid = false; ctx->last_consumed = true; ctx->max_id = last_id; ctx->n_appends++;
+        return 0;
+    }
     // the expansion kernel reads the packed batch in place (pinned, device-mapped): what crosses PCIe is the packed form
     HQ_HIP(hqk::ready_unpack_adds((uint32_t)n, n_id_runs, reinterpret_cast<const uint64_t *>(hd + o_is), reinterpret_cast<const uint32_t *>(hd + o_if), id_off ? reinterpret_cast<const uint32_t *>(hd + o_off) : nullptr,
                                   n_prio_runs, reinterpret_cast<const uint64_t *>(hd + o_pv), reinterpret_cast<const uint32_t *>(hd + o_pf), reinterpret_cast<const uint16_t *>(hd + o_rq),
-                                  reinterpret_cast<uint64_t *>(d), reinterpret_cast<uint64_t *>(d + L.o_p), reinterpret_cast<uint32_t *>(d + L.o_q), ctx->stream));
-    return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + L.o_p), reinterpret_cast<const uint32_t *>(d + L.o_q), (uint32_t)n);
+                                  reinterpret_cast<uint64_t *>(d), reinterpret_cast<uint64_t *>(d + L.o_p), reinterpret_cast<uint32_t *>(d + L.o_q), 0, nullptr, ctx->stream));
+    return rebuild_ready(ctx, reinterpret_cast<const uint64_t *>(d), reinterpret_cast<const uint64_t *>(d + L.o_p), reinterpret_cast<const uint32_t *>(d + L.o_q), (uint32_t)n, first_id, last_id);
 }
 
 int hqtick_ready_add(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, const uint64_t *task_priority, const uint32_t *task_rq) {
@@ -1963,6 +2012,9 @@ void hqtick_debug_set_block_guard(uint32_t verify, uint32_t tick_seq, int corrup
 void hqtick_debug_last_block_guard(uint32_t *verified, uint32_t *mismatch, uint32_t *rejected) {
     if (verified) *verified = g_last_guard[0]; if (mismatch) *mismatch = g_last_guard[1]; if (rejected) *rejected = g_last_guard[2];
 }
+thread_local hqhost::BlockMemo *g_memo = nullptr; thread_local uint32_t g_last_memo = 0;
+void hqtick_debug_set_block_memo(int on) { if (on && !g_memo) g_memo = new hqhost::BlockMemo(); if (!on) { delete g_memo; g_memo = nullptr; } }
+uint32_t hqtick_debug_last_block_memo(void) { return g_last_memo; }
 void hqtick_debug_set_price_emulation(int on, uint32_t min_cols) { g_price_emulation = on; g_price_min_cols = min_cols; }
 // the host stages as ONE RANK of a sharded scheduler: emulated sweeps / class blocks over this rank's share, completed through `fn` (tests/test_sharded.py: gloo)
 thread_local hqtick_exchange_fn g_xfn = nullptr; thread_local void *g_xuser = nullptr; thread_local uint32_t g_xrank = 0, g_xworld = 1, g_xmin_blocks = 1, g_xmin_classes = 1, g_xcalls = 0;
@@ -2006,7 +2058,7 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
     EmulatedBlocks emu(g_block_budget);
     emu.corrupt_mode = g_corrupt_mode; emu.corrupt_class = g_corrupt_class; emu.corrupt_fill = g_corrupt_fill;
     if (g_block_emulation) { pb.blocks = &emu; pb.block_min_classes = 1; }
-    pb.block_verify = g_block_verify; pb.tick_seq = g_tick_seq;
+    pb.block_verify = g_block_verify; pb.tick_seq = g_tick_seq; pb.memo = g_memo;
     hqprice::EmulatedSweeper pemu;
     if (g_price_emulation) { pemu.budget = g_block_budget; if (g_price_min_cols) pemu.min_cols = g_price_min_cols; pb.pricer = &pemu; }
     hqhost::Counts cnt;
@@ -2022,6 +2074,7 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
     } else cnt = hqhost::run_scheduling_solver(pb, batches);
     if (cnt.error) return fail(ctx, cnt.error, cnt.errmsg);
     g_last_guard[0] = cnt.blocks_verified; g_last_guard[1] = cnt.blocks_mismatch; g_last_guard[2] = cnt.blocks_rejected;
+    g_last_memo = cnt.blocks_memo;
     g_last_blocks_device = cnt.blocks_device; g_last_blocks_host = cnt.blocks_host; g_last_price_sweeps = (uint32_t)cnt.price_sweeps; g_last_price_rounds = (uint32_t)cnt.price_rounds;
     g_last_stage_us[0] = cnt.t_classify_us; g_last_stage_us[1] = cnt.t_blocks_us; g_last_stage_us[2] = cnt.t_decode_us;
     ctx->cnt_rq.clear(); ctx->cnt_variant.clear(); ctx->cnt_worker.clear(); ctx->cnt_value.clear();
@@ -2179,6 +2232,7 @@ int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on) {
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out) {
     if (!ctx || !out) return HQTICK_E_INVALID;
     *out = ctx->stats;
+    out->ready_appends = ctx->n_appends;
     return 0;
 }
 

@@ -145,7 +145,10 @@ hipError_t repack_worker_rows(const uint64_t *old_total, const uint64_t *old_fre
 hipError_t ready_mark_removed(const uint64_t *ids, uint32_t *rq, uint64_t n, const uint64_t *rm, uint32_t n_rm, uint32_t *n_done, hipStream_t s);
 // hqtick_ready_add_packed: the packed batch (pinned, device-mapped memory) -> the id / priority / rq columns of the batch in HBM
 hipError_t ready_unpack_adds(uint32_t n, uint32_t n_id_runs, const uint64_t *id_start, const uint32_t *id_first, const uint32_t *id_off, uint32_t n_prio_runs, const uint64_t *prio_value,
-                             const uint32_t *prio_first, const uint16_t *rq, uint64_t *aid, uint64_t *aprio, uint32_t *arq, hipStream_t s);
+                             const uint32_t *prio_first, const uint16_t *rq, uint64_t *aid, uint64_t *aprio, uint32_t *arq, uint64_t last_resident_id, uint32_t *err_flag, hipStream_t s);
+// a batch whose ids all sort behind the resident set: appended at the tail of the columns (no rebuild)
+hipError_t ready_append(const uint64_t *aid, const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t last_resident_id, uint64_t *nid, uint64_t *nprio, uint32_t *nrq,
+                        uint32_t *err_flag, hipStream_t s);
 hipError_t ready_live_count(const uint32_t *rq, uint64_t n, uint32_t *slice_cnt, hipStream_t s);
 hipError_t ready_rebuild(const uint64_t *oid, const uint64_t *oprio, const uint32_t *orq, uint64_t n, uint32_t n_live, const uint32_t *slice_off, const uint64_t *aid,
                    const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t *nid, uint64_t *nprio, uint32_t *nrq, uint8_t *pre8, uint32_t *err_flag, hipStream_t s);

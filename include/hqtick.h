@@ -95,6 +95,11 @@ enum { HQ_REC_PREFILL = 0, HQ_REC_ASSIGN = 1 };
  * that opens a run has its job_task_id in the run record (hqtick_rec_run16.first_lo).  2 bytes per record instead of 4: the mapping kernel's launch is
  * bound by these bytes crossing PCIe (C3: 25.6 -> ~20 us).  result.rec_task_lo / runs are NULL then; see rec_delta16 / runs16. */
 #define HQTICK_FLAG_COMPACT_DELTA16 4u
+/* hqtick_config.flags (ABI 8): do not keep class-block answers from tick to tick.  By default a context remembers the last 64 class blocks its HOST solver
+ * answered with a certified canonical optimum, keyed by the block's whole model (every coefficient, byte for byte), and answers an identical block from that
+ * table: between two ticks of a steady cluster the blocks rarely change while the code that solves them has gone cold.  The answer is the one the solver would
+ * give again; kernel_stats.n_classes_memo counts the hits.  bench.py's headline sets this flag (nothing cached inside its timed region). */
+#define HQTICK_FLAG_NO_BLOCK_MEMO 8u
 
 /* redirect_kind of a result entry (scheduler/mapping.rs:66-101):
  *   FROM_PREFILL  the task sat in a prefill set: Prefilled{old} -> Retracting{old}, retract sent to `old`, redirects.insert(task, (worker, v))
@@ -569,9 +574,12 @@ typedef struct hqtick_kernel_stats {
     /* the guard on k_block_solve's answers: classes of the launch the host solved itself while the kernel ran (HQTICK_BLOCK_VERIFY, default 2 per launch, a window that
      * moves with the tick count) / of those: answers that differed (any: the whole launch is re-solved on the host) / answers thrown out by the per-class checks
      * (fits the rows, no room left for another task) and re-solved on the host */
-    uint32_t n_classes_verified, n_classes_mismatch, n_classes_rejected, guard_pad;
+    uint32_t n_classes_verified, n_classes_mismatch, n_classes_rejected;
+    uint32_t n_classes_memo;               /* host class blocks of the last tick answered from the context's table of earlier identical blocks (HQTICK_FLAG_NO_BLOCK_MEMO: 0) */
     /* sharded placement solve (hqtick_set_exchange / hqtick_comm_init): the ranks' exchanges inside the last tick */
-    uint32_t exchange_calls, exchange_pad; /* all-gathers of host buffers (one per sharded sweep, one per pattern fetch, one per class-block launch)          */
+    uint32_t exchange_calls;               /* all-gathers of host buffers (one per sharded sweep, one per pattern fetch, one per class-block launch)          */
+    uint32_t ready_appends;                /* NOT per tick: hqtick_ready_add* batches of this context that were appended behind the resident columns (fresh ids,
+                                            * room at the tail: one kernel) instead of merged into new ones (HQTICK_APPEND=0: never)                       */
     uint64_t exchange_bytes;               /* bytes received by this rank in them                                                                              */
     double exchange_us;                    /* host wall clock inside them                                                                                      */
 } hqtick_kernel_stats;

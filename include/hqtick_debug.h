@@ -109,6 +109,10 @@ int hqwire_debug_encode_host_order(const struct hqwire_tables *tables, const str
  * exactly fills a row every column needs is feasible and maximal, yet not the optimum), 0 = off. */
 void hqtick_debug_set_block_guard(uint32_t verify, uint32_t tick_seq, int corrupt_mode, uint32_t corrupt_class, uint32_t corrupt_fill);
 void hqtick_debug_last_block_guard(uint32_t *verified, uint32_t *mismatch, uint32_t *rejected);
+/* The table of earlier class-block answers (hqtick.h: HQTICK_FLAG_NO_BLOCK_MEMO) for hqtick_debug_host_stages: on = 1 keeps one per thread from call to call,
+ * 0 drops it (the default: every block is solved).  _last_block_memo: host blocks of the last call answered from it. */
+void hqtick_debug_set_block_memo(int on);
+uint32_t hqtick_debug_last_block_memo(void);
 /* hqtick_debug_host_stages as ONE RANK of a sharded scheduler (include/hqtick.h: hqtick_set_exchange): the emulated sweeps / class blocks run over this rank's
  * share and are completed through `fn`; min_blocks / min_classes = the thresholds below which every rank solves the whole model.  fn = NULL: off. */
 void hqtick_debug_set_exchange(hqtick_exchange_fn fn, void *user, uint32_t rank, uint32_t world, uint32_t min_blocks, uint32_t min_classes);

@@ -3,6 +3,7 @@ the wavefront is emulated by a loop over its 64 lanes (libhqtick_test.so, hqtick
 the CPU suite executes the code the GPU runs.  Checked against the exact host solver (csrc/milp.cpp, canonical optimum) block by block, and
 against the canonical oracle (HiGHS) on whole ticks of the steady-state shapes.  The GPU tests of the kernel itself: tests/test_gpu_blocks.py."""
 import ctypes as C
+import dataclasses
 
 import numpy as np
 import pytest
@@ -262,3 +263,42 @@ def test_device_block_answers_are_not_taken_on_trust():
     assert sum(seen) == 1  # exactly the tick whose window held class 7
     got, n_emu, n_host, (ver, mis, rej) = _guarded(cfg, snap, verify=0xFFFFFFFF, mode=3, cls=7, fill=caught_at)
     assert mis == 1 and got.counts == clean.counts
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_block_memo_answers_are_the_solvers(seed):
+    """The table of earlier class-block answers (HQTICK_FLAG_NO_BLOCK_MEMO switches it off in a context): the second pass over a snapshot answers every host
+    block from it and returns what the first returned; a snapshot whose free amounts moved builds other blocks, misses, and gets the solver's answer — the
+    same as a run without the table."""
+    lib = _testhooks.load()
+    lib.hqtick_debug_set_block_memo.argtypes = [C.c_int]
+    lib.hqtick_debug_last_block_memo.restype = C.c_uint32
+    snap = workloads.make_steady("c3" if seed % 2 == 0 else "c4", seed=seed, n_tasks=30_000, n_workers=12 + seed)
+    cfg = abi.make_config(time_limit_s=30.0)
+    plain = HostStages(cfg).stages(snap)
+    a, b = C.c_uint32(), C.c_uint32()
+    lib.hqtick_debug_last_blocks(C.byref(a), C.byref(b))
+    n_host = b.value
+    assert n_host > 0 and lib.hqtick_debug_last_block_memo() == 0
+    lib.hqtick_debug_set_block_memo(1)
+    try:
+        first = HostStages(cfg).stages(snap)
+        n_first = lib.hqtick_debug_last_block_memo()  # (equal classes cannot occur inside one tick — a class IS its model — so the first pass finds nothing)
+        second = HostStages(cfg).stages(snap)
+        lib.hqtick_debug_last_blocks(C.byref(a), C.byref(b))
+        assert n_first == 0 and lib.hqtick_debug_last_block_memo() == b.value == n_host
+        assert first.counts == plain.counts and second.counts == plain.counts and second.batches == plain.batches
+        assert second.is_optimal == plain.is_optimal and second.is_canonical == plain.is_canonical
+        moved = dataclasses.replace(snap, _keep=[], worker_free=snap.worker_free.copy())
+        moved.worker_free[: len(moved.worker_free) // 2, 0] = np.maximum(moved.worker_free[: len(moved.worker_free) // 2, 0], 10_000) - 10_000 // 2
+        lib.hqtick_debug_set_block_memo(0)
+        want = HostStages(cfg).stages(moved)
+        lib.hqtick_debug_set_block_memo(1)
+        HostStages(cfg).stages(snap)  # (the table holds the unmoved blocks)
+        got = HostStages(cfg).stages(moved)
+        hits = lib.hqtick_debug_last_block_memo()
+        lib.hqtick_debug_last_blocks(C.byref(a), C.byref(b))
+        assert hits < b.value  # the moved workers' blocks are new
+        assert got.counts == want.counts and got.batches == want.batches
+    finally:
+        lib.hqtick_debug_set_block_memo(0)

@@ -393,3 +393,83 @@ def test_packed_adds_equal_plain_adds(seed):
     with pytest.raises(HqTickError):
         b.ready_add_packed([((1 << 50) + 10, 2), (1 << 50, 2)], [(p0, 4)], np.zeros(4, np.uint16))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fresh_batches_are_appended(seed):
+    """A batch whose ids lie behind everything resident is written at the tail of the columns by one kernel (kernel_stats.ready_appends counts them) instead of
+    being merged into fresh columns; anything else — ids between resident ones, no room left — still merges.  Whichever way a batch went, the ticks that follow
+    equal the oracle's on the full snapshot, and a refused batch leaves the set as it was."""
+    from hyperqueue_amd.tick import HqTickError, Tick
+    from oracle.oracle import Oracle
+
+    rng = np.random.default_rng(900 + seed)
+    cfg = abi.make_config(time_limit_s=20.0)
+    snap = workloads.make("c3", n_tasks=12_000, n_workers=24, seed=seed)
+    t = Tick(cfg)
+    t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+    ids, prio, rq = snap.task_id.copy(), snap.task_priority.copy(), snap.task_rq.copy()
+    empty = dataclasses_replace_ready(snap)
+    p0 = int(snap.task_priority[0])
+    next_id = int(ids[-1]) + 1
+    appended = 0
+    for step in range(8):
+        kind = ["plain", "packed", "packed_off", "between"][step % 4] if step else "plain"
+        n = int(rng.integers(1, 3000))
+        before = t.kernel_stats()["ready_appends"]
+        if kind == "between":  # ids below the resident maximum (a job numbered between the resident ones): the merge path
+            base = (1 << 32) | (50_000 + 10_000 * step)
+            new_ids = np.uint64(base) + np.arange(n, dtype=np.uint64)
+            assert not np.isin(new_ids, ids).any()
+        elif kind == "packed_off":
+            off = np.cumsum(rng.integers(1, 4, n)).astype(np.uint32)
+            new_ids = np.uint64(next_id) + off.astype(np.uint64)
+        else:
+            new_ids = np.uint64(next_id) + np.arange(n, dtype=np.uint64)
+        new_rq = rng.integers(0, 8, n).astype(np.uint32)
+        new_prio = np.full(n, p0, np.uint64)
+        if kind in ("plain", "between"):
+            t.ready_add(new_ids, new_prio, new_rq)
+        elif kind == "packed":
+            half = max(1, n // 2)
+            runs = [(next_id, half), (next_id + half, n - half)] if n - half else [(next_id, n)]
+            t.ready_add_packed(runs, [(p0, n)], new_rq.astype(np.uint16))
+        else:
+            t.ready_add_packed([(next_id, n)], [(p0, n)], new_rq.astype(np.uint16), off)
+        took_append = t.kernel_stats()["ready_appends"] - before
+        # the first batch after an upload finds no room (the upload sized the columns exactly) and merges — leaving room; fresh batches after that append
+        assert took_append == (0 if kind == "between" or step == 0 else 1), (step, kind)
+        appended += took_append
+        ids, prio, rq = np.concatenate([ids, new_ids]), np.concatenate([prio, new_prio]), np.concatenate([rq, new_rq])
+        order = np.argsort(ids, kind="stable"); ids, prio, rq = ids[order], prio[order], rq[order]
+        next_id = max(next_id, int(ids[-1]) + 1)
+        assert t.ready_count() == len(ids)
+        got = t.tick(empty, resident=True)
+        assert_same(got, Oracle(cfg, canonical=True).tick(dataclasses.replace(snap, _keep=[], task_id=ids, task_priority=prio, task_rq=rq)))
+        t.ready_consume_last()
+        gone = np.asarray(sorted(tt for recs in got.records for (tt, _, _) in recs), np.uint64)
+        keep = ~np.isin(ids, gone)
+        ids, prio, rq = ids[keep], prio[keep], rq[keep]
+        assert t.ready_count() == len(ids)
+    assert appended >= 4
+    # refused batches (each would have been appended): not ascending, a reserved request id, the resident maximum once more — the set stays as it was
+    n_before = t.ready_count()
+    bad = np.uint64(next_id) + np.asarray([0, 2, 1, 3], np.uint64)
+    with pytest.raises(HqTickError):
+        t.ready_add(bad, np.full(4, p0, np.uint64), np.zeros(4, np.uint32))
+    with pytest.raises(HqTickError):
+        t.ready_add_packed([(next_id, 3)], [(p0, 3)], np.zeros(3, np.uint16), np.asarray([0, 5, 5], np.uint32))
+    with pytest.raises(HqTickError):
+        t.ready_add_packed([(next_id + 10, 2), (next_id, 2)], [(p0, 4)], np.zeros(4, np.uint16))
+    with pytest.raises(HqTickError):
+        t.ready_add_packed([(next_id, 3)], [(p0, 3)], np.asarray([0, 0xFFFF, 0], np.uint16))
+    with pytest.raises(HqTickError):
+        t.ready_add(ids[-1:], np.full(1, p0, np.uint64), np.zeros(1, np.uint32))
+    assert t.ready_count() == n_before
+    got = t.tick(empty, resident=True)
+    assert_same(got, Oracle(cfg, canonical=True).tick(dataclasses.replace(snap, _keep=[], task_id=ids, task_priority=prio, task_rq=rq)))
+    # and a good batch right after the refused ones is appended
+    before = t.kernel_stats()["ready_appends"]
+    t.ready_add(np.uint64(next_id) + np.arange(5, dtype=np.uint64), np.full(5, p0, np.uint64), np.zeros(5, np.uint32))
+    assert t.kernel_stats()["ready_appends"] == before + 1 and t.ready_count() == n_before + 5
+    t.close()
