@@ -232,7 +232,13 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
     next_id = int(snap.task_id[-1]) + 1
     n_staged = 0
     rows, last_snap, prev_free, n_changed = [], None, None, []
-    for step in range(steps + 3):
+    # the loop's times come from steps without per-kernel timing events (as the headline's: ~6 runtime calls per tick less); three more steps with the events on give the
+    # kernels' durations
+    timing_was_on = not (cfg.flags & abi.HQTICK_FLAG_NO_KERNEL_TIMING)
+    ts.set_kernel_timing(False)
+    for step in range(steps + 3 + (3 if timing_was_on else 0)):
+        if step == steps + 3:
+            ts.set_kernel_timing(True)
         free = total - running @ need
         assert (free >= 0).all()
         assigned = [[(int(q), 0) for q in np.repeat(np.arange(Q), running[w])] for w in range(W)]
@@ -276,8 +282,8 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
                          ("n_classes", "n_classes_device", "n_classes_host", "block_solve_us", "block_steps_max", "solve_classify_us", "solve_blocks_us", "solve_decode_us", "level_hist_us", "select_us", "other_us")}))
         running -= rng.binomial(running, release)
     ts.close()
-    use = rows[3:]
-    med = lambda k: float(np.median([r[k] for r in use]))
+    use, kuse = rows[3:steps + 3], (rows[steps + 3:] or rows[3:])
+    med = lambda k: float(np.median([r[k] for r in (kuse if k in ("block_solve_us", "level_hist_us", "select_us", "other_us") else use)]))
     step_s = np.asarray([r["add"] + r["tick"] + r["consume"] for r in use])
     out = {
         "workload": f"c3 steady state: {len(snap.task_id)} ready tasks (resident, refilled), {W} workers each running a packed mix of which a random {int(release * 100)} % finishes per tick",
@@ -732,6 +738,7 @@ def main():
         # everything a tick hands out has finished before the next one, and as many new tasks have become ready.  The ready set stays in HBM
         # and is updated by deltas (hqtick_ready_consume_last / hqtick_ready_add) — nothing is re-uploaded but the new tasks.
         ts = Tick(loop_cfg)
+        ts.set_kernel_timing(False)  # as in the headline's timed region: no per-kernel timing events
         ts.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
         if not args.no_resident_cluster:
             ts.cluster_upload(sc)  # as in the headline loop: the workers are empty again before every tick, no row changes
@@ -741,9 +748,8 @@ def main():
         rq_of = snap.task_rq.copy()  # rq by (job_task_id - 1): every id here is job 1, task 1..n
         res = ts.tick_raw(sc, resident=True)
         gone = handed_out(res)
-        ts.ready_consume_last()
         next_id = int(snap.task_id[-1]) + 1
-        t_add, t_tick, t_cons, per_step, memo_hits = [], [], [], [], 0
+        t_delta, t_cons, t_tick, per_step, memo_hits = [], [], [], [], 0
         for _ in range(args.steady_steps + 2):
             k = len(gone)
             new_rq = rq_of[(gone & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1]  # arrivals replace exactly what left, class by class
@@ -756,26 +762,30 @@ def main():
                 v_id[:] = np.arange(next_id, next_id + k, dtype=np.uint64)
                 v_prio[:] = snap.task_priority[0]
                 v_rq[:] = new_rq
-            a = time.perf_counter()
+            # The step's delta: what the last tick handed out leaves the resident set (hqtick_ready_consume_last queues one kernel and returns), the arrivals join it
+            # (one kernel when they are appended; the add returns when the set is ready, i.e. it waits for both).  The GPU has been idle since the tick returned —
+            # the driver's own bookkeeping above is not part of the step, and none of the device's work hides behind it.
+            a = time.perf_counter(); ts.ready_consume_last()
+            a2 = time.perf_counter()
             if args.plain_adds:
                 ts.ready_add_staged(k)
             else:
                 ts.ready_add_packed([(next_id, k)], [(int(snap.task_priority[0]), k)], rq16)
             next_id += k
             b = time.perf_counter(); res = ts.tick_raw(sc, resident=True)
-            c = time.perf_counter(); ts.ready_consume_last(); torch.cuda.synchronize()
-            d = time.perf_counter()
+            c = time.perf_counter()
             gone = handed_out(res)
             memo_hits += int(ts.kernel_stats()["n_classes_memo"])
-            t_add.append(b - a); t_tick.append(c - b); t_cons.append(d - c); per_step.append(len(gone))
+            t_delta.append(b - a); t_cons.append(a2 - a); t_tick.append(c - b); per_step.append(len(gone))
         per_step = int(np.median(per_step[2:]))
-        t_add, t_tick, t_cons = (np.asarray(x[2:]) for x in (t_add, t_tick, t_cons))
-        step = t_add + t_tick + t_cons
+        t_delta, t_cons, t_tick = (np.asarray(x[2:]) for x in (t_delta, t_cons, t_tick))
+        step = t_delta + t_tick
         out["steady_state"] = {
-            "what": "per step: hqtick_ready_add_packed / _staged (the new tasks) + hqtick_run_resident + hqtick_ready_consume_last; workers empty again before every tick (sleep-0 tasks)",
-            "steps": args.steady_steps, "ready_set_before_each_tick": int(ts.ready_count()) + per_step, "tasks_handed_out_per_step": per_step,
+            "what": "per step: hqtick_ready_consume_last + hqtick_ready_add_packed / _staged (the new tasks; returns once the resident set is ready: one wait for both) + hqtick_run_resident; "
+                    "workers empty again before every tick (sleep-0 tasks)",
+            "steps": args.steady_steps, "ready_set_before_each_tick": int(ts.ready_count()), "tasks_handed_out_per_step": per_step,
             "p50_step_ms": 1e3 * float(np.median(step)), "tasks_per_s": per_step / float(np.median(step)),
-            "p50_add_us": 1e6 * float(np.median(t_add)), "p50_tick_us": 1e6 * float(np.median(t_tick)), "p50_consume_us": 1e6 * float(np.median(t_cons)),
+            "p50_consume_plus_add_us": 1e6 * float(np.median(t_delta)), "of_which_consume_call_us": 1e6 * float(np.median(t_cons)), "p50_tick_us": 1e6 * float(np.median(t_tick)),
             "add_batches_appended_behind_the_resident_columns": int(ts.kernel_stats()["ready_appends"]), "of_add_batches": args.steady_steps + 2,
             "host_class_blocks_answered_from_the_contexts_table": memo_hits,
             "delta_bytes_host_to_device_per_step": per_step * (20 if args.plain_adds else 2), "adds": "plain columns (20 B per task)" if args.plain_adds else "packed (hqtick_ready_add_packed: 2 B per task)",

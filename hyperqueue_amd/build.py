@@ -22,7 +22,9 @@ HOOKED = ["hqtick.cpp", "wire.hip"]          # sources that carry #ifdef HQTICK_
 TEST_ONLY = ["debug_capi.cpp", "price_emul.cpp"]               # sources of the test library only
 HEADERS = ["kernels.h", "block_core.h", "price_core.h", "price.h", "price_emul.h", "price_dev.h", "lp_tab.h", "dev_wave.h", "block_solve.h", "graph.h", "devbuf.h", "host_model.h", "milp.h", "hb_order.h", "wire_core.h",
            os.path.join("..", "..", "include", "hqwire.h"), os.path.join("..", "..", "include", "hqtick.h"), os.path.join("..", "..", "include", "hqtick_debug.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-result", "-Wno-unused-value",
+         "-msse4.1"]  # host side: floor / round / nearbyint as one instruction instead of a call into libm (every x86-64 host of an MI355X has it; no FMA, so no result changes)
+FLAGS += os.environ.get("HQTICK_EXTRA_CXXFLAGS", "").split()  # experiments (tools/exp/sprof.py --lines wants -g); a change of this variable needs --force
 # The price sweeps choose among tied block optima by floating-point comparisons: no fused multiply-add contraction in the two places that run that
 # arithmetic (the kernel and its CPU emulation), so that a GPU tick and the emulated tick of the CPU suite walk the same sequence of prices.
 # (block_core.h's explicit fma() calls are the same operation on both sides.)

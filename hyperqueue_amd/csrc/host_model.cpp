@@ -851,6 +851,13 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         return false;
     };
 
+    {   // one allocation per array of the model instead of a doubling series (an upper estimate: every worker takes every variant of every batch)
+        size_t nvar = 0; for (const TaskBatch &batch : batches) nvar += pb.rqs[batch.rq].n_variants;
+        const size_t est_cols = nw * nvar + 64, est_rows = nw * ((size_t)R + 3) + 4 * batches.size() + 64;
+        m.obj.reserve(est_cols); m.kind.reserve(est_cols); m.col_group.reserve(est_cols); col_ub.reserve(est_cols);
+        m.rtype.reserve(est_rows); m.rhs.reserve(est_rows); m.roff.reserve(est_rows + 1);
+        m.rcol.reserve(est_cols * 4); m.rcoef.reserve(est_cols * 4);
+    }
     for (size_t wi = 0; wi < nw; wi++) {  // :95
         uint32_t w = solver_workers[wi];
         if (!worker_off.empty() && worker_off[w]) continue;  // empty in every optimum (see the separable section): no columns, no rows
@@ -957,7 +964,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         return col;
     };
     static const bool trace_model = getenv("HQMILP_TRACE") != nullptr;
-    if (trace_model) fprintf(stderr, "[model] worker blocks built at %.3f ms\n", (clock_us() - t_model0) / 1e3);
+    if (trace_model) fprintf(stderr, "[model] model build entered %.3f ms after the solver; worker blocks built at %.3f ms\n", (t_model0 - t_enter) / 1e3, (clock_us() - t_model0) / 1e3);
     GapCache gaps(pb);
     // the gap depends on the worker's total resources and on what runs there: workers with the same signature share one computation per (blocker, batch)
     std::vector<uint32_t> gap_sig; std::map<std::vector<uint64_t>, uint32_t> sig_ids;
@@ -987,7 +994,11 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         if (it == sig_ids.end()) it = sig_ids.emplace(std::move(key), (uint32_t)sig_ids.size()).first;
         return gap_sig[w] = it->second;
     };
+    std::vector<uint32_t> gap_of_sig; bool sigs_done = false; uint32_t batch_no = UINT32_MAX;
+    std::vector<std::vector<uint8_t>> cap_cache; size_t n_triples = 0;
+    std::vector<uint32_t> bcols_off, bcols_end((size_t)ws.n, 0); std::vector<int> bcols; std::vector<uint64_t> bcols_ub; uint32_t bcols_batch = UINT32_MAX;
     for (const TaskBatch &batch : batches) {
+        batch_no++;
         auto cc = count_cols.find(batch.rq);
         if (cc == count_cols.end()) continue;
         const RequestView &brv = pb.rqs[batch.rq];
@@ -1010,11 +1021,25 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                         if (it != group_cols.end() && group_can_run_rq(g, brq)) no_gap.push_back(it->second);
                     }
                 } else {
+                    if (cap_cache.size() < pb.rqs.size()) cap_cache.resize(pb.rqs.size());
+                    std::vector<uint8_t> &cap_brq = cap_cache[brq];  // can the worker run the blocker at all (Worker::is_capable_to_run_rqv): once per request class, not per (batch, cut, blocker)
+                    if (cap_brq.empty()) { cap_brq.assign(ws.n, 0); for (uint32_t w : solver_workers) cap_brq[w] = pb.capable_rqv(ws, w, brq) ? 1 : 0; }
+                    if (bcols_batch != batch_no) {  // the batch's placement columns per worker and the sum of their bounds: once per batch
+                        bcols_batch = batch_no; bcols_off.assign((size_t)ws.n + 1, 0); bcols.clear(); bcols_ub.assign(ws.n, 0);
+                        for (uint32_t w : solver_workers) {
+                            bcols_off[w] = (uint32_t)bcols.size();
+                            for (uint8_t v = 0; v < brv.n_variants; v++) { const int pc = place_get(w, batch.rq, v); if (pc >= 0) { bcols.push_back(pc); bcols_ub[w] += col_ub[(size_t)pc]; } }
+                            bcols_end[w] = (uint32_t)bcols.size();
+                        }
+                    }
+                    n_triples++;
+                    if (!sigs_done) { for (uint32_t w : solver_workers) sig_of(w); sigs_done = true; }  // (every worker's signature up front: the table below is indexed by it)
+                    gap_of_sig.assign(sig_ids.size(), UINT32_MAX);
                     for (uint32_t w : solver_workers) {
-                        if (!pb.capable_rqv(ws, w, brq)) continue;
-                        uint32_t gap;
-                        {   // what the blocker leaves of this worker: once per (blocker, worker signature), then one fit per batch
-                            const uint32_t sg = sig_of(w);
+                        if (!cap_brq[w]) continue;
+                        uint32_t gap = gap_of_sig[gap_sig[w]];
+                        if (gap == UINT32_MAX) {   // what the blocker leaves of a worker with this signature, and how many tasks of the batch fit into that: once per (batch, blocker, signature)
+                            const uint32_t sg = gap_sig[w];
                             const size_t li = (size_t)brq * n_sig_cap + sg;
                             if (li >= left_state.size()) { left_state.resize(((size_t)pb.rqs.size()) * n_sig_cap, 0); left_of.resize(left_state.size()); }
                             if (left_state[li] == 0) {
@@ -1024,10 +1049,10 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                                 left_state[li] = gaps.leftover(brq, tot, na ? agg_rq.data() + a0 : nullptr, na ? agg_variant.data() + a0 : nullptr, na, na ? agg_cnt.data() + a0 : nullptr, left_of[li]) ? 1 : 2;
                             }
                             gap = left_state[li] == 1 ? gaps.fit(batch.rq, left_of[li]) : 0;
+                            gap_of_sig[sg] = gap;
                         }
-                        cols.clear();
-                        uint64_t cols_ub = 0;
-                        for (uint8_t v = 0; v < brv.n_variants; v++) { const int pc = place_get(w, batch.rq, v); if (pc >= 0) { cols.push_back(pc); cols_ub += col_ub[(size_t)pc]; } }
+                        const int *wc = bcols.data() + bcols_off[w]; const size_t nwc = bcols_end[w] - bcols_off[w];
+                        const uint64_t cols_ub = bcols_ub[w];
                         if (gap > 0) {
                             // (a row no point within the columns' own bounds can violate is not emitted: with cuts in the thousands and workers that hold
                             // a hundred tasks that is every one of the W x cuts x blockers rows of a large tick — the model's points are the same)
@@ -1036,10 +1061,10 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                             if (bounded && fl_cached == -2) fl_cached = short_flag(brq, bl.second);  // (created at its first use, as get_bvar does; the same flag for every worker of this pair)
                             const int fl = bounded ? fl_cached : -1;
                             if (cols_ub <= (uint64_t)cut.size + gap) continue;
-                            if (bounded && fl >= 0) emit_plus(hqmilp::ROW_MAX, (double)cut.size + bsize + (double)gap, cols, fl, bsize);
-                            else if (!bounded) { m.begin_row(hqmilp::ROW_MAX, (double)cut.size + (double)gap); for (int c : cols) m.term(c, 1.0); m.end_row(); }
+                            if (bounded && fl >= 0) { cols.assign(wc, wc + nwc); emit_plus(hqmilp::ROW_MAX, (double)cut.size + bsize + (double)gap, cols, fl, bsize); }
+                            else if (!bounded) { m.begin_row(hqmilp::ROW_MAX, (double)cut.size + (double)gap); for (size_t k = 0; k < nwc; k++) m.term(wc[k], 1.0); m.end_row(); }
                         } else {
-                            no_gap.insert(no_gap.end(), cols.begin(), cols.end());
+                            no_gap.insert(no_gap.end(), wc, wc + nwc);
                         }
                     }
                 }
@@ -1064,7 +1089,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     }
     m.row_implied.resize(m.nrows(), 0);
     const double t_model1 = clock_us();
-    if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu worker signatures\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), sig_ids.size());
+    if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu worker signatures, %zu (batch, cut, blocker) passes over the workers\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), sig_ids.size(), n_triples);
     hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438
     out.pre_us = t_model0 - t_enter; out.model_us = t_model1 - t_model0; out.milp_us = clock_us() - t_model1; out.price_sweeps = sol.price_sweeps; out.price_rounds = sol.price_rounds; out.price_us = sol.price_total_us;
     out.milp_nodes = sol.nodes; out.milp_cols = m.ncols(); out.milp_rows = m.nrows(); out.milp_components = sol.n_components;

@@ -1555,6 +1555,8 @@ int hqtick_ready_add_packed(hqtick_ctx *ctx, uint64_t n, uint32_t n_id_runs, con
     auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_is = 0, o_if = al(o_is + (size_t)n_id_runs * 8), o_pv = al(o_if + (size_t)(n_id_runs + 1) * 4), o_pf = al(o_pv + (size_t)n_prio_runs * 8), o_off = al(o_pf + (size_t)(n_prio_runs + 1) * 4),
                  o_rq = al(o_off + (id_off ? (size_t)n * 4 : 0)), bytes = al(o_rq + (size_t)n * 2);
+    static const bool trace_add = getenv("HQTICK_TRACE_ADD") != nullptr;  // (experiments: where the microseconds of an add go, one line per call on stderr)
+    const double ta0 = trace_add ? now_us() : 0.0;
     if (!ctx->h_addp.ensure(bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc packed delta staging");
     const AddLayout L = add_layout(n);
     if (!ctx->d_add.ensure(L.bytes)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc delta staging");
@@ -1572,12 +1574,15 @@ int hqtick_ready_add_packed(hqtick_ctx *ctx, uint64_t n, uint32_t n_id_runs, con
     if (append_enabled() && N > 0 && ctx->max_id_valid && first_id > ctx->max_id && last_id >= first_id &&
         ctx->d_tid.cap >= (N + n) * 8 + 8 && ctx->d_tprio.cap >= (N + n) * 8 + 8 && ctx->d_trq.cap >= (N + n) * 4 + 8) {
         // fresh ids, room at the tail: the expansion kernel writes the batch where it belongs and validates it — the whole add is this one launch
+        const double ta1 = trace_add ? now_us() : 0.0;
         if (!ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc");
         uint32_t *flag = ctx->h_q.as<uint32_t>(); flag[0] = 0;
         HQ_HIP(hqk::ready_unpack_adds((uint32_t)n, n_id_runs, reinterpret_cast<const uint64_t *>(hd + o_is), reinterpret_cast<const uint32_t *>(hd + o_if), id_off ? reinterpret_cast<const uint32_t *>(hd + o_off) : nullptr,
                                       n_prio_runs, reinterpret_cast<const uint64_t *>(hd + o_pv), reinterpret_cast<const uint32_t *>(hd + o_pf), reinterpret_cast<const uint16_t *>(hd + o_rq),
                                       ctx->d_tid.as<uint64_t>() + N, ctx->d_tprio.as<uint64_t>() + N, ctx->d_trq.as<uint32_t>() + N, ctx->max_id, ctx->h_q.dev<uint32_t>(), ctx->stream));
+        const double ta2 = trace_add ? now_us() : 0.0;
         HQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (trace_add) fprintf(stderr, "hqtick add (append, packed): n %llu prepare %.1f us, launch %.1f us, wait %.1f us\n", (unsigned long long)n, ta1 - ta0, ta2 - ta1, now_us() - ta2);
         if (flag[0] & 4u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: a task id is already in the ready set");
         if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
         if (flag[0] & 16u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");

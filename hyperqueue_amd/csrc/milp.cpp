@@ -18,6 +18,8 @@
 #include <cmath>
 #include <climits>
 #include <cstring>
+#include <functional>
+#include <future>
 #include <numeric>
 #include <string>
 #include <unordered_map>
@@ -1183,7 +1185,10 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
         const double GRID = 10000.0;
         std::vector<long long> ci;
         std::vector<uint8_t> reach;
-        std::vector<long long> last_ci; double last_rhs = 0.0, last_new = 0.0; bool have_last = false;  // the rows of identical workers are identical: one pass for all of them
+        // the rows of identical workers are identical — one pass for all of them — but they alternate (a worker's cpu row, its gpu row, its memory row, the next worker's
+        // cpu row ...): the last few distinct rows are kept, not only the last one
+        struct Seen { std::vector<long long> ci; double rhs, new_rhs; };
+        std::vector<Seen> seen_rows; size_t seen_next = 0; const size_t SEEN_CAP = 8;
         struct Cut { int row; long long d, rhs; };
         std::vector<Cut> cuts; std::vector<long long> cut_d;
         for (int i = 0; i < src.nrows(); i++) {
@@ -1198,7 +1203,9 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             }
             if (!ok) continue;
             double new_rhs;
-            if (have_last && ci == last_ci && src.rhs[i] == last_rhs) new_rhs = last_new;
+            const Seen *hit = nullptr;
+            for (const Seen &sr : seen_rows) if (sr.rhs == src.rhs[i] && sr.ci == ci) { hit = &sr; break; }
+            if (hit) new_rhs = hit->new_rhs;
             else {
                 long long g = 0;
                 for (long long c : ci) { long long x = c, y = g; while (y) { const long long t = x % y; x = y; y = t; } g = x; }
@@ -1211,7 +1218,8 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
                     while (units > 0 && !reach[(size_t)units]) units--;
                 }
                 new_rhs = (double)(units * g) / GRID;
-                last_ci = ci; last_rhs = src.rhs[i]; last_new = new_rhs; have_last = true;
+                if (seen_rows.size() < SEEN_CAP) seen_rows.push_back({ci, src.rhs[i], new_rhs});
+                else { seen_rows[seen_next % SEEN_CAP] = {ci, src.rhs[i], new_rhs}; seen_next++; }
             }
             if (new_rhs < src.rhs[i] - 1e-9) {
                 if (!need_snap) { snapped = mdl_in; need_snap = true; }
@@ -1265,7 +1273,8 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
     // ---- column upper bounds implied by <=/== rows with non-negative coefficients (all columns have lb 0) ----
     std::vector<double> ub(n, INF);
     for (int j = 0; j < n; j++) if (mdl.kind[j] == COL_BOOL) ub[j] = 1.0;
-    for (int pass = 0; pass < 2; pass++) {
+    bool chained = false;  // some bound was derived from other columns' bounds: those may have tightened later in the pass, so a second pass follows (else it would repeat the first)
+    for (int pass = 0; pass < 2 && (pass == 0 || chained); pass++) {
         for (int i = 0; i < m; i++) {
             if (mdl.rtype[i] == ROW_MIN) continue;
             int a = mdl.roff[i], b = mdl.roff[i + 1];
@@ -1278,6 +1287,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
                 // sum(pos) == |negc| * y  (MN group rows, solver.rs:211-218): y <= sum(ub pos)/|negc|
                 double s = 0; bool fin = true;
                 for (int k = a; k < b; k++) if (mdl.rcoef[k] > 0) { if (ub[mdl.rcol[k]] >= INF) fin = false; else s += mdl.rcoef[k] * ub[mdl.rcol[k]]; }
+                chained = true;
                 if (fin) ub[neg] = std::min(ub[neg], std::floor(s / -negc + 1e-9));
             }
         }
@@ -1288,24 +1298,37 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
     // ---- a feasible point for the whole model, before any LP: seeds every component's search and is the answer for components the
     // dense method cannot take ----
     tmark("bounds done");
+    // (large models: on a second thread, while this one finds the components and builds their rows — it reads the model and the bounds only, and the
+    // result is joined at its first use: nothing depends on which thread was faster)
     std::vector<double> hx;
-    bool have_hx = sparse_greedy(mdl, ub, hx);
-    tmark("sparse greedy done");
-    if ((int)mdl.start.size() == n) {  // caller's starting point: taken if feasible and better
-        bool ok = true; double zs = 0.0, zh = 0.0;
-        for (int j = 0; j < n && ok; j++) { double v = mdl.start[j]; if (v < -1e-9 || v > ub[j] + 1e-9 || std::fabs(v - std::round(v)) > 1e-9) ok = false; zs += mdl.obj[j] * v; }
-        for (int i = 0; i < m && ok; i++) {
-            double a = 0.0, sc = 0.0;
-            for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) { a += mdl.rcoef[k] * mdl.start[mdl.rcol[k]]; sc = std::max(sc, std::fabs(mdl.rcoef[k])); }
-            const double tol = 1e-9 * std::max(1.0, sc);
-            if (mdl.rtype[i] != ROW_MIN && a > mdl.rhs[i] + tol) ok = false;
-            if (mdl.rtype[i] != ROW_MAX && a < mdl.rhs[i] - tol) ok = false;
+    bool have_hx = false, hx_joined = false;
+    std::future<bool> hx_future;
+    static const bool async_greedy = getenv("HQMILP_ASYNC_GREEDY") && atoi(getenv("HQMILP_ASYNC_GREEDY")) != 0;  // (off by default: here the second thread finishes later than this one would have — a cold core)
+    const bool hx_async = async_greedy && n >= 2000;
+    if (hx_async) hx_future = std::async(std::launch::async, [&mdl, &ub, &hx]() { return sparse_greedy(mdl, ub, hx); });
+    auto join_hx = [&]() {
+        if (hx_joined) return;
+        hx_joined = true;
+        have_hx = hx_async ? hx_future.get() : sparse_greedy(mdl, ub, hx);
+        tmark("sparse greedy done");
+        if ((int)mdl.start.size() == n) {  // caller's starting point: taken if feasible and better
+            bool ok = true; double zs = 0.0, zh = 0.0;
+            for (int j = 0; j < n && ok; j++) { double v = mdl.start[j]; if (v < -1e-9 || v > ub[j] + 1e-9 || std::fabs(v - std::round(v)) > 1e-9) ok = false; zs += mdl.obj[j] * v; }
+            for (int i = 0; i < m && ok; i++) {
+                double a = 0.0, sc = 0.0;
+                for (int k = mdl.roff[i]; k < mdl.roff[i + 1]; k++) { a += mdl.rcoef[k] * mdl.start[mdl.rcol[k]]; sc = std::max(sc, std::fabs(mdl.rcoef[k])); }
+                const double tol = 1e-9 * std::max(1.0, sc);
+                if (mdl.rtype[i] != ROW_MIN && a > mdl.rhs[i] + tol) ok = false;
+                if (mdl.rtype[i] != ROW_MAX && a < mdl.rhs[i] - tol) ok = false;
+            }
+            if (ok) {
+                if (have_hx) for (int j = 0; j < n; j++) zh += mdl.obj[j] * hx[j];
+                if (!have_hx || zs > zh) { hx = mdl.start; have_hx = true; }
+            }
         }
-        if (ok) {
-            if (have_hx) for (int j = 0; j < n; j++) zh += mdl.obj[j] * hx[j];
-            if (!have_hx || zs > zh) { hx = mdl.start; have_hx = true; }
-        }
-    }
+    };
+    struct JoinGuard { std::function<void()> f; ~JoinGuard() { f(); } } join_guard{[&]() { if (hx_async && !hx_joined && hx_future.valid()) hx_future.wait(); }};  // (early returns below: the thread reads locals of this frame)
+    if (!hx_async) join_hx();
 
     // ---- connected components ----
     DSU dsu(n);
@@ -1392,6 +1415,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
                 continue;
             }
         }
+        join_hx();
         if (have_hx) {  // incumbent from the sparse heuristic (restricted to this component it is feasible for the component)
             cs.bx.resize(cs.n); double z = 0.0;
             for (int k = 0; k < cs.n; k++) { cs.bx[k] = hx[cols[k]]; z += cs.c[k] * cs.bx[k]; }

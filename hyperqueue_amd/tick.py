@@ -70,6 +70,7 @@ class Tick:
         if rc != 0:
             raise HqTickError(rc, "hqtick_create failed (no gfx950 device / HIP runtime?)")
         self._ctx = ctx
+        self._add_packed = None
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -190,14 +191,14 @@ class Tick:
         """hqtick_ready_add_packed (ABI 8): id_runs = [(first id, length)], prio_runs = [(priority, length)], task_rq u16 per task, id_off = None (consecutive ids inside a
         run) or u32 offsets from the run's first id — 2-6 bytes per task over PCIe instead of hqtick_ready_add's 20"""
         rq = np.ascontiguousarray(task_rq, np.uint16)
-        n = len(rq)
-        ist = np.ascontiguousarray([r[0] for r in id_runs], np.uint64); iln = np.ascontiguousarray([r[1] for r in id_runs], np.uint32)
-        pv = np.ascontiguousarray([r[0] for r in prio_runs], np.uint64); pln = np.ascontiguousarray([r[1] for r in prio_runs], np.uint32)
+        ist = np.array([r[0] for r in id_runs], np.uint64); iln = np.array([r[1] for r in id_runs], np.uint32)
+        pv = np.array([r[0] for r in prio_runs], np.uint64); pln = np.array([r[1] for r in prio_runs], np.uint32)
         off = None if id_off is None else np.ascontiguousarray(id_off, np.uint32)
-        u16p = C.POINTER(C.c_uint16)
-        self._lib.hqtick_ready_add_packed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, abi.u64p, abi.u32p, abi.u32p, C.c_uint32, abi.u64p, abi.u32p, u16p]
-        self._chk(self._lib.hqtick_ready_add_packed(self._ctx, n, len(ist), ist.ctypes.data_as(abi.u64p), iln.ctypes.data_as(abi.u32p), off.ctypes.data_as(abi.u32p) if off is not None else None,
-                                                   len(pv), pv.ctypes.data_as(abi.u64p), pln.ctypes.data_as(abi.u32p), rq.ctypes.data_as(u16p)))
+        f = self._add_packed
+        if f is None:  # (plain addresses: building five typed ctypes pointers per call costs more than the library spends preparing the launch)
+            f = self._add_packed = self._lib.hqtick_ready_add_packed
+            f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(f(self._ctx, len(rq), len(ist), ist.ctypes.data, iln.ctypes.data, off.ctypes.data if off is not None else None, len(pv), pv.ctypes.data, pln.ctypes.data, rq.ctypes.data))
 
     def cluster_remove_workers(self, worker_id):
         """on_remove_worker (ABI 7): by id; later rows move up.  Returns [(task, target worker id, variant)]: Retracting tasks of the removed workers that carried a

@@ -35,11 +35,15 @@ for i in range(n + 3):
     k = len(gone)
     new_rq = rq_of[(gone & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1]
     rq_of = np.concatenate([rq_of, new_rq])
-    v_id, v_prio, v_rq = ts.ready_add_stage(k)
-    v_id[:] = np.arange(next_id, next_id + k, dtype=np.uint64); next_id += k
-    v_prio[:] = snap.task_priority[0]
-    v_rq[:] = new_rq
-    a = time.perf_counter(); ts.ready_add_staged(k)
+    if "--packed" in sys.argv:
+        rq16 = new_rq.astype(np.uint16)
+        a = time.perf_counter(); ts.ready_add_packed([(next_id, k)], [(int(snap.task_priority[0]), k)], rq16); next_id += k
+    else:
+        v_id, v_prio, v_rq = ts.ready_add_stage(k)
+        v_id[:] = np.arange(next_id, next_id + k, dtype=np.uint64); next_id += k
+        v_prio[:] = snap.task_priority[0]
+        v_rq[:] = new_rq
+        a = time.perf_counter(); ts.ready_add_staged(k)
     b = time.perf_counter(); res = ts.tick_raw(sc, resident=True)
     c = time.perf_counter(); ts.ready_consume_last(); torch.cuda.synchronize()
     d = time.perf_counter()
