@@ -8,14 +8,14 @@
 #include <ucontext.h>
 
 #define CAP (1 << 20)
-static uint64_t g_pc[CAP];
+static uint64_t g_pc[CAP], g_ret[CAP];  // the interrupted pc, and the word on top of its stack (the return address while a leaf like memcpy / memset runs)
 static volatile uint32_t g_n;
 
 static void on_prof(int sig, siginfo_t *si, void *uc_) {
     (void)sig; (void)si;
     ucontext_t *uc = (ucontext_t *)uc_;
     uint32_t i = g_n;
-    if (i < CAP) { g_pc[i] = (uint64_t)uc->uc_mcontext.gregs[REG_RIP]; g_n = i + 1; }
+    if (i < CAP) { g_pc[i] = (uint64_t)uc->uc_mcontext.gregs[REG_RIP]; g_ret[i] = *(const uint64_t *)uc->uc_mcontext.gregs[REG_RSP]; g_n = i + 1; }
 }
 
 void sprof_start(int period_us) {
@@ -34,3 +34,4 @@ uint32_t sprof_stop(void) {
 }
 
 const uint64_t *sprof_samples(void) { return g_pc; }
+const uint64_t *sprof_returns(void) { return g_ret; }

@@ -19,7 +19,10 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 20
 lib = _testhooks.load()
 lib.hqtick_debug_set_price_emulation.argtypes = [C.c_int, C.c_uint32]
 lib.hqtick_debug_set_price_emulation(1, 0)
-snap = workloads.make_steady(name[:-7]) if name.endswith("_steady") else workloads.make(name)
+if name == "unsat":  # bench.py's config4_unsaturated: c4's cluster, fewer ready tasks than it could run — one coupled model of all 4096 workers
+    snap = workloads.make("c4", seed=8, n_workers=4096, n_tasks=56_761)
+else:
+    snap = workloads.make_steady(name[:-7]) if name.endswith("_steady") else workloads.make(name)
 import numpy as np  # noqa: E402
 from host_stages import scan_outputs  # noqa: E402
 
@@ -27,10 +30,11 @@ hs = HostStages(abi.make_config(time_limit_s=20.0))
 hs.stages(snap)
 sp = C.CDLL(os.path.join(ROOT, "tools", "exp", "bin", "libsprof.so"))
 sp.sprof_samples.restype = C.POINTER(C.c_uint64)
+sp.sprof_returns.restype = C.POINTER(C.c_uint64)
 sc = snap.to_c()
 flags, tmc, levels, hist = scan_outputs(sc)  # (the python restatement of the scan kernels' outputs: once, outside the samples)
 PERIOD = 100
-pcs = []
+pcs, rets = [], []
 for _ in range(iters):
     out = abi.ResultC()
     sp.sprof_start(PERIOD)  # only the library call is sampled
@@ -38,6 +42,7 @@ for _ in range(iters):
     k = sp.sprof_stop()
     assert rc >= 0
     pcs += [sp.sprof_samples()[i] for i in range(k)]
+    rets += [sp.sprof_returns()[i] for i in range(k)]
 n = len(pcs)
 libpath = os.path.join(ROOT, "hyperqueue_amd", "libhqtick_test.so")
 base, text_end, others = None, 0, []
@@ -76,6 +81,7 @@ for k, v in sorted(host.items(), key=lambda kv: -kv[1])[:45]:
 
 if "--lines" in sys.argv:  # needs a library built with HQTICK_EXTRA_CXXFLAGS=-g: samples by source line (the innermost frame under csrc/)
     rels = collections.Counter(pc - base for pc in pcs if base <= pc < text_end)
+    callers = collections.Counter(rt - base for pc, rt in zip(pcs, rets) if not (base <= pc < text_end) and base <= rt < text_end)  # a leaf of libc / libm called from the library
     keys = list(rels)
     res = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-symbolizer", "--obj=" + libpath, "--inlines", "--no-demangle"], input="\n".join(hex(k) for k in keys) + "\n", capture_output=True, text=True).stdout
     lines = collections.Counter()
@@ -90,4 +96,19 @@ if "--lines" in sys.argv:  # needs a library built with HQTICK_EXTRA_CXXFLAGS=-g
         lines[":".join(f.split(":")[:2])] += rels[k]
     print("\nby source line (innermost frame under csrc/):")
     for k, v in sorted(lines.items(), key=lambda kv: -kv[1])[:90]:
+        print(f"{v * PERIOD / 1e3 / iters:7.3f} ms  {k}")
+
+    keys = list(callers)
+    res = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-symbolizer", "--obj=" + libpath, "--inlines", "--no-demangle"], input="\n".join(hex(k) for k in keys) + "\n", capture_output=True, text=True).stdout
+    lines = collections.Counter()
+    for k, blockt in zip(keys, res.strip().split("\n\n")):
+        own = [ln for ln in blockt.splitlines() if ln.startswith("/") and "/csrc/" in ln]
+        if not own:
+            continue
+        f = own[0].split("/csrc/")[1]
+        if any(x in f for x in ("price_emul", "block_core", "price_core", "dev_wave")):
+            continue
+        lines[":".join(f.split(":")[:2])] += callers[k]
+    print("\nlibc / libm leaves by the line that called them (return address on top of the stack):")
+    for k, v in sorted(lines.items(), key=lambda kv: -kv[1])[:40]:
         print(f"{v * PERIOD / 1e3 / iters:7.3f} ms  {k}")
