@@ -1445,11 +1445,11 @@ int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, c
         uint64_t *last_back = reinterpret_cast<uint64_t *>(ctx->h_q.as<unsigned char>() + 16);  // the new last id comes back with the flags: the bound appends are decided by
         if (new_n) HQ_HIP(hipMemcpyAsync(last_back, ctx->d_tid2.as<uint64_t>() + (new_n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
         HQ_HIP(hipStreamSynchronize(ctx->stream));
-        if (new_n) { ctx->max_id = *last_back; ctx->max_id_valid = true; first_id = last_id = 0; }
         if (flag[1] != ctx->n_live) return fail(ctx, HQTICK_E_DEVICE, "resident ready set: live-task count out of sync");
         if (flag[0] & 4u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: a task id is already in the ready set");
         if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
         if (flag[0] & 16u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
+        if (new_n) { ctx->max_id = *last_back; ctx->max_id_valid = true; }  // (only of columns that are swapped in: a refused batch leaves the bound as it was)
     }
     std::swap(ctx->d_tid, ctx->d_tid2); std::swap(ctx->d_tprio, ctx->d_tprio2); std::swap(ctx->d_trq, ctx->d_trq2);
     ctx->n_ready = new_n; ctx->n_live = new_n; ctx->last_valid = false; ctx->last_consumed = true;

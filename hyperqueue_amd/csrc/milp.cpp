@@ -18,8 +18,6 @@
 #include <cmath>
 #include <climits>
 #include <cstring>
-#include <functional>
-#include <future>
 #include <numeric>
 #include <string>
 #include <unordered_map>
@@ -1300,18 +1298,13 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
     // ---- a feasible point for the whole model, before any LP: seeds every component's search and is the answer for components the
     // dense method cannot take ----
     tmark("bounds done");
-    // (large models: on a second thread, while this one finds the components and builds their rows — it reads the model and the bounds only, and the
-    // result is joined at its first use: nothing depends on which thread was faster)
+    // (joined at its first use below: measured on a second thread — std::async — it finished LATER than this thread would have, here and on the MI355X host)
     std::vector<double> hx;
     bool have_hx = false, hx_joined = false;
-    std::future<bool> hx_future;
-    static const bool async_greedy = getenv("HQMILP_ASYNC_GREEDY") && atoi(getenv("HQMILP_ASYNC_GREEDY")) != 0;  // (off by default: here the second thread finishes later than this one would have — a cold core)
-    const bool hx_async = async_greedy && n >= 2000;
-    if (hx_async) hx_future = std::async(std::launch::async, [&mdl, &ub, &hx]() { return sparse_greedy(mdl, ub, hx); });
     auto join_hx = [&]() {
         if (hx_joined) return;
         hx_joined = true;
-        have_hx = hx_async ? hx_future.get() : sparse_greedy(mdl, ub, hx);
+        have_hx = sparse_greedy(mdl, ub, hx);
         tmark("sparse greedy done");
         if ((int)mdl.start.size() == n) {  // caller's starting point: taken if feasible and better
             bool ok = true; double zs = 0.0, zh = 0.0;
@@ -1329,8 +1322,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             }
         }
     };
-    struct JoinGuard { std::function<void()> f; ~JoinGuard() { f(); } } join_guard{[&]() { if (hx_async && !hx_joined && hx_future.valid()) hx_future.wait(); }};  // (early returns below: the thread reads locals of this frame)
-    if (!hx_async) join_hx();
+    join_hx();
 
     // ---- connected components ----
     DSU dsu(n);
