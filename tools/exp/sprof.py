@@ -19,6 +19,9 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 20
 lib = _testhooks.load()
 lib.hqtick_debug_set_price_emulation.argtypes = [C.c_int, C.c_uint32]
 lib.hqtick_debug_set_price_emulation(1, 0)
+if "--blocks" in sys.argv:  # class blocks through the emulated k_block_solve (its own functions are filtered out like the sweeps')
+    lib.hqtick_debug_set_block_emulation.argtypes = [C.c_int, C.c_uint32]
+    lib.hqtick_debug_set_block_emulation(1, 4096)
 if name == "unsat":  # bench.py's config4_unsaturated: c4's cluster, fewer ready tasks than it could run — one coupled model of all 4096 workers
     snap = workloads.make("c4", seed=8, n_workers=4096, n_tasks=56_761)
 else:

@@ -36,3 +36,5 @@ run_trace steady_c3 python $ROOT/tools/steady_probe.py c3 20
 run_trace wire python $ROOT/tools/wire_bench.py --iters 50
 find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 ls -la "$OUT"
+# 4. the whole GPU suite on this build (what the driver runs at round end)
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > "$OUT/gpu_suite.log"; cat "$OUT/gpu_suite.log"
