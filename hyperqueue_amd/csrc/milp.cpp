@@ -18,6 +18,7 @@
 #include <cmath>
 #include <climits>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <string>
 #include <unordered_map>
@@ -44,6 +45,7 @@ struct CompSolver {
     std::vector<double> c, lb, ub;
     // the coupled solve by price sweeps (csrc/price.h): where the sweeps run, and what the model's builder said about its structure
     hqprice::Sweeper *sweeper = nullptr;
+    std::function<void()> lazy_incumbent;  // set instead of an incumbent for a component that goes to the sweeps first: called when they leave it open (solve())
     std::vector<double> row_scale;       // R's row i times row_scale[i] = the model's row
     std::vector<uint8_t> row_implied;
     std::vector<int32_t> col_group;
@@ -837,6 +839,7 @@ struct CompSolver {
                 if (!pa.x.empty() && (!have || pa.x_value > best)) { bx = pa.x; best = pa.x_value; have = true; }
                 root_bound = std::min(root_bound, pa.bound * (1.0 + 1e-9) + 1e-12);
                 if (certified()) { canonical_done = false; xout = bx; trace("certified by the price sweeps"); return 1; }
+                if (lazy_incumbent) { lazy_incumbent(); lazy_incumbent = nullptr; }
                 if (have && n > 2000) {  // what the sweeps leave open goes to the host's window search, against their bound (smaller models: the tree below)
                     trace("window search against the price bound");
                     lns_schedule(deadline - 0.05);
@@ -847,6 +850,7 @@ struct CompSolver {
                 }
             }
         }
+        if (lazy_incumbent && !in_lns) { lazy_incumbent(); lazy_incumbent = nullptr; }  // the sweeps did not take the component (or left it open): the search below wants the heuristic's point
         row_unit.assign((size_t)R.m, 0.0);
         for (int i = 0; i < R.m && !in_lns && n <= 2000; i++) {  // (not inside the windows of the large-model search: their sub-models are tuned as they are)
             const int a = R.off[i], b = R.off[i + 1];
@@ -1298,7 +1302,10 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
     // ---- a feasible point for the whole model, before any LP: seeds every component's search and is the answer for components the
     // dense method cannot take ----
     tmark("bounds done");
-    // (joined at its first use below: measured on a second thread — std::async — it finished LATER than this thread would have, here and on the MI355X host)
+    // Computed at its first use: a component that goes to the price sweeps (csrc/price.h) does not need it — the sweeps build their own incumbent, and its only
+    // other role there, naming the flag configuration to start from, "every flag on" plays as well (c3p: 10 sweeps instead of 11) — so such a component asks for
+    // it only when the sweeps leave it open (CompSolver::lazy_incumbent); at 8 k columns the pass is a tenth of the coupled tick's host time.
+    // (Tried on a second thread instead — std::async: it finished LATER than this thread would have, here and on the MI355X host.)
     std::vector<double> hx;
     bool have_hx = false, hx_joined = false;
     auto join_hx = [&]() {
@@ -1322,7 +1329,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             }
         }
     };
-    join_hx();
+    static const bool lazy_greedy = !(getenv("HQMILP_LAZY_GREEDY") && atoi(getenv("HQMILP_LAZY_GREEDY")) == 0);  // (A/B switch)
 
     // ---- connected components ----
     DSU dsu(n);
@@ -1409,12 +1416,15 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
                 continue;
             }
         }
-        join_hx();
-        if (have_hx) {  // incumbent from the sparse heuristic (restricted to this component it is feasible for the component)
-            cs.bx.resize(cs.n); double z = 0.0;
-            for (int k = 0; k < cs.n; k++) { cs.bx[k] = hx[cols[k]]; z += cs.c[k] * cs.bx[k]; }
-            cs.have = true; cs.best = z;
-        }
+        auto seed = [&]() {  // incumbent from the sparse heuristic (restricted to this component it is feasible for the component)
+            join_hx();
+            if (!have_hx) return;
+            std::vector<double> bx((size_t)cs.n); double z = 0.0;
+            for (int k = 0; k < cs.n; k++) { bx[(size_t)k] = hx[cols[k]]; z += cs.c[k] * bx[(size_t)k]; }
+            if (!cs.have || z > cs.best) { cs.bx = std::move(bx); cs.have = true; cs.best = z; }
+        };
+        const bool to_sweeps = lazy_greedy && cs.sweeper && rel_gap > 0.0 && cs.n >= (int)sweeper->min_cols && (int)mdl.start.size() != n;  // (CompSolver::run's own condition; a caller's starting point is looked at now)
+        if (to_sweeps) cs.lazy_incumbent = seed; else seed();
         tmark("component rows built");
         std::vector<double> xo;
         int st = cs.run(canonical, xo);
