@@ -1330,6 +1330,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
         }
     };
     static const bool lazy_greedy = !(getenv("HQMILP_LAZY_GREEDY") && atoi(getenv("HQMILP_LAZY_GREEDY")) == 0);  // (A/B switch)
+    const int LAZY_GREEDY_COLS = 2048;
 
     // ---- connected components ----
     DSU dsu(n);
@@ -1423,7 +1424,9 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             for (int k = 0; k < cs.n; k++) { bx[(size_t)k] = hx[cols[k]]; z += cs.c[k] * bx[(size_t)k]; }
             if (!cs.have || z > cs.best) { cs.bx = std::move(bx); cs.have = true; cs.best = z; }
         };
-        const bool to_sweeps = lazy_greedy && cs.sweeper && rel_gap > 0.0 && cs.n >= (int)sweeper->min_cols && (int)mdl.start.size() != n;  // (CompSolver::run's own condition; a caller's starting point is looked at now)
+        // (CompSolver::run's own condition, and only LARGE components: below ~2 k columns the pass costs tens of microseconds and the flag configuration it names
+        // is sometimes the better start — GPU seed 2011 of tests/test_gpu_price.py is certified from it and not from "every flag on"; a caller's starting point is looked at now)
+        const bool to_sweeps = lazy_greedy && cs.sweeper && rel_gap > 0.0 && cs.n >= (int)sweeper->min_cols && cs.n >= LAZY_GREEDY_COLS && (int)mdl.start.size() != n;
         if (to_sweeps) cs.lazy_incumbent = seed; else seed();
         tmark("component rows built");
         std::vector<double> xo;
