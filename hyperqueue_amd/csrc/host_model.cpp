@@ -975,12 +975,19 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     auto build_agg = [&]() {
         agg_off.assign((size_t)ws.n + 1, 0);
         if (pb.custom || !ws.assigned_off) return;
-        std::vector<uint32_t> keys;
+        // (counted per variant slot, not sorted: a busy worker runs a hundred tasks of a handful of kinds — sorting 1024 such lists was a millisecond of a 3 ms tick)
+        std::vector<uint32_t> keys, cnt(NVS, 0);
         for (uint32_t w = 0; w < ws.n; w++) {
             keys.clear();
-            for (uint32_t i = ws.assigned_off[w]; i < ws.assigned_off[w + 1]; i++) keys.push_back((ws.assigned_rq[i] << 8) | ws.assigned_variant[i]);
-            std::sort(keys.begin(), keys.end());
-            for (size_t i = 0; i < keys.size();) { size_t j = i; while (j < keys.size() && keys[j] == keys[i]) j++; agg_rq.push_back(keys[i] >> 8); agg_variant.push_back((uint8_t)(keys[i] & 0xFFu)); agg_cnt.push_back((uint32_t)(j - i)); i = j; }
+            for (uint32_t i = ws.assigned_off[w]; i < ws.assigned_off[w + 1]; i++) {
+                const uint32_t slot = pb.rqs[ws.assigned_rq[i]].first_variant + ws.assigned_variant[i];
+                if (cnt[slot]++ == 0) keys.push_back((ws.assigned_rq[i] << 8) | ws.assigned_variant[i]);
+            }
+            std::sort(keys.begin(), keys.end());  // the distinct kinds only, ascending (rq, variant) as before
+            for (uint32_t k : keys) {
+                const uint32_t slot = pb.rqs[k >> 8].first_variant + (k & 0xFFu);
+                agg_rq.push_back(k >> 8); agg_variant.push_back((uint8_t)(k & 0xFFu)); agg_cnt.push_back(cnt[slot]); cnt[slot] = 0;
+            }
             agg_off[w + 1] = (uint32_t)agg_rq.size();
         }
     };
