@@ -22,7 +22,11 @@ lib.hqtick_debug_set_price_emulation(1, 0)
 if "--blocks" in sys.argv:  # class blocks through the emulated k_block_solve (its own functions are filtered out like the sweeps')
     lib.hqtick_debug_set_block_emulation.argtypes = [C.c_int, C.c_uint32]
     lib.hqtick_debug_set_block_emulation(1, 4096)
-if name == "unsat":  # bench.py's config4_unsaturated: c4's cluster, fewer ready tasks than it could run — one coupled model of all 4096 workers
+if name in ("wave", "0.2", "0.45", "c3ps"):  # tools/price_probe.py's coupled snapshots (the config-5 first wave, the unsaturated 1024-worker probes)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import price_probe
+    snap = price_probe.snapshot(name)
+elif name == "unsat":  # bench.py's config4_unsaturated: c4's cluster, fewer ready tasks than it could run — one coupled model of all 4096 workers
     snap = workloads.make("c4", seed=8, n_workers=4096, n_tasks=56_761)
 else:
     snap = workloads.make_steady(name[:-7]) if name.endswith("_steady") else workloads.make(name)
