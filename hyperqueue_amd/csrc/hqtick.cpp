@@ -1412,8 +1412,10 @@ int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, c
         // tombstones until hqtick_ready_consume_last / _compact find more tombstones than tasks).  The steady loop's add: 136 -> ~50 us.
         if (!ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc");
         uint32_t *flag = ctx->h_q.as<uint32_t>(); flag[0] = 0;
-        HQ_HIP(hqk::ready_append(aid, aprio, arq, n_add, ctx->max_id, ctx->d_tid.as<uint64_t>() + N, ctx->d_tprio.as<uint64_t>() + N, ctx->d_trq.as<uint32_t>() + N, ctx->h_q.dev<uint32_t>(), ctx->stream));
-        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        bool waits_on_kernel = false;
+        hqk::time_next_launch(nullptr, ctx->ev[11]);
+        HQ_HIP_LAST(hqk::ready_append(aid, aprio, arq, n_add, ctx->max_id, ctx->d_tid.as<uint64_t>() + N, ctx->d_tprio.as<uint64_t>() + N, ctx->d_trq.as<uint32_t>() + N, ctx->h_q.dev<uint32_t>(), ctx->stream), waits_on_kernel);
+        if (waits_on_kernel) HQ_HIP(hipEventSynchronize(ctx->ev[11])); else HQ_HIP(hipStreamSynchronize(ctx->stream));  // (the dispatch's own completion signal: HQ_HIP_LAST)
         if (flag[0] & 4u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: a task id is already in the ready set");
         if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
         if (flag[0] & 16u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
@@ -1577,11 +1579,13 @@ int hqtick_ready_add_packed(hqtick_ctx *ctx, uint64_t n, uint32_t n_id_runs, con
         const double ta1 = trace_add ? now_us() : 0.0;
         if (!ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc");
         uint32_t *flag = ctx->h_q.as<uint32_t>(); flag[0] = 0;
-        HQ_HIP(hqk::ready_unpack_adds((uint32_t)n, n_id_runs, reinterpret_cast<const uint64_t *>(hd + o_is), reinterpret_cast<const uint32_t *>(hd + o_if), id_off ? reinterpret_cast<const uint32_t *>(hd + o_off) : nullptr,
+        bool waits_on_kernel = false;
+        hqk::time_next_launch(nullptr, ctx->ev[11]);
+        HQ_HIP_LAST(hqk::ready_unpack_adds((uint32_t)n, n_id_runs, reinterpret_cast<const uint64_t *>(hd + o_is), reinterpret_cast<const uint32_t *>(hd + o_if), id_off ? reinterpret_cast<const uint32_t *>(hd + o_off) : nullptr,
                                       n_prio_runs, reinterpret_cast<const uint64_t *>(hd + o_pv), reinterpret_cast<const uint32_t *>(hd + o_pf), reinterpret_cast<const uint16_t *>(hd + o_rq),
-                                      ctx->d_tid.as<uint64_t>() + N, ctx->d_tprio.as<uint64_t>() + N, ctx->d_trq.as<uint32_t>() + N, ctx->max_id, ctx->h_q.dev<uint32_t>(), ctx->stream));
+                                      ctx->d_tid.as<uint64_t>() + N, ctx->d_tprio.as<uint64_t>() + N, ctx->d_trq.as<uint32_t>() + N, ctx->max_id, ctx->h_q.dev<uint32_t>(), ctx->stream), waits_on_kernel);
         const double ta2 = trace_add ? now_us() : 0.0;
-        HQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (waits_on_kernel) HQ_HIP(hipEventSynchronize(ctx->ev[11])); else HQ_HIP(hipStreamSynchronize(ctx->stream));  // (the dispatch's own completion signal: HQ_HIP_LAST)
         if (trace_add) fprintf(stderr, "hqtick add (append, packed): n %llu prepare %.1f us, launch %.1f us, wait %.1f us\n", (unsigned long long)n, ta1 - ta0, ta2 - ta1, now_us() - ta2);
         if (flag[0] & 4u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: a task id is already in the ready set");
         if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");

@@ -1256,14 +1256,14 @@ hipError_t ready_unpack_adds(uint32_t n, uint32_t n_id_runs, const uint64_t *id_
                              const uint32_t *prio_first, const uint16_t *rq, uint64_t *aid, uint64_t *aprio, uint32_t *arq, uint64_t last_resident_id, uint32_t *err_flag, hipStream_t s) {
     if (n == 0) return hipSuccess;
     PackedAdds pa{n, n_id_runs, n_prio_runs, id_start, id_first, id_off, prio_value, prio_first, rq};
-    hipLaunchKernelGGL(k_unpack_adds, dim3((n + 255) / 256), dim3(256), 0, s, pa, aid, aprio, arq, last_resident_id, err_flag);
+    HQK_TIMED_LAUNCH(k_unpack_adds, dim3((n + 255) / 256), dim3(256), 0, s, pa, aid, aprio, arq, last_resident_id, err_flag);  // (the caller may wait on the dispatch's own completion signal: time_next_launch)
     return hipGetLastError();
 }
 
 hipError_t ready_append(const uint64_t *aid, const uint64_t *aprio, const uint32_t *arq, uint32_t n_add, uint64_t last_resident_id, uint64_t *nid, uint64_t *nprio, uint32_t *nrq,
                         uint32_t *err_flag, hipStream_t s) {
     if (n_add == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_append_adds, dim3((n_add + 255) / 256), dim3(256), 0, s, aid, aprio, arq, n_add, last_resident_id, nid, nprio, nrq, err_flag);
+    HQK_TIMED_LAUNCH(k_append_adds, dim3((n_add + 255) / 256), dim3(256), 0, s, aid, aprio, arq, n_add, last_resident_id, nid, nprio, nrq, err_flag);
     return hipGetLastError();
 }
 
