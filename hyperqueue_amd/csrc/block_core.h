@@ -30,7 +30,6 @@
 // the device kernel (block_solve.hip, Wave = one wavefront) and the host emulation the CPU tests run (lanes in a loop).
 #pragma once
 #include <cmath>
-#include <cstddef>
 #include <cstdint>
 
 #if defined(__HIPCC__)
@@ -47,9 +46,7 @@ namespace hqblock {
 constexpr int NMAX = 32;     // columns of one block
 constexpr int MMAX = 4;      // resource rows of one block
 constexpr int WAVE = 64;
-constexpr int PCAP = 192;    // dual points kept per block (a C3-shaped block has at most 80, a C4-shaped one — 16 columns — 175: measured over 68 698 blocks of the steady-state
-                             // and unsaturated ticks; what does not fit is dropped: weaker bounds, same answer).  400 until round 4: those 8.7 KB kept the block at 40.8 KB of
-                             // LDS = THREE blocks per CU, 768 on the chip — a sweep of 1024 blocks ran in two rounds; 32.0 KB is five per CU, 1280 on the chip
+constexpr int PCAP = 400;    // dual points kept per block (a C3-shaped block has ~65; what does not fit is dropped: weaker bounds, same answer)
 constexpr int DPRE = 48;     // dual points a level of the walk looks at (C3-shaped: <= 43)
 constexpr int GCOLS = 64;    // (batch, variant) columns of a tick the eligibility mask can address
 constexpr int32_t UB_LIMIT = 65535;  // a column that could be taken more often than this goes to the host solver
@@ -187,8 +184,7 @@ template <class W>
 HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTable &cl, uint32_t cls) {
     const uint32_t R = ct_in.R, NC = ct_in.n_cols;
     uint8_t *area = reinterpret_cast<uint8_t *>(&S.py[0][0]);
-    // (the pool, and behind it the work problem's arrays up to `wcap`: nothing in there is written before dual_candidate / setup_work, which run after the block is built)
-    static_assert(offsetof(Shared, wcap) - offsetof(Shared, py) >= BLOB_MAX + 64 * 8 * 2, "the staging area overlays the dual pool and the work problem behind it");
+    static_assert(sizeof(double) * PCAP * MMAX >= BLOB_MAX + 64 * 8 * 2, "the staging area overlays the dual pool");
     uint64_t *sfree = reinterpret_cast<uint64_t *>(area + BLOB_MAX), *stotal = sfree + 64;
     // integer amounts while the rows are brought onto their own grid (gcd); overlays the greedy vectors, which are not in use yet
     static_assert(sizeof(uint16_t) * NMAX * WAVE >= sizeof(int64_t) * (MMAX * NMAX + MMAX), "a64 overlays gx");
