@@ -294,7 +294,7 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
         "all_ticks_optimal_and_canonical": bool(all(r["optimal"] and r["canonical"] for r in use)),
         "block_solve_kernel": {"avg_us": med("block_solve_us"), "classes_per_launch": int(med("n_classes_device")), "classes_per_s": med("n_classes_device") / (med("block_solve_us") * 1e-6) if med("block_solve_us") > 0 else None,
                                "max_search_steps": int(max(r["block_steps_max"] for r in use)),
-                               "bound": "latency / integer-f64 ALU in LDS: one wavefront per class, 40.8 KB of LDS per block; a 32 KB variant (room for five blocks per CU instead of three, round 4) changed no duration and hardly the resident waves (DESIGN.md §12); not an HBM-bound kernel (a class reads ~60 B)"},
+                               "bound": "latency / integer-f64 ALU in LDS: one wavefront per class, 25.9 KB of LDS per block = six blocks resident per CU (measured: tools/exp/resident_wg.hip; 40.8 KB and four per CU until round 4); not an HBM-bound kernel (a class reads ~60 B)"},
         "tick_stages_us": {"gpu_phase_a_scans": med("t_scan"), "batches": med("t_batches"), "placement": med("t_solve"), "placement_worker_classes": med("solve_classify_us"),
                            "placement_block_solves_incl_launch_and_wait": med("solve_blocks_us"), "placement_counts_in_map_order": med("solve_decode_us"), "mapping_plan_gpu_phase_c": med("t_map")},
     }
@@ -819,7 +819,7 @@ def main():
                                                    "sweeps_ms": info[2]["price_sweep_us"] / 1e3, "sweeps": int(info[2]["price_sweeps"]), "flag_configurations": int(info[2]["price_rounds"])},
                                  "price_sweep_kernel": {"kernel": "k_price_sweep", "blocks_per_sweep": 1024, "avg_sweep_us": (info[2]["price_sweep_us"] / info[2]["price_sweeps"]) if info[2]["price_sweeps"] else None,
                                                         "block_solves_per_s": (1024 * info[2]["price_sweeps"] / (info[2]["price_sweep_us"] * 1e-6)) if info[2]["price_sweep_us"] > 0 else None,
-                                                        "bound": "latency / integer-f64 ALU in LDS: one wavefront per worker block (exact bounded knapsack under the current prices), ~41 KB of LDS (a 32 KB variant with room for five blocks per CU instead of three left the sweep where it was, DESIGN.md §12); "
+                                                        "bound": "latency / integer-f64 ALU in LDS: one wavefront per worker block (exact bounded knapsack under the current prices), 25.9 KB of LDS = six blocks resident per CU (1536 on the chip: a sweep of up to that many blocks is one round); "
                                                                  "not an HBM kernel (a block reads 0.5-2 KB), not MFMA work; figure of merit: exact block solves per second (launch -> totals in pinned memory)"},
                                  "is_optimal_means": "certified within HiGHS's default mip_rel_gap = 1e-4, which is all the reference's solve_bounded asks for (solver/highs.rs:65-68)"}
         if args.cpu_ticks > 0:

@@ -30,6 +30,7 @@
 // the device kernel (block_solve.hip, Wave = one wavefront) and the host emulation the CPU tests run (lanes in a loop).
 #pragma once
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 
 #if defined(__HIPCC__)
@@ -46,7 +47,9 @@ namespace hqblock {
 constexpr int NMAX = 32;     // columns of one block
 constexpr int MMAX = 4;      // resource rows of one block
 constexpr int WAVE = 64;
-constexpr int PCAP = 400;    // dual points kept per block (a C3-shaped block has ~65; what does not fit is dropped: weaker bounds, same answer)
+constexpr int PCAP = 192;    // dual points kept per block (a C3-shaped block has at most 80, a C4-shaped one — 16 columns — 175: measured over 68 698 blocks of the steady-state
+                             // and unsaturated ticks; what does not fit is dropped: weaker bounds, same answer).  400 until round 4: with the
+                             // level lists and the greedy's vectors sharing their storage the block is 25.9 KB of LDS instead of 40.8: six resident per CU instead of four
 constexpr int DPRE = 48;     // dual points a level of the walk looks at (C3-shaped: <= 43)
 constexpr int GCOLS = 64;    // (batch, variant) columns of a tick the eligibility mask can address
 constexpr int32_t UB_LIMIT = 65535;  // a column that could be taken more often than this goes to the host solver
@@ -102,8 +105,18 @@ struct Shared {  // one block's working set: LDS on the device
     double wc[NMAX];
     double wa[MMAX][NMAX], winv[MMAX][NMAX];
     uint32_t wmask[NMAX + 1];       // block columns at positions < k
-    uint16_t dl[NMAX + 1][DPRE];    // per level: pool entries that are vertices of that level's dual polyhedron
-    float dpen[NMAX + 1][DPRE];     // ... and the penalty of a capped column (phase 2), rounded up
+    // The level lists of the walk and the greedy's vectors share their storage: the greedy runs (and its best lane is copied into xbest) before setup_work
+    // builds the first list.  (6 KB of the block's LDS: with it the block is 25.9 KB — six blocks per CU instead of four, tools/exp/resident_wg.hip.)
+    union {
+        struct {
+            uint16_t dl[NMAX + 1][DPRE];    // per level: pool entries that are vertices of that level's dual polyhedron
+            float dpen[NMAX + 1][DPRE];     // ... and the penalty of a capped column (phase 2), rounded up
+        };
+        struct {
+            uint8_t perm[NMAX][WAVE];       // greedy: [column slot][lane] — lanes side by side, so that a wavefront's accesses spread over the LDS banks
+            uint16_t gx[NMAX][WAVE];
+        };
+    };
     int32_t wcap[NMAX];             // upper cap of a position (INT32_MAX = none)
     int32_t colcap[NMAX];           // upper cap of a block column (INT32_MAX = none): the priced blocks of the coupled solve (price_core.h) carry their model bounds here
     uint32_t dcnt[NMAX + 1];
@@ -116,8 +129,6 @@ struct Shared {  // one block's working set: LDS on the device
     uint32_t xbest[NMAX];
     double best;
     // greedy
-    uint8_t perm[NMAX][WAVE];       // [column slot][lane]: lanes side by side, so that a wavefront's accesses spread over the LDS banks
-    uint16_t gx[NMAX][WAVE];
     double lane_val[WAVE];
     uint32_t lane_rng[WAVE];        // setup_work: level ranges of the pool entry a lane is looking at
     uint64_t lmask[NMAX + 1];       // setup_work: per level, which of the 64 entries of the current pass enter its list
@@ -184,7 +195,8 @@ template <class W>
 HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTable &cl, uint32_t cls) {
     const uint32_t R = ct_in.R, NC = ct_in.n_cols;
     uint8_t *area = reinterpret_cast<uint8_t *>(&S.py[0][0]);
-    static_assert(sizeof(double) * PCAP * MMAX >= BLOB_MAX + 64 * 8 * 2, "the staging area overlays the dual pool");
+    // (the pool, and behind it the work problem's arrays up to `wcap`: nothing in there is written before dual_candidate / setup_work, which run after the block is built)
+    static_assert(offsetof(Shared, dl) - offsetof(Shared, py) >= BLOB_MAX + 64 * 8 * 2, "the staging area overlays the dual pool and the work problem behind it, up to the level lists (whose storage holds a64 meanwhile)");
     uint64_t *sfree = reinterpret_cast<uint64_t *>(area + BLOB_MAX), *stotal = sfree + 64;
     // integer amounts while the rows are brought onto their own grid (gcd); overlays the greedy vectors, which are not in use yet
     static_assert(sizeof(uint16_t) * NMAX * WAVE >= sizeof(int64_t) * (MMAX * NMAX + MMAX), "a64 overlays gx");

@@ -2,7 +2,7 @@
 // /root/reference/crates/tako/src/internal/scheduler/solver.rs:95-192, then the solve of solver/highs.rs:65-88) — one wavefront per class.
 //
 // Launch shape: grid = number of worker classes (about one per worker on a steady-state cluster: 1024-4096), block = 64 threads = ONE wave64,
-// 39 KB of LDS per block (dual vertices, level stack, the 64 greedy vectors) -> 4 blocks per CU, 1024 blocks resident on the 256 CUs, spread
+// 25.9 KB of LDS per block (dual vertices, level stack; the 64 greedy vectors share the level lists' storage) -> 6 blocks per CU, 1536 resident on the 256 CUs, spread
 // round-robin over the 8 XCDs by the dispatcher; blocks share nothing but the read-only column table (a few hundred bytes, L2-resident), so no
 // XCD-aware mapping is needed.  Integer / f64 scalar work on data that lives in LDS: not an HBM-bound kernel, not MFMA work either — its
 // figure of merit is classes solved per second.  The algorithm is in block_core.h (shared with the CPU emulation the tests run).

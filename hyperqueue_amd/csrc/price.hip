@@ -2,8 +2,8 @@
 // model's wide rows (run_scheduling_solver's model, /root/reference/crates/tako/src/internal/scheduler/solver.rs:95-430, which the reference hands to
 // HiGHS, solver/highs.rs:65-88; the method is in price.h, the per-block algorithm in price_core.h / block_core.h).
 //
-// Launch shape: grid = number of blocks (one per worker: 1024-4096), block = 64 threads = ONE wave64, ~41 KB of LDS per block (dual vertices, level
-// stack, the 64 greedy vectors) -> 4 blocks per CU, 1024 resident on the 256 CUs, dealt round-robin over the 8 XCDs by the dispatcher; the blocks
+// Launch shape: grid = number of blocks (one per worker: 1024-4096), block = 64 threads = ONE wave64, 25.9 KB of LDS per block (dual vertices, level
+// stack; the 64 greedy vectors share the level lists' storage) -> 6 blocks per CU (measured: tools/exp/resident_wg.hip), 1536 resident on the 256 CUs, dealt round-robin over the 8 XCDs by the dispatcher; the blocks
 // share nothing but the prices (<= 1 KB, in the kernel arguments) — no XCD-aware mapping is needed.  Integer / f64 scalar work on LDS-resident data:
 // not an HBM kernel (a block reads ~0.5-2 KB of tables) and not MFMA work; its figure of merit is block solves per second.
 //
