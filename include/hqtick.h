@@ -332,10 +332,12 @@ int hqtick_run_resident(hqtick_ctx *ctx, const hqtick_snapshot *snapshot, hqtick
  *   hqtick_ready_add           new ready tasks, ids strictly ascending — TaskQueues::add_ready_task scheduler/taskqueue.rs:37-43
  *   hqtick_ready_add_stage /   the same without a copy on the host (ABI 6): _stage hands out the three columns of the library's pinned staging buffer for
  *   hqtick_ready_add_staged    n tasks (valid until the next ready_add* call), the reactor writes the new tasks there, _staged(n' <= n) merges the first n'
- *   hqtick_ready_compact       drop the tombstones now (done automatically when they outnumber the live tasks, and by every add)
+ *   hqtick_ready_compact       drop the tombstones now (done automatically when they outnumber the live tasks, and by every add that merges)
  *   hqtick_ready_count         live tasks in the set
- * Removal writes a tombstone into the rq column (4 B per task); add / compact stream the columns once (20 B read + 20 B written per
- * live task) through a merge kernel.  Request id 0xFFFFFFFF is reserved for the tombstone.
+ * Removal writes a tombstone into the rq column (4 B per task).  An add whose first id lies behind every resident id (freshly minted ids: the usual batch) and
+ * that finds room behind the columns is APPENDED there by one kernel, which also validates it (ABI 8; hqtick_kernel_stats.ready_appends counts); any other add, and
+ * compact, stream the columns once (20 B read + 20 B written per live task) through a merge kernel and leave room for as many tasks again.  A refused batch
+ * (ids not ascending, an id already resident, a reserved request id) leaves the set as it was.  Request id 0xFFFFFFFF is reserved for the tombstone.
  */
 int hqtick_ready_consume_last(hqtick_ctx *ctx);
 int hqtick_ready_remove(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id);
