@@ -55,7 +55,10 @@ def build(force: bool = False) -> str:
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src):
         return _LIB_PATH
     os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", _LIB_PATH, src[0]])
+    # built beside its place and moved there: several test processes may find the library stale at once (pytest -n, the CPU campaigns), and none may load a half-written file
+    tmp = f"{_LIB_PATH}.{os.getpid()}.tmp"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", tmp, src[0]])
+    os.replace(tmp, _LIB_PATH)
     return _LIB_PATH
 
 
