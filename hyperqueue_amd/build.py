@@ -75,10 +75,12 @@ def _compile(src: str, hooks: bool, force: bool, verbose: bool) -> str:
 def _link(lib: str, objs, verbose: bool) -> str:
     if os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(o) for o in list(objs) + [EXPORTS]):
         return lib
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORTS, "-o", lib] + list(objs) + ["-ldl"]
+    tmp = f"{lib}.{os.getpid()}.tmp"  # linked beside its place and moved there: a process that has the old library mapped keeps it, one that loads meanwhile never sees half a file
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORTS, "-o", tmp] + list(objs) + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, lib)
     return lib
 
 
