@@ -476,6 +476,7 @@ def main():
     ap.add_argument("--no-multi-extras", dest="multi_extras", action="store_false", help="N > 1: skip the blocks after the timed region (configs[3]'s coupled tick with the solve split over the ranks vs replicated; c4 strong scaling)")
     ap.add_argument("--extras-timeout", type=float, default=240.0, help="N > 1: seconds the extra blocks may take before the line is printed without them")
     ap.add_argument("--plain-adds", action="store_true", help="steady-state loop: new tasks as three full columns (hqtick_ready_add_staged, 20 B per task) instead of the packed form")
+    ap.add_argument("--two-call-consume", action="store_true", help="the loops: hqtick_run_resident + hqtick_ready_consume_last as two calls (up to round 4) instead of HQTICK_FLAG_CONSUME_IN_TICK")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
     ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
     args = ap.parse_args()
@@ -533,6 +534,8 @@ def main():
     # solve would be a lookup — so the headline context switches it off (nothing cached inside the timed region); the loops below, whose ticks see a changing ready set,
     # run the product's default and say how often the table answered.
     loop_cfg = type(cfg).from_buffer_copy(cfg)
+    if not args.two_call_consume:
+        loop_cfg.flags |= abi.HQTICK_FLAG_CONSUME_IN_TICK  # the loops' ticks take what they hand out themselves, as take_tasks does inside the reference's tick (hqtick_ready_consume_last: a no-op)
     cfg.flags |= abi.HQTICK_FLAG_NO_BLOCK_MEMO
     rec_bytes = 10 if args.full_records else (4 if args.u32_records else 2)  # what one record costs on PCIe (runs and spans on top in the compact forms)
     sc = snap.to_c()
@@ -781,8 +784,9 @@ def main():
         t_delta, t_cons, t_tick = (np.asarray(x[2:]) for x in (t_delta, t_cons, t_tick))
         step = t_delta + t_tick
         out["steady_state"] = {
-            "what": "per step: hqtick_ready_consume_last + hqtick_ready_add_packed / _staged (the new tasks; returns once the resident set is ready: one wait for both) + hqtick_run_resident; "
-                    "workers empty again before every tick (sleep-0 tasks)",
+            "what": "per step: hqtick_ready_consume_last (a no-op under HQTICK_FLAG_CONSUME_IN_TICK, the loops' default: the tick's selection kernel takes what it hands out; --two-call-consume: "
+                    "its own kernel) + hqtick_ready_add_packed / _staged (the new tasks; returns once the resident set is ready) + hqtick_run_resident; workers empty again before every tick (sleep-0 tasks)",
+            "consume": "two calls (hqtick_ready_consume_last runs the selection once more in mark mode)" if args.two_call_consume else "inside the tick (HQTICK_FLAG_CONSUME_IN_TICK)",
             "steps": args.steady_steps, "ready_set_before_each_tick": int(ts.ready_count()), "tasks_handed_out_per_step": per_step,
             "p50_step_ms": 1e3 * float(np.median(step)), "tasks_per_s": per_step / float(np.median(step)),
             "p50_consume_plus_add_us": 1e6 * float(np.median(t_delta)), "of_which_consume_call_us": 1e6 * float(np.median(t_cons)), "p50_tick_us": 1e6 * float(np.median(t_tick)),

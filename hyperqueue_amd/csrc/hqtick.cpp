@@ -87,6 +87,7 @@ struct hqtick_ctx {
     uint64_t n_live = 0; uint32_t last_n_sel = 0; bool last_consumed = true;
     uint64_t max_id = 0; bool max_id_valid = false;  // an upper bound of every resident id (the last one after an upload / a rebuild): a batch that starts above it is appended
     uint32_t n_appends = 0;
+    bool consumed_unconfirmed = false;  // HQTICK_FLAG_CONSUME_IN_TICK: the running tick has written its tombstones; cleared when it returns without an error
     hqhost::BlockMemo block_memo;  // host class blocks of earlier ticks (host_model.h)
     uint64_t add_staged_n = 0;  // tasks hqtick_ready_add_stage made room for (0: nothing staged)
     // scans
@@ -1058,10 +1059,13 @@ struct TickRun {
             uint32_t *flags = reinterpret_cast<uint32_t *>(ctx->h_rec.as<uint8_t>() + o_fl);
             flags[0] = 0;  // K5b reports a capacity overflow straight into this pinned word
             ctx->last_n_sel = n_sel; ctx->last_consumed = false;
+            const bool consume_in_tick = use_resident && (ctx->cfg.flags & HQTICK_FLAG_CONSUME_IN_TICK) != 0;  // K4 writes the tombstones of what it selects
             ctx->last_geom = sc.geom; ctx->last_L = L; ctx->last_Q = Q; ctx->last_G = sc.G; ctx->last_tb = o_tb; ctx->last_plan_bytes = plan_words * 4; ctx->last_valid = true;
             if (ctx->timing) hqk::time_next_launch(ctx->ev[4], ctx->ev[5]);
             HQ_HIP_TIMED(hqk::select_scatter(ctx->d_tid.as<uint64_t>(), ctx->d_gkey.as<uint16_t>(), N, Q, sc.G, sc.geom, ctx->d_wave_tab.as<uint32_t>(), ctx->h_plan.as<uint32_t>() + o_tb,
-                                d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, plan_words * 4, nullptr, ctx->stream));
+                                d + o_tb, ctx->d_sel_task.as<uint64_t>(), ctx->d_sel_level.as<uint16_t>(), ctx->h_plan.dev<void>(), ctx->d_map.p, plan_words * 4,
+                                consume_in_tick ? ctx->d_trq.as<uint32_t>() : nullptr, ctx->stream, consume_in_tick ? 1u : 0u));
+            if (consume_in_tick) { ctx->n_live -= n_sel; ctx->last_consumed = true; ctx->consumed_unconfirmed = true; }  // (confirmed when the tick returns without an error: run_tick)
             if (!sweep_launched && n_tr < nkeys) {
                 if (ctx->timing) hqk::time_next_launch(ctx->ev[1], ctx->ev[6]);
                 HQ_HIP_TIMED(hqk::sweep_bits(mk, max_count, max_nk, ctx->stream));
@@ -1267,6 +1271,14 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
         TickRun run(ctx, s, out, use_resident);
         rc = run.run();
     }
+    if (ctx->consumed_unconfirmed) {  // HQTICK_FLAG_CONSUME_IN_TICK: the selection has written its tombstones
+        ctx->consumed_unconfirmed = false;
+        if (rc < 0) {  // ... and the tick did not come back: what it took cannot be put back — the set is dropped, the host uploads it again
+            (void)hipStreamSynchronize(ctx->stream);
+            ctx->resident = false; ctx->last_valid = false;
+            ctx->err += " (HQTICK_FLAG_CONSUME_IN_TICK: the tick had already taken its tasks; the resident ready set is dropped, upload it again)";
+        }
+    }
     if (rc >= 0 && retr_resident) {  // what create_task_mapping did to task states and redirects (mapping.rs:66-101), applied to the table
         const uint32_t W = s->n_workers;
         for (uint32_t w = 0; w < W && w + 1 < ctx->retract_off.size(); w++)   // Prefilled{old} -> Retracting{old}: out of a prefill set, not in a queue
@@ -1420,6 +1432,7 @@ int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, c
         if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
         if (flag[0] & 16u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
         ctx->n_ready = N + n_add; ctx->n_live += n_add; ctx->last_valid = false; ctx->last_consumed = true; ctx->max_id = last_id; ctx->n_appends++;
+        if (ctx->n_ready > 4096 && ctx->n_live * 2 < ctx->n_ready) return rebuild_ready(ctx, nullptr, nullptr, nullptr, 0);  // (see hqtick_ready_add_packed)
         return 0;
     }
     // (a rebuild leaves room behind the columns: the next fresh batches are appended)
@@ -1469,7 +1482,10 @@ uint64_t hqtick_ready_count(const hqtick_ctx *ctx) { return ctx && ctx->resident
 int hqtick_ready_consume_last(hqtick_ctx *ctx) {
     if (!ctx) return HQTICK_E_INVALID;
     if (!ctx->resident) return fail(ctx, HQTICK_E_INVALID, "no resident ready set");
-    if (ctx->last_consumed) return 0;  // nothing handed out since the last consume
+    if (ctx->last_consumed) {  // nothing handed out since the last consume (or the tick consumed it itself: HQTICK_FLAG_CONSUME_IN_TICK)
+        if (ctx->n_ready > 4096 && ctx->n_live * 2 < ctx->n_ready) { HQ_HIP(hipSetDevice(ctx->device)); return rebuild_ready(ctx, nullptr, nullptr, nullptr, 0); }
+        return 0;
+    }
     if (!ctx->last_valid) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_consume_last needs a preceding hqtick_run_resident");
     HQ_HIP(hipSetDevice(ctx->device));
     const uint32_t *d = ctx->d_map.as<uint32_t>();
@@ -1591,6 +1607,7 @@ int hqtick_ready_add_packed(hqtick_ctx *ctx, uint64_t n, uint32_t n_id_runs, con
         if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
         if (flag[0] & 16u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
         ctx->n_ready = N + n; ctx->n_live += n; ctx->last_valid = false; ctx->last_consumed = true; ctx->max_id = last_id; ctx->n_appends++;
+        if (ctx->n_ready > 4096 && ctx->n_live * 2 < ctx->n_ready) return rebuild_ready(ctx, nullptr, nullptr, nullptr, 0);  // (a host that never calls consume_last — HQTICK_FLAG_CONSUME_IN_TICK — compacts here)
         return 0;
     }
     // the expansion kernel reads the packed batch in place (pinned, device-mapped): what crosses PCIe is the packed form

@@ -75,7 +75,7 @@ struct WorkerEvalArgs {
 // plan (plan_bytes from plan_src, pinned, to plan_dst, HBM) with ride-along workgroups when G <= 64, else with its own launch.
 hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_t n, uint32_t Q, uint32_t G, WaveGeom geom,
                     const uint32_t *wave_off, const uint32_t *take_host, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_key,
-                    const void *plan_src, void *plan_dst, size_t plan_bytes, uint32_t *mark_rq, hipStream_t s);
+                    const void *plan_src, void *plan_dst, size_t plan_bytes, uint32_t *mark_rq, hipStream_t s, uint32_t mark_and_select = 0);  // mark_rq alone: tombstones instead of the selection; with mark_and_select: both
 // mark_rq != NULL: consume mode — instead of scattering, every selected task gets rq = RQ_TOMBSTONE in that column.
 // A small table from pinned (device-mapped) host memory into HBM by a kernel of the stream (16-byte loads across PCIe): a few microseconds where the copy
 // engine's hipMemcpyAsync costs 10-15 on its own.  bytes is rounded up to 16: both buffers must have that slack.

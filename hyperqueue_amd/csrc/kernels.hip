@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
                                                      const uint32_t *__restrict__ base, SelPlanN<PN> pa, uint64_t *__restrict__ sel_task,
                                                      uint16_t *__restrict__ sel_key, uint32_t n_select_blocks,
                                                      const uint4 *__restrict__ copy_src, uint4 *__restrict__ copy_dst, uint32_t copy_n16,
-                                                     uint32_t *__restrict__ mark_rq) {
+                                                     uint32_t *__restrict__ mark_rq, uint32_t mark_and_select) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t n_copy_blocks = gridDim.x - n_select_blocks;
     if (blockIdx.x < n_copy_blocks) {  // ride-along workgroups, dispatched FIRST so their PCIe round trip hides under the selection:
@@ -411,9 +411,9 @@ __global__ void __launch_bounds__(WPB * 64) k_select(const uint64_t *__restrict_
                 const uint32_t cur = s_cnt[g];  // wave-private counter: leaders of distinct groups write distinct words
                 const uint32_t rank = cur + before;
                 if (rank < tk[g]) {
-                    if (mark_rq) {  // consume mode (hqtick_ready_consume_last): the task leaves the ready set
-                        mark_rq[b + (uint64_t)u * 64 + lane] = RQ_TOMBSTONE;
-                    } else {
+                    if (mark_rq) mark_rq[b + (uint64_t)u * 64 + lane] = RQ_TOMBSTONE;  // the task leaves the ready set: hqtick_ready_consume_last (then nothing else is written), or
+                                                                                      // the tick itself under HQTICK_FLAG_CONSUME_IN_TICK (mark_and_select: the selection as well)
+                    if (!mark_rq || mark_and_select) {
                         uint32_t dst = bs[g] + rank;
                         const uint32_t nc = tnc[g];
                         if (nc) {  // worker-major: position p of the request's queue -> (worker p % n, its task p / n)
@@ -1124,7 +1124,7 @@ hipError_t copy_pinned_to_hbm(const void *src, void *dst, size_t bytes, hipStrea
 
 hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_t n, uint32_t Q, uint32_t G, WaveGeom geom,
                     const uint32_t *wave_off, const uint32_t *take_host, const uint32_t *take_dev, uint64_t *sel_task, uint16_t *sel_key,
-                    const void *plan_src, void *plan_dst, size_t plan_bytes, uint32_t *mark_rq, hipStream_t s) {
+                    const void *plan_src, void *plan_dst, size_t plan_bytes, uint32_t *mark_rq, hipStream_t s, uint32_t mark_and_select) {
     const uint32_t n16 = (uint32_t)((plan_bytes + 15) / 16);
     const bool sel = n != 0 && geom.n_waves != 0 && G != 0;
     hipError_t e;
@@ -1137,13 +1137,13 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
             for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; pa.tnc[g] = take_host[2 * G + g]; pa.tsb[g] = take_host[3 * G + g]; }
             HQK_TIMED_LAUNCH((k_select<4, 0, 16>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
                                (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
-                               reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq);
+                               reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq, mark_and_select);
         } else {
             SelPlanN<64> pa{};
             for (uint32_t g = 0; g < G; g++) { pa.take[g] = take_host[g]; pa.base[g] = take_host[G + g]; pa.tnc[g] = take_host[2 * G + g]; pa.tsb[g] = take_host[3 * G + g]; }
             HQK_TIMED_LAUNCH((k_select<4, 0, 64>), dim3(nsb + ncb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off,
                                (const uint32_t *)nullptr, (const uint32_t *)nullptr, pa, sel_task, sel_key, nsb, reinterpret_cast<const uint4 *>(plan_src),
-                               reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq);
+                               reinterpret_cast<uint4 *>(plan_dst), n16, mark_rq, mark_and_select);
         }
         return hipGetLastError();
     }
@@ -1159,14 +1159,14 @@ hipError_t select_scatter(const uint64_t *task_id, const uint16_t *gkey, uint64_
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         const uint32_t nsb = (geom.n_waves + 3) / 4;
         HQK_TIMED_LAUNCH(kern, dim3(nsb), dim3(256), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
-                           sel_task, sel_key, nsb, (const uint4 *)nullptr, (uint4 *)nullptr, 0u, mark_rq);
+                           sel_task, sel_key, nsb, (const uint4 *)nullptr, (uint4 *)nullptr, 0u, mark_rq, mark_and_select);
         return hipGetLastError();
     }
     size_t lds = (size_t)G * 4;
     auto kern = k_select<1, 2, 1>;
     if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     HQK_TIMED_LAUNCH(kern, dim3(geom.n_waves), dim3(64), lds, s, task_id, gkey, n, Q, G, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, wave_off, take_dev, take_dev + G, none,
-                       sel_task, sel_key, geom.n_waves, (const uint4 *)nullptr, (uint4 *)nullptr, 0u, mark_rq);
+                       sel_task, sel_key, geom.n_waves, (const uint4 *)nullptr, (uint4 *)nullptr, 0u, mark_rq, mark_and_select);
     return hipGetLastError();
 }
 

@@ -100,6 +100,12 @@ enum { HQ_REC_PREFILL = 0, HQ_REC_ASSIGN = 1 };
  * table: between two ticks of a steady cluster the blocks rarely change while the code that solves them has gone cold.  The answer is the one the solver would
  * give again; kernel_stats.n_classes_memo counts the hits.  bench.py's headline sets this flag (nothing cached inside its timed region). */
 #define HQTICK_FLAG_NO_BLOCK_MEMO 8u
+/* hqtick_config.flags (ABI 8): hqtick_run_resident takes what it hands out out of the resident ready set ITSELF — as take_tasks / take_tasks_for_prefill / take_one do
+ * inside the reference's tick (scheduler/taskqueue.rs:304-373): the selection kernel writes the tombstones while it selects, one kernel and one call per tick less
+ * than hqtick_run_resident + hqtick_ready_consume_last (which is a no-op then).  The price: a tick that FAILS after its selection was launched has already taken
+ * its tasks — the context drops the resident set (the next call says so) and the host uploads it again.  Without the flag a tick changes nothing until
+ * hqtick_ready_consume_last says so. */
+#define HQTICK_FLAG_CONSUME_IN_TICK 16u
 
 /* redirect_kind of a result entry (scheduler/mapping.rs:66-101):
  *   FROM_PREFILL  the task sat in a prefill set: Prefilled{old} -> Retracting{old}, retract sent to `old`, redirects.insert(task, (worker, v))

@@ -472,3 +472,43 @@ def test_fresh_batches_are_appended(seed):
     t.ready_add(np.uint64(next_id) + np.arange(5, dtype=np.uint64), np.full(5, p0, np.uint64), np.zeros(5, np.uint32))
     assert t.kernel_stats()["ready_appends"] == before + 1 and t.ready_count() == n_before + 5
     t.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_consume_in_tick_equals_tick_then_consume(seed):
+    """HQTICK_FLAG_CONSUME_IN_TICK: the selection kernel writes the tombstones of what it selects (take_tasks inside the reference's tick), hqtick_ready_consume_last is a
+    no-op.  Same arrivals, same cancels: every tick hands out what the two-call form hands out, the live counts agree after every step, and the set compacts on its own
+    (inside an add) once the tombstones outnumber the live tasks."""
+    from hyperqueue_amd.tick import Tick
+
+    rng = np.random.default_rng(1200 + seed)
+    snap = workloads.make("c3", n_tasks=150_000, n_workers=32, seed=seed)
+    cfg_a = abi.make_config(time_limit_s=20.0)
+    cfg_b = abi.make_config(time_limit_s=20.0, flags=abi.HQTICK_FLAG_CONSUME_IN_TICK)
+    a, b = Tick(cfg_a), Tick(cfg_b)
+    for t in (a, b):
+        t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+    empty = dataclasses_replace_ready(snap)
+    p0 = int(snap.task_priority[0])
+    next_id = int(snap.task_id[-1]) + 1
+    live = set(int(i) for i in snap.task_id)
+    for step in range(14):
+        ra = a.tick(empty, resident=True)
+        rb = b.tick(empty, resident=True)
+        assert_same(rb, ra)
+        a.ready_consume_last()
+        if step % 3 == 0:
+            b.ready_consume_last()  # allowed, and changes nothing
+        live -= {tt for recs in ra.records for (tt, _, _) in recs}
+        assert a.ready_count() == b.ready_count() == len(live), step
+        n = int(rng.integers(1, 400))  # fewer arrivals than departures: the tombstones pile up until a compaction
+        rq16 = rng.integers(0, 8, n).astype(np.uint16)
+        for t in (a, b):
+            t.ready_add_packed([(next_id, n)], [(p0, n)], rq16)
+        live |= set(range(next_id, next_id + n)); next_id += n
+        if step == 6:  # a cancel in between
+            victims = np.asarray(sorted(rng.choice(sorted(live), size=50, replace=False)), np.uint64)
+            assert a.ready_remove(victims) == 50 and b.ready_remove(victims) == 50
+            live -= set(int(v) for v in victims)
+        assert a.ready_count() == b.ready_count() == len(live)
+    a.close(); b.close()

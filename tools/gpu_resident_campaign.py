@@ -24,7 +24,8 @@ from oracle.oracle import Oracle
 def one(seed):
     rng = np.random.default_rng(31_000 + seed)
     W = int(rng.choice([8, 16, 24, 48]))
-    cfg = abi.make_config(time_limit_s=20.0)
+    in_tick = seed % 2 == 1  # every other scenario: the tick takes what it hands out itself (HQTICK_FLAG_CONSUME_IN_TICK), consume_last is a no-op
+    cfg = abi.make_config(time_limit_s=20.0, flags=abi.HQTICK_FLAG_CONSUME_IN_TICK if in_tick else 0)
     snap = workloads.make("c3", n_tasks=int(rng.integers(60_000, 200_000)), n_workers=W, seed=seed)
     t = Tick(cfg)
     t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
@@ -33,7 +34,7 @@ def one(seed):
     p0 = int(snap.task_priority[0])
     next_id = int(ids[-1]) + 1
     low = 1
-    stats = dict(seed=seed, W=W, steps=0, appended=0, merged=0, full_compares=0, levels=1, removed=0)
+    stats = dict(seed=seed, W=W, in_tick=in_tick, steps=0, appended=0, merged=0, full_compares=0, levels=1, removed=0)
     o = Oracle(cfg, canonical=True)
     for step in range(int(rng.integers(6, 12))):
         kind = str(rng.choice(["plain", "staged", "packed", "packed_off", "between", "plain", "packed"]))
