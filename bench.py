@@ -662,7 +662,7 @@ def main():
     dom = "level_hist"
     b2b = {}
     prof_k1 = committed_profile("k_level_hist")
-    # What an event-bracketed launch costs at least, whatever it does: tools/exp/dispatch_floor.hip on this hardware (profiles/r03/dispatch_floor.txt) — an EMPTY
+    # What an event-bracketed launch costs at least, whatever it does: tools/exp/dispatch_floor.hip on this hardware (profiles/r03/dispatch_floor.txt, again in profiles/r04/dispatch_floor.txt: 3.88-3.92 us) — an EMPTY
     # kernel records 3.9 us for every grid from 64 x 1024 to 1024 x 256 threads, K1's work as a persistent grid of any shape 4.1-4.3 us.  (Round 2 measured the
     # same floor through hqtick_time_kernel, which has moved to the measurement library libhqtick_test.so with the other tool hooks.)
     empty_us = 3.92
@@ -694,7 +694,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                      "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": dom_us, "avg_launch_us_back_to_back": b2b.get(dom),
                      "empty_launch_us": empty_us,
-                     "empty_launch_note": "from profiles/r03/dispatch_floor.txt (tools/exp/dispatch_floor.hip, this hardware): an EMPTY kernel records 3.9 us under the same per-dispatch "
+                     "empty_launch_note": "from profiles/r03/dispatch_floor.txt and, run again, profiles/r04/dispatch_floor.txt (tools/exp/dispatch_floor.hip, this hardware): an EMPTY kernel records 3.9 us under the same per-dispatch "
                                           "events for EVERY grid shape tried (64 x 1024 ... 1024 x 256 threads), and K1's work as a persistent grid of any of those shapes 4.1-4.3 us: at 1 M tasks the "
                                           "launch sits on a fixed per-dispatch floor, not on its workgroup count — 12 MB cannot be priced above 12 MB / 3.9 us = 0.38 of 8 TB/s by this measure, "
                                           "whatever the kernel does (VERDICT r02 item 3 asked for a persistent grid or a micro-benchmark proving the floor: this is the latter)",
