@@ -105,6 +105,7 @@ const char *build(const Request &rq, Prob &P) {
     }
     struct WideTmp { double h; uint8_t ge; std::vector<std::pair<int, int32_t>> cols; std::vector<std::pair<int, double>> g; };
     std::vector<WideTmp> wide;
+    std::vector<std::pair<int, long long>> ai;  // (one allocation for all block rows)
     for (int i = 0; i < rq.m; i++) {
         const int a = rq.roff[i], e = rq.roff[i + 1];
         if (a == e) continue;
@@ -134,7 +135,7 @@ const char *build(const Request &rq, Prob &P) {
                 return "block with more than 4 rows";
             }
             long long g = 0; bool ok = true;
-            std::vector<std::pair<int, long long>> ai;
+            ai.clear();
             for (int k = a; k < e && ok; k++) {
                 const double v = rq.rcoef[k] * sc * GRID, rv = std::round(v);
                 if (rv < 1.0 || std::fabs(v - rv) > 1e-6 * std::max(1.0, rv) || rv >= 4.0e15) ok = false;
@@ -171,6 +172,7 @@ const char *build(const Request &rq, Prob &P) {
         }
         if (n_bcols == 0) return "row over global columns only";
         WideTmp w; w.ge = is_ge ? 1 : 0;
+        w.cols.reserve((size_t)(e - a));
         const double sign = is_le ? 1.0 : -1.0;
         w.h = sign * (is_le ? rq.rhi[i] : rq.rlo[i]) * sc;
         for (int k = a; k < e; k++) {
@@ -198,9 +200,16 @@ const char *build(const Request &rq, Prob &P) {
     P.h.resize(P.K); P.ge.resize(P.K); P.g_rows.assign(P.G, {});
     std::vector<uint32_t> cnt(T.n_cols + 1, 0);
     P.r_off.assign(1, 0);
+    { size_t tot = 0; for (const WideTmp &w : wide) tot += w.cols.size(); P.r_col.reserve(tot); P.r_coef.reserve(tot); P.r_off.reserve(wide.size() + 1); }
+    std::vector<uint64_t> sig(P.K);   // a hash of every wide row's left-hand side, taken in the same pass (the groups of identical left-hand sides below compare hashes first)
     for (int k = 0; k < P.K; k++) {
         P.h[k] = wide[k].h; P.ge[k] = wide[k].ge;
-        for (auto &t : wide[k].cols) { cnt[t.first + 1]++; P.r_col.push_back(t.first); P.r_coef.push_back(t.second); }
+        uint64_t hsh = 1469598103934665603ull;
+        for (auto &t : wide[k].cols) {
+            cnt[t.first + 1]++; P.r_col.push_back(t.first); P.r_coef.push_back(t.second);
+            hsh = (hsh ^ (uint64_t)(uint32_t)t.first) * 1099511628211ull; hsh = (hsh ^ (uint64_t)(uint32_t)t.second) * 1099511628211ull;
+        }
+        sig[k] = hsh;
         P.r_off.push_back((int)P.r_col.size());
         for (auto &t : wide[k].g) P.g_rows[t.first].push_back({k, t.second});
     }
@@ -216,8 +225,7 @@ const char *build(const Request &rq, Prob &P) {
     P.grp_of.assign(P.K, -1);
     {
         std::vector<int> rep;
-        std::vector<uint64_t> sig(P.K);   // (a hash of the left-hand side first: the rows are a thousand terms long, an ordered map of them compares them term by term)
-        for (int k = 0; k < P.K; k++) { uint64_t h = 1469598103934665603ull; for (auto &t : wide[k].cols) { h = (h ^ (uint64_t)(uint32_t)t.first) * 1099511628211ull; h = (h ^ (uint64_t)(uint32_t)t.second) * 1099511628211ull; } sig[k] = h; }
+        // (the hash of the left-hand side first: the rows are a thousand terms long, an ordered map of them compares them term by term)
         for (int k = 0; k < P.K; k++) {
             int g = -1;
             for (size_t i = 0; i < rep.size() && g < 0; i++) if (sig[rep[i]] == sig[k] && wide[rep[i]].cols == wide[k].cols) g = (int)i;
