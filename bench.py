@@ -1,15 +1,18 @@
 #!/usr/bin/env python
 """bench.py — tasks assigned/sec and tick latency of the MI355X-native tako scheduling tick.
 
-A "step" is one scheduling tick (run_scheduling_inner, /root/reference/crates/tako/src/internal/scheduler/main.rs:50-72) over
-the synthetic workload `c3` (BASELINE.json configs[2]: 1 M ready tasks over 8 mixed {cpus, gpus, mem} request classes incl.
-fractional GPUs, 1024 workers), cold: every worker empty, every task ready.  The ready-set columns are resident in HBM when
-the timed region starts (hqtick_upload_ready); worker/request tables (50 KB) are part of the snapshot handed over each tick.
+A "step" is one scheduling tick (run_scheduling_inner, /root/reference/crates/tako/src/internal/scheduler/main.rs:50-72) over the synthetic
+workload `c3p` = BASELINE.json configs[2] as SURVEY.md §8(d) / BASELINE.md §3 write it: 1 M ready tasks over 8 mixed {cpus, gpus, mem} request
+classes incl. fractional GPUs, THREE user-priority levels at 80 / 15 / 5 %, 1024 workers; cold: every worker empty, every task ready.  The
+priority cuts (scheduler/batches.rs:97-171) couple every worker's block through wide rows (scheduler/solver.rs:233-253,274-429): the placement
+is ONE model of 8 205 columns, solved by price sweeps on the MI355X (k_price_sweep).  The ready-set columns are resident in HBM
+when the timed region starts (hqtick_upload_ready), worker / request tables too (hqtick_cluster_upload).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3]
-  N > 1: launched by torch.distributed.run, one rank per GPU: ONE scheduler whose workers are hash-sharded over the ranks
-  (hyperqueue_amd/sharded.py); weak scaling — 1024 workers and 1 M ready tasks per GPU; one RCCL all-gather merges
-  the shards' assignment vectors; value = tasks assigned by the whole job per second.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3p]
+  N > 1: launched by torch.distributed.run, one rank per GPU (or self-launched): ONE scheduler whose workers are hash-sharded over the ranks
+  (hyperqueue_amd/sharded.py); weak scaling — 1024 workers and 1 M ready tasks per GPU; every rank sweeps its own worker range
+  (one small all-gather per sweep), one RCCL all-gather merges the shards' assignment vectors; value = tasks assigned by the whole job per second.
+  `--workload c3` is the one-level variant (every class saturated: the placement separates per worker) — round 1-4's headline, now a neighbour.
 
 Prints ONE JSON line on rank 0.
 """
@@ -40,42 +43,51 @@ def cpu_model() -> str:
 
 
 def cpu_baseline(snap, ticks: int):
-    """The CPU oracle (restatement of the reference tick + HiGHS 1.8.0 for the MILP) on this host, 1 core, same snapshot."""
+    """The CPU oracle (restatement of the reference tick + HiGHS 1.8.0 for the MILP, with the reference's solver options) on this host, 1 core, same snapshot.
+    On the three-level workload one tick runs into the reference's own 5 s time limit (scheduler/state.rs: mip_time_limit) and returns an uncertified incumbent."""
     from hyperqueue_amd import abi
     from oracle.oracle import Oracle
 
     o = Oracle(abi.make_config(time_limit_s=5.0), reference_solver_options=True)  # HiGHS with its default options, as the reference runs it
-    lat, assigned = [], 0
+    lat, assigned, opt = [], 0, True
     for _ in range(ticks):
         t0 = time.perf_counter()
         r = o.tick(snap)
         lat.append(time.perf_counter() - t0)
         assigned = sum(1 for recs in r.records for (_, _, k) in recs if k == abi.HQ_REC_ASSIGN)
+        opt = bool(r.is_optimal)
     st = o.stage_times_us()
     med = float(np.median(lat))
+    try:
+        model = o.last_model()
+    except Exception:  # noqa: BLE001
+        model = None
     return {
         "value": assigned / med, "unit": "tasks/s", "cores": 1, "cpu": cpu_model(), "kind": "port",
-        "sample": f"{ticks} cold tick(s) of the full workload ({len(snap.task_id)} tasks x {len(snap.worker_id)} workers), "
-                  f"median {med:.2f} s/tick, {assigned} tasks assigned/tick",
-        "tick_s": med, "assigned_per_tick": assigned,
+        "sample": f"{ticks} cold tick(s) of the full workload ({len(snap.task_id)} tasks x {len(snap.worker_id)} workers, {len(np.unique(snap.task_priority))} priority level(s)), "
+                  f"median {med:.2f} s/tick, {assigned} tasks assigned/tick" + ("" if opt else "; HiGHS stopped at the reference's 5 s time limit with an uncertified incumbent (SchedulerResult::NeedMoreCompute)"),
+        "tick_s": med, "assigned_per_tick": assigned, "is_optimal": opt,
         "stages_us": {k: round(v, 1) for k, v in st.items()},
         "note": "restatement of the reference (C++ -O2) + HiGHS 1.8.0 via scipy for the MILP; not the reference binary (no Rust toolchain)",
+        "_model": model,
     }
 
 
-def committed_profile(kernel_substr: str):
+def committed_profile(kernel_substr: str, stem: str = "bench_c3p"):
     """HBM bytes per launch and kernel-trace durations of one kernel, READ at run time from the newest committed rocprofv3 summaries of the bench command
-    (profiles/rNN/bench_c3*.summary.csv, written by profiles/summarize.py; FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md §HBM, each counter in its own --pmc pass).
+    (profiles/rNN/<stem>*.summary.csv, written by profiles/summarize.py; FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md §HBM, each counter in its own --pmc pass).
     A PMC pass cannot run inside this process (one profiler session per run), so the line quotes the committed passes — and says which files.  None: no such files."""
     import glob
 
     root = os.path.join(ROOT, "profiles")
     for d in sorted(glob.glob(os.path.join(root, "r[0-9][0-9]")), reverse=True):
-        files = {k: os.path.join(d, f"bench_c3{suf}.summary.csv") for k, suf in (("trace", ""), ("fetch", "_FETCH_SIZE"), ("write", "_WRITE_SIZE"))}
-        if not all(os.path.exists(f) for f in files.values()):
+        files = {k: os.path.join(d, f"{stem}{suf}.summary.csv") for k, suf in (("trace", ""), ("fetch", "_FETCH_SIZE"), ("write", "_WRITE_SIZE"))}
+        if not os.path.exists(files["trace"]):
             continue
 
-        def row(path):  # (kernel names carry commas — `k_level_hist<4, true>` — and are not quoted: the numeric columns are split off from the right)
+        def row(path):  # (kernel names carry commas — `k_level_hist<4, true, 8>` — and are not quoted: the numeric columns are split off from the right)
+            if not os.path.exists(path):
+                return None
             lines = [l.rstrip("\n") for l in open(path) if not l.startswith("==")]
             hdr = lines[0].split(",")
             for l in lines[1:]:
@@ -85,15 +97,16 @@ def committed_profile(kernel_substr: str):
             return None
 
         tr, fe, wr = row(files["trace"]), row(files["fetch"]), row(files["write"])
-        if not (tr and fe and wr):
+        if not tr:
             continue
-        fetch, write = int(float(fe["FETCH_SIZE_x2_bytes"])), int(float(wr["WRITE_SIZE_bytes"]))
-        return {"traffic_bytes_per_launch": fetch + write, "fetch_x2_bytes": fetch, "write_bytes": write,
-                "kernel_trace": {"launches": int(tr["launches"]), "avg_ns": float(tr["avg_ns"]), "min_ns": float(tr["min_ns"]), "max_ns": float(tr["max_ns"])},
-                "files": [os.path.relpath(f, ROOT) for f in files.values()],
-                "note": "per launch, from the committed rocprofv3 passes of `bench.py --steps 50 --warmup 5` (headline loop only); kernel-trace average over the event-less launches of the "
-                        "timed region (K1 as the first packet behind the host's writes: its recorded span includes the queue's system-scope acquire) and the event-carrying "
-                        "launches of the stats pass — profiles/r04/k1_per_launch.txt lists them one by one"}
+        out = {"kernel_trace": {"launches": int(tr["launches"]), "avg_ns": float(tr["avg_ns"]), "min_ns": float(tr["min_ns"]), "max_ns": float(tr["max_ns"])},
+               "files": [os.path.relpath(f, ROOT) for f in files.values() if os.path.exists(f)],
+               "note": "per launch, from the committed rocprofv3 passes of `bench.py --headline-only` (the same command, headline loop only): every launch of this kernel in "
+                       "that run carries the same dispatch events as in the timed region, so the kernel-trace average and the live figure describe one population"}
+        if fe and wr:
+            fetch, write = int(float(fe["FETCH_SIZE_x2_bytes"])), int(float(wr["WRITE_SIZE_bytes"]))
+            out.update({"traffic_bytes_per_launch": fetch + write, "fetch_x2_bytes": fetch, "write_bytes": write})
+        return out
     return None
 
 
@@ -452,18 +465,123 @@ def self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def one_level_cold_tick(cfg, args, rec_bytes: int):
+    """The one-level variant c3 (every class saturated: the placement separates per worker into one 8-column block, solved on the host in ~12 us): round 1-4's headline,
+    now a neighbour of the three-level tick.  Cold tick repeated on the resident set; per-kernel durations from a second pass with dispatch events on."""
+    from hyperqueue_amd import abi, workloads
+    from hyperqueue_amd.tick import Tick
+
+    snap = workloads.make("c3", seed=args.seed)
+    sc = snap.to_c()
+    t = Tick(cfg)
+    t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
+    if not args.no_resident_cluster:
+        t.cluster_upload(sc)
+    t.set_kernel_timing(False)
+    for _ in range(5):
+        t.tick_raw(sc, resident=True)
+    lat, stages = [], []
+    for _ in range(50):
+        t0 = time.perf_counter(); res = t.tick_raw(sc, resident=True); lat.append(time.perf_counter() - t0)
+        stages.append((res.t_scan_us, res.t_batches_us, res.t_solve_us, res.t_mapping_us, res.t_total_us))
+    t.set_kernel_timing(True)
+    kstats = []
+    for _ in range(20):
+        t.tick_raw(sc, resident=True); kstats.append(t.kernel_stats())
+    ks = kstats[-1]
+    t.close()
+    n_ready, assigned, prefilled = len(snap.task_id), int(ks["n_assigned"]), int(ks["n_prefilled"])
+    sel = assigned + prefilled
+    mean = lambda k: float(np.mean([x[k] for x in kstats]))
+    G = len(snap.requests)
+    kernels = {
+        "level_hist": dict(us=mean("level_hist_us"), bytes=n_ready * 12, bound="hbm", what="K1: priority u64 + rq u32 of every ready task"),
+        "scan_waves": dict(us=mean("scan_us"), bytes=G * ((n_ready + 255) // 256) * 8, bound="latency", what="K1b: per-slice counts -> offsets"),
+        "select_scatter": dict(us=mean("select_us"), bytes=n_ready * 2 + sel * 18, bound="hbm", what="K4: group key u16 of every ready task + id u64 of the slices that still feed a group + (id, key) of the taken ones"),
+        "sweep_bits": dict(us=mean("sweep_us"), bytes=0, bound="latency", what="K5a: round-robin bit rows"),
+        "expand_mapping": dict(us=mean("other_us"), bytes=sel * 10 + sel * rec_bytes, bound="pcie", what="K5b: gathers (id, level) and writes the records straight into pinned host memory"),
+    }
+    for k in kernels.values():
+        k["GBps"] = k["bytes"] / (k["us"] * 1e-6) / 1e9 if k["us"] > 0 else 0.0
+        k["us"] = round(k["us"], 2)
+    em = kernels["expand_mapping"]
+    pcie_bytes, pcie_peak = sel * rec_bytes, 63.0
+    med = float(np.median(lat))
+    return {
+        "workload": f"c3: {n_ready} ready tasks x {len(snap.worker_id)} workers, 8 request classes, ONE priority level, cold tick repeated on the resident ready set (best case: one host-solved class block)",
+        "tasks_assigned_per_sec": assigned / med, "p50_tick_ms": 1e3 * med, "p95_tick_ms": 1e3 * float(np.percentile(lat, 95)), "assigned_per_tick": assigned, "prefilled_per_tick": prefilled,
+        "tick_algorithmic_bytes": int(ks["algorithmic_bytes"]), "tick_bytes_per_s_end_to_end_GBps": ks["algorithmic_bytes"] / med / 1e9,
+        "kernels": kernels,
+        "tick_stages_us": dict(zip(["gpu_phase_a_scans", "batches", "solve", "mapping_plan_gpu_phase_c", "total_in_library"], [round(float(x), 1) for x in np.median(np.asarray(stages), axis=0)])),
+        "time_dominant_kernel": {"kernel": "expand_mapping", "bound": "pcie", "achieved": pcie_bytes / (em["us"] * 1e-6) / 1e9 if em["us"] > 0 else 0.0, "peak": pcie_peak, "unit": "GB/s",
+                                 "frac": (pcie_bytes / (em["us"] * 1e-6) / 1e9 / pcie_peak) if em["us"] > 0 else 0.0, "bytes_over_pcie_per_launch": pcie_bytes, "avg_launch_us": em["us"], "bytes_per_record": rec_bytes},
+    }, snap
+
+
+def preflight(rank: int, world: int, local_rank: int) -> int:
+    """`--preflight`: does the library's own RCCL communicator come up on this node?  Builds it (hqtick_comm_unique_id on rank 0, the 128-byte id over torch.distributed,
+    hqtick_comm_init everywhere), runs ONE 4 KB all-gather through hqtick_shard_allgather and checks every rank's block — nothing else.  Rank 0 prints one JSON line."""
+    import torch
+
+    from hyperqueue_amd import abi
+    from hyperqueue_amd.sharded import ShardedTick, sink_layout
+
+    out = {"preflight": "hqtick_comm_init + one all-gather of 4 KB per rank", "ranks": world}
+    wd = watchdog(120.0, lambda: (rank == 0) and print(json.dumps(dict(out, error="did not come back within 120 s"))))
+    try:
+        st = ShardedTick(abi.make_config(device_index=local_rank), rank=rank, world=world, records_per_shard=256)
+        out["collective"] = st.collective; out["ranks_in_the_library_communicator"] = int(st.comm_world)
+        dev = torch.device("cuda", local_rank)
+        total = 4096
+        sink = torch.full((total,), rank + 1, dtype=torch.uint8, device=dev)
+        merged = torch.zeros(total * world, dtype=torch.uint8, device=dev)
+        ok = False
+        if st.collective == "library":
+            lib = st.t._lib
+            rc = lib.hqtick_set_record_sink(st.t._ctx, C.c_void_p(sink.data_ptr()), C.c_size_t(total))
+            t0 = time.perf_counter()
+            rc = rc or lib.hqtick_shard_allgather(st.t._ctx, C.c_void_p(merged.data_ptr()), C.c_size_t(merged.numel()))
+            torch.cuda.synchronize()
+            out["allgather_ms_first_call"] = 1e3 * (time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            rc = rc or lib.hqtick_shard_allgather(st.t._ctx, C.c_void_p(merged.data_ptr()), C.c_size_t(merged.numel()))
+            torch.cuda.synchronize()
+            out["allgather_ms_second_call"] = 1e3 * (time.perf_counter() - t0)
+            got = merged.cpu().numpy().reshape(world, total)
+            ok = rc == 0 and all((got[r] == r + 1).all() for r in range(world))
+            out["rc"] = int(rc)
+            if rc:
+                out["error"] = st.t._err()
+        out["ranks_seen"] = int(sum(1 for r in range(world) if (merged.cpu().numpy().reshape(world, total)[r] == r + 1).all()))
+        out["ok"] = bool(ok)
+        st.t.close()
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e); out["ok"] = False
+    wd.cancel()
+    flag = torch.tensor([1 if out.get("ok") else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+    if world > 1:
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    out["ok_on_every_rank"] = bool(int(flag.item()))
+    if rank == 0:
+        print(json.dumps(out)); sys.stdout.flush()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0 if out["ok_on_every_rank"] else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=None, help="c2 / c3 / c4; default c3 (BASELINE configs[2], the headline) — on N > 1 GPUs per rank (weak scaling: 1024 workers and 1 M ready tasks per GPU, "
-                                                   "hash-sharded + one RCCL all-gather); c4 = BASELINE configs[3] as written (4096 workers, 1 M tasks, strong scaling)")
+    ap.add_argument("--workload", default=None, help="c3p (default: BASELINE configs[2] as SURVEY 8d writes it, three priority levels) / c3 (one level) / c2 / c4; on N > 1 GPUs per rank "
+                                                   "(weak scaling: 1024 workers and 1 M ready tasks per GPU, hash-sharded + one RCCL all-gather); c4 = BASELINE configs[3] as written (strong scaling)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="N > 1: weak = the workload grows with N (default for c2 / c3), strong = the configuration as written (default for c4 = BASELINE configs[3])")
-    ap.add_argument("--cpu-ticks", type=int, default=3, help="ticks of the CPU baseline (0 = skip)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="N > 1: weak = the workload grows with N (default for c2 / c3 / c3p), strong = the configuration as written (default for c4 = BASELINE configs[3])")
+    ap.add_argument("--cpu-ticks", type=int, default=1, help="ticks of the CPU baseline (0 = skip): one tick of the reference-configured HiGHS on c3p runs into its 5 s limit")
+    ap.add_argument("--headline-only", action="store_true", help="the timed region and its line only: no neighbours, loops, extras, CPU baseline (what profiles/rNN/bench_c3p*.summary.csv are taken from)")
     ap.add_argument("--no-resident-cluster", action="store_true", help="pack the worker tables per tick instead of keeping them in HBM (hqtick_cluster_*)")
-    ap.add_argument("--priority-ticks", type=int, default=5, help="ticks of the three-priority-level variant c3p (0 = skip)")
+    ap.add_argument("--priority-ticks", type=int, default=5, help="ticks of the other coupled workloads (busy cluster with three levels, configs[3] unsaturated), 0 = skip")
     ap.add_argument("--steady-steps", type=int, default=20, help="steps of the steady-state (delta-updated resident set) measurement, 0 = skip")
     ap.add_argument("--hetero-steps", type=int, default=25, help="ticks of the heterogeneous-worker steady state (SURVEY 8d: 10 %% of the running tasks finish per tick), 0 = skip")
     ap.add_argument("--dag-steps", type=int, default=12, help="ticks of the config-5 loop (1 M-node DAG in the device graph + 10 %% worker churn per tick), 0 = skip")
@@ -471,15 +589,19 @@ def main():
     ap.add_argument("--wire-iters", type=int, default=50, help="launch triples of the wire-encoding measurement (row f3, in a subprocess), 0 = skip")
     ap.add_argument("--full-records", action="store_true", help="10-byte records (u64 id, variant, kind) instead of the compact emission (HQTICK_FLAG_COMPACT_RECORDS)")
     ap.add_argument("--u32-records", action="store_true", help="compact emission with 4-byte low halves (ABI 4/5) instead of the 16-bit differences of ABI 6 (HQTICK_FLAG_COMPACT_DELTA16)")
-    ap.add_argument("--no-b2b", dest="b2b", action="store_false", help="skip the 100 back-to-back launches of K1 / K4 (so that a rocprofv3 summary of this run averages the in-tick launches only)")
-    ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1/K4 bandwidth measurement on 4 M / 16 M task ready sets")
+    ap.add_argument("--no-roofline-sweep", dest="roofline_sweep", action="store_false", help="skip the K1 bandwidth measurement on 4 M / 16 M task ready sets")
     ap.add_argument("--no-multi-extras", dest="multi_extras", action="store_false", help="N > 1: skip the blocks after the timed region (configs[3]'s coupled tick with the solve split over the ranks vs replicated; c4 strong scaling)")
     ap.add_argument("--extras-timeout", type=float, default=240.0, help="N > 1: seconds the extra blocks may take before the line is printed without them")
+    ap.add_argument("--run-timeout", type=float, default=900.0, help="N > 1: seconds the whole run may take before rank 0 prints what it has and every rank ends (a lost rank must not hang the node)")
+    ap.add_argument("--preflight", action="store_true", help="N > 1: only build the library's RCCL communicator (hqtick_comm_init), run one 4 KB all-gather through it and print the ranks seen")
     ap.add_argument("--plain-adds", action="store_true", help="steady-state loop: new tasks as three full columns (hqtick_ready_add_staged, 20 B per task) instead of the packed form")
     ap.add_argument("--two-call-consume", action="store_true", help="the loops: hqtick_run_resident + hqtick_ready_consume_last as two calls (up to round 4) instead of HQTICK_FLAG_CONSUME_IN_TICK")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded code path (device record sink + merge + D2H) even with one rank")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick (kernel table and roofline are then empty)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="HQTICK_FLAG_NO_KERNEL_TIMING: no HIP events inside the tick at all (the roofline object is then empty)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.cpu_ticks = args.priority_ticks = args.steady_steps = args.hetero_steps = args.dag_steps = args.wire_iters = 0
+        args.roofline_sweep = False
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: launch the N ranks ourselves (one process per GPU, the same command line the driver uses) and hand their
@@ -491,9 +613,9 @@ def main():
     if rank == 0 and world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running (and reporting n_gpus =) {world} rank(s)", file=sys.stderr)
     if args.workload is None:
-        # one curve for N = 1, 2, 4, 8: the headline workload (BASELINE configs[2]) per GPU — weak scaling, 1024 workers and 1 M ready tasks per rank.  configs[3] as
-        # written (c4: 4096 workers hash-sharded over the ranks, strong scaling) is `--workload c4`, and rides along in the N > 1 line as `config4_strong`.
-        args.workload = "c3"
+        # one curve for N = 1, 2, 4, 8: the headline workload (BASELINE configs[2] with its three priority levels) per GPU — weak scaling, 1024 workers and 1 M ready
+        # tasks per rank.  configs[3] as written (c4: 4096 workers hash-sharded over the ranks, strong scaling) is `--workload c4`, and rides along in the N > 1 line.
+        args.workload = "c3p"
     import torch
 
     if not torch.cuda.is_available():
@@ -514,11 +636,15 @@ def main():
     from hyperqueue_amd import abi, workloads
     from hyperqueue_amd.tick import Tick
 
-    # N = 1: the plain tick.  N > 1: ONE scheduler whose workers are hash-sharded over the ranks (hyperqueue_amd/sharded.py): every rank
-    # holds the same snapshot (ready set replicated in its HBM), expands the records of its own workers, and one RCCL all-gather merges
-    # the shards' assignment vectors; rank 0 then pulls the merged vector to the host.  Weak scaling: 1024 workers and 1 M ready tasks
-    # per GPU, so every request class stays saturated and each rank emits the same number of records as the N = 1 run.
-    n_workers_per_gpu, n_tasks_per_gpu = {"c2": (256, 100_000), "c3": (1024, 1_000_000), "c4": (4096, 1_000_000)}.get(args.workload, (1024, 1_000_000))
+    if args.preflight:
+        raise SystemExit(preflight(rank, world, local_rank))
+    partial = {"metric": "tasks_assigned_per_sec", "value": None, "unit": "tasks/s", "n_gpus": world, "error": "run timed out before the timed region finished"}
+    run_wd = watchdog(args.run_timeout, lambda: (rank == 0) and print(json.dumps(partial))) if world > 1 else None
+
+    # N = 1: the plain tick.  N > 1: ONE scheduler whose workers are hash-sharded over the ranks (hyperqueue_amd/sharded.py): every rank holds the same snapshot (ready set
+    # replicated in its HBM), sweeps its own worker range of the coupled model (one small all-gather per sweep), expands the records of its own workers, and one
+    # RCCL all-gather merges the shards' assignment vectors; rank 0 then pulls the merged vector to the host.  Weak scaling: 1024 workers and 1 M ready tasks per GPU.
+    n_workers_per_gpu, n_tasks_per_gpu = {"c2": (256, 100_000), "c3": (1024, 1_000_000), "c3p": (1024, 1_000_000), "c4": (4096, 1_000_000)}.get(args.workload, (1024, 1_000_000))
     # --scaling strong: the configuration as BASELINE.json writes it, whatever N is (configs[3]: c4 = 4096 workers, 1 M tasks, hash-sharded over the GPUs)
     scaling = args.scaling or ("strong" if args.workload == "c4" else "weak")
     mult = world if scaling == "weak" else 1
@@ -530,7 +656,7 @@ def main():
         cfg.flags |= abi.HQTICK_FLAG_COMPACT_RECORDS  # records cross PCIe as u32 low halves + runs of (job, variant, kind): include/hqtick.h
         if not args.u32_records:
             cfg.flags |= abi.HQTICK_FLAG_COMPACT_DELTA16  # ... as 16-bit differences of the low halves (ABI 6): 2 bytes per record
-    # The product keeps the answers of its last host-solved class blocks (hqtick.h: HQTICK_FLAG_NO_BLOCK_MEMO).  The headline repeats ONE tick: with the table on, its block
+    # The product keeps the answers of its last host-solved class blocks (hqtick.h: HQTICK_FLAG_NO_BLOCK_MEMO).  The headline repeats ONE tick: with the table on, a block
     # solve would be a lookup — so the headline context switches it off (nothing cached inside the timed region); the loops below, whose ticks see a changing ready set,
     # run the product's default and say how often the table answered.
     loop_cfg = type(cfg).from_buffer_copy(cfg)
@@ -540,6 +666,7 @@ def main():
     rec_bytes = 10 if args.full_records else (4 if args.u32_records else 2)  # what one record costs on PCIe (runs and spans on top in the compact forms)
     sc = snap.to_c()
     W_all = len(snap.worker_id)
+    st = None
     if world == 1 and not args.force_sharded:
         tick = Tick(cfg)
         tick.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
@@ -571,9 +698,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if not (world == 1 and not args.force_sharded):
+    if st is not None:
         # The sinks are fixed-capacity blocks (one all-gather, one D2H of the merged vector): size them to what the workload really emits — the largest shard
-        # of a first tick plus 10 % — instead of the a-priori bound above, which is 1.6x the C3 tick's records and would travel over xGMI and PCIe every tick.
+        # of a first tick plus 10 % — instead of the a-priori bound above, which would travel over xGMI and PCIe every tick.
         # The first multi-rank tick also proves the merge path: if the library's RCCL communicator fails its first all-gather on ANY rank, every rank falls back
         # to torch.distributed's collective for the rest of the run (and the line says which one carried the timed ticks).
         first_err = None
@@ -602,7 +729,9 @@ def main():
         st.set_capacity(int(1.1 * n_max) + 1024)
         host_merged = None
 
-    tick.set_kernel_timing(False)  # the timed region carries no timing events at all
+    # The timed region carries dispatch events around ONE kernel, K1 (k_level_hist, the launch that streams the ready set: hqtick_set_kernel_timing(ctx, 2)) — the roofline
+    # figure is the average over exactly these launches, and a rocprofv3 kernel trace of this command (`--headline-only`) sees the same population.
+    tick.set_kernel_timing(False if args.no_kernel_timing else 2)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -612,108 +741,89 @@ def main():
         t0 = time.perf_counter()
         res = step()
         lat.append(time.perf_counter() - t0)
-        stages.append((res.t_scan_us, res.t_batches_us, res.t_solve_us, res.t_mapping_us, res.t_total_us))
+        stages.append((res.t_scan_us, res.t_batches_us, res.t_solve_us, res.t_mapping_us, res.t_total_us, int(res.status), int(res.is_optimal)))
+        kstats.append(tick.kernel_stats())  # (one ctypes call per tick, inside the timed region: ~3 us of a ~4 ms step)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t_begin
-    # per-kernel durations: a second pass over the same ticks with every measured kernel bracketed by start / stop events at its dispatch
-    # (hipExtLaunchKernel — the kernel's own duration, as rocprofv3's kernel trace reports it)
-    if not args.no_kernel_timing:
-        tick.set_kernel_timing(True)
-    for _ in range(max(10, min(args.steps, 50))):
-        step()
-        kstats.append(tick.kernel_stats())
-    torch.cuda.synchronize()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ks = kstats[-1]
     assigned, prefilled = int(ks["n_assigned"]), int(ks["n_prefilled"])  # whole-job counts: the placement is replicated on every rank
-    total_assigned = assigned
     if rank != 0:
         if dist is not None:
-            if args.multi_extras:
+            if args.multi_extras and not args.headline_only:
                 watchdog(args.extras_timeout, lambda: None)
                 multi_rank_extras(cfg, rank, world, local_rank)
             dist.destroy_process_group()
         return
 
     n_ready, W, R = len(snap.task_id), len(snap.worker_id), snap.n_resources
-    mean = lambda k: float(np.mean([s[k] for s in kstats]))
-    sel = assigned + prefilled
-    G = max(1, len(snap.requests) * len(np.unique(snap.task_priority)))  # groups = requests x distinct priority levels
-    # per kernel: HIP-event duration inside the timed ticks (us), algorithmic bytes per launch, what bounds it
-    kernels = {
-        "level_hist": dict(us=mean("level_hist_us"), bytes=n_ready * 12, bound="hbm", what="K1: priority u64 + rq u32 of every ready task"),
-        "scan_waves": dict(us=mean("scan_us"), bytes=G * ((n_ready + 255) // 256) * 8, bound="latency", what="K1b: per-slice counts -> offsets"),
-        "select_scatter": dict(us=mean("select_us"), bytes=n_ready * 8 + sel * 10, bound="hbm", what="K4: id u64 of every ready task + (id, level) of the taken ones"),
-        "sweep_bits": dict(us=mean("sweep_us"), bytes=0, bound="latency", what="K5a: round-robin bit rows"),
-        "expand_mapping": dict(us=mean("other_us"), bytes=(sel * 10 + sel * (10 if world > 1 else rec_bytes)) // world, bound="pcie" if world == 1 else "hbm-latency",
-                               what="K5b: gathers (id, level) and writes this rank's records " + ("straight into pinned host memory" if world == 1 else "into the HBM record sink")),
-    }
-    for k in kernels.values():
-        k["GBps"] = k["bytes"] / (k["us"] * 1e-6) / 1e9 if k["us"] > 0 else 0.0
-        k["us"] = round(k["us"], 2)
-    # Roofline kernel = K1, the pass that streams the ready set (largest algorithmic byte count per launch).  Its duration is measured with
-    # HIP events twice: bracketing the single launch inside every timed tick (carries ~2-3 us of event/dispatch latency on an idle stream),
-    # and around 100 back-to-back launches on the same stream right after the timed region (amortises it; this is the figure rocprofv3's
-    # kernel trace agrees with, profiles/r01/final/).  `achieved` uses the back-to-back figure; the in-tick one is reported next to it.
-    dom = "level_hist"
-    b2b = {}
-    prof_k1 = committed_profile("k_level_hist")
-    # What an event-bracketed launch costs at least, whatever it does: tools/exp/dispatch_floor.hip on this hardware (profiles/r03/dispatch_floor.txt, again in profiles/r04/dispatch_floor.txt: 3.88-3.92 us) — an EMPTY
-    # kernel records 3.9 us for every grid from 64 x 1024 to 1024 x 256 threads, K1's work as a persistent grid of any shape 4.1-4.3 us.  (Round 2 measured the
-    # same floor through hqtick_time_kernel, which has moved to the measurement library libhqtick_test.so with the other tool hooks.)
-    empty_us = 3.92
-    dom_us = kernels[dom]["us"]  # the launch inside the tick, dispatch-level events
-    achieved, peak = (kernels[dom]["bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0), 8000.0
-    pcie_peak = 63.0  # GB/s, PCIe Gen5 x16 one direction (what K5b's stores into pinned host memory cross)
-    em = kernels["expand_mapping"]
-    pcie_bytes = sel * rec_bytes // world
-    value = total_assigned * args.steps / elapsed
+    n_levels = int(len(np.unique(snap.task_priority)))
+    med = lambda k: float(np.median([x[k] for x in kstats]))
+    mean = lambda k: float(np.mean([x[k] for x in kstats]))
+    value = assigned * args.steps / elapsed
+    p50 = float(np.median(lat))
+    # Roofline kernel = K1, the pass that streams the ready set (largest algorithmic byte count per launch: 12 B per ready task).  Duration = average over the launches
+    # of the TIMED REGION itself (start / stop events at the dispatch, hipExtLaunchKernel).
+    k1_us = mean("level_hist_us")
+    k1_bytes, peak = n_ready * 12, 8000.0
+    achieved = k1_bytes / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
+    prof_k1 = committed_profile("k_level_hist") if args.workload == "c3p" else None
+    prof_sw = committed_profile("k_price_sweep") if args.workload == "c3p" else None
+    sweeps, sweep_us = med("price_sweeps"), med("price_sweep_us")
+    coupled = sweeps > 0
+    blocks = W_all // world if (st is not None and world > 1) else W_all
+    all_done = bool(all(s[5] == abi.HQTICK_DONE and s[6] for s in stages))
+    stage_med = [round(float(x), 1) for x in np.median(np.asarray([s[:5] for s in stages]), axis=0)]
+    par = "single" if world == 1 else (f"worker-shards x{world}: FxHash(worker_id) % {world}, ready set replicated, every rank sweeps its own worker range (one small all-gather per price sweep), "
+                                        "one RCCL all-gather of the record sinks " + (f"inside libhqtick.so (hqtick_shard_allgather; communicator of {getattr(st, 'comm_world', world)} ranks)"
+                                                                                    if getattr(st, "collective", "") == "library" else f"through torch.distributed ({getattr(st, 'collective', '?')})") + ", merged vector D2H on rank 0")
     out = {
         "metric": "tasks_assigned_per_sec", "value": value, "unit": "tasks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {n_ready} ready tasks x {W} workers x {R} resource kinds, {len(snap.requests)} request classes, "
-                               f"{len(np.unique(snap.task_priority))} priority level(s), cold tick (every class saturated: the placement separates per worker; "
-                               "the same size with three priority levels is `multi_priority` below)",
-                   "parallelism": "single" if world == 1 else f"worker-shards x{world}: FxHash(worker_id) % {world}, ready set replicated, one RCCL all-gather of the record sinks "
-                                   + (f"inside libhqtick.so (hqtick_shard_allgather; communicator of {getattr(st, 'comm_world', world)} ranks)" if getattr(st, "collective", "") == "library"
-                                      else f"through torch.distributed ({getattr(st, 'collective', '?')})") + ", merged vector D2H on rank 0",
-                   "ranks": world, "ranks_in_the_library_communicator": int(getattr(st, "comm_world", 0)) if world > 1 or args.force_sharded else 0,
-                   "ready_set": "resident in HBM", "seed": args.seed},
-        "p50_tick_ms": 1e3 * float(np.median(lat)), "p95_tick_ms": 1e3 * float(np.percentile(lat, 95)),
+        "config": {"workload": f"{args.workload}: {n_ready} ready tasks x {W} workers x {R} resource kinds, {len(snap.requests)} request classes, {n_levels} priority level(s)"
+                               + (" at 80/15/5 % (BASELINE configs[2] as SURVEY 8d / BASELINE.md 3 write it), cold tick: the priority cuts couple every worker — ONE placement model of "
+                                  f"{int(med('milp_cols'))} columns x {int(med('milp_rows'))} rows solved by price sweeps on the MI355X (k_price_sweep) under a host master" if coupled else
+                                  ", cold tick (every class saturated: the placement separates per worker)"),
+                   "priority_levels": n_levels, "parallelism": par, "ranks": world,
+                   "ranks_in_the_library_communicator": int(getattr(st, "comm_world", 0)) if st is not None else 0,
+                   "ready_set": "resident in HBM", "seed": args.seed,
+                   # the headline's own numbers, here as well (the driver's record keeps `config` and `roofline` whole)
+                   "p50_tick_ms": 1e3 * p50, "p95_tick_ms": 1e3 * float(np.percentile(lat, 95)), "assigned_per_tick": assigned, "prefilled_per_tick": prefilled,
+                   "every_timed_tick_done_and_certified": all_done, "price_sweeps_per_tick": int(sweeps), "flag_configurations_per_tick": int(med("price_rounds")),
+                   "tick_stages_us": dict(zip(["gpu_phase_a_scans", "batches", "solve", "mapping_plan_gpu_phase_c", "total_in_library"], stage_med)),
+                   "coupled_solve_us": {"build_model": med("model_us"), "solve": med("milp_us"), "of_which_price_path": med("price_us"), "of_which_inside_sweeps_launch_to_totals": sweep_us},
+                   "price_sweeps_share_of_tick": sweep_us / (1e6 * p50) if p50 > 0 else None,
+                   "is_optimal_means": "certified within HiGHS's default mip_rel_gap = 1e-4, which is all the reference's solve_bounded asks for (solver/highs.rs:65-68)"},
+        "p50_tick_ms": 1e3 * p50, "p95_tick_ms": 1e3 * float(np.percentile(lat, 95)),
         "assigned_per_tick": assigned, "prefilled_per_tick": prefilled,
         "tick_algorithmic_bytes": int(ks["algorithmic_bytes"]),
-        "tick_bytes_per_s_end_to_end_GBps": ks["algorithmic_bytes"] / float(np.median(lat)) / 1e9,
-        "tick_bytes_per_s_gpu_kernels_GBps": ks["algorithmic_bytes"] / (sum(v["us"] for v in kernels.values()) * 1e-6) / 1e9,
-        "kernels": kernels,
-        "tick_stages_us": dict(zip(["gpu_phase_a_scans", "batches", "solve", "mapping_plan_gpu_phase_c", "total_in_library"], [round(float(x), 1) for x in np.median(np.asarray(stages), axis=0)])),
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                     "algorithmic_bytes_per_launch": kernels[dom]["bytes"], "avg_launch_us": dom_us, "avg_launch_us_back_to_back": b2b.get(dom),
-                     "empty_launch_us": empty_us,
-                     "empty_launch_note": "from profiles/r03/dispatch_floor.txt and, run again, profiles/r04/dispatch_floor.txt (tools/exp/dispatch_floor.hip, this hardware): an EMPTY kernel records 3.9 us under the same per-dispatch "
-                                          "events for EVERY grid shape tried (64 x 1024 ... 1024 x 256 threads), and K1's work as a persistent grid of any of those shapes 4.1-4.3 us: at 1 M tasks the "
-                                          "launch sits on a fixed per-dispatch floor, not on its workgroup count — 12 MB cannot be priced above 12 MB / 3.9 us = 0.38 of 8 TB/s by this measure, "
-                                          "whatever the kernel does (VERDICT r02 item 3 asked for a persistent grid or a micro-benchmark proving the floor: this is the latter)",
-                     "traffic": (prof_k1 or {}).get("traffic_bytes_per_launch") if args.workload == "c3" else None,
-                     "rocprofv3": prof_k1 if args.workload == "c3" else None,
-                     "timing": "start / stop events at the dispatch of the launch INSIDE the tick (hipExtLaunchKernel), averaged over the stats pass after the timed region; "
-                               "the rocprofv3 kernel trace of this command (profiles/r02/) lists the same launches",
-                     "note": "K1 streams the whole ready set (12 B/task).  At 1 M tasks the set (20 MB) lives in the 256 MiB Infinity Cache across ticks and a launch is latency-bound "
-                             "(12 MB = 1.9 us at 6.3 TB/s achievable): see roofline_vs_n / profiles/r02 for the same kernel beyond the cache.  K2 (worker evaluation) rides along K1b's "
-                             "launch, not this one (HQTICK_K2_RIDE_ALONG=1 puts it back: 5.8 us instead of 4.7)"},
-        "roofline_time_dominant_kernel": {"kernel": "expand_mapping", "bound": "pcie", "achieved": pcie_bytes / (em["us"] * 1e-6) / 1e9 if em["us"] > 0 else 0.0, "peak": pcie_peak, "unit": "GB/s",
-                                          "frac": (pcie_bytes / (em["us"] * 1e-6) / 1e9 / pcie_peak) if em["us"] > 0 else 0.0, "bytes_over_pcie_per_launch": pcie_bytes, "avg_launch_us": em["us"],
-                                          "bytes_per_record": rec_bytes,
-                                          "note": "K5b writes the records straight into the caller's pinned host buffer.  Emission forms (include/hqtick.h): 10 B per record (--full-records), "
-                                                  "4 B low halves + 12 B per run of equal (job, variant, kind) + 8 B per worker (--u32-records, ABI 4/5), or — the default since ABI 6 — 16-bit "
-                                                  "differences of the low halves (2 B per record, 6 B where a difference does not fit) + 16 B per run.  On the MI355X (DESIGN.md 3c): ~12 us of the "
-                                                  "launch is the kernel itself (gathers from HBM, LDS placement, run scan), the rest the bytes crossing PCIe at the link's rate (~60 GB/s): "
-                                                  "25.5 us with 4 B per record, 20.0 us with 2 B"},
+        "tick_bytes_per_s_end_to_end_GBps": ks["algorithmic_bytes"] / p50 / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "k_level_hist (K1)", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                     "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_us": k1_us, "launches_averaged": len(kstats),
+                     "traffic": (prof_k1 or {}).get("traffic_bytes_per_launch"),
+                     "rocprofv3": prof_k1,
+                     "timing": "start / stop events at the dispatch (hipExtLaunchKernel) of EVERY K1 launch of the timed region (hqtick_set_kernel_timing(ctx, 2): K1 alone carries events), "
+                               "averaged over those launches; `rocprofv3` quotes the committed kernel trace of `bench.py --headline-only`, the same launches",
+                     "note": "K1 streams the whole ready set (12 B/task) and is the tick's only pass over it.  At 1 M tasks the set (20 MB) lives in the 256 MiB Infinity Cache across "
+                             "ticks and a launch is latency-bound (12 MB = 1.9 us at 6.3 TB/s achievable): `roofline_vs_n` has the same kernel beyond the cache.  It is NOT where a "
+                             "three-level tick spends its GPU time: see `dominant_kernel`",
+                     # the kernel the three-level tick's GPU time goes to: not an HBM kernel, priced by its own figure of merit
+                     "dominant_kernel": ({"kernel": "k_price_sweep", "launches_per_tick": int(sweeps), "blocks_per_launch": int(blocks), "avg_us_launch_to_totals_on_host": sweep_us / sweeps,
+                                          "block_solves_per_s": blocks * sweeps / (sweep_us * 1e-6) if sweep_us > 0 else None, "share_of_tick": sweep_us / (1e6 * p50),
+                                          "rocprofv3": prof_sw,
+                                          "bound": "latency: one wavefront per worker block walks dependent chains on LDS-resident data (exact bounded knapsack under the current prices, <= 32 columns x 4 rows; "
+                                                   "25.9 KB of LDS = six blocks per CU, 1536 resident: a sweep of 1024 blocks is ONE round whose length is the slowest block's chain).  A block reads 0.5-2 KB: "
+                                                   "not an HBM kernel, not MFMA work.  Counters (profiles/r04, --pmc passes): LDS instructions active 5 % of the wave cycles, VALU 15 %",
+                                          "figure_of_merit": "exact block solves per second, launch -> totals visible on the host"} if coupled else None)},
     }
+    if run_wd is not None:
+        run_wd.cancel()
+    nb = {}
     if world == 1 and not args.force_sharded and not args.no_kernel_timing and args.roofline_sweep:
         sweep = []
         for n_big in (4_000_000, 16_000_000):
@@ -721,37 +831,43 @@ def main():
             t2 = Tick(cfg)
             t2.upload_ready(s2.task_id, s2.task_priority, s2.task_rq, sorted_=True)
             sc2 = s2.to_c()
+            t2.cluster_upload(sc2)
+            t2.set_kernel_timing(2)
             for _ in range(2):
                 t2.tick_raw(sc2, resident=True)
-            ks2 = []
-            for _ in range(12):  # in-tick launches under per-dispatch events (hqtick_set_kernel_timing is on by default)
-                t2.tick_raw(sc2, resident=True); ks2.append(t2.kernel_stats())
-            for nm, key, bpt in (("level_hist", "level_hist_us", 12), ("select_scatter", "select_us", 8)):
-                us = float(np.mean([k[key] for k in ks2[2:]]))
-                row = {"kernel": nm, "n_ready": n_big, "avg_launch_us": round(us, 2)}
-                if nm == "level_hist":  # K1 reads every task: N x 12 B is what crosses HBM (profiles/r02: FETCH_SIZE x2 = 12 B x N)
-                    row.update({"GBps": n_big * bpt / (us * 1e-6) / 1e9, "frac": n_big * bpt / (us * 1e-6) / 1e9 / peak})
-                else:  # K4's slices stop as soon as the groups they could feed are exhausted (65 536 + 122 880 tasks are taken out of N)
-                    row["note"] = "slices behind the last taken task of their groups exit after their first 256-task tile: the bytes read depend on the slice size, no bandwidth figure"
-                sweep.append(row)
+            us = []
+            for _ in range(8):  # in-tick launches under per-dispatch events
+                t2.tick_raw(sc2, resident=True); us.append(t2.kernel_stats()["level_hist_us"])
+            u = float(np.mean(us))
+            sweep.append({"kernel": "level_hist", "n_ready": n_big, "avg_launch_us": round(u, 2), "GBps": n_big * 12 / (u * 1e-6) / 1e9, "frac": n_big * 12 / (u * 1e-6) / 1e9 / peak})
             t2.close()
-        out["roofline_vs_n"] = sweep
-    if world == 1 and not args.force_sharded and args.steady_steps > 0:
+        out["roofline"]["roofline_vs_n"] = sweep
+    snap1 = None
+    if world == 1 and not args.force_sharded and not args.headline_only and args.workload == "c3p":
+        try:
+            out["one_level_cold_tick"], snap1 = one_level_cold_tick(cfg, args, rec_bytes)
+            nb["c3_one_priority_level_cold_tick"] = {k: out["one_level_cold_tick"][k] for k in ("tasks_assigned_per_sec", "p50_tick_ms", "assigned_per_tick")}
+        except Exception as e:  # noqa: BLE001
+            out["one_level_cold_tick"] = {"error": repr(e)}
+    if snap1 is None and args.workload == "c3":
+        snap1 = snap
+    sc1 = snap1.to_c() if snap1 is not None else None
+    if world == 1 and not args.force_sharded and args.steady_steps > 0 and snap1 is not None:
         # Steady state of the reference's own throughput benchmark shape (benchmarks/experiment-per-task-overhead.py: zero-worker, `sleep 0`):
         # everything a tick hands out has finished before the next one, and as many new tasks have become ready.  The ready set stays in HBM
         # and is updated by deltas (hqtick_ready_consume_last / hqtick_ready_add) — nothing is re-uploaded but the new tasks.
         ts = Tick(loop_cfg)
-        ts.set_kernel_timing(False)  # as in the headline's timed region: no per-kernel timing events
-        ts.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
+        ts.set_kernel_timing(False)  # no per-kernel timing events
+        ts.upload_ready(snap1.task_id, snap1.task_priority, snap1.task_rq, sorted_=True)
         if not args.no_resident_cluster:
-            ts.cluster_upload(sc)  # as in the headline loop: the workers are empty again before every tick, no row changes
+            ts.cluster_upload(sc1)  # the workers are empty again before every tick, no row changes
         def handed_out(res):  # ids of the records of a tick (assigned + prefilled)
             return abi.record_task_ids(res, W)
 
-        rq_of = snap.task_rq.copy()  # rq by (job_task_id - 1): every id here is job 1, task 1..n
-        res = ts.tick_raw(sc, resident=True)
+        rq_of = snap1.task_rq.copy()  # rq by (job_task_id - 1): every id here is job 1, task 1..n
+        res = ts.tick_raw(sc1, resident=True)
         gone = handed_out(res)
-        next_id = int(snap.task_id[-1]) + 1
+        next_id = int(snap1.task_id[-1]) + 1
         t_delta, t_cons, t_tick, per_step, memo_hits = [], [], [], [], 0
         for _ in range(args.steady_steps + 2):
             k = len(gone)
@@ -763,7 +879,7 @@ def main():
             if args.plain_adds:
                 v_id, v_prio, v_rq = ts.ready_add_stage(k)
                 v_id[:] = np.arange(next_id, next_id + k, dtype=np.uint64)
-                v_prio[:] = snap.task_priority[0]
+                v_prio[:] = snap1.task_priority[0]
                 v_rq[:] = new_rq
             # The step's delta: what the last tick handed out leaves the resident set (hqtick_ready_consume_last queues one kernel and returns), the arrivals join it
             # (one kernel when they are appended; the add returns when the set is ready, i.e. it waits for both).  The GPU has been idle since the tick returned —
@@ -773,74 +889,36 @@ def main():
             if args.plain_adds:
                 ts.ready_add_staged(k)
             else:
-                ts.ready_add_packed([(next_id, k)], [(int(snap.task_priority[0]), k)], rq16)
+                ts.ready_add_packed([(next_id, k)], [(int(snap1.task_priority[0]), k)], rq16)
             next_id += k
-            b = time.perf_counter(); res = ts.tick_raw(sc, resident=True)
+            b = time.perf_counter(); res = ts.tick_raw(sc1, resident=True)
             c = time.perf_counter()
             gone = handed_out(res)
             memo_hits += int(ts.kernel_stats()["n_classes_memo"])
             t_delta.append(b - a); t_cons.append(a2 - a); t_tick.append(c - b); per_step.append(len(gone))
         per_step = int(np.median(per_step[2:]))
         t_delta, t_cons, t_tick = (np.asarray(x[2:]) for x in (t_delta, t_cons, t_tick))
-        step = t_delta + t_tick
+        stp = t_delta + t_tick
         out["steady_state"] = {
-            "what": "per step: hqtick_ready_consume_last (a no-op under HQTICK_FLAG_CONSUME_IN_TICK, the loops' default: the tick's selection kernel takes what it hands out; --two-call-consume: "
-                    "its own kernel) + hqtick_ready_add_packed / _staged (the new tasks; returns once the resident set is ready) + hqtick_run_resident; workers empty again before every tick (sleep-0 tasks)",
+            "what": "one priority level (c3).  Per step: hqtick_ready_consume_last (a no-op under HQTICK_FLAG_CONSUME_IN_TICK, the loops' default: the tick's selection kernel takes what it hands out; "
+                    "--two-call-consume: its own kernel) + hqtick_ready_add_packed / _staged (the new tasks; returns once the resident set is ready) + hqtick_run_resident; workers empty again before every tick (sleep-0 tasks)",
             "consume": "two calls (hqtick_ready_consume_last runs the selection once more in mark mode)" if args.two_call_consume else "inside the tick (HQTICK_FLAG_CONSUME_IN_TICK)",
             "steps": args.steady_steps, "ready_set_before_each_tick": int(ts.ready_count()), "tasks_handed_out_per_step": per_step,
-            "p50_step_ms": 1e3 * float(np.median(step)), "tasks_per_s": per_step / float(np.median(step)),
+            "p50_step_ms": 1e3 * float(np.median(stp)), "tasks_per_s": per_step / float(np.median(stp)),
             "p50_consume_plus_add_us": 1e6 * float(np.median(t_delta)), "of_which_consume_call_us": 1e6 * float(np.median(t_cons)), "p50_tick_us": 1e6 * float(np.median(t_tick)),
             "add_batches_appended_behind_the_resident_columns": int(ts.kernel_stats()["ready_appends"]), "of_add_batches": args.steady_steps + 2,
             "host_class_blocks_answered_from_the_contexts_table": memo_hits,
             "delta_bytes_host_to_device_per_step": per_step * (20 if args.plain_adds else 2), "adds": "plain columns (20 B per task)" if args.plain_adds else "packed (hqtick_ready_add_packed: 2 B per task)",
         }
         ts.close()
-    if world == 1 and not args.force_sharded and args.workload == "c3" and args.hetero_steps > 0:
-        out["steady_hetero"] = steady_hetero(loop_cfg, snap, args.hetero_steps, args.seed, min(args.cpu_ticks, 1))
-    if world == 1 and not args.force_sharded and args.workload == "c3" and args.dag_steps > 0:
+        nb["steady_state_add_tick_consume_one_level"] = {"tasks_handed_out_per_sec": out["steady_state"]["tasks_per_s"], "p50_step_ms": out["steady_state"]["p50_step_ms"], "p50_tick_us_inside_the_loop": out["steady_state"]["p50_tick_us"]}
+    if world == 1 and not args.force_sharded and snap1 is not None and args.hetero_steps > 0:
+        out["steady_hetero"] = steady_hetero(loop_cfg, snap1, args.hetero_steps, args.seed, min(args.cpu_ticks, 1))
+    if world == 1 and not args.force_sharded and snap1 is not None and args.dag_steps > 0:
         out["dag_churn"] = dag_churn(loop_cfg, args.dag_steps, args.seed, args.dag_classes, "random", min(args.cpu_ticks, 1))
         out["dag_churn_layered"] = dag_churn(loop_cfg, args.dag_steps, args.seed, args.dag_classes, "layered", min(args.cpu_ticks, 1))
-    if world == 1 and not args.force_sharded and args.workload == "c3" and args.priority_ticks > 0:
-        # the same size with three user-priority levels (SURVEY §8d's C3 mix, 80/15/5 %): priority cuts couple every worker, the model is one
-        # 8 k-column x 22 k-row component and the tick is dominated by the host-side exact solve (reported, not the headline: BASELINE.json's
-        # config names no priorities)
-        sp = workloads.make("c3p", seed=args.seed)
-        tp = Tick(cfg)
-        tp.upload_ready(sp.task_id, sp.task_priority, sp.task_rq, sorted_=True)
-        scp = sp.to_c()
-        tl, info = [], None
-        for _ in range(args.priority_ticks):
-            t0 = time.perf_counter(); rp = tp.tick_raw(scp, resident=True); tl.append(time.perf_counter() - t0)
-            info = (rp.status, int(rp.is_optimal), tp.kernel_stats(), rp.t_solve_us)
-            ncp = rp.n_counts  # (rq, variant, worker index) -> count of the last tick, for the objective comparison below
-            gdp = dict(zip(zip(abi._np(rp.count_rq, ncp, np.uint32).tolist(), abi._np(rp.count_variant, ncp, np.uint8).tolist(), abi._np(rp.count_worker, ncp, np.uint32).tolist()),
-                           abi._np(rp.count_value, ncp, np.uint32).tolist())) if ncp else {}
-        out["multi_priority"] = {"workload": "c3p: c3 with user priorities {0, 1, 2} at 80/15/5 %", "ticks": args.priority_ticks, "p50_tick_ms": 1e3 * float(np.median(tl)),
-                                 "status": info[0], "is_optimal": bool(info[1]), "assigned_per_tick": int(info[2]["n_assigned"]), "prefilled_per_tick": int(info[2]["n_prefilled"]),
-                                 "solve_ms": info[3] / 1e3, "tasks_assigned_per_sec": int(info[2]["n_assigned"]) / float(np.median(tl)),
-                                 "model": {"columns": int(info[2]["milp_cols"]), "rows": int(info[2]["milp_rows"]), "note": "rows no point within the column bounds can violate are not emitted (DESIGN.md §4b)"},
-                                 "coupled_solve": {"build_model_ms": info[2]["model_us"] / 1e3, "solve_ms": info[2]["milp_us"] / 1e3, "price_solve_ms": info[2]["price_us"] / 1e3,
-                                                   "sweeps_ms": info[2]["price_sweep_us"] / 1e3, "sweeps": int(info[2]["price_sweeps"]), "flag_configurations": int(info[2]["price_rounds"])},
-                                 "price_sweep_kernel": {"kernel": "k_price_sweep", "blocks_per_sweep": 1024, "avg_sweep_us": (info[2]["price_sweep_us"] / info[2]["price_sweeps"]) if info[2]["price_sweeps"] else None,
-                                                        "block_solves_per_s": (1024 * info[2]["price_sweeps"] / (info[2]["price_sweep_us"] * 1e-6)) if info[2]["price_sweep_us"] > 0 else None,
-                                                        "bound": "latency / integer-f64 ALU in LDS: one wavefront per worker block (exact bounded knapsack under the current prices), 25.9 KB of LDS = six blocks resident per CU (1536 on the chip: a sweep of up to that many blocks is one round); "
-                                                                 "not an HBM kernel (a block reads 0.5-2 KB), not MFMA work; figure of merit: exact block solves per second (launch -> totals in pinned memory)"},
-                                 "is_optimal_means": "certified within HiGHS's default mip_rel_gap = 1e-4, which is all the reference's solve_bounded asks for (solver/highs.rs:65-68)"}
-        if args.cpu_ticks > 0:
-            try:  # the same snapshot through the reference-configured HiGHS (one tick, 5 s limit as in the reference): what the drop-in replaces on this workload
-                from oracle.oracle import Oracle
-                op = Oracle(abi.make_config(time_limit_s=5.0), reference_solver_options=True)
-                t0 = time.perf_counter(); wp = op.tick(sp); tcp = time.perf_counter() - t0
-                mp = op.last_model()
-                xg = np.asarray([gdp.get((int(mp["crq"][j]), int(mp["cvariant"][j]), int(mp["cworker"][j])), 0) if mp["ctype"][j] == 0 else 0 for j in range(len(mp["obj"]))], np.float64)
-                out["multi_priority"]["objective"] = {"gpu_tick": float(np.dot(mp["obj"], xg)), "cpu_baseline": float(mp["objective"])}
-                out["multi_priority"]["cpu_baseline"] = {"tick_s": tcp, "is_optimal": bool(wp.is_optimal), "kind": "port", "cores": 1, "cpu": cpu_model(),
-                                                         "assigned_per_tick": sum(1 for recs in wp.records for (_, _, k) in recs if k == abi.HQ_REC_ASSIGN),
-                                                         "sample": "1 tick of the full c3p workload, HiGHS 1.8.0 with the reference's options (time_limit = 5 s only)"}
-            except Exception as e:
-                out["multi_priority"]["cpu_baseline"] = {"error": repr(e)}
-        tp.close()
-        # ... and the same three priority levels on a BUSY cluster (workloads.make_steady: every worker runs a packed mix of which 10 % just finished, ~930 distinct free
+    if world == 1 and not args.force_sharded and args.workload == "c3p" and args.priority_ticks > 0:
+        # the same three priority levels on a BUSY cluster (workloads.make_steady: every worker runs a packed mix of which 10 % just finished, ~930 distinct free
         # vectors): the everyday production tick — priorities AND heterogeneous workers.  The cuts make it one coupled model of all 1024 workers.
         try:
             ss = workloads.make_steady("c3p", seed=args.seed)
@@ -855,9 +933,7 @@ def main():
             out["multi_priority_busy_cluster"] = {"workload": "c3p on a cluster mid-run (workloads.make_steady('c3p')): 1 M ready tasks at three priority levels, 1024 workers with ~930 distinct free vectors",
                                                   "p50_tick_ms": 1e3 * float(np.median(tl2[1:])), "status": inf2[0], "is_optimal": bool(inf2[1]), "assigned_per_tick": int(inf2[2]["n_assigned"]),
                                                   "prefilled_per_tick": int(inf2[2]["n_prefilled"]), "model_columns": int(inf2[2]["milp_cols"]), "model_rows": int(inf2[2]["milp_rows"]),
-                                                  "price_sweeps": int(inf2[2]["price_sweeps"]), "coupled_solve_ms": inf2[2]["milp_us"] / 1e3, "build_model_ms": inf2[2]["model_us"] / 1e3,
-                                                  "note": "round 2's host search ran into its limit on this tick (status NEED_MORE_COMPUTE after seconds); the first price sweep's own patterns are feasible "
-                                                          "for the wide rows here, so one sweep certifies it"}
+                                                  "price_sweeps": int(inf2[2]["price_sweeps"]), "coupled_solve_ms": inf2[2]["milp_us"] / 1e3, "build_model_ms": inf2[2]["model_us"] / 1e3}
             if args.cpu_ticks > 0:
                 from oracle.oracle import Oracle
                 oq = Oracle(abi.make_config(time_limit_s=5.0), reference_solver_options=True)
@@ -885,31 +961,36 @@ def main():
                                           "sweeps_ms": inf4[2]["price_sweep_us"] / 1e3, "avg_sweep_us": (inf4[2]["price_sweep_us"] / inf4[2]["price_sweeps"]) if inf4[2]["price_sweeps"] else None,
                                           "coupled_solve_ms": inf4[2]["milp_us"] / 1e3, "build_model_ms": inf4[2]["model_us"] / 1e3,
                                           "tasks_assigned_per_sec": int(inf4[2]["n_assigned"]) / float(np.median(tl4[1:])),
-                                          "note": "4096 blocks of 16 columns per sweep: four rounds of resident workgroups on the 256 CUs; parity: tests/test_gpu_price.py::test_config4_unsaturated_full_tick_on_the_gpu"}
+                                          "note": "4096 blocks of 16 columns per sweep; parity: tests/test_gpu_price.py::test_config4_unsaturated_full_tick_on_the_gpu"}
         except Exception as e:
             out["config4_unsaturated"] = {"error": repr(e)}
     if world == 1 and args.cpu_ticks > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(snap, args.cpu_ticks)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-            out["tick_latency_ratio_vs_cpu"] = out["cpu_baseline"]["tick_s"] / float(np.median(lat))
+            out["tick_latency_ratio_vs_cpu"] = out["cpu_baseline"]["tick_s"] / p50
+            if coupled:
+                try:  # both sides maximise the same objective: c.x of the GPU tick's counts in the oracle's own model of the snapshot
+                    res = step()
+                    ncp = res.n_counts
+                    gdp = dict(zip(zip(abi._np(res.count_rq, ncp, np.uint32).tolist(), abi._np(res.count_variant, ncp, np.uint8).tolist(), abi._np(res.count_worker, ncp, np.uint32).tolist()),
+                                   abi._np(res.count_value, ncp, np.uint32).tolist())) if ncp else {}
+                    mp = out["cpu_baseline"].pop("_model")
+                    xg = np.asarray([gdp.get((int(mp["crq"][j]), int(mp["cvariant"][j]), int(mp["cworker"][j])), 0) if mp["ctype"][j] == 0 else 0 for j in range(len(mp["obj"]))], np.float64)
+                    out["objective"] = {"gpu_tick": float(np.dot(mp["obj"], xg)), "cpu_baseline": float(mp["objective"]), "cpu_baseline_is_optimal": out["cpu_baseline"].get("is_optimal"),
+                                        "note": "same snapshot, same objective (scheduler/solver.rs:542-571); the reference-configured HiGHS stops at its 5 s time limit on this model"}
+                except Exception as e:  # noqa: BLE001
+                    out["objective"] = {"error": repr(e)}
+            out["cpu_baseline"].pop("_model", None)
         except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
             out["cpu_baseline"] = {"error": repr(e)}
-    if world == 1 and not args.force_sharded and args.workload == "c3" and args.wire_iters > 0:
+    if world == 1 and not args.force_sharded and snap1 is not None and args.wire_iters > 0:
         out["wire"] = wire_block(args.wire_iters)
-    # The headline is the best case twice over (one priority level: the placement separates into one 8-column block; the same tick repeated on a resident set, nothing
-    # consumed).  Its two honest neighbours ride right behind `value`: the same workload inside add -> tick -> consume, and SURVEY §8d's C3 as written, with three
-    # priority levels (one coupled model of all workers).  Details of both further down the line (`steady_state`, `multi_priority`).
-    nb = {}
-    ss, mp_ = out.get("steady_state"), out.get("multi_priority")
-    if isinstance(ss, dict) and "tasks_per_s" in ss:
-        nb["steady_state_add_tick_consume"] = {"tasks_handed_out_per_sec": ss["tasks_per_s"], "p50_step_ms": ss["p50_step_ms"], "p50_tick_us_inside_the_loop": ss["p50_tick_us"]}
-    if isinstance(mp_, dict) and "tasks_assigned_per_sec" in mp_:
-        nb["c3_with_three_priority_levels"] = {"tasks_assigned_per_sec": mp_["tasks_assigned_per_sec"], "p50_tick_ms": mp_["p50_tick_ms"], "is_optimal": mp_["is_optimal"]}
     head = ("metric", "value", "unit")
-    out = {**{k: out[k] for k in head}, "value_is": "cold c3 tick, one priority level, repeated on the resident ready set (best case); see `neighbours`", "neighbours": nb,
-           **{k: v for k, v in out.items() if k not in head}}
-    if dist is not None and args.multi_extras:
+    out = {**{k: out[k] for k in head}, "value_is": (f"cold {args.workload} tick with {n_levels} priority level(s), repeated on the resident ready set: tasks assigned per second of wall time "
+                                                    "(every tick certified: status DONE, is_optimal)" if all_done else f"cold {args.workload} tick; NOT every timed tick was certified"),
+           "neighbours": nb, **{k: v for k, v in out.items() if k not in head}}
+    if dist is not None and args.multi_extras and not args.headline_only:
         # after everything the line is quoted on: if a rank gets lost in there, the watchdog prints the line as it stands and ends the process
         wd = watchdog(args.extras_timeout, lambda: print(json.dumps(dict(out, multi_rank={"error": f"did not come back within {args.extras_timeout:.0f} s"}))))
         out["multi_rank"] = multi_rank_extras(cfg, rank, world, local_rank)

@@ -1096,7 +1096,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     }
     m.row_implied.resize(m.nrows(), 0);
     const double t_model1 = clock_us();
-    if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu worker signatures, %zu (batch, cut, blocker) passes over the workers\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), sig_ids.size(), n_triples);
+    if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu terms, %zu worker signatures, %zu (batch, cut, blocker) passes over the workers\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), m.rcol.size(), sig_ids.size(), n_triples);
     hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438
     out.pre_us = t_model0 - t_enter; out.model_us = t_model1 - t_model0; out.milp_us = clock_us() - t_model1; out.price_sweeps = sol.price_sweeps; out.price_rounds = sol.price_rounds; out.price_us = sol.price_total_us;
     out.milp_nodes = sol.nodes; out.milp_cols = m.ncols(); out.milp_rows = m.nrows(); out.milp_components = sol.n_components;

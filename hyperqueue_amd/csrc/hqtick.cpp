@@ -92,7 +92,7 @@ struct hqtick_ctx {
     uint64_t add_staged_n = 0;  // tasks hqtick_ready_add_stage made room for (0: nothing staged)
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
-    bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true;  // level table of the previous tick (re-validated by K1 every tick)
+    bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true, timing_k1 = false;  // (timing_k1: events around K1 alone, hqtick_set_kernel_timing(ctx, 2))  // level table of the previous tick (re-validated by K1 every tick)
     PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_addp, h_retr, h_blk, h_k5a;
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
     hqprice::DeviceSweeper *pricer = nullptr;  // k_price_sweep: the block sweeps of the coupled placement (csrc/price.hip); HQTICK_PRICE=0 keeps coupled ticks on the host search
@@ -439,7 +439,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
                                                                                  // 32 k slices of 2048 tasks keep K1 / K4 at 8 k workgroups and K1b at 8 steps)
             g.tasks_per_wave = (uint32_t)tpw; g.n_waves = (uint32_t)((N + tpw - 1) / tpw); g.tab_stride = (g.n_waves + 15u) & ~15u;
             if (!ctx->d_wave_tab.ensure((size_t)g.tab_stride * sc->G * 4) || !ctx->d_gkey.ensure(N * 2 + 16)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc histogram");
-            if (ctx->timing) hqk::time_next_launch(ctx->ev[2], ctx->ev[3]);
+            if (ctx->timing || ctx->timing_k1) hqk::time_next_launch(ctx->ev[2], ctx->ev[3]);
             if (ctx->k2_own_stream) HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc), ctx->stream2));
             HQ_HIP_TIMED(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
                                    ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->k2_on_hist ? &wea : nullptr, ctx->stream));
@@ -481,7 +481,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
                 for (uint32_t q = 0; q < Q; q++) tot += sc->hist[(size_t)l * Q + q];
                 if (tot == 0) ctx->levels_valid = false;
             }
-            if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[2], ctx->ev[3]); if (us_ >= 0) ctx->stats.level_hist_us = us_; }
+            if (ctx->timing || ctx->timing_k1) { const double us_ = elapsed_us(ctx->ev[2], ctx->ev[3]); if (us_ >= 0) ctx->stats.level_hist_us = us_; }
             if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[0], ctx->ev[8]); if (us_ >= 0) ctx->stats.scan_us = us_; }
         }
         return 0;
@@ -2042,6 +2042,8 @@ thread_local hqhost::BlockMemo *g_memo = nullptr; thread_local uint32_t g_last_m
 void hqtick_debug_set_block_memo(int on) { if (on && !g_memo) g_memo = new hqhost::BlockMemo(); if (!on) { delete g_memo; g_memo = nullptr; } }
 uint32_t hqtick_debug_last_block_memo(void) { return g_last_memo; }
 void hqtick_debug_set_price_emulation(int on, uint32_t min_cols) { g_price_emulation = on; g_price_min_cols = min_cols; }
+thread_local int g_price_fault = -1;
+void hqtick_debug_set_price_fault(int fail_at) { g_price_fault = fail_at; }
 // the host stages as ONE RANK of a sharded scheduler: emulated sweeps / class blocks over this rank's share, completed through `fn` (tests/test_sharded.py: gloo)
 thread_local hqtick_exchange_fn g_xfn = nullptr; thread_local void *g_xuser = nullptr; thread_local uint32_t g_xrank = 0, g_xworld = 1, g_xmin_blocks = 1, g_xmin_classes = 1, g_xcalls = 0;
 void hqtick_debug_set_exchange(hqtick_exchange_fn fn, void *user, uint32_t rank, uint32_t world, uint32_t min_blocks, uint32_t min_classes) {
@@ -2086,7 +2088,7 @@ int hqtick_debug_host_stages(const hqtick_config *config, const hqtick_snapshot 
     if (g_block_emulation) { pb.blocks = &emu; pb.block_min_classes = 1; }
     pb.block_verify = g_block_verify; pb.tick_seq = g_tick_seq; pb.memo = g_memo;
     hqprice::EmulatedSweeper pemu;
-    if (g_price_emulation) { pemu.budget = g_block_budget; if (g_price_min_cols) pemu.min_cols = g_price_min_cols; pb.pricer = &pemu; }
+    if (g_price_emulation) { pemu.fail_at = g_price_fault; pemu.budget = g_block_budget; if (g_price_min_cols) pemu.min_cols = g_price_min_cols; pb.pricer = &pemu; }
     hqhost::Counts cnt;
     if (g_xfn && g_xworld > 1) {  // this call is one rank of a sharded scheduler
         struct FnExchange : hqprice::Exchange { bool allgather(const void *snd, void *rcv, size_t bytes) override { return g_xfn(g_xuser, snd, rcv, bytes) == 0; } } xch;
@@ -2251,7 +2253,7 @@ const uint64_t *hqtick_block_profile_last(const hqtick_ctx *ctx, uint32_t *n_cla
 
 int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on) {
     if (!ctx) return HQTICK_E_INVALID;
-    ctx->timing = on != 0;
+    ctx->timing = on == 1; ctx->timing_k1 = on == 2;
     return 0;
 }
 

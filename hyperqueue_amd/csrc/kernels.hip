@@ -220,7 +220,9 @@ __global__ void __launch_bounds__(256) k_worker_eval(EvalArgs ea) {
 // LDS layout: [levels: lds_levels u64][counters: WPB*G u32].
 struct Levels4 { uint64_t v[4]; };
 
-template <int WPB, bool SMALL_L>
+// NCOPY: copies of a wavefront's counter row (lane & (NCOPY - 1) picks one): a tick has a handful of groups, so the 64 lanes of one ds_add hit a handful of
+// addresses and the LDS serialises them per address — with 8 copies at most 8 lanes share a counter.  The copies are summed when the slice is published.
+template <int WPB, bool SMALL_L, int NCOPY>
 __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restrict__ prio, const uint32_t *__restrict__ rq, uint64_t n,
                                                          const uint64_t *__restrict__ levels, Levels4 l4, uint32_t L, uint32_t Q,
                                                          uint32_t tasks_per_wave, uint32_t n_waves, uint32_t stride, uint32_t lds_levels,
@@ -234,11 +236,12 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
     const uint32_t hist_block = blockIdx.x - n_eval_blocks;
     const uint32_t G = L * Q;
     uint64_t *s_levels = reinterpret_cast<uint64_t *>(smem);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)(SMALL_L ? 0 : lds_levels) * 8) + (threadIdx.x >> 6) * G;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)(SMALL_L ? 0 : lds_levels) * 8) + (threadIdx.x >> 6) * G * NCOPY;
     const uint32_t lane = lane_id();
+    uint32_t *my_cnt = s_cnt + (lane & (uint32_t)(NCOPY - 1)) * G;
     const uint32_t wave = hist_block * WPB + (threadIdx.x >> 6);
     if (!SMALL_L) for (uint32_t i = threadIdx.x; i < lds_levels; i += blockDim.x) s_levels[i] = levels[i];
-    for (uint32_t g = lane; g < G; g += 64) s_cnt[g] = 0;
+    for (uint32_t g = lane; g < G * NCOPY; g += 64) s_cnt[g] = 0;
     if (!SMALL_L) __syncthreads();
     if (wave >= n_waves) return;
     const uint64_t *lvp = lds_levels ? s_levels : levels;
@@ -254,7 +257,7 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
         if (lv >= L) { err |= 1u; return GKEY_INVALID; }       // priority missing from the level table
         if (q >= Q) { err |= 2u; return GKEY_INVALID; }        // request id out of range
         const uint32_t g = lv * Q + q;
-        atomicAdd(&s_cnt[g], 1u);
+        atomicAdd(&my_cnt[g], 1u);
         return (uint16_t)g;
     };
     for (uint64_t b = begin; b < end; b += 256) {
@@ -279,7 +282,12 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
     }
     if (err) atomicOr(err_flag, err);
     // publish this slice's counts, transposed to [G][stride] so the scan and K4 read rows contiguously
-    for (uint32_t g = lane; g < G; g += 64) wave_tab[(size_t)g * stride + wave] = s_cnt[g];
+    for (uint32_t g = lane; g < G; g += 64) {
+        uint32_t c = s_cnt[g];
+#pragma unroll
+        for (int k = 1; k < NCOPY; k++) c += s_cnt[(uint32_t)k * G + g];
+        wave_tab[(size_t)g * stride + wave] = c;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K1b
@@ -1076,17 +1084,20 @@ hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, cons
         neb = (ride_along->W + 31) / 32; eval_lds = worker_eval_lds(ride_along->R, ride_along->rt.n_variants, ride_along->n_entries);
     }
     hipError_t e;
-#define HQK_LAUNCH_HIST(WPB, SMALL, GRID, BLOCK)                                                                                                     \
+#define HQK_LAUNCH_HIST(WPB, SMALL, NCOPY, GRID, BLOCK)                                                                                                     \
     do {                                                                                                                                             \
-        size_t lds = (size_t)ll * 8 + (size_t)(WPB) * G * 4;                                                                                          \
+        size_t lds = (size_t)ll * 8 + (size_t)(WPB) * G * 4 * (NCOPY);                                                                                \
         if (eval_lds > lds) lds = eval_lds;                                                                                                          \
-        auto kern = k_level_hist<WPB, SMALL>;                                                                                                        \
+        auto kern = k_level_hist<WPB, SMALL, NCOPY>;                                                                                                        \
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e; \
         HQK_TIMED_LAUNCH(kern, dim3((GRID) + neb), dim3(BLOCK), lds, s, prio, rq, n, levels, l4, L, Q, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, ll, wave_tab, gkey, \
                            err_flag, neb, ea);                                                                                                       \
     } while (0)
-    if (geom.waves_per_block == 4) { if (small) HQK_LAUNCH_HIST(4, true, (geom.n_waves + 3) / 4, 256); else HQK_LAUNCH_HIST(4, false, (geom.n_waves + 3) / 4, 256); }
-    else { if (small) HQK_LAUNCH_HIST(1, true, geom.n_waves, 64); else HQK_LAUNCH_HIST(1, false, geom.n_waves, 64); }
+    if (geom.waves_per_block == 4) {
+        if (small && G <= 64) HQK_LAUNCH_HIST(4, true, 8, (geom.n_waves + 3) / 4, 256);  // a handful of groups: eight copies of the counter row (8 KB of LDS at most)
+        else if (small) HQK_LAUNCH_HIST(4, true, 1, (geom.n_waves + 3) / 4, 256);
+        else HQK_LAUNCH_HIST(4, false, 1, (geom.n_waves + 3) / 4, 256);
+    } else { if (small) HQK_LAUNCH_HIST(1, true, 1, geom.n_waves, 64); else HQK_LAUNCH_HIST(1, false, 1, geom.n_waves, 64); }
 #undef HQK_LAUNCH_HIST
     return hipGetLastError();
 }

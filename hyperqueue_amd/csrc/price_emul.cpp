@@ -15,12 +15,13 @@ bool EmulatedSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     T = &t; caps = t.col_cap; bcaps = t.blk_cap; n_sweeps = 0; cap_sweeps = max_sweeps;
     pats.clear();
     blk_cx.assign(t.n_blocks, 0.0); blk_rc.assign(t.n_blocks, 0.0); blk_bnd.assign(t.n_blocks, 0.0); blk_steps.assign(t.n_blocks, 0);
-    return t.K <= (uint32_t)KMAX;
+    return t.K <= (uint32_t)KMAX && fail_at != 0;
 }
 bool EmulatedSweeper::set_caps(const int32_t *c) { caps.assign(c, c + T->n_cols); return true; }
 bool EmulatedSweeper::set_block_caps(const double *c) { bcaps.assign(c, c + (size_t)T->n_blocks * MMAX); return true; }
 bool EmulatedSweeper::sweep_range(const double *pi, uint32_t b0, uint32_t b1, RangeValues &rv) {
     if (n_sweeps >= cap_sweeps || !T || b1 > T->n_blocks || b0 > b1) return false;
+    if (fail_at >= 1 && n_sweeps == (uint32_t)(fail_at - 1)) return false;
     static thread_local hqblock::Shared *S = new hqblock::Shared();
     hqblock::HostWave wv;
     const HostTables &t = *T;

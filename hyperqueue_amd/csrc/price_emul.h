@@ -16,6 +16,8 @@ struct EmulatedSweeper : Sweeper {
     std::vector<uint32_t> blk_steps;
     std::vector<long long> slots;
     uint32_t n_sweeps = 0, cap_sweeps = 0;
+    // fault injection (hqtick_debug_set_price_fault): begin() refuses the model (fail_at == 0) / the sweep number fail_at - 1 fails (fail_at >= 1); -1: off
+    int fail_at = -1;
     bool begin(const HostTables &t, uint32_t max_sweeps) override;
     bool set_caps(const int32_t *col_cap) override;
     bool set_block_caps(const double *blk_cap) override;

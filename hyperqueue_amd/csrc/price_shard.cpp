@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <vector>
 
 #include "price.h"
 #include "price_core.h"
@@ -42,10 +43,23 @@ void totals_from_blocks(uint32_t nb, uint32_t K, const double *cx, const double 
 
 bool ShardedSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     inner.budget = budget;
-    if (!inner.begin(t, max_sweeps)) return false;
-    T = &t; n_sweeps = 0;
-    pass = ex.world <= 1 || t.n_blocks < min_blocks;
-    if (pass) return true;
+    const bool inner_ok = inner.begin(t, max_sweeps);
+    T = nullptr; n_sweeps = 0;
+    pass = ex.world <= 1 || t.n_blocks < min_blocks;   // (a function of the model alone: the same on every rank)
+    if (pass) { if (inner_ok) T = &t; return inner_ok; }
+    {   // A sharded model: every rank owes the others its part of every sweep's all-gather.  A rank whose device refused the model must not leave alone (the others
+        // would wait for it in the first sweep): ONE status word is exchanged before anything else, and all ranks take the sweeps or leave them together — the
+        // way ShardedBlocks (csrc/hqtick.cpp) treats a failed inner solver.
+        uint64_t mine = inner_ok ? 1u : 0u;
+        std::vector<uint64_t> all(ex.world, 0);
+        const double t0 = now_s();
+        if (!ex.allgather(&mine, all.data(), 8)) { if (inner_ok) inner.end(); return false; }
+        ex.us += (now_s() - t0) * 1e6; ex.n_calls++; ex.n_bytes += 8 * (size_t)ex.world;
+        bool everyone = true;
+        for (uint64_t v : all) everyone = everyone && v == 1u;
+        if (!everyone) { if (inner_ok) inner.end(); return false; }
+    }
+    T = &t;
     const uint32_t W = ex.world, nb = t.n_blocks, per = part_size(nb);
     rank_b0.assign(W, 0); rank_b1.assign(W, 0); rank_p0.assign(W, 0); rank_p1.assign(W, 0);
     max_blocks = max_parts = max_cols = 0;
@@ -67,28 +81,29 @@ bool ShardedSweeper::sweep(const double *pi, SweepTotals &out) {
     const HostTables &t = *T;
     const uint32_t me = ex.rank, W = ex.world, mb = max_blocks, mp = max_parts, K = t.K;
     RangeValues rv;
-    if (!inner.sweep_range(pi, rank_b0[me], rank_b1[me], rv)) return false;
+    const bool mine_ok = inner.sweep_range(pi, rank_b0[me], rank_b1[me], rv);   // a failed local sweep still takes part in the exchange (flag bit 1): the others are waiting in it
     const size_t o_cx = 8, o_rc = o_cx + (size_t)mb * 8, o_bnd = o_rc + (size_t)mb * 8, o_act = o_bnd + (size_t)mb * 8, o_st = o_act + (size_t)mp * K * 8, bytes = al8(o_st + (size_t)mb * 4);
     send.assign(bytes, 0); recv.resize(bytes * W);
     {
         const uint32_t b0 = rank_b0[me], n = rank_b1[me] - b0, p0 = rank_p0[me], np_ = rank_p1[me] - p0;
-        const uint64_t flag = now_s() > guard_s ? 1u : 0u;
+        const uint64_t flag = (now_s() > guard_s ? 1u : 0u) | (mine_ok ? 0u : 2u);
         memcpy(send.data(), &flag, 8);
-        if (n) { memcpy(send.data() + o_cx, rv.cx + b0, (size_t)n * 8); memcpy(send.data() + o_rc, rv.rc + b0, (size_t)n * 8); memcpy(send.data() + o_bnd, rv.bnd + b0, (size_t)n * 8);
+        if (n && mine_ok) { memcpy(send.data() + o_cx, rv.cx + b0, (size_t)n * 8); memcpy(send.data() + o_rc, rv.rc + b0, (size_t)n * 8); memcpy(send.data() + o_bnd, rv.bnd + b0, (size_t)n * 8);
                  memcpy(send.data() + o_st, rv.steps + b0, (size_t)n * 4); }
-        if (np_) memcpy(send.data() + o_act, rv.part_act + (size_t)p0 * K, (size_t)np_ * K * 8);
+        if (np_ && mine_ok) memcpy(send.data() + o_act, rv.part_act + (size_t)p0 * K, (size_t)np_ * K * 8);
     }
     const double t0 = now_s();
     if (!ex.allgather(send.data(), recv.data(), bytes)) return false;
     ex.us += (now_s() - t0) * 1e6; ex.n_calls++; ex.n_bytes += bytes * W;
-    bool up = false;
+    bool up = false, someone_failed = false;
     for (uint32_t r = 0; r < W; r++) {
         const unsigned char *b = recv.data() + (size_t)r * bytes;
-        uint64_t flag; memcpy(&flag, b, 8); up = up || flag != 0;
+        uint64_t flag; memcpy(&flag, b, 8); up = up || (flag & 1u) != 0; someone_failed = someone_failed || (flag & 2u) != 0;
         const uint32_t b0 = rank_b0[r], n = rank_b1[r] - b0, p0 = rank_p0[r], np_ = rank_p1[r] - p0;
         if (n) { memcpy(cx.data() + b0, b + o_cx, (size_t)n * 8); memcpy(rc.data() + b0, b + o_rc, (size_t)n * 8); memcpy(bnd.data() + b0, b + o_bnd, (size_t)n * 8); memcpy(steps.data() + b0, b + o_st, (size_t)n * 4); }
         if (np_) memcpy(part_act.data() + (size_t)p0 * K, b + o_act, (size_t)np_ * K * 8);
     }
+    if (someone_failed) return false;   // every rank sees the same flags: all of them hand the model to the host search, at the same sweep
     if (up) time_up = true;
     totals_from_blocks(t.n_blocks, K, cx.data(), rc.data(), bnd.data(), steps.data(), part_act.data(), out);
     n_sweeps++;
@@ -103,23 +118,26 @@ const uint16_t *ShardedSweeper::patterns(uint32_t first, uint32_t count) {
     const uint32_t me = ex.rank, W = ex.world, mc = max_cols, nc = t.n_cols;
     pats.assign((size_t)count * nc + 1, 0);
     if (count == 0) return pats.data();
-    const uint16_t *mine = inner.patterns(first, count);
-    if (!mine) return nullptr;
-    const size_t bytes = al8((size_t)count * mc * 2);
+    const uint16_t *mine = inner.patterns(first, count);   // nullptr: this rank's copy failed — it still takes part in the exchange ([u64 ok][patterns]) and all ranks give up together
+    const size_t bytes = al8(8 + (size_t)count * mc * 2);
     send.assign(bytes, 0); recv.resize(bytes * W);
     {
+        const uint64_t ok = mine ? 1u : 0u;
+        memcpy(send.data(), &ok, 8);
         const uint32_t c0 = t.blk_off[rank_b0[me]], n = t.blk_off[rank_b1[me]] - c0;
-        for (uint32_t s = 0; s < count && n; s++) memcpy(send.data() + (size_t)s * mc * 2, mine + (size_t)s * nc + c0, (size_t)n * 2);
+        for (uint32_t s = 0; s < count && n && mine; s++) memcpy(send.data() + 8 + (size_t)s * mc * 2, mine + (size_t)s * nc + c0, (size_t)n * 2);
     }
     const double t0 = now_s();
     if (!ex.allgather(send.data(), recv.data(), bytes)) return nullptr;
     ex.us += (now_s() - t0) * 1e6; ex.n_calls++; ex.n_bytes += bytes * W;
+    bool everyone = true;
     for (uint32_t r = 0; r < W; r++) {
         const uint32_t c0 = t.blk_off[rank_b0[r]], n = t.blk_off[rank_b1[r]] - c0;
         const unsigned char *b = recv.data() + (size_t)r * bytes;
-        for (uint32_t s = 0; s < count && n; s++) memcpy(pats.data() + (size_t)s * nc + c0, b + (size_t)s * mc * 2, (size_t)n * 2);
+        uint64_t ok; memcpy(&ok, b, 8); everyone = everyone && ok == 1u;
+        for (uint32_t s = 0; s < count && n; s++) memcpy(pats.data() + (size_t)s * nc + c0, b + 8 + (size_t)s * mc * 2, (size_t)n * 2);
     }
-    return pats.data();
+    return everyone ? pats.data() : nullptr;
 }
 
 }  // namespace hqprice

@@ -323,9 +323,10 @@ class Tick:
             raise HqTickError(rc, self._err())
         return us.value
 
-    def set_kernel_timing(self, on: bool):
+    def set_kernel_timing(self, on):
+        """False / True: every measured kernel; 2: K1 (k_level_hist) alone"""
         self._lib.hqtick_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
-        self._chk(self._lib.hqtick_set_kernel_timing(self._ctx, 1 if on else 0))
+        self._chk(self._lib.hqtick_set_kernel_timing(self._ctx, 2 if on == 2 else (1 if on else 0)))
 
     def kernel_stats(self) -> dict:
         ks = abi.KernelStatsC()

@@ -594,7 +594,9 @@ typedef struct hqtick_kernel_stats {
 int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
 /* Switch the per-kernel timing on / off at run time (HQTICK_FLAG_NO_KERNEL_TIMING sets the initial state).  When on, the measured kernels are
  * bracketed by start / stop events AT THE DISPATCH (hipExtLaunchKernel): the duration is the kernel's own, the figure rocprofv3's kernel trace
- * reports, without the latency of markers queued around it. */
+ * reports, without the latency of markers queued around it.  on = 2: the events go around K1 alone (k_level_hist, the launch that streams the ready
+ * set: the kernel the roofline figure is quoted on) — what bench.py's timed region runs with, so that every K1 launch of the run is measured the same
+ * way and the live figure and a rocprofv3 kernel trace of the same command describe the same launches. */
 int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on);
 #if defined(__GNUC__)
 #pragma GCC visibility pop

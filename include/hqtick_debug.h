@@ -83,6 +83,9 @@ const uint64_t *hqtick_block_profile_last(const hqtick_ctx *ctx, uint32_t *n_cla
  * on != 0: hqtick_debug_host_stages (this thread) hands coupled models of at least min_cols columns (0: the default) to the sweeps — the code path
  * of a GPU tick, minus the hardware. */
 void hqtick_debug_set_price_emulation(int on, uint32_t min_cols);
+/* fault injection into this thread's emulated sweeps: fail_at = 0: the sweeper refuses the model at begin(); k >= 1: its k-th sweep fails; -1: off.  (A rank of a
+ * sharded solve whose device fails must still take part in the exchange the others wait in: tests/test_shard_solve.py) */
+void hqtick_debug_set_price_fault(int fail_at);
 /* sweeps over all blocks / flag configurations of the last hqtick_debug_host_stages call (0: the host search ran alone) */
 void hqtick_debug_last_price(uint32_t *sweeps, uint32_t *rounds);
 /* hqtick_debug_milp_solve on a model that carries the builder's structure hints (col_group: block of every column, -1 = a column of the whole model;

@@ -217,3 +217,37 @@ def test_two_processes_over_gloo():
         assert p.exitcode == 0
     for (_, out) in res:
         assert all(out.values()), res
+
+
+@pytest.mark.parametrize("fail_at", [0, 1, 4])
+def test_a_rank_whose_sweeper_fails_does_not_leave_the_others_in_the_exchange(fail_at):
+    """rank 1's sweeper refuses the model at begin() (0) or fails its 1st / 4th sweep.  It still takes part in the exchange the other ranks wait in, carries
+    a 'failed' flag, and ALL ranks hand the model to the host search at the same point — same answer on every rank, no rank blocked (the join would time out)."""
+    lib = _lib()
+    lib.hqtick_debug_set_price_fault.argtypes = [C.c_int]
+    snap = COUPLED["c3p-64"]()
+    world = 3
+    ex = ThreadExchange(world)
+    out, errs = [None] * world, []
+
+    def main(r):
+        try:
+            lib.hqtick_debug_set_price_fault(fail_at if r == 1 else -1)  # (thread-local)
+            mine = dataclasses.replace(snap, _keep=[])
+            out[r] = _stages(mine, 20.0, 16, False, r, world, ex.fn(r), 1, 1)
+        except BaseException as e:  # noqa: BLE001
+            errs.append((r, e)); ex.bar.abort()
+        finally:
+            lib.hqtick_debug_set_price_fault(-1)
+
+    ts = [threading.Thread(target=main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+        assert not t.is_alive(), "a rank is still waiting in the exchange"
+    assert not errs, errs
+    for (got, sw, rd, _calls) in out[1:]:
+        _same(got, out[0][0])
+        assert (sw, rd) == (out[0][1], out[0][2])
+    assert out[0][0].status in (abi.HQTICK_DONE, abi.HQTICK_NEED_MORE_COMPUTE)
