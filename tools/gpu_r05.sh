@@ -1,0 +1,47 @@
+#!/usr/bin/env bash
+# GPU-side steps of round 5, one script:   gpurun --timeout N -- 'bash tools/gpu_r05.sh <step> [...]'
+# Everything lands under gpurun_out/r05/; the summaries worth keeping are copied into profiles/r05/ afterwards (profiles/r05/README.md says which call made which file).
+set -u
+export TMPDIR=/tmp
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/r05
+mkdir -p "$OUT"
+HEAD="python $ROOT/bench.py --steps 50 --warmup 5 --headline-only"
+run_trace() {  # name, command...
+  local name=$1; shift
+  ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- "$@" > "$OUT/$name.log" 2>&1 )
+  python profiles/summarize.py "$OUT/$name" > "$OUT/$name.summary.csv" 2>> "$OUT/$name.log"
+}
+run_pmc() {  # name, counter(s), command...
+  local name=$1 c=$2; shift 2
+  ( cd /tmp && timeout 500 rocprofv3 --pmc $c --output-format csv -d "$OUT/${name}_${c// /_}" -- "$@" > "$OUT/${name}_${c// /_}.log" 2>&1 )
+  python profiles/summarize.py "$OUT/${name}_${c// /_}" > "$OUT/${name}_${c// /_}.summary.csv" 2>> "$OUT/${name}_${c// /_}.log"
+}
+for step in "$@"; do
+case $step in
+  tests)     timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 | tee "$OUT/gpu_suite.log" ;;
+  smoke)     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.log" ;;
+  bench)     timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 600 "$OUT/bench.err"; python tools/bench_digest.py "$OUT/bench.json" ;;
+  headline)  timeout 300 $HEAD > "$OUT/bench_headline.json" 2> "$OUT/bench_headline.err"; tail -c 400 "$OUT/bench_headline.err"; python tools/bench_digest.py "$OUT/bench_headline.json" ;;
+  trace)     # the headline command under the kernel trace: K1 / k_price_sweep per launch, and the line it printed while traced
+             run_trace bench_c3p $HEAD
+             python profiles/per_launch.py "$OUT/bench_c3p" k_level_hist > "$OUT/k1_per_launch.txt" 2>&1
+             python profiles/per_launch.py "$OUT/bench_c3p" k_price_sweep > "$OUT/sweep_per_launch.txt" 2>&1
+             grep '^{' "$OUT/bench_c3p.log" | tail -1 > "$OUT/bench_c3p_under_rocprof.json"; python tools/bench_digest.py "$OUT/bench_c3p_under_rocprof.json"
+             cat "$OUT/bench_c3p.summary.csv" ;;
+  pmc)       for c in FETCH_SIZE WRITE_SIZE; do run_pmc bench_c3p $c $HEAD; done; head -12 "$OUT"/bench_c3p_FETCH_SIZE.summary.csv "$OUT"/bench_c3p_WRITE_SIZE.summary.csv ;;
+  sweepctr)  # what the sweep kernel's waves do: VALU / LDS activity of k_price_sweep (own passes, --pmc only)
+             run_pmc sweepctr "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" $HEAD
+             run_pmc sweepctr2 "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" $HEAD
+             grep -h "price_sweep\|^kernel" "$OUT"/sweepctr*.summary.csv ;;
+  stage)     HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p wave --no-host --repeat 2 2>&1 | grep -E "price profile|price \{" | tee "$OUT/price_sweep_stage_profile.txt" ;;
+  coupled)   timeout 600 python tools/price_probe.py c3p wave 0.2 0.45 --no-host --timeline --repeat 1 2>&1 | grep -E "timeline|price " | tee "$OUT/coupled_ticks.txt" ;;
+  pricetests) timeout 900 python -m pytest tests/test_gpu_price.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -6 | tee "$OUT/gpu_price_tests.log" ;;
+  preflight) timeout 200 python bench.py --gpus 1 --preflight 2>&1 | tail -3 | tee "$OUT/preflight.log" ;;
+  campaign)  timeout 1200 python tools/gpu_price_campaign.py 2>&1 | tail -12 | tee "$OUT/price_campaign.txt" ;;
+  clean)     find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} + ;;
+  *)         echo "unknown step $step" ;;
+esac
+done
+find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} + 2>/dev/null
+true
