@@ -752,6 +752,11 @@ def main():
         elapsed = float(t.item())
     ks = kstats[-1]
     assigned, prefilled = int(ks["n_assigned"]), int(ks["n_prefilled"])  # whole-job counts: the placement is replicated on every rank
+    # (rq, variant, worker index) -> count of the last timed tick, for the objective comparison with the CPU baseline further down (the result arrays belong to the
+    # context and live until its next tick; the snapshot's C view is re-made by whoever calls snap.to_c() next — so this is read here)
+    ncp = int(res.n_counts)
+    gdp = dict(zip(zip(abi._np(res.count_rq, ncp, np.uint32).tolist(), abi._np(res.count_variant, ncp, np.uint8).tolist(), abi._np(res.count_worker, ncp, np.uint32).tolist()),
+                   abi._np(res.count_value, ncp, np.uint32).tolist())) if (ncp and rank == 0) else {}
     if rank != 0:
         if dist is not None:
             if args.multi_extras and not args.headline_only:
@@ -971,10 +976,6 @@ def main():
             out["tick_latency_ratio_vs_cpu"] = out["cpu_baseline"]["tick_s"] / p50
             if coupled:
                 try:  # both sides maximise the same objective: c.x of the GPU tick's counts in the oracle's own model of the snapshot
-                    res = step()
-                    ncp = res.n_counts
-                    gdp = dict(zip(zip(abi._np(res.count_rq, ncp, np.uint32).tolist(), abi._np(res.count_variant, ncp, np.uint8).tolist(), abi._np(res.count_worker, ncp, np.uint32).tolist()),
-                                   abi._np(res.count_value, ncp, np.uint32).tolist())) if ncp else {}
                     mp = out["cpu_baseline"].pop("_model")
                     xg = np.asarray([gdp.get((int(mp["crq"][j]), int(mp["cvariant"][j]), int(mp["cworker"][j])), 0) if mp["ctype"][j] == 0 else 0 for j in range(len(mp["obj"]))], np.float64)
                     out["objective"] = {"gpu_tick": float(np.dot(mp["obj"], xg)), "cpu_baseline": float(mp["objective"]), "cpu_baseline_is_optimal": out["cpu_baseline"].get("is_optimal"),

@@ -43,18 +43,46 @@ struct Prob {
     std::vector<double> h;                     // wide rows in <= form
     std::vector<uint8_t> ge;                   // the row was a `>=` row (entered negated)
     std::vector<std::vector<std::pair<int, double>>> g_rows;   // per global column: (wide row, coefficient in <= form)
-    std::vector<int> r_off, r_col; std::vector<int32_t> r_coef;  // wide rows row-wise over the flat columns
-    std::vector<uint32_t> c_off; std::vector<uint16_t> c_row; std::vector<int32_t> c_coef;  // ... and column-wise (host side: rounding and repair work per ROW)
     // Wide rows with the same left-hand side over the block columns (the cut rows of one batch against its several blockers differ in their flag only) share
-    // ONE activity: the device prices and accumulates per GROUP (T.K groups, price of a group = sum of its rows' prices), the host expands to rows.
+    // ONE activity: the device prices and accumulates per GROUP (T.K groups, price of a group = sum of its rows' prices), and the host keeps the left-hand
+    // sides per group as well — row-wise here, column-wise in T.col_woff / T.w_row / T.w_coef — and expands to rows where a row's own right-hand side matters
+    // (c3p at BASELINE size: 70 wide rows, 16 distinct left-hand sides, 71 680 against 16 384 terms).
     std::vector<int> grp_of;   // [K] row -> group
     int KG = 0;
+    std::vector<int> g_off, g_col; std::vector<int32_t> g_coef;   // [KG] the distinct left-hand sides over the flat columns, terms in the model's order
+    std::vector<int> gr_off, gr_row;                              // [KG] the rows of a group, ascending
+    size_t row_terms = 0;                                         // terms of the K rows as the model wrote them (statistics)
     std::vector<CapRow> caps;
     std::vector<int32_t> base_cap;
     std::vector<int> block_of_flat;
 };
 
 long long gcd_ll(long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a < 0 ? -a : a; }
+
+// The groups' left-hand sides -> P's row-wise and column-wise tables (P.grp_of, P.KG set; lhs[g] = (flat column, coefficient) in the model's order)
+void finish_groups(Prob &P, const std::vector<std::vector<std::pair<int, int32_t>>> &lhs) {
+    HostTables &T = P.T;
+    const int KG = P.KG;
+    T.K = (uint32_t)KG;
+    size_t tot = 0; for (auto &l : lhs) tot += l.size();
+    P.g_off.assign(1, 0); P.g_off.reserve((size_t)KG + 1); P.g_col.clear(); P.g_col.reserve(tot); P.g_coef.clear(); P.g_coef.reserve(tot);
+    std::vector<uint32_t> gcnt(T.n_cols + 1, 0);
+    for (int g = 0; g < KG; g++) {
+        for (auto &t : lhs[(size_t)g]) { P.g_col.push_back(t.first); P.g_coef.push_back(t.second); gcnt[t.first + 1]++; }
+        P.g_off.push_back((int)P.g_col.size());
+    }
+    T.col_woff.assign(T.n_cols + 1, 0);
+    for (uint32_t f = 0; f < T.n_cols; f++) T.col_woff[f + 1] = T.col_woff[f] + gcnt[f + 1];
+    T.w_row.resize(T.col_woff[T.n_cols]); T.w_coef.resize(T.col_woff[T.n_cols]);
+    std::vector<uint32_t> cur(T.col_woff.begin(), T.col_woff.end() - 1);
+    for (int g = 0; g < KG; g++) for (int e = P.g_off[g]; e < P.g_off[g + 1]; e++) { const uint32_t p = cur[P.g_col[e]]++; T.w_row[p] = (uint16_t)g; T.w_coef[p] = P.g_coef[e]; }
+    // rows of every group, ascending
+    P.gr_off.assign((size_t)KG + 1, 0);
+    for (int k = 0; k < P.K; k++) P.gr_off[P.grp_of[k] + 1]++;
+    for (int g = 0; g < KG; g++) P.gr_off[g + 1] += P.gr_off[g];
+    P.gr_row.resize(P.K);
+    { std::vector<int> c2(P.gr_off.begin(), P.gr_off.end() - 1); for (int k = 0; k < P.K; k++) P.gr_row[c2[P.grp_of[k]]++] = k; }
+}
 
 // The component -> blocks + wide rows.  Returns nullptr on success, else what kept the model on the host.
 const char *build(const Request &rq, Prob &P) {
@@ -198,50 +226,29 @@ const char *build(const Request &rq, Prob &P) {
     P.K = (int)wide.size();
     if (P.K == 0) return "no wide row";
     P.h.resize(P.K); P.ge.resize(P.K); P.g_rows.assign(P.G, {});
-    std::vector<uint32_t> cnt(T.n_cols + 1, 0);
-    P.r_off.assign(1, 0);
-    { size_t tot = 0; for (const WideTmp &w : wide) tot += w.cols.size(); P.r_col.reserve(tot); P.r_coef.reserve(tot); P.r_off.reserve(wide.size() + 1); }
-    std::vector<uint64_t> sig(P.K);   // a hash of every wide row's left-hand side, taken in the same pass (the groups of identical left-hand sides below compare hashes first)
+    std::vector<uint64_t> sig(P.K);   // a hash of every wide row's left-hand side (the groups of identical left-hand sides below compare hashes first)
     for (int k = 0; k < P.K; k++) {
         P.h[k] = wide[k].h; P.ge[k] = wide[k].ge;
         uint64_t hsh = 1469598103934665603ull;
-        for (auto &t : wide[k].cols) {
-            cnt[t.first + 1]++; P.r_col.push_back(t.first); P.r_coef.push_back(t.second);
-            hsh = (hsh ^ (uint64_t)(uint32_t)t.first) * 1099511628211ull; hsh = (hsh ^ (uint64_t)(uint32_t)t.second) * 1099511628211ull;
-        }
-        sig[k] = hsh;
-        P.r_off.push_back((int)P.r_col.size());
+        for (auto &t : wide[k].cols) { hsh = (hsh ^ (uint64_t)(uint32_t)t.first) * 1099511628211ull; hsh = (hsh ^ (uint64_t)(uint32_t)t.second) * 1099511628211ull; }
+        sig[k] = hsh; P.row_terms += wide[k].cols.size();
         for (auto &t : wide[k].g) P.g_rows[t.first].push_back({k, t.second});
     }
-    // row-level column CSR (host)
-    P.c_off.assign(T.n_cols + 1, 0);
-    for (uint32_t f = 0; f < T.n_cols; f++) P.c_off[f + 1] = P.c_off[f] + cnt[f + 1];
-    P.c_row.resize(P.c_off[T.n_cols]); P.c_coef.resize(P.c_off[T.n_cols]);
-    {
-        std::vector<uint32_t> cur(P.c_off.begin(), P.c_off.end() - 1);
-        for (int k = 0; k < P.K; k++) for (auto &t : wide[k].cols) { const uint32_t p = cur[t.first]++; P.c_row[p] = (uint16_t)k; P.c_coef[p] = t.second; }
-    }
-    // groups of rows with identical left-hand sides, and the device's column CSR over groups
+    // groups of rows with identical left-hand sides
     P.grp_of.assign(P.K, -1);
-    {
-        std::vector<int> rep;
-        // (the hash of the left-hand side first: the rows are a thousand terms long, an ordered map of them compares them term by term)
-        for (int k = 0; k < P.K; k++) {
-            int g = -1;
-            for (size_t i = 0; i < rep.size() && g < 0; i++) if (sig[rep[i]] == sig[k] && wide[rep[i]].cols == wide[k].cols) g = (int)i;
-            if (g < 0) { g = (int)rep.size(); rep.push_back(k); }
-            P.grp_of[k] = g;
-        }
-        P.KG = (int)rep.size(); T.K = (uint32_t)P.KG;
-        if (P.KG > KMAX_HOST) return "more than 128 distinct wide left-hand sides";
-        std::vector<uint32_t> gcnt(T.n_cols + 1, 0);
-        for (int g = 0; g < P.KG; g++) for (auto &t : wide[rep[g]].cols) gcnt[t.first + 1]++;
-        T.col_woff.assign(T.n_cols + 1, 0);
-        for (uint32_t f = 0; f < T.n_cols; f++) T.col_woff[f + 1] = T.col_woff[f] + gcnt[f + 1];
-        T.w_row.resize(T.col_woff[T.n_cols]); T.w_coef.resize(T.col_woff[T.n_cols]);
-        std::vector<uint32_t> cur(T.col_woff.begin(), T.col_woff.end() - 1);
-        for (int g = 0; g < P.KG; g++) for (auto &t : wide[rep[g]].cols) { const uint32_t p = cur[t.first]++; T.w_row[p] = (uint16_t)g; T.w_coef[p] = t.second; }
+    std::vector<int> rep;
+    // (the hash of the left-hand side first: the rows are a thousand terms long, an ordered map of them compares them term by term)
+    for (int k = 0; k < P.K; k++) {
+        int g = -1;
+        for (size_t i = 0; i < rep.size() && g < 0; i++) if (sig[rep[i]] == sig[k] && wide[rep[i]].cols == wide[k].cols) g = (int)i;
+        if (g < 0) { g = (int)rep.size(); rep.push_back(k); }
+        P.grp_of[k] = g;
     }
+    P.KG = (int)rep.size();
+    if (P.KG > KMAX_HOST) return "more than 128 distinct wide left-hand sides";
+    std::vector<std::vector<std::pair<int, int32_t>>> lhs((size_t)P.KG);
+    for (int g = 0; g < P.KG; g++) lhs[(size_t)g] = std::move(wide[rep[g]].cols);
+    finish_groups(P, lhs);
     P.base_cap = T.col_cap;
     return nullptr;
 }
@@ -461,8 +468,11 @@ struct Solver {
             wgt[r] = (tight ? 1.0 : 0.02) / std::max(1.0, std::fabs(hB[r]));
         }
         auto block_act = [&](uint32_t b, const uint16_t *x, std::vector<double> &out) {  // A_w x of block b for the pattern row x (flat layout)
-            std::fill(out.begin(), out.end(), 0.0);
-            for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { const uint16_t xv = x[f]; if (!xv) continue; for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) out[P.c_row[e]] += (double)P.c_coef[e] * (double)xv; }
+            // per group (the rows of a group share its left-hand side), then every row its group's value: the sums run over the block's columns in the same order either way
+            double ga[KMAX_HOST];
+            for (int g = 0; g < P.KG; g++) ga[g] = 0.0;
+            for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { const uint16_t xv = x[f]; if (!xv) continue; for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) ga[T.w_row[e]] += (double)T.w_coef[e] * (double)xv; }
+            for (int r = 0; r < K; r++) out[r] = ga[P.grp_of[r]];
         };
         std::vector<uint16_t> x(T.n_cols, 0);
         std::vector<double> cum(K, 0.0), tgt(K, 0.0);
@@ -515,8 +525,8 @@ struct Solver {
             for (int pass = 0; pass < 64 && ge_short(cum) > 0.0; pass++) {
                 const double base = ge_short(cum);
                 cl.clear();
-                std::vector<char> is_short(K, 0);
-                for (int r = 0; r < K; r++) is_short[r] = P.ge[r] && cum[r] > hB[r] + 1e-9;
+                std::vector<int> short_in(P.KG, 0);   // short `>=` rows per group
+                for (int r = 0; r < K; r++) if (P.ge[r] && cum[r] > hB[r] + 1e-9) short_in[P.grp_of[r]]++;
                 for (uint32_t b = 0; b < T.n_blocks; b++) {
                     for (int k : pool) {
                         if (k == chosen[b]) continue;
@@ -528,7 +538,7 @@ struct Solver {
                             const int d = (int)px[f] - (int)x[f];
                             if (!d) continue;
                             differs = true; dv += T.col_cost[f] * (double)d;
-                            for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) if (is_short[P.c_row[e]]) gain -= (double)P.c_coef[e] * (double)d;
+                            for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) { const int ns = short_in[T.w_row[e]]; if (ns) gain -= (double)ns * ((double)T.w_coef[e] * (double)d); }  // (integers in f64: exact, whatever the grouping)
                         }
                         if (!differs || !(gain > 1e-9)) continue;
                         cl.push_back({std::min(gain, base) * 10.0 * cmax + dv, b, k});
@@ -548,7 +558,7 @@ struct Solver {
                         const uint16_t *px = pat_of(cd.k); double gain = 0.0;
                         for (uint32_t f = T.blk_off[cd.b]; f < T.blk_off[cd.b + 1]; f++) {
                             const int d = (int)px[f] - (int)x[f];
-                            if (d) for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) { const int r = P.c_row[e]; if (P.ge[r] && cum[r] > hB[r] + 1e-9) gain -= (double)P.c_coef[e] * (double)d; }
+                            if (d) for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) { const int g = T.w_row[e]; for (int q = P.gr_off[g]; q < P.gr_off[g + 1]; q++) { const int r = P.gr_row[q]; if (P.ge[r] && cum[r] > hB[r] + 1e-9) gain -= (double)T.w_coef[e] * (double)d; } }
                         }
                         if (!(gain > 1e-9)) continue;
                     }
@@ -568,16 +578,17 @@ struct Solver {
         for (int r = 0; r < K; r++) {
             if (cum[r] <= hB[r] + 1e-9) continue;
             std::vector<int> cols;
-            for (int k = P.r_off[r]; k < P.r_off[r + 1]; k++) if (P.r_coef[k] > 0 && x[P.r_col[k]] > 0) cols.push_back(k);
-            std::sort(cols.begin(), cols.end(), [&](int a, int b) { const double ca = T.col_cost[P.r_col[a]] / P.r_coef[a], cb = T.col_cost[P.r_col[b]] / P.r_coef[b]; return ca < cb || (ca == cb && a > b); });
+            const int gr = P.grp_of[r];
+            for (int k = P.g_off[gr]; k < P.g_off[gr + 1]; k++) if (P.g_coef[k] > 0 && x[P.g_col[k]] > 0) cols.push_back(k);
+            std::sort(cols.begin(), cols.end(), [&](int a, int b) { const double ca = T.col_cost[P.g_col[a]] / P.g_coef[a], cb = T.col_cost[P.g_col[b]] / P.g_coef[b]; return ca < cb || (ca == cb && a > b); });
             for (int k : cols) {
-                const int f = P.r_col[k];
+                const int f = P.g_col[k];
                 while (x[f] > (lo_of ? (uint16_t)(*lo_of)[f] : 0) && cum[r] > hB[r] + 1e-9) {
                     bool ok = true;
-                    for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1] && ok; e++) if (P.c_coef[e] < 0 && cum[P.c_row[e]] - (double)P.c_coef[e] > hB[P.c_row[e]] + 1e-9) ok = false;
+                    for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1] && ok; e++) if (T.w_coef[e] < 0) { const int g = T.w_row[e]; for (int q = P.gr_off[g]; q < P.gr_off[g + 1] && ok; q++) if (cum[P.gr_row[q]] - (double)T.w_coef[e] > hB[P.gr_row[q]] + 1e-9) ok = false; }
                     if (!ok) break;
                     x[f]--;
-                    for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) cum[P.c_row[e]] -= (double)P.c_coef[e];
+                    for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) { const int g = T.w_row[e]; for (int q = P.gr_off[g]; q < P.gr_off[g + 1]; q++) cum[P.gr_row[q]] -= (double)T.w_coef[e]; }
                 }
                 if (cum[r] <= hB[r] + 1e-9) break;
             }
@@ -616,7 +627,7 @@ struct Solver {
             const int32_t l = lo_arr[f];
             if (l <= 0) continue;
             node_lo.push_back({f, l}); node_cl += T.col_cost[f] * (double)l;
-            for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) node_Al[P.c_row[e]] += (double)P.c_coef[e] * (double)l;
+            for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) { const int g = T.w_row[e]; for (int q = P.gr_off[g]; q < P.gr_off[g + 1]; q++) node_Al[P.gr_row[q]] += (double)T.w_coef[e] * (double)l; }
             const int b = P.block_of_flat[f];
             for (int r = 0; r < MMAX_BLOCK; r++) bcap[(size_t)b * MMAX_BLOCK + r] -= T.col_a[(size_t)f * MMAX_BLOCK + r] * (double)l;
         }
@@ -727,6 +738,7 @@ Answer solve(const Request &rq, Sweeper &sw) {
     if (const char *why = build(rq, S.P)) { ans.why = why; return ans; }
     tmark("model flattened");
     Prob &P = S.P;
+    if (rq.trace) fprintf(stderr, "[price] %u blocks, %u block columns, %d wide rows with %d distinct left-hand sides (%zu / %zu terms), %d flags, %zu conditional bounds\n", P.T.n_blocks, P.T.n_cols, P.K, P.KG, P.row_terms, P.T.w_row.size(), P.G, P.caps.size());
     const int K = P.K, G = P.G;
     sw.stat_sweeps = 0; sw.stat_sweep_us = 0;
     sw.guard_s = rq.deadline_s - 0.3 * rq.time_limit_s; sw.time_up = false;  // (first read at the first sweep)
@@ -739,9 +751,10 @@ Answer solve(const Request &rq, Sweeper &sw) {
         double cmax = 0.0; for (double c : P.T.col_cost) cmax = std::max(cmax, c);
         for (int k = 0; k < K; k++) {
             double p = 0.0; bool neg = false; int32_t amin = INT32_MAX;
-            for (int t = P.r_off[k]; t < P.r_off[k + 1]; t++) {
-                const int32_t a = P.r_coef[t];
-                if (a > 0) p = std::max(p, P.T.col_cost[P.r_col[t]] / (double)a); else { neg = true; amin = std::min(amin, -a); }
+            const int gk = P.grp_of[k];
+            for (int t = P.g_off[gk]; t < P.g_off[gk + 1]; t++) {
+                const int32_t a = P.g_coef[t];
+                if (a > 0) p = std::max(p, P.T.col_cost[P.g_col[t]] / (double)a); else { neg = true; amin = std::min(amin, -a); }
             }
             if (neg) p = std::max(p, 64.0 * cmax / (double)std::max<int32_t>(1, amin));
             S.pmax[k] = p;
@@ -813,7 +826,11 @@ Answer solve(const Request &rq, Sweeper &sw) {
     auto drop_flags = [&](std::vector<double> &B, const std::vector<double> &x) {
         bool dropped = false;
         std::vector<double> act(K, 0.0);
-        for (int k = 0; k < K; k++) for (int t = P.r_off[k]; t < P.r_off[k + 1]; t++) act[k] += (double)P.r_coef[t] * x[P.model_of[P.r_col[t]]];
+        {
+            std::vector<double> ga(P.KG, 0.0);
+            for (int g = 0; g < P.KG; g++) for (int t = P.g_off[g]; t < P.g_off[g + 1]; t++) ga[g] += (double)P.g_coef[t] * x[P.model_of[P.g_col[t]]];
+            for (int k = 0; k < K; k++) act[k] += ga[P.grp_of[k]];
+        }
         for (int g = 0; g < G; g++) for (auto &t : P.g_rows[g]) act[t.first] += t.second * x[P.gmodel[g]];
         for (int g = 0; g < G; g++) {
             if (B[g] != 1.0 || P.gcost[g] != 0.0 || x[P.gmodel[g]] != 1.0) continue;
@@ -996,13 +1013,19 @@ Answer solve(const Request &rq, Sweeper &sw) {
     ans.bound = std::min(S.relaxed_bound, bp_bound > -INF ? bp_bound : INF);
     ans.sweeps = (uint32_t)sw.stat_sweeps;
     // for the host's guided windows: blocks, their values and the reduced costs at the last prices
-    if (!final_pi.empty()) {
+    // (only what the sweeps leave open goes on to the host's windows: a certified answer needs neither)
+    const bool closed = best_value > -INF && ans.bound <= best_value + rq.rel_gap * std::fabs(best_value);
+    if (!final_pi.empty() && !closed) {
         ans.block_of.assign(rq.n, -1); ans.rcost.assign(rq.n, 0.0);
+        std::vector<std::pair<int, double>> rows;
         for (uint32_t f = 0; f < P.T.n_cols; f++) {
             const int j = P.model_of[f];
             ans.block_of[j] = P.block_of_flat[f];
             double r = P.T.col_cost[f];
-            for (uint32_t e = P.c_off[f]; e < P.c_off[f + 1]; e++) r -= final_pi[P.c_row[e]] * (double)P.c_coef[e];
+            rows.clear();   // the column's rows in ascending order (the order the prices are subtracted in is part of the value's last bits)
+            for (uint32_t e = P.T.col_woff[f]; e < P.T.col_woff[f + 1]; e++) { const int g = P.T.w_row[e]; for (int q = P.gr_off[g]; q < P.gr_off[g + 1]; q++) rows.push_back({P.gr_row[q], (double)P.T.w_coef[e]}); }
+            std::sort(rows.begin(), rows.end());
+            for (auto &t : rows) r -= final_pi[t.first] * t.second;
             ans.rcost[j] = r;
         }
     }
