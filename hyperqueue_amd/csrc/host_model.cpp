@@ -951,6 +951,12 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             group_cols[{batch.rq, g}] = col;
         }
     }
+    // Structure hint for the coupled solve (milp.h: Model::row_lhs): rows whose leading terms are one and the same list — a request's count columns (its batch-size row
+    // and its "blocker short" rows), the columns of the workers on which a blocker leaves no gap (every cut of the batch against that blocker) — carry the list's id.
+    int next_lhs_id = 0;
+    std::vector<int> count_ids;
+    auto count_lhs_id = [&](uint32_t rq) { if (count_ids.size() <= rq) count_ids.resize((size_t)rq + 1, -1); if (count_ids[rq] < 0) count_ids[rq] = next_lhs_id++; return count_ids[rq]; };
+    auto mark_lhs = [&](int id, size_t len) { m.row_lhs.resize((size_t)m.nrows(), -1); m.row_lhs_len.resize((size_t)m.nrows(), 0); if (id >= 0) { m.row_lhs.back() = id; m.row_lhs_len.back() = (int32_t)len; } };
     // priority cuts  :229-430
     std::map<std::pair<uint32_t, uint32_t>, int> short_flags;  // blocked_priority_vars
     auto short_flag = [&](uint32_t rq, uint32_t size) -> int {  // get_bvar  :233-253
@@ -959,7 +965,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         auto cc = count_cols.find(rq);
         if (cc == count_cols.end()) return -1;
         int col = addc(0.0, hqmilp::COL_BOOL, -1);
-        emit_plus(hqmilp::ROW_MIN, (double)size, cc->second, col, (double)size);
+        emit_plus(hqmilp::ROW_MIN, (double)size, cc->second, col, (double)size); mark_lhs(count_lhs_id(rq), cc->second.size());
         short_flags[{rq, size}] = col;
         return col;
     };
@@ -1012,75 +1018,90 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         if (!batch.limit_reached) {  // :264-271
             m.begin_row(hqmilp::ROW_MAX, (double)batch.size);
             for (int c : cc->second) m.term(c, 1.0);
-            m.end_row();
+            m.end_row(); mark_lhs(count_lhs_id(batch.rq), cc->second.size());
         }
         double bsize = (double)batch.size;
         std::vector<uint32_t> capped_by;  // blocked_by_unbounded
+        // What a blocker leaves of every worker depends on (batch, blocker) alone — not on the cut: the workers' gaps, the columns of the workers without a gap
+        // (zero_cond) and the workers with one are worked out ONCE per pair and every cut of the batch against that blocker reads them (c3p at BASELINE size:
+        // 91 (cut, blocker) passes over 1024 workers -> 16).  The rows and the flag columns come out in the reference's order all the same.
+        struct PairMemo { bool done = false; int lhs_id = -1; std::vector<int> no_gap; std::vector<std::pair<uint32_t, uint32_t>> with_gap; };  // with_gap: (worker, gap), ascending workers
+        std::vector<PairMemo> pair_memo;
         for (const PriorityCut &cut : batch.cuts) {
             for (auto &bl : cut.blockers) {
                 uint32_t brq = bl.first; bool bounded = bl.second != HQ_BLOCKER_UNBOUNDED;
-                std::vector<int> no_gap;  // zero_cond
+                std::vector<int> no_gap_mn;  // zero_cond of a multi-node batch
+                const std::vector<int> *no_gap = &no_gap_mn;
+                int no_gap_id = -1;
                 std::vector<int> cols;
                 int fl_cached = -2;
                 if (pb.rq_multi_node(batch.rq)) {
                     for (uint32_t g = 0; g < pb.n_groups; g++) {
                         auto it = group_cols.find({batch.rq, g});
-                        if (it != group_cols.end() && group_can_run_rq(g, brq)) no_gap.push_back(it->second);
+                        if (it != group_cols.end() && group_can_run_rq(g, brq)) no_gap_mn.push_back(it->second);
                     }
                 } else {
-                    if (cap_cache.size() < pb.rqs.size()) cap_cache.resize(pb.rqs.size());
-                    std::vector<uint8_t> &cap_brq = cap_cache[brq];  // can the worker run the blocker at all (Worker::is_capable_to_run_rqv): once per request class, not per (batch, cut, blocker)
-                    if (cap_brq.empty()) { cap_brq.assign(ws.n, 0); for (uint32_t w : solver_workers) cap_brq[w] = pb.capable_rqv(ws, w, brq) ? 1 : 0; }
-                    if (bcols_batch != batch_no) {  // the batch's placement columns per worker and the sum of their bounds: once per batch
-                        bcols_batch = batch_no; bcols_off.assign((size_t)ws.n + 1, 0); bcols.clear(); bcols_ub.assign(ws.n, 0);
-                        for (uint32_t w : solver_workers) {
-                            bcols_off[w] = (uint32_t)bcols.size();
-                            for (uint8_t v = 0; v < brv.n_variants; v++) { const int pc = place_get(w, batch.rq, v); if (pc >= 0) { bcols.push_back(pc); bcols_ub[w] += col_ub[(size_t)pc]; } }
-                            bcols_end[w] = (uint32_t)bcols.size();
-                        }
-                    }
-                    n_triples++;
-                    if (!sigs_done) { for (uint32_t w : solver_workers) sig_of(w); sigs_done = true; }  // (every worker's signature up front: the table below is indexed by it)
-                    gap_of_sig.assign(sig_ids.size(), UINT32_MAX);
-                    for (uint32_t w : solver_workers) {
-                        if (!cap_brq[w]) continue;
-                        uint32_t gap = gap_of_sig[gap_sig[w]];
-                        if (gap == UINT32_MAX) {   // what the blocker leaves of a worker with this signature, and how many tasks of the batch fit into that: once per (batch, blocker, signature)
-                            const uint32_t sg = gap_sig[w];
-                            const size_t li = (size_t)brq * n_sig_cap + sg;
-                            if (li >= left_state.size()) { left_state.resize(((size_t)pb.rqs.size()) * n_sig_cap, 0); left_of.resize(left_state.size()); }
-                            if (left_state[li] == 0) {
-                                Amounts tot; tot.a.assign(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
-                                if (agg_off.empty()) build_agg();
-                                const uint32_t a0 = agg_off[w], na = agg_off[w + 1] - a0;
-                                left_state[li] = gaps.leftover(brq, tot, na ? agg_rq.data() + a0 : nullptr, na ? agg_variant.data() + a0 : nullptr, na, na ? agg_cnt.data() + a0 : nullptr, left_of[li]) ? 1 : 2;
+                    if (pair_memo.size() < pb.rqs.size()) pair_memo.resize(pb.rqs.size());
+                    PairMemo &pm = pair_memo[brq];
+                    if (!pm.done) {
+                        pm.done = true;
+                        if (cap_cache.size() < pb.rqs.size()) cap_cache.resize(pb.rqs.size());
+                        std::vector<uint8_t> &cap_brq = cap_cache[brq];  // can the worker run the blocker at all (Worker::is_capable_to_run_rqv): once per request class, not per (batch, cut, blocker)
+                        if (cap_brq.empty()) { cap_brq.assign(ws.n, 0); for (uint32_t w : solver_workers) cap_brq[w] = pb.capable_rqv(ws, w, brq) ? 1 : 0; }
+                        if (bcols_batch != batch_no) {  // the batch's placement columns per worker and the sum of their bounds: once per batch
+                            bcols_batch = batch_no; bcols_off.assign((size_t)ws.n + 1, 0); bcols.clear(); bcols_ub.assign(ws.n, 0);
+                            for (uint32_t w : solver_workers) {
+                                bcols_off[w] = (uint32_t)bcols.size();
+                                for (uint8_t v = 0; v < brv.n_variants; v++) { const int pc = place_get(w, batch.rq, v); if (pc >= 0) { bcols.push_back(pc); bcols_ub[w] += col_ub[(size_t)pc]; } }
+                                bcols_end[w] = (uint32_t)bcols.size();
                             }
-                            gap = left_state[li] == 1 ? gaps.fit(batch.rq, left_of[li]) : 0;
-                            gap_of_sig[sg] = gap;
                         }
+                        n_triples++;
+                        if (!sigs_done) { for (uint32_t w : solver_workers) sig_of(w); sigs_done = true; }  // (every worker's signature up front: the table below is indexed by it)
+                        gap_of_sig.assign(sig_ids.size(), UINT32_MAX);
+                        for (uint32_t w : solver_workers) {
+                            if (!cap_brq[w]) continue;
+                            uint32_t gap = gap_of_sig[gap_sig[w]];
+                            if (gap == UINT32_MAX) {   // what the blocker leaves of a worker with this signature, and how many tasks of the batch fit into that: once per (batch, blocker, signature)
+                                const uint32_t sg = gap_sig[w];
+                                const size_t li = (size_t)brq * n_sig_cap + sg;
+                                if (li >= left_state.size()) { left_state.resize(((size_t)pb.rqs.size()) * n_sig_cap, 0); left_of.resize(left_state.size()); }
+                                if (left_state[li] == 0) {
+                                    Amounts tot; tot.a.assign(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
+                                    if (agg_off.empty()) build_agg();
+                                    const uint32_t a0 = agg_off[w], na = agg_off[w + 1] - a0;
+                                    left_state[li] = gaps.leftover(brq, tot, na ? agg_rq.data() + a0 : nullptr, na ? agg_variant.data() + a0 : nullptr, na, na ? agg_cnt.data() + a0 : nullptr, left_of[li]) ? 1 : 2;
+                                }
+                                gap = left_state[li] == 1 ? gaps.fit(batch.rq, left_of[li]) : 0;
+                                gap_of_sig[sg] = gap;
+                            }
+                            if (gap > 0) pm.with_gap.push_back({w, gap});
+                            else pm.no_gap.insert(pm.no_gap.end(), bcols.data() + bcols_off[w], bcols.data() + bcols_end[w]);
+                        }
+                        if (!pm.no_gap.empty()) pm.lhs_id = next_lhs_id++;
+                    }
+                    no_gap = &pm.no_gap; no_gap_id = pm.lhs_id;
+                    for (auto &wg : pm.with_gap) {
+                        const uint32_t w = wg.first, gap = wg.second;
                         const int *wc = bcols.data() + bcols_off[w]; const size_t nwc = bcols_end[w] - bcols_off[w];
                         const uint64_t cols_ub = bcols_ub[w];
-                        if (gap > 0) {
-                            // (a row no point within the columns' own bounds can violate is not emitted: with cuts in the thousands and workers that hold
-                            // a hundred tasks that is every one of the W x cuts x blockers rows of a large tick — the model's points are the same)
-                            // The flag column itself is created as the reference creates it (get_bvar, :233-253: even for a worker without a placement
-                            // column) — the model's COLUMNS, and with them the canonical tie-break, stay exactly the reference's.
-                            if (bounded && fl_cached == -2) fl_cached = short_flag(brq, bl.second);  // (created at its first use, as get_bvar does; the same flag for every worker of this pair)
-                            const int fl = bounded ? fl_cached : -1;
-                            if (cols_ub <= (uint64_t)cut.size + gap) continue;
-                            if (bounded && fl >= 0) { cols.assign(wc, wc + nwc); emit_plus(hqmilp::ROW_MAX, (double)cut.size + bsize + (double)gap, cols, fl, bsize); }
-                            else if (!bounded) { m.begin_row(hqmilp::ROW_MAX, (double)cut.size + (double)gap); for (size_t k = 0; k < nwc; k++) m.term(wc[k], 1.0); m.end_row(); }
-                        } else {
-                            no_gap.insert(no_gap.end(), wc, wc + nwc);
-                        }
+                        // (a row no point within the columns' own bounds can violate is not emitted: with cuts in the thousands and workers that hold
+                        // a hundred tasks that is every one of the W x cuts x blockers rows of a large tick — the model's points are the same)
+                        // The flag column itself is created as the reference creates it (get_bvar, :233-253: even for a worker without a placement
+                        // column) — the model's COLUMNS, and with them the canonical tie-break, stay exactly the reference's.
+                        if (bounded && fl_cached == -2) fl_cached = short_flag(brq, bl.second);  // (created at its first use, as get_bvar does; the same flag for every worker of this pair)
+                        const int fl = bounded ? fl_cached : -1;
+                        if (cols_ub <= (uint64_t)cut.size + gap) continue;
+                        if (bounded && fl >= 0) { cols.assign(wc, wc + nwc); emit_plus(hqmilp::ROW_MAX, (double)cut.size + bsize + (double)gap, cols, fl, bsize); }
+                        else if (!bounded) { m.begin_row(hqmilp::ROW_MAX, (double)cut.size + (double)gap); for (size_t k = 0; k < nwc; k++) m.term(wc[k], 1.0); m.end_row(); }
                     }
                 }
-                if (no_gap.empty()) continue;
+                if (no_gap->empty()) continue;
                 int fl;
-                if (bounded && (fl = short_flag(brq, bl.second)) >= 0) emit_plus(hqmilp::ROW_MAX, bsize + (double)cut.size, no_gap, fl, bsize);
+                if (bounded && (fl = short_flag(brq, bl.second)) >= 0) { emit_plus(hqmilp::ROW_MAX, bsize + (double)cut.size, *no_gap, fl, bsize); mark_lhs(no_gap_id, no_gap->size()); }
                 else if (!bounded && std::find(capped_by.begin(), capped_by.end(), brq) == capped_by.end()) {
                     capped_by.push_back(brq);
-                    m.begin_row(hqmilp::ROW_MAX, (double)cut.size); for (int c : no_gap) m.term(c, 1.0); m.end_row();
+                    m.begin_row(hqmilp::ROW_MAX, (double)cut.size); for (int c : *no_gap) m.term(c, 1.0); m.end_row(); mark_lhs(no_gap_id, no_gap->size());
                 }
             }
         }
@@ -1095,6 +1116,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         }
     }
     m.row_implied.resize(m.nrows(), 0);
+    m.row_lhs.resize((size_t)m.nrows(), -1); m.row_lhs_len.resize((size_t)m.nrows(), 0);
     const double t_model1 = clock_us();
     if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu terms, %zu worker signatures, %zu (batch, cut, blocker) passes over the workers\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), m.rcol.size(), sig_ids.size(), n_triples);
     hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438

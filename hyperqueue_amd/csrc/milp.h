@@ -38,8 +38,11 @@ struct Model {
     //   col_group[j] >= 0: column j belongs to that block (the tick: a worker's placement columns, solver.rs:95-192); -1: a column of the whole model
     //                      (the "blocker short" flags, solver.rs:233-253).  What the price sweeps of csrc/price.cpp decompose along.
     //   row_implied[i] != 0: row i is implied, for INTEGER points, by the other rows of its block (a cut from the block's own integer optimum)
+    //   row_lhs[i] >= 0: the first row_lhs_len[i] terms of row i are the SAME list (columns, coefficients, order) in every row that carries this id — a batch's cut rows
+    //                      against its blockers differ in their flag and right-hand side only; -1: no statement.  What lets the coupled solve read such a list once.
     std::vector<int32_t> col_group;
     std::vector<uint8_t> row_implied;
+    std::vector<int32_t> row_lhs, row_lhs_len;
     int ncols() const { return (int)obj.size(); }
     int nrows() const { return (int)rhs.size(); }
     int add_col(double w, uint8_t k) {
