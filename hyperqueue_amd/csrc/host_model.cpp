@@ -834,6 +834,9 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     std::map<uint32_t, std::vector<int>> count_cols;               // tasks_count_vars   :89
     std::vector<std::vector<std::pair<int, double>>> res_terms(R);
     std::vector<std::pair<int, double>> cpu_terms, block_terms;
+    std::vector<uint8_t> res_carry(R, 0);
+    // structure hint (milp.h: Model::row_block): the row holds columns of ONE worker's block and nothing else
+    auto mark_block = [&](int32_t wi_) { m.row_block.resize((size_t)m.nrows(), -1); m.row_block.back() = wi_; };
     auto emit = [&](uint8_t type, double rhs, const std::vector<std::pair<int, double>> &terms) { m.begin_row(type, rhs); for (auto &t : terms) m.term(t.first, t.second); m.end_row(); };
     auto emit_plus = [&](uint8_t type, double rhs, const std::vector<int> &cols, int extra, double coef) { m.begin_row(type, rhs); for (int c : cols) m.term(c, 1.0); m.term(extra, coef); m.end_row(); };
     // WorkerGroup::is_capable_to_run_rq  server/workergroup.rs:35-52 (over the real worker map)
@@ -920,16 +923,16 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             double all_cpus = units(tot[0]), need = all_cpus * ((double)mu - 1.0) + units(fre[0]);
             if (!(need < 0.0001)) {
                 int col = addc(0.0, hqmilp::COL_BOOL, (int32_t)wi);
-                cpu_terms.push_back({col, -need}); emit(hqmilp::ROW_MIN, 0.0, cpu_terms); cpu_terms.pop_back();
-                cpu_terms.push_back({col, -all_cpus}); emit(hqmilp::ROW_MAX, 0.0, cpu_terms); cpu_terms.pop_back();
+                cpu_terms.push_back({col, -need}); emit(hqmilp::ROW_MIN, 0.0, cpu_terms); cpu_terms.pop_back(); mark_block((int32_t)wi);
+                cpu_terms.push_back({col, -all_cpus}); emit(hqmilp::ROW_MAX, 0.0, cpu_terms); cpu_terms.pop_back(); mark_block((int32_t)wi);
             }
         }
         if (!block_z.empty() && block_z[w] >= 0.0 && block_terms.size() >= 2)  // the worker's block optimum caps its share of the objective (see block_z)
-            { emit(hqmilp::ROW_MAX, block_z[w] * (1.0 + 1e-9) + 1e-12, block_terms); m.row_implied.resize(m.nrows(), 0); m.row_implied.back() = 1; }  // (implied, for integer points, by the worker's resource rows)
+            { emit(hqmilp::ROW_MAX, block_z[w] * (1.0 + 1e-9) + 1e-12, block_terms); m.row_implied.resize(m.nrows(), 0); m.row_implied.back() = 1; mark_block((int32_t)wi); }  // (implied, for integer points, by the worker's resource rows)
         for (uint32_t r = 0; r < R; r++) {  // :177-191 (an unbounded resource keeps its terms for the next worker, as in the reference)
-            if (fre[r] == HQ_AMOUNT_MAX) continue;
-            if (!res_terms[r].empty()) emit(hqmilp::ROW_MAX, units(fre[r]), res_terms[r]);
-            res_terms[r].clear();
+            if (fre[r] == HQ_AMOUNT_MAX) { if (!res_terms[r].empty()) res_carry[r] = 1; continue; }
+            if (!res_terms[r].empty()) { emit(hqmilp::ROW_MAX, units(fre[r]), res_terms[r]); mark_block(res_carry[r] ? -1 : (int32_t)wi); }  // (a row that carries an earlier worker's terms is not one block's)
+            res_terms[r].clear(); res_carry[r] = 0;
         }
     }
     // multi-node group sizes  :193-227
@@ -1116,7 +1119,8 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         }
     }
     m.row_implied.resize(m.nrows(), 0);
-    m.row_lhs.resize((size_t)m.nrows(), -1); m.row_lhs_len.resize((size_t)m.nrows(), 0);
+    m.row_lhs.resize((size_t)m.nrows(), -1); m.row_lhs_len.resize((size_t)m.nrows(), 0); m.row_block.resize((size_t)m.nrows(), -1);
+    m.col_ub = col_ub; m.col_ub.resize((size_t)m.ncols(), UINT32_MAX);
     const double t_model1 = clock_us();
     if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu terms, %zu worker signatures, %zu (batch, cut, blocker) passes over the workers\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), m.rcol.size(), sig_ids.size(), n_triples);
     hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438

@@ -2042,6 +2042,7 @@ thread_local hqhost::BlockMemo *g_memo = nullptr; thread_local uint32_t g_last_m
 void hqtick_debug_set_block_memo(int on) { if (on && !g_memo) g_memo = new hqhost::BlockMemo(); if (!on) { delete g_memo; g_memo = nullptr; } }
 uint32_t hqtick_debug_last_block_memo(void) { return g_last_memo; }
 void hqtick_debug_set_price_emulation(int on, uint32_t min_cols) { g_price_emulation = on; g_price_min_cols = min_cols; }
+void hqtick_debug_set_fast_path(int on) { hqmilp::set_fast_path(on); }
 thread_local int g_price_fault = -1;
 void hqtick_debug_set_price_fault(int fail_at) { g_price_fault = fail_at; }
 // the host stages as ONE RANK of a sharded scheduler: emulated sweeps / class blocks over this rank's share, completed through `fn` (tests/test_sharded.py: gloo)

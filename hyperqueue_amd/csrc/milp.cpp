@@ -1150,6 +1150,11 @@ bool sparse_greedy(const Model &mdl, const std::vector<double> &ub, std::vector<
 
 }  // namespace
 
+void columns_by_cost_desc(const double *c, int n, std::vector<int> &out) { order_by_cost_desc(c, n, out); }
+
+thread_local int g_fast_path = -1;
+void set_fast_path(int on) { g_fast_path = on; }
+
 // Row feasibility follows the solver the reference uses: HiGHS accepts a MIP solution whose rows are violated by at most
 // mip_feasibility_tolerance = 1e-6 (absolute, original units).  That matters for one kind of row: the min_utilization pair of
 // scheduler/solver.rs:501-540 multiplies its on/off flag by a value derived from an f32 (0.3 -> 0.30000001192...), e.g.
@@ -1164,6 +1169,51 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
     static const bool tracing_solve = getenv("HQMILP_TRACE") != nullptr;
     const double ts0 = wall();
     auto tmark = [&](const char *what) { if (tracing_solve && mdl_in.ncols() > 1000) fprintf(stderr, "[milp] solve(): %s at %.3f ms\n", what, (wall() - ts0) * 1e3); };
+    // ---- the coupled tick's fast path: a large model whose builder said how it is made — one block of columns per worker (col_group), rows that share their leading
+    // terms (row_lhs) — goes to the price sweeps AS IT IS (hqprice::solve_model): no snapped copy, no integer-hull pass, no components, no scaled row copy, no
+    // column-wise copy for the greedy raise; the sweeps' own exact block solves need none of them.  What comes back certified is checked against every row of the model
+    // right here and returned; anything else (a shape the flattening refuses, no certificate) takes the classic path below from the start, as if this had not run.
+    // (c3p at BASELINE size: 1.7 ms of presolve + components + row copy and 1.0 ms of flattening on the build container -> 0.5 ms.)
+    static const bool fast_env = !(getenv("HQMILP_FAST") && atoi(getenv("HQMILP_FAST")) == 0);  // (A/B switch)
+    const bool fast_on = g_fast_path < 0 ? fast_env : g_fast_path != 0;                          // (... and the tests' own: tests/test_price.py compares the two paths)
+    const int FAST_MIN_COLS = 2048;   // (= LAZY_GREEDY_COLS below: the models that go to the sweeps without an incumbent of the host's)
+    if (fast_on && sweeper && rel_gap > 0.0 && mdl_in.ncols() >= FAST_MIN_COLS && mdl_in.ncols() >= (int)sweeper->min_cols && (int)mdl_in.col_group.size() == mdl_in.ncols() &&
+        (int)mdl_in.row_lhs.size() == mdl_in.nrows() && (int)mdl_in.row_lhs_len.size() == mdl_in.nrows() && (int)mdl_in.start.size() != mdl_in.ncols()) {
+        const int n = mdl_in.ncols(), m = mdl_in.nrows();
+        hqprice::ModelView mv;
+        mv.n = n; mv.m = m; mv.obj = mdl_in.obj.data(); mv.kind = mdl_in.kind.data(); mv.rtype = mdl_in.rtype.data(); mv.rhs = mdl_in.rhs.data();
+        mv.roff = mdl_in.roff.data(); mv.rcol = mdl_in.rcol.data(); mv.rcoef = mdl_in.rcoef.data(); mv.col_group = mdl_in.col_group.data();
+        mv.row_implied = (int)mdl_in.row_implied.size() == m ? mdl_in.row_implied.data() : nullptr; mv.row_lhs = mdl_in.row_lhs.data(); mv.row_lhs_len = mdl_in.row_lhs_len.data();
+        if ((int)mdl_in.row_block.size() == m && (int)mdl_in.col_ub.size() == n) { mv.row_block = mdl_in.row_block.data(); mv.col_ub = mdl_in.col_ub.data(); }
+        double cost_scale = 1.0;
+        const double tf0 = wall();
+        hqprice::Answer pa = hqprice::solve_model(mv, rel_gap, time_limit_s, ts0 + (time_limit_s > 0 ? time_limit_s : 1e18), tracing_solve, *sweeper, &cost_scale);
+        if (tracing_solve) fprintf(stderr, "[milp] fast path: ran %d (%s) sweeps %u rounds %u bound %.9f point %.9f, %.3f ms of which %.3f ms inside the sweeps\n", (int)pa.ran, pa.why, pa.sweeps, pa.rounds, pa.ran ? pa.bound : -1.0, pa.x.empty() ? -1.0 : pa.x_value, (wall() - tf0) * 1e3, sweeper->stat_sweep_us / 1e3);
+        if (pa.ran && (int)pa.x.size() == n && pa.bound * (1.0 + 1e-9) + 1e-12 <= pa.x_value + rel_gap * std::fabs(pa.x_value)) {
+            // the point against EVERY row and bound of the model, in the model's own units
+            bool ok = true;
+            for (int j = 0; j < n && ok; j++) { const double v = pa.x[(size_t)j]; if (v < -1e-9 || std::fabs(v - std::round(v)) > 1e-9 || (mdl_in.kind[j] == COL_BOOL && v > 1.0 + 1e-9)) ok = false; }
+            for (int i = 0; i < m && ok; i++) {
+                double a = 0.0, sc = 0.0;
+                for (int k = mdl_in.roff[i]; k < mdl_in.roff[i + 1]; k++) { a += mdl_in.rcoef[k] * pa.x[(size_t)mdl_in.rcol[k]]; sc = std::max(sc, std::fabs(mdl_in.rcoef[k])); }
+                const double tol = std::max(ROW_TOL, 1e-9 * std::max(1.0, sc));   // (HiGHS's own mip_feasibility_tolerance, see ROW_TOL below: the min_utilization rows' f32 coefficients)
+                if (mdl_in.rtype[i] != ROW_MIN && a > mdl_in.rhs[i] + tol) ok = false;
+                if (mdl_in.rtype[i] != ROW_MAX && a < mdl_in.rhs[i] - tol) ok = false;
+            }
+            if (ok) {
+                Result res;
+                res.x = std::move(pa.x);
+                for (double &v : res.x) v = std::round(v);
+                res.feasible = true; res.optimal = true; res.canonical = false;   // certified within rel_gap; which of the tied optima it is stays the sweeps' choice
+                res.n_components = 1; res.nodes = pa.sweeps; res.price_sweeps = (int)pa.sweeps; res.price_rounds = (int)pa.rounds; res.price_total_us = (wall() - tf0) * 1e6;
+                double z = 0.0; for (int j = 0; j < n; j++) z += mdl_in.obj[j] * res.x[(size_t)j];
+                res.objective = z;
+                tmark("fast path certified");
+                return res;
+            }
+            if (tracing_solve) fprintf(stderr, "[milp] fast path: the certified point fails a row of the model: classic path\n");
+        }
+    }
     Model snapped;  // a copy of the model only when a coefficient really has to be snapped (a block of a worker class has no BOOL column at all)
     bool need_snap = false;
     for (size_t k = 0; k < mdl_in.rcoef.size() && !need_snap; k++) {

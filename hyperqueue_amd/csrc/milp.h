@@ -43,6 +43,11 @@ struct Model {
     std::vector<int32_t> col_group;
     std::vector<uint8_t> row_implied;
     std::vector<int32_t> row_lhs, row_lhs_len;
+    //   row_block[i] >= 0: every column of row i belongs to that block (col_group value) and to nothing else — a worker's resource rows; -1: no statement
+    //   col_ub[j] != UINT32_MAX: column j cannot exceed this value in any integer point (what the worker's free resources allow: min over the request's entries of
+    //                            floor(free / amount), in exact integers) — a bound the rows imply, handed over so that nobody has to derive it again
+    std::vector<int32_t> row_block;
+    std::vector<uint32_t> col_ub;
     int ncols() const { return (int)obj.size(); }
     int nrows() const { return (int)rhs.size(); }
     int add_col(double w, uint8_t k) {
@@ -83,5 +88,10 @@ const double REFERENCE_MIP_REL_GAP = 1e-4;
 // sweeper (optional): the block sweeps of the coupled solve (csrc/price.h) — on the MI355X in the tick (k_price_sweep), the emulated wavefront in the CPU
 // tests; nullptr: the host-only search.  Used for large components whose columns carry `col_group`.
 Result solve(const Model &m, double time_limit_s, bool canonical = true, double rel_gap = REFERENCE_MIP_REL_GAP, hqprice::Sweeper *sweeper = nullptr);
+
+// columns by descending cost, ties by ascending index (a stable order of the indices): the order the solver's greedy raises go through the columns in
+void columns_by_cost_desc(const double *c, int n, std::vector<int> &out);
+// the coupled tick's fast path (solve(): large structured models straight to the price sweeps) for this thread: 1 on, 0 off, -1 the default (on unless HQMILP_FAST=0)
+void set_fast_path(int on);
 
 }  // namespace hqmilp

@@ -10,6 +10,7 @@
 #include <numeric>
 
 #include "lp_tab.h"
+#include "milp.h"
 
 namespace hqprice {
 namespace {
@@ -57,6 +58,8 @@ struct Prob {
     std::vector<int> block_of_flat;
 };
 
+// round half away from zero without the call into libm (-msse4.1 gives floor / nearbyint as one instruction, not round); |v| < 2^51
+inline double round_fast(double v) { return (double)(long long)(v + (v >= 0.0 ? 0.5 : -0.5)); }
 long long gcd_ll(long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a < 0 ? -a : a; }
 
 // The groups' left-hand sides -> P's row-wise and column-wise tables (P.grp_of, P.KG set; lhs[g] = (flat column, coefficient) in the model's order)
@@ -730,12 +733,12 @@ struct Solver {
 
 }  // namespace
 
-Answer solve(const Request &rq, Sweeper &sw) {
+namespace {
+// everything after the model has been flattened into S.P
+Answer run_solver(Solver &S, const double tp0) {
     Answer ans;
-    Solver S(rq, sw);
-    const double tp0 = now_us();
+    const Request &rq = S.rq; Sweeper &sw = S.sw;
     auto tmark = [&](const char *what) { if (rq.trace) fprintf(stderr, "[price] %s at %.3f ms (sweeps so far %.3f ms)\n", what, (now_us() - tp0) / 1e3, sw.stat_sweep_us / 1e3); };
-    if (const char *why = build(rq, S.P)) { ans.why = why; return ans; }
     tmark("model flattened");
     Prob &P = S.P;
     if (rq.trace) fprintf(stderr, "[price] %u blocks, %u block columns, %d wide rows with %d distinct left-hand sides (%zu / %zu terms), %d flags, %zu conditional bounds\n", P.T.n_blocks, P.T.n_cols, P.K, P.KG, P.row_terms, P.T.w_row.size(), P.G, P.caps.size());
@@ -1030,6 +1033,343 @@ Answer solve(const Request &rq, Sweeper &sw) {
         }
     }
     return ans;
+}
+}  // namespace
+
+namespace {
+
+double g_tt[8];
+// ---- the model as its builder wrote it -> blocks + wide rows (what build() does for a scaled component copy; same tables, same numbering) -------------------------
+// Returns nullptr on success, else what keeps the model on the classic path.  ub: the derived column bounds (model columns), c: obj / cmax.
+const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &ub, std::vector<double> &c, double &cmax) {
+    const int n = mv.n, m = mv.m;
+    if (!mv.col_group || !mv.row_lhs || !mv.row_lhs_len) return "no structure hints";
+    // blocks in order of their first column (the tick: worker order)
+    int max_group = -1;
+    for (int j = 0; j < n; j++) max_group = std::max(max_group, mv.col_group[j]);
+    std::vector<int> block_of_group((size_t)max_group + 1, -1), bsize, blk(n, -1);
+    for (int j = 0; j < n; j++) {
+        const int g = mv.col_group[j];
+        if (g < 0) { P.gmodel.push_back(j); continue; }
+        if (block_of_group[g] < 0) { block_of_group[g] = (int)bsize.size(); bsize.push_back(0); }
+        blk[j] = block_of_group[g];
+        if (++bsize[blk[j]] > NMAX_BLOCK) return "block with more than 32 columns";
+    }
+    const int nb = (int)bsize.size();
+    if (nb < 8) return "fewer than 8 blocks";
+    cmax = 0.0;
+    for (int j = 0; j < n; j++) cmax = std::max(cmax, std::fabs(mv.obj[j]));
+    if (cmax == 0.0) cmax = 1.0;
+    c.resize(n);
+    for (int j = 0; j < n; j++) c[j] = mv.obj[j] / cmax;
+    P.G = (int)P.gmodel.size();
+    for (int j : P.gmodel) {
+        if (mv.kind[j] != 1) return "global column that is not 0/1";
+        if (c[j] < 0.0) return "global column with negative cost";
+        P.gcost.push_back(c[j]);
+    }
+    std::vector<int> gidx(n, -1);
+    for (int g = 0; g < P.G; g++) gidx[P.gmodel[g]] = g;
+    // ---- column bounds, as hqmilp::solve derives them: a row without a negative coefficient bounds every column it holds by floor(rhs / coef + 1e-9).  A shared list of
+    // leading terms is walked once, against the smallest right-hand side of its rows (the bound is monotone in the right-hand side).
+    int n_lhs = 0;
+    for (int i = 0; i < m; i++) n_lhs = std::max(n_lhs, mv.row_lhs[i] + 1);
+    struct Fam { int first = -1, len = 0; bool has_neg = false, scanned = false; double rhs_min = INF;
+                 // of the list's block columns: their block (-2 none yet), more than one block, a global column inside, count, integer coefficients
+                 int b0 = -2; bool multi = false, has_g = false, integral = true; int n_bcols = 0; double amax = 0.0; };
+    std::vector<Fam> fam((size_t)n_lhs);
+    ub.assign(n, INF);
+    for (int j = 0; j < n; j++) if (mv.kind[j] == 1) ub[j] = 1.0;
+    const bool hinted = mv.row_block && mv.col_ub;   // the builder's own bounds of the block columns: the rows of single blocks need not be walked for theirs
+    if (hinted) for (int j = 0; j < n; j++) if (mv.col_ub[j] != UINT32_MAX) ub[j] = std::min(ub[j], (double)mv.col_ub[j]);
+    auto bound_terms = [&](int a, int e, double rhs) { for (int k = a; k < e; k++) if (mv.rcoef[k] > 0.0) { double &u = ub[mv.rcol[k]]; u = std::min(u, std::floor(rhs / mv.rcoef[k] + 1e-9)); } };
+    for (int i = 0; i < m; i++) {
+        const int a = mv.roff[i], e = mv.roff[i + 1];
+        if (a == e) { const double b = mv.rhs[i]; const bool ok = mv.rtype[i] == 1 ? b >= -1e-9 : (mv.rtype[i] == 0 ? b <= 1e-9 : std::fabs(b) <= 1e-9); if (!ok) return "infeasible empty row"; continue; }
+        if (hinted && mv.row_block[i] >= 0) continue;
+        const int L = mv.row_lhs[i];
+        int tail = a;
+        bool neg = false;
+        if (L >= 0) {
+            Fam &f = fam[(size_t)L];
+            const int len = mv.row_lhs_len[i];
+            if (len < 0 || a + len > e) return "bad structure hint";
+            if (f.first < 0) { f.first = i; f.len = len; for (int k = a; k < a + len; k++) if (mv.rcoef[k] < 0.0) f.has_neg = true; }
+            else if (f.len != len) return "bad structure hint";
+            neg = f.has_neg; tail = a + len;
+        }
+        for (int k = tail; k < e; k++) if (mv.rcoef[k] < 0.0) neg = true;
+        if (mv.rtype[i] == 0 || neg) continue;   // a `>=` row, or a negative coefficient: no bound from here (the multi-node rows that do bound through one are not for this path)
+        if (mv.rhs[i] < -1e-9) return "infeasible row";
+        if (L >= 0) fam[(size_t)L].rhs_min = std::min(fam[(size_t)L].rhs_min, mv.rhs[i]);
+        bound_terms(tail, e, mv.rhs[i]);
+    }
+    for (const Fam &f : fam) if (f.first >= 0 && f.rhs_min < INF) bound_terms(mv.roff[f.first], mv.roff[f.first] + f.len, f.rhs_min);
+    g_tt[0] = now_us();
+    HostTables &T = P.T;
+    T.n_blocks = (uint32_t)nb;
+    T.blk_off.assign((size_t)nb + 1, 0);
+    for (int b = 0; b < nb; b++) T.blk_off[b + 1] = T.blk_off[b] + (uint32_t)bsize[b];
+    T.n_cols = T.blk_off[nb];
+    P.flat_of.assign(n, -1); P.model_of.assign(T.n_cols, -1); P.block_of_flat.assign(T.n_cols, -1);
+    {
+        std::vector<uint32_t> cur(T.blk_off.begin(), T.blk_off.end() - 1);
+        for (int j = 0; j < n; j++) if (blk[j] >= 0) { const int f = (int)cur[blk[j]]++; P.flat_of[j] = f; P.model_of[f] = j; P.block_of_flat[f] = blk[j]; }
+    }
+    T.col_cost.assign(T.n_cols, 0.0); T.col_a.assign((size_t)T.n_cols * MMAX_BLOCK, 0.0); T.col_cap.assign(T.n_cols, 0);
+    T.blk_m.assign(nb, 0); T.blk_cap.assign((size_t)nb * MMAX_BLOCK, 0.0);
+    for (uint32_t f = 0; f < T.n_cols; f++) {
+        const int j = P.model_of[f];
+        if (c[j] < 0.0) return "negative cost";
+        if (!(ub[j] <= 65535.0)) return "column bound above 65535";
+        T.col_cost[f] = c[j];
+        T.col_cap[f] = (int32_t)std::floor(ub[j] + 1e-9);
+    }
+    // ---- the rows
+    struct WideRow { double h; uint8_t ge; int lhs_key; int own = -1; std::vector<std::pair<int, double>> g; };   // lhs_key: 2 * L + (`>=` row), or -1 with its own list `own`
+    std::vector<WideRow> wide;
+    std::vector<std::vector<std::pair<int, int32_t>>> own_lists;   // left-hand sides of wide rows outside every family (sign applied)
+    std::vector<std::pair<int, long long>> ai;
+    struct GcdMemo { int n = -1; long long g = 0; long long v[32]; };
+    GcdMemo gcd_memo[8]; unsigned gcd_next = 0;
+    // what a range of terms looks like to the classification below
+    struct Scan { int b0 = -2; bool multi = false, has_g = false, nonneg = true; int n_bcols = 0; double amax = 0.0; };
+    auto scan = [&](int a, int e, Scan &sc) {
+        for (int k = a; k < e; k++) {
+            const int j = mv.rcol[k];
+            if (mv.rcoef[k] < 0.0) sc.nonneg = false;
+            sc.amax += mv.rcoef[k] * ub[j];
+            if (blk[j] < 0) { sc.has_g = true; continue; }
+            sc.n_bcols++;
+            if (sc.b0 == -2) sc.b0 = blk[j]; else if (blk[j] != sc.b0) sc.multi = true;
+        }
+    };
+    for (int i = 0; i < m; i++) {
+        const int a = mv.roff[i], e = mv.roff[i + 1];
+        if (a == e) continue;
+        const bool is_le = mv.rtype[i] == 1, is_ge = mv.rtype[i] == 0;
+        const double rhs = mv.rhs[i];
+        const int L = mv.row_lhs[i];
+        Scan sc; int tail = a;
+        if (L >= 0) {
+            Fam &f = fam[(size_t)L];
+            if (!f.scanned) {
+                f.scanned = true;
+                Scan fs; scan(a, a + f.len, fs);
+                f.b0 = fs.b0; f.multi = fs.multi; f.has_g = fs.has_g; f.n_bcols = fs.n_bcols; f.amax = fs.amax;
+                for (int k = a; k < a + f.len; k++) { const double v = mv.rcoef[k], rv = round_fast(v); if (std::fabs(v - rv) > 1e-7 * std::max(1.0, std::fabs(rv)) || std::fabs(rv) > 1.0e9) f.integral = false; }
+            }
+            if (f.multi && !f.has_g) {   // the list spans blocks: a wide row whose left-hand side is the family's
+                sc.b0 = f.b0; sc.multi = true; sc.has_g = false; sc.nonneg = !f.has_neg; sc.n_bcols = f.n_bcols; sc.amax = f.amax;
+                tail = a + f.len;
+            }
+        }
+        const bool fam_row = tail != a;
+        const int hint_b = (hinted && !fam_row && mv.row_block[i] >= 0 && mv.row_block[i] <= max_group) ? block_of_group[mv.row_block[i]] : -1;
+        if (hint_b >= 0) {   // the builder says: one block's row — no need to look its columns' blocks up
+            if (mv.row_implied && mv.row_implied[i]) continue;
+            sc.b0 = hint_b; sc.n_bcols = e - a;
+            for (int k = a; k < e; k++) { if (mv.rcoef[k] < 0.0) sc.nonneg = false; sc.amax += mv.rcoef[k] * ub[mv.rcol[k]]; }
+        } else scan(tail, e, sc);   // (a family row: its own terms behind the shared list; any other row: all of it)
+        if (!sc.multi && !sc.has_g && sc.b0 >= 0) {  // a row of one block
+            if (mv.row_implied && mv.row_implied[i]) continue;  // implied for integer points by the block's other rows: the sweeps solve the blocks in integers
+            if (is_le && sc.nonneg && sc.amax <= rhs * (1.0 + 1e-12) + 1e-9) continue;  // no point within the column bounds can violate it
+            if (!is_le || !sc.nonneg || rhs < 0.0) return "block row that is not a packing row";
+            const int b0 = sc.b0, r = T.blk_m[b0];
+            if (r >= MMAX_BLOCK) return "block with more than 4 rows";
+            long long g = 0; bool ok = true;
+            ai.clear();
+            for (int k = a; k < e && ok; k++) {
+                const double v = mv.rcoef[k] * GRID, rv = round_fast(v);
+                if (rv < 1.0 || std::fabs(v - rv) > 1e-6 * std::max(1.0, rv) || rv >= 4.0e15) ok = false;
+                else ai.push_back({P.flat_of[mv.rcol[k]], (long long)rv});
+            }
+            if (ok) {   // the row's gcd: identical workers repeat the same few coefficient lists, and a 64-bit remainder per term is most of this loop
+                const GcdMemo *hit = nullptr;
+                for (const GcdMemo &gm : gcd_memo) if (gm.n == (int)ai.size()) { bool same = true; for (int q = 0; q < gm.n && same; q++) same = gm.v[q] == ai[(size_t)q].second; if (same) { hit = &gm; break; } }
+                if (hit) g = hit->g;
+                else {
+                    for (auto &t : ai) g = gcd_ll(g, t.second);
+                    if (ai.size() <= 32) { GcdMemo &gm = gcd_memo[gcd_next++ % 8]; gm.n = (int)ai.size(); gm.g = g; for (size_t q = 0; q < ai.size(); q++) gm.v[q] = ai[q].second; }
+                }
+            }
+            if (!ok) return "block row off the ResourceAmount grid";
+            const double capv = rhs * GRID;
+            if (capv >= 4.0e15) return "block row capacity too large";
+            const long long capi = (long long)std::floor(capv + 1e-6);
+            if (g < 1) g = 1;
+            for (auto &t : ai) T.col_a[(size_t)t.first * MMAX_BLOCK + r] += (double)(t.second / g);  // (duplicate terms of one row are summed)
+            T.blk_cap[(size_t)b0 * MMAX_BLOCK + r] = (double)(capi / g);
+            T.blk_m[b0] = (uint8_t)(r + 1);
+            continue;
+        }
+        if (!is_le && !is_ge) return "equality or range row across blocks";
+        if (is_le && sc.nonneg && sc.amax <= rhs * (1.0 + 1e-12) + 1e-9) continue;   // vacuous within the column bounds
+        if (is_ge && sc.nonneg && rhs <= 1e-12) continue;                            // holds at zero
+        if (!sc.multi && sc.has_g && sc.n_bcols >= 1 && is_le && sc.nonneg) {  // one block + flags: a conditional bound of the block's column(s)
+            if (sc.n_bcols != 1) return "conditional bound over several columns of a block";
+            CapRow cr; cr.flat = -1; cr.rhs = 0.0;
+            double cx = 0.0;
+            for (int k = a; k < e; k++) if (blk[mv.rcol[k]] >= 0) { cr.flat = P.flat_of[mv.rcol[k]]; cx = mv.rcoef[k]; }
+            if (!(cx > 0.0)) return "conditional bound with a zero coefficient";
+            cr.rhs = rhs / cx;
+            for (int k = a; k < e; k++) if (blk[mv.rcol[k]] < 0) cr.g.push_back({gidx[mv.rcol[k]], mv.rcoef[k] / cx});
+            P.caps.push_back(std::move(cr));
+            continue;
+        }
+        if (sc.n_bcols == 0) return "row over global columns only";
+        WideRow w; w.ge = is_ge ? 1 : 0;
+        const double sign = is_le ? 1.0 : -1.0;
+        w.h = sign * rhs;
+        if (fam_row) {
+            if (!fam[(size_t)L].integral) return "wide row with a non-integer coefficient";
+            w.lhs_key = 2 * L + (is_ge ? 1 : 0);
+        } else { w.lhs_key = -1; w.own = (int)own_lists.size(); own_lists.emplace_back(); own_lists.back().reserve((size_t)(e - a)); }
+        for (int k = tail; k < e; k++) {
+            const int j = mv.rcol[k];
+            const double v = sign * mv.rcoef[k];
+            if (blk[j] < 0) { w.g.push_back({gidx[j], v}); continue; }
+            if (fam_row) return "block column behind a shared list";
+            const double rv = round_fast(v);
+            if (std::fabs(v - rv) > 1e-7 * std::max(1.0, std::fabs(rv)) || std::fabs(rv) > 1.0e9) return "wide row with a non-integer coefficient";
+            if (rv != 0.0) own_lists.back().push_back({P.flat_of[j], (int32_t)rv});
+        }
+        P.row_terms += (size_t)(e - a) - w.g.size();
+        wide.push_back(std::move(w));
+        if ((int)wide.size() > 1024) return "more than 1024 wide rows";
+    }
+    g_tt[1] = now_us();
+    for (int b = 0; b < nb; b++) if (T.blk_m[b] == 0) {   // every resource row of this worker is slack at its column bounds: a never-binding row (the kernel wants one)
+        double total = 0.0;
+        for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { T.col_a[(size_t)f * MMAX_BLOCK] = 1.0; total += (double)T.col_cap[f]; }
+        T.blk_cap[(size_t)b * MMAX_BLOCK] = total;
+        T.blk_m[b] = 1;
+    }
+    P.K = (int)wide.size();
+    if (P.K == 0) return "no wide row";
+    P.h.resize(P.K); P.ge.resize(P.K); P.g_rows.assign(P.G, {});
+    // groups: rows with the same (list, sign) share one; lists of different families with the same content are merged too (build() does, by content), and the groups are
+    // numbered in the order of their first row — the numbering build() arrives at
+    P.grp_of.assign(P.K, -1);
+    std::vector<std::vector<std::pair<int, int32_t>>> lhs;
+    std::vector<uint64_t> lhs_hash;
+    std::vector<int> group_of_key((size_t)2 * n_lhs, -1);
+    auto materialise = [&](int key, std::vector<std::pair<int, int32_t>> &out) {   // the family's list with the row's sign, zero coefficients dropped
+        const Fam &f = fam[(size_t)(key >> 1)];
+        const int a = mv.roff[f.first];
+        const double sign = (key & 1) ? -1.0 : 1.0;
+        out.clear(); out.reserve((size_t)f.len);
+        for (int k = a; k < a + f.len; k++) { const double rv = round_fast(sign * mv.rcoef[k]); if (rv != 0.0) out.push_back({P.flat_of[mv.rcol[k]], (int32_t)rv}); }
+    };
+    auto hash_of = [](const std::vector<std::pair<int, int32_t>> &l) { uint64_t h = 1469598103934665603ull; for (auto &t : l) { h = (h ^ (uint64_t)(uint32_t)t.first) * 1099511628211ull; h = (h ^ (uint64_t)(uint32_t)t.second) * 1099511628211ull; } return h; };
+    std::vector<std::pair<int, int32_t>> tmp;
+    for (int k = 0; k < P.K; k++) {
+        WideRow &w = wide[(size_t)k];
+        P.h[k] = w.h; P.ge[k] = w.ge;
+        for (auto &t : w.g) P.g_rows[t.first].push_back({k, t.second});
+        if (w.lhs_key >= 0 && group_of_key[(size_t)w.lhs_key] >= 0) { P.grp_of[k] = group_of_key[(size_t)w.lhs_key]; continue; }
+        std::vector<std::pair<int, int32_t>> *l;
+        if (w.lhs_key >= 0) { materialise(w.lhs_key, tmp); l = &tmp; } else l = &own_lists[(size_t)w.own];
+        const uint64_t hsh = hash_of(*l);
+        int g = -1;
+        for (size_t i = 0; i < lhs.size() && g < 0; i++) if (lhs_hash[i] == hsh && lhs[i] == *l) g = (int)i;
+        if (g < 0) { g = (int)lhs.size(); lhs.push_back(std::move(*l)); lhs_hash.push_back(hsh); }
+        if (w.lhs_key >= 0) group_of_key[(size_t)w.lhs_key] = g;
+        P.grp_of[k] = g;
+    }
+    P.KG = (int)lhs.size();
+    if (P.KG > KMAX_HOST) return "more than 128 distinct wide left-hand sides";
+    g_tt[2] = now_us();
+    finish_groups(P, lhs);
+    g_tt[3] = now_us();
+    P.base_cap = T.col_cap;
+    return nullptr;
+}
+
+// The candidate point of a flag configuration against the flattened model, raised greedily (most valuable columns first) as far as the blocks' rows, the wide rows
+// and the conditional bounds allow — what CompSolver::polish_point does on the component's scaled rows.  The integers are exact here: block rows on their own grid,
+// wide rows with integer coefficients.  x: the model's columns (in / out).
+struct Polisher {
+    const Prob &P; int n;
+    std::vector<int> order;   // flat columns by descending cost, ties by ascending model column
+    explicit Polisher(const Prob &p, int n_, const std::vector<double> &c) : P(p), n(n_) {
+        // (the order of hqmilp::columns_by_cost_desc over the model's columns, restricted to the block columns)
+        std::vector<int> all; hqmilp::columns_by_cost_desc(c.data(), n_, all);
+        order.reserve(P.T.n_cols);
+        for (int j : all) if (P.flat_of[j] >= 0) order.push_back(P.flat_of[j]);
+    }
+    bool run(std::vector<double> &x, double &value) const {
+        const HostTables &T = P.T; const int K = P.K, G = P.G;
+        if ((int)x.size() != n) return false;
+        std::vector<double> xf(T.n_cols), B(G);
+        for (uint32_t f = 0; f < T.n_cols; f++) { xf[f] = x[P.model_of[f]]; if (xf[f] < -1e-9 || xf[f] > (double)P.base_cap[f] + 1e-9 || std::fabs(xf[f] - std::round(xf[f])) > 1e-9) return false; xf[f] = std::round(xf[f]); }
+        for (int g = 0; g < G; g++) { B[g] = x[P.gmodel[g]]; if (B[g] != 0.0 && B[g] != 1.0) return false; }
+        // block rows
+        std::vector<double> bact((size_t)T.n_blocks * MMAX_BLOCK, 0.0);
+        for (uint32_t b = 0; b < T.n_blocks; b++) {
+            double *ba = &bact[(size_t)b * MMAX_BLOCK];
+            for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) if (xf[f] != 0.0) for (int r = 0; r < MMAX_BLOCK; r++) ba[r] += T.col_a[(size_t)f * MMAX_BLOCK + r] * xf[f];
+            for (int r = 0; r < (int)T.blk_m[b]; r++) if (ba[r] > T.blk_cap[(size_t)b * MMAX_BLOCK + r]) return false;
+        }
+        // wide rows: activity per group, the flags' part per row
+        std::vector<double> ga(P.KG, 0.0), fl(K, 0.0);
+        for (int g = 0; g < P.KG; g++) for (int t = P.g_off[g]; t < P.g_off[g + 1]; t++) ga[g] += (double)P.g_coef[t] * xf[P.g_col[t]];
+        for (int g = 0; g < G; g++) if (B[g] != 0.0) for (auto &t : P.g_rows[g]) fl[t.first] += t.second * B[g];
+        for (int k = 0; k < K; k++) if (ga[P.grp_of[k]] + fl[k] > P.h[k] + 1e-9 * std::max(1.0, std::fabs(P.h[k]))) return false;
+        // conditional bounds with these flags
+        std::vector<double> cap(T.n_cols);
+        for (uint32_t f = 0; f < T.n_cols; f++) cap[f] = (double)P.base_cap[f];
+        for (const CapRow &cr : P.caps) { double r = cr.rhs; for (auto &t : cr.g) r -= t.second * B[t.first]; const double cc = std::floor(r + 1e-9); if (xf[cr.flat] > cc) return false; cap[cr.flat] = std::min(cap[cr.flat], cc); }
+        for (int f : order) {
+            if (!(T.col_cost[f] > 0.0)) break;
+            double step = cap[f] - xf[f];
+            if (step < 1.0) continue;
+            const uint32_t b = (uint32_t)P.block_of_flat[f];
+            const double *ba = &bact[(size_t)b * MMAX_BLOCK];
+            for (int r = 0; r < (int)T.blk_m[b] && step >= 1.0; r++) { const double a = T.col_a[(size_t)f * MMAX_BLOCK + r]; if (a > 0.0) { const double room = T.blk_cap[(size_t)b * MMAX_BLOCK + r] - ba[r]; if (room < a) { step = 0.0; break; } step = std::min(step, std::floor(room / a + 1e-9)); } }
+            for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1] && step >= 1.0; e++) {
+                const double a = (double)T.w_coef[e];
+                if (!(a > 0.0)) continue;   // (a `>=` row entered negated: more of the column only helps it)
+                const int g = T.w_row[e];
+                for (int q = P.gr_off[g]; q < P.gr_off[g + 1]; q++) { const int k = P.gr_row[q]; const double room = P.h[k] - (ga[g] + fl[k]); if (room < 0.5 * a) { step = 0.0; break; } step = std::min(step, std::floor(room / a + 1e-9)); }
+            }
+            if (step < 1.0) continue;
+            xf[f] += step;
+            double *bw = &bact[(size_t)b * MMAX_BLOCK];
+            for (int r = 0; r < MMAX_BLOCK; r++) bw[r] += T.col_a[(size_t)f * MMAX_BLOCK + r] * step;
+            for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) ga[T.w_row[e]] += (double)T.w_coef[e] * step;
+        }
+        double z = 0.0;
+        for (uint32_t f = 0; f < T.n_cols; f++) { x[P.model_of[f]] = xf[f]; z += T.col_cost[f] * xf[f]; }
+        for (int g = 0; g < G; g++) z += P.gcost[g] * B[g];
+        value = z;
+        return true;
+    }
+};
+
+}  // namespace
+
+Answer solve_model(const ModelView &mv, double rel_gap, double time_limit_s, double deadline_s, bool trace, Sweeper &sw, double *cost_scale) {
+    const double tp0 = now_us();
+    Request rq;
+    rq.n = mv.n; rq.m = mv.m; rq.rel_gap = rel_gap; rq.time_limit_s = time_limit_s; rq.deadline_s = deadline_s; rq.trace = trace;
+    Solver S(rq, sw);
+    std::vector<double> ub, c; double cmax = 1.0;
+    const double tte = now_us();
+    if (const char *why = build_from_model(mv, S.P, ub, c, cmax)) { Answer ans; ans.why = why; return ans; }
+    const double ttb = now_us();
+    if (cost_scale) *cost_scale = cmax;
+    Polisher pol(S.P, mv.n, c);
+    if (getenv("HQPRICE_TT")) fprintf(stderr, "[tt] pre-bounds+bounds %.1f rows %.1f groups %.1f finish %.1f tail %.1f polisher %.1f\n", g_tt[0] - tte, g_tt[1] - g_tt[0], g_tt[2] - g_tt[1], g_tt[3] - g_tt[2], ttb - g_tt[3], now_us() - ttb);
+    rq.polish = [&pol](std::vector<double> &x, double &value) { return pol.run(x, value); };
+    return run_solver(S, tp0);
+}
+
+Answer solve(const Request &rq, Sweeper &sw) {
+    Solver S(rq, sw);
+    const double tp0 = now_us();
+    if (const char *why = build(rq, S.P)) { Answer ans; ans.why = why; return ans; }
+    return run_solver(S, tp0);
 }
 
 }  // namespace hqprice

@@ -98,6 +98,22 @@ struct Answer {
 
 Answer solve(const Request &rq, Sweeper &sw);
 
+// The same solve straight from the model as its builder wrote it (hqmilp::Model's arrays, csrc/milp.h) — no component copy, no row scaling, and every list of
+// leading terms that several rows share (row_lhs) read ONCE: the coupled tick's fast path (csrc/milp.cpp, solve()).  Column bounds are derived here the way
+// hqmilp::solve derives them (BOOL: 1; every `<=` / `==` row without a negative coefficient bounds its columns).  Answer::x is over the model's columns,
+// Answer::bound / x_value in units of obj / *cost_scale (the largest |obj|).  The candidate point was checked against the blocks' rows, the wide rows and the
+// conditional bounds and raised greedily; the caller still checks it against ALL rows of the model.
+struct ModelView {
+    int n = 0, m = 0;
+    const double *obj = nullptr; const uint8_t *kind = nullptr;         // kind: 0 = nat, 1 = bool (hqmilp::COL_*)
+    const uint8_t *rtype = nullptr; const double *rhs = nullptr;        // rtype: 0 = `>=`, 1 = `<=`, 2 = `==` (hqmilp::ROW_*)
+    const int *roff = nullptr, *rcol = nullptr; const double *rcoef = nullptr;
+    const int32_t *col_group = nullptr; const uint8_t *row_implied = nullptr;   // row_implied may be nullptr
+    const int32_t *row_lhs = nullptr, *row_lhs_len = nullptr;
+    const int32_t *row_block = nullptr; const uint32_t *col_ub = nullptr;   // optional (milp.h: Model::row_block / col_ub)
+};
+Answer solve_model(const ModelView &mv, double rel_gap, double time_limit_s, double deadline_s, bool trace, Sweeper &sw, double *cost_scale);
+
 // All-gather of small host buffers between the ranks of a sharded scheduler: librccl inside the library (hqtick_comm_init) or a callback of the host
 // (hqtick_set_exchange) — csrc/hqtick.cpp.  Every rank contributes `bytes` (the same everywhere); recv gets world x bytes, rank-major.
 struct Exchange {

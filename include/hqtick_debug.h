@@ -86,6 +86,9 @@ void hqtick_debug_set_price_emulation(int on, uint32_t min_cols);
 /* fault injection into this thread's emulated sweeps: fail_at = 0: the sweeper refuses the model at begin(); k >= 1: its k-th sweep fails; -1: off.  (A rank of a
  * sharded solve whose device fails must still take part in the exchange the others wait in: tests/test_shard_solve.py) */
 void hqtick_debug_set_price_fault(int fail_at);
+/* The coupled tick's fast path (csrc/milp.cpp, solve(): a large model with the builder's structure hints goes to the sweeps as it is) for this thread:
+ * 1 on, 0 off (every model takes the classic path: presolve, components, scaled row copy), -1 the default. */
+void hqtick_debug_set_fast_path(int on);
 /* sweeps over all blocks / flag configurations of the last hqtick_debug_host_stages call (0: the host search ran alone) */
 void hqtick_debug_last_price(uint32_t *sweeps, uint32_t *rounds);
 /* hqtick_debug_milp_solve on a model that carries the builder's structure hints (col_group: block of every column, -1 = a column of the whole model;

@@ -145,3 +145,56 @@ def test_c4_shaped_coupled_ticks_by_price_sweeps(variant):
     model = o.last_model()
     zg, zh = _objective(model, got), _objective(model, host)
     assert zg >= zh * (1.0 - 1e-4), (zg, zh)
+
+
+# ------------------------------------------------------------------------------------------------ the coupled tick's fast path
+def _host_stages_path(snap, fast, tl=20.0):
+    import ctypes as C
+
+    from host_stages import HostStages
+    from hyperqueue_amd import _testhooks, abi
+
+    lib = _testhooks.load()
+    lib.hqtick_debug_set_price_emulation.argtypes = [C.c_int, C.c_uint32]
+    lib.hqtick_debug_set_fast_path.argtypes = [C.c_int]
+    lib.hqtick_debug_last_price.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.hqtick_debug_set_price_emulation(1, 0)
+    lib.hqtick_debug_set_fast_path(1 if fast else 0)
+    try:
+        got = HostStages(abi.make_config(time_limit_s=tl)).stages(snap)
+    finally:
+        lib.hqtick_debug_set_price_emulation(0, 0)
+        lib.hqtick_debug_set_fast_path(-1)
+    sw, rd = C.c_uint32(), C.c_uint32()
+    lib.hqtick_debug_last_price(C.byref(sw), C.byref(rd))
+    return got, sw.value, rd.value
+
+
+def _busy(name, **kw):
+    from hyperqueue_amd import workloads
+
+    return workloads.make_steady(name, **kw)
+
+
+FAST_CASES = {
+    "c3p-256": lambda: __import__("hyperqueue_amd.workloads", fromlist=["make"]).make("c3p", n_tasks=400_000, n_workers=256),
+    "c3p-300-seed3": lambda: __import__("hyperqueue_amd.workloads", fromlist=["make"]).make("c3p", seed=3, n_tasks=500_000, n_workers=300),
+    "c3p-busy-288": lambda: _busy("c3p", seed=1, n_workers=288, n_tasks=300_000),
+    "c4-unsat-160": lambda: __import__("hyperqueue_amd.workloads", fromlist=["make"]).make("c4", seed=8, n_workers=160, n_tasks=2_300),
+    "c3-unsat-320": lambda: __import__("hyperqueue_amd.workloads", fromlist=["make"]).make("c3", seed=5, n_workers=320, n_tasks=9_000),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FAST_CASES))
+def test_the_fast_path_walks_the_classic_paths_sweeps(name):
+    """A large coupled model with the builder's structure hints (Model::col_group / row_lhs / row_block / col_ub) goes to the price sweeps straight from the model
+    (csrc/milp.cpp solve(), hqprice::solve_model): no presolve, no components, no scaled row copy, shared left-hand sides read once.  The flattened blocks and wide
+    rows must be the ones the classic path (component copy -> hqprice::solve) arrives at: same sweeps, same flag configurations, same status, same counts."""
+    snap = FAST_CASES[name]()
+    fast, sw_f, rd_f = _host_stages_path(snap, True)
+    classic, sw_c, rd_c = _host_stages_path(snap, False)
+    assert sw_f > 0 and sw_c > 0  # both went through the sweeps
+    assert (fast.status, fast.is_optimal) == (classic.status, classic.is_optimal)
+    assert fast.batches == classic.batches
+    assert (sw_f, rd_f) == (sw_c, rd_c)
+    assert fast.counts == classic.counts
