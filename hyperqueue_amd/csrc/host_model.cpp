@@ -838,7 +838,9 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     // structure hint (milp.h: Model::row_block): the row holds columns of ONE worker's block and nothing else
     auto mark_block = [&](int32_t wi_) { m.row_block.resize((size_t)m.nrows(), -1); m.row_block.back() = wi_; };
     auto emit = [&](uint8_t type, double rhs, const std::vector<std::pair<int, double>> &terms) { m.begin_row(type, rhs); for (auto &t : terms) m.term(t.first, t.second); m.end_row(); };
-    auto emit_plus = [&](uint8_t type, double rhs, const std::vector<int> &cols, int extra, double coef) { m.begin_row(type, rhs); for (int c : cols) m.term(c, 1.0); m.term(extra, coef); m.end_row(); };
+    // a list of columns with coefficient 1 (the count columns of a request, the columns of the workers a blocker leaves no gap on: a thousand terms each, written many times)
+    auto ones = [&](const std::vector<int> &cols) { m.rcol.insert(m.rcol.end(), cols.begin(), cols.end()); m.rcoef.resize(m.rcol.size(), 1.0); };
+    auto emit_plus = [&](uint8_t type, double rhs, const std::vector<int> &cols, int extra, double coef) { m.begin_row(type, rhs); ones(cols); m.term(extra, coef); m.end_row(); };
     // WorkerGroup::is_capable_to_run_rq  server/workergroup.rs:35-52 (over the real worker map)
     auto group_can_run = [&](uint32_t g, const VariantView &vv, uint32_t slot) {
         uint32_t need = vv.multi_node() ? vv.n_nodes : 1;
@@ -1020,7 +1022,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         const RequestView &brv = pb.rqs[batch.rq];
         if (!batch.limit_reached) {  // :264-271
             m.begin_row(hqmilp::ROW_MAX, (double)batch.size);
-            for (int c : cc->second) m.term(c, 1.0);
+            ones(cc->second);
             m.end_row(); mark_lhs(count_lhs_id(batch.rq), cc->second.size());
         }
         double bsize = (double)batch.size;
@@ -1081,7 +1083,10 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                             if (gap > 0) pm.with_gap.push_back({w, gap});
                             else pm.no_gap.insert(pm.no_gap.end(), bcols.data() + bcols_off[w], bcols.data() + bcols_end[w]);
                         }
-                        if (!pm.no_gap.empty()) pm.lhs_id = next_lhs_id++;
+                        if (!pm.no_gap.empty()) {   // blockers that leave no gap on the same workers give the same list: one id (identical workers: every blocker of the batch)
+                            for (const PairMemo &o : pair_memo) if (&o != &pm && o.lhs_id >= 0 && o.no_gap == pm.no_gap) { pm.lhs_id = o.lhs_id; break; }
+                            if (pm.lhs_id < 0) pm.lhs_id = next_lhs_id++;
+                        }
                     }
                     no_gap = &pm.no_gap; no_gap_id = pm.lhs_id;
                     for (auto &wg : pm.with_gap) {
@@ -1104,7 +1109,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 if (bounded && (fl = short_flag(brq, bl.second)) >= 0) { emit_plus(hqmilp::ROW_MAX, bsize + (double)cut.size, *no_gap, fl, bsize); mark_lhs(no_gap_id, no_gap->size()); }
                 else if (!bounded && std::find(capped_by.begin(), capped_by.end(), brq) == capped_by.end()) {
                     capped_by.push_back(brq);
-                    m.begin_row(hqmilp::ROW_MAX, (double)cut.size); for (int c : *no_gap) m.term(c, 1.0); m.end_row(); mark_lhs(no_gap_id, no_gap->size());
+                    m.begin_row(hqmilp::ROW_MAX, (double)cut.size); ones(*no_gap); m.end_row(); mark_lhs(no_gap_id, no_gap->size());
                 }
             }
         }

@@ -1193,10 +1193,19 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             // the point against EVERY row and bound of the model, in the model's own units
             bool ok = true;
             for (int j = 0; j < n && ok; j++) { const double v = pa.x[(size_t)j]; if (v < -1e-9 || std::fabs(v - std::round(v)) > 1e-9 || (mdl_in.kind[j] == COL_BOOL && v > 1.0 + 1e-9)) ok = false; }
+            std::vector<double> lhs_act; std::vector<uint8_t> lhs_seen;   // the activity of a shared list of leading terms: once per list
             for (int i = 0; i < m && ok; i++) {
-                double a = 0.0, sc = 0.0;
-                for (int k = mdl_in.roff[i]; k < mdl_in.roff[i + 1]; k++) { a += mdl_in.rcoef[k] * pa.x[(size_t)mdl_in.rcol[k]]; sc = std::max(sc, std::fabs(mdl_in.rcoef[k])); }
-                const double tol = std::max(ROW_TOL, 1e-9 * std::max(1.0, sc));   // (HiGHS's own mip_feasibility_tolerance, see ROW_TOL below: the min_utilization rows' f32 coefficients)
+                double a = 0.0;
+                int k0 = mdl_in.roff[i];
+                const int L = mdl_in.row_lhs[i];
+                if (L >= 0) {
+                    if ((size_t)L >= lhs_seen.size()) { lhs_seen.resize((size_t)L + 1, 0); lhs_act.resize((size_t)L + 1, 0.0); }
+                    const int len = mdl_in.row_lhs_len[i];
+                    if (!lhs_seen[(size_t)L]) { double s = 0.0; for (int k = k0; k < k0 + len; k++) s += mdl_in.rcoef[k] * pa.x[(size_t)mdl_in.rcol[k]]; lhs_act[(size_t)L] = s; lhs_seen[(size_t)L] = 1; }
+                    a = lhs_act[(size_t)L]; k0 += len;
+                }
+                for (int k = k0; k < mdl_in.roff[i + 1]; k++) a += mdl_in.rcoef[k] * pa.x[(size_t)mdl_in.rcol[k]];
+                const double tol = std::max(ROW_TOL, 1e-9 * std::max(1.0, std::fabs(mdl_in.rhs[i])));   // (HiGHS's own mip_feasibility_tolerance, see ROW_TOL below)
                 if (mdl_in.rtype[i] != ROW_MIN && a > mdl_in.rhs[i] + tol) ok = false;
                 if (mdl_in.rtype[i] != ROW_MAX && a < mdl_in.rhs[i] - tol) ok = false;
             }

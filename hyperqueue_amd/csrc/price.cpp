@@ -478,24 +478,43 @@ struct Solver {
             for (int r = 0; r < K; r++) out[r] = ga[P.grp_of[r]];
         };
         std::vector<uint16_t> x(T.n_cols, 0);
-        std::vector<double> cum(K, 0.0), tgt(K, 0.0);
-        std::vector<std::vector<double>> cand(Q, std::vector<double>(K));
+        std::vector<double> cum(K, 0.0);
         std::vector<int> chosen(T.n_blocks, 0);
-        for (uint32_t bi = 0; bi < T.n_blocks; bi++) {
-            const uint32_t b = variant == 1 ? T.n_blocks - 1 - bi : bi;
-            const uint32_t part = b / per;
-            for (int q = 0; q < Q; q++) { const double l = lam(active[q], part); if (!(l > 1e-9)) continue; block_act(b, pat_of(active[q]), cand[q]); for (int r = 0; r < K; r++) tgt[r] += l * cand[q][r]; }
-            int bq = -1; double be = INF;
-            for (int q = 0; q < Q; q++) {
-                if (!(lam(active[q], part) > 1e-9)) continue;  // (only the cuts the part's LP point is made of: their patterns are optimal at the final prices)
-                double e = 0.0;
-                for (int r = 0; r < K; r++) e += std::fabs(cum[r] + cand[q][r] - tgt[r]) * wgt[r];
-                if (e < be - 1e-15) { be = e; bq = q; }
+        {   // The diffusion runs per GROUP of rows with one left-hand side: their running totals, targets and candidates are the same numbers (a row's own part is its
+            // right-hand side, which enters through the weight), so the error sum_r |cum_r + cand_r - tgt_r| w_r is sum_g |cum_g + cand_g - tgt_g| W_g with W_g the
+            // group's summed weights — a quarter of the terms on a three-level tick (70 rows, 16 left-hand sides).
+            const int KG = P.KG;
+            std::vector<double> wg(KG, 0.0), cumg(KG, 0.0), tgtg(KG, 0.0), candg((size_t)Q * KG);
+            for (int r = 0; r < K; r++) wg[P.grp_of[r]] += wgt[r];
+            std::vector<char> on(Q);
+            for (uint32_t bi = 0; bi < T.n_blocks; bi++) {
+                const uint32_t b = variant == 1 ? T.n_blocks - 1 - bi : bi;
+                const uint32_t part = b / per;
+                for (int q = 0; q < Q; q++) {
+                    const double l = lam(active[q], part);
+                    on[q] = l > 1e-9;   // (only the cuts the part's LP point is made of: their patterns are optimal at the final prices)
+                    if (!on[q]) continue;
+                    double *cg = &candg[(size_t)q * KG];
+                    for (int g = 0; g < KG; g++) cg[g] = 0.0;
+                    const uint16_t *px = pat_of(active[q]);
+                    for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { const uint16_t xv = px[f]; if (!xv) continue; for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) cg[T.w_row[e]] += (double)T.w_coef[e] * (double)xv; }
+                    for (int g = 0; g < KG; g++) tgtg[g] += l * cg[g];
+                }
+                int bq = -1; double be = INF;
+                for (int q = 0; q < Q; q++) {
+                    if (!on[q]) continue;
+                    const double *cg = &candg[(size_t)q * KG];
+                    double e = 0.0;
+                    for (int g = 0; g < KG; g++) e += std::fabs(cumg[g] + cg[g] - tgtg[g]) * wg[g];
+                    if (e < be - 1e-15) { be = e; bq = q; }
+                }
+                if (bq < 0) return {};
+                const double *cb = &candg[(size_t)bq * KG];
+                for (int g = 0; g < KG; g++) cumg[g] += cb[g];
+                chosen[b] = active[bq];
+                memcpy(&x[T.blk_off[b]], pat_of(active[bq]) + T.blk_off[b], (size_t)(T.blk_off[b + 1] - T.blk_off[b]) * 2);
             }
-            if (bq < 0) return {};
-            for (int r = 0; r < K; r++) cum[r] += cand[bq][r];
-            chosen[b] = active[bq];
-            memcpy(&x[T.blk_off[b]], pat_of(active[bq]) + T.blk_off[b], (size_t)(T.blk_off[b + 1] - T.blk_off[b]) * 2);
+            for (int r = 0; r < K; r++) cum[r] = cumg[P.grp_of[r]];
         }
         if (rq.trace) fprintf(stderr, "[price]   rounding: diffusion done at %.3f us, %d active cuts\n", now_us() - t_r0, Q);
         // `>=` rows that came out short: single-block pattern switches (any sweep's pattern of that block) that close the shortfall at the least loss
@@ -1038,7 +1057,6 @@ Answer run_solver(Solver &S, const double tp0) {
 
 namespace {
 
-double g_tt[8];
 // ---- the model as its builder wrote it -> blocks + wide rows (what build() does for a scaled component copy; same tables, same numbering) -------------------------
 // Returns nullptr on success, else what keeps the model on the classic path.  ub: the derived column bounds (model columns), c: obj / cmax.
 const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &ub, std::vector<double> &c, double &cmax) {
@@ -1105,7 +1123,7 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
         bound_terms(tail, e, mv.rhs[i]);
     }
     for (const Fam &f : fam) if (f.first >= 0 && f.rhs_min < INF) bound_terms(mv.roff[f.first], mv.roff[f.first] + f.len, f.rhs_min);
-    g_tt[0] = now_us();
+    
     HostTables &T = P.T;
     T.n_blocks = (uint32_t)nb;
     T.blk_off.assign((size_t)nb + 1, 0);
@@ -1238,7 +1256,7 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
         wide.push_back(std::move(w));
         if ((int)wide.size() > 1024) return "more than 1024 wide rows";
     }
-    g_tt[1] = now_us();
+    
     for (int b = 0; b < nb; b++) if (T.blk_m[b] == 0) {   // every resource row of this worker is slack at its column bounds: a never-binding row (the kernel wants one)
         double total = 0.0;
         for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { T.col_a[(size_t)f * MMAX_BLOCK] = 1.0; total += (double)T.col_cap[f]; }
@@ -1279,9 +1297,9 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
     }
     P.KG = (int)lhs.size();
     if (P.KG > KMAX_HOST) return "more than 128 distinct wide left-hand sides";
-    g_tt[2] = now_us();
+    
     finish_groups(P, lhs);
-    g_tt[3] = now_us();
+    
     P.base_cap = T.col_cap;
     return nullptr;
 }
@@ -1291,13 +1309,7 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
 // wide rows with integer coefficients.  x: the model's columns (in / out).
 struct Polisher {
     const Prob &P; int n;
-    std::vector<int> order;   // flat columns by descending cost, ties by ascending model column
-    explicit Polisher(const Prob &p, int n_, const std::vector<double> &c) : P(p), n(n_) {
-        // (the order of hqmilp::columns_by_cost_desc over the model's columns, restricted to the block columns)
-        std::vector<int> all; hqmilp::columns_by_cost_desc(c.data(), n_, all);
-        order.reserve(P.T.n_cols);
-        for (int j : all) if (P.flat_of[j] >= 0) order.push_back(P.flat_of[j]);
-    }
+    explicit Polisher(const Prob &p, int n_) : P(p), n(n_) {}
     bool run(std::vector<double> &x, double &value) const {
         const HostTables &T = P.T; const int K = P.K, G = P.G;
         if ((int)x.size() != n) return false;
@@ -1320,8 +1332,23 @@ struct Polisher {
         std::vector<double> cap(T.n_cols);
         for (uint32_t f = 0; f < T.n_cols; f++) cap[f] = (double)P.base_cap[f];
         for (const CapRow &cr : P.caps) { double r = cr.rhs; for (auto &t : cr.g) r -= t.second * B[t.first]; const double cc = std::floor(r + 1e-9); if (xf[cr.flat] > cc) return false; cap[cr.flat] = std::min(cap[cr.flat], cc); }
+        // The raise goes through the columns by descending cost (ties: ascending model column — CompSolver::polish_point's order).  Raising only ever uses room up, so
+        // a column whose own block has no room for one more of it NOW never gets any: the few that do are found first, and only those are ordered.
+        std::vector<int> order;
+        for (uint32_t b = 0; b < T.n_blocks; b++) {
+            const double *ba = &bact[(size_t)b * MMAX_BLOCK], *bc = &T.blk_cap[(size_t)b * MMAX_BLOCK];
+            const int mb = (int)T.blk_m[b];
+            bool full = false;   // (a row without any room left rules the whole block out at once — as long as every column uses it, which is not given: checked per column)
+            (void)full;
+            for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) {
+                if (!(T.col_cost[f] > 0.0) || cap[f] - xf[f] < 1.0) continue;
+                bool room = true;
+                for (int r = 0; r < mb && room; r++) { const double a = T.col_a[(size_t)f * MMAX_BLOCK + r]; if (a > 0.0 && bc[r] - ba[r] < a) room = false; }
+                if (room) order.push_back((int)f);
+            }
+        }
+        std::sort(order.begin(), order.end(), [&](int p, int q) { return T.col_cost[p] > T.col_cost[q] || (T.col_cost[p] == T.col_cost[q] && P.model_of[p] < P.model_of[q]); });
         for (int f : order) {
-            if (!(T.col_cost[f] > 0.0)) break;
             double step = cap[f] - xf[f];
             if (step < 1.0) continue;
             const uint32_t b = (uint32_t)P.block_of_flat[f];
@@ -1355,12 +1382,9 @@ Answer solve_model(const ModelView &mv, double rel_gap, double time_limit_s, dou
     rq.n = mv.n; rq.m = mv.m; rq.rel_gap = rel_gap; rq.time_limit_s = time_limit_s; rq.deadline_s = deadline_s; rq.trace = trace;
     Solver S(rq, sw);
     std::vector<double> ub, c; double cmax = 1.0;
-    const double tte = now_us();
-    if (const char *why = build_from_model(mv, S.P, ub, c, cmax)) { Answer ans; ans.why = why; return ans; }
-    const double ttb = now_us();
-    if (cost_scale) *cost_scale = cmax;
-    Polisher pol(S.P, mv.n, c);
-    if (getenv("HQPRICE_TT")) fprintf(stderr, "[tt] pre-bounds+bounds %.1f rows %.1f groups %.1f finish %.1f tail %.1f polisher %.1f\n", g_tt[0] - tte, g_tt[1] - g_tt[0], g_tt[2] - g_tt[1], g_tt[3] - g_tt[2], ttb - g_tt[3], now_us() - ttb);
+        if (const char *why = build_from_model(mv, S.P, ub, c, cmax)) { Answer ans; ans.why = why; return ans; }
+        if (cost_scale) *cost_scale = cmax;
+    Polisher pol(S.P, mv.n);
     rq.polish = [&pol](std::vector<double> &x, double &value) { return pol.run(x, value); };
     return run_solver(S, tp0);
 }
