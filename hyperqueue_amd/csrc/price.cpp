@@ -337,10 +337,20 @@ struct Solver {
         const int K = P.K;
         const uint32_t per = (P.T.n_blocks + PARTS - 1) / PARTS;
         const int NP = (int)((P.T.n_blocks + per - 1) / per);  // parts that hold blocks
-        Rows M; M.n = K + NP;
-        std::vector<double> mc(K + NP), mlb(K + NP, 0.0), mub(K + NP);
-        for (int k = 0; k < K; k++) { mc[k] = -hB[k] / theta_scale; mub[k] = pmax[k]; }
-        for (int p = 0; p < NP; p++) { mc[K + p] = -1.0; mub[K + p] = 4.0; }
+        // With the flags fixed, the rows of one group are ONE left-hand side against several right-hand sides: only the tightest can bind, the others get price 0.  The
+        // master prices that one row per group (a three-level tick: 16 of 70 rows — a tableau a third as wide, and none of its degenerate ties among identical columns).
+        std::vector<int> lk; lk.reserve(P.KG);
+        for (int g = 0; g < P.KG; g++) {
+            int best = -1;
+            for (int q = P.gr_off[g]; q < P.gr_off[g + 1]; q++) { const int k = P.gr_row[q]; if (best < 0 || hB[k] < hB[best]) best = k; }
+            if (best >= 0) lk.push_back(best);
+        }
+        std::sort(lk.begin(), lk.end());
+        const int KL = (int)lk.size();
+        Rows M; M.n = KL + NP;
+        std::vector<double> mc(KL + NP), mlb(KL + NP, 0.0), mub(KL + NP);
+        for (int i = 0; i < KL; i++) { mc[i] = -hB[lk[i]] / theta_scale; mub[i] = pmax[lk[i]]; }
+        for (int p = 0; p < NP; p++) { mc[KL + p] = -1.0; mub[KL + p] = 4.0; }
         std::vector<double> cut_scale;
         std::vector<std::pair<int, double>> terms;
         size_t in_master = cut_lo;
@@ -349,8 +359,8 @@ struct Solver {
                 const Cut &c = cuts[in_master];
                 for (int p = 0; p < NP; p++) {
                     terms.clear(); double sc = 1.0;
-                    for (int k = 0; k < K; k++) { const long long a = c.pact[(size_t)p * K + k]; if (a != 0) { const double v = (double)a / theta_scale; terms.push_back({k, v}); sc = std::max(sc, std::fabs(v)); } }
-                    terms.push_back({K + p, 1.0});
+                    for (int i = 0; i < KL; i++) { const long long a = c.pact[(size_t)p * K + lk[i]]; if (a != 0) { const double v = (double)a / theta_scale; terms.push_back({i, v}); sc = std::max(sc, std::fabs(v)); } }
+                    terms.push_back({KL + p, 1.0});
                     for (auto &t : terms) t.second /= sc;
                     M.add(terms, c.pcx[p] / theta_scale / sc, INF);
                     cut_scale.push_back(sc);
@@ -363,7 +373,7 @@ struct Solver {
         Tab mt; mt.init(&M, mc, mlb, mub);
         double ub_best = INF; std::vector<double> pi_best(K, 0.0);
         for (size_t k = cut_lo; k < cuts.size(); k++) { const double L = fixed_value(cuts[k], hB, cB); if (L < ub_best) { ub_best = L; pi_best = cuts[k].pi; } }
-        std::vector<double> pi(K), pi_prev_master;
+        std::vector<double> pi(K, 0.0), pi_prev_master;
         double lb_master = -INF;
         bool converged = false;
         for (int it = 0; it < 200; it++) {
@@ -372,10 +382,11 @@ struct Solver {
             if (ub_best < cutoff) { if (rq.trace) fprintf(stderr, "[price] configuration bounded by %.9f, below the incumbent %.9f\n", ub_best, cutoff); return false; }  // even the relaxation of this configuration is below the incumbent
             if (ub_best - lb_master <= tol * std::fabs(ub_best)) { converged = true; break; }
             bool same = !pi_prev_master.empty();
-            for (int k = 0; k < K && same; k++) same = std::fabs(mt.x[k] - pi_prev_master[k]) <= 1e-15 + 1e-12 * std::fabs(mt.x[k]);
-            pi_prev_master.assign(mt.x.begin(), mt.x.begin() + K);
+            for (int i = 0; i < KL && same; i++) same = std::fabs(mt.x[i] - pi_prev_master[i]) <= 1e-15 + 1e-12 * std::fabs(mt.x[i]);
+            pi_prev_master.assign(mt.x.begin(), mt.x.begin() + KL);
             const double alpha = (it < 3 || same) ? 0.0 : 0.3;       // in-out: between the best point so far and the master's proposal
-            for (int k = 0; k < K; k++) pi[k] = alpha * pi_best[k] + (1.0 - alpha) * mt.x[k];
+            for (int k = 0; k < K; k++) pi[k] = alpha * pi_best[k];
+            for (int i = 0; i < KL; i++) pi[lk[i]] += (1.0 - alpha) * mt.x[i];
             const int ci = evaluate(pi);
             if (ci < 0) break;
             if (sw.time_up) { if (rq.trace) fprintf(stderr, "[price] 70 %% of the time limit gone inside the master loop\n"); return false; }
@@ -405,13 +416,14 @@ struct Solver {
             size_t bk = cut_lo; double bv = -INF;
             for (size_t k = cut_lo; k < cuts.size(); k++) {
                 double v = cuts[k].pcx[p];
-                for (int r = 0; r < K; r++) v -= mt.x[r] * (double)cuts[k].pact[(size_t)p * K + r];
+                for (int i = 0; i < KL; i++) v -= mt.x[i] * (double)cuts[k].pact[(size_t)p * K + lk[i]];
                 if (v > bv) { bv = v; bk = k; }
             }
             lambda[bk * PARTS + p] = 1.0; lsum[p] = 1.0;
         }
         for (size_t k = cut_lo; k < cuts.size(); k++) for (int p = 0; p < NP; p++) lambda[k * PARTS + p] /= lsum[p];
-        pi_out.assign(mt.x.begin(), mt.x.begin() + K);
+        pi_out.assign(K, 0.0);
+        for (int i = 0; i < KL; i++) pi_out[lk[i]] = mt.x[i];
         *bound_out = ub_best;
         return true;
     }
