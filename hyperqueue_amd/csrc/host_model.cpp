@@ -812,7 +812,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             out.n_classes = ncls; out.t_classify_us = t_sep1 - t_sep0; out.t_blocks_us = t_sep2 - t_sep1; out.t_decode_us = clock_us() - t_sep2;
             return out;
         }
-        out = Counts();  // fall through to the general path
+        { const double a_ = t_sep1 - t_sep0, b_ = t_sep2 - t_sep1; out = Counts(); out.t_classify_us = a_; out.t_blocks_us = b_; }  // fall through to the general path (the two times: for the trace below)
     }
 
     // the gap rows below dereference the snapshot's assigned (rq, variant) lists: a bad index is the caller's error, not a crash
@@ -975,7 +975,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         return col;
     };
     static const bool trace_model = getenv("HQMILP_TRACE") != nullptr;
-    if (trace_model) fprintf(stderr, "[model] model build entered %.3f ms after the solver; worker blocks built at %.3f ms\n", (t_model0 - t_enter) / 1e3, (clock_us() - t_model0) / 1e3);
+    if (trace_model) fprintf(stderr, "[model] model build entered %.3f ms after the solver (worker classes %.3f, class blocks %.3f, lazy rows / empty workers / start %.3f); worker blocks built at %.3f ms\n", (t_model0 - t_enter) / 1e3, out.t_classify_us / 1e3, out.t_blocks_us / 1e3, (t_model0 - t_enter - out.t_classify_us - out.t_blocks_us) / 1e3, (clock_us() - t_model0) / 1e3);
     GapCache gaps(pb);
     // the gap depends on the worker's total resources and on what runs there: workers with the same signature share one computation per (blocker, batch)
     std::vector<uint32_t> gap_sig; std::map<std::vector<uint64_t>, uint32_t> sig_ids;
@@ -1129,6 +1129,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     const double t_model1 = clock_us();
     if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu terms, %zu worker signatures, %zu (batch, cut, blocker) passes over the workers\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), m.rcol.size(), sig_ids.size(), n_triples);
     hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438
+    if (trace_model) fprintf(stderr, "[model] solve done %.3f ms after the model\n", (clock_us() - t_model1) / 1e3);
     out.pre_us = t_model0 - t_enter; out.model_us = t_model1 - t_model0; out.milp_us = clock_us() - t_model1; out.price_sweeps = sol.price_sweeps; out.price_rounds = sol.price_rounds; out.price_us = sol.price_total_us;
     out.milp_nodes = sol.nodes; out.milp_cols = m.ncols(); out.milp_rows = m.nrows(); out.milp_components = sol.n_components;
     if (!sol.feasible) return out;
@@ -1171,6 +1172,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     for (uint32_t k : ord) { out.keys.push_back(key_list[k]); out.per_key.push_back(std::move(key_counts[k])); }
     hqhb::insertion_order(mn_hash.data(), (uint32_t)mn_hash.size(), ord);
     for (uint32_t k : ord) { out.mn_rq.push_back(mn_list[k]); out.mn_sets.push_back(std::move(mn_sets[k])); }
+    if (trace_model) fprintf(stderr, "[model] decoded %.3f ms after the model, %.3f ms after the solver was entered\n", (clock_us() - t_model1) / 1e3, (clock_us() - t_enter) / 1e3);
     return out;
 }
 

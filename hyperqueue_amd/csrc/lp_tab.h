@@ -174,6 +174,29 @@ struct Tab {
     void set_lb(int j, double v) { lb[j] = v; if (st[j] == AT_LO) shift_nonbasic(j, v); else if (st[j] == AT_UP && ub[j] < v) shift_nonbasic(j, v); }
     void set_ub(int j, double v) { ub[j] = v; if (st[j] == AT_UP) shift_nonbasic(j, v); else if (st[j] == AT_LO && lb[j] > v) shift_nonbasic(j, v); }
 
+    // A lower bound of how much the LP optimum drops when column j's upper bound is tightened to nv < x[j] — the first step of the dual simplex that would follow
+    // (the leaving variable is j itself, the objective moves by the smallest ratio times the infeasibility, and never back): one ratio test, no pivot, no copy.
+    // INF: no entering column, the tightened LP is infeasible.  The tableau must be optimal.
+    double loss_if_ub(int j, double nv) const {
+        if (x[j] <= nv + FEAS_TOL) return 0.0;
+        const double delta = x[j] - nv;
+        if (st[j] != BASIC) return std::fabs(d[j]) * delta;  // nonbasic (at its upper bound): moving it costs its reduced cost per unit, at least
+        int r = -1;
+        for (int i = 0; i < ma; i++) if (B[i] == j) { r = i; break; }
+        if (r < 0) return 0.0;
+        const double *prow = &T[(size_t)r * stride];
+        const int N = width();
+        double bratio = INF;
+        for (int q = 0; q < N; q++) {
+            if (st[q] == BASIC || lb[q] == ub[q]) continue;
+            const double a = prow[q];
+            if (!((st[q] == AT_LO && a > PIV_TOL) || (st[q] == AT_UP && a < -PIV_TOL))) continue;
+            const double ratio = std::fabs(d[q]) / std::fabs(a);
+            if (ratio < bratio) bratio = ratio;
+        }
+        return bratio >= INF ? INF : bratio * delta;
+    }
+
     // dual simplex over the active rows
     int reoptimise(long max_iters) {
         const int N = width();

@@ -125,6 +125,27 @@ struct CompSolver {
         value = z;
         return true;
     }
+    // see run(): true (and the point in xout) when the LP optimum is integral, equals the incumbent and no other integer point comes within the canonical window of it
+    bool unique_optimum(std::vector<double> &xout) {
+        if (!have || n == 0 || n > 4096) return false;
+        Tab u; u.init(&R, c, lb, ub); u.deadline = deadline;
+        if (solve_counted(u) != LP_OPT) return false;
+        lp_iters += u.iters;
+        const double z = u.objective();
+        if (std::fabs(z - best) > 1e-9 * std::max(1.0, std::fabs(best))) { if (tracing) fprintf(stderr, "[uniq] gap z %.12f best %.12f\n", z, best); return false; }   // an integrality gap: the incumbent is not the LP's vertex
+        for (int j = 0; j < n; j++) if (std::fabs(u.x[j] - std::round(u.x[j])) > INT_TOL || std::round(u.x[j]) != std::round(bx[(size_t)j])) { if (tracing) fprintf(stderr, "[uniq] x[%d] %.6f vs %.1f\n", j, u.x[j], bx[(size_t)j]); return false; }
+        if (slack_unit.size() != (size_t)R.m) find_slack_units();
+        const double window = 2e-9 * std::fabs(best) + 1e-12;
+        for (int k = 0; k < u.width(); k++) {
+            if (u.st[k] == BASIC || u.lb[k] == u.ub[k]) continue;
+            double step = 1.0;
+            if (k >= n) { step = slack_unit[(size_t)u.arow[k - n]]; if (!(step > 0.0)) { if (tracing) fprintf(stderr, "[uniq] row %d without unit, d %.3e\n", u.arow[k - n], u.d[k]); return false; } }
+            if (!(std::fabs(u.d[k]) * step > window)) { if (tracing) fprintf(stderr, "[uniq] col %d d %.3e step %.3e window %.3e\n", k, u.d[k], step, window); return false; }
+        }
+        xout.assign((size_t)n, 0.0);
+        for (int j = 0; j < n; j++) xout[(size_t)j] = std::round(u.x[j]);
+        return true;
+    }
     // ---- Gomory mixed-integer cuts at the root ------------------------------------------------------------------------------------------------------------------
     // The tick's coupled models are pure integer programs whose LP bound sits percent above the optimum (every worker a knapsack with fractional requests, the
     // batch-size rows across them) and whose Lagrangian / Dantzig-Wolfe bound still sits 2e-4..6e-4 above it on small clusters mid-run — twice the reference's
@@ -990,11 +1011,18 @@ struct CompSolver {
                 return 1;
             }
         }
-        if (tracing && !in_lns) fprintf(stderr, "[milp] n=%d final incumbent %.9f timed_out %d nodes %ld\n", n, have ? best : -1.0, (int)timed_out, nodes);
+        if (tracing && !in_lns) fprintf(stderr, "[milp] n=%d t=%.6fs final incumbent %.9f timed_out %d nodes %ld\n", n, wall() - t_begin, have ? best : -1.0, (int)timed_out, nodes);
         if (!have) return 0;
         xout = bx;
         if (timed_out) return 2;
         if (!canonical || n == 0) return 1;
+        // Before any probe: is the optimum UNIQUE?  Solve the plain LP once more (tens of microseconds at the sizes this matters for).  If its vertex is integral, worth
+        // exactly the incumbent, and dual non-degenerate by a margin — every nonbasic column's reduced cost, times the smallest step the column can take between integer
+        // points (1 for a structural column, the row's own grid for a slack), exceeds the canonical rule's window of 1e-9 |best| — then every OTHER integer point
+        // loses more than the window: x* is the only point the rule can return, and the probes below (one tableau copy + LP per placed column: 0.6 ms on an 80-column
+        // tick of a few dozen ready tasks, 15 probes) have nothing to decide.  The (W - idx) / W factor of the tick's objective makes this the common case.
+        if (!in_lns && unique_optimum(xout)) { trace("unique optimum: no tie-break probes"); return 1; }
+        xout = bx;
         // phase 2: among vectors with c.x >= best - tol, minimise the LAST column, then the one before it, ... (bound probing,
         // one feasibility B&B per probe)
         double tol = 1e-9 * std::fabs(best);
@@ -1023,6 +1051,11 @@ struct CompSolver {
                 // first probe just below the current value: most columns fail it immediately
                 double mid = first ? hi - 1 : std::floor((lo + hi) / 2);
                 first = false;
+                {   // most probes fail, and most of those fail at the first step of their LP: the ratio test on the parent tableau bounds what the tightened bound costs
+                    // (Tab::loss_if_ub) — below the threshold by a margin: no copy, no pivot, the probe has failed
+                    const double loss = warm.loss_if_ub(j, mid);
+                    if (loss >= INF || warm.objective() - loss < best - 2.0 * tol - 1e-12) { lo = mid + 1; continue; }
+                }
                 Tab t = warm;
                 work += (double)(warm.ma + 1) * (double)warm.width();
                 t.set_ub(j, mid);
@@ -1032,6 +1065,7 @@ struct CompSolver {
                 if (timed_out) { xout = cur; canonical_done = false; return 1; }  // optimal (phase 1 proved it) but the tie-break ran out of budget
                 if (ok) { cur = sol; hi = sol[j]; } else lo = mid + 1;
             }
+            if (tracing && !in_lns && cur[j] > lb[j]) fprintf(stderr, "[milp]   t=%.6fs column %d settled at %.0f (nodes %ld)\n", wall() - t_begin, j, hi, nodes);
             const bool unmoved = std::fabs(warm.x[j] - hi) <= FEAS_TOL;  // already sitting there: fixing it changes neither the point nor its optimality
             warm.set_lb(j, hi); warm.set_ub(j, hi);
             if (unmoved) continue;
@@ -1043,6 +1077,7 @@ struct CompSolver {
             }
         }
         xout = cur;
+        trace("tie-break done");
         return 1;
     }
 };
@@ -1452,7 +1487,8 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             for (auto &t : terms) t.second /= sc;
             double b = mdl.rhs[i] / sc;
             cs.R.add(terms, mdl.rtype[i] == ROW_MAX ? -INF : b, mdl.rtype[i] == ROW_MIN ? INF : b);
-            if (sweeper) { cs.row_scale.push_back(sc); cs.row_implied.push_back((size_t)i < mdl.row_implied.size() ? mdl.row_implied[(size_t)i] : 0); }
+            cs.row_scale.push_back(sc);
+            if (sweeper) cs.row_implied.push_back((size_t)i < mdl.row_implied.size() ? mdl.row_implied[(size_t)i] : 0);
         }
         if (sweeper && (int)mdl.col_group.size() == n) { cs.sweeper = sweeper; cs.col_group.resize(cs.n); for (int k = 0; k < cs.n; k++) cs.col_group[k] = mdl.col_group[cols[k]]; }
         // identical components (same rows, bounds and — up to 2^-40 relative — the same normalised costs) share one solve:
