@@ -131,8 +131,8 @@ const BlockMemo::Entry *BlockMemo::find(const hqmilp::Model &m) {
 }
 
 void BlockMemo::put(const hqmilp::Result &r) {
-    if (entries.size() < CAP) entries.emplace_back();
-    Entry &e = entries[entries.size() < CAP ? entries.size() - 1 : (next++ % CAP)];
+    const size_t slot = entries.size() < CAP ? (entries.emplace_back(), entries.size() - 1) : (next++ % CAP);   // (the index before the table is full: its last slot too)
+    Entry &e = entries[slot];
     e.hash = scratch_hash; e.key = scratch; e.x = r.x; e.nodes = r.nodes; e.n_components = r.n_components;
 }
 

@@ -1273,10 +1273,25 @@ int run_tick(hqtick_ctx *ctx, const hqtick_snapshot *s, hqtick_result *out, bool
     }
     if (ctx->consumed_unconfirmed) {  // HQTICK_FLAG_CONSUME_IN_TICK: the selection has written its tombstones
         ctx->consumed_unconfirmed = false;
-        if (rc < 0) {  // ... and the tick did not come back: what it took cannot be put back — the set is dropped, the host uploads it again
-            (void)hipStreamSynchronize(ctx->stream);
-            ctx->resident = false; ctx->last_valid = false;
-            ctx->err += " (HQTICK_FLAG_CONSUME_IN_TICK: the tick had already taken its tasks; the resident ready set is dropped, upload it again)";
+        if (rc < 0) {
+            // ... and the tick did not come back (a record sink too small, a mapping capacity exceeded, a failed exchange: errors a host can recover from).  What it took
+            // goes back: this tick's K1 left a valid group key on every task that was live, so the tombstones K4 wrote are recognisable and their request ids
+            // recoverable (k_restore_consumed: one pass over the key and request-id columns).  Only if THAT fails is the set dropped and the host uploads it again.
+            const std::string why = ctx->err;
+            bool restored = false;
+            if (hipStreamSynchronize(ctx->stream) == hipSuccess && ctx->last_valid && ctx->last_Q && ctx->h_q.ensure(64)) {
+                uint32_t *cntp = ctx->h_q.as<uint32_t>();
+                cntp[0] = 0;
+                if (hqk::ready_restore_consumed(ctx->d_gkey.as<uint16_t>(), ctx->d_trq.as<uint32_t>(), ctx->n_ready, ctx->last_Q, ctx->h_q.dev<uint32_t>(), ctx->stream) == hipSuccess &&
+                    hipStreamSynchronize(ctx->stream) == hipSuccess && cntp[0] <= ctx->last_n_sel) {
+                    ctx->n_live += ctx->last_n_sel;   // (what the tick had subtracted when it launched the selection; the kernel may have run for any part of it)
+                    restored = true;
+                }
+            }
+            ctx->last_valid = false; ctx->last_consumed = true; ctx->last_n_sel = 0;   // nothing of this tick is left to consume
+            ctx->err = why;
+            if (restored) ctx->err += " (HQTICK_FLAG_CONSUME_IN_TICK: what the tick had taken is back in the resident ready set)";
+            else { ctx->resident = false; ctx->err += " (HQTICK_FLAG_CONSUME_IN_TICK: the tick had already taken its tasks and they could not be put back; the resident ready set is dropped, upload it again)"; }
         }
     }
     if (rc >= 0 && retr_resident) {  // what create_task_mapping did to task states and redirects (mapping.rs:66-101), applied to the table
@@ -1438,15 +1453,20 @@ int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, c
     // (a rebuild leaves room behind the columns: the next fresh batches are appended)
     const uint64_t room = new_n + std::max<uint64_t>(new_n, 4096);
     if (!ctx->d_tid2.ensure(room * 8 + 8) || !ctx->d_tprio2.ensure(room * 8 + 8) || !ctx->d_trq2.ensure(room * 4 + 8)) return fail(ctx, HQTICK_E_DEVICE, "hipMalloc ready set (rebuild)");
-    if (N == 0) {  // nothing resident: the batch becomes the ready set
+    uint64_t first_batch_last_id = 0;
+    if (N == 0) {  // nothing resident: the batch becomes the ready set — through the same validation as an appended one (ascending ids, no reserved request id:
+                   // a refused batch leaves the set as it was, here: empty), written by the kernel that checks it
         if (n_add) {
-            HQ_HIP(hipMemcpyAsync(ctx->d_tid2.p, aid, (size_t)n_add * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(ctx->d_tprio2.p, aprio, (size_t)n_add * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            HQ_HIP(hipMemcpyAsync(ctx->d_trq2.p, arq, (size_t)n_add * 4, hipMemcpyDeviceToDevice, ctx->stream));
-            // The batch came through the pinned staging buffer (hqtick_ready_add_staged's host-to-device copy is queued ahead of these): the caller may
-            // stage the NEXT batch into the same buffer as soon as this call returns, so the copies must be over by then (the merge path
-            // below synchronises for its validation flags anyway).
+            if (!ctx->h_q.ensure(64)) return fail(ctx, HQTICK_E_DEVICE, "hipHostMalloc");
+            uint32_t *flag = ctx->h_q.as<uint32_t>(); flag[0] = 0;
+            HQ_HIP(hqk::ready_append(aid, aprio, arq, n_add, 0xFFFFFFFFFFFFFFFFull, ctx->d_tid2.as<uint64_t>(), ctx->d_tprio2.as<uint64_t>(), ctx->d_trq2.as<uint32_t>(), ctx->h_q.dev<uint32_t>(), ctx->stream));
+            uint64_t *last_back = reinterpret_cast<uint64_t *>(ctx->h_q.as<unsigned char>() + 16);
+            HQ_HIP(hipMemcpyAsync(last_back, ctx->d_tid2.as<uint64_t>() + (n_add - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+            // (the batch came through the pinned staging buffer: the caller may stage the NEXT batch into it as soon as this call returns, so the kernel must be over by then)
             HQ_HIP(hipStreamSynchronize(ctx->stream));
+            if (flag[0] & 8u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: ids not strictly ascending");
+            if (flag[0] & 16u) return fail(ctx, HQTICK_E_INVALID, "hqtick_ready_add: request id 0xFFFFFFFF is reserved");
+            first_batch_last_id = *last_back;
         }
     } else {
         const uint32_t n_slices = (uint32_t)((N + 255) / 256), stride = (n_slices + 15u) & ~15u;
@@ -1468,9 +1488,7 @@ int rebuild_ready(hqtick_ctx *ctx, const uint64_t *aid, const uint64_t *aprio, c
     }
     std::swap(ctx->d_tid, ctx->d_tid2); std::swap(ctx->d_tprio, ctx->d_tprio2); std::swap(ctx->d_trq, ctx->d_trq2);
     ctx->n_ready = new_n; ctx->n_live = new_n; ctx->last_valid = false; ctx->last_consumed = true;
-    if (N == 0 && n_add) {  // (the empty set took the batch as it is: its last id is the bound when the caller named it)
-        if (last_id >= first_id && first_id > 0) { ctx->max_id = last_id; ctx->max_id_valid = true; } else ctx->max_id_valid = false;
-    }
+    if (N == 0 && n_add) { ctx->max_id = first_batch_last_id; ctx->max_id_valid = true; }  // (the validated batch's own last id, read back from the device: the bound later appends are decided by)
     return 0;
 }
 }  // namespace

@@ -142,6 +142,7 @@ hipError_t repack_worker_rows(const uint64_t *old_total, const uint64_t *old_fre
 
 // Resident ready-set deltas: tombstone the given ids (sorted id column, binary search), count live tasks per
 // 256-task slice, and rebuild the columns dropping tombstones while merging a sorted batch of new tasks.
+hipError_t ready_restore_consumed(const uint16_t *gkey, uint32_t *rq, uint64_t n, uint32_t Q, uint32_t *n_done, hipStream_t s);
 hipError_t ready_mark_removed(const uint64_t *ids, uint32_t *rq, uint64_t n, const uint64_t *rm, uint32_t n_rm, uint32_t *n_done, hipStream_t s);
 // hqtick_ready_add_packed: the packed batch (pinned, device-mapped memory) -> the id / priority / rq columns of the batch in HBM
 hipError_t ready_unpack_adds(uint32_t n, uint32_t n_id_runs, const uint64_t *id_start, const uint32_t *id_first, const uint32_t *id_off, uint32_t n_prio_runs, const uint64_t *prio_value,

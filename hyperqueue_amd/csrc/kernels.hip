@@ -809,6 +809,19 @@ __global__ void __launch_bounds__(256) k_mark_removed(const uint64_t *__restrict
     }
 }
 
+// HQTICK_FLAG_CONSUME_IN_TICK, a tick that failed after its selection was launched: put back what it took.  K1 of that tick wrote a valid group key for every task
+// that was live when it ran (tombstones got GKEY_INVALID) and nothing has overwritten the column since, so "group key valid, request id a tombstone" is exactly
+// "tombstoned by this tick's K4" — and the request id it had is key % Q.  One streaming pass (6 B per task), no search, no list of what was selected.
+__global__ void __launch_bounds__(256) k_restore_consumed(const uint16_t *__restrict__ gkey, uint32_t *__restrict__ rq, uint64_t n, uint32_t Q, uint32_t *__restrict__ n_done) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint16_t g = gkey[i];
+        if (g != GKEY_INVALID && rq[i] == RQ_TOMBSTONE) { rq[i] = (uint32_t)g % Q; mine++; }
+    }
+    if (mine) atomicAdd(n_done, mine);
+}
+
 // live tasks per 256-task slice
 __global__ void __launch_bounds__(256) k_live_count(const uint32_t *__restrict__ rq, uint64_t n, uint32_t n_slices, uint32_t *__restrict__ slice_cnt) {
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
@@ -924,7 +937,8 @@ __global__ void __launch_bounds__(256) k_append_adds(const uint64_t *__restrict_
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_add) return;
     const uint64_t key = aid[j];
-    if (j > 0 ? aid[j - 1] >= key : key <= last_resident_id) atomicOr(err_flag, j > 0 ? 8u : 4u);  // not ascending / not behind the resident set (the host checked the latter)
+    // not ascending / not behind the resident set (the host checked the latter; last_resident_id = UINT64_MAX: nothing is resident, the first id is free)
+    if (j > 0 ? aid[j - 1] >= key : (last_resident_id != 0xFFFFFFFFFFFFFFFFull && key <= last_resident_id)) atomicOr(err_flag, j > 0 ? 8u : 4u);
     const uint32_t q = arq[j];
     if (q == RQ_TOMBSTONE) atomicOr(err_flag, 16u);
     nid[j] = key; nprio[j] = aprio[j]; nrq[j] = q;
@@ -1236,6 +1250,13 @@ hipError_t repack_worker_rows(const uint64_t *old_total, const uint64_t *old_fre
                               const uint64_t *add_total, const uint64_t *add_free, const int64_t *add_rem, uint64_t *new_total, uint64_t *new_free, int64_t *new_rem, hipStream_t s) {
     if (W_new == 0 || R == 0) return hipSuccess;
     hipLaunchKernelGGL(k_repack_worker_rows, dim3((W_new * R + 255) / 256), dim3(256), 0, s, old_total, old_free, old_rem, W_old, R, W_new, src, add_total, add_free, add_rem, new_total, new_free, new_rem);
+    return hipGetLastError();
+}
+
+hipError_t ready_restore_consumed(const uint16_t *gkey, uint32_t *rq, uint64_t n, uint32_t Q, uint32_t *n_done, hipStream_t s) {
+    if (n == 0 || Q == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_restore_consumed, dim3(blocks), dim3(256), 0, s, gkey, rq, n, Q, n_done);
     return hipGetLastError();
 }
 

@@ -808,7 +808,10 @@ Answer run_solver(Solver &S, const double tp0) {
     // usable came out) and leaves the point in x.
     auto try_config = [&](const std::vector<double> &B, std::vector<double> &x) -> double {
         tried.push_back(B);
-        if (sw.time_up) return -INF;  // (the one clock of this path, read at the sweeps: see Request::deadline_s, Sweeper::time_up)
+        // (the one clock of this path: read at the sweeps, and — where no other rank depends on the reading — here, so that the host-only stretches between sweeps
+        // (master LPs, rounding, polish) cannot carry a tick past its guard either; a sharded sweeper merges the ranks' readings inside its exchange, nowhere else)
+        if (!sw.merges_clock() && now_us() * 1e-6 > sw.guard_s) sw.time_up = true;
+        if (sw.time_up) return -INF;
         ans.rounds++;
         double cB = 0.0;
         for (int k = 0; k < K; k++) hB[k] = P.h[k];
@@ -992,6 +995,7 @@ Answer run_solver(Solver &S, const double tp0) {
         while (!stack.empty() && nodes < BP_MAX_NODES && (int)S.cuts.size() + 8 < S.max_sweeps && S.work < BP_MAX_WORK * rq.time_limit_s && S.sweep_steps < BP_MAX_STEPS * rq.time_limit_s &&
                !sw.time_up && !S.failed) {
             BPNode nd = std::move(stack.back()); stack.pop_back();
+            if (!sw.merges_clock() && now_us() * 1e-6 > sw.guard_s) { sw.time_up = true; stack.push_back(std::move(nd)); break; }
             if (closes(nd.bound)) { closed_max = std::max(closed_max, nd.bound); continue; }
             nodes++;
             if (!S.apply_node(nd, lo_arr, hi_arr)) { if (S.failed) break; continue; }  // empty node

@@ -102,9 +102,11 @@ enum { HQ_REC_PREFILL = 0, HQ_REC_ASSIGN = 1 };
 #define HQTICK_FLAG_NO_BLOCK_MEMO 8u
 /* hqtick_config.flags (ABI 8): hqtick_run_resident takes what it hands out out of the resident ready set ITSELF — as take_tasks / take_tasks_for_prefill / take_one do
  * inside the reference's tick (scheduler/taskqueue.rs:304-373): the selection kernel writes the tombstones while it selects, one kernel and one call per tick less
- * than hqtick_run_resident + hqtick_ready_consume_last (which is a no-op then).  The price: a tick that FAILS after its selection was launched has already taken
- * its tasks — the context drops the resident set (the next call says so) and the host uploads it again.  Without the flag a tick changes nothing until
- * hqtick_ready_consume_last says so. */
+ * than hqtick_run_resident + hqtick_ready_consume_last (which is a no-op then).  A tick that FAILS after its selection was launched (a record sink too small, a
+ * capacity exceeded, a failed exchange) puts back what it took — the group keys its scan left behind tell which tombstones are its own — and the set is as it
+ * was before the call; only if that restore itself fails (a device error) does the context drop the resident set (hqtick_last_error says which happened) and the
+ * host uploads it again.  Without the flag a tick changes nothing until hqtick_ready_consume_last says so: the two-call form stays the default and is what a
+ * drop-in should start from; the flag is for a host whose ticks are short enough for one kernel and one call to matter (bench.py's add -> tick loops). */
 #define HQTICK_FLAG_CONSUME_IN_TICK 16u
 
 /* redirect_kind of a result entry (scheduler/mapping.rs:66-101):

@@ -512,3 +512,44 @@ def test_consume_in_tick_equals_tick_then_consume(seed):
             live -= set(int(v) for v in victims)
         assert a.ready_count() == b.ready_count() == len(live)
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_a_failed_consume_in_tick_puts_its_tasks_back():
+    """under HQTICK_FLAG_CONSUME_IN_TICK the selection kernel has tombstoned what it selects when a later step of the tick fails (here: a record sink
+    too small for the tick, HQTICK_E_CAPACITY — an error a host recovers from by handing in a larger sink).  The context puts the tasks back (the group keys
+    the tick's own scan left behind say which tombstones are its): the live count is what it was, the set stays resident, and the next tick — with a sink that
+    fits — hands out exactly what a fresh context hands out on the same set."""
+    import ctypes as C
+
+    import torch
+
+    from hyperqueue_amd.sharded import sink_layout
+    from hyperqueue_amd.tick import HqTickError, Tick
+
+    snap = workloads.make("c3", n_tasks=200_000, n_workers=64, seed=5)
+    cfg = abi.make_config(time_limit_s=20.0, flags=abi.HQTICK_FLAG_CONSUME_IN_TICK)
+    t = Tick(cfg)
+    t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+    lib = t._lib
+    lib.hqtick_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.hqtick_set_record_sink.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    assert lib.hqtick_set_shard(t._ctx, 0, 1) == 0
+    W = len(snap.worker_id)
+    small = torch.zeros(sink_layout(W, 16)[4], dtype=torch.uint8, device="cuda")  # room for 16 records: the tick emits thousands
+    assert lib.hqtick_set_record_sink(t._ctx, C.c_void_p(small.data_ptr()), C.c_size_t(small.numel())) == 0
+    empty = dataclasses_replace_ready(snap)
+    n0 = t.ready_count()
+    with pytest.raises(HqTickError) as ei:
+        t.tick(empty, resident=True)
+    assert "back in the resident ready set" in str(ei.value)
+    assert t.ready_count() == n0
+    assert lib.hqtick_set_record_sink(t._ctx, None, 0) == 0  # back to records in host memory
+    got = t.tick(empty, resident=True)
+    ref = Tick(abi.make_config(time_limit_s=20.0))
+    ref.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
+    want = ref.tick(empty, resident=True)
+    assert_same(got, want)
+    handed = sum(len(r) for r in got.records)
+    assert handed > 0 and t.ready_count() == n0 - handed
+    t.close(); ref.close()
