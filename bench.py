@@ -166,6 +166,22 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random",
                          sweeps=ks_now["price_sweeps"], sweep_us=ks_now["price_sweep_us"], milp_us=ks_now["milp_us"], cols=ks_now["milp_cols"]))
         if len(rec_task) == 0:
             break
+    # EXTENSION (hqtick_graph_blevel, include/hqtick.h): BASELINE config 5 names a "dynamic b-level recompute"; the reference has none, so this is measured
+    # AFTER the loop — no tick above saw a b-level — on what the loop left of the graph: longest path to a sink for every task, into the low 32 bits of its priority.
+    blevel = None
+    try:
+        n_left = int(t.graph_stats()["n_tasks"])
+        b0 = time.perf_counter(); bi = t.graph_blevel(update_ready=True); b1 = time.perf_counter()
+        gs = t.graph_stats()
+        edges_left = int(gs["n_edges_live"])
+        blevel = {"what": "EXTENSION, no reference counterpart, parity unpinned (checker: oracle/graph_oracle.py blevels()); not used by any tick of this loop",
+                  "tasks_in_graph": n_left, "live_edges": edges_left, "sweeps": bi["sweeps"], "max_level": bi["max_level"], "ready_tasks_updated": bi["ready_updated"],
+                  "call_ms": 1e3 * (b1 - b0), "kernels_us": gs["last_kernel_us"],
+                  # per sweep every live slot walks its consumer list: 16 B of slot state + 8 B per edge + 4 B per consumer value read, 4 B written
+                  "algorithmic_bytes": int(bi["sweeps"] * (n_left * 20 + edges_left * 12)),
+                  "GBps": (bi["sweeps"] * (n_left * 20 + edges_left * 12)) / (gs["last_kernel_us"] * 1e-6) / 1e9 if gs["last_kernel_us"] > 0 else None}
+    except Exception as e:  # noqa: BLE001
+        blevel = {"error": repr(e)}
     st = t.graph_stats()
     t.close()
     first = rows[0]  # the first wave: every source of the DAG that the cold tick could place finishes at once
@@ -216,6 +232,7 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random",
                        "algorithmic_bytes": int(first_bytes), "GBps": first_bytes / (first["finish_kernel_us"] * 1e-6) / 1e9 if first["finish_kernel_us"] > 0 else None,
                        "tick_us": 1e6 * first["tick"], "handed_out": first["n_out"], "price_sweeps": int(first["sweeps"]), "model_columns": int(first["cols"]), "is_optimal": bool(first["optimal"])},
         "ready_set_p50": int(med("ready")), "all_ticks_optimal": bool(all(r["optimal"] for r in use)),
+        "blevel_recompute": blevel,
     }
 
 

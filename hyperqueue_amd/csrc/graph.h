@@ -77,6 +77,10 @@ class Graph {
     int remove(uint64_t n, const uint64_t *id, bool recursive, hipStream_t s);
     // test accessor: Task::get_unfinished_deps; 0xFFFFFFFF for an id that is not in the graph
     int unfinished(uint64_t n, const uint64_t *id, uint32_t *out, hipStream_t s);
+    // EXTENSION (no reference counterpart, parity unpinned): the b-level of every task — longest path to a sink of what is still in the graph — into the low 32
+    // bits of its priority (common/priority.rs:43-66: the "scheduler priority" bits the reference never writes).  Returns the sweeps it took.
+    int blevel(uint32_t *max_level, const uint64_t *ready_id, const uint32_t *ready_rq, uint64_t *ready_prio, uint64_t n_ready, uint32_t *n_ready_updated, hipStream_t s);
+    int priorities(uint64_t n, const uint64_t *id, uint64_t *out, hipStream_t s);  // test accessor: the priorities the graph holds (0 for an unknown id)
     void clear();
     void release();
 
@@ -104,6 +108,7 @@ class Graph {
     hqbuf::DevBuf d_id, d_prio, d_order, d_rq, d_unf, d_gen, d_head, d_free, d_tmpc, d_tmpb;
     hqbuf::DevBuf d_htk, d_htv;
     hqbuf::DevBuf d_rn, d_ro, d_rl, d_edge, d_rn2, d_ro2, d_rl2, d_edge2;
+    hqbuf::DevBuf d_bl;
     hqbuf::DevBuf d_ctl, d_stage, d_eds, d_erk, d_okey, d_oval, d_out_id, d_out_prio, d_out_rq, d_big;
     hqbuf::PinBuf h_ctl, h_stage, h_out;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

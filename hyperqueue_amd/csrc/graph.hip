@@ -324,6 +324,59 @@ __global__ void __launch_bounds__(256) k_g_unfinished(View v, const uint64_t *__
     out[i] = sl == NONE ? 0xFFFFFFFFu : v.unfinished[sl];
 }
 
+// ------------------------------------------------------------------------------------------------------- b-level (extension)
+// BASELINE.json's config 5 names a "dynamic b-level recompute"; the reference has none (Priority's low 32 bits — "scheduler priority",
+// common/priority.rs:43-66 — are never written), so this is an EXTENSION with no reference counterpart: parity unpinned, off unless the host calls
+// hqtick_graph_blevel, and no parity run does.  b-level(t) = 0 for a task without a live consumer, else 1 + the largest b-level among its consumers: the
+// length of the longest path from t to a sink of what is still in the graph.
+// One sweep: every live slot recomputes its value from its consumers' current values (a pull over its own edge list — the edges run producer -> consumer, so
+// nobody writes anybody else's word and no atomics are needed).  Values only grow, a stale read only delays: the fixed point is the longest path, reached after
+// at most depth + 1 sweeps; `changed` says when.
+__global__ void __launch_bounds__(256) k_g_blevel_sweep(View v, uint32_t n_slots, uint32_t *__restrict__ bl, uint32_t *__restrict__ changed) {
+    const uint32_t sl = blockIdx.x * 256 + threadIdx.x;
+    bool ch = false;
+    if (sl < n_slots && v.unfinished[sl] != ST_FREE) {
+        uint32_t best = 0;
+        for (uint32_t r = v.head[sl]; r != NONE; r = v.run_next[r]) {
+            const uint32_t off = v.run_off[r], len = v.run_len[r];
+            for (uint32_t e = 0; e < len; e++) {
+                const uint2 ed = v.edge[off + e];
+                if (v.gen[ed.x] != ed.y || v.unfinished[ed.x] == ST_FREE) continue;  // the consumer has left the graph
+                const uint32_t c = bl[ed.x];
+                const uint32_t cand = c == 0xFFFFFFFFu ? c : c + 1;
+                best = cand > best ? cand : best;
+            }
+        }
+        if (best != bl[sl]) { bl[sl] = best; ch = true; }
+    }
+    if (__ballot(ch) && (threadIdx.x & 63) == 0) atomicOr(changed, 1u);
+}
+// the result into the low 32 bits of the tasks' priorities (where Priority::add_priority_u32 would put a scheduler priority); the largest value comes back
+__global__ void __launch_bounds__(256) k_g_blevel_store(View v, uint32_t n_slots, const uint32_t *__restrict__ bl, uint32_t *__restrict__ max_out) {
+    const uint32_t sl = blockIdx.x * 256 + threadIdx.x;
+    uint32_t mine = 0;
+    if (sl < n_slots && v.unfinished[sl] != ST_FREE) { mine = bl[sl]; v.prio[sl] = (v.prio[sl] & 0xFFFFFFFF00000000ull) | (uint64_t)mine; }
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(mine, off, 64); mine = o > mine ? o : mine; }
+    if ((threadIdx.x & 63) == 0 && mine) atomicMax(max_out, mine);
+}
+// ... and of the tasks that already sit in the resident ready set (ids -> slots through the hash table); tombstones and ids the graph does not hold are left alone
+__global__ void __launch_bounds__(256) k_g_blevel_ready(View v, const uint64_t *__restrict__ ids, const uint32_t *__restrict__ rq, uint64_t *__restrict__ prio, uint64_t n, uint32_t *__restrict__ n_done) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    bool hit = false;
+    if (i < n && rq[i] != 0xFFFFFFFFu) {
+        const uint32_t sl = ht_find(v, ids[i]);
+        if (sl != NONE) { prio[i] = v.prio[sl]; hit = true; }
+    }
+    const uint32_t c = (uint32_t)__popcll(__ballot(hit));
+    if (c && (threadIdx.x & 63) == 0) atomicAdd(n_done, c);
+}
+__global__ void __launch_bounds__(256) k_g_priorities(View v, const uint64_t *__restrict__ ids, uint32_t n, uint64_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t sl = ht_find(v, ids[i]);
+    out[i] = sl == NONE ? 0ull : v.prio[sl];
+}
+
 __global__ void k_g_publish(View v, Ctl *host_copy) { if (threadIdx.x < sizeof(Ctl) / 4) reinterpret_cast<uint32_t *>(host_copy)[threadIdx.x] = reinterpret_cast<uint32_t *>(v.ctl)[threadIdx.x]; }
 
 __global__ void __launch_bounds__(256) k_g_gather(View v, const uint64_t *__restrict__ okey, const uint32_t *__restrict__ oval, uint32_t n, uint64_t *__restrict__ out_id,
@@ -475,7 +528,7 @@ void Graph::clear() {
 
 void Graph::release() {
     for (hqbuf::DevBuf *b : {&d_id, &d_prio, &d_order, &d_rq, &d_unf, &d_gen, &d_head, &d_free, &d_tmpc, &d_tmpb, &d_htk, &d_htv, &d_rn, &d_ro, &d_rl, &d_edge, &d_rn2, &d_ro2,
-                             &d_rl2, &d_edge2, &d_ctl, &d_stage, &d_eds, &d_erk, &d_okey, &d_oval, &d_out_id, &d_out_prio, &d_out_rq, &d_big})
+                             &d_rl2, &d_edge2, &d_ctl, &d_stage, &d_eds, &d_erk, &d_okey, &d_oval, &d_out_id, &d_out_prio, &d_out_rq, &d_big, &d_bl})
         b->release();
     h_ctl.release(); h_stage.release(); h_out.release();
     if (ev0) hipEventDestroy(ev0);
@@ -706,6 +759,54 @@ int Graph::unfinished(uint64_t n, const uint64_t *id, uint32_t *out, hipStream_t
     if (!d_erk.ensure(n * 4 + 64)) return fail(HQTICK_E_DEVICE, "hipMalloc graph staging");
     hipLaunchKernelGGL(k_g_unfinished, dim3(nblk(n)), dim3(256), 0, s, view(), d_stage.as<uint64_t>(), (uint32_t)n, d_erk.as<uint32_t>());
     G_HIP(hipMemcpyAsync(out, d_erk.p, n * 4, hipMemcpyDeviceToHost, s));
+    G_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+// b-level of every task in the graph into the low 32 bits of its priority (extension: see k_g_blevel_sweep).  Returns the number of sweeps (>= 1) or a negative
+// HQTICK_E_* code; *max_level = the largest b-level.  ready_*: the resident ready columns to refresh from the graph's priorities (may be null).
+int Graph::blevel(uint32_t *max_level, const uint64_t *ready_id, const uint32_t *ready_rq, uint64_t *ready_prio, uint64_t n_ready, uint32_t *n_ready_updated, hipStream_t s) {
+    if (max_level) *max_level = 0;
+    if (n_ready_updated) *n_ready_updated = 0;
+    if (!init(s)) return fail(HQTICK_E_DEVICE, "dependency graph: device setup failed");
+    if (n_slots == 0) return 0;
+    if (!d_bl.ensure(n_slots * 4 + 64) || !h_stage.ensure(64)) return fail(HQTICK_E_DEVICE, "hipMalloc b-level");
+    View v = view();
+    uint32_t *flag = h_stage.as<uint32_t>(), *dflag = h_stage.dev<uint32_t>();
+    G_HIP(hipMemsetAsync(d_bl.p, 0, n_slots * 4, s));
+    G_HIP(hipEventRecord(ev0, s));
+    int sweeps = 0;
+    for (;;) {
+        flag[0] = 0;
+        for (uint32_t l = 0; l < BFS_LEVELS_PER_SYNC; l++) { hipLaunchKernelGGL(k_g_blevel_sweep, dim3(nblk(n_slots)), dim3(256), 0, s, v, (uint32_t)n_slots, d_bl.as<uint32_t>(), dflag); sweeps++; }
+        hipLaunchKernelGGL(k_g_blevel_sweep, dim3(nblk(n_slots)), dim3(256), 0, s, v, (uint32_t)n_slots, d_bl.as<uint32_t>(), dflag + 1);  // (the group's last sweep on a word of its own: nothing changed in it = done)
+        sweeps++;
+        G_HIP(hipGetLastError());
+        G_HIP(hipStreamSynchronize(s));
+        if (!flag[1]) break;
+        flag[1] = 0;
+        if (sweeps > 1 << 20) return fail(HQTICK_E_DEVICE, "b-level: the sweeps do not settle (a cycle in the dependency graph?)");
+    }
+    flag[2] = 0; flag[3] = 0;
+    hipLaunchKernelGGL(k_g_blevel_store, dim3(nblk(n_slots)), dim3(256), 0, s, v, (uint32_t)n_slots, d_bl.as<uint32_t>(), dflag + 2);
+    if (ready_id && ready_prio && n_ready) hipLaunchKernelGGL(k_g_blevel_ready, dim3((unsigned)((n_ready + 255) / 256)), dim3(256), 0, s, v, ready_id, ready_rq, ready_prio, n_ready, dflag + 3);
+    G_HIP(hipEventRecord(ev1, s));
+    G_HIP(hipGetLastError());
+    G_HIP(hipStreamSynchronize(s));
+    if (max_level) *max_level = flag[2];
+    if (n_ready_updated) *n_ready_updated = flag[3];
+    if (ev0) { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) last_us_ = ms * 1000.0; }
+    return sweeps;
+}
+
+int Graph::priorities(uint64_t n, const uint64_t *id, uint64_t *out, hipStream_t s) {
+    if (n == 0) return 0;
+    if (!init(s)) return fail(HQTICK_E_DEVICE, "dependency graph: device setup failed");
+    if (n_slots == 0) { for (uint64_t i = 0; i < n; i++) out[i] = 0; return 0; }
+    if (int rc = stage(n, id, s)) return rc;
+    if (!d_okey.ensure(n * 8 + 64)) return fail(HQTICK_E_DEVICE, "hipMalloc graph staging");
+    hipLaunchKernelGGL(k_g_priorities, dim3(nblk(n)), dim3(256), 0, s, view(), d_stage.as<uint64_t>(), (uint32_t)n, d_okey.as<uint64_t>());
+    G_HIP(hipMemcpyAsync(out, d_okey.p, n * 8, hipMemcpyDeviceToHost, s));
     G_HIP(hipStreamSynchronize(s));
     return 0;
 }

@@ -1707,6 +1707,25 @@ int hqtick_graph_unfinished(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id
     return r < 0 ? graph_fail(ctx, r) : 0;
 }
 
+int hqtick_graph_blevel(hqtick_ctx *ctx, uint32_t flags, uint32_t *max_level, uint32_t *n_ready_updated) {
+    if (!ctx) return HQTICK_E_INVALID;
+    if (flags & ~(uint32_t)HQTICK_BLEVEL_UPDATE_READY) return fail(ctx, HQTICK_E_INVALID, "hqtick_graph_blevel: unknown flag");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, HQTICK_E_DEVICE, "hipSetDevice");
+    const bool upd = (flags & HQTICK_BLEVEL_UPDATE_READY) && ctx->resident && ctx->n_ready;
+    int r = ctx->graph.blevel(max_level, upd ? ctx->d_tid.as<uint64_t>() : nullptr, upd ? ctx->d_trq.as<uint32_t>() : nullptr, upd ? ctx->d_tprio.as<uint64_t>() : nullptr, upd ? ctx->n_ready : 0,
+                              n_ready_updated, ctx->stream);
+    if (r < 0) return graph_fail(ctx, r);
+    if (upd) { ctx->levels_valid = false; ctx->last_valid = false; }  // the ready set's priorities changed: the next tick rediscovers its levels
+    return r;
+}
+
+int hqtick_graph_priorities(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, uint64_t *out) {
+    if (!ctx || (n && (!task_id || !out))) return HQTICK_E_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, HQTICK_E_DEVICE, "hipSetDevice");
+    int r = ctx->graph.priorities(n, task_id, out, ctx->stream);
+    return r < 0 ? graph_fail(ctx, r) : 0;
+}
+
 int hqtick_graph_get_stats(const hqtick_ctx *ctx, hqtick_graph_stats *out) {
     if (!ctx || !out) return HQTICK_E_INVALID;
     hqgraph::Stats st = ctx->graph.stats();

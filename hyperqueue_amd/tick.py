@@ -287,6 +287,22 @@ class Tick:
         self._chk(self._lib.hqtick_graph_remove(self._ctx, len(a), a.ctypes.data_as(abi.u64p), 1 if recursive else 0))
         return self._graph_last_ids()
 
+    def graph_blevel(self, update_ready: bool = False) -> dict:
+        """EXTENSION (include/hqtick.h: hqtick_graph_blevel; no reference counterpart, parity unpinned): b-levels into the low 32 bits of the graph's priorities."""
+        mx, upd = C.c_uint32(0), C.c_uint32(0)
+        self._lib.hqtick_graph_blevel.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        rc = self._lib.hqtick_graph_blevel(self._ctx, 1 if update_ready else 0, C.byref(mx), C.byref(upd))
+        if rc < 0:
+            self._chk(rc)
+        return {"sweeps": int(rc), "max_level": int(mx.value), "ready_updated": int(upd.value)}
+
+    def graph_priorities(self, task_id) -> np.ndarray:
+        a = np.ascontiguousarray(task_id, np.uint64)
+        out = np.zeros(len(a), np.uint64)
+        self._lib.hqtick_graph_priorities.argtypes = [C.c_void_p, C.c_uint64, abi.u64p, abi.u64p]
+        self._chk(self._lib.hqtick_graph_priorities(self._ctx, len(a), a.ctypes.data_as(abi.u64p), out.ctypes.data_as(abi.u64p)))
+        return out
+
     def graph_unfinished(self, task_id) -> np.ndarray:
         a = np.ascontiguousarray(task_id, np.uint64)
         out = np.zeros(len(a), np.uint32)

@@ -40,7 +40,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define HQTICK_ABI_VERSION 8u  /* 8: HQ_WORKERS_RESIDENT, hqtick_cluster_last_reassigned; 7: hqtick_kernel_stats carries the price-sweep figures of coupled ticks; cluster membership deltas */
+#define HQTICK_ABI_VERSION 9u  /* 9: hqtick_graph_blevel / _priorities (extension), hqtick_set_kernel_timing(ctx, 2), a failed CONSUME_IN_TICK tick restores its tasks; 8: HQ_WORKERS_RESIDENT, hqtick_cluster_last_reassigned; 7: hqtick_kernel_stats carries the price-sweep figures of coupled ticks; cluster membership deltas */
 
 /* ResourceAmount::MAX                                    common/resources/amount.rs:31 */
 #define HQ_AMOUNT_MAX UINT64_MAX
@@ -483,6 +483,18 @@ const uint64_t *hqtick_graph_last_ids(const hqtick_ctx *ctx, uint64_t *n);
 uint64_t hqtick_graph_last_unknown(const hqtick_ctx *ctx);
 int hqtick_graph_unfinished(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, uint32_t *out);
 int hqtick_graph_get_stats(const hqtick_ctx *ctx, hqtick_graph_stats *out);
+/* EXTENSION — no reference counterpart, parity unpinned, OFF unless called (BASELINE.json configs[4] names a "dynamic b-level recompute"; the reference has none:
+ * the low 32 bits of Priority, "scheduler priority", are never written — common/priority.rs:43-66, server/task.rs:175-177).
+ * hqtick_graph_blevel: b-level(t) = 0 for a task no task still in the graph depends on, else 1 + the largest b-level among its consumers — the longest path
+ * from t to a sink — for every task of the device-resident graph, by level-synchronous sweeps over its consumer lists; the value REPLACES the low 32 bits of the
+ * task's priority (what Priority::add_priority_u32 would add to a priority whose low bits are zero), so that tasks released by later hqtick_graph_finish calls
+ * carry it into the ready set.  HQTICK_BLEVEL_UPDATE_READY: the tasks already in the resident ready set get their graph priorities too (one pass over the ready
+ * columns, ids -> graph slots through the hash table; *n_ready_updated = how many).  Returns the number of sweeps (>= 0) or a negative error; *max_level = the
+ * largest b-level (the depth of the graph).  A host that wants the reference's behaviour never calls it; no parity test does.
+ * hqtick_graph_priorities: the priorities the graph holds for the given ids (0 for an id it does not hold): test accessor. */
+#define HQTICK_BLEVEL_UPDATE_READY 1u
+int hqtick_graph_blevel(hqtick_ctx *ctx, uint32_t flags, uint32_t *max_level, uint32_t *n_ready_updated);
+int hqtick_graph_priorities(hqtick_ctx *ctx, uint64_t n, const uint64_t *task_id, uint64_t *out);
 
 /*
  * Multi-GPU: worker sharding.  Every rank (one ctx per GPU) runs the tick on the SAME snapshot — scans, batches and the

@@ -113,3 +113,38 @@ class GraphOracle:
     def unfinished(self, id_: int) -> int:
         t = self.tasks.get(id_)
         return 0xFFFFFFFF if t is None else t.unfinished
+
+    # ---- EXTENSION, no reference counterpart (the reference writes no scheduler priority; common/priority.rs:43-66) — parity unpinned -------------
+    def blevels(self) -> dict[int, int]:
+        """b-level of every task in the map: 0 without a consumer in the map, else 1 + the largest b-level among its consumers (longest path to a sink).
+        The checker of hqtick_graph_blevel (include/hqtick.h); a definition, not a restatement: the reference has nothing to restate here."""
+        bl: dict[int, int] = {}
+        # the consumers of a task are minted after it (a dependency names an existing task): descending id order visits consumers first — but ids need not be
+        # minted in order across calls, so this is a plain memoised depth-first walk with an explicit stack
+        for root in self.tasks:
+            if root in bl:
+                continue
+            stack = [(root, iter(self.tasks[root].consumers))]
+            while stack:
+                node, it = stack[-1]
+                advanced = False
+                for c in it:
+                    if c in self.tasks and c not in bl:
+                        stack.append((c, iter(self.tasks[c].consumers)))
+                        advanced = True
+                        break
+                if advanced:
+                    continue
+                live = [bl[c] for c in self.tasks[node].consumers if c in self.tasks]
+                bl[node] = 1 + max(live) if live else 0
+                stack.pop()
+        return bl
+
+    def apply_blevels(self) -> int:
+        """Priority's low 32 bits := b-level (what hqtick_graph_blevel does to the device graph, and — with HQTICK_BLEVEL_UPDATE_READY — to the ready set).  Returns the depth."""
+        bl = self.blevels()
+        for id_, t in self.tasks.items():
+            t.priority = (t.priority & 0xFFFFFFFF00000000) | min(bl[id_], 0xFFFFFFFF)
+            if id_ in self.ready:
+                self.ready[id_] = (t.priority, self.ready[id_][1])
+        return max(bl.values(), default=0)

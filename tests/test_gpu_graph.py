@@ -249,3 +249,67 @@ def test_c5_dag_with_worker_churn_equals_oracle(T):
         assert T.ready_count() == len(g.ready) and T.graph_stats()["n_tasks"] == len(g.tasks)
         handed += len(finished); steps += 1
     assert not g.tasks and handed == n and steps > 5
+
+
+# ---- EXTENSION: hqtick_graph_blevel (include/hqtick.h) — no reference counterpart, parity unpinned; the checker is oracle/graph_oracle.py's definition --------------
+def test_the_low_priority_bits_stay_zero_unless_the_host_asks(T):
+    """the reference never writes Priority's low 32 bits (common/priority.rs:43-66): neither does a graph nobody called hqtick_graph_blevel on"""
+    ids, prio, rq, off, dep = workloads.make_dag(5_000, seed=2)
+    ready = T.graph_add_tasks(ids, prio, rq, (off, dep))
+    assert (T.graph_priorities(ids) & np.uint64(0xFFFFFFFF) == 0).all()
+    T.ready_remove(ready)
+    rel, _ = T.graph_finish(ready)
+    assert len(rel) and (T.graph_priorities(rel) & np.uint64(0xFFFFFFFF) == 0).all()
+
+
+@pytest.mark.parametrize("shape,seed", [("random", 1), ("random", 4), ("layered", 2)])
+def test_blevel_equals_the_oracles_definition(T, shape, seed):
+    from oracle.graph_oracle import GraphOracle
+
+    n = 30_000
+    ids, prio, rq, off, dep = workloads.make_dag(n, seed=seed) if shape == "random" else workloads.make_dag_layered(n, width=600, seed=seed)
+    g = GraphOracle()
+    g.on_new_tasks([(int(ids[i]), int(prio[i]), int(rq[i]), [int(x) for x in dep[off[i]:off[i + 1]]]) for i in range(n)])
+    ready = T.graph_add_tasks(ids, prio, rq, (off, dep)).tolist()
+    for wave in range(3):  # on the full graph, and again after waves of finishes and a recursive removal have eaten into it
+        info = T.graph_blevel(update_ready=True)
+        depth = g.apply_blevels()
+        live = np.asarray(sorted(g.tasks), np.uint64)
+        assert info["max_level"] == depth and info["sweeps"] >= 1
+        assert T.graph_priorities(live).tolist() == [g.tasks[int(i)].priority for i in live]
+        assert info["ready_updated"] == len(g.ready)
+        # the ready set carries the new priorities: the next tick ranks by them.  (checked through the graph's released tasks below and through a tick in the test after this one)
+        take = ready[: max(1, len(ready) // 2)]
+        assert T.ready_remove(np.asarray(take, np.uint64)) == len(take)
+        g.take_from_ready(take)
+        rel_w, _ = g.task_finished(take)
+        rel, unk = T.graph_finish(take)
+        assert unk == 0 and rel.tolist() == rel_w
+        if wave == 1 and len(g.tasks) > 10:
+            victim = sorted(g.tasks)[len(g.tasks) // 2]
+            gone_w, _ = g.remove([victim], recursive=True)
+            gone = T.graph_remove(np.asarray([victim], np.uint64), recursive=True)
+            assert gone.tolist() == gone_w
+        ready = sorted(g.ready)
+    assert depth >= 1
+
+
+def test_a_tick_ranks_by_the_b_levels_once_they_are_in_the_ready_set(T):
+    """after hqtick_graph_blevel(UPDATE_READY) the resident ready set's priorities carry the b-levels: the tick on it equals the oracle's tick on a snapshot with those priorities"""
+    from oracle.graph_oracle import GraphOracle
+    from oracle.oracle import Oracle
+
+    n, W = 4_000, 4
+    ids, prio, rq, off, dep = workloads.make_dag(n, seed=6)
+    rq = (rq % np.uint32(3)).astype(np.uint32)
+    g = GraphOracle()
+    g.on_new_tasks([(int(ids[i]), int(prio[i]), int(rq[i]), [int(x) for x in dep[off[i]:off[i + 1]]]) for i in range(n)])
+    T.graph_add_tasks(ids, prio, rq, (off, dep))
+    T.graph_blevel(update_ready=True)
+    g.apply_blevels()
+    drv = workloads.DagChurn(n_workers=W, churn=0.0, seed=1)
+    rid = sorted(g.ready)
+    assert len({g.ready[i][0] for i in rid}) > 1  # several b-levels among the sources: the tick has levels to rank
+    want = Oracle(abi.make_config(time_limit_s=20.0), canonical=True).tick(drv.snapshot(rid, [g.ready[i][0] for i in rid], [g.ready[i][1] for i in rid]))
+    got = T.tick(drv.snapshot(), resident=True)
+    assert got.batches == want.batches and got.counts == want.counts and got.records == want.records

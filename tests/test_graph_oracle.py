@@ -52,3 +52,22 @@ def test_unknown_finished_is_counted():
     g.on_new_tasks([(1, 0, 0, [])])
     g.take_from_ready([1])
     assert g.task_finished([7, 1, 1]) == ([], 2)
+
+
+# ---- the b-level extension's checker (no reference counterpart: a definition, checked on graphs small enough to do by hand) -----------------------------------------
+def test_blevels_are_the_longest_paths_to_a_sink():
+    from oracle.graph_oracle import GraphOracle
+
+    g = GraphOracle()
+    #   1 -> 2 -> 4 -> 6        3 -> 4        5 (alone)        2 -> 7
+    g.on_new_tasks([(1, 10 << 32, 0, []), (2, 10 << 32, 0, [1]), (3, 10 << 32, 0, []), (4, 10 << 32, 0, [2, 3]), (5, 10 << 32, 0, []), (6, 10 << 32, 0, [4]), (7, 10 << 32, 0, [2])])
+    assert g.blevels() == {1: 3, 2: 2, 3: 2, 4: 1, 5: 0, 6: 0, 7: 0}
+    assert g.apply_blevels() == 3
+    assert g.tasks[1].priority == (10 << 32) | 3 and g.ready[1][0] == (10 << 32) | 3 and g.ready[5][0] == 10 << 32
+    # the path through 4 goes away with it: 2 keeps its consumer 7, 3 becomes a sink
+    g.remove([4], recursive=True)
+    assert g.blevels() == {1: 2, 2: 1, 3: 0, 5: 0, 7: 0}
+    # finished tasks leave the map: what is left is measured
+    g.take_from_ready([1, 3, 5])
+    g.task_finished([1])
+    assert g.blevels() == {2: 1, 3: 0, 5: 0, 7: 0}
