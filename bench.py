@@ -546,7 +546,7 @@ def preflight(rank: int, world: int, local_rank: int) -> int:
     out = {"preflight": "hqtick_comm_init + one all-gather of 4 KB per rank", "ranks": world}
     wd = watchdog(120.0, lambda: (rank == 0) and print(json.dumps(dict(out, error="did not come back within 120 s"))))
     try:
-        st = ShardedTick(abi.make_config(device_index=local_rank), rank=rank, world=world, records_per_shard=256)
+        st = ShardedTick(abi.make_config(device_index=local_rank), rank=rank, world=world, records_per_shard=256, collective="library")  # (the library's own communicator, also with one rank)
         out["collective"] = st.collective; out["ranks_in_the_library_communicator"] = int(st.comm_world)
         dev = torch.device("cuda", local_rank)
         total = 4096

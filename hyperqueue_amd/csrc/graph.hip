@@ -772,26 +772,28 @@ int Graph::blevel(uint32_t *max_level, const uint64_t *ready_id, const uint32_t 
     if (n_slots == 0) return 0;
     if (!d_bl.ensure(n_slots * 4 + 64) || !h_stage.ensure(64)) return fail(HQTICK_E_DEVICE, "hipMalloc b-level");
     View v = view();
-    uint32_t *flag = h_stage.as<uint32_t>(), *dflag = h_stage.dev<uint32_t>();
-    G_HIP(hipMemsetAsync(d_bl.p, 0, n_slots * 4, s));
+    // flag words behind the values, in HBM (a wavefront that changes something ORs into one: 15 k atomics per sweep — over PCIe into pinned memory they took 2.4 ms
+    // per sweep of 1 M tasks, in HBM they are free): [0] a change in the group's first sweeps, [1] in its last one, [2] largest b-level, [3] ready tasks refreshed
+    uint32_t *dflag = d_bl.as<uint32_t>() + n_slots, *flag = h_stage.as<uint32_t>();
+    G_HIP(hipMemsetAsync(d_bl.p, 0, n_slots * 4 + 16, s));
     G_HIP(hipEventRecord(ev0, s));
     int sweeps = 0;
     for (;;) {
-        flag[0] = 0;
         for (uint32_t l = 0; l < BFS_LEVELS_PER_SYNC; l++) { hipLaunchKernelGGL(k_g_blevel_sweep, dim3(nblk(n_slots)), dim3(256), 0, s, v, (uint32_t)n_slots, d_bl.as<uint32_t>(), dflag); sweeps++; }
         hipLaunchKernelGGL(k_g_blevel_sweep, dim3(nblk(n_slots)), dim3(256), 0, s, v, (uint32_t)n_slots, d_bl.as<uint32_t>(), dflag + 1);  // (the group's last sweep on a word of its own: nothing changed in it = done)
         sweeps++;
         G_HIP(hipGetLastError());
+        G_HIP(hipMemcpyAsync(flag, dflag, 16, hipMemcpyDeviceToHost, s));
         G_HIP(hipStreamSynchronize(s));
         if (!flag[1]) break;
-        flag[1] = 0;
+        G_HIP(hipMemsetAsync(dflag, 0, 8, s));
         if (sweeps > 1 << 20) return fail(HQTICK_E_DEVICE, "b-level: the sweeps do not settle (a cycle in the dependency graph?)");
     }
-    flag[2] = 0; flag[3] = 0;
     hipLaunchKernelGGL(k_g_blevel_store, dim3(nblk(n_slots)), dim3(256), 0, s, v, (uint32_t)n_slots, d_bl.as<uint32_t>(), dflag + 2);
     if (ready_id && ready_prio && n_ready) hipLaunchKernelGGL(k_g_blevel_ready, dim3((unsigned)((n_ready + 255) / 256)), dim3(256), 0, s, v, ready_id, ready_rq, ready_prio, n_ready, dflag + 3);
     G_HIP(hipEventRecord(ev1, s));
     G_HIP(hipGetLastError());
+    G_HIP(hipMemcpyAsync(flag, dflag, 16, hipMemcpyDeviceToHost, s));
     G_HIP(hipStreamSynchronize(s));
     if (max_level) *max_level = flag[2];
     if (n_ready_updated) *n_ready_updated = flag[3];

@@ -863,13 +863,45 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         m.rtype.reserve(est_rows); m.rhs.reserve(est_rows); m.roff.reserve(est_rows + 1);
         m.rcol.reserve(est_cols * 4); m.rcoef.reserve(est_cols * 4);
     }
+    // A worker whose snapshot rows equal the previous worker's (WorkerGroups: same total / free / remaining time / min_utilization / flags, nothing blocked) gets the
+    // same block — the same columns, bounds and rows — up to the objective's factor (W - idx): the block of the group's first worker is kept as a TEMPLATE (the slices
+    // of the model it wrote, column numbers relative to its first column) and stamped out for the rest.  A cold cluster is one group; a cluster mid-run has about one
+    // group per worker and builds every block as before.  Only plain blocks are templates: single-node placement columns and `<=` rows over them, nothing carried.
+    struct BlockTemplate {
+        uint32_t group = UINT32_MAX; bool ok = false;
+        std::vector<double> s, wq; std::vector<uint32_t> slot, rq, ub;          // per column: cost without the order factor, weight, variant slot, request, bound
+        std::vector<double> rhs; std::vector<uint8_t> implied; std::vector<int> roff{0}, rcol; std::vector<double> rcoef;   // per row (all `<=`, all of this block)
+    } tmpl;
+    std::vector<double> rec_s, rec_wq; std::vector<uint32_t> rec_slot, rec_rq;   // what the loop below records per placement column while it builds a block
     for (size_t wi = 0; wi < nw; wi++) {  // :95
         uint32_t w = solver_workers[wi];
         if (!worker_off.empty() && worker_off[w]) continue;  // empty in every optimum (see the separable section): no columns, no rows
         const uint64_t *tot = ws.total + (size_t)w * R, *fre = ws.free_ + (size_t)w * R;
+        double order_factor = (double)(nw - wi);
+        const uint32_t my_group = (ws.rows.valid && !pb.custom) ? ws.rows.of[w] : UINT32_MAX;
+        if (tmpl.ok && my_group != UINT32_MAX && my_group == tmpl.group) {   // the template's block, for this worker
+            const int base = m.ncols();
+            for (size_t k = 0; k < tmpl.s.size(); k++) {
+                const int col = addc(tmpl.s[k] * order_factor * tmpl.wq[k] / (double)nw, hqmilp::COL_NAT, (int32_t)wi);
+                place_col[(size_t)w * NVS + tmpl.slot[k]] = col;
+                col_ub.resize((size_t)col + 1, UINT32_MAX); col_ub[col] = tmpl.ub[k];
+                count_cols[tmpl.rq[k]].push_back(col);
+            }
+            for (size_t r = 0; r + 1 < tmpl.roff.size(); r++) {
+                m.begin_row(hqmilp::ROW_MAX, tmpl.rhs[r]);
+                for (int t = tmpl.roff[r]; t < tmpl.roff[r + 1]; t++) m.term(base + tmpl.rcol[t], tmpl.rcoef[t]);
+                m.end_row();
+                if (tmpl.implied[r]) { m.row_implied.resize(m.nrows(), 0); m.row_implied.back() = 1; }
+                mark_block((int32_t)wi);
+            }
+            continue;
+        }
+        const int rec_col0 = m.ncols(), rec_row0 = m.nrows(), rec_term0 = (int)m.rcol.size();
+        rec_s.clear(); rec_wq.clear(); rec_slot.clear(); rec_rq.clear();
+        bool rec_plain = my_group != UINT32_MAX;   // (stays true while the block is one a template can describe)
+        for (uint32_t r = 0; r < R; r++) if (res_carry[r] || !res_terms[r].empty()) rec_plain = false;   // terms carried in from an unbounded resource of an earlier worker
         cpu_terms.clear();
         block_terms.clear();
-        double order_factor = (double)(nw - wi);
         for (const TaskBatch &batch : batches) {
             const RequestView &rv = pb.rqs[batch.rq];
             bool any_variant = false;
@@ -896,6 +928,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     }
                     int col = addc(s * order_factor * ((double)vv.weight / FRACTIONS) / (double)nw, hqmilp::COL_NAT, (int32_t)wi);
                     place_col[(size_t)w * NVS + slot] = col;
+                    rec_s.push_back(s); rec_wq.push_back((double)vv.weight / FRACTIONS); rec_slot.push_back(slot); rec_rq.push_back(batch.rq);
                     {   // the column's own bound: min over its entries of floor(free / amount)
                         uint64_t ubc = UINT32_MAX;
                         for (uint32_t e = 0; e < vv.n_entries; e++) {
@@ -935,6 +968,28 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             if (fre[r] == HQ_AMOUNT_MAX) { if (!res_terms[r].empty()) res_carry[r] = 1; continue; }
             if (!res_terms[r].empty()) { emit(hqmilp::ROW_MAX, units(fre[r]), res_terms[r]); mark_block(res_carry[r] ? -1 : (int32_t)wi); }  // (a row that carries an earlier worker's terms is not one block's)
             res_terms[r].clear(); res_carry[r] = 0;
+        }
+        // this worker's block as the template of the workers of its group that follow — if it is a plain one: placement columns only (every column the loop created was
+        // recorded), `<=` rows over them only, nothing carried over to the next worker
+        tmpl.ok = false;
+        if (rec_plain && (size_t)(m.ncols() - rec_col0) == rec_s.size() && !rec_s.empty()) {
+            bool plain = true;
+            for (uint32_t r = 0; r < R; r++) if (res_carry[r] || !res_terms[r].empty()) plain = false;
+            for (int i = rec_row0; i < m.nrows() && plain; i++) if (m.rtype[i] != hqmilp::ROW_MAX) plain = false;
+            for (int t = rec_term0; t < (int)m.rcol.size() && plain; t++) if (m.rcol[t] < rec_col0) plain = false;
+            if (plain) {
+                tmpl.group = my_group; tmpl.ok = true;
+                tmpl.s = rec_s; tmpl.wq = rec_wq; tmpl.slot = rec_slot; tmpl.rq = rec_rq;
+                tmpl.ub.assign(col_ub.begin() + rec_col0, col_ub.begin() + m.ncols());
+                tmpl.rhs.assign(m.rhs.begin() + rec_row0, m.rhs.end());
+                tmpl.implied.assign((size_t)(m.nrows() - rec_row0), 0);
+                for (int i = rec_row0; i < m.nrows(); i++) if ((size_t)i < m.row_implied.size() && m.row_implied[i]) tmpl.implied[(size_t)(i - rec_row0)] = 1;
+                tmpl.roff.assign(1, 0); tmpl.rcol.clear(); tmpl.rcoef.clear();
+                for (int i = rec_row0; i < m.nrows(); i++) {
+                    for (int t = m.roff[i]; t < m.roff[i + 1]; t++) { tmpl.rcol.push_back(m.rcol[t] - rec_col0); tmpl.rcoef.push_back(m.rcoef[t]); }
+                    tmpl.roff.push_back((int)tmpl.rcol.size());
+                }
+            }
         }
     }
     // multi-node group sizes  :193-227
@@ -1064,6 +1119,24 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                         n_triples++;
                         if (!sigs_done) { for (uint32_t w : solver_workers) sig_of(w); sigs_done = true; }  // (every worker's signature up front: the table below is indexed by it)
                         gap_of_sig.assign(sig_ids.size(), UINT32_MAX);
+                        bool all_capable = true;
+                        if (sig_ids.size() == 1) for (uint32_t w : solver_workers) if (!cap_brq[w]) { all_capable = false; break; }
+                        if (sig_ids.size() == 1 && all_capable && !solver_workers.empty()) {
+                            // identical workers (a cold cluster): ONE gap for all of them — either every worker's columns go into the no-gap list (which is then the
+                            // batch's column list as it stands) or every worker carries the gap
+                            const uint32_t w0 = solver_workers[0];
+                            const size_t li = (size_t)brq * n_sig_cap + gap_sig[w0];
+                            if (li >= left_state.size()) { left_state.resize(((size_t)pb.rqs.size()) * n_sig_cap, 0); left_of.resize(left_state.size()); }
+                            if (left_state[li] == 0) {
+                                Amounts tot; tot.a.assign(ws.total + (size_t)w0 * R, ws.total + (size_t)(w0 + 1) * R);
+                                if (agg_off.empty()) build_agg();
+                                const uint32_t a0 = agg_off[w0], na = agg_off[w0 + 1] - a0;
+                                left_state[li] = gaps.leftover(brq, tot, na ? agg_rq.data() + a0 : nullptr, na ? agg_variant.data() + a0 : nullptr, na, na ? agg_cnt.data() + a0 : nullptr, left_of[li]) ? 1 : 2;
+                            }
+                            const uint32_t gap = left_state[li] == 1 ? gaps.fit(batch.rq, left_of[li]) : 0;
+                            if (gap > 0) { pm.with_gap.reserve(solver_workers.size()); for (uint32_t w : solver_workers) pm.with_gap.push_back({w, gap}); }
+                            else pm.no_gap.assign(bcols.begin(), bcols.end());
+                        } else
                         for (uint32_t w : solver_workers) {
                             if (!cap_brq[w]) continue;
                             uint32_t gap = gap_of_sig[gap_sig[w]];

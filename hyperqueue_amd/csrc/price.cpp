@@ -1351,14 +1351,17 @@ struct Polisher {
         // The raise goes through the columns by descending cost (ties: ascending model column — CompSolver::polish_point's order).  Raising only ever uses room up, so
         // a column whose own block has no room for one more of it NOW never gets any: the few that do are found first, and only those are ordered.
         std::vector<int> order;
+        // (the same holds for the wide rows: a group whose tightest row has no room for the column's coefficient rules the column out for good — on an unsaturated
+        // tick the batch-size rows are tight after the rounding and nearly every worker has room: without this test 60 000 columns were candidates, for nothing)
+        std::vector<double> gslack(P.KG, INF);
+        for (int k = 0; k < K; k++) { const int g = P.grp_of[k]; gslack[g] = std::min(gslack[g], P.h[k] - (ga[g] + fl[k])); }
         for (uint32_t b = 0; b < T.n_blocks; b++) {
             const double *ba = &bact[(size_t)b * MMAX_BLOCK], *bc = &T.blk_cap[(size_t)b * MMAX_BLOCK];
             const int mb = (int)T.blk_m[b];
-            bool full = false;   // (a row without any room left rules the whole block out at once — as long as every column uses it, which is not given: checked per column)
-            (void)full;
             for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) {
                 if (!(T.col_cost[f] > 0.0) || cap[f] - xf[f] < 1.0) continue;
                 bool room = true;
+                for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1] && room; e++) { const double a = (double)T.w_coef[e]; if (a > 0.0 && gslack[T.w_row[e]] < 0.5 * a) room = false; }
                 for (int r = 0; r < mb && room; r++) { const double a = T.col_a[(size_t)f * MMAX_BLOCK + r]; if (a > 0.0 && bc[r] - ba[r] < a) room = false; }
                 if (room) order.push_back((int)f);
             }
