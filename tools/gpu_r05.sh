@@ -19,7 +19,7 @@ run_pmc() {  # name, counter(s), command...
 }
 for step in "$@"; do
 case $step in
-  tests)     timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 | tee "$OUT/gpu_suite.log" ;;
+  tests)     timeout 1500 python -m pytest tests -m gpu -q -x > "$OUT/gpu_suite.full.log" 2>&1; grep -E "passed|failed|error|Error|solver limits" "$OUT/gpu_suite.full.log" | tail -12 | tee "$OUT/gpu_suite.log" ;;
   smoke)     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.log" ;;
   bench)     timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 600 "$OUT/bench.err"; python tools/bench_digest.py "$OUT/bench.json" ;;
   headline)  timeout 300 $HEAD > "$OUT/bench_headline.json" 2> "$OUT/bench_headline.err"; tail -c 400 "$OUT/bench_headline.err"; python tools/bench_digest.py "$OUT/bench_headline.json" ;;
@@ -36,8 +36,8 @@ case $step in
              grep -h "price_sweep\|^kernel" "$OUT"/sweepctr*.summary.csv ;;
   stage)     HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p wave --no-host --repeat 2 2>&1 | grep -E "price profile|price \{" | tee "$OUT/price_sweep_stage_profile.txt" ;;
   coupled)   timeout 600 python tools/price_probe.py c3p wave 0.2 0.45 --no-host --timeline --repeat 1 2>&1 | grep -E "timeline|price " | tee "$OUT/coupled_ticks.txt" ;;
-  pricetests) timeout 900 python -m pytest tests/test_gpu_price.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -6 | tee "$OUT/gpu_price_tests.log" ;;
-  preflight) timeout 200 python bench.py --gpus 1 --preflight 2>&1 | tail -3 | tee "$OUT/preflight.log" ;;
+  pricetests) timeout 900 python -m pytest tests/test_gpu_price.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | grep -E "passed|failed|error|Error|solver limits" | tail -6 | tee "$OUT/gpu_price_tests.log" ;;
+  preflight) timeout 200 python bench.py --gpus 1 --preflight 2>&1 | grep -E "^\{|Error|error" | tail -3 | tee "$OUT/preflight.log" ;;
   campaign)  timeout 1200 python tools/gpu_price_campaign.py 2>&1 | tail -12 | tee "$OUT/price_campaign.txt" ;;
   clean)     find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} + ;;
   *)         echo "unknown step $step" ;;
