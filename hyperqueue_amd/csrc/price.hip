@@ -77,10 +77,18 @@ __global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
     // the last workgroup: totals in a fixed order (lane l takes blocks l, l + 64, ...; lane 0 adds the 64 partial sums in lane order)
     const uint32_t nb = a.t.n_blocks;
     double cx = 0.0, rc = 0.0, bnd = 0.0; uint32_t nbud = 0, mx = 0;
-    for (uint32_t b = threadIdx.x; b < nb; b += WAVE) {
-        cx += a.out.blk_cx[b]; rc += a.out.blk_rc[b]; bnd += a.out.blk_bnd[b];
-        const uint32_t st = a.out.blk_steps[b];
-        nbud += st >> 31; const uint32_t s = st & 0x7FFFFFFFu; mx = s > mx ? s : mx;
+    // (eight of a lane's blocks per round: the loads of a round are issued together and the sums then run in the same order as before — block l, l + 64, ... —
+    // so the totals are bit for bit the old ones; one round trip to L2 per eight blocks instead of one per block: this workgroup is the tail of every sweep)
+    for (uint32_t b0 = threadIdx.x; b0 < nb; b0 += WAVE * 8) {
+        double vcx[8], vrc[8], vbd[8]; uint32_t vst[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t b = b0 + (uint32_t)u * WAVE; const bool in = b < nb; vcx[u] = in ? a.out.blk_cx[b] : 0.0; vrc[u] = in ? a.out.blk_rc[b] : 0.0; vbd[u] = in ? a.out.blk_bnd[b] : 0.0; vst[u] = in ? a.out.blk_steps[b] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (b0 + (uint32_t)u * WAVE >= nb) break;
+            cx += vcx[u]; rc += vrc[u]; bnd += vbd[u];
+            nbud += vst[u] >> 31; const uint32_t s = vst[u] & 0x7FFFFFFFu; mx = s > mx ? s : mx;
+        }
     }
     double *red = &S.py[0][0];  // the pool's storage again: 3 x 64 doubles + 2 x 64 words
     uint32_t *redu = reinterpret_cast<uint32_t *>(red + 3 * WAVE);
@@ -88,7 +96,13 @@ __global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
         const uint32_t per = part_size(nb), g = threadIdx.x >> 2, p = threadIdx.x & 3u;
         const uint32_t b0 = g * per, b1 = b0 + per < nb ? b0 + per : nb;
         double s = 0.0;
-        for (uint32_t b = b0 + p; b < b1; b += 4) s += a.out.blk_cx[b];
+        for (uint32_t bb = b0 + p; bb < b1; bb += 32) {   // (eight loads in flight, summed in the order b0 + p, + 4, + 8, ... as before)
+            double v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t b = bb + 4u * (uint32_t)u; v8[u] = b < b1 ? a.out.blk_cx[b] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { if (bb + 4u * (uint32_t)u >= b1) break; s += v8[u]; }
+        }
         red[threadIdx.x] = s;
         __syncthreads();
         if (p == 0) a.res->part_cx[g] = ((red[threadIdx.x] + red[threadIdx.x + 1]) + red[threadIdx.x + 2]) + red[threadIdx.x + 3];

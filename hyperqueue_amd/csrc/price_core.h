@@ -72,14 +72,22 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
     });
     if (wv.first()) { S.status = hqblock::ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = m; S.npool = 0; S.usedres = 0; }
     wv.sync();
-    // lane q: reduced cost of column q
+    // lane q: reduced cost of column q.  (The column's entries in the wide rows are read four at a time — the loads of a group are independent of one another and of
+    // the sum, which then runs over them in the same order as a one-by-one loop: a dependent chain of global loads per entry was 6 us of every sweep.)
     wv.each([&](int lane) {
         double rc = -1.0, cost = 0.0;
         if ((uint32_t)lane < nb) {
             const uint32_t j = c0 + (uint32_t)lane;
+            const uint32_t e0 = t.col_woff[j], e1 = t.col_woff[j + 1];
             cost = t.col_cost[j];
             rc = cost;
-            for (uint32_t e = t.col_woff[j]; e < t.col_woff[j + 1]; e++) rc -= spi[t.w_row[e]] * (double)t.w_coef[e];
+            for (uint32_t e = e0; e < e1; e += 4) {
+                uint16_t wr[4]; int32_t wc[4];
+                HQB_UNROLL
+                for (int u = 0; u < 4; u++) { const bool in = e + (uint32_t)u < e1; wr[u] = in ? t.w_row[e + (uint32_t)u] : (uint16_t)0; wc[u] = in ? t.w_coef[e + (uint32_t)u] : 0; }
+                HQB_UNROLL
+                for (int u = 0; u < 4; u++) { if (e + (uint32_t)u >= e1) break; rc -= spi[wr[u]] * (double)wc[u]; }
+            }
         }
         S.lane_val[lane] = rc;
     });
