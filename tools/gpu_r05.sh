@@ -38,7 +38,12 @@ case $step in
   coupled)   timeout 600 python tools/price_probe.py c3p wave 0.2 0.45 --no-host --timeline --repeat 1 2>&1 | grep -E "timeline|price " | tee "$OUT/coupled_ticks.txt" ;;
   pricetests) timeout 900 python -m pytest tests/test_gpu_price.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | grep -E "passed|failed|error|Error|solver limits" | tail -6 | tee "$OUT/gpu_price_tests.log" ;;
   preflight) timeout 200 python bench.py --gpus 1 --preflight 2>&1 | grep -E "^\{|Error|error" | tail -3 | tee "$OUT/preflight.log" ;;
-  campaign)  timeout 1200 python tools/gpu_price_campaign.py 2>&1 | tail -12 | tee "$OUT/price_campaign.txt" ;;
+  campaign)  # fresh seeds for the families of rounds 3 / 4 on this round's build: coupled ticks at cluster scale (GPU tick vs emulated sweeps vs oracle mapping),
+             # resident-delta scenarios, class blocks on the device, the fuzz family through the tick
+             timeout 500 python tools/gpu_price_campaign.py 900 60 > "$OUT/price_campaign.txt" 2>&1; tail -2 "$OUT/price_campaign.txt"
+             timeout 400 python tools/gpu_resident_campaign.py 500 60 > "$OUT/resident_campaign.txt" 2>&1; tail -1 "$OUT/resident_campaign.txt"
+             timeout 300 python tools/gpu_block_campaign.py 900 60 > "$OUT/block_campaign.txt" 2>&1; tail -1 "$OUT/block_campaign.txt"
+             timeout 400 python tools/fuzz_more.py 12000 12800 > "$OUT/fuzz_campaign.txt" 2>&1; tail -3 "$OUT/fuzz_campaign.txt" ;;
   clean)     find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} + ;;
   *)         echo "unknown step $step" ;;
 esac
