@@ -1,4 +1,4 @@
-"""Host-side mirror of the slice of tako's `Core` that the scheduling tick reads and writes.
+"""TEST SUPPORT (not part of the product, which is libhqtick.so): host-side mirror of the slice of tako's `Core` that the scheduling tick reads and writes.
 
 The reference keeps this state in Rust (`Core`, `Worker`, `Task`, `TaskQueues`; paths relative to
 /root/reference/crates/tako/src/internal/): server/core.rs, server/worker.rs:41-78, server/task.rs:22-43,
