@@ -374,10 +374,10 @@ struct Solver {
         double ub_best = INF; std::vector<double> pi_best(K, 0.0);
         for (size_t k = cut_lo; k < cuts.size(); k++) { const double L = fixed_value(cuts[k], hB, cB); if (L < ub_best) { ub_best = L; pi_best = cuts[k].pi; } }
         std::vector<double> pi(K, 0.0), pi_prev_master;
-        double lb_master = -INF;
+        double lb_master = -INF, lp_us = 0.0;
         bool converged = false;
         for (int it = 0; it < 200; it++) {
-            { const int st = mt.solve(200000); if (st != LP_OPT) { if (rq.trace) fprintf(stderr, "[price] master LP status %d at iteration %d (%d cuts)\n", st, it, M.m); return false; } }
+            { const double tl0 = now_us(); const int st = mt.solve(200000); lp_us += now_us() - tl0; if (st != LP_OPT) { if (rq.trace) fprintf(stderr, "[price] master LP status %d at iteration %d (%d cuts)\n", st, it, M.m); return false; } }
             lb_master = -mt.objective() * theta_scale + cB;
             if (ub_best < cutoff) { if (rq.trace) fprintf(stderr, "[price] configuration bounded by %.9f, below the incumbent %.9f\n", ub_best, cutoff); return false; }  // even the relaxation of this configuration is below the incumbent
             if (ub_best - lb_master <= tol * std::fabs(ub_best)) { converged = true; break; }
@@ -422,6 +422,7 @@ struct Solver {
             lambda[bk * PARTS + p] = 1.0; lsum[p] = 1.0;
         }
         for (size_t k = cut_lo; k < cuts.size(); k++) for (int p = 0; p < NP; p++) lambda[k * PARTS + p] /= lsum[p];
+        if (rq.trace) fprintf(stderr, "[price]   master: %d priced rows + %d parts, %d cut rows, %ld pivots, %.1f us inside the LP (%d active rows)\n", KL, NP, M.m, mt.iters, lp_us, mt.ma);
         pi_out.assign(K, 0.0);
         for (int i = 0; i < KL; i++) pi_out[lk[i]] = mt.x[i];
         *bound_out = ub_best;

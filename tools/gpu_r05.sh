@@ -37,6 +37,8 @@ case $step in
   stage)     HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p wave --no-host --repeat 2 2>&1 | grep -E "price profile|price \{" | tee "$OUT/price_sweep_stage_profile.txt" ;;
   coupled)   timeout 600 python tools/price_probe.py c3p wave 0.2 0.45 --no-host --timeline --repeat 1 2>&1 | grep -E "timeline|price " | tee "$OUT/coupled_ticks.txt" ;;
   pricetests) timeout 900 python -m pytest tests/test_gpu_price.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | grep -E "passed|failed|error|Error|solver limits" | tail -6 | tee "$OUT/gpu_price_tests.log" ;;
+  sharded)   # the sharded code path with one rank (record sink + the library's collective + D2H of the merged vector), on the headline workload
+             timeout 300 python bench.py --steps 10 --warmup 3 --headline-only --force-sharded > "$OUT/bench_force_sharded.json" 2> "$OUT/bench_force_sharded.err"; tail -c 300 "$OUT/bench_force_sharded.err"; python tools/bench_digest.py "$OUT/bench_force_sharded.json" | head -4 ;;
   preflight) timeout 200 python bench.py --gpus 1 --preflight 2>&1 | grep -E "^\{|Error|error" | tail -3 | tee "$OUT/preflight.log" ;;
   campaign)  # fresh seeds for the families of rounds 3 / 4 on this round's build: coupled ticks at cluster scale (GPU tick vs emulated sweeps vs oracle mapping),
              # resident-delta scenarios, class blocks on the device, the fuzz family through the tick
