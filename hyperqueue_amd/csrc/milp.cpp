@@ -1227,7 +1227,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
         if (pa.ran && (int)pa.x.size() == n && pa.bound * (1.0 + 1e-9) + 1e-12 <= pa.x_value + rel_gap * std::fabs(pa.x_value)) {
             // the point against EVERY row and bound of the model, in the model's own units
             bool ok = true;
-            for (int j = 0; j < n && ok; j++) { const double v = pa.x[(size_t)j]; if (v < -1e-9 || std::fabs(v - std::round(v)) > 1e-9 || (mdl_in.kind[j] == COL_BOOL && v > 1.0 + 1e-9)) ok = false; }
+            for (int j = 0; j < n && ok; j++) { const double v = pa.x[(size_t)j]; if (v < -1e-9 || std::fabs(v - std::floor(v + 0.5)) > 1e-9 || (mdl_in.kind[j] == COL_BOOL && v > 1.0 + 1e-9)) ok = false; }
             std::vector<double> lhs_act; std::vector<uint8_t> lhs_seen;   // the activity of a shared list of leading terms: once per list
             for (int i = 0; i < m && ok; i++) {
                 double a = 0.0;
@@ -1247,7 +1247,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
             if (ok) {
                 Result res;
                 res.x = std::move(pa.x);
-                for (double &v : res.x) v = std::round(v);
+                for (double &v : res.x) v = std::floor(v + 0.5);   // (non-negative integers up to rounding noise: checked above)
                 res.feasible = true; res.optimal = true; res.canonical = false;   // certified within rel_gap; which of the tied optima it is stays the sweeps' choice
                 res.n_components = 1; res.nodes = pa.sweeps; res.price_sweeps = (int)pa.sweeps; res.price_rounds = (int)pa.rounds; res.price_total_us = (wall() - tf0) * 1e6;
                 double z = 0.0; for (int j = 0; j < n; j++) z += mdl_in.obj[j] * res.x[(size_t)j];

@@ -1331,7 +1331,7 @@ struct Polisher {
         const HostTables &T = P.T; const int K = P.K, G = P.G;
         if ((int)x.size() != n) return false;
         std::vector<double> xf(T.n_cols), B(G);
-        for (uint32_t f = 0; f < T.n_cols; f++) { xf[f] = x[P.model_of[f]]; if (xf[f] < -1e-9 || xf[f] > (double)P.base_cap[f] + 1e-9 || std::fabs(xf[f] - std::round(xf[f])) > 1e-9) return false; xf[f] = std::round(xf[f]); }
+        for (uint32_t f = 0; f < T.n_cols; f++) { const double v = x[P.model_of[f]], rv = round_fast(v); if (v < -1e-9 || v > (double)P.base_cap[f] + 1e-9 || std::fabs(v - rv) > 1e-9) return false; xf[f] = rv; }
         for (int g = 0; g < G; g++) { B[g] = x[P.gmodel[g]]; if (B[g] != 0.0 && B[g] != 1.0) return false; }
         // block rows
         std::vector<double> bact((size_t)T.n_blocks * MMAX_BLOCK, 0.0);
