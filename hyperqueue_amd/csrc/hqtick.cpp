@@ -2080,6 +2080,8 @@ void hqtick_debug_set_block_memo(int on) { if (on && !g_memo) g_memo = new hqhos
 uint32_t hqtick_debug_last_block_memo(void) { return g_last_memo; }
 void hqtick_debug_set_price_emulation(int on, uint32_t min_cols) { g_price_emulation = on; g_price_min_cols = min_cols; }
 void hqtick_debug_set_fast_path(int on) { hqmilp::set_fast_path(on); }
+void hqtick_debug_check_model_hints(int on) { hqprice::set_check_hints(on != 0); }
+int hqtick_debug_model_hint_mismatches(void) { return hqprice::hint_mismatches(); }
 thread_local int g_price_fault = -1;
 void hqtick_debug_set_price_fault(int fail_at) { g_price_fault = fail_at; }
 // the host stages as ONE RANK of a sharded scheduler: emulated sweeps / class blocks over this rank's share, completed through `fn` (tests/test_sharded.py: gloo)

@@ -1074,6 +1074,7 @@ Answer run_solver(Solver &S, const double tp0) {
 
 namespace {
 
+thread_local bool g_check_hints = false; thread_local int g_hint_mismatches = 0;
 // ---- the model as its builder wrote it -> blocks + wide rows (what build() does for a scaled component copy; same tables, same numbering) -------------------------
 // Returns nullptr on success, else what keeps the model on the classic path.  ub: the derived column bounds (model columns), c: obj / cmax.
 const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &ub, std::vector<double> &c, double &cmax) {
@@ -1131,6 +1132,10 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
             if (len < 0 || a + len > e) return "bad structure hint";
             if (f.first < 0) { f.first = i; f.len = len; for (int k = a; k < a + len; k++) if (mv.rcoef[k] < 0.0) f.has_neg = true; }
             else if (f.len != len) return "bad structure hint";
+            else {   // (hints are checked, not trusted: the later rows of a list must really carry it — two memcmps per row)
+                const int a0 = mv.roff[f.first];
+                if (memcmp(mv.rcol + a, mv.rcol + a0, (size_t)len * sizeof(int)) != 0 || memcmp(mv.rcoef + a, mv.rcoef + a0, (size_t)len * sizeof(double)) != 0) return "structure hint: rows of one row_lhs id differ";
+            }
             neg = f.has_neg; tail = a + len;
         }
         for (int k = tail; k < e; k++) if (mv.rcoef[k] < 0.0) neg = true;
@@ -1140,6 +1145,18 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
         bound_terms(tail, e, mv.rhs[i]);
     }
     for (const Fam &f : fam) if (f.first >= 0 && f.rhs_min < INF) bound_terms(mv.roff[f.first], mv.roff[f.first] + f.len, f.rhs_min);
+    if (hinted && g_check_hints) {   // tests: the builder's column bounds must be what the skipped single-block rows give — not tighter (a point lost), not looser
+        std::vector<double> chk(n, INF);
+        for (int j = 0; j < n; j++) if (mv.kind[j] == 1) chk[j] = 1.0;
+        for (int i = 0; i < m; i++) {
+            if (mv.row_block[i] < 0 || mv.rtype[i] == 0) continue;
+            bool neg = false;
+            for (int k = mv.roff[i]; k < mv.roff[i + 1]; k++) if (mv.rcoef[k] < 0.0) neg = true;
+            if (neg) continue;
+            for (int k = mv.roff[i]; k < mv.roff[i + 1]; k++) if (mv.rcoef[k] > 0.0) chk[mv.rcol[k]] = std::min(chk[mv.rcol[k]], std::floor(mv.rhs[i] / mv.rcoef[k] + 1e-9));
+        }
+        for (int j = 0; j < n; j++) if (mv.col_ub[j] != UINT32_MAX && chk[j] < INF && (double)mv.col_ub[j] != chk[j]) { g_hint_mismatches++; return "structure hint: col_ub differs from what the block's rows give"; }
+    }
     
     HostTables &T = P.T;
     T.n_blocks = (uint32_t)nb;
@@ -1204,7 +1221,12 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
         if (hint_b >= 0) {   // the builder says: one block's row — no need to look its columns' blocks up
             if (mv.row_implied && mv.row_implied[i]) continue;
             sc.b0 = hint_b; sc.n_bcols = e - a;
-            for (int k = a; k < e; k++) { if (mv.rcoef[k] < 0.0) sc.nonneg = false; sc.amax += mv.rcoef[k] * ub[mv.rcol[k]]; }
+            const int32_t hb = mv.row_block[i];
+            for (int k = a; k < e; k++) {
+                if (mv.col_group[mv.rcol[k]] != hb) return "structure hint: a row_block row holds a column of another block";   // (hints are checked, not trusted)
+                if (mv.rcoef[k] < 0.0) sc.nonneg = false;
+                sc.amax += mv.rcoef[k] * ub[mv.rcol[k]];
+            }
         } else scan(tail, e, sc);   // (a family row: its own terms behind the shared list; any other row: all of it)
         if (!sc.multi && !sc.has_g && sc.b0 >= 0) {  // a row of one block
             if (mv.row_implied && mv.row_implied[i]) continue;  // implied for integer points by the block's other rows: the sweeps solve the blocks in integers
@@ -1408,6 +1430,9 @@ Answer solve_model(const ModelView &mv, double rel_gap, double time_limit_s, dou
     rq.polish = [&pol](std::vector<double> &x, double &value) { return pol.run(x, value); };
     return run_solver(S, tp0);
 }
+
+void set_check_hints(bool on) { g_check_hints = on; g_hint_mismatches = 0; }
+int hint_mismatches() { return g_hint_mismatches; }
 
 Answer solve(const Request &rq, Sweeper &sw) {
     Solver S(rq, sw);

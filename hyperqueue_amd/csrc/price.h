@@ -112,6 +112,9 @@ struct ModelView {
     const int32_t *row_lhs = nullptr, *row_lhs_len = nullptr;
     const int32_t *row_block = nullptr; const uint32_t *col_ub = nullptr;   // optional (milp.h: Model::row_block / col_ub)
 };
+// tests: also check the builder's column bounds against the rows they stand for (this thread); mismatches since the last call that switched it on
+void set_check_hints(bool on);
+int hint_mismatches();
 Answer solve_model(const ModelView &mv, double rel_gap, double time_limit_s, double deadline_s, bool trace, Sweeper &sw, double *cost_scale);
 
 // All-gather of small host buffers between the ranks of a sharded scheduler: librccl inside the library (hqtick_comm_init) or a callback of the host

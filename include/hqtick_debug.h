@@ -89,6 +89,11 @@ void hqtick_debug_set_price_fault(int fail_at);
 /* The coupled tick's fast path (csrc/milp.cpp, solve(): a large model with the builder's structure hints goes to the sweeps as it is) for this thread:
  * 1 on, 0 off (every model takes the classic path: presolve, components, scaled row copy), -1 the default. */
 void hqtick_debug_set_fast_path(int on);
+/* The fast path reads the model builder's structure hints (csrc/milp.h: Model::col_group / row_lhs / row_block / col_ub).  Shared lists and row_block rows are
+ * always checked against the rows themselves (a wrong hint sends the model down the classic path); on != 0 makes this thread also recompute every hinted column bound
+ * from the rows it stands for.  _mismatches: models refused for that reason since the check was switched on. */
+void hqtick_debug_check_model_hints(int on);
+int hqtick_debug_model_hint_mismatches(void);
 /* sweeps over all blocks / flag configurations of the last hqtick_debug_host_stages call (0: the host search ran alone) */
 void hqtick_debug_last_price(uint32_t *sweeps, uint32_t *rounds);
 /* hqtick_debug_milp_solve on a model that carries the builder's structure hints (col_group: block of every column, -1 = a column of the whole model;

@@ -160,11 +160,15 @@ def _host_stages_path(snap, fast, tl=20.0):
     lib.hqtick_debug_last_price.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.hqtick_debug_set_price_emulation(1, 0)
     lib.hqtick_debug_set_fast_path(1 if fast else 0)
+    lib.hqtick_debug_check_model_hints.argtypes = [C.c_int]
+    lib.hqtick_debug_check_model_hints(1)  # the builder's column bounds recomputed from the rows they stand for
     try:
         got = HostStages(abi.make_config(time_limit_s=tl)).stages(snap)
+        assert lib.hqtick_debug_model_hint_mismatches() == 0
     finally:
         lib.hqtick_debug_set_price_emulation(0, 0)
         lib.hqtick_debug_set_fast_path(-1)
+        lib.hqtick_debug_check_model_hints(0)
     sw, rd = C.c_uint32(), C.c_uint32()
     lib.hqtick_debug_last_price(C.byref(sw), C.byref(rd))
     return got, sw.value, rd.value
