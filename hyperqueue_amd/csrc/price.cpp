@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <numeric>
 
@@ -333,7 +334,12 @@ struct Solver {
     // own c.x and activities, and the master keeps one theta per part — its model of the dual function is the sum of PARTS piecewise-linear models
     // instead of one, which takes a third of the sweeps to the same accuracy (the first wave of the layered config-5 DAG: 61 -> 19-22).  The workers
     // are in objective order (factor (W - idx) / W, solver.rs:542-571), so contiguous ranges are the parts that differ most from one another.
-    bool kelley(const std::vector<double> &hB, double cB, double cutoff, double tol, std::vector<double> &lambda, std::vector<double> &pi_out, double *bound_out) {
+    //
+    // `probe` (optional, called once, when the master is within 1 %): shown the master's fractional point — the columns' activities in every wide row — and its
+    // lower bound; true = the caller goes to another configuration, this walk ends (false is returned).  `no_sweeps`: only what the cuts at hand settle — false as
+    // soon as the master would need another sweep.
+    std::function<bool(const std::vector<double> &, double)> probe;
+    bool kelley(const std::vector<double> &hB, double cB, double cutoff, double tol, std::vector<double> &lambda, std::vector<double> &pi_out, double *bound_out, bool no_sweeps = false) {
         const int K = P.K;
         const uint32_t per = (P.T.n_blocks + PARTS - 1) / PARTS;
         const int NP = (int)((P.T.n_blocks + per - 1) / per);  // parts that hold blocks
@@ -375,12 +381,52 @@ struct Solver {
         for (size_t k = cut_lo; k < cuts.size(); k++) { const double L = fixed_value(cuts[k], hB, cB); if (L < ub_best) { ub_best = L; pi_best = cuts[k].pi; } }
         std::vector<double> pi(K, 0.0), pi_prev_master;
         double lb_master = -INF, lp_us = 0.0;
-        bool converged = false;
+        bool converged = false, probed = false;
+        // multipliers per (cut, part) of the master as it stands (after a solve): every part's sum to 1
+        auto multipliers = [&](std::vector<double> &lambda) {
+            lambda.assign(cuts.size() * PARTS, 0.0);
+            std::vector<double> lsum(NP, 0.0);
+            for (size_t r = 0; r / NP + cut_lo < cuts.size() && r < (size_t)M.m; r++) {
+                const int a = mt.where[r];
+                if (a < 0 || mt.st[M.n + a] == BASIC) continue;
+                const size_t k = r / NP + cut_lo; const int p = (int)(r % NP);
+                const double v = std::fabs(mt.d[M.n + a]) / cut_scale[r];
+                lambda[k * PARTS + p] = v; lsum[p] += v;
+            }
+            for (int p = 0; p < NP; p++) if (!(lsum[p] > 0.0)) {
+                // no cut of the part binds: its theta sits on its bound 0 — at the final prices the part's workers take nothing (or nothing worth anything).
+                // Its point is the pattern of the cut that is worth most at those prices.
+                size_t bk = cut_lo; double bv = -INF;
+                for (size_t k = cut_lo; k < cuts.size(); k++) {
+                    double v = cuts[k].pcx[p];
+                    for (int i = 0; i < KL; i++) v -= mt.x[i] * (double)cuts[k].pact[(size_t)p * K + lk[i]];
+                    if (v > bv) { bv = v; bk = k; }
+                }
+                lambda[bk * PARTS + p] = 1.0; lsum[p] = 1.0;
+            }
+            for (size_t k = cut_lo; k < cuts.size(); k++) for (int p = 0; p < NP; p++) lambda[k * PARTS + p] /= lsum[p];
+        };
         for (int it = 0; it < 200; it++) {
             { const double tl0 = now_us(); const int st = mt.solve(200000); lp_us += now_us() - tl0; if (st != LP_OPT) { if (rq.trace) fprintf(stderr, "[price] master LP status %d at iteration %d (%d cuts)\n", st, it, M.m); return false; } }
             lb_master = -mt.objective() * theta_scale + cB;
             if (ub_best < cutoff) { if (rq.trace) fprintf(stderr, "[price] configuration bounded by %.9f, below the incumbent %.9f\n", ub_best, cutoff); return false; }  // even the relaxation of this configuration is below the incumbent
             if (ub_best - lb_master <= tol * std::fabs(ub_best)) { converged = true; break; }
+            if (no_sweeps) return false;
+            if (probe && !probed && it >= 2 && ub_best - lb_master <= 1e-2 * std::fabs(ub_best)) {
+                probed = true;
+                std::vector<double> lam, colact(K, 0.0);
+                multipliers(lam);
+                for (size_t k = cut_lo; k < cuts.size(); k++) for (int p = 0; p < NP; p++) {
+                    const double l = lam[k * PARTS + p];
+                    if (l == 0.0) continue;
+                    const long long *pa = &cuts[k].pact[(size_t)p * K];
+                    for (int r = 0; r < K; r++) colact[r] += l * (double)pa[r];
+                }
+                auto keep = std::move(probe); probe = nullptr;   // (the probe runs a master of its own: not this one's again)
+                const bool go = keep(colact, lb_master);
+                probe = std::move(keep);
+                if (go) return false;
+            }
             bool same = !pi_prev_master.empty();
             for (int i = 0; i < KL && same; i++) same = std::fabs(mt.x[i] - pi_prev_master[i]) <= 1e-15 + 1e-12 * std::fabs(mt.x[i]);
             pi_prev_master.assign(mt.x.begin(), mt.x.begin() + KL);
@@ -400,28 +446,7 @@ struct Solver {
             lb_master = -mt.objective() * theta_scale + cB;
             if (ub_best - lb_master > 1e-3 * std::fabs(ub_best)) { if (rq.trace) fprintf(stderr, "[price] master not converged: %.9f vs %.9f\n", ub_best, lb_master); return false; }  // nowhere near: no usable multipliers
         }
-        // multipliers per (cut, part): every part's sum to 1
-        lambda.assign(cuts.size() * PARTS, 0.0);
-        std::vector<double> lsum(NP, 0.0);
-        for (size_t r = 0; r / NP + cut_lo < cuts.size() && r < (size_t)M.m; r++) {
-            const int a = mt.where[r];
-            if (a < 0 || mt.st[M.n + a] == BASIC) continue;
-            const size_t k = r / NP + cut_lo; const int p = (int)(r % NP);
-            const double v = std::fabs(mt.d[M.n + a]) / cut_scale[r];
-            lambda[k * PARTS + p] = v; lsum[p] += v;
-        }
-        for (int p = 0; p < NP; p++) if (!(lsum[p] > 0.0)) {
-            // no cut of the part binds: its theta sits on its bound 0 — at the final prices the part's workers take nothing (or nothing worth anything).
-            // Its point is the pattern of the cut that is worth most at those prices.
-            size_t bk = cut_lo; double bv = -INF;
-            for (size_t k = cut_lo; k < cuts.size(); k++) {
-                double v = cuts[k].pcx[p];
-                for (int i = 0; i < KL; i++) v -= mt.x[i] * (double)cuts[k].pact[(size_t)p * K + lk[i]];
-                if (v > bv) { bv = v; bk = k; }
-            }
-            lambda[bk * PARTS + p] = 1.0; lsum[p] = 1.0;
-        }
-        for (size_t k = cut_lo; k < cuts.size(); k++) for (int p = 0; p < NP; p++) lambda[k * PARTS + p] /= lsum[p];
+        multipliers(lambda);
         if (rq.trace) fprintf(stderr, "[price]   master: %d priced rows + %d parts, %d cut rows, %ld pivots, %.1f us inside the LP (%d active rows)\n", KL, NP, M.m, mt.iters, lp_us, mt.ma);
         pi_out.assign(K, 0.0);
         for (int i = 0; i < KL; i++) pi_out[lk[i]] = mt.x[i];
@@ -804,9 +829,11 @@ Answer run_solver(Solver &S, const double tp0) {
     std::vector<int32_t> caps(P.base_cap);
     std::vector<double> final_pi;
     std::vector<std::vector<double>> tried;   // flag configurations already solved
+    auto was_tried = [&](const std::vector<double> &B) { for (auto &t : tried) if (t == B) return true; return false; };
     auto certified = [&]() { return best_value > -INF && S.relaxed_bound <= best_value + rq.rel_gap * std::fabs(best_value); };
     // One flag configuration: master to convergence, one pattern per block, repair, the caller's polish.  Returns the point's value (-INF: nothing
     // usable came out) and leaves the point in x.
+    std::vector<double> jump_to;   // set by try_config's probe: the configuration to go to instead (try_config returns -INF then)
     auto try_config = [&](const std::vector<double> &B, std::vector<double> &x) -> double {
         tried.push_back(B);
         // (the one clock of this path: read at the sweeps, and — where no other rank depends on the reading — here, so that the host-only stretches between sweeps
@@ -828,7 +855,37 @@ Answer run_solver(Solver &S, const double tp0) {
         std::vector<double> lambda, pi;
         double bound_B = INF;
         const double cutoff = best_value > -INF ? best_value * (1.0 - 1e-12) : -INF;
-        if (!S.kelley(hB, cB, cutoff, std::max(1e-6, rq.rel_gap / 50.0), lambda, pi, &bound_B)) return -INF;
+        const double tol = std::max(1e-6, rq.rel_gap / 50.0);
+        // Once this configuration's master is within 1 %: would the flags its fractional point does not need, dropped, give a configuration whose master is ALREADY
+        // converged on the cuts at hand, at a bound no worse?  Then that is where the walk goes — this configuration would be left for it anyway after its own
+        // convergence, rounding and polish (the three-level C3 tick: 9 sweeps on the incumbent's flags, then a successor that converged without one more; now 4).
+        jump_to.clear();
+        S.probe = nullptr;
+        if (G > 0 && P.caps.empty()) S.probe = [&](const std::vector<double> &colact, double lb_here) -> bool {
+            std::vector<double> Bp = B, act = colact;
+            for (int g = 0; g < G; g++) if (Bp[g] == 1.0) for (auto &t : P.g_rows[g]) act[t.first] += t.second;
+            bool dropped = false;
+            for (int g = 0; g < G; g++) {
+                if (Bp[g] != 1.0 || P.gcost[g] != 0.0) continue;
+                bool ok = true;
+                for (auto &t : P.g_rows[g]) if (act[t.first] - t.second > P.h[t.first] + 1e-7 * (1.0 + std::fabs(P.h[t.first]))) ok = false;
+                if (!ok) continue;
+                Bp[g] = 0.0; dropped = true;
+                for (auto &t : P.g_rows[g]) act[t.first] -= t.second;
+            }
+            if (!dropped || was_tried(Bp)) return false;
+            std::vector<double> hBp(K); double cBp = 0.0;
+            for (int k = 0; k < K; k++) hBp[k] = P.h[k];
+            for (int g = 0; g < G; g++) { cBp += P.gcost[g] * Bp[g]; for (auto &t : P.g_rows[g]) hBp[t.first] -= t.second * Bp[g]; }
+            std::vector<double> lam2, pi2; double b2 = INF;
+            if (!S.kelley(hBp, cBp, -INF, tol, lam2, pi2, &b2, true) || b2 < lb_here) return false;
+            if (rq.trace) fprintf(stderr, "[price] configuration %u left for the one its fractional point names: converged on the %zu cuts at hand, bound %.9f\n", ans.rounds, S.cuts.size(), b2);
+            jump_to = Bp;
+            return true;
+        };
+        const bool conv = S.kelley(hB, cB, cutoff, tol, lambda, pi, &bound_B);
+        S.probe = nullptr;
+        if (!conv) return -INF;
         tmark("master converged");
         final_pi = pi;
         std::vector<uint16_t> xf = S.round_patterns(lambda, pi, hB);
@@ -880,12 +937,13 @@ Answer run_solver(Solver &S, const double tp0) {
         }
         return dropped;
     };
-    auto was_tried = [&](const std::vector<double> &B) { for (auto &t : tried) if (t == B) return true; return false; };
     // a configuration and what dropping leads to from there
     auto descend = [&](std::vector<double> B) {
         for (int round = 0; round < MAX_ROUNDS && !S.failed && !was_tried(B); round++) {
             std::vector<double> x;
-            if (try_config(B, x) == -INF) break;
+            const double v = try_config(B, x);
+            if (!jump_to.empty()) { B = jump_to; jump_to.clear(); continue; }
+            if (v == -INF) break;
             if (certified()) break;
             if (!drop_flags(B, x)) break;
         }
