@@ -339,7 +339,17 @@ struct Solver {
     // lower bound; true = the caller goes to another configuration, this walk ends (false is returned).  `no_sweeps`: only what the cuts at hand settle — false as
     // soon as the master would need another sweep.
     std::function<bool(const std::vector<double> &, double)> probe;
+    // what a no_sweeps walk that converged found: the caller goes to that configuration next, whose own walk would solve the same master again
+    struct Settled { bool valid = false; std::vector<double> hB, lambda, pi; double cB = 0.0, bound = 0.0; size_t n_cuts = 0, cut_lo = 0; } settled;
     bool kelley(const std::vector<double> &hB, double cB, double cutoff, double tol, std::vector<double> &lambda, std::vector<double> &pi_out, double *bound_out, bool no_sweeps = false) {
+        if (!no_sweeps && settled.valid) {
+            settled.valid = false;
+            if (settled.n_cuts == cuts.size() && settled.cut_lo == cut_lo && settled.cB == cB && settled.hB == hB) {
+                if (settled.bound < cutoff) return false;
+                lambda = std::move(settled.lambda); pi_out = std::move(settled.pi); *bound_out = settled.bound;
+                return true;
+            }
+        }
         const int K = P.K;
         const uint32_t per = (P.T.n_blocks + PARTS - 1) / PARTS;
         const int NP = (int)((P.T.n_blocks + per - 1) / per);  // parts that hold blocks
@@ -451,6 +461,7 @@ struct Solver {
         pi_out.assign(K, 0.0);
         for (int i = 0; i < KL; i++) pi_out[lk[i]] = mt.x[i];
         *bound_out = ub_best;
+        if (no_sweeps) { settled.valid = true; settled.hB = hB; settled.cB = cB; settled.lambda = lambda; settled.pi = pi_out; settled.bound = ub_best; settled.n_cuts = cuts.size(); settled.cut_lo = cut_lo; }
         return true;
     }
 
@@ -565,7 +576,7 @@ struct Solver {
             // Passes: every switch that would help under the current totals is scored once, the list is walked best first and a switch applied if it still
             // helps under the totals as they are by then (one block once per pass) — a pass costs what ONE move of a best-move-at-a-time loop costs.
             struct Cand { double score; uint32_t b; int k; };
-            std::vector<Cand> cl;
+            std::vector<Cand> cl; std::vector<double> colshort, coltight;
             auto evaluate_switch = [&](uint32_t b, int k, double v0, double &score) {  // a0 = the block's current activities
                 const uint16_t *px = pat_of(k);
                 block_act(b, px, a1);
@@ -587,20 +598,35 @@ struct Solver {
                 cl.clear();
                 std::vector<int> short_in(P.KG, 0);   // short `>=` rows per group
                 for (int r = 0; r < K; r++) if (P.ge[r] && cum[r] > hB[r] + 1e-9) short_in[P.grp_of[r]]++;
+                // what one more task of column f takes off the short rows (its entries in their groups, once per pass instead of once per candidate)
+                // ... and what one task LESS of it costs on the `>=` rows that hold with (almost) nothing to spare.  A row with slack s that the switch moves by D is short
+                // by max(0, D - s) afterwards; summed over those rows that is at least sum(D) - sum(s), the linear form below: a bound from BELOW on what the full look
+                // subtracts, as the gain here is one from above on what it adds — the filter drops no switch the full look would take.  (The three-level C3 tick:
+                // 323 full looks at switches that close the short row by emptying its neighbour, before the first one that does not.)
+                std::vector<int> tight_in(P.KG, 0);
+                double spare = 0.0;
+                for (int r = 0; r < K; r++) if (P.ge[r] && cum[r] <= hB[r] + 1e-9 && hB[r] - cum[r] <= 2.0 + 1e-9) { tight_in[P.grp_of[r]]++; spare += std::max(0.0, hB[r] - cum[r]); }
+                colshort.assign(T.n_cols, 0.0); coltight.assign(T.n_cols, 0.0);
+                for (uint32_t f = 0; f < T.n_cols; f++) for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) {
+                    const int ns = short_in[T.w_row[e]], nt = tight_in[T.w_row[e]];
+                    if (ns) colshort[f] += (double)ns * (double)T.w_coef[e];
+                    if (nt) coltight[f] += (double)nt * (double)T.w_coef[e];
+                }
                 for (uint32_t b = 0; b < T.n_blocks; b++) {
                     for (int k : pool) {
                         if (k == chosen[b]) continue;
                         const uint16_t *px = pat_of(k);
                         // a cheap score first — what the switch takes off the short rows (its columns' entries in those rows only) against the value it gives
                         // up; the full look (every row, new violations) happens when the switch is about to be applied
-                        double gain = 0.0, dv = 0.0; bool differs = false;
+                        double gain = 0.0, dv = 0.0, dmg = 0.0; bool differs = false;
                         for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) {
                             const int d = (int)px[f] - (int)x[f];
                             if (!d) continue;
                             differs = true; dv += T.col_cost[f] * (double)d;
-                            for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) { const int ns = short_in[T.w_row[e]]; if (ns) gain -= (double)ns * ((double)T.w_coef[e] * (double)d); }  // (integers in f64: exact, whatever the grouping)
+                            gain -= colshort[f] * (double)d;  // (integers in f64: exact, whatever the grouping)
+                            dmg += coltight[f] * (double)d;
                         }
-                        if (!differs || !(gain > 1e-9)) continue;
+                        if (!differs || !(gain - std::max(0.0, dmg - spare) > 1e-9)) continue;
                         cl.push_back({std::min(gain, base) * 10.0 * cmax + dv, b, k});
                     }
                 }
@@ -878,7 +904,7 @@ Answer run_solver(Solver &S, const double tp0) {
             for (int k = 0; k < K; k++) hBp[k] = P.h[k];
             for (int g = 0; g < G; g++) { cBp += P.gcost[g] * Bp[g]; for (auto &t : P.g_rows[g]) hBp[t.first] -= t.second * Bp[g]; }
             std::vector<double> lam2, pi2; double b2 = INF;
-            if (!S.kelley(hBp, cBp, -INF, tol, lam2, pi2, &b2, true) || b2 < lb_here) return false;
+            if (!S.kelley(hBp, cBp, -INF, tol, lam2, pi2, &b2, true) || b2 < lb_here) { S.settled.valid = false; return false; }
             if (rq.trace) fprintf(stderr, "[price] configuration %u left for the one its fractional point names: converged on the %zu cuts at hand, bound %.9f\n", ans.rounds, S.cuts.size(), b2);
             jump_to = Bp;
             return true;
