@@ -335,7 +335,7 @@ struct Solver {
     // instead of one, which takes a third of the sweeps to the same accuracy (the first wave of the layered config-5 DAG: 61 -> 19-22).  The workers
     // are in objective order (factor (W - idx) / W, solver.rs:542-571), so contiguous ranges are the parts that differ most from one another.
     //
-    // `probe` (optional, called once, when the master is within 1 %): shown the master's fractional point — the columns' activities in every wide row — and its
+    // `probe` (optional; called after a master round that is within 10 %, at most three times): shown the master's fractional point — the columns' activities in every wide row — and its
     // lower bound; true = the caller goes to another configuration, this walk ends (false is returned).  `no_sweeps`: only what the cuts at hand settle — false as
     // soon as the master would need another sweep.
     std::function<bool(const std::vector<double> &, double)> probe;
@@ -391,7 +391,7 @@ struct Solver {
         for (size_t k = cut_lo; k < cuts.size(); k++) { const double L = fixed_value(cuts[k], hB, cB); if (L < ub_best) { ub_best = L; pi_best = cuts[k].pi; } }
         std::vector<double> pi(K, 0.0), pi_prev_master;
         double lb_master = -INF, lp_us = 0.0;
-        bool converged = false, probed = false;
+        bool converged = false; int probes = 0;
         // multipliers per (cut, part) of the master as it stands (after a solve): every part's sum to 1
         auto multipliers = [&](std::vector<double> &lambda) {
             lambda.assign(cuts.size() * PARTS, 0.0);
@@ -422,8 +422,8 @@ struct Solver {
             if (ub_best < cutoff) { if (rq.trace) fprintf(stderr, "[price] configuration bounded by %.9f, below the incumbent %.9f\n", ub_best, cutoff); return false; }  // even the relaxation of this configuration is below the incumbent
             if (ub_best - lb_master <= tol * std::fabs(ub_best)) { converged = true; break; }
             if (no_sweeps) return false;
-            if (probe && !probed && it >= 2 && ub_best - lb_master <= 1e-2 * std::fabs(ub_best)) {
-                probed = true;
+            if (probe && probes < 3 && it >= 1 && ub_best - lb_master <= 0.1 * std::fabs(ub_best)) {
+                probes++;
                 std::vector<double> lam, colact(K, 0.0);
                 multipliers(lam);
                 for (size_t k = cut_lo; k < cuts.size(); k++) for (int p = 0; p < NP; p++) {
@@ -882,9 +882,9 @@ Answer run_solver(Solver &S, const double tp0) {
         double bound_B = INF;
         const double cutoff = best_value > -INF ? best_value * (1.0 - 1e-12) : -INF;
         const double tol = std::max(1e-6, rq.rel_gap / 50.0);
-        // Once this configuration's master is within 1 %: would the flags its fractional point does not need, dropped, give a configuration whose master is ALREADY
+        // Once this configuration's master is within 10 %: would the flags its fractional point does not need, dropped, give a configuration whose master is ALREADY
         // converged on the cuts at hand, at a bound no worse?  Then that is where the walk goes — this configuration would be left for it anyway after its own
-        // convergence, rounding and polish (the three-level C3 tick: 9 sweeps on the incumbent's flags, then a successor that converged without one more; now 4).
+        // convergence, rounding and polish (the three-level C3 tick: 9 sweeps on the incumbent's flags, then a successor that converged without one more; now 3).
         jump_to.clear();
         S.probe = nullptr;
         if (G > 0 && P.caps.empty()) S.probe = [&](const std::vector<double> &colact, double lb_here) -> bool {

@@ -36,7 +36,7 @@ case $step in
              grep -h "price_sweep\|^kernel" "$OUT"/sweepctr*.summary.csv ;;
   stage)     HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p wave --no-host --repeat 2 2>&1 | grep -E "price profile|price \{" | tee "$OUT/price_sweep_stage_profile.txt" ;;
   hosttrace) # the host side of the coupled tick, stage by stage, on this box's cores (HQMILP_TRACE marks; the last of three ticks)
-             HQMILP_TRACE=1 timeout 300 python tools/price_probe.py c3p --no-host --repeat 3 2>&1 | grep -E "^\[(price|milp|model)\]" | tail -40 | tee "$OUT/host_trace_c3p.txt" ;;
+             HQMILP_TRACE=1 timeout 300 python tools/price_probe.py c3p --no-host --repeat 3 2>&1 | grep -E "^\[(price|milp|model)\]" > "$OUT/host_trace_c3p.txt"; tail -24 "$OUT/host_trace_c3p.txt" ;;
   coupled)   timeout 600 python tools/price_probe.py c3p wave 0.2 0.45 --no-host --timeline --repeat 1 2>&1 | grep -E "timeline|price " | tee "$OUT/coupled_ticks.txt" ;;
   pricetests) timeout 900 python -m pytest tests/test_gpu_price.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | grep -E "passed|failed|error|Error|solver limits" | tail -6 | tee "$OUT/gpu_price_tests.log" ;;
   sharded)   # the sharded code path with one rank (record sink + the library's collective + D2H of the merged vector), on the headline workload

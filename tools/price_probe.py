@@ -60,7 +60,7 @@ def timeline(t, snap, which, n=12):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--repeat"]
     repeat = int(sys.argv[sys.argv.index("--repeat") + 1]) if "--repeat" in sys.argv else 3
     cases = args or ["c3p", "wave", "0.2", "0.45"]
     out = {}
