@@ -938,6 +938,15 @@ def main():
         out["steady_hetero"] = steady_hetero(loop_cfg, snap1, args.hetero_steps, args.seed, min(args.cpu_ticks, 1))
     if world == 1 and not args.force_sharded and snap1 is not None and args.dag_steps > 0:
         out["dag_churn"] = dag_churn(loop_cfg, args.dag_steps, args.seed, args.dag_classes, "random", min(args.cpu_ticks, 1))
+        # the same loop with the coupled solve stopping where the reference's stops (HQTICK_FLAG_CERTIFICATE_ONLY: the 1e-4 certificate, no exact / canonical pass) —
+        # what a single scheduler would run; the default above pays for an answer that is a function of the snapshot alone
+        try:
+            quick_cfg = type(cfg).from_buffer_copy(loop_cfg); quick_cfg.flags |= abi.HQTICK_FLAG_CERTIFICATE_ONLY
+            qd = dag_churn(quick_cfg, args.dag_steps, args.seed, args.dag_classes, "random", 0)
+            out["dag_churn"]["certificate_only"] = {"flag": "HQTICK_FLAG_CERTIFICATE_ONLY (is_optimal = 1, is_canonical = 0: the reference's own stopping rule, solver/highs.rs:65-88)",
+                                                    **{k: qd[k] for k in ("p50_tick_us", "p50_coupled_solve_us", "p50_model_columns", "p50_step_ms", "tasks_handed_out_per_step", "tasks_per_s", "all_ticks_optimal", "steps")}}
+        except Exception as e:  # noqa: BLE001
+            out["dag_churn"]["certificate_only"] = {"error": repr(e)}
         out["dag_churn_layered"] = dag_churn(loop_cfg, args.dag_steps, args.seed, args.dag_classes, "layered", min(args.cpu_ticks, 1))
     if world == 1 and not args.force_sharded and args.workload == "c3p" and args.priority_ticks > 0:
         # the same three priority levels on a BUSY cluster (workloads.make_steady: every worker runs a packed mix of which 10 % just finished, ~930 distinct free

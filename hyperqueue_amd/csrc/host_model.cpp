@@ -716,10 +716,10 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 // the early workers exactly — the part the LP-rounding heuristics of the solver are weakest at.
                 bool usable = true;
                 for (uint8_t fl : class_has_flag) if (fl) usable = false;  // min_utilization flags are not part of the hint
-                if (usable && pb.pricer) {
-                    size_t kept = 0; for (uint32_t w : solver_workers) if (!worker_off[w]) kept++;
-                    if (kept * NC >= 2 * (size_t)pb.pricer->min_cols) usable = false;
-                }  // the price sweeps build their own incumbent: the W sequential block solves would cost more than they do
+                size_t kept = 0; for (uint32_t w : solver_workers) if (!worker_off[w]) kept++;
+                if (usable && pb.pricer && kept * NC >= 2 * (size_t)pb.pricer->min_cols) usable = false;  // the price sweeps build their own incumbent: the W sequential block solves would cost more than they do
+                // (a solve that stops at its certificate finds the point of a small model faster than these block solves run: 213 -> 142 us on an 80-column tick)
+                if (usable && pb.certificate_only && kept * NC <= 512) usable = false;
                 if (usable) {
                     std::vector<double> rem(nb);
                     for (size_t b = 0; b < nb; b++) rem[b] = batches[b].limit_reached ? 1e18 : (double)batches[b].size;
@@ -1201,7 +1201,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     m.col_ub = col_ub; m.col_ub.resize((size_t)m.ncols(), UINT32_MAX);
     const double t_model1 = clock_us();
     if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu terms, %zu worker signatures, %zu (batch, cut, blocker) passes over the workers\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), m.rcol.size(), sig_ids.size(), n_triples);
-    hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, true, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438
+    hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, !pb.certificate_only, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438
     if (trace_model) fprintf(stderr, "[model] solve done %.3f ms after the model\n", (clock_us() - t_model1) / 1e3);
     out.pre_us = t_model0 - t_enter; out.model_us = t_model1 - t_model0; out.milp_us = clock_us() - t_model1; out.price_sweeps = sol.price_sweeps; out.price_rounds = sol.price_rounds; out.price_us = sol.price_total_us;
     out.milp_nodes = sol.nodes; out.milp_cols = m.ncols(); out.milp_rows = m.nrows(); out.milp_components = sol.n_components;

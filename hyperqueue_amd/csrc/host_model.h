@@ -122,6 +122,7 @@ struct Problem {
     WorkerSet real;                      // core.worker_map
     const WorkerSet *custom = nullptr;   // what-if query: fake workers replace the worker list of the solver
     double time_limit_s = 5.0;
+    bool certificate_only = false;       // HQTICK_FLAG_CERTIFICATE_ONLY: the coupled model's solve stops at the rel_gap certificate, as the reference's does
     bool rq_multi_node(uint32_t rq) const { return variants[rqs[rq].first_variant].multi_node(); }
     // Worker::is_capable_to_run_rqv  server/worker.rs:277-296
     bool capable_rqv(const WorkerSet &ws, uint32_t w, uint32_t rq) const {

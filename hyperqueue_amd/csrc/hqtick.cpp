@@ -330,7 +330,7 @@ int eval_workers_sync(hqtick_ctx *ctx, const hqtick_snapshot *s, uint32_t W, con
 }
 
 void fill_problem(hqhost::Problem &pb, const hqtick_snapshot *s, const hqtick_config &cfg, const WorkerEval &ev) {
-    pb.R = s->n_resources; pb.n_groups = s->n_groups ? s->n_groups : 1; pb.time_limit_s = cfg.mip_time_limit_s;
+    pb.R = s->n_resources; pb.n_groups = s->n_groups ? s->n_groups : 1; pb.time_limit_s = cfg.mip_time_limit_s; pb.certificate_only = (cfg.flags & HQTICK_FLAG_CERTIFICATE_ONLY) != 0;
     uint32_t nv = s->n_requests ? s->rq_variant_off[s->n_requests] : 0;
     pb.rqs.resize(s->n_requests); pb.variants.resize(nv);
     for (uint32_t q = 0; q < s->n_requests; q++) pb.rqs[q] = {s->rq_variant_off[q], s->rq_variant_off[q + 1] - s->rq_variant_off[q]};

@@ -988,6 +988,7 @@ struct CompSolver {
             lns_schedule(deadline - 0.05);
             if (certified()) by_root_bound = true; else timed_out = true;
         }
+        if (!timed_out && (gap_pruned || by_root_bound) && have && !in_lns && !canonical) { canonical_done = false; trace("certificate only (asked for)"); xout = bx; return 1; }  // the reference's own stopping rule
         if (!timed_out && (gap_pruned || by_root_bound) && have && !in_lns) {
             // Certified within rel_gap, which is all the reference asks of its solver.  The canonical answer needs the EXACT optimum: one more search
             // from the root with the exact pruning rule only, on a deterministic work budget (element updates, not seconds: every replica of a

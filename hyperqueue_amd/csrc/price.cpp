@@ -1265,9 +1265,8 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
     struct WideRow { double h; uint8_t ge; int lhs_key; int own = -1; std::vector<std::pair<int, double>> g; };   // lhs_key: 2 * L + (`>=` row), or -1 with its own list `own`
     std::vector<WideRow> wide;
     std::vector<std::vector<std::pair<int, int32_t>>> own_lists;   // left-hand sides of wide rows outside every family (sign applied)
-    std::vector<std::pair<int, long long>> ai;
-    struct GcdMemo { int n = -1; long long g = 0; long long v[32]; };
-    GcdMemo gcd_memo[8]; unsigned gcd_next = 0;
+    struct RowMemo { int n = -1; long long g = 1; double raw[32]; double scaled[64]; };
+    RowMemo row_memo[8], memo_big; unsigned memo_next = 0;
     // what a range of terms looks like to the classification below
     struct Scan { int b0 = -2; bool multi = false, has_g = false, nonneg = true; int n_bcols = 0; double amax = 0.0; };
     auto scan = [&](int a, int e, Scan &sc) {
@@ -1318,28 +1317,32 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
             if (!is_le || !sc.nonneg || rhs < 0.0) return "block row that is not a packing row";
             const int b0 = sc.b0, r = T.blk_m[b0];
             if (r >= MMAX_BLOCK) return "block with more than 4 rows";
-            long long g = 0; bool ok = true;
-            ai.clear();
-            for (int k = a; k < e && ok; k++) {
-                const double v = mv.rcoef[k] * GRID, rv = round_fast(v);
-                if (rv < 1.0 || std::fabs(v - rv) > 1e-6 * std::max(1.0, rv) || rv >= 4.0e15) ok = false;
-                else ai.push_back({P.flat_of[mv.rcol[k]], (long long)rv});
-            }
-            if (ok) {   // the row's gcd: identical workers repeat the same few coefficient lists, and a 64-bit remainder per term is most of this loop
-                const GcdMemo *hit = nullptr;
-                for (const GcdMemo &gm : gcd_memo) if (gm.n == (int)ai.size()) { bool same = true; for (int q = 0; q < gm.n && same; q++) same = gm.v[q] == ai[(size_t)q].second; if (same) { hit = &gm; break; } }
-                if (hit) g = hit->g;
-                else {
-                    for (auto &t : ai) g = gcd_ll(g, t.second);
-                    if (ai.size() <= 32) { GcdMemo &gm = gcd_memo[gcd_next++ % 8]; gm.n = (int)ai.size(); gm.g = g; for (size_t q = 0; q < ai.size(); q++) gm.v[q] = ai[q].second; }
+            // identical workers repeat the same few coefficient lists: a list seen before (compared as the doubles it is) has its grid integers and their gcd ready —
+            // no product, rounding and 64-bit remainder per term
+            const int nt = e - a;
+            const RowMemo *hit = nullptr;
+            for (const RowMemo &rm : row_memo) if (rm.n == nt && memcmp(rm.raw, mv.rcoef + a, (size_t)nt * sizeof(double)) == 0) { hit = &rm; break; }
+            if (!hit) {
+                if (nt > 64) return "block row with more than 64 terms";
+                long long vi[64], g = 0;
+                for (int k = 0; k < nt; k++) {
+                    const double v = mv.rcoef[a + k] * GRID, rv = round_fast(v);
+                    if (rv < 1.0 || std::fabs(v - rv) > 1e-6 * std::max(1.0, rv) || rv >= 4.0e15) return "block row off the ResourceAmount grid";
+                    vi[k] = (long long)rv;
+                    g = gcd_ll(g, vi[k]);
                 }
+                if (g < 1) g = 1;
+                RowMemo &rm = nt <= 32 ? row_memo[memo_next++ % 8] : memo_big;
+                rm.n = nt <= 32 ? nt : -1; rm.g = g;
+                if (nt <= 32) memcpy(rm.raw, mv.rcoef + a, (size_t)nt * sizeof(double));
+                for (int k = 0; k < nt; k++) rm.scaled[k] = (double)(vi[k] / g);
+                hit = &rm;
             }
-            if (!ok) return "block row off the ResourceAmount grid";
+            const long long g = hit->g;
             const double capv = rhs * GRID;
             if (capv >= 4.0e15) return "block row capacity too large";
             const long long capi = (long long)std::floor(capv + 1e-6);
-            if (g < 1) g = 1;
-            for (auto &t : ai) T.col_a[(size_t)t.first * MMAX_BLOCK + r] += (double)(t.second / g);  // (duplicate terms of one row are summed)
+            for (int k = 0; k < nt; k++) T.col_a[(size_t)P.flat_of[mv.rcol[a + k]] * MMAX_BLOCK + r] += hit->scaled[k];  // (duplicate terms of one row are summed)
             T.blk_cap[(size_t)b0 * MMAX_BLOCK + r] = (double)(capi / g);
             T.blk_m[b0] = (uint8_t)(r + 1);
             continue;

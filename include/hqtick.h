@@ -108,6 +108,14 @@ enum { HQ_REC_PREFILL = 0, HQ_REC_ASSIGN = 1 };
  * host uploads it again.  Without the flag a tick changes nothing until hqtick_ready_consume_last says so: the two-call form stays the default and is what a
  * drop-in should start from; the flag is for a host whose ticks are short enough for one kernel and one call to matter (bench.py's add -> tick loops). */
 #define HQTICK_FLAG_CONSUME_IN_TICK 16u
+/* hqtick_config.flags (ABI 9): stop the coupled model's solve where the reference's solver stops — at the certificate.  HiGHS under solve_bounded returns as soon as
+ * its incumbent is within mip_rel_gap = 1e-4 of the dual bound (solver/highs.rs:65-88); this library by default goes on to the EXACT optimum and then to the canonical
+ * one among the tied optima (result.is_canonical = 1: the answer is a function of the snapshot alone, what parity tier T1 and replicas of a sharded scheduler compare
+ * byte for byte).  That proof is most of a small coupled tick (an 80-column model of a few dozen ready tasks: certified after 0.1 ms, canonical after 0.8 ms; a
+ * 128-column one: 0.3 ms against 26 ms).  With the flag the tick returns the certified point: is_optimal = 1, is_canonical = 0, the objective within 1e-4 of the
+ * optimum exactly as the reference's — for a single scheduler whose ticks must be short.  (Ticks the class blocks or the price sweeps settle are not affected:
+ * separable placements stay exact and canonical, swept ones were certificates already.) */
+#define HQTICK_FLAG_CERTIFICATE_ONLY 32u
 
 /* redirect_kind of a result entry (scheduler/mapping.rs:66-101):
  *   FROM_PREFILL  the task sat in a prefill set: Prefilled{old} -> Retracting{old}, retract sent to `old`, redirects.insert(task, (worker, v))

@@ -94,3 +94,41 @@ def test_c3p_at_baseline_size_is_certified():
     snap = workloads.make("c3p", n_tasks=1_000_000, n_workers=1024)
     got = HostStages(abi.make_config(time_limit_s=45.0)).stages(snap)
     assert got.status == abi.HQTICK_DONE and got.is_optimal
+
+
+SMALL = [(1024, 30), (1024, 60), (1024, 89), (1024, 150), (64, 40), (16, 25)]
+
+
+@pytest.mark.parametrize("W,n_ready", SMALL)
+def test_certificate_only_stops_where_the_reference_stops(W, n_ready):
+    """HQTICK_FLAG_CERTIFICATE_ONLY (include/hqtick.h): the small coupled ticks of the DAG loop — a few dozen ready tasks on a mostly idle cluster — end at the 1e-4
+    certificate as HiGHS does under solve_bounded (solver/highs.rs:65-88): is_optimal = 1, is_canonical = 0, the same batches, an objective within 1e-4 of the one the
+    default (exact + canonical) solve reaches and of the oracle's, and a placement that fits every worker."""
+    from oracle.oracle import Oracle
+
+    ids, prio, rq, off, dep = workloads.make_dag(200_000, seed=0)
+    drv = workloads.DagChurn(n_workers=W, churn=0.1, seed=0)
+    snap = drv.snapshot(ids[:n_ready], prio[:n_ready], (rq[:n_ready] % 8).astype(np.uint32))
+    exact = HostStages(abi.make_config(time_limit_s=20.0)).stages(snap)
+    quick = HostStages(abi.make_config(time_limit_s=20.0, flags=abi.HQTICK_FLAG_CERTIFICATE_ONLY)).stages(snap)
+    assert exact.status == quick.status == abi.HQTICK_DONE and exact.is_optimal and quick.is_optimal
+    assert quick.batches == exact.batches
+    o = Oracle(abi.make_config(time_limit_s=20.0))
+    want = o.tick(snap)
+    model = o.last_model()
+    ze, zq, zw = _objective(model, exact), _objective(model, quick), float(model["objective"])
+    assert abs(ze - zw) <= 1.0e-4 * zw and abs(zq - zw) <= 1.0e-4 * zw, (ze, zq, zw)  # (the oracle's HiGHS stops at 1e-4 too)
+    assert zq <= ze * (1.0 + 1e-9) and ze - zq <= 1.0e-4 * ze, (zq, ze)
+    # the certified point is a placement: every worker's resources hold, no batch hands out more than it has
+    R = snap.n_resources
+    free = np.asarray(snap.worker_free, np.int64).reshape(-1, R).copy()
+    total = np.asarray(snap.worker_total, np.int64).reshape(-1, R)
+    placed = {}
+    for (q, v, w, c) in quick.counts:
+        placed[q] = placed.get(q, 0) + c
+        for (r, kind, a) in snap.requests[q][v]["entries"]:
+            free[w, r] -= c * (int(total[w, r]) if kind == abi.HQ_ENTRY_ALL else int(a))
+    assert (free >= 0).all()
+    ready_per_rq = np.bincount(np.asarray(snap.task_rq), minlength=len(snap.requests))
+    for q, c in placed.items():
+        assert c <= ready_per_rq[q], (q, c)

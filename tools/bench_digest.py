@@ -19,5 +19,9 @@ for k in ("steady_hetero", "dag_churn", "dag_churn_layered", "multi_priority_bus
     v = d.get(k)
     if isinstance(v, dict):
         print(k, {kk: v[kk] for kk in ("p50_tick_ms", "p50_step_ms", "p50_tick_us", "tasks_per_s", "error", "is_optimal", "price_sweeps", "p50_price_sweeps_per_tick", "tasks_assigned_per_sec") if kk in v})
+        if isinstance(v.get("certificate_only"), dict):
+            print("  certificate_only", {kk: v["certificate_only"].get(kk) for kk in ("p50_tick_us", "p50_coupled_solve_us", "p50_step_ms", "all_ticks_optimal", "error") if kk in v["certificate_only"]})
+        if isinstance(v.get("tick_stages_us"), dict):
+            print("  stages", {kk: round(x, 1) for kk, x in v["tick_stages_us"].items()})
 cb = d.get("cpu_baseline") or {}
 print("cpu_baseline", {k: cb.get(k) for k in ("value", "tick_s", "assigned_per_tick", "is_optimal", "error")}, "speedup", d.get("speedup_vs_cpu_baseline"), "objective", d.get("objective"))
