@@ -240,6 +240,25 @@ uint32_t max_count(const Amounts &have, const VariantView &rq) {  // task_max_co
     }
     return any ? (uint32_t)best : 0;
 }
+// the same two on a worker's row of R amounts where it lies (every resource index of a validated snapshot is below R): no vector per (blocker, worker) pair
+inline uint32_t max_count_row(const uint64_t *have, uint32_t R, const VariantView &rq) {
+    bool any = false; uint64_t best = 0;
+    for (uint32_t e = 0; e < rq.n_entries; e++) {
+        const uint64_t h = rq.res[e] < R ? have[rq.res[e]] : 0;
+        const uint64_t c = rq.kind[e] == HQ_ENTRY_ALL ? (h ? 1 : 0) : std::min<uint64_t>(h / rq.amount[e], HQ_MAX_TASK_PER_WORKER);
+        if (!any || c < best) best = c;
+        any = true;
+    }
+    return any ? (uint32_t)best : 0;
+}
+inline void take_away_row(uint64_t *have, uint32_t R, const VariantView &rq, uint64_t times) {
+    for (uint32_t e = 0; e < rq.n_entries; e++) {
+        const uint32_t r = rq.res[e];
+        if (r >= R) continue;
+        if (rq.kind[e] == HQ_ENTRY_ALL) have[r] = 0;
+        else { const uint64_t d = rq.amount[e] * times; have[r] = have[r] > d ? have[r] - d : 0; }
+    }
+}
 void take_away(Amounts &have, const VariantView &rq, uint64_t times) {  // remove / remove_multiple  workerload.rs:156-177
     for (uint32_t e = 0; e < rq.n_entries; e++) {
         uint32_t r = rq.res[e];
@@ -306,6 +325,26 @@ struct GapCache {
         }
         for (uint32_t i = 0; i < n_asg; i++) if (asg_rq[i] != high_rq) take_away(left, pb.variants[pb.rqs[asg_rq[i]].first_variant + asg_variant[i]], asg_cnt ? asg_cnt[i] : 1);
         return true;
+    }
+    // the common blocker — one variant, no `all` entry — on the worker's row itself: true and the leftover in left[0..R), or false: not this shape (the caller takes
+    // leftover() above, which also knows the gap-is-0 rules)
+    bool leftover_row(uint32_t high_rq, const uint64_t *total, uint32_t R, const uint32_t *asg_rq, const uint8_t *asg_variant, uint32_t n_asg, const uint32_t *asg_cnt, uint64_t *left) {
+        if (pb.rq_multi_node(high_rq)) return false;
+        const RequestView &h = pb.rqs[high_rq];
+        if (h.n_variants != 1) return false;
+        const VariantView &hv = pb.variants[h.first_variant];
+        for (uint32_t e = 0; e < hv.n_entries; e++) if (hv.kind[e] == HQ_ENTRY_ALL || hv.res[e] >= R) return false;
+        for (uint32_t r = 0; r < R; r++) left[r] = total[r];
+        take_away_row(left, R, hv, max_count_row(total, R, hv));
+        for (uint32_t i = 0; i < n_asg; i++) if (asg_rq[i] != high_rq) take_away_row(left, R, pb.variants[pb.rqs[asg_rq[i]].first_variant + asg_variant[i]], asg_cnt ? asg_cnt[i] : 1);
+        return true;
+    }
+    uint32_t fit_row(uint32_t low_rq, const uint64_t *left, uint32_t R) {
+        if (pb.rq_multi_node(low_rq)) return 0;
+        const RequestView &l = pb.rqs[low_rq];
+        uint32_t best = 0;
+        for (uint32_t v = 0; v < l.n_variants; v++) { const uint32_t c = max_count_row(left, R, pb.variants[l.first_variant + v]); if (v == 0 || c < best) best = c; }
+        return best;
     }
     // how many tasks of the batch fit into what is left (gap.rs:86-92)
     uint32_t fit(uint32_t low_rq, const Amounts &left) {
@@ -1033,9 +1072,12 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     if (trace_model) fprintf(stderr, "[model] model build entered %.3f ms after the solver (worker classes %.3f, class blocks %.3f, lazy rows / empty workers / start %.3f); worker blocks built at %.3f ms\n", (t_model0 - t_enter) / 1e3, out.t_classify_us / 1e3, out.t_blocks_us / 1e3, (t_model0 - t_enter - out.t_classify_us - out.t_blocks_us) / 1e3, (clock_us() - t_model0) / 1e3);
     GapCache gaps(pb);
     // the gap depends on the worker's total resources and on what runs there: workers with the same signature share one computation per (blocker, batch)
-    std::vector<uint32_t> gap_sig; std::map<std::vector<uint64_t>, uint32_t> sig_ids;
+    // (signatures: a flat table of hashes over (total row, running kinds) with the first worker of each as its representative — the rows are compared where they lie)
+    std::vector<uint32_t> gap_sig, sig_rep, sig_table; std::vector<uint64_t> sig_hash;
     const size_t n_sig_cap = (size_t)ws.n + 1;  // signatures are numbered below the worker count
-    std::vector<uint8_t> left_state; std::vector<Amounts> left_of;  // per (blocker rq, signature): 0 not computed, 1 leftover in left_of, 2 gap is 0 by rule
+    // per (blocker, signature) — blockers numbered as they turn up: 0 not computed, 1 leftover in left_of (the general rule), 2 gap is 0 by rule, 3 leftover in left_row
+    std::vector<int32_t> blocker_ord; uint32_t n_blockers_seen = 0;
+    std::vector<uint8_t> left_state; std::vector<Amounts> left_of; std::vector<uint64_t> left_row;
     // a worker's running tasks as distinct (rq, variant) pairs with counts (a busy worker runs ~100 tasks of ~8 kinds: the gap of every (blocker, batch) pair walks this list)
     std::vector<uint32_t> agg_off, agg_rq, agg_cnt; std::vector<uint8_t> agg_variant;
     auto build_agg = [&]() {
@@ -1058,14 +1100,44 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         }
     };
     auto sig_of = [&](uint32_t w) -> uint32_t {
-        if (gap_sig.empty()) gap_sig.assign(ws.n, UINT32_MAX);
+        if (gap_sig.empty()) { gap_sig.assign(ws.n, UINT32_MAX); size_t cap = 64; while (cap < 2 * (size_t)ws.n + 2) cap <<= 1; sig_table.assign(cap, UINT32_MAX); }
         if (gap_sig[w] != UINT32_MAX) return gap_sig[w];
-        std::vector<uint64_t> key(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
         if (agg_off.empty()) build_agg();
-        for (uint32_t i = agg_off[w]; i < agg_off[w + 1]; i++) key.push_back(((uint64_t)agg_cnt[i] << 32) | ((uint64_t)agg_rq[i] << 8) | agg_variant[i]);  // (sorted by (rq, variant): the multiset of running tasks decides — saturating subtractions commute)
-        auto it = sig_ids.find(key);
-        if (it == sig_ids.end()) it = sig_ids.emplace(std::move(key), (uint32_t)sig_ids.size()).first;
-        return gap_sig[w] = it->second;
+        const uint64_t *tw = ws.total + (size_t)w * R;
+        const uint32_t a0 = agg_off[w], na = agg_off[w + 1] - a0;
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ na;
+        for (uint32_t r = 0; r < R; r++) { h ^= tw[r]; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+        for (uint32_t i = a0; i < a0 + na; i++) { h ^= ((uint64_t)agg_cnt[i] << 32) | ((uint64_t)agg_rq[i] << 8) | agg_variant[i]; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; }  // (sorted by (rq, variant): the multiset of running tasks decides — saturating subtractions commute)
+        const size_t mask = sig_table.size() - 1;
+        for (size_t pos = (size_t)h & mask;; pos = (pos + 1) & mask) {
+            const uint32_t id = sig_table[pos];
+            if (id == UINT32_MAX) { sig_table[pos] = (uint32_t)sig_rep.size(); sig_rep.push_back(w); sig_hash.push_back(h); return gap_sig[w] = (uint32_t)sig_rep.size() - 1; }
+            if (sig_hash[id] != h) continue;
+            const uint32_t o = sig_rep[id], b0 = agg_off[o];
+            if (agg_off[o + 1] - b0 != na || memcmp(ws.total + (size_t)o * R, tw, (size_t)R * 8) != 0) continue;
+            if (na && (memcmp(agg_rq.data() + b0, agg_rq.data() + a0, (size_t)na * 4) != 0 || memcmp(agg_variant.data() + b0, agg_variant.data() + a0, na) != 0 || memcmp(agg_cnt.data() + b0, agg_cnt.data() + a0, (size_t)na * 4) != 0)) continue;
+            return gap_sig[w] = id;
+        }
+    };
+    // what the blocker leaves of the workers with signature sg (w: one of them), once per (blocker, signature); then how many tasks of the batch fit into that
+    auto gap_of = [&](uint32_t brq, uint32_t low_rq, uint32_t sg, uint32_t w) -> uint32_t {
+        if (blocker_ord.empty()) blocker_ord.assign(pb.rqs.size(), -1);
+        if (blocker_ord[brq] < 0) {
+            blocker_ord[brq] = (int32_t)n_blockers_seen++;
+            left_state.resize((size_t)n_blockers_seen * n_sig_cap, 0); left_row.resize((size_t)n_blockers_seen * n_sig_cap * R); left_of.resize(left_state.size());
+        }
+        const size_t li = (size_t)blocker_ord[brq] * n_sig_cap + sg;
+        if (left_state[li] == 0) {
+            if (agg_off.empty()) build_agg();
+            const uint32_t a0 = agg_off[w], na = agg_off[w + 1] - a0;
+            const uint32_t *arq = na ? agg_rq.data() + a0 : nullptr, *acnt = na ? agg_cnt.data() + a0 : nullptr; const uint8_t *avar = na ? agg_variant.data() + a0 : nullptr;
+            if (gaps.leftover_row(brq, ws.total + (size_t)w * R, R, arq, avar, na, acnt, &left_row[li * R])) left_state[li] = 3;
+            else {
+                Amounts tot; tot.a.assign(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
+                left_state[li] = gaps.leftover(brq, tot, arq, avar, na, acnt, left_of[li]) ? 1 : 2;
+            }
+        }
+        return left_state[li] == 3 ? gaps.fit_row(low_rq, &left_row[li * R], R) : (left_state[li] == 1 ? gaps.fit(low_rq, left_of[li]) : 0);
     };
     std::vector<uint32_t> gap_of_sig; bool sigs_done = false; uint32_t batch_no = UINT32_MAX;
     std::vector<std::vector<uint8_t>> cap_cache; size_t n_triples = 0;
@@ -1118,43 +1190,25 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                         }
                         n_triples++;
                         if (!sigs_done) { for (uint32_t w : solver_workers) sig_of(w); sigs_done = true; }  // (every worker's signature up front: the table below is indexed by it)
-                        gap_of_sig.assign(sig_ids.size(), UINT32_MAX);
+                        gap_of_sig.assign(sig_rep.size(), UINT32_MAX);
                         bool all_capable = true;
-                        if (sig_ids.size() == 1) for (uint32_t w : solver_workers) if (!cap_brq[w]) { all_capable = false; break; }
-                        if (sig_ids.size() == 1 && all_capable && !solver_workers.empty()) {
+                        if (sig_rep.size() == 1) for (uint32_t w : solver_workers) if (!cap_brq[w]) { all_capable = false; break; }
+                        if (sig_rep.size() == 1 && all_capable && !solver_workers.empty()) {
                             // identical workers (a cold cluster): ONE gap for all of them — either every worker's columns go into the no-gap list (which is then the
                             // batch's column list as it stands) or every worker carries the gap
                             const uint32_t w0 = solver_workers[0];
-                            const size_t li = (size_t)brq * n_sig_cap + gap_sig[w0];
-                            if (li >= left_state.size()) { left_state.resize(((size_t)pb.rqs.size()) * n_sig_cap, 0); left_of.resize(left_state.size()); }
-                            if (left_state[li] == 0) {
-                                Amounts tot; tot.a.assign(ws.total + (size_t)w0 * R, ws.total + (size_t)(w0 + 1) * R);
-                                if (agg_off.empty()) build_agg();
-                                const uint32_t a0 = agg_off[w0], na = agg_off[w0 + 1] - a0;
-                                left_state[li] = gaps.leftover(brq, tot, na ? agg_rq.data() + a0 : nullptr, na ? agg_variant.data() + a0 : nullptr, na, na ? agg_cnt.data() + a0 : nullptr, left_of[li]) ? 1 : 2;
-                            }
-                            const uint32_t gap = left_state[li] == 1 ? gaps.fit(batch.rq, left_of[li]) : 0;
+                            const uint32_t gap = gap_of(brq, batch.rq, gap_sig[w0], w0);
                             if (gap > 0) { pm.with_gap.reserve(solver_workers.size()); for (uint32_t w : solver_workers) pm.with_gap.push_back({w, gap}); }
                             else pm.no_gap.assign(bcols.begin(), bcols.end());
-                        } else
+                        } else {
+                        pm.no_gap.reserve(bcols.size());
                         for (uint32_t w : solver_workers) {
                             if (!cap_brq[w]) continue;
                             uint32_t gap = gap_of_sig[gap_sig[w]];
-                            if (gap == UINT32_MAX) {   // what the blocker leaves of a worker with this signature, and how many tasks of the batch fit into that: once per (batch, blocker, signature)
-                                const uint32_t sg = gap_sig[w];
-                                const size_t li = (size_t)brq * n_sig_cap + sg;
-                                if (li >= left_state.size()) { left_state.resize(((size_t)pb.rqs.size()) * n_sig_cap, 0); left_of.resize(left_state.size()); }
-                                if (left_state[li] == 0) {
-                                    Amounts tot; tot.a.assign(ws.total + (size_t)w * R, ws.total + (size_t)(w + 1) * R);
-                                    if (agg_off.empty()) build_agg();
-                                    const uint32_t a0 = agg_off[w], na = agg_off[w + 1] - a0;
-                                    left_state[li] = gaps.leftover(brq, tot, na ? agg_rq.data() + a0 : nullptr, na ? agg_variant.data() + a0 : nullptr, na, na ? agg_cnt.data() + a0 : nullptr, left_of[li]) ? 1 : 2;
-                                }
-                                gap = left_state[li] == 1 ? gaps.fit(batch.rq, left_of[li]) : 0;
-                                gap_of_sig[sg] = gap;
-                            }
+                            if (gap == UINT32_MAX) gap = gap_of_sig[gap_sig[w]] = gap_of(brq, batch.rq, gap_sig[w], w);   // once per (batch, blocker, signature)
                             if (gap > 0) pm.with_gap.push_back({w, gap});
                             else pm.no_gap.insert(pm.no_gap.end(), bcols.data() + bcols_off[w], bcols.data() + bcols_end[w]);
+                        }
                         }
                         if (!pm.no_gap.empty()) {   // blockers that leave no gap on the same workers give the same list: one id (identical workers: every blocker of the batch)
                             for (const PairMemo &o : pair_memo) if (&o != &pm && o.lhs_id >= 0 && o.no_gap == pm.no_gap) { pm.lhs_id = o.lhs_id; break; }
@@ -1200,7 +1254,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     m.row_lhs.resize((size_t)m.nrows(), -1); m.row_lhs_len.resize((size_t)m.nrows(), 0); m.row_block.resize((size_t)m.nrows(), -1);
     m.col_ub = col_ub; m.col_ub.resize((size_t)m.ncols(), UINT32_MAX);
     const double t_model1 = clock_us();
-    if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu terms, %zu worker signatures, %zu (batch, cut, blocker) passes over the workers\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), m.rcol.size(), sig_ids.size(), n_triples);
+    if (trace_model) fprintf(stderr, "[model] cuts done at %.3f ms: %d columns, %d rows, %zu terms, %zu worker signatures, %zu (batch, cut, blocker) passes over the workers\n", (t_model1 - t_model0) / 1e3, m.ncols(), m.nrows(), m.rcol.size(), sig_rep.size(), n_triples);
     hqmilp::Result sol = hqmilp::solve(m, pb.time_limit_s, !pb.certificate_only, hqmilp::REFERENCE_MIP_REL_GAP, pb.pricer);  // :432-438
     if (trace_model) fprintf(stderr, "[model] solve done %.3f ms after the model\n", (clock_us() - t_model1) / 1e3);
     out.pre_us = t_model0 - t_enter; out.model_us = t_model1 - t_model0; out.milp_us = clock_us() - t_model1; out.price_sweeps = sol.price_sweeps; out.price_rounds = sol.price_rounds; out.price_us = sol.price_total_us;
