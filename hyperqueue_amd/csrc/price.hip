@@ -30,6 +30,10 @@
 namespace hqprice {
 
 static_assert(PARTS == ASLOTS, "the master's parts are the kernel's activity slots");
+// Activity vectors per part on the device (SweepOut::asub).  With one, the 64 blocks of a part (1024-block model; 256 at 4096 blocks) add into the same K addresses:
+// device-scope atomics are resolved at the memory side, one after the other per address, and the block that comes last sees ~16 us between its walk's end and its
+// results' (r05 stage profile: median 2.7 us, slowest block 16.2) — the tail of every sweep.  Four vectors: a quarter of the queue; the last workgroup adds them up.
+constexpr int ASUB = 4;
 
 namespace {
 
@@ -67,7 +71,13 @@ __global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
     __threadfence();
     if (a.local) {  // this rank's share of a sharded sweep: per-block values and the partial activity vectors as they are, no totals
         for (uint32_t b = a.first + threadIdx.x; b < a.first + gridDim.x; b += WAVE) { a.lv_cx[b] = a.out.blk_cx[b]; a.lv_rc[b] = a.out.blk_rc[b]; a.lv_bnd[b] = a.out.blk_bnd[b]; a.lv_steps[b] = a.out.blk_steps[b]; }
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ASLOTS * a.t.K; i += WAVE) { a.res->part_act[i] = a.out.act[i]; a.out.act[i] = 0; }
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ASLOTS * a.t.K; i += WAVE) {
+            const uint32_t sl = i / a.t.K, k = i - sl * a.t.K;
+            long long v = 0;
+#pragma unroll
+            for (int sub = 0; sub < ASUB; sub++) { long long *p = &a.out.act[((size_t)sl * ASUB + sub) * a.t.K + k]; v += *p; *p = 0; }
+            a.res->part_act[i] = v;
+        }
         if (threadIdx.x == 0) *a.ticket = 0;
         __threadfence_system();
         __syncthreads();
@@ -112,7 +122,15 @@ __global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < a.t.K; k += WAVE) {  // the ASLOTS partial vectors -> the sweep's activities (and the slots ready for the next sweep)
         long long sum = 0;
-        for (int sl = 0; sl < ASLOTS; sl++) { const long long v = a.out.act[(size_t)sl * a.t.K + k]; sum += v; a.res->part_act[(size_t)sl * a.t.K + k] = v; a.out.act[(size_t)sl * a.t.K + k] = 0; }
+        for (int sl = 0; sl < ASLOTS; sl++) {
+            long long vs[ASUB];
+#pragma unroll
+            for (int sub = 0; sub < ASUB; sub++) { long long *p = &a.out.act[((size_t)sl * ASUB + sub) * a.t.K + k]; vs[sub] = *p; *p = 0; }
+            long long v = 0;
+#pragma unroll
+            for (int sub = 0; sub < ASUB; sub++) v += vs[sub];
+            sum += v; a.res->part_act[(size_t)sl * a.t.K + k] = v;
+        }
         a.res->act[k] = sum;
     }
     if (threadIdx.x == 0) {
@@ -142,14 +160,14 @@ bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     o_a = al16(o_cost + (size_t)t.n_cols * 8); o_ccap = al16(o_a + (size_t)t.n_cols * MMAX * 8); o_woff = al16(o_ccap + (size_t)t.n_cols * 4);
     o_wrow = al16(o_woff + (size_t)(t.n_cols + 1) * 4); o_wcoef = al16(o_wrow + nw * 2); tab_bytes = al16(o_wcoef + nw * 4);
     if (!h_stage.ensure(tab_bytes) || !d_tab.ensure(tab_bytes) || !h_res.ensure(sizeof(SweepResult) + 64)) return false;
-    if (!d_pats.ensure((size_t)max_sweeps * t.n_cols * 2) || !d_blk.ensure((size_t)t.n_blocks * 28 + 64) || !d_sync.ensure(64 + (size_t)ASLOTS * KMAX * 8)) return false;
+    if (!d_pats.ensure((size_t)max_sweeps * t.n_cols * 2) || !d_blk.ensure((size_t)t.n_blocks * 28 + 64) || !d_sync.ensure(64 + (size_t)ASLOTS * ASUB * KMAX * 8)) return false;
     unsigned char *h = h_stage.as<unsigned char>();
     memcpy(h + o_off, t.blk_off.data(), (size_t)(t.n_blocks + 1) * 4); memcpy(h + o_m, t.blk_m.data(), t.n_blocks); memcpy(h + o_cap, t.blk_cap.data(), (size_t)t.n_blocks * MMAX * 8);
     memcpy(h + o_cost, t.col_cost.data(), (size_t)t.n_cols * 8); memcpy(h + o_a, t.col_a.data(), (size_t)t.n_cols * MMAX * 8); memcpy(h + o_ccap, t.col_cap.data(), (size_t)t.n_cols * 4);
     memcpy(h + o_woff, t.col_woff.data(), (size_t)(t.n_cols + 1) * 4);
     if (nw) { memcpy(h + o_wrow, t.w_row.data(), nw * 2); memcpy(h + o_wcoef, t.w_coef.data(), nw * 4); }
     if (hipMemcpyAsync(d_tab.p, h, tab_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return false;
-    if (hipMemsetAsync(d_sync.p, 0, 64 + (size_t)ASLOTS * KMAX * 8, stream) != hipSuccess) return false;  // ticket + the wide rows' accumulators
+    if (hipMemsetAsync(d_sync.p, 0, 64 + (size_t)ASLOTS * ASUB * KMAX * 8, stream) != hipSuccess) return false;  // ticket + the wide rows' accumulators
     SweepResult *r = h_res.as<SweepResult>();
     seq = r->seq;  // (whatever the last solve left: the next sweep writes seq + 1)
     return true;
@@ -195,7 +213,7 @@ bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool loca
                  (const int32_t *)(d + o_ccap), (const uint32_t *)(d + o_woff), (const uint16_t *)(d + o_wrow), (const int32_t *)(d + o_wcoef)};
     unsigned char *blk = d_blk.as<unsigned char>();
     a.out = SweepOut{d_pats.as<uint16_t>() + (size_t)n_sweeps * t.n_cols, (double *)blk, (double *)(blk + (size_t)t.n_blocks * 8), (double *)(blk + (size_t)t.n_blocks * 16),
-                     (long long *)(d_sync.as<unsigned char>() + 64), (uint32_t *)(blk + (size_t)t.n_blocks * 24), profile ? h_prof.dev<uint64_t>() : nullptr};
+                     (long long *)(d_sync.as<unsigned char>() + 64), (uint32_t *)(blk + (size_t)t.n_blocks * 24), profile ? h_prof.dev<uint64_t>() : nullptr, (uint32_t)ASUB};
     a.budget = budget; a.seq = ++seq; a.ticket = d_sync.as<uint32_t>(); a.res = h_res.dev<SweepResult>();
     a.first = b0; a.local = local ? 1u : 0u;
     if (local) { unsigned char *lv = h_blkv.dev<unsigned char>(); a.lv_cx = (double *)lv; a.lv_rc = (double *)(lv + (size_t)t.n_blocks * 8); a.lv_bnd = (double *)(lv + (size_t)t.n_blocks * 16); a.lv_steps = (uint32_t *)(lv + (size_t)t.n_blocks * 24); }

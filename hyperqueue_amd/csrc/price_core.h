@@ -50,6 +50,10 @@ struct SweepOut {
     long long *act;       // [ASLOTS * K] partial sums over blocks of A_w x — integer coefficients, so the atomic sums are exact and order-free
     uint32_t *blk_steps;  // [n_blocks] search steps (0 = closed at the root); bit 31: budget exhausted
     uint64_t *prof;       // optional [n_blocks * 8]: wavefront clock at the stage boundaries (tools/price_probe.py --profile); nullptr = off
+    // `act` may hold asub (a power of two) vectors per part instead of one: block b adds into vector b % asub of its part, whoever adds the totals up sums them.  The
+    // device spreads its atomics that way (64 blocks of a part on one address queue up at the memory side — the last of them waits ~16 us: price.hip); the host
+    // emulation keeps one vector per part (0 or 1 here).
+    uint32_t asub = 1;
 };
 
 // columns of a priced block whose reduced cost is at most this fraction of the block's largest original cost stay at zero (their possible
@@ -218,7 +222,8 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
     });
     wv.sync();
     wv.each([&](int lane) {
-        long long *slot = out.act + (size_t)(b / part_size(t.n_blocks)) * t.K;
+        const uint32_t nsub = out.asub ? out.asub : 1u;
+        long long *slot = out.act + ((size_t)(b / part_size(t.n_blocks)) * nsub + (b & (nsub - 1u))) * t.K;
         for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) if (lact[k] != 0) wv.atomic_add_i64(&slot[k], lact[k]);
     });
     if (wv.first()) {

@@ -273,3 +273,33 @@ def test_config5_loop_through_the_resident_state_on_the_gpu():
         assert swept >= 3  # the loop's ticks are coupled models of the whole cluster: k_price_sweep solved them
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("n_ready", [30, 89, 150])
+def test_certificate_only_small_ticks_on_the_gpu(n_ready):
+    """HQTICK_FLAG_CERTIFICATE_ONLY through the C ABI: the DAG loop's small coupled ticks (host search, no sweeps) stop at the reference's own 1e-4 certificate —
+    is_optimal, not canonical, an objective within 1e-4 of the default tick's exact optimum, every row of the reference's model satisfied, and everything downstream of
+    the placement (decode, create_task_mapping, proactive filling: scheduler/mapping.rs:23-234) record for record what the oracle makes of the same counts."""
+    from oracle.oracle import Oracle
+
+    ids, prio, rq, off, dep = workloads.make_dag(200_000, seed=0)
+    drv = workloads.DagChurn(n_workers=1024, churn=0.1, seed=0)
+    snap = drv.snapshot(ids[:n_ready], prio[:n_ready], (rq[:n_ready] % 8).astype(np.uint32))
+    exact, _ = _tick(snap)
+    t = Tick(abi.make_config(time_limit_s=5.0, flags=abi.HQTICK_FLAG_CERTIFICATE_ONLY))
+    try:
+        got = t.tick(snap)
+    finally:
+        t.close()
+    assert exact.status == got.status == abi.HQTICK_DONE and exact.is_optimal and got.is_optimal
+    assert exact.is_canonical and not got.is_canonical
+    o = Oracle(abi.make_config(time_limit_s=5.0))
+    want = o.tick_given(snap, got.counts, is_optimal=True)
+    model = o.last_model()
+    x, xe = _model_point(model, got.counts), _model_point(model, exact.counts)
+    assert _rows_hold(model, x)
+    z, ze = float(np.dot(model["obj"], x)), float(np.dot(model["obj"], xe))
+    assert z <= ze * (1.0 + 1e-9) and ze - z <= 1.0e-4 * ze, (z, ze)
+    assert got.batches == want.batches and got.counts == want.counts and got.records == want.records
+    assert got.retracts == want.retracts and got.redirects == want.redirects
+    assert (got.new_free == want.new_free).all()
