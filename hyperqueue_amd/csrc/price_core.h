@@ -84,6 +84,12 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
             const uint32_t j = c0 + (uint32_t)lane;
             const uint32_t e0 = t.col_woff[j], e1 = t.col_woff[j + 1];
             cost = t.col_cost[j];
+            // (everything else the block reads of its column, in the same round trip: bound and amounts wait in the work problem's storage — idle until setup_work —
+            // for the test below and the compaction, instead of being fetched there behind a barrier each)
+            S.wcap[lane] = t.col_cap[j];
+            HQB_UNROLL
+            for (int r = 0; r < MMAX; r++) S.wa[r][lane] = t.col_a[(size_t)j * MMAX + r];
+            S.wc[lane] = cost;
             rc = cost;
             for (uint32_t e = e0; e < e1; e += 4) {
                 uint16_t wr[4]; int32_t wc[4];
@@ -97,27 +103,26 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
     });
     wv.sync();
     int lmax = -1;
-    const double cmax = wv.argmax([&](int lane) { return (uint32_t)lane < nb ? t.col_cost[c0 + (uint32_t)lane] : -1.0; }, &lmax);
+    const double cmax = wv.argmax([&](int lane) { return (uint32_t)lane < nb ? S.wc[lane] : -1.0; }, &lmax);
     const double thr = (cmax > 0.0 ? cmax : 1.0) * RC_DROP;
-    const uint64_t elig = wv.ballot([&](int lane) { return (uint32_t)lane < nb && S.lane_val[lane] > thr && t.col_cap[c0 + (uint32_t)lane] >= 1; });
+    const uint64_t elig = wv.ballot([&](int lane) { return (uint32_t)lane < nb && S.lane_val[lane] > thr && S.wcap[lane] >= 1; });
     const int n = __builtin_popcountll(elig);
     wv.sync();  // every lane has read the prices: the pool's storage may be written again
     // the columns that stay: compacted, reduced cost as the block's cost
     wv.each([&](int lane) {
         if (!((elig >> lane) & 1)) return;
         const int q = __builtin_popcountll(elig & ((1ull << lane) - 1ull));
-        const uint32_t j = c0 + (uint32_t)lane;
         S.c[q] = S.lane_val[lane];
         S.gcol[q] = lane;
-        S.colcap[q] = t.col_cap[j];
-        for (int r = 0; r < MMAX; r++) { const double v = r < m ? t.col_a[(size_t)j * MMAX + r] : 0.0; S.a[r][q] = v; S.ainv[r][q] = v > 0.0 ? 1.0 / v : 0.0; }
+        S.colcap[q] = S.wcap[lane];
+        for (int r = 0; r < MMAX; r++) { const double v = r < m ? S.wa[r][lane] : 0.0; S.a[r][q] = v; S.ainv[r][q] = v > 0.0 ? 1.0 / v : 0.0; }
     });
     // what the dropped columns could add at most (0 < rc <= thr): part of the block's bound
     double dropped = 0.0;
     for (uint32_t q = 0; q < nb; q++) {
         const double rc = S.lane_val[q];
         if (((elig >> q) & 1) || !(rc > 0.0)) continue;
-        dropped += rc * (double)(t.col_cap[c0 + q] < 65536 ? t.col_cap[c0 + q] : 65536);
+        dropped += rc * (double)(S.wcap[q] < 65536 ? S.wcap[q] : 65536);
     }
     wv.sync();
     for (int q = n; q < NMAX; q++) if (wv.first()) { S.c[q] = 0.0; for (int r = 0; r < MMAX; r++) { S.a[r][q] = 0.0; S.ainv[r][q] = 0.0; } }
@@ -226,9 +231,13 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
         long long *slot = out.act + ((size_t)(b / part_size(t.n_blocks)) * nsub + (b & (nsub - 1u))) * t.K;
         for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) if (lact[k] != 0) wv.atomic_add_i64(&slot[k], lact[k]);
     });
+    // (the original costs of the kept columns: one load per lane, side by side — lane 0 reading them one after the other was a chain of n global loads, 16 us on an
+    // eight-column block against 3 us on the median one: the tail of every sweep)
+    wv.each([&](int lane) { if (lane < n) S.lane_val[lane] = t.col_cost[c0 + (uint32_t)S.gcol[lane]]; });  // (S.wc holds the work problem's costs by now)
+    wv.sync();
     if (wv.first()) {
         double cx = 0.0, rc = 0.0;  // fixed order: the same sums on every replica
-        for (int q = 0; q < n; q++) { const double xv = (double)S.xbest[q]; cx += t.col_cost[c0 + (uint32_t)S.gcol[q]] * xv; rc += S.c[q] * xv; }
+        for (int q = 0; q < n; q++) { const double xv = (double)S.xbest[q]; cx += S.lane_val[q] * xv; rc += S.c[q] * xv; }
         out.blk_cx[b] = cx;
         out.blk_rc[b] = rc;
         // the walk closes a node whose bound is within 1e-12 (relative) of the incumbent: the optimum is not above best * (1 + 1e-12)
