@@ -30,10 +30,10 @@
 namespace hqprice {
 
 static_assert(PARTS == ASLOTS, "the master's parts are the kernel's activity slots");
-// Activity vectors per part on the device (SweepOut::asub).  With one, the 64 blocks of a part (1024-block model; 256 at 4096 blocks) add into the same K addresses:
-// device-scope atomics are resolved at the memory side, one after the other per address, and the block that comes last sees ~16 us between its walk's end and its
-// results' (r05 stage profile: median 2.7 us, slowest block 16.2) — the tail of every sweep.  Four vectors: a quarter of the queue; the last workgroup adds them up.
-constexpr int ASUB = 4;
+// Activity vectors per part on the device (SweepOut::asub).  With one, the 64 blocks of a part (1024-block model; 256 at 4096 blocks) add into the same K addresses.
+// Four vectors per part were measured in round 5 (a quarter of the queue per address; the last workgroup adds them up): the sweep took as long and the slowest block's
+// last stage stayed at ~16 us — the atomics are not what it waits for.  One vector it stays; the plumbing is kept for the next attempt (a power of two).
+constexpr int ASUB = 1;
 
 namespace {
 

@@ -50,9 +50,8 @@ struct SweepOut {
     long long *act;       // [ASLOTS * K] partial sums over blocks of A_w x — integer coefficients, so the atomic sums are exact and order-free
     uint32_t *blk_steps;  // [n_blocks] search steps (0 = closed at the root); bit 31: budget exhausted
     uint64_t *prof;       // optional [n_blocks * 8]: wavefront clock at the stage boundaries (tools/price_probe.py --profile); nullptr = off
-    // `act` may hold asub (a power of two) vectors per part instead of one: block b adds into vector b % asub of its part, whoever adds the totals up sums them.  The
-    // device spreads its atomics that way (64 blocks of a part on one address queue up at the memory side — the last of them waits ~16 us: price.hip); the host
-    // emulation keeps one vector per part (0 or 1 here).
+    // `act` may hold asub (a power of two) vectors per part instead of one: block b adds into vector b % asub of its part, whoever adds the totals up sums them
+    // (price.hip: ASUB; the host emulation keeps one vector per part — 0 or 1 here).
     uint32_t asub = 1;
 };
 
