@@ -1055,7 +1055,20 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     int next_lhs_id = 0;
     std::vector<int> count_ids;
     auto count_lhs_id = [&](uint32_t rq) { if (count_ids.size() <= rq) count_ids.resize((size_t)rq + 1, -1); if (count_ids[rq] < 0) count_ids[rq] = next_lhs_id++; return count_ids[rq]; };
-    auto mark_lhs = [&](int id, size_t len) { m.row_lhs.resize((size_t)m.nrows(), -1); m.row_lhs_len.resize((size_t)m.nrows(), 0); if (id >= 0) { m.row_lhs.back() = id; m.row_lhs_len.back() = (int32_t)len; } };
+    // A row `list (+ extra term)`: the list — a request's count columns, the no-gap columns of a (batch, blocker) pair — is written into the model ONCE, under its id
+    // (milp.h: Model::list_off); every row that starts with it names it and stores only what follows.  id < 0 (a multi-node batch's lists): an ordinary row.
+    std::vector<int> list_of_id;
+    auto list_row = [&](uint8_t type, double rhs, int id, const std::vector<int> &cols, int extra, double coef) {
+        m.begin_row(type, rhs);
+        if (id < 0) ones(cols);
+        if (extra >= 0) m.term(extra, coef);
+        m.end_row();
+        m.row_lhs.resize((size_t)m.nrows(), -1); m.row_lhs_len.resize((size_t)m.nrows(), 0);
+        if (id < 0) return;
+        if ((size_t)id >= list_of_id.size()) list_of_id.resize((size_t)id + 1, -1);
+        if (list_of_id[(size_t)id] < 0) list_of_id[(size_t)id] = m.add_list(cols.data(), cols.size());
+        m.row_lhs.back() = list_of_id[(size_t)id]; m.row_lhs_len.back() = (int32_t)cols.size();
+    };
     // priority cuts  :229-430
     std::map<std::pair<uint32_t, uint32_t>, int> short_flags;  // blocked_priority_vars
     auto short_flag = [&](uint32_t rq, uint32_t size) -> int {  // get_bvar  :233-253
@@ -1064,7 +1077,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         auto cc = count_cols.find(rq);
         if (cc == count_cols.end()) return -1;
         int col = addc(0.0, hqmilp::COL_BOOL, -1);
-        emit_plus(hqmilp::ROW_MIN, (double)size, cc->second, col, (double)size); mark_lhs(count_lhs_id(rq), cc->second.size());
+        list_row(hqmilp::ROW_MIN, (double)size, count_lhs_id(rq), cc->second, col, (double)size);
         short_flags[{rq, size}] = col;
         return col;
     };
@@ -1148,9 +1161,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         if (cc == count_cols.end()) continue;
         const RequestView &brv = pb.rqs[batch.rq];
         if (!batch.limit_reached) {  // :264-271
-            m.begin_row(hqmilp::ROW_MAX, (double)batch.size);
-            ones(cc->second);
-            m.end_row(); mark_lhs(count_lhs_id(batch.rq), cc->second.size());
+            list_row(hqmilp::ROW_MAX, (double)batch.size, count_lhs_id(batch.rq), cc->second, -1, 0.0);
         }
         double bsize = (double)batch.size;
         std::vector<uint32_t> capped_by;  // blocked_by_unbounded
@@ -1233,10 +1244,10 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 }
                 if (no_gap->empty()) continue;
                 int fl;
-                if (bounded && (fl = short_flag(brq, bl.second)) >= 0) { emit_plus(hqmilp::ROW_MAX, bsize + (double)cut.size, *no_gap, fl, bsize); mark_lhs(no_gap_id, no_gap->size()); }
+                if (bounded && (fl = short_flag(brq, bl.second)) >= 0) list_row(hqmilp::ROW_MAX, bsize + (double)cut.size, no_gap_id, *no_gap, fl, bsize);
                 else if (!bounded && std::find(capped_by.begin(), capped_by.end(), brq) == capped_by.end()) {
                     capped_by.push_back(brq);
-                    m.begin_row(hqmilp::ROW_MAX, (double)cut.size); ones(*no_gap); m.end_row(); mark_lhs(no_gap_id, no_gap->size());
+                    list_row(hqmilp::ROW_MAX, (double)cut.size, no_gap_id, *no_gap, -1, 0.0);
                 }
             }
         }

@@ -1201,9 +1201,10 @@ void set_fast_path(int on) { g_fast_path = on; }
 // exactly what HiGHS accepts there.
 const double ROW_TOL = 1e-6;
 
-Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double rel_gap, hqprice::Sweeper *sweeper) {
+namespace {
+// true: `res` is the model's certified answer
+bool solve_fast(const Model &mdl_in, double time_limit_s, double rel_gap, hqprice::Sweeper *sweeper, const double ts0, Result &res_out) {
     static const bool tracing_solve = getenv("HQMILP_TRACE") != nullptr;
-    const double ts0 = wall();
     auto tmark = [&](const char *what) { if (tracing_solve && mdl_in.ncols() > 1000) fprintf(stderr, "[milp] solve(): %s at %.3f ms\n", what, (wall() - ts0) * 1e3); };
     // ---- the coupled tick's fast path: a large model whose builder said how it is made — one block of columns per worker (col_group), rows that share their leading
     // terms (row_lhs) — goes to the price sweeps AS IT IS (hqprice::solve_model): no snapped copy, no integer-hull pass, no components, no scaled row copy, no
@@ -1219,7 +1220,7 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
         hqprice::ModelView mv;
         mv.n = n; mv.m = m; mv.obj = mdl_in.obj.data(); mv.kind = mdl_in.kind.data(); mv.rtype = mdl_in.rtype.data(); mv.rhs = mdl_in.rhs.data();
         mv.roff = mdl_in.roff.data(); mv.rcol = mdl_in.rcol.data(); mv.rcoef = mdl_in.rcoef.data(); mv.col_group = mdl_in.col_group.data();
-        mv.row_implied = (int)mdl_in.row_implied.size() == m ? mdl_in.row_implied.data() : nullptr; mv.row_lhs = mdl_in.row_lhs.data(); mv.row_lhs_len = mdl_in.row_lhs_len.data();
+        mv.row_implied = (int)mdl_in.row_implied.size() == m ? mdl_in.row_implied.data() : nullptr; mv.row_lhs = mdl_in.row_lhs.data(); mv.row_lhs_len = mdl_in.row_lhs_len.data(); mv.list_off = mdl_in.list_off.data(); mv.list_col = mdl_in.list_col.data(); mv.n_lists = (int)mdl_in.list_off.size() - 1;
         if ((int)mdl_in.row_block.size() == m && (int)mdl_in.col_ub.size() == n) { mv.row_block = mdl_in.row_block.data(); mv.col_ub = mdl_in.col_ub.data(); }
         double cost_scale = 1.0;
         const double tf0 = wall();
@@ -1236,9 +1237,8 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
                 const int L = mdl_in.row_lhs[i];
                 if (L >= 0) {
                     if ((size_t)L >= lhs_seen.size()) { lhs_seen.resize((size_t)L + 1, 0); lhs_act.resize((size_t)L + 1, 0.0); }
-                    const int len = mdl_in.row_lhs_len[i];
-                    if (!lhs_seen[(size_t)L]) { double s = 0.0; for (int k = k0; k < k0 + len; k++) s += mdl_in.rcoef[k] * pa.x[(size_t)mdl_in.rcol[k]]; lhs_act[(size_t)L] = s; lhs_seen[(size_t)L] = 1; }
-                    a = lhs_act[(size_t)L]; k0 += len;
+                    if (!lhs_seen[(size_t)L]) { double s = 0.0; for (int k = mdl_in.list_off[L]; k < mdl_in.list_off[L + 1]; k++) s += pa.x[(size_t)mdl_in.list_col[k]]; lhs_act[(size_t)L] = s; lhs_seen[(size_t)L] = 1; }
+                    a = lhs_act[(size_t)L];   // (the list's terms: coefficient 1 each, not among the row's stored terms)
                 }
                 for (int k = k0; k < mdl_in.roff[i + 1]; k++) a += mdl_in.rcoef[k] * pa.x[(size_t)mdl_in.rcol[k]];
                 const double tol = std::max(ROW_TOL, 1e-9 * std::max(1.0, std::fabs(mdl_in.rhs[i])));   // (HiGHS's own mip_feasibility_tolerance, see ROW_TOL below)
@@ -1254,11 +1254,32 @@ Result solve(const Model &mdl_in, double time_limit_s, bool canonical, double re
                 double z = 0.0; for (int j = 0; j < n; j++) z += mdl_in.obj[j] * res.x[(size_t)j];
                 res.objective = z;
                 tmark("fast path certified");
-                return res;
+                res_out = std::move(res);
+                return true;
             }
             if (tracing_solve) fprintf(stderr, "[milp] fast path: the certified point fails a row of the model: classic path\n");
         }
     }
+    return false;
+}
+}  // namespace
+
+static Result solve_classic(const Model &mdl_in, double time_limit_s, bool canonical, double rel_gap, hqprice::Sweeper *sweeper, const double ts0);
+
+Result solve(const Model &mdl_arg, double time_limit_s, bool canonical, double rel_gap, hqprice::Sweeper *sweeper) {
+    const double ts_entry = wall();
+    { Result r; if (solve_fast(mdl_arg, time_limit_s, rel_gap, sweeper, ts_entry, r)) return r; }
+    if (mdl_arg.has_lists()) {   // every other consumer works on the plain form
+        Model plain = mdl_arg;
+        plain.expand_lists();
+        return solve_classic(plain, time_limit_s, canonical, rel_gap, sweeper, ts_entry);
+    }
+    return solve_classic(mdl_arg, time_limit_s, canonical, rel_gap, sweeper, ts_entry);
+}
+
+static Result solve_classic(const Model &mdl_in, double time_limit_s, bool canonical, double rel_gap, hqprice::Sweeper *sweeper, const double ts0) {
+    static const bool tracing_solve = getenv("HQMILP_TRACE") != nullptr;
+    auto tmark = [&](const char *what) { if (tracing_solve && mdl_in.ncols() > 1000) fprintf(stderr, "[milp] solve(): %s at %.3f ms\n", what, (wall() - ts0) * 1e3); };
     Model snapped;  // a copy of the model only when a coefficient really has to be snapped (a block of a worker class has no BOOL column at all)
     bool need_snap = false;
     for (size_t k = 0; k < mdl_in.rcoef.size() && !need_snap; k++) {

@@ -16,6 +16,7 @@
 // the same direction the objective's (W - idx) factor pushes.
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <vector>
 
 namespace hqprice { struct Sweeper; }
@@ -38,11 +39,38 @@ struct Model {
     //   col_group[j] >= 0: column j belongs to that block (the tick: a worker's placement columns, solver.rs:95-192); -1: a column of the whole model
     //                      (the "blocker short" flags, solver.rs:233-253).  What the price sweeps of csrc/price.cpp decompose along.
     //   row_implied[i] != 0: row i is implied, for INTEGER points, by the other rows of its block (a cut from the block's own integer optimum)
-    //   row_lhs[i] >= 0: the first row_lhs_len[i] terms of row i are the SAME list (columns, coefficients, order) in every row that carries this id — a batch's cut rows
-    //                      against its blockers differ in their flag and right-hand side only; -1: no statement.  What lets the coupled solve read such a list once.
+    //   row_lhs[i] >= 0: the left-hand side of row i BEGINS with shared list row_lhs[i] (below), every column of it with coefficient 1 — a batch's cut rows against
+    //                      its blockers differ in their flag and right-hand side only.  Those terms are NOT in rcol / rcoef (the row's stored terms are what follows
+    //                      the list: a flag, usually): a three-level C3 tick has 70 such rows over 16 lists of ~1000 columns — written once per list instead of once per
+    //                      row, read once per list by the coupled solve.  row_lhs_len[i] = the list's length.  -1: an ordinary row.  expand_lists() turns the model
+    //                      into its plain form (what every consumer other than the coupled solve's fast path works on).
     std::vector<int32_t> col_group;
     std::vector<uint8_t> row_implied;
     std::vector<int32_t> row_lhs, row_lhs_len;
+    std::vector<int> list_off{0}, list_col;   // shared lists: list l = list_col[list_off[l] .. list_off[l + 1])
+    int add_list(const int *cols, size_t n) { list_col.insert(list_col.end(), cols, cols + n); list_off.push_back((int)list_col.size()); return (int)list_off.size() - 2; }
+    bool has_lists() const { return list_off.size() > 1; }
+    void expand_lists() {   // the plain form: every row carries all its terms (a list's first, in the list's order, coefficient 1), no list left
+        if (!has_lists()) return;
+        const int m = nrows();
+        std::vector<int> noff; noff.reserve((size_t)m + 1); noff.push_back(0);
+        size_t total = rcol.size();
+        for (int i = 0; i < m; i++) if (i < (int)row_lhs.size() && row_lhs[i] >= 0) total += (size_t)(list_off[row_lhs[i] + 1] - list_off[row_lhs[i]]);
+        std::vector<int> ncol; std::vector<double> ncoef; ncol.reserve(total); ncoef.reserve(total);
+        for (int i = 0; i < m; i++) {
+            if (i < (int)row_lhs.size() && row_lhs[i] >= 0) {
+                const int l = row_lhs[i];
+                ncol.insert(ncol.end(), list_col.begin() + list_off[l], list_col.begin() + list_off[l + 1]);
+                ncoef.resize(ncol.size(), 1.0);
+            }
+            ncol.insert(ncol.end(), rcol.begin() + roff[i], rcol.begin() + roff[i + 1]);
+            ncoef.insert(ncoef.end(), rcoef.begin() + roff[i], rcoef.begin() + roff[i + 1]);
+            noff.push_back((int)ncol.size());
+        }
+        roff.swap(noff); rcol.swap(ncol); rcoef.swap(ncoef);
+        list_off.assign(1, 0); list_col.clear();
+        std::fill(row_lhs.begin(), row_lhs.end(), -1); std::fill(row_lhs_len.begin(), row_lhs_len.end(), 0);
+    }
     //   row_block[i] >= 0: every column of row i belongs to that block (col_group value) and to nothing else — a worker's resource rows; -1: no statement
     //   col_ub[j] != UINT32_MAX: column j cannot exceed this value in any integer point (what the worker's free resources allow: min over the request's entries of
     //                            floor(free / amount), in exact integers) — a bound the rows imply, handed over so that nobody has to derive it again

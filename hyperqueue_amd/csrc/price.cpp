@@ -1192,8 +1192,8 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
     for (int g = 0; g < P.G; g++) gidx[P.gmodel[g]] = g;
     // ---- column bounds, as hqmilp::solve derives them: a row without a negative coefficient bounds every column it holds by floor(rhs / coef + 1e-9).  A shared list of
     // leading terms is walked once, against the smallest right-hand side of its rows (the bound is monotone in the right-hand side).
-    int n_lhs = 0;
-    for (int i = 0; i < m; i++) n_lhs = std::max(n_lhs, mv.row_lhs[i] + 1);
+    const int n_lhs = mv.n_lists;
+    for (int i = 0; i < m; i++) if (mv.row_lhs[i] >= n_lhs) return "bad structure hint";
     struct Fam { int first = -1, len = 0; bool has_neg = false, scanned = false; double rhs_min = INF;
                  // of the list's block columns: their block (-2 none yet), more than one block, a global column inside, count, integer coefficients
                  int b0 = -2; bool multi = false, has_g = false, integral = true; int n_bcols = 0; double amax = 0.0; };
@@ -1203,32 +1203,25 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
     const bool hinted = mv.row_block && mv.col_ub;   // the builder's own bounds of the block columns: the rows of single blocks need not be walked for theirs
     if (hinted) for (int j = 0; j < n; j++) if (mv.col_ub[j] != UINT32_MAX) ub[j] = std::min(ub[j], (double)mv.col_ub[j]);
     auto bound_terms = [&](int a, int e, double rhs) { for (int k = a; k < e; k++) if (mv.rcoef[k] > 0.0) { double &u = ub[mv.rcol[k]]; u = std::min(u, std::floor(rhs / mv.rcoef[k] + 1e-9)); } };
+    for (int l = 0; l < n_lhs; l++) for (int k = mv.list_off[l]; k < mv.list_off[l + 1]; k++) if (mv.list_col[k] < 0 || mv.list_col[k] >= n) return "bad structure hint";
     for (int i = 0; i < m; i++) {
         const int a = mv.roff[i], e = mv.roff[i + 1];
-        if (a == e) { const double b = mv.rhs[i]; const bool ok = mv.rtype[i] == 1 ? b >= -1e-9 : (mv.rtype[i] == 0 ? b <= 1e-9 : std::fabs(b) <= 1e-9); if (!ok) return "infeasible empty row"; continue; }
+        if (a == e && mv.row_lhs[i] < 0) { const double b = mv.rhs[i]; const bool ok = mv.rtype[i] == 1 ? b >= -1e-9 : (mv.rtype[i] == 0 ? b <= 1e-9 : std::fabs(b) <= 1e-9); if (!ok) return "infeasible empty row"; continue; }
         if (hinted && mv.row_block[i] >= 0) continue;
         const int L = mv.row_lhs[i];
-        int tail = a;
+        const int tail = a;   // (a shared list's terms are not among the row's stored ones: those are all tail)
         bool neg = false;
-        if (L >= 0) {
-            Fam &f = fam[(size_t)L];
-            const int len = mv.row_lhs_len[i];
-            if (len < 0 || a + len > e) return "bad structure hint";
-            if (f.first < 0) { f.first = i; f.len = len; for (int k = a; k < a + len; k++) if (mv.rcoef[k] < 0.0) f.has_neg = true; }
-            else if (f.len != len) return "bad structure hint";
-            else {   // (hints are checked, not trusted: the later rows of a list must really carry it — two memcmps per row)
-                const int a0 = mv.roff[f.first];
-                if (memcmp(mv.rcol + a, mv.rcol + a0, (size_t)len * sizeof(int)) != 0 || memcmp(mv.rcoef + a, mv.rcoef + a0, (size_t)len * sizeof(double)) != 0) return "structure hint: rows of one row_lhs id differ";
-            }
-            neg = f.has_neg; tail = a + len;
-        }
+        if (L >= 0) { Fam &f = fam[(size_t)L]; if (f.first < 0) { f.first = i; f.len = mv.list_off[L + 1] - mv.list_off[L]; } }
         for (int k = tail; k < e; k++) if (mv.rcoef[k] < 0.0) neg = true;
         if (mv.rtype[i] == 0 || neg) continue;   // a `>=` row, or a negative coefficient: no bound from here (the multi-node rows that do bound through one are not for this path)
         if (mv.rhs[i] < -1e-9) return "infeasible row";
         if (L >= 0) fam[(size_t)L].rhs_min = std::min(fam[(size_t)L].rhs_min, mv.rhs[i]);
         bound_terms(tail, e, mv.rhs[i]);
     }
-    for (const Fam &f : fam) if (f.first >= 0 && f.rhs_min < INF) bound_terms(mv.roff[f.first], mv.roff[f.first] + f.len, f.rhs_min);
+    for (int l = 0; l < n_lhs; l++) if (fam[(size_t)l].first >= 0 && fam[(size_t)l].rhs_min < INF) {   // coefficient 1: the bound is the right-hand side itself
+        const double bnd = std::floor(fam[(size_t)l].rhs_min + 1e-9);
+        for (int k = mv.list_off[l]; k < mv.list_off[l + 1]; k++) { double &u = ub[mv.list_col[k]]; u = std::min(u, bnd); }
+    }
     if (hinted && g_check_hints) {   // tests: the builder's column bounds must be what the skipped single-block rows give — not tighter (a point lost), not looser
         std::vector<double> chk(n, INF);
         for (int j = 0; j < n; j++) if (mv.kind[j] == 1) chk[j] = 1.0;
@@ -1281,25 +1274,28 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
     };
     for (int i = 0; i < m; i++) {
         const int a = mv.roff[i], e = mv.roff[i + 1];
-        if (a == e) continue;
+        if (a == e && mv.row_lhs[i] < 0) continue;
         const bool is_le = mv.rtype[i] == 1, is_ge = mv.rtype[i] == 0;
         const double rhs = mv.rhs[i];
         const int L = mv.row_lhs[i];
-        Scan sc; int tail = a;
+        Scan sc; const int tail = a;
+        bool fam_row = false;
         if (L >= 0) {
             Fam &f = fam[(size_t)L];
-            if (!f.scanned) {
+            if (!f.scanned) {   // the list itself, once: which blocks its columns are of, what it can reach at most (coefficient 1 each)
                 f.scanned = true;
-                Scan fs; scan(a, a + f.len, fs);
-                f.b0 = fs.b0; f.multi = fs.multi; f.has_g = fs.has_g; f.n_bcols = fs.n_bcols; f.amax = fs.amax;
-                for (int k = a; k < a + f.len; k++) { const double v = mv.rcoef[k], rv = round_fast(v); if (std::fabs(v - rv) > 1e-7 * std::max(1.0, std::fabs(rv)) || std::fabs(rv) > 1.0e9) f.integral = false; }
+                for (int k = mv.list_off[L]; k < mv.list_off[L + 1]; k++) {
+                    const int j = mv.list_col[k];
+                    f.amax += ub[j];
+                    if (blk[j] < 0) { f.has_g = true; continue; }
+                    f.n_bcols++;
+                    if (f.b0 == -2) f.b0 = blk[j]; else if (blk[j] != f.b0) f.multi = true;
+                }
             }
-            if (f.multi && !f.has_g) {   // the list spans blocks: a wide row whose left-hand side is the family's
-                sc.b0 = f.b0; sc.multi = true; sc.has_g = false; sc.nonneg = !f.has_neg; sc.n_bcols = f.n_bcols; sc.amax = f.amax;
-                tail = a + f.len;
-            }
+            if (!(f.multi && !f.has_g)) return "shared list that is not a wide left-hand side";   // (one block's list, or a flag inside it: the plain form's business)
+            sc.b0 = f.b0; sc.multi = true; sc.has_g = false; sc.nonneg = true; sc.n_bcols = f.n_bcols; sc.amax = f.amax;
+            fam_row = true;
         }
-        const bool fam_row = tail != a;
         const int hint_b = (hinted && !fam_row && mv.row_block[i] >= 0 && mv.row_block[i] <= max_group) ? block_of_group[mv.row_block[i]] : -1;
         if (hint_b >= 0) {   // the builder says: one block's row — no need to look its columns' blocks up
             if (mv.row_implied && mv.row_implied[i]) continue;
@@ -1310,7 +1306,7 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
                 if (mv.rcoef[k] < 0.0) sc.nonneg = false;
                 sc.amax += mv.rcoef[k] * ub[mv.rcol[k]];
             }
-        } else scan(tail, e, sc);   // (a family row: its own terms behind the shared list; any other row: all of it)
+        } else scan(tail, e, sc);   // (a row with a shared list: its own terms behind the list; any other row: all of it)
         if (!sc.multi && !sc.has_g && sc.b0 >= 0) {  // a row of one block
             if (mv.row_implied && mv.row_implied[i]) continue;  // implied for integer points by the block's other rows: the sweeps solve the blocks in integers
             if (is_le && sc.nonneg && sc.amax <= rhs * (1.0 + 1e-12) + 1e-9) continue;  // no point within the column bounds can violate it
@@ -1366,7 +1362,6 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
         const double sign = is_le ? 1.0 : -1.0;
         w.h = sign * rhs;
         if (fam_row) {
-            if (!fam[(size_t)L].integral) return "wide row with a non-integer coefficient";
             w.lhs_key = 2 * L + (is_ge ? 1 : 0);
         } else { w.lhs_key = -1; w.own = (int)own_lists.size(); own_lists.emplace_back(); own_lists.back().reserve((size_t)(e - a)); }
         for (int k = tail; k < e; k++) {
@@ -1378,7 +1373,7 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
             if (std::fabs(v - rv) > 1e-7 * std::max(1.0, std::fabs(rv)) || std::fabs(rv) > 1.0e9) return "wide row with a non-integer coefficient";
             if (rv != 0.0) own_lists.back().push_back({P.flat_of[j], (int32_t)rv});
         }
-        P.row_terms += (size_t)(e - a) - w.g.size();
+        P.row_terms += (size_t)(e - a) - w.g.size() + (fam_row ? (size_t)fam[(size_t)L].len : 0);
         wide.push_back(std::move(w));
         if ((int)wide.size() > 1024) return "more than 1024 wide rows";
     }
@@ -1399,11 +1394,10 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
     std::vector<uint64_t> lhs_hash;
     std::vector<int> group_of_key((size_t)2 * n_lhs, -1);
     auto materialise = [&](int key, std::vector<std::pair<int, int32_t>> &out) {   // the family's list with the row's sign, zero coefficients dropped
-        const Fam &f = fam[(size_t)(key >> 1)];
-        const int a = mv.roff[f.first];
-        const double sign = (key & 1) ? -1.0 : 1.0;
-        out.clear(); out.reserve((size_t)f.len);
-        for (int k = a; k < a + f.len; k++) { const double rv = round_fast(sign * mv.rcoef[k]); if (rv != 0.0) out.push_back({P.flat_of[mv.rcol[k]], (int32_t)rv}); }
+        const int l = key >> 1;
+        const int32_t sign = (key & 1) ? -1 : 1;
+        out.clear(); out.reserve((size_t)(mv.list_off[l + 1] - mv.list_off[l]));
+        for (int k = mv.list_off[l]; k < mv.list_off[l + 1]; k++) out.push_back({P.flat_of[mv.list_col[k]], sign});
     };
     auto hash_of = [](const std::vector<std::pair<int, int32_t>> &l) { uint64_t h = 1469598103934665603ull; for (auto &t : l) { h = (h ^ (uint64_t)(uint32_t)t.first) * 1099511628211ull; h = (h ^ (uint64_t)(uint32_t)t.second) * 1099511628211ull; } return h; };
     std::vector<std::pair<int, int32_t>> tmp;

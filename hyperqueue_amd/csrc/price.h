@@ -110,6 +110,7 @@ struct ModelView {
     const int *roff = nullptr, *rcol = nullptr; const double *rcoef = nullptr;
     const int32_t *col_group = nullptr; const uint8_t *row_implied = nullptr;   // row_implied may be nullptr
     const int32_t *row_lhs = nullptr, *row_lhs_len = nullptr;
+    const int *list_off = nullptr, *list_col = nullptr; int n_lists = 0;   // the shared lists row_lhs names (milp.h: Model::list_off / list_col): coefficient 1 each, not among the rows' stored terms
     const int32_t *row_block = nullptr; const uint32_t *col_ub = nullptr;   // optional (milp.h: Model::row_block / col_ub)
 };
 // tests: also check the builder's column bounds against the rows they stand for (this thread); mismatches since the last call that switched it on
