@@ -910,6 +910,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
         uint32_t group = UINT32_MAX; bool ok = false;
         std::vector<double> s, wq; std::vector<uint32_t> slot, rq, ub;          // per column: cost without the order factor, weight, variant slot, request, bound
         std::vector<double> rhs; std::vector<uint8_t> implied; std::vector<int> roff{0}, rcol; std::vector<double> rcoef;   // per row (all `<=`, all of this block)
+        std::vector<std::vector<int> *> cc;   // per column: its request's list of count columns (a node of count_cols: stays where it is) — not a map walk per column
     } tmpl;
     std::vector<double> rec_s, rec_wq; std::vector<uint32_t> rec_slot, rec_rq;   // what the loop below records per placement column while it builds a block
     for (size_t wi = 0; wi < nw; wi++) {  // :95
@@ -924,7 +925,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                 const int col = addc(tmpl.s[k] * order_factor * tmpl.wq[k] / (double)nw, hqmilp::COL_NAT, (int32_t)wi);
                 place_col[(size_t)w * NVS + tmpl.slot[k]] = col;
                 col_ub.resize((size_t)col + 1, UINT32_MAX); col_ub[col] = tmpl.ub[k];
-                count_cols[tmpl.rq[k]].push_back(col);
+                tmpl.cc[k]->push_back(col);
             }
             for (size_t r = 0; r + 1 < tmpl.roff.size(); r++) {
                 m.begin_row(hqmilp::ROW_MAX, tmpl.rhs[r]);
@@ -1019,6 +1020,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             if (plain) {
                 tmpl.group = my_group; tmpl.ok = true;
                 tmpl.s = rec_s; tmpl.wq = rec_wq; tmpl.slot = rec_slot; tmpl.rq = rec_rq;
+                tmpl.cc.resize(tmpl.rq.size()); for (size_t k = 0; k < tmpl.rq.size(); k++) tmpl.cc[k] = &count_cols[tmpl.rq[k]];
                 tmpl.ub.assign(col_ub.begin() + rec_col0, col_ub.begin() + m.ncols());
                 tmpl.rhs.assign(m.rhs.begin() + rec_row0, m.rhs.end());
                 tmpl.implied.assign((size_t)(m.nrows() - rec_row0), 0);
