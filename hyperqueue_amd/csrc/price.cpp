@@ -835,16 +835,18 @@ Answer run_solver(Solver &S, const double tp0) {
     S.pmax.assign(K, 0.0);
     {
         double cmax = 0.0; for (double c : P.T.col_cost) cmax = std::max(cmax, c);
-        for (int k = 0; k < K; k++) {
+        // (per GROUP: the rows of a group share their left-hand side — one division per term of a list, not one per term of every row that carries it)
+        std::vector<double> gp(P.KG, 0.0);
+        for (int g = 0; g < P.KG; g++) {
             double p = 0.0; bool neg = false; int32_t amin = INT32_MAX;
-            const int gk = P.grp_of[k];
-            for (int t = P.g_off[gk]; t < P.g_off[gk + 1]; t++) {
+            for (int t = P.g_off[g]; t < P.g_off[g + 1]; t++) {
                 const int32_t a = P.g_coef[t];
                 if (a > 0) p = std::max(p, P.T.col_cost[P.g_col[t]] / (double)a); else { neg = true; amin = std::min(amin, -a); }
             }
             if (neg) p = std::max(p, 64.0 * cmax / (double)std::max<int32_t>(1, amin));
-            S.pmax[k] = p;
+            gp[g] = p;
         }
+        for (int k = 0; k < K; k++) S.pmax[k] = gp[P.grp_of[k]];
     }
     std::vector<double> pi0(K, 0.0);
     if (S.evaluate(pi0) < 0) { ans.why = "sweep failed"; return ans; }
@@ -1399,7 +1401,7 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
         out.clear(); out.reserve((size_t)(mv.list_off[l + 1] - mv.list_off[l]));
         for (int k = mv.list_off[l]; k < mv.list_off[l + 1]; k++) out.push_back({P.flat_of[mv.list_col[k]], sign});
     };
-    auto hash_of = [](const std::vector<std::pair<int, int32_t>> &l) { uint64_t h = 1469598103934665603ull; for (auto &t : l) { h = (h ^ (uint64_t)(uint32_t)t.first) * 1099511628211ull; h = (h ^ (uint64_t)(uint32_t)t.second) * 1099511628211ull; } return h; };
+    auto hash_of = [](const std::vector<std::pair<int, int32_t>> &l) { uint64_t h = 1469598103934665603ull; for (auto &t : l) h = (h ^ ((uint64_t)(uint32_t)t.first | ((uint64_t)(uint32_t)t.second << 32))) * 1099511628211ull; return h; };
     std::vector<std::pair<int, int32_t>> tmp;
     for (int k = 0; k < P.K; k++) {
         WideRow &w = wide[(size_t)k];
