@@ -70,12 +70,24 @@ __global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
     if (!s_last) return;
     __threadfence();
     if (a.local) {  // this rank's share of a sharded sweep: per-block values and the partial activity vectors as they are, no totals
-        for (uint32_t b = a.first + threadIdx.x; b < a.first + gridDim.x; b += WAVE) { a.lv_cx[b] = a.out.blk_cx[b]; a.lv_rc[b] = a.out.blk_rc[b]; a.lv_bnd[b] = a.out.blk_bnd[b]; a.lv_steps[b] = a.out.blk_steps[b]; }
+        for (uint32_t b0 = a.first + threadIdx.x; b0 < a.first + gridDim.x; b0 += WAVE * 8) {   // (eight blocks' loads in flight, then their stores: see below)
+            double vcx[8], vrc[8], vbd[8]; uint32_t vst[8];
+            const uint32_t end = a.first + gridDim.x;
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t b = b0 + (uint32_t)u * WAVE; const bool in = b < end; vcx[u] = in ? a.out.blk_cx[b] : 0.0; vrc[u] = in ? a.out.blk_rc[b] : 0.0; vbd[u] = in ? a.out.blk_bnd[b] : 0.0; vst[u] = in ? a.out.blk_steps[b] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t b = b0 + (uint32_t)u * WAVE; if (b < end) { a.lv_cx[b] = vcx[u]; a.lv_rc[b] = vrc[u]; a.lv_bnd[b] = vbd[u]; a.lv_steps[b] = vst[u]; } }
+        }
         for (uint32_t i = threadIdx.x; i < (uint32_t)ASLOTS * a.t.K; i += WAVE) {
             const uint32_t sl = i / a.t.K, k = i - sl * a.t.K;
+            long long vs[ASUB];
+#pragma unroll
+            for (int sub = 0; sub < ASUB; sub++) vs[sub] = a.out.act[((size_t)sl * ASUB + sub) * a.t.K + k];
+#pragma unroll
+            for (int sub = 0; sub < ASUB; sub++) a.out.act[((size_t)sl * ASUB + sub) * a.t.K + k] = 0;
             long long v = 0;
 #pragma unroll
-            for (int sub = 0; sub < ASUB; sub++) { long long *p = &a.out.act[((size_t)sl * ASUB + sub) * a.t.K + k]; v += *p; *p = 0; }
+            for (int sub = 0; sub < ASUB; sub++) v += vs[sub];
             a.res->part_act[i] = v;
         }
         if (threadIdx.x == 0) *a.ticket = 0;
@@ -121,14 +133,19 @@ __global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
     red[threadIdx.x] = cx; red[WAVE + threadIdx.x] = rc; red[2 * WAVE + threadIdx.x] = bnd; redu[threadIdx.x] = nbud; redu[WAVE + threadIdx.x] = mx;
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < a.t.K; k += WAVE) {  // the ASLOTS partial vectors -> the sweep's activities (and the slots ready for the next sweep)
-        long long sum = 0;
-        for (int sl = 0; sl < ASLOTS; sl++) {
-            long long vs[ASUB];
+        // (all loads first, then the stores: with a store to the host's pinned result between two loads the compiler keeps their order — it cannot know the
+        // two do not alias — and the sixteen loads become sixteen round trips to memory the other workgroups have just written)
+        long long vs[ASLOTS * ASUB];
 #pragma unroll
-            for (int sub = 0; sub < ASUB; sub++) { long long *p = &a.out.act[((size_t)sl * ASUB + sub) * a.t.K + k]; vs[sub] = *p; *p = 0; }
+        for (int i = 0; i < ASLOTS * ASUB; i++) vs[i] = a.out.act[(size_t)i * a.t.K + k];
+#pragma unroll
+        for (int i = 0; i < ASLOTS * ASUB; i++) a.out.act[(size_t)i * a.t.K + k] = 0;
+        long long sum = 0;
+#pragma unroll
+        for (int sl = 0; sl < ASLOTS; sl++) {
             long long v = 0;
 #pragma unroll
-            for (int sub = 0; sub < ASUB; sub++) v += vs[sub];
+            for (int sub = 0; sub < ASUB; sub++) v += vs[sl * ASUB + sub];
             sum += v; a.res->part_act[(size_t)sl * a.t.K + k] = v;
         }
         a.res->act[k] = sum;
