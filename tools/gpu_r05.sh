@@ -35,6 +35,9 @@ case $step in
              run_pmc sweepctr2 "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" $HEAD
              grep -h "price_sweep\|^kernel" "$OUT"/sweepctr*.summary.csv ;;
   stage)     HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p wave --no-host --repeat 2 2>&1 | grep -E "price profile|price \{" | tee "$OUT/price_sweep_stage_profile.txt" ;;
+  heterotrace) # the kernels of the heterogeneous steady-state loop (136 worker classes per tick through k_block_solve)
+             run_trace bench_hetero python $ROOT/bench.py --steps 2 --warmup 1 --hetero-steps 25 --dag-steps 0 --priority-ticks 0 --cpu-ticks 0 --steady-steps 0 --wire-iters 0
+             cat "$OUT/bench_hetero.summary.csv" ;;
   hosttrace) # the host side of the coupled tick, stage by stage, on this box's cores (HQMILP_TRACE marks; the last of three ticks)
              HQMILP_TRACE=1 timeout 300 python tools/price_probe.py c3p --no-host --repeat 3 2>&1 | grep -E "^\[(price|milp|model)\]" > "$OUT/host_trace_c3p.txt"; tail -24 "$OUT/host_trace_c3p.txt" ;;
   coupled)   timeout 600 python tools/price_probe.py c3p wave 0.2 0.45 --no-host --timeline --repeat 1 2>&1 | grep -E "timeline|price " | tee "$OUT/coupled_ticks.txt" ;;
