@@ -540,30 +540,41 @@ struct Solver {
             const int KG = P.KG;
             std::vector<double> wg(KG, 0.0), cumg(KG, 0.0), tgtg(KG, 0.0), candg((size_t)Q * KG);
             for (int r = 0; r < K; r++) wg[P.grp_of[r]] += wgt[r];
-            std::vector<char> on(Q);
+            std::vector<char> on(Q); std::vector<const double *> cgp(Q, nullptr);
             for (uint32_t bi = 0; bi < T.n_blocks; bi++) {
                 const uint32_t b = variant == 1 ? T.n_blocks - 1 - bi : bi;
                 const uint32_t part = b / per;
+                // (three blocks in four carry the SAME pattern in every cut of their part: its activities are worked out once, the targets take the same additions in
+                // the same order, and with nothing to choose between the first cut's pattern is the choice — as the comparison below would make it)
+                int first = -1; bool all_same = true;
+                const size_t blk_bytes = (size_t)(T.blk_off[b + 1] - T.blk_off[b]) * 2;
                 for (int q = 0; q < Q; q++) {
                     const double l = lam(active[q], part);
                     on[q] = l > 1e-9;   // (only the cuts the part's LP point is made of: their patterns are optimal at the final prices)
                     if (!on[q]) continue;
-                    double *cg = &candg[(size_t)q * KG];
-                    for (int g = 0; g < KG; g++) cg[g] = 0.0;
                     const uint16_t *px = pat_of(active[q]);
-                    for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { const uint16_t xv = px[f]; if (!xv) continue; for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) cg[T.w_row[e]] += (double)T.w_coef[e] * (double)xv; }
+                    if (first >= 0 && memcmp(px + T.blk_off[b], pat_of(active[first]) + T.blk_off[b], blk_bytes) == 0) cgp[q] = cgp[first];
+                    else {
+                        if (first < 0) first = q; else all_same = false;
+                        double *cg = &candg[(size_t)q * KG];
+                        for (int g = 0; g < KG; g++) cg[g] = 0.0;
+                        for (uint32_t f = T.blk_off[b]; f < T.blk_off[b + 1]; f++) { const uint16_t xv = px[f]; if (!xv) continue; for (uint32_t e = T.col_woff[f]; e < T.col_woff[f + 1]; e++) cg[T.w_row[e]] += (double)T.w_coef[e] * (double)xv; }
+                        cgp[q] = cg;
+                    }
+                    const double *cg = cgp[q];
                     for (int g = 0; g < KG; g++) tgtg[g] += l * cg[g];
                 }
                 int bq = -1; double be = INF;
-                for (int q = 0; q < Q; q++) {
+                if (all_same) bq = first;
+                else for (int q = 0; q < Q; q++) {
                     if (!on[q]) continue;
-                    const double *cg = &candg[(size_t)q * KG];
+                    const double *cg = cgp[q];
                     double e = 0.0;
                     for (int g = 0; g < KG; g++) e += std::fabs(cumg[g] + cg[g] - tgtg[g]) * wg[g];
                     if (e < be - 1e-15) { be = e; bq = q; }
                 }
                 if (bq < 0) return {};
-                const double *cb = &candg[(size_t)bq * KG];
+                const double *cb = cgp[bq];
                 for (int g = 0; g < KG; g++) cumg[g] += cb[g];
                 chosen[b] = active[bq];
                 memcpy(&x[T.blk_off[b]], pat_of(active[bq]) + T.blk_off[b], (size_t)(T.blk_off[b + 1] - T.blk_off[b]) * 2);
