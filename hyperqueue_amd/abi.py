@@ -11,8 +11,8 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-HQTICK_ABI_VERSION = 9
-HQTICK_FLAG_NO_KERNEL_TIMING, HQTICK_FLAG_COMPACT_RECORDS, HQTICK_FLAG_COMPACT_DELTA16, HQTICK_FLAG_NO_BLOCK_MEMO, HQTICK_FLAG_CONSUME_IN_TICK, HQTICK_FLAG_CERTIFICATE_ONLY = 1, 2, 4, 8, 16, 32
+HQTICK_ABI_VERSION = 10
+HQTICK_FLAG_NO_KERNEL_TIMING, HQTICK_FLAG_COMPACT_RECORDS, HQTICK_FLAG_COMPACT_DELTA16, HQTICK_FLAG_NO_BLOCK_MEMO, HQTICK_FLAG_CONSUME_IN_TICK, HQTICK_FLAG_CERTIFICATE_ONLY, HQTICK_FLAG_NO_TICK_CACHES = 1, 2, 4, 8, 16, 32, 64
 HQ_AMOUNT_MAX = 0xFFFF_FFFF_FFFF_FFFF
 HQ_FRACTIONS_PER_UNIT = 10_000
 HQ_MAX_TASK_PER_WORKER = 1024

@@ -16,17 +16,20 @@ namespace {
 
 // Iteration order of a Map<WorkerId,_> built from `ids` (hb_order.h), memoised on the id list: every (request, variant) key
 // of one tick — and usually consecutive ticks — inserts the same workers.
+// 32 entries, found by a hash of the list: a busy C4 cluster has up to 16 distinct lists per tick (one per (request, variant) key), and with the four entries this
+// memo started with every tick recomputed all of them — 250 of the tick's 1 370 us.  Lives across ticks (flush_tick_caches() empties it: HQTICK_FLAG_NO_TICK_CACHES).
+struct OrderEntry { uint64_t hash = 0; bool used = false; std::vector<uint32_t> ids, order; };
+thread_local OrderEntry order_cache[32];
+thread_local unsigned order_next = 0;
 const std::vector<uint32_t> &cached_worker_order(const std::vector<uint32_t> &ids) {
-    // 32 entries, found by a hash of the list: a busy C4 cluster has up to 16 distinct lists per tick (one per (request, variant) key), and with the four entries this
-    // memo started with every tick recomputed all of them — 250 of the tick's 1 370 us.
-    struct Entry { uint64_t hash = 0; std::vector<uint32_t> ids, order; };
-    static thread_local Entry cache[32];
-    static thread_local unsigned next = 0;
+    typedef OrderEntry Entry;
+    Entry (&cache)[32] = order_cache;
+    unsigned &next = order_next;
     uint64_t h = 0x9E3779B97F4A7C15ull ^ ids.size();
     for (uint32_t v : ids) { h ^= v; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
-    for (Entry &e : cache) if (e.hash == h && e.ids.size() == ids.size() && (ids.empty() || memcmp(e.ids.data(), ids.data(), ids.size() * 4) == 0)) return e.order;
+    for (Entry &e : cache) if (e.used && e.hash == h && e.ids.size() == ids.size() && (ids.empty() || memcmp(e.ids.data(), ids.data(), ids.size() * 4) == 0)) return e.order;
     Entry &e = cache[next++ & 31];
-    e.hash = h; e.ids = ids;
+    e.hash = h; e.ids = ids; e.used = true;
     hqhb::insertion_order_u32(ids.data(), (uint32_t)ids.size(), e.order);
     return e.order;
 }
@@ -56,6 +59,8 @@ void prune_cuts(std::vector<PriorityCut> &cuts, size_t prefix, size_t limit) {
 }
 
 }  // namespace
+
+void flush_tick_caches() { for (OrderEntry &e : order_cache) e.used = false; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // workers with identical rows (host_model.h, WorkerGroups)

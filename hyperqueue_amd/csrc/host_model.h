@@ -96,6 +96,9 @@ struct BlockSolver {
     bool begun_ok = false;
 };
 
+// Forget what earlier ticks left behind on this thread (the memoised Map iteration orders): HQTICK_FLAG_NO_TICK_CACHES.
+void flush_tick_caches();
+
 // The last class blocks the host solver answered with a certified canonical optimum, keyed by the block's whole model: an identical block of a later tick is
 // answered from here (hqtick.h: HQTICK_FLAG_NO_BLOCK_MEMO).  Small on purpose — a steady cluster has a handful of host-solved classes; the device solves the many.
 struct BlockMemo {

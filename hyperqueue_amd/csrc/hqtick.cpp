@@ -1161,6 +1161,7 @@ struct TickRun {
     int run() {
         t0 = now_us();
         ctx->ntl = 0;
+        if (ctx->cfg.flags & HQTICK_FLAG_NO_TICK_CACHES) { ctx->levels_valid = false; hqhost::flush_tick_caches(); }  // nothing derived survives from the last tick
         memset(out, 0, sizeof(*out));
         ctx->stats = hqtick_kernel_stats{};
         int rc = validate(ctx, s, !use_resident);
@@ -1168,7 +1169,12 @@ struct TickRun {
         HQ_HIP(hipSetDevice(ctx->device));
         if ((rc = load_ready_set())) return rc;
         // ---------------- GPU phase A ----------------
-        const std::function<void()> prep = [&]() { fill_problem(pb, s, ctx->cfg, ev); };  // request/worker views: no GPU output needed yet
+        const std::function<void()> prep = [&]() {   // request/worker views: no GPU output needed yet
+            fill_problem(pb, s, ctx->cfg, ev);
+            // HQTICK_FLAG_CERTIFICATE_ONLY is for ONE scheduler: replicas (a shard of several, a record sink that is merged with others', an exchange) must return the
+            // canonical point — what the merge compares byte for byte — so the flag is ignored there (include/hqtick.h).
+            if (pb.certificate_only && (ctx->shard_count > 1 || ctx->sink || ctx->xfn || ctx->comm)) pb.certificate_only = false;
+        };
         if ((rc = phase_a(ctx, s, &ev, &sc, &prep))) return rc;
         mark();  // 0: phase A done
         const double t1 = now_us();
@@ -1181,7 +1187,7 @@ struct TickRun {
         DeviceBlocks dev_blocks(ctx);
         pb.blocks = &dev_blocks; pb.block_min_classes = ctx->block_min_classes; pb.pricer = ctx->pricer;
         pb.block_verify = ctx->block_verify; pb.tick_seq = ctx->tick_seq++;
-        pb.memo = (ctx->cfg.flags & HQTICK_FLAG_NO_BLOCK_MEMO) ? nullptr : &ctx->block_memo;
+        pb.memo = (ctx->cfg.flags & (HQTICK_FLAG_NO_BLOCK_MEMO | HQTICK_FLAG_NO_TICK_CACHES)) ? nullptr : &ctx->block_memo;
         double shard_sweep_us = -1.0;
         ctx->x_calls = 0; ctx->x_bytes = 0; ctx->x_us = 0;
         if (CtxExchange::available(ctx)) {  // the ranks of a sharded scheduler split the sweeps and the class blocks (no-ops below their thresholds)
@@ -1715,7 +1721,9 @@ int hqtick_graph_blevel(hqtick_ctx *ctx, uint32_t flags, uint32_t *max_level, ui
     int r = ctx->graph.blevel(max_level, upd ? ctx->d_tid.as<uint64_t>() : nullptr, upd ? ctx->d_trq.as<uint32_t>() : nullptr, upd ? ctx->d_tprio.as<uint64_t>() : nullptr, upd ? ctx->n_ready : 0,
                               n_ready_updated, ctx->stream);
     if (r < 0) return graph_fail(ctx, r);
-    if (upd) { ctx->levels_valid = false; ctx->last_valid = false; }  // the ready set's priorities changed: the next tick rediscovers its levels
+    // the ready set's priorities changed: the next tick rediscovers its levels.  A pending hqtick_ready_consume_last is left alone — its replay reads the group keys, the
+    // per-slice counters and the plan of the last tick, none of which the priority rewrite touches.
+    if (upd) ctx->levels_valid = false;
     return r;
 }
 
@@ -2293,7 +2301,7 @@ const uint64_t *hqtick_block_profile_last(const hqtick_ctx *ctx, uint32_t *n_cla
 
 int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on) {
     if (!ctx) return HQTICK_E_INVALID;
-    ctx->timing = on == 1; ctx->timing_k1 = on == 2;
+    ctx->timing = on != 0 && on != 2; ctx->timing_k1 = on == 2;  // (any non-zero value but 2 = every measured kernel, as before ABI 9)
     return 0;
 }
 

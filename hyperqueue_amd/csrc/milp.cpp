@@ -1245,19 +1245,24 @@ bool solve_fast(const Model &mdl_in, double time_limit_s, double rel_gap, hqpric
                 if (mdl_in.rtype[i] != ROW_MIN && a > mdl_in.rhs[i] + tol) ok = false;
                 if (mdl_in.rtype[i] != ROW_MAX && a < mdl_in.rhs[i] - tol) ok = false;
             }
+            double z_pt = 0.0;
+            if (ok) {   // the certificate once more, on the objective of the ROUNDED point in the model's own costs — not on the value the sweeps reported
+                for (int j = 0; j < n; j++) z_pt += mdl_in.obj[j] * std::floor(pa.x[(size_t)j] + 0.5);
+                const double zs = cost_scale > 0.0 ? z_pt / cost_scale : z_pt;
+                if (!(pa.bound * (1.0 + 1e-9) + 1e-12 <= zs + rel_gap * std::fabs(zs))) ok = false;
+            }
             if (ok) {
                 Result res;
                 res.x = std::move(pa.x);
                 for (double &v : res.x) v = std::floor(v + 0.5);   // (non-negative integers up to rounding noise: checked above)
                 res.feasible = true; res.optimal = true; res.canonical = false;   // certified within rel_gap; which of the tied optima it is stays the sweeps' choice
                 res.n_components = 1; res.nodes = pa.sweeps; res.price_sweeps = (int)pa.sweeps; res.price_rounds = (int)pa.rounds; res.price_total_us = (wall() - tf0) * 1e6;
-                double z = 0.0; for (int j = 0; j < n; j++) z += mdl_in.obj[j] * res.x[(size_t)j];
-                res.objective = z;
+                res.objective = z_pt;
                 tmark("fast path certified");
                 res_out = std::move(res);
                 return true;
             }
-            if (tracing_solve) fprintf(stderr, "[milp] fast path: the certified point fails a row of the model: classic path\n");
+            if (tracing_solve) fprintf(stderr, "[milp] fast path: the certified point fails a row of the model (or its own objective misses the certificate): classic path\n");
         }
     }
     return false;

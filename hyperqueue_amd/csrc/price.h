@@ -149,7 +149,7 @@ struct ShardedSweeper : Sweeper {
     bool sweep(const double *pi, SweepTotals &out) override;
     const uint16_t *patterns(uint32_t first, uint32_t count) override;
     void end() override { inner.end(); T = nullptr; }
-    bool merges_clock() const override { return !pass; }
+    bool merges_clock() const override { return ex.world > 1; }   // (also when every rank sweeps the whole of a small model: one word per rank and sweep)
 };
 
 }  // namespace hqprice

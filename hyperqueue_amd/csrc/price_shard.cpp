@@ -77,7 +77,21 @@ bool ShardedSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
 // blob of one rank and sweep: [u64 clock flag][cx mb][rc mb][bnd mb] doubles, [part_act mp * K] i64, [steps mb] u32
 bool ShardedSweeper::sweep(const double *pi, SweepTotals &out) {
     if (!T) return false;
-    if (pass) { n_sweeps++; return inner.sweep(pi, out); }
+    if (pass) {
+        n_sweeps++;
+        const bool ok = inner.sweep(pi, out);
+        if (ex.world <= 1) return ok;
+        // Replicas that sweep the whole (small) model each: the clock readings are still merged — one word per rank — so that all of them leave the sweeps at the
+        // same sweep (a local reading here or in the master could split the replicas near the time guard).  A failed sweep takes part, like below.
+        const uint64_t mine = (now_s() > guard_s ? 1u : 0u) | (ok ? 0u : 2u);
+        std::vector<uint64_t> all(ex.world, 0);
+        const double t0 = now_s();
+        if (!ex.allgather(&mine, all.data(), 8)) return false;
+        ex.us += (now_s() - t0) * 1e6; ex.n_calls++; ex.n_bytes += 8 * (size_t)ex.world;
+        bool someone_failed = false;
+        for (uint64_t v : all) { if (v & 1u) time_up = true; if (v & 2u) someone_failed = true; }
+        return !someone_failed;
+    }
     const HostTables &t = *T;
     const uint32_t me = ex.rank, W = ex.world, mb = max_blocks, mp = max_parts, K = t.K;
     RangeValues rv;

@@ -40,7 +40,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define HQTICK_ABI_VERSION 9u  /* 9: hqtick_graph_blevel / _priorities (extension), hqtick_set_kernel_timing(ctx, 2), a failed CONSUME_IN_TICK tick restores its tasks; 8: HQ_WORKERS_RESIDENT, hqtick_cluster_last_reassigned; 7: hqtick_kernel_stats carries the price-sweep figures of coupled ticks; cluster membership deltas */
+#define HQTICK_ABI_VERSION 10u  /* 10: HQTICK_FLAG_NO_TICK_CACHES, hqtick_set_kernel_timing takes any non-zero value but 2 as 1, hqtick_graph_blevel leaves a pending hqtick_ready_consume_last alone; 9: hqtick_graph_blevel / _priorities (extension), hqtick_set_kernel_timing(ctx, 2), a failed CONSUME_IN_TICK tick restores its tasks; 8: HQ_WORKERS_RESIDENT, hqtick_cluster_last_reassigned; 7: hqtick_kernel_stats carries the price-sweep figures of coupled ticks; cluster membership deltas */
 
 /* ResourceAmount::MAX                                    common/resources/amount.rs:31 */
 #define HQ_AMOUNT_MAX UINT64_MAX
@@ -114,8 +114,16 @@ enum { HQ_REC_PREFILL = 0, HQ_REC_ASSIGN = 1 };
  * byte for byte).  That proof is most of a small coupled tick (an 80-column model of a few dozen ready tasks: certified after 0.1 ms, canonical after 0.8 ms; a
  * 128-column one: 0.3 ms against 26 ms).  With the flag the tick returns the certified point: is_optimal = 1, is_canonical = 0, the objective within 1e-4 of the
  * optimum exactly as the reference's — for a single scheduler whose ticks must be short.  (Ticks the class blocks or the price sweeps settle are not affected:
- * separable placements stay exact and canonical, swept ones were certificates already.) */
+ * separable placements stay exact and canonical, swept ones were certificates already.)  IGNORED (ABI 10) on a context that is one of several replicas — after
+ * hqtick_set_shard with more than one shard, with a record sink, an exchange callback or a communicator set — whose answers are compared and merged byte for byte. */
 #define HQTICK_FLAG_CERTIFICATE_ONLY 32u
+/* hqtick_config.flags (ABI 10): nothing DERIVED survives from one tick to the next.  By default a context keeps, next to the resident inputs (ready set, cluster
+ * tables), three things it worked out in earlier ticks: the table of host-solved class blocks (NO_BLOCK_MEMO above), the priority-level table of the resident ready
+ * set (re-validated by the scan kernel of every tick, rebuilt when a new priority shows up) and the hashbrown iteration orders of the worker-id lists it has seen
+ * (Map<WorkerId, _> of scheduler/mapping.rs:36-43, memoised on the whole id list).  All three are pure functions of the tick's inputs, so the results do not change;
+ * with this flag every tick works them out again.  For measurements: a loop that repeats one identical tick would otherwise hit all three on every iteration
+ * (bench.py's headline sets the flag and says so in its line).  Implies HQTICK_FLAG_NO_BLOCK_MEMO. */
+#define HQTICK_FLAG_NO_TICK_CACHES 64u
 
 /* redirect_kind of a result entry (scheduler/mapping.rs:66-101):
  *   FROM_PREFILL  the task sat in a prefill set: Prefilled{old} -> Retracting{old}, retract sent to `old`, redirects.insert(task, (worker, v))
@@ -498,7 +506,8 @@ int hqtick_graph_get_stats(const hqtick_ctx *ctx, hqtick_graph_stats *out);
  * task's priority (what Priority::add_priority_u32 would add to a priority whose low bits are zero), so that tasks released by later hqtick_graph_finish calls
  * carry it into the ready set.  HQTICK_BLEVEL_UPDATE_READY: the tasks already in the resident ready set get their graph priorities too (one pass over the ready
  * columns, ids -> graph slots through the hash table; *n_ready_updated = how many).  Returns the number of sweeps (>= 0) or a negative error; *max_level = the
- * largest b-level (the depth of the graph).  A host that wants the reference's behaviour never calls it; no parity test does.
+ * largest b-level (the depth of the graph).  A host that wants the reference's behaviour never calls it; no parity test does.  It may be called between
+ * hqtick_run_resident and hqtick_ready_consume_last: the pending consume is not disturbed (it replays the last tick's selection, which does not read priorities).
  * hqtick_graph_priorities: the priorities the graph holds for the given ids (0 for an id it does not hold): test accessor. */
 #define HQTICK_BLEVEL_UPDATE_READY 1u
 int hqtick_graph_blevel(hqtick_ctx *ctx, uint32_t flags, uint32_t *max_level, uint32_t *n_ready_updated);
@@ -618,7 +627,7 @@ int hqtick_kernel_stats_last(const hqtick_ctx *ctx, hqtick_kernel_stats *out);
  * bracketed by start / stop events AT THE DISPATCH (hipExtLaunchKernel): the duration is the kernel's own, the figure rocprofv3's kernel trace
  * reports, without the latency of markers queued around it.  on = 2: the events go around K1 alone (k_level_hist, the launch that streams the ready
  * set: the kernel the roofline figure is quoted on) — what bench.py's timed region runs with, so that every K1 launch of the run is measured the same
- * way and the live figure and a rocprofv3 kernel trace of the same command describe the same launches. */
+ * way and the live figure and a rocprofv3 kernel trace of the same command describe the same launches.  0 = off; any other value = every measured kernel. */
 int hqtick_set_kernel_timing(hqtick_ctx *ctx, int on);
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -313,3 +313,26 @@ def test_a_tick_ranks_by_the_b_levels_once_they_are_in_the_ready_set(T):
     want = Oracle(abi.make_config(time_limit_s=20.0), canonical=True).tick(drv.snapshot(rid, [g.ready[i][0] for i in rid], [g.ready[i][1] for i in rid]))
     got = T.tick(drv.snapshot(), resident=True)
     assert got.batches == want.batches and got.counts == want.counts and got.records == want.records
+
+
+def test_blevel_between_a_tick_and_its_consume_leaves_the_consume_alone(T):
+    """a host on the two-call protocol may call hqtick_graph_blevel(UPDATE_READY) between hqtick_run_resident and hqtick_ready_consume_last — the pending
+    consume replays the tick's selection (group keys, per-slice counters, plan), which the priority rewrite does not touch: what the tick handed out leaves the set."""
+    n, W = 4_000, 4
+    ids, prio, rq, off, dep = workloads.make_dag(n, seed=9)
+    rq = (rq % np.uint32(3)).astype(np.uint32)
+    ready = T.graph_add_tasks(ids, prio, rq, (off, dep))
+    drv = workloads.DagChurn(n_workers=W, churn=0.0, seed=1)
+    before = T.ready_count()
+    assert before == len(ready)
+    snap = drv.snapshot()   # (kept alive: the C view points into its arrays)
+    res = T.tick_raw(snap.to_c(), resident=True)
+    handed = abi.record_task_ids(res, W).copy()
+    assert len(handed)
+    info = T.graph_blevel(update_ready=True)
+    assert info["ready_updated"] == before
+    T.ready_consume_last()   # used to fail with E_INVALID ('needs a preceding hqtick_run_resident'): the tasks stayed live and the next tick handed them out again
+    assert T.ready_count() == before - len(handed)
+    res2 = T.tick_raw(snap.to_c(), resident=True)
+    again = set(abi.record_task_ids(res2, W).tolist()) & set(handed.tolist())
+    assert not again

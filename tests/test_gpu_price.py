@@ -303,3 +303,27 @@ def test_certificate_only_small_ticks_on_the_gpu(n_ready):
     assert got.batches == want.batches and got.counts == want.counts and got.records == want.records
     assert got.retracts == want.retracts and got.redirects == want.redirects
     assert (got.new_free == want.new_free).all()
+
+
+def test_no_tick_caches_changes_nothing_but_the_work():
+    """HQTICK_FLAG_NO_TICK_CACHES (ABI 10; bench.py's headline context): the level table of the resident ready set is rediscovered and the Map iteration orders are
+    recomputed on EVERY tick — the three caches are pure functions of the inputs, so a repeated tick returns the same answer with and without the flag, and the flagged
+    context really does the discovery again (its kernel is timed on the second tick too)."""
+    snap = workloads.make("c3p", n_tasks=400_000, n_workers=256)
+    outs = {}
+    for name, flags in (("default", 0), ("cold", abi.HQTICK_FLAG_NO_TICK_CACHES)):
+        t = Tick(abi.make_config(time_limit_s=5.0, flags=flags))
+        try:
+            t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
+            t.cluster_upload(snap.to_c())
+            first = t.tick(snap, resident=True)
+            second = t.tick(snap, resident=True)
+            outs[name] = (first, second, t.kernel_stats())
+        finally:
+            t.close()
+    for name, (first, second, ks) in outs.items():
+        assert first.status == second.status == abi.HQTICK_DONE and second.is_optimal, name
+        assert first.batches == second.batches and first.counts == second.counts and first.records == second.records, name
+    a, b = outs["default"], outs["cold"]
+    assert a[1].batches == b[1].batches and a[1].counts == b[1].counts and a[1].records == b[1].records
+    assert a[2]["distinct_us"] == 0 and b[2]["distinct_us"] > 0   # second tick: the default context trusted its level table, the flagged one rebuilt it

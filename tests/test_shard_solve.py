@@ -147,11 +147,13 @@ def test_sharded_class_blocks_equal_the_unsharded_launch(name, n_workers, seed, 
         assert sw == 0 and calls == 1
 
 
-def test_below_the_thresholds_every_rank_solves_the_whole_model_without_an_exchange():
+def test_below_the_thresholds_every_rank_sweeps_the_whole_model_and_only_the_clock_is_exchanged():
+    """a small model: every rank sweeps all of it; what still crosses is ONE word per rank and sweep — the clock reading (and a 'failed' bit), so that replicas near
+    the time guard leave the sweeps at the same sweep"""
     snap = COUPLED["c3p-64"]()
     plain, sweeps, rounds, _ = _stages(snap, 20.0, 16, False)
     for (got, sw, rd, calls) in run_ranks(snap, 2, blocks=False, min_blocks=1025):
-        assert (sw, rd, calls) == (sweeps, rounds, 0)
+        assert (sw, rd, calls) == (sweeps, rounds, sweeps)
         _same(got, plain)
 
 
