@@ -912,7 +912,7 @@ def main():
         run_wd.cancel()
     # ---- the same loop with the product's default caches live (level table + Map-order memo): rides along in the line, is NOT `value` ----
     p50_warm = None
-    if world == 1 and not args.force_sharded and not args.warm_caches:
+    if world == 1 and not args.force_sharded and not args.warm_caches and not args.headline_only:   # (--headline-only is what the rocprofv3 passes run: the timed loop's launches alone)
         try:
             tw = Tick(warm_cfg)
             tw.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
@@ -1106,6 +1106,27 @@ def main():
                                           "note": "4096 blocks of 16 columns per sweep; parity: tests/test_gpu_price.py::test_config4_unsaturated_full_tick_on_the_gpu"}
         except Exception as e:
             out["config4_unsaturated"] = {"error": repr(e)}
+        # ... and BASELINE configs[3] AS WRITTEN ("C4 as C3 but 4096 workers ... 2-variant OR-list"): c4p = 1 M tasks at three priority levels x 4096 workers —
+        # the largest model the contract names (65 536 placement columns + cut / blocker rows over 4096 blocks); parity: tests/test_gpu_price.py::test_c4p_full_tick_on_the_gpu
+        try:
+            s4p = workloads.make("c4p", seed=args.seed)
+            t4p = Tick(cfg)
+            t4p.upload_ready(s4p.task_id, s4p.task_priority, s4p.task_rq, sorted_=True)
+            sc4p = s4p.to_c()
+            t4p.cluster_upload(sc4p)
+            tl4p, inf4p = [], None
+            for _ in range(max(3, args.priority_ticks) + 1):
+                t0 = time.perf_counter(); r4p = t4p.tick_raw(sc4p, resident=True); tl4p.append(time.perf_counter() - t0)
+                inf4p = (int(r4p.status), int(r4p.is_optimal), t4p.kernel_stats())
+            t4p.close()
+            out["config4_three_levels"] = {"workload": "c4p: 1 M ready tasks at three priority levels (80/15/5 %) x 4096 workers, every class a 2-variant OR-list (BASELINE configs[3] as BASELINE.md 3 writes it), cold tick, no cross-tick caches",
+                                           "p50_tick_ms": 1e3 * float(np.median(tl4p[1:])), "status": inf4p[0], "is_optimal": bool(inf4p[1]), "assigned_per_tick": int(inf4p[2]["n_assigned"]),
+                                           "prefilled_per_tick": int(inf4p[2]["n_prefilled"]), "model_columns": int(inf4p[2]["milp_cols"]), "model_rows": int(inf4p[2]["milp_rows"]),
+                                           "price_sweeps": int(inf4p[2]["price_sweeps"]), "sweeps_ms": inf4p[2]["price_sweep_us"] / 1e3, "coupled_solve_ms": inf4p[2]["milp_us"] / 1e3,
+                                           "build_model_ms": inf4p[2]["model_us"] / 1e3, "tasks_assigned_per_sec": int(inf4p[2]["n_assigned"]) / float(np.median(tl4p[1:]))}
+        except Exception as e:
+            out["config4_three_levels"] = {"error": repr(e)}
+        write_extras(args.extras_file, out)
     if cpu is not None and "error" not in cpu:
         # ratios against a baseline that STOPPED at the reference's 5 s time limit with an uncertified incumbent measure that limit, not equivalent work:
         # reported as lower bounds, next to the objective both sides reached on the same snapshot

@@ -6,7 +6,8 @@ C++/Rust harness can regenerate the same inputs.
   c3  1 000 000 tasks over 8 request classes on {cpus, gpus/amd, mem} incl. 0.5 / 0.25 GPU fractions, 1024 workers
       (128 c / 8 g / 512 m), one priority level, every class saturated  -> the placement model is separable per worker
   c3p c3 with three user-priority levels (80/15/5 %): couples all workers through priority cuts (reported, not benched)
-  c4  c3 classes as 2-variant OR-lists, 4096 workers                (sharded case)
+  c4  c3 classes as 2-variant OR-lists, 4096 workers                (sharded case; one priority level)
+  c4p c4 with c3p's three priority levels: configs[3] as BASELINE.md §3 writes it ("as C3") — 65 536 placement columns plus cut / blocker rows over 4096 blocks
   c5  make_dag(): 1 000 000-node random DAG over the c3 classes, fan-in ~ Poisson(3) from lower ids (dependency-graph case)
   c3s / c4s  make_steady(): c3 / c4 in the STEADY STATE of SURVEY.md §8(d) — every worker is running a packed mix of tasks of which a random
       10 % have just finished, so the free vectors differ from worker to worker (about one worker class per worker) while the ready set is
@@ -93,9 +94,10 @@ def make(name: str, seed: int = 0, n_tasks: Optional[int] = None, n_workers: Opt
         pr = [(0, 0.80), (1, 0.15), (2, 0.05)] if name == "c3p" else None
         ids, prio, rq = _tasks(n_tasks or 1_000_000, [c[1] for c in C3_CLASSES], seed, pr)
         return abi.Snapshot(requests=[[_variant(c[0])] for c in C3_CLASSES], task_id=ids, task_priority=prio, task_rq=rq, **w)
-    if name == "c4":
+    if name in ("c4", "c4p"):   # c4p: BASELINE configs[3] as BASELINE.md §3 / SURVEY §8(d) write it — "as C3" (three priority levels at 80/15/5 %) with 2-variant OR-lists
         w = _uniform_workers(n_workers or 4096, 1, [128, 8, 512])
-        ids, prio, rq = _tasks(n_tasks or 1_000_000, [c[1] for c in C3_CLASSES], seed)
+        pr = [(0, 0.80), (1, 0.15), (2, 0.05)] if name == "c4p" else None
+        ids, prio, rq = _tasks(n_tasks or 1_000_000, [c[1] for c in C3_CLASSES], seed, pr)
         reqs = [[_variant(c[0]), _variant(alt)] for c, alt in zip(C3_CLASSES, C4_ALTERNATIVES)]
         return abi.Snapshot(requests=reqs, task_id=ids, task_priority=prio, task_rq=rq, **w)
     raise ValueError(f"unknown workload {name}")

@@ -25,6 +25,7 @@ from hyperqueue_amd import abi, workloads  # noqa: E402
 
 COUPLED = {
     "c3p_full": dict(kind="c3p"),                  # BASELINE.md C3 with three priority levels: 1 M tasks x 1024 workers
+    "c4p_full": dict(kind="c4p"),                  # BASELINE configs[3] as BASELINE.md §3 writes it ("as C3": three priority levels): 1 M tasks x 4096 workers, 2-variant OR-lists — 65 552 columns x 12 422 rows
     "c5_first_wave": dict(kind="wave"),            # BASELINE config 5, first tick: the 49 642 sources of the 1 M-node DAG on the idle cluster
     "unsaturated_1024_20": dict(kind="unsat", fill=0.2),
     "c3p_steady_256": dict(kind="steady", n_workers=256, n_tasks=400_000, seed=7),
@@ -34,6 +35,8 @@ COUPLED = {
 def coupled_snapshot(gen: dict):
     if gen["kind"] == "c3p":
         return workloads.make("c3p", n_tasks=1_000_000, n_workers=1024), abi.make_config(time_limit_s=20.0)
+    if gen["kind"] == "c4p":
+        return workloads.make("c4p", n_tasks=1_000_000, n_workers=4096), abi.make_config(time_limit_s=60.0)
     if gen["kind"] == "steady":
         return workloads.make_steady("c3p", seed=gen["seed"], n_workers=gen["n_workers"], n_tasks=gen["n_tasks"]), abi.make_config(time_limit_s=20.0)
     ids, prio, rq, off, dep = workloads.make_dag(1_000_000, seed=0)

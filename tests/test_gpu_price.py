@@ -138,6 +138,17 @@ def test_c3p_full_tick_on_the_gpu():
     _full_tick_checks(snap, lambda m: sum(3.0 * (W - w) / W / W for w in range(W)))
 
 
+def test_c4p_full_tick_on_the_gpu():
+    """BASELINE configs[3] as BASELINE.md §3 / SURVEY §8(d) write it ("C4 as C3 but 4096 workers ... 2-variant OR-list"): 1 M tasks at three priority levels
+    (80/15/5 %) x 4096 workers — 65 536 placement columns + 16 flags, 12 422 rows: cut / blocker rows over 4096 blocks (scheduler/solver.rs:233-253,274-429).
+    DONE + is_optimal, objective within 1e-4 of the bound that needs no solver, every row of the oracle's model, T3 given counts."""
+    W = 4096
+    snap = workloads.make("c4p", n_tasks=1_000_000, n_workers=W)
+    assert len(np.unique(snap.task_priority)) == 3
+    got, ks, z, bound = _full_tick_checks(snap, lambda m: sum(3.0 * (W - w) / W / W for w in range(W)))
+    assert ks["milp_cols"] == 65552 and ks["milp_rows"] == 12422
+
+
 def _lp_bound(model):
     """LP relaxation of the oracle's model (HiGHS simplex: seconds at 8 192 columns) — an upper bound of the MILP optimum"""
     from scipy.optimize import linprog

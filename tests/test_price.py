@@ -82,6 +82,28 @@ def test_c3p_at_baseline_size_by_price_sweeps():
     assert bound * (1.0 - 1e-4) <= zg <= bound * (1.0 + 1e-9), (zg, bound)
 
 
+def test_c4p_at_baseline_size_by_price_sweeps():
+    """BASELINE configs[3] as BASELINE.md §3 / SURVEY §8(d) write it — "as C3" with 4096 workers and every class a 2-variant OR-list: three priority levels at
+    80/15/5 % over 1 M tasks.  The largest model the contract names: 65 536 placement columns + 16 flags, 12 422 rows (cut / blocker rows over 4096 blocks,
+    scheduler/solver.rs:233-253,274-429).  Certified against the bound that needs no solver (every worker packed completely); every row of the oracle's model holds."""
+    from limits import model_point, rows_hold
+    from oracle.oracle import Oracle
+
+    W = 4096
+    snap = workloads.make("c4p", n_tasks=1_000_000, n_workers=W)
+    got, sweeps, rounds = stages(snap, True, tl=60.0)
+    assert sweeps > 0 and got.status == abi.HQTICK_DONE and got.is_optimal
+    o = Oracle(abi.make_config(time_limit_s=0.5), reference_solver_options=True)
+    o.tick(snap)  # (for the model only: HiGHS does not finish it)
+    model = o.last_model()
+    assert len(model["obj"]) == 65552 and len(np.unique(snap.task_priority)) == 3
+    x = model_point(model, got.counts)
+    assert rows_hold(model, x)
+    zg = _objective(model, got)
+    bound = sum(3.0 * (W - w) / W / W for w in range(W))
+    assert bound * (1.0 - 1e-4) <= zg <= bound * (1.0 + 1e-9), (zg, bound)
+
+
 @pytest.mark.parametrize("W,fill", [(128, 0.45), (256, 0.20), (256, 0.45), (512, 0.20), (1024, 0.20), (1024, 0.45)])
 def test_unsaturated_cluster_by_price_sweeps(dag_sources, W, fill):
     """fewer ready tasks than the cluster holds: batch-size rows across all workers (every DAG tick)"""

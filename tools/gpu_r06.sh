@@ -1,12 +1,12 @@
 #!/usr/bin/env bash
-# GPU-side steps of round 5, one script:   gpurun --timeout N -- 'bash tools/gpu_r05.sh <step> [...]'
-# Everything lands under gpurun_out/r05/; the summaries worth keeping are copied into profiles/r05/ afterwards (profiles/r05/README.md says which call made which file).
+# GPU-side steps of round 6, one script:   gpurun --timeout N -- 'bash tools/gpu_r06.sh <step> [...]'
+# Everything lands under gpurun_out/r06/; the summaries worth keeping are copied into profiles/r06/ afterwards (profiles/r06/README.md says which call made which file).
 set -u
 export TMPDIR=/tmp
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/r05
+OUT=$ROOT/gpurun_out/r06
 mkdir -p "$OUT"
-HEAD="python $ROOT/bench.py --steps 50 --warmup 5 --headline-only"
+HEAD="python $ROOT/bench.py --steps 50 --warmup 5 --headline-only --extras-file $OUT/bench_headline_extras.json"
 run_trace() {  # name, command...
   local name=$1; shift
   ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- "$@" > "$OUT/$name.log" 2>&1 )
@@ -21,7 +21,7 @@ for step in "$@"; do
 case $step in
   tests)     timeout 1500 python -m pytest tests -m gpu -q -x > "$OUT/gpu_suite.full.log" 2>&1; grep -E "passed|failed|error|Error|solver limits" "$OUT/gpu_suite.full.log" | tail -12 | tee "$OUT/gpu_suite.log" ;;
   smoke)     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.log" ;;
-  bench)     timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 600 "$OUT/bench.err"; python tools/bench_digest.py "$OUT/bench.json" ;;
+  bench)     timeout 900 python bench.py --steps 20 --warmup 5 --extras-file "$OUT/bench_extras.json" > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 600 "$OUT/bench.err"; python tools/bench_digest.py "$OUT/bench.json" "$OUT/bench_extras.json" ;;
   headline)  timeout 300 $HEAD > "$OUT/bench_headline.json" 2> "$OUT/bench_headline.err"; tail -c 400 "$OUT/bench_headline.err"; python tools/bench_digest.py "$OUT/bench_headline.json" ;;
   trace)     # the headline command under the kernel trace: K1 / k_price_sweep per launch, and the line it printed while traced
              run_trace bench_c3p $HEAD
@@ -30,9 +30,9 @@ case $step in
              grep '^{' "$OUT/bench_c3p.log" | tail -1 > "$OUT/bench_c3p_under_rocprof.json"; python tools/bench_digest.py "$OUT/bench_c3p_under_rocprof.json"
              cat "$OUT/bench_c3p.summary.csv" ;;
   pmc)       for c in FETCH_SIZE WRITE_SIZE; do run_pmc bench_c3p $c $HEAD; done; head -12 "$OUT"/bench_c3p_FETCH_SIZE.summary.csv "$OUT"/bench_c3p_WRITE_SIZE.summary.csv ;;
-  sweepctr)  # what the sweep kernel's waves do: VALU / LDS activity of k_price_sweep (own passes, --pmc only)
-             run_pmc sweepctr "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" $HEAD
-             run_pmc sweepctr2 "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" $HEAD
+  sweepctr)  # what the sweep kernel's waves do: occupancy, VALU / LDS activity of k_price_sweep (own passes, --pmc only)
+             run_pmc sweepctr "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" $HEAD
+             run_pmc sweepctr2 "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" $HEAD
              grep -h "price_sweep\|^kernel" "$OUT"/sweepctr*.summary.csv ;;
   stage)     HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p wave --no-host --repeat 2 2>&1 | grep -E "price profile|price \{" | tee "$OUT/price_sweep_stage_profile.txt" ;;
   heterotrace) # the kernels of the heterogeneous steady-state loop (136 worker classes per tick through k_block_solve)
