@@ -38,6 +38,7 @@ struct DSUlite {
 void order_by_cost_desc(const double *c, int n, std::vector<int> &out);
 
 const bool cuts_on = !(getenv("HQMILP_CUTS") && atoi(getenv("HQMILP_CUTS")) == 0);
+const bool tree_cuts_on = !(getenv("HQMILP_TREE_CUTS") && atoi(getenv("HQMILP_TREE_CUTS")) == 0);  // (A/B switch: the certification tree on the rows + root cuts)
 
 struct CompSolver {
     int n = 0;
@@ -264,6 +265,10 @@ struct CompSolver {
     // Rounds of cuts on a COPY of the rows, for the bound only: the tree below keeps working on the model's own rows (its canonical answers must not depend on the
     // numerics of cut rows).  A round's value counts when its tableau is dual feasible; the final value is taken from a COLD solve over the final rows, the larger of
     // the two when they differ.
+    // The rows with the accepted cuts stay (`RCm`): the CERTIFICATION phases of the tree run on them (search(): a node's LP bound then starts from the cut-tightened
+    // root instead of the plain LP's, percent above it — the difference between 18 nodes and millions on small clusters mid-run); the exact /
+    // canonical pass after a certificate goes back to the model's own rows.
+    Rows RCm; bool rc_valid = false;
     void root_cuts(const Tab &root0) {
         if (in_lns || n > 600 || rel_gap <= 0.0) return;  // (the models the sweeps never see, 256 columns and below by default, and a little beyond; an LP of 1000+ columns is too slow to re-solve 40 times)
         const double work_cap = work + 3.0e8 * std::max(0.2, time_limit_s / 5.0);  // a deterministic budget (tableau element updates: ~0.3 s of a 5 s limit), like every other one in here
@@ -299,6 +304,17 @@ struct CompSolver {
             }
         }
         cuts_added = RC.m - R.m;
+        if (RC.m > R.m && have && !certified()) {
+            // The cut LP's own point as a primal lead (RENS): where the rounds took the bound down to within a few 1e-4 of the optimum, the point that attains it is integral
+            // in most columns — those are fixed, the fractional ones move between floor and ceiling, and the small model that is left is solved exactly.  (The 100-column
+            // clusters of tools/price_fuzz.py on the host-only path: the windows' incumbent sits 2e-4 below an optimum the cut bound names to 1e-9.)
+            std::vector<double> base(root.x.begin(), root.x.begin() + n);
+            std::vector<int> wcols;
+            for (int j = 0; j < n; j++) { const double r = std::round(base[j]); if (std::fabs(base[j] - r) <= INT_TOL) base[j] = std::min(ub[j], std::max(lb[j], r)); else wcols.push_back(j); }
+            if (wcols.empty()) greedy_from(base);
+            else if ((int)wcols.size() <= 96) { const double before = best; lns_solve(wcols, deadline, 20000, &base); if (tracing) fprintf(stderr, "[milp] n=%d RENS at the cut LP's point (%d fractional columns): %.9f -> %.9f\n", n, (int)wcols.size(), before, best); }
+        }
+        if (RC.m > R.m && tree_cuts_on) { RCm = std::move(RC); rc_valid = true; row_unit.resize((size_t)RCm.m, 0.0); }
     }
 
     void round_and_repair(const Tab &t) {
@@ -950,12 +966,20 @@ struct CompSolver {
                 trace(strong ? "strong-branching phase" : "dive phase");
                 aborted = false; node_budget = nodes + bud;
                 if (node_cap >= 0) node_budget = std::min(node_budget, node_cap);
-                if (phase > 0) { lp_iters += root.iters; root = Tab(); root.init(&R, c, lb, ub); root.deadline = deadline; }
+                const bool on_cuts = rc_valid && rel_gap > 0.0 && work_limit < 0 && !in_lns;   // a certification phase with root cuts at hand: the tree works on the tightened rows
+                if (phase > 0 || (on_cuts && root.R != &RCm)) { lp_iters += root.iters; root = Tab(); root.init(on_cuts ? &RCm : &R, c, lb, ub); root.deadline = deadline; }
                 if (root_bound == INF && solve_counted(root) == LP_OPT) root_bound = root.objective();  // dfs_opt finds the tableau solved
                 dfs_opt(root);
                 if (cert_stop) break;
                 if (!aborted || timed_out) break;
                 if (node_cap >= 0 && nodes >= node_cap) { timed_out = true; break; }
+                if (phase == 0 && !in_lns && !rc_valid && cuts_on && rel_gap > 0.0 && work_limit < 0 && n < LNS_FIRST_COLS && !certified()) {
+                    // a small model the first dive did not close (the larger ones had their cut rounds before the windows): GMI rounds at the root now — on the 100-column
+                    // clusters mid-run of tools/price_fuzz.py they take the LP bound from 6-7 % above the optimum down to the optimum itself
+                    Tab r0; r0.init(&R, c, lb, ub); r0.deadline = deadline;
+                    if (solve_counted(r0) == LP_OPT) { root_bound = std::min(root_bound, r0.objective()); root_cuts(r0); trace("root cuts done (after the first dive)"); }
+                    if (certified()) { cert_stop = true; break; }
+                }
                 if (phase == 0 && !in_lns && !lns_done) {  // the dive did not finish: improve its incumbent before the expensive phases
                     // at most 30 % of what is left, and not more than three times what the dive itself took: a model that strong branching proves
                     // in a second must not spend six in here first
