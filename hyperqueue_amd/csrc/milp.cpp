@@ -38,6 +38,7 @@ struct DSUlite {
 void order_by_cost_desc(const double *c, int n, std::vector<int> &out);
 
 const bool cuts_on = !(getenv("HQMILP_CUTS") && atoi(getenv("HQMILP_CUTS")) == 0);
+const bool hull_on = !(getenv("HQMILP_HULL_CUTS") && atoi(getenv("HQMILP_HULL_CUTS")) == 0);  // (A/B switch: block-hull cuts in the root rounds)
 const bool tree_cuts_on = !(getenv("HQMILP_TREE_CUTS") && atoi(getenv("HQMILP_TREE_CUTS")) == 0);  // (A/B switch: the certification tree on the rows + root cuts)
 
 struct CompSolver {
@@ -251,6 +252,96 @@ struct CompSolver {
         cuts_added += added;
         return added;
     }
+    // ---- Block-hull cuts at the root (what the bound of small coupled models was missing) ------------------------------------------------------
+    // The model is one small block per worker (its builder says which: col_group) plus rows across them.  For ANY cost vector r over a block's columns,
+    //     r . x_b <= V_b(r) = max { r . x_b : the block's own rows and bounds, x_b integer }
+    // holds at every integer point of the model — a facet-or-face of the block's integer hull, found by solving the block EXACTLY (8-16 columns, <= 4 rows: tens of
+    // microseconds).  With r = the Lagrangian costs at the current LP optimum (c minus the duals of every row that is not the block's own) these are the cuts of
+    // Dantzig-Wolfe / Kelley written in the original space: rounds of them take the LP bound down to the decomposition bound, which on clusters mid-run sits an order
+    // of magnitude closer to the optimum than 40 rounds of GMI cuts alone reach (tools/price_fuzz.py seed 2047: 2.9e-3 against 7e-4), and the GMI rounds that follow
+    // start from THERE — cuts across blocks on top of the blocks' hulls, which is the combination HiGHS closes these models with at its root.
+    // Everything counted, nothing timed: block solves run on a node cap.
+    struct HullBlocks {
+        bool ready = false, usable = false;
+        std::vector<std::vector<int>> cols;      // per block: its columns
+        std::vector<Rows> rows;                  // per block: the rows that live inside it (local column ids)
+        std::vector<uint8_t> row_internal;       // per row of R: 1 = inside one block
+    } hb;
+    void find_hull_blocks() {
+        hb.ready = true; hb.usable = false;
+        if ((int)col_group.size() != n) return;
+        int gmax = -1; for (int j = 0; j < n; j++) gmax = std::max(gmax, (int)col_group[j]);
+        if (gmax < 1) return;
+        std::vector<int> id((size_t)gmax + 1, -1), local(n, -1);
+        for (int j = 0; j < n; j++) { const int g = col_group[j]; if (g < 0) continue; if (id[g] < 0) { id[g] = (int)hb.cols.size(); hb.cols.emplace_back(); } local[j] = (int)hb.cols[id[g]].size(); hb.cols[id[g]].push_back(j); }
+        const int nb = (int)hb.cols.size();
+        if (nb < 2) return;
+        for (auto &bc : hb.cols) if (bc.size() > 64) return;   // (a block of that size is not a worker's)
+        hb.rows.assign(nb, Rows());
+        for (int b = 0; b < nb; b++) hb.rows[b].n = (int)hb.cols[b].size();
+        hb.row_internal.assign((size_t)R.m, 0);
+        std::vector<std::pair<int, double>> terms;
+        for (int i = 0; i < R.m; i++) {
+            int b = -1; bool inside = R.off[i + 1] > R.off[i];
+            for (int k = R.off[i]; k < R.off[i + 1] && inside; k++) { const int g = col_group[R.col[k]]; if (g < 0) { inside = false; break; } const int bb = id[g]; if (b < 0) b = bb; else if (bb != b) inside = false; }
+            if (!inside) continue;
+            hb.row_internal[(size_t)i] = 1;
+            terms.clear();
+            for (int k = R.off[i]; k < R.off[i + 1]; k++) terms.push_back({local[R.col[k]], R.coef[k]});
+            hb.rows[b].add(terms, R.lo[i], R.hi[i]);
+        }
+        hb.usable = true;
+    }
+    long hull_solves = 0;
+    // one round: cuts for the blocks whose LP point beats their integer optimum at the current Lagrangian costs; returns how many were added to RC
+    int hull_round(Tab &t, Rows &RC) {
+        if (!hb.ready) find_hull_blocks();
+        if (!hb.usable) return 0;
+        // Lagrangian costs: c_j minus the duals of the active rows that are NOT internal to a block (cut rows included).  The dual of active row a is the reduced
+        // cost of its slack column (zero while the slack is basic).
+        std::vector<double> r(c.begin(), c.end());
+        for (int a = 0; a < t.ma; a++) {
+            const int i = t.arow[a];
+            if (i < R.m && hb.row_internal[(size_t)i]) continue;
+            const double y = t.st[t.n + a] == BASIC ? 0.0 : t.d[t.n + a];
+            if (y == 0.0) continue;
+            for (int k = RC.off[i]; k < RC.off[i + 1]; k++) r[RC.col[k]] -= y * RC.coef[k];
+        }
+        int added = 0;
+        std::vector<std::pair<int, double>> terms;
+        for (size_t b = 0; b < hb.cols.size(); b++) {
+            const std::vector<int> &bc = hb.cols[b];
+            const int nbc = (int)bc.size();
+            double lpv = 0.0, rmax = 0.0, trivial = 0.0;
+            for (int l = 0; l < nbc; l++) { const int j = bc[l]; lpv += r[j] * t.x[j]; rmax = std::max(rmax, std::fabs(r[j])); trivial += r[j] > 0.0 ? r[j] * ub[j] : r[j] * lb[j]; }
+            if (!(rmax > 1e-12)) continue;
+            if (lpv <= 1e-7 * rmax) continue;   // (V_b >= r . lb-point; with lb = 0 nothing below zero can be violated)
+            CompSolver sub; sub.n = nbc; sub.in_lns = true; sub.deadline = deadline; sub.node_cap = 4000; sub.tracing = false;
+            sub.c.resize(nbc); sub.lb.resize(nbc); sub.ub.resize(nbc); sub.R = hb.rows[b];
+            for (int l = 0; l < nbc; l++) { const int j = bc[l]; sub.c[l] = r[j] / rmax; sub.lb[l] = lb[j]; sub.ub[l] = r[j] > 0.0 ? ub[j] : lb[j]; }   // a column that does not pay stays at its lower bound
+            std::vector<double> xb;
+            const int st = sub.run(false, xb);
+            nodes += sub.nodes; work += sub.work; hull_solves++;
+            if (tracing && getenv("HQMILP_HULL_TRACE")) fprintf(stderr, "[hull] block %zu: %d cols st %d nodes %ld work %.3g\n", b, nbc, st, sub.nodes, sub.work);
+            if (st != 1 || (int)xb.size() != nbc) continue;   // not solved to the end within its cap: no cut from this block
+            double V = 0.0; for (int l = 0; l < nbc; l++) V += r[bc[l]] * xb[l];
+            if (lpv <= V + 1e-6 * rmax * std::max(1.0, std::fabs(V / rmax))) continue;
+            // r . x_b <= V, scaled to max |coef| = 1 and relaxed a hair; never against the incumbent (cannot be: it is an integer point of the block)
+            terms.clear();
+            for (int l = 0; l < nbc; l++) { const int j = bc[l]; if (r[j] > 0.0 && std::fabs(r[j]) >= 1e-9 * rmax) terms.push_back({j, r[j] / rmax}); }
+            // (columns with r_j <= 0 were held at their lower bound in the block solve: dropping them from the cut keeps it valid only for lb = 0 — check)
+            bool lb0 = true; for (int l = 0; l < nbc; l++) if (lb[bc[l]] != 0.0) lb0 = false;
+            if (!lb0) continue;
+            double rhs = V / rmax; rhs += 1e-9 * (std::fabs(rhs) + 1.0);
+            if (have) { double li = 0.0; for (auto &tm : terms) li += tm.second * bx[tm.first]; if (li > rhs) continue; }
+            RC.add(terms, -INF, rhs);
+            slack_unit.push_back(0.0);
+            t.where.push_back(-1);
+            added++;
+        }
+        cuts_added += added;
+        return added;
+    }
     // Dual feasibility of a solved tableau (max problem: a nonbasic column at its lower bound must not gain, one at its upper bound must not lose): what makes its
     // objective a BOUND.  The dense tableau is never refactored, and cuts bring coefficient ranges of 1e6 into it: a warm re-solve can come back "optimal" from a
     // basis whose reduced costs have drifted (tools/price_fuzz.py seed 29: 142.262 where a cold solve of the same rows gives 142.399) — such a value bounds nothing.
@@ -268,33 +359,47 @@ struct CompSolver {
     // The rows with the accepted cuts stay (`RCm`): the CERTIFICATION phases of the tree run on them (search(): a node's LP bound then starts from the cut-tightened
     // root instead of the plain LP's, percent above it — the difference between 18 nodes and millions on small clusters mid-run); the exact /
     // canonical pass after a certificate goes back to the model's own rows.
-    Rows RCm; bool rc_valid = false;
+    Rows RCm; bool rc_valid = false; double rc_bound = INF;
+    // Two passes, the second only when the first leaves the model open: GMI rounds alone, then block-hull cuts with GMI rounds on top.  Neither dominates (price_fuzz
+    // 2020: GMI alone names the optimum to 1e-9, with the hull cuts the rounds stall 1.6e-4 above it; 2017: GMI alone stalls 8.4e-4 above, with the hull cuts the
+    // root closes) — the tree gets the rows of the pass with the lower bound.
     void root_cuts(const Tab &root0) {
+        root_cuts_pass(root0, false);
+        if (hull_on && have && !certified() && !in_lns && n <= 600 && rel_gap > 0.0) { if (!hb.ready) find_hull_blocks(); if (hb.usable) root_cuts_pass(root0, true); }
+    }
+    void root_cuts_pass(const Tab &root0, const bool with_hull) {
         if (in_lns || n > 600 || rel_gap <= 0.0) return;  // (the models the sweeps never see, 256 columns and below by default, and a little beyond; an LP of 1000+ columns is too slow to re-solve 40 times)
-        const double work_cap = work + 3.0e8 * std::max(0.2, time_limit_s / 5.0);  // a deterministic budget (tableau element updates: ~0.3 s of a 5 s limit), like every other one in here
+        const double work_cap = work + (getenv("HQMILP_CUT_WORK") ? atof(getenv("HQMILP_CUT_WORK")) : 3.0e8) * std::max(0.2, time_limit_s / 5.0);  // a deterministic budget (tableau element updates: ~0.3 s of a 5 s limit), like every other one in here
         Rows RC = R;
         find_slack_units();
         Tab root = root0; root.R = &RC;
         double prev = root.objective(), accepted = prev;
-        int stall = 0;
-        for (int round = 0; round < 40 && !time_up() && work < work_cap; round++) {
+        int stall = 0, hull_stall = 0;
+        int round = 0;
+        for (; round < 80 && !time_up() && work < work_cap; round++) {
             if (have && accepted <= best + rel_gap * std::fabs(best)) break;
-            const int added = gmi_round(root, RC, 40 + n / 8);
-            if (!added) break;
+            // block-hull cuts while they move the bound; GMI cuts (across blocks) when they no longer do — and then the hulls again, at the point the GMI rounds moved to
+            int added = 0; const char *kind = "GMI";
+            if (with_hull && hull_stall < 2) { added = hull_round(root, RC); if (added) kind = "block-hull"; }
+            const bool was_hull = added > 0;
+            if (!added) { added = gmi_round(root, RC, 40 + n / 8); hull_stall = 0; }
+            if (!added) { if (tracing) fprintf(stderr, "[milp] n=%d cut round %d: nothing to add\n", n, round); break; }
             bool ok = solve_counted(root) == LP_OPT && dual_feasible(root, 1e-7);
             if (!ok) {  // once more from a cold start over the same rows
                 root = Tab(); root.init(&RC, c, lb, ub); root.deadline = deadline;
                 ok = solve_counted(root) == LP_OPT && dual_feasible(root, 1e-7);
-                if (!ok) break;
+                if (!ok) { if (tracing) fprintf(stderr, "[milp] n=%d cut round %d: LP not re-solved\n", n, round); break; }
             }
             const double z = root.objective();
-            if (tracing) fprintf(stderr, "[milp] n=%d cut round %d: %d cuts, LP bound %.9f -> %.9f (%d rows active of %d)\n", n, round, added, prev, z, root.ma, RC.m);
+            if (tracing) fprintf(stderr, "[milp] n=%d cut round %d: %d %s cuts, LP bound %.9f -> %.9f (%d rows active of %d) work %.3g\n", n, round, added, kind, prev, z, root.ma, RC.m, work);
+            if (was_hull && prev - z < 1e-6 * std::fabs(prev)) hull_stall++;
             if (z > accepted * (1.0 + 1e-9) + 1e-12) break;  // a bound cannot rise when rows are added: the arithmetic has gone wrong, keep what was accepted
             accepted = z;
             if (prev - z < 1e-7 * std::fabs(prev)) { if (++stall >= 3) break; } else stall = 0;
             prev = z;
             if (RC.m > 40 * n + 4000) break;
         }
+        if (tracing) fprintf(stderr, "[milp] n=%d cut rounds over after %d: work %.3g of %.3g, time_up %d\n", n, round, work, work_cap, (int)timed_out);
         if (RC.m > R.m && accepted < root0.objective()) {  // the certificate's bound: confirmed by a cold solve of the final rows
             Tab cold; cold.init(&RC, c, lb, ub); cold.deadline = deadline;
             if (solve_counted(cold) == LP_OPT && dual_feasible(cold, 1e-7)) {
@@ -314,7 +419,7 @@ struct CompSolver {
             if (wcols.empty()) greedy_from(base);
             else if ((int)wcols.size() <= 96) { const double before = best; lns_solve(wcols, deadline, 20000, &base); if (tracing) fprintf(stderr, "[milp] n=%d RENS at the cut LP's point (%d fractional columns): %.9f -> %.9f\n", n, (int)wcols.size(), before, best); }
         }
-        if (RC.m > R.m && tree_cuts_on) { RCm = std::move(RC); rc_valid = true; row_unit.resize((size_t)RCm.m, 0.0); }
+        if (RC.m > R.m && tree_cuts_on && (!rc_valid || accepted < rc_bound)) { RCm = std::move(RC); rc_valid = true; rc_bound = accepted; row_unit.resize((size_t)RCm.m, 0.0); }
     }
 
     void round_and_repair(const Tab &t) {
@@ -1541,7 +1646,8 @@ static Result solve_classic(const Model &mdl_in, double time_limit_s, bool canon
             cs.row_scale.push_back(sc);
             if (sweeper) cs.row_implied.push_back((size_t)i < mdl.row_implied.size() ? mdl.row_implied[(size_t)i] : 0);
         }
-        if (sweeper && (int)mdl.col_group.size() == n) { cs.sweeper = sweeper; cs.col_group.resize(cs.n); for (int k = 0; k < cs.n; k++) cs.col_group[k] = mdl.col_group[cols[k]]; }
+        if ((int)mdl.col_group.size() == n) { cs.col_group.resize(cs.n); for (int k = 0; k < cs.n; k++) cs.col_group[k] = mdl.col_group[cols[k]]; }   // (the block-hull cuts of the root use it too)
+        if (sweeper && (int)mdl.col_group.size() == n) cs.sweeper = sweeper;
         // identical components (same rows, bounds and — up to 2^-40 relative — the same normalised costs) share one solve:
         // workers with equal free/total vectors produce them by the hundred (solver.rs:95-192 builds one block per worker)
         std::string sig;

@@ -66,13 +66,35 @@ def test_device_sweeps_walk_the_emulations_path(name, monkeypatch):
     assert got.batches == want.batches and got.counts == want.counts
 
 
-# Seeds of the family below that the product may leave uncertified within 5 s although plain HiGHS certifies them (the primal side of small
-# hard models).  Explicit and counted: the list may shrink, test_the_allow_list_is_short keeps it from growing.
-UNCERTIFIED_ALLOWED = frozenset({2017, 2020})
+# Seeds of the family below that the product may leave uncertified within 5 s although plain HiGHS certifies them.  EMPTY since round 6: 2017 and 2020 (three
+# rounds on this list) are certified in < 1 s — the certification tree now works on the rows + root cuts, small models get cut rounds, block-hull cuts.
+UNCERTIFIED_ALLOWED = frozenset()
 
 
-def test_the_allow_list_is_short():
-    assert len(UNCERTIFIED_ALLOWED) <= 2
+def test_the_allow_list_is_empty():
+    assert UNCERTIFIED_ALLOWED == frozenset()
+
+
+@pytest.mark.parametrize("seed", [2017, 2020])
+def test_the_former_allow_list_seeds_are_certified(seed, monkeypatch):
+    """the two ticks rounds 3-5 answered NeedMoreCompute where the reference answers Done (scheduler/main.rs:50-72): DONE + is_optimal now, forced through the sweeps
+    (as the family test does) AND on the product's default path (104 / 272 columns: below the sweeps' default threshold, the host search alone)"""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from limits import check_given_counts, plain_highs
+    from price_fuzz import scenario
+    from test_host_stages import _completed_objective
+
+    snap = scenario(seed)[0]
+    for min_cols in (16, None):
+        got, ks = _tick(snap, min_cols=min_cols, monkeypatch=monkeypatch) if min_cols else _tick(snap)
+        assert got.status == abi.HQTICK_DONE and got.is_optimal, (seed, min_cols)
+        check_given_counts(snap, got, 5.0)   # every row of the reference's model + T3 given counts
+        want, hm = plain_highs(snap, 5.0)
+        assert want.is_optimal
+        z, zr = _completed_objective(hm, got), float(hm["objective"])
+        assert z >= zr * (1.0 - 2e-4) - 1e-12, (z, zr)   # two 1e-4 certificates of the same optimum
 
 
 @pytest.mark.parametrize("seed", range(2000, 2024))
