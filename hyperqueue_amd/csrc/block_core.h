@@ -84,16 +84,21 @@ struct Output {
     uint64_t *prof;     // optional [n_classes * 8] timestamps (wavefront clock) at the stage boundaries of solve_block; nullptr = off
 };
 
-struct Shared {  // one block's working set: LDS on the device
+// Templated on the column capacity N: the working set of a block of <= N columns.  The algorithm never looks at N beyond "does the block fit" (n <= N), so a block's
+// answer is the same whatever N it is solved under; what changes is the footprint — 25.9 KB at N = 32, 17.6 KB at N = 16, 13.5 KB at N = 8 — i.e. how many blocks a
+// CU holds at once (six / nine / eleven): k_price_sweep picks the smallest N its model's widest block fits (price.hip).
+template <int N_>
+struct SharedN {  // one block's working set: LDS on the device
+    static constexpr int NN = N_;
     int n, m, status;
     uint32_t steps, steps_p1;
     uint64_t usedres;               // resources some eligible column touches
-    int gcol[NMAX];                 // block column -> tick column
-    double c[NMAX];
-    double a[MMAX][NMAX], ainv[MMAX][NMAX];  // amounts on the row's own grid (integers carried in f64) and their reciprocals (0 where the column does not use the row)
+    int gcol[N_];                 // block column -> tick column
+    double c[N_];
+    double a[MMAX][N_], ainv[MMAX][N_];  // amounts on the row's own grid (integers carried in f64) and their reciprocals (0 where the column does not use the row)
     double cap[MMAX];
-    uint8_t pi[NMAX];               // block columns by ascending size (the search decides the large ones first)
-    uint8_t pd[NMAX];               // block columns by descending value density (first greedy order)
+    uint8_t pi[N_];               // block columns by ascending size (the search decides the large ones first)
+    uint8_t pd[N_];               // block columns by descending value density (first greedy order)
     // dual pool
     uint32_t npool;
     alignas(16) double py[PCAP][MMAX];  // (16-byte aligned: the staging area of build_block overlays it)
@@ -101,38 +106,39 @@ struct Shared {  // one block's working set: LDS on the device
     uint16_t porder[PCAP];          // pool entries by ascending y . cap: the tightest bounds at the root come first in every level's list
     // work problem: columns in search order (position wn - 1 is decided first)
     int wn;
-    uint8_t wcol[NMAX];
-    double wc[NMAX];
-    double wa[MMAX][NMAX], winv[MMAX][NMAX];
-    uint32_t wmask[NMAX + 1];       // block columns at positions < k
+    uint8_t wcol[N_];
+    double wc[N_];
+    double wa[MMAX][N_], winv[MMAX][N_];
+    uint32_t wmask[N_ + 1];       // block columns at positions < k
     // The level lists of the walk and the greedy's vectors share their storage: the greedy runs (and its best lane is copied into xbest) before setup_work
     // builds the first list.  (6 KB of the block's LDS: with it the block is 25.9 KB — six blocks per CU instead of four, tools/exp/resident_wg.hip.)
     union {
         struct {
-            uint16_t dl[NMAX + 1][DPRE];    // per level: pool entries that are vertices of that level's dual polyhedron
-            float dpen[NMAX + 1][DPRE];     // ... and the penalty of a capped column (phase 2), rounded up
+            uint16_t dl[N_ + 1][DPRE];    // per level: pool entries that are vertices of that level's dual polyhedron
+            float dpen[N_ + 1][DPRE];     // ... and the penalty of a capped column (phase 2), rounded up
         };
         struct {
-            uint8_t perm[NMAX][WAVE];       // greedy: [column slot][lane] — lanes side by side, so that a wavefront's accesses spread over the LDS banks
-            uint16_t gx[NMAX][WAVE];
+            uint8_t perm[N_][WAVE];       // greedy: [column slot][lane] — lanes side by side, so that a wavefront's accesses spread over the LDS banks
+            uint16_t gx[N_][WAVE];
         };
     };
-    int32_t wcap[NMAX];             // upper cap of a position (INT32_MAX = none)
-    int32_t colcap[NMAX];           // upper cap of a block column (INT32_MAX = none): the priced blocks of the coupled solve (price_core.h) carry their model bounds here
-    uint32_t dcnt[NMAX + 1];
+    int32_t wcap[N_];             // upper cap of a position (INT32_MAX = none)
+    int32_t colcap[N_];           // upper cap of a block column (INT32_MAX = none): the priced blocks of the coupled solve (price_core.h) carry their model bounds here
+    uint32_t dcnt[N_ + 1];
     // level stack of the walk (level k = number of positions still free)
-    double rem[NMAX + 1][MMAX];
-    double zfix[NMAX + 1];
-    int32_t ptr[NMAX + 1], ub[NMAX + 1];
-    uint32_t xsel[NMAX];            // by position
+    double rem[N_ + 1][MMAX];
+    double zfix[N_ + 1];
+    int32_t ptr[N_ + 1], ub[N_ + 1];
+    uint32_t xsel[N_];            // by position
     // incumbent / completion, by block column
-    uint32_t xbest[NMAX];
+    uint32_t xbest[N_];
     double best;
     // greedy
     double lane_val[WAVE];
     uint32_t lane_rng[WAVE];        // setup_work: level ranges of the pool entry a lane is looking at
-    uint64_t lmask[NMAX + 1];       // setup_work: per level, which of the 64 entries of the current pass enter its list
+    uint64_t lmask[N_ + 1];       // setup_work: per level, which of the 64 entries of the current pass enter its list
 };
+using Shared = SharedN<NMAX>;
 
 constexpr int BLOB_MAX = 8192;               // largest column table the kernel stages in LDS
 struct alignas(16) V16 { uint64_t lo, hi; };
@@ -171,7 +177,8 @@ HQB_HD int64_t gcd64(int64_t a, int64_t b) {  // binary gcd: shifts and subtract
 }
 
 // min over the level's dual points of y . rem: an upper bound of the LP over the positions [0, k), hence of its integer optimum
-HQB_HD double lp_bound(const Shared &S, int k, const double *rem) {
+template <class SH>
+HQB_HD double lp_bound(const SH &S, int k, const double *rem) {
     const int cnt = (int)(S.dcnt[k] < (uint32_t)DPRE ? S.dcnt[k] : (uint32_t)DPRE);
     if (cnt == 0) return 1e300;
     const double r0 = rem[0], r1 = rem[1], r2 = rem[2], r3 = rem[3];
@@ -191,20 +198,20 @@ HQB_HD double lp_bound(const Shared &S, int k, const double *rem) {
 // The tables arrive in device-visible HOST memory (pinned): every dependent load from there is a PCIe round trip (~2 us), so the wavefront
 // first copies the column table (one allocation, a few hundred bytes) and its class's free / total rows into LDS with one wide load per lane —
 // the staging area overlays the dual pool, which is empty at this point — and lane g then builds column g from LDS.
-template <class W>
-HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTable &cl, uint32_t cls) {
+template <class W, class SH>
+HQB_HD void build_block(W &wv, SH &S, const ColTable &ct_in, const ClassTable &cl, uint32_t cls) {
     const uint32_t R = ct_in.R, NC = ct_in.n_cols;
     uint8_t *area = reinterpret_cast<uint8_t *>(&S.py[0][0]);
     // (the pool, and behind it the work problem's arrays up to `wcap`: nothing in there is written before dual_candidate / setup_work, which run after the block is built)
-    static_assert(offsetof(Shared, dl) - offsetof(Shared, py) >= BLOB_MAX + 64 * 8 * 2, "the staging area overlays the dual pool and the work problem behind it, up to the level lists (whose storage holds a64 meanwhile)");
+    static_assert(offsetof(SH, dl) - offsetof(SH, py) >= BLOB_MAX + 64 * 8 * 2, "the staging area overlays the dual pool and the work problem behind it, up to the level lists (whose storage holds a64 meanwhile)");
     uint64_t *sfree = reinterpret_cast<uint64_t *>(area + BLOB_MAX), *stotal = sfree + 64;
     // integer amounts while the rows are brought onto their own grid (gcd); overlays the greedy vectors, which are not in use yet
-    static_assert(sizeof(uint16_t) * NMAX * WAVE >= sizeof(int64_t) * (MMAX * NMAX + MMAX), "a64 overlays gx");
-    int64_t (*a64)[NMAX] = reinterpret_cast<int64_t (*)[NMAX]>(&S.gx[0][0]);
-    int64_t *cap64 = &a64[MMAX - 1][NMAX - 1] + 1;
+    static_assert(sizeof(uint16_t) * SH::NN * WAVE >= sizeof(int64_t) * (MMAX * SH::NN + MMAX), "a64 overlays gx");
+    int64_t (*a64)[SH::NN] = reinterpret_cast<int64_t (*)[SH::NN]>(&S.gx[0][0]);
+    int64_t *cap64 = &a64[MMAX - 1][SH::NN - 1] + 1;
     ColTable ct = ct_in;
     if (wv.first()) { S.status = ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = 0; S.npool = 0; S.usedres = 0; }
-    wv.each([&](int lane) { if (lane < NMAX) S.colcap[lane] = 2147483647; });
+    wv.each([&](int lane) { if (lane < SH::NN) S.colcap[lane] = 2147483647; });
     if (NC > (uint32_t)GCOLS || R > 64 || NC == 0) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
     const uint64_t elig = cl.elig[cls] & (NC >= 64 ? ~0ull : ((1ull << NC) - 1ull));
     const bool staged = ct_in.blob != nullptr && ct_in.blob_bytes <= (uint32_t)BLOB_MAX && (ct_in.blob_bytes & 15u) == 0;
@@ -215,7 +222,7 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTabl
             for (uint32_t i = (uint32_t)lane; i < ct_in.blob_bytes / 16; i += WAVE) dst[i] = src[i];
         }
         for (uint32_t i = (uint32_t)lane; i < R; i += WAVE) { sfree[i] = cl.free_[(size_t)cls * R + i]; stotal[i] = cl.total[(size_t)cls * R + i]; }
-        for (int i = lane; i < MMAX * NMAX; i += WAVE) a64[i / NMAX][i % NMAX] = 0;
+        for (int i = lane; i < MMAX * SH::NN; i += WAVE) a64[i / SH::NN][i % SH::NN] = 0;
         if (lane < MMAX) cap64[lane] = 0;
     });
     wv.sync();
@@ -227,7 +234,7 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTabl
         ct.weight = reinterpret_cast<const uint32_t *>(re(ct_in.weight)); ct.pool = reinterpret_cast<const double *>(re(ct_in.pool));
     }
     const int n = __builtin_popcountll(elig);
-    if (n > NMAX) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
+    if (n > SH::NN) { if (wv.first()) S.status = ST_UNSUPPORTED; wv.sync(); return; }
     // column g by lane g: cost in the reference's operation order (create_sn_var, solver.rs:550-568), the resources it touches
     wv.each([&](int lane) {
         const uint32_t g = (uint32_t)lane;
@@ -273,7 +280,7 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTabl
         int64_t g = 0;
         if (lane < m) for (int j = 0; j < n; j++) g = gcd64(g, a64[lane][j]);
         if (g < 1) g = 1;
-        for (int j = 0; j < NMAX; j++) {
+        for (int j = 0; j < SH::NN; j++) {
             const double v = (lane < m && j < n) ? (double)a64[lane][j] / (double)g : 0.0;  // exact: g divides the amount, both below 2^52
             S.a[lane][j] = v; S.ainv[lane][j] = v > 0.0 ? 1.0 / v : 0.0;
         }
@@ -317,8 +324,8 @@ HQB_HD void build_block(W &wv, Shared &S, const ColTable &ct_in, const ClassTabl
 
 // ---- step 2: dual points ------------------------------------------------------------------------------------------------------------------------
 // Basis number t of the C(n + m, m) choices of m tight constraints among {column j: a_j . y = c_j} and {row r: y_r = 0}.
-template <class W>
-HQB_HD void dual_candidate(W &wv, Shared &S, uint32_t t) {
+template <class W, class SH>
+HQB_HD void dual_candidate(W &wv, SH &S, uint32_t t) {
     const int n = S.n, m = S.m;
     double M[MMAX][MMAX + 1];
     HQB_UNROLL
@@ -411,7 +418,8 @@ HQB_HD void dual_candidate(W &wv, Shared &S, uint32_t t) {
 // ---- step 3: greedy incumbents -----------------------------------------------------------------------------------------------------------------
 HQB_HD uint32_t xorshift32(uint32_t &s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
 
-HQB_HD void greedy_lane(Shared &S, int lane) {
+template <class SH>
+HQB_HD void greedy_lane(SH &S, int lane) {
     const int n = S.n, m = S.m;
     // lane 0: by value density (descending); 1: large requests first; 2: small first; 3 / 4: the model's order and its reverse; others: shuffles
     for (int j = 0; j < n; j++) S.perm[j][lane] = lane == 0 ? S.pd[j] : lane == 1 ? S.pi[n - 1 - j] : lane == 2 ? S.pi[j] : lane == 4 ? (uint8_t)(n - 1 - j) : (uint8_t)j;
@@ -438,8 +446,8 @@ HQB_HD void greedy_lane(Shared &S, int lane) {
 // (phase 2's probes).  Level lists: a pool point bounds the level with free set F when it is a vertex of F's dual polyhedron (tight within F
 // within cover).  With a capped column j in F the LP has one more dual variable, the multiplier of x_j <= L; its vertices are the ones above
 // plus (y, mu = c_j - a_j . y > 0) with y a vertex for F \ {j}: those enter with the penalty L * mu   (bound = y . rem + penalty).
-template <class W>
-HQB_HD void setup_work(W &wv, Shared &S, uint32_t cols, int capcol, int32_t capval) {
+template <class W, class SH>
+HQB_HD void setup_work(W &wv, SH &S, uint32_t cols, int capcol, int32_t capval) {
     const uint64_t selmask = wv.ballot([&](int lane) { return lane < S.n && ((cols >> S.pi[lane]) & 1); });
     wv.each([&](int lane) {
         if (lane >= S.n || !((selmask >> lane) & 1)) return;
@@ -464,7 +472,7 @@ HQB_HD void setup_work(W &wv, Shared &S, uint32_t cols, int capcol, int32_t capv
     // Level lists in pool order (porder: tightest at the root first).  The level sets are nested (F_1 < F_2 < ... ), so an entry is a vertex for
     // a contiguous range of levels — [lo, hi] as it is, [lo2, hi2] through the capped column's multiplier — which its lane works out once; one
     // ballot per level then gives every entry its slot (prefix popcount), with nothing but registers between the ballots.
-    if (wv.first()) for (int k = 0; k <= NMAX; k++) S.dcnt[k] = 0;
+    if (wv.first()) for (int k = 0; k <= SH::NN; k++) S.dcnt[k] = 0;
     wv.sync();
     for (uint32_t base = 0; base < np; base += WAVE) {
         wv.each([&](int lane) {
@@ -521,7 +529,8 @@ HQB_HD void setup_work(W &wv, Shared &S, uint32_t cols, int capcol, int32_t capv
     }
 }
 
-HQB_HD int32_t level_ub(const Shared &S, int k) {  // how often the column at position k - 1 fits into rem[k]
+template <class SH>
+HQB_HD int32_t level_ub(const SH &S, int k) {  // how often the column at position k - 1 fits into rem[k]
     const int p = k - 1;
     int32_t ub = S.wcap[p];
     for (int r = 0; r < S.m; r++) if (S.wa[r][p] > 0.0) { const int32_t q = fits(S.rem[k][r], S.wa[r][p], S.winv[r][p]); ub = q < ub ? q : ub; }
@@ -529,7 +538,8 @@ HQB_HD int32_t level_ub(const Shared &S, int k) {  // how often the column at po
 }
 
 // Two positions left (1 and 0): position 1 takes v1, position 0 follows exactly with its maximum.
-HQB_HD bool terminal_lane(const Shared &S, int32_t v1, int32_t *x0_out, double *val_out) {
+template <class SH>
+HQB_HD bool terminal_lane(const SH &S, int32_t v1, int32_t *x0_out, double *val_out) {
     if (v1 < 0 || v1 > S.ub[2]) return false;
     int32_t x0max = S.wcap[0];
     for (int r = 0; r < S.m; r++) {
@@ -552,8 +562,8 @@ static uint32_t g_trace_maxlist = 0, g_trace_maxpool = 0; static unsigned long g
 //   MODE_FIND  stop at the first complete point whose objective is >= thr and write it into S.xbest (work columns only); *found_out tells
 //              whether there was one.
 // Returns false when the step budget ran out.
-template <class W>
-HQB_HD bool walk(W &wv, Shared &S, int mode, double thr, uint32_t *budget, bool *found_out) {
+template <class W, class SH>
+HQB_HD bool walk(W &wv, SH &S, int mode, double thr, uint32_t *budget, bool *found_out) {
     const int wn = S.wn, m = S.m;
     bool found = false;
     if (wn == 1) {  // a single position: no search
@@ -659,8 +669,8 @@ HQB_HD bool walk(W &wv, Shared &S, int mode, double thr, uint32_t *budget, bool 
 }
 
 // ---- the whole block ----------------------------------------------------------------------------------------------------------------------------
-template <class W>
-HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &cl, uint32_t cls, const Output &out, uint32_t budget) {
+template <class W, class SH>
+HQB_HD void solve_block(W &wv, SH &S, const ColTable &ct, const ClassTable &cl, uint32_t cls, const Output &out, uint32_t budget) {
     uint64_t *prof = out.prof ? out.prof + (size_t)cls * 8 : nullptr;
     if (prof && wv.first()) prof[0] = wv.now();
     build_block(wv, S, ct, cl, cls);
@@ -678,7 +688,7 @@ HQB_HD void solve_block(W &wv, Shared &S, const ColTable &ct, const ClassTable &
     {   // pool order: ascending y . cap (rank counting; the keys sit in the not-yet-used penalty array)
         const uint32_t np = S.npool < (uint32_t)PCAP ? S.npool : (uint32_t)PCAP;
         float *pkey = &S.dpen[0][0];
-        static_assert((NMAX + 1) * DPRE >= PCAP, "pool keys overlay dpen");
+        static_assert((SH::NN + 1) * DPRE >= PCAP, "pool keys overlay dpen");
         wv.each([&](int lane) { for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) pkey[i] = (float)(S.py[i][0] * S.cap[0] + S.py[i][1] * S.cap[1] + S.py[i][2] * S.cap[2] + S.py[i][3] * S.cap[3]); });
         wv.sync();
         wv.each([&](int lane) {

@@ -59,8 +59,12 @@ struct SweepArgs {
     double pi[KMAX];
 };
 
+// SH = hqblock::SharedN<N>, N = 8 / 16 / 32: the smallest working set the model's widest block fits (block_core.h) — 13.5 / 17.6 / 25.9 KB of LDS per workgroup, i.e.
+// eleven / nine / six blocks resident per CU: a 4096-block sweep of 16-column blocks (BASELINE configs[3]) runs in two generations of resident workgroups instead of
+// three.  The answers do not depend on N.
+template <class SH>
 __global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
-    __shared__ Shared S;
+    __shared__ SH S;
     __shared__ uint32_t s_last;
     hqblock::DevWave wv;
     solve_priced_block(wv, S, a.t, a.pi, a.first + blockIdx.x, a.out, a.budget);
@@ -172,6 +176,9 @@ bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     if (t.K > (uint32_t)KMAX || t.n_blocks == 0) return false;
     if (profile && !h_prof.ensure((size_t)t.n_blocks * 64 + 64)) return false;
     T = &t; n_sweeps = 0; cap_sweeps = max_sweeps;
+    max_block_cols = 0;
+    for (uint32_t b = 0; b < t.n_blocks; b++) max_block_cols = std::max(max_block_cols, t.blk_off[b + 1] - t.blk_off[b]);
+    if (force_nmax) max_block_cols = (uint32_t)hqblock::NMAX;   // (HQTICK_PRICE_NMAX=1: the full-size working set whatever the model — A/B switch)
     const size_t nw = t.w_row.size();
     o_off = 0; o_m = al16(o_off + (size_t)(t.n_blocks + 1) * 4); o_cap = al16(o_m + t.n_blocks); o_cost = al16(o_cap + (size_t)t.n_blocks * MMAX * 8);
     o_a = al16(o_cost + (size_t)t.n_cols * 8); o_ccap = al16(o_a + (size_t)t.n_cols * MMAX * 8); o_woff = al16(o_ccap + (size_t)t.n_cols * 4);
@@ -238,7 +245,9 @@ bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool loca
     memset(a.pi, 0, sizeof(a.pi));
     memcpy(a.pi, pi, (size_t)t.K * 8);
     const double t0 = now_us();
-    hipLaunchKernelGGL(k_price_sweep, dim3(b1 - b0), dim3(WAVE), 0, stream, a);
+    if (max_block_cols <= 8) hipLaunchKernelGGL(k_price_sweep<hqblock::SharedN<8>>, dim3(b1 - b0), dim3(WAVE), 0, stream, a);
+    else if (max_block_cols <= 16) hipLaunchKernelGGL(k_price_sweep<hqblock::SharedN<16>>, dim3(b1 - b0), dim3(WAVE), 0, stream, a);
+    else hipLaunchKernelGGL(k_price_sweep<hqblock::SharedN<hqblock::NMAX>>, dim3(b1 - b0), dim3(WAVE), 0, stream, a);
     if (hipGetLastError() != hipSuccess) return false;
     // wait for the sweep's own completion word (pinned memory); the stream synchronisation is the fallback after 2 s
     volatile SweepResult *r = h_res.as<SweepResult>();

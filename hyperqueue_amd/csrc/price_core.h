@@ -59,8 +59,8 @@ struct SweepOut {
 // contribution is added to the block's bound)
 constexpr double RC_DROP = 1e-12;
 
-template <class W>
-HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *pi, uint32_t b, const SweepOut &out, uint32_t budget) {
+template <class W, class SH>
+HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, uint32_t b, const SweepOut &out, uint32_t budget) {
     const uint32_t c0 = t.blk_off[b], nb = t.blk_off[b + 1] - c0;
     const int m = (int)t.blk_m[b];
     uint64_t *prof = out.prof ? out.prof + (size_t)b * 8 : nullptr;
@@ -70,7 +70,7 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
     static_assert(hqblock::PCAP * MMAX >= KMAX, "the prices are staged in the dual pool's storage");
     wv.each([&](int lane) {
         for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) spi[k] = pi[k];
-        if (lane < NMAX) S.colcap[lane] = 2147483647;
+        if (lane < SH::NN) S.colcap[lane] = 2147483647;
         if (lane < MMAX) S.cap[lane] = lane < m ? t.blk_cap[(size_t)b * MMAX + lane] : 0.0;
     });
     if (wv.first()) { S.status = hqblock::ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = m; S.npool = 0; S.usedres = 0; }
@@ -124,7 +124,7 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
         dropped += rc * (double)(S.wcap[q] < 65536 ? S.wcap[q] : 65536);
     }
     wv.sync();
-    for (int q = n; q < NMAX; q++) if (wv.first()) { S.c[q] = 0.0; for (int r = 0; r < MMAX; r++) { S.a[r][q] = 0.0; S.ainv[r][q] = 0.0; } }
+    for (int q = n; q < SH::NN; q++) if (wv.first()) { S.c[q] = 0.0; for (int r = 0; r < MMAX; r++) { S.a[r][q] = 0.0; S.ainv[r][q] = 0.0; } }
     if (wv.first()) S.n = n;
     wv.sync();
     uint16_t *x = out.x + c0;
@@ -210,9 +210,10 @@ HQB_HD void solve_priced_block(W &wv, Shared &S, const Tables &t, const double *
     wv.sync();
     if (prof && wv.first()) prof[5] = wv.now();  // walk
     // results: the pattern, its value at the original and at the reduced costs, the block's contribution to the wide rows — summed per block in LDS first
-    // (the level stack's storage: the walk is over), then ONE global atomic per row the block touches
-    long long *lact = reinterpret_cast<long long *>(&S.rem[0][0]);
-    static_assert(sizeof(S.rem) >= sizeof(long long) * KMAX, "the block's activities are summed in the level stack's storage");
+    // (the dual pool's storage: the walk is over — and the pool is the one array whose size does not shrink with the working set's column capacity), then ONE global
+    // atomic per row the block touches
+    long long *lact = reinterpret_cast<long long *>(&S.py[0][0]);
+    static_assert(sizeof(S.py) >= sizeof(long long) * KMAX, "the block's activities are summed in the dual pool's storage");
     wv.each([&](int lane) { for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) lact[k] = 0; });
     wv.sync();
     wv.each([&](int lane) {

@@ -17,6 +17,8 @@ struct DeviceSweeper : Sweeper {
     const HostTables *T = nullptr;
     size_t o_off = 0, o_m = 0, o_cap = 0, o_cost = 0, o_a = 0, o_ccap = 0, o_woff = 0, o_wrow = 0, o_wcoef = 0, tab_bytes = 0;
     uint32_t n_sweeps = 0, cap_sweeps = 0, seq = 0;
+    uint32_t max_block_cols = 0;   // widest block of the model at hand: picks the kernel's working-set size (price.hip)
+    bool force_nmax = getenv("HQTICK_PRICE_NMAX") != nullptr;
     double last_kernel_us = 0;   // duration of the last sweep as the host saw it (launch -> result visible)
     // statistics for the bench line
     uint64_t total_sweeps = 0, total_block_solves = 0; double total_us = 0;
