@@ -34,7 +34,7 @@ case $step in
              run_pmc sweepctr "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" $HEAD
              run_pmc sweepctr2 "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" $HEAD
              grep -h "price_sweep\|^kernel" "$OUT"/sweepctr*.summary.csv ;;
-  stage)     HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p wave --no-host --repeat 2 2>&1 | grep -E "price profile|price \{" | tee "$OUT/price_sweep_stage_profile.txt" ;;
+  stage)     HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p wave c4u c4p --no-host --repeat 2 2>&1 | grep -E "price profile|price \{" | tee "$OUT/price_sweep_stage_profile.txt" ;;
   heterotrace) # the kernels of the heterogeneous steady-state loop (136 worker classes per tick through k_block_solve)
              run_trace bench_hetero python $ROOT/bench.py --steps 2 --warmup 1 --hetero-steps 25 --dag-steps 0 --priority-ticks 0 --cpu-ticks 0 --steady-steps 0 --wire-iters 0
              cat "$OUT/bench_hetero.summary.csv" ;;

@@ -18,6 +18,10 @@ def snapshot(which):
         return workloads.make("c3p", n_tasks=1_000_000, n_workers=1024)
     if which == "c3ps":  # a busy cluster (every worker its own free vector) + three priority levels + 1 M ready tasks: the everyday production tick
         return workloads.make_steady("c3p", seed=0)
+    if which == "c4u":   # BASELINE configs[3]'s cluster, unsaturated: 4096 blocks of 16 columns per sweep
+        return workloads.make("c4", seed=8, n_workers=4096, n_tasks=56_761)
+    if which == "c4p":   # BASELINE configs[3] as written: three priority levels x 4096 workers x 2-variant OR-lists
+        return workloads.make("c4p")
     if which.startswith("c3p:"):
         w = int(which.split(":")[1])
         return workloads.make("c3p", n_tasks=1000 * w, n_workers=w)
