@@ -93,7 +93,7 @@ struct hqtick_ctx {
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
     bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true, timing_k1 = false;  // (timing_k1: events around K1 alone, hqtick_set_kernel_timing(ctx, 2))  // level table of the previous tick (re-validated by K1 every tick)
-    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_addp, h_retr, h_blk, h_k5a;
+    PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_addp, h_retr, h_blk, h_k5a, h_lv;   // (h_lv: the level table as k_sort_levels writes it)
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
     hqprice::DeviceSweeper *pricer = nullptr;  // k_price_sweep: the block sweeps of the coupled placement (csrc/price.hip); HQTICK_PRICE=0 keeps coupled ticks on the host search
     uint32_t block_budget = 4096, block_min_classes = 12;  // k_block_solve: search steps per class before the host solver takes it; classes below which the host solves alone
@@ -382,7 +382,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
     const uint32_t W = s->n_workers, R = s->n_resources, Q = s->n_requests;
     const uint64_t N = ctx->n_ready;
     sc->Q = Q; sc->L = 0; sc->G = 0; sc->levels.clear(); sc->hist.clear();
-    if (!ctx->d_set.ensure((size_t)hqk::PRIO_SET_CAP * 8) || !ctx->d_flags.ensure(64) || !ctx->d_levels.ensure((size_t)(hqk::MAX_LEVELS + 2) * 8) || !ctx->d_nlevels.ensure(16))
+    if (!ctx->d_set.ensure((size_t)(hqk::PRIO_SET_CAP + hqk::MAX_LEVELS) * 8) || !ctx->h_lv.ensure((size_t)(hqk::MAX_LEVELS + 4) * 8) || !ctx->d_flags.ensure(64) || !ctx->d_levels.ensure((size_t)(hqk::MAX_LEVELS + 2) * 8) || !ctx->d_nlevels.ensure(16))
         return fail(ctx, HQTICK_E_DEVICE, "hipMalloc phase A");
     const bool scan = N != 0 && Q != 0;
     const uint32_t nvs = Q ? s->rq_variant_off[Q] : 0;
@@ -398,17 +398,16 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
                 HQ_HIP(hqk::distinct_priorities(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream));
                 levels_fresh = true;
                 HQ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-                HQ_HIP(hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->stream));
-                uint32_t flags[4] = {0, 0, 0, 0};
-                HQ_HIP(hipMemcpyAsync(&L, ctx->d_nlevels.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-                HQ_HIP(hipMemcpyAsync(flags, ctx->d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+                // (the sort kernel writes count, flags and the table straight into pinned memory and clears the flag words for the scan: one synchronisation, no copy)
+                volatile uint32_t *hl = ctx->h_lv.as<uint32_t>();
+                hl[0] = 0; hl[1] = 0; hl[2] = 0;
+                HQ_HIP(hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->h_lv.dev<uint64_t>(), ctx->stream));
                 HQ_HIP(hipStreamSynchronize(ctx->stream));
+                L = hl[0];
+                const uint32_t flags[2] = {hl[1], hl[2]};
                 if (flags[1] || L == 0xFFFFFFFFu || L > hqk::MAX_LEVELS) return fail(ctx, HQTICK_E_CAPACITY, "more than 4096 distinct priority levels in the ready set");
                 if (L == 0) return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level");
-                ctx->h_levels.resize(L);
-                HQ_HIP(hipMemcpyAsync(ctx->h_levels.data(), ctx->d_levels.p, (size_t)L * 8, hipMemcpyDeviceToHost, ctx->stream));
-                HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
-                HQ_HIP(hipStreamSynchronize(ctx->stream));
+                ctx->h_levels.assign(ctx->h_lv.as<uint64_t>() + 2, ctx->h_lv.as<uint64_t>() + 2 + L);
                 float ms = 0;
                 if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->stats.distinct_us = ms * 1000.0;
                 ctx->levels_valid = true; ctx->cached_L = L;
@@ -1379,7 +1378,7 @@ void hqtick_destroy(hqtick_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->comm) { rccl_destroy_comm(ctx); }
     ctx->graph.release();
-    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_addp.release(); ctx->h_retr.release(); ctx->h_blk.release(); ctx->h_blkprof.release(); ctx->h_k5a.release();
+    ctx->h_up.release(); ctx->h_up2.release(); ctx->h_q.release(); ctx->h_a.release(); ctx->h_plan.release(); ctx->h_rec.release(); ctx->h_sinkhdr.release(); ctx->h_add.release(); ctx->h_addp.release(); ctx->h_retr.release(); ctx->h_blk.release(); ctx->h_blkprof.release(); ctx->h_k5a.release(); ctx->h_lv.release();
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);

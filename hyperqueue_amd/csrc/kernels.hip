@@ -59,15 +59,20 @@ __device__ __forceinline__ uint32_t level_of(const uint64_t *lv, uint32_t L, uin
 }
 
 // ------------------------------------------------------------------------------------------------ K0
+static const uint32_t LEVEL_CAP = hqk::MAX_LEVELS;  // distinct priority levels one tick can carry (32 KiB of LDS in k_sort_levels; the compact list behind the set)
 __global__ void __launch_bounds__(256) k_distinct_priorities(const uint64_t *__restrict__ prio, const uint32_t *__restrict__ rq, uint64_t n,
                                                              uint64_t *__restrict__ set, uint32_t *__restrict__ flags) {
     __shared__ unsigned long long cache[256];  // block-local claim table: one wave per block publishes a given value
     for (int i = threadIdx.x; i < 256; i += blockDim.x) cache[i] = PRIO_EMPTY;
     __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t rounds = (n + 4 * stride - 1) / (4 * stride);
-    uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint64_t r = 0; r < rounds; r++, i0 += 4 * stride) {
+    // Workgroup b reads the tasks [1024 b, 1024 b + 1024) — the very range workgroup b of K1 (k_level_hist: four wavefronts x 256 tasks) reads next, and workgroups are
+    // dealt to the XCDs round-robin by their index: a tick that has to rediscover its levels leaves every slice of the priority / request columns in the L2 of the XCD
+    // that scans it a moment later.  (Grid-stride over the whole array, as this kernel was until round 6, spread every XCD's reads over all slices: K1 behind it took
+    // 7.6 us against 5.5 behind nothing — profiles/r06.)
+    const uint64_t stride = 256;
+    const uint64_t rounds = 1;
+    uint64_t i0 = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    for (uint64_t r = 0; r < rounds; r++) {
         uint64_t pv[4];
         bool av[4];
 #pragma unroll
@@ -97,6 +102,10 @@ __global__ void __launch_bounds__(256) k_distinct_priorities(const uint64_t *__r
                             if (cur == lead) { done = true; break; }
                             if (cur == PRIO_EMPTY) {
                                 uint64_t old = atomicCAS((unsigned long long *)&set[slot], (unsigned long long)PRIO_EMPTY, (unsigned long long)lead);
+                                if (old == PRIO_EMPTY) {  // this lane put the value into the set: it also goes onto the compact list behind the set (what k_sort_levels reads)
+                                    const uint32_t k = atomicAdd(&flags[3], 1u);
+                                    if (k < LEVEL_CAP) set[PRIO_SET_CAP + k] = lead;
+                                }
                                 if (old == PRIO_EMPTY || old == lead) { done = true; break; }
                             }
                             slot = (slot + 1) & (PRIO_SET_CAP - 1);
@@ -112,26 +121,23 @@ __global__ void __launch_bounds__(256) k_distinct_priorities(const uint64_t *__r
 }
 
 // ------------------------------------------------------------------------------------------------ K0b
-static const uint32_t LEVEL_CAP = hqk::MAX_LEVELS;  // distinct priority levels one tick can carry (32 KiB of LDS)
 
-__global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict__ set, const uint32_t *__restrict__ flags,
-                                                      uint64_t *__restrict__ levels, uint32_t *__restrict__ n_levels) {
+__global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict__ set, uint32_t *__restrict__ flags,
+                                                      uint64_t *__restrict__ levels, uint32_t *__restrict__ n_levels, uint64_t *__restrict__ host_out) {
+    // The distinct values arrive as a compact list behind the set (k_distinct_priorities appends a value when it inserts it; flags[3] counts them): a tick with three
+    // levels sorts three values instead of scanning the 32 768 slots of the set (11.8 -> ~3 us: round 6 — the cold headline pays for this kernel on every tick).
+    // Out: the level table in HBM (K1 reads it) AND, when host_out is given (pinned, device-mapped), [n_levels | flags[0] | flags[1]] + the table straight into host
+    // memory — one stream synchronisation instead of three copies and two; the flag words are cleared for the scan that follows.
     extern __shared__ uint64_t lv[];  // LEVEL_CAP entries
-    __shared__ uint32_t cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    for (uint32_t i = threadIdx.x; i < LEVEL_CAP; i += blockDim.x) lv[i] = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < PRIO_SET_CAP; i += blockDim.x) {
-        uint64_t v = set[i];
-        if (v != PRIO_EMPTY) {
-            uint32_t k = atomicAdd(&cnt, 1u);
-            if (k < LEVEL_CAP) lv[k] = v;
-        }
+    const uint32_t n = flags[3], f0 = flags[0], f1 = flags[1];
+    __syncthreads();   // (every thread has read the flag words before thread 0 clears them at the end)
+    if (n > LEVEL_CAP) {
+        if (threadIdx.x == 0) { n_levels[0] = 0xFFFFFFFFu; if (host_out) { reinterpret_cast<uint32_t *>(host_out)[0] = 0xFFFFFFFFu; reinterpret_cast<uint32_t *>(host_out)[1] = f0; reinterpret_cast<uint32_t *>(host_out)[2] = f1; } flags[0] = flags[1] = flags[2] = flags[3] = 0; }
+        return;
     }
-    __syncthreads();
-    uint32_t n = cnt;
-    if (n > LEVEL_CAP) { if (threadIdx.x == 0) n_levels[0] = 0xFFFFFFFFu; return; }
     uint32_t P = 1; while (P < n) P <<= 1;
+    for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) lv[i] = i < n ? set[PRIO_SET_CAP + i] : 0;
+    __syncthreads();
     // bitonic sort, descending; the zero padding sinks to the end
     for (uint32_t k = 2; k <= P; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -146,9 +152,14 @@ __global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict
             __syncthreads();
         }
     }
-    uint32_t shift = (flags[0] & 1u) ? 1u : 0u;  // Priority == u64::MAX present: it is the top level
-    if (threadIdx.x == 0) { if (shift) levels[0] = PRIO_EMPTY; n_levels[0] = n + shift; }
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) levels[i + shift] = lv[i];
+    uint32_t shift = (f0 & 1u) ? 1u : 0u;  // Priority == u64::MAX present: it is the top level
+    if (threadIdx.x == 0) {
+        if (shift) { levels[0] = PRIO_EMPTY; if (host_out) host_out[2] = PRIO_EMPTY; }
+        n_levels[0] = n + shift;
+        if (host_out) { reinterpret_cast<uint32_t *>(host_out)[0] = n + shift; reinterpret_cast<uint32_t *>(host_out)[1] = f0; reinterpret_cast<uint32_t *>(host_out)[2] = f1; reinterpret_cast<uint32_t *>(host_out)[3] = 0; }
+        flags[0] = flags[1] = flags[2] = flags[3] = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { levels[i + shift] = lv[i]; if (host_out) host_out[2 + i + shift] = lv[i]; }
 }
 
 // ------------------------------------------------------------------------------------------------ K2
@@ -1000,14 +1011,13 @@ __global__ void __launch_bounds__(256) k_check_sorted(const uint64_t *__restrict
 // ================================================================================================ host wrappers
 hipError_t distinct_priorities(const uint64_t *prio, const uint32_t *rq, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    uint64_t blocks = (n + 1023) / 1024;
-    if (blocks > 512) blocks = 512;  // two blocks per CU: every block publishes each distinct value once, so fewer blocks = fewer same-address atomics
+    uint64_t blocks = (n + 1023) / 1024;  // K1's geometry (see the kernel): one workgroup per 1024 tasks; every workgroup publishes each distinct value once (a read of the set's slot, mostly)
     hipLaunchKernelGGL(k_distinct_priorities, dim3((unsigned)blocks), dim3(256), 0, s, prio, rq, n, set, flags);
     return hipGetLastError();
 }
 
-hipError_t sort_levels(const uint64_t *set, const uint32_t *flags, uint64_t *levels, uint32_t *n_levels, hipStream_t s) {
-    hipLaunchKernelGGL(k_sort_levels, dim3(1), dim3(1024), LEVEL_CAP * 8, s, set, flags, levels, n_levels);
+hipError_t sort_levels(const uint64_t *set, uint32_t *flags, uint64_t *levels, uint32_t *n_levels, uint64_t *host_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sort_levels, dim3(1), dim3(1024), LEVEL_CAP * 8, s, set, flags, levels, n_levels, host_out);
     return hipGetLastError();
 }
 
