@@ -92,7 +92,7 @@ struct hqtick_ctx {
     uint64_t add_staged_n = 0;  // tasks hqtick_ready_add_stage made room for (0: nothing staged)
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
-    bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true, timing_k1 = false;  // (timing_k1: events around K1 alone, hqtick_set_kernel_timing(ctx, 2))  // level table of the previous tick (re-validated by K1 every tick)
+    uint32_t lv_seq = 0; bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true, timing_k1 = false;  // (timing_k1: events around K1 alone, hqtick_set_kernel_timing(ctx, 2))  // level table of the previous tick (re-validated by K1 every tick)
     PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_addp, h_retr, h_blk, h_k5a, h_lv;   // (h_lv: the level table as k_sort_levels writes it)
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
     hqprice::DeviceSweeper *pricer = nullptr;  // k_price_sweep: the block sweeps of the coupled placement (csrc/price.hip); HQTICK_PRICE=0 keeps coupled ticks on the host search
@@ -400,16 +400,23 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
                 HQ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
                 // (the sort kernel writes count, flags and the table straight into pinned memory and clears the flag words for the scan: one synchronisation, no copy)
                 volatile uint32_t *hl = ctx->h_lv.as<uint32_t>();
-                hl[0] = 0; hl[1] = 0; hl[2] = 0;
-                HQ_HIP(hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->h_lv.dev<uint64_t>(), ctx->stream));
-                HQ_HIP(hipStreamSynchronize(ctx->stream));
+                const uint32_t lv_seq = ++ctx->lv_seq ? ctx->lv_seq : ++ctx->lv_seq;   // (never 0)
+                hl[0] = 0; hl[1] = 0; hl[2] = 0; hl[3] = 0;
+                HQ_HIP(hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->h_lv.dev<uint64_t>(), lv_seq, ctx->stream));
+                {   // wait on the kernel's own completion word (the stream synchronisation is the fallback after 2 s)
+                    const double w0 = now_us();
+                    for (uint64_t spins = 0;; spins++) {
+                        if (__atomic_load_n(&ctx->h_lv.as<uint32_t>()[3], __ATOMIC_ACQUIRE) == lv_seq) break;
+                        if ((spins & 0xFFFF) == 0xFFFF && now_us() - w0 > 2.0e6) { HQ_HIP(hipStreamSynchronize(ctx->stream)); if (__atomic_load_n(&ctx->h_lv.as<uint32_t>()[3], __ATOMIC_ACQUIRE) != lv_seq) return fail(ctx, HQTICK_E_DEVICE, "level discovery did not complete"); break; }
+                    }
+                }
                 L = hl[0];
                 const uint32_t flags[2] = {hl[1], hl[2]};
                 if (flags[1] || L == 0xFFFFFFFFu || L > hqk::MAX_LEVELS) return fail(ctx, HQTICK_E_CAPACITY, "more than 4096 distinct priority levels in the ready set");
                 if (L == 0) return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level");
                 ctx->h_levels.assign(ctx->h_lv.as<uint64_t>() + 2, ctx->h_lv.as<uint64_t>() + 2 + L);
                 float ms = 0;
-                if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->stats.distinct_us = ms * 1000.0;
+                if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess || (hipEventSynchronize(ctx->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess)) ctx->stats.distinct_us = ms * 1000.0;  // (the kernel behind ev[1] has finished: the wait, if the runtime has not noticed yet, is short)
                 ctx->levels_valid = true; ctx->cached_L = L;
             }
             L = ctx->cached_L;

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) k_distinct_priorities(const uint64_t *__r
 // ------------------------------------------------------------------------------------------------ K0b
 
 __global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict__ set, uint32_t *__restrict__ flags,
-                                                      uint64_t *__restrict__ levels, uint32_t *__restrict__ n_levels, uint64_t *__restrict__ host_out) {
+                                                      uint64_t *__restrict__ levels, uint32_t *__restrict__ n_levels, uint64_t *__restrict__ host_out, uint32_t seq) {
     // The distinct values arrive as a compact list behind the set (k_distinct_priorities appends a value when it inserts it; flags[3] counts them): a tick with three
     // levels sorts three values instead of scanning the 32 768 slots of the set (11.8 -> ~3 us: round 6 — the cold headline pays for this kernel on every tick).
     // Out: the level table in HBM (K1 reads it) AND, when host_out is given (pinned, device-mapped), [n_levels | flags[0] | flags[1]] + the table straight into host
@@ -132,7 +132,10 @@ __global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict
     const uint32_t n = flags[3], f0 = flags[0], f1 = flags[1];
     __syncthreads();   // (every thread has read the flag words before thread 0 clears them at the end)
     if (n > LEVEL_CAP) {
-        if (threadIdx.x == 0) { n_levels[0] = 0xFFFFFFFFu; if (host_out) { reinterpret_cast<uint32_t *>(host_out)[0] = 0xFFFFFFFFu; reinterpret_cast<uint32_t *>(host_out)[1] = f0; reinterpret_cast<uint32_t *>(host_out)[2] = f1; } flags[0] = flags[1] = flags[2] = flags[3] = 0; }
+        if (threadIdx.x == 0) {
+            n_levels[0] = 0xFFFFFFFFu; flags[0] = flags[1] = flags[2] = flags[3] = 0;
+            if (host_out) { uint32_t *ho = reinterpret_cast<uint32_t *>(host_out); ho[0] = 0xFFFFFFFFu; ho[1] = f0; ho[2] = f1; __threadfence_system(); __hip_atomic_store(&ho[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
         return;
     }
     uint32_t P = 1; while (P < n) P <<= 1;
@@ -156,10 +159,15 @@ __global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict
     if (threadIdx.x == 0) {
         if (shift) { levels[0] = PRIO_EMPTY; if (host_out) host_out[2] = PRIO_EMPTY; }
         n_levels[0] = n + shift;
-        if (host_out) { reinterpret_cast<uint32_t *>(host_out)[0] = n + shift; reinterpret_cast<uint32_t *>(host_out)[1] = f0; reinterpret_cast<uint32_t *>(host_out)[2] = f1; reinterpret_cast<uint32_t *>(host_out)[3] = 0; }
+        if (host_out) { reinterpret_cast<uint32_t *>(host_out)[0] = n + shift; reinterpret_cast<uint32_t *>(host_out)[1] = f0; reinterpret_cast<uint32_t *>(host_out)[2] = f1; }
         flags[0] = flags[1] = flags[2] = flags[3] = 0;
     }
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { levels[i + shift] = lv[i]; if (host_out) host_out[2 + i + shift] = lv[i]; }
+    if (host_out) {   // the completion word last (system-scope release): the host spins on it instead of synchronising the stream (~3 us against ~10: the GPU sits idle meanwhile)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&reinterpret_cast<uint32_t *>(host_out)[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K2
@@ -1016,8 +1024,8 @@ hipError_t distinct_priorities(const uint64_t *prio, const uint32_t *rq, uint64_
     return hipGetLastError();
 }
 
-hipError_t sort_levels(const uint64_t *set, uint32_t *flags, uint64_t *levels, uint32_t *n_levels, uint64_t *host_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_sort_levels, dim3(1), dim3(1024), LEVEL_CAP * 8, s, set, flags, levels, n_levels, host_out);
+hipError_t sort_levels(const uint64_t *set, uint32_t *flags, uint64_t *levels, uint32_t *n_levels, uint64_t *host_out, uint32_t seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_sort_levels, dim3(1), dim3(1024), LEVEL_CAP * 8, s, set, flags, levels, n_levels, host_out, seq);
     return hipGetLastError();
 }
 
