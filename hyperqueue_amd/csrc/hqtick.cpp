@@ -92,7 +92,7 @@ struct hqtick_ctx {
     uint64_t add_staged_n = 0;  // tasks hqtick_ready_add_stage made room for (0: nothing staged)
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
-    uint32_t lv_seq = 0; bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true, timing_k1 = false;  // (timing_k1: events around K1 alone, hqtick_set_kernel_timing(ctx, 2))  // level table of the previous tick (re-validated by K1 every tick)
+    uint32_t lv_seq = 0; bool no_spec_scan = getenv("HQTICK_NO_SPEC_SCAN") != nullptr; bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true, timing_k1 = false;  // (timing_k1: events around K1 alone, hqtick_set_kernel_timing(ctx, 2))  // level table of the previous tick (re-validated by K1 every tick)
     PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_addp, h_retr, h_blk, h_k5a, h_lv;   // (h_lv: the level table as k_sort_levels writes it)
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
     hqprice::DeviceSweeper *pricer = nullptr;  // k_price_sweep: the block sweeps of the coupled placement (csrc/price.hip); HQTICK_PRICE=0 keeps coupled ticks on the host search
@@ -390,6 +390,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
     for (int attempt = 0; attempt < 2; attempt++) {
         uint32_t L = 0;
         bool levels_fresh = false;  // the level table was (re)built by this attempt
+        bool spec = false;          // ... and the scan was launched behind the discovery without waiting for it (sized for four levels)
         if (scan) {
             if (!ctx->levels_valid) {
                 HQ_HIP(hipMemsetAsync(ctx->d_set.p, 0xFF, (size_t)hqk::PRIO_SET_CAP * 8, ctx->stream));
@@ -403,6 +404,13 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
                 const uint32_t lv_seq = ++ctx->lv_seq ? ctx->lv_seq : ++ctx->lv_seq;   // (never 0)
                 hl[0] = 0; hl[1] = 0; hl[2] = 0; hl[3] = 0;
                 HQ_HIP(hqk::sort_levels(ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->d_levels.as<uint64_t>(), ctx->d_nlevels.as<uint32_t>(), ctx->h_lv.dev<uint64_t>(), lv_seq, ctx->stream));
+                // SPECULATIVE SCAN (round 6): with at most 4 levels x Q <= 64 groups — the variant of K1 the BASELINE ticks run — the scan is launched right behind the
+                // discovery, sized for four levels, and reads the table and its length from HBM (kernels.h: level_hist, n_levels_dev): no host round trip, no idle GPU
+                // between the two (K1 behind a 15-33 us gap took 6.4-7.2 us against 5.5, profiles/r06).  More than four levels: K1 refuses, the table is read below
+                // and this loop's second pass launches the general variant.
+                spec = attempt == 0 && (uint64_t)4 * Q <= 64 && !ctx->no_spec_scan;
+                if (spec) L = 4;   // (levels_valid stays false until the table has been read, after the scan)
+                else
                 {   // wait on the kernel's own completion word (the stream synchronisation is the fallback after 2 s)
                     const double w0 = now_us();
                     for (uint64_t spins = 0;; spins++) {
@@ -410,16 +418,19 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
                         if ((spins & 0xFFFF) == 0xFFFF && now_us() - w0 > 2.0e6) { HQ_HIP(hipStreamSynchronize(ctx->stream)); if (__atomic_load_n(&ctx->h_lv.as<uint32_t>()[3], __ATOMIC_ACQUIRE) != lv_seq) return fail(ctx, HQTICK_E_DEVICE, "level discovery did not complete"); break; }
                     }
                 }
+                if (!spec) {
                 L = hl[0];
                 const uint32_t flags[2] = {hl[1], hl[2]};
                 if (flags[1] || L == 0xFFFFFFFFu || L > hqk::MAX_LEVELS) return fail(ctx, HQTICK_E_CAPACITY, "more than 4096 distinct priority levels in the ready set");
                 if (L == 0) return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level");
                 ctx->h_levels.assign(ctx->h_lv.as<uint64_t>() + 2, ctx->h_lv.as<uint64_t>() + 2 + L);
+                }
                 float ms = 0;
+                if (!spec)
                 if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess || (hipEventSynchronize(ctx->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess)) ctx->stats.distinct_us = ms * 1000.0;  // (the kernel behind ev[1] has finished: the wait, if the runtime has not noticed yet, is short)
-                ctx->levels_valid = true; ctx->cached_L = L;
+                if (!spec) { ctx->levels_valid = true; ctx->cached_L = L; }
             }
-            L = ctx->cached_L;
+            L = spec ? 4u : ctx->cached_L;
             uint64_t G64 = (uint64_t)L * Q;
             if (G64 > hqk::MAX_GROUPS) return fail(ctx, HQTICK_E_CAPACITY, "levels x requests exceeds 16384 groups");
             sc->L = L; sc->G = (uint32_t)G64;
@@ -448,8 +459,8 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
             if (ctx->timing || ctx->timing_k1) hqk::time_next_launch(ctx->ev[2], ctx->ev[3]);
             if (ctx->k2_own_stream) HQ_HIP(hqk::worker_eval(uv.total, uv.free_, uv.rem, W, R, uv.rt, uv.n_entries, hd + o_fl, reinterpret_cast<uint32_t *>(hd + o_tmc), ctx->stream2));
             HQ_HIP_TIMED(hqk::level_hist(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_levels.as<uint64_t>(), ctx->h_levels.data(), L, Q, g, ctx->d_wave_tab.as<uint32_t>(),
-                                   ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->k2_on_hist ? &wea : nullptr, ctx->stream));
-            hqk::time_next_launch(ctx->timing ? ctx->ev[0] : nullptr, ctx->ev[8]);  // ev[8]: K1b's completion — what the host waits on below
+                                   ctx->d_gkey.as<uint16_t>(), ctx->d_flags.as<uint32_t>() + 2, ctx->k2_on_hist ? &wea : nullptr, ctx->stream, spec ? ctx->d_nlevels.as<uint32_t>() : nullptr));
+            hqk::time_next_launch((ctx->timing && !spec) ? ctx->ev[0] : nullptr, ctx->ev[8]);  // ev[8]: K1b's completion — what the host waits on below
             HQ_HIP_LAST(hqk::scan_waves(ctx->d_wave_tab.as<uint32_t>(), g, sc->G, reinterpret_cast<uint32_t *>(hd + o_hist), ctx->d_flags.as<uint32_t>() + 2,
                                    reinterpret_cast<uint32_t *>(hd) + 2, ctx->stream, (ctx->k2_own_stream || ctx->k2_on_hist) ? nullptr : &wea), scan_is_last);
             if (s->n_retracting) scan_is_last = false;  // k_rank_of follows
@@ -469,6 +480,18 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
         if (scan && scan_is_last) HQ_HIP(hipEventSynchronize(ctx->ev[8])); else HQ_HIP(hipStreamSynchronize(ctx->stream));
         if (scan && ctx->k2_own_stream) HQ_HIP(hipStreamSynchronize(ctx->stream2));
         const uint32_t *flags = reinterpret_cast<const uint32_t *>(h);
+        if (spec) {   // the discovery's own results, now that everything behind it has finished too
+            const uint32_t *hl = ctx->h_lv.as<uint32_t>();
+            const uint32_t La = hl[0];
+            if (hl[2] || La == 0xFFFFFFFFu || La > hqk::MAX_LEVELS) { ctx->levels_valid = false; return fail(ctx, HQTICK_E_CAPACITY, "more than 4096 distinct priority levels in the ready set"); }
+            if (La == 0) { ctx->levels_valid = false; return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level"); }
+            ctx->h_levels.assign(ctx->h_lv.as<uint64_t>() + 2, ctx->h_lv.as<uint64_t>() + 2 + La);
+            ctx->levels_valid = true; ctx->cached_L = La;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->stats.distinct_us = ms * 1000.0;
+            if ((flags[2] & 4u) || La > 4) continue;   // more levels than the speculative launch was sized for: the table is known now, scan again with the right variant
+            sc->L = La; sc->G = La * Q;                // (group keys and the rows of the per-slice table do not depend on how many levels the launch was sized for)
+        }
         if (scan && (flags[2] & 2u)) return fail(ctx, HQTICK_E_INVALID, "ready set holds a request id >= n_requests");
         if (scan && (flags[2] & 1u)) {  // a priority the cached level table does not know: rebuild the table once
             ctx->levels_valid = false;
@@ -488,7 +511,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
                 if (tot == 0) ctx->levels_valid = false;
             }
             if (ctx->timing || ctx->timing_k1) { const double us_ = elapsed_us(ctx->ev[2], ctx->ev[3]); if (us_ >= 0) ctx->stats.level_hist_us = us_; }
-            if (ctx->timing) { const double us_ = elapsed_us(ctx->ev[0], ctx->ev[8]); if (us_ >= 0) ctx->stats.scan_us = us_; }
+            if (ctx->timing && !spec) { const double us_ = elapsed_us(ctx->ev[0], ctx->ev[8]); if (us_ >= 0) ctx->stats.scan_us = us_; }  // (a speculative scan shares ev[0] with the discovery: K1b untimed on that tick)
         }
         return 0;
     }

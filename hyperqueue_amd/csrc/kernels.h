@@ -42,7 +42,10 @@ hipError_t sort_levels(const uint64_t *set, uint32_t *flags, uint64_t *levels, u
 // the kernel arguments when L <= 4, so the common case needs neither a staging load nor a barrier).
 struct WorkerEvalArgs;  // K2 riding along (below)
 hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, const uint64_t *levels_host, uint32_t L,
-                uint32_t Q, WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, const WorkerEvalArgs *ride_along, hipStream_t s);
+                uint32_t Q, WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, const WorkerEvalArgs *ride_along, hipStream_t s,
+                const uint32_t *n_levels_dev = nullptr);
+// n_levels_dev (device, may be NULL): the launch does not know the level table yet — k_sort_levels is still ahead of it on the stream.  L is then the bound the launch
+// is sized for (<= 4), the kernel reads the count and the table from HBM and sets bit 4 of err_flag if there are more levels than that (or none).
 // K1b: exclusive scan of every wave_tab row (in place -> offsets) and the row totals into hist[G].
 // err_in (device) is forwarded to err_out (may be pinned host memory) by the same launch.
 hipError_t empty_like_level_hist(WaveGeom geom, hipStream_t s);  // an empty kernel of K1's grid (calibration of the per-dispatch timing)

@@ -246,13 +246,23 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
                                                          const uint64_t *__restrict__ levels, Levels4 l4, uint32_t L, uint32_t Q,
                                                          uint32_t tasks_per_wave, uint32_t n_waves, uint32_t stride, uint32_t lds_levels,
                                                          uint32_t *__restrict__ wave_tab, uint16_t *__restrict__ gkey,
-                                                         uint32_t *__restrict__ err_flag, uint32_t n_eval_blocks, EvalArgs ea) {
+                                                         uint32_t *__restrict__ err_flag, uint32_t n_eval_blocks, EvalArgs ea,
+                                                         const uint32_t *__restrict__ n_levels_dev) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (blockIdx.x < n_eval_blocks) {  // ride-along workgroups (dispatched first): K2, whose PCIe round trips hide under the scan
         worker_eval_block(smem, blockIdx.x, ea);
         return;
     }
     const uint32_t hist_block = blockIdx.x - n_eval_blocks;
+    if (SMALL_L && n_levels_dev) {
+        // Launched right behind the level discovery, before the host has seen its result (a tick that rediscovers its levels: round 6): the table and its length come
+        // from HBM — k_sort_levels has just written them — and `L` is only the bound the launch was sized for (4).  More levels than that: the scan refuses (err bit 4),
+        // the host reads the table and launches the general variant.  Uniform scalar loads, a few hundred ns; no host round trip between discovery and scan.
+        const uint32_t Ld = n_levels_dev[0];
+        if (Ld == 0 || Ld > L) { if (hist_block == 0 && threadIdx.x == 0) atomicOr(err_flag, 4u); return; }
+        L = Ld;
+        for (uint32_t i = 0; i < 4; i++) l4.v[i] = i < Ld ? levels[i] : 0;
+    }
     const uint32_t G = L * Q;
     uint64_t *s_levels = reinterpret_cast<uint64_t *>(smem);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)(SMALL_L ? 0 : lds_levels) * 8) + (threadIdx.x >> 6) * G * NCOPY;
@@ -1102,13 +1112,14 @@ hipError_t empty_like_level_hist(WaveGeom geom, hipStream_t s) {
 }
 
 hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, const uint64_t *levels, const uint64_t *levels_host, uint32_t L, uint32_t Q,
-                WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, const WorkerEvalArgs *ride_along, hipStream_t s) {
+                WaveGeom geom, uint32_t *wave_tab, uint16_t *gkey, uint32_t *err_flag, const WorkerEvalArgs *ride_along, hipStream_t s, const uint32_t *n_levels_dev) {
     if (n == 0 || geom.n_waves == 0) return hipSuccess;
     const uint32_t G = L * Q;
-    const bool small = L <= 4 && levels_host != nullptr;
+    if (n_levels_dev && (L > 4 || G > 64 || geom.waves_per_block != 4)) return hipErrorInvalidValue;   // (the speculative launch exists for the small variant only)
+    const bool small = L <= 4 && (levels_host != nullptr || n_levels_dev != nullptr);
     const uint32_t ll = small ? 0 : lds_levels_for(L);
     Levels4 l4{};
-    if (small) for (uint32_t i = 0; i < L; i++) l4.v[i] = levels_host[i];
+    if (small && !n_levels_dev) for (uint32_t i = 0; i < L; i++) l4.v[i] = levels_host[i];
     EvalArgs ea{};
     uint32_t neb = 0; size_t eval_lds = 0;
     if (ride_along && ride_along->W && ride_along->rt.n_variants) {
@@ -1123,7 +1134,7 @@ hipError_t level_hist(const uint64_t *prio, const uint32_t *rq, uint64_t n, cons
         auto kern = k_level_hist<WPB, SMALL, NCOPY>;                                                                                                        \
         if (lds > 48 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e; \
         HQK_TIMED_LAUNCH(kern, dim3((GRID) + neb), dim3(BLOCK), lds, s, prio, rq, n, levels, l4, L, Q, geom.tasks_per_wave, geom.n_waves, geom.tab_stride, ll, wave_tab, gkey, \
-                           err_flag, neb, ea);                                                                                                       \
+                           err_flag, neb, ea, n_levels_dev);                                                                                                       \
     } while (0)
     if (geom.waves_per_block == 4) {
         if (small && G <= 64) HQK_LAUNCH_HIST(4, true, 8, (geom.n_waves + 3) / 4, 256);  // a handful of groups: eight copies of the counter row (8 KB of LDS at most)

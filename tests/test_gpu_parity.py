@@ -447,3 +447,37 @@ def test_c3p_full_sharded_replicas_agree():
     finally:
         t.close()
     assert plain.counts == results[0].counts and records == plain.records and (plain.new_free == results[0].new_free).all()
+
+
+@pytest.mark.parametrize("n_levels,n_classes", [(1, 8), (3, 8), (4, 8), (5, 8), (9, 3), (3, 20), (70, 8)])
+def test_a_tick_that_discovers_its_levels_scans_right_behind_the_discovery(n_levels, n_classes, oracle, monkeypatch):
+    """Round 6: a tick without a level table (the first tick on a ready set; every tick under HQTICK_FLAG_NO_TICK_CACHES) launches K1 behind the discovery kernels
+    without waiting for them, sized for four levels, and K1 reads the table from HBM.  <= 4 levels x <= 16 requests: that scan stands.  More levels: K1 refuses, the
+    tick reads the table and scans again with the general variant.  More than 16 requests: no speculation.  Either way the answer is the oracle's — and the same as
+    with the speculation switched off (HQTICK_NO_SPEC_SCAN), on the first tick and on the second."""
+    from hyperqueue_amd.core import priority_from_user
+
+    snap = workloads.make("c3", seed=5, n_tasks=6_000, n_workers=6)
+    rng = np.random.default_rng(n_levels * 100 + n_classes)
+    if n_classes != 8:   # requests cpus = 1 .. n_classes, so that Q differs from the c3 table
+        snap.requests = [[workloads._variant([(0, 1 + (q % 4))])] for q in range(n_classes)]
+    snap.task_rq = rng.integers(0, n_classes, len(snap.task_id)).astype(np.uint32)
+    snap.task_priority = np.asarray([priority_from_user(int(p)) for p in rng.integers(0, n_levels, len(snap.task_id))], np.uint64)
+    want = oracle.tick(snap)
+    outs = []
+    for no_spec in (False, True):
+        if no_spec:
+            monkeypatch.setenv("HQTICK_NO_SPEC_SCAN", "1")
+        else:
+            monkeypatch.delenv("HQTICK_NO_SPEC_SCAN", raising=False)
+        for flags in (0, abi.HQTICK_FLAG_NO_TICK_CACHES):
+            t = Tick(abi.make_config(time_limit_s=20.0, flags=flags))
+            try:
+                t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq, sorted_=True)
+                first = t.tick(snap, resident=True)
+                second = t.tick(snap, resident=True)
+            finally:
+                t.close()
+            assert_same(first, want)
+            assert_same(second, want)
+            outs.append(first)
