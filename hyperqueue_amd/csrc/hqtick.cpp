@@ -382,7 +382,7 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
     const uint32_t W = s->n_workers, R = s->n_resources, Q = s->n_requests;
     const uint64_t N = ctx->n_ready;
     sc->Q = Q; sc->L = 0; sc->G = 0; sc->levels.clear(); sc->hist.clear();
-    if (!ctx->d_set.ensure((size_t)(hqk::PRIO_SET_CAP + hqk::MAX_LEVELS) * 8) || !ctx->h_lv.ensure((size_t)(hqk::MAX_LEVELS + 4) * 8) || !ctx->d_flags.ensure(64) || !ctx->d_levels.ensure((size_t)(hqk::MAX_LEVELS + 2) * 8) || !ctx->d_nlevels.ensure(16))
+    if (!ctx->d_set.ensure((size_t)(hqk::PRIO_SET_CAP + hqk::MAX_LEVELS) * 8) || !ctx->h_lv.ensure((size_t)(hqk::MAX_LEVELS + 4) * 8) || !ctx->d_flags.ensure(64) || !ctx->d_levels.ensure((size_t)(hqk::MAX_LEVELS + 2) * 8) || !ctx->d_nlevels.ensure(64))   // (a 40-byte head: count + the first four levels, kernels.hip: k_sort_levels)
         return fail(ctx, HQTICK_E_DEVICE, "hipMalloc phase A");
     const bool scan = N != 0 && Q != 0;
     const uint32_t nvs = Q ? s->rq_variant_off[Q] : 0;

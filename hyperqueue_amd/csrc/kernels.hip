@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict
     __syncthreads();   // (every thread has read the flag words before thread 0 clears them at the end)
     if (n > LEVEL_CAP) {
         if (threadIdx.x == 0) {
-            n_levels[0] = 0xFFFFFFFFu; flags[0] = flags[1] = flags[2] = flags[3] = 0;
+            n_levels[0] = 0xFFFFFFFFu; n_levels[1] = 0; flags[0] = flags[1] = flags[2] = flags[3] = 0;   // (as a u64 head: 0xFFFFFFFF levels — the speculative scan refuses)
             if (host_out) { uint32_t *ho = reinterpret_cast<uint32_t *>(host_out); ho[0] = 0xFFFFFFFFu; ho[1] = f0; ho[2] = f1; __threadfence_system(); __hip_atomic_store(&ho[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
         return;
@@ -159,6 +159,11 @@ __global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict
     if (threadIdx.x == 0) {
         if (shift) { levels[0] = PRIO_EMPTY; if (host_out) host_out[2] = PRIO_EMPTY; }
         n_levels[0] = n + shift;
+        {   // the head K1's speculative launch reads in ONE round trip: [count | level 0 .. 3] as five u64 (kernels.h: level_hist, n_levels_dev)
+            uint64_t *head = reinterpret_cast<uint64_t *>(n_levels);
+            head[0] = n + shift;
+            for (uint32_t i = 0; i < 4; i++) { const uint32_t k = i - shift; head[1 + i] = (shift && i == 0) ? PRIO_EMPTY : (k < n ? lv[k] : 0); }
+        }
         if (host_out) { reinterpret_cast<uint32_t *>(host_out)[0] = n + shift; reinterpret_cast<uint32_t *>(host_out)[1] = f0; reinterpret_cast<uint32_t *>(host_out)[2] = f1; }
         flags[0] = flags[1] = flags[2] = flags[3] = 0;
     }
@@ -258,10 +263,12 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
         // Launched right behind the level discovery, before the host has seen its result (a tick that rediscovers its levels: round 6): the table and its length come
         // from HBM — k_sort_levels has just written them — and `L` is only the bound the launch was sized for (4).  More levels than that: the scan refuses (err bit 4),
         // the host reads the table and launches the general variant.  Uniform scalar loads, a few hundred ns; no host round trip between discovery and scan.
-        const uint32_t Ld = n_levels_dev[0];
+        const uint64_t *head = reinterpret_cast<const uint64_t *>(n_levels_dev);   // [count | level 0 .. 3]: five independent loads, one round trip
+        const uint64_t h0 = head[0], h1 = head[1], h2 = head[2], h3 = head[3], h4 = head[4];
+        const uint32_t Ld = (uint32_t)h0;
         if (Ld == 0 || Ld > L) { if (hist_block == 0 && threadIdx.x == 0) atomicOr(err_flag, 4u); return; }
         L = Ld;
-        for (uint32_t i = 0; i < 4; i++) l4.v[i] = i < Ld ? levels[i] : 0;
+        l4.v[0] = h1; l4.v[1] = h2; l4.v[2] = h3; l4.v[3] = h4;
     }
     const uint32_t G = L * Q;
     uint64_t *s_levels = reinterpret_cast<uint64_t *>(smem);

@@ -456,6 +456,7 @@ def test_a_tick_that_discovers_its_levels_scans_right_behind_the_discovery(n_lev
     tick reads the table and scans again with the general variant.  More than 16 requests: no speculation.  Either way the answer is the oracle's — and the same as
     with the speculation switched off (HQTICK_NO_SPEC_SCAN), on the first tick and on the second."""
     from hyperqueue_amd.core import priority_from_user
+    from hyperqueue_amd.tick import Tick
 
     snap = workloads.make("c3", seed=5, n_tasks=6_000, n_workers=6)
     rng = np.random.default_rng(n_levels * 100 + n_classes)
