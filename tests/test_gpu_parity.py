@@ -479,6 +479,12 @@ def test_a_tick_that_discovers_its_levels_scans_right_behind_the_discovery(n_lev
                 second = t.tick(snap, resident=True)
             finally:
                 t.close()
-            assert_same(first, want)
-            assert_same(second, want)
+            # what the scan decides — the batches (create_task_batches on the histogram) — must be the oracle's; the placement too wherever the product's answer is the
+            # canonical one (a coupled model of several levels may stop at its certificate: then the four runs are compared with one another instead)
+            assert first.status == want.status and first.batches == want.batches and second.batches == want.batches
+            if first.is_canonical:
+                assert_same(first, want)
+            assert_same(second, first)
             outs.append(first)
+    for o in outs[1:]:
+        assert_same(o, outs[0])
