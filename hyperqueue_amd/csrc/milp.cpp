@@ -384,14 +384,17 @@ struct CompSolver {
             const bool was_hull = added > 0;
             if (!added) { added = gmi_round(root, RC, 40 + n / 8); hull_stall = 0; }
             if (!added) { if (tracing) fprintf(stderr, "[milp] n=%d cut round %d: nothing to add\n", n, round); break; }
-            bool ok = solve_counted(root) == LP_OPT && dual_feasible(root, 1e-7);
+            // (the warm re-solve on a pivot allowance: behind block-hull cuts the vertex is highly degenerate and the dual simplex can stall for thousands of pivots — price_fuzz
+            // seed 2047: 4 300 against the ~700 a cold solve of the same rows takes; past the allowance the cold solve below takes over)
+            bool ok;
+            { const double before = root.ops; const int r = root.solve(with_hull ? std::max(600L, 3L * (long)root.ma) : 200000L); work += root.ops - before; ok = r == LP_OPT && dual_feasible(root, 1e-7); }
             if (!ok) {  // once more from a cold start over the same rows
                 root = Tab(); root.init(&RC, c, lb, ub); root.deadline = deadline;
                 ok = solve_counted(root) == LP_OPT && dual_feasible(root, 1e-7);
                 if (!ok) { if (tracing) fprintf(stderr, "[milp] n=%d cut round %d: LP not re-solved\n", n, round); break; }
             }
             const double z = root.objective();
-            if (tracing) fprintf(stderr, "[milp] n=%d cut round %d: %d %s cuts, LP bound %.9f -> %.9f (%d rows active of %d) work %.3g\n", n, round, added, kind, prev, z, root.ma, RC.m, work);
+            if (tracing) fprintf(stderr, "[milp] n=%d cut round %d: %d %s cuts, LP bound %.9f -> %.9f (%d rows active of %d) work %.3g iters %ld\n", n, round, added, kind, prev, z, root.ma, RC.m, work, (long)root.iters);
             if (was_hull && prev - z < 1e-6 * std::fabs(prev)) hull_stall++;
             if (z > accepted * (1.0 + 1e-9) + 1e-12) break;  // a bound cannot rise when rows are added: the arithmetic has gone wrong, keep what was accepted
             accepted = z;
