@@ -360,6 +360,20 @@ struct CompSolver {
     // root instead of the plain LP's, percent above it — the difference between 18 nodes and millions on small clusters mid-run); the exact /
     // canonical pass after a certificate goes back to the model's own rows.
     Rows RCm; bool rc_valid = false; double rc_bound = INF;
+    std::vector<double> cut_lp_x;   // the LP point over RCm
+    // RINS at the cut LP's point: the columns on which that point and the incumbent agree stay where they are, the rest is a small model solved exactly.  With the
+    // bound a few 1e-4 above the incumbent the two agree almost everywhere (price_fuzz seed 2056: the windows' incumbent sits 8e-5 below the optimum, 1.1e-4 below
+    // the bound — one exchange between three workers away from the certificate).
+    bool rins_at_cut_point() {
+        if (!rc_valid || !have || in_lns || (int)cut_lp_x.size() != n) return false;
+        std::vector<int> wcols;
+        for (int j = 0; j < n; j++) if (std::fabs(cut_lp_x[j] - bx[j]) > 0.5 - 1e-9 || std::fabs(cut_lp_x[j] - std::round(cut_lp_x[j])) > INT_TOL) wcols.push_back(j);
+        if (wcols.empty() || (int)wcols.size() > 160) return false;
+        const double before = best;
+        const bool imp = lns_solve(wcols, deadline, 50000);
+        if (tracing) fprintf(stderr, "[milp] n=%d RINS at the cut LP's point (%d free columns): %.9f -> %.9f\n", n, (int)wcols.size(), before, best);
+        return imp;
+    }
     // Two passes, the second only when the first leaves the model open: GMI rounds alone, then block-hull cuts with GMI rounds on top.  Neither dominates (price_fuzz
     // 2020: GMI alone names the optimum to 1e-9, with the hull cuts the rounds stall 1.6e-4 above it; 2017: GMI alone stalls 8.4e-4 above, with the hull cuts the
     // root closes) — the tree gets the rows of the pass with the lower bound.
@@ -422,7 +436,7 @@ struct CompSolver {
             if (wcols.empty()) greedy_from(base);
             else if ((int)wcols.size() <= 96) { const double before = best; lns_solve(wcols, deadline, 20000, &base); if (tracing) fprintf(stderr, "[milp] n=%d RENS at the cut LP's point (%d fractional columns): %.9f -> %.9f\n", n, (int)wcols.size(), before, best); }
         }
-        if (RC.m > R.m && tree_cuts_on && (!rc_valid || accepted < rc_bound)) { RCm = std::move(RC); rc_valid = true; rc_bound = accepted; row_unit.resize((size_t)RCm.m, 0.0); }
+        if (RC.m > R.m && tree_cuts_on && (!rc_valid || accepted < rc_bound)) { RCm = std::move(RC); rc_valid = true; rc_bound = accepted; row_unit.resize((size_t)RCm.m, 0.0); cut_lp_x.assign(root.x.begin(), root.x.begin() + n); }
     }
 
     void round_and_repair(const Tab &t) {
@@ -961,6 +975,35 @@ struct CompSolver {
     }
     long node_cap = -1;  // hard cap on the nodes of this solver (window sub-problems)
 
+    // The price sweeps as a LATE phase (round 6): a model below the sweeps' own threshold (Sweeper::min_cols: a sweep costs ~80 us whatever the block count, and the host
+    // tree is usually done first) that the host's search has NOT closed after its root cuts and a first proving phase goes to the sweeps after all — their
+    // branch-and-price bound is the decomposition bound per node, which on clusters mid-run closes what the LP + cut bound of the tree leaves open (tools/price_fuzz.py
+    // seeds 2005 / 2045: certified with the sweeps forced on, NeedMoreCompute on the product's default path).  Deterministic like the early phase: no clock inside.
+    bool swept = false;
+    bool late_sweeps() {
+        if (swept || !sweeper || in_lns || rel_gap <= 0.0 || work_limit >= 0 || n < 16 || (int)col_group.size() != n) return false;
+        for (int j = 0; j < n; j++) if (lb[j] != 0.0) return false;
+        swept = true;
+        const double tp0 = wall();
+        hqprice::Request rq;
+        rq.n = n; rq.m = R.m; rq.roff = R.off.data(); rq.rcol = R.col.data(); rq.rcoef = R.coef.data(); rq.rlo = R.lo.data(); rq.rhi = R.hi.data();
+        rq.row_scale = row_scale.data(); rq.row_implied = (int)row_implied.size() == R.m ? row_implied.data() : nullptr; rq.col_group = col_group.data();
+        rq.c = c.data(); rq.ub = ub.data(); rq.incumbent = have ? bx.data() : nullptr; rq.incumbent_value = best; rq.rel_gap = rel_gap; rq.trace = tracing; rq.time_limit_s = time_limit_s; rq.deadline_s = deadline;
+        rq.polish = [this](std::vector<double> &x, double &value) { return polish_point(x, value); };
+        const uint32_t keep_min = sweeper->min_cols;
+        sweeper->min_cols = 1;   // (the threshold was the reason this model came to the host first)
+        hqprice::Answer pa = hqprice::solve(rq, *sweeper);
+        sweeper->min_cols = keep_min;
+        price_us += (wall() - tp0) * 1e6;
+        if (tracing) fprintf(stderr, "[milp] n=%d late price sweeps: ran %d (%s) sweeps %u rounds %u bound %.9f point %.9f incumbent %.9f, %.3f ms\n", n, (int)pa.ran, pa.why, pa.sweeps, pa.rounds, pa.ran ? pa.bound : -1.0, pa.x.empty() ? -1.0 : pa.x_value, have ? best : -1.0, (wall() - tp0) * 1e3);
+        if (!pa.ran) return false;
+        price_sweeps += (int)pa.sweeps; price_rounds += (int)pa.rounds;
+        nodes += pa.sweeps;
+        if (!pa.x.empty() && (!have || pa.x_value > best)) { bx = pa.x; best = pa.x_value; have = true; }
+        root_bound = std::min(root_bound, pa.bound * (1.0 + 1e-9) + 1e-12);
+        return certified();
+    }
+
     // returns: 0 infeasible, 1 optimal, 2 incumbent only (time limit)
     int run(bool canonical, std::vector<double> &xout) {
         // (first: a model the sweeps certify needs neither the root tableau nor the greedy pass from zero below — 1.6 ms of a 3 ms tick at 8 k columns)
@@ -978,6 +1021,7 @@ struct CompSolver {
             if (lbzero) pa = hqprice::solve(rq, *sweeper);
             price_us = (wall() - tp0) * 1e6;
             if (tracing) fprintf(stderr, "[milp] n=%d price sweeps: ran %d (%s) sweeps %u rounds %u bound %.9f point %.9f incumbent %.9f, %.3f ms of which %.3f ms inside the sweeps\n", n, (int)pa.ran, pa.why, pa.sweeps, pa.rounds, pa.ran ? pa.bound : -1.0, pa.x.empty() ? -1.0 : pa.x_value, have ? best : -1.0, price_us / 1e3, sweeper->stat_sweep_us / 1e3);
+            swept = true;
             if (pa.ran) {
                 price_sweeps = (int)pa.sweeps; price_rounds = (int)pa.rounds;
                 nodes += pa.sweeps;
@@ -1064,6 +1108,7 @@ struct CompSolver {
             lns_schedule(deadline, false);  // cheap windows only (what they leave open the tree below usually closes faster than bigger windows would), until they
                                             // stall or the incumbent is certified — not until a clock says so: replicas of a sharded scheduler walk the same sequence
             lns_done = true;
+            if (!certified()) rins_at_cut_point();
         }
         const int first_strong = lns_done ? 1 : 0;  // with the windows' incumbent in hand the proof comes first, the dive (an incumbent finder) second
         auto search = [&]() {
@@ -1072,7 +1117,10 @@ struct CompSolver {
             for (int phase = 0;; phase++) {
                 strong = ((phase + first_strong) & 1) != 0;
                 trace(strong ? "strong-branching phase" : "dive phase");
-                aborted = false; node_budget = nodes + bud;
+                // (with the sweeps still to come for a small model — late_sweeps() — the first phase runs on an eighth of its budget: a model it does not close by then goes to
+                // the branch-and-price, whose per-node bound is the decomposition's; easy models never get there)
+                const bool sweeps_ahead = phase == 0 && !swept && sweeper && !in_lns && rel_gap > 0.0 && work_limit < 0 && n >= 16 && (int)col_group.size() == n;
+                aborted = false; node_budget = nodes + (sweeps_ahead ? std::max<long>(250, bud / 8) : bud);
                 if (node_cap >= 0) node_budget = std::min(node_budget, node_cap);
                 const bool on_cuts = rc_valid && rel_gap > 0.0 && work_limit < 0 && !in_lns;   // a certification phase with root cuts at hand: the tree works on the tightened rows
                 if (phase > 0 || (on_cuts && root.R != &RCm)) { lp_iters += root.iters; root = Tab(); root.init(on_cuts ? &RCm : &R, c, lb, ub); root.deadline = deadline; }
@@ -1097,6 +1145,8 @@ struct CompSolver {
                     lns_done = true;
                     if (rel_gap > 0.0 && work_limit < 0 && certified()) { cert_stop = true; break; }
                 }
+                if (phase == 0 && !certified() && rins_at_cut_point() && certified()) { cert_stop = true; break; }
+                if (phase == 0 && !swept && late_sweeps()) { cert_stop = true; break; }   // the first phase (on a shortened budget, below) has failed: the sweeps' branch-and-price before the tree gets its full budgets
                 if (phase & 1) bud *= 4;
             }
             aborted = false; strong = false; node_budget = -1;
