@@ -312,8 +312,8 @@ struct CompSolver {
         for (size_t b = 0; b < hb.cols.size(); b++) {
             const std::vector<int> &bc = hb.cols[b];
             const int nbc = (int)bc.size();
-            double lpv = 0.0, rmax = 0.0, trivial = 0.0;
-            for (int l = 0; l < nbc; l++) { const int j = bc[l]; lpv += r[j] * t.x[j]; rmax = std::max(rmax, std::fabs(r[j])); trivial += r[j] > 0.0 ? r[j] * ub[j] : r[j] * lb[j]; }
+            double lpv = 0.0, rmax = 0.0;
+            for (int l = 0; l < nbc; l++) { const int j = bc[l]; lpv += r[j] * t.x[j]; rmax = std::max(rmax, std::fabs(r[j])); }
             if (!(rmax > 1e-12)) continue;
             if (lpv <= 1e-7 * rmax) continue;   // (V_b >= r . lb-point; with lb = 0 nothing below zero can be violated)
             CompSolver sub; sub.n = nbc; sub.in_lns = true; sub.deadline = deadline; sub.node_cap = 4000; sub.tracing = false;
