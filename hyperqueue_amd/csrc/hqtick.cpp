@@ -92,7 +92,7 @@ struct hqtick_ctx {
     uint64_t add_staged_n = 0;  // tasks hqtick_ready_add_stage made room for (0: nothing staged)
     // scans
     DevBuf d_set, d_flags, d_levels, d_nlevels, d_wave_tab, d_hist, d_gkey;
-    uint32_t lv_seq = 0; bool no_spec_scan = getenv("HQTICK_NO_SPEC_SCAN") != nullptr; bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true, timing_k1 = false;  // (timing_k1: events around K1 alone, hqtick_set_kernel_timing(ctx, 2))  // level table of the previous tick (re-validated by K1 every tick)
+    uint32_t lv_seq = 0; bool set_clean = false; bool no_spec_scan = getenv("HQTICK_NO_SPEC_SCAN") != nullptr; bool levels_valid = false; uint32_t cached_L = 0; std::vector<uint64_t> h_levels; bool timing = true, timing_k1 = false;  // (timing_k1: events around K1 alone, hqtick_set_kernel_timing(ctx, 2))  // level table of the previous tick (re-validated by K1 every tick)
     PinBuf h_up, h_up2, h_q, h_a, h_plan, h_rec, h_sinkhdr, h_add, h_addp, h_retr, h_blk, h_k5a, h_lv;   // (h_lv: the level table as k_sort_levels writes it)
     PinBuf h_blkprof; uint32_t n_blkprof = 0; bool block_profile = false;
     hqprice::DeviceSweeper *pricer = nullptr;  // k_price_sweep: the block sweeps of the coupled placement (csrc/price.hip); HQTICK_PRICE=0 keeps coupled ticks on the host search
@@ -393,12 +393,18 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
         bool spec = false;          // ... and the scan was launched behind the discovery without waiting for it (sized for four levels)
         if (scan) {
             if (!ctx->levels_valid) {
-                HQ_HIP(hipMemsetAsync(ctx->d_set.p, 0xFF, (size_t)hqk::PRIO_SET_CAP * 8, ctx->stream));
-                HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
-                HQ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+                // (the set and the flag words are EMPTY / zero between ticks: k_sort_levels clears what a discovery used, the scan clears its own flag — the two fills are for
+                // the first discovery of a context and for the one after a tick that did not come back)
+                if (!ctx->set_clean) {
+                    HQ_HIP(hipMemsetAsync(ctx->d_set.p, 0xFF, (size_t)hqk::PRIO_SET_CAP * 8, ctx->stream));
+                    HQ_HIP(hipMemsetAsync(ctx->d_flags.p, 0, 64, ctx->stream));
+                }
+                ctx->set_clean = false;   // until this tick has seen the discovery's result
+                const bool time_k0 = ctx->timing;   // (two marker packets around K0: only when every kernel is timed)
+                if (time_k0) HQ_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
                 HQ_HIP(hqk::distinct_priorities(ctx->d_tprio.as<uint64_t>(), ctx->d_trq.as<uint32_t>(), N, ctx->d_set.as<uint64_t>(), ctx->d_flags.as<uint32_t>(), ctx->stream));
                 levels_fresh = true;
-                HQ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+                if (time_k0) HQ_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
                 // (the sort kernel writes count, flags and the table straight into pinned memory and clears the flag words for the scan: one synchronisation, no copy)
                 volatile uint32_t *hl = ctx->h_lv.as<uint32_t>();
                 const uint32_t lv_seq = ++ctx->lv_seq ? ctx->lv_seq : ++ctx->lv_seq;   // (never 0)
@@ -424,9 +430,10 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
                 if (flags[1] || L == 0xFFFFFFFFu || L > hqk::MAX_LEVELS) return fail(ctx, HQTICK_E_CAPACITY, "more than 4096 distinct priority levels in the ready set");
                 if (L == 0) return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level");
                 ctx->h_levels.assign(ctx->h_lv.as<uint64_t>() + 2, ctx->h_lv.as<uint64_t>() + 2 + L);
+                ctx->set_clean = true;
                 }
                 float ms = 0;
-                if (!spec)
+                if (!spec && time_k0)
                 if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess || (hipEventSynchronize(ctx->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess)) ctx->stats.distinct_us = ms * 1000.0;  // (the kernel behind ev[1] has finished: the wait, if the runtime has not noticed yet, is short)
                 if (!spec) { ctx->levels_valid = true; ctx->cached_L = L; }
             }
@@ -486,9 +493,9 @@ int phase_a(hqtick_ctx *ctx, const hqtick_snapshot *s, WorkerEval *ev, Scan *sc,
             if (hl[2] || La == 0xFFFFFFFFu || La > hqk::MAX_LEVELS) { ctx->levels_valid = false; return fail(ctx, HQTICK_E_CAPACITY, "more than 4096 distinct priority levels in the ready set"); }
             if (La == 0) { ctx->levels_valid = false; return fail(ctx, HQTICK_E_DEVICE, "level discovery returned no level"); }
             ctx->h_levels.assign(ctx->h_lv.as<uint64_t>() + 2, ctx->h_lv.as<uint64_t>() + 2 + La);
-            ctx->levels_valid = true; ctx->cached_L = La;
+            ctx->levels_valid = true; ctx->cached_L = La; ctx->set_clean = true;
             float ms = 0;
-            if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->stats.distinct_us = ms * 1000.0;
+            if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->stats.distinct_us = ms * 1000.0;
             if ((flags[2] & 4u) || La > 4) continue;   // more levels than the speculative launch was sized for: the table is known now, scan again with the right variant
             sc->L = La; sc->G = La * Q;                // (group keys and the rows of the per-slice table do not depend on how many levels the launch was sized for)
         }

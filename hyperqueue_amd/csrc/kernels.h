@@ -34,7 +34,7 @@ static const uint32_t RQ_TOMBSTONE = 0xFFFFFFFFu;  // rq column value of a task 
 // flags[0] |= 1 when some priority equals PRIO_EMPTY itself, flags[1] = 1 on overflow.
 hipError_t distinct_priorities(const uint64_t *prio, const uint32_t *rq, uint64_t n, uint64_t *set, uint32_t *flags, hipStream_t s);  // rq (may be NULL): tasks with rq == RQ_TOMBSTONE do not count
 // K0b: compact the set and sort it descending into levels[]; n_levels[0] = L.  Single workgroup.
-hipError_t sort_levels(const uint64_t *set, uint32_t *flags, uint64_t *levels, uint32_t *n_levels, uint64_t *host_out, uint32_t seq, hipStream_t s);  // set: PRIO_SET_CAP slots + the compact list of MAX_LEVELS values behind them; host_out (may be NULL): pinned, device-mapped, [n_levels u32 | flags0 u32 | flags1 u32 | seq u32 (written last, system-scope release)][levels ...]; clears flags[0..3]
+hipError_t sort_levels(uint64_t *set, uint32_t *flags, uint64_t *levels, uint32_t *n_levels, uint64_t *host_out, uint32_t seq, hipStream_t s);  // set: PRIO_SET_CAP slots + the compact list of MAX_LEVELS values behind them; host_out (may be NULL): pinned, device-mapped, [n_levels u32 | flags0 u32 | flags1 u32 | seq u32 (written last, system-scope release)][levels ...]; clears flags[0..3] AND the set's slots of the listed values (the set is EMPTY again unless it reports more than MAX_LEVELS values)
 
 // K1: per-slice histogram of (level, rq) groups.  wave_tab is [G][tab_stride] (G = L*Q, g = level*Q + rq); also writes
 // the per-task group key gkey[i] = g (GKEY_INVALID for a task whose priority / rq is not in the tables) that K4 re-reads

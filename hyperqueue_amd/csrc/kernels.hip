@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k_distinct_priorities(const uint64_t *__r
 
 // ------------------------------------------------------------------------------------------------ K0b
 
-__global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict__ set, uint32_t *__restrict__ flags,
+__global__ void __launch_bounds__(1024) k_sort_levels(uint64_t *__restrict__ set, uint32_t *__restrict__ flags,
                                                       uint64_t *__restrict__ levels, uint32_t *__restrict__ n_levels, uint64_t *__restrict__ host_out, uint32_t seq) {
     // The distinct values arrive as a compact list behind the set (k_distinct_priorities appends a value when it inserts it; flags[3] counts them): a tick with three
     // levels sorts three values instead of scanning the 32 768 slots of the set (11.8 -> ~3 us: round 6 — the cold headline pays for this kernel on every tick).
@@ -141,6 +141,18 @@ __global__ void __launch_bounds__(1024) k_sort_levels(const uint64_t *__restrict
     uint32_t P = 1; while (P < n) P <<= 1;
     for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) lv[i] = i < n ? set[PRIO_SET_CAP + i] : 0;
     __syncthreads();
+    {   // leave the set EMPTY again: the slots of the listed values are located first (read-only: a cleared slot would cut another value's probe chain), then cleared —
+        // the next discovery needs no 256 KB fill in front of it (two `fillBufferAligned` launches per cold tick until round 6)
+        uint32_t my_slot[4]; int ns = 0;   // (LEVEL_CAP / 1024 threads)
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint64_t v = lv[i];
+            uint32_t slot = (uint32_t)mix64(v) & (PRIO_SET_CAP - 1);
+            for (uint32_t probe = 0; probe < PRIO_SET_CAP && set[slot] != v; probe++) slot = (slot + 1) & (PRIO_SET_CAP - 1);
+            my_slot[ns++] = slot;
+        }
+        __syncthreads();
+        for (int k = 0; k < ns; k++) set[my_slot[k]] = PRIO_EMPTY;
+    }
     // bitonic sort, descending; the zero padding sinks to the end
     for (uint32_t k = 2; k <= P; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -1041,7 +1053,7 @@ hipError_t distinct_priorities(const uint64_t *prio, const uint32_t *rq, uint64_
     return hipGetLastError();
 }
 
-hipError_t sort_levels(const uint64_t *set, uint32_t *flags, uint64_t *levels, uint32_t *n_levels, uint64_t *host_out, uint32_t seq, hipStream_t s) {
+hipError_t sort_levels(uint64_t *set, uint32_t *flags, uint64_t *levels, uint32_t *n_levels, uint64_t *host_out, uint32_t seq, hipStream_t s) {
     hipLaunchKernelGGL(k_sort_levels, dim3(1), dim3(1024), LEVEL_CAP * 8, s, set, flags, levels, n_levels, host_out, seq);
     return hipGetLastError();
 }
