@@ -339,6 +339,94 @@ struct Solver {
     // `probe` (optional; called after a master round that is within 10 %, at most three times): shown the master's fractional point — the columns' activities in every wide row — and its
     // lower bound; true = the caller goes to another configuration, this walk ends (false is returned).  `no_sweeps`: only what the cuts at hand settle — false as
     // soon as the master would need another sweep.
+    // Starting prices from the model AGGREGATED over chunks of its blocks (round 6).  Where the blocks of a part are the same block up to their costs — a cluster of identical
+    // workers: every cold tick, every DAG tick on an idle cluster — the part is one block with `count` times the capacities and the mean cost, and the model is an LP of
+    // PARTS x (columns of a block) variables under the priced wide rows: a hundred microseconds of dual simplex.  Its duals of the wide rows are where the decomposition's
+    // prices end up, up to what integrality and the cost spread inside a part change — a far better first proposal than a fraction of the price caps.  A proposal like any
+    // other (the cut it yields is exact); false: the blocks of some part differ, the caller keeps its scaled proposal.
+    bool aggregate_prices(const std::vector<double> &hB, const std::vector<int> &lk, std::vector<double> &pi) {
+        const HostTables &T = P.T;
+        // chunks of blocks = the aggregated model's granularity: as fine as ~256 LP variables allow (the dense dual simplex of lp_tab.h: ~0.1 ms there, milliseconds at 1024) —
+        // 32 chunks of eight-column blocks, 16 of sixteen-column ones.  Measured in sweeps (emulated, deterministic): config-5 first wave 10 -> 7, the 20 % probe 15 -> 11,
+        // configs[3]'s unsaturated cluster 19 -> 16; with 64 chunks 7 / 10 / 14, at ten times the LP.
+        static const int chunks_env = getenv("HQPRICE_AGG_CHUNKS") ? atoi(getenv("HQPRICE_AGG_CHUNKS")) : 0;
+        uint32_t widest = 1;
+        for (uint32_t b = 0; b < T.n_blocks; b++) widest = std::max(widest, T.blk_off[b + 1] - T.blk_off[b]);
+        const int agg_chunks = chunks_env > 0 ? chunks_env : std::min(64, std::max(PARTS, (int)(256u / widest)));
+        const uint32_t nb = T.n_blocks, per = (nb + (uint32_t)agg_chunks - 1) / (uint32_t)agg_chunks;
+        const int NP = (int)((nb + per - 1) / per), KL = (int)lk.size();
+        if (NP < 2 || KL == 0) return false;
+        if (P.G != 0) return false;   // (models with flags: the aggregated duals of one configuration mislead the walk over configurations — c3p 3 -> 4 sweeps, c4p 9 -> 16)
+        std::vector<uint32_t> pb0(NP), pcnt(NP), pnc(NP), voff(NP + 1, 0);
+        for (int p = 0; p < NP; p++) {
+            const uint32_t b0 = (uint32_t)p * per, b1 = std::min(nb, b0 + per);
+            pb0[p] = b0; pcnt[p] = b1 - b0; pnc[p] = T.blk_off[b0 + 1] - T.blk_off[b0];
+            const uint32_t c0 = T.blk_off[b0], nc = pnc[p];
+            for (uint32_t b = b0 + 1; b < b1; b++) {   // the same block? (amounts, bounds, capacities, membership in the wide rows — everything but the costs)
+                const uint32_t c = T.blk_off[b];
+                if (T.blk_off[b + 1] - c != nc || T.blk_m[b] != T.blk_m[b0]) return false;
+                if (memcmp(&T.blk_cap[(size_t)b * MMAX_BLOCK], &T.blk_cap[(size_t)b0 * MMAX_BLOCK], sizeof(double) * MMAX_BLOCK) != 0) return false;
+                if (memcmp(&T.col_a[(size_t)c * MMAX_BLOCK], &T.col_a[(size_t)c0 * MMAX_BLOCK], sizeof(double) * MMAX_BLOCK * nc) != 0) return false;
+                if (memcmp(&T.col_cap[c], &T.col_cap[c0], sizeof(int32_t) * nc) != 0) return false;
+                for (uint32_t q = 0; q < nc; q++) {
+                    const uint32_t e0 = T.col_woff[c0 + q], e1 = T.col_woff[c0 + q + 1], f0 = T.col_woff[c + q];
+                    if (T.col_woff[c + q + 1] - f0 != e1 - e0) return false;
+                    if (e1 > e0 && (memcmp(&T.w_row[f0], &T.w_row[e0], sizeof(uint16_t) * (e1 - e0)) != 0 || memcmp(&T.w_coef[f0], &T.w_coef[e0], sizeof(int32_t) * (e1 - e0)) != 0)) return false;
+                }
+            }
+            voff[p + 1] = voff[p] + nc;
+        }
+        const int nv = (int)voff[NP];
+        if (nv == 0 || nv > 8192) return false;
+        Rows A; A.n = nv;
+        std::vector<double> ac(nv), alb(nv, 0.0), aub(nv);
+        std::vector<std::pair<int, double>> terms;
+        for (int p = 0; p < NP; p++) {
+            const uint32_t c0 = T.blk_off[pb0[p]], nc = pnc[p];
+            for (uint32_t q = 0; q < nc; q++) {
+                double sum = 0.0;
+                for (uint32_t b = 0; b < pcnt[p]; b++) sum += T.col_cost[T.blk_off[pb0[p] + b] + q];
+                ac[voff[p] + q] = sum / (double)pcnt[p] / theta_scale;
+                aub[voff[p] + q] = (double)pcnt[p] * (double)T.col_cap[c0 + q];
+            }
+            for (int r = 0; r < (int)T.blk_m[pb0[p]]; r++) {
+                terms.clear(); double sc = 0.0;
+                for (uint32_t q = 0; q < nc; q++) { const double a = T.col_a[(size_t)(c0 + q) * MMAX_BLOCK + r]; if (a != 0.0) { terms.push_back({(int)(voff[p] + q), a}); sc = std::max(sc, std::fabs(a)); } }
+                if (terms.empty()) continue;
+                for (auto &t : terms) t.second /= sc;
+                A.add(terms, -INF, (double)pcnt[p] * T.blk_cap[(size_t)pb0[p] * MMAX_BLOCK + r] / sc);
+            }
+        }
+        const int first_wide = A.m;
+        std::vector<double> wscale(KL, 1.0);
+        for (int i = 0; i < KL; i++) {
+            const int g = P.grp_of[lk[i]];
+            terms.clear(); double sc = 0.0;
+            for (int p = 0; p < NP; p++) {
+                const uint32_t c0 = T.blk_off[pb0[p]];
+                for (uint32_t q = 0; q < pnc[p]; q++) for (uint32_t e = T.col_woff[c0 + q]; e < T.col_woff[c0 + q + 1]; e++) if ((int)T.w_row[e] == g) { terms.push_back({(int)(voff[p] + q), (double)T.w_coef[e]}); sc = std::max(sc, std::fabs((double)T.w_coef[e])); }
+            }
+            if (terms.empty()) { A.add({{0, 0.0}}, -INF, INF); continue; }
+            for (auto &t : terms) t.second /= sc;
+            wscale[i] = sc;
+            A.add(terms, -INF, hB[lk[i]] / sc);
+        }
+        Tab at; at.init(&A, ac, alb, aub);
+        if (at.solve(20000) != LP_OPT) return false;
+        work += at.ops;
+        pi.assign(P.K, 0.0);
+        bool any = false;
+        for (int i = 0; i < KL; i++) {
+            const int a = at.where[first_wide + i];
+            if (a < 0 || at.st[A.n + a] == BASIC) continue;
+            double y = std::fabs(at.d[A.n + a]) / wscale[i] * theta_scale;   // the row's dual, back in the units of the prices (cost per unit of the row's activity)
+            if (!(y > 0.0)) continue;
+            pi[lk[i]] = std::min(y, pmax[lk[i]]);
+            any = true;
+        }
+        return any;
+    }
+
     std::function<bool(const std::vector<double> &, double)> probe;
     // what a no_sweeps walk that converged found: the caller goes to that configuration next, whose own walk would solve the same master again
     struct Settled { bool valid = false; std::vector<double> hB, lambda, pi; double cB = 0.0, bound = 0.0; size_t n_cuts = 0, cut_lo = 0; } settled;
@@ -447,7 +535,12 @@ struct Solver {
             // The very first master has one cut (the patterns at pi = 0) and nothing that holds its prices back: its proposal sits on the price caps, where every column
             // of a priced row has stopped paying — far beyond the prices that only have to break ties or shave the marginal tasks.  A sixteenth of it is evaluated
             // instead (a valid point like any other: the cut it yields is exact): the 65 536-column unsaturated tick 22 -> 19 sweeps, 78 fuzz seeds 36 924 -> 34 596.
-            if (it == 0 && cut_lo == 0 && cuts.size() == 1) for (int k = 0; k < K; k++) pi[k] *= FIRST_PROPOSAL_SCALE;
+            if (it == 0 && cut_lo == 0 && cuts.size() == 1) {
+                std::vector<double> pa;
+                static const bool agg_on = !(getenv("HQPRICE_AGG_START") && atoi(getenv("HQPRICE_AGG_START")) == 0);   // (A/B switch)
+                if (agg_on && aggregate_prices(hB, lk, pa)) { pi = pa; if (rq.trace) fprintf(stderr, "[price]   first proposal: the duals of the model aggregated over chunks of blocks\n"); }
+                else for (int k = 0; k < K; k++) pi[k] *= FIRST_PROPOSAL_SCALE;
+            }
             const int ci = evaluate(pi);
             if (ci < 0) break;
             if (sw.time_up) { if (rq.trace) fprintf(stderr, "[price] 70 %% of the time limit gone inside the master loop\n"); return false; }
