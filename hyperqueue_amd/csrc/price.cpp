@@ -356,6 +356,10 @@ struct Solver {
         const uint32_t nb = T.n_blocks, per = (nb + (uint32_t)agg_chunks - 1) / (uint32_t)agg_chunks;
         const int NP = (int)((nb + per - 1) / per), KL = (int)lk.size();
         if (NP < 2 || KL == 0) return false;
+        // Only where a sweep is expensive: the aggregated LP (~256 variables through the dense dual simplex) costs ~1 ms on the MI355X box's host — three sweeps of a
+        // 4096-block model, a dozen of a 1024-block one.  (Measured with it on everywhere: layered DAG loop 17 -> 14 sweeps but 2.00 -> 2.13 ms per tick; configs[3]'s
+        // unsaturated cluster 19 -> 16 sweeps and 8.8 -> 7.6 ms.)
+        if ((uint64_t)T.n_cols < 32768) return false;
         if (P.G != 0) return false;   // (models with flags: the aggregated duals of one configuration mislead the walk over configurations — c3p 3 -> 4 sweeps, c4p 9 -> 16)
         std::vector<uint32_t> pb0(NP), pcnt(NP), pnc(NP), voff(NP + 1, 0);
         for (int p = 0; p < NP; p++) {
