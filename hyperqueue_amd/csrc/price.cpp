@@ -359,7 +359,8 @@ struct Solver {
         // Only where a sweep is expensive: the aggregated LP (~256 variables through the dense dual simplex) costs ~1 ms on the MI355X box's host — three sweeps of a
         // 4096-block model, a dozen of a 1024-block one.  (Measured with it on everywhere: layered DAG loop 17 -> 14 sweeps but 2.00 -> 2.13 ms per tick; configs[3]'s
         // unsaturated cluster 19 -> 16 sweeps and 8.8 -> 7.6 ms.)
-        if ((uint64_t)T.n_cols < 32768) return false;
+        static const uint64_t min_cols_env = getenv("HQPRICE_AGG_MINCOLS") ? (uint64_t)atoll(getenv("HQPRICE_AGG_MINCOLS")) : 32768;   // (experiments)
+        if ((uint64_t)T.n_cols < min_cols_env) return false;
         if (P.G != 0) return false;   // (models with flags: the aggregated duals of one configuration mislead the walk over configurations — c3p 3 -> 4 sweeps, c4p 9 -> 16)
         std::vector<uint32_t> pb0(NP), pcnt(NP), pnc(NP), voff(NP + 1, 0);
         for (int p = 0; p < NP; p++) {
