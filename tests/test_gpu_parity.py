@@ -419,6 +419,36 @@ def test_long_rows_scan_kernel_equals_short_rows_kernel(monkeypatch):
     assert (a.new_free == b.new_free).all()
 
 
+def test_c4p_full_sharded_replicas_agree():
+    """BASELINE configs[3] AS WRITTEN (c4p: three priority levels x 4096 workers x 2-variant OR-lists, 65 552 columns) the way the contract runs it — workers
+    hash-sharded, here over EIGHT shards: every rank solves the same model on its own context, the replicated stages must agree bit for bit, and the merged shard
+    records must be the plain tick's records."""
+    from hyperqueue_amd import sharded
+    from hyperqueue_amd.tick import Tick
+
+    snap = workloads.make("c4p")
+    cfg = abi.make_config(time_limit_s=20.0)
+    W, R, world, cap = len(snap.worker_id), snap.n_resources, 8, 1 << 16
+    sinks, results = [], []
+    for r in range(world):
+        st = sharded.ShardedTick(cfg, rank=r, world=world, records_per_shard=cap)
+        res_c, sink = st.tick_local(snap.to_c(), W)
+        sinks.append(sink.cpu().numpy().copy())
+        results.append(abi.parse_result(res_c, W, R))
+        assert st.t.kernel_stats()["price_sweeps"] > 0
+        st.t.close()
+    records = sharded.merge_shards(np.concatenate(sinks), world, W, cap)
+    for r in results[1:]:
+        assert r.is_optimal and r.counts == results[0].counts and r.batches == results[0].batches and (r.new_free == results[0].new_free).all()
+    t = Tick(cfg)
+    try:
+        plain = t.tick(snap)
+    finally:
+        t.close()
+    assert plain.status == abi.HQTICK_DONE and plain.is_optimal
+    assert plain.counts == results[0].counts and records == plain.records and (plain.new_free == results[0].new_free).all()
+
+
 def test_c3p_full_sharded_replicas_agree():
     """BASELINE C3 with three priority levels (one coupled model of 8 205 columns, solved by the price sweeps) as FOUR worker shards: every rank solves the same
     model on its own context — the replicated stages must agree bit for bit (counts, batches, free vectors: the price path has no clock on a tick that certifies), and

@@ -110,6 +110,7 @@ COUPLED = {
     "fuzz-2003": lambda: _fuzz(2003),   # 128 workers
     "fuzz-2005": lambda: _fuzz(2005),
     "c4-unsat-96": lambda: workloads.make("c4", seed=8, n_workers=96, n_tasks=1_400),
+    "c4p-96": lambda: workloads.make("c4p", n_tasks=24_000, n_workers=96),   # configs[3] as written, reduced: sixteen-column blocks + priority cuts and flags
 }
 
 
