@@ -473,6 +473,11 @@ struct CompSolver {
     double rel_gap = 0.0;
     bool gap_pruned = false;
     double root_bound = INF;  // LP bound of the whole component, once the root LP is solved
+    // Branch on a fractional FLAG before any placement column (round 6).  The flags are the model's big-M switches (blocker / cut rows, scheduler/solver.rs:233-253,395-429):
+    // with one of them fractional the LP pays for a little of everything, and no branching on placement counts pins it down — price_fuzz seeds 2056 / 2057 / 2130 go from
+    // `NeedMoreCompute` after 5 s to certificates in 0.3-4 s (emulated sweeps) with nothing else changed.  The static rule ranks columns by cost, and a flag costs nothing:
+    // it used to come last.  HQMILP_FLAGS_FIRST=0: the old order (A/B).
+    bool flags_first = !(getenv("HQMILP_FLAGS_FIRST") && atoi(getenv("HQMILP_FLAGS_FIRST")) == 0);
     bool certified() const { return have && rel_gap > 0.0 && root_bound <= best + rel_gap * std::fabs(best); }
     // (read once per process: a CompSolver is constructed per window of the window search and per class block — thousands per tick)
     static bool trace_enabled() { static const bool on = getenv("HQMILP_TRACE") != nullptr; return on; }
@@ -519,6 +524,12 @@ struct CompSolver {
         if (nodes == 1 && tracing && !in_lns) fprintf(stderr, "[milp] n=%d root LP %.9f incumbent %.9f rel gap %.3e\n", n, z, have ? best : -1.0, have ? (z - best) / best : 0.0);
         if (cannot_improve(z)) return;
         int j = pick_fractional(t);
+        if (flags_first && (int)col_group.size() == n) {   // a fractional FLAG (a global 0/1 column of the builder: col_group < 0) before any placement column
+            int jf = -1; double bf = 0.0;
+            for (int k = 0; k < n; k++) { if (col_group[k] >= 0) continue; const double fr = std::fabs(t.x[k] - std::round(t.x[k])); if (fr > INT_TOL && fr > bf) { bf = fr; jf = k; } }
+            if (jf >= 0) j = jf;
+        }
+        const int j_flag = (flags_first && j >= 0 && (int)col_group.size() == n && col_group[j] < 0) ? j : -1;
         if (j >= 0 && (nodes == 1 || (nodes & 63) == 0)) {  // root and every 64th node: try to close the gap from this LP point
             round_and_repair(t);
             if (cannot_improve(z)) return;
@@ -553,7 +564,7 @@ struct CompSolver {
             // enumerates the symmetric packings one by one (8 workers x 5 classes, 86 of 88 tasks fit: 2.4 M nodes without proof in 10 s), branching on
             // the total decides what the symmetric packings have in common.
             int ba = -1; double bfr = 1e-6;
-            for (int a = 0; a < t.ma && strong; a++) {
+            for (int a = 0; a < t.ma && strong && j_flag < 0; a++) {
                 const double u = row_unit[(size_t)t.arow[a]];
                 if (u <= 0.0) continue;
                 const double act = t.x[t.n + a] / u, fr = std::fabs(act - std::round(act));
@@ -574,7 +585,7 @@ struct CompSolver {
             }
         }
         const int SB = 32;
-        if (strong && have && (double)t.ma * (double)t.width() <= 4.0e6) {  // two tableau copies per candidate: not for the large models
+        if (strong && have && j_flag < 0 && (double)t.ma * (double)t.width() <= 4.0e6) {  // two tableau copies per candidate: not for the large models
             // strong branching over the SB most valuable fractional columns: both children are solved, the column whose children lose the most
             // bound is branched on, and a child that cannot hold anything better fixes the column the other way at once
             std::vector<std::pair<double, int>> cand;
