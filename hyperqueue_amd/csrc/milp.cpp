@@ -359,7 +359,7 @@ struct CompSolver {
     // The rows with the accepted cuts stay (`RCm`): the CERTIFICATION phases of the tree run on them (search(): a node's LP bound then starts from the cut-tightened
     // root instead of the plain LP's, percent above it — the difference between 18 nodes and millions on small clusters mid-run); the exact /
     // canonical pass after a certificate goes back to the model's own rows.
-    Rows RCm; bool rc_valid = false; double rc_bound = INF;
+    Rows RCm; bool rc_valid = false; double rc_bound = INF; long cut_infeas_refuted = 0, drift_resolves = 0;
     std::vector<double> cut_lp_x;   // the LP point over RCm
     // RINS at the cut LP's point: the columns on which that point and the incumbent agree stay where they are, the rest is a small model solved exactly.  With the
     // bound a few 1e-4 above the incumbent the two agree almost everywhere (price_fuzz seed 2056: the windows' incumbent sits 8e-5 below the optimum, 1.1e-4 below
@@ -519,9 +519,51 @@ struct CompSolver {
             if (elems > 1.0e6 && deadline - wall() < 2.0e-8 * elems) { timed_out = true; return; }
         }
         int s = solve_counted(t);
+        static const bool node_trace = getenv("HQMILP_NODE_TRACE") != nullptr;
+        if (node_trace && !in_lns && n > 100) fprintf(stderr, "[node] %ld status %d z %.9f best %.9f rows %s ma %d\n", nodes, s, s == LP_OPT ? t.objective() : -1.0, best, t.R == &RCm ? "cuts" : "plain", t.ma);
+        if (s == LP_INFEAS && rc_valid && t.R == &RCm) {
+            // "Infeasible" on the rows + cuts closes a whole subtree, and the dense tableau is never refactored: with a few hundred cut rows of mixed scale in it the dual
+            // ratio test can come up empty on an LP that has points (price_fuzz seed 2057: four such nodes closed a tree in eleven, 1.04e-4 below a point the host path
+            // held).  The claim is checked on the model's OWN rows under the node's bounds, from a cold start: infeasible there too — closed; otherwise the subtree is
+            // searched on those rows (slower bound, sound).
+            Tab plain; plain.init(&R, c, std::vector<double>(t.lb.begin(), t.lb.begin() + n), std::vector<double>(t.ub.begin(), t.ub.begin() + n)); plain.deadline = deadline;
+            const int ps = solve_counted(plain);
+            if (node_trace && !in_lns && n > 100) fprintf(stderr, "[node] %ld infeasible on the cut rows; on the model's own rows: status %d z %.9f\n", nodes, ps, ps == LP_OPT ? plain.objective() : -1.0);
+            if (ps == LP_LIMIT) { timed_out = true; return; }
+            if (ps != LP_OPT) return;
+            cut_infeas_refuted++;
+            t = std::move(plain);
+            s = LP_OPT;
+        }
         if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return; }
         double z = t.objective();
         if (nodes == 1 && tracing && !in_lns) fprintf(stderr, "[milp] n=%d root LP %.9f incumbent %.9f rel gap %.3e\n", n, z, have ? best : -1.0, have ? (z - best) / best : 0.0);
+        const bool on_cut_rows = rc_valid && t.R == &RCm;
+        bool drifted = false;
+        if (on_cut_rows) {
+            // A node's bound is its tableau's objective only while the tableau is DUAL FEASIBLE — and this one is never refactored: cut rows bring coefficient ranges of
+            // 1e6 into it, and after a few hundred pivots the reduced costs can have drifted (price_fuzz seed 2057: a node closed at 21.586 whose cold solve gives
+            // 21.614, above the threshold; a point 1.04e-4 better than the "certified" incumbent sat in it).  On the rows + cuts a node that is about to be closed by
+            // its bound on a drifted tableau is solved again from a cold start over the same rows and bounds, and a drifted tableau tightens no bounds below.
+            drifted = !dual_feasible(t, 1e-7);
+            const bool closes = have && (z <= best + 1e-12 * std::fabs(best) || (quantum > 0.0 && z < best + quantum * (1.0 - 1e-6)) || (rel_gap > 0.0 && z <= best + rel_gap * std::fabs(best)));
+            if (drifted && closes) {
+                Tab cold; cold.init(&RCm, c, std::vector<double>(t.lb.begin(), t.lb.begin() + n), std::vector<double>(t.ub.begin(), t.ub.begin() + n)); cold.deadline = deadline;
+                const int cs = solve_counted(cold);
+                if (node_trace && !in_lns && n > 100) fprintf(stderr, "[node] %ld would close at %.9f on a drifted tableau; cold solve of the same rows and bounds: status %d z %.9f\n", nodes, z, cs, cs == LP_OPT ? cold.objective() : -1.0);
+                if (cs == LP_LIMIT) { timed_out = true; return; }
+                if (cs == LP_INFEAS) {   // (the same cross-check as above: "infeasible" on the cut rows is confirmed on the model's own)
+                    Tab plain; plain.init(&R, c, std::vector<double>(t.lb.begin(), t.lb.begin() + n), std::vector<double>(t.ub.begin(), t.ub.begin() + n)); plain.deadline = deadline;
+                    const int ps = solve_counted(plain);
+                    if (ps == LP_LIMIT) { timed_out = true; return; }
+                    if (ps != LP_OPT) return;
+                    t = std::move(plain);
+                } else t = std::move(cold);
+                drift_resolves++;
+                z = t.objective();
+                drifted = t.R == &RCm && !dual_feasible(t, 1e-7);
+            }
+        }
         if (cannot_improve(z)) return;
         int j = pick_fractional(t);
         if (flags_first && (int)col_group.size() == n) {   // a fractional FLAG (a global 0/1 column of the builder: col_group < 0) before any placement column
@@ -541,7 +583,7 @@ struct CompSolver {
             best = zz;
             return;
         }
-        if (have) {
+        if (have && !drifted) {
             // Reduced-cost bound tightening: moving a nonbasic column k by delta away from its bound costs at least |d_k| delta of the LP bound z (the
             // duals of the active rows bound the whole model), and only points worth `need` or more are of interest below this node.  With the
             // near-optimal incumbents of the window search the room z - need is a few objective quanta, which pins most columns.
