@@ -28,8 +28,15 @@ for seed in range(first, first + count):
         t.close()
     o = Oracle(abi.make_config(time_limit_s=5.0), reference_solver_options=True)
     t0 = time.time(); want = o.tick(snap); dr = time.time() - t0
-    rows.append((seed, bool(got.is_optimal), bool(want.is_optimal), dt, dr, int(ks["price_sweeps"]), int(ks["milp_cols"])))
+    # two certificates of the same optimum cannot be more than 1e-4 (relative) apart: the product's point in HiGHS's own model against HiGHS's objective
+    from test_host_stages import _completed_objective
+    hm = o.last_model()
+    zp, zr = _completed_objective(hm, got), float(hm["objective"])
+    apart = bool(got.is_optimal and want.is_optimal and abs(zp - zr) > 1e-4 * max(abs(zp), abs(zr)) + 1e-12)
+    if apart:
+        print("CERTIFICATES APART", seed, zp, zr, (zr - zp) / zr, flush=True)
+    rows.append((seed, bool(got.is_optimal), bool(want.is_optimal), dt, dr, int(ks["price_sweeps"]), int(ks["milp_cols"]), apart))
     print(seed, "product", bool(got.is_optimal), f"{dt:.3f}s", "sweeps", int(ks["price_sweeps"]), "cols", int(ks["milp_cols"]), "| HiGHS", bool(want.is_optimal), f"{dr:.3f}s", flush=True)
 n = len(rows)
 print(f"{n} ticks: product certified {sum(r[1] for r in rows)}, HiGHS certified {sum(r[2] for r in rows)}; HiGHS but not the product: {[r[0] for r in rows if r[2] and not r[1]]}; the product but not HiGHS: {[r[0] for r in rows if r[1] and not r[2]]}; "
-      f"product time {sum(r[3] for r in rows):.1f} s, HiGHS time {sum(r[4] for r in rows):.1f} s")
+      f"product time {sum(r[3] for r in rows):.1f} s, HiGHS time {sum(r[4] for r in rows):.1f} s; both certified and more than 1e-4 apart: {[r[0] for r in rows if r[7]]}")
