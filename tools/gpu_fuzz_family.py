@@ -18,7 +18,8 @@ if "--default-path" not in sys.argv:
 from oracle.oracle import Oracle
 
 rows = []
-for seed in range(first, first + count):
+seeds = [int(a) for a in sys.argv[1:] if a.isdigit()] if "--seeds" in sys.argv else list(range(first, first + count))
+for seed in seeds:
     snap = scenario(seed)[0]
     t = Tick(abi.make_config(time_limit_s=5.0))
     try:
@@ -34,7 +35,9 @@ for seed in range(first, first + count):
     zp, zr = _completed_objective(hm, got), float(hm["objective"])
     apart = bool(got.is_optimal and want.is_optimal and abs(zp - zr) > 1e-4 * max(abs(zp), abs(zr)) + 1e-12)
     if apart:
-        print("CERTIFICATES APART", seed, zp, zr, (zr - zp) / zr, flush=True)
+        from limits import model_point, rows_hold
+        feasible = rows_hold(hm, model_point(hm, got.counts))   # the product's point against every row of the reference's model (as HiGHS got it)
+        print("CERTIFICATES APART", seed, "product", zp, "HiGHS", zr, "(HiGHS - product) / HiGHS", (zr - zp) / zr, "| the product's point satisfies every row of the reference's model:", feasible, flush=True)
     rows.append((seed, bool(got.is_optimal), bool(want.is_optimal), dt, dr, int(ks["price_sweeps"]), int(ks["milp_cols"]), apart))
     print(seed, "product", bool(got.is_optimal), f"{dt:.3f}s", "sweeps", int(ks["price_sweeps"]), "cols", int(ks["milp_cols"]), "| HiGHS", bool(want.is_optimal), f"{dr:.3f}s", flush=True)
 n = len(rows)
