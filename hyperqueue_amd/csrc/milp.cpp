@@ -538,14 +538,20 @@ struct CompSolver {
         if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return; }
         double z = t.objective();
         if (nodes == 1 && tracing && !in_lns) fprintf(stderr, "[milp] n=%d root LP %.9f incumbent %.9f rel gap %.3e\n", n, z, have ? best : -1.0, have ? (z - best) / best : 0.0);
-        const bool on_cut_rows = rc_valid && t.R == &RCm;
+        bool on_cut_rows = rc_valid && t.R == &RCm;
         bool drifted = false;
         if (on_cut_rows) {
             // A node's bound is its tableau's objective only while the tableau is DUAL FEASIBLE — and this one is never refactored: cut rows bring coefficient ranges of
             // 1e6 into it, and after a few hundred pivots the reduced costs can have drifted (price_fuzz seed 2057: a node closed at 21.586 whose cold solve gives
             // 21.614, above the threshold; a point 1.04e-4 better than the "certified" incumbent sat in it).  On the rows + cuts a node that is about to be closed by
             // its bound on a drifted tableau is solved again from a cold start over the same rows and bounds, and a drifted tableau tightens no bounds below.
-            drifted = !dual_feasible(t, 1e-7);
+            // (dual side: the reduced costs' signs; primal side: every active row's slack column against the row's activity at the structural columns' values)
+            auto consistent = [&](const Tab &q) {
+                if (!dual_feasible(q, 1e-7)) return false;
+                for (int a = 0; a < q.ma; a++) { const double act = q.R->activity(q.arow[a], q.x.data()); if (std::fabs(act - q.x[q.n + a]) > 1e-7 * std::max(1.0, std::fabs(act))) return false; }
+                return true;
+            };
+            drifted = !consistent(t);
             const bool closes = have && (z <= best + 1e-12 * std::fabs(best) || (quantum > 0.0 && z < best + quantum * (1.0 - 1e-6)) || (rel_gap > 0.0 && z <= best + rel_gap * std::fabs(best)));
             if (drifted && closes) {
                 Tab cold; cold.init(&RCm, c, std::vector<double>(t.lb.begin(), t.lb.begin() + n), std::vector<double>(t.ub.begin(), t.ub.begin() + n)); cold.deadline = deadline;
@@ -561,7 +567,8 @@ struct CompSolver {
                 } else t = std::move(cold);
                 drift_resolves++;
                 z = t.objective();
-                drifted = t.R == &RCm && !dual_feasible(t, 1e-7);
+                on_cut_rows = rc_valid && t.R == &RCm;
+                drifted = on_cut_rows && !consistent(t);
             }
         }
         if (cannot_improve(z)) return;
@@ -577,10 +584,24 @@ struct CompSolver {
             if (cannot_improve(z)) return;
         }
         if (j < 0) {
-            have = true; bx.assign(t.x.begin(), t.x.begin() + n);
-            for (auto &v : bx) v = std::round(v);
-            double zz = 0.0; for (int k = 0; k < n; k++) zz += c[k] * bx[k];
-            best = zz;
+            std::vector<double> xi(t.x.begin(), t.x.begin() + n);
+            for (auto &v : xi) v = std::round(v);
+            if (on_cut_rows) {   // (a drifted tableau's "integral optimum" need not satisfy the model: checked against its own rows and bounds first)
+                bool ok = true;
+                for (int k = 0; k < n && ok; k++) if (xi[k] < lb[k] - FEAS_TOL || xi[k] > ub[k] + FEAS_TOL) ok = false;
+                for (int i = 0; i < R.m && ok; i++) { const double a = R.activity(i, xi.data()); if (a < R.lo[i] - FEAS_TOL || a > R.hi[i] + FEAS_TOL) ok = false; }
+                if (!ok) {
+                    if (drifted) {   // once more from a cold start: the node is searched on from an exact tableau
+                        Tab cold; cold.init(&RCm, c, std::vector<double>(t.lb.begin(), t.lb.begin() + n), std::vector<double>(t.ub.begin(), t.ub.begin() + n)); cold.deadline = deadline;
+                        nodes--;   // (the same node again)
+                        drift_resolves++;
+                        dfs_opt(cold);
+                    }
+                    return;
+                }
+            }
+            double zz = 0.0; for (int k = 0; k < n; k++) zz += c[k] * xi[k];
+            if (!have || zz > best || !on_cut_rows) { have = true; bx = std::move(xi); best = zz; }
             return;
         }
         if (have && !drifted) {
@@ -646,9 +667,11 @@ struct CompSolver {
                     int cs = solve_counted(c);
                     nodes++;
                     if (cs == LP_LIMIT) { timed_out = true; return; }
-                    dead[side] = cs != LP_OPT || cannot_improve(c.objective());
-                    dz[side] = cs == LP_OPT ? std::max(0.0, z - c.objective()) : 1e9;
-                    if (!dead[side] && pick_fractional(c) < 0) {  // the child's LP optimum is integral: a better incumbent, and this child is finished
+                    // (on the rows + cuts a child's warm tableau may have drifted — see the top of this function: there the children only SCORE the candidates; whether
+                    // one of them is closed is decided when the search gets to it, with the cold re-solve behind it)
+                    dead[side] = !on_cut_rows && (cs != LP_OPT || cannot_improve(c.objective()));
+                    dz[side] = cs == LP_OPT ? std::max(0.0, z - c.objective()) : (on_cut_rows ? z : 1e9);
+                    if (!on_cut_rows && !dead[side] && pick_fractional(c) < 0) {  // the child's LP optimum is integral: a better incumbent, and this child is finished
                         bx.assign(c.x.begin(), c.x.begin() + n);
                         for (auto &v : bx) v = std::round(v);
                         double zz = 0.0; for (int q = 0; q < n; q++) zz += this->c[q] * bx[q];
