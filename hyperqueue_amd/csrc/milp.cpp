@@ -360,6 +360,16 @@ struct CompSolver {
     // root instead of the plain LP's, percent above it — the difference between 18 nodes and millions on small clusters mid-run); the exact /
     // canonical pass after a certificate goes back to the model's own rows.
     Rows RCm; bool rc_valid = false; double rc_bound = INF; long cut_infeas_refuted = 0, drift_resolves = 0;
+    // (debugging, HQMILP_WATCH_X=<file of n values>: a known feasible point; every node that is closed while it still contains the point says why)
+    std::vector<double> watch_x; bool watch_loaded = false;
+    bool watch_inside(const Tab &q) {
+        if (!watch_loaded) { watch_loaded = true; if (const char *f = getenv("HQMILP_WATCH_X")) if (!in_lns && n > 100) { FILE *fp = fopen(f, "r"); if (fp) { double v; while ((int)watch_x.size() < n && fscanf(fp, "%lf", &v) == 1) watch_x.push_back(v); fclose(fp); if ((int)watch_x.size() != n) watch_x.clear(); } } }
+        if (watch_x.empty()) return false;
+        for (int k = 0; k < n; k++) if (watch_x[k] < q.lb[k] - 1e-7 || watch_x[k] > q.ub[k] + 1e-7) return false;
+        for (int a = 0; a < q.ma; a++) { const double act = q.R->activity(q.arow[a], watch_x.data()); if (act < q.lb[q.n + a] - 1e-7 || act > q.ub[q.n + a] + 1e-7) return false; }
+        return true;
+    }
+    void watch_closed(const Tab &q, const char *why, double z) { if (watch_inside(q)) { double zw = 0.0; for (int k = 0; k < n; k++) zw += c[k] * watch_x[k]; fprintf(stderr, "[watch] node %ld CLOSED (%s) at z %.9f while it holds the watched point of value %.9f; best %.9f, rows %s\n", nodes, why, z, zw, best, q.R == &RCm ? "cuts" : "plain"); } }
     std::vector<double> cut_lp_x;   // the LP point over RCm
     // RINS at the cut LP's point: the columns on which that point and the incumbent agree stay where they are, the rest is a small model solved exactly.  With the
     // bound a few 1e-4 above the incumbent the two agree almost everywhere (price_fuzz seed 2056: the windows' incumbent sits 8e-5 below the optimum, 1.1e-4 below
@@ -530,12 +540,12 @@ struct CompSolver {
             const int ps = solve_counted(plain);
             if (node_trace && !in_lns && n > 100) fprintf(stderr, "[node] %ld infeasible on the cut rows; on the model's own rows: status %d z %.9f\n", nodes, ps, ps == LP_OPT ? plain.objective() : -1.0);
             if (ps == LP_LIMIT) { timed_out = true; return; }
-            if (ps != LP_OPT) return;
+            if (ps != LP_OPT) { watch_closed(t, "infeasible, confirmed on the model's rows", -1.0); return; }
             cut_infeas_refuted++;
             t = std::move(plain);
             s = LP_OPT;
         }
-        if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; return; }
+        if (s != LP_OPT) { if (s == LP_LIMIT) timed_out = true; else watch_closed(t, "infeasible", -1.0); return; }
         double z = t.objective();
         if (nodes == 1 && tracing && !in_lns) fprintf(stderr, "[milp] n=%d root LP %.9f incumbent %.9f rel gap %.3e\n", n, z, have ? best : -1.0, have ? (z - best) / best : 0.0);
         bool on_cut_rows = rc_valid && t.R == &RCm;
@@ -562,7 +572,7 @@ struct CompSolver {
                     Tab plain; plain.init(&R, c, std::vector<double>(t.lb.begin(), t.lb.begin() + n), std::vector<double>(t.ub.begin(), t.ub.begin() + n)); plain.deadline = deadline;
                     const int ps = solve_counted(plain);
                     if (ps == LP_LIMIT) { timed_out = true; return; }
-                    if (ps != LP_OPT) return;
+                    if (ps != LP_OPT) { watch_closed(t, "cold solve infeasible, confirmed on the model's rows", -1.0); return; }
                     t = std::move(plain);
                 } else t = std::move(cold);
                 drift_resolves++;
@@ -571,7 +581,7 @@ struct CompSolver {
                 drifted = on_cut_rows && !consistent(t);
             }
         }
-        if (cannot_improve(z)) return;
+        if (cannot_improve(z)) { watch_closed(t, "bound", z); return; }
         int j = pick_fractional(t);
         if (flags_first && (int)col_group.size() == n) {   // a fractional FLAG (a global 0/1 column of the builder: col_group < 0) before any placement column
             int jf = -1; double bf = 0.0;
@@ -581,7 +591,7 @@ struct CompSolver {
         const int j_flag = (flags_first && j >= 0 && (int)col_group.size() == n && col_group[j] < 0) ? j : -1;
         if (j >= 0 && (nodes == 1 || (nodes & 63) == 0)) {  // root and every 64th node: try to close the gap from this LP point
             round_and_repair(t);
-            if (cannot_improve(z)) return;
+            if (cannot_improve(z)) { watch_closed(t, "bound after round-and-repair", z); return; }
         }
         if (j < 0) {
             std::vector<double> xi(t.x.begin(), t.x.begin() + n);
@@ -678,13 +688,13 @@ struct CompSolver {
                         best = zz; have = true; dead[side] = true;
                     }
                 }
-                if (dead[0] && dead[1]) return;  // neither child can improve: the node is done
+                if (dead[0] && dead[1]) { watch_closed(t, "both strong-branching children dead", z); return; }  // neither child can improve: the node is done
                 if (dead[0] || dead[1]) {        // one child is empty: tighten the column here and re-solve the node
                     if (dead[0]) t.set_ub(k, std::floor(vk + INT_TOL)); else t.set_lb(k, std::ceil(vk - INT_TOL));
                     int cs = solve_counted(t);
                     if (cs != LP_OPT) { if (cs == LP_LIMIT) timed_out = true; return; }
                     z = t.objective();
-                    if (cannot_improve(z)) return;
+                    if (cannot_improve(z)) { watch_closed(t, "bound after a strong-branching fixing", z); return; }
                     continue;
                 }
                 const double score = std::max(dz[0], 1e-9) * std::max(dz[1], 1e-9);
