@@ -568,7 +568,8 @@ struct CompSolver {
                 const int cs = solve_counted(cold);
                 if (node_trace && !in_lns && n > 100) fprintf(stderr, "[node] %ld would close at %.9f on a drifted tableau; cold solve of the same rows and bounds: status %d z %.9f\n", nodes, z, cs, cs == LP_OPT ? cold.objective() : -1.0);
                 if (cs == LP_LIMIT) { timed_out = true; return; }
-                if (cs == LP_INFEAS) {   // (the same cross-check as above: "infeasible" on the cut rows is confirmed on the model's own)
+                if (cs == LP_INFEAS || (cs == LP_OPT && !consistent(cold))) {   // "infeasible" on the cut rows is confirmed on the model's own rows (as above) — and a cold solve that is ITSELF
+                    // inconsistent (the cut rows' scale again) decides nothing: the node goes on on the model's own rows
                     Tab plain; plain.init(&R, c, std::vector<double>(t.lb.begin(), t.lb.begin() + n), std::vector<double>(t.ub.begin(), t.ub.begin() + n)); plain.deadline = deadline;
                     const int ps = solve_counted(plain);
                     if (ps == LP_LIMIT) { timed_out = true; return; }
