@@ -353,6 +353,13 @@ struct CompSolver {
         }
         return true;
     }
+    // ... and the primal side of the same question: every active row's slack column must be the row's activity at the structural columns' values (both are updated
+    // incrementally by the pivots).  A tableau that fails either test bounds nothing and closes nothing.
+    static bool consistent(const Tab &q) {
+        if (!dual_feasible(q, 1e-7)) return false;
+        for (int a = 0; a < q.ma; a++) { const double act = q.R->activity(q.arow[a], q.x.data()); if (std::fabs(act - q.x[q.n + a]) > 1e-7 * std::max(1.0, std::fabs(act))) return false; }
+        return true;
+    }
     // Rounds of cuts on a COPY of the rows, for the bound only: the tree below keeps working on the model's own rows (its canonical answers must not depend on the
     // numerics of cut rows).  A round's value counts when its tableau is dual feasible; the final value is taken from a COLD solve over the final rows, the larger of
     // the two when they differ.
@@ -411,10 +418,10 @@ struct CompSolver {
             // (the warm re-solve on a pivot allowance: behind block-hull cuts the vertex is highly degenerate and the dual simplex can stall for thousands of pivots — price_fuzz
             // seed 2047: 4 300 against the ~700 a cold solve of the same rows takes; past the allowance the cold solve below takes over)
             bool ok;
-            { const double before = root.ops; const int r = root.solve(with_hull ? std::max(600L, 3L * (long)root.ma) : 200000L); work += root.ops - before; ok = r == LP_OPT && dual_feasible(root, 1e-7); }
+            { const double before = root.ops; const int r = root.solve(with_hull ? std::max(600L, 3L * (long)root.ma) : 200000L); work += root.ops - before; ok = r == LP_OPT && consistent(root); }
             if (!ok) {  // once more from a cold start over the same rows
                 root = Tab(); root.init(&RC, c, lb, ub); root.deadline = deadline;
-                ok = solve_counted(root) == LP_OPT && dual_feasible(root, 1e-7);
+                ok = solve_counted(root) == LP_OPT && consistent(root);
                 if (!ok) { if (tracing) fprintf(stderr, "[milp] n=%d cut round %d: LP not re-solved\n", n, round); break; }
             }
             const double z = root.objective();
@@ -429,7 +436,7 @@ struct CompSolver {
         if (tracing) fprintf(stderr, "[milp] n=%d cut rounds over after %d: work %.3g of %.3g, time_up %d\n", n, round, work, work_cap, (int)timed_out);
         if (RC.m > R.m && accepted < root0.objective()) {  // the certificate's bound: confirmed by a cold solve of the final rows
             Tab cold; cold.init(&RC, c, lb, ub); cold.deadline = deadline;
-            if (solve_counted(cold) == LP_OPT && dual_feasible(cold, 1e-7)) {
+            if (solve_counted(cold) == LP_OPT && consistent(cold)) {
                 const double zc = cold.objective();
                 if (tracing) fprintf(stderr, "[milp] n=%d cuts: %d rows added, bound %.9f (cold solve of the final rows: %.9f)\n", n, RC.m - R.m, accepted, zc);
                 root_bound = std::min(root_bound, std::max(accepted, zc) * (1.0 + 1e-9) + 1e-12);
@@ -555,12 +562,6 @@ struct CompSolver {
             // 1e6 into it, and after a few hundred pivots the reduced costs can have drifted (price_fuzz seed 2057: a node closed at 21.586 whose cold solve gives
             // 21.614, above the threshold; a point 1.04e-4 better than the "certified" incumbent sat in it).  On the rows + cuts a node that is about to be closed by
             // its bound on a drifted tableau is solved again from a cold start over the same rows and bounds, and a drifted tableau tightens no bounds below.
-            // (dual side: the reduced costs' signs; primal side: every active row's slack column against the row's activity at the structural columns' values)
-            auto consistent = [&](const Tab &q) {
-                if (!dual_feasible(q, 1e-7)) return false;
-                for (int a = 0; a < q.ma; a++) { const double act = q.R->activity(q.arow[a], q.x.data()); if (std::fabs(act - q.x[q.n + a]) > 1e-7 * std::max(1.0, std::fabs(act))) return false; }
-                return true;
-            };
             drifted = !consistent(t);
             const bool closes = have && (z <= best + 1e-12 * std::fabs(best) || (quantum > 0.0 && z < best + quantum * (1.0 - 1e-6)) || (rel_gap > 0.0 && z <= best + rel_gap * std::fabs(best)));
             if (drifted && closes) {
