@@ -104,6 +104,10 @@ struct SharedN {  // one block's working set: LDS on the device
     alignas(16) double py[PCAP][MMAX];  // (16-byte aligned: the staging area of build_block overlays it)
     uint32_t pcover[PCAP], ptight[PCAP];
     uint16_t porder[PCAP];          // pool entries by ascending y . cap: the tightest bounds at the root come first in every level's list
+    float pkey[PCAP];               // y . cap of an entry (the sort key), written with the entry
+    uint16_t ptix[PCAP];            // the entry's basis number: equal keys are ordered by it, so that the order does not depend on who found which entry first
+    uint32_t cnext;                 // next chunk of basis numbers to hand out (blocks worked on by several wavefronts: pool_sections)
+    uint32_t bar, gdone;            // ... the pool wavefronts' barrier counter, and the greedy wavefront's flag
     // work problem: columns in search order (position wn - 1 is decided first)
     int wn;
     uint8_t wcol[N_];
@@ -124,6 +128,7 @@ struct SharedN {  // one block's working set: LDS on the device
     };
     int32_t wcap[N_];             // upper cap of a position (INT32_MAX = none)
     int32_t colcap[N_];           // upper cap of a block column (INT32_MAX = none): the priced blocks of the coupled solve (price_core.h) carry their model bounds here
+    uint32_t woff[N_ + 1];        // priced blocks: where the columns' wide-row entries begin (price_core.h)
     uint32_t dcnt[N_ + 1];
     // level stack of the walk (level k = number of positions still free)
     double rem[N_ + 1][MMAX];
@@ -409,9 +414,12 @@ HQB_HD void dual_candidate(W &wv, SH &S, uint32_t t) {
     f *= 1.0 + 1e-15;
     const uint32_t slot = wv.atomic_inc(&S.npool);
     if (slot < (uint32_t)PCAP) {
+        double yf[MMAX];
         HQB_UNROLL
-        for (int r = 0; r < MMAX; r++) S.py[slot][r] = y[r] * f;
+        for (int r = 0; r < MMAX; r++) { yf[r] = y[r] * f; S.py[slot][r] = yf[r]; }
         S.pcover[slot] = cover; S.ptight[slot] = tight;
+        S.pkey[slot] = (float)(yf[0] * S.cap[0] + yf[1] * S.cap[1] + yf[2] * S.cap[2] + yf[3] * S.cap[3]);
+        S.ptix[slot] = (uint16_t)t;   // (C(NMAX + MMAX, MMAX) = 58 905 basis numbers at most)
     }
 }
 
@@ -439,6 +447,76 @@ HQB_HD void greedy_lane(SH &S, int lane) {
     double z = 0.0;
     for (int j = n - 1; j >= 0; j--) z = z + S.c[j] * (double)S.gx[j][lane];
     S.lane_val[lane] = z;
+}
+
+// ---- steps 2 + 3 as a section of the block that EVERY wavefront of its workgroup takes part in ---------------------------------------------------
+// A block is one dependent chain (build -> duals -> greedy -> level lists -> walk), and with one wavefront per block the chain's longest links are the pool — C(n + m, m)
+// 4 x 4 eliminations through 64 lanes: 8 rounds on an 8-column block, 76 on a 16-column one (16 of a c3p block's 44 us, 41-82 of a configs[3] block's) — and the 64
+// greedy fills behind it (8-11 us).  Neither needs the other, and the candidates are independent of one another, so a block may bring W::WAVES wavefronts (its
+// workgroup: one per SIMD of the CU for four): the MAIN wavefront (index 0) runs the chain, the others wait at group barrier A, take part in this section and leave
+// (pool_helper).  The LAST wavefront runs the greedy fills and raises a flag; the others ("pool wavefronts", the main one among them) take the basis numbers in
+// chunks of 64 from a counter in LDS, then order the pool together.  The pool wavefronts meet at barriers of their own (a counter in LDS: the workgroup's s_barrier
+// would make them wait for the greedy fills); the main wavefront waits for the flag when it leaves the section.
+// Who finds which entry first is then a matter of timing, and nothing may depend on it: the pool's ORDER (porder) is by (key, basis number), a total order, and a pool
+// that overflows — where the slot an entry gets decides whether it is kept at all — is thrown away and built again by the main wavefront alone in the one-wavefront
+// order (never seen on 68 698 measured blocks; it keeps the answers of a block a function of the block).
+template <class W, class SH>
+HQB_HD void pool_sections(W &wv, SH &S) {
+    const int n = S.n, m = S.m;
+    const uint32_t total = binom((uint32_t)(n + m), m);
+    auto all_by_lane = [&]() { wv.each([&](int lane) { for (uint32_t t = (uint32_t)lane; t < total; t += WAVE) dual_candidate(wv, S, t); }); };
+    uint32_t phase = 0;  // barriers of the pool wavefronts passed so far
+    if (W::WAVES == 1) {
+        all_by_lane();
+        wv.each([&](int lane) { greedy_lane(S, lane); });
+        wv.sync();
+    } else {
+        if (wv.wave_index() == W::WAVES - 1) {  // the greedy wavefront
+            wv.each([&](int lane) { greedy_lane(S, lane); });
+            wv.raise(&S.gdone);
+            return;
+        }
+        for (;;) {
+            const uint32_t base = wv.grab(&S.cnext, (uint32_t)WAVE);
+            if (base >= total) break;
+            wv.each([&](int lane) { const uint32_t t = base + (uint32_t)lane; if (t < total) dual_candidate(wv, S, t); });
+        }
+        wv.pool_barrier(&S.bar, ++phase);  // the pool is complete
+        if (S.npool > (uint32_t)PCAP) {
+            wv.pool_barrier(&S.bar, ++phase);  // (everyone has looked at npool)
+            if (wv.wave_index() == 0) { if (wv.first()) S.npool = 0; wv.sync(); all_by_lane(); }
+            wv.pool_barrier(&S.bar, ++phase);
+        }
+    }
+    // pool order: ascending y . cap, equal keys by basis number (rank counting)
+    const uint32_t np = S.npool < (uint32_t)PCAP ? S.npool : (uint32_t)PCAP;
+    wv.each_of_pool([&](int tid, int nthreads) {
+        for (uint32_t i = (uint32_t)tid; i < np; i += (uint32_t)nthreads) {
+            const float mine = S.pkey[i]; const uint16_t mt = S.ptix[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < np; j++) { const float o = S.pkey[j]; rank += (o < mine || (o == mine && S.ptix[j] < mt)) ? 1u : 0u; }
+            S.porder[rank] = (uint16_t)i;
+        }
+    });
+    wv.pool_barrier(&S.bar, ++phase);  // the pool is ordered: the helpers among the pool wavefronts are done
+}
+// the main wavefront: open the section (group barrier A), take part, and leave with the greedy fills done as well
+template <class W, class SH>
+HQB_HD void pool_main(W &wv, SH &S) {
+    if (wv.first()) { S.cnext = 0; S.bar = 0; S.gdone = 0; }
+    wv.group_sync();
+    pool_sections(wv, S);
+    wv.await(&S.gdone);
+}
+// ... which the main wavefront also passes when there is no block to work on (S.n == 0 or a status other than ST_OK), so that the helpers are released
+template <class W>
+HQB_HD void pool_skip(W &wv) { wv.group_sync(); }
+// every other wavefront of the workgroup: this is all it does
+template <class W, class SH>
+HQB_HD void pool_helper(W &wv, SH &S) {
+    wv.group_sync();  // A: the block is built (n, m, a, c, cap, pi, pd, colcap)
+    if (S.status != ST_OK || S.n == 0) return;
+    pool_sections(wv, S);
 }
 
 // ---- the work problem of one walk ---------------------------------------------------------------------------------------------------------------
@@ -678,32 +756,13 @@ HQB_HD void solve_block(W &wv, SH &S, const ColTable &ct, const ClassTable &cl, 
     uint32_t *x = out.x + (size_t)cls * ct.n_cols;
     wv.each([&](int lane) { for (uint32_t g = lane; g < ct.n_cols; g += WAVE) x[g] = 0; });
     if (S.status != ST_OK || S.n == 0) {
+        pool_skip(wv);
         if (wv.first()) { out.status[cls] = (uint32_t)S.status; out.steps[cls] = 0; }
         return;
     }
-    const int n = S.n, m = S.m;
-    const uint32_t total = binom((uint32_t)(n + m), m);
-    wv.each([&](int lane) { for (uint32_t t = (uint32_t)lane; t < total; t += WAVE) dual_candidate(wv, S, t); });
-    wv.sync();
-    {   // pool order: ascending y . cap (rank counting; the keys sit in the not-yet-used penalty array)
-        const uint32_t np = S.npool < (uint32_t)PCAP ? S.npool : (uint32_t)PCAP;
-        float *pkey = &S.dpen[0][0];
-        static_assert((SH::NN + 1) * DPRE >= PCAP, "pool keys overlay dpen");
-        wv.each([&](int lane) { for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) pkey[i] = (float)(S.py[i][0] * S.cap[0] + S.py[i][1] * S.cap[1] + S.py[i][2] * S.cap[2] + S.py[i][3] * S.cap[3]); });
-        wv.sync();
-        wv.each([&](int lane) {
-            for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) {
-                const float mine = pkey[i];
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < np; j++) { const float o = pkey[j]; rank += (o < mine || (o == mine && j < i)) ? 1u : 0u; }
-                S.porder[rank] = (uint16_t)i;
-            }
-        });
-        wv.sync();
-    }
+    const int n = S.n;
+    pool_main(wv, S);  // dual pool (ordered) and greedy fills
     if (prof && wv.first()) prof[2] = wv.now();
-    wv.each([&](int lane) { greedy_lane(S, lane); });
-    wv.sync();
     if (prof && wv.first()) prof[3] = wv.now();
     {
         int l = 0;
@@ -800,6 +859,15 @@ HQB_HD void solve_block(W &wv, SH &S, const ColTable &ct, const ClassTable &cl, 
 
 // ---- host emulation of a wavefront (CPU tests; also what documents the contract of the Wave policy) ---------------------------------------------
 struct HostWave {
+    static constexpr int WAVES = 1;   // wavefronts of a block's workgroup (pool_sections); the emulation is one
+    int wave_index() const { return 0; }
+    void group_sync() {}
+    void pool_barrier(uint32_t *, uint32_t) {}
+    void raise(uint32_t *p) { *p = 1; }
+    void await(uint32_t *) {}
+    template <class T> void put(T *p, T v) { *p = v; }   // a result other workgroups of the launch read (device: a store that is visible device-wide once acknowledged)
+    uint32_t grab(uint32_t *p, uint32_t n) { const uint32_t v = *p; *p += n; return v; }
+    template <class F> void each_of_pool(F f) { for (int l = 0; l < WAVE; l++) f(l, WAVE); }
     uint64_t now() const { return 0; }
     bool first() const { return true; }
     void sync() {}

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "block_core.h"
 #include "dev_wave.h"
 #include "kernels.h"
@@ -18,7 +20,17 @@ namespace hqblock {
 
 namespace {
 
-__global__ __launch_bounds__(WAVE) void k_block_solve(ColTable ct, ClassTable cl, Output out, uint32_t budget) {
+// NW wavefronts per class block: wavefront 0 runs the block's chain, the others take part in its dual pool / greedy section and leave (block_core.h: pool_sections).
+// A steady-state tick has a few hundred classes on 1024 SIMDs: the helpers sit on SIMDs that would idle.
+template <int NW>
+__global__ __launch_bounds__(WAVE * NW) void k_block_solve(ColTable ct, ClassTable cl, Output out, uint32_t budget) {
+    __shared__ Shared S;
+    DevGroup<NW> wv;
+    if (threadIdx.x >= WAVE) { pool_helper(wv, S); return; }
+    solve_block(wv, S, ct, cl, blockIdx.x, out, budget);
+}
+template <>
+__global__ __launch_bounds__(WAVE) void k_block_solve<1>(ColTable ct, ClassTable cl, Output out, uint32_t budget) {
     __shared__ Shared S;
     DevWave wv;
     solve_block(wv, S, ct, cl, blockIdx.x, out, budget);
@@ -29,7 +41,11 @@ __global__ __launch_bounds__(WAVE) void k_block_solve(ColTable ct, ClassTable cl
 hipError_t block_solve(const ColTable &ct, const ClassTable &cl, const Output &out, uint32_t budget, hipStream_t s) {
     if (cl.n_classes == 0) return hipSuccess;
     hqk::LaunchTimer t = hqk::take_launch_timer();
-    hipExtLaunchKernelGGL(k_block_solve, dim3(cl.n_classes), dim3(WAVE), 0, s, t.start, t.stop, 0, ct, cl, out, budget);
+    static const int force_waves = getenv("HQTICK_BLOCK_WAVES") ? atoi(getenv("HQTICK_BLOCK_WAVES")) : 0;   // A/B switch (1 / 2 / 4)
+    const int nw = force_waves ? force_waves : cl.n_classes <= 1024u ? 4 : cl.n_classes <= 2048u ? 2 : 1;
+    if (nw == 4) hipExtLaunchKernelGGL(k_block_solve<4>, dim3(cl.n_classes), dim3(WAVE * 4), 0, s, t.start, t.stop, 0, ct, cl, out, budget);
+    else if (nw == 2) hipExtLaunchKernelGGL(k_block_solve<2>, dim3(cl.n_classes), dim3(WAVE * 2), 0, s, t.start, t.stop, 0, ct, cl, out, budget);
+    else hipExtLaunchKernelGGL(k_block_solve<1>, dim3(cl.n_classes), dim3(WAVE), 0, s, t.start, t.stop, 0, ct, cl, out, budget);
     return hipGetLastError();
 }
 

@@ -1,4 +1,9 @@
-// The Wave policy of block_core.h / price_core.h on the device: one wave64 per block (blockDim.x == 64), lane = threadIdx.x.
+// The Wave policies of block_core.h / price_core.h on the device.
+//   DevWave       one wave64 per block (blockDim.x == 64), lane = threadIdx.x.
+//   DevGroup<NW>  a workgroup of NW wave64 per block (blockDim.x == 64 NW, one wavefront on each SIMD of the CU for NW = 4): wavefront 0 is the block's MAIN wavefront and
+//                 runs the chain; the others enter through hqblock::pool_helper and take part in the pool section only.  sync() is the main wavefront's own (a
+//                 wavefront executes in lockstep and its LDS operations complete in order: a compiler fence, no s_barrier — the helpers have left by then, and a
+//                 hardware barrier per search step would cost more than the helpers save); group_sync() is the workgroup's barrier.
 // (The host emulation the CPU tests run is hqblock::HostWave in block_core.h.)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -8,6 +13,17 @@
 namespace hqblock {
 
 struct DevWave {
+    static constexpr int WAVES = 1;
+    __device__ int wave_index() const { return 0; }
+    __device__ void group_sync() { __syncthreads(); }
+    __device__ void pool_barrier(uint32_t *, uint32_t) { __syncthreads(); }
+    __device__ void raise(uint32_t *) {}
+    __device__ void await(uint32_t *) {}
+    // a result other workgroups of the launch read: written through to where the whole device sees it (no L2 write-back fence needed behind it, only the acknowledgement)
+    __device__ void put(double *p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ void put(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ uint32_t grab(uint32_t *p, uint32_t n) { uint32_t v = 0; if (threadIdx.x == 0) v = atomicAdd(p, n); return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+    template <class F> __device__ void each_of_pool(F f) { f((int)threadIdx.x, WAVE); }
     __device__ uint64_t now() const { return wall_clock64(); }  // 100 MHz
     __device__ bool first() const { return threadIdx.x == 0; }
     __device__ void sync() { __syncthreads(); }
@@ -38,6 +54,75 @@ struct DevWave {
             if (ov > v || (ov == v && ol < l)) { v = ov; l = ol; }
         }
         *lane = v < 0.0 ? -1 : l;
+        return v < 0.0 ? -1.0 : v;
+    }
+};
+
+template <int NW>
+struct DevGroup {
+    static constexpr int WAVES = NW;
+    __device__ static int lane() { return (int)(threadIdx.x & 63u); }
+    __device__ int wave_index() const { return (int)(threadIdx.x >> 6); }
+    __device__ void group_sync() { __syncthreads(); }
+    // barrier number `phase` of the NW - 1 pool wavefronts (all but the last): a counter in LDS, lane 0 of each adds one and waits for (NW - 1) * phase
+    __device__ void pool_barrier(uint32_t *ctr, uint32_t phase) {
+        if (NW <= 2) { sync(); return; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane() == 0) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(NW - 1) * phase) __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    __device__ void raise(uint32_t *flag) {   // the calling wavefront's LDS writes, then the flag
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane() == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ void await(uint32_t *flag) {
+        if (lane() == 0) while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    // a result other workgroups of the launch read: written through to where the whole device sees it (no L2 write-back fence needed behind it, only the acknowledgement)
+    __device__ void put(double *p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ void put(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ uint32_t grab(uint32_t *p, uint32_t n) { uint32_t v = 0; if (lane() == 0) v = atomicAdd(p, n); return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+    template <class F> __device__ void each_of_pool(F f) { f((int)threadIdx.x, WAVE * (NW - 1)); }
+    __device__ uint64_t now() const { return wall_clock64(); }
+    __device__ bool first() const { return threadIdx.x == 0; }  // (lane 0 of the main wavefront: the helpers never ask)
+    __device__ void sync() {  // within the calling wavefront (see above)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ uint32_t atomic_inc(uint32_t *p) { return atomicAdd(p, 1u); }
+    __device__ void atomic_or64(uint64_t *p, uint64_t v) { atomicOr((unsigned long long *)p, (unsigned long long)v); }
+    __device__ void atomic_add_i64(long long *p, long long v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
+    __device__ void lds_add_i64(long long *p, long long v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
+    __device__ static int ctz(uint64_t m) { return __ffsll((long long)m) - 1; }
+    template <class F> __device__ void each(F f) { f(lane()); }
+    template <class F> __device__ uint64_t ballot(F f) { return __ballot(f(lane()) ? 1 : 0); }
+    template <class I, class Ch> __device__ uint64_t ballot_chunked(int nchunks, I init, Ch chunk) {
+        Probe st;
+        bool alive = init(lane(), st);
+        for (int c = 0; c < nchunks; c++) {
+            if (!__ballot(alive ? 1 : 0)) break;
+            if (alive) alive = chunk(lane(), st, c);
+        }
+        return __ballot(alive ? 1 : 0);
+    }
+    template <class F> __device__ double argmax(F f, int *lane_out) {
+        double v = f(lane());
+        int l = lane();
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(v, off, 64);
+            const int ol = __shfl_xor(l, off, 64);
+            if (ov > v || (ov == v && ol < l)) { v = ov; l = ol; }
+        }
+        *lane_out = v < 0.0 ? -1 : l;
         return v < 0.0 ? -1.0 : v;
     }
 };

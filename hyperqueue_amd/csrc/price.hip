@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "dev_wave.h"
@@ -46,11 +47,15 @@ struct SweepResult {   // pinned host memory, written by the last workgroup of a
     uint32_t seq;      // written last (release, system scope)
 };
 
+struct PartVal { uint32_t nbud, mx; };   // one part's sums, handed from the part's last block to the sweep's last block (HBM)
+
 struct SweepArgs {
     Tables t;
     SweepOut out;
     uint32_t budget, seq;
-    uint32_t *ticket;
+    uint32_t *tickets;     // [0] the sweep's, [1 + p] part p's
+    long long *pact;       // [ASLOTS * K] the parts' activity vectors on their way from the parts' last blocks to the sweep's last block
+    PartVal *pval;         // [ASLOTS]
     SweepResult *res;
     // worker-range shards (price.h: ShardedSweeper): the grid covers the blocks [first, first + gridDim.x) only, and instead of the sweep's totals the last
     // workgroup leaves the range's per-block values in pinned memory (lv_*: arrays indexed by absolute block) — the totals are added up after the ranks' all-gather
@@ -59,123 +64,175 @@ struct SweepArgs {
     double pi[KMAX];
 };
 
-// SH = hqblock::SharedN<N>, N = 8 / 16 / 32: the smallest working set the model's widest block fits (block_core.h) — 13.5 / 17.6 / 25.9 KB of LDS per workgroup, i.e.
-// eleven / nine / six blocks resident per CU: a 4096-block sweep of 16-column blocks (BASELINE configs[3]) runs in two generations of resident workgroups instead of
-// three.  The answers do not depend on N.
-template <class SH>
-__global__ __launch_bounds__(WAVE) void k_price_sweep(const SweepArgs a) {
+// Values that travel between workgroups of ONE launch (per-block results, the parts' sums, tickets) are written and read with device-scope relaxed atomics: the store
+// goes through to where every XCD sees it, the load does not look into a cache that may hold last sweep's line.  Ordering comes from waiting for the stores'
+// acknowledgements (a workgroup-scope release fence = s_waitcnt vmcnt(0)) before the ticket is taken — not from a device-scope release fence, whose L2 write-back
+// cost every block 5-7 us (16 on the last ones) in front of a ticket 1024 blocks queued for (profiles/r06: price_sweep_waves.txt).
+__device__ __forceinline__ double ld_dev(const double *p) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ long long ld_dev(const long long *p) { return (long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_dev(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(double *p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(long long *p, long long v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... and what the host reads (pinned memory): system scope
+__device__ __forceinline__ void st_host(double *p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_host(long long *p, long long v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_host(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void acked() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }   // every store / atomic of this wavefront so far is acknowledged
+
+// SH = hqblock::SharedN<N>, N = 8 / 16 / 32: the smallest working set the model's widest block fits (block_core.h) — i.e. how many blocks a CU holds at once.  The
+// answers do not depend on N.
+// NW: wavefronts per block.  Wavefront 0 runs the block's chain; the others take part in the dual pool / greedy section (block_core.h: pool_sections) and leave.  A
+// sweep is as long as its slowest block's chain, and on a model of <= 4 blocks per CU every helper sits on a SIMD that would otherwise idle (NW = 4: one wavefront per
+// SIMD); VGPRs (one allocation for every wavefront of the kernel) bound the residency to 16-20 wavefronts per CU, so wider models take fewer helpers (launch()).
+//
+// The end of a sweep, in two levels (the master's 16 PARTS = contiguous ranges of blocks): every block takes a ticket of its PART; the part's last block adds the
+// part's c.x, hands the part's activity vector over (and zeroes the accumulator for the next sweep), writes the part's rows of the result straight into the host's
+// pinned memory, and takes the sweep's ticket; the last of those adds the per-block values of the whole sweep and writes totals + sequence word.  Two short queues
+// (64-256 and 16 deep) instead of one of 1024-4096, and the parts' work runs on 16 CUs side by side.  The ORDER of every floating-point sum is the one of price.h:
+// totals_from_blocks — as it was when one workgroup did all of this: a GPU tick, a sharded tick and the emulated tick walk the same sequence of prices.
+template <class SH, int NW>
+__global__ __launch_bounds__(WAVE * NW) void k_price_sweep(const SweepArgs a) {
     __shared__ SH S;
-    __shared__ uint32_t s_last;
-    hqblock::DevWave wv;
-    solve_priced_block(wv, S, a.t, a.pi, a.first + blockIdx.x, a.out, a.budget);
-    __threadfence();  // the block's results before its ticket
-    if (threadIdx.x == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (a.local) {  // this rank's share of a sharded sweep: per-block values and the partial activity vectors as they are, no totals
-        for (uint32_t b0 = a.first + threadIdx.x; b0 < a.first + gridDim.x; b0 += WAVE * 8) {   // (eight blocks' loads in flight, then their stores: see below)
+    using WV = typename std::conditional<NW == 1, hqblock::DevWave, hqblock::DevGroup<NW>>::type;
+    WV wv;
+    if (NW > 1 && threadIdx.x >= WAVE) { hqblock::pool_helper(wv, S); return; }
+    const uint32_t lane = threadIdx.x;   // (from here on the main wavefront is alone)
+    const uint32_t nb = a.t.n_blocks, K = a.t.K, per = part_size(nb), b = a.first + blockIdx.x, p = b / per;
+    solve_priced_block(wv, S, a.t, a.pi, b, a.out, a.budget);
+    uint64_t *prof = a.out.prof ? a.out.prof + (size_t)b * PSLOTS : nullptr;
+    const uint32_t r0 = a.first, r1 = a.first + gridDim.x;   // the launch's blocks; the part's blocks among them:
+    const uint32_t pb0 = p * per > r0 ? p * per : r0, pe = p * per + per < nb ? p * per + per : nb, pb1 = pe < r1 ? pe : r1;
+    acked();  // the block's values and its activity atomics, before its ticket
+    if (prof && lane == 0) prof[11] = wv.now();
+    uint32_t last = 0;
+    if (lane == 0) last = __hip_atomic_fetch_add(&a.tickets[1 + p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pb1 - pb0 - 1 ? 1u : 0u;
+    last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
+    if (prof && lane == 0) prof[12] = wv.now();
+    if (!last) return;
+    {   // the part's last block
+        uint32_t nbud = 0, mx = 0;
+        for (uint32_t bb = pb0 + lane; bb < pb1; bb += WAVE * 4) {   // (four of a lane's blocks in flight)
+            uint32_t vst[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t q = bb + (uint32_t)u * WAVE; vst[u] = q < pb1 ? ld_dev(&a.out.blk_steps[q]) : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { nbud += vst[u] >> 31; const uint32_t st = vst[u] & 0x7FFFFFFFu; mx = st > mx ? st : mx; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { nbud += __shfl_xor(nbud, off, 64); const uint32_t om = __shfl_xor(mx, off, 64); mx = om > mx ? om : mx; }
+        double pcx = 0.0;
+        if (!a.local) {
+            // c.x of the part in the order of price.h: totals_from_blocks — four running sums, sum q over the part's blocks q, q + 4, q + 8, ... one after the other, then
+            // ((s0 + s1) + s2) + s3.  The loads are side by side (256 blocks per round, staged in the pool's storage); lanes 0-3 then add from LDS in that order.
+            double *scr = &S.py[0][0];
+            static_assert(sizeof(S.py) >= 256 * sizeof(double), "a round of the part's c.x values is staged in the dual pool's storage");
+            double s4 = 0.0;
+            for (uint32_t c0 = p * per; c0 < pe; c0 += 256) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint32_t q = c0 + lane + (uint32_t)u * WAVE; v[u] = q < pe ? ld_dev(&a.out.blk_cx[q]) : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) scr[lane + (uint32_t)u * WAVE] = v[u];
+                wv.sync();
+                const uint32_t cnt = pe - c0 < 256u ? pe - c0 : 256u;
+                if (lane < 4) for (uint32_t i = lane; i < cnt; i += 4) s4 += scr[i];
+                wv.sync();
+            }
+            const double s1 = __shfl(s4, 1, 64), s2 = __shfl(s4, 2, 64), s3 = __shfl(s4, 3, 64);
+            pcx = ((s4 + s1) + s2) + s3;   // (lane 0's value is the part's)
+        }
+        for (uint32_t k = lane; k < K; k += WAVE) {
+            long long *acc = &a.out.act[(size_t)p * K + k];
+            const long long v = ld_dev(acc);
+            st_dev(acc, 0);
+            st_dev(&a.pact[(size_t)p * K + k], v);
+            st_host(&a.res->part_act[(size_t)p * K + k], v);
+        }
+        if (lane == 0) {
+            st_dev(&a.pval[p].nbud, nbud); st_dev(&a.pval[p].mx, mx);
+            if (!a.local) st_host(&a.res->part_cx[p], pcx);
+            st_dev(&a.tickets[1 + p], 0u);
+        }
+        acked();
+    }
+    const uint32_t p_first = r0 / per, p_last = (r1 - 1) / per;
+    if (lane == 0) last = __hip_atomic_fetch_add(&a.tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p_last - p_first ? 1u : 0u;
+    last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
+    if (!last) return;
+    // the sweep's last block
+    if (a.local) {  // this rank's share of a sharded sweep: the per-block values as they are (the totals are added up after the ranks' all-gather); its parts' activity rows are in place
+        for (uint32_t b0 = r0 + lane; b0 < r1; b0 += WAVE * 8) {   // (eight blocks' loads in flight, then their stores)
             double vcx[8], vrc[8], vbd[8]; uint32_t vst[8];
-            const uint32_t end = a.first + gridDim.x;
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const uint32_t b = b0 + (uint32_t)u * WAVE; const bool in = b < end; vcx[u] = in ? a.out.blk_cx[b] : 0.0; vrc[u] = in ? a.out.blk_rc[b] : 0.0; vbd[u] = in ? a.out.blk_bnd[b] : 0.0; vst[u] = in ? a.out.blk_steps[b] : 0u; }
+            for (int u = 0; u < 8; u++) { const uint32_t q = b0 + (uint32_t)u * WAVE; const bool in = q < r1; vcx[u] = in ? ld_dev(&a.out.blk_cx[q]) : 0.0; vrc[u] = in ? ld_dev(&a.out.blk_rc[q]) : 0.0; vbd[u] = in ? ld_dev(&a.out.blk_bnd[q]) : 0.0; vst[u] = in ? ld_dev(&a.out.blk_steps[q]) : 0u; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const uint32_t b = b0 + (uint32_t)u * WAVE; if (b < end) { a.lv_cx[b] = vcx[u]; a.lv_rc[b] = vrc[u]; a.lv_bnd[b] = vbd[u]; a.lv_steps[b] = vst[u]; } }
+            for (int u = 0; u < 8; u++) { const uint32_t q = b0 + (uint32_t)u * WAVE; if (q < r1) { st_host(&a.lv_cx[q], vcx[u]); st_host(&a.lv_rc[q], vrc[u]); st_host(&a.lv_bnd[q], vbd[u]); st_host(&a.lv_steps[q], vst[u]); } }
         }
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ASLOTS * a.t.K; i += WAVE) {
-            const uint32_t sl = i / a.t.K, k = i - sl * a.t.K;
-            long long vs[ASUB];
+    } else {
+        const uint32_t n_parts = (nb + per - 1) / per;   // parts that hold blocks (the others' rows of the result are zero)
+        // the sweep's totals in the order of price.h: totals_from_blocks — lane l adds the blocks l, l + 64, ... one after the other, lane 0 then the 64 partial sums
+        // in lane order (eight of a lane's blocks in flight per round)
+        double cx = 0.0, rc = 0.0, bnd = 0.0;
+        for (uint32_t b0 = lane; b0 < nb; b0 += WAVE * 8) {
+            double vcx[8], vrc[8], vbd[8];
 #pragma unroll
-            for (int sub = 0; sub < ASUB; sub++) vs[sub] = a.out.act[((size_t)sl * ASUB + sub) * a.t.K + k];
+            for (int u = 0; u < 8; u++) { const uint32_t q = b0 + (uint32_t)u * WAVE; const bool in = q < nb; vcx[u] = in ? ld_dev(&a.out.blk_cx[q]) : 0.0; vrc[u] = in ? ld_dev(&a.out.blk_rc[q]) : 0.0; vbd[u] = in ? ld_dev(&a.out.blk_bnd[q]) : 0.0; }
 #pragma unroll
-            for (int sub = 0; sub < ASUB; sub++) a.out.act[((size_t)sl * ASUB + sub) * a.t.K + k] = 0;
-            long long v = 0;
-#pragma unroll
-            for (int sub = 0; sub < ASUB; sub++) v += vs[sub];
-            a.res->part_act[i] = v;
+            for (int u = 0; u < 8; u++) { if (b0 + (uint32_t)u * WAVE >= nb) break; cx += vcx[u]; rc += vrc[u]; bnd += vbd[u]; }
         }
-        if (threadIdx.x == 0) *a.ticket = 0;
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(&a.res->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
-    // the last workgroup: totals in a fixed order (lane l takes blocks l, l + 64, ...; lane 0 adds the 64 partial sums in lane order)
-    const uint32_t nb = a.t.n_blocks;
-    double cx = 0.0, rc = 0.0, bnd = 0.0; uint32_t nbud = 0, mx = 0;
-    // (eight of a lane's blocks per round: the loads of a round are issued together and the sums then run in the same order as before — block l, l + 64, ... —
-    // so the totals are bit for bit the old ones; one round trip to L2 per eight blocks instead of one per block: this workgroup is the tail of every sweep)
-    for (uint32_t b0 = threadIdx.x; b0 < nb; b0 += WAVE * 8) {
-        double vcx[8], vrc[8], vbd[8]; uint32_t vst[8];
+        double *red = &S.py[0][0];
+        red[lane] = cx; red[WAVE + lane] = rc; red[2 * WAVE + lane] = bnd;
+        uint32_t pn = 0, pm = 0;
+        if (lane < n_parts) { pn = ld_dev(&a.pval[lane].nbud); pm = ld_dev(&a.pval[lane].mx); }
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t b = b0 + (uint32_t)u * WAVE; const bool in = b < nb; vcx[u] = in ? a.out.blk_cx[b] : 0.0; vrc[u] = in ? a.out.blk_rc[b] : 0.0; vbd[u] = in ? a.out.blk_bnd[b] : 0.0; vst[u] = in ? a.out.blk_steps[b] : 0u; }
+        for (int off = 8; off >= 1; off >>= 1) { pn += __shfl_xor(pn, off, 64); const uint32_t om = __shfl_xor(pm, off, 64); pm = om > pm ? om : pm; }   // (lanes 0-15 hold the parts)
+        wv.sync();
+        double tcx = 0.0, trc = 0.0, tb = 0.0;
+        if (lane == 0) for (int l = 0; l < WAVE; l++) { tcx += red[l]; trc += red[WAVE + l]; tb += red[2 * WAVE + l]; }
+        const uint32_t tn = pn, tm = pm;
+        for (uint32_t k = lane; k < K; k += WAVE) {
+            long long vs[ASLOTS];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (b0 + (uint32_t)u * WAVE >= nb) break;
-            cx += vcx[u]; rc += vrc[u]; bnd += vbd[u];
-            nbud += vst[u] >> 31; const uint32_t s = vst[u] & 0x7FFFFFFFu; mx = s > mx ? s : mx;
+            for (int i = 0; i < ASLOTS; i++) vs[i] = (uint32_t)i < n_parts ? ld_dev(&a.pact[(size_t)i * K + k]) : 0;
+            long long sum = 0;
+#pragma unroll
+            for (int i = 0; i < ASLOTS; i++) { sum += vs[i]; if ((uint32_t)i >= n_parts) st_host(&a.res->part_act[(size_t)i * K + k], 0); }
+            st_host(&a.res->act[k], sum);
         }
+        if (lane >= n_parts && lane < (uint32_t)ASLOTS) st_host(&a.res->part_cx[lane], 0.0);
+        if (lane == 0) { st_host(&a.res->cx, tcx); st_host(&a.res->rc, trc); st_host(&a.res->bnd, tb); st_host(&a.res->n_budget, tn); st_host(&a.res->max_steps, tm); }
     }
-    double *red = &S.py[0][0];  // the pool's storage again: 3 x 64 doubles + 2 x 64 words
-    uint32_t *redu = reinterpret_cast<uint32_t *>(red + 3 * WAVE);
-    {   // c.x per part, in a fixed order: four lanes per part take every fourth block of its range, the first of them adds the four partial sums
-        const uint32_t per = part_size(nb), g = threadIdx.x >> 2, p = threadIdx.x & 3u;
-        const uint32_t b0 = g * per, b1 = b0 + per < nb ? b0 + per : nb;
-        double s = 0.0;
-        for (uint32_t bb = b0 + p; bb < b1; bb += 32) {   // (eight loads in flight, summed in the order b0 + p, + 4, + 8, ... as before)
-            double v8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const uint32_t b = bb + 4u * (uint32_t)u; v8[u] = b < b1 ? a.out.blk_cx[b] : 0.0; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) { if (bb + 4u * (uint32_t)u >= b1) break; s += v8[u]; }
-        }
-        red[threadIdx.x] = s;
-        __syncthreads();
-        if (p == 0) a.res->part_cx[g] = ((red[threadIdx.x] + red[threadIdx.x + 1]) + red[threadIdx.x + 2]) + red[threadIdx.x + 3];
-        __syncthreads();
-    }
-    red[threadIdx.x] = cx; red[WAVE + threadIdx.x] = rc; red[2 * WAVE + threadIdx.x] = bnd; redu[threadIdx.x] = nbud; redu[WAVE + threadIdx.x] = mx;
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < a.t.K; k += WAVE) {  // the ASLOTS partial vectors -> the sweep's activities (and the slots ready for the next sweep)
-        // (all loads first, then the stores: with a store to the host's pinned result between two loads the compiler keeps their order — it cannot know the
-        // two do not alias — and the sixteen loads become sixteen round trips to memory the other workgroups have just written)
-        long long vs[ASLOTS * ASUB];
-#pragma unroll
-        for (int i = 0; i < ASLOTS * ASUB; i++) vs[i] = a.out.act[(size_t)i * a.t.K + k];
-#pragma unroll
-        for (int i = 0; i < ASLOTS * ASUB; i++) a.out.act[(size_t)i * a.t.K + k] = 0;
-        long long sum = 0;
-#pragma unroll
-        for (int sl = 0; sl < ASLOTS; sl++) {
-            long long v = 0;
-#pragma unroll
-            for (int sub = 0; sub < ASUB; sub++) v += vs[sl * ASUB + sub];
-            sum += v; a.res->part_act[(size_t)sl * a.t.K + k] = v;
-        }
-        a.res->act[k] = sum;
-    }
-    if (threadIdx.x == 0) {
-        double tcx = 0.0, trc = 0.0, tb = 0.0; uint32_t tn = 0, tm = 0;
-        for (int l = 0; l < WAVE; l++) { tcx += red[l]; trc += red[WAVE + l]; tb += red[2 * WAVE + l]; tn += redu[l]; tm = redu[WAVE + l] > tm ? redu[WAVE + l] : tm; }
-        a.res->cx = tcx; a.res->rc = trc; a.res->bnd = tb; a.res->n_budget = tn; a.res->max_steps = tm;
-        *a.ticket = 0;
-    }
+    if (lane == 0) st_dev(&a.tickets[0], 0u);
+    if (prof && lane == 0) prof[13] = wv.now();
     __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&a.res->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    wv.sync();
+    if (prof && lane == 0) prof[14] = wv.now();
+    if (lane == 0) __hip_atomic_store(&a.res->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
+// d_sync: [tickets: 32 words][accumulators ASLOTS x KMAX i64][hand-over rows ASLOTS x KMAX i64][PartVal x ASLOTS]
+constexpr size_t SYNC_ACT = 128, SYNC_PACT = SYNC_ACT + (size_t)ASLOTS * KMAX * 8, SYNC_PVAL = SYNC_PACT + (size_t)ASLOTS * KMAX * 8, SYNC_BYTES = SYNC_PVAL + (size_t)ASLOTS * sizeof(PartVal);
+
+// stage profile (HQTICK_PRICE_PROFILE=1): intervals between the stamps of price_core.h / the kernel's tail
+constexpr int NPROF = 13;
+const int PROF_FROM[NPROF] = {0, 1, 3, 4, 5, 5, 8, 9, 10, 6, 11, 12, 13};
+const int PROF_TO[NPROF]   = {1, 2, 4, 5, 6, 8, 9, 10, 6, 11, 12, 13, 14};
+const char *const PROF_NAME[NPROF] = {"reduced costs + compaction", "dual pool + order + greedy fills", "level lists + root bound", "walk", "results + activities", "[results: zero the sums", "pattern + sums in LDS", "atomics + cost loads", "values]",
+                                      "acknowledgements before the ticket", "part ticket", "part sums + sweep ticket + totals (last block)", "system fence (last block)"};
 
 size_t al16(size_t v) { return (v + 15) & ~(size_t)15; }
 double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
 
-DeviceSweeper::~DeviceSweeper() { h_stage.release(); h_res.release(); h_pats.release(); h_blkv.release(); d_tab.release(); d_pats.release(); d_blk.release(); d_sync.release(); }
+DeviceSweeper::~DeviceSweeper() { h_stage.release(); h_res.release(); h_pats.release(); h_blkv.release(); d_tab.release(); d_pats.release(); d_blk.release(); d_sync.release(); d_prof.release(); }
 
 bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     if (t.K > (uint32_t)KMAX || t.n_blocks == 0) return false;
-    if (profile && !h_prof.ensure((size_t)t.n_blocks * 64 + 64)) return false;
+    if (profile && (!h_prof.ensure((size_t)t.n_blocks * PSLOTS * 8 + 64) || !d_prof.ensure((size_t)t.n_blocks * PSLOTS * 8 + 64))) return false;
     T = &t; n_sweeps = 0; cap_sweeps = max_sweeps;
+    if (!cus_known) { int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cus = (uint32_t)cus; cus_known = true; }
     max_block_cols = 0;
     for (uint32_t b = 0; b < t.n_blocks; b++) max_block_cols = std::max(max_block_cols, t.blk_off[b + 1] - t.blk_off[b]);
     if (force_nmax) max_block_cols = (uint32_t)hqblock::NMAX;   // (HQTICK_PRICE_NMAX=1: the full-size working set whatever the model — A/B switch)
@@ -184,14 +241,14 @@ bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     o_a = al16(o_cost + (size_t)t.n_cols * 8); o_ccap = al16(o_a + (size_t)t.n_cols * MMAX * 8); o_woff = al16(o_ccap + (size_t)t.n_cols * 4);
     o_wrow = al16(o_woff + (size_t)(t.n_cols + 1) * 4); o_wcoef = al16(o_wrow + nw * 2); tab_bytes = al16(o_wcoef + nw * 4);
     if (!h_stage.ensure(tab_bytes) || !d_tab.ensure(tab_bytes) || !h_res.ensure(sizeof(SweepResult) + 64)) return false;
-    if (!d_pats.ensure((size_t)max_sweeps * t.n_cols * 2) || !d_blk.ensure((size_t)t.n_blocks * 28 + 64) || !d_sync.ensure(64 + (size_t)ASLOTS * ASUB * KMAX * 8)) return false;
+    if (!d_pats.ensure((size_t)max_sweeps * t.n_cols * 2) || !d_blk.ensure((size_t)t.n_blocks * 28 + 64) || !d_sync.ensure(SYNC_BYTES)) return false;
     unsigned char *h = h_stage.as<unsigned char>();
     memcpy(h + o_off, t.blk_off.data(), (size_t)(t.n_blocks + 1) * 4); memcpy(h + o_m, t.blk_m.data(), t.n_blocks); memcpy(h + o_cap, t.blk_cap.data(), (size_t)t.n_blocks * MMAX * 8);
     memcpy(h + o_cost, t.col_cost.data(), (size_t)t.n_cols * 8); memcpy(h + o_a, t.col_a.data(), (size_t)t.n_cols * MMAX * 8); memcpy(h + o_ccap, t.col_cap.data(), (size_t)t.n_cols * 4);
     memcpy(h + o_woff, t.col_woff.data(), (size_t)(t.n_cols + 1) * 4);
     if (nw) { memcpy(h + o_wrow, t.w_row.data(), nw * 2); memcpy(h + o_wcoef, t.w_coef.data(), nw * 4); }
     if (hipMemcpyAsync(d_tab.p, h, tab_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return false;
-    if (hipMemsetAsync(d_sync.p, 0, 64 + (size_t)ASLOTS * ASUB * KMAX * 8, stream) != hipSuccess) return false;  // ticket + the wide rows' accumulators
+    if (hipMemsetAsync(d_sync.p, 0, SYNC_BYTES, stream) != hipSuccess) return false;  // tickets + the wide rows' accumulators (+ the parts' hand-over rows)
     SweepResult *r = h_res.as<SweepResult>();
     seq = r->seq;  // (whatever the last solve left: the next sweep writes seq + 1)
     return true;
@@ -237,17 +294,24 @@ bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool loca
                  (const int32_t *)(d + o_ccap), (const uint32_t *)(d + o_woff), (const uint16_t *)(d + o_wrow), (const int32_t *)(d + o_wcoef)};
     unsigned char *blk = d_blk.as<unsigned char>();
     a.out = SweepOut{d_pats.as<uint16_t>() + (size_t)n_sweeps * t.n_cols, (double *)blk, (double *)(blk + (size_t)t.n_blocks * 8), (double *)(blk + (size_t)t.n_blocks * 16),
-                     (long long *)(d_sync.as<unsigned char>() + 64), (uint32_t *)(blk + (size_t)t.n_blocks * 24), profile ? h_prof.dev<uint64_t>() : nullptr, (uint32_t)ASUB};
-    a.budget = budget; a.seq = ++seq; a.ticket = d_sync.as<uint32_t>(); a.res = h_res.dev<SweepResult>();
+                     (long long *)(d_sync.as<unsigned char>() + SYNC_ACT), (uint32_t *)(blk + (size_t)t.n_blocks * 24), profile ? d_prof.as<uint64_t>() : nullptr, (uint32_t)ASUB, dbg};
+    a.budget = budget; a.seq = ++seq; a.tickets = d_sync.as<uint32_t>(); a.pact = (long long *)(d_sync.as<unsigned char>() + SYNC_PACT); a.pval = (PartVal *)(d_sync.as<unsigned char>() + SYNC_PVAL); a.res = h_res.dev<SweepResult>();
     a.first = b0; a.local = local ? 1u : 0u;
     if (local) { unsigned char *lv = h_blkv.dev<unsigned char>(); a.lv_cx = (double *)lv; a.lv_rc = (double *)(lv + (size_t)t.n_blocks * 8); a.lv_bnd = (double *)(lv + (size_t)t.n_blocks * 16); a.lv_steps = (uint32_t *)(lv + (size_t)t.n_blocks * 24); }
     else { a.lv_cx = a.lv_rc = a.lv_bnd = nullptr; a.lv_steps = nullptr; }
     memset(a.pi, 0, sizeof(a.pi));
     memcpy(a.pi, pi, (size_t)t.K * 8);
     const double t0 = now_us();
-    if (max_block_cols <= 8) hipLaunchKernelGGL(k_price_sweep<hqblock::SharedN<8>>, dim3(b1 - b0), dim3(WAVE), 0, stream, a);
-    else if (max_block_cols <= 16) hipLaunchKernelGGL(k_price_sweep<hqblock::SharedN<16>>, dim3(b1 - b0), dim3(WAVE), 0, stream, a);
-    else hipLaunchKernelGGL(k_price_sweep<hqblock::SharedN<hqblock::NMAX>>, dim3(b1 - b0), dim3(WAVE), 0, stream, a);
+    // wavefronts per block: four while every workgroup of the sweep is resident at once at that width (<= 4 blocks per CU), two up to 8 per CU, else one
+    const uint32_t nblk = b1 - b0;
+    const int nw = force_waves ? force_waves : nblk <= 4u * n_cus ? 4 : nblk <= 8u * n_cus ? 2 : 1;
+#define HQ_SWEEP(SH_, NW_) hipLaunchKernelGGL((k_price_sweep<SH_, NW_>), dim3(nblk), dim3(WAVE * NW_), 0, stream, a)
+#define HQ_SWEEP_N(SH_) do { if (nw == 4) HQ_SWEEP(SH_, 4); else if (nw == 2) HQ_SWEEP(SH_, 2); else HQ_SWEEP(SH_, 1); } while (0)
+    if (max_block_cols <= 8) HQ_SWEEP_N(hqblock::SharedN<8>);
+    else if (max_block_cols <= 16) HQ_SWEEP_N(hqblock::SharedN<16>);
+    else HQ_SWEEP_N(hqblock::SharedN<hqblock::NMAX>);
+#undef HQ_SWEEP_N
+#undef HQ_SWEEP
     if (hipGetLastError() != hipSuccess) return false;
     // wait for the sweep's own completion word (pinned memory); the stream synchronisation is the fallback after 2 s
     volatile SweepResult *r = h_res.as<SweepResult>();
@@ -261,9 +325,20 @@ bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool loca
     }
     last_kernel_us = now_us() - t0;
     if (profile) {  // HQTICK_PRICE_PROFILE=1: per-stage medians over the blocks of this sweep (100 MHz wavefront clock), accumulated for end()
+        // (the stamps are written to HBM — stores into pinned memory would put a PCIe acknowledgement into every wait of the block — and copied once the kernel has ended)
+        if (hipMemcpyAsync(h_prof.p, d_prof.p, (size_t)t.n_blocks * PSLOTS * 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return false;
         const uint64_t *pr = h_prof.as<uint64_t>();
-        for (int st = 0; st < 6; st++) { std::vector<double> v; v.reserve(t.n_blocks); for (uint32_t b = 0; b < t.n_blocks; b++) if (pr[(size_t)b * 8 + st + 1] >= pr[(size_t)b * 8 + st] && pr[(size_t)b * 8 + st + 1]) v.push_back((double)(pr[(size_t)b * 8 + st + 1] - pr[(size_t)b * 8 + st]) / 100.0); if (v.empty()) continue; std::sort(v.begin(), v.end()); prof_med[st] += v[v.size() / 2]; prof_max[st] += v.back(); }
-        double smax = 0; for (uint32_t b = 0; b < t.n_blocks; b++) smax = std::max(smax, (double)pr[(size_t)b * 8 + 7]);
+        for (int st = 0; st < NPROF; st++) {
+            const int from = PROF_FROM[st], to = PROF_TO[st];
+            std::vector<double> v; v.reserve(t.n_blocks);
+            for (uint32_t b = 0; b < t.n_blocks; b++) { const uint64_t t0s = pr[(size_t)b * PSLOTS + from], t1s = pr[(size_t)b * PSLOTS + to]; if (t0s && t1s >= t0s) v.push_back((double)(t1s - t0s) / 100.0); }
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end()); prof_med[st] += v[v.size() / 2]; prof_max[st] += v.back();
+        }
+        uint64_t first = ~0ull, last_done = 0, seq_at = 0;
+        for (uint32_t b = 0; b < t.n_blocks; b++) { const uint64_t *q = pr + (size_t)b * PSLOTS; if (q[0] && q[0] < first) first = q[0]; if (q[6] > last_done) last_done = q[6]; if (q[14] > seq_at) seq_at = q[14]; }
+        if (first != ~0ull) { prof_span += (double)(last_done - first) / 100.0; if (seq_at) prof_tail += (double)(seq_at - last_done) / 100.0; }
+        double smax = 0; for (uint32_t b = 0; b < t.n_blocks; b++) smax = std::max(smax, (double)pr[(size_t)b * PSLOTS + 7]);
         prof_steps += smax; prof_n++;
     }
     total_sweeps++; total_block_solves += b1 - b0; total_us += last_kernel_us;
@@ -291,11 +366,11 @@ const uint16_t *DeviceSweeper::patterns(uint32_t first, uint32_t count) {
 
 void DeviceSweeper::end() {
     if (profile && prof_n) {
-        static const char *names[6] = {"reduced costs + compaction", "dual pool + order", "greedy fills", "level lists + root bound", "walk", "results + activities"};
         fprintf(stderr, "[price profile] %d sweeps, per block and sweep (us; median over blocks / slowest block, averaged over the sweeps):", prof_n);
-        for (int st = 0; st < 6; st++) fprintf(stderr, "  %s %.1f / %.1f;", names[st], prof_med[st] / prof_n, prof_max[st] / prof_n);
+        for (int st = 0; st < NPROF; st++) fprintf(stderr, "  %s %.1f / %.1f;", PROF_NAME[st], prof_med[st] / prof_n, prof_max[st] / prof_n);
+        fprintf(stderr, "  first block's start -> last block's results %.1f, -> completion word stored %.1f more;", prof_span / prof_n, prof_tail / prof_n);
         fprintf(stderr, "  most search steps of a block %.0f; sweep as the host saw it %.1f us\n", prof_steps / prof_n, total_us / (double)std::max<uint64_t>(1, total_sweeps));
-        for (int st = 0; st < 6; st++) prof_med[st] = prof_max[st] = 0; prof_steps = 0; prof_n = 0;
+        for (int st = 0; st < NPROF; st++) prof_med[st] = prof_max[st] = 0; prof_steps = 0; prof_span = prof_tail = 0; prof_n = 0;
     }
     T = nullptr;
 }

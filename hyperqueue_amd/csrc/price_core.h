@@ -49,22 +49,24 @@ struct SweepOut {
     double *blk_bnd;      // [n_blocks] >= V_w(pi): equal to blk_rc (plus rounding slack) unless the block's search ran out of budget, then its LP bound
     long long *act;       // [ASLOTS * K] partial sums over blocks of A_w x — integer coefficients, so the atomic sums are exact and order-free
     uint32_t *blk_steps;  // [n_blocks] search steps (0 = closed at the root); bit 31: budget exhausted
-    uint64_t *prof;       // optional [n_blocks * 8]: wavefront clock at the stage boundaries (tools/price_probe.py --profile); nullptr = off
+    uint64_t *prof;       // optional [n_blocks * PSLOTS]: wavefront clock at the stage boundaries (HQTICK_PRICE_PROFILE=1); nullptr = off
     // `act` may hold asub (a power of two) vectors per part instead of one: block b adds into vector b % asub of its part, whoever adds the totals up sums them
     // (price.hip: ASUB; the host emulation keeps one vector per part — 0 or 1 here).
     uint32_t asub = 1;
+    uint32_t dbg = 0;     // experiments only (HQTICK_PRICE_DBG): bit 0 = no global atomics (the sweep's activities are then wrong: timing runs)
 };
 
 // columns of a priced block whose reduced cost is at most this fraction of the block's largest original cost stay at zero (their possible
 // contribution is added to the block's bound)
 constexpr double RC_DROP = 1e-12;
+constexpr int PSLOTS = 16;  // profile stamps per block: 0-7 the stages of solve_priced_block (7: search steps), 8-10 inside its last stage, 11-14 the kernel's tail (price.hip)
 
 template <class W, class SH>
 HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, uint32_t b, const SweepOut &out, uint32_t budget) {
     const uint32_t c0 = t.blk_off[b], nb = t.blk_off[b + 1] - c0;
     const int m = (int)t.blk_m[b];
-    uint64_t *prof = out.prof ? out.prof + (size_t)b * 8 : nullptr;
-    if (prof && wv.first()) { prof[0] = wv.now(); for (int i = 1; i < 8; i++) prof[i] = 0; }
+    uint64_t *prof = out.prof ? out.prof + (size_t)b * PSLOTS : nullptr;
+    if (prof && wv.first()) { prof[0] = wv.now(); for (int i = 1; i < PSLOTS; i++) prof[i] = 0; }
     // stage the prices: the dual pool is empty at this point, its storage is the staging area
     double *spi = &S.py[0][0];
     static_assert(hqblock::PCAP * MMAX >= KMAX, "the prices are staged in the dual pool's storage");
@@ -82,6 +84,7 @@ HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, 
         if ((uint32_t)lane < nb) {
             const uint32_t j = c0 + (uint32_t)lane;
             const uint32_t e0 = t.col_woff[j], e1 = t.col_woff[j + 1];
+            S.woff[lane] = e0; if ((uint32_t)lane + 1 == nb) S.woff[nb] = e1;   // (for the results stage)
             cost = t.col_cost[j];
             // (everything else the block reads of its column, in the same round trip: bound and amounts wait in the work problem's storage — idle until setup_work —
             // for the test below and the compaction, instead of being fetched there behind a barrier each)
@@ -129,8 +132,9 @@ HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, 
     wv.sync();
     uint16_t *x = out.x + c0;
     if (n == 0) {
+        hqblock::pool_skip(wv);
         wv.each([&](int lane) { if ((uint32_t)lane < nb) x[lane] = 0; });
-        if (wv.first()) { out.blk_cx[b] = 0.0; out.blk_rc[b] = 0.0; out.blk_bnd[b] = dropped; out.blk_steps[b] = 0; }
+        if (wv.first()) { wv.put(&out.blk_cx[b], 0.0); wv.put(&out.blk_rc[b], 0.0); wv.put(&out.blk_bnd[b], dropped); wv.put(&out.blk_steps[b], 0u); }
         return;
     }
     if (prof && wv.first()) prof[1] = wv.now();  // reduced costs, columns compacted
@@ -165,28 +169,9 @@ HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, 
         S.pd[rank] = (uint8_t)lane;
     });
     wv.sync();
-    // dual pool
-    const uint32_t total = hqblock::binom((uint32_t)(n + m), m);
-    wv.each([&](int lane) { for (uint32_t tt = (uint32_t)lane; tt < total; tt += WAVE) hqblock::dual_candidate(wv, S, tt); });
-    wv.sync();
-    {
-        const uint32_t np = S.npool < (uint32_t)hqblock::PCAP ? S.npool : (uint32_t)hqblock::PCAP;
-        float *pkey = &S.dpen[0][0];
-        wv.each([&](int lane) { for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) pkey[i] = (float)(S.py[i][0] * S.cap[0] + S.py[i][1] * S.cap[1] + S.py[i][2] * S.cap[2] + S.py[i][3] * S.cap[3]); });
-        wv.sync();
-        wv.each([&](int lane) {
-            for (uint32_t i = (uint32_t)lane; i < np; i += WAVE) {
-                const float mine = pkey[i];
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < np; j++) { const float o = pkey[j]; rank += (o < mine || (o == mine && j < i)) ? 1u : 0u; }
-                S.porder[rank] = (uint16_t)i;
-            }
-        });
-        wv.sync();
-    }
-    if (prof && wv.first()) prof[2] = wv.now();  // dual pool built and ordered
-    wv.each([&](int lane) { hqblock::greedy_lane(S, lane); });
-    wv.sync();
+    // dual pool (ordered) and greedy fills: the section the workgroup's other wavefronts take part in (block_core.h: pool_sections)
+    hqblock::pool_main(wv, S);
+    if (prof && wv.first()) prof[2] = wv.now();  // dual pool built and ordered, greedy fills done
     if (prof && wv.first()) prof[3] = wv.now();  // greedy fills
     {
         int l = 0;
@@ -216,33 +201,53 @@ HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, 
     static_assert(sizeof(S.py) >= sizeof(long long) * KMAX, "the block's activities are summed in the dual pool's storage");
     wv.each([&](int lane) { for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) lact[k] = 0; });
     wv.sync();
+    if (prof && wv.first()) prof[8] = wv.now();
+    // (lane = column: the pattern; then lane = ENTRY of the block's wide-row lists — they are one contiguous range — two per lane in flight, the entry's column found by
+    // counting the list starts at or before it: one or two round trips for the block instead of a chain of them per column, 0.5 us median / 20 us on the last blocks)
     wv.each([&](int lane) {
         if ((uint32_t)lane >= nb) return;
         uint32_t xv = 0;
         if ((elig >> lane) & 1) xv = S.xbest[__builtin_popcountll(elig & ((1ull << lane) - 1ull))];
         x[lane] = (uint16_t)xv;
-        if (!xv) return;
-        const uint32_t j = c0 + (uint32_t)lane;
-        for (uint32_t e = t.col_woff[j]; e < t.col_woff[j + 1]; e++) wv.lds_add_i64(&lact[t.w_row[e]], (long long)t.w_coef[e] * (long long)xv);
+        S.wcap[lane] = (int32_t)xv;   // (the work problem is done with its caps)
     });
     wv.sync();
+    {
+        const uint32_t E0 = S.woff[0], E = S.woff[nb] - E0;
+        wv.each([&](int lane) {
+            for (uint32_t r0 = (uint32_t)lane; r0 < E; r0 += 2u * WAVE) {
+                const uint32_t r1 = r0 + (uint32_t)WAVE;
+                const bool two = r1 < E;
+                const uint16_t wr0 = t.w_row[E0 + r0], wr1 = two ? t.w_row[E0 + r1] : (uint16_t)0;
+                const int32_t wc0 = t.w_coef[E0 + r0], wc1 = two ? t.w_coef[E0 + r1] : 0;
+                uint32_t q0 = 0, q1 = 0;
+                for (uint32_t i = 1; i < nb; i++) { const uint32_t o = S.woff[i] - E0; q0 += o <= r0 ? 1u : 0u; q1 += o <= r1 ? 1u : 0u; }
+                const long long x0 = (long long)S.wcap[q0], x1 = two ? (long long)S.wcap[q1] : 0;
+                if (x0) wv.lds_add_i64(&lact[wr0], (long long)wc0 * x0);
+                if (x1) wv.lds_add_i64(&lact[wr1], (long long)wc1 * x1);
+            }
+        });
+    }
+    wv.sync();
+    if (prof && wv.first()) prof[9] = wv.now();
     wv.each([&](int lane) {
         const uint32_t nsub = out.asub ? out.asub : 1u;
         long long *slot = out.act + ((size_t)(b / part_size(t.n_blocks)) * nsub + (b & (nsub - 1u))) * t.K;
-        for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) if (lact[k] != 0) wv.atomic_add_i64(&slot[k], lact[k]);
+        for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) if (lact[k] != 0 && !(out.dbg & 1u)) wv.atomic_add_i64(&slot[k], lact[k]);
     });
     // (the original costs of the kept columns: one load per lane, side by side — lane 0 reading them one after the other was a chain of n global loads, 16 us on an
     // eight-column block against 3 us on the median one: the tail of every sweep)
     wv.each([&](int lane) { if (lane < n) S.lane_val[lane] = t.col_cost[c0 + (uint32_t)S.gcol[lane]]; });  // (S.wc holds the work problem's costs by now)
     wv.sync();
+    if (prof && wv.first()) prof[10] = wv.now();
     if (wv.first()) {
         double cx = 0.0, rc = 0.0;  // fixed order: the same sums on every replica
         for (int q = 0; q < n; q++) { const double xv = (double)S.xbest[q]; cx += S.lane_val[q] * xv; rc += S.c[q] * xv; }
-        out.blk_cx[b] = cx;
-        out.blk_rc[b] = rc;
+        wv.put(&out.blk_cx[b], cx);
+        wv.put(&out.blk_rc[b], rc);
         // the walk closes a node whose bound is within 1e-12 (relative) of the incumbent: the optimum is not above best * (1 + 1e-12)
-        out.blk_bnd[b] = (ok ? rc * (1.0 + 2e-12) : (root > rc ? root : rc)) + dropped;
-        out.blk_steps[b] = S.steps | (ok ? 0u : 0x80000000u);
+        wv.put(&out.blk_bnd[b], (ok ? rc * (1.0 + 2e-12) : (root > rc ? root : rc)) + dropped);
+        wv.put(&out.blk_steps[b], S.steps | (ok ? 0u : 0x80000000u));
         if (prof) { prof[6] = wv.now(); prof[7] = S.steps; }
     }
 }

@@ -12,13 +12,17 @@ namespace hqprice {
 struct DeviceSweeper : Sweeper {
     hipStream_t stream = nullptr;
     hqbuf::PinBuf h_stage, h_res, h_pats, h_prof, h_blkv;
-    bool profile = getenv("HQTICK_PRICE_PROFILE") != nullptr; double prof_med[6] = {0}, prof_max[6] = {0}, prof_steps = 0; int prof_n = 0;
-    hqbuf::DevBuf d_tab, d_pats, d_blk, d_sync;
+    bool profile = getenv("HQTICK_PRICE_PROFILE") != nullptr; double prof_med[16] = {0}, prof_max[16] = {0}, prof_steps = 0, prof_span = 0, prof_tail = 0; int prof_n = 0;
+    hqbuf::DevBuf d_tab, d_pats, d_blk, d_sync, d_prof;
     const HostTables *T = nullptr;
     size_t o_off = 0, o_m = 0, o_cap = 0, o_cost = 0, o_a = 0, o_ccap = 0, o_woff = 0, o_wrow = 0, o_wcoef = 0, tab_bytes = 0;
     uint32_t n_sweeps = 0, cap_sweeps = 0, seq = 0;
     uint32_t max_block_cols = 0;   // widest block of the model at hand: picks the kernel's working-set size (price.hip)
     bool force_nmax = getenv("HQTICK_PRICE_NMAX") != nullptr;
+    int force_waves = getenv("HQTICK_PRICE_WAVES") ? atoi(getenv("HQTICK_PRICE_WAVES")) : 0;   // A/B switch: wavefronts per block (1 / 2 / 4; 0 = by the sweep's width, price.hip: launch)
+    uint32_t dbg = getenv("HQTICK_PRICE_DBG") ? (uint32_t)atoi(getenv("HQTICK_PRICE_DBG")) : 0u;   // experiments (price_core.h: SweepOut::dbg)
+    uint32_t n_cus = 256;        // compute units of the device the stream belongs to (begin() asks)
+    bool cus_known = false;
     double last_kernel_us = 0;   // duration of the last sweep as the host saw it (launch -> result visible)
     // statistics for the bench line
     uint64_t total_sweeps = 0, total_block_solves = 0; double total_us = 0;
