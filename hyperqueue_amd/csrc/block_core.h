@@ -114,21 +114,19 @@ struct SharedN {  // one block's working set: LDS on the device
     double wc[N_];
     double wa[MMAX][N_], winv[MMAX][N_];
     uint32_t wmask[N_ + 1];       // block columns at positions < k
-    // The level lists of the walk and the greedy's vectors share their storage: the greedy runs (and its best lane is copied into xbest) before setup_work
-    // builds the first list.  (6 KB of the block's LDS: with it the block is 25.9 KB — six blocks per CU instead of four, tools/exp/resident_wg.hip.)
-    union {
-        struct {
-            uint16_t dl[N_ + 1][DPRE];    // per level: pool entries that are vertices of that level's dual polyhedron
-            float dpen[N_ + 1][DPRE];     // ... and the penalty of a capped column (phase 2), rounded up
-        };
-        struct {
-            uint8_t perm[N_][WAVE];       // greedy: [column slot][lane] — lanes side by side, so that a wavefront's accesses spread over the LDS banks
-            uint16_t gx[N_][WAVE];
-        };
-    };
+    // level lists of the walk
+    uint16_t dl[N_ + 1][DPRE];    // per level: pool entries that are vertices of that level's dual polyhedron
+    float dpen[N_ + 1][DPRE];     // ... and the penalty of a capped column (phase 2), rounded up
+    // the greedy's vectors.  (Until round 6 they shared the level lists' storage; with the greedy fills on a wavefront of their own the main wavefront builds the
+    // first level lists WHILE the fills run — pool_main / pool_await — and the two need their own 1.5 / 3 / 6 KB at 8 / 16 / 32 columns.)
+    uint8_t perm[N_][WAVE];       // [column slot][lane] — lanes side by side, so that a wavefront's accesses spread over the LDS banks
+    uint16_t gx[N_][WAVE];
+    double gval[WAVE];            // the fills' values
     int32_t wcap[N_];             // upper cap of a position (INT32_MAX = none)
     int32_t colcap[N_];           // upper cap of a block column (INT32_MAX = none): the priced blocks of the coupled solve (price_core.h) carry their model bounds here
     uint32_t woff[N_ + 1];        // priced blocks: where the columns' wide-row entries begin (price_core.h)
+    static constexpr int ECAP = 16 * N_;   // ... and the entries themselves, when the block has at most this many (c3p: 70 on 8 columns)
+    uint16_t ewr[ECAP]; int32_t ewc[ECAP];
     uint32_t dcnt[N_ + 1];
     // level stack of the walk (level k = number of positions still free)
     double rem[N_ + 1][MMAX];
@@ -446,7 +444,7 @@ HQB_HD void greedy_lane(SH &S, int lane) {
     }
     double z = 0.0;
     for (int j = n - 1; j >= 0; j--) z = z + S.c[j] * (double)S.gx[j][lane];
-    S.lane_val[lane] = z;
+    S.gval[lane] = z;
 }
 
 // ---- steps 2 + 3 as a section of the block that EVERY wavefront of its workgroup takes part in ---------------------------------------------------
@@ -500,13 +498,21 @@ HQB_HD void pool_sections(W &wv, SH &S) {
     });
     wv.pool_barrier(&S.bar, ++phase);  // the pool is ordered: the helpers among the pool wavefronts are done
 }
-// the main wavefront: open the section (group barrier A), take part, and leave with the greedy fills done as well
+// the main wavefront: open the section (group barrier A) and take part; the pool is complete and ordered when it returns, the greedy fills may still be running ...
 template <class W, class SH>
 HQB_HD void pool_main(W &wv, SH &S) {
     if (wv.first()) { S.cnext = 0; S.bar = 0; S.gdone = 0; }
     wv.group_sync();
     pool_sections(wv, S);
+}
+// ... until here: the first incumbent = the best of the 64 fills (the main wavefront builds the first level lists in between: setup_work needs the pool, not the fills)
+template <class W, class SH>
+HQB_HD void pool_await(W &wv, SH &S) {
     wv.await(&S.gdone);
+    int l = 0;
+    const double top = wv.argmax([&](int lane) { return S.gval[lane]; }, &l);
+    if (wv.first()) { S.best = top; for (int j = 0; j < S.n; j++) S.xbest[j] = S.gx[j][l]; }
+    wv.sync();
 }
 // ... which the main wavefront also passes when there is no block to work on (S.n == 0 or a status other than ST_OK), so that the helpers are released
 template <class W>
@@ -703,25 +709,28 @@ HQB_HD bool walk(W &wv, SH &S, int mode, double thr, uint32_t *budget, bool *fou
         // inner level: 64 values of the column at `pos` at once
         const double cut = mode == MODE_FIND ? thr : S.best + 1e-12 * (S.best < 0 ? -S.best : S.best);
         const double zk = S.zfix[k], cj = S.wc[pos];
-        // child bounds, the level's duals in chunks of 8 (tightest first): once a chunk has pruned every child the rest is not evaluated
+        // child bounds: child v survives when fixed part + min over the level's duals of (y . rem(v) + penalty) clears the cut.  The minimum is taken over ALL of the
+        // level's duals whatever the order they are looked at in (wv.ballot_bound: 64 children x chunks of 8 duals, tightest first, stopping once every child is
+        // pruned): the surviving set does not depend on it.
         const int cnt = (int)(S.dcnt[k - 1] < (uint32_t)DPRE ? S.dcnt[k - 1] : (uint32_t)DPRE);
-        const uint64_t mask = wv.ballot_chunked((cnt + 7) / 8,
-            [&](int lane, Probe &st) {
-                const int32_t v = p - lane;
+        const uint64_t mask = wv.ballot_bound(cnt, p + 1 < WAVE ? p + 1 : WAVE,
+            [&](int child, Probe &st) {
+                const int32_t v = p - child;
                 if (v < 0 || v > ubk) return false;
                 for (int r = 0; r < MMAX; r++) st.rem[r] = fma(-(double)v, S.wa[r][pos], S.rem[k][r]);
                 st.base = zk + cj * (double)v; st.b = 1e300;
                 return true;
             },
-            [&](int lane, Probe &st, int c) {
-                const int hi = (c + 1) * 8 < cnt ? (c + 1) * 8 : cnt;
-                double b = st.b;
-                for (int i = c * 8; i < hi; i++) {
+            [&](const Probe &st, int i0, int i1) {   // min over the duals [i0, i1)
+                double b = 1e300;
+                for (int i = i0; i < i1; i++) {
                     const double *d = S.py[S.dl[k - 1][i]];
                     const double val = d[0] * st.rem[0] + d[1] * st.rem[1] + d[2] * st.rem[2] + d[3] * st.rem[3] + (double)S.dpen[k - 1][i];
                     b = val < b ? val : b;
                 }
-                st.b = b;
+                return b;
+            },
+            [&](const Probe &st, double b) {
                 const double bound = st.base + b;
                 return mode == MODE_FIND ? bound >= cut : bound > cut;
             });
@@ -764,17 +773,12 @@ HQB_HD void solve_block(W &wv, SH &S, const ColTable &ct, const ClassTable &cl, 
     pool_main(wv, S);  // dual pool (ordered) and greedy fills
     if (prof && wv.first()) prof[2] = wv.now();
     if (prof && wv.first()) prof[3] = wv.now();
-    {
-        int l = 0;
-        const double top = wv.argmax([&](int lane) { return S.lane_val[lane]; }, &l);
-        if (wv.first()) { S.best = top; for (int j = 0; j < n; j++) S.xbest[j] = S.gx[j][l]; }
-        wv.sync();
-    }
     const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
     uint32_t left = budget;
     bool ok = true;
     // phase 1 unless the incumbent already meets the root bound
     setup_work(wv, S, all, -1, 0);
+    pool_await(wv, S);
     {
         double cap[MMAX];
         for (int r = 0; r < MMAX; r++) cap[r] = S.cap[r];
@@ -878,14 +882,13 @@ struct HostWave {
     static int ctz(uint64_t m) { int i = 0; while (!((m >> i) & 1)) i++; return i; }
     template <class F> void each(F f) { for (int l = 0; l < WAVE; l++) f(l); }
     template <class F> uint64_t ballot(F f) { uint64_t m = 0; for (int l = 0; l < WAVE; l++) if (f(l)) m |= 1ull << l; return m; }
-    // lanes whose init() holds and whose chunk(c) holds for every c < nchunks.  The device stops as soon as no lane is left (block_solve.hip).
-    template <class I, class Ch> uint64_t ballot_chunked(int nchunks, I init, Ch chunk) {
+    // children (lanes < nchild) whose init() holds and whose decide() holds for the minimum of part() over all cnt duals
+    template <class I, class P, class D> uint64_t ballot_bound(int cnt, int nchild, I init, P part, D decide) {
         uint64_t m = 0;
-        for (int l = 0; l < WAVE; l++) {
+        for (int l = 0; l < nchild; l++) {
             Probe st;
-            bool alive = init(l, st);
-            for (int c = 0; c < nchunks && alive; c++) alive = chunk(l, st, c);
-            if (alive) m |= 1ull << l;
+            if (!init(l, st)) continue;
+            if (decide(st, part(st, 0, cnt))) m |= 1ull << l;
         }
         return m;
     }

@@ -42,7 +42,7 @@ hipError_t block_solve(const ColTable &ct, const ClassTable &cl, const Output &o
     if (cl.n_classes == 0) return hipSuccess;
     hqk::LaunchTimer t = hqk::take_launch_timer();
     static const int force_waves = getenv("HQTICK_BLOCK_WAVES") ? atoi(getenv("HQTICK_BLOCK_WAVES")) : 0;   // A/B switch (1 / 2 / 4)
-    const int nw = force_waves ? force_waves : cl.n_classes <= 1024u ? 4 : cl.n_classes <= 2048u ? 2 : 1;
+    const int nw = force_waves == 1 || force_waves == 2 ? force_waves : 4;
     if (nw == 4) hipExtLaunchKernelGGL(k_block_solve<4>, dim3(cl.n_classes), dim3(WAVE * 4), 0, s, t.start, t.stop, 0, ct, cl, out, budget);
     else if (nw == 2) hipExtLaunchKernelGGL(k_block_solve<2>, dim3(cl.n_classes), dim3(WAVE * 2), 0, s, t.start, t.stop, 0, ct, cl, out, budget);
     else hipExtLaunchKernelGGL(k_block_solve<1>, dim3(cl.n_classes), dim3(WAVE), 0, s, t.start, t.stop, 0, ct, cl, out, budget);

@@ -12,6 +12,23 @@
 
 namespace hqblock {
 
+// The children of a level of the walk against the level's duals (block_core.h: walk): every lane is one child; chunks of 8 duals, tightest first, and once a chunk has
+// pruned every child the rest is not looked at — which is the common case after the FIRST chunk.  (Round 6 also tried the duals sliced over the idle lanes when a level
+// has fewer children than lanes, with a butterfly minimum over the slices: every step then pays the full minimum and five shuffles, and the walks were 15-20 % slower.)
+template <class I, class P, class D>
+__device__ __forceinline__ uint64_t dev_ballot_bound(int lane, int cnt, int nchild, I init, P part, D decide) {
+    (void)nchild;
+    const int nch = (cnt + 7) >> 3;
+    Probe st;
+    bool alive = init(lane, st);
+    double b = 1e300;
+    for (int c = 0; c < nch; c++) {
+        if (!__ballot(alive ? 1 : 0)) break;
+        if (alive) { const double v = part(st, c * 8, (c + 1) * 8 < cnt ? (c + 1) * 8 : cnt); b = v < b ? v : b; alive = decide(st, b); }
+    }
+    return __ballot(alive ? 1 : 0);
+}
+
 struct DevWave {
     static constexpr int WAVES = 1;
     __device__ int wave_index() const { return 0; }
@@ -34,15 +51,7 @@ struct DevWave {
     __device__ static int ctz(uint64_t m) { return __ffsll((long long)m) - 1; }
     template <class F> __device__ void each(F f) { f((int)threadIdx.x); }
     template <class F> __device__ uint64_t ballot(F f) { return __ballot(f((int)threadIdx.x) ? 1 : 0); }
-    template <class I, class Ch> __device__ uint64_t ballot_chunked(int nchunks, I init, Ch chunk) {
-        Probe st;
-        bool alive = init((int)threadIdx.x, st);
-        for (int c = 0; c < nchunks; c++) {
-            if (!__ballot(alive ? 1 : 0)) break;  // every child is pruned: the remaining duals cannot bring one back
-            if (alive) alive = chunk((int)threadIdx.x, st, c);
-        }
-        return __ballot(alive ? 1 : 0);
-    }
+    template <class I, class P, class D> __device__ uint64_t ballot_bound(int cnt, int nchild, I init, P part, D decide) { return dev_ballot_bound((int)threadIdx.x, cnt, nchild, init, part, decide); }
     template <class F> __device__ double argmax(F f, int *lane) {
         // butterfly over the wavefront: every lane ends with (largest value, lowest lane holding it)
         double v = f((int)threadIdx.x);
@@ -104,15 +113,7 @@ struct DevGroup {
     __device__ static int ctz(uint64_t m) { return __ffsll((long long)m) - 1; }
     template <class F> __device__ void each(F f) { f(lane()); }
     template <class F> __device__ uint64_t ballot(F f) { return __ballot(f(lane()) ? 1 : 0); }
-    template <class I, class Ch> __device__ uint64_t ballot_chunked(int nchunks, I init, Ch chunk) {
-        Probe st;
-        bool alive = init(lane(), st);
-        for (int c = 0; c < nchunks; c++) {
-            if (!__ballot(alive ? 1 : 0)) break;
-            if (alive) alive = chunk(lane(), st, c);
-        }
-        return __ballot(alive ? 1 : 0);
-    }
+    template <class I, class P, class D> __device__ uint64_t ballot_bound(int cnt, int nchild, I init, P part, D decide) { return dev_ballot_bound((int)lane(), cnt, nchild, init, part, decide); }
     template <class F> __device__ double argmax(F f, int *lane_out) {
         double v = f(lane());
         int l = lane();

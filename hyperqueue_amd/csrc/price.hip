@@ -54,7 +54,7 @@ struct SweepArgs {
     SweepOut out;
     uint32_t budget, seq;
     uint32_t *tickets;     // [0] the sweep's, [1 + p] part p's
-    long long *pact;       // [ASLOTS * K] the parts' activity vectors on their way from the parts' last blocks to the sweep's last block
+    long long *tact;       // [K] the sweep's activities: the parts' last blocks add their vectors up here, the sweep's last block reads and zeroes it
     PartVal *pval;         // [ASLOTS]
     SweepResult *res;
     // worker-range shards (price.h: ShardedSweeper): the grid covers the blocks [first, first + gridDim.x) only, and instead of the sweep's totals the last
@@ -71,7 +71,6 @@ struct SweepArgs {
 __device__ __forceinline__ double ld_dev(const double *p) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 __device__ __forceinline__ long long ld_dev(const long long *p) { return (long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t ld_dev(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_dev(double *p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(long long *p, long long v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // ... and what the host reads (pinned memory): system scope
@@ -110,44 +109,39 @@ __global__ __launch_bounds__(WAVE * NW) void k_price_sweep(const SweepArgs a) {
     last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
     if (prof && lane == 0) prof[12] = wv.now();
     if (!last) return;
-    {   // the part's last block
+    {   // the part's last block.  Everything it reads is asked for before anything is used: one round trip (per 256 blocks of the part)
+        long long va[2] = {0, 0};   // the part's activity vector (K <= KMAX = 128: two per lane)
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const uint32_t k = lane + (uint32_t)u * WAVE; if (k < K) va[u] = ld_dev(&a.out.act[(size_t)p * K + k]); }
+        // c.x of the part in the order of price.h: totals_from_blocks — four running sums, sum q over the part's blocks q, q + 4, q + 8, ... one after the other, then
+        // ((s0 + s1) + s2) + s3: the loads side by side (256 blocks per round, staged in the pool's storage), lanes 0-3 then add from LDS in that order.  The search
+        // steps of the part's blocks (budget flags, maximum) ride in the same rounds.
+        double *scr = &S.py[0][0];
+        static_assert(sizeof(S.py) >= 256 * sizeof(double), "a round of the part's c.x values is staged in the dual pool's storage");
         uint32_t nbud = 0, mx = 0;
-        for (uint32_t bb = pb0 + lane; bb < pb1; bb += WAVE * 4) {   // (four of a lane's blocks in flight)
-            uint32_t vst[4];
+        double s4 = 0.0;
+        for (uint32_t c0 = p * per; c0 < pe; c0 += 256) {
+            double v[4]; uint32_t vst[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t q = bb + (uint32_t)u * WAVE; vst[u] = q < pb1 ? ld_dev(&a.out.blk_steps[q]) : 0u; }
+            for (int u = 0; u < 4; u++) { const uint32_t q = c0 + lane + (uint32_t)u * WAVE; v[u] = (q < pe && !a.local) ? ld_dev(&a.out.blk_cx[q]) : 0.0; vst[u] = (q >= pb0 && q < pb1) ? ld_dev(&a.out.blk_steps[q]) : 0u; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { nbud += vst[u] >> 31; const uint32_t st = vst[u] & 0x7FFFFFFFu; mx = st > mx ? st : mx; }
+            for (int u = 0; u < 4; u++) { scr[lane + (uint32_t)u * WAVE] = v[u]; nbud += vst[u] >> 31; const uint32_t st = vst[u] & 0x7FFFFFFFu; mx = st > mx ? st : mx; }
+            wv.sync();
+            const uint32_t cnt = pe - c0 < 256u ? pe - c0 : 256u;
+            if (lane < 4 && !a.local) for (uint32_t i = lane; i < cnt; i += 4) s4 += scr[i];
+            wv.sync();
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { nbud += __shfl_xor(nbud, off, 64); const uint32_t om = __shfl_xor(mx, off, 64); mx = om > mx ? om : mx; }
-        double pcx = 0.0;
-        if (!a.local) {
-            // c.x of the part in the order of price.h: totals_from_blocks — four running sums, sum q over the part's blocks q, q + 4, q + 8, ... one after the other, then
-            // ((s0 + s1) + s2) + s3.  The loads are side by side (256 blocks per round, staged in the pool's storage); lanes 0-3 then add from LDS in that order.
-            double *scr = &S.py[0][0];
-            static_assert(sizeof(S.py) >= 256 * sizeof(double), "a round of the part's c.x values is staged in the dual pool's storage");
-            double s4 = 0.0;
-            for (uint32_t c0 = p * per; c0 < pe; c0 += 256) {
-                double v[4];
+        const double s1 = __shfl(s4, 1, 64), s2 = __shfl(s4, 2, 64), s3 = __shfl(s4, 3, 64);
+        const double pcx = ((s4 + s1) + s2) + s3;   // (lane 0's value is the part's)
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const uint32_t q = c0 + lane + (uint32_t)u * WAVE; v[u] = q < pe ? ld_dev(&a.out.blk_cx[q]) : 0.0; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) scr[lane + (uint32_t)u * WAVE] = v[u];
-                wv.sync();
-                const uint32_t cnt = pe - c0 < 256u ? pe - c0 : 256u;
-                if (lane < 4) for (uint32_t i = lane; i < cnt; i += 4) s4 += scr[i];
-                wv.sync();
-            }
-            const double s1 = __shfl(s4, 1, 64), s2 = __shfl(s4, 2, 64), s3 = __shfl(s4, 3, 64);
-            pcx = ((s4 + s1) + s2) + s3;   // (lane 0's value is the part's)
-        }
-        for (uint32_t k = lane; k < K; k += WAVE) {
-            long long *acc = &a.out.act[(size_t)p * K + k];
-            const long long v = ld_dev(acc);
-            st_dev(acc, 0);
-            st_dev(&a.pact[(size_t)p * K + k], v);
-            st_host(&a.res->part_act[(size_t)p * K + k], v);
+        for (int u = 0; u < 2; u++) {
+            const uint32_t k = lane + (uint32_t)u * WAVE;
+            if (k >= K) continue;
+            st_dev(&a.out.act[(size_t)p * K + k], 0);   // the accumulator, ready for the next sweep
+            st_host(&a.res->part_act[(size_t)p * K + k], va[u]);
+            if (va[u] != 0 && !a.local) atomicAdd(reinterpret_cast<unsigned long long *>(&a.tact[k]), (unsigned long long)va[u]);   // the sweep's activities: the parts' vectors added up (exact, order-free)
         }
         if (lane == 0) {
             st_dev(&a.pval[p].nbud, nbud); st_dev(&a.pval[p].mx, mx);
@@ -171,6 +165,12 @@ __global__ __launch_bounds__(WAVE * NW) void k_price_sweep(const SweepArgs a) {
         }
     } else {
         const uint32_t n_parts = (nb + per - 1) / per;   // parts that hold blocks (the others' rows of the result are zero)
+        // (asked for first, used last: the sweep's activities and the parts' step statistics)
+        long long ta[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const uint32_t k = lane + (uint32_t)u * WAVE; if (k < K) ta[u] = ld_dev(&a.tact[k]); }
+        uint32_t pn = 0, pm = 0;
+        if (lane < n_parts) { pn = ld_dev(&a.pval[lane].nbud); pm = ld_dev(&a.pval[lane].mx); }
         // the sweep's totals in the order of price.h: totals_from_blocks — lane l adds the blocks l, l + 64, ... one after the other, lane 0 then the 64 partial sums
         // in lane order (eight of a lane's blocks in flight per round)
         double cx = 0.0, rc = 0.0, bnd = 0.0;
@@ -183,25 +183,21 @@ __global__ __launch_bounds__(WAVE * NW) void k_price_sweep(const SweepArgs a) {
         }
         double *red = &S.py[0][0];
         red[lane] = cx; red[WAVE + lane] = rc; red[2 * WAVE + lane] = bnd;
-        uint32_t pn = 0, pm = 0;
-        if (lane < n_parts) { pn = ld_dev(&a.pval[lane].nbud); pm = ld_dev(&a.pval[lane].mx); }
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) { pn += __shfl_xor(pn, off, 64); const uint32_t om = __shfl_xor(pm, off, 64); pm = om > pm ? om : pm; }   // (lanes 0-15 hold the parts)
         wv.sync();
         double tcx = 0.0, trc = 0.0, tb = 0.0;
         if (lane == 0) for (int l = 0; l < WAVE; l++) { tcx += red[l]; trc += red[WAVE + l]; tb += red[2 * WAVE + l]; }
-        const uint32_t tn = pn, tm = pm;
-        for (uint32_t k = lane; k < K; k += WAVE) {
-            long long vs[ASLOTS];
 #pragma unroll
-            for (int i = 0; i < ASLOTS; i++) vs[i] = (uint32_t)i < n_parts ? ld_dev(&a.pact[(size_t)i * K + k]) : 0;
-            long long sum = 0;
-#pragma unroll
-            for (int i = 0; i < ASLOTS; i++) { sum += vs[i]; if ((uint32_t)i >= n_parts) st_host(&a.res->part_act[(size_t)i * K + k], 0); }
-            st_host(&a.res->act[k], sum);
+        for (int u = 0; u < 2; u++) {
+            const uint32_t k = lane + (uint32_t)u * WAVE;
+            if (k >= K) continue;
+            st_dev(&a.tact[k], 0);
+            st_host(&a.res->act[k], ta[u]);
+            for (uint32_t i = n_parts; i < (uint32_t)ASLOTS; i++) st_host(&a.res->part_act[(size_t)i * K + k], 0);
         }
         if (lane >= n_parts && lane < (uint32_t)ASLOTS) st_host(&a.res->part_cx[lane], 0.0);
-        if (lane == 0) { st_host(&a.res->cx, tcx); st_host(&a.res->rc, trc); st_host(&a.res->bnd, tb); st_host(&a.res->n_budget, tn); st_host(&a.res->max_steps, tm); }
+        if (lane == 0) { st_host(&a.res->cx, tcx); st_host(&a.res->rc, trc); st_host(&a.res->bnd, tb); st_host(&a.res->n_budget, pn); st_host(&a.res->max_steps, pm); }
     }
     if (lane == 0) st_dev(&a.tickets[0], 0u);
     if (prof && lane == 0) prof[13] = wv.now();
@@ -211,8 +207,8 @@ __global__ __launch_bounds__(WAVE * NW) void k_price_sweep(const SweepArgs a) {
     if (lane == 0) __hip_atomic_store(&a.res->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// d_sync: [tickets: 32 words][accumulators ASLOTS x KMAX i64][hand-over rows ASLOTS x KMAX i64][PartVal x ASLOTS]
-constexpr size_t SYNC_ACT = 128, SYNC_PACT = SYNC_ACT + (size_t)ASLOTS * KMAX * 8, SYNC_PVAL = SYNC_PACT + (size_t)ASLOTS * KMAX * 8, SYNC_BYTES = SYNC_PVAL + (size_t)ASLOTS * sizeof(PartVal);
+// d_sync: [tickets: 32 words][accumulators ASLOTS x KMAX i64][the sweep's activities KMAX i64][PartVal x ASLOTS]
+constexpr size_t SYNC_ACT = 128, SYNC_PACT = SYNC_ACT + (size_t)ASLOTS * KMAX * 8, SYNC_PVAL = SYNC_PACT + (size_t)KMAX * 8, SYNC_BYTES = SYNC_PVAL + (size_t)ASLOTS * sizeof(PartVal);
 
 // stage profile (HQTICK_PRICE_PROFILE=1): intervals between the stamps of price_core.h / the kernel's tail
 constexpr int NPROF = 13;
@@ -232,7 +228,6 @@ bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     if (t.K > (uint32_t)KMAX || t.n_blocks == 0) return false;
     if (profile && (!h_prof.ensure((size_t)t.n_blocks * PSLOTS * 8 + 64) || !d_prof.ensure((size_t)t.n_blocks * PSLOTS * 8 + 64))) return false;
     T = &t; n_sweeps = 0; cap_sweeps = max_sweeps;
-    if (!cus_known) { int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cus = (uint32_t)cus; cus_known = true; }
     max_block_cols = 0;
     for (uint32_t b = 0; b < t.n_blocks; b++) max_block_cols = std::max(max_block_cols, t.blk_off[b + 1] - t.blk_off[b]);
     if (force_nmax) max_block_cols = (uint32_t)hqblock::NMAX;   // (HQTICK_PRICE_NMAX=1: the full-size working set whatever the model — A/B switch)
@@ -295,16 +290,17 @@ bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool loca
     unsigned char *blk = d_blk.as<unsigned char>();
     a.out = SweepOut{d_pats.as<uint16_t>() + (size_t)n_sweeps * t.n_cols, (double *)blk, (double *)(blk + (size_t)t.n_blocks * 8), (double *)(blk + (size_t)t.n_blocks * 16),
                      (long long *)(d_sync.as<unsigned char>() + SYNC_ACT), (uint32_t *)(blk + (size_t)t.n_blocks * 24), profile ? d_prof.as<uint64_t>() : nullptr, (uint32_t)ASUB, dbg};
-    a.budget = budget; a.seq = ++seq; a.tickets = d_sync.as<uint32_t>(); a.pact = (long long *)(d_sync.as<unsigned char>() + SYNC_PACT); a.pval = (PartVal *)(d_sync.as<unsigned char>() + SYNC_PVAL); a.res = h_res.dev<SweepResult>();
+    a.budget = budget; a.seq = ++seq; a.tickets = d_sync.as<uint32_t>(); a.tact = (long long *)(d_sync.as<unsigned char>() + SYNC_PACT); a.pval = (PartVal *)(d_sync.as<unsigned char>() + SYNC_PVAL); a.res = h_res.dev<SweepResult>();
     a.first = b0; a.local = local ? 1u : 0u;
     if (local) { unsigned char *lv = h_blkv.dev<unsigned char>(); a.lv_cx = (double *)lv; a.lv_rc = (double *)(lv + (size_t)t.n_blocks * 8); a.lv_bnd = (double *)(lv + (size_t)t.n_blocks * 16); a.lv_steps = (uint32_t *)(lv + (size_t)t.n_blocks * 24); }
     else { a.lv_cx = a.lv_rc = a.lv_bnd = nullptr; a.lv_steps = nullptr; }
     memset(a.pi, 0, sizeof(a.pi));
     memcpy(a.pi, pi, (size_t)t.K * 8);
     const double t0 = now_us();
-    // wavefronts per block: four while every workgroup of the sweep is resident at once at that width (<= 4 blocks per CU), two up to 8 per CU, else one
+    // wavefronts per block: four.  (Measured on configs[3]'s 4096 sixteen-column blocks as well, where the helpers cost residency — six blocks per CU instead of
+    // nine: 193 us per sweep against 219 with two and 226 with one; profiles/r06/price_sweep_waves.txt.)
     const uint32_t nblk = b1 - b0;
-    const int nw = force_waves ? force_waves : nblk <= 4u * n_cus ? 4 : nblk <= 8u * n_cus ? 2 : 1;
+    const int nw = force_waves == 1 || force_waves == 2 ? force_waves : 4;
 #define HQ_SWEEP(SH_, NW_) hipLaunchKernelGGL((k_price_sweep<SH_, NW_>), dim3(nblk), dim3(WAVE * NW_), 0, stream, a)
 #define HQ_SWEEP_N(SH_) do { if (nw == 4) HQ_SWEEP(SH_, 4); else if (nw == 2) HQ_SWEEP(SH_, 2); else HQ_SWEEP(SH_, 1); } while (0)
     if (max_block_cols <= 8) HQ_SWEEP_N(hqblock::SharedN<8>);

@@ -70,30 +70,38 @@ HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, 
     // stage the prices: the dual pool is empty at this point, its storage is the staging area
     double *spi = &S.py[0][0];
     static_assert(hqblock::PCAP * MMAX >= KMAX, "the prices are staged in the dual pool's storage");
+    // Round trip 1: lane q reads everything the block needs of its column q — where its wide-row entries begin, cost, bound, amounts (they wait in the work problem's
+    // storage, idle until setup_work, for the test below and the compaction) — while the prices are copied into LDS.
     wv.each([&](int lane) {
         for (uint32_t k = (uint32_t)lane; k < t.K; k += WAVE) spi[k] = pi[k];
         if (lane < SH::NN) S.colcap[lane] = 2147483647;
         if (lane < MMAX) S.cap[lane] = lane < m ? t.blk_cap[(size_t)b * MMAX + lane] : 0.0;
-    });
-    if (wv.first()) { S.status = hqblock::ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = m; S.npool = 0; S.usedres = 0; }
-    wv.sync();
-    // lane q: reduced cost of column q.  (The column's entries in the wide rows are read four at a time — the loads of a group are independent of one another and of
-    // the sum, which then runs over them in the same order as a one-by-one loop: a dependent chain of global loads per entry was 6 us of every sweep.)
-    wv.each([&](int lane) {
-        double rc = -1.0, cost = 0.0;
         if ((uint32_t)lane < nb) {
             const uint32_t j = c0 + (uint32_t)lane;
-            const uint32_t e0 = t.col_woff[j], e1 = t.col_woff[j + 1];
-            S.woff[lane] = e0; if ((uint32_t)lane + 1 == nb) S.woff[nb] = e1;   // (for the results stage)
-            cost = t.col_cost[j];
-            // (everything else the block reads of its column, in the same round trip: bound and amounts wait in the work problem's storage — idle until setup_work —
-            // for the test below and the compaction, instead of being fetched there behind a barrier each)
+            S.woff[lane] = t.col_woff[j]; if ((uint32_t)lane + 1 == nb) S.woff[nb] = t.col_woff[j + 1];
+            S.wc[lane] = t.col_cost[j];
             S.wcap[lane] = t.col_cap[j];
             HQB_UNROLL
             for (int r = 0; r < MMAX; r++) S.wa[r][lane] = t.col_a[(size_t)j * MMAX + r];
-            S.wc[lane] = cost;
-            rc = cost;
-            for (uint32_t e = e0; e < e1; e += 4) {
+        }
+    });
+    if (wv.first()) { S.status = hqblock::ST_OK; S.steps = 0; S.steps_p1 = 0; S.n = 0; S.m = m; S.npool = 0; S.usedres = 0; }
+    wv.sync();
+    // Round trip 2: the block's wide-row entries — one contiguous range — lane = ENTRY, side by side into LDS (when they fit: ECAP; a chain of loads per column
+    // otherwise, four at a time).  The reduced costs then add up from LDS in the entries' order, and the results stage finds them there again.
+    const uint32_t E0 = nb ? S.woff[0] : 0u, E = nb ? S.woff[nb] - E0 : 0u;
+    const bool cached = E <= (uint32_t)SH::ECAP;
+    if (cached) {
+        wv.each([&](int lane) { for (uint32_t r = (uint32_t)lane; r < E; r += WAVE) { S.ewr[r] = t.w_row[E0 + r]; S.ewc[r] = t.w_coef[E0 + r]; } });
+        wv.sync();
+    }
+    wv.each([&](int lane) {
+        double rc = -1.0;
+        if ((uint32_t)lane < nb) {
+            const uint32_t e0 = S.woff[lane], e1 = S.woff[lane + 1];
+            rc = S.wc[lane];
+            if (cached) { for (uint32_t e = e0 - E0; e < e1 - E0; e++) rc -= spi[S.ewr[e]] * (double)S.ewc[e]; }
+            else for (uint32_t e = e0; e < e1; e += 4) {
                 uint16_t wr[4]; int32_t wc[4];
                 HQB_UNROLL
                 for (int u = 0; u < 4; u++) { const bool in = e + (uint32_t)u < e1; wr[u] = in ? t.w_row[e + (uint32_t)u] : (uint16_t)0; wc[u] = in ? t.w_coef[e + (uint32_t)u] : 0; }
@@ -171,16 +179,11 @@ HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, 
     wv.sync();
     // dual pool (ordered) and greedy fills: the section the workgroup's other wavefronts take part in (block_core.h: pool_sections)
     hqblock::pool_main(wv, S);
-    if (prof && wv.first()) prof[2] = wv.now();  // dual pool built and ordered, greedy fills done
-    if (prof && wv.first()) prof[3] = wv.now();  // greedy fills
-    {
-        int l = 0;
-        const double top = wv.argmax([&](int lane) { return S.lane_val[lane]; }, &l);
-        if (wv.first()) { S.best = top; for (int j = 0; j < n; j++) S.xbest[j] = S.gx[j][l]; }
-        wv.sync();
-    }
+    if (prof && wv.first()) prof[2] = wv.now();  // dual pool built and ordered
+    if (prof && wv.first()) prof[3] = wv.now();
     const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
     hqblock::setup_work(wv, S, all, -1, 0);
+    hqblock::pool_await(wv, S);  // the greedy fills (they ran beside the pool and the level lists): the first incumbent
     double capv[MMAX];
     for (int r = 0; r < MMAX; r++) capv[r] = S.cap[r];
     const double root = hqblock::lp_bound(S, n, capv);
@@ -212,22 +215,19 @@ HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, 
         S.wcap[lane] = (int32_t)xv;   // (the work problem is done with its caps)
     });
     wv.sync();
-    {
-        const uint32_t E0 = S.woff[0], E = S.woff[nb] - E0;
-        wv.each([&](int lane) {
-            for (uint32_t r0 = (uint32_t)lane; r0 < E; r0 += 2u * WAVE) {
-                const uint32_t r1 = r0 + (uint32_t)WAVE;
-                const bool two = r1 < E;
-                const uint16_t wr0 = t.w_row[E0 + r0], wr1 = two ? t.w_row[E0 + r1] : (uint16_t)0;
-                const int32_t wc0 = t.w_coef[E0 + r0], wc1 = two ? t.w_coef[E0 + r1] : 0;
-                uint32_t q0 = 0, q1 = 0;
-                for (uint32_t i = 1; i < nb; i++) { const uint32_t o = S.woff[i] - E0; q0 += o <= r0 ? 1u : 0u; q1 += o <= r1 ? 1u : 0u; }
-                const long long x0 = (long long)S.wcap[q0], x1 = two ? (long long)S.wcap[q1] : 0;
-                if (x0) wv.lds_add_i64(&lact[wr0], (long long)wc0 * x0);
-                if (x1) wv.lds_add_i64(&lact[wr1], (long long)wc1 * x1);
-            }
-        });
-    }
+    wv.each([&](int lane) {
+        for (uint32_t r0 = (uint32_t)lane; r0 < E; r0 += 2u * WAVE) {
+            const uint32_t r1 = r0 + (uint32_t)WAVE;
+            const bool two = r1 < E;
+            const uint16_t wr0 = cached ? S.ewr[r0] : t.w_row[E0 + r0], wr1 = !two ? (uint16_t)0 : cached ? S.ewr[r1] : t.w_row[E0 + r1];
+            const int32_t wc0 = cached ? S.ewc[r0] : t.w_coef[E0 + r0], wc1 = !two ? 0 : cached ? S.ewc[r1] : t.w_coef[E0 + r1];
+            uint32_t q0 = 0, q1 = 0;
+            for (uint32_t i = 1; i < nb; i++) { const uint32_t o = S.woff[i] - E0; q0 += o <= r0 ? 1u : 0u; q1 += o <= r1 ? 1u : 0u; }
+            const long long x0 = (long long)S.wcap[q0], x1 = two ? (long long)S.wcap[q1] : 0;
+            if (x0) wv.lds_add_i64(&lact[wr0], (long long)wc0 * x0);
+            if (x1) wv.lds_add_i64(&lact[wr1], (long long)wc1 * x1);
+        }
+    });
     wv.sync();
     if (prof && wv.first()) prof[9] = wv.now();
     wv.each([&](int lane) {

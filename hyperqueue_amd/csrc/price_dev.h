@@ -19,10 +19,8 @@ struct DeviceSweeper : Sweeper {
     uint32_t n_sweeps = 0, cap_sweeps = 0, seq = 0;
     uint32_t max_block_cols = 0;   // widest block of the model at hand: picks the kernel's working-set size (price.hip)
     bool force_nmax = getenv("HQTICK_PRICE_NMAX") != nullptr;
-    int force_waves = getenv("HQTICK_PRICE_WAVES") ? atoi(getenv("HQTICK_PRICE_WAVES")) : 0;   // A/B switch: wavefronts per block (1 / 2 / 4; 0 = by the sweep's width, price.hip: launch)
+    int force_waves = getenv("HQTICK_PRICE_WAVES") ? atoi(getenv("HQTICK_PRICE_WAVES")) : 0;   // A/B switch: wavefronts per block (1 / 2; anything else: 4, price.hip: launch)
     uint32_t dbg = getenv("HQTICK_PRICE_DBG") ? (uint32_t)atoi(getenv("HQTICK_PRICE_DBG")) : 0u;   // experiments (price_core.h: SweepOut::dbg)
-    uint32_t n_cus = 256;        // compute units of the device the stream belongs to (begin() asks)
-    bool cus_known = false;
     double last_kernel_us = 0;   // duration of the last sweep as the host saw it (launch -> result visible)
     // statistics for the bench line
     uint64_t total_sweeps = 0, total_block_solves = 0; double total_us = 0;

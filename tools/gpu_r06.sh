@@ -36,7 +36,7 @@ case $step in
              grep -h "price_sweep\|^kernel" "$OUT"/sweepctr*.summary.csv ;;
   stage)     HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p wave c4u c4p --no-host --repeat 2 2>&1 | grep -E "price profile|price \{" | tee "$OUT/price_sweep_stage_profile.txt" ;;
   waves)     # k_price_sweep with 1 / 2 / 4 wavefronts per block (HQTICK_PRICE_WAVES): the stage profile of each, then one run without the activity atomics (timing only)
-             for w in 1 2 4; do echo "== HQTICK_PRICE_WAVES=$w"; HQTICK_PRICE_WAVES=$w HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p c4u c4p --no-host --repeat 2 2>&1 | grep -E "price profile|price \{"; done | tee "$OUT/price_sweep_waves.txt"
+             for w in ${WAVES_LIST:-1 2 4}; do echo "== HQTICK_PRICE_WAVES=$w"; HQTICK_PRICE_WAVES=$w HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p c4u c4p --no-host --repeat 2 2>&1 | grep -E "price profile|price \{"; done | tee "$OUT/price_sweep_waves.txt"
              echo "== HQTICK_PRICE_WAVES=4, no activity atomics (timing only)" | tee -a "$OUT/price_sweep_waves.txt"
              HQTICK_PRICE_DBG=1 HQTICK_PRICE_WAVES=4 HQTICK_PRICE_PROFILE=1 timeout 300 python tools/price_probe.py c3p --no-host --repeat 2 2>&1 | grep -E "price profile" | tee -a "$OUT/price_sweep_waves.txt" ;;
   blocktests) timeout 900 python -m pytest tests/test_gpu_blocks.py -m gpu -q -x 2>&1 | grep -E "passed|failed|error|Error" | tail -6 | tee "$OUT/gpu_block_tests.log" ;;
