@@ -31,10 +31,10 @@
 namespace hqprice {
 
 static_assert(PARTS == ASLOTS, "the master's parts are the kernel's activity slots");
-// Activity vectors per part on the device (SweepOut::asub).  With one, the 64 blocks of a part (1024-block model; 256 at 4096 blocks) add into the same K addresses.
-// Four vectors per part were measured in round 5 (a quarter of the queue per address; the last workgroup adds them up): the sweep took as long and the slowest block's
-// last stage stayed at ~16 us — the atomics are not what it waits for.  One vector it stays; the plumbing is kept for the next attempt (a power of two).
-constexpr int ASUB = 1;
+// Activity vectors per part on the device (SweepOut::asub): block b adds into vector b % ASUB of its part, the part's last block adds them up.  With one, the 64 blocks
+// of a part (1024-block model; 256 at 4096 blocks) queue at the same K addresses — one cache line on c3p — at the moment they all finish: the last ones waited 3-5 us
+// for their acknowledgements (profiles/r06/price_sweep_waves.txt).  (Round 5 measured four vectors with no gain: the device fence behind them hid it then.)
+constexpr int ASUB = 4;
 
 namespace {
 
@@ -110,9 +110,13 @@ __global__ __launch_bounds__(WAVE * NW) void k_price_sweep(const SweepArgs a) {
     if (prof && lane == 0) prof[12] = wv.now();
     if (!last) return;
     {   // the part's last block.  Everything it reads is asked for before anything is used: one round trip (per 256 blocks of the part)
-        long long va[2] = {0, 0};   // the part's activity vector (K <= KMAX = 128: two per lane)
+        long long vs[2][ASUB];   // the part's activity vectors (K <= KMAX = 128: two entries per lane)
 #pragma unroll
-        for (int u = 0; u < 2; u++) { const uint32_t k = lane + (uint32_t)u * WAVE; if (k < K) va[u] = ld_dev(&a.out.act[(size_t)p * K + k]); }
+        for (int u = 0; u < 2; u++) {
+            const uint32_t k = lane + (uint32_t)u * WAVE;
+#pragma unroll
+            for (int sub = 0; sub < ASUB; sub++) vs[u][sub] = k < K ? ld_dev(&a.out.act[((size_t)p * ASUB + sub) * K + k]) : 0;
+        }
         // c.x of the part in the order of price.h: totals_from_blocks — four running sums, sum q over the part's blocks q, q + 4, q + 8, ... one after the other, then
         // ((s0 + s1) + s2) + s3: the loads side by side (256 blocks per round, staged in the pool's storage), lanes 0-3 then add from LDS in that order.  The search
         // steps of the part's blocks (budget flags, maximum) ride in the same rounds.
@@ -139,9 +143,11 @@ __global__ __launch_bounds__(WAVE * NW) void k_price_sweep(const SweepArgs a) {
         for (int u = 0; u < 2; u++) {
             const uint32_t k = lane + (uint32_t)u * WAVE;
             if (k >= K) continue;
-            st_dev(&a.out.act[(size_t)p * K + k], 0);   // the accumulator, ready for the next sweep
-            st_host(&a.res->part_act[(size_t)p * K + k], va[u]);
-            if (va[u] != 0 && !a.local) atomicAdd(reinterpret_cast<unsigned long long *>(&a.tact[k]), (unsigned long long)va[u]);   // the sweep's activities: the parts' vectors added up (exact, order-free)
+            long long v = 0;
+#pragma unroll
+            for (int sub = 0; sub < ASUB; sub++) { v += vs[u][sub]; st_dev(&a.out.act[((size_t)p * ASUB + sub) * K + k], 0); }   // (the accumulators, ready for the next sweep)
+            st_host(&a.res->part_act[(size_t)p * K + k], v);
+            if (v != 0 && !a.local) atomicAdd(reinterpret_cast<unsigned long long *>(&a.tact[k]), (unsigned long long)v);   // the sweep's activities: the parts' vectors added up (exact, order-free)
         }
         if (lane == 0) {
             st_dev(&a.pval[p].nbud, nbud); st_dev(&a.pval[p].mx, mx);
@@ -207,8 +213,8 @@ __global__ __launch_bounds__(WAVE * NW) void k_price_sweep(const SweepArgs a) {
     if (lane == 0) __hip_atomic_store(&a.res->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// d_sync: [tickets: 32 words][accumulators ASLOTS x KMAX i64][the sweep's activities KMAX i64][PartVal x ASLOTS]
-constexpr size_t SYNC_ACT = 128, SYNC_PACT = SYNC_ACT + (size_t)ASLOTS * KMAX * 8, SYNC_PVAL = SYNC_PACT + (size_t)KMAX * 8, SYNC_BYTES = SYNC_PVAL + (size_t)ASLOTS * sizeof(PartVal);
+// d_sync: [tickets: 32 words][accumulators ASLOTS x ASUB x KMAX i64][the sweep's activities KMAX i64][PartVal x ASLOTS]
+constexpr size_t SYNC_ACT = 128, SYNC_PACT = SYNC_ACT + (size_t)ASLOTS * ASUB * KMAX * 8, SYNC_PVAL = SYNC_PACT + (size_t)KMAX * 8, SYNC_BYTES = SYNC_PVAL + (size_t)ASLOTS * sizeof(PartVal);
 
 // stage profile (HQTICK_PRICE_PROFILE=1): intervals between the stamps of price_core.h / the kernel's tail
 constexpr int NPROF = 13;

@@ -146,35 +146,27 @@ HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, 
         return;
     }
     if (prof && wv.first()) prof[1] = wv.now();  // reduced costs, columns compacted
-    // search order (ascending size) and greedy order (descending value density), by rank counting — as build_block does for a class block
+    // search order (ascending size) and greedy order (descending value density), by rank counting — as build_block does for a class block (both keys in one pass,
+    // both ranks in the next: the density keys wait in the greedy's value array, which nobody reads before the fills have written it)
     wv.each([&](int lane) {
         if (lane >= n) return;
-        double sz = 0.0;
-        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0.0) sz += S.a[r][lane] / (S.cap[r] + 1.0);
+        double sz = 0.0, w = 0.0;
+        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0.0) { sz += S.a[r][lane] / (S.cap[r] + 1.0); w += S.cap[r] > 0.0 ? S.a[r][lane] / S.cap[r] : 1e30; }
         S.lane_val[lane] = sz;
+        S.gval[lane] = w > 0.0 ? S.c[lane] / w : 0.0;
     });
     wv.sync();
     wv.each([&](int lane) {
         if (lane >= n) return;
-        const double mine = S.lane_val[lane];
-        int rank = 0;
-        for (int i = 0; i < n; i++) { const double o = S.lane_val[i]; if (o < mine || (o == mine && i < lane)) rank++; }
+        const double mine = S.lane_val[lane], dens = S.gval[lane];
+        int rank = 0, drank = 0;
+        for (int i = 0; i < n; i++) {
+            const double o = S.lane_val[i], od = S.gval[i];
+            if (o < mine || (o == mine && i < lane)) rank++;
+            if (od > dens || (od == dens && i < lane)) drank++;
+        }
         S.pi[rank] = (uint8_t)lane;
-    });
-    wv.sync();
-    wv.each([&](int lane) {
-        if (lane >= n) return;
-        double w = 0.0;
-        for (int r = 0; r < m; r++) if (S.a[r][lane] > 0.0) w += S.cap[r] > 0.0 ? S.a[r][lane] / S.cap[r] : 1e30;
-        S.lane_val[lane] = w > 0.0 ? S.c[lane] / w : 0.0;
-    });
-    wv.sync();
-    wv.each([&](int lane) {
-        if (lane >= n) return;
-        const double mine = S.lane_val[lane];
-        int rank = 0;
-        for (int i = 0; i < n; i++) { const double o = S.lane_val[i]; if (o > mine || (o == mine && i < lane)) rank++; }
-        S.pd[rank] = (uint8_t)lane;
+        S.pd[drank] = (uint8_t)lane;
     });
     wv.sync();
     // dual pool (ordered) and greedy fills: the section the workgroup's other wavefronts take part in (block_core.h: pool_sections)
