@@ -290,14 +290,27 @@ struct Solver {
     bool base_caps = true;        // the sweeps run under the model's own column bounds (only those bound the relaxed model)
     Solver(const Request &r, Sweeper &s) : rq(r), sw(s) {}
 
-    // one sweep at pi; returns the cut's index or -1
-    int evaluate(const std::vector<double> &pi) {
-        if ((int)cuts.size() >= max_sweeps) return -1;
-        SweepTotals tot;
+    // one sweep at pi; returns the cut's index or -1.  In two halves for the caller with work to do meanwhile: evaluate_launch(pi), ..., evaluate(pi, true).
+    bool evaluate_launch(const std::vector<double> &pi) {
+        if ((int)cuts.size() >= max_sweeps) return false;
         std::vector<double> pig(P.KG, 0.0);
         for (int k = 0; k < P.K; k++) pig[P.grp_of[k]] += pi[k];
         const double t0 = now_us();
-        if (!sw.sweep(pig.data(), tot)) { failed = true; return -1; }
+        sw.pending_k = (uint32_t)P.KG;
+        if (!sw.sweep_launch(pig.data())) { failed = true; return false; }
+        sw.stat_sweep_us += now_us() - t0;
+        return true;
+    }
+    int evaluate(const std::vector<double> &pi, bool launched = false) {
+        if ((int)cuts.size() >= max_sweeps) return -1;
+        SweepTotals tot;
+        const double t0 = now_us();
+        if (launched) { if (!sw.sweep_finish(tot)) { failed = true; return -1; } }
+        else {
+            std::vector<double> pig(P.KG, 0.0);
+            for (int k = 0; k < P.K; k++) pig[P.grp_of[k]] += pi[k];
+            if (!sw.sweep(pig.data(), tot)) { failed = true; return -1; }
+        }
         sw.stat_sweep_us += now_us() - t0; sw.stat_sweeps++;
         if (!sw.merges_clock() && now_us() * 1e-6 > sw.guard_s) sw.time_up = true;  // (a sharded sweeper has merged the ranks' readings inside sweep(): a local reading here could split the replicas)
         sweep_steps += 64.0 + (double)tot.max_steps;
@@ -945,6 +958,10 @@ Answer run_solver(Solver &S, const double tp0) {
     S.max_sweeps = (int)std::min<size_t>(4096, std::max<size_t>(256, ((size_t)64 << 20) / ((size_t)P.T.n_cols * 2 + 1)));  // the device keeps every sweep's patterns: at most 64 MB of them
     if (!sw.begin(P.T, (uint32_t)S.max_sweeps)) { ans.why = "sweeper refused the model"; return ans; }
     struct Ender { Sweeper &s; ~Ender() { s.end(); } } ender{sw};
+    tmark("tables handed to the sweeper");
+    // the first sweep runs at zero prices: it needs the tables and nothing else, so it is on its way while the host works out the price caps
+    std::vector<double> pi0(K, 0.0);
+    if (!S.evaluate_launch(pi0)) { ans.why = "sweep failed"; return ans; }
     // price caps: beyond pmax every column of the row has a negative reduced cost (`<=` rows); for `>=` rows a multiple of the largest cost per unit
     S.pmax.assign(K, 0.0);
     {
@@ -962,8 +979,9 @@ Answer run_solver(Solver &S, const double tp0) {
         }
         for (int k = 0; k < K; k++) S.pmax[k] = gp[P.grp_of[k]];
     }
-    std::vector<double> pi0(K, 0.0);
-    if (S.evaluate(pi0) < 0) { ans.why = "sweep failed"; return ans; }
+    tmark("price caps done");
+    if (S.evaluate(pi0, true) < 0) { ans.why = "sweep failed"; return ans; }
+    tmark("first sweep (prices 0) done");
     S.theta_scale = std::max(S.cuts[0].bnd, 1e-9);
     ans.ran = true;
     double best_value = rq.incumbent ? rq.incumbent_value : -INF;

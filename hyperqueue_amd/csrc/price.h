@@ -52,6 +52,11 @@ struct Sweeper {
     virtual bool set_caps(const int32_t *col_cap) = 0;                      // new column bounds for the following sweeps
     virtual bool set_block_caps(const double *blk_cap) = 0;                 // new row capacities [n_blocks * 4] (a branch that fixes part of a block's content)
     virtual bool sweep(const double *pi, SweepTotals &out) = 0;             // sweep number = count of sweeps since begin()
+    // the same in two halves, for a caller with host work that does not depend on the sweep's outcome (the first sweep of a solve runs at zero prices): launch, ..., finish.
+    // The default runs the whole sweep in finish().
+    virtual bool sweep_launch(const double *pi) { pending_pi.assign(pi, pi + pending_k); return true; }
+    virtual bool sweep_finish(SweepTotals &out) { return sweep(pending_pi.data(), out); }
+    std::vector<double> pending_pi; uint32_t pending_k = 0;   // (set by whoever calls sweep_launch: the number of prices)
     virtual const uint16_t *patterns(uint32_t first, uint32_t count) = 0;   // host pointer to the patterns of sweeps [first, first + count): [count][n_cols]
     virtual void end() = 0;
     // one sweep over the blocks [b0, b1) only — this rank's worker range of a sharded scheduler; the patterns of the other blocks' columns are left untouched

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_price_sweep(const SweepArgs a) {
             if (!a.local) st_host(&a.res->part_cx[p], pcx);
             st_dev(&a.tickets[1 + p], 0u);
         }
-        acked();
+        __threadfence_system();   // this block's rows of the host's result are in place before its ticket says so (16 blocks side by side: ~0.5 us)
     }
     const uint32_t p_first = r0 / per, p_last = (r1 - 1) / per;
     if (lane == 0) last = __hip_atomic_fetch_add(&a.tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p_last - p_first ? 1u : 0u;
@@ -228,7 +228,7 @@ double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::
 
 }  // namespace
 
-DeviceSweeper::~DeviceSweeper() { h_stage.release(); h_res.release(); h_pats.release(); h_blkv.release(); d_tab.release(); d_pats.release(); d_blk.release(); d_sync.release(); d_prof.release(); }
+DeviceSweeper::~DeviceSweeper() { h_stage.release(); h_res.release(); h_pats.release(); h_pin.release(); h_blkv.release(); d_tab.release(); d_pats.release(); d_blk.release(); d_sync.release(); d_prof.release(); }
 
 bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     if (t.K > (uint32_t)KMAX || t.n_blocks == 0) return false;
@@ -242,6 +242,8 @@ bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     o_a = al16(o_cost + (size_t)t.n_cols * 8); o_ccap = al16(o_a + (size_t)t.n_cols * MMAX * 8); o_woff = al16(o_ccap + (size_t)t.n_cols * 4);
     o_wrow = al16(o_woff + (size_t)(t.n_cols + 1) * 4); o_wcoef = al16(o_wrow + nw * 2); tab_bytes = al16(o_wcoef + nw * 4);
     if (!h_stage.ensure(tab_bytes) || !d_tab.ensure(tab_bytes) || !h_res.ensure(sizeof(SweepResult) + 64)) return false;
+    if (!h_pin.ensure((size_t)std::min<uint32_t>(max_sweeps, PIN_SWEEPS) * t.n_cols * 2 + 64)) return false;
+    in_flight = false;
     if (!d_pats.ensure((size_t)max_sweeps * t.n_cols * 2) || !d_blk.ensure((size_t)t.n_blocks * 28 + 64) || !d_sync.ensure(SYNC_BYTES)) return false;
     unsigned char *h = h_stage.as<unsigned char>();
     memcpy(h + o_off, t.blk_off.data(), (size_t)(t.n_blocks + 1) * 4); memcpy(h + o_m, t.blk_m.data(), t.n_blocks); memcpy(h + o_cap, t.blk_cap.data(), (size_t)t.n_blocks * MMAX * 8);
@@ -286,15 +288,23 @@ bool DeviceSweeper::sweep_range(const double *pi, uint32_t b0, uint32_t b1, Rang
     return true;
 }
 
-bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool local, SweepTotals *outp) {
-    if (!T || n_sweeps >= cap_sweeps || b1 <= b0) return false;
+bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool local, SweepTotals *outp) { return launch_only(pi, b0, b1, local) && wait_done(outp); }
+bool DeviceSweeper::sweep_launch(const double *pi) { return launch_only(pi, 0, T ? T->n_blocks : 0, false); }
+bool DeviceSweeper::sweep_finish(SweepTotals &out) { return wait_done(&out); }
+
+bool DeviceSweeper::launch_only(const double *pi, uint32_t b0, uint32_t b1, bool local) {
+    if (!T || n_sweeps >= cap_sweeps || b1 <= b0 || in_flight) return false;
     const HostTables &t = *T;
     unsigned char *d = d_tab.as<unsigned char>();
     SweepArgs a;
     a.t = Tables{t.n_blocks, t.n_cols, t.K, (const uint32_t *)(d + o_off), (const uint8_t *)(d + o_m), (const double *)(d + o_cap), (const double *)(d + o_cost), (const double *)(d + o_a),
                  (const int32_t *)(d + o_ccap), (const uint32_t *)(d + o_woff), (const uint16_t *)(d + o_wrow), (const int32_t *)(d + o_wcoef)};
     unsigned char *blk = d_blk.as<unsigned char>();
-    a.out = SweepOut{d_pats.as<uint16_t>() + (size_t)n_sweeps * t.n_cols, (double *)blk, (double *)(blk + (size_t)t.n_blocks * 8), (double *)(blk + (size_t)t.n_blocks * 16),
+    // the patterns of the first PIN_SWEEPS sweeps go straight into pinned host memory (16 B per block over PCIe, complete when the completion word is: every block waits
+    // for its stores' acknowledgements before its ticket) — the primal side then reads them in place instead of behind a copy and a stream synchronisation; later sweeps
+    // (long branch-and-price runs) keep theirs in the HBM ring
+    uint16_t *xdst = n_sweeps < PIN_SWEEPS ? h_pin.dev<uint16_t>() + (size_t)n_sweeps * t.n_cols : d_pats.as<uint16_t>() + (size_t)n_sweeps * t.n_cols;
+    a.out = SweepOut{xdst, (double *)blk, (double *)(blk + (size_t)t.n_blocks * 8), (double *)(blk + (size_t)t.n_blocks * 16),
                      (long long *)(d_sync.as<unsigned char>() + SYNC_ACT), (uint32_t *)(blk + (size_t)t.n_blocks * 24), profile ? d_prof.as<uint64_t>() : nullptr, (uint32_t)ASUB, dbg};
     a.budget = budget; a.seq = ++seq; a.tickets = d_sync.as<uint32_t>(); a.tact = (long long *)(d_sync.as<unsigned char>() + SYNC_PACT); a.pval = (PartVal *)(d_sync.as<unsigned char>() + SYNC_PVAL); a.res = h_res.dev<SweepResult>();
     a.first = b0; a.local = local ? 1u : 0u;
@@ -315,13 +325,22 @@ bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool loca
 #undef HQ_SWEEP_N
 #undef HQ_SWEEP
     if (hipGetLastError() != hipSuccess) return false;
+    in_flight = true; flight_t0 = t0; flight_blocks = b1 - b0;
+    return true;
+}
+
+bool DeviceSweeper::wait_done(SweepTotals *outp) {
+    if (!T || !in_flight) return false;
+    in_flight = false;
+    const HostTables &t = *T;
+    const double t0 = flight_t0;
     // wait for the sweep's own completion word (pinned memory); the stream synchronisation is the fallback after 2 s
     volatile SweepResult *r = h_res.as<SweepResult>();
     for (uint64_t spins = 0;; spins++) {
-        if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) == a.seq) break;
+        if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) == seq) break;
         if ((spins & 0xFFFF) == 0xFFFF && now_us() - t0 > 2.0e6) {
             if (hipStreamSynchronize(stream) != hipSuccess) return false;
-            if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) != a.seq) return false;
+            if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) != seq) return false;
             break;
         }
     }
@@ -343,7 +362,7 @@ bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool loca
         double smax = 0; for (uint32_t b = 0; b < t.n_blocks; b++) smax = std::max(smax, (double)pr[(size_t)b * PSLOTS + 7]);
         prof_steps += smax; prof_n++;
     }
-    total_sweeps++; total_block_solves += b1 - b0; total_us += last_kernel_us;
+    total_sweeps++; total_block_solves += flight_blocks; total_us += last_kernel_us;
     n_sweeps++;
     if (!outp) return true;
     SweepTotals &out = *outp;
@@ -357,11 +376,14 @@ bool DeviceSweeper::launch(const double *pi, uint32_t b0, uint32_t b1, bool loca
 }
 
 const uint16_t *DeviceSweeper::patterns(uint32_t first, uint32_t count) {
-    if (!T || first + count > n_sweeps) return nullptr;
-    const size_t bytes = (size_t)count * T->n_cols * 2;
+    if (!T || first + count > n_sweeps || in_flight) return nullptr;
+    const size_t nc = T->n_cols, bytes = (size_t)count * nc * 2;
+    if (first + count <= PIN_SWEEPS) return h_pin.as<uint16_t>() + (size_t)first * nc;   // in place (launch_only)
     if (!h_pats.ensure(bytes + 64)) return nullptr;
     if (count == 0) return h_pats.as<uint16_t>();
-    if (hipMemcpyAsync(h_pats.p, d_pats.as<uint16_t>() + (size_t)first * T->n_cols, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return nullptr;
+    const uint32_t n_pin = first < PIN_SWEEPS ? PIN_SWEEPS - first : 0;   // sweeps of the range that sit in pinned memory
+    if (n_pin) memcpy(h_pats.p, h_pin.as<uint16_t>() + (size_t)first * nc, (size_t)n_pin * nc * 2);
+    if (hipMemcpyAsync(h_pats.as<uint16_t>() + (size_t)n_pin * nc, d_pats.as<uint16_t>() + (size_t)(first + n_pin) * nc, bytes - (size_t)n_pin * nc * 2, hipMemcpyDeviceToHost, stream) != hipSuccess) return nullptr;
     if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
     return h_pats.as<uint16_t>();
 }

@@ -11,7 +11,9 @@ namespace hqprice {
 
 struct DeviceSweeper : Sweeper {
     hipStream_t stream = nullptr;
-    hqbuf::PinBuf h_stage, h_res, h_pats, h_prof, h_blkv;
+    hqbuf::PinBuf h_stage, h_res, h_pats, h_pin, h_prof, h_blkv;
+    static constexpr uint32_t PIN_SWEEPS = 64;   // sweeps whose patterns the kernel writes into pinned memory (price.hip: launch_only)
+    bool in_flight = false; double flight_t0 = 0; uint32_t flight_blocks = 0;   // a sweep launched and not yet waited for
     bool profile = getenv("HQTICK_PRICE_PROFILE") != nullptr; double prof_med[16] = {0}, prof_max[16] = {0}, prof_steps = 0, prof_span = 0, prof_tail = 0; int prof_n = 0;
     hqbuf::DevBuf d_tab, d_pats, d_blk, d_sync, d_prof;
     const HostTables *T = nullptr;
@@ -32,6 +34,10 @@ struct DeviceSweeper : Sweeper {
     bool sweep(const double *pi, SweepTotals &out) override;
     bool sweep_range(const double *pi, uint32_t b0, uint32_t b1, RangeValues &out) override;   // this rank's blocks of a sharded sweep (price.h: ShardedSweeper)
     bool launch(const double *pi, uint32_t b0, uint32_t b1, bool local, SweepTotals *out);
+    bool launch_only(const double *pi, uint32_t b0, uint32_t b1, bool local);
+    bool wait_done(SweepTotals *out);
+    bool sweep_launch(const double *pi) override;
+    bool sweep_finish(SweepTotals &out) override;
     const uint16_t *patterns(uint32_t first, uint32_t count) override;
     void end() override;
 };
