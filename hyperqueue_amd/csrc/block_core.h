@@ -668,11 +668,18 @@ HQB_HD bool walk(W &wv, SH &S, int mode, double thr, uint32_t *budget, bool *fou
     int k = wn;
     uint32_t steps = 0;
     bool in_budget = true;
+    // The state of the CURRENT level lives in registers (it is the same in every lane): next value to try, upper bound, what is left of the rows, the fixed part of the
+    // objective — and the incumbent's value.  A descent works the next level's state out in every lane from those registers; lane 0 also writes it to the level stack
+    // in LDS, which is read again only when the walk comes BACK to a level (until round 6 every step began by reading its level from LDS, behind the barrier that
+    // followed lane 0's writes: two or three LDS round trips of a step's seven).
+    int32_t p = 0, ubk = 0; double remk[MMAX], zk = 0.0;
+    auto load_level = [&](int kk) { p = S.ptr[kk]; ubk = S.ub[kk]; for (int r = 0; r < MMAX; r++) remk[r] = S.rem[kk][r]; zk = S.zfix[kk]; };
+    load_level(k);
+    double best = S.best;
     while (k <= wn) {
         if (steps >= *budget) { in_budget = false; break; }
         steps++;
-        const int32_t p = S.ptr[k], ubk = S.ub[k];
-        if (p < 0) { k++; continue; }  // level exhausted
+        if (p < 0) { k++; if (k <= wn) load_level(k); continue; }  // level exhausted
         const int pos = k - 1;
         if (k == 2) {  // leaves: every lane a complete point
             auto eval = [&](int lane, int32_t *x0, double *val) { return terminal_lane(S, p - lane, x0, val); };
@@ -692,23 +699,25 @@ HQB_HD bool walk(W &wv, SH &S, int mode, double thr, uint32_t *budget, bool *fou
             } else {
                 int l = -1;
                 const double top = wv.argmax([&](int lane) { int32_t x0; double val; return eval(lane, &x0, &val) ? val : -1.0; }, &l);
-                if (l >= 0 && top > S.best) {
-                    wv.sync();  // every lane has read S.best
+                if (l >= 0 && top > best) {
                     if (wv.first()) {
                         int32_t x0 = 0; double val = 0; eval(l, &x0, &val);
                         S.xsel[1] = (uint32_t)(p - l); S.xsel[0] = (uint32_t)x0;
                         for (int q = 0; q < wn; q++) S.xbest[S.wcol[q]] = S.xsel[q];
                         S.best = val;
                     }
+                    best = top;   // (= val: the same lane's evaluation)
+                    wv.sync();
                 }
             }
-            if (wv.first()) S.ptr[2] = p - WAVE;
-            wv.sync();
+            p -= WAVE;
             continue;
         }
         // inner level: 64 values of the column at `pos` at once
-        const double cut = mode == MODE_FIND ? thr : S.best + 1e-12 * (S.best < 0 ? -S.best : S.best);
-        const double zk = S.zfix[k], cj = S.wc[pos];
+        const double cut = mode == MODE_FIND ? thr : best + 1e-12 * (best < 0 ? -best : best);
+        const double cj = S.wc[pos];
+        double waj[MMAX];
+        for (int r = 0; r < MMAX; r++) waj[r] = S.wa[r][pos];
         // child bounds: child v survives when fixed part + min over the level's duals of (y . rem(v) + penalty) clears the cut.  The minimum is taken over ALL of the
         // level's duals whatever the order they are looked at in (wv.ballot_bound: 64 children x chunks of 8 duals, tightest first, stopping once every child is
         // pruned): the surviving set does not depend on it.
@@ -717,7 +726,7 @@ HQB_HD bool walk(W &wv, SH &S, int mode, double thr, uint32_t *budget, bool *fou
             [&](int child, Probe &st) {
                 const int32_t v = p - child;
                 if (v < 0 || v > ubk) return false;
-                for (int r = 0; r < MMAX; r++) st.rem[r] = fma(-(double)v, S.wa[r][pos], S.rem[k][r]);
+                for (int r = 0; r < MMAX; r++) st.rem[r] = fma(-(double)v, waj[r], remk[r]);
                 st.base = zk + cj * (double)v; st.b = 1e300;
                 return true;
             },
@@ -734,19 +743,27 @@ HQB_HD bool walk(W &wv, SH &S, int mode, double thr, uint32_t *budget, bool *fou
                 const double bound = st.base + b;
                 return mode == MODE_FIND ? bound >= cut : bound > cut;
             });
-        if (!mask) { if (wv.first()) S.ptr[k] = p - WAVE; wv.sync(); continue; }
+        if (!mask) { p -= WAVE; continue; }
         const int l = wv.ctz(mask);
         const int32_t v = p - l;
+        // descend: the next level's state, in every lane
+        double nrem[MMAX];
+        for (int r = 0; r < MMAX; r++) nrem[r] = fma(-(double)v, waj[r], remk[r]);
+        const double nz = zk + cj * (double)v;
+        int32_t nub = S.wcap[pos - 1];
+        for (int r = 0; r < m; r++) if (S.wa[r][pos - 1] > 0.0) { const int32_t q = fits(nrem[r], S.wa[r][pos - 1], S.winv[r][pos - 1]); nub = q < nub ? q : nub; }
         if (wv.first()) {
             S.xsel[pos] = (uint32_t)v;
-            S.ptr[k] = v - 1;
-            for (int r = 0; r < MMAX; r++) S.rem[k - 1][r] = fma(-(double)v, S.wa[r][pos], S.rem[k][r]);
-            S.zfix[k - 1] = zk + cj * (double)v;
-            S.ub[k - 1] = level_ub(S, k - 1);
-            S.ptr[k - 1] = S.ub[k - 1];
+            S.ptr[k] = v - 1;   // (where this level goes on when the walk comes back)
+            for (int r = 0; r < MMAX; r++) S.rem[k - 1][r] = nrem[r];
+            S.zfix[k - 1] = nz;
+            S.ub[k - 1] = nub;
+            S.ptr[k - 1] = nub;
         }
         wv.sync();
         k--;
+        p = nub; ubk = nub; zk = nz;
+        for (int r = 0; r < MMAX; r++) remk[r] = nrem[r];
     }
     *budget -= steps < *budget ? steps : *budget;
     if (wv.first()) S.steps += steps;

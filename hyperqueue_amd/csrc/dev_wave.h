@@ -29,6 +29,34 @@ __device__ __forceinline__ uint64_t dev_ballot_bound(int lane, int cnt, int nchi
     return __ballot(alive ? 1 : 0);
 }
 
+// The wavefront's largest value of a double per lane, in every lane: a prefix maximum inside the rows of 16 lanes by DPP row shifts, the rows joined by the two row
+// broadcasts, lane 63 read back — a dozen cycles per step where a butterfly of ds_bpermute shuffles paid an LDS-crossbar round trip per step (the leaves of a walk take
+// one arg-max per step: ~0.4 us of a ~1 us step).  max() is exact, so the value is the butterfly's.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_step(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int tlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false), thi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    const double t = __hiloint2double(thi, tlo);
+    return t > v ? t : v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = dpp_max_step<0x111, 0xF>(v);  // row_shr:1
+    v = dpp_max_step<0x112, 0xF>(v);  // row_shr:2
+    v = dpp_max_step<0x114, 0xF>(v);  // row_shr:4
+    v = dpp_max_step<0x118, 0xF>(v);  // row_shr:8   (lane 15 of every row: the row's maximum)
+    v = dpp_max_step<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3  (lane 63: the wavefront's)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// largest value, lowest lane among equals (the value returned is that lane's own); *lane = -1 when every value is negative
+__device__ __forceinline__ double dev_argmax(double v, int *lane_out) {
+    const double m = wave_max_f64(v);
+    if (m < 0.0) { *lane_out = -1; return -1.0; }
+    const int l = __ffsll((long long)__ballot(v == m ? 1 : 0)) - 1;
+    *lane_out = l;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 struct DevWave {
     static constexpr int WAVES = 1;
     __device__ int wave_index() const { return 0; }
@@ -52,19 +80,7 @@ struct DevWave {
     template <class F> __device__ void each(F f) { f((int)threadIdx.x); }
     template <class F> __device__ uint64_t ballot(F f) { return __ballot(f((int)threadIdx.x) ? 1 : 0); }
     template <class I, class P, class D> __device__ uint64_t ballot_bound(int cnt, int nchild, I init, P part, D decide) { return dev_ballot_bound((int)threadIdx.x, cnt, nchild, init, part, decide); }
-    template <class F> __device__ double argmax(F f, int *lane) {
-        // butterfly over the wavefront: every lane ends with (largest value, lowest lane holding it)
-        double v = f((int)threadIdx.x);
-        int l = (int)threadIdx.x;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(v, off, 64);
-            const int ol = __shfl_xor(l, off, 64);
-            if (ov > v || (ov == v && ol < l)) { v = ov; l = ol; }
-        }
-        *lane = v < 0.0 ? -1 : l;
-        return v < 0.0 ? -1.0 : v;
-    }
+    template <class F> __device__ double argmax(F f, int *lane) { return dev_argmax(f((int)threadIdx.x), lane); }
 };
 
 template <int NW>
@@ -114,18 +130,7 @@ struct DevGroup {
     template <class F> __device__ void each(F f) { f(lane()); }
     template <class F> __device__ uint64_t ballot(F f) { return __ballot(f(lane()) ? 1 : 0); }
     template <class I, class P, class D> __device__ uint64_t ballot_bound(int cnt, int nchild, I init, P part, D decide) { return dev_ballot_bound((int)lane(), cnt, nchild, init, part, decide); }
-    template <class F> __device__ double argmax(F f, int *lane_out) {
-        double v = f(lane());
-        int l = lane();
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(v, off, 64);
-            const int ol = __shfl_xor(l, off, 64);
-            if (ov > v || (ov == v && ol < l)) { v = ov; l = ol; }
-        }
-        *lane_out = v < 0.0 ? -1 : l;
-        return v < 0.0 ? -1.0 : v;
-    }
+    template <class F> __device__ double argmax(F f, int *lane_out) { return dev_argmax(f(lane()), lane_out); }
 };
 
 }  // namespace hqblock
