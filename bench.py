@@ -296,7 +296,7 @@ def dag_churn(cfg, steps: int, seed: int, n_classes: int, shape: str = "random",
 def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: float = 0.10):
     """SURVEY.md §8(d) steady state on one GPU: after the cold tick, every running task finishes with probability `release` before the next tick
     ("free a random 10 % of assigned tasks per tick and re-run"), so the workers' free vectors all differ (about one worker class per worker) and
-    the placement is ~1000 different bounded knapsacks per tick — solved by k_block_solve, one wavefront per class.  The ready set stays
+    the placement is ~1000 different bounded knapsacks per tick — solved by k_block_solve, one workgroup of four wavefronts per class.  The ready set stays
     resident and saturated (arrivals replace what was handed out, class by class).  Prefilled tasks leave the queue but are not tracked as
     running (the sleep-0 model of benchmarks/experiment-per-task-overhead.py: they are done before the next tick)."""
     import dataclasses
@@ -381,7 +381,7 @@ def steady_hetero(cfg, snap, steps: int, seed: int, cpu_ticks: int, release: flo
         "all_ticks_optimal_and_canonical": bool(all(r["optimal"] and r["canonical"] for r in use)),
         "block_solve_kernel": {"avg_us": med("block_solve_us"), "classes_per_launch": int(med("n_classes_device")), "classes_per_s": med("n_classes_device") / (med("block_solve_us") * 1e-6) if med("block_solve_us") > 0 else None,
                                "max_search_steps": int(max(r["block_steps_max"] for r in use)),
-                               "bound": "latency / integer-f64 ALU in LDS: one wavefront per class, 25.9 KB of LDS per block = six blocks resident per CU (measured: tools/exp/resident_wg.hip; 40.8 KB and four per CU until round 4); not an HBM-bound kernel (a class reads ~60 B)"},
+                               "bound": "latency / integer-f64 ALU in LDS: a workgroup of four wavefronts per class (one runs the chain, the others share its dual pool and run its greedy fills), 36.9 KB of LDS per block = four blocks resident per CU; not an HBM-bound kernel (a class reads ~60 B)"},
         "tick_stages_us": {"gpu_phase_a_scans": med("t_scan"), "batches": med("t_batches"), "placement": med("t_solve"), "placement_worker_classes": med("solve_classify_us"),
                            "placement_block_solves_incl_launch_and_wait": med("solve_blocks_us"), "placement_counts_in_map_order": med("solve_decode_us"), "mapping_plan_gpu_phase_c": med("t_map")},
     }
@@ -903,9 +903,10 @@ def main():
                      "dominant_kernel": ({"kernel": "k_price_sweep", "launches_per_tick": int(sweeps), "blocks_per_launch": int(blocks), "avg_us_launch_to_totals_on_host": sweep_us / sweeps,
                                           "block_solves_per_s": blocks * sweeps / (sweep_us * 1e-6) if sweep_us > 0 else None, "share_of_tick": sweep_us / (1e6 * p50),
                                           "rocprofv3": prof_sw,
-                                          "bound": "latency: one wavefront per worker block walks dependent chains on LDS-resident data (exact bounded knapsack under the current prices, <= 32 columns x 4 rows; "
-                                                   "25.9 KB of LDS = six blocks per CU, 1536 resident: a sweep of 1024 blocks is ONE round whose length is the slowest block's chain).  A block reads 0.5-2 KB: "
-                                                   "not an HBM kernel, not MFMA work.  Counters (profiles/r04, --pmc passes): LDS instructions active 5 % of the wave cycles, VALU 15 %",
+                                          "bound": "latency: a workgroup of four wavefronts per worker block — one walks the block's dependent chain on LDS-resident data (exact bounded knapsack under the current "
+                                                   "prices, <= 32 columns x 4 rows), the others share its dual pool and run its greedy fills — 17.5 / 23.9 / 36.9 KB of LDS at 8 / 16 / 32 columns, six blocks per CU "
+                                                   "(wavefront slots): a sweep of 1024 blocks is ONE round whose length is the slowest block's chain.  A block reads 0.5-2 KB: not an HBM kernel, not MFMA work.  "
+                                                   "Counters: profiles/r06/sweepctr_*.csv (--pmc passes of the headline command)",
                                           "figure_of_merit": "exact block solves per second, launch -> totals visible on the host"} if coupled else None)},
     }
     if run_wd is not None:

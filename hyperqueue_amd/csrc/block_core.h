@@ -1,4 +1,5 @@
-// Exact solver of ONE worker-class block of the separable placement model, one wavefront per block.
+// Exact solver of ONE worker-class block of the separable placement model: one wavefront runs the block's chain (up to three more share its dual pool and run its
+// greedy fills: pool_sections).
 //
 // Where it sits: run_scheduling_solver (/root/reference/crates/tako/src/internal/scheduler/solver.rs:95-192) creates, per worker, one `nat`
 // column per (batch, variant) the worker can run now and one row per resource: sum_j a[r][j] x_j <= free[r].  On a tick without priority

@@ -1,9 +1,9 @@
 // k_block_solve: the per-worker-class blocks of the separable placement model (run_scheduling_solver's hot loop,
-// /root/reference/crates/tako/src/internal/scheduler/solver.rs:95-192, then the solve of solver/highs.rs:65-88) — one wavefront per class.
+// /root/reference/crates/tako/src/internal/scheduler/solver.rs:95-192, then the solve of solver/highs.rs:65-88) — one workgroup per class.
 //
-// Launch shape: grid = number of worker classes (about one per worker on a steady-state cluster: 1024-4096), block = 64 threads = ONE wave64,
-// 25.9 KB of LDS per block (dual vertices, level stack; the 64 greedy vectors share the level lists' storage) -> 6 blocks per CU, 1536 resident on the 256 CUs, spread
-// round-robin over the 8 XCDs by the dispatcher; blocks share nothing but the read-only column table (a few hundred bytes, L2-resident), so no
+// Launch shape: grid = number of worker classes (about one per worker on a steady-state cluster: 1024-4096), block = 256 threads = FOUR wave64 (one runs the class's chain,
+// the others share its dual pool and run its greedy fills, then leave: block_core.h, pool_sections), 36.9 KB of LDS per block (dual vertices, level stack, greedy
+// vectors) -> 4 blocks per CU, 1024 resident on the 256 CUs, spread round-robin over the 8 XCDs by the dispatcher; blocks share nothing but the read-only column table (a few hundred bytes, L2-resident), so no
 // XCD-aware mapping is needed.  Integer / f64 scalar work on data that lives in LDS: not an HBM-bound kernel, not MFMA work either — its
 // figure of merit is classes solved per second.  The algorithm is in block_core.h (shared with the CPU emulation the tests run).
 #include <hip/hip_runtime.h>

@@ -2,18 +2,19 @@
 // model's wide rows (run_scheduling_solver's model, /root/reference/crates/tako/src/internal/scheduler/solver.rs:95-430, which the reference hands to
 // HiGHS, solver/highs.rs:65-88; the method is in price.h, the per-block algorithm in price_core.h / block_core.h).
 //
-// Launch shape: grid = number of blocks (one per worker: 1024-4096), block = 64 threads = ONE wave64, 25.9 KB of LDS per block (dual vertices, level
-// stack; the 64 greedy vectors share the level lists' storage) -> 6 blocks per CU (measured: tools/exp/resident_wg.hip), 1536 resident on the 256 CUs, dealt round-robin over the 8 XCDs by the dispatcher; the blocks
+// Launch shape: grid = number of blocks (one per worker: 1024-4096), block = 256 threads = FOUR wave64 — one runs the block's chain, the others share its dual pool and run
+// its greedy fills, then leave (block_core.h: pool_sections) —, 17.5 / 23.9 / 36.9 KB of LDS per block at 8 / 16 / 32 columns (dual vertices, level stack, greedy vectors,
+// the block's wide-row entries) -> 6 blocks per CU (wavefront slots: 81 VGPRs), 1536 resident on the 256 CUs, dealt round-robin over the 8 XCDs by the dispatcher; the blocks
 // share nothing but the prices (<= 1 KB, in the kernel arguments) — no XCD-aware mapping is needed.  Integer / f64 scalar work on LDS-resident data:
 // not an HBM kernel (a block reads ~0.5-2 KB of tables) and not MFMA work; its figure of merit is block solves per second.
 //
 // A sweep is one link of a serial chain (master LP on the host -> prices -> sweep -> cut -> master ...), so its LATENCY is what counts:
 //   * prices travel in the kernel arguments: no copy, no PCIe read by 1024 wavefronts;
 //   * the wide rows' activities are integer, accumulated with 64-bit atomics in HBM: exact, order-free, the same on every replica;
-//   * the last workgroup to finish (a ticket in HBM) adds up the per-block values in a fixed order and writes the sweep's totals + a sequence
-//     number straight into pinned host memory; the host waits on that word instead of a stream synchronisation (the marker packet behind
-//     hipStreamSynchronize costs ~6 us per call);
-//   * the patterns stay in HBM (a ring of sweeps) and cross PCIe once, when the master has converged and the primal side needs them.
+//   * the end of a sweep is two levels of tickets in HBM (per part, then per sweep): the parts' last blocks and then the sweep's last block add up the per-block values in
+//     a fixed order and write the sweep's totals + a sequence number straight into pinned host memory; the host waits on that word instead of a stream synchronisation
+//     (the marker packet behind hipStreamSynchronize costs ~6 us per call);
+//   * the patterns of the first 64 sweeps are written straight into pinned host memory (the primal side reads them in place), later ones stay in an HBM ring.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

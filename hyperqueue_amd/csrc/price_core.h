@@ -7,7 +7,7 @@
 // (csrc/price.cpp: Dantzig-Wolfe / Lagrangian over the wide rows, a cutting-plane master of K + 1 variables on the host), and what is left per set
 // of prices pi is W independent bounded integer knapsacks
 //        V_w(pi) = max { (c_w - pi A_w) . x :  R_w x <= free_w,  0 <= x <= cap,  x integer }        (<= 32 columns, <= 4 rows)
-// — the W-way data parallelism of the coupled tick, one wavefront per worker, solved EXACTLY (integer blocks, not their LP relaxation: the bound
+// — the W-way data parallelism of the coupled tick, one workgroup per worker (one wavefront of it runs the block's chain, the others share its dual pool and run its greedy fills), solved EXACTLY (integer blocks, not their LP relaxation: the bound
 // pi . h + sum_w V_w(pi) is then at least as tight as the LP bound HiGHS starts from, and every sweep's maximisers are integer patterns the primal
 // side can use as they are).  The block solver is block_core.h's: dual-vertex pool, 64 greedy fills, depth-first walk with 64 children per step.
 //

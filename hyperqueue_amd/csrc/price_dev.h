@@ -1,4 +1,4 @@
-// The price sweeps of the coupled solve on the MI355X (csrc/price.hip): k_price_sweep, one wavefront per worker block.
+// The price sweeps of the coupled solve on the MI355X (csrc/price.hip): k_price_sweep, one workgroup (four wavefronts) per worker block.
 #pragma once
 #include <hip/hip_runtime.h>
 
