@@ -37,7 +37,11 @@ for seed in seeds:
     if apart:
         from limits import model_point, rows_hold
         feasible = rows_hold(hm, model_point(hm, got.counts))   # the product's point against every row of the reference's model (as HiGHS got it)
-        print("CERTIFICATES APART", seed, "product", zp, "HiGHS", zr, "(HiGHS - product) / HiGHS", (zr - zp) / zr, "| the product's point satisfies every row of the reference's model:", feasible, flush=True)
+        # ... and who is right: the exact oracle (HiGHS with and without presolve, rel gap 0, the better verified answer — oracle/oracle.py: _highs says why neither mode of
+        # scipy's HiGHS 1.8.0 is trusted alone)
+        ex = Oracle(abi.make_config(time_limit_s=60.0)); ex.tick(snap); ze = float(ex.last_model()["objective"])
+        print("CERTIFICATES APART", seed, "product", zp, "HiGHS", zr, "(HiGHS - product) / HiGHS", (zr - zp) / zr, "| the product's point satisfies every row of the reference's model:", feasible,
+              "| exact oracle:", ze, "-> within 1e-4 of it: product", abs(zp - ze) <= 1e-4 * abs(ze), ", reference-configured HiGHS", abs(zr - ze) <= 1e-4 * abs(ze), flush=True)
     rows.append((seed, bool(got.is_optimal), bool(want.is_optimal), dt, dr, int(ks["price_sweeps"]), int(ks["milp_cols"]), apart))
     print(seed, "product", bool(got.is_optimal), f"{dt:.3f}s", "sweeps", int(ks["price_sweeps"]), "cols", int(ks["milp_cols"]), "| HiGHS", bool(want.is_optimal), f"{dr:.3f}s", flush=True)
 n = len(rows)
