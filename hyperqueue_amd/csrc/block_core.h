@@ -109,6 +109,7 @@ struct SharedN {  // one block's working set: LDS on the device
     uint16_t ptix[PCAP];            // the entry's basis number: equal keys are ordered by it, so that the order does not depend on who found which entry first
     uint32_t cnext;                 // next chunk of basis numbers to hand out (blocks worked on by several wavefronts: pool_sections)
     uint32_t bar, gdone;            // ... the pool wavefronts' barrier counter, and the greedy wavefront's flag
+    uint32_t redo_at;               // a pool with more entries than this is rebuilt by the main wavefront alone (PCAP; tests force the path with a small value)
     // work problem: columns in search order (position wn - 1 is decided first)
     int wn;
     uint8_t wcol[N_];
@@ -481,7 +482,7 @@ HQB_HD void pool_sections(W &wv, SH &S) {
             wv.each([&](int lane) { const uint32_t t = base + (uint32_t)lane; if (t < total) dual_candidate(wv, S, t); });
         }
         wv.pool_barrier(&S.bar, ++phase);  // the pool is complete
-        if (S.npool > (uint32_t)PCAP) {
+        if (S.npool > S.redo_at) {
             wv.pool_barrier(&S.bar, ++phase);  // (everyone has looked at npool)
             if (wv.wave_index() == 0) { if (wv.first()) S.npool = 0; wv.sync(); all_by_lane(); }
             wv.pool_barrier(&S.bar, ++phase);
@@ -501,8 +502,8 @@ HQB_HD void pool_sections(W &wv, SH &S) {
 }
 // the main wavefront: open the section (group barrier A) and take part; the pool is complete and ordered when it returns, the greedy fills may still be running ...
 template <class W, class SH>
-HQB_HD void pool_main(W &wv, SH &S) {
-    if (wv.first()) { S.cnext = 0; S.bar = 0; S.gdone = 0; }
+HQB_HD void pool_main(W &wv, SH &S, uint32_t redo_at = (uint32_t)PCAP) {
+    if (wv.first()) { S.cnext = 0; S.bar = 0; S.gdone = 0; S.redo_at = redo_at; }
     wv.group_sync();
     pool_sections(wv, S);
 }

@@ -53,7 +53,7 @@ struct SweepOut {
     // `act` may hold asub (a power of two) vectors per part instead of one: block b adds into vector b % asub of its part, whoever adds the totals up sums them
     // (price.hip: ASUB; the host emulation keeps one vector per part — 0 or 1 here).
     uint32_t asub = 1;
-    uint32_t dbg = 0;     // experiments only (HQTICK_PRICE_DBG): bit 0 = no global atomics (the sweep's activities are then wrong: timing runs)
+    uint32_t dbg = 0;     // experiments only (HQTICK_PRICE_DBG): bit 0 = no global atomics (the sweep's activities are then wrong: timing runs), bit 1 = pools above 8 entries are rebuilt by the main wavefront (same answers: tests)
 };
 
 // columns of a priced block whose reduced cost is at most this fraction of the block's largest original cost stay at zero (their possible
@@ -170,7 +170,7 @@ HQB_HD void solve_priced_block(W &wv, SH &S, const Tables &t, const double *pi, 
     });
     wv.sync();
     // dual pool (ordered) and greedy fills: the section the workgroup's other wavefronts take part in (block_core.h: pool_sections)
-    hqblock::pool_main(wv, S);
+    hqblock::pool_main(wv, S, (out.dbg & 2u) ? 8u : (uint32_t)hqblock::PCAP);   // (dbg bit 1: every pool of more than 8 entries takes the rebuild path — tests)
     if (prof && wv.first()) prof[2] = wv.now();  // dual pool built and ordered
     if (prof && wv.first()) prof[3] = wv.now();
     const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);

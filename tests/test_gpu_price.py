@@ -360,3 +360,18 @@ def test_no_tick_caches_changes_nothing_but_the_work():
     a, b = outs["default"], outs["cold"]
     assert a[1].batches == b[1].batches and a[1].counts == b[1].counts and a[1].records == b[1].records
     assert a[2]["distinct_us"] == 0 and b[2]["distinct_us"] > 0   # second tick: the default context trusted its level table, the flagged one rebuilt it
+
+
+@pytest.mark.parametrize("name,kw", [("c3p", dict(n_tasks=250_000, n_workers=256)), ("c4", dict(seed=8, n_workers=256, n_tasks=3_600))])
+def test_a_pool_rebuilt_by_the_main_wavefront_gives_the_same_tick(monkeypatch, name, kw):
+    """k_price_sweep's blocks are workgroups of four wavefronts; the dual pool is found by three of them at once, and a pool that overflows its storage — where the
+    slot an entry gets decides whether it is kept — is thrown away and rebuilt by the main wavefront alone (block_core.h: pool_sections).  No measured block overflows,
+    so the path is forced: HQTICK_PRICE_DBG=2 sends every pool above 8 entries through it.  Same sweeps, same rounds, same counts, same records."""
+    snap = workloads.make(name, **kw)
+    monkeypatch.setenv("HQTICK_PRICE_MIN_COLS", "16")
+    t = Tick(abi.make_config(time_limit_s=5.0)); want = t.tick(snap); kw_ = t.kernel_stats(); t.close()
+    monkeypatch.setenv("HQTICK_PRICE_DBG", "2")
+    t = Tick(abi.make_config(time_limit_s=5.0)); got = t.tick(snap); kg = t.kernel_stats(); t.close()
+    assert kw_["price_sweeps"] > 0 and (kg["price_sweeps"], kg["price_rounds"]) == (kw_["price_sweeps"], kw_["price_rounds"])
+    assert got.status == want.status and got.is_optimal == want.is_optimal
+    assert got.counts == want.counts and got.records == want.records and (got.new_free == want.new_free).all()
