@@ -390,6 +390,7 @@ const uint16_t *DeviceSweeper::patterns(uint32_t first, uint32_t count) {
 }
 
 void DeviceSweeper::end() {
+    if (in_flight) { hipStreamSynchronize(stream); in_flight = false; }   // (a solve that gave up between sweep_launch and sweep_finish: the kernel must not outlive the tables' owner)
     if (profile && prof_n) {
         fprintf(stderr, "[price profile] %d sweeps, per block and sweep (us; median over blocks / slowest block, averaged over the sweeps):", prof_n);
         for (int st = 0; st < NPROF; st++) fprintf(stderr, "  %s %.1f / %.1f;", PROF_NAME[st], prof_med[st] / prof_n, prof_max[st] / prof_n);
