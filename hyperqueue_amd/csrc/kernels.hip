@@ -271,30 +271,45 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
         return;
     }
     const uint32_t hist_block = blockIdx.x - n_eval_blocks;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = hist_block * WPB + (threadIdx.x >> 6);
+    const uint64_t begin = (uint64_t)wave * tasks_per_wave;
+    const uint64_t end = begin + tasks_per_wave < n ? begin + tasks_per_wave : n;
+    // The slice's first 256 tasks are asked for before anything that needs the level table: behind a level discovery the table is a round trip to HBM away (written
+    // by another XCD a moment ago), and that round trip used to sit in FRONT of the columns' — two memory latencies in a kernel that is four of them long (round 6).
+    ulonglong2 pv[2], pn[2];
+    uint2 qv[2], qn[2];
+    auto load_tiles = [&](uint64_t b, ulonglong2 *pd, uint2 *qd) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {  // both tiles' loads in flight before the first use
+            const uint64_t i = b + (uint64_t)u * 128 + 2 * lane;
+            if (i + 1 < end) { pd[u] = *reinterpret_cast<const ulonglong2 *>(prio + i); qd[u] = *reinterpret_cast<const uint2 *>(rq + i); }
+            else if (i < end) { pd[u] = make_ulonglong2(prio[i], 0); qd[u] = make_uint2(rq[i], 0); }
+        }
+    };
+    if (wave < n_waves) load_tiles(begin, pv, qv);
+    const uint32_t GL = L * Q;   // the counter rows' layout follows the level count the launch was sized for (what the LDS was sized for, too)
+    uint64_t *s_levels = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)(SMALL_L ? 0 : lds_levels) * 8) + (threadIdx.x >> 6) * GL * NCOPY;
+    uint32_t *my_cnt = s_cnt + (lane & (uint32_t)(NCOPY - 1)) * GL;
+    if (!SMALL_L) for (uint32_t i = threadIdx.x; i < lds_levels; i += blockDim.x) s_levels[i] = levels[i];
+    for (uint32_t g = lane; g < GL * NCOPY; g += 64) s_cnt[g] = 0;
     if (SMALL_L && n_levels_dev) {
         // Launched right behind the level discovery, before the host has seen its result (a tick that rediscovers its levels: round 6): the table and its length come
         // from HBM — k_sort_levels has just written them — and `L` is only the bound the launch was sized for (4).  More levels than that: the scan refuses (err bit 4),
         // the host reads the table and launches the general variant.  Uniform scalar loads, a few hundred ns; no host round trip between discovery and scan.
         const uint64_t *head = reinterpret_cast<const uint64_t *>(n_levels_dev);   // [count | level 0 .. 3]: five independent loads, one round trip
-        const uint64_t h0 = head[0], h1 = head[1], h2 = head[2], h3 = head[3], h4 = head[4];
+        uint64_t h0 = head[0], h1 = head[1], h2 = head[2], h3 = head[3], h4 = head[4];
+        asm volatile("" : "+s"(h0), "+s"(h1), "+s"(h2), "+s"(h3), "+s"(h4));   // all five asked for before the count is looked at (the compiler sank the levels' loads below the test on the count: a second round trip)
         const uint32_t Ld = (uint32_t)h0;
         if (Ld == 0 || Ld > L) { if (hist_block == 0 && threadIdx.x == 0) atomicOr(err_flag, 4u); return; }
         L = Ld;
         l4.v[0] = h1; l4.v[1] = h2; l4.v[2] = h3; l4.v[3] = h4;
     }
     const uint32_t G = L * Q;
-    uint64_t *s_levels = reinterpret_cast<uint64_t *>(smem);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)(SMALL_L ? 0 : lds_levels) * 8) + (threadIdx.x >> 6) * G * NCOPY;
-    const uint32_t lane = lane_id();
-    uint32_t *my_cnt = s_cnt + (lane & (uint32_t)(NCOPY - 1)) * G;
-    const uint32_t wave = hist_block * WPB + (threadIdx.x >> 6);
-    if (!SMALL_L) for (uint32_t i = threadIdx.x; i < lds_levels; i += blockDim.x) s_levels[i] = levels[i];
-    for (uint32_t g = lane; g < G * NCOPY; g += 64) s_cnt[g] = 0;
     if (!SMALL_L) __syncthreads();
     if (wave >= n_waves) return;
     const uint64_t *lvp = lds_levels ? s_levels : levels;
-    const uint64_t begin = (uint64_t)wave * tasks_per_wave;
-    const uint64_t end = begin + tasks_per_wave < n ? begin + tasks_per_wave : n;
     uint32_t err = 0;
     // (priority, rq) -> group key, counting it; GKEY_INVALID for a task the tables do not cover
     auto classify = [&](uint64_t p, uint32_t q) -> uint16_t {
@@ -309,14 +324,8 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
         return (uint16_t)g;
     };
     for (uint64_t b = begin; b < end; b += 256) {
-        ulonglong2 pv[2];
-        uint2 qv[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {  // both tiles' loads in flight before the first use
-            const uint64_t i = b + (uint64_t)u * 128 + 2 * lane;
-            if (i + 1 < end) { pv[u] = *reinterpret_cast<const ulonglong2 *>(prio + i); qv[u] = *reinterpret_cast<const uint2 *>(rq + i); }
-            else if (i < end) { pv[u] = make_ulonglong2(prio[i], 0); qv[u] = make_uint2(rq[i], 0); }
-        }
+        const bool more = b + 256 < end;
+        if (more) load_tiles(b + 256, pn, qn);   // the next 256 tasks are on their way while these are classified
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const uint64_t i = b + (uint64_t)u * 128 + 2 * lane;
@@ -327,13 +336,17 @@ __global__ void __launch_bounds__(WPB * 64) k_level_hist(const uint64_t *__restr
                 gkey[i] = classify(pv[u].x, qv[u].x);
             }
         }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) { pv[u] = pn[u]; qv[u] = qn[u]; }
+        }
     }
     if (err) atomicOr(err_flag, err);
     // publish this slice's counts, transposed to [G][stride] so the scan and K4 read rows contiguously
     for (uint32_t g = lane; g < G; g += 64) {
         uint32_t c = s_cnt[g];
 #pragma unroll
-        for (int k = 1; k < NCOPY; k++) c += s_cnt[(uint32_t)k * G + g];
+        for (int k = 1; k < NCOPY; k++) c += s_cnt[(uint32_t)k * GL + g];
         wave_tab[(size_t)g * stride + wave] = c;
     }
 }

@@ -252,7 +252,9 @@ bool DeviceSweeper::begin(const HostTables &t, uint32_t max_sweeps) {
     memcpy(h + o_woff, t.col_woff.data(), (size_t)(t.n_cols + 1) * 4);
     if (nw) { memcpy(h + o_wrow, t.w_row.data(), nw * 2); memcpy(h + o_wcoef, t.w_coef.data(), nw * 4); }
     if (hipMemcpyAsync(d_tab.p, h, tab_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return false;
-    if (hipMemsetAsync(d_sync.p, 0, SYNC_BYTES, stream) != hipSuccess) return false;  // tickets + the wide rows' accumulators (+ the parts' hand-over rows)
+    // tickets + the wide rows' accumulators: every completed sweep leaves them zero (the parts' and the sweep's last blocks put back what they used), so only a fresh
+    // buffer, or one a sweep did not come back from, is cleared (a fill kernel and ~5 us of runtime calls per coupled solve otherwise)
+    if (!sync_clean) { if (hipMemsetAsync(d_sync.p, 0, SYNC_BYTES, stream) != hipSuccess) return false; }
     SweepResult *r = h_res.as<SweepResult>();
     seq = r->seq;  // (whatever the last solve left: the next sweep writes seq + 1)
     return true;
@@ -326,7 +328,7 @@ bool DeviceSweeper::launch_only(const double *pi, uint32_t b0, uint32_t b1, bool
 #undef HQ_SWEEP_N
 #undef HQ_SWEEP
     if (hipGetLastError() != hipSuccess) return false;
-    in_flight = true; flight_t0 = t0; flight_blocks = b1 - b0;
+    in_flight = true; sync_clean = false; flight_t0 = t0; flight_blocks = b1 - b0;
     return true;
 }
 
@@ -346,6 +348,7 @@ bool DeviceSweeper::wait_done(SweepTotals *outp) {
         }
     }
     last_kernel_us = now_us() - t0;
+    sync_clean = true;   // (the completion word is the sweep's last store)
     if (profile) {  // HQTICK_PRICE_PROFILE=1: per-stage medians over the blocks of this sweep (100 MHz wavefront clock), accumulated for end()
         // (the stamps are written to HBM — stores into pinned memory would put a PCIe acknowledgement into every wait of the block — and copied once the kernel has ended)
         if (hipMemcpyAsync(h_prof.p, d_prof.p, (size_t)t.n_blocks * PSLOTS * 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return false;

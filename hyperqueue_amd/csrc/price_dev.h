@@ -13,6 +13,7 @@ struct DeviceSweeper : Sweeper {
     hipStream_t stream = nullptr;
     hqbuf::PinBuf h_stage, h_res, h_pats, h_pin, h_prof, h_blkv;
     static constexpr uint32_t PIN_SWEEPS = 64;   // sweeps whose patterns the kernel writes into pinned memory (price.hip: launch_only)
+    bool sync_clean = false;   // d_sync is all zero (price.hip: begin)
     bool in_flight = false; double flight_t0 = 0; uint32_t flight_blocks = 0;   // a sweep launched and not yet waited for
     bool profile = getenv("HQTICK_PRICE_PROFILE") != nullptr; double prof_med[16] = {0}, prof_max[16] = {0}, prof_steps = 0, prof_span = 0, prof_tail = 0; int prof_n = 0;
     hqbuf::DevBuf d_tab, d_pats, d_blk, d_sync, d_prof;
