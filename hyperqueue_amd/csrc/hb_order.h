@@ -8,7 +8,6 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
-#include <emmintrin.h>
 #include <vector>
 
 namespace hqhb {
@@ -19,19 +18,13 @@ inline uint64_t hash_rq_variant(uint32_t rq, uint8_t v) { return fx_step(fx_step
 
 // Simulates inserting n distinct keys (given by their 64-bit hashes, in insertion order) into an empty table and
 // returns, in iteration order, the insertion index of every element.
-// The table is kept the way hashbrown keeps it: one control byte per bucket (0xFF = EMPTY, anything else = taken) followed by a mirror of the first group, so that
-// a group — 16 consecutive control bytes from an arbitrary position — is ONE unaligned SSE2 load and "first vacant bucket of the group" one movemask + count of
-// trailing zeros (round 6: the scalar form looked at up to 16 buckets per probe with a wrap each, ~10 ns per placement; a heterogeneous tick simulates ~8 maps of
-// 600-1000 workers, each of them placed about twice over its growth history).  Tables smaller than a group (4 / 8 buckets) see EMPTY padding between their
-// buckets and the mirror, and an index that lands on the padding is looked up again in the aligned group at 0 — as the scalar form did.
 inline void insertion_order(const uint64_t *hashes, uint32_t n, std::vector<uint32_t> &order) {
-    const size_t GROUP = 16;                 // SSE2 group width on x86-64
+    const int GROUP = 16;                 // SSE2 group width on x86-64
+    const uint32_t VACANT = 0xFFFFFFFFu;
     using std::size_t;
-    // two (control bytes, bucket -> insertion index) pairs that swap roles at every growth: no allocation per growth step
-    static thread_local std::vector<uint8_t> ctrl_a, ctrl_b;
-    static thread_local std::vector<uint32_t> val_a, val_b;
-    std::vector<uint8_t> *ctrl = &ctrl_a, *ctrl_spare = &ctrl_b;
-    std::vector<uint32_t> *val = &val_a, *val_spare = &val_b;
+    // two bucket arrays (bucket -> insertion index, VACANT = empty control byte) that swap roles at every growth: no allocation per growth step
+    static thread_local std::vector<uint32_t> buf_a, buf_b;
+    std::vector<uint32_t> *owner = &buf_a, *spare = &buf_b;
     size_t nbuckets = 0, used = 0, room = 0;
     auto capacity_of = [](size_t nb) { return nb <= 8 ? nb - 1 : nb / 8 * 7; };
     auto buckets_for = [](size_t cap) -> size_t {
@@ -42,54 +35,53 @@ inline void insertion_order(const uint64_t *hashes, uint32_t n, std::vector<uint
         while (p < want) p <<= 1;
         return p;
     };
-    auto empties = [](const uint8_t *c) -> unsigned { return (unsigned)_mm_movemask_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(c))); };
-    // first vacant bucket along the triangular probe sequence, marked taken (in place and in the mirror)
-    auto take = [&](uint8_t *c, size_t nb, uint64_t h) -> size_t {
-        const size_t mask = nb - 1;
-        size_t pos = (size_t)h & mask, stride = 0, idx;
+    // first vacant bucket along the triangular probe sequence; groups are GROUP consecutive control bytes starting
+    // at an arbitrary position, and tables smaller than a group see vacant padding before their mirrored bytes.
+    auto place = [&](uint32_t *tab, size_t nb, uint64_t h) -> size_t {
+        size_t mask = nb - 1, pos = (size_t)h & mask, stride = 0;
+        if (nb >= (size_t)GROUP) {  // the common case: a group is 16 consecutive buckets (wrapping)
+            for (;;) {
+                for (int b = 0; b < GROUP; b++) { const size_t idx = (pos + b) & mask; if (tab[idx] == VACANT) return idx; }
+                stride += GROUP;
+                pos = (pos + stride) & mask;
+            }
+        }
         for (;;) {
-            const unsigned m = empties(c + pos);
-            if (m) {
-                idx = (pos + (size_t)__builtin_ctz(m)) & mask;
-                if (nb < GROUP && c[idx] != 0xFF) idx = (size_t)__builtin_ctz(empties(c));   // landed on the padding of a tiny table: the aligned group at 0
-                break;
+            for (int b = 0; b < GROUP; b++) {
+                size_t lane = pos + b;
+                const bool vacant = lane < nb ? tab[lane] == VACANT : (lane < (size_t)GROUP ? true : tab[lane - GROUP] == VACANT);
+                if (vacant) {
+                    size_t idx = lane & mask;
+                    if (tab[idx] != VACANT) {  // landed on padding of a tiny table: rescan from bucket 0
+                        for (size_t i = 0; i < nb; i++) if (tab[i] == VACANT) return i;
+                    }
+                    return idx;
+                }
             }
             stride += GROUP;
             pos = (pos + stride) & mask;
         }
-        c[idx] = 0;
-        c[((idx - GROUP) & mask) + GROUP] = 0;
-        return idx;
     };
     for (uint32_t i = 0; i < n; i++) {
         if (room == 0) {  // reserve(1): grow to hold max(items + 1, full_capacity + 1) and re-insert in iteration order
             size_t want = nbuckets == 0 ? 1 : (used + 1 > capacity_of(nbuckets) + 1 ? used + 1 : capacity_of(nbuckets) + 1);
             size_t nb = buckets_for(want);
-            ctrl_spare->assign(nb + GROUP, 0xFF);
-            if (val_spare->size() < nb) val_spare->resize(nb);
-            uint8_t *big = ctrl_spare->data(); uint32_t *bigv = val_spare->data();
-            const uint8_t *old = ctrl->data(); const uint32_t *oldv = val->data();
-            for (size_t b0 = 0; b0 < nbuckets; b0 += GROUP) {
-                unsigned full = ~empties(old + b0) & 0xFFFFu;
-                if (nbuckets < GROUP) full &= (1u << nbuckets) - 1u;
-                while (full) { const size_t b = b0 + (size_t)__builtin_ctz(full); full &= full - 1; bigv[take(big, nb, hashes[oldv[b]])] = oldv[b]; }
-            }
-            std::swap(ctrl, ctrl_spare); std::swap(val, val_spare);
+            spare->assign(nb, VACANT);
+            uint32_t *big = spare->data(); const uint32_t *old = owner->data();
+            for (size_t b = 0; b < nbuckets; b++) if (old[b] != VACANT) big[place(big, nb, hashes[old[b]])] = old[b];
+            std::swap(owner, spare);
             nbuckets = nb;
             room = capacity_of(nb) - used;
         }
-        (*val)[take(ctrl->data(), nbuckets, hashes[i])] = i;
+        uint32_t *tab = owner->data();
+        tab[place(tab, nbuckets, hashes[i])] = i;
         used++;
         room--;
     }
-    order.resize(n);
-    uint32_t *out = order.data();
-    const uint8_t *c = ctrl->data(); const uint32_t *v = val->data();
-    for (size_t b0 = 0; b0 < nbuckets; b0 += GROUP) {
-        unsigned full = ~empties(c + b0) & 0xFFFFu;
-        if (nbuckets < GROUP) full &= (1u << nbuckets) - 1u;
-        while (full) { *out++ = v[b0 + (size_t)__builtin_ctz(full)]; full &= full - 1; }
-    }
+    order.clear();
+    order.reserve(n);
+    const uint32_t *tab = owner->data();
+    for (size_t b = 0; b < nbuckets; b++) if (tab[b] != VACANT) order.push_back(tab[b]);
 }
 
 inline void insertion_order_u32(const uint32_t *keys, uint32_t n, std::vector<uint32_t> &order) {
