@@ -85,7 +85,8 @@ inline void insertion_order(const uint64_t *hashes, uint32_t n, std::vector<uint
 }
 
 inline void insertion_order_u32(const uint32_t *keys, uint32_t n, std::vector<uint32_t> &order) {
-    std::vector<uint64_t> h(n);
+    static thread_local std::vector<uint64_t> h;   // (no allocation per simulated map)
+    if (h.size() < n) h.resize(n);
     for (uint32_t i = 0; i < n; i++) h[i] = hash_worker_id(keys[i]);
     insertion_order(h.data(), n, order);
 }

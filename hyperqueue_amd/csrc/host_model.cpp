@@ -823,8 +823,15 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
                     if (!wl) {
                         lists.emplace_back();
                         WorkerList &l = lists.back();
-                        l.mask = mask; l.widx.reserve(solver_workers.size()); ids.clear(); ids.reserve(solver_workers.size());
-                        for (uint32_t w : solver_workers) if (mask[wclass[w]]) { ids.push_back(ws.id[w]); l.widx.push_back(w); }
+                        l.mask = mask;
+                        {   // the key's workers, in solver order: written unconditionally, kept by advancing the cursor (no push_back, no branch on the class mask)
+                            const size_t nsw = solver_workers.size();
+                            ids.resize(nsw + 1); l.widx.resize(nsw + 1);
+                            uint32_t *idp = ids.data(), *wxp = l.widx.data(); size_t nk = 0;
+                            const uint8_t *mk = mask.data(); const uint32_t *wc = wclass.data(), *wid = ws.id;
+                            for (size_t i = 0; i < nsw; i++) { const uint32_t w = solver_workers[i]; idp[nk] = wid[w]; wxp[nk] = w; nk += mk[wc[w]]; }
+                            ids.resize(nk); l.widx.resize(nk);
+                        }
                         l.order = cached_worker_order(ids);
                         wl = &l;
                     }
@@ -1284,6 +1291,7 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
     // decode  :439-481; Map iteration orders via hb_order.h
     std::vector<uint64_t> key_hash; std::vector<std::pair<uint32_t, uint8_t>> key_list; std::vector<std::vector<std::pair<uint32_t, uint32_t>>> key_counts;
     std::vector<uint64_t> mn_hash; std::vector<uint32_t> mn_list; std::vector<std::vector<std::vector<uint32_t>>> mn_sets;
+    std::vector<uint32_t> dec_ids, dec_widx, dec_cnt;
     for (const TaskBatch &batch : batches) {
         const RequestView &rv = pb.rqs[batch.rq];
         if (pb.rq_multi_node(batch.rq)) {
@@ -1297,14 +1305,23 @@ Counts run_scheduling_solver(const Problem &pb, const std::vector<TaskBatch> &ba
             if (!sets.empty()) { mn_hash.push_back(hqhb::hash_rq_variant(batch.rq, 0)); mn_list.push_back(batch.rq); mn_sets.push_back(sets); }
         } else {
             for (uint8_t v = 0; v < rv.n_variants; v++) {
-                std::vector<uint32_t> ids, widx, cnt;
-                for (uint32_t w : solver_workers) {
-                    const int pc = place_get(w, batch.rq, v);
-                    if (pc < 0) continue;
-                    uint32_t c = (uint32_t)std::round(sol.x[pc]);
-                    if (c > 0) { ids.push_back(ws.id[w]); widx.push_back(w); cnt.push_back(c); }
+                // the key's workers with a non-zero count, in solver order: every worker's triple is written, the cursor advances on a non-zero count (no push_back, no
+                // libm round per (worker, key) pair — the point is integral to 1e-9 and not negative: x + 0.5 truncated is the same integer)
+                const size_t nsw = solver_workers.size();
+                dec_ids.resize(nsw + 1); dec_widx.resize(nsw + 1); dec_cnt.resize(nsw + 1);
+                uint32_t *idp = dec_ids.data(), *wxp = dec_widx.data(), *cp = dec_cnt.data(); size_t nk = 0;
+                const int *pcol = place_col.data() + rv.first_variant + v;
+                const double *xs = sol.x.data();
+                for (size_t i = 0; i < nsw; i++) {
+                    const uint32_t w = solver_workers[i];
+                    const int pc = pcol[(size_t)w * NVS];
+                    const double xv = pc >= 0 ? xs[pc] : 0.0;
+                    const uint32_t c = xv > 0.0 ? (uint32_t)(xv + 0.5) : 0u;
+                    idp[nk] = ws.id[w]; wxp[nk] = w; cp[nk] = c; nk += c > 0 ? 1 : 0;
                 }
-                if (ids.empty()) continue;
+                if (nk == 0) continue;
+                dec_ids.resize(nk);
+                const std::vector<uint32_t> &ids = dec_ids, &widx = dec_widx, &cnt = dec_cnt;
                 const std::vector<uint32_t> &word = cached_worker_order(ids);
                 std::vector<std::pair<uint32_t, uint32_t>> ordered; ordered.reserve(word.size());
                 for (uint32_t k : word) ordered.push_back({widx[k], cnt[k]});
