@@ -70,17 +70,27 @@ void finish_groups(Prob &P, const std::vector<std::vector<std::pair<int, int32_t
     const int KG = P.KG;
     T.K = (uint32_t)KG;
     size_t tot = 0; for (auto &l : lhs) tot += l.size();
-    P.g_off.assign(1, 0); P.g_off.reserve((size_t)KG + 1); P.g_col.clear(); P.g_col.reserve(tot); P.g_coef.clear(); P.g_coef.reserve(tot);
+    // (sized once and written through pointers: ~16 k terms per tick on c3p, three passes — a push_back per term was a third of the flattening)
+    P.g_off.assign((size_t)KG + 1, 0); P.g_col.resize(tot); P.g_coef.resize(tot);
     std::vector<uint32_t> gcnt(T.n_cols + 1, 0);
-    for (int g = 0; g < KG; g++) {
-        for (auto &t : lhs[(size_t)g]) { P.g_col.push_back(t.first); P.g_coef.push_back(t.second); gcnt[t.first + 1]++; }
-        P.g_off.push_back((int)P.g_col.size());
+    {
+        auto *gc = P.g_col.data(); auto *gk = P.g_coef.data(); uint32_t *cnt = gcnt.data() + 1; size_t pos = 0;
+        for (int g = 0; g < KG; g++) {
+            const std::pair<int, int32_t> *l = lhs[(size_t)g].data();
+            for (size_t i = 0, e = lhs[(size_t)g].size(); i < e; i++) { gc[pos] = l[i].first; gk[pos] = l[i].second; cnt[l[i].first]++; pos++; }
+            P.g_off[(size_t)g + 1] = (int)pos;
+        }
     }
     T.col_woff.assign(T.n_cols + 1, 0);
     for (uint32_t f = 0; f < T.n_cols; f++) T.col_woff[f + 1] = T.col_woff[f] + gcnt[f + 1];
     T.w_row.resize(T.col_woff[T.n_cols]); T.w_coef.resize(T.col_woff[T.n_cols]);
-    std::vector<uint32_t> cur(T.col_woff.begin(), T.col_woff.end() - 1);
-    for (int g = 0; g < KG; g++) for (int e = P.g_off[g]; e < P.g_off[g + 1]; e++) { const uint32_t p = cur[P.g_col[e]]++; T.w_row[p] = (uint16_t)g; T.w_coef[p] = P.g_coef[e]; }
+    {
+        std::vector<uint32_t> &cur = gcnt;   // (the counts are done with: the cursors take their place)
+        for (uint32_t f = 0; f < T.n_cols; f++) cur[f] = T.col_woff[f];
+        uint32_t *cp = cur.data(); uint16_t *wr = T.w_row.data(); auto *wc = T.w_coef.data();
+        const auto *gc = P.g_col.data(); const auto *gk = P.g_coef.data();
+        for (int g = 0; g < KG; g++) for (int e = P.g_off[g], e1 = P.g_off[g + 1]; e < e1; e++) { const uint32_t p = cp[gc[e]]++; wr[p] = (uint16_t)g; wc[p] = gk[e]; }
+    }
     // rows of every group, ascending
     P.gr_off.assign((size_t)KG + 1, 0);
     for (int k = 0; k < P.K; k++) P.gr_off[P.grp_of[k] + 1]++;
@@ -1530,8 +1540,10 @@ const char *build_from_model(const ModelView &mv, Prob &P, std::vector<double> &
     auto materialise = [&](int key, std::vector<std::pair<int, int32_t>> &out) {   // the family's list with the row's sign, zero coefficients dropped
         const int l = key >> 1;
         const int32_t sign = (key & 1) ? -1 : 1;
-        out.clear(); out.reserve((size_t)(mv.list_off[l + 1] - mv.list_off[l]));
-        for (int k = mv.list_off[l]; k < mv.list_off[l + 1]; k++) out.push_back({P.flat_of[mv.list_col[k]], sign});
+        const int k0 = mv.list_off[l], k1 = mv.list_off[l + 1];
+        out.resize((size_t)(k1 - k0));
+        std::pair<int, int32_t> *o = out.data(); const int *fo = P.flat_of.data();
+        for (int k = k0; k < k1; k++) o[k - k0] = {fo[mv.list_col[k]], sign};
     };
     auto hash_of = [](const std::vector<std::pair<int, int32_t>> &l) { uint64_t h = 1469598103934665603ull; for (auto &t : l) h = (h ^ ((uint64_t)(uint32_t)t.first | ((uint64_t)(uint32_t)t.second << 32))) * 1099511628211ull; return h; };
     std::vector<std::pair<int, int32_t>> tmp;
