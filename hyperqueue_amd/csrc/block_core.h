@@ -122,7 +122,7 @@ struct SharedN {  // one block's working set: LDS on the device
     // the greedy's vectors.  (Until round 6 they shared the level lists' storage; with the greedy fills on a wavefront of their own the main wavefront builds the
     // first level lists WHILE the fills run — pool_main / pool_await — and the two need their own 1.5 / 3 / 6 KB at 8 / 16 / 32 columns.)
     uint8_t perm[N_][WAVE];       // [column slot][lane] — lanes side by side, so that a wavefront's accesses spread over the LDS banks
-    uint16_t gx[N_][WAVE];
+    alignas(8) uint16_t gx[N_][WAVE];   // (8-byte aligned: build_block overlays its int64 amounts here — UBSan found them on a 4-byte boundary at N = 32)
     double gval[WAVE];            // the fills' values
     int32_t wcap[N_];             // upper cap of a position (INT32_MAX = none)
     int32_t colcap[N_];           // upper cap of a block column (INT32_MAX = none): the priced blocks of the coupled solve (price_core.h) carry their model bounds here
