@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Flat profile of the REAL tick's host side on the GPU box (tools/exp/sprof.c): python tools/exp/sprof_gpu.py [c3p|c4u|c4p|wave] [iterations]
+"""Flat profile of the REAL tick's host side on the GPU box (tools/exp/sprof.c): python tools/exp/sprof_gpu.py [c3p|c4u|c4p|wave|c3_steady] [iterations]
 The resident cold tick of bench.py's headline loop (ready set + cluster tables in HBM, HQTICK_FLAG_NO_TICK_CACHES) through libhqtick.so; the program counter is sampled
 every 50 us of wall time while the library call runs.  Waiting for a kernel shows up as the function that spins (DeviceSweeper::wait_done, the stream synchronisations)."""
 import bisect, collections, ctypes as C, os, subprocess, sys
@@ -15,7 +15,11 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-o", "/tmp/libsprof.so", os.path.join(ROOT, "tools", "exp", "sprof.c")], check=True)
 sp = C.CDLL("/tmp/libsprof.so")
 sp.sprof_samples.restype = C.POINTER(C.c_uint64); sp.sprof_returns.restype = C.POINTER(C.c_uint64)
-snap = price_probe.snapshot(name)
+if name.endswith("_steady"):   # a cluster mid-run: every worker its own free vector, the class blocks through k_block_solve (workloads.make_steady)
+    from hyperqueue_amd import workloads
+    snap = workloads.make_steady(name[:-7])
+else:
+    snap = price_probe.snapshot(name)
 t = Tick(abi.make_config(time_limit_s=5.0, flags=getattr(abi, "HQTICK_FLAG_NO_TICK_CACHES", 0)))
 t.upload_ready(snap.task_id, snap.task_priority, snap.task_rq)
 sc = snap.to_c()
