@@ -360,6 +360,39 @@ struct CompSolver {
         for (int a = 0; a < q.ma; a++) { const double act = q.R->activity(q.arow[a], q.x.data()); if (std::fabs(act - q.x[q.n + a]) > 1e-7 * std::max(1.0, std::fabs(act))) return false; }
         return true;
     }
+    // A bound that does not need the tableau to be right (Neumaier / Shcherbina's safe dual bound).  For ANY multipliers lambda of the active rows
+    //        max { c.x : rows, boxes }  <=  sum_j max_{lb_j <= x_j <= ub_j} (c_j - sum_a lambda_a A_aj) x_j  +  sum_a max_{lo_a <= s <= hi_a} lambda_a s
+    // (add lambda_a (s_a - A_a.x) = 0 to the objective and drop the coupling) — evaluated from the ROWS' own coefficients in plain arithmetic, a few thousand
+    // multiply-adds.  With the slack columns' reduced costs as multipliers it reproduces the LP value of an exact tableau; from a drifted tableau it is a little
+    // weaker and still a bound.  Rows that are not active are simply relaxed; a multiplier that would need an infinite side of its row is set to zero.  Both sign
+    // conventions are tried (each is valid) and the smaller value returned; INF when neither is finite.
+    static double safe_dual_bound(const Tab &q) {
+        const Rows &RR = *q.R;
+        double out = INF;
+        std::vector<double> r((size_t)q.n);
+        for (int sign = 1; sign >= -1; sign -= 2) {
+            for (int j = 0; j < q.n; j++) r[(size_t)j] = q.cost[j];
+            double b = 0.0; bool finite = true;
+            for (int a = 0; a < q.ma; a++) {
+                double lam = (double)sign * q.d[q.n + a];
+                const double lo = q.lb[q.n + a], hi = q.ub[q.n + a];
+                if (!(lam == lam)) { lam = 0.0; }
+                if (lam > 0.0 && hi >= INF * 0.5) lam = 0.0;
+                if (lam < 0.0 && lo <= -INF * 0.5) lam = 0.0;
+                if (lam == 0.0) continue;
+                b += lam > 0.0 ? lam * hi : lam * lo;
+                const int i = q.arow[a];
+                for (int k = RR.off[i]; k < RR.off[i + 1]; k++) r[(size_t)RR.col[k]] -= lam * RR.coef[k];
+            }
+            for (int j = 0; j < q.n && finite; j++) {
+                const double rj = r[(size_t)j];
+                if (rj > 0.0) { if (q.ub[j] >= INF * 0.5) finite = false; else b += rj * q.ub[j]; }
+                else if (rj < 0.0) { if (q.lb[j] <= -INF * 0.5) finite = false; else b += rj * q.lb[j]; }
+            }
+            if (finite && b == b && b < out) out = b;
+        }
+        return out;
+    }
     // Rounds of cuts on a COPY of the rows, for the bound only: the tree below keeps working on the model's own rows (its canonical answers must not depend on the
     // numerics of cut rows).  A round's value counts when its tableau is dual feasible; the final value is taken from a COLD solve over the final rows, the larger of
     // the two when they differ.
@@ -440,6 +473,13 @@ struct CompSolver {
                 const double zc = cold.objective();
                 if (tracing) fprintf(stderr, "[milp] n=%d cuts: %d rows added, bound %.9f (cold solve of the final rows: %.9f)\n", n, RC.m - R.m, accepted, zc);
                 root_bound = std::min(root_bound, std::max(accepted, zc) * (1.0 + 1e-9) + 1e-12);
+            } else {
+                // The cold tableau over several hundred cut rows has drifted past the consistency test (price_fuzz 2317: the rounds had the bound 7e-5 above the
+                // incumbent and the certificate was dropped here).  A tableau that cannot be trusted still NAMES multipliers, and the bound they give is computed from
+                // the rows themselves: the smaller of what the warm and the cold tableau's multipliers prove.
+                const double sw = safe_dual_bound(root), sc = safe_dual_bound(cold), sb = std::min(sw, sc);
+                if (tracing) fprintf(stderr, "[milp] n=%d cuts: %d rows added, bound %.9f; the cold solve of the final rows is not consistent: safe dual bound %.9f (warm multipliers %.9f, cold %.9f)\n", n, RC.m - R.m, accepted, sb, sw, sc);
+                if (sb < INF * 0.5) root_bound = std::min(root_bound, sb * (1.0 + 1e-9) + 1e-12);
             }
         }
         cuts_added = RC.m - R.m;
@@ -1282,7 +1322,7 @@ struct CompSolver {
                 return 1;
             }
         }
-        if (tracing && !in_lns) fprintf(stderr, "[milp] n=%d t=%.6fs final incumbent %.9f timed_out %d nodes %ld\n", n, wall() - t_begin, have ? best : -1.0, (int)timed_out, nodes);
+        if (tracing && !in_lns) fprintf(stderr, "[milp] n=%d t=%.6fs final incumbent %.9f timed_out %d nodes %ld (drifted nodes re-solved cold: %ld)\n", n, wall() - t_begin, have ? best : -1.0, (int)timed_out, nodes, drift_resolves);
         if (!have) return 0;
         xout = bx;
         if (timed_out) return 2;
