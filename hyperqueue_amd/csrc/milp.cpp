@@ -438,6 +438,7 @@ struct CompSolver {
         find_slack_units();
         Tab root = root0; root.R = &RC;
         double prev = root.objective(), accepted = prev;
+        double best_safe = INF;   // the smallest safe dual bound of an accepted round's tableau: a bound on the model whatever rows come later
         int stall = 0, hull_stall = 0;
         int round = 0;
         for (; round < 80 && !time_up() && work < work_cap; round++) {
@@ -462,6 +463,7 @@ struct CompSolver {
             if (was_hull && prev - z < 1e-6 * std::fabs(prev)) hull_stall++;
             if (z > accepted * (1.0 + 1e-9) + 1e-12) break;  // a bound cannot rise when rows are added: the arithmetic has gone wrong, keep what was accepted
             accepted = z;
+            best_safe = std::min(best_safe, safe_dual_bound(root));
             if (prev - z < 1e-7 * std::fabs(prev)) { if (++stall >= 3) break; } else stall = 0;
             prev = z;
             if (RC.m > 40 * n + 4000) break;
@@ -476,8 +478,8 @@ struct CompSolver {
             } else {
                 // The cold tableau over several hundred cut rows has drifted past the consistency test (price_fuzz 2317: the rounds had the bound 7e-5 above the
                 // incumbent and the certificate was dropped here).  A tableau that cannot be trusted still NAMES multipliers, and the bound they give is computed from
-                // the rows themselves: the smaller of what the warm and the cold tableau's multipliers prove.
-                const double sw = safe_dual_bound(root), sc = safe_dual_bound(cold), sb = std::min(sw, sc);
+                // the rows themselves: the smallest of what the accepted rounds', the last warm and the cold tableau's multipliers prove.
+                const double sw = std::min(best_safe, safe_dual_bound(root)), sc = safe_dual_bound(cold), sb = std::min(sw, sc);
                 if (tracing) fprintf(stderr, "[milp] n=%d cuts: %d rows added, bound %.9f; the cold solve of the final rows is not consistent: safe dual bound %.9f (warm multipliers %.9f, cold %.9f)\n", n, RC.m - R.m, accepted, sb, sw, sc);
                 if (sb < INF * 0.5) root_bound = std::min(root_bound, sb * (1.0 + 1e-9) + 1e-12);
             }
