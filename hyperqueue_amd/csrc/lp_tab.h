@@ -14,7 +14,8 @@ namespace lp {
 
 constexpr double INF = 1e300;
 constexpr double FEAS_TOL = 1e-9;   // primal bound violation (rows are scaled to max |coef| = 1)
-constexpr double PIV_TOL = 1e-9;
+constexpr double PIV_TOL = 1e-7;   // (rows are scaled to max |coef| = 1: a tableau entry below this is rounding noise, not a coefficient.  1e-9 until the last session of round 6:
+                                   //  pivots on such entries were what made cold solves of several hundred cut rows fail their own consistency test — tools/exp/README.md)
 constexpr double INT_TOL = 1e-7;
 constexpr int LNS_FIRST_COLS = 128;          // models from this size on improve the greedy incumbent by window search before any tree search
 constexpr double EXACT_PASS_WORK = 5.0e7;    // floor of the exact pass's budget after a gap certificate, in tableau element updates (~50 ms)
