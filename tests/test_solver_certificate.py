@@ -132,3 +132,37 @@ def test_certificate_only_stops_where_the_reference_stops(W, n_ready):
     ready_per_rq = np.bincount(np.asarray(snap.task_rq), minlength=len(snap.requests))
     for q, c in placed.items():
         assert c <= ready_per_rq[q], (q, c)
+
+
+def test_a_certificate_survives_on_the_safe_dual_bound():
+    """csrc/milp.cpp: root_cuts_pass confirms the cut rounds' bound by a cold solve of the final rows; when that tableau fails its consistency test the bound is taken from
+    its multipliers instead (safe_dual_bound: the Lagrangian over the boxes, evaluated from the rows — valid whatever the tableau's state).  price_fuzz seed 2317 is the tick
+    that lost its certificate there; with the pivot tolerance of 1e-7 its cold solve is consistent again, so the fallback is forced: same status, same
+    objective, and the trace names the bound it used."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import price_fuzz\nfrom test_price import stages\nfrom test_host_stages import _objective\nfrom hyperqueue_amd import abi\nfrom oracle.oracle import Oracle\n"
+        "snap = price_fuzz.scenario(2317)[0]\ngot, sweeps, rounds = stages(snap, True, tl=20.0)\n"
+        "o = Oracle(abi.make_config(time_limit_s=0.05), reference_solver_options=True)\n"
+        "try:\n    o.tick(snap)\nexcept Exception:\n    pass\n"
+        "print('RESULT', int(got.status), int(got.is_optimal), repr(_objective(o.last_model(), got)))\n"
+    ) % (root, os.path.join(root, "tests"), os.path.join(root, "tools"))
+    outs = []
+    for forced in (False, True):
+        env = dict(os.environ, HQMILP_TRACE="1")
+        env.pop("HQMILP_FORCE_SAFE_BOUND", None)
+        if forced:
+            env["HQMILP_FORCE_SAFE_BOUND"] = "1"
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+        outs.append((int(line[1]), int(line[2]), float(line[3]), "safe dual bound" in p.stderr))
+    (st0, opt0, z0, named0), (st1, opt1, z1, named1) = outs
+    assert (st0, opt0) == (0, 1) and (st1, opt1) == (0, 1)
+    assert not named0 and named1   # the fallback is taken only where the cold solve does not confirm (here: because it was told so)
+    assert abs(z0 - z1) <= 1e-9 * abs(z0)
